@@ -1,0 +1,230 @@
+"""ctypes loader for the CPU oracle (oracle/sla_oracle.c).
+
+TEST INFRASTRUCTURE ONLY.  Importable from tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py -- never from the product package (sla_amd).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+GMRES_, CGNE_, BCG_, CGS_, BICGSTAB_ = range(5)  # Sparse.hs:1007-1011 constructor order
+OK, ERR_DIM, ERR_UNSUPPORTED, ERR_OOB = 0, 1, 2, 3
+
+_i64p = np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS")
+_f64p = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+
+
+class _Csr(C.Structure):
+    _fields_ = [("m", C.c_int64), ("n", C.c_int64), ("rowptr", C.c_void_p),
+                ("colidx", C.c_void_p), ("val", C.c_void_p)]
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "liboracle.so")
+    src = os.path.join(_HERE, "sla_oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "liboracle.so"])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(_HERE, "liboracle.so")
+        if not os.path.exists(so):
+            build()
+        L = C.CDLL(so)
+        L.orc_dot.restype = C.c_double
+        L.orc_norm2.restype = C.c_double
+        L.orc_norm2sq.restype = C.c_double
+        _LIB = L
+    return _LIB
+
+
+def _i64(a):
+    return np.ascontiguousarray(a, dtype=np.int64)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _p(a):
+    return C.c_void_p(a.ctypes.data)
+
+
+class Csr:
+    """Host CSR (int64 indices, f64 values) in the reference's canonical layout."""
+
+    def __init__(self, m, n, rowptr, colidx, val):
+        self.m, self.n = int(m), int(n)
+        self.rowptr, self.colidx, self.val = _i64(rowptr), _i64(colidx), _f64(val)
+
+    @property
+    def nnz(self):
+        return int(self.rowptr[-1])
+
+    def view(self):
+        return _Csr(self.m, self.n, self.rowptr.ctypes.data, self.colidx.ctypes.data,
+                    self.val.ctypes.data)
+
+
+def coo_to_csr(m, n, row, col, val):
+    """fromListSM + toCSR layout.  Returns (rc, Csr|None)."""
+    row, col, val = _i64(row), _i64(col), _f64(val)
+    nnz = len(row)
+    rowptr = np.zeros(m + 1, dtype=np.int64)
+    colidx = np.zeros(max(nnz, 1), dtype=np.int64)
+    vout = np.zeros(max(nnz, 1), dtype=np.float64)
+    nout = C.c_int64(0)
+    rc = lib().orc_coo_to_csr(C.c_int64(m), C.c_int64(n), C.c_int64(nnz), _p(row), _p(col), _p(val),
+                              _p(rowptr), _p(colidx), _p(vout), C.byref(nout))
+    if rc != OK:
+        return rc, None
+    k = nout.value
+    return rc, Csr(m, n, rowptr, colidx[:k].copy(), vout[:k].copy())
+
+
+def cs_ptr(n, sorted_ix):
+    ix = _i64(sorted_ix)
+    out = np.zeros(n + 1, dtype=np.int64)
+    lib().orc_cs_ptr(C.c_int64(n), _p(ix), C.c_int64(len(ix)), _p(out))
+    return out
+
+
+def transpose(A):
+    tp = np.zeros(A.n + 1, dtype=np.int64)
+    tc = np.zeros(max(A.nnz, 1), dtype=np.int64)
+    tv = np.zeros(max(A.nnz, 1), dtype=np.float64)
+    lib().orc_csr_transpose(C.c_int64(A.m), C.c_int64(A.n), _p(A.rowptr), _p(A.colidx), _p(A.val),
+                            _p(tp), _p(tc), _p(tv))
+    return Csr(A.n, A.m, tp, tc[:A.nnz].copy(), tv[:A.nnz].copy())
+
+
+def is_diagonal(A):
+    return bool(lib().orc_is_diagonal(C.c_int64(A.m), _p(A.rowptr), _p(A.colidx)))
+
+
+def spmv(A, x):
+    x = _f64(x)
+    y = np.zeros(A.m, dtype=np.float64)
+    lib().orc_spmv(C.c_int64(A.m), _p(A.rowptr), _p(A.colidx), _p(A.val), _p(x), _p(y))
+    return y
+
+
+def dot(x, y):
+    x, y = _f64(x), _f64(y)
+    return lib().orc_dot(C.c_int64(len(x)), _p(x), _p(y))
+
+
+def norm2(x):
+    x = _f64(x)
+    return lib().orc_norm2(C.c_int64(len(x)), _p(x))
+
+
+def norm2sq(x):
+    x = _f64(x)
+    return lib().orc_norm2sq(C.c_int64(len(x)), _p(x))
+
+
+class BicgstabState:
+    def __init__(self, A, b, x0):
+        self.A, n = A, A.m
+        self.x, self.r, self.p = (np.zeros(n) for _ in range(3))
+        v = A.view()
+        lib().orc_bicgstab_init(C.byref(v), _p(_f64(b)), _p(_f64(x0)), _p(self.x), _p(self.r), _p(self.p))
+
+    def step(self, r0hat, k=1):
+        v = self.A.view()
+        r0hat = _f64(r0hat)
+        for _ in range(k):
+            lib().orc_bicgstab_step(C.byref(v), _p(r0hat), _p(self.x), _p(self.r), _p(self.p))
+        return self
+
+
+class CgsState:
+    def __init__(self, A, b, x0):
+        self.A, n = A, A.m
+        self.x, self.r, self.p, self.u = (np.zeros(n) for _ in range(4))
+        v = A.view()
+        lib().orc_cgs_init(C.byref(v), _p(_f64(b)), _p(_f64(x0)), _p(self.x), _p(self.r), _p(self.p), _p(self.u))
+
+    def step(self, rhat, k=1):
+        v = self.A.view()
+        rhat = _f64(rhat)
+        for _ in range(k):
+            lib().orc_cgs_step(C.byref(v), _p(rhat), _p(self.x), _p(self.r), _p(self.p), _p(self.u))
+        return self
+
+
+class CgneState:
+    def __init__(self, A, b, x0):
+        self.A, self.At = A, transpose(A)
+        self.x, self.r, self.p = np.zeros(A.n), np.zeros(A.m), np.zeros(A.n)
+        v, vt = A.view(), self.At.view()
+        lib().orc_cgne_init(C.byref(v), C.byref(vt), _p(_f64(b)), _p(_f64(x0)), _p(self.x), _p(self.r), _p(self.p))
+
+    def step(self, k=1):
+        v, vt = self.A.view(), self.At.view()
+        for _ in range(k):
+            lib().orc_cgne_step(C.byref(v), C.byref(vt), _p(self.x), _p(self.r), _p(self.p))
+        return self
+
+
+def linsolve0(method, A, b, x0):
+    """Returns (rc, x, iters, resnorm, r0norm)."""
+    b, x0 = _f64(b), _f64(x0)
+    x = np.zeros(max(A.n, A.m), dtype=np.float64)
+    it, res, r0 = C.c_int64(0), C.c_double(0), C.c_double(0)
+    v = A.view()
+    rc = lib().orc_linsolve0(C.c_int(method), C.byref(v), C.c_int64(len(b)), _p(b), _p(x0), _p(x),
+                             C.byref(it), C.byref(res), C.byref(r0))
+    return rc, x[:A.n], it.value, res.value, r0.value
+
+
+def arnoldi(A, b, kn):
+    """Returns (rc, Q[n, k+1], H[k+1, k], k) trimmed to the steps actually taken."""
+    b = _f64(b)
+    n = A.n
+    Q = np.zeros((kn + 1) * n, dtype=np.float64)
+    H = np.zeros((kn + 1) * kn, dtype=np.float64)
+    kd = C.c_int64(0)
+    v = A.view()
+    rc = lib().orc_arnoldi(C.byref(v), C.c_int64(len(b)), _p(b), C.c_int64(kn), _p(Q), _p(H), C.byref(kd))
+    if rc != OK:
+        return rc, None, None, 0
+    k = kd.value
+    Qm = Q.reshape(kn + 1, n).T[:, :k + 1].copy()
+    Hm = H.reshape(kn, kn + 1).T[:k + 1, :k].copy()
+    return rc, Qm, Hm, k
+
+
+def gmres(A, b, x0, restart=30, max_restarts=10, tol_abs=1e-6, tol_rel=1e-4):
+    b, x0 = _f64(b), _f64(x0)
+    x = np.zeros(A.n, dtype=np.float64)
+    it, res, r0 = C.c_int64(0), C.c_double(0), C.c_double(0)
+    v = A.view()
+    rc = lib().orc_gmres(C.byref(v), C.c_int64(len(b)), _p(b), _p(x0), C.c_int64(restart),
+                         C.c_int64(max_restarts), C.c_double(tol_abs), C.c_double(tol_rel), _p(x),
+                         C.byref(it), C.byref(res), C.byref(r0))
+    return rc, x, it.value, res.value, r0.value
+
+
+def matmat(A, B):
+    """(##): returns (rc, Csr) structurally dense over rows(A) x cols(B)."""
+    cap = max(A.m * B.n, 1)
+    cp = np.zeros(A.m + 1, dtype=np.int64)
+    cc = np.zeros(cap, dtype=np.int64)
+    cv = np.zeros(cap, dtype=np.float64)
+    nn = C.c_int64(0)
+    va, vb = A.view(), B.view()
+    rc = lib().orc_matmat(C.byref(va), C.byref(vb), _p(cp), _p(cc), _p(cv), C.c_int64(cap), C.byref(nn))
+    if rc != OK:
+        return rc, None
+    k = nn.value
+    return rc, Csr(A.m, B.n, cp, cc[:k].copy(), cv[:k].copy())

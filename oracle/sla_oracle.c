@@ -1,0 +1,509 @@
+/*
+ * sla_oracle.c -- CPU restatement of the reference hot path.  See sla_oracle.h for status.
+ * TEST INFRASTRUCTURE ONLY: never linked into or called from the product (libsla_hip.so).
+ *
+ * Every function cites the reference file:line (relative to /root/reference) it restates.
+ * Arithmetic conventions restated from the reference:
+ *   - `sum` over an IntMap = strict left fold from 0 in ascending key order
+ *     (src/Data/Sparse/Internal/IntM.hs:17 derived Foldable, base-4.18 Foldable.sum);
+ *   - a*x then + : two roundings, never an FMA (build with -ffp-contract=off);
+ *   - x ^-^ y = x ^+^ negateV y  (Class.hs:68-69)  ->  x + (-(y));
+ *   - scalar norm2Sq = (**2) -> libm pow(x, 2.0)  (Class.hs:405-408).
+ */
+#include "sla_oracle.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ---------------------------------------------------------------- A0: construction */
+
+static int key_less_eq(const int64_t *row, const int64_t *col, int64_t a, int64_t b) {
+    if (row[a] != row[b]) return row[a] < row[b];
+    return col[a] <= col[b];
+}
+
+/* stable bottom-up merge sort of a permutation by (row, col) */
+static int sort_perm(int64_t nnz, const int64_t *row, const int64_t *col, int64_t *perm) {
+    int64_t *tmp = (int64_t *)malloc(sizeof(int64_t) * (size_t)(nnz > 0 ? nnz : 1));
+    if (!tmp) return ORC_ERR_ALLOC;
+    int64_t *src = perm, *dst = tmp;
+    for (int64_t w = 1; w < nnz; w *= 2) {
+        for (int64_t lo = 0; lo < nnz; lo += 2 * w) {
+            int64_t mid = lo + w < nnz ? lo + w : nnz;
+            int64_t hi = lo + 2 * w < nnz ? lo + 2 * w : nnz;
+            int64_t i = lo, j = mid, k = lo;
+            while (i < mid && j < hi) {
+                if (key_less_eq(row, col, src[i], src[j])) dst[k++] = src[i++];
+                else dst[k++] = src[j++];
+            }
+            while (i < mid) dst[k++] = src[i++];
+            while (j < hi) dst[k++] = src[j++];
+        }
+        int64_t *t = src; src = dst; dst = t;
+    }
+    if (src != perm) memcpy(perm, src, sizeof(int64_t) * (size_t)nnz);
+    free(tmp);
+    return ORC_OK;
+}
+
+/* fromListSM (SpMatrix.hs:218-224): foldl' of insertSpMatrix (:205-210) = IntMap.insert, so a
+ * later (i,j) replaces an earlier one (insertIM2, IntMap2.hs:24-28).  The IntMap-of-IntMap
+ * traversal order (ascending row, ascending col) is the CSR order of CSR.hs:74-78. */
+int orc_coo_to_csr(int64_t m, int64_t n, int64_t nnz, const int64_t *row, const int64_t *col,
+                   const double *val, int64_t *rowptr, int64_t *colidx, double *valout,
+                   int64_t *nnz_out) {
+    for (int64_t k = 0; k < nnz; ++k)
+        if (row[k] < 0 || row[k] >= m || col[k] < 0 || col[k] >= n) return ORC_ERR_OOB;
+    int64_t *perm = (int64_t *)malloc(sizeof(int64_t) * (size_t)(nnz > 0 ? nnz : 1));
+    if (!perm) return ORC_ERR_ALLOC;
+    for (int64_t k = 0; k < nnz; ++k) perm[k] = k;
+    int rc = sort_perm(nnz, row, col, perm);
+    if (rc) { free(perm); return rc; }
+    int64_t out = 0;
+    int64_t *rows_sorted = (int64_t *)malloc(sizeof(int64_t) * (size_t)(nnz > 0 ? nnz : 1));
+    if (!rows_sorted) { free(perm); return ORC_ERR_ALLOC; }
+    for (int64_t k = 0; k < nnz; ++k) {
+        int64_t a = perm[k];
+        /* the stable sort keeps input order inside a (row,col) group: keep its LAST member */
+        if (k + 1 < nnz && row[perm[k + 1]] == row[a] && col[perm[k + 1]] == col[a]) continue;
+        rows_sorted[out] = row[a];
+        colidx[out] = col[a];
+        valout[out] = val[a];
+        ++out;
+    }
+    orc_cs_ptr(m, rows_sorted, out, rowptr);
+    *nnz_out = out;
+    free(rows_sorted);
+    free(perm);
+    return ORC_OK;
+}
+
+/* csPtrV (==) n xs (vector/.../Vector/Utils.hs:12-26): ptr[0]=0, ptr[i+1]=ptr[i]+#{x==i};
+ * doc example [1,1,2,3], n=4 -> [0,0,2,3,4]. */
+void orc_cs_ptr(int64_t n, const int64_t *sorted_ix, int64_t len, int64_t *ptr) {
+    int64_t pos = 0, count = 0;
+    ptr[0] = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        while (pos < len && sorted_ix[pos] == i) { ++pos; ++count; }
+        ptr[i + 1] = count;
+    }
+}
+
+/* transposeIM2 = ifoldlIM2 (flip insertIM2) (IntMap2.hs:88-89): row j of A^T holds a_ij keyed by
+ * i, traversed ascending in i. */
+int orc_csr_transpose(int64_t m, int64_t n, const int64_t *rowptr, const int64_t *colidx,
+                      const double *val, int64_t *t_rowptr, int64_t *t_colidx, double *t_val) {
+    int64_t nnz = rowptr[m];
+    for (int64_t j = 0; j <= n; ++j) t_rowptr[j] = 0;
+    for (int64_t k = 0; k < nnz; ++k) t_rowptr[colidx[k] + 1]++;
+    for (int64_t j = 0; j < n; ++j) t_rowptr[j + 1] += t_rowptr[j];
+    int64_t *cursor = (int64_t *)malloc(sizeof(int64_t) * (size_t)(n > 0 ? n : 1));
+    if (!cursor) return ORC_ERR_ALLOC;
+    for (int64_t j = 0; j < n; ++j) cursor[j] = t_rowptr[j];
+    for (int64_t i = 0; i < m; ++i)
+        for (int64_t k = rowptr[i]; k < rowptr[i + 1]; ++k) {
+            int64_t d = cursor[colidx[k]]++;
+            t_colidx[d] = i;
+            t_val[d] = val[k];
+        }
+    free(cursor);
+    return ORC_OK;
+}
+
+/* isDiagonalSM (SpMatrix.hs:411-415): #rows whose map has exactly one entry, on the diagonal,
+ * must equal nrows. */
+int orc_is_diagonal(int64_t m, const int64_t *rowptr, const int64_t *colidx) {
+    int64_t d = 0;
+    for (int64_t i = 0; i < m; ++i)
+        if (rowptr[i + 1] - rowptr[i] == 1 && colidx[rowptr[i]] == i) ++d;
+    return d == m;
+}
+
+/* ---------------------------------------------------------------- A1..A4: BLAS-1 / SpMV */
+
+/* matVecSD (Common.hs:247-250): fmap (`dotu` x) rows; dotu u v = sum (liftI2 (*) u v)
+ * (:259-260): acc = 0; for ascending j: acc = acc + a_ij * x_j. */
+void orc_spmv(int64_t m, const int64_t *rowptr, const int64_t *colidx, const double *val,
+              const double *x, double *y) {
+    for (int64_t i = 0; i < m; ++i) {
+        double acc = 0.0;
+        for (int64_t k = rowptr[i]; k < rowptr[i + 1]; ++k) {
+            double prod = val[k] * x[colidx[k]];
+            acc = acc + prod;
+        }
+        y[i] = acc;
+    }
+}
+
+/* v <.> w = sum (liftI2 (<.>) v w)  (SpVector.hs:116-117; Double: (<.>) = (*), Class.hs:400) */
+double orc_dot(int64_t n, const double *x, const double *y) {
+    double acc = 0.0;
+    for (int64_t i = 0; i < n; ++i) {
+        double prod = x[i] * y[i];
+        acc = acc + prod;
+    }
+    return acc;
+}
+
+/* norm2Sq = sum . fmap norm2Sq (SpVector.hs:122); scalar norm2Sq = (**2) (Class.hs:407) */
+double orc_norm2sq(int64_t n, const double *x) {
+    double acc = 0.0;
+    for (int64_t i = 0; i < n; ++i) {
+        double sq = pow(x[i], 2.0);
+        acc = acc + sq;
+    }
+    return acc;
+}
+
+/* norm2 c = sqrt (norm2Sq c)  (SpVector.hs:128) */
+double orc_norm2(int64_t n, const double *x) { return sqrt(orc_norm2sq(n, x)); }
+
+/* (^+^) = liftU2 (+)  (SpVector.hs:107-108) on dense operands */
+void orc_add(int64_t n, const double *x, const double *y, double *out) {
+    for (int64_t i = 0; i < n; ++i) out[i] = x[i] + y[i];
+}
+/* x ^-^ y = x ^+^ negateV y  (Class.hs:68-69) */
+void orc_sub(int64_t n, const double *x, const double *y, double *out) {
+    for (int64_t i = 0; i < n; ++i) out[i] = x[i] + (-y[i]);
+}
+/* n .* v = fmap (n *) v  (SpVector.hs:112-114) */
+void orc_scale(int64_t n, double a, const double *x, double *out) {
+    for (int64_t i = 0; i < n; ++i) out[i] = a * x[i];
+}
+
+static double *vnew(int64_t n) { return (double *)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1)); }
+
+/* ---------------------------------------------------------------- A5: BiCGSTAB */
+
+/* bicgsInit aa b x0 = BICGSTAB x0 r0 r0, r0 = b ^-^ (aa #> x0)   (Sparse.hs:962-965) */
+void orc_bicgstab_init(const orc_csr *A, const double *b, const double *x0, double *x, double *r,
+                       double *p) {
+    int64_t n = A->m;
+    double *ax = vnew(n);
+    orc_spmv(A->m, A->rowptr, A->colidx, A->val, x0, ax);
+    orc_sub(n, b, ax, r);
+    memcpy(p, r, sizeof(double) * (size_t)n);
+    if (x != x0) memcpy(x, x0, sizeof(double) * (size_t)n);
+    free(ax);
+}
+
+/* bicgstabStep (Sparse.hs:972-981) */
+int orc_bicgstab_step(const orc_csr *A, const double *r0hat, double *x, double *r, double *p) {
+    int64_t n = A->m;
+    double *aap = vnew(n), *s = vnew(n), *aas = vnew(n), *t = vnew(n), *t2 = vnew(n);
+    if (!aap || !s || !aas || !t || !t2) return ORC_ERR_ALLOC;
+    orc_spmv(A->m, A->rowptr, A->colidx, A->val, p, aap);          /* aap = aa #> p          */
+    double rr0 = orc_dot(n, r, r0hat);
+    double alpha = rr0 / orc_dot(n, aap, r0hat);                    /* alphaj                 */
+    orc_scale(n, alpha, aap, t);
+    orc_sub(n, r, t, s);                                            /* sj = r ^-^ (alpha.*aap)*/
+    orc_spmv(A->m, A->rowptr, A->colidx, A->val, s, aas);           /* aasj = aa #> sj        */
+    double omega = orc_dot(n, aas, s) / orc_dot(n, aas, aas);       /* omegaj                 */
+    orc_scale(n, alpha, p, t);
+    orc_add(n, x, t, x);                                            /* (x ^+^ alpha.*p)       */
+    orc_scale(n, omega, s, t);
+    orc_add(n, x, t, x);                                            /*   ^+^ omega.*sj        */
+    double *rnew = t2;
+    orc_scale(n, omega, aas, t);
+    orc_sub(n, s, t, rnew);                                         /* rj1 = sj ^-^ omega.*aas*/
+    double beta = orc_dot(n, rnew, r0hat) / rr0 * alpha / omega;    /* ((a/b)*alpha)/omega    */
+    orc_scale(n, omega, aap, t);
+    orc_sub(n, p, t, t);                                            /* p ^-^ omega.*aap       */
+    orc_scale(n, beta, t, t);
+    orc_add(n, rnew, t, p);                                         /* pj1                    */
+    memcpy(r, rnew, sizeof(double) * (size_t)n);
+    free(aap); free(s); free(aas); free(t); free(t2);
+    return ORC_OK;
+}
+
+/* ---------------------------------------------------------------- A6: CGS */
+
+/* cgsInit aa b x0 = CGS x0 r0 r0 r0   (Sparse.hs:921-924) */
+void orc_cgs_init(const orc_csr *A, const double *b, const double *x0, double *x, double *r,
+                  double *p, double *u) {
+    int64_t n = A->m;
+    orc_bicgstab_init(A, b, x0, x, r, p);
+    memcpy(u, r, sizeof(double) * (size_t)n);
+}
+
+/* cgsStep (Sparse.hs:928-939) */
+int orc_cgs_step(const orc_csr *A, const double *rhat, double *x, double *r, double *p, double *u) {
+    int64_t n = A->m;
+    double *aap = vnew(n), *q = vnew(n), *uq = vnew(n), *t = vnew(n), *auq = vnew(n);
+    if (!aap || !q || !uq || !t || !auq) return ORC_ERR_ALLOC;
+    orc_spmv(A->m, A->rowptr, A->colidx, A->val, p, aap);           /* aap = aa #> p          */
+    double rr = orc_dot(n, r, rhat);
+    double alpha = rr / orc_dot(n, aap, rhat);                      /* alphaj                 */
+    orc_scale(n, alpha, aap, t);
+    orc_sub(n, u, t, q);                                            /* q = u ^-^ alpha.*aap   */
+    orc_add(n, u, q, uq);                                           /* u ^+^ q                */
+    orc_scale(n, alpha, uq, t);
+    orc_add(n, x, t, x);                                            /* xj1                    */
+    orc_spmv(A->m, A->rowptr, A->colidx, A->val, uq, auq);          /* aa #> (u ^+^ q)        */
+    orc_scale(n, alpha, auq, t);
+    orc_sub(n, r, t, r);                                            /* rj1 (in place)         */
+    double beta = orc_dot(n, r, rhat) / rr;                         /* betaj                  */
+    orc_scale(n, beta, q, t);
+    orc_add(n, r, t, u);                                            /* uj1 = rj1 ^+^ beta.*q  */
+    orc_scale(n, beta, p, t);
+    orc_add(n, q, t, t);                                            /* q ^+^ beta.*p          */
+    orc_scale(n, beta, t, t);
+    orc_add(n, u, t, p);                                            /* pj1                    */
+    free(aap); free(q); free(uq); free(t); free(auq);
+    return ORC_OK;
+}
+
+/* ---------------------------------------------------------------- A7: CGNE */
+
+/* cgneInit (Sparse.hs:864-868): r0 = b ^-^ (aa #> x0); p0 = transposeSM aa #> r0 */
+void orc_cgne_init(const orc_csr *A, const orc_csr *At, const double *b, const double *x0,
+                   double *x, double *r, double *p) {
+    int64_t n = A->m;
+    double *ax = vnew(n);
+    orc_spmv(A->m, A->rowptr, A->colidx, A->val, x0, ax);
+    orc_sub(n, b, ax, r);
+    orc_spmv(At->m, At->rowptr, At->colidx, At->val, r, p);
+    if (x != x0) memcpy(x, x0, sizeof(double) * (size_t)A->n);
+    free(ax);
+}
+
+/* cgneStep (Sparse.hs:870-878) */
+int orc_cgne_step(const orc_csr *A, const orc_csr *At, double *x, double *r, double *p) {
+    int64_t m = A->m, n = A->n;
+    double *t = vnew(n > m ? n : m), *ap = vnew(m), *atr = vnew(n);
+    if (!t || !ap || !atr) return ORC_ERR_ALLOC;
+    double rr = orc_dot(m, r, r);
+    double alpha = rr / orc_dot(n, p, p);                           /* alphai                 */
+    orc_scale(n, alpha, p, t);
+    orc_add(n, x, t, x);                                            /* x1                     */
+    orc_spmv(A->m, A->rowptr, A->colidx, A->val, p, ap);
+    orc_scale(m, alpha, ap, t);
+    orc_sub(m, r, t, r);                                            /* r1                     */
+    double beta = orc_dot(m, r, r) / rr;                            /* beta                   */
+    orc_spmv(At->m, At->rowptr, At->colidx, At->val, r, atr);       /* transpose aa #> r1     */
+    orc_scale(n, beta, p, t);
+    orc_add(n, atr, t, p);                                          /* p1                     */
+    free(t); free(ap); free(atr);
+    return ORC_OK;
+}
+
+/* ---------------------------------------------------------------- A8: linSolve0 */
+
+/* trueResidualNorm x = norm2 ((aa #> x) ^-^ b)   (Sparse.hs:1041) */
+static double true_resnorm(const orc_csr *A, const double *x, const double *b, double *w) {
+    orc_spmv(A->m, A->rowptr, A->colidx, A->val, x, w);
+    orc_sub(A->m, w, b, w);
+    return orc_norm2(A->m, w);
+}
+
+/* linSolve0 (Sparse.hs:1016-1072) */
+int orc_linsolve0(int method, const orc_csr *A, int64_t nb, const double *b, const double *x0,
+                  double *x_out, int64_t *iters_out, double *resnorm_out, double *r0norm_out) {
+    int64_t m = A->m, n = A->n;
+    *iters_out = 0; *resnorm_out = NAN; *r0norm_out = NAN;
+    if (m != nb) return ORC_ERR_DIM;                                /* :1022                  */
+    if (orc_is_diagonal(m, A->rowptr, A->colidx)) {                 /* :1024-1025             */
+        /* reciprocal aa #> b: row i = 0 + recip(a_ii) * b_i (Class.hs:174, Common.hs:247) */
+        for (int64_t i = 0; i < m; ++i) {
+            double prod = (1.0 / A->val[A->rowptr[i]]) * b[i];
+            x_out[i] = 0.0 + prod;
+        }
+        return ORC_OK;
+    }
+    if (method != ORC_BICGSTAB && method != ORC_CGS && method != ORC_CGNE)
+        return ORC_ERR_UNSUPPORTED;                                 /* :1031                  */
+    int64_t nv = n > m ? n : m;
+    double *r0hat = vnew(nv), *x = vnew(nv), *r = vnew(nv), *p = vnew(nv), *u = vnew(nv), *w = vnew(nv);
+    int64_t *tp = NULL, *tc = NULL; double *tv = NULL;
+    orc_csr At = {0};
+    if (!r0hat || !x || !r || !p || !u || !w) return ORC_ERR_ALLOC;
+    orc_spmv(m, A->rowptr, A->colidx, A->val, x0, w);
+    orc_sub(m, b, w, r0hat);                                        /* r0hat (:1032)          */
+    double r0norm = orc_norm2(m, r0hat);                            /* :1033                  */
+    double tol = fmax(1e-6, 1e-4 * r0norm);                         /* :1034-1037             */
+    *r0norm_out = r0norm;
+    const int64_t nits = 200;
+    if (method == ORC_BICGSTAB) orc_bicgstab_init(A, b, x0, x, r, p);
+    else if (method == ORC_CGS) orc_cgs_init(A, b, x0, x, r, p, u);
+    else {
+        int64_t nnz = A->rowptr[m];
+        tp = (int64_t *)malloc(sizeof(int64_t) * (size_t)(n + 1));
+        tc = (int64_t *)malloc(sizeof(int64_t) * (size_t)(nnz > 0 ? nnz : 1));
+        tv = vnew(nnz);
+        if (!tp || !tc || !tv) return ORC_ERR_ALLOC;
+        orc_csr_transpose(m, n, A->rowptr, A->colidx, A->val, tp, tc, tv);
+        At.m = n; At.n = m; At.rowptr = tp; At.colidx = tc; At.val = tv;
+        orc_cgne_init(A, &At, b, x0, x, r, p);
+    }
+    int64_t it = 0;
+    for (;;) {                                                      /* runIter (:1043-1052)   */
+        if (it >= nits) break;                                      /* silent return at 200   */
+        if (method == ORC_BICGSTAB) orc_bicgstab_step(A, r0hat, x, r, p);
+        else if (method == ORC_CGS) orc_cgs_step(A, r0hat, x, r, p, u);
+        else orc_cgne_step(A, &At, x, r, p);
+        double res = true_resnorm(A, x, b, w);
+        *resnorm_out = res;
+        ++it;
+        if (res <= tol) break;                                      /* NaN compares false     */
+    }
+    *iters_out = it;
+    memcpy(x_out, x, sizeof(double) * (size_t)n);
+    free(r0hat); free(x); free(r); free(p); free(u); free(w); free(tp); free(tc); free(tv);
+    return ORC_OK;
+}
+
+/* ---------------------------------------------------------------- A9: Arnoldi */
+
+/* normalize2 v = v ./ norm2 v = (recip (norm2 v)) .* v   (Class.hs:94-95, SpVector.hs:126) */
+static void normalize2(int64_t n, const double *v, double *out) {
+    double s = 1.0 / orc_norm2(n, v);
+    orc_scale(n, s, v, out);
+}
+
+/* arnoldi (Sparse.hs:630-667).  Loop state (qv, hh, i, fbreak) starts at i = 1 with two basis
+ * vectors; stops when i == kn || fbreak.  Returned k_done = final i (= nmax). */
+int orc_arnoldi(const orc_csr *A, int64_t nb, const double *b, int64_t kn, double *Q, double *H,
+                int64_t *k_done) {
+    int64_t m = A->m, n = A->n;
+    if (n != nb) return ORC_ERR_DIM;                                /* :636-637               */
+    int64_t ldh = kn + 1;
+    for (int64_t k = 0; k < ldh * kn; ++k) H[k] = 0.0;
+    double *aq = vnew(m), *acc = vnew(m), *t = vnew(m), *hcol = vnew(kn + 2);
+    if (!aq || !acc || !t || !hcol) return ORC_ERR_ALLOC;
+    double *q0 = Q, *q1 = Q + n;
+    normalize2(n, b, q0);                                           /* q0 = normalize2 b      */
+    orc_spmv(m, A->rowptr, A->colidx, A->val, q0, aq);              /* aq0 = aa #> q0         */
+    double h11 = orc_dot(n, q0, aq);                                /* h11 = q0 `dot` aq0     */
+    orc_scale(n, h11, q0, t);
+    orc_sub(n, aq, t, acc);                                         /* q1nn                   */
+    double h21 = orc_norm2(n, acc);                                 /* norm2' q1nn            */
+    normalize2(n, acc, q1);
+    H[0] = h11;
+    if (kn >= 1) H[1] = h21;
+    int64_t i = 1;
+    int fbreak = 0;
+    while (!(i == kn || fbreak)) {                                  /* modifyUntil tf (:638)  */
+        const double *qi = Q + i * n;                               /* V.last qv              */
+        orc_spmv(m, A->rowptr, A->colidx, A->val, qi, aq);          /* aqi                    */
+        for (int64_t k = 0; k <= i; ++k) hcol[k] = orc_dot(n, Q + k * n, aq);   /* :655       */
+        /* V.foldl' (^+^) zv (zipWith (.*) hhcoli qv): zv is the EMPTY map, so the first
+         * union passes h0*q0 through unchanged. */
+        orc_scale(n, hcol[0], Q, acc);
+        for (int64_t k = 1; k <= i; ++k) {
+            orc_scale(n, hcol[k], Q + k * n, t);
+            orc_add(n, acc, t, acc);
+        }
+        orc_sub(n, aq, acc, acc);                                   /* qipnn (:657-658)       */
+        double nrm = orc_norm2(n, acc);                             /* qipnorm                */
+        normalize2(n, acc, Q + (i + 1) * n);                        /* qip                    */
+        for (int64_t k = 0; k <= i; ++k) H[i * ldh + k] = hcol[k];
+        H[i * ldh + i + 1] = nrm;
+        fbreak = fabs(nrm) <= 1e-12;                                /* nearZero (Eps.hs:41-42)*/
+        ++i;
+    }
+    *k_done = i;
+    free(aq); free(acc); free(t); free(hcol);
+    return ORC_OK;
+}
+
+/* ---------------------------------------------------------------- A10: GMRES(m) */
+
+/* min_y || beta e1 - H y ||, H (k+1) x k column-major with leading dimension ldh, by Givens
+ * rotations + back substitution (the commented sketch Sparse.hs:837-848 does qr + triUpperSolve). */
+static void hessenberg_lsq(int64_t k, int64_t ldh, const double *H, double beta, double *y) {
+    double *R = vnew((k + 1) * k), *g = vnew(k + 1);
+    for (int64_t j = 0; j < k; ++j)
+        for (int64_t i = 0; i <= k; ++i) R[j * (k + 1) + i] = H[j * ldh + i];
+    for (int64_t i = 0; i <= k; ++i) g[i] = 0.0;
+    g[0] = beta;
+    for (int64_t j = 0; j < k; ++j) {
+        double a = R[j * (k + 1) + j], b = R[j * (k + 1) + j + 1];
+        double d = hypot(a, b), c = 1.0, s = 0.0;
+        if (d != 0.0) { c = a / d; s = b / d; }
+        for (int64_t l = j; l < k; ++l) {
+            double u = R[l * (k + 1) + j], v = R[l * (k + 1) + j + 1];
+            R[l * (k + 1) + j] = c * u + s * v;
+            R[l * (k + 1) + j + 1] = -s * u + c * v;
+        }
+        double gu = g[j], gv = g[j + 1];
+        g[j] = c * gu + s * gv;
+        g[j + 1] = -s * gu + c * gv;
+    }
+    for (int64_t i = k - 1; i >= 0; --i) {
+        double acc = g[i];
+        for (int64_t l = i + 1; l < k; ++l) acc -= R[l * (k + 1) + i] * y[l];
+        y[i] = acc / R[i * (k + 1) + i];
+    }
+    free(R); free(g);
+}
+
+int orc_gmres(const orc_csr *A, int64_t nb, const double *b, const double *x0, int64_t restart,
+              int64_t max_restarts, double tol_abs, double tol_rel, double *x_out,
+              int64_t *iters_out, double *resnorm_out, double *r0norm_out) {
+    int64_t m = A->m, n = A->n;
+    *iters_out = 0; *resnorm_out = NAN; *r0norm_out = NAN;
+    if (m != nb || m != n) return ORC_ERR_DIM;
+    double *x = vnew(n), *r = vnew(n), *w = vnew(n), *Q = vnew(n * (restart + 1)),
+           *H = vnew((restart + 1) * restart), *y = vnew(restart), *t = vnew(n);
+    if (!x || !r || !w || !Q || !H || !y || !t) return ORC_ERR_ALLOC;
+    memcpy(x, x0, sizeof(double) * (size_t)n);
+    double tol = 0.0;
+    for (int64_t cyc = 0; cyc <= max_restarts; ++cyc) {
+        orc_spmv(m, A->rowptr, A->colidx, A->val, x, w);
+        orc_sub(n, b, w, r);
+        double beta = orc_norm2(n, r);
+        if (cyc == 0) { *r0norm_out = beta; tol = fmax(tol_abs, tol_rel * beta); }
+        *resnorm_out = beta;
+        if (beta <= tol || cyc == max_restarts) break;
+        int64_t k = 0;
+        orc_arnoldi(A, n, r, restart, Q, H, &k);
+        hessenberg_lsq(k, restart + 1, H, beta, y);
+        for (int64_t j = 0; j < k; ++j) {                           /* x += Q[:, :k] y        */
+            orc_scale(n, y[j], Q + j * n, t);
+            orc_add(n, x, t, x);
+        }
+        *iters_out += k;
+    }
+    memcpy(x_out, x, sizeof(double) * (size_t)n);
+    free(x); free(r); free(w); free(Q); free(H); free(y); free(t);
+    return ORC_OK;
+}
+
+/* ---------------------------------------------------------------- A11: (##) */
+
+/* matMatUnsafeWith transposeIM2 (SpMatrix.hs:808-811): for every row key of A and every column
+ * key of B: sum (liftI2 (*) colB rowA), ascending k; explicit zeros are kept. */
+int orc_matmat(const orc_csr *A, const orc_csr *B, int64_t *c_rowptr, int64_t *c_colidx,
+               double *c_val, int64_t cap, int64_t *c_nnz) {
+    if (A->n != B->m) return ORC_ERR_DIM;                           /* matMatCheck (:795)     */
+    int64_t bnnz = B->rowptr[B->m];
+    int64_t *tp = (int64_t *)malloc(sizeof(int64_t) * (size_t)(B->n + 1));
+    int64_t *tc = (int64_t *)malloc(sizeof(int64_t) * (size_t)(bnnz > 0 ? bnnz : 1));
+    double *tv = vnew(bnnz);
+    if (!tp || !tc || !tv) return ORC_ERR_ALLOC;
+    orc_csr_transpose(B->m, B->n, B->rowptr, B->colidx, B->val, tp, tc, tv);
+    int64_t out = 0;
+    c_rowptr[0] = 0;
+    for (int64_t i = 0; i < A->m; ++i) {
+        int64_t a0 = A->rowptr[i], a1 = A->rowptr[i + 1];
+        if (a1 > a0) {                                              /* row key present in A   */
+            for (int64_t j = 0; j < B->n; ++j) {
+                int64_t b0 = tp[j], b1 = tp[j + 1];
+                if (b1 == b0) continue;                             /* column key absent in B */
+                double acc = 0.0;
+                int64_t ka = a0, kb = b0;
+                while (ka < a1 && kb < b1) {                        /* intersectionWith (*)   */
+                    if (A->colidx[ka] < tc[kb]) ++ka;
+                    else if (A->colidx[ka] > tc[kb]) ++kb;
+                    else { double prod = tv[kb] * A->val[ka]; acc = acc + prod; ++ka; ++kb; }
+                }
+                if (out >= cap) { free(tp); free(tc); free(tv); return ORC_ERR_ALLOC; }
+                c_colidx[out] = j; c_val[out] = acc; ++out;
+            }
+        }
+        c_rowptr[i + 1] = out;
+    }
+    *c_nnz = out;
+    free(tp); free(tc); free(tv);
+    return ORC_OK;
+}
