@@ -1,0 +1,234 @@
+#!/usr/bin/env python
+"""bench.py -- BiCGSTAB iterations/s (+ CSR SpMV GB/s against the HBM3E roofline) on MI355X.
+
+One "step" = one bicgstabStep (Sparse.hs:972-981: 2 SpMV + 5 inner products + 6 vector updates, all on
+the device) on the BASELINE.json workload.  Default workload = configs[3], the one the metric is quoted
+on at 1/2/4/8 GPUs: the 10M-row (216^3 = 10 077 696) fp64 7-point 3-D Laplacian; at N > 1 it is
+row-sharded in contiguous slabs (strong scaling: total size fixed) with an RCCL all-gather of the SpMV
+input per SpMV.  Inputs are resident in HBM before the timed region.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload laplace3d_10m|poisson2d_1m|banded_2m|random_spd_1m]
+                    [--mode step|linsolve0] [--no-cpu-baseline]
+
+For N > 1 launch through torch.distributed.run (one rank per GPU); rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "sparse-linear-algebra_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
+
+
+def workload(name, row_begin=0, row_end=None):
+    from sla_amd import workloads as wl
+    if name == "laplace3d_10m":
+        return "10M-row fp64 7-pt 3-D Laplacian (216^3 = 10077696 rows), BiCGSTAB", wl.laplace3d(216, 216, 216, row_begin, row_end)
+    if name == "poisson2d_1m":
+        return "1M-row fp64 5-pt Poisson (1000x1000), BiCGSTAB", wl.poisson2d(1000, 1000, row_begin, row_end)
+    if name == "banded_2m":
+        return "2M-row fp64 non-symmetric banded (5 bands), BiCGSTAB", wl.banded_nonsym(2000000, 99, row_begin, row_end)
+    if name == "laplace3d_small":
+        return "64^3 7-pt Laplacian (test size)", wl.laplace3d(64, 64, 64, row_begin, row_end)
+    if name == "random_spd_1m":
+        dims, (rp, ci, va) = wl.random_spd(1000000, 16, 42)
+        row_end = dims[0] if row_end is None else row_end
+        from sla_amd.partition import local_rows_of
+        return "1M-row fp64 random SPD (~33 nnz/row), BiCGSTAB", (dims, local_rows_of(rp, ci, va, row_begin, row_end))
+    raise SystemExit(f"unknown workload {name}")
+
+
+def cpu_baseline(dims, rp, ci, va, b, seconds):
+    """The oracle (scalar C port of the reference's algorithm, 1 thread) timed on this host, on a bounded
+    sample: as many bicgstabStep's of the SAME matrix as fit in ~`seconds`."""
+    from oracle import oracle as orc
+    n = dims[0]
+    Ao = orc.Csr(n, n, rp, ci, va)
+    x0 = np.zeros(n)
+    st = orc.BicgstabState(Ao, b, x0)
+    r0hat = b.copy()
+    t0 = time.perf_counter()
+    st.step(r0hat, 1)
+    t1 = time.perf_counter() - t0
+    steps = max(2, min(200, int(seconds / max(t1, 1e-6))))
+    t0 = time.perf_counter()
+    st.step(r0hat, steps)
+    dt = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    reps = max(1, min(50, int(0.25 * seconds / max(t1 / 3, 1e-6))))
+    for _ in range(reps):
+        orc.spmv(Ao, b)
+    dts = (time.perf_counter() - t0) / reps
+    return {"value": steps / dt, "unit": "iters/s", "cores": 1, "kind": "port",
+            "sample": f"{steps} bicgstabStep iterations of the same {n}-row matrix, single thread, oracle/sla_oracle.c (gcc -O2 -ffp-contract=off)",
+            "host_cores_available": os.cpu_count(),
+            "spmv_gbps": (12 * len(ci) + 20 * n) / dts / 1e9}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default=os.environ.get("SLA_BENCH_WORKLOAD", "laplace3d_10m"))
+    ap.add_argument("--mode", default="step", choices=["step", "linsolve0"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        # control plane (unique-id broadcast, barriers, max-over-ranks) on gloo; the data plane is the
+        # library's own RCCL communicator over xGMI
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+
+    import sla_amd as sla
+    from sla_amd import _lib
+    from sla_amd.partition import row_block
+
+    if world > 1:
+        import torch
+        uid = [sla.Context.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        ctx = sla.Context(local_rank, rank, world, uid[0])
+    else:
+        ctx = sla.Context(0)
+    sla.set_default_context(ctx)
+
+    # ---- build this rank's slab on the host, lower it once to the device CSR ---------------------------
+    desc0, (dims, _) = workload(args.workload, 0, 1)
+    n = dims[0]
+    rb, re_ = row_block(n, rank, world)
+    desc, (dims, (rp, ci, va)) = workload(args.workload, rb, re_)
+    nnz_local = int(rp[-1])
+    A = sla.fromCSRRows(dims, rb, rp, ci, va, ctx)
+    b_local = np.add.reduceat(va, rp[:-1]) if nnz_local else np.zeros(0)   # b = A . 1  (x* = 1), x0 = 0
+    nnz = nnz_local
+    if world > 1:
+        import torch
+        t = torch.tensor([nnz_local], dtype=torch.int64)
+        dist.all_reduce(t)
+        nnz = int(t.item())
+    bvec = sla.DeviceVector(ctx, n, b_local, local=True)
+    x0 = sla.DeviceVector(ctx, n)
+
+    def sync_all():
+        ctx.sync()
+        if world > 1:
+            import torch
+            torch.cuda.synchronize()
+            dist.barrier()
+
+    extra = {}
+    if args.mode == "step":
+        st = sla.bicgsInit(A, bvec, x0)
+        st.step(args.warmup)
+        sync_all()
+        ctx.prof_start(_lib.KERNEL_SPMV_DOT, args.steps)
+        t0 = time.perf_counter()
+        st.step(args.steps)
+        sync_all()
+        dt = time.perf_counter() - t0
+        launches, mean_ms, min_ms = ctx.prof_stop()
+        step_bytes = 24 * nnz + 160 * n
+        mode_desc = "bicgstabStep (2 SpMV, no true-residual SpMV)"
+    else:
+        # reference-faithful linSolve0 iteration: bicgstabStep + true residual ||A x - b|| every iteration
+        lib = _lib.lib()
+        import ctypes as C
+        out = sla.DeviceVector(ctx, n)
+        info = _lib.SolveInfo()
+        o = _lib.SolveOpts(args.warmup, 0.0, 0.0, 16, 1)
+        _lib.check(lib.sla_linsolve0(4, A.h, bvec.h, x0.h, C.byref(o), out.h, C.byref(info)))
+        sync_all()
+        o = _lib.SolveOpts(args.steps, 0.0, 0.0, max(args.steps, 1), 1)      # tol 0: run exactly K iterations
+        ctx.prof_start(_lib.KERNEL_SPMV_DOT, args.steps)
+        t0 = time.perf_counter()
+        _lib.check(lib.sla_linsolve0(4, A.h, bvec.h, x0.h, C.byref(o), out.h, C.byref(info)))
+        sync_all()
+        dt = time.perf_counter() - t0
+        launches, mean_ms, min_ms = ctx.prof_stop()
+        step_bytes = 36 * nnz + 180 * n
+        mode_desc = "linSolve0 iteration (bicgstabStep + per-iteration true residual, 3 SpMV)"
+        extra["linsolve0_iters"] = info.iters
+
+    if world > 1:
+        import torch
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # ---- plain SpMV bandwidth (rank-local rows; includes the all-gather when sharded) -------------------
+    xv, yv = sla.DeviceVector(ctx, n, np.ones(re_ - rb), local=True), sla.DeviceVector(ctx, n)
+    lib = _lib.lib()
+    for _ in range(5):
+        _lib.check(lib.sla_spmv(A.h, xv.h, yv.h))
+    sync_all()
+    reps = 50
+    ctx.prof_start(_lib.KERNEL_SPMV, reps)
+    for _ in range(reps):
+        _lib.check(lib.sla_spmv(A.h, xv.h, yv.h))
+    sp_launch, sp_mean_ms, sp_min_ms = ctx.prof_stop()
+    n_local = re_ - rb
+    spmv_bytes_local = 12 * nnz_local + 20 * n_local
+
+    if rank == 0:
+        k1_bytes = 12 * nnz_local + 28 * n_local      # K1 = SpMV (12 nnz + 20 n) + r0hat read for the fused dot (8 n)
+        achieved = k1_bytes / (mean_ms * 1e-3) / 1e9 if launches else 0.0
+        rec = {
+            "metric": "bicgstab_iters_per_sec",
+            "value": args.steps / dt,
+            "unit": "iters/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": desc, "rows": n, "nnz": nnz, "timed": mode_desc,
+                       "index_types": "i32 col / i32 rowptr", "parallelism": f"row-block x{world}",
+                       "spmv_kernel": A.kernel_info()},
+            "step_gbps": step_bytes / (dt / args.steps) / 1e9 / 1.0,
+            "step_frac_of_hbm_peak": step_bytes / (dt / args.steps) / 1e9 / (HBM_PEAK_GBS * world),
+            "spmv_gbps": spmv_bytes_local * world / (sp_mean_ms * 1e-3) / 1e9 if sp_launch else None,
+            "spmv_ms": sp_mean_ms,
+            "roofline": {"bound": "hbm", "kernel": "spmv_stream_kernel<EPI_DOT> (K1: Ap = A p fused with Ap . r0hat)",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "bytes_per_launch": k1_bytes, "avg_launch_ms": mean_ms, "min_launch_ms": min_ms,
+                         "launches_timed": launches},
+        }
+        rec.update(extra)
+        if not args.no_cpu_baseline and world == 1:
+            rec["cpu_baseline"] = cpu_baseline(dims, rp, ci, va, b_local, args.cpu_seconds)
+        print(json.dumps(rec), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,213 @@
+/*
+ * sla_hip.h -- C ABI of libsla_hip.so: the MI355X (gfx950) backend for the SpMV-dominated
+ * hot path of ocramz/sparse-linear-algebra (Numeric.LinearAlgebra.Sparse).
+ *
+ * The reference has no FFI of its own (it is pure Haskell); its extension surface is the
+ * typeclass set of src/Numeric/LinearAlgebra/Class.hs with the instances in
+ * src/Data/Sparse/{Common,SpVector,SpMatrix}.hs.  Each entry point below names the reference
+ * method (file:line, relative to the reference repo) it stands in for; INTEGRATION.md shows the
+ * `foreign import ccall` module a maintainer adds on the Haskell side.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; int64_t = Haskell Int, double = Haskell Double;
+ *   - every call returns an sla_status; sla_last_error() gives a thread-local message;
+ *   - host arrays are borrowed for the duration of the call; handles are owned by the library
+ *     and released by the matching *_destroy;
+ *   - a context and everything created from it is single-threaded (one caller at a time);
+ *   - all device work is enqueued on the context's HIP stream; calls that return values to the
+ *     host synchronise, the others may return after enqueue;
+ *   - non-convergence is NOT an error (Sparse.hs:1045 returns silently after 200 iterations): it
+ *     is reported in sla_solve_info.flags.
+ */
+#ifndef SLA_HIP_H
+#define SLA_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    SLA_OK = 0,
+    SLA_ERR_DIM_MISMATCH = 1,       /* MatVecSizeMismatchException (Control/Exception/Common.hs:44-51),
+                                       `error "matVec : mismatched dimensions"` (Common.hs:250) */
+    SLA_ERR_UNSUPPORTED_METHOD = 2, /* IterE "linSolve0" "Only BICGSTAB_, CGS_, and CGNE_ ..." (Sparse.hs:1031) */
+    SLA_ERR_OOB = 3,                /* `error "insertSpMatrix : index out of bounds"` (SpMatrix.hs:208) */
+    SLA_ERR_HIP = 4,
+    SLA_ERR_RCCL = 5,
+    SLA_ERR_ALLOC = 6,
+    SLA_ERR_INVALID = 7,            /* NULL handle, negative size, size beyond the device index width */
+    SLA_ERR_NO_DEVICE = 8           /* no HIP device: the library has no CPU fallback */
+} sla_status;
+
+/* LinSolveMethod, constructor order of Sparse.hs:1007-1011 */
+typedef enum { SLA_GMRES_ = 0, SLA_CGNE_ = 1, SLA_BCG_ = 2, SLA_CGS_ = 3, SLA_BICGSTAB_ = 4 } sla_method;
+
+/* duplicate policy of sla_csr_from_coo */
+typedef enum {
+    SLA_DUP_LAST_WINS = 0, /* fromListSM (SpMatrix.hs:218-224, IntMap2.hs:24-28) */
+    SLA_DUP_SUM = 1        /* MatrixMarket-style assembly (extension; not a reference behaviour) */
+} sla_dup_policy;
+
+typedef struct sla_ctx *sla_ctx_t;       /* one GPU (one rank of a row-sharded job): stream, scratch, RCCL comm */
+typedef struct sla_csr *sla_csr_t;       /* device CSR (this rank's row block); immutable after creation */
+typedef struct sla_vec *sla_vec_t;       /* device dense f64 vector (this rank's row block) */
+typedef struct sla_solver *sla_solver_t; /* CGS / BiCGSTAB / CGNE state record on the device */
+
+/* solver options; NULL = the reference's hard-coded values (Sparse.hs:1034-1037) */
+typedef struct {
+    int32_t max_iters;     /* nits   = 200  */
+    double tol_abs;        /* tolAbs = 1e-6 */
+    double tol_rel;        /* tolRel = 1e-4 */
+    int32_t check_every;   /* host polls the device convergence flag every this many iterations
+                              (default 16); the device itself tests the TRUE residual after EVERY
+                              iteration exactly as runIter does (Sparse.hs:1043-1052), so the
+                              returned iterate is the reference's regardless of this value */
+    int32_t true_residual; /* 1 (default) = recompute ||A x - b|| each iteration like the reference;
+                              0 = extension: skip the check SpMV and run max_iters steps */
+} sla_solve_opts;
+
+enum { /* sla_solve_info.flags */
+    SLA_FLAG_CONVERGED = 1,   /* resnorm <= tol reached */
+    SLA_FLAG_MAX_ITERS = 2,   /* returned after max_iters without meeting tol (reference: silent) */
+    SLA_FLAG_DIAGONAL = 4,    /* isDiagonalSM shortcut taken (Sparse.hs:1024-1025) */
+    SLA_FLAG_BREAKDOWN = 8,   /* Arnoldi: nearZero h_{i+1,i} (Sparse.hs:665-667) */
+    SLA_FLAG_NONFINITE = 16   /* residual became NaN/Inf (reference propagates NaN, no guard) */
+};
+
+typedef struct {
+    int32_t iters;   /* solver steps taken */
+    int32_t flags;
+    double resnorm;  /* last true residual norm ||A x - b||_2 evaluated (NaN if none) */
+    double r0norm;   /* ||b - A x0||_2 */
+    double tol;      /* max tol_abs (tol_rel * r0norm) */
+} sla_solve_info;
+
+/* which state vector sla_solver_get returns: record fields _x/_r/_p/_u (Sparse.hs:919),
+ * _xBicgstab/_rBicgstab/_pBicgstab (:959-960), _xCgne/_rCgne/_pCgne (:855-856) */
+typedef enum { SLA_STATE_X = 0, SLA_STATE_R = 1, SLA_STATE_P = 2, SLA_STATE_U = 3 } sla_state_field;
+
+/* ---- context ---------------------------------------------------------------------------------- */
+
+/* Single-GPU context on `device_id`.  SLA_ERR_NO_DEVICE when no GPU is visible. */
+int sla_ctx_create(int device_id, sla_ctx_t *out);
+/* One rank of a row-sharded job (one process per GPU).  unique_id = the 128 bytes produced by
+ * sla_dist_unique_id on rank 0 and distributed out of band (bench.py uses torch.distributed). */
+int sla_dist_unique_id(void *unique_id_128);
+int sla_ctx_create_dist(int device_id, int rank, int nranks, const void *unique_id_128, sla_ctx_t *out);
+int sla_ctx_destroy(sla_ctx_t);
+int sla_ctx_sync(sla_ctx_t);  /* hipStreamSynchronize of the context stream */
+int sla_ctx_rank(sla_ctx_t, int *rank, int *nranks);
+/* rows [begin, end) of an m-row matrix / m-vector owned by this rank (contiguous 1-D row blocks) */
+int sla_ctx_row_range(sla_ctx_t, int64_t m, int64_t *begin, int64_t *end);
+const char *sla_last_error(void);
+const char *sla_version(void);
+
+/* ---- A0: SpMatrix -> device CSR ("lower once") ------------------------------------------------ */
+
+/* fromListSM (m,n) triples (SpMatrix.hs:218-224): sort by (row, col), duplicates resolved by
+ * `dup_policy`, canonical CSR of vector/src/Data/Sparse/Internal/CSR.hs:43-50,74-78.  Every rank
+ * passes the full triple list and keeps its own row block. */
+int sla_csr_from_coo(sla_ctx_t, int64_t m, int64_t n, int64_t nnz, const int64_t *row, const int64_t *col,
+                     const double *val, int dup_policy, sla_csr_t *out);
+/* Already-canonical CSR (ascending columns inside each row, no duplicates).  `rowptr` has m+1 entries. */
+int sla_csr_from_csr(sla_ctx_t, int64_t m, int64_t n, const int64_t *rowptr, const int64_t *colidx,
+                     const double *val, sla_csr_t *out);
+/* Pre-sharded input: this rank's rows [row_begin, row_begin+row_count) of an m x n matrix, with
+ * rowptr_local[0] == 0 and GLOBAL column indices.  row range must equal sla_ctx_row_range(m). */
+int sla_csr_from_csr_rows(sla_ctx_t, int64_t m, int64_t n, int64_t row_begin, int64_t row_count,
+                          const int64_t *rowptr_local, const int64_t *colidx, const double *val, sla_csr_t *out);
+int sla_csr_destroy(sla_csr_t);
+/* dim / nnz of SpMatrix (local_rows/local_nnz = this rank's block) */
+int sla_csr_dims(sla_csr_t, int64_t *m, int64_t *n, int64_t *nnz_local, int64_t *rows_local);
+/* Device arrays copied back and widened to int64 for bit-exact index parity checks (local block;
+ * rowptr has rows_local+1 entries starting at 0). */
+int sla_csr_export(sla_csr_t, int64_t *rowptr, int64_t *colidx, double *val);
+/* isDiagonalSM (SpMatrix.hs:411-415) evaluated at creation (global answer on every rank) */
+int sla_csr_is_diagonal(sla_csr_t, int *out);
+
+/* ---- SpVector (dense on the device) ------------------------------------------------------------ */
+
+/* fromListDenseSV / mkSpVR / fromVector (SpVector.hs:183,194,240): `host` holds all n entries; each
+ * rank keeps its block.  host == NULL gives zeroV. */
+int sla_vec_create(sla_ctx_t, int64_t n, const double *host, sla_vec_t *out);
+/* this rank's block only: `host_local` holds the entries of sla_ctx_row_range(n) */
+int sla_vec_create_local(sla_ctx_t, int64_t n, const double *host_local, sla_vec_t *out);
+int sla_vec_destroy(sla_vec_t);
+int sla_vec_dim(sla_vec_t, int64_t *n, int64_t *n_local);
+/* toVectorDense (SpVector.hs:250): all n entries (all-gathered when sharded) */
+int sla_vec_to_host(sla_vec_t, double *host);
+int sla_vec_to_host_local(sla_vec_t, double *host_local);
+int sla_vec_copy(sla_vec_t src, sla_vec_t dst);
+
+/* ---- A1..A4: (#>), (<#), (<.>), norm2, (^+^) (^-^) (.*) ----------------------------------------- */
+
+int sla_spmv(sla_csr_t A, sla_vec_t x, sla_vec_t y);   /* y = A #> x   (Common.hs:242-250) */
+int sla_spmv_t(sla_csr_t A, sla_vec_t x, sla_vec_t y); /* y = x <# A = transpose A #> x (Common.hs:253-256) */
+int sla_dot(sla_vec_t x, sla_vec_t y, double *out);    /* x <.> y      (SpVector.hs:116-117) */
+int sla_nrm2(sla_vec_t x, double *out);                /* norm2 x      (SpVector.hs:119-129) */
+int sla_axpby(double a, sla_vec_t x, double b, sla_vec_t y); /* y := a .* x ^+^ b .* y (SpVector.hs:107-114) */
+int sla_scal(double a, sla_vec_t x);                   /* x := a .* x; normalize2 = scal (1/norm2 x) */
+
+/* ---- A5..A7: solver state records ---------------------------------------------------------------- */
+
+/* cgsInit / bicgsInit / cgneInit (Sparse.hs:921-924, 962-965, 864-868).  `method` is SLA_CGS_,
+ * SLA_BICGSTAB_ or SLA_CGNE_.  The shadow residual r0hat = b - A x0 of the README usage
+ * (README.md:205-226) is kept inside the state. */
+int sla_solver_init(int method, sla_csr_t A, sla_vec_t b, sla_vec_t x0, sla_solver_t *out);
+/* k applications of cgsStep / bicgstabStep / cgneStep (Sparse.hs:928-939, 972-981, 870-878):
+ * `iterate step s !! k`.  Enqueues and returns; no convergence test. */
+int sla_solver_step(sla_solver_t, int k_steps);
+/* copy a state field (_x, _r, _p, _u) into `out` */
+int sla_solver_get(sla_solver_t, int field, sla_vec_t out);
+int sla_solver_destroy(sla_solver_t);
+/* convenience spellings used by the Haskell shim */
+int sla_bicgstab_init(sla_csr_t A, sla_vec_t b, sla_vec_t x0, sla_solver_t *out);
+int sla_bicgstab_step(sla_solver_t, int k_steps);
+int sla_cgs_init(sla_csr_t A, sla_vec_t b, sla_vec_t x0, sla_solver_t *out);
+int sla_cgs_step(sla_solver_t, int k_steps);
+
+/* ---- A8: linSolve0 ----------------------------------------------------------------------------- */
+
+/* linSolve0 method aa b x0 (Sparse.hs:1016-1072): size guard -> diagonal shortcut -> loop of
+ * (step; true residual; test) entirely on the device.  SLA_GMRES_ / SLA_BCG_ return
+ * SLA_ERR_UNSUPPORTED_METHOD exactly like the reference (use sla_gmres for the extension). */
+int sla_linsolve0(int method, sla_csr_t A, sla_vec_t b, sla_vec_t x0, const sla_solve_opts *opts,
+                  sla_vec_t x_out, sla_solve_info *info);
+
+/* ---- A9/A10: Arnoldi, GMRES(m), (<\>) ------------------------------------------------------------ */
+
+/* arnoldi aa b kn (Sparse.hs:630-667).  Q_colmajor: n x (kn+1) host buffer (may be NULL to skip the
+ * copy), H_colmajor: (kn+1) x kn host buffer with leading dimension kn+1, *k_done = number of H
+ * columns produced (< kn after a breakdown).  Q holds this rank's rows when sharded (ld = n_local). */
+int sla_arnoldi(sla_csr_t A, sla_vec_t b, int kn, double *Q_colmajor, double *H_colmajor, int *k_done);
+/* Restarted GMRES(m) on the device Arnoldi (the reference's gmres is commented out, Sparse.hs:828-848:
+ * parity is pinned at the arnoldi level only).  opts->max_iters bounds the total Arnoldi steps. */
+int sla_gmres(sla_csr_t A, sla_vec_t b, sla_vec_t x0, int restart, const sla_solve_opts *opts,
+              sla_vec_t x_out, sla_solve_info *info);
+/* aa <\> b (Class.hs:244-249) as the dead instance defined it (Sparse.hs:1080-1084): GMRES from
+ * x0 = 0.1 * ones. */
+int sla_linsolve(sla_csr_t A, sla_vec_t b, sla_vec_t x_out, sla_solve_info *info);
+
+/* ---- measurement hooks (bench.py) ---------------------------------------------------------------- */
+
+/* kernels whose launches can be bracketed by HIP events on the context stream */
+typedef enum {
+    SLA_KERNEL_SPMV = 0,      /* plain y = A x */
+    SLA_KERNEL_SPMV_DOT = 1,  /* K1: Ap = A p fused with Ap . r0hat */
+    SLA_KERNEL_SPMV_DOT2 = 2, /* K3: As = A s fused with As . s, As . As */
+    SLA_KERNEL_SPMV_RES = 3,  /* true-residual SpMV fused with ||A x - b||^2 */
+    SLA_KERNEL_COUNT = 8
+} sla_kernel_id;
+/* record up to `max_launches` event pairs around launches of `kernel_id` from now on */
+int sla_prof_start(sla_ctx_t, int kernel_id, int max_launches);
+/* synchronise, return the number of recorded launches and their mean / min duration in ms */
+int sla_prof_stop(sla_ctx_t, int *launches, double *mean_ms, double *min_ms);
+/* name of the SpMV algorithm picked for A ("stream", "scalar") and its launch geometry */
+int sla_csr_kernel_info(sla_csr_t, char *buf, int buflen);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SLA_HIP_H */

@@ -1,0 +1,535 @@
+// sla_api.cpp -- C ABI: context, SpMatrix lowering, SpVector, (#>) (<#) (<.>) norm2 axpby.
+// Reference citations per entry point are in include/sla_hip.h.
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <limits>
+
+#include "sla_internal.hpp"
+
+namespace sla {
+
+static thread_local std::string g_last_error;
+void set_error(const std::string &msg) { g_last_error = msg; }
+int fail(int code, const std::string &msg) {
+    g_last_error = msg;
+    return code;
+}
+
+ProfScope::ProfScope(sla_ctx *ctx, int kernel_id) : c(ctx), on(false) {
+    if (c->prof_kernel == kernel_id && c->prof_count < c->prof_max) {
+        on = true;
+        (void)hipEventRecord(c->prof_ev[2 * (size_t)c->prof_count], c->stream);
+    }
+}
+ProfScope::~ProfScope() {
+    if (on) {
+        (void)hipEventRecord(c->prof_ev[2 * (size_t)c->prof_count + 1], c->stream);
+        c->prof_count++;
+    }
+}
+
+static int64_t shard_of(const sla_ctx *c, int64_t n) { return (n + c->nranks - 1) / c->nranks; }
+
+static void row_range(const sla_ctx *c, int64_t m, int64_t *b, int64_t *e) {
+    const int64_t s = shard_of(c, m);
+    *b = std::min<int64_t>(m, s * c->rank);
+    *e = std::min<int64_t>(m, s * (c->rank + 1));
+}
+
+static int ensure_xfull(sla_ctx *c, int64_t count) {
+    if (c->xfull_cap >= count) return SLA_OK;
+    if (c->d_xfull) (void)hipFree(c->d_xfull);
+    c->d_xfull = nullptr;
+    c->xfull_cap = 0;
+    SLA_HIP_TRY(hipMalloc((void **)&c->d_xfull, sizeof(double) * (size_t)std::max<int64_t>(count, 1)));
+    c->xfull_cap = count;
+    return SLA_OK;
+}
+
+// full-length gather base for an SpMV whose input is `x` (all-gather over xGMI when sharded)
+int gather_raw(sla_ctx *c, const double *local, int64_t shard, const double **base) {
+    if (c->nranks == 1) {
+        *base = local;
+        return SLA_OK;
+    }
+    SLA_TRY(ensure_xfull(c, shard * c->nranks));
+    SLA_TRY(dist_allgather_f64(c, local, c->d_xfull, shard));
+    *base = c->d_xfull;
+    return SLA_OK;
+}
+int gather_x(sla_vec *x, const double **base) { return gather_raw(x->ctx, x->d, x->shard, base); }
+
+// sums of one or two partial arrays -> host (global over ranks); synchronises the stream
+int reduce_to_host(sla_ctx *c, const double *p1, const double *p2, int np, double *out) {
+    SLA_TRY(launch_finalize(c, p1, p2, np, c->d_result));
+    const double *src = c->d_result;
+    if (c->nranks > 1) {
+        if (!p2) SLA_HIP_TRY(hipMemsetAsync(c->d_result + 1, 0, sizeof(double), c->stream));
+        SLA_TRY(dist_allgather_f64(c, c->d_result, c->d_result + 16, 2));
+        SLA_TRY(launch_finalize_cols(c, c->d_result + 16, c->nranks, 1, 2, 2, c->d_result + 8));
+        src = c->d_result + 8;
+    }
+    SLA_HIP_TRY(hipMemcpyAsync(c->h_result, src, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    SLA_HIP_TRY(hipStreamSynchronize(c->stream));
+    out[0] = c->h_result[0];
+    if (p2) out[1] = c->h_result[1];
+    return SLA_OK;
+}
+
+int vec_alloc(sla_ctx *c, int64_t n, sla_vec **out) {
+    sla_vec *v = new sla_vec();
+    v->ctx = c;
+    v->n = n;
+    v->shard = shard_of(c, n);
+    int64_t b, e;
+    row_range(c, n, &b, &e);
+    v->begin = b;
+    v->n_local = e - b;
+    hipError_t err = hipMalloc((void **)&v->d, sizeof(double) * (size_t)std::max<int64_t>(v->shard, 1));
+    if (err != hipSuccess) {
+        delete v;
+        return fail(SLA_ERR_ALLOC, std::string("hipMalloc(vector): ") + hipGetErrorString(err));
+    }
+    err = hipMemsetAsync(v->d, 0, sizeof(double) * (size_t)std::max<int64_t>(v->shard, 1), c->stream);
+    if (err != hipSuccess) {
+        (void)hipFree(v->d);
+        delete v;
+        return fail(SLA_ERR_HIP, std::string("hipMemsetAsync: ") + hipGetErrorString(err));
+    }
+    *out = v;
+    return SLA_OK;
+}
+
+static int csr_upload(sla_ctx *c, int64_t m, int64_t n, int64_t row_begin, int64_t rows, const int64_t *rowptr,
+                      const int64_t *col, const double *val, sla_csr **out) {
+    const int64_t nnz = rowptr[rows];
+    if (n > (int64_t)std::numeric_limits<int32_t>::max() || rows >= (int64_t)std::numeric_limits<int32_t>::max())
+        return fail(SLA_ERR_INVALID, "matrix dimension exceeds the 32-bit device index width");
+    sla_csr *A = new sla_csr();
+    A->ctx = c;
+    A->m = m;
+    A->n = n;
+    A->row_begin = row_begin;
+    A->rows = rows;
+    A->nnz = nnz;
+    A->rp64 = nnz > (int64_t)std::numeric_limits<int32_t>::max();
+    std::vector<int32_t> rb;
+    build_row_blocks(rows, rowptr, rb, A->max_row_nnz);
+    A->nrb = (int32_t)rb.size() - 1;
+    int diag_not = host_is_diagonal(rows, row_begin, rowptr, col) ? 0 : 1;
+    if (m != n && rows > 0) { /* isDiagonalSM only counts (i,i) entries; nothing extra to do */ }
+    hipError_t err = hipSuccess;
+    auto upload = [&](void **dst, const void *src, size_t bytes) {
+        if (err != hipSuccess) return;
+        err = hipMalloc(dst, std::max<size_t>(bytes, 8));
+        if (err == hipSuccess && bytes) err = hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
+    };
+    {
+        std::vector<int32_t> col32((size_t)nnz);
+        for (int64_t k = 0; k < nnz; ++k) col32[(size_t)k] = (int32_t)col[k];
+        upload((void **)&A->d_col, col32.data(), sizeof(int32_t) * (size_t)nnz);
+    }
+    if (A->rp64) {
+        upload(&A->d_rowptr, rowptr, sizeof(int64_t) * (size_t)(rows + 1));
+    } else {
+        std::vector<int32_t> rp32((size_t)rows + 1);
+        for (int64_t i = 0; i <= rows; ++i) rp32[(size_t)i] = (int32_t)rowptr[i];
+        upload(&A->d_rowptr, rp32.data(), sizeof(int32_t) * (size_t)(rows + 1));
+    }
+    upload((void **)&A->d_val, val, sizeof(double) * (size_t)nnz);
+    upload((void **)&A->d_rb, rb.data(), sizeof(int32_t) * rb.size());
+    if (err != hipSuccess) {
+        sla_csr_destroy(A);
+        return fail(SLA_ERR_ALLOC, std::string("CSR upload: ") + hipGetErrorString(err));
+    }
+    int rc = dist_allreduce_max_i32(c, &diag_not);
+    if (rc != SLA_OK) {
+        sla_csr_destroy(A);
+        return rc;
+    }
+    A->is_diagonal = diag_not == 0;
+    *out = A;
+    return SLA_OK;
+}
+
+// lazily built transpose (transposeSM, SpMatrix.hs:717); single-rank contexts only
+int csr_transposed(sla_csr *A, sla_csr **out) {
+    if (A->transposed) {
+        *out = A->transposed;
+        return SLA_OK;
+    }
+    if (A->ctx->nranks != 1)
+        return fail(SLA_ERR_INVALID, "transpose SpMV ((<#), CGNE_) is not available on a row-sharded matrix");
+    HostCsr h, t;
+    h.m = A->m;
+    h.n = A->n;
+    h.rowptr.resize((size_t)A->rows + 1);
+    h.col.resize((size_t)A->nnz);
+    h.val.resize((size_t)A->nnz);
+    SLA_TRY(sla_csr_export(A, h.rowptr.data(), h.col.data(), h.val.data()));
+    transpose_csr(h, t);
+    sla_csr *T = nullptr;
+    SLA_TRY(csr_upload(A->ctx, t.m, t.n, 0, t.m, t.rowptr.data(), t.col.data(), t.val.data(), &T));
+    A->transposed = T;
+    *out = T;
+    return SLA_OK;
+}
+
+}  // namespace sla
+
+using namespace sla;
+
+extern "C" {
+
+const char *sla_last_error(void) { return g_last_error.c_str(); }
+const char *sla_version(void) { return "sla_hip 0.1 (gfx950)"; }
+
+static int ctx_create_common(int device_id, int rank, int nranks, const void *uid, sla_ctx_t *out) {
+    if (!out || nranks < 1 || rank < 0 || rank >= nranks) return fail(SLA_ERR_INVALID, "sla_ctx_create: bad arguments");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(SLA_ERR_NO_DEVICE, "no HIP device visible: libsla_hip has no CPU fallback");
+    if (device_id < 0 || device_id >= ndev) return fail(SLA_ERR_INVALID, "sla_ctx_create: device id out of range");
+    SLA_HIP_TRY(hipSetDevice(device_id));
+    sla_ctx *c = new sla_ctx();
+    c->device = device_id;
+    c->rank = rank;
+    c->nranks = nranks;
+    SLA_HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    SLA_HIP_TRY(hipMalloc((void **)&c->d_parts, sizeof(double) * 4 * kMaxParts));
+    SLA_HIP_TRY(hipMalloc((void **)&c->d_result, sizeof(double) * 4096));
+    SLA_HIP_TRY(hipHostMalloc((void **)&c->h_result, sizeof(double) * 64, hipHostMallocDefault));
+    if (const char *s = getenv("SLA_SPMV_ALGO")) c->spmv_algo = (strcmp(s, "scalar") == 0) ? 1 : 0;
+    if (const char *s = getenv("SLA_XCD_REMAP")) c->xcd_remap = atoi(s);
+    if (const char *s = getenv("SLA_SPMV_GRID")) {
+        int g = atoi(s);
+        if (g >= 1 && g <= kMaxParts) c->spmv_grid_max = g;
+    }
+    if (uid) {
+        int rc = dist_comm_init(c, uid);
+        if (rc != SLA_OK) {
+            sla_ctx_destroy(c);
+            return rc;
+        }
+    }
+    *out = c;
+    return SLA_OK;
+}
+
+int sla_ctx_create(int device_id, sla_ctx_t *out) { return ctx_create_common(device_id, 0, 1, nullptr, out); }
+
+int sla_dist_unique_id(void *unique_id_128) {
+    if (!unique_id_128) return fail(SLA_ERR_INVALID, "null unique id buffer");
+    return dist_unique_id(unique_id_128);
+}
+
+int sla_ctx_create_dist(int device_id, int rank, int nranks, const void *unique_id_128, sla_ctx_t *out) {
+    if (!unique_id_128) return fail(SLA_ERR_INVALID, "null unique id");
+    return ctx_create_common(device_id, rank, nranks, unique_id_128, out);
+}
+
+int sla_ctx_destroy(sla_ctx_t c) {
+    if (!c) return SLA_OK;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    dist_comm_destroy(c);
+    for (hipEvent_t ev : c->prof_ev) (void)hipEventDestroy(ev);
+    if (c->d_parts) (void)hipFree(c->d_parts);
+    if (c->d_result) (void)hipFree(c->d_result);
+    if (c->h_result) (void)hipHostFree(c->h_result);
+    if (c->d_xfull) (void)hipFree(c->d_xfull);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return SLA_OK;
+}
+
+int sla_ctx_sync(sla_ctx_t c) {
+    if (!c) return fail(SLA_ERR_INVALID, "null context");
+    SLA_HIP_TRY(hipStreamSynchronize(c->stream));
+    return SLA_OK;
+}
+
+int sla_ctx_rank(sla_ctx_t c, int *rank, int *nranks) {
+    if (!c) return fail(SLA_ERR_INVALID, "null context");
+    if (rank) *rank = c->rank;
+    if (nranks) *nranks = c->nranks;
+    return SLA_OK;
+}
+
+int sla_ctx_row_range(sla_ctx_t c, int64_t m, int64_t *begin, int64_t *end) {
+    if (!c || m < 0) return fail(SLA_ERR_INVALID, "sla_ctx_row_range: bad arguments");
+    int64_t b, e;
+    row_range(c, m, &b, &e);
+    if (begin) *begin = b;
+    if (end) *end = e;
+    return SLA_OK;
+}
+
+// ---- CSR ------------------------------------------------------------------------------------------
+
+int sla_csr_from_coo(sla_ctx_t c, int64_t m, int64_t n, int64_t nnz, const int64_t *row, const int64_t *col,
+                     const double *val, int dup_policy, sla_csr_t *out) {
+    if (!c || !out || (nnz > 0 && (!row || !col || !val))) return fail(SLA_ERR_INVALID, "sla_csr_from_coo: null argument");
+    HostCsr h;
+    SLA_TRY(build_csr_from_coo(m, n, nnz, row, col, val, dup_policy, h));
+    return sla_csr_from_csr(c, m, n, h.rowptr.data(), h.col.data(), h.val.data(), out);
+}
+
+int sla_csr_from_csr(sla_ctx_t c, int64_t m, int64_t n, const int64_t *rowptr, const int64_t *colidx,
+                     const double *val, sla_csr_t *out) {
+    if (!c || !out || !rowptr || m < 0 || n < 0) return fail(SLA_ERR_INVALID, "sla_csr_from_csr: bad argument");
+    int64_t b, e;
+    row_range(c, m, &b, &e);
+    if (c->nranks == 1) return sla_csr_from_csr_rows(c, m, n, 0, m, rowptr, colidx, val, out);
+    std::vector<int64_t> rp((size_t)(e - b) + 1);
+    for (int64_t i = b; i <= e; ++i) rp[(size_t)(i - b)] = rowptr[i] - rowptr[b];
+    return sla_csr_from_csr_rows(c, m, n, b, e - b, rp.data(), colidx + rowptr[b], val + rowptr[b], out);
+}
+
+int sla_csr_from_csr_rows(sla_ctx_t c, int64_t m, int64_t n, int64_t row_begin, int64_t row_count,
+                          const int64_t *rowptr_local, const int64_t *colidx, const double *val, sla_csr_t *out) {
+    if (!c || !out || !rowptr_local || m < 0 || n < 0 || row_count < 0)
+        return fail(SLA_ERR_INVALID, "sla_csr_from_csr_rows: bad argument");
+    int64_t b, e;
+    row_range(c, m, &b, &e);
+    if (row_begin != b || row_count != e - b)
+        return fail(SLA_ERR_INVALID, "sla_csr_from_csr_rows: rows do not match sla_ctx_row_range");
+    if (rowptr_local[0] != 0) return fail(SLA_ERR_INVALID, "rowptr_local[0] must be 0");
+    const int64_t nnz = rowptr_local[row_count];
+    if (nnz > 0 && (!colidx || !val)) return fail(SLA_ERR_INVALID, "null colidx/val");
+    for (int64_t i = 0; i < row_count; ++i) {
+        if (rowptr_local[i + 1] < rowptr_local[i]) return fail(SLA_ERR_INVALID, "rowptr not monotone");
+        for (int64_t k = rowptr_local[i]; k < rowptr_local[i + 1]; ++k) {
+            if (colidx[k] < 0 || colidx[k] >= n) return fail(SLA_ERR_OOB, "insertSpMatrix : index out of bounds");
+            if (k > rowptr_local[i] && colidx[k] <= colidx[k - 1])
+                return fail(SLA_ERR_INVALID, "columns must be strictly ascending inside a row (canonical CSR)");
+        }
+    }
+    (void)hipSetDevice(c->device);
+    return csr_upload(c, m, n, row_begin, row_count, rowptr_local, colidx, val, out);
+}
+
+int sla_csr_destroy(sla_csr_t A) {
+    if (!A) return SLA_OK;
+    if (A->transposed) sla_csr_destroy(A->transposed);
+    if (A->d_rowptr) (void)hipFree(A->d_rowptr);
+    if (A->d_col) (void)hipFree(A->d_col);
+    if (A->d_val) (void)hipFree(A->d_val);
+    if (A->d_rb) (void)hipFree(A->d_rb);
+    delete A;
+    return SLA_OK;
+}
+
+int sla_csr_dims(sla_csr_t A, int64_t *m, int64_t *n, int64_t *nnz_local, int64_t *rows_local) {
+    if (!A) return fail(SLA_ERR_INVALID, "null matrix");
+    if (m) *m = A->m;
+    if (n) *n = A->n;
+    if (nnz_local) *nnz_local = A->nnz;
+    if (rows_local) *rows_local = A->rows;
+    return SLA_OK;
+}
+
+int sla_csr_export(sla_csr_t A, int64_t *rowptr, int64_t *colidx, double *val) {
+    if (!A) return fail(SLA_ERR_INVALID, "null matrix");
+    sla_ctx *c = A->ctx;
+    SLA_HIP_TRY(hipStreamSynchronize(c->stream));
+    if (rowptr) {
+        if (A->rp64) {
+            SLA_HIP_TRY(hipMemcpy(rowptr, A->d_rowptr, sizeof(int64_t) * (size_t)(A->rows + 1), hipMemcpyDeviceToHost));
+        } else {
+            std::vector<int32_t> t((size_t)A->rows + 1);
+            SLA_HIP_TRY(hipMemcpy(t.data(), A->d_rowptr, sizeof(int32_t) * t.size(), hipMemcpyDeviceToHost));
+            for (size_t i = 0; i < t.size(); ++i) rowptr[i] = t[i];
+        }
+    }
+    if (colidx && A->nnz) {
+        std::vector<int32_t> t((size_t)A->nnz);
+        SLA_HIP_TRY(hipMemcpy(t.data(), A->d_col, sizeof(int32_t) * t.size(), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < t.size(); ++i) colidx[i] = t[i];
+    }
+    if (val && A->nnz) SLA_HIP_TRY(hipMemcpy(val, A->d_val, sizeof(double) * (size_t)A->nnz, hipMemcpyDeviceToHost));
+    return SLA_OK;
+}
+
+int sla_csr_is_diagonal(sla_csr_t A, int *out) {
+    if (!A || !out) return fail(SLA_ERR_INVALID, "null argument");
+    *out = A->is_diagonal ? 1 : 0;
+    return SLA_OK;
+}
+
+int sla_csr_kernel_info(sla_csr_t A, char *buf, int buflen) {
+    if (!A || !buf || buflen <= 0) return fail(SLA_ERR_INVALID, "null argument");
+    snprintf(buf, (size_t)buflen, "algo=%s grid=%d block=%d row_blocks=%d nnz_per_row_block=%d max_row_nnz=%lld rowptr=%s xcd_remap=%d",
+             A->ctx->spmv_algo == 1 ? "scalar" : "stream", spmv_grid(A), kBlock, A->nrb, kNnzPerRowBlock,
+             (long long)A->max_row_nnz, A->rp64 ? "i64" : "i32", A->ctx->xcd_remap);
+    return SLA_OK;
+}
+
+// ---- vectors ----------------------------------------------------------------------------------------
+
+int sla_vec_create(sla_ctx_t c, int64_t n, const double *host, sla_vec_t *out) {
+    if (!c || !out || n < 0) return fail(SLA_ERR_INVALID, "sla_vec_create: bad argument");
+    (void)hipSetDevice(c->device);
+    sla_vec *v = nullptr;
+    SLA_TRY(vec_alloc(c, n, &v));
+    if (host && v->n_local > 0) {
+        hipError_t e = hipMemcpyAsync(v->d, host + v->begin, sizeof(double) * (size_t)v->n_local, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) {
+            sla_vec_destroy(v);
+            return fail(SLA_ERR_HIP, std::string("vector upload: ") + hipGetErrorString(e));
+        }
+    }
+    *out = v;
+    return SLA_OK;
+}
+
+int sla_vec_create_local(sla_ctx_t c, int64_t n, const double *host_local, sla_vec_t *out) {
+    if (!c || !out || n < 0) return fail(SLA_ERR_INVALID, "sla_vec_create_local: bad argument");
+    (void)hipSetDevice(c->device);
+    sla_vec *v = nullptr;
+    SLA_TRY(vec_alloc(c, n, &v));
+    if (host_local && v->n_local > 0) {
+        hipError_t e = hipMemcpyAsync(v->d, host_local, sizeof(double) * (size_t)v->n_local, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) {
+            sla_vec_destroy(v);
+            return fail(SLA_ERR_HIP, std::string("vector upload: ") + hipGetErrorString(e));
+        }
+    }
+    *out = v;
+    return SLA_OK;
+}
+
+int sla_vec_destroy(sla_vec_t v) {
+    if (!v) return SLA_OK;
+    if (v->d) (void)hipFree(v->d);
+    delete v;
+    return SLA_OK;
+}
+
+int sla_vec_dim(sla_vec_t v, int64_t *n, int64_t *n_local) {
+    if (!v) return fail(SLA_ERR_INVALID, "null vector");
+    if (n) *n = v->n;
+    if (n_local) *n_local = v->n_local;
+    return SLA_OK;
+}
+
+int sla_vec_to_host_local(sla_vec_t v, double *host_local) {
+    if (!v || !host_local) return fail(SLA_ERR_INVALID, "null argument");
+    sla_ctx *c = v->ctx;
+    if (v->n_local > 0)
+        SLA_HIP_TRY(hipMemcpyAsync(host_local, v->d, sizeof(double) * (size_t)v->n_local, hipMemcpyDeviceToHost, c->stream));
+    SLA_HIP_TRY(hipStreamSynchronize(c->stream));
+    return SLA_OK;
+}
+
+int sla_vec_to_host(sla_vec_t v, double *host) {
+    if (!v || !host) return fail(SLA_ERR_INVALID, "null argument");
+    sla_ctx *c = v->ctx;
+    if (c->nranks == 1) return sla_vec_to_host_local(v, host);
+    const double *base = nullptr;
+    SLA_TRY(gather_x(v, &base));
+    SLA_HIP_TRY(hipMemcpyAsync(host, base, sizeof(double) * (size_t)v->n, hipMemcpyDeviceToHost, c->stream));
+    SLA_HIP_TRY(hipStreamSynchronize(c->stream));
+    return SLA_OK;
+}
+
+int sla_vec_copy(sla_vec_t src, sla_vec_t dst) {
+    if (!src || !dst) return fail(SLA_ERR_INVALID, "null vector");
+    if (src->n != dst->n || src->ctx != dst->ctx) return fail(SLA_ERR_DIM_MISMATCH, "sla_vec_copy: mismatched dimensions");
+    if (src->shard > 0)
+        SLA_HIP_TRY(hipMemcpyAsync(dst->d, src->d, sizeof(double) * (size_t)src->shard, hipMemcpyDeviceToDevice, src->ctx->stream));
+    return SLA_OK;
+}
+
+// ---- (#>) (<#) (<.>) norm2 axpby ---------------------------------------------------------------------
+
+int sla_spmv(sla_csr_t A, sla_vec_t x, sla_vec_t y) {
+    if (!A || !x || !y) return fail(SLA_ERR_INVALID, "null argument");
+    if (A->n != x->n) return fail(SLA_ERR_DIM_MISMATCH, "matVec : mismatched dimensions");  // Common.hs:250
+    if (A->m != y->n) return fail(SLA_ERR_DIM_MISMATCH, "matVec : result vector has the wrong dimension");
+    if (x == y) return fail(SLA_ERR_INVALID, "sla_spmv: x and y must be distinct");
+    SpmvLaunch l;
+    SLA_TRY(gather_x(x, &l.x));
+    l.y = y->d;
+    l.kernel_id = SLA_KERNEL_SPMV;
+    return launch_spmv(A, l);
+}
+
+int sla_spmv_t(sla_csr_t A, sla_vec_t x, sla_vec_t y) {
+    if (!A || !x || !y) return fail(SLA_ERR_INVALID, "null argument");
+    if (A->m != x->n) return fail(SLA_ERR_DIM_MISMATCH, "vecMat : mismatching dimensions");  // Common.hs:256
+    if (A->n != y->n) return fail(SLA_ERR_DIM_MISMATCH, "vecMat : result vector has the wrong dimension");
+    sla_csr *T = nullptr;
+    SLA_TRY(csr_transposed(A, &T));
+    return sla_spmv(T, x, y);
+}
+
+int sla_dot(sla_vec_t x, sla_vec_t y, double *out) {
+    if (!x || !y || !out) return fail(SLA_ERR_INVALID, "null argument");
+    if (x->ctx != y->ctx) return fail(SLA_ERR_INVALID, "vectors from different contexts");
+    // the reference's liftI2 takes max of the dims and never checks (SpVector.hs:64); dense device
+    // vectors need equal length
+    if (x->n != y->n) return fail(SLA_ERR_DIM_MISMATCH, "<.> : mismatched dimensions");
+    sla_ctx *c = x->ctx;
+    SLA_TRY(launch_dot(c, x->n_local, x->d, y->d, c->d_parts));
+    return reduce_to_host(c, c->d_parts, nullptr, vec_grid(x->n_local), out);
+}
+
+int sla_nrm2(sla_vec_t x, double *out) {
+    double ss = 0.0;
+    SLA_TRY(sla_dot(x, x, &ss));
+    *out = sqrt(ss);  // norm2 = sqrt . norm2Sq
+    return SLA_OK;
+}
+
+int sla_axpby(double a, sla_vec_t x, double b, sla_vec_t y) {
+    if (!x || !y) return fail(SLA_ERR_INVALID, "null argument");
+    if (x->n != y->n || x->ctx != y->ctx) return fail(SLA_ERR_DIM_MISMATCH, "^+^ : mismatched dimensions");
+    return launch_axpby(x->ctx, x->n_local, a, x->d, b, y->d);
+}
+
+int sla_scal(double a, sla_vec_t x) {
+    if (!x) return fail(SLA_ERR_INVALID, "null argument");
+    return launch_scal(x->ctx, x->n_local, a, x->d);
+}
+
+// ---- measurement hooks ---------------------------------------------------------------------------------
+
+int sla_prof_start(sla_ctx_t c, int kernel_id, int max_launches) {
+    if (!c || max_launches < 0 || kernel_id < 0 || kernel_id >= SLA_KERNEL_COUNT) return fail(SLA_ERR_INVALID, "sla_prof_start: bad argument");
+    while ((int)c->prof_ev.size() < 2 * max_launches) {
+        hipEvent_t ev;
+        SLA_HIP_TRY(hipEventCreate(&ev));
+        c->prof_ev.push_back(ev);
+    }
+    c->prof_kernel = kernel_id;
+    c->prof_max = max_launches;
+    c->prof_count = 0;
+    return SLA_OK;
+}
+
+int sla_prof_stop(sla_ctx_t c, int *launches, double *mean_ms, double *min_ms) {
+    if (!c) return fail(SLA_ERR_INVALID, "null context");
+    SLA_HIP_TRY(hipStreamSynchronize(c->stream));
+    double sum = 0.0, mn = 1e300;
+    for (int i = 0; i < c->prof_count; ++i) {
+        float ms = 0.f;
+        SLA_HIP_TRY(hipEventElapsedTime(&ms, c->prof_ev[2 * (size_t)i], c->prof_ev[2 * (size_t)i + 1]));
+        sum += ms;
+        if (ms < mn) mn = ms;
+    }
+    if (launches) *launches = c->prof_count;
+    if (mean_ms) *mean_ms = c->prof_count ? sum / c->prof_count : 0.0;
+    if (min_ms) *min_ms = c->prof_count ? mn : 0.0;
+    c->prof_kernel = -1;
+    c->prof_max = 0;
+    return SLA_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,243 @@
+// sla_internal.hpp -- shared declarations of libsla_hip.so (not part of the public C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "sla_hip.h"
+
+namespace sla {
+
+// ---------------------------------------------------------------------------------------------
+// geometry constants
+// ---------------------------------------------------------------------------------------------
+constexpr int kBlock = 256;          // threads per workgroup (4 wavefronts of 64)
+constexpr int kNnzPerRowBlock = 1024; // products staged in LDS per row block (8 KiB)
+constexpr int kMaxRowsPerRowBlock = 256;
+constexpr int kMaxParts = 2048;      // partial-sum slots per reduction (256 CUs x 8)
+constexpr int kVecGridMax = 1024;    // grid cap of the streaming BLAS-1 kernels
+constexpr int kSpmvGridMax = 2048;   // persistent grid cap of the SpMV kernels
+constexpr int kMaxKrylov = 64;       // max Arnoldi basis columns handled by the fused GS kernels
+
+// Device-resident scalars of one solver.  Written only by block 0 / thread 0 of a kernel and
+// read by LATER kernels on the same stream (kernel boundaries order the accesses).
+struct SolverScalars {
+    double rho2[2];  // r . r0hat (CGNE: r . r), double-buffered by step parity: a step reads
+                     // rho2[par] everywhere and its last kernel writes rho2[par ^ 1]
+    double alpha, omega, beta;
+    double resnorm;  // last true residual norm evaluated on the device
+    double tol;      // max tolAbs (tolRel * r0norm)
+    double r0norm;
+    double hnorm;    // Arnoldi: h_{i+1,i}
+    int32_t done;    // 1 once resnorm <= tol (or Arnoldi breakdown); later kernels return at once
+    int32_t iters;   // steps started while not done
+    int32_t flags;
+    int32_t kdone;   // Arnoldi: number of H columns produced
+};
+
+// epilogues fused into the SpMV kernels
+enum Epi : int {
+    EPI_NONE = 0,     // y = A x
+    EPI_DOT = 1,      // y = A x ; p1 += y . w                         (K1 / C1)
+    EPI_DOT2 = 2,     // y = A x ; p1 += y . w ; p2 += y . y           (K3)
+    EPI_RES = 3,      // p1 += (A x - b)^2, y not stored              (true residual)
+    EPI_AXPY_DOT = 4, // z = z - alpha * (A x) ; p1 += z . w (w==null: z . z)   (CGS C3, CGNE N1)
+    EPI_XPBY_NRM = 5, // z = (A x) + beta * z ; p1 += z . z            (CGNE N3)
+    EPI_SUB = 6       // y = b - A x                                   (init: r0 = b ^-^ A x0)
+};
+
+template <typename RP>
+struct SpmvArgs {
+    const RP *rowptr;        // local rows + 1, rowptr[0] == 0
+    const int32_t *col;      // global column indices
+    const double *val;
+    const double *x;         // gather base (full-length x)
+    double *y;               // local rows (may be null for EPI_RES)
+    const int32_t *rb;       // row-block starts, nrb + 1 entries
+    int32_t nrb;
+    int32_t rows;            // local rows
+    const double *w;         // epilogue operand (w / b)
+    double *z;               // epilogue in-out operand
+    double *p1, *p2;         // partial outputs, one slot per block
+    SolverScalars *sc;       // may be null (stand-alone SpMV)
+    const double *pres;      // prologue: partials of the previous true-residual evaluation (or null)
+    int32_t npres, pres_stride;
+    const double *pa, *pb;   // prologue partials feeding alpha / beta for EPI_AXPY_DOT / EPI_XPBY_NRM
+    int32_t npa, pa_stride;
+    int32_t step_begin;      // bit 0: this launch opens a solver step (iters++); bit 1: step parity
+};
+
+}  // namespace sla
+
+// ---------------------------------------------------------------------------------------------
+// handle types of the C ABI
+// ---------------------------------------------------------------------------------------------
+struct sla_ctx {
+    int device = 0, rank = 0, nranks = 1;
+    hipStream_t stream = nullptr;
+    void *comm = nullptr;            // ncclComm_t when nranks > 1 (or a 1-rank test comm)
+    double *d_parts = nullptr;       // 4 * kMaxParts doubles of scratch partials
+    double *d_result = nullptr;      // small device scratch for scalar results / per-rank sums
+    double *h_result = nullptr;      // pinned host mirror
+    double *d_xfull = nullptr;       // all-gather landing buffer (nranks * shard) when sharded
+    int64_t xfull_cap = 0;
+    int spmv_algo = 0;               // 0 stream, 1 scalar (SLA_SPMV_ALGO)
+    int xcd_remap = 1;               // SLA_XCD_REMAP
+    int spmv_grid_max = sla::kSpmvGridMax;
+    // profiling
+    int prof_kernel = -1, prof_max = 0;
+    std::vector<hipEvent_t> prof_ev;
+    int prof_count = 0;
+};
+
+struct sla_vec {
+    sla_ctx *ctx = nullptr;
+    int64_t n = 0;        // global dimension
+    int64_t n_local = 0;  // this rank's entries
+    int64_t shard = 0;    // allocation length (= ceil(n / nranks), zero padded)
+    int64_t begin = 0;    // global index of the first local entry
+    double *d = nullptr;
+};
+
+struct sla_csr {
+    sla_ctx *ctx = nullptr;
+    int64_t m = 0, n = 0;            // global dims
+    int64_t row_begin = 0, rows = 0; // local row block
+    int64_t nnz = 0;                 // local nnz
+    bool rp64 = false;
+    void *d_rowptr = nullptr;        // int32 or int64
+    int32_t *d_col = nullptr;
+    double *d_val = nullptr;
+    int32_t *d_rb = nullptr;
+    int32_t nrb = 0;
+    bool is_diagonal = false;        // global isDiagonalSM
+    sla_csr *transposed = nullptr;   // built lazily (single-rank only)
+    int64_t max_row_nnz = 0;
+};
+
+struct sla_solver {
+    sla_ctx *ctx = nullptr;
+    sla_csr *A = nullptr;
+    int method = 0;
+    sla_vec *x = nullptr, *r = nullptr, *p = nullptr, *u = nullptr;
+    sla_vec *r0hat = nullptr, *b = nullptr;
+    sla_vec *t1 = nullptr, *t2 = nullptr, *t3 = nullptr;  // Ap / s / As  (CGS: aap / q / uq)
+    double *d_parts = nullptr;  // 6 * kMaxParts
+    double *d_gath = nullptr;   // per-rank sums, 8 slots * 2 * nranks
+    sla::SolverScalars *d_sc = nullptr;
+    sla::SolverScalars *h_sc = nullptr;  // pinned
+    bool have_res = false;               // d_parts[RES] holds the residual of the current x
+    alignas(8) char ctl_storage[128];    // driver-private step bookkeeping (sla_solvers.cpp)
+};
+
+namespace sla {
+
+// error plumbing ---------------------------------------------------------------------------------
+void set_error(const std::string &msg);
+int fail(int code, const std::string &msg);
+#define SLA_HIP_TRY(expr)                                                                        \
+    do {                                                                                         \
+        hipError_t _e = (expr);                                                                  \
+        if (_e != hipSuccess)                                                                    \
+            return ::sla::fail(SLA_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+    } while (0)
+#define SLA_TRY(expr)                  \
+    do {                               \
+        int _rc = (expr);              \
+        if (_rc != SLA_OK) return _rc; \
+    } while (0)
+
+// profiling scope: brackets a launch with events when the context is recording that kernel id
+struct ProfScope {
+    sla_ctx *c;
+    bool on;
+    ProfScope(sla_ctx *ctx, int kernel_id);
+    ~ProfScope();
+};
+
+// host CSR builder (sla_csr_build.cpp) -------------------------------------------------------------
+struct HostCsr {
+    int64_t m = 0, n = 0;
+    std::vector<int64_t> rowptr;
+    std::vector<int64_t> col;
+    std::vector<double> val;
+};
+int build_csr_from_coo(int64_t m, int64_t n, int64_t nnz, const int64_t *row, const int64_t *col,
+                       const double *val, int dup_policy, HostCsr &out);
+void transpose_csr(const HostCsr &a, HostCsr &t);
+bool host_is_diagonal(int64_t rows, int64_t row_begin, const int64_t *rowptr, const int64_t *col);
+void build_row_blocks(int64_t rows, const int64_t *rowptr, std::vector<int32_t> &rb, int64_t &max_row_nnz);
+
+// distributed plumbing (sla_dist.cpp) ---------------------------------------------------------------
+int dist_unique_id(void *out128);
+int dist_comm_init(sla_ctx *ctx, const void *unique_id);
+int dist_comm_destroy(sla_ctx *ctx);
+int dist_allgather_f64(sla_ctx *ctx, const double *send, double *recv, int64_t count);
+int dist_allreduce_max_i32(sla_ctx *ctx, int *value_host);
+
+// shared helpers of sla_api.cpp --------------------------------------------------------------------------
+int gather_x(sla_vec *x, const double **base);
+int gather_raw(sla_ctx *c, const double *local, int64_t shard, const double **base);
+int reduce_to_host(sla_ctx *c, const double *p1, const double *p2, int np, double *out);
+int vec_alloc(sla_ctx *c, int64_t n, sla_vec **out);
+int csr_transposed(sla_csr *A, sla_csr **out);
+
+// kernel launchers (sla_kernels.hip) -----------------------------------------------------------------
+struct Parts {  // a partial-sum array as seen by a consumer prologue: p[i * stride], i < n
+    const double *p; int n; int stride;
+};
+struct SpmvLaunch {
+    int epi = EPI_NONE;
+    const double *x = nullptr;  // gather base
+    double *y = nullptr;
+    const double *w = nullptr;
+    double *z = nullptr;
+    double *p1 = nullptr, *p2 = nullptr;
+    SolverScalars *sc = nullptr;
+    const double *pres = nullptr; int npres = 0, pres_stride = 1;
+    const double *pa = nullptr, *pb = nullptr; int npa = 0, pa_stride = 1;
+    int step_begin = 0;
+    int kernel_id = SLA_KERNEL_SPMV;
+};
+int spmv_grid(const sla_csr *A);  // number of blocks (= partial slots written) of an SpMV launch on A
+int launch_spmv(const sla_csr *A, const SpmvLaunch &l);
+
+int vec_grid(int64_t n_local);
+// p1[b] = sum x.y over block b's elements (grid = vec_grid)
+int launch_dot(sla_ctx *c, int64_t n, const double *x, const double *y, double *p1);
+// out[0] = sum(p1[0..np)), out[1] = sum(p2[0..np)) (p2 may be null); one block
+int launch_finalize(sla_ctx *c, const double *p1, const double *p2, int np, double *out);
+// out[j] = sum_i parts[j * cs + i * stride], i < np, j < ncols; one block
+int launch_finalize_cols(sla_ctx *c, const double *parts, int np, int cs, int stride, int ncols, double *out);
+int launch_diag_solve(sla_ctx *c, int64_t n, const double *diag, const double *b, double *x);
+int launch_axpby(sla_ctx *c, int64_t n, double a, const double *x, double b, double *y);
+int launch_scal(sla_ctx *c, int64_t n, double a, double *x);
+int launch_fill(sla_ctx *c, int64_t n, double a, double *x);
+
+// BiCGSTAB (Sparse.hs:972-981)
+int launch_bicg_k2(sla_ctx *c, int64_t n, SolverScalars *sc, Parts apr, int par, const double *r, const double *ap, double *s);
+int launch_bicg_k4(sla_ctx *c, int64_t n, SolverScalars *sc, Parts ass, Parts asas, const double *p, const double *s,
+                   const double *as, const double *r0hat, double *x, double *r, double *prho);
+int launch_bicg_k5(sla_ctx *c, int64_t n, SolverScalars *sc, Parts rhonew, int par, const double *r, const double *ap, double *p);
+// CGS (Sparse.hs:928-939)
+int launch_cgs_c2(sla_ctx *c, int64_t n, SolverScalars *sc, Parts apr, int par, const double *u, const double *aap,
+                  double *q, double *uq, double *x);
+int launch_cgs_c4(sla_ctx *c, int64_t n, SolverScalars *sc, Parts rhonew, int par, const double *r, const double *q,
+                  double *u, double *p);
+// CGNE (Sparse.hs:870-878)
+int launch_cgne_n2(sla_ctx *c, int64_t n, SolverScalars *sc, const double *p, double *x);
+// residual check at the end of a host batch (one block): publishes resnorm / done
+int launch_check(sla_ctx *c, SolverScalars *sc, Parts res);
+int launch_init_scalars(sla_ctx *c, SolverScalars *sc, Parts rho, Parts r0sq, double tol_abs, double tol_rel);
+// Arnoldi (Sparse.hs:630-667); Q column-major with leading dimension ldq
+int launch_arn_dots(sla_ctx *c, int64_t n, const double *Q, int64_t ldq, int ncols, const double *w, double *parts, SolverScalars *sc);
+int arn_grid(int64_t n);  // grid (= partials per column) of the Arnoldi kernels
+// partial i of column j lives at hp[j * cs + i * stride], i < np
+int launch_arn_update(sla_ctx *c, int64_t n, const double *Q, int64_t ldq, int ncols, const double *hp, int np, int cs,
+                      int stride, double *w, double *pn, double *Hcol, SolverScalars *sc);
+int launch_arn_normalize(sla_ctx *c, int64_t n, Parts nrm, const double *w, double *qnext, double *hsub,
+                         SolverScalars *sc, int first);
+int launch_gemv_accum(sla_ctx *c, int64_t n, const double *Q, int64_t ldq, int ncols, const double *ycoef_dev, double *x);
+
+}  // namespace sla

@@ -1,0 +1,633 @@
+// sla_solvers.cpp -- host drivers of the on-device solver loops (C ABI rows A5..A10).
+//
+// The host only ENQUEUES kernels; every scalar (alpha, omega, beta, rho, residual norm, the
+// convergence decision) lives in device memory (sla::SolverScalars).  linSolve0's per-iteration
+// "recompute the true residual and test it" (Sparse.hs:1043-1052) runs on the device: once the test
+// passes, every later kernel of the batch returns immediately, so the iterate handed back is exactly
+// the reference's x' of the first converged step, while the host polls only every `check_every` steps.
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+
+#include "sla_internal.hpp"
+
+using namespace sla;
+
+namespace {
+
+enum Slot { P_APR = 0, P_ASS = 1, P_ASAS = 2, P_RHO = 3, P_RES = 4, P_TMP = 5, P_SLOTS = 6 };
+
+double *slot(sla_solver *S, int s) { return S->d_parts + (size_t)s * kMaxParts; }
+
+// Make the partials a producer kernel just wrote (np per array) consumable: on one GPU they are used
+// as they are; when sharded, each rank folds its partials to one value per array and the per-rank
+// values are all-gathered, to be summed in rank order by every consumer.
+int publish(sla_solver *S, int s1, int s2, int np, Parts *o1, Parts *o2) {
+    sla_ctx *c = S->ctx;
+    if (c->nranks == 1) {
+        *o1 = Parts{slot(S, s1), np, 1};
+        if (o2) *o2 = Parts{s2 >= 0 ? slot(S, s2) : nullptr, np, 1};
+        return SLA_OK;
+    }
+    double *loc = S->d_gath + (size_t)P_SLOTS * 2 * c->nranks;  // 2 doubles of staging
+    SLA_TRY(launch_finalize(c, slot(S, s1), s2 >= 0 ? slot(S, s2) : nullptr, np, loc));
+    if (s2 < 0) SLA_HIP_TRY(hipMemsetAsync(loc + 1, 0, sizeof(double), c->stream));
+    double *g = S->d_gath + (size_t)s1 * 2 * c->nranks;
+    SLA_TRY(dist_allgather_f64(c, loc, g, 2));
+    *o1 = Parts{g, c->nranks, 2};
+    if (o2) *o2 = Parts{g + 1, c->nranks, 2};
+    return SLA_OK;
+}
+
+int solver_alloc(sla_csr *A, int method, sla_solver **out) {
+    sla_ctx *c = A->ctx;
+    sla_solver *S = new sla_solver();
+    S->ctx = c;
+    S->A = A;
+    S->method = method;
+    const int64_t nx = A->n, nr = A->m;
+    int rc = SLA_OK;
+    auto mk = [&](int64_t n, sla_vec **v) { if (rc == SLA_OK) rc = vec_alloc(c, n, v); };
+    mk(nx, &S->x);
+    mk(nr, &S->r);
+    mk(nx, &S->p);
+    mk(nr, &S->r0hat);
+    mk(nr, &S->b);
+    if (method == SLA_CGS_) mk(nr, &S->u);
+    if (method != SLA_CGNE_) { mk(nr, &S->t1); mk(nr, &S->t2); mk(nr, &S->t3); }
+    hipError_t e = hipSuccess;
+    if (rc == SLA_OK) e = hipMalloc((void **)&S->d_parts, sizeof(double) * P_SLOTS * kMaxParts);
+    if (rc == SLA_OK && e == hipSuccess) e = hipMalloc((void **)&S->d_gath, sizeof(double) * ((size_t)P_SLOTS * 2 * c->nranks + 8));
+    if (rc == SLA_OK && e == hipSuccess) e = hipMalloc((void **)&S->d_sc, sizeof(SolverScalars));
+    if (rc == SLA_OK && e == hipSuccess) e = hipHostMalloc((void **)&S->h_sc, sizeof(SolverScalars), hipHostMallocDefault);
+    if (rc == SLA_OK && e != hipSuccess) rc = fail(SLA_ERR_ALLOC, std::string("solver allocation: ") + hipGetErrorString(e));
+    if (rc != SLA_OK) {
+        sla_solver_destroy(S);
+        return rc;
+    }
+    *out = S;
+    return SLA_OK;
+}
+
+struct StepCtl {
+    int step_index = 0;  // parity source
+    Parts res{nullptr, 0, 1};
+    Parts pp{nullptr, 0, 1};  // CGNE: p . p partials of the current p
+};
+
+// true residual of the current x: partials of ||A x - b||^2   (trueResidualNorm, Sparse.hs:1041)
+int enqueue_residual(sla_solver *S, Parts *res) {
+    SpmvLaunch l;
+    l.epi = EPI_RES;
+    SLA_TRY(gather_x(S->x, &l.x));
+    l.w = S->b->d;
+    l.p1 = slot(S, P_RES);
+    l.sc = S->d_sc;
+    l.kernel_id = SLA_KERNEL_SPMV_RES;
+    SLA_TRY(launch_spmv(S->A, l));
+    return publish(S, P_RES, -1, spmv_grid(S->A), res, nullptr);
+}
+
+// bicgstabStep (Sparse.hs:972-981)
+int enqueue_bicgstab(sla_solver *S, int par, const Parts *check) {
+    sla_ctx *c = S->ctx;
+    sla_csr *A = S->A;
+    const int64_t n = S->x->n_local;
+    const int g = spmv_grid(A);
+    Parts apr, ass, asas, rhon;
+    {
+        SpmvLaunch l;  // K1: aap = aa #> p ; aap <.> r0hat
+        l.epi = EPI_DOT;
+        SLA_TRY(gather_x(S->p, &l.x));
+        l.y = S->t1->d;
+        l.w = S->r0hat->d;
+        l.p1 = slot(S, P_APR);
+        l.sc = S->d_sc;
+        if (check && check->p) { l.pres = check->p; l.npres = check->n; l.pres_stride = check->stride; }
+        l.step_begin = 1 | (par << 1);
+        l.kernel_id = SLA_KERNEL_SPMV_DOT;
+        SLA_TRY(launch_spmv(A, l));
+        SLA_TRY(publish(S, P_APR, -1, g, &apr, nullptr));
+    }
+    SLA_TRY(launch_bicg_k2(c, n, S->d_sc, apr, par, S->r->d, S->t1->d, S->t2->d));
+    {
+        SpmvLaunch l;  // K3: aasj = aa #> sj ; aasj <.> sj ; aasj <.> aasj
+        l.epi = EPI_DOT2;
+        SLA_TRY(gather_x(S->t2, &l.x));
+        l.y = S->t3->d;
+        l.w = S->t2->d;
+        l.p1 = slot(S, P_ASS);
+        l.p2 = slot(S, P_ASAS);
+        l.sc = S->d_sc;
+        l.kernel_id = SLA_KERNEL_SPMV_DOT2;
+        SLA_TRY(launch_spmv(A, l));
+        SLA_TRY(publish(S, P_ASS, P_ASAS, g, &ass, &asas));
+    }
+    SLA_TRY(launch_bicg_k4(c, n, S->d_sc, ass, asas, S->p->d, S->t2->d, S->t3->d, S->r0hat->d, S->x->d, S->r->d, slot(S, P_RHO)));
+    SLA_TRY(publish(S, P_RHO, -1, vec_grid(n), &rhon, nullptr));
+    SLA_TRY(launch_bicg_k5(c, n, S->d_sc, rhon, par, S->r->d, S->t1->d, S->p->d));
+    return SLA_OK;
+}
+
+// cgsStep (Sparse.hs:928-939)
+int enqueue_cgs(sla_solver *S, int par, const Parts *check) {
+    sla_ctx *c = S->ctx;
+    sla_csr *A = S->A;
+    const int64_t n = S->x->n_local;
+    const int g = spmv_grid(A);
+    Parts apr, rhon;
+    {
+        SpmvLaunch l;  // C1: aap = aa #> p ; aap <.> rhat
+        l.epi = EPI_DOT;
+        SLA_TRY(gather_x(S->p, &l.x));
+        l.y = S->t1->d;
+        l.w = S->r0hat->d;
+        l.p1 = slot(S, P_APR);
+        l.sc = S->d_sc;
+        if (check && check->p) { l.pres = check->p; l.npres = check->n; l.pres_stride = check->stride; }
+        l.step_begin = 1 | (par << 1);
+        l.kernel_id = SLA_KERNEL_SPMV_DOT;
+        SLA_TRY(launch_spmv(A, l));
+        SLA_TRY(publish(S, P_APR, -1, g, &apr, nullptr));
+    }
+    SLA_TRY(launch_cgs_c2(c, n, S->d_sc, apr, par, S->u->d, S->t1->d, S->t2->d, S->t3->d, S->x->d));
+    {
+        SpmvLaunch l;  // C3: rj1 = r ^-^ alphaj .* (aa #> (u ^+^ q)) ; rj1 <.> rhat
+        l.epi = EPI_AXPY_DOT;
+        SLA_TRY(gather_x(S->t3, &l.x));
+        l.z = S->r->d;
+        l.w = S->r0hat->d;
+        l.p1 = slot(S, P_RHO);
+        l.sc = S->d_sc;
+        l.step_begin = par << 1;
+        l.kernel_id = SLA_KERNEL_SPMV_DOT2;
+        SLA_TRY(launch_spmv(A, l));
+        SLA_TRY(publish(S, P_RHO, -1, g, &rhon, nullptr));
+    }
+    SLA_TRY(launch_cgs_c4(c, n, S->d_sc, rhon, par, S->r->d, S->t2->d, S->u->d, S->p->d));
+    return SLA_OK;
+}
+
+// cgneStep (Sparse.hs:870-878); ctl->pp carries p . p of the current p
+int enqueue_cgne(sla_solver *S, int par, const Parts *check, StepCtl *ctl) {
+    sla_ctx *c = S->ctx;
+    sla_csr *A = S->A, *T = nullptr;
+    SLA_TRY(csr_transposed(A, &T));
+    Parts rr1;
+    {
+        SpmvLaunch l;  // N1: alphai = (r.r)/(p.p) ; r1 = r ^-^ alphai .* (aa #> p) ; r1 . r1
+        l.epi = EPI_AXPY_DOT;
+        SLA_TRY(gather_x(S->p, &l.x));
+        l.z = S->r->d;
+        l.w = nullptr;
+        l.pa = ctl->pp.p;
+        l.npa = ctl->pp.n;
+        l.pa_stride = ctl->pp.stride;
+        l.p1 = slot(S, P_RHO);
+        l.sc = S->d_sc;
+        if (check && check->p) { l.pres = check->p; l.npres = check->n; l.pres_stride = check->stride; }
+        l.step_begin = 1 | (par << 1);
+        l.kernel_id = SLA_KERNEL_SPMV_DOT;
+        SLA_TRY(launch_spmv(A, l));
+        SLA_TRY(publish(S, P_RHO, -1, spmv_grid(A), &rr1, nullptr));
+    }
+    SLA_TRY(launch_cgne_n2(c, S->x->n_local, S->d_sc, S->p->d, S->x->d));  // x1 = x ^+^ alphai .* p
+    {
+        SpmvLaunch l;  // N3: beta = (r1.r1)/(r.r) ; p1 = transpose aa #> r1 ^+^ beta .* p ; p1 . p1
+        l.epi = EPI_XPBY_NRM;
+        SLA_TRY(gather_x(S->r, &l.x));
+        l.z = S->p->d;
+        l.pa = rr1.p;
+        l.npa = rr1.n;
+        l.pa_stride = rr1.stride;
+        l.p1 = slot(S, P_ASS);
+        l.sc = S->d_sc;
+        l.step_begin = par << 1;
+        l.kernel_id = SLA_KERNEL_SPMV_DOT2;
+        SLA_TRY(launch_spmv(T, l));
+        SLA_TRY(publish(S, P_ASS, -1, spmv_grid(T), &ctl->pp, nullptr));
+    }
+    return SLA_OK;
+}
+
+StepCtl &ctl_of(sla_solver *S) {
+    static_assert(sizeof(StepCtl) <= 128, "StepCtl fits the solver's opaque block");
+    return *reinterpret_cast<StepCtl *>(S->ctl_storage);
+}
+
+int enqueue_step(sla_solver *S, bool with_residual) {
+    StepCtl &ctl = ctl_of(S);
+    const int par = ctl.step_index & 1;
+    const Parts *check = S->have_res ? &ctl.res : nullptr;
+    if (S->method == SLA_BICGSTAB_) SLA_TRY(enqueue_bicgstab(S, par, check));
+    else if (S->method == SLA_CGS_) SLA_TRY(enqueue_cgs(S, par, check));
+    else SLA_TRY(enqueue_cgne(S, par, check, &ctl));
+    ctl.step_index++;
+    S->have_res = false;
+    if (with_residual) {
+        SLA_TRY(enqueue_residual(S, &ctl.res));
+        S->have_res = true;
+    }
+    return SLA_OK;
+}
+
+int read_scalars(sla_solver *S) {
+    sla_ctx *c = S->ctx;
+    SLA_HIP_TRY(hipMemcpyAsync(S->h_sc, S->d_sc, sizeof(SolverScalars), hipMemcpyDeviceToHost, c->stream));
+    SLA_HIP_TRY(hipStreamSynchronize(c->stream));
+    return SLA_OK;
+}
+
+// *Init (Sparse.hs:921-924, 962-965, 864-868) + the tolerance of linSolve0 (:1032-1037)
+int solver_init_common(int method, sla_csr *A, sla_vec *b, sla_vec *x0, double tol_abs, double tol_rel, sla_solver **out) {
+    if (!A || !b || !x0 || !out) return fail(SLA_ERR_INVALID, "solver init: null argument");
+    if (method != SLA_BICGSTAB_ && method != SLA_CGS_ && method != SLA_CGNE_)
+        return fail(SLA_ERR_UNSUPPORTED_METHOD, "Only BICGSTAB_, CGS_, and CGNE_ are implemented");
+    if (A->m != b->n) return fail(SLA_ERR_DIM_MISMATCH, "linSolve0 : matrix rows and rhs dimension differ");
+    if (A->n != x0->n) return fail(SLA_ERR_DIM_MISMATCH, "matVec : mismatched dimensions");
+    if (method != SLA_CGNE_ && A->m != A->n) return fail(SLA_ERR_DIM_MISMATCH, "CGS/BiCGSTAB need a square matrix");
+    sla_ctx *c = A->ctx;
+    (void)hipSetDevice(c->device);
+    sla_solver *S = nullptr;
+    SLA_TRY(solver_alloc(A, method, &S));
+    new (&ctl_of(S)) StepCtl();
+    int rc = SLA_OK;
+    do {
+        if ((rc = sla_vec_copy(x0, S->x)) != SLA_OK) break;
+        if ((rc = sla_vec_copy(b, S->b)) != SLA_OK) break;
+        SpmvLaunch l;  // r0 = b ^-^ (aa #> x0)
+        l.epi = EPI_SUB;
+        if ((rc = gather_x(S->x, &l.x)) != SLA_OK) break;
+        l.y = S->r->d;
+        l.w = S->b->d;
+        if ((rc = launch_spmv(A, l)) != SLA_OK) break;
+        if ((rc = sla_vec_copy(S->r, S->r0hat)) != SLA_OK) break;
+        if (method == SLA_CGNE_) {
+            sla_csr *T = nullptr;
+            if ((rc = csr_transposed(A, &T)) != SLA_OK) break;
+            SpmvLaunch lt;  // p0 = transposeSM aa #> r0
+            if ((rc = gather_x(S->r, &lt.x)) != SLA_OK) break;
+            lt.y = S->p->d;
+            if ((rc = launch_spmv(T, lt)) != SLA_OK) break;
+            if ((rc = launch_dot(c, S->p->n_local, S->p->d, S->p->d, slot(S, P_ASS))) != SLA_OK) break;
+            if ((rc = publish(S, P_ASS, -1, vec_grid(S->p->n_local), &ctl_of(S).pp, nullptr)) != SLA_OK) break;
+        } else {
+            if ((rc = sla_vec_copy(S->r, S->p)) != SLA_OK) break;
+            if (method == SLA_CGS_ && (rc = sla_vec_copy(S->r, S->u)) != SLA_OK) break;
+        }
+        // rho = r0 . r0hat = r0 . r0 ; r0norm = sqrt (r0 . r0)
+        Parts rho;
+        if ((rc = launch_dot(c, S->r->n_local, S->r->d, S->r->d, slot(S, P_TMP))) != SLA_OK) break;
+        if ((rc = publish(S, P_TMP, -1, vec_grid(S->r->n_local), &rho, nullptr)) != SLA_OK) break;
+        if ((rc = launch_init_scalars(c, S->d_sc, rho, rho, tol_abs, tol_rel)) != SLA_OK) break;
+    } while (0);
+    if (rc != SLA_OK) {
+        sla_solver_destroy(S);
+        return rc;
+    }
+    *out = S;
+    return SLA_OK;
+}
+
+void fill_info(sla_solver *S, sla_solve_info *info, bool hit_max) {
+    if (!info) return;
+    const SolverScalars &h = *S->h_sc;
+    info->iters = h.iters;
+    info->flags = h.flags | (h.done ? 0 : (hit_max ? SLA_FLAG_MAX_ITERS : 0));
+    info->resnorm = h.resnorm;
+    info->r0norm = h.r0norm;
+    info->tol = h.tol;
+}
+
+// ---- Arnoldi workspace -------------------------------------------------------------------------------
+struct ArnoldiWs {
+    sla_ctx *c = nullptr;
+    int64_t n = 0, n_local = 0, ld = 0;
+    int kn = 0;
+    double *Q = nullptr, *w = nullptr, *H = nullptr, *parts = nullptr, *gath = nullptr, *ycoef = nullptr;
+    SolverScalars *d_sc = nullptr, *h_sc = nullptr;
+    std::vector<double> Hhost;
+    ~ArnoldiWs() {
+        if (Q) (void)hipFree(Q);
+        if (w) (void)hipFree(w);
+        if (H) (void)hipFree(H);
+        if (parts) (void)hipFree(parts);
+        if (gath) (void)hipFree(gath);
+        if (ycoef) (void)hipFree(ycoef);
+        if (d_sc) (void)hipFree(d_sc);
+        if (h_sc) (void)hipHostFree(h_sc);
+    }
+};
+
+int arn_alloc(ArnoldiWs &ws, sla_csr *A, sla_vec *like, int kn) {
+    sla_ctx *c = A->ctx;
+    ws.c = c;
+    ws.n = like->n;
+    ws.n_local = like->n_local;
+    ws.ld = std::max<int64_t>(like->shard + (like->shard & 1), 2);  // even leading dimension: 16-byte aligned columns
+    ws.kn = kn;
+    const size_t qbytes = sizeof(double) * (size_t)ws.ld * (size_t)(kn + 1);
+    SLA_HIP_TRY(hipMalloc((void **)&ws.Q, qbytes));
+    SLA_HIP_TRY(hipMemsetAsync(ws.Q, 0, qbytes, c->stream));
+    SLA_HIP_TRY(hipMalloc((void **)&ws.w, sizeof(double) * (size_t)ws.ld));
+    SLA_HIP_TRY(hipMemsetAsync(ws.w, 0, sizeof(double) * (size_t)ws.ld, c->stream));
+    SLA_HIP_TRY(hipMalloc((void **)&ws.H, sizeof(double) * (size_t)(kn + 1) * (size_t)kn));
+    SLA_HIP_TRY(hipMalloc((void **)&ws.parts, sizeof(double) * (size_t)(kMaxKrylov + 2) * 256));
+    SLA_HIP_TRY(hipMalloc((void **)&ws.gath, sizeof(double) * ((size_t)(kMaxKrylov + 2) * (size_t)c->nranks + kMaxKrylov + 8)));
+    SLA_HIP_TRY(hipMalloc((void **)&ws.ycoef, sizeof(double) * (kMaxKrylov + 2)));
+    SLA_HIP_TRY(hipMalloc((void **)&ws.d_sc, sizeof(SolverScalars)));
+    SLA_HIP_TRY(hipHostMalloc((void **)&ws.h_sc, sizeof(SolverScalars), hipHostMallocDefault));
+    ws.Hhost.assign((size_t)(kn + 1) * (size_t)kn, 0.0);
+    return SLA_OK;
+}
+
+// per-column partials written by a producer -> what the consumer kernel should read
+struct ColParts { const double *p; int np, cs, stride; };
+int arn_publish(ArnoldiWs &ws, const double *parts, int np, int ncols, ColParts *out) {
+    sla_ctx *c = ws.c;
+    if (c->nranks == 1) {
+        *out = ColParts{parts, np, np, 1};
+        return SLA_OK;
+    }
+    double *loc = ws.gath + (size_t)(kMaxKrylov + 2) * c->nranks;
+    SLA_TRY(launch_finalize_cols(c, parts, np, np, 1, ncols, loc));
+    SLA_TRY(dist_allgather_f64(c, loc, ws.gath, ncols));  // layout [rank][ncols]
+    *out = ColParts{ws.gath, c->nranks, 1, ncols};
+    return SLA_OK;
+}
+
+// arnoldi aa src kn (Sparse.hs:630-667) with src given as a raw local device pointer.
+// Runs `kn` columns at most; Hhost (ld = ws.kn + 1) and *k_done are valid on return (synchronises).
+int arn_run(ArnoldiWs &ws, sla_csr *A, const double *src_local, int kn, int *k_done) {
+    sla_ctx *c = ws.c;
+    const int64_t n = ws.n_local;
+    const int ldh = ws.kn + 1;
+    const int g = arn_grid(n);
+    SLA_HIP_TRY(hipMemsetAsync(ws.H, 0, sizeof(double) * (size_t)ldh * (size_t)ws.kn, c->stream));
+    SLA_HIP_TRY(hipMemsetAsync(ws.d_sc, 0, sizeof(SolverScalars), c->stream));
+    ColParts cp;
+    // q0 = normalize2 b
+    SLA_TRY(launch_dot(c, n, src_local, src_local, ws.parts));
+    SLA_TRY(arn_publish(ws, ws.parts, vec_grid(n), 1, &cp));
+    SLA_TRY(launch_arn_normalize(c, n, Parts{cp.p, cp.np, cp.stride}, src_local, ws.Q, nullptr, ws.d_sc, 1));
+    for (int i = 0; i < kn; ++i) {
+        const double *qi = ws.Q + (size_t)i * ws.ld;
+        SpmvLaunch l;  // aqi = aa #> qi
+        SLA_TRY(gather_raw(c, qi, (ws.n + c->nranks - 1) / c->nranks, &l.x));
+        l.y = ws.w;
+        l.sc = ws.d_sc;
+        SLA_TRY(launch_spmv(A, l));
+        // hhcoli = fmap (`dot` aqi) qv
+        SLA_TRY(launch_arn_dots(c, n, ws.Q, ws.ld, i + 1, ws.w, ws.parts, ws.d_sc));
+        SLA_TRY(arn_publish(ws, ws.parts, g, i + 1, &cp));
+        // qipnn = aqi ^-^ sum_k h_k q_k ; partial ||qipnn||^2 ; H[0..i, i]
+        double *pn = ws.parts + (size_t)kMaxKrylov * 256;
+        SLA_TRY(launch_arn_update(c, n, ws.Q, ws.ld, i + 1, cp.p, cp.np, cp.cs, cp.stride, ws.w, pn,
+                                  ws.H + (size_t)i * ldh, ws.d_sc));
+        ColParts cn;
+        SLA_TRY(arn_publish(ws, pn, g, 1, &cn));
+        // qip = normalize2 qipnn ; H[i+1, i] = norm2' qipnn ; breakdown test (not in arnInit)
+        SLA_TRY(launch_arn_normalize(c, n, Parts{cn.p, cn.np, cn.stride}, ws.w, ws.Q + (size_t)(i + 1) * ws.ld,
+                                     ws.H + (size_t)i * ldh + i + 1, ws.d_sc, i == 0 ? 1 : 0));
+    }
+    SLA_HIP_TRY(hipMemcpyAsync(ws.Hhost.data(), ws.H, sizeof(double) * (size_t)ldh * (size_t)ws.kn, hipMemcpyDeviceToHost, c->stream));
+    SLA_HIP_TRY(hipMemcpyAsync(ws.h_sc, ws.d_sc, sizeof(SolverScalars), hipMemcpyDeviceToHost, c->stream));
+    SLA_HIP_TRY(hipStreamSynchronize(c->stream));
+    *k_done = ws.h_sc->kdone;
+    return SLA_OK;
+}
+
+// min_y || beta e1 - H y ||_2 for the (k+1) x k Hessenberg H (column-major, ld = ldh): Givens QR +
+// back substitution (the reference's commented gmres does qr + triUpperSolve, Sparse.hs:837-848)
+void hessenberg_lsq(int k, int ldh, const double *H, double beta, double *y) {
+    std::vector<double> R((size_t)(k + 1) * (size_t)k), g((size_t)k + 1, 0.0);
+    for (int j = 0; j < k; ++j)
+        for (int i = 0; i <= k; ++i) R[(size_t)j * (k + 1) + i] = H[(size_t)j * ldh + i];
+    g[0] = beta;
+    for (int j = 0; j < k; ++j) {
+        const double a = R[(size_t)j * (k + 1) + j], b = R[(size_t)j * (k + 1) + j + 1];
+        const double d = hypot(a, b);
+        double cs = 1.0, sn = 0.0;
+        if (d != 0.0) { cs = a / d; sn = b / d; }
+        for (int l = j; l < k; ++l) {
+            const double u = R[(size_t)l * (k + 1) + j], v = R[(size_t)l * (k + 1) + j + 1];
+            R[(size_t)l * (k + 1) + j] = cs * u + sn * v;
+            R[(size_t)l * (k + 1) + j + 1] = -sn * u + cs * v;
+        }
+        const double gu = g[(size_t)j], gv = g[(size_t)j + 1];
+        g[(size_t)j] = cs * gu + sn * gv;
+        g[(size_t)j + 1] = -sn * gu + cs * gv;
+    }
+    for (int i = k - 1; i >= 0; --i) {
+        double acc = g[(size_t)i];
+        for (int l = i + 1; l < k; ++l) acc -= R[(size_t)l * (k + 1) + i] * y[l];
+        y[i] = acc / R[(size_t)i * (k + 1) + i];
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int sla_solver_init(int method, sla_csr_t A, sla_vec_t b, sla_vec_t x0, sla_solver_t *out) {
+    return solver_init_common(method, A, b, x0, 1e-6, 1e-4, out);
+}
+
+int sla_solver_step(sla_solver_t S, int k_steps) {
+    if (!S || k_steps < 0) return fail(SLA_ERR_INVALID, "sla_solver_step: bad argument");
+    (void)hipSetDevice(S->ctx->device);
+    for (int k = 0; k < k_steps; ++k) SLA_TRY(enqueue_step(S, false));
+    return SLA_OK;
+}
+
+int sla_solver_get(sla_solver_t S, int field, sla_vec_t out) {
+    if (!S || !out) return fail(SLA_ERR_INVALID, "null argument");
+    sla_vec *src = nullptr;
+    switch (field) {
+        case SLA_STATE_X: src = S->x; break;
+        case SLA_STATE_R: src = S->r; break;
+        case SLA_STATE_P: src = S->p; break;
+        case SLA_STATE_U: src = S->u; break;
+    }
+    if (!src) return fail(SLA_ERR_INVALID, "sla_solver_get: this method has no such state field");
+    return sla_vec_copy(src, out);
+}
+
+int sla_solver_destroy(sla_solver_t S) {
+    if (!S) return SLA_OK;
+    if (S->ctx && S->ctx->stream) (void)hipStreamSynchronize(S->ctx->stream);
+    sla_vec *vs[] = {S->x, S->r, S->p, S->u, S->r0hat, S->b, S->t1, S->t2, S->t3};
+    for (sla_vec *v : vs) sla_vec_destroy(v);
+    if (S->d_parts) (void)hipFree(S->d_parts);
+    if (S->d_gath) (void)hipFree(S->d_gath);
+    if (S->d_sc) (void)hipFree(S->d_sc);
+    if (S->h_sc) (void)hipHostFree(S->h_sc);
+    delete S;
+    return SLA_OK;
+}
+
+int sla_bicgstab_init(sla_csr_t A, sla_vec_t b, sla_vec_t x0, sla_solver_t *out) { return sla_solver_init(SLA_BICGSTAB_, A, b, x0, out); }
+int sla_bicgstab_step(sla_solver_t S, int k) {
+    if (!S || S->method != SLA_BICGSTAB_) return fail(SLA_ERR_INVALID, "not a BiCGSTAB state");
+    return sla_solver_step(S, k);
+}
+int sla_cgs_init(sla_csr_t A, sla_vec_t b, sla_vec_t x0, sla_solver_t *out) { return sla_solver_init(SLA_CGS_, A, b, x0, out); }
+int sla_cgs_step(sla_solver_t S, int k) {
+    if (!S || S->method != SLA_CGS_) return fail(SLA_ERR_INVALID, "not a CGS state");
+    return sla_solver_step(S, k);
+}
+
+int sla_linsolve0(int method, sla_csr_t A, sla_vec_t b, sla_vec_t x0, const sla_solve_opts *opts, sla_vec_t x_out,
+                  sla_solve_info *info) {
+    if (!A || !b || !x0 || !x_out) return fail(SLA_ERR_INVALID, "sla_linsolve0: null argument");
+    sla_solve_opts o = {200, 1e-6, 1e-4, 16, 1};
+    if (opts) {
+        o = *opts;
+        if (o.max_iters <= 0) o.max_iters = 200;
+        if (o.check_every <= 0) o.check_every = 16;
+    }
+    if (info) { info->iters = 0; info->flags = 0; info->resnorm = NAN; info->r0norm = NAN; info->tol = NAN; }
+    // | m /= nb = throwM (MatVecSizeMismatchException "linSolve0" dm nb)      (Sparse.hs:1022)
+    if (A->m != b->n) return fail(SLA_ERR_DIM_MISMATCH, "linSolve0 : matrix rows and rhs dimension differ");
+    if (x_out->n != A->n) return fail(SLA_ERR_DIM_MISMATCH, "linSolve0 : output vector has the wrong dimension");
+    sla_ctx *c = A->ctx;
+    (void)hipSetDevice(c->device);
+    // solve aa' b' | isDiagonalSM aa' = return $ reciprocal aa' #> b'           (Sparse.hs:1024-1025)
+    if (A->is_diagonal) {
+        SLA_TRY(launch_diag_solve(c, b->n_local, A->d_val, b->d, x_out->d));
+        SLA_HIP_TRY(hipStreamSynchronize(c->stream));
+        if (info) info->flags = SLA_FLAG_DIAGONAL;
+        return SLA_OK;
+    }
+    if (method != SLA_BICGSTAB_ && method != SLA_CGS_ && method != SLA_CGNE_)
+        return fail(SLA_ERR_UNSUPPORTED_METHOD, "linSolve0 : Only BICGSTAB_, CGS_, and CGNE_ are implemented");  // :1031
+    sla_solver *S = nullptr;
+    SLA_TRY(solver_init_common(method, A, b, x0, o.tol_abs, o.tol_rel, &S));
+    int rc = SLA_OK, total = 0;
+    while (total < o.max_iters) {  // runIter n state | n >= nits = return x        (:1045)
+        const int k = std::min(o.check_every, o.max_iters - total);
+        for (int j = 0; j < k && rc == SLA_OK; ++j) rc = enqueue_step(S, o.true_residual != 0);
+        if (rc != SLA_OK) break;
+        total += k;
+        if (o.true_residual) {
+            if ((rc = launch_check(c, S->d_sc, ctl_of(S).res)) != SLA_OK) break;
+            if ((rc = read_scalars(S)) != SLA_OK) break;
+            if (S->h_sc->done) break;
+        }
+    }
+    if (rc == SLA_OK && !o.true_residual) {  // extension mode: report the final true residual once
+        Parts res;
+        if ((rc = enqueue_residual(S, &res)) == SLA_OK && (rc = launch_check(c, S->d_sc, res)) == SLA_OK) rc = read_scalars(S);
+    }
+    if (rc == SLA_OK) rc = sla_vec_copy(S->x, x_out);
+    if (rc == SLA_OK) {
+        hipError_t e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) rc = fail(SLA_ERR_HIP, hipGetErrorString(e));
+    }
+    if (rc == SLA_OK) fill_info(S, info, true);
+    sla_solver_destroy(S);
+    return rc;
+}
+
+int sla_arnoldi(sla_csr_t A, sla_vec_t b, int kn, double *Q_colmajor, double *H_colmajor, int *k_done) {
+    if (!A || !b || !H_colmajor || !k_done) return fail(SLA_ERR_INVALID, "sla_arnoldi: null argument");
+    // | otherwise = throwM (MatVecSizeMismatchException "arnoldi" (m,n) nb)      (Sparse.hs:637)
+    if (A->n != b->n) return fail(SLA_ERR_DIM_MISMATCH, "arnoldi : matrix columns and vector dimension differ");
+    if (A->m != A->n) return fail(SLA_ERR_DIM_MISMATCH, "arnoldi : matrix must be square");
+    if (kn < 1 || kn + 1 > kMaxKrylov) return fail(SLA_ERR_INVALID, "sla_arnoldi: kn must be in [1, 63]");
+    sla_ctx *c = A->ctx;
+    (void)hipSetDevice(c->device);
+    ArnoldiWs ws;
+    SLA_TRY(arn_alloc(ws, A, b, kn));
+    int k = 0;
+    SLA_TRY(arn_run(ws, A, b->d, kn, &k));
+    memcpy(H_colmajor, ws.Hhost.data(), sizeof(double) * (size_t)(kn + 1) * (size_t)kn);
+    *k_done = k;
+    if (Q_colmajor && b->n_local > 0) {
+        // this rank's rows of the k+1 basis vectors, leading dimension n_local
+        SLA_HIP_TRY(hipMemcpy2D(Q_colmajor, sizeof(double) * (size_t)b->n_local, ws.Q, sizeof(double) * (size_t)ws.ld,
+                                sizeof(double) * (size_t)b->n_local, (size_t)(k + 1), hipMemcpyDeviceToHost));
+    }
+    return SLA_OK;
+}
+
+int sla_gmres(sla_csr_t A, sla_vec_t b, sla_vec_t x0, int restart, const sla_solve_opts *opts, sla_vec_t x_out,
+              sla_solve_info *info) {
+    if (!A || !b || !x0 || !x_out) return fail(SLA_ERR_INVALID, "sla_gmres: null argument");
+    sla_solve_opts o = {200, 1e-6, 1e-4, 16, 1};
+    if (opts) { o = *opts; if (o.max_iters <= 0) o.max_iters = 200; }
+    if (info) { info->iters = 0; info->flags = 0; info->resnorm = NAN; info->r0norm = NAN; info->tol = NAN; }
+    if (A->m != b->n) return fail(SLA_ERR_DIM_MISMATCH, "gmres : matrix rows and rhs dimension differ");
+    if (A->m != A->n || A->n != x0->n || x_out->n != A->n) return fail(SLA_ERR_DIM_MISMATCH, "gmres : mismatched dimensions");
+    if (restart < 1) return fail(SLA_ERR_INVALID, "sla_gmres: restart must be >= 1");
+    restart = std::min<int64_t>({(int64_t)restart, (int64_t)kMaxKrylov - 1, std::max<int64_t>(A->n, 1)});
+    sla_ctx *c = A->ctx;
+    (void)hipSetDevice(c->device);
+    ArnoldiWs ws;
+    SLA_TRY(arn_alloc(ws, A, b, restart));
+    sla_vec *x = nullptr, *r = nullptr;
+    SLA_TRY(vec_alloc(c, A->n, &x));
+    int rc = vec_alloc(c, A->n, &r);
+    double tol = 0.0, beta = NAN, r0norm = NAN;
+    int total = 0, flags = 0;
+    bool first = true;
+    std::vector<double> y((size_t)restart + 1);
+    if (rc == SLA_OK) rc = sla_vec_copy(x0, x);
+    while (rc == SLA_OK) {
+        SpmvLaunch l;  // r = b ^-^ (aa #> x)
+        l.epi = EPI_SUB;
+        if ((rc = gather_x(x, &l.x)) != SLA_OK) break;
+        l.y = r->d;
+        l.w = b->d;
+        if ((rc = launch_spmv(A, l)) != SLA_OK) break;
+        double ss = 0.0;
+        if ((rc = launch_dot(c, r->n_local, r->d, r->d, c->d_parts)) != SLA_OK) break;
+        if ((rc = reduce_to_host(c, c->d_parts, nullptr, vec_grid(r->n_local), &ss)) != SLA_OK) break;
+        beta = sqrt(ss);
+        if (first) { r0norm = beta; tol = fmax(o.tol_abs, o.tol_rel * beta); first = false; }
+        if (beta <= tol) { flags |= SLA_FLAG_CONVERGED; break; }
+        if (!(beta == beta) || isinf(beta)) { flags |= SLA_FLAG_NONFINITE; break; }
+        if (total >= o.max_iters) { flags |= SLA_FLAG_MAX_ITERS; break; }
+        const int mc = std::min(restart, o.max_iters - total);
+        int k = 0;
+        if ((rc = arn_run(ws, A, r->d, mc, &k)) != SLA_OK) break;
+        if (ws.h_sc->flags & SLA_FLAG_BREAKDOWN) flags |= SLA_FLAG_BREAKDOWN;
+        hessenberg_lsq(k, ws.kn + 1, ws.Hhost.data(), beta, y.data());
+        hipError_t e = hipMemcpyAsync(ws.ycoef, y.data(), sizeof(double) * (size_t)k, hipMemcpyHostToDevice, c->stream);
+        if (e != hipSuccess) { rc = fail(SLA_ERR_HIP, hipGetErrorString(e)); break; }
+        if ((rc = launch_gemv_accum(c, x->n_local, ws.Q, ws.ld, k, ws.ycoef, x->d)) != SLA_OK) break;
+        e = hipStreamSynchronize(c->stream);  // y is host memory reused next cycle
+        if (e != hipSuccess) { rc = fail(SLA_ERR_HIP, hipGetErrorString(e)); break; }
+        total += k;
+    }
+    if (rc == SLA_OK) rc = sla_vec_copy(x, x_out);
+    if (rc == SLA_OK) {
+        hipError_t e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) rc = fail(SLA_ERR_HIP, hipGetErrorString(e));
+    }
+    if (rc == SLA_OK && info) {
+        info->iters = total;
+        info->flags = flags;
+        info->resnorm = beta;
+        info->r0norm = r0norm;
+        info->tol = tol;
+    }
+    sla_vec_destroy(x);
+    sla_vec_destroy(r);
+    return rc;
+}
+
+// instance LinearSystem (SpVector Double): aa <\> b = linSolve0 GMRES_ aa b (mkSpVR n $ replicate n 0.1)
+// (dead code in the reference, Sparse.hs:1080-1084)
+int sla_linsolve(sla_csr_t A, sla_vec_t b, sla_vec_t x_out, sla_solve_info *info) {
+    if (!A || !b || !x_out) return fail(SLA_ERR_INVALID, "sla_linsolve: null argument");
+    sla_vec *x0 = nullptr;
+    SLA_TRY(vec_alloc(A->ctx, A->n, &x0));
+    int rc = launch_fill(A->ctx, x0->n_local, 0.1, x0->d);
+    if (rc == SLA_OK) rc = sla_gmres(A, b, x0, 30, nullptr, x_out, info);
+    sla_vec_destroy(x0);
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,580 @@
+"""Host-side mirror of the reference's Numeric.LinearAlgebra.Sparse surface for the hot path, on top of
+the C ABI (include/sla_hip.h).  Names follow the reference so that tests read like test/LibSpec.hs:
+
+    fromListSM, fromListDenseSM, fromListSV, fromListDenseSV, mkSpVR, onesSV, zeroSV,
+    matVec (#>), vecMat (<#), dot (<.>), norm2, normalize2, SpVector + / - / scalar *  (^+^ ^-^ .*),
+    matMat (##), transpose, linSolve0 + LinSolveMethod, cgsInit/cgsStep, bicgsInit/bicgstabStep,
+    cgneInit/cgneStep, arnoldi, linSolve (<\\>), gmres.
+
+A SpMatrix is lowered ONCE to the device CSR at construction (sla_csr_from_coo does the sort / dedupe);
+SpVectors keep the reference's structural sparsity on the host (sorted index + value arrays) and are
+dense on the device.  Reference file:line citations are in include/sla_hip.h and on each function.
+"""
+import ctypes as C
+import enum
+
+import numpy as np
+
+from . import _lib
+from ._lib import (IndexOutOfBounds, IterationException, MatVecSizeMismatchException, SlaError,
+                   SolveInfo, SolveOpts, check, lib)
+
+_p = lambda a: C.c_void_p(a.ctypes.data)  # noqa: E731
+
+
+class LinSolveMethod(enum.IntEnum):
+    """Sparse.hs:1007-1011 (constructor order)."""
+    GMRES_ = 0
+    CGNE_ = 1
+    BCG_ = 2
+    CGS_ = 3
+    BICGSTAB_ = 4
+
+
+GMRES_, CGNE_, BCG_, CGS_, BICGSTAB_ = LinSolveMethod
+
+
+class Context:
+    """One GPU (one rank of a row-sharded job)."""
+
+    def __init__(self, device_id=0, rank=0, nranks=1, unique_id=None):
+        self.h = C.c_void_p()
+        if nranks == 1 and unique_id is None:
+            check(lib().sla_ctx_create(device_id, C.byref(self.h)))
+        else:
+            buf = (C.c_char * 128).from_buffer_copy(bytes(unique_id))
+            check(lib().sla_ctx_create_dist(device_id, rank, nranks, C.cast(buf, C.c_void_p), C.byref(self.h)))
+        self.rank, self.nranks = rank, nranks
+
+    @staticmethod
+    def unique_id():
+        buf = (C.c_char * 128)()
+        check(lib().sla_dist_unique_id(C.cast(buf, C.c_void_p)))
+        return bytes(buf)
+
+    def row_range(self, m):
+        b, e = C.c_int64(), C.c_int64()
+        check(lib().sla_ctx_row_range(self.h, m, C.byref(b), C.byref(e)))
+        return b.value, e.value
+
+    def sync(self):
+        check(lib().sla_ctx_sync(self.h))
+
+    def prof_start(self, kernel_id, max_launches):
+        check(lib().sla_prof_start(self.h, kernel_id, max_launches))
+
+    def prof_stop(self):
+        n, mean, mn = C.c_int(), C.c_double(), C.c_double()
+        check(lib().sla_prof_stop(self.h, C.byref(n), C.byref(mean), C.byref(mn)))
+        return n.value, mean.value, mn.value
+
+    def close(self):
+        if self.h:
+            lib().sla_ctx_destroy(self.h)
+            self.h = C.c_void_p()
+
+
+_default_ctx = None
+
+
+def default_context():
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context(0)
+    return _default_ctx
+
+
+def set_default_context(ctx):
+    global _default_ctx
+    _default_ctx = ctx
+
+
+# ---- device handles ------------------------------------------------------------------------------------
+
+class DeviceVector:
+    """sla_vec_t owner."""
+
+    def __init__(self, ctx, n, host=None, local=False):
+        self.ctx, self.n = ctx, int(n)
+        self.h = C.c_void_p()
+        if host is None:
+            check(lib().sla_vec_create(ctx.h, self.n, None, C.byref(self.h)))
+        else:
+            a = np.ascontiguousarray(host, dtype=np.float64)
+            f = lib().sla_vec_create_local if local else lib().sla_vec_create
+            check(f(ctx.h, self.n, _p(a), C.byref(self.h)))
+
+    def to_host(self):
+        out = np.empty(self.n, dtype=np.float64)
+        check(lib().sla_vec_to_host(self.h, _p(out)))
+        return out
+
+    def to_host_local(self):
+        nl = C.c_int64()
+        check(lib().sla_vec_dim(self.h, None, C.byref(nl)))
+        out = np.empty(nl.value, dtype=np.float64)
+        check(lib().sla_vec_to_host_local(self.h, _p(out)))
+        return out
+
+    def __del__(self):
+        try:
+            if self.h and self.ctx.h:
+                lib().sla_vec_destroy(self.h)
+        except Exception:
+            pass
+
+
+# ---- SpVector -------------------------------------------------------------------------------------------
+
+class SpVector:
+    """SV dim (IntM a) (SpVector.hs:42-43): sorted keys `ix`, values `vals`."""
+
+    def __init__(self, dim, ix, vals, ctx=None):
+        self.dim = int(dim)
+        self.ix = np.ascontiguousarray(ix, dtype=np.int64)
+        self.vals = np.ascontiguousarray(vals, dtype=np.float64)
+        self._ctx = ctx                          # resolved lazily: host algebra needs no GPU
+        self._dev = None
+
+    @property
+    def ctx(self):
+        return self._ctx or default_context()
+
+    # -- structure
+    def nnz(self):
+        return len(self.ix)
+
+    def toDenseListSV(self):                     # SpVector.hs:300
+        d = np.zeros(self.dim)
+        d[self.ix] = self.vals
+        return d
+
+    toVectorDense = toDenseListSV                # SpVector.hs:250
+
+    def toListSV(self):                          # SpVector.hs:294-295
+        return list(zip(self.ix.tolist(), self.vals.tolist()))
+
+    def device(self):
+        if self._dev is None:
+            self._dev = DeviceVector(self.ctx, self.dim, self.toDenseListSV())
+        return self._dev
+
+    # -- Eq / Show are structural in the reference
+    def __eq__(self, o):
+        return (isinstance(o, SpVector) and self.dim == o.dim and np.array_equal(self.ix, o.ix)
+                and np.array_equal(self.vals, o.vals))
+
+    def __repr__(self):
+        return f"SV ({self.dim}) {self.toListSV()}"
+
+    # -- AdditiveGroup / VectorSpace (SpVector.hs:107-114): unionWith (+), fmap
+    def _union(self, o, sign):
+        dim = max(self.dim, o.dim)               # liftU2 takes max of the dims (SpVector.hs:63)
+        keys = np.union1d(self.ix, o.ix)
+        a = np.zeros(len(keys)); b = np.zeros(len(keys))
+        ia, ib = np.searchsorted(keys, self.ix), np.searchsorted(keys, o.ix)
+        ma = np.zeros(len(keys), bool); mb = np.zeros(len(keys), bool)
+        a[ia] = self.vals; ma[ia] = True
+        b[ib] = sign * o.vals; mb[ib] = True     # x ^-^ y = x ^+^ negateV y (Class.hs:68-69)
+        v = np.where(ma & mb, a + b, np.where(ma, a, b))
+        return SpVector(dim, keys, v, self._ctx)
+
+    def __add__(self, o):
+        return self._union(o, 1.0)
+
+    def __sub__(self, o):
+        return self._union(o, -1.0)
+
+    def __neg__(self):
+        return SpVector(self.dim, self.ix, -self.vals, self._ctx)
+
+    def __rmul__(self, a):                       # a .* v
+        return SpVector(self.dim, self.ix, float(a) * self.vals, self._ctx)
+
+    def __mul__(self, a):                        # v *. a
+        return self.__rmul__(a)
+
+
+def _dense_spvector(dim, arr, ctx=None):
+    return SpVector(dim, np.arange(dim, dtype=np.int64), np.asarray(arr, dtype=np.float64)[:dim], ctx)
+
+
+def fromListSV(d, iix, ctx=None):
+    """fromListSV d iix (SpVector.hs:275-278): foldr insert => the FIRST duplicate wins; out-of-bounds
+    entries are silently dropped."""
+    seen = {}
+    for i, x in iix:
+        i = int(i)
+        if 0 <= i < d and i not in seen:
+            seen[i] = float(x)
+    keys = sorted(seen)
+    return SpVector(d, keys, [seen[k] for k in keys], ctx)
+
+
+def fromListDenseSV(d, ll, ctx=None):
+    """fromListDenseSV d ll (SpVector.hs:194-195)."""
+    ll = list(ll)[:d]
+    return SpVector(d, np.arange(len(ll)), ll, ctx)
+
+
+def mkSpVR(d, ll, ctx=None):
+    """mkSpVR d ll = SV d (mkIm ll) (SpVector.hs:183, IntM.hs:114-115): keys 0..len-1, zeros kept."""
+    ll = list(ll)
+    return SpVector(d, np.arange(len(ll)), ll, ctx)
+
+
+def fromVector(arr, ctx=None):
+    """fromVector (SpVector.hs:240-243): every entry becomes a key."""
+    arr = np.asarray(arr, dtype=np.float64)
+    return _dense_spvector(len(arr), arr, ctx)
+
+
+def onesSV(d, ctx=None):
+    return _dense_spvector(d, np.ones(d), ctx)
+
+
+def zeroSV(d, ctx=None):
+    return SpVector(d, [], [], ctx)
+
+
+# ---- SpMatrix -------------------------------------------------------------------------------------------
+
+class SpMatrix:
+    """SM (r,c) (IntM (IntM a)) (SpMatrix.hs:52-54), lowered once to the device CSR."""
+
+    def __init__(self, dims, handle, ctx):
+        self.dims = (int(dims[0]), int(dims[1]))
+        self.h = handle
+        self.ctx = ctx
+        self._host = None
+
+    @property
+    def nrows(self):
+        return self.dims[0]
+
+    @property
+    def ncols(self):
+        return self.dims[1]
+
+    def csr(self):
+        """(rowptr, colidx, val) of this rank's row block, int64 / f64, copied back from the device."""
+        if self._host is None:
+            nnz, rows = C.c_int64(), C.c_int64()
+            check(lib().sla_csr_dims(self.h, None, None, C.byref(nnz), C.byref(rows)))
+            rp = np.zeros(rows.value + 1, dtype=np.int64)
+            ci = np.zeros(max(nnz.value, 1), dtype=np.int64)
+            va = np.zeros(max(nnz.value, 1), dtype=np.float64)
+            check(lib().sla_csr_export(self.h, _p(rp), _p(ci), _p(va)))
+            self._host = (rp, ci[:nnz.value], va[:nnz.value])
+        return self._host
+
+    def nnz(self):
+        return int(self.csr()[0][-1])
+
+    def isDiagonalSM(self):                       # SpMatrix.hs:411-415
+        out = C.c_int()
+        check(lib().sla_csr_is_diagonal(self.h, C.byref(out)))
+        return bool(out.value)
+
+    def toListSM(self):
+        """toListSM (SpMatrix.hs:251-253) yields DESCENDING (row, col) order (a consing left fold)."""
+        rp, ci, va = self.csr()
+        out = [(i, int(ci[k]), float(va[k])) for i in range(len(rp) - 1) for k in range(rp[i], rp[i + 1])]
+        return out[::-1]
+
+    def toDense(self):
+        rp, ci, va = self.csr()
+        D = np.zeros(self.dims)
+        for i in range(len(rp) - 1):
+            D[i, ci[rp[i]:rp[i + 1]]] = va[rp[i]:rp[i + 1]]
+        return D
+
+    def kernel_info(self):
+        buf = C.create_string_buffer(512)
+        check(lib().sla_csr_kernel_info(self.h, buf, 512))
+        return buf.value.decode()
+
+    def __eq__(self, o):                          # structural, like the derived Eq
+        if not isinstance(o, SpMatrix) or self.dims != o.dims:
+            return False
+        a, b = self.csr(), o.csr()
+        return all(np.array_equal(x, y) for x, y in zip(a, b))
+
+    def __matmul__(self, o):
+        return matMat(self, o) if isinstance(o, SpMatrix) else matVec(self, o)
+
+    def __del__(self):
+        try:
+            if self.h and self.ctx.h:
+                lib().sla_csr_destroy(self.h)
+        except Exception:
+            pass
+
+
+def fromListSM(dims, triples, ctx=None):
+    """fromListSM (m,n) iix (SpMatrix.hs:218-224): last duplicate wins, out-of-bounds raises."""
+    ctx = ctx or default_context()
+    t = list(triples)
+    r = np.array([a[0] for a in t], dtype=np.int64)
+    c = np.array([a[1] for a in t], dtype=np.int64)
+    v = np.array([a[2] for a in t], dtype=np.float64)
+    return fromCOO(dims, r, c, v, ctx)
+
+
+def fromCOO(dims, rows, cols, vals, ctx=None, dup_policy=0):
+    ctx = ctx or default_context()
+    r = np.ascontiguousarray(rows, dtype=np.int64)
+    c = np.ascontiguousarray(cols, dtype=np.int64)
+    v = np.ascontiguousarray(vals, dtype=np.float64)
+    h = C.c_void_p()
+    check(lib().sla_csr_from_coo(ctx.h, int(dims[0]), int(dims[1]), len(r), _p(r), _p(c), _p(v), dup_policy, C.byref(h)))
+    return SpMatrix(dims, h, ctx)
+
+
+def fromCSR(dims, rowptr, colidx, vals, ctx=None):
+    """Already-canonical CSR (ascending columns, no duplicates); the whole matrix on every rank."""
+    ctx = ctx or default_context()
+    rp = np.ascontiguousarray(rowptr, dtype=np.int64)
+    ci = np.ascontiguousarray(colidx, dtype=np.int64)
+    va = np.ascontiguousarray(vals, dtype=np.float64)
+    h = C.c_void_p()
+    check(lib().sla_csr_from_csr(ctx.h, int(dims[0]), int(dims[1]), _p(rp), _p(ci), _p(va), C.byref(h)))
+    return SpMatrix(dims, h, ctx)
+
+
+def fromCSRRows(dims, row_begin, rowptr_local, colidx, vals, ctx=None):
+    """This rank's row block only (global column indices)."""
+    ctx = ctx or default_context()
+    rp = np.ascontiguousarray(rowptr_local, dtype=np.int64)
+    ci = np.ascontiguousarray(colidx, dtype=np.int64)
+    va = np.ascontiguousarray(vals, dtype=np.float64)
+    h = C.c_void_p()
+    check(lib().sla_csr_from_csr_rows(ctx.h, int(dims[0]), int(dims[1]), int(row_begin), len(rp) - 1,
+                                      _p(rp), _p(ci), _p(va), C.byref(h)))
+    return SpMatrix(dims, h, ctx)
+
+
+def fromListDenseSM(m, ll, ctx=None):
+    """fromListDenseSM m ll (SpMatrix.hs:239-241): column-major, entry k -> (k mod m, k div m)."""
+    ll = list(ll)
+    n = len(ll) // m
+    return fromListSM((m, n), [(k % m, k // m, ll[k]) for k in range(m * n)], ctx)
+
+
+def sparsifySM(A):
+    """sparsifySM: drop entries with |x| <= 1e-12 (Eps.hs:41-42)."""
+    t = [(i, j, x) for (i, j, x) in A.toListSM()[::-1] if abs(x) > 1e-12]
+    return fromListSM(A.dims, t, A.ctx)
+
+
+def transpose(A):
+    """transposeSM (SpMatrix.hs:717)."""
+    return fromListSM((A.ncols, A.nrows), [(j, i, x) for (i, j, x) in A.toListSM()[::-1]], A.ctx)
+
+
+def matMat(A, B):
+    """(##) (SpMatrix.hs:768-811): structurally dense over rows(A) x cols(B), explicit zeros kept.
+    Host-side helper for the small Hessenberg algebra only."""
+    if A.ncols != B.nrows:
+        raise MatVecSizeMismatchException(_lib.ERR_DIM_MISMATCH, f"matMat : incompatible matrix sizes{(A.dims, B.dims)}")
+    rpa, cia, vaa = A.csr()
+    Bd, cols_b = B.toDense(), sorted(set(B.csr()[1].tolist()))
+    out = []
+    for i in range(A.nrows):
+        if rpa[i + 1] == rpa[i]:
+            continue
+        for j in cols_b:
+            acc = 0.0
+            rpb = B.csr()
+            for k in range(rpa[i], rpa[i + 1]):
+                kk = int(cia[k])
+                # intersection with column j of B: only structurally present b_kj contribute
+                lo, hi = rpb[0][kk], rpb[0][kk + 1]
+                pos = np.searchsorted(rpb[1][lo:hi], j)
+                if pos < hi - lo and rpb[1][lo + pos] == j:
+                    acc = acc + Bd[kk, j] * vaa[k]
+            out.append((i, j, acc))
+    return fromListSM((A.nrows, B.ncols), out, A.ctx)
+
+
+# ---- (#>) (<#) (<.>) norms ---------------------------------------------------------------------------
+
+def matVec(A, x):
+    """A #> x (Common.hs:242-250).  The result has a key for every row present in A (and no others)."""
+    if A.ncols != x.dim:
+        raise MatVecSizeMismatchException(_lib.ERR_DIM_MISMATCH, f"matVec : mismatched dimensions {(A.ncols, x.dim)}")
+    y = DeviceVector(A.ctx, A.nrows)
+    check(lib().sla_spmv(A.h, x.device().h, y.h))
+    yd = y.to_host()
+    rp = A.csr()[0]
+    keys = np.nonzero(np.diff(rp) > 0)[0]
+    return SpVector(A.nrows, keys, yd[keys], A.ctx)
+
+
+def vecMat(x, A):
+    """x <# A (Common.hs:253-256)."""
+    if A.nrows != x.dim:
+        raise MatVecSizeMismatchException(_lib.ERR_DIM_MISMATCH, f"vecMat : mismatching dimensions {(x.dim, A.nrows)}")
+    y = DeviceVector(A.ctx, A.ncols)
+    check(lib().sla_spmv_t(A.h, x.device().h, y.h))
+    yd = y.to_host()
+    keys = np.unique(A.csr()[1])
+    return SpVector(A.ncols, keys, yd[keys], A.ctx)
+
+
+def dot(x, y):
+    """x <.> y (SpVector.hs:116-117), evaluated on the device."""
+    n = max(x.dim, y.dim)
+    a = x if x.dim == n else SpVector(n, x.ix, x.vals, x.ctx)
+    b = y if y.dim == n else SpVector(n, y.ix, y.vals, y.ctx)
+    out = C.c_double()
+    check(lib().sla_dot(a.device().h, b.device().h, C.byref(out)))
+    return out.value
+
+
+def norm2(x):
+    """norm2 (SpVector.hs:119-129)."""
+    out = C.c_double()
+    check(lib().sla_nrm2(x.device().h, C.byref(out)))
+    return out.value
+
+
+def norm2Sq(x):
+    return dot(x, x)
+
+
+def normalize2(x):
+    """normalize2 v = (recip (norm2 v)) .* v (Class.hs:94-95, SpVector.hs:126)."""
+    return (1.0 / norm2(x)) * x
+
+
+def nearZero(a):
+    return abs(a) <= 1e-12                       # Eps.hs:41-42
+
+
+# ---- solver state records -----------------------------------------------------------------------------
+
+class _SolverState:
+    fields = ()
+
+    def __init__(self, method, A, b, x0):
+        self.A, self.method = A, method
+        self.h = C.c_void_p()
+        bh = b.h if isinstance(b, DeviceVector) else b.device().h      # DeviceVector: sharded callers
+        xh = x0.h if isinstance(x0, DeviceVector) else x0.device().h
+        check(lib().sla_solver_init(int(method), A.h, bh, xh, C.byref(self.h)))
+
+    def _get(self, field, dim):
+        v = DeviceVector(self.A.ctx, dim)
+        check(lib().sla_solver_get(self.h, field, v.h))
+        return fromVector(v.to_host(), self.A.ctx)
+
+    def step(self, k=1):
+        check(lib().sla_solver_step(self.h, int(k)))
+        return self
+
+    def __del__(self):
+        try:
+            if self.h and self.A.ctx.h:
+                lib().sla_solver_destroy(self.h)
+        except Exception:
+            pass
+
+
+class BICGSTAB(_SolverState):
+    """data BICGSTAB = BICGSTAB {_xBicgstab, _rBicgstab, _pBicgstab} (Sparse.hs:959-960)."""
+    _xBicgstab = property(lambda s: s._get(0, s.A.ncols))
+    _rBicgstab = property(lambda s: s._get(1, s.A.nrows))
+    _pBicgstab = property(lambda s: s._get(2, s.A.ncols))
+
+
+class CGS(_SolverState):
+    """data CGS = CGS {_x, _r, _p, _u} (Sparse.hs:919)."""
+    _x = property(lambda s: s._get(0, s.A.ncols))
+    _r = property(lambda s: s._get(1, s.A.nrows))
+    _p = property(lambda s: s._get(2, s.A.ncols))
+    _u = property(lambda s: s._get(3, s.A.nrows))
+
+
+class CGNE(_SolverState):
+    """data CGNE = CGNE {_xCgne, _rCgne, _pCgne} (Sparse.hs:855-856)."""
+    _xCgne = property(lambda s: s._get(0, s.A.ncols))
+    _rCgne = property(lambda s: s._get(1, s.A.nrows))
+    _pCgne = property(lambda s: s._get(2, s.A.ncols))
+
+
+def bicgsInit(aa, b, x0):
+    return BICGSTAB(BICGSTAB_, aa, b, x0)         # Sparse.hs:962-965
+
+
+def bicgstabStep(state, k=1):
+    """k applications of bicgstabStep aa r0hat (Sparse.hs:972-981); the state is updated in place on
+    the device (r0hat = b - A x0 is kept inside it)."""
+    return state.step(k)
+
+
+def cgsInit(aa, b, x0):
+    return CGS(CGS_, aa, b, x0)                   # Sparse.hs:921-924
+
+
+def cgsStep(state, k=1):
+    return state.step(k)                          # Sparse.hs:928-939
+
+
+def cgneInit(aa, b, x0):
+    return CGNE(CGNE_, aa, b, x0)                 # Sparse.hs:864-868
+
+
+def cgneStep(state, k=1):
+    return state.step(k)                          # Sparse.hs:870-878
+
+
+# ---- linSolve0 / arnoldi / gmres / (<\>) ---------------------------------------------------------------
+
+def _opts(kw):
+    if not kw:
+        return None
+    o = SolveOpts(kw.get("max_iters", 200), kw.get("tol_abs", 1e-6), kw.get("tol_rel", 1e-4),
+                  kw.get("check_every", 16), kw.get("true_residual", 1))
+    return C.byref(o)
+
+
+def linSolve0(method, aa, b, x0, return_info=False, **opts):
+    """linSolve0 method aa b x0 (Sparse.hs:1016-1072).  Raises MatVecSizeMismatchException /
+    IterationException like the reference; never raises on non-convergence."""
+    out = DeviceVector(aa.ctx, aa.ncols)
+    info = SolveInfo()
+    check(lib().sla_linsolve0(int(method), aa.h, b.device().h, x0.device().h, _opts(opts), out.h, C.byref(info)))
+    x = fromVector(out.to_host(), aa.ctx)
+    return (x, info.as_dict()) if return_info else x
+
+
+def arnoldi(aa, b, kn):
+    """arnoldi aa b kn (Sparse.hs:630-667) -> (Q, H) as dense arrays n x (k+1), (k+1) x k."""
+    n = aa.ncols
+    if n != b.dim:
+        raise MatVecSizeMismatchException(_lib.ERR_DIM_MISMATCH, f"arnoldi {aa.dims} {b.dim}")
+    Q = np.zeros((kn + 1) * n, dtype=np.float64)
+    H = np.zeros((kn + 1) * kn, dtype=np.float64)
+    kd = C.c_int()
+    check(lib().sla_arnoldi(aa.h, b.device().h, int(kn), _p(Q), _p(H), C.byref(kd)))
+    k = kd.value
+    return Q.reshape(kn + 1, n).T[:, :k + 1].copy(), H.reshape(kn, kn + 1).T[:k + 1, :k].copy()
+
+
+def gmres(aa, b, x0, restart=30, return_info=False, **opts):
+    """Restarted GMRES(m) on the device Arnoldi (extension: the reference's gmres is commented out)."""
+    out = DeviceVector(aa.ctx, aa.ncols)
+    info = SolveInfo()
+    check(lib().sla_gmres(aa.h, b.device().h, x0.device().h, int(restart), _opts(opts), out.h, C.byref(info)))
+    x = fromVector(out.to_host(), aa.ctx)
+    return (x, info.as_dict()) if return_info else x
+
+
+def linSolve(aa, b, return_info=False):
+    """aa <\\> b (Class.hs:244-249; dead instance Sparse.hs:1080-1084: GMRES from x0 = 0.1 * ones)."""
+    out = DeviceVector(aa.ctx, aa.ncols)
+    info = SolveInfo()
+    check(lib().sla_linsolve(aa.h, b.device().h, out.h, C.byref(info)))
+    x = fromVector(out.to_host(), aa.ctx)
+    return (x, info.as_dict()) if return_info else x

@@ -1,0 +1,125 @@
+"""Synthetic inputs of BASELINE.json's configs.  Host-side numpy generators that emit
+canonical CSR (ascending columns) for a contiguous row range, so a rank can build only its own slab."""
+import numpy as np
+
+
+def _stencil_rows(row_begin, row_end, offsets, valid_fn, value_fn):
+    """CSR for rows [row_begin, row_end) of a stencil matrix.  `offsets` ascending column offsets,
+    valid_fn(rows, t) -> bool mask, value_fn(rows, t) -> values for stencil leg t."""
+    rows = np.arange(row_begin, row_end, dtype=np.int64)
+    nr, no = len(rows), len(offsets)
+    valid = np.empty((nr, no), dtype=bool)
+    cols = np.empty((nr, no), dtype=np.int64)
+    vals = np.empty((nr, no), dtype=np.float64)
+    for t, off in enumerate(offsets):
+        valid[:, t] = valid_fn(rows, t)
+        cols[:, t] = rows + off
+        vals[:, t] = value_fn(rows, t)
+    rowptr = np.zeros(nr + 1, dtype=np.int64)
+    np.cumsum(valid.sum(axis=1), out=rowptr[1:])
+    return rowptr, cols[valid], vals[valid]
+
+
+def poisson2d(nx, ny, row_begin=0, row_end=None):
+    """Config 2: 5-point Poisson on an nx x ny grid, row = j*nx + i, diag 4, off-diag -1, Dirichlet."""
+    n = nx * ny
+    row_end = n if row_end is None else row_end
+    offsets = [-nx, -1, 0, 1, nx]
+
+    def valid(rows, t):
+        i, j = rows % nx, rows // nx
+        return [j > 0, i > 0, np.ones(len(rows), bool), i < nx - 1, j < ny - 1][t]
+
+    def value(rows, t):
+        return np.full(len(rows), 4.0 if t == 2 else -1.0)
+
+    return (n, n), _stencil_rows(row_begin, row_end, offsets, valid, value)
+
+
+def laplace3d(nx, ny, nz, row_begin=0, row_end=None):
+    """Config 4: 7-point Laplacian on nx x ny x nz, row = (k*ny + j)*nx + i, diag 6, off-diag -1,
+    Dirichlet.  Contiguous row blocks are slabs in k (the slowest index)."""
+    n = nx * ny * nz
+    row_end = n if row_end is None else row_end
+    offsets = [-nx * ny, -nx, -1, 0, 1, nx, nx * ny]
+
+    def valid(rows, t):
+        i = rows % nx
+        j = (rows // nx) % ny
+        k = rows // (nx * ny)
+        return [k > 0, j > 0, i > 0, np.ones(len(rows), bool), i < nx - 1, j < ny - 1, k < nz - 1][t]
+
+    def value(rows, t):
+        return np.full(len(rows), 6.0 if t == 3 else -1.0)
+
+    return (n, n), _stencil_rows(row_begin, row_end, offsets, valid, value)
+
+
+def banded_nonsym(n, seed=99, row_begin=0, row_end=None):
+    """Config 5: bands at offsets {-2,-1,0,+1,+3} with values {-1,-1.5,4.2,-0.5,-1} x (1 +- 5 % noise):
+    diagonally dominant, non-symmetric."""
+    row_end = n if row_end is None else row_end
+    offsets = [-2, -1, 0, 1, 3]
+    base = [-1.0, -1.5, 4.2, -0.5, -1.0]
+
+    def valid(rows, t):
+        c = rows + offsets[t]
+        return (c >= 0) & (c < n)
+
+    def value(rows, t):
+        # counter-based noise so that any row range reproduces the same matrix
+        h = (rows * 5 + t).astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15) + np.uint64(seed)
+        h ^= h >> np.uint64(31)
+        h *= np.uint64(0xBF58476D1CE4E5B9)
+        h ^= h >> np.uint64(29)
+        u = (h >> np.uint64(11)).astype(np.float64) / float(1 << 53)      # [0,1)
+        return base[t] * (1.0 + 0.05 * (2.0 * u - 1.0))
+
+    return (n, n), _stencil_rows(row_begin, row_end, offsets, valid, value)
+
+
+def random_spd(n, k=16, seed=42):
+    """Config 3a: symmetric, strictly diagonally dominant random matrix: k off-diagonal picks per row
+    (value U(-1,1)), symmetrised over the union pattern, diagonal = 1 + sum |offdiag|  => SPD,
+    ~2k+1 entries per row.  Returns the full CSR (not row-range aware)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    r = np.repeat(np.arange(n, dtype=np.int64), k)
+    c = rng.integers(0, n, size=n * k, dtype=np.int64)
+    v = rng.uniform(-1.0, 1.0, size=n * k)
+    keep = r != c
+    r, c, v = r[keep], c[keep], 0.5 * v[keep]
+    rr = np.concatenate([r, c])
+    cc = np.concatenate([c, r])
+    vv = np.concatenate([v, v])
+    key = rr * n + cc
+    order = np.argsort(key, kind="stable")
+    key, vv = key[order], vv[order]
+    uniq, start = np.unique(key, return_index=True)
+    vsum = np.add.reduceat(vv, start)                                     # (R + R^T)/2 on the union pattern
+    ur, uc = uniq // n, uniq % n
+    absrow = np.zeros(n)
+    np.add.at(absrow, ur, np.abs(vsum))
+    dr = np.arange(n, dtype=np.int64)
+    key2 = np.concatenate([uniq, dr * n + dr])
+    val2 = np.concatenate([vsum, 1.0 + absrow])
+    order = np.argsort(key2, kind="stable")
+    key2, val2 = key2[order], val2[order]
+    rows = key2 // n
+    rowptr = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(np.bincount(rows, minlength=n), out=rowptr[1:])
+    return (n, n), (rowptr, key2 % n, val2)
+
+
+def dense_row_spd(n, nnz_per_row, seed=42):
+    """Config 3b: density honoured at small n (e.g. n = 200 000, 1 % => 2000 per row)."""
+    return random_spd(n, k=nnz_per_row // 2, seed=seed)
+
+
+def spmv_bytes(nnz, n):
+    """B_spmv = 12 nnz + 20 n (f64 values, i32 columns, i32 row pointers)."""
+    return 12 * nnz + 20 * n
+
+
+def bicgstab_step_bytes(nnz, n, true_residual=False):
+    """B_bicgstab_step = 24 nnz + 160 n (+ 12 nnz + 20 n with the reference's per-iteration residual)."""
+    return 24 * nnz + 160 * n + (12 * nnz + 20 * n if true_residual else 0)
