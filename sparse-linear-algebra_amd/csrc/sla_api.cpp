@@ -134,7 +134,13 @@ static int csr_upload(sla_ctx *c, int64_t m, int64_t n, int64_t row_begin, int64
     }
     if (A->rp64) {
         upload(&A->d_rowptr, rowptr, sizeof(int64_t) * (size_t)(rows + 1));
+        std::vector<int64_t> rbk(rb.size());
+        for (size_t b = 0; b < rb.size(); ++b) rbk[b] = rowptr[rb[b]];
+        upload(&A->d_rbk, rbk.data(), sizeof(int64_t) * rbk.size());
     } else {
+        std::vector<int32_t> rbk(rb.size());
+        for (size_t b = 0; b < rb.size(); ++b) rbk[b] = (int32_t)rowptr[rb[b]];
+        upload(&A->d_rbk, rbk.data(), sizeof(int32_t) * rbk.size());
         std::vector<int32_t> rp32((size_t)rows + 1);
         for (int64_t i = 0; i <= rows; ++i) rp32[(size_t)i] = (int32_t)rowptr[i];
         upload(&A->d_rowptr, rp32.data(), sizeof(int32_t) * (size_t)(rows + 1));
@@ -320,6 +326,7 @@ int sla_csr_destroy(sla_csr_t A) {
     if (A->d_col) (void)hipFree(A->d_col);
     if (A->d_val) (void)hipFree(A->d_val);
     if (A->d_rb) (void)hipFree(A->d_rb);
+    if (A->d_rbk) (void)hipFree(A->d_rbk);
     delete A;
     return SLA_OK;
 }

@@ -55,6 +55,7 @@ struct SpmvArgs {
     const double *x;         // gather base (full-length x)
     double *y;               // local rows (may be null for EPI_RES)
     const int32_t *rb;       // row-block starts, nrb + 1 entries
+    const RP *rbk;           // rowptr[rb[b]]: entry offset of each row block, nrb + 1 entries
     int32_t nrb;
     int32_t rows;            // local rows
     const double *w;         // epilogue operand (w / b)
@@ -110,6 +111,7 @@ struct sla_csr {
     int32_t *d_col = nullptr;
     double *d_val = nullptr;
     int32_t *d_rb = nullptr;
+    void *d_rbk = nullptr;           // int32 or int64, like d_rowptr
     int32_t nrb = 0;
     bool is_diagonal = false;        // global isDiagonalSM
     sla_csr *transposed = nullptr;   // built lazily (single-rank only)

@@ -181,7 +181,8 @@ def test_bicgstab_and_cgs_steps_vs_oracle(sla, n):
             xd = (sd._xBicgstab if kind == "bicgstab" else sd._x).toDenseListSV()
             pd = (sd._pBicgstab if kind == "bicgstab" else sd._p).toDenseListSV()
             assert np.linalg.norm(xd - so.x) <= 1e-9 * np.linalg.norm(so.x), (kind, k)
-            assert np.linalg.norm(pd - so.p) <= 1e-7 * max(np.linalg.norm(so.p), 1e-300), (kind, k)
+            # p collapses to rounding noise once the Krylov space is exhausted (n = 5): absolute floor
+            assert np.linalg.norm(pd - so.p) <= 1e-7 * np.linalg.norm(so.p) + 1e-12 * np.linalg.norm(r0hat), (kind, k)
 
 
 def test_cgne_steps_vs_oracle(sla):

@@ -1,0 +1,130 @@
+// kbench.cpp -- kernel-level A/B harness (development tool, not part of the product or the tests).
+// Times individual launches of the library's own kernels on the 7-pt Laplacian with HIP events.
+//   hipcc -O2 -std=c++17 --offload-arch=gfx950 -Iinclude -Isparse-linear-algebra_amd/csrc tools/kbench.cpp \
+//         -Lsparse-linear-algebra_amd/lib -lsla_hip -Wl,-rpath,$PWD/sparse-linear-algebra_amd/lib -o tools/kbench
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "sla_internal.hpp"
+
+using namespace sla;
+
+#define CK(x)                                                                   \
+    do {                                                                        \
+        int _rc = (x);                                                          \
+        if (_rc) { printf("FAIL %s: %d %s\n", #x, _rc, sla_last_error()); exit(1); } \
+    } while (0)
+
+static void laplace3d(int nx, int ny, int nz, std::vector<int64_t> &rp, std::vector<int64_t> &ci, std::vector<double> &va) {
+    int64_t n = (int64_t)nx * ny * nz;
+    rp.assign(n + 1, 0);
+    ci.reserve(n * 7);
+    va.reserve(n * 7);
+    for (int64_t r = 0; r < n; ++r) {
+        int i = r % nx, j = (r / nx) % ny, k = r / ((int64_t)nx * ny);
+        if (k > 0) { ci.push_back(r - (int64_t)nx * ny); va.push_back(-1); }
+        if (j > 0) { ci.push_back(r - nx); va.push_back(-1); }
+        if (i > 0) { ci.push_back(r - 1); va.push_back(-1); }
+        ci.push_back(r); va.push_back(6);
+        if (i < nx - 1) { ci.push_back(r + 1); va.push_back(-1); }
+        if (j < ny - 1) { ci.push_back(r + nx); va.push_back(-1); }
+        if (k < nz - 1) { ci.push_back(r + (int64_t)nx * ny); va.push_back(-1); }
+        rp[r + 1] = (int64_t)ci.size();
+    }
+}
+
+struct Timer {
+    hipEvent_t a, b;
+    hipStream_t s;
+    Timer(hipStream_t st) : s(st) { hipEventCreate(&a); hipEventCreate(&b); }
+    template <class F> double run(F f, int reps) {
+        for (int i = 0; i < 3; ++i) f();
+        hipStreamSynchronize(s);
+        std::vector<double> t;
+        for (int i = 0; i < reps; ++i) {
+            hipEventRecord(a, s);
+            f();
+            hipEventRecord(b, s);
+            hipEventSynchronize(b);
+            float ms;
+            hipEventElapsedTime(&ms, a, b);
+            t.push_back(ms);
+        }
+        std::sort(t.begin(), t.end());
+        return t[t.size() / 2];
+    }
+};
+
+int main(int argc, char **argv) {
+    int N = argc > 1 ? atoi(argv[1]) : 216;
+    std::vector<int64_t> rp, ci;
+    std::vector<double> va;
+    laplace3d(N, N, N, rp, ci, va);
+    int64_t n = (int64_t)N * N * N, nnz = rp[n];
+    sla_ctx_t c;
+    CK(sla_ctx_create(0, &c));
+    sla_csr_t A;
+    CK(sla_csr_from_csr(c, n, n, rp.data(), ci.data(), va.data(), &A));
+    std::vector<double> ones(n, 1.0);
+    sla_vec_t x, y, w, z;
+    CK(sla_vec_create(c, n, ones.data(), &x));
+    CK(sla_vec_create(c, n, nullptr, &y));
+    CK(sla_vec_create(c, n, ones.data(), &w));
+    CK(sla_vec_create(c, n, ones.data(), &z));
+    Timer T(c->stream);
+    double bytes = 12.0 * nnz + 20.0 * n;
+    printf("n=%lld nnz=%lld B_spmv=%.1f MB\n", (long long)n, (long long)nnz, bytes / 1e6);
+    auto report = [&](const char *name, double ms, double b) { printf("%-44s %8.3f ms  %8.1f GB/s\n", name, ms, b / ms / 1e6); };
+
+    if (argc > 2 && !strcmp(argv[2], "pmc")) {
+        // few launches, for counter collection: known-bytes calibrators + the SpMV variants
+        SpmvLaunch l;
+        l.x = x->d; l.y = y->d;
+        SpmvLaunch d = l;
+        d.epi = EPI_DOT; d.w = w->d; d.p1 = c->d_parts;
+        for (int i = 0; i < 3; ++i) {
+            launch_axpby(c, n, 2.0, x->d, 1.0, y->d);   // 16 n read + 8 n write
+            launch_dot(c, n, x->d, w->d, c->d_parts);   // 16 n read
+            launch_fill(c, n, 1.0, z->d);               // 8 n write
+            launch_spmv(A, l);
+            launch_spmv(A, d);
+        }
+        hipStreamSynchronize(c->stream);
+        return 0;
+    }
+    for (int algo = 0; algo < 2; ++algo) {
+        c->spmv_algo = algo;
+        for (int remap = 0; remap < 2; ++remap) {
+            c->xcd_remap = remap;
+            for (int g : {1024, 2048}) {
+                c->spmv_grid_max = g;
+                char nm[128];
+                SpmvLaunch l;
+                l.x = x->d; l.y = y->d;
+                snprintf(nm, sizeof nm, "%s plain remap=%d grid=%d", algo ? "scalar" : "stream", remap, g);
+                report(nm, T.run([&] { launch_spmv(A, l); }, 20), bytes);
+                SpmvLaunch d = l;
+                d.epi = EPI_DOT; d.w = w->d; d.p1 = c->d_parts;
+                snprintf(nm, sizeof nm, "%s dot(w separate) remap=%d grid=%d", algo ? "scalar" : "stream", remap, g);
+                report(nm, T.run([&] { launch_spmv(A, d); }, 20), bytes + 8.0 * n);
+                d.w = x->d;
+                snprintf(nm, sizeof nm, "%s dot(w = x) remap=%d grid=%d", algo ? "scalar" : "stream", remap, g);
+                report(nm, T.run([&] { launch_spmv(A, d); }, 20), bytes);
+                SpmvLaunch d2 = l;
+                d2.epi = EPI_DOT2; d2.w = x->d; d2.p1 = c->d_parts; d2.p2 = c->d_parts + kMaxParts;
+                snprintf(nm, sizeof nm, "%s dot2(w = x) remap=%d grid=%d", algo ? "scalar" : "stream", remap, g);
+                report(nm, T.run([&] { launch_spmv(A, d2); }, 20), bytes);
+            }
+        }
+    }
+    c->spmv_algo = 0; c->xcd_remap = 1; c->spmv_grid_max = 2048;
+    // streaming ceiling of the BLAS-1 kernels on this box
+    report("axpby (24 n)", T.run([&] { launch_axpby(c, n, 2.0, x->d, 1.0, y->d); }, 20), 24.0 * n);
+    report("dot (16 n)", T.run([&] { launch_dot(c, n, x->d, w->d, c->d_parts); }, 20), 16.0 * n);
+    report("fill (8 n)", T.run([&] { launch_fill(c, n, 1.0, y->d); }, 20), 8.0 * n);
+    return 0;
+}
