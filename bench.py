@@ -93,7 +93,14 @@ def main():
         args.gpus = world
 
     dist = None
-    if world > 1:
+    # SLA_BENCH_FORCE_DIST=1 drives the multi-rank code path (torch first, gloo control plane, RCCL
+    # communicator, forced collectives) on a single GPU: the only way to rehearse it on a 1-GPU box
+    use_dist = world > 1 or os.environ.get("SLA_BENCH_FORCE_DIST") == "1"
+    if use_dist and world == 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ["SLA_FORCE_COLLECTIVES"] = "1"
+    if use_dist:
         import torch
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -106,7 +113,7 @@ def main():
     from sla_amd import _lib
     from sla_amd.partition import row_block
 
-    if world > 1:
+    if use_dist:
         import torch
         uid = [sla.Context.unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
@@ -124,7 +131,7 @@ def main():
     A = sla.fromCSRRows(dims, rb, rp, ci, va, ctx)
     b_local = np.add.reduceat(va, rp[:-1]) if nnz_local else np.zeros(0)   # b = A . 1  (x* = 1), x0 = 0
     nnz = nnz_local
-    if world > 1:
+    if use_dist:
         import torch
         t = torch.tensor([nnz_local], dtype=torch.int64)
         dist.all_reduce(t)
@@ -134,7 +141,7 @@ def main():
 
     def sync_all():
         ctx.sync()
-        if world > 1:
+        if use_dist:
             import torch
             torch.cuda.synchronize()
             dist.barrier()
@@ -172,7 +179,7 @@ def main():
         mode_desc = "linSolve0 iteration (bicgstabStep + per-iteration true residual, 3 SpMV)"
         extra["linsolve0_iters"] = info.iters
 
-    if world > 1:
+    if use_dist:
         import torch
         t = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -221,11 +228,21 @@ def main():
                          "bytes_per_launch": k1_bytes, "avg_launch_ms": mean_ms, "min_launch_ms": min_ms,
                          "launches_timed": launches},
         }
+        # HBM traffic of the dominant kernel: measured with PMC counters in separate rocprofv3 passes
+        # (bench.py cannot collect counters on itself) and committed under profiles/
+        try:
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                tr = json.load(f).get(f"{args.workload}/{args.mode}/n{world}")
+            if tr:
+                rec["roofline"]["traffic"] = tr["traffic_bytes"]
+                rec["roofline"]["traffic_source"] = tr["source"]
+        except OSError:
+            pass
         rec.update(extra)
         if not args.no_cpu_baseline and world == 1:
             rec["cpu_baseline"] = cpu_baseline(dims, rp, ci, va, b_local, args.cpu_seconds)
         print(json.dumps(rec), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

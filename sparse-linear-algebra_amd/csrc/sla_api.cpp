@@ -51,7 +51,7 @@ static int ensure_xfull(sla_ctx *c, int64_t count) {
 
 // full-length gather base for an SpMV whose input is `x` (all-gather over xGMI when sharded)
 int gather_raw(sla_ctx *c, const double *local, int64_t shard, const double **base) {
-    if (c->nranks == 1) {
+    if (!c->collectives) {
         *base = local;
         return SLA_OK;
     }
@@ -66,7 +66,7 @@ int gather_x(sla_vec *x, const double **base) { return gather_raw(x->ctx, x->d, 
 int reduce_to_host(sla_ctx *c, const double *p1, const double *p2, int np, double *out) {
     SLA_TRY(launch_finalize(c, p1, p2, np, c->d_result));
     const double *src = c->d_result;
-    if (c->nranks > 1) {
+    if (c->collectives) {
         if (!p2) SLA_HIP_TRY(hipMemsetAsync(c->d_result + 1, 0, sizeof(double), c->stream));
         SLA_TRY(dist_allgather_f64(c, c->d_result, c->d_result + 16, 2));
         SLA_TRY(launch_finalize_cols(c, c->d_result + 16, c->nranks, 1, 2, 2, c->d_result + 8));
@@ -221,6 +221,8 @@ static int ctx_create_common(int device_id, int rank, int nranks, const void *ui
             sla_ctx_destroy(c);
             return rc;
         }
+        const char *f = getenv("SLA_FORCE_COLLECTIVES");
+        c->collectives = nranks > 1 || (f && atoi(f) != 0);
     }
     *out = c;
     return SLA_OK;
@@ -438,7 +440,7 @@ int sla_vec_to_host_local(sla_vec_t v, double *host_local) {
 int sla_vec_to_host(sla_vec_t v, double *host) {
     if (!v || !host) return fail(SLA_ERR_INVALID, "null argument");
     sla_ctx *c = v->ctx;
-    if (c->nranks == 1) return sla_vec_to_host_local(v, host);
+    if (!c->collectives) return sla_vec_to_host_local(v, host);
     const double *base = nullptr;
     SLA_TRY(gather_x(v, &base));
     SLA_HIP_TRY(hipMemcpyAsync(host, base, sizeof(double) * (size_t)v->n, hipMemcpyDeviceToHost, c->stream));

@@ -110,7 +110,7 @@ int dist_allgather_f64(sla_ctx *ctx, const double *send, double *recv, int64_t c
 
 // max over ranks of a host int (used for the global isDiagonalSM / method agreement); synchronises
 int dist_allreduce_max_i32(sla_ctx *ctx, int *value_host) {
-    if (ctx->nranks == 1 || !ctx->comm) return SLA_OK;
+    if (!ctx->collectives || !ctx->comm) return SLA_OK;
     int *d = (int *)ctx->d_result;
     SLA_HIP_TRY(hipMemcpyAsync(d, value_host, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
     int rc = rccl().all_reduce(d, d, 1, kNcclInt32, kNcclMax, (NcclComm)ctx->comm, ctx->stream);

@@ -85,6 +85,7 @@ struct sla_ctx {
     int64_t xfull_cap = 0;
     int spmv_algo = 0;               // 0 stream, 1 scalar (SLA_SPMV_ALGO)
     int xcd_remap = 1;               // SLA_XCD_REMAP
+    bool collectives = false;        // nranks > 1, or SLA_FORCE_COLLECTIVES=1 on a 1-rank communicator (test hook)
     int spmv_grid_max = sla::kSpmvGridMax;
     // profiling
     int prof_kernel = -1, prof_max = 0;

@@ -25,7 +25,7 @@ double *slot(sla_solver *S, int s) { return S->d_parts + (size_t)s * kMaxParts; 
 // values are all-gathered, to be summed in rank order by every consumer.
 int publish(sla_solver *S, int s1, int s2, int np, Parts *o1, Parts *o2) {
     sla_ctx *c = S->ctx;
-    if (c->nranks == 1) {
+    if (!c->collectives) {
         *o1 = Parts{slot(S, s1), np, 1};
         if (o2) *o2 = Parts{s2 >= 0 ? slot(S, s2) : nullptr, np, 1};
         return SLA_OK;
@@ -346,7 +346,7 @@ int arn_alloc(ArnoldiWs &ws, sla_csr *A, sla_vec *like, int kn) {
 struct ColParts { const double *p; int np, cs, stride; };
 int arn_publish(ArnoldiWs &ws, const double *parts, int np, int ncols, ColParts *out) {
     sla_ctx *c = ws.c;
-    if (c->nranks == 1) {
+    if (!c->collectives) {
         *out = ColParts{parts, np, np, 1};
         return SLA_OK;
     }

@@ -1,0 +1,91 @@
+"""Worker of tests/test_dist_gloo.py: one rank of a world-size-N gloo job that rehearses, on CPU, the
+row-sharded algorithm libsla_hip runs over RCCL: slab generation, padded-shard all-gather of the SpMV
+input, rank-ordered sums of per-rank partials, and one BiCGSTAB step assembled from sharded pieces.
+The oracle is used here as the per-rank checker arithmetic (this is a test, not the product)."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "sparse-linear-algebra_amd")):
+    sys.path.insert(0, p)
+
+from oracle import oracle as orc  # noqa: E402
+
+
+def main():
+    dist.init_process_group(backend="gloo")
+    rank, P = dist.get_rank(), dist.get_world_size()
+    # import the partition / workload modules without loading the HIP library
+    import importlib.util
+    def load(name):
+        spec = importlib.util.spec_from_file_location(name, os.path.join(ROOT, "sparse-linear-algebra_amd", "sla_amd", name + ".py"))
+        m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m); return m
+    part, wl = load("partition"), load("workloads")
+
+    dims, (rp, ci, va) = wl.laplace3d(8, 7, 9)
+    n = dims[0]
+    full = orc.Csr(n, n, rp, ci, va)
+    b, e = part.row_block(n, rank, P)
+    S = part.shard_size(n, P)
+    _, (rpl, cil, val) = wl.laplace3d(8, 7, 9, b, e)                 # this rank builds ONLY its slab
+    assert np.array_equal(rpl, rp[b:e + 1] - rp[b])
+    loc = orc.Csr(e - b, n, rpl, cil, val)                           # global column ids
+
+    def allgather(x_local):
+        send = torch.from_numpy(part.pad_shard(x_local, S))
+        recv = [torch.zeros(S, dtype=torch.float64) for _ in range(P)]
+        dist.all_gather(recv, send)
+        return torch.cat(recv).numpy()                               # global index g lives at g
+
+    def gdot(u, v):                                                  # per-rank fold, rank-ordered sum
+        mine = torch.tensor([orc.dot(u, v)], dtype=torch.float64)
+        parts = [torch.zeros(1, dtype=torch.float64) for _ in range(P)]
+        dist.all_gather(parts, mine)
+        acc = 0.0
+        for t in parts:
+            acc += float(t.item())
+        return acc
+
+    def spmv(x_local):
+        return orc.spmv(loc, allgather(x_local)[:n])
+
+    rng = np.random.default_rng(5)
+    xg = rng.standard_normal(n)
+    y_full = orc.spmv(full, xg)
+    y_loc = spmv(xg[b:e])
+    assert np.array_equal(y_loc, y_full[b:e]), "sharded SpMV != whole-matrix SpMV"
+    d = gdot(xg[b:e], y_loc)
+    assert abs(d - orc.dot(xg, y_full)) <= 1e-12 * abs(d)
+
+    # one bicgstabStep from sharded pieces vs the oracle's whole-matrix step
+    bg = orc.spmv(full, np.ones(n))
+    x0 = np.full(n, 0.1)
+    so = orc.BicgstabState(full, bg, x0)
+    r0hat_g = bg - orc.spmv(full, x0)
+    so.step(r0hat_g, 1)
+    x, r = x0[b:e].copy(), (bg[b:e] - spmv(x0[b:e]))
+    p, r0hat = r.copy(), r.copy()
+    rho = gdot(r, r0hat)
+    ap = spmv(p)
+    alpha = rho / gdot(ap, r0hat)
+    s = r - alpha * ap
+    as_ = spmv(s)
+    omega = gdot(as_, s) / gdot(as_, as_)
+    x = (x + alpha * p) + omega * s
+    r = s - omega * as_
+    beta = gdot(r, r0hat) / rho * alpha / omega
+    p = r + beta * (p - omega * ap)
+    assert np.allclose(x, so.x[b:e], rtol=1e-12, atol=1e-13)
+    assert np.allclose(p, so.p[b:e], rtol=1e-10, atol=1e-12)
+    dist.barrier()
+    if rank == 0:
+        print("DIST_OK", P)
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -394,3 +394,27 @@ def test_row_partition_matches_python(sla):
     ctx = sla.default_context()
     for m in (0, 1, 7, 1000, 10077696):
         assert ctx.row_range(m) == row_block(m, 0, 1)
+
+
+# ---- row-sharded code path rehearsed on one GPU (1-rank RCCL communicator, forced collectives) -------------
+
+def test_forced_collectives_match_single_gpu_path(sla, monkeypatch):
+    from sla_amd import workloads as wl
+    monkeypatch.setenv("SLA_FORCE_COLLECTIVES", "1")
+    ctx = sla.Context(0, 0, 1, sla.Context.unique_id())
+    dims, (rp, ci, va) = wl.poisson2d(50, 40)
+    n = dims[0]
+    b = np.add.reduceat(va, rp[:-1])
+    outs = []
+    for c in (ctx, sla.default_context()):
+        A = sla.fromCSRRows(dims, 0, rp, ci, va, c)
+        bv, x0 = sla.fromVector(b, c), sla.fromVector(np.zeros(n), c)
+        x, info = sla.linSolve0(sla.BICGSTAB_, A, bv, x0, return_info=True)
+        xc, infoc = sla.linSolve0(sla.CGS_, A, bv, x0, return_info=True)
+        Q, H = sla.arnoldi(A, bv, 6)
+        xg, infog = sla.gmres(A, bv, x0, restart=20, return_info=True)
+        outs.append((x.toDenseListSV(), info["iters"], xc.toDenseListSV(), infoc["iters"], H, xg.toDenseListSV(),
+                     sla.dot(bv, bv), sla.matVec(A, bv).toDenseListSV()))
+    for a, b_ in zip(*outs):
+        assert np.array_equal(a, b_)          # per-rank folding + rank-order sum == the 1-GPU reduction order
+    ctx.close()
