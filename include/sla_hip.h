@@ -207,6 +207,15 @@ int sla_prof_stop(sla_ctx_t, int *launches, double *mean_ms, double *min_ms);
 /* name of the SpMV algorithm picked for A ("stream", "scalar") and its launch geometry */
 int sla_csr_kernel_info(sla_csr_t, char *buf, int buflen);
 
+/* ---- row-sharded exchange planning (pure host arithmetic, no GPU needed) ------------------------------ */
+
+/* Given every rank's referenced column window windows[2*q] = cmin_q, windows[2*q+1] = cmax_q (cmax < cmin:
+ * no entries) of an n-column matrix split in ceil(n/nranks)-row blocks, return for `rank` the contiguous
+ * x ranges (global begin, length; per peer) it sends and receives per SpMV, and whether the window
+ * exchange replaces the plain all-gather.  This is the plan sla_csr_from_* derives internally. */
+int sla_plan_window_exchange(int nranks, int rank, int64_t n, const int64_t *windows, int64_t *send_begin,
+                             int64_t *send_len, int64_t *recv_begin, int64_t *recv_len, int *use_window);
+
 #ifdef __cplusplus
 }
 #endif

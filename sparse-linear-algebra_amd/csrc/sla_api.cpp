@@ -50,17 +50,49 @@ static int ensure_xfull(sla_ctx *c, int64_t count) {
 }
 
 // full-length gather base for an SpMV whose input is `x` (all-gather over xGMI when sharded)
-int gather_raw(sla_ctx *c, const double *local, int64_t shard, const double **base) {
+int gather_raw(sla_ctx *c, const sla_csr *A, const double *local, int64_t shard, const double **base) {
     if (!c->collectives) {
         *base = local;
         return SLA_OK;
     }
     SLA_TRY(ensure_xfull(c, shard * c->nranks));
-    SLA_TRY(dist_allgather_f64(c, local, c->d_xfull, shard));
+    if (A && A->xplan && c->x_exchange != 1 && (A->xplan->use_window || c->x_exchange == 2)) {
+        const int64_t b = std::min<int64_t>(A->n, shard * c->rank), e = std::min<int64_t>(A->n, shard * (c->rank + 1));
+        SLA_TRY(dist_exchange_window(c, *A->xplan, local, b, e - b, c->d_xfull));
+    } else {
+        SLA_TRY(dist_allgather_f64(c, local, c->d_xfull, shard));
+    }
     *base = c->d_xfull;
     return SLA_OK;
 }
-int gather_x(sla_vec *x, const double **base) { return gather_raw(x->ctx, x->d, x->shard, base); }
+int gather_x(const sla_csr *A, sla_vec *x, const double **base) { return gather_raw(x->ctx, A, x->d, x->shard, base); }
+
+// sharded only: all-gather every rank's referenced column window and derive the exchange plan
+static int build_xplan(sla_csr *A, int64_t rows, const int64_t *rowptr, const int64_t *col) {
+    sla_ctx *c = A->ctx;
+    if (!c->collectives) return SLA_OK;
+    int64_t w[2] = {1, 0};  // empty
+    const int64_t nnz = rowptr[rows];
+    if (nnz > 0) {
+        w[0] = col[0];
+        w[1] = col[0];
+        for (int64_t i = 0; i < rows; ++i)
+            if (rowptr[i + 1] > rowptr[i]) {  // canonical CSR: first / last entry of a row are its min / max
+                w[0] = std::min(w[0], col[rowptr[i]]);
+                w[1] = std::max(w[1], col[rowptr[i + 1] - 1]);
+            }
+    }
+    // ship the two int64 as raw 8-byte words through the f64 all-gather (no arithmetic touches them)
+    double *d = c->d_result + 64;
+    SLA_HIP_TRY(hipMemcpyAsync(d, w, sizeof(w), hipMemcpyHostToDevice, c->stream));
+    SLA_TRY(dist_allgather_f64(c, d, d + 8, 2));
+    std::vector<int64_t> all((size_t)2 * c->nranks);
+    SLA_HIP_TRY(hipMemcpyAsync(all.data(), d + 8, sizeof(int64_t) * all.size(), hipMemcpyDeviceToHost, c->stream));
+    SLA_HIP_TRY(hipStreamSynchronize(c->stream));
+    A->xplan = new XPlan();
+    plan_window_exchange(c->nranks, c->rank, A->n, all.data(), *A->xplan);
+    return SLA_OK;
+}
 
 // sums of one or two partial arrays -> host (global over ranks); synchronises the stream
 int reduce_to_host(sla_ctx *c, const double *p1, const double *p2, int np, double *out) {
@@ -157,6 +189,11 @@ static int csr_upload(sla_ctx *c, int64_t m, int64_t n, int64_t row_begin, int64
         return rc;
     }
     A->is_diagonal = diag_not == 0;
+    rc = build_xplan(A, rows, rowptr, col);
+    if (rc != SLA_OK) {
+        sla_csr_destroy(A);
+        return rc;
+    }
     *out = A;
     return SLA_OK;
 }
@@ -211,6 +248,7 @@ static int ctx_create_common(int device_id, int rank, int nranks, const void *ui
     SLA_HIP_TRY(hipHostMalloc((void **)&c->h_result, sizeof(double) * 64, hipHostMallocDefault));
     if (const char *s = getenv("SLA_SPMV_ALGO")) c->spmv_algo = (strcmp(s, "scalar") == 0) ? 1 : 0;
     if (const char *s = getenv("SLA_XCD_REMAP")) c->xcd_remap = atoi(s);
+    if (const char *s = getenv("SLA_X_EXCHANGE")) c->x_exchange = strcmp(s, "allgather") == 0 ? 1 : (strcmp(s, "window") == 0 ? 2 : 0);
     if (const char *s = getenv("SLA_SPMV_GRID")) {
         int g = atoi(s);
         if (g >= 1 && g <= kMaxParts) c->spmv_grid_max = g;
@@ -324,6 +362,7 @@ int sla_csr_from_csr_rows(sla_ctx_t c, int64_t m, int64_t n, int64_t row_begin, 
 int sla_csr_destroy(sla_csr_t A) {
     if (!A) return SLA_OK;
     if (A->transposed) sla_csr_destroy(A->transposed);
+    delete A->xplan;
     if (A->d_rowptr) (void)hipFree(A->d_rowptr);
     if (A->d_col) (void)hipFree(A->d_col);
     if (A->d_val) (void)hipFree(A->d_val);
@@ -442,7 +481,7 @@ int sla_vec_to_host(sla_vec_t v, double *host) {
     sla_ctx *c = v->ctx;
     if (!c->collectives) return sla_vec_to_host_local(v, host);
     const double *base = nullptr;
-    SLA_TRY(gather_x(v, &base));
+    SLA_TRY(gather_x(nullptr, v, &base));
     SLA_HIP_TRY(hipMemcpyAsync(host, base, sizeof(double) * (size_t)v->n, hipMemcpyDeviceToHost, c->stream));
     SLA_HIP_TRY(hipStreamSynchronize(c->stream));
     return SLA_OK;
@@ -464,7 +503,7 @@ int sla_spmv(sla_csr_t A, sla_vec_t x, sla_vec_t y) {
     if (A->m != y->n) return fail(SLA_ERR_DIM_MISMATCH, "matVec : result vector has the wrong dimension");
     if (x == y) return fail(SLA_ERR_INVALID, "sla_spmv: x and y must be distinct");
     SpmvLaunch l;
-    SLA_TRY(gather_x(x, &l.x));
+    SLA_TRY(gather_x(A, x, &l.x));
     l.y = y->d;
     l.kernel_id = SLA_KERNEL_SPMV;
     return launch_spmv(A, l);
@@ -506,6 +545,21 @@ int sla_axpby(double a, sla_vec_t x, double b, sla_vec_t y) {
 int sla_scal(double a, sla_vec_t x) {
     if (!x) return fail(SLA_ERR_INVALID, "null argument");
     return launch_scal(x->ctx, x->n_local, a, x->d);
+}
+
+int sla_plan_window_exchange(int nranks, int rank, int64_t n, const int64_t *windows, int64_t *send_begin,
+                             int64_t *send_len, int64_t *recv_begin, int64_t *recv_len, int *use_window) {
+    if (nranks < 1 || rank < 0 || rank >= nranks || n < 0 || !windows) return fail(SLA_ERR_INVALID, "sla_plan_window_exchange: bad argument");
+    XPlan plan;
+    plan_window_exchange(nranks, rank, n, windows, plan);
+    for (int q = 0; q < nranks; ++q) {
+        if (send_begin) send_begin[q] = plan.send_begin[(size_t)q];
+        if (send_len) send_len[q] = plan.send_len[(size_t)q];
+        if (recv_begin) recv_begin[q] = plan.recv_begin[(size_t)q];
+        if (recv_len) recv_len[q] = plan.recv_len[(size_t)q];
+    }
+    if (use_window) *use_window = plan.use_window ? 1 : 0;
+    return SLA_OK;
 }
 
 // ---- measurement hooks ---------------------------------------------------------------------------------

@@ -10,6 +10,7 @@
 #include <dlfcn.h>
 #include <string.h>
 
+#include <algorithm>
 #include <mutex>
 
 #include "sla_internal.hpp"
@@ -24,6 +25,9 @@ typedef int (*fn_comm_init_rank)(NcclComm *, int, NcclUniqueId, int);
 typedef int (*fn_comm_destroy)(NcclComm);
 typedef int (*fn_all_gather)(const void *, void *, size_t, int, NcclComm, hipStream_t);
 typedef int (*fn_all_reduce)(const void *, void *, size_t, int, int, NcclComm, hipStream_t);
+typedef int (*fn_send)(const void *, size_t, int, int, NcclComm, hipStream_t);
+typedef int (*fn_recv)(void *, size_t, int, int, NcclComm, hipStream_t);
+typedef int (*fn_group)(void);
 typedef const char *(*fn_err_string)(int);
 constexpr int kNcclFloat64 = 8, kNcclInt32 = 2, kNcclMax = 2;
 
@@ -34,6 +38,9 @@ struct Rccl {
     fn_comm_destroy comm_destroy = nullptr;
     fn_all_gather all_gather = nullptr;
     fn_all_reduce all_reduce = nullptr;
+    fn_send send = nullptr;
+    fn_recv recv = nullptr;
+    fn_group group_start = nullptr, group_end = nullptr;
     fn_err_string err_string = nullptr;
     std::string load_error;
 };
@@ -56,6 +63,10 @@ Rccl &rccl() {
         r.comm_destroy = (fn_comm_destroy)dlsym(r.handle, "ncclCommDestroy");
         r.all_gather = (fn_all_gather)dlsym(r.handle, "ncclAllGather");
         r.all_reduce = (fn_all_reduce)dlsym(r.handle, "ncclAllReduce");
+        r.send = (fn_send)dlsym(r.handle, "ncclSend");
+        r.recv = (fn_recv)dlsym(r.handle, "ncclRecv");
+        r.group_start = (fn_group)dlsym(r.handle, "ncclGroupStart");
+        r.group_end = (fn_group)dlsym(r.handle, "ncclGroupEnd");
         r.err_string = (fn_err_string)dlsym(r.handle, "ncclGetErrorString");
         if (!r.get_unique_id || !r.comm_init_rank || !r.comm_destroy || !r.all_gather || !r.all_reduce)
             r.load_error = "librccl is missing a required symbol";
@@ -106,6 +117,65 @@ int dist_allgather_f64(sla_ctx *ctx, const double *send, double *recv, int64_t c
     int rc = rccl().all_gather(send, recv, (size_t)count, kNcclFloat64, (NcclComm)ctx->comm, ctx->stream);
     if (rc != 0) return rccl_fail("ncclAllGather", rc);
     return SLA_OK;
+}
+
+// Halo / window exchange: every rank receives only the x entries its rows reference and sends only what
+// its peers' rows reference (contiguous ranges, one grouped ncclSend/ncclRecv per peer pair), then drops
+// its own shard in place.  For a slab-partitioned stencil this is two plane-sized messages per SpMV
+// instead of an all-gather of the whole vector.
+int dist_exchange_window(sla_ctx *ctx, const XPlan &plan, const double *xlocal, int64_t my_begin, int64_t n_local, double *xfull) {
+    Rccl &r = rccl();
+    if (!ctx->comm) return fail(SLA_ERR_RCCL, "window exchange requested on a context without a communicator");
+    if (!r.send || !r.recv || !r.group_start || !r.group_end) return fail(SLA_ERR_RCCL, "librccl lacks ncclSend/ncclRecv");
+    if (n_local > 0)
+        SLA_HIP_TRY(hipMemcpyAsync(xfull + my_begin, xlocal, sizeof(double) * (size_t)n_local, hipMemcpyDeviceToDevice, ctx->stream));
+    int rc = r.group_start();
+    if (rc != 0) return rccl_fail("ncclGroupStart", rc);
+    for (int q = 0; q < ctx->nranks; ++q) {
+        if (q == ctx->rank) continue;
+        if (plan.recv_len[(size_t)q] > 0) {
+            rc = r.recv(xfull + plan.recv_begin[(size_t)q], (size_t)plan.recv_len[(size_t)q], kNcclFloat64, q, (NcclComm)ctx->comm, ctx->stream);
+            if (rc != 0) { r.group_end(); return rccl_fail("ncclRecv", rc); }
+        }
+        if (plan.send_len[(size_t)q] > 0) {
+            rc = r.send(xlocal + (plan.send_begin[(size_t)q] - my_begin), (size_t)plan.send_len[(size_t)q], kNcclFloat64, q, (NcclComm)ctx->comm, ctx->stream);
+            if (rc != 0) { r.group_end(); return rccl_fail("ncclSend", rc); }
+        }
+    }
+    rc = r.group_end();
+    if (rc != 0) return rccl_fail("ncclGroupEnd", rc);
+    return SLA_OK;
+}
+
+// Pure host planning, identical on every rank given the same `windows` table.
+void plan_window_exchange(int nranks, int rank, int64_t n, const int64_t *windows, XPlan &plan) {
+    const int64_t S = (n + nranks - 1) / nranks;
+    auto own = [&](int q, int64_t &b, int64_t &e) { b = std::min<int64_t>(n, S * q); e = std::min<int64_t>(n, S * (q + 1)); };
+    auto isect = [](int64_t a0, int64_t a1, int64_t b0, int64_t b1, int64_t &o0, int64_t &len) {
+        const int64_t lo = std::max(a0, b0), hi = std::min(a1, b1);
+        o0 = lo; len = hi > lo ? hi - lo : 0;
+    };
+    plan.send_begin.assign((size_t)nranks, 0); plan.send_len.assign((size_t)nranks, 0);
+    plan.recv_begin.assign((size_t)nranks, 0); plan.recv_len.assign((size_t)nranks, 0);
+    int64_t mb, me;
+    own(rank, mb, me);
+    int64_t worst_recv = 0;
+    for (int p = 0; p < nranks; ++p) {       // received entries of the busiest rank decide the mode
+        int64_t tot = 0;
+        const int64_t w0 = windows[2 * p], w1 = windows[2 * p + 1] + 1;   // half-open
+        for (int q = 0; q < nranks; ++q) {
+            if (q == p) continue;
+            int64_t qb, qe, o, len;
+            own(q, qb, qe);
+            isect(w0, w1, qb, qe, o, len);
+            tot += len;
+            if (p == rank) { plan.recv_begin[(size_t)q] = o; plan.recv_len[(size_t)q] = len; }
+            if (q == rank) { plan.send_begin[(size_t)p] = o; plan.send_len[(size_t)p] = len; }
+        }
+        worst_recv = std::max(worst_recv, tot);
+    }
+    // a window exchange pays when the busiest rank receives well under what an all-gather delivers
+    plan.use_window = nranks > 1 && worst_recv * 2 < (n - S > 0 ? n - S : 1);
 }
 
 // max over ranks of a host int (used for the global isDiagonalSM / method agreement); synchronises

@@ -71,6 +71,19 @@ struct SpmvArgs {
 
 }  // namespace sla
 
+namespace sla {
+// Exchange plan of the row-sharded SpMV: this rank's rows only reference columns in [cmin, cmax], so it
+// needs from peer q the part of that window q owns, and sends q the part of q's window it owns.
+struct XPlan {
+    bool use_window = false;                 // false: plain all-gather of the padded shards
+    std::vector<int64_t> send_begin, send_len;  // per peer, global index / length
+    std::vector<int64_t> recv_begin, recv_len;
+};
+// pure host planning (also exported as sla_plan_window_exchange for the CPU tests)
+void plan_window_exchange(int nranks, int rank, int64_t n, const int64_t *windows /* [2*nranks] cmin,cmax (cmax<cmin: empty) */,
+                          XPlan &plan);
+}  // namespace sla
+
 // ---------------------------------------------------------------------------------------------
 // handle types of the C ABI
 // ---------------------------------------------------------------------------------------------
@@ -85,6 +98,7 @@ struct sla_ctx {
     int64_t xfull_cap = 0;
     int spmv_algo = 0;               // 0 stream, 1 scalar (SLA_SPMV_ALGO)
     int xcd_remap = 1;               // SLA_XCD_REMAP
+    int x_exchange = 0;              // 0 auto (window exchange when it pays), 1 always all-gather, 2 always window (SLA_X_EXCHANGE=allgather|window)
     bool collectives = false;        // nranks > 1, or SLA_FORCE_COLLECTIVES=1 on a 1-rank communicator (test hook)
     int spmv_grid_max = sla::kSpmvGridMax;
     // profiling
@@ -116,6 +130,7 @@ struct sla_csr {
     int32_t nrb = 0;
     bool is_diagonal = false;        // global isDiagonalSM
     sla_csr *transposed = nullptr;   // built lazily (single-rank only)
+    sla::XPlan *xplan = nullptr;     // sharded only: which x entries this rank exchanges with each peer
     int64_t max_row_nnz = 0;
 };
 
@@ -177,11 +192,13 @@ int dist_unique_id(void *out128);
 int dist_comm_init(sla_ctx *ctx, const void *unique_id);
 int dist_comm_destroy(sla_ctx *ctx);
 int dist_allgather_f64(sla_ctx *ctx, const double *send, double *recv, int64_t count);
+int dist_exchange_window(sla_ctx *ctx, const XPlan &plan, const double *xlocal, int64_t my_begin, int64_t n_local, double *xfull);
 int dist_allreduce_max_i32(sla_ctx *ctx, int *value_host);
 
 // shared helpers of sla_api.cpp --------------------------------------------------------------------------
-int gather_x(sla_vec *x, const double **base);
-int gather_raw(sla_ctx *c, const double *local, int64_t shard, const double **base);
+// full-length gather base for an SpMV with matrix A (null: plain all-gather) whose input is `x`
+int gather_x(const sla_csr *A, sla_vec *x, const double **base);
+int gather_raw(sla_ctx *c, const sla_csr *A, const double *local, int64_t shard, const double **base);
 int reduce_to_host(sla_ctx *c, const double *p1, const double *p2, int np, double *out);
 int vec_alloc(sla_ctx *c, int64_t n, sla_vec **out);
 int csr_transposed(sla_csr *A, sla_csr **out);

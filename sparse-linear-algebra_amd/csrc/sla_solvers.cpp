@@ -80,7 +80,7 @@ struct StepCtl {
 int enqueue_residual(sla_solver *S, Parts *res) {
     SpmvLaunch l;
     l.epi = EPI_RES;
-    SLA_TRY(gather_x(S->x, &l.x));
+    SLA_TRY(gather_x(S->A, S->x, &l.x));
     l.w = S->b->d;
     l.p1 = slot(S, P_RES);
     l.sc = S->d_sc;
@@ -99,7 +99,7 @@ int enqueue_bicgstab(sla_solver *S, int par, const Parts *check) {
     {
         SpmvLaunch l;  // K1: aap = aa #> p ; aap <.> r0hat
         l.epi = EPI_DOT;
-        SLA_TRY(gather_x(S->p, &l.x));
+        SLA_TRY(gather_x(S->A, S->p, &l.x));
         l.y = S->t1->d;
         l.w = S->r0hat->d;
         l.p1 = slot(S, P_APR);
@@ -114,7 +114,7 @@ int enqueue_bicgstab(sla_solver *S, int par, const Parts *check) {
     {
         SpmvLaunch l;  // K3: aasj = aa #> sj ; aasj <.> sj ; aasj <.> aasj
         l.epi = EPI_DOT2;
-        SLA_TRY(gather_x(S->t2, &l.x));
+        SLA_TRY(gather_x(S->A, S->t2, &l.x));
         l.y = S->t3->d;
         l.w = S->t2->d;
         l.p1 = slot(S, P_ASS);
@@ -140,7 +140,7 @@ int enqueue_cgs(sla_solver *S, int par, const Parts *check) {
     {
         SpmvLaunch l;  // C1: aap = aa #> p ; aap <.> rhat
         l.epi = EPI_DOT;
-        SLA_TRY(gather_x(S->p, &l.x));
+        SLA_TRY(gather_x(S->A, S->p, &l.x));
         l.y = S->t1->d;
         l.w = S->r0hat->d;
         l.p1 = slot(S, P_APR);
@@ -155,7 +155,7 @@ int enqueue_cgs(sla_solver *S, int par, const Parts *check) {
     {
         SpmvLaunch l;  // C3: rj1 = r ^-^ alphaj .* (aa #> (u ^+^ q)) ; rj1 <.> rhat
         l.epi = EPI_AXPY_DOT;
-        SLA_TRY(gather_x(S->t3, &l.x));
+        SLA_TRY(gather_x(S->A, S->t3, &l.x));
         l.z = S->r->d;
         l.w = S->r0hat->d;
         l.p1 = slot(S, P_RHO);
@@ -178,7 +178,7 @@ int enqueue_cgne(sla_solver *S, int par, const Parts *check, StepCtl *ctl) {
     {
         SpmvLaunch l;  // N1: alphai = (r.r)/(p.p) ; r1 = r ^-^ alphai .* (aa #> p) ; r1 . r1
         l.epi = EPI_AXPY_DOT;
-        SLA_TRY(gather_x(S->p, &l.x));
+        SLA_TRY(gather_x(S->A, S->p, &l.x));
         l.z = S->r->d;
         l.w = nullptr;
         l.pa = ctl->pp.p;
@@ -196,7 +196,7 @@ int enqueue_cgne(sla_solver *S, int par, const Parts *check, StepCtl *ctl) {
     {
         SpmvLaunch l;  // N3: beta = (r1.r1)/(r.r) ; p1 = transpose aa #> r1 ^+^ beta .* p ; p1 . p1
         l.epi = EPI_XPBY_NRM;
-        SLA_TRY(gather_x(S->r, &l.x));
+        SLA_TRY(gather_x(S->A, S->r, &l.x));
         l.z = S->p->d;
         l.pa = rr1.p;
         l.npa = rr1.n;
@@ -258,7 +258,7 @@ int solver_init_common(int method, sla_csr *A, sla_vec *b, sla_vec *x0, double t
         if ((rc = sla_vec_copy(b, S->b)) != SLA_OK) break;
         SpmvLaunch l;  // r0 = b ^-^ (aa #> x0)
         l.epi = EPI_SUB;
-        if ((rc = gather_x(S->x, &l.x)) != SLA_OK) break;
+        if ((rc = gather_x(S->A, S->x, &l.x)) != SLA_OK) break;
         l.y = S->r->d;
         l.w = S->b->d;
         if ((rc = launch_spmv(A, l)) != SLA_OK) break;
@@ -267,7 +267,7 @@ int solver_init_common(int method, sla_csr *A, sla_vec *b, sla_vec *x0, double t
             sla_csr *T = nullptr;
             if ((rc = csr_transposed(A, &T)) != SLA_OK) break;
             SpmvLaunch lt;  // p0 = transposeSM aa #> r0
-            if ((rc = gather_x(S->r, &lt.x)) != SLA_OK) break;
+            if ((rc = gather_x(S->A, S->r, &lt.x)) != SLA_OK) break;
             lt.y = S->p->d;
             if ((rc = launch_spmv(T, lt)) != SLA_OK) break;
             if ((rc = launch_dot(c, S->p->n_local, S->p->d, S->p->d, slot(S, P_ASS))) != SLA_OK) break;
@@ -374,7 +374,7 @@ int arn_run(ArnoldiWs &ws, sla_csr *A, const double *src_local, int kn, int *k_d
     for (int i = 0; i < kn; ++i) {
         const double *qi = ws.Q + (size_t)i * ws.ld;
         SpmvLaunch l;  // aqi = aa #> qi
-        SLA_TRY(gather_raw(c, qi, (ws.n + c->nranks - 1) / c->nranks, &l.x));
+        SLA_TRY(gather_raw(c, A, qi, (ws.n + c->nranks - 1) / c->nranks, &l.x));
         l.y = ws.w;
         l.sc = ws.d_sc;
         SLA_TRY(launch_spmv(A, l));
@@ -577,7 +577,7 @@ int sla_gmres(sla_csr_t A, sla_vec_t b, sla_vec_t x0, int restart, const sla_sol
     while (rc == SLA_OK) {
         SpmvLaunch l;  // r = b ^-^ (aa #> x)
         l.epi = EPI_SUB;
-        if ((rc = gather_x(x, &l.x)) != SLA_OK) break;
+        if ((rc = gather_x(A, x, &l.x)) != SLA_OK) break;
         l.y = r->d;
         l.w = b->d;
         if ((rc = launch_spmv(A, l)) != SLA_OK) break;

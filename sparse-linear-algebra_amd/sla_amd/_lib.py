@@ -100,6 +100,7 @@ PROTOTYPES = [
     ("sla_prof_start", _int, [_vp, _int, _int]),
     ("sla_prof_stop", _int, [_vp, _pint, _pdbl, _pdbl]),
     ("sla_csr_kernel_info", _int, [_vp, C.c_char_p, _int]),
+    ("sla_plan_window_exchange", _int, [_int, _int, _i64, _vp, _vp, _vp, _vp, _vp, _pint]),
 ]
 
 _LIB = None

@@ -25,3 +25,17 @@ def local_rows_of(rowptr, colidx, val, begin, end):
     """Slice rows [begin, end) out of a full canonical CSR (rowptr rebased to 0, global columns)."""
     lo, hi = rowptr[begin], rowptr[end]
     return rowptr[begin:end + 1] - lo, colidx[lo:hi], val[lo:hi]
+
+
+def plan_window_exchange(nranks, rank, n, windows):
+    """The library's own exchange plan (sla_plan_window_exchange, pure host arithmetic): returns
+    (send_begin, send_len, recv_begin, recv_len, use_window) for `rank`."""
+    import ctypes as C
+    import numpy as np
+    from . import _lib
+    w = np.ascontiguousarray(windows, dtype=np.int64).reshape(-1)
+    outs = [np.zeros(nranks, dtype=np.int64) for _ in range(4)]
+    use = C.c_int()
+    _lib.check(_lib.lib().sla_plan_window_exchange(nranks, rank, int(n), C.c_void_p(w.ctypes.data),
+                                                   *[C.c_void_p(o.ctypes.data) for o in outs], C.byref(use)))
+    return (*outs, bool(use.value))
