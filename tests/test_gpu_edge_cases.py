@@ -1,0 +1,111 @@
+"""Edge cases of the C ABI on the GPU: empty / ragged / rectangular inputs, degenerate sizes, misuse."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def sla():
+    import sla_amd
+    return sla_amd
+
+
+def test_empty_matrix_and_zero_vectors(sla):
+    A = sla.fromListSM((5, 5), [])
+    assert A.nnz() == 0 and A.csr()[0].tolist() == [0] * 6
+    y = sla.matVec(A, sla.onesSV(5))
+    assert y.nnz() == 0 and y.toDenseListSV().tolist() == [0.0] * 5       # no row keys at all
+    assert not A.isDiagonalSM()
+    z = sla.zeroSV(4)
+    assert sla.dot(z, sla.onesSV(4)) == 0.0 and sla.norm2(z) == 0.0
+
+
+def test_one_by_one_and_diagonal(sla):
+    A = sla.fromListSM((1, 1), [(0, 0, 4.0)])
+    assert A.isDiagonalSM()
+    x = sla.linSolve0(sla.BICGSTAB_, A, sla.mkSpVR(1, [2.0]), sla.mkSpVR(1, [0.0]))
+    assert x.toDenseListSV().tolist() == [0.5]
+
+
+def test_rectangular_matvec_and_vecmat(sla):
+    rng = np.random.default_rng(3)
+    m, n, nnz = 70, 1300, 2500
+    r, c, v = rng.integers(0, m, nnz), rng.integers(0, n, nnz), rng.standard_normal(nnz)
+    A = sla.fromCOO((m, n), r, c, v)
+    rc, Ao = orc.coo_to_csr(m, n, r, c, v)
+    x, w = rng.standard_normal(n), rng.standard_normal(m)
+    assert np.allclose(sla.matVec(A, sla.fromVector(x)).toDenseListSV(), orc.spmv(Ao, x), rtol=1e-13, atol=1e-13)
+    assert np.allclose(sla.vecMat(sla.fromVector(w), A).toDenseListSV(), orc.spmv(orc.transpose(Ao), w), rtol=1e-13, atol=1e-13)
+    with pytest.raises(sla.MatVecSizeMismatchException):
+        sla.matVec(A, sla.onesSV(m))
+
+
+def test_rows_at_block_limits(sla):
+    # rows of exactly 1024 / 1025 entries (LDS row-block limit) and a 256-row block of single entries
+    rng = np.random.default_rng(9)
+    n = 4000
+    rows, cols, vals = [], [], []
+    for i, k in ((0, 1024), (1, 1025), (2, 1), (3, 1023), (4, 2049)):
+        cj = np.sort(rng.choice(n, size=k, replace=False))
+        rows.append(np.full(k, i)); cols.append(cj); vals.append(rng.standard_normal(k))
+    for i in range(5, 5 + 600):
+        rows.append([i]); cols.append([int(rng.integers(0, n))]); vals.append([float(rng.standard_normal())])
+    r, c, v = np.concatenate(rows), np.concatenate(cols), np.concatenate(vals)
+    A = sla.fromCOO((n, n), r, c, v)
+    rc, Ao = orc.coo_to_csr(n, n, r, c, v)
+    x = rng.standard_normal(n)
+    y, yo = sla.matVec(A, sla.fromVector(x)).toDenseListSV(), orc.spmv(Ao, x)
+    assert np.allclose(y, yo, rtol=1e-12, atol=1e-12)
+    assert np.array_equal(y[5:605], yo[5:605])
+
+
+def test_duplicate_policy_sum_extension(sla):
+    A = sla.fromCOO((2, 2), [0, 0, 1], [1, 1, 0], [1.0, 2.0, 5.0], dup_policy=1)
+    assert A.toDense().tolist() == [[0.0, 3.0], [5.0, 0.0]]
+
+
+def test_non_canonical_csr_rejected(sla):
+    with pytest.raises(sla.SlaError):
+        sla.fromCSR((2, 2), [0, 2, 2], [1, 0], [1.0, 2.0])          # descending columns
+    with pytest.raises(sla.IndexOutOfBounds):
+        sla.fromCSR((2, 2), [0, 1, 2], [0, 5], [1.0, 2.0])
+
+
+def test_null_handles_and_bad_arguments(sla):
+    L = sla._lib.lib()
+    assert L.sla_spmv(None, None, None) == sla._lib.ERR_INVALID
+    assert L.sla_solver_step(None, 1) == sla._lib.ERR_INVALID
+    out = C.c_void_p()
+    assert L.sla_ctx_create(99, C.byref(out)) == sla._lib.ERR_INVALID
+    A = sla.fromListSM((3, 3), [(0, 0, 1.0), (1, 2, 2.0), (2, 1, 1.0)])
+    with pytest.raises(sla.SlaError):
+        sla.arnoldi(A, sla.onesSV(3), 0)
+    with pytest.raises(sla.MatVecSizeMismatchException):
+        sla.cgsInit(A, sla.onesSV(4), sla.onesSV(3))
+
+
+def test_nan_propagation_like_reference(sla):
+    # iterating past convergence gives 0/0 = NaN in the reference (README.md:220); no exception here either
+    A = sla.fromListSM((3, 3), [(0, 0, 2), (1, 0, 4), (1, 1, 3), (1, 2, 2), (2, 2, 5)])
+    s = sla.bicgsInit(A, sla.fromListDenseSV(3, [3, 2, 5]), sla.fromListSV(3, []))
+    s.step(20)
+    x = s._xBicgstab.toDenseListSV()
+    assert x.shape == (3,)                                            # NaN or converged: just no crash
+    x, info = sla.linSolve0(sla.BICGSTAB_, A, sla.fromListDenseSV(3, [3, 2, 5]), sla.fromListSV(3, []), return_info=True)
+    assert info["converged"] and info["iters"] <= 3
+
+
+def test_rerun_is_bit_identical(sla):
+    from sla_amd import workloads as wl
+    dims, (rp, ci, va) = wl.banded_nonsym(30000)
+    A = sla.fromCSR(dims, rp, ci, va)
+    b = sla.fromVector(np.random.default_rng(1).standard_normal(dims[0]))
+    x0 = sla.fromVector(np.zeros(dims[0]))
+    a = sla.linSolve0(sla.BICGSTAB_, A, b, x0).toDenseListSV()
+    c = sla.linSolve0(sla.BICGSTAB_, A, b, x0).toDenseListSV()
+    assert np.array_equal(a, c)                                       # deterministic two-stage reductions
