@@ -18,6 +18,7 @@ constexpr int kMaxRowsPerRowBlock = 256;
 constexpr int kMaxParts = 2048;      // partial-sum slots per reduction (256 CUs x 8)
 constexpr int kVecGridMax = 1024;    // grid cap of the streaming BLAS-1 kernels
 constexpr int kSpmvGridMax = 2048;   // persistent grid cap of the SpMV kernels
+constexpr int kArnGridMax = 1024;    // grid cap (= partials per column) of the Arnoldi kernels
 constexpr int kMaxKrylov = 64;       // max Arnoldi basis columns handled by the fused GS kernels
 
 // Device-resident scalars of one solver.  Written only by block 0 / thread 0 of a kernel and

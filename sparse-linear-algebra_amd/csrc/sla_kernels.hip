@@ -843,7 +843,7 @@ __global__ void __launch_bounds__(kBlock) gemv_accum_kernel(int64_t n, const dou
 
 int arn_grid(int64_t n) {
     int g = vec_grid(n);
-    return g > 256 ? 256 : g;
+    return g > kArnGridMax ? kArnGridMax : g;
 }
 
 #define SLA_NC_DISPATCH(ncols, CALL)                              \

@@ -333,7 +333,7 @@ int arn_alloc(ArnoldiWs &ws, sla_csr *A, sla_vec *like, int kn) {
     SLA_HIP_TRY(hipMalloc((void **)&ws.w, sizeof(double) * (size_t)ws.ld));
     SLA_HIP_TRY(hipMemsetAsync(ws.w, 0, sizeof(double) * (size_t)ws.ld, c->stream));
     SLA_HIP_TRY(hipMalloc((void **)&ws.H, sizeof(double) * (size_t)(kn + 1) * (size_t)kn));
-    SLA_HIP_TRY(hipMalloc((void **)&ws.parts, sizeof(double) * (size_t)(kMaxKrylov + 2) * 256));
+    SLA_HIP_TRY(hipMalloc((void **)&ws.parts, sizeof(double) * (size_t)(kMaxKrylov + 2) * kArnGridMax));
     SLA_HIP_TRY(hipMalloc((void **)&ws.gath, sizeof(double) * ((size_t)(kMaxKrylov + 2) * (size_t)c->nranks + kMaxKrylov + 8)));
     SLA_HIP_TRY(hipMalloc((void **)&ws.ycoef, sizeof(double) * (kMaxKrylov + 2)));
     SLA_HIP_TRY(hipMalloc((void **)&ws.d_sc, sizeof(SolverScalars)));
@@ -346,12 +346,14 @@ int arn_alloc(ArnoldiWs &ws, sla_csr *A, sla_vec *like, int kn) {
 struct ColParts { const double *p; int np, cs, stride; };
 int arn_publish(ArnoldiWs &ws, const double *parts, int np, int ncols, ColParts *out) {
     sla_ctx *c = ws.c;
-    if (!c->collectives) {
-        *out = ColParts{parts, np, np, 1};
-        return SLA_OK;
-    }
+    // one tiny launch folds the per-workgroup partials to ncols values, so that the producers can use a
+    // chip-filling grid without every consumer workgroup re-reducing ncols x grid partials
     double *loc = ws.gath + (size_t)(kMaxKrylov + 2) * c->nranks;
     SLA_TRY(launch_finalize_cols(c, parts, np, np, 1, ncols, loc));
+    if (!c->collectives) {
+        *out = ColParts{loc, 1, 1, 1};
+        return SLA_OK;
+    }
     SLA_TRY(dist_allgather_f64(c, loc, ws.gath, ncols));  // layout [rank][ncols]
     *out = ColParts{ws.gath, c->nranks, 1, ncols};
     return SLA_OK;
@@ -382,7 +384,7 @@ int arn_run(ArnoldiWs &ws, sla_csr *A, const double *src_local, int kn, int *k_d
         SLA_TRY(launch_arn_dots(c, n, ws.Q, ws.ld, i + 1, ws.w, ws.parts, ws.d_sc));
         SLA_TRY(arn_publish(ws, ws.parts, g, i + 1, &cp));
         // qipnn = aqi ^-^ sum_k h_k q_k ; partial ||qipnn||^2 ; H[0..i, i]
-        double *pn = ws.parts + (size_t)kMaxKrylov * 256;
+        double *pn = ws.parts + (size_t)kMaxKrylov * kArnGridMax;
         SLA_TRY(launch_arn_update(c, n, ws.Q, ws.ld, i + 1, cp.p, cp.np, cp.cs, cp.stride, ws.w, pn,
                                   ws.H + (size_t)i * ldh, ws.d_sc));
         ColParts cn;
