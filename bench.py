@@ -191,14 +191,19 @@ def main():
         _lib.check(lib.sla_linsolve0(4, A.h, bvec.h, x0.h, C.byref(o), out.h, C.byref(info)))
         sync_all()
         o = _lib.SolveOpts(args.steps, 0.0, 0.0, max(args.steps, 1), 1)      # tol 0: run exactly K iterations
-        ctx.prof_start(_lib.KERNEL_SPMV_DOT, args.steps)
+        dual = not use_dist and os.environ.get("SLA_DUAL_SPMV", "1") != "0" and os.environ.get("SLA_SPMV_ALGO", "stream") == "stream"
+        ctx.prof_start(_lib.KERNEL_SPMV_DUAL if dual else _lib.KERNEL_SPMV_DOT, args.steps)
         t0 = time.perf_counter()
         _lib.check(lib.sla_linsolve0(4, A.h, bvec.h, x0.h, C.byref(o), out.h, C.byref(info)))
         sync_all()
         dt = time.perf_counter() - t0
         launches, mean_ms, min_ms = ctx.prof_stop()
-        step_bytes = 36 * nnz + 180 * n
-        mode_desc = "linSolve0 iteration (bicgstabStep + per-iteration true residual, 3 SpMV)"
+        # dual SpMV: the residual of the previous iterate rides on K1's matrix sweep (x and b are the only
+        # extra streams): 24 nnz + 176 n per iteration instead of the three-sweep 36 nnz + 180 n
+        step_bytes = 24 * nnz + 176 * n if dual else 36 * nnz + 180 * n
+        mode_desc = ("linSolve0 iteration (bicgstabStep + per-iteration true residual fused into K1: 2 matrix sweeps)" if dual
+                     else "linSolve0 iteration (bicgstabStep + per-iteration true residual, 3 SpMV)")
+        extra["dual_spmv"] = dual
         extra["linsolve0_iters"] = info.iters
 
     if use_dist:
@@ -225,6 +230,8 @@ def main():
         k1_bytes = 12 * nnz_local + 28 * n_local      # K1 = SpMV (12 nnz + 20 n) + r0hat read for the fused dot (8 n)
         if args.mode == "gmres":
             k1_bytes = 12 * nnz_local + 20 * n_local  # the Arnoldi SpMV is the plain kernel
+        if args.mode == "linsolve0" and extra.get("dual_spmv"):
+            k1_bytes = 12 * nnz_local + 44 * n_local  # K1 + gather of x (8 n) + b (8 n) for the fused residual
         achieved = k1_bytes / (mean_ms * 1e-3) / 1e9 if launches else 0.0
         rec = {
             "metric": "bicgstab_iters_per_sec" if args.mode != "gmres" else "gmres_arnoldi_steps_per_sec",

@@ -198,6 +198,7 @@ typedef enum {
     SLA_KERNEL_SPMV_DOT = 1,  /* K1: Ap = A p fused with Ap . r0hat */
     SLA_KERNEL_SPMV_DOT2 = 2, /* K3: As = A s fused with As . s, As . As */
     SLA_KERNEL_SPMV_RES = 3,  /* true-residual SpMV fused with ||A x - b||^2 */
+    SLA_KERNEL_SPMV_DUAL = 4, /* K1 + true residual of the previous iterate from ONE matrix sweep (linSolve0) */
     SLA_KERNEL_COUNT = 8
 } sla_kernel_id;
 /* record up to `max_launches` event pairs around launches of `kernel_id` from now on */

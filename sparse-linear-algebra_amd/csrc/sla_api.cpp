@@ -248,6 +248,7 @@ static int ctx_create_common(int device_id, int rank, int nranks, const void *ui
     SLA_HIP_TRY(hipHostMalloc((void **)&c->h_result, sizeof(double) * 64, hipHostMallocDefault));
     if (const char *s = getenv("SLA_SPMV_ALGO")) c->spmv_algo = (strcmp(s, "scalar") == 0) ? 1 : 0;
     if (const char *s = getenv("SLA_XCD_REMAP")) c->xcd_remap = atoi(s);
+    if (const char *s = getenv("SLA_DUAL_SPMV")) c->dual_spmv = atoi(s);
     if (const char *s = getenv("SLA_X_EXCHANGE")) c->x_exchange = strcmp(s, "allgather") == 0 ? 1 : (strcmp(s, "window") == 0 ? 2 : 0);
     if (const char *s = getenv("SLA_SPMV_GRID")) {
         int g = atoi(s);

@@ -99,6 +99,7 @@ struct sla_ctx {
     int64_t xfull_cap = 0;
     int spmv_algo = 0;               // 0 stream, 1 scalar (SLA_SPMV_ALGO)
     int xcd_remap = 1;               // SLA_XCD_REMAP
+    int dual_spmv = 1;               // linSolve0: fuse the true-residual SpMV into the next K1 (SLA_DUAL_SPMV=0 disables)
     int x_exchange = 0;              // 0 auto (window exchange when it pays), 1 always all-gather, 2 always window (SLA_X_EXCHANGE=allgather|window)
     bool collectives = false;        // nranks > 1, or SLA_FORCE_COLLECTIVES=1 on a 1-rank communicator (test hook)
     int spmv_grid_max = sla::kSpmvGridMax;
@@ -219,6 +220,7 @@ struct SpmvLaunch {
     const double *pres = nullptr; int npres = 0, pres_stride = 1;
     const double *pa = nullptr, *pb = nullptr; int npa = 0, pa_stride = 1;
     int step_begin = 0;
+    const double *x2 = nullptr, *b2 = nullptr;  // dual SpMV: also leave partials of ||A x2 - b2||^2 in p2
     int kernel_id = SLA_KERNEL_SPMV;
 };
 int spmv_grid(const sla_csr *A);  // number of blocks (= partial slots written) of an SpMV launch on A
@@ -237,13 +239,14 @@ int launch_scal(sla_ctx *c, int64_t n, double a, double *x);
 int launch_fill(sla_ctx *c, int64_t n, double a, double *x);
 
 // BiCGSTAB (Sparse.hs:972-981)
-int launch_bicg_k2(sla_ctx *c, int64_t n, SolverScalars *sc, Parts apr, int par, const double *r, const double *ap, double *s);
+int launch_bicg_k2(sla_ctx *c, int64_t n, SolverScalars *sc, Parts apr, int par, Parts res, int count_iter,
+                   const double *r, const double *ap, double *s);
 int launch_bicg_k4(sla_ctx *c, int64_t n, SolverScalars *sc, Parts ass, Parts asas, const double *p, const double *s,
                    const double *as, const double *r0hat, double *x, double *r, double *prho);
 int launch_bicg_k5(sla_ctx *c, int64_t n, SolverScalars *sc, Parts rhonew, int par, const double *r, const double *ap, double *p);
 // CGS (Sparse.hs:928-939)
-int launch_cgs_c2(sla_ctx *c, int64_t n, SolverScalars *sc, Parts apr, int par, const double *u, const double *aap,
-                  double *q, double *uq, double *x);
+int launch_cgs_c2(sla_ctx *c, int64_t n, SolverScalars *sc, Parts apr, int par, Parts res, int count_iter,
+                  const double *u, const double *aap, double *q, double *uq, double *x);
 int launch_cgs_c4(sla_ctx *c, int64_t n, SolverScalars *sc, Parts rhonew, int par, const double *r, const double *q,
                   double *u, double *p);
 // CGNE (Sparse.hs:870-878)

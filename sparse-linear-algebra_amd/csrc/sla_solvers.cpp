@@ -90,7 +90,7 @@ int enqueue_residual(sla_solver *S, Parts *res) {
 }
 
 // bicgstabStep (Sparse.hs:972-981)
-int enqueue_bicgstab(sla_solver *S, int par, const Parts *check) {
+int enqueue_bicgstab(sla_solver *S, int par, const Parts *check, bool dual_prev) {
     sla_ctx *c = S->ctx;
     sla_csr *A = S->A;
     const int64_t n = S->x->n_local;
@@ -105,12 +105,19 @@ int enqueue_bicgstab(sla_solver *S, int par, const Parts *check) {
         l.p1 = slot(S, P_APR);
         l.sc = S->d_sc;
         if (check && check->p) { l.pres = check->p; l.npres = check->n; l.pres_stride = check->stride; }
-        l.step_begin = 1 | (par << 1);
+        l.step_begin = (dual_prev ? 0 : 1) | (par << 1);
         l.kernel_id = SLA_KERNEL_SPMV_DOT;
+        if (dual_prev) {  // the same matrix sweep also evaluates ||A x - b||^2 of the current x
+            l.x2 = S->x->d;
+            l.b2 = S->b->d;
+            l.p2 = slot(S, P_RES);
+            l.kernel_id = SLA_KERNEL_SPMV_DUAL;
+        }
         SLA_TRY(launch_spmv(A, l));
         SLA_TRY(publish(S, P_APR, -1, g, &apr, nullptr));
     }
-    SLA_TRY(launch_bicg_k2(c, n, S->d_sc, apr, par, S->r->d, S->t1->d, S->t2->d));
+    SLA_TRY(launch_bicg_k2(c, n, S->d_sc, apr, par, dual_prev ? Parts{slot(S, P_RES), g, 1} : Parts{nullptr, 0, 1},
+                           dual_prev ? 1 : 0, S->r->d, S->t1->d, S->t2->d));
     {
         SpmvLaunch l;  // K3: aasj = aa #> sj ; aasj <.> sj ; aasj <.> aasj
         l.epi = EPI_DOT2;
@@ -131,7 +138,7 @@ int enqueue_bicgstab(sla_solver *S, int par, const Parts *check) {
 }
 
 // cgsStep (Sparse.hs:928-939)
-int enqueue_cgs(sla_solver *S, int par, const Parts *check) {
+int enqueue_cgs(sla_solver *S, int par, const Parts *check, bool dual_prev) {
     sla_ctx *c = S->ctx;
     sla_csr *A = S->A;
     const int64_t n = S->x->n_local;
@@ -146,12 +153,19 @@ int enqueue_cgs(sla_solver *S, int par, const Parts *check) {
         l.p1 = slot(S, P_APR);
         l.sc = S->d_sc;
         if (check && check->p) { l.pres = check->p; l.npres = check->n; l.pres_stride = check->stride; }
-        l.step_begin = 1 | (par << 1);
+        l.step_begin = (dual_prev ? 0 : 1) | (par << 1);
         l.kernel_id = SLA_KERNEL_SPMV_DOT;
+        if (dual_prev) {
+            l.x2 = S->x->d;
+            l.b2 = S->b->d;
+            l.p2 = slot(S, P_RES);
+            l.kernel_id = SLA_KERNEL_SPMV_DUAL;
+        }
         SLA_TRY(launch_spmv(A, l));
         SLA_TRY(publish(S, P_APR, -1, g, &apr, nullptr));
     }
-    SLA_TRY(launch_cgs_c2(c, n, S->d_sc, apr, par, S->u->d, S->t1->d, S->t2->d, S->t3->d, S->x->d));
+    SLA_TRY(launch_cgs_c2(c, n, S->d_sc, apr, par, dual_prev ? Parts{slot(S, P_RES), g, 1} : Parts{nullptr, 0, 1},
+                          dual_prev ? 1 : 0, S->u->d, S->t1->d, S->t2->d, S->t3->d, S->x->d));
     {
         SpmvLaunch l;  // C3: rj1 = r ^-^ alphaj .* (aa #> (u ^+^ q)) ; rj1 <.> rhat
         l.epi = EPI_AXPY_DOT;
@@ -216,20 +230,28 @@ StepCtl &ctl_of(sla_solver *S) {
     return *reinterpret_cast<StepCtl *>(S->ctl_storage);
 }
 
-int enqueue_step(sla_solver *S, bool with_residual) {
+// One solver step.  res_after: follow it with the stand-alone true-residual SpMV (KR).  dual_prev: this
+// step's K1 also evaluates the true residual of the CURRENT x (the previous step's x') and K2 tests it --
+// the reference's "step; recompute residual; test" order with two matrix sweeps per iteration, not three.
+int enqueue_step(sla_solver *S, bool res_after, bool dual_prev) {
     StepCtl &ctl = ctl_of(S);
     const int par = ctl.step_index & 1;
     const Parts *check = S->have_res ? &ctl.res : nullptr;
-    if (S->method == SLA_BICGSTAB_) SLA_TRY(enqueue_bicgstab(S, par, check));
-    else if (S->method == SLA_CGS_) SLA_TRY(enqueue_cgs(S, par, check));
+    if (S->method == SLA_BICGSTAB_) SLA_TRY(enqueue_bicgstab(S, par, check, dual_prev));
+    else if (S->method == SLA_CGS_) SLA_TRY(enqueue_cgs(S, par, check, dual_prev));
     else SLA_TRY(enqueue_cgne(S, par, check, &ctl));
     ctl.step_index++;
     S->have_res = false;
-    if (with_residual) {
+    if (res_after) {
         SLA_TRY(enqueue_residual(S, &ctl.res));
         S->have_res = true;
     }
     return SLA_OK;
+}
+
+// the dual-SpMV flow needs x and p resident on this rank as whole vectors and the stream kernel
+bool dual_ok(const sla_solver *S) {
+    return !S->ctx->collectives && S->ctx->spmv_algo == 0 && S->ctx->dual_spmv && S->method != SLA_CGNE_;
 }
 
 int read_scalars(sla_solver *S) {
@@ -439,7 +461,7 @@ int sla_solver_init(int method, sla_csr_t A, sla_vec_t b, sla_vec_t x0, sla_solv
 int sla_solver_step(sla_solver_t S, int k_steps) {
     if (!S || k_steps < 0) return fail(SLA_ERR_INVALID, "sla_solver_step: bad argument");
     (void)hipSetDevice(S->ctx->device);
-    for (int k = 0; k < k_steps; ++k) SLA_TRY(enqueue_step(S, false));
+    for (int k = 0; k < k_steps; ++k) SLA_TRY(enqueue_step(S, false, false));
     return SLA_OK;
 }
 
@@ -509,7 +531,12 @@ int sla_linsolve0(int method, sla_csr_t A, sla_vec_t b, sla_vec_t x0, const sla_
     int rc = SLA_OK, total = 0;
     while (total < o.max_iters) {  // runIter n state | n >= nits = return x        (:1045)
         const int k = std::min(o.check_every, o.max_iters - total);
-        for (int j = 0; j < k && rc == SLA_OK; ++j) rc = enqueue_step(S, o.true_residual != 0);
+        const bool dual = o.true_residual != 0 && dual_ok(S);
+        for (int j = 0; j < k && rc == SLA_OK; ++j) {
+            if (!o.true_residual) rc = enqueue_step(S, false, false);
+            else if (!dual) rc = enqueue_step(S, true, false);
+            else rc = enqueue_step(S, /*res_after=*/j == k - 1, /*dual_prev=*/j > 0);
+        }
         if (rc != SLA_OK) break;
         total += k;
         if (o.true_residual) {

@@ -13,7 +13,7 @@ CSRC = os.path.join(_ROOT, "csrc")
  ERR_NO_DEVICE) = range(9)
 
 FLAG_CONVERGED, FLAG_MAX_ITERS, FLAG_DIAGONAL, FLAG_BREAKDOWN, FLAG_NONFINITE = 1, 2, 4, 8, 16
-KERNEL_SPMV, KERNEL_SPMV_DOT, KERNEL_SPMV_DOT2, KERNEL_SPMV_RES = 0, 1, 2, 3
+KERNEL_SPMV, KERNEL_SPMV_DOT, KERNEL_SPMV_DOT2, KERNEL_SPMV_RES, KERNEL_SPMV_DUAL = 0, 1, 2, 3, 4
 
 
 class SlaError(RuntimeError):

@@ -109,3 +109,31 @@ def test_rerun_is_bit_identical(sla):
     a = sla.linSolve0(sla.BICGSTAB_, A, b, x0).toDenseListSV()
     c = sla.linSolve0(sla.BICGSTAB_, A, b, x0).toDenseListSV()
     assert np.array_equal(a, c)                                       # deterministic two-stage reductions
+
+
+def test_dual_spmv_flow_equals_three_sweep_flow(sla, monkeypatch):
+    """linSolve0 with the true residual fused into the next K1 (default) must return exactly what the
+    three-SpMV-per-iteration flow returns: same iterate, same iteration count, same residual."""
+    from sla_amd import workloads as wl
+    dims, (rp, ci, va) = wl.laplace3d(30, 20, 25)
+    n = dims[0]
+    b = np.random.default_rng(4).standard_normal(n)
+    res = []
+    for dual in ("1", "0"):
+        monkeypatch.setenv("SLA_DUAL_SPMV", dual)
+        ctx = sla.Context(0)
+        A = sla.fromCSR(dims, rp, ci, va, ctx)
+        for meth in (sla.BICGSTAB_, sla.CGS_):
+            for ce in (16, 5, 1):
+                x, info = sla.linSolve0(meth, A, sla.fromVector(b, ctx), sla.fromVector(np.zeros(n), ctx),
+                                        return_info=True, check_every=ce)
+                res.append((dual, int(meth), ce, x.toDenseListSV(), info["iters"], info["resnorm"], info["converged"]))
+        del A
+        ctx.close()
+    half = len(res) // 2
+    ref = {}
+    for (dual, meth, ce, x, it, rn, cv) in res:
+        key = meth
+        if key not in ref:
+            ref[key] = (x, it, rn, cv)
+        assert cv and it == ref[key][1] and np.array_equal(x, ref[key][0]) and rn == ref[key][2], (dual, meth, ce, it)
