@@ -67,10 +67,38 @@ def cpu_baseline(dims, rp, ci, va, b, seconds):
     for _ in range(reps):
         orc.spmv(Ao, b)
     dts = (time.perf_counter() - t0) / reps
-    return {"value": steps / dt, "unit": "iters/s", "cores": 1, "kind": "port",
-            "sample": f"{steps} bicgstabStep iterations of the same {n}-row matrix, single thread, oracle/sla_oracle.c (gcc -O2 -ffp-contract=off)",
-            "host_cores_available": os.cpu_count(),
-            "spmv_gbps": (12 * len(ci) + 20 * n) / dts / 1e9}
+    out = {"value": steps / dt, "unit": "iters/s", "cores": 1, "kind": "port",
+           "sample": f"{steps} bicgstabStep iterations of the same {n}-row matrix, single thread, oracle/sla_oracle.c (gcc -O2 -ffp-contract=off)",
+           "host_cores_available": os.cpu_count(),
+           "spmv_gbps": (12 * len(ci) + 20 * n) / dts / 1e9}
+    # "fair CPU": the same port built with OpenMP (row-parallel SpMV, parallel reductions), all host cores
+    try:
+        threads = len(os.sched_getaffinity(0))
+        try:  # a container CPU quota (cgroup v2 cpu.max) caps the useful thread count below the visible cores
+            quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+            if quota != "max":
+                threads = max(1, min(threads, int(int(quota) / int(period))))
+        except (OSError, ValueError):
+            pass
+        os.environ.setdefault("OMP_NUM_THREADS", str(threads))
+        os.environ.setdefault("OMP_PROC_BIND", "spread")
+        orc.use_omp(True)
+        st = orc.BicgstabState(Ao, b, x0)
+        st.step(r0hat, 2)                                     # warm up the thread team / first touch
+        t0 = time.perf_counter()
+        st.step(r0hat, 1)
+        t1 = max(time.perf_counter() - t0, 1e-6)
+        osteps = max(5, min(400, int(0.4 * seconds / t1)))
+        t0 = time.perf_counter()
+        st.step(r0hat, osteps)
+        odt = time.perf_counter() - t0
+        out["omp"] = {"value": osteps / odt, "unit": "iters/s", "cores": threads, "kind": "port",
+                      "sample": f"{osteps} bicgstabStep iterations, OpenMP build of the same port (liboracle_omp.so), {threads} threads"}
+    except Exception as e:  # the OpenMP leg is informative only
+        out["omp"] = {"error": repr(e)}
+    finally:
+        orc.use_omp(False)
+    return out
 
 
 def main():

@@ -46,6 +46,29 @@ def lib():
     return _LIB
 
 
+_LIB_SERIAL = None
+
+
+def use_omp(flag):
+    """Switch to / from liboracle_omp.so, the OpenMP "fair CPU" TIMING build (row-parallel SpMV, parallel
+    reductions: not the reference's summation order, never used for parity checks)."""
+    global _LIB, _LIB_SERIAL
+    if _LIB_SERIAL is None:
+        _LIB_SERIAL = lib()
+    if not flag:
+        _LIB = _LIB_SERIAL
+        return _LIB
+    so = os.path.join(_HERE, "liboracle_omp.so")
+    if not os.path.exists(so):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "liboracle_omp.so"])
+    L = C.CDLL(so)
+    L.orc_dot.restype = C.c_double
+    L.orc_norm2.restype = C.c_double
+    L.orc_norm2sq.restype = C.c_double
+    _LIB = L
+    return _LIB
+
+
 def _i64(a):
     return np.ascontiguousarray(a, dtype=np.int64)
 

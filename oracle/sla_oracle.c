@@ -125,6 +125,9 @@ int orc_is_diagonal(int64_t m, const int64_t *rowptr, const int64_t *colidx) {
  * (:259-260): acc = 0; for ascending j: acc = acc + a_ij * x_j. */
 void orc_spmv(int64_t m, const int64_t *rowptr, const int64_t *colidx, const double *val,
               const double *x, double *y) {
+#ifdef ORC_OMP /* row-parallel: per-row order unchanged (liboracle_omp.so, "fair CPU" timing only) */
+#pragma omp parallel for schedule(static)
+#endif
     for (int64_t i = 0; i < m; ++i) {
         double acc = 0.0;
         for (int64_t k = rowptr[i]; k < rowptr[i + 1]; ++k) {
@@ -138,6 +141,9 @@ void orc_spmv(int64_t m, const int64_t *rowptr, const int64_t *colidx, const dou
 /* v <.> w = sum (liftI2 (<.>) v w)  (SpVector.hs:116-117; Double: (<.>) = (*), Class.hs:400) */
 double orc_dot(int64_t n, const double *x, const double *y) {
     double acc = 0.0;
+#ifdef ORC_OMP /* parallel reduction: NOT the reference's summation order; timing build only */
+#pragma omp parallel for reduction(+ : acc) schedule(static)
+#endif
     for (int64_t i = 0; i < n; ++i) {
         double prod = x[i] * y[i];
         acc = acc + prod;
@@ -148,6 +154,9 @@ double orc_dot(int64_t n, const double *x, const double *y) {
 /* norm2Sq = sum . fmap norm2Sq (SpVector.hs:122); scalar norm2Sq = (**2) (Class.hs:407) */
 double orc_norm2sq(int64_t n, const double *x) {
     double acc = 0.0;
+#ifdef ORC_OMP
+#pragma omp parallel for reduction(+ : acc) schedule(static)
+#endif
     for (int64_t i = 0; i < n; ++i) {
         double sq = pow(x[i], 2.0);
         acc = acc + sq;
@@ -160,14 +169,23 @@ double orc_norm2(int64_t n, const double *x) { return sqrt(orc_norm2sq(n, x)); }
 
 /* (^+^) = liftU2 (+)  (SpVector.hs:107-108) on dense operands */
 void orc_add(int64_t n, const double *x, const double *y, double *out) {
+#ifdef ORC_OMP
+#pragma omp parallel for schedule(static)
+#endif
     for (int64_t i = 0; i < n; ++i) out[i] = x[i] + y[i];
 }
 /* x ^-^ y = x ^+^ negateV y  (Class.hs:68-69) */
 void orc_sub(int64_t n, const double *x, const double *y, double *out) {
+#ifdef ORC_OMP
+#pragma omp parallel for schedule(static)
+#endif
     for (int64_t i = 0; i < n; ++i) out[i] = x[i] + (-y[i]);
 }
 /* n .* v = fmap (n *) v  (SpVector.hs:112-114) */
 void orc_scale(int64_t n, double a, const double *x, double *out) {
+#ifdef ORC_OMP
+#pragma omp parallel for schedule(static)
+#endif
     for (int64_t i = 0; i < n; ++i) out[i] = a * x[i];
 }
 
