@@ -38,6 +38,16 @@ def workload(name, row_begin=0, row_end=None):
         return "2M-row fp64 non-symmetric banded (5 bands), BiCGSTAB", wl.banded_nonsym(2000000, 99, row_begin, row_end)
     if name == "laplace3d_small":
         return "64^3 7-pt Laplacian (test size)", wl.laplace3d(64, 64, 64, row_begin, row_end)
+    if name == "random_spd_10m":
+        dims, (rp, ci, va) = wl.random_spd(10000000, 16, 42)
+        row_end = dims[0] if row_end is None else row_end
+        from sla_amd.partition import local_rows_of
+        return "10M-row fp64 random SPD (~33 nnz/row, density 3.3e-6)", (dims, local_rows_of(rp, ci, va, row_begin, row_end))
+    if name == "dense_rows_200k":
+        dims, (rp, ci, va) = wl.random_spd(200000, 1000, 42)
+        row_end = dims[0] if row_end is None else row_end
+        from sla_amd.partition import local_rows_of
+        return "200k-row fp64 random SPD at 1 % density (~2000 nnz/row)", (dims, local_rows_of(rp, ci, va, row_begin, row_end))
     if name == "random_spd_1m":
         dims, (rp, ci, va) = wl.random_spd(1000000, 16, 42)
         row_end = dims[0] if row_end is None else row_end
@@ -108,6 +118,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default=os.environ.get("SLA_BENCH_WORKLOAD", "laplace3d_10m"))
     ap.add_argument("--mode", default="step", choices=["step", "linsolve0", "gmres"])
+    ap.add_argument("--method", default="bicgstab", choices=["bicgstab", "cgs"], help="step mode: which solver step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
@@ -151,10 +162,15 @@ def main():
     sla.set_default_context(ctx)
 
     # ---- build this rank's slab on the host, lower it once to the device CSR ---------------------------
-    desc0, (dims, _) = workload(args.workload, 0, 1)
-    n = dims[0]
-    rb, re_ = row_block(n, rank, world)
-    desc, (dims, (rp, ci, va)) = workload(args.workload, rb, re_)
+    if world == 1:
+        desc, (dims, (rp, ci, va)) = workload(args.workload, 0, None)
+        n = dims[0]
+        rb, re_ = 0, n
+    else:
+        desc0, (dims, _) = workload(args.workload, 0, 1)
+        n = dims[0]
+        rb, re_ = row_block(n, rank, world)
+        desc, (dims, (rp, ci, va)) = workload(args.workload, rb, re_)
     nnz_local = int(rp[-1])
     A = sla.fromCSRRows(dims, rb, rp, ci, va, ctx)
     b_local = np.add.reduceat(va, rp[:-1]) if nnz_local else np.zeros(0)   # b = A . 1  (x* = 1), x0 = 0
@@ -176,7 +192,7 @@ def main():
 
     extra = {}
     if args.mode == "step":
-        st = sla.bicgsInit(A, bvec, x0)
+        st = sla.bicgsInit(A, bvec, x0) if args.method == "bicgstab" else sla.cgsInit(A, bvec, x0)
         st.step(args.warmup)
         sync_all()
         ctx.prof_start(_lib.KERNEL_SPMV_DOT, args.steps)
@@ -186,7 +202,7 @@ def main():
         dt = time.perf_counter() - t0
         launches, mean_ms, min_ms = ctx.prof_stop()
         step_bytes = 24 * nnz + 160 * n
-        mode_desc = "bicgstabStep (2 SpMV, no true-residual SpMV)"
+        mode_desc = f"{'bicgstabStep' if args.method == 'bicgstab' else 'cgsStep'} (2 SpMV, no true-residual SpMV)"
     elif args.mode == "gmres":
         # config 5: GMRES(30) on the device Arnoldi; a "step" = one Arnoldi step (SpMV + 2-pass classical GS)
         lib = _lib.lib()

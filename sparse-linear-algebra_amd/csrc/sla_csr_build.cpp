@@ -83,7 +83,8 @@ bool host_is_diagonal(int64_t rows, int64_t row_begin, const int64_t *rowptr, co
 }
 
 // Greedy row blocks for the CSR-stream kernel: <= kNnzPerRowBlock entries and <= kMaxRowsPerRowBlock
-// rows per block; a row longer than kNnzPerRowBlock is a block of its own.
+// rows per block; rows longer than kNnzPerRowBlock form blocks of up to 4 such rows (<= kWaveRowMax
+// entries each) or a block of their own (longer still).
 void build_row_blocks(int64_t rows, const int64_t *rowptr, std::vector<int32_t> &rb, int64_t &max_row_nnz) {
     rb.clear();
     rb.push_back(0);
@@ -98,10 +99,19 @@ void build_row_blocks(int64_t rows, const int64_t *rowptr, std::vector<int32_t> 
             cnt += len;
             ++r;
         }
-        if (r == r0) {  // a single row that does not fit: long-row block
+        if (r == r0) {  // the row does not fit the LDS stage: long-row block
             const int64_t len = rowptr[r + 1] - rowptr[r];
             if (len > max_row_nnz) max_row_nnz = len;
             ++r;
+            if (len <= kWaveRowMax) {
+                // group up to 4 consecutive long rows (one wavefront each in the kernel)
+                while (r < rows && r - r0 < 4) {
+                    const int64_t l2 = rowptr[r + 1] - rowptr[r];
+                    if (l2 <= kNnzPerRowBlock || l2 > kWaveRowMax) break;
+                    if (l2 > max_row_nnz) max_row_nnz = l2;
+                    ++r;
+                }
+            }
         }
         rb.push_back((int32_t)r);
         r0 = r;

@@ -15,6 +15,7 @@ namespace sla {
 constexpr int kBlock = 256;          // threads per workgroup (4 wavefronts of 64)
 constexpr int kNnzPerRowBlock = 1024; // products staged in LDS per row block (8 KiB)
 constexpr int kMaxRowsPerRowBlock = 256;
+constexpr int kWaveRowMax = 16384;   // rows of 1025..16384 entries: one wavefront each, 4 per row block; longer: whole workgroup
 constexpr int kMaxParts = 2048;      // partial-sum slots per reduction (256 CUs x 8)
 constexpr int kVecGridMax = 1024;    // grid cap of the streaming BLAS-1 kernels
 constexpr int kSpmvGridMax = 2048;   // persistent grid cap of the SpMV kernels

@@ -234,8 +234,35 @@ __global__ void __launch_bounds__(kBlock, 8) spmv_stream_kernel(SpmvArgs<RP> a, 
                     if (g < nrows && l == 0) spmv_epilogue<EPI, RP>(a, r0 + g, acc, coef, acc1, acc2);
                 }
                 buf ^= 1;
+            } else if (nrows > 1 || k1 - k0 <= (RP)kWaveRowMax) {
+                // up to 4 long rows (> 1024 entries each): one wavefront per row, no LDS, no barrier,
+                // 4 coalesced col/val loads in flight per lane
+                const int wv = tid >> 6, ln = tid & 63;
+                if (wv < nrows) {
+                    const RP s0 = a.rowptr[r0 + wv], s1 = a.rowptr[r0 + wv + 1];
+                    double acc = 0.0;
+                    RP k = s0 + ln;
+                    for (; k + 192 < s1; k += 256) {
+                        const int32_t c0 = __builtin_nontemporal_load(a.col + k);
+                        const int32_t c1 = __builtin_nontemporal_load(a.col + k + 64);
+                        const int32_t c2 = __builtin_nontemporal_load(a.col + k + 128);
+                        const int32_t c3 = __builtin_nontemporal_load(a.col + k + 192);
+                        const double v0 = __builtin_nontemporal_load(a.val + k);
+                        const double v1 = __builtin_nontemporal_load(a.val + k + 64);
+                        const double v2 = __builtin_nontemporal_load(a.val + k + 128);
+                        const double v3 = __builtin_nontemporal_load(a.val + k + 192);
+                        acc += v0 * a.x[c0];
+                        acc += v1 * a.x[c1];
+                        acc += v2 * a.x[c2];
+                        acc += v3 * a.x[c3];
+                    }
+                    for (; k < s1; k += 64) acc += a.val[k] * a.x[a.col[k]];
+                    acc = wave_sum(acc);
+                    if (ln == 0) spmv_epilogue<EPI, RP>(a, r0 + wv, acc, coef, acc1, acc2);
+                }
+                if (has_next) { SLA_ISSUE_LOADS(nr0, nr1, nk0, nk1) }
             } else {
-                // one long row owned by the whole workgroup (the partitioner never mixes it with others)
+                // one very long row (> kWaveRowMax entries) owned by the whole workgroup
                 double acc = 0.0;
                 RP k = k0 + tid;
                 for (; k + 3 * kBlock < k1; k += 4 * kBlock) {
@@ -380,6 +407,39 @@ __global__ void __launch_bounds__(kBlock, 8) spmv_dual_kernel(SpmvArgs<RP> a, co
                     }
                 }
                 __syncthreads();
+            } else if (nrows > 1 || k1 - k0 <= (RP)kWaveRowMax) {
+                const int wv = tid >> 6, ln = tid & 63;
+                if (wv < nrows) {
+                    const RP s0 = a.rowptr[r0 + wv], s1 = a.rowptr[r0 + wv + 1];
+                    double ya = 0.0, yb = 0.0;
+                    RP k = s0 + ln;
+                    for (; k + 64 < s1; k += 128) {
+                        const int32_t c0 = __builtin_nontemporal_load(a.col + k);
+                        const int32_t c1 = __builtin_nontemporal_load(a.col + k + 64);
+                        const double v0 = __builtin_nontemporal_load(a.val + k);
+                        const double v1 = __builtin_nontemporal_load(a.val + k + 64);
+                        ya += v0 * a.x[c0];
+                        yb += v0 * x2[c0];
+                        ya += v1 * a.x[c1];
+                        yb += v1 * x2[c1];
+                    }
+                    for (; k < s1; k += 64) {
+                        const int32_t cc = a.col[k];
+                        const double vv = a.val[k];
+                        ya += vv * a.x[cc];
+                        yb += vv * x2[cc];
+                    }
+                    ya = wave_sum(ya);
+                    yb = wave_sum(yb);
+                    if (ln == 0) {
+                        const int row = r0 + wv;
+                        a.y[row] = ya;
+                        acc1 += ya * a.w[row];
+                        const double t = yb - b2[row];
+                        acc2 += t * t;
+                    }
+                }
+                if (has_next) { SLA_ISSUE_LOADS(nr0, nr1, nk0, nk1) }
             } else {
                 double ya = 0.0, yb = 0.0;
                 for (RP k = k0 + tid; k < k1; k += kBlock) {

@@ -137,3 +137,24 @@ def test_dual_spmv_flow_equals_three_sweep_flow(sla, monkeypatch):
         if key not in ref:
             ref[key] = (x, it, rn, cv)
         assert cv and it == ref[key][1] and np.array_equal(x, ref[key][0]) and rn == ref[key][2], (dual, meth, ce, it)
+
+
+def test_consecutive_long_rows_wave_per_row_and_block_per_row(sla):
+    # rows of 1025..16384 entries are grouped 4 per row block (one wavefront each); longer rows get the
+    # whole workgroup; mixed with short rows in between
+    rng = np.random.default_rng(21)
+    n = 30000
+    lens = [1500, 3000, 1100, 2000, 5000, 20000, 1200, 3, 0, 1025, 16384, 16385, 7]
+    rows, cols, vals = [], [], []
+    for i, k in enumerate(lens):
+        if k:
+            cj = np.sort(rng.choice(n, size=k, replace=False))
+            rows.append(np.full(k, i)); cols.append(cj); vals.append(rng.standard_normal(k))
+    r, c, v = np.concatenate(rows), np.concatenate(cols), np.concatenate(vals)
+    m = len(lens)
+    A = sla.fromCOO((m, n), r, c, v)
+    rc, Ao = orc.coo_to_csr(m, n, r, c, v)
+    x = rng.standard_normal(n)
+    y, yo = sla.matVec(A, sla.fromVector(x)).toDenseListSV(), orc.spmv(Ao, x)
+    bound = np.diff(Ao.rowptr) * np.finfo(float).eps * orc.spmv(orc.Csr(m, n, Ao.rowptr, Ao.colidx, np.abs(Ao.val)), np.abs(x))
+    assert np.all(np.abs(y - yo) <= bound + 1e-300)
