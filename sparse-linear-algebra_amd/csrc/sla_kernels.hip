@@ -154,7 +154,10 @@ __device__ __forceinline__ RbWalk rb_walk(int nrb, int xcd_remap) {
 // descriptors (rb, rbk) are indexed by the block number only, so they prefetch without a dependent
 // chain.  s_prod / s_rp are double-buffered: one barrier per row block.
 template <int EPI, typename RP>
-__global__ void __launch_bounds__(kBlock, 8) spmv_stream_kernel(SpmvArgs<RP> a, int xcd_remap) {
+__global__ void __launch_bounds__(kBlock, 8) spmv_stream_kernel(SpmvArgs<RP> a, const RP *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                                                 const double *__restrict__ val, const int32_t *__restrict__ rb,
+                                                                 const RP *__restrict__ rbk, const double *__restrict__ xg,
+                                                                 int xcd_remap) {
     __shared__ double s_prod[2][kNnzPerRowBlock];
     __shared__ int s_rp[2][kMaxRowsPerRowBlock + 1];
     __shared__ double s_red[4];
@@ -166,8 +169,8 @@ __global__ void __launch_bounds__(kBlock, 8) spmv_stream_kernel(SpmvArgs<RP> a, 
     const RbWalk wk = rb_walk(a.nrb, xcd_remap);
     int b = wk.first;
     if (b < wk.last) {
-        int r0 = a.rb[b], r1 = a.rb[b + 1];
-        RP k0 = a.rbk[b], k1 = a.rbk[b + 1];
+        int r0 = rb[b], r1 = rb[b + 1];
+        RP k0 = rbk[b], k1 = rbk[b + 1];
         int32_t c[4];
         double v[4];
         RP rpn = 0;
@@ -178,25 +181,37 @@ __global__ void __launch_bounds__(kBlock, 8) spmv_stream_kernel(SpmvArgs<RP> a, 
             _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                  \
                 const int i = tid + j * kBlock;                                              \
                 if (i < cnt_) {                                                              \
-                    c[j] = __builtin_nontemporal_load(a.col + (k0_) + i);                    \
-                    v[j] = __builtin_nontemporal_load(a.val + (k0_) + i);                    \
+                    c[j] = __builtin_nontemporal_load(col + (k0_) + i);                    \
+                    v[j] = __builtin_nontemporal_load(val + (k0_) + i);                    \
                 }                                                                            \
             }                                                                                \
-            if (tid < (r1_) - (r0_)) rpn = a.rowptr[(r0_) + tid];                            \
+            if (tid < (r1_) - (r0_)) rpn = rowptr[(r0_) + tid];                            \
         }
         SLA_ISSUE_LOADS(r0, r1, k0, k1)
+        // Row-block descriptors are scalar loads.  They share lgkmcnt with LDS traffic and return out of
+        // order, so consuming one drains all of them: fetch the descriptors of block b+2 AFTER block b+1's
+        // have been consumed (right behind the prefetch loads), a whole iteration before they are needed.
+        int nr0 = 0, nr1 = 0;
+        RP nk0 = 0, nk1 = 0;
+        if (b + wk.step < wk.last) {
+            nr0 = rb[b + wk.step];
+            nr1 = rb[b + wk.step + 1];
+            nk0 = rbk[b + wk.step];
+            nk1 = rbk[b + wk.step + 1];
+        }
+#define SLA_FETCH_DESC()          \
+        if (has_next2) {          \
+            fr0 = rb[bnn];        \
+            fr1 = rb[bnn + 1];    \
+            fk0 = rbk[bnn];       \
+            fk1 = rbk[bnn + 1];   \
+        }
         int buf = 0;
         for (;;) {
-            const int bn = b + wk.step;
-            const bool has_next = bn < wk.last;
-            int nr0 = 0, nr1 = 0;
-            RP nk0 = 0, nk1 = 0;
-            if (has_next) {
-                nr0 = a.rb[bn];
-                nr1 = a.rb[bn + 1];
-                nk0 = a.rbk[bn];
-                nk1 = a.rbk[bn + 1];
-            }
+            const int bn = b + wk.step, bnn = bn + wk.step;
+            const bool has_next = bn < wk.last, has_next2 = bnn < wk.last;
+            int fr0 = 0, fr1 = 0;   // descriptors two row blocks ahead (scalar loads, issued below)
+            RP fk0 = 0, fk1 = 0;
             const int nrows = r1 - r0;
             if (k1 - k0 <= (RP)kNnzPerRowBlock) {
                 const int cnt = (int)(k1 - k0);
@@ -207,9 +222,10 @@ __global__ void __launch_bounds__(kBlock, 8) spmv_stream_kernel(SpmvArgs<RP> a, 
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int i = tid + j * kBlock;
-                    if (i < cnt) prod[i] = v[j] * a.x[c[j]];
+                    if (i < cnt) prod[i] = v[j] * xg[c[j]];
                 }
                 if (has_next) { SLA_ISSUE_LOADS(nr0, nr1, nk0, nk1) }
+                SLA_FETCH_DESC()
                 __syncthreads();
                 if (nrows > 64 || cnt <= 8 * nrows) {
                     // one lane per row, ascending left fold: the reference's summation order exactly
@@ -239,48 +255,50 @@ __global__ void __launch_bounds__(kBlock, 8) spmv_stream_kernel(SpmvArgs<RP> a, 
                 // 4 coalesced col/val loads in flight per lane
                 const int wv = tid >> 6, ln = tid & 63;
                 if (wv < nrows) {
-                    const RP s0 = a.rowptr[r0 + wv], s1 = a.rowptr[r0 + wv + 1];
+                    const RP s0 = rowptr[r0 + wv], s1 = rowptr[r0 + wv + 1];
                     double acc = 0.0;
                     RP k = s0 + ln;
                     for (; k + 192 < s1; k += 256) {
-                        const int32_t c0 = __builtin_nontemporal_load(a.col + k);
-                        const int32_t c1 = __builtin_nontemporal_load(a.col + k + 64);
-                        const int32_t c2 = __builtin_nontemporal_load(a.col + k + 128);
-                        const int32_t c3 = __builtin_nontemporal_load(a.col + k + 192);
-                        const double v0 = __builtin_nontemporal_load(a.val + k);
-                        const double v1 = __builtin_nontemporal_load(a.val + k + 64);
-                        const double v2 = __builtin_nontemporal_load(a.val + k + 128);
-                        const double v3 = __builtin_nontemporal_load(a.val + k + 192);
-                        acc += v0 * a.x[c0];
-                        acc += v1 * a.x[c1];
-                        acc += v2 * a.x[c2];
-                        acc += v3 * a.x[c3];
+                        const int32_t c0 = __builtin_nontemporal_load(col + k);
+                        const int32_t c1 = __builtin_nontemporal_load(col + k + 64);
+                        const int32_t c2 = __builtin_nontemporal_load(col + k + 128);
+                        const int32_t c3 = __builtin_nontemporal_load(col + k + 192);
+                        const double v0 = __builtin_nontemporal_load(val + k);
+                        const double v1 = __builtin_nontemporal_load(val + k + 64);
+                        const double v2 = __builtin_nontemporal_load(val + k + 128);
+                        const double v3 = __builtin_nontemporal_load(val + k + 192);
+                        acc += v0 * xg[c0];
+                        acc += v1 * xg[c1];
+                        acc += v2 * xg[c2];
+                        acc += v3 * xg[c3];
                     }
-                    for (; k < s1; k += 64) acc += a.val[k] * a.x[a.col[k]];
+                    for (; k < s1; k += 64) acc += val[k] * xg[col[k]];
                     acc = wave_sum(acc);
                     if (ln == 0) spmv_epilogue<EPI, RP>(a, r0 + wv, acc, coef, acc1, acc2);
                 }
                 if (has_next) { SLA_ISSUE_LOADS(nr0, nr1, nk0, nk1) }
+                SLA_FETCH_DESC()
             } else {
                 // one very long row (> kWaveRowMax entries) owned by the whole workgroup
                 double acc = 0.0;
                 RP k = k0 + tid;
                 for (; k + 3 * kBlock < k1; k += 4 * kBlock) {
-                    const int32_t c0 = __builtin_nontemporal_load(a.col + k);
-                    const int32_t c1 = __builtin_nontemporal_load(a.col + k + kBlock);
-                    const int32_t c2 = __builtin_nontemporal_load(a.col + k + 2 * kBlock);
-                    const int32_t c3 = __builtin_nontemporal_load(a.col + k + 3 * kBlock);
-                    const double v0 = __builtin_nontemporal_load(a.val + k);
-                    const double v1 = __builtin_nontemporal_load(a.val + k + kBlock);
-                    const double v2 = __builtin_nontemporal_load(a.val + k + 2 * kBlock);
-                    const double v3 = __builtin_nontemporal_load(a.val + k + 3 * kBlock);
-                    acc += v0 * a.x[c0];
-                    acc += v1 * a.x[c1];
-                    acc += v2 * a.x[c2];
-                    acc += v3 * a.x[c3];
+                    const int32_t c0 = __builtin_nontemporal_load(col + k);
+                    const int32_t c1 = __builtin_nontemporal_load(col + k + kBlock);
+                    const int32_t c2 = __builtin_nontemporal_load(col + k + 2 * kBlock);
+                    const int32_t c3 = __builtin_nontemporal_load(col + k + 3 * kBlock);
+                    const double v0 = __builtin_nontemporal_load(val + k);
+                    const double v1 = __builtin_nontemporal_load(val + k + kBlock);
+                    const double v2 = __builtin_nontemporal_load(val + k + 2 * kBlock);
+                    const double v3 = __builtin_nontemporal_load(val + k + 3 * kBlock);
+                    acc += v0 * xg[c0];
+                    acc += v1 * xg[c1];
+                    acc += v2 * xg[c2];
+                    acc += v3 * xg[c3];
                 }
-                for (; k < k1; k += kBlock) acc += a.val[k] * a.x[a.col[k]];
+                for (; k < k1; k += kBlock) acc += val[k] * xg[col[k]];
                 if (has_next) { SLA_ISSUE_LOADS(nr0, nr1, nk0, nk1) }
+                SLA_FETCH_DESC()
                 const double s = block_sum(acc, s_red);
                 if (tid == 0) spmv_epilogue<EPI, RP>(a, r0, s, coef, acc1, acc2);
             }
@@ -290,7 +308,12 @@ __global__ void __launch_bounds__(kBlock, 8) spmv_stream_kernel(SpmvArgs<RP> a, 
             r1 = nr1;
             k0 = nk0;
             k1 = nk1;
+            nr0 = fr0;
+            nr1 = fr1;
+            nk0 = fk0;
+            nk1 = fk1;
         }
+#undef SLA_FETCH_DESC
 #undef SLA_ISSUE_LOADS
     }
     if constexpr (EPI == EPI_DOT || EPI == EPI_DOT2 || EPI == EPI_RES || EPI == EPI_AXPY_DOT ||
@@ -311,7 +334,10 @@ __global__ void __launch_bounds__(kBlock, 8) spmv_stream_kernel(SpmvArgs<RP> a, 
 // Same row-block walk and software pipeline as spmv_stream_kernel; the two product arrays share the
 // LDS budget, so the stage is single-buffered (two barriers per row block).
 template <typename RP>
-__global__ void __launch_bounds__(kBlock, 8) spmv_dual_kernel(SpmvArgs<RP> a, const double *x2, const double *b2,
+__global__ void __launch_bounds__(kBlock, 8) spmv_dual_kernel(SpmvArgs<RP> a, const RP *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                                                 const double *__restrict__ val, const int32_t *__restrict__ rb,
+                                                                 const RP *__restrict__ rbk, const double *__restrict__ xg,
+                                                               const double *__restrict__ x2, const double *__restrict__ b2,
                                                                int xcd_remap) {
     __shared__ double s_prod[2][kNnzPerRowBlock];
     __shared__ int s_rp[kMaxRowsPerRowBlock + 1];
@@ -323,8 +349,8 @@ __global__ void __launch_bounds__(kBlock, 8) spmv_dual_kernel(SpmvArgs<RP> a, co
     const RbWalk wk = rb_walk(a.nrb, xcd_remap);
     int b = wk.first;
     if (b < wk.last) {
-        int r0 = a.rb[b], r1 = a.rb[b + 1];
-        RP k0 = a.rbk[b], k1 = a.rbk[b + 1];
+        int r0 = rb[b], r1 = rb[b + 1];
+        RP k0 = rbk[b], k1 = rbk[b + 1];
         int32_t c[4];
         double v[4];
         RP rpn = 0;
@@ -334,24 +360,36 @@ __global__ void __launch_bounds__(kBlock, 8) spmv_dual_kernel(SpmvArgs<RP> a, co
             _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                  \
                 const int i = tid + j * kBlock;                                              \
                 if (i < cnt_) {                                                              \
-                    c[j] = __builtin_nontemporal_load(a.col + (k0_) + i);                    \
-                    v[j] = __builtin_nontemporal_load(a.val + (k0_) + i);                    \
+                    c[j] = __builtin_nontemporal_load(col + (k0_) + i);                    \
+                    v[j] = __builtin_nontemporal_load(val + (k0_) + i);                    \
                 }                                                                            \
             }                                                                                \
-            if (tid < (r1_) - (r0_)) rpn = a.rowptr[(r0_) + tid];                            \
+            if (tid < (r1_) - (r0_)) rpn = rowptr[(r0_) + tid];                            \
         }
         SLA_ISSUE_LOADS(r0, r1, k0, k1)
+        // Row-block descriptors are scalar loads.  They share lgkmcnt with LDS traffic and return out of
+        // order, so consuming one drains all of them: fetch the descriptors of block b+2 AFTER block b+1's
+        // have been consumed (right behind the prefetch loads), a whole iteration before they are needed.
+        int nr0 = 0, nr1 = 0;
+        RP nk0 = 0, nk1 = 0;
+        if (b + wk.step < wk.last) {
+            nr0 = rb[b + wk.step];
+            nr1 = rb[b + wk.step + 1];
+            nk0 = rbk[b + wk.step];
+            nk1 = rbk[b + wk.step + 1];
+        }
+#define SLA_FETCH_DESC()          \
+        if (has_next2) {          \
+            fr0 = rb[bnn];        \
+            fr1 = rb[bnn + 1];    \
+            fk0 = rbk[bnn];       \
+            fk1 = rbk[bnn + 1];   \
+        }
         for (;;) {
-            const int bn = b + wk.step;
-            const bool has_next = bn < wk.last;
-            int nr0 = 0, nr1 = 0;
-            RP nk0 = 0, nk1 = 0;
-            if (has_next) {
-                nr0 = a.rb[bn];
-                nr1 = a.rb[bn + 1];
-                nk0 = a.rbk[bn];
-                nk1 = a.rbk[bn + 1];
-            }
+            const int bn = b + wk.step, bnn = bn + wk.step;
+            const bool has_next = bn < wk.last, has_next2 = bnn < wk.last;
+            int fr0 = 0, fr1 = 0;   // descriptors two row blocks ahead (scalar loads, issued below)
+            RP fk0 = 0, fk1 = 0;
             const int nrows = r1 - r0;
             if (k1 - k0 <= (RP)kNnzPerRowBlock) {
                 const int cnt = (int)(k1 - k0);
@@ -361,11 +399,12 @@ __global__ void __launch_bounds__(kBlock, 8) spmv_dual_kernel(SpmvArgs<RP> a, co
                 for (int j = 0; j < 4; ++j) {
                     const int i = tid + j * kBlock;
                     if (i < cnt) {
-                        s_prod[0][i] = v[j] * a.x[c[j]];
+                        s_prod[0][i] = v[j] * xg[c[j]];
                         s_prod[1][i] = v[j] * x2[c[j]];
                     }
                 }
                 if (has_next) { SLA_ISSUE_LOADS(nr0, nr1, nk0, nk1) }
+                SLA_FETCH_DESC()
                 __syncthreads();
                 if (nrows > 64 || cnt <= 8 * nrows) {
                     if (tid < nrows) {
@@ -410,23 +449,23 @@ __global__ void __launch_bounds__(kBlock, 8) spmv_dual_kernel(SpmvArgs<RP> a, co
             } else if (nrows > 1 || k1 - k0 <= (RP)kWaveRowMax) {
                 const int wv = tid >> 6, ln = tid & 63;
                 if (wv < nrows) {
-                    const RP s0 = a.rowptr[r0 + wv], s1 = a.rowptr[r0 + wv + 1];
+                    const RP s0 = rowptr[r0 + wv], s1 = rowptr[r0 + wv + 1];
                     double ya = 0.0, yb = 0.0;
                     RP k = s0 + ln;
                     for (; k + 64 < s1; k += 128) {
-                        const int32_t c0 = __builtin_nontemporal_load(a.col + k);
-                        const int32_t c1 = __builtin_nontemporal_load(a.col + k + 64);
-                        const double v0 = __builtin_nontemporal_load(a.val + k);
-                        const double v1 = __builtin_nontemporal_load(a.val + k + 64);
-                        ya += v0 * a.x[c0];
+                        const int32_t c0 = __builtin_nontemporal_load(col + k);
+                        const int32_t c1 = __builtin_nontemporal_load(col + k + 64);
+                        const double v0 = __builtin_nontemporal_load(val + k);
+                        const double v1 = __builtin_nontemporal_load(val + k + 64);
+                        ya += v0 * xg[c0];
                         yb += v0 * x2[c0];
-                        ya += v1 * a.x[c1];
+                        ya += v1 * xg[c1];
                         yb += v1 * x2[c1];
                     }
                     for (; k < s1; k += 64) {
-                        const int32_t cc = a.col[k];
-                        const double vv = a.val[k];
-                        ya += vv * a.x[cc];
+                        const int32_t cc = col[k];
+                        const double vv = val[k];
+                        ya += vv * xg[cc];
                         yb += vv * x2[cc];
                     }
                     ya = wave_sum(ya);
@@ -440,15 +479,17 @@ __global__ void __launch_bounds__(kBlock, 8) spmv_dual_kernel(SpmvArgs<RP> a, co
                     }
                 }
                 if (has_next) { SLA_ISSUE_LOADS(nr0, nr1, nk0, nk1) }
+                SLA_FETCH_DESC()
             } else {
                 double ya = 0.0, yb = 0.0;
                 for (RP k = k0 + tid; k < k1; k += kBlock) {
-                    const int32_t cc = a.col[k];
-                    const double vv = a.val[k];
-                    ya += vv * a.x[cc];
+                    const int32_t cc = col[k];
+                    const double vv = val[k];
+                    ya += vv * xg[cc];
                     yb += vv * x2[cc];
                 }
                 if (has_next) { SLA_ISSUE_LOADS(nr0, nr1, nk0, nk1) }
+                SLA_FETCH_DESC()
                 const double sa = block_sum(ya, s_red);
                 const double sb = block_sum(yb, s_red);
                 if (tid == 0) {
@@ -464,7 +505,12 @@ __global__ void __launch_bounds__(kBlock, 8) spmv_dual_kernel(SpmvArgs<RP> a, co
             r1 = nr1;
             k0 = nk0;
             k1 = nk1;
+            nr0 = fr0;
+            nr1 = fr1;
+            nk0 = fk0;
+            nk1 = fk1;
         }
+#undef SLA_FETCH_DESC
 #undef SLA_ISSUE_LOADS
     }
     const double s1 = block_sum(acc1, s_red);
@@ -541,14 +587,17 @@ static int launch_spmv_t(const sla_csr *A, const SpmvLaunch &l) {
     ProfScope prof(c, l.kernel_id);
     if (l.x2) {
         if constexpr (EPI == EPI_DOT) {
-            hipLaunchKernelGGL((spmv_dual_kernel<RP>), dim3(grid), dim3(kBlock), 0, c->stream, a, l.x2, l.b2, c->xcd_remap);
+            hipLaunchKernelGGL((spmv_dual_kernel<RP>), dim3(grid), dim3(kBlock), 0, c->stream, a, a.rowptr, a.col, a.val, a.rb, a.rbk, a.x,
+                               l.x2, l.b2, c->xcd_remap);
         } else {
             return fail(SLA_ERR_INVALID, "dual SpMV is only defined for the K1 epilogue");
         }
     } else if (c->spmv_algo == 1)
         hipLaunchKernelGGL((spmv_scalar_kernel<EPI, RP>), dim3(grid), dim3(kBlock), 0, c->stream, a, c->xcd_remap);
+
     else
-        hipLaunchKernelGGL((spmv_stream_kernel<EPI, RP>), dim3(grid), dim3(kBlock), 0, c->stream, a, c->xcd_remap);
+        hipLaunchKernelGGL((spmv_stream_kernel<EPI, RP>), dim3(grid), dim3(kBlock), 0, c->stream, a, a.rowptr, a.col, a.val, a.rb, a.rbk, a.x,
+                           c->xcd_remap);
     SLA_HIP_TRY(hipGetLastError());
     return SLA_OK;
 }

@@ -37,6 +37,44 @@ static void laplace3d(int nx, int ny, int nz, std::vector<int64_t> &rp, std::vec
     }
 }
 
+// ---- micro-kernels: what do the SpMV's raw streams cost without the SpMV? ----------------------------
+// persistent grid, per iteration a workgroup consumes 1024 consecutive (col,val) pairs with the same
+// lane-strided 4 B / 8 B non-temporal loads as spmv_stream_kernel
+template <int MODE>
+__global__ void __launch_bounds__(256, 8) k_stream(const int32_t *col, const double *val, int64_t nnz, double *out) {
+    __shared__ double s_prod[2][1024];
+    const int tid = threadIdx.x;
+    double acc = 0.0;
+    int buf = 0;
+    const int64_t nchunk = nnz / 1024;
+    for (int64_t ch = blockIdx.x; ch < nchunk; ch += gridDim.x) {
+        const int64_t k0 = ch * 1024;
+        int32_t c[4];
+        double v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            c[j] = __builtin_nontemporal_load(col + k0 + tid + j * 256);
+            v[j] = __builtin_nontemporal_load(val + k0 + tid + j * 256);
+        }
+        if (MODE == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc += v[j] * (double)c[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s_prod[buf][tid + j * 256] = v[j] * (double)c[j];
+            __syncthreads();
+            if (tid < 146) {
+                double a = 0.0;
+                for (int k = tid * 7; k < tid * 7 + 7; ++k) a += s_prod[buf][k];
+                acc += a;
+                if (MODE == 2) out[1024 + ch * 146 + tid] = a;   // y-like coalesced 8 B store
+            }
+            buf ^= 1;
+        }
+    }
+    if (acc == 123.456) out[tid] = acc;
+}
+
 struct Timer {
     hipEvent_t a, b;
     hipStream_t s;
@@ -96,7 +134,7 @@ int main(int argc, char **argv) {
         hipStreamSynchronize(c->stream);
         return 0;
     }
-    for (int algo = 0; algo < 2; ++algo) {
+    for (int algo = 0; algo < 1; ++algo) {
         c->spmv_algo = algo;
         for (int remap = 0; remap < 2; ++remap) {
             c->xcd_remap = remap;
@@ -105,23 +143,46 @@ int main(int argc, char **argv) {
                 char nm[128];
                 SpmvLaunch l;
                 l.x = x->d; l.y = y->d;
-                snprintf(nm, sizeof nm, "%s plain remap=%d grid=%d", algo ? "scalar" : "stream", remap, g);
+                snprintf(nm, sizeof nm, "%s plain remap=%d grid=%d", (algo ? "scalar" : "stream"), remap, g);
                 report(nm, T.run([&] { launch_spmv(A, l); }, 20), bytes);
                 SpmvLaunch d = l;
                 d.epi = EPI_DOT; d.w = w->d; d.p1 = c->d_parts;
-                snprintf(nm, sizeof nm, "%s dot(w separate) remap=%d grid=%d", algo ? "scalar" : "stream", remap, g);
+                snprintf(nm, sizeof nm, "%s dot(w separate) remap=%d grid=%d", (algo ? "scalar" : "stream"), remap, g);
                 report(nm, T.run([&] { launch_spmv(A, d); }, 20), bytes + 8.0 * n);
                 d.w = x->d;
-                snprintf(nm, sizeof nm, "%s dot(w = x) remap=%d grid=%d", algo ? "scalar" : "stream", remap, g);
+                snprintf(nm, sizeof nm, "%s dot(w = x) remap=%d grid=%d", (algo ? "scalar" : "stream"), remap, g);
                 report(nm, T.run([&] { launch_spmv(A, d); }, 20), bytes);
                 SpmvLaunch d2 = l;
                 d2.epi = EPI_DOT2; d2.w = x->d; d2.p1 = c->d_parts; d2.p2 = c->d_parts + kMaxParts;
-                snprintf(nm, sizeof nm, "%s dot2(w = x) remap=%d grid=%d", algo ? "scalar" : "stream", remap, g);
+                snprintf(nm, sizeof nm, "%s dot2(w = x) remap=%d grid=%d", (algo ? "scalar" : "stream"), remap, g);
                 report(nm, T.run([&] { launch_spmv(A, d2); }, 20), bytes);
             }
         }
     }
     c->spmv_algo = 0; c->xcd_remap = 1; c->spmv_grid_max = 2048;
+    {   // same structure, columns collapsed to 0..6: every gather hits L1 -> cost of the streams alone
+        std::vector<int64_t> ci2(ci.size());
+        for (int64_t r = 0; r < n; ++r)
+            for (int64_t k = rp[r]; k < rp[r + 1]; ++k) ci2[k] = k - rp[r];
+        sla_csr_t B;
+        CK(sla_csr_from_csr(c, n, n, rp.data(), ci2.data(), va.data(), &B));
+        SpmvLaunch l;
+        l.x = x->d; l.y = y->d;
+        report("stream plain, gathers collapsed to x[0..6]", T.run([&] { launch_spmv(B, l); }, 20), bytes - 8.0 * n);
+        SpmvLaunch d = l;
+        d.epi = EPI_DOT; d.w = w->d; d.p1 = c->d_parts;
+        report("stream dot,   gathers collapsed to x[0..6]", T.run([&] { launch_spmv(B, d); }, 20), bytes);
+        sla_csr_destroy(B);
+    }
+    {   // raw stream micro-kernels on the matrix arrays themselves
+        double *scratch;
+        hipMalloc(&scratch, sizeof(double) * (size_t)(n + 4096));
+        const double sb = 12.0 * nnz;
+        report("micro: col+val strided loads only", T.run([&] { hipLaunchKernelGGL(k_stream<0>, dim3(2048), dim3(256), 0, c->stream, A->d_col, A->d_val, nnz, scratch); }, 20), sb);
+        report("micro: + LDS stage + barrier + row sums", T.run([&] { hipLaunchKernelGGL(k_stream<1>, dim3(2048), dim3(256), 0, c->stream, A->d_col, A->d_val, nnz, scratch); }, 20), sb);
+        report("micro: + y store", T.run([&] { hipLaunchKernelGGL(k_stream<2>, dim3(2048), dim3(256), 0, c->stream, A->d_col, A->d_val, nnz, scratch); }, 20), sb + 8.0 * (nnz / 7.0));
+        hipFree(scratch);
+    }
     // streaming ceiling of the BLAS-1 kernels on this box
     report("axpby (24 n)", T.run([&] { launch_axpby(c, n, 2.0, x->d, 1.0, y->d); }, 20), 24.0 * n);
     report("dot (16 n)", T.run([&] { launch_dot(c, n, x->d, w->d, c->d_parts); }, 20), 16.0 * n);
