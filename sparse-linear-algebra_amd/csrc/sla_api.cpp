@@ -179,6 +179,23 @@ static int csr_upload(sla_ctx *c, int64_t m, int64_t n, int64_t row_begin, int64
     }
     upload((void **)&A->d_val, val, sizeof(double) * (size_t)nnz);
     upload((void **)&A->d_rb, rb.data(), sizeof(int32_t) * rb.size());
+    {
+        // LDS x window of each row block: kXWin columns starting kXWinHalo left of its first diagonal column
+        std::vector<int32_t> rbw(rb.size(), 0);
+        int64_t inside = 0, total = 0;
+        const int64_t wmax = std::max<int64_t>(0, n - kXWin);
+        for (size_t b = 0; b + 1 < rb.size(); ++b) {
+            const int64_t w = std::min<int64_t>(wmax, std::max<int64_t>(0, row_begin + rb[b] - kXWinHalo));
+            rbw[b] = (int32_t)w;
+            const int64_t k0 = rowptr[rb[b]], k1 = rowptr[rb[b + 1]];
+            if (k1 - k0 > kNnzPerRowBlock) continue;  // long-row blocks gather from global memory
+            total += k1 - k0;
+            for (int64_t k = k0; k < k1; ++k) inside += (col[k] >= w && col[k] < w + kXWin) ? 1 : 0;
+        }
+        A->xwin_fraction = total ? (double)inside / (double)total : 0.0;
+        A->use_xwin = A->xwin_fraction >= 0.5;
+        upload((void **)&A->d_rbw, rbw.data(), sizeof(int32_t) * rbw.size());
+    }
     if (err != hipSuccess) {
         sla_csr_destroy(A);
         return fail(SLA_ERR_ALLOC, std::string("CSR upload: ") + hipGetErrorString(err));
@@ -249,6 +266,7 @@ static int ctx_create_common(int device_id, int rank, int nranks, const void *ui
     if (const char *s = getenv("SLA_SPMV_ALGO")) c->spmv_algo = (strcmp(s, "scalar") == 0) ? 1 : 0;
     if (const char *s = getenv("SLA_XCD_REMAP")) c->xcd_remap = atoi(s);
     if (const char *s = getenv("SLA_DUAL_SPMV")) c->dual_spmv = atoi(s);
+    if (const char *s = getenv("SLA_XWIN")) c->xwin = atoi(s);
     if (const char *s = getenv("SLA_X_EXCHANGE")) c->x_exchange = strcmp(s, "allgather") == 0 ? 1 : (strcmp(s, "window") == 0 ? 2 : 0);
     if (const char *s = getenv("SLA_SPMV_GRID")) {
         int g = atoi(s);
@@ -369,6 +387,7 @@ int sla_csr_destroy(sla_csr_t A) {
     if (A->d_val) (void)hipFree(A->d_val);
     if (A->d_rb) (void)hipFree(A->d_rb);
     if (A->d_rbk) (void)hipFree(A->d_rbk);
+    if (A->d_rbw) (void)hipFree(A->d_rbw);
     delete A;
     return SLA_OK;
 }
@@ -413,7 +432,7 @@ int sla_csr_is_diagonal(sla_csr_t A, int *out) {
 int sla_csr_kernel_info(sla_csr_t A, char *buf, int buflen) {
     if (!A || !buf || buflen <= 0) return fail(SLA_ERR_INVALID, "null argument");
     snprintf(buf, (size_t)buflen, "algo=%s grid=%d block=%d row_blocks=%d nnz_per_row_block=%d max_row_nnz=%lld rowptr=%s xcd_remap=%d",
-             A->ctx->spmv_algo == 1 ? "scalar" : "stream", spmv_grid(A), kBlock, A->nrb, kNnzPerRowBlock,
+             A->ctx->spmv_algo == 1 ? "scalar" : (A->use_xwin && A->ctx->xwin ? "stream+xwin" : "stream"), spmv_grid(A), kBlock, A->nrb, kNnzPerRowBlock,
              (long long)A->max_row_nnz, A->rp64 ? "i64" : "i32", A->ctx->xcd_remap);
     return SLA_OK;
 }

@@ -15,6 +15,8 @@ namespace sla {
 constexpr int kBlock = 256;          // threads per workgroup (4 wavefronts of 64)
 constexpr int kNnzPerRowBlock = 1024; // products staged in LDS per row block (8 KiB)
 constexpr int kMaxRowsPerRowBlock = 256;
+constexpr int kXWin = 768;           // doubles of x staged in LDS per row block by spmv_xwin_kernel (6 KiB)
+constexpr int kXWinHalo = 256;       // the window starts kXWinHalo columns left of the block's first diagonal column
 constexpr int kWaveRowMax = 16384;   // rows of 1025..16384 entries: one wavefront each, 4 per row block; longer: whole workgroup
 constexpr int kMaxParts = 2048;      // partial-sum slots per reduction (256 CUs x 8)
 constexpr int kVecGridMax = 1024;    // grid cap of the streaming BLAS-1 kernels
@@ -100,6 +102,7 @@ struct sla_ctx {
     int64_t xfull_cap = 0;
     int spmv_algo = 0;               // 0 stream, 1 scalar (SLA_SPMV_ALGO)
     int xcd_remap = 1;               // SLA_XCD_REMAP
+    int xwin = 1;                    // allow the LDS x-window SpMV kernel (SLA_XWIN=0 disables)
     int dual_spmv = 1;               // linSolve0: fuse the true-residual SpMV into the next K1 (SLA_DUAL_SPMV=0 disables)
     int x_exchange = 0;              // 0 auto (window exchange when it pays), 1 always all-gather, 2 always window (SLA_X_EXCHANGE=allgather|window)
     bool collectives = false;        // nranks > 1, or SLA_FORCE_COLLECTIVES=1 on a 1-rank communicator (test hook)
@@ -130,6 +133,9 @@ struct sla_csr {
     double *d_val = nullptr;
     int32_t *d_rb = nullptr;
     void *d_rbk = nullptr;           // int32 or int64, like d_rowptr
+    int32_t *d_rbw = nullptr;        // first column of each row block's LDS x window
+    bool use_xwin = false;           // enough entries fall inside the windows for spmv_xwin_kernel to pay
+    double xwin_fraction = 0.0;
     int32_t nrb = 0;
     bool is_diagonal = false;        // global isDiagonalSM
     sla_csr *transposed = nullptr;   // built lazily (single-rank only)

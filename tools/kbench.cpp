@@ -136,25 +136,26 @@ int main(int argc, char **argv) {
     }
     for (int algo = 0; algo < 1; ++algo) {
         c->spmv_algo = algo;
-        for (int remap = 0; remap < 2; ++remap) {
-            c->xcd_remap = remap;
+        for (int remap = 1; remap < 4; ++remap) {
+            c->xwin = remap >= 2 ? 0 : 1; if (remap == 3) continue;
+            c->xcd_remap = 1;
             for (int g : {1024, 2048}) {
                 c->spmv_grid_max = g;
                 char nm[128];
                 SpmvLaunch l;
                 l.x = x->d; l.y = y->d;
-                snprintf(nm, sizeof nm, "%s plain remap=%d grid=%d", (algo ? "scalar" : "stream"), remap, g);
+                snprintf(nm, sizeof nm, "%s plain xwin=%d grid=%d", (algo ? "scalar" : "stream"), c->xwin, g);
                 report(nm, T.run([&] { launch_spmv(A, l); }, 20), bytes);
                 SpmvLaunch d = l;
                 d.epi = EPI_DOT; d.w = w->d; d.p1 = c->d_parts;
-                snprintf(nm, sizeof nm, "%s dot(w separate) remap=%d grid=%d", (algo ? "scalar" : "stream"), remap, g);
+                snprintf(nm, sizeof nm, "%s dot(w separate) xwin=%d grid=%d", (algo ? "scalar" : "stream"), c->xwin, g);
                 report(nm, T.run([&] { launch_spmv(A, d); }, 20), bytes + 8.0 * n);
                 d.w = x->d;
-                snprintf(nm, sizeof nm, "%s dot(w = x) remap=%d grid=%d", (algo ? "scalar" : "stream"), remap, g);
+                snprintf(nm, sizeof nm, "%s dot(w = x) xwin=%d grid=%d", (algo ? "scalar" : "stream"), c->xwin, g);
                 report(nm, T.run([&] { launch_spmv(A, d); }, 20), bytes);
                 SpmvLaunch d2 = l;
                 d2.epi = EPI_DOT2; d2.w = x->d; d2.p1 = c->d_parts; d2.p2 = c->d_parts + kMaxParts;
-                snprintf(nm, sizeof nm, "%s dot2(w = x) remap=%d grid=%d", (algo ? "scalar" : "stream"), remap, g);
+                snprintf(nm, sizeof nm, "%s dot2(w = x) xwin=%d grid=%d", (algo ? "scalar" : "stream"), c->xwin, g);
                 report(nm, T.run([&] { launch_spmv(A, d2); }, 20), bytes);
             }
         }
