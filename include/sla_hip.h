@@ -118,6 +118,11 @@ int sla_csr_from_csr(sla_ctx_t, int64_t m, int64_t n, const int64_t *rowptr, con
  * rowptr_local[0] == 0 and GLOBAL column indices.  row range must equal sla_ctx_row_range(m). */
 int sla_csr_from_csr_rows(sla_ctx_t, int64_t m, int64_t n, int64_t row_begin, int64_t row_count,
                           const int64_t *rowptr_local, const int64_t *colidx, const double *val, sla_csr_t *out);
+/* MatrixMarket ingestion with the loader semantics of the reference's test/Perf.hs:20-45: `matrix
+ * coordinate real general`, 1-based -> 0-based, entries fed to fromListSM in file order, no symmetric
+ * expansion; `matrix array` files give dense vectors (right-hand sides). */
+int sla_csr_from_matrix_market(sla_ctx_t, const char *path, int dup_policy, sla_csr_t *out);
+int sla_vec_from_matrix_market(sla_ctx_t, const char *path, sla_vec_t *out);
 int sla_csr_destroy(sla_csr_t);
 /* dim / nnz of SpMatrix (local_rows/local_nnz = this rank's block) */
 int sla_csr_dims(sla_csr_t, int64_t *m, int64_t *n, int64_t *nnz_local, int64_t *rows_local);

@@ -267,6 +267,7 @@ static int ctx_create_common(int device_id, int rank, int nranks, const void *ui
     if (const char *s = getenv("SLA_XCD_REMAP")) c->xcd_remap = atoi(s);
     if (const char *s = getenv("SLA_DUAL_SPMV")) c->dual_spmv = atoi(s);
     if (const char *s = getenv("SLA_XWIN")) c->xwin = atoi(s);
+    if (const char *s = getenv("SLA_DEVICE_COO_MIN")) c->device_coo_min = atoll(s);
     if (const char *s = getenv("SLA_X_EXCHANGE")) c->x_exchange = strcmp(s, "allgather") == 0 ? 1 : (strcmp(s, "window") == 0 ? 2 : 0);
     if (const char *s = getenv("SLA_SPMV_GRID")) {
         int g = atoi(s);
@@ -340,6 +341,16 @@ int sla_csr_from_coo(sla_ctx_t c, int64_t m, int64_t n, int64_t nnz, const int64
                      const double *val, int dup_policy, sla_csr_t *out) {
     if (!c || !out || (nnz > 0 && (!row || !col || !val))) return fail(SLA_ERR_INVALID, "sla_csr_from_coo: null argument");
     HostCsr h;
+    if (!c->collectives && nnz >= c->device_coo_min && device_coo_supported(m, n, nnz)) {
+        if (m < 0 || n < 0) return fail(SLA_ERR_INVALID, "negative dimension");
+        for (int64_t k = 0; k < nnz; ++k)
+            if (row[k] < 0 || row[k] >= m || col[k] < 0 || col[k] >= n)
+                return fail(SLA_ERR_OOB, "insertSpMatrix : index out of bounds");
+        (void)hipSetDevice(c->device);
+        SLA_TRY(device_coo_to_csr(c, m, n, nnz, row, col, val, dup_policy, h));
+        // already canonical by construction: skip the validation pass of sla_csr_from_csr
+        return csr_upload(c, m, n, 0, m, h.rowptr.data(), h.col.data(), h.val.data(), out);
+    }
     SLA_TRY(build_csr_from_coo(m, n, nnz, row, col, val, dup_policy, h));
     return sla_csr_from_csr(c, m, n, h.rowptr.data(), h.col.data(), h.val.data(), out);
 }

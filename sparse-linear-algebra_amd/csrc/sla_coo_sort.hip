@@ -1,0 +1,148 @@
+// sla_coo_sort.hip -- device side of "lower once" for large triple lists.
+//
+// fromListSM (Data/Sparse/SpMatrix.hs:205-224) = foldl' of IntMap inserts: ascending (row, col) order,
+// the LAST duplicate wins.  On the device: a STABLE radix sort (rocPRIM) of the 64-bit key (row << 32 | col)
+// carrying the input position keeps duplicates in input order, the last member of each key group is kept
+// (or the group is summed left-to-right in input order for SLA_DUP_SUM), an exclusive scan gives the output
+// slots and a binary search per row gives csPtrV's row pointers (vector/.../Vector/Utils.hs:12-26).
+// The result is bit-identical to the host builder in sla_csr_build.cpp (tests/test_gpu_edge_cases.py).
+#include <hip/hip_runtime.h>
+
+#include <cstring>  // rocPRIM's texture iterator calls the host memset without including it
+
+#include <rocprim/rocprim.hpp>
+
+#include "sla_internal.hpp"
+
+namespace sla {
+
+namespace {
+
+__global__ void __launch_bounds__(256) coo_keys_kernel(int64_t nnz, const int64_t *row, const int64_t *col, uint64_t *key,
+                                                        uint32_t *idx) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nnz; i += (int64_t)gridDim.x * 256) {
+        key[i] = ((uint64_t)row[i] << 32) | (uint64_t)(uint32_t)col[i];
+        idx[i] = (uint32_t)i;
+    }
+}
+
+// flag[i] = 1 when sorted entry i is the LAST of its (row, col) group
+__global__ void __launch_bounds__(256) coo_flag_kernel(int64_t nnz, const uint64_t *key, uint32_t *flag) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nnz; i += (int64_t)gridDim.x * 256)
+        flag[i] = (i + 1 == nnz || key[i + 1] != key[i]) ? 1u : 0u;
+}
+
+__global__ void __launch_bounds__(256) coo_emit_kernel(int64_t nnz, const uint64_t *key, const uint32_t *idx, const uint32_t *flag,
+                                                        const uint32_t *pos, const double *val, int sum_dups, int64_t *col_out,
+                                                        double *val_out, int64_t *row_out) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nnz; i += (int64_t)gridDim.x * 256) {
+        if (!flag[i]) continue;
+        const uint64_t k = key[i];
+        double v = val[idx[i]];  // last member = last in input order (stable sort)
+        if (sum_dups) {          // left-to-right in input order, like the host builder
+            int64_t j = i;
+            while (j > 0 && key[j - 1] == k) --j;
+            v = val[idx[j]];
+            for (int64_t t = j + 1; t <= i; ++t) v += val[idx[t]];
+        }
+        const uint32_t p = pos[i];
+        col_out[p] = (int64_t)(uint32_t)k;
+        row_out[p] = (int64_t)(k >> 32);
+        val_out[p] = v;
+    }
+}
+
+// rowptr[r] = first output slot whose row is >= r  (csPtrV: empty rows repeat the previous value)
+__global__ void __launch_bounds__(256) coo_rowptr_kernel(int64_t m, int64_t nout, const int64_t *row_out, int64_t *rowptr) {
+    for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r <= m; r += (int64_t)gridDim.x * 256) {
+        int64_t lo = 0, hi = nout;
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (row_out[mid] < r) lo = mid + 1;
+            else hi = mid;
+        }
+        rowptr[r] = lo;
+    }
+}
+
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 8); }
+    template <class T> T *as() { return (T *)p; }
+};
+
+}  // namespace
+
+bool device_coo_supported(int64_t m, int64_t n, int64_t nnz) {
+    return m < ((int64_t)1 << 31) && n < ((int64_t)1 << 32) && nnz > 0 && nnz < ((int64_t)1 << 32) - 1;
+}
+
+// Indices must already be bounds-checked by the caller.  Synchronises the context stream.
+int device_coo_to_csr(sla_ctx *c, int64_t m, int64_t n, int64_t nnz, const int64_t *row, const int64_t *col,
+                      const double *val, int dup_policy, HostCsr &out) {
+    hipStream_t st = c->stream;
+    DevBuf d_row, d_col, d_val, d_key, d_key2, d_idx, d_idx2, d_flag, d_pos, d_tmp, d_colo, d_valo, d_rowo, d_rp;
+    const size_t N = (size_t)nnz;
+    SLA_HIP_TRY(d_row.alloc(8 * N));
+    SLA_HIP_TRY(d_col.alloc(8 * N));
+    SLA_HIP_TRY(d_val.alloc(8 * N));
+    SLA_HIP_TRY(d_key.alloc(8 * N));
+    SLA_HIP_TRY(d_key2.alloc(8 * N));
+    SLA_HIP_TRY(d_idx.alloc(4 * N));
+    SLA_HIP_TRY(d_idx2.alloc(4 * N));
+    SLA_HIP_TRY(hipMemcpyAsync(d_row.p, row, 8 * N, hipMemcpyHostToDevice, st));
+    SLA_HIP_TRY(hipMemcpyAsync(d_col.p, col, 8 * N, hipMemcpyHostToDevice, st));
+    SLA_HIP_TRY(hipMemcpyAsync(d_val.p, val, 8 * N, hipMemcpyHostToDevice, st));
+    const int grid = (int)std::min<int64_t>((nnz + 255) / 256, 4096);
+    hipLaunchKernelGGL(coo_keys_kernel, dim3(grid), dim3(256), 0, st, nnz, d_row.as<int64_t>(), d_col.as<int64_t>(),
+                       d_key.as<uint64_t>(), d_idx.as<uint32_t>());
+    // stable LSD radix sort on the significant key bits only
+    int row_bits = 1, col_bits = 1;
+    while (((int64_t)1 << row_bits) < m) ++row_bits;
+    while (((int64_t)1 << col_bits) < n) ++col_bits;
+    size_t tmp_bytes = 0;
+    SLA_HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, d_key.as<uint64_t>(), d_key2.as<uint64_t>(), d_idx.as<uint32_t>(),
+                                          d_idx2.as<uint32_t>(), N, 0, 32 + row_bits, st));
+    SLA_HIP_TRY(d_tmp.alloc(tmp_bytes));
+    SLA_HIP_TRY(rocprim::radix_sort_pairs(d_tmp.p, tmp_bytes, d_key.as<uint64_t>(), d_key2.as<uint64_t>(), d_idx.as<uint32_t>(),
+                                          d_idx2.as<uint32_t>(), N, 0, 32 + row_bits, st));
+    (void)col_bits;
+    // rows / cols are no longer needed on the device: reuse their storage for flags / positions
+    uint32_t *flag = d_row.as<uint32_t>(), *pos = d_col.as<uint32_t>();
+    hipLaunchKernelGGL(coo_flag_kernel, dim3(grid), dim3(256), 0, st, nnz, d_key2.as<uint64_t>(), flag);
+    size_t scan_bytes = 0;
+    SLA_HIP_TRY(rocprim::exclusive_scan(nullptr, scan_bytes, flag, pos, 0u, N, rocprim::plus<uint32_t>(), st));
+    DevBuf d_scan;
+    SLA_HIP_TRY(d_scan.alloc(scan_bytes));
+    SLA_HIP_TRY(rocprim::exclusive_scan(d_scan.p, scan_bytes, flag, pos, 0u, N, rocprim::plus<uint32_t>(), st));
+    uint32_t last_pos = 0, last_flag = 0;
+    SLA_HIP_TRY(hipMemcpyAsync(&last_pos, pos + (N - 1), 4, hipMemcpyDeviceToHost, st));
+    SLA_HIP_TRY(hipMemcpyAsync(&last_flag, flag + (N - 1), 4, hipMemcpyDeviceToHost, st));
+    SLA_HIP_TRY(hipStreamSynchronize(st));
+    const int64_t nout = (int64_t)last_pos + (int64_t)last_flag;
+    SLA_HIP_TRY(d_colo.alloc(8 * (size_t)nout));
+    SLA_HIP_TRY(d_valo.alloc(8 * (size_t)nout));
+    SLA_HIP_TRY(d_rowo.alloc(8 * (size_t)nout));
+    SLA_HIP_TRY(d_rp.alloc(8 * (size_t)(m + 1)));
+    hipLaunchKernelGGL(coo_emit_kernel, dim3(grid), dim3(256), 0, st, nnz, d_key2.as<uint64_t>(), d_idx2.as<uint32_t>(), flag, pos,
+                       d_val.as<double>(), dup_policy == SLA_DUP_SUM ? 1 : 0, d_colo.as<int64_t>(), d_valo.as<double>(),
+                       d_rowo.as<int64_t>());
+    const int grid_r = (int)std::min<int64_t>((m + 1 + 255) / 256, 4096);
+    hipLaunchKernelGGL(coo_rowptr_kernel, dim3(grid_r), dim3(256), 0, st, m, nout, d_rowo.as<int64_t>(), d_rp.as<int64_t>());
+    SLA_HIP_TRY(hipGetLastError());
+    out.m = m;
+    out.n = n;
+    out.rowptr.resize((size_t)m + 1);
+    out.col.resize((size_t)nout);
+    out.val.resize((size_t)nout);
+    SLA_HIP_TRY(hipMemcpyAsync(out.rowptr.data(), d_rp.p, 8 * (size_t)(m + 1), hipMemcpyDeviceToHost, st));
+    if (nout) {
+        SLA_HIP_TRY(hipMemcpyAsync(out.col.data(), d_colo.p, 8 * (size_t)nout, hipMemcpyDeviceToHost, st));
+        SLA_HIP_TRY(hipMemcpyAsync(out.val.data(), d_valo.p, 8 * (size_t)nout, hipMemcpyDeviceToHost, st));
+    }
+    SLA_HIP_TRY(hipStreamSynchronize(st));
+    return SLA_OK;
+}
+
+}  // namespace sla

@@ -102,6 +102,7 @@ struct sla_ctx {
     int64_t xfull_cap = 0;
     int spmv_algo = 0;               // 0 stream, 1 scalar (SLA_SPMV_ALGO)
     int xcd_remap = 1;               // SLA_XCD_REMAP
+    int64_t device_coo_min = 1 << 20; // triple lists at least this long are sorted on the GPU (SLA_DEVICE_COO_MIN)
     int xwin = 1;                    // allow the LDS x-window SpMV kernel (SLA_XWIN=0 disables)
     int dual_spmv = 1;               // linSolve0: fuse the true-residual SpMV into the next K1 (SLA_DUAL_SPMV=0 disables)
     int x_exchange = 0;              // 0 auto (window exchange when it pays), 1 always all-gather, 2 always window (SLA_X_EXCHANGE=allgather|window)
@@ -193,6 +194,10 @@ struct HostCsr {
 int build_csr_from_coo(int64_t m, int64_t n, int64_t nnz, const int64_t *row, const int64_t *col,
                        const double *val, int dup_policy, HostCsr &out);
 void transpose_csr(const HostCsr &a, HostCsr &t);
+// device-side sort / dedupe of large triple lists (sla_coo_sort.hip); bit-identical to build_csr_from_coo
+bool device_coo_supported(int64_t m, int64_t n, int64_t nnz);
+int device_coo_to_csr(sla_ctx *c, int64_t m, int64_t n, int64_t nnz, const int64_t *row, const int64_t *col,
+                      const double *val, int dup_policy, HostCsr &out);
 bool host_is_diagonal(int64_t rows, int64_t row_begin, const int64_t *rowptr, const int64_t *col);
 void build_row_blocks(int64_t rows, const int64_t *rowptr, std::vector<int32_t> &rb, int64_t &max_row_nnz);
 

@@ -354,6 +354,30 @@ def fromCSRRows(dims, row_begin, rowptr_local, colidx, vals, ctx=None):
     return SpMatrix(dims, h, ctx)
 
 
+def readMatrixMarket(path, ctx=None, dup_policy=0):
+    """`matrix coordinate real general` file -> SpMatrix with the loader semantics of test/Perf.hs:20-45
+    (1-based -> 0-based, file order into fromListSM, no symmetric expansion)."""
+    ctx = ctx or default_context()
+    h = C.c_void_p()
+    check(lib().sla_csr_from_matrix_market(ctx.h, str(path).encode(), dup_policy, C.byref(h)))
+    m, n = C.c_int64(), C.c_int64()
+    check(lib().sla_csr_dims(h, C.byref(m), C.byref(n), None, None))
+    return SpMatrix((m.value, n.value), h, ctx)
+
+
+def readMatrixMarketArray(path, ctx=None):
+    """`matrix array` file -> dense SpVector (the right-hand side of test/Perf.hs)."""
+    ctx = ctx or default_context()
+    h = C.c_void_p()
+    check(lib().sla_vec_from_matrix_market(ctx.h, str(path).encode(), C.byref(h)))
+    n = C.c_int64()
+    check(lib().sla_vec_dim(h, C.byref(n), None))
+    out = np.empty(n.value, dtype=np.float64)
+    check(lib().sla_vec_to_host(h, _p(out)))
+    lib().sla_vec_destroy(h)
+    return fromVector(out, ctx)
+
+
 def fromListDenseSM(m, ll, ctx=None):
     """fromListDenseSM m ll (SpMatrix.hs:239-241): column-major, entry k -> (k mod m, k div m)."""
     ll = list(ll)

@@ -158,3 +158,33 @@ def test_consecutive_long_rows_wave_per_row_and_block_per_row(sla):
     y, yo = sla.matVec(A, sla.fromVector(x)).toDenseListSV(), orc.spmv(Ao, x)
     bound = np.diff(Ao.rowptr) * np.finfo(float).eps * orc.spmv(orc.Csr(m, n, Ao.rowptr, Ao.colidx, np.abs(Ao.val)), np.abs(x))
     assert np.all(np.abs(y - yo) <= bound + 1e-300)
+
+
+@pytest.mark.parametrize("policy", [0, 1])
+def test_device_coo_sort_equals_host_builder_and_oracle(sla, monkeypatch, policy):
+    """Large triple lists are sorted / deduplicated on the GPU (rocPRIM radix sort); the result must be
+    bit-identical to the host builder and, for last-wins, to the oracle's fromListSM restatement."""
+    rng = np.random.default_rng(77)
+    m, n, nnz = 5000, 7000, 200000
+    r, c = rng.integers(0, m, nnz), rng.integers(0, n, nnz)
+    r[:500], c[:500] = r[500:1000], c[500:1000]          # plenty of duplicates, some of them triples
+    r[1000:1200], c[1000:1200] = r[:200], c[:200]
+    v = rng.standard_normal(nnz)
+    outs = []
+    for thr in ("1", str(1 << 40)):                       # device path, host path
+        monkeypatch.setenv("SLA_DEVICE_COO_MIN", thr)
+        ctx = sla.Context(0)
+        A = sla.fromCOO((m, n), r, c, v, ctx, dup_policy=policy)
+        outs.append(tuple(a.copy() for a in A.csr()))
+        del A
+        ctx.close()
+    for a, b_ in zip(*outs):
+        assert np.array_equal(a, b_)
+    if policy == 0:
+        rc, Ao = orc.coo_to_csr(m, n, r, c, v)
+        assert np.array_equal(outs[0][0], Ao.rowptr) and np.array_equal(outs[0][1], Ao.colidx) and np.array_equal(outs[0][2], Ao.val)
+    monkeypatch.setenv("SLA_DEVICE_COO_MIN", "1")
+    ctx = sla.Context(0)
+    with pytest.raises(sla.IndexOutOfBounds):
+        sla.fromCOO((4, 4), [0, 4], [0, 0], [1.0, 1.0], ctx)
+    ctx.close()

@@ -418,3 +418,24 @@ def test_forced_collectives_match_single_gpu_path(sla, monkeypatch):
     for a, b_ in zip(*outs):
         assert np.array_equal(a, b_)          # per-rank folding + rank-order sum == the 1-GPU reduction order
     ctx.close()
+
+
+def test_matrix_market_ingestion_e05r0000(sla):
+    # test/Perf.hs:20-45 loads test/data/e05r0000.mtx (+ rhs) and solves; BCG_ is no longer implemented in the
+    # reference, so solve with what is: BICGSTAB_ may stall on this non-symmetric CFD matrix, GMRES must not
+    A = sla.readMatrixMarket(f"{GOLDEN}/e05r0000.mtx")
+    dims, r, c, v = read_mtx_coordinate(f"{GOLDEN}/e05r0000.mtx")
+    rc, Ao = orc.coo_to_csr(dims[0], dims[1], r, c, v)
+    rp, ci, va = A.csr()
+    assert A.dims == (236, 236) and np.array_equal(rp, Ao.rowptr) and np.array_equal(ci, Ao.colidx) and np.array_equal(va, Ao.val)
+    b = sla.readMatrixMarketArray(f"{GOLDEN}/e05r0000_rhs1.mtx")
+    assert np.array_equal(b.toDenseListSV(), read_mtx_array(f"{GOLDEN}/e05r0000_rhs1.mtx"))
+    x, info = sla.gmres(A, b, sla.fromVector(np.full(236, 0.1)), restart=60, return_info=True, max_iters=2000)
+    rco, xo, it_o, res_o, r0_o = orc.gmres(Ao, b.toDenseListSV(), np.full(236, 0.1), restart=60, max_restarts=40)
+    res = np.linalg.norm(orc.spmv(Ao, x.toDenseListSV()) - b.toDenseListSV())
+    assert abs(info["r0norm"] - r0_o) <= 1e-10 * r0_o
+    assert res <= max(info["resnorm"] * (1 + 1e-6), 1e-12) * 1.001 + 1e-12
+    with pytest.raises(sla.SlaError):
+        sla.readMatrixMarket(f"{GOLDEN}/does_not_exist.mtx")
+    with pytest.raises(sla.SlaError):
+        sla.readMatrixMarket(f"{GOLDEN}/e05r0000_rhs1.mtx")      # an array file is not a coordinate matrix
