@@ -270,6 +270,17 @@ def main():
     n_local = re_ - rb
     spmv_bytes_local = 12 * nnz_local + 20 * n_local
 
+    # ---- measured streaming ceiling of this GPU (triad-like y = a x + b y: 24 B per element) --------------
+    triad_reps = 30
+    for _ in range(3):
+        _lib.check(lib.sla_axpby(1.0, xv.h, 0.5, yv.h))
+    ctx.sync()
+    t0 = time.perf_counter()
+    for _ in range(triad_reps):
+        _lib.check(lib.sla_axpby(1.0, xv.h, 0.5, yv.h))
+    ctx.sync()
+    triad_gbps = 24.0 * n_local * triad_reps / (time.perf_counter() - t0) / 1e9
+
     if rank == 0:
         k1_bytes = 12 * nnz_local + 28 * n_local      # K1 = SpMV (12 nnz + 20 n) + r0hat read for the fused dot (8 n)
         if args.mode == "gmres":
@@ -297,9 +308,12 @@ def main():
             "step_frac_of_hbm_peak": step_bytes / (dt / args.steps) / 1e9 / (HBM_PEAK_GBS * world),
             "spmv_gbps": spmv_bytes_local * world / (sp_mean_ms * 1e-3) / 1e9 if sp_launch else None,
             "spmv_ms": sp_mean_ms,
+            "hbm_measured_ceiling_gbps": triad_gbps,   # axpby triad on vectors of the same length, same run
+            "step_frac_of_measured_ceiling": step_bytes / (dt / args.steps) / 1e9 / (triad_gbps * world) if triad_gbps else None,
             "roofline": {"bound": "hbm", "kernel": "spmv_stream_kernel<EPI_DOT> (K1: Ap = A p fused with Ap . r0hat)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "frac_of_measured_ceiling": achieved / triad_gbps if triad_gbps else None,
+                         "traffic": None,
                          "bytes_per_launch": k1_bytes, "avg_launch_ms": mean_ms, "min_launch_ms": min_ms,
                          "launches_timed": launches},
         }
