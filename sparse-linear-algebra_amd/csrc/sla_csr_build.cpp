@@ -85,7 +85,7 @@ bool host_is_diagonal(int64_t rows, int64_t row_begin, const int64_t *rowptr, co
 // Greedy row blocks for the CSR-stream kernel: <= kNnzPerRowBlock entries and <= kMaxRowsPerRowBlock
 // rows per block; rows longer than kNnzPerRowBlock form blocks of up to 4 such rows (<= kWaveRowMax
 // entries each) or a block of their own (longer still).
-void build_row_blocks(int64_t rows, const int64_t *rowptr, std::vector<int32_t> &rb, int64_t &max_row_nnz) {
+void build_row_blocks(int64_t rows, const int64_t *rowptr, std::vector<int32_t> &rb, int64_t &max_row_nnz, int row_align) {
     rb.clear();
     rb.push_back(0);
     max_row_nnz = 0;
@@ -99,6 +99,10 @@ void build_row_blocks(int64_t rows, const int64_t *rowptr, std::vector<int32_t> 
             cnt += len;
             ++r;
         }
+        // optional (SLA_ROW_ALIGN=16): end short-row blocks on a multiple of 16 rows so that the y / rowptr
+        // segments of a block start and end on 128-byte lines.  Off by default: measured 1.5 % slower on the
+        // 216^3 Laplacian (fewer entries per block outweigh the unsplit cache lines).
+        if (row_align > 1 && r < rows && r - r0 > 2 * row_align) r -= r % row_align;
         if (r == r0) {  // the row does not fit the LDS stage: long-row block
             const int64_t len = rowptr[r + 1] - rowptr[r];
             if (len > max_row_nnz) max_row_nnz = len;
