@@ -196,6 +196,39 @@ static int csr_upload(sla_ctx *c, int64_t m, int64_t n, int64_t row_begin, int64
         A->use_xwin = A->xwin_fraction >= 0.5;
         upload((void **)&A->d_rbw, rbw.data(), sizeof(int32_t) * rbw.size());
     }
+    {
+        // dictionary of diagonal offsets: worthwhile (and representable in a byte) when col - row takes at
+        // most 256 distinct values, i.e. for stencil / banded structure
+        std::vector<int64_t> offs;
+        bool ok = nnz > 0;
+        for (int64_t i = 0; i < rows && ok; ++i) {
+            const int64_t gr = row_begin + i;
+            for (int64_t k = rowptr[i]; k < rowptr[i + 1]; ++k) {
+                const int64_t d = col[k] - gr;
+                bool found = false;
+                for (int64_t o : offs) if (o == d) { found = true; break; }   // <= 256 entries: a linear scan is fine
+                if (!found) {
+                    if (offs.size() == 256) { ok = false; break; }
+                    offs.push_back(d);
+                }
+            }
+        }
+        if (ok) {
+            std::sort(offs.begin(), offs.end());
+            std::vector<int32_t> dict(256, (int32_t)offs.back());
+            for (size_t t = 0; t < offs.size(); ++t) dict[t] = (int32_t)offs[t];
+            std::vector<uint8_t> codes((size_t)nnz);
+            for (int64_t i = 0; i < rows; ++i) {
+                const int64_t gr = row_begin + i;
+                for (int64_t k = rowptr[i]; k < rowptr[i + 1]; ++k)
+                    codes[(size_t)k] = (uint8_t)(std::lower_bound(offs.begin(), offs.end(), col[k] - gr) - offs.begin());
+            }
+            upload((void **)&A->d_code, codes.data(), codes.size());
+            upload((void **)&A->d_dict, dict.data(), sizeof(int32_t) * dict.size());
+            A->use_diag = true;
+            A->ndiag = (int)offs.size();
+        }
+    }
     if (err != hipSuccess) {
         sla_csr_destroy(A);
         return fail(SLA_ERR_ALLOC, std::string("CSR upload: ") + hipGetErrorString(err));
@@ -267,6 +300,7 @@ static int ctx_create_common(int device_id, int rank, int nranks, const void *ui
     if (const char *s = getenv("SLA_XCD_REMAP")) c->xcd_remap = atoi(s);
     if (const char *s = getenv("SLA_DUAL_SPMV")) c->dual_spmv = atoi(s);
     if (const char *s = getenv("SLA_XWIN")) c->xwin = atoi(s);
+    if (const char *s = getenv("SLA_DIAG")) c->diag = atoi(s);
     if (const char *s = getenv("SLA_ROW_ALIGN")) c->row_align = atoi(s);
     if (const char *s = getenv("SLA_DEVICE_COO_MIN")) c->device_coo_min = atoll(s);
     if (const char *s = getenv("SLA_X_EXCHANGE")) c->x_exchange = strcmp(s, "allgather") == 0 ? 1 : (strcmp(s, "window") == 0 ? 2 : 0);
@@ -400,6 +434,8 @@ int sla_csr_destroy(sla_csr_t A) {
     if (A->d_rb) (void)hipFree(A->d_rb);
     if (A->d_rbk) (void)hipFree(A->d_rbk);
     if (A->d_rbw) (void)hipFree(A->d_rbw);
+    if (A->d_code) (void)hipFree(A->d_code);
+    if (A->d_dict) (void)hipFree(A->d_dict);
     delete A;
     return SLA_OK;
 }
@@ -444,7 +480,7 @@ int sla_csr_is_diagonal(sla_csr_t A, int *out) {
 int sla_csr_kernel_info(sla_csr_t A, char *buf, int buflen) {
     if (!A || !buf || buflen <= 0) return fail(SLA_ERR_INVALID, "null argument");
     snprintf(buf, (size_t)buflen, "algo=%s grid=%d block=%d row_blocks=%d nnz_per_row_block=%d max_row_nnz=%lld rowptr=%s xcd_remap=%d",
-             A->ctx->spmv_algo == 1 ? "scalar" : (A->use_xwin && A->ctx->xwin ? "stream+xwin" : "stream"), spmv_grid(A), kBlock, A->nrb, kNnzPerRowBlock,
+             A->ctx->spmv_algo == 1 ? "scalar" : (A->use_diag && A->ctx->diag ? (A->use_xwin && A->ctx->xwin ? "stream+diagdict+xwin" : "stream+diagdict") : (A->use_xwin && A->ctx->xwin ? "stream+xwin" : "stream")), spmv_grid(A), kBlock, A->nrb, kNnzPerRowBlock,
              (long long)A->max_row_nnz, A->rp64 ? "i64" : "i32", A->ctx->xcd_remap);
     return SLA_OK;
 }

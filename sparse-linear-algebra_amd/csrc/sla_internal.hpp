@@ -104,6 +104,7 @@ struct sla_ctx {
     int xcd_remap = 1;               // SLA_XCD_REMAP
     int64_t device_coo_min = 1 << 20; // triple lists at least this long are sorted on the GPU (SLA_DEVICE_COO_MIN)
     int row_align = 0;               // > 1: row blocks end on multiples of this many rows (SLA_ROW_ALIGN; measured -1.5 % at 16)
+    int diag = 1;                    // allow the dictionary-compressed-index SpMV kernel (SLA_DIAG=0 disables)
     int xwin = 1;                    // allow the LDS x-window SpMV kernel (SLA_XWIN=0 disables)
     int dual_spmv = 1;               // linSolve0: fuse the true-residual SpMV into the next K1 (SLA_DUAL_SPMV=0 disables)
     int x_exchange = 0;              // 0 auto (window exchange when it pays), 1 always all-gather, 2 always window (SLA_X_EXCHANGE=allgather|window)
@@ -136,6 +137,10 @@ struct sla_csr {
     int32_t *d_rb = nullptr;
     void *d_rbk = nullptr;           // int32 or int64, like d_rowptr
     int32_t *d_rbw = nullptr;        // first column of each row block's LDS x window
+    uint8_t *d_code = nullptr;       // dictionary-compressed column indices: code[k] indexes d_dict (col - row offsets)
+    int32_t *d_dict = nullptr;       // 256 sorted diagonal offsets (unused slots repeat the last one)
+    bool use_diag = false;           // <= 256 distinct (col - row) values: spmv_diag_kernel streams 9 B per entry
+    int ndiag = 0;
     bool use_xwin = false;           // enough entries fall inside the windows for spmv_xwin_kernel to pay
     double xwin_fraction = 0.0;
     int32_t nrb = 0;
