@@ -929,6 +929,238 @@ __global__ void __launch_bounds__(kBlock, 8) spmv_diag_kernel(SpmvArgs<RP> a, co
     }
 }
 
+// Dual SpMV on the dictionary-compressed indices: K1 plus the true residual of the previous iterate from one
+// sweep over val (8 B) + code (1 B); the column is decoded once per entry and used for both gathers.
+template <typename RP, bool XW>
+__global__ void __launch_bounds__(kBlock, 8) spmv_dual_diag_kernel(SpmvArgs<RP> a, const RP *__restrict__ rowptr,
+                                                               const uint8_t *__restrict__ code, const double *__restrict__ val,
+                                                               const int32_t *__restrict__ rb, const RP *__restrict__ rbk,
+                                                               const double *__restrict__ xg, const int32_t *__restrict__ rbw,
+                                                               const int32_t *__restrict__ dict, int32_t ncols, int32_t grow0,
+                                                               const double *__restrict__ x2, const double *__restrict__ b2,
+                                                               int xcd_remap) {
+    constexpr int EPI = EPI_DOT;
+    __shared__ double s_val[kNnzPerRowBlock];
+    __shared__ uint8_t s_code[kNnzPerRowBlock];
+    __shared__ int s_rp[2][kMaxRowsPerRowBlock + 1];
+    __shared__ double s_xw[XW ? kXWin : 1];
+    __shared__ int s_dict[256];
+    __shared__ double s_red[4];
+    const int tid = threadIdx.x;
+    double coef;
+    if (!spmv_prologue<EPI, RP>(a, s_red, coef)) return;
+    s_dict[tid] = dict[tid];
+    __syncthreads();
+
+    double acc1 = 0.0, acc2 = 0.0;
+    const RbWalk wk = rb_walk(a.nrb, xcd_remap);
+    int b = wk.first;
+    if (b < wk.last) {
+        int r0 = rb[b], r1 = rb[b + 1];
+        RP k0 = rbk[b], k1 = rbk[b + 1];
+        int32_t c[4];
+        double v[4];
+        double xw[XW ? kXWin / kBlock : 1];
+        int wlo = XW ? rbw[b] : 0;
+        RP rpn = 0;
+#define SLA_ISSUE_LOADS(r0_, r1_, k0_, k1_, wlo_)                                           \
+        if ((k1_) - (k0_) <= (RP)kNnzPerRowBlock) {                                          \
+            const int cnt_ = (int)((k1_) - (k0_));                                           \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                  \
+                const int i = tid + j * kBlock;                                              \
+                if (i < cnt_) {                                                              \
+                    c[j] = __builtin_nontemporal_load(code + (k0_) + i);                     \
+                    v[j] = __builtin_nontemporal_load(val + (k0_) + i);                      \
+                }                                                                            \
+            }                                                                                \
+            if (tid < (r1_) - (r0_)) rpn = rowptr[(r0_) + tid];                              \
+            if (XW) {                                                                        \
+                _Pragma("unroll") for (int j = 0; j < kXWin / kBlock; ++j) {                 \
+                    const int i = (wlo_) + tid + j * kBlock;                                 \
+                    xw[j] = i < ncols ? xg[i] : 0.0;                                         \
+                }                                                                            \
+            }                                                                                \
+        }
+        SLA_ISSUE_LOADS(r0, r1, k0, k1, wlo)
+        int nr0 = 0, nr1 = 0, nwlo = 0;
+        RP nk0 = 0, nk1 = 0;
+        if (b + wk.step < wk.last) {
+            if (XW) nwlo = rbw[b + wk.step];
+            nr0 = rb[b + wk.step];
+            nr1 = rb[b + wk.step + 1];
+            nk0 = rbk[b + wk.step];
+            nk1 = rbk[b + wk.step + 1];
+        }
+        // x[col] for col = global row + diagonal offset: LDS window first, L1/L2 otherwise
+        auto xat = [&](int colg) -> double {
+            if (XW) {
+                const unsigned off = (unsigned)(colg - wlo);
+                if (off < (unsigned)kXWin) return s_xw[off];
+            }
+            return xg[colg];
+        };
+        int buf = 0;
+        for (;;) {
+            const int bn = b + wk.step, bnn = bn + wk.step;
+            const bool has_next = bn < wk.last, has_next2 = bnn < wk.last;
+            int fr0 = 0, fr1 = 0, fwlo = 0;
+            RP fk0 = 0, fk1 = 0;
+            const int nrows = r1 - r0;
+            if (k1 - k0 <= (RP)kNnzPerRowBlock) {
+                const int cnt = (int)(k1 - k0);
+                int *rp = s_rp[buf];
+                if (tid < nrows) rp[tid] = (int)(rpn - k0);
+                if (tid == 0) rp[nrows] = cnt;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int i = tid + j * kBlock;
+                    if (i < cnt) {
+                        s_val[i] = v[j];
+                        s_code[i] = (uint8_t)c[j];
+                    }
+                }
+                if (XW) {
+#pragma unroll
+                    for (int j = 0; j < kXWin / kBlock; ++j) s_xw[tid + j * kBlock] = xw[j];
+                }
+                __syncthreads();
+                if (has_next) { SLA_ISSUE_LOADS(nr0, nr1, nk0, nk1, nwlo) }
+                if (has_next2) {
+                    if (XW) fwlo = rbw[bnn];
+                    fr0 = rb[bnn];
+                    fr1 = rb[bnn + 1];
+                    fk0 = rbk[bnn];
+                    fk1 = rbk[bnn + 1];
+                }
+                if (nrows > 64 || cnt <= 8 * nrows) {
+                    // one lane per row: decode, gather, multiply, add -- ascending, separately rounded
+                    if (tid < nrows) {
+                        const int s = rp[tid], e = rp[tid + 1];
+                        const int grow = grow0 + r0 + tid;
+                        double acc = 0.0, yb = 0.0;
+                        {
+#pragma clang fp contract(off)  // a*x then +: two roundings like the reference, never an FMA
+                            for (int k = s; k < e; ++k) {
+                                const int cg = grow + s_dict[s_code[k]];
+                                const double vv = s_val[k];
+                                const double prod = vv * xat(cg);
+                                const double prod2 = vv * x2[cg];
+                                acc = acc + prod;
+                                yb = yb + prod2;
+                            }
+                        }
+                        const int row = r0 + tid;
+                        a.y[row] = acc;
+                        acc1 += acc * a.w[row];
+                        const double t = yb - b2[row];
+                        acc2 += t * t;
+                    }
+                } else {
+                    int np2 = 1;
+                    while (np2 < nrows) np2 <<= 1;
+                    const int tpr = min(64, kBlock / np2);
+                    const int g = tid / tpr, l = tid - g * tpr;
+                    double acc = 0.0, yb = 0.0;
+                    if (g < nrows) {
+                        const int e = rp[g + 1];
+                        const int grow = grow0 + r0 + g;
+                        for (int k = rp[g] + l; k < e; k += tpr) {
+                            const int cg = grow + s_dict[s_code[k]];
+                            acc += s_val[k] * xat(cg);
+                            yb += s_val[k] * x2[cg];
+                        }
+                    }
+                    for (int off = tpr >> 1; off > 0; off >>= 1) {
+                        acc += __shfl_xor(acc, off, 64);
+                        yb += __shfl_xor(yb, off, 64);
+                    }
+                    if (g < nrows && l == 0) {
+                        const int row = r0 + g;
+                        a.y[row] = acc;
+                        acc1 += acc * a.w[row];
+                        const double t = yb - b2[row];
+                        acc2 += t * t;
+                    }
+                }
+                __syncthreads();
+                buf ^= 1;
+            } else if (nrows > 1 || k1 - k0 <= (RP)kWaveRowMax) {
+                const int wv = tid >> 6, ln = tid & 63;
+                if (wv < nrows) {
+                    const RP s0 = rowptr[r0 + wv], s1 = rowptr[r0 + wv + 1];
+                    const int grow = grow0 + r0 + wv;
+                    double acc = 0.0, yb = 0.0;
+                    for (RP k = s0 + ln; k < s1; k += 64) {
+                        const int cg = grow + s_dict[code[k]];
+                        const double vv = val[k];
+                        acc += vv * xg[cg];
+                        yb += vv * x2[cg];
+                    }
+                    acc = wave_sum(acc);
+                    yb = wave_sum(yb);
+                    if (ln == 0) {
+                        const int row = r0 + wv;
+                        a.y[row] = acc;
+                        acc1 += acc * a.w[row];
+                        const double t = yb - b2[row];
+                        acc2 += t * t;
+                    }
+                }
+                if (has_next) { SLA_ISSUE_LOADS(nr0, nr1, nk0, nk1, nwlo) }
+                if (has_next2) {
+                    if (XW) fwlo = rbw[bnn];
+                    fr0 = rb[bnn];
+                    fr1 = rb[bnn + 1];
+                    fk0 = rbk[bnn];
+                    fk1 = rbk[bnn + 1];
+                }
+            } else {
+                double acc = 0.0, yb = 0.0;
+                const int grow = grow0 + r0;
+                for (RP k = k0 + tid; k < k1; k += kBlock) {
+                    const int cg = grow + s_dict[code[k]];
+                    acc += val[k] * xg[cg];
+                    yb += val[k] * x2[cg];
+                }
+                if (has_next) { SLA_ISSUE_LOADS(nr0, nr1, nk0, nk1, nwlo) }
+                if (has_next2) {
+                    if (XW) fwlo = rbw[bnn];
+                    fr0 = rb[bnn];
+                    fr1 = rb[bnn + 1];
+                    fk0 = rbk[bnn];
+                    fk1 = rbk[bnn + 1];
+                }
+                const double sum = block_sum(acc, s_red);
+                const double sumb = block_sum(yb, s_red);
+                if (tid == 0) {
+                    a.y[r0] = sum;
+                    acc1 += sum * a.w[r0];
+                    const double t = sumb - b2[r0];
+                    acc2 += t * t;
+                }
+            }
+            if (!has_next) break;
+            b = bn;
+            r0 = nr0;
+            r1 = nr1;
+            k0 = nk0;
+            k1 = nk1;
+            wlo = nwlo;
+            nwlo = fwlo;
+            nr0 = fr0;
+            nr1 = fr1;
+            nk0 = fk0;
+            nk1 = fk1;
+        }
+#undef SLA_ISSUE_LOADS
+    }
+    const double s1 = block_sum(acc1, s_red);
+    if (tid == 0) a.p1[blockIdx.x] = s1;
+    const double s2 = block_sum(acc2, s_red);
+    if (tid == 0) a.p2[blockIdx.x] = s2;
+}
+
+
 // One lane per row, grid-stride: the A/B baseline for the stream kernel (SLA_SPMV_ALGO=scalar).
 template <int EPI, typename RP>
 __global__ void __launch_bounds__(kBlock) spmv_scalar_kernel(SpmvArgs<RP> a, int xcd_remap) {
@@ -997,6 +1229,14 @@ static int launch_spmv_t(const sla_csr *A, const SpmvLaunch &l) {
     ProfScope prof(c, l.kernel_id);
     if (l.x2) {
         if constexpr (EPI == EPI_DOT) {
+            if (A->use_diag && c->diag) {
+                if (A->use_xwin && c->xwin)
+                    hipLaunchKernelGGL((spmv_dual_diag_kernel<RP, true>), dim3(grid), dim3(kBlock), 0, c->stream, a, a.rowptr, A->d_code, a.val,
+                                       a.rb, a.rbk, a.x, A->d_rbw, A->d_dict, (int32_t)A->n, (int32_t)A->row_begin, l.x2, l.b2, c->xcd_remap);
+                else
+                    hipLaunchKernelGGL((spmv_dual_diag_kernel<RP, false>), dim3(grid), dim3(kBlock), 0, c->stream, a, a.rowptr, A->d_code, a.val,
+                                       a.rb, a.rbk, a.x, A->d_rbw, A->d_dict, (int32_t)A->n, (int32_t)A->row_begin, l.x2, l.b2, c->xcd_remap);
+            } else
             hipLaunchKernelGGL((spmv_dual_kernel<RP>), dim3(grid), dim3(kBlock), 0, c->stream, a, a.rowptr, a.col, a.val, a.rb, a.rbk, a.x,
                                l.x2, l.b2, c->xcd_remap);
         } else {
