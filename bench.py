@@ -282,6 +282,7 @@ def main():
     triad_gbps = 24.0 * n_local * triad_reps / (time.perf_counter() - t0) / 1e9
 
     if rank == 0:
+        kinfo = A.kernel_info()
         k1_bytes = 12 * nnz_local + 28 * n_local      # K1 = SpMV (12 nnz + 20 n) + r0hat read for the fused dot (8 n)
         if args.mode == "gmres":
             k1_bytes = 12 * nnz_local + 20 * n_local  # the Arnoldi SpMV is the plain kernel
@@ -310,7 +311,10 @@ def main():
             "spmv_ms": sp_mean_ms,
             "hbm_measured_ceiling_gbps": triad_gbps,   # axpby triad on vectors of the same length, same run
             "step_frac_of_measured_ceiling": step_bytes / (dt / args.steps) / 1e9 / (triad_gbps * world) if triad_gbps else None,
-            "roofline": {"bound": "hbm", "kernel": "spmv_stream_kernel<EPI_DOT> (K1: Ap = A p fused with Ap . r0hat)",
+            "roofline": {"bound": "hbm",
+                         "kernel": f"{kinfo.split()[0]} {'K1D (K1 + true residual, one sweep)' if extra.get('dual_spmv') else ('plain SpMV' if args.mode == 'gmres' else 'K1: Ap = A p fused with Ap . r0hat')}",
+                         "bytes_definition": "algorithmic: f64 values + i32 column indices + i32 row pointers (SURVEY 8(d)); the "
+                                             "diagdict kernels stream 1-byte column codes instead, so PMC traffic can be below it",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "frac_of_measured_ceiling": achieved / triad_gbps if triad_gbps else None,
                          "traffic": None,
