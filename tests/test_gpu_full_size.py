@@ -1,0 +1,78 @@
+"""BASELINE.json configurations at (or near) full size: size-independent properties and the bench contract."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def sla():
+    import sla_amd
+    return sla_amd
+
+
+def test_config5_banded_2m_gmres30(sla):
+    from sla_amd import workloads as wl
+    dims, (rp, ci, va) = wl.banded_nonsym(2000000)                       # config 5
+    n = dims[0]
+    A = sla.fromCSR(dims, rp, ci, va)
+    assert "diagdict" in A.kernel_info()                                 # 5 diagonals -> 1-byte column codes
+    b = np.add.reduceat(va, rp[:-1])                                     # b = A 1
+    x, info = sla.gmres(A, sla.fromVector(b), sla.fromVector(np.zeros(n)), restart=30, return_info=True)
+    xd = x.toDenseListSV()
+    r = sla.matVec(A, x).toDenseListSV() - b
+    assert info["converged"] and np.linalg.norm(r) <= info["tol"] * (1 + 1e-9)
+    assert np.abs(xd - 1.0).max() <= 1e-3                                # diagonally dominant: x* = 1
+    # non-symmetric: (A u).v != (A v).u in general, but (A^T) is consistent with A: u.(A v) = (u <# A).v
+    rng = np.random.default_rng(0)
+    u, v = rng.standard_normal(n), rng.standard_normal(n)
+    av = sla.matVec(A, sla.fromVector(v)).toDenseListSV()
+    ua = sla.vecMat(sla.fromVector(u), A).toDenseListSV()
+    assert abs(np.dot(u, av) - np.dot(ua, v)) <= 1e-9 * abs(np.dot(u, av))
+
+
+def test_config3a_random_spd_1m_cgs_vs_bicgstab(sla):
+    from sla_amd import workloads as wl
+    dims, (rp, ci, va) = wl.random_spd(300000, 16, 42)                   # config 3a construction, reduced n
+    n = dims[0]
+    A = sla.fromCSR(dims, rp, ci, va)
+    assert "diagdict" not in A.kernel_info()                             # random columns: i32 kernels
+    rng = np.random.default_rng(7)
+    xs = rng.standard_normal(n)
+    b = sla.matVec(A, sla.fromVector(xs)).toDenseListSV()
+    u, v = rng.standard_normal(n), rng.standard_normal(n)
+    au = sla.matVec(A, sla.fromVector(u)).toDenseListSV()
+    avv = sla.matVec(A, sla.fromVector(v)).toDenseListSV()
+    assert abs(np.dot(v, au) - np.dot(u, avv)) <= 1e-10 * abs(np.dot(v, au))     # symmetric
+    assert np.dot(u, au) > 0                                                      # positive definite
+    for meth in (sla.CGS_, sla.BICGSTAB_):
+        x, info = sla.linSolve0(meth, A, sla.fromVector(b), sla.fromVector(np.zeros(n)), return_info=True)
+        assert info["converged"] and info["iters"] <= 60
+        assert np.linalg.norm(x.toDenseListSV() - xs) <= 1e-3 * np.linalg.norm(xs)
+
+
+def test_bench_contract_small():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "laplace3d_small", "--steps", "8",
+                          "--warmup", "2", "--cpu-seconds", "0.5"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                               # ONE JSON line
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 8 and d["warmup"] == 2 and d["dtype"] == "f64" and d["vs_baseline"] is None
+    assert "workload" in d["config"] and "model" not in d["config"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in d["roofline"], k
+    assert d["roofline"]["bound"] == "hbm" and d["roofline"]["peak"] == 8000.0
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in d["cpu_baseline"], k
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] == 1
+    assert abs(d["value"] - 1e3 / d["ms_per_step"]) <= 1e-6 * d["value"]
