@@ -111,6 +111,29 @@ int reduce_to_host(sla_ctx *c, const double *p1, const double *p2, int np, doubl
     return SLA_OK;
 }
 
+static constexpr size_t kVecPoolMaxBytes = (size_t)16 << 30;  // keep at most 16 GiB of idle vector buffers
+
+static hipError_t pool_alloc(sla_ctx *c, size_t bytes, void **p) {
+    auto it = c->vec_pool.find(bytes);
+    if (it != c->vec_pool.end()) {
+        *p = it->second;
+        c->vec_pool.erase(it);
+        c->vec_pool_bytes -= bytes;
+        return hipSuccess;
+    }
+    return hipMalloc(p, bytes);
+}
+
+static void pool_free(sla_ctx *c, void *p, size_t bytes) {
+    if (!p) return;
+    if (c && c->vec_pool_bytes + bytes <= kVecPoolMaxBytes && c->vec_pool.size() < 64) {
+        c->vec_pool.emplace(bytes, p);
+        c->vec_pool_bytes += bytes;
+    } else {
+        (void)hipFree(p);
+    }
+}
+
 int vec_alloc(sla_ctx *c, int64_t n, sla_vec **out) {
     sla_vec *v = new sla_vec();
     v->ctx = c;
@@ -120,14 +143,14 @@ int vec_alloc(sla_ctx *c, int64_t n, sla_vec **out) {
     row_range(c, n, &b, &e);
     v->begin = b;
     v->n_local = e - b;
-    hipError_t err = hipMalloc((void **)&v->d, sizeof(double) * (size_t)std::max<int64_t>(v->shard, 1));
+    hipError_t err = pool_alloc(c, sizeof(double) * (size_t)std::max<int64_t>(v->shard, 1), (void **)&v->d);
     if (err != hipSuccess) {
         delete v;
         return fail(SLA_ERR_ALLOC, std::string("hipMalloc(vector): ") + hipGetErrorString(err));
     }
     err = hipMemsetAsync(v->d, 0, sizeof(double) * (size_t)std::max<int64_t>(v->shard, 1), c->stream);
     if (err != hipSuccess) {
-        (void)hipFree(v->d);
+        pool_free(c, v->d, sizeof(double) * (size_t)std::max<int64_t>(v->shard, 1));
         delete v;
         return fail(SLA_ERR_HIP, std::string("hipMemsetAsync: ") + hipGetErrorString(err));
     }
@@ -338,6 +361,8 @@ int sla_ctx_destroy(sla_ctx_t c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     dist_comm_destroy(c);
+    for (auto &kv : c->vec_pool) (void)hipFree(kv.second);
+    c->vec_pool.clear();
     for (hipEvent_t ev : c->prof_ev) (void)hipEventDestroy(ev);
     if (c->d_parts) (void)hipFree(c->d_parts);
     if (c->d_result) (void)hipFree(c->d_result);
@@ -523,7 +548,7 @@ int sla_vec_create_local(sla_ctx_t c, int64_t n, const double *host_local, sla_v
 
 int sla_vec_destroy(sla_vec_t v) {
     if (!v) return SLA_OK;
-    if (v->d) (void)hipFree(v->d);
+    pool_free(v->ctx, v->d, sizeof(double) * (size_t)std::max<int64_t>(v->shard, 1));
     delete v;
     return SLA_OK;
 }

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -110,6 +111,11 @@ struct sla_ctx {
     int x_exchange = 0;              // 0 auto (window exchange when it pays), 1 always all-gather, 2 always window (SLA_X_EXCHANGE=allgather|window)
     bool collectives = false;        // nranks > 1, or SLA_FORCE_COLLECTIVES=1 on a 1-rank communicator (test hook)
     int spmv_grid_max = sla::kSpmvGridMax;
+    // Device-vector pool: a pure `linSolve0` call allocates ~10 vectors and frees them again; hipMalloc /
+    // hipFree of 80 MB blocks cost milliseconds each, so freed vector buffers are kept (by exact size) and
+    // handed out again.  Reuse is ordered by the context stream, so no synchronisation is needed.
+    std::multimap<size_t, void *> vec_pool;
+    size_t vec_pool_bytes = 0;
     // profiling
     int prof_kernel = -1, prof_max = 0;
     std::vector<hipEvent_t> prof_ev;

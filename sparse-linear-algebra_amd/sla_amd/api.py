@@ -145,6 +145,8 @@ class SpVector:
         return len(self.ix)
 
     def toDenseListSV(self):                     # SpVector.hs:300
+        if len(self.ix) == self.dim:
+            return self.vals.copy()
         d = np.zeros(self.dim)
         d[self.ix] = self.vals
         return d
@@ -154,9 +156,15 @@ class SpVector:
     def toListSV(self):                          # SpVector.hs:294-295
         return list(zip(self.ix.tolist(), self.vals.tolist()))
 
+    def _dense_view(self):
+        """Dense values without a scatter when every index is present (the solver inputs / outputs)."""
+        if len(self.ix) == self.dim:
+            return self.vals
+        return self.toDenseListSV()
+
     def device(self):
         if self._dev is None:
-            self._dev = DeviceVector(self.ctx, self.dim, self.toDenseListSV())
+            self._dev = DeviceVector(self.ctx, self.dim, self._dense_view())
         return self._dev
 
     # -- Eq / Show are structural in the reference
