@@ -159,7 +159,50 @@ int vec_alloc(sla_ctx *c, int64_t n, sla_vec **out) {
 }
 
 static int csr_upload(sla_ctx *c, int64_t m, int64_t n, int64_t row_begin, int64_t rows, const int64_t *rowptr,
-                      const int64_t *col, const double *val, sla_csr **out) {
+                      const int64_t *col, const double *val, sla_csr **out, bool panel_view = false);
+
+// Column panels for irregular matrices (see launch_spmv_panels): panel p = the entries with column in
+// [p W, (p+1) W), as a CSR view over the same rows.  Worth it when x does not fit the XCD-private L2 and
+// every row still has about one entry per panel.
+static int build_panels(sla_csr *A, int64_t m, int64_t n, int64_t row_begin, int64_t rows, const int64_t *rowptr,
+                        const int64_t *col, const double *val) {
+    sla_ctx *c = A->ctx;
+    const int64_t nnz = rowptr[rows];
+    if (!c->panels || A->use_diag || A->xwin_fraction >= 0.5 || rows == 0) return SLA_OK;
+    const int64_t W = std::max<int64_t>(c->panel_cols, 1);
+    if (n <= 2 * W) return SLA_OK;                                   // x (nearly) fits the L2 already
+    int64_t P = std::min<int64_t>((n + W - 1) / W, nnz / rows);      // >= ~1 entry per row per panel
+    if (P < 2) return SLA_OK;
+    const int64_t Wp = (n + P - 1) / P;
+    std::vector<int64_t> cur(rowptr, rowptr + rows), prp((size_t)rows + 1), pcol;
+    std::vector<double> pval;
+    for (int64_t p = 0; p < P; ++p) {
+        const int64_t chi = std::min<int64_t>(n, (p + 1) * Wp);
+        pcol.clear();
+        pval.clear();
+        prp[0] = 0;
+        for (int64_t i = 0; i < rows; ++i) {
+            int64_t k = cur[(size_t)i];
+            const int64_t e = rowptr[i + 1];
+            while (k < e && col[k] < chi) {
+                pcol.push_back(col[k]);
+                pval.push_back(val[k]);
+                ++k;
+            }
+            cur[(size_t)i] = k;
+            prp[(size_t)i + 1] = (int64_t)pcol.size();
+        }
+        sla_csr *V = nullptr;
+        SLA_TRY(csr_upload(c, m, n, row_begin, rows, prp.data(), pcol.data(), pval.data(), &V, true));
+        V->is_panel_view = true;
+        A->panels.push_back(V);
+    }
+    SLA_HIP_TRY(hipMalloc((void **)&A->d_panel_y, sizeof(double) * (size_t)std::max<int64_t>(rows, 1)));
+    return SLA_OK;
+}
+
+static int csr_upload(sla_ctx *c, int64_t m, int64_t n, int64_t row_begin, int64_t rows, const int64_t *rowptr,
+                      const int64_t *col, const double *val, sla_csr **out, bool panel_view) {
     const int64_t nnz = rowptr[rows];
     if (n > (int64_t)std::numeric_limits<int32_t>::max() || rows >= (int64_t)std::numeric_limits<int32_t>::max())
         return fail(SLA_ERR_INVALID, "matrix dimension exceeds the 32-bit device index width");
@@ -202,7 +245,7 @@ static int csr_upload(sla_ctx *c, int64_t m, int64_t n, int64_t row_begin, int64
     }
     upload((void **)&A->d_val, val, sizeof(double) * (size_t)nnz);
     upload((void **)&A->d_rb, rb.data(), sizeof(int32_t) * rb.size());
-    {
+    if (!panel_view) {
         // LDS x window of each row block: kXWin columns starting kXWinHalo left of its first diagonal column
         std::vector<int32_t> rbw(rb.size(), 0);
         int64_t inside = 0, total = 0;
@@ -219,7 +262,7 @@ static int csr_upload(sla_ctx *c, int64_t m, int64_t n, int64_t row_begin, int64
         A->use_xwin = A->xwin_fraction >= 0.5;
         upload((void **)&A->d_rbw, rbw.data(), sizeof(int32_t) * rbw.size());
     }
-    {
+    if (!panel_view) {
         // dictionary of diagonal offsets: worthwhile (and representable in a byte) when col - row takes at
         // most 256 distinct values, i.e. for stencil / banded structure
         std::vector<int64_t> offs;
@@ -256,6 +299,10 @@ static int csr_upload(sla_ctx *c, int64_t m, int64_t n, int64_t row_begin, int64
         sla_csr_destroy(A);
         return fail(SLA_ERR_ALLOC, std::string("CSR upload: ") + hipGetErrorString(err));
     }
+    if (panel_view) {
+        *out = A;
+        return SLA_OK;
+    }
     int rc = dist_allreduce_max_i32(c, &diag_not);
     if (rc != SLA_OK) {
         sla_csr_destroy(A);
@@ -263,6 +310,7 @@ static int csr_upload(sla_ctx *c, int64_t m, int64_t n, int64_t row_begin, int64
     }
     A->is_diagonal = diag_not == 0;
     rc = build_xplan(A, rows, rowptr, col);
+    if (rc == SLA_OK) rc = build_panels(A, m, n, row_begin, rows, rowptr, col, val);
     if (rc != SLA_OK) {
         sla_csr_destroy(A);
         return rc;
@@ -324,6 +372,8 @@ static int ctx_create_common(int device_id, int rank, int nranks, const void *ui
     if (const char *s = getenv("SLA_DUAL_SPMV")) c->dual_spmv = atoi(s);
     if (const char *s = getenv("SLA_XWIN")) c->xwin = atoi(s);
     if (const char *s = getenv("SLA_DIAG")) c->diag = atoi(s);
+    if (const char *s = getenv("SLA_PANELS")) c->panels = atoi(s);
+    if (const char *s = getenv("SLA_PANEL_COLS")) c->panel_cols = atoll(s);
     if (const char *s = getenv("SLA_ROW_ALIGN")) c->row_align = atoi(s);
     if (const char *s = getenv("SLA_DEVICE_COO_MIN")) c->device_coo_min = atoll(s);
     if (const char *s = getenv("SLA_X_EXCHANGE")) c->x_exchange = strcmp(s, "allgather") == 0 ? 1 : (strcmp(s, "window") == 0 ? 2 : 0);
@@ -452,6 +502,8 @@ int sla_csr_from_csr_rows(sla_ctx_t c, int64_t m, int64_t n, int64_t row_begin, 
 int sla_csr_destroy(sla_csr_t A) {
     if (!A) return SLA_OK;
     if (A->transposed) sla_csr_destroy(A->transposed);
+    for (sla_csr *V : A->panels) sla_csr_destroy(V);
+    if (A->d_panel_y) (void)hipFree(A->d_panel_y);
     delete A->xplan;
     if (A->d_rowptr) (void)hipFree(A->d_rowptr);
     if (A->d_col) (void)hipFree(A->d_col);
@@ -505,7 +557,7 @@ int sla_csr_is_diagonal(sla_csr_t A, int *out) {
 int sla_csr_kernel_info(sla_csr_t A, char *buf, int buflen) {
     if (!A || !buf || buflen <= 0) return fail(SLA_ERR_INVALID, "null argument");
     snprintf(buf, (size_t)buflen, "algo=%s grid=%d block=%d row_blocks=%d nnz_per_row_block=%d max_row_nnz=%lld rowptr=%s xcd_remap=%d",
-             A->ctx->spmv_algo == 1 ? "scalar" : (A->use_diag && A->ctx->diag ? (A->use_xwin && A->ctx->xwin ? "stream+diagdict+xwin" : "stream+diagdict") : (A->use_xwin && A->ctx->xwin ? "stream+xwin" : "stream")), spmv_grid(A), kBlock, A->nrb, kNnzPerRowBlock,
+             A->ctx->spmv_algo == 1 ? "scalar" : (!A->panels.empty() && A->ctx->panels) ? "stream+colpanels" : (A->use_diag && A->ctx->diag ? (A->use_xwin && A->ctx->xwin ? "stream+diagdict+xwin" : "stream+diagdict") : (A->use_xwin && A->ctx->xwin ? "stream+xwin" : "stream")), spmv_grid(A), kBlock, A->nrb, kNnzPerRowBlock,
              (long long)A->max_row_nnz, A->rp64 ? "i64" : "i32", A->ctx->xcd_remap);
     return SLA_OK;
 }

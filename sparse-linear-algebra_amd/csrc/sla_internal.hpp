@@ -72,6 +72,7 @@ struct SpmvArgs {
     const double *pa, *pb;   // prologue partials feeding alpha / beta for EPI_AXPY_DOT / EPI_XPBY_NRM
     int32_t npa, pa_stride;
     int32_t step_begin;      // bit 0: this launch opens a solver step (iters++); bit 1: step parity
+    const double *yinit;     // column-panel passes: running row sums of the previous panels (or null)
 };
 
 }  // namespace sla
@@ -105,6 +106,8 @@ struct sla_ctx {
     int xcd_remap = 1;               // SLA_XCD_REMAP
     int64_t device_coo_min = 1 << 20; // triple lists at least this long are sorted on the GPU (SLA_DEVICE_COO_MIN)
     int row_align = 0;               // > 1: row blocks end on multiples of this many rows (SLA_ROW_ALIGN; measured -1.5 % at 16)
+    int panels = 1;                  // allow the column-panel SpMV for irregular matrices (SLA_PANELS=0 disables)
+    int64_t panel_cols = 384 * 1024; // panel width in columns (SLA_PANEL_COLS): 3 MiB of x per pass
     int diag = 1;                    // allow the dictionary-compressed-index SpMV kernel (SLA_DIAG=0 disables)
     int xwin = 1;                    // allow the LDS x-window SpMV kernel (SLA_XWIN=0 disables)
     int dual_spmv = 1;               // linSolve0: fuse the true-residual SpMV into the next K1 (SLA_DUAL_SPMV=0 disables)
@@ -152,6 +155,9 @@ struct sla_csr {
     int32_t nrb = 0;
     bool is_diagonal = false;        // global isDiagonalSM
     sla_csr *transposed = nullptr;   // built lazily (single-rank only)
+    std::vector<sla_csr *> panels;   // column-panel views (irregular matrices whose x does not fit the L2), else empty
+    double *d_panel_y = nullptr;     // running row sums for epilogues that do not store y
+    bool is_panel_view = false;
     sla::XPlan *xplan = nullptr;     // sharded only: which x entries this rank exchanges with each peer
     int64_t max_row_nnz = 0;
 };
@@ -245,6 +251,8 @@ struct SpmvLaunch {
     const double *pa = nullptr, *pb = nullptr; int npa = 0, pa_stride = 1;
     int step_begin = 0;
     const double *x2 = nullptr, *b2 = nullptr;  // dual SpMV: also leave partials of ||A x2 - b2||^2 in p2
+    const double *yinit = nullptr;              // column-panel pass: continue these running row sums
+    int in_panel = 0;
     int kernel_id = SLA_KERNEL_SPMV;
 };
 int spmv_grid(const sla_csr *A);  // number of blocks (= partial slots written) of an SpMV launch on A

@@ -231,7 +231,9 @@ __global__ void __launch_bounds__(kBlock, 8) spmv_stream_kernel(SpmvArgs<RP> a, 
                     // one lane per row, ascending left fold: the reference's summation order exactly
                     if (tid < nrows) {
                         const int s = rp[tid], e = rp[tid + 1];
-                        double acc = 0.0;
+                        // column-panel passes continue the running sum of the previous panels: still one
+                        // ascending left fold per row
+                        double acc = a.yinit ? a.yinit[r0 + tid] : 0.0;
                         for (int k = s; k < e; ++k) acc += prod[k];
                         spmv_epilogue<EPI, RP>(a, r0 + tid, acc, coef, acc1, acc2);
                     }
@@ -247,7 +249,10 @@ __global__ void __launch_bounds__(kBlock, 8) spmv_stream_kernel(SpmvArgs<RP> a, 
                         for (int k = rp[g] + l; k < e; k += tpr) acc += prod[k];
                     }
                     for (int off = tpr >> 1; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
-                    if (g < nrows && l == 0) spmv_epilogue<EPI, RP>(a, r0 + g, acc, coef, acc1, acc2);
+                    if (g < nrows && l == 0) {
+                        if (a.yinit) acc += a.yinit[r0 + g];
+                        spmv_epilogue<EPI, RP>(a, r0 + g, acc, coef, acc1, acc2);
+                    }
                 }
                 buf ^= 1;
             } else if (nrows > 1 || k1 - k0 <= (RP)kWaveRowMax) {
@@ -274,7 +279,10 @@ __global__ void __launch_bounds__(kBlock, 8) spmv_stream_kernel(SpmvArgs<RP> a, 
                     }
                     for (; k < s1; k += 64) acc += val[k] * xg[col[k]];
                     acc = wave_sum(acc);
-                    if (ln == 0) spmv_epilogue<EPI, RP>(a, r0 + wv, acc, coef, acc1, acc2);
+                    if (ln == 0) {
+                        if (a.yinit) acc += a.yinit[r0 + wv];
+                        spmv_epilogue<EPI, RP>(a, r0 + wv, acc, coef, acc1, acc2);
+                    }
                 }
                 if (has_next) { SLA_ISSUE_LOADS(nr0, nr1, nk0, nk1) }
                 SLA_FETCH_DESC()
@@ -299,8 +307,11 @@ __global__ void __launch_bounds__(kBlock, 8) spmv_stream_kernel(SpmvArgs<RP> a, 
                 for (; k < k1; k += kBlock) acc += val[k] * xg[col[k]];
                 if (has_next) { SLA_ISSUE_LOADS(nr0, nr1, nk0, nk1) }
                 SLA_FETCH_DESC()
-                const double s = block_sum(acc, s_red);
-                if (tid == 0) spmv_epilogue<EPI, RP>(a, r0, s, coef, acc1, acc2);
+                double s = block_sum(acc, s_red);
+                if (tid == 0) {
+                    if (a.yinit) s += a.yinit[r0];
+                    spmv_epilogue<EPI, RP>(a, r0, s, coef, acc1, acc2);
+                }
             }
             if (!has_next) break;
             b = bn;
@@ -1191,6 +1202,8 @@ __global__ void __launch_bounds__(kBlock) spmv_scalar_kernel(SpmvArgs<RP> a, int
 
 int spmv_grid(const sla_csr *A) {
     const sla_ctx *c = A->ctx;
+    // with column panels the fused partials are written by the LAST panel pass: its grid is the one that counts
+    if (!A->panels.empty() && c->panels && c->spmv_algo == 0) return spmv_grid(A->panels.back());
     int64_t g;
     if (c->spmv_algo == 1) g = (A->rows + kBlock - 1) / kBlock;
     else g = A->nrb;
@@ -1200,8 +1213,48 @@ int spmv_grid(const sla_csr *A) {
 }
 
 template <int EPI, typename RP>
+static int launch_spmv_t(const sla_csr *A, const SpmvLaunch &l);
+
+// Column-panel SpMV for matrices whose gathers do not fit the XCD-private L2: the matrix is stored a second
+// time panel-major (panel p holds the entries with column in [p W, (p+1) W), W * 8 B <= ~3 MB), and y = A x
+// is evaluated as P passes y += A_p x in ascending panel order, so every gather of a pass hits a window of
+// x that stays L2-resident.  Each pass continues the row's running sum (yinit), i.e. the per-row order is
+// still one ascending left fold; the fused epilogue runs in the last pass only.
+template <int EPI, typename RP>
+static int launch_spmv_panels(const sla_csr *A, const SpmvLaunch &l) {
+    const size_t P = A->panels.size();
+    ProfScope prof(A->ctx, l.kernel_id);  // one timed interval for the whole panel sequence
+    double *ytmp = l.y;
+    if (!ytmp) ytmp = A->d_panel_y;  // epilogues that never store y (EPI_RES, EPI_AXPY_DOT, ...) still need the running sum
+    for (size_t p = 0; p < P; ++p) {
+        const bool last = p + 1 == P;
+        SpmvLaunch lp = l;
+        lp.yinit = p == 0 ? nullptr : ytmp;
+        lp.kernel_id = -2;               // never matches: the enclosing scope does the timing
+        int rc;
+        if (!last) {
+            lp.epi = EPI_NONE;
+            lp.y = ytmp;
+            lp.pres = nullptr;            // prologue checks / step bookkeeping happen once, in the last pass
+            lp.step_begin = 0;
+            lp.pa = nullptr;
+            rc = launch_spmv_t<EPI_NONE, RP>(A->panels[p], lp);
+        } else {
+            rc = launch_spmv_t<EPI, RP>(A->panels[p], lp);
+        }
+        if (rc != SLA_OK) return rc;
+    }
+    return SLA_OK;
+}
+
+template <int EPI, typename RP>
 static int launch_spmv_t(const sla_csr *A, const SpmvLaunch &l) {
     sla_ctx *c = A->ctx;
+    if (!A->panels.empty() && c->panels && c->spmv_algo == 0 && !l.x2 && !l.in_panel) {
+        SpmvLaunch lp = l;
+        lp.in_panel = 1;
+        return launch_spmv_panels<EPI, RP>(A, lp);
+    }
     SpmvArgs<RP> a;
     a.rowptr = (const RP *)A->d_rowptr;
     a.col = A->d_col;
@@ -1225,6 +1278,7 @@ static int launch_spmv_t(const sla_csr *A, const SpmvLaunch &l) {
     a.npa = l.npa;
     a.pa_stride = l.pa_stride;
     a.step_begin = l.step_begin;
+    a.yinit = l.yinit;
     const int grid = spmv_grid(A);
     ProfScope prof(c, l.kernel_id);
     if (l.x2) {

@@ -251,7 +251,9 @@ int enqueue_step(sla_solver *S, bool res_after, bool dual_prev) {
 
 // the dual-SpMV flow needs x and p resident on this rank as whole vectors and the stream kernel
 bool dual_ok(const sla_solver *S) {
-    return !S->ctx->collectives && S->ctx->spmv_algo == 0 && S->ctx->dual_spmv && S->method != SLA_CGNE_;
+    // (with column panels the residual SpMV is cheaper as its own panel-blocked sweep than fused into K1)
+    return !S->ctx->collectives && S->ctx->spmv_algo == 0 && S->ctx->dual_spmv && S->method != SLA_CGNE_ &&
+           (S->A->panels.empty() || !S->ctx->panels);
 }
 
 int read_scalars(sla_solver *S) {

@@ -188,3 +188,70 @@ def test_device_coo_sort_equals_host_builder_and_oracle(sla, monkeypatch, policy
     with pytest.raises(sla.IndexOutOfBounds):
         sla.fromCOO((4, 4), [0, 4], [0, 0], [1.0, 1.0], ctx)
     ctx.close()
+
+
+def test_column_panel_spmv_equals_plain_path(sla, monkeypatch):
+    """Irregular matrices whose x does not fit the L2 are swept in column panels (y += A_p x in ascending panel
+    order, each pass continuing the row's running sum).  Forced here with tiny panels: the result must equal the
+    un-panelled path bit for bit on short rows, and the solvers must behave identically."""
+    from sla_amd import workloads as wl
+    dims, (rp, ci, va) = wl.random_spd(3000, 3, 11)          # ~7 entries per row, random columns
+    n = dims[0]
+    Ao = orc.Csr(n, n, rp, ci, va)
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal(n)
+    b = orc.spmv(Ao, rng.standard_normal(n))
+    res = {}
+    for mode, env in (("panels", {"SLA_PANEL_COLS": "500"}), ("plain", {"SLA_PANELS": "0"})):
+        for k in ("SLA_PANEL_COLS", "SLA_PANELS"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        ctx = sla.Context(0)
+        A = sla.fromCSR(dims, rp, ci, va, ctx)
+        assert ("colpanels" in A.kernel_info()) == (mode == "panels"), A.kernel_info()
+        y = sla.matVec(A, sla.fromVector(x, ctx)).toDenseListSV()
+        yt = sla.vecMat(sla.fromVector(x, ctx), A).toDenseListSV()
+        out = [y, yt]
+        for meth in (sla.BICGSTAB_, sla.CGS_, sla.CGNE_):
+            xs, info = sla.linSolve0(meth, A, sla.fromVector(b, ctx), sla.fromVector(np.zeros(n), ctx), return_info=True)
+            out += [xs.toDenseListSV(), info["iters"], info["resnorm"]]
+        Q, H = sla.arnoldi(A, sla.fromVector(b, ctx), 8)
+        out += [H]
+        res[mode] = out
+        del A
+        ctx.close()
+    assert np.array_equal(res["panels"][0], orc.spmv(Ao, x))                # the reference's left fold, bit for bit
+    assert np.array_equal(res["panels"][0], res["plain"][0]) and np.array_equal(res["panels"][1], res["plain"][1])
+    # the fused inner products are grouped by the LAST panel's row blocks, so solver scalars differ in the last
+    # bits between the two paths: compare to solver tolerance, not bitwise
+    for a, b_ in zip(res["panels"][2:], res["plain"][2:]):
+        if isinstance(a, np.ndarray):
+            assert np.linalg.norm(a - b_) <= 1e-8 * max(np.linalg.norm(b_), 1e-30)
+        elif isinstance(a, int):
+            assert abs(a - b_) <= 1
+        else:
+            assert abs(a - b_) <= 1e-6 * max(abs(b_), 1e-6)
+
+
+def test_column_panels_with_long_and_mid_rows(sla, monkeypatch):
+    rng = np.random.default_rng(31)
+    m = n = 6000
+    lens = rng.choice([0, 2, 9, 40, 300, 1500, 5000], size=m, p=[0.05, 0.5, 0.3, 0.1, 0.03, 0.015, 0.005])
+    rows, cols, vals = [], [], []
+    for i, k in enumerate(lens):
+        if k:
+            cj = rng.choice(n, size=int(k), replace=False)
+            rows.append(np.full(int(k), i)); cols.append(cj); vals.append(rng.standard_normal(int(k)))
+    r, c, v = np.concatenate(rows), np.concatenate(cols), np.concatenate(vals)
+    monkeypatch.setenv("SLA_PANEL_COLS", "700")
+    ctx = sla.Context(0)
+    A = sla.fromCOO((m, n), r, c, v, ctx)
+    assert "colpanels" in A.kernel_info()
+    rc, Ao = orc.coo_to_csr(m, n, r, c, v)
+    x = rng.standard_normal(n)
+    y, yo = sla.matVec(A, sla.fromVector(x, ctx)).toDenseListSV(), orc.spmv(Ao, x)
+    bound = (np.diff(Ao.rowptr) + 8) * np.finfo(float).eps * orc.spmv(orc.Csr(m, n, Ao.rowptr, Ao.colidx, np.abs(Ao.val)), np.abs(x))
+    assert np.all(np.abs(y - yo) <= bound + 1e-300)
+    del A
+    ctx.close()
