@@ -319,27 +319,58 @@ static int csr_upload(sla_ctx *c, int64_t m, int64_t n, int64_t row_begin, int64
     return SLA_OK;
 }
 
-// lazily built transpose (transposeSM, SpMatrix.hs:717); single-rank contexts only
+// lazily built transpose (transposeSM, SpMatrix.hs:717).  Row-sharded: the transpose of this rank's row block
+// only -- all n rows of A^T, but just the columns this rank owns; its SpMV yields a full-length PARTIAL result
+// that spmv_transposed reduce-scatters over the ranks.
 int csr_transposed(sla_csr *A, sla_csr **out) {
     if (A->transposed) {
         *out = A->transposed;
         return SLA_OK;
     }
-    if (A->ctx->nranks != 1)
-        return fail(SLA_ERR_INVALID, "transpose SpMV ((<#), CGNE_) is not available on a row-sharded matrix");
     HostCsr h, t;
-    h.m = A->m;
+    h.m = A->rows;
     h.n = A->n;
     h.rowptr.resize((size_t)A->rows + 1);
     h.col.resize((size_t)A->nnz);
     h.val.resize((size_t)A->nnz);
     SLA_TRY(sla_csr_export(A, h.rowptr.data(), h.col.data(), h.val.data()));
-    transpose_csr(h, t);
+    transpose_csr(h, t);  // t: n rows, columns = LOCAL row ids 0..rows-1
     sla_csr *T = nullptr;
-    SLA_TRY(csr_upload(A->ctx, t.m, t.n, 0, t.m, t.rowptr.data(), t.col.data(), t.val.data(), &T));
+    if (!A->ctx->collectives) {
+        SLA_TRY(csr_upload(A->ctx, t.m, t.n, 0, t.m, t.rowptr.data(), t.col.data(), t.val.data(), &T));
+    } else {
+        // a private view (no exchange plan, no collectives at creation): columns stay local row ids, the
+        // gather base is this rank's shard
+        SLA_TRY(csr_upload(A->ctx, t.m, A->m, 0, t.m, t.rowptr.data(), t.col.data(), t.val.data(), &T, true));
+    }
     A->transposed = T;
     *out = T;
     return SLA_OK;
+}
+
+// y = transpose A #> x (vecMatSD, Common.hs:253-256) on local shards; row-sharded: partial + reduce-scatter
+int spmv_transposed(sla_csr *A, const double *x_local, double *y_local, int64_t y_shard) {
+    sla_ctx *c = A->ctx;
+    sla_csr *T = nullptr;
+    SLA_TRY(csr_transposed(A, &T));
+    SpmvLaunch l;
+    l.x = x_local;
+    if (!c->collectives) {
+        l.y = y_local;
+        return launch_spmv(T, l);
+    }
+    const int64_t full = y_shard * c->nranks;
+    if (c->tfull_cap < full) {
+        if (c->d_tfull) (void)hipFree(c->d_tfull);
+        c->d_tfull = nullptr;
+        c->tfull_cap = 0;
+        SLA_HIP_TRY(hipMalloc((void **)&c->d_tfull, sizeof(double) * (size_t)std::max<int64_t>(full, 1)));
+        SLA_HIP_TRY(hipMemsetAsync(c->d_tfull, 0, sizeof(double) * (size_t)std::max<int64_t>(full, 1), c->stream));
+        c->tfull_cap = full;
+    }
+    l.y = c->d_tfull;  // rows >= n (padding) are never written and stay zero
+    SLA_TRY(launch_spmv(T, l));
+    return dist_reduce_scatter_f64(c, c->d_tfull, y_local, y_shard);
 }
 
 }  // namespace sla
@@ -418,6 +449,7 @@ int sla_ctx_destroy(sla_ctx_t c) {
     if (c->d_result) (void)hipFree(c->d_result);
     if (c->h_result) (void)hipHostFree(c->h_result);
     if (c->d_xfull) (void)hipFree(c->d_xfull);
+    if (c->d_tfull) (void)hipFree(c->d_tfull);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return SLA_OK;
@@ -658,9 +690,8 @@ int sla_spmv_t(sla_csr_t A, sla_vec_t x, sla_vec_t y) {
     if (!A || !x || !y) return fail(SLA_ERR_INVALID, "null argument");
     if (A->m != x->n) return fail(SLA_ERR_DIM_MISMATCH, "vecMat : mismatching dimensions");  // Common.hs:256
     if (A->n != y->n) return fail(SLA_ERR_DIM_MISMATCH, "vecMat : result vector has the wrong dimension");
-    sla_csr *T = nullptr;
-    SLA_TRY(csr_transposed(A, &T));
-    return sla_spmv(T, x, y);
+    if (x == y) return fail(SLA_ERR_INVALID, "sla_spmv_t: x and y must be distinct");
+    return spmv_transposed(A, x->d, y->d, y->shard);
 }
 
 int sla_dot(sla_vec_t x, sla_vec_t y, double *out) {

@@ -25,6 +25,7 @@ typedef int (*fn_comm_init_rank)(NcclComm *, int, NcclUniqueId, int);
 typedef int (*fn_comm_destroy)(NcclComm);
 typedef int (*fn_all_gather)(const void *, void *, size_t, int, NcclComm, hipStream_t);
 typedef int (*fn_all_reduce)(const void *, void *, size_t, int, int, NcclComm, hipStream_t);
+typedef int (*fn_reduce_scatter)(const void *, void *, size_t, int, int, NcclComm, hipStream_t);
 typedef int (*fn_send)(const void *, size_t, int, int, NcclComm, hipStream_t);
 typedef int (*fn_recv)(void *, size_t, int, int, NcclComm, hipStream_t);
 typedef int (*fn_group)(void);
@@ -38,6 +39,7 @@ struct Rccl {
     fn_comm_destroy comm_destroy = nullptr;
     fn_all_gather all_gather = nullptr;
     fn_all_reduce all_reduce = nullptr;
+    fn_reduce_scatter reduce_scatter = nullptr;
     fn_send send = nullptr;
     fn_recv recv = nullptr;
     fn_group group_start = nullptr, group_end = nullptr;
@@ -63,6 +65,7 @@ Rccl &rccl() {
         r.comm_destroy = (fn_comm_destroy)dlsym(r.handle, "ncclCommDestroy");
         r.all_gather = (fn_all_gather)dlsym(r.handle, "ncclAllGather");
         r.all_reduce = (fn_all_reduce)dlsym(r.handle, "ncclAllReduce");
+        r.reduce_scatter = (fn_reduce_scatter)dlsym(r.handle, "ncclReduceScatter");
         r.send = (fn_send)dlsym(r.handle, "ncclSend");
         r.recv = (fn_recv)dlsym(r.handle, "ncclRecv");
         r.group_start = (fn_group)dlsym(r.handle, "ncclGroupStart");
@@ -116,6 +119,15 @@ int dist_allgather_f64(sla_ctx *ctx, const double *send, double *recv, int64_t c
     if (!ctx->comm) return fail(SLA_ERR_RCCL, "all-gather requested on a context without a communicator");
     int rc = rccl().all_gather(send, recv, (size_t)count, kNcclFloat64, (NcclComm)ctx->comm, ctx->stream);
     if (rc != 0) return rccl_fail("ncclAllGather", rc);
+    return SLA_OK;
+}
+
+// sum over ranks of full-length partial vectors, each rank keeping its shard (sharded transpose SpMV)
+int dist_reduce_scatter_f64(sla_ctx *ctx, const double *send, double *recv, int64_t recvcount) {
+    Rccl &r = rccl();
+    if (!ctx->comm || !r.reduce_scatter) return fail(SLA_ERR_RCCL, "reduce-scatter requested without a communicator");
+    int rc = r.reduce_scatter(send, recv, (size_t)recvcount, kNcclFloat64, 0 /* ncclSum */, (NcclComm)ctx->comm, ctx->stream);
+    if (rc != 0) return rccl_fail("ncclReduceScatter", rc);
     return SLA_OK;
 }
 

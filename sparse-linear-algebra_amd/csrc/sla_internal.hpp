@@ -102,6 +102,8 @@ struct sla_ctx {
     double *h_result = nullptr;      // pinned host mirror
     double *d_xfull = nullptr;       // all-gather landing buffer (nranks * shard) when sharded
     int64_t xfull_cap = 0;
+    double *d_tfull = nullptr;       // full-length partial result of a sharded transpose SpMV (before the reduce-scatter)
+    int64_t tfull_cap = 0;
     int spmv_algo = 0;               // 0 stream, 1 scalar (SLA_SPMV_ALGO)
     int xcd_remap = 1;               // SLA_XCD_REMAP
     int64_t device_coo_min = 1 << 20; // triple lists at least this long are sorted on the GPU (SLA_DEVICE_COO_MIN)
@@ -224,6 +226,7 @@ int dist_unique_id(void *out128);
 int dist_comm_init(sla_ctx *ctx, const void *unique_id);
 int dist_comm_destroy(sla_ctx *ctx);
 int dist_allgather_f64(sla_ctx *ctx, const double *send, double *recv, int64_t count);
+int dist_reduce_scatter_f64(sla_ctx *ctx, const double *send, double *recv, int64_t recvcount);
 int dist_exchange_window(sla_ctx *ctx, const XPlan &plan, const double *xlocal, int64_t my_begin, int64_t n_local, double *xfull);
 int dist_allreduce_max_i32(sla_ctx *ctx, int *value_host);
 
@@ -234,6 +237,7 @@ int gather_raw(sla_ctx *c, const sla_csr *A, const double *local, int64_t shard,
 int reduce_to_host(sla_ctx *c, const double *p1, const double *p2, int np, double *out);
 int vec_alloc(sla_ctx *c, int64_t n, sla_vec **out);
 int csr_transposed(sla_csr *A, sla_csr **out);
+int spmv_transposed(sla_csr *A, const double *x_local, double *y_local, int64_t y_shard);
 
 // kernel launchers (sla_kernels.hip) -----------------------------------------------------------------
 struct Parts {  // a partial-sum array as seen by a consumer prologue: p[i * stride], i < n
@@ -283,6 +287,8 @@ int launch_cgs_c4(sla_ctx *c, int64_t n, SolverScalars *sc, Parts rhonew, int pa
                   double *u, double *p);
 // CGNE (Sparse.hs:870-878)
 int launch_cgne_n2(sla_ctx *c, int64_t n, SolverScalars *sc, const double *p, double *x);
+// unfused N3 for the sharded path: beta ; p1 = t ^+^ beta .* p (t = transpose aa #> r1 after the reduce-scatter) ; p1 . p1
+int launch_cgne_n3b(sla_ctx *c, int64_t n, SolverScalars *sc, Parts rr1, int par, const double *t, double *p, double *ppout);
 // residual check at the end of a host batch (one block): publishes resnorm / done
 int launch_check(sla_ctx *c, SolverScalars *sc, Parts res);
 int launch_init_scalars(sla_ctx *c, SolverScalars *sc, Parts rho, Parts r0sq, double tol_abs, double tol_rel);

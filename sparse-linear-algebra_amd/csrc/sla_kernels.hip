@@ -12,6 +12,15 @@
 //     FIRST consumer kernel re-reduces the partials in a fixed order in its prologue and block 0
 //     publishes the scalar for later kernels.  No atomics, no host round trip inside an iteration.
 //
+// SpMV variants, all sharing the row-block walk, the software pipeline and the epilogues (launch_spmv_t picks):
+//   spmv_stream_kernel     general CSR-stream: val + i32 col, products staged in LDS
+//   spmv_xwin_kernel       + a 768-entry window of x staged in LDS (entries clustered around the diagonal)
+//   spmv_diag_kernel       + 1-byte dictionary codes instead of i32 columns (<= 256 distinct diagonals),
+//                            gather moved to the row phase
+//   spmv_dual_kernel / spmv_dual_diag_kernel   K1 and the true residual of the previous iterate in one sweep
+//   launch_spmv_panels     column-panel passes of spmv_stream_kernel for irregular matrices with x > L2
+//   spmv_scalar_kernel     one lane per row (A/B baseline, SLA_SPMV_ALGO=scalar)
+//
 // Reference semantics implemented (file:line relative to the reference repo):
 //   (#>)  Data/Sparse/Common.hs:242-260      (<.>)/norm2  Data/Sparse/SpVector.hs:116-129
 //   bicgstabStep Numeric/LinearAlgebra/Sparse.hs:972-981   cgsStep :928-939   cgneStep :870-878
@@ -1618,6 +1627,38 @@ __global__ void __launch_bounds__(kBlock) cgne_n2_kernel(int64_t n, SolverScalar
     SLA_VEC_LOOP_END
     if (SLA_HAS_TAIL(n)) x[n - 1] += alpha * p[n - 1];
 }
+// CGNE N3, unfused (row-sharded path): beta = (r1.r1)/(r.r) ; p1 = t ^+^ beta .* p ; partial p1 . p1
+__global__ void __launch_bounds__(kBlock) cgne_n3b_kernel(int64_t n, SolverScalars *sc, Parts rr1, int par, const double *t,
+                                                           double *p, double *ppout) {
+    __shared__ double s_red[4];
+    if (sc->done) return;
+    const double rr = reduce_parts(rr1.p, rr1.n, rr1.stride, s_red);
+    const double beta = rr / sc->rho2[par];
+    if (blockIdx.x == 0 && threadIdx.x == 0) { sc->beta = beta; sc->rho2[par ^ 1] = rr; }
+    double acc = 0.0;
+    SLA_VEC_LOOP_BEGIN(n)
+        const double2 tv = ld2(t, i2);
+        double2 pv = ld2(p, i2);
+        pv.x = tv.x + beta * pv.x;
+        pv.y = tv.y + beta * pv.y;
+        st2(p, i2, pv);
+        acc += pv.x * pv.x;
+        acc += pv.y * pv.y;
+    SLA_VEC_LOOP_END
+    if (SLA_HAS_TAIL(n)) {
+        const double pv = t[n - 1] + beta * p[n - 1];
+        p[n - 1] = pv;
+        acc += pv * pv;
+    }
+    const double s = block_sum(acc, s_red);
+    if (threadIdx.x == 0) ppout[blockIdx.x] = s;
+}
+int launch_cgne_n3b(sla_ctx *c, int64_t n, SolverScalars *sc, Parts rr1, int par, const double *t, double *p, double *ppout) {
+    hipLaunchKernelGGL(cgne_n3b_kernel, dim3(vec_grid(n)), dim3(kBlock), 0, c->stream, n, sc, rr1, par, t, p, ppout);
+    SLA_HIP_TRY(hipGetLastError());
+    return SLA_OK;
+}
+
 int launch_cgne_n2(sla_ctx *c, int64_t n, SolverScalars *sc, const double *p, double *x) {
     hipLaunchKernelGGL(cgne_n2_kernel, dim3(vec_grid(n)), dim3(kBlock), 0, c->stream, n, sc, p, x);
     SLA_HIP_TRY(hipGetLastError());

@@ -56,6 +56,7 @@ int solver_alloc(sla_csr *A, int method, sla_solver **out) {
     mk(nr, &S->b);
     if (method == SLA_CGS_) mk(nr, &S->u);
     if (method != SLA_CGNE_) { mk(nr, &S->t1); mk(nr, &S->t2); mk(nr, &S->t3); }
+    else if (c->collectives) mk(nx, &S->t1);  // CGNE, row-sharded: landing buffer of the reduce-scattered A^T r
     hipError_t e = hipSuccess;
     if (rc == SLA_OK) e = hipMalloc((void **)&S->d_parts, sizeof(double) * P_SLOTS * kMaxParts);
     if (rc == SLA_OK && e == hipSuccess) e = hipMalloc((void **)&S->d_gath, sizeof(double) * ((size_t)P_SLOTS * 2 * c->nranks + 8));
@@ -189,6 +190,7 @@ int enqueue_cgne(sla_solver *S, int par, const Parts *check, StepCtl *ctl) {
     sla_csr *A = S->A, *T = nullptr;
     SLA_TRY(csr_transposed(A, &T));
     Parts rr1;
+    const bool sharded = c->collectives;
     {
         SpmvLaunch l;  // N1: alphai = (r.r)/(p.p) ; r1 = r ^-^ alphai .* (aa #> p) ; r1 . r1
         l.epi = EPI_AXPY_DOT;
@@ -207,7 +209,12 @@ int enqueue_cgne(sla_solver *S, int par, const Parts *check, StepCtl *ctl) {
         SLA_TRY(publish(S, P_RHO, -1, spmv_grid(A), &rr1, nullptr));
     }
     SLA_TRY(launch_cgne_n2(c, S->x->n_local, S->d_sc, S->p->d, S->x->d));  // x1 = x ^+^ alphai .* p
-    {
+    if (sharded) {
+        // N3 unfused: t = transpose aa #> r1 (local partial + reduce-scatter), then p1 = t ^+^ beta .* p ; p1 . p1
+        SLA_TRY(spmv_transposed(A, S->r->d, S->t1->d, S->t1->shard));
+        SLA_TRY(launch_cgne_n3b(c, S->p->n_local, S->d_sc, rr1, par, S->t1->d, S->p->d, slot(S, P_ASS)));
+        SLA_TRY(publish(S, P_ASS, -1, vec_grid(S->p->n_local), &ctl->pp, nullptr));
+    } else {
         SpmvLaunch l;  // N3: beta = (r1.r1)/(r.r) ; p1 = transpose aa #> r1 ^+^ beta .* p ; p1 . p1
         l.epi = EPI_XPBY_NRM;
         SLA_TRY(gather_x(S->A, S->r, &l.x));
@@ -288,12 +295,8 @@ int solver_init_common(int method, sla_csr *A, sla_vec *b, sla_vec *x0, double t
         if ((rc = launch_spmv(A, l)) != SLA_OK) break;
         if ((rc = sla_vec_copy(S->r, S->r0hat)) != SLA_OK) break;
         if (method == SLA_CGNE_) {
-            sla_csr *T = nullptr;
-            if ((rc = csr_transposed(A, &T)) != SLA_OK) break;
-            SpmvLaunch lt;  // p0 = transposeSM aa #> r0
-            if ((rc = gather_x(S->A, S->r, &lt.x)) != SLA_OK) break;
-            lt.y = S->p->d;
-            if ((rc = launch_spmv(T, lt)) != SLA_OK) break;
+            // p0 = transposeSM aa #> r0
+            if ((rc = spmv_transposed(A, S->r->d, S->p->d, S->p->shard)) != SLA_OK) break;
             if ((rc = launch_dot(c, S->p->n_local, S->p->d, S->p->d, slot(S, P_ASS))) != SLA_OK) break;
             if ((rc = publish(S, P_ASS, -1, vec_grid(S->p->n_local), &ctl_of(S).pp, nullptr)) != SLA_OK) break;
         } else {

@@ -126,6 +126,13 @@ def main():
     p = r + beta * (p - omega * ap)
     assert np.allclose(x, so.x[b:e], rtol=1e-12, atol=1e-13)
     assert np.allclose(p, so.p[b:e], rtol=1e-10, atol=1e-12)
+    # sharded transpose SpMV (CGNE, <#): local transposed block -> full-length partial -> sum over ranks -> own shard
+    wv = rng.standard_normal(n)
+    tl = orc.transpose(loc)                                        # n rows, columns = local row ids
+    partial = torch.from_numpy(orc.spmv(tl, wv[b:e]))
+    dist.all_reduce(partial)                                       # (the library reduce-scatters; the shard is the same)
+    ref_t = orc.spmv(orc.transpose(full), wv)
+    assert np.allclose(partial.numpy()[b:e], ref_t[b:e], rtol=1e-13, atol=1e-13)
     dist.barrier()
     if rank == 0:
         print("DIST_OK", P)

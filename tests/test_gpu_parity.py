@@ -407,7 +407,7 @@ def test_forced_collectives_match_single_gpu_path(sla, monkeypatch):
     dims, (rp, ci, va) = wl.poisson2d(50, 40)
     n = dims[0]
     b = np.add.reduceat(va, rp[:-1])
-    outs = []
+    outs, cgne = [], []
     for c in (ctx, sla.default_context()):
         A = sla.fromCSRRows(dims, 0, rp, ci, va, c)
         bv, x0 = sla.fromVector(b, c), sla.fromVector(np.zeros(n), c)
@@ -416,9 +416,17 @@ def test_forced_collectives_match_single_gpu_path(sla, monkeypatch):
         Q, H = sla.arnoldi(A, bv, 6)
         xg, infog = sla.gmres(A, bv, x0, restart=20, return_info=True)
         outs.append((x.toDenseListSV(), info["iters"], xc.toDenseListSV(), infoc["iters"], H, xg.toDenseListSV(),
-                     sla.dot(bv, bv), sla.matVec(A, bv).toDenseListSV()))
+                     sla.dot(bv, bv), sla.matVec(A, bv).toDenseListSV(), sla.vecMat(bv, A).toDenseListSV()))
+        # CGNE, sharded: partial A^T r + reduce-scatter, unfused N3 (well-conditioned system so that it converges)
+        d2, (rp2, ci2, va2) = wl.random_spd(600, 3, 9)
+        A2 = sla.fromCSRRows(d2, 0, rp2, ci2, va2, c)
+        b2 = sla.fromVector(np.add.reduceat(va2, rp2[:-1]), c)
+        xn, infon = sla.linSolve0(sla.CGNE_, A2, b2, sla.fromVector(np.zeros(600), c), return_info=True)
+        cgne.append((xn.toDenseListSV(), infon["iters"], infon["converged"]))
     for a, b_ in zip(*outs):
         assert np.array_equal(a, b_)          # per-rank folding + rank-order sum == the 1-GPU reduction order
+    assert cgne[0][2] and cgne[1][2] and abs(cgne[0][1] - cgne[1][1]) <= 1
+    assert np.linalg.norm(cgne[0][0] - cgne[1][0]) <= 1e-6 * np.linalg.norm(cgne[1][0])
     ctx.close()
 
 
