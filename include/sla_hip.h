@@ -123,6 +123,13 @@ int sla_csr_from_csr_rows(sla_ctx_t, int64_t m, int64_t n, int64_t row_begin, in
  * expansion; `matrix array` files give dense vectors (right-hand sides). */
 int sla_csr_from_matrix_market(sla_ctx_t, const char *path, int dup_policy, sla_csr_t *out);
 int sla_vec_from_matrix_market(sla_ctx_t, const char *path, sla_vec_t *out);
+/* jacobiPre x = recip <$> extractDiag x (Sparse.hs:689-690): the diagonal matrix of reciprocal diagonal
+ * entries (rows without a stored diagonal entry stay empty).  Single-rank contexts. */
+int sla_jacobi_pre(sla_csr_t A, sla_csr_t *out);
+/* D #~# A for a DIAGONAL left factor D (matMatSparsified, SpMatrix.hs:816-824, restricted to the case the
+ * preconditioners need): row i of the result is d_ii * row i of A, entries with |x| <= 1e-12 dropped, rows
+ * without a D entry dropped.  `jacobiPre aa #~# aa` is the left-Jacobi-preconditioned operator. */
+int sla_csr_diag_mul(sla_csr_t D, sla_csr_t A, sla_csr_t *out);
 int sla_csr_destroy(sla_csr_t);
 /* dim / nnz of SpMatrix (local_rows/local_nnz = this rank's block) */
 int sla_csr_dims(sla_csr_t, int64_t *m, int64_t *n, int64_t *nnz_local, int64_t *rows_local);

@@ -531,6 +531,65 @@ int sla_csr_from_csr_rows(sla_ctx_t c, int64_t m, int64_t n, int64_t row_begin, 
     return csr_upload(c, m, n, row_begin, row_count, rowptr_local, colidx, val, out);
 }
 
+static int export_host(sla_csr_t A, HostCsr &h) {
+    h.m = A->m;
+    h.n = A->n;
+    h.rowptr.resize((size_t)A->rows + 1);
+    h.col.resize((size_t)A->nnz);
+    h.val.resize((size_t)A->nnz);
+    return sla_csr_export(A, h.rowptr.data(), h.col.data(), h.val.data());
+}
+
+int sla_jacobi_pre(sla_csr_t A, sla_csr_t *out) {
+    if (!A || !out) return fail(SLA_ERR_INVALID, "null argument");
+    if (A->ctx->collectives) return fail(SLA_ERR_INVALID, "sla_jacobi_pre: single-rank contexts only");
+    HostCsr h, d;
+    SLA_TRY(export_host(A, h));
+    d.m = A->m;
+    d.n = A->n;
+    d.rowptr.assign((size_t)A->m + 1, 0);
+    for (int64_t i = 0; i < A->m; ++i) {  // extractDiag keeps (i,i) where stored; fmap recip
+        for (int64_t k = h.rowptr[(size_t)i]; k < h.rowptr[(size_t)i + 1]; ++k)
+            if (h.col[(size_t)k] == i) {
+                d.col.push_back(i);
+                d.val.push_back(1.0 / h.val[(size_t)k]);
+            }
+        d.rowptr[(size_t)i + 1] = (int64_t)d.col.size();
+    }
+    return csr_upload(A->ctx, d.m, d.n, 0, d.m, d.rowptr.data(), d.col.data(), d.val.data(), out);
+}
+
+int sla_csr_diag_mul(sla_csr_t D, sla_csr_t A, sla_csr_t *out) {
+    if (!D || !A || !out) return fail(SLA_ERR_INVALID, "null argument");
+    if (D->ctx != A->ctx || A->ctx->collectives) return fail(SLA_ERR_INVALID, "sla_csr_diag_mul: one single-rank context");
+    if (D->n != A->m) return fail(SLA_ERR_DIM_MISMATCH, "matMat : incompatible matrix sizes");  // SpMatrix.hs:795
+    HostCsr hd, ha, r;
+    SLA_TRY(export_host(D, hd));
+    SLA_TRY(export_host(A, ha));
+    for (int64_t i = 0; i < D->m; ++i) {
+        const int64_t len = hd.rowptr[(size_t)i + 1] - hd.rowptr[(size_t)i];
+        if (len > 1 || (len == 1 && hd.col[(size_t)hd.rowptr[(size_t)i]] != i))
+            return fail(SLA_ERR_INVALID, "sla_csr_diag_mul: the left factor must be diagonal");
+    }
+    r.m = D->m;
+    r.n = A->n;
+    r.rowptr.assign((size_t)D->m + 1, 0);
+    for (int64_t i = 0; i < D->m; ++i) {
+        if (hd.rowptr[(size_t)i + 1] > hd.rowptr[(size_t)i]) {
+            const double dii = hd.val[(size_t)hd.rowptr[(size_t)i]];
+            for (int64_t k = ha.rowptr[(size_t)i]; k < ha.rowptr[(size_t)i + 1]; ++k) {
+                const double x = 0.0 + ha.val[(size_t)k] * dii;  // dott: sum (liftI2 (*) colA rowD), one term
+                if (fabs(x) > 1e-12) {                           // sparsifySM (Eps.hs:41-42)
+                    r.col.push_back(ha.col[(size_t)k]);
+                    r.val.push_back(x);
+                }
+            }
+        }
+        r.rowptr[(size_t)i + 1] = (int64_t)r.col.size();
+    }
+    return csr_upload(A->ctx, r.m, r.n, 0, r.m, r.rowptr.data(), r.col.data(), r.val.data(), out);
+}
+
 int sla_csr_destroy(sla_csr_t A) {
     if (!A) return SLA_OK;
     if (A->transposed) sla_csr_destroy(A->transposed);

@@ -70,6 +70,8 @@ PROTOTYPES = [
     ("sla_csr_from_csr_rows", _int, [_vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _pp]),
     ("sla_csr_from_matrix_market", _int, [_vp, C.c_char_p, _int, _pp]),
     ("sla_vec_from_matrix_market", _int, [_vp, C.c_char_p, _pp]),
+    ("sla_jacobi_pre", _int, [_vp, _pp]),
+    ("sla_csr_diag_mul", _int, [_vp, _vp, _pp]),
     ("sla_csr_destroy", _int, [_vp]),
     ("sla_csr_dims", _int, [_vp, _pi64, _pi64, _pi64, _pi64]),
     ("sla_csr_export", _int, [_vp, _vp, _vp, _vp]),

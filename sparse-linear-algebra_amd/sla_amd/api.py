@@ -399,6 +399,21 @@ def sparsifySM(A):
     return fromListSM(A.dims, t, A.ctx)
 
 
+def jacobiPre(A):
+    """jacobiPre x = recip <$> extractDiag x (Sparse.hs:689-690)."""
+    h = C.c_void_p()
+    check(lib().sla_jacobi_pre(A.h, C.byref(h)))
+    return SpMatrix(A.dims, h, A.ctx)
+
+
+def diagMatMatSparsified(D, A):
+    """D #~# A for a diagonal D (matMatSparsified, SpMatrix.hs:816-824): the left-preconditioned operator
+    `jacobiPre aa #~# aa` without a general SpGEMM."""
+    h = C.c_void_p()
+    check(lib().sla_csr_diag_mul(D.h, A.h, C.byref(h)))
+    return SpMatrix((D.nrows, A.ncols), h, A.ctx)
+
+
 def transpose(A):
     """transposeSM (SpMatrix.hs:717)."""
     return fromListSM((A.ncols, A.nrows), [(j, i, x) for (i, j, x) in A.toListSM()[::-1]], A.ctx)

@@ -449,3 +449,32 @@ def test_matrix_market_ingestion_e05r0000(sla):
         sla.readMatrixMarket(f"{GOLDEN}/does_not_exist.mtx")
     with pytest.raises(sla.SlaError):
         sla.readMatrixMarket(f"{GOLDEN}/e05r0000_rhs1.mtx")      # an array file is not a coordinate matrix
+
+
+def test_jacobi_preconditioner_builders(sla):
+    # jacobiPre (Sparse.hs:689-690) and the diagonal #~# that applies it: M = recip <$> extractDiag A
+    from sla_amd import workloads as wl
+    dims, (rp, ci, va) = wl.banded_nonsym(3000)
+    n = dims[0]
+    A, Ao = sla.fromCSR(dims, rp, ci, va), orc.Csr(n, n, rp, ci, va)
+    M = sla.jacobiPre(A)
+    assert M.isDiagonalSM()
+    diag = np.array([va[rp[i]:rp[i + 1]][ci[rp[i]:rp[i + 1]] == i][0] for i in range(n)])
+    assert np.array_equal(M.csr()[2], 1.0 / diag)
+    MA = sla.diagMatMatSparsified(M, A)
+    rc, Mo = orc.coo_to_csr(n, n, np.arange(n), np.arange(n), 1.0 / diag)
+    rc, Co = orc.matmat(Mo, Ao)                                  # (##) in the oracle, then sparsify
+    keep = np.abs(Co.val) > 1e-12
+    rows_o = np.repeat(np.arange(n), np.diff(Co.rowptr))[keep]
+    rpm, cim, vam = MA.csr()
+    assert np.array_equal(cim, Co.colidx[keep]) and np.array_equal(vam, Co.val[keep])
+    assert np.array_equal(np.repeat(np.arange(n), np.diff(rpm)), rows_o)
+    # left-preconditioned solve converges at least as fast on this diagonally dominant system
+    b = orc.spmv(Ao, np.ones(n))
+    x, info = sla.linSolve0(sla.BICGSTAB_, A, sla.fromVector(b), sla.fromVector(np.zeros(n)), return_info=True)
+    xp, infop = sla.linSolve0(sla.BICGSTAB_, MA, sla.matVec(M, sla.fromVector(b)), sla.fromVector(np.zeros(n)), return_info=True)
+    assert info["converged"] and infop["converged"] and infop["iters"] <= info["iters"] + 1
+    assert np.abs(xp.toDenseListSV() - 1.0).max() <= 5e-3                 # linSolve0 stops at 1e-4 * ||r0||
+    S = sla.fromListSM((2, 2), [(0, 0, 2.0), (0, 1, 1.0), (1, 1, 4.0)])
+    with pytest.raises(sla.SlaError):
+        sla.diagMatMatSparsified(S, S)                            # left factor not diagonal
