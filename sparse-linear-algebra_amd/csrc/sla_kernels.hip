@@ -1394,11 +1394,11 @@ __global__ void __launch_bounds__(kBlock) dot_kernel(int64_t n, const double *x,
     if (threadIdx.x == 0) p1[blockIdx.x] = s;
 }
 
-// out[j] = sum_i parts[j * cs + i * stride], j < ncols; one workgroup
+// out[j] = sum_i parts[j * cs + i * stride], j < ncols; one workgroup per column (grid-stride over columns)
 __global__ void __launch_bounds__(kBlock) finalize_kernel(const double *parts, int np, int cs, int stride, int ncols,
                                                            double *out) {
     __shared__ double s_red[4];
-    for (int j = 0; j < ncols; ++j) {
+    for (int j = blockIdx.x; j < ncols; j += gridDim.x) {
         const double s = reduce_parts(parts + (int64_t)j * cs, np, stride, s_red);
         if (threadIdx.x == 0) out[j] = s;
     }
@@ -1444,7 +1444,7 @@ int launch_finalize(sla_ctx *c, const double *p1, const double *p2, int np, doub
     return SLA_OK;
 }
 int launch_finalize_cols(sla_ctx *c, const double *parts, int np, int cs, int stride, int ncols, double *out) {
-    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(kBlock), 0, c->stream, parts, np, cs, stride, ncols, out);
+    hipLaunchKernelGGL(finalize_kernel, dim3(ncols > 0 ? ncols : 1), dim3(kBlock), 0, c->stream, parts, np, cs, stride, ncols, out);
     SLA_HIP_TRY(hipGetLastError());
     return SLA_OK;
 }
