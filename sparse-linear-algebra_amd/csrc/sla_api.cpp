@@ -215,7 +215,7 @@ static int csr_upload(sla_ctx *c, int64_t m, int64_t n, int64_t row_begin, int64
     A->nnz = nnz;
     A->rp64 = nnz > (int64_t)std::numeric_limits<int32_t>::max();
     std::vector<int32_t> rb;
-    build_row_blocks(rows, rowptr, rb, A->max_row_nnz, c->row_align);
+    build_row_blocks(rows, rowptr, rb, A->max_row_nnz, c->row_align, c->rb_nnz);
     A->nrb = (int32_t)rb.size() - 1;
     int diag_not = host_is_diagonal(rows, row_begin, rowptr, col) ? 0 : 1;
     if (m != n && rows > 0) { /* isDiagonalSM only counts (i,i) entries; nothing extra to do */ }
@@ -406,6 +406,7 @@ static int ctx_create_common(int device_id, int rank, int nranks, const void *ui
     if (const char *s = getenv("SLA_PANELS")) c->panels = atoi(s);
     if (const char *s = getenv("SLA_PANEL_COLS")) c->panel_cols = atoll(s);
     if (const char *s = getenv("SLA_ROW_ALIGN")) c->row_align = atoi(s);
+    if (const char *s = getenv("SLA_RB_NNZ")) c->rb_nnz = atoi(s);
     if (const char *s = getenv("SLA_DEVICE_COO_MIN")) c->device_coo_min = atoll(s);
     if (const char *s = getenv("SLA_X_EXCHANGE")) c->x_exchange = strcmp(s, "allgather") == 0 ? 1 : (strcmp(s, "window") == 0 ? 2 : 0);
     if (const char *s = getenv("SLA_SPMV_GRID")) {

@@ -85,7 +85,9 @@ bool host_is_diagonal(int64_t rows, int64_t row_begin, const int64_t *rowptr, co
 // Greedy row blocks for the CSR-stream kernel: <= kNnzPerRowBlock entries and <= kMaxRowsPerRowBlock
 // rows per block; rows longer than kNnzPerRowBlock form blocks of up to 4 such rows (<= kWaveRowMax
 // entries each) or a block of their own (longer still).
-void build_row_blocks(int64_t rows, const int64_t *rowptr, std::vector<int32_t> &rb, int64_t &max_row_nnz, int row_align) {
+void build_row_blocks(int64_t rows, const int64_t *rowptr, std::vector<int32_t> &rb, int64_t &max_row_nnz, int row_align,
+                      int nnz_target) {
+    if (nnz_target <= 0 || nnz_target > kNnzPerRowBlock) nnz_target = kNnzPerRowBlock;
     rb.clear();
     rb.push_back(0);
     max_row_nnz = 0;
@@ -95,7 +97,7 @@ void build_row_blocks(int64_t rows, const int64_t *rowptr, std::vector<int32_t> 
         while (r < rows && r - r0 < kMaxRowsPerRowBlock) {
             const int64_t len = rowptr[r + 1] - rowptr[r];
             if (len > max_row_nnz) max_row_nnz = len;
-            if (cnt + len > kNnzPerRowBlock) break;
+            if (cnt + len > (r == r0 ? kNnzPerRowBlock : nnz_target)) break;  // a single row may use the whole stage
             cnt += len;
             ++r;
         }

@@ -107,6 +107,7 @@ struct sla_ctx {
     int spmv_algo = 0;               // 0 stream, 1 scalar (SLA_SPMV_ALGO)
     int xcd_remap = 1;               // SLA_XCD_REMAP
     int64_t device_coo_min = 1 << 20; // triple lists at least this long are sorted on the GPU (SLA_DEVICE_COO_MIN)
+    int rb_nnz = 0;                  // 0: automatic row-block size (SLA_RB_NNZ overrides, <= 1024)
     int row_align = 0;               // > 1: row blocks end on multiples of this many rows (SLA_ROW_ALIGN; measured -1.5 % at 16)
     int panels = 1;                  // allow the column-panel SpMV for irregular matrices (SLA_PANELS=0 disables)
     int64_t panel_cols = 384 * 1024; // panel width in columns (SLA_PANEL_COLS): 3 MiB of x per pass
@@ -219,7 +220,8 @@ bool device_coo_supported(int64_t m, int64_t n, int64_t nnz);
 int device_coo_to_csr(sla_ctx *c, int64_t m, int64_t n, int64_t nnz, const int64_t *row, const int64_t *col,
                       const double *val, int dup_policy, HostCsr &out);
 bool host_is_diagonal(int64_t rows, int64_t row_begin, const int64_t *rowptr, const int64_t *col);
-void build_row_blocks(int64_t rows, const int64_t *rowptr, std::vector<int32_t> &rb, int64_t &max_row_nnz, int row_align);
+void build_row_blocks(int64_t rows, const int64_t *rowptr, std::vector<int32_t> &rb, int64_t &max_row_nnz, int row_align,
+                      int nnz_target);
 
 // distributed plumbing (sla_dist.cpp) ---------------------------------------------------------------
 int dist_unique_id(void *out128);
