@@ -96,6 +96,11 @@ int sla_ctx_create(int device_id, sla_ctx_t *out);
  * sla_dist_unique_id on rank 0 and distributed out of band (bench.py uses torch.distributed). */
 int sla_dist_unique_id(void *unique_id_128);
 int sla_ctx_create_dist(int device_id, int rank, int nranks, const void *unique_id_128, sla_ctx_t *out);
+/* TEST BACKEND: rank `rank` of an in-process loopback group -- every rank is a host thread of one process,
+ * all on `device_id`; collectives are device copies behind host barriers.  It runs the real row-sharded code
+ * path (row offsets, exchange plan, rank-ordered sums, reduce-scatter layout) with nranks > 1 on a 1-GPU box,
+ * where RCCL refuses two ranks per GPU.  Contexts that pass the same group_key form one group. */
+int sla_ctx_create_loopback(int device_id, int rank, int nranks, int group_key, sla_ctx_t *out);
 int sla_ctx_destroy(sla_ctx_t);
 int sla_ctx_sync(sla_ctx_t);  /* hipStreamSynchronize of the context stream */
 int sla_ctx_rank(sla_ctx_t, int *rank, int *nranks);

@@ -438,6 +438,18 @@ int sla_ctx_create_dist(int device_id, int rank, int nranks, const void *unique_
     return ctx_create_common(device_id, rank, nranks, unique_id_128, out);
 }
 
+int sla_ctx_create_loopback(int device_id, int rank, int nranks, int group_key, sla_ctx_t *out) {
+    SLA_TRY(ctx_create_common(device_id, rank, nranks, nullptr, out));
+    int rc = dist_loopback_join(*out, group_key);
+    if (rc != SLA_OK) {
+        sla_ctx_destroy(*out);
+        *out = nullptr;
+        return rc;
+    }
+    (*out)->collectives = true;
+    return SLA_OK;
+}
+
 int sla_ctx_destroy(sla_ctx_t c) {
     if (!c) return SLA_OK;
     (void)hipSetDevice(c->device);

@@ -11,7 +11,10 @@
 #include <string.h>
 
 #include <algorithm>
+#include <condition_variable>
+#include <map>
 #include <mutex>
+#include <vector>
 
 #include "sla_internal.hpp"
 
@@ -77,6 +80,37 @@ Rccl &rccl() {
     return r;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Loopback "communicator" (TEST BACKEND): all ranks are host threads of ONE process driving contexts on ONE
+// GPU; a collective = publish my pointer, barrier, copy what I need out of my peers' buffers, barrier.  Slow,
+// but it runs the real sharded code path (row offsets, window exchange plan, rank-ordered sums,
+// reduce-scatter layout) with P > 1 on a single-GPU box, where RCCL refuses to place two ranks.
+// ---------------------------------------------------------------------------------------------------------
+struct LoopGroup {
+    int nranks = 0, joined = 0, left = 0;
+    std::mutex mu;
+    std::condition_variable cv;
+    int waiting = 0;
+    uint64_t generation = 0;
+    std::vector<const void *> ptr;
+    std::vector<int64_t> aux;
+    void barrier() {
+        std::unique_lock<std::mutex> lk(mu);
+        const uint64_t gen = generation;
+        if (++waiting == nranks) {
+            waiting = 0;
+            ++generation;
+            cv.notify_all();
+        } else {
+            cv.wait(lk, [&] { return generation != gen; });
+        }
+    }
+};
+std::mutex g_loop_mu;
+std::map<int, LoopGroup *> g_loop_groups;
+
+LoopGroup *loop_of(sla_ctx *c) { return (LoopGroup *)c->loop; }
+
 int rccl_fail(const char *what, int rc) {
     Rccl &r = rccl();
     std::string msg = std::string(what) + " failed";
@@ -107,7 +141,32 @@ int dist_comm_init(sla_ctx *ctx, const void *unique_id) {
     return SLA_OK;
 }
 
+int dist_loopback_join(sla_ctx *ctx, int group_key) {
+    std::lock_guard<std::mutex> lk(g_loop_mu);
+    LoopGroup *&g = g_loop_groups[group_key];
+    if (!g) {
+        g = new LoopGroup();
+        g->nranks = ctx->nranks;
+        g->ptr.assign((size_t)ctx->nranks, nullptr);
+        g->aux.assign((size_t)ctx->nranks, 0);
+    }
+    if (g->nranks != ctx->nranks) return fail(SLA_ERR_INVALID, "loopback group joined with a different nranks");
+    g->joined++;
+    ctx->loop = g;
+    return SLA_OK;
+}
+
 int dist_comm_destroy(sla_ctx *ctx) {
+    if (ctx->loop) {
+        std::lock_guard<std::mutex> lk(g_loop_mu);
+        LoopGroup *g = (LoopGroup *)ctx->loop;
+        if (++g->left == g->nranks) {
+            for (auto it = g_loop_groups.begin(); it != g_loop_groups.end(); ++it)
+                if (it->second == g) { g_loop_groups.erase(it); break; }
+            delete g;
+        }
+        ctx->loop = nullptr;
+    }
     if (ctx->comm) {
         rccl().comm_destroy((NcclComm)ctx->comm);
         ctx->comm = nullptr;
@@ -116,6 +175,17 @@ int dist_comm_destroy(sla_ctx *ctx) {
 }
 
 int dist_allgather_f64(sla_ctx *ctx, const double *send, double *recv, int64_t count) {
+    if (LoopGroup *g = loop_of(ctx)) {
+        SLA_HIP_TRY(hipStreamSynchronize(ctx->stream));
+        g->ptr[(size_t)ctx->rank] = send;
+        g->barrier();
+        for (int q = 0; q < ctx->nranks; ++q)
+            SLA_HIP_TRY(hipMemcpyAsync(recv + (size_t)q * (size_t)count, g->ptr[(size_t)q], sizeof(double) * (size_t)count,
+                                       hipMemcpyDeviceToDevice, ctx->stream));
+        SLA_HIP_TRY(hipStreamSynchronize(ctx->stream));
+        g->barrier();
+        return SLA_OK;
+    }
     if (!ctx->comm) return fail(SLA_ERR_RCCL, "all-gather requested on a context without a communicator");
     int rc = rccl().all_gather(send, recv, (size_t)count, kNcclFloat64, (NcclComm)ctx->comm, ctx->stream);
     if (rc != 0) return rccl_fail("ncclAllGather", rc);
@@ -124,6 +194,20 @@ int dist_allgather_f64(sla_ctx *ctx, const double *send, double *recv, int64_t c
 
 // sum over ranks of full-length partial vectors, each rank keeping its shard (sharded transpose SpMV)
 int dist_reduce_scatter_f64(sla_ctx *ctx, const double *send, double *recv, int64_t recvcount) {
+    if (LoopGroup *g = loop_of(ctx)) {
+        SLA_HIP_TRY(hipStreamSynchronize(ctx->stream));
+        g->ptr[(size_t)ctx->rank] = send;
+        g->barrier();
+        std::vector<double> acc((size_t)recvcount, 0.0), tmp((size_t)recvcount);
+        for (int q = 0; q < ctx->nranks; ++q) {  // rank-ordered sum of the peers' segments for my shard
+            SLA_HIP_TRY(hipMemcpy(tmp.data(), (const double *)g->ptr[(size_t)q] + (size_t)ctx->rank * (size_t)recvcount,
+                                  sizeof(double) * (size_t)recvcount, hipMemcpyDeviceToHost));
+            for (size_t i = 0; i < acc.size(); ++i) acc[i] += tmp[i];
+        }
+        SLA_HIP_TRY(hipMemcpy(recv, acc.data(), sizeof(double) * (size_t)recvcount, hipMemcpyHostToDevice));
+        g->barrier();
+        return SLA_OK;
+    }
     Rccl &r = rccl();
     if (!ctx->comm || !r.reduce_scatter) return fail(SLA_ERR_RCCL, "reduce-scatter requested without a communicator");
     int rc = r.reduce_scatter(send, recv, (size_t)recvcount, kNcclFloat64, 0 /* ncclSum */, (NcclComm)ctx->comm, ctx->stream);
@@ -136,6 +220,23 @@ int dist_reduce_scatter_f64(sla_ctx *ctx, const double *send, double *recv, int6
 // its own shard in place.  For a slab-partitioned stencil this is two plane-sized messages per SpMV
 // instead of an all-gather of the whole vector.
 int dist_exchange_window(sla_ctx *ctx, const XPlan &plan, const double *xlocal, int64_t my_begin, int64_t n_local, double *xfull) {
+    if (LoopGroup *g = loop_of(ctx)) {
+        SLA_HIP_TRY(hipStreamSynchronize(ctx->stream));
+        g->ptr[(size_t)ctx->rank] = xlocal;
+        g->aux[(size_t)ctx->rank] = my_begin;
+        g->barrier();
+        if (n_local > 0)
+            SLA_HIP_TRY(hipMemcpyAsync(xfull + my_begin, xlocal, sizeof(double) * (size_t)n_local, hipMemcpyDeviceToDevice, ctx->stream));
+        for (int q = 0; q < ctx->nranks; ++q) {
+            if (q == ctx->rank || plan.recv_len[(size_t)q] <= 0) continue;
+            const double *src = (const double *)g->ptr[(size_t)q] + (plan.recv_begin[(size_t)q] - g->aux[(size_t)q]);
+            SLA_HIP_TRY(hipMemcpyAsync(xfull + plan.recv_begin[(size_t)q], src, sizeof(double) * (size_t)plan.recv_len[(size_t)q],
+                                       hipMemcpyDeviceToDevice, ctx->stream));
+        }
+        SLA_HIP_TRY(hipStreamSynchronize(ctx->stream));
+        g->barrier();
+        return SLA_OK;
+    }
     Rccl &r = rccl();
     if (!ctx->comm) return fail(SLA_ERR_RCCL, "window exchange requested on a context without a communicator");
     if (!r.send || !r.recv || !r.group_start || !r.group_end) return fail(SLA_ERR_RCCL, "librccl lacks ncclSend/ncclRecv");
@@ -192,6 +293,15 @@ void plan_window_exchange(int nranks, int rank, int64_t n, const int64_t *window
 
 // max over ranks of a host int (used for the global isDiagonalSM / method agreement); synchronises
 int dist_allreduce_max_i32(sla_ctx *ctx, int *value_host) {
+    if (LoopGroup *g = loop_of(ctx)) {
+        g->aux[(size_t)ctx->rank] = *value_host;
+        g->barrier();
+        int mx = *value_host;
+        for (int q = 0; q < ctx->nranks; ++q) mx = std::max<int>(mx, (int)g->aux[(size_t)q]);
+        g->barrier();
+        *value_host = mx;
+        return SLA_OK;
+    }
     if (!ctx->collectives || !ctx->comm) return SLA_OK;
     int *d = (int *)ctx->d_result;
     SLA_HIP_TRY(hipMemcpyAsync(d, value_host, sizeof(int), hipMemcpyHostToDevice, ctx->stream));

@@ -97,6 +97,7 @@ struct sla_ctx {
     int device = 0, rank = 0, nranks = 1;
     hipStream_t stream = nullptr;
     void *comm = nullptr;            // ncclComm_t when nranks > 1 (or a 1-rank test comm)
+    void *loop = nullptr;            // in-process loopback group (test backend: all ranks are threads on one GPU)
     double *d_parts = nullptr;       // 4 * kMaxParts doubles of scratch partials
     double *d_result = nullptr;      // small device scratch for scalar results / per-rank sums
     double *h_result = nullptr;      // pinned host mirror
@@ -227,6 +228,7 @@ void build_row_blocks(int64_t rows, const int64_t *rowptr, std::vector<int32_t> 
 int dist_unique_id(void *out128);
 int dist_comm_init(sla_ctx *ctx, const void *unique_id);
 int dist_comm_destroy(sla_ctx *ctx);
+int dist_loopback_join(sla_ctx *ctx, int group_key);
 int dist_allgather_f64(sla_ctx *ctx, const double *send, double *recv, int64_t count);
 int dist_reduce_scatter_f64(sla_ctx *ctx, const double *send, double *recv, int64_t recvcount);
 int dist_exchange_window(sla_ctx *ctx, const XPlan &plan, const double *xlocal, int64_t my_begin, int64_t n_local, double *xfull);

@@ -46,6 +46,15 @@ class Context:
             check(lib().sla_ctx_create_dist(device_id, rank, nranks, C.cast(buf, C.c_void_p), C.byref(self.h)))
         self.rank, self.nranks = rank, nranks
 
+    @classmethod
+    def loopback(cls, rank, nranks, group_key, device_id=0):
+        """TEST BACKEND: one rank (= one host thread) of an in-process group on a single GPU."""
+        self = cls.__new__(cls)
+        self.h = C.c_void_p()
+        check(lib().sla_ctx_create_loopback(device_id, rank, nranks, group_key, C.byref(self.h)))
+        self.rank, self.nranks = rank, nranks
+        return self
+
     @staticmethod
     def unique_id():
         buf = (C.c_char * 128)()

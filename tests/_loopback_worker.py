@@ -1,0 +1,127 @@
+"""Worker of tests/test_gpu_loopback.py: P ranks as P host threads on ONE GPU through the library's in-process
+loopback communicator (sla_ctx_create_loopback).  Runs the real row-sharded code path -- slabs with
+row_begin > 0, the window (halo) exchange plan, rank-ordered inner products, the reduce-scattered transpose --
+and compares with the single-GPU path and the oracle."""
+import ctypes as C
+import os
+import sys
+import threading
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "sparse-linear-algebra_amd")):
+    sys.path.insert(0, p)
+
+import sla_amd as sla  # noqa: E402
+from sla_amd import _lib, workloads as wl  # noqa: E402
+from oracle import oracle as orc  # noqa: E402
+
+P = int(sys.argv[1])
+KIND = sys.argv[2] if len(sys.argv) > 2 else "laplace"
+lib = _lib.lib()
+
+
+def gen(b=0, e=None):
+    if KIND == "laplace":
+        return wl.laplace3d(14, 11, 13, b, e)            # window exchange (slab stencil), dictionary codes
+    if KIND == "banded":
+        return wl.banded_nonsym(5003, 99, b, e)          # ragged last shard, non-symmetric
+    dims, (rp, ci, va) = wl.random_spd(2400, 4, 3)       # random columns: all-gather path
+    e = dims[0] if e is None else e
+    from sla_amd.partition import local_rows_of
+    return dims, local_rows_of(rp, ci, va, b, e)
+
+
+dims, (RP, CI, VA) = gen()
+n = dims[0]
+Ao = orc.Csr(n, n, RP, CI, VA)
+rng = np.random.default_rng(12)
+xg = rng.standard_normal(n)
+bg = orc.spmv(Ao, np.ones(n))
+results, errors = {}, []
+
+
+def solve(ctx, method, A, bvec, x0, **kw):
+    out = sla.DeviceVector(ctx, n)
+    info = _lib.SolveInfo()
+    o = _lib.SolveOpts(kw.get("max_iters", 200), 1e-6, 1e-4, kw.get("check_every", 16), 1)
+    _lib.check(lib.sla_linsolve0(int(method), A.h, bvec.h, x0.h, C.byref(o), out.h, C.byref(info)))
+    return out, info
+
+
+def rank_main(rank):
+    try:
+        ctx = sla.Context.loopback(rank, P, 4242)
+        b, e = ctx.row_range(n)
+        d, (rp, ci, va) = gen(b, e)
+        A = sla.fromCSRRows(d, b, rp, ci, va, ctx)
+        xv = sla.DeviceVector(ctx, n, xg[b:e], local=True)
+        yv = sla.DeviceVector(ctx, n)
+        _lib.check(lib.sla_spmv(A.h, xv.h, yv.h))
+        r = {"kernel": A.kernel_info(), "y": yv.to_host_local(), "range": (b, e)}
+        _lib.check(lib.sla_spmv_t(A.h, xv.h, yv.h))
+        r["yt"] = yv.to_host_local()
+        dd = C.c_double()
+        _lib.check(lib.sla_dot(xv.h, xv.h, C.byref(dd)))
+        r["dot"] = dd.value
+        r["full"] = yv.to_host()                                      # all-gathered copy on every rank
+        bvec = sla.DeviceVector(ctx, n, bg[b:e], local=True)
+        x0 = sla.DeviceVector(ctx, n)
+        for name, meth in (("bicgstab", sla.BICGSTAB_), ("cgs", sla.CGS_), ("cgne", sla.CGNE_)):
+            out, info = solve(ctx, meth, A, bvec, x0)
+            r[name] = (out.to_host_local(), info.iters, info.flags, info.resnorm)
+        Q = np.zeros((6 + 1) * (e - b))
+        H = np.zeros((6 + 1) * 6)
+        kd = C.c_int()
+        _lib.check(lib.sla_arnoldi(A.h, bvec.h, 6, C.c_void_p(Q.ctypes.data), C.c_void_p(H.ctypes.data), C.byref(kd)))
+        r["H"], r["k"] = H.copy(), kd.value
+        outg = sla.DeviceVector(ctx, n)
+        infog = _lib.SolveInfo()
+        _lib.check(lib.sla_gmres(A.h, bvec.h, x0.h, 20, None, outg.h, C.byref(infog)))
+        r["gmres"] = (outg.to_host_local(), infog.iters, infog.flags)
+        results[rank] = r
+        ctx.sync()
+    except Exception as ex:  # noqa: BLE001
+        errors.append((rank, repr(ex)))
+        os._exit(3)                                                   # the other ranks would wait forever
+
+
+threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(P)]
+for t in threads:
+    t.start()
+for t in threads:
+    t.join()
+assert not errors, errors
+
+cat = lambda key: np.concatenate([results[r][key] for r in range(P)])  # noqa: E731
+y = cat("y")
+yo = orc.spmv(Ao, xg)
+if KIND == "random":     # > 8 stored entries per row on average: wavefront-segmented sums, last-bit grouping differences
+    assert np.abs(y - yo).max() <= 4e-15 * np.abs(VA).max() * np.abs(xg).max() * 16, np.abs(y - yo).max()
+else:
+    assert np.array_equal(y, yo), "sharded (#>) must equal the whole-matrix left fold bit for bit"
+yt = cat("yt")
+assert np.allclose(yt, orc.spmv(orc.transpose(Ao), xg), rtol=1e-13, atol=1e-13)
+assert all(np.array_equal(results[r]["full"], yt) for r in range(P))
+assert all(results[r]["dot"] == results[0]["dot"] for r in range(P))            # rank-ordered sum: identical on all ranks
+assert abs(results[0]["dot"] - orc.dot(xg, xg)) <= 1e-12 * orc.dot(xg, xg)
+for name, ometh in (("bicgstab", orc.BICGSTAB_), ("cgs", orc.CGS_), ("cgne", orc.CGNE_)):
+    x = np.concatenate([results[r][name][0] for r in range(P)])
+    iters = {results[r][name][1] for r in range(P)}
+    assert len(iters) == 1, (name, iters)                                         # every rank took the same decisions
+    rc, xo, it_o, res_o, r0_o = orc.linsolve0(ometh, Ao, bg, np.zeros(n))
+    res = np.linalg.norm(orc.spmv(Ao, x) - bg)
+    if it_o >= 200:                                   # linSolve0 returns silently at 200 iterations (Sparse.hs:1069)
+        assert iters.pop() == 200 and (results[0][name][2] & 2) == 2, name
+        assert abs(res - res_o) <= 1e-3 * max(res_o, 1e-30) + 1e-9, (name, res, res_o)
+    else:
+        assert (results[0][name][2] & 1) == 1 and abs(iters.pop() - it_o) <= 3, (name, it_o)
+        assert res <= max(1e-6, 1e-4 * r0_o) * (1 + 1e-9)
+Hs = [results[r]["H"] for r in range(P)]
+assert all(np.array_equal(Hs[0], h) for h in Hs)
+rc, Qo, Ho, k = orc.arnoldi(Ao, bg, 6)
+assert results[0]["k"] == k and np.abs(Hs[0].reshape(6, 7).T[:k + 1, :k] - Ho).max() <= 1e-10 * np.abs(Ho).max()
+xgm = np.concatenate([results[r]["gmres"][0] for r in range(P)])
+assert (results[0]["gmres"][2] & 1) == 1 and np.linalg.norm(orc.spmv(Ao, xgm) - bg) <= 1e-4 * np.linalg.norm(bg) + 1e-6
+print("LOOPBACK_OK", P, KIND, results[0]["kernel"].split()[0])

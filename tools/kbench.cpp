@@ -68,6 +68,15 @@ __global__ void __launch_bounds__(256, 8) k_stream(const int32_t *col, const dou
                 for (int k = tid * 7; k < tid * 7 + 7; ++k) a += s_prod[buf][k];
                 acc += a;
                 if (MODE == 2) out[1024 + ch * 146 + tid] = a;   // y-like coalesced 8 B store
+                if (MODE == 3) __builtin_nontemporal_store(a, out + 1024 + ch * 146 + tid);   // same, non-temporal
+            }
+            if (MODE == 4) out[1024 + ch * 256 + tid] = acc;     // all 256 lanes, 2 KiB aligned per iteration
+            if (MODE == 5 && tid < 146) {                        // row sums staged in LDS, stored 16 B per lane
+                s_prod[buf][tid] = acc;
+            }
+            if (MODE == 5) {
+                __syncthreads();
+                if (tid < 73) reinterpret_cast<double2 *>(out + 1024 + ch * 146)[tid] = make_double2(s_prod[buf][2 * tid], s_prod[buf][2 * tid + 1]);
             }
             buf ^= 1;
         }
@@ -177,11 +186,14 @@ int main(int argc, char **argv) {
     }
     {   // raw stream micro-kernels on the matrix arrays themselves
         double *scratch;
-        hipMalloc(&scratch, sizeof(double) * (size_t)(n + 4096));
+        hipMalloc(&scratch, sizeof(double) * (size_t)(2 * n + 4096));
         const double sb = 12.0 * nnz;
         report("micro: col+val strided loads only", T.run([&] { hipLaunchKernelGGL(k_stream<0>, dim3(2048), dim3(256), 0, c->stream, A->d_col, A->d_val, nnz, scratch); }, 20), sb);
         report("micro: + LDS stage + barrier + row sums", T.run([&] { hipLaunchKernelGGL(k_stream<1>, dim3(2048), dim3(256), 0, c->stream, A->d_col, A->d_val, nnz, scratch); }, 20), sb);
         report("micro: + y store", T.run([&] { hipLaunchKernelGGL(k_stream<2>, dim3(2048), dim3(256), 0, c->stream, A->d_col, A->d_val, nnz, scratch); }, 20), sb + 8.0 * (nnz / 7.0));
+        report("micro: + y store, non-temporal", T.run([&] { hipLaunchKernelGGL(k_stream<3>, dim3(2048), dim3(256), 0, c->stream, A->d_col, A->d_val, nnz, scratch); }, 20), sb + 8.0 * (nnz / 7.0));
+        report("micro: + 256-lane aligned store", T.run([&] { hipLaunchKernelGGL(k_stream<4>, dim3(2048), dim3(256), 0, c->stream, A->d_col, A->d_val, nnz, scratch); }, 20), sb + 8.0 * 256 * (nnz / 1024.0));
+        report("micro: + y store 16 B/lane via LDS", T.run([&] { hipLaunchKernelGGL(k_stream<5>, dim3(2048), dim3(256), 0, c->stream, A->d_col, A->d_val, nnz, scratch); }, 20), sb + 8.0 * (nnz / 7.0));
         hipFree(scratch);
     }
     // streaming ceiling of the BLAS-1 kernels on this box
