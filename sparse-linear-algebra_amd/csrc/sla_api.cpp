@@ -295,6 +295,106 @@ static int csr_upload(sla_ctx *c, int64_t m, int64_t n, int64_t row_begin, int64
             A->ndiag = (int)offs.size();
         }
     }
+    if (!panel_view && !A->rp64 && nnz > 0 && A->max_row_nnz <= kVdMaxRowNnz) {
+        // value-indexed form: dictionary of (col - row, value bit pattern) pairs, one byte per entry
+        struct Pair { int64_t off; uint64_t bits; };
+        auto bits_of = [](double v) { uint64_t u; memcpy(&u, &v, 8); return u; };
+        constexpr int kSlots = 1024;                       // open addressing, <= 256 live keys
+        std::vector<int> slot(kSlots, -1);
+        std::vector<Pair> pairs;
+        auto find = [&](int64_t off, uint64_t bits, bool insert) -> int {
+            uint64_t h = ((uint64_t)off * 0x9E3779B97F4A7C15ull) ^ (bits * 0xC2B2AE3D27D4EB4Full);
+            h ^= h >> 29;
+            for (int i = (int)(h & (kSlots - 1));; i = (i + 1) & (kSlots - 1)) {
+                const int id = slot[(size_t)i];
+                if (id < 0) {
+                    if (!insert || pairs.size() == 256) return -1;
+                    slot[(size_t)i] = (int)pairs.size();
+                    pairs.push_back({off, bits});
+                    return (int)pairs.size() - 1;
+                }
+                if (pairs[(size_t)id].off == off && pairs[(size_t)id].bits == bits) return id;
+            }
+        };
+        bool ok = true;
+        for (int64_t i = 0; i < rows && ok; ++i) {
+            const int64_t gr = row_begin + i;
+            for (int64_t k = rowptr[i]; k < rowptr[i + 1]; ++k)
+                if (find(col[k] - gr, bits_of(val[k]), true) < 0) { ok = false; break; }
+        }
+        if (ok) {
+            // canonical table order: by offset, then by value bits (independent of the input order)
+            std::vector<int> order(pairs.size()), rank(pairs.size());
+            for (size_t t = 0; t < order.size(); ++t) order[t] = (int)t;
+            std::sort(order.begin(), order.end(), [&](int x, int y) {
+                return pairs[(size_t)x].off != pairs[(size_t)y].off ? pairs[(size_t)x].off < pairs[(size_t)y].off
+                                                                      : pairs[(size_t)x].bits < pairs[(size_t)y].bits;
+            });
+            std::vector<int32_t> doff(256, 0);
+            std::vector<double> dval(256, 0.0);
+            for (size_t t = 0; t < order.size(); ++t) {
+                rank[(size_t)order[t]] = (int)t;
+                doff[t] = (int32_t)pairs[(size_t)order[t]].off;
+                memcpy(&dval[t], &pairs[(size_t)order[t]].bits, 8);
+            }
+            std::vector<uint8_t> codes(((size_t)nnz + 3) / 4 * 4 + 16, 0);
+            for (int64_t i = 0; i < rows; ++i) {
+                const int64_t gr = row_begin + i;
+                for (int64_t k = rowptr[i]; k < rowptr[i + 1]; ++k)
+                    codes[(size_t)k] = (uint8_t)rank[(size_t)find(col[k] - gr, bits_of(val[k]), false)];
+            }
+            upload((void **)&A->d_vcode, codes.data(), codes.size());
+            upload((void **)&A->d_vdoff, doff.data(), sizeof(int32_t) * doff.size());
+            upload((void **)&A->d_vdval, dval.data(), sizeof(double) * dval.size());
+            A->use_vdict = true;
+            A->npairs = (int)pairs.size();
+            A->nblk_vd = (int32_t)((rows + kVdRows - 1) / kVdRows);
+            // wave-sliced form: per 128 rows (two per lane) the sorted union of the pair codes with an even-row and
+            // an odd-row lane mask each.  Taken when the slices are reasonably full (>= 1/4 of the row slots busy
+            // on average) and x is addressable with a 32-bit byte offset.
+            const int64_t nsl = (rows + 127) / 128;
+            std::vector<int32_t> wptr((size_t)nsl + 1, 0);
+            std::vector<uint64_t> wme, wmo;
+            std::vector<double> wval;
+            std::vector<int32_t> woff;
+            uint64_t lane_mask[2][256];
+            bool wok = n < ((int64_t)1 << 28);
+            for (int64_t sl = 0; sl < nsl && wok; ++sl) {
+                uint64_t present[4] = {0, 0, 0, 0};
+                const int64_t rlo = sl * 128, rhi = std::min<int64_t>(rows, rlo + 128);
+                for (int64_t i = rlo; i < rhi; ++i)
+                    for (int64_t k = rowptr[i]; k < rowptr[i + 1]; ++k) {
+                        const int cd = codes[(size_t)k];
+                        if (!((present[cd >> 6] >> (cd & 63)) & 1)) {
+                            present[cd >> 6] |= 1ull << (cd & 63);
+                            lane_mask[0][cd] = lane_mask[1][cd] = 0;
+                        }
+                        lane_mask[(i - rlo) & 1][cd] |= 1ull << ((i - rlo) >> 1);
+                    }
+                for (int cd = 0; cd < 256; ++cd)   // ascending code = ascending (offset, value bits)
+                    if ((present[cd >> 6] >> (cd & 63)) & 1) {
+                        wme.push_back(lane_mask[0][cd]);
+                        wmo.push_back(lane_mask[1][cd]);
+                        wval.push_back(dval[(size_t)cd]);
+                        woff.push_back(doff[(size_t)cd]);
+                    }
+                wptr[(size_t)sl + 1] = (int32_t)wme.size();
+                if ((int64_t)wme.size() * 32 > nnz + 2048) wok = false;   // < 1/4 full: the byte-code kernel is the better form
+            }
+            if (wok) {
+                A->nwent = (int64_t)wme.size();
+                for (int t = 0; t < 8; ++t) { wme.push_back(0); wmo.push_back(0); wval.push_back(0.0); woff.push_back(0); }
+                upload((void **)&A->d_wptr, wptr.data(), sizeof(int32_t) * wptr.size());
+                upload((void **)&A->d_wme, wme.data(), sizeof(uint64_t) * wme.size());
+                upload((void **)&A->d_wmo, wmo.data(), sizeof(uint64_t) * wmo.size());
+                upload((void **)&A->d_wval, wval.data(), sizeof(double) * wval.size());
+                upload((void **)&A->d_woff, woff.data(), sizeof(int32_t) * woff.size());
+                A->use_wdia = true;
+                A->nslices = (int32_t)nsl;
+                A->nblk_wd = (int32_t)((nsl + 3) / 4);
+            }
+        }
+    }
     if (err != hipSuccess) {
         sla_csr_destroy(A);
         return fail(SLA_ERR_ALLOC, std::string("CSR upload: ") + hipGetErrorString(err));
@@ -403,6 +503,8 @@ static int ctx_create_common(int device_id, int rank, int nranks, const void *ui
     if (const char *s = getenv("SLA_DUAL_SPMV")) c->dual_spmv = atoi(s);
     if (const char *s = getenv("SLA_XWIN")) c->xwin = atoi(s);
     if (const char *s = getenv("SLA_DIAG")) c->diag = atoi(s);
+    if (const char *s = getenv("SLA_VDICT")) c->vdict = atoi(s);
+    if (const char *s = getenv("SLA_WDIA")) c->wdia = atoi(s);
     if (const char *s = getenv("SLA_PANELS")) c->panels = atoi(s);
     if (const char *s = getenv("SLA_PANEL_COLS")) c->panel_cols = atoll(s);
     if (const char *s = getenv("SLA_ROW_ALIGN")) c->row_align = atoi(s);
@@ -617,6 +719,14 @@ int sla_csr_destroy(sla_csr_t A) {
     if (A->d_rbw) (void)hipFree(A->d_rbw);
     if (A->d_code) (void)hipFree(A->d_code);
     if (A->d_dict) (void)hipFree(A->d_dict);
+    if (A->d_wptr) (void)hipFree(A->d_wptr);
+    if (A->d_wme) (void)hipFree(A->d_wme);
+    if (A->d_wmo) (void)hipFree(A->d_wmo);
+    if (A->d_wval) (void)hipFree(A->d_wval);
+    if (A->d_woff) (void)hipFree(A->d_woff);
+    if (A->d_vcode) (void)hipFree(A->d_vcode);
+    if (A->d_vdoff) (void)hipFree(A->d_vdoff);
+    if (A->d_vdval) (void)hipFree(A->d_vdval);
     delete A;
     return SLA_OK;
 }
@@ -661,7 +771,7 @@ int sla_csr_is_diagonal(sla_csr_t A, int *out) {
 int sla_csr_kernel_info(sla_csr_t A, char *buf, int buflen) {
     if (!A || !buf || buflen <= 0) return fail(SLA_ERR_INVALID, "null argument");
     snprintf(buf, (size_t)buflen, "algo=%s grid=%d block=%d row_blocks=%d nnz_per_row_block=%d max_row_nnz=%lld rowptr=%s xcd_remap=%d",
-             A->ctx->spmv_algo == 1 ? "scalar" : (!A->panels.empty() && A->ctx->panels) ? "stream+colpanels" : (A->use_diag && A->ctx->diag ? (A->use_xwin && A->ctx->xwin ? "stream+diagdict+xwin" : "stream+diagdict") : (A->use_xwin && A->ctx->xwin ? "stream+xwin" : "stream")), spmv_grid(A), kBlock, A->nrb, kNnzPerRowBlock,
+             A->ctx->spmv_algo == 1 ? "scalar" : (A->use_wdia && A->ctx->wdia) ? "wdia" : (A->use_vdict && A->ctx->vdict) ? (A->use_xwin && A->ctx->xwin ? "vdict+xwin" : "vdict") : (!A->panels.empty() && A->ctx->panels) ? "stream+colpanels" : (A->use_diag && A->ctx->diag ? (A->use_xwin && A->ctx->xwin ? "stream+diagdict+xwin" : "stream+diagdict") : (A->use_xwin && A->ctx->xwin ? "stream+xwin" : "stream")), spmv_grid(A), kBlock, A->nrb, kNnzPerRowBlock,
              (long long)A->max_row_nnz, A->rp64 ? "i64" : "i32", A->ctx->xcd_remap);
     return SLA_OK;
 }

@@ -18,6 +18,8 @@ constexpr int kNnzPerRowBlock = 1024; // products staged in LDS per row block (8
 constexpr int kMaxRowsPerRowBlock = 256;
 constexpr int kXWin = 768;           // doubles of x staged in LDS per row block by spmv_xwin_kernel (6 KiB)
 constexpr int kXWinHalo = 256;       // the window starts kXWinHalo columns left of the block's first diagonal column
+constexpr int kVdRows = 256;         // rows per block of spmv_vdict_kernel (one lane per row)
+constexpr int kVdMaxRowNnz = 31;     // longest row the value-indexed kernel takes (256 rows x 31 B of codes fit its LDS stage)
 constexpr int kWaveRowMax = 16384;   // rows of 1025..16384 entries: one wavefront each, 4 per row block; longer: whole workgroup
 constexpr int kMaxParts = 2048;      // partial-sum slots per reduction (256 CUs x 8)
 constexpr int kVecGridMax = 1024;    // grid cap of the streaming BLAS-1 kernels
@@ -113,6 +115,8 @@ struct sla_ctx {
     int panels = 1;                  // allow the column-panel SpMV for irregular matrices (SLA_PANELS=0 disables)
     int64_t panel_cols = 384 * 1024; // panel width in columns (SLA_PANEL_COLS): 3 MiB of x per pass
     int diag = 1;                    // allow the dictionary-compressed-index SpMV kernel (SLA_DIAG=0 disables)
+    int wdia = 1;                    // allow the wave-sliced SpMV kernel (SLA_WDIA=0 disables)
+    int vdict = 1;                   // allow the value-indexed SpMV kernel (SLA_VDICT=0 disables)
     int xwin = 1;                    // allow the LDS x-window SpMV kernel (SLA_XWIN=0 disables)
     int dual_spmv = 1;               // linSolve0: fuse the true-residual SpMV into the next K1 (SLA_DUAL_SPMV=0 disables)
     int x_exchange = 0;              // 0 auto (window exchange when it pays), 1 always all-gather, 2 always window (SLA_X_EXCHANGE=allgather|window)
@@ -154,6 +158,21 @@ struct sla_csr {
     int32_t *d_dict = nullptr;       // 256 sorted diagonal offsets (unused slots repeat the last one)
     bool use_diag = false;           // <= 256 distinct (col - row) values: spmv_diag_kernel streams 9 B per entry
     int ndiag = 0;
+    uint8_t *d_vcode = nullptr;      // value-indexed form: code[k] indexes the (offset, value) pair table (padded to dwords)
+    int32_t *d_vdoff = nullptr;      // 256 pair offsets (col - row), sorted by (offset, value bits)
+    double *d_vdval = nullptr;       // 256 pair values
+    bool use_vdict = false;          // <= 256 distinct (col - row, value) pairs, rows <= kVdMaxRowNnz: spmv_vdict_kernel streams 1 B per entry
+    int npairs = 0;
+    int32_t nblk_vd = 0;             // ceil(rows / kVdRows)
+    int32_t *d_wptr = nullptr;       // wave-sliced form: first record of each 128-row slice, nslices + 1 entries
+    unsigned long long *d_wme = nullptr;    // per record: lanes whose EVEN row (2 lane) of the slice holds the entry ...
+    unsigned long long *d_wmo = nullptr;    // ... lanes whose ODD row (2 lane + 1) holds it ...
+    double *d_wval = nullptr;               // ... its value ...
+    int32_t *d_woff = nullptr;              // ... and its diagonal offset (col - row); all padded by 8 records
+    bool use_wdia = false;
+    int32_t nslices = 0;
+    int32_t nblk_wd = 0;             // ceil(nslices / 4): workgroup steps of spmv_wdia_kernel
+    int64_t nwent = 0;
     bool use_xwin = false;           // enough entries fall inside the windows for spmv_xwin_kernel to pay
     double xwin_fraction = 0.0;
     int32_t nrb = 0;

@@ -17,6 +17,11 @@
 //   spmv_xwin_kernel       + a 768-entry window of x staged in LDS (entries clustered around the diagonal)
 //   spmv_diag_kernel       + 1-byte dictionary codes instead of i32 columns (<= 256 distinct diagonals),
 //                            gather moved to the row phase
+//   spmv_wdia_kernel       per 128-row slice the union of its (offset, value) pairs with lane masks, all in SGPRs,
+//                            two rows per lane: one 16-byte gather + 2 x (v_mul + v_add) per entry, no LDS, no
+//                            barrier (constant-coefficient stencils)
+//   spmv_vdict_kernel      1-byte codes into a table of (diagonal offset, value) pairs: no val stream at all
+//                            (<= 256 distinct pairs: constant-coefficient stencils), 256-row blocks, lane per row
 //   spmv_dual_kernel / spmv_dual_diag_kernel   K1 and the true residual of the previous iterate in one sweep
 //   launch_spmv_panels     column-panel passes of spmv_stream_kernel for irregular matrices with x > L2
 //   spmv_scalar_kernel     one lane per row (A/B baseline, SLA_SPMV_ALGO=scalar)
@@ -26,6 +31,8 @@
 //   bicgstabStep Numeric/LinearAlgebra/Sparse.hs:972-981   cgsStep :928-939   cgneStep :870-878
 //   linSolve0 runIter :1043-1052               arnoldi :630-667
 #include <hip/hip_runtime.h>
+
+#include <type_traits>
 
 #include "sla_internal.hpp"
 
@@ -1194,6 +1201,423 @@ __global__ void __launch_bounds__(kBlock, 8) spmv_dual_diag_kernel(SpmvArgs<RP> 
 }
 
 
+// ---------------------------------------------------------------------------------------------
+// Value-indexed SpMV: one byte per stored entry
+// ---------------------------------------------------------------------------------------------
+// Stencil / constant-coefficient banded matrices repeat a handful of (diagonal offset, value) PAIRS:
+// the 7-point Laplacian has 7.  When the lowering finds <= 256 distinct pairs (values compared by bit
+// pattern, so the compression is lossless) and no row longer than kVdMaxRowNnz, it keeps one byte per entry
+// that indexes a table of (offset, value).  This kernel then streams 1 B per entry + rowptr instead of
+// 9-12 B: the matrix all but disappears from the HBM traffic and the sweep is bounded by the vectors
+// (x, y and the fused-epilogue operand).  Fixed 256-row blocks, one lane per row: the row is the reference's
+// ascending left fold with separately rounded multiply and add, bit for bit.  Code bytes are staged in LDS as
+// whole dwords; the x window, the software pipeline (next block's loads fly during the row phase, block
+// extents rowptr[256 b] come through scalar loads two blocks ahead) and the epilogues are those of
+// spmv_diag_kernel.  DUAL adds the true residual of a second vector (linSolve0's fused check).
+constexpr int kVdCodeDw = kBlock * 8;  // dwords of code staged per block (8 per lane)
+template <int EPI, bool XW, bool DUAL>
+__global__ void __launch_bounds__(kBlock, 8) spmv_vdict_kernel(SpmvArgs<int32_t> a, const int32_t *__restrict__ rowptr,
+                                                                const uint32_t *__restrict__ cw, const double *__restrict__ xg,
+                                                                const int32_t *__restrict__ doff, const double *__restrict__ dval,
+                                                                int32_t nblk, int32_t ncols, int32_t grow0,
+                                                                const double *__restrict__ x2, const double *__restrict__ b2,
+                                                                int xcd_remap) {
+    __shared__ uint32_t s_cw[kVdCodeDw];
+    __shared__ int s_rp[kBlock + 1];
+    __shared__ double s_xw[XW ? kXWin : 1];
+    __shared__ int s_doff[256];
+    __shared__ double s_dval[256];
+    __shared__ double s_red[4];
+    const int tid = threadIdx.x;
+    double coef;
+    if (!spmv_prologue<EPI, int32_t>(a, s_red, coef)) return;
+    s_doff[tid] = doff[tid];
+    s_dval[tid] = dval[tid];
+    __syncthreads();
+
+    double acc1 = 0.0, acc2 = 0.0;
+    const RbWalk wk = rb_walk(nblk, xcd_remap);
+    const int rows = a.rows;
+    const int wmax = max(0, ncols - kXWin);
+    int b = wk.first;
+    if (b < wk.last) {
+        uint32_t c[8];
+        double xw[XW ? kXWin / kBlock : 1];
+        int rpn = 0;
+        // extents of row block b_: rows [r0, r0 + nrows), entries [k0, k1)
+#define SLA_VD_DESC(b_, r0_, nr_, k0_, k1_)          \
+        r0_ = (b_) * kVdRows;                        \
+        nr_ = min(kVdRows, rows - r0_);              \
+        k0_ = rowptr[r0_];                           \
+        k1_ = rowptr[r0_ + nr_];
+#define SLA_VD_LOADS(r0_, nr_, k0_, k1_, wlo_)                                              \
+        {                                                                                    \
+            const int kb_ = (k0_) & ~3;                                                      \
+            const int ndw_ = ((k1_) - kb_ + 3) >> 2;                                         \
+            const uint32_t *src_ = cw + (kb_ >> 2);                                          \
+            _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                  \
+                const int i = tid + j * kBlock;                                              \
+                if (i < ndw_) c[j] = __builtin_nontemporal_load(src_ + i);                   \
+            }                                                                                \
+            if (tid < (nr_)) rpn = rowptr[(r0_) + tid];                                      \
+            if (XW) {                                                                        \
+                _Pragma("unroll") for (int j = 0; j < kXWin / kBlock; ++j) {                 \
+                    const int i = (wlo_) + tid + j * kBlock;                                 \
+                    xw[j] = i < ncols ? xg[i] : 0.0;                                         \
+                }                                                                            \
+            }                                                                                \
+        }
+#define SLA_VD_WLO(r0_) min(wmax, max(0, grow0 + (r0_) - kXWinHalo))
+        int r0, nrows, k0, k1;
+        SLA_VD_DESC(b, r0, nrows, k0, k1)
+        int wlo = SLA_VD_WLO(r0);
+        SLA_VD_LOADS(r0, nrows, k0, k1, wlo)
+        int nr0 = 0, nnr = 0, nk0 = 0, nk1 = 0;
+        if (b + wk.step < wk.last) { SLA_VD_DESC(b + wk.step, nr0, nnr, nk0, nk1) }
+        auto xat = [&](int colg) -> double {
+            if (XW) {
+                const unsigned off = (unsigned)(colg - wlo);
+                if (off < (unsigned)kXWin) return s_xw[off];
+            }
+            return xg[colg];
+        };
+        const uint8_t *cb = (const uint8_t *)s_cw;
+        for (;;) {
+            const int bn = b + wk.step, bnn = bn + wk.step;
+            const bool has_next = bn < wk.last, has_next2 = bnn < wk.last;
+            int fr0 = 0, fnr = 0, fk0 = 0, fk1 = 0;
+            const int kb = k0 & ~3;
+            {
+                const int ndw = (k1 - kb + 3) >> 2;
+                if (tid < nrows) s_rp[tid] = rpn - kb;
+                if (tid == 0) s_rp[nrows] = k1 - kb;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int i = tid + j * kBlock;
+                    if (i < ndw) s_cw[i] = c[j];
+                }
+                if (XW) {
+#pragma unroll
+                    for (int j = 0; j < kXWin / kBlock; ++j) s_xw[tid + j * kBlock] = xw[j];
+                }
+            }
+            __syncthreads();
+            const int nwlo = has_next ? SLA_VD_WLO(nr0) : 0;
+            if (has_next) { SLA_VD_LOADS(nr0, nnr, nk0, nk1, nwlo) }
+            if (has_next2) { SLA_VD_DESC(bnn, fr0, fnr, fk0, fk1) }
+            if (tid < nrows) {
+                const int s = s_rp[tid], e = s_rp[tid + 1];
+                const int grow = grow0 + r0 + tid;
+                double acc = 0.0, yb = 0.0;
+                {
+#pragma clang fp contract(off)  // a*x then +: two roundings like the reference, never an FMA
+                    int k = s;
+                    for (; k + 4 <= e; k += 4) {  // 4 gathers in flight, summed in order
+                        const int c0 = cb[k], c1 = cb[k + 1], c2 = cb[k + 2], c3 = cb[k + 3];
+                        const int g0 = grow + s_doff[c0], g1 = grow + s_doff[c1];
+                        const int g2 = grow + s_doff[c2], g3 = grow + s_doff[c3];
+                        const double v0 = s_dval[c0], v1 = s_dval[c1], v2 = s_dval[c2], v3 = s_dval[c3];
+                        const double p0 = v0 * xat(g0), p1 = v1 * xat(g1);
+                        const double p2 = v2 * xat(g2), p3 = v3 * xat(g3);
+                        acc = acc + p0;
+                        acc = acc + p1;
+                        acc = acc + p2;
+                        acc = acc + p3;
+                        if constexpr (DUAL) {
+                            const double q0 = v0 * x2[g0], q1 = v1 * x2[g1];
+                            const double q2 = v2 * x2[g2], q3 = v3 * x2[g3];
+                            yb = yb + q0;
+                            yb = yb + q1;
+                            yb = yb + q2;
+                            yb = yb + q3;
+                        }
+                    }
+                    for (; k < e; ++k) {
+                        const int c0 = cb[k];
+                        const int g0 = grow + s_doff[c0];
+                        const double v0 = s_dval[c0];
+                        const double p0 = v0 * xat(g0);
+                        acc = acc + p0;
+                        if constexpr (DUAL) {
+                            const double q0 = v0 * x2[g0];
+                            yb = yb + q0;
+                        }
+                    }
+                }
+                const int row = r0 + tid;
+                if constexpr (DUAL) {
+                    a.y[row] = acc;
+                    acc1 += acc * a.w[row];
+                    const double t = yb - b2[row];
+                    acc2 += t * t;
+                } else {
+                    spmv_epilogue<EPI, int32_t>(a, row, acc, coef, acc1, acc2);
+                }
+            }
+            if (!has_next) break;
+            __syncthreads();
+            b = bn;
+            r0 = nr0;
+            nrows = nnr;
+            k0 = nk0;
+            k1 = nk1;
+            wlo = nwlo;
+            nr0 = fr0;
+            nnr = fnr;
+            nk0 = fk0;
+            nk1 = fk1;
+        }
+#undef SLA_VD_WLO
+#undef SLA_VD_LOADS
+#undef SLA_VD_DESC
+    }
+    if constexpr (DUAL || EPI == EPI_DOT || EPI == EPI_DOT2 || EPI == EPI_RES || EPI == EPI_AXPY_DOT ||
+                  EPI == EPI_XPBY_NRM) {
+        const double s1 = block_sum(acc1, s_red);
+        if (tid == 0) a.p1[blockIdx.x] = s1;
+    }
+    if constexpr (DUAL || EPI == EPI_DOT2) {
+        const double s2 = block_sum(acc2, s_red);
+        if (tid == 0) a.p2[blockIdx.x] = s2;
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Wave-sliced (offset, value) SpMV: the matrix lives in scalar registers
+// ---------------------------------------------------------------------------------------------
+// Same eligibility as the value-indexed form (<= 256 distinct (col - row, value) pairs), stored per SLICE of
+// 128 consecutive rows -- one wavefront, TWO adjacent rows per lane -- as the sorted union of the pairs its
+// rows use, each with two 64-bit lane masks (even rows / odd rows of the slice that hold it):
+// {mask_even, mask_odd, value, offset} = 28 B per record, kept as four arrays.  A slice of the 7-point
+// Laplacian is 7 records = 1.5 B per row, so the sweep moves the vectors and little else.
+// Everything about an entry is wave-uniform, so the records come through SCALAR loads; a lane mask goes
+// straight into EXEC (inverse ballot), the value is an SGPR operand of v_mul_f64 and the offset folds into
+// the scalar base address of the gather.  What bounds such a kernel is the vector-memory instruction rate of
+// the CU (a wave-wide 8-byte access costs as much as a 16-byte one: one-row-per-lane variants of this kernel
+// and spmv_vdict_kernel both stalled at ~10 vector-memory instructions per 64 rows), hence the row pairs:
+// every gather, the epilogue operand and the result are ONE 16-byte access per lane, 9 instructions per 128
+// rows of the 7-point stencil.  The union is sorted by (offset, value bits) and a row holds at most one entry
+// per offset, so every row still adds its products in ascending column order with separately rounded
+// multiply and add: the reference's left fold, bit for bit.  Up to 8 gathers are in flight per lane.
+typedef unsigned long long wd_u64x8 __attribute__((ext_vector_type(8), aligned(8)));
+typedef double wd_f64x8 __attribute__((ext_vector_type(8), aligned(8)));
+typedef int wd_i32x8 __attribute__((ext_vector_type(8), aligned(4)));
+typedef double wd_f64x2u __attribute__((ext_vector_type(2), aligned(8)));  // a row pair of x at any 8-byte boundary
+typedef double wd_f64x2 __attribute__((ext_vector_type(2)));
+
+struct WdRec {  // lane k < 8 holds record k of the slice's first chunk (both masks 0: no such record)
+    unsigned long long me, mo;
+    double v;
+    int o;
+};
+__device__ __forceinline__ unsigned long long wd_lane_u64(unsigned long long x, int k) {
+    const unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)x, k), hi = __builtin_amdgcn_readlane((int)(unsigned)(x >> 32), k);
+    return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ double wd_lane_f64(double x, int k) {
+    return __longlong_as_double((long long)wd_lane_u64((unsigned long long)__double_as_longlong(x), k));
+}
+
+// Latency: a wavefront's chain per slice would be descriptor -> records -> gathers -> store, three dependent
+// trips to memory.  The descriptor (scalar) is fetched two slices ahead and the records one slice ahead --
+// by lanes 0..7, one record each, through the in-order vector queue; v_readlane moves a field to SGPRs when
+// it is used -- so a wavefront waits on memory once per slice.
+template <int EPI>
+__global__ void __launch_bounds__(kBlock, 8) spmv_wdia_kernel(SpmvArgs<int32_t> a, const int32_t *__restrict__ sptr,
+                                                               const unsigned long long *__restrict__ wme,
+                                                               const unsigned long long *__restrict__ wmo,
+                                                               const double *__restrict__ wval, const int32_t *__restrict__ woff,
+                                                               const double *__restrict__ xg, int32_t nblk, int32_t nslices,
+                                                               int32_t grow0, int32_t xlen, int xcd_remap) {
+    __shared__ double s_red[4];
+    const int tid = threadIdx.x;
+    double coef;
+    if (!spmv_prologue<EPI, int32_t>(a, s_red, coef)) return;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    double acc1 = 0.0, acc2 = 0.0;
+    const RbWalk wk = rb_walk(nblk, xcd_remap);
+    constexpr bool kUsesW = EPI == EPI_DOT || EPI == EPI_DOT2 || EPI == EPI_RES || EPI == EPI_SUB || EPI == EPI_AXPY_DOT;
+    constexpr bool kUsesZ = EPI == EPI_AXPY_DOT || EPI == EPI_XPBY_NRM;
+    // slice descriptor of workgroup step b (wave-uniform): first record, record count (0: nothing to do)
+    auto load_desc = [&](int b, int &e0, int &cnt) {
+        e0 = 0;
+        cnt = 0;
+        const int s = b * 4 + wave;
+        if (b < wk.last && s < nslices) {
+            e0 = sptr[s];
+            cnt = sptr[s + 1] - e0;
+        }
+    };
+    auto load_rec = [&](int e0, int cnt, WdRec &r) {
+        r.me = 0ull;
+        r.mo = 0ull;
+        r.v = 0.0;
+        r.o = 0;
+        if (lane < 8 && lane < cnt) {
+            r.me = wme[e0 + lane];
+            r.mo = wmo[e0 + lane];
+            r.v = wval[e0 + lane];
+            r.o = woff[e0 + lane];
+        }
+    };
+    int b = wk.first;
+    int e0_c, cnt_c, e0_n, cnt_n;
+    WdRec rc, rn;
+    load_desc(b, e0_c, cnt_c);
+    load_desc(b + wk.step, e0_n, cnt_n);
+    load_rec(e0_c, cnt_c, rc);
+    for (; b < wk.last; b += wk.step) {
+        int e0_f, cnt_f;
+        load_rec(e0_n, cnt_n, rn);               // next slice's records: in flight behind this slice's gathers
+        load_desc(b + 2 * wk.step, e0_f, cnt_f);
+#if defined(SLA_WD_PREFETCH)
+        // L2 prefetch for this wavefront's NEXT slice of the two streams nobody has touched yet: the leading
+        // edge of x (largest diagonal offset; stencils repeat their offsets slice after slice) and the
+        // epilogue operand.  One dword per 128-byte line, lanes 0..7 / 8..15.
+        int pf = 0;
+        if (cnt_n > 0 && lane < 16) {
+            const int rown = ((b + wk.step) * 4 + wave) * 128;
+            const int olast = __builtin_amdgcn_readlane(rc.o, 7 < cnt_c - 1 ? 7 : (cnt_c > 0 ? cnt_c - 1 : 0));
+            if (lane < 8) {
+                const long long idx = (long long)grow0 + rown + olast + lane * 16;
+                if (idx >= 0 && idx < (long long)xlen) pf = *(const int *)(xg + idx);
+            } else if (kUsesW && a.w != nullptr) {
+                const int idx = rown + (lane - 8) * 16;
+                if (idx < a.rows) pf = *(const int *)(a.w + idx);
+            }
+        }
+#endif
+        if (cnt_c > 0) {
+            const int row = (b * 4 + wave) * 128 + 2 * lane;  // this lane's rows: row, row + 1
+            const bool va = row < a.rows, vb = row + 1 < a.rows;
+            // epilogue operands: issued before the gathers so they fly together
+            wd_f64x2 wv = {0.0, 0.0}, zv = {0.0, 0.0};
+            if (vb) {
+#if defined(SLA_WD_NT_W)
+                if constexpr (kUsesW) { if (EPI != EPI_AXPY_DOT || a.w) wv = __builtin_nontemporal_load((const wd_f64x2 *)(a.w + row)); }
+#else
+                if constexpr (kUsesW) { if (EPI != EPI_AXPY_DOT || a.w) wv = *(const wd_f64x2 *)(a.w + row); }
+#endif
+                if constexpr (kUsesZ) zv = *(const wd_f64x2 *)(a.z + row);
+            } else if (va) {
+                if constexpr (kUsesW) { if (EPI != EPI_AXPY_DOT || a.w) wv.x = a.w[row]; }
+                if constexpr (kUsesZ) zv.x = a.z[row];
+            }
+            // byte offset of x[global row]; a record's diagonal offset moves the scalar base instead
+            const uint32_t g8 = (uint32_t)(grow0 + row) * 8u;
+            double ya = 0.0, yb = 0.0;
+            wd_f64x2 xv[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const unsigned long long me = wd_lane_u64(rc.me, k), mo = wd_lane_u64(rc.mo, k);
+                const int ok = __builtin_amdgcn_readlane(rc.o, k);
+                xv[k] = wd_f64x2{0.0, 0.0};
+                const char *base = (const char *)(xg + ok) + g8;
+                // both rows of the lane hold the entry: one 16-byte gather; a row alone (matrix edge, ragged
+                // pattern): its own 8 bytes, so nothing outside x is ever touched
+                if (__builtin_amdgcn_inverse_ballot_w64(me & mo)) xv[k] = *(const wd_f64x2u *)base;
+                if (__builtin_amdgcn_inverse_ballot_w64(me & ~mo)) xv[k].x = *(const double *)base;
+                if (__builtin_amdgcn_inverse_ballot_w64(mo & ~me)) xv[k].y = *(const double *)(base + 8);
+            }
+            {
+#pragma clang fp contract(off)  // a*x then +: two roundings like the reference, never an FMA
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const unsigned long long me = wd_lane_u64(rc.me, k), mo = wd_lane_u64(rc.mo, k);
+                    const double vk = wd_lane_f64(rc.v, k);
+                    if (__builtin_amdgcn_inverse_ballot_w64(me)) {
+                        const double p = vk * xv[k].x;
+                        ya = ya + p;
+                    }
+                    if (__builtin_amdgcn_inverse_ballot_w64(mo)) {
+                        const double p = vk * xv[k].y;
+                        yb = yb + p;
+                    }
+                }
+                // slices with more than 8 records (27-point stencils, ...): the rest one by one through scalar loads
+                for (int c = 8; c < cnt_c; ++c) {
+                    const unsigned long long me = wme[e0_c + c], mo = wmo[e0_c + c];
+                    const double vk = wval[e0_c + c];
+                    const char *base = (const char *)(xg + woff[e0_c + c]) + g8;
+                    if (__builtin_amdgcn_inverse_ballot_w64(me)) {
+                        const double p = vk * *(const double *)base;
+                        ya = ya + p;
+                    }
+                    if (__builtin_amdgcn_inverse_ballot_w64(mo)) {
+                        const double p = vk * *(const double *)(base + 8);
+                        yb = yb + p;
+                    }
+                }
+            }
+            if (va) {
+                wd_f64x2 out = {ya, yb};  // what the epilogue stores (y or z), if it stores
+                bool store_y = false, store_z = false;
+                if constexpr (EPI == EPI_NONE) {
+                    store_y = true;
+                } else if constexpr (EPI == EPI_DOT) {
+                    store_y = true;
+                    acc1 += ya * wv.x;
+                    if (vb) acc1 += yb * wv.y;
+                } else if constexpr (EPI == EPI_DOT2) {
+                    store_y = true;
+                    acc1 += ya * wv.x;
+                    acc2 += ya * ya;
+                    if (vb) { acc1 += yb * wv.y; acc2 += yb * yb; }
+                } else if constexpr (EPI == EPI_RES) {
+                    const double ta = ya - wv.x, tb = yb - wv.y;  // (aa #> x) ^-^ b
+                    acc1 += ta * ta;
+                    if (vb) acc1 += tb * tb;
+                } else if constexpr (EPI == EPI_AXPY_DOT) {
+                    out.x = zv.x - coef * ya;
+                    out.y = zv.y - coef * yb;
+                    store_z = true;
+                    acc1 += out.x * (a.w ? wv.x : out.x);
+                    if (vb) acc1 += out.y * (a.w ? wv.y : out.y);
+                } else if constexpr (EPI == EPI_XPBY_NRM) {
+                    out.x = ya + coef * zv.x;
+                    out.y = yb + coef * zv.y;
+                    store_z = true;
+                    acc1 += out.x * out.x;
+                    if (vb) acc1 += out.y * out.y;
+                } else if constexpr (EPI == EPI_SUB) {
+                    out.x = wv.x - ya;  // b ^-^ (aa #> x)
+                    out.y = wv.y - yb;
+                    store_y = true;
+                }
+                double *dst = store_y ? a.y : (store_z ? a.z : nullptr);
+                if (dst) {
+#if defined(SLA_WD_SC1_Y)
+                    if (vb) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst + row), "v"(out) : "memory");
+#elif defined(SLA_WD_NT_Y)
+                    if (vb) __builtin_nontemporal_store(out, (wd_f64x2 *)(dst + row));
+#else
+                    if (vb) *(wd_f64x2 *)(dst + row) = out;
+#endif
+                    else dst[row] = out.x;
+                }
+            }
+        }
+#if defined(SLA_WD_PREFETCH)
+        asm volatile("" ::"v"(pf));
+#endif
+        e0_c = e0_n;
+        cnt_c = cnt_n;
+        rc = rn;
+        e0_n = e0_f;
+        cnt_n = cnt_f;
+    }
+    if constexpr (EPI == EPI_DOT || EPI == EPI_DOT2 || EPI == EPI_RES || EPI == EPI_AXPY_DOT || EPI == EPI_XPBY_NRM) {
+        const double s1 = block_sum(acc1, s_red);
+        if (tid == 0) a.p1[blockIdx.x] = s1;
+    }
+    if constexpr (EPI == EPI_DOT2) {
+        const double s2 = block_sum(acc2, s_red);
+        if (tid == 0) a.p2[blockIdx.x] = s2;
+    }
+}
+
 // One lane per row, grid-stride: the A/B baseline for the stream kernel (SLA_SPMV_ALGO=scalar).
 template <int EPI, typename RP>
 __global__ void __launch_bounds__(kBlock) spmv_scalar_kernel(SpmvArgs<RP> a, int xcd_remap) {
@@ -1228,6 +1652,8 @@ int spmv_grid(const sla_csr *A) {
     if (!A->panels.empty() && c->panels && c->spmv_algo == 0) return spmv_grid(A->panels.back());
     int64_t g;
     if (c->spmv_algo == 1) g = (A->rows + kBlock - 1) / kBlock;
+    else if (A->use_wdia && c->wdia) g = A->nblk_wd;
+    else if (A->use_vdict && c->vdict) g = A->nblk_vd;
     else g = A->nrb;
     if (g < 1) g = 1;
     if (g > c->spmv_grid_max) g = c->spmv_grid_max;
@@ -1303,6 +1729,35 @@ static int launch_spmv_t(const sla_csr *A, const SpmvLaunch &l) {
     a.yinit = l.yinit;
     const int grid = spmv_grid(A);
     ProfScope prof(c, l.kernel_id);
+    if (A->use_wdia && c->wdia && c->spmv_algo == 0 && !l.x2) {
+        if constexpr (std::is_same<RP, int32_t>::value) {
+            hipLaunchKernelGGL((spmv_wdia_kernel<EPI>), dim3(grid), dim3(kBlock), 0, c->stream, a, A->d_wptr, A->d_wme, A->d_wmo,
+                               A->d_wval, A->d_woff, a.x, A->nblk_wd, A->nslices, (int32_t)A->row_begin, (int32_t)A->n, c->xcd_remap);
+            SLA_HIP_TRY(hipGetLastError());
+            return SLA_OK;
+        }
+    }
+    if (A->use_vdict && c->vdict && c->spmv_algo == 0) {
+        if constexpr (std::is_same<RP, int32_t>::value) {
+            const bool xw = A->use_xwin && c->xwin;
+#define SLA_VD_LAUNCH(E, XW_, DUAL_)                                                                                        \
+            hipLaunchKernelGGL((spmv_vdict_kernel<E, XW_, DUAL_>), dim3(grid), dim3(kBlock), 0, c->stream, a, a.rowptr,        \
+                               (const uint32_t *)A->d_vcode, a.x, A->d_vdoff, A->d_vdval, A->nblk_vd, (int32_t)A->n,          \
+                               (int32_t)A->row_begin, l.x2, l.b2, c->xcd_remap)
+            if (l.x2) {
+                if constexpr (EPI == EPI_DOT) {
+                    if (xw) SLA_VD_LAUNCH(EPI_DOT, true, true);
+                    else SLA_VD_LAUNCH(EPI_DOT, false, true);
+                } else {
+                    return fail(SLA_ERR_INVALID, "dual SpMV is only defined for the K1 epilogue");
+                }
+            } else if (xw) SLA_VD_LAUNCH(EPI, true, false);
+            else SLA_VD_LAUNCH(EPI, false, false);
+#undef SLA_VD_LAUNCH
+            SLA_HIP_TRY(hipGetLastError());
+            return SLA_OK;
+        }
+    }
     if (l.x2) {
         if constexpr (EPI == EPI_DOT) {
             if (A->use_diag && c->diag) {

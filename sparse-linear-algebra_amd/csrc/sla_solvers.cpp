@@ -260,7 +260,9 @@ int enqueue_step(sla_solver *S, bool res_after, bool dual_prev) {
 bool dual_ok(const sla_solver *S) {
     // (with column panels the residual SpMV is cheaper as its own panel-blocked sweep than fused into K1)
     return !S->ctx->collectives && S->ctx->spmv_algo == 0 && S->ctx->dual_spmv && S->method != SLA_CGNE_ &&
-           (S->A->panels.empty() || !S->ctx->panels);
+           (S->A->panels.empty() || !S->ctx->panels) &&
+           // (the wave-sliced form streams ~2 B of matrix per row: fusing the two sweeps saves nothing there)
+           !(S->A->use_wdia && S->ctx->wdia);
 }
 
 int read_scalars(sla_solver *S) {

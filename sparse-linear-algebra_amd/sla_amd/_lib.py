@@ -6,7 +6,8 @@ import subprocess
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)                       # sparse-linear-algebra_amd/
-LIB_PATH = os.path.join(_ROOT, "lib", "libsla_hip.so")
+# SLA_HIP_LIB: load another build of the same library (kernel A/B experiments, tools/build_variant.sh)
+LIB_PATH = os.environ.get("SLA_HIP_LIB") or os.path.join(_ROOT, "lib", "libsla_hip.so")
 CSRC = os.path.join(_ROOT, "csrc")
 
 (OK, ERR_DIM_MISMATCH, ERR_UNSUPPORTED_METHOD, ERR_OOB, ERR_HIP, ERR_RCCL, ERR_ALLOC, ERR_INVALID,

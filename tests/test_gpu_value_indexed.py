@@ -1,0 +1,146 @@
+"""The value-indexed SpMV forms (spmv_wdia_kernel: wave-sliced (offset, value) records in SGPRs, two rows per
+lane; spmv_vdict_kernel: one byte per entry) against the oracle's left fold, bit for bit, and against each other
+and the general kernels -- including the shapes that stress them: odd row counts, ragged patterns where only
+one row of a lane pair holds an entry, more than 8 records per slice, several values on one diagonal, rows at
+the matrix edge, -0.0 / Inf operands, and every fused epilogue through the solver steps."""
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def sla():
+    import sla_amd
+    return sla_amd
+
+
+def _stencil(n, offsets, value_of, keep=None):
+    """CSR of a banded matrix: entry (i, i + off) = value_of(i, t) for each offset t, dropped where keep(i, t) is False."""
+    from sla_amd import workloads as wl
+    offsets = sorted(offsets)
+
+    def valid(rows, t):
+        c = rows + offsets[t]
+        ok = (c >= 0) & (c < n)
+        if keep is not None:
+            ok &= keep(rows, t)
+        return ok
+
+    return (n, n), wl._stencil_rows(0, n, offsets, valid, lambda rows, t: value_of(rows, offsets[t]))
+
+
+def _cases():
+    from sla_amd import workloads as wl
+    rng = np.random.default_rng(5)
+    drop = rng.random((4099, 16)) < 0.3
+    return {
+        "laplace3d 14x11x13": wl.laplace3d(14, 11, 13),
+        "poisson2d 37x29 (odd n)": wl.poisson2d(37, 29),
+        "tridiag n=1": _stencil(1, [-1, 0, 1], lambda r, o: np.full(len(r), 2.0 if o == 0 else -1.0)),
+        "tridiag n=129": _stencil(129, [-1, 0, 1], lambda r, o: np.full(len(r), 2.0 if o == 0 else -1.0)),
+        # 13 diagonals: more than one 8-record chunk per slice
+        "13 diagonals n=3001": _stencil(3001, [-700, -64, -9, -3, -2, -1, 0, 1, 2, 5, 63, 128, 900],
+                                         lambda r, o: np.full(len(r), 20.0 if o == 0 else -1.0 - 0.125 * (o % 7))),
+        # ragged: 30 % of the entries missing at random, so lane pairs often hold an entry in one row only
+        "ragged 11 diagonals n=4099": _stencil(4099, [-300, -17, -4, -2, -1, 0, 1, 3, 16, 250, 1025],
+                                                lambda r, o: np.full(len(r), 9.0 if o == 0 else 0.5 + (o % 3)),
+                                                keep=lambda r, t: ~drop[r, t] | (t == 5)),
+        # three different values along each diagonal (row mod 3): several records share an offset
+        "3 values per diagonal n=2500": _stencil(2500, [-50, -1, 0, 1, 50],
+                                                  lambda r, o: (8.0 if o == 0 else -1.0) * (1.0 + 0.25 * (r % 3))),
+        # signed zeros and a row of explicit zeros must survive (they are values like any other)
+        "explicit +-0.0 n=777": _stencil(777, [-2, 0, 2], lambda r, o: np.where(r % 5 == 0, -0.0 if o else 0.0, 3.0 + o)),
+    }
+
+
+def _oracle_csr(dims, csr):
+    rp, ci, va = csr
+    return orc.Csr(dims[0], dims[1], rp, ci, va)
+
+
+@pytest.mark.parametrize("name", list(_cases()))
+def test_value_indexed_forms_fold_like_the_reference(sla, monkeypatch, name):
+    dims, csr = _cases()[name]
+    n = dims[0]
+    Ao = _oracle_csr(dims, csr)
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal(n)
+    x[rng.integers(0, n, max(1, n // 50))] = -0.0
+    want = orc.spmv(Ao, x)
+    want_t = orc.spmv(orc.transpose(Ao), x)
+    got = {}
+    for form, env in (("wdia", {}), ("vdict", {"SLA_WDIA": "0"}), ("diag", {"SLA_WDIA": "0", "SLA_VDICT": "0"}),
+                      ("stream", {"SLA_WDIA": "0", "SLA_VDICT": "0", "SLA_DIAG": "0", "SLA_XWIN": "0"})):
+        for k in ("SLA_WDIA", "SLA_VDICT", "SLA_DIAG", "SLA_XWIN"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        ctx = sla.Context(0)
+        A = sla.fromCSR(dims, *csr, ctx)
+        if form in ("wdia", "vdict"):
+            assert form in A.kernel_info().split()[0], (form, A.kernel_info())
+        y = sla.matVec(A, sla.fromVector(x, ctx)).toDenseListSV()
+        yt = sla.vecMat(sla.fromVector(x, ctx), A).toDenseListSV()
+        got[form] = y
+        if form in ("wdia", "vdict") or len(csr[1]) <= 8 * n:
+            # every row is the ascending left fold with separately rounded a*x and +: identical bits, signed zeros included
+            assert np.array_equal(y.view(np.uint64), want.view(np.uint64)), (name, form, np.abs(y - want).max())
+            assert np.array_equal(yt.view(np.uint64), want_t.view(np.uint64)), (name, form, "transpose")
+        else:   # the general kernels sum rows of more than 8 entries (on average) by wavefront segments: rounding-level differences
+            assert np.allclose(y, want, rtol=1e-13, atol=1e-13) and np.allclose(yt, want_t, rtol=1e-13, atol=1e-13)
+        del A
+        ctx.close()
+
+
+@pytest.mark.parametrize("name", ["laplace3d 14x11x13", "ragged 11 diagonals n=4099", "3 values per diagonal n=2500"])
+def test_value_indexed_epilogues_through_the_solvers(sla, monkeypatch, name):
+    """K1/K3 (dot, dot2), the true-residual sweep, CGS's and CGNE's fused updates, r0 = b - A x0: same iterates as
+    the general kernels (the per-row results are bit-identical; only partial-sum grouping differs)."""
+    dims, csr = _cases()[name]
+    n = dims[0]
+    Ao = _oracle_csr(dims, csr)
+    b = orc.spmv(Ao, np.linspace(-1.0, 2.0, n))
+    out = {}
+    for form, env in (("wdia", {}), ("vdict", {"SLA_WDIA": "0"}), ("stream", {"SLA_WDIA": "0", "SLA_VDICT": "0", "SLA_DIAG": "0"})):
+        for k in ("SLA_WDIA", "SLA_VDICT", "SLA_DIAG"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        ctx = sla.Context(0)
+        A = sla.fromCSR(dims, *csr, ctx)
+        for meth in (sla.BICGSTAB_, sla.CGS_, sla.CGNE_):
+            x, info = sla.linSolve0(meth, A, sla.fromVector(b, ctx), sla.fromVector(np.full(n, 0.25), ctx), return_info=True)
+            out[(form, int(meth))] = (x.toDenseListSV(), info["iters"], info["resnorm"])
+        del A
+        ctx.close()
+    for meth, ometh in ((sla.BICGSTAB_, orc.BICGSTAB_), (sla.CGS_, orc.CGS_), (sla.CGNE_, orc.CGNE_)):
+        rc, xo, it_o, res_o, r0_o = orc.linsolve0(ometh, Ao, b, np.full(n, 0.25))
+        ref = out[("stream", int(meth))]
+        for form in ("wdia", "vdict"):
+            x, it, rn = out[(form, int(meth))]
+            assert abs(it - ref[1]) <= 1 and abs(it - it_o) <= 2, (name, form, meth, it, ref[1], it_o)
+            if it_o < 200:
+                assert np.linalg.norm(orc.spmv(Ao, x) - b) <= max(1e-6, 1e-4 * r0_o) * (1 + 1e-9)
+            if it == ref[1]:       # same number of steps: the iterates agree up to the partial-sum grouping, amplified by the solver
+                scale = np.abs(ref[0]).max() + 1e-300
+                assert np.abs(x - ref[0]).max() <= 1e-5 * scale, (name, form, meth)
+
+
+def test_value_indexed_propagates_inf_and_nan_only_where_the_reference_does(sla):
+    """Lanes masked off in a slice must not touch x at all: an Inf next to a missing neighbour stays out of that row."""
+    n = 640
+    dims, csr = _stencil(n, [-1, 0, 1], lambda r, o: np.full(len(r), 2.0 if o == 0 else -1.0),
+                         keep=lambda r, t: ~((r % 64 == 10) & (t == 2)))       # rows 10, 74, ... have no (i, i+1) entry
+    Ao = _oracle_csr(dims, csr)
+    x = np.ones(n)
+    x[11] = np.inf           # row 10 does not reference x[11]; rows 11 and 12 do
+    x[300] = np.nan
+    A = sla.fromCSR(dims, *csr)
+    assert "wdia" in A.kernel_info()
+    y = sla.matVec(A, sla.fromVector(x)).toDenseListSV()
+    want = orc.spmv(Ao, x)
+    assert np.isfinite(y[10]) and np.isinf(y[11]) and np.isinf(y[12])
+    assert np.array_equal(np.isnan(y), np.isnan(want)) and np.array_equal(y[~np.isnan(y)], want[~np.isnan(want)])
