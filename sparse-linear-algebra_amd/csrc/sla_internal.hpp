@@ -115,6 +115,7 @@ struct sla_ctx {
     int panels = 1;                  // allow the column-panel SpMV for irregular matrices (SLA_PANELS=0 disables)
     int64_t panel_cols = 384 * 1024; // panel width in columns (SLA_PANEL_COLS): 3 MiB of x per pass
     int diag = 1;                    // allow the dictionary-compressed-index SpMV kernel (SLA_DIAG=0 disables)
+    int wd_tile = -1;                // plane tiling of the wave-sliced walk: -1 automatic, 0 off, > 0 steps per tile (SLA_WD_TILE)
     int wdia = 1;                    // allow the wave-sliced SpMV kernel (SLA_WDIA=0 disables)
     int vdict = 1;                   // allow the value-indexed SpMV kernel (SLA_VDICT=0 disables)
     int xwin = 1;                    // allow the LDS x-window SpMV kernel (SLA_XWIN=0 disables)
@@ -171,6 +172,7 @@ struct sla_csr {
     int32_t *d_woff = nullptr;              // ... and its diagonal offset (col - row); all padded by 8 records
     bool use_wdia = false;
     int32_t nslices = 0;
+    int32_t *d_wsched = nullptr;     // visiting order of the 512-row steps (null: ascending); see csr_upload
     int32_t nblk_wd = 0;             // ceil(nslices / 4): workgroup steps of spmv_wdia_kernel
     int64_t nwent = 0;
     bool use_xwin = false;           // enough entries fall inside the windows for spmv_xwin_kernel to pay
@@ -201,6 +203,19 @@ struct sla_solver {
 };
 
 namespace sla {
+
+// Guarded device allocation for everything an SpMV may gather from (vectors, the exchange landing buffer, the
+// Arnoldi basis): kGuardBytes of readable slack on both sides.  spmv_wdia_kernel gathers row PAIRS with one
+// 16-byte load; when only one row of a pair holds an entry, the other half may lie one element outside
+// [0, n) -- inside the slack, never used (the fold is masked per row).
+constexpr size_t kGuardBytes = 256;
+inline hipError_t guard_malloc(void **p, size_t bytes) {
+    void *raw = nullptr;
+    const hipError_t e = hipMalloc(&raw, bytes + 2 * kGuardBytes);
+    if (e == hipSuccess) *p = (char *)raw + kGuardBytes;
+    return e;
+}
+inline hipError_t guard_free(void *p) { return p ? hipFree((char *)p - kGuardBytes) : hipSuccess; }
 
 // error plumbing ---------------------------------------------------------------------------------
 void set_error(const std::string &msg);

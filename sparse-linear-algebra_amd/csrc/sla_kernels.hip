@@ -1406,6 +1406,19 @@ typedef int wd_i32x8 __attribute__((ext_vector_type(8), aligned(4)));
 typedef double wd_f64x2u __attribute__((ext_vector_type(2), aligned(8)));  // a row pair of x at any 8-byte boundary
 typedef double wd_f64x2 __attribute__((ext_vector_type(2)));
 
+#if defined(SLA_WD_TRACE)
+__device__ unsigned long long wd_trace[64 * 16 * 4];
+extern "C" int sla_debug_wd_trace(unsigned long long *host) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(wd_trace), sizeof(wd_trace));
+}
+#define WD_STAMP(i)                                                                                            \
+    if (trace_on && iter < 16) {                                                                               \
+        const unsigned long long t_ = __builtin_readcyclecounter();                                            \
+        if (lane == 0) wd_trace[((blockIdx.x >> 5) * 16 + iter) * 4 + (i)] = t_;                               \
+    }
+#else
+#define WD_STAMP(i)
+#endif
 struct WdRec {  // lane k < 8 holds record k of the slice's first chunk (both masks 0: no such record)
     unsigned long long me, mo;
     double v;
@@ -1429,7 +1442,7 @@ __global__ void __launch_bounds__(kBlock, 8) spmv_wdia_kernel(SpmvArgs<int32_t> 
                                                                const unsigned long long *__restrict__ wmo,
                                                                const double *__restrict__ wval, const int32_t *__restrict__ woff,
                                                                const double *__restrict__ xg, int32_t nblk, int32_t nslices,
-                                                               int32_t grow0, int32_t xlen, int xcd_remap) {
+                                                               int32_t grow0, int32_t xlen, const int32_t *__restrict__ sched, int xcd_remap) {
     __shared__ double s_red[4];
     const int tid = threadIdx.x;
     double coef;
@@ -1441,13 +1454,19 @@ __global__ void __launch_bounds__(kBlock, 8) spmv_wdia_kernel(SpmvArgs<int32_t> 
     constexpr bool kUsesW = EPI == EPI_DOT || EPI == EPI_DOT2 || EPI == EPI_RES || EPI == EPI_SUB || EPI == EPI_AXPY_DOT;
     constexpr bool kUsesZ = EPI == EPI_AXPY_DOT || EPI == EPI_XPBY_NRM;
     // slice descriptor of workgroup step b (wave-uniform): first record, record count (0: nothing to do)
-    auto load_desc = [&](int b, int &e0, int &cnt) {
+    // `sched` (optional) is the order in which the 512-row steps are visited (see csr_upload: steps a far diagonal
+    // apart are made neighbours in time so that the three planes a 3-D stencil row touches meet in the L2)
+    auto load_desc = [&](int b, int &blk, int &e0, int &cnt) {
         e0 = 0;
         cnt = 0;
-        const int s = b * 4 + wave;
-        if (b < wk.last && s < nslices) {
-            e0 = sptr[s];
-            cnt = sptr[s + 1] - e0;
+        blk = 0;
+        if (b < wk.last) {
+            blk = sched ? sched[b] : b;
+            const int s = blk * 4 + wave;
+            if (s < nslices) {
+                e0 = sptr[s];
+                cnt = sptr[s + 1] - e0;
+            }
         }
     };
     auto load_rec = [&](int e0, int cnt, WdRec &r) {
@@ -1463,34 +1482,22 @@ __global__ void __launch_bounds__(kBlock, 8) spmv_wdia_kernel(SpmvArgs<int32_t> 
         }
     };
     int b = wk.first;
-    int e0_c, cnt_c, e0_n, cnt_n;
+    int blk_c, e0_c, cnt_c, blk_n, e0_n, cnt_n;
     WdRec rc, rn;
-    load_desc(b, e0_c, cnt_c);
-    load_desc(b + wk.step, e0_n, cnt_n);
+    load_desc(b, blk_c, e0_c, cnt_c);
+    load_desc(b + wk.step, blk_n, e0_n, cnt_n);
     load_rec(e0_c, cnt_c, rc);
-    for (; b < wk.last; b += wk.step) {
-        int e0_f, cnt_f;
-        load_rec(e0_n, cnt_n, rn);               // next slice's records: in flight behind this slice's gathers
-        load_desc(b + 2 * wk.step, e0_f, cnt_f);
-#if defined(SLA_WD_PREFETCH)
-        // L2 prefetch for this wavefront's NEXT slice of the two streams nobody has touched yet: the leading
-        // edge of x (largest diagonal offset; stencils repeat their offsets slice after slice) and the
-        // epilogue operand.  One dword per 128-byte line, lanes 0..7 / 8..15.
-        int pf = 0;
-        if (cnt_n > 0 && lane < 16) {
-            const int rown = ((b + wk.step) * 4 + wave) * 128;
-            const int olast = __builtin_amdgcn_readlane(rc.o, 7 < cnt_c - 1 ? 7 : (cnt_c > 0 ? cnt_c - 1 : 0));
-            if (lane < 8) {
-                const long long idx = (long long)grow0 + rown + olast + lane * 16;
-                if (idx >= 0 && idx < (long long)xlen) pf = *(const int *)(xg + idx);
-            } else if (kUsesW && a.w != nullptr) {
-                const int idx = rown + (lane - 8) * 16;
-                if (idx < a.rows) pf = *(const int *)(a.w + idx);
-            }
-        }
+#if defined(SLA_WD_TRACE)
+    const bool trace_on = (blockIdx.x & 31) == 0 && wave == 0 && EPI == EPI_DOT;
+    int iter = 0;
 #endif
+    for (; b < wk.last; b += wk.step) {
+        int blk_f, e0_f, cnt_f;
+        WD_STAMP(0)
+        load_rec(e0_n, cnt_n, rn);               // next slice's records: in flight behind this slice's gathers
+        load_desc(b + 2 * wk.step, blk_f, e0_f, cnt_f);
         if (cnt_c > 0) {
-            const int row = (b * 4 + wave) * 128 + 2 * lane;  // this lane's rows: row, row + 1
+            const int row = (blk_c * 4 + wave) * 128 + 2 * lane;  // this lane's rows: row, row + 1
             const bool va = row < a.rows, vb = row + 1 < a.rows;
             // epilogue operands: issued before the gathers so they fly together
             wd_f64x2 wv = {0.0, 0.0}, zv = {0.0, 0.0};
@@ -1508,33 +1515,39 @@ __global__ void __launch_bounds__(kBlock, 8) spmv_wdia_kernel(SpmvArgs<int32_t> 
             // byte offset of x[global row]; a record's diagonal offset moves the scalar base instead
             const uint32_t g8 = (uint32_t)(grow0 + row) * 8u;
             double ya = 0.0, yb = 0.0;
-            wd_f64x2 xv[8];
+            wd_f64x2 xv[8];  // gathered row pairs
+#pragma unroll
+            for (int k = 0; k < 8; ++k) asm("" : "=v"(xv[k]));  // "defined" without an instruction: a lane that does not
+                                                                // load holds garbage, which EXEC never lets the fold use
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                const unsigned long long me = wd_lane_u64(rc.me, k), mo = wd_lane_u64(rc.mo, k);
+                const unsigned long long mb = wd_lane_u64(rc.me | rc.mo, k);  // lanes with the entry in either row (0: no record k)
                 const int ok = __builtin_amdgcn_readlane(rc.o, k);
-                xv[k] = wd_f64x2{0.0, 0.0};
-                const char *base = (const char *)(xg + ok) + g8;
-                // both rows of the lane hold the entry: one 16-byte gather; a row alone (matrix edge, ragged
-                // pattern): its own 8 bytes, so nothing outside x is ever touched
-                if (__builtin_amdgcn_inverse_ballot_w64(me & mo)) xv[k] = *(const wd_f64x2u *)base;
-                if (__builtin_amdgcn_inverse_ballot_w64(me & ~mo)) xv[k].x = *(const double *)base;
-                if (__builtin_amdgcn_inverse_ballot_w64(mo & ~me)) xv[k].y = *(const double *)(base + 8);
+                // one 16-byte gather per lane.  When only one row of the pair holds the entry the other half is
+                // loaded and ignored; at the two ends of x it lies in the guard slack (guard_malloc).
+                if (__builtin_amdgcn_inverse_ballot_w64(mb)) xv[k] = *(const wd_f64x2u *)((const char *)(xg + ok) + g8);
             }
+            WD_STAMP(1)
+#if defined(SLA_WD_TRACE)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            WD_STAMP(2)
+#endif
             {
 #pragma clang fp contract(off)  // a*x then +: two roundings like the reference, never an FMA
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
+                    if (k >= cnt_c) break;  // wave-uniform
                     const unsigned long long me = wd_lane_u64(rc.me, k), mo = wd_lane_u64(rc.mo, k);
                     const double vk = wd_lane_f64(rc.v, k);
-                    if (__builtin_amdgcn_inverse_ballot_w64(me)) {
-                        const double p = vk * xv[k].x;
-                        ya = ya + p;
-                    }
-                    if (__builtin_amdgcn_inverse_ballot_w64(mo)) {
-                        const double p = vk * xv[k].y;
-                        yb = yb + p;
-                    }
+                    // EXEC = the even rows that hold the entry, then the odd rows; v_mul_f64 then v_add_f64 (two
+                    // roundings).  All 64 lanes are active here (wave-uniform control flow only): EXEC goes back to -1.
+                    double p;
+                    asm volatile(
+                        "s_mov_b64 exec, %[me]\n\tv_mul_f64 %[p], %[v], %[xa]\n\tv_add_f64 %[ya], %[ya], %[p]\n\t"
+                        "s_mov_b64 exec, %[mo]\n\tv_mul_f64 %[p], %[v], %[xb]\n\tv_add_f64 %[yb], %[yb], %[p]\n\t"
+                        "s_mov_b64 exec, -1"
+                        : [ya] "+v"(ya), [yb] "+v"(yb), [p] "=&v"(p)
+                        : [me] "s"(me), [mo] "s"(mo), [v] "s"(vk), [xa] "v"(xv[k].x), [xb] "v"(xv[k].y));
                 }
                 // slices with more than 8 records (27-point stencils, ...): the rest one by one through scalar loads
                 for (int c = 8; c < cnt_c; ++c) {
@@ -1599,12 +1612,15 @@ __global__ void __launch_bounds__(kBlock, 8) spmv_wdia_kernel(SpmvArgs<int32_t> 
                 }
             }
         }
-#if defined(SLA_WD_PREFETCH)
-        asm volatile("" ::"v"(pf));
+        WD_STAMP(3)
+#if defined(SLA_WD_TRACE)
+        ++iter;
 #endif
+        blk_c = blk_n;
         e0_c = e0_n;
         cnt_c = cnt_n;
         rc = rn;
+        blk_n = blk_f;
         e0_n = e0_f;
         cnt_n = cnt_f;
     }
@@ -1732,7 +1748,8 @@ static int launch_spmv_t(const sla_csr *A, const SpmvLaunch &l) {
     if (A->use_wdia && c->wdia && c->spmv_algo == 0 && !l.x2) {
         if constexpr (std::is_same<RP, int32_t>::value) {
             hipLaunchKernelGGL((spmv_wdia_kernel<EPI>), dim3(grid), dim3(kBlock), 0, c->stream, a, A->d_wptr, A->d_wme, A->d_wmo,
-                               A->d_wval, A->d_woff, a.x, A->nblk_wd, A->nslices, (int32_t)A->row_begin, (int32_t)A->n, c->xcd_remap);
+                               A->d_wval, A->d_woff, a.x, A->nblk_wd, A->nslices, (int32_t)A->row_begin, (int32_t)A->n,
+                               c->wd_tile != 0 ? A->d_wsched : nullptr, c->xcd_remap);
             SLA_HIP_TRY(hipGetLastError());
             return SLA_OK;
         }

@@ -338,7 +338,7 @@ struct ArnoldiWs {
     SolverScalars *d_sc = nullptr, *h_sc = nullptr;
     std::vector<double> Hhost;
     ~ArnoldiWs() {
-        if (Q) (void)hipFree(Q);
+        if (Q) (void)guard_free(Q);
         if (w) (void)hipFree(w);
         if (H) (void)hipFree(H);
         if (parts) (void)hipFree(parts);
@@ -357,7 +357,7 @@ int arn_alloc(ArnoldiWs &ws, sla_csr *A, sla_vec *like, int kn) {
     ws.ld = std::max<int64_t>(like->shard + (like->shard & 1), 2);  // even leading dimension: 16-byte aligned columns
     ws.kn = kn;
     const size_t qbytes = sizeof(double) * (size_t)ws.ld * (size_t)(kn + 1);
-    SLA_HIP_TRY(hipMalloc((void **)&ws.Q, qbytes));
+    SLA_HIP_TRY(guard_malloc((void **)&ws.Q, qbytes));  // SpMV gathers from its columns
     SLA_HIP_TRY(hipMemsetAsync(ws.Q, 0, qbytes, c->stream));
     SLA_HIP_TRY(hipMalloc((void **)&ws.w, sizeof(double) * (size_t)ws.ld));
     SLA_HIP_TRY(hipMemsetAsync(ws.w, 0, sizeof(double) * (size_t)ws.ld, c->stream));

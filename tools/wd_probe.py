@@ -81,3 +81,37 @@ def run_axpby(R, reps=60):
 if not sys.argv[1:] or "axpby" in sys.argv[1:]:
     for R in (1, 6):
         run_axpby(R)
+
+
+def run_scal(R, reps=60):
+    xs = [sla.DeviceVector(ctx, n, np.full(n, 1.0 + i)) for i in range(R)]
+    for i in range(R):
+        _lib.check(lib.sla_scal(C.c_double(1.0000001), xs[i].h))
+    ctx.sync()
+    t0 = time.perf_counter()
+    for k in range(reps):
+        _lib.check(lib.sla_scal(C.c_double(1.0000001), xs[k % R].h))
+    ctx.sync()
+    dt = (time.perf_counter() - t0) / reps
+    print("scal  (16 B/row = %.0f MB)        R=%d  %7.1f us/launch  %.2f TB/s" % (16 * n / 1e6, R, dt * 1e6, 16 * n / dt / 1e12), flush=True)
+
+
+def run_copy(R, reps=60):
+    xs = [sla.DeviceVector(ctx, n, np.full(n, 1.0 + i)) for i in range(R)]
+    ys = [sla.DeviceVector(ctx, n) for i in range(R)]
+    for i in range(R):
+        _lib.check(lib.sla_vec_copy(xs[i].h, ys[i].h))
+    ctx.sync()
+    t0 = time.perf_counter()
+    for k in range(reps):
+        _lib.check(lib.sla_vec_copy(xs[k % R].h, ys[k % R].h))
+    ctx.sync()
+    dt = (time.perf_counter() - t0) / reps
+    print("copy  (16 B/row = %.0f MB)        R=%d  %7.1f us/launch  %.2f TB/s" % (16 * n / 1e6, R, dt * 1e6, 16 * n / dt / 1e12), flush=True)
+
+
+if not sys.argv[1:] or "scal" in sys.argv[1:]:
+    for R in (1, 6, 12):
+        run_scal(R)
+    for R in (1, 6):
+        run_copy(R)
