@@ -125,7 +125,7 @@ int main(int argc, char **argv) {
     Timer T(c->stream);
     double bytes = 12.0 * nnz + 20.0 * n;
     printf("n=%lld nnz=%lld B_spmv=%.1f MB\n", (long long)n, (long long)nnz, bytes / 1e6);
-    auto report = [&](const char *name, double ms, double b) { printf("%-44s %8.3f ms  %8.1f GB/s\n", name, ms, b / ms / 1e6); };
+    auto report = [&](const char *name, double ms, double b) { printf("%-52s %8.3f ms  %8.1f GB/s\n", name, ms, b / ms / 1e6); };
 
     if (argc > 2 && !strcmp(argv[2], "pmc")) {
         // few launches, for counter collection: known-bytes calibrators + the SpMV variants
@@ -143,47 +143,34 @@ int main(int argc, char **argv) {
         hipStreamSynchronize(c->stream);
         return 0;
     }
-    for (int algo = 0; algo < 1; ++algo) {
-        c->spmv_algo = algo;
-        for (int remap = 1; remap < 4; ++remap) {
-            c->xwin = remap >= 2 ? 0 : 1; if (remap == 3) continue;
-            c->xcd_remap = 1;
-            for (int g : {1024, 2048}) {
-                c->spmv_grid_max = g;
-                char nm[128];
-                SpmvLaunch l;
-                l.x = x->d; l.y = y->d;
-                snprintf(nm, sizeof nm, "%s plain xwin=%d grid=%d", (algo ? "scalar" : "stream"), c->xwin, g);
-                report(nm, T.run([&] { launch_spmv(A, l); }, 20), bytes);
-                SpmvLaunch d = l;
-                d.epi = EPI_DOT; d.w = w->d; d.p1 = c->d_parts;
-                snprintf(nm, sizeof nm, "%s dot(w separate) xwin=%d grid=%d", (algo ? "scalar" : "stream"), c->xwin, g);
-                report(nm, T.run([&] { launch_spmv(A, d); }, 20), bytes + 8.0 * n);
-                d.w = x->d;
-                snprintf(nm, sizeof nm, "%s dot(w = x) xwin=%d grid=%d", (algo ? "scalar" : "stream"), c->xwin, g);
-                report(nm, T.run([&] { launch_spmv(A, d); }, 20), bytes);
-                SpmvLaunch d2 = l;
-                d2.epi = EPI_DOT2; d2.w = x->d; d2.p1 = c->d_parts; d2.p2 = c->d_parts + kMaxParts;
-                snprintf(nm, sizeof nm, "%s dot2(w = x) xwin=%d grid=%d", (algo ? "scalar" : "stream"), c->xwin, g);
-                report(nm, T.run([&] { launch_spmv(A, d2); }, 20), bytes);
-            }
+    // every SpMV form the library has for this matrix, selected through the context's knobs (one x / y pair: the
+    // vectors stay in the memory-side cache between launches; bench.py times the rotating, HBM-resident case)
+    struct Form { const char *name; int wdia, vdict, diag, xwin; };
+    const Form forms[] = {{"wdia (wave-sliced pairs)", 1, 1, 1, 1}, {"vdict+xwin (1 B/entry)", 0, 1, 1, 1},
+                          {"diagdict+xwin (val + 1 B)", 0, 0, 1, 1}, {"stream+xwin (val + i32)", 0, 0, 0, 1},
+                          {"stream (val + i32)", 0, 0, 0, 0}};
+    for (const Form &f : forms) {
+        c->wdia = f.wdia; c->vdict = f.vdict; c->diag = f.diag; c->xwin = f.xwin;
+        c->xcd_remap = 1;
+        for (int g : {1024, 2048}) {
+            c->spmv_grid_max = g;
+            char nm[128];
+            SpmvLaunch l;
+            l.x = x->d; l.y = y->d;
+            snprintf(nm, sizeof nm, "%s plain grid=%d", f.name, g);
+            report(nm, T.run([&] { launch_spmv(A, l); }, 20), bytes);
+            SpmvLaunch d = l;
+            d.epi = EPI_DOT; d.w = w->d; d.p1 = c->d_parts;
+            snprintf(nm, sizeof nm, "%s dot(w separate) grid=%d", f.name, g);
+            report(nm, T.run([&] { launch_spmv(A, d); }, 20), bytes + 8.0 * n);
+            SpmvLaunch d2 = l;
+            d2.epi = EPI_DOT2; d2.w = x->d; d2.p1 = c->d_parts; d2.p2 = c->d_parts + kMaxParts;
+            snprintf(nm, sizeof nm, "%s dot2(w = x) grid=%d", f.name, g);
+            report(nm, T.run([&] { launch_spmv(A, d2); }, 20), bytes);
         }
     }
+    c->wdia = c->vdict = c->diag = c->xwin = 1;
     c->spmv_algo = 0; c->xcd_remap = 1; c->spmv_grid_max = 2048;
-    {   // same structure, columns collapsed to 0..6: every gather hits L1 -> cost of the streams alone
-        std::vector<int64_t> ci2(ci.size());
-        for (int64_t r = 0; r < n; ++r)
-            for (int64_t k = rp[r]; k < rp[r + 1]; ++k) ci2[k] = k - rp[r];
-        sla_csr_t B;
-        CK(sla_csr_from_csr(c, n, n, rp.data(), ci2.data(), va.data(), &B));
-        SpmvLaunch l;
-        l.x = x->d; l.y = y->d;
-        report("stream plain, gathers collapsed to x[0..6]", T.run([&] { launch_spmv(B, l); }, 20), bytes - 8.0 * n);
-        SpmvLaunch d = l;
-        d.epi = EPI_DOT; d.w = w->d; d.p1 = c->d_parts;
-        report("stream dot,   gathers collapsed to x[0..6]", T.run([&] { launch_spmv(B, d); }, 20), bytes);
-        sla_csr_destroy(B);
-    }
     {   // raw stream micro-kernels on the matrix arrays themselves
         double *scratch;
         hipMalloc(&scratch, sizeof(double) * (size_t)(2 * n + 4096));
