@@ -534,6 +534,11 @@ static int ctx_create_common(int device_id, int rank, int nranks, const void *ui
     if (const char *s = getenv("SLA_RB_NNZ")) c->rb_nnz = atoi(s);
     if (const char *s = getenv("SLA_DEVICE_COO_MIN")) c->device_coo_min = atoll(s);
     if (const char *s = getenv("SLA_X_EXCHANGE")) c->x_exchange = strcmp(s, "allgather") == 0 ? 1 : (strcmp(s, "window") == 0 ? 2 : 0);
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess && cus > 0)
+            c->wd_grid_max = std::min<int>(kMaxParts, std::max(8, (kWdBlocksPerCu * cus) & ~7));
+    }
     if (const char *s = getenv("SLA_SPMV_GRID")) {
         int g = atoi(s);
         if (g >= 1 && g <= kMaxParts) c->spmv_grid_max = g;

@@ -18,6 +18,7 @@ constexpr int kNnzPerRowBlock = 1024; // products staged in LDS per row block (8
 constexpr int kMaxRowsPerRowBlock = 256;
 constexpr int kXWin = 768;           // doubles of x staged in LDS per row block by spmv_xwin_kernel (6 KiB)
 constexpr int kXWinHalo = 256;       // the window starts kXWinHalo columns left of the block's first diagonal column
+constexpr int kWdBlocksPerCu = 6;    // resident workgroups per CU of spmv_wdia_kernel (its persistent grid = 6 x CUs)
 constexpr int kVdRows = 256;         // rows per block of spmv_vdict_kernel (one lane per row)
 constexpr int kVdMaxRowNnz = 31;     // longest row the value-indexed kernel takes (256 rows x 31 B of codes fit its LDS stage)
 constexpr int kWaveRowMax = 16384;   // rows of 1025..16384 entries: one wavefront each, 4 per row block; longer: whole workgroup
@@ -123,6 +124,7 @@ struct sla_ctx {
     int x_exchange = 0;              // 0 auto (window exchange when it pays), 1 always all-gather, 2 always window (SLA_X_EXCHANGE=allgather|window)
     bool collectives = false;        // nranks > 1, or SLA_FORCE_COLLECTIVES=1 on a 1-rank communicator (test hook)
     int spmv_grid_max = sla::kSpmvGridMax;
+    int wd_grid_max = sla::kWdBlocksPerCu * 256;  // persistent grid of spmv_wdia_kernel: kWdBlocksPerCu x CUs (a multiple of 8)
     // Device-vector pool: a pure `linSolve0` call allocates ~10 vectors and frees them again; hipMalloc /
     // hipFree of 80 MB blocks cost milliseconds each, so freed vector buffers are kept (by exact size) and
     // handed out again.  Reuse is ordered by the context stream, so no synchronisation is needed.

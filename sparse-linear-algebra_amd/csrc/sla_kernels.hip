@@ -32,6 +32,7 @@
 //   linSolve0 runIter :1043-1052               arnoldi :630-667
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <type_traits>
 
 #include "sla_internal.hpp"
@@ -1436,8 +1437,11 @@ __device__ __forceinline__ double wd_lane_f64(double x, int k) {
 // trips to memory.  The descriptor (scalar) is fetched two slices ahead and the records one slice ahead --
 // by lanes 0..7, one record each, through the in-order vector queue; v_readlane moves a field to SGPRs when
 // it is used -- so a wavefront waits on memory once per slice.
+// Six workgroups per CU, not eight: 85 VGPRs instead of 64 end the spills of the fused epilogues, and the CU's L1
+// serves more of the overlapping gathers with fewer wavefronts streaming through it (measured same-box:
+// 8 / 7 / 6 / 5 / 4 per CU = 2890 / 3110 / 3170 / 3140 / 2940 BiCGSTAB it/s).
 template <int EPI>
-__global__ void __launch_bounds__(kBlock, 8) spmv_wdia_kernel(SpmvArgs<int32_t> a, const int32_t *__restrict__ sptr,
+__global__ void __launch_bounds__(kBlock, kWdBlocksPerCu) spmv_wdia_kernel(SpmvArgs<int32_t> a, const int32_t *__restrict__ sptr,
                                                                const unsigned long long *__restrict__ wme,
                                                                const unsigned long long *__restrict__ wmo,
                                                                const double *__restrict__ wval, const int32_t *__restrict__ woff,
@@ -1668,7 +1672,7 @@ int spmv_grid(const sla_csr *A) {
     if (!A->panels.empty() && c->panels && c->spmv_algo == 0) return spmv_grid(A->panels.back());
     int64_t g;
     if (c->spmv_algo == 1) g = (A->rows + kBlock - 1) / kBlock;
-    else if (A->use_wdia && c->wdia) g = A->nblk_wd;
+    else if (A->use_wdia && c->wdia) g = std::min<int64_t>(A->nblk_wd, c->wd_grid_max);
     else if (A->use_vdict && c->vdict) g = A->nblk_vd;
     else g = A->nrb;
     if (g < 1) g = 1;
