@@ -152,8 +152,10 @@ int main(int argc, char **argv) {
     for (const Form &f : forms) {
         c->wdia = f.wdia; c->vdict = f.vdict; c->diag = f.diag; c->xwin = f.xwin;
         c->xcd_remap = 1;
-        for (int g : {1024, 2048}) {
-            c->spmv_grid_max = g;
+        for (int g0 : {1024, 2048}) {
+            const int g = f.wdia ? (g0 == 2048 ? kWdBlocksPerCu * 256 : g0) : g0;   // the wave-sliced kernel runs 6 workgroups per CU
+            c->spmv_grid_max = g0;
+            c->wd_grid_max = g;
             char nm[128];
             SpmvLaunch l;
             l.x = x->d; l.y = y->d;
