@@ -38,7 +38,8 @@ typedef enum {
     SLA_ERR_RCCL = 5,
     SLA_ERR_ALLOC = 6,
     SLA_ERR_INVALID = 7,            /* NULL handle, negative size, size beyond the device index width */
-    SLA_ERR_NO_DEVICE = 8           /* no HIP device: the library has no CPU fallback */
+    SLA_ERR_NO_DEVICE = 8,          /* no HIP device: the library has no CPU fallback */
+    SLA_ERR_NEEDS_PIVOTING = 9      /* NeedsPivoting "triLowerSolve" "L (i, i)" (Control/Exception/Common.hs:58; Sparse.hs:757, :792) */
 } sla_status;
 
 /* LinSolveMethod, constructor order of Sparse.hs:1007-1011 */
@@ -135,6 +136,22 @@ int sla_jacobi_pre(sla_csr_t A, sla_csr_t *out);
  * preconditioners need): row i of the result is d_ii * row i of A, entries with |x| <= 1e-12 dropped, rows
  * without a D entry dropped.  `jacobiPre aa #~# aa` is the left-Jacobi-preconditioned operator. */
 int sla_csr_diag_mul(sla_csr_t D, sla_csr_t A, sla_csr_t *out);
+/* triLowerSolve (upper == 0, Sparse.hs:750-776) / triUpperSolve (upper != 0, :784-811): forward / backward
+ * substitution x_i = (b_i - subrow_i . x) / t_ii with the diagonal and the strictly lower (upper) part of T; entries
+ * on the other side are ignored like the reference's extractSubRow does.  Every row is the ascending left fold of
+ * separately rounded products followed by one subtraction and one division (bit-identical to the reference's order);
+ * the result goes through sparsifySV (|x_i| <= 1e-12 reads back as 0).  A diagonal entry that is missing or
+ * |t_ii| <= 1e-12 => SLA_ERR_NEEDS_PIVOTING (the reference throws NeedsPivoting), `bad_row` (may be NULL) receives the row.
+ * Rows are level-scheduled at the first call (one launch per dependency level, replayed as a HIP graph while b / x
+ * stay the same buffers).  Single-rank contexts; T square, b and x of its dimension, x != b. */
+int sla_tri_solve(sla_csr_t T, int upper, sla_vec_t b, sla_vec_t x, int64_t *bad_row);
+/* number of dependency levels / the widest level of the schedule sla_tri_solve uses (builds it if needed) */
+int sla_tri_solve_info(sla_csr_t T, int upper, int64_t *levels, int64_t *widest_level);
+/* mSsorPre aa omega = (l, r), l = (eye n ^-^ scale omega e) ## reciprocal d, r = d ^-^ scale omega f with e / d / f the
+ * strictly lower / diagonal / strictly upper parts of aa (Sparse.hs:712-720, diagPartitions :673-678).  Both factors
+ * hold the structurally non-zero entries ((##) itself would keep explicit zeros over the whole index set; the
+ * values at the stored positions are identical).  Single-rank contexts. */
+int sla_ssor_pre(sla_csr_t A, double omega, sla_csr_t *l, sla_csr_t *r);
 int sla_csr_destroy(sla_csr_t);
 /* dim / nnz of SpMatrix (local_rows/local_nnz = this rank's block) */
 int sla_csr_dims(sla_csr_t, int64_t *m, int64_t *n, int64_t *nnz_local, int64_t *rows_local);

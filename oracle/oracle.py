@@ -251,3 +251,37 @@ def matmat(A, B):
         return rc, None
     k = nn.value
     return rc, Csr(A.m, B.n, cp, cc[:k].copy(), cv[:k].copy())
+
+
+ERR_PIVOT = 5
+
+
+def _tri(fn, T, b):
+    x = np.zeros(T.m, dtype=np.float64)
+    bad = C.c_int64(-1)
+    v = T.view()
+    rc = fn(C.byref(v), _p(_f64(b)), _p(x), C.byref(bad))
+    return rc, x, bad.value
+
+
+def tri_lower_solve(T, b):
+    """triLowerSolve (Sparse.hs:750-776): (rc, x, bad_row); rc == ERR_PIVOT when l_ii is missing / near zero."""
+    return _tri(lib().orc_tri_lower_solve, T, b)
+
+
+def tri_upper_solve(T, b):
+    """triUpperSolve (Sparse.hs:784-811)."""
+    return _tri(lib().orc_tri_upper_solve, T, b)
+
+
+def ssor_pre(A, omega):
+    """mSsorPre (Sparse.hs:712-720): (rc, L, R) with L = (I - omega E) ## reciprocal D, R = D - omega F."""
+    cap = int(A.rowptr[-1]) + A.m + 1
+    lp, rp = np.zeros(A.m + 1, dtype=np.int64), np.zeros(A.m + 1, dtype=np.int64)
+    lc, rc_ = np.zeros(cap, dtype=np.int64), np.zeros(cap, dtype=np.int64)
+    lv, rv = np.zeros(cap), np.zeros(cap)
+    v = A.view()
+    rc = lib().orc_ssor_pre(C.byref(v), C.c_double(omega), _p(lp), _p(lc), _p(lv), _p(rp), _p(rc_), _p(rv))
+    if rc != OK:
+        return rc, None, None
+    return rc, Csr(A.m, A.n, lp, lc[:lp[-1]].copy(), lv[:lp[-1]].copy()), Csr(A.m, A.n, rp, rc_[:rp[-1]].copy(), rv[:rp[-1]].copy())

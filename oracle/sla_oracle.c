@@ -525,3 +525,87 @@ int orc_matmat(const orc_csr *A, const orc_csr *B, int64_t *c_rowptr, int64_t *c
     free(tp); free(tc); free(tv);
     return ORC_OK;
 }
+
+/* ---------------------------------------------------------------------------------------------
+ * triangular solves and the SSOR factors
+ * ------------------------------------------------------------------------------------------- */
+static double tri_diag(const orc_csr *T, int64_t i) {                /* ll @@ (i, i): 0 when absent */
+    for (int64_t k = T->rowptr[i]; k < T->rowptr[i + 1]; ++k)
+        if (T->colidx[k] == i) return T->val[k];
+    return 0.0;
+}
+static int is_nz(double v) { return !(fabs(v) <= 1e-12); }          /* isNz = not . nearZero        */
+
+/* triLowerSolve, Sparse.hs:750-776: w_i = (b_i - subrow(i, 0..i-1) `dot` w) / l_ii, i ascending */
+int orc_tri_lower_solve(const orc_csr *T, const double *b, double *x, int64_t *bad_row) {
+    if (T->m != T->n) return ORC_ERR_DIM;
+    for (int64_t i = 0; i < T->m; ++i) {
+        double lii = tri_diag(T, i);
+        if (!is_nz(lii)) { if (bad_row) *bad_row = i; return ORC_ERR_PIVOT; }   /* oops i (:757)   */
+        double r = 0.0;
+        for (int64_t k = T->rowptr[i]; k < T->rowptr[i + 1]; ++k) {
+            int64_t j = T->colidx[k];
+            if (j < i) { double prod = T->val[k] * x[j]; r = r + prod; }        /* ascending fold  */
+        }
+        x[i] = (b[i] - r) / lii;                                                  /* (:760)          */
+    }
+    for (int64_t i = 0; i < T->m; ++i) if (!is_nz(x[i])) x[i] = 0.0;             /* sparsifySV (:776) */
+    return ORC_OK;
+}
+
+/* triUpperSolve, Sparse.hs:784-811: x_i = (w_i - subrow(i, i+1..n-1) `dot` x) / u_ii, i descending */
+int orc_tri_upper_solve(const orc_csr *T, const double *b, double *x, int64_t *bad_row) {
+    if (T->m != T->n) return ORC_ERR_DIM;
+    for (int64_t i = T->m - 1; i >= 0; --i) {
+        double uii = tri_diag(T, i);
+        if (!is_nz(uii)) { if (bad_row) *bad_row = i; return ORC_ERR_PIVOT; }
+        double r = 0.0;
+        for (int64_t k = T->rowptr[i]; k < T->rowptr[i + 1]; ++k) {
+            int64_t j = T->colidx[k];
+            if (j > i) { double prod = T->val[k] * x[j]; r = r + prod; }
+        }
+        x[i] = (b[i] - r) / uii;
+    }
+    for (int64_t i = 0; i < T->m; ++i) if (!is_nz(x[i])) x[i] = 0.0;
+    return ORC_OK;
+}
+
+/* mSsorPre, Sparse.hs:712-720 */
+int orc_ssor_pre(const orc_csr *A, double omega, int64_t *l_rowptr, int64_t *l_colidx, double *l_val,
+                 int64_t *r_rowptr, int64_t *r_colidx, double *r_val) {
+    if (A->m != A->n) return ORC_ERR_DIM;
+    int64_t n = A->m, lo = 0, ro = 0;
+    double *rd = vnew(n);                       /* reciprocal d: recip of the STORED diagonal entries */
+    char *has = (char *)calloc((size_t)(n > 0 ? n : 1), 1);
+    if (!rd || !has) return ORC_ERR_ALLOC;
+    for (int64_t i = 0; i < n; ++i)
+        for (int64_t k = A->rowptr[i]; k < A->rowptr[i + 1]; ++k)
+            if (A->colidx[k] == i) { rd[i] = 1.0 / A->val[k]; has[i] = 1; }
+    l_rowptr[0] = 0;
+    r_rowptr[0] = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        /* row i of (eye n ^-^ scale omega e): -(omega * e_ij) for j < i (x ^-^ y = x ^+^ negated y), then 1 at j = i;
+         * times column j of reciprocal d = a single entry rd[j] at (j, j) when the diagonal entry is stored */
+        for (int64_t k = A->rowptr[i]; k < A->rowptr[i + 1]; ++k) {
+            int64_t j = A->colidx[k];
+            if (j < i && has[j]) {
+                double m = -(omega * A->val[k]);
+                double prod = rd[j] * m, acc = 0.0;                 /* sum of the one-term intersection */
+                acc = acc + prod;
+                l_colidx[lo] = j; l_val[lo] = acc; ++lo;
+            }
+        }
+        if (has[i]) { double prod = rd[i] * 1.0, acc = 0.0; acc = acc + prod; l_colidx[lo] = i; l_val[lo] = acc; ++lo; }
+        l_rowptr[i + 1] = lo;
+        /* r = d ^-^ scale omega f: d_ii at j = i, -(omega * f_ij) for j > i */
+        for (int64_t k = A->rowptr[i]; k < A->rowptr[i + 1]; ++k) {
+            int64_t j = A->colidx[k];
+            if (j == i) { r_colidx[ro] = j; r_val[ro] = A->val[k]; ++ro; }
+            else if (j > i) { r_colidx[ro] = j; r_val[ro] = -(omega * A->val[k]); ++ro; }
+        }
+        r_rowptr[i + 1] = ro;
+    }
+    free(rd);
+    free(has);
+    return ORC_OK;
+}

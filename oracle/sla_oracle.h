@@ -101,6 +101,22 @@ int orc_gmres(const orc_csr *A, int64_t nb, const double *b, const double *x0, i
 int orc_matmat(const orc_csr *A, const orc_csr *B, int64_t *c_rowptr, int64_t *c_colidx,
                double *c_val, int64_t cap, int64_t *c_nnz);
 
+/* triLowerSolve / triUpperSolve (Sparse.hs:750-811).  Forward / backward substitution with
+ * the diagonal and the strictly lower (upper) part of T; entries on the other side are ignored
+ * (extractSubRow takes columns 0..i-1 / i+1..n-1 only).  A diagonal entry that is missing or |.| <= 1e-12
+ * (isNz, Eps.hs:41-42) => ORC_ERR_PIVOT with *bad_row set (the reference throws NeedsPivoting).  The result
+ * goes through sparsifySV: entries with |x_i| <= 1e-12 read back as 0.0. */
+#define ORC_ERR_PIVOT 5
+int orc_tri_lower_solve(const orc_csr *T, const double *b, double *x, int64_t *bad_row);
+int orc_tri_upper_solve(const orc_csr *T, const double *b, double *x, int64_t *bad_row);
+
+/* mSsorPre (Sparse.hs:712-720): L = (I - omega E) ## reciprocal D, R = D - omega F with E / D / F the strictly
+ * lower / diagonal / strictly upper parts of A (diagPartitions, :673-678).  Both as CSR holding the structurally
+ * non-zero entries only ((##) itself keeps explicit zeros over the whole index set; the values at the stored
+ * positions are the same).  Capacities: nnz(A) + n each. */
+int orc_ssor_pre(const orc_csr *A, double omega, int64_t *l_rowptr, int64_t *l_colidx, double *l_val,
+                 int64_t *r_rowptr, int64_t *r_colidx, double *r_val);
+
 #ifdef __cplusplus
 }
 #endif

@@ -145,6 +145,22 @@ struct sla_vec {
     double *d = nullptr;
 };
 
+// level schedule of a triangular solve with one triangle of a matrix (sla_tri_solve)
+struct sla_tri_plan {
+    int64_t nlevels = 0, widest = 0;
+    std::vector<int64_t> level_ptr;   // rows of level l: order[level_ptr[l] .. level_ptr[l + 1])
+    int32_t *d_order = nullptr;       // rows sorted by (level, row)
+    // the triangle re-stored in that order (a lane's row is then found without the order -> rowptr indirection and
+    // neighbouring lanes read neighbouring entries): strictly-triangular entries of schedule slot t are
+    // tcol/tval[tptr[t] .. tptr[t + 1]), its diagonal entry tdiag[t]
+    int64_t *d_tptr = nullptr;
+    int32_t *d_tcol = nullptr;
+    double *d_tval = nullptr, *d_tdiag = nullptr;
+    hipGraphExec_t graph = nullptr;   // the level launches captured for (gb, gx)
+    const double *gb = nullptr;
+    double *gx = nullptr;
+};
+
 struct sla_csr {
     sla_ctx *ctx = nullptr;
     int64_t m = 0, n = 0;            // global dims
@@ -185,6 +201,7 @@ struct sla_csr {
     std::vector<sla_csr *> panels;   // column-panel views (irregular matrices whose x does not fit the L2), else empty
     double *d_panel_y = nullptr;     // running row sums for epilogues that do not store y
     bool is_panel_view = false;
+    sla_tri_plan *tri[2] = {nullptr, nullptr};  // [0] lower, [1] upper triangle schedules (built on first use)
     sla::XPlan *xplan = nullptr;     // sharded only: which x entries this rank exchanges with each peer
     int64_t max_row_nnz = 0;
 };
@@ -341,5 +358,8 @@ int launch_arn_update(sla_ctx *c, int64_t n, const double *Q, int64_t ldq, int n
 int launch_arn_normalize(sla_ctx *c, int64_t n, Parts nrm, const double *w, double *qnext, double *hsub,
                          SolverScalars *sc, int first);
 int launch_gemv_accum(sla_ctx *c, int64_t n, const double *Q, int64_t ldq, int ncols, const double *ycoef_dev, double *x);
+// one dependency level of a triangular solve: rows order[0..count), one lane per row
+int launch_tri_level(const sla_csr *T, const sla_tri_plan *p, int64_t first, int64_t count, const double *b, double *x);
+int launch_tri_sparsify(sla_ctx *c, int64_t n, double *x);  // sparsifySV: |x_i| <= 1e-12 -> 0
 
 }  // namespace sla

@@ -4,7 +4,7 @@ ocramz/sparse-linear-algebra, mirroring the names of Numeric.LinearAlgebra.Spars
 The compute path is libsla_hip.so (hand-written HIP); importing this package without the built
 library raises ImportError -- there is no CPU fallback."""
 from . import _lib
-from ._lib import (IndexOutOfBounds, IterationException, MatVecSizeMismatchException, SlaError,  # noqa: F401
+from ._lib import (IndexOutOfBounds, IterationException, MatVecSizeMismatchException, NeedsPivoting, SlaError,  # noqa: F401
                    SolveInfo, SolveOpts, build)
 from .api import *  # noqa: F401,F403
 from .api import (BICGSTAB_, BCG_, CGNE_, CGS_, GMRES_, Context, DeviceVector, LinSolveMethod, SpMatrix,  # noqa: F401

@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get("SLA_HIP_LIB") or os.path.join(_ROOT, "lib", "libsla_h
 CSRC = os.path.join(_ROOT, "csrc")
 
 (OK, ERR_DIM_MISMATCH, ERR_UNSUPPORTED_METHOD, ERR_OOB, ERR_HIP, ERR_RCCL, ERR_ALLOC, ERR_INVALID,
- ERR_NO_DEVICE) = range(9)
+ ERR_NO_DEVICE, ERR_NEEDS_PIVOTING) = range(10)
 
 FLAG_CONVERGED, FLAG_MAX_ITERS, FLAG_DIAGONAL, FLAG_BREAKDOWN, FLAG_NONFINITE = 1, 2, 4, 8, 16
 KERNEL_SPMV, KERNEL_SPMV_DOT, KERNEL_SPMV_DOT2, KERNEL_SPMV_RES, KERNEL_SPMV_DUAL = 0, 1, 2, 3, 4
@@ -31,6 +31,10 @@ class MatVecSizeMismatchException(SlaError):
 
 class IterationException(SlaError):
     """IterE (Control/Exception/Common.hs:67-76), thrown by linSolve0 for GMRES_/BCG_ (Sparse.hs:1031)."""
+
+
+class NeedsPivoting(SlaError):
+    """NeedsPivoting (Control/Exception/Common.hs:58-61), thrown by triLowerSolve / triUpperSolve (Sparse.hs:757, :792)."""
 
 
 class IndexOutOfBounds(SlaError):
@@ -74,6 +78,9 @@ PROTOTYPES = [
     ("sla_vec_from_matrix_market", _int, [_vp, C.c_char_p, _pp]),
     ("sla_jacobi_pre", _int, [_vp, _pp]),
     ("sla_csr_diag_mul", _int, [_vp, _vp, _pp]),
+    ("sla_tri_solve", _int, [_vp, _int, _vp, _vp, _pi64]),
+    ("sla_tri_solve_info", _int, [_vp, _int, _pi64, _pi64]),
+    ("sla_ssor_pre", _int, [_vp, C.c_double, _pp, _pp]),
     ("sla_csr_destroy", _int, [_vp]),
     ("sla_csr_dims", _int, [_vp, _pi64, _pi64, _pi64, _pi64]),
     ("sla_csr_export", _int, [_vp, _vp, _vp, _vp]),
@@ -149,4 +156,6 @@ def check(rc):
         raise IterationException(rc, msg)
     if rc == ERR_OOB:
         raise IndexOutOfBounds(rc, msg)
+    if rc == ERR_NEEDS_PIVOTING:
+        raise NeedsPivoting(rc, msg)
     raise SlaError(rc, msg)

@@ -415,6 +415,44 @@ def jacobiPre(A):
     return SpMatrix(A.dims, h, A.ctx)
 
 
+def _tri_solve(T, b, upper):
+    ctx = T.ctx
+    bv = b.device() if isinstance(b, SpVector) else b
+    out = DeviceVector(ctx, T.nrows)
+    bad = C.c_int64(-1)
+    check(lib().sla_tri_solve(T.h, 1 if upper else 0, bv.h, out.h, C.byref(bad)))
+    if not isinstance(b, SpVector):
+        return out
+    x = out.to_host()                       # sparsifySV: the near-zero entries are structurally absent
+    ix = np.nonzero(x)[0]
+    return fromListSV(T.nrows, list(zip(ix.tolist(), x[ix].tolist())), ctx) if len(ix) < len(x) else fromVector(x, ctx)
+
+
+def triLowerSolve(ll, b):
+    """Forward substitution (Sparse.hs:750-776); raises NeedsPivoting when l_ii is missing or |l_ii| <= 1e-12.
+    SpVector in -> SpVector out (sparsifySV applied), DeviceVector in -> DeviceVector out."""
+    return _tri_solve(ll, b, False)
+
+
+def triUpperSolve(uu, w):
+    """Backward substitution (Sparse.hs:784-811)."""
+    return _tri_solve(uu, w, True)
+
+
+def triSolveLevels(T, upper=False):
+    """(dependency levels, rows in the widest level) of the schedule the triangular solve uses."""
+    lv, wd = C.c_int64(0), C.c_int64(0)
+    check(lib().sla_tri_solve_info(T.h, 1 if upper else 0, C.byref(lv), C.byref(wd)))
+    return lv.value, wd.value
+
+
+def mSsorPre(aa, omega):
+    """mSsorPre aa omega = (l, r) (Sparse.hs:712-720): l = (eye n ^-^ scale omega e) ## reciprocal d, r = d ^-^ scale omega f."""
+    hl, hr = C.c_void_p(), C.c_void_p()
+    check(lib().sla_ssor_pre(aa.h, float(omega), C.byref(hl), C.byref(hr)))
+    return SpMatrix(aa.dims, hl, aa.ctx), SpMatrix(aa.dims, hr, aa.ctx)
+
+
 def diagMatMatSparsified(D, A):
     """D #~# A for a diagonal D (matMatSparsified, SpMatrix.hs:816-824): the left-preconditioned operator
     `jacobiPre aa #~# aa` without a general SpGEMM."""

@@ -76,3 +76,20 @@ def test_bench_contract_small():
         assert k in d["cpu_baseline"], k
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] == 1
     assert abs(d["value"] - 1e3 / d["ms_per_step"]) <= 1e-6 * d["value"]
+
+
+def test_full_size_triangular_solves_recover_ones(sla):
+    """SURVEY 8(f).2 at BASELINE size: forward / backward substitution with the triangles of the 216^3 Laplacian
+    (10 M rows, 646 dependency levels = hyperplanes of the grid).  With b = T . 1 every row's arithmetic is exact in
+    fp64 (small integers, division by 6), so the substitution must return 1.0 in all 10 077 696 rows."""
+    from sla_amd import workloads as wl
+    dims, (rp, ci, va) = wl.laplace3d(216, 216, 216)
+    n = dims[0]
+    T = sla.fromCSR(dims, rp, ci, va)
+    rows = np.repeat(np.arange(n), np.diff(rp))
+    for upper in (False, True):
+        keep = (ci >= rows) if upper else (ci <= rows)
+        b = np.bincount(rows[keep], weights=va[keep], minlength=n)           # (triangle of A) . 1
+        assert sla.triSolveLevels(T, upper) == (216 * 3 - 2, 34992)
+        x = (sla.triUpperSolve if upper else sla.triLowerSolve)(T, sla.DeviceVector(T.ctx, n, b)).to_host()
+        assert np.array_equal(x, np.ones(n))

@@ -250,3 +250,57 @@ def test_e05r0000_spmv_matches_float_sum():
     y = orc.spmv(A, rhs)
     D = dense_of(A)
     assert np.allclose(y, D @ rhs, rtol=1e-13, atol=1e-13 * np.abs(D).sum(1).max() * np.abs(rhs).max())
+
+
+# ---- triangular solves and the SSOR factors -------------------------------------------------
+@pytest.mark.parametrize("name", ["ltri0", "utri0", "ltri1", "utri1"])
+def test_triangular_solves_reference_cases(name):
+    """specTriangularSolve (LibSpec.hs:203-213): the reference checks nearZero ||T xhat - b||; the fixtures'
+    comments also give xhat itself, which the substitution reproduces exactly."""
+    e = golden()["triangular"][name]
+    dims, r, c, v = coo_of(e)
+    rc, T = orc.coo_to_csr(dims[0], dims[1], r, c, v)
+    assert rc == orc.OK
+    solve = orc.tri_upper_solve if e["upper"] else orc.tri_lower_solve
+    rc, x, bad = solve(T, np.array(e["b"]))
+    assert rc == orc.OK and x.tolist() == e["x"]
+    assert orc.norm2(orc.spmv(T, x) - np.array(e["b"])) <= 1e-12
+
+
+def test_triangular_solve_semantics():
+    # entries on the other side of the diagonal are ignored (extractSubRow takes 0..i-1 / i+1..n-1 only)
+    rc, T = orc.coo_to_csr(3, 3, np.array([0, 0, 1, 1, 2, 2, 2]), np.array([0, 2, 0, 1, 0, 1, 2]),
+                           np.array([2.0, 99.0, 1.0, 4.0, 3.0, 2.0, 3.0]))
+    rc, x, _ = orc.tri_lower_solve(T, np.array([4.0, 10.0, 19.0]))
+    assert rc == orc.OK and x.tolist() == [2.0, 2.0, 3.0]
+    # a missing or near-zero diagonal entry => NeedsPivoting with the row (Sparse.hs:757, :792)
+    rc, T = orc.coo_to_csr(3, 3, np.array([0, 1, 2, 2]), np.array([0, 0, 1, 2]), np.array([2.0, 1.0, 1.0, 1e-13]))
+    rc, x, bad = orc.tri_lower_solve(T, np.ones(3))
+    assert rc == orc.ERR_PIVOT and bad == 1
+    rc, T = orc.coo_to_csr(2, 2, np.array([0, 1]), np.array([0, 1]), np.array([2.0, 1e-13]))
+    rc, x, bad = orc.tri_upper_solve(T, np.ones(2))
+    assert rc == orc.ERR_PIVOT and bad == 1
+    # sparsifySV on the way out: |x_i| <= 1e-12 reads back as 0 (but is used unsparsified by the later rows)
+    rc, T = orc.coo_to_csr(2, 2, np.array([0, 1, 1]), np.array([0, 0, 1]), np.array([1.0, 1e12, 1.0]))
+    rc, x, _ = orc.tri_lower_solve(T, np.array([1e-13, 1.0]))
+    assert x.tolist() == [0.0, 1.0 - 1e12 * 1e-13]
+
+
+def test_ssor_factors_match_the_matrix_ring_definition():
+    """mSsorPre (Sparse.hs:712-720) against its own definition evaluated with the oracle's (##), (^-^) restated densely."""
+    g = golden()["aa2"] if "coo" in golden().get("aa2", {}) or "dense_colmajor" in golden().get("aa2", {}) else golden()["readme"]
+    dims, r, c, v = coo_of(g)
+    rc, A = orc.coo_to_csr(dims[0], dims[1], r, c, v)
+    n = A.m
+    D = dense_of(A)
+    omega = 1.25
+    rc, L, R = orc.ssor_pre(A, omega)
+    assert rc == orc.OK
+    E, F, d = np.tril(D, -1), np.triu(D, 1), np.diag(D)
+    stored = np.zeros((n, n), bool)
+    for i in range(n):
+        stored[i, A.colidx[A.rowptr[i]:A.rowptr[i + 1]]] = True
+    rd = np.where(np.diag(stored), 1.0 / np.where(d == 0, 1.0, d), 0.0)
+    want_l = (np.eye(n) + -(omega * E)) * rd[None, :]
+    want_r = np.diag(d) + -(omega * F)
+    assert np.array_equal(dense_of(L), want_l) and np.array_equal(dense_of(R), want_r)
