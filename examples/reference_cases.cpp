@@ -66,6 +66,16 @@ int main() {
     ArnoldiResult ar = arnoldi(aa4, mkSpVR(3, {1, 1, 1}), 3);
     EXPECT(ar.k >= 1 && ar.k <= 3);
 
+    // specTriangularSolve (LibSpec.hs:203-213, fixtures :1409-1434): nearZero || T xhat - b ||
+    SpMatrix ltri1 = fromListSM({3, 3}, {{0, 0, 2}, {1, 0, 1}, {1, 1, 4}, {2, 1, 2}, {2, 2, 3}});
+    SpMatrix utri1 = fromListSM({3, 3}, {{0, 0, 2}, {0, 1, 1}, {0, 2, 1}, {1, 1, 4}, {1, 2, 2}, {2, 2, 3}});
+    SpVector bl = fromListDenseSV(3, {4, 10, 17}), bu = fromListDenseSV(3, {9, 14, 9});
+    EXPECT(nearZero(norm2(matVec(ltri1, triLowerSolve(ltri1, bl)) - bl)));
+    EXPECT(nearZero(norm2(matVec(utri1, triUpperSolve(utri1, bu)) - bu)));
+    threw = false;
+    try { triLowerSolve(fromListSM({2, 2}, {{0, 0, 1.0}, {1, 0, 1.0}}), mkSpVR(2, {1, 1})); } catch (const NeedsPivoting &) { threw = true; }
+    EXPECT(threw);
+
     std::printf(failures ? "reference_cases: %d FAILED\n" : "reference_cases: all passed\n", failures);
     return failures ? 1 : 0;
 }

@@ -27,6 +27,7 @@ namespace sla {
 
 struct MatVecSizeMismatchException : std::runtime_error { using std::runtime_error::runtime_error; };
 struct IterationException : std::runtime_error { using std::runtime_error::runtime_error; };
+struct NeedsPivoting : std::runtime_error { using std::runtime_error::runtime_error; };  // Control/Exception/Common.hs:58
 struct SlaError : std::runtime_error {
     int code;
     SlaError(int c, const std::string &m) : std::runtime_error(m), code(c) {}
@@ -39,6 +40,7 @@ inline void check(int rc) {
         case SLA_ERR_DIM_MISMATCH: throw MatVecSizeMismatchException(msg);
         case SLA_ERR_UNSUPPORTED_METHOD: throw IterationException(msg);
         case SLA_ERR_OOB: throw std::out_of_range(msg);
+        case SLA_ERR_NEEDS_PIVOTING: throw NeedsPivoting(msg);
         default: throw SlaError(rc, msg);
     }
 }
@@ -177,6 +179,18 @@ inline SpVector vecMat(const SpVector &x, const SpMatrix &A) {  // x <# A
     SpVector y(A.ncols());
     check(sla_spmv_t(A.get(), x.get(), y.get()));
     return y;
+}
+
+// forward / backward substitution with one triangle of T (Sparse.hs:750-811); throws NeedsPivoting
+inline SpVector triLowerSolve(const SpMatrix &ll, const SpVector &b) {
+    SpVector x(ll.nrows());
+    check(sla_tri_solve(ll.get(), 0, b.get(), x.get(), nullptr));
+    return x;
+}
+inline SpVector triUpperSolve(const SpMatrix &uu, const SpVector &w) {
+    SpVector x(uu.nrows());
+    check(sla_tri_solve(uu.get(), 1, w.get(), x.get(), nullptr));
+    return x;
 }
 
 // solver state records
