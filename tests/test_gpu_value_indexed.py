@@ -144,3 +144,43 @@ def test_value_indexed_propagates_inf_and_nan_only_where_the_reference_does(sla)
     want = orc.spmv(Ao, x)
     assert np.isfinite(y[10]) and np.isinf(y[11]) and np.isinf(y[12])
     assert np.array_equal(np.isnan(y), np.isnan(want)) and np.array_equal(y[~np.isnan(y)], want[~np.isnan(want)])
+
+
+def test_value_indexed_randomised_patterns(sla):
+    """60 seeded random banded matrices (square and rectangular, 1..900 rows, up to 14 diagonals anywhere in the matrix,
+    1-4 distinct values per diagonal, random holes, some with an empty leading / trailing block of rows): whatever form
+    the lowering picks, (#>) and (<#) are the oracle's left fold bit for bit and the forms agree with each other."""
+    rng = np.random.default_rng(2024)
+    picked = {"wdia": 0, "vdict": 0, "other": 0}
+    for case in range(60):
+        m = int(rng.integers(1, 900))
+        n = m if case % 3 else int(rng.integers(1, 900))
+        nd = int(rng.integers(1, 15))
+        offs = np.unique(rng.integers(-min(m, 400), min(n, 400) + 1, nd))
+        pal = {int(o): rng.choice([-2.0, -1.0, -0.5, 0.25, 1.0, 3.0, 6.0, -0.0], size=int(rng.integers(1, 5))) for o in offs}
+        hole = rng.random() * 0.5
+        lead, trail = (int(rng.integers(0, m // 3 + 1)), int(rng.integers(0, m // 3 + 1))) if case % 5 == 0 else (0, 0)
+        rows, cols, vals = [], [], []
+        for i in range(lead, m - trail):
+            for o in offs:
+                j = i + int(o)
+                if 0 <= j < n and rng.random() >= hole:
+                    rows.append(i), cols.append(j), vals.append(float(pal[int(o)][(i * 7 + j) % len(pal[int(o)])]))
+        r, c, v = np.array(rows, np.int64), np.array(cols, np.int64), np.array(vals)
+        rc, Ao = orc.coo_to_csr(m, n, r, c, v)
+        assert rc == orc.OK
+        x = rng.standard_normal(n)
+        xt = rng.standard_normal(m)
+        want, want_t = orc.spmv(Ao, x), orc.spmv(orc.transpose(Ao), xt)
+        A = sla.fromCSR((m, n), Ao.rowptr, Ao.colidx, Ao.val)
+        algo = A.kernel_info().split()[0]
+        picked["wdia" if "wdia" in algo else "vdict" if "vdict" in algo else "other"] += 1
+        y = sla.matVec(A, sla.fromVector(x)).toDenseListSV()
+        yt = sla.vecMat(sla.fromVector(xt), A).toDenseListSV()
+        exact = "wdia" in algo or "vdict" in algo or len(v) <= 8 * m
+        if exact:
+            assert np.array_equal(y.view(np.uint64), want.view(np.uint64)), (case, algo, m, n, offs)
+        else:
+            assert np.allclose(y, want, rtol=1e-13, atol=1e-13), (case, algo)
+        assert np.allclose(yt, want_t, rtol=1e-13, atol=1e-13), (case, algo, "transpose")
+    assert picked["wdia"] >= 20, picked      # the generator is meant to exercise the value-indexed forms
