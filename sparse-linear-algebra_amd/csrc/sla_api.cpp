@@ -539,6 +539,10 @@ static int ctx_create_common(int device_id, int rank, int nranks, const void *ui
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess && cus > 0)
             c->wd_grid_max = std::min<int>(kMaxParts, std::max(8, (kWdBlocksPerCu * cus) & ~7));
     }
+    if (const char *s = getenv("SLA_WD_GRID")) {
+        const int g = atoi(s);
+        if (g >= 8 && g <= kMaxParts) c->wd_grid_max = g & ~7;
+    }
     if (const char *s = getenv("SLA_SPMV_GRID")) {
         int g = atoi(s);
         if (g >= 1 && g <= kMaxParts) c->spmv_grid_max = g;

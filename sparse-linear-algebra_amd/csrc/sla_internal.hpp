@@ -18,7 +18,14 @@ constexpr int kNnzPerRowBlock = 1024; // products staged in LDS per row block (8
 constexpr int kMaxRowsPerRowBlock = 256;
 constexpr int kXWin = 768;           // doubles of x staged in LDS per row block by spmv_xwin_kernel (6 KiB)
 constexpr int kXWinHalo = 256;       // the window starts kXWinHalo columns left of the block's first diagonal column
-constexpr int kWdBlocksPerCu = 6;    // resident workgroups per CU of spmv_wdia_kernel (its persistent grid = 6 x CUs)
+#if !defined(SLA_WD_OCC)
+#define SLA_WD_OCC 6
+#endif
+#if !defined(SLA_WD_STAGES)
+#define SLA_WD_STAGES 1
+#endif
+constexpr int kWdBlocksPerCu = SLA_WD_OCC;      // resident workgroups per CU of spmv_wdia_kernel (its persistent grid = that x CUs)
+constexpr int kWdGatherStages = SLA_WD_STAGES;  // 2: the gathers of the next slice are issued before the current one is folded
 constexpr int kVdRows = 256;         // rows per block of spmv_vdict_kernel (one lane per row)
 constexpr int kVdMaxRowNnz = 31;     // longest row the value-indexed kernel takes (256 rows x 31 B of codes fit its LDS stage)
 constexpr int kWaveRowMax = 16384;   // rows of 1025..16384 entries: one wavefront each, 4 per row block; longer: whole workgroup

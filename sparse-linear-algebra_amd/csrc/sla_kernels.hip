@@ -1416,6 +1416,7 @@ extern "C" int sla_debug_wd_trace(unsigned long long *host) {
     if (trace_on && iter < 16) {                                                                               \
         const unsigned long long t_ = __builtin_readcyclecounter();                                            \
         if (lane == 0) wd_trace[((blockIdx.x >> 5) * 16 + iter) * 4 + (i)] = t_;                               \
+        if ((i) == 3) ++iter;                                                                                  \
     }
 #else
 #define WD_STAMP(i)
@@ -1485,148 +1486,196 @@ __global__ void __launch_bounds__(kBlock, kWdBlocksPerCu) spmv_wdia_kernel(SpmvA
             r.o = woff[e0 + lane];
         }
     };
+    // one slice between "gathers issued" and "folded": the gathered row pairs, the epilogue operands and the record
+    // fields the fold needs
+    struct Stage {
+        wd_f64x2 xv[8];
+        wd_f64x2 wv, zv;
+        unsigned long long me, mo;  // lane k: masks of record k
+        double v;                   // lane k: value of record k
+        int blk, e0, cnt;
+    };
+    // issue the epilogue-operand loads and the gathers of the slice described by (blk, e0, cnt, r)
+    auto issue = [&](Stage &st, int blk, int e0, int cnt, const WdRec &r) {
+        st.blk = blk;
+        st.e0 = e0;
+        st.cnt = cnt;
+        st.me = r.me;
+        st.mo = r.mo;
+        st.v = r.v;
+        st.wv = wd_f64x2{0.0, 0.0};
+        st.zv = wd_f64x2{0.0, 0.0};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) asm("" : "=v"(st.xv[k]));  // "defined" without an instruction: a lane that does not
+                                                               // load holds garbage, which EXEC never lets the fold use
+        if (cnt <= 0) return;
+        const int row = (blk * 4 + wave) * 128 + 2 * lane;  // this lane's rows: row, row + 1
+        const bool va = row < a.rows, vb = row + 1 < a.rows;
+        if (vb) {
+            if constexpr (kUsesW) { if (EPI != EPI_AXPY_DOT || a.w) st.wv = *(const wd_f64x2 *)(a.w + row); }
+            if constexpr (kUsesZ) st.zv = *(const wd_f64x2 *)(a.z + row);
+        } else if (va) {
+            if constexpr (kUsesW) { if (EPI != EPI_AXPY_DOT || a.w) st.wv.x = a.w[row]; }
+            if constexpr (kUsesZ) st.zv.x = a.z[row];
+        }
+        // byte offset of x[global row]; a record's diagonal offset moves the scalar base instead
+        const uint32_t g8 = (uint32_t)(grow0 + row) * 8u;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const unsigned long long mb = wd_lane_u64(r.me | r.mo, k);  // lanes with the entry in either row (0: no record k)
+            const int ok = __builtin_amdgcn_readlane(r.o, k);
+            // one 16-byte gather per lane.  When only one row of the pair holds the entry the other half is
+            // loaded and ignored; at the two ends of x it lies in the guard slack (guard_malloc).
+            if (__builtin_amdgcn_inverse_ballot_w64(mb)) st.xv[k] = *(const wd_f64x2u *)((const char *)(xg + ok) + g8);
+        }
+    };
+    // fold the slice's products row by row and run the epilogue
+    auto fold = [&](const Stage &st) {
+        if (st.cnt <= 0) return;
+        const int row = (st.blk * 4 + wave) * 128 + 2 * lane;
+        const bool va = row < a.rows, vb = row + 1 < a.rows;
+        double ya = 0.0, yb = 0.0;
+        {
+#pragma clang fp contract(off)  // a*x then +: two roundings like the reference, never an FMA
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if (k >= st.cnt) break;  // wave-uniform
+                const unsigned long long me = wd_lane_u64(st.me, k), mo = wd_lane_u64(st.mo, k);
+                const double vk = wd_lane_f64(st.v, k);
+                // EXEC = the even rows that hold the entry, then the odd rows; v_mul_f64 then v_add_f64 (two
+                // roundings).  All 64 lanes are active here (wave-uniform control flow only): EXEC goes back to -1.
+                double p;
+                asm volatile(
+                    "s_mov_b64 exec, %[me]\n\tv_mul_f64 %[p], %[v], %[xa]\n\tv_add_f64 %[ya], %[ya], %[p]\n\t"
+                    "s_mov_b64 exec, %[mo]\n\tv_mul_f64 %[p], %[v], %[xb]\n\tv_add_f64 %[yb], %[yb], %[p]\n\t"
+                    "s_mov_b64 exec, -1"
+                    : [ya] "+v"(ya), [yb] "+v"(yb), [p] "=&v"(p)
+                    : [me] "s"(me), [mo] "s"(mo), [v] "s"(vk), [xa] "v"(st.xv[k].x), [xb] "v"(st.xv[k].y));
+            }
+            // slices with more than 8 records (27-point stencils, ...): the rest one by one through scalar loads
+            const uint32_t g8 = (uint32_t)(grow0 + row) * 8u;
+            for (int c = 8; c < st.cnt; ++c) {
+                const unsigned long long me = wme[st.e0 + c], mo = wmo[st.e0 + c];
+                const double vk = wval[st.e0 + c];
+                const char *base = (const char *)(xg + woff[st.e0 + c]) + g8;
+                if (__builtin_amdgcn_inverse_ballot_w64(me)) {
+                    const double p = vk * *(const double *)base;
+                    ya = ya + p;
+                }
+                if (__builtin_amdgcn_inverse_ballot_w64(mo)) {
+                    const double p = vk * *(const double *)(base + 8);
+                    yb = yb + p;
+                }
+            }
+        }
+        if (va) {
+            const wd_f64x2 wv = st.wv, zv = st.zv;
+            wd_f64x2 out = {ya, yb};  // what the epilogue stores (y or z), if it stores
+            bool store_y = false, store_z = false;
+            if constexpr (EPI == EPI_NONE) {
+                store_y = true;
+            } else if constexpr (EPI == EPI_DOT) {
+                store_y = true;
+                acc1 += ya * wv.x;
+                if (vb) acc1 += yb * wv.y;
+            } else if constexpr (EPI == EPI_DOT2) {
+                store_y = true;
+                acc1 += ya * wv.x;
+                acc2 += ya * ya;
+                if (vb) { acc1 += yb * wv.y; acc2 += yb * yb; }
+            } else if constexpr (EPI == EPI_RES) {
+                const double ta = ya - wv.x, tb = yb - wv.y;  // (aa #> x) ^-^ b
+                acc1 += ta * ta;
+                if (vb) acc1 += tb * tb;
+            } else if constexpr (EPI == EPI_AXPY_DOT) {
+                out.x = zv.x - coef * ya;
+                out.y = zv.y - coef * yb;
+                store_z = true;
+                acc1 += out.x * (a.w ? wv.x : out.x);
+                if (vb) acc1 += out.y * (a.w ? wv.y : out.y);
+            } else if constexpr (EPI == EPI_XPBY_NRM) {
+                out.x = ya + coef * zv.x;
+                out.y = yb + coef * zv.y;
+                store_z = true;
+                acc1 += out.x * out.x;
+                if (vb) acc1 += out.y * out.y;
+            } else if constexpr (EPI == EPI_SUB) {
+                out.x = wv.x - ya;  // b ^-^ (aa #> x)
+                out.y = wv.y - yb;
+                store_y = true;
+            }
+            double *dst = store_y ? a.y : (store_z ? a.z : nullptr);
+            if (dst) {
+                if (vb) *(wd_f64x2 *)(dst + row) = out;
+                else dst[row] = out.x;
+            }
+        }
+    };
     int b = wk.first;
-    int blk_c, e0_c, cnt_c, blk_n, e0_n, cnt_n;
-    WdRec rc, rn;
-    load_desc(b, blk_c, e0_c, cnt_c);
-    load_desc(b + wk.step, blk_n, e0_n, cnt_n);
-    load_rec(e0_c, cnt_c, rc);
 #if defined(SLA_WD_TRACE)
     const bool trace_on = (blockIdx.x & 31) == 0 && wave == 0 && EPI == EPI_DOT;
     int iter = 0;
 #endif
-    for (; b < wk.last; b += wk.step) {
-        int blk_f, e0_f, cnt_f;
-        WD_STAMP(0)
-        load_rec(e0_n, cnt_n, rn);               // next slice's records: in flight behind this slice's gathers
-        load_desc(b + 2 * wk.step, blk_f, e0_f, cnt_f);
-        if (cnt_c > 0) {
-            const int row = (blk_c * 4 + wave) * 128 + 2 * lane;  // this lane's rows: row, row + 1
-            const bool va = row < a.rows, vb = row + 1 < a.rows;
-            // epilogue operands: issued before the gathers so they fly together
-            wd_f64x2 wv = {0.0, 0.0}, zv = {0.0, 0.0};
-            if (vb) {
-#if defined(SLA_WD_NT_W)
-                if constexpr (kUsesW) { if (EPI != EPI_AXPY_DOT || a.w) wv = __builtin_nontemporal_load((const wd_f64x2 *)(a.w + row)); }
-#else
-                if constexpr (kUsesW) { if (EPI != EPI_AXPY_DOT || a.w) wv = *(const wd_f64x2 *)(a.w + row); }
-#endif
-                if constexpr (kUsesZ) zv = *(const wd_f64x2 *)(a.z + row);
-            } else if (va) {
-                if constexpr (kUsesW) { if (EPI != EPI_AXPY_DOT || a.w) wv.x = a.w[row]; }
-                if constexpr (kUsesZ) zv.x = a.z[row];
-            }
-            // byte offset of x[global row]; a record's diagonal offset moves the scalar base instead
-            const uint32_t g8 = (uint32_t)(grow0 + row) * 8u;
-            double ya = 0.0, yb = 0.0;
-            wd_f64x2 xv[8];  // gathered row pairs
-#pragma unroll
-            for (int k = 0; k < 8; ++k) asm("" : "=v"(xv[k]));  // "defined" without an instruction: a lane that does not
-                                                                // load holds garbage, which EXEC never lets the fold use
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const unsigned long long mb = wd_lane_u64(rc.me | rc.mo, k);  // lanes with the entry in either row (0: no record k)
-                const int ok = __builtin_amdgcn_readlane(rc.o, k);
-                // one 16-byte gather per lane.  When only one row of the pair holds the entry the other half is
-                // loaded and ignored; at the two ends of x it lies in the guard slack (guard_malloc).
-                if (__builtin_amdgcn_inverse_ballot_w64(mb)) xv[k] = *(const wd_f64x2u *)((const char *)(xg + ok) + g8);
-            }
-            WD_STAMP(1)
-#if defined(SLA_WD_TRACE)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            WD_STAMP(2)
-#endif
-            {
-#pragma clang fp contract(off)  // a*x then +: two roundings like the reference, never an FMA
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    if (k >= cnt_c) break;  // wave-uniform
-                    const unsigned long long me = wd_lane_u64(rc.me, k), mo = wd_lane_u64(rc.mo, k);
-                    const double vk = wd_lane_f64(rc.v, k);
-                    // EXEC = the even rows that hold the entry, then the odd rows; v_mul_f64 then v_add_f64 (two
-                    // roundings).  All 64 lanes are active here (wave-uniform control flow only): EXEC goes back to -1.
-                    double p;
-                    asm volatile(
-                        "s_mov_b64 exec, %[me]\n\tv_mul_f64 %[p], %[v], %[xa]\n\tv_add_f64 %[ya], %[ya], %[p]\n\t"
-                        "s_mov_b64 exec, %[mo]\n\tv_mul_f64 %[p], %[v], %[xb]\n\tv_add_f64 %[yb], %[yb], %[p]\n\t"
-                        "s_mov_b64 exec, -1"
-                        : [ya] "+v"(ya), [yb] "+v"(yb), [p] "=&v"(p)
-                        : [me] "s"(me), [mo] "s"(mo), [v] "s"(vk), [xa] "v"(xv[k].x), [xb] "v"(xv[k].y));
-                }
-                // slices with more than 8 records (27-point stencils, ...): the rest one by one through scalar loads
-                for (int c = 8; c < cnt_c; ++c) {
-                    const unsigned long long me = wme[e0_c + c], mo = wmo[e0_c + c];
-                    const double vk = wval[e0_c + c];
-                    const char *base = (const char *)(xg + woff[e0_c + c]) + g8;
-                    if (__builtin_amdgcn_inverse_ballot_w64(me)) {
-                        const double p = vk * *(const double *)base;
-                        ya = ya + p;
-                    }
-                    if (__builtin_amdgcn_inverse_ballot_w64(mo)) {
-                        const double p = vk * *(const double *)(base + 8);
-                        yb = yb + p;
-                    }
-                }
-            }
-            if (va) {
-                wd_f64x2 out = {ya, yb};  // what the epilogue stores (y or z), if it stores
-                bool store_y = false, store_z = false;
-                if constexpr (EPI == EPI_NONE) {
-                    store_y = true;
-                } else if constexpr (EPI == EPI_DOT) {
-                    store_y = true;
-                    acc1 += ya * wv.x;
-                    if (vb) acc1 += yb * wv.y;
-                } else if constexpr (EPI == EPI_DOT2) {
-                    store_y = true;
-                    acc1 += ya * wv.x;
-                    acc2 += ya * ya;
-                    if (vb) { acc1 += yb * wv.y; acc2 += yb * yb; }
-                } else if constexpr (EPI == EPI_RES) {
-                    const double ta = ya - wv.x, tb = yb - wv.y;  // (aa #> x) ^-^ b
-                    acc1 += ta * ta;
-                    if (vb) acc1 += tb * tb;
-                } else if constexpr (EPI == EPI_AXPY_DOT) {
-                    out.x = zv.x - coef * ya;
-                    out.y = zv.y - coef * yb;
-                    store_z = true;
-                    acc1 += out.x * (a.w ? wv.x : out.x);
-                    if (vb) acc1 += out.y * (a.w ? wv.y : out.y);
-                } else if constexpr (EPI == EPI_XPBY_NRM) {
-                    out.x = ya + coef * zv.x;
-                    out.y = yb + coef * zv.y;
-                    store_z = true;
-                    acc1 += out.x * out.x;
-                    if (vb) acc1 += out.y * out.y;
-                } else if constexpr (EPI == EPI_SUB) {
-                    out.x = wv.x - ya;  // b ^-^ (aa #> x)
-                    out.y = wv.y - yb;
-                    store_y = true;
-                }
-                double *dst = store_y ? a.y : (store_z ? a.z : nullptr);
-                if (dst) {
-#if defined(SLA_WD_SC1_Y)
-                    if (vb) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst + row), "v"(out) : "memory");
-#elif defined(SLA_WD_NT_Y)
-                    if (vb) __builtin_nontemporal_store(out, (wd_f64x2 *)(dst + row));
-#else
-                    if (vb) *(wd_f64x2 *)(dst + row) = out;
-#endif
-                    else dst[row] = out.x;
-                }
-            }
+    if constexpr (kWdGatherStages == 2) {
+        // descriptors three slices ahead, records two ahead, gathers one ahead: while slice i is folded the gathers of
+        // slice i + 1 and the records of slice i + 2 are in flight
+        int blk1, e01, cnt1, blk2, e02, cnt2, blk3, e03, cnt3;
+        WdRec r1, r2;
+        Stage sa, sb;
+        {
+            int blk0, e00, cnt0;
+            WdRec r0;
+            load_desc(b, blk0, e00, cnt0);
+            load_desc(b + wk.step, blk1, e01, cnt1);
+            load_desc(b + 2 * wk.step, blk2, e02, cnt2);
+            load_rec(e00, cnt0, r0);
+            load_rec(e01, cnt1, r1);
+            issue(sa, blk0, e00, cnt0, r0);
         }
-        WD_STAMP(3)
-#if defined(SLA_WD_TRACE)
-        ++iter;
-#endif
-        blk_c = blk_n;
-        e0_c = e0_n;
-        cnt_c = cnt_n;
-        rc = rn;
-        blk_n = blk_f;
-        e0_n = e0_f;
-        cnt_n = cnt_f;
+#define SLA_WD_STEP(cur, nxt)                         \
+        {                                             \
+            WD_STAMP(0)                               \
+            load_rec(e02, cnt2, r2);                  \
+            load_desc(b + 3 * wk.step, blk3, e03, cnt3); \
+            issue(nxt, blk1, e01, cnt1, r1);          \
+            WD_STAMP(1)                               \
+            fold(cur);                                \
+            WD_STAMP(3)                               \
+            b += wk.step;                             \
+            r1 = r2;                                  \
+            blk1 = blk2; e01 = e02; cnt1 = cnt2;      \
+            blk2 = blk3; e02 = e03; cnt2 = cnt3;      \
+        }
+        while (b < wk.last) {
+            SLA_WD_STEP(sa, sb)
+            if (b >= wk.last) break;
+            SLA_WD_STEP(sb, sa)
+        }
+#undef SLA_WD_STEP
+    } else {
+        int blk_c, e0_c, cnt_c, blk_n, e0_n, cnt_n;
+        WdRec rc, rn;
+        Stage st;
+        load_desc(b, blk_c, e0_c, cnt_c);
+        load_desc(b + wk.step, blk_n, e0_n, cnt_n);
+        load_rec(e0_c, cnt_c, rc);
+        for (; b < wk.last; b += wk.step) {
+            int blk_f, e0_f, cnt_f;
+            WD_STAMP(0)
+            load_rec(e0_n, cnt_n, rn);               // next slice's records: in flight behind this slice's gathers
+            load_desc(b + 2 * wk.step, blk_f, e0_f, cnt_f);
+            issue(st, blk_c, e0_c, cnt_c, rc);
+            WD_STAMP(1)
+            fold(st);
+            WD_STAMP(3)
+            blk_c = blk_n;
+            e0_c = e0_n;
+            cnt_c = cnt_n;
+            rc = rn;
+            blk_n = blk_f;
+            e0_n = e0_f;
+            cnt_n = cnt_f;
+        }
     }
     if constexpr (EPI == EPI_DOT || EPI == EPI_DOT2 || EPI == EPI_RES || EPI == EPI_AXPY_DOT || EPI == EPI_XPBY_NRM) {
         const double s1 = block_sum(acc1, s_red);
