@@ -262,10 +262,11 @@ static int csr_upload(sla_ctx *c, int64_t m, int64_t n, int64_t row_begin, int64
         A->use_xwin = A->xwin_fraction >= 0.5;
         upload((void **)&A->d_rbw, rbw.data(), sizeof(int32_t) * rbw.size());
     }
+    std::vector<int64_t> offs;          // sorted distinct diagonal offsets (<= 256) when the matrix has that structure
+    std::vector<uint8_t> dcodes;        // per entry: index into offs
     if (!panel_view) {
         // dictionary of diagonal offsets: worthwhile (and representable in a byte) when col - row takes at
         // most 256 distinct values, i.e. for stencil / banded structure
-        std::vector<int64_t> offs;
         bool ok = nnz > 0;
         for (int64_t i = 0; i < rows && ok; ++i) {
             const int64_t gr = row_begin + i;
@@ -283,7 +284,8 @@ static int csr_upload(sla_ctx *c, int64_t m, int64_t n, int64_t row_begin, int64
             std::sort(offs.begin(), offs.end());
             std::vector<int32_t> dict(256, (int32_t)offs.back());
             for (size_t t = 0; t < offs.size(); ++t) dict[t] = (int32_t)offs[t];
-            std::vector<uint8_t> codes((size_t)nnz);
+            std::vector<uint8_t> &codes = dcodes;
+            codes.resize((size_t)nnz);
             for (int64_t i = 0; i < rows; ++i) {
                 const int64_t gr = row_begin + i;
                 for (int64_t k = rowptr[i]; k < rowptr[i + 1]; ++k)
@@ -417,6 +419,61 @@ static int csr_upload(sla_ctx *c, int64_t m, int64_t n, int64_t row_begin, int64
             }
         }
     }
+    if (!panel_view && A->use_diag && !A->use_wdia && !A->rp64 && c->wdia_vv && n < ((int64_t)1 << 28) && nnz > 0) {
+        // Wave-sliced form for VARIABLE coefficients (banded / stencil structure, arbitrary values): per 128-row slice the
+        // sorted union of its diagonal offsets with the two row masks each, and per record a block of 128 values laid out
+        // like the rows (lane l holds rows 2l, 2l+1: one 16-byte load).  8 B per stored slot instead of 8 + 1 B per entry
+        // plus rowptr, no codes, no LDS.  Taken when at least half of the slots hold an entry.
+        const int64_t nsl = (rows + 127) / 128;
+        std::vector<int32_t> wptr((size_t)nsl + 1, 0);
+        std::vector<uint64_t> wme, wmo;
+        std::vector<int32_t> woff;
+        std::vector<double> wvb;
+        uint64_t lane_mask[2][256];
+        int slot_of[256];
+        bool wok = true;
+        for (int64_t sl = 0; sl < nsl && wok; ++sl) {
+            uint64_t present[4] = {0, 0, 0, 0};
+            const int64_t rlo = sl * 128, rhi = std::min<int64_t>(rows, rlo + 128);
+            for (int64_t i = rlo; i < rhi; ++i)
+                for (int64_t k = rowptr[i]; k < rowptr[i + 1]; ++k) {
+                    const int cd = dcodes[(size_t)k];
+                    if (!((present[cd >> 6] >> (cd & 63)) & 1)) {
+                        present[cd >> 6] |= 1ull << (cd & 63);
+                        lane_mask[0][cd] = lane_mask[1][cd] = 0;
+                    }
+                    lane_mask[(i - rlo) & 1][cd] |= 1ull << ((i - rlo) >> 1);
+                }
+            const size_t first = wme.size();
+            for (int cd = 0; cd < 256; ++cd)   // ascending code = ascending offset
+                if ((present[cd >> 6] >> (cd & 63)) & 1) {
+                    slot_of[cd] = (int)(wme.size() - first);
+                    wme.push_back(lane_mask[0][cd]);
+                    wmo.push_back(lane_mask[1][cd]);
+                    woff.push_back((int32_t)offs[(size_t)cd]);
+                }
+            wvb.resize(wme.size() * 128, 0.0);
+            for (int64_t i = rlo; i < rhi; ++i)
+                for (int64_t k = rowptr[i]; k < rowptr[i + 1]; ++k)
+                    wvb[(first + (size_t)slot_of[dcodes[(size_t)k]]) * 128 + (size_t)(i - rlo)] = val[k];
+            wptr[(size_t)sl + 1] = (int32_t)wme.size();
+            if ((int64_t)wme.size() * 64 > nnz + 4096) wok = false;   // less than half of the slots used
+        }
+        if (wok) {
+            A->nwent = (int64_t)wme.size();
+            for (int t = 0; t < 8; ++t) { wme.push_back(0); wmo.push_back(0); woff.push_back(0); }
+            wvb.resize(wme.size() * 128, 0.0);
+            upload((void **)&A->d_wptr, wptr.data(), sizeof(int32_t) * wptr.size());
+            upload((void **)&A->d_wme, wme.data(), sizeof(uint64_t) * wme.size());
+            upload((void **)&A->d_wmo, wmo.data(), sizeof(uint64_t) * wmo.size());
+            upload((void **)&A->d_woff, woff.data(), sizeof(int32_t) * woff.size());
+            upload((void **)&A->d_wvblk, wvb.data(), sizeof(double) * wvb.size());
+            A->use_wdia = true;
+            A->wd_vv = true;
+            A->nslices = (int32_t)nsl;
+            A->nblk_wd = (int32_t)((nsl + 3) / 4);
+        }
+    }
     if (err != hipSuccess) {
         sla_csr_destroy(A);
         return fail(SLA_ERR_ALLOC, std::string("CSR upload: ") + hipGetErrorString(err));
@@ -528,6 +585,7 @@ static int ctx_create_common(int device_id, int rank, int nranks, const void *ui
     if (const char *s = getenv("SLA_VDICT")) c->vdict = atoi(s);
     if (const char *s = getenv("SLA_WDIA")) c->wdia = atoi(s);
     if (const char *s = getenv("SLA_WD_TILE")) c->wd_tile = atoi(s);
+    if (const char *s = getenv("SLA_WDIA_VV")) c->wdia_vv = atoi(s);
     if (const char *s = getenv("SLA_PANELS")) c->panels = atoi(s);
     if (const char *s = getenv("SLA_PANEL_COLS")) c->panel_cols = atoll(s);
     if (const char *s = getenv("SLA_ROW_ALIGN")) c->row_align = atoi(s);
@@ -536,8 +594,10 @@ static int ctx_create_common(int device_id, int rank, int nranks, const void *ui
     if (const char *s = getenv("SLA_X_EXCHANGE")) c->x_exchange = strcmp(s, "allgather") == 0 ? 1 : (strcmp(s, "window") == 0 ? 2 : 0);
     {
         int cus = 0;
-        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess && cus > 0)
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess && cus > 0) {
             c->wd_grid_max = std::min<int>(kMaxParts, std::max(8, (kWdBlocksPerCu * cus) & ~7));
+            c->wd_grid_max_vv = std::min<int>(kMaxParts, std::max(8, (kWdBlocksPerCuVV * cus) & ~7));
+        }
     }
     if (const char *s = getenv("SLA_WD_GRID")) {
         const int g = atoi(s);
@@ -929,6 +989,7 @@ int sla_csr_destroy(sla_csr_t A) {
     tri_plan_free(A->tri[1]);
     if (A->d_wptr) (void)hipFree(A->d_wptr);
     if (A->d_wsched) (void)hipFree(A->d_wsched);
+    if (A->d_wvblk) (void)hipFree(A->d_wvblk);
     if (A->d_wme) (void)hipFree(A->d_wme);
     if (A->d_wmo) (void)hipFree(A->d_wmo);
     if (A->d_wval) (void)hipFree(A->d_wval);
@@ -980,7 +1041,7 @@ int sla_csr_is_diagonal(sla_csr_t A, int *out) {
 int sla_csr_kernel_info(sla_csr_t A, char *buf, int buflen) {
     if (!A || !buf || buflen <= 0) return fail(SLA_ERR_INVALID, "null argument");
     snprintf(buf, (size_t)buflen, "algo=%s grid=%d block=%d row_blocks=%d nnz_per_row_block=%d max_row_nnz=%lld rowptr=%s xcd_remap=%d",
-             A->ctx->spmv_algo == 1 ? "scalar" : (A->use_wdia && A->ctx->wdia) ? "wdia" : (A->use_vdict && A->ctx->vdict) ? (A->use_xwin && A->ctx->xwin ? "vdict+xwin" : "vdict") : (!A->panels.empty() && A->ctx->panels) ? "stream+colpanels" : (A->use_diag && A->ctx->diag ? (A->use_xwin && A->ctx->xwin ? "stream+diagdict+xwin" : "stream+diagdict") : (A->use_xwin && A->ctx->xwin ? "stream+xwin" : "stream")), spmv_grid(A), kBlock, A->nrb, kNnzPerRowBlock,
+             A->ctx->spmv_algo == 1 ? "scalar" : (A->use_wdia && wd_on(A)) ? (A->wd_vv ? "wdia-vv" : "wdia") : (A->use_vdict && A->ctx->vdict) ? (A->use_xwin && A->ctx->xwin ? "vdict+xwin" : "vdict") : (!A->panels.empty() && A->ctx->panels) ? "stream+colpanels" : (A->use_diag && A->ctx->diag ? (A->use_xwin && A->ctx->xwin ? "stream+diagdict+xwin" : "stream+diagdict") : (A->use_xwin && A->ctx->xwin ? "stream+xwin" : "stream")), spmv_grid(A), kBlock, A->nrb, kNnzPerRowBlock,
              (long long)A->max_row_nnz, A->rp64 ? "i64" : "i32", A->ctx->xcd_remap);
     return SLA_OK;
 }

@@ -25,6 +25,7 @@ constexpr int kXWinHalo = 256;       // the window starts kXWinHalo columns left
 #define SLA_WD_STAGES 1
 #endif
 constexpr int kWdBlocksPerCu = SLA_WD_OCC;      // resident workgroups per CU of spmv_wdia_kernel (its persistent grid = that x CUs)
+constexpr int kWdBlocksPerCuVV = 5;             // same for the variable-coefficient variant (per-row value blocks: 102 VGPRs)
 constexpr int kWdGatherStages = SLA_WD_STAGES;  // 2: the gathers of the next slice are issued before the current one is folded
 constexpr int kVdRows = 256;         // rows per block of spmv_vdict_kernel (one lane per row)
 constexpr int kVdMaxRowNnz = 31;     // longest row the value-indexed kernel takes (256 rows x 31 B of codes fit its LDS stage)
@@ -123,6 +124,8 @@ struct sla_ctx {
     int panels = 1;                  // allow the column-panel SpMV for irregular matrices (SLA_PANELS=0 disables)
     int64_t panel_cols = 384 * 1024; // panel width in columns (SLA_PANEL_COLS): 3 MiB of x per pass
     int diag = 1;                    // allow the dictionary-compressed-index SpMV kernel (SLA_DIAG=0 disables)
+    int wdia_vv = 1;                 // allow the variable-coefficient wave-sliced form (SLA_WDIA_VV=0 disables)
+    int wd_grid_max_vv = sla::kWdBlocksPerCuVV * 256;
     int wd_tile = -1;                // plane tiling of the wave-sliced walk: -1 automatic, 0 off, > 0 steps per tile (SLA_WD_TILE)
     int wdia = 1;                    // allow the wave-sliced SpMV kernel (SLA_WDIA=0 disables)
     int vdict = 1;                   // allow the value-indexed SpMV kernel (SLA_VDICT=0 disables)
@@ -197,6 +200,8 @@ struct sla_csr {
     int32_t *d_woff = nullptr;              // ... and its diagonal offset (col - row); all padded by 8 records
     bool use_wdia = false;
     int32_t nslices = 0;
+    double *d_wvblk = nullptr;       // variable-coefficient variant: 128 values per record, laid out like the slice's rows
+    bool wd_vv = false;
     int32_t *d_wsched = nullptr;     // visiting order of the 512-row steps (null: ascending); see csr_upload
     int32_t nblk_wd = 0;             // ceil(nslices / 4): workgroup steps of spmv_wdia_kernel
     int64_t nwent = 0;
@@ -229,6 +234,8 @@ struct sla_solver {
 };
 
 namespace sla {
+// is the wave-sliced SpMV form of A enabled by the context's knobs?
+inline bool wd_on(const sla_csr *A) { return A->wd_vv ? (A->ctx->wdia && A->ctx->wdia_vv) : A->ctx->wdia != 0; }
 
 // Guarded device allocation for everything an SpMV may gather from (vectors, the exchange landing buffer, the
 // Arnoldi basis): kGuardBytes of readable slack on both sides.  spmv_wdia_kernel gathers row PAIRS with one

@@ -1441,12 +1441,14 @@ __device__ __forceinline__ double wd_lane_f64(double x, int k) {
 // Six workgroups per CU, not eight: 85 VGPRs instead of 64 end the spills of the fused epilogues, and the CU's L1
 // serves more of the overlapping gathers with fewer wavefronts streaming through it (measured same-box:
 // 8 / 7 / 6 / 5 / 4 per CU = 2890 / 3110 / 3170 / 3140 / 2940 BiCGSTAB it/s).
-template <int EPI>
-__global__ void __launch_bounds__(kBlock, kWdBlocksPerCu) spmv_wdia_kernel(SpmvArgs<int32_t> a, const int32_t *__restrict__ sptr,
+// VV: variable coefficients -- a record carries no scalar value but a block of 128 values laid out like the slice's
+// rows (wvblk), fetched with one more 16-byte load per lane; everything else is shared.
+template <int EPI, bool VV>
+__global__ void __launch_bounds__(kBlock, VV ? kWdBlocksPerCuVV : kWdBlocksPerCu) spmv_wdia_kernel(SpmvArgs<int32_t> a, const int32_t *__restrict__ sptr,
                                                                const unsigned long long *__restrict__ wme,
                                                                const unsigned long long *__restrict__ wmo,
                                                                const double *__restrict__ wval, const int32_t *__restrict__ woff,
-                                                               const double *__restrict__ xg, int32_t nblk, int32_t nslices,
+                                                               const double *__restrict__ wvblk, const double *__restrict__ xg, int32_t nblk, int32_t nslices,
                                                                int32_t grow0, int32_t xlen, const int32_t *__restrict__ sched, int xcd_remap) {
     __shared__ double s_red[4];
     const int tid = threadIdx.x;
@@ -1482,7 +1484,7 @@ __global__ void __launch_bounds__(kBlock, kWdBlocksPerCu) spmv_wdia_kernel(SpmvA
         if (lane < 8 && lane < cnt) {
             r.me = wme[e0 + lane];
             r.mo = wmo[e0 + lane];
-            r.v = wval[e0 + lane];
+            if (!VV) r.v = wval[e0 + lane];
             r.o = woff[e0 + lane];
         }
     };
@@ -1490,6 +1492,7 @@ __global__ void __launch_bounds__(kBlock, kWdBlocksPerCu) spmv_wdia_kernel(SpmvA
     // fields the fold needs
     struct Stage {
         wd_f64x2 xv[8];
+        wd_f64x2 vv[VV ? 8 : 1];    // VV: the row pair's two values of record k
         wd_f64x2 wv, zv;
         unsigned long long me, mo;  // lane k: masks of record k
         double v;                   // lane k: value of record k
@@ -1506,8 +1509,10 @@ __global__ void __launch_bounds__(kBlock, kWdBlocksPerCu) spmv_wdia_kernel(SpmvA
         st.wv = wd_f64x2{0.0, 0.0};
         st.zv = wd_f64x2{0.0, 0.0};
 #pragma unroll
-        for (int k = 0; k < 8; ++k) asm("" : "=v"(st.xv[k]));  // "defined" without an instruction: a lane that does not
-                                                               // load holds garbage, which EXEC never lets the fold use
+        for (int k = 0; k < 8; ++k) {  // "defined" without an instruction: a lane that does not load holds garbage,
+            asm("" : "=v"(st.xv[k]));  // which EXEC never lets the fold use
+            if (VV) asm("" : "=v"(st.vv[k]));
+        }
         if (cnt <= 0) return;
         const int row = (blk * 4 + wave) * 128 + 2 * lane;  // this lane's rows: row, row + 1
         const bool va = row < a.rows, vb = row + 1 < a.rows;
@@ -1526,7 +1531,10 @@ __global__ void __launch_bounds__(kBlock, kWdBlocksPerCu) spmv_wdia_kernel(SpmvA
             const int ok = __builtin_amdgcn_readlane(r.o, k);
             // one 16-byte gather per lane.  When only one row of the pair holds the entry the other half is
             // loaded and ignored; at the two ends of x it lies in the guard slack (guard_malloc).
-            if (__builtin_amdgcn_inverse_ballot_w64(mb)) st.xv[k] = *(const wd_f64x2u *)((const char *)(xg + ok) + g8);
+            if (__builtin_amdgcn_inverse_ballot_w64(mb)) {
+                st.xv[k] = *(const wd_f64x2u *)((const char *)(xg + ok) + g8);
+                if (VV) st.vv[k] = *(const wd_f64x2 *)(wvblk + ((size_t)(e0 + k) << 7) + 2 * lane);
+            }
         }
     };
     // fold the slice's products row by row and run the epilogue
@@ -1541,10 +1549,19 @@ __global__ void __launch_bounds__(kBlock, kWdBlocksPerCu) spmv_wdia_kernel(SpmvA
             for (int k = 0; k < 8; ++k) {
                 if (k >= st.cnt) break;  // wave-uniform
                 const unsigned long long me = wd_lane_u64(st.me, k), mo = wd_lane_u64(st.mo, k);
-                const double vk = wd_lane_f64(st.v, k);
                 // EXEC = the even rows that hold the entry, then the odd rows; v_mul_f64 then v_add_f64 (two
                 // roundings).  All 64 lanes are active here (wave-uniform control flow only): EXEC goes back to -1.
                 double p;
+                if constexpr (VV) {
+                    asm volatile(
+                        "s_mov_b64 exec, %[me]\n\tv_mul_f64 %[p], %[va], %[xa]\n\tv_add_f64 %[ya], %[ya], %[p]\n\t"
+                        "s_mov_b64 exec, %[mo]\n\tv_mul_f64 %[p], %[vb], %[xb]\n\tv_add_f64 %[yb], %[yb], %[p]\n\t"
+                        "s_mov_b64 exec, -1"
+                        : [ya] "+v"(ya), [yb] "+v"(yb), [p] "=&v"(p)
+                        : [me] "s"(me), [mo] "s"(mo), [va] "v"(st.vv[k].x), [vb] "v"(st.vv[k].y), [xa] "v"(st.xv[k].x), [xb] "v"(st.xv[k].y));
+                    continue;
+                }
+                const double vk = wd_lane_f64(st.v, k);
                 asm volatile(
                     "s_mov_b64 exec, %[me]\n\tv_mul_f64 %[p], %[v], %[xa]\n\tv_add_f64 %[ya], %[ya], %[p]\n\t"
                     "s_mov_b64 exec, %[mo]\n\tv_mul_f64 %[p], %[v], %[xb]\n\tv_add_f64 %[yb], %[yb], %[p]\n\t"
@@ -1556,14 +1573,15 @@ __global__ void __launch_bounds__(kBlock, kWdBlocksPerCu) spmv_wdia_kernel(SpmvA
             const uint32_t g8 = (uint32_t)(grow0 + row) * 8u;
             for (int c = 8; c < st.cnt; ++c) {
                 const unsigned long long me = wme[st.e0 + c], mo = wmo[st.e0 + c];
-                const double vk = wval[st.e0 + c];
                 const char *base = (const char *)(xg + woff[st.e0 + c]) + g8;
+                const double *vb = VV ? wvblk + ((size_t)(st.e0 + c) << 7) + 2 * lane : nullptr;
+                const double vk = VV ? 0.0 : wval[st.e0 + c];
                 if (__builtin_amdgcn_inverse_ballot_w64(me)) {
-                    const double p = vk * *(const double *)base;
+                    const double p = (VV ? vb[0] : vk) * *(const double *)base;
                     ya = ya + p;
                 }
                 if (__builtin_amdgcn_inverse_ballot_w64(mo)) {
-                    const double p = vk * *(const double *)(base + 8);
+                    const double p = (VV ? vb[1] : vk) * *(const double *)(base + 8);
                     yb = yb + p;
                 }
             }
@@ -1721,7 +1739,7 @@ int spmv_grid(const sla_csr *A) {
     if (!A->panels.empty() && c->panels && c->spmv_algo == 0) return spmv_grid(A->panels.back());
     int64_t g;
     if (c->spmv_algo == 1) g = (A->rows + kBlock - 1) / kBlock;
-    else if (A->use_wdia && c->wdia) g = std::min<int64_t>(A->nblk_wd, c->wd_grid_max);
+    else if (A->use_wdia && wd_on(A)) g = std::min<int64_t>(A->nblk_wd, A->wd_vv ? c->wd_grid_max_vv : c->wd_grid_max);
     else if (A->use_vdict && c->vdict) g = A->nblk_vd;
     else g = A->nrb;
     if (g < 1) g = 1;
@@ -1798,11 +1816,17 @@ static int launch_spmv_t(const sla_csr *A, const SpmvLaunch &l) {
     a.yinit = l.yinit;
     const int grid = spmv_grid(A);
     ProfScope prof(c, l.kernel_id);
-    if (A->use_wdia && c->wdia && c->spmv_algo == 0 && !l.x2) {
+    if (A->use_wdia && wd_on(A) && c->spmv_algo == 0 && !l.x2) {
         if constexpr (std::is_same<RP, int32_t>::value) {
-            hipLaunchKernelGGL((spmv_wdia_kernel<EPI>), dim3(grid), dim3(kBlock), 0, c->stream, a, A->d_wptr, A->d_wme, A->d_wmo,
-                               A->d_wval, A->d_woff, a.x, A->nblk_wd, A->nslices, (int32_t)A->row_begin, (int32_t)A->n,
-                               c->wd_tile != 0 ? A->d_wsched : nullptr, c->xcd_remap);
+            const int32_t *sched = c->wd_tile != 0 ? A->d_wsched : nullptr;
+            if (A->wd_vv)
+                hipLaunchKernelGGL((spmv_wdia_kernel<EPI, true>), dim3(grid), dim3(kBlock), 0, c->stream, a, A->d_wptr, A->d_wme, A->d_wmo,
+                                   A->d_wval, A->d_woff, A->d_wvblk, a.x, A->nblk_wd, A->nslices, (int32_t)A->row_begin, (int32_t)A->n,
+                                   sched, c->xcd_remap);
+            else
+                hipLaunchKernelGGL((spmv_wdia_kernel<EPI, false>), dim3(grid), dim3(kBlock), 0, c->stream, a, A->d_wptr, A->d_wme, A->d_wmo,
+                                   A->d_wval, A->d_woff, A->d_wvblk, a.x, A->nblk_wd, A->nslices, (int32_t)A->row_begin, (int32_t)A->n,
+                                   sched, c->xcd_remap);
             SLA_HIP_TRY(hipGetLastError());
             return SLA_OK;
         }

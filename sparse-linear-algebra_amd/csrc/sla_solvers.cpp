@@ -262,7 +262,7 @@ bool dual_ok(const sla_solver *S) {
     return !S->ctx->collectives && S->ctx->spmv_algo == 0 && S->ctx->dual_spmv && S->method != SLA_CGNE_ &&
            (S->A->panels.empty() || !S->ctx->panels) &&
            // (the wave-sliced form streams ~2 B of matrix per row: fusing the two sweeps saves nothing there)
-           !(S->A->use_wdia && S->ctx->wdia);
+           !(S->A->use_wdia && wd_on(S->A));
 }
 
 int read_scalars(sla_solver *S) {

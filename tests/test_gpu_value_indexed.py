@@ -184,3 +184,57 @@ def test_value_indexed_randomised_patterns(sla):
             assert np.allclose(y, want, rtol=1e-13, atol=1e-13), (case, algo)
         assert np.allclose(yt, want_t, rtol=1e-13, atol=1e-13), (case, algo, "transpose")
     assert picked["wdia"] >= 20, picked      # the generator is meant to exercise the value-indexed forms
+
+
+def _vv_cases():
+    from sla_amd import workloads as wl
+    rng = np.random.default_rng(77)
+    drop = rng.random((5003, 16)) < 0.25
+    noise = rng.standard_normal((5003, 16))
+    return {
+        "banded_nonsym 4001 (config 5 structure)": wl.banded_nonsym(4001),
+        "11 diagonals, random values, n=3001": _stencil(3001, [-700, -64, -9, -2, -1, 0, 1, 2, 63, 128, 900],
+                                                        lambda r, o: (12.0 if o == 0 else -1.0) * (1.0 + 0.1 * noise[r, (o % 13)])),
+        "ragged 9 diagonals, random values, odd n=5003": _stencil(5003, [-300, -17, -2, -1, 0, 1, 3, 250, 1025],
+                                                                   lambda r, o: 7.0 * (o == 0) + noise[r, o % 11],
+                                                                   keep=lambda r, t: ~drop[r, t] | (t == 4)),
+    }
+
+
+@pytest.mark.parametrize("name", list(_vv_cases()))
+def test_variable_coefficient_wave_sliced_form(sla, monkeypatch, name):
+    """Banded / stencil structure with arbitrary values: the wave-sliced kernel with per-row value blocks ("wdia-vv") --
+    the oracle's fold bit for bit, and the solvers agree with the general kernels."""
+    dims, csr = _vv_cases()[name]
+    n = dims[0]
+    Ao = _oracle_csr(dims, csr)
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal(n)
+    want, want_t = orc.spmv(Ao, x), orc.spmv(orc.transpose(Ao), x)
+    b = orc.spmv(Ao, np.linspace(-1.0, 1.0, n))
+    sols = {}
+    for form, env in (("wdia-vv", {}), ("general", {"SLA_WDIA_VV": "0"})):
+        monkeypatch.delenv("SLA_WDIA_VV", raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        ctx = sla.Context(0)
+        A = sla.fromCSR(dims, *csr, ctx)
+        algo = A.kernel_info().split()[0]
+        assert ("wdia-vv" in algo) == (form == "wdia-vv"), (form, algo)
+        y = sla.matVec(A, sla.fromVector(x, ctx)).toDenseListSV()
+        yt = sla.vecMat(sla.fromVector(x, ctx), A).toDenseListSV()
+        if form == "wdia-vv" or len(csr[1]) <= 8 * n:
+            assert np.array_equal(y.view(np.uint64), want.view(np.uint64)), (name, form)
+            assert np.array_equal(yt.view(np.uint64), want_t.view(np.uint64)), (name, form, "transpose")
+        else:
+            assert np.allclose(y, want, rtol=1e-13, atol=1e-13)
+        for meth in (sla.BICGSTAB_, sla.CGS_, sla.CGNE_):
+            xs, info = sla.linSolve0(meth, A, sla.fromVector(b, ctx), sla.fromVector(np.zeros(n), ctx), return_info=True)
+            sols[(form, int(meth))] = (xs.toDenseListSV(), info["iters"])
+        del A
+        ctx.close()
+    for meth in (sla.BICGSTAB_, sla.CGS_, sla.CGNE_):
+        (xa, ia), (xb, ib) = sols[("wdia-vv", int(meth))], sols[("general", int(meth))]
+        assert abs(ia - ib) <= 1, (name, meth, ia, ib)
+        if ia == ib:
+            assert np.abs(xa - xb).max() <= 1e-5 * (np.abs(xb).max() + 1e-300)
