@@ -28,4 +28,5 @@ done
 timeout 300 tools/kbench > $S/${tag}_kbench_spmv_variants.txt 2>&1
 bash tools/pmc_kbench.sh ${tag}_kbench tools/kbench x pmc 2>&1 | grep -E "axpby_kernel|dot_kernel|fill_kernel" > $S/${tag}_kbench_pmc_calibration.txt
 timeout 120 tools/xcc_probe > $S/${tag}_xcc_probe.txt 2>&1
+timeout 120 tools/l1_probe > $S/${tag}_l1_probe.txt 2>&1
 ls -la $S | head -40
