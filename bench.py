@@ -3,12 +3,14 @@
 
 One "step" = one bicgstabStep (Sparse.hs:972-981: 2 SpMV + 5 inner products + 6 vector updates, all on
 the device) on the BASELINE.json workload.  Default workload = configs[3], the one the metric is quoted
-on at 1/2/4/8 GPUs: the 10M-row (216^3 = 10 077 696) fp64 7-point 3-D Laplacian; at N > 1 it is
-row-sharded in contiguous slabs (strong scaling: total size fixed) with an RCCL all-gather of the SpMV
-input per SpMV.  Inputs are resident in HBM before the timed region.
+on at 1/2/4/8 GPUs: the 10M-row (216^3 = 10 077 696) fp64 7-point 3-D Laplacian (the "~1 % density" of
+configs[2] would be 10^12 entries; its 33-entries-per-row reading is --workload random_spd_10m); at N > 1 it is
+row-sharded in contiguous slabs (strong scaling: total size fixed), each SpMV preceded by an exchange of its input
+over RCCL (the slab's halo planes through grouped ncclSend/ncclRecv, or the all-gather when a matrix needs most
+of x).  Inputs are resident in HBM before the timed region.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload laplace3d_10m|poisson2d_1m|banded_2m|random_spd_1m]
-                    [--mode step|linsolve0] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--method bicgstab|cgs] [--mode step|linsolve0|gmres] [--no-cpu-baseline]
+                    [--workload laplace3d_10m|poisson2d_1m|banded_2m|random_spd_1m|random_spd_10m|dense_rows_200k]
 
 For N > 1 launch through torch.distributed.run (one rank per GPU); rank 0 prints ONE JSON line.
 """
