@@ -586,6 +586,7 @@ static int ctx_create_common(int device_id, int rank, int nranks, const void *ui
     if (const char *s = getenv("SLA_WDIA")) c->wdia = atoi(s);
     if (const char *s = getenv("SLA_WD_TILE")) c->wd_tile = atoi(s);
     if (const char *s = getenv("SLA_WDIA_VV")) c->wdia_vv = atoi(s);
+    if (const char *s = getenv("SLA_VEC_NT")) c->vec_nt = atoi(s);
     if (const char *s = getenv("SLA_PANELS")) c->panels = atoi(s);
     if (const char *s = getenv("SLA_PANEL_COLS")) c->panel_cols = atoll(s);
     if (const char *s = getenv("SLA_ROW_ALIGN")) c->row_align = atoi(s);

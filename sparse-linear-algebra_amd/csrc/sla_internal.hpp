@@ -124,6 +124,8 @@ struct sla_ctx {
     int panels = 1;                  // allow the column-panel SpMV for irregular matrices (SLA_PANELS=0 disables)
     int64_t panel_cols = 384 * 1024; // panel width in columns (SLA_PANEL_COLS): 3 MiB of x per pass
     int diag = 1;                    // allow the dictionary-compressed-index SpMV kernel (SLA_DIAG=0 disables)
+    int vec_nt = -1;                 // non-temporal loads in the BiCGSTAB vector kernels: -1 when the vectors overflow the memory-side cache, 0 / 1 (SLA_VEC_NT)
+    int64_t mall_bytes = 256ll << 20; // capacity of the memory-side cache (MI355X: 256 MiB)
     int wdia_vv = 1;                 // allow the variable-coefficient wave-sliced form (SLA_WDIA_VV=0 disables)
     int wd_grid_max_vv = sla::kWdBlocksPerCuVV * 256;
     int wd_tile = -1;                // plane tiling of the wave-sliced walk: -1 automatic, 0 off, > 0 steps per tile (SLA_WD_TILE)

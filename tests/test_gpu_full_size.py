@@ -22,7 +22,7 @@ def test_config5_banded_2m_gmres30(sla):
     dims, (rp, ci, va) = wl.banded_nonsym(2000000)                       # config 5
     n = dims[0]
     A = sla.fromCSR(dims, rp, ci, va)
-    assert "diagdict" in A.kernel_info()                                 # 5 diagonals -> 1-byte column codes
+    assert "wdia-vv" in A.kernel_info()                                  # 5 noisy diagonals -> variable-coefficient wave-sliced form
     b = np.add.reduceat(va, rp[:-1])                                     # b = A 1
     x, info = sla.gmres(A, sla.fromVector(b), sla.fromVector(np.zeros(n)), restart=30, return_info=True)
     xd = x.toDenseListSV()
