@@ -1449,11 +1449,12 @@ __global__ void __launch_bounds__(kBlock, VV ? kWdBlocksPerCuVV : kWdBlocksPerCu
                                                                const unsigned long long *__restrict__ wmo,
                                                                const double *__restrict__ wval, const int32_t *__restrict__ woff,
                                                                const double *__restrict__ wvblk, const double *__restrict__ xg, int32_t nblk, int32_t nslices,
-                                                               int32_t grow0, int32_t xlen, const int32_t *__restrict__ sched, int xcd_remap) {
+                                                               int32_t grow0, int32_t xlen, const int32_t *__restrict__ sched, int xcd_remap, int stream_nt) {
     __shared__ double s_red[4];
     const int tid = threadIdx.x;
     double coef;
     if (!spmv_prologue<EPI, int32_t>(a, s_red, coef)) return;
+    const bool w_nt = stream_nt && a.w != xg + grow0;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
     double acc1 = 0.0, acc2 = 0.0;
@@ -1517,13 +1518,14 @@ __global__ void __launch_bounds__(kBlock, VV ? kWdBlocksPerCuVV : kWdBlocksPerCu
         const int row = (blk * 4 + wave) * 128 + 2 * lane;  // this lane's rows: row, row + 1
         const bool va = row < a.rows, vb = row + 1 < a.rows;
         if (vb) {
-#if defined(SLA_WD_NT_W)
-            if constexpr (kUsesW) { if (EPI != EPI_AXPY_DOT || a.w) st.wv = __builtin_nontemporal_load((const wd_f64x2 *)(a.w + row)); }
-            if constexpr (kUsesZ) st.zv = __builtin_nontemporal_load((const wd_f64x2 *)(a.z + row));
-#else
-            if constexpr (kUsesW) { if (EPI != EPI_AXPY_DOT || a.w) st.wv = *(const wd_f64x2 *)(a.w + row); }
-            if constexpr (kUsesZ) st.zv = *(const wd_f64x2 *)(a.z + row);
-#endif
+            // epilogue operands are single-use streams: past the caches when the vectors overflow them anyway (see
+            // vec_stream_nt) -- except an operand that IS the gathered vector (K3: w = s = x), which must stay
+            if constexpr (kUsesW) {
+                if (EPI != EPI_AXPY_DOT || a.w)
+                    st.wv = w_nt ? __builtin_nontemporal_load((const wd_f64x2 *)(a.w + row)) : *(const wd_f64x2 *)(a.w + row);
+            }
+            if constexpr (kUsesZ)
+                st.zv = stream_nt ? __builtin_nontemporal_load((const wd_f64x2 *)(a.z + row)) : *(const wd_f64x2 *)(a.z + row);
         } else if (va) {
             if constexpr (kUsesW) { if (EPI != EPI_AXPY_DOT || a.w) st.wv.x = a.w[row]; }
             if constexpr (kUsesZ) st.zv.x = a.z[row];
@@ -1738,6 +1740,11 @@ __global__ void __launch_bounds__(kBlock) spmv_scalar_kernel(SpmvArgs<RP> a, int
     }
 }
 
+// do the solver's vectors (7 of n entries for BiCGSTAB) overflow the memory-side cache?  Then stream them past it.
+static bool vec_stream_nt(const sla_ctx *c, int64_t n) {
+    return c->vec_nt < 0 ? 7 * 8 * n > c->mall_bytes : c->vec_nt != 0;
+}
+
 int spmv_grid(const sla_csr *A) {
     const sla_ctx *c = A->ctx;
     // with column panels the fused partials are written by the LAST panel pass: its grid is the one that counts
@@ -1827,11 +1834,11 @@ static int launch_spmv_t(const sla_csr *A, const SpmvLaunch &l) {
             if (A->wd_vv)
                 hipLaunchKernelGGL((spmv_wdia_kernel<EPI, true>), dim3(grid), dim3(kBlock), 0, c->stream, a, A->d_wptr, A->d_wme, A->d_wmo,
                                    A->d_wval, A->d_woff, A->d_wvblk, a.x, A->nblk_wd, A->nslices, (int32_t)A->row_begin, (int32_t)A->n,
-                                   sched, c->xcd_remap);
+                                   sched, c->xcd_remap, vec_stream_nt(c, A->rows) ? 1 : 0);
             else
                 hipLaunchKernelGGL((spmv_wdia_kernel<EPI, false>), dim3(grid), dim3(kBlock), 0, c->stream, a, A->d_wptr, A->d_wme, A->d_wmo,
                                    A->d_wval, A->d_woff, A->d_wvblk, a.x, A->nblk_wd, A->nslices, (int32_t)A->row_begin, (int32_t)A->n,
-                                   sched, c->xcd_remap);
+                                   sched, c->xcd_remap, vec_stream_nt(c, A->rows) ? 1 : 0);
             SLA_HIP_TRY(hipGetLastError());
             return SLA_OK;
         }
@@ -2106,11 +2113,6 @@ __global__ void __launch_bounds__(kBlock) bicg_k5_kernel(int64_t n, SolverScalar
     if (SLA_HAS_TAIL(n)) p[n - 1] = r[n - 1] + beta * (p[n - 1] - omega * ap[n - 1]);
 }
 
-// do the solver's vectors (7 of n entries for BiCGSTAB) overflow the memory-side cache?  Then stream them past it.
-static bool vec_stream_nt(const sla_ctx *c, int64_t n) {
-    return c->vec_nt < 0 ? 7 * 8 * n > c->mall_bytes : c->vec_nt != 0;
-}
-
 int launch_bicg_k2(sla_ctx *c, int64_t n, SolverScalars *sc, Parts apr, int par, Parts res, int count_iter,
                    const double *r, const double *ap, double *s) {
     if (vec_stream_nt(c, n))
@@ -2142,6 +2144,7 @@ int launch_bicg_k5(sla_ctx *c, int64_t n, SolverScalars *sc, Parts rhonew, int p
 // CGS (Sparse.hs:928-939): C2 / C4 (C1 = SpMV+dot, C3 = SpMV + r update + dot)
 // ---------------------------------------------------------------------------------------------
 // C2: alphaj ; q = u ^-^ alphaj .* aap ; uq = u ^+^ q ; xj1 = x ^+^ alphaj .* uq
+template <bool NT>
 __global__ void __launch_bounds__(kBlock) cgs_c2_kernel(int64_t n, SolverScalars *sc, Parts apr, int par,
                                                          Parts res, int count_iter, const double *u,
                                                          const double *aap, double *q, double *uq, double *x) {
@@ -2152,8 +2155,8 @@ __global__ void __launch_bounds__(kBlock) cgs_c2_kernel(int64_t n, SolverScalars
     const double alpha = sc->rho2[par] / reduce_parts(apr.p, apr.n, apr.stride, s_red);
     if (blockIdx.x == 0 && threadIdx.x == 0) sc->alpha = alpha;
     SLA_VEC_LOOP_BEGIN(n)
-        const double2 uv = ld2(u, i2), av = ld2(aap, i2);
-        double2 xv = ld2(x, i2);
+        const double2 uv = ld2s<NT>(u, i2), av = ld2s<NT>(aap, i2);
+        double2 xv = ld2s<NT>(x, i2);
         const double2 qv = make_double2(uv.x - alpha * av.x, uv.y - alpha * av.y);
         const double2 sv = make_double2(uv.x + qv.x, uv.y + qv.y);
         xv.x += alpha * sv.x;
@@ -2172,6 +2175,7 @@ __global__ void __launch_bounds__(kBlock) cgs_c2_kernel(int64_t n, SolverScalars
 }
 
 // C4: betaj = (rj1 <.> rhat) / (r <.> rhat) ; uj1 = rj1 ^+^ betaj .* q ; pj1 = uj1 ^+^ betaj .* (q ^+^ betaj .* p)
+template <bool NT>
 __global__ void __launch_bounds__(kBlock) cgs_c4_kernel(int64_t n, SolverScalars *sc, Parts rhonew, int par,
                                                          const double *r, const double *q, double *u, double *p) {
     __shared__ double s_red[4];
@@ -2180,8 +2184,8 @@ __global__ void __launch_bounds__(kBlock) cgs_c4_kernel(int64_t n, SolverScalars
     const double beta = rn / sc->rho2[par];
     if (blockIdx.x == 0 && threadIdx.x == 0) { sc->beta = beta; sc->rho2[par ^ 1] = rn; }
     SLA_VEC_LOOP_BEGIN(n)
-        const double2 rv = ld2(r, i2), qv = ld2(q, i2);
-        double2 pv = ld2(p, i2);
+        const double2 rv = ld2s<NT>(r, i2), qv = ld2s<NT>(q, i2);
+        double2 pv = ld2s<NT>(p, i2);
         const double2 uv = make_double2(rv.x + beta * qv.x, rv.y + beta * qv.y);
         pv.x = uv.x + beta * (qv.x + beta * pv.x);
         pv.y = uv.y + beta * (qv.y + beta * pv.y);
@@ -2198,13 +2202,19 @@ __global__ void __launch_bounds__(kBlock) cgs_c4_kernel(int64_t n, SolverScalars
 
 int launch_cgs_c2(sla_ctx *c, int64_t n, SolverScalars *sc, Parts apr, int par, Parts res, int count_iter,
                   const double *u, const double *aap, double *q, double *uq, double *x) {
-    hipLaunchKernelGGL(cgs_c2_kernel, dim3(vec_grid(n)), dim3(kBlock), 0, c->stream, n, sc, apr, par, res, count_iter, u, aap, q, uq, x);
+    if (vec_stream_nt(c, n))
+        hipLaunchKernelGGL(cgs_c2_kernel<true>, dim3(vec_grid(n)), dim3(kBlock), 0, c->stream, n, sc, apr, par, res, count_iter, u, aap, q, uq, x);
+    else
+        hipLaunchKernelGGL(cgs_c2_kernel<false>, dim3(vec_grid(n)), dim3(kBlock), 0, c->stream, n, sc, apr, par, res, count_iter, u, aap, q, uq, x);
     SLA_HIP_TRY(hipGetLastError());
     return SLA_OK;
 }
 int launch_cgs_c4(sla_ctx *c, int64_t n, SolverScalars *sc, Parts rhonew, int par, const double *r, const double *q,
                   double *u, double *p) {
-    hipLaunchKernelGGL(cgs_c4_kernel, dim3(vec_grid(n)), dim3(kBlock), 0, c->stream, n, sc, rhonew, par, r, q, u, p);
+    if (vec_stream_nt(c, n))
+        hipLaunchKernelGGL(cgs_c4_kernel<true>, dim3(vec_grid(n)), dim3(kBlock), 0, c->stream, n, sc, rhonew, par, r, q, u, p);
+    else
+        hipLaunchKernelGGL(cgs_c4_kernel<false>, dim3(vec_grid(n)), dim3(kBlock), 0, c->stream, n, sc, rhonew, par, r, q, u, p);
     SLA_HIP_TRY(hipGetLastError());
     return SLA_OK;
 }
