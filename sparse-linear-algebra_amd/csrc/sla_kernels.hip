@@ -2076,7 +2076,8 @@ __global__ void __launch_bounds__(kBlock) bicg_k4_kernel(int64_t n, SolverScalar
         double2 xv = ld2s<NT>(x, i2);
         xv.x = (xv.x + alpha * pv.x) + omega * sv.x;
         xv.y = (xv.y + alpha * pv.y) + omega * sv.y;
-        st2(x, i2, xv);
+        if (NT) st2_nt(x, i2, xv);  // nobody reads x before the next K4: do not let it push the live vectors out
+        else st2(x, i2, xv);
         const double2 rv = make_double2(sv.x - omega * av.x, sv.y - omega * av.y);
         st2(r, i2, rv);
         acc += rv.x * hv.x;
