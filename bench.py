@@ -38,6 +38,8 @@ def workload(name, row_begin=0, row_end=None):
         return "1M-row fp64 5-pt Poisson (1000x1000), BiCGSTAB", wl.poisson2d(1000, 1000, row_begin, row_end)
     if name == "banded_2m":
         return "2M-row fp64 non-symmetric banded (5 bands), BiCGSTAB", wl.banded_nonsym(2000000, 99, row_begin, row_end)
+    if name == "laplace3d_1m":   # the size of one rank's slab of the 216^3 problem at 8 GPUs
+        return "108^3 7-pt Laplacian (1.26M rows)", wl.laplace3d(108, 108, 108, row_begin, row_end)
     if name == "laplace3d_small":
         return "64^3 7-pt Laplacian (test size)", wl.laplace3d(64, 64, 64, row_begin, row_end)
     if name == "random_spd_10m":
