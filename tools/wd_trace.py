@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Per-wave timeline of spmv_wdia_kernel<EPI_DOT> inside a BiCGSTAB step (trace build: tools/build_variant.sh trace
 -DSLA_WD_TRACE=1; run with SLA_HIP_LIB=.../libsla_hip_trace.so).  Prints, for wave 0 of every 32nd workgroup, the
-cycles spent per slice in: issue (records + gathers), wait (s_waitcnt vmcnt(0)), fold + store."""
+cycles spent per slice in: issue (records + epilogue operands + gathers) and wait + fold + store."""
 import ctypes as C
 import os
 import sys
@@ -30,8 +30,10 @@ assert rc == 0, rc
 t = buf.reshape(64, 16, 4).astype(np.int64)
 for g in range(0, 64, 8):
     rows = []
-    for i in range(11):
+    for i in range(14):
         if t[g, i, 3] == 0:
             break
-        rows.append("%5d/%5d/%5d" % (t[g, i, 1] - t[g, i, 0], t[g, i, 2] - t[g, i, 1], t[g, i, 3] - t[g, i, 2]))
-    print("wg %4d start %d  issue/wait/fold cycles:" % (g * 32, t[g, 0, 0] - t[:, 0, 0].min()), " ".join(rows), " total", t[g, max(0, len(rows) - 1), 3] - t[g, 0, 0])
+        rows.append("%5d/%5d" % (t[g, i, 1] - t[g, i, 0], t[g, i, 3] - t[g, i, 1]))
+    if rows:
+        print("wg %4d issue / wait+fold cycles per slice:" % (g * 32), " ".join(rows),
+              " total", t[g, len(rows) - 1, 3] - t[g, 0, 0])
