@@ -65,7 +65,24 @@ int gather_raw(sla_ctx *c, const sla_csr *A, const double *local, int64_t shard,
     *base = c->d_xfull;
     return SLA_OK;
 }
-int gather_x(const sla_csr *A, sla_vec *x, const double **base) { return gather_raw(x->ctx, A, x->d, x->shard, base); }
+int gather_x(const sla_csr *A, sla_vec *x, const double **base) {
+    sla_ctx *c = x->ctx;
+    if (c->collectives && c->halo_inplace && A && A->xplan && c->x_exchange != 1 && (A->xplan->use_window || c->x_exchange == 2)) {
+        // the neighbours' planes fit the slack around this vector: receive them in place, gather from x - first_row
+        const XPlan &pl = *A->xplan;
+        const int64_t b = x->begin, cap = (int64_t)(c->vec_guard / sizeof(double)) - 8;   // (8: the row-pair gathers' own slack)
+        bool fits = true;
+        for (int q = 0; q < c->nranks && fits; ++q)
+            if (q != c->rank && pl.recv_len[(size_t)q] > 0)
+                fits = pl.recv_begin[(size_t)q] >= b - cap && pl.recv_begin[(size_t)q] + pl.recv_len[(size_t)q] <= b + x->shard + cap;
+        if (fits) {
+            SLA_TRY(dist_exchange_window(c, pl, x->d, b, x->n_local, x->d - b));
+            *base = x->d - b;
+            return SLA_OK;
+        }
+    }
+    return gather_raw(c, A, x->d, x->shard, base);
+}
 
 // sharded only: all-gather every rank's referenced column window and derive the exchange plan
 static int build_xplan(sla_csr *A, int64_t rows, const int64_t *rowptr, const int64_t *col) {
@@ -99,7 +116,6 @@ int reduce_to_host(sla_ctx *c, const double *p1, const double *p2, int np, doubl
     SLA_TRY(launch_finalize(c, p1, p2, np, c->d_result));
     const double *src = c->d_result;
     if (c->collectives) {
-        if (!p2) SLA_HIP_TRY(hipMemsetAsync(c->d_result + 1, 0, sizeof(double), c->stream));
         SLA_TRY(dist_allgather_f64(c, c->d_result, c->d_result + 16, 2));
         SLA_TRY(launch_finalize_cols(c, c->d_result + 16, c->nranks, 1, 2, 2, c->d_result + 8));
         src = c->d_result + 8;
@@ -121,7 +137,7 @@ static hipError_t pool_alloc(sla_ctx *c, size_t bytes, void **p) {
         c->vec_pool_bytes -= bytes;
         return hipSuccess;
     }
-    return guard_malloc(p, bytes);
+    return guard_malloc(p, bytes, c->vec_guard);
 }
 
 static void pool_free(sla_ctx *c, void *p, size_t bytes) {
@@ -130,7 +146,7 @@ static void pool_free(sla_ctx *c, void *p, size_t bytes) {
         c->vec_pool.emplace(bytes, p);
         c->vec_pool_bytes += bytes;
     } else {
-        (void)guard_free(p);
+        (void)guard_free(p, c ? c->vec_guard : kGuardBytes);
     }
 }
 
@@ -587,6 +603,7 @@ static int ctx_create_common(int device_id, int rank, int nranks, const void *ui
     if (const char *s = getenv("SLA_WD_TILE")) c->wd_tile = atoi(s);
     if (const char *s = getenv("SLA_WDIA_VV")) c->wdia_vv = atoi(s);
     if (const char *s = getenv("SLA_VEC_NT")) c->vec_nt = atoi(s);
+    if (const char *s = getenv("SLA_HALO_INPLACE")) c->halo_inplace = atoi(s);
     if (const char *s = getenv("SLA_PANELS")) c->panels = atoi(s);
     if (const char *s = getenv("SLA_PANEL_COLS")) c->panel_cols = atoll(s);
     if (const char *s = getenv("SLA_ROW_ALIGN")) c->row_align = atoi(s);
@@ -616,6 +633,7 @@ static int ctx_create_common(int device_id, int rank, int nranks, const void *ui
         }
         const char *f = getenv("SLA_FORCE_COLLECTIVES");
         c->collectives = nranks > 1 || (f && atoi(f) != 0);
+        if (c->collectives) c->vec_guard = kHaloBytes;
     }
     *out = c;
     return SLA_OK;
@@ -642,6 +660,7 @@ int sla_ctx_create_loopback(int device_id, int rank, int nranks, int group_key, 
         return rc;
     }
     (*out)->collectives = true;
+    (*out)->vec_guard = kHaloBytes;
     return SLA_OK;
 }
 
@@ -650,7 +669,7 @@ int sla_ctx_destroy(sla_ctx_t c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     dist_comm_destroy(c);
-    for (auto &kv : c->vec_pool) (void)guard_free(kv.second);
+    for (auto &kv : c->vec_pool) (void)guard_free(kv.second, c->vec_guard);
     c->vec_pool.clear();
     for (hipEvent_t ev : c->prof_ev) (void)hipEventDestroy(ev);
     if (c->d_parts) (void)hipFree(c->d_parts);

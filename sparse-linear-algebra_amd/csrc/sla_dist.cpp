@@ -225,7 +225,7 @@ int dist_exchange_window(sla_ctx *ctx, const XPlan &plan, const double *xlocal, 
         g->ptr[(size_t)ctx->rank] = xlocal;
         g->aux[(size_t)ctx->rank] = my_begin;
         g->barrier();
-        if (n_local > 0)
+        if (n_local > 0 && xfull + my_begin != xlocal)
             SLA_HIP_TRY(hipMemcpyAsync(xfull + my_begin, xlocal, sizeof(double) * (size_t)n_local, hipMemcpyDeviceToDevice, ctx->stream));
         for (int q = 0; q < ctx->nranks; ++q) {
             if (q == ctx->rank || plan.recv_len[(size_t)q] <= 0) continue;
@@ -240,7 +240,7 @@ int dist_exchange_window(sla_ctx *ctx, const XPlan &plan, const double *xlocal, 
     Rccl &r = rccl();
     if (!ctx->comm) return fail(SLA_ERR_RCCL, "window exchange requested on a context without a communicator");
     if (!r.send || !r.recv || !r.group_start || !r.group_end) return fail(SLA_ERR_RCCL, "librccl lacks ncclSend/ncclRecv");
-    if (n_local > 0)
+    if (n_local > 0 && xfull + my_begin != xlocal)
         SLA_HIP_TRY(hipMemcpyAsync(xfull + my_begin, xlocal, sizeof(double) * (size_t)n_local, hipMemcpyDeviceToDevice, ctx->stream));
     int rc = r.group_start();
     if (rc != 0) return rccl_fail("ncclGroupStart", rc);

@@ -34,6 +34,8 @@ constexpr int kMaxParts = 2048;      // partial-sum slots per reduction (256 CUs
 constexpr int kVecGridMax = 1024;    // grid cap of the streaming BLAS-1 kernels
 constexpr int kSpmvGridMax = 2048;   // persistent grid cap of the SpMV kernels
 constexpr int kArnGridMax = 1024;    // grid cap (= partials per column) of the Arnoldi kernels
+constexpr size_t kGuardBytes = 256;             // readable slack on both sides of every buffer an SpMV gathers from
+constexpr size_t kHaloBytes = (size_t)4 << 20;  // the same for vectors of sharded contexts: room for the neighbours' halo planes
 constexpr int kMaxKrylov = 64;       // max Arnoldi basis columns handled by the fused GS kernels
 
 // Device-resident scalars of one solver.  Written only by block 0 / thread 0 of a kernel and
@@ -134,6 +136,8 @@ struct sla_ctx {
     int xwin = 1;                    // allow the LDS x-window SpMV kernel (SLA_XWIN=0 disables)
     int dual_spmv = 1;               // linSolve0: fuse the true-residual SpMV into the next K1 (SLA_DUAL_SPMV=0 disables)
     int x_exchange = 0;              // 0 auto (window exchange when it pays), 1 always all-gather, 2 always window (SLA_X_EXCHANGE=allgather|window)
+    int halo_inplace = 1;            // window exchange straight into the slack around the vector (SLA_HALO_INPLACE=0: via the landing buffer)
+    size_t vec_guard = sla::kGuardBytes;  // slack on both sides of every pooled vector (kHaloBytes once the context is sharded)
     bool collectives = false;        // nranks > 1, or SLA_FORCE_COLLECTIVES=1 on a 1-rank communicator (test hook)
     int spmv_grid_max = sla::kSpmvGridMax;
     int wd_grid_max = sla::kWdBlocksPerCu * 256;  // persistent grid of spmv_wdia_kernel: kWdBlocksPerCu x CUs (a multiple of 8)
@@ -243,14 +247,15 @@ inline bool wd_on(const sla_csr *A) { return A->wd_vv ? (A->ctx->wdia && A->ctx-
 // Arnoldi basis): kGuardBytes of readable slack on both sides.  spmv_wdia_kernel gathers row PAIRS with one
 // 16-byte load; when only one row of a pair holds an entry, the other half may lie one element outside
 // [0, n) -- inside the slack, never used (the fold is masked per row).
-constexpr size_t kGuardBytes = 256;
-inline hipError_t guard_malloc(void **p, size_t bytes) {
+// On sharded contexts the vectors get kHaloBytes instead: the window (halo) exchange then receives the neighbours' planes
+// straight into the slack around the rank's own rows, and the SpMV gathers from `vector - first_row` with no copy at all.
+inline hipError_t guard_malloc(void **p, size_t bytes, size_t guard = kGuardBytes) {
     void *raw = nullptr;
-    const hipError_t e = hipMalloc(&raw, bytes + 2 * kGuardBytes);
-    if (e == hipSuccess) *p = (char *)raw + kGuardBytes;
+    const hipError_t e = hipMalloc(&raw, bytes + 2 * guard);
+    if (e == hipSuccess) *p = (char *)raw + guard;
     return e;
 }
-inline hipError_t guard_free(void *p) { return p ? hipFree((char *)p - kGuardBytes) : hipSuccess; }
+inline hipError_t guard_free(void *p, size_t guard = kGuardBytes) { return p ? hipFree((char *)p - guard) : hipSuccess; }
 
 // error plumbing ---------------------------------------------------------------------------------
 void set_error(const std::string &msg);
@@ -300,6 +305,7 @@ int dist_comm_destroy(sla_ctx *ctx);
 int dist_loopback_join(sla_ctx *ctx, int group_key);
 int dist_allgather_f64(sla_ctx *ctx, const double *send, double *recv, int64_t count);
 int dist_reduce_scatter_f64(sla_ctx *ctx, const double *send, double *recv, int64_t recvcount);
+// xfull == xlocal - my_begin: in-place (the own rows are where they belong already, nothing is copied)
 int dist_exchange_window(sla_ctx *ctx, const XPlan &plan, const double *xlocal, int64_t my_begin, int64_t n_local, double *xfull);
 int dist_allreduce_max_i32(sla_ctx *ctx, int *value_host);
 

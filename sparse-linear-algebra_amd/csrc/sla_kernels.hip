@@ -2009,9 +2009,15 @@ int launch_dot(sla_ctx *c, int64_t n, const double *x, const double *y, double *
     SLA_HIP_TRY(hipGetLastError());
     return SLA_OK;
 }
+// out[0] = sum p1, out[1] = sum p2 (0 when p2 is null): two workgroups, one launch
+__global__ void __launch_bounds__(kBlock) finalize2_kernel(const double *p1, const double *p2, int np, double *out) {
+    __shared__ double s_red[4];
+    const double *p = blockIdx.x == 0 ? p1 : p2;
+    const double s = p ? reduce_parts(p, np, 1, s_red) : 0.0;
+    if (threadIdx.x == 0) out[blockIdx.x] = s;
+}
 int launch_finalize(sla_ctx *c, const double *p1, const double *p2, int np, double *out) {
-    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(kBlock), 0, c->stream, p1, np, 0, 1, 1, out);
-    if (p2) hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(kBlock), 0, c->stream, p2, np, 0, 1, 1, out + 1);
+    hipLaunchKernelGGL(finalize2_kernel, dim3(2), dim3(kBlock), 0, c->stream, p1, p2, np, out);
     SLA_HIP_TRY(hipGetLastError());
     return SLA_OK;
 }

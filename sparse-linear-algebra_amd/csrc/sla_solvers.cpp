@@ -31,8 +31,7 @@ int publish(sla_solver *S, int s1, int s2, int np, Parts *o1, Parts *o2) {
         return SLA_OK;
     }
     double *loc = S->d_gath + (size_t)P_SLOTS * 2 * c->nranks;  // 2 doubles of staging
-    SLA_TRY(launch_finalize(c, slot(S, s1), s2 >= 0 ? slot(S, s2) : nullptr, np, loc));
-    if (s2 < 0) SLA_HIP_TRY(hipMemsetAsync(loc + 1, 0, sizeof(double), c->stream));
+    SLA_TRY(launch_finalize(c, slot(S, s1), s2 >= 0 ? slot(S, s2) : nullptr, np, loc));   // loc[1] = 0 without a second array
     double *g = S->d_gath + (size_t)s1 * 2 * c->nranks;
     SLA_TRY(dist_allgather_f64(c, loc, g, 2));
     *o1 = Parts{g, c->nranks, 2};
