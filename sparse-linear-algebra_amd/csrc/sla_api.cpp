@@ -76,6 +76,8 @@ int gather_x(const sla_csr *A, sla_vec *x, const double **base) {
             if (q != c->rank && pl.recv_len[(size_t)q] > 0)
                 fits = pl.recv_begin[(size_t)q] >= b - cap && pl.recv_begin[(size_t)q] + pl.recv_len[(size_t)q] <= b + x->shard + cap;
         if (fits) {
+            static const bool dbg = getenv("SLA_DEBUG_EXCHANGE") != nullptr;
+            if (dbg) fprintf(stderr, "[sla] rank %d: in-place halo exchange (own rows %lld..%lld)\n", c->rank, (long long)b, (long long)(b + x->n_local));
             SLA_TRY(dist_exchange_window(c, pl, x->d, b, x->n_local, x->d - b));
             *base = x->d - b;
             return SLA_OK;
