@@ -3,7 +3,7 @@
 --   libsla_hip.so (include/sla_hip.h).  Re-exports the reference's names so callers only change an import.
 --   NOT compiled in the authoring image (no GHC there); see haskell/README.md.
 module Numeric.LinearAlgebra.Sparse.HIP
-  ( linSolve0, LinSolveMethod(..), (#>), (<.>), norm2, arnoldi, (<\>)
+  ( linSolve0, LinSolveMethod(..), (#>), (<.>), norm2, arnoldi, (<\>), triLowerSolve, triUpperSolve
   , BICGSTAB, bicgsInit, bicgstabStep, _xBicgstab, _rBicgstab, _pBicgstab
   , CGS, cgsInit, cgsStep, _x, _r, _p, _u
   ) where
@@ -16,7 +16,7 @@ import Foreign.C.String
 import Foreign.C.Types
 import System.IO.Unsafe (unsafePerformIO)
 
-import Control.Exception.Common (IterationException (..), OperandSizeMismatch (..))
+import Control.Exception.Common (IterationException (..), MatrixException (..), OperandSizeMismatch (..))
 import qualified Data.Sparse.SpMatrix as R
 import qualified Data.Sparse.SpVector as R
 import Numeric.LinearAlgebra.Sparse (LinSolveMethod (..))
@@ -39,6 +39,7 @@ foreign import ccall safe "&sla_solver_destroy" p_solver_destroy  :: FunPtr (Ptr
 foreign import ccall safe "sla_linsolve0"       c_linsolve0       :: CInt -> Ptr Csr -> Ptr Vec -> Ptr Vec -> Ptr () -> Ptr Vec -> Ptr () -> IO CInt
 foreign import ccall safe "sla_arnoldi"         c_arnoldi         :: Ptr Csr -> Ptr Vec -> CInt -> Ptr Double -> Ptr Double -> Ptr CInt -> IO CInt
 foreign import ccall safe "sla_linsolve"        c_linsolve        :: Ptr Csr -> Ptr Vec -> Ptr Vec -> Ptr () -> IO CInt
+foreign import ccall safe "sla_tri_solve"       c_tri_solve       :: Ptr Csr -> CInt -> Ptr Vec -> Ptr Vec -> Ptr Int64 -> IO CInt
 foreign import ccall unsafe "sla_last_error"    c_last_error      :: IO CString
 
 {-# NOINLINE defaultCtx #-}
@@ -51,6 +52,7 @@ check _ 0 = return ()
 check who 1 = c_last_error >>= peekCString >>= \s -> throwM (MatVecSizeMismatchException (who ++ " : " ++ s) (0, 0) 0)
 check who 2 = throwM (IterE who "Only BICGSTAB_, CGS_, and CGNE_ are implemented" :: IterationException ())
 check _ 3 = error "insertSpMatrix : index out of bounds"
+check who 9 = c_last_error >>= peekCString >>= \s -> throwM (NeedsPivoting who s :: MatrixException ())
 check who _ = c_last_error >>= peekCString >>= \s -> ioError (userError (who ++ ": " ++ s))
 
 -- | fromListSM semantics are re-applied by the library (sort, last duplicate wins); toListSM's descending
@@ -158,3 +160,15 @@ aa <\> b = liftIO $ do
   a <- lower aa; vb <- upload b; vo <- zeros (R.ncols aa)
   withForeignPtr a $ \pa -> withForeignPtr vb $ \pb -> withForeignPtr vo $ \po -> c_linsolve pa pb po nullPtr >>= check "<\\>"
   download (R.ncols aa) vo
+
+-- | triLowerSolve / triUpperSolve (Sparse.hs:750-811): status 9 is the reference's NeedsPivoting (mapped in `check`);
+--   the device result is already sparsifySV-ed
+triLowerSolve, triUpperSolve :: (MonadThrow m, MonadIO m) => R.SpMatrix Double -> R.SpVector Double -> m (R.SpVector Double)
+triLowerSolve = triSolve 0 "triLowerSolve"
+triUpperSolve = triSolve 1 "triUpperSolve"
+
+triSolve :: (MonadThrow m, MonadIO m) => CInt -> String -> R.SpMatrix Double -> R.SpVector Double -> m (R.SpVector Double)
+triSolve upper who tt b = liftIO $ do
+  t <- lower tt; vb <- upload b; vo <- zeros (R.nrows tt)
+  withForeignPtr t $ \pt -> withForeignPtr vb $ \pb -> withForeignPtr vo $ \po -> c_tri_solve pt upper pb po nullPtr >>= check who
+  R.sparsifySV <$> download (R.nrows tt) vo
