@@ -27,6 +27,9 @@ for w in laplace3d_10m poisson2d_1m random_spd_1m; do
 done
 timeout 300 tools/kbench > $S/${tag}_kbench_spmv_variants.txt 2>&1
 bash tools/pmc_kbench.sh ${tag}_kbench tools/kbench x pmc 2>&1 | grep -E "axpby_kernel|dot_kernel|fill_kernel" > $S/${tag}_kbench_pmc_calibration.txt
+# same-box ablation of the knobs behind the default line (BiCGSTAB it/s, K1 ms, rotating SpMV ms)
+tools/ab.sh DEFAULT=1 SLA_VEC_NT=0 SLA_WD_TILE=0 SLA_XCD_REMAP=0 SLA_WDIA=0 "SLA_WDIA=0 SLA_VDICT=0" "SLA_WDIA=0 SLA_VDICT=0 SLA_VEC_NT=0" \
+  "SLA_WDIA=0 SLA_VDICT=0 SLA_DIAG=0 SLA_VEC_NT=0" "SLA_WDIA=0 SLA_VDICT=0 SLA_DIAG=0 SLA_XWIN=0 SLA_VEC_NT=0" DEFAULT=2 > $S/${tag}_ablation.txt 2>&1
 timeout 120 tools/xcc_probe > $S/${tag}_xcc_probe.txt 2>&1
 timeout 120 tools/l1_probe > $S/${tag}_l1_probe.txt 2>&1
 ls -la $S | head -40
