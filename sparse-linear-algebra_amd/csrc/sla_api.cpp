@@ -400,6 +400,7 @@ static int csr_upload(sla_ctx *c, int64_t m, int64_t n, int64_t row_begin, int64
                     }
                 wptr[(size_t)sl + 1] = (int32_t)wme.size();
                 if ((int64_t)wme.size() * 32 > nnz + 2048) wok = false;   // < 1/4 full: the byte-code kernel is the better form
+                if (wptr[(size_t)sl + 1] - wptr[(size_t)sl] > kWdMaxSliceRecords) wok = false;   // the records past the 8 pipelined ones go one by one
             }
             if (wok) {
                 A->nwent = (int64_t)wme.size();
@@ -476,6 +477,7 @@ static int csr_upload(sla_ctx *c, int64_t m, int64_t n, int64_t row_begin, int64
                     wvb[(first + (size_t)slot_of[dcodes[(size_t)k]]) * 128 + (size_t)(i - rlo)] = val[k];
             wptr[(size_t)sl + 1] = (int32_t)wme.size();
             if ((int64_t)wme.size() * 64 > nnz + 4096) wok = false;   // less than half of the slots used
+            if (wptr[(size_t)sl + 1] - wptr[(size_t)sl] > kWdMaxSliceRecords) wok = false;
         }
         if (wok) {
             A->nwent = (int64_t)wme.size();
