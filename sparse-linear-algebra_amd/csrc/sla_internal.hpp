@@ -25,9 +25,12 @@ constexpr int kXWinHalo = 256;       // the window starts kXWinHalo columns left
 #define SLA_WD_STAGES 1
 #endif
 constexpr int kWdBlocksPerCu = SLA_WD_OCC;      // resident workgroups per CU of spmv_wdia_kernel (its persistent grid = that x CUs)
-constexpr int kWdBlocksPerCuVV = 5;             // same for the variable-coefficient variant (per-row value blocks: 102 VGPRs)
+#if !defined(SLA_WD_OCC_VV)
+#define SLA_WD_OCC_VV 5
+#endif
+constexpr int kWdBlocksPerCuVV = SLA_WD_OCC_VV;             // same for the variable-coefficient variant (per-row value blocks: 102 VGPRs)
 constexpr int kWdMaxSliceRecords = 40;          // wave-sliced forms: more diagonals per 128-row slice than this and the older kernels are used
-                                                // (27-point stencils measured: wdia 40 us = vdict 42 us, diagdict 167 us)
+                                                // (27-point stencil, 128^3: wdia 25.5 us, vdict 42 us, diagdict 167 us)
 constexpr int kWdGatherStages = SLA_WD_STAGES;  // 2: the gathers of the next slice are issued before the current one is folded
 constexpr int kVdRows = 256;         // rows per block of spmv_vdict_kernel (one lane per row)
 constexpr int kVdMaxRowNnz = 31;     // longest row the value-indexed kernel takes (256 rows x 31 B of codes fit its LDS stage)

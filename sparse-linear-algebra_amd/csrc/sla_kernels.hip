@@ -1499,6 +1499,51 @@ __global__ void __launch_bounds__(kBlock, VV ? kWdBlocksPerCuVV : kWdBlocksPerCu
         double v;                   // lane k: value of record k
         int blk, e0, cnt;
     };
+    // gathers of the 8 records held by lanes 0..7 of `r` (first record e0) for the row pair starting at `row`
+    auto gather8 = [&](const WdRec &r, int e0, int row, wd_f64x2 *xv, wd_f64x2 *vv) {
+        // byte offset of x[global row]; a record's diagonal offset moves the scalar base instead
+        const uint32_t g8 = (uint32_t)(grow0 + row) * 8u;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const unsigned long long mb = wd_lane_u64(r.me | r.mo, k);  // lanes with the entry in either row (0: no record k)
+            const int ok = __builtin_amdgcn_readlane(r.o, k);
+            // one 16-byte gather per lane.  When only one row of the pair holds the entry the other half is
+            // loaded and ignored; at the two ends of x it lies in the guard slack (guard_malloc).
+            if (__builtin_amdgcn_inverse_ballot_w64(mb)) {
+                xv[k] = *(const wd_f64x2u *)((const char *)(xg + ok) + g8);
+                if (VV) vv[k] = *(const wd_f64x2 *)(wvblk + ((size_t)(e0 + k) << 7) + 2 * lane);
+            }
+        }
+    };
+    // the products of up to 8 records folded into the row pair's sums, in record (= ascending column) order
+    auto fold8 = [&](unsigned long long rme, unsigned long long rmo, double rv, int nrec, const wd_f64x2 *xv, const wd_f64x2 *vv,
+                     double &ya, double &yb) {
+#pragma clang fp contract(off)  // a*x then +: two roundings like the reference, never an FMA
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (k >= nrec) break;  // wave-uniform
+            const unsigned long long me = wd_lane_u64(rme, k), mo = wd_lane_u64(rmo, k);
+            // EXEC = the even rows that hold the entry, then the odd rows; v_mul_f64 then v_add_f64 (two
+            // roundings).  All 64 lanes are active here (wave-uniform control flow only): EXEC goes back to -1.
+            double p;
+            if constexpr (VV) {
+                asm volatile(
+                    "s_mov_b64 exec, %[me]\n\tv_mul_f64 %[p], %[va], %[xa]\n\tv_add_f64 %[ya], %[ya], %[p]\n\t"
+                    "s_mov_b64 exec, %[mo]\n\tv_mul_f64 %[p], %[vb], %[xb]\n\tv_add_f64 %[yb], %[yb], %[p]\n\t"
+                    "s_mov_b64 exec, -1"
+                    : [ya] "+v"(ya), [yb] "+v"(yb), [p] "=&v"(p)
+                    : [me] "s"(me), [mo] "s"(mo), [va] "v"(vv[k].x), [vb] "v"(vv[k].y), [xa] "v"(xv[k].x), [xb] "v"(xv[k].y));
+            } else {
+                const double vk = wd_lane_f64(rv, k);
+                asm volatile(
+                    "s_mov_b64 exec, %[me]\n\tv_mul_f64 %[p], %[v], %[xa]\n\tv_add_f64 %[ya], %[ya], %[p]\n\t"
+                    "s_mov_b64 exec, %[mo]\n\tv_mul_f64 %[p], %[v], %[xb]\n\tv_add_f64 %[yb], %[yb], %[p]\n\t"
+                    "s_mov_b64 exec, -1"
+                    : [ya] "+v"(ya), [yb] "+v"(yb), [p] "=&v"(p)
+                    : [me] "s"(me), [mo] "s"(mo), [v] "s"(vk), [xa] "v"(xv[k].x), [xb] "v"(xv[k].y));
+            }
+        }
+    };
     // issue the epilogue-operand loads and the gathers of the slice described by (blk, e0, cnt, r)
     auto issue = [&](Stage &st, int blk, int e0, int cnt, const WdRec &r) {
         st.blk = blk;
@@ -1530,19 +1575,7 @@ __global__ void __launch_bounds__(kBlock, VV ? kWdBlocksPerCuVV : kWdBlocksPerCu
             if constexpr (kUsesW) { if (EPI != EPI_AXPY_DOT || a.w) st.wv.x = a.w[row]; }
             if constexpr (kUsesZ) st.zv.x = a.z[row];
         }
-        // byte offset of x[global row]; a record's diagonal offset moves the scalar base instead
-        const uint32_t g8 = (uint32_t)(grow0 + row) * 8u;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const unsigned long long mb = wd_lane_u64(r.me | r.mo, k);  // lanes with the entry in either row (0: no record k)
-            const int ok = __builtin_amdgcn_readlane(r.o, k);
-            // one 16-byte gather per lane.  When only one row of the pair holds the entry the other half is
-            // loaded and ignored; at the two ends of x it lies in the guard slack (guard_malloc).
-            if (__builtin_amdgcn_inverse_ballot_w64(mb)) {
-                st.xv[k] = *(const wd_f64x2u *)((const char *)(xg + ok) + g8);
-                if (VV) st.vv[k] = *(const wd_f64x2 *)(wvblk + ((size_t)(e0 + k) << 7) + 2 * lane);
-            }
-        }
+        gather8(r, e0, row, st.xv, st.vv);
     };
     // fold the slice's products row by row and run the epilogue
     auto fold = [&](const Stage &st) {
@@ -1550,48 +1583,20 @@ __global__ void __launch_bounds__(kBlock, VV ? kWdBlocksPerCuVV : kWdBlocksPerCu
         const int row = (st.blk * 4 + wave) * 128 + 2 * lane;
         const bool va = row < a.rows, vb = row + 1 < a.rows;
         double ya = 0.0, yb = 0.0;
-        {
-#pragma clang fp contract(off)  // a*x then +: two roundings like the reference, never an FMA
+        fold8(st.me, st.mo, st.v, st.cnt, st.xv, st.vv, ya, yb);
+        // slices with more than 8 records (27-point stencils, wide bands): further chunks of 8, fetched, gathered and
+        // folded one after the other (no pipelining across chunks)
+        for (int c0 = 8; c0 < st.cnt; c0 += 8) {
+            WdRec rr;
+            load_rec(st.e0 + c0, st.cnt - c0, rr);
+            wd_f64x2 xt[8], vt[VV ? 8 : 1];
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                if (k >= st.cnt) break;  // wave-uniform
-                const unsigned long long me = wd_lane_u64(st.me, k), mo = wd_lane_u64(st.mo, k);
-                // EXEC = the even rows that hold the entry, then the odd rows; v_mul_f64 then v_add_f64 (two
-                // roundings).  All 64 lanes are active here (wave-uniform control flow only): EXEC goes back to -1.
-                double p;
-                if constexpr (VV) {
-                    asm volatile(
-                        "s_mov_b64 exec, %[me]\n\tv_mul_f64 %[p], %[va], %[xa]\n\tv_add_f64 %[ya], %[ya], %[p]\n\t"
-                        "s_mov_b64 exec, %[mo]\n\tv_mul_f64 %[p], %[vb], %[xb]\n\tv_add_f64 %[yb], %[yb], %[p]\n\t"
-                        "s_mov_b64 exec, -1"
-                        : [ya] "+v"(ya), [yb] "+v"(yb), [p] "=&v"(p)
-                        : [me] "s"(me), [mo] "s"(mo), [va] "v"(st.vv[k].x), [vb] "v"(st.vv[k].y), [xa] "v"(st.xv[k].x), [xb] "v"(st.xv[k].y));
-                    continue;
-                }
-                const double vk = wd_lane_f64(st.v, k);
-                asm volatile(
-                    "s_mov_b64 exec, %[me]\n\tv_mul_f64 %[p], %[v], %[xa]\n\tv_add_f64 %[ya], %[ya], %[p]\n\t"
-                    "s_mov_b64 exec, %[mo]\n\tv_mul_f64 %[p], %[v], %[xb]\n\tv_add_f64 %[yb], %[yb], %[p]\n\t"
-                    "s_mov_b64 exec, -1"
-                    : [ya] "+v"(ya), [yb] "+v"(yb), [p] "=&v"(p)
-                    : [me] "s"(me), [mo] "s"(mo), [v] "s"(vk), [xa] "v"(st.xv[k].x), [xb] "v"(st.xv[k].y));
+                asm("" : "=v"(xt[k]));
+                if (VV) asm("" : "=v"(vt[k]));
             }
-            // slices with more than 8 records (27-point stencils, ...): the rest one by one through scalar loads
-            const uint32_t g8 = (uint32_t)(grow0 + row) * 8u;
-            for (int c = 8; c < st.cnt; ++c) {
-                const unsigned long long me = wme[st.e0 + c], mo = wmo[st.e0 + c];
-                const char *base = (const char *)(xg + woff[st.e0 + c]) + g8;
-                const double *vb = VV ? wvblk + ((size_t)(st.e0 + c) << 7) + 2 * lane : nullptr;
-                const double vk = VV ? 0.0 : wval[st.e0 + c];
-                if (__builtin_amdgcn_inverse_ballot_w64(me)) {
-                    const double p = (VV ? vb[0] : vk) * *(const double *)base;
-                    ya = ya + p;
-                }
-                if (__builtin_amdgcn_inverse_ballot_w64(mo)) {
-                    const double p = (VV ? vb[1] : vk) * *(const double *)(base + 8);
-                    yb = yb + p;
-                }
-            }
+            gather8(rr, st.e0 + c0, row, xt, vt);
+            fold8(rr.me, rr.mo, rr.v, st.cnt - c0, xt, vt, ya, yb);
         }
         if (va) {
             const wd_f64x2 wv = st.wv, zv = st.zv;
