@@ -1464,9 +1464,11 @@ __global__ void __launch_bounds__(kBlock, VV ? kWdBlocksPerCuVV : kWdBlocksPerCu
     // slice descriptor of workgroup step b (wave-uniform): first record, record count (0: nothing to do)
     // `sched` (optional) is the order in which the 512-row steps are visited (see csr_upload: steps a far diagonal
     // apart are made neighbours in time so that the three planes a 3-D stencil row touches meet in the L2)
+    // cnt < 0: no slice (past the end); cnt == 0: a slice whose rows hold no entry -- its rows still run the epilogue
+    // (r = b - A x, ||A x - b||, z -= alpha A p ... are defined on empty rows too)
     auto load_desc = [&](int b, int &blk, int &e0, int &cnt) {
         e0 = 0;
-        cnt = 0;
+        cnt = -1;
         blk = 0;
         if (b < wk.last) {
             blk = sched ? sched[b] : b;
@@ -1559,7 +1561,7 @@ __global__ void __launch_bounds__(kBlock, VV ? kWdBlocksPerCuVV : kWdBlocksPerCu
             asm("" : "=v"(st.xv[k]));  // which EXEC never lets the fold use
             if (VV) asm("" : "=v"(st.vv[k]));
         }
-        if (cnt <= 0) return;
+        if (cnt < 0) return;
         const int row = (blk * 4 + wave) * 128 + 2 * lane;  // this lane's rows: row, row + 1
         const bool va = row < a.rows, vb = row + 1 < a.rows;
         if (vb) {
@@ -1579,7 +1581,7 @@ __global__ void __launch_bounds__(kBlock, VV ? kWdBlocksPerCuVV : kWdBlocksPerCu
     };
     // fold the slice's products row by row and run the epilogue
     auto fold = [&](const Stage &st) {
-        if (st.cnt <= 0) return;
+        if (st.cnt < 0) return;
         const int row = (st.blk * 4 + wave) * 128 + 2 * lane;
         const bool va = row < a.rows, vb = row + 1 < a.rows;
         double ya = 0.0, yb = 0.0;

@@ -238,3 +238,37 @@ def test_variable_coefficient_wave_sliced_form(sla, monkeypatch, name):
         assert abs(ia - ib) <= 1, (name, meth, ia, ib)
         if ia == ib:
             assert np.abs(xa - xb).max() <= 1e-5 * (np.abs(xb).max() + 1e-300)
+
+
+@pytest.mark.parametrize("values", ["constant", "arbitrary"])
+def test_rows_without_entries_still_run_the_epilogues(sla, values):
+    """Whole 128-row slices without a stored entry (and single empty rows): r0 = b - A x0, the residual, CGS's and CGNE's
+    fused updates are defined there too (y_i = 0).  One step of every solver against the oracle."""
+    n = 900
+    rng = np.random.default_rng(8)
+    empty = np.zeros(n, bool)
+    empty[:300] = True            # two whole slices and a bit
+    empty[640:700] = True
+    empty[rng.integers(300, 640, 20)] = True
+    dims, csr = _stencil(n, [-40, -1, 0, 1, 3, 64],
+                         (lambda r, o: np.full(len(r), 9.0 if o == 0 else -1.0)) if values == "constant"
+                         else (lambda r, o: (9.0 if o == 0 else 0.0) + np.cos(r * 0.37 + o)),
+                         keep=lambda r, t: ~empty[r])
+    Ao = _oracle_csr(dims, csr)
+    A = sla.fromCSR(dims, *csr)
+    assert ("wdia-vv" if values == "arbitrary" else "wdia") in A.kernel_info().split()[0]
+    b, x0 = rng.standard_normal(n), rng.standard_normal(n)
+    r0 = b - orc.spmv(Ao, x0)
+    for init, fld_r, fld_x, ocls in ((sla.bicgsInit, "_rBicgstab", "_xBicgstab", orc.BicgstabState), (sla.cgsInit, "_r", "_x", orc.CgsState),
+                                     (sla.cgneInit, "_rCgne", "_xCgne", orc.CgneState)):
+        st = init(A, sla.fromVector(b), sla.fromVector(x0))
+        assert np.array_equal(getattr(st, fld_r).toDenseListSV(), r0)              # EPI_SUB on empty rows: r_i = b_i
+        os_ = ocls(Ao, b, x0)
+        st.step(1)
+        os_.step(1) if ocls is orc.CgneState else os_.step(r0, 1)
+        for fld, want in ((fld_x, os_.x), (fld_r, os_.r)):
+            got = getattr(st, fld).toDenseListSV()
+            assert np.allclose(got, want, rtol=1e-10, atol=1e-10 * (np.abs(want).max() + 1)), (values, fld)
+    x, info = sla.linSolve0(sla.BICGSTAB_, A, sla.fromVector(b), sla.fromVector(x0), return_info=True, max_iters=3)
+    res = orc.spmv(Ao, x.toDenseListSV()) - b                                       # EPI_RES counts the empty rows' b_i
+    assert abs(info["resnorm"] - np.linalg.norm(res)) <= 1e-9 * np.linalg.norm(res)
