@@ -22,7 +22,36 @@ KIND = sys.argv[2] if len(sys.argv) > 2 else "laplace"
 lib = _lib.lib()
 
 
+_FUZZ = {}
+
+
+def _fuzz_matrix(seed):
+    """Random diagonally dominant banded matrix: 3..12 diagonals within +-400 (the halo of a slab), constant or
+    arbitrary values, some rows ragged; odd sizes so that slabs start at odd rows."""
+    if seed in _FUZZ:
+        return _FUZZ[seed]
+    r = np.random.default_rng(seed)
+    nn = int(r.integers(700, 4000)) | 1
+    offs = np.unique(np.append(r.integers(-400, 401, int(r.integers(2, 12))), 0))
+    const = seed % 2 == 0
+    hole = r.random() * 0.3 if seed % 3 == 0 else 0.0
+    rows, cols, vals = [], [], []
+    for i in range(nn):
+        for o in offs:
+            j = i + int(o)
+            if 0 <= j < nn and (o == 0 or r.random() >= hole):
+                v = (2.0 * len(offs) if o == 0 else -1.0) if const else ((2.0 * len(offs) if o == 0 else 0.0) + r.uniform(-1, 1))
+                rows.append(i), cols.append(j), vals.append(v)
+    rc, A = orc.coo_to_csr(nn, nn, np.array(rows, np.int64), np.array(cols, np.int64), np.array(vals))
+    _FUZZ[seed] = ((nn, nn), (A.rowptr, A.colidx, A.val))
+    return _FUZZ[seed]
+
+
 def gen(b=0, e=None):
+    if KIND.startswith("fuzz"):
+        from sla_amd.partition import local_rows_of
+        dims, (rp, ci, va) = _fuzz_matrix(int(KIND[4:] or 0))
+        return dims, local_rows_of(rp, ci, va, b, dims[0] if e is None else e)
     if KIND == "laplace":
         return wl.laplace3d(14, 11, 13, b, e)            # window exchange (slab stencil), dictionary codes
     if KIND == "banded":
@@ -97,7 +126,7 @@ assert not errors, errors
 cat = lambda key: np.concatenate([results[r][key] for r in range(P)])  # noqa: E731
 y = cat("y")
 yo = orc.spmv(Ao, xg)
-if KIND == "random":     # > 8 stored entries per row on average: wavefront-segmented sums, last-bit grouping differences
+if KIND == "random" or (KIND.startswith("fuzz") and "wdia" not in results[0]["kernel"] and len(VA) > 8 * n):     # > 8 stored entries per row on average: wavefront-segmented sums, last-bit grouping differences
     assert np.abs(y - yo).max() <= 4e-15 * np.abs(VA).max() * np.abs(xg).max() * 16, np.abs(y - yo).max()
 else:
     assert np.array_equal(y, yo), "sharded (#>) must equal the whole-matrix left fold bit for bit"
@@ -121,7 +150,12 @@ for name, ometh in (("bicgstab", orc.BICGSTAB_), ("cgs", orc.CGS_), ("cgne", orc
 Hs = [results[r]["H"] for r in range(P)]
 assert all(np.array_equal(Hs[0], h) for h in Hs)
 rc, Qo, Ho, k = orc.arnoldi(Ao, bg, 6)
-assert results[0]["k"] == k and np.abs(Hs[0].reshape(6, 7).T[:k + 1, :k] - Ho).max() <= 1e-10 * np.abs(Ho).max()
+_hd = np.abs(Hs[0].reshape(6, 7).T[:k + 1, :k] - Ho).max() if results[0]["k"] == k else np.inf
+if os.environ.get("SLA_LOOPBACK_DEBUG"):
+    print("arnoldi k", results[0]["k"], k, "max|dH|", _hd, "max|H|", np.abs(Ho).max(), "H diag", np.diag(Ho)[:k])
+# (b = A 1 is almost an eigenvector of the random constant-band matrices: tiny sub-diagonal entries of H amplify the
+# last-bit differences of the inner products, hence the looser bound for the fuzz kinds)
+assert results[0]["k"] == k and _hd <= (1e-6 if KIND.startswith("fuzz") else 1e-10) * np.abs(Ho).max(), (results[0]["k"], k, _hd)
 xgm = np.concatenate([results[r]["gmres"][0] for r in range(P)])
 assert (results[0]["gmres"][2] & 1) == 1 and np.linalg.norm(orc.spmv(Ao, xgm) - bg) <= 1e-4 * np.linalg.norm(bg) + 1e-6
 print("LOOPBACK_OK", P, KIND, results[0]["kernel"].split()[0])
