@@ -2177,7 +2177,8 @@ __global__ void __launch_bounds__(kBlock) cgs_c2_kernel(int64_t n, SolverScalars
         xv.y += alpha * sv.y;
         st2(q, i2, qv);
         st2(uq, i2, sv);
-        st2(x, i2, xv);
+        if (NT) st2_nt(x, i2, xv);  // (as in K4: x is not read again before the next step)
+        else st2(x, i2, xv);
     SLA_VEC_LOOP_END
     if (SLA_HAS_TAIL(n)) {
         const int64_t i = n - 1;
