@@ -5,6 +5,8 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
+#include <thread>
 #include <limits>
 
 #include "sla_internal.hpp"
@@ -219,11 +221,50 @@ static int build_panels(sla_csr *A, int64_t m, int64_t n, int64_t row_begin, int
     return SLA_OK;
 }
 
+// The lowering analyses (dictionaries, codes, slice records) are row-parallel: run fn(t, lo, hi) over T contiguous row
+// ranges whose boundaries are multiples of `align` rows, on T host threads (SLA_HOST_THREADS, default <= 16).
+static int host_threads() {
+    static const int t = [] {
+        const char *s = getenv("SLA_HOST_THREADS");
+        int v = s ? atoi(s) : (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
+        return std::max(1, std::min(v, 64));
+    }();
+    return t;
+}
+template <class F>
+static int par_rows(int64_t rows, int64_t align, F fn, int64_t serial_below = 200000) {
+    int T = host_threads();
+    const int64_t units = (rows + align - 1) / align;
+    if (units < 64 || rows < serial_below) T = 1;
+    T = (int)std::min<int64_t>(T, std::max<int64_t>(units, 1));
+    auto range = [&](int t, int64_t &lo, int64_t &hi) {
+        lo = std::min<int64_t>(rows, units * t / T * align);
+        hi = std::min<int64_t>(rows, units * (t + 1) / T * align);
+    };
+    if (T == 1) { fn(0, (int64_t)0, rows); return 1; }
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; ++t) {
+        int64_t lo, hi;
+        range(t, lo, hi);
+        th.emplace_back([=, &fn] { fn(t, lo, hi); });
+    }
+    for (auto &x : th) x.join();
+    return T;
+}
+
 static int csr_upload(sla_ctx *c, int64_t m, int64_t n, int64_t row_begin, int64_t rows, const int64_t *rowptr,
                       const int64_t *col, const double *val, sla_csr **out, bool panel_view) {
     const int64_t nnz = rowptr[rows];
     if (n > (int64_t)std::numeric_limits<int32_t>::max() || rows >= (int64_t)std::numeric_limits<int32_t>::max())
         return fail(SLA_ERR_INVALID, "matrix dimension exceeds the 32-bit device index width");
+    static const bool dbg_lower = getenv("SLA_DEBUG_LOWER") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!dbg_lower || panel_view) return;
+        const auto t = std::chrono::steady_clock::now();
+        fprintf(stderr, "[sla] lowering: %-28s %7.1f ms\n", what, std::chrono::duration<double, std::milli>(t - t_last).count());
+        t_last = t;
+    };
     sla_csr *A = new sla_csr();
     A->ctx = c;
     A->m = m;
@@ -243,9 +284,19 @@ static int csr_upload(sla_ctx *c, int64_t m, int64_t n, int64_t row_begin, int64
         err = hipMalloc(dst, std::max<size_t>(bytes, 8));
         if (err == hipSuccess && bytes) err = hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
     };
+    // the values go up on a second host thread while this one narrows and uploads the indices (pageable copies are
+    // bound by the staging memcpy of the calling thread, not by the link)
+    hipError_t err_val = hipSuccess;
+    std::thread val_up([&] {
+        err_val = hipSetDevice(c->device);
+        if (err_val == hipSuccess) err_val = hipMalloc((void **)&A->d_val, std::max<size_t>(sizeof(double) * (size_t)nnz, 8));
+        if (err_val == hipSuccess && nnz) err_val = hipMemcpy(A->d_val, val, sizeof(double) * (size_t)nnz, hipMemcpyHostToDevice);
+    });
     {
         std::vector<int32_t> col32((size_t)nnz);
-        for (int64_t k = 0; k < nnz; ++k) col32[(size_t)k] = (int32_t)col[k];
+        par_rows(rows, 1, [&](int, int64_t lo, int64_t hi) {
+            for (int64_t k = rowptr[lo]; k < rowptr[hi]; ++k) col32[(size_t)k] = (int32_t)col[k];
+        });
         upload((void **)&A->d_col, col32.data(), sizeof(int32_t) * (size_t)nnz);
     }
     if (A->rp64) {
@@ -261,42 +312,68 @@ static int csr_upload(sla_ctx *c, int64_t m, int64_t n, int64_t row_begin, int64
         for (int64_t i = 0; i <= rows; ++i) rp32[(size_t)i] = (int32_t)rowptr[i];
         upload(&A->d_rowptr, rp32.data(), sizeof(int32_t) * (size_t)(rows + 1));
     }
-    upload((void **)&A->d_val, val, sizeof(double) * (size_t)nnz);
     upload((void **)&A->d_rb, rb.data(), sizeof(int32_t) * rb.size());
+    val_up.join();
+    if (err == hipSuccess) err = err_val;
+    lap("row blocks + CSR upload");
     if (!panel_view) {
         // LDS x window of each row block: kXWin columns starting kXWinHalo left of its first diagonal column
         std::vector<int32_t> rbw(rb.size(), 0);
         int64_t inside = 0, total = 0;
         const int64_t wmax = std::max<int64_t>(0, n - kXWin);
-        for (size_t b = 0; b + 1 < rb.size(); ++b) {
-            const int64_t w = std::min<int64_t>(wmax, std::max<int64_t>(0, row_begin + rb[b] - kXWinHalo));
-            rbw[b] = (int32_t)w;
-            const int64_t k0 = rowptr[rb[b]], k1 = rowptr[rb[b + 1]];
-            if (k1 - k0 > kNnzPerRowBlock) continue;  // long-row blocks gather from global memory
-            total += k1 - k0;
-            for (int64_t k = k0; k < k1; ++k) inside += (col[k] >= w && col[k] < w + kXWin) ? 1 : 0;
-        }
+        std::vector<int64_t> part_in((size_t)host_threads(), 0), part_tot((size_t)host_threads(), 0);
+        par_rows((int64_t)rb.size() - 1, 1, [&](int t, int64_t blo, int64_t bhi) {
+            int64_t in = 0, tot = 0;
+            for (int64_t b = blo; b < bhi; ++b) {
+                const int64_t w = std::min<int64_t>(wmax, std::max<int64_t>(0, row_begin + rb[(size_t)b] - kXWinHalo));
+                rbw[(size_t)b] = (int32_t)w;
+                const int64_t k0 = rowptr[rb[(size_t)b]], k1 = rowptr[rb[(size_t)b + 1]];
+                if (k1 - k0 > kNnzPerRowBlock) continue;  // long-row blocks gather from global memory
+                tot += k1 - k0;
+                for (int64_t k = k0; k < k1; ++k) in += (col[k] >= w && col[k] < w + kXWin) ? 1 : 0;
+            }
+            part_in[(size_t)t] = in;
+            part_tot[(size_t)t] = tot;
+        }, 4096);
+        for (size_t t = 0; t < part_in.size(); ++t) { inside += part_in[t]; total += part_tot[t]; }
         A->xwin_fraction = total ? (double)inside / (double)total : 0.0;
         A->use_xwin = A->xwin_fraction >= 0.5;
         upload((void **)&A->d_rbw, rbw.data(), sizeof(int32_t) * rbw.size());
     }
+    lap("x-window statistics");
     std::vector<int64_t> offs;          // sorted distinct diagonal offsets (<= 256) when the matrix has that structure
     std::vector<uint8_t> dcodes;        // per entry: index into offs
     if (!panel_view) {
         // dictionary of diagonal offsets: worthwhile (and representable in a byte) when col - row takes at
         // most 256 distinct values, i.e. for stencil / banded structure
         bool ok = nnz > 0;
-        for (int64_t i = 0; i < rows && ok; ++i) {
-            const int64_t gr = row_begin + i;
-            for (int64_t k = rowptr[i]; k < rowptr[i + 1]; ++k) {
-                const int64_t d = col[k] - gr;
-                bool found = false;
-                for (int64_t o : offs) if (o == d) { found = true; break; }   // <= 256 entries: a linear scan is fine
-                if (!found) {
+        {   // distinct offsets: per-thread sets, merged
+            std::vector<std::vector<int64_t>> loc((size_t)host_threads());
+            std::vector<char> bad((size_t)host_threads(), 0);
+            par_rows(rows, 1, [&](int t, int64_t lo, int64_t hi) {
+                std::vector<int64_t> &mine = loc[(size_t)t];
+                for (int64_t i = lo; i < hi && !bad[(size_t)t]; ++i) {
+                    const int64_t gr = row_begin + i;
+                    for (int64_t k = rowptr[i]; k < rowptr[i + 1]; ++k) {
+                        const int64_t d = col[k] - gr;
+                        bool found = false;
+                        for (int64_t o : mine) if (o == d) { found = true; break; }   // <= 256 entries: a linear scan is fine
+                        if (!found) {
+                            if (mine.size() == 256) { bad[(size_t)t] = 1; break; }
+                            mine.push_back(d);
+                        }
+                    }
+                }
+            });
+            for (size_t t = 0; t < loc.size() && ok; ++t) {
+                if (bad[t]) ok = false;
+                for (int64_t d : loc[t]) {
+                    if (std::find(offs.begin(), offs.end(), d) != offs.end()) continue;
                     if (offs.size() == 256) { ok = false; break; }
                     offs.push_back(d);
                 }
             }
+            if (!ok) offs.clear();
         }
         if (ok) {
             std::sort(offs.begin(), offs.end());
@@ -304,11 +381,13 @@ static int csr_upload(sla_ctx *c, int64_t m, int64_t n, int64_t row_begin, int64
             for (size_t t = 0; t < offs.size(); ++t) dict[t] = (int32_t)offs[t];
             std::vector<uint8_t> &codes = dcodes;
             codes.resize((size_t)nnz);
-            for (int64_t i = 0; i < rows; ++i) {
-                const int64_t gr = row_begin + i;
-                for (int64_t k = rowptr[i]; k < rowptr[i + 1]; ++k)
-                    codes[(size_t)k] = (uint8_t)(std::lower_bound(offs.begin(), offs.end(), col[k] - gr) - offs.begin());
-            }
+            par_rows(rows, 1, [&](int, int64_t lo, int64_t hi) {
+                for (int64_t i = lo; i < hi; ++i) {
+                    const int64_t gr = row_begin + i;
+                    for (int64_t k = rowptr[i]; k < rowptr[i + 1]; ++k)
+                        codes[(size_t)k] = (uint8_t)(std::lower_bound(offs.begin(), offs.end(), col[k] - gr) - offs.begin());
+                }
+            });
             upload((void **)&A->d_code, codes.data(), codes.size());
             upload((void **)&A->d_dict, dict.data(), sizeof(int32_t) * dict.size());
             A->use_diag = true;
@@ -320,27 +399,44 @@ static int csr_upload(sla_ctx *c, int64_t m, int64_t n, int64_t row_begin, int64
         struct Pair { int64_t off; uint64_t bits; };
         auto bits_of = [](double v) { uint64_t u; memcpy(&u, &v, 8); return u; };
         constexpr int kSlots = 1024;                       // open addressing, <= 256 live keys
-        std::vector<int> slot(kSlots, -1);
-        std::vector<Pair> pairs;
-        auto find = [&](int64_t off, uint64_t bits, bool insert) -> int {
-            uint64_t h = ((uint64_t)off * 0x9E3779B97F4A7C15ull) ^ (bits * 0xC2B2AE3D27D4EB4Full);
-            h ^= h >> 29;
-            for (int i = (int)(h & (kSlots - 1));; i = (i + 1) & (kSlots - 1)) {
-                const int id = slot[(size_t)i];
-                if (id < 0) {
-                    if (!insert || pairs.size() == 256) return -1;
-                    slot[(size_t)i] = (int)pairs.size();
-                    pairs.push_back({off, bits});
-                    return (int)pairs.size() - 1;
+        struct PairTable {
+            std::vector<int> slot = std::vector<int>(kSlots, -1);
+            std::vector<Pair> pairs;
+            int find(int64_t off, uint64_t bits, bool insert) {
+                uint64_t h = ((uint64_t)off * 0x9E3779B97F4A7C15ull) ^ (bits * 0xC2B2AE3D27D4EB4Full);
+                h ^= h >> 29;
+                for (int i = (int)(h & (kSlots - 1));; i = (i + 1) & (kSlots - 1)) {
+                    const int id = slot[(size_t)i];
+                    if (id < 0) {
+                        if (!insert || pairs.size() == 256) return -1;
+                        slot[(size_t)i] = (int)pairs.size();
+                        pairs.push_back({off, bits});
+                        return (int)pairs.size() - 1;
+                    }
+                    if (pairs[(size_t)id].off == off && pairs[(size_t)id].bits == bits) return id;
                 }
-                if (pairs[(size_t)id].off == off && pairs[(size_t)id].bits == bits) return id;
             }
         };
+        PairTable tab;                                     // the matrix's table: per-thread tables, merged
+        std::vector<Pair> &pairs = tab.pairs;
+        auto find = [&](int64_t off, uint64_t bits, bool insert) -> int { return tab.find(off, bits, insert); };
         bool ok = true;
-        for (int64_t i = 0; i < rows && ok; ++i) {
-            const int64_t gr = row_begin + i;
-            for (int64_t k = rowptr[i]; k < rowptr[i + 1]; ++k)
-                if (find(col[k] - gr, bits_of(val[k]), true) < 0) { ok = false; break; }
+        {
+            std::vector<PairTable> loc((size_t)host_threads());
+            std::vector<char> bad((size_t)host_threads(), 0);
+            par_rows(rows, 1, [&](int t, int64_t lo, int64_t hi) {
+                PairTable &mine = loc[(size_t)t];
+                for (int64_t i = lo; i < hi && !bad[(size_t)t]; ++i) {
+                    const int64_t gr = row_begin + i;
+                    for (int64_t k = rowptr[i]; k < rowptr[i + 1]; ++k)
+                        if (mine.find(col[k] - gr, bits_of(val[k]), true) < 0) { bad[(size_t)t] = 1; break; }
+                }
+            });
+            for (size_t t = 0; t < loc.size() && ok; ++t) {
+                if (bad[t]) ok = false;
+                for (const Pair &pr : loc[t].pairs)
+                    if (ok && find(pr.off, pr.bits, true) < 0) ok = false;
+            }
         }
         if (ok) {
             // canonical table order: by offset, then by value bits (independent of the input order)
@@ -358,11 +454,13 @@ static int csr_upload(sla_ctx *c, int64_t m, int64_t n, int64_t row_begin, int64
                 memcpy(&dval[t], &pairs[(size_t)order[t]].bits, 8);
             }
             std::vector<uint8_t> codes(((size_t)nnz + 3) / 4 * 4 + 16, 0);
-            for (int64_t i = 0; i < rows; ++i) {
-                const int64_t gr = row_begin + i;
-                for (int64_t k = rowptr[i]; k < rowptr[i + 1]; ++k)
-                    codes[(size_t)k] = (uint8_t)rank[(size_t)find(col[k] - gr, bits_of(val[k]), false)];
-            }
+            par_rows(rows, 1, [&](int, int64_t lo, int64_t hi) {   // (lookups only: the table is read-only now)
+                for (int64_t i = lo; i < hi; ++i) {
+                    const int64_t gr = row_begin + i;
+                    for (int64_t k = rowptr[i]; k < rowptr[i + 1]; ++k)
+                        codes[(size_t)k] = (uint8_t)rank[(size_t)find(col[k] - gr, bits_of(val[k]), false)];
+                }
+            });
             upload((void **)&A->d_vcode, codes.data(), codes.size());
             upload((void **)&A->d_vdoff, doff.data(), sizeof(int32_t) * doff.size());
             upload((void **)&A->d_vdval, dval.data(), sizeof(double) * dval.size());
@@ -377,30 +475,50 @@ static int csr_upload(sla_ctx *c, int64_t m, int64_t n, int64_t row_begin, int64
             std::vector<uint64_t> wme, wmo;
             std::vector<double> wval;
             std::vector<int32_t> woff;
-            uint64_t lane_mask[2][256];
             bool wok = n < ((int64_t)1 << 28);
-            for (int64_t sl = 0; sl < nsl && wok; ++sl) {
-                uint64_t present[4] = {0, 0, 0, 0};
-                const int64_t rlo = sl * 128, rhi = std::min<int64_t>(rows, rlo + 128);
-                for (int64_t i = rlo; i < rhi; ++i)
-                    for (int64_t k = rowptr[i]; k < rowptr[i + 1]; ++k) {
-                        const int cd = codes[(size_t)k];
-                        if (!((present[cd >> 6] >> (cd & 63)) & 1)) {
-                            present[cd >> 6] |= 1ull << (cd & 63);
-                            lane_mask[0][cd] = lane_mask[1][cd] = 0;
-                        }
-                        lane_mask[(i - rlo) & 1][cd] |= 1ull << ((i - rlo) >> 1);
+            if (wok) {   // slices are independent: each thread builds the records of a contiguous range of slices
+                struct Part { std::vector<uint64_t> me, mo; std::vector<double> v; std::vector<int32_t> o, cnt; };
+                std::vector<Part> part((size_t)host_threads());
+                const int T = par_rows(rows, 128, [&](int t, int64_t lo, int64_t hi) {
+                    Part &P = part[(size_t)t];
+                    uint64_t lane_mask[2][256];
+                    for (int64_t rlo = lo; rlo < hi; rlo += 128) {
+                        uint64_t present[4] = {0, 0, 0, 0};
+                        const int64_t rhi = std::min<int64_t>(hi, rlo + 128);
+                        for (int64_t i = rlo; i < rhi; ++i)
+                            for (int64_t k = rowptr[i]; k < rowptr[i + 1]; ++k) {
+                                const int cd = codes[(size_t)k];
+                                if (!((present[cd >> 6] >> (cd & 63)) & 1)) {
+                                    present[cd >> 6] |= 1ull << (cd & 63);
+                                    lane_mask[0][cd] = lane_mask[1][cd] = 0;
+                                }
+                                lane_mask[(i - rlo) & 1][cd] |= 1ull << ((i - rlo) >> 1);
+                            }
+                        const size_t first = P.me.size();
+                        for (int cd = 0; cd < 256; ++cd)   // ascending code = ascending (offset, value bits)
+                            if ((present[cd >> 6] >> (cd & 63)) & 1) {
+                                P.me.push_back(lane_mask[0][cd]);
+                                P.mo.push_back(lane_mask[1][cd]);
+                                P.v.push_back(dval[(size_t)cd]);
+                                P.o.push_back(doff[(size_t)cd]);
+                            }
+                        P.cnt.push_back((int32_t)(P.me.size() - first));
                     }
-                for (int cd = 0; cd < 256; ++cd)   // ascending code = ascending (offset, value bits)
-                    if ((present[cd >> 6] >> (cd & 63)) & 1) {
-                        wme.push_back(lane_mask[0][cd]);
-                        wmo.push_back(lane_mask[1][cd]);
-                        wval.push_back(dval[(size_t)cd]);
-                        woff.push_back(doff[(size_t)cd]);
+                });
+                int64_t sl = 0;
+                for (int t = 0; t < T && wok; ++t) {
+                    const Part &P = part[(size_t)t];
+                    for (int32_t cnt : P.cnt) {
+                        if (cnt > kWdMaxSliceRecords) wok = false;   // the records past the 8 pipelined ones go chunk by chunk
+                        wptr[(size_t)sl + 1] = wptr[(size_t)sl] + cnt;
+                        ++sl;
                     }
-                wptr[(size_t)sl + 1] = (int32_t)wme.size();
+                    wme.insert(wme.end(), P.me.begin(), P.me.end());
+                    wmo.insert(wmo.end(), P.mo.begin(), P.mo.end());
+                    wval.insert(wval.end(), P.v.begin(), P.v.end());
+                    woff.insert(woff.end(), P.o.begin(), P.o.end());
+                }
                 if ((int64_t)wme.size() * 32 > nnz + 2048) wok = false;   // < 1/4 full: the byte-code kernel is the better form
-                if (wptr[(size_t)sl + 1] - wptr[(size_t)sl] > kWdMaxSliceRecords) wok = false;   // the records past the 8 pipelined ones go one by one
             }
             if (wok) {
                 A->nwent = (int64_t)wme.size();
@@ -438,6 +556,7 @@ static int csr_upload(sla_ctx *c, int64_t m, int64_t n, int64_t row_begin, int64
             }
         }
     }
+    lap("pair dictionary + wave slices");
     if (!panel_view && A->use_diag && !A->use_wdia && !A->rp64 && c->wdia_vv && n < ((int64_t)1 << 28) && nnz > 0) {
         // Wave-sliced form for VARIABLE coefficients (banded / stencil structure, arbitrary values): per 128-row slice the
         // sorted union of its diagonal offsets with the two row masks each, and per record a block of 128 values laid out
@@ -494,6 +613,7 @@ static int csr_upload(sla_ctx *c, int64_t m, int64_t n, int64_t row_begin, int64
             A->nblk_wd = (int32_t)((nsl + 3) / 4);
         }
     }
+    lap("variable-coefficient slices");
     if (err != hipSuccess) {
         sla_csr_destroy(A);
         return fail(SLA_ERR_ALLOC, std::string("CSR upload: ") + hipGetErrorString(err));
