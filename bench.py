@@ -241,7 +241,7 @@ def main():
         o = _lib.SolveOpts(args.steps, 0.0, 0.0, max(args.steps, 1), 1)      # tol 0: run exactly K iterations
         # (the wave-sliced form streams ~2 B of matrix per row: nothing to fuse, the library keeps the sweeps apart)
         dual = (not use_dist and os.environ.get("SLA_DUAL_SPMV", "1") != "0" and os.environ.get("SLA_SPMV_ALGO", "stream") == "stream"
-                and "algo=wdia" not in A.kernel_info())
+                and "algo=wdia" not in A.kernel_info() and "ldspanels" not in A.kernel_info())
         ctx.prof_start(_lib.KERNEL_SPMV_DUAL if dual else _lib.KERNEL_SPMV_DOT, args.steps)
         t0 = time.perf_counter()
         _lib.check(lib.sla_linsolve0(4, A.h, bvec.h, x0.h, C.byref(o), out.h, C.byref(info)))

@@ -614,6 +614,73 @@ static int csr_upload(sla_ctx *c, int64_t m, int64_t n, int64_t row_begin, int64
         }
     }
     lap("variable-coefficient slices");
+    if (!panel_view && !A->use_wdia && !A->use_vdict && rows > 0 && err == hipSuccess) {
+        // LDS-panel form (spmv_lpanel_kernel): worthwhile when a row has enough entries per kLpW-column panel to
+        // keep a wavefront's lanes busy, affordable when the (panel, row) pointer table stays a fraction of the matrix
+        const int64_t P = (n + kLpW - 1) / kLpW;
+        const int64_t W = ((n + P - 1) / P + 63) / 64 * 64;   // equal panels (a narrow last panel would be all short segments)
+        const size_t rpsz = A->rp64 ? sizeof(int64_t) : sizeof(int32_t);
+        if (P <= 4096 && nnz >= (int64_t)kLpMinSeg * rows * P && (P + 1) * rows * (int64_t)rpsz <= nnz * 12 / 4) {
+            std::vector<int64_t> pp((size_t)((P + 1) * rows));
+            par_rows(rows, 1, [&](int, int64_t lo, int64_t hi) {
+                for (int64_t i = lo; i < hi; ++i) {
+                    const int64_t *cb = col + rowptr[i], *ce = col + rowptr[i + 1];
+                    const int64_t *cur = cb;
+                    for (int64_t p = 0; p <= P; ++p) {
+                        cur = std::lower_bound(cur, ce, p * W);
+                        pp[(size_t)(p * rows + i)] = rowptr[i] + (cur - cb);
+                    }
+                }
+            }, 4096);
+            if (A->rp64) {
+                upload(&A->d_lpp, pp.data(), sizeof(int64_t) * pp.size());
+            } else {
+                std::vector<int32_t> pp32(pp.begin(), pp.end());
+                upload(&A->d_lpp, pp32.data(), sizeof(int32_t) * pp32.size());
+            }
+            if (err == hipSuccess) err = hipMalloc((void **)&A->d_lpy, sizeof(double) * (size_t)(P * rows));
+            // row chunks: ~32 tasks per workgroup of the persistent grid (measured: 8 -> 0.936 ms, 32 -> 0.900 ms, 64 ->
+            // 0.902 ms on the 200k-row 1 % matrix), at least 64 rows (4 per wavefront) each
+            const int tasks_per_cu = getenv("SLA_LP_TASKS") ? std::max(1, atoi(getenv("SLA_LP_TASKS"))) : 32;
+            const int64_t want = std::max<int64_t>(1, (tasks_per_cu * (int64_t)c->n_cu + P - 1) / P);
+            const int64_t chunk = std::max<int64_t>(64, (rows + want - 1) / want);
+            const int64_t C = (rows + chunk - 1) / chunk;
+            A->lp_P = (int32_t)P;
+            A->lp_W = (int32_t)W;
+            A->lp_chunk = (int32_t)chunk;
+            A->lp_C = (int32_t)C;
+            // tasks (panel-major) are dealt out in contiguous runs of equal ENTRY counts, one run per workgroup
+            const int64_t ntasks = P * C;
+            const int G = (int)std::min<int64_t>(ntasks, c->n_cu);
+            // (a segment costs a memory round trip however short it is -- with entries alone balanced, workgroups holding
+            // 34-entry segments took 2.4x as long as those with 154-entry ones: weigh a row like row_cost entries)
+            const int64_t row_cost = getenv("SLA_LP_ROWCOST") ? atoll(getenv("SLA_LP_ROWCOST")) : 256;
+            std::vector<int64_t> upto((size_t)ntasks + 1, 0);   // weight before task t
+            for (int64_t p = 0; p < P; ++p)
+                for (int64_t cc = 0; cc < C; ++cc) {
+                    const int64_t lo = cc * chunk, hi = std::min<int64_t>(rows, lo + chunk);
+                    int64_t w = 0;
+                    for (int64_t i = lo; i < hi; ++i) w += pp[(size_t)((p + 1) * rows + i)] - pp[(size_t)(p * rows + i)];
+                    upto[(size_t)(p * C + cc) + 1] = upto[(size_t)(p * C + cc)] + w + row_cost * (hi - lo);
+                }
+            std::vector<int32_t> tb((size_t)G + 1, 0);
+            for (int g = 1; g < G; ++g) {
+                const int64_t target = upto[(size_t)ntasks] / G * g;
+                tb[(size_t)g] = (int32_t)(std::lower_bound(upto.begin(), upto.end(), target) - upto.begin());
+                tb[(size_t)g] = std::max(tb[(size_t)g], tb[(size_t)g - 1]);
+            }
+            tb[(size_t)G] = (int32_t)ntasks;
+            if (dbg_lower) {
+                fprintf(stderr, "[sla] lpanel: P=%lld C=%lld chunk=%lld G=%d total=%lld tb:", (long long)P, (long long)C, (long long)chunk, G, (long long)upto[(size_t)ntasks]);
+                for (int g = 0; g <= G; g += std::max(1, G / 16)) fprintf(stderr, " %d", tb[(size_t)g]);
+                fprintf(stderr, "\n");
+            }
+            A->lp_G = G;
+            upload((void **)&A->d_lpt, tb.data(), sizeof(int32_t) * tb.size());
+            A->use_lpanel = err == hipSuccess;
+        }
+    }
+    lap("LDS panel table");
     if (err != hipSuccess) {
         sla_csr_destroy(A);
         return fail(SLA_ERR_ALLOC, std::string("CSR upload: ") + hipGetErrorString(err));
@@ -629,7 +696,7 @@ static int csr_upload(sla_ctx *c, int64_t m, int64_t n, int64_t row_begin, int64
     }
     A->is_diagonal = diag_not == 0;
     rc = build_xplan(A, rows, rowptr, col);
-    if (rc == SLA_OK) rc = build_panels(A, m, n, row_begin, rows, rowptr, col, val);
+    if (rc == SLA_OK && !(A->use_lpanel && c->lpanel)) rc = build_panels(A, m, n, row_begin, rows, rowptr, col, val);
     if (rc != SLA_OK) {
         sla_csr_destroy(A);
         return rc;
@@ -724,6 +791,7 @@ static int ctx_create_common(int device_id, int rank, int nranks, const void *ui
     if (const char *s = getenv("SLA_DIAG")) c->diag = atoi(s);
     if (const char *s = getenv("SLA_VDICT")) c->vdict = atoi(s);
     if (const char *s = getenv("SLA_WDIA")) c->wdia = atoi(s);
+    if (const char *s = getenv("SLA_LPANEL")) c->lpanel = atoi(s);
     if (const char *s = getenv("SLA_WD_TILE")) c->wd_tile = atoi(s);
     if (const char *s = getenv("SLA_WDIA_VV")) c->wdia_vv = atoi(s);
     if (const char *s = getenv("SLA_VEC_NT")) c->vec_nt = atoi(s);
@@ -737,6 +805,7 @@ static int ctx_create_common(int device_id, int rank, int nranks, const void *ui
     {
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess && cus > 0) {
+            c->n_cu = cus;
             c->wd_grid_max = std::min<int>(kMaxParts, std::max(8, (kWdBlocksPerCu * cus) & ~7));
             c->wd_grid_max_vv = std::min<int>(kMaxParts, std::max(8, (kWdBlocksPerCuVV * cus) & ~7));
         }
@@ -1133,6 +1202,9 @@ int sla_csr_destroy(sla_csr_t A) {
     tri_plan_free(A->tri[1]);
     if (A->d_wptr) (void)hipFree(A->d_wptr);
     if (A->d_wsched) (void)hipFree(A->d_wsched);
+    if (A->d_lpp) (void)hipFree(A->d_lpp);
+    if (A->d_lpy) (void)hipFree(A->d_lpy);
+    if (A->d_lpt) (void)hipFree(A->d_lpt);
     if (A->d_wvblk) (void)hipFree(A->d_wvblk);
     if (A->d_wme) (void)hipFree(A->d_wme);
     if (A->d_wmo) (void)hipFree(A->d_wmo);
@@ -1185,7 +1257,7 @@ int sla_csr_is_diagonal(sla_csr_t A, int *out) {
 int sla_csr_kernel_info(sla_csr_t A, char *buf, int buflen) {
     if (!A || !buf || buflen <= 0) return fail(SLA_ERR_INVALID, "null argument");
     snprintf(buf, (size_t)buflen, "algo=%s grid=%d block=%d row_blocks=%d nnz_per_row_block=%d max_row_nnz=%lld rowptr=%s xcd_remap=%d",
-             A->ctx->spmv_algo == 1 ? "scalar" : (A->use_wdia && wd_on(A)) ? (A->wd_vv ? "wdia-vv" : "wdia") : (A->use_vdict && A->ctx->vdict) ? (A->use_xwin && A->ctx->xwin ? "vdict+xwin" : "vdict") : (!A->panels.empty() && A->ctx->panels) ? "stream+colpanels" : (A->use_diag && A->ctx->diag ? (A->use_xwin && A->ctx->xwin ? "stream+diagdict+xwin" : "stream+diagdict") : (A->use_xwin && A->ctx->xwin ? "stream+xwin" : "stream")), spmv_grid(A), kBlock, A->nrb, kNnzPerRowBlock,
+             A->ctx->spmv_algo == 1 ? "scalar" : (A->use_wdia && wd_on(A)) ? (A->wd_vv ? "wdia-vv" : "wdia") : (A->use_vdict && A->ctx->vdict) ? (A->use_xwin && A->ctx->xwin ? "vdict+xwin" : "vdict") : (A->use_lpanel && A->ctx->lpanel) ? "stream+ldspanels" : (!A->panels.empty() && A->ctx->panels) ? "stream+colpanels" : (A->use_diag && A->ctx->diag ? (A->use_xwin && A->ctx->xwin ? "stream+diagdict+xwin" : "stream+diagdict") : (A->use_xwin && A->ctx->xwin ? "stream+xwin" : "stream")), spmv_grid(A), kBlock, A->nrb, kNnzPerRowBlock,
              (long long)A->max_row_nnz, A->rp64 ? "i64" : "i32", A->ctx->xcd_remap);
     return SLA_OK;
 }

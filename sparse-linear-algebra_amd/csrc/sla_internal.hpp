@@ -33,6 +33,13 @@ constexpr int kWdMaxSliceRecords = 40;          // wave-sliced forms: more diago
                                                 // (27-point stencil, 128^3: wdia 25.5 us, vdict 42 us, diagdict 167 us)
 constexpr int kWdGatherStages = SLA_WD_STAGES;  // 2: the gathers of the next slice are issued before the current one is folded
 constexpr int kVdRows = 256;         // rows per block of spmv_vdict_kernel (one lane per row)
+constexpr int kLpW = 16384;          // columns of x one workgroup of spmv_lpanel_kernel keeps in LDS (128 KiB)
+constexpr int kLpBlock = 1024;       // its workgroup: 16 wavefronts, one per CU (LDS-bound occupancy)
+#ifndef SLA_LP_ROWS
+#define SLA_LP_ROWS 2
+#endif
+constexpr int kLpRowsInFlight = SLA_LP_ROWS;   // (row, panel) segments a wavefront of spmv_lpanel_kernel keeps in flight (2: 0.900 ms, 3: 0.910, 4: 0.926)
+constexpr int kLpMinSeg = 24;        // mean entries per (row, panel) segment below which the form is not worth it
 constexpr int kVdMaxRowNnz = 31;     // longest row the value-indexed kernel takes (256 rows x 31 B of codes fit its LDS stage)
 constexpr int kWaveRowMax = 16384;   // rows of 1025..16384 entries: one wavefront each, 4 per row block; longer: whole workgroup
 constexpr int kMaxParts = 2048;      // partial-sum slots per reduction (256 CUs x 8)
@@ -138,6 +145,8 @@ struct sla_ctx {
     int wd_tile = -1;                // plane tiling of the wave-sliced walk: -1 automatic, 0 off, > 0 steps per tile (SLA_WD_TILE)
     int wdia = 1;                    // allow the wave-sliced SpMV kernel (SLA_WDIA=0 disables)
     int vdict = 1;                   // allow the value-indexed SpMV kernel (SLA_VDICT=0 disables)
+    int n_cu = 256;                  // compute units of the device (persistent grids)
+    int lpanel = 1;                  // allow the LDS-panel SpMV kernel for matrices with dense rows (SLA_LPANEL=0 disables)
     int xwin = 1;                    // allow the LDS x-window SpMV kernel (SLA_XWIN=0 disables)
     int dual_spmv = 1;               // linSolve0: fuse the true-residual SpMV into the next K1 (SLA_DUAL_SPMV=0 disables)
     int x_exchange = 0;              // 0 auto (window exchange when it pays), 1 always all-gather, 2 always window (SLA_X_EXCHANGE=allgather|window)
@@ -209,6 +218,13 @@ struct sla_csr {
     unsigned long long *d_wmo = nullptr;    // ... lanes whose ODD row (2 lane + 1) holds it ...
     double *d_wval = nullptr;               // ... its value ...
     int32_t *d_woff = nullptr;              // ... and its diagonal offset (col - row); all padded by 8 records
+    // LDS-panel form (rows with many entries per 16384-column panel): per (panel, row) entry ranges into col / val
+    void *d_lpp = nullptr;           // (P + 1) x rows, RP-typed, panel-major: pp[p][i] = first entry of row i with col >= p * lp_W
+    int32_t *d_lpt = nullptr;        // lp_G + 1 task boundaries: workgroup g runs tasks [lpt[g], lpt[g+1]) (equal entries each)
+    int32_t lp_G = 0;
+    double *d_lpy = nullptr;         // P x rows partial sums, summed in ascending panel order by lpanel_finish_kernel
+    bool use_lpanel = false;
+    int32_t lp_P = 0, lp_W = 0, lp_C = 0, lp_chunk = 0;   // panels, columns per panel, row chunks per panel, rows per chunk
     bool use_wdia = false;
     int32_t nslices = 0;
     double *d_wvblk = nullptr;       // variable-coefficient variant: 128 values per record, laid out like the slice's rows

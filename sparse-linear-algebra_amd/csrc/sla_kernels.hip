@@ -1719,6 +1719,117 @@ __global__ void __launch_bounds__(kBlock, VV ? kWdBlocksPerCuVV : kWdBlocksPerCu
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// LDS-panel SpMV for matrices with dense rows ("1 % density": hundreds of entries per row, random columns)
+// ---------------------------------------------------------------------------------------------
+// Random 8-byte gathers from the L2 move a 128-byte line into the L1 each (64 B/clk/CU): ~0.3 gathers per clock per
+// CU, which bounds the stream kernel at ~1/4 of the HBM rate on such matrices.  The LDS serves the same gathers at
+// 128 B/clk of useful data, so x is cut into equal panels of W <= kLpW columns: a workgroup keeps one panel of x in LDS and
+// streams the (row, panel) segments of its row chunks -- one wavefront per segment, lanes striding over the entries
+// in ascending order, two segments in flight per wavefront -- into per-panel partial sums.  Tasks (panel, row chunk)
+// are dealt out panel-major in contiguous runs of equal entry counts (task_begin), so a workgroup reloads x about once.  lpanel_finish_kernel then
+// adds the partials of a row in ascending panel order and runs the fused epilogue.
+template <typename RP>
+__global__ void __launch_bounds__(kLpBlock) spmv_lpanel_kernel(const RP *__restrict__ pp, const int32_t *__restrict__ col,
+                                                               const double *__restrict__ val, const double *__restrict__ xg,
+                                                               double *__restrict__ ypart, const int32_t *__restrict__ task_begin,
+                                                               int rows, int n, int W, int chunk_rows, int C, const SolverScalars *sc) {
+    extern __shared__ double lp_xs[];
+    if (sc && sc->done) return;
+    const int tid = threadIdx.x, wv = tid >> 6, ln = tid & 63;
+    const int t0 = task_begin[blockIdx.x], t1 = task_begin[blockIdx.x + 1];
+    int curp = -1;
+    for (int t = t0; t < t1; ++t) {
+        const int p = t / C, c = t - p * C;
+        const int w0 = p * W;
+        if (p != curp) {
+            __syncthreads();
+            const int wn = min(W, n - w0);
+            for (int j = tid; j < wn; j += kLpBlock) lp_xs[j] = xg[w0 + j];
+            __syncthreads();
+            curp = p;
+        }
+        const int lo = c * chunk_rows, hi = min(rows, lo + chunk_rows);
+        const RP *ps = pp + (int64_t)p * rows, *pe = ps + rows;
+        double *yp = ypart + (int64_t)p * rows;
+        constexpr int kWaves = kLpBlock / 64;
+        constexpr int R = kLpRowsInFlight;
+        for (int i0 = lo + wv; i0 < hi; i0 += R * kWaves) {
+            // R segments per wavefront at a time: a segment is short (~ nnz_row / panels entries), one alone leaves the
+            // wavefront waiting out a memory round trip per row
+            const int ibase = __builtin_amdgcn_readfirstlane(i0);
+            RP k[R], e[R];
+            double acc[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int i = ibase + r * kWaves;
+                const bool has = i < hi;
+                k[r] = (has ? ps[i] : 0) + ln;
+                e[r] = has ? pe[i] : 0;
+                acc[r] = 0.0;
+            }
+            bool more = true;
+            while (more) {
+                int32_t cj[R][4];
+                double vj[R][4];
+                // all loads of the round in flight before the first use (<= 256 entries per segment and round)
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (k[r] + 64 * j < e[r]) {
+                            cj[r][j] = __builtin_nontemporal_load(col + k[r] + 64 * j);
+                            vj[r][j] = __builtin_nontemporal_load(val + k[r] + 64 * j);
+                        }
+                    }
+                }
+                more = false;
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (k[r] + 64 * j < e[r]) {
+                            const double prod = vj[r][j] * lp_xs[cj[r][j] - w0];
+                            acc[r] = acc[r] + prod;
+                        }
+                    }
+                    k[r] += 256;
+                    more |= __builtin_amdgcn_readfirstlane(k[r] - ln) < e[r];   // (uniform: the segment's next base)
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int i = ibase + r * kWaves;
+                const double sum = wave_sum(acc[r]);
+                if (ln == 0 && i < hi) yp[i] = sum;
+            }
+        }
+    }
+}
+
+// y_i = sum over panels (ascending) of the partials + the fused epilogue; one lane per row.
+template <int EPI, typename RP>
+__global__ void __launch_bounds__(kBlock) lpanel_finish_kernel(SpmvArgs<RP> a, const double *__restrict__ ypart, int P) {
+    __shared__ double s_red[4];
+    double coef;
+    if (!spmv_prologue<EPI, RP>(a, s_red, coef)) return;
+    double acc1 = 0.0, acc2 = 0.0;
+    for (int64_t row = (int64_t)blockIdx.x * kBlock + threadIdx.x; row < a.rows; row += (int64_t)gridDim.x * kBlock) {
+        double acc = ypart[row];
+        for (int p = 1; p < P; ++p) acc = acc + ypart[(int64_t)p * a.rows + row];
+        spmv_epilogue<EPI, RP>(a, (int)row, acc, coef, acc1, acc2);
+    }
+    if constexpr (EPI == EPI_DOT || EPI == EPI_DOT2 || EPI == EPI_RES || EPI == EPI_AXPY_DOT ||
+                  EPI == EPI_XPBY_NRM) {
+        const double s1 = block_sum(acc1, s_red);
+        if (threadIdx.x == 0) a.p1[blockIdx.x] = s1;
+    }
+    if constexpr (EPI == EPI_DOT2) {
+        const double s2 = block_sum(acc2, s_red);
+        if (threadIdx.x == 0) a.p2[blockIdx.x] = s2;
+    }
+}
+
 // One lane per row, grid-stride: the A/B baseline for the stream kernel (SLA_SPMV_ALGO=scalar).
 template <int EPI, typename RP>
 __global__ void __launch_bounds__(kBlock) spmv_scalar_kernel(SpmvArgs<RP> a, int xcd_remap) {
@@ -1757,7 +1868,7 @@ int spmv_grid(const sla_csr *A) {
     // with column panels the fused partials are written by the LAST panel pass: its grid is the one that counts
     if (!A->panels.empty() && c->panels && c->spmv_algo == 0) return spmv_grid(A->panels.back());
     int64_t g;
-    if (c->spmv_algo == 1) g = (A->rows + kBlock - 1) / kBlock;
+    if (c->spmv_algo == 1 || (A->use_lpanel && c->lpanel)) g = (A->rows + kBlock - 1) / kBlock;   // (lpanel: its finish kernel)
     else if (A->use_wdia && wd_on(A)) g = std::min<int64_t>(A->nblk_wd, A->wd_vv ? c->wd_grid_max_vv : c->wd_grid_max);
     else if (A->use_vdict && c->vdict) g = A->nblk_vd;
     else g = A->nrb;
@@ -1835,6 +1946,21 @@ static int launch_spmv_t(const sla_csr *A, const SpmvLaunch &l) {
     a.yinit = l.yinit;
     const int grid = spmv_grid(A);
     ProfScope prof(c, l.kernel_id);
+    if (A->use_lpanel && c->lpanel && c->spmv_algo == 0 && !l.x2 && !l.yinit) {
+        static bool lds_attr = false;
+        if (!lds_attr) {
+            SLA_HIP_TRY(hipFuncSetAttribute((const void *)spmv_lpanel_kernel<RP>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            (int)(kLpW * sizeof(double))));
+            lds_attr = true;
+        }
+        hipLaunchKernelGGL((spmv_lpanel_kernel<RP>), dim3(A->lp_G), dim3(kLpBlock), kLpW * sizeof(double), c->stream,
+                           (const RP *)A->d_lpp, a.col, a.val, a.x, A->d_lpy, A->d_lpt, a.rows, (int)A->n, A->lp_W, A->lp_chunk, A->lp_C,
+                           (const SolverScalars *)a.sc);
+        SLA_HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL((lpanel_finish_kernel<EPI, RP>), dim3(grid), dim3(kBlock), 0, c->stream, a, A->d_lpy, A->lp_P);
+        SLA_HIP_TRY(hipGetLastError());
+        return SLA_OK;
+    }
     if (A->use_wdia && wd_on(A) && c->spmv_algo == 0 && !l.x2) {
         if constexpr (std::is_same<RP, int32_t>::value) {
             const int32_t *sched = c->wd_tile != 0 ? A->d_wsched : nullptr;

@@ -261,7 +261,9 @@ bool dual_ok(const sla_solver *S) {
     return !S->ctx->collectives && S->ctx->spmv_algo == 0 && S->ctx->dual_spmv && S->method != SLA_CGNE_ &&
            (S->A->panels.empty() || !S->ctx->panels) &&
            // (the wave-sliced form streams ~2 B of matrix per row: fusing the two sweeps saves nothing there)
-           !(S->A->use_wdia && wd_on(S->A));
+           !(S->A->use_wdia && wd_on(S->A)) &&
+           // (the LDS-panel form has no fused two-vector variant; two of its sweeps beat one L2-gathering dual sweep)
+           !(S->A->use_lpanel && S->ctx->lpanel);
 }
 
 int read_scalars(sla_solver *S) {

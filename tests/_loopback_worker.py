@@ -56,7 +56,10 @@ def gen(b=0, e=None):
         return wl.laplace3d(14, 11, 13, b, e)            # window exchange (slab stencil), dictionary codes
     if KIND == "banded":
         return wl.banded_nonsym(5003, 99, b, e)          # ragged last shard, non-symmetric
-    dims, (rp, ci, va) = wl.random_spd(2400, 4, 3)       # random columns: all-gather path
+    if KIND == "dense":                                  # ~120 entries per row: LDS-panel form on every slab
+        dims, (rp, ci, va) = wl.random_spd(2400, 60, 5)
+    else:
+        dims, (rp, ci, va) = wl.random_spd(2400, 4, 3)   # random columns: all-gather path
     e = dims[0] if e is None else e
     from sla_amd.partition import local_rows_of
     return dims, local_rows_of(rp, ci, va, b, e)
@@ -126,7 +129,7 @@ assert not errors, errors
 cat = lambda key: np.concatenate([results[r][key] for r in range(P)])  # noqa: E731
 y = cat("y")
 yo = orc.spmv(Ao, xg)
-if KIND == "random" or (KIND.startswith("fuzz") and "wdia" not in results[0]["kernel"] and len(VA) > 8 * n):     # > 8 stored entries per row on average: wavefront-segmented sums, last-bit grouping differences
+if KIND in ("random", "dense") or (KIND.startswith("fuzz") and "wdia" not in results[0]["kernel"] and len(VA) > 8 * n):     # > 8 stored entries per row on average: wavefront-segmented sums, last-bit grouping differences
     assert np.abs(y - yo).max() <= 4e-15 * np.abs(VA).max() * np.abs(xg).max() * 16, np.abs(y - yo).max()
 else:
     assert np.array_equal(y, yo), "sharded (#>) must equal the whole-matrix left fold bit for bit"

@@ -245,13 +245,17 @@ def test_column_panels_with_long_and_mid_rows(sla, monkeypatch):
             rows.append(np.full(int(k), i)); cols.append(cj); vals.append(rng.standard_normal(int(k)))
     r, c, v = np.concatenate(rows), np.concatenate(cols), np.concatenate(vals)
     monkeypatch.setenv("SLA_PANEL_COLS", "700")
-    ctx = sla.Context(0)
-    A = sla.fromCOO((m, n), r, c, v, ctx)
-    assert "colpanels" in A.kernel_info()
     rc, Ao = orc.coo_to_csr(m, n, r, c, v)
     x = rng.standard_normal(n)
-    y, yo = sla.matVec(A, sla.fromVector(x, ctx)).toDenseListSV(), orc.spmv(Ao, x)
+    yo = orc.spmv(Ao, x)
     bound = (np.diff(Ao.rowptr) + 8) * np.finfo(float).eps * orc.spmv(orc.Csr(m, n, Ao.rowptr, Ao.colidx, np.abs(Ao.val)), np.abs(x))
-    assert np.all(np.abs(y - yo) <= bound + 1e-300)
-    del A
-    ctx.close()
+    # (52 entries per row on average and x fits one LDS panel: the lowering prefers the LDS-panel form by default)
+    for lpanel, form in (("0", "colpanels"), ("1", "ldspanels")):
+        monkeypatch.setenv("SLA_LPANEL", lpanel)
+        ctx = sla.Context(0)
+        A = sla.fromCOO((m, n), r, c, v, ctx)
+        assert form in A.kernel_info()
+        y = sla.matVec(A, sla.fromVector(x, ctx)).toDenseListSV()
+        assert np.all(np.abs(y - yo) <= bound + 1e-300), form
+        del A
+        ctx.close()

@@ -1,0 +1,177 @@
+"""The LDS-panel SpMV form (spmv_lpanel_kernel + lpanel_finish_kernel: x cut into 16384-column panels held in LDS, one
+wavefront per (row, panel) segment, per-panel partial sums added in ascending panel order) against the oracle and
+against the stream kernel it replaces on matrices with dense rows: several panels, a single panel, rectangular
+shapes, empty / one-entry / very long rows next to each other, non-finite operands, and every fused epilogue through
+the solvers.  Rows this long are summed by wavefront segments in every GPU form, so parity is the rounding bound of
+SURVEY 8(a) row A1 (|dy_i| <= gamma_k sum_j |a_ij x_j|), not bit equality."""
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def sla():
+    import sla_amd
+    return sla_amd
+
+
+def _dense_rows(m, n, per_row, seed, ragged=False, dominant=False):
+    """m x n CSR with ~per_row uniformly random distinct columns per row (ascending), values in [-1, 1)."""
+    rng = np.random.default_rng(seed)
+    rp = [0]
+    cols, vals = [], []
+    for i in range(m):
+        k = per_row
+        if ragged:
+            k = (0, 1, 3, per_row, 4 * per_row, 700)[i % 6]      # empty, short and > 256-entry segments side by side
+        k = min(k, n)
+        c = np.sort(rng.choice(n, size=k, replace=False)) if k else np.zeros(0, np.int64)
+        v = rng.uniform(-1.0, 1.0, k)
+        if dominant and i < n:
+            if i not in c:
+                c = np.sort(np.append(c, i))
+                v = np.append(v, 0.0)
+            v[np.searchsorted(c, i)] = float(k) + 1.0
+        cols.append(c.astype(np.int64))
+        vals.append(v)
+        rp.append(rp[-1] + len(c))
+    return (m, n), (np.array(rp, np.int64), np.concatenate(cols), np.concatenate(vals))
+
+
+def _bound(csr, x, m):
+    """gamma_k * sum |a_ij x_j| per row, k = entries of the row (plus the panel additions)."""
+    rp, ci, va = csr
+    absum = np.add.reduceat(np.append(np.abs(va * x[ci]), 0.0), np.minimum(rp[:-1], len(va)))[:m]
+    absum[np.diff(rp) == 0] = 0.0
+    return (np.diff(rp) + 64) * 1.2e-16 * absum + 1e-300
+
+
+CASES = {
+    "3 panels, square 40000 x 40000, 100 per row": lambda: _dense_rows(40000, 40000, 100, 1),
+    "4 panels, wide 700 x 60000, 400 per row": lambda: _dense_rows(700, 60000, 400, 2),
+    "1 panel, tall 9000 x 3000, 64 per row": lambda: _dense_rows(9000, 3000, 64, 3),
+    "ragged rows (0, 1, 3, 80, 320, 700 entries), 2 panels": lambda: _dense_rows(3001, 20000, 80, 4, ragged=True),
+    "panel edge: n = 16384 + 1": lambda: _dense_rows(2000, 16385, 200, 5),
+}
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_lds_panels_match_the_oracle_and_the_stream_kernel(sla, monkeypatch, name):
+    dims, csr = CASES[name]()
+    m, n = dims
+    Ao = orc.Csr(m, n, *csr)
+    rng = np.random.default_rng(8)
+    x, xt = rng.standard_normal(n), rng.standard_normal(m)
+    want, want_t = orc.spmv(Ao, x), orc.spmv(orc.transpose(Ao), xt)
+    got = {}
+    for form, env in (("ldspanels", None), ("stream", "0")):
+        monkeypatch.delenv("SLA_LPANEL", raising=False)
+        if env is not None:
+            monkeypatch.setenv("SLA_LPANEL", env)
+        ctx = sla.Context(0)
+        A = sla.fromCSR(dims, *csr, ctx)
+        assert ("ldspanels" in A.kernel_info()) == (form == "ldspanels"), (name, A.kernel_info())
+        y = sla.matVec(A, sla.fromVector(x, ctx)).toDenseListSV()
+        yt = sla.vecMat(sla.fromVector(xt, ctx), A).toDenseListSV()
+        assert np.all(np.abs(y - want) <= _bound(csr, x, m)), (name, form, np.abs(y - want).max())
+        assert np.allclose(yt, want_t, rtol=1e-12, atol=1e-12), (name, form, "transpose")
+        got[form] = y
+        del A
+        ctx.close()
+    assert np.all(np.abs(got["ldspanels"] - got["stream"]) <= 2 * _bound(csr, x, m))
+    empty = np.diff(csr[0]) == 0
+    assert np.all(got["ldspanels"][empty] == 0.0)            # a row key with an empty row map gives 0.0 (Common.hs:242-250)
+
+
+def test_lds_panels_touch_only_the_referenced_entries_of_x(sla):
+    """Non-finite entries of x reach exactly the rows that reference them (a whole panel of x sits in LDS, but a lane
+    only reads the columns of its own entries)."""
+    dims, csr = _dense_rows(1500, 20000, 90, 6)
+    m, n = dims
+    Ao = orc.Csr(m, n, *csr)
+    x = np.random.default_rng(9).standard_normal(n)
+    x[[5, 16383, 16384, 19999]] = [np.inf, np.nan, -np.inf, np.nan]
+    A = sla.fromCSR(dims, *csr)
+    assert "ldspanels" in A.kernel_info()
+    y = sla.matVec(A, sla.fromVector(x)).toDenseListSV()
+    want = orc.spmv(Ao, x)
+    assert np.array_equal(np.isnan(y), np.isnan(want)) and np.array_equal(np.isinf(y), np.isinf(want))
+    fin = np.isfinite(want)
+    assert fin.any() and (~fin).any()
+    assert np.array_equal(np.sign(y[np.isinf(y)]), np.sign(want[np.isinf(want)]))
+    assert np.allclose(y[fin], want[fin], rtol=1e-12, atol=1e-12)
+
+
+def test_lds_panels_epilogues_through_the_solvers(sla, monkeypatch):
+    """K1/K3 (dot, dot2), the true-residual sweep (stand-alone: the fused two-vector sweep is not used with this form),
+    CGS's and CGNE's fused updates, r0 = b - A x0, Arnoldi and GMRES on a diagonally dominant matrix with dense rows:
+    the same iteration counts as the oracle and the stream kernel, iterates equal up to partial-sum grouping."""
+    dims, csr = _dense_rows(18000, 18000, 70, 7, dominant=True)
+    n = dims[0]
+    Ao = orc.Csr(n, n, *csr)
+    b = orc.spmv(Ao, np.linspace(-1.0, 2.0, n))
+    x0 = np.full(n, 0.25)
+    out = {}
+    for form, env in (("ldspanels", None), ("stream", "0")):
+        monkeypatch.delenv("SLA_LPANEL", raising=False)
+        if env is not None:
+            monkeypatch.setenv("SLA_LPANEL", env)
+        ctx = sla.Context(0)
+        A = sla.fromCSR(dims, *csr, ctx)
+        assert ("ldspanels" in A.kernel_info()) == (form == "ldspanels")
+        for meth in (sla.BICGSTAB_, sla.CGS_, sla.CGNE_):
+            x, info = sla.linSolve0(meth, A, sla.fromVector(b, ctx), sla.fromVector(x0, ctx), return_info=True)
+            out[(form, int(meth))] = (x.toDenseListSV(), info["iters"])
+        Q, H = sla.arnoldi(A, sla.fromVector(b, ctx), 5)
+        out[(form, "H")] = H
+        del A
+        ctx.close()
+    for meth, ometh in ((sla.BICGSTAB_, orc.BICGSTAB_), (sla.CGS_, orc.CGS_), (sla.CGNE_, orc.CGNE_)):
+        rc, xo, it_o, res_o, r0_o = orc.linsolve0(ometh, Ao, b, x0)
+        x, it = out[("ldspanels", int(meth))]
+        xs, its = out[("stream", int(meth))]
+        assert it == its and abs(it - it_o) <= 1, (meth, it, its, it_o)
+        assert it_o < 200 and np.linalg.norm(orc.spmv(Ao, x) - b) <= max(1e-6, 1e-4 * r0_o) * (1 + 1e-9)
+        assert np.abs(x - xs).max() <= 1e-8 * (np.abs(xs).max() + 1e-300), meth
+        assert np.abs(x - xo).max() <= 1e-8 * (np.abs(xo).max() + 1e-300), meth
+    rc, Qo, Ho, k = orc.arnoldi(Ao, b, 5)
+    Hl = out[("ldspanels", "H")]
+    # (single-pass classical Gram-Schmidt amplifies the last-bit differences of the long-row sums from column to column)
+    assert Hl.shape == Ho.shape and np.abs(Hl - Ho).max() <= 1e-7 * np.abs(Ho).max()
+    assert np.abs(Hl - out[("stream", "H")]).max() <= 1e-7 * np.abs(Ho).max()
+
+
+def test_lds_panels_randomised_shapes(sla):
+    """24 seeded random matrices with dense rows -- 1..5 panels, tall / wide / square, uniform and strongly skewed row
+    lengths (most rows short, a few holding most entries), empty leading / trailing rows: (#>) within the rounding
+    bound of the oracle's left fold, the epilogue b - A x (EPI_SUB) and the fused residual norm through linSolve0's
+    first check included."""
+    rng = np.random.default_rng(77)
+    taken = 0
+    for case in range(24):
+        m = int(rng.integers(300, 5000))
+        n = int(rng.integers(200, 70000))
+        base = int(rng.integers(30, 200)) * (1 + n // 16384)
+        if case % 3 == 0:      # skewed: 85 % of the rows short, the rest long
+            lens = np.where(rng.random(m) < 0.85, rng.integers(0, 12, m), rng.integers(base * 4, base * 8, m))
+        else:
+            lens = rng.integers(base // 2, base * 2, m)
+        lens = np.minimum(lens, n)
+        if case % 4 == 0:
+            lens[: m // 10] = 0
+            lens[-(m // 7):] = 0
+        rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        ci = np.concatenate([np.sort(rng.choice(n, size=int(k), replace=False)) for k in lens] + [np.zeros(0, np.int64)]).astype(np.int64)
+        va = rng.uniform(-2.0, 2.0, len(ci))
+        Ao = orc.Csr(m, n, rp, ci, va)
+        x = rng.standard_normal(n)
+        A = sla.fromCSR((m, n), rp, ci, va)
+        taken += "ldspanels" in A.kernel_info()
+        y = sla.matVec(A, sla.fromVector(x)).toDenseListSV()
+        want = orc.spmv(Ao, x)
+        assert np.all(np.abs(y - want) <= _bound((rp, ci, va), x, m)), (case, A.kernel_info(), np.abs(y - want).max())
+        del A
+    assert taken >= 12, taken
