@@ -272,7 +272,8 @@ static int csr_upload(sla_ctx *c, int64_t m, int64_t n, int64_t row_begin, int64
     A->row_begin = row_begin;
     A->rows = rows;
     A->nnz = nnz;
-    A->rp64 = nnz > (int64_t)std::numeric_limits<int32_t>::max();
+    // (SLA_FORCE_RP64=1: test hook -- run the 64-bit row-pointer instantiations of the kernels on small matrices)
+    A->rp64 = nnz > (int64_t)std::numeric_limits<int32_t>::max() || (getenv("SLA_FORCE_RP64") && atoi(getenv("SLA_FORCE_RP64")));
     std::vector<int32_t> rb;
     build_row_blocks(rows, rowptr, rb, A->max_row_nnz, c->row_align, c->rb_nnz);
     A->nrb = (int32_t)rb.size() - 1;

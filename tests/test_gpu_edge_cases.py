@@ -259,3 +259,69 @@ def test_column_panels_with_long_and_mid_rows(sla, monkeypatch):
         assert np.all(np.abs(y - yo) <= bound + 1e-300), form
         del A
         ctx.close()
+
+
+def test_64_bit_row_pointer_kernels(sla, monkeypatch):
+    """Matrices with more than 2^31 - 1 stored entries switch every general kernel to its int64 row-pointer
+    instantiation (the value-indexed forms are 32-bit only and step aside).  SLA_FORCE_RP64=1 runs those instantiations
+    at test sizes: stencil (stream + dictionary codes + x window), irregular short rows (stream, column panels), dense
+    rows (LDS panels) and rows at the row-block limits, (#>), (<#) and the solver epilogues against the oracle."""
+    from sla_amd import workloads as wl
+    rng = np.random.default_rng(41)
+
+    def dense_rows(m, n, k):
+        rp = np.arange(m + 1, dtype=np.int64) * k
+        ci = np.concatenate([np.sort(rng.choice(n, size=k, replace=False)) for _ in range(m)]).astype(np.int64)
+        return (m, n), (rp, ci, rng.uniform(-1, 1, m * k))
+
+    def limits():
+        n, rows, cols, vals = 4000, [], [], []
+        for i, k in ((0, 1024), (1, 1025), (2, 1), (3, 2049), (5, 3000)):
+            cj = np.sort(rng.choice(n, size=k, replace=False))
+            rows.append(np.full(k, i)); cols.append(cj); vals.append(rng.standard_normal(k))
+        rc, A = orc.coo_to_csr(n, n, np.concatenate(rows), np.concatenate(cols), np.concatenate(vals))
+        return (n, n), (A.rowptr, A.colidx, A.val)
+
+    cases = {
+        "laplace3d": (wl.laplace3d(13, 9, 11), {}, "diagdict"),
+        "laplace3d, plain stream": (wl.laplace3d(13, 9, 11), {"SLA_DIAG": "0", "SLA_XWIN": "0"}, "algo=stream "),
+        "random_spd short rows": (wl.random_spd(3000, 4, 3), {}, "algo=stream"),
+        "random_spd, column panels": (wl.random_spd(5000, 6, 4), {"SLA_PANEL_COLS": "600"}, "colpanels"),
+        "dense rows, LDS panels": (dense_rows(900, 20000, 120), {}, "ldspanels"),
+        "row-block limits": (limits(), {"SLA_LPANEL": "0"}, "algo=stream"),
+        "scalar kernel": (wl.random_spd(2000, 5, 6), {"SLA_SPMV_ALGO": "scalar"}, "scalar"),
+    }
+    knobs = ("SLA_DIAG", "SLA_XWIN", "SLA_PANEL_COLS", "SLA_LPANEL", "SLA_SPMV_ALGO")
+    for name, ((dims, csr), env, form) in cases.items():
+        for k in knobs:
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        monkeypatch.setenv("SLA_WDIA", "0")      # (the 32-bit run takes the same general form as the 64-bit one)
+        monkeypatch.setenv("SLA_VDICT", "0")
+        m, n = dims
+        Ao = orc.Csr(m, n, *csr)
+        x, w = rng.standard_normal(n), rng.standard_normal(m)
+        want, want_t = orc.spmv(Ao, x), orc.spmv(orc.transpose(Ao), w)
+        res = {}
+        for rp64 in ("1", "0"):
+            monkeypatch.setenv("SLA_FORCE_RP64", rp64)
+            ctx = sla.Context(0)
+            A = sla.fromCSR(dims, *csr, ctx)
+            info = A.kernel_info()
+            assert form in info + " " and ("rowptr=i64" in info) == (rp64 == "1"), (name, info)
+            y = sla.matVec(A, sla.fromVector(x, ctx)).toDenseListSV()
+            yt = sla.vecMat(sla.fromVector(w, ctx), A).toDenseListSV()
+            out = [y, yt]
+            if m == n and "limits" not in name and "dense" not in name:
+                b = orc.spmv(Ao, np.ones(n))
+                for meth in (sla.BICGSTAB_, sla.CGS_, sla.CGNE_):
+                    xs, inf = sla.linSolve0(meth, A, sla.fromVector(b, ctx), sla.fromVector(np.zeros(n), ctx), return_info=True)
+                    out += [xs.toDenseListSV(), inf["iters"]]
+            res[rp64] = out
+            del A
+            ctx.close()
+        assert np.allclose(res["1"][0], want, rtol=1e-12, atol=1e-12), name
+        assert np.allclose(res["1"][1], want_t, rtol=1e-12, atol=1e-12), name
+        for a, b_ in zip(res["1"], res["0"]):       # the index width changes nothing else: same bits, same iteration counts
+            assert np.array_equal(a, b_) if isinstance(a, np.ndarray) else a == b_, name
