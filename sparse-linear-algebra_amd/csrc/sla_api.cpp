@@ -288,11 +288,16 @@ static int csr_upload(sla_ctx *c, int64_t m, int64_t n, int64_t row_begin, int64
     // the values go up on a second host thread while this one narrows and uploads the indices (pageable copies are
     // bound by the staging memcpy of the calling thread, not by the link)
     hipError_t err_val = hipSuccess;
+    struct Joiner {   // (a host allocation failing below must not unwind past a joinable thread)
+        std::thread &t;
+        ~Joiner() { if (t.joinable()) t.join(); }
+    };
     std::thread val_up([&] {
         err_val = hipSetDevice(c->device);
         if (err_val == hipSuccess) err_val = hipMalloc((void **)&A->d_val, std::max<size_t>(sizeof(double) * (size_t)nnz, 8));
         if (err_val == hipSuccess && nnz) err_val = hipMemcpy(A->d_val, val, sizeof(double) * (size_t)nnz, hipMemcpyHostToDevice);
     });
+    Joiner val_up_joiner{val_up};
     {
         std::vector<int32_t> col32((size_t)nnz);
         par_rows(rows, 1, [&](int, int64_t lo, int64_t hi) {
@@ -648,6 +653,14 @@ static int csr_upload(sla_ctx *c, int64_t m, int64_t n, int64_t row_begin, int64
             const int64_t C = (rows + chunk - 1) / chunk;
             A->lp_P = (int32_t)P;
             A->lp_W = (int32_t)W;
+            int64_t clo = n, chi = -1;
+            for (int64_t i = 0; i < rows; ++i)
+                if (rowptr[i + 1] > rowptr[i]) {   // canonical CSR: first / last entry of a row are its min / max column
+                    clo = std::min(clo, col[rowptr[i]]);
+                    chi = std::max(chi, col[rowptr[i + 1] - 1]);
+                }
+            A->lp_col_lo = (int32_t)clo;
+            A->lp_col_hi = (int32_t)chi;
             A->lp_chunk = (int32_t)chunk;
             A->lp_C = (int32_t)C;
             // tasks (panel-major) are dealt out in contiguous runs of equal ENTRY counts, one run per workgroup
@@ -657,13 +670,13 @@ static int csr_upload(sla_ctx *c, int64_t m, int64_t n, int64_t row_begin, int64
             // 34-entry segments took 2.4x as long as those with 154-entry ones: weigh a row like row_cost entries)
             const int64_t row_cost = getenv("SLA_LP_ROWCOST") ? atoll(getenv("SLA_LP_ROWCOST")) : 256;
             std::vector<int64_t> upto((size_t)ntasks + 1, 0);   // weight before task t
-            for (int64_t p = 0; p < P; ++p)
-                for (int64_t cc = 0; cc < C; ++cc) {
-                    const int64_t lo = cc * chunk, hi = std::min<int64_t>(rows, lo + chunk);
-                    int64_t w = 0;
-                    for (int64_t i = lo; i < hi; ++i) w += pp[(size_t)((p + 1) * rows + i)] - pp[(size_t)(p * rows + i)];
-                    upto[(size_t)(p * C + cc) + 1] = upto[(size_t)(p * C + cc)] + w + row_cost * (hi - lo);
-                }
+            for (int64_t t = 0; t < ntasks; ++t) {   // (panel-major; row-chunk-major was tried: 0.906 -> 0.971 ms, x reloaded per task)
+                const int64_t p = t / C, cc = t % C;
+                const int64_t lo = cc * chunk, hi = std::min<int64_t>(rows, lo + chunk);
+                int64_t w = 0;
+                for (int64_t i = lo; i < hi; ++i) w += pp[(size_t)((p + 1) * rows + i)] - pp[(size_t)(p * rows + i)];
+                upto[(size_t)t + 1] = upto[(size_t)t] + w + row_cost * (hi - lo);
+            }
             std::vector<int32_t> tb((size_t)G + 1, 0);
             for (int g = 1; g < G; ++g) {
                 const int64_t target = upto[(size_t)ntasks] / G * g;
@@ -902,54 +915,74 @@ int sla_ctx_row_range(sla_ctx_t c, int64_t m, int64_t *begin, int64_t *end) {
 
 int sla_csr_from_coo(sla_ctx_t c, int64_t m, int64_t n, int64_t nnz, const int64_t *row, const int64_t *col,
                      const double *val, int dup_policy, sla_csr_t *out) {
-    if (!c || !out || (nnz > 0 && (!row || !col || !val))) return fail(SLA_ERR_INVALID, "sla_csr_from_coo: null argument");
-    HostCsr h;
-    if (!c->collectives && nnz >= c->device_coo_min && device_coo_supported(m, n, nnz)) {
-        if (m < 0 || n < 0) return fail(SLA_ERR_INVALID, "negative dimension");
-        for (int64_t k = 0; k < nnz; ++k)
-            if (row[k] < 0 || row[k] >= m || col[k] < 0 || col[k] >= n)
+    return no_throw("sla_csr_from_coo", [&]() -> int {
+        if (!c || !out || (nnz > 0 && (!row || !col || !val))) return fail(SLA_ERR_INVALID, "sla_csr_from_coo: null argument");
+        HostCsr h;
+        if (!c->collectives && nnz >= c->device_coo_min && device_coo_supported(m, n, nnz)) {
+            if (m < 0 || n < 0) return fail(SLA_ERR_INVALID, "negative dimension");
+            std::vector<char> oob((size_t)host_threads(), 0);
+            par_rows(nnz, 1, [&](int t, int64_t lo, int64_t hi) {
+                char bad = 0;
+                for (int64_t k = lo; k < hi; ++k) bad |= (row[k] < 0) | (row[k] >= m) | (col[k] < 0) | (col[k] >= n);
+                oob[(size_t)t] = bad;
+            });
+            if (std::find(oob.begin(), oob.end(), (char)1) != oob.end())
                 return fail(SLA_ERR_OOB, "insertSpMatrix : index out of bounds");
-        (void)hipSetDevice(c->device);
-        SLA_TRY(device_coo_to_csr(c, m, n, nnz, row, col, val, dup_policy, h));
-        // already canonical by construction: skip the validation pass of sla_csr_from_csr
-        return csr_upload(c, m, n, 0, m, h.rowptr.data(), h.col.data(), h.val.data(), out);
-    }
-    SLA_TRY(build_csr_from_coo(m, n, nnz, row, col, val, dup_policy, h));
-    return sla_csr_from_csr(c, m, n, h.rowptr.data(), h.col.data(), h.val.data(), out);
+            (void)hipSetDevice(c->device);
+            SLA_TRY(device_coo_to_csr(c, m, n, nnz, row, col, val, dup_policy, h));
+            // already canonical by construction: skip the validation pass of sla_csr_from_csr
+            return csr_upload(c, m, n, 0, m, h.rowptr.data(), h.col.data(), h.val.data(), out);
+        }
+        SLA_TRY(build_csr_from_coo(m, n, nnz, row, col, val, dup_policy, h));
+        return sla_csr_from_csr(c, m, n, h.rowptr.data(), h.col.data(), h.val.data(), out);
+    });
 }
 
 int sla_csr_from_csr(sla_ctx_t c, int64_t m, int64_t n, const int64_t *rowptr, const int64_t *colidx,
                      const double *val, sla_csr_t *out) {
-    if (!c || !out || !rowptr || m < 0 || n < 0) return fail(SLA_ERR_INVALID, "sla_csr_from_csr: bad argument");
-    int64_t b, e;
-    row_range(c, m, &b, &e);
-    if (c->nranks == 1) return sla_csr_from_csr_rows(c, m, n, 0, m, rowptr, colidx, val, out);
-    std::vector<int64_t> rp((size_t)(e - b) + 1);
-    for (int64_t i = b; i <= e; ++i) rp[(size_t)(i - b)] = rowptr[i] - rowptr[b];
-    return sla_csr_from_csr_rows(c, m, n, b, e - b, rp.data(), colidx + rowptr[b], val + rowptr[b], out);
+    return no_throw("sla_csr_from_csr", [&]() -> int {
+        if (!c || !out || !rowptr || m < 0 || n < 0) return fail(SLA_ERR_INVALID, "sla_csr_from_csr: bad argument");
+        int64_t b, e;
+        row_range(c, m, &b, &e);
+        if (c->nranks == 1) return sla_csr_from_csr_rows(c, m, n, 0, m, rowptr, colidx, val, out);
+        std::vector<int64_t> rp((size_t)(e - b) + 1);
+        for (int64_t i = b; i <= e; ++i) rp[(size_t)(i - b)] = rowptr[i] - rowptr[b];
+        return sla_csr_from_csr_rows(c, m, n, b, e - b, rp.data(), colidx + rowptr[b], val + rowptr[b], out);
+    });
 }
 
 int sla_csr_from_csr_rows(sla_ctx_t c, int64_t m, int64_t n, int64_t row_begin, int64_t row_count,
                           const int64_t *rowptr_local, const int64_t *colidx, const double *val, sla_csr_t *out) {
-    if (!c || !out || !rowptr_local || m < 0 || n < 0 || row_count < 0)
-        return fail(SLA_ERR_INVALID, "sla_csr_from_csr_rows: bad argument");
-    int64_t b, e;
-    row_range(c, m, &b, &e);
-    if (row_begin != b || row_count != e - b)
-        return fail(SLA_ERR_INVALID, "sla_csr_from_csr_rows: rows do not match sla_ctx_row_range");
-    if (rowptr_local[0] != 0) return fail(SLA_ERR_INVALID, "rowptr_local[0] must be 0");
-    const int64_t nnz = rowptr_local[row_count];
-    if (nnz > 0 && (!colidx || !val)) return fail(SLA_ERR_INVALID, "null colidx/val");
-    for (int64_t i = 0; i < row_count; ++i) {
-        if (rowptr_local[i + 1] < rowptr_local[i]) return fail(SLA_ERR_INVALID, "rowptr not monotone");
-        for (int64_t k = rowptr_local[i]; k < rowptr_local[i + 1]; ++k) {
-            if (colidx[k] < 0 || colidx[k] >= n) return fail(SLA_ERR_OOB, "insertSpMatrix : index out of bounds");
-            if (k > rowptr_local[i] && colidx[k] <= colidx[k - 1])
-                return fail(SLA_ERR_INVALID, "columns must be strictly ascending inside a row (canonical CSR)");
-        }
-    }
-    (void)hipSetDevice(c->device);
-    return csr_upload(c, m, n, row_begin, row_count, rowptr_local, colidx, val, out);
+    return no_throw("sla_csr_from_csr_rows", [&]() -> int {
+        if (!c || !out || !rowptr_local || m < 0 || n < 0 || row_count < 0)
+            return fail(SLA_ERR_INVALID, "sla_csr_from_csr_rows: bad argument");
+        int64_t b, e;
+        row_range(c, m, &b, &e);
+        if (row_begin != b || row_count != e - b)
+            return fail(SLA_ERR_INVALID, "sla_csr_from_csr_rows: rows do not match sla_ctx_row_range");
+        if (rowptr_local[0] != 0) return fail(SLA_ERR_INVALID, "rowptr_local[0] must be 0");
+        const int64_t nnz = rowptr_local[row_count];
+        if (nnz > 0 && (!colidx || !val)) return fail(SLA_ERR_INVALID, "null colidx/val");
+        // monotone row pointers first (the column checks below index through them), then rows in parallel; the
+        // lowest-numbered kind of violation wins so that the result does not depend on the thread count
+        for (int64_t i = 0; i < row_count; ++i)
+            if (rowptr_local[i + 1] < rowptr_local[i]) return fail(SLA_ERR_INVALID, "rowptr not monotone");
+        std::vector<int> bad((size_t)host_threads(), 0);   // 1: out of bounds, 2: not strictly ascending
+        par_rows(row_count, 1, [&](int t, int64_t lo, int64_t hi) {
+            int b_ = 0;
+            for (int64_t i = lo; i < hi && b_ != 1; ++i)
+                for (int64_t k = rowptr_local[i]; k < rowptr_local[i + 1]; ++k) {
+                    if (colidx[k] < 0 || colidx[k] >= n) { b_ = 1; break; }
+                    if (k > rowptr_local[i] && colidx[k] <= colidx[k - 1]) b_ = 2;
+                }
+            bad[(size_t)t] = b_;
+        });
+        if (std::find(bad.begin(), bad.end(), 1) != bad.end()) return fail(SLA_ERR_OOB, "insertSpMatrix : index out of bounds");
+        if (std::find(bad.begin(), bad.end(), 2) != bad.end())
+            return fail(SLA_ERR_INVALID, "columns must be strictly ascending inside a row (canonical CSR)");
+        (void)hipSetDevice(c->device);
+        return csr_upload(c, m, n, row_begin, row_count, rowptr_local, colidx, val, out);
+    });
 }
 
 static int export_host(sla_csr_t A, HostCsr &h) {
@@ -962,22 +995,24 @@ static int export_host(sla_csr_t A, HostCsr &h) {
 }
 
 int sla_jacobi_pre(sla_csr_t A, sla_csr_t *out) {
-    if (!A || !out) return fail(SLA_ERR_INVALID, "null argument");
-    if (A->ctx->collectives) return fail(SLA_ERR_INVALID, "sla_jacobi_pre: single-rank contexts only");
-    HostCsr h, d;
-    SLA_TRY(export_host(A, h));
-    d.m = A->m;
-    d.n = A->n;
-    d.rowptr.assign((size_t)A->m + 1, 0);
-    for (int64_t i = 0; i < A->m; ++i) {  // extractDiag keeps (i,i) where stored; fmap recip
-        for (int64_t k = h.rowptr[(size_t)i]; k < h.rowptr[(size_t)i + 1]; ++k)
-            if (h.col[(size_t)k] == i) {
-                d.col.push_back(i);
-                d.val.push_back(1.0 / h.val[(size_t)k]);
-            }
-        d.rowptr[(size_t)i + 1] = (int64_t)d.col.size();
-    }
-    return csr_upload(A->ctx, d.m, d.n, 0, d.m, d.rowptr.data(), d.col.data(), d.val.data(), out);
+    return no_throw("sla_jacobi_pre", [&]() -> int {
+        if (!A || !out) return fail(SLA_ERR_INVALID, "null argument");
+        if (A->ctx->collectives) return fail(SLA_ERR_INVALID, "sla_jacobi_pre: single-rank contexts only");
+        HostCsr h, d;
+        SLA_TRY(export_host(A, h));
+        d.m = A->m;
+        d.n = A->n;
+        d.rowptr.assign((size_t)A->m + 1, 0);
+        for (int64_t i = 0; i < A->m; ++i) {  // extractDiag keeps (i,i) where stored; fmap recip
+            for (int64_t k = h.rowptr[(size_t)i]; k < h.rowptr[(size_t)i + 1]; ++k)
+                if (h.col[(size_t)k] == i) {
+                    d.col.push_back(i);
+                    d.val.push_back(1.0 / h.val[(size_t)k]);
+                }
+            d.rowptr[(size_t)i + 1] = (int64_t)d.col.size();
+        }
+        return csr_upload(A->ctx, d.m, d.n, 0, d.m, d.rowptr.data(), d.col.data(), d.val.data(), out);
+    });
 }
 
 // ---- triangular solves, SSOR factors -------------------------------------------------------
@@ -1080,109 +1115,115 @@ int sla_tri_solve_info(sla_csr_t T, int upper, int64_t *levels, int64_t *widest_
 }
 
 int sla_tri_solve(sla_csr_t T, int upper, sla_vec_t b, sla_vec_t x, int64_t *bad_row) {
-    if (!T || !b || !x) return fail(SLA_ERR_INVALID, "null argument");
-    sla_ctx *c = T->ctx;
-    if (c->collectives || T->m != T->n) return fail(SLA_ERR_INVALID, "sla_tri_solve: square matrices on single-rank contexts only");
-    if (b->ctx != c || x->ctx != c || b->d == x->d) return fail(SLA_ERR_INVALID, "sla_tri_solve: b and x must be distinct vectors of the matrix's context");
-    if (b->n != T->m || x->n != T->m) return fail(SLA_ERR_DIM_MISMATCH, "triangular solve : mismatched dimensions");
-    upper = upper ? 1 : 0;
-    (void)hipSetDevice(c->device);
-    SLA_TRY(tri_plan_build(T, upper, bad_row));
-    sla_tri_plan *p = T->tri[upper];
-    if (T->m == 0) return SLA_OK;
-    if (!p->graph || p->gb != b->d || p->gx != x->d) {
-        // capture the level launches once per (b, x) buffer pair; later solves with the same buffers replay the graph
-        if (p->graph) { (void)hipGraphExecDestroy(p->graph); p->graph = nullptr; }
-        hipGraph_t g = nullptr;
-        SLA_HIP_TRY(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-        int rc = SLA_OK;
-        for (int64_t l = 0; l < p->nlevels && rc == SLA_OK; ++l)
-            rc = launch_tri_level(T, p, p->level_ptr[(size_t)l], p->level_ptr[(size_t)l + 1] - p->level_ptr[(size_t)l], b->d, x->d);
-        if (rc == SLA_OK) rc = launch_tri_sparsify(c, T->m, x->d);
-        const hipError_t e = hipStreamEndCapture(c->stream, &g);
-        if (rc != SLA_OK) { if (g) (void)hipGraphDestroy(g); return rc; }
-        SLA_HIP_TRY(e);
-        const hipError_t ei = hipGraphInstantiate(&p->graph, g, nullptr, nullptr, 0);
-        (void)hipGraphDestroy(g);
-        SLA_HIP_TRY(ei);
-        p->gb = b->d;
-        p->gx = x->d;
-    }
-    SLA_HIP_TRY(hipGraphLaunch(p->graph, c->stream));
-    return SLA_OK;
+    return no_throw("sla_tri_solve", [&]() -> int {
+        if (!T || !b || !x) return fail(SLA_ERR_INVALID, "null argument");
+        sla_ctx *c = T->ctx;
+        if (c->collectives || T->m != T->n) return fail(SLA_ERR_INVALID, "sla_tri_solve: square matrices on single-rank contexts only");
+        if (b->ctx != c || x->ctx != c || b->d == x->d) return fail(SLA_ERR_INVALID, "sla_tri_solve: b and x must be distinct vectors of the matrix's context");
+        if (b->n != T->m || x->n != T->m) return fail(SLA_ERR_DIM_MISMATCH, "triangular solve : mismatched dimensions");
+        upper = upper ? 1 : 0;
+        (void)hipSetDevice(c->device);
+        SLA_TRY(tri_plan_build(T, upper, bad_row));
+        sla_tri_plan *p = T->tri[upper];
+        if (T->m == 0) return SLA_OK;
+        if (!p->graph || p->gb != b->d || p->gx != x->d) {
+            // capture the level launches once per (b, x) buffer pair; later solves with the same buffers replay the graph
+            if (p->graph) { (void)hipGraphExecDestroy(p->graph); p->graph = nullptr; }
+            hipGraph_t g = nullptr;
+            SLA_HIP_TRY(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+            int rc = SLA_OK;
+            for (int64_t l = 0; l < p->nlevels && rc == SLA_OK; ++l)
+                rc = launch_tri_level(T, p, p->level_ptr[(size_t)l], p->level_ptr[(size_t)l + 1] - p->level_ptr[(size_t)l], b->d, x->d);
+            if (rc == SLA_OK) rc = launch_tri_sparsify(c, T->m, x->d);
+            const hipError_t e = hipStreamEndCapture(c->stream, &g);
+            if (rc != SLA_OK) { if (g) (void)hipGraphDestroy(g); return rc; }
+            SLA_HIP_TRY(e);
+            const hipError_t ei = hipGraphInstantiate(&p->graph, g, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(g);
+            SLA_HIP_TRY(ei);
+            p->gb = b->d;
+            p->gx = x->d;
+        }
+        SLA_HIP_TRY(hipGraphLaunch(p->graph, c->stream));
+        return SLA_OK;
+    });
 }
 
 int sla_ssor_pre(sla_csr_t A, double omega, sla_csr_t *l, sla_csr_t *r) {
-    if (!A || !l || !r) return fail(SLA_ERR_INVALID, "null argument");
-    if (A->ctx->collectives) return fail(SLA_ERR_INVALID, "sla_ssor_pre: single-rank contexts only");
-    if (A->m != A->n) return fail(SLA_ERR_DIM_MISMATCH, "mSsorPre : square matrices only");
-    HostCsr h, L, R;
-    SLA_TRY(export_host(A, h));
-    const int64_t n = A->m;
-    std::vector<double> rd((size_t)n, 0.0);      // reciprocal d: recip of the stored diagonal entries
-    std::vector<char> has((size_t)n, 0);
-    for (int64_t i = 0; i < n; ++i)
-        for (int64_t k = h.rowptr[(size_t)i]; k < h.rowptr[(size_t)i + 1]; ++k)
-            if (h.col[(size_t)k] == i) { rd[(size_t)i] = 1.0 / h.val[(size_t)k]; has[(size_t)i] = 1; }
-    L.m = R.m = L.n = R.n = n;
-    L.rowptr.assign((size_t)n + 1, 0);
-    R.rowptr.assign((size_t)n + 1, 0);
-    for (int64_t i = 0; i < n; ++i) {
-        for (int64_t k = h.rowptr[(size_t)i]; k < h.rowptr[(size_t)i + 1]; ++k) {
-            const int64_t j = h.col[(size_t)k];
-            if (j < i && has[(size_t)j]) {                       // (eye ^-^ omega e)_ij = -(omega e_ij); times (1 / d_jj): one-term sum
-                const double m = -(omega * h.val[(size_t)k]);
-                L.col.push_back(j);
-                L.val.push_back(0.0 + rd[(size_t)j] * m);
+    return no_throw("sla_ssor_pre", [&]() -> int {
+        if (!A || !l || !r) return fail(SLA_ERR_INVALID, "null argument");
+        if (A->ctx->collectives) return fail(SLA_ERR_INVALID, "sla_ssor_pre: single-rank contexts only");
+        if (A->m != A->n) return fail(SLA_ERR_DIM_MISMATCH, "mSsorPre : square matrices only");
+        HostCsr h, L, R;
+        SLA_TRY(export_host(A, h));
+        const int64_t n = A->m;
+        std::vector<double> rd((size_t)n, 0.0);      // reciprocal d: recip of the stored diagonal entries
+        std::vector<char> has((size_t)n, 0);
+        for (int64_t i = 0; i < n; ++i)
+            for (int64_t k = h.rowptr[(size_t)i]; k < h.rowptr[(size_t)i + 1]; ++k)
+                if (h.col[(size_t)k] == i) { rd[(size_t)i] = 1.0 / h.val[(size_t)k]; has[(size_t)i] = 1; }
+        L.m = R.m = L.n = R.n = n;
+        L.rowptr.assign((size_t)n + 1, 0);
+        R.rowptr.assign((size_t)n + 1, 0);
+        for (int64_t i = 0; i < n; ++i) {
+            for (int64_t k = h.rowptr[(size_t)i]; k < h.rowptr[(size_t)i + 1]; ++k) {
+                const int64_t j = h.col[(size_t)k];
+                if (j < i && has[(size_t)j]) {                       // (eye ^-^ omega e)_ij = -(omega e_ij); times (1 / d_jj): one-term sum
+                    const double m = -(omega * h.val[(size_t)k]);
+                    L.col.push_back(j);
+                    L.val.push_back(0.0 + rd[(size_t)j] * m);
+                }
             }
+            if (has[(size_t)i]) { L.col.push_back(i); L.val.push_back(0.0 + rd[(size_t)i] * 1.0); }
+            L.rowptr[(size_t)i + 1] = (int64_t)L.col.size();
+            for (int64_t k = h.rowptr[(size_t)i]; k < h.rowptr[(size_t)i + 1]; ++k) {
+                const int64_t j = h.col[(size_t)k];
+                if (j == i) { R.col.push_back(j); R.val.push_back(h.val[(size_t)k]); }
+                else if (j > i) { R.col.push_back(j); R.val.push_back(-(omega * h.val[(size_t)k])); }
+            }
+            R.rowptr[(size_t)i + 1] = (int64_t)R.col.size();
         }
-        if (has[(size_t)i]) { L.col.push_back(i); L.val.push_back(0.0 + rd[(size_t)i] * 1.0); }
-        L.rowptr[(size_t)i + 1] = (int64_t)L.col.size();
-        for (int64_t k = h.rowptr[(size_t)i]; k < h.rowptr[(size_t)i + 1]; ++k) {
-            const int64_t j = h.col[(size_t)k];
-            if (j == i) { R.col.push_back(j); R.val.push_back(h.val[(size_t)k]); }
-            else if (j > i) { R.col.push_back(j); R.val.push_back(-(omega * h.val[(size_t)k])); }
-        }
-        R.rowptr[(size_t)i + 1] = (int64_t)R.col.size();
-    }
-    sla_csr *lo = nullptr, *ro = nullptr;
-    SLA_TRY(csr_upload(A->ctx, n, n, 0, n, L.rowptr.data(), L.col.data(), L.val.data(), &lo));
-    const int rc = csr_upload(A->ctx, n, n, 0, n, R.rowptr.data(), R.col.data(), R.val.data(), &ro);
-    if (rc != SLA_OK) { sla_csr_destroy(lo); return rc; }
-    *l = lo;
-    *r = ro;
-    return SLA_OK;
+        sla_csr *lo = nullptr, *ro = nullptr;
+        SLA_TRY(csr_upload(A->ctx, n, n, 0, n, L.rowptr.data(), L.col.data(), L.val.data(), &lo));
+        const int rc = csr_upload(A->ctx, n, n, 0, n, R.rowptr.data(), R.col.data(), R.val.data(), &ro);
+        if (rc != SLA_OK) { sla_csr_destroy(lo); return rc; }
+        *l = lo;
+        *r = ro;
+        return SLA_OK;
+    });
 }
 
 int sla_csr_diag_mul(sla_csr_t D, sla_csr_t A, sla_csr_t *out) {
-    if (!D || !A || !out) return fail(SLA_ERR_INVALID, "null argument");
-    if (D->ctx != A->ctx || A->ctx->collectives) return fail(SLA_ERR_INVALID, "sla_csr_diag_mul: one single-rank context");
-    if (D->n != A->m) return fail(SLA_ERR_DIM_MISMATCH, "matMat : incompatible matrix sizes");  // SpMatrix.hs:795
-    HostCsr hd, ha, r;
-    SLA_TRY(export_host(D, hd));
-    SLA_TRY(export_host(A, ha));
-    for (int64_t i = 0; i < D->m; ++i) {
-        const int64_t len = hd.rowptr[(size_t)i + 1] - hd.rowptr[(size_t)i];
-        if (len > 1 || (len == 1 && hd.col[(size_t)hd.rowptr[(size_t)i]] != i))
-            return fail(SLA_ERR_INVALID, "sla_csr_diag_mul: the left factor must be diagonal");
-    }
-    r.m = D->m;
-    r.n = A->n;
-    r.rowptr.assign((size_t)D->m + 1, 0);
-    for (int64_t i = 0; i < D->m; ++i) {
-        if (hd.rowptr[(size_t)i + 1] > hd.rowptr[(size_t)i]) {
-            const double dii = hd.val[(size_t)hd.rowptr[(size_t)i]];
-            for (int64_t k = ha.rowptr[(size_t)i]; k < ha.rowptr[(size_t)i + 1]; ++k) {
-                const double x = 0.0 + ha.val[(size_t)k] * dii;  // dott: sum (liftI2 (*) colA rowD), one term
-                if (fabs(x) > 1e-12) {                           // sparsifySM (Eps.hs:41-42)
-                    r.col.push_back(ha.col[(size_t)k]);
-                    r.val.push_back(x);
+    return no_throw("sla_csr_diag_mul", [&]() -> int {
+        if (!D || !A || !out) return fail(SLA_ERR_INVALID, "null argument");
+        if (D->ctx != A->ctx || A->ctx->collectives) return fail(SLA_ERR_INVALID, "sla_csr_diag_mul: one single-rank context");
+        if (D->n != A->m) return fail(SLA_ERR_DIM_MISMATCH, "matMat : incompatible matrix sizes");  // SpMatrix.hs:795
+        HostCsr hd, ha, r;
+        SLA_TRY(export_host(D, hd));
+        SLA_TRY(export_host(A, ha));
+        for (int64_t i = 0; i < D->m; ++i) {
+            const int64_t len = hd.rowptr[(size_t)i + 1] - hd.rowptr[(size_t)i];
+            if (len > 1 || (len == 1 && hd.col[(size_t)hd.rowptr[(size_t)i]] != i))
+                return fail(SLA_ERR_INVALID, "sla_csr_diag_mul: the left factor must be diagonal");
+        }
+        r.m = D->m;
+        r.n = A->n;
+        r.rowptr.assign((size_t)D->m + 1, 0);
+        for (int64_t i = 0; i < D->m; ++i) {
+            if (hd.rowptr[(size_t)i + 1] > hd.rowptr[(size_t)i]) {
+                const double dii = hd.val[(size_t)hd.rowptr[(size_t)i]];
+                for (int64_t k = ha.rowptr[(size_t)i]; k < ha.rowptr[(size_t)i + 1]; ++k) {
+                    const double x = 0.0 + ha.val[(size_t)k] * dii;  // dott: sum (liftI2 (*) colA rowD), one term
+                    if (fabs(x) > 1e-12) {                           // sparsifySM (Eps.hs:41-42)
+                        r.col.push_back(ha.col[(size_t)k]);
+                        r.val.push_back(x);
+                    }
                 }
             }
+            r.rowptr[(size_t)i + 1] = (int64_t)r.col.size();
         }
-        r.rowptr[(size_t)i + 1] = (int64_t)r.col.size();
-    }
-    return csr_upload(A->ctx, r.m, r.n, 0, r.m, r.rowptr.data(), r.col.data(), r.val.data(), out);
+        return csr_upload(A->ctx, r.m, r.n, 0, r.m, r.rowptr.data(), r.col.data(), r.val.data(), out);
+    });
 }
 
 int sla_csr_destroy(sla_csr_t A) {
@@ -1228,25 +1269,27 @@ int sla_csr_dims(sla_csr_t A, int64_t *m, int64_t *n, int64_t *nnz_local, int64_
 }
 
 int sla_csr_export(sla_csr_t A, int64_t *rowptr, int64_t *colidx, double *val) {
-    if (!A) return fail(SLA_ERR_INVALID, "null matrix");
-    sla_ctx *c = A->ctx;
-    SLA_HIP_TRY(hipStreamSynchronize(c->stream));
-    if (rowptr) {
-        if (A->rp64) {
-            SLA_HIP_TRY(hipMemcpy(rowptr, A->d_rowptr, sizeof(int64_t) * (size_t)(A->rows + 1), hipMemcpyDeviceToHost));
-        } else {
-            std::vector<int32_t> t((size_t)A->rows + 1);
-            SLA_HIP_TRY(hipMemcpy(t.data(), A->d_rowptr, sizeof(int32_t) * t.size(), hipMemcpyDeviceToHost));
-            for (size_t i = 0; i < t.size(); ++i) rowptr[i] = t[i];
+    return no_throw("sla_csr_export", [&]() -> int {
+        if (!A) return fail(SLA_ERR_INVALID, "null matrix");
+        sla_ctx *c = A->ctx;
+        SLA_HIP_TRY(hipStreamSynchronize(c->stream));
+        if (rowptr) {
+            if (A->rp64) {
+                SLA_HIP_TRY(hipMemcpy(rowptr, A->d_rowptr, sizeof(int64_t) * (size_t)(A->rows + 1), hipMemcpyDeviceToHost));
+            } else {
+                std::vector<int32_t> t((size_t)A->rows + 1);
+                SLA_HIP_TRY(hipMemcpy(t.data(), A->d_rowptr, sizeof(int32_t) * t.size(), hipMemcpyDeviceToHost));
+                for (size_t i = 0; i < t.size(); ++i) rowptr[i] = t[i];
+            }
         }
-    }
-    if (colidx && A->nnz) {
-        std::vector<int32_t> t((size_t)A->nnz);
-        SLA_HIP_TRY(hipMemcpy(t.data(), A->d_col, sizeof(int32_t) * t.size(), hipMemcpyDeviceToHost));
-        for (size_t i = 0; i < t.size(); ++i) colidx[i] = t[i];
-    }
-    if (val && A->nnz) SLA_HIP_TRY(hipMemcpy(val, A->d_val, sizeof(double) * (size_t)A->nnz, hipMemcpyDeviceToHost));
-    return SLA_OK;
+        if (colidx && A->nnz) {
+            std::vector<int32_t> t((size_t)A->nnz);
+            SLA_HIP_TRY(hipMemcpy(t.data(), A->d_col, sizeof(int32_t) * t.size(), hipMemcpyDeviceToHost));
+            for (size_t i = 0; i < t.size(); ++i) colidx[i] = t[i];
+        }
+        if (val && A->nnz) SLA_HIP_TRY(hipMemcpy(val, A->d_val, sizeof(double) * (size_t)A->nnz, hipMemcpyDeviceToHost));
+        return SLA_OK;
+    });
 }
 
 int sla_csr_is_diagonal(sla_csr_t A, int *out) {
@@ -1356,11 +1399,13 @@ int sla_spmv(sla_csr_t A, sla_vec_t x, sla_vec_t y) {
 }
 
 int sla_spmv_t(sla_csr_t A, sla_vec_t x, sla_vec_t y) {
-    if (!A || !x || !y) return fail(SLA_ERR_INVALID, "null argument");
-    if (A->m != x->n) return fail(SLA_ERR_DIM_MISMATCH, "vecMat : mismatching dimensions");  // Common.hs:256
-    if (A->n != y->n) return fail(SLA_ERR_DIM_MISMATCH, "vecMat : result vector has the wrong dimension");
-    if (x == y) return fail(SLA_ERR_INVALID, "sla_spmv_t: x and y must be distinct");
-    return spmv_transposed(A, x->d, y->d, y->shard);
+    return no_throw("sla_spmv_t", [&]() -> int {
+        if (!A || !x || !y) return fail(SLA_ERR_INVALID, "null argument");
+        if (A->m != x->n) return fail(SLA_ERR_DIM_MISMATCH, "vecMat : mismatching dimensions");  // Common.hs:256
+        if (A->n != y->n) return fail(SLA_ERR_DIM_MISMATCH, "vecMat : result vector has the wrong dimension");
+        if (x == y) return fail(SLA_ERR_INVALID, "sla_spmv_t: x and y must be distinct");
+        return spmv_transposed(A, x->d, y->d, y->shard);
+    });
 }
 
 int sla_dot(sla_vec_t x, sla_vec_t y, double *out) {

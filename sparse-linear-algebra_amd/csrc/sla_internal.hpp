@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <map>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -146,6 +147,7 @@ struct sla_ctx {
     int wdia = 1;                    // allow the wave-sliced SpMV kernel (SLA_WDIA=0 disables)
     int vdict = 1;                   // allow the value-indexed SpMV kernel (SLA_VDICT=0 disables)
     int n_cu = 256;                  // compute units of the device (persistent grids)
+    int lp_attr = 0;                 // spmv_lpanel_kernel<i32 / i64> had its dynamic-LDS limit raised on this device (bits 0 / 1)
     int lpanel = 1;                  // allow the LDS-panel SpMV kernel for matrices with dense rows (SLA_LPANEL=0 disables)
     int xwin = 1;                    // allow the LDS x-window SpMV kernel (SLA_XWIN=0 disables)
     int dual_spmv = 1;               // linSolve0: fuse the true-residual SpMV into the next K1 (SLA_DUAL_SPMV=0 disables)
@@ -220,6 +222,7 @@ struct sla_csr {
     int32_t *d_woff = nullptr;              // ... and its diagonal offset (col - row); all padded by 8 records
     // LDS-panel form (rows with many entries per 16384-column panel): per (panel, row) entry ranges into col / val
     void *d_lpp = nullptr;           // (P + 1) x rows, RP-typed, panel-major: pp[p][i] = first entry of row i with col >= p * lp_W
+    int32_t lp_col_lo = 0, lp_col_hi = -1;   // smallest / largest column any of these rows references
     int32_t *d_lpt = nullptr;        // lp_G + 1 task boundaries: workgroup g runs tasks [lpt[g], lpt[g+1]) (equal entries each)
     int32_t lp_G = 0;
     double *d_lpy = nullptr;         // P x rows partial sums, summed in ascending panel order by lpanel_finish_kernel
@@ -281,6 +284,19 @@ inline hipError_t guard_free(void *p, size_t guard = kGuardBytes) { return p ? h
 // error plumbing ---------------------------------------------------------------------------------
 void set_error(const std::string &msg);
 int fail(int code, const std::string &msg);
+// No C++ exception may cross the C ABI: a failed host allocation inside an entry point becomes SLA_ERR_ALLOC.
+template <class F>
+inline int no_throw(const char *what, F body) {
+    try {
+        return body();
+    } catch (const std::bad_alloc &) {
+        return fail(SLA_ERR_ALLOC, std::string(what) + ": out of host memory");
+    } catch (const std::exception &e) {
+        return fail(SLA_ERR_INVALID, std::string(what) + ": " + e.what());
+    } catch (...) {
+        return fail(SLA_ERR_INVALID, std::string(what) + ": unknown C++ exception");
+    }
+}
 #define SLA_HIP_TRY(expr)                                                                        \
     do {                                                                                         \
         hipError_t _e = (expr);                                                                  \

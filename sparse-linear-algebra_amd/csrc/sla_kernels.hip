@@ -1733,7 +1733,8 @@ template <typename RP>
 __global__ void __launch_bounds__(kLpBlock) spmv_lpanel_kernel(const RP *__restrict__ pp, const int32_t *__restrict__ col,
                                                                const double *__restrict__ val, const double *__restrict__ xg,
                                                                double *__restrict__ ypart, const int32_t *__restrict__ task_begin,
-                                                               int rows, int n, int W, int chunk_rows, int C, const SolverScalars *sc) {
+                                                               int rows, int n, int W, int chunk_rows, int C, int col_lo, int col_hi,
+                                                               const SolverScalars *sc) {
     extern __shared__ double lp_xs[];
     if (sc && sc->done) return;
     const int tid = threadIdx.x, wv = tid >> 6, ln = tid & 63;
@@ -1745,7 +1746,9 @@ __global__ void __launch_bounds__(kLpBlock) spmv_lpanel_kernel(const RP *__restr
         if (p != curp) {
             __syncthreads();
             const int wn = min(W, n - w0);
-            for (int j = tid; j < wn; j += kLpBlock) lp_xs[j] = xg[w0 + j];
+            // only [col_lo, col_hi] is referenced by these rows -- and, on a row slab gathering from its in-place halo
+            // window, the only part of x that is backed by memory at all
+            for (int j = tid; j < wn; j += kLpBlock) lp_xs[j] = (w0 + j >= col_lo && w0 + j <= col_hi) ? xg[w0 + j] : 0.0;
             __syncthreads();
             curp = p;
         }
@@ -1947,14 +1950,14 @@ static int launch_spmv_t(const sla_csr *A, const SpmvLaunch &l) {
     const int grid = spmv_grid(A);
     ProfScope prof(c, l.kernel_id);
     if (A->use_lpanel && c->lpanel && c->spmv_algo == 0 && !l.x2 && !l.yinit) {
-        static bool lds_attr = false;
-        if (!lds_attr) {
+        const int attr_bit = std::is_same<RP, int32_t>::value ? 1 : 2;   // per context = per device: 128 KiB of dynamic LDS
+        if (!(c->lp_attr & attr_bit)) {
             SLA_HIP_TRY(hipFuncSetAttribute((const void *)spmv_lpanel_kernel<RP>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                             (int)(kLpW * sizeof(double))));
-            lds_attr = true;
+            c->lp_attr |= attr_bit;
         }
         hipLaunchKernelGGL((spmv_lpanel_kernel<RP>), dim3(A->lp_G), dim3(kLpBlock), kLpW * sizeof(double), c->stream,
-                           (const RP *)A->d_lpp, a.col, a.val, a.x, A->d_lpy, A->d_lpt, a.rows, (int)A->n, A->lp_W, A->lp_chunk, A->lp_C,
+                           (const RP *)A->d_lpp, a.col, a.val, a.x, A->d_lpy, A->d_lpt, a.rows, (int)A->n, A->lp_W, A->lp_chunk, A->lp_C, A->lp_col_lo, A->lp_col_hi,
                            (const SolverScalars *)a.sc);
         SLA_HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL((lpanel_finish_kernel<EPI, RP>), dim3(grid), dim3(kBlock), 0, c->stream, a, A->d_lpy, A->lp_P);

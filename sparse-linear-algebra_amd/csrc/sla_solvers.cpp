@@ -463,7 +463,9 @@ void hessenberg_lsq(int k, int ldh, const double *H, double beta, double *y) {
 extern "C" {
 
 int sla_solver_init(int method, sla_csr_t A, sla_vec_t b, sla_vec_t x0, sla_solver_t *out) {
-    return solver_init_common(method, A, b, x0, 1e-6, 1e-4, out);
+    return no_throw("sla_solver_init", [&]() -> int {
+        return solver_init_common(method, A, b, x0, 1e-6, 1e-4, out);
+    });
 }
 
 int sla_solver_step(sla_solver_t S, int k_steps) {
@@ -512,159 +514,167 @@ int sla_cgs_step(sla_solver_t S, int k) {
 
 int sla_linsolve0(int method, sla_csr_t A, sla_vec_t b, sla_vec_t x0, const sla_solve_opts *opts, sla_vec_t x_out,
                   sla_solve_info *info) {
-    if (!A || !b || !x0 || !x_out) return fail(SLA_ERR_INVALID, "sla_linsolve0: null argument");
-    sla_solve_opts o = {200, 1e-6, 1e-4, 16, 1};
-    if (opts) {
-        o = *opts;
-        if (o.max_iters <= 0) o.max_iters = 200;
-        if (o.check_every <= 0) o.check_every = 16;
-    }
-    if (info) { info->iters = 0; info->flags = 0; info->resnorm = NAN; info->r0norm = NAN; info->tol = NAN; }
-    // | m /= nb = throwM (MatVecSizeMismatchException "linSolve0" dm nb)      (Sparse.hs:1022)
-    if (A->m != b->n) return fail(SLA_ERR_DIM_MISMATCH, "linSolve0 : matrix rows and rhs dimension differ");
-    if (x_out->n != A->n) return fail(SLA_ERR_DIM_MISMATCH, "linSolve0 : output vector has the wrong dimension");
-    sla_ctx *c = A->ctx;
-    (void)hipSetDevice(c->device);
-    // solve aa' b' | isDiagonalSM aa' = return $ reciprocal aa' #> b'           (Sparse.hs:1024-1025)
-    if (A->is_diagonal) {
-        SLA_TRY(launch_diag_solve(c, b->n_local, A->d_val, b->d, x_out->d));
-        SLA_HIP_TRY(hipStreamSynchronize(c->stream));
-        if (info) info->flags = SLA_FLAG_DIAGONAL;
-        return SLA_OK;
-    }
-    if (method != SLA_BICGSTAB_ && method != SLA_CGS_ && method != SLA_CGNE_)
-        return fail(SLA_ERR_UNSUPPORTED_METHOD, "linSolve0 : Only BICGSTAB_, CGS_, and CGNE_ are implemented");  // :1031
-    sla_solver *S = nullptr;
-    SLA_TRY(solver_init_common(method, A, b, x0, o.tol_abs, o.tol_rel, &S));
-    int rc = SLA_OK, total = 0;
-    while (total < o.max_iters) {  // runIter n state | n >= nits = return x        (:1045)
-        const int k = std::min(o.check_every, o.max_iters - total);
-        const bool dual = o.true_residual != 0 && dual_ok(S);
-        for (int j = 0; j < k && rc == SLA_OK; ++j) {
-            if (!o.true_residual) rc = enqueue_step(S, false, false);
-            else if (!dual) rc = enqueue_step(S, true, false);
-            else rc = enqueue_step(S, /*res_after=*/j == k - 1, /*dual_prev=*/j > 0);
+    return no_throw("sla_linsolve0", [&]() -> int {
+        if (!A || !b || !x0 || !x_out) return fail(SLA_ERR_INVALID, "sla_linsolve0: null argument");
+        sla_solve_opts o = {200, 1e-6, 1e-4, 16, 1};
+        if (opts) {
+            o = *opts;
+            if (o.max_iters <= 0) o.max_iters = 200;
+            if (o.check_every <= 0) o.check_every = 16;
         }
-        if (rc != SLA_OK) break;
-        total += k;
-        if (o.true_residual) {
-            if ((rc = launch_check(c, S->d_sc, ctl_of(S).res)) != SLA_OK) break;
-            if ((rc = read_scalars(S)) != SLA_OK) break;
-            if (S->h_sc->done) break;
+        if (info) { info->iters = 0; info->flags = 0; info->resnorm = NAN; info->r0norm = NAN; info->tol = NAN; }
+        // | m /= nb = throwM (MatVecSizeMismatchException "linSolve0" dm nb)      (Sparse.hs:1022)
+        if (A->m != b->n) return fail(SLA_ERR_DIM_MISMATCH, "linSolve0 : matrix rows and rhs dimension differ");
+        if (x_out->n != A->n) return fail(SLA_ERR_DIM_MISMATCH, "linSolve0 : output vector has the wrong dimension");
+        sla_ctx *c = A->ctx;
+        (void)hipSetDevice(c->device);
+        // solve aa' b' | isDiagonalSM aa' = return $ reciprocal aa' #> b'           (Sparse.hs:1024-1025)
+        if (A->is_diagonal) {
+            SLA_TRY(launch_diag_solve(c, b->n_local, A->d_val, b->d, x_out->d));
+            SLA_HIP_TRY(hipStreamSynchronize(c->stream));
+            if (info) info->flags = SLA_FLAG_DIAGONAL;
+            return SLA_OK;
         }
-    }
-    if (rc == SLA_OK && !o.true_residual) {  // extension mode: report the final true residual once
-        Parts res;
-        if ((rc = enqueue_residual(S, &res)) == SLA_OK && (rc = launch_check(c, S->d_sc, res)) == SLA_OK) rc = read_scalars(S);
-    }
-    if (rc == SLA_OK) rc = sla_vec_copy(S->x, x_out);
-    if (rc == SLA_OK) {
-        hipError_t e = hipStreamSynchronize(c->stream);
-        if (e != hipSuccess) rc = fail(SLA_ERR_HIP, hipGetErrorString(e));
-    }
-    if (rc == SLA_OK) fill_info(S, info, true);
-    sla_solver_destroy(S);
-    return rc;
+        if (method != SLA_BICGSTAB_ && method != SLA_CGS_ && method != SLA_CGNE_)
+            return fail(SLA_ERR_UNSUPPORTED_METHOD, "linSolve0 : Only BICGSTAB_, CGS_, and CGNE_ are implemented");  // :1031
+        sla_solver *S = nullptr;
+        SLA_TRY(solver_init_common(method, A, b, x0, o.tol_abs, o.tol_rel, &S));
+        int rc = SLA_OK, total = 0;
+        while (total < o.max_iters) {  // runIter n state | n >= nits = return x        (:1045)
+            const int k = std::min(o.check_every, o.max_iters - total);
+            const bool dual = o.true_residual != 0 && dual_ok(S);
+            for (int j = 0; j < k && rc == SLA_OK; ++j) {
+                if (!o.true_residual) rc = enqueue_step(S, false, false);
+                else if (!dual) rc = enqueue_step(S, true, false);
+                else rc = enqueue_step(S, /*res_after=*/j == k - 1, /*dual_prev=*/j > 0);
+            }
+            if (rc != SLA_OK) break;
+            total += k;
+            if (o.true_residual) {
+                if ((rc = launch_check(c, S->d_sc, ctl_of(S).res)) != SLA_OK) break;
+                if ((rc = read_scalars(S)) != SLA_OK) break;
+                if (S->h_sc->done) break;
+            }
+        }
+        if (rc == SLA_OK && !o.true_residual) {  // extension mode: report the final true residual once
+            Parts res;
+            if ((rc = enqueue_residual(S, &res)) == SLA_OK && (rc = launch_check(c, S->d_sc, res)) == SLA_OK) rc = read_scalars(S);
+        }
+        if (rc == SLA_OK) rc = sla_vec_copy(S->x, x_out);
+        if (rc == SLA_OK) {
+            hipError_t e = hipStreamSynchronize(c->stream);
+            if (e != hipSuccess) rc = fail(SLA_ERR_HIP, hipGetErrorString(e));
+        }
+        if (rc == SLA_OK) fill_info(S, info, true);
+        sla_solver_destroy(S);
+        return rc;
+    });
 }
 
 int sla_arnoldi(sla_csr_t A, sla_vec_t b, int kn, double *Q_colmajor, double *H_colmajor, int *k_done) {
-    if (!A || !b || !H_colmajor || !k_done) return fail(SLA_ERR_INVALID, "sla_arnoldi: null argument");
-    // | otherwise = throwM (MatVecSizeMismatchException "arnoldi" (m,n) nb)      (Sparse.hs:637)
-    if (A->n != b->n) return fail(SLA_ERR_DIM_MISMATCH, "arnoldi : matrix columns and vector dimension differ");
-    if (A->m != A->n) return fail(SLA_ERR_DIM_MISMATCH, "arnoldi : matrix must be square");
-    if (kn < 1 || kn + 1 > kMaxKrylov) return fail(SLA_ERR_INVALID, "sla_arnoldi: kn must be in [1, 63]");
-    sla_ctx *c = A->ctx;
-    (void)hipSetDevice(c->device);
-    ArnoldiWs ws;
-    SLA_TRY(arn_alloc(ws, A, b, kn));
-    int k = 0;
-    SLA_TRY(arn_run(ws, A, b->d, kn, &k));
-    memcpy(H_colmajor, ws.Hhost.data(), sizeof(double) * (size_t)(kn + 1) * (size_t)kn);
-    *k_done = k;
-    if (Q_colmajor && b->n_local > 0) {
-        // this rank's rows of the k+1 basis vectors, leading dimension n_local
-        SLA_HIP_TRY(hipMemcpy2D(Q_colmajor, sizeof(double) * (size_t)b->n_local, ws.Q, sizeof(double) * (size_t)ws.ld,
-                                sizeof(double) * (size_t)b->n_local, (size_t)(k + 1), hipMemcpyDeviceToHost));
-    }
-    return SLA_OK;
+    return no_throw("sla_arnoldi", [&]() -> int {
+        if (!A || !b || !H_colmajor || !k_done) return fail(SLA_ERR_INVALID, "sla_arnoldi: null argument");
+        // | otherwise = throwM (MatVecSizeMismatchException "arnoldi" (m,n) nb)      (Sparse.hs:637)
+        if (A->n != b->n) return fail(SLA_ERR_DIM_MISMATCH, "arnoldi : matrix columns and vector dimension differ");
+        if (A->m != A->n) return fail(SLA_ERR_DIM_MISMATCH, "arnoldi : matrix must be square");
+        if (kn < 1 || kn + 1 > kMaxKrylov) return fail(SLA_ERR_INVALID, "sla_arnoldi: kn must be in [1, 63]");
+        sla_ctx *c = A->ctx;
+        (void)hipSetDevice(c->device);
+        ArnoldiWs ws;
+        SLA_TRY(arn_alloc(ws, A, b, kn));
+        int k = 0;
+        SLA_TRY(arn_run(ws, A, b->d, kn, &k));
+        memcpy(H_colmajor, ws.Hhost.data(), sizeof(double) * (size_t)(kn + 1) * (size_t)kn);
+        *k_done = k;
+        if (Q_colmajor && b->n_local > 0) {
+            // this rank's rows of the k+1 basis vectors, leading dimension n_local
+            SLA_HIP_TRY(hipMemcpy2D(Q_colmajor, sizeof(double) * (size_t)b->n_local, ws.Q, sizeof(double) * (size_t)ws.ld,
+                                    sizeof(double) * (size_t)b->n_local, (size_t)(k + 1), hipMemcpyDeviceToHost));
+        }
+        return SLA_OK;
+    });
 }
 
 int sla_gmres(sla_csr_t A, sla_vec_t b, sla_vec_t x0, int restart, const sla_solve_opts *opts, sla_vec_t x_out,
               sla_solve_info *info) {
-    if (!A || !b || !x0 || !x_out) return fail(SLA_ERR_INVALID, "sla_gmres: null argument");
-    sla_solve_opts o = {200, 1e-6, 1e-4, 16, 1};
-    if (opts) { o = *opts; if (o.max_iters <= 0) o.max_iters = 200; }
-    if (info) { info->iters = 0; info->flags = 0; info->resnorm = NAN; info->r0norm = NAN; info->tol = NAN; }
-    if (A->m != b->n) return fail(SLA_ERR_DIM_MISMATCH, "gmres : matrix rows and rhs dimension differ");
-    if (A->m != A->n || A->n != x0->n || x_out->n != A->n) return fail(SLA_ERR_DIM_MISMATCH, "gmres : mismatched dimensions");
-    if (restart < 1) return fail(SLA_ERR_INVALID, "sla_gmres: restart must be >= 1");
-    restart = std::min<int64_t>({(int64_t)restart, (int64_t)kMaxKrylov - 1, std::max<int64_t>(A->n, 1)});
-    sla_ctx *c = A->ctx;
-    (void)hipSetDevice(c->device);
-    ArnoldiWs ws;
-    SLA_TRY(arn_alloc(ws, A, b, restart));
-    sla_vec *x = nullptr, *r = nullptr;
-    SLA_TRY(vec_alloc(c, A->n, &x));
-    int rc = vec_alloc(c, A->n, &r);
-    double tol = 0.0, beta = NAN, r0norm = NAN;
-    int total = 0, flags = 0;
-    bool first = true;
-    std::vector<double> y((size_t)restart + 1);
-    if (rc == SLA_OK) rc = sla_vec_copy(x0, x);
-    while (rc == SLA_OK) {
-        SpmvLaunch l;  // r = b ^-^ (aa #> x)
-        l.epi = EPI_SUB;
-        if ((rc = gather_x(A, x, &l.x)) != SLA_OK) break;
-        l.y = r->d;
-        l.w = b->d;
-        if ((rc = launch_spmv(A, l)) != SLA_OK) break;
-        double ss = 0.0;
-        if ((rc = launch_dot(c, r->n_local, r->d, r->d, c->d_parts)) != SLA_OK) break;
-        if ((rc = reduce_to_host(c, c->d_parts, nullptr, vec_grid(r->n_local), &ss)) != SLA_OK) break;
-        beta = sqrt(ss);
-        if (first) { r0norm = beta; tol = fmax(o.tol_abs, o.tol_rel * beta); first = false; }
-        if (beta <= tol) { flags |= SLA_FLAG_CONVERGED; break; }
-        if (!(beta == beta) || isinf(beta)) { flags |= SLA_FLAG_NONFINITE; break; }
-        if (total >= o.max_iters) { flags |= SLA_FLAG_MAX_ITERS; break; }
-        const int mc = std::min(restart, o.max_iters - total);
-        int k = 0;
-        if ((rc = arn_run(ws, A, r->d, mc, &k)) != SLA_OK) break;
-        if (ws.h_sc->flags & SLA_FLAG_BREAKDOWN) flags |= SLA_FLAG_BREAKDOWN;
-        hessenberg_lsq(k, ws.kn + 1, ws.Hhost.data(), beta, y.data());
-        hipError_t e = hipMemcpyAsync(ws.ycoef, y.data(), sizeof(double) * (size_t)k, hipMemcpyHostToDevice, c->stream);
-        if (e != hipSuccess) { rc = fail(SLA_ERR_HIP, hipGetErrorString(e)); break; }
-        if ((rc = launch_gemv_accum(c, x->n_local, ws.Q, ws.ld, k, ws.ycoef, x->d)) != SLA_OK) break;
-        e = hipStreamSynchronize(c->stream);  // y is host memory reused next cycle
-        if (e != hipSuccess) { rc = fail(SLA_ERR_HIP, hipGetErrorString(e)); break; }
-        total += k;
-    }
-    if (rc == SLA_OK) rc = sla_vec_copy(x, x_out);
-    if (rc == SLA_OK) {
-        hipError_t e = hipStreamSynchronize(c->stream);
-        if (e != hipSuccess) rc = fail(SLA_ERR_HIP, hipGetErrorString(e));
-    }
-    if (rc == SLA_OK && info) {
-        info->iters = total;
-        info->flags = flags;
-        info->resnorm = beta;
-        info->r0norm = r0norm;
-        info->tol = tol;
-    }
-    sla_vec_destroy(x);
-    sla_vec_destroy(r);
-    return rc;
+    return no_throw("sla_gmres", [&]() -> int {
+        if (!A || !b || !x0 || !x_out) return fail(SLA_ERR_INVALID, "sla_gmres: null argument");
+        sla_solve_opts o = {200, 1e-6, 1e-4, 16, 1};
+        if (opts) { o = *opts; if (o.max_iters <= 0) o.max_iters = 200; }
+        if (info) { info->iters = 0; info->flags = 0; info->resnorm = NAN; info->r0norm = NAN; info->tol = NAN; }
+        if (A->m != b->n) return fail(SLA_ERR_DIM_MISMATCH, "gmres : matrix rows and rhs dimension differ");
+        if (A->m != A->n || A->n != x0->n || x_out->n != A->n) return fail(SLA_ERR_DIM_MISMATCH, "gmres : mismatched dimensions");
+        if (restart < 1) return fail(SLA_ERR_INVALID, "sla_gmres: restart must be >= 1");
+        restart = std::min<int64_t>({(int64_t)restart, (int64_t)kMaxKrylov - 1, std::max<int64_t>(A->n, 1)});
+        sla_ctx *c = A->ctx;
+        (void)hipSetDevice(c->device);
+        ArnoldiWs ws;
+        SLA_TRY(arn_alloc(ws, A, b, restart));
+        sla_vec *x = nullptr, *r = nullptr;
+        SLA_TRY(vec_alloc(c, A->n, &x));
+        int rc = vec_alloc(c, A->n, &r);
+        double tol = 0.0, beta = NAN, r0norm = NAN;
+        int total = 0, flags = 0;
+        bool first = true;
+        std::vector<double> y((size_t)restart + 1);
+        if (rc == SLA_OK) rc = sla_vec_copy(x0, x);
+        while (rc == SLA_OK) {
+            SpmvLaunch l;  // r = b ^-^ (aa #> x)
+            l.epi = EPI_SUB;
+            if ((rc = gather_x(A, x, &l.x)) != SLA_OK) break;
+            l.y = r->d;
+            l.w = b->d;
+            if ((rc = launch_spmv(A, l)) != SLA_OK) break;
+            double ss = 0.0;
+            if ((rc = launch_dot(c, r->n_local, r->d, r->d, c->d_parts)) != SLA_OK) break;
+            if ((rc = reduce_to_host(c, c->d_parts, nullptr, vec_grid(r->n_local), &ss)) != SLA_OK) break;
+            beta = sqrt(ss);
+            if (first) { r0norm = beta; tol = fmax(o.tol_abs, o.tol_rel * beta); first = false; }
+            if (beta <= tol) { flags |= SLA_FLAG_CONVERGED; break; }
+            if (!(beta == beta) || isinf(beta)) { flags |= SLA_FLAG_NONFINITE; break; }
+            if (total >= o.max_iters) { flags |= SLA_FLAG_MAX_ITERS; break; }
+            const int mc = std::min(restart, o.max_iters - total);
+            int k = 0;
+            if ((rc = arn_run(ws, A, r->d, mc, &k)) != SLA_OK) break;
+            if (ws.h_sc->flags & SLA_FLAG_BREAKDOWN) flags |= SLA_FLAG_BREAKDOWN;
+            hessenberg_lsq(k, ws.kn + 1, ws.Hhost.data(), beta, y.data());
+            hipError_t e = hipMemcpyAsync(ws.ycoef, y.data(), sizeof(double) * (size_t)k, hipMemcpyHostToDevice, c->stream);
+            if (e != hipSuccess) { rc = fail(SLA_ERR_HIP, hipGetErrorString(e)); break; }
+            if ((rc = launch_gemv_accum(c, x->n_local, ws.Q, ws.ld, k, ws.ycoef, x->d)) != SLA_OK) break;
+            e = hipStreamSynchronize(c->stream);  // y is host memory reused next cycle
+            if (e != hipSuccess) { rc = fail(SLA_ERR_HIP, hipGetErrorString(e)); break; }
+            total += k;
+        }
+        if (rc == SLA_OK) rc = sla_vec_copy(x, x_out);
+        if (rc == SLA_OK) {
+            hipError_t e = hipStreamSynchronize(c->stream);
+            if (e != hipSuccess) rc = fail(SLA_ERR_HIP, hipGetErrorString(e));
+        }
+        if (rc == SLA_OK && info) {
+            info->iters = total;
+            info->flags = flags;
+            info->resnorm = beta;
+            info->r0norm = r0norm;
+            info->tol = tol;
+        }
+        sla_vec_destroy(x);
+        sla_vec_destroy(r);
+        return rc;
+    });
 }
 
 // instance LinearSystem (SpVector Double): aa <\> b = linSolve0 GMRES_ aa b (mkSpVR n $ replicate n 0.1)
 // (dead code in the reference, Sparse.hs:1080-1084)
 int sla_linsolve(sla_csr_t A, sla_vec_t b, sla_vec_t x_out, sla_solve_info *info) {
-    if (!A || !b || !x_out) return fail(SLA_ERR_INVALID, "sla_linsolve: null argument");
-    sla_vec *x0 = nullptr;
-    SLA_TRY(vec_alloc(A->ctx, A->n, &x0));
-    int rc = launch_fill(A->ctx, x0->n_local, 0.1, x0->d);
-    if (rc == SLA_OK) rc = sla_gmres(A, b, x0, 30, nullptr, x_out, info);
-    sla_vec_destroy(x0);
-    return rc;
+    return no_throw("sla_linsolve", [&]() -> int {
+        if (!A || !b || !x_out) return fail(SLA_ERR_INVALID, "sla_linsolve: null argument");
+        sla_vec *x0 = nullptr;
+        SLA_TRY(vec_alloc(A->ctx, A->n, &x0));
+        int rc = launch_fill(A->ctx, x0->n_local, 0.1, x0->d);
+        if (rc == SLA_OK) rc = sla_gmres(A, b, x0, 30, nullptr, x_out, info);
+        sla_vec_destroy(x0);
+        return rc;
+    });
 }
 
 }  // extern "C"

@@ -56,6 +56,20 @@ def gen(b=0, e=None):
         return wl.laplace3d(14, 11, 13, b, e)            # window exchange (slab stencil), dictionary codes
     if KIND == "banded":
         return wl.banded_nonsym(5003, 99, b, e)          # ragged last shard, non-symmetric
+    if KIND == "denseband":                              # ~240 of 301 diagonals filled at random: no offset dictionary (> 256
+        if "denseband" not in _FUZZ:                     # offsets), LDS-panel form gathering from the in-place halo window
+            r = np.random.default_rng(77)
+            nn = 6001
+            rows, cols, vals = [], [], []
+            for i in range(nn):
+                j = np.arange(max(0, i - 150), min(nn, i + 151))
+                j = j[(r.random(len(j)) < 0.8) | (j == i)]
+                rows.append(np.full(len(j), i)), cols.append(j), vals.append(np.where(j == i, 300.0, r.uniform(-1, 1, len(j))))
+            rc, A = orc.coo_to_csr(nn, nn, np.concatenate(rows), np.concatenate(cols), np.concatenate(vals))
+            _FUZZ["denseband"] = ((nn, nn), (A.rowptr, A.colidx, A.val))
+        from sla_amd.partition import local_rows_of
+        dims, (rp, ci, va) = _FUZZ["denseband"]
+        return dims, local_rows_of(rp, ci, va, b, dims[0] if e is None else e)
     if KIND == "dense":                                  # ~120 entries per row: LDS-panel form on every slab
         dims, (rp, ci, va) = wl.random_spd(2400, 60, 5)
     else:
@@ -129,7 +143,7 @@ assert not errors, errors
 cat = lambda key: np.concatenate([results[r][key] for r in range(P)])  # noqa: E731
 y = cat("y")
 yo = orc.spmv(Ao, xg)
-if KIND in ("random", "dense") or (KIND.startswith("fuzz") and "wdia" not in results[0]["kernel"] and len(VA) > 8 * n):     # > 8 stored entries per row on average: wavefront-segmented sums, last-bit grouping differences
+if KIND in ("random", "dense", "denseband") or (KIND.startswith("fuzz") and "wdia" not in results[0]["kernel"] and len(VA) > 8 * n):     # > 8 stored entries per row on average: wavefront-segmented sums, last-bit grouping differences
     assert np.abs(y - yo).max() <= 4e-15 * np.abs(VA).max() * np.abs(xg).max() * 16, np.abs(y - yo).max()
 else:
     assert np.array_equal(y, yo), "sharded (#>) must equal the whole-matrix left fold bit for bit"
@@ -157,8 +171,10 @@ _hd = np.abs(Hs[0].reshape(6, 7).T[:k + 1, :k] - Ho).max() if results[0]["k"] ==
 if os.environ.get("SLA_LOOPBACK_DEBUG"):
     print("arnoldi k", results[0]["k"], k, "max|dH|", _hd, "max|H|", np.abs(Ho).max(), "H diag", np.diag(Ho)[:k])
 # (b = A 1 is almost an eigenvector of the random constant-band matrices: tiny sub-diagonal entries of H amplify the
-# last-bit differences of the inner products, hence the looser bound for the fuzz kinds)
-assert results[0]["k"] == k and _hd <= (1e-6 if KIND.startswith("fuzz") else 1e-10) * np.abs(Ho).max(), (results[0]["k"], k, _hd)
+# last-bit differences of the inner products, hence the looser bound for the fuzz and the dominant dense kinds)
+assert results[0]["k"] == k and _hd <= (1e-6 if KIND.startswith("fuzz") or KIND.startswith("dense") else 1e-10) * np.abs(Ho).max(), (results[0]["k"], k, _hd)
 xgm = np.concatenate([results[r]["gmres"][0] for r in range(P)])
 assert (results[0]["gmres"][2] & 1) == 1 and np.linalg.norm(orc.spmv(Ao, xgm) - bg) <= 1e-4 * np.linalg.norm(bg) + 1e-6
+if KIND in ("dense", "denseband"):
+    assert all("ldspanels" in results[r]["kernel"] for r in range(P)), results[0]["kernel"]
 print("LOOPBACK_OK", P, KIND, results[0]["kernel"].split()[0])

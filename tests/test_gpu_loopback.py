@@ -10,7 +10,7 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-@pytest.mark.parametrize("kind", ["laplace", "banded", "random", "dense"])
+@pytest.mark.parametrize("kind", ["laplace", "banded", "random", "dense", "denseband"])
 @pytest.mark.parametrize("nranks", [2, 3, 4])
 def test_sharded_path_on_loopback_ranks(nranks, kind):
     out = subprocess.run([sys.executable, os.path.join(HERE, "_loopback_worker.py"), str(nranks), kind],

@@ -12,8 +12,8 @@ dims, (rp, ci, va) = wl.random_spd(rows, k, 42)
 n, nnz = dims[0], len(ci)
 bytes_ = nnz * 12 + (n + 1) * 4 + 2 * n * 8
 x = np.random.default_rng(0).standard_normal(n)
-for env in ({"SLA_LPANEL": "0"}, {}, {"SLA_LP_BALANCE": "0"}, {"SLA_LP_ROWCOST": "0"}, {"SLA_LP_TASKS": "8"}, {"SLA_LP_TASKS": "64"}):
-    for kk in ("SLA_LPANEL", "SLA_LP_TASKS", "SLA_LP_BALANCE", "SLA_LP_ROWCOST"):
+for env in ({"SLA_LPANEL": "0"}, {}, {"SLA_LP_TASKS": "8"}, {"SLA_LP_TASKS": "64"}, {"SLA_LP_ROWCOST": "0"}):
+    for kk in ("SLA_LPANEL", "SLA_LP_TASKS", "SLA_LP_ROWCOST"):
         os.environ.pop(kk, None)
     os.environ.update(env)
     ctx = sla.Context(0)

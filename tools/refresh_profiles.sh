@@ -25,6 +25,7 @@ cp "$(find $S/ks -name '*kernel_stats.csv' | head -1)" $S/${tag}_bench_kernel_st
 for w in laplace3d_10m poisson2d_1m random_spd_1m; do
   bash tools/pmc_kbench.sh ${tag}_$w python bench.py --workload $w --steps 20 --warmup 3 --no-cpu-baseline > $S/${tag}_bench_pmc_counters_$w.txt 2>&1
 done
+bash tools/pmc_kbench.sh ${tag}_dense_rows_200k python bench.py --workload dense_rows_200k --steps 10 --warmup 2 --no-cpu-baseline > $S/${tag}_bench_pmc_counters_dense_rows_200k.txt 2>&1
 timeout 300 tools/kbench > $S/${tag}_kbench_spmv_variants.txt 2>&1
 bash tools/pmc_kbench.sh ${tag}_kbench tools/kbench x pmc 2>&1 | grep -E "axpby_kernel|dot_kernel|fill_kernel" > $S/${tag}_kbench_pmc_calibration.txt
 # same-box ablation of the knobs behind the default line (BiCGSTAB it/s, K1 ms, rotating SpMV ms)
