@@ -67,17 +67,31 @@ int gather_raw(sla_ctx *c, const sla_csr *A, const double *local, int64_t shard,
     *base = c->d_xfull;
     return SLA_OK;
 }
+bool halo_inplace_extents(const sla_csr *A, const sla_vec *x, int64_t *left, int64_t *right) {
+    const sla_ctx *c = x->ctx;
+    if (!(c->collectives && c->halo_inplace && A && A->xplan && c->x_exchange != 1 && (A->xplan->use_window || c->x_exchange == 2)))
+        return false;
+    const XPlan &pl = *A->xplan;
+    const int64_t b = x->begin, cap = (int64_t)(c->vec_guard / sizeof(double)) - 8;   // (8: the row-pair gathers' own slack)
+    int64_t lo = b, hi = b + x->n_local;
+    for (int q = 0; q < c->nranks; ++q)
+        if (q != c->rank && pl.recv_len[(size_t)q] > 0) {
+            if (pl.recv_begin[(size_t)q] < b - cap || pl.recv_begin[(size_t)q] + pl.recv_len[(size_t)q] > b + x->shard + cap) return false;
+            lo = std::min(lo, pl.recv_begin[(size_t)q]);
+            hi = std::max(hi, pl.recv_begin[(size_t)q] + pl.recv_len[(size_t)q]);
+        }
+    if (left) *left = b - lo;
+    if (right) *right = hi - (b + x->n_local);
+    return true;
+}
+
 int gather_x(const sla_csr *A, sla_vec *x, const double **base) {
     sla_ctx *c = x->ctx;
-    if (c->collectives && c->halo_inplace && A && A->xplan && c->x_exchange != 1 && (A->xplan->use_window || c->x_exchange == 2)) {
+    if (c->collectives) {
         // the neighbours' planes fit the slack around this vector: receive them in place, gather from x - first_row
-        const XPlan &pl = *A->xplan;
-        const int64_t b = x->begin, cap = (int64_t)(c->vec_guard / sizeof(double)) - 8;   // (8: the row-pair gathers' own slack)
-        bool fits = true;
-        for (int q = 0; q < c->nranks && fits; ++q)
-            if (q != c->rank && pl.recv_len[(size_t)q] > 0)
-                fits = pl.recv_begin[(size_t)q] >= b - cap && pl.recv_begin[(size_t)q] + pl.recv_len[(size_t)q] <= b + x->shard + cap;
-        if (fits) {
+        const int64_t b = x->begin;
+        if (halo_inplace_extents(A, x, nullptr, nullptr)) {
+            const XPlan &pl = *A->xplan;
             static const bool dbg = getenv("SLA_DEBUG_EXCHANGE") != nullptr;
             if (dbg) fprintf(stderr, "[sla] rank %d: in-place halo exchange (own rows %lld..%lld)\n", c->rank, (long long)b, (long long)(b + x->n_local));
             SLA_TRY(dist_exchange_window(c, pl, x->d, b, x->n_local, x->d - b));
@@ -806,6 +820,7 @@ static int ctx_create_common(int device_id, int rank, int nranks, const void *ui
     if (const char *s = getenv("SLA_VDICT")) c->vdict = atoi(s);
     if (const char *s = getenv("SLA_WDIA")) c->wdia = atoi(s);
     if (const char *s = getenv("SLA_LPANEL")) c->lpanel = atoi(s);
+    if (const char *s = getenv("SLA_BICG_GHOST")) c->bicg_ghost = atoi(s);
     if (const char *s = getenv("SLA_WD_TILE")) c->wd_tile = atoi(s);
     if (const char *s = getenv("SLA_WDIA_VV")) c->wdia_vv = atoi(s);
     if (const char *s = getenv("SLA_VEC_NT")) c->vec_nt = atoi(s);

@@ -180,8 +180,9 @@ int dist_allgather_f64(sla_ctx *ctx, const double *send, double *recv, int64_t c
         g->ptr[(size_t)ctx->rank] = send;
         g->barrier();
         for (int q = 0; q < ctx->nranks; ++q)
-            SLA_HIP_TRY(hipMemcpyAsync(recv + (size_t)q * (size_t)count, g->ptr[(size_t)q], sizeof(double) * (size_t)count,
-                                       hipMemcpyDeviceToDevice, ctx->stream));
+            if (recv + (size_t)q * (size_t)count != g->ptr[(size_t)q])   // (in place: the own slot is already there)
+                SLA_HIP_TRY(hipMemcpyAsync(recv + (size_t)q * (size_t)count, g->ptr[(size_t)q], sizeof(double) * (size_t)count,
+                                           hipMemcpyDeviceToDevice, ctx->stream));
         SLA_HIP_TRY(hipStreamSynchronize(ctx->stream));
         g->barrier();
         return SLA_OK;
@@ -258,6 +259,43 @@ int dist_exchange_window(sla_ctx *ctx, const XPlan &plan, const double *xlocal, 
     rc = r.group_end();
     if (rc != 0) return rccl_fail("ncclGroupEnd", rc);
     return SLA_OK;
+}
+
+// The same all-gather written as grouped point-to-point transfers: inside a dist_group_begin/end pair together with a
+// window exchange, everything is ONE pure send/recv group (the all-to-all pattern), i.e. one RCCL launch.
+int dist_allgather_p2p_f64(sla_ctx *ctx, const double *send, double *recv, int64_t count) {
+    if (loop_of(ctx) || !ctx->comm || ctx->nranks == 1) return dist_allgather_f64(ctx, send, recv, count);
+    Rccl &r = rccl();
+    if (!r.send || !r.recv || !r.group_start || !r.group_end) return dist_allgather_f64(ctx, send, recv, count);
+    if (send != recv + (size_t)ctx->rank * (size_t)count)   // (in-place callers already hold their own slot)
+        SLA_HIP_TRY(hipMemcpyAsync(recv + (size_t)ctx->rank * (size_t)count, send, sizeof(double) * (size_t)count, hipMemcpyDeviceToDevice, ctx->stream));
+    int rc = r.group_start();
+    if (rc != 0) return rccl_fail("ncclGroupStart", rc);
+    for (int q = 0; q < ctx->nranks; ++q) {   // every rank posts its transfers in the same (peer-ascending, recv-then-send) order
+        if (q == ctx->rank) continue;
+        rc = r.recv(recv + (size_t)q * (size_t)count, (size_t)count, kNcclFloat64, q, (NcclComm)ctx->comm, ctx->stream);
+        if (rc != 0) { r.group_end(); return rccl_fail("ncclRecv", rc); }
+        rc = r.send(send, (size_t)count, kNcclFloat64, q, (NcclComm)ctx->comm, ctx->stream);
+        if (rc != 0) { r.group_end(); return rccl_fail("ncclSend", rc); }
+    }
+    rc = r.group_end();
+    if (rc != 0) return rccl_fail("ncclGroupEnd", rc);
+    return SLA_OK;
+}
+
+int dist_group_begin(sla_ctx *ctx) {
+    if (loop_of(ctx) || !ctx->comm) return SLA_OK;   // (the loopback backend completes every collective before it returns)
+    Rccl &r = rccl();
+    if (!r.group_start) return fail(SLA_ERR_RCCL, "librccl lacks ncclGroupStart");
+    const int rc = r.group_start();
+    return rc != 0 ? rccl_fail("ncclGroupStart", rc) : SLA_OK;
+}
+int dist_group_end(sla_ctx *ctx) {
+    if (loop_of(ctx) || !ctx->comm) return SLA_OK;
+    Rccl &r = rccl();
+    if (!r.group_end) return fail(SLA_ERR_RCCL, "librccl lacks ncclGroupEnd");
+    const int rc = r.group_end();
+    return rc != 0 ? rccl_fail("ncclGroupEnd", rc) : SLA_OK;
 }
 
 // Pure host planning, identical on every rank given the same `windows` table.

@@ -147,6 +147,7 @@ struct sla_ctx {
     int wdia = 1;                    // allow the wave-sliced SpMV kernel (SLA_WDIA=0 disables)
     int vdict = 1;                   // allow the value-indexed SpMV kernel (SLA_VDICT=0 disables)
     int n_cu = 256;                  // compute units of the device (persistent grids)
+    int bicg_ghost = 1;              // sharded BiCGSTAB keeps ghost rows: 3 grouped exchanges per step instead of 5 (SLA_BICG_GHOST=0: plain flow)
     int lp_attr = 0;                 // spmv_lpanel_kernel<i32 / i64> had its dynamic-LDS limit raised on this device (bits 0 / 1)
     int lpanel = 1;                  // allow the LDS-panel SpMV kernel for matrices with dense rows (SLA_LPANEL=0 disables)
     int xwin = 1;                    // allow the LDS x-window SpMV kernel (SLA_XWIN=0 disables)
@@ -260,6 +261,10 @@ struct sla_solver {
     sla::SolverScalars *d_sc = nullptr;
     sla::SolverScalars *h_sc = nullptr;  // pinned
     bool have_res = false;               // d_parts[RES] holds the residual of the current x
+    // sharded BiCGSTAB with ghost rows (sla_solvers.cpp): r, p, Ap and s are kept valid on the ghl / ghr rows this
+    // rank's SpMV reads from its neighbours, so a step needs 3 grouped exchanges instead of 5
+    bool ghost = false;
+    int64_t ghl = 0, ghr = 0;
     alignas(8) char ctl_storage[128];    // driver-private step bookkeeping (sla_solvers.cpp)
 };
 
@@ -344,6 +349,12 @@ int dist_allgather_f64(sla_ctx *ctx, const double *send, double *recv, int64_t c
 int dist_reduce_scatter_f64(sla_ctx *ctx, const double *send, double *recv, int64_t recvcount);
 // xfull == xlocal - my_begin: in-place (the own rows are where they belong already, nothing is copied)
 int dist_exchange_window(sla_ctx *ctx, const XPlan &plan, const double *xlocal, int64_t my_begin, int64_t n_local, double *xfull);
+int dist_allgather_p2p_f64(sla_ctx *ctx, const double *send, double *recv, int64_t count);   // all-gather as grouped send/recv
+// the collectives issued between the two calls go out as ONE grouped launch (ncclGroupStart / ncclGroupEnd)
+int dist_group_begin(sla_ctx *ctx);
+int dist_group_end(sla_ctx *ctx);
+// does the window (halo) exchange of A land in place around vectors of x's shape?  If so: the ghost rows on either side
+bool halo_inplace_extents(const sla_csr *A, const sla_vec *x, int64_t *left, int64_t *right);
 int dist_allreduce_max_i32(sla_ctx *ctx, int *value_host);
 
 // shared helpers of sla_api.cpp --------------------------------------------------------------------------

@@ -39,6 +39,24 @@ int publish(sla_solver *S, int s1, int s2, int np, Parts *o1, Parts *o2) {
     return SLA_OK;
 }
 
+// ghost-row flow: the per-rank sums AND the neighbours' rows of `halo` (in place, around its own rows) in one grouped launch
+static int publish_with_halo(sla_solver *S, int s1, int s2, int np, Parts *o1, Parts *o2, sla_vec *halo) {
+    sla_ctx *c = S->ctx;
+    double *g = S->d_gath + (size_t)s1 * 2 * c->nranks;
+    double *loc = g + 2 * c->rank;   // in place: this rank's sums are written straight into their slot of the gathered table
+    SLA_TRY(launch_finalize(c, slot(S, s1), s2 >= 0 ? slot(S, s2) : nullptr, np, loc));
+    // (the per-rank sums travel as point-to-point transfers too, so that the group is a pure send/recv group)
+    SLA_TRY(dist_group_begin(c));
+    int rc = dist_allgather_p2p_f64(c, loc, g, 2);
+    if (rc == SLA_OK) rc = dist_exchange_window(c, *S->A->xplan, halo->d, halo->begin, halo->n_local, halo->d - halo->begin);
+    const int rc_end = dist_group_end(c);
+    if (rc != SLA_OK) return rc;
+    SLA_TRY(rc_end);
+    *o1 = Parts{g, c->nranks, 2};
+    if (o2) *o2 = Parts{g + 1, c->nranks, 2};
+    return SLA_OK;
+}
+
 int solver_alloc(sla_csr *A, int method, sla_solver **out) {
     sla_ctx *c = A->ctx;
     sla_solver *S = new sla_solver();
@@ -90,7 +108,58 @@ int enqueue_residual(sla_solver *S, Parts *res) {
 }
 
 // bicgstabStep (Sparse.hs:972-981)
+// bicgstabStep on a row slab with GHOST rows.  The plain sharded flow below exchanges the halo of p before K1 and of s
+// before K3 and all-gathers three groups of partial sums: five dependent collectives per step, which is what bounds
+// strong scaling (the slab kernels take ~10 us each).  Here r, p, Ap and s are kept valid on the ghost rows as well:
+//   halo(Ap) travels with the alpha partials (Ap is complete after K1), K2 then forms s = r - alpha Ap on own + ghost rows;
+//   halo(r') travels with the rho partials (r' is complete after K4), K5 then forms p' = r' + beta (p - omega Ap) on own +
+//   ghost rows from halo(r'), halo(p) (kept from the previous step) and halo(Ap) (still in place).
+// Three grouped launches per step, no exchange in front of either SpMV; every ghost value is computed by the same
+// kernel from the same bits as on its owner, so the iterates are bit-identical to the plain flow.
+static int enqueue_bicgstab_ghost(sla_solver *S, int par, const Parts *check) {
+    sla_ctx *c = S->ctx;
+    sla_csr *A = S->A;
+    const int64_t n = S->x->n_local, b = S->x->begin;
+    const int64_t gl = S->ghl + (S->ghl & 1);        // (even, so that the extended kernels keep their 16-byte pairs aligned;
+    const int64_t next = n + gl + S->ghr;             //  the extra element lies in the allocation's slack and is never read)
+    const int g = spmv_grid(A);
+    Parts apr, ass, asas, rhon;
+    {
+        SpmvLaunch l;  // K1: aap = aa #> p ; aap <.> r0hat        (halo(p) is valid: no exchange)
+        l.epi = EPI_DOT;
+        l.x = S->p->d - b;
+        l.y = S->t1->d;
+        l.w = S->r0hat->d;
+        l.p1 = slot(S, P_APR);
+        l.sc = S->d_sc;
+        if (check && check->p) { l.pres = check->p; l.npres = check->n; l.pres_stride = check->stride; }
+        l.step_begin = 1 | (par << 1);
+        l.kernel_id = SLA_KERNEL_SPMV_DOT;
+        SLA_TRY(launch_spmv(A, l));
+        SLA_TRY(publish_with_halo(S, P_APR, -1, g, &apr, nullptr, S->t1));
+    }
+    SLA_TRY(launch_bicg_k2(c, next, S->d_sc, apr, par, Parts{nullptr, 0, 1}, 0, S->r->d - gl, S->t1->d - gl, S->t2->d - gl));
+    {
+        SpmvLaunch l;  // K3: aasj = aa #> sj ; aasj <.> sj ; aasj <.> aasj      (halo(s) was computed by K2)
+        l.epi = EPI_DOT2;
+        l.x = S->t2->d - b;
+        l.y = S->t3->d;
+        l.w = S->t2->d;
+        l.p1 = slot(S, P_ASS);
+        l.p2 = slot(S, P_ASAS);
+        l.sc = S->d_sc;
+        l.kernel_id = SLA_KERNEL_SPMV_DOT2;
+        SLA_TRY(launch_spmv(A, l));
+        SLA_TRY(publish(S, P_ASS, P_ASAS, g, &ass, &asas));
+    }
+    SLA_TRY(launch_bicg_k4(c, n, S->d_sc, ass, asas, S->p->d, S->t2->d, S->t3->d, S->r0hat->d, S->x->d, S->r->d, slot(S, P_RHO)));
+    SLA_TRY(publish_with_halo(S, P_RHO, -1, vec_grid(n), &rhon, nullptr, S->r));
+    SLA_TRY(launch_bicg_k5(c, next, S->d_sc, rhon, par, S->r->d - gl, S->t1->d - gl, S->p->d - gl));
+    return SLA_OK;
+}
+
 int enqueue_bicgstab(sla_solver *S, int par, const Parts *check, bool dual_prev) {
+    if (S->ghost) return enqueue_bicgstab_ghost(S, par, check);
     sla_ctx *c = S->ctx;
     sla_csr *A = S->A;
     const int64_t n = S->x->n_local;
@@ -305,6 +374,22 @@ int solver_init_common(int method, sla_csr *A, sla_vec *b, sla_vec *x0, double t
         } else {
             if ((rc = sla_vec_copy(S->r, S->p)) != SLA_OK) break;
             if (method == SLA_CGS_ && (rc = sla_vec_copy(S->r, S->u)) != SLA_OK) break;
+        }
+        if (method == SLA_BICGSTAB_ && c->collectives && c->bicg_ghost) {
+            // ghost-row flow (enqueue_bicgstab_ghost): every rank must take the same decision -- the collectives differ
+            int64_t gl = 0, gr = 0;
+            int not_ok = (A->m == A->n && S->r->shard == S->p->shard && halo_inplace_extents(A, S->p, &gl, &gr)) ? 0 : 1;
+            if ((rc = dist_allreduce_max_i32(c, &not_ok)) != SLA_OK) break;
+            if (!not_ok) {
+                S->ghost = true;
+                S->ghl = gl;
+                S->ghr = gr;
+                if (getenv("SLA_DEBUG_EXCHANGE"))
+                    fprintf(stderr, "[sla] rank %d: ghost-row BiCGSTAB, %lld + %lld ghost rows\n", c->rank, (long long)gl, (long long)gr);
+                // halo(r0), halo(p0): the invariant every step starts from
+                if ((rc = dist_exchange_window(c, *A->xplan, S->r->d, S->r->begin, S->r->n_local, S->r->d - S->r->begin)) != SLA_OK) break;
+                if ((rc = dist_exchange_window(c, *A->xplan, S->p->d, S->p->begin, S->p->n_local, S->p->d - S->p->begin)) != SLA_OK) break;
+            }
         }
         // rho = r0 . r0hat = r0 . r0 ; r0norm = sqrt (r0 . r0)
         Parts rho;

@@ -126,6 +126,90 @@ def main():
     p = r + beta * (p - omega * ap)
     assert np.allclose(x, so.x[b:e], rtol=1e-12, atol=1e-13)
     assert np.allclose(p, so.p[b:e], rtol=1e-10, atol=1e-12)
+    # ---- ghost-row BiCGSTAB (enqueue_bicgstab_ghost): 3 exchanges per step instead of 5, same bits --------------------
+    # r, p, Ap and s are kept valid on the ghost rows (the neighbours' rows this slab reads); halo(Ap) travels with the
+    # alpha partials and halo(r') with the rho partials, each as ONE batch of point-to-point transfers -- per-rank sums
+    # included, like the library's pure send/recv group -- and no exchange precedes either SpMV.
+    ext = np.zeros(S * P, dtype=bool)
+    ext[b:e] = True
+    for q in range(P):
+        if q != rank and rl[q] > 0:
+            ext[rb_[q]: rb_[q] + rl[q]] = True
+
+    def sums_and_halo(mine, vfull):
+        """all-gather of this rank's partial sums + halo exchange of vfull (in place), as one p2p batch"""
+        k = len(mine)
+        got = {rank: np.array(mine, dtype=np.float64)}
+        ops, sb_, hb = [], {}, {}
+        for q in range(P):
+            if q == rank:
+                continue
+            sb_[q] = torch.zeros(k, dtype=torch.float64)
+            ops.append(dist.P2POp(dist.irecv, sb_[q], q))
+            ops.append(dist.P2POp(dist.isend, torch.tensor(mine, dtype=torch.float64), q))
+        for q in range(P):
+            if q == rank:
+                continue
+            if rl[q] > 0:
+                hb[q] = torch.zeros(int(rl[q]), dtype=torch.float64)
+                ops.append(dist.P2POp(dist.irecv, hb[q], q))
+            if sl[q] > 0:
+                ops.append(dist.P2POp(dist.isend, torch.from_numpy(vfull[sb[q]: sb[q] + sl[q]].copy()), q))
+        for w_ in (dist.batch_isend_irecv(ops) if ops else []):
+            w_.wait()
+        for q, t in sb_.items():
+            got[q] = t.numpy()
+        for q, t in hb.items():
+            vfull[rb_[q]: rb_[q] + rl[q]] = t.numpy()
+        tot = np.zeros(k)
+        for q in range(P):                                           # rank-ordered sum, like gdot
+            tot = tot + got[q]
+        return tot
+
+    def plain_steps(k):
+        x, r = x0[b:e].copy(), (bg[b:e] - orc.spmv(loc, window_exchange(x0[b:e])[:n]))
+        p, r0h = r.copy(), r.copy()
+        rho = gdot(r, r0h)
+        for _ in range(k):
+            ap = orc.spmv(loc, window_exchange(p)[:n])               # exchange 1
+            alpha = rho / gdot(ap, r0h)                              # exchange 2
+            s = r - alpha * ap
+            as_ = orc.spmv(loc, window_exchange(s)[:n])              # exchange 3
+            omega = gdot(as_, s) / gdot(as_, as_)                    # exchange 4 (one all-gather of two sums in the library)
+            x = (x + alpha * p) + omega * s
+            r = s - omega * as_
+            rho1 = gdot(r, r0h)                                      # exchange 5
+            beta = rho1 / rho * alpha / omega
+            p = r + beta * (p - omega * ap)
+            rho = rho1
+        return x, r, p
+
+    def ghost_steps(k):
+        nanv = lambda: np.full(S * P, np.nan)                        # noqa: E731  (rows outside own + ghost stay NaN: never read)
+        x = x0[b:e].copy()
+        R, Pv, AP, Sv = nanv(), nanv(), nanv(), nanv()
+        R[b:e] = bg[b:e] - orc.spmv(loc, window_exchange(x0[b:e])[:n])
+        r0h = R[b:e].copy()
+        R[:] = window_exchange(R[b:e])                               # invariant at step start: halo(r), halo(p) valid
+        Pv[:] = R
+        rho = gdot(R[b:e], r0h)
+        for _ in range(k):
+            AP[b:e] = orc.spmv(loc, Pv[:n])
+            alpha = rho / sums_and_halo([orc.dot(AP[b:e], r0h)], AP)[0]          # exchange 1: alpha partials + halo(Ap)
+            Sv[ext] = R[ext] - alpha * AP[ext]
+            as_ = orc.spmv(loc, Sv[:n])
+            omega = gdot(as_, Sv[b:e]) / gdot(as_, as_)                          # exchange 2
+            x = (x + alpha * Pv[b:e]) + omega * Sv[b:e]
+            R[b:e] = Sv[b:e] - omega * as_
+            rho1 = sums_and_halo([orc.dot(R[b:e], r0h)], R)[0]                   # exchange 3: rho partials + halo(r')
+            beta = rho1 / rho * alpha / omega
+            Pv[ext] = R[ext] + beta * (Pv[ext] - omega * AP[ext])
+            rho = rho1
+        return x, R[b:e].copy(), Pv[b:e].copy()
+
+    for a_, g_ in zip(plain_steps(3), ghost_steps(3)):
+        assert np.array_equal(a_, g_), "ghost-row flow must reproduce the plain sharded flow bit for bit"
+
     # sharded transpose SpMV (CGNE, <#): local transposed block -> full-length partial -> sum over ranks -> own shard
     wv = rng.standard_normal(n)
     tl = orc.transpose(loc)                                        # n rows, columns = local row ids

@@ -25,3 +25,20 @@ def test_sharded_path_on_random_banded_matrices(seed, nranks):
     out = subprocess.run([sys.executable, os.path.join(HERE, "_loopback_worker.py"), str(nranks), "fuzz%d" % seed],
                          stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
     assert out.returncode == 0 and f"LOOPBACK_OK {nranks} fuzz{seed}" in out.stdout, out.stdout[-3000:]
+
+
+@pytest.mark.parametrize("kind,nranks", [("laplace", 3), ("banded", 2), ("denseband", 4), ("fuzz2", 3), ("fuzz5", 2), ("random", 2)])
+def test_ghost_row_bicgstab_equals_the_plain_sharded_flow(kind, nranks):
+    """Sharded BiCGSTAB keeps r, p, Ap and s valid on the ghost rows and needs 3 grouped exchanges per step instead of 5
+    (enqueue_bicgstab_ghost).  Every ghost value is computed from the same bits by the same kernel as on its owner, so
+    the solution must be BIT-identical to the plain flow (SLA_BICG_GHOST=0), with the same iteration count.  ("random"
+    uses the all-gather exchange: the ghost flow must step aside there, on every rank alike.)"""
+    got = {}
+    for ghost in ("1", "0"):
+        env = dict(os.environ, SLA_BICG_GHOST=ghost, SLA_DEBUG_EXCHANGE="1")
+        out = subprocess.run([sys.executable, os.path.join(HERE, "_loopback_worker.py"), str(nranks), kind], env=env,
+                             stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+        assert out.returncode == 0 and f"LOOPBACK_OK {nranks} {kind}" in out.stdout, out.stdout[-3000:]
+        got[ghost] = [l for l in out.stdout.splitlines() if l.startswith("XHASH")]
+        assert ("ghost-row BiCGSTAB" in out.stdout) == (ghost == "1" and kind != "random"), out.stdout[-2000:]
+    assert got["1"] and got["1"] == got["0"], got
