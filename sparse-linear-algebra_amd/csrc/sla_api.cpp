@@ -640,7 +640,8 @@ static int csr_upload(sla_ctx *c, int64_t m, int64_t n, int64_t row_begin, int64
         const int64_t P = (n + kLpW - 1) / kLpW;
         const int64_t W = ((n + P - 1) / P + 63) / 64 * 64;   // equal panels (a narrow last panel would be all short segments)
         const size_t rpsz = A->rp64 ? sizeof(int64_t) : sizeof(int32_t);
-        if (P <= 4096 && nnz >= (int64_t)kLpMinSeg * rows * P && (P + 1) * rows * (int64_t)rpsz <= nnz * 12 / 4) {
+        const int64_t min_seg = getenv("SLA_LP_MINSEG") ? atoll(getenv("SLA_LP_MINSEG")) : kLpMinSeg;
+        if (P <= 4096 && nnz >= min_seg * rows * P && (P + 1) * rows * (int64_t)rpsz <= nnz * 12 / 4) {
             std::vector<int64_t> pp((size_t)((P + 1) * rows));
             par_rows(rows, 1, [&](int, int64_t lo, int64_t hi) {
                 for (int64_t i = lo; i < hi; ++i) {
@@ -667,6 +668,14 @@ static int csr_upload(sla_ctx *c, int64_t m, int64_t n, int64_t row_begin, int64
             const int64_t C = (rows + chunk - 1) / chunk;
             A->lp_P = (int32_t)P;
             A->lp_W = (int32_t)W;
+            {   // lanes per segment ~ half the mean segment length (so that two strided loads cover a typical segment)
+                const int64_t seg = nnz / (rows * P);
+                // measured, 200 k rows x 13 panels, ms per (#>) [64 / 32 / 16 / 8 lanes]: segment 153: 0.90 / 1.15 / 1.33 / 1.80;
+                // 92: 0.68 / 0.73 / 0.87 / 1.15; 61: 0.65 / 0.52 / 0.59 / 0.77; 30: 0.61 / 0.36 / 0.36 / 0.43; 15: 0.58 / 0.32 /
+                // 0.26 / 0.27 (stream kernel: 2.21 / 1.39 / 1.07 / 0.56 / 0.28)
+                A->lp_cfg = seg >= 80 ? 0 : seg >= 40 ? 1 : 2;
+                if (const char *e = getenv("SLA_LP_CFG")) A->lp_cfg = std::max(0, std::min(3, atoi(e)));
+            }
             int64_t clo = n, chi = -1;
             for (int64_t i = 0; i < rows; ++i)
                 if (rowptr[i + 1] > rowptr[i]) {   // canonical CSR: first / last entry of a row are its min / max column

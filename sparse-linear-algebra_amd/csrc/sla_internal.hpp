@@ -40,7 +40,7 @@ constexpr int kLpBlock = 1024;       // its workgroup: 16 wavefronts, one per CU
 #define SLA_LP_ROWS 2
 #endif
 constexpr int kLpRowsInFlight = SLA_LP_ROWS;   // (row, panel) segments a wavefront of spmv_lpanel_kernel keeps in flight (2: 0.900 ms, 3: 0.910, 4: 0.926)
-constexpr int kLpMinSeg = 24;        // mean entries per (row, panel) segment below which the form is not worth it
+constexpr int kLpMinSeg = 16;        // mean entries per (row, panel) segment below which the stream kernel wins (tiny segments waste sectors)
 constexpr int kVdMaxRowNnz = 31;     // longest row the value-indexed kernel takes (256 rows x 31 B of codes fit its LDS stage)
 constexpr int kWaveRowMax = 16384;   // rows of 1025..16384 entries: one wavefront each, 4 per row block; longer: whole workgroup
 constexpr int kMaxParts = 2048;      // partial-sum slots per reduction (256 CUs x 8)
@@ -228,6 +228,7 @@ struct sla_csr {
     int32_t lp_G = 0;
     double *d_lpy = nullptr;         // P x rows partial sums, summed in ascending panel order by lpanel_finish_kernel
     bool use_lpanel = false;
+    int32_t lp_cfg = 0;              // lane-group shape of spmv_lpanel_kernel (0: 64 lanes per segment ... 3: 8 lanes)
     int32_t lp_P = 0, lp_W = 0, lp_C = 0, lp_chunk = 0;   // panels, columns per panel, row chunks per panel, rows per chunk
     bool use_wdia = false;
     int32_t nslices = 0;

@@ -1729,15 +1729,20 @@ __global__ void __launch_bounds__(kBlock, VV ? kWdBlocksPerCuVV : kWdBlocksPerCu
 // in ascending order, two segments in flight per wavefront -- into per-panel partial sums.  Tasks (panel, row chunk)
 // are dealt out panel-major in contiguous runs of equal entry counts (task_begin), so a workgroup reloads x about once.  lpanel_finish_kernel then
 // adds the partials of a row in ascending panel order and runs the fused epilogue.
-template <typename RP>
+template <typename RP, int L, int R, int J>
 __global__ void __launch_bounds__(kLpBlock) spmv_lpanel_kernel(const RP *__restrict__ pp, const int32_t *__restrict__ col,
                                                                const double *__restrict__ val, const double *__restrict__ xg,
                                                                double *__restrict__ ypart, const int32_t *__restrict__ task_begin,
                                                                int rows, int n, int W, int chunk_rows, int C, int col_lo, int col_hi,
                                                                const SolverScalars *sc) {
+    // L lanes per (row, panel) segment, R segments per lane group and round, J strided loads per segment and round: a
+    // wavefront keeps (64 / L) * R segments = 64 * R * J entries in flight.  A round costs a memory round trip however
+    // little it carries (measured: ~0.9 us), so short segments get narrow groups -- see the table at the launch.
     extern __shared__ double lp_xs[];
     if (sc && sc->done) return;
     const int tid = threadIdx.x, wv = tid >> 6, ln = tid & 63;
+    constexpr int GW = 64 / L, GPB = (kLpBlock / 64) * GW;   // lane groups per wavefront / per workgroup
+    const int gid = wv * GW + ln / L, gl = ln % L;
     const int t0 = task_begin[blockIdx.x], t1 = task_begin[blockIdx.x + 1];
     int curp = -1;
     for (int t = t0; t < t1; ++t) {
@@ -1755,56 +1760,60 @@ __global__ void __launch_bounds__(kLpBlock) spmv_lpanel_kernel(const RP *__restr
         const int lo = c * chunk_rows, hi = min(rows, lo + chunk_rows);
         const RP *ps = pp + (int64_t)p * rows, *pe = ps + rows;
         double *yp = ypart + (int64_t)p * rows;
-        constexpr int kWaves = kLpBlock / 64;
-        constexpr int R = kLpRowsInFlight;
-        for (int i0 = lo + wv; i0 < hi; i0 += R * kWaves) {
-            // R segments per wavefront at a time: a segment is short (~ nnz_row / panels entries), one alone leaves the
-            // wavefront waiting out a memory round trip per row
-            const int ibase = __builtin_amdgcn_readfirstlane(i0);
+        for (int base = lo; base < hi; base += R * GPB) {   // (wavefront-uniform trip count)
+            // (fetching the next round's segment pointers a round ahead was tried: no gain where each shape is used)
             RP k[R], e[R];
             double acc[R];
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                const int i = ibase + r * kWaves;
+                int i = base + r * GPB + gid;
+                if constexpr (L == 64) i = __builtin_amdgcn_readfirstlane(i);   // one segment per wavefront: scalar pointer loads
                 const bool has = i < hi;
-                k[r] = (has ? ps[i] : 0) + ln;
+                k[r] = (has ? ps[i] : 0) + gl;
                 e[r] = has ? pe[i] : 0;
                 acc[r] = 0.0;
             }
             bool more = true;
             while (more) {
-                int32_t cj[R][4];
-                double vj[R][4];
-                // all loads of the round in flight before the first use (<= 256 entries per segment and round)
+                int32_t cj[R][J];
+                double vj[R][J];
+                // all loads of the round in flight before the first use
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        if (k[r] + 64 * j < e[r]) {
-                            cj[r][j] = __builtin_nontemporal_load(col + k[r] + 64 * j);
-                            vj[r][j] = __builtin_nontemporal_load(val + k[r] + 64 * j);
+                    for (int j = 0; j < J; ++j) {
+                        if (k[r] + L * j < e[r]) {
+                            cj[r][j] = __builtin_nontemporal_load(col + k[r] + L * j);
+                            vj[r][j] = __builtin_nontemporal_load(val + k[r] + L * j);
                         }
                     }
                 }
-                more = false;
+                bool mine = false;
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        if (k[r] + 64 * j < e[r]) {
+                    for (int j = 0; j < J; ++j) {
+                        if (k[r] + L * j < e[r]) {
                             const double prod = vj[r][j] * lp_xs[cj[r][j] - w0];
                             acc[r] = acc[r] + prod;
                         }
                     }
-                    k[r] += 256;
-                    more |= __builtin_amdgcn_readfirstlane(k[r] - ln) < e[r];   // (uniform: the segment's next base)
+                    k[r] += L * J;
+                    mine |= k[r] - gl < e[r];   // (the segment's next base: uniform over the lane group)
                 }
+                more = __builtin_amdgcn_ballot_w64(mine) != 0;
             }
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                const int i = ibase + r * kWaves;
-                const double sum = wave_sum(acc[r]);
-                if (ln == 0 && i < hi) yp[i] = sum;
+                const int i = base + r * GPB + gid;
+                double sum = acc[r];
+                if constexpr (L == 64) {
+                    sum = wave_sum(sum);
+                } else {
+#pragma unroll
+                    for (int off = L / 2; off > 0; off >>= 1) sum = sum + __shfl_xor(sum, off, 64);
+                }
+                if (gl == 0 && i < hi) yp[i] = sum;
             }
         }
     }
@@ -1950,15 +1959,28 @@ static int launch_spmv_t(const sla_csr *A, const SpmvLaunch &l) {
     const int grid = spmv_grid(A);
     ProfScope prof(c, l.kernel_id);
     if (A->use_lpanel && c->lpanel && c->spmv_algo == 0 && !l.x2 && !l.yinit) {
-        const int attr_bit = std::is_same<RP, int32_t>::value ? 1 : 2;   // per context = per device: 128 KiB of dynamic LDS
-        if (!(c->lp_attr & attr_bit)) {
-            SLA_HIP_TRY(hipFuncSetAttribute((const void *)spmv_lpanel_kernel<RP>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                            (int)(kLpW * sizeof(double))));
-            c->lp_attr |= attr_bit;
+        // lane-group shape by mean segment length (A->lp_cfg, set at lowering): 64 lanes x 2 segments x 4 loads for long
+        // segments, narrower groups with more segments per wavefront for short ones
+#define SLA_LP_LAUNCH(CFG, L_, R_, J_)                                                                                         \
+        case CFG: {                                                                                                             \
+            const int attr_bit = 1 << (2 * CFG + (std::is_same<RP, int32_t>::value ? 0 : 1));                                   \
+            if (!(c->lp_attr & attr_bit)) {   /* per context = per device: 128 KiB of dynamic LDS */                            \
+                SLA_HIP_TRY(hipFuncSetAttribute((const void *)spmv_lpanel_kernel<RP, L_, R_, J_>,                               \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kLpW * sizeof(double))));     \
+                c->lp_attr |= attr_bit;                                                                                         \
+            }                                                                                                                   \
+            hipLaunchKernelGGL((spmv_lpanel_kernel<RP, L_, R_, J_>), dim3(A->lp_G), dim3(kLpBlock), kLpW * sizeof(double),      \
+                               c->stream, (const RP *)A->d_lpp, a.col, a.val, a.x, A->d_lpy, A->d_lpt, a.rows, (int)A->n,       \
+                               A->lp_W, A->lp_chunk, A->lp_C, A->lp_col_lo, A->lp_col_hi, (const SolverScalars *)a.sc);         \
+        } break;
+        switch (A->lp_cfg) {
+            SLA_LP_LAUNCH(1, 32, 4, 2)
+            SLA_LP_LAUNCH(2, 16, 4, 2)
+            SLA_LP_LAUNCH(3, 8, 4, 2)
+            default:
+            SLA_LP_LAUNCH(0, 64, kLpRowsInFlight, 4)
         }
-        hipLaunchKernelGGL((spmv_lpanel_kernel<RP>), dim3(A->lp_G), dim3(kLpBlock), kLpW * sizeof(double), c->stream,
-                           (const RP *)A->d_lpp, a.col, a.val, a.x, A->d_lpy, A->d_lpt, a.rows, (int)A->n, A->lp_W, A->lp_chunk, A->lp_C, A->lp_col_lo, A->lp_col_hi,
-                           (const SolverScalars *)a.sc);
+#undef SLA_LP_LAUNCH
         SLA_HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL((lpanel_finish_kernel<EPI, RP>), dim3(grid), dim3(kBlock), 0, c->stream, a, A->d_lpy, A->lp_P);
         SLA_HIP_TRY(hipGetLastError());

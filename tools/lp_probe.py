@@ -1,5 +1,5 @@
-"""LDS-panel SpMV (spmv_lpanel_kernel) on the 1 %-density matrix: time per (#>) for a few task granularities and
-against the stream kernel.  python tools/lp_probe.py [rows] [half_nnz_per_row]"""
+"""LDS-panel SpMV (spmv_lpanel_kernel) on random matrices with dense rows: time per (#>) of the stream kernel, of the
+default lowering and -- with a third argument -- of every lane-group shape.  python tools/lp_probe.py [rows] [half_nnz_per_row] [sweep]"""
 import os, sys, time
 sys.path.insert(0, "sparse-linear-algebra_amd"); sys.path.insert(0, ".")
 import numpy as np
@@ -12,8 +12,10 @@ dims, (rp, ci, va) = wl.random_spd(rows, k, 42)
 n, nnz = dims[0], len(ci)
 bytes_ = nnz * 12 + (n + 1) * 4 + 2 * n * 8
 x = np.random.default_rng(0).standard_normal(n)
-for env in ({"SLA_LPANEL": "0"}, {}, {"SLA_LP_TASKS": "8"}, {"SLA_LP_TASKS": "64"}, {"SLA_LP_ROWCOST": "0"}):
-    for kk in ("SLA_LPANEL", "SLA_LP_TASKS", "SLA_LP_ROWCOST"):
+SWEEP = ({"SLA_LP_MINSEG": "1", "SLA_LP_CFG": "0"}, {"SLA_LP_MINSEG": "1", "SLA_LP_CFG": "1"}, {"SLA_LP_MINSEG": "1", "SLA_LP_CFG": "2"},
+         {"SLA_LP_MINSEG": "1", "SLA_LP_CFG": "3"}) if len(sys.argv) > 3 else ()
+for env in ({"SLA_LPANEL": "0"}, {}) + SWEEP:
+    for kk in ("SLA_LPANEL", "SLA_LP_TASKS", "SLA_LP_ROWCOST", "SLA_LP_MINSEG", "SLA_LP_CFG"):
         os.environ.pop(kk, None)
     os.environ.update(env)
     ctx = sla.Context(0)
