@@ -55,6 +55,9 @@ CASES = {
     "1 panel, tall 9000 x 3000, 64 per row": lambda: _dense_rows(9000, 3000, 64, 3),
     "ragged rows (0, 1, 3, 80, 320, 700 entries), 2 panels": lambda: _dense_rows(3001, 20000, 80, 4, ragged=True),
     "panel edge: n = 16384 + 1": lambda: _dense_rows(2000, 16385, 200, 5),
+    "fewer rows than one chunk: 7 x 40000, 3000 per row": lambda: _dense_rows(7, 40000, 3000, 6),
+    "one row, one panel: 1 x 500, 400 entries": lambda: _dense_rows(1, 500, 400, 7),
+    "16-lane groups: 5000 x 30000, 40 per row": lambda: _dense_rows(5000, 30000, 40, 8),
 }
 
 
