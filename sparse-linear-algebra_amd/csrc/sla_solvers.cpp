@@ -206,8 +206,53 @@ int enqueue_bicgstab(sla_solver *S, int par, const Parts *check, bool dual_prev)
     return SLA_OK;
 }
 
+// cgsStep on a row slab with ghost rows (see enqueue_bicgstab_ghost): u, p, aap, q and u + q are kept valid on the ghost
+// rows.  halo(aap) travels with the alpha partials, C2 then forms q and u + q on own + ghost rows; halo(r') travels with
+// the rho partials, C4 then forms u' and p' on own + ghost rows.  Two grouped exchanges per step instead of four, same bits.
+static int enqueue_cgs_ghost(sla_solver *S, int par, const Parts *check) {
+    sla_ctx *c = S->ctx;
+    sla_csr *A = S->A;
+    const int64_t n = S->x->n_local, b = S->x->begin;
+    const int64_t gl = S->ghl + (S->ghl & 1), next = n + gl + S->ghr;
+    const int g = spmv_grid(A);
+    Parts apr, rhon;
+    {
+        SpmvLaunch l;  // C1: aap = aa #> p ; aap <.> rhat          (halo(p) is valid: no exchange)
+        l.epi = EPI_DOT;
+        l.x = S->p->d - b;
+        l.y = S->t1->d;
+        l.w = S->r0hat->d;
+        l.p1 = slot(S, P_APR);
+        l.sc = S->d_sc;
+        if (check && check->p) { l.pres = check->p; l.npres = check->n; l.pres_stride = check->stride; }
+        l.step_begin = 1 | (par << 1);
+        l.kernel_id = SLA_KERNEL_SPMV_DOT;
+        SLA_TRY(launch_spmv(A, l));
+        SLA_TRY(publish_with_halo(S, P_APR, -1, g, &apr, nullptr, S->t1));
+    }
+    // (x rides along over the ghost range: its slack holds nothing anybody reads)
+    SLA_TRY(launch_cgs_c2(c, next, S->d_sc, apr, par, Parts{nullptr, 0, 1}, 0, S->u->d - gl, S->t1->d - gl, S->t2->d - gl,
+                          S->t3->d - gl, S->x->d - gl));
+    {
+        SpmvLaunch l;  // C3: rj1 = r ^-^ alphaj .* (aa #> (u ^+^ q)) ; rj1 <.> rhat      (halo(u + q) was computed by C2)
+        l.epi = EPI_AXPY_DOT;
+        l.x = S->t3->d - b;
+        l.z = S->r->d;
+        l.w = S->r0hat->d;
+        l.p1 = slot(S, P_RHO);
+        l.sc = S->d_sc;
+        l.step_begin = par << 1;
+        l.kernel_id = SLA_KERNEL_SPMV_DOT2;
+        SLA_TRY(launch_spmv(A, l));
+        SLA_TRY(publish_with_halo(S, P_RHO, -1, g, &rhon, nullptr, S->r));
+    }
+    SLA_TRY(launch_cgs_c4(c, next, S->d_sc, rhon, par, S->r->d - gl, S->t2->d - gl, S->u->d - gl, S->p->d - gl));
+    return SLA_OK;
+}
+
 // cgsStep (Sparse.hs:928-939)
 int enqueue_cgs(sla_solver *S, int par, const Parts *check, bool dual_prev) {
+    if (S->ghost) return enqueue_cgs_ghost(S, par, check);
     sla_ctx *c = S->ctx;
     sla_csr *A = S->A;
     const int64_t n = S->x->n_local;
@@ -375,8 +420,9 @@ int solver_init_common(int method, sla_csr *A, sla_vec *b, sla_vec *x0, double t
             if ((rc = sla_vec_copy(S->r, S->p)) != SLA_OK) break;
             if (method == SLA_CGS_ && (rc = sla_vec_copy(S->r, S->u)) != SLA_OK) break;
         }
-        if (method == SLA_BICGSTAB_ && c->collectives && c->bicg_ghost) {
-            // ghost-row flow (enqueue_bicgstab_ghost): every rank must take the same decision -- the collectives differ
+        if ((method == SLA_BICGSTAB_ || method == SLA_CGS_) && c->collectives && c->bicg_ghost) {
+            // ghost-row flow (enqueue_bicgstab_ghost / enqueue_cgs_ghost): every rank must take the same decision -- the
+            // collectives differ
             int64_t gl = 0, gr = 0;
             int not_ok = (A->m == A->n && S->r->shard == S->p->shard && halo_inplace_extents(A, S->p, &gl, &gr)) ? 0 : 1;
             if ((rc = dist_allreduce_max_i32(c, &not_ok)) != SLA_OK) break;
@@ -385,10 +431,11 @@ int solver_init_common(int method, sla_csr *A, sla_vec *b, sla_vec *x0, double t
                 S->ghl = gl;
                 S->ghr = gr;
                 if (getenv("SLA_DEBUG_EXCHANGE"))
-                    fprintf(stderr, "[sla] rank %d: ghost-row BiCGSTAB, %lld + %lld ghost rows\n", c->rank, (long long)gl, (long long)gr);
-                // halo(r0), halo(p0): the invariant every step starts from
-                if ((rc = dist_exchange_window(c, *A->xplan, S->r->d, S->r->begin, S->r->n_local, S->r->d - S->r->begin)) != SLA_OK) break;
+                    fprintf(stderr, "[sla] rank %d: ghost-row %s, %lld + %lld ghost rows\n", c->rank, method == SLA_CGS_ ? "CGS" : "BiCGSTAB", (long long)gl, (long long)gr);
+                // halo(p0) and halo(r0) (BiCGSTAB) / halo(u0) (CGS): the invariant every step starts from
+                sla_vec *second = method == SLA_CGS_ ? S->u : S->r;
                 if ((rc = dist_exchange_window(c, *A->xplan, S->p->d, S->p->begin, S->p->n_local, S->p->d - S->p->begin)) != SLA_OK) break;
+                if ((rc = dist_exchange_window(c, *A->xplan, second->d, second->begin, second->n_local, second->d - second->begin)) != SLA_OK) break;
             }
         }
         // rho = r0 . r0hat = r0 . r0 ; r0norm = sqrt (r0 . r0)

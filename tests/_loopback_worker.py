@@ -178,6 +178,6 @@ assert (results[0]["gmres"][2] & 1) == 1 and np.linalg.norm(orc.spmv(Ao, xgm) - 
 if KIND in ("dense", "denseband"):
     assert all("ldspanels" in results[r]["kernel"] for r in range(P)), results[0]["kernel"]
 import hashlib  # noqa: E402
-print("XHASH", hashlib.sha1(np.concatenate([results[r]["bicgstab"][0] for r in range(P)]).tobytes()).hexdigest(),
-      results[0]["bicgstab"][1])
+for _m in ("bicgstab", "cgs"):
+    print("XHASH", _m, hashlib.sha1(np.concatenate([results[r][_m][0] for r in range(P)]).tobytes()).hexdigest(), results[0][_m][1])
 print("LOOPBACK_OK", P, KIND, results[0]["kernel"].split()[0])

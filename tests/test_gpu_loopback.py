@@ -28,9 +28,9 @@ def test_sharded_path_on_random_banded_matrices(seed, nranks):
 
 
 @pytest.mark.parametrize("kind,nranks", [("laplace", 3), ("banded", 2), ("denseband", 4), ("fuzz2", 3), ("fuzz5", 2), ("random", 2)])
-def test_ghost_row_bicgstab_equals_the_plain_sharded_flow(kind, nranks):
+def test_ghost_row_bicgstab_and_cgs_equal_the_plain_sharded_flow(kind, nranks):
     """Sharded BiCGSTAB keeps r, p, Ap and s valid on the ghost rows and needs 3 grouped exchanges per step instead of 5
-    (enqueue_bicgstab_ghost).  Every ghost value is computed from the same bits by the same kernel as on its owner, so
+    (enqueue_bicgstab_ghost); CGS likewise 2 instead of 4 (enqueue_cgs_ghost).  Every ghost value is computed from the same bits by the same kernel as on its owner, so
     the solution must be BIT-identical to the plain flow (SLA_BICG_GHOST=0), with the same iteration count.  ("random"
     uses the all-gather exchange: the ghost flow must step aside there, on every rank alike.)"""
     got = {}
@@ -40,5 +40,7 @@ def test_ghost_row_bicgstab_equals_the_plain_sharded_flow(kind, nranks):
                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
         assert out.returncode == 0 and f"LOOPBACK_OK {nranks} {kind}" in out.stdout, out.stdout[-3000:]
         got[ghost] = [l for l in out.stdout.splitlines() if l.startswith("XHASH")]
-        assert ("ghost-row BiCGSTAB" in out.stdout) == (ghost == "1" and kind != "random"), out.stdout[-2000:]
+        for name in ("ghost-row BiCGSTAB", "ghost-row CGS"):
+            assert (name in out.stdout) == (ghost == "1" and kind != "random"), out.stdout[-2000:]
+    assert len(got["1"]) == 2
     assert got["1"] and got["1"] == got["0"], got
