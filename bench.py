@@ -321,6 +321,15 @@ def main():
             "config": {"workload": desc, "rows": n, "nnz": nnz, "timed": mode_desc,
                        "index_types": "i32 col / i32 rowptr", "parallelism": f"row-block x{world}",
                        "spmv_kernel": A.kernel_info()},
+        }
+        if use_dist:   # what the sharded step exchanges
+            kinfo_x = A.kernel_info()
+            ghost = ("x_exchange=window" in kinfo_x and os.environ.get("SLA_BICG_GHOST", "1") != "0" and args.mode == "step")
+            rec["config"]["exchange"] = (
+                ("halo (window) send/recv received in place" if "x_exchange=window" in kinfo_x else "all-gather of x")
+                + (f"; ghost-row {args.method}: {3 if args.method == 'bicgstab' else 2} grouped exchanges per step" if ghost
+                   else "; plain flow"))
+        rec.update({
             "step_gbps": step_bytes / (dt / args.steps) / 1e9 / 1.0,
             "step_frac_of_hbm_peak": step_bytes / (dt / args.steps) / 1e9 / (HBM_PEAK_GBS * world),
             "spmv_gbps": spmv_bytes_local * world / (sp_mean_ms * 1e-3) / 1e9 if sp_launch else None,
@@ -341,7 +350,7 @@ def main():
                          "traffic": None, "hbm_achieved": None, "hbm_frac": None,
                          "bytes_per_launch": k1_bytes, "avg_launch_ms": mean_ms, "min_launch_ms": min_ms,
                          "launches_timed": launches},
-        }
+        })
         # HBM traffic of the dominant kernel: measured with PMC counters in separate rocprofv3 passes
         # (bench.py cannot collect counters on itself) and committed under profiles/
         try:
