@@ -288,7 +288,7 @@ static int csr_upload(sla_ctx *c, int64_t m, int64_t n, int64_t row_begin, int64
     A->rows = rows;
     A->nnz = nnz;
     // (SLA_FORCE_RP64=1: test hook -- run the 64-bit row-pointer instantiations of the kernels on small matrices)
-    A->rp64 = nnz > (int64_t)std::numeric_limits<int32_t>::max() || (getenv("SLA_FORCE_RP64") && atoi(getenv("SLA_FORCE_RP64")));
+    A->rp64 = nnz > (int64_t)std::numeric_limits<int32_t>::max() || c->force_rp64 != 0;
     std::vector<int32_t> rb;
     build_row_blocks(rows, rowptr, rb, A->max_row_nnz, c->row_align, c->rb_nnz);
     A->nrb = (int32_t)rb.size() - 1;
@@ -641,7 +641,7 @@ static int csr_upload(sla_ctx *c, int64_t m, int64_t n, int64_t row_begin, int64
         const int64_t P = (n + kLpW - 1) / kLpW;
         const int64_t W = ((n + P - 1) / P + 63) / 64 * 64;   // equal panels (a narrow last panel would be all short segments)
         const size_t rpsz = A->rp64 ? sizeof(int64_t) : sizeof(int32_t);
-        const int64_t min_seg = getenv("SLA_LP_MINSEG") ? atoll(getenv("SLA_LP_MINSEG")) : kLpMinSeg;
+        const int64_t min_seg = c->lp_min_seg;
         if (P <= 4096 && nnz >= min_seg * rows * P && (P + 1) * rows * (int64_t)rpsz <= nnz * 12 / 4) {
             std::vector<int64_t> pp((size_t)((P + 1) * rows));
             par_rows(rows, 1, [&](int, int64_t lo, int64_t hi) {
@@ -663,7 +663,7 @@ static int csr_upload(sla_ctx *c, int64_t m, int64_t n, int64_t row_begin, int64
             if (err == hipSuccess) err = hipMalloc((void **)&A->d_lpy, sizeof(double) * (size_t)(P * rows));
             // row chunks: ~32 tasks per workgroup of the persistent grid (measured: 8 -> 0.936 ms, 32 -> 0.900 ms, 64 ->
             // 0.902 ms on the 200k-row 1 % matrix), at least 64 rows (4 per wavefront) each
-            const int tasks_per_cu = getenv("SLA_LP_TASKS") ? std::max(1, atoi(getenv("SLA_LP_TASKS"))) : 32;
+            const int tasks_per_cu = std::max(1, c->lp_tasks);
             const int64_t want = std::max<int64_t>(1, (tasks_per_cu * (int64_t)c->n_cu + P - 1) / P);
             const int64_t chunk = std::max<int64_t>(64, (rows + want - 1) / want);
             const int64_t C = (rows + chunk - 1) / chunk;
@@ -675,7 +675,7 @@ static int csr_upload(sla_ctx *c, int64_t m, int64_t n, int64_t row_begin, int64
                 // 92: 0.68 / 0.73 / 0.87 / 1.15; 61: 0.65 / 0.52 / 0.59 / 0.77; 30: 0.61 / 0.36 / 0.36 / 0.43; 15: 0.58 / 0.32 /
                 // 0.26 / 0.27 (stream kernel: 2.21 / 1.39 / 1.07 / 0.56 / 0.28)
                 A->lp_cfg = seg >= 80 ? 0 : seg >= 40 ? 1 : 2;
-                if (const char *e = getenv("SLA_LP_CFG")) A->lp_cfg = std::max(0, std::min(3, atoi(e)));
+                if (c->lp_cfg >= 0) A->lp_cfg = std::min(3, c->lp_cfg);
             }
             int64_t clo = n, chi = -1;
             for (int64_t i = 0; i < rows; ++i)
@@ -692,7 +692,7 @@ static int csr_upload(sla_ctx *c, int64_t m, int64_t n, int64_t row_begin, int64
             const int G = (int)std::min<int64_t>(ntasks, c->n_cu);
             // (a segment costs a memory round trip however short it is -- with entries alone balanced, workgroups holding
             // 34-entry segments took 2.4x as long as those with 154-entry ones: weigh a row like row_cost entries)
-            const int64_t row_cost = getenv("SLA_LP_ROWCOST") ? atoll(getenv("SLA_LP_ROWCOST")) : 256;
+            const int64_t row_cost = c->lp_rowcost;
             std::vector<int64_t> upto((size_t)ntasks + 1, 0);   // weight before task t
             for (int64_t t = 0; t < ntasks; ++t) {   // (panel-major; row-chunk-major was tried: 0.906 -> 0.971 ms, x reloaded per task)
                 const int64_t p = t / C, cc = t % C;
@@ -830,6 +830,11 @@ static int ctx_create_common(int device_id, int rank, int nranks, const void *ui
     if (const char *s = getenv("SLA_VDICT")) c->vdict = atoi(s);
     if (const char *s = getenv("SLA_WDIA")) c->wdia = atoi(s);
     if (const char *s = getenv("SLA_LPANEL")) c->lpanel = atoi(s);
+    if (const char *s = getenv("SLA_LP_MINSEG")) c->lp_min_seg = std::max(1, atoi(s));
+    if (const char *s = getenv("SLA_LP_TASKS")) c->lp_tasks = atoi(s);
+    if (const char *s = getenv("SLA_LP_CFG")) c->lp_cfg = atoi(s);
+    if (const char *s = getenv("SLA_LP_ROWCOST")) c->lp_rowcost = std::max(0, atoi(s));
+    if (const char *s = getenv("SLA_FORCE_RP64")) c->force_rp64 = atoi(s);
     if (const char *s = getenv("SLA_BICG_GHOST")) c->bicg_ghost = atoi(s);
     if (const char *s = getenv("SLA_WD_TILE")) c->wd_tile = atoi(s);
     if (const char *s = getenv("SLA_WDIA_VV")) c->wdia_vv = atoi(s);

@@ -149,6 +149,8 @@ struct sla_ctx {
     int n_cu = 256;                  // compute units of the device (persistent grids)
     int bicg_ghost = 1;              // sharded BiCGSTAB keeps ghost rows: 3 grouped exchanges per step instead of 5 (SLA_BICG_GHOST=0: plain flow)
     int lp_attr = 0;                 // spmv_lpanel_kernel<i32 / i64> had its dynamic-LDS limit raised on this device (bits 0 / 1)
+    int lp_min_seg = sla::kLpMinSeg, lp_tasks = 32, lp_cfg = -1, lp_rowcost = 256;   // its tuning knobs (SLA_LP_MINSEG / _TASKS / _CFG / _ROWCOST)
+    int force_rp64 = 0;              // test hook: 64-bit row pointers at any size (SLA_FORCE_RP64)
     int lpanel = 1;                  // allow the LDS-panel SpMV kernel for matrices with dense rows (SLA_LPANEL=0 disables)
     int xwin = 1;                    // allow the LDS x-window SpMV kernel (SLA_XWIN=0 disables)
     int dual_spmv = 1;               // linSolve0: fuse the true-residual SpMV into the next K1 (SLA_DUAL_SPMV=0 disables)
