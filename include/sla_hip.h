@@ -242,7 +242,7 @@ int sla_prof_stop(sla_ctx_t, int *launches, double *mean_ms, double *min_ms);
 /* name of the SpMV form picked for A at lowering time and its launch geometry: "wdia" (wave-sliced (offset, value)
  * records: constant-coefficient stencils), "vdict[+xwin]" (one byte per entry), "stream+diagdict[+xwin]" (values +
  * 1-byte column codes), "stream[+xwin]" (values + i32 columns), "stream+ldspanels" (dense rows: x in LDS panels), "stream+colpanels" (irregular,
- * x > L2), "scalar" */
+ * x > L2), "scalar"; row-sharded matrices add " x_exchange=window|allgather" */
 int sla_csr_kernel_info(sla_csr_t, char *buf, int buflen);
 
 /* ---- row-sharded exchange planning (pure host arithmetic, no GPU needed) ------------------------------ */
