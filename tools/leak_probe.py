@@ -10,6 +10,7 @@ def free():
     torch.cuda.synchronize(); return torch.cuda.mem_get_info()[0] / 1e6
 dims, (rp, ci, va) = wl.laplace3d(60, 60, 60)
 dimsb, (rpb, cib, vab) = wl.banded_nonsym(200000)
+dimsd, (rpd, cid, vad) = wl.random_spd(20000, 60, 3)      # ~120 entries per row: LDS-panel form (table, partials, task runs)
 n = dims[0]
 b = np.ones(n)
 f0 = None
@@ -22,7 +23,10 @@ for it in range(60):
     t = sla.triLowerSolve(A, sla.DeviceVector(ctx, n, b))
     g = sla.gmres(B, sla.fromVector(np.ones(dimsb[0]), ctx), sla.fromVector(np.zeros(dimsb[0]), ctx), restart=10)
     L, R = sla.mSsorPre(A, 1.0)
-    del A, B, x, y, t, g, L, R
+    D = sla.fromCSR(dimsd, rpd, cid, vad, ctx)
+    assert "ldspanels" in D.kernel_info()
+    xd = sla.linSolve0(sla.CGNE_, D, sla.fromVector(np.ones(dimsd[0]), ctx), sla.fromVector(np.zeros(dimsd[0]), ctx))
+    del A, B, x, y, t, g, L, R, D, xd
     ctx.close()
     if it == 5: f0 = free()
 print("free MB after warm-up:", f0, "at end:", free(), "delta:", f0 - free())
