@@ -210,6 +210,51 @@ def main():
     for a_, g_ in zip(plain_steps(3), ghost_steps(3)):
         assert np.array_equal(a_, g_), "ghost-row flow must reproduce the plain sharded flow bit for bit"
 
+    # ---- ghost-row CGS (enqueue_cgs_ghost): 2 exchanges per step instead of 4 ------------------------------------------
+    def cgs_plain(k):
+        x, r = x0[b:e].copy(), (bg[b:e] - orc.spmv(loc, window_exchange(x0[b:e])[:n]))
+        p, u, rh = r.copy(), r.copy(), r.copy()
+        rho = gdot(r, rh)
+        for _ in range(k):
+            aap = orc.spmv(loc, window_exchange(p)[:n])              # exchange 1
+            alpha = rho / gdot(aap, rh)                              # exchange 2
+            q = u - alpha * aap
+            uq = u + q
+            x = x + alpha * uq
+            r = r - alpha * orc.spmv(loc, window_exchange(uq)[:n])   # exchange 3
+            rho1 = gdot(r, rh)                                       # exchange 4
+            beta = rho1 / rho
+            u = r + beta * q
+            p = u + beta * (q + beta * p)
+            rho = rho1
+        return x, r, p, u
+
+    def cgs_ghost(k):
+        nanv = lambda: np.full(S * P, np.nan)                        # noqa: E731
+        x = x0[b:e].copy()
+        R, Pv, U, AAP, Q, UQ = nanv(), nanv(), nanv(), nanv(), nanv(), nanv()
+        R[b:e] = bg[b:e] - orc.spmv(loc, window_exchange(x0[b:e])[:n])
+        rh = R[b:e].copy()
+        Pv[:] = window_exchange(R[b:e])                              # invariant at step start: halo(p), halo(u) valid
+        U[:] = Pv
+        rho = gdot(R[b:e], rh)
+        for _ in range(k):
+            AAP[b:e] = orc.spmv(loc, Pv[:n])
+            alpha = rho / sums_and_halo([orc.dot(AAP[b:e], rh)], AAP)[0]         # exchange 1: alpha partials + halo(aap)
+            Q[ext] = U[ext] - alpha * AAP[ext]
+            UQ[ext] = U[ext] + Q[ext]
+            x = x + alpha * UQ[b:e]
+            R[b:e] = R[b:e] - alpha * orc.spmv(loc, UQ[:n])
+            rho1 = sums_and_halo([orc.dot(R[b:e], rh)], R)[0]                    # exchange 2: rho partials + halo(r')
+            beta = rho1 / rho
+            U[ext] = R[ext] + beta * Q[ext]
+            Pv[ext] = U[ext] + beta * (Q[ext] + beta * Pv[ext])
+            rho = rho1
+        return x, R[b:e].copy(), Pv[b:e].copy(), U[b:e].copy()
+
+    for a_, g_ in zip(cgs_plain(3), cgs_ghost(3)):
+        assert np.array_equal(a_, g_), "ghost-row CGS must reproduce the plain sharded flow bit for bit"
+
     # sharded transpose SpMV (CGNE, <#): local transposed block -> full-length partial -> sum over ranks -> own shard
     wv = rng.standard_normal(n)
     tl = orc.transpose(loc)                                        # n rows, columns = local row ids
