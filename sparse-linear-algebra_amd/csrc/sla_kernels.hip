@@ -60,7 +60,18 @@ __device__ __forceinline__ double block_sum(double v, double *s4) {
 // fixed-order re-reduction of a partial array written by an EARLIER kernel
 __device__ __forceinline__ double reduce_parts(const double *p, int n, int stride, double *s4) {
     double a = 0.0;
-    for (int i = threadIdx.x; i < n; i += kBlock) a += p[(int64_t)i * stride];
+    if (n > 0 && n <= 8 * kBlock) {
+        // the usual case (<= 2048 partials): all eight loads of a thread in flight at once instead of a chain of
+        // dependent round trips at the head of every consumer kernel; same additions in the same order
+        double v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = p[(int64_t)min((int)threadIdx.x + j * kBlock, n - 1) * stride];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if ((int)threadIdx.x + j * kBlock < n) a += v[j];
+    } else {
+        for (int i = threadIdx.x; i < n; i += kBlock) a += p[(int64_t)i * stride];
+    }
     return block_sum(a, s4);
 }
 
