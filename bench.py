@@ -324,11 +324,12 @@ def main():
         }
         if use_dist:   # what the sharded step exchanges
             kinfo_x = A.kernel_info()
-            ghost = ("x_exchange=window" in kinfo_x and os.environ.get("SLA_BICG_GHOST", "1") != "0" and args.mode == "step")
+            ghost = ("x_exchange=window" in kinfo_x and os.environ.get("SLA_BICG_GHOST", "1") != "0" and args.mode in ("step", "linsolve0"))
             rec["config"]["exchange"] = (
                 ("halo (window) send/recv received in place" if "x_exchange=window" in kinfo_x else "all-gather of x")
-                + (f"; ghost-row {args.method}: {3 if args.method == 'bicgstab' else 2} grouped exchanges per step" if ghost
-                   else "; plain flow"))
+                + (f"; ghost-row {args.method}: {3 if args.method == 'bicgstab' else 2} grouped exchanges per step"
+                   + (" + the residual sweep's own exchange and sum" if args.mode == "linsolve0" else "") if ghost
+                   else ("; plain flow" if args.mode != "gmres" else "; Arnoldi: one exchange per SpMV, per-column sums all-gathered")))
         rec.update({
             "step_gbps": step_bytes / (dt / args.steps) / 1e9 / 1.0,
             "step_frac_of_hbm_peak": step_bytes / (dt / args.steps) / 1e9 / (HBM_PEAK_GBS * world),
