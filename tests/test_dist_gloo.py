@@ -8,7 +8,7 @@ import pytest
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-@pytest.mark.parametrize("nproc", [2, 3])
+@pytest.mark.parametrize("nproc", [2, 3, 4])
 def test_row_sharded_algorithm_on_gloo(nproc):
     port = 29600 + nproc
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
