@@ -27,7 +27,7 @@ def test_sharded_path_on_random_banded_matrices(seed, nranks):
     assert out.returncode == 0 and f"LOOPBACK_OK {nranks} fuzz{seed}" in out.stdout, out.stdout[-3000:]
 
 
-@pytest.mark.parametrize("kind,nranks", [("laplace", 3), ("banded", 2), ("denseband", 4), ("fuzz2", 3), ("fuzz5", 2), ("random", 2)])
+@pytest.mark.parametrize("kind,nranks", [("laplace", 3), ("laplace", 8), ("banded", 2), ("denseband", 4), ("fuzz2", 3), ("fuzz5", 2), ("random", 2)])
 def test_ghost_row_bicgstab_and_cgs_equal_the_plain_sharded_flow(kind, nranks):
     """Sharded BiCGSTAB keeps r, p, Ap and s valid on the ghost rows and needs 3 grouped exchanges per step instead of 5
     (enqueue_bicgstab_ghost); CGS likewise 2 instead of 4 (enqueue_cgs_ghost).  Every ghost value is computed from the same bits by the same kernel as on its owner, so
