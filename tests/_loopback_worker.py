@@ -54,6 +54,8 @@ def gen(b=0, e=None):
         return dims, local_rows_of(rp, ci, va, b, dims[0] if e is None else e)
     if KIND == "tiny":                                   # 5 rows: with 3 or 4 ranks the last rank owns one row or none
         return wl.laplace3d(5, 1, 1, b, e)
+    if KIND == "tinyband":                               # 17-row tridiagonal: on 16 ranks seven of them own nothing, yet the
+        return wl.laplace3d(17, 1, 1, b, e)              # exchange is the window kind (one element from each neighbour)
     if KIND == "laplace":
         return wl.laplace3d(14, 11, 13, b, e)            # window exchange (slab stencil), dictionary codes
     if KIND == "banded":

@@ -27,13 +27,14 @@ def test_sharded_path_on_random_banded_matrices(seed, nranks):
     assert out.returncode == 0 and f"LOOPBACK_OK {nranks} fuzz{seed}" in out.stdout, out.stdout[-3000:]
 
 
-@pytest.mark.parametrize("kind,nranks", [("laplace", 3), ("laplace", 8), ("tiny", 4), ("banded", 2), ("denseband", 4), ("fuzz2", 3), ("fuzz5", 2), ("random", 2)])
+@pytest.mark.parametrize("kind,nranks", [("laplace", 3), ("laplace", 8), ("tiny", 4), ("tinyband", 16), ("banded", 2), ("denseband", 4), ("fuzz2", 3), ("fuzz5", 2), ("random", 2)])
 def test_ghost_row_bicgstab_and_cgs_equal_the_plain_sharded_flow(kind, nranks):
     """Sharded BiCGSTAB keeps r, p, Ap and s valid on the ghost rows and needs 3 grouped exchanges per step instead of 5
     (enqueue_bicgstab_ghost); CGS likewise 2 instead of 4 (enqueue_cgs_ghost).  Every ghost value is computed from the same bits by the same kernel as on its owner, so
     the solution must be BIT-identical to the plain flow (SLA_BICG_GHOST=0), with the same iteration count.  ("random" and the
     5-row "tiny" matrix -- whose last rank owns no row at all -- use the all-gather exchange: the ghost flow must step aside
-    there, on every rank alike.)"""
+    there, on every rank alike.  "tinyband": 17 tridiagonal rows on 16 ranks, seven of them without rows, window exchange
+    with ONE ghost row per side -- the odd count that the extended kernels round up to keep their 16-byte pairs aligned.)"""
     got = {}
     for ghost in ("1", "0"):
         env = dict(os.environ, SLA_BICG_GHOST=ghost, SLA_DEBUG_EXCHANGE="1")
