@@ -78,10 +78,49 @@ def banded_nonsym(n, seed=99, row_begin=0, row_end=None):
     return (n, n), _stencil_rows(row_begin, row_end, offsets, valid, value)
 
 
+_WLGEN = None
+
+
+def _wlgen():
+    """libsla_wlgen.so (csrc/sla_wlgen.c): counting-sort assembly of the same matrix in seconds instead of the
+    minutes two global numpy argsorts take at n = 10 M.  None when it has not been built."""
+    global _WLGEN
+    if _WLGEN is None:
+        import ctypes as C
+        import os
+        so = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "lib", "libsla_wlgen.so")
+        if not os.path.exists(so):
+            _WLGEN = False
+        else:
+            L = C.CDLL(so)
+            L.sla_wl_random_spd.restype = C.c_int64
+            L.sla_wl_random_spd.argtypes = [C.c_int64, C.c_int64] + [C.c_void_p] * 5
+            _WLGEN = L
+    return _WLGEN or None
+
+
 def random_spd(n, k=16, seed=42):
     """Config 3a: symmetric, strictly diagonally dominant random matrix: k off-diagonal picks per row
     (value U(-1,1)), symmetrised over the union pattern, diagonal = 1 + sum |offdiag|  => SPD,
     ~2k+1 entries per row.  Returns the full CSR (not row-range aware)."""
+    L = _wlgen()
+    if L is None:
+        return random_spd_numpy(n, k, seed)
+    rng = np.random.Generator(np.random.PCG64(seed))
+    c = rng.integers(0, n, size=n * k, dtype=np.int64)
+    v = rng.uniform(-1.0, 1.0, size=n * k)
+    cap = 2 * n * k + n
+    rowptr = np.empty(n + 1, dtype=np.int64)
+    col = np.empty(cap, dtype=np.int64)
+    val = np.empty(cap, dtype=np.float64)
+    nnz = L.sla_wl_random_spd(n, k, c.ctypes.data, v.ctypes.data, rowptr.ctypes.data, col.ctypes.data, val.ctypes.data)
+    if nnz < 0:
+        raise MemoryError("sla_wl_random_spd")
+    return (n, n), (rowptr, col[:nnz], val[:nnz])
+
+
+def random_spd_numpy(n, k=16, seed=42):
+    """The same matrix assembled with numpy only (the definition; random_spd must reproduce it bit for bit)."""
     rng = np.random.Generator(np.random.PCG64(seed))
     r = np.repeat(np.arange(n, dtype=np.int64), k)
     c = rng.integers(0, n, size=n * k, dtype=np.int64)
@@ -95,7 +134,13 @@ def random_spd(n, k=16, seed=42):
     order = np.argsort(key, kind="stable")
     key, vv = key[order], vv[order]
     uniq, start = np.unique(key, return_index=True)
-    vsum = np.add.reduceat(vv, start)                                     # (R + R^T)/2 on the union pattern
+    # (R + R^T)/2 on the union pattern; duplicates summed LEFT TO RIGHT in list order (np.add.reduceat would
+    # add a group's first element to the sum of the rest, which differs in the last bit for groups of >= 3)
+    glen = np.diff(np.append(start, len(vv)))
+    vsum = vv[start].copy()
+    for j in range(1, int(glen.max()) if len(glen) else 0):
+        g = np.nonzero(glen > j)[0]
+        vsum[g] += vv[start[g] + j]
     ur, uc = uniq // n, uniq % n
     absrow = np.zeros(n)
     np.add.at(absrow, ur, np.abs(vsum))

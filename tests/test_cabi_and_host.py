@@ -91,3 +91,17 @@ def test_row_partition():
             assert blocks[0][0] == 0 and blocks[-1][1] == m
             assert all(blocks[i][1] == blocks[i + 1][0] for i in range(P - 1))
             assert all(e - b <= shard_size(m, P) for b, e in blocks)
+
+
+def test_fast_random_spd_assembly_equals_the_numpy_definition():
+    """csrc/sla_wlgen.c (counting sort by row, used for the 10 M-row inputs) must reproduce the numpy definition of
+    BASELINE config 3's matrix bit for bit -- duplicates of 2, 3 and more picks, long rows, one-row matrices."""
+    import __graft_entry__ as g
+    g.build()
+    from sla_amd import workloads as wl
+    assert wl._wlgen() is not None
+    for n, k, seed in ((1, 3, 1), (50, 16, 3), (2000, 16, 42), (300, 200, 5), (40, 100, 9), (3000, 700, 1)):
+        a, b = wl.random_spd(n, k, seed), wl.random_spd_numpy(n, k, seed)
+        assert a[0] == b[0]
+        for u, w in zip(a[1], b[1]):
+            assert u.dtype == w.dtype and np.array_equal(u, w), (n, k)
