@@ -734,7 +734,9 @@ static int csr_upload(sla_ctx *c, int64_t m, int64_t n, int64_t row_begin, int64
     }
     A->is_diagonal = diag_not == 0;
     rc = build_xplan(A, rows, rowptr, col);
-    if (rc == SLA_OK && !(A->use_lpanel && c->lpanel)) rc = build_panels(A, m, n, row_begin, rows, rowptr, col, val);
+    if (rc == SLA_OK) rc = build_tiles(A, n, rows, rowptr, col, val);
+    lap("tile form");
+    if (rc == SLA_OK && !(A->use_lpanel && c->lpanel) && !A->use_tiles) rc = build_panels(A, m, n, row_begin, rows, rowptr, col, val);
     if (rc != SLA_OK) {
         sla_csr_destroy(A);
         return rc;
@@ -841,6 +843,9 @@ static int ctx_create_common(int device_id, int rank, int nranks, const void *ui
     if (const char *s = getenv("SLA_VEC_NT")) c->vec_nt = atoi(s);
     if (const char *s = getenv("SLA_HALO_INPLACE")) c->halo_inplace = atoi(s);
     if (const char *s = getenv("SLA_PANELS")) c->panels = atoi(s);
+    if (const char *s = getenv("SLA_TILES")) c->tiles = atoi(s);
+    if (const char *s = getenv("SLA_TILE_SHIFT")) c->tile_shift = atoi(s);
+    if (const char *s = getenv("SLA_TILE_SLACK")) c->tile_slack = atoi(s);
     if (const char *s = getenv("SLA_PANEL_COLS")) c->panel_cols = atoll(s);
     if (const char *s = getenv("SLA_ROW_ALIGN")) c->row_align = atoi(s);
     if (const char *s = getenv("SLA_RB_NNZ")) c->rb_nnz = atoi(s);
@@ -1261,6 +1266,11 @@ int sla_csr_destroy(sla_csr_t A) {
     if (A->transposed) sla_csr_destroy(A->transposed);
     for (sla_csr *V : A->panels) sla_csr_destroy(V);
     if (A->d_panel_y) (void)hipFree(A->d_panel_y);
+    if (A->d_tlrow) (void)hipFree(A->d_tlrow);
+    if (A->d_tloff) (void)hipFree(A->d_tloff);
+    if (A->d_tlidx) (void)hipFree(A->d_tlidx);
+    if (A->d_tlval) (void)hipFree(A->d_tlval);
+    if (A->d_tlprog) (void)hipFree(A->d_tlprog);
     delete A->xplan;
     if (A->d_rowptr) (void)hipFree(A->d_rowptr);
     if (A->d_col) (void)hipFree(A->d_col);
@@ -1331,13 +1341,19 @@ int sla_csr_is_diagonal(sla_csr_t A, int *out) {
 int sla_csr_kernel_info(sla_csr_t A, char *buf, int buflen) {
     if (!A || !buf || buflen <= 0) return fail(SLA_ERR_INVALID, "null argument");
     snprintf(buf, (size_t)buflen, "algo=%s grid=%d block=%d row_blocks=%d nnz_per_row_block=%d max_row_nnz=%lld rowptr=%s xcd_remap=%d",
-             A->ctx->spmv_algo == 1 ? "scalar" : (A->use_wdia && wd_on(A)) ? (A->wd_vv ? "wdia-vv" : "wdia") : (A->use_vdict && A->ctx->vdict) ? (A->use_xwin && A->ctx->xwin ? "vdict+xwin" : "vdict") : (A->use_lpanel && A->ctx->lpanel) ? "stream+ldspanels" : (!A->panels.empty() && A->ctx->panels) ? "stream+colpanels" : (A->use_diag && A->ctx->diag ? (A->use_xwin && A->ctx->xwin ? "stream+diagdict+xwin" : "stream+diagdict") : (A->use_xwin && A->ctx->xwin ? "stream+xwin" : "stream")), spmv_grid(A), kBlock, A->nrb, kNnzPerRowBlock,
+             A->ctx->spmv_algo == 1 ? "scalar" : (A->use_wdia && wd_on(A)) ? (A->wd_vv ? "wdia-vv" : "wdia") : (A->use_vdict && A->ctx->vdict) ? (A->use_xwin && A->ctx->xwin ? "vdict+xwin" : "vdict") : (A->use_lpanel && A->ctx->lpanel) ? "stream+ldspanels" : tiles_on(A) ? "tiles" : (!A->panels.empty() && A->ctx->panels) ? "stream+colpanels" : (A->use_diag && A->ctx->diag ? (A->use_xwin && A->ctx->xwin ? "stream+diagdict+xwin" : "stream+diagdict") : (A->use_xwin && A->ctx->xwin ? "stream+xwin" : "stream")), spmv_grid(A), kBlock, A->nrb, kNnzPerRowBlock,
              (long long)A->max_row_nnz, A->rp64 ? "i64" : "i32", A->ctx->xcd_remap);
     if (A->use_lpanel && A->ctx->lpanel && A->ctx->spmv_algo == 0) {   // LDS-panel geometry
         const size_t used = strlen(buf);
         if (used + 1 < (size_t)buflen)
             snprintf(buf + used, (size_t)buflen - used, " lds_panels=%d panel_cols=%d lanes_per_segment=%d tasks=%d", A->lp_P, A->lp_W,
                      64 >> A->lp_cfg, A->lp_P * A->lp_C);
+    }
+    if (tiles_on(A)) {   // tile geometry; exact_fold: every row is folded entry by entry in ascending column order
+        const size_t used = strlen(buf);
+        if (used + 1 < (size_t)buflen)
+            snprintf(buf + used, (size_t)buflen - used, " slices=%d panels=%d panel_cols=%d max_segment=%lld exact_fold=1", A->tl_S, A->tl_P,
+                     1 << A->tl_shift, (long long)A->tl_maxseg);
     }
     if (A->xplan) {   // row-sharded: how the SpMV input is exchanged
         const size_t used = strlen(buf);

@@ -43,6 +43,14 @@ constexpr int kLpRowsInFlight = SLA_LP_ROWS;   // (row, panel) segments a wavefr
 constexpr int kLpMinSeg = 16;        // mean entries per (row, panel) segment below which the stream kernel wins (tiny segments waste sectors)
 constexpr int kVdMaxRowNnz = 31;     // longest row the value-indexed kernel takes (256 rows x 31 B of codes fit its LDS stage)
 constexpr int kWaveRowMax = 16384;   // rows of 1025..16384 entries: one wavefront each, 4 per row block; longer: whole workgroup
+#ifndef SLA_TILE_ROWS
+#define SLA_TILE_ROWS 1024
+#endif
+#ifndef SLA_TILE_OCC
+#define SLA_TILE_OCC 4
+#endif
+constexpr int kTileRows = SLA_TILE_ROWS;  // rows per slice of spmv_tile_kernel: one wavefront's row sums in LDS (8 KiB)
+constexpr int kTileBlocksPerCu = SLA_TILE_OCC;  // its resident workgroups per CU (4 x 32 KiB of LDS, <= 128 VGPRs)
 constexpr int kMaxParts = 2048;      // partial-sum slots per reduction (256 CUs x 8)
 constexpr int kVecGridMax = 1024;    // grid cap of the streaming BLAS-1 kernels
 constexpr int kSpmvGridMax = 2048;   // persistent grid cap of the SpMV kernels
@@ -136,6 +144,9 @@ struct sla_ctx {
     int64_t device_coo_min = 1 << 20; // triple lists at least this long are sorted on the GPU (SLA_DEVICE_COO_MIN)
     int rb_nnz = 0;                  // 0: automatic row-block size (SLA_RB_NNZ overrides, <= 1024)
     int row_align = 0;               // > 1: row blocks end on multiples of this many rows (SLA_ROW_ALIGN; measured -1.5 % at 16)
+    int tiles = 1;                   // allow the row-slice x column-panel tile SpMV for irregular matrices with x > L2 (SLA_TILES=0: column-panel passes)
+    int tile_slack = 3;              // panel pacing: a wavefront starts panel step q once its XCD has finished step q - slack (SLA_TILE_SLACK, 0: no pacing)
+    int tile_shift = 17;             // log2 of its panel width in columns (SLA_TILE_SHIFT): 1 MiB of x per panel (slack 3 / shift 17: 2.26 ms at 10 M rows; 2 / 18: 2.31; 6 / 16: 2.35)
     int panels = 1;                  // allow the column-panel SpMV for irregular matrices (SLA_PANELS=0 disables)
     int64_t panel_cols = 384 * 1024; // panel width in columns (SLA_PANEL_COLS): 3 MiB of x per pass
     int diag = 1;                    // allow the dictionary-compressed-index SpMV kernel (SLA_DIAG=0 disables)
@@ -247,6 +258,17 @@ struct sla_csr {
     std::vector<sla_csr *> panels;   // column-panel views (irregular matrices whose x does not fit the L2), else empty
     double *d_panel_y = nullptr;     // running row sums for epilogues that do not store y
     bool is_panel_view = false;
+    // row-slice x column-panel tiles (irregular matrices whose x does not fit one XCD's L2; sla_lower_tiles.cpp): the entries
+    // re-ordered by (slice, panel, row, column); a wavefront keeps a slice's row sums in LDS while it walks the panels
+    bool use_tiles = false;
+    int32_t tl_S = 0, tl_P = 0, tl_shift = 17;   // slices, panels, log2(columns per panel)
+    int32_t *d_tlrow = nullptr;      // tl_S + 1 slice row starts
+    uint32_t *d_tloff = nullptr;     // tl_S x (tl_P + 1): first entry of tile (s, j), relative to the slice's first entry rowptr[tlrow[s]]
+    uint32_t *d_tlidx = nullptr;     // per entry: (row - tlrow[s]) << tl_shift | (col - j * W)
+    double *d_tlval = nullptr;
+    unsigned *d_tlprog = nullptr;    // per-XCD (round, panel) arrival counters of the launch in flight (panel pacing)
+    size_t tlprog_bytes = 0;
+    int64_t tl_maxseg = 0;           // longest (row, panel) segment = layers of the deepest tile
     sla_tri_plan *tri[2] = {nullptr, nullptr};  // [0] lower, [1] upper triangle schedules (built on first use)
     sla::XPlan *xplan = nullptr;     // sharded only: which x entries this rank exchanges with each peer
     int64_t max_row_nnz = 0;
@@ -391,6 +413,11 @@ struct SpmvLaunch {
 };
 int spmv_grid(const sla_csr *A);  // number of blocks (= partial slots written) of an SpMV launch on A
 int launch_spmv(const sla_csr *A, const SpmvLaunch &l);
+bool tiles_on(const sla_csr *A);                               // is the tile form of A in use?
+int launch_spmv_tiles(const sla_csr *A, const SpmvLaunch &l);   // sla_spmv_tiles.hip
+int tiles_grid(const sla_csr *A);
+// sla_lower_tiles.cpp: builds the tile form of A when it pays (irregular structure, x larger than the L2); no-op otherwise
+int build_tiles(sla_csr *A, int64_t n, int64_t rows, const int64_t *rowptr, const int64_t *col, const double *val);
 
 int vec_grid(int64_t n_local);
 // p1[b] = sum x.y over block b's elements (grid = vec_grid)

@@ -36,140 +36,9 @@
 #include <type_traits>
 
 #include "sla_internal.hpp"
+#include "sla_device.hpp"
 
 namespace sla {
-
-// ---------------------------------------------------------------------------------------------
-// reduction helpers (deterministic)
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-}
-
-// sum over the 256 threads of the block, returned to every thread.  s4: 4 doubles of LDS.
-__device__ __forceinline__ double block_sum(double v, double *s4) {
-    v = wave_sum(v);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) s4[threadIdx.x >> 6] = v;
-    __syncthreads();
-    return ((s4[0] + s4[1]) + s4[2]) + s4[3];
-}
-
-// fixed-order re-reduction of a partial array written by an EARLIER kernel
-__device__ __forceinline__ double reduce_parts(const double *p, int n, int stride, double *s4) {
-    double a = 0.0;
-    if (n > 0 && n <= 8 * kBlock) {
-        // the usual case (<= 2048 partials): all eight loads of a thread in flight at once instead of a chain of
-        // dependent round trips at the head of every consumer kernel; same additions in the same order
-        double v[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = p[(int64_t)min((int)threadIdx.x + j * kBlock, n - 1) * stride];
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-            if ((int)threadIdx.x + j * kBlock < n) a += v[j];
-    } else {
-        for (int i = threadIdx.x; i < n; i += kBlock) a += p[(int64_t)i * stride];
-    }
-    return block_sum(a, s4);
-}
-
-__device__ __forceinline__ bool is_finite(double v) { return v == v && fabs(v) != INFINITY; }
-
-// runIter's test (Sparse.hs:1047-1050) on the partials of ||A x - b||^2 left by an earlier kernel.
-// Every workgroup takes the same decision; workgroup 0 publishes it.  Returns true when converged.
-__device__ __forceinline__ bool residual_converged(SolverScalars *sc, const double *p, int n, int stride, double *s4) {
-    const double rn = sqrt(reduce_parts(p, n, stride, s4));
-    const bool conv = rn <= sc->tol;
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        sc->resnorm = rn;
-        if (conv) { sc->done = 1; sc->flags |= SLA_FLAG_CONVERGED; }
-        if (!is_finite(rn)) sc->flags |= SLA_FLAG_NONFINITE;
-    }
-    return conv;
-}
-
-// ---------------------------------------------------------------------------------------------
-// SpMV epilogues
-// ---------------------------------------------------------------------------------------------
-template <int EPI, typename RP>
-__device__ __forceinline__ void spmv_epilogue(const SpmvArgs<RP> &a, int row, double yv, double coef,
-                                              double &acc1, double &acc2) {
-    if constexpr (EPI == EPI_NONE) {
-        a.y[row] = yv;
-    } else if constexpr (EPI == EPI_DOT) {
-        a.y[row] = yv;
-        acc1 += yv * a.w[row];
-    } else if constexpr (EPI == EPI_DOT2) {
-        a.y[row] = yv;
-        acc1 += yv * a.w[row];
-        acc2 += yv * yv;
-    } else if constexpr (EPI == EPI_RES) {
-        double t = yv - a.w[row];  // (aa #> x) ^-^ b
-        acc1 += t * t;
-    } else if constexpr (EPI == EPI_AXPY_DOT) {
-        double z = a.z[row] - coef * yv;
-        a.z[row] = z;
-        acc1 += z * (a.w ? a.w[row] : z);
-    } else if constexpr (EPI == EPI_XPBY_NRM) {
-        double z = yv + coef * a.z[row];
-        a.z[row] = z;
-        acc1 += z * z;
-    } else if constexpr (EPI == EPI_SUB) {
-        a.y[row] = a.w[row] - yv;  // b ^-^ (aa #> x)
-    }
-}
-
-// Prologue shared by the SpMV kernels.  Returns false when the block must exit (solver done).
-template <int EPI, typename RP>
-__device__ __forceinline__ bool spmv_prologue(const SpmvArgs<RP> &a, double *s4, double &coef) {
-    SolverScalars *sc = a.sc;
-    coef = 0.0;
-    if (sc == nullptr) return true;
-    if (sc->done) return false;
-    if (a.pres) {
-        if (residual_converged(sc, a.pres, a.npres, a.pres_stride, s4)) return false;
-    }
-    if (a.step_begin & 1) {
-        if (blockIdx.x == 0 && threadIdx.x == 0) sc->iters += 1;
-    }
-    const int par = (a.step_begin >> 1) & 1;
-    if constexpr (EPI == EPI_AXPY_DOT) {
-        if (a.pa) {  // CGNE: alpha = (r.r) / (p.p)
-            coef = sc->rho2[par] / reduce_parts(a.pa, a.npa, a.pa_stride, s4);
-            if (blockIdx.x == 0 && threadIdx.x == 0) sc->alpha = coef;
-        } else {
-            coef = sc->alpha;
-        }
-    } else if constexpr (EPI == EPI_XPBY_NRM) {  // CGNE: beta = (r1.r1) / (r.r)
-        double rr1 = reduce_parts(a.pa, a.npa, a.pa_stride, s4);
-        coef = rr1 / sc->rho2[par];
-        if (blockIdx.x == 0 && threadIdx.x == 0) { sc->beta = coef; sc->rho2[par ^ 1] = rr1; }
-    }
-    return true;
-}
-
-// XCD-aware persistent walk over row blocks: workgroup g runs on XCD g % 8, so give XCD k the k-th
-// contiguous eighth of the row blocks; its private 4 MiB L2 then holds one sliding window of x.
-struct RbWalk {
-    int first, step, last;
-};
-__device__ __forceinline__ RbWalk rb_walk(int nrb, int xcd_remap) {
-    RbWalk w;
-    const int G = gridDim.x;
-    if (xcd_remap && (G & 7) == 0 && nrb >= G) {
-        const int xcd = blockIdx.x & 7, l = blockIdx.x >> 3, per = (nrb + 7) >> 3;
-        w.first = xcd * per + l;
-        w.step = G >> 3;
-        w.last = min((xcd + 1) * per, nrb);
-    } else {
-        w.first = blockIdx.x;
-        w.step = G;
-        w.last = nrb;
-    }
-    return w;
-}
 
 // ---------------------------------------------------------------------------------------------
 // CSR-stream SpMV
@@ -1889,6 +1758,7 @@ static bool vec_stream_nt(const sla_ctx *c, int64_t n) {
 int spmv_grid(const sla_csr *A) {
     const sla_ctx *c = A->ctx;
     // with column panels the fused partials are written by the LAST panel pass: its grid is the one that counts
+    if (tiles_on(A)) return tiles_grid(A);
     if (!A->panels.empty() && c->panels && c->spmv_algo == 0) return spmv_grid(A->panels.back());
     int64_t g;
     if (c->spmv_algo == 1 || (A->use_lpanel && c->lpanel)) g = (A->rows + kBlock - 1) / kBlock;   // (lpanel: its finish kernel)
@@ -2084,6 +1954,7 @@ static int launch_spmv_rp(const sla_csr *A, const SpmvLaunch &l) {
 }
 
 int launch_spmv(const sla_csr *A, const SpmvLaunch &l) {
+    if (tiles_on(A) && !l.x2 && !l.yinit) return launch_spmv_tiles(A, l);
     return A->rp64 ? launch_spmv_rp<int64_t>(A, l) : launch_spmv_rp<int32_t>(A, l);
 }
 

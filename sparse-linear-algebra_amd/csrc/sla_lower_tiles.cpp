@@ -1,0 +1,151 @@
+// sla_lower_tiles.cpp -- lowering analysis for the row-slice x column-panel tile form (kernel: sla_spmv_tiles.hip).
+//
+// Taken for irregular matrices (no diagonal dictionary, entries not clustered around the diagonal, rows not dense
+// enough for the LDS-panel form) whose x is larger than two L2-sized panels.  The canonical CSR arrays stay (export,
+// transpose, fallback kernels); this adds a second, tile-major copy of the entries (12 B each) plus
+//   tlrow[S + 1]        slice row starts: slices of <= kTileRows rows holding about nnz / S entries each, S = a whole
+//                       number of rounds of the kernel's persistent grid (every wavefront gets the same number of slices);
+//   tloff[S x (P + 1)]  first entry of tile (slice, panel) relative to the slice's first entry (= rowptr[tlrow[s]]: a
+//                       slice owns the same entry range in both orders, so slices are built independently, in parallel).
+#include <algorithm>
+#include <cstring>
+#include <limits>
+#include <thread>
+#include <vector>
+
+#include "sla_internal.hpp"
+
+namespace sla {
+
+int build_tiles(sla_csr *A, int64_t n, int64_t rows, const int64_t *rowptr, const int64_t *col, const double *val) {
+    sla_ctx *c = A->ctx;
+    const int64_t nnz = rowptr[rows];
+    if (!c->tiles || rows == 0 || nnz == 0) return SLA_OK;
+    if (A->use_diag || A->use_wdia || A->use_vdict || A->xwin_fraction >= 0.5) return SLA_OK;   // stencil / banded structure
+    if (A->use_lpanel && c->lpanel) return SLA_OK;                                               // dense rows: x panels in LDS
+    const int shift = std::max(10, std::min(21, c->tile_shift));
+    const int64_t W = (int64_t)1 << shift;
+    if (n <= 2 * W) return SLA_OK;                       // x (nearly) fits the L2 already
+    if (shift + 10 > 32) return SLA_OK;
+    const int64_t P = (n + W - 1) / W;
+    if (P > 16384) return SLA_OK;
+    // slices: whole rounds of the persistent grid (kTileBlocksPerCu workgroups of 4 wavefronts per CU)
+    const int64_t waves = (int64_t)kTileBlocksPerCu * c->n_cu * (kBlock / 64);
+    const int64_t rounds = std::max<int64_t>(1, (rows + (int64_t)kTileRows * waves - 1) / ((int64_t)kTileRows * waves));
+    int64_t S0 = rounds * waves;
+    S0 = std::max<int64_t>(1, std::min<int64_t>(S0, (rows + 63) / 64));
+    const int64_t target = (nnz + S0 - 1) / S0;
+    std::vector<int32_t> srow;
+    srow.reserve((size_t)S0 + 64);
+    srow.push_back(0);
+    {
+        int64_t r = 0;
+        while (r < rows) {
+            // close the slice at kTileRows rows or once it holds `target` entries (a row is never split)
+            const int64_t rcap = std::min<int64_t>(rows, r + kTileRows);
+            const int64_t want = rowptr[r] + target;
+            int64_t e = std::upper_bound(rowptr + r + 1, rowptr + rcap + 1, want) - rowptr;   // first row end beyond the target
+            e = std::max<int64_t>(r + 1, std::min<int64_t>(e, rcap));
+            if (rowptr[e] - rowptr[r] > (int64_t)std::numeric_limits<uint32_t>::max() - 1024) return SLA_OK;   // 32-bit tile offsets
+            srow.push_back((int32_t)e);
+            r = e;
+        }
+    }
+    const int64_t S = (int64_t)srow.size() - 1;
+    if (S * (P + 1) > ((int64_t)1 << 31) || S * (P + 1) * 4 > nnz * 12 / 2) return SLA_OK;   // offset table must stay a fraction of the matrix
+    std::vector<uint32_t> toff((size_t)(S * (P + 1)));
+    std::vector<uint32_t> tidx((size_t)nnz);
+    std::vector<double> tval((size_t)nnz);
+    const uint32_t cmask = (uint32_t)(W - 1);
+    int T = (int)std::min<int64_t>(std::max(1u, std::min(16u, std::thread::hardware_concurrency())), S);
+    if (const char *e = getenv("SLA_HOST_THREADS")) T = std::max(1, std::min(atoi(e), 64));
+    if (nnz < 2000000) T = 1;
+    std::vector<int64_t> maxseg((size_t)T, 0);
+    // Inside a tile the entries are ordered by (layer, row): layer = rank of the entry inside its (row, panel) segment in
+    // ascending column order.  A layer holds every row at most once, rows ascending, so 64 consecutive entries of a layer
+    // are 64 DIFFERENT rows -- the kernel adds them to the row sums with plain LDS read-modify-writes, no cross-lane
+    // work -- and a row's entries are still added one by one in ascending column order (layer l before layer l + 1).
+    std::vector<int64_t> breaks((size_t)T, 0);
+    auto work = [&](int t) {
+        std::vector<uint32_t> pos((size_t)P + 1);
+        std::vector<std::vector<uint32_t>> lay((size_t)P);       // per panel: rows holding more than l entries, then layer starts
+        int64_t mseg = 0, nbreaks = 0;
+        for (int64_t s = S * t / T; s < S * (t + 1) / T; ++s) {
+            const int64_t r0 = srow[(size_t)s], r1 = srow[(size_t)s + 1], k0 = rowptr[r0];
+            uint32_t *off = toff.data() + (size_t)(s * (P + 1));
+            std::fill(pos.begin(), pos.end(), 0u);
+            for (auto &v : lay) v.clear();
+            for (int64_t i = r0; i < r1; ++i) {
+                int64_t k = rowptr[i];
+                const int64_t e = rowptr[i + 1];
+                while (k < e) {                                   // one (row, panel) segment
+                    const int64_t j = col[k] >> shift;
+                    int64_t len = 0;
+                    while (k < e && (col[k] >> shift) == j) { ++k; ++len; }
+                    pos[(size_t)j + 1] += (uint32_t)len;
+                    std::vector<uint32_t> &L = lay[(size_t)j];
+                    if ((int64_t)L.size() < len) L.resize((size_t)len, 0u);
+                    for (int64_t q = 0; q < len; ++q) L[(size_t)q]++;
+                    mseg = std::max(mseg, len);
+                }
+            }
+            for (int64_t j = 0; j < P; ++j) pos[(size_t)j + 1] += pos[(size_t)j];
+            std::memcpy(off, pos.data(), sizeof(uint32_t) * (size_t)(P + 1));
+            for (int64_t j = 0; j < P; ++j) {                     // counts -> first slot of each layer inside the tile
+                std::vector<uint32_t> &L = lay[(size_t)j];
+                uint32_t run = 0;
+                for (size_t q = 0; q < L.size(); ++q) { const uint32_t c = L[q]; L[q] = run; run += c; }
+                if (!L.empty()) nbreaks += (int64_t)L.size() - 1;
+            }
+            for (int64_t i = r0; i < r1; ++i) {
+                int64_t k = rowptr[i];
+                const int64_t e = rowptr[i + 1];
+                while (k < e) {
+                    const int64_t j = col[k] >> shift;
+                    std::vector<uint32_t> &L = lay[(size_t)j];
+                    for (int64_t q = 0; k < e && (col[k] >> shift) == j; ++k, ++q) {
+                        const size_t o = (size_t)(k0 + pos[(size_t)j] + L[(size_t)q]++);
+                        tidx[o] = ((uint32_t)(i - r0) << shift) | ((uint32_t)col[k] & cmask);
+                        tval[o] = val[k];
+                    }
+                }
+            }
+        }
+        maxseg[(size_t)t] = mseg;
+        breaks[(size_t)t] = nbreaks;
+    };
+    if (T == 1) {
+        work(0);
+    } else {
+        std::vector<std::thread> th;
+        for (int t = 0; t < T; ++t) th.emplace_back(work, t);
+        for (auto &x : th) x.join();
+    }
+    A->tl_maxseg = *std::max_element(maxseg.begin(), maxseg.end());
+    {   // every layer boundary inside a 64-entry group costs one more LDS pass: matrices made of long (row, panel) segments
+        // (dense rows) belong to the LDS-panel / stream kernels
+        int64_t nb = 0;
+        for (int64_t b : breaks) nb += b;
+        if (nb * 8 > nnz) return SLA_OK;
+    }
+    hipError_t err = hipSuccess;
+    auto upload = [&](void **dst, const void *src, size_t bytes) {
+        if (err != hipSuccess) return;
+        err = hipMalloc(dst, std::max<size_t>(bytes + 64, 8));   // (+64: the streams are read in whole dwords / qwords only, slack for safety)
+        if (err == hipSuccess && bytes) err = hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
+    };
+    upload((void **)&A->d_tlrow, srow.data(), sizeof(int32_t) * srow.size());
+    upload((void **)&A->d_tloff, toff.data(), sizeof(uint32_t) * toff.size());
+    upload((void **)&A->d_tlidx, tidx.data(), sizeof(uint32_t) * tidx.size());
+    upload((void **)&A->d_tlval, tval.data(), sizeof(double) * tval.size());
+    A->tlprog_bytes = sizeof(int) * 8 * 128;   // pacing table: one progress slot per workgroup, 128 per XCD; zeroed before every launch
+    if (err == hipSuccess) err = hipMalloc((void **)&A->d_tlprog, A->tlprog_bytes);
+    if (err != hipSuccess) return fail(SLA_ERR_ALLOC, std::string("tile form upload: ") + hipGetErrorString(err));
+    A->tl_S = (int32_t)S;
+    A->tl_P = (int32_t)P;
+    A->tl_shift = shift;
+    A->use_tiles = true;
+    return SLA_OK;
+}
+
+}  // namespace sla

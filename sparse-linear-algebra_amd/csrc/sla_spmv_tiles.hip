@@ -1,0 +1,287 @@
+// sla_spmv_tiles.hip -- (#>) for irregular matrices whose x does not fit one XCD's L2 (BASELINE config 3a: 10 M rows,
+// ~33 uniformly random columns per row).  Reference semantics: Data/Sparse/Common.hs:242-260 (ascending left fold per row).
+//
+// What bounds this case (tools/gather_probe.cpp, profiles/r02_gather_probe.txt): a random 8-byte gather moves a whole
+// 128-byte line into the L1.  Served from an L2-resident window (<= 3 MiB) the chip sustains ~225 G gathers/s; from the
+// memory-side cache or HBM (x = 80 MB) only ~55 G/s -- 330 M gathers = 1.45 ms against 6 ms.  So the gathers must hit
+// the L2, i.e. the matrix has to be walked in column panels of <= 2 MiB of x.  Round 1 did that with P = 26 full passes
+// over the rows (y, rowptr re-streamed per pass: 2.7x the algorithmic bytes, PMC).  Here the row sums stay ON CHIP:
+//
+//   * rows are cut into slices of <= 1024 rows (equal entry counts), one wavefront per slice, its row sums in LDS (8 KiB);
+//   * the slice's entries are stored tile-major -- ordered by (panel, row, column), 12 B each: the value and one dword
+//     (row - slice_row0) << 18 | (col - panel * 2^18) -- so a wavefront streams them with coalesced non-temporal loads,
+//     gathers x from the panel all wavefronts of the XCD are on at that moment, and adds the products into LDS;
+//   * inside a tile the entries are ordered by (layer, row), layer = rank of the entry inside its (row, panel) segment in
+//     ascending column order: 64 consecutive entries of one layer are 64 different rows, so a group of 64 products goes
+//     into the row sums with ONE conflict-free LDS read-modify-write (y_r = y_r + a_rc x_c, separately rounded) and no
+//     cross-lane work; a group that spans a layer boundary (rows not ascending) is split there and done in as many passes.
+//     A row's products are therefore added ONE BY ONE in ascending column order (panels ascending, layers ascending): every
+//     row is the reference's left fold bit for bit, whatever its length (an instruction-count matter too: the first
+//     version chained the runs of a (row, column)-sorted tile through DPP shifts -- ~300 instructions per 64 entries,
+//     issue-bound at 130 G entries/s even with x in the L2; this one needs ~25);
+//   * all wavefronts start at panel 0 and carry equal work, so they sweep the panels in near lock step and the XCD's
+//     L2 holds the current panel; x itself (80 MB) sits in the 256 MiB memory-side cache between the sweeps;
+//   * y is written once per row, in the fused epilogue (dot / dot2 / residual / CGS / CGNE variants): HBM traffic =
+//     12 B per entry + the vectors = the algorithmic bytes.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <type_traits>
+
+#include "sla_internal.hpp"
+#include "sla_device.hpp"
+
+namespace sla {
+
+#ifndef SLA_TILE_U
+#define SLA_TILE_U 4
+#endif
+constexpr int kTileU = SLA_TILE_U;   // 64-entry groups per chunk: 256 entries in flight per wavefront (+ the next chunk's streams)
+
+struct TileChunk {
+    uint32_t idx[kTileU];
+    double val[kTileU];
+    double xv[kTileU];
+    int cnt;      // entries of this chunk (<= 64 * kTileU)
+    int panel;
+};
+
+// lane i <- lane i - 1 across the whole wavefront (DPP wave_shr:1); lane 0 <- lane0val
+__device__ __forceinline__ int wave_shr1(int v, int lane0val) { return __builtin_amdgcn_update_dpp(lane0val, v, 0x138, 0xf, 0xf, false); }
+
+// Add one chunk (kTileU groups of 64 consecutive entries of one tile; the chunk's entries [0, cnt) are valid, the lanes past
+// them hold copies of the last entry) into the slice's row sums yl[].
+__device__ __forceinline__ void tile_fold_chunk(double *yl, const TileChunk &c, int shift, int lane) {
+#pragma clang fp contract(off)
+#pragma unroll
+    for (int u = 0; u < kTileU; ++u) {
+        const int cg = c.cnt - 64 * u;                 // valid lanes of this group (wavefront-uniform)
+        if (cg <= 0) break;
+        const uint32_t rl = c.idx[u] >> shift;
+        const double p = c.val[u] * c.xv[u];
+        const bool act = lane < cg;
+        // layer boundaries: rows inside a layer ascend strictly; lane 0 always starts a pass
+        const uint32_t rprev = (uint32_t)wave_shr1((int)rl, -1);
+        unsigned long long B = __ballot(act && lane > 0 && rl <= rprev);
+        if (B == 0) {                                  // one layer: 64 different rows
+            if (act) yl[rl] = yl[rl] + p;
+        } else {
+            int lo = 0;
+            for (;;) {                                 // passes [lo, hi) between boundaries, in order
+                const int hi = B ? __builtin_ctzll(B) : 64;
+                if (act && lane >= lo && lane < hi) yl[rl] = yl[rl] + p;
+                if (!B) break;
+                B &= B - 1;
+                lo = hi;
+            }
+        }
+    }
+}
+
+template <int EPI, typename RP>
+__global__ void __launch_bounds__(kBlock, kTileBlocksPerCu)
+spmv_tile_kernel(SpmvArgs<RP> a, const RP *__restrict__ rowptr, const int32_t *__restrict__ srow, const uint32_t *__restrict__ toff,
+                 const uint32_t *__restrict__ tidx, const double *__restrict__ tval, const double *__restrict__ xg, int S, int P,
+                 int shift, unsigned *prog, int slack) {
+    __shared__ double s_y[kBlock / 64][kTileRows];
+    __shared__ double s_red[4];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    double coef;
+    if (!spmv_prologue<EPI, RP>(a, s_red, coef)) return;
+    double acc1 = 0.0, acc2 = 0.0;
+    double *yl = s_y[wave];
+    const uint32_t cmask = (1u << shift) - 1u;
+    const int stride = (int)gridDim.x * (kBlock / 64);
+    // Panel pacing.  The gathers only hit the L2 while the wavefronts of an XCD are on (nearly) the same panel, and left
+    // alone they drift apart within a fraction of a slice (the SIMD arbiter favours the oldest wavefront; measured without
+    // pacing: 78 % L2 misses, 33 GB through the fabric per launch).  So a wavefront does not START panel step q before every
+    // workgroup of its XCD has finished step q - slack.  Progress is published WITHOUT atomics (device-scope atomics execute
+    // on the memory side of the fabric: 512 wavefronts bumping one counter cost ~100 us per step, measured): each
+    // workgroup keeps its wavefronts' step counts in LDS and plain-stores their minimum into its own slot of a per-XCD
+    // table -- the store stays in the XCD's L2 -- and a waiting wavefront reads the <= 128 slots of its XCD with L1-bypassing
+    // loads (one or two loads per poll, wavefront min).  Workgroup b runs on XCD b % 8 (HW_REG_XCC_ID, tools/xcc_probe.cpp)
+    // and the grid is fully resident (kTileBlocksPerCu per CU).  Pacing is a throttle, never a correctness condition: a
+    // wavefront that waits too long (grid not co-resident) stops pacing for the rest of the launch.
+    __shared__ int s_prog[kBlock / 64];
+    if (tid < kBlock / 64) s_prog[tid] = 0;
+    __syncthreads();
+    const int xcd = (int)blockIdx.x & 7;
+    const int nwg_xcd = ((int)gridDim.x - xcd + 7) >> 3;
+    const int rounds = (S + stride - 1) / stride;
+    int *slots = prog ? (int *)prog + xcd * 128 : nullptr;      // <= 128 workgroups per XCD (kTileBlocksPerCu x 32 CUs)
+    int *myslot = slots ? slots + ((int)blockIdx.x >> 3) : nullptr;
+    bool pace = slack > 0 && slots != nullptr && nwg_xcd <= 128;
+    int known = 0;                                               // steps every workgroup of the XCD is known to have finished
+    auto publish = [&](int done) {                               // this wavefront has finished `done` steps
+        if (!slots) return;
+        if (lane == 0) {
+            // Two wavefronts publishing at once may each miss the other's LDS update, and the staler minimum may reach the slot
+            // last.  Stores of one wavefront to one address stay in order, so re-reading the minimum after the store and
+            // storing again until it is stable leaves the slot at the true minimum.
+            ((volatile int *)s_prog)[wave] = done;
+            int stored = -1;
+            for (;;) {
+                int m = done;
+#pragma unroll
+                for (int w = 0; w < kBlock / 64; ++w) m = min(m, ((volatile int *)s_prog)[w]);
+                if (m == stored) break;
+                __hip_atomic_store(myslot, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                stored = m;
+            }
+        }
+    };
+    auto wait_for = [&](int need) {                              // until all workgroups of the XCD have finished `need` steps
+        int spins = 0;
+        while (pace && known < need) {
+            int v = 0x7fffffff;
+            if (lane < nwg_xcd) v = __hip_atomic_load(slots + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane + 64 < nwg_xcd) v = min(v, __hip_atomic_load(slots + lane + 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v = min(v, __shfl_xor(v, off, 64));
+            known = v;
+            if (known >= need) break;
+            __builtin_amdgcn_s_sleep(4);
+            if (++spins > 50000) pace = false;
+        }
+    };
+    int round = 0;
+    for (int sv = (int)blockIdx.x * (kBlock / 64) + wave;; sv += stride, ++round) {
+        const int s = __builtin_amdgcn_readfirstlane(sv);   // everything per slice is wavefront-uniform: keep it in SGPRs
+        if (round >= rounds || s >= S) {   // no (more) slices: count as finished with everything, the others must not wait for this one
+            publish(0x7fffffff);
+            break;
+        }
+        const int r0 = __builtin_amdgcn_readfirstlane(srow[s]), nr = __builtin_amdgcn_readfirstlane(srow[s + 1]) - r0;
+        for (int r = lane; r < nr; r += 64) yl[r] = 0.0;
+        RP base = rowptr[r0];
+        if constexpr (sizeof(RP) == 4) {
+            base = (RP)__builtin_amdgcn_readfirstlane((int)base);
+        } else {
+            base = (RP)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned long long)base >> 32)) << 32) |
+                        (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned long long)base));
+        }
+        const uint32_t *tp = toff + (size_t)s * (size_t)(P + 1);
+        // walk the slice's tiles chunk by chunk (a chunk never crosses a tile); all of this is wavefront-uniform
+        int j = -1;
+        uint32_t k = 0, k1 = 0, plo = 0, phi = 0;
+        auto advance = [&]() -> bool {
+            while (k >= k1) {
+                if (j >= 0) publish(round * P + j + 1);   // done issuing tile j
+                ++j;
+                if (j >= P) return false;
+                wait_for(round * P + j - slack + 1);
+                if ((j & 63) == 0) {   // the next 64 tile offsets, one per lane (no dependent load per tile)
+                    plo = tp[min(j + lane, P)];
+                    phi = tp[min(j + lane + 1, P)];
+                }
+                k = (uint32_t)__builtin_amdgcn_readlane((int)plo, j & 63);
+                k1 = (uint32_t)__builtin_amdgcn_readlane((int)phi, j & 63);
+            }
+            return true;
+        };
+        auto issue = [&](TileChunk &c) {   // the chunk at (j, k): its index / value streams (lanes past the end re-read the last entry)
+            c.cnt = (int)min((uint32_t)(64 * kTileU), k1 - k);
+            c.panel = j;
+            const uint32_t *ip = tidx + (base + (RP)k);
+            const double *vp = tval + (base + (RP)k);
+#pragma unroll
+            for (int u = 0; u < kTileU; ++u) {
+                const uint32_t i = (uint32_t)min(lane + 64 * u, c.cnt - 1) & (64 * kTileU - 1);
+                c.idx[u] = __builtin_nontemporal_load(ip + i);
+                c.val[u] = __builtin_nontemporal_load(vp + i);
+            }
+            k += 64 * kTileU;
+        };
+        auto gather = [&](TileChunk &c) {
+            const char *xb = (const char *)(xg + ((size_t)c.panel << shift));
+#pragma unroll
+            for (int u = 0; u < kTileU; ++u) c.xv[u] = *(const double *)(xb + (uint32_t)((c.idx[u] & cmask) << 3));
+        };
+        // three chunks in flight per wavefront: A is folded while B's gathers and C's index / value streams are outstanding
+        TileChunk A, B, C;
+        bool hA = advance(), hB = false, hC = false;
+        if (hA) issue(A);
+        hB = hA && advance();
+        if (hB) issue(B);
+        if (hA) gather(A);
+        for (;;) {   // unrolled by three: the chunks rotate through the roles without register copies
+            if (!hA) break;
+            hC = hB && advance(); if (hC) issue(C); if (hB) gather(B);
+            tile_fold_chunk(yl, A, shift, lane);
+            if (!hB) break;
+            hA = hC && advance(); if (hA) issue(A); if (hC) gather(C);
+            tile_fold_chunk(yl, B, shift, lane);
+            if (!hC) break;
+            hB = hA && advance(); if (hB) issue(B); if (hA) gather(A);
+            tile_fold_chunk(yl, C, shift, lane);
+        }
+        for (int r = lane; r < nr; r += 64) spmv_epilogue<EPI, RP>(a, r0 + r, yl[r], coef, acc1, acc2);
+    }
+    if constexpr (EPI == EPI_DOT || EPI == EPI_DOT2 || EPI == EPI_RES || EPI == EPI_AXPY_DOT || EPI == EPI_XPBY_NRM) {
+        const double s1 = block_sum(acc1, s_red);
+        if (tid == 0) a.p1[blockIdx.x] = s1;
+    }
+    if constexpr (EPI == EPI_DOT2) {
+        const double s2 = block_sum(acc2, s_red);
+        if (tid == 0) a.p2[blockIdx.x] = s2;
+    }
+}
+
+bool tiles_on(const sla_csr *A) { return A->use_tiles && A->ctx->tiles && A->ctx->spmv_algo == 0; }
+
+int tiles_grid(const sla_csr *A) {
+    const int64_t blocks = ((int64_t)A->tl_S + kBlock / 64 - 1) / (kBlock / 64);
+    return (int)std::max<int64_t>(1, std::min<int64_t>(blocks, (int64_t)kTileBlocksPerCu * A->ctx->n_cu));
+}
+
+template <int EPI, typename RP>
+static int launch_tiles_t(const sla_csr *A, const SpmvLaunch &l) {
+    sla_ctx *c = A->ctx;
+    SpmvArgs<RP> a{};
+    a.rowptr = (const RP *)A->d_rowptr;
+    a.col = A->d_col;
+    a.val = A->d_val;
+    a.x = l.x;
+    a.y = l.y;
+    a.rows = (int32_t)A->rows;
+    a.w = l.w;
+    a.z = l.z;
+    a.p1 = l.p1;
+    a.p2 = l.p2;
+    a.sc = l.sc;
+    a.pres = l.pres;
+    a.npres = l.npres;
+    a.pres_stride = l.pres_stride;
+    a.pa = l.pa;
+    a.pb = l.pb;
+    a.npa = l.npa;
+    a.pa_stride = l.pa_stride;
+    a.step_begin = l.step_begin;
+    a.yinit = nullptr;
+    ProfScope prof(c, l.kernel_id);
+    if (A->d_tlprog) SLA_HIP_TRY(hipMemsetAsync(A->d_tlprog, 0, A->tlprog_bytes, c->stream));   // the pacing table of this launch
+    hipLaunchKernelGGL((spmv_tile_kernel<EPI, RP>), dim3(tiles_grid(A)), dim3(kBlock), 0, c->stream, a, a.rowptr, A->d_tlrow, A->d_tloff,
+                       A->d_tlidx, A->d_tlval, l.x, A->tl_S, A->tl_P, A->tl_shift, A->d_tlprog, c->tile_slack);
+    SLA_HIP_TRY(hipGetLastError());
+    return SLA_OK;
+}
+
+template <typename RP>
+static int launch_tiles_rp(const sla_csr *A, const SpmvLaunch &l) {
+    switch (l.epi) {
+        case EPI_NONE: return launch_tiles_t<EPI_NONE, RP>(A, l);
+        case EPI_DOT: return launch_tiles_t<EPI_DOT, RP>(A, l);
+        case EPI_DOT2: return launch_tiles_t<EPI_DOT2, RP>(A, l);
+        case EPI_RES: return launch_tiles_t<EPI_RES, RP>(A, l);
+        case EPI_AXPY_DOT: return launch_tiles_t<EPI_AXPY_DOT, RP>(A, l);
+        case EPI_XPBY_NRM: return launch_tiles_t<EPI_XPBY_NRM, RP>(A, l);
+        case EPI_SUB: return launch_tiles_t<EPI_SUB, RP>(A, l);
+    }
+    return fail(SLA_ERR_INVALID, "launch_spmv_tiles: unknown epilogue");
+}
+
+int launch_spmv_tiles(const sla_csr *A, const SpmvLaunch &l) {
+    return A->rp64 ? launch_tiles_rp<int64_t>(A, l) : launch_tiles_rp<int32_t>(A, l);
+}
+
+}  // namespace sla

@@ -1,0 +1,112 @@
+"""BASELINE.json configs 2, 3a, 3b, 4, 5 at FULL size against the CPU oracle.
+
+Each test lowers the full-size matrix through the C ABI, multiplies a seeded random x on the device and compares
+with `orc.spmv` (the reference's ascending left fold, Common.hs:247-260 / IntM.hs:78-108) row by row:
+
+  * forms that fold a row in one lane (wdia, wdia-vv: the stencil / banded configs 2, 4, 5) must be BIT-EXACT --
+    at size this exercises what the small tests cannot: the plane-tiled `sched[]` walk, the guard-slack reads at both
+    ends of x, the 32-bit byte offsets of the record gathers;
+  * config 3a (10 M rows, 33 random columns per row: the tile form) folds every row entry by entry in ascending column
+    order as well: BIT-EXACT too;
+  * config 3b (LDS panels at 2000 entries per row) reduces a row in wavefront segments:
+    |dy_i| <= nnz_i * eps * sum_j |a_ij x_j| (the bound of SURVEY 8(a) A1).
+
+Then two `bicgstabStep`s of the oracle (Sparse.hs:972-981) are compared with the device state record at 1e-9.
+"""
+import gc
+
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+EPS = np.finfo(np.float64).eps
+
+
+@pytest.fixture(scope="module")
+def sla():
+    import sla_amd
+    return sla_amd
+
+
+def _check(sla, dims, rp, ci, va, expect_form, bit_exact, b_mode, tag):
+    n = dims[0]
+    A = sla.fromCSR(dims, rp, ci, va)
+    info = A.kernel_info()
+    assert expect_form in info, (tag, info)
+    Ao = orc.Csr(n, n, rp, ci, va)
+    rng = np.random.default_rng(20260928)
+    x = rng.standard_normal(n)
+    y = sla.matVec(A, sla.fromVector(x)).toDenseListSV()
+    yo = orc.spmv(Ao, x)
+    if bit_exact:
+        assert np.array_equal(y, yo), (tag, info, int(np.count_nonzero(y != yo)))
+    else:
+        bound = np.diff(rp) * EPS * orc.spmv(orc.Csr(n, n, rp, ci, np.abs(va)), np.abs(x))
+        bad = np.abs(y - yo) > bound
+        assert not bad.any(), (tag, info, int(bad.sum()), float(np.abs(y - yo).max()))
+        assert np.linalg.norm(y - yo) <= 1e-14 * np.linalg.norm(yo)
+    # two reference steps: state records agree to 1e-9 (x, r, p of Sparse.hs:959-960)
+    if b_mode == "ones":
+        b = np.add.reduceat(va, rp[:-1])                       # b = A . 1
+    else:
+        b = orc.spmv(Ao, np.random.default_rng(7).standard_normal(n))   # b = A x*, x* ~ N(0,1) seed 7 (config 3)
+    x0 = np.zeros(n)
+    so = orc.BicgstabState(Ao, b, x0)
+    sd = sla.bicgsInit(A, sla.fromVector(b), sla.fromVector(x0))
+    so.step(b, 2)                                              # r0hat = b - A 0 = b
+    sd.step(2)
+    for name, dev, ref in (("x", sd._xBicgstab, so.x), ("r", sd._rBicgstab, so.r), ("p", sd._pBicgstab, so.p)):
+        d = dev.toDenseListSV()
+        assert np.linalg.norm(d - ref) <= 1e-9 * np.linalg.norm(ref), (tag, name)
+    del sd, A
+    gc.collect()
+
+
+def test_config2_poisson_1m_bit_exact_vs_oracle(sla):
+    from sla_amd import workloads as wl
+    dims, (rp, ci, va) = wl.poisson2d(1000, 1000)
+    _check(sla, dims, rp, ci, va, "wdia", True, "ones", "config2")
+
+
+def test_config4_laplace3d_10m_bit_exact_vs_oracle(sla):
+    from sla_amd import workloads as wl
+    dims, (rp, ci, va) = wl.laplace3d(216, 216, 216)
+    assert dims[0] == 10077696
+    _check(sla, dims, rp, ci, va, "wdia", True, "ones", "config4")
+
+
+def test_config5_banded_2m_bit_exact_vs_oracle(sla):
+    from sla_amd import workloads as wl
+    dims, (rp, ci, va) = wl.banded_nonsym(2000000)
+    _check(sla, dims, rp, ci, va, "wdia-vv", True, "ones", "config5")
+
+
+def test_config3a_random_spd_10m_vs_oracle(sla):
+    from sla_amd import workloads as wl
+    dims, (rp, ci, va) = wl.random_spd(10000000, 16, 42)
+    assert dims[0] == 10000000 and rp[-1] == 329999456
+    _check(sla, dims, rp, ci, va, "algo=tiles", True, "xstar", "config3a")
+
+
+def test_config3a_cgs_two_steps_vs_oracle_1m(sla):
+    """CGS on config 3a's construction (1 M rows: the oracle's two steps stay in seconds)."""
+    from sla_amd import workloads as wl
+    dims, (rp, ci, va) = wl.random_spd(1000000, 16, 42)
+    n = dims[0]
+    A, Ao = sla.fromCSR(dims, rp, ci, va), orc.Csr(n, n, rp, ci, va)
+    b = orc.spmv(Ao, np.random.default_rng(7).standard_normal(n))
+    x0 = np.zeros(n)
+    so, sd = orc.CgsState(Ao, b, x0), sla.cgsInit(A, sla.fromVector(b), sla.fromVector(x0))
+    so.step(b, 2)
+    sd.step(2)
+    for name, dev, ref in (("x", sd._x, so.x), ("r", sd._r, so.r), ("p", sd._p, so.p), ("u", sd._u, so.u)):
+        assert np.linalg.norm(dev.toDenseListSV() - ref) <= 1e-9 * np.linalg.norm(ref), name
+
+
+def test_config3b_dense_rows_200k_vs_oracle(sla):
+    from sla_amd import workloads as wl
+    dims, (rp, ci, va) = wl.random_spd(200000, 1000, 42)
+    assert dims[0] == 200000 and 1990 <= rp[-1] / dims[0] <= 2001      # 1 % density honoured
+    _check(sla, dims, rp, ci, va, "ldspanels", False, "xstar", "config3b")

@@ -1,0 +1,141 @@
+"""The row-slice x column-panel tile form of (#>) (spmv_tile_kernel, csrc/sla_spmv_tiles.hip; lowering
+csrc/sla_lower_tiles.cpp) against the oracle.  The form is meant for irregular matrices whose x exceeds an L2-sized
+panel (2^17 columns by default); SLA_TILE_SHIFT=10 (1024-column panels) forces it onto test-sized matrices so that
+every structural case runs in seconds: many panels (> 64: the tile-offset block reload), empty rows and empty tiles,
+rectangular shapes, 64-bit row pointers, (row, panel) segments of several entries (layer boundaries inside a 64-entry
+group: multi-pass groups), rows with hundreds of entries per panel (the lowering must step aside) and every fused
+epilogue through the solvers.
+
+Parity: inside a tile the entries are ordered by (layer, row) and every product is added to its row sum on its own, in
+ascending column order, with separately rounded multiply and add -- BIT-EXACT with the reference's left fold
+(Common.hs:247-260) whatever the row length.  Matrices the lowering leaves to the older forms are checked against
+|dy_i| <= nnz_i * eps * sum_j |a_ij x_j|."""
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+EPS = np.finfo(np.float64).eps
+
+
+@pytest.fixture(scope="module")
+def sla():
+    import sla_amd
+    return sla_amd
+
+
+def _rand_rows(m, n, row_len, seed):
+    """m x n CSR, row i holds row_len(i) distinct uniformly random columns (ascending), values in [-1, 1)."""
+    rng = np.random.default_rng(seed)
+    rp = [0]
+    cols, vals = [], []
+    for i in range(m):
+        k = min(int(row_len(i, rng)), n)
+        c = np.sort(rng.choice(n, size=k, replace=False)) if k else np.zeros(0, np.int64)
+        cols.append(c.astype(np.int64))
+        vals.append(rng.uniform(-1.0, 1.0, k))
+        rp.append(rp[-1] + k)
+    return (m, n), (np.array(rp, np.int64), np.concatenate(cols) if cols else np.zeros(0, np.int64),
+                    np.concatenate(vals) if vals else np.zeros(0))
+
+
+CASES = {
+    # name: (builder, tile form expected)
+    "5 panels, 6 per row": (lambda: _rand_rows(5000, 5000, lambda i, r: 6, 1), True),
+    "98 panels (> 64: offset block reload), 40 per row": (lambda: _rand_rows(3000, 100000, lambda i, r: 40, 2), True),
+    "ragged: empty / 1 / 3 / 33 / 200 entries": (lambda: _rand_rows(7001, 30000, lambda i, r: (0, 1, 3, 33, 200)[i % 5], 3), True),
+    "2 entries per row, 147 panels (mostly empty tiles)": (lambda: _rand_rows(150000, 150000, lambda i, r: 2, 4), True),
+    "wide 900 x 70000": (lambda: _rand_rows(900, 70000, lambda i, r: r.integers(0, 60), 5), True),
+    "tall 60000 x 2500, segments of ~2 (layer boundaries in most groups)": (lambda: _rand_rows(60000, 2500, lambda i, r: 5, 6), True),
+    "segments of ~6: 2500 x 8000, 48 per row": (lambda: _rand_rows(2500, 8000, lambda i, r: 48, 10), True),
+    "one row": (lambda: _rand_rows(1, 9000, lambda i, r: 77, 7), False),
+    "dense rows among sparse ones (hundreds of layers)": (lambda: _rand_rows(4000, 12000, lambda i, r: 9000 if i % 1000 == 7 else 4, 8), False),
+    "all rows dense-ish: 300 per row, 3 panels (100-layer tiles)": (lambda: _rand_rows(2500, 3000, lambda i, r: 300, 9), True),
+}
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_tiles_match_the_oracle(sla, monkeypatch, name):
+    build, expect_tiles = CASES[name]
+    dims, csr = build()
+    m, n = dims
+    rp, ci, va = csr
+    Ao = orc.Csr(m, n, rp, ci, va)
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal(n)
+    want = orc.spmv(Ao, x)
+    bound = np.diff(rp) * EPS * orc.spmv(orc.Csr(m, n, rp, ci, np.abs(va)), np.abs(x)) + 1e-300
+    monkeypatch.setenv("SLA_TILE_SHIFT", "10")
+    monkeypatch.setenv("SLA_LPANEL", "0")                        # (the dense-row cases would otherwise take the LDS-panel form)
+    for rp64 in ("0", "1"):
+        monkeypatch.setenv("SLA_FORCE_RP64", rp64)
+        ctx = sla.Context(0)
+        A = sla.fromCSR(dims, rp, ci, va, ctx)
+        info = A.kernel_info()
+        assert ("algo=tiles" in info) == expect_tiles, (name, info)
+        y = sla.matVec(A, sla.fromVector(x, ctx)).toDenseListSV()
+        if expect_tiles:
+            assert "exact_fold=1" in info
+            assert np.array_equal(y, want), (name, rp64, int(np.count_nonzero(y != want)))
+        else:
+            assert np.all(np.abs(y - want) <= bound), (name, rp64, float(np.abs(y - want).max()))
+        y2 = sla.matVec(A, sla.fromVector(x, ctx)).toDenseListSV()
+        assert np.array_equal(y, y2)                             # deterministic
+    # the same matrix on the forms the tile form replaces
+    monkeypatch.setenv("SLA_FORCE_RP64", "0")
+    monkeypatch.setenv("SLA_TILES", "0")
+    ctx = sla.Context(0)
+    A = sla.fromCSR(dims, rp, ci, va, ctx)
+    assert "tiles" not in A.kernel_info()
+    y0 = sla.matVec(A, sla.fromVector(x, ctx)).toDenseListSV()
+    assert np.all(np.abs(y0 - want) <= bound)
+
+
+def test_tiles_transpose_and_solver_epilogues(sla, monkeypatch):
+    """(<#), bicgsInit / bicgstabStep (EPI_SUB, EPI_DOT, EPI_DOT2), cgsStep (EPI_AXPY_DOT), cgneStep (EPI_AXPY_DOT on A,
+    EPI_XPBY_NRM on the transpose) and linSolve0's residual sweep (EPI_RES) on the tile form."""
+    from sla_amd import workloads as wl
+    monkeypatch.setenv("SLA_TILE_SHIFT", "10")
+    ctx = sla.Context(0)
+    n = 6000
+    dims, (rp, ci, va) = wl.random_spd(n, 5, 3)
+    A, Ao = sla.fromCSR(dims, rp, ci, va, ctx), orc.Csr(n, n, rp, ci, va)
+    assert "algo=tiles" in A.kernel_info()
+    rng = np.random.default_rng(5)
+    u = rng.standard_normal(n)
+    assert np.array_equal(sla.vecMat(sla.fromVector(u, ctx), A).toDenseListSV(), orc.spmv(orc.transpose(Ao), u))
+    xs = rng.standard_normal(n)
+    b, x0 = orc.spmv(Ao, xs), np.full(n, 0.1)
+    r0hat = b - orc.spmv(Ao, x0)
+    so, sd = orc.BicgstabState(Ao, b, x0), sla.bicgsInit(A, sla.fromVector(b, ctx), sla.fromVector(x0, ctx))
+    assert np.array_equal(sd._rBicgstab.toDenseListSV(), so.r)               # r0 = b - A x0: exact fold, same subtraction
+    for k in (1, 2):
+        so.step(r0hat, k); sd.step(k)
+        assert np.linalg.norm(sd._xBicgstab.toDenseListSV() - so.x) <= 1e-9 * np.linalg.norm(so.x)
+        assert np.linalg.norm(sd._pBicgstab.toDenseListSV() - so.p) <= 1e-8 * np.linalg.norm(so.p)
+    so, sd = orc.CgsState(Ao, b, x0), sla.cgsInit(A, sla.fromVector(b, ctx), sla.fromVector(x0, ctx))
+    so.step(r0hat, 3); sd.step(3)
+    assert np.linalg.norm(sd._x.toDenseListSV() - so.x) <= 1e-9 * np.linalg.norm(so.x)
+    assert np.linalg.norm(sd._u.toDenseListSV() - so.u) <= 1e-8 * np.linalg.norm(so.u)
+    so, sd = orc.CgneState(Ao, b, x0), sla.cgneInit(A, sla.fromVector(b, ctx), sla.fromVector(x0, ctx))
+    so.step(3); sd.step(3)
+    assert np.linalg.norm(sd._xCgne.toDenseListSV() - so.x) <= 1e-9 * np.linalg.norm(so.x)
+    for meth in (sla.BICGSTAB_, sla.CGS_, sla.CGNE_):
+        x, info = sla.linSolve0(meth, A, sla.fromVector(b, ctx), sla.fromVector(x0, ctx), return_info=True)
+        rc, xo, it_o, res_o, r0_o = orc.linsolve0(meth, Ao, b, x0)
+        assert info["converged"] and abs(info["iters"] - it_o) <= 2, (meth, info, it_o)
+        assert np.linalg.norm(orc.spmv(Ao, x.toDenseListSV()) - b) <= info["tol"] * (1 + 1e-9)
+        assert abs(info["r0norm"] - r0_o) <= 1e-12 * r0_o
+
+
+def test_default_panel_width_picks_tiles_only_beyond_the_l2(sla):
+    from sla_amd import workloads as wl
+    ctx = sla.Context(0)
+    dims, (rp, ci, va) = wl.random_spd(250000, 4, 1)          # x = 2 MB: fits the L2, no panels of any kind
+    assert "tiles" not in sla.fromCSR(dims, rp, ci, va, ctx).kernel_info()
+    dims, (rp, ci, va) = wl.random_spd(700000, 4, 1)          # 5.6 MB of x: six 1 MiB panels
+    A = sla.fromCSR(dims, rp, ci, va, ctx)
+    assert "algo=tiles" in A.kernel_info() and "panels=6" in A.kernel_info(), A.kernel_info()
+    x = np.random.default_rng(2).standard_normal(dims[0])
+    assert np.array_equal(sla.matVec(A, sla.fromVector(x, ctx)).toDenseListSV(), orc.spmv(orc.Csr(*dims, rp, ci, va), x))
