@@ -3,21 +3,39 @@
 
 One "step" = one bicgstabStep (Sparse.hs:972-981: 2 SpMV + 5 inner products + 6 vector updates, all on
 the device) on the BASELINE.json workload.  Default workload = configs[3], the one the metric is quoted
-on at 1/2/4/8 GPUs: the 10M-row (216^3 = 10 077 696) fp64 7-point 3-D Laplacian (the "~1 % density" of
-configs[2] would be 10^12 entries; its 33-entries-per-row reading is --workload random_spd_10m); at N > 1 it is
+on at 1/2/4/8 GPUs: the 10M-row (216^3 = 10 077 696) fp64 7-point 3-D Laplacian; at N > 1 it is
 row-sharded in contiguous slabs (strong scaling: total size fixed), each SpMV preceded by an exchange of its input
 over RCCL (the slab's halo planes through grouped ncclSend/ncclRecv, or the all-gather when a matrix needs most
 of x).  Inputs are resident in HBM before the timed region.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--method bicgstab|cgs] [--mode step|linsolve0|gmres] [--no-cpu-baseline]
-                    [--workload laplace3d_10m|poisson2d_1m|banded_2m|random_spd_1m|random_spd_10m|dense_rows_200k]
+The ONE JSON line rank 0 prints carries, next to the contract fields:
+  kernels         every kernel of the timed step (K1..K5), HIP-event timed inside the timed region on the library's
+                  stream: ms, the bytes of the storage form it streams (`bytes`), the SURVEY 8(d) CSR figure
+                  (`csr_bytes`), GB/s and fraction of the 8 TB/s peak for both;
+  roofline        the DOMINANT kernel of the step (largest share of the step time).  `frac` is priced on the bytes of the
+                  storage form actually streamed and is <= 1; `effective_*` uses the SURVEY 8(d) CSR bytes (a losslessly
+                  compressed matrix form makes that exceed the streamed figure);
+  general_csr     the same matrix with the value-indexed / dictionary forms off (SLA_WDIA=0 SLA_VDICT=0 SLA_DIAG=0): the
+                  plain f64 + i32 CSR-stream kernel -- "CSR SpMV achieved HBM GB/s" in the literal sense;
+  random_spd_10m  BASELINE configs[2] (10 M rows, ~33 random columns per row: the north star's target matrix);
+  cpu_baseline    the oracle port timed on this host's cores (bounded sample).
 
-For N > 1 launch through torch.distributed.run (one rank per GPU); rank 0 prints ONE JSON line.
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--method bicgstab|cgs] [--mode step|linsolve0|gmres]
+                    [--workload laplace3d_10m|poisson2d_1m|banded_2m|random_spd_1m|random_spd_10m|dense_rows_200k]
+                    [--no-cpu-baseline] [--no-extra-blocks]
+
+N > 1: either launched by torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE in the environment) or stand-alone --
+`python bench.py --gpus N` then spawns the N ranks itself (one process per GPU, rendezvous on 127.0.0.1).  With fewer
+than N GPUs visible and SLA_BENCH_LOOPBACK=1 the N ranks run as threads of one process on one GPU through the library's
+loopback communicator (a rehearsal of the sharded flow, flagged "loopback": true -- not a scaling measurement).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -32,6 +50,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; 
 
 def workload(name, row_begin=0, row_end=None):
     from sla_amd import workloads as wl
+    from sla_amd.partition import local_rows_of
     if name == "laplace3d_10m":
         return "10M-row fp64 7-pt 3-D Laplacian (216^3 = 10077696 rows), BiCGSTAB", wl.laplace3d(216, 216, 216, row_begin, row_end)
     if name == "poisson2d_1m":
@@ -42,21 +61,14 @@ def workload(name, row_begin=0, row_end=None):
         return "108^3 7-pt Laplacian (1.26M rows)", wl.laplace3d(108, 108, 108, row_begin, row_end)
     if name == "laplace3d_small":
         return "64^3 7-pt Laplacian (test size)", wl.laplace3d(64, 64, 64, row_begin, row_end)
-    if name == "random_spd_10m":
-        dims, (rp, ci, va) = wl.random_spd(10000000, 16, 42)
-        row_end = dims[0] if row_end is None else row_end
-        from sla_amd.partition import local_rows_of
-        return "10M-row fp64 random SPD (~33 nnz/row, density 3.3e-6)", (dims, local_rows_of(rp, ci, va, row_begin, row_end))
-    if name == "dense_rows_200k":
-        dims, (rp, ci, va) = wl.random_spd(200000, 1000, 42)
-        row_end = dims[0] if row_end is None else row_end
-        from sla_amd.partition import local_rows_of
-        return "200k-row fp64 random SPD at 1 % density (~2000 nnz/row)", (dims, local_rows_of(rp, ci, va, row_begin, row_end))
-    if name == "random_spd_1m":
-        dims, (rp, ci, va) = wl.random_spd(1000000, 16, 42)
-        row_end = dims[0] if row_end is None else row_end
-        from sla_amd.partition import local_rows_of
-        return "1M-row fp64 random SPD (~33 nnz/row), BiCGSTAB", (dims, local_rows_of(rp, ci, va, row_begin, row_end))
+    rand = {"random_spd_10m": (10000000, 16, "10M-row fp64 random SPD (~33 nnz/row, density 3.3e-6)"),
+            "dense_rows_200k": (200000, 1000, "200k-row fp64 random SPD at 1 % density (~2000 nnz/row)"),
+            "random_spd_1m": (1000000, 16, "1M-row fp64 random SPD (~33 nnz/row), BiCGSTAB"),
+            "random_spd_small": (60000, 16, "60k-row random SPD (test size)")}
+    if name in rand:
+        n, k, desc = rand[name]
+        dims, (rp, ci, va) = wl.random_spd(n, k, 42)
+        return desc, (dims, local_rows_of(rp, ci, va, row_begin, dims[0] if row_end is None else row_end))
     raise SystemExit(f"unknown workload {name}")
 
 
@@ -85,7 +97,9 @@ def cpu_baseline(dims, rp, ci, va, b, seconds):
            "sample": f"{steps} bicgstabStep iterations of the same {n}-row matrix, single thread, oracle/sla_oracle.c (gcc -O2 -ffp-contract=off)",
            "host_cores_available": os.cpu_count(),
            "spmv_gbps": (12 * len(ci) + 20 * n) / dts / 1e9}
-    # "fair CPU": the same port built with OpenMP (row-parallel SpMV, parallel reductions), all host cores
+    # the same port built with OpenMP (row-parallel SpMV, parallel reductions), all host cores; every thread first-touches
+    # its own rows of the matrix copy and of the vectors it works on (orc_numa_copy), so a multi-socket host is not
+    # starved by one NUMA node's memory
     try:
         threads = len(os.sched_getaffinity(0))
         try:  # a container CPU quota (cgroup v2 cpu.max) caps the useful thread count below the visible cores
@@ -96,17 +110,20 @@ def cpu_baseline(dims, rp, ci, va, b, seconds):
             pass
         os.environ.setdefault("OMP_NUM_THREADS", str(threads))
         os.environ.setdefault("OMP_PROC_BIND", "spread")
+        os.environ.setdefault("OMP_PLACES", "cores")
         orc.use_omp(True)
-        st = orc.BicgstabState(Ao, b, x0)
-        st.step(r0hat, 2)                                     # warm up the thread team / first touch
+        Ap, bp, r0p = orc.numa_copy(Ao), orc.numa_vec(b), orc.numa_vec(r0hat)
+        st = orc.BicgstabState(Ap, bp, x0)                    # (its x / r / p are first written by the parallel init loops)
+        st.step(r0p, 2)                                       # warm up the thread team
         t0 = time.perf_counter()
-        st.step(r0hat, 1)
+        st.step(r0p, 1)
         t1 = max(time.perf_counter() - t0, 1e-6)
         osteps = max(5, min(400, int(0.4 * seconds / t1)))
         t0 = time.perf_counter()
-        st.step(r0hat, osteps)
+        st.step(r0p, osteps)
         odt = time.perf_counter() - t0
         out["omp"] = {"value": osteps / odt, "unit": "iters/s", "cores": threads, "kind": "port",
+                      "first_touch": "matrix and vectors copied row-parallel before timing (orc_par_copy_csr)",
                       "sample": f"{osteps} bicgstabStep iterations, OpenMP build of the same port (liboracle_omp.so), {threads} threads"}
     except Exception as e:  # the OpenMP leg is informative only
         out["omp"] = {"error": repr(e)}
@@ -115,55 +132,133 @@ def cpu_baseline(dims, rp, ci, va, b, seconds):
     return out
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default=os.environ.get("SLA_BENCH_WORKLOAD", "laplace3d_10m"))
-    ap.add_argument("--mode", default="step", choices=["step", "linsolve0", "gmres"])
-    ap.add_argument("--method", default="bicgstab", choices=["bicgstab", "cgs"], help="step mode: which solver step")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    args = ap.parse_args()
+def kernel_table(ctx, A, nnz_local, n_local, method):
+    """Per-kernel HIP-event statistics of the last ctx.prof_start(KERNEL_ALL) recording, priced two ways: `bytes` = the
+    compulsory bytes of the storage form the kernel streams (matrix_bytes of sla_csr_kernel_info + the vectors),
+    `csr_bytes` = the algorithmic CSR figure of SURVEY 8(d)."""
+    from sla_amd import _lib
+    info = A.kernel_info()
+    mb = int(info.split("matrix_bytes=")[1].split()[0]) if "matrix_bytes=" in info else 12 * nnz_local + 4 * n_local
+    n, z = n_local, nnz_local
+    if method == "bicgstab":
+        defs = [("K1", _lib.KERNEL_SPMV_DOT, "Ap = A p ; Ap . r0hat", mb + 24 * n, 12 * z + 28 * n),
+                ("K2", _lib.KERNEL_BICG_K2, "alpha ; s = r - alpha Ap", 24 * n, 24 * n),
+                ("K3", _lib.KERNEL_SPMV_DOT2, "As = A s ; As . s, As . As", mb + 16 * n, 12 * z + 20 * n),
+                ("K4", _lib.KERNEL_BICG_K4, "omega ; x += alpha p + omega s ; r = s - omega As ; r . r0hat", 56 * n, 56 * n),
+                ("K5", _lib.KERNEL_BICG_K5, "beta ; p = r + beta (p - omega Ap)", 32 * n, 32 * n)]
+    else:   # cgsStep (Sparse.hs:928-939): SURVEY 8(d) B_cgs_step
+        defs = [("C1", _lib.KERNEL_SPMV_DOT, "A p ; A p . rhat", mb + 24 * n, 12 * z + 28 * n),
+                ("C2", _lib.KERNEL_CGS_C2, "alpha ; q = u - alpha A p ; u + q", 32 * n, 32 * n),
+                ("C3", _lib.KERNEL_SPMV_DOT2, "A (u + q) ; x, r updates ; r . rhat", mb + 56 * n, 12 * z + 60 * n),
+                ("C4", _lib.KERNEL_CGS_C4, "beta ; u, p updates", 40 * n, 40 * n)]
+    out = {}
+    for name, kid, what, bts, csr in defs:
+        cnt, mean, mn = ctx.prof_query(kid)
+        if not cnt:
+            continue
+        out[name] = {"id": kid, "what": what, "launches": cnt, "ms": mean, "min_ms": mn, "bytes": bts, "csr_bytes": csr,
+                     "gbps": bts / mean / 1e6, "frac": bts / mean / 1e6 / HBM_PEAK_GBS,
+                     "effective_gbps": csr / mean / 1e6, "effective_frac": csr / mean / 1e6 / HBM_PEAK_GBS}
+    return out
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
-        args.gpus = world
 
-    dist = None
-    # SLA_BENCH_FORCE_DIST=1 drives the multi-rank code path (torch first, gloo control plane, RCCL
-    # communicator, forced collectives) on a single GPU: the only way to rehearse it on a 1-GPU box
-    use_dist = world > 1 or os.environ.get("SLA_BENCH_FORCE_DIST") == "1"
-    if use_dist and world == 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        os.environ["SLA_FORCE_COLLECTIVES"] = "1"
-    if use_dist:
-        import torch
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        # control plane (unique-id broadcast, barriers, max-over-ranks) on gloo; the data plane is the
-        # library's own RCCL communicator over xGMI
-        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+def timed_steps(ctx, st, steps, warmup, sync_all):
+    """Warm-up (which also finds the kernel with the largest share of a step), then EXACTLY `steps` timed steps bracketed by
+    barrier + sync, with HIP events around the dominant kernel's launches only (events around all five kernels of a
+    0.3 ms step cost ~8 % of it), then an untimed pass of the same length with every kernel event-timed for the table.
+    Returns (seconds of the timed region, (launches, mean ms, min ms) of the dominant kernel inside it, its kernel id)."""
+    from sla_amd import _lib
+    ids = (_lib.KERNEL_SPMV_DOT, _lib.KERNEL_SPMV_DOT2, _lib.KERNEL_BICG_K2, _lib.KERNEL_BICG_K4, _lib.KERNEL_BICG_K5,
+           _lib.KERNEL_CGS_C2, _lib.KERNEL_CGS_C4)
+    ctx.prof_start(_lib.KERNEL_ALL, max(warmup, 1) * 6 + 8)
+    st.step(max(warmup, 1))
+    ctx.prof_stop()
+    tot = {k: (lambda c, m, _: c * m)(*ctx.prof_query(k)) for k in ids}
+    dom = max(tot, key=tot.get)
+    sync_all()
+    ctx.prof_start(dom, steps)
+    t0 = time.perf_counter()
+    st.step(steps)
+    sync_all()
+    dt = time.perf_counter() - t0
+    dom_stats = ctx.prof_stop()
+    ctx.prof_start(_lib.KERNEL_ALL, steps * 6 + 8)      # untimed: the per-kernel table
+    st.step(steps)
+    ctx.prof_stop()
+    return dt, dom_stats, dom
 
+
+def side_block(name, dims, rp, ci, va, env, steps, warmup):
+    """One more driver-timed block in the same process: lower (dims, rp, ci, va) on a fresh context created under the
+    knob settings `env`, time `steps` bicgstabSteps (barrier + sync on both sides) with every kernel event-timed."""
+    import sla_amd as sla
+    saved = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        ctx = sla.Context(0)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    n, nnz = dims[0], int(rp[-1])
+    A = sla.fromCSRRows(dims, 0, rp, ci, va, ctx)
+    b = np.add.reduceat(va, rp[:-1])
+    st = sla.bicgsInit(A, sla.DeviceVector(ctx, n, b, local=True), sla.DeviceVector(ctx, n))
+    dt, _, _ = timed_steps(ctx, st, steps, warmup, ctx.sync)
+    kt = kernel_table(ctx, A, nnz, n, "bicgstab")
+    k1 = kt.get("K1", {})
+    rec = {"workload": name, "rows": n, "nnz": nnz, "steps": steps, "warmup": warmup, "env": env,
+           "value": steps / dt, "unit": "iters/s", "ms_per_step": dt / steps * 1e3,
+           "step_gbps_csr": (24 * nnz + 160 * n) / (dt / steps) / 1e9,
+           "step_frac_of_hbm_peak_csr": (24 * nnz + 160 * n) / (dt / steps) / 1e9 / HBM_PEAK_GBS,
+           "k1_ms": k1.get("ms"), "k1_gbps": k1.get("gbps"), "k1_frac": k1.get("frac"),
+           "k1_csr_gbps": k1.get("effective_gbps"), "k1_csr_frac": k1.get("effective_frac"),
+           "kernels": {k: {"ms": v["ms"], "frac": v["frac"]} for k, v in kt.items()},
+           "spmv_kernel": A.kernel_info()}
+    del st, A
+    ctx.close()
+    return rec
+
+
+def pmc_traffic(workload_name, mode, world, kernel_name, kinfo):
+    """HBM bytes per launch from the committed PMC passes (bench.py cannot collect counters on itself)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            tr = json.load(f).get(f"{workload_name}/{mode}/n{world}/{kernel_name}")
+        if tr and tr.get("kernel_algo", "") in kinfo:
+            return tr
+    except OSError:
+        pass
+    return None
+
+
+def run_rank(args, rank, world, local_rank, dist_mode, loop=None):
+    """dist_mode: None (single GPU), "rccl" (one process per GPU; torch.distributed for the control plane),
+    "loopback" (threads of one process on one GPU; `loop` = (barrier, shared dict))."""
     import sla_amd as sla
     from sla_amd import _lib
     from sla_amd.partition import row_block
 
-    if use_dist:
+    dist = None
+    if dist_mode == "rccl":
         import torch
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        torch.cuda.set_device(local_rank)
+        # control plane (unique-id broadcast, barriers, max-over-ranks) on gloo; the data plane is the library's own
+        # RCCL communicator over xGMI
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
         uid = [sla.Context.unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
         ctx = sla.Context(local_rank, rank, world, uid[0])
+    elif dist_mode == "loopback":
+        ctx = sla.Context.loopback(rank, world, 4242)
     else:
         ctx = sla.Context(0)
-    sla.set_default_context(ctx)
+        sla.set_default_context(ctx)
 
     # ---- build this rank's slab on the host, lower it once to the device CSR ---------------------------
     if world == 1:
@@ -171,46 +266,62 @@ def main():
         n = dims[0]
         rb, re_ = 0, n
     else:
-        desc0, (dims, _) = workload(args.workload, 0, 1)
+        _, (dims, _) = workload(args.workload, 0, 1)
         n = dims[0]
         rb, re_ = row_block(n, rank, world)
         desc, (dims, (rp, ci, va)) = workload(args.workload, rb, re_)
     nnz_local = int(rp[-1])
+    n_local = re_ - rb
     A = sla.fromCSRRows(dims, rb, rp, ci, va, ctx)
     b_local = np.add.reduceat(va, rp[:-1]) if nnz_local else np.zeros(0)   # b = A . 1  (x* = 1), x0 = 0
-    nnz = nnz_local
-    if use_dist:
-        import torch
-        t = torch.tensor([nnz_local], dtype=torch.int64)
-        dist.all_reduce(t)
-        nnz = int(t.item())
+    if len(b_local) != n_local:                                              # (rows without entries at a slab's end)
+        b_local = np.resize(b_local, n_local)
+
+    def allreduce(v, op="sum"):
+        if dist_mode == "rccl":
+            import torch
+            t = torch.tensor([v], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX if op == "max" else dist.ReduceOp.SUM)
+            return float(t.item())
+        if dist_mode == "loopback":
+            barrier, shared = loop
+            shared.setdefault(("ar", op), {})[rank] = v
+            barrier.wait()
+            vals = list(shared[("ar", op)].values())
+            out = max(vals) if op == "max" else sum(vals)
+            barrier.wait()
+            if rank == 0:
+                shared[("ar", op)] = {}
+            barrier.wait()
+            return out
+        return v
+
+    nnz = int(allreduce(nnz_local))
     bvec = sla.DeviceVector(ctx, n, b_local, local=True)
     x0 = sla.DeviceVector(ctx, n)
 
     def sync_all():
         ctx.sync()
-        if use_dist:
+        if dist_mode == "rccl":
             import torch
             torch.cuda.synchronize()
             dist.barrier()
+        elif dist_mode == "loopback":
+            loop[0].wait()
 
     extra = {}
+    lib = _lib.lib()
+    import ctypes as C
+    kt = {}
     if args.mode == "step":
         st = sla.bicgsInit(A, bvec, x0) if args.method == "bicgstab" else sla.cgsInit(A, bvec, x0)
-        st.step(args.warmup)
-        sync_all()
-        ctx.prof_start(_lib.KERNEL_SPMV_DOT, args.steps)
-        t0 = time.perf_counter()
-        st.step(args.steps)
-        sync_all()
-        dt = time.perf_counter() - t0
-        launches, mean_ms, min_ms = ctx.prof_stop()
+        dt, dom_stats, dom_id = timed_steps(ctx, st, args.steps, args.warmup, sync_all)
+        kt = kernel_table(ctx, A, nnz_local, n_local, args.method)
+        launches, mean_ms, min_ms = dom_stats
         step_bytes = 24 * nnz + 160 * n
         mode_desc = f"{'bicgstabStep' if args.method == 'bicgstab' else 'cgsStep'} (2 SpMV, no true-residual SpMV)"
     elif args.mode == "gmres":
         # config 5: GMRES(30) on the device Arnoldi; a "step" = one Arnoldi step (SpMV + 2-pass classical GS)
-        lib = _lib.lib()
-        import ctypes as C
         out = sla.DeviceVector(ctx, n)
         info = _lib.SolveInfo()
         restart = 30
@@ -231,17 +342,15 @@ def main():
         extra["gmres_iters"] = info.iters
     else:
         # reference-faithful linSolve0 iteration: bicgstabStep + true residual ||A x - b|| every iteration
-        lib = _lib.lib()
-        import ctypes as C
         out = sla.DeviceVector(ctx, n)
         info = _lib.SolveInfo()
         o = _lib.SolveOpts(args.warmup, 0.0, 0.0, 16, 1)
         _lib.check(lib.sla_linsolve0(4, A.h, bvec.h, x0.h, C.byref(o), out.h, C.byref(info)))
         sync_all()
         o = _lib.SolveOpts(args.steps, 0.0, 0.0, max(args.steps, 1), 1)      # tol 0: run exactly K iterations
-        # (the wave-sliced form streams ~2 B of matrix per row: nothing to fuse, the library keeps the sweeps apart)
-        dual = (not use_dist and os.environ.get("SLA_DUAL_SPMV", "1") != "0" and os.environ.get("SLA_SPMV_ALGO", "stream") == "stream"
-                and "algo=wdia" not in A.kernel_info() and "ldspanels" not in A.kernel_info())
+        kinfo0 = A.kernel_info()
+        dual = (dist_mode is None and os.environ.get("SLA_DUAL_SPMV", "1") != "0" and os.environ.get("SLA_SPMV_ALGO", "stream") == "stream"
+                and "algo=wdia" not in kinfo0 and "ldspanels" not in kinfo0 and "algo=tiles" not in kinfo0 and "colpanels" not in kinfo0)
         ctx.prof_start(_lib.KERNEL_SPMV_DUAL if dual else _lib.KERNEL_SPMV_DOT, args.steps)
         t0 = time.perf_counter()
         _lib.check(lib.sla_linsolve0(4, A.h, bvec.h, x0.h, C.byref(o), out.h, C.byref(info)))
@@ -256,33 +365,25 @@ def main():
         extra["dual_spmv"] = dual
         extra["linsolve0_iters"] = info.iters
 
-    if use_dist:
-        import torch
-        t = torch.tensor([dt], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = allreduce(dt, "max")
 
-    # ---- plain SpMV bandwidth (rank-local rows; includes the all-gather when sharded) -------------------
+    # ---- plain SpMV bandwidth (rank-local rows; includes the exchange when sharded) -----------------------
     # Over ROTATING vector pairs: with one pair the 2 x 80 MB stay in the 256 MB memory-side cache (MALL) between
-    # launches and the figure flatters the kernel; inside a solver the vectors never stay there.  The single-pair
-    # (cache-resident) time is reported next to it.
-    lib = _lib.lib()
-    n_local = re_ - rb
+    # launches and the figure flatters the kernel; inside a solver the vectors never stay there.
     pairs = max(1, min(6, int(2.0e9 // max(1, 16 * n_local))))      # <= 2 GB of extra vectors
     xs = [sla.DeviceVector(ctx, n, np.full(n_local, 1.0 + 0.125 * i), local=True) for i in range(pairs)]
     ys = [sla.DeviceVector(ctx, n) for _ in range(pairs)]
-    xv, yv = xs[0], ys[0]
     for i in range(max(5, pairs)):
         _lib.check(lib.sla_spmv(A.h, xs[i % pairs].h, ys[i % pairs].h))
     sync_all()
-    reps = 60
+    reps = 60 if n_local < 5000000 or "wdia" in A.kernel_info() else 24
     ctx.prof_start(_lib.KERNEL_SPMV, reps)
     for i in range(reps):
         _lib.check(lib.sla_spmv(A.h, xs[i % pairs].h, ys[i % pairs].h))
     sp_launch, sp_mean_ms, sp_min_ms = ctx.prof_stop()
     ctx.prof_start(_lib.KERNEL_SPMV, reps)
     for _ in range(reps):
-        _lib.check(lib.sla_spmv(A.h, xv.h, yv.h))
+        _lib.check(lib.sla_spmv(A.h, xs[0].h, ys[0].h))
     _, sp_cached_ms, _ = ctx.prof_stop()
     spmv_bytes_local = 12 * nnz_local + 20 * n_local
 
@@ -296,80 +397,193 @@ def main():
         _lib.check(lib.sla_axpby(1.0, xs[i % pairs].h, 0.5, ys[i % pairs].h))
     ctx.sync()
     triad_gbps = 24.0 * n_local * triad_reps / (time.perf_counter() - t0) / 1e9
+    comm_ranks = ctx.comm_ranks()
+    sync_all()
+    if rank != 0:
+        return None
 
-    if rank == 0:
-        kinfo = A.kernel_info()
-        k1_bytes = 12 * nnz_local + 28 * n_local      # K1 = SpMV (12 nnz + 20 n) + r0hat read for the fused dot (8 n)
-        if args.mode == "gmres":
-            k1_bytes = 12 * nnz_local + 20 * n_local  # the Arnoldi SpMV is the plain kernel
-        if args.mode == "linsolve0" and extra.get("dual_spmv"):
-            k1_bytes = 12 * nnz_local + 44 * n_local  # K1 + gather of x (8 n) + b (8 n) for the fused residual
+    kinfo = A.kernel_info()
+    rec = {
+        "metric": "bicgstab_iters_per_sec" if args.mode != "gmres" else "gmres_arnoldi_steps_per_sec",
+        "value": args.steps / dt,
+        "unit": "iters/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": desc, "rows": n, "nnz": nnz, "timed": mode_desc,
+                   "index_types": "i32 col / i32 rowptr", "parallelism": f"row-block x{world}",
+                   "spmv_kernel": kinfo},
+        "rccl_ranks": comm_ranks if dist_mode == "rccl" else None,
+    }
+    if dist_mode == "loopback":
+        rec["loopback"] = True
+        rec["loopback_note"] = (f"{world} ranks as threads of one process on ONE GPU through the library's loopback communicator "
+                                "(SLA_BENCH_LOOPBACK=1): a rehearsal of the sharded flow, not a multi-GPU measurement")
+        rec["loopback_ranks"] = comm_ranks
+    if dist_mode:   # what the sharded step exchanges
+        ghost = ("x_exchange=window" in kinfo and os.environ.get("SLA_BICG_GHOST", "1") != "0" and args.mode in ("step", "linsolve0"))
+        rec["config"]["exchange"] = (
+            ("halo (window) send/recv received in place" if "x_exchange=window" in kinfo else "all-gather of x")
+            + (f"; ghost-row {args.method}: {3 if args.method == 'bicgstab' else 2} grouped exchanges per step"
+               + (" + the residual sweep's own exchange and sum" if args.mode == "linsolve0" else "") if ghost
+               else ("; plain flow" if args.mode != "gmres" else "; Arnoldi: one exchange per SpMV, per-column sums all-gathered")))
+    rec.update({
+        "step_gbps_csr": step_bytes / (dt / args.steps) / 1e9,   # SURVEY 8(d) CSR bytes of the step / step time ("effective")
+        "spmv_gbps": spmv_bytes_local * world / (sp_mean_ms * 1e-3) / 1e9 if sp_launch else None,
+        "spmv_ms": sp_mean_ms,                     # rotating over `spmv_vector_pairs` x / y pairs (HBM-resident)
+        "spmv_ms_cache_resident": sp_cached_ms,    # one pair re-used: x and y stay in the memory-side cache
+        "spmv_vector_pairs": pairs,
+        "hbm_measured_ceiling_gbps": triad_gbps,   # axpby triad over the same rotating vectors, same run
+    })
+    # ---- roofline: the dominant kernel of the timed step -------------------------------------------------
+    if kt:
+        step_ms = dt / args.steps * 1e3
+        dom = next(k for k in kt if kt[k]["id"] == dom_id)
+        d = dict(kt[dom])
+        if launches:   # the dominant kernel's own events INSIDE the timed region
+            d.update({"launches": launches, "ms": mean_ms, "min_ms": min_ms, "gbps": d["bytes"] / mean_ms / 1e6,
+                      "frac": d["bytes"] / mean_ms / 1e6 / HBM_PEAK_GBS, "effective_gbps": d["csr_bytes"] / mean_ms / 1e6,
+                      "effective_frac": d["csr_bytes"] / mean_ms / 1e6 / HBM_PEAK_GBS})
+        rec["kernels"] = kt
+        rec["step_bytes_streamed"] = sum(v["bytes"] for v in kt.values())
+        rec["step_gbps"] = rec["step_bytes_streamed"] / (dt / args.steps) / 1e9
+        rec["step_frac_of_hbm_peak"] = rec["step_gbps"] / (HBM_PEAK_GBS * world)
+        rec["roofline"] = {
+            "bound": "hbm", "kernel": f"{dom}: {d['what']}" + (f" [{kinfo.split()[0]}]" if dom in ("K1", "K3", "C1", "C3") else ""),
+            "share_of_step": d["ms"] * d["launches"] / args.steps / step_ms,
+            "bytes_definition": "compulsory bytes of the storage form the kernel streams (matrix_bytes of the chosen SpMV form + the "
+                                "vectors; equal to the SURVEY 8(d) figure for the vector kernels and for the plain CSR forms); "
+                                "effective_* prices the same time on the SURVEY 8(d) CSR bytes (f64 values + i32 columns + i32 row pointers)",
+            "achieved": d["gbps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": d["frac"],
+            "effective_achieved": d["effective_gbps"], "effective_frac": d["effective_frac"],
+            "frac_of_measured_ceiling": d["gbps"] / triad_gbps if triad_gbps else None,
+            "traffic": None, "hbm_achieved": None, "hbm_frac": None,
+            "bytes_per_launch": d["bytes"], "csr_bytes_per_launch": d["csr_bytes"], "avg_launch_ms": d["ms"], "min_launch_ms": d["min_ms"],
+            "launches_timed": d["launches"],
+            "timing": "HIP events around this kernel's launches inside the timed region (library stream); the `kernels` table comes "
+                      "from an untimed pass of the same length right after it, every kernel event-timed"}
+        tr = pmc_traffic(args.workload, args.mode, world, dom, kinfo)
+        if tr:
+            rec["roofline"].update({"traffic": tr["traffic_bytes"], "traffic_source": tr["source"],
+                                    "hbm_achieved": tr["traffic_bytes"] / (d["ms"] * 1e-3) / 1e9,
+                                    "hbm_frac": tr["traffic_bytes"] / (d["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS})
+    else:   # gmres / linsolve0 modes: the SpMV kernel that was event-timed
+        k1_bytes = 12 * nnz_local + (20 if args.mode == "gmres" else 44 if extra.get("dual_spmv") else 28) * n_local
         achieved = k1_bytes / (mean_ms * 1e-3) / 1e9 if launches else 0.0
-        rec = {
-            "metric": "bicgstab_iters_per_sec" if args.mode != "gmres" else "gmres_arnoldi_steps_per_sec",
-            "value": args.steps / dt,
-            "unit": "iters/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True,
-            "scaling": "strong",
-            "vs_baseline": None,
-            "dtype": "f64",
-            "data": "synthetic",
-            "config": {"workload": desc, "rows": n, "nnz": nnz, "timed": mode_desc,
-                       "index_types": "i32 col / i32 rowptr", "parallelism": f"row-block x{world}",
-                       "spmv_kernel": A.kernel_info()},
-        }
-        if use_dist:   # what the sharded step exchanges
-            kinfo_x = A.kernel_info()
-            ghost = ("x_exchange=window" in kinfo_x and os.environ.get("SLA_BICG_GHOST", "1") != "0" and args.mode in ("step", "linsolve0"))
-            rec["config"]["exchange"] = (
-                ("halo (window) send/recv received in place" if "x_exchange=window" in kinfo_x else "all-gather of x")
-                + (f"; ghost-row {args.method}: {3 if args.method == 'bicgstab' else 2} grouped exchanges per step"
-                   + (" + the residual sweep's own exchange and sum" if args.mode == "linsolve0" else "") if ghost
-                   else ("; plain flow" if args.mode != "gmres" else "; Arnoldi: one exchange per SpMV, per-column sums all-gathered")))
-        rec.update({
-            "step_gbps": step_bytes / (dt / args.steps) / 1e9 / 1.0,
-            "step_frac_of_hbm_peak": step_bytes / (dt / args.steps) / 1e9 / (HBM_PEAK_GBS * world),
-            "spmv_gbps": spmv_bytes_local * world / (sp_mean_ms * 1e-3) / 1e9 if sp_launch else None,
-            "spmv_ms": sp_mean_ms,                     # rotating over `spmv_vector_pairs` x / y pairs (HBM-resident)
-            "spmv_ms_cache_resident": sp_cached_ms,    # one pair re-used: x and y stay in the memory-side cache
-            "spmv_vector_pairs": pairs,
-            "hbm_measured_ceiling_gbps": triad_gbps,   # axpby triad over the same rotating vectors, same run
-            "step_frac_of_measured_ceiling": step_bytes / (dt / args.steps) / 1e9 / (triad_gbps * world) if triad_gbps else None,
-            "roofline": {"bound": "hbm",
-                         "kernel": f"{kinfo.split()[0]} {'K1D (K1 + true residual, one sweep)' if extra.get('dual_spmv') else ('plain SpMV' if args.mode == 'gmres' else 'K1: Ap = A p fused with Ap . r0hat')}",
-                         "bytes_definition": "algorithmic CSR bytes of SURVEY 8(d): f64 values + i32 column indices + i32 row "
-                                             "pointers + the vectors.  The value-indexed kernels (wdia / vdict: constant-coefficient "
-                                             "stencils) and the dictionary-index kernel stream a losslessly compressed matrix, so "
-                                             "`traffic` (PMC) is BELOW this figure and `frac` can exceed 1; `hbm_achieved` = traffic "
-                                             "/ launch time is the bandwidth the DRAM side actually delivered",
-                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "frac_of_measured_ceiling": achieved / triad_gbps if triad_gbps else None,
-                         "traffic": None, "hbm_achieved": None, "hbm_frac": None,
-                         "bytes_per_launch": k1_bytes, "avg_launch_ms": mean_ms, "min_launch_ms": min_ms,
-                         "launches_timed": launches},
-        })
-        # HBM traffic of the dominant kernel: measured with PMC counters in separate rocprofv3 passes
-        # (bench.py cannot collect counters on itself) and committed under profiles/
+        rec["roofline"] = {"bound": "hbm", "kernel": f"{kinfo.split()[0]} SpMV of the timed mode", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                           "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None, "bytes_per_launch": k1_bytes,
+                           "bytes_definition": "SURVEY 8(d) CSR bytes (a value-indexed form streams fewer: see --mode step for the split)",
+                           "avg_launch_ms": mean_ms, "min_launch_ms": min_ms, "launches_timed": launches}
+    rec.update(extra)
+    # ---- the blocks the default line carries next to the headline (single GPU, default workload only) --------
+    if world == 1 and args.mode == "step" and args.method == "bicgstab" and args.workload == "laplace3d_10m" and not args.no_extra_blocks:
+        bs, bw = max(10, args.steps // 2), max(3, args.warmup // 2)
         try:
-            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-                tr = json.load(f).get(f"{args.workload}/{args.mode}/n{world}")
-            if tr:
-                rec["roofline"]["traffic"] = tr["traffic_bytes"]
-                rec["roofline"]["traffic_source"] = tr["source"]
-                if tr.get("kernel_algo", "") in kinfo and launches:   # the counters were taken on this kernel
-                    rec["roofline"]["hbm_achieved"] = tr["traffic_bytes"] / (mean_ms * 1e-3) / 1e9
-                    rec["roofline"]["hbm_frac"] = rec["roofline"]["hbm_achieved"] / HBM_PEAK_GBS
-        except OSError:
-            pass
-        rec.update(extra)
-        if not args.no_cpu_baseline and world == 1:
-            rec["cpu_baseline"] = cpu_baseline(dims, rp, ci, va, b_local, args.cpu_seconds)
+            rec["general_csr"] = side_block(desc, dims, rp, ci, va, {"SLA_WDIA": "0", "SLA_VDICT": "0", "SLA_DIAG": "0"}, bs, bw)
+        except Exception as e:
+            rec["general_csr"] = {"error": repr(e)}
+    if not args.no_cpu_baseline and world == 1:
+        rec["cpu_baseline"] = cpu_baseline(dims, rp, ci, va, b_local, args.cpu_seconds)
+    if world == 1 and args.mode == "step" and args.method == "bicgstab" and args.workload == "laplace3d_10m" and not args.no_extra_blocks:
+        del xs, ys, bvec, x0, A
+        rp = ci = va = None
+        try:
+            d3, (dm3, (rp3, ci3, va3)) = workload("random_spd_10m")
+            rec["random_spd_10m"] = side_block(d3, dm3, rp3, ci3, va3, {}, max(10, args.steps // 4), max(3, args.warmup // 2))
+        except Exception as e:
+            rec["random_spd_10m"] = {"error": repr(e)}
+    return rec
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: one child process per GPU, torchrun-style environment."""
+    port = free_port()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    sys.exit(rc)
+
+
+def loopback_ranks(args):
+    """N ranks as N threads on ONE GPU (library loopback communicator): rehearsal of the sharded flow on a 1-GPU box."""
+    barrier = threading.Barrier(args.gpus)
+    shared, out, err = {}, {}, []
+
+    def work(r):
+        try:
+            out[r] = run_rank(args, r, args.gpus, 0, "loopback", (barrier, shared))
+        except BaseException as e:  # noqa: BLE001 -- a dead rank must not leave the others in a barrier
+            err.append(e)
+            barrier.abort()
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(args.gpus)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    if err:
+        raise err[0]
+    return out[0]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default=os.environ.get("SLA_BENCH_WORKLOAD", "laplace3d_10m"))
+    ap.add_argument("--mode", default="step", choices=["step", "linsolve0", "gmres"])
+    ap.add_argument("--method", default="bicgstab", choices=["bicgstab", "cgs"], help="step mode: which solver step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-blocks", action="store_true", help="skip the general_csr / random_spd_10m blocks of the default line")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    args = ap.parse_args()
+
+    world_env = os.environ.get("WORLD_SIZE")
+    if world_env is None and args.gpus > 1:
+        import sla_amd as sla
+        have = sla.Context.device_count()
+        if have >= args.gpus:
+            spawn_ranks(args)                      # does not return
+        if os.environ.get("SLA_BENCH_LOOPBACK") == "1" and have >= 1:
+            rec = loopback_ranks(args)
+            print(json.dumps(rec), flush=True)
+            return
+        raise SystemExit(f"--gpus {args.gpus}: only {have} GPU(s) visible (SLA_BENCH_LOOPBACK=1 rehearses the sharded flow on one GPU)")
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(world_env or "1")
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    args.gpus = world
+    # SLA_BENCH_FORCE_DIST=1 drives the multi-rank code path (gloo control plane, RCCL communicator, forced collectives)
+    # with a 1-rank communicator on a single GPU
+    use_dist = world > 1 or os.environ.get("SLA_BENCH_FORCE_DIST") == "1"
+    if use_dist and world == 1:
+        os.environ["SLA_FORCE_COLLECTIVES"] = "1"
+    rec = run_rank(args, rank, world, local_rank, "rccl" if use_dist else None)
+    if rank == 0:
         print(json.dumps(rec), flush=True)
     if use_dist:
+        import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
 

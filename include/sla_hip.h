@@ -228,17 +228,30 @@ int sla_linsolve(sla_csr_t A, sla_vec_t b, sla_vec_t x_out, sla_solve_info *info
 
 /* kernels whose launches can be bracketed by HIP events on the context stream */
 typedef enum {
+    SLA_KERNEL_ALL = -1,      /* sla_prof_start: record every kernel below, each launch tagged with its id */
     SLA_KERNEL_SPMV = 0,      /* plain y = A x */
     SLA_KERNEL_SPMV_DOT = 1,  /* K1: Ap = A p fused with Ap . r0hat */
     SLA_KERNEL_SPMV_DOT2 = 2, /* K3: As = A s fused with As . s, As . As */
     SLA_KERNEL_SPMV_RES = 3,  /* true-residual SpMV fused with ||A x - b||^2 */
     SLA_KERNEL_SPMV_DUAL = 4, /* K1 + true residual of the previous iterate from ONE matrix sweep (linSolve0) */
-    SLA_KERNEL_COUNT = 8
+    SLA_KERNEL_BICG_K2 = 5,   /* alpha ; s = r - alpha Ap */
+    SLA_KERNEL_BICG_K4 = 6,   /* omega ; x += alpha p + omega s ; r = s - omega As ; r . r0hat */
+    SLA_KERNEL_BICG_K5 = 7,   /* beta ; p = r + beta (p - omega Ap) */
+    SLA_KERNEL_CGS_C2 = 8,    /* alpha ; q = u - alpha A p ; u + q ; x += alpha (u + q) */
+    SLA_KERNEL_CGS_C4 = 9,    /* beta ; u = r + beta q ; p = u + beta (q + beta p) */
+    SLA_KERNEL_COUNT = 16
 } sla_kernel_id;
-/* record up to `max_launches` event pairs around launches of `kernel_id` from now on */
+/* record up to `max_launches` event pairs around launches of `kernel_id` (SLA_KERNEL_ALL: of every kernel above) from now on */
 int sla_prof_start(sla_ctx_t, int kernel_id, int max_launches);
-/* synchronise, return the number of recorded launches and their mean / min duration in ms */
+/* synchronise, return the number of recorded launches and their mean / min duration in ms (over all recorded kernels) */
 int sla_prof_stop(sla_ctx_t, int *launches, double *mean_ms, double *min_ms);
+/* after sla_prof_stop: the same statistics for one kernel id of the last recording */
+int sla_prof_query(sla_ctx_t, int kernel_id, int *launches, double *mean_ms, double *min_ms);
+/* number of HIP devices visible to this process (0 without a GPU; never fails) */
+int sla_device_count(int *count);
+/* ranks of the communicator behind this context: ncclCommCount for an RCCL communicator, the group size for the loopback
+ * test backend, 1 for a single-GPU context */
+int sla_ctx_comm_ranks(sla_ctx_t, int *nranks);
 /* name of the SpMV form picked for A at lowering time and its launch geometry: "wdia" (wave-sliced (offset, value)
  * records: constant-coefficient stencils), "vdict[+xwin]" (one byte per entry), "stream+diagdict[+xwin]" (values +
  * 1-byte column codes), "stream[+xwin]" (values + i32 columns), "stream+ldspanels" (dense rows: x in LDS panels), "stream+colpanels" (irregular,

@@ -133,6 +133,21 @@ def is_diagonal(A):
     return bool(lib().orc_is_diagonal(C.c_int64(A.m), _p(A.rowptr), _p(A.colidx)))
 
 
+def numa_copy(A):
+    """A copy of A whose pages are first touched row-parallel by the CURRENT library's thread team (use_omp(True) first):
+    the OpenMP timing leg then reads every row block from the NUMA node of the thread that owns it."""
+    rp, ci, va = np.empty_like(A.rowptr), np.empty_like(A.colidx), np.empty_like(A.val)
+    lib().orc_par_copy_csr(C.c_int64(A.m), _p(A.rowptr), _p(A.colidx), _p(A.val), _p(rp), _p(ci), _p(va))
+    return Csr(A.m, A.n, rp, ci, va)
+
+
+def numa_vec(v):
+    v = _f64(v)
+    out = np.empty_like(v)
+    lib().orc_par_copy_f64(C.c_int64(len(v)), _p(v), _p(out))
+    return out
+
+
 def spmv(A, x):
     x = _f64(x)
     y = np.zeros(A.m, dtype=np.float64)

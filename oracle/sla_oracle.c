@@ -189,6 +189,30 @@ void orc_scale(int64_t n, double a, const double *x, double *out) {
     for (int64_t i = 0; i < n; ++i) out[i] = a * x[i];
 }
 
+/* TIMING BUILD ONLY (liboracle_omp.so): copies whose pages are first touched by the thread that will read them in the
+ * row-parallel loops above (schedule(static) over rows / elements), so that a multi-socket host serves every thread from
+ * its own NUMA node.  Plain copies in the serial build. */
+void orc_par_copy_csr(int64_t m, const int64_t *rowptr, const int64_t *colidx, const double *val, int64_t *rowptr2,
+                      int64_t *colidx2, double *val2) {
+#ifdef ORC_OMP
+#pragma omp parallel for schedule(static)
+#endif
+    for (int64_t i = 0; i < m; ++i) {
+        rowptr2[i] = rowptr[i];
+        for (int64_t k = rowptr[i]; k < rowptr[i + 1]; ++k) {
+            colidx2[k] = colidx[k];
+            val2[k] = val[k];
+        }
+    }
+    rowptr2[m] = rowptr[m];
+}
+void orc_par_copy_f64(int64_t n, const double *src, double *dst) {
+#ifdef ORC_OMP
+#pragma omp parallel for schedule(static)
+#endif
+    for (int64_t i = 0; i < n; ++i) dst[i] = src[i];
+}
+
 static double *vnew(int64_t n) { return (double *)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1)); }
 
 /* ---------------------------------------------------------------- A5: BiCGSTAB */

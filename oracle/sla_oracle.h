@@ -46,6 +46,10 @@ int orc_csr_transpose(int64_t m, int64_t n, const int64_t *rowptr, const int64_t
 int orc_is_diagonal(int64_t m, const int64_t *rowptr, const int64_t *colidx);
 
 /* A1: (#>) = matVecSD, Common.hs:247-250 + dotu :259-260 */
+/* timing build helpers (first-touch copies for the OpenMP leg of bench.py's cpu_baseline; plain copies otherwise) */
+void orc_par_copy_csr(int64_t m, const int64_t *rowptr, const int64_t *colidx, const double *val, int64_t *rowptr2,
+                      int64_t *colidx2, double *val2);
+void orc_par_copy_f64(int64_t n, const double *src, double *dst);
 void orc_spmv(int64_t m, const int64_t *rowptr, const int64_t *colidx, const double *val,
               const double *x, double *y);
 /* A2: (<.>), SpVector.hs:116-117 */

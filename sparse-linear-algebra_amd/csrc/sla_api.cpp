@@ -22,8 +22,9 @@ int fail(int code, const std::string &msg) {
 }
 
 ProfScope::ProfScope(sla_ctx *ctx, int kernel_id) : c(ctx), on(false) {
-    if (c->prof_kernel == kernel_id && c->prof_count < c->prof_max) {
+    if (kernel_id >= 0 && (c->prof_kernel == kernel_id || c->prof_kernel == SLA_KERNEL_ALL) && c->prof_count < c->prof_max) {
         on = true;
+        c->prof_ids[(size_t)c->prof_count] = kernel_id;
         (void)hipEventRecord(c->prof_ev[2 * (size_t)c->prof_count], c->stream);
     }
 }
@@ -1349,6 +1350,24 @@ int sla_csr_kernel_info(sla_csr_t A, char *buf, int buflen) {
             snprintf(buf + used, (size_t)buflen - used, " lds_panels=%d panel_cols=%d lanes_per_segment=%d tasks=%d", A->lp_P, A->lp_W,
                      64 >> A->lp_cfg, A->lp_P * A->lp_C);
     }
+    {   // bytes of matrix data the chosen form streams per (#>) (what K1's HBM roofline is priced against in bench.py)
+        const sla_ctx *c = A->ctx;
+        const int64_t rps = A->rp64 ? 8 : 4;
+        int64_t mb;
+        if (c->spmv_algo == 1) mb = 12 * A->nnz + rps * (A->rows + 1);
+        else if (A->use_wdia && wd_on(A)) mb = A->nwent * (A->wd_vv ? 20 + 128 * 8 : 28) + 4 * ((int64_t)A->nslices + 1);
+        else if (A->use_vdict && c->vdict) mb = A->nnz + 4 * (A->rows + 1);
+        else if (A->use_lpanel && c->lpanel) mb = 12 * A->nnz + (int64_t)(A->lp_P + 1) * A->rows * rps + 16 * (int64_t)A->lp_P * A->rows;
+        else if (tiles_on(A)) mb = 12 * A->nnz + 4 * (int64_t)A->tl_S * (A->tl_P + 1) + 4 * ((int64_t)A->tl_S + 1) + rps * A->tl_S;
+        else if (!A->panels.empty() && c->panels) mb = 12 * A->nnz + (int64_t)A->panels.size() * (rps * A->rows + 8 * (int64_t)A->nrb) + 16 * ((int64_t)A->panels.size() - 1) * A->rows;
+        else mb = (A->use_diag && c->diag ? 9 : 12) * A->nnz + rps * (A->rows + 1) + (4 + rps) * (int64_t)A->nrb;
+        const size_t used = strlen(buf);
+        if (used + 1 < (size_t)buflen) snprintf(buf + used, (size_t)buflen - used, " matrix_bytes=%lld", (long long)mb);
+        if (!A->panels.empty() && c->panels && !tiles_on(A) && c->spmv_algo == 0) {
+            const size_t u2 = strlen(buf);
+            if (u2 + 1 < (size_t)buflen) snprintf(buf + u2, (size_t)buflen - u2, " col_panels=%d", (int)A->panels.size());
+        }
+    }
     if (tiles_on(A)) {   // tile geometry; exact_fold: every row is folded entry by entry in ascending column order
         const size_t used = strlen(buf);
         if (used + 1 < (size_t)buflen)
@@ -1513,32 +1532,61 @@ int sla_plan_window_exchange(int nranks, int rank, int64_t n, const int64_t *win
 // ---- measurement hooks ---------------------------------------------------------------------------------
 
 int sla_prof_start(sla_ctx_t c, int kernel_id, int max_launches) {
-    if (!c || max_launches < 0 || kernel_id < 0 || kernel_id >= SLA_KERNEL_COUNT) return fail(SLA_ERR_INVALID, "sla_prof_start: bad argument");
+    if (!c || max_launches < 0 || kernel_id < SLA_KERNEL_ALL || kernel_id >= SLA_KERNEL_COUNT) return fail(SLA_ERR_INVALID, "sla_prof_start: bad argument");
     while ((int)c->prof_ev.size() < 2 * max_launches) {
         hipEvent_t ev;
         SLA_HIP_TRY(hipEventCreate(&ev));
         c->prof_ev.push_back(ev);
     }
+    c->prof_ids.assign((size_t)max_launches, -2);
+    c->prof_ms.clear();
     c->prof_kernel = kernel_id;
     c->prof_max = max_launches;
     c->prof_count = 0;
     return SLA_OK;
 }
 
+static void prof_stats(const sla_ctx *c, int kernel_id, int *launches, double *mean_ms, double *min_ms) {
+    double sum = 0.0, mn = 1e300;
+    int cnt = 0;
+    for (size_t i = 0; i < c->prof_ms.size(); ++i) {
+        if (kernel_id != SLA_KERNEL_ALL && c->prof_ids[i] != kernel_id) continue;
+        sum += c->prof_ms[i];
+        mn = std::min<double>(mn, c->prof_ms[i]);
+        ++cnt;
+    }
+    if (launches) *launches = cnt;
+    if (mean_ms) *mean_ms = cnt ? sum / cnt : 0.0;
+    if (min_ms) *min_ms = cnt ? mn : 0.0;
+}
+
+int sla_prof_query(sla_ctx_t c, int kernel_id, int *launches, double *mean_ms, double *min_ms) {
+    if (!c || kernel_id < SLA_KERNEL_ALL || kernel_id >= SLA_KERNEL_COUNT) return fail(SLA_ERR_INVALID, "sla_prof_query: bad argument");
+    prof_stats(c, kernel_id, launches, mean_ms, min_ms);
+    return SLA_OK;
+}
+
+int sla_device_count(int *count) {
+    if (!count) return fail(SLA_ERR_INVALID, "null argument");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
+    *count = n;
+    return SLA_OK;
+}
+
+int sla_ctx_comm_ranks(sla_ctx_t c, int *nranks) {
+    if (!c || !nranks) return fail(SLA_ERR_INVALID, "null argument");
+    return dist_comm_count(c, nranks);
+}
+
 int sla_prof_stop(sla_ctx_t c, int *launches, double *mean_ms, double *min_ms) {
     if (!c) return fail(SLA_ERR_INVALID, "null context");
     SLA_HIP_TRY(hipStreamSynchronize(c->stream));
-    double sum = 0.0, mn = 1e300;
-    for (int i = 0; i < c->prof_count; ++i) {
-        float ms = 0.f;
-        SLA_HIP_TRY(hipEventElapsedTime(&ms, c->prof_ev[2 * (size_t)i], c->prof_ev[2 * (size_t)i + 1]));
-        sum += ms;
-        if (ms < mn) mn = ms;
-    }
-    if (launches) *launches = c->prof_count;
-    if (mean_ms) *mean_ms = c->prof_count ? sum / c->prof_count : 0.0;
-    if (min_ms) *min_ms = c->prof_count ? mn : 0.0;
-    c->prof_kernel = -1;
+    c->prof_ms.assign((size_t)c->prof_count, 0.f);
+    for (int i = 0; i < c->prof_count; ++i)
+        SLA_HIP_TRY(hipEventElapsedTime(&c->prof_ms[(size_t)i], c->prof_ev[2 * (size_t)i], c->prof_ev[2 * (size_t)i + 1]));
+    prof_stats(c, SLA_KERNEL_ALL, launches, mean_ms, min_ms);
+    c->prof_kernel = -2;
     c->prof_max = 0;
     return SLA_OK;
 }

@@ -26,6 +26,7 @@ typedef void *NcclComm;
 typedef int (*fn_get_unique_id)(NcclUniqueId *);
 typedef int (*fn_comm_init_rank)(NcclComm *, int, NcclUniqueId, int);
 typedef int (*fn_comm_destroy)(NcclComm);
+typedef int (*fn_comm_count)(NcclComm, int *);
 typedef int (*fn_all_gather)(const void *, void *, size_t, int, NcclComm, hipStream_t);
 typedef int (*fn_all_reduce)(const void *, void *, size_t, int, int, NcclComm, hipStream_t);
 typedef int (*fn_reduce_scatter)(const void *, void *, size_t, int, int, NcclComm, hipStream_t);
@@ -40,6 +41,7 @@ struct Rccl {
     fn_get_unique_id get_unique_id = nullptr;
     fn_comm_init_rank comm_init_rank = nullptr;
     fn_comm_destroy comm_destroy = nullptr;
+    fn_comm_count comm_count = nullptr;
     fn_all_gather all_gather = nullptr;
     fn_all_reduce all_reduce = nullptr;
     fn_reduce_scatter reduce_scatter = nullptr;
@@ -66,6 +68,7 @@ Rccl &rccl() {
         r.get_unique_id = (fn_get_unique_id)dlsym(r.handle, "ncclGetUniqueId");
         r.comm_init_rank = (fn_comm_init_rank)dlsym(r.handle, "ncclCommInitRank");
         r.comm_destroy = (fn_comm_destroy)dlsym(r.handle, "ncclCommDestroy");
+        r.comm_count = (fn_comm_count)dlsym(r.handle, "ncclCommCount");
         r.all_gather = (fn_all_gather)dlsym(r.handle, "ncclAllGather");
         r.all_reduce = (fn_all_reduce)dlsym(r.handle, "ncclAllReduce");
         r.reduce_scatter = (fn_reduce_scatter)dlsym(r.handle, "ncclReduceScatter");
@@ -170,6 +173,20 @@ int dist_comm_destroy(sla_ctx *ctx) {
     if (ctx->comm) {
         rccl().comm_destroy((NcclComm)ctx->comm);
         ctx->comm = nullptr;
+    }
+    return SLA_OK;
+}
+
+// how many ranks does the communicator behind this context span (what RCCL itself reports)
+int dist_comm_count(sla_ctx *ctx, int *nranks) {
+    *nranks = 1;
+    if (LoopGroup *g = loop_of(ctx)) {
+        *nranks = g->nranks;
+    } else if (ctx->comm) {
+        Rccl &r = rccl();
+        if (!r.comm_count) return fail(SLA_ERR_RCCL, "librccl has no ncclCommCount");
+        const int rc = r.comm_count((NcclComm)ctx->comm, nranks);
+        if (rc != 0) return rccl_fail("ncclCommCount", rc);
     }
     return SLA_OK;
 }

@@ -177,7 +177,9 @@ struct sla_ctx {
     std::multimap<size_t, void *> vec_pool;
     size_t vec_pool_bytes = 0;
     // profiling
-    int prof_kernel = -1, prof_max = 0;
+    int prof_kernel = -2, prof_max = 0;   // -2: not recording, SLA_KERNEL_ALL (-1): every kernel id, else one id
+    std::vector<int> prof_ids;            // kernel id of each recorded launch
+    std::vector<float> prof_ms;           // durations of the last recording (filled by sla_prof_stop)
     std::vector<hipEvent_t> prof_ev;
     int prof_count = 0;
 };
@@ -381,6 +383,7 @@ int dist_group_end(sla_ctx *ctx);
 // does the window (halo) exchange of A land in place around vectors of x's shape?  If so: the ghost rows on either side
 bool halo_inplace_extents(const sla_csr *A, const sla_vec *x, int64_t *left, int64_t *right);
 int dist_allreduce_max_i32(sla_ctx *ctx, int *value_host);
+int dist_comm_count(sla_ctx *ctx, int *nranks);
 
 // shared helpers of sla_api.cpp --------------------------------------------------------------------------
 // full-length gather base for an SpMV with matrix A (null: plain all-gather) whose input is `x`

@@ -2162,6 +2162,7 @@ __global__ void __launch_bounds__(kBlock) bicg_k5_kernel(int64_t n, SolverScalar
 
 int launch_bicg_k2(sla_ctx *c, int64_t n, SolverScalars *sc, Parts apr, int par, Parts res, int count_iter,
                    const double *r, const double *ap, double *s) {
+    ProfScope prof(c, SLA_KERNEL_BICG_K2);
     if (vec_stream_nt(c, n))
         hipLaunchKernelGGL(bicg_k2_kernel<true>, dim3(vec_grid(n)), dim3(kBlock), 0, c->stream, n, sc, apr, par, res, count_iter, r, ap, s);
     else
@@ -2171,6 +2172,7 @@ int launch_bicg_k2(sla_ctx *c, int64_t n, SolverScalars *sc, Parts apr, int par,
 }
 int launch_bicg_k4(sla_ctx *c, int64_t n, SolverScalars *sc, Parts ass, Parts asas, const double *p, const double *s,
                    const double *as, const double *r0hat, double *x, double *r, double *prho) {
+    ProfScope prof(c, SLA_KERNEL_BICG_K4);
     if (vec_stream_nt(c, n))
         hipLaunchKernelGGL(bicg_k4_kernel<true>, dim3(vec_grid(n)), dim3(kBlock), 0, c->stream, n, sc, ass, asas, p, s, as, r0hat, x, r, prho);
     else
@@ -2179,6 +2181,7 @@ int launch_bicg_k4(sla_ctx *c, int64_t n, SolverScalars *sc, Parts ass, Parts as
     return SLA_OK;
 }
 int launch_bicg_k5(sla_ctx *c, int64_t n, SolverScalars *sc, Parts rhonew, int par, const double *r, const double *ap, double *p) {
+    ProfScope prof(c, SLA_KERNEL_BICG_K5);
     if (vec_stream_nt(c, n))
         hipLaunchKernelGGL(bicg_k5_kernel<true>, dim3(vec_grid(n)), dim3(kBlock), 0, c->stream, n, sc, rhonew, par, r, ap, p);
     else
@@ -2250,6 +2253,7 @@ __global__ void __launch_bounds__(kBlock) cgs_c4_kernel(int64_t n, SolverScalars
 
 int launch_cgs_c2(sla_ctx *c, int64_t n, SolverScalars *sc, Parts apr, int par, Parts res, int count_iter,
                   const double *u, const double *aap, double *q, double *uq, double *x) {
+    ProfScope prof(c, SLA_KERNEL_CGS_C2);
     if (vec_stream_nt(c, n))
         hipLaunchKernelGGL(cgs_c2_kernel<true>, dim3(vec_grid(n)), dim3(kBlock), 0, c->stream, n, sc, apr, par, res, count_iter, u, aap, q, uq, x);
     else
@@ -2259,6 +2263,7 @@ int launch_cgs_c2(sla_ctx *c, int64_t n, SolverScalars *sc, Parts apr, int par, 
 }
 int launch_cgs_c4(sla_ctx *c, int64_t n, SolverScalars *sc, Parts rhonew, int par, const double *r, const double *q,
                   double *u, double *p) {
+    ProfScope prof(c, SLA_KERNEL_CGS_C4);
     if (vec_stream_nt(c, n))
         hipLaunchKernelGGL(cgs_c4_kernel<true>, dim3(vec_grid(n)), dim3(kBlock), 0, c->stream, n, sc, rhonew, par, r, q, u, p);
     else

@@ -14,7 +14,9 @@ CSRC = os.path.join(_ROOT, "csrc")
  ERR_NO_DEVICE, ERR_NEEDS_PIVOTING) = range(10)
 
 FLAG_CONVERGED, FLAG_MAX_ITERS, FLAG_DIAGONAL, FLAG_BREAKDOWN, FLAG_NONFINITE = 1, 2, 4, 8, 16
+KERNEL_ALL = -1
 KERNEL_SPMV, KERNEL_SPMV_DOT, KERNEL_SPMV_DOT2, KERNEL_SPMV_RES, KERNEL_SPMV_DUAL = 0, 1, 2, 3, 4
+KERNEL_BICG_K2, KERNEL_BICG_K4, KERNEL_BICG_K5, KERNEL_CGS_C2, KERNEL_CGS_C4 = 5, 6, 7, 8, 9
 
 
 class SlaError(RuntimeError):
@@ -112,6 +114,9 @@ PROTOTYPES = [
     ("sla_linsolve", _int, [_vp, _vp, _vp, C.POINTER(SolveInfo)]),
     ("sla_prof_start", _int, [_vp, _int, _int]),
     ("sla_prof_stop", _int, [_vp, _pint, _pdbl, _pdbl]),
+    ("sla_prof_query", _int, [_vp, _int, _pint, _pdbl, _pdbl]),
+    ("sla_device_count", _int, [_pint]),
+    ("sla_ctx_comm_ranks", _int, [_vp, _pint]),
     ("sla_csr_kernel_info", _int, [_vp, C.c_char_p, _int]),
     ("sla_plan_window_exchange", _int, [_int, _int, _i64, _vp, _vp, _vp, _vp, _vp, _pint]),
 ]

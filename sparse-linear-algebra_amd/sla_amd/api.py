@@ -77,6 +77,24 @@ class Context:
         check(lib().sla_prof_stop(self.h, C.byref(n), C.byref(mean), C.byref(mn)))
         return n.value, mean.value, mn.value
 
+    def prof_query(self, kernel_id):
+        """(launches, mean ms, min ms) of one kernel id of the last recording (after prof_stop)."""
+        n, mean, mn = C.c_int(), C.c_double(), C.c_double()
+        check(lib().sla_prof_query(self.h, kernel_id, C.byref(n), C.byref(mean), C.byref(mn)))
+        return n.value, mean.value, mn.value
+
+    def comm_ranks(self):
+        """Ranks the communicator behind this context spans (ncclCommCount for RCCL)."""
+        n = C.c_int()
+        check(lib().sla_ctx_comm_ranks(self.h, C.byref(n)))
+        return n.value
+
+    @staticmethod
+    def device_count():
+        n = C.c_int()
+        check(lib().sla_device_count(C.byref(n)))
+        return n.value
+
     def close(self):
         if self.h:
             lib().sla_ctx_destroy(self.h)

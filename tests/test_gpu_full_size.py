@@ -76,6 +76,33 @@ def test_bench_contract_small():
         assert k in d["cpu_baseline"], k
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] == 1
     assert abs(d["value"] - 1e3 / d["ms_per_step"]) <= 1e-6 * d["value"]
+    # a roofline statement: every printed fraction is priced on bytes the kernel really streams and stays <= 1
+    assert 0.0 < d["roofline"]["frac"] <= 1.0 and d["roofline"]["achieved"] <= d["roofline"]["peak"]
+    assert set(d["kernels"]) == {"K1", "K2", "K3", "K4", "K5"}
+    for k in d["kernels"].values():
+        assert 0.0 < k["frac"] <= 1.0 and k["bytes"] <= k["csr_bytes"] + 64 and k["launches"] == 8
+    assert d["roofline"]["kernel"].split(":")[0] in d["kernels"] and d["roofline"]["launches_timed"] == 8
+    assert d["rccl_ranks"] is None and "general_csr" not in d          # (side blocks ride on the default workload only)
+
+
+def test_bench_two_ranks_without_a_launcher_loopback_rehearsal():
+    """`python bench.py --gpus 2` as the driver types it, on a 1-GPU box: with SLA_BENCH_LOOPBACK=1 the two ranks run as threads
+    through the library's loopback communicator (the real sharded flow: slabs, halo exchange plan, rank-ordered sums)."""
+    env = dict(os.environ, SLA_BENCH_LOOPBACK="1")
+    env.pop("WORLD_SIZE", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "laplace3d_small", "--steps", "8",
+                          "--warmup", "2"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    import sla_amd
+    if sla_amd.Context.device_count() >= 2:
+        assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and "loopback" not in d      # a real node: RCCL saw both ranks
+    else:
+        assert d["n_gpus"] == 2 and d["loopback"] is True and d["loopback_ranks"] == 2
+    assert "x_exchange=window" in d["config"]["spmv_kernel"] and "ghost-row bicgstab: 3 grouped exchanges" in d["config"]["exchange"]
+    assert d["steps"] == 8 and 0.0 < d["roofline"]["frac"] <= 1.0
 
 
 def test_full_size_triangular_solves_recover_ones(sla):
