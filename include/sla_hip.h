@@ -152,6 +152,12 @@ int sla_tri_solve_info(sla_csr_t T, int upper, int64_t *levels, int64_t *widest_
  * hold the structurally non-zero entries ((##) itself would keep explicit zeros over the whole index set; the
  * values at the stored positions are identical).  Single-rank contexts. */
 int sla_ssor_pre(sla_csr_t A, double omega, sla_csr_t *l, sla_csr_t *r);
+/* m1 ## m2 (transpose_b == 0) and m1 ##^ m2 = m1 ## transpose m2 (transpose_b != 0): matMat_ (SpMatrix.hs:768-811).  The result is
+ * STRUCTURALLY DENSE over (rows of m1 holding an entry) x (columns of m2 holding an entry) -- an empty intersection still
+ * yields an explicit 0.0, like the reference's `sum (liftI2 (*) col row)`; every entry is the ascending left fold, from 0,
+ * of separately rounded products.  Incompatible sizes => SLA_ERR_DIM_MISMATCH with the reference's message
+ * ("matMat : incompatible matrix sizes", :795).  Single-rank contexts; at most 2^28 result entries. */
+int sla_csr_matmat(sla_csr_t A, sla_csr_t B, int transpose_b, sla_csr_t *out);
 int sla_csr_destroy(sla_csr_t);
 /* dim / nnz of SpMatrix (local_rows/local_nnz = this rank's block) */
 int sla_csr_dims(sla_csr_t, int64_t *m, int64_t *n, int64_t *nnz_local, int64_t *rows_local);

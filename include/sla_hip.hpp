@@ -12,6 +12,7 @@
 // Exceptions mirror Control/Exception/Common.hs: MatVecSizeMismatchException, IterationException (IterE);
 // an out-of-bounds fromListSM throws std::out_of_range (the reference calls `error`).
 #pragma once
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <memory>
@@ -145,9 +146,22 @@ class SpMatrix {
         check(sla_csr_from_coo(Context::instance().get(), m, n, (int64_t)r.size(), r.data(), c.data(), v.data(), SLA_DUP_LAST_WINS, &a));
         h_.reset(a, sla_csr_destroy);
     }
+    SpMatrix(int64_t m, int64_t n, sla_csr_t owned) : m_(m), n_(n) { h_.reset(owned, sla_csr_destroy); }   // adopt a library handle
     int64_t nrows() const { return m_; }
     int64_t ncols() const { return n_; }
     sla_csr_t get() const { return h_.get(); }
+    // toListSM in ascending (row, col) order (the reference's is the reverse, SpMatrix.hs:251-253)
+    std::vector<Triple> toAscList() const {
+        int64_t nnz = 0, rows = 0;
+        check(sla_csr_dims(h_.get(), nullptr, nullptr, &nnz, &rows));
+        std::vector<int64_t> rp((size_t)rows + 1), ci((size_t)std::max<int64_t>(nnz, 1));
+        std::vector<double> va((size_t)std::max<int64_t>(nnz, 1));
+        check(sla_csr_export(h_.get(), rp.data(), ci.data(), va.data()));
+        std::vector<Triple> out;
+        for (int64_t i = 0; i < rows; ++i)
+            for (int64_t k = rp[(size_t)i]; k < rp[(size_t)i + 1]; ++k) out.emplace_back(i, ci[(size_t)k], va[(size_t)k]);
+        return out;
+    }
     bool isDiagonalSM() const {  // SpMatrix.hs:411-415
         int d;
         check(sla_csr_is_diagonal(h_.get(), &d));
@@ -168,6 +182,18 @@ inline SpMatrix fromListDenseSM(int64_t m, const std::vector<double> &ll) {
     std::vector<SpMatrix::Triple> t;
     for (int64_t k = 0; k < m * n; ++k) t.emplace_back(k % m, k / m, ll[(size_t)k]);
     return SpMatrix(m, n, t);
+}
+
+// m1 ## m2 and m1 ##^ m2 (matMat_ AB / ABt, SpMatrix.hs:768-811); size mismatch throws like `error "matMat : ..."`
+inline SpMatrix matMat(const SpMatrix &A, const SpMatrix &B) {
+    sla_csr_t c;
+    check(sla_csr_matmat(A.get(), B.get(), 0, &c));
+    return SpMatrix(A.nrows(), B.ncols(), c);
+}
+inline SpMatrix matMatT(const SpMatrix &A, const SpMatrix &B) {
+    sla_csr_t c;
+    check(sla_csr_matmat(A.get(), B.get(), 1, &c));
+    return SpMatrix(A.nrows(), B.nrows(), c);
 }
 
 inline SpVector matVec(const SpMatrix &A, const SpVector &x) {  // A #> x

@@ -197,6 +197,18 @@ int vec_alloc(sla_ctx *c, int64_t n, sla_vec **out) {
 static int csr_upload(sla_ctx *c, int64_t m, int64_t n, int64_t row_begin, int64_t rows, const int64_t *rowptr,
                       const int64_t *col, const double *val, sla_csr **out, bool panel_view = false);
 
+// A rank whose input fails validation still owes its peers the agreement collective of csr_upload (they would block in it
+// forever): contribute "failed", then report the local error.
+static int csr_reject(sla_ctx *c, int rc) {
+    if (c && c->collectives) {
+        const std::string msg = g_last_error;
+        int agree = 2;
+        (void)dist_allreduce_max_i32(c, &agree);
+        set_error(msg);
+    }
+    return rc;
+}
+
 // Column panels for irregular matrices (see launch_spmv_panels): panel p = the entries with column in
 // [p W, (p+1) W), as a CSR view over the same rows.  Worth it when x does not fit the XCD-private L2 and
 // every row still has about one entry per panel.
@@ -289,7 +301,8 @@ static int csr_upload(sla_ctx *c, int64_t m, int64_t n, int64_t row_begin, int64
     A->rows = rows;
     A->nnz = nnz;
     // (SLA_FORCE_RP64=1: test hook -- run the 64-bit row-pointer instantiations of the kernels on small matrices)
-    A->rp64 = nnz > (int64_t)std::numeric_limits<int32_t>::max() || c->force_rp64 != 0;
+    // (SLA_FORCE_RP64=2: the parent only -- its column-panel views keep their natural 32-bit width, the mixed case of a > 2^31-entry matrix)
+    A->rp64 = nnz > (int64_t)std::numeric_limits<int32_t>::max() || c->force_rp64 == 1 || (c->force_rp64 == 2 && !panel_view);
     std::vector<int32_t> rb;
     build_row_blocks(rows, rowptr, rb, A->max_row_nnz, c->row_align, c->rb_nnz);
     A->nrb = (int32_t)rb.size() - 1;
@@ -720,20 +733,28 @@ static int csr_upload(sla_ctx *c, int64_t m, int64_t n, int64_t row_begin, int64
         }
     }
     lap("LDS panel table");
+    if (panel_view) {
+        if (err != hipSuccess) {
+            sla_csr_destroy(A);
+            return fail(SLA_ERR_ALLOC, std::string("CSR upload: ") + hipGetErrorString(err));
+        }
+        *out = A;
+        return SLA_OK;
+    }
+    // Every rank enters the agreement collective, failed or not (a rank returning early would leave its peers blocked in
+    // it): the all-reduced maximum carries isDiagonalSM's verdict in bit 0 and "some rank failed" as a value >= 2.
+    int agree = err != hipSuccess ? 2 : diag_not;
+    int rc = dist_allreduce_max_i32(c, &agree);
     if (err != hipSuccess) {
         sla_csr_destroy(A);
         return fail(SLA_ERR_ALLOC, std::string("CSR upload: ") + hipGetErrorString(err));
     }
-    if (panel_view) {
-        *out = A;
-        return SLA_OK;
-    }
-    int rc = dist_allreduce_max_i32(c, &diag_not);
+    if (rc == SLA_OK && agree >= 2) rc = fail(SLA_ERR_INVALID, "matrix creation failed on another rank of the row-sharded job");
     if (rc != SLA_OK) {
         sla_csr_destroy(A);
         return rc;
     }
-    A->is_diagonal = diag_not == 0;
+    A->is_diagonal = agree == 0;
     rc = build_xplan(A, rows, rowptr, col);
     if (rc == SLA_OK) rc = build_tiles(A, n, rows, rowptr, col, val);
     lap("tile form");
@@ -795,7 +816,10 @@ int spmv_transposed(sla_csr *A, const double *x_local, double *y_local, int64_t 
         SLA_HIP_TRY(hipMemsetAsync(c->d_tfull, 0, sizeof(double) * (size_t)std::max<int64_t>(full, 1), c->stream));
         c->tfull_cap = full;
     }
-    l.y = c->d_tfull;  // rows >= n (padding) are never written and stay zero
+    // the padding rows [n, shard * nranks) must read as zero in the reduce-scatter (an earlier, larger matrix may have left
+    // its partials there: the buffer is per context, not per matrix)
+    if (full > T->m) SLA_HIP_TRY(hipMemsetAsync(c->d_tfull + T->m, 0, sizeof(double) * (size_t)(full - T->m), c->stream));
+    l.y = c->d_tfull;
     SLA_TRY(launch_spmv(T, l));
     return dist_reduce_scatter_f64(c, c->d_tfull, y_local, y_shard);
 }
@@ -821,10 +845,16 @@ static int ctx_create_common(int device_id, int rank, int nranks, const void *ui
     c->device = device_id;
     c->rank = rank;
     c->nranks = nranks;
-    SLA_HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    SLA_HIP_TRY(hipMalloc((void **)&c->d_parts, sizeof(double) * 4 * kMaxParts));
-    SLA_HIP_TRY(hipMalloc((void **)&c->d_result, sizeof(double) * 4096));
-    SLA_HIP_TRY(hipHostMalloc((void **)&c->h_result, sizeof(double) * 64, hipHostMallocDefault));
+    {   // (a failing allocation must not leak the half-built context)
+        hipError_t he = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        if (he == hipSuccess) he = hipMalloc((void **)&c->d_parts, sizeof(double) * 4 * kMaxParts);
+        if (he == hipSuccess) he = hipMalloc((void **)&c->d_result, sizeof(double) * 4096);
+        if (he == hipSuccess) he = hipHostMalloc((void **)&c->h_result, sizeof(double) * 64, hipHostMallocDefault);
+        if (he != hipSuccess) {
+            sla_ctx_destroy(c);
+            return fail(SLA_ERR_HIP, std::string("sla_ctx_create: ") + hipGetErrorString(he));
+        }
+    }
     if (const char *s = getenv("SLA_SPMV_ALGO")) c->spmv_algo = (strcmp(s, "scalar") == 0) ? 1 : 0;
     if (const char *s = getenv("SLA_XCD_REMAP")) c->xcd_remap = atoi(s);
     if (const char *s = getenv("SLA_DUAL_SPMV")) c->dual_spmv = atoi(s);
@@ -995,14 +1025,14 @@ int sla_csr_from_csr_rows(sla_ctx_t c, int64_t m, int64_t n, int64_t row_begin, 
         int64_t b, e;
         row_range(c, m, &b, &e);
         if (row_begin != b || row_count != e - b)
-            return fail(SLA_ERR_INVALID, "sla_csr_from_csr_rows: rows do not match sla_ctx_row_range");
-        if (rowptr_local[0] != 0) return fail(SLA_ERR_INVALID, "rowptr_local[0] must be 0");
+            return csr_reject(c, fail(SLA_ERR_INVALID, "sla_csr_from_csr_rows: rows do not match sla_ctx_row_range"));
+        if (rowptr_local[0] != 0) return csr_reject(c, fail(SLA_ERR_INVALID, "rowptr_local[0] must be 0"));
         const int64_t nnz = rowptr_local[row_count];
-        if (nnz > 0 && (!colidx || !val)) return fail(SLA_ERR_INVALID, "null colidx/val");
+        if (nnz > 0 && (!colidx || !val)) return csr_reject(c, fail(SLA_ERR_INVALID, "null colidx/val"));
         // monotone row pointers first (the column checks below index through them), then rows in parallel; the
         // lowest-numbered kind of violation wins so that the result does not depend on the thread count
         for (int64_t i = 0; i < row_count; ++i)
-            if (rowptr_local[i + 1] < rowptr_local[i]) return fail(SLA_ERR_INVALID, "rowptr not monotone");
+            if (rowptr_local[i + 1] < rowptr_local[i]) return csr_reject(c, fail(SLA_ERR_INVALID, "rowptr not monotone"));
         std::vector<int> bad((size_t)host_threads(), 0);   // 1: out of bounds, 2: not strictly ascending
         par_rows(row_count, 1, [&](int t, int64_t lo, int64_t hi) {
             int b_ = 0;
@@ -1013,9 +1043,9 @@ int sla_csr_from_csr_rows(sla_ctx_t c, int64_t m, int64_t n, int64_t row_begin, 
                 }
             bad[(size_t)t] = b_;
         });
-        if (std::find(bad.begin(), bad.end(), 1) != bad.end()) return fail(SLA_ERR_OOB, "insertSpMatrix : index out of bounds");
+        if (std::find(bad.begin(), bad.end(), 1) != bad.end()) return csr_reject(c, fail(SLA_ERR_OOB, "insertSpMatrix : index out of bounds"));
         if (std::find(bad.begin(), bad.end(), 2) != bad.end())
-            return fail(SLA_ERR_INVALID, "columns must be strictly ascending inside a row (canonical CSR)");
+            return csr_reject(c, fail(SLA_ERR_INVALID, "columns must be strictly ascending inside a row (canonical CSR)"));
         (void)hipSetDevice(c->device);
         return csr_upload(c, m, n, row_begin, row_count, rowptr_local, colidx, val, out);
     });

@@ -59,6 +59,18 @@ __device__ __forceinline__ bool residual_converged(SolverScalars *sc, const doub
     return conv;
 }
 
+// Arnoldi breakdown (Sparse.hs:665-667) is flagged by arn_normalize_kernel and acted upon by the kernels that FOLLOW it: the
+// flag was written by an earlier launch, so every workgroup of this launch takes the same exit; workgroup 0 promotes it
+// to `done` (which arn_normalize_kernel itself tests).  Solver flows never raise SLA_FLAG_BREAKDOWN.
+__device__ __forceinline__ bool arn_stopped(SolverScalars *sc) {
+    if (sc->done) return true;
+    if (sc->flags & SLA_FLAG_BREAKDOWN) {
+        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) sc->done = 1;
+        return true;
+    }
+    return false;
+}
+
 // ---------------------------------------------------------------------------------------------
 // SpMV epilogues
 // ---------------------------------------------------------------------------------------------
@@ -96,7 +108,7 @@ __device__ __forceinline__ bool spmv_prologue(const SpmvArgs<RP> &a, double *s4,
     SolverScalars *sc = a.sc;
     coef = 0.0;
     if (sc == nullptr) return true;
-    if (sc->done) return false;
+    if (arn_stopped(sc)) return false;
     if (a.pres) {
         if (residual_converged(sc, a.pres, a.npres, a.pres_stride, s4)) return false;
     }

@@ -1790,15 +1790,17 @@ static int launch_spmv_panels(const sla_csr *A, const SpmvLaunch &l) {
         lp.yinit = p == 0 ? nullptr : ytmp;
         lp.kernel_id = -2;               // never matches: the enclosing scope does the timing
         int rc;
+        // (a view holds only its panel's entries: it may use 32-bit row pointers where the parent needs 64-bit ones)
+        const sla_csr *V = A->panels[p];
         if (!last) {
             lp.epi = EPI_NONE;
             lp.y = ytmp;
             lp.pres = nullptr;            // prologue checks / step bookkeeping happen once, in the last pass
             lp.step_begin = 0;
             lp.pa = nullptr;
-            rc = launch_spmv_t<EPI_NONE, RP>(A->panels[p], lp);
+            rc = V->rp64 ? launch_spmv_t<EPI_NONE, int64_t>(V, lp) : launch_spmv_t<EPI_NONE, int32_t>(V, lp);
         } else {
-            rc = launch_spmv_t<EPI, RP>(A->panels[p], lp);
+            rc = V->rp64 ? launch_spmv_t<EPI, int64_t>(V, lp) : launch_spmv_t<EPI, int32_t>(V, lp);
         }
         if (rc != SLA_OK) return rc;
     }
@@ -2392,7 +2394,7 @@ template <int NC>
 __global__ void __launch_bounds__(kBlock) arn_dots_kernel(int64_t n, const double *Q, int64_t ldq, int ncols,
                                                            const double *w, double *parts, SolverScalars *sc) {
     __shared__ double s_w[4][NC];
-    if (sc->done) return;
+    if (arn_stopped(sc)) return;
     Q += (int64_t)blockIdx.y * NC * ldq;
     parts += (int64_t)blockIdx.y * NC * gridDim.x;
     ncols = min(ncols - (int)blockIdx.y * NC, NC);
@@ -2436,7 +2438,7 @@ __global__ void __launch_bounds__(kBlock) arn_update_kernel(int64_t n, const dou
                                                              double *pn, double *Hcol, SolverScalars *sc) {
     __shared__ double s_h[NC];
     __shared__ double s_red[4];
-    if (sc->done) return;
+    if (arn_stopped(sc)) return;
     // every workgroup re-reduces the ncols dot products in the same fixed order
     for (int j = threadIdx.x >> 6; j < ncols; j += 4) {
         double a = 0.0;
@@ -2490,8 +2492,12 @@ __global__ void __launch_bounds__(kBlock) arn_normalize_kernel(int64_t n, Parts 
         if (hsub) *hsub = nn;
         sc->hnorm = nn;
         if (hsub) sc->kdone += 1;
-        // arnInit performs no breakdown test (:643-651); arnoldiStep does (:665-667)
-        if (!first && fabs(nn) <= 1e-12) { sc->done = 1; sc->flags |= SLA_FLAG_BREAKDOWN; }
+        // arnInit performs no breakdown test (:643-651); arnoldiStep does (:665-667).  Only the FLAG is raised here: `done` is
+        // this kernel's own exit test, and workgroups starting after workgroup 0 wrote it would skip their part of q_{i+1}
+        // (the reference appends the complete normalize2 result).  The next kernel of the chain (the SpMV of step i + 1:
+        // spmv_prologue / arn_stopped) sees the flag -- written by an EARLIER launch, so every workgroup agrees -- exits and
+        // promotes it to `done`.
+        if (!first && fabs(nn) <= 1e-12) sc->flags |= SLA_FLAG_BREAKDOWN;
     }
     SLA_VEC_LOOP_BEGIN(n)
         const double2 wv = ld2(w, i2);

@@ -2,6 +2,7 @@
 // coordinate real general files, 1-based indices shifted to 0-based (toD3), entries fed to fromListSM in
 // file order (so a repeated (i,j) resolves to the LAST one), no symmetric expansion; array files give the
 // dense right-hand side (buildSparse only drops |x| <= 1e-12, which is a no-op for a dense device vector).
+#include <cctype>
 #include <errno.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -26,6 +27,8 @@ struct File {
 int read_header(FILE *f, const char *path, std::string &banner, char *line, size_t cap) {
     if (!fgets(line, (int)cap, f)) return fail(SLA_ERR_INVALID, std::string("empty MatrixMarket file: ") + path);
     banner = line;
+    // (the format is case-insensitive: `%%MatrixMarket MATRIX Coordinate Real General` is legal)
+    for (size_t i = 14; i < banner.size(); ++i) banner[i] = (char)tolower((unsigned char)banner[i]);
     if (banner.compare(0, 14, "%%MatrixMarket") != 0) return fail(SLA_ERR_INVALID, std::string("missing %%MatrixMarket banner: ") + path);
     do {
         if (!fgets(line, (int)cap, f)) return fail(SLA_ERR_INVALID, std::string("truncated MatrixMarket header: ") + path);

@@ -484,29 +484,24 @@ def transpose(A):
     return fromListSM((A.ncols, A.nrows), [(j, i, x) for (i, j, x) in A.toListSM()[::-1]], A.ctx)
 
 
-def matMat(A, B):
-    """(##) (SpMatrix.hs:768-811): structurally dense over rows(A) x cols(B), explicit zeros kept.
-    Host-side helper for the small Hessenberg algebra only."""
-    if A.ncols != B.nrows:
-        raise MatVecSizeMismatchException(_lib.ERR_DIM_MISMATCH, f"matMat : incompatible matrix sizes{(A.dims, B.dims)}")
-    rpa, cia, vaa = A.csr()
-    Bd, cols_b = B.toDense(), sorted(set(B.csr()[1].tolist()))
-    out = []
-    for i in range(A.nrows):
-        if rpa[i + 1] == rpa[i]:
-            continue
-        for j in cols_b:
-            acc = 0.0
-            rpb = B.csr()
-            for k in range(rpa[i], rpa[i + 1]):
-                kk = int(cia[k])
-                # intersection with column j of B: only structurally present b_kj contribute
-                lo, hi = rpb[0][kk], rpb[0][kk + 1]
-                pos = np.searchsorted(rpb[1][lo:hi], j)
-                if pos < hi - lo and rpb[1][lo + pos] == j:
-                    acc = acc + Bd[kk, j] * vaa[k]
-            out.append((i, j, acc))
-    return fromListSM((A.nrows, B.ncols), out, A.ctx)
+def _matmat(A, B, transpose_b):
+    if A.ncols != (B.ncols if transpose_b else B.nrows):
+        raise MatVecSizeMismatchException(_lib.ERR_DIM_MISMATCH, f"matMat : incompatible matrix sizes{(A.dims, B.dims[::-1] if transpose_b else B.dims)}")
+    h = C.c_void_p()
+    check(lib().sla_csr_matmat(A.h, B.h, 1 if transpose_b else 0, C.byref(h)))
+    m, n = C.c_int64(), C.c_int64()
+    check(lib().sla_csr_dims(h, C.byref(m), C.byref(n), None, None))
+    return SpMatrix((m.value, n.value), h, A.ctx)
+
+
+def matMat(A, B):   # also SpMatrix.__matmul__ style helpers below
+    """A ## B (matMat_ AB, SpMatrix.hs:768-811) on the device: structurally dense over rows(A) x cols(B), explicit zeros kept."""
+    return _matmat(A, B, False)
+
+
+def matMatT(A, B):
+    """A ##^ B = A ## transpose B (matMat_ ABt)."""
+    return _matmat(A, B, True)
 
 
 # ---- (#>) (<#) (<.>) norms ---------------------------------------------------------------------------

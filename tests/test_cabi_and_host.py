@@ -105,3 +105,10 @@ def test_fast_random_spd_assembly_equals_the_numpy_definition():
         assert a[0] == b[0]
         for u, w in zip(a[1], b[1]):
             assert u.dtype == w.dtype and np.array_equal(u, w), (n, k)
+
+
+def test_matrix_market_banner_is_case_insensitive():
+    """ the reader lower-cases the banner before matching `coordinate real general` -- checked on the source, the
+    entry point itself needs a GPU context (tests/test_gpu_edge_cases.py reads the golden .mtx files through it)."""
+    src = open(os.path.join(ROOT, "sparse-linear-algebra_amd", "csrc", "sla_mmio.cpp")).read()
+    assert "tolower" in src and src.index("tolower") < src.index('banner.find("coordinate")')

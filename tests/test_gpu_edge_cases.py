@@ -325,3 +325,23 @@ def test_64_bit_row_pointer_kernels(sla, monkeypatch):
         assert np.allclose(res["1"][1], want_t, rtol=1e-12, atol=1e-12), name
         for a, b_ in zip(res["1"], res["0"]):       # the index width changes nothing else: same bits, same iteration counts
             assert np.array_equal(a, b_) if isinstance(a, np.ndarray) else a == b_, name
+
+
+def test_column_panel_views_keep_their_own_row_pointer_width(sla, monkeypatch):
+    """a matrix with more than 2^31 - 1 entries has 64-bit row pointers while each of its column-panel
+    views, holding a fraction of the entries, uses 32-bit ones; the panel passes must run the instantiation of the VIEW.
+    SLA_FORCE_RP64=2 forces the 64-bit width on the parent only, which reproduces that mix at test size."""
+    from sla_amd import workloads as wl
+    dims, (rp, ci, va) = wl.random_spd(3000, 3, 11)
+    n = dims[0]
+    Ao = orc.Csr(n, n, rp, ci, va)
+    x = np.random.default_rng(6).standard_normal(n)
+    b = orc.spmv(Ao, np.random.default_rng(7).standard_normal(n))
+    monkeypatch.setenv("SLA_PANEL_COLS", "500")
+    monkeypatch.setenv("SLA_FORCE_RP64", "2")
+    ctx = sla.Context(0)
+    A = sla.fromCSR(dims, rp, ci, va, ctx)
+    assert "colpanels" in A.kernel_info() and "rowptr=i64" in A.kernel_info(), A.kernel_info()
+    assert np.array_equal(sla.matVec(A, sla.fromVector(x, ctx)).toDenseListSV(), orc.spmv(Ao, x))
+    xs, info = sla.linSolve0(sla.BICGSTAB_, A, sla.fromVector(b, ctx), sla.fromVector(np.zeros(n), ctx), return_info=True)
+    assert info["converged"] and np.linalg.norm(orc.spmv(Ao, xs.toDenseListSV()) - b) <= info["tol"] * (1 + 1e-9)
