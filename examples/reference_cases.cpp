@@ -41,6 +41,24 @@ int main() {
     cgsStep(c, 3);
     EXPECT(nearZero(norm2(c._x() - mkSpVR(3, {1.5, -2, 1}))));
 
+    // the reference's PURE steps: iterate (bicgstabStep aa r0hat) s0 keeps every element (README.md:222-226)
+    {
+        SolverState s0 = bicgsInit(amat, b, x0);
+        SolverState s1 = s0.stepped(), s3 = s1.stepped().stepped();
+        EXPECT(norm2(s0._x() - x0) == 0.0);                                    // s0 is still s0
+        EXPECT(nearZero(norm2(s3._x() - mkSpVR(3, {1.5, -2, 1}))));
+        EXPECT(norm2(s1._x() - s3._x()) > 1e-6);
+    }
+    // m1 ## m2 (LibSpec.hs:61-62, fixtures :1263-1271) and the size check of matMat_ (SpMatrix.hs:795)
+    {
+        SpMatrix m1 = fromListDenseSM(2, {1, 3, 2, 4}), m2 = fromListDenseSM(2, {5, 7, 6, 8});
+        auto c = matMat(m1, m2).toAscList();   // m1m2 = fromListDenseSM 2 [19,43,22,50]
+        EXPECT(c.size() == 4 && std::get<2>(c[0]) == 19.0 && std::get<2>(c[1]) == 22.0 && std::get<2>(c[2]) == 43.0 && std::get<2>(c[3]) == 50.0);
+        bool bad = false;
+        try { matMat(m1, fromListSM({3, 2}, {{0, 0, 1.0}})); } catch (const MatVecSizeMismatchException &) { bad = true; }
+        EXPECT(bad);
+    }
+
     // specLinSolve (LibSpec.hs:286-300): aa0 2x2 dense, aa2 3x3 SPD tridiagonal
     SpMatrix aa0 = fromListDenseSM(2, {1, 3, 2, 4});
     SpMatrix aa2 = fromListSM({3, 3}, {{0, 0, 2}, {1, 0, -1}, {0, 1, -1}, {1, 1, 2}, {2, 1, -1}, {1, 2, -1}, {2, 2, 2}});

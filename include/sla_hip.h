@@ -201,6 +201,13 @@ int sla_solver_init(int method, sla_csr_t A, sla_vec_t b, sla_vec_t x0, sla_solv
 int sla_solver_step(sla_solver_t, int k_steps);
 /* copy a state field (_x, _r, _p, _u) into `out` */
 int sla_solver_get(sla_solver_t, int field, sla_vec_t out);
+/* A deep copy of a state record.  The reference's step functions are pure (`bicgstabStep aa r0hat s` returns a new record,
+ * Sparse.hs:972-981): a binding that must keep s while stepping on -- `iterate (bicgstabStep aa r0hat) s0 !! k`,
+ * README.md:222-226 -- clones first, then steps the clone (the shim's bicgstabStep / cgsStep do exactly that). */
+int sla_solver_clone(sla_solver_t, sla_solver_t *out);
+/* Replace the shadow residual of a CGS / BiCGSTAB state -- the explicit `r0hat` / `rhat` argument of bicgstabStep / cgsStep
+ * (sla_solver_init stores r0 = b - A x0, the README's choice) -- and re-evaluate the carried rho = r . r0hat with it. */
+int sla_solver_set_shadow(sla_solver_t, sla_vec_t r0hat);
 int sla_solver_destroy(sla_solver_t);
 /* convenience spellings used by the Haskell shim */
 int sla_bicgstab_init(sla_csr_t A, sla_vec_t b, sla_vec_t x0, sla_solver_t *out);

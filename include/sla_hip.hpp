@@ -227,9 +227,19 @@ class SolverState {
         check(sla_solver_init((int)m, A.get(), b.get(), x0.get(), &s));
         h_.reset(s, sla_solver_destroy);
     }
-    SolverState &step(int k = 1) {
+    SolverState &step(int k = 1) {   // k steps in place (the fast path)
         check(sla_solver_step(h_.get(), k));
         return *this;
+    }
+    // the reference's pure step (bicgstabStep aa r0hat s / cgsStep aa rhat s, Sparse.hs:928, :972): a NEW record, *this untouched
+    SolverState stepped(const SpVector *r0hat = nullptr, int k = 1) const {
+        SolverState out(*this);
+        sla_solver_t t;
+        check(sla_solver_clone(h_.get(), &t));
+        out.h_.reset(t, sla_solver_destroy);
+        if (r0hat) check(sla_solver_set_shadow(t, r0hat->get()));
+        check(sla_solver_step(t, k));
+        return out;
     }
     SpVector field(int f, int64_t n) const {
         SpVector out(n);

@@ -452,6 +452,7 @@ int launch_cgne_n3b(sla_ctx *c, int64_t n, SolverScalars *sc, Parts rr1, int par
 // residual check at the end of a host batch (one block): publishes resnorm / done
 int launch_check(sla_ctx *c, SolverScalars *sc, Parts res);
 int launch_init_scalars(sla_ctx *c, SolverScalars *sc, Parts rho, Parts r0sq, double tol_abs, double tol_rel);
+int launch_set_rho(sla_ctx *c, SolverScalars *sc, Parts rho, int par);   // sc->rho2[par] = sum(rho)
 // Arnoldi (Sparse.hs:630-667); Q column-major with leading dimension ldq
 int launch_arn_dots(sla_ctx *c, int64_t n, const double *Q, int64_t ldq, int ncols, const double *w, double *parts, SolverScalars *sc);
 int arn_grid(int64_t n);  // grid (= partials per column) of the Arnoldi kernels

@@ -2377,6 +2377,17 @@ __global__ void __launch_bounds__(kBlock) init_scalars_kernel(SolverScalars *sc,
         sc->kdone = 0;
     }
 }
+__global__ void __launch_bounds__(kBlock) set_rho_kernel(SolverScalars *sc, Parts rho, int par) {
+    __shared__ double s_red[4];
+    const double v = reduce_parts(rho.p, rho.n, rho.stride, s_red);
+    if (threadIdx.x == 0) sc->rho2[par] = v;
+}
+int launch_set_rho(sla_ctx *c, SolverScalars *sc, Parts rho, int par) {
+    hipLaunchKernelGGL(set_rho_kernel, dim3(1), dim3(kBlock), 0, c->stream, sc, rho, par);
+    SLA_HIP_TRY(hipGetLastError());
+    return SLA_OK;
+}
+
 int launch_init_scalars(sla_ctx *c, SolverScalars *sc, Parts rho, Parts r0sq, double tol_abs, double tol_rel) {
     hipLaunchKernelGGL(init_scalars_kernel, dim3(1), dim3(kBlock), 0, c->stream, sc, rho, r0sq, tol_abs, tol_rel);
     SLA_HIP_TRY(hipGetLastError());

@@ -620,6 +620,80 @@ int sla_solver_get(sla_solver_t S, int field, sla_vec_t out) {
     return sla_vec_copy(src, out);
 }
 
+// A deep copy of a state record: the reference's step functions are PURE (`bicgstabStep aa r0hat s` returns a new record and
+// leaves s alone, Sparse.hs:972-981), so `iterate (bicgstabStep aa r0hat) s0 !! k` or keeping s_j around while stepping on
+// needs states that do not alias.  Everything the step kernels read is copied on the context stream: the state vectors,
+// the partial sums the next kernel's prologue reduces, the per-rank tables, the device scalars, the step bookkeeping.
+int sla_solver_clone(sla_solver_t S, sla_solver_t *out) {
+    return no_throw("sla_solver_clone", [&]() -> int {
+        if (!S || !out) return fail(SLA_ERR_INVALID, "sla_solver_clone: null argument");
+        sla_ctx *c = S->ctx;
+        (void)hipSetDevice(c->device);
+        sla_solver *T = nullptr;
+        SLA_TRY(solver_alloc(S->A, S->method, &T));
+        int rc = SLA_OK;
+        sla_vec *src[] = {S->x, S->r, S->p, S->u, S->r0hat, S->b, S->t1, S->t2, S->t3};
+        sla_vec *dst[] = {T->x, T->r, T->p, T->u, T->r0hat, T->b, T->t1, T->t2, T->t3};
+        for (int i = 0; i < 9 && rc == SLA_OK; ++i)
+            if (src[i] && dst[i]) {
+                // (sla_vec_copy moves the own rows; the ghost-row flows also keep the neighbours' planes valid in the slack around
+                // them, so copy the whole guarded allocation when the state runs that flow)
+                if (S->ghost) {
+                    const size_t g = c->vec_guard, bytes = sizeof(double) * (size_t)std::max<int64_t>(src[i]->shard, 1) + 2 * g;
+                    if (hipMemcpyAsync((char *)dst[i]->d - g, (const char *)src[i]->d - g, bytes, hipMemcpyDeviceToDevice, c->stream) != hipSuccess)
+                        rc = fail(SLA_ERR_HIP, "sla_solver_clone: device copy failed");
+                } else {
+                    rc = sla_vec_copy(src[i], dst[i]);
+                }
+            }
+        hipError_t e = hipSuccess;
+        if (rc == SLA_OK) e = hipMemcpyAsync(T->d_parts, S->d_parts, sizeof(double) * P_SLOTS * kMaxParts, hipMemcpyDeviceToDevice, c->stream);
+        if (rc == SLA_OK && e == hipSuccess)
+            e = hipMemcpyAsync(T->d_gath, S->d_gath, sizeof(double) * ((size_t)P_SLOTS * 2 * c->nranks + 8), hipMemcpyDeviceToDevice, c->stream);
+        if (rc == SLA_OK && e == hipSuccess) e = hipMemcpyAsync(T->d_sc, S->d_sc, sizeof(SolverScalars), hipMemcpyDeviceToDevice, c->stream);
+        if (rc == SLA_OK && e != hipSuccess) rc = fail(SLA_ERR_HIP, std::string("sla_solver_clone: ") + hipGetErrorString(e));
+        if (rc != SLA_OK) {
+            sla_solver_destroy(T);
+            return rc;
+        }
+        *T->h_sc = *S->h_sc;
+        T->have_res = S->have_res;
+        T->ghost = S->ghost;
+        T->ghl = S->ghl;
+        T->ghr = S->ghr;
+        // the bookkeeping holds pointers into the source's partial / per-rank tables: rebase them onto the copy's
+        new (&ctl_of(T)) StepCtl(ctl_of(S));
+        auto rebase = [&](Parts &p) {
+            if (!p.p) return;
+            if (p.p >= S->d_parts && p.p < S->d_parts + (size_t)P_SLOTS * kMaxParts) p.p = T->d_parts + (p.p - S->d_parts);
+            else p.p = T->d_gath + (p.p - S->d_gath);
+        };
+        rebase(ctl_of(T).res);
+        rebase(ctl_of(T).pp);
+        *out = T;
+        return SLA_OK;
+    });
+}
+
+// Replace the shadow residual r0hat of a CGS / BiCGSTAB state (the explicit `r0hat` / `rhat` argument of bicgstabStep /
+// cgsStep, Sparse.hs:928, :972; sla_solver_init stores r0 = b - A x0 there, the README's choice) and re-evaluate the
+// carried rho = r . r0hat with it -- the reference recomputes `r <.> r0hat` at the top of every step.
+int sla_solver_set_shadow(sla_solver_t S, sla_vec_t r0hat) {
+    return no_throw("sla_solver_set_shadow", [&]() -> int {
+        if (!S || !r0hat) return fail(SLA_ERR_INVALID, "sla_solver_set_shadow: null argument");
+        if (S->method != SLA_BICGSTAB_ && S->method != SLA_CGS_) return fail(SLA_ERR_INVALID, "sla_solver_set_shadow: CGS / BiCGSTAB states only");
+        if (r0hat->n != S->r0hat->n) return fail(SLA_ERR_DIM_MISMATCH, "sla_solver_set_shadow: dimension mismatch");
+        if (S->ghost) return fail(SLA_ERR_INVALID, "sla_solver_set_shadow: not available on the ghost-row sharded flow");
+        sla_ctx *c = S->ctx;
+        (void)hipSetDevice(c->device);
+        SLA_TRY(sla_vec_copy(r0hat, S->r0hat));
+        Parts rho;
+        SLA_TRY(launch_dot(c, S->r->n_local, S->r->d, S->r0hat->d, slot(S, P_TMP)));
+        SLA_TRY(publish(S, P_TMP, -1, vec_grid(S->r->n_local), &rho, nullptr));
+        return launch_set_rho(c, S->d_sc, rho, ctl_of(S).step_index & 1);
+    });
+}
+
 int sla_solver_destroy(sla_solver_t S) {
     if (!S) return SLA_OK;
     if (S->ctx && S->ctx->stream) (void)hipStreamSynchronize(S->ctx->stream);

@@ -104,6 +104,8 @@ PROTOTYPES = [
     ("sla_solver_init", _int, [_int, _vp, _vp, _vp, _pp]),
     ("sla_solver_step", _int, [_vp, _int]),
     ("sla_solver_get", _int, [_vp, _int, _vp]),
+    ("sla_solver_clone", _int, [_vp, _pp]),
+    ("sla_solver_set_shadow", _int, [_vp, _vp]),
     ("sla_solver_destroy", _int, [_vp]),
     ("sla_bicgstab_init", _int, [_vp, _vp, _vp, _pp]),
     ("sla_bicgstab_step", _int, [_vp, _int]),

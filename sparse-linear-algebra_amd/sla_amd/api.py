@@ -577,7 +577,22 @@ class _SolverState:
         return fromVector(v.to_host(), self.A.ctx)
 
     def step(self, k=1):
+        """k steps IN PLACE on the device (the fast path: `iterate step s !! k` without materialising the k records)."""
         check(lib().sla_solver_step(self.h, int(k)))
+        return self
+
+    def clone(self):
+        """A deep copy of the state record (sla_solver_clone): stepping the copy leaves this record untouched."""
+        other = object.__new__(type(self))
+        other.A, other.method = self.A, self.method
+        other.h = C.c_void_p()
+        check(lib().sla_solver_clone(self.h, C.byref(other.h)))
+        return other
+
+    def set_shadow(self, r0hat):
+        """Replace the shadow residual (the explicit r0hat / rhat argument of bicgstabStep / cgsStep)."""
+        rh = r0hat.h if isinstance(r0hat, DeviceVector) else r0hat.device().h
+        check(lib().sla_solver_set_shadow(self.h, rh))
         return self
 
     def __del__(self):
@@ -614,18 +629,33 @@ def bicgsInit(aa, b, x0):
     return BICGSTAB(BICGSTAB_, aa, b, x0)         # Sparse.hs:962-965
 
 
-def bicgstabStep(state, k=1):
-    """k applications of bicgstabStep aa r0hat (Sparse.hs:972-981); the state is updated in place on
-    the device (r0hat = b - A x0 is kept inside it)."""
-    return state.step(k)
+def _pure_step(args, k):
+    """The reference's calling conventions: step(state [, k]) -- the in-place device fast path this package started with --
+    or step(aa, r0hat, state): PURE like the Haskell (Sparse.hs:928, :972) -- a new record is returned, `state` keeps its
+    value, so `iterate (bicgstabStep aa r0hat) s0 !! 20` (README.md:222-226) does not alias its elements."""
+    if len(args) == 1:
+        return args[0].step(k)
+    aa, r0hat, state = args
+    if aa is not state.A:
+        raise ValueError("the state record was initialised with a different matrix")
+    out = state.clone()
+    if r0hat is not None:
+        out.set_shadow(r0hat)
+    return out.step(k)
+
+
+def bicgstabStep(*args, k=1):
+    """bicgstabStep aa r0hat state (Sparse.hs:972-981) -> new state; bicgstabStep(state, k=..) steps in place."""
+    return _pure_step(args, k)
 
 
 def cgsInit(aa, b, x0):
     return CGS(CGS_, aa, b, x0)                   # Sparse.hs:921-924
 
 
-def cgsStep(state, k=1):
-    return state.step(k)                          # Sparse.hs:928-939
+def cgsStep(*args, k=1):
+    """cgsStep aa rhat state (Sparse.hs:928-939) -> new state; cgsStep(state, k=..) steps in place."""
+    return _pure_step(args, k)
 
 
 def cgneInit(aa, b, x0):

@@ -478,3 +478,37 @@ def test_jacobi_preconditioner_builders(sla):
     S = sla.fromListSM((2, 2), [(0, 0, 2.0), (0, 1, 1.0), (1, 1, 4.0)])
     with pytest.raises(sla.SlaError):
         sla.diagMatMatSparsified(S, S)                            # left factor not diagonal
+
+
+def test_pure_step_functions_do_not_alias_and_take_an_explicit_shadow_residual(sla):
+    """bicgstabStep aa r0hat s / cgsStep aa rhat s (Sparse.hs:972-981, 928-939) are pure in the reference: the README's
+    `iterate (bicgstabStep aa r0hat) s0 !! k` (README.md:222-226) needs every element to stay what it was.  Through
+    sla_solver_clone the mirror's three-argument form returns a NEW record; an r0hat other than b - A x0 goes through
+    sla_solver_set_shadow and matches the oracle stepping with that r0hat."""
+    n = 400
+    dims, rp, ci, va, xs = _spd_problem(n, 21)
+    A, Ao = sla.fromCSR(dims, rp, ci, va), orc.Csr(n, n, rp, ci, va)
+    b, x0 = orc.spmv(Ao, xs), np.full(n, 0.1)
+    r0 = b - orc.spmv(Ao, x0)
+    rng = np.random.default_rng(3)
+    shadow = r0 + 0.05 * rng.standard_normal(n)                      # some other r0hat (not orthogonal to r0)
+    for init, step, ostate, xf in ((sla.bicgsInit, sla.bicgstabStep, orc.BicgstabState, "_xBicgstab"), (sla.cgsInit, sla.cgsStep, orc.CgsState, "_x")):
+        s0 = init(A, dense_vec(sla, b), dense_vec(sla, x0))
+        x_before = getattr(s0, xf).toDenseListSV()
+        chain = [s0]
+        for _ in range(4):                                           # iterate (step aa r0hat) s0
+            chain.append(step(A, None, chain[-1]))
+        assert np.array_equal(getattr(s0, xf).toDenseListSV(), x_before)          # s0 is still s0
+        so = ostate(Ao, b, x0)
+        for k in range(1, 5):
+            so.step(r0, 1)
+            assert np.linalg.norm(getattr(chain[k], xf).toDenseListSV() - so.x) <= 1e-9 * np.linalg.norm(so.x), k
+        assert len({id(c) for c in chain}) == 5 and len({c.h.value for c in chain}) == 5
+        inplace = init(A, dense_vec(sla, b), dense_vec(sla, x0)).step(4)            # the in-place fast path agrees bit for bit
+        assert np.array_equal(getattr(inplace, xf).toDenseListSV(), getattr(chain[4], xf).toDenseListSV())
+        # explicit shadow residual
+        s1 = step(A, dense_vec(sla, shadow), step(A, dense_vec(sla, shadow), s0))
+        so = ostate(Ao, b, x0)
+        so.step(shadow, 2)
+        assert np.linalg.norm(getattr(s1, xf).toDenseListSV() - so.x) <= 1e-9 * np.linalg.norm(so.x)
+        assert np.linalg.norm(getattr(s1, xf).toDenseListSV() - getattr(chain[2], xf).toDenseListSV()) > 1e-6 * np.linalg.norm(so.x)
