@@ -152,6 +152,15 @@ int sla_tri_solve_info(sla_csr_t T, int upper, int64_t *levels, int64_t *widest_
  * hold the structurally non-zero entries ((##) itself would keep explicit zeros over the whole index set; the
  * values at the stored positions are identical).  Single-rank contexts. */
 int sla_ssor_pre(sla_csr_t A, double omega, sla_csr_t *l, sla_csr_t *r);
+/* ilu0Pre aa = (L, U) (Sparse.hs:696-706): the reference defines it as the COMPLETE Doolittle factorisation `lu aa`
+ * (:488-527; unit diagonal in L) with every entry outside aa's stored positions removed afterwards.
+ *   exact_lu != 0: that definition, entry for entry (complete LU with fill-in, then the filter); at most 4096 rows.
+ *   exact_lu == 0: EXTENSION -- the incomplete factorisation proper: the same recurrences on aa's stored positions only, any
+ *                  size; bit-identical to the exact mode whenever `lu aa` creates no fill outside aa's pattern.
+ * Values failing isNz (|x| <= 1e-12) are not stored (row 0 of U and column 0 of L excepted, as in luInit); a pivot u_jj failing
+ * isNz while rows below remain => SLA_ERR_NEEDS_PIVOTING ("NeedsPivoting solveForLij U(j,j)"), *bad_row = j (may be NULL).
+ * Host-side set-up (like sla_ssor_pre); apply the factors with sla_tri_solve.  Single-rank contexts, square matrices. */
+int sla_ilu0_pre(sla_csr_t A, int exact_lu, sla_csr_t *l, sla_csr_t *u, int64_t *bad_row);
 /* m1 ## m2 (transpose_b == 0) and m1 ##^ m2 = m1 ## transpose m2 (transpose_b != 0): matMat_ (SpMatrix.hs:768-811).  The result is
  * STRUCTURALLY DENSE over (rows of m1 holding an entry) x (columns of m2 holding an entry) -- an empty intersection still
  * yields an explicit 0.0, like the reference's `sum (liftI2 (*) col row)`; every entry is the ascending left fold, from 0,

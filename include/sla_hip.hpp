@@ -184,6 +184,13 @@ inline SpMatrix fromListDenseSM(int64_t m, const std::vector<double> &ll) {
     return SpMatrix(m, n, t);
 }
 
+// ilu0Pre aa (Sparse.hs:696-706): (L, U); exact = the reference's complete-LU-then-filter definition (<= 4096 rows)
+inline std::pair<SpMatrix, SpMatrix> ilu0Pre(const SpMatrix &A, bool exact = true) {
+    sla_csr_t l, u;
+    check(sla_ilu0_pre(A.get(), exact ? 1 : 0, &l, &u, nullptr));
+    return {SpMatrix(A.nrows(), A.ncols(), l), SpMatrix(A.nrows(), A.ncols(), u)};
+}
+
 // m1 ## m2 and m1 ##^ m2 (matMat_ AB / ABt, SpMatrix.hs:768-811); size mismatch throws like `error "matMat : ..."`
 inline SpMatrix matMat(const SpMatrix &A, const SpMatrix &B) {
     sla_csr_t c;

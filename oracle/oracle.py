@@ -300,3 +300,22 @@ def ssor_pre(A, omega):
     if rc != OK:
         return rc, None, None
     return rc, Csr(A.m, A.n, lp, lc[:lp[-1]].copy(), lv[:lp[-1]].copy()), Csr(A.m, A.n, rp, rc_[:rp[-1]].copy(), rv[:rp[-1]].copy())
+
+
+def lu(A, ilu0=False):
+    """lu (Sparse.hs:488-527) / ilu0Pre (:696-706): (rc, L, U, bad_row); rc == ERR_PIVOT when a pivot u_jj fails isNz."""
+    n = A.m
+    cap = max(n * n, 1)
+    lp, up = np.zeros(n + 1, dtype=np.int64), np.zeros(n + 1, dtype=np.int64)
+    lc, uc = np.zeros(cap, dtype=np.int64), np.zeros(cap, dtype=np.int64)
+    lv, uv = np.zeros(cap), np.zeros(cap)
+    bad = C.c_int64(-1)
+    v = A.view()
+    rc = lib().orc_lu(C.byref(v), C.c_int(1 if ilu0 else 0), _p(lp), _p(lc), _p(lv), _p(up), _p(uc), _p(uv), C.byref(bad))
+    if rc != OK:
+        return rc, None, None, bad.value
+    return rc, Csr(n, n, lp, lc[:lp[-1]].copy(), lv[:lp[-1]].copy()), Csr(n, n, up, uc[:up[-1]].copy(), uv[:up[-1]].copy()), -1
+
+
+def ilu0_pre(A):
+    return lu(A, ilu0=True)

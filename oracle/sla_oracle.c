@@ -633,3 +633,89 @@ int orc_ssor_pre(const orc_csr *A, double omega, int64_t *l_rowptr, int64_t *l_c
     free(has);
     return ORC_OK;
 }
+
+/* ---------------------------------------------------------------------------------------------
+ * lu (Doolittle, Sparse.hs:488-527) and ilu0Pre (:696-706) -- the reference's definition of "ILU(0)" is
+ * the COMPLETE factorisation filtered to A's pattern afterwards.  Dense restatement (n x n value + presence arrays; toy
+ * sizes only, like the reference's own IntMap version), following the reference's loop order literally:
+ *   luInit : L = eye n with column 0 = a_i0 / u00 for the STORED a_i0, i >= 1 (unfiltered); U = row 0 of A (unfiltered)
+ *   i = 1 .. n-1:  row i of U: u_ij = a_ij - contractSub l u i j (i-1), j = i .. n-1, kept when isNz        (uUpd)
+ *                  col i of L: l_ri = (a_ri - contractSub l u r i (r-1)) / u_ii, r = i+1 .. n-1, kept when isNz (lUpd);
+ *                  not (isNz u_ii) with rows left to solve => NeedsPivoting "solveForLij" "U(i,i)"
+ *   contractSub a b i j n = foldlWithKey' (\acc k x -> if k > n then acc else acc + x * b @@! (k, j)) 0 (row i of a)
+ *                           (SpMatrix.hs:857-864): ascending k over the STORED entries of the row, absent b entries read 0.
+ * ------------------------------------------------------------------------------------------- */
+static double contract_sub(int64_t n, const char *lp, const double *lv, const char *up, const double *uv, int64_t i,
+                           int64_t j, int64_t kmax) {
+    double acc = 0.0;
+    for (int64_t k = 0; k < n; ++k) {
+        if (!lp[i * n + k] || k > kmax) continue;
+        double b = up[k * n + j] ? uv[k * n + j] : 0.0;
+        double prod = lv[i * n + k] * b;
+        acc = acc + prod;
+    }
+    return acc;
+}
+
+/* L and U as dense n x n (row-major) value / presence arrays.  Returns ORC_OK, ORC_ERR_DIM (not square) or ORC_ERR_PIVOT. */
+int orc_lu_dense(const orc_csr *A, double *lv, char *lp, double *uv, char *up, int64_t *bad) {
+    if (A->m != A->n) return ORC_ERR_DIM;
+    const int64_t n = A->m;
+    double *av = vnew(n * n);
+    char *ap = (char *)calloc((size_t)(n * n > 0 ? n * n : 1), 1);
+    if (!av || !ap) return ORC_ERR_ALLOC;
+    memset(lp, 0, (size_t)(n * n)); memset(up, 0, (size_t)(n * n));
+    for (int64_t i = 0; i < n; ++i)
+        for (int64_t k = A->rowptr[i]; k < A->rowptr[i + 1]; ++k) { av[i * n + A->colidx[k]] = A->val[k]; ap[i * n + A->colidx[k]] = 1; }
+    int rc = ORC_OK;
+    /* luInit */
+    for (int64_t i = 0; i < n; ++i) { lp[i * n + i] = 1; lv[i * n + i] = 1.0; }
+    for (int64_t j = 0; j < n; ++j) if (ap[j]) { up[j] = 1; uv[j] = av[j]; }
+    const double u00 = up[0] ? uv[0] : 0.0;
+    if (!is_nz(u00)) { if (bad) *bad = 0; rc = ORC_ERR_PIVOT; }
+    if (rc == ORC_OK) {
+        for (int64_t i = 1; i < n; ++i) if (ap[i * n]) { lp[i * n] = 1; lv[i * n] = av[i * n] / u00; }
+        for (int64_t i = 1; i < n && rc == ORC_OK; ++i) {
+            for (int64_t j = i; j < n; ++j) {                               /* uUpd */
+                double a = ap[i * n + j] ? av[i * n + j] : 0.0;
+                double u = a - contract_sub(n, lp, lv, up, uv, i, j, i - 1);
+                if (is_nz(u)) { up[i * n + j] = 1; uv[i * n + j] = u; }
+            }
+            for (int64_t r = i + 1; r < n; ++r) {                           /* lUpd */
+                double ujj = up[i * n + i] ? uv[i * n + i] : 0.0;
+                if (!is_nz(ujj)) { if (bad) *bad = i; rc = ORC_ERR_PIVOT; break; }
+                double a = ap[r * n + i] ? av[r * n + i] : 0.0;
+                double l = (a - contract_sub(n, lp, lv, up, uv, r, i, r - 1)) / ujj;
+                if (is_nz(l)) { lp[r * n + i] = 1; lv[r * n + i] = l; }
+            }
+        }
+    }
+    free(av); free(ap);
+    return rc;
+}
+
+/* lu (filter == 0) / ilu0Pre (filter != 0: entries kept only where A stores one, `ifilterSM (isJust . lookupSM aa)`) as CSR */
+int orc_lu(const orc_csr *A, int filter, int64_t *l_rowptr, int64_t *l_colidx, double *l_val, int64_t *u_rowptr,
+           int64_t *u_colidx, double *u_val, int64_t *bad) {
+    if (A->m != A->n) return ORC_ERR_DIM;
+    const int64_t n = A->m, nn = n * n > 0 ? n * n : 1;
+    double *lv = vnew(nn), *uv = vnew(nn);
+    char *lp = (char *)malloc((size_t)nn), *up = (char *)malloc((size_t)nn), *ap = (char *)calloc((size_t)nn, 1);
+    if (!lv || !uv || !lp || !up || !ap) return ORC_ERR_ALLOC;
+    int rc = orc_lu_dense(A, lv, lp, uv, up, bad);
+    for (int64_t i = 0; i < n; ++i)
+        for (int64_t k = A->rowptr[i]; k < A->rowptr[i + 1]; ++k) ap[i * n + A->colidx[k]] = 1;
+    int64_t lo = 0, uo = 0;
+    l_rowptr[0] = u_rowptr[0] = 0;
+    for (int64_t i = 0; i < n && rc == ORC_OK; ++i) {
+        for (int64_t j = 0; j < n; ++j) {
+            if (filter && !ap[i * n + j]) continue;
+            if (lp[i * n + j]) { l_colidx[lo] = j; l_val[lo] = lv[i * n + j]; ++lo; }
+            if (up[i * n + j]) { u_colidx[uo] = j; u_val[uo] = uv[i * n + j]; ++uo; }
+        }
+        l_rowptr[i + 1] = lo;
+        u_rowptr[i + 1] = uo;
+    }
+    free(lv); free(uv); free(lp); free(up); free(ap);
+    return rc;
+}

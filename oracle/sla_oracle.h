@@ -124,4 +124,11 @@ int orc_ssor_pre(const orc_csr *A, double omega, int64_t *l_rowptr, int64_t *l_c
 #ifdef __cplusplus
 }
 #endif
+/* lu (Sparse.hs:488-527) and ilu0Pre (:696-706): the complete Doolittle factorisation (filter == 0) and its
+ * restriction to A's stored positions (filter != 0), restated on dense n x n arrays (toy sizes, like the reference's).  CSR
+ * outputs need capacity n * n each.  ORC_ERR_PIVOT + *bad = j when u_jj fails isNz while rows remain to be solved. */
+int orc_lu(const orc_csr *A, int filter, int64_t *l_rowptr, int64_t *l_colidx, double *l_val, int64_t *u_rowptr,
+           int64_t *u_colidx, double *u_val, int64_t *bad);
+int orc_lu_dense(const orc_csr *A, double *lv, char *lp, double *uv, char *up, int64_t *bad);
+
 #endif

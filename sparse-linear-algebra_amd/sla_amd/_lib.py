@@ -86,6 +86,7 @@ PROTOTYPES = [
     ("sla_csr_destroy", _int, [_vp]),
     ("sla_csr_dims", _int, [_vp, _pi64, _pi64, _pi64, _pi64]),
     ("sla_csr_matmat", _int, [_vp, _vp, _int, _pp]),
+    ("sla_ilu0_pre", _int, [_vp, _int, _pp, _pp, _vp]),
     ("sla_csr_export", _int, [_vp, _vp, _vp, _vp]),
     ("sla_csr_is_diagonal", _int, [_vp, _pint]),
     ("sla_vec_create", _int, [_vp, _i64, _vp, _pp]),

@@ -471,6 +471,15 @@ def mSsorPre(aa, omega):
     return SpMatrix(aa.dims, hl, aa.ctx), SpMatrix(aa.dims, hr, aa.ctx)
 
 
+def ilu0Pre(aa, exact=True):
+    """ilu0Pre aa = (l, u) (Sparse.hs:696-706): the complete `lu aa` filtered to aa's stored positions (exact=True, the
+    reference's definition, <= 4096 rows) or the incomplete factorisation on aa's pattern proper (exact=False: an extension,
+    any size, identical whenever lu creates no fill outside the pattern).  Raises NeedsPivoting like `lu`."""
+    hl, hu, bad = C.c_void_p(), C.c_void_p(), C.c_int64(-1)
+    check(lib().sla_ilu0_pre(aa.h, 1 if exact else 0, C.byref(hl), C.byref(hu), C.byref(bad)))
+    return SpMatrix(aa.dims, hl, aa.ctx), SpMatrix(aa.dims, hu, aa.ctx)
+
+
 def diagMatMatSparsified(D, A):
     """D #~# A for a diagonal D (matMatSparsified, SpMatrix.hs:816-824): the left-preconditioned operator
     `jacobiPre aa #~# aa` without a general SpGEMM."""

@@ -111,3 +111,78 @@ def test_ssor_factors_and_their_solves(sla, omega):
     wd = sla.triLowerSolve(L, sla.DeviceVector(L.ctx, n, b))
     zd = sla.triUpperSolve(R, wd).to_host()
     assert np.array_equal(zd, z)
+
+
+# ---- ilu0Pre (Sparse.hs:696-706) -------------------------------------------------------------------------
+
+def _same_csr(M, Mo):
+    rp, ci, va = M.csr()
+    assert np.array_equal(rp, Mo.rowptr) and np.array_equal(ci, Mo.colidx) and np.array_equal(va, Mo.val)
+
+
+def test_ilu0_pre_is_the_filtered_complete_lu_bit_for_bit(sla):
+    """exact mode = the reference's definition (complete Doolittle `lu`, then keep aa's stored positions): index structure and
+    values equal the oracle's restatement exactly, on the reference's own checkLu matrices (aa0, tm0, tm7: LibSpec.hs:186-194)
+    and on random matrices with heavy fill-in."""
+    from refdata import coo_of, golden, tridiag_coo
+    G = golden()
+    cases = [coo_of(G["aa0"]), coo_of(G["lu"]["tm0"]), tridiag_coo(G["lu"]["tm7"]["n"], *G["lu"]["tm7"]["tridiag"])]
+    rng = np.random.default_rng(4)
+    for n, fill in ((7, 0.5), (40, 0.15), (120, 0.05)):
+        nz = int(fill * n * n)
+        r, c = rng.integers(0, n, nz), rng.integers(0, n, nz)
+        v = rng.uniform(-1, 1, nz)
+        r, c, v = np.append(r, np.arange(n)), np.append(c, np.arange(n)), np.append(v, n + rng.uniform(0, 1, n))   # dominant diagonal last (wins)
+        cases.append(((n, n), r, c, v))
+    for dims, r, c, v in cases:
+        A = sla.fromCOO(dims, r, c, v)
+        rc, Ao = orc.coo_to_csr(dims[0], dims[1], r, c, v)
+        rc, Lo, Uo, _ = orc.ilu0_pre(Ao)
+        assert rc == orc.OK
+        L, U = sla.ilu0Pre(A)
+        _same_csr(L, Lo)
+        _same_csr(U, Uo)
+        # and it is what the name promises: entries only where aa stores one
+        Ap = A.toDense() != 0
+        assert not (L.toDense() != 0)[~Ap & ~np.eye(dims[0], dtype=bool)].any() and not (U.toDense() != 0)[~Ap].any()
+
+
+def test_incomplete_mode_equals_the_exact_one_without_fill_and_scales(sla):
+    """exact=False (extension: the recurrences on aa's pattern only) returns the very same factors whenever `lu` creates no
+    fill outside the pattern -- tridiagonal, pentadiagonal without gaps, block diagonal with full blocks -- and runs at sizes
+    where the complete LU is out of reach; its factors then go through the level-scheduled triangular solves."""
+    from refdata import tridiag_coo
+    rng = np.random.default_rng(9)
+    n = 300
+    penta = [(i, j, (6.0 if i == j else rng.uniform(-1, 1))) for i in range(n) for j in range(max(0, i - 2), min(n, i + 3))]
+    blocks = [(b * 5 + i, b * 5 + j, (9.0 if i == j else rng.uniform(-1, 1))) for b in range(40) for i in range(5) for j in range(5)]
+    for dims, r, c, v in (tridiag_coo(500, -1, 2, -1),
+                          ((n, n), *map(np.array, zip(*penta))), ((200, 200), *map(np.array, zip(*blocks)))):
+        A = sla.fromCOO(dims, np.asarray(r, np.int64), np.asarray(c, np.int64), np.asarray(v, float))
+        Le, Ue = sla.ilu0Pre(A, exact=True)
+        Li, Ui = sla.ilu0Pre(A, exact=False)
+        for X, Y in ((Le, Li), (Ue, Ui)):
+            for a, b in zip(X.csr(), Y.csr()):
+                assert np.array_equal(a, b)
+    # 1 M-row 5-point Poisson matrix: ILU(0) proper; M^-1 = U^-1 L^-1 applied with sla_tri_solve brings ||b - A x|| down
+    from sla_amd import workloads as wl
+    dims, (rp, ci, va) = wl.poisson2d(1000, 1000)
+    A = sla.fromCSR(dims, rp, ci, va)
+    with pytest.raises(sla.SlaError):
+        sla.ilu0Pre(A, exact=True)                                           # the complete LU is limited to 4096 rows
+    L, U = sla.ilu0Pre(A, exact=False)
+    assert L.nnz() == (len(ci) + dims[0]) // 2 and U.nnz() == (len(ci) + dims[0]) // 2    # pattern of A, split at the diagonal
+    b = np.add.reduceat(va, rp[:-1])
+    bv = sla.DeviceVector(A.ctx, dims[0], b)
+    z = sla.triUpperSolve(U, sla.triLowerSolve(L, bv)).to_host()              # z = M^-1 b ~ A^-1 b = 1
+    r0, r1 = np.linalg.norm(b), np.linalg.norm(b - orc.spmv(orc.Csr(*dims, rp, ci, va), z))
+    assert r1 < 0.75 * r0
+
+
+def test_ilu0_pre_needs_pivoting(sla):
+    A = sla.fromListSM((3, 3), [(0, 0, 1.0), (0, 1, 2.0), (1, 0, 2.0), (1, 1, 4.0), (2, 1, 1.0), (2, 2, 1.0)])   # u_11 = 4 - 2 * 2 = 0
+    for exact in (True, False):
+        with pytest.raises(sla.NeedsPivoting):
+            sla.ilu0Pre(A, exact=exact)
+    with pytest.raises(sla.NeedsPivoting):
+        sla.ilu0Pre(sla.fromListSM((2, 2), [(0, 1, 1.0), (1, 0, 1.0)]))                                           # u_00 missing

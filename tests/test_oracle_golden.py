@@ -304,3 +304,47 @@ def test_ssor_factors_match_the_matrix_ring_definition():
     want_l = (np.eye(n) + -(omega * E)) * rd[None, :]
     want_r = np.diag(d) + -(omega * F)
     assert np.array_equal(dense_of(L), want_l) and np.array_equal(dense_of(R), want_r)
+
+
+# ---- lu / ilu0Pre ---------------------------------------------------------------------
+
+def _check_lu(A):
+    """checkLu (LibSpec.hs:424-434): nearZero (normFrobenius (sparsifySM ((l ## u) ^-^ a))) && isUpperTriSM u && isLowerTriSM l."""
+    rc, L, U, bad = orc.lu(A)
+    assert rc == orc.OK, (rc, bad)
+    Ld, Ud, Ad = dense_of(L), dense_of(U), dense_of(A)
+    D = Ld @ Ud - Ad
+    D[np.abs(D) <= 1e-12] = 0.0                                           # sparsifySM
+    assert np.linalg.norm(D, "fro") <= 1e-12
+    assert np.array_equal(np.triu(Ud), Ud) and np.array_equal(np.tril(Ld), Ld)
+    assert np.array_equal(np.diag(Ld), np.ones(A.m))                     # Doolittle: unit diagonal of L
+    return L, U
+
+
+def test_lu_reference_cases_and_ilu0_definition():
+    aa0 = csr_of(G["aa0"])                                                # LibSpec.hs:186
+    tm0 = csr_of(G["lu"]["tm0"])                                          # :188
+    t = G["lu"]["tm7"]
+    (m, n), r, c, v = tridiag_coo(t["n"], *t["tridiag"])                  # :194
+    rc, tm7 = orc.coo_to_csr(m, n, r, c, v)
+    for A in (aa0, tm0, tm7):
+        L, U = _check_lu(A)
+        # ilu0Pre = lu filtered to A's stored positions (Sparse.hs:696-706); these matrices produce no fill, so nothing is lost
+        rc, Lh, Uh, _ = orc.ilu0_pre(A)
+        assert np.array_equal(dense_of(Lh), dense_of(L)) and np.array_equal(dense_of(Uh), dense_of(U))
+    # a matrix WITH fill: the arrow pointing the wrong way -- lu fills the whole trailing block, ilu0Pre keeps A's pattern only
+    n = 6
+    rows = [0] * n + list(range(1, n)) + list(range(1, n))
+    cols = list(range(n)) + [0] * (n - 1) + list(range(1, n))
+    vals = [4.0] + [1.0] * (n - 1) + [1.0] * (n - 1) + [3.0] * (n - 1)
+    rc, A = orc.coo_to_csr(n, n, np.array(rows), np.array(cols), np.array(vals))
+    L, U = _check_lu(A)
+    assert L.nnz > A.nnz - (n - 1) or U.nnz > n + (n - 1)                 # fill-in happened
+    rc, Lh, Uh, _ = orc.ilu0_pre(A)
+    Ap = dense_of(A) != 0
+    assert not (dense_of(Lh) != 0)[~Ap].any() and not (dense_of(Uh) != 0)[~Ap].any()
+    assert np.array_equal(dense_of(Lh)[Ap], dense_of(L)[Ap]) and np.array_equal(dense_of(Uh)[Ap], dense_of(U)[Ap])
+    # NeedsPivoting "solveForLij" "U(j,j)" (Sparse.hs:491, :519-521): zero pivot with rows left to solve
+    rc, A = orc.coo_to_csr(3, 3, np.array([0, 0, 1, 1, 2, 2]), np.array([0, 1, 0, 1, 1, 2]), np.array([1.0, 2.0, 2.0, 4.0, 1.0, 1.0]))
+    rc, L, U, bad = orc.lu(A)
+    assert rc == orc.ERR_PIVOT and bad == 1
