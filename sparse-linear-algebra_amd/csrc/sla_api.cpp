@@ -131,6 +131,81 @@ static int build_xplan(sla_csr *A, int64_t rows, const int64_t *rowptr, const in
     return SLA_OK;
 }
 
+// Row-sharded comm / compute overlap.  For the wave-sliced forms the 512-row steps are split into the
+// INTERIOR ones -- every row references columns of this rank's own block only: they can run while the halo exchange is in
+// flight -- and the BOUNDARY ones, each list in the visiting order of the full walk (the plane-tiled `sched` when there is
+// one).  Taken when the window exchange is in use and most steps are interior.
+static int build_overlap_lists(sla_csr *A, int64_t m, int64_t n, int64_t row_begin, int64_t rows, const int64_t *rowptr, const int64_t *col) {
+    sla_ctx *c = A->ctx;
+    if (!c->collectives || c->overlap < 0 || !A->use_wdia || !A->xplan || m != n || rows == 0) return SLA_OK;
+    if (!(A->xplan->use_window || c->x_exchange == 2) || c->x_exchange == 1) return SLA_OK;
+    const int64_t lo = row_begin, hi = row_begin + rows;
+    std::vector<char> bnd((size_t)A->nblk_wd, 0);
+    for (int64_t i = 0; i < rows; ++i)
+        if (rowptr[i + 1] > rowptr[i] && (col[rowptr[i]] < lo || col[rowptr[i + 1] - 1] >= hi)) bnd[(size_t)(i / 512)] = 1;   // canonical CSR: min / max column
+    std::vector<int32_t> li, lb;
+    for (int32_t t = 0; t < A->nblk_wd; ++t) {
+        const int32_t s = A->h_wsched.empty() ? t : A->h_wsched[(size_t)t];
+        (bnd[(size_t)s] ? lb : li).push_back(s);
+    }
+    if (lb.empty() || li.size() < lb.size()) return SLA_OK;   // nothing to exchange for / too little to hide it behind
+    SLA_HIP_TRY(hipMalloc((void **)&A->d_ov_int, sizeof(int32_t) * li.size()));
+    SLA_HIP_TRY(hipMalloc((void **)&A->d_ov_bnd, sizeof(int32_t) * lb.size()));
+    SLA_HIP_TRY(hipMemcpy(A->d_ov_int, li.data(), sizeof(int32_t) * li.size(), hipMemcpyHostToDevice));
+    SLA_HIP_TRY(hipMemcpy(A->d_ov_bnd, lb.data(), sizeof(int32_t) * lb.size(), hipMemcpyHostToDevice));
+    A->ov_nint = (int32_t)li.size();
+    A->ov_nbnd = (int32_t)lb.size();
+    return SLA_OK;
+}
+
+// (#>) with its input exchange.  When the matrix has interior / boundary step lists and the halo lands in place around x:
+//   compute stream:  ... producers of x | record(x ready) | interior launch .................. | wait(halo done) | boundary launch
+//   comm stream:                         wait(x ready) | halo send / recv (RCCL) | record(halo done)
+// so the exchange costs nothing beyond the boundary launch.  The fused partial sums of the two launches occupy consecutive
+// slots (interior first): *np = their total.  SLA_OVERLAP=0 runs the very same launches with the exchange serialised on
+// the compute stream (bit-identical results: same kernels, same partial layout).
+int spmv_exchanged(sla_csr *A, sla_vec *x, SpmvLaunch l, int *np) {
+    sla_ctx *c = A->ctx;
+    if (np) *np = spmv_grid(A);
+    if (!(overlap_split(A) && !l.x2 && !l.yinit && x->ctx == c && halo_inplace_extents(A, x, nullptr, nullptr))) {
+        SLA_TRY(gather_x(A, x, &l.x));
+        return launch_spmv(A, l);
+    }
+    const int64_t b = x->begin;
+    if (c->overlap > 0) {
+        if (!c->comm_stream) {
+            SLA_HIP_TRY(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
+            SLA_HIP_TRY(hipEventCreateWithFlags(&c->ev_x_ready, hipEventDisableTiming));
+            SLA_HIP_TRY(hipEventCreateWithFlags(&c->ev_x_done, hipEventDisableTiming));
+        }
+        SLA_HIP_TRY(hipEventRecord(c->ev_x_ready, c->stream));
+        SLA_HIP_TRY(hipStreamWaitEvent(c->comm_stream, c->ev_x_ready, 0));
+        hipStream_t compute = c->stream;
+        c->stream = c->comm_stream;   // (the exchange enqueues on "the context stream")
+        const int rc = dist_exchange_window(c, *A->xplan, x->d, b, x->n_local, x->d - b);
+        c->stream = compute;
+        SLA_TRY(rc);
+        SLA_HIP_TRY(hipEventRecord(c->ev_x_done, c->comm_stream));
+    } else {
+        SLA_TRY(dist_exchange_window(c, *A->xplan, x->d, b, x->n_local, x->d - b));
+    }
+    l.x = x->d - b;
+    SpmvLaunch li = l;
+    li.part = 1;
+    SLA_TRY(launch_spmv(A, li));
+    if (c->overlap > 0) SLA_HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_x_done, 0));
+    const int gi = overlap_grid(A, 1);
+    SpmvLaunch lb = l;
+    lb.part = 2;
+    lb.pres = nullptr;         // the residual test and the step count belong to the first launch
+    lb.step_begin &= ~1;
+    if (lb.p1) lb.p1 += gi;
+    if (lb.p2) lb.p2 += gi;
+    SLA_TRY(launch_spmv(A, lb));
+    if (np) *np = gi + overlap_grid(A, 2);
+    return SLA_OK;
+}
+
 // sums of one or two partial arrays -> host (global over ranks); synchronises the stream
 int reduce_to_host(sla_ctx *c, const double *p1, const double *p2, int np, double *out) {
     SLA_TRY(launch_finalize(c, p1, p2, np, c->d_result));
@@ -587,6 +662,7 @@ static int csr_upload(sla_ctx *c, int64_t m, int64_t n, int64_t row_begin, int64
                     }
                     std::stable_sort(sched.begin(), sched.end(), [&](int32_t x, int32_t y) { return key[(size_t)x] < key[(size_t)y]; });
                     upload((void **)&A->d_wsched, sched.data(), sizeof(int32_t) * sched.size());
+                    A->h_wsched = sched;
                 }
             }
         }
@@ -756,6 +832,7 @@ static int csr_upload(sla_ctx *c, int64_t m, int64_t n, int64_t row_begin, int64
     }
     A->is_diagonal = agree == 0;
     rc = build_xplan(A, rows, rowptr, col);
+    if (rc == SLA_OK) rc = build_overlap_lists(A, m, n, row_begin, rows, rowptr, col);
     if (rc == SLA_OK) rc = build_tiles(A, n, rows, rowptr, col, val);
     lap("tile form");
     if (rc == SLA_OK && !(A->use_lpanel && c->lpanel) && !A->use_tiles) rc = build_panels(A, m, n, row_begin, rows, rowptr, col, val);
@@ -874,6 +951,7 @@ static int ctx_create_common(int device_id, int rank, int nranks, const void *ui
     if (const char *s = getenv("SLA_VEC_NT")) c->vec_nt = atoi(s);
     if (const char *s = getenv("SLA_HALO_INPLACE")) c->halo_inplace = atoi(s);
     if (const char *s = getenv("SLA_PANELS")) c->panels = atoi(s);
+    if (const char *s = getenv("SLA_OVERLAP")) c->overlap = atoi(s);
     if (const char *s = getenv("SLA_TILES")) c->tiles = atoi(s);
     if (const char *s = getenv("SLA_TILE_SHIFT")) c->tile_shift = atoi(s);
     if (const char *s = getenv("SLA_TILE_SLACK")) c->tile_slack = atoi(s);
@@ -950,6 +1028,9 @@ int sla_ctx_destroy(sla_ctx_t c) {
     if (c->h_result) (void)hipHostFree(c->h_result);
     if (c->d_xfull) (void)guard_free(c->d_xfull);
     if (c->d_tfull) (void)hipFree(c->d_tfull);
+    if (c->ev_x_ready) (void)hipEventDestroy(c->ev_x_ready);
+    if (c->ev_x_done) (void)hipEventDestroy(c->ev_x_done);
+    if (c->comm_stream) (void)hipStreamDestroy(c->comm_stream);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return SLA_OK;
@@ -1302,6 +1383,8 @@ int sla_csr_destroy(sla_csr_t A) {
     if (A->d_tlidx) (void)hipFree(A->d_tlidx);
     if (A->d_tlval) (void)hipFree(A->d_tlval);
     if (A->d_tlprog) (void)hipFree(A->d_tlprog);
+    if (A->d_ov_int) (void)hipFree(A->d_ov_int);
+    if (A->d_ov_bnd) (void)hipFree(A->d_ov_bnd);
     delete A->xplan;
     if (A->d_rowptr) (void)hipFree(A->d_rowptr);
     if (A->d_col) (void)hipFree(A->d_col);
@@ -1404,6 +1487,11 @@ int sla_csr_kernel_info(sla_csr_t A, char *buf, int buflen) {
             snprintf(buf + used, (size_t)buflen - used, " slices=%d panels=%d panel_cols=%d max_segment=%lld exact_fold=1", A->tl_S, A->tl_P,
                      1 << A->tl_shift, (long long)A->tl_maxseg);
     }
+    if (overlap_split(A)) {
+        const size_t used = strlen(buf);
+        if (used + 1 < (size_t)buflen)
+            snprintf(buf + used, (size_t)buflen - used, " overlap=%s interior_steps=%d boundary_steps=%d", A->ctx->overlap > 0 ? "streams" : "serial", A->ov_nint, A->ov_nbnd);
+    }
     if (A->xplan) {   // row-sharded: how the SpMV input is exchanged
         const size_t used = strlen(buf);
         if (used + 1 < (size_t)buflen)
@@ -1499,10 +1587,9 @@ int sla_spmv(sla_csr_t A, sla_vec_t x, sla_vec_t y) {
     if (A->m != y->n) return fail(SLA_ERR_DIM_MISMATCH, "matVec : result vector has the wrong dimension");
     if (x == y) return fail(SLA_ERR_INVALID, "sla_spmv: x and y must be distinct");
     SpmvLaunch l;
-    SLA_TRY(gather_x(A, x, &l.x));
     l.y = y->d;
     l.kernel_id = SLA_KERNEL_SPMV;
-    return launch_spmv(A, l);
+    return spmv_exchanged(A, x, l, nullptr);
 }
 
 int sla_spmv_t(sla_csr_t A, sla_vec_t x, sla_vec_t y) {

@@ -144,6 +144,10 @@ struct sla_ctx {
     int64_t device_coo_min = 1 << 20; // triple lists at least this long are sorted on the GPU (SLA_DEVICE_COO_MIN)
     int rb_nnz = 0;                  // 0: automatic row-block size (SLA_RB_NNZ overrides, <= 1024)
     int row_align = 0;               // > 1: row blocks end on multiples of this many rows (SLA_ROW_ALIGN; measured -1.5 % at 16)
+    int overlap = 1;                 // sharded (#>): 1 interior rows run while the halo exchange is in flight (second stream), 0 same split launches with
+                                     // the exchange serialised on the compute stream (A/B, bit-identical), -1 no split at all (SLA_OVERLAP)
+    hipStream_t comm_stream = nullptr;   // created on first use
+    hipEvent_t ev_x_ready = nullptr, ev_x_done = nullptr;
     int tiles = 1;                   // allow the row-slice x column-panel tile SpMV for irregular matrices with x > L2 (SLA_TILES=0: column-panel passes)
     int tile_slack = 3;              // panel pacing: a wavefront starts panel step q once its XCD has finished step q - slack (SLA_TILE_SLACK, 0: no pacing)
     int tile_shift = 17;             // log2 of its panel width in columns (SLA_TILE_SHIFT): 1 MiB of x per panel (slack 3 / shift 17: 2.26 ms at 10 M rows; 2 / 18: 2.31; 6 / 16: 2.35)
@@ -272,6 +276,11 @@ struct sla_csr {
     size_t tlprog_bytes = 0;
     int64_t tl_maxseg = 0;           // longest (row, panel) segment = layers of the deepest tile
     sla_tri_plan *tri[2] = {nullptr, nullptr};  // [0] lower, [1] upper triangle schedules (built on first use)
+    // comm / compute overlap of the sharded (#>) (wave-sliced forms): the 512-row steps whose rows reference own columns only
+    // (interior: they can run while the halo exchange is in flight) and the rest, each in the visiting order of d_wsched
+    int32_t *d_ov_int = nullptr, *d_ov_bnd = nullptr;
+    int32_t ov_nint = 0, ov_nbnd = 0;
+    std::vector<int32_t> h_wsched;   // host copy of d_wsched (empty: ascending order)
     sla::XPlan *xplan = nullptr;     // sharded only: which x entries this rank exchanges with each peer
     int64_t max_row_nnz = 0;
 };
@@ -413,9 +422,15 @@ struct SpmvLaunch {
     const double *yinit = nullptr;              // column-panel pass: continue these running row sums
     int in_panel = 0;
     int kernel_id = SLA_KERNEL_SPMV;
+    int part = 0;                               // row-sharded overlap: 0 all rows, 1 the interior steps only, 2 the boundary steps only
 };
 int spmv_grid(const sla_csr *A);  // number of blocks (= partial slots written) of an SpMV launch on A
 int launch_spmv(const sla_csr *A, const SpmvLaunch &l);
+// exchange the input vector of a (#>) and launch it; on row-sharded contexts the interior rows run while the halo is in flight.
+// *np (may be null) = partial slots the launch(es) wrote (spmv_grid(A) unless the launch was split)
+int spmv_exchanged(sla_csr *A, sla_vec *x, SpmvLaunch l, int *np);
+bool overlap_split(const sla_csr *A);   // does (#>) on A run as interior + boundary launches?
+int overlap_grid(const sla_csr *A, int part);
 bool tiles_on(const sla_csr *A);                               // is the tile form of A in use?
 int launch_spmv_tiles(const sla_csr *A, const SpmvLaunch &l);   // sla_spmv_tiles.hip
 int tiles_grid(const sla_csr *A);

@@ -1755,6 +1755,15 @@ static bool vec_stream_nt(const sla_ctx *c, int64_t n) {
     return c->vec_nt < 0 ? 7 * 8 * n > c->mall_bytes : c->vec_nt != 0;
 }
 
+// row-sharded overlap (sla_api.cpp: spmv_exchanged): interior / boundary launches of the wave-sliced forms
+bool overlap_split(const sla_csr *A) {
+    return A->ov_nint > 0 && A->ov_nbnd > 0 && A->ctx->overlap >= 0 && A->ctx->collectives && A->use_wdia && wd_on(A) && A->ctx->spmv_algo == 0 && !A->rp64;
+}
+int overlap_grid(const sla_csr *A, int part) {
+    const int cap = A->wd_vv ? A->ctx->wd_grid_max_vv : A->ctx->wd_grid_max;
+    return part == 1 ? std::max(1, std::min<int>(A->ov_nint, cap)) : std::max(1, std::min<int>(A->ov_nbnd, 256));
+}
+
 int spmv_grid(const sla_csr *A) {
     const sla_ctx *c = A->ctx;
     // with column panels the fused partials are written by the LAST panel pass: its grid is the one that counts
@@ -1872,13 +1881,17 @@ static int launch_spmv_t(const sla_csr *A, const SpmvLaunch &l) {
     if (A->use_wdia && wd_on(A) && c->spmv_algo == 0 && !l.x2) {
         if constexpr (std::is_same<RP, int32_t>::value) {
             const int32_t *sched = c->wd_tile != 0 ? A->d_wsched : nullptr;
+            int32_t nblk_wd = A->nblk_wd;
+            int grid = ::sla::spmv_grid(A);
+            if (l.part == 1) { sched = A->d_ov_int; nblk_wd = A->ov_nint; grid = overlap_grid(A, 1); }
+            else if (l.part == 2) { sched = A->d_ov_bnd; nblk_wd = A->ov_nbnd; grid = overlap_grid(A, 2); }
             if (A->wd_vv)
                 hipLaunchKernelGGL((spmv_wdia_kernel<EPI, true>), dim3(grid), dim3(kBlock), 0, c->stream, a, A->d_wptr, A->d_wme, A->d_wmo,
-                                   A->d_wval, A->d_woff, A->d_wvblk, a.x, A->nblk_wd, A->nslices, (int32_t)A->row_begin, (int32_t)A->n,
+                                   A->d_wval, A->d_woff, A->d_wvblk, a.x, nblk_wd, A->nslices, (int32_t)A->row_begin, (int32_t)A->n,
                                    sched, c->xcd_remap, vec_stream_nt(c, A->rows) ? 1 : 0);
             else
                 hipLaunchKernelGGL((spmv_wdia_kernel<EPI, false>), dim3(grid), dim3(kBlock), 0, c->stream, a, A->d_wptr, A->d_wme, A->d_wmo,
-                                   A->d_wval, A->d_woff, A->d_wvblk, a.x, A->nblk_wd, A->nslices, (int32_t)A->row_begin, (int32_t)A->n,
+                                   A->d_wval, A->d_woff, A->d_wvblk, a.x, nblk_wd, A->nslices, (int32_t)A->row_begin, (int32_t)A->n,
                                    sched, c->xcd_remap, vec_stream_nt(c, A->rows) ? 1 : 0);
             SLA_HIP_TRY(hipGetLastError());
             return SLA_OK;

@@ -98,13 +98,13 @@ struct StepCtl {
 int enqueue_residual(sla_solver *S, Parts *res) {
     SpmvLaunch l;
     l.epi = EPI_RES;
-    SLA_TRY(gather_x(S->A, S->x, &l.x));
     l.w = S->b->d;
     l.p1 = slot(S, P_RES);
     l.sc = S->d_sc;
     l.kernel_id = SLA_KERNEL_SPMV_RES;
-    SLA_TRY(launch_spmv(S->A, l));
-    return publish(S, P_RES, -1, spmv_grid(S->A), res, nullptr);
+    int gk = 0;
+    SLA_TRY(spmv_exchanged(S->A, S->x, l, &gk));
+    return publish(S, P_RES, -1, gk, res, nullptr);
 }
 
 // bicgstabStep (Sparse.hs:972-981)
@@ -168,7 +168,6 @@ int enqueue_bicgstab(sla_solver *S, int par, const Parts *check, bool dual_prev)
     {
         SpmvLaunch l;  // K1: aap = aa #> p ; aap <.> r0hat
         l.epi = EPI_DOT;
-        SLA_TRY(gather_x(S->A, S->p, &l.x));
         l.y = S->t1->d;
         l.w = S->r0hat->d;
         l.p1 = slot(S, P_APR);
@@ -182,23 +181,24 @@ int enqueue_bicgstab(sla_solver *S, int par, const Parts *check, bool dual_prev)
             l.p2 = slot(S, P_RES);
             l.kernel_id = SLA_KERNEL_SPMV_DUAL;
         }
-        SLA_TRY(launch_spmv(A, l));
-        SLA_TRY(publish(S, P_APR, -1, g, &apr, nullptr));
+        int gk = g;   // (row-sharded: the interior rows run while the halo of p is in flight, spmv_exchanged)
+        SLA_TRY(spmv_exchanged(A, S->p, l, &gk));
+        SLA_TRY(publish(S, P_APR, -1, gk, &apr, nullptr));
     }
     SLA_TRY(launch_bicg_k2(c, n, S->d_sc, apr, par, dual_prev ? Parts{slot(S, P_RES), g, 1} : Parts{nullptr, 0, 1},
                            dual_prev ? 1 : 0, S->r->d, S->t1->d, S->t2->d));
     {
         SpmvLaunch l;  // K3: aasj = aa #> sj ; aasj <.> sj ; aasj <.> aasj
         l.epi = EPI_DOT2;
-        SLA_TRY(gather_x(S->A, S->t2, &l.x));
         l.y = S->t3->d;
         l.w = S->t2->d;
         l.p1 = slot(S, P_ASS);
         l.p2 = slot(S, P_ASAS);
         l.sc = S->d_sc;
         l.kernel_id = SLA_KERNEL_SPMV_DOT2;
-        SLA_TRY(launch_spmv(A, l));
-        SLA_TRY(publish(S, P_ASS, P_ASAS, g, &ass, &asas));
+        int gk = g;
+        SLA_TRY(spmv_exchanged(A, S->t2, l, &gk));
+        SLA_TRY(publish(S, P_ASS, P_ASAS, gk, &ass, &asas));
     }
     SLA_TRY(launch_bicg_k4(c, n, S->d_sc, ass, asas, S->p->d, S->t2->d, S->t3->d, S->r0hat->d, S->x->d, S->r->d, slot(S, P_RHO)));
     SLA_TRY(publish(S, P_RHO, -1, vec_grid(n), &rhon, nullptr));
@@ -261,7 +261,6 @@ int enqueue_cgs(sla_solver *S, int par, const Parts *check, bool dual_prev) {
     {
         SpmvLaunch l;  // C1: aap = aa #> p ; aap <.> rhat
         l.epi = EPI_DOT;
-        SLA_TRY(gather_x(S->A, S->p, &l.x));
         l.y = S->t1->d;
         l.w = S->r0hat->d;
         l.p1 = slot(S, P_APR);
@@ -275,23 +274,24 @@ int enqueue_cgs(sla_solver *S, int par, const Parts *check, bool dual_prev) {
             l.p2 = slot(S, P_RES);
             l.kernel_id = SLA_KERNEL_SPMV_DUAL;
         }
-        SLA_TRY(launch_spmv(A, l));
-        SLA_TRY(publish(S, P_APR, -1, g, &apr, nullptr));
+        int gk = g;
+        SLA_TRY(spmv_exchanged(A, S->p, l, &gk));
+        SLA_TRY(publish(S, P_APR, -1, gk, &apr, nullptr));
     }
     SLA_TRY(launch_cgs_c2(c, n, S->d_sc, apr, par, dual_prev ? Parts{slot(S, P_RES), g, 1} : Parts{nullptr, 0, 1},
                           dual_prev ? 1 : 0, S->u->d, S->t1->d, S->t2->d, S->t3->d, S->x->d));
     {
         SpmvLaunch l;  // C3: rj1 = r ^-^ alphaj .* (aa #> (u ^+^ q)) ; rj1 <.> rhat
         l.epi = EPI_AXPY_DOT;
-        SLA_TRY(gather_x(S->A, S->t3, &l.x));
         l.z = S->r->d;
         l.w = S->r0hat->d;
         l.p1 = slot(S, P_RHO);
         l.sc = S->d_sc;
         l.step_begin = par << 1;
         l.kernel_id = SLA_KERNEL_SPMV_DOT2;
-        SLA_TRY(launch_spmv(A, l));
-        SLA_TRY(publish(S, P_RHO, -1, g, &rhon, nullptr));
+        int gk = g;
+        SLA_TRY(spmv_exchanged(A, S->t3, l, &gk));
+        SLA_TRY(publish(S, P_RHO, -1, gk, &rhon, nullptr));
     }
     SLA_TRY(launch_cgs_c4(c, n, S->d_sc, rhon, par, S->r->d, S->t2->d, S->u->d, S->p->d));
     return SLA_OK;
@@ -307,7 +307,6 @@ int enqueue_cgne(sla_solver *S, int par, const Parts *check, StepCtl *ctl) {
     {
         SpmvLaunch l;  // N1: alphai = (r.r)/(p.p) ; r1 = r ^-^ alphai .* (aa #> p) ; r1 . r1
         l.epi = EPI_AXPY_DOT;
-        SLA_TRY(gather_x(S->A, S->p, &l.x));
         l.z = S->r->d;
         l.w = nullptr;
         l.pa = ctl->pp.p;
@@ -318,8 +317,9 @@ int enqueue_cgne(sla_solver *S, int par, const Parts *check, StepCtl *ctl) {
         if (check && check->p) { l.pres = check->p; l.npres = check->n; l.pres_stride = check->stride; }
         l.step_begin = 1 | (par << 1);
         l.kernel_id = SLA_KERNEL_SPMV_DOT;
-        SLA_TRY(launch_spmv(A, l));
-        SLA_TRY(publish(S, P_RHO, -1, spmv_grid(A), &rr1, nullptr));
+        int gk = 0;
+        SLA_TRY(spmv_exchanged(A, S->p, l, &gk));
+        SLA_TRY(publish(S, P_RHO, -1, gk, &rr1, nullptr));
     }
     SLA_TRY(launch_cgne_n2(c, S->x->n_local, S->d_sc, S->p->d, S->x->d));  // x1 = x ^+^ alphai .* p
     if (sharded) {
@@ -406,10 +406,9 @@ int solver_init_common(int method, sla_csr *A, sla_vec *b, sla_vec *x0, double t
         if ((rc = sla_vec_copy(b, S->b)) != SLA_OK) break;
         SpmvLaunch l;  // r0 = b ^-^ (aa #> x0)
         l.epi = EPI_SUB;
-        if ((rc = gather_x(S->A, S->x, &l.x)) != SLA_OK) break;
         l.y = S->r->d;
         l.w = S->b->d;
-        if ((rc = launch_spmv(A, l)) != SLA_OK) break;
+        if ((rc = spmv_exchanged(A, S->x, l, nullptr)) != SLA_OK) break;
         if ((rc = sla_vec_copy(S->r, S->r0hat)) != SLA_OK) break;
         if (method == SLA_CGNE_) {
             // p0 = transposeSM aa #> r0
@@ -827,10 +826,9 @@ int sla_gmres(sla_csr_t A, sla_vec_t b, sla_vec_t x0, int restart, const sla_sol
         while (rc == SLA_OK) {
             SpmvLaunch l;  // r = b ^-^ (aa #> x)
             l.epi = EPI_SUB;
-            if ((rc = gather_x(A, x, &l.x)) != SLA_OK) break;
             l.y = r->d;
             l.w = b->d;
-            if ((rc = launch_spmv(A, l)) != SLA_OK) break;
+            if ((rc = spmv_exchanged(A, x, l, nullptr)) != SLA_OK) break;
             double ss = 0.0;
             if ((rc = launch_dot(c, r->n_local, r->d, r->d, c->d_parts)) != SLA_OK) break;
             if ((rc = reduce_to_host(c, c->d_parts, nullptr, vec_grid(r->n_local), &ss)) != SLA_OK) break;

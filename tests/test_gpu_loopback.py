@@ -37,7 +37,9 @@ def test_ghost_row_bicgstab_and_cgs_equal_the_plain_sharded_flow(kind, nranks):
     with ONE ghost row per side -- the odd count that the extended kernels round up to keep their 16-byte pairs aligned.)"""
     got = {}
     for ghost in ("1", "0"):
-        env = dict(os.environ, SLA_BICG_GHOST=ghost, SLA_DEBUG_EXCHANGE="1")
+        # (SLA_OVERLAP=-1: the plain flow's exchange-preceded SpMVs would otherwise run as interior + boundary launches, whose fused
+        # partial sums are grouped differently from the ghost flow's single launches -- same mathematics, other last bits)
+        env = dict(os.environ, SLA_BICG_GHOST=ghost, SLA_DEBUG_EXCHANGE="1", SLA_OVERLAP="-1")
         out = subprocess.run([sys.executable, os.path.join(HERE, "_loopback_worker.py"), str(nranks), kind], env=env,
                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
         assert out.returncode == 0 and f"LOOPBACK_OK {nranks} {kind}" in out.stdout, out.stdout[-3000:]
@@ -46,3 +48,33 @@ def test_ghost_row_bicgstab_and_cgs_equal_the_plain_sharded_flow(kind, nranks):
             assert (name in out.stdout) == (ghost == "1" and kind not in ("random", "tiny")), out.stdout[-2000:]
     assert len(got["1"]) == 2
     assert got["1"] and got["1"] == got["0"], got
+
+
+@pytest.mark.parametrize("nranks", [2, 4])
+def test_overlapped_halo_exchange_equals_the_serial_flow_bit_for_bit(nranks):
+    """the sharded (#>) runs the interior 512-row steps while the halo exchange is in flight on a second
+    stream and the boundary steps after it (spmv_exchanged).  SLA_OVERLAP=0 issues the very same two launches with the
+    exchange serialised on the compute stream: every solver iterate must be BIT-identical (plain sharded flows,
+    SLA_BICG_GHOST=0: an exchange precedes each SpMV).  SLA_OVERLAP=-1 (one unsplit launch) groups the fused partial sums
+    differently: same (#>) bits -- the worker compares those with the oracle in every mode -- and iteration counts within 4."""
+    got, kern = {}, {}
+    for ov in ("1", "0", "-1"):
+        env = dict(os.environ, SLA_OVERLAP=ov, SLA_BICG_GHOST="0")
+        out = subprocess.run([sys.executable, os.path.join(HERE, "_loopback_worker.py"), str(nranks), "laplace_big"], env=env,
+                             stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+        assert out.returncode == 0 and f"LOOPBACK_OK {nranks} laplace_big" in out.stdout, out.stdout[-3000:]
+        got[ov] = [l for l in out.stdout.splitlines() if l.startswith("XHASH")]
+        kern[ov] = [l for l in out.stdout.splitlines() if l.startswith("KERNEL")][0]
+    assert "overlap=streams" in kern["1"] and "overlap=serial" in kern["0"] and "overlap=" not in kern["-1"], kern
+    assert "interior_steps=" in kern["1"] and "x_exchange=window" in kern["1"]
+    assert len(got["1"]) == 2 and got["1"] == got["0"], got
+    for a, b in zip(got["1"], got["-1"]):                                                    # iteration counts: Krylov-sensitive (50 vs 53 on 2 ranks)
+        assert abs(int(a.split()[-1]) - int(b.split()[-1])) <= 4, (a, b)
+
+
+def test_overlap_also_under_the_ghost_row_flows():
+    """With the ghost-row BiCGSTAB / CGS (default) only the residual sweeps, the initial r0 = b - A x0, CGNE, GMRES and plain
+    (#>) still exchange before a SpMV: those take the overlapped path, the rest is untouched."""
+    out = subprocess.run([sys.executable, os.path.join(HERE, "_loopback_worker.py"), "3", "laplace_big"],
+                         stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert out.returncode == 0 and "LOOPBACK_OK 3 laplace_big" in out.stdout and "overlap=streams" in out.stdout, out.stdout[-3000:]
