@@ -467,10 +467,13 @@ struct ArnoldiWs {
     int64_t n = 0, n_local = 0, ld = 0;
     int kn = 0;
     double *Q = nullptr, *w = nullptr, *H = nullptr, *parts = nullptr, *gath = nullptr, *ycoef = nullptr;
+    double *Qalloc = nullptr;   // what guard_free gets back (Q = Qalloc + halo when the basis columns carry halo slack)
+    int64_t halo = 0;           // row-sharded, window exchange: slack on both sides of every basis column for the neighbours' planes
+    int64_t begin = 0, shard = 0;
     SolverScalars *d_sc = nullptr, *h_sc = nullptr;
     std::vector<double> Hhost;
     ~ArnoldiWs() {
-        if (Q) (void)guard_free(Q);
+        if (Qalloc) (void)guard_free(Qalloc);
         if (w) (void)hipFree(w);
         if (H) (void)hipFree(H);
         if (parts) (void)hipFree(parts);
@@ -488,9 +491,22 @@ int arn_alloc(ArnoldiWs &ws, sla_csr *A, sla_vec *like, int kn) {
     ws.n_local = like->n_local;
     ws.ld = std::max<int64_t>(like->shard + (like->shard & 1), 2);  // even leading dimension: 16-byte aligned columns
     ws.kn = kn;
+    ws.begin = like->begin;
+    ws.shard = like->shard;
+    {   // Row-sharded with the window exchange: give every basis column the slack the neighbours' halo planes need, so that
+        // aa #> q_i receives them IN PLACE around the column (and overlaps the exchange with the interior rows, spmv_exchanged)
+        // instead of going through the full-length landing buffer with a copy of the own rows.
+        int64_t gl = 0, gr = 0;
+        if (c->collectives && A->m == A->n && halo_inplace_extents(A, like, &gl, &gr)) {
+            ws.halo = std::max(gl, gr) + 8;
+            ws.halo += ws.halo & 1;
+            ws.ld += 2 * ws.halo;
+        }
+    }
     const size_t qbytes = sizeof(double) * (size_t)ws.ld * (size_t)(kn + 1);
-    SLA_HIP_TRY(guard_malloc((void **)&ws.Q, qbytes));  // SpMV gathers from its columns
-    SLA_HIP_TRY(hipMemsetAsync(ws.Q, 0, qbytes, c->stream));
+    SLA_HIP_TRY(guard_malloc((void **)&ws.Qalloc, qbytes));  // SpMV gathers from its columns
+    SLA_HIP_TRY(hipMemsetAsync(ws.Qalloc, 0, qbytes, c->stream));
+    ws.Q = ws.Qalloc + ws.halo;
     SLA_HIP_TRY(hipMalloc((void **)&ws.w, sizeof(double) * (size_t)ws.ld));
     SLA_HIP_TRY(hipMemsetAsync(ws.w, 0, sizeof(double) * (size_t)ws.ld, c->stream));
     SLA_HIP_TRY(hipMalloc((void **)&ws.H, sizeof(double) * (size_t)(kn + 1) * (size_t)kn));
@@ -537,10 +553,21 @@ int arn_run(ArnoldiWs &ws, sla_csr *A, const double *src_local, int kn, int *k_d
     for (int i = 0; i < kn; ++i) {
         const double *qi = ws.Q + (size_t)i * ws.ld;
         SpmvLaunch l;  // aqi = aa #> qi
-        SLA_TRY(gather_raw(c, A, qi, (ws.n + c->nranks - 1) / c->nranks, &l.x));
         l.y = ws.w;
         l.sc = ws.d_sc;
-        SLA_TRY(launch_spmv(A, l));
+        if (ws.halo > 0) {   // the column as a vector view with its own halo slack: in-place exchange, interior rows overlapped
+            sla_vec qv;
+            qv.ctx = c;
+            qv.n = ws.n;
+            qv.n_local = ws.n_local;
+            qv.shard = ws.shard;
+            qv.begin = ws.begin;
+            qv.d = const_cast<double *>(qi);
+            SLA_TRY(spmv_exchanged(A, &qv, l, nullptr));
+        } else {
+            SLA_TRY(gather_raw(c, A, qi, (ws.n + c->nranks - 1) / c->nranks, &l.x));
+            SLA_TRY(launch_spmv(A, l));
+        }
         // hhcoli = fmap (`dot` aqi) qv
         SLA_TRY(launch_arn_dots(c, n, ws.Q, ws.ld, i + 1, ws.w, ws.parts, ws.d_sc));
         SLA_TRY(arn_publish(ws, ws.parts, g, i + 1, &cp));
