@@ -25,6 +25,7 @@ import Data.Int (Int64)
 import Foreign
 import Foreign.C.String
 import Foreign.C.Types
+import System.Environment (lookupEnv)
 import System.IO.Unsafe (unsafePerformIO)
 import System.Mem.StableName
 
@@ -37,6 +38,7 @@ import Numeric.LinearAlgebra.Sparse (LinSolveMethod (..))
 data Ctx; data Csr; data Vec; data Solver
 
 foreign import ccall safe "sla_ctx_create"        c_ctx_create        :: CInt -> Ptr (Ptr Ctx) -> IO CInt
+foreign import ccall safe "sla_ctx_create_multi"  c_ctx_create_multi  :: CInt -> Ptr CInt -> Ptr (Ptr Ctx) -> IO CInt
 foreign import ccall safe "sla_csr_from_coo"      c_csr_from_coo      :: Ptr Ctx -> Int64 -> Int64 -> Int64 -> Ptr Int64 -> Ptr Int64 -> Ptr Double -> CInt -> Ptr (Ptr Csr) -> IO CInt
 foreign import ccall safe "sla_csr_dims"          c_csr_dims          :: Ptr Csr -> Ptr Int64 -> Ptr Int64 -> Ptr Int64 -> Ptr Int64 -> IO CInt
 foreign import ccall safe "sla_csr_export"        c_csr_export        :: Ptr Csr -> Ptr Int64 -> Ptr Int64 -> Ptr Double -> IO CInt
@@ -60,9 +62,13 @@ foreign import ccall safe "sla_linsolve"          c_linsolve          :: Ptr Csr
 foreign import ccall safe "sla_tri_solve"         c_tri_solve         :: Ptr Csr -> CInt -> Ptr Vec -> Ptr Vec -> Ptr Int64 -> IO CInt
 foreign import ccall unsafe "sla_last_error"      c_last_error        :: IO CString
 
+-- | One GPU by default; SLA_GPUS=n makes every matrix / vector / solver of this module span the first n devices of the
+--   node (sla_ctx_create_multi: the library fans each call out to one rank per device, RCCL between them).
 {-# NOINLINE defaultCtx #-}
 defaultCtx :: Ptr Ctx
-defaultCtx = unsafePerformIO $ alloca $ \p -> c_ctx_create 0 p >>= check "sla_ctx_create" >> peek p
+defaultCtx = unsafePerformIO $ do
+  n <- maybe 1 read <$> lookupEnv "SLA_GPUS"
+  alloca $ \p -> (if n > 1 then c_ctx_create_multi (fromIntegral (n :: Int)) nullPtr p else c_ctx_create 0 p) >>= check "sla_ctx_create" >> peek p
 
 -- | status code -> the reference's exception / error (Control/Exception/Common.hs:44-76).  INTEGRATION.md section 2 shows
 --   this very function.

@@ -93,6 +93,15 @@ typedef enum { SLA_STATE_X = 0, SLA_STATE_R = 1, SLA_STATE_P = 2, SLA_STATE_U = 
 
 /* Single-GPU context on `device_id`.  SLA_ERR_NO_DEVICE when no GPU is visible. */
 int sla_ctx_create(int device_id, sla_ctx_t *out);
+/* ONE caller, n_gpus devices (the reference's caller is a single Haskell program): the library creates one rank
+ * context per device -- RCCL communicator from one unique id, like ncclCommInitAll -- and returns a PARENT context.  Matrices
+ * and vectors created from it are given / returned WHOLE (rows split in contiguous blocks over the devices); every call on
+ * them runs on all devices at once, one internal host thread per device (the per-rank calls contain collectives, so they are
+ * issued concurrently exactly as n processes would).  (#>), (<.>), norm2, the vector algebra, the solver state records,
+ * linSolve0, arnoldi, GMRES and (<\>) are available; what is not sharded (##, preconditioner set-up, triangular solves,
+ * pre-sharded input) returns SLA_ERR_INVALID.  device_ids == NULL means 0 .. n_gpus-1; a REPEATED device id selects the
+ * in-process loopback communicator (test backend: RCCL refuses two ranks on one GPU); n_gpus == 1 is sla_ctx_create. */
+int sla_ctx_create_multi(int n_gpus, const int *device_ids, sla_ctx_t *out);
 /* One rank of a row-sharded job (one process per GPU).  unique_id = the 128 bytes produced by
  * sla_dist_unique_id on rank 0 and distributed out of band (bench.py uses torch.distributed). */
 int sla_dist_unique_id(void *unique_id_128);

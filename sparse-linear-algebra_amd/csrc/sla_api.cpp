@@ -1016,6 +1016,7 @@ int sla_ctx_create_loopback(int device_id, int rank, int nranks, int group_key, 
 }
 
 int sla_ctx_destroy(sla_ctx_t c) {
+    if (c && !c->kids.empty()) return m_ctx_destroy(c);
     if (!c) return SLA_OK;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
@@ -1037,6 +1038,7 @@ int sla_ctx_destroy(sla_ctx_t c) {
 }
 
 int sla_ctx_sync(sla_ctx_t c) {
+    if (c && !c->kids.empty()) return m_ctx_sync(c);
     if (!c) return fail(SLA_ERR_INVALID, "null context");
     SLA_HIP_TRY(hipStreamSynchronize(c->stream));
     return SLA_OK;
@@ -1062,6 +1064,7 @@ int sla_ctx_row_range(sla_ctx_t c, int64_t m, int64_t *begin, int64_t *end) {
 
 int sla_csr_from_coo(sla_ctx_t c, int64_t m, int64_t n, int64_t nnz, const int64_t *row, const int64_t *col,
                      const double *val, int dup_policy, sla_csr_t *out) {
+    if (c && !c->kids.empty()) return m_csr_from_coo(c, m, n, nnz, row, col, val, dup_policy, out);
     return no_throw("sla_csr_from_coo", [&]() -> int {
         if (!c || !out || (nnz > 0 && (!row || !col || !val))) return fail(SLA_ERR_INVALID, "sla_csr_from_coo: null argument");
         HostCsr h;
@@ -1087,6 +1090,7 @@ int sla_csr_from_coo(sla_ctx_t c, int64_t m, int64_t n, int64_t nnz, const int64
 
 int sla_csr_from_csr(sla_ctx_t c, int64_t m, int64_t n, const int64_t *rowptr, const int64_t *colidx,
                      const double *val, sla_csr_t *out) {
+    if (c && !c->kids.empty()) return m_csr_from_csr(c, m, n, rowptr, colidx, val, out);
     return no_throw("sla_csr_from_csr", [&]() -> int {
         if (!c || !out || !rowptr || m < 0 || n < 0) return fail(SLA_ERR_INVALID, "sla_csr_from_csr: bad argument");
         int64_t b, e;
@@ -1100,6 +1104,7 @@ int sla_csr_from_csr(sla_ctx_t c, int64_t m, int64_t n, const int64_t *rowptr, c
 
 int sla_csr_from_csr_rows(sla_ctx_t c, int64_t m, int64_t n, int64_t row_begin, int64_t row_count,
                           const int64_t *rowptr_local, const int64_t *colidx, const double *val, sla_csr_t *out) {
+    if (c && !c->kids.empty()) return multi_unsupported("sla_csr_from_csr_rows (pre-sharded input)");
     return no_throw("sla_csr_from_csr_rows", [&]() -> int {
         if (!c || !out || !rowptr_local || m < 0 || n < 0 || row_count < 0)
             return fail(SLA_ERR_INVALID, "sla_csr_from_csr_rows: bad argument");
@@ -1142,6 +1147,7 @@ static int export_host(sla_csr_t A, HostCsr &h) {
 }
 
 int sla_jacobi_pre(sla_csr_t A, sla_csr_t *out) {
+    if (A && !A->kids.empty()) return multi_unsupported("sla_jacobi_pre");
     return no_throw("sla_jacobi_pre", [&]() -> int {
         if (!A || !out) return fail(SLA_ERR_INVALID, "null argument");
         if (A->ctx->collectives) return fail(SLA_ERR_INVALID, "sla_jacobi_pre: single-rank contexts only");
@@ -1251,6 +1257,7 @@ static int tri_plan_build(sla_csr *T, int upper, int64_t *bad_row) {
 }
 
 int sla_tri_solve_info(sla_csr_t T, int upper, int64_t *levels, int64_t *widest_level) {
+    if (T && !T->kids.empty()) return multi_unsupported("sla_tri_solve_info");
     if (!T) return fail(SLA_ERR_INVALID, "null matrix");
     if (T->ctx->collectives || T->m != T->n) return fail(SLA_ERR_INVALID, "sla_tri_solve: square matrices on single-rank contexts only");
     upper = upper ? 1 : 0;
@@ -1262,6 +1269,7 @@ int sla_tri_solve_info(sla_csr_t T, int upper, int64_t *levels, int64_t *widest_
 }
 
 int sla_tri_solve(sla_csr_t T, int upper, sla_vec_t b, sla_vec_t x, int64_t *bad_row) {
+    if (T && !T->kids.empty()) return multi_unsupported("sla_tri_solve");
     return no_throw("sla_tri_solve", [&]() -> int {
         if (!T || !b || !x) return fail(SLA_ERR_INVALID, "null argument");
         sla_ctx *c = T->ctx;
@@ -1297,6 +1305,7 @@ int sla_tri_solve(sla_csr_t T, int upper, sla_vec_t b, sla_vec_t x, int64_t *bad
 }
 
 int sla_ssor_pre(sla_csr_t A, double omega, sla_csr_t *l, sla_csr_t *r) {
+    if (A && !A->kids.empty()) return multi_unsupported("sla_ssor_pre");
     return no_throw("sla_ssor_pre", [&]() -> int {
         if (!A || !l || !r) return fail(SLA_ERR_INVALID, "null argument");
         if (A->ctx->collectives) return fail(SLA_ERR_INVALID, "sla_ssor_pre: single-rank contexts only");
@@ -1341,6 +1350,7 @@ int sla_ssor_pre(sla_csr_t A, double omega, sla_csr_t *l, sla_csr_t *r) {
 }
 
 int sla_csr_diag_mul(sla_csr_t D, sla_csr_t A, sla_csr_t *out) {
+    if ((D && !D->kids.empty()) || (A && !A->kids.empty())) return multi_unsupported("sla_csr_diag_mul");
     return no_throw("sla_csr_diag_mul", [&]() -> int {
         if (!D || !A || !out) return fail(SLA_ERR_INVALID, "null argument");
         if (D->ctx != A->ctx || A->ctx->collectives) return fail(SLA_ERR_INVALID, "sla_csr_diag_mul: one single-rank context");
@@ -1374,6 +1384,7 @@ int sla_csr_diag_mul(sla_csr_t D, sla_csr_t A, sla_csr_t *out) {
 }
 
 int sla_csr_destroy(sla_csr_t A) {
+    if (A && !A->kids.empty()) return m_csr_destroy(A);
     if (!A) return SLA_OK;
     if (A->transposed) sla_csr_destroy(A->transposed);
     for (sla_csr *V : A->panels) sla_csr_destroy(V);
@@ -1423,6 +1434,7 @@ int sla_csr_dims(sla_csr_t A, int64_t *m, int64_t *n, int64_t *nnz_local, int64_
 }
 
 int sla_csr_export(sla_csr_t A, int64_t *rowptr, int64_t *colidx, double *val) {
+    if (A && !A->kids.empty()) return m_csr_export(A, rowptr, colidx, val);
     return no_throw("sla_csr_export", [&]() -> int {
         if (!A) return fail(SLA_ERR_INVALID, "null matrix");
         sla_ctx *c = A->ctx;
@@ -1453,6 +1465,7 @@ int sla_csr_is_diagonal(sla_csr_t A, int *out) {
 }
 
 int sla_csr_kernel_info(sla_csr_t A, char *buf, int buflen) {
+    if (A && !A->kids.empty()) return sla_csr_kernel_info(A->kids[0], buf, buflen);
     if (!A || !buf || buflen <= 0) return fail(SLA_ERR_INVALID, "null argument");
     snprintf(buf, (size_t)buflen, "algo=%s grid=%d block=%d row_blocks=%d nnz_per_row_block=%d max_row_nnz=%lld rowptr=%s xcd_remap=%d",
              A->ctx->spmv_algo == 1 ? "scalar" : (A->use_wdia && wd_on(A)) ? (A->wd_vv ? "wdia-vv" : "wdia") : (A->use_vdict && A->ctx->vdict) ? (A->use_xwin && A->ctx->xwin ? "vdict+xwin" : "vdict") : (A->use_lpanel && A->ctx->lpanel) ? "stream+ldspanels" : tiles_on(A) ? "tiles" : (!A->panels.empty() && A->ctx->panels) ? "stream+colpanels" : (A->use_diag && A->ctx->diag ? (A->use_xwin && A->ctx->xwin ? "stream+diagdict+xwin" : "stream+diagdict") : (A->use_xwin && A->ctx->xwin ? "stream+xwin" : "stream")), spmv_grid(A), kBlock, A->nrb, kNnzPerRowBlock,
@@ -1504,6 +1517,7 @@ int sla_csr_kernel_info(sla_csr_t A, char *buf, int buflen) {
 // ---- vectors ----------------------------------------------------------------------------------------
 
 int sla_vec_create(sla_ctx_t c, int64_t n, const double *host, sla_vec_t *out) {
+    if (c && !c->kids.empty()) return m_vec_create(c, n, host, out);
     if (!c || !out || n < 0) return fail(SLA_ERR_INVALID, "sla_vec_create: bad argument");
     (void)hipSetDevice(c->device);
     sla_vec *v = nullptr;
@@ -1521,6 +1535,7 @@ int sla_vec_create(sla_ctx_t c, int64_t n, const double *host, sla_vec_t *out) {
 }
 
 int sla_vec_create_local(sla_ctx_t c, int64_t n, const double *host_local, sla_vec_t *out) {
+    if (c && !c->kids.empty()) return m_vec_create(c, n, host_local, out);   // the caller of a multi-device context owns every row
     if (!c || !out || n < 0) return fail(SLA_ERR_INVALID, "sla_vec_create_local: bad argument");
     (void)hipSetDevice(c->device);
     sla_vec *v = nullptr;
@@ -1538,6 +1553,7 @@ int sla_vec_create_local(sla_ctx_t c, int64_t n, const double *host_local, sla_v
 }
 
 int sla_vec_destroy(sla_vec_t v) {
+    if (v && !v->kids.empty()) return m_vec_destroy(v);
     if (!v) return SLA_OK;
     pool_free(v->ctx, v->d, sizeof(double) * (size_t)std::max<int64_t>(v->shard, 1));
     delete v;
@@ -1552,6 +1568,7 @@ int sla_vec_dim(sla_vec_t v, int64_t *n, int64_t *n_local) {
 }
 
 int sla_vec_to_host_local(sla_vec_t v, double *host_local) {
+    if (v && !v->kids.empty()) return m_vec_to_host(v, host_local);
     if (!v || !host_local) return fail(SLA_ERR_INVALID, "null argument");
     sla_ctx *c = v->ctx;
     if (v->n_local > 0)
@@ -1561,6 +1578,7 @@ int sla_vec_to_host_local(sla_vec_t v, double *host_local) {
 }
 
 int sla_vec_to_host(sla_vec_t v, double *host) {
+    if (v && !v->kids.empty()) return m_vec_to_host(v, host);
     if (!v || !host) return fail(SLA_ERR_INVALID, "null argument");
     sla_ctx *c = v->ctx;
     if (!c->collectives) return sla_vec_to_host_local(v, host);
@@ -1572,6 +1590,7 @@ int sla_vec_to_host(sla_vec_t v, double *host) {
 }
 
 int sla_vec_copy(sla_vec_t src, sla_vec_t dst) {
+    if (src && !src->kids.empty()) return m_vec_copy(src, dst);
     if (!src || !dst) return fail(SLA_ERR_INVALID, "null vector");
     if (src->n != dst->n || src->ctx != dst->ctx) return fail(SLA_ERR_DIM_MISMATCH, "sla_vec_copy: mismatched dimensions");
     if (src->shard > 0)
@@ -1582,6 +1601,7 @@ int sla_vec_copy(sla_vec_t src, sla_vec_t dst) {
 // ---- (#>) (<#) (<.>) norm2 axpby ---------------------------------------------------------------------
 
 int sla_spmv(sla_csr_t A, sla_vec_t x, sla_vec_t y) {
+    if (A && !A->kids.empty()) return m_spmv(A, x, y, false);
     if (!A || !x || !y) return fail(SLA_ERR_INVALID, "null argument");
     if (A->n != x->n) return fail(SLA_ERR_DIM_MISMATCH, "matVec : mismatched dimensions");  // Common.hs:250
     if (A->m != y->n) return fail(SLA_ERR_DIM_MISMATCH, "matVec : result vector has the wrong dimension");
@@ -1593,6 +1613,7 @@ int sla_spmv(sla_csr_t A, sla_vec_t x, sla_vec_t y) {
 }
 
 int sla_spmv_t(sla_csr_t A, sla_vec_t x, sla_vec_t y) {
+    if (A && !A->kids.empty()) return m_spmv(A, x, y, true);
     return no_throw("sla_spmv_t", [&]() -> int {
         if (!A || !x || !y) return fail(SLA_ERR_INVALID, "null argument");
         if (A->m != x->n) return fail(SLA_ERR_DIM_MISMATCH, "vecMat : mismatching dimensions");  // Common.hs:256
@@ -1603,6 +1624,7 @@ int sla_spmv_t(sla_csr_t A, sla_vec_t x, sla_vec_t y) {
 }
 
 int sla_dot(sla_vec_t x, sla_vec_t y, double *out) {
+    if (x && !x->kids.empty()) return out ? m_dot(x, y, out) : fail(SLA_ERR_INVALID, "null argument");
     if (!x || !y || !out) return fail(SLA_ERR_INVALID, "null argument");
     if (x->ctx != y->ctx) return fail(SLA_ERR_INVALID, "vectors from different contexts");
     // the reference's liftI2 takes max of the dims and never checks (SpVector.hs:64); dense device
@@ -1614,6 +1636,7 @@ int sla_dot(sla_vec_t x, sla_vec_t y, double *out) {
 }
 
 int sla_nrm2(sla_vec_t x, double *out) {
+    if (x && !x->kids.empty()) return out ? m_nrm2(x, out) : fail(SLA_ERR_INVALID, "null argument");
     double ss = 0.0;
     SLA_TRY(sla_dot(x, x, &ss));
     *out = sqrt(ss);  // norm2 = sqrt . norm2Sq
@@ -1621,12 +1644,14 @@ int sla_nrm2(sla_vec_t x, double *out) {
 }
 
 int sla_axpby(double a, sla_vec_t x, double b, sla_vec_t y) {
+    if (x && !x->kids.empty()) return m_axpby(a, x, b, y);
     if (!x || !y) return fail(SLA_ERR_INVALID, "null argument");
     if (x->n != y->n || x->ctx != y->ctx) return fail(SLA_ERR_DIM_MISMATCH, "^+^ : mismatched dimensions");
     return launch_axpby(x->ctx, x->n_local, a, x->d, b, y->d);
 }
 
 int sla_scal(double a, sla_vec_t x) {
+    if (x && !x->kids.empty()) return m_scal(a, x);
     if (!x) return fail(SLA_ERR_INVALID, "null argument");
     return launch_scal(x->ctx, x->n_local, a, x->d);
 }
@@ -1649,6 +1674,7 @@ int sla_plan_window_exchange(int nranks, int rank, int64_t n, const int64_t *win
 // ---- measurement hooks ---------------------------------------------------------------------------------
 
 int sla_prof_start(sla_ctx_t c, int kernel_id, int max_launches) {
+    if (c && !c->kids.empty()) { for (sla_ctx *k : c->kids) SLA_TRY(sla_prof_start(k, kernel_id, max_launches)); return SLA_OK; }
     if (!c || max_launches < 0 || kernel_id < SLA_KERNEL_ALL || kernel_id >= SLA_KERNEL_COUNT) return fail(SLA_ERR_INVALID, "sla_prof_start: bad argument");
     while ((int)c->prof_ev.size() < 2 * max_launches) {
         hipEvent_t ev;
@@ -1678,6 +1704,7 @@ static void prof_stats(const sla_ctx *c, int kernel_id, int *launches, double *m
 }
 
 int sla_prof_query(sla_ctx_t c, int kernel_id, int *launches, double *mean_ms, double *min_ms) {
+    if (c && !c->kids.empty()) return sla_prof_query(c->kids[0], kernel_id, launches, mean_ms, min_ms);
     if (!c || kernel_id < SLA_KERNEL_ALL || kernel_id >= SLA_KERNEL_COUNT) return fail(SLA_ERR_INVALID, "sla_prof_query: bad argument");
     prof_stats(c, kernel_id, launches, mean_ms, min_ms);
     return SLA_OK;
@@ -1692,11 +1719,13 @@ int sla_device_count(int *count) {
 }
 
 int sla_ctx_comm_ranks(sla_ctx_t c, int *nranks) {
+    if (c && !c->kids.empty()) return sla_ctx_comm_ranks(c->kids[0], nranks);
     if (!c || !nranks) return fail(SLA_ERR_INVALID, "null argument");
     return dist_comm_count(c, nranks);
 }
 
 int sla_prof_stop(sla_ctx_t c, int *launches, double *mean_ms, double *min_ms) {
+    if (c && !c->kids.empty()) { for (size_t r = c->kids.size(); r-- > 1;) SLA_TRY(sla_prof_stop(c->kids[r], nullptr, nullptr, nullptr)); return sla_prof_stop(c->kids[0], launches, mean_ms, min_ms); }
     if (!c) return fail(SLA_ERR_INVALID, "null context");
     SLA_HIP_TRY(hipStreamSynchronize(c->stream));
     c->prof_ms.assign((size_t)c->prof_count, 0.f);

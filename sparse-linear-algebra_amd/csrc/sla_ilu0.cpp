@@ -46,6 +46,7 @@ inline double lookup(const std::vector<Ent> &row, int64_t c) {   // m @@! (i, c)
 using namespace sla;
 
 extern "C" int sla_ilu0_pre(sla_csr_t A, int exact_lu, sla_csr_t *l_out, sla_csr_t *u_out, int64_t *bad_row) {
+    if (A && !A->kids.empty()) return multi_unsupported("sla_ilu0_pre");
     return no_throw("sla_ilu0_pre", [&]() -> int {
         if (!A || !l_out || !u_out) return fail(SLA_ERR_INVALID, "sla_ilu0_pre: null argument");
         sla_ctx *c = A->ctx;

@@ -128,6 +128,7 @@ void plan_window_exchange(int nranks, int rank, int64_t n, const int64_t *window
 // handle types of the C ABI
 // ---------------------------------------------------------------------------------------------
 struct sla_ctx {
+    std::vector<sla_ctx *> kids;     // non-empty: the PARENT of a single-process multi-device group (sla_multi.cpp); nothing below is used then
     int device = 0, rank = 0, nranks = 1;
     hipStream_t stream = nullptr;
     void *comm = nullptr;            // ncclComm_t when nranks > 1 (or a 1-rank test comm)
@@ -189,6 +190,7 @@ struct sla_ctx {
 };
 
 struct sla_vec {
+    std::vector<sla_vec *> kids;     // non-empty: a bundle of per-rank vectors of a multi-device context
     sla_ctx *ctx = nullptr;
     int64_t n = 0;        // global dimension
     int64_t n_local = 0;  // this rank's entries
@@ -214,6 +216,7 @@ struct sla_tri_plan {
 };
 
 struct sla_csr {
+    std::vector<sla_csr *> kids;     // non-empty: a bundle of per-rank row blocks of a multi-device context
     sla_ctx *ctx = nullptr;
     int64_t m = 0, n = 0;            // global dims
     int64_t row_begin = 0, rows = 0; // local row block
@@ -286,6 +289,7 @@ struct sla_csr {
 };
 
 struct sla_solver {
+    std::vector<sla_solver *> kids;  // non-empty: a bundle of per-rank states of a multi-device context
     sla_ctx *ctx = nullptr;
     sla_csr *A = nullptr;
     int method = 0;
@@ -303,6 +307,38 @@ struct sla_solver {
     int64_t ghl = 0, ghr = 0;
     alignas(8) char ctl_storage[128];    // driver-private step bookkeeping (sla_solvers.cpp)
 };
+
+// single-process multi-device bundles (sla_multi.cpp): every m_* runs the per-rank entry point on all ranks concurrently
+namespace sla {
+int m_ctx_destroy(sla_ctx *p);
+int m_ctx_sync(sla_ctx *p);
+int m_csr_from_coo(sla_ctx *p, int64_t m, int64_t n, int64_t nnz, const int64_t *row, const int64_t *col, const double *val, int dup, sla_csr_t *out);
+int m_csr_from_csr(sla_ctx *p, int64_t m, int64_t n, const int64_t *rp, const int64_t *ci, const double *va, sla_csr_t *out);
+int m_csr_from_matrix_market(sla_ctx *p, const char *path, int dup, sla_csr_t *out);
+int m_csr_destroy(sla_csr *A);
+int m_csr_export(sla_csr *A, int64_t *rowptr, int64_t *colidx, double *val);
+int m_vec_create(sla_ctx *p, int64_t n, const double *host, sla_vec_t *out);
+int m_vec_from_matrix_market(sla_ctx *p, const char *path, sla_vec_t *out);
+int m_vec_destroy(sla_vec *v);
+int m_vec_to_host(sla_vec *v, double *host);
+int m_vec_copy(sla_vec *s, sla_vec *d);
+int m_spmv(sla_csr *A, sla_vec *x, sla_vec *y, bool transposed);
+int m_dot(sla_vec *x, sla_vec *y, double *out);
+int m_nrm2(sla_vec *x, double *out);
+int m_axpby(double a, sla_vec *x, double b, sla_vec *y);
+int m_scal(double a, sla_vec *x);
+int m_solver_init(int method, sla_csr *A, sla_vec *b, sla_vec *x0, sla_solver_t *out);
+int m_solver_step(sla_solver *S, int k);
+int m_solver_get(sla_solver *S, int field, sla_vec *out);
+int m_solver_clone(sla_solver *S, sla_solver_t *out);
+int m_solver_set_shadow(sla_solver *S, sla_vec *r0hat);
+int m_solver_destroy(sla_solver *S);
+int m_linsolve0(int method, sla_csr *A, sla_vec *b, sla_vec *x0, const sla_solve_opts *o, sla_vec *xo, sla_solve_info *info);
+int m_gmres(sla_csr *A, sla_vec *b, sla_vec *x0, int restart, const sla_solve_opts *o, sla_vec *xo, sla_solve_info *info);
+int m_linsolve(sla_csr *A, sla_vec *b, sla_vec *xo, sla_solve_info *info);
+int m_arnoldi(sla_csr *A, sla_vec *b, int kn, double *Q, double *H, int *k_done);
+int multi_unsupported(const char *what);
+}  // namespace sla
 
 namespace sla {
 // is the wave-sliced SpMV form of A enabled by the context's knobs?

@@ -52,6 +52,7 @@ __global__ void __launch_bounds__(kBlock) matmat_kernel(const RPA *__restrict__ 
 using namespace sla;
 
 extern "C" int sla_csr_matmat(sla_csr_t A, sla_csr_t B, int transpose_b, sla_csr_t *out) {
+    if ((A && !A->kids.empty()) || (B && !B->kids.empty())) return multi_unsupported("sla_csr_matmat");
     return no_throw("sla_csr_matmat", [&]() -> int {
         if (!A || !B || !out) return fail(SLA_ERR_INVALID, "sla_csr_matmat: null argument");
         if (A->ctx != B->ctx) return fail(SLA_ERR_INVALID, "sla_csr_matmat: operands belong to different contexts");

@@ -41,6 +41,7 @@ int read_header(FILE *f, const char *path, std::string &banner, char *line, size
 extern "C" {
 
 int sla_csr_from_matrix_market(sla_ctx_t c, const char *path, int dup_policy, sla_csr_t *out) {
+    if (c && !c->kids.empty()) return sla::m_csr_from_matrix_market(c, path, dup_policy, out);
     return no_throw("sla_csr_from_matrix_market", [&]() -> int {
         if (!c || !path || !out) return fail(SLA_ERR_INVALID, "sla_csr_from_matrix_market: null argument");
         File fl(path);
@@ -69,6 +70,7 @@ int sla_csr_from_matrix_market(sla_ctx_t c, const char *path, int dup_policy, sl
 }
 
 int sla_vec_from_matrix_market(sla_ctx_t c, const char *path, sla_vec_t *out) {
+    if (c && !c->kids.empty()) return sla::m_vec_from_matrix_market(c, path, out);
     return no_throw("sla_vec_from_matrix_market", [&]() -> int {
         if (!c || !path || !out) return fail(SLA_ERR_INVALID, "sla_vec_from_matrix_market: null argument");
         File fl(path);

@@ -621,12 +621,14 @@ void hessenberg_lsq(int k, int ldh, const double *H, double beta, double *y) {
 extern "C" {
 
 int sla_solver_init(int method, sla_csr_t A, sla_vec_t b, sla_vec_t x0, sla_solver_t *out) {
+    if (A && !A->kids.empty()) return m_solver_init(method, A, b, x0, out);
     return no_throw("sla_solver_init", [&]() -> int {
         return solver_init_common(method, A, b, x0, 1e-6, 1e-4, out);
     });
 }
 
 int sla_solver_step(sla_solver_t S, int k_steps) {
+    if (S && !S->kids.empty()) return k_steps >= 0 ? m_solver_step(S, k_steps) : fail(SLA_ERR_INVALID, "sla_solver_step: bad argument");
     if (!S || k_steps < 0) return fail(SLA_ERR_INVALID, "sla_solver_step: bad argument");
     (void)hipSetDevice(S->ctx->device);
     for (int k = 0; k < k_steps; ++k) SLA_TRY(enqueue_step(S, false, false));
@@ -634,6 +636,7 @@ int sla_solver_step(sla_solver_t S, int k_steps) {
 }
 
 int sla_solver_get(sla_solver_t S, int field, sla_vec_t out) {
+    if (S && !S->kids.empty()) return m_solver_get(S, field, out);
     if (!S || !out) return fail(SLA_ERR_INVALID, "null argument");
     sla_vec *src = nullptr;
     switch (field) {
@@ -651,6 +654,7 @@ int sla_solver_get(sla_solver_t S, int field, sla_vec_t out) {
 // needs states that do not alias.  Everything the step kernels read is copied on the context stream: the state vectors,
 // the partial sums the next kernel's prologue reduces, the per-rank tables, the device scalars, the step bookkeeping.
 int sla_solver_clone(sla_solver_t S, sla_solver_t *out) {
+    if (S && !S->kids.empty()) return out ? m_solver_clone(S, out) : fail(SLA_ERR_INVALID, "null argument");
     return no_throw("sla_solver_clone", [&]() -> int {
         if (!S || !out) return fail(SLA_ERR_INVALID, "sla_solver_clone: null argument");
         sla_ctx *c = S->ctx;
@@ -705,6 +709,7 @@ int sla_solver_clone(sla_solver_t S, sla_solver_t *out) {
 // cgsStep, Sparse.hs:928, :972; sla_solver_init stores r0 = b - A x0 there, the README's choice) and re-evaluate the
 // carried rho = r . r0hat with it -- the reference recomputes `r <.> r0hat` at the top of every step.
 int sla_solver_set_shadow(sla_solver_t S, sla_vec_t r0hat) {
+    if (S && !S->kids.empty()) return m_solver_set_shadow(S, r0hat);
     return no_throw("sla_solver_set_shadow", [&]() -> int {
         if (!S || !r0hat) return fail(SLA_ERR_INVALID, "sla_solver_set_shadow: null argument");
         if (S->method != SLA_BICGSTAB_ && S->method != SLA_CGS_) return fail(SLA_ERR_INVALID, "sla_solver_set_shadow: CGS / BiCGSTAB states only");
@@ -721,6 +726,7 @@ int sla_solver_set_shadow(sla_solver_t S, sla_vec_t r0hat) {
 }
 
 int sla_solver_destroy(sla_solver_t S) {
+    if (S && !S->kids.empty()) return m_solver_destroy(S);
     if (!S) return SLA_OK;
     if (S->ctx && S->ctx->stream) (void)hipStreamSynchronize(S->ctx->stream);
     sla_vec *vs[] = {S->x, S->r, S->p, S->u, S->r0hat, S->b, S->t1, S->t2, S->t3};
@@ -746,6 +752,7 @@ int sla_cgs_step(sla_solver_t S, int k) {
 
 int sla_linsolve0(int method, sla_csr_t A, sla_vec_t b, sla_vec_t x0, const sla_solve_opts *opts, sla_vec_t x_out,
                   sla_solve_info *info) {
+    if (A && !A->kids.empty()) return m_linsolve0(method, A, b, x0, opts, x_out, info);
     return no_throw("sla_linsolve0", [&]() -> int {
         if (!A || !b || !x0 || !x_out) return fail(SLA_ERR_INVALID, "sla_linsolve0: null argument");
         sla_solve_opts o = {200, 1e-6, 1e-4, 16, 1};
@@ -804,6 +811,7 @@ int sla_linsolve0(int method, sla_csr_t A, sla_vec_t b, sla_vec_t x0, const sla_
 }
 
 int sla_arnoldi(sla_csr_t A, sla_vec_t b, int kn, double *Q_colmajor, double *H_colmajor, int *k_done) {
+    if (A && !A->kids.empty()) return (H_colmajor && k_done) ? m_arnoldi(A, b, kn, Q_colmajor, H_colmajor, k_done) : fail(SLA_ERR_INVALID, "sla_arnoldi: null argument");
     return no_throw("sla_arnoldi", [&]() -> int {
         if (!A || !b || !H_colmajor || !k_done) return fail(SLA_ERR_INVALID, "sla_arnoldi: null argument");
         // | otherwise = throwM (MatVecSizeMismatchException "arnoldi" (m,n) nb)      (Sparse.hs:637)
@@ -829,6 +837,7 @@ int sla_arnoldi(sla_csr_t A, sla_vec_t b, int kn, double *Q_colmajor, double *H_
 
 int sla_gmres(sla_csr_t A, sla_vec_t b, sla_vec_t x0, int restart, const sla_solve_opts *opts, sla_vec_t x_out,
               sla_solve_info *info) {
+    if (A && !A->kids.empty()) return m_gmres(A, b, x0, restart, opts, x_out, info);
     return no_throw("sla_gmres", [&]() -> int {
         if (!A || !b || !x0 || !x_out) return fail(SLA_ERR_INVALID, "sla_gmres: null argument");
         sla_solve_opts o = {200, 1e-6, 1e-4, 16, 1};
@@ -897,6 +906,7 @@ int sla_gmres(sla_csr_t A, sla_vec_t b, sla_vec_t x0, int restart, const sla_sol
 // instance LinearSystem (SpVector Double): aa <\> b = linSolve0 GMRES_ aa b (mkSpVR n $ replicate n 0.1)
 // (dead code in the reference, Sparse.hs:1080-1084)
 int sla_linsolve(sla_csr_t A, sla_vec_t b, sla_vec_t x_out, sla_solve_info *info) {
+    if (A && !A->kids.empty()) return m_linsolve(A, b, x_out, info);
     return no_throw("sla_linsolve", [&]() -> int {
         if (!A || !b || !x_out) return fail(SLA_ERR_INVALID, "sla_linsolve: null argument");
         sla_vec *x0 = nullptr;

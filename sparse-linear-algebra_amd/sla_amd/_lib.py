@@ -66,6 +66,7 @@ PROTOTYPES = [
     ("sla_ctx_create", _int, [_int, _pp]),
     ("sla_dist_unique_id", _int, [_vp]),
     ("sla_ctx_create_dist", _int, [_int, _int, _int, _vp, _pp]),
+    ("sla_ctx_create_multi", _int, [_int, _vp, _pp]),
     ("sla_ctx_create_loopback", _int, [_int, _int, _int, _int, _pp]),
     ("sla_ctx_destroy", _int, [_vp]),
     ("sla_ctx_sync", _int, [_vp]),

@@ -55,6 +55,17 @@ class Context:
         self.rank, self.nranks = rank, nranks
         return self
 
+    @classmethod
+    def multi(cls, device_ids):
+        """ONE caller driving len(device_ids) GPUs (sla_ctx_create_multi): matrices / vectors are given and returned whole, the
+        library fans every call out to one rank per device.  A repeated device id selects the loopback test backend."""
+        self = cls.__new__(cls)
+        self.h = C.c_void_p()
+        ids = (C.c_int * len(device_ids))(*device_ids)
+        check(lib().sla_ctx_create_multi(len(device_ids), C.cast(ids, C.c_void_p), C.byref(self.h)))
+        self.rank, self.nranks = 0, 1          # the caller's view: it owns every row
+        return self
+
     @staticmethod
     def unique_id():
         buf = (C.c_char * 128)()
