@@ -355,40 +355,43 @@ static int par_rows(int64_t rows, int64_t align, F fn, int64_t serial_below = 20
     return T;
 }
 
-static int csr_upload(sla_ctx *c, int64_t m, int64_t n, int64_t row_begin, int64_t rows, const int64_t *rowptr,
-                      const int64_t *col, const double *val, sla_csr **out, bool panel_view) {
-    const int64_t nnz = rowptr[rows];
-    if (n > (int64_t)std::numeric_limits<int32_t>::max() || rows >= (int64_t)std::numeric_limits<int32_t>::max())
-        return fail(SLA_ERR_INVALID, "matrix dimension exceeds the 32-bit device index width");
-    static const bool dbg_lower = getenv("SLA_DEBUG_LOWER") != nullptr;
-    auto t_last = std::chrono::steady_clock::now();
-    auto lap = [&](const char *what) {
-        if (!dbg_lower || panel_view) return;
-        const auto t = std::chrono::steady_clock::now();
-        fprintf(stderr, "[sla] lowering: %-28s %7.1f ms\n", what, std::chrono::duration<double, std::milli>(t - t_last).count());
-        t_last = t;
-    };
-    sla_csr *A = new sla_csr();
-    A->ctx = c;
-    A->m = m;
-    A->n = n;
-    A->row_begin = row_begin;
-    A->rows = rows;
-    A->nnz = nnz;
-    // (SLA_FORCE_RP64=1: test hook -- run the 64-bit row-pointer instantiations of the kernels on small matrices)
-    // (SLA_FORCE_RP64=2: the parent only -- its column-panel views keep their natural 32-bit width, the mixed case of a > 2^31-entry matrix)
-    A->rp64 = nnz > (int64_t)std::numeric_limits<int32_t>::max() || c->force_rp64 == 1 || (c->force_rp64 == 2 && !panel_view);
-    std::vector<int32_t> rb;
-    build_row_blocks(rows, rowptr, rb, A->max_row_nnz, c->row_align, c->rb_nnz);
-    A->nrb = (int32_t)rb.size() - 1;
-    int diag_not = host_is_diagonal(rows, row_begin, rowptr, col) ? 0 : 1;
-    if (m != n && rows > 0) { /* isDiagonalSM only counts (i,i) entries; nothing extra to do */ }
+// ---------------------------------------------------------------------------------------------------------------
+// csr_upload = one lowering analysis per function.  What they share travels in `Low`; SLA_LOW_LOCALS re-opens it under the
+// names the analyses use.
+// ---------------------------------------------------------------------------------------------------------------
+struct Low {
+    sla_ctx *c;
+    sla_csr *A;
+    int64_t m, n, row_begin, rows, nnz;
+    const int64_t *rowptr, *col;
+    const double *val;
+    bool panel_view, dbg_lower;
     hipError_t err = hipSuccess;
-    auto upload = [&](void **dst, const void *src, size_t bytes) {
+    std::vector<int32_t> rb;            // row-block starts
+    std::vector<int64_t> offs;          // sorted distinct diagonal offsets (<= 256) when the matrix has that structure
+    std::vector<uint8_t> dcodes;        // per entry: index into offs
+    void upload(void **dst, const void *src, size_t bytes) {
         if (err != hipSuccess) return;
         err = hipMalloc(dst, std::max<size_t>(bytes, 8));
         if (err == hipSuccess && bytes) err = hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
-    };
+    }
+};
+#define SLA_LOW_LOCALS(L)                                                                                                  \
+    [[maybe_unused]] sla_ctx *c = (L).c;                                                                                   \
+    [[maybe_unused]] sla_csr *A = (L).A;                                                                                   \
+    [[maybe_unused]] const int64_t m = (L).m, n = (L).n, row_begin = (L).row_begin, rows = (L).rows, nnz = (L).nnz;        \
+    [[maybe_unused]] const int64_t *rowptr = (L).rowptr, *col = (L).col;                                                   \
+    [[maybe_unused]] const double *val = (L).val;                                                                          \
+    [[maybe_unused]] const bool panel_view = (L).panel_view, dbg_lower = (L).dbg_lower;                                    \
+    [[maybe_unused]] hipError_t &err = (L).err;                                                                            \
+    [[maybe_unused]] std::vector<int32_t> &rb = (L).rb;                                                                    \
+    [[maybe_unused]] std::vector<int64_t> &offs = (L).offs;                                                                \
+    [[maybe_unused]] std::vector<uint8_t> &dcodes = (L).dcodes;                                                            \
+    [[maybe_unused]] auto upload = [&](void **dst_, const void *src_, size_t bytes_) { (L).upload(dst_, src_, bytes_); }
+
+// canonical CSR arrays (i32 columns, i32 / i64 row pointers) + the row-block tables of the general kernels
+static void low_csr_arrays(Low &L) {
+    SLA_LOW_LOCALS(L);
     // the values go up on a second host thread while this one narrows and uploads the indices (pageable copies are
     // bound by the staging memcpy of the calling thread, not by the link)
     hipError_t err_val = hipSuccess;
@@ -425,7 +428,11 @@ static int csr_upload(sla_ctx *c, int64_t m, int64_t n, int64_t row_begin, int64
     upload((void **)&A->d_rb, rb.data(), sizeof(int32_t) * rb.size());
     val_up.join();
     if (err == hipSuccess) err = err_val;
-    lap("row blocks + CSR upload");
+}
+
+// LDS x window of every row block (spmv_xwin_kernel) and the share of the entries that fall inside
+static void low_xwin_statistics(Low &L) {
+    SLA_LOW_LOCALS(L);
     if (!panel_view) {
         // LDS x window of each row block: kXWin columns starting kXWinHalo left of its first diagonal column
         std::vector<int32_t> rbw(rb.size(), 0);
@@ -450,9 +457,11 @@ static int csr_upload(sla_ctx *c, int64_t m, int64_t n, int64_t row_begin, int64
         A->use_xwin = A->xwin_fraction >= 0.5;
         upload((void **)&A->d_rbw, rbw.data(), sizeof(int32_t) * rbw.size());
     }
-    lap("x-window statistics");
-    std::vector<int64_t> offs;          // sorted distinct diagonal offsets (<= 256) when the matrix has that structure
-    std::vector<uint8_t> dcodes;        // per entry: index into offs
+}
+
+// dictionary of diagonal offsets + 1-byte column codes (spmv_diag_kernel): <= 256 distinct col - row values
+static void low_diagonal_dictionary(Low &L) {
+    SLA_LOW_LOCALS(L);
     if (!panel_view) {
         // dictionary of diagonal offsets: worthwhile (and representable in a byte) when col - row takes at
         // most 256 distinct values, i.e. for stencil / banded structure
@@ -504,6 +513,12 @@ static int csr_upload(sla_ctx *c, int64_t m, int64_t n, int64_t row_begin, int64
             A->ndiag = (int)offs.size();
         }
     }
+}
+
+// value-indexed forms for constant-coefficient stencils: (offset, value) pair dictionary + byte codes (spmv_vdict_kernel), the
+// wave-sliced records and the plane-tiled visiting order (spmv_wdia_kernel)
+static void low_value_indexed(Low &L) {
+    SLA_LOW_LOCALS(L);
     if (!panel_view && !A->rp64 && nnz > 0 && A->max_row_nnz <= kVdMaxRowNnz) {
         // value-indexed form: dictionary of (col - row, value bit pattern) pairs, one byte per entry
         struct Pair { int64_t off; uint64_t bits; };
@@ -667,7 +682,11 @@ static int csr_upload(sla_ctx *c, int64_t m, int64_t n, int64_t row_begin, int64
             }
         }
     }
-    lap("pair dictionary + wave slices");
+}
+
+// wave-sliced form for variable coefficients (wdia-vv): diagonal records with per-row value blocks
+static void low_wave_sliced_variable(Low &L) {
+    SLA_LOW_LOCALS(L);
     if (!panel_view && A->use_diag && !A->use_wdia && !A->rp64 && c->wdia_vv && n < ((int64_t)1 << 28) && nnz > 0) {
         // Wave-sliced form for VARIABLE coefficients (banded / stencil structure, arbitrary values): per 128-row slice the
         // sorted union of its diagonal offsets with the two row masks each, and per record a block of 128 values laid out
@@ -724,7 +743,11 @@ static int csr_upload(sla_ctx *c, int64_t m, int64_t n, int64_t row_begin, int64
             A->nblk_wd = (int32_t)((nsl + 3) / 4);
         }
     }
-    lap("variable-coefficient slices");
+}
+
+// LDS-panel form for dense rows (spmv_lpanel_kernel): per (panel, row) entry ranges + the task runs of the persistent grid
+static void low_lds_panels(Low &L) {
+    SLA_LOW_LOCALS(L);
     if (!panel_view && !A->use_wdia && !A->use_vdict && rows > 0 && err == hipSuccess) {
         // LDS-panel form (spmv_lpanel_kernel): worthwhile when a row has enough entries per kLpW-column panel to
         // keep a wavefront's lanes busy, affordable when the (panel, row) pointer table stays a fraction of the matrix
@@ -808,6 +831,47 @@ static int csr_upload(sla_ctx *c, int64_t m, int64_t n, int64_t row_begin, int64
             A->use_lpanel = err == hipSuccess;
         }
     }
+}
+
+static int csr_upload(sla_ctx *c, int64_t m, int64_t n, int64_t row_begin, int64_t rows, const int64_t *rowptr,
+                      const int64_t *col, const double *val, sla_csr **out, bool panel_view) {
+    const int64_t nnz = rowptr[rows];
+    if (n > (int64_t)std::numeric_limits<int32_t>::max() || rows >= (int64_t)std::numeric_limits<int32_t>::max())
+        return fail(SLA_ERR_INVALID, "matrix dimension exceeds the 32-bit device index width");
+    static const bool dbg_lower = getenv("SLA_DEBUG_LOWER") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!dbg_lower || panel_view) return;
+        const auto t = std::chrono::steady_clock::now();
+        fprintf(stderr, "[sla] lowering: %-28s %7.1f ms\n", what, std::chrono::duration<double, std::milli>(t - t_last).count());
+        t_last = t;
+    };
+    sla_csr *A = new sla_csr();
+    A->ctx = c;
+    A->m = m;
+    A->n = n;
+    A->row_begin = row_begin;
+    A->rows = rows;
+    A->nnz = nnz;
+    // (SLA_FORCE_RP64=1: test hook -- run the 64-bit row-pointer instantiations of the kernels on small matrices)
+    // (SLA_FORCE_RP64=2: the parent only -- its column-panel views keep their natural 32-bit width, the mixed case of a > 2^31-entry matrix)
+    A->rp64 = nnz > (int64_t)std::numeric_limits<int32_t>::max() || c->force_rp64 == 1 || (c->force_rp64 == 2 && !panel_view);
+    Low L{c, A, m, n, row_begin, rows, nnz, rowptr, col, val, panel_view, dbg_lower};
+    hipError_t &err = L.err;
+    build_row_blocks(rows, rowptr, L.rb, A->max_row_nnz, c->row_align, c->rb_nnz);
+    A->nrb = (int32_t)L.rb.size() - 1;
+    int diag_not = host_is_diagonal(rows, row_begin, rowptr, col) ? 0 : 1;
+    if (m != n && rows > 0) { /* isDiagonalSM only counts (i,i) entries; nothing extra to do */ }
+    low_csr_arrays(L);
+    lap("row blocks + CSR upload");
+    low_xwin_statistics(L);
+    lap("x-window statistics");
+    low_diagonal_dictionary(L);
+    low_value_indexed(L);
+    lap("pair dictionary + wave slices");
+    low_wave_sliced_variable(L);
+    lap("variable-coefficient slices");
+    low_lds_panels(L);
     lap("LDS panel table");
     if (panel_view) {
         if (err != hipSuccess) {
@@ -910,6 +974,44 @@ extern "C" {
 const char *sla_last_error(void) { return g_last_error.c_str(); }
 const char *sla_version(void) { return "sla_hip 0.1 (gfx950)"; }
 
+// The A/B and test knobs ("Knobs"): every one defaults to the measured-best setting; they are read ONCE, when a
+// context is created, from this one table.
+static void ctx_read_knobs(sla_ctx *c) {
+    static const struct { const char *env; int sla_ctx::*field; } kIntKnobs[] = {
+        {"SLA_STEP_GRAPH", &sla_ctx::step_graph},
+        {"SLA_XCD_REMAP", &sla_ctx::xcd_remap},
+        {"SLA_DUAL_SPMV", &sla_ctx::dual_spmv},
+        {"SLA_XWIN", &sla_ctx::xwin},
+        {"SLA_DIAG", &sla_ctx::diag},
+        {"SLA_VDICT", &sla_ctx::vdict},
+        {"SLA_WDIA", &sla_ctx::wdia},
+        {"SLA_LPANEL", &sla_ctx::lpanel},
+        {"SLA_LP_TASKS", &sla_ctx::lp_tasks},
+        {"SLA_LP_CFG", &sla_ctx::lp_cfg},
+        {"SLA_FORCE_RP64", &sla_ctx::force_rp64},
+        {"SLA_BICG_GHOST", &sla_ctx::bicg_ghost},
+        {"SLA_WD_TILE", &sla_ctx::wd_tile},
+        {"SLA_WDIA_VV", &sla_ctx::wdia_vv},
+        {"SLA_VEC_NT", &sla_ctx::vec_nt},
+        {"SLA_HALO_INPLACE", &sla_ctx::halo_inplace},
+        {"SLA_PANELS", &sla_ctx::panels},
+        {"SLA_OVERLAP", &sla_ctx::overlap},
+        {"SLA_TILES", &sla_ctx::tiles},
+        {"SLA_TILE_SHIFT", &sla_ctx::tile_shift},
+        {"SLA_TILE_SLACK", &sla_ctx::tile_slack},
+        {"SLA_ROW_ALIGN", &sla_ctx::row_align},
+        {"SLA_RB_NNZ", &sla_ctx::rb_nnz},
+    };
+    for (const auto &k : kIntKnobs)
+        if (const char *s = getenv(k.env)) c->*(k.field) = atoi(s);
+    if (const char *s = getenv("SLA_SPMV_ALGO")) c->spmv_algo = (strcmp(s, "scalar") == 0) ? 1 : 0;
+    if (const char *s = getenv("SLA_LP_MINSEG")) c->lp_min_seg = std::max(1, atoi(s));
+    if (const char *s = getenv("SLA_LP_ROWCOST")) c->lp_rowcost = std::max(0, atoi(s));
+    if (const char *s = getenv("SLA_PANEL_COLS")) c->panel_cols = atoll(s);
+    if (const char *s = getenv("SLA_DEVICE_COO_MIN")) c->device_coo_min = atoll(s);
+    if (const char *s = getenv("SLA_X_EXCHANGE")) c->x_exchange = strcmp(s, "allgather") == 0 ? 1 : (strcmp(s, "window") == 0 ? 2 : 0);
+}
+
 static int ctx_create_common(int device_id, int rank, int nranks, const void *uid, sla_ctx_t *out) {
     if (!out || nranks < 1 || rank < 0 || rank >= nranks) return fail(SLA_ERR_INVALID, "sla_ctx_create: bad arguments");
     int ndev = 0;
@@ -932,34 +1034,7 @@ static int ctx_create_common(int device_id, int rank, int nranks, const void *ui
             return fail(SLA_ERR_HIP, std::string("sla_ctx_create: ") + hipGetErrorString(he));
         }
     }
-    if (const char *s = getenv("SLA_SPMV_ALGO")) c->spmv_algo = (strcmp(s, "scalar") == 0) ? 1 : 0;
-    if (const char *s = getenv("SLA_XCD_REMAP")) c->xcd_remap = atoi(s);
-    if (const char *s = getenv("SLA_DUAL_SPMV")) c->dual_spmv = atoi(s);
-    if (const char *s = getenv("SLA_XWIN")) c->xwin = atoi(s);
-    if (const char *s = getenv("SLA_DIAG")) c->diag = atoi(s);
-    if (const char *s = getenv("SLA_VDICT")) c->vdict = atoi(s);
-    if (const char *s = getenv("SLA_WDIA")) c->wdia = atoi(s);
-    if (const char *s = getenv("SLA_LPANEL")) c->lpanel = atoi(s);
-    if (const char *s = getenv("SLA_LP_MINSEG")) c->lp_min_seg = std::max(1, atoi(s));
-    if (const char *s = getenv("SLA_LP_TASKS")) c->lp_tasks = atoi(s);
-    if (const char *s = getenv("SLA_LP_CFG")) c->lp_cfg = atoi(s);
-    if (const char *s = getenv("SLA_LP_ROWCOST")) c->lp_rowcost = std::max(0, atoi(s));
-    if (const char *s = getenv("SLA_FORCE_RP64")) c->force_rp64 = atoi(s);
-    if (const char *s = getenv("SLA_BICG_GHOST")) c->bicg_ghost = atoi(s);
-    if (const char *s = getenv("SLA_WD_TILE")) c->wd_tile = atoi(s);
-    if (const char *s = getenv("SLA_WDIA_VV")) c->wdia_vv = atoi(s);
-    if (const char *s = getenv("SLA_VEC_NT")) c->vec_nt = atoi(s);
-    if (const char *s = getenv("SLA_HALO_INPLACE")) c->halo_inplace = atoi(s);
-    if (const char *s = getenv("SLA_PANELS")) c->panels = atoi(s);
-    if (const char *s = getenv("SLA_OVERLAP")) c->overlap = atoi(s);
-    if (const char *s = getenv("SLA_TILES")) c->tiles = atoi(s);
-    if (const char *s = getenv("SLA_TILE_SHIFT")) c->tile_shift = atoi(s);
-    if (const char *s = getenv("SLA_TILE_SLACK")) c->tile_slack = atoi(s);
-    if (const char *s = getenv("SLA_PANEL_COLS")) c->panel_cols = atoll(s);
-    if (const char *s = getenv("SLA_ROW_ALIGN")) c->row_align = atoi(s);
-    if (const char *s = getenv("SLA_RB_NNZ")) c->rb_nnz = atoi(s);
-    if (const char *s = getenv("SLA_DEVICE_COO_MIN")) c->device_coo_min = atoll(s);
-    if (const char *s = getenv("SLA_X_EXCHANGE")) c->x_exchange = strcmp(s, "allgather") == 0 ? 1 : (strcmp(s, "window") == 0 ? 2 : 0);
+    ctx_read_knobs(c);
     {
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess && cus > 0) {

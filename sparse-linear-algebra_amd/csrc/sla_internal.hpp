@@ -145,6 +145,8 @@ struct sla_ctx {
     int64_t device_coo_min = 1 << 20; // triple lists at least this long are sorted on the GPU (SLA_DEVICE_COO_MIN)
     int rb_nnz = 0;                  // 0: automatic row-block size (SLA_RB_NNZ overrides, <= 1024)
     int row_align = 0;               // > 1: row blocks end on multiples of this many rows (SLA_ROW_ALIGN; measured -1.5 % at 16)
+    int step_graph = -1;             // replay solver steps as a captured HIP graph: -1 when the matrix has <= step_graph_max_rows rows, 0 never, 1 always (SLA_STEP_GRAPH)
+    int64_t step_graph_max_rows = 2500000;
     int overlap = 1;                 // sharded (#>): 1 interior rows run while the halo exchange is in flight (second stream), 0 same split launches with
                                      // the exchange serialised on the compute stream (A/B, bit-identical), -1 no split at all (SLA_OVERLAP)
     hipStream_t comm_stream = nullptr;   // created on first use
@@ -301,6 +303,7 @@ struct sla_solver {
     sla::SolverScalars *d_sc = nullptr;
     sla::SolverScalars *h_sc = nullptr;  // pinned
     bool have_res = false;               // d_parts[RES] holds the residual of the current x
+    hipGraphExec_t step_graph = nullptr; // two consecutive steps (even, odd parity) captured for replay (sla_solver_step, launch-bound sizes)
     // sharded BiCGSTAB with ghost rows (sla_solvers.cpp): r, p, Ap and s are kept valid on the ghl / ghr rows this
     // rank's SpMV reads from its neighbours, so a step needs 3 grouped exchanges instead of 5
     bool ghost = false;

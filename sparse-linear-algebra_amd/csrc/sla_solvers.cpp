@@ -630,8 +630,45 @@ int sla_solver_init(int method, sla_csr_t A, sla_vec_t b, sla_vec_t x0, sla_solv
 int sla_solver_step(sla_solver_t S, int k_steps) {
     if (S && !S->kids.empty()) return k_steps >= 0 ? m_solver_step(S, k_steps) : fail(SLA_ERR_INVALID, "sla_solver_step: bad argument");
     if (!S || k_steps < 0) return fail(SLA_ERR_INVALID, "sla_solver_step: bad argument");
-    (void)hipSetDevice(S->ctx->device);
-    for (int k = 0; k < k_steps; ++k) SLA_TRY(enqueue_step(S, false, false));
+    sla_ctx *c = S->ctx;
+    (void)hipSetDevice(c->device);
+    int k = 0;
+    // Launch-bound sizes ("Launches and HIP graphs"): below ~2 M rows the five dependent launches of a step
+    // cost about as much as its kernels.  Two consecutive steps (both parities of the double-buffered rho) are captured ONCE
+    // into a HIP graph and replayed: the same kernels with the same arguments in the same order -- bit-identical iterates --
+    // at the dependent-node latency of a graph instead of five stream dispatches per step.
+    const bool graph_ok = c->step_graph != 0 && !c->collectives && c->prof_kernel == -2 && !S->have_res && S->method != SLA_CGNE_ &&
+                          (c->step_graph > 0 || S->A->rows <= c->step_graph_max_rows) && k_steps >= 4;
+    if (graph_ok) {
+        if (ctl_of(S).step_index & 1) {   // the captured pair starts at even parity
+            SLA_TRY(enqueue_step(S, false, false));
+            ++k;
+        }
+        if (!S->step_graph) {
+            hipGraph_t g = nullptr;
+            SLA_HIP_TRY(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+            int rc = enqueue_step(S, false, false);
+            if (rc == SLA_OK) rc = enqueue_step(S, false, false);
+            const hipError_t e = hipStreamEndCapture(c->stream, &g);
+            ctl_of(S).step_index -= 2;   // (captured, not executed)
+            if (rc != SLA_OK || e != hipSuccess) {
+                if (g) (void)hipGraphDestroy(g);
+                if (rc != SLA_OK) return rc;
+                return fail(SLA_ERR_HIP, std::string("step graph capture: ") + hipGetErrorString(e));
+            }
+            const hipError_t ei = hipGraphInstantiate(&S->step_graph, g, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(g);
+            if (ei != hipSuccess) {
+                S->step_graph = nullptr;
+                return fail(SLA_ERR_HIP, std::string("step graph instantiate: ") + hipGetErrorString(ei));
+            }
+        }
+        for (; k + 2 <= k_steps; k += 2) {
+            SLA_HIP_TRY(hipGraphLaunch(S->step_graph, c->stream));
+            ctl_of(S).step_index += 2;
+        }
+    }
+    for (; k < k_steps; ++k) SLA_TRY(enqueue_step(S, false, false));
     return SLA_OK;
 }
 
@@ -731,6 +768,7 @@ int sla_solver_destroy(sla_solver_t S) {
     if (S->ctx && S->ctx->stream) (void)hipStreamSynchronize(S->ctx->stream);
     sla_vec *vs[] = {S->x, S->r, S->p, S->u, S->r0hat, S->b, S->t1, S->t2, S->t3};
     for (sla_vec *v : vs) sla_vec_destroy(v);
+    if (S->step_graph) (void)hipGraphExecDestroy(S->step_graph);
     if (S->d_parts) (void)hipFree(S->d_parts);
     if (S->d_gath) (void)hipFree(S->d_gath);
     if (S->d_sc) (void)hipFree(S->d_sc);

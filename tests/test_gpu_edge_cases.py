@@ -345,3 +345,35 @@ def test_column_panel_views_keep_their_own_row_pointer_width(sla, monkeypatch):
     assert np.array_equal(sla.matVec(A, sla.fromVector(x, ctx)).toDenseListSV(), orc.spmv(Ao, x))
     xs, info = sla.linSolve0(sla.BICGSTAB_, A, sla.fromVector(b, ctx), sla.fromVector(np.zeros(n), ctx), return_info=True)
     assert info["converged"] and np.linalg.norm(orc.spmv(Ao, xs.toDenseListSV()) - b) <= info["tol"] * (1 + 1e-9)
+
+
+def test_step_graph_replay_is_bit_identical_to_stream_launches(sla, monkeypatch):
+    """sla_solver_step replays pairs of steps as a captured HIP graph at launch-bound sizes: same kernels, same arguments, same
+    order => the iterates must equal the stream-launched ones bit for bit, from even and odd starting parity, for BiCGSTAB and
+    CGS, with leftovers, on a clone (which captures its own graph) and after the graph was built."""
+    from sla_amd import workloads as wl
+    dims, (rp, ci, va) = wl.poisson2d(60, 50)
+    n = dims[0]
+    b = np.add.reduceat(va, rp[:-1])
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("SLA_STEP_GRAPH", mode)
+        ctx = sla.Context(0)
+        A = sla.fromCSR(dims, rp, ci, va, ctx)
+        res = []
+        for init, xf in ((sla.bicgsInit, "_xBicgstab"), (sla.cgsInit, "_x")):
+            s = init(A, sla.fromVector(b, ctx), sla.fromVector(np.zeros(n), ctx))
+            s.step(7)                         # even start: 3 replays + 1 plain step
+            res.append(getattr(s, xf).toDenseListSV())
+            s.step(6)                         # odd start: 1 plain step, 2 replays, 1 plain
+            res.append(getattr(s, xf).toDenseListSV())
+            t = s.clone().step(5)
+            res.append(getattr(t, xf).toDenseListSV())
+            s.step(1)
+            s.step(4)
+            res.append(getattr(s, xf).toDenseListSV())
+        out[mode] = res
+        ctx.close()
+    for a, b_ in zip(out["1"], out["0"]):
+        assert np.array_equal(a, b_)
+    assert np.isfinite(out["1"][0]).all() and np.linalg.norm(out["1"][3] - 1.0) < 1e-3      # it converges to x* = 1
