@@ -44,13 +44,14 @@ constexpr int kLpMinSeg = 16;        // mean entries per (row, panel) segment be
 constexpr int kVdMaxRowNnz = 31;     // longest row the value-indexed kernel takes (256 rows x 31 B of codes fit its LDS stage)
 constexpr int kWaveRowMax = 16384;   // rows of 1025..16384 entries: one wavefront each, 4 per row block; longer: whole workgroup
 #ifndef SLA_TILE_ROWS
-#define SLA_TILE_ROWS 1024
+#define SLA_TILE_ROWS 4096
 #endif
 #ifndef SLA_TILE_OCC
-#define SLA_TILE_OCC 4
+#define SLA_TILE_OCC 1
 #endif
-constexpr int kTileRows = SLA_TILE_ROWS;  // rows per slice of spmv_tile_kernel: one wavefront's row sums in LDS (8 KiB)
-constexpr int kTileBlocksPerCu = SLA_TILE_OCC;  // its resident workgroups per CU (4 x 32 KiB of LDS, <= 128 VGPRs)
+constexpr int kTileRows = SLA_TILE_ROWS;  // rows per slice of spmv_tile_kernel: one wavefront's row sums in LDS (32 KiB)
+constexpr int kTileBlocksPerCu = SLA_TILE_OCC;  // its resident workgroups per CU (1 x 128 KiB of LDS, 4 wavefronts with 12 x 64 gathers in flight each: few, fat
+                                                // wavefronts drift apart less and keep more misses in flight than 16 thin ones -- 2.26 -> 1.98 ms at 10 M rows)
 constexpr int kMaxParts = 2048;      // partial-sum slots per reduction (256 CUs x 8)
 constexpr int kVecGridMax = 1024;    // grid cap of the streaming BLAS-1 kernels
 constexpr int kSpmvGridMax = 2048;   // persistent grid cap of the SpMV kernels
@@ -153,7 +154,7 @@ struct sla_ctx {
     hipEvent_t ev_x_ready = nullptr, ev_x_done = nullptr;
     int tiles = 1;                   // allow the row-slice x column-panel tile SpMV for irregular matrices with x > L2 (SLA_TILES=0: column-panel passes)
     int tile_slack = 3;              // panel pacing: a wavefront starts panel step q once its XCD has finished step q - slack (SLA_TILE_SLACK, 0: no pacing)
-    int tile_shift = 17;             // log2 of its panel width in columns (SLA_TILE_SHIFT): 1 MiB of x per panel (slack 3 / shift 17: 2.26 ms at 10 M rows; 2 / 18: 2.31; 6 / 16: 2.35)
+    int tile_shift = 17;             // log2 of its panel width in columns (SLA_TILE_SHIFT): 1 MiB of x per panel (slack 3 / shift 17: 1.98 ms at 10 M rows; slack 4: 2.18, slack 2: 2.1; shift 16: +6 %, shift 18: +15 %)
     int panels = 1;                  // allow the column-panel SpMV for irregular matrices (SLA_PANELS=0 disables)
     int64_t panel_cols = 384 * 1024; // panel width in columns (SLA_PANEL_COLS): 3 MiB of x per pass
     int diag = 1;                    // allow the dictionary-compressed-index SpMV kernel (SLA_DIAG=0 disables)

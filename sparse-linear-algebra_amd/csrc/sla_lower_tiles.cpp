@@ -23,13 +23,14 @@ int build_tiles(sla_csr *A, int64_t n, int64_t rows, const int64_t *rowptr, cons
     if (!c->tiles || rows == 0 || nnz == 0) return SLA_OK;
     if (A->use_diag || A->use_wdia || A->use_vdict || A->xwin_fraction >= 0.5) return SLA_OK;   // stencil / banded structure
     if (A->use_lpanel && c->lpanel) return SLA_OK;                                               // dense rows: x panels in LDS
-    const int shift = std::max(10, std::min(21, c->tile_shift));
+    int row_bits = 0;
+    while (((int64_t)1 << row_bits) < kTileRows) ++row_bits;
+    const int shift = std::max(10, std::min(32 - row_bits, c->tile_shift));   // (slice row, panel column) packed in 32 bits
     const int64_t W = (int64_t)1 << shift;
     if (n <= 2 * W) return SLA_OK;                       // x (nearly) fits the L2 already
-    if (shift + 10 > 32) return SLA_OK;
     const int64_t P = (n + W - 1) / W;
     if (P > 16384) return SLA_OK;
-    // slices: whole rounds of the persistent grid (kTileBlocksPerCu workgroups of 4 wavefronts per CU)
+    // slices: whole rounds of the persistent grid (kTileBlocksPerCu workgroup(s) of 4 wavefronts per CU)
     const int64_t waves = (int64_t)kTileBlocksPerCu * c->n_cu * (kBlock / 64);
     const int64_t rounds = std::max<int64_t>(1, (rows + (int64_t)kTileRows * waves - 1) / ((int64_t)kTileRows * waves));
     int64_t S0 = rounds * waves;
@@ -138,7 +139,7 @@ int build_tiles(sla_csr *A, int64_t n, int64_t rows, const int64_t *rowptr, cons
     upload((void **)&A->d_tloff, toff.data(), sizeof(uint32_t) * toff.size());
     upload((void **)&A->d_tlidx, tidx.data(), sizeof(uint32_t) * tidx.size());
     upload((void **)&A->d_tlval, tval.data(), sizeof(double) * tval.size());
-    A->tlprog_bytes = sizeof(int) * 8 * 128;   // pacing table: one progress slot per workgroup, 128 per XCD; zeroed before every launch
+    A->tlprog_bytes = sizeof(int) * 8 * 256;   // pacing table: one progress slot per workgroup, 256 per XCD; zeroed before every launch
     if (err == hipSuccess) err = hipMalloc((void **)&A->d_tlprog, A->tlprog_bytes);
     if (err != hipSuccess) return fail(SLA_ERR_ALLOC, std::string("tile form upload: ") + hipGetErrorString(err));
     A->tl_S = (int32_t)S;

@@ -34,9 +34,9 @@
 namespace sla {
 
 #ifndef SLA_TILE_U
-#define SLA_TILE_U 4
+#define SLA_TILE_U 12
 #endif
-constexpr int kTileU = SLA_TILE_U;   // 64-entry groups per chunk: 256 entries in flight per wavefront (+ the next chunk's streams)
+constexpr int kTileU = SLA_TILE_U;   // 64-entry groups per chunk: 768 gathers in flight per wavefront (+ the next chunk's streams)
 
 struct TileChunk {
     uint32_t idx[kTileU];
@@ -98,8 +98,8 @@ spmv_tile_kernel(SpmvArgs<RP> a, const RP *__restrict__ rowptr, const int32_t *_
     // workgroup of its XCD has finished step q - slack.  Progress is published WITHOUT atomics (device-scope atomics execute
     // on the memory side of the fabric: 512 wavefronts bumping one counter cost ~100 us per step, measured): each
     // workgroup keeps its wavefronts' step counts in LDS and plain-stores their minimum into its own slot of a per-XCD
-    // table -- the store stays in the XCD's L2 -- and a waiting wavefront reads the <= 128 slots of its XCD with L1-bypassing
-    // loads (one or two loads per poll, wavefront min).  Workgroup b runs on XCD b % 8 (HW_REG_XCC_ID, tools/xcc_probe.cpp)
+    // table -- the store stays in the XCD's L2 -- and a waiting wavefront reads the <= 256 slots of its XCD with L1-bypassing
+    // loads (up to four loads per poll, wavefront min).  Workgroup b runs on XCD b % 8 (HW_REG_XCC_ID, tools/xcc_probe.cpp)
     // and the grid is fully resident (kTileBlocksPerCu per CU).  Pacing is a throttle, never a correctness condition: a
     // wavefront that waits too long (grid not co-resident) stops pacing for the rest of the launch.
     __shared__ int s_prog[kBlock / 64];
@@ -108,9 +108,9 @@ spmv_tile_kernel(SpmvArgs<RP> a, const RP *__restrict__ rowptr, const int32_t *_
     const int xcd = (int)blockIdx.x & 7;
     const int nwg_xcd = ((int)gridDim.x - xcd + 7) >> 3;
     const int rounds = (S + stride - 1) / stride;
-    int *slots = prog ? (int *)prog + xcd * 128 : nullptr;      // <= 128 workgroups per XCD (kTileBlocksPerCu x 32 CUs)
+    int *slots = prog ? (int *)prog + xcd * 256 : nullptr;      // <= 256 workgroups per XCD (kTileBlocksPerCu x 32 CUs)
     int *myslot = slots ? slots + ((int)blockIdx.x >> 3) : nullptr;
-    bool pace = slack > 0 && slots != nullptr && nwg_xcd <= 128;
+    bool pace = slack > 0 && slots != nullptr && nwg_xcd <= 256;
     int known = 0;                                               // steps every workgroup of the XCD is known to have finished
     auto publish = [&](int done) {                               // this wavefront has finished `done` steps
         if (!slots) return;
@@ -134,8 +134,9 @@ spmv_tile_kernel(SpmvArgs<RP> a, const RP *__restrict__ rowptr, const int32_t *_
         int spins = 0;
         while (pace && known < need) {
             int v = 0x7fffffff;
-            if (lane < nwg_xcd) v = __hip_atomic_load(slots + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (lane + 64 < nwg_xcd) v = min(v, __hip_atomic_load(slots + lane + 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (lane + 64 * q < nwg_xcd) v = min(v, __hip_atomic_load(slots + lane + 64 * q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) v = min(v, __shfl_xor(v, off, 64));
             known = v;
@@ -186,7 +187,7 @@ spmv_tile_kernel(SpmvArgs<RP> a, const RP *__restrict__ rowptr, const int32_t *_
             const double *vp = tval + (base + (RP)k);
 #pragma unroll
             for (int u = 0; u < kTileU; ++u) {
-                const uint32_t i = (uint32_t)min(lane + 64 * u, c.cnt - 1) & (64 * kTileU - 1);
+                const uint32_t i = (uint32_t)min(lane + 64 * u, c.cnt - 1);   // (cnt >= 1: advance() left k < k1)
                 c.idx[u] = __builtin_nontemporal_load(ip + i);
                 c.val[u] = __builtin_nontemporal_load(vp + i);
             }
