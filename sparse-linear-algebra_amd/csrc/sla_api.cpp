@@ -600,9 +600,10 @@ static void low_value_indexed(Low &L) {
             std::vector<uint64_t> wme, wmo;
             std::vector<double> wval;
             std::vector<int32_t> woff;
+            std::vector<uint8_t> wcode;
             bool wok = n < ((int64_t)1 << 28);
             if (wok) {   // slices are independent: each thread builds the records of a contiguous range of slices
-                struct Part { std::vector<uint64_t> me, mo; std::vector<double> v; std::vector<int32_t> o, cnt; };
+                struct Part { std::vector<uint64_t> me, mo; std::vector<double> v; std::vector<int32_t> o, cnt; std::vector<uint8_t> cd; };
                 std::vector<Part> part((size_t)host_threads());
                 const int T = par_rows(rows, 128, [&](int t, int64_t lo, int64_t hi) {
                     Part &P = part[(size_t)t];
@@ -626,6 +627,7 @@ static void low_value_indexed(Low &L) {
                                 P.mo.push_back(lane_mask[1][cd]);
                                 P.v.push_back(dval[(size_t)cd]);
                                 P.o.push_back(doff[(size_t)cd]);
+                                P.cd.push_back((uint8_t)cd);
                             }
                         P.cnt.push_back((int32_t)(P.me.size() - first));
                     }
@@ -642,6 +644,7 @@ static void low_value_indexed(Low &L) {
                     wmo.insert(wmo.end(), P.mo.begin(), P.mo.end());
                     wval.insert(wval.end(), P.v.begin(), P.v.end());
                     woff.insert(woff.end(), P.o.begin(), P.o.end());
+                    wcode.insert(wcode.end(), P.cd.begin(), P.cd.end());
                 }
                 if ((int64_t)wme.size() * 32 > nnz + 2048) wok = false;   // < 1/4 full: the byte-code kernel is the better form
             }
@@ -656,6 +659,53 @@ static void low_value_indexed(Low &L) {
                 A->use_wdia = true;
                 A->nslices = (int32_t)nsl;
                 A->nblk_wd = (int32_t)((nsl + 3) / 4);
+                {   // LDS windows: cluster the offsets (doff[] is ascending); a record then names an element of the staged buffer
+                    WdWin W;
+                    bool lok = true;
+                    int32_t wmax[kWdWinMax] = {};
+                    for (int t = 0; t < A->npairs && lok; ++t) {
+                        const int32_t o = doff[(size_t)t];
+                        if (W.n > 0 && o - wmax[W.n - 1] < kWdWinMerge) { wmax[W.n - 1] = o; continue; }
+                        if (W.n == kWdWinMax) { lok = false; break; }
+                        W.omin[W.n] = o & ~1;        // (floor to even: staged as aligned 16-byte pairs)
+                        wmax[W.n] = o;
+                        ++W.n;
+                    }
+                    for (int k = 0; k < W.n && lok; ++k) {
+                        const int32_t elems = wmax[k] - W.omin[k] + 512 + 2;   // + 1: odd first row of a slab, + 1: second row of the last pair
+                        W.pb[k + 1] = W.pb[k] + (elems + 1) / 2;
+                    }
+                    W.pairs = W.pb[W.n];
+                    if (lok && W.n > 0 && W.pairs <= kWdWinMaxPairs && A->npairs <= 8) {
+                        // uniform records: every slice carries all pairs in table order; a pair it does not use has empty masks
+                        WdUni U;
+                        U.n = A->npairs;
+                        for (int t = 0; t < A->npairs; ++t) {
+                            int k = 0;
+                            while (k + 1 < W.n && doff[(size_t)t] >= W.omin[k + 1]) ++k;
+                            U.lpos[t] = 2 * W.pb[k] + (doff[(size_t)t] - W.omin[k]);
+                            U.val[t] = dval[(size_t)t];
+                        }
+                        std::vector<uint64_t> wum((size_t)nsl * 16, 0);
+                        for (int64_t sl2 = 0; sl2 < nsl; ++sl2)
+                            for (int32_t e = wptr[(size_t)sl2]; e < wptr[(size_t)sl2 + 1]; ++e) {
+                                wum[(size_t)sl2 * 16 + wcode[(size_t)e]] = wme[(size_t)e];
+                                wum[(size_t)sl2 * 16 + 8 + wcode[(size_t)e]] = wmo[(size_t)e];
+                            }
+                        upload((void **)&A->d_wum, wum.data(), sizeof(uint64_t) * wum.size());
+                        int64_t clo = n, chi = -1;                // (columns ascend inside a row)
+                        for (int64_t i = 0; i < rows; ++i)
+                            if (rowptr[i + 1] > rowptr[i]) {
+                                clo = std::min<int64_t>(clo, col[rowptr[i]]);
+                                chi = std::max<int64_t>(chi, col[rowptr[i + 1] - 1]);
+                            }
+                        A->wd_col_lo = (int32_t)clo;
+                        A->wd_col_hi = (int32_t)chi;
+                        A->wd_win = W;
+                        A->wd_uni = U;
+                        A->wd_lds = true;
+                    }
+                }
                 // Visiting order of the 512-row steps.  A 3-D stencil row touches x one PLANE (the far diagonal, D rows)
                 // behind and ahead; swept in row order, a line of x is needed again 2 D rows later, by which time
                 // the vectors streaming through the 4 MiB L2 have evicted it (216^3: D = 46656, 1.35 extra reads
@@ -991,6 +1041,9 @@ static void ctx_read_knobs(sla_ctx *c) {
         {"SLA_FORCE_RP64", &sla_ctx::force_rp64},
         {"SLA_BICG_GHOST", &sla_ctx::bicg_ghost},
         {"SLA_WD_TILE", &sla_ctx::wd_tile},
+        {"SLA_WD_LDS", &sla_ctx::wd_lds},
+        {"SLA_WD_LDS_OCC", &sla_ctx::wd_lds_occ},
+        {"SLA_WD_NT_STORE", &sla_ctx::wd_nt_store},
         {"SLA_WDIA_VV", &sla_ctx::wdia_vv},
         {"SLA_VEC_NT", &sla_ctx::vec_nt},
         {"SLA_HALO_INPLACE", &sla_ctx::halo_inplace},
@@ -1492,6 +1545,7 @@ int sla_csr_destroy(sla_csr_t A) {
     if (A->d_wmo) (void)hipFree(A->d_wmo);
     if (A->d_wval) (void)hipFree(A->d_wval);
     if (A->d_woff) (void)hipFree(A->d_woff);
+    if (A->d_wum) (void)hipFree(A->d_wum);
     if (A->d_vcode) (void)hipFree(A->d_vcode);
     if (A->d_vdoff) (void)hipFree(A->d_vdoff);
     if (A->d_vdval) (void)hipFree(A->d_vdval);
@@ -1543,7 +1597,7 @@ int sla_csr_kernel_info(sla_csr_t A, char *buf, int buflen) {
     if (A && !A->kids.empty()) return sla_csr_kernel_info(A->kids[0], buf, buflen);
     if (!A || !buf || buflen <= 0) return fail(SLA_ERR_INVALID, "null argument");
     snprintf(buf, (size_t)buflen, "algo=%s grid=%d block=%d row_blocks=%d nnz_per_row_block=%d max_row_nnz=%lld rowptr=%s xcd_remap=%d",
-             A->ctx->spmv_algo == 1 ? "scalar" : (A->use_wdia && wd_on(A)) ? (A->wd_vv ? "wdia-vv" : "wdia") : (A->use_vdict && A->ctx->vdict) ? (A->use_xwin && A->ctx->xwin ? "vdict+xwin" : "vdict") : (A->use_lpanel && A->ctx->lpanel) ? "stream+ldspanels" : tiles_on(A) ? "tiles" : (!A->panels.empty() && A->ctx->panels) ? "stream+colpanels" : (A->use_diag && A->ctx->diag ? (A->use_xwin && A->ctx->xwin ? "stream+diagdict+xwin" : "stream+diagdict") : (A->use_xwin && A->ctx->xwin ? "stream+xwin" : "stream")), spmv_grid(A), kBlock, A->nrb, kNnzPerRowBlock,
+             A->ctx->spmv_algo == 1 ? "scalar" : (A->use_wdia && wd_on(A)) ? (A->wd_vv ? "wdia-vv" : wd_lds_on(A) ? "wdia+ldswin" : "wdia") : (A->use_vdict && A->ctx->vdict) ? (A->use_xwin && A->ctx->xwin ? "vdict+xwin" : "vdict") : (A->use_lpanel && A->ctx->lpanel) ? "stream+ldspanels" : tiles_on(A) ? "tiles" : (!A->panels.empty() && A->ctx->panels) ? "stream+colpanels" : (A->use_diag && A->ctx->diag ? (A->use_xwin && A->ctx->xwin ? "stream+diagdict+xwin" : "stream+diagdict") : (A->use_xwin && A->ctx->xwin ? "stream+xwin" : "stream")), spmv_grid(A), kBlock, A->nrb, kNnzPerRowBlock,
              (long long)A->max_row_nnz, A->rp64 ? "i64" : "i32", A->ctx->xcd_remap);
     if (A->use_lpanel && A->ctx->lpanel && A->ctx->spmv_algo == 0) {   // LDS-panel geometry
         const size_t used = strlen(buf);
@@ -1556,6 +1610,7 @@ int sla_csr_kernel_info(sla_csr_t A, char *buf, int buflen) {
         const int64_t rps = A->rp64 ? 8 : 4;
         int64_t mb;
         if (c->spmv_algo == 1) mb = 12 * A->nnz + rps * (A->rows + 1);
+        else if (A->use_wdia && wd_on(A) && wd_lds_on(A)) mb = 128 * (int64_t)A->nslices;   // 16 lane masks per slice
         else if (A->use_wdia && wd_on(A)) mb = A->nwent * (A->wd_vv ? 20 + 128 * 8 : 28) + 4 * ((int64_t)A->nslices + 1);
         else if (A->use_vdict && c->vdict) mb = A->nnz + 4 * (A->rows + 1);
         else if (A->use_lpanel && c->lpanel) mb = 12 * A->nnz + (int64_t)(A->lp_P + 1) * A->rows * rps + 16 * (int64_t)A->lp_P * A->rows;

@@ -152,4 +152,56 @@ __device__ __forceinline__ RbWalk rb_walk(int nrb, int xcd_remap) {
     return w;
 }
 
+typedef double wd_f64x2u __attribute__((ext_vector_type(2), aligned(8)));  // a row pair of x at any 8-byte boundary
+typedef double wd_f64x2 __attribute__((ext_vector_type(2)));
+
+// the fused epilogue of a row pair (row, row + 1; vb: the second row exists) of the wave-sliced kernels
+template <int EPI>
+__device__ __forceinline__ void wd_epilogue(const SpmvArgs<int32_t> &a, int row, bool vb, double ya, double yb, wd_f64x2 wv, wd_f64x2 zv,
+                                            double coef, double &acc1, double &acc2, bool nt_store = false) {
+    wd_f64x2 out = {ya, yb};  // what the epilogue stores (y or z), if it stores
+    bool store_y = false, store_z = false;
+    if constexpr (EPI == EPI_NONE) {
+        store_y = true;
+    } else if constexpr (EPI == EPI_DOT) {
+        store_y = true;
+        acc1 += ya * wv.x;
+        if (vb) acc1 += yb * wv.y;
+    } else if constexpr (EPI == EPI_DOT2) {
+        store_y = true;
+        acc1 += ya * wv.x;
+        acc2 += ya * ya;
+        if (vb) { acc1 += yb * wv.y; acc2 += yb * yb; }
+    } else if constexpr (EPI == EPI_RES) {
+        const double ta = ya - wv.x, tb = yb - wv.y;  // (aa #> x) ^-^ b
+        acc1 += ta * ta;
+        if (vb) acc1 += tb * tb;
+    } else if constexpr (EPI == EPI_AXPY_DOT) {
+        out.x = zv.x - coef * ya;
+        out.y = zv.y - coef * yb;
+        store_z = true;
+        acc1 += out.x * (a.w ? wv.x : out.x);
+        if (vb) acc1 += out.y * (a.w ? wv.y : out.y);
+    } else if constexpr (EPI == EPI_XPBY_NRM) {
+        out.x = ya + coef * zv.x;
+        out.y = yb + coef * zv.y;
+        store_z = true;
+        acc1 += out.x * out.x;
+        if (vb) acc1 += out.y * out.y;
+    } else if constexpr (EPI == EPI_SUB) {
+        out.x = wv.x - ya;  // b ^-^ (aa #> x)
+        out.y = wv.y - yb;
+        store_y = true;
+    }
+    double *dst = store_y ? a.y : (store_z ? a.z : nullptr);
+    if (dst) {
+        if (vb) {
+            if (nt_store) __builtin_nontemporal_store(out, (wd_f64x2 *)(dst + row));
+            else *(wd_f64x2 *)(dst + row) = out;
+        } else {
+            dst[row] = out.x;
+        }
+    }
+}
+
 }  // namespace sla

@@ -33,6 +33,22 @@ constexpr int kWdBlocksPerCuVV = SLA_WD_OCC_VV;             // same for the vari
 constexpr int kWdMaxSliceRecords = 40;          // wave-sliced forms: more diagonals per 128-row slice than this and the older kernels are used
                                                 // (27-point stencil, 128^3: wdia 25.5 us, vdict 42 us, diagdict 167 us)
 constexpr int kWdGatherStages = SLA_WD_STAGES;  // 2: the gathers of the next slice are issued before the current one is folded
+// LDS-window variant (spmv_wdia_lds_kernel): the diagonal offsets of the matrix are clustered into <= kWdWinMax windows; a
+// workgroup stages x[step base + omin_k, ... + span_k + 512] of every window in LDS once per 512-row step
+constexpr int kWdWinMax = 8;
+constexpr int kWdWinMerge = 512;     // offsets closer than this share a window (a separate window costs 512 more elements)
+constexpr int kWdWinMaxPairs = 1536; // 16-byte pairs per LDS buffer (24 KiB; two buffers)
+constexpr int kWdWinLoads = kWdWinMaxPairs / 256;   // staging loads per lane and step, at most
+struct WdWin {
+    int32_t n = 0, pairs = 0;        // windows; 16-byte pairs of one LDS buffer
+    int32_t omin[kWdWinMax] = {};    // first offset of window k (even)
+    int32_t pb[kWdWinMax + 1] = {};  // its first pair in the buffer; pb[n] = pairs
+};
+struct WdUni {                       // uniform records: the matrix's <= 8 (offset, value) pairs in table order
+    int32_t n = 0;
+    int32_t lpos[8] = {};            // element of the staged buffer that x[step base + offset] lands on
+    double val[8] = {};
+};
 constexpr int kVdRows = 256;         // rows per block of spmv_vdict_kernel (one lane per row)
 constexpr int kLpW = 16384;          // columns of x one workgroup of spmv_lpanel_kernel keeps in LDS (128 KiB)
 constexpr int kLpBlock = 1024;       // its workgroup: 16 wavefronts, one per CU (LDS-bound occupancy)
@@ -162,6 +178,9 @@ struct sla_ctx {
     int64_t mall_bytes = 256ll << 20; // capacity of the memory-side cache (MI355X: 256 MiB)
     int wdia_vv = 1;                 // allow the variable-coefficient wave-sliced form (SLA_WDIA_VV=0 disables)
     int wd_grid_max_vv = sla::kWdBlocksPerCuVV * 256;
+    int wd_lds = 1;                  // stencils with <= 8 (offset, value) pairs: uniform records + x windows staged in LDS (SLA_WD_LDS; 2: at any size)
+    int wd_nt_store = 0;             // its y / z stores past the caches (SLA_WD_NT_STORE)
+    int wd_lds_occ = 0;              // its workgroups per CU (SLA_WD_LDS_OCC; 0: as many as the LDS holds, at most 4)
     int wd_tile = -1;                // plane tiling of the wave-sliced walk: -1 automatic, 0 off, > 0 steps per tile (SLA_WD_TILE)
     int wdia = 1;                    // allow the wave-sliced SpMV kernel (SLA_WDIA=0 disables)
     int vdict = 1;                   // allow the value-indexed SpMV kernel (SLA_VDICT=0 disables)
@@ -246,6 +265,11 @@ struct sla_csr {
     unsigned long long *d_wmo = nullptr;    // ... lanes whose ODD row (2 lane + 1) holds it ...
     double *d_wval = nullptr;               // ... its value ...
     int32_t *d_woff = nullptr;              // ... and its diagonal offset (col - row); all padded by 8 records
+    unsigned long long *d_wum = nullptr;    // LDS-window variant (<= 8 pairs): per slice 8 even-row masks then 8 odd-row masks, in table order
+    bool wd_lds = false;
+    sla::WdWin wd_win;
+    sla::WdUni wd_uni;
+    int32_t wd_col_lo = 0, wd_col_hi = -1;  // smallest / largest column these rows reference: what the staged windows may read
     // LDS-panel form (rows with many entries per 16384-column panel): per (panel, row) entry ranges into col / val
     void *d_lpp = nullptr;           // (P + 1) x rows, RP-typed, panel-major: pp[p][i] = first entry of row i with col >= p * lp_W
     int32_t lp_col_lo = 0, lp_col_hi = -1;   // smallest / largest column any of these rows references
@@ -346,6 +370,9 @@ int multi_unsupported(const char *what);
 
 namespace sla {
 // is the wave-sliced SpMV form of A enabled by the context's knobs?
+// (its workgroups need a few steps each to amortise the staging pipeline's fill: below that the gather kernel is faster -- 1 M-row
+// Poisson: 22 500 vs 21 300 it/s; SLA_WD_LDS=2 forces it)
+inline bool wd_lds_on(const sla_csr *A) { return A->wd_lds && !A->wd_vv && (A->ctx->wd_lds == 2 || (A->ctx->wd_lds == 1 && A->nblk_wd >= 16 * 4 * A->ctx->n_cu)); }
 inline bool wd_on(const sla_csr *A) { return A->wd_vv ? (A->ctx->wdia && A->ctx->wdia_vv) : A->ctx->wdia != 0; }
 
 // Guarded device allocation for everything an SpMV may gather from (vectors, the exchange landing buffer, the
@@ -473,6 +500,8 @@ bool overlap_split(const sla_csr *A);   // does (#>) on A run as interior + boun
 int overlap_grid(const sla_csr *A, int part);
 bool tiles_on(const sla_csr *A);                               // is the tile form of A in use?
 int launch_spmv_tiles(const sla_csr *A, const SpmvLaunch &l);   // sla_spmv_tiles.hip
+int launch_wdia_lds(const sla_csr *A, int epi, const SpmvArgs<int32_t> &a, const int32_t *sched, int32_t nblk, int grid, int stream_nt);   // sla_spmv_wdia_lds.hip
+int wd_lds_grid(const sla_csr *A);
 int tiles_grid(const sla_csr *A);
 // sla_lower_tiles.cpp: builds the tile form of A when it pays (irregular structure, x larger than the L2); no-op otherwise
 int build_tiles(sla_csr *A, int64_t n, int64_t rows, const int64_t *rowptr, const int64_t *col, const double *val);

@@ -1284,8 +1284,6 @@ __global__ void __launch_bounds__(kBlock, 8) spmv_vdict_kernel(SpmvArgs<int32_t>
 typedef unsigned long long wd_u64x8 __attribute__((ext_vector_type(8), aligned(8)));
 typedef double wd_f64x8 __attribute__((ext_vector_type(8), aligned(8)));
 typedef int wd_i32x8 __attribute__((ext_vector_type(8), aligned(4)));
-typedef double wd_f64x2u __attribute__((ext_vector_type(2), aligned(8)));  // a row pair of x at any 8-byte boundary
-typedef double wd_f64x2 __attribute__((ext_vector_type(2)));
 
 #if defined(SLA_WD_TRACE)
 __device__ unsigned long long wd_trace[64 * 16 * 4];
@@ -1480,48 +1478,7 @@ __global__ void __launch_bounds__(kBlock, VV ? kWdBlocksPerCuVV : kWdBlocksPerCu
             gather8(rr, st.e0 + c0, row, xt, vt);
             fold8(rr.me, rr.mo, rr.v, st.cnt - c0, xt, vt, ya, yb);
         }
-        if (va) {
-            const wd_f64x2 wv = st.wv, zv = st.zv;
-            wd_f64x2 out = {ya, yb};  // what the epilogue stores (y or z), if it stores
-            bool store_y = false, store_z = false;
-            if constexpr (EPI == EPI_NONE) {
-                store_y = true;
-            } else if constexpr (EPI == EPI_DOT) {
-                store_y = true;
-                acc1 += ya * wv.x;
-                if (vb) acc1 += yb * wv.y;
-            } else if constexpr (EPI == EPI_DOT2) {
-                store_y = true;
-                acc1 += ya * wv.x;
-                acc2 += ya * ya;
-                if (vb) { acc1 += yb * wv.y; acc2 += yb * yb; }
-            } else if constexpr (EPI == EPI_RES) {
-                const double ta = ya - wv.x, tb = yb - wv.y;  // (aa #> x) ^-^ b
-                acc1 += ta * ta;
-                if (vb) acc1 += tb * tb;
-            } else if constexpr (EPI == EPI_AXPY_DOT) {
-                out.x = zv.x - coef * ya;
-                out.y = zv.y - coef * yb;
-                store_z = true;
-                acc1 += out.x * (a.w ? wv.x : out.x);
-                if (vb) acc1 += out.y * (a.w ? wv.y : out.y);
-            } else if constexpr (EPI == EPI_XPBY_NRM) {
-                out.x = ya + coef * zv.x;
-                out.y = yb + coef * zv.y;
-                store_z = true;
-                acc1 += out.x * out.x;
-                if (vb) acc1 += out.y * out.y;
-            } else if constexpr (EPI == EPI_SUB) {
-                out.x = wv.x - ya;  // b ^-^ (aa #> x)
-                out.y = wv.y - yb;
-                store_y = true;
-            }
-            double *dst = store_y ? a.y : (store_z ? a.z : nullptr);
-            if (dst) {
-                if (vb) *(wd_f64x2 *)(dst + row) = out;
-                else dst[row] = out.x;
-            }
-        }
+        if (va) wd_epilogue<EPI>(a, row, vb, ya, yb, st.wv, st.zv, coef, acc1, acc2);
     };
     int b = wk.first;
 #if defined(SLA_WD_TRACE)
@@ -1760,7 +1717,7 @@ bool overlap_split(const sla_csr *A) {
     return A->ov_nint > 0 && A->ov_nbnd > 0 && A->ctx->overlap >= 0 && A->ctx->collectives && A->use_wdia && wd_on(A) && A->ctx->spmv_algo == 0 && !A->rp64;
 }
 int overlap_grid(const sla_csr *A, int part) {
-    const int cap = A->wd_vv ? A->ctx->wd_grid_max_vv : A->ctx->wd_grid_max;
+    const int cap = A->wd_vv ? A->ctx->wd_grid_max_vv : wd_lds_on(A) ? wd_lds_grid(A) : A->ctx->wd_grid_max;
     return part == 1 ? std::max(1, std::min<int>(A->ov_nint, cap)) : std::max(1, std::min<int>(A->ov_nbnd, 256));
 }
 
@@ -1771,7 +1728,7 @@ int spmv_grid(const sla_csr *A) {
     if (!A->panels.empty() && c->panels && c->spmv_algo == 0) return spmv_grid(A->panels.back());
     int64_t g;
     if (c->spmv_algo == 1 || (A->use_lpanel && c->lpanel)) g = (A->rows + kBlock - 1) / kBlock;   // (lpanel: its finish kernel)
-    else if (A->use_wdia && wd_on(A)) g = std::min<int64_t>(A->nblk_wd, A->wd_vv ? c->wd_grid_max_vv : c->wd_grid_max);
+    else if (A->use_wdia && wd_on(A)) g = std::min<int64_t>(A->nblk_wd, A->wd_vv ? c->wd_grid_max_vv : wd_lds_on(A) ? wd_lds_grid(A) : c->wd_grid_max);
     else if (A->use_vdict && c->vdict) g = A->nblk_vd;
     else g = A->nrb;
     if (g < 1) g = 1;
@@ -1885,6 +1842,8 @@ static int launch_spmv_t(const sla_csr *A, const SpmvLaunch &l) {
             int grid = ::sla::spmv_grid(A);
             if (l.part == 1) { sched = A->d_ov_int; nblk_wd = A->ov_nint; grid = overlap_grid(A, 1); }
             else if (l.part == 2) { sched = A->d_ov_bnd; nblk_wd = A->ov_nbnd; grid = overlap_grid(A, 2); }
+            if (wd_lds_on(A))
+                return launch_wdia_lds(A, l.epi, a, sched, nblk_wd, grid, (vec_stream_nt(c, A->rows) ? 1 : 0) | (c->wd_nt_store ? 2 : 0));
             if (A->wd_vv)
                 hipLaunchKernelGGL((spmv_wdia_kernel<EPI, true>), dim3(grid), dim3(kBlock), 0, c->stream, a, A->d_wptr, A->d_wme, A->d_wmo,
                                    A->d_wval, A->d_woff, A->d_wvblk, a.x, nblk_wd, A->nslices, (int32_t)A->row_begin, (int32_t)A->n,

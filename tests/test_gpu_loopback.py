@@ -27,6 +27,19 @@ def test_sharded_path_on_random_banded_matrices(seed, nranks):
     assert out.returncode == 0 and f"LOOPBACK_OK {nranks} fuzz{seed}" in out.stdout, out.stdout[-3000:]
 
 
+@pytest.mark.parametrize("kind,nranks", [("laplace", 3), ("fuzz1", 2), ("fuzz2", 3), ("fuzz4", 5), ("tinyband", 16), ("laplace_big", 2)])
+def test_sharded_path_with_the_lds_window_kernel(kind, nranks):
+    """SLA_WD_LDS=2 takes stencil slabs of <= 8 pairs through spmv_wdia_lds_kernel at any size: slabs with row_begin > 0 (odd
+    first rows: the staged windows start one element early), ghost-extended x, interior / boundary step lists of the overlapped
+    exchange.  The worker compares every (#>) with the oracle bit for bit and the solvers with its iterates."""
+    env = dict(os.environ, SLA_WD_LDS="2")
+    out = subprocess.run([sys.executable, os.path.join(HERE, "_loopback_worker.py"), str(nranks), kind], env=env,
+                         stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert out.returncode == 0 and f"LOOPBACK_OK {nranks} {kind}" in out.stdout, out.stdout[-3000:]
+    if kind.startswith("laplace"):
+        assert "ldswin" in out.stdout, out.stdout[-3000:]
+
+
 @pytest.mark.parametrize("kind,nranks", [("laplace", 3), ("laplace", 8), ("tiny", 4), ("tinyband", 16), ("banded", 2), ("denseband", 4), ("fuzz2", 3), ("fuzz5", 2), ("random", 2)])
 def test_ghost_row_bicgstab_and_cgs_equal_the_plain_sharded_flow(kind, nranks):
     """Sharded BiCGSTAB keeps r, p, Ap and s valid on the ghost rows and needs 3 grouped exchanges per step instead of 5

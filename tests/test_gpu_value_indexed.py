@@ -1,5 +1,6 @@
 """The value-indexed SpMV forms (spmv_wdia_kernel: wave-sliced (offset, value) records in SGPRs, two rows per
-lane; spmv_vdict_kernel: one byte per entry) against the oracle's left fold, bit for bit, and against each other
+lane; spmv_wdia_lds_kernel: uniform records + x windows staged in LDS for stencils of <= 8 pairs, forced at these sizes
+with SLA_WD_LDS=2; spmv_vdict_kernel: one byte per entry) against the oracle's left fold, bit for bit, and against each other
 and the general kernels -- including the shapes that stress them: odd row counts, ragged patterns where only
 one row of a lane pair holds an entry, more than 8 records per slice, several values on one diagonal, rows at
 the matrix edge, -0.0 / Inf operands, and every fused epilogue through the solver steps."""
@@ -48,6 +49,10 @@ def _cases():
         "ragged 11 diagonals n=4099": _stencil(4099, [-300, -17, -4, -2, -1, 0, 1, 3, 16, 250, 1025],
                                                 lambda r, o: np.full(len(r), 9.0 if o == 0 else 0.5 + (o % 3)),
                                                 keep=lambda r, t: ~drop[r, t] | (t == 5)),
+        # <= 8 pairs (the LDS-window kernel's domain), three windows, 30 % of the entries missing, odd row count
+        "ragged 7 diagonals n=4099": _stencil(4099, [-1300, -40, -1, 0, 1, 40, 1300],
+                                               lambda r, o: np.full(len(r), 9.0 if o == 0 else 0.5 + (o % 3)),
+                                               keep=lambda r, t: ~drop[r, t] | (t == 3)),
         # three different values along each diagonal (row mod 3): several records share an offset
         "3 values per diagonal n=2500": _stencil(2500, [-50, -1, 0, 1, 50],
                                                   lambda r, o: (8.0 if o == 0 else -1.0) * (1.0 + 0.25 * (r % 3))),
@@ -72,14 +77,21 @@ def test_value_indexed_forms_fold_like_the_reference(sla, monkeypatch, name):
     want = orc.spmv(Ao, x)
     want_t = orc.spmv(orc.transpose(Ao), x)
     got = {}
-    for form, env in (("wdia", {}), ("vdict", {"SLA_WDIA": "0"}), ("diag", {"SLA_WDIA": "0", "SLA_VDICT": "0"}),
+    lds_cases = ("laplace3d 14x11x13", "poisson2d 37x29 (odd n)", "tridiag n=1", "tridiag n=129", "ragged 7 diagonals n=4099",
+                 "explicit +-0.0 n=777")
+    for form, env in (("wdia", {"SLA_WD_LDS": "0"}), ("wdia+ldswin", {"SLA_WD_LDS": "2"}), ("vdict", {"SLA_WDIA": "0"}),
+                      ("diag", {"SLA_WDIA": "0", "SLA_VDICT": "0"}),
                       ("stream", {"SLA_WDIA": "0", "SLA_VDICT": "0", "SLA_DIAG": "0", "SLA_XWIN": "0"})):
-        for k in ("SLA_WDIA", "SLA_VDICT", "SLA_DIAG", "SLA_XWIN"):
+        for k in ("SLA_WDIA", "SLA_VDICT", "SLA_DIAG", "SLA_XWIN", "SLA_WD_LDS"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         ctx = sla.Context(0)
         A = sla.fromCSR(dims, *csr, ctx)
+        if form == "wdia+ldswin":
+            # the LDS-window kernel takes stencils of <= 8 (offset, value) pairs; the others stay on the gather kernel
+            assert ("ldswin" in A.kernel_info().split()[0]) == (name in lds_cases), (name, A.kernel_info())
+            form = "wdia"
         if form in ("wdia", "vdict"):
             assert form in A.kernel_info().split()[0], (form, A.kernel_info())
         y = sla.matVec(A, sla.fromVector(x, ctx)).toDenseListSV()
@@ -95,7 +107,8 @@ def test_value_indexed_forms_fold_like_the_reference(sla, monkeypatch, name):
         ctx.close()
 
 
-@pytest.mark.parametrize("name", ["laplace3d 14x11x13", "ragged 11 diagonals n=4099", "3 values per diagonal n=2500"])
+@pytest.mark.parametrize("name", ["laplace3d 14x11x13", "ragged 11 diagonals n=4099", "ragged 7 diagonals n=4099",
+                                  "3 values per diagonal n=2500"])
 def test_value_indexed_epilogues_through_the_solvers(sla, monkeypatch, name):
     """K1/K3 (dot, dot2), the true-residual sweep, CGS's and CGNE's fused updates, r0 = b - A x0: same iterates as
     the general kernels (the per-row results are bit-identical; only partial-sum grouping differs)."""
@@ -104,8 +117,9 @@ def test_value_indexed_epilogues_through_the_solvers(sla, monkeypatch, name):
     Ao = _oracle_csr(dims, csr)
     b = orc.spmv(Ao, np.linspace(-1.0, 2.0, n))
     out = {}
-    for form, env in (("wdia", {}), ("vdict", {"SLA_WDIA": "0"}), ("stream", {"SLA_WDIA": "0", "SLA_VDICT": "0", "SLA_DIAG": "0"})):
-        for k in ("SLA_WDIA", "SLA_VDICT", "SLA_DIAG"):
+    for form, env in (("wdia", {"SLA_WD_LDS": "0"}), ("ldswin", {"SLA_WD_LDS": "2"}), ("vdict", {"SLA_WDIA": "0"}),
+                      ("stream", {"SLA_WDIA": "0", "SLA_VDICT": "0", "SLA_DIAG": "0"})):
+        for k in ("SLA_WDIA", "SLA_VDICT", "SLA_DIAG", "SLA_WD_LDS"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -119,7 +133,7 @@ def test_value_indexed_epilogues_through_the_solvers(sla, monkeypatch, name):
     for meth, ometh in ((sla.BICGSTAB_, orc.BICGSTAB_), (sla.CGS_, orc.CGS_), (sla.CGNE_, orc.CGNE_)):
         rc, xo, it_o, res_o, r0_o = orc.linsolve0(ometh, Ao, b, np.full(n, 0.25))
         ref = out[("stream", int(meth))]
-        for form in ("wdia", "vdict"):
+        for form in ("wdia", "ldswin", "vdict"):
             x, it, rn = out[(form, int(meth))]
             assert abs(it - ref[1]) <= 1 and abs(it - it_o) <= 2, (name, form, meth, it, ref[1], it_o)
             if it_o < 200:
@@ -129,8 +143,10 @@ def test_value_indexed_epilogues_through_the_solvers(sla, monkeypatch, name):
                 assert np.abs(x - ref[0]).max() <= 1e-5 * scale, (name, form, meth)
 
 
-def test_value_indexed_propagates_inf_and_nan_only_where_the_reference_does(sla):
+@pytest.mark.parametrize("wd_lds", ["0", "2"])
+def test_value_indexed_propagates_inf_and_nan_only_where_the_reference_does(sla, monkeypatch, wd_lds):
     """Lanes masked off in a slice must not touch x at all: an Inf next to a missing neighbour stays out of that row."""
+    monkeypatch.setenv("SLA_WD_LDS", wd_lds)
     n = 640
     dims, csr = _stencil(n, [-1, 0, 1], lambda r, o: np.full(len(r), 2.0 if o == 0 else -1.0),
                          keep=lambda r, t: ~((r % 64 == 10) & (t == 2)))       # rows 10, 74, ... have no (i, i+1) entry
@@ -138,20 +154,24 @@ def test_value_indexed_propagates_inf_and_nan_only_where_the_reference_does(sla)
     x = np.ones(n)
     x[11] = np.inf           # row 10 does not reference x[11]; rows 11 and 12 do
     x[300] = np.nan
-    A = sla.fromCSR(dims, *csr)
-    assert "wdia" in A.kernel_info()
-    y = sla.matVec(A, sla.fromVector(x)).toDenseListSV()
+    A = sla.fromCSR(dims, *csr, sla.Context(0))
+    assert "wdia" in A.kernel_info() and ("ldswin" in A.kernel_info()) == (wd_lds == "2")
+    y = sla.matVec(A, sla.fromVector(x, A.ctx)).toDenseListSV()
     want = orc.spmv(Ao, x)
     assert np.isfinite(y[10]) and np.isinf(y[11]) and np.isinf(y[12])
     assert np.array_equal(np.isnan(y), np.isnan(want)) and np.array_equal(y[~np.isnan(y)], want[~np.isnan(want)])
 
 
-def test_value_indexed_randomised_patterns(sla):
-    """60 seeded random banded matrices (square and rectangular, 1..900 rows, up to 14 diagonals anywhere in the matrix,
+@pytest.mark.parametrize("wd_lds", ["0", "2"])
+def test_value_indexed_randomised_patterns(sla, monkeypatch, wd_lds):
+    """(wd_lds = 2: the patterns of <= 8 pairs go through the LDS-window kernel)
+    60 seeded random banded matrices (square and rectangular, 1..900 rows, up to 14 diagonals anywhere in the matrix,
     1-4 distinct values per diagonal, random holes, some with an empty leading / trailing block of rows): whatever form
     the lowering picks, (#>) and (<#) are the oracle's left fold bit for bit and the forms agree with each other."""
+    monkeypatch.setenv("SLA_WD_LDS", wd_lds)
+    ctx = sla.Context(0)
     rng = np.random.default_rng(2024)
-    picked = {"wdia": 0, "vdict": 0, "other": 0}
+    picked = {"wdia": 0, "vdict": 0, "other": 0, "ldswin": 0}
     for case in range(60):
         m = int(rng.integers(1, 900))
         n = m if case % 3 else int(rng.integers(1, 900))
@@ -172,11 +192,12 @@ def test_value_indexed_randomised_patterns(sla):
         x = rng.standard_normal(n)
         xt = rng.standard_normal(m)
         want, want_t = orc.spmv(Ao, x), orc.spmv(orc.transpose(Ao), xt)
-        A = sla.fromCSR((m, n), Ao.rowptr, Ao.colidx, Ao.val)
+        A = sla.fromCSR((m, n), Ao.rowptr, Ao.colidx, Ao.val, ctx)
         algo = A.kernel_info().split()[0]
         picked["wdia" if "wdia" in algo else "vdict" if "vdict" in algo else "other"] += 1
-        y = sla.matVec(A, sla.fromVector(x)).toDenseListSV()
-        yt = sla.vecMat(sla.fromVector(xt), A).toDenseListSV()
+        picked["ldswin"] += "ldswin" in algo
+        y = sla.matVec(A, sla.fromVector(x, ctx)).toDenseListSV()
+        yt = sla.vecMat(sla.fromVector(xt, ctx), A).toDenseListSV()
         exact = "wdia" in algo or "vdict" in algo or len(v) <= 8 * m
         if exact:
             assert np.array_equal(y.view(np.uint64), want.view(np.uint64)), (case, algo, m, n, offs)
@@ -184,6 +205,7 @@ def test_value_indexed_randomised_patterns(sla):
             assert np.allclose(y, want, rtol=1e-13, atol=1e-13), (case, algo)
         assert np.allclose(yt, want_t, rtol=1e-13, atol=1e-13), (case, algo, "transpose")
     assert picked["wdia"] >= 20, picked      # the generator is meant to exercise the value-indexed forms
+    assert (picked["ldswin"] >= 5) == (wd_lds == "2") and (picked["ldswin"] == 0) == (wd_lds == "0"), picked
 
 
 def _vv_cases():

@@ -1,0 +1,219 @@
+// stencil_probe.cpp -- would an LDS-staged x window pay for the wave-sliced stencil SpMV?  (MI355X, round 2)
+//
+// spmv_wdia_kernel gathers every (offset, value) record of a 128-row slice straight from global memory: 7 wave-wide
+// 16-byte loads per slice for the 7-pt Laplacian, all of them touching nearly the same lines.  Cache-resident it takes
+// 38 us at 10 M rows where the HBM time of x + y is 26 us.  This probe times the bare access pattern both ways on a
+// 216^3 grid (constant coefficients, no boundary handling: x is padded by one plane on both sides):
+//   direct   two rows per lane, 7 global 16-byte gathers, fold, 16-byte store                      (the product's pattern)
+//   lds      a workgroup stages the three x windows of its 512-row step in LDS (in-plane window of 512 + 2 * 216
+//            elements, the planes behind / ahead: 4 global 16-byte loads per lane instead of 7, next step's loads in
+//            flight during the fold), the 7 operands come from LDS
+//   hipcc --offload-arch=gfx950 -O3 -o tools/stencil_probe tools/stencil_probe.cpp
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include <algorithm>
+#include <cmath>
+
+#define CK(e) do { hipError_t _e = (e); if (_e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(_e), __LINE__); exit(1); } } while (0)
+
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ d2 ld2(const double *p) {   // 16 bytes at 8-byte alignment
+    d2 v;
+    __builtin_memcpy(&v, p, 16);
+    return v;
+}
+
+__device__ __forceinline__ d2 fold7(d2 a, d2 b, d2 c, d2 d, d2 e, d2 f, d2 g) {
+#pragma clang fp contract(off)
+    d2 s = -1.0 * a;
+    s = s + -1.0 * b;
+    s = s + -1.0 * c;
+    s = s + 6.0 * d;
+    s = s + -1.0 * e;
+    s = s + -1.0 * f;
+    s = s + -1.0 * g;
+    return s;
+}
+
+// step i of this workgroup: plain = grid-stride over the row order; sched = XCD x (= blockIdx.x % 8) owns T / 8 in-plane tiles
+// and walks them plane by plane (the product's sched[] order): the plane behind / ahead of a step is in the XCD's own L2
+__device__ const int *g_sched;   // the product's visiting order (sla_api.cpp: steps keyed by position inside the plane / tile)
+__device__ const int *g_sweep;   // plane sweep: XCD x owns the steps whose position inside the plane falls into its eighth; 8 lists of
+__device__ int g_sweep_per;      // g_sweep_per entries (padded with -1), each plane-major
+template <int SCHED>
+__device__ __forceinline__ int step_of(int i, int nsteps, int T) {
+    if constexpr (SCHED == 3) {
+        const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+        const int b = local + i * (gridDim.x >> 3);
+        return b < g_sweep_per ? g_sweep[xcd * g_sweep_per + b] : -1;
+    } else if constexpr (SCHED == 2) {   // XCD-contiguous walk of the order array, like rb_walk
+        const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3, per = (nsteps + 7) >> 3;
+        const int b = xcd * per + local + i * (gridDim.x >> 3);
+        return b < min((xcd + 1) * per, nsteps) ? g_sched[b] : -1;
+    } else if constexpr (SCHED == 0) {
+        const int s = blockIdx.x + i * gridDim.x;
+        return s < nsteps ? s : -1;
+    } else {
+        const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3, nloc = gridDim.x >> 3, tx = T >> 3;
+        const int q = local + nloc * i;
+        const int s = (q / tx) * T + xcd * tx + q % tx;
+        return s < nsteps ? s : -1;
+    }
+}
+
+template <int OCC, int SCHED>
+__global__ void __launch_bounds__(256, OCC) direct_kernel(const double *__restrict__ x, double *__restrict__ y, int nsteps, int D1, int D2) {
+    const int tid = threadIdx.x;
+    const int T = D2 / 512;
+    for (int i = 0;; ++i) {
+        const int s = step_of<SCHED>(i, nsteps, T);
+        if (s < 0) break;
+        const double *b = x + (size_t)s * 512 + 2 * tid;
+        const d2 a = ld2(b - D2), bb = ld2(b - D1), c = ld2(b - 1), d = ld2(b), e = ld2(b + 1), f = ld2(b + D1), g = ld2(b + D2);
+        const d2 r = fold7(a, bb, c, d, e, f, g);
+        __builtin_nontemporal_store(r, (d2 *)(y + (size_t)s * 512 + 2 * tid));
+    }
+}
+
+// D1 <= 256, even; x + 512 s - D1 and x + 512 s +- D2 16-byte aligned
+template <int OCC, int SCHED>
+__global__ void __launch_bounds__(256, OCC) lds_kernel(const double *__restrict__ x, double *__restrict__ y, int nsteps, int D1, int D2) {
+    __shared__ d2 buf[2][1024];   // [0, 512): in-plane window (512 + 2 D1 elements), [512, 768): plane behind, [768, 1024): plane ahead
+    const int tid = threadIdx.x;
+    const int h1 = D1 >> 1;       // the in-plane window is 256 + D1 pairs: lanes < D1 load a second pair
+    d2 r0, r1, r2, r3;
+    auto load = [&](int s) {
+        const double *b = x + (size_t)s * 512 + 2 * tid;
+        r0 = *(const d2 *)(b - D1);
+        r1 = tid < D1 ? *(const d2 *)(b - D1 + 512) : d2{0.0, 0.0};
+        r2 = *(const d2 *)(b - D2);
+        r3 = *(const d2 *)(b + D2);
+    };
+    auto stage = [&](int p) {
+        buf[p][tid] = r0;
+        if (tid < D1) buf[p][256 + tid] = r1;
+        buf[p][512 + tid] = r2;
+        buf[p][768 + tid] = r3;
+    };
+    const int T = D2 / 512;
+    int s = step_of<SCHED>(0, nsteps, T), p = 0;
+    if (s < 0) return;
+    load(s);
+    stage(0);
+    __syncthreads();
+    for (int i = 1; s >= 0; ++i, p ^= 1) {
+        const int sn = step_of<SCHED>(i, nsteps, T);
+        if (sn >= 0) load(sn);
+        const double *w = (const double *)buf[p] + D1 + 2 * tid;
+        const d2 a = buf[p][512 + tid], g = buf[p][768 + tid];
+        const d2 bb = *(const d2 *)(w - D1), f = *(const d2 *)(w + D1);
+        const d2 d = *(const d2 *)w;
+        const double lo = w[-1], hi = w[2];
+        const d2 c = d2{lo, d.x}, e = d2{d.y, hi};
+        const d2 r = fold7(a, bb, c, d, e, f, g);
+        __builtin_nontemporal_store(r, (d2 *)(y + (size_t)s * 512 + 2 * tid));
+        if (sn >= 0) stage(p ^ 1);
+        __syncthreads();
+        s = sn;
+        (void)h1;
+    }
+}
+
+int main(int argc, char **argv) {
+    const int G = argc > 1 ? atoi(argv[1]) : 216;
+    const int D1 = G, D2 = G * G;
+    const size_t n = (size_t)G * G * G / 512 * 512;
+    const int nsteps = (int)(n / 512);
+    const int pairs = 4, reps = 40;
+    const size_t pad = (size_t)D2 + 512;
+    std::vector<double> hx(n + 2 * pad);
+    uint64_t z = 88172645463325252ull;
+    for (auto &v : hx) { z ^= z << 13; z ^= z >> 7; z ^= z << 17; v = (double)(z >> 11) * (1.0 / 9007199254740992.0) - 0.5; }
+    std::vector<double *> dx(pairs), dy(pairs);
+    for (int i = 0; i < pairs; ++i) {
+        CK(hipMalloc(&dx[i], (n + 2 * pad) * 8));
+        CK(hipMalloc(&dy[i], n * 8));
+        CK(hipMemcpy(dx[i], hx.data(), (n + 2 * pad) * 8, hipMemcpyHostToDevice));
+    }
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    std::vector<double> ref(n), got(n);
+    auto run = [&](const char *name, auto launch, bool check) {
+        for (int i = 0; i < 4; ++i) launch(dx[i % pairs] + pad, dy[i % pairs]);
+        CK(hipDeviceSynchronize());
+        CK(hipEventRecord(e0));
+        for (int i = 0; i < reps; ++i) launch(dx[i % pairs] + pad, dy[i % pairs]);
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        CK(hipEventRecord(e0));
+        for (int i = 0; i < reps; ++i) launch(dx[0] + pad, dy[0]);
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        float ms1;
+        CK(hipEventElapsedTime(&ms1, e0, e1));
+        CK(hipMemcpy(got.data(), dy[0], n * 8, hipMemcpyDeviceToHost));
+        const char *ok = "";
+        if (!check) ref = got;
+        else ok = memcmp(ref.data(), got.data(), n * 8) == 0 ? "  bit-identical to direct" : "  MISMATCH";
+        const double us = ms * 1e3 / reps;
+        printf("%-28s %7.1f us  %6.2f TB/s of x + y (rotating %d pairs; one pair: %.1f us)%s\n", name, us, 16.0 * n / us * 1e-6, pairs, ms1 * 1e3 / reps, ok);
+    };
+    printf("# %d^3 grid: %zu rows, %d steps of 512 rows\n", G, n, nsteps);
+#define DIRECT(OCC, SC) run(SC == 3 ? "direct sweep occ " #OCC : SC == 2 ? "direct order[] occ " #OCC : SC ? "direct sched occ " #OCC : "direct occ " #OCC, [&](const double *x, double *y) { hipLaunchKernelGGL((direct_kernel<OCC, SC>), dim3(256 * OCC), dim3(256), 0, 0, x, y, nsteps, D1, D2); }, !first); first = false
+#define LDSK(OCC, SC) run(SC == 3 ? "lds sweep occ " #OCC : SC == 2 ? "lds order[] occ " #OCC : SC ? "lds sched occ " #OCC : "lds occ " #OCC, [&](const double *x, double *y) { hipLaunchKernelGGL((lds_kernel<OCC, SC>), dim3(256 * OCC), dim3(256), 0, 0, x, y, nsteps, D1, D2); }, true)
+    {   // the product's order: stable sort of the steps by (position inside the plane) / tile
+        const double bpp = (double)D2 / 512.0;
+        const int tile = (int)std::max(8.0, bpp / 6.0 + 0.5);
+        std::vector<int> order(nsteps), key(nsteps);
+        for (int b = 0; b < nsteps; ++b) { order[b] = b; key[b] = (int)(fmod((double)b, bpp) / tile); }
+        std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return key[x] < key[y]; });
+        int *d;
+        CK(hipMalloc(&d, sizeof(int) * nsteps));
+        CK(hipMemcpy(d, order.data(), sizeof(int) * nsteps, hipMemcpyHostToDevice));
+        CK(hipMemcpyToSymbol(HIP_SYMBOL(g_sched), &d, sizeof(d)));
+        printf("# order[]: %.3f steps per plane, tiles of %d steps\n", bpp, tile);
+    }
+    {   // plane sweep, in-plane eighths per XCD
+        const double bpp = (double)D2 / 512.0;
+        std::vector<std::vector<int>> lists(8);
+        for (int b = 0; b < nsteps; ++b) lists[std::min(7, (int)(fmod((double)b, bpp) * 8.0 / bpp))].push_back(b);
+        size_t per = 0;
+        for (auto &l : lists) per = std::max(per, l.size());
+        std::vector<int> flat(8 * per, -1);
+        for (int x = 0; x < 8; ++x) std::copy(lists[x].begin(), lists[x].end(), flat.begin() + x * per);
+        int *d;
+        const int iper = (int)per;
+        CK(hipMalloc(&d, sizeof(int) * flat.size()));
+        CK(hipMemcpy(d, flat.data(), sizeof(int) * flat.size(), hipMemcpyHostToDevice));
+        CK(hipMemcpyToSymbol(HIP_SYMBOL(g_sweep), &d, sizeof(d)));
+        CK(hipMemcpyToSymbol(HIP_SYMBOL(g_sweep_per), &iper, sizeof(iper)));
+    }
+    bool first = true;
+    DIRECT(6, 0);
+    LDSK(3, 0);
+    DIRECT(6, 2);
+    LDSK(3, 2);
+    LDSK(4, 2);
+    DIRECT(6, 3);
+    DIRECT(4, 3);
+    LDSK(3, 3);
+    LDSK(4, 3);
+    LDSK(5, 3);
+    if (D2 % (512 * 8) == 0) {   // whole tiles per plane and XCD
+        DIRECT(6, 1);
+        DIRECT(4, 1);
+        DIRECT(8, 1);
+        LDSK(2, 1);
+        LDSK(3, 1);
+        LDSK(4, 1);
+    }
+    return 0;
+}

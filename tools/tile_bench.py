@@ -1,6 +1,6 @@
 #!/usr/bin/env python
-"""One process, one matrix, many knob settings: (#>) and K1 timings of config 3a per configuration.
-usage: python tools/tile_bench.py [n] "SLA_TILE_SLACK=2 SLA_TILE_SHIFT=17" "SLA_TILES=0" ...   (env knobs are read per Context)"""
+"""One process, one matrix, many knob settings: (#>) timings per configuration (config 3a unless a 3-D grid is named).
+usage: python tools/tile_bench.py [n | laplace3d:G] "SLA_TILE_SLACK=2 SLA_TILE_SHIFT=17" "SLA_TILES=0" ...   (env knobs are read per Context)"""
 import os
 import sys
 import time
@@ -13,10 +13,16 @@ import sla_amd as sla
 from sla_amd import _lib, workloads as wl
 
 args = sys.argv[1:]
-n = int(args.pop(0)) if args and args[0].isdigit() else 10000000
 t0 = time.time()
-dims, (rp, ci, va) = wl.random_spd(n, 16, 42)
-print(f"# random_spd n={n} nnz={rp[-1]} generated in {time.time() - t0:.1f} s", flush=True)
+if args and args[0].startswith("laplace3d:"):
+    g = int(args.pop(0).split(":")[1])
+    dims, (rp, ci, va) = wl.laplace3d(g, g, g)
+    n = dims[0]
+    print(f"# laplace3d {g}^3 n={n} nnz={rp[-1]} generated in {time.time() - t0:.1f} s", flush=True)
+else:
+    n = int(args.pop(0)) if args and args[0].isdigit() else 10000000
+    dims, (rp, ci, va) = wl.random_spd(n, 16, 42)
+    print(f"# random_spd n={n} nnz={rp[-1]} generated in {time.time() - t0:.1f} s", flush=True)
 alg = 12 * int(rp[-1]) + 20 * n
 for cfg in args or ["DEFAULT=1"]:
     saved = {}
@@ -45,7 +51,7 @@ for cfg in args or ["DEFAULT=1"]:
         _lib.check(lib.sla_spmv(A.h, xs[0].h, ys[0].h))
     _, one_ms, one_min = ctx.prof_stop()
     info = A.kernel_info()
-    print(f"{cfg:60s} spmv {rot_ms:.3f} ms (min {rot_min:.3f}; one pair {one_ms:.3f})  {alg / rot_ms / 1e6:7.1f} GB/s = {alg / rot_ms / 8e9:.3f} of peak | lower {tl:.1f} s | {info.split()[0]} {info[info.find('slices'):]}", flush=True)
+    print(f"{cfg:60s} spmv {rot_ms:.3f} ms (min {rot_min:.3f}; one pair {one_ms:.3f})  {alg / rot_ms / 1e6:7.1f} GB/s = {alg / rot_ms / 8e9:.3f} of peak | lower {tl:.1f} s | {info.split()[0]} {info[info.find('slices'):] if 'slices' in info else ''}", flush=True)
     del xs, ys, A, ctx
     for k, v in saved.items():
         if v is None:
