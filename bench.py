@@ -146,10 +146,11 @@ def kernel_table(ctx, A, nnz_local, n_local, method):
                 ("K3", _lib.KERNEL_SPMV_DOT2, "As = A s ; As . s, As . As", mb + 16 * n, 12 * z + 20 * n),
                 ("K4", _lib.KERNEL_BICG_K4, "omega ; x += alpha p + omega s ; r = s - omega As ; r . r0hat", 56 * n, 56 * n),
                 ("K5", _lib.KERNEL_BICG_K5, "beta ; p = r + beta (p - omega Ap)", 32 * n, 32 * n)]
-    else:   # cgsStep (Sparse.hs:928-939): SURVEY 8(d) B_cgs_step
+    else:   # cgsStep (Sparse.hs:928-939); the vectors each launch really streams (sla_solvers.cpp: enqueue_cgs -- the x update
+        # rides in C2, which reads u, A p, x and writes q, u + q, x; C3 reads u + q, r, rhat and writes r)
         defs = [("C1", _lib.KERNEL_SPMV_DOT, "A p ; A p . rhat", mb + 24 * n, 12 * z + 28 * n),
-                ("C2", _lib.KERNEL_CGS_C2, "alpha ; q = u - alpha A p ; u + q", 32 * n, 32 * n),
-                ("C3", _lib.KERNEL_SPMV_DOT2, "A (u + q) ; x, r updates ; r . rhat", mb + 56 * n, 12 * z + 60 * n),
+                ("C2", _lib.KERNEL_CGS_C2, "alpha ; q = u - alpha A p ; u + q ; x += alpha (u + q)", 48 * n, 48 * n),
+                ("C3", _lib.KERNEL_SPMV_DOT2, "r -= alpha A (u + q) ; r . rhat", mb + 32 * n, 12 * z + 36 * n),
                 ("C4", _lib.KERNEL_CGS_C4, "beta ; u, p updates", 40 * n, 40 * n)]
     out = {}
     for name, kid, what, bts, csr in defs:

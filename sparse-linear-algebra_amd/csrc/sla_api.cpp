@@ -686,6 +686,7 @@ static void low_value_indexed(Low &L) {
                             U.lpos[t] = 2 * W.pb[k] + (doff[(size_t)t] - W.omin[k]);
                             U.val[t] = dval[(size_t)t];
                         }
+
                         std::vector<uint64_t> wum((size_t)nsl * 16, 0);
                         for (int64_t sl2 = 0; sl2 < nsl; ++sl2)
                             for (int32_t e = wptr[(size_t)sl2]; e < wptr[(size_t)sl2 + 1]; ++e) {
@@ -701,6 +702,11 @@ static void low_value_indexed(Low &L) {
                             }
                         A->wd_col_lo = (int32_t)clo;
                         A->wd_col_hi = (int32_t)chi;
+                        // x[own row] from the staged buffer (an epilogue operand that is the gathered vector): offset 0 inside a
+                        // window, and every own row inside the column range the windows are filled for
+                        if (clo <= row_begin && row_begin + rows - 1 <= chi)
+                            for (int k = 0; k < W.n; ++k)
+                                if (W.omin[k] <= 0 && 0 <= wmax[k]) U.lpos0 = 2 * W.pb[k] - W.omin[k];
                         A->wd_win = W;
                         A->wd_uni = U;
                         A->wd_lds = true;

@@ -47,6 +47,7 @@ struct WdWin {
 struct WdUni {                       // uniform records: the matrix's <= 8 (offset, value) pairs in table order
     int32_t n = 0;
     int32_t lpos[8] = {};            // element of the staged buffer that x[step base + offset] lands on
+    int32_t lpos0 = -1;              // ... that x[step base] itself lands on (-1: no window covers offset 0)
     double val[8] = {};
 };
 constexpr int kVdRows = 256;         // rows per block of spmv_vdict_kernel (one lane per row)
@@ -170,7 +171,7 @@ struct sla_ctx {
     hipEvent_t ev_x_ready = nullptr, ev_x_done = nullptr;
     int tiles = 1;                   // allow the row-slice x column-panel tile SpMV for irregular matrices with x > L2 (SLA_TILES=0: column-panel passes)
     int tile_slack = 3;              // panel pacing: a wavefront starts panel step q once its XCD has finished step q - slack (SLA_TILE_SLACK, 0: no pacing)
-    int tile_shift = 17;             // log2 of its panel width in columns (SLA_TILE_SHIFT): 1 MiB of x per panel (slack 3 / shift 17: 1.98 ms at 10 M rows; slack 4: 2.18, slack 2: 2.1; shift 16: +6 %, shift 18: +15 %)
+    int tile_shift = 0;              // log2 of its panel width in columns (SLA_TILE_SHIFT; 0: 17 from 6 M columns on, 16 below -- at 10 M rows slack 3 / shift 17: 1.98 ms, slack 4: 2.18, slack 2: 2.1, shift 16: 2.03-2.28, shift 18: +15 %)
     int panels = 1;                  // allow the column-panel SpMV for irregular matrices (SLA_PANELS=0 disables)
     int64_t panel_cols = 384 * 1024; // panel width in columns (SLA_PANEL_COLS): 3 MiB of x per pass
     int diag = 1;                    // allow the dictionary-compressed-index SpMV kernel (SLA_DIAG=0 disables)

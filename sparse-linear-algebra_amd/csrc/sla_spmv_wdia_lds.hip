@@ -37,6 +37,8 @@ __global__ void __launch_bounds__(kBlock, NW <= 4 ? 4 : 3) spmv_wdia_lds_kernel(
     double coef;
     if (!spmv_prologue<EPI, int32_t>(a, s_red, coef)) return;
     const bool w_nt = (stream_nt & 1) && a.w != xg + grow0;
+    // an operand that IS the gathered vector (K3: As . s) is taken from the staged window instead of a sixth global load
+    const bool w_lds = uni.lpos0 >= 0 && a.w == xg + grow0;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
     double acc1 = 0.0, acc2 = 0.0;
@@ -90,7 +92,7 @@ __global__ void __launch_bounds__(kBlock, NW <= 4 ? 4 : 3) spmv_wdia_lds_kernel(
         zv = wd_f64x2{0.0, 0.0};
         const int prow = max(0, min(row, a.rows - 2));            // (one row: its pair's second element is guard slack)
         if constexpr (kUsesW) {
-            if (EPI != EPI_AXPY_DOT || a.w)
+            if ((EPI != EPI_AXPY_DOT || a.w) && !w_lds)
                 wv = w_nt ? __builtin_nontemporal_load((const wd_f64x2u *)(a.w + prow)) : *(const wd_f64x2u *)(a.w + prow);
         }
         if constexpr (kUsesZ)
@@ -155,6 +157,9 @@ __global__ void __launch_bounds__(kBlock, NW <= 4 ? 4 : 3) spmv_wdia_lds_kernel(
             }
             if (va) {
                 fix_operands(row, wv, zv);
+                if constexpr (kUsesW) {
+                    if (w_lds) wv = *(const wd_f64x2u *)(lb + ((uint32_t)(par + wave * 128 + 2 * lane + uni.lpos0) << 3));
+                }
                 wd_epilogue<EPI>(a, row, vb, ya, yb, wv, zv, coef, acc1, acc2, (stream_nt & 2) != 0);
             }
         }

@@ -42,4 +42,6 @@ pmc $S/${tag}_bench_pmc_counters.txt python bench.py --steps 20 --warmup 3 --no-
 pmc $S/${tag}_bench_pmc_counters_random_spd_10m.txt python bench.py --workload random_spd_10m --steps 8 --warmup 2 --no-cpu-baseline
 pmc $S/${tag}_bench_pmc_counters_poisson2d_1m.txt python bench.py --workload poisson2d_1m --steps 20 --warmup 3 --no-cpu-baseline
 pmc $S/${tag}_bench_pmc_counters_dense_rows_200k.txt python bench.py --workload dense_rows_200k --steps 10 --warmup 2 --no-cpu-baseline
+# the bare 7-pt access pattern: gathers vs LDS-staged windows, visiting orders (tools/stencil_probe.cpp)
+[ -x tools/stencil_probe ] && { timeout 120 tools/stencil_probe 216; timeout 120 tools/stencil_probe 256; } > $S/${tag}_stencil_probe.txt 2>&1
 ls -la $S | head -40

@@ -42,19 +42,18 @@ __device__ __forceinline__ d2 fold7(d2 a, d2 b, d2 c, d2 d, d2 e, d2 f, d2 g) {
 
 // step i of this workgroup: plain = grid-stride over the row order; sched = XCD x (= blockIdx.x % 8) owns T / 8 in-plane tiles
 // and walks them plane by plane (the product's sched[] order): the plane behind / ahead of a step is in the XCD's own L2
-__device__ const int *g_sched;   // the product's visiting order (sla_api.cpp: steps keyed by position inside the plane / tile)
-__device__ const int *g_sweep;   // plane sweep: XCD x owns the steps whose position inside the plane falls into its eighth; 8 lists of
-__device__ int g_sweep_per;      // g_sweep_per entries (padded with -1), each plane-major
+// ord: SCHED 2 = the product's visiting order (sla_api.cpp: steps keyed by position inside the plane / tile); SCHED 3 = plane
+// sweep: XCD x owns the steps whose position inside the plane falls into its eighth, 8 lists of `per` entries (padded with -1)
 template <int SCHED>
-__device__ __forceinline__ int step_of(int i, int nsteps, int T) {
+__device__ __forceinline__ int step_of(int i, int nsteps, int T, const int *__restrict__ ord, int per) {
     if constexpr (SCHED == 3) {
         const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
         const int b = local + i * (gridDim.x >> 3);
-        return b < g_sweep_per ? g_sweep[xcd * g_sweep_per + b] : -1;
+        return b < per ? ord[xcd * per + b] : -1;
     } else if constexpr (SCHED == 2) {   // XCD-contiguous walk of the order array, like rb_walk
-        const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3, per = (nsteps + 7) >> 3;
-        const int b = xcd * per + local + i * (gridDim.x >> 3);
-        return b < min((xcd + 1) * per, nsteps) ? g_sched[b] : -1;
+        const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3, per8 = (nsteps + 7) >> 3;
+        const int b = xcd * per8 + local + i * (gridDim.x >> 3);
+        return b < min((xcd + 1) * per8, nsteps) ? ord[b] : -1;
     } else if constexpr (SCHED == 0) {
         const int s = blockIdx.x + i * gridDim.x;
         return s < nsteps ? s : -1;
@@ -67,11 +66,11 @@ __device__ __forceinline__ int step_of(int i, int nsteps, int T) {
 }
 
 template <int OCC, int SCHED>
-__global__ void __launch_bounds__(256, OCC) direct_kernel(const double *__restrict__ x, double *__restrict__ y, int nsteps, int D1, int D2) {
+__global__ void __launch_bounds__(256, OCC) direct_kernel(const double *__restrict__ x, double *__restrict__ y, int nsteps, int D1, int D2, const int *__restrict__ ord, int per) {
     const int tid = threadIdx.x;
     const int T = D2 / 512;
     for (int i = 0;; ++i) {
-        const int s = step_of<SCHED>(i, nsteps, T);
+        const int s = step_of<SCHED>(i, nsteps, T, ord, per);
         if (s < 0) break;
         const double *b = x + (size_t)s * 512 + 2 * tid;
         const d2 a = ld2(b - D2), bb = ld2(b - D1), c = ld2(b - 1), d = ld2(b), e = ld2(b + 1), f = ld2(b + D1), g = ld2(b + D2);
@@ -82,7 +81,7 @@ __global__ void __launch_bounds__(256, OCC) direct_kernel(const double *__restri
 
 // D1 <= 256, even; x + 512 s - D1 and x + 512 s +- D2 16-byte aligned
 template <int OCC, int SCHED>
-__global__ void __launch_bounds__(256, OCC) lds_kernel(const double *__restrict__ x, double *__restrict__ y, int nsteps, int D1, int D2) {
+__global__ void __launch_bounds__(256, OCC) lds_kernel(const double *__restrict__ x, double *__restrict__ y, int nsteps, int D1, int D2, const int *__restrict__ ord, int per) {
     __shared__ d2 buf[2][1024];   // [0, 512): in-plane window (512 + 2 D1 elements), [512, 768): plane behind, [768, 1024): plane ahead
     const int tid = threadIdx.x;
     const int h1 = D1 >> 1;       // the in-plane window is 256 + D1 pairs: lanes < D1 load a second pair
@@ -101,13 +100,13 @@ __global__ void __launch_bounds__(256, OCC) lds_kernel(const double *__restrict_
         buf[p][768 + tid] = r3;
     };
     const int T = D2 / 512;
-    int s = step_of<SCHED>(0, nsteps, T), p = 0;
+    int s = step_of<SCHED>(0, nsteps, T, ord, per), p = 0;
     if (s < 0) return;
     load(s);
     stage(0);
     __syncthreads();
     for (int i = 1; s >= 0; ++i, p ^= 1) {
-        const int sn = step_of<SCHED>(i, nsteps, T);
+        const int sn = step_of<SCHED>(i, nsteps, T, ord, per);
         if (sn >= 0) load(sn);
         const double *w = (const double *)buf[p] + D1 + 2 * tid;
         const d2 a = buf[p][512 + tid], g = buf[p][768 + tid];
@@ -121,6 +120,67 @@ __global__ void __launch_bounds__(256, OCC) lds_kernel(const double *__restrict_
         __syncthreads();
         s = sn;
         (void)h1;
+    }
+}
+
+
+// the same with the windows of step i + 2 in flight while step i is folded (two register sets): a workgroup's step no longer
+// waits for a full memory round trip
+template <int OCC, int SCHED>
+__global__ void __launch_bounds__(256, OCC) lds2_kernel(const double *__restrict__ x, double *__restrict__ y, int nsteps, int D1, int D2, const int *__restrict__ ord, int per) {
+    __shared__ d2 buf[2][1024];
+    const int tid = threadIdx.x;
+    const int T = D2 / 512;
+    d2 ra[4], rb[4];
+    auto load = [&](int s, d2 *r) {
+        const double *b = x + (size_t)s * 512 + 2 * tid;
+        r[0] = *(const d2 *)(b - D1);
+        r[1] = *(const d2 *)(b - D1 + (tid < D1 ? 512 : 0));
+        r[2] = *(const d2 *)(b - D2);
+        r[3] = *(const d2 *)(b + D2);
+    };
+    auto stage = [&](int p, const d2 *r) {
+        buf[p][tid] = r[0];
+        if (tid < D1) buf[p][256 + tid] = r[1];
+        buf[p][512 + tid] = r[2];
+        buf[p][768 + tid] = r[3];
+    };
+    auto fold = [&](int p, int s) {
+        const double *w = (const double *)buf[p] + D1 + 2 * tid;
+        const d2 a = buf[p][512 + tid], g = buf[p][768 + tid];
+        const d2 bb = *(const d2 *)(w - D1), f = *(const d2 *)(w + D1);
+        const d2 d = *(const d2 *)w;
+        const double lo = w[-1], hi = w[2];
+        const d2 c = d2{lo, d.x}, e = d2{d.y, hi};
+        const d2 r = fold7(a, bb, c, d, e, f, g);
+        __builtin_nontemporal_store(r, (d2 *)(y + (size_t)s * 512 + 2 * tid));
+    };
+    int s0 = step_of<SCHED>(0, nsteps, T, ord, per);
+    if (s0 < 0) return;
+    int s1 = step_of<SCHED>(1, nsteps, T, ord, per);
+    load(s0, ra);
+    if (s1 >= 0) load(s1, rb);
+    if (s1 >= 0) __builtin_amdgcn_s_waitcnt(0x0f74); else __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(4) / vmcnt(0): the first set is here
+    stage(0, ra);
+    __syncthreads();
+    // steps i, i + 1 per trip: ra holds the windows of step i + 2 while i is folded, rb those of i + 3 while i + 1 is folded
+    for (int i = 0;; i += 2) {
+        const int s2 = step_of<SCHED>(i + 2, nsteps, T, ord, per);
+        if (s2 >= 0) load(s2, ra);
+        fold(0, s0);
+        if (s1 < 0) break;
+        if (s2 >= 0) __builtin_amdgcn_s_waitcnt(0x0f74); else __builtin_amdgcn_s_waitcnt(0x0f70);
+        stage(1, rb);
+        __syncthreads();
+        const int s3 = step_of<SCHED>(i + 3, nsteps, T, ord, per);
+        if (s3 >= 0) load(s3, rb);
+        fold(1, s1);
+        if (s2 < 0) break;
+        if (s3 >= 0) __builtin_amdgcn_s_waitcnt(0x0f74); else __builtin_amdgcn_s_waitcnt(0x0f70);
+        stage(0, ra);
+        __syncthreads();
+        s0 = s2;
+        s1 = s3;
     }
 }
 
@@ -167,8 +227,9 @@ int main(int argc, char **argv) {
         printf("%-28s %7.1f us  %6.2f TB/s of x + y (rotating %d pairs; one pair: %.1f us)%s\n", name, us, 16.0 * n / us * 1e-6, pairs, ms1 * 1e3 / reps, ok);
     };
     printf("# %d^3 grid: %zu rows, %d steps of 512 rows\n", G, n, nsteps);
-#define DIRECT(OCC, SC) run(SC == 3 ? "direct sweep occ " #OCC : SC == 2 ? "direct order[] occ " #OCC : SC ? "direct sched occ " #OCC : "direct occ " #OCC, [&](const double *x, double *y) { hipLaunchKernelGGL((direct_kernel<OCC, SC>), dim3(256 * OCC), dim3(256), 0, 0, x, y, nsteps, D1, D2); }, !first); first = false
-#define LDSK(OCC, SC) run(SC == 3 ? "lds sweep occ " #OCC : SC == 2 ? "lds order[] occ " #OCC : SC ? "lds sched occ " #OCC : "lds occ " #OCC, [&](const double *x, double *y) { hipLaunchKernelGGL((lds_kernel<OCC, SC>), dim3(256 * OCC), dim3(256), 0, 0, x, y, nsteps, D1, D2); }, true)
+#define DIRECT(OCC, SC) run(SC == 3 ? "direct sweep occ " #OCC : SC == 2 ? "direct order[] occ " #OCC : SC ? "direct sched occ " #OCC : "direct occ " #OCC, [&](const double *x, double *y) { hipLaunchKernelGGL((direct_kernel<OCC, SC>), dim3(256 * OCC), dim3(256), 0, 0, x, y, nsteps, D1, D2, SC == 3 ? d_sweep : d_order, sweep_per); }, !first); first = false
+#define LDSK(OCC, SC) run(SC == 3 ? "lds sweep occ " #OCC : SC == 2 ? "lds order[] occ " #OCC : SC ? "lds sched occ " #OCC : "lds occ " #OCC, [&](const double *x, double *y) { hipLaunchKernelGGL((lds_kernel<OCC, SC>), dim3(256 * OCC), dim3(256), 0, 0, x, y, nsteps, D1, D2, SC == 3 ? d_sweep : d_order, sweep_per); }, true)
+    int *d_order = nullptr, *d_sweep = nullptr, sweep_per = 0;
     {   // the product's order: stable sort of the steps by (position inside the plane) / tile
         const double bpp = (double)D2 / 512.0;
         const int tile = (int)std::max(8.0, bpp / 6.0 + 0.5);
@@ -178,7 +239,7 @@ int main(int argc, char **argv) {
         int *d;
         CK(hipMalloc(&d, sizeof(int) * nsteps));
         CK(hipMemcpy(d, order.data(), sizeof(int) * nsteps, hipMemcpyHostToDevice));
-        CK(hipMemcpyToSymbol(HIP_SYMBOL(g_sched), &d, sizeof(d)));
+        d_order = d;
         printf("# order[]: %.3f steps per plane, tiles of %d steps\n", bpp, tile);
     }
     {   // plane sweep, in-plane eighths per XCD
@@ -193,15 +254,19 @@ int main(int argc, char **argv) {
         const int iper = (int)per;
         CK(hipMalloc(&d, sizeof(int) * flat.size()));
         CK(hipMemcpy(d, flat.data(), sizeof(int) * flat.size(), hipMemcpyHostToDevice));
-        CK(hipMemcpyToSymbol(HIP_SYMBOL(g_sweep), &d, sizeof(d)));
-        CK(hipMemcpyToSymbol(HIP_SYMBOL(g_sweep_per), &iper, sizeof(iper)));
+        d_sweep = d;
+        sweep_per = iper;
     }
+#define LDS2(OCC, SC) run(SC == 3 ? "lds dist-2 sweep occ " #OCC : SC == 2 ? "lds dist-2 order[] occ " #OCC : "lds dist-2 occ " #OCC, [&](const double *x, double *y) { hipLaunchKernelGGL((lds2_kernel<OCC, SC>), dim3(256 * OCC), dim3(256), 0, 0, x, y, nsteps, D1, D2, SC == 3 ? d_sweep : d_order, sweep_per); }, true)
     bool first = true;
     DIRECT(6, 0);
     LDSK(3, 0);
     DIRECT(6, 2);
     LDSK(3, 2);
     LDSK(4, 2);
+    LDS2(3, 2);
+    LDS2(4, 2);
+    LDS2(4, 3);
     DIRECT(6, 3);
     DIRECT(4, 3);
     LDSK(3, 3);
