@@ -134,8 +134,8 @@ def test_default_panel_width_picks_tiles_only_beyond_the_l2(sla):
     ctx = sla.Context(0)
     dims, (rp, ci, va) = wl.random_spd(250000, 4, 1)          # x = 2 MB: fits the L2, no panels of any kind
     assert "tiles" not in sla.fromCSR(dims, rp, ci, va, ctx).kernel_info()
-    dims, (rp, ci, va) = wl.random_spd(700000, 4, 1)          # 5.6 MB of x: six 1 MiB panels
+    dims, (rp, ci, va) = wl.random_spd(700000, 4, 1)          # 5.6 MB of x: eleven 512 KiB panels (2^16 columns below 6 M columns)
     A = sla.fromCSR(dims, rp, ci, va, ctx)
-    assert "algo=tiles" in A.kernel_info() and "panels=6" in A.kernel_info(), A.kernel_info()
+    assert "algo=tiles" in A.kernel_info() and "panels=11 panel_cols=65536" in A.kernel_info(), A.kernel_info()
     x = np.random.default_rng(2).standard_normal(dims[0])
     assert np.array_equal(sla.matVec(A, sla.fromVector(x, ctx)).toDenseListSV(), orc.spmv(orc.Csr(*dims, rp, ci, va), x))
