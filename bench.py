@@ -141,11 +141,18 @@ def kernel_table(ctx, A, nnz_local, n_local, method):
     mb = int(info.split("matrix_bytes=")[1].split()[0]) if "matrix_bytes=" in info else 12 * nnz_local + 4 * n_local
     n, z = n_local, nnz_local
     if method == "bicgstab":
+        # single-rank flow (SLA_BICG_FUSE45, default): K3 also reads r0hat (rho_{j+1} = s . r0hat - omega As . r0hat by linearity),
+        # K4 and K5 are ONE sweep over p, s, As, x, Ap -> x, r, p; the reference's split (sharded contexts, SLA_BICG_FUSE45=0)
+        # shows up as K4 + K5 instead of K45
+        fused = ctx.prof_query(_lib.KERNEL_BICG_K45)[0] > 0
         defs = [("K1", _lib.KERNEL_SPMV_DOT, "Ap = A p ; Ap . r0hat", mb + 24 * n, 12 * z + 28 * n),
                 ("K2", _lib.KERNEL_BICG_K2, "alpha ; s = r - alpha Ap", 24 * n, 24 * n),
-                ("K3", _lib.KERNEL_SPMV_DOT2, "As = A s ; As . s, As . As", mb + 16 * n, 12 * z + 20 * n),
+                ("K3", _lib.KERNEL_SPMV_DOT2, "As = A s ; As . s, As . As" + (", As . r0hat, s . r0hat" if fused else ""),
+                 mb + (24 if fused else 16) * n, 12 * z + (28 if fused else 20) * n),
                 ("K4", _lib.KERNEL_BICG_K4, "omega ; x += alpha p + omega s ; r = s - omega As ; r . r0hat", 56 * n, 56 * n),
-                ("K5", _lib.KERNEL_BICG_K5, "beta ; p = r + beta (p - omega Ap)", 32 * n, 32 * n)]
+                ("K5", _lib.KERNEL_BICG_K5, "beta ; p = r + beta (p - omega Ap)", 32 * n, 32 * n),
+                ("K45", _lib.KERNEL_BICG_K45, "omega, beta ; x += alpha p + omega s ; r = s - omega As ; p = r + beta (p - omega Ap)",
+                 64 * n, 64 * n)]
     else:   # cgsStep (Sparse.hs:928-939); the vectors each launch really streams (sla_solvers.cpp: enqueue_cgs -- the x update
         # rides in C2, which reads u, A p, x and writes q, u + q, x; C3 reads u + q, r, rhat and writes r)
         defs = [("C1", _lib.KERNEL_SPMV_DOT, "A p ; A p . rhat", mb + 24 * n, 12 * z + 28 * n),
@@ -170,7 +177,7 @@ def timed_steps(ctx, st, steps, warmup, sync_all, event_free=False):
     Returns (seconds of the timed region, (launches, mean ms, min ms) of the dominant kernel inside it, its kernel id)."""
     from sla_amd import _lib
     ids = (_lib.KERNEL_SPMV_DOT, _lib.KERNEL_SPMV_DOT2, _lib.KERNEL_BICG_K2, _lib.KERNEL_BICG_K4, _lib.KERNEL_BICG_K5,
-           _lib.KERNEL_CGS_C2, _lib.KERNEL_CGS_C4)
+           _lib.KERNEL_CGS_C2, _lib.KERNEL_CGS_C4, _lib.KERNEL_BICG_K45)
     ctx.prof_start(_lib.KERNEL_ALL, max(warmup, 1) * 6 + 8)
     st.step(max(warmup, 1))
     ctx.prof_stop()

@@ -270,6 +270,7 @@ typedef enum {
     SLA_KERNEL_BICG_K5 = 7,   /* beta ; p = r + beta (p - omega Ap) */
     SLA_KERNEL_CGS_C2 = 8,    /* alpha ; q = u - alpha A p ; u + q ; x += alpha (u + q) */
     SLA_KERNEL_CGS_C4 = 9,    /* beta ; u = r + beta q ; p = u + beta (q + beta p) */
+    SLA_KERNEL_BICG_K45 = 10, /* K4 + K5 in one sweep (single-rank flow; K3 then also sums As . r0hat and s . r0hat) */
     SLA_KERNEL_COUNT = 16
 } sla_kernel_id;
 /* record up to `max_launches` event pairs around launches of `kernel_id` (SLA_KERNEL_ALL: of every kernel above) from now on */

@@ -1047,6 +1047,7 @@ static void ctx_read_knobs(sla_ctx *c) {
         {"SLA_FORCE_RP64", &sla_ctx::force_rp64},
         {"SLA_BICG_GHOST", &sla_ctx::bicg_ghost},
         {"SLA_WD_TILE", &sla_ctx::wd_tile},
+        {"SLA_BICG_FUSE45", &sla_ctx::bicg_fuse45},
         {"SLA_WD_LDS", &sla_ctx::wd_lds},
         {"SLA_WD_LDS_OCC", &sla_ctx::wd_lds_occ},
         {"SLA_WD_NT_STORE", &sla_ctx::wd_nt_store},

@@ -97,7 +97,7 @@ struct SolverScalars {
 enum Epi : int {
     EPI_NONE = 0,     // y = A x
     EPI_DOT = 1,      // y = A x ; p1 += y . w                         (K1 / C1)
-    EPI_DOT2 = 2,     // y = A x ; p1 += y . w ; p2 += y . y           (K3)
+    EPI_DOT2 = 2,     // y = A x ; p1 += y . w ; p2 += y . y           (K3); with p3 / p4 also p3 += y . z ; p4 += w . z (fused K4+K5 flow)
     EPI_RES = 3,      // p1 += (A x - b)^2, y not stored              (true residual)
     EPI_AXPY_DOT = 4, // z = z - alpha * (A x) ; p1 += z . w (w==null: z . z)   (CGS C3, CGNE N1)
     EPI_XPBY_NRM = 5, // z = (A x) + beta * z ; p1 += z . z            (CGNE N3)
@@ -118,6 +118,9 @@ struct SpmvArgs {
     const double *w;         // epilogue operand (w / b)
     double *z;               // epilogue in-out operand
     double *p1, *p2;         // partial outputs, one slot per block
+    double *p3, *p4;         // EPI_DOT2 only, may be null: partials of y . z and w . z (z read-only there)
+    mutable double acc3, acc4;   // their per-thread accumulators (a kernel parameter is a private copy: the epilogue adds here, so the
+                                 // kernels keep their two-accumulator signatures)
     SolverScalars *sc;       // may be null (stand-alone SpMV)
     const double *pres;      // prologue: partials of the previous true-residual evaluation (or null)
     int32_t npres, pres_stride;
@@ -179,6 +182,7 @@ struct sla_ctx {
     int64_t mall_bytes = 256ll << 20; // capacity of the memory-side cache (MI355X: 256 MiB)
     int wdia_vv = 1;                 // allow the variable-coefficient wave-sliced form (SLA_WDIA_VV=0 disables)
     int wd_grid_max_vv = sla::kWdBlocksPerCuVV * 256;
+    int bicg_fuse45 = 1;             // single-rank BiCGSTAB: K4 + K5 in one sweep, rho through K3's extra sums (SLA_BICG_FUSE45)
     int wd_lds = 1;                  // stencils with <= 8 (offset, value) pairs: uniform records + x windows staged in LDS (SLA_WD_LDS; 2: at any size)
     int wd_nt_store = 0;             // its y / z stores past the caches (SLA_WD_NT_STORE)
     int wd_lds_occ = 0;              // its workgroups per CU (SLA_WD_LDS_OCC; 0: as many as the LDS holds, at most 4)
@@ -482,6 +486,7 @@ struct SpmvLaunch {
     const double *w = nullptr;
     double *z = nullptr;
     double *p1 = nullptr, *p2 = nullptr;
+    double *p3 = nullptr, *p4 = nullptr;       // EPI_DOT2: y . z and w . z (z read-only)
     SolverScalars *sc = nullptr;
     const double *pres = nullptr; int npres = 0, pres_stride = 1;
     const double *pa = nullptr, *pb = nullptr; int npa = 0, pa_stride = 1;
@@ -525,6 +530,8 @@ int launch_bicg_k2(sla_ctx *c, int64_t n, SolverScalars *sc, Parts apr, int par,
 int launch_bicg_k4(sla_ctx *c, int64_t n, SolverScalars *sc, Parts ass, Parts asas, const double *p, const double *s,
                    const double *as, const double *r0hat, double *x, double *r, double *prho);
 int launch_bicg_k5(sla_ctx *c, int64_t n, SolverScalars *sc, Parts rhonew, int par, const double *r, const double *ap, double *p);
+int launch_bicg_k45(sla_ctx *c, int64_t n, SolverScalars *sc, Parts ass, Parts asas, Parts tr0, Parts sr0, int par, const double *s,
+                    const double *as, const double *ap, double *x, double *r, double *p);
 // CGS (Sparse.hs:928-939)
 int launch_cgs_c2(sla_ctx *c, int64_t n, SolverScalars *sc, Parts apr, int par, Parts res, int count_iter,
                   const double *u, const double *aap, double *q, double *uq, double *x);

@@ -233,6 +233,7 @@ __global__ void __launch_bounds__(kBlock, 8) spmv_stream_kernel(SpmvArgs<RP> a, 
         const double s2 = block_sum(acc2, s_red);
         if (tid == 0) a.p2[blockIdx.x] = s2;
     }
+    spmv_extra_partials<EPI>(a, s_red, tid);
 }
 
 // CSR-stream SpMV with an LDS-staged window of x.  For matrices whose entries cluster around the diagonal
@@ -429,6 +430,7 @@ __global__ void __launch_bounds__(kBlock, 8) spmv_xwin_kernel(SpmvArgs<RP> a, co
         const double s2 = block_sum(acc2, s_red);
         if (tid == 0) a.p2[blockIdx.x] = s2;
     }
+    spmv_extra_partials<EPI>(a, s_red, tid);
 }
 
 // Dual SpMV: ONE pass over the matrix applied to two vectors.  y = A x with the K1 epilogue (p1 += y . w)
@@ -848,6 +850,7 @@ __global__ void __launch_bounds__(kBlock, 8) spmv_diag_kernel(SpmvArgs<RP> a, co
         const double s2 = block_sum(acc2, s_red);
         if (tid == 0) a.p2[blockIdx.x] = s2;
     }
+    spmv_extra_partials<EPI>(a, s_red, tid);
 }
 
 // Dual SpMV on the dictionary-compressed indices: K1 plus the true residual of the previous iterate from one
@@ -1261,6 +1264,7 @@ __global__ void __launch_bounds__(kBlock, 8) spmv_vdict_kernel(SpmvArgs<int32_t>
         const double s2 = block_sum(acc2, s_red);
         if (tid == 0) a.p2[blockIdx.x] = s2;
     }
+    spmv_extra_partials<EPI>(a, s_red, tid);
 }
 
 
@@ -1338,7 +1342,7 @@ __global__ void __launch_bounds__(kBlock, VV ? kWdBlocksPerCuVV : kWdBlocksPerCu
     double acc1 = 0.0, acc2 = 0.0;
     const RbWalk wk = rb_walk(nblk, xcd_remap);
     constexpr bool kUsesW = EPI == EPI_DOT || EPI == EPI_DOT2 || EPI == EPI_RES || EPI == EPI_SUB || EPI == EPI_AXPY_DOT;
-    constexpr bool kUsesZ = EPI == EPI_AXPY_DOT || EPI == EPI_XPBY_NRM;
+    constexpr bool kUsesZ = EPI == EPI_AXPY_DOT || EPI == EPI_XPBY_NRM || EPI == EPI_DOT2;   // (EPI_DOT2: only with p3, read-only)
     // slice descriptor of workgroup step b (wave-uniform): first record, record count (0: nothing to do)
     // `sched` (optional) is the order in which the 512-row steps are visited (see csr_upload: steps a far diagonal
     // apart are made neighbours in time so that the three planes a 3-D stencil row touches meet in the L2)
@@ -1449,11 +1453,13 @@ __global__ void __launch_bounds__(kBlock, VV ? kWdBlocksPerCuVV : kWdBlocksPerCu
                 if (EPI != EPI_AXPY_DOT || a.w)
                     st.wv = w_nt ? __builtin_nontemporal_load((const wd_f64x2 *)(a.w + row)) : *(const wd_f64x2 *)(a.w + row);
             }
-            if constexpr (kUsesZ)
-                st.zv = stream_nt ? __builtin_nontemporal_load((const wd_f64x2 *)(a.z + row)) : *(const wd_f64x2 *)(a.z + row);
+            if constexpr (kUsesZ) {
+                if (EPI != EPI_DOT2 || a.p3)
+                    st.zv = stream_nt ? __builtin_nontemporal_load((const wd_f64x2 *)(a.z + row)) : *(const wd_f64x2 *)(a.z + row);
+            }
         } else if (va) {
             if constexpr (kUsesW) { if (EPI != EPI_AXPY_DOT || a.w) st.wv.x = a.w[row]; }
-            if constexpr (kUsesZ) st.zv.x = a.z[row];
+            if constexpr (kUsesZ) { if (EPI != EPI_DOT2 || a.p3) st.zv.x = a.z[row]; }
         }
         gather8(r, e0, row, st.xv, st.vv);
     };
@@ -1554,6 +1560,7 @@ __global__ void __launch_bounds__(kBlock, VV ? kWdBlocksPerCuVV : kWdBlocksPerCu
         const double s2 = block_sum(acc2, s_red);
         if (tid == 0) a.p2[blockIdx.x] = s2;
     }
+    spmv_extra_partials<EPI>(a, s_red, tid);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1677,6 +1684,7 @@ __global__ void __launch_bounds__(kBlock) lpanel_finish_kernel(SpmvArgs<RP> a, c
         const double s2 = block_sum(acc2, s_red);
         if (threadIdx.x == 0) a.p2[blockIdx.x] = s2;
     }
+    spmv_extra_partials<EPI>(a, s_red, (int)threadIdx.x);
 }
 
 // One lane per row, grid-stride: the A/B baseline for the stream kernel (SLA_SPMV_ALGO=scalar).
@@ -1705,6 +1713,7 @@ __global__ void __launch_bounds__(kBlock) spmv_scalar_kernel(SpmvArgs<RP> a, int
         const double s2 = block_sum(acc2, s_red);
         if (threadIdx.x == 0) a.p2[blockIdx.x] = s2;
     }
+    spmv_extra_partials<EPI>(a, s_red, (int)threadIdx.x);
 }
 
 // do the solver's vectors (7 of n entries for BiCGSTAB) overflow the memory-side cache?  Then stream them past it.
@@ -1795,6 +1804,10 @@ static int launch_spmv_t(const sla_csr *A, const SpmvLaunch &l) {
     a.z = l.z;
     a.p1 = l.p1;
     a.p2 = l.p2;
+    a.p3 = l.p3;
+    a.p4 = l.p4;
+    a.acc3 = 0.0;
+    a.acc4 = 0.0;
     a.sc = l.sc;
     a.pres = l.pres;
     a.npres = l.npres;
@@ -2114,6 +2127,55 @@ __global__ void __launch_bounds__(kBlock) bicg_k4_kernel(int64_t n, SolverScalar
     if (threadIdx.x == 0) prho[blockIdx.x] = t;
 }
 
+// K4 + K5 in one sweep (single-rank contexts, SLA_BICG_FUSE45).  K5 needs beta = rho_{j+1} / rho_j * alpha / omega with
+// rho_{j+1} = r_{j+1} . r0hat, a sum over ALL rows of the r_{j+1} that K4 is only just writing -- which is why the reference's step
+// splits there.  By linearity r_{j+1} . r0hat = (s - omega As) . r0hat = s . r0hat - omega (As . r0hat), and both of those sums
+// are available BEFORE the sweep when K3 (which streams s and As anyway) also reads r0hat: EPI_DOT2 with p3 / p4.  The update
+// formulas of x, r and p are the reference's, term by term; only rho is evaluated through the identity (its rounding error is
+// eps (|s| + |omega| |As|) . |r0hat| either way: the elementwise r_{j+1} = s - omega As carries the same cancellation).  Eight
+// vector passes (p, s, As, x, Ap in; x, r, p out) instead of seven + four, and the r0hat pass moves into K3: 16 instead of 19
+// passes per step.
+template <bool NT>
+__global__ void __launch_bounds__(kBlock) bicg_k45_kernel(int64_t n, SolverScalars *sc, Parts ass, Parts asas, Parts tr0, Parts sr0,
+                                                           int par, const double *s, const double *as, const double *ap, double *x,
+                                                           double *r, double *p) {
+    __shared__ double s_red[4];
+    if (sc->done) return;
+    const double num = reduce_parts(ass.p, ass.n, ass.stride, s_red);
+    const double den = reduce_parts(asas.p, asas.n, asas.stride, s_red);
+    const double t0 = reduce_parts(tr0.p, tr0.n, tr0.stride, s_red);
+    const double s0 = reduce_parts(sr0.p, sr0.n, sr0.stride, s_red);
+    const double omega = num / den, alpha = sc->alpha;
+    const double rn = s0 - omega * t0;                       // = r_{j+1} . r0hat
+    const double beta = rn / sc->rho2[par] * alpha / omega;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        sc->omega = omega;
+        sc->beta = beta;
+        sc->rho2[par ^ 1] = rn;
+    }
+    SLA_VEC_LOOP_BEGIN(n)
+        const double2 sv = ld2s<NT>(s, i2), av = ld2s<NT>(as, i2), vv = ld2s<NT>(ap, i2);
+        double2 pv = ld2s<NT>(p, i2), xv = ld2s<NT>(x, i2);
+        xv.x = (xv.x + alpha * pv.x) + omega * sv.x;
+        xv.y = (xv.y + alpha * pv.y) + omega * sv.y;
+        if (NT) st2_nt(x, i2, xv);  // nobody reads x before the next step's sweep
+        else st2(x, i2, xv);
+        const double2 rv = make_double2(sv.x - omega * av.x, sv.y - omega * av.y);
+        if (NT) st2_nt(r, i2, rv);  // r is next read by K2, after K1 has streamed 250 MB: only p (K1's x) should stay cached
+        else st2(r, i2, rv);
+        pv.x = rv.x + beta * (pv.x - omega * vv.x);
+        pv.y = rv.y + beta * (pv.y - omega * vv.y);
+        st2(p, i2, pv);
+    SLA_VEC_LOOP_END
+    if (SLA_HAS_TAIL(n)) {
+        const int64_t i = n - 1;
+        x[i] = (x[i] + alpha * p[i]) + omega * s[i];
+        const double rv = s[i] - omega * as[i];
+        r[i] = rv;
+        p[i] = rv + beta * (p[i] - omega * ap[i]);
+    }
+}
+
 // K5: betaj = (rj1 <.> r0hat)/(r <.> r0hat) * alphaj / omegaj ; pj1 = rj1 ^+^ betaj .* (p ^-^ omegaj .* aap)
 template <bool NT>
 __global__ void __launch_bounds__(kBlock) bicg_k5_kernel(int64_t n, SolverScalars *sc, Parts rhonew, int par,
@@ -2160,6 +2222,16 @@ int launch_bicg_k5(sla_ctx *c, int64_t n, SolverScalars *sc, Parts rhonew, int p
         hipLaunchKernelGGL(bicg_k5_kernel<true>, dim3(vec_grid(n)), dim3(kBlock), 0, c->stream, n, sc, rhonew, par, r, ap, p);
     else
         hipLaunchKernelGGL(bicg_k5_kernel<false>, dim3(vec_grid(n)), dim3(kBlock), 0, c->stream, n, sc, rhonew, par, r, ap, p);
+    SLA_HIP_TRY(hipGetLastError());
+    return SLA_OK;
+}
+int launch_bicg_k45(sla_ctx *c, int64_t n, SolverScalars *sc, Parts ass, Parts asas, Parts tr0, Parts sr0, int par, const double *s,
+                    const double *as, const double *ap, double *x, double *r, double *p) {
+    ProfScope prof(c, SLA_KERNEL_BICG_K45);
+    if (vec_stream_nt(c, n))
+        hipLaunchKernelGGL(bicg_k45_kernel<true>, dim3(vec_grid(n)), dim3(kBlock), 0, c->stream, n, sc, ass, asas, tr0, sr0, par, s, as, ap, x, r, p);
+    else
+        hipLaunchKernelGGL(bicg_k45_kernel<false>, dim3(vec_grid(n)), dim3(kBlock), 0, c->stream, n, sc, ass, asas, tr0, sr0, par, s, as, ap, x, r, p);
     SLA_HIP_TRY(hipGetLastError());
     return SLA_OK;
 }

@@ -16,7 +16,7 @@ using namespace sla;
 
 namespace {
 
-enum Slot { P_APR = 0, P_ASS = 1, P_ASAS = 2, P_RHO = 3, P_RES = 4, P_TMP = 5, P_SLOTS = 6 };
+enum Slot { P_APR = 0, P_ASS = 1, P_ASAS = 2, P_RHO = 3, P_RES = 4, P_TMP = 5, P_TR0 = 6, P_SR0 = 7, P_SLOTS = 8 };
 
 double *slot(sla_solver *S, int s) { return S->d_parts + (size_t)s * kMaxParts; }
 
@@ -196,9 +196,20 @@ int enqueue_bicgstab(sla_solver *S, int par, const Parts *check, bool dual_prev)
         l.p2 = slot(S, P_ASAS);
         l.sc = S->d_sc;
         l.kernel_id = SLA_KERNEL_SPMV_DOT2;
+        // single rank: the sweep also sums As . r0hat and s . r0hat, which give rho_{j+1} before r_{j+1} exists, so that K4 and
+        // K5 become one sweep (bicg_k45_kernel); sharded contexts keep the reference's split (their partial sums travel in pairs)
+        const bool fuse = c->bicg_fuse45 && !c->collectives;
+        if (fuse) {
+            l.z = S->r0hat->d;
+            l.p3 = slot(S, P_TR0);
+            l.p4 = slot(S, P_SR0);
+        }
         int gk = g;
         SLA_TRY(spmv_exchanged(A, S->t2, l, &gk));
         SLA_TRY(publish(S, P_ASS, P_ASAS, gk, &ass, &asas));
+        if (fuse)
+            return launch_bicg_k45(c, n, S->d_sc, ass, asas, Parts{slot(S, P_TR0), gk, 1}, Parts{slot(S, P_SR0), gk, 1}, par, S->t2->d,
+                                   S->t3->d, S->t1->d, S->x->d, S->r->d, S->p->d);
     }
     SLA_TRY(launch_bicg_k4(c, n, S->d_sc, ass, asas, S->p->d, S->t2->d, S->t3->d, S->r0hat->d, S->x->d, S->r->d, slot(S, P_RHO)));
     SLA_TRY(publish(S, P_RHO, -1, vec_grid(n), &rhon, nullptr));

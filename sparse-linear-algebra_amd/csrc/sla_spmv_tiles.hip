@@ -226,6 +226,7 @@ spmv_tile_kernel(SpmvArgs<RP> a, const RP *__restrict__ rowptr, const int32_t *_
         const double s2 = block_sum(acc2, s_red);
         if (tid == 0) a.p2[blockIdx.x] = s2;
     }
+    spmv_extra_partials<EPI>(a, s_red, tid);
 }
 
 bool tiles_on(const sla_csr *A) { return A->use_tiles && A->ctx->tiles && A->ctx->spmv_algo == 0; }
@@ -249,6 +250,8 @@ static int launch_tiles_t(const sla_csr *A, const SpmvLaunch &l) {
     a.z = l.z;
     a.p1 = l.p1;
     a.p2 = l.p2;
+    a.p3 = l.p3;
+    a.p4 = l.p4;
     a.sc = l.sc;
     a.pres = l.pres;
     a.npres = l.npres;

@@ -44,7 +44,7 @@ __global__ void __launch_bounds__(kBlock, NW <= 4 ? 4 : 3) spmv_wdia_lds_kernel(
     double acc1 = 0.0, acc2 = 0.0;
     const RbWalk wk = rb_walk(nblk, xcd_remap);
     constexpr bool kUsesW = EPI == EPI_DOT || EPI == EPI_DOT2 || EPI == EPI_RES || EPI == EPI_SUB || EPI == EPI_AXPY_DOT;
-    constexpr bool kUsesZ = EPI == EPI_AXPY_DOT || EPI == EPI_XPBY_NRM;
+    constexpr bool kUsesZ = EPI == EPI_AXPY_DOT || EPI == EPI_XPBY_NRM || EPI == EPI_DOT2;   // (EPI_DOT2: only with p3, read-only)
     // element 2 pb[k] of a buffer holds x[grow0 - par + 512 blk + omin[k]]: an even index, so the staging loads are aligned pairs
     // whatever the parity of a row slab's first row
     const int par = grow0 & 1;
@@ -95,8 +95,10 @@ __global__ void __launch_bounds__(kBlock, NW <= 4 ? 4 : 3) spmv_wdia_lds_kernel(
             if ((EPI != EPI_AXPY_DOT || a.w) && !w_lds)
                 wv = w_nt ? __builtin_nontemporal_load((const wd_f64x2u *)(a.w + prow)) : *(const wd_f64x2u *)(a.w + prow);
         }
-        if constexpr (kUsesZ)
-            zv = (stream_nt & 1) ? __builtin_nontemporal_load((const wd_f64x2u *)(a.z + prow)) : *(const wd_f64x2u *)(a.z + prow);
+        if constexpr (kUsesZ) {
+            if (EPI != EPI_DOT2 || a.p3)
+                zv = (stream_nt & 1) ? __builtin_nontemporal_load((const wd_f64x2u *)(a.z + prow)) : *(const wd_f64x2u *)(a.z + prow);
+        }
     };
     auto fix_operands = [&](int row, wd_f64x2 &wv, wd_f64x2 &zv) {
         if (row + 1 == a.rows && row > 0) {
@@ -180,6 +182,7 @@ __global__ void __launch_bounds__(kBlock, NW <= 4 ? 4 : 3) spmv_wdia_lds_kernel(
         const double s2 = block_sum(acc2, s_red);
         if (tid == 0) a.p2[blockIdx.x] = s2;
     }
+    spmv_extra_partials<EPI>(a, s_red, tid);
 }
 
 static int wd_lds_nw(const sla_csr *A) { return A->wd_win.pairs <= 4 * 256 ? 4 : kWdWinLoads; }

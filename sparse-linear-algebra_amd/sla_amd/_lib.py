@@ -17,6 +17,7 @@ FLAG_CONVERGED, FLAG_MAX_ITERS, FLAG_DIAGONAL, FLAG_BREAKDOWN, FLAG_NONFINITE = 
 KERNEL_ALL = -1
 KERNEL_SPMV, KERNEL_SPMV_DOT, KERNEL_SPMV_DOT2, KERNEL_SPMV_RES, KERNEL_SPMV_DUAL = 0, 1, 2, 3, 4
 KERNEL_BICG_K2, KERNEL_BICG_K4, KERNEL_BICG_K5, KERNEL_CGS_C2, KERNEL_CGS_C4 = 5, 6, 7, 8, 9
+KERNEL_BICG_K45 = 10
 
 
 class SlaError(RuntimeError):

@@ -57,9 +57,13 @@ def test_config3a_random_spd_1m_cgs_vs_bicgstab(sla):
         assert np.linalg.norm(x.toDenseListSV() - xs) <= 1e-3 * np.linalg.norm(xs)
 
 
-def test_bench_contract_small():
+@pytest.mark.parametrize("fuse45", ["1", "0"])
+def test_bench_contract_small(fuse45):
+    """fuse45 = 1 (default, single rank): K4 and K5 are one sweep (K45), K3 also streams r0hat; 0: the reference's split."""
+    env = dict(os.environ, SLA_BICG_FUSE45=fuse45)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "laplace3d_small", "--steps", "8",
-                          "--warmup", "2", "--cpu-seconds", "0.5"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+                          "--warmup", "2", "--cpu-seconds", "0.5"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300,
+                         env=env)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1                                               # ONE JSON line
@@ -78,7 +82,7 @@ def test_bench_contract_small():
     assert abs(d["value"] - 1e3 / d["ms_per_step"]) <= 1e-6 * d["value"]
     # a roofline statement: every printed fraction is priced on bytes the kernel really streams and stays <= 1
     assert 0.0 < d["roofline"]["frac"] <= 1.0 and d["roofline"]["achieved"] <= d["roofline"]["peak"]
-    assert set(d["kernels"]) == {"K1", "K2", "K3", "K4", "K5"}
+    assert set(d["kernels"]) == ({"K1", "K2", "K3", "K45"} if fuse45 == "1" else {"K1", "K2", "K3", "K4", "K5"})
     for k in d["kernels"].values():
         assert 0.0 < k["frac"] <= 1.0 and k["bytes"] <= k["csr_bytes"] + 64 and k["launches"] == 8
     assert d["roofline"]["kernel"].split(":")[0] in d["kernels"] and d["roofline"]["launches_timed"] == 8

@@ -401,14 +401,21 @@ def test_row_partition_matches_python(sla):
 # ---- row-sharded code path rehearsed on one GPU (1-rank RCCL communicator, forced collectives) -------------
 
 def test_forced_collectives_match_single_gpu_path(sla, monkeypatch):
+    """Per-rank folding + rank-order summation reproduce the 1-GPU reduction order BIT FOR BIT.  Both contexts run the
+    reference's K4 / K5 split (SLA_BICG_FUSE45=0; knobs are read when a context is created): the single-rank default fuses
+    them and evaluates rho through an identity, sharded contexts never do -- that difference is
+    test_bicgstab_fused_k45_flow_vs_reference_split's subject, not this test's."""
     from sla_amd import workloads as wl
+    monkeypatch.setenv("SLA_BICG_FUSE45", "0")
     monkeypatch.setenv("SLA_FORCE_COLLECTIVES", "1")
     ctx = sla.Context(0, 0, 1, sla.Context.unique_id())
+    monkeypatch.delenv("SLA_FORCE_COLLECTIVES")
+    plain = sla.Context(0)
     dims, (rp, ci, va) = wl.poisson2d(50, 40)
     n = dims[0]
     b = np.add.reduceat(va, rp[:-1])
     outs, cgne = [], []
-    for c in (ctx, sla.default_context()):
+    for c in (ctx, plain):
         A = sla.fromCSRRows(dims, 0, rp, ci, va, c)
         bv, x0 = sla.fromVector(b, c), sla.fromVector(np.zeros(n), c)
         x, info = sla.linSolve0(sla.BICGSTAB_, A, bv, x0, return_info=True)
@@ -428,6 +435,56 @@ def test_forced_collectives_match_single_gpu_path(sla, monkeypatch):
     assert cgne[0][2] and cgne[1][2] and abs(cgne[0][1] - cgne[1][1]) <= 1
     assert np.linalg.norm(cgne[0][0] - cgne[1][0]) <= 1e-6 * np.linalg.norm(cgne[1][0])
     ctx.close()
+    plain.close()
+
+
+@pytest.mark.parametrize("problem", ["poisson2d 50x40", "laplace3d 14x11x13", "spd 400"])
+def test_bicgstab_fused_k45_flow_vs_reference_split(sla, monkeypatch, problem):
+    """Single-rank BiCGSTAB fuses K4 and K5 (default): rho_{j+1} = s . r0hat - omega (As . r0hat) from K3's sweep instead of
+    (s - omega As) . r0hat from K4's.  x, r, p are updated by the reference's formulas either way; rho differs at rounding
+    level, which a Krylov iteration amplifies like any other rounding difference.  Bounds from a CPU experiment on these very
+    problems (tools/rho_identity_experiment.py, profiles/r02_rho_identity_experiment.txt), which compares the identity with
+    the reference's formula under mere regroupings of the dot-product sums: the iterates after 5 / 10 / 20 steps differ by
+    1e-16 / 1e-15 / 1e-11 either way; iterations to convergence on poisson2d 50x40 are 61..67 for the reference's formula
+    (oracle 63), 60..66 for the identity, and 23 / 6 for everything on the other two.  Hence: 5 steps agree to 1e-10; full
+    solves both converge within 4 iterations of the oracle's count (the largest deviation among the 14 CPU variants) and
+    within 6 of each other (the width of the regrouping-only range), both meet the residual tolerance; every state also
+    against the oracle (which evaluates rho the reference's way)."""
+    from sla_amd import workloads as wl
+    if problem.startswith("poisson"):
+        dims, (rp, ci, va) = wl.poisson2d(50, 40)
+    elif problem.startswith("laplace"):
+        dims, (rp, ci, va) = wl.laplace3d(14, 11, 13)
+    else:
+        dims, rp, ci, va, _ = _spd_problem(400, 77)
+    n = dims[0]
+    Ao = orc.Csr(n, n, rp, ci, va)
+    b = orc.spmv(Ao, np.linspace(-1.0, 2.0, n))
+    x0 = np.full(n, 0.1)
+    r0hat = b - orc.spmv(Ao, x0)
+    got = {}
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("SLA_BICG_FUSE45", fuse)
+        c = sla.Context(0)
+        A = sla.fromCSR(dims, rp, ci, va, c)
+        sd = sla.bicgsInit(A, sla.fromVector(b, c), sla.fromVector(x0, c))
+        sd.step(5)
+        st5 = tuple(v.toDenseListSV() for v in (sd._xBicgstab, sd._rBicgstab, sd._pBicgstab))
+        x, info = sla.linSolve0(sla.BICGSTAB_, A, sla.fromVector(b, c), sla.fromVector(x0, c), return_info=True)
+        got[fuse] = (st5, x.toDenseListSV(), info)
+        del sd, A
+        c.close()
+    so = orc.BicgstabState(Ao, b, x0)
+    so.step(r0hat, 5)
+    for a, b_, o in zip(got["1"][0], got["0"][0], (so.x, so.r, so.p)):
+        assert np.linalg.norm(a - b_) <= 1e-10 * np.linalg.norm(b_), problem
+        assert np.linalg.norm(a - o) <= 1e-9 * np.linalg.norm(o) and np.linalg.norm(b_ - o) <= 1e-9 * np.linalg.norm(o), problem
+    i1, i0 = got["1"][2], got["0"][2]
+    it_o = orc.linsolve0(orc.BICGSTAB_, Ao, b, x0)[2]
+    assert i1["converged"] and i0["converged"], (problem, i1, i0)
+    assert abs(i1["iters"] - it_o) <= 4 and abs(i0["iters"] - it_o) <= 4 and abs(i1["iters"] - i0["iters"]) <= 6, (problem, i1["iters"], i0["iters"], it_o)
+    for k in ("1", "0"):
+        assert np.linalg.norm(orc.spmv(Ao, got[k][1]) - b) <= got[k][2]["tol"] * (1 + 1e-9), (problem, k)
 
 
 def test_matrix_market_ingestion_e05r0000(sla):

@@ -36,7 +36,7 @@ def bytes_of(c):
 
 
 KERNELS = {"K1": r"void sla::spmv_\w+<1[,>]", "K3": r"void sla::spmv_\w+<2[,>]", "K2": r"void sla::bicg_k2_kernel",
-           "K4": r"void sla::bicg_k4_kernel", "K5": r"void sla::bicg_k5_kernel"}
+           "K4": r"void sla::bicg_k4_kernel", "K5": r"void sla::bicg_k5_kernel", "K45": r"void sla::bicg_k45_kernel"}
 traffic = {"_comment": "HBM bytes per launch of each kernel of the timed BiCGSTAB step from rocprofv3 PMC passes (separate --pmc runs, "
                        "kernel-trace only; tools/refresh_profiles.sh).  read = TCC_EA0_RDREQ x 128 B (no 32-byte requests occur; "
                        "FETCH_SIZE reads half of that on gfx950), write = WRITE_SIZE KiB x 1024.  Memory-side-cache hits are counted, "
