@@ -84,14 +84,15 @@ __device__ __forceinline__ void spmv_epilogue(const SpmvArgs<RP> &a, int row, do
         acc1 += yv * a.w[row];
     } else if constexpr (EPI == EPI_DOT2) {
         a.y[row] = yv;
-        const double wv = a.w[row];
+        acc1 += yv * a.w[row];
+        acc2 += yv * yv;
+    } else if constexpr (EPI == EPI_DOT4) {   // fused K4+K5 flow: As . r0hat and s . r0hat from the same sweep
+        a.y[row] = yv;
+        const double wv = a.w[row], zv = a.z[row];
         acc1 += yv * wv;
         acc2 += yv * yv;
-        if (a.p3) {   // (wave-uniform) fused K4+K5 flow: As . r0hat and s . r0hat from the same sweep
-            const double zv = a.z[row];
-            a.acc3 += yv * zv;
-            a.acc4 += wv * zv;
-        }
+        a.acc3 += yv * zv;
+        a.acc4 += wv * zv;
     } else if constexpr (EPI == EPI_RES) {
         double t = yv - a.w[row];  // (aa #> x) ^-^ b
         acc1 += t * t;
@@ -108,16 +109,14 @@ __device__ __forceinline__ void spmv_epilogue(const SpmvArgs<RP> &a, int row, do
     }
 }
 
-// the two extra partial sums of EPI_DOT2 (see SpmvArgs::p3): called by every SpMV kernel after its p1 / p2 partials
+// the two extra partial sums of EPI_DOT4 (see SpmvArgs::p3): called by every SpMV kernel after its p1 / p2 partials
 template <int EPI, typename RP>
 __device__ __forceinline__ void spmv_extra_partials(const SpmvArgs<RP> &a, double *s4, int tid) {
-    if constexpr (EPI == EPI_DOT2) {
-        if (a.p3) {
-            const double s3 = block_sum(a.acc3, s4);
-            if (tid == 0) a.p3[blockIdx.x] = s3;
-            const double s4v = block_sum(a.acc4, s4);
-            if (tid == 0) a.p4[blockIdx.x] = s4v;
-        }
+    if constexpr (EPI == EPI_DOT4) {
+        const double s3 = block_sum(a.acc3, s4);
+        if (tid == 0) a.p3[blockIdx.x] = s3;
+        const double s4v = block_sum(a.acc4, s4);
+        if (tid == 0) a.p4[blockIdx.x] = s4v;
     }
 }
 
@@ -191,11 +190,13 @@ __device__ __forceinline__ void wd_epilogue(const SpmvArgs<int32_t> &a, int row,
         acc1 += ya * wv.x;
         acc2 += ya * ya;
         if (vb) { acc1 += yb * wv.y; acc2 += yb * yb; }
-        if (a.p3) {   // (wave-uniform; zv = the row pair of the read-only operand z)
-            a.acc3 += ya * zv.x;
-            a.acc4 += wv.x * zv.x;
-            if (vb) { a.acc3 += yb * zv.y; a.acc4 += wv.y * zv.y; }
-        }
+    } else if constexpr (EPI == EPI_DOT4) {   // (zv = the row pair of the read-only operand z)
+        store_y = true;
+        acc1 += ya * wv.x;
+        acc2 += ya * ya;
+        a.acc3 += ya * zv.x;
+        a.acc4 += wv.x * zv.x;
+        if (vb) { acc1 += yb * wv.y; acc2 += yb * yb; a.acc3 += yb * zv.y; a.acc4 += wv.y * zv.y; }
     } else if constexpr (EPI == EPI_RES) {
         const double ta = ya - wv.x, tb = yb - wv.y;  // (aa #> x) ^-^ b
         acc1 += ta * ta;

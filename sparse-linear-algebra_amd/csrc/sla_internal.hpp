@@ -97,11 +97,14 @@ struct SolverScalars {
 enum Epi : int {
     EPI_NONE = 0,     // y = A x
     EPI_DOT = 1,      // y = A x ; p1 += y . w                         (K1 / C1)
-    EPI_DOT2 = 2,     // y = A x ; p1 += y . w ; p2 += y . y           (K3); with p3 / p4 also p3 += y . z ; p4 += w . z (fused K4+K5 flow)
+    EPI_DOT2 = 2,     // y = A x ; p1 += y . w ; p2 += y . y           (K3)
     EPI_RES = 3,      // p1 += (A x - b)^2, y not stored              (true residual)
     EPI_AXPY_DOT = 4, // z = z - alpha * (A x) ; p1 += z . w (w==null: z . z)   (CGS C3, CGNE N1)
     EPI_XPBY_NRM = 5, // z = (A x) + beta * z ; p1 += z . z            (CGNE N3)
-    EPI_SUB = 6       // y = b - A x                                   (init: r0 = b ^-^ A x0)
+    EPI_SUB = 6,      // y = b - A x                                   (init: r0 = b ^-^ A x0)
+    EPI_DOT4 = 7      // EPI_DOT2 and p3 += y . z ; p4 += w . z (z read-only)   (K3 of the fused K4+K5 flow).  A separate instantiation, not a
+                      // run-time option of EPI_DOT2: carrying the optional operand tripled the scratch of the variable-coefficient K3 (16 -> 44
+                      // B per lane) and cost the reference's split flow 4 % on the 2 M-row banded problem even when unused (measured)
 };
 
 template <typename RP>
@@ -118,7 +121,7 @@ struct SpmvArgs {
     const double *w;         // epilogue operand (w / b)
     double *z;               // epilogue in-out operand
     double *p1, *p2;         // partial outputs, one slot per block
-    double *p3, *p4;         // EPI_DOT2 only, may be null: partials of y . z and w . z (z read-only there)
+    double *p3, *p4;         // EPI_DOT4 only: partials of y . z and w . z (z read-only there)
     mutable double acc3, acc4;   // their per-thread accumulators (a kernel parameter is a private copy: the epilogue adds here, so the
                                  // kernels keep their two-accumulator signatures)
     SolverScalars *sc;       // may be null (stand-alone SpMV)
@@ -486,7 +489,7 @@ struct SpmvLaunch {
     const double *w = nullptr;
     double *z = nullptr;
     double *p1 = nullptr, *p2 = nullptr;
-    double *p3 = nullptr, *p4 = nullptr;       // EPI_DOT2: y . z and w . z (z read-only)
+    double *p3 = nullptr, *p4 = nullptr;       // EPI_DOT4: y . z and w . z (z read-only)
     SolverScalars *sc = nullptr;
     const double *pres = nullptr; int npres = 0, pres_stride = 1;
     const double *pa = nullptr, *pb = nullptr; int npa = 0, pa_stride = 1;

@@ -224,12 +224,12 @@ __global__ void __launch_bounds__(kBlock, 8) spmv_stream_kernel(SpmvArgs<RP> a, 
 #undef SLA_FETCH_DESC
 #undef SLA_ISSUE_LOADS
     }
-    if constexpr (EPI == EPI_DOT || EPI == EPI_DOT2 || EPI == EPI_RES || EPI == EPI_AXPY_DOT ||
+    if constexpr (EPI == EPI_DOT || EPI == EPI_DOT2 || EPI == EPI_DOT4 || EPI == EPI_RES || EPI == EPI_AXPY_DOT ||
                   EPI == EPI_XPBY_NRM) {
         const double s1 = block_sum(acc1, s_red);
         if (tid == 0) a.p1[blockIdx.x] = s1;
     }
-    if constexpr (EPI == EPI_DOT2) {
+    if constexpr (EPI == EPI_DOT2 || EPI == EPI_DOT4) {
         const double s2 = block_sum(acc2, s_red);
         if (tid == 0) a.p2[blockIdx.x] = s2;
     }
@@ -421,12 +421,12 @@ __global__ void __launch_bounds__(kBlock, 8) spmv_xwin_kernel(SpmvArgs<RP> a, co
 #undef SLA_FETCH_DESC
 #undef SLA_ISSUE_LOADS
     }
-    if constexpr (EPI == EPI_DOT || EPI == EPI_DOT2 || EPI == EPI_RES || EPI == EPI_AXPY_DOT ||
+    if constexpr (EPI == EPI_DOT || EPI == EPI_DOT2 || EPI == EPI_DOT4 || EPI == EPI_RES || EPI == EPI_AXPY_DOT ||
                   EPI == EPI_XPBY_NRM) {
         const double s1 = block_sum(acc1, s_red);
         if (tid == 0) a.p1[blockIdx.x] = s1;
     }
-    if constexpr (EPI == EPI_DOT2) {
+    if constexpr (EPI == EPI_DOT2 || EPI == EPI_DOT4) {
         const double s2 = block_sum(acc2, s_red);
         if (tid == 0) a.p2[blockIdx.x] = s2;
     }
@@ -841,12 +841,12 @@ __global__ void __launch_bounds__(kBlock, 8) spmv_diag_kernel(SpmvArgs<RP> a, co
         }
 #undef SLA_ISSUE_LOADS
     }
-    if constexpr (EPI == EPI_DOT || EPI == EPI_DOT2 || EPI == EPI_RES || EPI == EPI_AXPY_DOT ||
+    if constexpr (EPI == EPI_DOT || EPI == EPI_DOT2 || EPI == EPI_DOT4 || EPI == EPI_RES || EPI == EPI_AXPY_DOT ||
                   EPI == EPI_XPBY_NRM) {
         const double s1 = block_sum(acc1, s_red);
         if (tid == 0) a.p1[blockIdx.x] = s1;
     }
-    if constexpr (EPI == EPI_DOT2) {
+    if constexpr (EPI == EPI_DOT2 || EPI == EPI_DOT4) {
         const double s2 = block_sum(acc2, s_red);
         if (tid == 0) a.p2[blockIdx.x] = s2;
     }
@@ -1255,12 +1255,12 @@ __global__ void __launch_bounds__(kBlock, 8) spmv_vdict_kernel(SpmvArgs<int32_t>
 #undef SLA_VD_LOADS
 #undef SLA_VD_DESC
     }
-    if constexpr (DUAL || EPI == EPI_DOT || EPI == EPI_DOT2 || EPI == EPI_RES || EPI == EPI_AXPY_DOT ||
+    if constexpr (DUAL || EPI == EPI_DOT || EPI == EPI_DOT2 || EPI == EPI_DOT4 || EPI == EPI_RES || EPI == EPI_AXPY_DOT ||
                   EPI == EPI_XPBY_NRM) {
         const double s1 = block_sum(acc1, s_red);
         if (tid == 0) a.p1[blockIdx.x] = s1;
     }
-    if constexpr (DUAL || EPI == EPI_DOT2) {
+    if constexpr (DUAL || EPI == EPI_DOT2 || EPI == EPI_DOT4) {
         const double s2 = block_sum(acc2, s_red);
         if (tid == 0) a.p2[blockIdx.x] = s2;
     }
@@ -1341,8 +1341,8 @@ __global__ void __launch_bounds__(kBlock, VV ? kWdBlocksPerCuVV : kWdBlocksPerCu
     const int lane = tid & 63;
     double acc1 = 0.0, acc2 = 0.0;
     const RbWalk wk = rb_walk(nblk, xcd_remap);
-    constexpr bool kUsesW = EPI == EPI_DOT || EPI == EPI_DOT2 || EPI == EPI_RES || EPI == EPI_SUB || EPI == EPI_AXPY_DOT;
-    constexpr bool kUsesZ = EPI == EPI_AXPY_DOT || EPI == EPI_XPBY_NRM || EPI == EPI_DOT2;   // (EPI_DOT2: only with p3, read-only)
+    constexpr bool kUsesW = EPI == EPI_DOT || EPI == EPI_DOT2 || EPI == EPI_DOT4 || EPI == EPI_DOT4 || EPI == EPI_RES || EPI == EPI_SUB || EPI == EPI_AXPY_DOT;
+    constexpr bool kUsesZ = EPI == EPI_AXPY_DOT || EPI == EPI_XPBY_NRM || EPI == EPI_DOT4;   // (EPI_DOT4: read-only)
     // slice descriptor of workgroup step b (wave-uniform): first record, record count (0: nothing to do)
     // `sched` (optional) is the order in which the 512-row steps are visited (see csr_upload: steps a far diagonal
     // apart are made neighbours in time so that the three planes a 3-D stencil row touches meet in the L2)
@@ -1453,13 +1453,11 @@ __global__ void __launch_bounds__(kBlock, VV ? kWdBlocksPerCuVV : kWdBlocksPerCu
                 if (EPI != EPI_AXPY_DOT || a.w)
                     st.wv = w_nt ? __builtin_nontemporal_load((const wd_f64x2 *)(a.w + row)) : *(const wd_f64x2 *)(a.w + row);
             }
-            if constexpr (kUsesZ) {
-                if (EPI != EPI_DOT2 || a.p3)
-                    st.zv = stream_nt ? __builtin_nontemporal_load((const wd_f64x2 *)(a.z + row)) : *(const wd_f64x2 *)(a.z + row);
-            }
+            if constexpr (kUsesZ)
+                st.zv = stream_nt ? __builtin_nontemporal_load((const wd_f64x2 *)(a.z + row)) : *(const wd_f64x2 *)(a.z + row);
         } else if (va) {
             if constexpr (kUsesW) { if (EPI != EPI_AXPY_DOT || a.w) st.wv.x = a.w[row]; }
-            if constexpr (kUsesZ) { if (EPI != EPI_DOT2 || a.p3) st.zv.x = a.z[row]; }
+            if constexpr (kUsesZ) st.zv.x = a.z[row];
         }
         gather8(r, e0, row, st.xv, st.vv);
     };
@@ -1552,11 +1550,11 @@ __global__ void __launch_bounds__(kBlock, VV ? kWdBlocksPerCuVV : kWdBlocksPerCu
             cnt_n = cnt_f;
         }
     }
-    if constexpr (EPI == EPI_DOT || EPI == EPI_DOT2 || EPI == EPI_RES || EPI == EPI_AXPY_DOT || EPI == EPI_XPBY_NRM) {
+    if constexpr (EPI == EPI_DOT || EPI == EPI_DOT2 || EPI == EPI_DOT4 || EPI == EPI_RES || EPI == EPI_AXPY_DOT || EPI == EPI_XPBY_NRM) {
         const double s1 = block_sum(acc1, s_red);
         if (tid == 0) a.p1[blockIdx.x] = s1;
     }
-    if constexpr (EPI == EPI_DOT2) {
+    if constexpr (EPI == EPI_DOT2 || EPI == EPI_DOT4) {
         const double s2 = block_sum(acc2, s_red);
         if (tid == 0) a.p2[blockIdx.x] = s2;
     }
@@ -1675,12 +1673,12 @@ __global__ void __launch_bounds__(kBlock) lpanel_finish_kernel(SpmvArgs<RP> a, c
         for (int p = 1; p < P; ++p) acc = acc + ypart[(int64_t)p * a.rows + row];
         spmv_epilogue<EPI, RP>(a, (int)row, acc, coef, acc1, acc2);
     }
-    if constexpr (EPI == EPI_DOT || EPI == EPI_DOT2 || EPI == EPI_RES || EPI == EPI_AXPY_DOT ||
+    if constexpr (EPI == EPI_DOT || EPI == EPI_DOT2 || EPI == EPI_DOT4 || EPI == EPI_RES || EPI == EPI_AXPY_DOT ||
                   EPI == EPI_XPBY_NRM) {
         const double s1 = block_sum(acc1, s_red);
         if (threadIdx.x == 0) a.p1[blockIdx.x] = s1;
     }
-    if constexpr (EPI == EPI_DOT2) {
+    if constexpr (EPI == EPI_DOT2 || EPI == EPI_DOT4) {
         const double s2 = block_sum(acc2, s_red);
         if (threadIdx.x == 0) a.p2[blockIdx.x] = s2;
     }
@@ -1704,12 +1702,12 @@ __global__ void __launch_bounds__(kBlock) spmv_scalar_kernel(SpmvArgs<RP> a, int
         }
         spmv_epilogue<EPI, RP>(a, (int)row, acc, coef, acc1, acc2);
     }
-    if constexpr (EPI == EPI_DOT || EPI == EPI_DOT2 || EPI == EPI_RES || EPI == EPI_AXPY_DOT ||
+    if constexpr (EPI == EPI_DOT || EPI == EPI_DOT2 || EPI == EPI_DOT4 || EPI == EPI_RES || EPI == EPI_AXPY_DOT ||
                   EPI == EPI_XPBY_NRM) {
         const double s1 = block_sum(acc1, s_red);
         if (threadIdx.x == 0) a.p1[blockIdx.x] = s1;
     }
-    if constexpr (EPI == EPI_DOT2) {
+    if constexpr (EPI == EPI_DOT2 || EPI == EPI_DOT4) {
         const double s2 = block_sum(acc2, s_red);
         if (threadIdx.x == 0) a.p2[blockIdx.x] = s2;
     }
@@ -1932,6 +1930,7 @@ static int launch_spmv_rp(const sla_csr *A, const SpmvLaunch &l) {
         case EPI_NONE: return launch_spmv_t<EPI_NONE, RP>(A, l);
         case EPI_DOT: return launch_spmv_t<EPI_DOT, RP>(A, l);
         case EPI_DOT2: return launch_spmv_t<EPI_DOT2, RP>(A, l);
+        case EPI_DOT4: return launch_spmv_t<EPI_DOT4, RP>(A, l);
         case EPI_RES: return launch_spmv_t<EPI_RES, RP>(A, l);
         case EPI_AXPY_DOT: return launch_spmv_t<EPI_AXPY_DOT, RP>(A, l);
         case EPI_XPBY_NRM: return launch_spmv_t<EPI_XPBY_NRM, RP>(A, l);
@@ -2130,7 +2129,7 @@ __global__ void __launch_bounds__(kBlock) bicg_k4_kernel(int64_t n, SolverScalar
 // K4 + K5 in one sweep (single-rank contexts, SLA_BICG_FUSE45).  K5 needs beta = rho_{j+1} / rho_j * alpha / omega with
 // rho_{j+1} = r_{j+1} . r0hat, a sum over ALL rows of the r_{j+1} that K4 is only just writing -- which is why the reference's step
 // splits there.  By linearity r_{j+1} . r0hat = (s - omega As) . r0hat = s . r0hat - omega (As . r0hat), and both of those sums
-// are available BEFORE the sweep when K3 (which streams s and As anyway) also reads r0hat: EPI_DOT2 with p3 / p4.  The update
+// are available BEFORE the sweep when K3 (which streams s and As anyway) also reads r0hat: EPI_DOT4.  The update
 // formulas of x, r and p are the reference's, term by term; only rho is evaluated through the identity (its rounding error is
 // eps (|s| + |omega| |As|) . |r0hat| either way: the elementwise r_{j+1} = s - omega As carries the same cancellation).  Eight
 // vector passes (p, s, As, x, Ap in; x, r, p out) instead of seven + four, and the r0hat pass moves into K3: 16 instead of 19

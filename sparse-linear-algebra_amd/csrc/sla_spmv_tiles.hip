@@ -218,11 +218,11 @@ spmv_tile_kernel(SpmvArgs<RP> a, const RP *__restrict__ rowptr, const int32_t *_
         }
         for (int r = lane; r < nr; r += 64) spmv_epilogue<EPI, RP>(a, r0 + r, yl[r], coef, acc1, acc2);
     }
-    if constexpr (EPI == EPI_DOT || EPI == EPI_DOT2 || EPI == EPI_RES || EPI == EPI_AXPY_DOT || EPI == EPI_XPBY_NRM) {
+    if constexpr (EPI == EPI_DOT || EPI == EPI_DOT2 || EPI == EPI_DOT4 || EPI == EPI_RES || EPI == EPI_AXPY_DOT || EPI == EPI_XPBY_NRM) {
         const double s1 = block_sum(acc1, s_red);
         if (tid == 0) a.p1[blockIdx.x] = s1;
     }
-    if constexpr (EPI == EPI_DOT2) {
+    if constexpr (EPI == EPI_DOT2 || EPI == EPI_DOT4) {
         const double s2 = block_sum(acc2, s_red);
         if (tid == 0) a.p2[blockIdx.x] = s2;
     }
@@ -276,6 +276,7 @@ static int launch_tiles_rp(const sla_csr *A, const SpmvLaunch &l) {
         case EPI_NONE: return launch_tiles_t<EPI_NONE, RP>(A, l);
         case EPI_DOT: return launch_tiles_t<EPI_DOT, RP>(A, l);
         case EPI_DOT2: return launch_tiles_t<EPI_DOT2, RP>(A, l);
+        case EPI_DOT4: return launch_tiles_t<EPI_DOT4, RP>(A, l);
         case EPI_RES: return launch_tiles_t<EPI_RES, RP>(A, l);
         case EPI_AXPY_DOT: return launch_tiles_t<EPI_AXPY_DOT, RP>(A, l);
         case EPI_XPBY_NRM: return launch_tiles_t<EPI_XPBY_NRM, RP>(A, l);

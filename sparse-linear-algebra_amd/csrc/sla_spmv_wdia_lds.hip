@@ -43,8 +43,8 @@ __global__ void __launch_bounds__(kBlock, NW <= 4 ? 4 : 3) spmv_wdia_lds_kernel(
     const int lane = tid & 63;
     double acc1 = 0.0, acc2 = 0.0;
     const RbWalk wk = rb_walk(nblk, xcd_remap);
-    constexpr bool kUsesW = EPI == EPI_DOT || EPI == EPI_DOT2 || EPI == EPI_RES || EPI == EPI_SUB || EPI == EPI_AXPY_DOT;
-    constexpr bool kUsesZ = EPI == EPI_AXPY_DOT || EPI == EPI_XPBY_NRM || EPI == EPI_DOT2;   // (EPI_DOT2: only with p3, read-only)
+    constexpr bool kUsesW = EPI == EPI_DOT || EPI == EPI_DOT2 || EPI == EPI_DOT4 || EPI == EPI_DOT4 || EPI == EPI_RES || EPI == EPI_SUB || EPI == EPI_AXPY_DOT;
+    constexpr bool kUsesZ = EPI == EPI_AXPY_DOT || EPI == EPI_XPBY_NRM || EPI == EPI_DOT4;   // (EPI_DOT4: read-only)
     // element 2 pb[k] of a buffer holds x[grow0 - par + 512 blk + omin[k]]: an even index, so the staging loads are aligned pairs
     // whatever the parity of a row slab's first row
     const int par = grow0 & 1;
@@ -95,10 +95,8 @@ __global__ void __launch_bounds__(kBlock, NW <= 4 ? 4 : 3) spmv_wdia_lds_kernel(
             if ((EPI != EPI_AXPY_DOT || a.w) && !w_lds)
                 wv = w_nt ? __builtin_nontemporal_load((const wd_f64x2u *)(a.w + prow)) : *(const wd_f64x2u *)(a.w + prow);
         }
-        if constexpr (kUsesZ) {
-            if (EPI != EPI_DOT2 || a.p3)
-                zv = (stream_nt & 1) ? __builtin_nontemporal_load((const wd_f64x2u *)(a.z + prow)) : *(const wd_f64x2u *)(a.z + prow);
-        }
+        if constexpr (kUsesZ)
+            zv = (stream_nt & 1) ? __builtin_nontemporal_load((const wd_f64x2u *)(a.z + prow)) : *(const wd_f64x2u *)(a.z + prow);
     };
     auto fix_operands = [&](int row, wd_f64x2 &wv, wd_f64x2 &zv) {
         if (row + 1 == a.rows && row > 0) {
@@ -174,11 +172,11 @@ __global__ void __launch_bounds__(kBlock, NW <= 4 ? 4 : 3) spmv_wdia_lds_kernel(
         blk_n = blk_f;
         blk_f = blk_g;
     }
-    if constexpr (EPI == EPI_DOT || EPI == EPI_DOT2 || EPI == EPI_RES || EPI == EPI_AXPY_DOT || EPI == EPI_XPBY_NRM) {
+    if constexpr (EPI == EPI_DOT || EPI == EPI_DOT2 || EPI == EPI_DOT4 || EPI == EPI_RES || EPI == EPI_AXPY_DOT || EPI == EPI_XPBY_NRM) {
         const double s1 = block_sum(acc1, s_red);
         if (tid == 0) a.p1[blockIdx.x] = s1;
     }
-    if constexpr (EPI == EPI_DOT2) {
+    if constexpr (EPI == EPI_DOT2 || EPI == EPI_DOT4) {
         const double s2 = block_sum(acc2, s_red);
         if (tid == 0) a.p2[blockIdx.x] = s2;
     }
@@ -222,6 +220,7 @@ int launch_wdia_lds(const sla_csr *A, int epi, const SpmvArgs<int32_t> &a, const
         case EPI_NONE: return launch_epi<EPI_NONE>(A, a, sched, nblk, grid, stream_nt);
         case EPI_DOT: return launch_epi<EPI_DOT>(A, a, sched, nblk, grid, stream_nt);
         case EPI_DOT2: return launch_epi<EPI_DOT2>(A, a, sched, nblk, grid, stream_nt);
+        case EPI_DOT4: return launch_epi<EPI_DOT4>(A, a, sched, nblk, grid, stream_nt);
         case EPI_RES: return launch_epi<EPI_RES>(A, a, sched, nblk, grid, stream_nt);
         case EPI_AXPY_DOT: return launch_epi<EPI_AXPY_DOT>(A, a, sched, nblk, grid, stream_nt);
         case EPI_XPBY_NRM: return launch_epi<EPI_XPBY_NRM>(A, a, sched, nblk, grid, stream_nt);
