@@ -3,7 +3,8 @@
 launch of every kernel of the BiCGSTAB step (K1..K5) = TCC_EA0_RDREQ x 128 B (all read requests are 128-byte on gfx950;
 equals FETCH_SIZE x 2 KiB, see r01_kbench_pmc_calibration.txt) + WRITE_SIZE KiB x 1024.  A logical K1 / K3 that takes
 several launches (column-panel passes: P - 1 launches of spmv_stream_kernel<0> before the fused last pass; LDS panels:
-the panel sweep before the finish kernel) is SUMMED over its launches."""
+the panel sweep before the finish kernel) is SUMMED over its launches.  K3 is the <2, ...> (EPI_DOT2) instantiation in the reference's split flow and the
+<7, ...> (EPI_DOT4: also As . r0hat, s . r0hat) one in the fused single-rank flow; a run holds one of them."""
 import json
 import os
 import re
@@ -35,7 +36,7 @@ def bytes_of(c):
     return rd, c["WRITE_SIZE"][1] * 1024
 
 
-KERNELS = {"K1": r"void sla::spmv_\w+<1[,>]", "K3": r"void sla::spmv_\w+<2[,>]", "K2": r"void sla::bicg_k2_kernel",
+KERNELS = {"K1": r"void sla::spmv_\w+<1[,>]", "K3": r"void sla::spmv_\w+<[27][,>]", "K2": r"void sla::bicg_k2_kernel",
            "K4": r"void sla::bicg_k4_kernel", "K5": r"void sla::bicg_k5_kernel", "K45": r"void sla::bicg_k45_kernel"}
 traffic = {"_comment": "HBM bytes per launch of each kernel of the timed BiCGSTAB step from rocprofv3 PMC passes (separate --pmc runs, "
                        "kernel-trace only; tools/refresh_profiles.sh).  read = TCC_EA0_RDREQ x 128 B (no 32-byte requests occur; "
