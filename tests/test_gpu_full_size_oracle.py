@@ -30,15 +30,16 @@ def sla():
     return sla_amd
 
 
-def _check(sla, dims, rp, ci, va, expect_form, bit_exact, b_mode, tag):
+def _check(sla, dims, rp, ci, va, expect_form, bit_exact, b_mode, tag, ctx=None):
     n = dims[0]
-    A = sla.fromCSR(dims, rp, ci, va)
+    ctx = ctx or sla.default_context()
+    A = sla.fromCSR(dims, rp, ci, va, ctx)
     info = A.kernel_info()
     assert expect_form in info, (tag, info)
     Ao = orc.Csr(n, n, rp, ci, va)
     rng = np.random.default_rng(20260928)
     x = rng.standard_normal(n)
-    y = sla.matVec(A, sla.fromVector(x)).toDenseListSV()
+    y = sla.matVec(A, sla.fromVector(x, ctx)).toDenseListSV()
     yo = orc.spmv(Ao, x)
     if bit_exact:
         assert np.array_equal(y, yo), (tag, info, int(np.count_nonzero(y != yo)))
@@ -54,7 +55,7 @@ def _check(sla, dims, rp, ci, va, expect_form, bit_exact, b_mode, tag):
         b = orc.spmv(Ao, np.random.default_rng(7).standard_normal(n))   # b = A x*, x* ~ N(0,1) seed 7 (config 3)
     x0 = np.zeros(n)
     so = orc.BicgstabState(Ao, b, x0)
-    sd = sla.bicgsInit(A, sla.fromVector(b), sla.fromVector(x0))
+    sd = sla.bicgsInit(A, sla.fromVector(b, ctx), sla.fromVector(x0, ctx))
     so.step(b, 2)                                              # r0hat = b - A 0 = b
     sd.step(2)
     for name, dev, ref in (("x", sd._xBicgstab, so.x), ("r", sd._rBicgstab, so.r), ("p", sd._pBicgstab, so.p)):
@@ -75,6 +76,17 @@ def test_config4_laplace3d_10m_bit_exact_vs_oracle(sla):
     dims, (rp, ci, va) = wl.laplace3d(216, 216, 216)
     assert dims[0] == 10077696
     _check(sla, dims, rp, ci, va, "wdia", True, "ones", "config4")
+
+
+def test_config4_laplace3d_10m_reference_split_flow_vs_oracle(sla, monkeypatch):
+    """The single-rank default fuses K4 and K5 (the test above); sharded contexts -- config 4 on 8 GPUs -- run the reference's
+    split.  The same full-size check on a context created with SLA_BICG_FUSE45=0."""
+    from sla_amd import workloads as wl
+    monkeypatch.setenv("SLA_BICG_FUSE45", "0")
+    ctx = sla.Context(0)
+    dims, (rp, ci, va) = wl.laplace3d(216, 216, 216)
+    _check(sla, dims, rp, ci, va, "wdia", True, "ones", "config4 split", ctx)
+    ctx.close()
 
 
 def test_config5_banded_2m_bit_exact_vs_oracle(sla):
