@@ -1637,6 +1637,11 @@ int sla_csr_kernel_info(sla_csr_t A, char *buf, int buflen) {
             snprintf(buf + used, (size_t)buflen - used, " slices=%d panels=%d panel_cols=%d max_segment=%lld exact_fold=1", A->tl_S, A->tl_P,
                      1 << A->tl_shift, (long long)A->tl_maxseg);
     }
+    if (A->use_wdia && wd_on(A) && wd_lds_on(A)) {   // LDS-window geometry: windows, staged 16-byte pairs per buffer (> 1024: the 6-load instantiation), pairs folded
+        const size_t used = strlen(buf);
+        if (used + 1 < (size_t)buflen)
+            snprintf(buf + used, (size_t)buflen - used, " windows=%d win_pairs=%d pairs=%d", A->wd_win.n, A->wd_win.pairs, A->wd_uni.n);
+    }
     if (overlap_split(A)) {
         const size_t used = strlen(buf);
         if (used + 1 < (size_t)buflen)

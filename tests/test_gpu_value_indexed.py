@@ -53,6 +53,9 @@ def _cases():
         "ragged 7 diagonals n=4099": _stencil(4099, [-1300, -40, -1, 0, 1, 40, 1300],
                                                lambda r, o: np.full(len(r), 9.0 if o == 0 else 0.5 + (o % 3)),
                                                keep=lambda r, t: ~drop[r, t] | (t == 3)),
+        # five far-apart diagonals: five windows, 1285 staged pairs -- the LDS-window kernel's 6-load instantiation (> 1024 pairs)
+        "5 far diagonals n=7001": _stencil(7001, [-3000, -1500, 0, 1500, 3000], lambda r, o: np.full(len(r), 7.0 if o == 0 else -1.0 - 0.5 * (o > 0)),
+                                          keep=lambda r, t: (r % 11 != 3) | (t == 2)),
         # three different values along each diagonal (row mod 3): several records share an offset
         "3 values per diagonal n=2500": _stencil(2500, [-50, -1, 0, 1, 50],
                                                   lambda r, o: (8.0 if o == 0 else -1.0) * (1.0 + 0.25 * (r % 3))),
@@ -78,7 +81,7 @@ def test_value_indexed_forms_fold_like_the_reference(sla, monkeypatch, name):
     want_t = orc.spmv(orc.transpose(Ao), x)
     got = {}
     lds_cases = ("laplace3d 14x11x13", "poisson2d 37x29 (odd n)", "tridiag n=1", "tridiag n=129", "ragged 7 diagonals n=4099",
-                 "explicit +-0.0 n=777")
+                 "5 far diagonals n=7001", "explicit +-0.0 n=777")
     for form, env in (("wdia", {"SLA_WD_LDS": "0"}), ("wdia+ldswin", {"SLA_WD_LDS": "2"}), ("vdict", {"SLA_WDIA": "0"}),
                       ("diag", {"SLA_WDIA": "0", "SLA_VDICT": "0"}),
                       ("stream", {"SLA_WDIA": "0", "SLA_VDICT": "0", "SLA_DIAG": "0", "SLA_XWIN": "0"})):
@@ -91,6 +94,8 @@ def test_value_indexed_forms_fold_like_the_reference(sla, monkeypatch, name):
         if form == "wdia+ldswin":
             # the LDS-window kernel takes stencils of <= 8 (offset, value) pairs; the others stay on the gather kernel
             assert ("ldswin" in A.kernel_info().split()[0]) == (name in lds_cases), (name, A.kernel_info())
+            if name == "5 far diagonals n=7001":     # (the instantiation with six staging loads per lane)
+                assert "windows=5" in A.kernel_info() and int(A.kernel_info().split("win_pairs=")[1].split()[0]) > 1024, A.kernel_info()
             form = "wdia"
         if form in ("wdia", "vdict"):
             assert form in A.kernel_info().split()[0], (form, A.kernel_info())
@@ -108,7 +113,7 @@ def test_value_indexed_forms_fold_like_the_reference(sla, monkeypatch, name):
 
 
 @pytest.mark.parametrize("name", ["laplace3d 14x11x13", "ragged 11 diagonals n=4099", "ragged 7 diagonals n=4099",
-                                  "3 values per diagonal n=2500"])
+                                  "5 far diagonals n=7001", "3 values per diagonal n=2500"])
 def test_value_indexed_epilogues_through_the_solvers(sla, monkeypatch, name):
     """K1/K3 (dot, dot2), the true-residual sweep, CGS's and CGNE's fused updates, r0 = b - A x0: same iterates as
     the general kernels (the per-row results are bit-identical; only partial-sum grouping differs)."""
