@@ -20,7 +20,9 @@ LDS = "--lds" in sys.argv
 argv = [a for a in sys.argv[1:] if not a.startswith("--")]
 cases = int(argv[0]) if len(argv) > 0 else 200
 rng = np.random.default_rng(int(argv[1]) if len(argv) > 1 else 1)
-lds_taken = lds_wide = singular_cases = 0
+lds_taken = lds_wide = 0
+compared = {"bicgstab": 0, "cgs": 0, "cgne": 0}
+skipped = dict(compared)
 algos = {}
 for case in range(cases):
     big = 6000 if LDS else 1500
@@ -76,15 +78,20 @@ for case in range(cases):
     if square and m >= 2:
         b = rng.standard_normal(m)
         x0 = rng.standard_normal(m) * 0.1
-        # An empty row makes the system singular: BiCGSTAB / CGS iterates then grow without bound (1e16 after two steps seen) and
-        # device and oracle differ by whatever the last bits of a near-zero denominator say -- with every kernel and flow alike,
-        # the pre-round-2 ones included.  Only CGNE (normal equations) is a defined iteration there and is compared.
-        singular = bool((np.diff(Ao.rowptr) == 0).any())
-        singular_cases += singular
+        # Two steps of a Krylov method are only comparable where they are well conditioned: near a breakdown (a singular matrix
+        # from the empty-row option, v . r0hat or p . p close to 0) the iterates reach 1e16 in two steps and device and oracle
+        # differ by whatever the last bits of a denominator say -- with every kernel and flow alike, the pre-round-2 ones
+        # included (seed 7 case 21: BiCGSTAB / CGS; seed 5 case 182: CGNE).  So the oracle is run twice, the second time with b
+        # perturbed at the 1e-15 level, and a method is compared only if that moves ITS result by less than 1e-9 (the device
+        # differs from the oracle by perturbations of that size: a 1000-fold margin under the 1e-6 tolerance below).
+        b_pert = b * (1.0 + 1e-15 * np.random.default_rng(1000003 + case).standard_normal(m))   # (own generator: the main stream stays reproducible)
         for name, init, ocls, fld in (("bicgstab", sla.bicgsInit, orc.BicgstabState, "_xBicgstab"), ("cgs", sla.cgsInit, orc.CgsState, "_x"),
                                      ("cgne", sla.cgneInit, orc.CgneState, "_xCgne")):
-            if singular and name != "cgne":
-                continue
+            o2 = ocls(Ao, b_pert, x0)
+            if name == "cgne":
+                o2.step(2)
+            else:
+                o2.step(b_pert - orc.spmv(Ao, x0), 2)
             st = init(A, sla.fromVector(b), sla.fromVector(x0))
             os_ = ocls(Ao, b, x0)
             r0hat = b - orc.spmv(Ao, x0)
@@ -94,13 +101,17 @@ for case in range(cases):
             else:
                 os_.step(r0hat, 2)
             got = getattr(st, fld).toDenseListSV()
-            if np.all(np.isfinite(os_.x)) and np.abs(os_.x).max() < 1e100:
-                scale = np.abs(os_.x).max() + 1e-300
-                err = np.abs(got - os_.x).max()
-                if os.environ.get("FUZZ_REPORT"):      # diagnose instead of stopping: print every solver comparison of the LAST case
-                    if case == cases - 1:
-                        print(f"case {case} {algo} {name}: max|x_dev - x_oracle| = {err:.3e}, max|x_oracle| = {scale:.3e}, m = {m}, offsets {offs.tolist()}")
-                else:
-                    assert err <= 1e-6 * scale + 1e-9, ("solver", name, case, algo, err, scale)
+            stable = np.all(np.isfinite(os_.x)) and np.all(np.isfinite(o2.x)) and \
+                np.abs(o2.x - os_.x).max() <= 1e-9 * (np.abs(os_.x).max() + 1e-300)
+            compared[name] += bool(stable)
+            skipped[name] += not stable
+            scale = np.abs(os_.x).max() + 1e-300
+            err = np.abs(got - os_.x).max()
+            if os.environ.get("FUZZ_REPORT"):          # diagnose instead of stopping: every solver comparison of the LAST case
+                if case == cases - 1:
+                    print(f"case {case} {algo} {name}: max|x_dev - x_oracle| = {err:.3e}, max|x_oracle| = {scale:.3e}, oracle moved by "
+                          f"{np.abs(o2.x - os_.x).max():.3e} under a 1e-15 perturbation of b ({'compared' if stable else 'skipped'}), m = {m}, offsets {offs.tolist()}")
+            elif stable:
+                assert err <= 1e-6 * scale + 1e-9, ("solver", name, case, algo, err, scale)
     del A
-print("fuzz ok:", cases, "cases;", algos, f"; {singular_cases} square cases with an empty row (singular: CGNE only)", f"; LDS-window kernel: {lds_taken} cases, {lds_wide} of them with > 1024 staged pairs" if LDS else "")
+print("fuzz ok:", cases, "cases;", algos, f"; solver comparisons made {compared}, skipped as ill-conditioned {skipped}", f"; LDS-window kernel: {lds_taken} cases, {lds_wide} of them with > 1024 staged pairs" if LDS else "")
