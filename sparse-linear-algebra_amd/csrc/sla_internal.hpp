@@ -104,7 +104,8 @@ enum Epi : int {
     EPI_SUB = 6,      // y = b - A x                                   (init: r0 = b ^-^ A x0)
     EPI_DOT4 = 7      // EPI_DOT2 and p3 += y . z ; p4 += w . z (z read-only)   (K3 of the fused K4+K5 flow).  A separate instantiation, not a
                       // run-time option of EPI_DOT2: carrying the optional operand tripled the scratch of the variable-coefficient K3 (16 -> 44
-                      // B per lane) and cost the reference's split flow 4 % on the 2 M-row banded problem even when unused (measured)
+                      // B per lane) and cost the reference's split flow 4 % on the 2 M-row banded problem even when unused (measured); that
+                      // kernel's EPI_DOT4 instantiation is compiled for one workgroup per CU less instead
 };
 
 template <typename RP>

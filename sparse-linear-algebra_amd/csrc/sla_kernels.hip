@@ -1325,8 +1325,9 @@ __device__ __forceinline__ double wd_lane_f64(double x, int k) {
 // 8 / 7 / 6 / 5 / 4 per CU = 2890 / 3110 / 3170 / 3140 / 2940 BiCGSTAB it/s).
 // VV: variable coefficients -- a record carries no scalar value but a block of 128 values laid out like the slice's
 // rows (wvblk), fetched with one more 16-byte load per lane; everything else is shared.
+// (VV with the four-sum epilogue: one workgroup per CU less -- 108 VGPRs and no scratch instead of 96 + 44 B of spills per lane)
 template <int EPI, bool VV>
-__global__ void __launch_bounds__(kBlock, VV ? kWdBlocksPerCuVV : kWdBlocksPerCu) spmv_wdia_kernel(SpmvArgs<int32_t> a, const int32_t *__restrict__ sptr,
+__global__ void __launch_bounds__(kBlock, VV ? (EPI == EPI_DOT4 ? kWdBlocksPerCuVV - 1 : kWdBlocksPerCuVV) : kWdBlocksPerCu) spmv_wdia_kernel(SpmvArgs<int32_t> a, const int32_t *__restrict__ sptr,
                                                                const unsigned long long *__restrict__ wme,
                                                                const unsigned long long *__restrict__ wmo,
                                                                const double *__restrict__ wval, const int32_t *__restrict__ woff,

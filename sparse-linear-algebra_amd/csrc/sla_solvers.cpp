@@ -198,9 +198,10 @@ int enqueue_bicgstab(sla_solver *S, int par, const Parts *check, bool dual_prev)
         l.kernel_id = SLA_KERNEL_SPMV_DOT2;
         // single rank: the sweep also sums As . r0hat and s . r0hat, which give rho_{j+1} before r_{j+1} exists, so that K4 and
         // K5 become one sweep (bicg_k45_kernel); sharded contexts keep the reference's split (their partial sums travel in pairs)
-        // Not on the variable-coefficient wave-sliced form: that kernel is register-bound at its 5 workgroups per CU and spills with
-        // a third operand (2 M-row banded problem, same box: split 11 350-11 460 it/s, fused 11 010-11 050).
-        const bool fuse = c->bicg_fuse45 && !c->collectives && !(A->use_wdia && A->wd_vv && wd_on(A));
+        // (the variable-coefficient wave-sliced kernel is register-bound at 5 workgroups per CU and spills with the third operand,
+        // so its EPI_DOT4 instantiation is compiled for 4: 2 M-row banded problem, same box, three interleaved runs each: split
+        // 11 501-11 581 it/s, fused 11 963-12 055)
+        const bool fuse = c->bicg_fuse45 && !c->collectives;
         if (fuse) {
             l.epi = EPI_DOT4;
             l.z = S->r0hat->d;

@@ -438,7 +438,7 @@ def test_forced_collectives_match_single_gpu_path(sla, monkeypatch):
     plain.close()
 
 
-@pytest.mark.parametrize("problem", ["poisson2d 50x40", "laplace3d 14x11x13", "spd 400"])
+@pytest.mark.parametrize("problem", ["poisson2d 50x40", "laplace3d 14x11x13", "spd 400", "banded_nonsym 4001 (wdia-vv)"])
 def test_bicgstab_fused_k45_flow_vs_reference_split(sla, monkeypatch, problem):
     """Single-rank BiCGSTAB fuses K4 and K5 (default): rho_{j+1} = s . r0hat - omega (As . r0hat) from K3's sweep instead of
     (s - omega As) . r0hat from K4's.  x, r, p are updated by the reference's formulas either way; rho differs at rounding
@@ -455,6 +455,8 @@ def test_bicgstab_fused_k45_flow_vs_reference_split(sla, monkeypatch, problem):
         dims, (rp, ci, va) = wl.poisson2d(50, 40)
     elif problem.startswith("laplace"):
         dims, (rp, ci, va) = wl.laplace3d(14, 11, 13)
+    elif problem.startswith("banded"):     # config 5's structure: the variable-coefficient wave-sliced kernel, whose four-sum
+        dims, (rp, ci, va) = wl.banded_nonsym(4001)   # instantiation is compiled for one workgroup per CU less
     else:
         dims, rp, ci, va, _ = _spd_problem(400, 77)
     n = dims[0]
@@ -467,6 +469,8 @@ def test_bicgstab_fused_k45_flow_vs_reference_split(sla, monkeypatch, problem):
         monkeypatch.setenv("SLA_BICG_FUSE45", fuse)
         c = sla.Context(0)
         A = sla.fromCSR(dims, rp, ci, va, c)
+        if problem.startswith("banded"):
+            assert "wdia-vv" in A.kernel_info(), A.kernel_info()
         sd = sla.bicgsInit(A, sla.fromVector(b, c), sla.fromVector(x0, c))
         sd.step(5)
         st5 = tuple(v.toDenseListSV() for v in (sd._xBicgstab, sd._rBicgstab, sd._pBicgstab))

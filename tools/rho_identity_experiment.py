@@ -51,7 +51,7 @@ def run(A, b, x0, dot, identity, steps=None):
 
 
 probs = {"poisson2d 50x40": wl.poisson2d(50, 40), "laplace3d 14x11x13": wl.laplace3d(14, 11, 13),
-         "spd 400": wl.random_spd(400, k=3, seed=77)}
+         "spd 400": wl.random_spd(400, k=3, seed=77), "banded_nonsym 4001": wl.banded_nonsym(4001)}
 chunks = (0, 2, 4, 7, 16, 64, 256)
 for name, (dims, (rp, ci, va)) in probs.items():
     n = dims[0]
