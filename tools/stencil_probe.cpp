@@ -8,6 +8,8 @@
 //   lds      a workgroup stages the three x windows of its 512-row step in LDS (in-plane window of 512 + 2 * 216
 //            elements, the planes behind / ahead: 4 global 16-byte loads per lane instead of 7, next step's loads in
 //            flight during the fold), the 7 operands come from LDS
+//   lds+axpy K2 folded into K3's staging (windows of r - alpha v computed on the fly, own rows of s written) against the axpy kernel
+//            followed by the staged SpMV: slower (last output line)
 //   hipcc --offload-arch=gfx950 -O3 -o tools/stencil_probe tools/stencil_probe.cpp
 #include <hip/hip_runtime.h>
 #include <cstdint>
@@ -15,6 +17,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
+#include <utility>
 #include <algorithm>
 #include <cmath>
 
@@ -184,6 +187,64 @@ __global__ void __launch_bounds__(256, OCC) lds2_kernel(const double *__restrict
     }
 }
 
+// K2 folded into K3's staging: the windows hold s = r - alpha v computed on the fly (8 staging loads per lane instead of 4), the
+// workgroup's own 512 rows of s are written out (K4+K5 need s), then the 7-point fold as before.  Against lds_kernel on a
+// precomputed s plus a separate kernel that forms s (3 vector passes).
+template <int OCC, int SCHED>
+__global__ void __launch_bounds__(256, OCC) lds_axpy_kernel(const double *__restrict__ r, const double *__restrict__ v, double alpha,
+                                                            double *__restrict__ sout, double *__restrict__ y, int nsteps, int D1, int D2,
+                                                            const int *__restrict__ ord, int per) {
+    __shared__ d2 buf[2][1024];
+    const int tid = threadIdx.x;
+    const int T = D2 / 512;
+    d2 a0, a1, a2, a3, b0, b1, b2, b3;
+    auto load = [&](int s) {
+        const size_t o = (size_t)s * 512 + 2 * tid;
+        const int second = tid < D1 ? 512 : 0;
+        a0 = *(const d2 *)(r + o - D1); b0 = *(const d2 *)(v + o - D1);
+        a1 = *(const d2 *)(r + o - D1 + second); b1 = *(const d2 *)(v + o - D1 + second);
+        a2 = *(const d2 *)(r + o - D2); b2 = *(const d2 *)(v + o - D2);
+        a3 = *(const d2 *)(r + o + D2); b3 = *(const d2 *)(v + o + D2);
+    };
+    auto stage = [&](int p, int s) {
+#pragma clang fp contract(off)
+        const d2 s0 = a0 - alpha * b0, s1 = a1 - alpha * b1, s2 = a2 - alpha * b2, s3 = a3 - alpha * b3;
+        buf[p][tid] = s0;
+        if (tid < D1) buf[p][256 + tid] = s1;
+        buf[p][512 + tid] = s2;
+        buf[p][768 + tid] = s3;
+    };
+    int s = step_of<SCHED>(0, nsteps, T, ord, per), p = 0;
+    if (s < 0) return;
+    load(s);
+    stage(0, s);
+    __syncthreads();
+    for (int i = 1; s >= 0; ++i, p ^= 1) {
+        const int sn = step_of<SCHED>(i, nsteps, T, ord, per);
+        if (sn >= 0) load(sn);
+        const double *w = (const double *)buf[p] + D1 + 2 * tid;
+        const d2 a = buf[p][512 + tid], g = buf[p][768 + tid];
+        const d2 bb = *(const d2 *)(w - D1), f = *(const d2 *)(w + D1);
+        const d2 d = *(const d2 *)w;
+        const double lo = w[-1], hi = w[2];
+        const d2 c = d2{lo, d.x}, e = d2{d.y, hi};
+        const d2 res = fold7(a, bb, c, d, e, f, g);
+        *(d2 *)(sout + (size_t)s * 512 + 2 * tid) = d;                       // this workgroup's own rows of s (read again by K4+K5)
+        __builtin_nontemporal_store(res, (d2 *)(y + (size_t)s * 512 + 2 * tid));
+        if (sn >= 0) stage(p ^ 1, sn);
+        __syncthreads();
+        s = sn;
+    }
+}
+
+__global__ void __launch_bounds__(256) axpy_kernel(const double *__restrict__ r, const double *__restrict__ v, double alpha, double *__restrict__ s, size_t n2) {
+#pragma clang fp contract(off)
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n2; i += (size_t)gridDim.x * 256) {
+        const d2 a = __builtin_nontemporal_load((const d2 *)r + i), b = __builtin_nontemporal_load((const d2 *)v + i);
+        ((d2 *)s)[i] = a - alpha * b;
+    }
+}
+
 int main(int argc, char **argv) {
     const int G = argc > 1 ? atoi(argv[1]) : 216;
     const int D1 = G, D2 = G * G;
@@ -279,6 +340,38 @@ int main(int argc, char **argv) {
         LDSK(2, 1);
         LDSK(3, 1);
         LDSK(4, 1);
+    }
+
+    {   // K2 + K3: separate (axpy kernel, then the staged SpMV on its result) vs folded into the staging
+        double *dv[pairs], *ds[pairs];
+        for (int i = 0; i < pairs; ++i) {
+            CK(hipMalloc(&dv[i], (n + 2 * pad) * 8));
+            CK(hipMalloc(&ds[i], (n + 2 * pad) * 8));
+            CK(hipMemcpy(dv[i], hx.data(), (n + 2 * pad) * 8, hipMemcpyHostToDevice));
+            CK(hipMemset(ds[i], 0, (n + 2 * pad) * 8));
+        }
+        const double alpha = 0.37;
+        auto both = [&](const char *name, auto launch) {
+            for (int i = 0; i < 4; ++i) launch(i % pairs);
+            CK(hipDeviceSynchronize());
+            CK(hipEventRecord(e0));
+            for (int i = 0; i < reps; ++i) launch(i % pairs);
+            CK(hipEventRecord(e1));
+            CK(hipEventSynchronize(e1));
+            float ms;
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            CK(hipMemcpy(got.data(), dy[0], n * 8, hipMemcpyDeviceToHost));
+            return std::make_pair(ms * 1e3 / reps, got);
+        };
+        auto sep = both("separate", [&](int i) {
+            hipLaunchKernelGGL(axpy_kernel, dim3(2048), dim3(256), 0, 0, dx[i], dv[i], alpha, ds[i], (n + 2 * pad) / 2);
+            hipLaunchKernelGGL((lds_kernel<4, 2>), dim3(1024), dim3(256), 0, 0, ds[i] + pad, dy[i], nsteps, D1, D2, d_order, sweep_per);
+        });
+        auto fus = both("fused", [&](int i) {
+            hipLaunchKernelGGL((lds_axpy_kernel<4, 2>), dim3(1024), dim3(256), 0, 0, dx[i] + pad, dv[i] + pad, alpha, ds[i] + pad, dy[i], nsteps, D1, D2, d_order, sweep_per);
+        });
+        printf("K2 + K3, product order, rotating %d vector sets: separate kernels %.1f us, K2 folded into the staging %.1f us%s\n", pairs, sep.first,
+               fus.first, memcmp(sep.second.data(), fus.second.data(), n * 8) == 0 ? "  (y bit-identical)" : "  (y MISMATCH)");
     }
     return 0;
 }
