@@ -123,6 +123,8 @@ def cpu_baseline(dims, rp, ci, va, b, seconds):
         st.step(r0p, osteps)
         odt = time.perf_counter() - t0
         out["omp"] = {"value": osteps / odt, "unit": "iters/s", "cores": threads, "kind": "port",
+                      "step_gbps_csr": (24 * len(ci) + 160 * n) * osteps / odt / 1e9,
+                      "temporaries": "kept across steps (no per-step malloc / first-touch faults in the timing build)",
                       "first_touch": "matrix and vectors copied row-parallel before timing (orc_par_copy_csr)",
                       "sample": f"{osteps} bicgstabStep iterations, OpenMP build of the same port (liboracle_omp.so), {threads} threads"}
     except Exception as e:  # the OpenMP leg is informative only
@@ -170,7 +172,20 @@ def kernel_table(ctx, A, nnz_local, n_local, method):
     return out
 
 
-def timed_steps(ctx, st, steps, warmup, sync_all, event_free=False):
+def exchange_table(ctx):
+    """Row-sharded contexts: HIP-event statistics of the collectives of the last KERNEL_ALL recording (rank 0's view; events on
+    the stream each one is issued on -- the second stream for a halo exchange that overlaps the interior rows)."""
+    from sla_amd import _lib
+    out = {}
+    for name, kid, what in (("x_exchange", _lib.KERNEL_EXCHANGE, "exchange of an SpMV's input vector (ncclAllGather / grouped halo ncclSend+ncclRecv)"),
+                            ("sums", _lib.KERNEL_SUMS, "per-rank partial sums made global (finalize + all-gather; ghost-row flows: the grouped exchange that also carries a halo)")):
+        cnt, mean, mn = ctx.prof_query(kid)
+        if cnt:
+            out[name] = {"what": what, "launches": cnt, "ms": mean, "min_ms": mn}
+    return out
+
+
+def timed_steps(ctx, st, steps, warmup, sync_all, event_free=False, conv=None):
     """Warm-up (which also finds the kernel with the largest share of a step), then EXACTLY `steps` timed steps bracketed by
     barrier + sync, with HIP events around the dominant kernel's launches only (events around all five kernels of a
     0.3 ms step cost ~8 % of it), then an untimed pass of the same length with every kernel event-timed for the table.
@@ -183,6 +198,8 @@ def timed_steps(ctx, st, steps, warmup, sync_all, event_free=False):
     ctx.prof_stop()
     tot = {k: (lambda c, m, _: c * m)(*ctx.prof_query(k)) for k in ids}
     dom = max(tot, key=tot.get)
+    if conv is not None:   # residual of the state the timed region starts from (collective when sharded: every rank calls it)
+        conv["res_before"] = state_residual(ctx, st, st.A.ncols)
     sync_all()
     if event_free:
         # launch-bound sizes: the library replays the steps as a captured HIP graph (sla_solver_step) -- kernels inside a graph
@@ -208,28 +225,54 @@ def timed_steps(ctx, st, steps, warmup, sync_all, event_free=False):
     return dt, dom_stats, dom
 
 
-def side_block(name, dims, rp, ci, va, env, steps, warmup):
-    """One more driver-timed block in the same process: lower (dims, rp, ci, va) on a fresh context created under the
-    knob settings `env`, time `steps` bicgstabSteps (barrier + sync on both sides) with every kernel event-timed."""
+def state_residual(ctx, st, n):
+    """||r|| of a solver state record (the recurrence residual), evaluated on the device."""
+    import ctypes as C
     import sla_amd as sla
-    saved = {k: os.environ.get(k) for k in env}
-    os.environ.update(env)
-    try:
-        ctx = sla.Context(0)
-    finally:
-        for k, v in saved.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
+    from sla_amd import _lib
+    r = sla.DeviceVector(ctx, n)
+    _lib.check(_lib.lib().sla_solver_get(st.h, 1, r.h))
+    out = C.c_double()
+    _lib.check(_lib.lib().sla_nrm2(r.h, C.byref(out)))
+    return out.value
+
+
+def convergence_note(ctx, st, n, r0norm, res_before):
+    """SURVEY 8(d) times >= 100 iterations per solver; a well-conditioned system converges sooner.  The kernels' work does not
+    depend on the data (no early exit in the step functions), so the timing stands -- but say so in the line."""
+    tol = max(1e-6, 1e-4 * r0norm)
+    res_after = state_residual(ctx, st, n)
+    ok = np.isfinite(res_after)
+    return {"r0norm": r0norm, "tol": tol, "resnorm_before_timed_region": res_before, "resnorm_after": res_after if ok else None,
+            "converged_before_timed_region": bool(res_before <= tol),
+            "note": "step functions have no early exit: the timed kernels do the same work on a converged state (timing is data-independent)"}
+
+
+def side_block(name, dims, rp, ci, va, options, steps, warmup, rhs="A.1"):
+    """One more driver-timed block in the same process: lower (dims, rp, ci, va) on a fresh context with the typed knob settings
+    `options` (sla_ctx_set_option), time `steps` bicgstabSteps (barrier + sync on both sides) with every kernel event-timed.
+    SURVEY 8(d) protocol: >= 5 warm-ups; rhs "A.1" (configs 2 / 4: x* = 1) or "A.x*" with x* = N(0, 1), seed 7 (config 3)."""
+    import sla_amd as sla
+    steps, warmup = max(steps, 20), max(warmup, 5)
+    ctx = sla.Context(0).set_options(**options)
     n, nnz = dims[0], int(rp[-1])
     A = sla.fromCSRRows(dims, 0, rp, ci, va, ctx)
-    b = np.add.reduceat(va, rp[:-1])
-    st = sla.bicgsInit(A, sla.DeviceVector(ctx, n, b, local=True), sla.DeviceVector(ctx, n))
-    dt, _, _ = timed_steps(ctx, st, steps, warmup, ctx.sync)
+    if rhs == "A.1":
+        bvec = sla.DeviceVector(ctx, n, np.add.reduceat(va, rp[:-1]), local=True)
+    else:
+        xstar = sla.DeviceVector(ctx, n, np.random.Generator(np.random.PCG64(7)).standard_normal(n), local=True)
+        bvec = sla.DeviceVector(ctx, n)
+        from sla_amd import _lib
+        _lib.check(_lib.lib().sla_spmv(A.h, xstar.h, bvec.h))
+        del xstar
+    st = sla.bicgsInit(A, bvec, sla.DeviceVector(ctx, n))
+    r0norm = state_residual(ctx, st, n)
+    conv = {}
+    dt, _, _ = timed_steps(ctx, st, steps, warmup, ctx.sync, conv=conv)
     kt = kernel_table(ctx, A, nnz, n, "bicgstab")
     k1 = kt.get("K1", {})
-    rec = {"workload": name, "rows": n, "nnz": nnz, "steps": steps, "warmup": warmup, "env": env,
+    rec = {"workload": name, "rows": n, "nnz": nnz, "steps": steps, "warmup": warmup, "options": options, "rhs": rhs + ", x0 = 0",
+           "convergence": convergence_note(ctx, st, n, r0norm, conv.get("res_before", float("nan"))),
            "value": steps / dt, "unit": "iters/s", "ms_per_step": dt / steps * 1e3,
            "step_gbps_csr": (24 * nnz + 160 * n) / (dt / steps) / 1e9,
            "step_frac_of_hbm_peak_csr": (24 * nnz + 160 * n) / (dt / steps) / 1e9 / HBM_PEAK_GBS,
@@ -239,6 +282,46 @@ def side_block(name, dims, rp, ci, va, env, steps, warmup):
            "spmv_kernel": A.kernel_info()}
     del st, A
     ctx.close()
+    return rec
+
+
+def sharded_random_block(ctx, name, rank, world, sync_all, allreduce, steps, warmup):
+    """BASELINE config 3a (n rows, 16 random picks per row, symmetrised: ~33 entries per row) row-sharded over the ranks of `ctx`:
+    every rank assembles its own slab (workloads.random_spd_rows), b = A x* with x* = N(0, 1) seed 7 (SURVEY 8(d)), x0 = 0;
+    timed like the headline (barrier + sync on both sides, max over ranks).  Every rank must call this (collectives inside)."""
+    import sla_amd as sla
+    from sla_amd import _lib, workloads as wl
+    from sla_amd.partition import row_block
+    n, k = {"random_spd_10m": (10000000, 16), "random_spd_small": (60000, 16)}[name]
+    rb, re_ = row_block(n, rank, world)
+    t0 = time.perf_counter()
+    dims, (rp, ci, va) = wl.random_spd_rows(n, k, 42, rb, re_)
+    t_gen = time.perf_counter() - t0
+    nnz_local, n_local = int(rp[-1]), re_ - rb
+    A = sla.fromCSRRows(dims, rb, rp, ci, va, ctx)
+    del rp, ci, va
+    xstar = sla.DeviceVector(ctx, n, np.random.Generator(np.random.PCG64(7)).standard_normal(n)[rb:re_], local=True)
+    bvec = sla.DeviceVector(ctx, n)
+    _lib.check(_lib.lib().sla_spmv(A.h, xstar.h, bvec.h))
+    st = sla.bicgsInit(A, bvec, sla.DeviceVector(ctx, n))
+    r0norm = state_residual(ctx, st, n)
+    conv = {}
+    dt, _, _ = timed_steps(ctx, st, steps, warmup, sync_all, conv=conv)
+    dt = allreduce(dt, "max")
+    nnz = int(allreduce(nnz_local))
+    kt = kernel_table(ctx, A, nnz_local, n_local, "bicgstab")
+    ex = exchange_table(ctx)
+    note = convergence_note(ctx, st, n, r0norm, conv.get("res_before", float("nan")))
+    k1 = kt.get("K1", {})
+    rec = {"workload": f"{n}-row fp64 random SPD (~33 nnz/row), row-sharded x{world}", "rows": n, "nnz": nnz, "steps": steps, "warmup": warmup,
+           "rhs": "A.x* (x* = N(0,1), seed 7), x0 = 0", "convergence": note,
+           "value": steps / dt, "unit": "iters/s", "ms_per_step": dt / steps * 1e3,
+           "step_gbps_csr": (24 * nnz + 160 * n) / (dt / steps) / 1e9,
+           "step_frac_of_hbm_peak_csr": (24 * nnz + 160 * n) / (dt / steps) / 1e9 / (HBM_PEAK_GBS * world),
+           "k1_ms": k1.get("ms"), "k1_frac": k1.get("frac"), "k1_csr_frac": k1.get("effective_frac"),
+           "kernels_rank0": {k_: {"ms": v["ms"], "frac": v["frac"]} for k_, v in kt.items()},
+           "exchanges_rank0": ex, "spmv_kernel": A.kernel_info(), "slab_assembly_s": t_gen}
+    del st, A, bvec, xstar
     return rec
 
 
@@ -340,6 +423,8 @@ def run_rank(args, rank, world, local_rank, dist_mode, loop=None):
         extra["step_graph"] = bool(graph)
         dt, dom_stats, dom_id = timed_steps(ctx, st, args.steps, args.warmup, sync_all, event_free=graph)
         kt = kernel_table(ctx, A, nnz_local, n_local, args.method)
+        if dist_mode:
+            extra["exchanges"] = exchange_table(ctx)
         launches, mean_ms, min_ms = dom_stats
         step_bytes = 24 * nnz + 160 * n
         mode_desc = f"{'bicgstabStep' if args.method == 'bicgstab' else 'cgsStep'} (2 SpMV, no true-residual SpMV)"
@@ -390,6 +475,13 @@ def run_rank(args, rank, world, local_rank, dist_mode, loop=None):
 
     dt = allreduce(dt, "max")
 
+    # ---- N > 1: the north star's literal target next to the Laplacian -- the 10 M-row random matrix on the SAME sharded context
+    # (x all-gathered per SpMV: its rows reference all of x), so that the driver's 1/2/4/8 sweep yields a curve for it as well
+    rblock = None
+    rname = {"auto": {"laplace3d_10m": "random_spd_10m", "laplace3d_small": "random_spd_small"}.get(args.workload)}.get(args.random_block, args.random_block)
+    if dist_mode and args.mode == "step" and args.method == "bicgstab" and rname and rname != "none":
+        rblock = sharded_random_block(ctx, rname, rank, world, sync_all, allreduce, max(20, args.steps // 4), max(5, args.warmup // 2))
+
     # ---- plain SpMV bandwidth (rank-local rows; includes the exchange when sharded) -----------------------
     # Over ROTATING vector pairs: with one pair the 2 x 80 MB stay in the 256 MB memory-side cache (MALL) between
     # launches and the figure flatters the kernel; inside a solver the vectors never stay there.
@@ -410,16 +502,15 @@ def run_rank(args, rank, world, local_rank, dist_mode, loop=None):
     _, sp_cached_ms, _ = ctx.prof_stop()
     spmv_bytes_local = 12 * nnz_local + 20 * n_local
 
-    # ---- measured streaming ceiling of this GPU (triad-like y = a x + b y: 24 B per element), same rotation ----
-    triad_reps = 36
-    for i in range(pairs):
-        _lib.check(lib.sla_axpby(1.0, xs[i].h, 0.5, ys[i].h))
-    ctx.sync()
-    t0 = time.perf_counter()
-    for i in range(triad_reps):
-        _lib.check(lib.sla_axpby(1.0, xs[i % pairs].h, 0.5, ys[i % pairs].h))
-    ctx.sync()
-    triad_gbps = 24.0 * n_local * triad_reps / (time.perf_counter() - t0) / 1e9
+    # ---- measured streaming ceiling of this GPU: the access shape of the vector kernels themselves (sla_stream_probe: R vectors
+    # read + W written per element, 16 B per lane, same grid, non-temporal loads past the memory-side cache), HIP-event timed.
+    # Pure read (8 R), the K4+K5 sweep's shape (5 R + 3 W) and a triad (2 R + 1 W); the ceiling is the best of the three.
+    del xs[1:], ys[1:]
+    probes = {}
+    for nm, (r_, w_) in (("read_8r", (8, 0)), ("sweep_5r3w", (5, 3)), ("triad_2r1w", (2, 1))):
+        pm, pmin, pg = ctx.stream_probe(r_, w_, max(n_local, 2), 20)
+        probes[nm] = {"ms": pm, "min_ms": pmin, "gbps": pg, "bytes": 8 * (r_ + w_) * (max(n_local, 2) & ~1)}
+    triad_gbps = max(v["gbps"] for v in probes.values())
     comm_ranks = ctx.comm_ranks()
     sync_all()
     if rank != 0:
@@ -462,7 +553,8 @@ def run_rank(args, rank, world, local_rank, dist_mode, loop=None):
         "spmv_ms": sp_mean_ms,                     # rotating over `spmv_vector_pairs` x / y pairs (HBM-resident)
         "spmv_ms_cache_resident": sp_cached_ms,    # one pair re-used: x and y stay in the memory-side cache
         "spmv_vector_pairs": pairs,
-        "hbm_measured_ceiling_gbps": triad_gbps,   # axpby triad over the same rotating vectors, same run
+        "hbm_measured_ceiling_gbps": triad_gbps,   # best of the three probe shapes below (same run, same vector length)
+        "hbm_measured": probes,
     })
     # ---- roofline: the dominant kernel of the timed step -------------------------------------------------
     if kt:
@@ -512,11 +604,13 @@ def run_rank(args, rank, world, local_rank, dist_mode, loop=None):
                                                "prices the same time on the SURVEY 8(d) CSR bytes",
                            "avg_launch_ms": mean_ms, "min_launch_ms": min_ms, "launches_timed": launches}
     rec.update(extra)
+    if rblock:
+        rec[rname if rname != "random_spd_small" else "random_spd_10m"] = rblock
     # ---- the blocks the default line carries next to the headline (single GPU, default workload only) --------
     if world == 1 and args.mode == "step" and args.method == "bicgstab" and args.workload == "laplace3d_10m" and not args.no_extra_blocks:
-        bs, bw = max(10, args.steps // 2), max(3, args.warmup // 2)
+        bs, bw = max(20, args.steps // 2), max(5, args.warmup // 2)
         try:
-            rec["general_csr"] = side_block(desc, dims, rp, ci, va, {"SLA_WDIA": "0", "SLA_VDICT": "0", "SLA_DIAG": "0"}, bs, bw)
+            rec["general_csr"] = side_block(desc, dims, rp, ci, va, {"wdia": 0, "vdict": 0, "diag": 0}, bs, bw)
         except Exception as e:
             rec["general_csr"] = {"error": repr(e)}
     if not args.no_cpu_baseline and world == 1:
@@ -526,7 +620,7 @@ def run_rank(args, rank, world, local_rank, dist_mode, loop=None):
         rp = ci = va = None
         try:
             d3, (dm3, (rp3, ci3, va3)) = workload("random_spd_10m")
-            rec["random_spd_10m"] = side_block(d3, dm3, rp3, ci3, va3, {}, max(10, args.steps // 4), max(3, args.warmup // 2))
+            rec["random_spd_10m"] = side_block(d3, dm3, rp3, ci3, va3, {}, max(20, args.steps // 4), max(5, args.warmup // 2), rhs="A.x*")
         except Exception as e:
             rec["random_spd_10m"] = {"error": repr(e)}
     return rec
@@ -588,6 +682,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-blocks", action="store_true", help="skip the general_csr / random_spd_10m blocks of the default line")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--random-block", default="auto",
+                    help="N > 1: also time the row-sharded random SPD matrix on the same context (auto: random_spd_10m next to the default workload; none)")
     args = ap.parse_args()
 
     world_env = os.environ.get("WORLD_SIZE")

@@ -113,6 +113,12 @@ int sla_ctx_create_dist(int device_id, int rank, int nranks, const void *unique_
 int sla_ctx_create_loopback(int device_id, int rank, int nranks, int group_key, sla_ctx_t *out);
 int sla_ctx_destroy(sla_ctx_t);
 int sla_ctx_sync(sla_ctx_t);  /* hipStreamSynchronize of the context stream */
+/* Typed entry for the tuning / A-B knobs of DESIGN.md section 4 (the same table the SLA_* environment variables feed when a
+ * context is created): name = the lower-case knob name without the SLA_ prefix ("wdia", "tile_shift", "x_exchange", ...),
+ * value = its textual value ("0", "17", "window").  Knobs that steer the lowering apply to matrices created AFTERWARDS.  On a
+ * multi-device parent the option is set on every rank context.  Unknown name / value out of range => SLA_ERR_INVALID. */
+int sla_ctx_set_option(sla_ctx_t, const char *name, const char *value);
+int sla_ctx_get_option(sla_ctx_t, const char *name, char *buf, int buflen);
 int sla_ctx_rank(sla_ctx_t, int *rank, int *nranks);
 /* rows [begin, end) of an m-row matrix / m-vector owned by this rank (contiguous 1-D row blocks) */
 int sla_ctx_row_range(sla_ctx_t, int64_t m, int64_t *begin, int64_t *end);
@@ -271,6 +277,10 @@ typedef enum {
     SLA_KERNEL_CGS_C2 = 8,    /* alpha ; q = u - alpha A p ; u + q ; x += alpha (u + q) */
     SLA_KERNEL_CGS_C4 = 9,    /* beta ; u = r + beta q ; p = u + beta (q + beta p) */
     SLA_KERNEL_BICG_K45 = 10, /* K4 + K5 in one sweep (single-rank flow; K3 then also sums As . r0hat and s . r0hat) */
+    SLA_KERNEL_EXCHANGE = 11, /* row-sharded: the exchange of an SpMV's input vector (ncclAllGather, or the grouped halo ncclSend/ncclRecv),
+                                 events on the stream it is issued on (the second stream when it overlaps the interior rows) */
+    SLA_KERNEL_SUMS = 12,     /* row-sharded: per-rank partial sums made global (finalize + all-gather; in the ghost-row flows the grouped
+                                 exchange that also carries a halo) */
     SLA_KERNEL_COUNT = 16
 } sla_kernel_id;
 /* record up to `max_launches` event pairs around launches of `kernel_id` (SLA_KERNEL_ALL: of every kernel above) from now on */
@@ -279,6 +289,15 @@ int sla_prof_start(sla_ctx_t, int kernel_id, int max_launches);
 int sla_prof_stop(sla_ctx_t, int *launches, double *mean_ms, double *min_ms);
 /* after sla_prof_stop: the same statistics for one kernel id of the last recording */
 int sla_prof_query(sla_ctx_t, int kernel_id, int *launches, double *mean_ms, double *min_ms);
+/* What this GPU sustains for the access shape of the solver's vector kernels: `reads` vectors read and `writes` vectors written
+ * per element (16 bytes per lane, the grid of the BLAS-1 kernels, non-temporal loads once the footprint overflows the
+ * memory-side cache), `reps` launches timed one by one with HIP events.  (reads, writes) = (8, 0) pure read, (5, 3) the K4+K5
+ * sweep, (2, 1) a triad.  bench.py's "measured ceiling": bytes = 8 (reads + writes) n per launch. */
+int sla_stream_probe(sla_ctx_t, int reads, int writes, int64_t n, int reps, double *mean_ms, double *min_ms);
+/* SLA_DEBUG_BINDING=1: launches, copies, collectives or device allocations issued by a thread that is not inside an entry
+ * point bound to the context they belong to (HIP's current device is per thread: the bug class of multi-device fan-out,
+ * invisible on a one-GPU box).  0 in a correct library; the GPU test suites assert it under the debug switch. */
+long sla_debug_binding_violations(void);
 /* number of HIP devices visible to this process (0 without a GPU; never fails) */
 int sla_device_count(int *count);
 /* ranks of the communicator behind this context: ncclCommCount for an RCCL communicator, the group size for the loopback

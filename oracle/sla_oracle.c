@@ -214,6 +214,34 @@ void orc_par_copy_f64(int64_t n, const double *src, double *dst) {
 }
 
 static double *vnew(int64_t n) { return (double *)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1)); }
+/* Temporaries of the step functions.  The faithful single-thread build allocates and frees them per step, as it always did.
+ * The OpenMP TIMING build (liboracle_omp.so, "fair CPU" leg of bench.py, never used for parity) keeps them: five 80 MB
+ * malloc / free pairs per step meant mmap + first-touch page faults inside every timed iteration.  New buffers
+ * are first-touched row-parallel so that their pages sit with the threads that work on them. */
+#ifdef ORC_OMP
+#define ORC_TMP_SLOTS 8
+static double *tmp_pool[ORC_TMP_SLOTS];
+static int64_t tmp_pool_n[ORC_TMP_SLOTS];
+static double *tnew(int64_t n) {
+    for (int i = 0; i < ORC_TMP_SLOTS; ++i)
+        if (tmp_pool[i] && tmp_pool_n[i] == n) { double *p = tmp_pool[i]; tmp_pool[i] = NULL; return p; }
+    double *p = vnew(n);
+    if (p) {
+#pragma omp parallel for schedule(static)
+        for (int64_t i = 0; i < n; ++i) p[i] = 0.0;
+    }
+    return p;
+}
+static void tfree(double *p, int64_t n) {
+    if (!p) return;
+    for (int i = 0; i < ORC_TMP_SLOTS; ++i)
+        if (!tmp_pool[i]) { tmp_pool[i] = p; tmp_pool_n[i] = n; return; }
+    free(p);
+}
+#else
+static double *tnew(int64_t n) { return vnew(n); }
+static void tfree(double *p, int64_t n) { (void)n; free(p); }
+#endif
 
 /* ---------------------------------------------------------------- A5: BiCGSTAB */
 
@@ -232,7 +260,7 @@ void orc_bicgstab_init(const orc_csr *A, const double *b, const double *x0, doub
 /* bicgstabStep (Sparse.hs:972-981) */
 int orc_bicgstab_step(const orc_csr *A, const double *r0hat, double *x, double *r, double *p) {
     int64_t n = A->m;
-    double *aap = vnew(n), *s = vnew(n), *aas = vnew(n), *t = vnew(n), *t2 = vnew(n);
+    double *aap = tnew(n), *s = tnew(n), *aas = tnew(n), *t = tnew(n), *t2 = tnew(n);
     if (!aap || !s || !aas || !t || !t2) return ORC_ERR_ALLOC;
     orc_spmv(A->m, A->rowptr, A->colidx, A->val, p, aap);          /* aap = aa #> p          */
     double rr0 = orc_dot(n, r, r0hat);
@@ -253,8 +281,8 @@ int orc_bicgstab_step(const orc_csr *A, const double *r0hat, double *x, double *
     orc_sub(n, p, t, t);                                            /* p ^-^ omega.*aap       */
     orc_scale(n, beta, t, t);
     orc_add(n, rnew, t, p);                                         /* pj1                    */
-    memcpy(r, rnew, sizeof(double) * (size_t)n);
-    free(aap); free(s); free(aas); free(t); free(t2);
+    orc_par_copy_f64(n, rnew, r);
+    tfree(aap, n); tfree(s, n); tfree(aas, n); tfree(t, n); tfree(t2, n);
     return ORC_OK;
 }
 
@@ -271,7 +299,7 @@ void orc_cgs_init(const orc_csr *A, const double *b, const double *x0, double *x
 /* cgsStep (Sparse.hs:928-939) */
 int orc_cgs_step(const orc_csr *A, const double *rhat, double *x, double *r, double *p, double *u) {
     int64_t n = A->m;
-    double *aap = vnew(n), *q = vnew(n), *uq = vnew(n), *t = vnew(n), *auq = vnew(n);
+    double *aap = tnew(n), *q = tnew(n), *uq = tnew(n), *t = tnew(n), *auq = tnew(n);
     if (!aap || !q || !uq || !t || !auq) return ORC_ERR_ALLOC;
     orc_spmv(A->m, A->rowptr, A->colidx, A->val, p, aap);           /* aap = aa #> p          */
     double rr = orc_dot(n, r, rhat);
@@ -291,7 +319,7 @@ int orc_cgs_step(const orc_csr *A, const double *rhat, double *x, double *r, dou
     orc_add(n, q, t, t);                                            /* q ^+^ beta.*p          */
     orc_scale(n, beta, t, t);
     orc_add(n, u, t, p);                                            /* pj1                    */
-    free(aap); free(q); free(uq); free(t); free(auq);
+    tfree(aap, n); tfree(q, n); tfree(uq, n); tfree(t, n); tfree(auq, n);
     return ORC_OK;
 }
 

@@ -5,6 +5,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstring>
 #include <thread>
@@ -16,6 +17,29 @@ namespace sla {
 
 static thread_local std::string g_last_error;
 void set_error(const std::string &msg) { g_last_error = msg; }
+
+// ---- device binding (sla_internal.hpp) -------------------------------------------------------------------------
+static thread_local const sla_ctx *t_bound = nullptr;
+int g_debug_binding = [] { const char *e = getenv("SLA_DEBUG_BINDING"); return e ? atoi(e) : 0; }();
+static std::atomic<long> g_binding_violations{0};
+const sla_ctx *bound_ctx() { return t_bound; }
+Bind::Bind(const sla_ctx *c) : prev(t_bound) {
+    if (!c || !c->kids.empty()) return;   // (a parent context owns no device: its rank contexts are bound on their worker threads)
+    if (!prev || prev->device != c->device) (void)hipSetDevice(c->device);
+    t_bound = c;
+}
+Bind::~Bind() {
+    if (prev && t_bound && prev->device != t_bound->device) (void)hipSetDevice(prev->device);
+    t_bound = prev;
+}
+void binding_violation(const sla_ctx *c, const char *what) {
+    const long k = ++g_binding_violations;
+    if (k <= 20)
+        fprintf(stderr, "[sla] BINDING VIOLATION #%ld: %s for context %p (rank %d, device %d) on a thread bound to %p\n", k, what, (const void *)c,
+                c ? c->rank : -1, c ? c->device : -1, (const void *)t_bound);
+    if (g_debug_binding >= 2) abort();
+}
+long binding_violations() { return g_binding_violations.load(); }
 int fail(int code, const std::string &msg) {
     g_last_error = msg;
     return code;
@@ -25,14 +49,20 @@ ProfScope::ProfScope(sla_ctx *ctx, int kernel_id) : c(ctx), on(false) {
     if (kernel_id >= 0 && (c->prof_kernel == kernel_id || c->prof_kernel == SLA_KERNEL_ALL) && c->prof_count < c->prof_max) {
         on = true;
         c->prof_ids[(size_t)c->prof_count] = kernel_id;
-        (void)hipEventRecord(c->prof_ev[2 * (size_t)c->prof_count], c->stream);
+        (void)hipEventRecord(c->prof_ev[2 * (size_t)c->prof_count], stream_of(c));
     }
 }
 ProfScope::~ProfScope() {
     if (on) {
-        (void)hipEventRecord(c->prof_ev[2 * (size_t)c->prof_count + 1], c->stream);
+        (void)hipEventRecord(c->prof_ev[2 * (size_t)c->prof_count + 1], stream_of(c));
         c->prof_count++;
     }
+}
+
+// A single-device handle combined with a bundle of a multi-device context (or with a handle of another context) passes the
+// dimension checks -- a bundle carries n but no device pointer -- and would fault on the device: refuse it here.
+int mixed_handles(const char *what) {
+    return fail(SLA_ERR_INVALID, std::string(what) + ": operands must all come from the same context (a multi-device bundle cannot be combined with a single-device handle)");
 }
 
 static int64_t shard_of(const sla_ctx *c, int64_t n) { return (n + c->nranks - 1) / c->nranks; }
@@ -48,7 +78,7 @@ static int ensure_xfull(sla_ctx *c, int64_t count) {
     if (c->d_xfull) (void)guard_free(c->d_xfull);
     c->d_xfull = nullptr;
     c->xfull_cap = 0;
-    SLA_HIP_TRY(guard_malloc((void **)&c->d_xfull, sizeof(double) * (size_t)std::max<int64_t>(count, 1)));
+    SLA_HIP_TRY(guard_malloc(c, (void **)&c->d_xfull, sizeof(double) * (size_t)std::max<int64_t>(count, 1)));
     c->xfull_cap = count;
     return SLA_OK;
 }
@@ -62,8 +92,10 @@ int gather_raw(sla_ctx *c, const sla_csr *A, const double *local, int64_t shard,
     SLA_TRY(ensure_xfull(c, shard * c->nranks));
     if (A && A->xplan && c->x_exchange != 1 && (A->xplan->use_window || c->x_exchange == 2)) {
         const int64_t b = std::min<int64_t>(A->n, shard * c->rank), e = std::min<int64_t>(A->n, shard * (c->rank + 1));
+        ProfScope prof(c, SLA_KERNEL_EXCHANGE);
         SLA_TRY(dist_exchange_window(c, *A->xplan, local, b, e - b, c->d_xfull));
     } else {
+        ProfScope prof(c, SLA_KERNEL_EXCHANGE);
         SLA_TRY(dist_allgather_f64(c, local, c->d_xfull, shard));
     }
     *base = c->d_xfull;
@@ -96,6 +128,7 @@ int gather_x(const sla_csr *A, sla_vec *x, const double **base) {
             const XPlan &pl = *A->xplan;
             static const bool dbg = getenv("SLA_DEBUG_EXCHANGE") != nullptr;
             if (dbg) fprintf(stderr, "[sla] rank %d: in-place halo exchange (own rows %lld..%lld)\n", c->rank, (long long)b, (long long)(b + x->n_local));
+            ProfScope prof(c, SLA_KERNEL_EXCHANGE);
             SLA_TRY(dist_exchange_window(c, pl, x->d, b, x->n_local, x->d - b));
             *base = x->d - b;
             return SLA_OK;
@@ -121,11 +154,11 @@ static int build_xplan(sla_csr *A, int64_t rows, const int64_t *rowptr, const in
     }
     // ship the two int64 as raw 8-byte words through the f64 all-gather (no arithmetic touches them)
     double *d = c->d_result + 64;
-    SLA_HIP_TRY(hipMemcpyAsync(d, w, sizeof(w), hipMemcpyHostToDevice, c->stream));
+    SLA_HIP_TRY(hipMemcpyAsync(d, w, sizeof(w), hipMemcpyHostToDevice, stream_of(c)));
     SLA_TRY(dist_allgather_f64(c, d, d + 8, 2));
     std::vector<int64_t> all((size_t)2 * c->nranks);
-    SLA_HIP_TRY(hipMemcpyAsync(all.data(), d + 8, sizeof(int64_t) * all.size(), hipMemcpyDeviceToHost, c->stream));
-    SLA_HIP_TRY(hipStreamSynchronize(c->stream));
+    SLA_HIP_TRY(hipMemcpyAsync(all.data(), d + 8, sizeof(int64_t) * all.size(), hipMemcpyDeviceToHost, stream_of(c)));
+    SLA_HIP_TRY(hipStreamSynchronize(stream_of(c)));
     A->xplan = new XPlan();
     plan_window_exchange(c->nranks, c->rank, A->n, all.data(), *A->xplan);
     return SLA_OK;
@@ -149,8 +182,8 @@ static int build_overlap_lists(sla_csr *A, int64_t m, int64_t n, int64_t row_beg
         (bnd[(size_t)s] ? lb : li).push_back(s);
     }
     if (lb.empty() || li.size() < lb.size()) return SLA_OK;   // nothing to exchange for / too little to hide it behind
-    SLA_HIP_TRY(hipMalloc((void **)&A->d_ov_int, sizeof(int32_t) * li.size()));
-    SLA_HIP_TRY(hipMalloc((void **)&A->d_ov_bnd, sizeof(int32_t) * lb.size()));
+    SLA_HIP_TRY(dev_malloc(c, (void **)&A->d_ov_int, sizeof(int32_t) * li.size()));
+    SLA_HIP_TRY(dev_malloc(c, (void **)&A->d_ov_bnd, sizeof(int32_t) * lb.size()));
     SLA_HIP_TRY(hipMemcpy(A->d_ov_int, li.data(), sizeof(int32_t) * li.size(), hipMemcpyHostToDevice));
     SLA_HIP_TRY(hipMemcpy(A->d_ov_bnd, lb.data(), sizeof(int32_t) * lb.size(), hipMemcpyHostToDevice));
     A->ov_nint = (int32_t)li.size();
@@ -178,22 +211,27 @@ int spmv_exchanged(sla_csr *A, sla_vec *x, SpmvLaunch l, int *np) {
             SLA_HIP_TRY(hipEventCreateWithFlags(&c->ev_x_ready, hipEventDisableTiming));
             SLA_HIP_TRY(hipEventCreateWithFlags(&c->ev_x_done, hipEventDisableTiming));
         }
-        SLA_HIP_TRY(hipEventRecord(c->ev_x_ready, c->stream));
+        SLA_HIP_TRY(hipEventRecord(c->ev_x_ready, stream_of(c)));
         SLA_HIP_TRY(hipStreamWaitEvent(c->comm_stream, c->ev_x_ready, 0));
         hipStream_t compute = c->stream;
         c->stream = c->comm_stream;   // (the exchange enqueues on "the context stream")
-        const int rc = dist_exchange_window(c, *A->xplan, x->d, b, x->n_local, x->d - b);
+        int rc;
+        {
+            ProfScope prof(c, SLA_KERNEL_EXCHANGE);   // (events on the comm stream)
+            rc = dist_exchange_window(c, *A->xplan, x->d, b, x->n_local, x->d - b);
+        }
         c->stream = compute;
         SLA_TRY(rc);
         SLA_HIP_TRY(hipEventRecord(c->ev_x_done, c->comm_stream));
     } else {
+        ProfScope prof(c, SLA_KERNEL_EXCHANGE);
         SLA_TRY(dist_exchange_window(c, *A->xplan, x->d, b, x->n_local, x->d - b));
     }
     l.x = x->d - b;
     SpmvLaunch li = l;
     li.part = 1;
     SLA_TRY(launch_spmv(A, li));
-    if (c->overlap > 0) SLA_HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_x_done, 0));
+    if (c->overlap > 0) SLA_HIP_TRY(hipStreamWaitEvent(stream_of(c), c->ev_x_done, 0));
     const int gi = overlap_grid(A, 1);
     SpmvLaunch lb = l;
     lb.part = 2;
@@ -215,8 +253,8 @@ int reduce_to_host(sla_ctx *c, const double *p1, const double *p2, int np, doubl
         SLA_TRY(launch_finalize_cols(c, c->d_result + 16, c->nranks, 1, 2, 2, c->d_result + 8));
         src = c->d_result + 8;
     }
-    SLA_HIP_TRY(hipMemcpyAsync(c->h_result, src, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    SLA_HIP_TRY(hipStreamSynchronize(c->stream));
+    SLA_HIP_TRY(hipMemcpyAsync(c->h_result, src, 2 * sizeof(double), hipMemcpyDeviceToHost, stream_of(c)));
+    SLA_HIP_TRY(hipStreamSynchronize(stream_of(c)));
     out[0] = c->h_result[0];
     if (p2) out[1] = c->h_result[1];
     return SLA_OK;
@@ -232,7 +270,7 @@ static hipError_t pool_alloc(sla_ctx *c, size_t bytes, void **p) {
         c->vec_pool_bytes -= bytes;
         return hipSuccess;
     }
-    return guard_malloc(p, bytes, c->vec_guard);
+    return guard_malloc(c, p, bytes, c->vec_guard);
 }
 
 static void pool_free(sla_ctx *c, void *p, size_t bytes) {
@@ -259,7 +297,7 @@ int vec_alloc(sla_ctx *c, int64_t n, sla_vec **out) {
         delete v;
         return fail(SLA_ERR_ALLOC, std::string("hipMalloc(vector): ") + hipGetErrorString(err));
     }
-    err = hipMemsetAsync(v->d, 0, sizeof(double) * (size_t)std::max<int64_t>(v->shard, 1), c->stream);
+    err = hipMemsetAsync(v->d, 0, sizeof(double) * (size_t)std::max<int64_t>(v->shard, 1), stream_of(c));
     if (err != hipSuccess) {
         pool_free(c, v->d, sizeof(double) * (size_t)std::max<int64_t>(v->shard, 1));
         delete v;
@@ -320,7 +358,7 @@ static int build_panels(sla_csr *A, int64_t m, int64_t n, int64_t row_begin, int
         V->is_panel_view = true;
         A->panels.push_back(V);
     }
-    SLA_HIP_TRY(hipMalloc((void **)&A->d_panel_y, sizeof(double) * (size_t)std::max<int64_t>(rows, 1)));
+    SLA_HIP_TRY(dev_malloc(c, (void **)&A->d_panel_y, sizeof(double) * (size_t)std::max<int64_t>(rows, 1)));
     return SLA_OK;
 }
 
@@ -372,7 +410,7 @@ struct Low {
     std::vector<uint8_t> dcodes;        // per entry: index into offs
     void upload(void **dst, const void *src, size_t bytes) {
         if (err != hipSuccess) return;
-        err = hipMalloc(dst, std::max<size_t>(bytes, 8));
+        err = dev_malloc(c, dst, std::max<size_t>(bytes, 8));
         if (err == hipSuccess && bytes) err = hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
     }
 };
@@ -400,8 +438,8 @@ static void low_csr_arrays(Low &L) {
         ~Joiner() { if (t.joinable()) t.join(); }
     };
     std::thread val_up([&] {
-        err_val = hipSetDevice(c->device);
-        if (err_val == hipSuccess) err_val = hipMalloc((void **)&A->d_val, std::max<size_t>(sizeof(double) * (size_t)nnz, 8));
+        Bind bind(c);   // (a new thread starts on device 0)
+        if (err_val == hipSuccess) err_val = dev_malloc(c, (void **)&A->d_val, std::max<size_t>(sizeof(double) * (size_t)nnz, 8));
         if (err_val == hipSuccess && nnz) err_val = hipMemcpy(A->d_val, val, sizeof(double) * (size_t)nnz, hipMemcpyHostToDevice);
     });
     Joiner val_up_joiner{val_up};
@@ -829,7 +867,7 @@ static void low_lds_panels(Low &L) {
                 std::vector<int32_t> pp32(pp.begin(), pp.end());
                 upload(&A->d_lpp, pp32.data(), sizeof(int32_t) * pp32.size());
             }
-            if (err == hipSuccess) err = hipMalloc((void **)&A->d_lpy, sizeof(double) * (size_t)(P * rows));
+            if (err == hipSuccess) err = dev_malloc(c, (void **)&A->d_lpy, sizeof(double) * (size_t)(P * rows));
             // row chunks: ~32 tasks per workgroup of the persistent grid (measured: 8 -> 0.936 ms, 32 -> 0.900 ms, 64 ->
             // 0.902 ms on the 200k-row 1 % matrix), at least 64 rows (4 per wavefront) each
             const int tasks_per_cu = std::max(1, c->lp_tasks);
@@ -1009,13 +1047,13 @@ int spmv_transposed(sla_csr *A, const double *x_local, double *y_local, int64_t 
         if (c->d_tfull) (void)hipFree(c->d_tfull);
         c->d_tfull = nullptr;
         c->tfull_cap = 0;
-        SLA_HIP_TRY(hipMalloc((void **)&c->d_tfull, sizeof(double) * (size_t)std::max<int64_t>(full, 1)));
-        SLA_HIP_TRY(hipMemsetAsync(c->d_tfull, 0, sizeof(double) * (size_t)std::max<int64_t>(full, 1), c->stream));
+        SLA_HIP_TRY(dev_malloc(c, (void **)&c->d_tfull, sizeof(double) * (size_t)std::max<int64_t>(full, 1)));
+        SLA_HIP_TRY(hipMemsetAsync(c->d_tfull, 0, sizeof(double) * (size_t)std::max<int64_t>(full, 1), stream_of(c)));
         c->tfull_cap = full;
     }
     // the padding rows [n, shard * nranks) must read as zero in the reduce-scatter (an earlier, larger matrix may have left
     // its partials there: the buffer is per context, not per matrix)
-    if (full > T->m) SLA_HIP_TRY(hipMemsetAsync(c->d_tfull + T->m, 0, sizeof(double) * (size_t)(full - T->m), c->stream));
+    if (full > T->m) SLA_HIP_TRY(hipMemsetAsync(c->d_tfull + T->m, 0, sizeof(double) * (size_t)(full - T->m), stream_of(c)));
     l.y = c->d_tfull;
     SLA_TRY(launch_spmv(T, l));
     return dist_reduce_scatter_f64(c, c->d_tfull, y_local, y_shard);
@@ -1028,48 +1066,106 @@ using namespace sla;
 extern "C" {
 
 const char *sla_last_error(void) { return g_last_error.c_str(); }
+long sla_debug_binding_violations(void) { return binding_violations(); }
 const char *sla_version(void) { return "sla_hip 0.1 (gfx950)"; }
 
-// The A/B and test knobs ("Knobs"): every one defaults to the measured-best setting; they are read ONCE, when a
-// context is created, from this one table.
+// The A/B and test knobs ("Knobs"): every one defaults to the measured-best setting.  ONE table serves both
+// ways of setting them: sla_ctx_set_option(ctx, "wdia", "0") -- the typed, per-context entry of the ABI -- and the environment
+// (SLA_WDIA=0, read once when a context is created).  A knob that steers the lowering takes effect for matrices created afterwards.
+namespace {
+struct IntKnob { const char *name; int sla_ctx::*field; int lo, hi; };
+const IntKnob kIntKnobs[] = {
+    {"step_graph", &sla_ctx::step_graph, -1, 1},
+    {"xcd_remap", &sla_ctx::xcd_remap, 0, 1},
+    {"dual_spmv", &sla_ctx::dual_spmv, 0, 1},
+    {"xwin", &sla_ctx::xwin, 0, 1},
+    {"diag", &sla_ctx::diag, 0, 1},
+    {"vdict", &sla_ctx::vdict, 0, 1},
+    {"wdia", &sla_ctx::wdia, 0, 1},
+    {"lpanel", &sla_ctx::lpanel, 0, 1},
+    {"lp_tasks", &sla_ctx::lp_tasks, 1, 1 << 20},
+    {"lp_cfg", &sla_ctx::lp_cfg, -1, 3},
+    {"lp_minseg", &sla_ctx::lp_min_seg, 1, 1 << 20},
+    {"lp_rowcost", &sla_ctx::lp_rowcost, 0, 1 << 20},
+    {"force_rp64", &sla_ctx::force_rp64, 0, 2},
+    {"bicg_ghost", &sla_ctx::bicg_ghost, 0, 1},
+    {"wd_tile", &sla_ctx::wd_tile, -1, 1 << 20},
+    {"bicg_fuse45", &sla_ctx::bicg_fuse45, 0, 1},
+    {"wd_lds", &sla_ctx::wd_lds, 0, 2},
+    {"wd_lds_occ", &sla_ctx::wd_lds_occ, 0, 4},
+    {"wd_nt_store", &sla_ctx::wd_nt_store, 0, 1},
+    {"wdia_vv", &sla_ctx::wdia_vv, 0, 1},
+    {"vec_nt", &sla_ctx::vec_nt, -1, 1},
+    {"halo_inplace", &sla_ctx::halo_inplace, 0, 1},
+    {"panels", &sla_ctx::panels, 0, 1},
+    {"overlap", &sla_ctx::overlap, -1, 1},
+    {"tiles", &sla_ctx::tiles, 0, 1},
+    {"tile_shift", &sla_ctx::tile_shift, 0, 20},
+    {"tile_slack", &sla_ctx::tile_slack, 0, 64},
+    {"row_align", &sla_ctx::row_align, 0, 256},
+    {"rb_nnz", &sla_ctx::rb_nnz, 0, 1024},
+    {"spmv_grid", &sla_ctx::spmv_grid_max, 1, kMaxParts},
+};
+const char *const kOtherKnobs[] = {"wd_grid", "spmv_algo", "panel_cols", "device_coo_min", "x_exchange"};
+
+// one option, by its lower-case name; false: unknown name or value out of range
+bool ctx_apply_option(sla_ctx *c, const std::string &name, const char *value) {
+    for (const IntKnob &k : kIntKnobs)
+        if (name == k.name) {
+            char *end = nullptr;
+            const long v = strtol(value, &end, 10);
+            if (end == value || v < k.lo || v > k.hi) return false;
+            c->*(k.field) = (int)v;
+            return true;
+        }
+    if (name == "wd_grid") {        // persistent grid of the wave-sliced kernels (a multiple of 8: one share per XCD)
+        const int g = atoi(value);
+        if (g < 8 || g > kMaxParts) return false;
+        c->wd_grid_max = g & ~7;
+        return true;
+    }
+    if (name == "spmv_algo") {
+        if (strcmp(value, "scalar") != 0 && strcmp(value, "stream") != 0) return false;
+        c->spmv_algo = strcmp(value, "scalar") == 0 ? 1 : 0;
+        return true;
+    }
+    if (name == "panel_cols") { c->panel_cols = atoll(value); return c->panel_cols > 0; }
+    if (name == "device_coo_min") { c->device_coo_min = atoll(value); return true; }
+    if (name == "x_exchange") {
+        if (strcmp(value, "allgather") == 0) c->x_exchange = 1;
+        else if (strcmp(value, "window") == 0) c->x_exchange = 2;
+        else if (strcmp(value, "auto") == 0) c->x_exchange = 0;
+        else return false;
+        return true;
+    }
+    return false;
+}
+std::string ctx_option_value(const sla_ctx *c, const std::string &name, bool *known) {
+    *known = true;
+    for (const IntKnob &k : kIntKnobs)
+        if (name == k.name) return std::to_string(c->*(k.field));
+    if (name == "wd_grid") return std::to_string(c->wd_grid_max);
+    if (name == "spmv_algo") return c->spmv_algo == 1 ? "scalar" : "stream";
+    if (name == "panel_cols") return std::to_string(c->panel_cols);
+    if (name == "device_coo_min") return std::to_string(c->device_coo_min);
+    if (name == "x_exchange") return c->x_exchange == 1 ? "allgather" : c->x_exchange == 2 ? "window" : "auto";
+    *known = false;
+    return "";
+}
+std::string env_name(const char *knob) {
+    std::string e = "SLA_";
+    for (const char *p = knob; *p; ++p) e += (char)toupper((unsigned char)*p);
+    return e;
+}
+}  // namespace
+
 static void ctx_read_knobs(sla_ctx *c) {
-    static const struct { const char *env; int sla_ctx::*field; } kIntKnobs[] = {
-        {"SLA_STEP_GRAPH", &sla_ctx::step_graph},
-        {"SLA_XCD_REMAP", &sla_ctx::xcd_remap},
-        {"SLA_DUAL_SPMV", &sla_ctx::dual_spmv},
-        {"SLA_XWIN", &sla_ctx::xwin},
-        {"SLA_DIAG", &sla_ctx::diag},
-        {"SLA_VDICT", &sla_ctx::vdict},
-        {"SLA_WDIA", &sla_ctx::wdia},
-        {"SLA_LPANEL", &sla_ctx::lpanel},
-        {"SLA_LP_TASKS", &sla_ctx::lp_tasks},
-        {"SLA_LP_CFG", &sla_ctx::lp_cfg},
-        {"SLA_FORCE_RP64", &sla_ctx::force_rp64},
-        {"SLA_BICG_GHOST", &sla_ctx::bicg_ghost},
-        {"SLA_WD_TILE", &sla_ctx::wd_tile},
-        {"SLA_BICG_FUSE45", &sla_ctx::bicg_fuse45},
-        {"SLA_WD_LDS", &sla_ctx::wd_lds},
-        {"SLA_WD_LDS_OCC", &sla_ctx::wd_lds_occ},
-        {"SLA_WD_NT_STORE", &sla_ctx::wd_nt_store},
-        {"SLA_WDIA_VV", &sla_ctx::wdia_vv},
-        {"SLA_VEC_NT", &sla_ctx::vec_nt},
-        {"SLA_HALO_INPLACE", &sla_ctx::halo_inplace},
-        {"SLA_PANELS", &sla_ctx::panels},
-        {"SLA_OVERLAP", &sla_ctx::overlap},
-        {"SLA_TILES", &sla_ctx::tiles},
-        {"SLA_TILE_SHIFT", &sla_ctx::tile_shift},
-        {"SLA_TILE_SLACK", &sla_ctx::tile_slack},
-        {"SLA_ROW_ALIGN", &sla_ctx::row_align},
-        {"SLA_RB_NNZ", &sla_ctx::rb_nnz},
+    auto from_env = [&](const char *knob) {
+        if (const char *s = getenv(env_name(knob).c_str()))
+            if (!ctx_apply_option(c, knob, s)) fprintf(stderr, "[sla] ignoring %s=%s (unknown value)\n", env_name(knob).c_str(), s);
     };
-    for (const auto &k : kIntKnobs)
-        if (const char *s = getenv(k.env)) c->*(k.field) = atoi(s);
-    if (const char *s = getenv("SLA_SPMV_ALGO")) c->spmv_algo = (strcmp(s, "scalar") == 0) ? 1 : 0;
-    if (const char *s = getenv("SLA_LP_MINSEG")) c->lp_min_seg = std::max(1, atoi(s));
-    if (const char *s = getenv("SLA_LP_ROWCOST")) c->lp_rowcost = std::max(0, atoi(s));
-    if (const char *s = getenv("SLA_PANEL_COLS")) c->panel_cols = atoll(s);
-    if (const char *s = getenv("SLA_DEVICE_COO_MIN")) c->device_coo_min = atoll(s);
-    if (const char *s = getenv("SLA_X_EXCHANGE")) c->x_exchange = strcmp(s, "allgather") == 0 ? 1 : (strcmp(s, "window") == 0 ? 2 : 0);
+    for (const IntKnob &k : kIntKnobs) from_env(k.name);
+    for (const char *k : kOtherKnobs) from_env(k);
 }
 
 static int ctx_create_common(int device_id, int rank, int nranks, const void *uid, sla_ctx_t *out) {
@@ -1084,17 +1180,17 @@ static int ctx_create_common(int device_id, int rank, int nranks, const void *ui
     c->device = device_id;
     c->rank = rank;
     c->nranks = nranks;
+    Bind bind(c);
     {   // (a failing allocation must not leak the half-built context)
         hipError_t he = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
-        if (he == hipSuccess) he = hipMalloc((void **)&c->d_parts, sizeof(double) * 4 * kMaxParts);
-        if (he == hipSuccess) he = hipMalloc((void **)&c->d_result, sizeof(double) * 4096);
+        if (he == hipSuccess) he = dev_malloc(c, (void **)&c->d_parts, sizeof(double) * 4 * kMaxParts);
+        if (he == hipSuccess) he = dev_malloc(c, (void **)&c->d_result, sizeof(double) * 4096);
         if (he == hipSuccess) he = hipHostMalloc((void **)&c->h_result, sizeof(double) * 64, hipHostMallocDefault);
         if (he != hipSuccess) {
             sla_ctx_destroy(c);
             return fail(SLA_ERR_HIP, std::string("sla_ctx_create: ") + hipGetErrorString(he));
         }
     }
-    ctx_read_knobs(c);
     {
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess && cus > 0) {
@@ -1103,14 +1199,7 @@ static int ctx_create_common(int device_id, int rank, int nranks, const void *ui
             c->wd_grid_max_vv = std::min<int>(kMaxParts, std::max(8, (kWdBlocksPerCuVV * cus) & ~7));
         }
     }
-    if (const char *s = getenv("SLA_WD_GRID")) {
-        const int g = atoi(s);
-        if (g >= 8 && g <= kMaxParts) c->wd_grid_max = g & ~7;
-    }
-    if (const char *s = getenv("SLA_SPMV_GRID")) {
-        int g = atoi(s);
-        if (g >= 1 && g <= kMaxParts) c->spmv_grid_max = g;
-    }
+    ctx_read_knobs(c);   // (after the device-derived defaults: SLA_WD_GRID overrides the per-CU grid)
     if (uid) {
         int rc = dist_comm_init(c, uid);
         if (rc != SLA_OK) {
@@ -1139,6 +1228,7 @@ int sla_ctx_create_dist(int device_id, int rank, int nranks, const void *unique_
 
 int sla_ctx_create_loopback(int device_id, int rank, int nranks, int group_key, sla_ctx_t *out) {
     SLA_TRY(ctx_create_common(device_id, rank, nranks, nullptr, out));
+    Bind bind(*out);
     int rc = dist_loopback_join(*out, group_key);
     if (rc != SLA_OK) {
         sla_ctx_destroy(*out);
@@ -1153,7 +1243,7 @@ int sla_ctx_create_loopback(int device_id, int rank, int nranks, int group_key, 
 int sla_ctx_destroy(sla_ctx_t c) {
     if (c && !c->kids.empty()) return m_ctx_destroy(c);
     if (!c) return SLA_OK;
-    (void)hipSetDevice(c->device);
+    Bind bind(c);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     dist_comm_destroy(c);
     for (auto &kv : c->vec_pool) (void)guard_free(kv.second, c->vec_guard);
@@ -1175,7 +1265,29 @@ int sla_ctx_destroy(sla_ctx_t c) {
 int sla_ctx_sync(sla_ctx_t c) {
     if (c && !c->kids.empty()) return m_ctx_sync(c);
     if (!c) return fail(SLA_ERR_INVALID, "null context");
-    SLA_HIP_TRY(hipStreamSynchronize(c->stream));
+    Bind bind(c);
+    SLA_HIP_TRY(hipStreamSynchronize(stream_of(c)));
+    return SLA_OK;
+}
+
+int sla_ctx_set_option(sla_ctx_t c, const char *name, const char *value) {
+    if (!c || !name || !value) return fail(SLA_ERR_INVALID, "sla_ctx_set_option: null argument");
+    if (!c->kids.empty()) {
+        for (sla_ctx *k : c->kids) SLA_TRY(sla_ctx_set_option(k, name, value));
+        return SLA_OK;
+    }
+    if (!ctx_apply_option(c, name, value))
+        return fail(SLA_ERR_INVALID, std::string("sla_ctx_set_option: unknown option or value out of range: ") + name + "=" + value);
+    return SLA_OK;
+}
+
+int sla_ctx_get_option(sla_ctx_t c, const char *name, char *buf, int buflen) {
+    if (c && !c->kids.empty()) return sla_ctx_get_option(c->kids[0], name, buf, buflen);
+    if (!c || !name || !buf || buflen <= 0) return fail(SLA_ERR_INVALID, "sla_ctx_get_option: null argument");
+    bool known = false;
+    const std::string v = ctx_option_value(c, name, &known);
+    if (!known) return fail(SLA_ERR_INVALID, std::string("sla_ctx_get_option: unknown option ") + name);
+    snprintf(buf, (size_t)buflen, "%s", v.c_str());
     return SLA_OK;
 }
 
@@ -1202,6 +1314,7 @@ int sla_csr_from_coo(sla_ctx_t c, int64_t m, int64_t n, int64_t nnz, const int64
     if (c && !c->kids.empty()) return m_csr_from_coo(c, m, n, nnz, row, col, val, dup_policy, out);
     return no_throw("sla_csr_from_coo", [&]() -> int {
         if (!c || !out || (nnz > 0 && (!row || !col || !val))) return fail(SLA_ERR_INVALID, "sla_csr_from_coo: null argument");
+        Bind bind(c);
         HostCsr h;
         if (!c->collectives && nnz >= c->device_coo_min && device_coo_supported(m, n, nnz)) {
             if (m < 0 || n < 0) return fail(SLA_ERR_INVALID, "negative dimension");
@@ -1213,7 +1326,6 @@ int sla_csr_from_coo(sla_ctx_t c, int64_t m, int64_t n, int64_t nnz, const int64
             });
             if (std::find(oob.begin(), oob.end(), (char)1) != oob.end())
                 return fail(SLA_ERR_OOB, "insertSpMatrix : index out of bounds");
-            (void)hipSetDevice(c->device);
             SLA_TRY(device_coo_to_csr(c, m, n, nnz, row, col, val, dup_policy, h));
             // already canonical by construction: skip the validation pass of sla_csr_from_csr
             return csr_upload(c, m, n, 0, m, h.rowptr.data(), h.col.data(), h.val.data(), out);
@@ -1228,6 +1340,7 @@ int sla_csr_from_csr(sla_ctx_t c, int64_t m, int64_t n, const int64_t *rowptr, c
     if (c && !c->kids.empty()) return m_csr_from_csr(c, m, n, rowptr, colidx, val, out);
     return no_throw("sla_csr_from_csr", [&]() -> int {
         if (!c || !out || !rowptr || m < 0 || n < 0) return fail(SLA_ERR_INVALID, "sla_csr_from_csr: bad argument");
+        Bind bind(c);
         int64_t b, e;
         row_range(c, m, &b, &e);
         if (c->nranks == 1) return sla_csr_from_csr_rows(c, m, n, 0, m, rowptr, colidx, val, out);
@@ -1243,6 +1356,7 @@ int sla_csr_from_csr_rows(sla_ctx_t c, int64_t m, int64_t n, int64_t row_begin, 
     return no_throw("sla_csr_from_csr_rows", [&]() -> int {
         if (!c || !out || !rowptr_local || m < 0 || n < 0 || row_count < 0)
             return fail(SLA_ERR_INVALID, "sla_csr_from_csr_rows: bad argument");
+        Bind bind(c);
         int64_t b, e;
         row_range(c, m, &b, &e);
         if (row_begin != b || row_count != e - b)
@@ -1267,7 +1381,6 @@ int sla_csr_from_csr_rows(sla_ctx_t c, int64_t m, int64_t n, int64_t row_begin, 
         if (std::find(bad.begin(), bad.end(), 1) != bad.end()) return csr_reject(c, fail(SLA_ERR_OOB, "insertSpMatrix : index out of bounds"));
         if (std::find(bad.begin(), bad.end(), 2) != bad.end())
             return csr_reject(c, fail(SLA_ERR_INVALID, "columns must be strictly ascending inside a row (canonical CSR)"));
-        (void)hipSetDevice(c->device);
         return csr_upload(c, m, n, row_begin, row_count, rowptr_local, colidx, val, out);
     });
 }
@@ -1286,6 +1399,7 @@ int sla_jacobi_pre(sla_csr_t A, sla_csr_t *out) {
     return no_throw("sla_jacobi_pre", [&]() -> int {
         if (!A || !out) return fail(SLA_ERR_INVALID, "null argument");
         if (A->ctx->collectives) return fail(SLA_ERR_INVALID, "sla_jacobi_pre: single-rank contexts only");
+        Bind bind(A->ctx);
         HostCsr h, d;
         SLA_TRY(export_host(A, h));
         d.m = A->m;
@@ -1375,7 +1489,7 @@ static int tri_plan_build(sla_csr *T, int upper, int64_t *bad_row) {
     hipError_t e = hipSuccess;
     auto up = [&](void **dst, const void *src, size_t bytes) {
         if (e != hipSuccess) return;
-        e = hipMalloc(dst, std::max<size_t>(bytes, 8));
+        e = dev_malloc(T->ctx, dst, std::max<size_t>(bytes, 8));
         if (e == hipSuccess && bytes) e = hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
     };
     up((void **)&p->d_order, order.data(), sizeof(int32_t) * order.size());
@@ -1396,7 +1510,7 @@ int sla_tri_solve_info(sla_csr_t T, int upper, int64_t *levels, int64_t *widest_
     if (!T) return fail(SLA_ERR_INVALID, "null matrix");
     if (T->ctx->collectives || T->m != T->n) return fail(SLA_ERR_INVALID, "sla_tri_solve: square matrices on single-rank contexts only");
     upper = upper ? 1 : 0;
-    (void)hipSetDevice(T->ctx->device);
+    Bind bind(T->ctx);
     SLA_TRY(tri_plan_build(T, upper, nullptr));
     if (levels) *levels = T->tri[upper]->nlevels;
     if (widest_level) *widest_level = T->tri[upper]->widest;
@@ -1408,11 +1522,11 @@ int sla_tri_solve(sla_csr_t T, int upper, sla_vec_t b, sla_vec_t x, int64_t *bad
     return no_throw("sla_tri_solve", [&]() -> int {
         if (!T || !b || !x) return fail(SLA_ERR_INVALID, "null argument");
         sla_ctx *c = T->ctx;
+        Bind bind(c);
         if (c->collectives || T->m != T->n) return fail(SLA_ERR_INVALID, "sla_tri_solve: square matrices on single-rank contexts only");
         if (b->ctx != c || x->ctx != c || b->d == x->d) return fail(SLA_ERR_INVALID, "sla_tri_solve: b and x must be distinct vectors of the matrix's context");
         if (b->n != T->m || x->n != T->m) return fail(SLA_ERR_DIM_MISMATCH, "triangular solve : mismatched dimensions");
         upper = upper ? 1 : 0;
-        (void)hipSetDevice(c->device);
         SLA_TRY(tri_plan_build(T, upper, bad_row));
         sla_tri_plan *p = T->tri[upper];
         if (T->m == 0) return SLA_OK;
@@ -1420,12 +1534,12 @@ int sla_tri_solve(sla_csr_t T, int upper, sla_vec_t b, sla_vec_t x, int64_t *bad
             // capture the level launches once per (b, x) buffer pair; later solves with the same buffers replay the graph
             if (p->graph) { (void)hipGraphExecDestroy(p->graph); p->graph = nullptr; }
             hipGraph_t g = nullptr;
-            SLA_HIP_TRY(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+            SLA_HIP_TRY(hipStreamBeginCapture(stream_of(c), hipStreamCaptureModeThreadLocal));
             int rc = SLA_OK;
             for (int64_t l = 0; l < p->nlevels && rc == SLA_OK; ++l)
                 rc = launch_tri_level(T, p, p->level_ptr[(size_t)l], p->level_ptr[(size_t)l + 1] - p->level_ptr[(size_t)l], b->d, x->d);
             if (rc == SLA_OK) rc = launch_tri_sparsify(c, T->m, x->d);
-            const hipError_t e = hipStreamEndCapture(c->stream, &g);
+            const hipError_t e = hipStreamEndCapture(stream_of(c), &g);
             if (rc != SLA_OK) { if (g) (void)hipGraphDestroy(g); return rc; }
             SLA_HIP_TRY(e);
             const hipError_t ei = hipGraphInstantiate(&p->graph, g, nullptr, nullptr, 0);
@@ -1434,7 +1548,7 @@ int sla_tri_solve(sla_csr_t T, int upper, sla_vec_t b, sla_vec_t x, int64_t *bad
             p->gb = b->d;
             p->gx = x->d;
         }
-        SLA_HIP_TRY(hipGraphLaunch(p->graph, c->stream));
+        SLA_HIP_TRY(hipGraphLaunch(p->graph, stream_of(c)));
         return SLA_OK;
     });
 }
@@ -1445,6 +1559,7 @@ int sla_ssor_pre(sla_csr_t A, double omega, sla_csr_t *l, sla_csr_t *r) {
         if (!A || !l || !r) return fail(SLA_ERR_INVALID, "null argument");
         if (A->ctx->collectives) return fail(SLA_ERR_INVALID, "sla_ssor_pre: single-rank contexts only");
         if (A->m != A->n) return fail(SLA_ERR_DIM_MISMATCH, "mSsorPre : square matrices only");
+        Bind bind(A->ctx);
         HostCsr h, L, R;
         SLA_TRY(export_host(A, h));
         const int64_t n = A->m;
@@ -1490,6 +1605,7 @@ int sla_csr_diag_mul(sla_csr_t D, sla_csr_t A, sla_csr_t *out) {
         if (!D || !A || !out) return fail(SLA_ERR_INVALID, "null argument");
         if (D->ctx != A->ctx || A->ctx->collectives) return fail(SLA_ERR_INVALID, "sla_csr_diag_mul: one single-rank context");
         if (D->n != A->m) return fail(SLA_ERR_DIM_MISMATCH, "matMat : incompatible matrix sizes");  // SpMatrix.hs:795
+        Bind bind(A->ctx);
         HostCsr hd, ha, r;
         SLA_TRY(export_host(D, hd));
         SLA_TRY(export_host(A, ha));
@@ -1521,6 +1637,7 @@ int sla_csr_diag_mul(sla_csr_t D, sla_csr_t A, sla_csr_t *out) {
 int sla_csr_destroy(sla_csr_t A) {
     if (A && !A->kids.empty()) return m_csr_destroy(A);
     if (!A) return SLA_OK;
+    Bind bind(A->ctx);
     if (A->transposed) sla_csr_destroy(A->transposed);
     for (sla_csr *V : A->panels) sla_csr_destroy(V);
     if (A->d_panel_y) (void)hipFree(A->d_panel_y);
@@ -1574,7 +1691,8 @@ int sla_csr_export(sla_csr_t A, int64_t *rowptr, int64_t *colidx, double *val) {
     return no_throw("sla_csr_export", [&]() -> int {
         if (!A) return fail(SLA_ERR_INVALID, "null matrix");
         sla_ctx *c = A->ctx;
-        SLA_HIP_TRY(hipStreamSynchronize(c->stream));
+        Bind bind(c);
+        SLA_HIP_TRY(hipStreamSynchronize(stream_of(c)));
         if (rowptr) {
             if (A->rp64) {
                 SLA_HIP_TRY(hipMemcpy(rowptr, A->d_rowptr, sizeof(int64_t) * (size_t)(A->rows + 1), hipMemcpyDeviceToHost));
@@ -1661,12 +1779,12 @@ int sla_csr_kernel_info(sla_csr_t A, char *buf, int buflen) {
 int sla_vec_create(sla_ctx_t c, int64_t n, const double *host, sla_vec_t *out) {
     if (c && !c->kids.empty()) return m_vec_create(c, n, host, out);
     if (!c || !out || n < 0) return fail(SLA_ERR_INVALID, "sla_vec_create: bad argument");
-    (void)hipSetDevice(c->device);
+    Bind bind(c);
     sla_vec *v = nullptr;
     SLA_TRY(vec_alloc(c, n, &v));
     if (host && v->n_local > 0) {
-        hipError_t e = hipMemcpyAsync(v->d, host + v->begin, sizeof(double) * (size_t)v->n_local, hipMemcpyHostToDevice, c->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        hipError_t e = hipMemcpyAsync(v->d, host + v->begin, sizeof(double) * (size_t)v->n_local, hipMemcpyHostToDevice, stream_of(c));
+        if (e == hipSuccess) e = hipStreamSynchronize(stream_of(c));
         if (e != hipSuccess) {
             sla_vec_destroy(v);
             return fail(SLA_ERR_HIP, std::string("vector upload: ") + hipGetErrorString(e));
@@ -1679,12 +1797,12 @@ int sla_vec_create(sla_ctx_t c, int64_t n, const double *host, sla_vec_t *out) {
 int sla_vec_create_local(sla_ctx_t c, int64_t n, const double *host_local, sla_vec_t *out) {
     if (c && !c->kids.empty()) return m_vec_create(c, n, host_local, out);   // the caller of a multi-device context owns every row
     if (!c || !out || n < 0) return fail(SLA_ERR_INVALID, "sla_vec_create_local: bad argument");
-    (void)hipSetDevice(c->device);
+    Bind bind(c);
     sla_vec *v = nullptr;
     SLA_TRY(vec_alloc(c, n, &v));
     if (host_local && v->n_local > 0) {
-        hipError_t e = hipMemcpyAsync(v->d, host_local, sizeof(double) * (size_t)v->n_local, hipMemcpyHostToDevice, c->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        hipError_t e = hipMemcpyAsync(v->d, host_local, sizeof(double) * (size_t)v->n_local, hipMemcpyHostToDevice, stream_of(c));
+        if (e == hipSuccess) e = hipStreamSynchronize(stream_of(c));
         if (e != hipSuccess) {
             sla_vec_destroy(v);
             return fail(SLA_ERR_HIP, std::string("vector upload: ") + hipGetErrorString(e));
@@ -1697,6 +1815,7 @@ int sla_vec_create_local(sla_ctx_t c, int64_t n, const double *host_local, sla_v
 int sla_vec_destroy(sla_vec_t v) {
     if (v && !v->kids.empty()) return m_vec_destroy(v);
     if (!v) return SLA_OK;
+    Bind bind(v->ctx);
     pool_free(v->ctx, v->d, sizeof(double) * (size_t)std::max<int64_t>(v->shard, 1));
     delete v;
     return SLA_OK;
@@ -1713,9 +1832,10 @@ int sla_vec_to_host_local(sla_vec_t v, double *host_local) {
     if (v && !v->kids.empty()) return m_vec_to_host(v, host_local);
     if (!v || !host_local) return fail(SLA_ERR_INVALID, "null argument");
     sla_ctx *c = v->ctx;
+    Bind bind(c);
     if (v->n_local > 0)
-        SLA_HIP_TRY(hipMemcpyAsync(host_local, v->d, sizeof(double) * (size_t)v->n_local, hipMemcpyDeviceToHost, c->stream));
-    SLA_HIP_TRY(hipStreamSynchronize(c->stream));
+        SLA_HIP_TRY(hipMemcpyAsync(host_local, v->d, sizeof(double) * (size_t)v->n_local, hipMemcpyDeviceToHost, stream_of(c)));
+    SLA_HIP_TRY(hipStreamSynchronize(stream_of(c)));
     return SLA_OK;
 }
 
@@ -1723,20 +1843,23 @@ int sla_vec_to_host(sla_vec_t v, double *host) {
     if (v && !v->kids.empty()) return m_vec_to_host(v, host);
     if (!v || !host) return fail(SLA_ERR_INVALID, "null argument");
     sla_ctx *c = v->ctx;
+    Bind bind(c);
     if (!c->collectives) return sla_vec_to_host_local(v, host);
     const double *base = nullptr;
     SLA_TRY(gather_x(nullptr, v, &base));
-    SLA_HIP_TRY(hipMemcpyAsync(host, base, sizeof(double) * (size_t)v->n, hipMemcpyDeviceToHost, c->stream));
-    SLA_HIP_TRY(hipStreamSynchronize(c->stream));
+    SLA_HIP_TRY(hipMemcpyAsync(host, base, sizeof(double) * (size_t)v->n, hipMemcpyDeviceToHost, stream_of(c)));
+    SLA_HIP_TRY(hipStreamSynchronize(stream_of(c)));
     return SLA_OK;
 }
 
 int sla_vec_copy(sla_vec_t src, sla_vec_t dst) {
     if (src && !src->kids.empty()) return m_vec_copy(src, dst);
     if (!src || !dst) return fail(SLA_ERR_INVALID, "null vector");
+    if (!dst->kids.empty()) return mixed_handles("sla_vec_copy");
     if (src->n != dst->n || src->ctx != dst->ctx) return fail(SLA_ERR_DIM_MISMATCH, "sla_vec_copy: mismatched dimensions");
+    Bind bind(src->ctx);
     if (src->shard > 0)
-        SLA_HIP_TRY(hipMemcpyAsync(dst->d, src->d, sizeof(double) * (size_t)src->shard, hipMemcpyDeviceToDevice, src->ctx->stream));
+        SLA_HIP_TRY(hipMemcpyAsync(dst->d, src->d, sizeof(double) * (size_t)src->shard, hipMemcpyDeviceToDevice, stream_of(src->ctx)));
     return SLA_OK;
 }
 
@@ -1745,9 +1868,11 @@ int sla_vec_copy(sla_vec_t src, sla_vec_t dst) {
 int sla_spmv(sla_csr_t A, sla_vec_t x, sla_vec_t y) {
     if (A && !A->kids.empty()) return m_spmv(A, x, y, false);
     if (!A || !x || !y) return fail(SLA_ERR_INVALID, "null argument");
+    if (!x->kids.empty() || !y->kids.empty() || x->ctx != A->ctx || y->ctx != A->ctx) return mixed_handles("sla_spmv");
     if (A->n != x->n) return fail(SLA_ERR_DIM_MISMATCH, "matVec : mismatched dimensions");  // Common.hs:250
     if (A->m != y->n) return fail(SLA_ERR_DIM_MISMATCH, "matVec : result vector has the wrong dimension");
     if (x == y) return fail(SLA_ERR_INVALID, "sla_spmv: x and y must be distinct");
+    Bind bind(A->ctx);
     SpmvLaunch l;
     l.y = y->d;
     l.kernel_id = SLA_KERNEL_SPMV;
@@ -1758,9 +1883,11 @@ int sla_spmv_t(sla_csr_t A, sla_vec_t x, sla_vec_t y) {
     if (A && !A->kids.empty()) return m_spmv(A, x, y, true);
     return no_throw("sla_spmv_t", [&]() -> int {
         if (!A || !x || !y) return fail(SLA_ERR_INVALID, "null argument");
+        if (!x->kids.empty() || !y->kids.empty() || x->ctx != A->ctx || y->ctx != A->ctx) return mixed_handles("sla_spmv_t");
         if (A->m != x->n) return fail(SLA_ERR_DIM_MISMATCH, "vecMat : mismatching dimensions");  // Common.hs:256
         if (A->n != y->n) return fail(SLA_ERR_DIM_MISMATCH, "vecMat : result vector has the wrong dimension");
         if (x == y) return fail(SLA_ERR_INVALID, "sla_spmv_t: x and y must be distinct");
+        Bind bind(A->ctx);
         return spmv_transposed(A, x->d, y->d, y->shard);
     });
 }
@@ -1768,11 +1895,13 @@ int sla_spmv_t(sla_csr_t A, sla_vec_t x, sla_vec_t y) {
 int sla_dot(sla_vec_t x, sla_vec_t y, double *out) {
     if (x && !x->kids.empty()) return out ? m_dot(x, y, out) : fail(SLA_ERR_INVALID, "null argument");
     if (!x || !y || !out) return fail(SLA_ERR_INVALID, "null argument");
+    if (!y->kids.empty()) return mixed_handles("sla_dot");
     if (x->ctx != y->ctx) return fail(SLA_ERR_INVALID, "vectors from different contexts");
     // the reference's liftI2 takes max of the dims and never checks (SpVector.hs:64); dense device
     // vectors need equal length
     if (x->n != y->n) return fail(SLA_ERR_DIM_MISMATCH, "<.> : mismatched dimensions");
     sla_ctx *c = x->ctx;
+    Bind bind(c);
     SLA_TRY(launch_dot(c, x->n_local, x->d, y->d, c->d_parts));
     return reduce_to_host(c, c->d_parts, nullptr, vec_grid(x->n_local), out);
 }
@@ -1788,13 +1917,16 @@ int sla_nrm2(sla_vec_t x, double *out) {
 int sla_axpby(double a, sla_vec_t x, double b, sla_vec_t y) {
     if (x && !x->kids.empty()) return m_axpby(a, x, b, y);
     if (!x || !y) return fail(SLA_ERR_INVALID, "null argument");
+    if (!y->kids.empty()) return mixed_handles("sla_axpby");
     if (x->n != y->n || x->ctx != y->ctx) return fail(SLA_ERR_DIM_MISMATCH, "^+^ : mismatched dimensions");
+    Bind bind(x->ctx);
     return launch_axpby(x->ctx, x->n_local, a, x->d, b, y->d);
 }
 
 int sla_scal(double a, sla_vec_t x) {
     if (x && !x->kids.empty()) return m_scal(a, x);
     if (!x) return fail(SLA_ERR_INVALID, "null argument");
+    Bind bind(x->ctx);
     return launch_scal(x->ctx, x->n_local, a, x->d);
 }
 
@@ -1818,6 +1950,7 @@ int sla_plan_window_exchange(int nranks, int rank, int64_t n, const int64_t *win
 int sla_prof_start(sla_ctx_t c, int kernel_id, int max_launches) {
     if (c && !c->kids.empty()) { for (sla_ctx *k : c->kids) SLA_TRY(sla_prof_start(k, kernel_id, max_launches)); return SLA_OK; }
     if (!c || max_launches < 0 || kernel_id < SLA_KERNEL_ALL || kernel_id >= SLA_KERNEL_COUNT) return fail(SLA_ERR_INVALID, "sla_prof_start: bad argument");
+    Bind bind(c);
     while ((int)c->prof_ev.size() < 2 * max_launches) {
         hipEvent_t ev;
         SLA_HIP_TRY(hipEventCreate(&ev));
@@ -1869,7 +2002,8 @@ int sla_ctx_comm_ranks(sla_ctx_t c, int *nranks) {
 int sla_prof_stop(sla_ctx_t c, int *launches, double *mean_ms, double *min_ms) {
     if (c && !c->kids.empty()) { for (size_t r = c->kids.size(); r-- > 1;) SLA_TRY(sla_prof_stop(c->kids[r], nullptr, nullptr, nullptr)); return sla_prof_stop(c->kids[0], launches, mean_ms, min_ms); }
     if (!c) return fail(SLA_ERR_INVALID, "null context");
-    SLA_HIP_TRY(hipStreamSynchronize(c->stream));
+    Bind bind(c);
+    SLA_HIP_TRY(hipStreamSynchronize(stream_of(c)));
     c->prof_ms.assign((size_t)c->prof_count, 0.f);
     for (int i = 0; i < c->prof_count; ++i)
         SLA_HIP_TRY(hipEventElapsedTime(&c->prof_ms[(size_t)i], c->prof_ev[2 * (size_t)i], c->prof_ev[2 * (size_t)i + 1]));

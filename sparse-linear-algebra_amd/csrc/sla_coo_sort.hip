@@ -81,7 +81,7 @@ bool device_coo_supported(int64_t m, int64_t n, int64_t nnz) {
 // Indices must already be bounds-checked by the caller.  Synchronises the context stream.
 int device_coo_to_csr(sla_ctx *c, int64_t m, int64_t n, int64_t nnz, const int64_t *row, const int64_t *col,
                       const double *val, int dup_policy, HostCsr &out) {
-    hipStream_t st = c->stream;
+    hipStream_t st = stream_of(c);
     DevBuf d_row, d_col, d_val, d_key, d_key2, d_idx, d_idx2, d_flag, d_pos, d_tmp, d_colo, d_valo, d_rowo, d_rp;
     const size_t N = (size_t)nnz;
     SLA_HIP_TRY(d_row.alloc(8 * N));

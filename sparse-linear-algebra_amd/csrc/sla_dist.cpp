@@ -193,19 +193,19 @@ int dist_comm_count(sla_ctx *ctx, int *nranks) {
 
 int dist_allgather_f64(sla_ctx *ctx, const double *send, double *recv, int64_t count) {
     if (LoopGroup *g = loop_of(ctx)) {
-        SLA_HIP_TRY(hipStreamSynchronize(ctx->stream));
+        SLA_HIP_TRY(hipStreamSynchronize(stream_of(ctx)));
         g->ptr[(size_t)ctx->rank] = send;
         g->barrier();
         for (int q = 0; q < ctx->nranks; ++q)
             if (recv + (size_t)q * (size_t)count != g->ptr[(size_t)q])   // (in place: the own slot is already there)
                 SLA_HIP_TRY(hipMemcpyAsync(recv + (size_t)q * (size_t)count, g->ptr[(size_t)q], sizeof(double) * (size_t)count,
-                                           hipMemcpyDeviceToDevice, ctx->stream));
-        SLA_HIP_TRY(hipStreamSynchronize(ctx->stream));
+                                           hipMemcpyDeviceToDevice, stream_of(ctx)));
+        SLA_HIP_TRY(hipStreamSynchronize(stream_of(ctx)));
         g->barrier();
         return SLA_OK;
     }
     if (!ctx->comm) return fail(SLA_ERR_RCCL, "all-gather requested on a context without a communicator");
-    int rc = rccl().all_gather(send, recv, (size_t)count, kNcclFloat64, (NcclComm)ctx->comm, ctx->stream);
+    int rc = rccl().all_gather(send, recv, (size_t)count, kNcclFloat64, (NcclComm)ctx->comm, stream_of(ctx));
     if (rc != 0) return rccl_fail("ncclAllGather", rc);
     return SLA_OK;
 }
@@ -213,7 +213,7 @@ int dist_allgather_f64(sla_ctx *ctx, const double *send, double *recv, int64_t c
 // sum over ranks of full-length partial vectors, each rank keeping its shard (sharded transpose SpMV)
 int dist_reduce_scatter_f64(sla_ctx *ctx, const double *send, double *recv, int64_t recvcount) {
     if (LoopGroup *g = loop_of(ctx)) {
-        SLA_HIP_TRY(hipStreamSynchronize(ctx->stream));
+        SLA_HIP_TRY(hipStreamSynchronize(stream_of(ctx)));
         g->ptr[(size_t)ctx->rank] = send;
         g->barrier();
         std::vector<double> acc((size_t)recvcount, 0.0), tmp((size_t)recvcount);
@@ -228,7 +228,7 @@ int dist_reduce_scatter_f64(sla_ctx *ctx, const double *send, double *recv, int6
     }
     Rccl &r = rccl();
     if (!ctx->comm || !r.reduce_scatter) return fail(SLA_ERR_RCCL, "reduce-scatter requested without a communicator");
-    int rc = r.reduce_scatter(send, recv, (size_t)recvcount, kNcclFloat64, 0 /* ncclSum */, (NcclComm)ctx->comm, ctx->stream);
+    int rc = r.reduce_scatter(send, recv, (size_t)recvcount, kNcclFloat64, 0 /* ncclSum */, (NcclComm)ctx->comm, stream_of(ctx));
     if (rc != 0) return rccl_fail("ncclReduceScatter", rc);
     return SLA_OK;
 }
@@ -239,19 +239,19 @@ int dist_reduce_scatter_f64(sla_ctx *ctx, const double *send, double *recv, int6
 // instead of an all-gather of the whole vector.
 int dist_exchange_window(sla_ctx *ctx, const XPlan &plan, const double *xlocal, int64_t my_begin, int64_t n_local, double *xfull) {
     if (LoopGroup *g = loop_of(ctx)) {
-        SLA_HIP_TRY(hipStreamSynchronize(ctx->stream));
+        SLA_HIP_TRY(hipStreamSynchronize(stream_of(ctx)));
         g->ptr[(size_t)ctx->rank] = xlocal;
         g->aux[(size_t)ctx->rank] = my_begin;
         g->barrier();
         if (n_local > 0 && xfull + my_begin != xlocal)
-            SLA_HIP_TRY(hipMemcpyAsync(xfull + my_begin, xlocal, sizeof(double) * (size_t)n_local, hipMemcpyDeviceToDevice, ctx->stream));
+            SLA_HIP_TRY(hipMemcpyAsync(xfull + my_begin, xlocal, sizeof(double) * (size_t)n_local, hipMemcpyDeviceToDevice, stream_of(ctx)));
         for (int q = 0; q < ctx->nranks; ++q) {
             if (q == ctx->rank || plan.recv_len[(size_t)q] <= 0) continue;
             const double *src = (const double *)g->ptr[(size_t)q] + (plan.recv_begin[(size_t)q] - g->aux[(size_t)q]);
             SLA_HIP_TRY(hipMemcpyAsync(xfull + plan.recv_begin[(size_t)q], src, sizeof(double) * (size_t)plan.recv_len[(size_t)q],
-                                       hipMemcpyDeviceToDevice, ctx->stream));
+                                       hipMemcpyDeviceToDevice, stream_of(ctx)));
         }
-        SLA_HIP_TRY(hipStreamSynchronize(ctx->stream));
+        SLA_HIP_TRY(hipStreamSynchronize(stream_of(ctx)));
         g->barrier();
         return SLA_OK;
     }
@@ -259,17 +259,17 @@ int dist_exchange_window(sla_ctx *ctx, const XPlan &plan, const double *xlocal, 
     if (!ctx->comm) return fail(SLA_ERR_RCCL, "window exchange requested on a context without a communicator");
     if (!r.send || !r.recv || !r.group_start || !r.group_end) return fail(SLA_ERR_RCCL, "librccl lacks ncclSend/ncclRecv");
     if (n_local > 0 && xfull + my_begin != xlocal)
-        SLA_HIP_TRY(hipMemcpyAsync(xfull + my_begin, xlocal, sizeof(double) * (size_t)n_local, hipMemcpyDeviceToDevice, ctx->stream));
+        SLA_HIP_TRY(hipMemcpyAsync(xfull + my_begin, xlocal, sizeof(double) * (size_t)n_local, hipMemcpyDeviceToDevice, stream_of(ctx)));
     int rc = r.group_start();
     if (rc != 0) return rccl_fail("ncclGroupStart", rc);
     for (int q = 0; q < ctx->nranks; ++q) {
         if (q == ctx->rank) continue;
         if (plan.recv_len[(size_t)q] > 0) {
-            rc = r.recv(xfull + plan.recv_begin[(size_t)q], (size_t)plan.recv_len[(size_t)q], kNcclFloat64, q, (NcclComm)ctx->comm, ctx->stream);
+            rc = r.recv(xfull + plan.recv_begin[(size_t)q], (size_t)plan.recv_len[(size_t)q], kNcclFloat64, q, (NcclComm)ctx->comm, stream_of(ctx));
             if (rc != 0) { r.group_end(); return rccl_fail("ncclRecv", rc); }
         }
         if (plan.send_len[(size_t)q] > 0) {
-            rc = r.send(xlocal + (plan.send_begin[(size_t)q] - my_begin), (size_t)plan.send_len[(size_t)q], kNcclFloat64, q, (NcclComm)ctx->comm, ctx->stream);
+            rc = r.send(xlocal + (plan.send_begin[(size_t)q] - my_begin), (size_t)plan.send_len[(size_t)q], kNcclFloat64, q, (NcclComm)ctx->comm, stream_of(ctx));
             if (rc != 0) { r.group_end(); return rccl_fail("ncclSend", rc); }
         }
     }
@@ -285,14 +285,14 @@ int dist_allgather_p2p_f64(sla_ctx *ctx, const double *send, double *recv, int64
     Rccl &r = rccl();
     if (!r.send || !r.recv || !r.group_start || !r.group_end) return dist_allgather_f64(ctx, send, recv, count);
     if (send != recv + (size_t)ctx->rank * (size_t)count)   // (in-place callers already hold their own slot)
-        SLA_HIP_TRY(hipMemcpyAsync(recv + (size_t)ctx->rank * (size_t)count, send, sizeof(double) * (size_t)count, hipMemcpyDeviceToDevice, ctx->stream));
+        SLA_HIP_TRY(hipMemcpyAsync(recv + (size_t)ctx->rank * (size_t)count, send, sizeof(double) * (size_t)count, hipMemcpyDeviceToDevice, stream_of(ctx)));
     int rc = r.group_start();
     if (rc != 0) return rccl_fail("ncclGroupStart", rc);
     for (int q = 0; q < ctx->nranks; ++q) {   // every rank posts its transfers in the same (peer-ascending, recv-then-send) order
         if (q == ctx->rank) continue;
-        rc = r.recv(recv + (size_t)q * (size_t)count, (size_t)count, kNcclFloat64, q, (NcclComm)ctx->comm, ctx->stream);
+        rc = r.recv(recv + (size_t)q * (size_t)count, (size_t)count, kNcclFloat64, q, (NcclComm)ctx->comm, stream_of(ctx));
         if (rc != 0) { r.group_end(); return rccl_fail("ncclRecv", rc); }
-        rc = r.send(send, (size_t)count, kNcclFloat64, q, (NcclComm)ctx->comm, ctx->stream);
+        rc = r.send(send, (size_t)count, kNcclFloat64, q, (NcclComm)ctx->comm, stream_of(ctx));
         if (rc != 0) { r.group_end(); return rccl_fail("ncclSend", rc); }
     }
     rc = r.group_end();
@@ -359,11 +359,11 @@ int dist_allreduce_max_i32(sla_ctx *ctx, int *value_host) {
     }
     if (!ctx->collectives || !ctx->comm) return SLA_OK;
     int *d = (int *)ctx->d_result;
-    SLA_HIP_TRY(hipMemcpyAsync(d, value_host, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-    int rc = rccl().all_reduce(d, d, 1, kNcclInt32, kNcclMax, (NcclComm)ctx->comm, ctx->stream);
+    SLA_HIP_TRY(hipMemcpyAsync(d, value_host, sizeof(int), hipMemcpyHostToDevice, stream_of(ctx)));
+    int rc = rccl().all_reduce(d, d, 1, kNcclInt32, kNcclMax, (NcclComm)ctx->comm, stream_of(ctx));
     if (rc != 0) return rccl_fail("ncclAllReduce", rc);
-    SLA_HIP_TRY(hipMemcpyAsync(value_host, d, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    SLA_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    SLA_HIP_TRY(hipMemcpyAsync(value_host, d, sizeof(int), hipMemcpyDeviceToHost, stream_of(ctx)));
+    SLA_HIP_TRY(hipStreamSynchronize(stream_of(ctx)));
     return SLA_OK;
 }
 

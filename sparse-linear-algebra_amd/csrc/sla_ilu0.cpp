@@ -51,6 +51,7 @@ extern "C" int sla_ilu0_pre(sla_csr_t A, int exact_lu, sla_csr_t *l_out, sla_csr
         if (!A || !l_out || !u_out) return fail(SLA_ERR_INVALID, "sla_ilu0_pre: null argument");
         sla_ctx *c = A->ctx;
         if (c->collectives) return fail(SLA_ERR_INVALID, "sla_ilu0_pre: single-rank contexts only");
+        Bind bind(c);
         if (A->m != A->n) return fail(SLA_ERR_DIM_MISMATCH, "ilu0Pre : the matrix must be square");
         const int64_t n = A->m;
         if (exact_lu && n > kIluExactMaxN)

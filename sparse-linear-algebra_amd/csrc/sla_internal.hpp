@@ -154,6 +154,7 @@ void plan_window_exchange(int nranks, int rank, int64_t n, const int64_t *window
 // ---------------------------------------------------------------------------------------------
 struct sla_ctx {
     std::vector<sla_ctx *> kids;     // non-empty: the PARENT of a single-process multi-device group (sla_multi.cpp); nothing below is used then
+    void *pool = nullptr;            // parent only: its persistent per-rank worker threads
     int device = 0, rank = 0, nranks = 1;
     hipStream_t stream = nullptr;
     void *comm = nullptr;            // ncclComm_t when nranks > 1 (or a 1-rank test comm)
@@ -176,6 +177,7 @@ struct sla_ctx {
                                      // the exchange serialised on the compute stream (A/B, bit-identical), -1 no split at all (SLA_OVERLAP)
     hipStream_t comm_stream = nullptr;   // created on first use
     hipEvent_t ev_x_ready = nullptr, ev_x_done = nullptr;
+    int xcd8 = -1;                   // 1: the device dispatches workgroup b to XCD b % 8 of 8 (probed once: what the tile kernel's panel pacing relies on), 0: it does not
     int tiles = 1;                   // allow the row-slice x column-panel tile SpMV for irregular matrices with x > L2 (SLA_TILES=0: column-panel passes)
     int tile_slack = 3;              // panel pacing: a wavefront starts panel step q once its XCD has finished step q - slack (SLA_TILE_SLACK, 0: no pacing)
     int tile_shift = 0;              // log2 of its panel width in columns (SLA_TILE_SHIFT; 0: 17 from 6 M columns on, 16 below -- at 10 M rows slack 3 / shift 17: 1.98 ms, slack 4: 2.18, slack 2: 2.1, shift 16: 2.03-2.28, shift 18: +15 %)
@@ -337,6 +339,7 @@ struct sla_solver {
     sla::SolverScalars *d_sc = nullptr;
     sla::SolverScalars *h_sc = nullptr;  // pinned
     bool have_res = false;               // d_parts[RES] holds the residual of the current x
+    bool step_graph_failed = false;      // capture / instantiation failed once: this state record keeps to plain stream launches
     hipGraphExec_t step_graph = nullptr; // two consecutive steps (even, odd parity) captured for replay (sla_solver_step, launch-bound sizes)
     // sharded BiCGSTAB with ghost rows (sla_solvers.cpp): r, p, Ap and s are kept valid on the ghl / ghr rows this
     // rank's SpMV reads from its neighbours, so a step needs 3 grouped exchanges instead of 5
@@ -384,15 +387,45 @@ namespace sla {
 inline bool wd_lds_on(const sla_csr *A) { return A->wd_lds && !A->wd_vv && (A->ctx->wd_lds == 2 || (A->ctx->wd_lds == 1 && A->nblk_wd >= 16 * 4 * A->ctx->n_cu)); }
 inline bool wd_on(const sla_csr *A) { return A->wd_vv ? (A->ctx->wdia && A->ctx->wdia_vv) : A->ctx->wdia != 0; }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Device binding.  HIP's current device is a per-THREAD setting and a new thread starts on device 0, so every C-ABI entry
+// point that can allocate, launch or call RCCL opens a `Bind` on its context first (hipSetDevice + a thread-local "this
+// thread is working for context c" token): the rank contexts of sla_ctx_create_multi are driven from worker threads, and
+// a caller may hop between contexts on different devices.  SLA_DEBUG_BINDING=1 makes the class of bug testable on a
+// one-GPU box, where every device id is 0 and a wrong current device is invisible: stream_of() (every launch, copy and
+// collective takes its stream through it) and dev_malloc() then require the calling thread to be inside an entry point
+// bound to THAT context; violations are counted (sla_debug_binding_violations) and reported on stderr, =2 aborts.
+struct Bind {
+    const sla_ctx *prev;
+    explicit Bind(const sla_ctx *c);
+    ~Bind();
+    Bind(const Bind &) = delete;
+    Bind &operator=(const Bind &) = delete;
+};
+extern int g_debug_binding;                                   // SLA_DEBUG_BINDING, read once
+void binding_violation(const sla_ctx *c, const char *what);   // out of line: count, report, maybe abort
+const sla_ctx *bound_ctx();
+inline void check_bound(const sla_ctx *c, const char *what) {
+    if (g_debug_binding && bound_ctx() != c) binding_violation(c, what);
+}
+inline hipStream_t stream_of(const sla_ctx *c) {
+    check_bound(c, "stream use");
+    return c->stream;
+}
+inline hipError_t dev_malloc(const sla_ctx *c, void **p, size_t bytes) {
+    check_bound(c, "hipMalloc");
+    return hipMalloc(p, bytes);
+}
+
 // Guarded device allocation for everything an SpMV may gather from (vectors, the exchange landing buffer, the
 // Arnoldi basis): kGuardBytes of readable slack on both sides.  spmv_wdia_kernel gathers row PAIRS with one
 // 16-byte load; when only one row of a pair holds an entry, the other half may lie one element outside
 // [0, n) -- inside the slack, never used (the fold is masked per row).
 // On sharded contexts the vectors get kHaloBytes instead: the window (halo) exchange then receives the neighbours' planes
 // straight into the slack around the rank's own rows, and the SpMV gathers from `vector - first_row` with no copy at all.
-inline hipError_t guard_malloc(void **p, size_t bytes, size_t guard = kGuardBytes) {
+inline hipError_t guard_malloc(const sla_ctx *c, void **p, size_t bytes, size_t guard = kGuardBytes) {
     void *raw = nullptr;
-    const hipError_t e = hipMalloc(&raw, bytes + 2 * guard);
+    const hipError_t e = dev_malloc(c, &raw, bytes + 2 * guard);
     if (e == hipSuccess) *p = (char *)raw + guard;
     return e;
 }
@@ -401,6 +434,8 @@ inline hipError_t guard_free(void *p, size_t guard = kGuardBytes) { return p ? h
 // error plumbing ---------------------------------------------------------------------------------
 void set_error(const std::string &msg);
 int fail(int code, const std::string &msg);
+int mixed_handles(const char *what);
+long binding_violations();
 // No C++ exception may cross the C ABI: a failed host allocation inside an entry point becomes SLA_ERR_ALLOC.
 template <class F>
 inline int no_throw(const char *what, F body) {
@@ -513,6 +548,7 @@ int launch_spmv_tiles(const sla_csr *A, const SpmvLaunch &l);   // sla_spmv_tile
 int launch_wdia_lds(const sla_csr *A, int epi, const SpmvArgs<int32_t> &a, const int32_t *sched, int32_t nblk, int grid, int stream_nt);   // sla_spmv_wdia_lds.hip
 int wd_lds_grid(const sla_csr *A);
 int tiles_grid(const sla_csr *A);
+int probe_xcd_layout(sla_ctx *c);   // sets c->xcd8 (sla_spmv_tiles.hip)
 // sla_lower_tiles.cpp: builds the tile form of A when it pays (irregular structure, x larger than the L2); no-op otherwise
 int build_tiles(sla_csr *A, int64_t n, int64_t rows, const int64_t *rowptr, const int64_t *col, const double *val);
 

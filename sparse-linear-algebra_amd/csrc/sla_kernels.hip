@@ -1725,8 +1725,13 @@ bool overlap_split(const sla_csr *A) {
     return A->ov_nint > 0 && A->ov_nbnd > 0 && A->ctx->overlap >= 0 && A->ctx->collectives && A->use_wdia && wd_on(A) && A->ctx->spmv_algo == 0 && !A->rp64;
 }
 int overlap_grid(const sla_csr *A, int part) {
-    const int cap = A->wd_vv ? A->ctx->wd_grid_max_vv : wd_lds_on(A) ? wd_lds_grid(A) : A->ctx->wd_grid_max;
-    return part == 1 ? std::max(1, std::min<int>(A->ov_nint, cap)) : std::max(1, std::min<int>(A->ov_nbnd, 256));
+    // the two launches write their fused partial sums into consecutive slots of ONE kMaxParts-slot array (interior first):
+    // the interior grid leaves room for the boundary launch's (a 299-CU part at 6 workgroups per CU, or SLA_WD_GRID=2048,
+    // would otherwise push the boundary partials into the next slot array)
+    const int gb = std::max(1, std::min<int>(A->ov_nbnd, 256));
+    if (part != 1) return gb;
+    const int cap = std::min(A->wd_vv ? A->ctx->wd_grid_max_vv : wd_lds_on(A) ? wd_lds_grid(A) : A->ctx->wd_grid_max, kMaxParts - gb);
+    return std::max(1, std::min<int>(A->ov_nint, cap));
 }
 
 int spmv_grid(const sla_csr *A) {
@@ -1831,7 +1836,7 @@ static int launch_spmv_t(const sla_csr *A, const SpmvLaunch &l) {
                 c->lp_attr |= attr_bit;                                                                                         \
             }                                                                                                                   \
             hipLaunchKernelGGL((spmv_lpanel_kernel<RP, L_, R_, J_>), dim3(A->lp_G), dim3(kLpBlock), kLpW * sizeof(double),      \
-                               c->stream, (const RP *)A->d_lpp, a.col, a.val, a.x, A->d_lpy, A->d_lpt, a.rows, (int)A->n,       \
+                               stream_of(c), (const RP *)A->d_lpp, a.col, a.val, a.x, A->d_lpy, A->d_lpt, a.rows, (int)A->n,       \
                                A->lp_W, A->lp_chunk, A->lp_C, A->lp_col_lo, A->lp_col_hi, (const SolverScalars *)a.sc);         \
         } break;
         switch (A->lp_cfg) {
@@ -1843,7 +1848,7 @@ static int launch_spmv_t(const sla_csr *A, const SpmvLaunch &l) {
         }
 #undef SLA_LP_LAUNCH
         SLA_HIP_TRY(hipGetLastError());
-        hipLaunchKernelGGL((lpanel_finish_kernel<EPI, RP>), dim3(grid), dim3(kBlock), 0, c->stream, a, A->d_lpy, A->lp_P);
+        hipLaunchKernelGGL((lpanel_finish_kernel<EPI, RP>), dim3(grid), dim3(kBlock), 0, stream_of(c), a, A->d_lpy, A->lp_P);
         SLA_HIP_TRY(hipGetLastError());
         return SLA_OK;
     }
@@ -1857,11 +1862,11 @@ static int launch_spmv_t(const sla_csr *A, const SpmvLaunch &l) {
             if (wd_lds_on(A))
                 return launch_wdia_lds(A, l.epi, a, sched, nblk_wd, grid, (vec_stream_nt(c, A->rows) ? 1 : 0) | (c->wd_nt_store ? 2 : 0));
             if (A->wd_vv)
-                hipLaunchKernelGGL((spmv_wdia_kernel<EPI, true>), dim3(grid), dim3(kBlock), 0, c->stream, a, A->d_wptr, A->d_wme, A->d_wmo,
+                hipLaunchKernelGGL((spmv_wdia_kernel<EPI, true>), dim3(grid), dim3(kBlock), 0, stream_of(c), a, A->d_wptr, A->d_wme, A->d_wmo,
                                    A->d_wval, A->d_woff, A->d_wvblk, a.x, nblk_wd, A->nslices, (int32_t)A->row_begin, (int32_t)A->n,
                                    sched, c->xcd_remap, vec_stream_nt(c, A->rows) ? 1 : 0);
             else
-                hipLaunchKernelGGL((spmv_wdia_kernel<EPI, false>), dim3(grid), dim3(kBlock), 0, c->stream, a, A->d_wptr, A->d_wme, A->d_wmo,
+                hipLaunchKernelGGL((spmv_wdia_kernel<EPI, false>), dim3(grid), dim3(kBlock), 0, stream_of(c), a, A->d_wptr, A->d_wme, A->d_wmo,
                                    A->d_wval, A->d_woff, A->d_wvblk, a.x, nblk_wd, A->nslices, (int32_t)A->row_begin, (int32_t)A->n,
                                    sched, c->xcd_remap, vec_stream_nt(c, A->rows) ? 1 : 0);
             SLA_HIP_TRY(hipGetLastError());
@@ -1872,7 +1877,7 @@ static int launch_spmv_t(const sla_csr *A, const SpmvLaunch &l) {
         if constexpr (std::is_same<RP, int32_t>::value) {
             const bool xw = A->use_xwin && c->xwin;
 #define SLA_VD_LAUNCH(E, XW_, DUAL_)                                                                                        \
-            hipLaunchKernelGGL((spmv_vdict_kernel<E, XW_, DUAL_>), dim3(grid), dim3(kBlock), 0, c->stream, a, a.rowptr,        \
+            hipLaunchKernelGGL((spmv_vdict_kernel<E, XW_, DUAL_>), dim3(grid), dim3(kBlock), 0, stream_of(c), a, a.rowptr,        \
                                (const uint32_t *)A->d_vcode, a.x, A->d_vdoff, A->d_vdval, A->nblk_vd, (int32_t)A->n,          \
                                (int32_t)A->row_begin, l.x2, l.b2, c->xcd_remap)
             if (l.x2) {
@@ -1893,32 +1898,32 @@ static int launch_spmv_t(const sla_csr *A, const SpmvLaunch &l) {
         if constexpr (EPI == EPI_DOT) {
             if (A->use_diag && c->diag) {
                 if (A->use_xwin && c->xwin)
-                    hipLaunchKernelGGL((spmv_dual_diag_kernel<RP, true>), dim3(grid), dim3(kBlock), 0, c->stream, a, a.rowptr, A->d_code, a.val,
+                    hipLaunchKernelGGL((spmv_dual_diag_kernel<RP, true>), dim3(grid), dim3(kBlock), 0, stream_of(c), a, a.rowptr, A->d_code, a.val,
                                        a.rb, a.rbk, a.x, A->d_rbw, A->d_dict, (int32_t)A->n, (int32_t)A->row_begin, l.x2, l.b2, c->xcd_remap);
                 else
-                    hipLaunchKernelGGL((spmv_dual_diag_kernel<RP, false>), dim3(grid), dim3(kBlock), 0, c->stream, a, a.rowptr, A->d_code, a.val,
+                    hipLaunchKernelGGL((spmv_dual_diag_kernel<RP, false>), dim3(grid), dim3(kBlock), 0, stream_of(c), a, a.rowptr, A->d_code, a.val,
                                        a.rb, a.rbk, a.x, A->d_rbw, A->d_dict, (int32_t)A->n, (int32_t)A->row_begin, l.x2, l.b2, c->xcd_remap);
             } else
-            hipLaunchKernelGGL((spmv_dual_kernel<RP>), dim3(grid), dim3(kBlock), 0, c->stream, a, a.rowptr, a.col, a.val, a.rb, a.rbk, a.x,
+            hipLaunchKernelGGL((spmv_dual_kernel<RP>), dim3(grid), dim3(kBlock), 0, stream_of(c), a, a.rowptr, a.col, a.val, a.rb, a.rbk, a.x,
                                l.x2, l.b2, c->xcd_remap);
         } else {
             return fail(SLA_ERR_INVALID, "dual SpMV is only defined for the K1 epilogue");
         }
     } else if (c->spmv_algo == 1)
-        hipLaunchKernelGGL((spmv_scalar_kernel<EPI, RP>), dim3(grid), dim3(kBlock), 0, c->stream, a, c->xcd_remap);
+        hipLaunchKernelGGL((spmv_scalar_kernel<EPI, RP>), dim3(grid), dim3(kBlock), 0, stream_of(c), a, c->xcd_remap);
     else if (A->use_diag && c->diag) {
         if (A->use_xwin && c->xwin)
-            hipLaunchKernelGGL((spmv_diag_kernel<EPI, RP, true>), dim3(grid), dim3(kBlock), 0, c->stream, a, a.rowptr, A->d_code, a.val, a.rb,
+            hipLaunchKernelGGL((spmv_diag_kernel<EPI, RP, true>), dim3(grid), dim3(kBlock), 0, stream_of(c), a, a.rowptr, A->d_code, a.val, a.rb,
                                a.rbk, a.x, A->d_rbw, A->d_dict, (int32_t)A->n, (int32_t)A->row_begin, c->xcd_remap);
         else
-            hipLaunchKernelGGL((spmv_diag_kernel<EPI, RP, false>), dim3(grid), dim3(kBlock), 0, c->stream, a, a.rowptr, A->d_code, a.val, a.rb,
+            hipLaunchKernelGGL((spmv_diag_kernel<EPI, RP, false>), dim3(grid), dim3(kBlock), 0, stream_of(c), a, a.rowptr, A->d_code, a.val, a.rb,
                                a.rbk, a.x, A->d_rbw, A->d_dict, (int32_t)A->n, (int32_t)A->row_begin, c->xcd_remap);
     } else {
         if (A->use_xwin && c->xwin)
-            hipLaunchKernelGGL((spmv_xwin_kernel<EPI, RP>), dim3(grid), dim3(kBlock), 0, c->stream, a, a.rowptr, a.col, a.val, a.rb, a.rbk,
+            hipLaunchKernelGGL((spmv_xwin_kernel<EPI, RP>), dim3(grid), dim3(kBlock), 0, stream_of(c), a, a.rowptr, a.col, a.val, a.rb, a.rbk,
                                a.x, A->d_rbw, (int32_t)A->n, c->xcd_remap);
         else
-            hipLaunchKernelGGL((spmv_stream_kernel<EPI, RP>), dim3(grid), dim3(kBlock), 0, c->stream, a, a.rowptr, a.col, a.val, a.rb, a.rbk,
+            hipLaunchKernelGGL((spmv_stream_kernel<EPI, RP>), dim3(grid), dim3(kBlock), 0, stream_of(c), a, a.rowptr, a.col, a.val, a.rb, a.rbk,
                                a.x, c->xcd_remap);
     }
     SLA_HIP_TRY(hipGetLastError());
@@ -2032,7 +2037,7 @@ __global__ void __launch_bounds__(kBlock) fill_kernel(int64_t n, double a, doubl
 }
 
 int launch_dot(sla_ctx *c, int64_t n, const double *x, const double *y, double *p1) {
-    hipLaunchKernelGGL(dot_kernel, dim3(vec_grid(n)), dim3(kBlock), 0, c->stream, n, x, y, p1);
+    hipLaunchKernelGGL(dot_kernel, dim3(vec_grid(n)), dim3(kBlock), 0, stream_of(c), n, x, y, p1);
     SLA_HIP_TRY(hipGetLastError());
     return SLA_OK;
 }
@@ -2044,27 +2049,27 @@ __global__ void __launch_bounds__(kBlock) finalize2_kernel(const double *p1, con
     if (threadIdx.x == 0) out[blockIdx.x] = s;
 }
 int launch_finalize(sla_ctx *c, const double *p1, const double *p2, int np, double *out) {
-    hipLaunchKernelGGL(finalize2_kernel, dim3(2), dim3(kBlock), 0, c->stream, p1, p2, np, out);
+    hipLaunchKernelGGL(finalize2_kernel, dim3(2), dim3(kBlock), 0, stream_of(c), p1, p2, np, out);
     SLA_HIP_TRY(hipGetLastError());
     return SLA_OK;
 }
 int launch_finalize_cols(sla_ctx *c, const double *parts, int np, int cs, int stride, int ncols, double *out) {
-    hipLaunchKernelGGL(finalize_kernel, dim3(ncols > 0 ? ncols : 1), dim3(kBlock), 0, c->stream, parts, np, cs, stride, ncols, out);
+    hipLaunchKernelGGL(finalize_kernel, dim3(ncols > 0 ? ncols : 1), dim3(kBlock), 0, stream_of(c), parts, np, cs, stride, ncols, out);
     SLA_HIP_TRY(hipGetLastError());
     return SLA_OK;
 }
 int launch_axpby(sla_ctx *c, int64_t n, double a, const double *x, double b, double *y) {
-    hipLaunchKernelGGL(axpby_kernel, dim3(vec_grid(n)), dim3(kBlock), 0, c->stream, n, a, x, b, y);
+    hipLaunchKernelGGL(axpby_kernel, dim3(vec_grid(n)), dim3(kBlock), 0, stream_of(c), n, a, x, b, y);
     SLA_HIP_TRY(hipGetLastError());
     return SLA_OK;
 }
 int launch_scal(sla_ctx *c, int64_t n, double a, double *x) {
-    hipLaunchKernelGGL(scal_kernel, dim3(vec_grid(n)), dim3(kBlock), 0, c->stream, n, a, x);
+    hipLaunchKernelGGL(scal_kernel, dim3(vec_grid(n)), dim3(kBlock), 0, stream_of(c), n, a, x);
     SLA_HIP_TRY(hipGetLastError());
     return SLA_OK;
 }
 int launch_fill(sla_ctx *c, int64_t n, double a, double *x) {
-    hipLaunchKernelGGL(fill_kernel, dim3(vec_grid(n)), dim3(kBlock), 0, c->stream, n, a, x);
+    hipLaunchKernelGGL(fill_kernel, dim3(vec_grid(n)), dim3(kBlock), 0, stream_of(c), n, a, x);
     SLA_HIP_TRY(hipGetLastError());
     return SLA_OK;
 }
@@ -2200,9 +2205,9 @@ int launch_bicg_k2(sla_ctx *c, int64_t n, SolverScalars *sc, Parts apr, int par,
                    const double *r, const double *ap, double *s) {
     ProfScope prof(c, SLA_KERNEL_BICG_K2);
     if (vec_stream_nt(c, n))
-        hipLaunchKernelGGL(bicg_k2_kernel<true>, dim3(vec_grid(n)), dim3(kBlock), 0, c->stream, n, sc, apr, par, res, count_iter, r, ap, s);
+        hipLaunchKernelGGL(bicg_k2_kernel<true>, dim3(vec_grid(n)), dim3(kBlock), 0, stream_of(c), n, sc, apr, par, res, count_iter, r, ap, s);
     else
-        hipLaunchKernelGGL(bicg_k2_kernel<false>, dim3(vec_grid(n)), dim3(kBlock), 0, c->stream, n, sc, apr, par, res, count_iter, r, ap, s);
+        hipLaunchKernelGGL(bicg_k2_kernel<false>, dim3(vec_grid(n)), dim3(kBlock), 0, stream_of(c), n, sc, apr, par, res, count_iter, r, ap, s);
     SLA_HIP_TRY(hipGetLastError());
     return SLA_OK;
 }
@@ -2210,18 +2215,18 @@ int launch_bicg_k4(sla_ctx *c, int64_t n, SolverScalars *sc, Parts ass, Parts as
                    const double *as, const double *r0hat, double *x, double *r, double *prho) {
     ProfScope prof(c, SLA_KERNEL_BICG_K4);
     if (vec_stream_nt(c, n))
-        hipLaunchKernelGGL(bicg_k4_kernel<true>, dim3(vec_grid(n)), dim3(kBlock), 0, c->stream, n, sc, ass, asas, p, s, as, r0hat, x, r, prho);
+        hipLaunchKernelGGL(bicg_k4_kernel<true>, dim3(vec_grid(n)), dim3(kBlock), 0, stream_of(c), n, sc, ass, asas, p, s, as, r0hat, x, r, prho);
     else
-        hipLaunchKernelGGL(bicg_k4_kernel<false>, dim3(vec_grid(n)), dim3(kBlock), 0, c->stream, n, sc, ass, asas, p, s, as, r0hat, x, r, prho);
+        hipLaunchKernelGGL(bicg_k4_kernel<false>, dim3(vec_grid(n)), dim3(kBlock), 0, stream_of(c), n, sc, ass, asas, p, s, as, r0hat, x, r, prho);
     SLA_HIP_TRY(hipGetLastError());
     return SLA_OK;
 }
 int launch_bicg_k5(sla_ctx *c, int64_t n, SolverScalars *sc, Parts rhonew, int par, const double *r, const double *ap, double *p) {
     ProfScope prof(c, SLA_KERNEL_BICG_K5);
     if (vec_stream_nt(c, n))
-        hipLaunchKernelGGL(bicg_k5_kernel<true>, dim3(vec_grid(n)), dim3(kBlock), 0, c->stream, n, sc, rhonew, par, r, ap, p);
+        hipLaunchKernelGGL(bicg_k5_kernel<true>, dim3(vec_grid(n)), dim3(kBlock), 0, stream_of(c), n, sc, rhonew, par, r, ap, p);
     else
-        hipLaunchKernelGGL(bicg_k5_kernel<false>, dim3(vec_grid(n)), dim3(kBlock), 0, c->stream, n, sc, rhonew, par, r, ap, p);
+        hipLaunchKernelGGL(bicg_k5_kernel<false>, dim3(vec_grid(n)), dim3(kBlock), 0, stream_of(c), n, sc, rhonew, par, r, ap, p);
     SLA_HIP_TRY(hipGetLastError());
     return SLA_OK;
 }
@@ -2229,9 +2234,9 @@ int launch_bicg_k45(sla_ctx *c, int64_t n, SolverScalars *sc, Parts ass, Parts a
                     const double *as, const double *ap, double *x, double *r, double *p) {
     ProfScope prof(c, SLA_KERNEL_BICG_K45);
     if (vec_stream_nt(c, n))
-        hipLaunchKernelGGL(bicg_k45_kernel<true>, dim3(vec_grid(n)), dim3(kBlock), 0, c->stream, n, sc, ass, asas, tr0, sr0, par, s, as, ap, x, r, p);
+        hipLaunchKernelGGL(bicg_k45_kernel<true>, dim3(vec_grid(n)), dim3(kBlock), 0, stream_of(c), n, sc, ass, asas, tr0, sr0, par, s, as, ap, x, r, p);
     else
-        hipLaunchKernelGGL(bicg_k45_kernel<false>, dim3(vec_grid(n)), dim3(kBlock), 0, c->stream, n, sc, ass, asas, tr0, sr0, par, s, as, ap, x, r, p);
+        hipLaunchKernelGGL(bicg_k45_kernel<false>, dim3(vec_grid(n)), dim3(kBlock), 0, stream_of(c), n, sc, ass, asas, tr0, sr0, par, s, as, ap, x, r, p);
     SLA_HIP_TRY(hipGetLastError());
     return SLA_OK;
 }
@@ -2301,9 +2306,9 @@ int launch_cgs_c2(sla_ctx *c, int64_t n, SolverScalars *sc, Parts apr, int par, 
                   const double *u, const double *aap, double *q, double *uq, double *x) {
     ProfScope prof(c, SLA_KERNEL_CGS_C2);
     if (vec_stream_nt(c, n))
-        hipLaunchKernelGGL(cgs_c2_kernel<true>, dim3(vec_grid(n)), dim3(kBlock), 0, c->stream, n, sc, apr, par, res, count_iter, u, aap, q, uq, x);
+        hipLaunchKernelGGL(cgs_c2_kernel<true>, dim3(vec_grid(n)), dim3(kBlock), 0, stream_of(c), n, sc, apr, par, res, count_iter, u, aap, q, uq, x);
     else
-        hipLaunchKernelGGL(cgs_c2_kernel<false>, dim3(vec_grid(n)), dim3(kBlock), 0, c->stream, n, sc, apr, par, res, count_iter, u, aap, q, uq, x);
+        hipLaunchKernelGGL(cgs_c2_kernel<false>, dim3(vec_grid(n)), dim3(kBlock), 0, stream_of(c), n, sc, apr, par, res, count_iter, u, aap, q, uq, x);
     SLA_HIP_TRY(hipGetLastError());
     return SLA_OK;
 }
@@ -2311,9 +2316,9 @@ int launch_cgs_c4(sla_ctx *c, int64_t n, SolverScalars *sc, Parts rhonew, int pa
                   double *u, double *p) {
     ProfScope prof(c, SLA_KERNEL_CGS_C4);
     if (vec_stream_nt(c, n))
-        hipLaunchKernelGGL(cgs_c4_kernel<true>, dim3(vec_grid(n)), dim3(kBlock), 0, c->stream, n, sc, rhonew, par, r, q, u, p);
+        hipLaunchKernelGGL(cgs_c4_kernel<true>, dim3(vec_grid(n)), dim3(kBlock), 0, stream_of(c), n, sc, rhonew, par, r, q, u, p);
     else
-        hipLaunchKernelGGL(cgs_c4_kernel<false>, dim3(vec_grid(n)), dim3(kBlock), 0, c->stream, n, sc, rhonew, par, r, q, u, p);
+        hipLaunchKernelGGL(cgs_c4_kernel<false>, dim3(vec_grid(n)), dim3(kBlock), 0, stream_of(c), n, sc, rhonew, par, r, q, u, p);
     SLA_HIP_TRY(hipGetLastError());
     return SLA_OK;
 }
@@ -2358,13 +2363,13 @@ __global__ void __launch_bounds__(kBlock) cgne_n3b_kernel(int64_t n, SolverScala
     if (threadIdx.x == 0) ppout[blockIdx.x] = s;
 }
 int launch_cgne_n3b(sla_ctx *c, int64_t n, SolverScalars *sc, Parts rr1, int par, const double *t, double *p, double *ppout) {
-    hipLaunchKernelGGL(cgne_n3b_kernel, dim3(vec_grid(n)), dim3(kBlock), 0, c->stream, n, sc, rr1, par, t, p, ppout);
+    hipLaunchKernelGGL(cgne_n3b_kernel, dim3(vec_grid(n)), dim3(kBlock), 0, stream_of(c), n, sc, rr1, par, t, p, ppout);
     SLA_HIP_TRY(hipGetLastError());
     return SLA_OK;
 }
 
 int launch_cgne_n2(sla_ctx *c, int64_t n, SolverScalars *sc, const double *p, double *x) {
-    hipLaunchKernelGGL(cgne_n2_kernel, dim3(vec_grid(n)), dim3(kBlock), 0, c->stream, n, sc, p, x);
+    hipLaunchKernelGGL(cgne_n2_kernel, dim3(vec_grid(n)), dim3(kBlock), 0, stream_of(c), n, sc, p, x);
     SLA_HIP_TRY(hipGetLastError());
     return SLA_OK;
 }
@@ -2376,7 +2381,7 @@ __global__ void __launch_bounds__(kBlock) diag_solve_kernel(int64_t n, const dou
         x[i] = (1.0 / diag[i]) * b[i];
 }
 int launch_diag_solve(sla_ctx *c, int64_t n, const double *diag, const double *b, double *x) {
-    hipLaunchKernelGGL(diag_solve_kernel, dim3(vec_grid(n)), dim3(kBlock), 0, c->stream, n, diag, b, x);
+    hipLaunchKernelGGL(diag_solve_kernel, dim3(vec_grid(n)), dim3(kBlock), 0, stream_of(c), n, diag, b, x);
     SLA_HIP_TRY(hipGetLastError());
     return SLA_OK;
 }
@@ -2396,7 +2401,7 @@ __global__ void __launch_bounds__(kBlock) check_kernel(SolverScalars *sc, Parts 
     }
 }
 int launch_check(sla_ctx *c, SolverScalars *sc, Parts res) {
-    hipLaunchKernelGGL(check_kernel, dim3(1), dim3(kBlock), 0, c->stream, sc, res);
+    hipLaunchKernelGGL(check_kernel, dim3(1), dim3(kBlock), 0, stream_of(c), sc, res);
     SLA_HIP_TRY(hipGetLastError());
     return SLA_OK;
 }
@@ -2427,13 +2432,13 @@ __global__ void __launch_bounds__(kBlock) set_rho_kernel(SolverScalars *sc, Part
     if (threadIdx.x == 0) sc->rho2[par] = v;
 }
 int launch_set_rho(sla_ctx *c, SolverScalars *sc, Parts rho, int par) {
-    hipLaunchKernelGGL(set_rho_kernel, dim3(1), dim3(kBlock), 0, c->stream, sc, rho, par);
+    hipLaunchKernelGGL(set_rho_kernel, dim3(1), dim3(kBlock), 0, stream_of(c), sc, rho, par);
     SLA_HIP_TRY(hipGetLastError());
     return SLA_OK;
 }
 
 int launch_init_scalars(sla_ctx *c, SolverScalars *sc, Parts rho, Parts r0sq, double tol_abs, double tol_rel) {
-    hipLaunchKernelGGL(init_scalars_kernel, dim3(1), dim3(kBlock), 0, c->stream, sc, rho, r0sq, tol_abs, tol_rel);
+    hipLaunchKernelGGL(init_scalars_kernel, dim3(1), dim3(kBlock), 0, stream_of(c), sc, rho, r0sq, tol_abs, tol_rel);
     SLA_HIP_TRY(hipGetLastError());
     return SLA_OK;
 }
@@ -2632,14 +2637,14 @@ __global__ void __launch_bounds__(kBlock) tri_sparsify_kernel(int64_t n, double 
 int launch_tri_level(const sla_csr *T, const sla_tri_plan *p, int64_t first, int64_t count, const double *b, double *x) {
     if (count <= 0) return SLA_OK;
     const int grid = (int)((count + kBlock - 1) / kBlock);
-    hipLaunchKernelGGL(tri_level_kernel, dim3(grid), dim3(kBlock), 0, T->ctx->stream, p->d_tptr, p->d_tcol, p->d_tval, p->d_tdiag,
+    hipLaunchKernelGGL(tri_level_kernel, dim3(grid), dim3(kBlock), 0, stream_of(T->ctx), p->d_tptr, p->d_tcol, p->d_tval, p->d_tdiag,
                        p->d_order, first, count, b, x);
     SLA_HIP_TRY(hipGetLastError());
     return SLA_OK;
 }
 
 int launch_tri_sparsify(sla_ctx *c, int64_t n, double *x) {
-    hipLaunchKernelGGL(tri_sparsify_kernel, dim3(vec_grid(n)), dim3(kBlock), 0, c->stream, n, x);
+    hipLaunchKernelGGL(tri_sparsify_kernel, dim3(vec_grid(n)), dim3(kBlock), 0, stream_of(c), n, x);
     SLA_HIP_TRY(hipGetLastError());
     return SLA_OK;
 }
@@ -2664,7 +2669,7 @@ int launch_arn_dots(sla_ctx *c, int64_t n, const double *Q, int64_t ldq, int nco
                     SolverScalars *sc) {
     const int g = arn_grid(n);
     if (ncols < 1 || ncols > 64) return fail(SLA_ERR_INVALID, "Krylov basis: 1..64 columns");
-    hipLaunchKernelGGL((arn_dots_kernel<kArnDotsGroup>), dim3(g, (ncols + kArnDotsGroup - 1) / kArnDotsGroup), dim3(kBlock), 0, c->stream,
+    hipLaunchKernelGGL((arn_dots_kernel<kArnDotsGroup>), dim3(g, (ncols + kArnDotsGroup - 1) / kArnDotsGroup), dim3(kBlock), 0, stream_of(c),
                        n, Q, ldq, ncols, w, parts, sc);
     SLA_HIP_TRY(hipGetLastError());
     return SLA_OK;
@@ -2675,11 +2680,11 @@ int launch_arn_update(sla_ctx *c, int64_t n, const double *Q, int64_t ldq, int n
     // the basis read so far (ncols columns) against the memory-side cache
     const bool nt = c->vec_nt < 0 ? (int64_t)ncols * 8 * n > c->mall_bytes : c->vec_nt != 0;
     if (nt) {
-#define CALL(NC) hipLaunchKernelGGL((arn_update_kernel<NC, true>), dim3(g), dim3(kBlock), 0, c->stream, n, Q, ldq, ncols, hp, np, cs, stride, w, pn, Hcol, sc)
+#define CALL(NC) hipLaunchKernelGGL((arn_update_kernel<NC, true>), dim3(g), dim3(kBlock), 0, stream_of(c), n, Q, ldq, ncols, hp, np, cs, stride, w, pn, Hcol, sc)
         SLA_NC_DISPATCH(ncols, CALL);
 #undef CALL
     } else {
-#define CALL(NC) hipLaunchKernelGGL((arn_update_kernel<NC, false>), dim3(g), dim3(kBlock), 0, c->stream, n, Q, ldq, ncols, hp, np, cs, stride, w, pn, Hcol, sc)
+#define CALL(NC) hipLaunchKernelGGL((arn_update_kernel<NC, false>), dim3(g), dim3(kBlock), 0, stream_of(c), n, Q, ldq, ncols, hp, np, cs, stride, w, pn, Hcol, sc)
         SLA_NC_DISPATCH(ncols, CALL);
 #undef CALL
     }
@@ -2688,13 +2693,13 @@ int launch_arn_update(sla_ctx *c, int64_t n, const double *Q, int64_t ldq, int n
 }
 int launch_arn_normalize(sla_ctx *c, int64_t n, Parts nrm, const double *w, double *qnext, double *hsub,
                          SolverScalars *sc, int first) {
-    hipLaunchKernelGGL(arn_normalize_kernel, dim3(arn_grid(n)), dim3(kBlock), 0, c->stream, n, nrm, w, qnext, hsub, sc, first);
+    hipLaunchKernelGGL(arn_normalize_kernel, dim3(arn_grid(n)), dim3(kBlock), 0, stream_of(c), n, nrm, w, qnext, hsub, sc, first);
     SLA_HIP_TRY(hipGetLastError());
     return SLA_OK;
 }
 int launch_gemv_accum(sla_ctx *c, int64_t n, const double *Q, int64_t ldq, int ncols, const double *ycoef_dev, double *x) {
     const int g = arn_grid(n);
-#define CALL(NC) hipLaunchKernelGGL((gemv_accum_kernel<NC>), dim3(g), dim3(kBlock), 0, c->stream, n, Q, ldq, ncols, ycoef_dev, x)
+#define CALL(NC) hipLaunchKernelGGL((gemv_accum_kernel<NC>), dim3(g), dim3(kBlock), 0, stream_of(c), n, Q, ldq, ncols, ycoef_dev, x)
     SLA_NC_DISPATCH(ncols, CALL);
 #undef CALL
     SLA_HIP_TRY(hipGetLastError());

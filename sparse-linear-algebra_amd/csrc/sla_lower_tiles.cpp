@@ -23,6 +23,12 @@ int build_tiles(sla_csr *A, int64_t n, int64_t rows, const int64_t *rowptr, cons
     if (!c->tiles || rows == 0 || nnz == 0) return SLA_OK;
     if (A->use_diag || A->use_wdia || A->use_vdict || A->xwin_fraction >= 0.5) return SLA_OK;   // stencil / banded structure
     if (A->use_lpanel && c->lpanel) return SLA_OK;                                               // dense rows: x panels in LDS
+    {   // the kernel keeps one slice's row sums per wavefront in static LDS (4 x kTileRows doubles = 128 KiB on the MI355X's 160 KiB)
+        int lds = 0;
+        if (hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, c->device) != hipSuccess ||
+            (int64_t)lds < (int64_t)(kBlock / 64) * kTileRows * 8 + 1024)
+            return SLA_OK;
+    }
     int row_bits = 0;
     while (((int64_t)1 << row_bits) < kTileRows) ++row_bits;
     // panel width: 2^17 columns (1 MiB of x) at 10 M rows, 2^16 below ~6 M (measured: 7-8 % faster at 0.5 / 1 / 3 M rows, 3-15 % slower at 10 M)
@@ -134,7 +140,7 @@ int build_tiles(sla_csr *A, int64_t n, int64_t rows, const int64_t *rowptr, cons
     hipError_t err = hipSuccess;
     auto upload = [&](void **dst, const void *src, size_t bytes) {
         if (err != hipSuccess) return;
-        err = hipMalloc(dst, std::max<size_t>(bytes + 64, 8));   // (+64: the streams are read in whole dwords / qwords only, slack for safety)
+        err = dev_malloc(c, dst, std::max<size_t>(bytes + 64, 8));   // (+64: the streams are read in whole dwords / qwords only, slack for safety)
         if (err == hipSuccess && bytes) err = hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
     };
     upload((void **)&A->d_tlrow, srow.data(), sizeof(int32_t) * srow.size());
@@ -142,8 +148,9 @@ int build_tiles(sla_csr *A, int64_t n, int64_t rows, const int64_t *rowptr, cons
     upload((void **)&A->d_tlidx, tidx.data(), sizeof(uint32_t) * tidx.size());
     upload((void **)&A->d_tlval, tval.data(), sizeof(double) * tval.size());
     A->tlprog_bytes = sizeof(int) * 8 * 256;   // pacing table: one progress slot per workgroup, 256 per XCD; zeroed before every launch
-    if (err == hipSuccess) err = hipMalloc((void **)&A->d_tlprog, A->tlprog_bytes);
+    if (err == hipSuccess) err = dev_malloc(c, (void **)&A->d_tlprog, A->tlprog_bytes);
     if (err != hipSuccess) return fail(SLA_ERR_ALLOC, std::string("tile form upload: ") + hipGetErrorString(err));
+    SLA_TRY(probe_xcd_layout(c));
     A->tl_S = (int32_t)S;
     A->tl_P = (int32_t)P;
     A->tl_shift = shift;

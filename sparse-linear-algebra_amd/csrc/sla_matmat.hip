@@ -58,6 +58,7 @@ extern "C" int sla_csr_matmat(sla_csr_t A, sla_csr_t B, int transpose_b, sla_csr
         if (A->ctx != B->ctx) return fail(SLA_ERR_INVALID, "sla_csr_matmat: operands belong to different contexts");
         sla_ctx *c = A->ctx;
         if (c->collectives) return fail(SLA_ERR_INVALID, "sla_csr_matmat: single-rank contexts only (## is not sharded, SURVEY 8(e))");
+        Bind bind(c);
         const int64_t inner_b = transpose_b ? B->n : B->m, out_cols = transpose_b ? B->m : B->n;
         if (A->n != inner_b)
             return fail(SLA_ERR_DIM_MISMATCH, "matMat : incompatible matrix sizes((" + std::to_string(A->m) + "," + std::to_string(A->n) + "),(" +
@@ -70,12 +71,12 @@ extern "C" int sla_csr_matmat(sla_csr_t A, sla_csr_t B, int transpose_b, sla_csr
             const size_t cnt = (size_t)M->rows + 1;
             std::vector<int64_t> rp(cnt);
             if (M->rp64) {
-                SLA_HIP_TRY(hipMemcpyAsync(rp.data(), M->d_rowptr, sizeof(int64_t) * cnt, hipMemcpyDeviceToHost, c->stream));
-                SLA_HIP_TRY(hipStreamSynchronize(c->stream));
+                SLA_HIP_TRY(hipMemcpyAsync(rp.data(), M->d_rowptr, sizeof(int64_t) * cnt, hipMemcpyDeviceToHost, stream_of(c)));
+                SLA_HIP_TRY(hipStreamSynchronize(stream_of(c)));
             } else {
                 std::vector<int32_t> rp32(cnt);
-                SLA_HIP_TRY(hipMemcpyAsync(rp32.data(), M->d_rowptr, sizeof(int32_t) * cnt, hipMemcpyDeviceToHost, c->stream));
-                SLA_HIP_TRY(hipStreamSynchronize(c->stream));
+                SLA_HIP_TRY(hipMemcpyAsync(rp32.data(), M->d_rowptr, sizeof(int32_t) * cnt, hipMemcpyDeviceToHost, stream_of(c)));
+                SLA_HIP_TRY(hipStreamSynchronize(stream_of(c)));
                 for (size_t i = 0; i < cnt; ++i) rp[i] = rp32[i];
             }
             for (int64_t i = 0; i < M->rows; ++i)
@@ -92,15 +93,15 @@ extern "C" int sla_csr_matmat(sla_csr_t A, sla_csr_t B, int transpose_b, sla_csr
         if (nr * nc > 0) {
             int32_t *d_rows = nullptr, *d_cols = nullptr;
             double *d_out = nullptr;
-            hipError_t e = hipMalloc((void **)&d_rows, sizeof(int32_t) * (size_t)nr);
-            if (e == hipSuccess) e = hipMalloc((void **)&d_cols, sizeof(int32_t) * (size_t)nc);
-            if (e == hipSuccess) e = hipMalloc((void **)&d_out, sizeof(double) * (size_t)(nr * nc));
-            if (e == hipSuccess) e = hipMemcpyAsync(d_rows, rows.data(), sizeof(int32_t) * (size_t)nr, hipMemcpyHostToDevice, c->stream);
-            if (e == hipSuccess) e = hipMemcpyAsync(d_cols, cols.data(), sizeof(int32_t) * (size_t)nc, hipMemcpyHostToDevice, c->stream);
+            hipError_t e = dev_malloc(c, (void **)&d_rows, sizeof(int32_t) * (size_t)nr);
+            if (e == hipSuccess) e = dev_malloc(c, (void **)&d_cols, sizeof(int32_t) * (size_t)nc);
+            if (e == hipSuccess) e = dev_malloc(c, (void **)&d_out, sizeof(double) * (size_t)(nr * nc));
+            if (e == hipSuccess) e = hipMemcpyAsync(d_rows, rows.data(), sizeof(int32_t) * (size_t)nr, hipMemcpyHostToDevice, stream_of(c));
+            if (e == hipSuccess) e = hipMemcpyAsync(d_cols, cols.data(), sizeof(int32_t) * (size_t)nc, hipMemcpyHostToDevice, stream_of(c));
             if (e == hipSuccess) {
                 const dim3 grid((unsigned)((nr * nc + kBlock - 1) / kBlock)), block(kBlock);
 #define SLA_MM(RA, RB)                                                                                                         \
-                hipLaunchKernelGGL((matmat_kernel<RA, RB>), grid, block, 0, c->stream, (const RA *)A->d_rowptr, A->d_col, A->d_val,   \
+                hipLaunchKernelGGL((matmat_kernel<RA, RB>), grid, block, 0, stream_of(c), (const RA *)A->d_rowptr, A->d_col, A->d_val,   \
                                    (const RB *)Bt->d_rowptr, Bt->d_col, Bt->d_val, d_rows, d_cols, nr, nc, d_out)
                 if (A->rp64 && Bt->rp64) SLA_MM(int64_t, int64_t);
                 else if (A->rp64) SLA_MM(int64_t, int32_t);
@@ -109,8 +110,8 @@ extern "C" int sla_csr_matmat(sla_csr_t A, sla_csr_t B, int transpose_b, sla_csr
 #undef SLA_MM
                 e = hipGetLastError();
             }
-            if (e == hipSuccess) e = hipMemcpyAsync(val.data(), d_out, sizeof(double) * (size_t)(nr * nc), hipMemcpyDeviceToHost, c->stream);
-            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(val.data(), d_out, sizeof(double) * (size_t)(nr * nc), hipMemcpyDeviceToHost, stream_of(c));
+            if (e == hipSuccess) e = hipStreamSynchronize(stream_of(c));
             (void)hipFree(d_rows);
             (void)hipFree(d_cols);
             (void)hipFree(d_out);

@@ -15,7 +15,9 @@
 #include <string.h>
 
 #include <atomic>
+#include <condition_variable>
 #include <functional>
+#include <mutex>
 #include <set>
 #include <string>
 #include <thread>
@@ -25,19 +27,78 @@
 
 namespace sla {
 
+// One persistent host thread per rank >= 1 of a parent context (rank 0's share runs on the caller's thread).  The per-rank entry
+// points contain collectives and host synchronisation, so they must be issued concurrently, exactly as N processes would;
+// spawning N threads per API call (every sla_dot on a multi context) cost a thread creation + join each time and gave every
+// call a brand-new thread whose current HIP device is 0.  A worker binds its device once when it starts and every entry point
+// it runs binds again (Bind, sla_internal.hpp).
+struct Worker {
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::function<void()> job;
+    bool has_job = false, done = false, quit = false;
+    void loop(int device) {
+        (void)hipSetDevice(device);
+        std::unique_lock<std::mutex> lk(mu);
+        for (;;) {
+            cv.wait(lk, [&] { return has_job || quit; });
+            if (quit) return;
+            lk.unlock();
+            job();
+            lk.lock();
+            has_job = false;
+            done = true;
+            cv.notify_all();
+        }
+    }
+    void post(std::function<void()> j) {
+        std::lock_guard<std::mutex> lk(mu);
+        job = std::move(j);
+        has_job = true;
+        done = false;
+        cv.notify_all();
+    }
+    void wait() {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return done; });
+    }
+};
+struct Pool {
+    std::vector<Worker *> w;   // w[r - 1] serves rank r
+    explicit Pool(const std::vector<int> &devices) {
+        for (size_t r = 1; r < devices.size(); ++r) {
+            Worker *k = new Worker();
+            const int dev = devices[r];
+            k->th = std::thread([k, dev] { k->loop(dev); });
+            w.push_back(k);
+        }
+    }
+    ~Pool() {
+        for (Worker *k : w) {
+            {
+                std::lock_guard<std::mutex> lk(k->mu);
+                k->quit = true;
+                k->cv.notify_all();
+            }
+            k->th.join();
+            delete k;
+        }
+    }
+};
+
 // f(rank) on every rank concurrently; the first failing rank's status and message are the call's
-int fanout(int n, const std::function<int(int)> &f) {
+static int fanout(Pool *pool, int n, const std::function<int(int)> &f) {
     std::vector<int> rc((size_t)n, SLA_OK);
     std::vector<std::string> msg((size_t)n);
-    std::vector<std::thread> th;
     for (int r = 1; r < n; ++r)
-        th.emplace_back([&, r] {
+        pool->w[(size_t)r - 1]->post([&, r] {
             rc[(size_t)r] = f(r);
             if (rc[(size_t)r] != SLA_OK) msg[(size_t)r] = sla_last_error();
         });
     rc[0] = f(0);
     if (rc[0] != SLA_OK) msg[0] = sla_last_error();
-    for (auto &t : th) t.join();
+    for (int r = 1; r < n; ++r) pool->w[(size_t)r - 1]->wait();
     for (int r = 0; r < n; ++r)
         if (rc[(size_t)r] != SLA_OK) {
             set_error(msg[(size_t)r]);
@@ -45,6 +106,7 @@ int fanout(int n, const std::function<int(int)> &f) {
         }
     return SLA_OK;
 }
+static int fanout(const sla_ctx *parent, const std::function<int(int)> &f) { return fanout((Pool *)parent->pool, (int)parent->kids.size(), f); }
 
 int multi_unsupported(const char *what) {
     return fail(SLA_ERR_INVALID, std::string(what) + ": not available on a multi-device context (not sharded, SURVEY 8(e)); use a single-device context");
@@ -60,14 +122,14 @@ static H *bundle(sla_ctx *parent, std::vector<H *> &kids) {
 
 // ---- context ------------------------------------------------------------------------------------------------
 int m_ctx_destroy(sla_ctx *p) {
-    const int n = (int)p->kids.size();
-    (void)fanout(n, [&](int r) { return sla_ctx_destroy(p->kids[(size_t)r]); });
+    (void)fanout(p, [&](int r) { return sla_ctx_destroy(p->kids[(size_t)r]); });
     p->kids.clear();
+    delete (Pool *)p->pool;
     delete p;
     return SLA_OK;
 }
 int m_ctx_sync(sla_ctx *p) {
-    return fanout((int)p->kids.size(), [&](int r) { return sla_ctx_sync(p->kids[(size_t)r]); });
+    return fanout(p, [&](int r) { return sla_ctx_sync(p->kids[(size_t)r]); });
 }
 
 // ---- matrices -----------------------------------------------------------------------------------------------
@@ -75,7 +137,7 @@ template <class F>
 static int make_csr(sla_ctx *p, sla_csr_t *out, F create) {
     const int n = (int)p->kids.size();
     std::vector<sla_csr *> kids((size_t)n, nullptr);
-    const int rc = fanout(n, [&](int r) { return create(p->kids[(size_t)r], &kids[(size_t)r]); });
+    const int rc = fanout(p, [&](int r) { return create(p->kids[(size_t)r], &kids[(size_t)r]); });
     if (rc != SLA_OK) {
         for (sla_csr *k : kids) sla_csr_destroy(k);
         return rc;
@@ -99,7 +161,7 @@ int m_csr_from_matrix_market(sla_ctx *p, const char *path, int dup, sla_csr_t *o
     return make_csr(p, out, [&](sla_ctx *c, sla_csr **o) { return sla_csr_from_matrix_market(c, path, dup, o); });
 }
 int m_csr_destroy(sla_csr *A) {
-    (void)fanout((int)A->kids.size(), [&](int r) { return sla_csr_destroy(A->kids[(size_t)r]); });
+    (void)fanout(A->ctx, [&](int r) { return sla_csr_destroy(A->kids[(size_t)r]); });
     A->kids.clear();
     delete A;
     return SLA_OK;
@@ -123,7 +185,7 @@ template <class F>
 static int make_vec(sla_ctx *p, sla_vec_t *out, F create) {
     const int n = (int)p->kids.size();
     std::vector<sla_vec *> kids((size_t)n, nullptr);
-    const int rc = fanout(n, [&](int r) { return create(p->kids[(size_t)r], &kids[(size_t)r]); });
+    const int rc = fanout(p, [&](int r) { return create(p->kids[(size_t)r], &kids[(size_t)r]); });
     if (rc != SLA_OK) {
         for (sla_vec *k : kids) sla_vec_destroy(k);
         return rc;
@@ -142,13 +204,13 @@ int m_vec_from_matrix_market(sla_ctx *p, const char *path, sla_vec_t *out) {
     return make_vec(p, out, [&](sla_ctx *c, sla_vec **o) { return sla_vec_from_matrix_market(c, path, o); });
 }
 int m_vec_destroy(sla_vec *v) {
-    (void)fanout((int)v->kids.size(), [&](int r) { return sla_vec_destroy(v->kids[(size_t)r]); });
+    (void)fanout(v->ctx, [&](int r) { return sla_vec_destroy(v->kids[(size_t)r]); });
     v->kids.clear();
     delete v;
     return SLA_OK;
 }
 int m_vec_to_host(sla_vec *v, double *host) {   // every rank downloads its own block into its slice: no collective
-    return fanout((int)v->kids.size(), [&](int r) {
+    return fanout(v->ctx, [&](int r) {
         sla_vec *k = v->kids[(size_t)r];
         return k->n_local > 0 ? sla_vec_to_host_local(k, host + k->begin) : SLA_OK;
     });
@@ -161,11 +223,11 @@ static bool same_shape(const H *a, const H *b) { return a && b && a->kids.size()
 
 int m_vec_copy(sla_vec *s, sla_vec *d) {
     SLA_NEED_BUNDLE(same_shape(s, d), "sla_vec_copy");
-    return fanout((int)s->kids.size(), [&](int r) { return sla_vec_copy(s->kids[(size_t)r], d->kids[(size_t)r]); });
+    return fanout(s->ctx, [&](int r) { return sla_vec_copy(s->kids[(size_t)r], d->kids[(size_t)r]); });
 }
 int m_spmv(sla_csr *A, sla_vec *x, sla_vec *y, bool transposed) {
     SLA_NEED_BUNDLE(x && y && A->kids.size() == x->kids.size() && same_shape(x, y) && A->ctx == x->ctx, "sla_spmv");
-    return fanout((int)A->kids.size(), [&](int r) {
+    return fanout(A->ctx, [&](int r) {
         return transposed ? sla_spmv_t(A->kids[(size_t)r], x->kids[(size_t)r], y->kids[(size_t)r])
                           : sla_spmv(A->kids[(size_t)r], x->kids[(size_t)r], y->kids[(size_t)r]);
     });
@@ -173,22 +235,22 @@ int m_spmv(sla_csr *A, sla_vec *x, sla_vec *y, bool transposed) {
 int m_dot(sla_vec *x, sla_vec *y, double *out) {   // every rank ends up with the same rank-ordered sum: take rank 0's
     SLA_NEED_BUNDLE(same_shape(x, y), "sla_dot");
     std::vector<double> v(x->kids.size(), 0.0);
-    SLA_TRY(fanout((int)x->kids.size(), [&](int r) { return sla_dot(x->kids[(size_t)r], y->kids[(size_t)r], &v[(size_t)r]); }));
+    SLA_TRY(fanout(x->ctx, [&](int r) { return sla_dot(x->kids[(size_t)r], y->kids[(size_t)r], &v[(size_t)r]); }));
     *out = v[0];
     return SLA_OK;
 }
 int m_nrm2(sla_vec *x, double *out) {
     std::vector<double> v(x->kids.size(), 0.0);
-    SLA_TRY(fanout((int)x->kids.size(), [&](int r) { return sla_nrm2(x->kids[(size_t)r], &v[(size_t)r]); }));
+    SLA_TRY(fanout(x->ctx, [&](int r) { return sla_nrm2(x->kids[(size_t)r], &v[(size_t)r]); }));
     *out = v[0];
     return SLA_OK;
 }
 int m_axpby(double a, sla_vec *x, double b, sla_vec *y) {
     SLA_NEED_BUNDLE(same_shape(x, y), "sla_axpby");
-    return fanout((int)x->kids.size(), [&](int r) { return sla_axpby(a, x->kids[(size_t)r], b, y->kids[(size_t)r]); });
+    return fanout(x->ctx, [&](int r) { return sla_axpby(a, x->kids[(size_t)r], b, y->kids[(size_t)r]); });
 }
 int m_scal(double a, sla_vec *x) {
-    return fanout((int)x->kids.size(), [&](int r) { return sla_scal(a, x->kids[(size_t)r]); });
+    return fanout(x->ctx, [&](int r) { return sla_scal(a, x->kids[(size_t)r]); });
 }
 
 // ---- solver state records -----------------------------------------------------------------------------------
@@ -196,7 +258,7 @@ int m_solver_init(int method, sla_csr *A, sla_vec *b, sla_vec *x0, sla_solver_t 
     SLA_NEED_BUNDLE(b && x0 && A->kids.size() == b->kids.size() && same_shape(b, x0) && A->ctx == b->ctx, "sla_solver_init");
     const int n = (int)A->kids.size();
     std::vector<sla_solver *> kids((size_t)n, nullptr);
-    const int rc = fanout(n, [&](int r) { return sla_solver_init(method, A->kids[(size_t)r], b->kids[(size_t)r], x0->kids[(size_t)r], &kids[(size_t)r]); });
+    const int rc = fanout(A->ctx, [&](int r) { return sla_solver_init(method, A->kids[(size_t)r], b->kids[(size_t)r], x0->kids[(size_t)r], &kids[(size_t)r]); });
     if (rc != SLA_OK) {
         for (sla_solver *k : kids) sla_solver_destroy(k);
         return rc;
@@ -207,16 +269,16 @@ int m_solver_init(int method, sla_csr *A, sla_vec *b, sla_vec *x0, sla_solver_t 
     return SLA_OK;
 }
 int m_solver_step(sla_solver *S, int k) {
-    return fanout((int)S->kids.size(), [&](int r) { return sla_solver_step(S->kids[(size_t)r], k); });
+    return fanout(S->ctx, [&](int r) { return sla_solver_step(S->kids[(size_t)r], k); });
 }
 int m_solver_get(sla_solver *S, int field, sla_vec *out) {
     SLA_NEED_BUNDLE(out && S->kids.size() == out->kids.size() && S->ctx == out->ctx, "sla_solver_get");
-    return fanout((int)S->kids.size(), [&](int r) { return sla_solver_get(S->kids[(size_t)r], field, out->kids[(size_t)r]); });
+    return fanout(S->ctx, [&](int r) { return sla_solver_get(S->kids[(size_t)r], field, out->kids[(size_t)r]); });
 }
 int m_solver_clone(sla_solver *S, sla_solver_t *out) {
     const int n = (int)S->kids.size();
     std::vector<sla_solver *> kids((size_t)n, nullptr);
-    const int rc = fanout(n, [&](int r) { return sla_solver_clone(S->kids[(size_t)r], &kids[(size_t)r]); });
+    const int rc = fanout(S->ctx, [&](int r) { return sla_solver_clone(S->kids[(size_t)r], &kids[(size_t)r]); });
     if (rc != SLA_OK) {
         for (sla_solver *k : kids) sla_solver_destroy(k);
         return rc;
@@ -228,10 +290,10 @@ int m_solver_clone(sla_solver *S, sla_solver_t *out) {
 }
 int m_solver_set_shadow(sla_solver *S, sla_vec *r0hat) {
     SLA_NEED_BUNDLE(r0hat && S->kids.size() == r0hat->kids.size() && S->ctx == r0hat->ctx, "sla_solver_set_shadow");
-    return fanout((int)S->kids.size(), [&](int r) { return sla_solver_set_shadow(S->kids[(size_t)r], r0hat->kids[(size_t)r]); });
+    return fanout(S->ctx, [&](int r) { return sla_solver_set_shadow(S->kids[(size_t)r], r0hat->kids[(size_t)r]); });
 }
 int m_solver_destroy(sla_solver *S) {
-    (void)fanout((int)S->kids.size(), [&](int r) { return sla_solver_destroy(S->kids[(size_t)r]); });
+    (void)fanout(S->ctx, [&](int r) { return sla_solver_destroy(S->kids[(size_t)r]); });
     S->kids.clear();
     delete S;
     return SLA_OK;
@@ -241,7 +303,7 @@ int m_solver_destroy(sla_solver *S) {
 int m_linsolve0(int method, sla_csr *A, sla_vec *b, sla_vec *x0, const sla_solve_opts *o, sla_vec *xo, sla_solve_info *info) {
     SLA_NEED_BUNDLE(b && x0 && xo && A->kids.size() == b->kids.size() && same_shape(b, x0) && same_shape(b, xo) && A->ctx == b->ctx, "sla_linsolve0");
     std::vector<sla_solve_info> infos(A->kids.size());
-    const int rc = fanout((int)A->kids.size(), [&](int r) {
+    const int rc = fanout(A->ctx, [&](int r) {
         return sla_linsolve0(method, A->kids[(size_t)r], b->kids[(size_t)r], x0->kids[(size_t)r], o, xo->kids[(size_t)r], &infos[(size_t)r]);
     });
     if (info) *info = infos[0];   // (every rank takes the same decisions from the same rank-ordered sums)
@@ -250,7 +312,7 @@ int m_linsolve0(int method, sla_csr *A, sla_vec *b, sla_vec *x0, const sla_solve
 int m_gmres(sla_csr *A, sla_vec *b, sla_vec *x0, int restart, const sla_solve_opts *o, sla_vec *xo, sla_solve_info *info) {
     SLA_NEED_BUNDLE(b && x0 && xo && A->kids.size() == b->kids.size() && same_shape(b, x0) && same_shape(b, xo) && A->ctx == b->ctx, "sla_gmres");
     std::vector<sla_solve_info> infos(A->kids.size());
-    const int rc = fanout((int)A->kids.size(), [&](int r) {
+    const int rc = fanout(A->ctx, [&](int r) {
         return sla_gmres(A->kids[(size_t)r], b->kids[(size_t)r], x0->kids[(size_t)r], restart, o, xo->kids[(size_t)r], &infos[(size_t)r]);
     });
     if (info) *info = infos[0];
@@ -259,7 +321,7 @@ int m_gmres(sla_csr *A, sla_vec *b, sla_vec *x0, int restart, const sla_solve_op
 int m_linsolve(sla_csr *A, sla_vec *b, sla_vec *xo, sla_solve_info *info) {
     SLA_NEED_BUNDLE(b && xo && A->kids.size() == b->kids.size() && same_shape(b, xo) && A->ctx == b->ctx, "sla_linsolve");
     std::vector<sla_solve_info> infos(A->kids.size());
-    const int rc = fanout((int)A->kids.size(), [&](int r) {
+    const int rc = fanout(A->ctx, [&](int r) {
         return sla_linsolve(A->kids[(size_t)r], b->kids[(size_t)r], xo->kids[(size_t)r], &infos[(size_t)r]);
     });
     if (info) *info = infos[0];
@@ -271,7 +333,7 @@ int m_arnoldi(sla_csr *A, sla_vec *b, int kn, double *Q, double *H, int *k_done)
     const int64_t nglob = b->n;
     std::vector<std::vector<double>> ql((size_t)n), hl((size_t)n);
     std::vector<int> kd((size_t)n, 0);
-    SLA_TRY(fanout(n, [&](int r) {
+    SLA_TRY(fanout(A->ctx, [&](int r) {
         sla_vec *bk = b->kids[(size_t)r];
         if (Q) ql[(size_t)r].assign((size_t)std::max<int64_t>(bk->n_local, 1) * (size_t)(kn + 1), 0.0);
         hl[(size_t)r].assign((size_t)(kn + 1) * (size_t)kn, 0.0);
@@ -301,23 +363,28 @@ extern "C" int sla_ctx_create_multi(int n_gpus, const int *device_ids, sla_ctx_t
         for (int r = 0; r < n_gpus; ++r) ids[(size_t)r] = device_ids ? device_ids[r] : r;
         const bool distinct = std::set<int>(ids.begin(), ids.end()).size() == ids.size();
         std::vector<sla_ctx *> kids((size_t)n_gpus, nullptr);
+        Pool *pool = new Pool(ids);
         int rc;
         if (distinct) {   // one RCCL rank per device, all created concurrently from one unique id (like ncclCommInitAll)
             char uid[128];
-            SLA_TRY(sla_dist_unique_id(uid));
-            rc = fanout(n_gpus, [&](int r) { return sla_ctx_create_dist(ids[(size_t)r], r, n_gpus, uid, &kids[(size_t)r]); });
+            rc = sla_dist_unique_id(uid);
+            if (rc == SLA_OK) rc = fanout(pool, n_gpus, [&](int r) { return sla_ctx_create_dist(ids[(size_t)r], r, n_gpus, uid, &kids[(size_t)r]); });
         } else {          // repeated device id: RCCL refuses two ranks on one GPU -> the in-process loopback communicator (test backend)
             static std::atomic<int> next_key{0x4d554c54};
             const int key = next_key.fetch_add(1);
-            rc = fanout(n_gpus, [&](int r) { return sla_ctx_create_loopback(ids[(size_t)r], r, n_gpus, key, &kids[(size_t)r]); });
+            rc = fanout(pool, n_gpus, [&](int r) { return sla_ctx_create_loopback(ids[(size_t)r], r, n_gpus, key, &kids[(size_t)r]); });
         }
         if (rc != SLA_OK) {
+            const std::string msg = sla_last_error();
             for (sla_ctx *k : kids) sla_ctx_destroy(k);
+            delete pool;
+            set_error(msg);
             return rc;
         }
         sla_ctx *p = new sla_ctx();
         p->device = ids[0];
         p->kids = kids;
+        p->pool = pool;
         *out = p;
         return SLA_OK;
     });

@@ -31,6 +31,7 @@ int publish(sla_solver *S, int s1, int s2, int np, Parts *o1, Parts *o2) {
         return SLA_OK;
     }
     double *loc = S->d_gath + (size_t)P_SLOTS * 2 * c->nranks;  // 2 doubles of staging
+    ProfScope prof(c, SLA_KERNEL_SUMS);
     SLA_TRY(launch_finalize(c, slot(S, s1), s2 >= 0 ? slot(S, s2) : nullptr, np, loc));   // loc[1] = 0 without a second array
     double *g = S->d_gath + (size_t)s1 * 2 * c->nranks;
     SLA_TRY(dist_allgather_f64(c, loc, g, 2));
@@ -44,6 +45,7 @@ static int publish_with_halo(sla_solver *S, int s1, int s2, int np, Parts *o1, P
     sla_ctx *c = S->ctx;
     double *g = S->d_gath + (size_t)s1 * 2 * c->nranks;
     double *loc = g + 2 * c->rank;   // in place: this rank's sums are written straight into their slot of the gathered table
+    ProfScope prof(c, SLA_KERNEL_SUMS);
     SLA_TRY(launch_finalize(c, slot(S, s1), s2 >= 0 ? slot(S, s2) : nullptr, np, loc));
     // (the per-rank sums travel as point-to-point transfers too, so that the group is a pure send/recv group)
     SLA_TRY(dist_group_begin(c));
@@ -75,9 +77,9 @@ int solver_alloc(sla_csr *A, int method, sla_solver **out) {
     if (method != SLA_CGNE_) { mk(nr, &S->t1); mk(nr, &S->t2); mk(nr, &S->t3); }
     else if (c->collectives) mk(nx, &S->t1);  // CGNE, row-sharded: landing buffer of the reduce-scattered A^T r
     hipError_t e = hipSuccess;
-    if (rc == SLA_OK) e = hipMalloc((void **)&S->d_parts, sizeof(double) * P_SLOTS * kMaxParts);
-    if (rc == SLA_OK && e == hipSuccess) e = hipMalloc((void **)&S->d_gath, sizeof(double) * ((size_t)P_SLOTS * 2 * c->nranks + 8));
-    if (rc == SLA_OK && e == hipSuccess) e = hipMalloc((void **)&S->d_sc, sizeof(SolverScalars));
+    if (rc == SLA_OK) e = dev_malloc(c, (void **)&S->d_parts, sizeof(double) * P_SLOTS * kMaxParts);
+    if (rc == SLA_OK && e == hipSuccess) e = dev_malloc(c, (void **)&S->d_gath, sizeof(double) * ((size_t)P_SLOTS * 2 * c->nranks + 8));
+    if (rc == SLA_OK && e == hipSuccess) e = dev_malloc(c, (void **)&S->d_sc, sizeof(SolverScalars));
     if (rc == SLA_OK && e == hipSuccess) e = hipHostMalloc((void **)&S->h_sc, sizeof(SolverScalars), hipHostMallocDefault);
     if (rc == SLA_OK && e != hipSuccess) rc = fail(SLA_ERR_ALLOC, std::string("solver allocation: ") + hipGetErrorString(e));
     if (rc != SLA_OK) {
@@ -397,8 +399,8 @@ bool dual_ok(const sla_solver *S) {
 
 int read_scalars(sla_solver *S) {
     sla_ctx *c = S->ctx;
-    SLA_HIP_TRY(hipMemcpyAsync(S->h_sc, S->d_sc, sizeof(SolverScalars), hipMemcpyDeviceToHost, c->stream));
-    SLA_HIP_TRY(hipStreamSynchronize(c->stream));
+    SLA_HIP_TRY(hipMemcpyAsync(S->h_sc, S->d_sc, sizeof(SolverScalars), hipMemcpyDeviceToHost, stream_of(c)));
+    SLA_HIP_TRY(hipStreamSynchronize(stream_of(c)));
     return SLA_OK;
 }
 
@@ -411,9 +413,20 @@ int solver_init_common(int method, sla_csr *A, sla_vec *b, sla_vec *x0, double t
     if (A->n != x0->n) return fail(SLA_ERR_DIM_MISMATCH, "matVec : mismatched dimensions");
     if (method != SLA_CGNE_ && A->m != A->n) return fail(SLA_ERR_DIM_MISMATCH, "CGS/BiCGSTAB need a square matrix");
     sla_ctx *c = A->ctx;
-    (void)hipSetDevice(c->device);
+    if (!b->kids.empty() || !x0->kids.empty() || b->ctx != c || x0->ctx != c) return mixed_handles("solver init");
+    Bind bind(c);
     sla_solver *S = nullptr;
-    SLA_TRY(solver_alloc(A, method, &S));
+    {   // a rank whose allocation fails must not leave its peers blocked in the first collective below: agree first
+        int rc_alloc = solver_alloc(A, method, &S);
+        const std::string msg = rc_alloc != SLA_OK ? sla_last_error() : "";
+        int bad = rc_alloc != SLA_OK ? 1 : 0;
+        if (c->collectives) SLA_TRY(dist_allreduce_max_i32(c, &bad));
+        if (rc_alloc != SLA_OK) return fail(rc_alloc, msg);
+        if (bad) {
+            sla_solver_destroy(S);
+            return fail(SLA_ERR_ALLOC, "solver state allocation failed on another rank of the row-sharded job");
+        }
+    }
     new (&ctl_of(S)) StepCtl();
     int rc = SLA_OK;
     do {
@@ -519,18 +532,30 @@ int arn_alloc(ArnoldiWs &ws, sla_csr *A, sla_vec *like, int kn) {
         }
     }
     const size_t qbytes = sizeof(double) * (size_t)ws.ld * (size_t)(kn + 1);
-    SLA_HIP_TRY(guard_malloc((void **)&ws.Qalloc, qbytes));  // SpMV gathers from its columns
-    SLA_HIP_TRY(hipMemsetAsync(ws.Qalloc, 0, qbytes, c->stream));
+    SLA_HIP_TRY(guard_malloc(c, (void **)&ws.Qalloc, qbytes));  // SpMV gathers from its columns
+    SLA_HIP_TRY(hipMemsetAsync(ws.Qalloc, 0, qbytes, stream_of(c)));
     ws.Q = ws.Qalloc + ws.halo;
-    SLA_HIP_TRY(hipMalloc((void **)&ws.w, sizeof(double) * (size_t)ws.ld));
-    SLA_HIP_TRY(hipMemsetAsync(ws.w, 0, sizeof(double) * (size_t)ws.ld, c->stream));
-    SLA_HIP_TRY(hipMalloc((void **)&ws.H, sizeof(double) * (size_t)(kn + 1) * (size_t)kn));
-    SLA_HIP_TRY(hipMalloc((void **)&ws.parts, sizeof(double) * (size_t)(kMaxKrylov + 2) * kArnGridMax));
-    SLA_HIP_TRY(hipMalloc((void **)&ws.gath, sizeof(double) * ((size_t)(kMaxKrylov + 2) * (size_t)c->nranks + kMaxKrylov + 8)));
-    SLA_HIP_TRY(hipMalloc((void **)&ws.ycoef, sizeof(double) * (kMaxKrylov + 2)));
-    SLA_HIP_TRY(hipMalloc((void **)&ws.d_sc, sizeof(SolverScalars)));
+    SLA_HIP_TRY(dev_malloc(c, (void **)&ws.w, sizeof(double) * (size_t)ws.ld));
+    SLA_HIP_TRY(hipMemsetAsync(ws.w, 0, sizeof(double) * (size_t)ws.ld, stream_of(c)));
+    SLA_HIP_TRY(dev_malloc(c, (void **)&ws.H, sizeof(double) * (size_t)(kn + 1) * (size_t)kn));
+    SLA_HIP_TRY(dev_malloc(c, (void **)&ws.parts, sizeof(double) * (size_t)(kMaxKrylov + 2) * kArnGridMax));
+    SLA_HIP_TRY(dev_malloc(c, (void **)&ws.gath, sizeof(double) * ((size_t)(kMaxKrylov + 2) * (size_t)c->nranks + kMaxKrylov + 8)));
+    SLA_HIP_TRY(dev_malloc(c, (void **)&ws.ycoef, sizeof(double) * (kMaxKrylov + 2)));
+    SLA_HIP_TRY(dev_malloc(c, (void **)&ws.d_sc, sizeof(SolverScalars)));
     SLA_HIP_TRY(hipHostMalloc((void **)&ws.h_sc, sizeof(SolverScalars), hipHostMallocDefault));
     ws.Hhost.assign((size_t)(kn + 1) * (size_t)kn, 0.0);
+    return SLA_OK;
+}
+
+// arn_alloc + agreement over the ranks: a rank whose allocation fails must not leave its peers blocked in the first collective
+int arn_alloc_agreed(ArnoldiWs &ws, sla_csr *A, sla_vec *like, int kn) {
+    sla_ctx *c = A->ctx;
+    const int rc = arn_alloc(ws, A, like, kn);
+    const std::string msg = rc != SLA_OK ? sla_last_error() : "";
+    int bad = rc != SLA_OK ? 1 : 0;
+    if (c->collectives) SLA_TRY(dist_allreduce_max_i32(c, &bad));
+    if (rc != SLA_OK) return fail(rc, msg);
+    if (bad) return fail(SLA_ERR_ALLOC, "Arnoldi workspace allocation failed on another rank of the row-sharded job");
     return SLA_OK;
 }
 
@@ -558,8 +583,8 @@ int arn_run(ArnoldiWs &ws, sla_csr *A, const double *src_local, int kn, int *k_d
     const int64_t n = ws.n_local;
     const int ldh = ws.kn + 1;
     const int g = arn_grid(n);
-    SLA_HIP_TRY(hipMemsetAsync(ws.H, 0, sizeof(double) * (size_t)ldh * (size_t)ws.kn, c->stream));
-    SLA_HIP_TRY(hipMemsetAsync(ws.d_sc, 0, sizeof(SolverScalars), c->stream));
+    SLA_HIP_TRY(hipMemsetAsync(ws.H, 0, sizeof(double) * (size_t)ldh * (size_t)ws.kn, stream_of(c)));
+    SLA_HIP_TRY(hipMemsetAsync(ws.d_sc, 0, sizeof(SolverScalars), stream_of(c)));
     ColParts cp;
     // q0 = normalize2 b
     SLA_TRY(launch_dot(c, n, src_local, src_local, ws.parts));
@@ -596,9 +621,9 @@ int arn_run(ArnoldiWs &ws, sla_csr *A, const double *src_local, int kn, int *k_d
         SLA_TRY(launch_arn_normalize(c, n, Parts{cn.p, cn.np, cn.stride}, ws.w, ws.Q + (size_t)(i + 1) * ws.ld,
                                      ws.H + (size_t)i * ldh + i + 1, ws.d_sc, i == 0 ? 1 : 0));
     }
-    SLA_HIP_TRY(hipMemcpyAsync(ws.Hhost.data(), ws.H, sizeof(double) * (size_t)ldh * (size_t)ws.kn, hipMemcpyDeviceToHost, c->stream));
-    SLA_HIP_TRY(hipMemcpyAsync(ws.h_sc, ws.d_sc, sizeof(SolverScalars), hipMemcpyDeviceToHost, c->stream));
-    SLA_HIP_TRY(hipStreamSynchronize(c->stream));
+    SLA_HIP_TRY(hipMemcpyAsync(ws.Hhost.data(), ws.H, sizeof(double) * (size_t)ldh * (size_t)ws.kn, hipMemcpyDeviceToHost, stream_of(c)));
+    SLA_HIP_TRY(hipMemcpyAsync(ws.h_sc, ws.d_sc, sizeof(SolverScalars), hipMemcpyDeviceToHost, stream_of(c)));
+    SLA_HIP_TRY(hipStreamSynchronize(stream_of(c)));
     *k_done = ws.h_sc->kdone;
     return SLA_OK;
 }
@@ -646,40 +671,44 @@ int sla_solver_step(sla_solver_t S, int k_steps) {
     if (S && !S->kids.empty()) return k_steps >= 0 ? m_solver_step(S, k_steps) : fail(SLA_ERR_INVALID, "sla_solver_step: bad argument");
     if (!S || k_steps < 0) return fail(SLA_ERR_INVALID, "sla_solver_step: bad argument");
     sla_ctx *c = S->ctx;
-    (void)hipSetDevice(c->device);
+    Bind bind(c);
     int k = 0;
     // Launch-bound sizes ("Launches and HIP graphs"): below ~2 M rows the five dependent launches of a step
     // cost about as much as its kernels.  Two consecutive steps (both parities of the double-buffered rho) are captured ONCE
     // into a HIP graph and replayed: the same kernels with the same arguments in the same order -- bit-identical iterates --
     // at the dependent-node latency of a graph instead of five stream dispatches per step.
-    const bool graph_ok = c->step_graph != 0 && !c->collectives && c->prof_kernel == -2 && !S->have_res && S->method != SLA_CGNE_ &&
-                          (c->step_graph > 0 || S->A->rows <= c->step_graph_max_rows) && k_steps >= 4;
+    const bool graph_ok = c->step_graph != 0 && !S->step_graph_failed && !c->collectives && c->prof_kernel == -2 && !S->have_res &&
+                          S->method != SLA_CGNE_ && (c->step_graph > 0 || S->A->rows <= c->step_graph_max_rows) && k_steps >= 4;
     if (graph_ok) {
         if (ctl_of(S).step_index & 1) {   // the captured pair starts at even parity
             SLA_TRY(enqueue_step(S, false, false));
             ++k;
         }
         if (!S->step_graph) {
+            // A failed capture or instantiation is not an error of the step: the graph is an optimisation.  Restore the step
+            // bookkeeping exactly (enqueue_step may have advanced it by 0, 1 or 2), never try again on this state record and
+            // fall through to the plain stream launches below.
             hipGraph_t g = nullptr;
-            SLA_HIP_TRY(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-            int rc = enqueue_step(S, false, false);
-            if (rc == SLA_OK) rc = enqueue_step(S, false, false);
-            const hipError_t e = hipStreamEndCapture(c->stream, &g);
-            ctl_of(S).step_index -= 2;   // (captured, not executed)
-            if (rc != SLA_OK || e != hipSuccess) {
-                if (g) (void)hipGraphDestroy(g);
-                if (rc != SLA_OK) return rc;
-                return fail(SLA_ERR_HIP, std::string("step graph capture: ") + hipGetErrorString(e));
+            const int index0 = ctl_of(S).step_index;
+            hipError_t e = hipStreamBeginCapture(stream_of(c), hipStreamCaptureModeThreadLocal);
+            if (e == hipSuccess) {
+                int rc = enqueue_step(S, false, false);
+                if (rc == SLA_OK) rc = enqueue_step(S, false, false);
+                e = hipStreamEndCapture(stream_of(c), &g);
+                if (rc != SLA_OK && e == hipSuccess) e = hipErrorUnknown;
             }
-            const hipError_t ei = hipGraphInstantiate(&S->step_graph, g, nullptr, nullptr, 0);
-            (void)hipGraphDestroy(g);
-            if (ei != hipSuccess) {
+            ctl_of(S).step_index = index0;   // (captured, not executed)
+            S->have_res = false;
+            if (e == hipSuccess) e = hipGraphInstantiate(&S->step_graph, g, nullptr, nullptr, 0);
+            if (g) (void)hipGraphDestroy(g);
+            if (e != hipSuccess) {
+                (void)hipGetLastError();
                 S->step_graph = nullptr;
-                return fail(SLA_ERR_HIP, std::string("step graph instantiate: ") + hipGetErrorString(ei));
+                S->step_graph_failed = true;
             }
         }
-        for (; k + 2 <= k_steps; k += 2) {
-            SLA_HIP_TRY(hipGraphLaunch(S->step_graph, c->stream));
+        for (; S->step_graph && k + 2 <= k_steps; k += 2) {
+            SLA_HIP_TRY(hipGraphLaunch(S->step_graph, stream_of(c)));
             ctl_of(S).step_index += 2;
         }
     }
@@ -698,6 +727,7 @@ int sla_solver_get(sla_solver_t S, int field, sla_vec_t out) {
         case SLA_STATE_U: src = S->u; break;
     }
     if (!src) return fail(SLA_ERR_INVALID, "sla_solver_get: this method has no such state field");
+    if (!out->kids.empty() || out->ctx != S->ctx) return mixed_handles("sla_solver_get");
     return sla_vec_copy(src, out);
 }
 
@@ -710,7 +740,7 @@ int sla_solver_clone(sla_solver_t S, sla_solver_t *out) {
     return no_throw("sla_solver_clone", [&]() -> int {
         if (!S || !out) return fail(SLA_ERR_INVALID, "sla_solver_clone: null argument");
         sla_ctx *c = S->ctx;
-        (void)hipSetDevice(c->device);
+        Bind bind(c);
         sla_solver *T = nullptr;
         SLA_TRY(solver_alloc(S->A, S->method, &T));
         int rc = SLA_OK;
@@ -722,17 +752,17 @@ int sla_solver_clone(sla_solver_t S, sla_solver_t *out) {
                 // them, so copy the whole guarded allocation when the state runs that flow)
                 if (S->ghost) {
                     const size_t g = c->vec_guard, bytes = sizeof(double) * (size_t)std::max<int64_t>(src[i]->shard, 1) + 2 * g;
-                    if (hipMemcpyAsync((char *)dst[i]->d - g, (const char *)src[i]->d - g, bytes, hipMemcpyDeviceToDevice, c->stream) != hipSuccess)
+                    if (hipMemcpyAsync((char *)dst[i]->d - g, (const char *)src[i]->d - g, bytes, hipMemcpyDeviceToDevice, stream_of(c)) != hipSuccess)
                         rc = fail(SLA_ERR_HIP, "sla_solver_clone: device copy failed");
                 } else {
                     rc = sla_vec_copy(src[i], dst[i]);
                 }
             }
         hipError_t e = hipSuccess;
-        if (rc == SLA_OK) e = hipMemcpyAsync(T->d_parts, S->d_parts, sizeof(double) * P_SLOTS * kMaxParts, hipMemcpyDeviceToDevice, c->stream);
+        if (rc == SLA_OK) e = hipMemcpyAsync(T->d_parts, S->d_parts, sizeof(double) * P_SLOTS * kMaxParts, hipMemcpyDeviceToDevice, stream_of(c));
         if (rc == SLA_OK && e == hipSuccess)
-            e = hipMemcpyAsync(T->d_gath, S->d_gath, sizeof(double) * ((size_t)P_SLOTS * 2 * c->nranks + 8), hipMemcpyDeviceToDevice, c->stream);
-        if (rc == SLA_OK && e == hipSuccess) e = hipMemcpyAsync(T->d_sc, S->d_sc, sizeof(SolverScalars), hipMemcpyDeviceToDevice, c->stream);
+            e = hipMemcpyAsync(T->d_gath, S->d_gath, sizeof(double) * ((size_t)P_SLOTS * 2 * c->nranks + 8), hipMemcpyDeviceToDevice, stream_of(c));
+        if (rc == SLA_OK && e == hipSuccess) e = hipMemcpyAsync(T->d_sc, S->d_sc, sizeof(SolverScalars), hipMemcpyDeviceToDevice, stream_of(c));
         if (rc == SLA_OK && e != hipSuccess) rc = fail(SLA_ERR_HIP, std::string("sla_solver_clone: ") + hipGetErrorString(e));
         if (rc != SLA_OK) {
             sla_solver_destroy(T);
@@ -768,7 +798,8 @@ int sla_solver_set_shadow(sla_solver_t S, sla_vec_t r0hat) {
         if (r0hat->n != S->r0hat->n) return fail(SLA_ERR_DIM_MISMATCH, "sla_solver_set_shadow: dimension mismatch");
         if (S->ghost) return fail(SLA_ERR_INVALID, "sla_solver_set_shadow: not available on the ghost-row sharded flow");
         sla_ctx *c = S->ctx;
-        (void)hipSetDevice(c->device);
+        if (!r0hat->kids.empty() || r0hat->ctx != c) return mixed_handles("sla_solver_set_shadow");
+        Bind bind(c);
         SLA_TRY(sla_vec_copy(r0hat, S->r0hat));
         Parts rho;
         SLA_TRY(launch_dot(c, S->r->n_local, S->r->d, S->r0hat->d, slot(S, P_TMP)));
@@ -780,6 +811,7 @@ int sla_solver_set_shadow(sla_solver_t S, sla_vec_t r0hat) {
 int sla_solver_destroy(sla_solver_t S) {
     if (S && !S->kids.empty()) return m_solver_destroy(S);
     if (!S) return SLA_OK;
+    Bind bind(S->ctx);
     if (S->ctx && S->ctx->stream) (void)hipStreamSynchronize(S->ctx->stream);
     sla_vec *vs[] = {S->x, S->r, S->p, S->u, S->r0hat, S->b, S->t1, S->t2, S->t3};
     for (sla_vec *v : vs) sla_vec_destroy(v);
@@ -819,11 +851,12 @@ int sla_linsolve0(int method, sla_csr_t A, sla_vec_t b, sla_vec_t x0, const sla_
         if (A->m != b->n) return fail(SLA_ERR_DIM_MISMATCH, "linSolve0 : matrix rows and rhs dimension differ");
         if (x_out->n != A->n) return fail(SLA_ERR_DIM_MISMATCH, "linSolve0 : output vector has the wrong dimension");
         sla_ctx *c = A->ctx;
-        (void)hipSetDevice(c->device);
+        if (!b->kids.empty() || !x0->kids.empty() || !x_out->kids.empty() || b->ctx != c || x0->ctx != c || x_out->ctx != c) return mixed_handles("sla_linsolve0");
+        Bind bind(c);
         // solve aa' b' | isDiagonalSM aa' = return $ reciprocal aa' #> b'           (Sparse.hs:1024-1025)
         if (A->is_diagonal) {
             SLA_TRY(launch_diag_solve(c, b->n_local, A->d_val, b->d, x_out->d));
-            SLA_HIP_TRY(hipStreamSynchronize(c->stream));
+            SLA_HIP_TRY(hipStreamSynchronize(stream_of(c)));
             if (info) info->flags = SLA_FLAG_DIAGONAL;
             return SLA_OK;
         }
@@ -854,7 +887,7 @@ int sla_linsolve0(int method, sla_csr_t A, sla_vec_t b, sla_vec_t x0, const sla_
         }
         if (rc == SLA_OK) rc = sla_vec_copy(S->x, x_out);
         if (rc == SLA_OK) {
-            hipError_t e = hipStreamSynchronize(c->stream);
+            hipError_t e = hipStreamSynchronize(stream_of(c));
             if (e != hipSuccess) rc = fail(SLA_ERR_HIP, hipGetErrorString(e));
         }
         if (rc == SLA_OK) fill_info(S, info, true);
@@ -872,9 +905,10 @@ int sla_arnoldi(sla_csr_t A, sla_vec_t b, int kn, double *Q_colmajor, double *H_
         if (A->m != A->n) return fail(SLA_ERR_DIM_MISMATCH, "arnoldi : matrix must be square");
         if (kn < 1 || kn + 1 > kMaxKrylov) return fail(SLA_ERR_INVALID, "sla_arnoldi: kn must be in [1, 63]");
         sla_ctx *c = A->ctx;
-        (void)hipSetDevice(c->device);
+        if (!b->kids.empty() || b->ctx != c) return mixed_handles("sla_arnoldi");
+        Bind bind(c);
         ArnoldiWs ws;
-        SLA_TRY(arn_alloc(ws, A, b, kn));
+        SLA_TRY(arn_alloc_agreed(ws, A, b, kn));
         int k = 0;
         SLA_TRY(arn_run(ws, A, b->d, kn, &k));
         memcpy(H_colmajor, ws.Hhost.data(), sizeof(double) * (size_t)(kn + 1) * (size_t)kn);
@@ -901,12 +935,29 @@ int sla_gmres(sla_csr_t A, sla_vec_t b, sla_vec_t x0, int restart, const sla_sol
         if (restart < 1) return fail(SLA_ERR_INVALID, "sla_gmres: restart must be >= 1");
         restart = std::min<int64_t>({(int64_t)restart, (int64_t)kMaxKrylov - 1, std::max<int64_t>(A->n, 1)});
         sla_ctx *c = A->ctx;
-        (void)hipSetDevice(c->device);
+        if (!b->kids.empty() || !x0->kids.empty() || !x_out->kids.empty() || b->ctx != c || x0->ctx != c || x_out->ctx != c) return mixed_handles("sla_gmres");
+        Bind bind(c);
         ArnoldiWs ws;
-        SLA_TRY(arn_alloc(ws, A, b, restart));
         sla_vec *x = nullptr, *r = nullptr;
-        SLA_TRY(vec_alloc(c, A->n, &x));
-        int rc = vec_alloc(c, A->n, &r);
+        int rc;
+        {   // all local allocations first, then one agreement (a rank failing here must not leave its peers in a collective)
+            rc = arn_alloc(ws, A, b, restart);
+            if (rc == SLA_OK) rc = vec_alloc(c, A->n, &x);
+            if (rc == SLA_OK) rc = vec_alloc(c, A->n, &r);
+            const std::string msg = rc != SLA_OK ? sla_last_error() : "";
+            int bad = rc != SLA_OK ? 1 : 0;
+            if (c->collectives) {
+                const int rca = dist_allreduce_max_i32(c, &bad);
+                if (rc == SLA_OK) rc = rca;
+            }
+            if (rc == SLA_OK && bad) rc = fail(SLA_ERR_ALLOC, "GMRES workspace allocation failed on another rank of the row-sharded job");
+            else if (rc != SLA_OK && !msg.empty()) set_error(msg);
+            if (rc != SLA_OK) {
+                sla_vec_destroy(x);
+                sla_vec_destroy(r);
+                return rc;
+            }
+        }
         double tol = 0.0, beta = NAN, r0norm = NAN;
         int total = 0, flags = 0;
         bool first = true;
@@ -931,16 +982,16 @@ int sla_gmres(sla_csr_t A, sla_vec_t b, sla_vec_t x0, int restart, const sla_sol
             if ((rc = arn_run(ws, A, r->d, mc, &k)) != SLA_OK) break;
             if (ws.h_sc->flags & SLA_FLAG_BREAKDOWN) flags |= SLA_FLAG_BREAKDOWN;
             hessenberg_lsq(k, ws.kn + 1, ws.Hhost.data(), beta, y.data());
-            hipError_t e = hipMemcpyAsync(ws.ycoef, y.data(), sizeof(double) * (size_t)k, hipMemcpyHostToDevice, c->stream);
+            hipError_t e = hipMemcpyAsync(ws.ycoef, y.data(), sizeof(double) * (size_t)k, hipMemcpyHostToDevice, stream_of(c));
             if (e != hipSuccess) { rc = fail(SLA_ERR_HIP, hipGetErrorString(e)); break; }
             if ((rc = launch_gemv_accum(c, x->n_local, ws.Q, ws.ld, k, ws.ycoef, x->d)) != SLA_OK) break;
-            e = hipStreamSynchronize(c->stream);  // y is host memory reused next cycle
+            e = hipStreamSynchronize(stream_of(c));  // y is host memory reused next cycle
             if (e != hipSuccess) { rc = fail(SLA_ERR_HIP, hipGetErrorString(e)); break; }
             total += k;
         }
         if (rc == SLA_OK) rc = sla_vec_copy(x, x_out);
         if (rc == SLA_OK) {
-            hipError_t e = hipStreamSynchronize(c->stream);
+            hipError_t e = hipStreamSynchronize(stream_of(c));
             if (e != hipSuccess) rc = fail(SLA_ERR_HIP, hipGetErrorString(e));
         }
         if (rc == SLA_OK && info) {
@@ -962,6 +1013,7 @@ int sla_linsolve(sla_csr_t A, sla_vec_t b, sla_vec_t x_out, sla_solve_info *info
     if (A && !A->kids.empty()) return m_linsolve(A, b, x_out, info);
     return no_throw("sla_linsolve", [&]() -> int {
         if (!A || !b || !x_out) return fail(SLA_ERR_INVALID, "sla_linsolve: null argument");
+        Bind bind(A->ctx);
         sla_vec *x0 = nullptr;
         SLA_TRY(vec_alloc(A->ctx, A->n, &x0));
         int rc = launch_fill(A->ctx, x0->n_local, 0.1, x0->d);

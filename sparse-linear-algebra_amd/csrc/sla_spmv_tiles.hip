@@ -142,7 +142,7 @@ spmv_tile_kernel(SpmvArgs<RP> a, const RP *__restrict__ rowptr, const int32_t *_
             known = v;
             if (known >= need) break;
             __builtin_amdgcn_s_sleep(4);
-            if (++spins > 50000) pace = false;
+            if (++spins > 2000) pace = false;   // (~2 ms of polling: a legitimate wait is tens of microseconds)
         }
     };
     int round = 0;
@@ -229,6 +229,27 @@ spmv_tile_kernel(SpmvArgs<RP> a, const RP *__restrict__ rowptr, const int32_t *_
     spmv_extra_partials<EPI>(a, s_red, tid);
 }
 
+// Panel pacing assumes the MI355X dispatch order: 8 XCDs, workgroup b on XCD b % 8 (tools/xcc_probe.cpp).  On another
+// partition mode or part the slots a wavefront polls would belong to workgroups of another XCD, whose workgroup-scope stores
+// may never become visible: every wavefront would spin to its limit on every launch.  So the layout is PROBED once per
+// context (HW_REG_XCC_ID of the first 256 workgroups of a launch) and pacing is only used when it is the expected one.
+__global__ void xcc_probe_kernel(int *out) {
+    if (threadIdx.x == 0) out[blockIdx.x] = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));   // XCC_ID, bits [3:0]
+}
+int probe_xcd_layout(sla_ctx *c) {
+    if (c->xcd8 >= 0) return SLA_OK;
+    int *d = (int *)(c->d_result + 1024);   // 256 ints of the context's scratch
+    hipLaunchKernelGGL(xcc_probe_kernel, dim3(256), dim3(64), 0, stream_of(c), d);
+    SLA_HIP_TRY(hipGetLastError());
+    int h[256];
+    SLA_HIP_TRY(hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, stream_of(c)));
+    SLA_HIP_TRY(hipStreamSynchronize(stream_of(c)));
+    int ok = 1;
+    for (int b = 0; b < 256; ++b) ok &= h[b] == (b & 7);
+    c->xcd8 = ok;
+    return SLA_OK;
+}
+
 bool tiles_on(const sla_csr *A) { return A->use_tiles && A->ctx->tiles && A->ctx->spmv_algo == 0; }
 
 int tiles_grid(const sla_csr *A) {
@@ -263,9 +284,9 @@ static int launch_tiles_t(const sla_csr *A, const SpmvLaunch &l) {
     a.step_begin = l.step_begin;
     a.yinit = nullptr;
     ProfScope prof(c, l.kernel_id);
-    if (A->d_tlprog) SLA_HIP_TRY(hipMemsetAsync(A->d_tlprog, 0, A->tlprog_bytes, c->stream));   // the pacing table of this launch
-    hipLaunchKernelGGL((spmv_tile_kernel<EPI, RP>), dim3(tiles_grid(A)), dim3(kBlock), 0, c->stream, a, a.rowptr, A->d_tlrow, A->d_tloff,
-                       A->d_tlidx, A->d_tlval, l.x, A->tl_S, A->tl_P, A->tl_shift, A->d_tlprog, c->tile_slack);
+    if (A->d_tlprog) SLA_HIP_TRY(hipMemsetAsync(A->d_tlprog, 0, A->tlprog_bytes, stream_of(c)));   // the pacing table of this launch
+    hipLaunchKernelGGL((spmv_tile_kernel<EPI, RP>), dim3(tiles_grid(A)), dim3(kBlock), 0, stream_of(c), a, a.rowptr, A->d_tlrow, A->d_tloff,
+                       A->d_tlidx, A->d_tlval, l.x, A->tl_S, A->tl_P, A->tl_shift, A->d_tlprog, c->xcd8 == 1 ? c->tile_slack : 0);
     SLA_HIP_TRY(hipGetLastError());
     return SLA_OK;
 }

@@ -198,7 +198,7 @@ template <int EPI, int NP>
 static int launch_np(const sla_csr *A, const SpmvArgs<int32_t> &a, const int32_t *sched, int32_t nblk, int grid, int stream_nt) {
     sla_ctx *c = A->ctx;
 #define SLA_WDL_LAUNCH(NW_)                                                                                                              \
-    hipLaunchKernelGGL((spmv_wdia_lds_kernel<EPI, NP, NW_>), dim3(grid), dim3(kBlock), 0, c->stream, a, (const wd_u64x8s *)A->d_wum, a.x, \
+    hipLaunchKernelGGL((spmv_wdia_lds_kernel<EPI, NP, NW_>), dim3(grid), dim3(kBlock), 0, stream_of(c), a, (const wd_u64x8s *)A->d_wum, a.x, \
                        nblk, A->nslices, (int32_t)A->row_begin, A->wd_col_lo, A->wd_col_hi + 1, sched, c->xcd_remap, stream_nt, A->wd_win, A->wd_uni)
     if (wd_lds_nw(A) == 4) SLA_WDL_LAUNCH(4);
     else SLA_WDL_LAUNCH(kWdWinLoads);

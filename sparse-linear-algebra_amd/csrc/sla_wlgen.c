@@ -141,3 +141,96 @@ int64_t sla_wl_random_spd(int64_t n, int64_t k, const int64_t *c, const double *
     free(start); free(e); free(cnt); free(diag);
     return nnz;
 }
+
+
+/* The same matrix, rows [rb, re) only (a rank of the row-sharded bench builds its own slab; global column ids):
+ * rowptr has re - rb + 1 entries starting at 0.  col == NULL: returns an upper bound of the slab's entry count (size the
+ * col / val buffers with it); otherwise fills rowptr / col / val and returns the slab's nnz.  -1: allocation failure.
+ * Bit-identical to rows [rb, re) of sla_wl_random_spd (tests/test_cabi_and_host.py). */
+int64_t sla_wl_random_spd_rows(int64_t n, int64_t k, const int64_t *c, const double *v, int64_t rb, int64_t re, int64_t *rowptr,
+                               int64_t *col, double *val) {
+    const int64_t picks = n * k, rows = re - rb;
+    int64_t *start = (int64_t *)calloc((size_t)rows + 1, sizeof(int64_t));
+    if (!start) return -1;
+#pragma omp parallel
+    {
+        const int nt = omp_get_num_threads(), t = omp_get_thread_num();
+        const int64_t lo = rb + rows * t / nt, hi = rb + rows * (t + 1) / nt;
+        for (int64_t r = lo; r < hi; ++r)
+            for (int64_t i = r * k; i < (r + 1) * k; ++i) start[r - rb + 1] += (c[i] != r);
+        for (int64_t i = 0; i < picks; ++i) {
+            const int64_t d = c[i];
+            if (d >= lo && d < hi && d != i / k) start[d - rb + 1]++;
+        }
+    }
+    for (int64_t i = 0; i < rows; ++i) start[i + 1] += start[i];
+    const int64_t total = start[rows];
+    if (!col) { free(start); return total + rows; }
+    ent_t *e = (ent_t *)malloc((size_t)(total ? total : 1) * sizeof(ent_t));
+    int64_t *fill = (int64_t *)malloc((size_t)(rows ? rows : 1) * sizeof(int64_t));
+    int64_t *cnt = (int64_t *)malloc((size_t)(rows ? rows : 1) * sizeof(int64_t));
+    double *diag = (double *)malloc((size_t)(rows ? rows : 1) * sizeof(double));
+    if (!e || !fill || !cnt || !diag) { free(start); free(e); free(fill); free(cnt); free(diag); return -1; }
+    memcpy(fill, start, (size_t)rows * sizeof(int64_t));
+#pragma omp parallel
+    {
+        const int nt = omp_get_num_threads(), t = omp_get_thread_num();
+        const int64_t lo = rb + rows * t / nt, hi = rb + rows * (t + 1) / nt;
+        for (int64_t r = lo; r < hi; ++r)           /* the (r, c) halves, list order */
+            for (int64_t i = r * k; i < (r + 1) * k; ++i)
+                if (c[i] != r) { ent_t w = {c[i], 0.5 * v[i]}; e[fill[r - rb]++] = w; }
+        for (int64_t i = 0; i < picks; ++i) {       /* then the mirrored (c, r) halves, list order */
+            const int64_t d = c[i];
+            if (d >= lo && d < hi) {
+                const int64_t r = i / k;
+                if (d != r) { ent_t w = {r, 0.5 * v[i]}; e[fill[d - rb]++] = w; }
+            }
+        }
+    }
+    free(fill);
+    int alloc_failed = 0;
+    int64_t longest = 0;
+    for (int64_t r = 0; r < rows; ++r) if (start[r + 1] - start[r] > longest) longest = start[r + 1] - start[r];
+#pragma omp parallel
+    {
+    ent_t *tmp = (ent_t *)malloc((size_t)(longest ? longest : 1) * sizeof(ent_t));
+#pragma omp for schedule(static, 4096)
+    for (int64_t r = 0; r < rows; ++r) {
+        ent_t *row = e + start[r];
+        const int64_t m = start[r + 1] - start[r];
+        if (m > 32 && !tmp) { alloc_failed = 1; continue; }
+        sort_row(row, m, tmp);
+        int64_t w = 0;
+        for (int64_t i = 0; i < m;) {
+            int64_t j = i + 1;
+            double s = row[i].val;
+            while (j < m && row[j].col == row[i].col) s += row[j++].val;
+            row[w].col = row[i].col;
+            row[w].val = s;
+            ++w;
+            i = j;
+        }
+        double a = 0.0;
+        for (int64_t i = 0; i < w; ++i) a += fabs(row[i].val);
+        cnt[r] = w;
+        diag[r] = 1.0 + a;
+    }
+    free(tmp);
+    }
+    if (alloc_failed) { free(start); free(e); free(cnt); free(diag); return -1; }
+    rowptr[0] = 0;
+    for (int64_t r = 0; r < rows; ++r) rowptr[r + 1] = rowptr[r] + cnt[r] + 1;
+#pragma omp parallel for schedule(static, 4096)
+    for (int64_t r = 0; r < rows; ++r) {
+        const ent_t *row = e + start[r];
+        const int64_t g = rb + r;
+        int64_t o = rowptr[r];
+        int64_t i = 0;
+        for (; i < cnt[r] && row[i].col < g; ++i, ++o) { col[o] = row[i].col; val[o] = row[i].val; }
+        col[o] = g; val[o] = diag[r]; ++o;
+        for (; i < cnt[r]; ++i, ++o) { col[o] = row[i].col; val[o] = row[i].val; }
+    }
+    const int64_t nnz = rowptr[rows];
+    free(start); free(e); free(cnt); free(diag);
+    return nnz;
+}

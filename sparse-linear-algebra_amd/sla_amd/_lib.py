@@ -18,6 +18,7 @@ KERNEL_ALL = -1
 KERNEL_SPMV, KERNEL_SPMV_DOT, KERNEL_SPMV_DOT2, KERNEL_SPMV_RES, KERNEL_SPMV_DUAL = 0, 1, 2, 3, 4
 KERNEL_BICG_K2, KERNEL_BICG_K4, KERNEL_BICG_K5, KERNEL_CGS_C2, KERNEL_CGS_C4 = 5, 6, 7, 8, 9
 KERNEL_BICG_K45 = 10
+KERNEL_EXCHANGE, KERNEL_SUMS = 11, 12
 
 
 class SlaError(RuntimeError):
@@ -72,6 +73,10 @@ PROTOTYPES = [
     ("sla_ctx_destroy", _int, [_vp]),
     ("sla_ctx_sync", _int, [_vp]),
     ("sla_ctx_rank", _int, [_vp, _pint, _pint]),
+    ("sla_ctx_set_option", _int, [_vp, C.c_char_p, C.c_char_p]),
+    ("sla_ctx_get_option", _int, [_vp, C.c_char_p, C.c_char_p, _int]),
+    ("sla_debug_binding_violations", C.c_long, []),
+    ("sla_stream_probe", _int, [_vp, _int, _int, _i64, _int, _pdbl, _pdbl]),
     ("sla_ctx_row_range", _int, [_vp, _i64, _pi64, _pi64]),
     ("sla_last_error", C.c_char_p, []),
     ("sla_version", C.c_char_p, []),

@@ -80,6 +80,33 @@ class Context:
     def sync(self):
         check(lib().sla_ctx_sync(self.h))
 
+    def set_option(self, name, value):
+        """Typed entry for the tuning / A-B knobs (sla_ctx_set_option): name = the knob's lower-case name ("wdia", "tile_shift",
+        "x_exchange", ...).  Lowering knobs apply to matrices created afterwards.  Returns self (chainable)."""
+        check(lib().sla_ctx_set_option(self.h, str(name).encode(), str(value).encode()))
+        return self
+
+    def set_options(self, **kw):
+        for k, v in kw.items():
+            self.set_option(k, v)
+        return self
+
+    def stream_probe(self, reads, writes, n, reps=20):
+        """(mean ms, min ms, GB/s at the mean) of a sweep reading `reads` and writing `writes` vectors of n doubles (sla_stream_probe)."""
+        mean, mn = C.c_double(), C.c_double()
+        check(lib().sla_stream_probe(self.h, reads, writes, int(n), reps, C.byref(mean), C.byref(mn)))
+        return mean.value, mn.value, 8.0 * (reads + writes) * (int(n) & ~1) / (mean.value * 1e-3) / 1e9
+
+    def get_option(self, name):
+        buf = C.create_string_buffer(64)
+        check(lib().sla_ctx_get_option(self.h, str(name).encode(), buf, 64))
+        return buf.value.decode()
+
+    @staticmethod
+    def binding_violations():
+        """SLA_DEBUG_BINDING=1: device work issued by a thread not bound to the context it belongs to (0 in a correct library)."""
+        return int(lib().sla_debug_binding_violations())
+
     def prof_start(self, kernel_id, max_launches):
         check(lib().sla_prof_start(self.h, kernel_id, max_launches))
 

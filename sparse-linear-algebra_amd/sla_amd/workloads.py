@@ -95,6 +95,8 @@ def _wlgen():
             L = C.CDLL(so)
             L.sla_wl_random_spd.restype = C.c_int64
             L.sla_wl_random_spd.argtypes = [C.c_int64, C.c_int64] + [C.c_void_p] * 5
+            L.sla_wl_random_spd_rows.restype = C.c_int64
+            L.sla_wl_random_spd_rows.argtypes = [C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64] + [C.c_void_p] * 3
             _WLGEN = L
     return _WLGEN or None
 
@@ -117,6 +119,30 @@ def random_spd(n, k=16, seed=42):
     if nnz < 0:
         raise MemoryError("sla_wl_random_spd")
     return (n, n), (rowptr, col[:nnz], val[:nnz])
+
+
+def random_spd_rows(n, k, seed, row_begin, row_end):
+    """Rows [row_begin, row_end) of random_spd(n, k, seed) (rowptr rebased to 0, global column ids) without assembling the
+    other rows: a rank of the row-sharded bench draws the full pick list (2 x n k numbers) and builds its own slab only."""
+    L = _wlgen()
+    if L is None:
+        from .partition import local_rows_of
+        dims, (rp, ci, va) = random_spd_numpy(n, k, seed)
+        return dims, local_rows_of(rp, ci, va, row_begin, row_end)
+    rng = np.random.Generator(np.random.PCG64(seed))
+    c = rng.integers(0, n, size=n * k, dtype=np.int64)
+    v = rng.uniform(-1.0, 1.0, size=n * k)
+    rows = row_end - row_begin
+    rowptr = np.empty(rows + 1, dtype=np.int64)
+    cap = L.sla_wl_random_spd_rows(n, k, c.ctypes.data, v.ctypes.data, row_begin, row_end, None, None, None)
+    if cap < 0:
+        raise MemoryError("sla_wl_random_spd_rows")
+    col = np.empty(max(cap, 1), dtype=np.int64)
+    val = np.empty(max(cap, 1), dtype=np.float64)
+    nnz = L.sla_wl_random_spd_rows(n, k, c.ctypes.data, v.ctypes.data, row_begin, row_end, rowptr.ctypes.data, col.ctypes.data, val.ctypes.data)
+    if nnz < 0:
+        raise MemoryError("sla_wl_random_spd_rows")
+    return (n, n), (rowptr, col[:nnz].copy(), val[:nnz].copy())
 
 
 def random_spd_numpy(n, k=16, seed=42):

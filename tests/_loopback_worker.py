@@ -58,6 +58,8 @@ def gen(b=0, e=None):
         return wl.laplace3d(17, 1, 1, b, e)              # exchange is the window kind (one element from each neighbour)
     if KIND == "laplace_big":                            # 64000 rows: slabs of >= 31 steps of 512 rows, 4 boundary steps per side --
         return wl.laplace3d(40, 40, 40, b, e)            # the interior / boundary split of the overlapped (#>) (spmv_exchanged)
+    if KIND == "laplace_2m":                             # 128^3: slabs of >= 1024 steps of 512 rows (quick mode only: see QUICK)
+        return wl.laplace3d(128, 128, 128, b, e)
     if KIND == "laplace":
         return wl.laplace3d(14, 11, 13, b, e)            # window exchange (slab stencil), dictionary codes
     if KIND == "banded":
@@ -75,6 +77,10 @@ def gen(b=0, e=None):
             _FUZZ["denseband"] = ((nn, nn), (A.rowptr, A.colidx, A.val))
         from sla_amd.partition import local_rows_of
         dims, (rp, ci, va) = _FUZZ["denseband"]
+        return dims, local_rows_of(rp, ci, va, b, dims[0] if e is None else e)
+    if KIND == "randtile":                               # 20000 rows x ~17 random columns with SLA_TILE_SHIFT=10: the row-slice x
+        dims, (rp, ci, va) = wl.random_spd(20000, 8, 11)  # column-panel TILE form on every slab (all-gathered x, row_begin > 0)
+        from sla_amd.partition import local_rows_of
         return dims, local_rows_of(rp, ci, va, b, dims[0] if e is None else e)
     if KIND == "dense":                                  # ~120 entries per row: LDS-panel form on every slab
         dims, (rp, ci, va) = wl.random_spd(2400, 60, 5)
@@ -102,6 +108,9 @@ def solve(ctx, method, A, bvec, x0, **kw):
     return out, info
 
 
+QUICK = KIND == "laplace_2m"   # large slabs: (#>) and three BiCGSTAB steps against the oracle only
+
+
 def rank_main(rank):
     try:
         ctx = sla.Context.loopback(rank, P, 4242)
@@ -112,6 +121,16 @@ def rank_main(rank):
         yv = sla.DeviceVector(ctx, n)
         _lib.check(lib.sla_spmv(A.h, xv.h, yv.h))
         r = {"kernel": A.kernel_info(), "y": yv.to_host_local(), "range": (b, e)}
+        if QUICK:
+            bvec = sla.DeviceVector(ctx, n, bg[b:e], local=True)
+            st = sla.bicgsInit(A, bvec, sla.DeviceVector(ctx, n))
+            st.step(3)
+            x3 = sla.DeviceVector(ctx, n)
+            _lib.check(lib.sla_solver_get(st.h, 0, x3.h))
+            r["x3"] = x3.to_host_local()
+            results[rank] = r
+            ctx.sync()
+            return
         _lib.check(lib.sla_spmv_t(A.h, xv.h, yv.h))
         r["yt"] = yv.to_host_local()
         dd = C.c_double()
@@ -153,6 +172,15 @@ if KIND in ("random", "dense", "denseband") or (KIND.startswith("fuzz") and "wdi
     assert np.abs(y - yo).max() <= 4e-15 * np.abs(VA).max() * np.abs(xg).max() * 16, np.abs(y - yo).max()
 else:
     assert np.array_equal(y, yo), "sharded (#>) must equal the whole-matrix left fold bit for bit"
+if QUICK:
+    so = orc.BicgstabState(Ao, bg, np.zeros(n))
+    so.step(bg, 3)
+    x3 = cat("x3")
+    assert np.linalg.norm(x3 - so.x) <= 1e-9 * np.linalg.norm(so.x), np.linalg.norm(x3 - so.x)
+    assert sla.Context.binding_violations() == 0
+    print("KERNEL", results[0]["kernel"])
+    print("LOOPBACK_OK", P, KIND, results[0]["kernel"].split()[0])
+    sys.exit(0)
 yt = cat("yt")
 assert np.allclose(yt, orc.spmv(orc.transpose(Ao), xg), rtol=1e-13, atol=1e-13)
 assert all(np.array_equal(results[r]["full"], yt) for r in range(P))
@@ -185,6 +213,9 @@ xgm = np.concatenate([results[r]["gmres"][0] for r in range(P)])
 assert (results[0]["gmres"][2] & 1) == 1 and np.linalg.norm(orc.spmv(Ao, xgm) - bg) <= 1e-4 * np.linalg.norm(bg) + 1e-6
 if KIND in ("dense", "denseband"):
     assert all("ldspanels" in results[r]["kernel"] for r in range(P)), results[0]["kernel"]
+if KIND == "randtile":   # (the tile form folds every row entry by entry in ascending column order: y was compared bit for bit above)
+    assert all("algo=tiles" in results[r]["kernel"] and "x_exchange=allgather" in results[r]["kernel"] for r in range(P)), results[0]["kernel"]
+assert sla.Context.binding_violations() == 0, "device work issued by a thread not bound to its context (SLA_DEBUG_BINDING)"
 import hashlib  # noqa: E402
 for _m in ("bicgstab", "cgs"):
     print("XHASH", _m, hashlib.sha1(np.concatenate([results[r][_m][0] for r in range(P)]).tobytes()).hexdigest(), results[0][_m][1])

@@ -9,8 +9,23 @@ for p in (ROOT, os.path.join(ROOT, "sparse-linear-algebra_amd"), os.path.join(RO
         sys.path.insert(0, p)
 
 
+# Every GPU test (and every worker process it spawns) runs under the library's device-binding assertion: launches, copies,
+# collectives and allocations must come from a thread that is inside an entry point bound to the context they belong to
+# (sla_internal.hpp: Bind / stream_of / dev_malloc).  On a one-GPU box a wrong current device is invisible -- every id is 0 --
+# so this is how the multi-device fan-out (sla_ctx_create_multi's worker threads) is checked there.  Read when the library loads.
+os.environ.setdefault("SLA_DEBUG_BINDING", "1")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(autouse=True)
+def _no_binding_violations(request):
+    yield
+    if "gpu" in request.keywords and _has_gpu():
+        import sla_amd
+        assert sla_amd.Context.binding_violations() == 0, "device work issued by a thread not bound to its context (SLA_DEBUG_BINDING)"
 
 
 def _has_gpu():

@@ -112,3 +112,14 @@ def test_matrix_market_banner_is_case_insensitive():
     entry point itself needs a GPU context (tests/test_gpu_edge_cases.py reads the golden .mtx files through it)."""
     src = open(os.path.join(ROOT, "sparse-linear-algebra_amd", "csrc", "sla_mmio.cpp")).read()
     assert "tolower" in src and src.index("tolower") < src.index('banner.find("coordinate")')
+
+
+def test_option_and_debug_symbols_are_exported():
+    """The typed knob entry (sla_ctx_set_option / _get_option) and the binding-violation counter are part of include/sla_hip.h."""
+    from sla_amd import _lib
+    names = [p[0] for p in _lib.PROTOTYPES]
+    for nm in ("sla_ctx_set_option", "sla_ctx_get_option", "sla_debug_binding_violations"):
+        assert nm in names
+    hdr = open(os.path.join(ROOT, "include", "sla_hip.h")).read()
+    for nm in names:
+        assert nm + "(" in hdr, nm

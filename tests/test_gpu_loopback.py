@@ -18,6 +18,31 @@ def test_sharded_path_on_loopback_ranks(nranks, kind):
     assert out.returncode == 0 and f"LOOPBACK_OK {nranks} {kind}" in out.stdout, out.stdout[-3000:]
 
 
+def test_split_launch_partials_stay_inside_their_slot_array():
+    """the interior and the boundary launch of an overlapped (#>) write their fused partial sums into consecutive
+    slots of one 2048-slot array.  With SLA_WD_GRID=2048 on slabs of >= 2048 interior steps (128^3 on 2 ranks) an unclamped
+    interior grid pushed the boundary partials into the NEXT array (omega silently wrong on the plain sharded flow): three
+    BiCGSTAB steps must match the oracle."""
+    env = dict(os.environ, SLA_WD_GRID="2048", SLA_BICG_GHOST="0")
+    out = subprocess.run([sys.executable, os.path.join(HERE, "_loopback_worker.py"), "2", "laplace_2m"], env=env,
+                         stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert out.returncode == 0 and "LOOPBACK_OK 2 laplace_2m" in out.stdout, out.stdout[-3000:]
+    assert "overlap=streams" in out.stdout and "grid=2048" in out.stdout, out.stdout[-2000:]
+
+
+@pytest.mark.parametrize("nranks", [2, 3, 4])
+def test_tile_form_on_row_slabs(nranks):
+    """The row-slice x column-panel tile form (BASELINE config 3a's SpMV) on ROW SLABS of a random matrix: SLA_TILE_SHIFT=10 makes
+    a 20 000-row matrix take it (20 panels), every rank lowers its own slab (row_begin > 0, global column ids, x all-gathered into
+    the full-length buffer).  The worker requires (#>) bit-identical to the oracle's left fold and runs BiCGSTAB, CGS, CGNE, Arnoldi
+    and GMRES through the fused epilogues of the tile kernel."""
+    env = dict(os.environ, SLA_TILE_SHIFT="10")
+    out = subprocess.run([sys.executable, os.path.join(HERE, "_loopback_worker.py"), str(nranks), "randtile"], env=env,
+                         stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert out.returncode == 0 and f"LOOPBACK_OK {nranks} randtile" in out.stdout, out.stdout[-3000:]
+    assert "algo=tiles" in out.stdout
+
+
 @pytest.mark.parametrize("seed,nranks", [(1, 2), (2, 3), (3, 4), (4, 5), (6, 3)])
 def test_sharded_path_on_random_banded_matrices(seed, nranks):
     """Random banded matrices (constant / arbitrary values, ragged rows, odd slab boundaries) through the sharded path:

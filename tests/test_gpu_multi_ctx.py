@@ -69,3 +69,60 @@ def test_one_caller_many_devices(sla, nranks):
         sla.mSsorPre(A, 1.0)
     del s0, s2, A
     ctx.close()
+
+
+def test_options_are_typed_per_context_and_reach_every_rank(sla):
+    """sla_ctx_set_option: the knob table without the environment.  Two contexts in one process hold different settings; a lowering
+    knob applies to matrices created afterwards; a multi-device parent hands the option to every rank context."""
+    from sla_amd import workloads as wl
+    dims, (rp, ci, va) = wl.laplace3d(20, 20, 20)
+    a, b = sla.Context(0), sla.Context(0)
+    a.set_options(wdia=0, vdict=0, diag=0)
+    assert a.get_option("wdia") == "0" and b.get_option("wdia") == "1"
+    Aa, Ab = sla.fromCSR(dims, rp, ci, va, a), sla.fromCSR(dims, rp, ci, va, b)
+    assert "algo=stream" in Aa.kernel_info() and "algo=wdia" in Ab.kernel_info()
+    x = np.random.default_rng(1).standard_normal(dims[0])
+    assert np.array_equal(sla.matVec(Aa, sla.fromVector(x, a)).toDenseListSV(), sla.matVec(Ab, sla.fromVector(x, b)).toDenseListSV())
+    with pytest.raises(sla.SlaError):
+        a.set_option("no_such_knob", 1)
+    with pytest.raises(sla.SlaError):
+        a.set_option("tile_shift", 99)
+    assert a.set_option("x_exchange", "window").get_option("x_exchange") == "window"
+    m = sla.Context.multi([0, 0])
+    m.set_option("bicg_ghost", 0)
+    assert m.get_option("bicg_ghost") == "0"
+    del Aa, Ab
+    for c in (a, b, m):
+        c.close()
+
+
+def test_single_device_handles_do_not_mix_with_bundles(sla):
+    """a bundle of a multi-device context carries n but no device pointer: combining it with a single-device matrix or
+    vector passed the dimension checks and faulted on the GPU.  Every such combination is refused with SLA_ERR_INVALID."""
+    from sla_amd import _lib, workloads as wl
+    import ctypes as C
+    lib = _lib.lib()
+    dims, (rp, ci, va) = wl.laplace3d(8, 8, 8)
+    n = dims[0]
+    one, many = sla.Context(0), sla.Context.multi([0, 0])
+    A1 = sla.fromCSR(dims, rp, ci, va, one)
+    v1, w1 = sla.DeviceVector(one, n, np.ones(n)), sla.DeviceVector(one, n)
+    vm, wm = sla.DeviceVector(many, n, np.ones(n)), sla.DeviceVector(many, n)
+    d = C.c_double()
+    info = _lib.SolveInfo()
+    st = C.c_void_p()
+    calls = [lambda: lib.sla_spmv(A1.h, vm.h, w1.h), lambda: lib.sla_spmv(A1.h, v1.h, wm.h), lambda: lib.sla_spmv_t(A1.h, vm.h, w1.h),
+             lambda: lib.sla_dot(v1.h, vm.h, C.byref(d)), lambda: lib.sla_axpby(1.0, v1.h, 1.0, vm.h), lambda: lib.sla_vec_copy(v1.h, vm.h),
+             lambda: lib.sla_solver_init(4, A1.h, vm.h, w1.h, C.byref(st)),
+             lambda: lib.sla_linsolve0(4, A1.h, v1.h, w1.h, None, wm.h, C.byref(info)),
+             lambda: lib.sla_gmres(A1.h, vm.h, w1.h, 10, None, w1.h, C.byref(info)),
+             lambda: lib.sla_dot(vm.h, v1.h, C.byref(d)), lambda: lib.sla_axpby(1.0, vm.h, 1.0, v1.h)]
+    for i, f in enumerate(calls):
+        assert f() == _lib.ERR_INVALID, i
+    other = sla.Context(0)
+    vo = sla.DeviceVector(other, n, np.ones(n))
+    assert lib.sla_spmv(A1.h, vo.h, w1.h) == _lib.ERR_INVALID          # a vector of another single-device context
+    assert lib.sla_spmv(A1.h, v1.h, w1.h) == _lib.OK
+    del A1, v1, w1, vm, wm, vo
+    for c in (one, many, other):
+        c.close()
