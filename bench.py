@@ -72,6 +72,18 @@ def workload(name, row_begin=0, row_end=None):
     raise SystemExit(f"unknown workload {name}")
 
 
+def host_threads_available():
+    """Cores this process may use: the affinity mask capped by a container CPU quota (cgroup v2 cpu.max)."""
+    threads = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            threads = max(1, min(threads, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return threads
+
+
 def cpu_baseline(dims, rp, ci, va, b, seconds):
     """The oracle (scalar C port of the reference's algorithm, 1 thread) timed on this host, on a bounded
     sample: as many bicgstabStep's of the SAME matrix as fit in ~`seconds`."""
@@ -101,13 +113,7 @@ def cpu_baseline(dims, rp, ci, va, b, seconds):
     # its own rows of the matrix copy and of the vectors it works on (orc_numa_copy), so a multi-socket host is not
     # starved by one NUMA node's memory
     try:
-        threads = len(os.sched_getaffinity(0))
-        try:  # a container CPU quota (cgroup v2 cpu.max) caps the useful thread count below the visible cores
-            quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
-            if quota != "max":
-                threads = max(1, min(threads, int(int(quota) / int(period))))
-        except (OSError, ValueError):
-            pass
+        threads = host_threads_available()
         os.environ.setdefault("OMP_NUM_THREADS", str(threads))
         os.environ.setdefault("OMP_PROC_BIND", "spread")
         os.environ.setdefault("OMP_PLACES", "cores")
@@ -295,7 +301,8 @@ def sharded_random_block(ctx, name, rank, world, sync_all, allreduce, steps, war
     n, k = {"random_spd_10m": (10000000, 16), "random_spd_small": (60000, 16)}[name]
     rb, re_ = row_block(n, rank, world)
     t0 = time.perf_counter()
-    dims, (rp, ci, va) = wl.random_spd_rows(n, k, 42, rb, re_)
+    # (the ranks of one node share its cores: each takes its share for the assembly -- an oversubscribed OpenMP team spins)
+    dims, (rp, ci, va) = wl.random_spd_rows(n, k, 42, rb, re_, threads=max(1, min(16, host_threads_available() // world)))
     t_gen = time.perf_counter() - t0
     nnz_local, n_local = int(rp[-1]), re_ - rb
     A = sla.fromCSRRows(dims, rb, rp, ci, va, ctx)

@@ -28,6 +28,7 @@ import Foreign.C.Types
 import System.Environment (lookupEnv)
 import System.IO.Unsafe (unsafePerformIO)
 import System.Mem.StableName
+import System.Mem.Weak (mkWeakPtr)
 
 import Control.Exception.Common (IterationException (..), MatrixException (..), OperandSizeMismatch (..))
 import qualified Data.Sparse.Internal.IntM as I      -- keys of the row map (IntM.hs:52-53)
@@ -87,8 +88,10 @@ pureThrow io = either (throwM :: MonadThrow m => SomeException -> m a) return (u
 
 -- | "Lower once": the device CSR of an 'R.SpMatrix', memoised per heap object.  The table is keyed by the hash of the
 --   matrix's 'StableName' (buckets hold the names themselves); the 'ForeignPtr' finalizer releases the device copy when
---   the entry is dropped ('forget') or the program ends.  fromListSM semantics are re-applied by the library (sort, last
---   duplicate wins), so toListSM's descending order is irrelevant.
+--   the entry is dropped.  Entries do not outlive their matrix: a weak pointer on the 'R.SpMatrix' (which the table itself
+--   does not keep alive -- a 'StableName' is not a reference) removes the entry when the matrix is garbage collected, so a
+--   program that builds matrices in a loop does not accumulate device copies.  fromListSM
+--   semantics are re-applied by the library (sort, last duplicate wins), so toListSM's descending order is irrelevant.
 {-# NOINLINE lowered #-}
 lowered :: IORef (IM.IntMap [(StableName (R.SpMatrix Double), ForeignPtr Csr)])
 lowered = unsafePerformIO (newIORef IM.empty)
@@ -102,6 +105,7 @@ lower aa = do
     Nothing -> do
       a <- upload1
       atomicModifyIORef' lowered (\t -> (IM.insertWith (++) (hashStableName sn) [(sn, a)] t, ()))
+      _ <- mkWeakPtr aa (Just (evict sn))      -- eviction when the matrix dies (the ForeignPtr finalizer then frees the device CSR)
       return a
   where
     (m, n) = R.dim aa
@@ -109,6 +113,10 @@ lower aa = do
     upload1 = withArrayLen is $ \nnz pr -> withArray js $ \pc -> withArray xs $ \pv -> alloca $ \out -> do
       c_csr_from_coo defaultCtx (fromIntegral m) (fromIntegral n) (fromIntegral nnz) pr pc pv 0 out >>= check "fromListSM"
       peek out >>= newForeignPtr p_csr_destroy
+
+evict :: StableName (R.SpMatrix Double) -> IO ()
+evict sn = atomicModifyIORef' lowered (\t -> (IM.update dropName (hashStableName sn) t, ()))
+  where dropName bucket = case filter ((/= sn) . fst) bucket of { [] -> Nothing; b -> Just b }
 
 upload :: R.SpVector Double -> IO (ForeignPtr Vec)
 upload v = withArray (R.toDenseListSV v) $ \p -> alloca $ \out -> do

@@ -67,6 +67,10 @@ typedef struct {
                               returned iterate is the reference's regardless of this value */
     int32_t true_residual; /* 1 (default) = recompute ||A x - b|| each iteration like the reference;
                               0 = extension: skip the check SpMV and run max_iters steps */
+    double *history;       /* sla_linsolve0: HOST buffer (may be NULL) receiving the residual trace -- history[j - 1] = the true residual
+                              norm ||A x_j - b|| the device evaluated after iteration j, j = 1 .. info->history_len: what cgsStepDebug
+                              (Sparse.hs:942-948) prints per iteration, kept in a device buffer during the solve and downloaded once */
+    int32_t history_cap;   /* its capacity in doubles (the trace stops there) */
 } sla_solve_opts;
 
 enum { /* sla_solve_info.flags */
@@ -83,6 +87,7 @@ typedef struct {
     double resnorm;  /* last true residual norm ||A x - b||_2 evaluated (NaN if none) */
     double r0norm;   /* ||b - A x0||_2 */
     double tol;      /* max tol_abs (tol_rel * r0norm) */
+    int32_t history_len; /* entries written to sla_solve_opts.history (= min (iters, history_cap); 0 without a trace) */
 } sla_solve_info;
 
 /* which state vector sla_solver_get returns: record fields _x/_r/_p/_u (Sparse.hs:919),

@@ -242,6 +242,21 @@ def arnoldi(A, b, kn):
     return rc, Qm, Hm, k
 
 
+def qr(a, stored=None):
+    """qr (Sparse.hs:306-331) of a dense m x n array (m >= n); stored: boolean mask of the IntMap's keys (None: the non-zeros).
+    Returns (rc, Q, R) with Q = transpose of the accumulated rotations, like the reference."""
+    a = np.asarray(a, dtype=np.float64)
+    m, n = a.shape
+    af = np.asfortranarray(a)
+    qt = np.zeros((m, m), dtype=np.float64, order="F")
+    r = np.zeros((m, n), dtype=np.float64, order="F")
+    st = None if stored is None else np.asfortranarray(np.asarray(stored, dtype=np.int8))
+    lib().orc_qr_dense.restype = C.c_int
+    rc = lib().orc_qr_dense(C.c_int64(m), C.c_int64(n), C.c_void_p(af.ctypes.data), None if st is None else C.c_void_p(st.ctypes.data),
+                            C.c_void_p(qt.ctypes.data), C.c_void_p(r.ctypes.data))
+    return rc, np.ascontiguousarray(qt.T), np.ascontiguousarray(r)
+
+
 def gmres(A, b, x0, restart=30, max_restarts=10, tol_abs=1e-6, tol_rel=1e-4):
     b, x0 = _f64(b), _f64(x0)
     x = np.zeros(A.n, dtype=np.float64)

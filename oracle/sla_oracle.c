@@ -478,33 +478,105 @@ int orc_arnoldi(const orc_csr *A, int64_t nb, const double *b, int64_t kn, doubl
 
 /* ---------------------------------------------------------------- A10: GMRES(m) */
 
-/* min_y || beta e1 - H y ||, H (k+1) x k column-major with leading dimension ldh, by Givens
- * rotations + back substitution (the commented sketch Sparse.hs:837-848 does qr + triUpperSolve). */
-static void hessenberg_lsq(int64_t k, int64_t ldh, const double *H, double beta, double *y) {
-    double *R = vnew((k + 1) * k), *g = vnew(k + 1);
-    for (int64_t j = 0; j < k; ++j)
-        for (int64_t i = 0; i <= k; ++i) R[j * (k + 1) + i] = H[j * ldh + i];
-    for (int64_t i = 0; i <= k; ++i) g[i] = 0.0;
-    g[0] = beta;
-    for (int64_t j = 0; j < k; ++j) {
-        double a = R[j * (k + 1) + j], b = R[j * (k + 1) + j + 1];
-        double d = hypot(a, b), c = 1.0, s = 0.0;
-        if (d != 0.0) { c = a / d; s = b / d; }
-        for (int64_t l = j; l < k; ++l) {
-            double u = R[l * (k + 1) + j], v = R[l * (k + 1) + j + 1];
-            R[l * (k + 1) + j] = c * u + s * v;
-            R[l * (k + 1) + j + 1] = -s * u + c * v;
+static int is_nz_val(double v) { return !(fabs(v) <= 1e-12); }      /* isNz = not . nearZero (Eps.hs:41-42) */
+int orc_tri_upper_solve(const orc_csr *T, const double *b, double *x, int64_t *bad_row);
+
+/* qr (Sparse.hs:306-331) with givens (:253-283) and givensCoef / hypot (:286-295), on a dense m x n array (m >= n, column-major,
+ * leading dimension m) that carries the IntMap's STRUCTURE next to the values: st[] marks the stored entries.
+ *   gminit = (eye m, mm, subdiagIndicesSM mm): the (i, j), i > j, stored in the INPUT, rows ascending, columns ascending inside a
+ *            row (IntMap2.hs:124-131) -- fixed up front, fill-in is never revisited;
+ *   per (i, j): nearZero (m @@ (i, j)) -> skip (:258); i' = the smallest row /= i whose FIRST stored column is j (:270-279), none ->
+ *            skip; (c, s, r) = givensCoef (m @@ (i', j)) (m @@ (i, j)) = (a / r, b / r, r), r = sqrt (a * a + b * b) -- sqrt, not libm hypot;
+ *            G = eye with (i, i) = c, (i, j) = - s, (j, i) = s, (j, j) = c (:263-267: rows i and j -- the COLUMN index j, not i': the
+ *            reference's own choice; on a Hessenberg matrix i' = j anyway);
+ *            qmatt' = g #~# qmatt, m' = g #~# m with #~# = sparsifySM . (##) (SpMatrix.hs:820-824): every entry of the two touched rows is
+ *            the ascending-k left fold from 0 of separately rounded products, then entries with |x| <= 1e-12 are dropped (also from
+ *            the untouched rows: sparsifySM filters the whole product);
+ *   result (transpose qt, r): Qt is returned as is (m x m, column-major), R in place of the input copy.
+ * The structure matters because candidateRows' looks at stored keys, not values. */
+static void qr_apply(int64_t m, int64_t ncols, int64_t i, int64_t j, double c, double s, double *M, char *st) {
+    for (int64_t col = 0; col < ncols; ++col) {
+        double *ci = M + col * m + i, *cj = M + col * m + j;
+        char *si = st + col * m + i, *sj = st + col * m + j;
+        /* row i of G: keys {j, i} ascending; row j of G: keys {j, i} ascending (j < i); intersections with the stored keys of column `col` */
+        double ri = 0.0, rj = 0.0;
+        if (*sj) { double p1 = (-s) * *cj; ri = ri + p1; double p2 = c * *cj; rj = rj + p2; }
+        if (*si) { double p1 = c * *ci; ri = ri + p1; double p2 = s * *ci; rj = rj + p2; }
+        *ci = ri;
+        *cj = rj;
+        *si = 1;   /* (##) yields an explicit entry for every (row key of G) x (column key of M) pair ... */
+        *sj = 1;
+    }
+    for (int64_t k = 0; k < m * ncols; ++k) {   /* ... and sparsifySM drops what fails isNz, everywhere */
+        if (st[k] && !is_nz_val(M[k])) { st[k] = 0; M[k] = 0.0; }
+    }
+}
+int orc_qr_dense(int64_t m, int64_t n, const double *A, const char *stored, double *Qt, double *R) {
+    if (m < n) return ORC_ERR_DIM;                                     /* "Givens: matrix must have rows >= cols" (:256) */
+    char *sr = (char *)malloc((size_t)(m * n > 0 ? m * n : 1)), *sq = (char *)malloc((size_t)(m * m > 0 ? m * m : 1));
+    int64_t *ii = (int64_t *)malloc(sizeof(int64_t) * (size_t)(m * n > 0 ? m * n : 1)), *jj = (int64_t *)malloc(sizeof(int64_t) * (size_t)(m * n > 0 ? m * n : 1));
+    if (!sr || !sq || !ii || !jj) return ORC_ERR_ALLOC;
+    for (int64_t k = 0; k < m * n; ++k) { R[k] = A[k]; sr[k] = stored ? stored[k] : (A[k] != 0.0); if (!sr[k]) R[k] = 0.0; }
+    for (int64_t k = 0; k < m * m; ++k) { Qt[k] = 0.0; sq[k] = 0; }
+    for (int64_t d = 0; d < m; ++d) { Qt[d * m + d] = 1.0; sq[d * m + d] = 1; }
+    int64_t cnt = 0;
+    for (int64_t i = 0; i < m; ++i)                                    /* subdiagIndices: rows ascending, columns ascending */
+        for (int64_t j = 0; j < n && j < i; ++j)
+            if (sr[j * m + i]) { ii[cnt] = i; jj[cnt] = j; ++cnt; }
+    for (int64_t t = 0; t < cnt; ++t) {
+        const int64_t i = ii[t], j = jj[t];
+        const double bval = sr[j * m + i] ? R[j * m + i] : 0.0;        /* aa @@ (i, j): 0 when absent */
+        if (!is_nz_val(bval)) continue;
+        int64_t ip = -1;
+        for (int64_t r = 0; r < m && ip < 0; ++r) {                    /* candidateRows': head of the ascending keys */
+            if (r == i || !sr[j * m + r]) continue;
+            int first = 1;
+            for (int64_t cc = 0; cc < j && first; ++cc) first = !sr[cc * m + r];
+            if (first) ip = r;
         }
-        double gu = g[j], gv = g[j + 1];
-        g[j] = c * gu + s * gv;
-        g[j + 1] = -s * gu + c * gv;
+        if (ip < 0) continue;
+        const double a = R[j * m + ip];
+        const double a2 = a * a, b2 = bval * bval;                     /* mag2 i = i * conj i */
+        const double rr = sqrt(a2 + b2);
+        const double c = a / rr, s = bval / rr;
+        qr_apply(m, m, i, j, c, s, Qt, sq);
+        qr_apply(m, n, i, j, c, s, R, sr);
     }
-    for (int64_t i = k - 1; i >= 0; --i) {
-        double acc = g[i];
-        for (int64_t l = i + 1; l < k; ++l) acc -= R[l * (k + 1) + i] * y[l];
-        y[i] = acc / R[i * (k + 1) + i];
+    free(sr); free(sq); free(ii); free(jj);
+    return ORC_OK;
+}
+
+/* The least-squares step of the commented gmres (Sparse.hs:837-848), in the reference's own terms:
+ *   b' = norm2' b .* ei mp1 1 ; (qh, rh) <- qr ha ; rhs' = takeSV (dim b' - 1) (transpose qh #> b') ;
+ *   rh' = takeRows (nrows rh - 1) rh ; yhat <- triUpperSolve rh' rhs'
+ * with ha the (k+1) x k Hessenberg matrix of arnoldi (stored entries: rows 0 .. j+1 of column j, as fromCols of the hhcoli builds
+ * it).  Independent of the product's Givens sweep (csrc/sla_solvers.cpp: hessenberg_lsq), which it is compared with. */
+static int hessenberg_lsq(int64_t k, int64_t ldh, const double *H, double beta, double *y) {
+    const int64_t m = k + 1;
+    double *Hk = vnew(m * k), *Qt = vnew(m * m), *R = vnew(m * k), *rhs = vnew(k), *tv = vnew(k * k + 1);
+    char *st = (char *)malloc((size_t)(m * k > 0 ? m * k : 1));
+    int64_t *tp = (int64_t *)malloc(sizeof(int64_t) * (size_t)(k + 1)), *tc = (int64_t *)malloc(sizeof(int64_t) * (size_t)(k * k + 1));
+    if (!Hk || !Qt || !R || !rhs || !tv || !st || !tp || !tc) return ORC_ERR_ALLOC;
+    for (int64_t j = 0; j < k; ++j)
+        for (int64_t i = 0; i < m; ++i) { Hk[j * m + i] = H[j * ldh + i]; st[j * m + i] = i <= j + 1; }
+    int rc = orc_qr_dense(m, k, Hk, st, Qt, R);
+    if (rc == ORC_OK) {
+        /* transpose qh = Qt ; (Qt #> b')_i = 0 + Qt(i, 0) * beta where Qt(i, 0) is stored (b' holds the single key 0) */
+        for (int64_t i = 0; i < k; ++i) { double p = Qt[0 * m + i] * beta; rhs[i] = 0.0 + p; }
+        orc_csr T;                                                   /* rh' = the first k rows of rh, its isNz entries */
+        int64_t nz = 0;
+        tp[0] = 0;
+        for (int64_t i = 0; i < k; ++i) {
+            for (int64_t j = 0; j < k; ++j)
+                if (is_nz_val(R[j * m + i])) { tc[nz] = j; tv[nz] = R[j * m + i]; ++nz; }
+            tp[i + 1] = nz;
+        }
+        T.m = k; T.n = k; T.rowptr = tp; T.colidx = tc; T.val = tv;
+        int64_t bad = -1;
+        rc = orc_tri_upper_solve(&T, rhs, y, &bad);
     }
-    free(R); free(g);
+    free(Hk); free(Qt); free(R); free(rhs); free(tv); free(st); free(tp); free(tc);
+    return rc;
 }
 
 int orc_gmres(const orc_csr *A, int64_t nb, const double *b, const double *x0, int64_t restart,
@@ -527,7 +599,7 @@ int orc_gmres(const orc_csr *A, int64_t nb, const double *b, const double *x0, i
         if (beta <= tol || cyc == max_restarts) break;
         int64_t k = 0;
         orc_arnoldi(A, n, r, restart, Q, H, &k);
-        hessenberg_lsq(k, restart + 1, H, beta, y);
+        if (hessenberg_lsq(k, restart + 1, H, beta, y) != ORC_OK) break;   /* NeedsPivoting in triUpperSolve: the reference would throw */
         for (int64_t j = 0; j < k; ++j) {                           /* x += Q[:, :k] y        */
             orc_scale(n, y[j], Q + j * n, t);
             orc_add(n, x, t, x);

@@ -13,7 +13,8 @@
  * NOT pinned by any reference test (all its exact assertions are on small integers); the
  * order used here (ascending index, strict left fold from 0.0, separate mul/add roundings)
  * follows containers' IntMap traversal order and base-4.18 Foldable.sum.  GMRES has no live
- * reference implementation: "parity unpinned" for orc_gmres.
+ * reference implementation ("parity unpinned" for orc_gmres as a whole); its least-squares step is the
+ * reference's qr + triUpperSolve, each pinned to the reference's own test cases.
  *
  * All indices are int64 (Haskell Int), all values IEEE f64 (Haskell Double).
  * Compile with -O2 -ffp-contract=off (GHC's x86-64 NCG never fuses mul+add).
@@ -93,8 +94,16 @@ int orc_linsolve0(int method, const orc_csr *A, int64_t nb, const double *b, con
 int orc_arnoldi(const orc_csr *A, int64_t nb, const double *b, int64_t kn, double *Q, double *H,
                 int64_t *k_done);
 
-/* A10: restarted GMRES(m) built on orc_arnoldi (commented sketch Sparse.hs:828-848: Arnoldi ->
- * Givens QR of H -> back substitution -> x = Q y).  PARITY UNPINNED by the reference. */
+/* qr (Sparse.hs:306-331; givens :253-283, givensCoef / hypot :286-295) on a dense column-major m x n array (m >= n) with its stored-entry
+ * structure: stored[k] != 0 marks the IntMap's keys (NULL: the non-zero values).  Qt (m x m) = the accumulated rotations (the
+ * reference returns transpose Qt), R (m x n) = the rotated matrix; both sparsified like the reference's #~# (|x| <= 1e-12 -> absent = 0).
+ * Pinned to the reference's own QR cases tm2 / tm4 / tm6 / issueMatrix through checkQr0 (test/MatrixFactorizationsSpec.hs:46-74). */
+int orc_qr_dense(int64_t m, int64_t n, const double *A, const char *stored, double *Qt, double *R);
+
+/* A10: restarted GMRES(m) built on orc_arnoldi, each cycle solved as the commented sketch does (Sparse.hs:837-848): qr of the
+ * Hessenberg matrix (orc_qr_dense), rhs' = the leading entries of transpose qh #> (norm2 r .* e1), triUpperSolve on the leading rows of
+ * rh (orc_tri_upper_solve), x = Q y.  The two building blocks are pinned by the reference's tests; their composition is not
+ * (the reference's gmres is commented out): PARITY UNPINNED for the composition. */
 int orc_gmres(const orc_csr *A, int64_t nb, const double *b, const double *x0, int64_t restart,
               int64_t max_restarts, double tol_abs, double tol_rel, double *x_out,
               int64_t *iters_out, double *resnorm_out, double *r0norm_out);

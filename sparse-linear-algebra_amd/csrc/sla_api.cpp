@@ -408,10 +408,13 @@ struct Low {
     std::vector<int32_t> rb;            // row-block starts
     std::vector<int64_t> offs;          // sorted distinct diagonal offsets (<= 256) when the matrix has that structure
     std::vector<uint8_t> dcodes;        // per entry: index into offs
+    // (every lowered array carries kArraySlack zeroed bytes behind its end: the pipelined stream kernel reads whole row blocks
+    // with clamped, unconditional loads, and an empty row block at the very end of the matrix reads "its" first entry there)
     void upload(void **dst, const void *src, size_t bytes) {
         if (err != hipSuccess) return;
-        err = dev_malloc(c, dst, std::max<size_t>(bytes, 8));
+        err = dev_malloc(c, dst, bytes + kArraySlack);
         if (err == hipSuccess && bytes) err = hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
+        if (err == hipSuccess) err = hipMemset((char *)*dst + bytes, 0, kArraySlack);
     }
 };
 #define SLA_LOW_LOCALS(L)                                                                                                  \
@@ -439,8 +442,9 @@ static void low_csr_arrays(Low &L) {
     };
     std::thread val_up([&] {
         Bind bind(c);   // (a new thread starts on device 0)
-        if (err_val == hipSuccess) err_val = dev_malloc(c, (void **)&A->d_val, std::max<size_t>(sizeof(double) * (size_t)nnz, 8));
+        if (err_val == hipSuccess) err_val = dev_malloc(c, (void **)&A->d_val, sizeof(double) * (size_t)nnz + kArraySlack);
         if (err_val == hipSuccess && nnz) err_val = hipMemcpy(A->d_val, val, sizeof(double) * (size_t)nnz, hipMemcpyHostToDevice);
+        if (err_val == hipSuccess) err_val = hipMemset((char *)A->d_val + sizeof(double) * (size_t)nnz, 0, kArraySlack);
     });
     Joiner val_up_joiner{val_up};
     {
@@ -1079,6 +1083,7 @@ const IntKnob kIntKnobs[] = {
     {"xcd_remap", &sla_ctx::xcd_remap, 0, 1},
     {"dual_spmv", &sla_ctx::dual_spmv, 0, 1},
     {"xwin", &sla_ctx::xwin, 0, 1},
+    {"stream_pipe", &sla_ctx::stream_pipe, 0, 1},
     {"diag", &sla_ctx::diag, 0, 1},
     {"vdict", &sla_ctx::vdict, 0, 1},
     {"wdia", &sla_ctx::wdia, 0, 1},
@@ -1722,7 +1727,7 @@ int sla_csr_kernel_info(sla_csr_t A, char *buf, int buflen) {
     if (A && !A->kids.empty()) return sla_csr_kernel_info(A->kids[0], buf, buflen);
     if (!A || !buf || buflen <= 0) return fail(SLA_ERR_INVALID, "null argument");
     snprintf(buf, (size_t)buflen, "algo=%s grid=%d block=%d row_blocks=%d nnz_per_row_block=%d max_row_nnz=%lld rowptr=%s xcd_remap=%d",
-             A->ctx->spmv_algo == 1 ? "scalar" : (A->use_wdia && wd_on(A)) ? (A->wd_vv ? "wdia-vv" : wd_lds_on(A) ? "wdia+ldswin" : "wdia") : (A->use_vdict && A->ctx->vdict) ? (A->use_xwin && A->ctx->xwin ? "vdict+xwin" : "vdict") : (A->use_lpanel && A->ctx->lpanel) ? "stream+ldspanels" : tiles_on(A) ? "tiles" : (!A->panels.empty() && A->ctx->panels) ? "stream+colpanels" : (A->use_diag && A->ctx->diag ? (A->use_xwin && A->ctx->xwin ? "stream+diagdict+xwin" : "stream+diagdict") : (A->use_xwin && A->ctx->xwin ? "stream+xwin" : "stream")), spmv_grid(A), kBlock, A->nrb, kNnzPerRowBlock,
+             A->ctx->spmv_algo == 1 ? "scalar" : (A->use_wdia && wd_on(A)) ? (A->wd_vv ? "wdia-vv" : wd_lds_on(A) ? "wdia+ldswin" : "wdia") : (A->use_vdict && A->ctx->vdict) ? (A->use_xwin && A->ctx->xwin ? "vdict+xwin" : "vdict") : (A->use_lpanel && A->ctx->lpanel) ? "stream+ldspanels" : tiles_on(A) ? "tiles" : (!A->panels.empty() && A->ctx->panels) ? "stream+colpanels" : (A->use_diag && A->ctx->diag ? (A->use_xwin && A->ctx->xwin ? "stream+diagdict+xwin" : "stream+diagdict") : (pipe_on(A) ? "stream+pipe" : A->use_xwin && A->ctx->xwin ? "stream+xwin" : "stream")), spmv_grid(A), kBlock, A->nrb, kNnzPerRowBlock,
              (long long)A->max_row_nnz, A->rp64 ? "i64" : "i32", A->ctx->xcd_remap);
     if (A->use_lpanel && A->ctx->lpanel && A->ctx->spmv_algo == 0) {   // LDS-panel geometry
         const size_t used = strlen(buf);

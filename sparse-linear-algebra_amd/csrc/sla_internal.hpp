@@ -73,6 +73,7 @@ constexpr int kMaxParts = 2048;      // partial-sum slots per reduction (256 CUs
 constexpr int kVecGridMax = 1024;    // grid cap of the streaming BLAS-1 kernels
 constexpr int kSpmvGridMax = 2048;   // persistent grid cap of the SpMV kernels
 constexpr int kArnGridMax = 1024;    // grid cap (= partials per column) of the Arnoldi kernels
+constexpr size_t kArraySlack = 64;              // zeroed bytes behind every lowered matrix array (clamped whole-block loads of the pipelined stream kernel)
 constexpr size_t kGuardBytes = 256;             // readable slack on both sides of every buffer an SpMV gathers from
 constexpr size_t kHaloBytes = (size_t)4 << 20;  // the same for vectors of sharded contexts: room for the neighbours' halo planes
 constexpr int kMaxKrylov = 64;       // max Arnoldi basis columns handled by the fused GS kernels
@@ -91,6 +92,8 @@ struct SolverScalars {
     int32_t iters;   // steps started while not done
     int32_t flags;
     int32_t kdone;   // Arnoldi: number of H columns produced
+    double *hist;    // linSolve0 with a residual trace: hist[j - 1] = true residual norm of the iterate after j steps (null: no trace)
+    int32_t hist_cap;
 };
 
 // epilogues fused into the SpMV kernels
@@ -202,6 +205,7 @@ struct sla_ctx {
     int force_rp64 = 0;              // test hook: 64-bit row pointers at any size (SLA_FORCE_RP64)
     int lpanel = 1;                  // allow the LDS-panel SpMV kernel for matrices with dense rows (SLA_LPANEL=0 disables)
     int xwin = 1;                    // allow the LDS x-window SpMV kernel (SLA_XWIN=0 disables)
+    int stream_pipe = 1;             // plain CSR-stream (#>): the three-stage pipelined kernel (sla_spmv_pipe.hip) instead of spmv_stream / spmv_xwin (SLA_STREAM_PIPE=0: those)
     int dual_spmv = 1;               // linSolve0: fuse the true-residual SpMV into the next K1 (SLA_DUAL_SPMV=0 disables)
     int x_exchange = 0;              // 0 auto (window exchange when it pays), 1 always all-gather, 2 always window (SLA_X_EXCHANGE=allgather|window)
     int halo_inplace = 1;            // window exchange straight into the slack around the vector (SLA_HALO_INPLACE=0: via the landing buffer)
@@ -345,6 +349,8 @@ struct sla_solver {
     // rank's SpMV reads from its neighbours, so a step needs 3 grouped exchanges instead of 5
     bool ghost = false;
     int64_t ghl = 0, ghr = 0;
+    double *d_hist = nullptr;            // linSolve0's residual trace (sla_solve_opts.history), one slot per iteration
+    int32_t hist_cap = 0;
     alignas(8) char ctl_storage[128];    // driver-private step bookkeeping (sla_solvers.cpp)
 };
 
@@ -545,8 +551,26 @@ bool overlap_split(const sla_csr *A);   // does (#>) on A run as interior + boun
 int overlap_grid(const sla_csr *A, int part);
 bool tiles_on(const sla_csr *A);                               // is the tile form of A in use?
 int launch_spmv_tiles(const sla_csr *A, const SpmvLaunch &l);   // sla_spmv_tiles.hip
+// the kernel families behind launch_spmv (sla_spmv.hip picks; `a` = the kernel argument block it assembled, `grid` = spmv_grid(A))
+int launch_spmv_stream(const sla_csr *A, int epi, const SpmvArgs<int32_t> &a, int grid);                     // sla_spmv_stream.hip
+int launch_spmv_stream(const sla_csr *A, int epi, const SpmvArgs<int64_t> &a, int grid);
+int launch_spmv_dual(const sla_csr *A, const SpmvArgs<int32_t> &a, const double *x2, const double *b2, int grid);
+int launch_spmv_dual(const sla_csr *A, const SpmvArgs<int64_t> &a, const double *x2, const double *b2, int grid);
+int launch_spmv_diag(const sla_csr *A, int epi, const SpmvArgs<int32_t> &a, int grid);                       // sla_spmv_dict.hip
+int launch_spmv_diag(const sla_csr *A, int epi, const SpmvArgs<int64_t> &a, int grid);
+int launch_spmv_dual_diag(const sla_csr *A, const SpmvArgs<int32_t> &a, const double *x2, const double *b2, int grid);
+int launch_spmv_dual_diag(const sla_csr *A, const SpmvArgs<int64_t> &a, const double *x2, const double *b2, int grid);
+int launch_spmv_vdict(const sla_csr *A, int epi, const SpmvArgs<int32_t> &a, const double *x2, const double *b2, int grid);
+int launch_spmv_wdia(const sla_csr *A, int epi, const SpmvArgs<int32_t> &a, const int32_t *sched, int32_t nblk_wd, int grid, int stream_nt);   // sla_spmv_wdia.hip
+int launch_spmv_lpanel(const sla_csr *A, int epi, const SpmvArgs<int32_t> &a, int grid);                     // sla_spmv_lpanel.hip
+int launch_spmv_lpanel(const sla_csr *A, int epi, const SpmvArgs<int64_t> &a, int grid);
+// do the solver's vectors (7 of n entries for BiCGSTAB) overflow the memory-side cache?  Then stream them past it.
+inline bool vec_stream_nt(const sla_ctx *c, int64_t n) { return c->vec_nt < 0 ? 7 * 8 * n > c->mall_bytes : c->vec_nt != 0; }
 int launch_wdia_lds(const sla_csr *A, int epi, const SpmvArgs<int32_t> &a, const int32_t *sched, int32_t nblk, int grid, int stream_nt);   // sla_spmv_wdia_lds.hip
 int wd_lds_grid(const sla_csr *A);
+bool pipe_on(const sla_csr *A);                                                                              // sla_spmv_pipe.hip
+int launch_spmv_pipe(const sla_csr *A, int epi, const SpmvArgs<int32_t> &a, int grid);
+int launch_spmv_pipe(const sla_csr *A, int epi, const SpmvArgs<int64_t> &a, int grid);
 int tiles_grid(const sla_csr *A);
 int probe_xcd_layout(sla_ctx *c);   // sets c->xcd8 (sla_spmv_tiles.hip)
 // sla_lower_tiles.cpp: builds the tile form of A when it pays (irregular structure, x larger than the L2); no-op otherwise
@@ -583,7 +607,7 @@ int launch_cgne_n2(sla_ctx *c, int64_t n, SolverScalars *sc, const double *p, do
 int launch_cgne_n3b(sla_ctx *c, int64_t n, SolverScalars *sc, Parts rr1, int par, const double *t, double *p, double *ppout);
 // residual check at the end of a host batch (one block): publishes resnorm / done
 int launch_check(sla_ctx *c, SolverScalars *sc, Parts res);
-int launch_init_scalars(sla_ctx *c, SolverScalars *sc, Parts rho, Parts r0sq, double tol_abs, double tol_rel);
+int launch_init_scalars(sla_ctx *c, SolverScalars *sc, Parts rho, Parts r0sq, double tol_abs, double tol_rel, double *hist = nullptr, int hist_cap = 0);
 int launch_set_rho(sla_ctx *c, SolverScalars *sc, Parts rho, int par);   // sc->rho2[par] = sum(rho)
 // Arnoldi (Sparse.hs:630-667); Q column-major with leading dimension ldq
 int launch_arn_dots(sla_ctx *c, int64_t n, const double *Q, int64_t ldq, int ncols, const double *w, double *parts, SolverScalars *sc);

@@ -405,7 +405,7 @@ int read_scalars(sla_solver *S) {
 }
 
 // *Init (Sparse.hs:921-924, 962-965, 864-868) + the tolerance of linSolve0 (:1032-1037)
-int solver_init_common(int method, sla_csr *A, sla_vec *b, sla_vec *x0, double tol_abs, double tol_rel, sla_solver **out) {
+int solver_init_common(int method, sla_csr *A, sla_vec *b, sla_vec *x0, double tol_abs, double tol_rel, sla_solver **out, int hist_cap = 0) {
     if (!A || !b || !x0 || !out) return fail(SLA_ERR_INVALID, "solver init: null argument");
     if (method != SLA_BICGSTAB_ && method != SLA_CGS_ && method != SLA_CGNE_)
         return fail(SLA_ERR_UNSUPPORTED_METHOD, "Only BICGSTAB_, CGS_, and CGNE_ are implemented");
@@ -430,6 +430,11 @@ int solver_init_common(int method, sla_csr *A, sla_vec *b, sla_vec *x0, double t
     new (&ctl_of(S)) StepCtl();
     int rc = SLA_OK;
     do {
+        if (hist_cap > 0) {   // (a local failure here is reported after the collectives below have run their course: no rank is left waiting)
+            if (dev_malloc(c, (void **)&S->d_hist, sizeof(double) * (size_t)hist_cap) == hipSuccess &&
+                hipMemsetAsync(S->d_hist, 0, sizeof(double) * (size_t)hist_cap, stream_of(c)) == hipSuccess)
+                S->hist_cap = hist_cap;
+        }
         if ((rc = sla_vec_copy(x0, S->x)) != SLA_OK) break;
         if ((rc = sla_vec_copy(b, S->b)) != SLA_OK) break;
         SpmvLaunch l;  // r0 = b ^-^ (aa #> x0)
@@ -469,7 +474,7 @@ int solver_init_common(int method, sla_csr *A, sla_vec *b, sla_vec *x0, double t
         Parts rho;
         if ((rc = launch_dot(c, S->r->n_local, S->r->d, S->r->d, slot(S, P_TMP))) != SLA_OK) break;
         if ((rc = publish(S, P_TMP, -1, vec_grid(S->r->n_local), &rho, nullptr)) != SLA_OK) break;
-        if ((rc = launch_init_scalars(c, S->d_sc, rho, rho, tol_abs, tol_rel)) != SLA_OK) break;
+        if ((rc = launch_init_scalars(c, S->d_sc, rho, rho, tol_abs, tol_rel, S->hist_cap ? S->d_hist : nullptr, S->hist_cap)) != SLA_OK) break;
     } while (0);
     if (rc != SLA_OK) {
         sla_solver_destroy(S);
@@ -819,6 +824,7 @@ int sla_solver_destroy(sla_solver_t S) {
     if (S->d_parts) (void)hipFree(S->d_parts);
     if (S->d_gath) (void)hipFree(S->d_gath);
     if (S->d_sc) (void)hipFree(S->d_sc);
+    if (S->d_hist) (void)hipFree(S->d_hist);
     if (S->h_sc) (void)hipHostFree(S->h_sc);
     delete S;
     return SLA_OK;
@@ -840,13 +846,14 @@ int sla_linsolve0(int method, sla_csr_t A, sla_vec_t b, sla_vec_t x0, const sla_
     if (A && !A->kids.empty()) return m_linsolve0(method, A, b, x0, opts, x_out, info);
     return no_throw("sla_linsolve0", [&]() -> int {
         if (!A || !b || !x0 || !x_out) return fail(SLA_ERR_INVALID, "sla_linsolve0: null argument");
-        sla_solve_opts o = {200, 1e-6, 1e-4, 16, 1};
+        sla_solve_opts o = {200, 1e-6, 1e-4, 16, 1, nullptr, 0};
         if (opts) {
             o = *opts;
             if (o.max_iters <= 0) o.max_iters = 200;
             if (o.check_every <= 0) o.check_every = 16;
         }
-        if (info) { info->iters = 0; info->flags = 0; info->resnorm = NAN; info->r0norm = NAN; info->tol = NAN; }
+        if (info) { info->iters = 0; info->flags = 0; info->resnorm = NAN; info->r0norm = NAN; info->tol = NAN; info->history_len = 0; }
+        const int hist_cap = (o.history && o.history_cap > 0 && o.true_residual) ? std::min(o.history_cap, o.max_iters) : 0;
         // | m /= nb = throwM (MatVecSizeMismatchException "linSolve0" dm nb)      (Sparse.hs:1022)
         if (A->m != b->n) return fail(SLA_ERR_DIM_MISMATCH, "linSolve0 : matrix rows and rhs dimension differ");
         if (x_out->n != A->n) return fail(SLA_ERR_DIM_MISMATCH, "linSolve0 : output vector has the wrong dimension");
@@ -863,7 +870,7 @@ int sla_linsolve0(int method, sla_csr_t A, sla_vec_t b, sla_vec_t x0, const sla_
         if (method != SLA_BICGSTAB_ && method != SLA_CGS_ && method != SLA_CGNE_)
             return fail(SLA_ERR_UNSUPPORTED_METHOD, "linSolve0 : Only BICGSTAB_, CGS_, and CGNE_ are implemented");  // :1031
         sla_solver *S = nullptr;
-        SLA_TRY(solver_init_common(method, A, b, x0, o.tol_abs, o.tol_rel, &S));
+        SLA_TRY(solver_init_common(method, A, b, x0, o.tol_abs, o.tol_rel, &S, hist_cap));
         int rc = SLA_OK, total = 0;
         while (total < o.max_iters) {  // runIter n state | n >= nits = return x        (:1045)
             const int k = std::min(o.check_every, o.max_iters - total);
@@ -891,6 +898,12 @@ int sla_linsolve0(int method, sla_csr_t A, sla_vec_t b, sla_vec_t x0, const sla_
             if (e != hipSuccess) rc = fail(SLA_ERR_HIP, hipGetErrorString(e));
         }
         if (rc == SLA_OK) fill_info(S, info, true);
+        if (rc == SLA_OK && S->hist_cap > 0) {   // the trace: one true residual norm per iteration taken (cgsStepDebug's output, Sparse.hs:942-948)
+            const int len = std::min<int>(S->h_sc->iters, S->hist_cap);
+            if (len > 0 && hipMemcpy(o.history, S->d_hist, sizeof(double) * (size_t)len, hipMemcpyDeviceToHost) != hipSuccess)
+                rc = fail(SLA_ERR_HIP, "sla_linsolve0: residual trace download failed");
+            else if (info) info->history_len = len;
+        }
         sla_solver_destroy(S);
         return rc;
     });
@@ -927,9 +940,9 @@ int sla_gmres(sla_csr_t A, sla_vec_t b, sla_vec_t x0, int restart, const sla_sol
     if (A && !A->kids.empty()) return m_gmres(A, b, x0, restart, opts, x_out, info);
     return no_throw("sla_gmres", [&]() -> int {
         if (!A || !b || !x0 || !x_out) return fail(SLA_ERR_INVALID, "sla_gmres: null argument");
-        sla_solve_opts o = {200, 1e-6, 1e-4, 16, 1};
+        sla_solve_opts o = {200, 1e-6, 1e-4, 16, 1, nullptr, 0};
         if (opts) { o = *opts; if (o.max_iters <= 0) o.max_iters = 200; }
-        if (info) { info->iters = 0; info->flags = 0; info->resnorm = NAN; info->r0norm = NAN; info->tol = NAN; }
+        if (info) { info->iters = 0; info->flags = 0; info->resnorm = NAN; info->r0norm = NAN; info->tol = NAN; info->history_len = 0; }
         if (A->m != b->n) return fail(SLA_ERR_DIM_MISMATCH, "gmres : matrix rows and rhs dimension differ");
         if (A->m != A->n || A->n != x0->n || x_out->n != A->n) return fail(SLA_ERR_DIM_MISMATCH, "gmres : mismatched dimensions");
         if (restart < 1) return fail(SLA_ERR_INVALID, "sla_gmres: restart must be >= 1");

@@ -1,0 +1,143 @@
+// sla_spmv.hip -- (#>) dispatch (Data/Sparse/Common.hs:242-260): which kernel family runs a launch on a lowered matrix, with what
+// grid, and the column-panel pass sequence.  The kernels themselves live with their families:
+//   sla_spmv_stream.hip   CSR-stream (values + i32 columns), LDS x window, dual (K1 + residual), one-lane-per-row baseline
+//   sla_spmv_pipe.hip     the three-stage pipelined CSR-stream kernel
+//   sla_spmv_dict.hip     1-byte column codes (diagonal dictionary) and 1-byte (offset, value) pair codes
+//   sla_spmv_wdia.hip     wave-sliced (offset, value) records in SGPRs;  sla_spmv_wdia_lds.hip: uniform records + LDS windows
+//   sla_spmv_lpanel.hip   dense rows: x panels in LDS;                   sla_spmv_tiles.hip: row-slice x column-panel tiles
+// All families share the fused epilogues / prologue of sla_device.hpp.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <type_traits>
+
+#include "sla_internal.hpp"
+
+namespace sla {
+
+// row-sharded overlap (sla_api.cpp: spmv_exchanged): interior / boundary launches of the wave-sliced forms
+bool overlap_split(const sla_csr *A) {
+    return A->ov_nint > 0 && A->ov_nbnd > 0 && A->ctx->overlap >= 0 && A->ctx->collectives && A->use_wdia && wd_on(A) && A->ctx->spmv_algo == 0 && !A->rp64;
+}
+int overlap_grid(const sla_csr *A, int part) {
+    // the two launches write their fused partial sums into consecutive slots of ONE kMaxParts-slot array (interior first):
+    // the interior grid leaves room for the boundary launch's (a 299-CU part at 6 workgroups per CU, or SLA_WD_GRID=2048,
+    // would otherwise push the boundary partials into the next slot array)
+    const int gb = std::max(1, std::min<int>(A->ov_nbnd, 256));
+    if (part != 1) return gb;
+    const int cap = std::min(A->wd_vv ? A->ctx->wd_grid_max_vv : wd_lds_on(A) ? wd_lds_grid(A) : A->ctx->wd_grid_max, kMaxParts - gb);
+    return std::max(1, std::min<int>(A->ov_nint, cap));
+}
+
+int spmv_grid(const sla_csr *A) {
+    const sla_ctx *c = A->ctx;
+    // with column panels the fused partials are written by the LAST panel pass: its grid is the one that counts
+    if (tiles_on(A)) return tiles_grid(A);
+    if (!A->panels.empty() && c->panels && c->spmv_algo == 0) return spmv_grid(A->panels.back());
+    int64_t g;
+    if (c->spmv_algo == 1 || (A->use_lpanel && c->lpanel)) g = (A->rows + kBlock - 1) / kBlock;   // (lpanel: its finish kernel)
+    else if (A->use_wdia && wd_on(A)) g = std::min<int64_t>(A->nblk_wd, A->wd_vv ? c->wd_grid_max_vv : wd_lds_on(A) ? wd_lds_grid(A) : c->wd_grid_max);
+    else if (A->use_vdict && c->vdict) g = A->nblk_vd;
+    else g = A->nrb;
+    if (g < 1) g = 1;
+    if (g > c->spmv_grid_max) g = c->spmv_grid_max;
+    return (int)g;
+}
+
+template <typename RP>
+static int launch_spmv_rp(const sla_csr *A, const SpmvLaunch &l);
+
+// Column-panel SpMV for matrices whose gathers do not fit the XCD-private L2: the matrix is stored a second
+// time panel-major (panel p holds the entries with column in [p W, (p+1) W), W * 8 B <= ~3 MB), and y = A x
+// is evaluated as P passes y += A_p x in ascending panel order, so every gather of a pass hits a window of
+// x that stays L2-resident.  Each pass continues the row's running sum (yinit), i.e. the per-row order is
+// still one ascending left fold; the fused epilogue runs in the last pass only.
+static int launch_spmv_panels(const sla_csr *A, const SpmvLaunch &l) {
+    const size_t P = A->panels.size();
+    ProfScope prof(A->ctx, l.kernel_id);  // one timed interval for the whole panel sequence
+    double *ytmp = l.y;
+    if (!ytmp) ytmp = A->d_panel_y;  // epilogues that never store y (EPI_RES, EPI_AXPY_DOT, ...) still need the running sum
+    for (size_t p = 0; p < P; ++p) {
+        const bool last = p + 1 == P;
+        SpmvLaunch lp = l;
+        lp.yinit = p == 0 ? nullptr : ytmp;
+        lp.kernel_id = -2;               // never matches: the enclosing scope does the timing
+        if (!last) {
+            lp.epi = EPI_NONE;
+            lp.y = ytmp;
+            lp.pres = nullptr;            // prologue checks / step bookkeeping happen once, in the last pass
+            lp.step_begin = 0;
+            lp.pa = nullptr;
+        }
+        // (a view holds only its panel's entries: it may use 32-bit row pointers where the parent needs 64-bit ones)
+        const sla_csr *V = A->panels[p];
+        SLA_TRY(V->rp64 ? launch_spmv_rp<int64_t>(V, lp) : launch_spmv_rp<int32_t>(V, lp));
+    }
+    return SLA_OK;
+}
+
+template <typename RP>
+static int launch_spmv_rp(const sla_csr *A, const SpmvLaunch &l) {
+    sla_ctx *c = A->ctx;
+    if (!A->panels.empty() && c->panels && c->spmv_algo == 0 && !l.x2 && !l.in_panel) {
+        SpmvLaunch lp = l;
+        lp.in_panel = 1;
+        return launch_spmv_panels(A, lp);
+    }
+    if (l.x2 && l.epi != EPI_DOT) return fail(SLA_ERR_INVALID, "dual SpMV is only defined for the K1 epilogue");
+    SpmvArgs<RP> a;
+    a.rowptr = (const RP *)A->d_rowptr;
+    a.col = A->d_col;
+    a.val = A->d_val;
+    a.x = l.x;
+    a.y = l.y;
+    a.rb = A->d_rb;
+    a.rbk = (const RP *)A->d_rbk;
+    a.nrb = A->nrb;
+    a.rows = (int32_t)A->rows;
+    a.w = l.w;
+    a.z = l.z;
+    a.p1 = l.p1;
+    a.p2 = l.p2;
+    a.p3 = l.p3;
+    a.p4 = l.p4;
+    a.acc3 = 0.0;
+    a.acc4 = 0.0;
+    a.sc = l.sc;
+    a.pres = l.pres;
+    a.npres = l.npres;
+    a.pres_stride = l.pres_stride;
+    a.pa = l.pa;
+    a.pb = l.pb;
+    a.npa = l.npa;
+    a.pa_stride = l.pa_stride;
+    a.step_begin = l.step_begin;
+    a.yinit = l.yinit;
+    const int grid = spmv_grid(A);
+    ProfScope prof(c, l.kernel_id);
+    if (A->use_lpanel && c->lpanel && c->spmv_algo == 0 && !l.x2 && !l.yinit) return launch_spmv_lpanel(A, l.epi, a, grid);
+    if constexpr (std::is_same<RP, int32_t>::value) {   // the value-indexed forms exist with 32-bit row pointers only
+        if (A->use_wdia && wd_on(A) && c->spmv_algo == 0 && !l.x2) {
+            const int32_t *sched = c->wd_tile != 0 ? A->d_wsched : nullptr;
+            int32_t nblk_wd = A->nblk_wd;
+            int g = grid;
+            if (l.part == 1) { sched = A->d_ov_int; nblk_wd = A->ov_nint; g = overlap_grid(A, 1); }
+            else if (l.part == 2) { sched = A->d_ov_bnd; nblk_wd = A->ov_nbnd; g = overlap_grid(A, 2); }
+            const int stream_nt = vec_stream_nt(c, A->rows) ? 1 : 0;
+            if (wd_lds_on(A)) return launch_wdia_lds(A, l.epi, a, sched, nblk_wd, g, stream_nt | (c->wd_nt_store ? 2 : 0));
+            return launch_spmv_wdia(A, l.epi, a, sched, nblk_wd, g, stream_nt);
+        }
+        if (A->use_vdict && c->vdict && c->spmv_algo == 0) return launch_spmv_vdict(A, l.epi, a, l.x2, l.b2, grid);
+    }
+    if (l.x2) return (A->use_diag && c->diag) ? launch_spmv_dual_diag(A, a, l.x2, l.b2, grid) : launch_spmv_dual(A, a, l.x2, l.b2, grid);
+    if (c->spmv_algo != 1 && A->use_diag && c->diag) return launch_spmv_diag(A, l.epi, a, grid);
+    if (c->spmv_algo != 1 && pipe_on(A)) return launch_spmv_pipe(A, l.epi, a, grid);
+    return launch_spmv_stream(A, l.epi, a, grid);   // (also the one-lane-per-row baseline, SLA_SPMV_ALGO=scalar)
+}
+
+int launch_spmv(const sla_csr *A, const SpmvLaunch &l) {
+    if (tiles_on(A) && !l.x2 && !l.yinit) return launch_spmv_tiles(A, l);
+    return A->rp64 ? launch_spmv_rp<int64_t>(A, l) : launch_spmv_rp<int32_t>(A, l);
+}
+
+}  // namespace sla

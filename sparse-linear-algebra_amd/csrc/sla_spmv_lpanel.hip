@@ -1,0 +1,190 @@
+// sla_spmv_lpanel.hip -- (#>) for matrices with dense rows (hundreds to thousands of entries per row, random columns): x is cut into
+// panels of 16384 columns kept in LDS by one 1024-thread workgroup per CU; (panel, row) segments streamed two at a time per
+// wavefront, partial sums per panel, finished in ascending panel order with the fused epilogue.  Data/Sparse/Common.hs:242-260.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <type_traits>
+
+#include "sla_internal.hpp"
+#include "sla_device.hpp"
+
+namespace sla {
+
+// ---------------------------------------------------------------------------------------------
+// LDS-panel SpMV for matrices with dense rows ("1 % density": hundreds of entries per row, random columns)
+// ---------------------------------------------------------------------------------------------
+// Random 8-byte gathers from the L2 move a 128-byte line into the L1 each (64 B/clk/CU): ~0.3 gathers per clock per
+// CU, which bounds the stream kernel at ~1/4 of the HBM rate on such matrices.  The LDS serves the same gathers at
+// 128 B/clk of useful data, so x is cut into equal panels of W <= kLpW columns: a workgroup keeps one panel of x in LDS and
+// streams the (row, panel) segments of its row chunks -- one wavefront per segment, lanes striding over the entries
+// in ascending order, two segments in flight per wavefront -- into per-panel partial sums.  Tasks (panel, row chunk)
+// are dealt out panel-major in contiguous runs of equal entry counts (task_begin), so a workgroup reloads x about once.  lpanel_finish_kernel then
+// adds the partials of a row in ascending panel order and runs the fused epilogue.
+template <typename RP, int L, int R, int J>
+__global__ void __launch_bounds__(kLpBlock) spmv_lpanel_kernel(const RP *__restrict__ pp, const int32_t *__restrict__ col,
+                                                               const double *__restrict__ val, const double *__restrict__ xg,
+                                                               double *__restrict__ ypart, const int32_t *__restrict__ task_begin,
+                                                               int rows, int n, int W, int chunk_rows, int C, int col_lo, int col_hi,
+                                                               const SolverScalars *sc) {
+    // L lanes per (row, panel) segment, R segments per lane group and round, J strided loads per segment and round: a
+    // wavefront keeps (64 / L) * R segments = 64 * R * J entries in flight.  A round costs a memory round trip however
+    // little it carries (measured: ~0.9 us), so short segments get narrow groups -- see the table at the launch.
+    extern __shared__ double lp_xs[];
+    if (sc && sc->done) return;
+    const int tid = threadIdx.x, wv = tid >> 6, ln = tid & 63;
+    constexpr int GW = 64 / L, GPB = (kLpBlock / 64) * GW;   // lane groups per wavefront / per workgroup
+    const int gid = wv * GW + ln / L, gl = ln % L;
+    const int t0 = task_begin[blockIdx.x], t1 = task_begin[blockIdx.x + 1];
+    int curp = -1;
+    for (int t = t0; t < t1; ++t) {
+        const int p = t / C, c = t - p * C;
+        const int w0 = p * W;
+        if (p != curp) {
+            __syncthreads();
+            const int wn = min(W, n - w0);
+            // only [col_lo, col_hi] is referenced by these rows -- and, on a row slab gathering from its in-place halo
+            // window, the only part of x that is backed by memory at all
+            for (int j = tid; j < wn; j += kLpBlock) lp_xs[j] = (w0 + j >= col_lo && w0 + j <= col_hi) ? xg[w0 + j] : 0.0;
+            __syncthreads();
+            curp = p;
+        }
+        const int lo = c * chunk_rows, hi = min(rows, lo + chunk_rows);
+        const RP *ps = pp + (int64_t)p * rows, *pe = ps + rows;
+        double *yp = ypart + (int64_t)p * rows;
+        for (int base = lo; base < hi; base += R * GPB) {   // (wavefront-uniform trip count)
+            // (fetching the next round's segment pointers a round ahead was tried: no gain where each shape is used)
+            RP k[R], e[R];
+            double acc[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                int i = base + r * GPB + gid;
+                if constexpr (L == 64) i = __builtin_amdgcn_readfirstlane(i);   // one segment per wavefront: scalar pointer loads
+                const bool has = i < hi;
+                k[r] = (has ? ps[i] : 0) + gl;
+                e[r] = has ? pe[i] : 0;
+                acc[r] = 0.0;
+            }
+            bool more = true;
+            while (more) {
+                int32_t cj[R][J];
+                double vj[R][J];
+                // all loads of the round in flight before the first use
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+#pragma unroll
+                    for (int j = 0; j < J; ++j) {
+                        if (k[r] + L * j < e[r]) {
+                            cj[r][j] = __builtin_nontemporal_load(col + k[r] + L * j);
+                            vj[r][j] = __builtin_nontemporal_load(val + k[r] + L * j);
+                        }
+                    }
+                }
+                bool mine = false;
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+#pragma unroll
+                    for (int j = 0; j < J; ++j) {
+                        if (k[r] + L * j < e[r]) {
+                            const double prod = vj[r][j] * lp_xs[cj[r][j] - w0];
+                            acc[r] = acc[r] + prod;
+                        }
+                    }
+                    k[r] += L * J;
+                    mine |= k[r] - gl < e[r];   // (the segment's next base: uniform over the lane group)
+                }
+                more = __builtin_amdgcn_ballot_w64(mine) != 0;
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int i = base + r * GPB + gid;
+                double sum = acc[r];
+                if constexpr (L == 64) {
+                    sum = wave_sum(sum);
+                } else {
+#pragma unroll
+                    for (int off = L / 2; off > 0; off >>= 1) sum = sum + __shfl_xor(sum, off, 64);
+                }
+                if (gl == 0 && i < hi) yp[i] = sum;
+            }
+        }
+    }
+}
+
+// y_i = sum over panels (ascending) of the partials + the fused epilogue; one lane per row.
+template <int EPI, typename RP>
+__global__ void __launch_bounds__(kBlock) lpanel_finish_kernel(SpmvArgs<RP> a, const double *__restrict__ ypart, int P) {
+    __shared__ double s_red[4];
+    double coef;
+    if (!spmv_prologue<EPI, RP>(a, s_red, coef)) return;
+    double acc1 = 0.0, acc2 = 0.0;
+    for (int64_t row = (int64_t)blockIdx.x * kBlock + threadIdx.x; row < a.rows; row += (int64_t)gridDim.x * kBlock) {
+        double acc = ypart[row];
+        for (int p = 1; p < P; ++p) acc = acc + ypart[(int64_t)p * a.rows + row];
+        spmv_epilogue<EPI, RP>(a, (int)row, acc, coef, acc1, acc2);
+    }
+    if constexpr (EPI == EPI_DOT || EPI == EPI_DOT2 || EPI == EPI_DOT4 || EPI == EPI_RES || EPI == EPI_AXPY_DOT ||
+                  EPI == EPI_XPBY_NRM) {
+        const double s1 = block_sum(acc1, s_red);
+        if (threadIdx.x == 0) a.p1[blockIdx.x] = s1;
+    }
+    if constexpr (EPI == EPI_DOT2 || EPI == EPI_DOT4) {
+        const double s2 = block_sum(acc2, s_red);
+        if (threadIdx.x == 0) a.p2[blockIdx.x] = s2;
+    }
+    spmv_extra_partials<EPI>(a, s_red, (int)threadIdx.x);
+}
+
+// launcher (called by launch_spmv, sla_spmv.hip): the panel kernel on its persistent task grid, then the finish kernel (row sums of
+// the panel partials in ascending panel order + the fused epilogue) on `grid` workgroups
+namespace {
+template <int EPI, typename RP>
+int launch_lpanel_t(const sla_csr *A, const SpmvArgs<RP> &a, int grid) {
+    sla_ctx *c = A->ctx;
+    // lane-group shape by mean segment length (A->lp_cfg, set at lowering): 64 lanes x 2 segments x 4 loads for long
+    // segments, narrower groups with more segments per wavefront for short ones
+#define SLA_LP_LAUNCH(CFG, L_, R_, J_)                                                                                         \
+    case CFG: {                                                                                                             \
+        const int attr_bit = 1 << (2 * CFG + (std::is_same<RP, int32_t>::value ? 0 : 1));                                   \
+        if (!(c->lp_attr & attr_bit)) {   /* per context = per device: 128 KiB of dynamic LDS */                            \
+            SLA_HIP_TRY(hipFuncSetAttribute((const void *)spmv_lpanel_kernel<RP, L_, R_, J_>,                               \
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kLpW * sizeof(double))));     \
+            c->lp_attr |= attr_bit;                                                                                         \
+        }                                                                                                                   \
+        hipLaunchKernelGGL((spmv_lpanel_kernel<RP, L_, R_, J_>), dim3(A->lp_G), dim3(kLpBlock), kLpW * sizeof(double),      \
+                           stream_of(c), (const RP *)A->d_lpp, a.col, a.val, a.x, A->d_lpy, A->d_lpt, a.rows, (int)A->n,       \
+                           A->lp_W, A->lp_chunk, A->lp_C, A->lp_col_lo, A->lp_col_hi, (const SolverScalars *)a.sc);         \
+    } break;
+    switch (A->lp_cfg) {
+        SLA_LP_LAUNCH(1, 32, 4, 2)
+        SLA_LP_LAUNCH(2, 16, 4, 2)
+        SLA_LP_LAUNCH(3, 8, 4, 2)
+        default:
+        SLA_LP_LAUNCH(0, 64, kLpRowsInFlight, 4)
+    }
+#undef SLA_LP_LAUNCH
+    SLA_HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL((lpanel_finish_kernel<EPI, RP>), dim3(grid), dim3(kBlock), 0, stream_of(c), a, A->d_lpy, A->lp_P);
+    SLA_HIP_TRY(hipGetLastError());
+    return SLA_OK;
+}
+template <typename RP>
+int launch_lpanel_rp(const sla_csr *A, int epi, const SpmvArgs<RP> &a, int grid) {
+    switch (epi) {
+        case EPI_NONE: return launch_lpanel_t<EPI_NONE, RP>(A, a, grid);
+        case EPI_DOT: return launch_lpanel_t<EPI_DOT, RP>(A, a, grid);
+        case EPI_DOT2: return launch_lpanel_t<EPI_DOT2, RP>(A, a, grid);
+        case EPI_DOT4: return launch_lpanel_t<EPI_DOT4, RP>(A, a, grid);
+        case EPI_RES: return launch_lpanel_t<EPI_RES, RP>(A, a, grid);
+        case EPI_AXPY_DOT: return launch_lpanel_t<EPI_AXPY_DOT, RP>(A, a, grid);
+        case EPI_XPBY_NRM: return launch_lpanel_t<EPI_XPBY_NRM, RP>(A, a, grid);
+        case EPI_SUB: return launch_lpanel_t<EPI_SUB, RP>(A, a, grid);
+    }
+    return fail(SLA_ERR_INVALID, "launch_spmv_lpanel: unknown epilogue");
+}
+}  // namespace
+
+int launch_spmv_lpanel(const sla_csr *A, int epi, const SpmvArgs<int32_t> &a, int grid) { return launch_lpanel_rp<int32_t>(A, epi, a, grid); }
+int launch_spmv_lpanel(const sla_csr *A, int epi, const SpmvArgs<int64_t> &a, int grid) { return launch_lpanel_rp<int64_t>(A, epi, a, grid); }
+
+}  // namespace sla

@@ -143,13 +143,17 @@ int64_t sla_wl_random_spd(int64_t n, int64_t k, const int64_t *c, const double *
 }
 
 
+void sla_wl_free(void *p) { free(p); }
+
 /* The same matrix, rows [rb, re) only (a rank of the row-sharded bench builds its own slab; global column ids):
- * rowptr has re - rb + 1 entries starting at 0.  col == NULL: returns an upper bound of the slab's entry count (size the
- * col / val buffers with it); otherwise fills rowptr / col / val and returns the slab's nnz.  -1: allocation failure.
+ * rowptr (caller's, re - rb + 1 entries) starts at 0; *col_out / *val_out are malloc'ed here (release with sla_wl_free).
+ * Returns the slab's nnz, -1 on allocation failure.  `threads` > 0 sets the OpenMP team (N ranks of one node must share the
+ * host's cores: an oversubscribed libgomp team spins in its barriers and takes minutes).
  * Bit-identical to rows [rb, re) of sla_wl_random_spd (tests/test_cabi_and_host.py). */
 int64_t sla_wl_random_spd_rows(int64_t n, int64_t k, const int64_t *c, const double *v, int64_t rb, int64_t re, int64_t *rowptr,
-                               int64_t *col, double *val) {
+                               int64_t **col_out, double **val_out, int threads) {
     const int64_t picks = n * k, rows = re - rb;
+    if (threads > 0) omp_set_num_threads(threads);
     int64_t *start = (int64_t *)calloc((size_t)rows + 1, sizeof(int64_t));
     if (!start) return -1;
 #pragma omp parallel
@@ -165,7 +169,6 @@ int64_t sla_wl_random_spd_rows(int64_t n, int64_t k, const int64_t *c, const dou
     }
     for (int64_t i = 0; i < rows; ++i) start[i + 1] += start[i];
     const int64_t total = start[rows];
-    if (!col) { free(start); return total + rows; }
     ent_t *e = (ent_t *)malloc((size_t)(total ? total : 1) * sizeof(ent_t));
     int64_t *fill = (int64_t *)malloc((size_t)(rows ? rows : 1) * sizeof(int64_t));
     int64_t *cnt = (int64_t *)malloc((size_t)(rows ? rows : 1) * sizeof(int64_t));
@@ -220,6 +223,11 @@ int64_t sla_wl_random_spd_rows(int64_t n, int64_t k, const int64_t *c, const dou
     if (alloc_failed) { free(start); free(e); free(cnt); free(diag); return -1; }
     rowptr[0] = 0;
     for (int64_t r = 0; r < rows; ++r) rowptr[r + 1] = rowptr[r] + cnt[r] + 1;
+    int64_t *col = (int64_t *)malloc((size_t)(rowptr[rows] ? rowptr[rows] : 1) * sizeof(int64_t));
+    double *val = (double *)malloc((size_t)(rowptr[rows] ? rowptr[rows] : 1) * sizeof(double));
+    if (!col || !val) { free(start); free(e); free(cnt); free(diag); free(col); free(val); return -1; }
+    *col_out = col;
+    *val_out = val;
 #pragma omp parallel for schedule(static, 4096)
     for (int64_t r = 0; r < rows; ++r) {
         const ent_t *row = e + start[r];

@@ -47,12 +47,12 @@ class IndexOutOfBounds(SlaError):
 
 class SolveOpts(C.Structure):
     _fields_ = [("max_iters", C.c_int32), ("tol_abs", C.c_double), ("tol_rel", C.c_double),
-                ("check_every", C.c_int32), ("true_residual", C.c_int32)]
+                ("check_every", C.c_int32), ("true_residual", C.c_int32), ("history", C.c_void_p), ("history_cap", C.c_int32)]
 
 
 class SolveInfo(C.Structure):
     _fields_ = [("iters", C.c_int32), ("flags", C.c_int32), ("resnorm", C.c_double),
-                ("r0norm", C.c_double), ("tol", C.c_double)]
+                ("r0norm", C.c_double), ("tol", C.c_double), ("history_len", C.c_int32)]
 
     def as_dict(self):
         return {"iters": self.iters, "flags": self.flags, "resnorm": self.resnorm,

@@ -728,9 +728,20 @@ def linSolve0(method, aa, b, x0, return_info=False, **opts):
     IterationException like the reference; never raises on non-convergence."""
     out = DeviceVector(aa.ctx, aa.ncols)
     info = SolveInfo()
-    check(lib().sla_linsolve0(int(method), aa.h, b.device().h, x0.device().h, _opts(opts), out.h, C.byref(info)))
+    hist = None
+    if opts.pop("history", False):     # residual trace: the true residual norm after every iteration (cgsStepDebug, Sparse.hs:942-948)
+        hist = np.zeros(max(int(opts.get("max_iters", 200)), 1), dtype=np.float64)
+        o = SolveOpts(opts.get("max_iters", 200), opts.get("tol_abs", 1e-6), opts.get("tol_rel", 1e-4), opts.get("check_every", 16),
+                      opts.get("true_residual", 1), hist.ctypes.data, len(hist))
+        po = C.byref(o)
+    else:
+        po = _opts(opts)
+    check(lib().sla_linsolve0(int(method), aa.h, b.device().h, x0.device().h, po, out.h, C.byref(info)))
     x = fromVector(out.to_host(), aa.ctx)
-    return (x, info.as_dict()) if return_info else x
+    d = info.as_dict()
+    if hist is not None:
+        d["history"] = hist[:info.history_len].copy()
+    return (x, d) if return_info else x
 
 
 def arnoldi(aa, b, kn):

@@ -96,7 +96,10 @@ def _wlgen():
             L.sla_wl_random_spd.restype = C.c_int64
             L.sla_wl_random_spd.argtypes = [C.c_int64, C.c_int64] + [C.c_void_p] * 5
             L.sla_wl_random_spd_rows.restype = C.c_int64
-            L.sla_wl_random_spd_rows.argtypes = [C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64] + [C.c_void_p] * 3
+            L.sla_wl_random_spd_rows.argtypes = [C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p,
+                                                 C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int]
+            L.sla_wl_free.restype = None
+            L.sla_wl_free.argtypes = [C.c_void_p]
             _WLGEN = L
     return _WLGEN or None
 
@@ -121,9 +124,11 @@ def random_spd(n, k=16, seed=42):
     return (n, n), (rowptr, col[:nnz], val[:nnz])
 
 
-def random_spd_rows(n, k, seed, row_begin, row_end):
+def random_spd_rows(n, k, seed, row_begin, row_end, threads=0):
     """Rows [row_begin, row_end) of random_spd(n, k, seed) (rowptr rebased to 0, global column ids) without assembling the
-    other rows: a rank of the row-sharded bench draws the full pick list (2 x n k numbers) and builds its own slab only."""
+    other rows: a rank of the row-sharded bench draws the full pick list (2 x n k numbers) and builds its own slab only.
+    threads > 0: the OpenMP team of the assembly (the ranks of one node share the host's cores)."""
+    import ctypes as C
     L = _wlgen()
     if L is None:
         from .partition import local_rows_of
@@ -134,15 +139,17 @@ def random_spd_rows(n, k, seed, row_begin, row_end):
     v = rng.uniform(-1.0, 1.0, size=n * k)
     rows = row_end - row_begin
     rowptr = np.empty(rows + 1, dtype=np.int64)
-    cap = L.sla_wl_random_spd_rows(n, k, c.ctypes.data, v.ctypes.data, row_begin, row_end, None, None, None)
-    if cap < 0:
-        raise MemoryError("sla_wl_random_spd_rows")
-    col = np.empty(max(cap, 1), dtype=np.int64)
-    val = np.empty(max(cap, 1), dtype=np.float64)
-    nnz = L.sla_wl_random_spd_rows(n, k, c.ctypes.data, v.ctypes.data, row_begin, row_end, rowptr.ctypes.data, col.ctypes.data, val.ctypes.data)
+    pc, pv = C.c_void_p(), C.c_void_p()
+    nnz = L.sla_wl_random_spd_rows(n, k, c.ctypes.data, v.ctypes.data, row_begin, row_end, rowptr.ctypes.data, C.byref(pc), C.byref(pv), int(threads))
     if nnz < 0:
         raise MemoryError("sla_wl_random_spd_rows")
-    return (n, n), (rowptr, col[:nnz].copy(), val[:nnz].copy())
+    try:
+        col = np.ctypeslib.as_array(C.cast(pc, C.POINTER(C.c_int64)), shape=(max(nnz, 1),))[:nnz].copy()
+        val = np.ctypeslib.as_array(C.cast(pv, C.POINTER(C.c_double)), shape=(max(nnz, 1),))[:nnz].copy()
+    finally:
+        L.sla_wl_free(pc)
+        L.sla_wl_free(pv)
+    return (n, n), (rowptr, col, val)
 
 
 def random_spd_numpy(n, k=16, seed=42):

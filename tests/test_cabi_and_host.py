@@ -123,3 +123,18 @@ def test_option_and_debug_symbols_are_exported():
     hdr = open(os.path.join(ROOT, "include", "sla_hip.h")).read()
     for nm in names:
         assert nm + "(" in hdr, nm
+
+
+def test_random_spd_slab_generator_equals_the_rows_of_the_full_matrix():
+    """bench.py --gpus N: every rank assembles only its own slab of BASELINE config 3a's matrix (workloads.random_spd_rows);
+    the slabs must be the rows of the one matrix random_spd defines, bit for bit, for any cut."""
+    from sla_amd import workloads as wl
+    from sla_amd.partition import local_rows_of, row_block
+    n, k = 30011, 8
+    dims, (rp, ci, va) = wl.random_spd(n, k, 42)
+    for world in (1, 2, 3, 8):
+        for rank in range(world):
+            b, e = row_block(n, rank, world)
+            d2, (rp2, ci2, va2) = wl.random_spd_rows(n, k, 42, b, e, threads=2)
+            r = local_rows_of(rp, ci, va, b, e)
+            assert d2 == dims and np.array_equal(rp2, r[0]) and np.array_equal(ci2, r[1]) and np.array_equal(va2, r[2]), (world, rank)

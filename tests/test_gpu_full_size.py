@@ -107,6 +107,13 @@ def test_bench_two_ranks_without_a_launcher_loopback_rehearsal():
         assert d["n_gpus"] == 2 and d["loopback"] is True and d["loopback_ranks"] == 2
     assert "x_exchange=window" in d["config"]["spmv_kernel"] and "ghost-row bicgstab: 3 grouped exchanges" in d["config"]["exchange"]
     assert d["steps"] == 8 and 0.0 < d["roofline"]["frac"] <= 1.0
+    # the north star's literal target rides along on the same sharded context (test size here): the random matrix with its x
+    # all-gathered per SpMV, timed like the headline, its collectives event-timed
+    rb = d["random_spd_10m"]
+    assert rb["value"] > 0 and "x_exchange=allgather" in rb["spmv_kernel"] and rb["rows"] == 60000
+    assert rb["exchanges_rank0"]["x_exchange"]["launches"] > 0 and rb["exchanges_rank0"]["sums"]["launches"] > 0
+    assert d["exchanges"]["sums"]["launches"] > 0
+    assert d["hbm_measured_ceiling_gbps"] >= d["hbm_measured"]["sweep_5r3w"]["gbps"] > 0
 
 
 def test_full_size_triangular_solves_recover_ones(sla):

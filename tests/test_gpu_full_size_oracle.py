@@ -30,7 +30,7 @@ def sla():
     return sla_amd
 
 
-def _check(sla, dims, rp, ci, va, expect_form, bit_exact, b_mode, tag, ctx=None):
+def _check(sla, dims, rp, ci, va, expect_form, bit_exact, b_mode, tag, ctx=None, cgs=False):
     n = dims[0]
     ctx = ctx or sla.default_context()
     A = sla.fromCSR(dims, rp, ci, va, ctx)
@@ -61,6 +61,13 @@ def _check(sla, dims, rp, ci, va, expect_form, bit_exact, b_mode, tag, ctx=None)
     for name, dev, ref in (("x", sd._xBicgstab, so.x), ("r", sd._rBicgstab, so.r), ("p", sd._pBicgstab, so.p)):
         d = dev.toDenseListSV()
         assert np.linalg.norm(d - ref) <= 1e-9 * np.linalg.norm(ref), (tag, name)
+    if cgs:   # two cgsStep's (Sparse.hs:928-939) on the same lowered matrix: the CGS epilogues (EPI_AXPY_DOT) of this SpMV form at full size
+        so, sc = orc.CgsState(Ao, b, x0), sla.cgsInit(A, sla.fromVector(b, ctx), sla.fromVector(x0, ctx))
+        so.step(b, 2)
+        sc.step(2)
+        for name, dev, ref in (("x", sc._x, so.x), ("r", sc._r, so.r), ("p", sc._p, so.p), ("u", sc._u, so.u)):
+            assert np.linalg.norm(dev.toDenseListSV() - ref) <= 1e-9 * np.linalg.norm(ref), (tag, "cgs", name)
+        del sc
     del sd, A
     gc.collect()
 
@@ -99,7 +106,8 @@ def test_config3a_random_spd_10m_vs_oracle(sla):
     from sla_amd import workloads as wl
     dims, (rp, ci, va) = wl.random_spd(10000000, 16, 42)
     assert dims[0] == 10000000 and rp[-1] == 329999456
-    _check(sla, dims, rp, ci, va, "algo=tiles", True, "xstar", "config3a")
+    # ... and CGS, the second half of config 3 ("CGS vs BiCGSTAB"), at the same 10 M rows through the tile form's fused epilogues
+    _check(sla, dims, rp, ci, va, "algo=tiles", True, "xstar", "config3a", cgs=True)
 
 
 def test_config3a_cgs_two_steps_vs_oracle_1m(sla):

@@ -573,3 +573,40 @@ def test_pure_step_functions_do_not_alias_and_take_an_explicit_shadow_residual(s
         so.step(shadow, 2)
         assert np.linalg.norm(getattr(s1, xf).toDenseListSV() - so.x) <= 1e-9 * np.linalg.norm(so.x)
         assert np.linalg.norm(getattr(s1, xf).toDenseListSV() - getattr(chain[2], xf).toDenseListSV()) > 1e-6 * np.linalg.norm(so.x)
+
+
+@pytest.mark.parametrize("method", ["BICGSTAB_", "CGS_", "CGNE_"])
+@pytest.mark.parametrize("check_every", [1, 5, 16])
+def test_residual_trace_equals_the_oracles_sequence(sla, method, check_every):
+    """sla_solve_opts.history ("per-iteration residual trace buffer on device"; cgsStepDebug, Sparse.hs:942-948,
+    is the reference's own per-iteration residual output): the true residual norms runIter evaluates after every step, kept
+    on the device and downloaded once.  Against the oracle's step-by-step sequence, for every host polling interval (the
+    trace is written by whichever kernel tests the residual: the next step's prologue or the end-of-batch check)."""
+    from sla_amd import workloads as wl
+    dims, (rp, ci, va) = wl.poisson2d(40, 37)
+    n = dims[0]
+    A, Ao = sla.fromCSR(dims, rp, ci, va), orc.Csr(n, n, rp, ci, va)
+    b = orc.spmv(Ao, np.linspace(-1.0, 2.0, n))
+    x, info = sla.linSolve0(getattr(sla, method), A, sla.fromVector(b), sla.fromVector(np.zeros(n)), return_info=True, history=True,
+                            check_every=check_every)
+    hist = info["history"]
+    assert len(hist) == info["iters"] > 3 and info["converged"]
+    st = {"BICGSTAB_": orc.BicgstabState, "CGS_": orc.CgsState, "CGNE_": orc.CgneState}[method](Ao, b, np.zeros(n))
+    seq = []
+    for _ in range(len(hist)):
+        st.step(b) if method != "CGNE_" else st.step()
+        seq.append(np.linalg.norm(orc.spmv(Ao, st.x) - b))
+    seq = np.array(seq)
+    # early iterations agree to rounding; a Krylov recurrence amplifies last-bit differences of the inner products step by step
+    assert np.all(np.abs(hist[:5] - seq[:5]) <= 1e-9 * seq[:5])
+    assert np.all(np.abs(hist - seq) <= 1e-4 * np.maximum(seq, info["tol"]))
+    assert hist[-1] == info["resnorm"] <= info["tol"] and np.all(hist[:-1] > info["tol"])
+    # a short buffer takes the first entries only; without the option nothing is traced
+    import ctypes as C
+    from sla_amd import _lib
+    buf = np.zeros(4)
+    o = _lib.SolveOpts(200, 1e-6, 1e-4, check_every, 1, buf.ctypes.data, 4)
+    out, inf2 = sla.DeviceVector(A.ctx, n), _lib.SolveInfo()
+    _lib.check(_lib.lib().sla_linsolve0(int(getattr(sla, method)), A.h, sla.fromVector(b).device().h, sla.fromVector(np.zeros(n)).device().h,
+                                        C.byref(o), out.h, C.byref(inf2)))
+    assert inf2.history_len == 4 and np.array_equal(buf, hist[:4]) and inf2.iters == info["iters"]

@@ -348,3 +348,67 @@ def test_lu_reference_cases_and_ilu0_definition():
     rc, A = orc.coo_to_csr(3, 3, np.array([0, 0, 1, 1, 2, 2]), np.array([0, 1, 0, 1, 1, 2]), np.array([1.0, 2.0, 2.0, 4.0, 1.0, 1.0]))
     rc, L, U, bad = orc.lu(A)
     assert rc == orc.ERR_PIVOT and bad == 1
+
+
+# ---- qr (Sparse.hs:306-331): the least-squares step of the oracle's GMRES, pinned to the reference's own QR cases -----
+
+def _qr_case(name):
+    c = G["qr"][name]
+    if "dense_colmajor" in c:                                               # fromListDenseSM n: column-major (SpMatrix.hs)
+        n = c["n"]
+        a = np.array(c["dense_colmajor"], dtype=float).reshape(n, n).T
+        return a, None
+    a = np.zeros(c["dims"])
+    st = np.zeros(c["dims"], dtype=bool)
+    for i, j, x in c["triples"]:
+        a[i, j], st[i, j] = x, True
+    return a, st
+
+
+@pytest.mark.parametrize("name", ["tm2", "tm4", "tm6", "issueMatrix"])
+def test_qr_reference_cases(name):
+    """checkQr0 (test/MatrixFactorizationsSpec.hs:60-74): nearZero (normFrobenius (sparsifySM (q ## r ^-^ a))), isOrthogonalSM q
+    (roundZeroOneSM (transpose q ## q) == eye), isUpperTriSM r -- on the cases the reference runs it on (:46-53)."""
+    a, st = _qr_case(name)
+    rc, q, r = orc.qr(a, st)
+    assert rc == orc.OK
+    d = q @ r - a
+    d[np.abs(d) <= 1e-12] = 0.0
+    assert np.linalg.norm(d) <= 1e-12                                       # c1
+    qtq = q.T @ q
+    rounded = np.where(np.abs(qtq) <= 1e-12, 0.0, np.where(np.abs(qtq - 1.0) <= 1e-12, 1.0, qtq))
+    assert np.array_equal(rounded, np.eye(len(a)))                          # c2
+    assert np.array_equal(r, np.triu(r))                                    # c3: structurally upper triangular (sparsified)
+
+
+def test_qr_is_the_reference_rotation_sequence():
+    """The rotations themselves on a small Hessenberg matrix, computed by hand from the reference's definitions: givensCoef
+    (c, s, r) = (a / r, b / r, sqrt (a a + b b)); G = eye with (i,i) = c, (i,j) = -s, (j,i) = s, (j,j) = c; m' = G ## m folded
+    ascending from 0.  One rotation zeroes (1, 0) of [[3, 1], [4, 2], [0, 5]] exactly: r = 5, c = 0.6, s = 0.8."""
+    a = np.array([[3.0, 1.0], [4.0, 2.0], [0.0, 5.0]])
+    st = np.array([[1, 1], [1, 1], [0, 1]], dtype=bool)
+    rc, q, r = orc.qr(a, st)
+    c, s = 3.0 / 5.0, 4.0 / 5.0
+    row0 = [(0.0 + c * 3.0) + s * 4.0, (0.0 + c * 1.0) + s * 2.0]
+    row1_1 = (0.0 + (-s) * 1.0) + c * 2.0
+    # second rotation: (2, 1) with a = row1_1 (row 1 is the first row whose first stored column is 1), b = 5
+    rr = np.sqrt(row1_1 * row1_1 + 25.0)
+    c2, s2 = row1_1 / rr, 5.0 / rr
+    assert r[0, 0] == row0[0] and r[0, 1] == row0[1] and r[1, 0] == 0.0 and r[2, 0] == 0.0 and r[2, 1] == 0.0
+    assert r[1, 1] == (0.0 + c2 * row1_1) + s2 * 5.0
+    assert np.linalg.norm(q @ r - a) <= 1e-14
+
+
+def test_gmres_least_squares_step_minimises_the_residual():
+    """orc_gmres solves each cycle as the commented sketch does (qr + triUpperSolve, Sparse.hs:837-848): against numpy's
+    least-squares solution of the same Hessenberg system the returned iterate must agree."""
+    rng = np.random.default_rng(5)
+    n = 40
+    M = rng.standard_normal((n, n)) + 8 * np.eye(n)
+    r_, c_ = np.nonzero(M)
+    rc, A = orc.coo_to_csr(n, n, r_.astype(np.int64), c_.astype(np.int64), M[r_, c_])
+    b = rng.standard_normal(n)
+    rc, x, iters, res, r0 = orc.gmres(A, b, np.zeros(n), restart=12, max_restarts=1)
+    rc, Q, H, k = orc.arnoldi(A, b, 12)
+    y = np.linalg.lstsq(H, np.linalg.norm(b) * np.eye(k + 1)[:, 0], rcond=None)[0]
+    assert iters == k and np.linalg.norm(x - Q[:, :k] @ y) <= 1e-10 * np.linalg.norm(x)
