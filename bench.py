@@ -551,7 +551,7 @@ def run_rank(args, rank, world, local_rank, dist_mode, loop=None):
         ghost = ("x_exchange=window" in kinfo and os.environ.get("SLA_BICG_GHOST", "1") != "0" and args.mode in ("step", "linsolve0"))
         rec["config"]["exchange"] = (
             ("halo (window) send/recv received in place" if "x_exchange=window" in kinfo else "all-gather of x")
-            + (f"; ghost-row {args.method}: {3 if args.method == 'bicgstab' else 2} grouped exchanges per step"
+            + (f"; ghost-row {args.method}: {(2 if ctx.get_option('bicg_fuse45') == '1' else 3) if args.method == 'bicgstab' else 2} grouped exchanges per step"
                + (" + the residual sweep's own exchange and sum" if args.mode == "linsolve0" else "") if ghost
                else ("; plain flow" if args.mode != "gmres" else "; Arnoldi: one exchange per SpMV, per-column sums all-gathered")))
     rec.update({

@@ -239,6 +239,8 @@ int spmv_exchanged(sla_csr *A, sla_vec *x, SpmvLaunch l, int *np) {
     lb.step_begin &= ~1;
     if (lb.p1) lb.p1 += gi;
     if (lb.p2) lb.p2 += gi;
+    if (lb.p3) lb.p3 += gi;
+    if (lb.p4) lb.p4 += gi;
     SLA_TRY(launch_spmv(A, lb));
     if (np) *np = gi + overlap_grid(A, 2);
     return SLA_OK;

@@ -205,7 +205,8 @@ struct sla_ctx {
     int force_rp64 = 0;              // test hook: 64-bit row pointers at any size (SLA_FORCE_RP64)
     int lpanel = 1;                  // allow the LDS-panel SpMV kernel for matrices with dense rows (SLA_LPANEL=0 disables)
     int xwin = 1;                    // allow the LDS x-window SpMV kernel (SLA_XWIN=0 disables)
-    int stream_pipe = 1;             // plain CSR-stream (#>): the three-stage pipelined kernel (sla_spmv_pipe.hip) instead of spmv_stream / spmv_xwin (SLA_STREAM_PIPE=0: those)
+    int stream_pipe = 0;             // plain CSR-stream (#>): the three-stage pipelined kernel (sla_spmv_pipe.hip) instead of spmv_stream / spmv_xwin
+                                     // (SLA_STREAM_PIPE=1; OFF by default: measured 7-12 % SLOWER than the one-deep prefetch)
     int dual_spmv = 1;               // linSolve0: fuse the true-residual SpMV into the next K1 (SLA_DUAL_SPMV=0 disables)
     int x_exchange = 0;              // 0 auto (window exchange when it pays), 1 always all-gather, 2 always window (SLA_X_EXCHANGE=allgather|window)
     int halo_inplace = 1;            // window exchange straight into the slack around the vector (SLA_HALO_INPLACE=0: via the landing buffer)

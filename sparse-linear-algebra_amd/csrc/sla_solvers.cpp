@@ -16,7 +16,8 @@ using namespace sla;
 
 namespace {
 
-enum Slot { P_APR = 0, P_ASS = 1, P_ASAS = 2, P_RHO = 3, P_RES = 4, P_TMP = 5, P_TR0 = 6, P_SR0 = 7, P_SLOTS = 8 };
+// (P_ASS .. P_SR0 are consecutive: the four sums of the fused K4+K5 flow are folded and exchanged as one block, publish4)
+enum Slot { P_APR = 0, P_ASS = 1, P_ASAS = 2, P_TR0 = 3, P_SR0 = 4, P_RHO = 5, P_RES = 6, P_TMP = 7, P_SLOTS = 8 };
 
 double *slot(sla_solver *S, int s) { return S->d_parts + (size_t)s * kMaxParts; }
 
@@ -56,6 +57,33 @@ static int publish_with_halo(sla_solver *S, int s1, int s2, int np, Parts *o1, P
     SLA_TRY(rc_end);
     *o1 = Parts{g, c->nranks, 2};
     if (o2) *o2 = Parts{g + 1, c->nranks, 2};
+    return SLA_OK;
+}
+
+// The four sums K3 leaves for the fused K4+K5 sweep (As . s, As . As, As . r0hat, s . r0hat; slots P_ASS .. P_SR0) made consumable.
+// One GPU: as they are.  Sharded: ONE fold launch (four columns), the per-rank quadruples all-gathered -- and, in the ghost-row
+// flow, the neighbours' rows of `halo` (As) in the same grouped launch, so that the sweep can run on own + ghost rows.
+static int publish4(sla_solver *S, int np, Parts out[4], sla_vec *halo) {
+    sla_ctx *c = S->ctx;
+    if (!c->collectives) {
+        for (int j = 0; j < 4; ++j) out[j] = Parts{slot(S, P_ASS + j), np, 1};
+        return SLA_OK;
+    }
+    ProfScope prof(c, SLA_KERNEL_SUMS);
+    double *g = S->d_gath + (size_t)P_ASS * 2 * c->nranks;   // 4 doubles per rank: the tables of P_ASS and P_ASAS are adjacent
+    double *loc = g + 4 * c->rank;                            // in place: this rank's sums go straight into their slot
+    SLA_TRY(launch_finalize_cols(c, slot(S, P_ASS), np, kMaxParts, 1, 4, loc));
+    if (halo) {
+        SLA_TRY(dist_group_begin(c));
+        int rc = dist_allgather_p2p_f64(c, loc, g, 4);
+        if (rc == SLA_OK) rc = dist_exchange_window(c, *S->A->xplan, halo->d, halo->begin, halo->n_local, halo->d - halo->begin);
+        const int rc_end = dist_group_end(c);
+        if (rc != SLA_OK) return rc;
+        SLA_TRY(rc_end);
+    } else {
+        SLA_TRY(dist_allgather_f64(c, loc, g, 4));
+    }
+    for (int j = 0; j < 4; ++j) out[j] = Parts{g + j, c->nranks, 4};
     return SLA_OK;
 }
 
@@ -118,6 +146,8 @@ int enqueue_residual(sla_solver *S, Parts *res) {
 //   ghost rows from halo(r'), halo(p) (kept from the previous step) and halo(Ap) (still in place).
 // Three grouped launches per step, no exchange in front of either SpMV; every ghost value is computed by the same
 // kernel from the same bits as on its owner, so the iterates are bit-identical to the plain flow.
+// With the fused K4+K5 sweep (SLA_BICG_FUSE45, default) it is TWO: halo(As) travels with K3's four sums and the sweep runs
+// on own + ghost rows (see below), which makes r' and p' valid there without a third exchange.
 static int enqueue_bicgstab_ghost(sla_solver *S, int par, const Parts *check) {
     sla_ctx *c = S->ctx;
     sla_csr *A = S->A;
@@ -151,6 +181,21 @@ static int enqueue_bicgstab_ghost(sla_solver *S, int par, const Parts *check) {
         l.p2 = slot(S, P_ASAS);
         l.sc = S->d_sc;
         l.kernel_id = SLA_KERNEL_SPMV_DOT2;
+        if (c->bicg_fuse45) {
+            // Fused K4+K5 on own + ghost rows: K3 also sums As . r0hat and s . r0hat (rho' by linearity, bicg_k45_kernel), halo(As)
+            // travels WITH the four sums, and the sweep then forms x', r' and p' on the ghost rows too from s (K2 left it there),
+            // As and Ap (their halos are in place) and the p it kept -- so NO third exchange and no K5: two grouped exchanges and
+            // four kernels per step.  (x rides along over the ghost range: its slack holds nothing anybody reads.)
+            l.epi = EPI_DOT4;
+            l.z = S->r0hat->d;
+            l.p3 = slot(S, P_TR0);
+            l.p4 = slot(S, P_SR0);
+            SLA_TRY(launch_spmv(A, l));
+            Parts q[4];
+            SLA_TRY(publish4(S, g, q, S->t3));
+            return launch_bicg_k45(c, next, S->d_sc, q[0], q[1], q[2], q[3], par, S->t2->d - gl, S->t3->d - gl, S->t1->d - gl, S->x->d - gl,
+                                   S->r->d - gl, S->p->d - gl);
+        }
         SLA_TRY(launch_spmv(A, l));
         SLA_TRY(publish(S, P_ASS, P_ASAS, g, &ass, &asas));
     }
@@ -198,12 +243,12 @@ int enqueue_bicgstab(sla_solver *S, int par, const Parts *check, bool dual_prev)
         l.p2 = slot(S, P_ASAS);
         l.sc = S->d_sc;
         l.kernel_id = SLA_KERNEL_SPMV_DOT2;
-        // single rank: the sweep also sums As . r0hat and s . r0hat, which give rho_{j+1} before r_{j+1} exists, so that K4 and
-        // K5 become one sweep (bicg_k45_kernel); sharded contexts keep the reference's split (their partial sums travel in pairs)
+        // the sweep also sums As . r0hat and s . r0hat, which give rho_{j+1} before r_{j+1} exists, so that K4 and K5 become one
+        // sweep (bicg_k45_kernel) -- on one GPU and, since round 3, on row-sharded contexts too (publish4)
         // (the variable-coefficient wave-sliced kernel is register-bound at 5 workgroups per CU and spills with the third operand,
         // so its EPI_DOT4 instantiation is compiled for 4: 2 M-row banded problem, same box, three interleaved runs each: split
         // 11 501-11 581 it/s, fused 11 963-12 055)
-        const bool fuse = c->bicg_fuse45 && !c->collectives;
+        const bool fuse = c->bicg_fuse45 != 0;
         if (fuse) {
             l.epi = EPI_DOT4;
             l.z = S->r0hat->d;
@@ -212,10 +257,12 @@ int enqueue_bicgstab(sla_solver *S, int par, const Parts *check, bool dual_prev)
         }
         int gk = g;
         SLA_TRY(spmv_exchanged(A, S->t2, l, &gk));
+        if (fuse) {   // (row-sharded: the four sums travel as ONE all-gather; the rho exchange and K5 are gone)
+            Parts q[4];
+            SLA_TRY(publish4(S, gk, q, nullptr));
+            return launch_bicg_k45(c, n, S->d_sc, q[0], q[1], q[2], q[3], par, S->t2->d, S->t3->d, S->t1->d, S->x->d, S->r->d, S->p->d);
+        }
         SLA_TRY(publish(S, P_ASS, P_ASAS, gk, &ass, &asas));
-        if (fuse)
-            return launch_bicg_k45(c, n, S->d_sc, ass, asas, Parts{slot(S, P_TR0), gk, 1}, Parts{slot(S, P_SR0), gk, 1}, par, S->t2->d,
-                                   S->t3->d, S->t1->d, S->x->d, S->r->d, S->p->d);
     }
     SLA_TRY(launch_bicg_k4(c, n, S->d_sc, ass, asas, S->p->d, S->t2->d, S->t3->d, S->r0hat->d, S->x->d, S->r->d, slot(S, P_RHO)));
     SLA_TRY(publish(S, P_RHO, -1, vec_grid(n), &rhon, nullptr));

@@ -10,13 +10,13 @@
 //
 // Here a workgroup works on three consecutive row blocks at once and issues its loads in the order they will be consumed:
 //     iteration of block b:   P  products of b -> LDS          (waits for the gathers of b, issued one iteration ago)
-//                             O  epilogue operands of b's rows (w / z / running sums: consumed at the end of this iteration)
+//                             O  epilogue operands of the rows of block b+1 (w / z / running sums)
 //                             G  gathers x[col] of block b+1   (its columns were streamed one iteration ago)
 //                             S  col / val / rowptr streams of block b+2
-//                             barrier ; R  row sums of b from LDS + fused epilogue
-// so the fold of b runs while the gathers of b+1 and the streams of b+2 are in flight, and the only waits are on loads issued a
-// whole iteration earlier (O is issued before G and S: its in-order return does not drain them).  Values alternate between
-// two register sets (loop unrolled by two) because a register copy would wait for the load that fills it.  Same row-block
+//                             barrier ; R  row sums of b from LDS + fused epilogue (operands loaded one iteration ago)
+// so the fold of b runs while the operands and gathers of b+1 and the streams of b+2 are in flight, and every wait is on a load
+// issued a whole iteration earlier.  Values, row pointers and operands alternate between two register sets (loop unrolled by
+// two) because a register copy would wait for the load that fills it.  Same row-block
 // tables, same LDS layout (products double-buffered: one barrier per row block), same per-row folds and epilogue arithmetic
 // as spmv_stream_kernel: identical bits.  Taken when no row is longer than a row block (the stream kernel keeps the
 // long-row cases).
@@ -124,13 +124,32 @@ __global__ void __launch_bounds__(kBlock, 8) spmv_pipe_kernel(SpmvArgs<RP> a, co
 #pragma unroll
             for (int j = 0; j < 4; ++j) xv[j] = xg[c[j]];
         };
-        // prime the pipeline: streams of b, gathers of b, streams of b+1
+        // which row does a lane finish in a block of nrows rows / cnt entries?  lane per row, or lane 0 of a power-of-two segment
+        struct Fin { bool lane_per_row; int tpr, g, l; };
+        auto fin_of = [&](int nrows, int cnt) {
+            Fin f;
+            f.lane_per_row = nrows > 64 || cnt <= 8 * nrows;
+            int np2 = 1;
+            while (np2 < nrows) np2 <<= 1;
+            f.tpr = min(64, kBlock / np2);
+            f.g = f.lane_per_row ? tid : tid / f.tpr;
+            f.l = f.lane_per_row ? 0 : tid - f.g * f.tpr;
+            return f;
+        };
+        auto operands = [&](int or0, int or1, RP ok0, RP ok1) {   // O: the epilogue operands of the row this lane finishes in that block
+            const Fin f = fin_of(or1 - or0, (int)(ok1 - ok0));
+            return epi_load<EPI, RP, YI>(a, or0 + min(f.g, max(or1 - or0 - 1, 0)));
+        };
+        // prime the pipeline: streams of b, operands of b, gathers of b, streams of b+1
+        EpiOps opsA, opsB;
         stream(r0, r1, k0, k1, vA, rpA);
+        opsA = operands(r0, r1, k0, k1);
         gather();
         stream(nr0, nr1, nk0, nk1, vB, rpB);
         int buf = 0;
-        // one iteration; vcur / rpcur belong to block b (and receive the streams of block b+2), the columns of block b+1 are in c[]
-        auto iteration = [&](double (&vcur)[4], RP &rpcur) {
+        // one iteration; vcur / rpcur / opscur belong to block b (vcur / rpcur then receive the streams of block b+2), opsnext receives
+        // the operands of block b+1, whose columns are in c[]
+        auto iteration = [&](double (&vcur)[4], RP &rpcur, const EpiOps &opscur, EpiOps &opsnext) {
             const int nrows = r1 - r0, cnt = (int)(k1 - k0);
             double *prod = s_prod[buf];
             int *rp = s_rp[buf];
@@ -143,15 +162,14 @@ __global__ void __launch_bounds__(kBlock, 8) spmv_pipe_kernel(SpmvArgs<RP> a, co
                 const double p = vcur[j] * xv[j];
                 if (i < cnt) prod[i] = p;
             }
-            // O: which row does this lane finish?  (lane per row, or lane 0 of a power-of-two segment of the wavefront)
-            const bool lane_per_row = nrows > 64 || cnt <= 8 * nrows;
-            int np2 = 1;
-            while (np2 < nrows) np2 <<= 1;
-            const int tpr = min(64, kBlock / np2);
-            const int g = lane_per_row ? tid : tid / tpr, l = lane_per_row ? 0 : tid - g * tpr;
+            const Fin f = fin_of(nrows, cnt);
+            const bool lane_per_row = f.lane_per_row;
+            const int tpr = f.tpr, g = f.g, l = f.l;
             const bool fin = g < nrows && l == 0;
-            const EpiOps ops = epi_load<EPI, RP, YI>(a, r0 + min(g, max(nrows - 1, 0)));
-            // G, S for the blocks behind
+            const EpiOps &ops = opscur;
+            // O (block b+1: consumed a whole iteration from now -- vector loads return in order, so an operand loaded for THIS
+            // block's fold would stall it for a full HBM round trip), then G, S for the blocks behind
+            opsnext = operands(nr0, nr1, nk0, nk1);
             gather();
             stream(fr0, fr1, fk0, fk1, vcur, rpcur);
             // descriptors three blocks ahead (scalar loads; consumed at the end of this iteration)
@@ -186,9 +204,9 @@ __global__ void __launch_bounds__(kBlock, 8) spmv_pipe_kernel(SpmvArgs<RP> a, co
             fr0 = gr0; fr1 = gr1; fk0 = gk0; fk1 = gk1;
         };
         for (int it = 0;;) {
-            iteration(vA, rpA);
+            iteration(vA, rpA, opsA, opsB);
             if (++it >= nb) break;
-            iteration(vB, rpB);
+            iteration(vB, rpB, opsB, opsA);
             if (++it >= nb) break;
         }
     }

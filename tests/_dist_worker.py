@@ -210,6 +210,68 @@ def main():
     for a_, g_ in zip(plain_steps(3), ghost_steps(3)):
         assert np.array_equal(a_, g_), "ghost-row flow must reproduce the plain sharded flow bit for bit"
 
+    # ---- the fused K4+K5 sweep on row-sharded contexts (round 3; the library's default, SLA_BICG_FUSE45) ----------------------
+    # rho' = s . r0hat - omega (As . r0hat) by linearity (bicg_k45_kernel), so K3's four sums -- As . s, As . As, As . r0hat,
+    # s . r0hat -- travel as ONE exchange and the rho exchange is gone: 4 exchanges per step on the plain flow; on the ghost-row
+    # flow halo(As) rides with the four sums and the sweep runs on own + ghost rows: TWO exchanges per step.
+    def fused_plain_steps(k):
+        x, r = x0[b:e].copy(), (bg[b:e] - orc.spmv(loc, window_exchange(x0[b:e])[:n]))
+        p, r0h = r.copy(), r.copy()
+        rho = gdot(r, r0h)
+        for _ in range(k):
+            ap = orc.spmv(loc, window_exchange(p)[:n])               # exchange 1
+            alpha = rho / gdot(ap, r0h)                              # exchange 2
+            s = r - alpha * ap
+            as_ = orc.spmv(loc, window_exchange(s)[:n])              # exchange 3
+            q = sums_only([orc.dot(as_, s), orc.dot(as_, as_), orc.dot(as_, r0h), orc.dot(s, r0h)])   # exchange 4: ONE all-gather of four sums
+            omega = q[0] / q[1]
+            rho1 = q[3] - omega * q[2]
+            beta = rho1 / rho * alpha / omega
+            x = (x + alpha * p) + omega * s
+            r = s - omega * as_
+            p = r + beta * (p - omega * ap)
+            rho = rho1
+        return x, r, p
+
+    def sums_only(mine):
+        parts = [torch.zeros(len(mine), dtype=torch.float64) for _ in range(P)]
+        dist.all_gather(parts, torch.tensor(mine, dtype=torch.float64))
+        tot = np.zeros(len(mine))
+        for q in range(P):
+            tot = tot + parts[q].numpy()
+        return tot
+
+    def fused_ghost_steps(k):
+        nanv = lambda: np.full(S * P, np.nan)                        # noqa: E731
+        X, R, Pv, AP, Sv, AS = nanv(), nanv(), nanv(), nanv(), nanv(), nanv()
+        X[b:e] = x0[b:e]
+        X[ext & np.isnan(X)] = 0.0                                   # (x rides along on the ghost rows: whatever is there)
+        R[b:e] = bg[b:e] - orc.spmv(loc, window_exchange(x0[b:e])[:n])
+        r0h = R[b:e].copy()
+        R[:] = window_exchange(R[b:e])
+        Pv[:] = R
+        rho = gdot(R[b:e], r0h)
+        for _ in range(k):
+            AP[b:e] = orc.spmv(loc, Pv[:n])
+            alpha = rho / sums_and_halo([orc.dot(AP[b:e], r0h)], AP)[0]          # exchange 1: alpha partials + halo(Ap)
+            Sv[ext] = R[ext] - alpha * AP[ext]
+            AS[b:e] = orc.spmv(loc, Sv[:n])
+            q = sums_and_halo([orc.dot(AS[b:e], Sv[b:e]), orc.dot(AS[b:e], AS[b:e]), orc.dot(AS[b:e], r0h), orc.dot(Sv[b:e], r0h)], AS)   # exchange 2: four sums + halo(As)
+            omega = q[0] / q[1]
+            rho1 = q[3] - omega * q[2]
+            beta = rho1 / rho * alpha / omega
+            X[ext] = (X[ext] + alpha * Pv[ext]) + omega * Sv[ext]
+            R[ext] = Sv[ext] - omega * AS[ext]
+            Pv[ext] = R[ext] + beta * (Pv[ext] - omega * AP[ext])
+            rho = rho1
+        return X[b:e].copy(), R[b:e].copy(), Pv[b:e].copy()
+
+    fp, fg = fused_plain_steps(3), fused_ghost_steps(3)
+    for a_, g_ in zip(fp, fg):
+        assert np.array_equal(a_, g_), "the fused ghost-row flow must reproduce the fused plain sharded flow bit for bit"
+    for a_, g_ in zip(plain_steps(3), fp):                           # rho' through the identity: a regrouping-level difference
+        assert np.allclose(a_, g_, rtol=1e-9, atol=1e-11)
+
     # ---- ghost-row CGS (enqueue_cgs_ghost): 2 exchanges per step instead of 4 ------------------------------------------
     def cgs_plain(k):
         x, r = x0[b:e].copy(), (bg[b:e] - orc.spmv(loc, window_exchange(x0[b:e])[:n]))

@@ -105,7 +105,7 @@ def test_bench_two_ranks_without_a_launcher_loopback_rehearsal():
         assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and "loopback" not in d      # a real node: RCCL saw both ranks
     else:
         assert d["n_gpus"] == 2 and d["loopback"] is True and d["loopback_ranks"] == 2
-    assert "x_exchange=window" in d["config"]["spmv_kernel"] and "ghost-row bicgstab: 3 grouped exchanges" in d["config"]["exchange"]
+    assert "x_exchange=window" in d["config"]["spmv_kernel"] and "ghost-row bicgstab: 2 grouped exchanges" in d["config"]["exchange"]
     assert d["steps"] == 8 and 0.0 < d["roofline"]["frac"] <= 1.0
     # the north star's literal target rides along on the same sharded context (test size here): the random matrix with its x
     # all-gathered per SpMV, timed like the headline, its collectives event-timed

@@ -1,0 +1,124 @@
+// stream_width_probe.cpp -- does the WIDTH of the per-lane loads bound the CSR-stream SpMV?  (round 3)
+//
+// PMC on spmv_stream_kernel (profiles/r03_pmc_stream_kernel.txt): the waves wait 85 % of their cycles, the L1s sit in
+// TCP_PENDING_STALL (data pending from the L2) half of the time, no FIFO-full, 6 % issue -- memory-side bound at 7.8 B/clk/CU
+// where the 16-byte-per-lane vector kernels reach 10.6.  The stream kernel loads 4 B (col) and 8 B (val) per lane, lane-strided:
+// 256 / 512 bytes per wave-instruction.  This probe runs the kernel's skeleton (7 entries per row, 146-row blocks of 1022
+// entries, products staged in LDS, one lane per row, y stored) with
+//   W0: dword col + dwordx2 val, 4 + 4 lane-strided loads per lane        (what spmv_stream_kernel does)
+//   W1: dwordx2 col + dwordx4 val, 2 + 2 loads per lane, 16-byte aligned  (512 B / 1 KiB per wave-instruction)
+// each without and with the x gather, 8 workgroups per CU, persistent grid of 2048.
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 tools/stream_width_probe.cpp -o tools/stream_width_probe
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <algorithm>
+#include <vector>
+
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+
+constexpr int kRows = 146, kEnt = 1022;
+
+template <int W, bool GATHER>
+__global__ void __launch_bounds__(256, 8) k_probe(const int *__restrict__ col, const double *__restrict__ val, const double *__restrict__ x,
+                                                  double *__restrict__ y, int nblk) {
+    __shared__ double s_prod[2][1024];
+    const int tid = threadIdx.x;
+    int buf = 0;
+    for (int b = blockIdx.x; b < nblk; b += gridDim.x) {
+        const long k0 = (long)b * kEnt;
+        double *prod = s_prod[buf];
+        if constexpr (W == 0) {
+            int c[4];
+            double v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int i = min(tid + 256 * j, kEnt - 1);
+                c[j] = __builtin_nontemporal_load(col + k0 + i);
+                v[j] = __builtin_nontemporal_load(val + k0 + i);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int i = tid + 256 * j;
+                const double xv = GATHER ? x[c[j]] : (double)c[j];
+                if (i < kEnt) prod[i] = v[j] * xv;
+            }
+        } else {
+            i32x2 c[2];
+            f64x2 v[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int i = min(2 * tid + 512 * j, kEnt - 2);   // (k0 is even: 8-byte aligned col pairs, 16-byte aligned val pairs)
+                c[j] = __builtin_nontemporal_load((const i32x2 *)(col + k0 + i));
+                v[j] = __builtin_nontemporal_load((const f64x2 *)(val + k0 + i));
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int i = 2 * tid + 512 * j;
+                const double xa = GATHER ? x[c[j].x] : (double)c[j].x, xb = GATHER ? x[c[j].y] : (double)c[j].y;
+                if (i < kEnt) *(f64x2 *)(prod + i) = f64x2{v[j].x * xa, v[j].y * xb};
+            }
+        }
+        __syncthreads();
+        if (tid < kRows) {
+            double acc = 0.0;
+            for (int k = tid * 7; k < tid * 7 + 7; ++k) acc += prod[k];
+            y[(long)b * kRows + tid] = acc;
+        }
+        buf ^= 1;
+    }
+}
+
+int main(int argc, char **argv) {
+    const int N = argc > 1 ? atoi(argv[1]) : 216;
+    const long n0 = (long)N * N * N, nblk = n0 / kRows, n = nblk * kRows, nnz = n * 7;
+    std::vector<int> hc((size_t)nnz);
+    std::vector<double> hv((size_t)nnz);
+    const long off[7] = {-(long)N * N, -N, -1, 0, 1, N, (long)N * N};
+    for (long r = 0; r < n; ++r)
+        for (int t = 0; t < 7; ++t) {
+            hc[(size_t)(7 * r + t)] = (int)std::min<long>(std::max<long>(r + off[t], 0), n - 1);
+            hv[(size_t)(7 * r + t)] = t == 3 ? 6.0 : -1.0;
+        }
+    int *col;
+    double *val, *x, *y;
+    hipMalloc(&col, 4 * (size_t)nnz + 64);
+    hipMalloc(&val, 8 * (size_t)nnz + 64);
+    hipMalloc(&x, 8 * (size_t)n);
+    hipMalloc(&y, 8 * (size_t)n);
+    hipMemcpy(col, hc.data(), 4 * (size_t)nnz, hipMemcpyHostToDevice);
+    hipMemcpy(val, hv.data(), 8 * (size_t)nnz, hipMemcpyHostToDevice);
+    std::vector<double> hx((size_t)n, 1.0);
+    hipMemcpy(x, hx.data(), 8 * (size_t)n, hipMemcpyHostToDevice);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    auto run = [&](const char *name, auto kern, double bytes) {
+        std::vector<float> t;
+        for (int i = 0; i < 13; ++i) {
+            hipEventRecord(e0, 0);
+            hipLaunchKernelGGL(kern, dim3(2048), dim3(256), 0, 0, col, val, x, y, (int)nblk);
+            hipEventRecord(e1, 0);
+            hipEventSynchronize(e1);
+            float ms;
+            hipEventElapsedTime(&ms, e0, e1);
+            if (i >= 3) t.push_back(ms);
+        }
+        std::sort(t.begin(), t.end());
+        printf("%-58s %8.1f us  %7.0f GB/s\n", name, t[t.size() / 2] * 1e3, bytes / t[t.size() / 2] / 1e6);
+    };
+    printf("rows %ld, entries %ld, %ld blocks of %d rows\n", n, nnz, nblk, kRows);
+    const double bs = 12.0 * nnz + 8.0 * n, bg = bs + 8.0 * n;
+    run("W0 dword col + dwordx2 val, no gather", k_probe<0, false>, bs);
+    run("W1 dwordx2 col + dwordx4 val, no gather", k_probe<1, false>, bs);
+    run("W0 dword col + dwordx2 val, x gathered", k_probe<0, true>, bg);
+    run("W1 dwordx2 col + dwordx4 val, x gathered", k_probe<1, true>, bg);
+    double s = 0;
+    std::vector<double> hy((size_t)n);
+    hipMemcpy(hy.data(), y, 8 * (size_t)n, hipMemcpyDeviceToHost);
+    for (long i = 0; i < n; i += 9973) s += hy[(size_t)i];
+    printf("checksum %.1f\n", s);
+    return 0;
+}
