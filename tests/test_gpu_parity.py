@@ -616,6 +616,6 @@ def test_residual_trace_equals_the_oracles_sequence(sla, method, check_every):
     buf = np.zeros(4)
     o = _lib.SolveOpts(200, 1e-6, 1e-4, check_every, 1, buf.ctypes.data, 4)
     out, inf2 = sla.DeviceVector(A.ctx, n), _lib.SolveInfo()
-    _lib.check(_lib.lib().sla_linsolve0(int(getattr(sla, method)), A.h, sla.fromVector(b).device().h, sla.fromVector(np.zeros(n)).device().h,
-                                        C.byref(o), out.h, C.byref(inf2)))
+    bv, zv = sla.DeviceVector(A.ctx, n, b), sla.DeviceVector(A.ctx, n)
+    _lib.check(_lib.lib().sla_linsolve0(int(getattr(sla, method)), A.h, bv.h, zv.h, C.byref(o), out.h, C.byref(inf2)))
     assert inf2.history_len == 4 and np.array_equal(buf, hist[:4]) and inf2.iters == info["iters"]
