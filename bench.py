@@ -72,6 +72,23 @@ def workload(name, row_begin=0, row_end=None):
     raise SystemExit(f"unknown workload {name}")
 
 
+import contextlib  # noqa: E402
+
+
+@contextlib.contextmanager
+def stdout_to_stderr():
+    """Route file descriptor 1 to stderr for the duration (native libraries that print on stdout)."""
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        yield
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved, 1)
+        os.close(saved)
+
+
 def host_threads_available():
     """Cores this process may use: the affinity mask capped by a container CPU quota (cgroup v2 cpu.max)."""
     threads = len(os.sched_getaffinity(0))
@@ -360,9 +377,10 @@ def run_rank(args, rank, world, local_rank, dist_mode, loop=None):
         torch.cuda.set_device(local_rank)
         # control plane (unique-id broadcast, barriers, max-over-ranks) on gloo; the data plane is the library's own
         # RCCL communicator over xGMI
-        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
-        uid = [sla.Context.unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
+        with stdout_to_stderr():      # (gloo announces its connections on stdout: the driver reads ONE JSON line there)
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+            uid = [sla.Context.unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0)
         ctx = sla.Context(local_rank, rank, world, uid[0])
     elif dist_mode == "loopback":
         ctx = sla.Context.loopback(rank, world, 4242)

@@ -205,6 +205,7 @@ struct sla_ctx {
     int force_rp64 = 0;              // test hook: 64-bit row pointers at any size (SLA_FORCE_RP64)
     int lpanel = 1;                  // allow the LDS-panel SpMV kernel for matrices with dense rows (SLA_LPANEL=0 disables)
     int xwin = 1;                    // allow the LDS x-window SpMV kernel (SLA_XWIN=0 disables)
+    int stream_wide = 1;             // spmv_stream_kernel: pairs of entries per load (8-byte col / 16-byte val loads) instead of one (SLA_STREAM_WIDE=0)
     int stream_pipe = 0;             // plain CSR-stream (#>): the three-stage pipelined kernel (sla_spmv_pipe.hip) instead of spmv_stream / spmv_xwin
                                      // (SLA_STREAM_PIPE=1; OFF by default: measured 7-12 % SLOWER than the one-deep prefetch)
     int dual_spmv = 1;               // linSolve0: fuse the true-residual SpMV into the next K1 (SLA_DUAL_SPMV=0 disables)
@@ -392,6 +393,10 @@ namespace sla {
 // (its workgroups need a few steps each to amortise the staging pipeline's fill: below that the gather kernel is faster -- 1 M-row
 // Poisson: 22 500 vs 21 300 it/s; SLA_WD_LDS=2 forces it)
 inline bool wd_lds_on(const sla_csr *A) { return A->wd_lds && !A->wd_vv && (A->ctx->wd_lds == 2 || (A->ctx->wd_lds == 1 && A->nblk_wd >= 16 * 4 * A->ctx->n_cu)); }
+// does the plain CSR-stream form of A stage an x window in LDS (spmv_xwin_kernel)?  Only without the paired loads of
+// spmv_stream_kernel (stream_wide, default): with them the plain kernel is the faster one (round 3: K1 222-231 vs 232-241 us,
+// K3 -- four sums since the fused K4+K5 flow -- 228-238 vs 258 us on the 216^3 Laplacian), so the window form is an A/B knob now
+inline bool stream_xwin_on(const sla_csr *A) { return A->use_xwin && A->ctx->xwin && !A->ctx->stream_wide; }
 inline bool wd_on(const sla_csr *A) { return A->wd_vv ? (A->ctx->wdia && A->ctx->wdia_vv) : A->ctx->wdia != 0; }
 
 // ---------------------------------------------------------------------------------------------------------------

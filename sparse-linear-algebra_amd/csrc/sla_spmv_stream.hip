@@ -16,6 +16,9 @@
 
 namespace sla {
 
+typedef int sla_i32x2 __attribute__((ext_vector_type(2)));
+typedef double sla_f64x2 __attribute__((ext_vector_type(2)));
+
 // ---------------------------------------------------------------------------------------------
 // CSR-stream SpMV
 // ---------------------------------------------------------------------------------------------
@@ -30,7 +33,7 @@ template <int EPI, typename RP>
 __global__ void __launch_bounds__(kBlock, 8) spmv_stream_kernel(SpmvArgs<RP> a, const RP *__restrict__ rowptr, const int32_t *__restrict__ col,
                                                                  const double *__restrict__ val, const int32_t *__restrict__ rb,
                                                                  const RP *__restrict__ rbk, const double *__restrict__ xg,
-                                                                 int xcd_remap) {
+                                                                 int xcd_remap, int wide) {
     __shared__ double s_prod[2][kNnzPerRowBlock];
     __shared__ int s_rp[2][kMaxRowsPerRowBlock + 1];
     __shared__ double s_red[4];
@@ -48,14 +51,35 @@ __global__ void __launch_bounds__(kBlock, 8) spmv_stream_kernel(SpmvArgs<RP> a, 
         double v[4];
         RP rpn = 0;
         // issue the streaming loads of row block (r0_, k0_, k1_) into c / v / rpn
+        // Wide form (default): every lane takes two PAIRS of consecutive entries -- one 8-byte col load and one 16-byte val load
+        // each, from the even entry at or below the block's first (kb): 512 B / 1 KiB per wave-instruction instead of 256 / 512
+        // with one entry per load.  Measured: -6 % time on the bare skeleton (tools/stream_width_probe.cpp), -4 % / -1 % on K1 of the
+        // 216^3 Laplacian on two boxes.  A pair may reach one entry before or behind the block (another block's entry, or the
+        // arrays' zeroed slack): loaded, never used.  The one block shape it cannot hold (1024 entries from an odd entry on)
+        // takes the narrow form.
+#define SLA_WIDE_OK(k0_, k1_) (wide && (int)((k1_) - (k0_)) + (int)((k0_) & 1) <= kNnzPerRowBlock)
 #define SLA_ISSUE_LOADS(r0_, r1_, k0_, k1_)                                              \
         if ((k1_) - (k0_) <= (RP)kNnzPerRowBlock) {                                          \
             const int cnt_ = (int)((k1_) - (k0_));                                           \
-            _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                  \
-                const int i = tid + j * kBlock;                                              \
-                if (i < cnt_) {                                                              \
-                    c[j] = __builtin_nontemporal_load(col + (k0_) + i);                    \
-                    v[j] = __builtin_nontemporal_load(val + (k0_) + i);                    \
+            if (SLA_WIDE_OK(k0_, k1_)) {                                                     \
+                const int odd_ = (int)((k0_) & 1);                                           \
+                const RP kb_ = (k0_) - odd_;                                                 \
+                _Pragma("unroll") for (int j = 0; j < 2; ++j) {                              \
+                    const int i = 2 * tid + j * 2 * kBlock;                                  \
+                    if (i < cnt_ + odd_) {                                                   \
+                        const sla_i32x2 cc = __builtin_nontemporal_load((const sla_i32x2 *)(col + kb_ + i)); \
+                        const sla_f64x2 vv = __builtin_nontemporal_load((const sla_f64x2 *)(val + kb_ + i)); \
+                        c[2 * j] = cc.x; c[2 * j + 1] = cc.y;                                \
+                        v[2 * j] = vv.x; v[2 * j + 1] = vv.y;                                \
+                    }                                                                        \
+                }                                                                            \
+            } else {                                                                         \
+                _Pragma("unroll") for (int j = 0; j < 4; ++j) {                              \
+                    const int i = tid + j * kBlock;                                          \
+                    if (i < cnt_) {                                                          \
+                        c[j] = __builtin_nontemporal_load(col + (k0_) + i);                \
+                        v[j] = __builtin_nontemporal_load(val + (k0_) + i);                \
+                    }                                                                        \
                 }                                                                            \
             }                                                                                \
             if (tid < (r1_) - (r0_)) rpn = rowptr[(r0_) + tid];                            \
@@ -92,10 +116,19 @@ __global__ void __launch_bounds__(kBlock, 8) spmv_stream_kernel(SpmvArgs<RP> a, 
                 int *rp = s_rp[buf];
                 if (tid < nrows) rp[tid] = (int)(rpn - k0);
                 if (tid == 0) rp[nrows] = cnt;
+                if (SLA_WIDE_OK(k0, k1)) {
+                    const int odd = (int)(k0 & 1);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int i = tid + j * kBlock;
-                    if (i < cnt) prod[i] = v[j] * xg[c[j]];
+                    for (int j = 0; j < 4; ++j) {
+                        const int i = 2 * tid + (j >> 1) * 2 * kBlock + (j & 1) - odd;   // (-1: the entry in front of an odd first entry)
+                        if ((unsigned)i < (unsigned)cnt) prod[i] = v[j] * xg[c[j]];
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int i = tid + j * kBlock;
+                        if (i < cnt) prod[i] = v[j] * xg[c[j]];
+                    }
                 }
                 if (has_next) { SLA_ISSUE_LOADS(nr0, nr1, nk0, nk1) }
                 SLA_FETCH_DESC()
@@ -199,6 +232,7 @@ __global__ void __launch_bounds__(kBlock, 8) spmv_stream_kernel(SpmvArgs<RP> a, 
         }
 #undef SLA_FETCH_DESC
 #undef SLA_ISSUE_LOADS
+#undef SLA_WIDE_OK
     }
     if constexpr (EPI == EPI_DOT || EPI == EPI_DOT2 || EPI == EPI_DOT4 || EPI == EPI_RES || EPI == EPI_AXPY_DOT ||
                   EPI == EPI_XPBY_NRM) {
@@ -639,12 +673,12 @@ int launch_stream_t(const sla_csr *A, const SpmvArgs<RP> &a, int grid) {
     sla_ctx *c = A->ctx;
     if (c->spmv_algo == 1)
         hipLaunchKernelGGL((spmv_scalar_kernel<EPI, RP>), dim3(grid), dim3(kBlock), 0, stream_of(c), a, c->xcd_remap);
-    else if (A->use_xwin && c->xwin)
+    else if (stream_xwin_on(A))
         hipLaunchKernelGGL((spmv_xwin_kernel<EPI, RP>), dim3(grid), dim3(kBlock), 0, stream_of(c), a, a.rowptr, a.col, a.val, a.rb, a.rbk,
                            a.x, A->d_rbw, (int32_t)A->n, c->xcd_remap);
     else
         hipLaunchKernelGGL((spmv_stream_kernel<EPI, RP>), dim3(grid), dim3(kBlock), 0, stream_of(c), a, a.rowptr, a.col, a.val, a.rb, a.rbk,
-                           a.x, c->xcd_remap);
+                           a.x, c->xcd_remap, c->stream_wide);
     SLA_HIP_TRY(hipGetLastError());
     return SLA_OK;
 }

@@ -286,6 +286,8 @@ def test_64_bit_row_pointer_kernels(sla, monkeypatch):
         "laplace3d": (wl.laplace3d(13, 9, 11), {}, "diagdict"),
         "laplace3d, plain stream": (wl.laplace3d(13, 9, 11), {"SLA_DIAG": "0", "SLA_XWIN": "0"}, "algo=stream "),
         "random_spd short rows": (wl.random_spd(3000, 4, 3), {}, "algo=stream"),
+        "laplace3d, x window (narrow loads)": (wl.laplace3d(13, 9, 11), {"SLA_DIAG": "0", "SLA_STREAM_WIDE": "0"}, "algo=stream+xwin"),
+        "random_spd, narrow loads": (wl.random_spd(3000, 4, 3), {"SLA_STREAM_WIDE": "0"}, "algo=stream"),
         "laplace3d, pipelined stream": (wl.laplace3d(13, 9, 11), {"SLA_DIAG": "0", "SLA_STREAM_PIPE": "1"}, "algo=stream+pipe"),
         "random_spd, pipelined stream": (wl.random_spd(3000, 4, 3), {"SLA_STREAM_PIPE": "1"}, "algo=stream+pipe"),
         "random_spd, column panels": (wl.random_spd(5000, 6, 4), {"SLA_PANEL_COLS": "600"}, "colpanels"),
@@ -293,7 +295,7 @@ def test_64_bit_row_pointer_kernels(sla, monkeypatch):
         "row-block limits": (limits(), {"SLA_LPANEL": "0"}, "algo=stream"),
         "scalar kernel": (wl.random_spd(2000, 5, 6), {"SLA_SPMV_ALGO": "scalar"}, "scalar"),
     }
-    knobs = ("SLA_DIAG", "SLA_XWIN", "SLA_PANEL_COLS", "SLA_LPANEL", "SLA_SPMV_ALGO", "SLA_STREAM_PIPE")
+    knobs = ("SLA_DIAG", "SLA_XWIN", "SLA_PANEL_COLS", "SLA_LPANEL", "SLA_SPMV_ALGO", "SLA_STREAM_PIPE", "SLA_STREAM_WIDE")
     for name, ((dims, csr), env, form) in cases.items():
         for k in knobs:
             monkeypatch.delenv(k, raising=False)

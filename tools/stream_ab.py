@@ -12,15 +12,15 @@ import bench  # noqa: E402
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 desc, (dims, (rp, ci, va)) = bench.workload("laplace3d_10m")
 base = {"wdia": 0, "vdict": 0, "diag": 0}
-for name, extra in (("pipe", {"stream_pipe": 1}), ("xwin", {"stream_pipe": 0}), ("stream", {"stream_pipe": 0, "xwin": 0}), ("pipe", {"stream_pipe": 1}),
-                    ("xwin", {"stream_pipe": 0})):
+for name, extra in (("wide", {"xwin": 0, "stream_wide": 1}), ("narrow", {"xwin": 0, "stream_wide": 0}), ("xwin", {}), ("wide", {"xwin": 0, "stream_wide": 1}),
+                    ("narrow", {"xwin": 0, "stream_wide": 0}), ("xwin", {}), ("pipe", {"stream_pipe": 1})):
     r = bench.side_block(desc, dims, rp, ci, va, dict(base, **extra), steps, 5)
     print(f"laplace3d_10m {name:7s} {r['value']:8.1f} it/s  K1 {r['k1_ms'] * 1e3:7.1f} us ({r['k1_frac']:.3f})  "
           + "  ".join(f"{k} {v['ms'] * 1e3:.1f}" for k, v in r["kernels"].items()) + "  " + r["spmv_kernel"].split()[0], flush=True)
 del rp, ci, va
 desc, (dims, (rp, ci, va)) = bench.workload("random_spd_1m")
-for name, extra in (("pipe", {"stream_pipe": 1, "tiles": 0, "panels": 0}), ("stream", {"stream_pipe": 0, "tiles": 0, "panels": 0}),
-                    ("pipe", {"stream_pipe": 1, "tiles": 0, "panels": 0}), ("tiles", {})):
+for name, extra in (("wide", {"stream_wide": 1, "tiles": 0, "panels": 0}), ("narrow", {"stream_wide": 0, "tiles": 0, "panels": 0}),
+                    ("wide", {"stream_wide": 1, "tiles": 0, "panels": 0}), ("tiles", {})):
     r = bench.side_block(desc, dims, rp, ci, va, extra, steps, 5, rhs="A.x*")
     print(f"random_spd_1m {name:7s} {r['value']:8.1f} it/s  K1 {r['k1_ms'] * 1e3:7.1f} us ({r['k1_frac']:.3f})  "
           + "  ".join(f"{k} {v['ms'] * 1e3:.1f}" for k, v in r["kernels"].items()) + "  " + r["spmv_kernel"].split()[0], flush=True)
