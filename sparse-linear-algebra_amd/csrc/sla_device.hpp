@@ -44,6 +44,36 @@ __device__ __forceinline__ double reduce_parts(const double *p, int n, int strid
     return block_sum(a, s4);
 }
 
+// The same re-reduction split in two so that a consumer kernel can ISSUE everything its prologue needs -- the partials of all its
+// sums, the device scalars, the first vector elements of its sweep -- before it WAITS for any of it: one memory round trip at the
+// head of the kernel instead of one per quantity (K2: done -> partials -> rho; K4+K5: four sums one after the other).  Same
+// additions in the same order as reduce_parts (n <= 8 * kBlock partials: kMaxParts = 2048).
+__device__ __forceinline__ void parts_issue(const double *p, int n, int stride, double (&v)[8]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = p[(int64_t)min((int)threadIdx.x + j * kBlock, n - 1) * stride];
+}
+__device__ __forceinline__ double parts_fold(const double (&v)[8], int n) {
+    double a = 0.0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        if ((int)threadIdx.x + j * kBlock < n) a += v[j];
+    return a;
+}
+// block_sum of K values behind ONE pair of barriers; sK: 4 * K doubles of LDS.  Per value the same operations as block_sum.
+template <int K>
+__device__ __forceinline__ void block_sum_multi(double (&v)[K], double *sK) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) v[k] = wave_sum(v[k]);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) sK[4 * k + (threadIdx.x >> 6)] = v[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < K; ++k) v[k] = ((sK[4 * k] + sK[4 * k + 1]) + sK[4 * k + 2]) + sK[4 * k + 3];
+}
+
 __device__ __forceinline__ bool is_finite(double v) { return v == v && fabs(v) != INFINITY; }
 
 // runIter's test (Sparse.hs:1047-1050) on the partials of ||A x - b||^2 left by an earlier kernel.

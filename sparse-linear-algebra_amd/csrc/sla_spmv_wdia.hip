@@ -79,8 +79,7 @@ __global__ void __launch_bounds__(kBlock, VV ? (EPI == EPI_DOT4 ? kWdBlocksPerCu
                                                                int32_t grow0, int32_t xlen, const int32_t *__restrict__ sched, int xcd_remap, int stream_nt) {
     __shared__ double s_red[4];
     const int tid = threadIdx.x;
-    double coef;
-    if (!spmv_prologue<EPI, int32_t>(a, s_red, coef)) return;
+    double coef = 0.0;   // (set by the prologue, which runs BEHIND the first descriptor / record loads: see below)
     const bool w_nt = stream_nt && a.w != xg + grow0;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
@@ -248,6 +247,7 @@ __global__ void __launch_bounds__(kBlock, VV ? (EPI == EPI_DOT4 ? kWdBlocksPerCu
             load_desc(b + 2 * wk.step, blk2, e02, cnt2);
             load_rec(e00, cnt0, r0);
             load_rec(e01, cnt1, r1);
+            if (!spmv_prologue<EPI, int32_t>(a, s_red, coef)) return;
             issue(sa, blk0, e00, cnt0, r0);
         }
 #define SLA_WD_STEP(cur, nxt)                         \
@@ -277,6 +277,11 @@ __global__ void __launch_bounds__(kBlock, VV ? (EPI == EPI_DOT4 ? kWdBlocksPerCu
         load_desc(b, blk_c, e0_c, cnt_c);
         load_desc(b + wk.step, blk_n, e0_n, cnt_n);
         load_rec(e0_c, cnt_c, rc);
+        // The prologue (solver done? residual test, step count, alpha / beta from partials) runs HERE, behind the first
+        // descriptor and record loads: its own loads share their round trip instead of preceding them -- the head of the kernel
+        // was five dependent trips to memory (prologue, schedule, descriptor, records, gathers), a third of a 10 us launch at
+        // 1 M rows.  A workgroup that must exit has only loaded a few words it does not use.
+        if (!spmv_prologue<EPI, int32_t>(a, s_red, coef)) return;
         for (; b < wk.last; b += wk.step) {
             int blk_f, e0_f, cnt_f;
             WD_STAMP(0)

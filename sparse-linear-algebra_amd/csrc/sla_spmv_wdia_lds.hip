@@ -34,8 +34,7 @@ __global__ void __launch_bounds__(kBlock, NW <= 4 ? 4 : 3) spmv_wdia_lds_kernel(
     __shared__ wd_f64x2 wd_buf[2][NW * 256];
     __shared__ double s_red[4];
     const int tid = threadIdx.x;
-    double coef;
-    if (!spmv_prologue<EPI, int32_t>(a, s_red, coef)) return;
+    double coef = 0.0;   // (set by the prologue, which runs behind the first window loads: see below)
     const bool w_nt = (stream_nt & 1) && a.w != xg + grow0;
     // an operand that IS the gathered vector (K3: As . s) is taken from the staged window instead of a sixth global load
     const bool w_lds = uni.lpos0 >= 0 && a.w == xg + grow0;
@@ -110,10 +109,10 @@ __global__ void __launch_bounds__(kBlock, NW <= 4 ? 4 : 3) spmv_wdia_lds_kernel(
     };
     int b = wk.first;
     int blk_c = load_blk(b), blk_n = load_blk(b + wk.step), blk_f = load_blk(b + 2 * wk.step);
-    if (b < wk.last) {
-        load_windows(blk_c);
-        stage(0);
-    }
+    if (b < wk.last) load_windows(blk_c);
+    // (the prologue's loads -- solver scalars, partials -- share the round trip of the first windows instead of preceding it)
+    if (!spmv_prologue<EPI, int32_t>(a, s_red, coef)) return;
+    if (b < wk.last) stage(0);
     __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): the loop is entered with nothing in flight (see its end)
     __syncthreads();
     // Per step: this slice's masks (scalar), its epilogue operands and the NEXT step's windows are issued first and are in flight

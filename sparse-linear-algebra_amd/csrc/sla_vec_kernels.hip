@@ -122,16 +122,26 @@ __global__ void __launch_bounds__(kBlock) bicg_k2_kernel(int64_t n, SolverScalar
                                                           Parts res, int count_iter, const double *r,
                                                           const double *ap, double *s) {
     __shared__ double s_red[4];
-    if (sc->done) return;
+    // everything the head of the kernel needs is issued before any of it is waited for: the scalars, the partials of
+    // Ap . r0hat and the first element pair of the sweep (one round trip instead of three in a row, with HBM already streaming)
+    const int64_t n2 = n >> 1, gs = (int64_t)gridDim.x * kBlock, i0 = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int done = sc->done;
+    const double rho = sc->rho2[par];
+    double pv[8];
+    parts_issue(apr.p, apr.n, apr.stride, pv);
+    const int64_t i0c = n2 > 0 ? min(i0, n2 - 1) : 0;   // (clamped: the loads are unconditional)
+    double2 a = make_double2(0.0, 0.0), b = a;
+    if (n2 > 0) { a = ld2s<NT>(r, i0c); b = ld2s<NT>(ap, i0c); }
+    if (done) return;
     // dual-SpMV flow: K1 of THIS step also evaluated the previous step's true residual; test it here
     if (res.p && residual_converged(sc, res.p, res.n, res.stride, s_red)) return;
     if (count_iter && blockIdx.x == 0 && threadIdx.x == 0) sc->iters += 1;
-    const double alpha = sc->rho2[par] / reduce_parts(apr.p, apr.n, apr.stride, s_red);
+    const double alpha = rho / block_sum(parts_fold(pv, apr.n), s_red);
     if (blockIdx.x == 0 && threadIdx.x == 0) sc->alpha = alpha;
-    SLA_VEC_LOOP_BEGIN(n)
-        const double2 a = ld2s<NT>(r, i2), b = ld2s<NT>(ap, i2);
+    for (int64_t i2 = i0; i2 < n2; i2 += gs) {
+        if (i2 != i0) { a = ld2s<NT>(r, i2); b = ld2s<NT>(ap, i2); }
         st2(s, i2, make_double2(a.x - alpha * b.x, a.y - alpha * b.y));
-    SLA_VEC_LOOP_END
+    }
     if (SLA_HAS_TAIL(n)) s[n - 1] = r[n - 1] - alpha * ap[n - 1];
 }
 
@@ -183,23 +193,33 @@ template <bool NT>
 __global__ void __launch_bounds__(kBlock) bicg_k45_kernel(int64_t n, SolverScalars *sc, Parts ass, Parts asas, Parts tr0, Parts sr0,
                                                            int par, const double *s, const double *as, const double *ap, double *x,
                                                            double *r, double *p) {
-    __shared__ double s_red[4];
-    if (sc->done) return;
-    const double num = reduce_parts(ass.p, ass.n, ass.stride, s_red);
-    const double den = reduce_parts(asas.p, asas.n, asas.stride, s_red);
-    const double t0 = reduce_parts(tr0.p, tr0.n, tr0.stride, s_red);
-    const double s0 = reduce_parts(sr0.p, sr0.n, sr0.stride, s_red);
-    const double omega = num / den, alpha = sc->alpha;
+    __shared__ double s_red[16];
+    // the four sums, the scalars and the first element pairs of the five input vectors are issued together (see bicg_k2_kernel)
+    const int64_t n2 = n >> 1, gs = (int64_t)gridDim.x * kBlock, i0 = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int done = sc->done;
+    const double alpha = sc->alpha, rho = sc->rho2[par];
+    double q0[8], q1[8], q2[8], q3[8];
+    parts_issue(ass.p, ass.n, ass.stride, q0);
+    parts_issue(asas.p, asas.n, asas.stride, q1);
+    parts_issue(tr0.p, tr0.n, tr0.stride, q2);
+    parts_issue(sr0.p, sr0.n, sr0.stride, q3);
+    const int64_t i0c = n2 > 0 ? min(i0, n2 - 1) : 0;
+    double2 sv = make_double2(0.0, 0.0), av = sv, vv = sv, pv = sv, xv = sv;
+    if (n2 > 0) { sv = ld2s<NT>(s, i0c); av = ld2s<NT>(as, i0c); vv = ld2s<NT>(ap, i0c); pv = ld2s<NT>(p, i0c); xv = ld2s<NT>(x, i0c); }
+    if (done) return;
+    double sums[4] = {parts_fold(q0, ass.n), parts_fold(q1, asas.n), parts_fold(q2, tr0.n), parts_fold(q3, sr0.n)};
+    block_sum_multi<4>(sums, s_red);
+    const double num = sums[0], den = sums[1], t0 = sums[2], s0 = sums[3];
+    const double omega = num / den;
     const double rn = s0 - omega * t0;                       // = r_{j+1} . r0hat
-    const double beta = rn / sc->rho2[par] * alpha / omega;
+    const double beta = rn / rho * alpha / omega;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         sc->omega = omega;
         sc->beta = beta;
         sc->rho2[par ^ 1] = rn;
     }
-    SLA_VEC_LOOP_BEGIN(n)
-        const double2 sv = ld2s<NT>(s, i2), av = ld2s<NT>(as, i2), vv = ld2s<NT>(ap, i2);
-        double2 pv = ld2s<NT>(p, i2), xv = ld2s<NT>(x, i2);
+    for (int64_t i2 = i0; i2 < n2; i2 += gs) {
+        if (i2 != i0) { sv = ld2s<NT>(s, i2); av = ld2s<NT>(as, i2); vv = ld2s<NT>(ap, i2); pv = ld2s<NT>(p, i2); xv = ld2s<NT>(x, i2); }
         xv.x = (xv.x + alpha * pv.x) + omega * sv.x;
         xv.y = (xv.y + alpha * pv.y) + omega * sv.y;
         if (NT) st2_nt(x, i2, xv);  // nobody reads x before the next step's sweep
@@ -210,7 +230,7 @@ __global__ void __launch_bounds__(kBlock) bicg_k45_kernel(int64_t n, SolverScala
         pv.x = rv.x + beta * (pv.x - omega * vv.x);
         pv.y = rv.y + beta * (pv.y - omega * vv.y);
         st2(p, i2, pv);
-    SLA_VEC_LOOP_END
+    }
     if (SLA_HAS_TAIL(n)) {
         const int64_t i = n - 1;
         x[i] = (x[i] + alpha * p[i]) + omega * s[i];
@@ -289,14 +309,22 @@ __global__ void __launch_bounds__(kBlock) cgs_c2_kernel(int64_t n, SolverScalars
                                                          Parts res, int count_iter, const double *u,
                                                          const double *aap, double *q, double *uq, double *x) {
     __shared__ double s_red[4];
-    if (sc->done) return;
+    // (scalars, partials and the first element pairs issued together: see bicg_k2_kernel)
+    const int64_t n2 = n >> 1, gs = (int64_t)gridDim.x * kBlock, i0 = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int done = sc->done;
+    const double rho = sc->rho2[par];
+    double pq[8];
+    parts_issue(apr.p, apr.n, apr.stride, pq);
+    const int64_t i0c = n2 > 0 ? min(i0, n2 - 1) : 0;
+    double2 uv = make_double2(0.0, 0.0), av = uv, xv = uv;
+    if (n2 > 0) { uv = ld2s<NT>(u, i0c); av = ld2s<NT>(aap, i0c); xv = ld2s<NT>(x, i0c); }
+    if (done) return;
     if (res.p && residual_converged(sc, res.p, res.n, res.stride, s_red)) return;
     if (count_iter && blockIdx.x == 0 && threadIdx.x == 0) sc->iters += 1;
-    const double alpha = sc->rho2[par] / reduce_parts(apr.p, apr.n, apr.stride, s_red);
+    const double alpha = rho / block_sum(parts_fold(pq, apr.n), s_red);
     if (blockIdx.x == 0 && threadIdx.x == 0) sc->alpha = alpha;
-    SLA_VEC_LOOP_BEGIN(n)
-        const double2 uv = ld2s<NT>(u, i2), av = ld2s<NT>(aap, i2);
-        double2 xv = ld2s<NT>(x, i2);
+    for (int64_t i2 = i0; i2 < n2; i2 += gs) {
+        if (i2 != i0) { uv = ld2s<NT>(u, i2); av = ld2s<NT>(aap, i2); xv = ld2s<NT>(x, i2); }
         const double2 qv = make_double2(uv.x - alpha * av.x, uv.y - alpha * av.y);
         const double2 sv = make_double2(uv.x + qv.x, uv.y + qv.y);
         xv.x += alpha * sv.x;
@@ -305,7 +333,7 @@ __global__ void __launch_bounds__(kBlock) cgs_c2_kernel(int64_t n, SolverScalars
         st2(uq, i2, sv);
         if (NT) st2_nt(x, i2, xv);  // (as in K4: x is not read again before the next step)
         else st2(x, i2, xv);
-    SLA_VEC_LOOP_END
+    }
     if (SLA_HAS_TAIL(n)) {
         const int64_t i = n - 1;
         const double qv = u[i] - alpha * aap[i], sv = u[i] + qv;
@@ -320,19 +348,26 @@ template <bool NT>
 __global__ void __launch_bounds__(kBlock) cgs_c4_kernel(int64_t n, SolverScalars *sc, Parts rhonew, int par,
                                                          const double *r, const double *q, double *u, double *p) {
     __shared__ double s_red[4];
-    if (sc->done) return;
-    const double rn = reduce_parts(rhonew.p, rhonew.n, rhonew.stride, s_red);
-    const double beta = rn / sc->rho2[par];
+    const int64_t n2 = n >> 1, gs = (int64_t)gridDim.x * kBlock, i0 = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int done = sc->done;
+    const double rho = sc->rho2[par];
+    double pq[8];
+    parts_issue(rhonew.p, rhonew.n, rhonew.stride, pq);
+    const int64_t i0c = n2 > 0 ? min(i0, n2 - 1) : 0;
+    double2 rv = make_double2(0.0, 0.0), qv = rv, pv = rv;
+    if (n2 > 0) { rv = ld2s<NT>(r, i0c); qv = ld2s<NT>(q, i0c); pv = ld2s<NT>(p, i0c); }
+    if (done) return;
+    const double rn = block_sum(parts_fold(pq, rhonew.n), s_red);
+    const double beta = rn / rho;
     if (blockIdx.x == 0 && threadIdx.x == 0) { sc->beta = beta; sc->rho2[par ^ 1] = rn; }
-    SLA_VEC_LOOP_BEGIN(n)
-        const double2 rv = ld2s<NT>(r, i2), qv = ld2s<NT>(q, i2);
-        double2 pv = ld2s<NT>(p, i2);
+    for (int64_t i2 = i0; i2 < n2; i2 += gs) {
+        if (i2 != i0) { rv = ld2s<NT>(r, i2); qv = ld2s<NT>(q, i2); pv = ld2s<NT>(p, i2); }
         const double2 uv = make_double2(rv.x + beta * qv.x, rv.y + beta * qv.y);
         pv.x = uv.x + beta * (qv.x + beta * pv.x);
         pv.y = uv.y + beta * (qv.y + beta * pv.y);
         st2(u, i2, uv);
         st2(p, i2, pv);
-    SLA_VEC_LOOP_END
+    }
     if (SLA_HAS_TAIL(n)) {
         const int64_t i = n - 1;
         const double uv = r[i] + beta * q[i];

@@ -71,6 +71,106 @@ __global__ void __launch_bounds__(256, 8) k_probe(const int *__restrict__ col, c
     }
 }
 
+
+// Structure variants of the W1 skeleton (no gather): which part costs what?
+//   M0 loads only (row sums in registers, nothing stored)   M1 + LDS stage + barrier + lane-per-row fold   M2 + y store (= W1 above)
+//   M3 = M2 with the next block's loads issued before the barrier (one-deep prefetch, like spmv_stream_kernel)
+template <int M, int OCC>
+__global__ void __launch_bounds__(256, OCC) k_struct(const int *__restrict__ col, const double *__restrict__ val, const double *__restrict__ x,
+                                                     double *__restrict__ y, int nblk) {
+    __shared__ double s_prod[2][1024];
+    const int tid = threadIdx.x;
+    int buf = 0;
+    double keep = 0.0;
+    i32x2 c[2];
+    f64x2 v[2];
+    auto issue = [&](int b) {
+        const long k0 = (long)b * kEnt;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int i = min(2 * tid + 512 * j, kEnt - 2);
+            c[j] = __builtin_nontemporal_load((const i32x2 *)(col + k0 + i));
+            v[j] = __builtin_nontemporal_load((const f64x2 *)(val + k0 + i));
+        }
+    };
+    int b = blockIdx.x;
+    if (M == 3 && b < nblk) issue(b);
+    for (; b < nblk; b += gridDim.x) {
+        if (M != 3) issue(b);
+        double *prod = s_prod[buf];
+        f64x2 p[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) p[j] = f64x2{v[j].x * (double)c[j].x, v[j].y * (double)c[j].y};
+        if (M == 0) {
+            keep += (p[0].x + p[0].y) + (p[1].x + p[1].y);
+            continue;
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int i = 2 * tid + 512 * j;
+            if (i < kEnt) *(f64x2 *)(prod + i) = p[j];
+        }
+        if (M == 3 && b + (int)gridDim.x < nblk) issue(b + gridDim.x);
+        __syncthreads();
+        if (tid < kRows) {
+            double acc = 0.0;
+            for (int k = tid * 7; k < tid * 7 + 7; ++k) acc += prod[k];
+            if (M >= 2) y[(long)b * kRows + tid] = acc;
+            else keep += acc;
+        }
+        buf ^= 1;
+    }
+    if (keep == 123.456) y[tid] = keep;
+}
+
+
+// The y store: 8 bytes per lane from `rows` lanes of a block whose y segment starts at block * rows * 8 bytes.  With 146 rows the
+// segments are 1168 bytes: every block's first and last 128-byte line is shared with a neighbour block (another workgroup, another
+// time).  ST 0: as the kernel does.  ST 1: 16 bytes per lane (row pairs through LDS).  ST 2: non-temporal.  ST 3: no store at all but
+// an equally sized LOAD of y (reads instead of writes).  `rows` 144 = whole lines per block.
+template <int ST>
+__global__ void __launch_bounds__(256, 8) k_store(const int *__restrict__ col, const double *__restrict__ val, const double *__restrict__ x,
+                                                  double *__restrict__ y, int nblk, int rows) {
+    __shared__ double s_prod[2][1024];
+    __shared__ double s_y[256];
+    const int tid = threadIdx.x;
+    const int ent = rows * 7;
+    int buf = 0;
+    double keep = 0.0;
+    for (int b = blockIdx.x; b < nblk; b += gridDim.x) {
+        const long k0 = (long)b * ent;
+        i32x2 c[2];
+        f64x2 v[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int i = min(2 * tid + 512 * j, ent - 2);
+            c[j] = __builtin_nontemporal_load((const i32x2 *)(col + k0 + i));
+            v[j] = __builtin_nontemporal_load((const f64x2 *)(val + k0 + i));
+        }
+        double *prod = s_prod[buf];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int i = 2 * tid + 512 * j;
+            if (i < ent) *(f64x2 *)(prod + i) = f64x2{v[j].x * (double)c[j].x, v[j].y * (double)c[j].y};
+        }
+        __syncthreads();
+        double acc = 0.0;
+        if (tid < rows) {
+            for (int k = tid * 7; k < tid * 7 + 7; ++k) acc += prod[k];
+            if (ST == 0) y[(long)b * rows + tid] = acc;
+            if (ST == 2) __builtin_nontemporal_store(acc, y + (long)b * rows + tid);
+            if (ST == 3) keep += acc + y[(long)b * rows + tid];
+            if (ST == 1) s_y[tid] = acc;
+        }
+        if (ST == 1) {
+            __syncthreads();
+            if (2 * tid < rows) *(f64x2 *)(y + (long)b * rows + 2 * tid) = f64x2{s_y[2 * tid], s_y[2 * tid + 1]};
+        }
+        buf ^= 1;
+    }
+    if (keep == 123.456) y[tid] = keep;
+}
+
 int main(int argc, char **argv) {
     const int N = argc > 1 ? atoi(argv[1]) : 216;
     const long n0 = (long)N * N * N, nblk = n0 / kRows, n = nblk * kRows, nnz = n * 7;
@@ -115,6 +215,51 @@ int main(int argc, char **argv) {
     run("W1 dwordx2 col + dwordx4 val, no gather", k_probe<1, false>, bs);
     run("W0 dword col + dwordx2 val, x gathered", k_probe<0, true>, bg);
     run("W1 dwordx2 col + dwordx4 val, x gathered", k_probe<1, true>, bg);
+    auto run2 = [&](const char *name, auto kern, int grid, double bytes) {
+        std::vector<float> t;
+        for (int i = 0; i < 13; ++i) {
+            hipEventRecord(e0, 0);
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, 0, col, val, x, y, (int)nblk);
+            hipEventRecord(e1, 0);
+            hipEventSynchronize(e1);
+            float ms;
+            hipEventElapsedTime(&ms, e0, e1);
+            if (i >= 3) t.push_back(ms);
+        }
+        std::sort(t.begin(), t.end());
+        printf("%-58s %8.1f us  %7.0f GB/s\n", name, t[t.size() / 2] * 1e3, bytes / t[t.size() / 2] / 1e6);
+    };
+    const double bl = 12.0 * nnz;
+    run2("M0 loads only, 8 WG/CU", k_struct<0, 8>, 2048, bl);
+    run2("M1 + LDS + barrier + fold, 8 WG/CU", k_struct<1, 8>, 2048, bl);
+    run2("M2 + y store, 8 WG/CU", k_struct<2, 8>, 2048, bs);
+    run2("M3 + one-deep prefetch, 8 WG/CU", k_struct<3, 8>, 2048, bs);
+    run2("M0 loads only, 4 WG/CU", k_struct<0, 4>, 1024, bl);
+    run2("M2 full, 4 WG/CU", k_struct<2, 4>, 1024, bs);
+    run2("M3 prefetch, 4 WG/CU", k_struct<3, 4>, 1024, bs);
+    run2("M2 full, 8 WG/CU, grid 4096", k_struct<2, 8>, 4096, bs);
+    run2("M2 full, 8 WG/CU, grid 16384", k_struct<2, 8>, 16384, bs);
+    auto run3 = [&](const char *name, auto kern, int rows) {
+        const int nb = (int)(n / rows);
+        std::vector<float> t;
+        for (int i = 0; i < 13; ++i) {
+            hipEventRecord(e0, 0);
+            hipLaunchKernelGGL(kern, dim3(2048), dim3(256), 0, 0, col, val, x, y, nb, rows);
+            hipEventRecord(e1, 0);
+            hipEventSynchronize(e1);
+            float ms;
+            hipEventElapsedTime(&ms, e0, e1);
+            if (i >= 3) t.push_back(ms);
+        }
+        std::sort(t.begin(), t.end());
+        printf("%-50s rows %3d %8.1f us  %7.0f GB/s\n", name, rows, t[t.size() / 2] * 1e3, (84.0 + 8.0) * nb * rows / t[t.size() / 2] / 1e6);
+    };
+    for (int rows : {146, 144, 128}) {
+        run3("ST0 8 B per lane", k_store<0>, rows);
+        run3("ST1 16 B per lane via LDS", k_store<1>, rows);
+        run3("ST2 8 B per lane, non-temporal", k_store<2>, rows);
+        run3("ST3 y LOADED instead of stored", k_store<3>, rows);
+    }
     double s = 0;
     std::vector<double> hy((size_t)n);
     hipMemcpy(hy.data(), y, 8 * (size_t)n, hipMemcpyDeviceToHost);
