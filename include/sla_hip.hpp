@@ -55,6 +55,11 @@ class Context {
     Context(const Context &) = delete;
     Context &operator=(const Context &) = delete;
     sla_ctx_t get() const { return h_; }
+    // typed knob entry (sla_ctx_set_option): e.g. set_option("bicg_fuse45", "0") for the reference's literal K4 / K5 split
+    Context &set_option(const std::string &name, const std::string &value) {
+        check(sla_ctx_set_option(h_, name.c_str(), value.c_str()));
+        return *this;
+    }
     static Context &instance() {
         static Context c(0);
         return c;

@@ -1760,8 +1760,8 @@ int sla_csr_kernel_info(sla_csr_t A, char *buf, int buflen) {
     if (tiles_on(A)) {   // tile geometry; exact_fold: every row is folded entry by entry in ascending column order
         const size_t used = strlen(buf);
         if (used + 1 < (size_t)buflen)
-            snprintf(buf + used, (size_t)buflen - used, " slices=%d panels=%d panel_cols=%d max_segment=%lld exact_fold=1", A->tl_S, A->tl_P,
-                     1 << A->tl_shift, (long long)A->tl_maxseg);
+            snprintf(buf + used, (size_t)buflen - used, " slices=%d panels=%d panel_cols=%d max_segment=%lld exact_fold=1 pacing=%s", A->tl_S, A->tl_P,
+                     1 << A->tl_shift, (long long)A->tl_maxseg, A->ctx->xcd8 == 1 && A->ctx->tile_slack > 0 ? "on" : "off");
     }
     if (A->use_wdia && wd_on(A) && wd_lds_on(A)) {   // LDS-window geometry: windows, staged 16-byte pairs per buffer (> 1024: the 6-load instantiation), pairs folded
         const size_t used = strlen(buf);

@@ -1,4 +1,4 @@
-// sla_device.hpp -- device-side helpers shared by the kernel translation units (sla_kernels.hip, sla_spmv_tiles.hip):
+// sla_device.hpp -- device-side helpers shared by the kernel translation units (sla_spmv_*.hip, sla_vec_kernels.hip, sla_arnoldi.hip, sla_spmv_tiles.hip):
 // deterministic reductions, the consumer-side re-reduction of partials, the fused SpMV epilogues / prologue and the
 // XCD-aware persistent walk.
 #pragma once

@@ -180,7 +180,7 @@ struct sla_ctx {
                                      // the exchange serialised on the compute stream (A/B, bit-identical), -1 no split at all (SLA_OVERLAP)
     hipStream_t comm_stream = nullptr;   // created on first use
     hipEvent_t ev_x_ready = nullptr, ev_x_done = nullptr;
-    int xcd8 = -1;                   // 1: the device dispatches workgroup b to XCD b % 8 of 8 (probed once: what the tile kernel's panel pacing relies on), 0: it does not
+    int xcd8 = -1;                   // 1: workgroups are dealt round-robin over 8 XCDs (those with equal b % 8 share one; probed once: what the tile kernel's panel pacing relies on), 0: not so
     int tiles = 1;                   // allow the row-slice x column-panel tile SpMV for irregular matrices with x > L2 (SLA_TILES=0: column-panel passes)
     int tile_slack = 3;              // panel pacing: a wavefront starts panel step q once its XCD has finished step q - slack (SLA_TILE_SLACK, 0: no pacing)
     int tile_shift = 0;              // log2 of its panel width in columns (SLA_TILE_SHIFT; 0: 17 from 6 M columns on, 16 below -- at 10 M rows slack 3 / shift 17: 1.98 ms, slack 4: 2.18, slack 2: 2.1, shift 16: 2.03-2.28, shift 18: +15 %)
@@ -526,7 +526,7 @@ int vec_alloc(sla_ctx *c, int64_t n, sla_vec **out);
 int csr_transposed(sla_csr *A, sla_csr **out);
 int spmv_transposed(sla_csr *A, const double *x_local, double *y_local, int64_t y_shard);
 
-// kernel launchers (sla_kernels.hip) -----------------------------------------------------------------
+// kernel launchers (sla_spmv.hip dispatch + the family files, sla_vec_kernels.hip, sla_arnoldi.hip, sla_tri.hip) -----------------------------------------------------------------
 struct Parts {  // a partial-sum array as seen by a consumer prologue: p[i * stride], i < n
     const double *p; int n; int stride;
 };

@@ -1,7 +1,7 @@
 // sla_spmv_pipe.hip -- the general CSR-stream (#>) (f64 values + i32 columns) as a THREE-stage software pipeline.
 // Reference semantics: Data/Sparse/Common.hs:242-260 (rows summed by one lane are the reference's ascending left fold).
 //
-// spmv_stream_kernel (sla_kernels.hip) prefetches the col / val / rowptr streams of the next row block, but every row block still
+// spmv_stream_kernel (sla_spmv_stream.hip) prefetches the col / val / rowptr streams of the next row block, but every row block still
 // pays two dependent memory round trips in its own critical path that nothing of its own hides: the gather x[col] (it can only
 // be issued once the columns have arrived, and the products wait for it: ~1 us from the L2) and the epilogue operands
 // (w[row] / z[row] are loaded after the row's fold -- and vector loads return IN ORDER, so waiting for them also drains the

@@ -36,6 +36,9 @@ namespace sla {
 #ifndef SLA_TILE_U
 #define SLA_TILE_U 12
 #endif
+#ifndef SLA_TILE_SPIN
+#define SLA_TILE_SPIN 2000   // polls before a wavefront stops pacing for the rest of the launch
+#endif
 constexpr int kTileU = SLA_TILE_U;   // 64-entry groups per chunk: 768 gathers in flight per wavefront (+ the next chunk's streams)
 
 struct TileChunk {
@@ -99,7 +102,7 @@ spmv_tile_kernel(SpmvArgs<RP> a, const RP *__restrict__ rowptr, const int32_t *_
     // on the memory side of the fabric: 512 wavefronts bumping one counter cost ~100 us per step, measured): each
     // workgroup keeps its wavefronts' step counts in LDS and plain-stores their minimum into its own slot of a per-XCD
     // table -- the store stays in the XCD's L2 -- and a waiting wavefront reads the <= 256 slots of its XCD with L1-bypassing
-    // loads (up to four loads per poll, wavefront min).  Workgroup b runs on XCD b % 8 (HW_REG_XCC_ID, tools/xcc_probe.cpp)
+    // loads (up to four loads per poll, wavefront min).  The workgroups b with equal b % 8 share an XCD (probe_xcd_layout below)
     // and the grid is fully resident (kTileBlocksPerCu per CU).  Pacing is a throttle, never a correctness condition: a
     // wavefront that waits too long (grid not co-resident) stops pacing for the rest of the launch.
     __shared__ int s_prog[kBlock / 64];
@@ -142,7 +145,7 @@ spmv_tile_kernel(SpmvArgs<RP> a, const RP *__restrict__ rowptr, const int32_t *_
             known = v;
             if (known >= need) break;
             __builtin_amdgcn_s_sleep(4);
-            if (++spins > 2000) pace = false;   // (~2 ms of polling: a legitimate wait is tens of microseconds)
+            if (++spins > SLA_TILE_SPIN) pace = false;
         }
     };
     int round = 0;
@@ -229,10 +232,14 @@ spmv_tile_kernel(SpmvArgs<RP> a, const RP *__restrict__ rowptr, const int32_t *_
     spmv_extra_partials<EPI>(a, s_red, tid);
 }
 
-// Panel pacing assumes the MI355X dispatch order: 8 XCDs, workgroup b on XCD b % 8 (tools/xcc_probe.cpp).  On another
-// partition mode or part the slots a wavefront polls would belong to workgroups of another XCD, whose workgroup-scope stores
-// may never become visible: every wavefront would spin to its limit on every launch.  So the layout is PROBED once per
-// context (HW_REG_XCC_ID of the first 256 workgroups of a launch) and pacing is only used when it is the expected one.
+// Panel pacing assumes the MI355X dispatch order: 8 XCDs, workgroups dealt out round-robin, so that the workgroups b with equal
+// b % 8 share an XCD.  WHICH XCD gets workgroup 0 is not fixed: a dispatch usually starts at XCD 0 (tools/xcc_probe.cpp) but the
+// first dispatch of a process was observed to start at XCD 7 (round 3: the probe below read 7 0 1 2 3 4 5 6 7 0 ... in the first
+// context of every process and 0 1 2 ... afterwards) -- a rotation, which neither the pacing groups nor the XCD-contiguous walks
+// (rb_walk) mind: they only need the GROUPS.  On another partition mode or part the slots a wavefront polls could belong to
+// workgroups of another XCD, whose workgroup-scope stores may never become visible: every wavefront would spin to its limit on
+// every launch.  So the layout is PROBED once per context (HW_REG_XCC_ID of the first 256 workgroups of a launch) and pacing is
+// only used when workgroups b and b % 8 share an XCD for every b and the eight groups sit on eight different XCDs.
 __global__ void xcc_probe_kernel(int *out) {
     if (threadIdx.x == 0) out[blockIdx.x] = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));   // XCC_ID, bits [3:0]
 }
@@ -245,7 +252,14 @@ int probe_xcd_layout(sla_ctx *c) {
     SLA_HIP_TRY(hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, stream_of(c)));
     SLA_HIP_TRY(hipStreamSynchronize(stream_of(c)));
     int ok = 1;
-    for (int b = 0; b < 256; ++b) ok &= h[b] == (b & 7);
+    for (int b = 0; b < 256; ++b) ok &= h[b] == h[b & 7];
+    for (int i = 0; i < 8; ++i)
+        for (int j = 0; j < i; ++j) ok &= h[i] != h[j];
+    if (getenv("SLA_DEBUG_LOWER")) {
+        fprintf(stderr, "[sla] xcd probe: ok=%d, first 24:", ok);
+        for (int b = 0; b < 24; ++b) fprintf(stderr, " %d", h[b]);
+        fprintf(stderr, "\n");
+    }
     c->xcd8 = ok;
     return SLA_OK;
 }

@@ -12,7 +12,7 @@
 //    offsets clustered into runs; 216^3: 3 windows, 1974 elements = 4 aligned 16-byte loads per lane instead of 7 unaligned
 //    gathers) and the records read LDS (ds_read2_b64).  The next step's windows are in flight in registers while the current
 //    step is folded; two LDS buffers, one barrier and one memory round trip per step.
-// Fold order, roundings and epilogue are those of spmv_wdia_kernel (sla_kernels.hip): the same bits
+// Fold order, roundings and epilogue are those of spmv_wdia_kernel (sla_spmv_wdia.hip): the same bits
 // (tests/test_gpu_value_indexed.py compares the two on every pattern).
 #include <hip/hip_runtime.h>
 

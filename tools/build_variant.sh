@@ -9,10 +9,10 @@ src=$root/sparse-linear-algebra_amd/csrc; out=$root/sparse-linear-algebra_amd/li
 mkdir -p $obj
 flags="-O3 -std=c++17 -fPIC -Wno-unused-function -I$root/include -I$src --offload-arch=gfx950 -munsafe-fp-atomics"
 pids=()
-for f in sla_kernels.hip sla_coo_sort.hip sla_spmv_tiles.hip sla_spmv_wdia_lds.hip sla_matmat.hip; do
+for f in $(cd $src && ls *.hip); do
   /opt/rocm/bin/hipcc $flags "$@" -c $src/$f -o $obj/${f%.*}.o & pids+=($!)
 done
-for f in sla_lower_tiles.cpp sla_ilu0.cpp sla_multi.cpp sla_api.cpp sla_solvers.cpp sla_csr_build.cpp sla_dist.cpp sla_mmio.cpp; do
+for f in $(cd $src && ls *.cpp); do
   /opt/rocm/bin/hipcc $flags "$@" -x hip -c $src/$f -o $obj/${f%.*}.o & pids+=($!)
 done
 for p in "${pids[@]}"; do wait $p; done

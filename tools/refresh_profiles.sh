@@ -1,7 +1,7 @@
 #!/bin/bash
 # Regenerates the measurement evidence of profiles/ on the GPU box (run through gpurun); everything lands in
 # gpurun_out/refresh/, tools/install_profiles.py then copies it into profiles/ and rebuilds pmc_traffic.json.
-#   gpurun --timeout 2400 -- 'bash tools/refresh_profiles.sh r02'
+#   gpurun --timeout 3000 -- 'bash tools/refresh_profiles.sh r03'
 set -u
 tag=${1:-r02}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
@@ -42,6 +42,40 @@ pmc $S/${tag}_bench_pmc_counters.txt python bench.py --steps 20 --warmup 3 --no-
 pmc $S/${tag}_bench_pmc_counters_random_spd_10m.txt python bench.py --workload random_spd_10m --steps 8 --warmup 2 --no-cpu-baseline
 pmc $S/${tag}_bench_pmc_counters_poisson2d_1m.txt python bench.py --workload poisson2d_1m --steps 20 --warmup 3 --no-cpu-baseline
 pmc $S/${tag}_bench_pmc_counters_dense_rows_200k.txt python bench.py --workload dense_rows_200k --steps 10 --warmup 2 --no-cpu-baseline
+# round 3: one rank's 8-GPU slab (108^3 rows) through a 1-rank RCCL communicator: ghost-row flow with the fused K4+K5 sweep on own + ghost rows
+# (2 grouped exchanges per step) against the reference's split (3), window and all-gather exchange
+for f in 1 0; do for xe in window allgather; do
+  SLA_BICG_FUSE45=$f SLA_BENCH_FORCE_DIST=1 SLA_X_EXCHANGE=$xe timeout 600 python bench.py --workload laplace3d_1m --no-cpu-baseline --steps 200 --warmup 20 2>/dev/null | tail -1 > $S/${tag}_bench_slab_1rank_rccl_${xe}_fuse$f.json
+done; done
+# the sharded flow rehearsed with two loopback ranks on this one GPU (both workloads in one line; not a scaling number)
+SLA_BENCH_LOOPBACK=1 timeout 900 python bench.py --gpus 2 --steps 40 --warmup 5 2>/dev/null | tail -1 > $S/${tag}_bench_loopback_2ranks.json
+# the CSR-stream skeleton: load widths, structure variants, the y store (tools/stream_width_probe.cpp)
+[ -x tools/stream_width_probe ] && timeout 120 tools/stream_width_probe 216 > $S/${tag}_stream_width_probe.txt 2>&1
+# L1 <-> L2 request counters of the tile kernel (config 3a) and of the CSR-stream kernel (general_csr): the fabric-side statement of their bounds
+for set in "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_PENDING_STALL_CYCLES_sum TCP_GATE_EN1_sum" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES" "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_REQ_sum"; do
+  d=$S/pmc_tmp; rm -rf $d; mkdir -p $d
+  timeout 600 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $d -o p -- python bench.py --workload random_spd_10m --steps 6 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
+  python - "$d" tile <<'PY' >> $S/${tag}_pmc_l1_l2_tile_kernel_10m.txt
+import csv, glob, collections, sys
+for f in sorted(glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True)):
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(f)):
+        agg[r["Kernel_Name"][:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for k, cs in agg.items():
+        if sys.argv[2] in k: print(k, {c: (len(v), sum(v) / len(v)) for c, v in cs.items()})
+PY
+  d=$S/pmc_tmp; rm -rf $d; mkdir -p $d
+  SLA_WDIA=0 SLA_VDICT=0 SLA_DIAG=0 timeout 600 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $d -o p -- python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-extra-blocks > /dev/null 2>&1
+  python - "$d" spmv_stream <<'PY' >> $S/${tag}_pmc_l1_l2_stream_kernel.txt
+import csv, glob, collections, sys
+for f in sorted(glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True)):
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(f)):
+        agg[r["Kernel_Name"][:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for k, cs in agg.items():
+        if sys.argv[2] in k: print(k, {c: (len(v), sum(v) / len(v)) for c, v in cs.items()})
+PY
+done
 # the bare 7-pt access pattern: gathers vs LDS-staged windows, visiting orders (tools/stencil_probe.cpp)
 [ -x tools/stencil_probe ] && { timeout 120 tools/stencil_probe 216; timeout 120 tools/stencil_probe 256; } > $S/${tag}_stencil_probe.txt 2>&1
 ls -la $S | head -40

@@ -137,7 +137,10 @@ __global__ void __launch_bounds__(256, 8) k_store(const int *__restrict__ col, c
     const int ent = rows * 7;
     int buf = 0;
     double keep = 0.0;
-    for (int b = blockIdx.x; b < nblk; b += gridDim.x) {
+    // ST 4: like ST 0, but a workgroup takes 4 CONSECUTIVE blocks per turn (the partial lines between them are its own)
+    const int CH = ST == 4 ? 4 : 1;
+    for (int bb = blockIdx.x * CH; bb < nblk; bb += gridDim.x * CH)
+    for (int b = bb; b < min(bb + CH, nblk); ++b) {
         const long k0 = (long)b * ent;
         i32x2 c[2];
         f64x2 v[2];
@@ -157,7 +160,7 @@ __global__ void __launch_bounds__(256, 8) k_store(const int *__restrict__ col, c
         double acc = 0.0;
         if (tid < rows) {
             for (int k = tid * 7; k < tid * 7 + 7; ++k) acc += prod[k];
-            if (ST == 0) y[(long)b * rows + tid] = acc;
+            if (ST == 0 || ST == 4) y[(long)b * rows + tid] = acc;
             if (ST == 2) __builtin_nontemporal_store(acc, y + (long)b * rows + tid);
             if (ST == 3) keep += acc + y[(long)b * rows + tid];
             if (ST == 1) s_y[tid] = acc;
@@ -259,6 +262,7 @@ int main(int argc, char **argv) {
         run3("ST1 16 B per lane via LDS", k_store<1>, rows);
         run3("ST2 8 B per lane, non-temporal", k_store<2>, rows);
         run3("ST3 y LOADED instead of stored", k_store<3>, rows);
+        run3("ST4 8 B per lane, 4 consecutive blocks per turn", k_store<4>, rows);
     }
     double s = 0;
     std::vector<double> hy((size_t)n);
