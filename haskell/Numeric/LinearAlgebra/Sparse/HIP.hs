@@ -40,6 +40,7 @@ data Ctx; data Csr; data Vec; data Solver
 
 foreign import ccall safe "sla_ctx_create"        c_ctx_create        :: CInt -> Ptr (Ptr Ctx) -> IO CInt
 foreign import ccall safe "sla_ctx_create_multi"  c_ctx_create_multi  :: CInt -> Ptr CInt -> Ptr (Ptr Ctx) -> IO CInt
+foreign import ccall safe "sla_ctx_set_option"    c_ctx_set_option    :: Ptr Ctx -> CString -> CString -> IO CInt
 foreign import ccall safe "sla_csr_from_coo"      c_csr_from_coo      :: Ptr Ctx -> Int64 -> Int64 -> Int64 -> Ptr Int64 -> Ptr Int64 -> Ptr Double -> CInt -> Ptr (Ptr Csr) -> IO CInt
 foreign import ccall safe "sla_csr_dims"          c_csr_dims          :: Ptr Csr -> Ptr Int64 -> Ptr Int64 -> Ptr Int64 -> Ptr Int64 -> IO CInt
 foreign import ccall safe "sla_csr_export"        c_csr_export        :: Ptr Csr -> Ptr Int64 -> Ptr Int64 -> Ptr Double -> IO CInt
@@ -69,7 +70,14 @@ foreign import ccall unsafe "sla_last_error"      c_last_error        :: IO CStr
 defaultCtx :: Ptr Ctx
 defaultCtx = unsafePerformIO $ do
   n <- maybe 1 read <$> lookupEnv "SLA_GPUS"
-  alloca $ \p -> (if n > 1 then c_ctx_create_multi (fromIntegral (n :: Int)) nullPtr p else c_ctx_create 0 p) >>= check "sla_ctx_create" >> peek p
+  c <- alloca $ \p -> (if n > 1 then c_ctx_create_multi (fromIntegral (n :: Int)) nullPtr p else c_ctx_create 0 p) >>= check "sla_ctx_create" >> peek p
+  -- SLA_REFERENCE_BETA=1: bicgstabStep with the reference's literal beta = (rj1 <.> r0hat) / (r <.> r0hat) * alphaj / omegaj from
+  -- the stored rj1 (K4 and K5 as separate kernels) instead of rho' through the linearity identity of the fused sweep (INTEGRATION.md)
+  lit <- lookupEnv "SLA_REFERENCE_BETA"
+  case lit of
+    Just "1" -> withCString "bicg_fuse45" $ \k -> withCString "0" $ \v -> c_ctx_set_option c k v >>= check "sla_ctx_set_option"
+    _ -> return ()
+  return c
 
 -- | status code -> the reference's exception / error (Control/Exception/Common.hs:44-76).  INTEGRATION.md section 2 shows
 --   this very function.
