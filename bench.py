@@ -718,14 +718,23 @@ def main():
         if have >= args.gpus:
             spawn_ranks(args)                      # does not return
         if os.environ.get("SLA_BENCH_LOOPBACK") == "1" and have >= 1:
+            sys.stdout.flush()
+            json_fd = os.dup(1)
+            os.dup2(2, 1)
             rec = loopback_ranks(args)
-            print(json.dumps(rec), flush=True)
+            sys.stdout.flush()
+            os.write(json_fd, (json.dumps(rec) + "\n").encode())
             return
         raise SystemExit(f"--gpus {args.gpus}: only {have} GPU(s) visible (SLA_BENCH_LOOPBACK=1 rehearses the sharded flow on one GPU)")
     rank = int(os.environ.get("RANK", "0"))
     world = int(world_env or "1")
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     args.gpus = world
+    # The driver reads ONE JSON line from rank 0's stdout.  Native libraries print there too (gloo announces its connections, RCCL its
+    # version banner at ncclCommInitRank): everything but the line goes to stderr, the line itself to the saved descriptor.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     # SLA_BENCH_FORCE_DIST=1 drives the multi-rank code path (gloo control plane, RCCL communicator, forced collectives)
     # with a 1-rank communicator on a single GPU
     use_dist = world > 1 or os.environ.get("SLA_BENCH_FORCE_DIST") == "1"
@@ -733,7 +742,8 @@ def main():
         os.environ["SLA_FORCE_COLLECTIVES"] = "1"
     rec = run_rank(args, rank, world, local_rank, "rccl" if use_dist else None)
     if rank == 0:
-        print(json.dumps(rec), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(rec) + "\n").encode())
     if use_dist:
         import torch.distributed as dist
         dist.barrier()

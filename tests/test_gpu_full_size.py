@@ -131,3 +131,18 @@ def test_full_size_triangular_solves_recover_ones(sla):
         assert sla.triSolveLevels(T, upper) == (216 * 3 - 2, 34992)
         x = (sla.triUpperSolve if upper else sla.triLowerSolve)(T, sla.DeviceVector(T.ctx, n, b)).to_host()
         assert np.array_equal(x, np.ones(n))
+
+
+def test_bench_stdout_is_one_json_line_on_the_rccl_path():
+    """The driver reads ONE JSON line from rank 0's stdout.  On the multi-rank path native libraries print there too (gloo
+    announces its connections, RCCL its version banner at ncclCommInitRank): exercised here with the 1-rank RCCL communicator
+    (SLA_BENCH_FORCE_DIST=1) -- stdout must hold exactly the line, everything else goes to stderr."""
+    env = dict(os.environ, SLA_BENCH_FORCE_DIST="1", SLA_X_EXCHANGE="window", MASTER_ADDR="127.0.0.1", MASTER_PORT="29577")
+    env.pop("WORLD_SIZE", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "laplace3d_small", "--steps", "8", "--warmup", "2",
+                          "--no-cpu-baseline"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.count("\n") == 1 and out.stdout.startswith("{"), out.stdout[:400]
+    d = json.loads(out.stdout)
+    assert d["rccl_ranks"] == 1 and d["exchanges"]["sums"]["launches"] > 0
+    assert set(d["kernels"]) == {"K1", "K2", "K3", "K45"}             # the fused sweep runs on sharded contexts too (round 3)

@@ -45,10 +45,10 @@ pmc $S/${tag}_bench_pmc_counters_dense_rows_200k.txt python bench.py --workload 
 # round 3: one rank's 8-GPU slab (108^3 rows) through a 1-rank RCCL communicator: ghost-row flow with the fused K4+K5 sweep on own + ghost rows
 # (2 grouped exchanges per step) against the reference's split (3), window and all-gather exchange
 for f in 1 0; do for xe in window allgather; do
-  SLA_BICG_FUSE45=$f SLA_BENCH_FORCE_DIST=1 SLA_X_EXCHANGE=$xe timeout 600 python bench.py --workload laplace3d_1m --no-cpu-baseline --steps 200 --warmup 20 2>/dev/null | tail -1 > $S/${tag}_bench_slab_1rank_rccl_${xe}_fuse$f.json
+  SLA_BICG_FUSE45=$f SLA_BENCH_FORCE_DIST=1 SLA_X_EXCHANGE=$xe timeout 600 python bench.py --workload laplace3d_1m --no-cpu-baseline --steps 200 --warmup 20 2>/dev/null | grep '^{' | tail -1 > $S/${tag}_bench_slab_1rank_rccl_${xe}_fuse$f.json
 done; done
 # the sharded flow rehearsed with two loopback ranks on this one GPU (both workloads in one line; not a scaling number)
-SLA_BENCH_LOOPBACK=1 timeout 900 python bench.py --gpus 2 --steps 40 --warmup 5 2>/dev/null | tail -1 > $S/${tag}_bench_loopback_2ranks.json
+SLA_BENCH_LOOPBACK=1 timeout 900 python bench.py --gpus 2 --steps 40 --warmup 5 2>/dev/null | grep '^{' | tail -1 > $S/${tag}_bench_loopback_2ranks.json
 # the CSR-stream skeleton: load widths, structure variants, the y store (tools/stream_width_probe.cpp)
 [ -x tools/stream_width_probe ] && timeout 120 tools/stream_width_probe 216 > $S/${tag}_stream_width_probe.txt 2>&1
 # L1 <-> L2 request counters of the tile kernel (config 3a) and of the CSR-stream kernel (general_csr): the fabric-side statement of their bounds

@@ -12,8 +12,8 @@ import bench  # noqa: E402
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 desc, (dims, (rp, ci, va)) = bench.workload("laplace3d_10m")
 base = {"wdia": 0, "vdict": 0, "diag": 0}
-for name, extra in (("wide", {}), ("ra128", {"row_align": 128}), ("ra64", {"row_align": 64}), ("ra16", {"row_align": 16}), ("wide", {}), ("ra128", {"row_align": 128}),
-                    ("ra128n", {"row_align": 128, "stream_wide": 0})):
+for name, extra in (("g2048", {}), ("g1024", {"spmv_grid": 1024}), ("g1536", {"spmv_grid": 1536}), ("g1280", {"spmv_grid": 1280}), ("g2048", {}), ("g1024", {"spmv_grid": 1024}),
+                    ("g1536", {"spmv_grid": 1536})):
     r = bench.side_block(desc, dims, rp, ci, va, dict(base, **extra), steps, 5)
     print(f"laplace3d_10m {name:7s} {r['value']:8.1f} it/s  K1 {r['k1_ms'] * 1e3:7.1f} us ({r['k1_frac']:.3f})  "
           + "  ".join(f"{k} {v['ms'] * 1e3:.1f}" for k, v in r["kernels"].items()) + "  " + r["spmv_kernel"].split()[0], flush=True)
