@@ -754,6 +754,51 @@ static void low_value_indexed(Low &L) {
                         A->wd_win = W;
                         A->wd_uni = U;
                         A->wd_lds = true;
+                        // Plane march (spmv_wdia_march_kernel): three windows {-D}, {in-plane}, {+D} with ONE pair in each far
+                        // window, D even, the in-plane window <= 512 pairs and around offset 0, an unsharded matrix.  The masks
+                        // are laid out per (tile, plane, wavefront) for rows plane * D + tile * 512 + wavefront * 128 + [0, 128)
+                        // -- a plane is not a whole number of 128-row slices (216^2 = 364.5 of them).
+                        const int np = A->npairs;
+                        const int64_t D = np >= 3 ? (int64_t)doff[(size_t)np - 1] : 0;
+                        if (W.n == 3 && (np == 5 || np == 7) && row_begin == 0 && rows == m && m == n && D >= 1024 && (D & 1) == 0 &&
+                            doff[0] == -D && doff[1] >= W.omin[1] && doff[(size_t)np - 2] <= wmax[1] && W.omin[1] <= 0 && wmax[1] >= 0 &&
+                            W.pb[2] - W.pb[1] <= 512 && rows >= 2 * D) {
+                            WdMarch G;
+                            G.D = (int32_t)D;
+                            G.T = (int32_t)((D + 511) / 512);
+                            G.planes = (int32_t)((rows + D - 1) / D);
+                            G.omin = W.omin[1];
+                            G.pairs = W.pb[2] - W.pb[1];
+                            const int slots = std::max(1, c->wd_march_occ) * c->n_cu;
+                            G.S = std::max(1, std::min(G.planes, slots / G.T));
+                            G.PS = (G.planes + G.S - 1) / G.S;
+                            G.S = (G.planes + G.PS - 1) / G.PS;
+                            G.ntasks = G.T * G.S;
+                            WdUni M;
+                            M.n = np;
+                            for (int t = 0; t < np; ++t) {
+                                const int64_t o = t == 0 ? 0 : t == np - 1 ? 0 : (int64_t)doff[(size_t)t];   // (relative to the pair's own plane)
+                                M.lpos[t] = (int32_t)(o - G.omin);
+                                M.val[t] = dval[(size_t)t];
+                            }
+                            M.lpos0 = -G.omin;
+                            std::vector<uint64_t> wm((size_t)G.T * (size_t)G.planes * 4 * 16, 0);
+                            par_rows(G.planes, 1, [&](int, int64_t plo, int64_t phi) {   // (the slices of a plane belong to one thread)
+                                for (int64_t kk = plo; kk < phi; ++kk) {
+                                    const int64_t r0 = kk * D, r1 = std::min<int64_t>(rows, r0 + D);
+                                    for (int64_t i = r0; i < r1; ++i) {
+                                        const int64_t pos = i - r0, tile = pos >> 9;
+                                        const size_t sl2 = ((size_t)(tile * G.planes + kk) * 4 + (size_t)((pos >> 7) & 3)) * 16;
+                                        const uint64_t bit = 1ull << ((pos & 127) >> 1);
+                                        for (int64_t k = rowptr[i]; k < rowptr[i + 1]; ++k) wm[sl2 + (size_t)(pos & 1) * 8 + codes[(size_t)k]] |= bit;
+                                    }
+                                }
+                            }, 4);
+                            upload((void **)&A->d_wum_m, wm.data(), sizeof(uint64_t) * wm.size());
+                            A->wd_mg = G;
+                            A->wd_muni = M;
+                            A->wd_march = true;
+                        }
                     }
                 }
                 // Visiting order of the 512-row steps.  A 3-D stencil row touches x one PLANE (the far diagonal, D rows)
@@ -1101,6 +1146,8 @@ const IntKnob kIntKnobs[] = {
     {"bicg_fuse45", &sla_ctx::bicg_fuse45, 0, 1},
     {"wd_lds", &sla_ctx::wd_lds, 0, 2},
     {"wd_lds_occ", &sla_ctx::wd_lds_occ, 0, 4},
+    {"wd_march", &sla_ctx::wd_march, 0, 2},
+    {"wd_march_occ", &sla_ctx::wd_march_occ, 1, 4},
     {"wd_nt_store", &sla_ctx::wd_nt_store, 0, 1},
     {"wdia_vv", &sla_ctx::wdia_vv, 0, 1},
     {"vec_nt", &sla_ctx::vec_nt, -1, 1},
@@ -1678,6 +1725,7 @@ int sla_csr_destroy(sla_csr_t A) {
     if (A->d_wval) (void)hipFree(A->d_wval);
     if (A->d_woff) (void)hipFree(A->d_woff);
     if (A->d_wum) (void)hipFree(A->d_wum);
+    if (A->d_wum_m) (void)hipFree(A->d_wum_m);
     if (A->d_vcode) (void)hipFree(A->d_vcode);
     if (A->d_vdoff) (void)hipFree(A->d_vdoff);
     if (A->d_vdval) (void)hipFree(A->d_vdval);
@@ -1730,7 +1778,7 @@ int sla_csr_kernel_info(sla_csr_t A, char *buf, int buflen) {
     if (A && !A->kids.empty()) return sla_csr_kernel_info(A->kids[0], buf, buflen);
     if (!A || !buf || buflen <= 0) return fail(SLA_ERR_INVALID, "null argument");
     snprintf(buf, (size_t)buflen, "algo=%s grid=%d block=%d row_blocks=%d nnz_per_row_block=%d max_row_nnz=%lld rowptr=%s xcd_remap=%d",
-             A->ctx->spmv_algo == 1 ? "scalar" : (A->use_wdia && wd_on(A)) ? (A->wd_vv ? "wdia-vv" : wd_lds_on(A) ? "wdia+ldswin" : "wdia") : (A->use_vdict && A->ctx->vdict) ? (A->use_xwin && A->ctx->xwin ? "vdict+xwin" : "vdict") : (A->use_lpanel && A->ctx->lpanel) ? "stream+ldspanels" : tiles_on(A) ? "tiles" : (!A->panels.empty() && A->ctx->panels) ? "stream+colpanels" : (A->use_diag && A->ctx->diag ? (A->use_xwin && A->ctx->xwin ? "stream+diagdict+xwin" : "stream+diagdict") : (pipe_on(A) ? "stream+pipe" : stream_xwin_on(A) ? "stream+xwin" : "stream")), spmv_grid(A), kBlock, A->nrb, kNnzPerRowBlock,
+             A->ctx->spmv_algo == 1 ? "scalar" : (A->use_wdia && wd_on(A)) ? (A->wd_vv ? "wdia-vv" : wd_march_on(A) ? "wdia+march" : wd_lds_on(A) ? "wdia+ldswin" : "wdia") : (A->use_vdict && A->ctx->vdict) ? (A->use_xwin && A->ctx->xwin ? "vdict+xwin" : "vdict") : (A->use_lpanel && A->ctx->lpanel) ? "stream+ldspanels" : tiles_on(A) ? "tiles" : (!A->panels.empty() && A->ctx->panels) ? "stream+colpanels" : (A->use_diag && A->ctx->diag ? (A->use_xwin && A->ctx->xwin ? "stream+diagdict+xwin" : "stream+diagdict") : (pipe_on(A) ? "stream+pipe" : stream_xwin_on(A) ? "stream+xwin" : "stream")), spmv_grid(A), kBlock, A->nrb, kNnzPerRowBlock,
              (long long)A->max_row_nnz, A->rp64 ? "i64" : "i32", A->ctx->xcd_remap);
     if (A->use_lpanel && A->ctx->lpanel && A->ctx->spmv_algo == 0) {   // LDS-panel geometry
         const size_t used = strlen(buf);

@@ -108,39 +108,57 @@ __device__ __forceinline__ bool arn_stopped(SolverScalars *sc) {
 // ---------------------------------------------------------------------------------------------
 // SpMV epilogues
 // ---------------------------------------------------------------------------------------------
+// the epilogue operands of a row (w: K1 / K3's dot operand, b of the residual forms; z: r0hat of the four-sum K3, the vector the
+// CGNE forms update): loaded apart from the epilogue so that a kernel can issue them with its other loads, a whole fold early
 template <int EPI, typename RP>
-__device__ __forceinline__ void spmv_epilogue(const SpmvArgs<RP> &a, int row, double yv, double coef,
-                                              double &acc1, double &acc2) {
+__device__ __forceinline__ void spmv_operands(const SpmvArgs<RP> &a, int row, double &wv, double &zv) {
+    wv = 0.0;
+    zv = 0.0;
+    if constexpr (EPI == EPI_DOT || EPI == EPI_DOT2 || EPI == EPI_DOT4 || EPI == EPI_RES || EPI == EPI_SUB) wv = a.w[row];
+    if constexpr (EPI == EPI_AXPY_DOT) {
+        if (a.w) wv = a.w[row];
+    }
+    if constexpr (EPI == EPI_DOT4 || EPI == EPI_AXPY_DOT || EPI == EPI_XPBY_NRM) zv = a.z[row];
+}
+template <int EPI, typename RP>
+__device__ __forceinline__ void spmv_epilogue_pre(const SpmvArgs<RP> &a, int row, double yv, double coef, double &acc1, double &acc2,
+                                                  double wv, double zv) {
     if constexpr (EPI == EPI_NONE) {
         a.y[row] = yv;
     } else if constexpr (EPI == EPI_DOT) {
         a.y[row] = yv;
-        acc1 += yv * a.w[row];
+        acc1 += yv * wv;
     } else if constexpr (EPI == EPI_DOT2) {
         a.y[row] = yv;
-        acc1 += yv * a.w[row];
+        acc1 += yv * wv;
         acc2 += yv * yv;
     } else if constexpr (EPI == EPI_DOT4) {   // fused K4+K5 flow: As . r0hat and s . r0hat from the same sweep
         a.y[row] = yv;
-        const double wv = a.w[row], zv = a.z[row];
         acc1 += yv * wv;
         acc2 += yv * yv;
         a.acc3 += yv * zv;
         a.acc4 += wv * zv;
     } else if constexpr (EPI == EPI_RES) {
-        double t = yv - a.w[row];  // (aa #> x) ^-^ b
+        double t = yv - wv;  // (aa #> x) ^-^ b
         acc1 += t * t;
     } else if constexpr (EPI == EPI_AXPY_DOT) {
-        double z = a.z[row] - coef * yv;
+        double z = zv - coef * yv;
         a.z[row] = z;
-        acc1 += z * (a.w ? a.w[row] : z);
+        acc1 += z * (a.w ? wv : z);
     } else if constexpr (EPI == EPI_XPBY_NRM) {
-        double z = yv + coef * a.z[row];
+        double z = yv + coef * zv;
         a.z[row] = z;
         acc1 += z * z;
     } else if constexpr (EPI == EPI_SUB) {
-        a.y[row] = a.w[row] - yv;  // b ^-^ (aa #> x)
+        a.y[row] = wv - yv;  // b ^-^ (aa #> x)
     }
+}
+template <int EPI, typename RP>
+__device__ __forceinline__ void spmv_epilogue(const SpmvArgs<RP> &a, int row, double yv, double coef,
+                                              double &acc1, double &acc2) {
+    double wv, zv;
+    spmv_operands<EPI, RP>(a, row, wv, zv);
+    spmv_epilogue_pre<EPI, RP>(a, row, yv, coef, acc1, acc2, wv, zv);
 }
 
 // the two extra partial sums of EPI_DOT4 (see SpmvArgs::p3): called by every SpMV kernel after its p1 / p2 partials

@@ -50,6 +50,18 @@ struct WdUni {                       // uniform records: the matrix's <= 8 (offs
     int32_t lpos0 = -1;              // ... that x[step base] itself lands on (-1: no window covers offset 0)
     double val[8] = {};
 };
+// plane-march variant (spmv_wdia_march_kernel): a 3-D stencil whose far offsets are one pair -D and one pair +D.  A workgroup owns
+// an in-plane tile of 512 rows and walks a run of planes; per step it stages ONE window (the in-plane window of the plane ahead),
+// the planes behind / ahead of a step are the buffers staged one step earlier / later.
+struct WdMarch {
+    int32_t D = 0;                   // plane stride = the far offset (even)
+    int32_t T = 0;                   // 512-row tiles per plane (the last one partial)
+    int32_t planes = 0;              // ceil(rows / D)
+    int32_t PS = 0, S = 0;           // planes per run, runs per tile
+    int32_t ntasks = 0;              // T * S, tile-major
+    int32_t omin = 0;                // first offset of the in-plane window (even, <= 0)
+    int32_t pairs = 0;               // its 16-byte pairs (<= 512)
+};
 constexpr int kVdRows = 256;         // rows per block of spmv_vdict_kernel (one lane per row)
 constexpr int kLpW = 16384;          // columns of x one workgroup of spmv_lpanel_kernel keeps in LDS (128 KiB)
 constexpr int kLpBlock = 1024;       // its workgroup: 16 wavefronts, one per CU (LDS-bound occupancy)
@@ -194,6 +206,8 @@ struct sla_ctx {
     int bicg_fuse45 = 1;             // single-rank BiCGSTAB: K4 + K5 in one sweep, rho through K3's extra sums (SLA_BICG_FUSE45)
     int wd_lds = 1;                  // stencils with <= 8 (offset, value) pairs: uniform records + x windows staged in LDS (SLA_WD_LDS; 2: at any size)
     int wd_nt_store = 0;             // its y / z stores past the caches (SLA_WD_NT_STORE)
+    int wd_march = 1;                // 3-D stencils on unsharded contexts: plane-march walk of the LDS-window form (SLA_WD_MARCH; 2: at any size, 0: never)
+    int wd_march_occ = 4;            // its workgroups per CU (32 KiB of LDS each)
     int wd_lds_occ = 0;              // its workgroups per CU (SLA_WD_LDS_OCC; 0: as many as the LDS holds, at most 4)
     int wd_tile = -1;                // plane tiling of the wave-sliced walk: -1 automatic, 0 off, > 0 steps per tile (SLA_WD_TILE)
     int wdia = 1;                    // allow the wave-sliced SpMV kernel (SLA_WDIA=0 disables)
@@ -286,6 +300,10 @@ struct sla_csr {
     bool wd_lds = false;
     sla::WdWin wd_win;
     sla::WdUni wd_uni;
+    bool wd_march = false;                  // plane-march variant of it (spmv_wdia_march_kernel): geometry, pair positions, masks in march order
+    sla::WdMarch wd_mg;
+    sla::WdUni wd_muni;
+    unsigned long long *d_wum_m = nullptr;  // per (tile, plane, wavefront): 8 even-row masks then 8 odd-row masks
     int32_t wd_col_lo = 0, wd_col_hi = -1;  // smallest / largest column these rows reference: what the staged windows may read
     // LDS-panel form (rows with many entries per 16384-column panel): per (panel, row) entry ranges into col / val
     void *d_lpp = nullptr;           // (P + 1) x rows, RP-typed, panel-major: pp[p][i] = first entry of row i with col >= p * lp_W
@@ -393,6 +411,9 @@ namespace sla {
 // (its workgroups need a few steps each to amortise the staging pipeline's fill: below that the gather kernel is faster -- 1 M-row
 // Poisson: 22 500 vs 21 300 it/s; SLA_WD_LDS=2 forces it)
 inline bool wd_lds_on(const sla_csr *A) { return A->wd_lds && !A->wd_vv && (A->ctx->wd_lds == 2 || (A->ctx->wd_lds == 1 && A->nblk_wd >= 16 * 4 * A->ctx->n_cu)); }
+inline bool wd_march_on(const sla_csr *A) {
+    return A->wd_march && wd_lds_on(A) && A->ctx->wd_march >= 1 && A->ctx->spmv_algo == 0 && (A->ctx->wd_march == 2 || A->wd_mg.planes >= 32);
+}
 // does the plain CSR-stream form of A stage an x window in LDS (spmv_xwin_kernel)?  Only without the paired loads of
 // spmv_stream_kernel (stream_wide, default): with them the plain kernel is the faster one (round 3: K1 222-231 vs 232-241 us,
 // K3 -- four sums since the fused K4+K5 flow -- 228-238 vs 258 us on the 216^3 Laplacian), so the window form is an A/B knob now
@@ -574,6 +595,8 @@ int launch_spmv_lpanel(const sla_csr *A, int epi, const SpmvArgs<int64_t> &a, in
 inline bool vec_stream_nt(const sla_ctx *c, int64_t n) { return c->vec_nt < 0 ? 7 * 8 * n > c->mall_bytes : c->vec_nt != 0; }
 int launch_wdia_lds(const sla_csr *A, int epi, const SpmvArgs<int32_t> &a, const int32_t *sched, int32_t nblk, int grid, int stream_nt);   // sla_spmv_wdia_lds.hip
 int wd_lds_grid(const sla_csr *A);
+int wd_march_grid(const sla_csr *A);
+int launch_wdia_march(const sla_csr *A, int epi, const SpmvArgs<int32_t> &a, int grid, int stream_nt);
 bool pipe_on(const sla_csr *A);                                                                              // sla_spmv_pipe.hip
 int launch_spmv_pipe(const sla_csr *A, int epi, const SpmvArgs<int32_t> &a, int grid);
 int launch_spmv_pipe(const sla_csr *A, int epi, const SpmvArgs<int64_t> &a, int grid);

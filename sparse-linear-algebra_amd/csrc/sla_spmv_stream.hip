@@ -14,6 +14,10 @@
 #include "sla_internal.hpp"
 #include "sla_device.hpp"
 
+#ifndef SLA_STREAM_PRE_OPERANDS
+#define SLA_STREAM_PRE_OPERANDS 1   // (0: operands loaded inside the epilogue, the round-2 order; A/B builds)
+#endif
+
 namespace sla {
 
 typedef int sla_i32x2 __attribute__((ext_vector_type(2)));
@@ -116,6 +120,13 @@ __global__ void __launch_bounds__(kBlock, 8) spmv_stream_kernel(SpmvArgs<RP> a, 
                 int *rp = s_rp[buf];
                 if (tid < nrows) rp[tid] = (int)(rpn - k0);
                 if (tid == 0) rp[nrows] = cnt;
+                // one lane per row (below): its epilogue operands travel with the gathers.  Loaded inside the epilogue they were one more
+                // exposed round trip between the fold and the y store (K3 with its two operands: 271 -> 228 us same-box at 216^3).
+                // (Holding the y store back to the next block's gathers, so that its acknowledgement never stands alone in front of a
+                // wait, was tried with it: four more VGPRs, the four-sum instantiation spills at 64 -- K3 back at 269 us.)
+                const bool lane_per_row = nrows > 64 || cnt <= 8 * nrows;
+                double wpre = 0.0, zpre = 0.0;
+                if (SLA_STREAM_PRE_OPERANDS == 1 && lane_per_row && tid < nrows) spmv_operands<EPI, RP>(a, r0 + tid, wpre, zpre);
                 if (SLA_WIDE_OK(k0, k1)) {
                     const int odd = (int)(k0 & 1);
 #pragma unroll
@@ -133,7 +144,7 @@ __global__ void __launch_bounds__(kBlock, 8) spmv_stream_kernel(SpmvArgs<RP> a, 
                 if (has_next) { SLA_ISSUE_LOADS(nr0, nr1, nk0, nk1) }
                 SLA_FETCH_DESC()
                 __syncthreads();
-                if (nrows > 64 || cnt <= 8 * nrows) {
+                if (lane_per_row) {
                     // one lane per row, ascending left fold: the reference's summation order exactly
                     if (tid < nrows) {
                         const int s = rp[tid], e = rp[tid + 1];
@@ -141,7 +152,8 @@ __global__ void __launch_bounds__(kBlock, 8) spmv_stream_kernel(SpmvArgs<RP> a, 
                         // ascending left fold per row
                         double acc = a.yinit ? a.yinit[r0 + tid] : 0.0;
                         for (int k = s; k < e; ++k) acc += prod[k];
-                        spmv_epilogue<EPI, RP>(a, r0 + tid, acc, coef, acc1, acc2);
+                        if (!SLA_STREAM_PRE_OPERANDS) spmv_operands<EPI, RP>(a, r0 + tid, wpre, zpre);
+                        spmv_epilogue_pre<EPI, RP>(a, r0 + tid, acc, coef, acc1, acc2, wpre, zpre);
                     }
                 } else {
                     // few, longer rows: a power-of-two segment of the wavefront per row

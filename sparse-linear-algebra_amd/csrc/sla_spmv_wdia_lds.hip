@@ -21,6 +21,10 @@
 #include "sla_internal.hpp"
 #include "sla_device.hpp"
 
+#ifndef SLA_WDL_LATE_STORE
+#define SLA_WDL_LATE_STORE 1   // (0: the round-2 order, y store in front of the end-of-step wait; A/B builds)
+#endif
+
 namespace sla {
 
 typedef unsigned long long wd_u64x8s __attribute__((ext_vector_type(8)));
@@ -132,28 +136,28 @@ __global__ void __launch_bounds__(kBlock, NW <= 4 ? 4 : 3) spmv_wdia_lds_kernel(
             mo = wum[2 * (size_t)s + 1];
         }
         const int blk_g = load_blk(b + 3 * wk.step);
+        const bool va = have && row < a.rows, vb = have && row + 1 < a.rows;
+        const char *lb = (const char *)wd_buf[p];
+        double ya = 0.0, yb = 0.0;
         if (have) {
-            const bool va = row < a.rows, vb = row + 1 < a.rows;
-            const char *lb = (const char *)wd_buf[p];
-            double ya = 0.0, yb = 0.0;
-            {
 #pragma clang fp contract(off)  // a*x then +: two roundings like the reference, never an FMA
-                wd_f64x2 xv[NP];
+            wd_f64x2 xv[NP];
 #pragma unroll
-                for (int k = 0; k < NP; ++k) xv[k] = *(const wd_f64x2u *)(lb + laddr[k]);
+            for (int k = 0; k < NP; ++k) xv[k] = *(const wd_f64x2u *)(lb + laddr[k]);
 #pragma unroll
-                for (int k = 0; k < NP; ++k) {
-                    // EXEC = the even rows that hold the entry, then the odd rows; v_mul_f64 then v_add_f64 (two roundings).
-                    // All 64 lanes are active here (wave-uniform control flow only): EXEC goes back to -1.
-                    double pr;
-                    asm volatile(
-                        "s_mov_b64 exec, %[me]\n\tv_mul_f64 %[p], %[v], %[xa]\n\tv_add_f64 %[ya], %[ya], %[p]\n\t"
-                        "s_mov_b64 exec, %[mo]\n\tv_mul_f64 %[p], %[v], %[xb]\n\tv_add_f64 %[yb], %[yb], %[p]\n\t"
-                        "s_mov_b64 exec, -1"
-                        : [ya] "+v"(ya), [yb] "+v"(yb), [p] "=&v"(pr)
-                        : [me] "s"(me[k]), [mo] "s"(mo[k]), [v] "v"(pval[k]), [xa] "v"(xv[k].x), [xb] "v"(xv[k].y));
-                }
+            for (int k = 0; k < NP; ++k) {
+                // EXEC = the even rows that hold the entry, then the odd rows; v_mul_f64 then v_add_f64 (two roundings).
+                // All 64 lanes are active here (wave-uniform control flow only): EXEC goes back to -1.
+                double pr;
+                asm volatile(
+                    "s_mov_b64 exec, %[me]\n\tv_mul_f64 %[p], %[v], %[xa]\n\tv_add_f64 %[ya], %[ya], %[p]\n\t"
+                    "s_mov_b64 exec, %[mo]\n\tv_mul_f64 %[p], %[v], %[xb]\n\tv_add_f64 %[yb], %[yb], %[p]\n\t"
+                    "s_mov_b64 exec, -1"
+                    : [ya] "+v"(ya), [yb] "+v"(yb), [p] "=&v"(pr)
+                    : [me] "s"(me[k]), [mo] "s"(mo[k]), [v] "v"(pval[k]), [xa] "v"(xv[k].x), [xb] "v"(xv[k].y));
             }
+        }
+        auto epilogue = [&]() {
             if (va) {
                 fix_operands(row, wv, zv);
                 if constexpr (kUsesW) {
@@ -161,11 +165,15 @@ __global__ void __launch_bounds__(kBlock, NW <= 4 ? 4 : 3) spmv_wdia_lds_kernel(
                 }
                 wd_epilogue<EPI>(a, row, vb, ya, yb, wv, zv, coef, acc1, acc2, (stream_nt & 2) != 0);
             }
-        }
-        // everything issued at the top has to be here now (the windows are staged next): saying so keeps the compiler from
-        // waiting conservatively in front of the next step's loads
+        };
+        // Everything issued at the top has to be here now (the windows are staged next); saying so keeps the compiler from waiting
+        // conservatively in front of the next step's loads.  The wait stands BEFORE this step's y store: vmcnt counts stores too on
+        // this part, and a wait behind the store held every step for the store's acknowledgement -- a full memory round trip with
+        // nothing else in flight (round 3).  Now the store of step i is acknowledged while step i + 1 is folded.
+        if (!SLA_WDL_LATE_STORE) epilogue();
         __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0)
         if (more) stage(p ^ 1);
+        if (SLA_WDL_LATE_STORE) epilogue();
         __syncthreads();
         blk_c = blk_n;
         blk_n = blk_f;

@@ -299,3 +299,94 @@ def test_rows_without_entries_still_run_the_epilogues(sla, values):
     x, info = sla.linSolve0(sla.BICGSTAB_, A, sla.fromVector(b), sla.fromVector(x0), return_info=True, max_iters=3)
     res = orc.spmv(Ao, x.toDenseListSV()) - b                                       # EPI_RES counts the empty rows' b_i
     assert abs(info["resnorm"] - np.linalg.norm(res)) <= 1e-9 * np.linalg.norm(res)
+
+
+def _march_cases():
+    from sla_amd import workloads as wl
+    rng = np.random.default_rng(9)
+    drop = rng.random((9000, 8)) < 0.3
+    return {
+        # D = 36 * 30 = 1080: tiles of 512, 512, 56 rows; 9 planes
+        "laplace3d 36x30x9": wl.laplace3d(36, 30, 9),
+        # D = 40 * 64 = 2560 = 5 whole tiles, 7 planes
+        "laplace3d 40x64x7": wl.laplace3d(40, 64, 7),
+        # 2-D 5-point stencil on a 1100-wide grid: D = 1100, in-plane window +-1
+        "poisson2d 1100x13": wl.poisson2d(1100, 13),
+        # ragged, odd row count, last plane partial (4099 = 3 * 1300 + 199), 30 % of the entries missing
+        "ragged 7 diagonals n=4099": _stencil(4099, [-1300, -40, -1, 0, 1, 40, 1300],
+                                               lambda r, o: np.full(len(r), 9.0 if o == 0 else 0.5 + (o % 3)),
+                                               keep=lambda r, t: ~drop[r, t] | (t == 3)),
+        # no (i, i + 2) entry in a third of the rows, in-plane offsets up to +-250 (window of 1014 elements), n = 7 D + 1
+        "wide in-plane window n=8401": _stencil(8401, [-1200, -250, -2, 0, 2, 250, 1200],
+                                                 lambda r, o: np.full(len(r), 11.0 if o == 0 else -1.0 - 0.25 * (abs(o) % 5)),
+                                                 keep=lambda r, t: (r % 3 != 1) | (t != 4)),
+    }
+
+
+@pytest.mark.parametrize("name", list(_march_cases()))
+@pytest.mark.parametrize("grid", [0, 8])
+def test_plane_march_form_folds_like_the_reference(sla, name, grid):
+    """spmv_wdia_march_kernel (a workgroup walks a run of planes of a 3-D stencil, one staged window per step): every row the
+    reference's left fold bit for bit, (<#) through the transposed matrix's own lowering, and the fused epilogues through the
+    solvers against the LDS-window form.  grid = 8: eight workgroups, so each walks several (tile, run) tasks."""
+    dims, csr = _march_cases()[name]
+    n = dims[0]
+    Ao = _oracle_csr(dims, csr)
+    rng = np.random.default_rng(13)
+    x = rng.standard_normal(n)
+    x[rng.integers(0, n, max(1, n // 50))] = -0.0
+    want = orc.spmv(Ao, x)
+    want_t = orc.spmv(orc.transpose(Ao), x)
+    b = orc.spmv(Ao, np.linspace(-1.0, 2.0, n))
+    out = {}
+    for march in (2, 0):
+        ctx = sla.Context(0).set_options(wd_lds=2, wd_march=march)
+        if grid:
+            ctx.set_option("spmv_grid", grid)
+        A = sla.fromCSR(dims, *csr, ctx)
+        assert ("wdia+march" in A.kernel_info().split()[0]) == (march == 2), A.kernel_info()
+        y = sla.matVec(A, sla.fromVector(x, ctx)).toDenseListSV()
+        yt = sla.vecMat(sla.fromVector(x, ctx), A).toDenseListSV()
+        assert np.array_equal(y.view(np.uint64), want.view(np.uint64)), (name, march, np.abs(y - want).max())
+        assert np.array_equal(yt.view(np.uint64), want_t.view(np.uint64)), (name, march, "transpose")
+        for meth in (sla.BICGSTAB_, sla.CGS_, sla.CGNE_):
+            xs, info = sla.linSolve0(meth, A, sla.fromVector(b, ctx), sla.fromVector(np.full(n, 0.25), ctx), return_info=True)
+            out[(march, int(meth))] = (xs.toDenseListSV(), info["iters"], info["resnorm"])
+        del A
+        ctx.close()
+    for meth in (sla.BICGSTAB_, sla.CGS_, sla.CGNE_):
+        (xm, itm, _), (xl, itl, _) = out[(2, int(meth))], out[(0, int(meth))]
+        assert abs(itm - itl) <= 1, (name, meth, itm, itl)
+        if itm == itl:      # same rows, differently grouped partial sums, amplified by the solver
+            assert np.abs(xm - xl).max() <= 2e-4 * (np.abs(xl).max() + 1e-300), (name, meth)
+        if itm < 200:
+            assert np.linalg.norm(orc.spmv(Ao, xm) - b) <= 1e-4 * np.linalg.norm(orc.spmv(Ao, np.full(n, 0.25)) - b) * (1 + 1e-9) + 1e-6
+
+
+def test_plane_march_form_step_for_step_against_the_oracle(sla):
+    """Two BiCGSTAB steps (fused sweep: K1 dot, K3 with four sums and the window operand) and two CGS steps on the march form
+    against the oracle's steps."""
+    from sla_amd import workloads as wl
+    dims, csr = wl.laplace3d(36, 30, 9)
+    n = dims[0]
+    Ao = _oracle_csr(dims, csr)
+    b = orc.spmv(Ao, np.linspace(-1.0, 2.0, n))
+    x0 = np.full(n, 0.25)
+    ctx = sla.Context(0).set_options(wd_lds=2, wd_march=2)
+    A = sla.fromCSR(dims, *csr, ctx)
+    assert "wdia+march" in A.kernel_info()
+    r0hat = b - orc.spmv(Ao, x0)
+    for fuse in (1, 0):     # the fused K4 + K5 sweep (K3 with four sums) and the reference's split
+        ctx.set_option("bicg_fuse45", fuse)
+        so, sd = orc.BicgstabState(Ao, b, x0), sla.bicgsInit(A, sla.fromVector(b, ctx), sla.fromVector(x0, ctx))
+        so.step(r0hat, 2)
+        sd.step(2)
+        for got, want in ((sd._xBicgstab, so.x), (sd._rBicgstab, so.r), (sd._pBicgstab, so.p)):
+            assert np.linalg.norm(got.toDenseListSV() - want) <= 1e-11 * np.linalg.norm(want), fuse
+    co, cd = orc.CgsState(Ao, b, x0), sla.cgsInit(A, sla.fromVector(b, ctx), sla.fromVector(x0, ctx))
+    co.step(r0hat, 2)
+    cd.step(2)
+    for got, want in ((cd._x, co.x), (cd._r, co.r), (cd._p, co.p)):
+        assert np.linalg.norm(got.toDenseListSV() - want) <= 1e-11 * np.linalg.norm(want)
+    del A
+    ctx.close()

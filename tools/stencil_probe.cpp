@@ -245,6 +245,75 @@ __global__ void __launch_bounds__(256) axpy_kernel(const double *__restrict__ r,
     }
 }
 
+
+// z-march (round 3): a workgroup owns an in-plane tile of 512 contiguous elements and walks a run of planes.  Per plane it loads
+// ONE window (512 + 2 D1 elements of the plane ahead) instead of three: the plane behind is the centre pair kept in a register,
+// the plane ahead is the centre of the window staged for the next step.  944 instead of 1974 elements through L1 / L2 per 512
+// rows (216^3).  Three LDS buffers in rotation, one barrier per step, DIST planes in flight in registers.
+// XCD x (= blockIdx.x % 8) owns TX consecutive tiles; a run is PS planes.
+template <int OCC, int DIST>
+__global__ void __launch_bounds__(256, OCC) march_kernel(const double *__restrict__ x, double *__restrict__ y, int D1, int D2, int G, int T,
+                                                         int TX, int PS) {
+    __shared__ d2 buf[3][512];
+    const int tid = threadIdx.x;
+    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+    const int tile = xcd * TX + local % TX, seg = local / TX;
+    if (tile >= T || local % TX >= TX) return;
+    const int k0 = seg * PS, k1 = min(k0 + PS, G);
+    if (k0 >= k1) return;
+    const int valid = min(512, D2 - tile * 512);
+    const int h1 = D1 >> 1;
+    const double *xt = x + (size_t)tile * 512 - D1 + 2 * tid;
+    auto ld = [&](int k, d2 &r0, d2 &r1) {
+        const double *b = xt + (ptrdiff_t)min(k, G) * D2;
+        r0 = *(const d2 *)b;
+        r1 = *(const d2 *)(b + (tid < D1 ? 512 : 0));
+    };
+    auto st = [&](int q, const d2 &r0, const d2 &r1) {
+        buf[q][tid] = r0;
+        if (tid < D1) buf[q][256 + tid] = r1;
+    };
+    d2 ra[DIST], rb[DIST], p0, p1;
+    ld(k0 - 1, p0, p1);
+    st(0, p0, p1);
+    ld(k0, p0, p1);
+    st(1, p0, p1);
+#pragma unroll
+    for (int i = 0; i < DIST; ++i) ld(k0 + 1 + i, ra[i], rb[i]);
+    __syncthreads();
+    d2 a = buf[0][h1 + tid];
+    int jb = 1;                                      // buffer of plane k
+    for (int k = k0; k < k1; k += DIST) {
+#pragma unroll
+        for (int i = 0; i < DIST; ++i) {
+            const int kk = k + i;
+            if (kk >= k1) break;
+            const int jn = jb == 2 ? 0 : jb + 1;     // buffer of plane kk + 1
+            st(jn, ra[i], rb[i]);
+            ld(kk + 1 + DIST, ra[i], rb[i]);
+            __syncthreads();
+            const double *w = (const double *)buf[jb] + D1 + 2 * tid;
+            const d2 g = buf[jn][h1 + tid];
+            const d2 bb = *(const d2 *)(w - D1), f = *(const d2 *)(w + D1);
+            const d2 d = *(const d2 *)w;
+            const double lo = w[-1], hi = w[2];
+            const d2 c = d2{lo, d.x}, e = d2{d.y, hi};
+            const d2 r = fold7(a, bb, c, d, e, f, g);
+            if (2 * tid < valid) __builtin_nontemporal_store(r, (d2 *)(y + (size_t)kk * D2 + (size_t)tile * 512 + 2 * tid));
+            a = d;
+            jb = jn;
+        }
+    }
+}
+
+// y = 6 x with the streaming shape of the vector kernels: what a plain pass over x + y costs on the same rotating buffers
+__global__ void __launch_bounds__(256) copy_kernel(const double *__restrict__ x, double *__restrict__ y, size_t n2) {
+    for (size_t i = blockIdx.x * 256 + threadIdx.x; i < n2; i += (size_t)gridDim.x * 256) {
+        const d2 v = ((const d2 *)x)[i];
+        __builtin_nontemporal_store(6.0 * v, (d2 *)y + i);
+    }
+}
+
 int main(int argc, char **argv) {
     const int G = argc > 1 ? atoi(argv[1]) : 216;
     const int D1 = G, D2 = G * G;
@@ -321,6 +390,24 @@ int main(int argc, char **argv) {
 #define LDS2(OCC, SC) run(SC == 3 ? "lds dist-2 sweep occ " #OCC : SC == 2 ? "lds dist-2 order[] occ " #OCC : "lds dist-2 occ " #OCC, [&](const double *x, double *y) { hipLaunchKernelGGL((lds2_kernel<OCC, SC>), dim3(256 * OCC), dim3(256), 0, 0, x, y, nsteps, D1, D2, SC == 3 ? d_sweep : d_order, sweep_per); }, true)
     bool first = true;
     DIRECT(6, 0);
+    if (getenv("PROBE_MARCH")) {
+    run("copy (16 B per lane)", [&](const double *x, double *y) { hipLaunchKernelGGL(copy_kernel, dim3(2048), dim3(256), 0, 0, x, y, n / 2); }, false);
+    first = true;
+    DIRECT(6, 0);
+    {
+        const int T = (D2 + 511) / 512, TX = (T + 7) / 8;
+#define MARCH(OCC, DIST) do { const int S = std::max(1, (OCC * 256) / (8 * TX)), PS = (G + S - 1) / S; char nm[64]; snprintf(nm, sizeof nm, "march occ %d dist %d runs of %d", OCC, DIST, PS); \
+        run(nm, [&](const double *x, double *y) { hipLaunchKernelGGL((march_kernel<OCC, DIST>), dim3(8 * TX * S), dim3(256), 0, 0, x, y, D1, D2, G, T, TX, PS); }, true); } while (0)
+        MARCH(3, 1); MARCH(3, 2); MARCH(3, 3);
+        MARCH(4, 1); MARCH(4, 2); MARCH(4, 3); MARCH(4, 4);
+        MARCH(5, 2); MARCH(5, 3);
+        MARCH(6, 2); MARCH(6, 3); MARCH(6, 4);
+        MARCH(8, 2); MARCH(8, 3);
+    }
+    LDSK(3, 3);
+    LDSK(4, 3);
+        return 0;
+    }
     LDSK(3, 0);
     DIRECT(6, 2);
     LDSK(3, 2);
