@@ -59,6 +59,10 @@ def workload(name, row_begin=0, row_end=None):
         return "2M-row fp64 non-symmetric banded (5 bands), BiCGSTAB", wl.banded_nonsym(2000000, 99, row_begin, row_end)
     if name == "laplace3d_1m":   # the size of one rank's slab of the 216^3 problem at 8 GPUs
         return "108^3 7-pt Laplacian (1.26M rows)", wl.laplace3d(108, 108, 108, row_begin, row_end)
+    if name == "laplace3d_5m":   # ... at 2 GPUs
+        return "216x216x108 7-pt Laplacian (5.04M rows)", wl.laplace3d(216, 216, 108, row_begin, row_end)
+    if name == "laplace3d_2m5":  # ... at 4 GPUs
+        return "216x216x54 7-pt Laplacian (2.52M rows)", wl.laplace3d(216, 216, 54, row_begin, row_end)
     if name == "laplace3d_small":
         return "64^3 7-pt Laplacian (test size)", wl.laplace3d(64, 64, 64, row_begin, row_end)
     rand = {"random_spd_10m": (10000000, 16, "10M-row fp64 random SPD (~33 nnz/row, density 3.3e-6)"),

@@ -1791,6 +1791,7 @@ int sla_csr_kernel_info(sla_csr_t A, char *buf, int buflen) {
         const int64_t rps = A->rp64 ? 8 : 4;
         int64_t mb;
         if (c->spmv_algo == 1) mb = 12 * A->nnz + rps * (A->rows + 1);
+        else if (A->use_wdia && wd_on(A) && wd_march_on(A)) mb = 128 * 4 * (int64_t)A->wd_mg.T * A->wd_mg.planes;   // 16 lane masks per (tile, plane, wavefront)
         else if (A->use_wdia && wd_on(A) && wd_lds_on(A)) mb = 128 * (int64_t)A->nslices;   // 16 lane masks per slice
         else if (A->use_wdia && wd_on(A)) mb = A->nwent * (A->wd_vv ? 20 + 128 * 8 : 28) + 4 * ((int64_t)A->nslices + 1);
         else if (A->use_vdict && c->vdict) mb = A->nnz + 4 * (A->rows + 1);
@@ -1811,7 +1812,12 @@ int sla_csr_kernel_info(sla_csr_t A, char *buf, int buflen) {
             snprintf(buf + used, (size_t)buflen - used, " slices=%d panels=%d panel_cols=%d max_segment=%lld exact_fold=1 pacing=%s", A->tl_S, A->tl_P,
                      1 << A->tl_shift, (long long)A->tl_maxseg, A->ctx->xcd8 == 1 && A->ctx->tile_slack > 0 ? "on" : "off");
     }
-    if (A->use_wdia && wd_on(A) && wd_lds_on(A)) {   // LDS-window geometry: windows, staged 16-byte pairs per buffer (> 1024: the 6-load instantiation), pairs folded
+    if (A->use_wdia && wd_on(A) && wd_march_on(A)) {   // plane-march geometry
+        const size_t used = strlen(buf);
+        if (used + 1 < (size_t)buflen)
+            snprintf(buf + used, (size_t)buflen - used, " plane=%d planes=%d tiles=%d runs=%d(x%d planes) win_pairs=%d pairs=%d", A->wd_mg.D, A->wd_mg.planes,
+                     A->wd_mg.T, A->wd_mg.S, A->wd_mg.PS, A->wd_mg.pairs, A->wd_muni.n);
+    } else if (A->use_wdia && wd_on(A) && wd_lds_on(A)) {   // LDS-window geometry: windows, staged 16-byte pairs per buffer (> 1024: the 6-load instantiation), pairs folded
         const size_t used = strlen(buf);
         if (used + 1 < (size_t)buflen)
             snprintf(buf + used, (size_t)buflen - used, " windows=%d win_pairs=%d pairs=%d", A->wd_win.n, A->wd_win.pairs, A->wd_uni.n);

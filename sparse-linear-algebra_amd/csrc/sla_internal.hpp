@@ -410,9 +410,13 @@ namespace sla {
 // is the wave-sliced SpMV form of A enabled by the context's knobs?
 // (its workgroups need a few steps each to amortise the staging pipeline's fill: below that the gather kernel is faster -- 1 M-row
 // Poisson: 22 500 vs 21 300 it/s; SLA_WD_LDS=2 forces it)
-inline bool wd_lds_on(const sla_csr *A) { return A->wd_lds && !A->wd_vv && (A->ctx->wd_lds == 2 || (A->ctx->wd_lds == 1 && A->nblk_wd >= 16 * 4 * A->ctx->n_cu)); }
+// (LDS windows: from 8 steps per workgroup on -- 16 before the y store moved behind the end-of-step wait, round 3)
+inline bool wd_lds_on(const sla_csr *A) { return A->wd_lds && !A->wd_vv && (A->ctx->wd_lds == 2 || (A->ctx->wd_lds == 1 && A->nblk_wd >= 8 * 4 * A->ctx->n_cu)); }
+// (plane march: from ~2 M rows and 48 planes on -- measured on 216 x 216 x k: k = 27: 17.9 k against 18.4 k it/s for the gather
+// kernel, k = 54: 12.9-13.0 k against 12.5 k, k = 108: 7.6 k against 7.3 k, profiles/r03_ab_slab_forms.txt)
 inline bool wd_march_on(const sla_csr *A) {
-    return A->wd_march && wd_lds_on(A) && A->ctx->wd_march >= 1 && A->ctx->spmv_algo == 0 && (A->ctx->wd_march == 2 || A->wd_mg.planes >= 32);
+    if (!A->wd_march || A->wd_vv || A->ctx->wd_march < 1 || A->ctx->wd_lds < 1 || A->ctx->spmv_algo != 0) return false;
+    return A->ctx->wd_march == 2 || (A->wd_mg.planes >= 48 && A->nblk_wd >= 4 * 4 * A->ctx->n_cu);
 }
 // does the plain CSR-stream form of A stage an x window in LDS (spmv_xwin_kernel)?  Only without the paired loads of
 // spmv_stream_kernel (stream_wide, default): with them the plain kernel is the faster one (round 3: K1 222-231 vs 232-241 us,

@@ -14,10 +14,6 @@
 #include "sla_internal.hpp"
 #include "sla_device.hpp"
 
-#ifndef SLA_STREAM_PRE_OPERANDS
-#define SLA_STREAM_PRE_OPERANDS 1   // (0: operands loaded inside the epilogue, the round-2 order; A/B builds)
-#endif
-
 namespace sla {
 
 typedef int sla_i32x2 __attribute__((ext_vector_type(2)));
@@ -126,7 +122,7 @@ __global__ void __launch_bounds__(kBlock, 8) spmv_stream_kernel(SpmvArgs<RP> a, 
                 // wait, was tried with it: four more VGPRs, the four-sum instantiation spills at 64 -- K3 back at 269 us.)
                 const bool lane_per_row = nrows > 64 || cnt <= 8 * nrows;
                 double wpre = 0.0, zpre = 0.0;
-                if (SLA_STREAM_PRE_OPERANDS == 1 && lane_per_row && tid < nrows) spmv_operands<EPI, RP>(a, r0 + tid, wpre, zpre);
+                if (lane_per_row && tid < nrows) spmv_operands<EPI, RP>(a, r0 + tid, wpre, zpre);
                 if (SLA_WIDE_OK(k0, k1)) {
                     const int odd = (int)(k0 & 1);
 #pragma unroll
@@ -152,7 +148,6 @@ __global__ void __launch_bounds__(kBlock, 8) spmv_stream_kernel(SpmvArgs<RP> a, 
                         // ascending left fold per row
                         double acc = a.yinit ? a.yinit[r0 + tid] : 0.0;
                         for (int k = s; k < e; ++k) acc += prod[k];
-                        if (!SLA_STREAM_PRE_OPERANDS) spmv_operands<EPI, RP>(a, r0 + tid, wpre, zpre);
                         spmv_epilogue_pre<EPI, RP>(a, r0 + tid, acc, coef, acc1, acc2, wpre, zpre);
                     }
                 } else {

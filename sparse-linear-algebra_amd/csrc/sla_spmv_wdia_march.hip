@@ -15,7 +15,9 @@
 //     march order, 128 bytes per (tile, plane, wavefront), rows outside the plane / the matrix with empty masks;
 //   * the window of plane k + 2, the epilogue operands of step k + 1 and the masks of step k are issued together and are in flight
 //     while step k is folded: one memory round trip per step, as in spmv_wdia_lds_kernel, with half the bytes; the step loop is
-//     unrolled four times so that the buffer of every pair is a compile-time offset;
+//     unrolled four times so that the buffer of every pair is a compile-time offset.  (Two planes in flight -- a second register
+//     set, counted waits -- measured same-box: K1 47.5 -> 49-50 us; the four-sum K3 then needs 133 VGPRs and drops to three
+//     workgroups per CU: 48.4 -> 59.6 us, profiles/r03_ab_march.txt);
 //   * fold order, roundings and epilogues are spmv_wdia_kernel's (shared wd_epilogue): every row bit-identical to the other forms
 //     (tests/test_gpu_value_indexed.py).  The partial sums of the fused dot products are grouped by task instead of by step.
 // Taken for 5- and 7-pair stencils (one pair at -D, one at +D) on unsharded matrices (sla_api.cpp: low_wave_sliced).
@@ -108,6 +110,7 @@ __global__ void __launch_bounds__(kBlock, 3) spmv_wdia_march_kernel(SpmvArgs<int
         ld(k0, pb0, pb1);
         ld(k0 + 1, r0, r1);
         load_operands(k0 * m.D + pos, wv, zv);
+
         if (first) {
             // (the prologue's loads -- solver scalars, partials -- share the round trip of the first windows)
             if (!spmv_prologue<EPI, int32_t>(a, s_red, coef)) return;

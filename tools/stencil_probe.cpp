@@ -306,6 +306,67 @@ __global__ void __launch_bounds__(256, OCC) march_kernel(const double *__restric
     }
 }
 
+// z-march with K2 folded into the staging (round 3): the window of r - alpha v is formed on the fly (two staging loads per vector and
+// lane instead of two), own rows of s written for K4+K5.  Product structure: one round trip per step, the wait in front of the stores.
+// FUSED = false: the same kernel on a precomputed s (what spmv_wdia_march_kernel does).
+template <int OCC, bool FUSED>
+__global__ void __launch_bounds__(256, OCC) march2_kernel(const double *__restrict__ r, const double *__restrict__ v, double alpha,
+                                                          double *__restrict__ sout, double *__restrict__ y, int D1, int D2, int G, int T, int TX, int PS) {
+    __shared__ d2 buf[4][512];
+    const int tid = threadIdx.x;
+    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+    const int tile = xcd * TX + local % TX, seg = local / TX;
+    if (tile >= T) return;
+    const int k0 = seg * PS, k1 = min(k0 + PS, G);
+    if (k0 >= k1) return;
+    const int valid = min(512, D2 - tile * 512);
+    const int h1 = D1 >> 1;
+    const size_t xo = (size_t)tile * 512 - D1 + 2 * tid;
+    const int second = tid < D1 ? 512 : 0;
+    d2 a0, a1, b0, b1;
+    auto ld = [&](int k) {
+        const ptrdiff_t o = (ptrdiff_t)min(k, G) * D2 + (ptrdiff_t)xo;
+        a0 = *(const d2 *)(r + o);
+        a1 = *(const d2 *)(r + o + second);
+        if (FUSED) { b0 = *(const d2 *)(v + o); b1 = *(const d2 *)(v + o + second); }
+    };
+    // own rows of the window: pairs [h1, h1 + 256): lane tid >= h1 holds one as its first pair, lane tid < h1 as its second
+    auto st = [&](int q, int k, bool own) {
+#pragma clang fp contract(off)
+        d2 s0 = a0, s1 = a1;
+        if (FUSED) { s0 = a0 - alpha * b0; s1 = a1 - alpha * b1; }
+        buf[q][tid] = s0;
+        if (tid < D1) buf[q][256 + tid] = s1;
+        if (FUSED && own) {
+            const int pr = tid >= h1 ? tid - h1 : tid + 256 - h1;       // this lane's own pair inside the tile
+            if (2 * pr < valid) *(d2 *)(sout + (size_t)k * D2 + (size_t)tile * 512 + 2 * pr) = tid >= h1 ? s0 : s1;
+        }
+    };
+    ld(k0 - 1); st(3, k0 - 1, false);
+    ld(k0); st(0, k0, true);
+    ld(k0 + 1); st(1, k0 + 1, k0 + 1 < k1);
+    __syncthreads();
+    for (int k = k0; k < k1; k += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int kk = k + u;
+            if (kk >= k1) break;
+            ld(min(kk + 2, k1));
+            const double *w = (const double *)buf[u] + D1 + 2 * tid;
+            const d2 a = buf[(u + 3) & 3][h1 + tid], g = buf[(u + 1) & 3][h1 + tid];
+            const d2 bb = *(const d2 *)(w - D1), f = *(const d2 *)(w + D1);
+            const d2 d = *(const d2 *)w;
+            const double lo = w[-1], hi = w[2];
+            const d2 c = d2{lo, d.x}, e = d2{d.y, hi};
+            const d2 res = fold7(a, bb, c, d, e, f, g);
+            __builtin_amdgcn_s_waitcnt(0x0f70);
+            st((u + 2) & 3, kk + 2, kk + 2 < k1);
+            if (2 * tid < valid) __builtin_nontemporal_store(res, (d2 *)(y + (size_t)kk * D2 + (size_t)tile * 512 + 2 * tid));
+            __syncthreads();
+        }
+    }
+}
+
 // y = 6 x with the streaming shape of the vector kernels: what a plain pass over x + y costs on the same rotating buffers
 __global__ void __launch_bounds__(256) copy_kernel(const double *__restrict__ x, double *__restrict__ y, size_t n2) {
     for (size_t i = blockIdx.x * 256 + threadIdx.x; i < n2; i += (size_t)gridDim.x * 256) {
@@ -390,7 +451,8 @@ int main(int argc, char **argv) {
 #define LDS2(OCC, SC) run(SC == 3 ? "lds dist-2 sweep occ " #OCC : SC == 2 ? "lds dist-2 order[] occ " #OCC : "lds dist-2 occ " #OCC, [&](const double *x, double *y) { hipLaunchKernelGGL((lds2_kernel<OCC, SC>), dim3(256 * OCC), dim3(256), 0, 0, x, y, nsteps, D1, D2, SC == 3 ? d_sweep : d_order, sweep_per); }, true)
     bool first = true;
     DIRECT(6, 0);
-    if (getenv("PROBE_MARCH")) {
+    const bool only_k23 = getenv("PROBE_K23") != nullptr;
+    if (getenv("PROBE_MARCH") && !only_k23) {
     run("copy (16 B per lane)", [&](const double *x, double *y) { hipLaunchKernelGGL(copy_kernel, dim3(2048), dim3(256), 0, 0, x, y, n / 2); }, false);
     first = true;
     DIRECT(6, 0);
@@ -408,6 +470,7 @@ int main(int argc, char **argv) {
     LDSK(4, 3);
         return 0;
     }
+    if (!only_k23) {
     LDSK(3, 0);
     DIRECT(6, 2);
     LDSK(3, 2);
@@ -429,6 +492,7 @@ int main(int argc, char **argv) {
         LDSK(4, 1);
     }
 
+    }
     {   // K2 + K3: separate (axpy kernel, then the staged SpMV on its result) vs folded into the staging
         double *dv[pairs], *ds[pairs];
         for (int i = 0; i < pairs; ++i) {
@@ -457,6 +521,19 @@ int main(int argc, char **argv) {
         auto fus = both("fused", [&](int i) {
             hipLaunchKernelGGL((lds_axpy_kernel<4, 2>), dim3(1024), dim3(256), 0, 0, dx[i] + pad, dv[i] + pad, alpha, ds[i] + pad, dy[i], nsteps, D1, D2, d_order, sweep_per);
         });
+        {
+            const int T = (D2 + 511) / 512, TX = (T + 7) / 8;
+            const int S = std::max(1, (4 * 256) / (8 * TX)), PS = (G + S - 1) / S;
+            auto msep = both("march separate", [&](int i) {
+                hipLaunchKernelGGL(axpy_kernel, dim3(2048), dim3(256), 0, 0, dx[i], dv[i], alpha, ds[i], (n + 2 * pad) / 2);
+                hipLaunchKernelGGL((march2_kernel<4, false>), dim3(8 * TX * S), dim3(256), 0, 0, ds[i] + pad, dv[i] + pad, alpha, ds[i] + pad, dy[i], D1, D2, G, T, TX, PS);
+            });
+            auto mfus = both("march fused", [&](int i) {
+                hipLaunchKernelGGL((march2_kernel<4, true>), dim3(8 * TX * S), dim3(256), 0, 0, dx[i] + pad, dv[i] + pad, alpha, ds[i] + pad, dy[i], D1, D2, G, T, TX, PS);
+            });
+            printf("K2 + K3, plane march, rotating %d vector sets: separate kernels %.1f us, K2 folded into the staging %.1f us%s\n", pairs, msep.first,
+                   mfus.first, memcmp(msep.second.data(), mfus.second.data(), n * 8) == 0 ? "  (y bit-identical)" : "  (y MISMATCH)");
+        }
         printf("K2 + K3, product order, rotating %d vector sets: separate kernels %.1f us, K2 folded into the staging %.1f us%s\n", pairs, sep.first,
                fus.first, memcmp(sep.second.data(), fus.second.data(), n * 8) == 0 ? "  (y bit-identical)" : "  (y MISMATCH)");
     }
