@@ -17,7 +17,8 @@
 //     while step k is folded: one memory round trip per step, as in spmv_wdia_lds_kernel, with half the bytes; the step loop is
 //     unrolled four times so that the buffer of every pair is a compile-time offset.  (Two planes in flight -- a second register
 //     set, counted waits -- measured same-box: K1 47.5 -> 49-50 us; the four-sum K3 then needs 133 VGPRs and drops to three
-//     workgroups per CU: 48.4 -> 59.6 us, profiles/r03_ab_march.txt);
+//     workgroups per CU: 48.4 -> 59.6 us; staging at the TOP of a step with compiler-counted waits, the loads in flight across
+//     the barrier: K1 45.0 -> 46.3 us; profiles/r03_ab_march.txt);
 //   * fold order, roundings and epilogues are spmv_wdia_kernel's (shared wd_epilogue): every row bit-identical to the other forms
 //     (tests/test_gpu_value_indexed.py).  The partial sums of the fused dot products are grouped by task instead of by step.
 // Taken for 5- and 7-pair stencils (one pair at -D, one at +D) on unsharded matrices (sla_api.cpp: low_wave_sliced).
