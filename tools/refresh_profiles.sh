@@ -78,4 +78,25 @@ PY
 done
 # the bare 7-pt access pattern: gathers vs LDS-staged windows, visiting orders (tools/stencil_probe.cpp)
 [ -x tools/stencil_probe ] && { timeout 120 tools/stencil_probe 216; timeout 120 tools/stencil_probe 256; } > $S/${tag}_stencil_probe.txt 2>&1
+# ... and the plane march: tile sizes, planes in flight (PROBE_MARCH), the fused K2 + K3 variants are the last lines of the file above
+[ -x tools/stencil_probe ] && { PROBE_MARCH=1 timeout 120 tools/stencil_probe 216; PROBE_MARCH=1 timeout 120 tools/stencil_probe 256; } > $S/${tag}_stencil_march_probe.txt 2>&1
+# the K4+K5 sweep's shape on rotating vector sets (nothing cached): loads / stores plain or non-temporal, in place, pipelined
+[ -x tools/sweep_probe ] && timeout 120 tools/sweep_probe > $S/${tag}_sweep_probe.txt 2>&1
+# same-box A/B of the stencil forms on the headline (gather / LDS windows / plane march) and on slab-sized problems
+bash tools/ab_march2.sh > $S/${tag}_ab_march_knobs.txt 2>&1
+bash tools/ab_slab.sh > $S/${tag}_ab_slab_forms.txt 2>&1
+# L1 <-> L2 request counters of the plane-march kernel (default workload)
+for set in "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_PENDING_STALL_CYCLES_sum TCP_GATE_EN1_sum" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES" "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_REQ_sum"; do
+  d=$S/pmc_tmp; rm -rf $d; mkdir -p $d
+  timeout 600 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $d -o p -- python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-extra-blocks > /dev/null 2>&1
+  python - "$d" wdia_march <<'PY' >> $S/${tag}_pmc_l1_l2_march_kernel.txt
+import csv, glob, collections, sys
+for f in sorted(glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True)):
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(f)):
+        agg[r["Kernel_Name"][:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for k, cs in agg.items():
+        if sys.argv[2] in k: print(k, {c: (len(v), sum(v) / len(v)) for c, v in cs.items()})
+PY
+done
 ls -la $S | head -40
