@@ -14,6 +14,14 @@
 
 namespace sla {
 
+// per-stream cache policy of the two BiCGSTAB sweeps at sizes that overflow the memory-side cache (ctx option vec_policy; bit set = the
+// stream goes past the caches).  K2: 0 r, 1 Ap, 2 s (store).  K4+K5: 3 s, 4 As, 5 Ap, 6 p, 7 x, 8 x (store), 9 r (store), 10 p (store).
+__device__ __forceinline__ double2 ldpol(const double *p, int64_t i2, int pol, int bit) { return (pol >> bit) & 1 ? ld2_nt(p, i2) : ld2_t(p, i2); }
+__device__ __forceinline__ void stpol(double *p, int64_t i2, double2 v, int pol, int bit) {
+    if ((pol >> bit) & 1) st2_nt(p, i2, v);
+    else st2_t(p, i2, v);
+}
+
 // ---------------------------------------------------------------------------------------------
 // streaming BLAS-1 kernels: 16 bytes per lane (double2), grid-stride, <= kVecGridMax workgroups
 // ---------------------------------------------------------------------------------------------
@@ -120,7 +128,7 @@ int launch_fill(sla_ctx *c, int64_t n, double a, double *x) {
 template <bool NT>
 __global__ void __launch_bounds__(kBlock) bicg_k2_kernel(int64_t n, SolverScalars *sc, Parts apr, int par,
                                                           Parts res, int count_iter, const double *r,
-                                                          const double *ap, double *s) {
+                                                          const double *ap, double *s, int pol) {
     __shared__ double s_red[4];
     // everything the head of the kernel needs is issued before any of it is waited for: the scalars, the partials of
     // Ap . r0hat and the first element pair of the sweep (one round trip instead of three in a row, with HBM already streaming)
@@ -131,7 +139,7 @@ __global__ void __launch_bounds__(kBlock) bicg_k2_kernel(int64_t n, SolverScalar
     parts_issue(apr.p, apr.n, apr.stride, pv);
     const int64_t i0c = n2 > 0 ? min(i0, n2 - 1) : 0;   // (clamped: the loads are unconditional)
     double2 a = make_double2(0.0, 0.0), b = a;
-    if (n2 > 0) { a = ld2s<NT>(r, i0c); b = ld2s<NT>(ap, i0c); }
+    if (n2 > 0) { a = ldpol(r, i0c, pol, 0); b = ldpol(ap, i0c, pol, 1); }
     if (done) return;
     // dual-SpMV flow: K1 of THIS step also evaluated the previous step's true residual; test it here
     if (res.p && residual_converged(sc, res.p, res.n, res.stride, s_red)) return;
@@ -139,8 +147,8 @@ __global__ void __launch_bounds__(kBlock) bicg_k2_kernel(int64_t n, SolverScalar
     const double alpha = rho / block_sum(parts_fold(pv, apr.n), s_red);
     if (blockIdx.x == 0 && threadIdx.x == 0) sc->alpha = alpha;
     for (int64_t i2 = i0; i2 < n2; i2 += gs) {
-        if (i2 != i0) { a = ld2s<NT>(r, i2); b = ld2s<NT>(ap, i2); }
-        st2(s, i2, make_double2(a.x - alpha * b.x, a.y - alpha * b.y));
+        if (i2 != i0) { a = ldpol(r, i2, pol, 0); b = ldpol(ap, i2, pol, 1); }
+        stpol(s, i2, make_double2(a.x - alpha * b.x, a.y - alpha * b.y), pol, 2);
     }
     if (SLA_HAS_TAIL(n)) s[n - 1] = r[n - 1] - alpha * ap[n - 1];
 }
@@ -192,7 +200,7 @@ __global__ void __launch_bounds__(kBlock) bicg_k4_kernel(int64_t n, SolverScalar
 template <bool NT>
 __global__ void __launch_bounds__(kBlock) bicg_k45_kernel(int64_t n, SolverScalars *sc, Parts ass, Parts asas, Parts tr0, Parts sr0,
                                                            int par, const double *s, const double *as, const double *ap, double *x,
-                                                           double *r, double *p) {
+                                                           double *r, double *p, int pol) {
     __shared__ double s_red[16];
     // the four sums, the scalars and the first element pairs of the five input vectors are issued together (see bicg_k2_kernel)
     const int64_t n2 = n >> 1, gs = (int64_t)gridDim.x * kBlock, i0 = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -205,7 +213,7 @@ __global__ void __launch_bounds__(kBlock) bicg_k45_kernel(int64_t n, SolverScala
     parts_issue(sr0.p, sr0.n, sr0.stride, q3);
     const int64_t i0c = n2 > 0 ? min(i0, n2 - 1) : 0;
     double2 sv = make_double2(0.0, 0.0), av = sv, vv = sv, pv = sv, xv = sv;
-    if (n2 > 0) { sv = ld2s<NT>(s, i0c); av = ld2s<NT>(as, i0c); vv = ld2s<NT>(ap, i0c); pv = ld2s<NT>(p, i0c); xv = ld2s<NT>(x, i0c); }
+    if (n2 > 0) { sv = ldpol(s, i0c, pol, 3); av = ldpol(as, i0c, pol, 4); vv = ldpol(ap, i0c, pol, 5); pv = ldpol(p, i0c, pol, 6); xv = ldpol(x, i0c, pol, 7); }
     if (done) return;
     double sums[4] = {parts_fold(q0, ass.n), parts_fold(q1, asas.n), parts_fold(q2, tr0.n), parts_fold(q3, sr0.n)};
     block_sum_multi<4>(sums, s_red);
@@ -219,17 +227,15 @@ __global__ void __launch_bounds__(kBlock) bicg_k45_kernel(int64_t n, SolverScala
         sc->rho2[par ^ 1] = rn;
     }
     for (int64_t i2 = i0; i2 < n2; i2 += gs) {
-        if (i2 != i0) { sv = ld2s<NT>(s, i2); av = ld2s<NT>(as, i2); vv = ld2s<NT>(ap, i2); pv = ld2s<NT>(p, i2); xv = ld2s<NT>(x, i2); }
+        if (i2 != i0) { sv = ldpol(s, i2, pol, 3); av = ldpol(as, i2, pol, 4); vv = ldpol(ap, i2, pol, 5); pv = ldpol(p, i2, pol, 6); xv = ldpol(x, i2, pol, 7); }
         xv.x = (xv.x + alpha * pv.x) + omega * sv.x;
         xv.y = (xv.y + alpha * pv.y) + omega * sv.y;
-        if (NT) st2_nt(x, i2, xv);  // nobody reads x before the next step's sweep
-        else st2(x, i2, xv);
+        stpol(x, i2, xv, pol, 8);   // (default past the caches: nobody reads x before the next step's sweep)
         const double2 rv = make_double2(sv.x - omega * av.x, sv.y - omega * av.y);
-        if (NT) st2_nt(r, i2, rv);  // r is next read by K2, after K1 has streamed 250 MB: only p (K1's x) should stay cached
-        else st2(r, i2, rv);
+        stpol(r, i2, rv, pol, 9);   // (default past the caches: r is next read by K2, after K1 has streamed 250 MB; only p, K1's x, should stay)
         pv.x = rv.x + beta * (pv.x - omega * vv.x);
         pv.y = rv.y + beta * (pv.y - omega * vv.y);
-        st2(p, i2, pv);
+        stpol(p, i2, pv, pol, 10);
     }
     if (SLA_HAS_TAIL(n)) {
         const int64_t i = n - 1;
@@ -264,9 +270,9 @@ int launch_bicg_k2(sla_ctx *c, int64_t n, SolverScalars *sc, Parts apr, int par,
                    const double *r, const double *ap, double *s) {
     ProfScope prof(c, SLA_KERNEL_BICG_K2);
     if (vec_stream_nt(c, n))
-        hipLaunchKernelGGL(bicg_k2_kernel<true>, dim3(vec_grid(n)), dim3(kBlock), 0, stream_of(c), n, sc, apr, par, res, count_iter, r, ap, s);
+        hipLaunchKernelGGL(bicg_k2_kernel<true>, dim3(vec_grid(n)), dim3(kBlock), 0, stream_of(c), n, sc, apr, par, res, count_iter, r, ap, s, c->vec_policy);
     else
-        hipLaunchKernelGGL(bicg_k2_kernel<false>, dim3(vec_grid(n)), dim3(kBlock), 0, stream_of(c), n, sc, apr, par, res, count_iter, r, ap, s);
+        hipLaunchKernelGGL(bicg_k2_kernel<false>, dim3(vec_grid(n)), dim3(kBlock), 0, stream_of(c), n, sc, apr, par, res, count_iter, r, ap, s, 0);
     SLA_HIP_TRY(hipGetLastError());
     return SLA_OK;
 }
@@ -293,9 +299,9 @@ int launch_bicg_k45(sla_ctx *c, int64_t n, SolverScalars *sc, Parts ass, Parts a
                     const double *as, const double *ap, double *x, double *r, double *p) {
     ProfScope prof(c, SLA_KERNEL_BICG_K45);
     if (vec_stream_nt(c, n))
-        hipLaunchKernelGGL(bicg_k45_kernel<true>, dim3(vec_grid(n)), dim3(kBlock), 0, stream_of(c), n, sc, ass, asas, tr0, sr0, par, s, as, ap, x, r, p);
+        hipLaunchKernelGGL(bicg_k45_kernel<true>, dim3(vec_grid(n)), dim3(kBlock), 0, stream_of(c), n, sc, ass, asas, tr0, sr0, par, s, as, ap, x, r, p, c->vec_policy);
     else
-        hipLaunchKernelGGL(bicg_k45_kernel<false>, dim3(vec_grid(n)), dim3(kBlock), 0, stream_of(c), n, sc, ass, asas, tr0, sr0, par, s, as, ap, x, r, p);
+        hipLaunchKernelGGL(bicg_k45_kernel<false>, dim3(vec_grid(n)), dim3(kBlock), 0, stream_of(c), n, sc, ass, asas, tr0, sr0, par, s, as, ap, x, r, p, 0);
     SLA_HIP_TRY(hipGetLastError());
     return SLA_OK;
 }
