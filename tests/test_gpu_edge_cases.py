@@ -111,7 +111,7 @@ def test_rerun_is_bit_identical(sla):
     assert np.array_equal(a, c)                                       # deterministic two-stage reductions
 
 
-def test_dual_spmv_flow_equals_three_sweep_flow(sla, monkeypatch):
+def test_dual_spmv_flow_equals_three_sweep_flow(sla):
     """linSolve0 with the true residual fused into the next K1 (default) must return exactly what the
     three-SpMV-per-iteration flow returns: same iterate, same iteration count, same residual."""
     from sla_amd import workloads as wl
@@ -120,8 +120,7 @@ def test_dual_spmv_flow_equals_three_sweep_flow(sla, monkeypatch):
     b = np.random.default_rng(4).standard_normal(n)
     res = []
     for dual in ("1", "0"):
-        monkeypatch.setenv("SLA_DUAL_SPMV", dual)
-        ctx = sla.Context(0)
+        ctx = sla.Context(0).set_option("dual_spmv", dual)
         A = sla.fromCSR(dims, rp, ci, va, ctx)
         for meth in (sla.BICGSTAB_, sla.CGS_):
             for ce in (16, 5, 1):
@@ -161,7 +160,7 @@ def test_consecutive_long_rows_wave_per_row_and_block_per_row(sla):
 
 
 @pytest.mark.parametrize("policy", [0, 1])
-def test_device_coo_sort_equals_host_builder_and_oracle(sla, monkeypatch, policy):
+def test_device_coo_sort_equals_host_builder_and_oracle(sla, policy):
     """Large triple lists are sorted / deduplicated on the GPU (rocPRIM radix sort); the result must be
     bit-identical to the host builder and, for last-wins, to the oracle's fromListSM restatement."""
     rng = np.random.default_rng(77)
@@ -172,8 +171,7 @@ def test_device_coo_sort_equals_host_builder_and_oracle(sla, monkeypatch, policy
     v = rng.standard_normal(nnz)
     outs = []
     for thr in ("1", str(1 << 40)):                       # device path, host path
-        monkeypatch.setenv("SLA_DEVICE_COO_MIN", thr)
-        ctx = sla.Context(0)
+        ctx = sla.Context(0).set_option("device_coo_min", thr)
         A = sla.fromCOO((m, n), r, c, v, ctx, dup_policy=policy)
         outs.append(tuple(a.copy() for a in A.csr()))
         del A
@@ -183,14 +181,13 @@ def test_device_coo_sort_equals_host_builder_and_oracle(sla, monkeypatch, policy
     if policy == 0:
         rc, Ao = orc.coo_to_csr(m, n, r, c, v)
         assert np.array_equal(outs[0][0], Ao.rowptr) and np.array_equal(outs[0][1], Ao.colidx) and np.array_equal(outs[0][2], Ao.val)
-    monkeypatch.setenv("SLA_DEVICE_COO_MIN", "1")
-    ctx = sla.Context(0)
+    ctx = sla.Context(0).set_option("device_coo_min", 1)
     with pytest.raises(sla.IndexOutOfBounds):
         sla.fromCOO((4, 4), [0, 4], [0, 0], [1.0, 1.0], ctx)
     ctx.close()
 
 
-def test_column_panel_spmv_equals_plain_path(sla, monkeypatch):
+def test_column_panel_spmv_equals_plain_path(sla):
     """Irregular matrices whose x does not fit the L2 are swept in column panels (y += A_p x in ascending panel
     order, each pass continuing the row's running sum).  Forced here with tiny panels: the result must equal the
     un-panelled path bit for bit on short rows, and the solvers must behave identically."""
@@ -202,12 +199,8 @@ def test_column_panel_spmv_equals_plain_path(sla, monkeypatch):
     x = rng.standard_normal(n)
     b = orc.spmv(Ao, rng.standard_normal(n))
     res = {}
-    for mode, env in (("panels", {"SLA_PANEL_COLS": "500"}), ("plain", {"SLA_PANELS": "0"})):
-        for k in ("SLA_PANEL_COLS", "SLA_PANELS"):
-            monkeypatch.delenv(k, raising=False)
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
-        ctx = sla.Context(0)
+    for mode, opts in (("panels", {"panel_cols": 500}), ("plain", {"panels": 0})):
+        ctx = sla.Context(0).set_options(**opts)
         A = sla.fromCSR(dims, rp, ci, va, ctx)
         assert ("colpanels" in A.kernel_info()) == (mode == "panels"), A.kernel_info()
         y = sla.matVec(A, sla.fromVector(x, ctx)).toDenseListSV()
@@ -234,7 +227,7 @@ def test_column_panel_spmv_equals_plain_path(sla, monkeypatch):
             assert abs(a - b_) <= 1e-6 * max(abs(b_), 1e-6)
 
 
-def test_column_panels_with_long_and_mid_rows(sla, monkeypatch):
+def test_column_panels_with_long_and_mid_rows(sla):
     rng = np.random.default_rng(31)
     m = n = 6000
     lens = rng.choice([0, 2, 9, 40, 300, 1500, 5000], size=m, p=[0.05, 0.5, 0.3, 0.1, 0.03, 0.015, 0.005])
@@ -244,15 +237,13 @@ def test_column_panels_with_long_and_mid_rows(sla, monkeypatch):
             cj = rng.choice(n, size=int(k), replace=False)
             rows.append(np.full(int(k), i)); cols.append(cj); vals.append(rng.standard_normal(int(k)))
     r, c, v = np.concatenate(rows), np.concatenate(cols), np.concatenate(vals)
-    monkeypatch.setenv("SLA_PANEL_COLS", "700")
     rc, Ao = orc.coo_to_csr(m, n, r, c, v)
     x = rng.standard_normal(n)
     yo = orc.spmv(Ao, x)
     bound = (np.diff(Ao.rowptr) + 8) * np.finfo(float).eps * orc.spmv(orc.Csr(m, n, Ao.rowptr, Ao.colidx, np.abs(Ao.val)), np.abs(x))
     # (52 entries per row on average and x fits one LDS panel: the lowering prefers the LDS-panel form by default)
     for lpanel, form in (("0", "colpanels"), ("1", "ldspanels")):
-        monkeypatch.setenv("SLA_LPANEL", lpanel)
-        ctx = sla.Context(0)
+        ctx = sla.Context(0).set_options(panel_cols=700, lpanel=lpanel)
         A = sla.fromCOO((m, n), r, c, v, ctx)
         assert form in A.kernel_info()
         y = sla.matVec(A, sla.fromVector(x, ctx)).toDenseListSV()
@@ -261,9 +252,9 @@ def test_column_panels_with_long_and_mid_rows(sla, monkeypatch):
         ctx.close()
 
 
-def test_64_bit_row_pointer_kernels(sla, monkeypatch):
+def test_64_bit_row_pointer_kernels(sla):
     """Matrices with more than 2^31 - 1 stored entries switch every general kernel to its int64 row-pointer
-    instantiation (the value-indexed forms are 32-bit only and step aside).  SLA_FORCE_RP64=1 runs those instantiations
+    instantiation (the value-indexed forms are 32-bit only and step aside).  the option force_rp64=1 runs those instantiations
     at test sizes: stencil (stream + dictionary codes + x window), irregular short rows (stream, column panels), dense
     rows (LDS panels) and rows at the row-block limits, (#>), (<#) and the solver epilogues against the oracle."""
     from sla_amd import workloads as wl
@@ -284,33 +275,26 @@ def test_64_bit_row_pointer_kernels(sla, monkeypatch):
 
     cases = {
         "laplace3d": (wl.laplace3d(13, 9, 11), {}, "diagdict"),
-        "laplace3d, plain stream": (wl.laplace3d(13, 9, 11), {"SLA_DIAG": "0", "SLA_XWIN": "0"}, "algo=stream "),
+        "laplace3d, plain stream": (wl.laplace3d(13, 9, 11), {"diag": 0, "xwin": 0}, "algo=stream "),
         "random_spd short rows": (wl.random_spd(3000, 4, 3), {}, "algo=stream"),
-        "laplace3d, x window (narrow loads)": (wl.laplace3d(13, 9, 11), {"SLA_DIAG": "0", "SLA_STREAM_WIDE": "0"}, "algo=stream+xwin"),
-        "random_spd, narrow loads": (wl.random_spd(3000, 4, 3), {"SLA_STREAM_WIDE": "0"}, "algo=stream"),
-        "laplace3d, pipelined stream": (wl.laplace3d(13, 9, 11), {"SLA_DIAG": "0", "SLA_STREAM_PIPE": "1"}, "algo=stream+pipe"),
-        "random_spd, pipelined stream": (wl.random_spd(3000, 4, 3), {"SLA_STREAM_PIPE": "1"}, "algo=stream+pipe"),
-        "random_spd, column panels": (wl.random_spd(5000, 6, 4), {"SLA_PANEL_COLS": "600"}, "colpanels"),
+        "laplace3d, x window (narrow loads)": (wl.laplace3d(13, 9, 11), {"diag": 0, "stream_wide": 0}, "algo=stream+xwin"),
+        "random_spd, narrow loads": (wl.random_spd(3000, 4, 3), {"stream_wide": 0}, "algo=stream"),
+        "laplace3d, pipelined stream": (wl.laplace3d(13, 9, 11), {"diag": 0, "stream_pipe": 1}, "algo=stream+pipe"),
+        "random_spd, pipelined stream": (wl.random_spd(3000, 4, 3), {"stream_pipe": 1}, "algo=stream+pipe"),
+        "random_spd, column panels": (wl.random_spd(5000, 6, 4), {"panel_cols": 600}, "colpanels"),
         "dense rows, LDS panels": (dense_rows(900, 20000, 120), {}, "ldspanels"),
-        "row-block limits": (limits(), {"SLA_LPANEL": "0"}, "algo=stream"),
-        "scalar kernel": (wl.random_spd(2000, 5, 6), {"SLA_SPMV_ALGO": "scalar"}, "scalar"),
+        "row-block limits": (limits(), {"lpanel": 0}, "algo=stream"),
+        "scalar kernel": (wl.random_spd(2000, 5, 6), {"spmv_algo": "scalar"}, "scalar"),
     }
-    knobs = ("SLA_DIAG", "SLA_XWIN", "SLA_PANEL_COLS", "SLA_LPANEL", "SLA_SPMV_ALGO", "SLA_STREAM_PIPE", "SLA_STREAM_WIDE")
-    for name, ((dims, csr), env, form) in cases.items():
-        for k in knobs:
-            monkeypatch.delenv(k, raising=False)
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
-        monkeypatch.setenv("SLA_WDIA", "0")      # (the 32-bit run takes the same general form as the 64-bit one)
-        monkeypatch.setenv("SLA_VDICT", "0")
+    for name, ((dims, csr), opts, form) in cases.items():
+        opts = dict(opts, wdia=0, vdict=0)       # (the 32-bit run takes the same general form as the 64-bit one)
         m, n = dims
         Ao = orc.Csr(m, n, *csr)
         x, w = rng.standard_normal(n), rng.standard_normal(m)
         want, want_t = orc.spmv(Ao, x), orc.spmv(orc.transpose(Ao), w)
         res = {}
         for rp64 in ("1", "0"):
-            monkeypatch.setenv("SLA_FORCE_RP64", rp64)
-            ctx = sla.Context(0)
+            ctx = sla.Context(0).set_options(force_rp64=rp64, **opts)
             A = sla.fromCSR(dims, *csr, ctx)
             info = A.kernel_info()
             assert form in info + " " and ("rowptr=i64" in info) == (rp64 == "1"), (name, info)
@@ -331,19 +315,17 @@ def test_64_bit_row_pointer_kernels(sla, monkeypatch):
             assert np.array_equal(a, b_) if isinstance(a, np.ndarray) else a == b_, name
 
 
-def test_column_panel_views_keep_their_own_row_pointer_width(sla, monkeypatch):
+def test_column_panel_views_keep_their_own_row_pointer_width(sla):
     """a matrix with more than 2^31 - 1 entries has 64-bit row pointers while each of its column-panel
     views, holding a fraction of the entries, uses 32-bit ones; the panel passes must run the instantiation of the VIEW.
-    SLA_FORCE_RP64=2 forces the 64-bit width on the parent only, which reproduces that mix at test size."""
+    The option force_rp64=2 forces the 64-bit width on the parent only, which reproduces that mix at test size."""
     from sla_amd import workloads as wl
     dims, (rp, ci, va) = wl.random_spd(3000, 3, 11)
     n = dims[0]
     Ao = orc.Csr(n, n, rp, ci, va)
     x = np.random.default_rng(6).standard_normal(n)
     b = orc.spmv(Ao, np.random.default_rng(7).standard_normal(n))
-    monkeypatch.setenv("SLA_PANEL_COLS", "500")
-    monkeypatch.setenv("SLA_FORCE_RP64", "2")
-    ctx = sla.Context(0)
+    ctx = sla.Context(0).set_options(panel_cols=500, force_rp64=2)
     A = sla.fromCSR(dims, rp, ci, va, ctx)
     assert "colpanels" in A.kernel_info() and "rowptr=i64" in A.kernel_info(), A.kernel_info()
     assert np.array_equal(sla.matVec(A, sla.fromVector(x, ctx)).toDenseListSV(), orc.spmv(Ao, x))
@@ -351,7 +333,7 @@ def test_column_panel_views_keep_their_own_row_pointer_width(sla, monkeypatch):
     assert info["converged"] and np.linalg.norm(orc.spmv(Ao, xs.toDenseListSV()) - b) <= info["tol"] * (1 + 1e-9)
 
 
-def test_step_graph_replay_is_bit_identical_to_stream_launches(sla, monkeypatch):
+def test_step_graph_replay_is_bit_identical_to_stream_launches(sla):
     """sla_solver_step replays pairs of steps as a captured HIP graph at launch-bound sizes: same kernels, same arguments, same
     order => the iterates must equal the stream-launched ones bit for bit, from even and odd starting parity, for BiCGSTAB and
     CGS, with leftovers, on a clone (which captures its own graph) and after the graph was built."""
@@ -361,8 +343,7 @@ def test_step_graph_replay_is_bit_identical_to_stream_launches(sla, monkeypatch)
     b = np.add.reduceat(va, rp[:-1])
     out = {}
     for mode in ("1", "0"):
-        monkeypatch.setenv("SLA_STEP_GRAPH", mode)
-        ctx = sla.Context(0)
+        ctx = sla.Context(0).set_option("step_graph", mode)
         A = sla.fromCSR(dims, rp, ci, va, ctx)
         res = []
         for init, xf in ((sla.bicgsInit, "_xBicgstab"), (sla.cgsInit, "_x")):

@@ -85,12 +85,11 @@ def test_config4_laplace3d_10m_bit_exact_vs_oracle(sla):
     _check(sla, dims, rp, ci, va, "wdia", True, "ones", "config4")
 
 
-def test_config4_laplace3d_10m_reference_split_flow_vs_oracle(sla, monkeypatch):
+def test_config4_laplace3d_10m_reference_split_flow_vs_oracle(sla):
     """The single-rank default fuses K4 and K5 (the test above); sharded contexts -- config 4 on 8 GPUs -- run the reference's
-    split.  The same full-size check on a context created with SLA_BICG_FUSE45=0."""
+    split.  The same full-size check on a context with the option bicg_fuse45=0."""
     from sla_amd import workloads as wl
-    monkeypatch.setenv("SLA_BICG_FUSE45", "0")
-    ctx = sla.Context(0)
+    ctx = sla.Context(0).set_option("bicg_fuse45", 0)
     dims, (rp, ci, va) = wl.laplace3d(216, 216, 216)
     _check(sla, dims, rp, ci, va, "wdia", True, "ones", "config4 split", ctx)
     ctx.close()

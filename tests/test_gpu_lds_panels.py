@@ -62,7 +62,7 @@ CASES = {
 
 
 @pytest.mark.parametrize("name", list(CASES))
-def test_lds_panels_match_the_oracle_and_the_stream_kernel(sla, monkeypatch, name):
+def test_lds_panels_match_the_oracle_and_the_stream_kernel(sla, name):
     dims, csr = CASES[name]()
     m, n = dims
     Ao = orc.Csr(m, n, *csr)
@@ -70,11 +70,8 @@ def test_lds_panels_match_the_oracle_and_the_stream_kernel(sla, monkeypatch, nam
     x, xt = rng.standard_normal(n), rng.standard_normal(m)
     want, want_t = orc.spmv(Ao, x), orc.spmv(orc.transpose(Ao), xt)
     got = {}
-    for form, env in (("ldspanels", None), ("stream", "0")):
-        monkeypatch.delenv("SLA_LPANEL", raising=False)
-        if env is not None:
-            monkeypatch.setenv("SLA_LPANEL", env)
-        ctx = sla.Context(0)
+    for form, opts in (("ldspanels", {}), ("stream", {"lpanel": 0})):
+        ctx = sla.Context(0).set_options(**opts)
         A = sla.fromCSR(dims, *csr, ctx)
         assert ("ldspanels" in A.kernel_info()) == (form == "ldspanels"), (name, A.kernel_info())
         y = sla.matVec(A, sla.fromVector(x, ctx)).toDenseListSV()
@@ -108,7 +105,7 @@ def test_lds_panels_touch_only_the_referenced_entries_of_x(sla):
     assert np.allclose(y[fin], want[fin], rtol=1e-12, atol=1e-12)
 
 
-def test_lds_panels_epilogues_through_the_solvers(sla, monkeypatch):
+def test_lds_panels_epilogues_through_the_solvers(sla):
     """K1/K3 (dot, dot2), the true-residual sweep (stand-alone: the fused two-vector sweep is not used with this form),
     CGS's and CGNE's fused updates, r0 = b - A x0, Arnoldi and GMRES on a diagonally dominant matrix with dense rows:
     the same iteration counts as the oracle and the stream kernel, iterates equal up to partial-sum grouping."""
@@ -118,11 +115,8 @@ def test_lds_panels_epilogues_through_the_solvers(sla, monkeypatch):
     b = orc.spmv(Ao, np.linspace(-1.0, 2.0, n))
     x0 = np.full(n, 0.25)
     out = {}
-    for form, env in (("ldspanels", None), ("stream", "0")):
-        monkeypatch.delenv("SLA_LPANEL", raising=False)
-        if env is not None:
-            monkeypatch.setenv("SLA_LPANEL", env)
-        ctx = sla.Context(0)
+    for form, opts in (("ldspanels", {}), ("stream", {"lpanel": 0})):
+        ctx = sla.Context(0).set_options(**opts)
         A = sla.fromCSR(dims, *csr, ctx)
         assert ("ldspanels" in A.kernel_info()) == (form == "ldspanels")
         for meth in (sla.BICGSTAB_, sla.CGS_, sla.CGNE_):

@@ -406,11 +406,10 @@ def test_forced_collectives_match_single_gpu_path(sla, monkeypatch):
     them and evaluates rho through an identity, sharded contexts never do -- that difference is
     test_bicgstab_fused_k45_flow_vs_reference_split's subject, not this test's."""
     from sla_amd import workloads as wl
-    monkeypatch.setenv("SLA_BICG_FUSE45", "0")
-    monkeypatch.setenv("SLA_FORCE_COLLECTIVES", "1")
-    ctx = sla.Context(0, 0, 1, sla.Context.unique_id())
+    monkeypatch.setenv("SLA_FORCE_COLLECTIVES", "1")       # (read when the communicator is built: not a per-context option)
+    ctx = sla.Context(0, 0, 1, sla.Context.unique_id()).set_option("bicg_fuse45", 0)
     monkeypatch.delenv("SLA_FORCE_COLLECTIVES")
-    plain = sla.Context(0)
+    plain = sla.Context(0).set_option("bicg_fuse45", 0)
     dims, (rp, ci, va) = wl.poisson2d(50, 40)
     n = dims[0]
     b = np.add.reduceat(va, rp[:-1])
@@ -439,7 +438,7 @@ def test_forced_collectives_match_single_gpu_path(sla, monkeypatch):
 
 
 @pytest.mark.parametrize("problem", ["poisson2d 50x40", "laplace3d 14x11x13", "spd 400", "banded_nonsym 4001 (wdia-vv)"])
-def test_bicgstab_fused_k45_flow_vs_reference_split(sla, monkeypatch, problem):
+def test_bicgstab_fused_k45_flow_vs_reference_split(sla, problem):
     """Single-rank BiCGSTAB fuses K4 and K5 (default): rho_{j+1} = s . r0hat - omega (As . r0hat) from K3's sweep instead of
     (s - omega As) . r0hat from K4's.  x, r, p are updated by the reference's formulas either way; rho differs at rounding
     level, which a Krylov iteration amplifies like any other rounding difference.  Bounds from a CPU experiment on these very
@@ -466,8 +465,7 @@ def test_bicgstab_fused_k45_flow_vs_reference_split(sla, monkeypatch, problem):
     r0hat = b - orc.spmv(Ao, x0)
     got = {}
     for fuse in ("1", "0"):
-        monkeypatch.setenv("SLA_BICG_FUSE45", fuse)
-        c = sla.Context(0)
+        c = sla.Context(0).set_option("bicg_fuse45", fuse)
         A = sla.fromCSR(dims, rp, ci, va, c)
         if problem.startswith("banded"):
             assert "wdia-vv" in A.kernel_info(), A.kernel_info()

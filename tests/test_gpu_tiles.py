@@ -56,7 +56,7 @@ CASES = {
 
 
 @pytest.mark.parametrize("name", list(CASES))
-def test_tiles_match_the_oracle(sla, monkeypatch, name):
+def test_tiles_match_the_oracle(sla, name):
     build, expect_tiles = CASES[name]
     dims, csr = build()
     m, n = dims
@@ -66,11 +66,8 @@ def test_tiles_match_the_oracle(sla, monkeypatch, name):
     x = rng.standard_normal(n)
     want = orc.spmv(Ao, x)
     bound = np.diff(rp) * EPS * orc.spmv(orc.Csr(m, n, rp, ci, np.abs(va)), np.abs(x)) + 1e-300
-    monkeypatch.setenv("SLA_TILE_SHIFT", "10")
-    monkeypatch.setenv("SLA_LPANEL", "0")                        # (the dense-row cases would otherwise take the LDS-panel form)
-    for rp64 in ("0", "1"):
-        monkeypatch.setenv("SLA_FORCE_RP64", rp64)
-        ctx = sla.Context(0)
+    for rp64 in ("0", "1"):                                      # (lpanel=0: the dense-row cases would otherwise take the LDS-panel form)
+        ctx = sla.Context(0).set_options(tile_shift=10, lpanel=0, force_rp64=rp64)
         A = sla.fromCSR(dims, rp, ci, va, ctx)
         info = A.kernel_info()
         assert ("algo=tiles" in info) == expect_tiles, (name, info)
@@ -83,21 +80,18 @@ def test_tiles_match_the_oracle(sla, monkeypatch, name):
         y2 = sla.matVec(A, sla.fromVector(x, ctx)).toDenseListSV()
         assert np.array_equal(y, y2)                             # deterministic
     # the same matrix on the forms the tile form replaces
-    monkeypatch.setenv("SLA_FORCE_RP64", "0")
-    monkeypatch.setenv("SLA_TILES", "0")
-    ctx = sla.Context(0)
+    ctx = sla.Context(0).set_options(tile_shift=10, lpanel=0, tiles=0)
     A = sla.fromCSR(dims, rp, ci, va, ctx)
     assert "tiles" not in A.kernel_info()
     y0 = sla.matVec(A, sla.fromVector(x, ctx)).toDenseListSV()
     assert np.all(np.abs(y0 - want) <= bound)
 
 
-def test_tiles_transpose_and_solver_epilogues(sla, monkeypatch):
+def test_tiles_transpose_and_solver_epilogues(sla):
     """(<#), bicgsInit / bicgstabStep (EPI_SUB, EPI_DOT, EPI_DOT2), cgsStep (EPI_AXPY_DOT), cgneStep (EPI_AXPY_DOT on A,
     EPI_XPBY_NRM on the transpose) and linSolve0's residual sweep (EPI_RES) on the tile form."""
     from sla_amd import workloads as wl
-    monkeypatch.setenv("SLA_TILE_SHIFT", "10")
-    ctx = sla.Context(0)
+    ctx = sla.Context(0).set_option("tile_shift", 10)
     n = 6000
     dims, (rp, ci, va) = wl.random_spd(n, 5, 3)
     A, Ao = sla.fromCSR(dims, rp, ci, va, ctx), orc.Csr(n, n, rp, ci, va)

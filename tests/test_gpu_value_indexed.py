@@ -1,6 +1,6 @@
 """The value-indexed SpMV forms (spmv_wdia_kernel: wave-sliced (offset, value) records in SGPRs, two rows per
 lane; spmv_wdia_lds_kernel: uniform records + x windows staged in LDS for stencils of <= 8 pairs, forced at these sizes
-with SLA_WD_LDS=2; spmv_vdict_kernel: one byte per entry) against the oracle's left fold, bit for bit, and against each other
+with the context option wd_lds=2; spmv_vdict_kernel: one byte per entry) against the oracle's left fold, bit for bit, and against each other
 and the general kernels -- including the shapes that stress them: odd row counts, ragged patterns where only
 one row of a lane pair holds an entry, more than 8 records per slice, several values on one diagonal, rows at
 the matrix edge, -0.0 / Inf operands, and every fused epilogue through the solver steps."""
@@ -70,7 +70,7 @@ def _oracle_csr(dims, csr):
 
 
 @pytest.mark.parametrize("name", list(_cases()))
-def test_value_indexed_forms_fold_like_the_reference(sla, monkeypatch, name):
+def test_value_indexed_forms_fold_like_the_reference(sla, name):
     dims, csr = _cases()[name]
     n = dims[0]
     Ao = _oracle_csr(dims, csr)
@@ -82,14 +82,10 @@ def test_value_indexed_forms_fold_like_the_reference(sla, monkeypatch, name):
     got = {}
     lds_cases = ("laplace3d 14x11x13", "poisson2d 37x29 (odd n)", "tridiag n=1", "tridiag n=129", "ragged 7 diagonals n=4099",
                  "5 far diagonals n=7001", "explicit +-0.0 n=777")
-    for form, env in (("wdia", {"SLA_WD_LDS": "0"}), ("wdia+ldswin", {"SLA_WD_LDS": "2"}), ("vdict", {"SLA_WDIA": "0"}),
-                      ("diag", {"SLA_WDIA": "0", "SLA_VDICT": "0"}),
-                      ("stream", {"SLA_WDIA": "0", "SLA_VDICT": "0", "SLA_DIAG": "0", "SLA_XWIN": "0"})):
-        for k in ("SLA_WDIA", "SLA_VDICT", "SLA_DIAG", "SLA_XWIN", "SLA_WD_LDS"):
-            monkeypatch.delenv(k, raising=False)
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
-        ctx = sla.Context(0)
+    for form, opts in (("wdia", {"wd_lds": 0}), ("wdia+ldswin", {"wd_lds": 2}), ("vdict", {"wdia": 0}),
+                       ("diag", {"wdia": 0, "vdict": 0}),
+                       ("stream", {"wdia": 0, "vdict": 0, "diag": 0, "xwin": 0})):
+        ctx = sla.Context(0).set_options(**opts)      # (typed per-context options: sla_ctx_set_option)
         A = sla.fromCSR(dims, *csr, ctx)
         if form == "wdia+ldswin":
             # the LDS-window kernel takes stencils of <= 8 (offset, value) pairs; the others stay on the gather kernel
@@ -114,7 +110,7 @@ def test_value_indexed_forms_fold_like_the_reference(sla, monkeypatch, name):
 
 @pytest.mark.parametrize("name", ["laplace3d 14x11x13", "ragged 11 diagonals n=4099", "ragged 7 diagonals n=4099",
                                   "5 far diagonals n=7001", "3 values per diagonal n=2500"])
-def test_value_indexed_epilogues_through_the_solvers(sla, monkeypatch, name):
+def test_value_indexed_epilogues_through_the_solvers(sla, name):
     """K1/K3 (dot, dot2), the true-residual sweep, CGS's and CGNE's fused updates, r0 = b - A x0: same iterates as
     the general kernels (the per-row results are bit-identical; only partial-sum grouping differs)."""
     dims, csr = _cases()[name]
@@ -122,13 +118,9 @@ def test_value_indexed_epilogues_through_the_solvers(sla, monkeypatch, name):
     Ao = _oracle_csr(dims, csr)
     b = orc.spmv(Ao, np.linspace(-1.0, 2.0, n))
     out = {}
-    for form, env in (("wdia", {"SLA_WD_LDS": "0"}), ("ldswin", {"SLA_WD_LDS": "2"}), ("vdict", {"SLA_WDIA": "0"}),
-                      ("stream", {"SLA_WDIA": "0", "SLA_VDICT": "0", "SLA_DIAG": "0"})):
-        for k in ("SLA_WDIA", "SLA_VDICT", "SLA_DIAG", "SLA_WD_LDS"):
-            monkeypatch.delenv(k, raising=False)
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
-        ctx = sla.Context(0)
+    for form, opts in (("wdia", {"wd_lds": 0}), ("ldswin", {"wd_lds": 2}), ("vdict", {"wdia": 0}),
+                       ("stream", {"wdia": 0, "vdict": 0, "diag": 0})):
+        ctx = sla.Context(0).set_options(**opts)
         A = sla.fromCSR(dims, *csr, ctx)
         for meth in (sla.BICGSTAB_, sla.CGS_, sla.CGNE_):
             x, info = sla.linSolve0(meth, A, sla.fromVector(b, ctx), sla.fromVector(np.full(n, 0.25), ctx), return_info=True)
@@ -148,10 +140,9 @@ def test_value_indexed_epilogues_through_the_solvers(sla, monkeypatch, name):
                 assert np.abs(x - ref[0]).max() <= 1e-5 * scale, (name, form, meth)
 
 
-@pytest.mark.parametrize("wd_lds", ["0", "2"])
-def test_value_indexed_propagates_inf_and_nan_only_where_the_reference_does(sla, monkeypatch, wd_lds):
+@pytest.mark.parametrize("wd_lds", [0, 2])
+def test_value_indexed_propagates_inf_and_nan_only_where_the_reference_does(sla, wd_lds):
     """Lanes masked off in a slice must not touch x at all: an Inf next to a missing neighbour stays out of that row."""
-    monkeypatch.setenv("SLA_WD_LDS", wd_lds)
     n = 640
     dims, csr = _stencil(n, [-1, 0, 1], lambda r, o: np.full(len(r), 2.0 if o == 0 else -1.0),
                          keep=lambda r, t: ~((r % 64 == 10) & (t == 2)))       # rows 10, 74, ... have no (i, i+1) entry
@@ -159,22 +150,21 @@ def test_value_indexed_propagates_inf_and_nan_only_where_the_reference_does(sla,
     x = np.ones(n)
     x[11] = np.inf           # row 10 does not reference x[11]; rows 11 and 12 do
     x[300] = np.nan
-    A = sla.fromCSR(dims, *csr, sla.Context(0))
-    assert "wdia" in A.kernel_info() and ("ldswin" in A.kernel_info()) == (wd_lds == "2")
+    A = sla.fromCSR(dims, *csr, sla.Context(0).set_option("wd_lds", wd_lds))
+    assert "wdia" in A.kernel_info() and ("ldswin" in A.kernel_info()) == (wd_lds == 2)
     y = sla.matVec(A, sla.fromVector(x, A.ctx)).toDenseListSV()
     want = orc.spmv(Ao, x)
     assert np.isfinite(y[10]) and np.isinf(y[11]) and np.isinf(y[12])
     assert np.array_equal(np.isnan(y), np.isnan(want)) and np.array_equal(y[~np.isnan(y)], want[~np.isnan(want)])
 
 
-@pytest.mark.parametrize("wd_lds", ["0", "2"])
-def test_value_indexed_randomised_patterns(sla, monkeypatch, wd_lds):
+@pytest.mark.parametrize("wd_lds", [0, 2])
+def test_value_indexed_randomised_patterns(sla, wd_lds):
     """(wd_lds = 2: the patterns of <= 8 pairs go through the LDS-window kernel)
     60 seeded random banded matrices (square and rectangular, 1..900 rows, up to 14 diagonals anywhere in the matrix,
     1-4 distinct values per diagonal, random holes, some with an empty leading / trailing block of rows): whatever form
     the lowering picks, (#>) and (<#) are the oracle's left fold bit for bit and the forms agree with each other."""
-    monkeypatch.setenv("SLA_WD_LDS", wd_lds)
-    ctx = sla.Context(0)
+    ctx = sla.Context(0).set_option("wd_lds", wd_lds)
     rng = np.random.default_rng(2024)
     picked = {"wdia": 0, "vdict": 0, "other": 0, "ldswin": 0}
     for case in range(60):
@@ -210,7 +200,7 @@ def test_value_indexed_randomised_patterns(sla, monkeypatch, wd_lds):
             assert np.allclose(y, want, rtol=1e-13, atol=1e-13), (case, algo)
         assert np.allclose(yt, want_t, rtol=1e-13, atol=1e-13), (case, algo, "transpose")
     assert picked["wdia"] >= 20, picked      # the generator is meant to exercise the value-indexed forms
-    assert (picked["ldswin"] >= 5) == (wd_lds == "2") and (picked["ldswin"] == 0) == (wd_lds == "0"), picked
+    assert (picked["ldswin"] >= 5) == (wd_lds == 2) and (picked["ldswin"] == 0) == (wd_lds == 0), picked
 
 
 def _vv_cases():
@@ -229,7 +219,7 @@ def _vv_cases():
 
 
 @pytest.mark.parametrize("name", list(_vv_cases()))
-def test_variable_coefficient_wave_sliced_form(sla, monkeypatch, name):
+def test_variable_coefficient_wave_sliced_form(sla, name):
     """Banded / stencil structure with arbitrary values: the wave-sliced kernel with per-row value blocks ("wdia-vv") --
     the oracle's fold bit for bit, and the solvers agree with the general kernels."""
     dims, csr = _vv_cases()[name]
@@ -240,11 +230,8 @@ def test_variable_coefficient_wave_sliced_form(sla, monkeypatch, name):
     want, want_t = orc.spmv(Ao, x), orc.spmv(orc.transpose(Ao), x)
     b = orc.spmv(Ao, np.linspace(-1.0, 1.0, n))
     sols = {}
-    for form, env in (("wdia-vv", {}), ("general", {"SLA_WDIA_VV": "0"})):
-        monkeypatch.delenv("SLA_WDIA_VV", raising=False)
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
-        ctx = sla.Context(0)
+    for form, opts in (("wdia-vv", {}), ("general", {"wdia_vv": 0})):
+        ctx = sla.Context(0).set_options(**opts)
         A = sla.fromCSR(dims, *csr, ctx)
         algo = A.kernel_info().split()[0]
         assert ("wdia-vv" in algo) == (form == "wdia-vv"), (form, algo)
