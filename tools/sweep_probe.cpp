@@ -50,6 +50,45 @@ __global__ void __launch_bounds__(256) sweep(long n2, const double *s, const dou
     }
 }
 
+
+// each lane takes W consecutive pairs (16 W bytes per stream): a wavefront touches 1 KB x W of every stream per iteration
+template <int W, bool NTS>
+__global__ void __launch_bounds__(256) sweep_wide(long n2, const double *s, const double *as, const double *ap, const double *xin, const double *pin,
+                                                  double *x, double *r, double *p, double alpha, double omega, double beta) {
+    const long gs = (long)gridDim.x * 256 * W;
+    for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * W; i + W <= n2; i += gs) {
+        d2 sv[W], av[W], vv[W], pv[W], xv[W];
+#pragma unroll
+        for (int j = 0; j < W; ++j) { sv[j] = ld<true>(s, i + j); av[j] = ld<true>(as, i + j); vv[j] = ld<true>(ap, i + j); pv[j] = ld<true>(pin, i + j); xv[j] = ld<true>(xin, i + j); }
+#pragma unroll
+        for (int j = 0; j < W; ++j) {
+            st<NTS>(x, i + j, (xv[j] + alpha * pv[j]) + omega * sv[j]);
+            const d2 rv = sv[j] - omega * av[j];
+            st<NTS>(r, i + j, rv);
+            st<false>(p, i + j, rv + beta * (pv[j] - omega * vv[j]));
+        }
+    }
+}
+// each WORKGROUP takes a contiguous block of B iterations (B x 4 KB of every stream) instead of striding by the grid
+template <int B, bool NTS>
+__global__ void __launch_bounds__(256) sweep_blocked(long n2, const double *s, const double *as, const double *ap, const double *xin, const double *pin,
+                                                     double *x, double *r, double *p, double alpha, double omega, double beta) {
+    const long chunks = (n2 + 256 * B - 1) / (256 * B);
+    for (long c = blockIdx.x; c < chunks; c += gridDim.x) {
+#pragma unroll
+        for (int j = 0; j < B; ++j) {
+            const long i = (c * B + j) * 256 + threadIdx.x;
+            if (i < n2) {
+                const d2 sv = ld<true>(s, i), av = ld<true>(as, i), vv = ld<true>(ap, i), pv = ld<true>(pin, i), xv = ld<true>(xin, i);
+                st<NTS>(x, i, (xv + alpha * pv) + omega * sv);
+                const d2 rv = sv - omega * av;
+                st<NTS>(r, i, rv);
+                st<false>(p, i, rv + beta * (pv - omega * vv));
+            }
+        }
+    }
+}
+
 int main(int argc, char **argv) {
     const long n = argc > 1 ? atol(argv[1]) : 10077696;
     const int sets = 3, reps = 30;
@@ -80,6 +119,10 @@ int main(int argc, char **argv) {
         run("in place  nt loads     nt stores x r   pipelined", grid, true, sweep<true, true, true>);
         run("in place  nt loads     plain stores    pipelined", grid, true, sweep<true, false, true>);
         run("distinct  nt loads     plain stores    pipelined", grid, false, sweep<true, false, true>);
+        run("in place  nt loads     nt stores x r   2 pairs per lane", grid, true, sweep_wide<2, true>);
+        run("in place  nt loads     nt stores x r   4 pairs per lane", grid, true, sweep_wide<4, true>);
+        run("in place  nt loads     nt stores x r   2 iterations per workgroup block", grid, true, sweep_blocked<2, true>);
+        run("in place  nt loads     nt stores x r   4 iterations per workgroup block", grid, true, sweep_blocked<4, true>);
     }
     return 0;
 }
