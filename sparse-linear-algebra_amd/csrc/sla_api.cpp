@@ -1151,7 +1151,7 @@ const IntKnob kIntKnobs[] = {
     {"wd_nt_store", &sla_ctx::wd_nt_store, 0, 1},
     {"wdia_vv", &sla_ctx::wdia_vv, 0, 1},
     {"vec_nt", &sla_ctx::vec_nt, -1, 1},
-    {"vec_policy", &sla_ctx::vec_policy, 0, 0x7ff},
+    {"vec_policy", &sla_ctx::vec_policy, 0, 0x7fff},
     {"halo_inplace", &sla_ctx::halo_inplace, 0, 1},
     {"panels", &sla_ctx::panels, 0, 1},
     {"overlap", &sla_ctx::overlap, -1, 1},

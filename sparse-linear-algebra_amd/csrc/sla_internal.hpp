@@ -199,7 +199,7 @@ struct sla_ctx {
     int panels = 1;                  // allow the column-panel SpMV for irregular matrices (SLA_PANELS=0 disables)
     int64_t panel_cols = 384 * 1024; // panel width in columns (SLA_PANEL_COLS): 3 MiB of x per pass
     int diag = 1;                    // allow the dictionary-compressed-index SpMV kernel (SLA_DIAG=0 disables)
-    int vec_policy = 0x3ff;          // per-stream cache policy of K2 and the K4+K5 sweep when vec_nt applies (sla_vec_kernels.hip: ldpol; default: every stream but the p store past the caches)
+    int vec_policy = 0x2bff;         // per-stream cache policy of K2 and the K4+K5 sweep when vec_nt applies (sla_vec_kernels.hip: ldpol; default: every BiCGSTAB stream but the p store, and CGS's q and u stores, past the caches)
     int vec_nt = -1;                 // non-temporal loads in the BiCGSTAB vector kernels: -1 when the vectors overflow the memory-side cache, 0 / 1 (SLA_VEC_NT)
     int64_t mall_bytes = 256ll << 20; // capacity of the memory-side cache (MI355X: 256 MiB)
     int wdia_vv = 1;                 // allow the variable-coefficient wave-sliced form (SLA_WDIA_VV=0 disables)

@@ -16,6 +16,7 @@ namespace sla {
 
 // per-stream cache policy of the two BiCGSTAB sweeps at sizes that overflow the memory-side cache (ctx option vec_policy; bit set = the
 // stream goes past the caches).  K2: 0 r, 1 Ap, 2 s (store).  K4+K5: 3 s, 4 As, 5 Ap, 6 p, 7 x, 8 x (store), 9 r (store), 10 p (store).
+// CGS stores: C2 11 q, 12 uq; C4 13 u, 14 p (their loads and C2's x store always go past the caches).
 __device__ __forceinline__ double2 ldpol(const double *p, int64_t i2, int pol, int bit) { return (pol >> bit) & 1 ? ld2_nt(p, i2) : ld2_t(p, i2); }
 __device__ __forceinline__ void stpol(double *p, int64_t i2, double2 v, int pol, int bit) {
     if ((pol >> bit) & 1) st2_nt(p, i2, v);
@@ -313,7 +314,7 @@ int launch_bicg_k45(sla_ctx *c, int64_t n, SolverScalars *sc, Parts ass, Parts a
 template <bool NT>
 __global__ void __launch_bounds__(kBlock) cgs_c2_kernel(int64_t n, SolverScalars *sc, Parts apr, int par,
                                                          Parts res, int count_iter, const double *u,
-                                                         const double *aap, double *q, double *uq, double *x) {
+                                                         const double *aap, double *q, double *uq, double *x, int pol) {
     __shared__ double s_red[4];
     // (scalars, partials and the first element pairs issued together: see bicg_k2_kernel)
     const int64_t n2 = n >> 1, gs = (int64_t)gridDim.x * kBlock, i0 = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -335,8 +336,8 @@ __global__ void __launch_bounds__(kBlock) cgs_c2_kernel(int64_t n, SolverScalars
         const double2 sv = make_double2(uv.x + qv.x, uv.y + qv.y);
         xv.x += alpha * sv.x;
         xv.y += alpha * sv.y;
-        st2(q, i2, qv);
-        st2(uq, i2, sv);
+        stpol(q, i2, qv, pol, 11);
+        stpol(uq, i2, sv, pol, 12);
         if (NT) st2_nt(x, i2, xv);  // (as in K4: x is not read again before the next step)
         else st2(x, i2, xv);
     }
@@ -352,7 +353,7 @@ __global__ void __launch_bounds__(kBlock) cgs_c2_kernel(int64_t n, SolverScalars
 // C4: betaj = (rj1 <.> rhat) / (r <.> rhat) ; uj1 = rj1 ^+^ betaj .* q ; pj1 = uj1 ^+^ betaj .* (q ^+^ betaj .* p)
 template <bool NT>
 __global__ void __launch_bounds__(kBlock) cgs_c4_kernel(int64_t n, SolverScalars *sc, Parts rhonew, int par,
-                                                         const double *r, const double *q, double *u, double *p) {
+                                                         const double *r, const double *q, double *u, double *p, int pol) {
     __shared__ double s_red[4];
     const int64_t n2 = n >> 1, gs = (int64_t)gridDim.x * kBlock, i0 = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const int done = sc->done;
@@ -371,8 +372,8 @@ __global__ void __launch_bounds__(kBlock) cgs_c4_kernel(int64_t n, SolverScalars
         const double2 uv = make_double2(rv.x + beta * qv.x, rv.y + beta * qv.y);
         pv.x = uv.x + beta * (qv.x + beta * pv.x);
         pv.y = uv.y + beta * (qv.y + beta * pv.y);
-        st2(u, i2, uv);
-        st2(p, i2, pv);
+        stpol(u, i2, uv, pol, 13);
+        stpol(p, i2, pv, pol, 14);
     }
     if (SLA_HAS_TAIL(n)) {
         const int64_t i = n - 1;
@@ -386,9 +387,9 @@ int launch_cgs_c2(sla_ctx *c, int64_t n, SolverScalars *sc, Parts apr, int par, 
                   const double *u, const double *aap, double *q, double *uq, double *x) {
     ProfScope prof(c, SLA_KERNEL_CGS_C2);
     if (vec_stream_nt(c, n))
-        hipLaunchKernelGGL(cgs_c2_kernel<true>, dim3(vec_grid(n)), dim3(kBlock), 0, stream_of(c), n, sc, apr, par, res, count_iter, u, aap, q, uq, x);
+        hipLaunchKernelGGL(cgs_c2_kernel<true>, dim3(vec_grid(n)), dim3(kBlock), 0, stream_of(c), n, sc, apr, par, res, count_iter, u, aap, q, uq, x, c->vec_policy);
     else
-        hipLaunchKernelGGL(cgs_c2_kernel<false>, dim3(vec_grid(n)), dim3(kBlock), 0, stream_of(c), n, sc, apr, par, res, count_iter, u, aap, q, uq, x);
+        hipLaunchKernelGGL(cgs_c2_kernel<false>, dim3(vec_grid(n)), dim3(kBlock), 0, stream_of(c), n, sc, apr, par, res, count_iter, u, aap, q, uq, x, 0);
     SLA_HIP_TRY(hipGetLastError());
     return SLA_OK;
 }
@@ -396,9 +397,9 @@ int launch_cgs_c4(sla_ctx *c, int64_t n, SolverScalars *sc, Parts rhonew, int pa
                   double *u, double *p) {
     ProfScope prof(c, SLA_KERNEL_CGS_C4);
     if (vec_stream_nt(c, n))
-        hipLaunchKernelGGL(cgs_c4_kernel<true>, dim3(vec_grid(n)), dim3(kBlock), 0, stream_of(c), n, sc, rhonew, par, r, q, u, p);
+        hipLaunchKernelGGL(cgs_c4_kernel<true>, dim3(vec_grid(n)), dim3(kBlock), 0, stream_of(c), n, sc, rhonew, par, r, q, u, p, c->vec_policy);
     else
-        hipLaunchKernelGGL(cgs_c4_kernel<false>, dim3(vec_grid(n)), dim3(kBlock), 0, stream_of(c), n, sc, rhonew, par, r, q, u, p);
+        hipLaunchKernelGGL(cgs_c4_kernel<false>, dim3(vec_grid(n)), dim3(kBlock), 0, stream_of(c), n, sc, rhonew, par, r, q, u, p, 0);
     SLA_HIP_TRY(hipGetLastError());
     return SLA_OK;
 }
