@@ -377,3 +377,46 @@ def test_plane_march_form_step_for_step_against_the_oracle(sla):
         assert np.linalg.norm(got.toDenseListSV() - want) <= 1e-11 * np.linalg.norm(want)
     del A
     ctx.close()
+
+
+def test_plane_march_randomised_patterns(sla):
+    """40 seeded random 5- / 7-pair stencils with one pair at -D and one at +D (D even, 1024..3000; in-plane offsets up to +-254: a window of at most 512 pairs; row
+    counts that are not multiples of D; random holes; several values share no offset): the march form must be taken, and (#>), (<#)
+    are the oracle's left fold bit for bit under random grid caps (several tasks per workgroup) and occupancies."""
+    rng = np.random.default_rng(777)
+    taken = 0
+    for case in range(40):
+        D = 2 * int(rng.integers(512, 1501))
+        npairs = 5 if case % 2 else 7
+        inner = sorted(set(int(v) for v in rng.integers(1, 255, npairs // 2 - 1)))
+        while len(inner) < npairs // 2 - 1:
+            inner = sorted(set(inner + [int(rng.integers(1, 255))]))
+        offsets = [-D] + [-o for o in reversed(inner)] + [0] + inner + [D]
+        n = int(rng.integers(2 * D, 7 * D)) + int(rng.integers(0, 2))
+        vals = {o: float(rng.choice([-2.0, -1.0, -0.5, 0.25, 3.0])) for o in offsets}
+        vals[0] = 9.0
+        hole = float(rng.random() * 0.4)
+        drop = rng.random((n, len(offsets))) < hole
+        dims, csr = _stencil(n, offsets, lambda r, o: np.full(len(r), vals[o]),
+                             keep=lambda r, t: ~drop[r, t] | (np.asarray(offsets)[t] == 0))
+        Ao = _oracle_csr(dims, csr)
+        x = rng.standard_normal(n)
+        want, want_t = orc.spmv(Ao, x), orc.spmv(orc.transpose(Ao), x)
+        ctx = sla.Context(0).set_options(wd_lds=2, wd_march=2, wd_march_occ=int(rng.integers(1, 5)))
+        if case % 3 == 0:
+            ctx.set_option("spmv_grid", 8 * int(rng.integers(1, 9)))
+        A = sla.fromCSR(dims, *csr, ctx)
+        info = A.kernel_info()
+        taken += "wdia+march" in info
+        assert "wdia+march" in info, (case, D, offsets, info)
+        y = sla.matVec(A, sla.fromVector(x, ctx)).toDenseListSV()
+        yt = sla.vecMat(sla.fromVector(x, ctx), A).toDenseListSV()
+        assert np.array_equal(y.view(np.uint64), want.view(np.uint64)), (case, D, n, offsets, info)
+        assert np.array_equal(yt.view(np.uint64), want_t.view(np.uint64)), (case, D, n, offsets, "transpose")
+        # the fused residual and dot epilogues against the general kernels' sums (same rows, other grouping)
+        b = orc.spmv(Ao, np.ones(n))
+        r = sla.matVec(A, sla.fromVector(np.ones(n), ctx)).toDenseListSV()
+        assert np.array_equal(r, b)
+        del A
+        ctx.close()
+    assert taken == 40
