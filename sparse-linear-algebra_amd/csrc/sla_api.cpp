@@ -919,6 +919,41 @@ static void low_lds_panels(Low &L) {
                 upload(&A->d_lpp, pp32.data(), sizeof(int32_t) * pp32.size());
             }
             if (err == hipSuccess) err = dev_malloc(c, (void **)&A->d_lpy, sizeof(double) * (size_t)(P * rows));
+            // panel-major second copy of the entries (sla_spmv_lpanel.hip: lp_reorder_kernel), built on the device from the arrays just
+            // uploaded; when it exists d_lpp is replaced by the P x rows + 1 segment starts into it.  12 B per entry: taken while it
+            // stays below 48 GB and the allocation succeeds (a failure here is not an error: the row-major arrays serve)
+            if (err == hipSuccess && c->lp_copy && nnz * 12 <= ((int64_t)48 << 30) && A->d_col && A->d_val) {
+                std::vector<int64_t> q((size_t)(P * rows) + 1, 0);
+                for (int64_t p = 0; p < P; ++p)
+                    for (int64_t i = 0; i < rows; ++i)
+                        q[(size_t)(p * rows + i) + 1] = q[(size_t)(p * rows + i)] + (pp[(size_t)((p + 1) * rows + i)] - pp[(size_t)(p * rows + i)]);
+                void *dq = nullptr;
+                int32_t *c2 = nullptr;
+                double *v2 = nullptr;
+                hipError_t e2 = dev_malloc(c, (void **)&c2, sizeof(int32_t) * (size_t)nnz + kArraySlack);
+                if (e2 == hipSuccess) e2 = dev_malloc(c, (void **)&v2, sizeof(double) * (size_t)nnz + kArraySlack);
+                if (e2 == hipSuccess) e2 = dev_malloc(c, &dq, rpsz * q.size() + kArraySlack);
+                if (e2 == hipSuccess) {
+                    if (A->rp64) {
+                        e2 = hipMemcpy(dq, q.data(), sizeof(int64_t) * q.size(), hipMemcpyHostToDevice);
+                    } else {
+                        std::vector<int32_t> q32(q.begin(), q.end());
+                        e2 = hipMemcpy(dq, q32.data(), sizeof(int32_t) * q32.size(), hipMemcpyHostToDevice);
+                    }
+                }
+                if (e2 == hipSuccess && launch_lp_reorder(c, A->rp64, A->d_lpp, dq, A->d_col, A->d_val, c2, v2, rows, P) != SLA_OK) e2 = hipErrorUnknown;
+                if (e2 == hipSuccess) {
+                    (void)hipFree(A->d_lpp);
+                    A->d_lpp = dq;
+                    A->d_lpcol = c2;
+                    A->d_lpval = v2;
+                } else {
+                    (void)hipGetLastError();
+                    if (c2) (void)hipFree(c2);
+                    if (v2) (void)hipFree(v2);
+                    if (dq) (void)hipFree(dq);
+                }
+            }
             // row chunks: ~32 tasks per workgroup of the persistent grid (measured: 8 -> 0.936 ms, 32 -> 0.900 ms, 64 ->
             // 0.902 ms on the 200k-row 1 % matrix), at least 64 rows (4 per wavefront) each
             const int tasks_per_cu = std::max(1, c->lp_tasks);
@@ -1137,6 +1172,7 @@ const IntKnob kIntKnobs[] = {
     {"wdia", &sla_ctx::wdia, 0, 1},
     {"lpanel", &sla_ctx::lpanel, 0, 1},
     {"lp_tasks", &sla_ctx::lp_tasks, 1, 1 << 20},
+    {"lp_copy", &sla_ctx::lp_copy, 0, 1},
     {"lp_cfg", &sla_ctx::lp_cfg, -1, 3},
     {"lp_minseg", &sla_ctx::lp_min_seg, 1, 1 << 20},
     {"lp_rowcost", &sla_ctx::lp_rowcost, 0, 1 << 20},
@@ -1719,6 +1755,8 @@ int sla_csr_destroy(sla_csr_t A) {
     if (A->d_wsched) (void)hipFree(A->d_wsched);
     if (A->d_lpp) (void)hipFree(A->d_lpp);
     if (A->d_lpy) (void)hipFree(A->d_lpy);
+    if (A->d_lpcol) (void)hipFree(A->d_lpcol);
+    if (A->d_lpval) (void)hipFree(A->d_lpval);
     if (A->d_lpt) (void)hipFree(A->d_lpt);
     if (A->d_wvblk) (void)hipFree(A->d_wvblk);
     if (A->d_wme) (void)hipFree(A->d_wme);
@@ -1784,8 +1822,8 @@ int sla_csr_kernel_info(sla_csr_t A, char *buf, int buflen) {
     if (A->use_lpanel && A->ctx->lpanel && A->ctx->spmv_algo == 0) {   // LDS-panel geometry
         const size_t used = strlen(buf);
         if (used + 1 < (size_t)buflen)
-            snprintf(buf + used, (size_t)buflen - used, " lds_panels=%d panel_cols=%d lanes_per_segment=%d tasks=%d", A->lp_P, A->lp_W,
-                     64 >> A->lp_cfg, A->lp_P * A->lp_C);
+            snprintf(buf + used, (size_t)buflen - used, " lds_panels=%d panel_cols=%d lanes_per_segment=%d tasks=%d entries=%s", A->lp_P, A->lp_W,
+                     64 >> A->lp_cfg, A->lp_P * A->lp_C, A->d_lpcol ? "panel-major-copy" : "row-major");
     }
     {   // bytes of matrix data the chosen form streams per (#>) (what K1's HBM roofline is priced against in bench.py)
         const sla_ctx *c = A->ctx;

@@ -218,6 +218,7 @@ struct sla_ctx {
     int lp_attr = 0;                 // spmv_lpanel_kernel<i32 / i64> had its dynamic-LDS limit raised on this device (bits 0 / 1)
     int lp_min_seg = sla::kLpMinSeg, lp_tasks = 32, lp_cfg = -1, lp_rowcost = 256;   // its tuning knobs (SLA_LP_MINSEG / _TASKS / _CFG / _ROWCOST)
     int force_rp64 = 0;              // test hook: 64-bit row pointers at any size (SLA_FORCE_RP64)
+    int lp_copy = 1;                 // LDS-panel form: stream a panel-major second copy of col / val (SLA_LP_COPY=0: the row-major arrays)
     int lpanel = 1;                  // allow the LDS-panel SpMV kernel for matrices with dense rows (SLA_LPANEL=0 disables)
     int xwin = 1;                    // allow the LDS x-window SpMV kernel (SLA_XWIN=0 disables)
     int stream_wide = 1;             // spmv_stream_kernel: pairs of entries per load (8-byte col / 16-byte val loads) instead of one (SLA_STREAM_WIDE=0)
@@ -311,6 +312,8 @@ struct sla_csr {
     int32_t lp_col_lo = 0, lp_col_hi = -1;   // smallest / largest column any of these rows references
     int32_t *d_lpt = nullptr;        // lp_G + 1 task boundaries: workgroup g runs tasks [lpt[g], lpt[g+1]) (equal entries each)
     int32_t lp_G = 0;
+    int32_t *d_lpcol = nullptr;      // panel-major second copy of the entries (segments of a panel contiguous, rows ascending): then
+    double *d_lpval = nullptr;       //   d_lpp holds P x rows + 1 segment starts into it instead of the (P + 1) x rows table
     double *d_lpy = nullptr;         // P x rows partial sums, summed in ascending panel order by lpanel_finish_kernel
     bool use_lpanel = false;
     int32_t lp_cfg = 0;              // lane-group shape of spmv_lpanel_kernel (0: 64 lanes per segment ... 3: 8 lanes)
@@ -594,7 +597,9 @@ int launch_spmv_dual_diag(const sla_csr *A, const SpmvArgs<int32_t> &a, const do
 int launch_spmv_dual_diag(const sla_csr *A, const SpmvArgs<int64_t> &a, const double *x2, const double *b2, int grid);
 int launch_spmv_vdict(const sla_csr *A, int epi, const SpmvArgs<int32_t> &a, const double *x2, const double *b2, int grid);
 int launch_spmv_wdia(const sla_csr *A, int epi, const SpmvArgs<int32_t> &a, const int32_t *sched, int32_t nblk_wd, int grid, int stream_nt);   // sla_spmv_wdia.hip
-int launch_spmv_lpanel(const sla_csr *A, int epi, const SpmvArgs<int32_t> &a, int grid);                     // sla_spmv_lpanel.hip
+int launch_lp_reorder(sla_ctx *c, bool rp64, const void *pp, const void *q, const int32_t *col, const double *val, int32_t *col2, double *val2,
+                      int64_t rows, int64_t P);                                                            // sla_spmv_lpanel.hip
+int launch_spmv_lpanel(const sla_csr *A, int epi, const SpmvArgs<int32_t> &a, int grid);
 int launch_spmv_lpanel(const sla_csr *A, int epi, const SpmvArgs<int64_t> &a, int grid);
 // do the solver's vectors (7 of n entries for BiCGSTAB) overflow the memory-side cache?  Then stream them past it.
 inline bool vec_stream_nt(const sla_ctx *c, int64_t n) { return c->vec_nt < 0 ? 7 * 8 * n > c->mall_bytes : c->vec_nt != 0; }

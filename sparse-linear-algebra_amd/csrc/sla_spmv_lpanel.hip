@@ -26,7 +26,7 @@ __global__ void __launch_bounds__(kLpBlock) spmv_lpanel_kernel(const RP *__restr
                                                                const double *__restrict__ val, const double *__restrict__ xg,
                                                                double *__restrict__ ypart, const int32_t *__restrict__ task_begin,
                                                                int rows, int n, int W, int chunk_rows, int C, int col_lo, int col_hi,
-                                                               const SolverScalars *sc) {
+                                                               const SolverScalars *sc, int panel_major) {
     // L lanes per (row, panel) segment, R segments per lane group and round, J strided loads per segment and round: a
     // wavefront keeps (64 / L) * R segments = 64 * R * J entries in flight.  A round costs a memory round trip however
     // little it carries (measured: ~0.9 us), so short segments get narrow groups -- see the table at the launch.
@@ -50,7 +50,9 @@ __global__ void __launch_bounds__(kLpBlock) spmv_lpanel_kernel(const RP *__restr
             curp = p;
         }
         const int lo = c * chunk_rows, hi = min(rows, lo + chunk_rows);
-        const RP *ps = pp + (int64_t)p * rows, *pe = ps + rows;
+        // segment (p, i): [pp[p][i], pp[p + 1][i]) of the row-major arrays, or -- panel-major copy, where the segments of a panel follow
+        // each other and a segment's edge lines are its neighbours' -- [q[p rows + i], q[p rows + i + 1])
+        const RP *ps = pp + (int64_t)p * rows, *pe = ps + (panel_major ? 1 : rows);
         double *yp = ypart + (int64_t)p * rows;
         for (int base = lo; base < hi; base += R * GPB) {   // (wavefront-uniform trip count)
             // (fetching the next round's segment pointers a round ahead was tried: no gain where each shape is used)
@@ -111,6 +113,37 @@ __global__ void __launch_bounds__(kLpBlock) spmv_lpanel_kernel(const RP *__restr
     }
 }
 
+// Panel-major second copy (lowering time): segment (p, i) of the row-major arrays goes to q[p rows + i].  Read row-major the
+// segments of a panel are ~150 entries each, 2000 entries apart: their first and last 128-byte lines are fetched again for the
+// neighbouring panels' segments, by other workgroups at other times -- 13 % of the kernel's HBM traffic on the 200 k x 2000-per-row
+// matrix (PMC: 5.47 GB per launch for 4.83 GB of entries).  One wavefront per segment.
+template <typename RP>
+__global__ void __launch_bounds__(kBlock) lp_reorder_kernel(const RP *__restrict__ pp, const RP *__restrict__ q, const int32_t *__restrict__ col,
+                                                            const double *__restrict__ val, int32_t *__restrict__ col2, double *__restrict__ val2,
+                                                            int64_t rows, int64_t nseg) {
+    const int ln = threadIdx.x & 63;
+    for (int64_t s = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); s < nseg; s += (int64_t)gridDim.x * (kBlock / 64)) {
+        const int64_t b = (int64_t)pp[s], e = (int64_t)pp[s + rows], d = (int64_t)q[s];
+        for (int64_t k = b + ln; k < e; k += 64) {
+            col2[d + (k - b)] = col[k];
+            val2[d + (k - b)] = val[k];
+        }
+    }
+}
+
+int launch_lp_reorder(sla_ctx *c, bool rp64, const void *pp, const void *q, const int32_t *col, const double *val, int32_t *col2, double *val2,
+                      int64_t rows, int64_t P) {
+    const int64_t nseg = rows * P;
+    const int grid = (int)std::min<int64_t>(64 * (int64_t)c->n_cu, std::max<int64_t>(1, (nseg + 3) / 4));
+    if (rp64)
+        hipLaunchKernelGGL(lp_reorder_kernel<int64_t>, dim3(grid), dim3(kBlock), 0, stream_of(c), (const int64_t *)pp, (const int64_t *)q, col, val, col2, val2, rows, nseg);
+    else
+        hipLaunchKernelGGL(lp_reorder_kernel<int32_t>, dim3(grid), dim3(kBlock), 0, stream_of(c), (const int32_t *)pp, (const int32_t *)q, col, val, col2, val2, rows, nseg);
+    SLA_HIP_TRY(hipGetLastError());
+    SLA_HIP_TRY(hipStreamSynchronize(stream_of(c)));
+    return SLA_OK;
+}
+
 // y_i = sum over panels (ascending) of the partials + the fused epilogue; one lane per row.
 template <int EPI, typename RP>
 __global__ void __launch_bounds__(kBlock) lpanel_finish_kernel(SpmvArgs<RP> a, const double *__restrict__ ypart, int P) {
@@ -152,8 +185,9 @@ int launch_lpanel_t(const sla_csr *A, const SpmvArgs<RP> &a, int grid) {
             c->lp_attr |= attr_bit;                                                                                         \
         }                                                                                                                   \
         hipLaunchKernelGGL((spmv_lpanel_kernel<RP, L_, R_, J_>), dim3(A->lp_G), dim3(kLpBlock), kLpW * sizeof(double),      \
-                           stream_of(c), (const RP *)A->d_lpp, a.col, a.val, a.x, A->d_lpy, A->d_lpt, a.rows, (int)A->n,       \
-                           A->lp_W, A->lp_chunk, A->lp_C, A->lp_col_lo, A->lp_col_hi, (const SolverScalars *)a.sc);         \
+                           stream_of(c), (const RP *)A->d_lpp, A->d_lpcol ? A->d_lpcol : a.col, A->d_lpval ? A->d_lpval : a.val, a.x, \
+                           A->d_lpy, A->d_lpt, a.rows, (int)A->n, A->lp_W, A->lp_chunk, A->lp_C, A->lp_col_lo, A->lp_col_hi,  \
+                           (const SolverScalars *)a.sc, A->d_lpcol ? 1 : 0);                                                \
     } break;
     switch (A->lp_cfg) {
         SLA_LP_LAUNCH(1, 32, 4, 2)

@@ -70,10 +70,12 @@ def test_lds_panels_match_the_oracle_and_the_stream_kernel(sla, name):
     x, xt = rng.standard_normal(n), rng.standard_normal(m)
     want, want_t = orc.spmv(Ao, x), orc.spmv(orc.transpose(Ao), xt)
     got = {}
-    for form, opts in (("ldspanels", {}), ("stream", {"lpanel": 0})):
+    for form, opts in (("ldspanels", {}), ("ldspanels row-major", {"lp_copy": 0}), ("stream", {"lpanel": 0})):
         ctx = sla.Context(0).set_options(**opts)
         A = sla.fromCSR(dims, *csr, ctx)
-        assert ("ldspanels" in A.kernel_info()) == (form == "ldspanels"), (name, A.kernel_info())
+        assert ("ldspanels" in A.kernel_info()) == form.startswith("ldspanels"), (name, A.kernel_info())
+        if form.startswith("ldspanels"):    # (the default streams a panel-major second copy of the entries)
+            assert ("entries=panel-major-copy" in A.kernel_info()) == (form == "ldspanels"), A.kernel_info()
         y = sla.matVec(A, sla.fromVector(x, ctx)).toDenseListSV()
         yt = sla.vecMat(sla.fromVector(xt, ctx), A).toDenseListSV()
         assert np.all(np.abs(y - want) <= _bound(csr, x, m)), (name, form, np.abs(y - want).max())
@@ -82,6 +84,7 @@ def test_lds_panels_match_the_oracle_and_the_stream_kernel(sla, name):
         del A
         ctx.close()
     assert np.all(np.abs(got["ldspanels"] - got["stream"]) <= 2 * _bound(csr, x, m))
+    assert np.array_equal(got["ldspanels"], got["ldspanels row-major"])      # same segments, same order: the same bits
     empty = np.diff(csr[0]) == 0
     assert np.all(got["ldspanels"][empty] == 0.0)            # a row key with an empty row map gives 0.0 (Common.hs:242-250)
 
