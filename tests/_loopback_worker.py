@@ -217,6 +217,8 @@ if KIND == "randtile":   # (the tile form folds every row entry by entry in asce
     assert all("algo=tiles" in results[r]["kernel"] and "x_exchange=allgather" in results[r]["kernel"] for r in range(P)), results[0]["kernel"]
 assert sla.Context.binding_violations() == 0, "device work issued by a thread not bound to its context (SLA_DEBUG_BINDING)"
 import hashlib  # noqa: E402
+if os.environ.get("LOOPBACK_DUMP"):     # (tools/sweep_ghost_flows.sh: how far apart are two flows whose hashes differ?)
+    np.savez(os.environ["LOOPBACK_DUMP"], **{_m: np.concatenate([results[r][_m][0] for r in range(P)]) for _m in ("bicgstab", "cgs")})
 for _m in ("bicgstab", "cgs"):
     print("XHASH", _m, hashlib.sha1(np.concatenate([results[r][_m][0] for r in range(P)]).tobytes()).hexdigest(), results[0][_m][1])
 print("KERNEL", results[0]["kernel"])

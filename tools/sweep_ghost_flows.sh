@@ -1,11 +1,24 @@
 #!/bin/bash
-# 40 seeded random banded matrices on 2-5 loopback ranks (one GPU): the ghost-row BiCGSTAB / CGS flows must give the same
-# bits (and iteration counts) as the plain sharded flows.  Run on the GPU box: gpurun -- 'bash tools/sweep_ghost_flows.sh'
-fail=0
+# 40 seeded random banded matrices on 2-5 loopback ranks (one GPU): the ghost-row BiCGSTAB / CGS flows against the plain sharded
+# flows: same iteration counts and the same x -- bit for bit where the two flows group their partial sums alike, to rounding level
+# (<= 1e-13 relative; measured: 1-2 ulp in 3-5 % of the entries, seeds 33 and 40) where the interior / boundary split of an
+# overlapped SpMV orders them differently.  Run on the GPU box: gpurun -- 'bash tools/sweep_ghost_flows.sh'
+fail=0; exact=0; close=0
 for seed in $(seq 1 40); do
   P=$((2 + seed % 4))
-  a=$(timeout 120 python tests/_loopback_worker.py $P fuzz$seed 2>&1 | grep -E "XHASH|LOOPBACK_OK" | tr '\n' ' ')
-  b=$(SLA_BICG_GHOST=0 timeout 120 python tests/_loopback_worker.py $P fuzz$seed 2>&1 | grep -E "XHASH|LOOPBACK_OK" | tr '\n' ' ')
-  if [ "$a" != "$b" ] || [ -z "$a" ]; then echo "MISMATCH seed $seed P $P: [$a] vs [$b]"; fail=1; fi
+  a=$(LOOPBACK_DUMP=/tmp/ghost_$seed.npz timeout 120 python tests/_loopback_worker.py $P fuzz$seed 2>&1 | grep -E "XHASH|LOOPBACK_OK" | tr '\n' ' ')
+  b=$(SLA_BICG_GHOST=0 LOOPBACK_DUMP=/tmp/plain_$seed.npz timeout 120 python tests/_loopback_worker.py $P fuzz$seed 2>&1 | grep -E "XHASH|LOOPBACK_OK" | tr '\n' ' ')
+  if [ -z "$a" ] || [ -z "$b" ]; then echo "FAILED seed $seed P $P: [$a] vs [$b]"; fail=1; continue; fi
+  if [ "$a" == "$b" ]; then exact=$((exact + 1)); continue; fi
+  python - $seed "$a" "$b" <<'PY' && close=$((close + 1)) || fail=1
+import sys, numpy as np
+s = sys.argv[1]
+g, p = np.load(f"/tmp/ghost_{s}.npz"), np.load(f"/tmp/plain_{s}.npz")
+its = lambda t: [w for w in t.split() if w.isdigit()]
+worst = max(np.abs(g[m] - p[m]).max() / np.abs(p[m]).max() for m in ("bicgstab", "cgs"))
+ok = worst <= 1e-13 and its(sys.argv[2]) == its(sys.argv[3])
+print(f"seed {s}: hashes differ, max relative difference {worst:.2e}, iteration counts {'equal' if its(sys.argv[2]) == its(sys.argv[3]) else 'DIFFER'} -> {'rounding level' if ok else 'MISMATCH'}")
+sys.exit(0 if ok else 1)
+PY
 done
-echo "sweep done fail=$fail"
+echo "sweep done: $exact bit-identical, $close at rounding level, fail=$fail"
