@@ -921,16 +921,16 @@ static void low_lds_panels(Low &L) {
             if (err == hipSuccess) err = dev_malloc(c, (void **)&A->d_lpy, sizeof(double) * (size_t)(P * rows));
             // panel-major second copy of the entries (sla_spmv_lpanel.hip: lp_reorder_kernel), built on the device from the arrays just
             // uploaded; when it exists d_lpp is replaced by the P x rows + 1 segment starts into it.  12 B per entry: taken while it
-            // stays below 48 GB and the allocation succeeds (a failure here is not an error: the row-major arrays serve)
+            // (10 B: 16-bit panel offsets) stays below 48 GB and the allocation succeeds (a failure here is not an error: the row-major arrays serve)
             if (err == hipSuccess && c->lp_copy && nnz * 12 <= ((int64_t)48 << 30) && A->d_col && A->d_val) {
                 std::vector<int64_t> q((size_t)(P * rows) + 1, 0);
                 for (int64_t p = 0; p < P; ++p)
                     for (int64_t i = 0; i < rows; ++i)
                         q[(size_t)(p * rows + i) + 1] = q[(size_t)(p * rows + i)] + (pp[(size_t)((p + 1) * rows + i)] - pp[(size_t)(p * rows + i)]);
                 void *dq = nullptr;
-                int32_t *c2 = nullptr;
+                uint16_t *c2 = nullptr;
                 double *v2 = nullptr;
-                hipError_t e2 = dev_malloc(c, (void **)&c2, sizeof(int32_t) * (size_t)nnz + kArraySlack);
+                hipError_t e2 = W <= 65536 ? dev_malloc(c, (void **)&c2, sizeof(uint16_t) * (size_t)nnz + kArraySlack) : hipErrorInvalidValue;
                 if (e2 == hipSuccess) e2 = dev_malloc(c, (void **)&v2, sizeof(double) * (size_t)nnz + kArraySlack);
                 if (e2 == hipSuccess) e2 = dev_malloc(c, &dq, rpsz * q.size() + kArraySlack);
                 if (e2 == hipSuccess) {
@@ -941,7 +941,7 @@ static void low_lds_panels(Low &L) {
                         e2 = hipMemcpy(dq, q32.data(), sizeof(int32_t) * q32.size(), hipMemcpyHostToDevice);
                     }
                 }
-                if (e2 == hipSuccess && launch_lp_reorder(c, A->rp64, A->d_lpp, dq, A->d_col, A->d_val, c2, v2, rows, P) != SLA_OK) e2 = hipErrorUnknown;
+                if (e2 == hipSuccess && launch_lp_reorder(c, A->rp64, A->d_lpp, dq, A->d_col, A->d_val, c2, v2, rows, P, (int32_t)W) != SLA_OK) e2 = hipErrorUnknown;
                 if (e2 == hipSuccess) {
                     (void)hipFree(A->d_lpp);
                     A->d_lpp = dq;
@@ -1834,7 +1834,7 @@ int sla_csr_kernel_info(sla_csr_t A, char *buf, int buflen) {
         else if (A->use_wdia && wd_on(A) && wd_lds_on(A)) mb = 128 * (int64_t)A->nslices;   // 16 lane masks per slice
         else if (A->use_wdia && wd_on(A)) mb = A->nwent * (A->wd_vv ? 20 + 128 * 8 : 28) + 4 * ((int64_t)A->nslices + 1);
         else if (A->use_vdict && c->vdict) mb = A->nnz + 4 * (A->rows + 1);
-        else if (A->use_lpanel && c->lpanel) mb = 12 * A->nnz + (int64_t)(A->lp_P + 1) * A->rows * rps + 16 * (int64_t)A->lp_P * A->rows;
+        else if (A->use_lpanel && c->lpanel) mb = (A->d_lpcol ? 10 : 12) * A->nnz + (int64_t)(A->lp_P + 1) * A->rows * rps + 16 * (int64_t)A->lp_P * A->rows;
         else if (tiles_on(A)) mb = 12 * A->nnz + 4 * (int64_t)A->tl_S * (A->tl_P + 1) + 4 * ((int64_t)A->tl_S + 1) + rps * A->tl_S;
         else if (!A->panels.empty() && c->panels) mb = 12 * A->nnz + (int64_t)A->panels.size() * (rps * A->rows + 8 * (int64_t)A->nrb) + 16 * ((int64_t)A->panels.size() - 1) * A->rows;
         else mb = (A->use_diag && c->diag ? 9 : 12) * A->nnz + rps * (A->rows + 1) + (4 + rps) * (int64_t)A->nrb;

@@ -312,7 +312,7 @@ struct sla_csr {
     int32_t lp_col_lo = 0, lp_col_hi = -1;   // smallest / largest column any of these rows references
     int32_t *d_lpt = nullptr;        // lp_G + 1 task boundaries: workgroup g runs tasks [lpt[g], lpt[g+1]) (equal entries each)
     int32_t lp_G = 0;
-    int32_t *d_lpcol = nullptr;      // panel-major second copy of the entries (segments of a panel contiguous, rows ascending): then
+    uint16_t *d_lpcol = nullptr;     // panel-major second copy of the entries (segments of a panel contiguous, rows ascending; columns as 16-bit offsets into the panel): then
     double *d_lpval = nullptr;       //   d_lpp holds P x rows + 1 segment starts into it instead of the (P + 1) x rows table
     double *d_lpy = nullptr;         // P x rows partial sums, summed in ascending panel order by lpanel_finish_kernel
     bool use_lpanel = false;
@@ -597,8 +597,8 @@ int launch_spmv_dual_diag(const sla_csr *A, const SpmvArgs<int32_t> &a, const do
 int launch_spmv_dual_diag(const sla_csr *A, const SpmvArgs<int64_t> &a, const double *x2, const double *b2, int grid);
 int launch_spmv_vdict(const sla_csr *A, int epi, const SpmvArgs<int32_t> &a, const double *x2, const double *b2, int grid);
 int launch_spmv_wdia(const sla_csr *A, int epi, const SpmvArgs<int32_t> &a, const int32_t *sched, int32_t nblk_wd, int grid, int stream_nt);   // sla_spmv_wdia.hip
-int launch_lp_reorder(sla_ctx *c, bool rp64, const void *pp, const void *q, const int32_t *col, const double *val, int32_t *col2, double *val2,
-                      int64_t rows, int64_t P);                                                            // sla_spmv_lpanel.hip
+int launch_lp_reorder(sla_ctx *c, bool rp64, const void *pp, const void *q, const int32_t *col, const double *val, uint16_t *col2, double *val2,
+                      int64_t rows, int64_t P, int32_t W);                                                            // sla_spmv_lpanel.hip
 int launch_spmv_lpanel(const sla_csr *A, int epi, const SpmvArgs<int32_t> &a, int grid);
 int launch_spmv_lpanel(const sla_csr *A, int epi, const SpmvArgs<int64_t> &a, int grid);
 // do the solver's vectors (7 of n entries for BiCGSTAB) overflow the memory-side cache?  Then stream them past it.

@@ -21,12 +21,13 @@ namespace sla {
 // in ascending order, two segments in flight per wavefront -- into per-panel partial sums.  Tasks (panel, row chunk)
 // are dealt out panel-major in contiguous runs of equal entry counts (task_begin), so a workgroup reloads x about once.  lpanel_finish_kernel then
 // adds the partials of a row in ascending panel order and runs the fused epilogue.
-template <typename RP, int L, int R, int J>
+// PM: the entries come from the panel-major copy, whose columns are 16-bit offsets into the panel (W <= 16384): 10 B per entry
+template <typename RP, int L, int R, int J, bool PM>
 __global__ void __launch_bounds__(kLpBlock) spmv_lpanel_kernel(const RP *__restrict__ pp, const int32_t *__restrict__ col,
                                                                const double *__restrict__ val, const double *__restrict__ xg,
                                                                double *__restrict__ ypart, const int32_t *__restrict__ task_begin,
                                                                int rows, int n, int W, int chunk_rows, int C, int col_lo, int col_hi,
-                                                               const SolverScalars *sc, int panel_major) {
+                                                               const SolverScalars *sc) {
     // L lanes per (row, panel) segment, R segments per lane group and round, J strided loads per segment and round: a
     // wavefront keeps (64 / L) * R segments = 64 * R * J entries in flight.  A round costs a memory round trip however
     // little it carries (measured: ~0.9 us), so short segments get narrow groups -- see the table at the launch.
@@ -52,7 +53,8 @@ __global__ void __launch_bounds__(kLpBlock) spmv_lpanel_kernel(const RP *__restr
         const int lo = c * chunk_rows, hi = min(rows, lo + chunk_rows);
         // segment (p, i): [pp[p][i], pp[p + 1][i]) of the row-major arrays, or -- panel-major copy, where the segments of a panel follow
         // each other and a segment's edge lines are its neighbours' -- [q[p rows + i], q[p rows + i + 1])
-        const RP *ps = pp + (int64_t)p * rows, *pe = ps + (panel_major ? 1 : rows);
+        const RP *ps = pp + (int64_t)p * rows, *pe = ps + (PM ? 1 : rows);
+        const uint16_t *col16 = (const uint16_t *)col;
         double *yp = ypart + (int64_t)p * rows;
         for (int base = lo; base < hi; base += R * GPB) {   // (wavefront-uniform trip count)
             // (fetching the next round's segment pointers a round ahead was tried: no gain where each shape is used)
@@ -77,7 +79,8 @@ __global__ void __launch_bounds__(kLpBlock) spmv_lpanel_kernel(const RP *__restr
 #pragma unroll
                     for (int j = 0; j < J; ++j) {
                         if (k[r] + L * j < e[r]) {
-                            cj[r][j] = __builtin_nontemporal_load(col + k[r] + L * j);
+                            if constexpr (PM) cj[r][j] = (int32_t)__builtin_nontemporal_load(col16 + k[r] + L * j);
+                            else cj[r][j] = __builtin_nontemporal_load(col + k[r] + L * j);   // (- w0 at the use: nothing may touch a loaded value in this phase)
                             vj[r][j] = __builtin_nontemporal_load(val + k[r] + L * j);
                         }
                     }
@@ -88,7 +91,7 @@ __global__ void __launch_bounds__(kLpBlock) spmv_lpanel_kernel(const RP *__restr
 #pragma unroll
                     for (int j = 0; j < J; ++j) {
                         if (k[r] + L * j < e[r]) {
-                            const double prod = vj[r][j] * lp_xs[cj[r][j] - w0];
+                            const double prod = vj[r][j] * lp_xs[cj[r][j] - (PM ? 0 : w0)];
                             acc[r] = acc[r] + prod;
                         }
                     }
@@ -116,29 +119,31 @@ __global__ void __launch_bounds__(kLpBlock) spmv_lpanel_kernel(const RP *__restr
 // Panel-major second copy (lowering time): segment (p, i) of the row-major arrays goes to q[p rows + i].  Read row-major the
 // segments of a panel are ~150 entries each, 2000 entries apart: their first and last 128-byte lines are fetched again for the
 // neighbouring panels' segments, by other workgroups at other times -- 13 % of the kernel's HBM traffic on the 200 k x 2000-per-row
-// matrix (PMC: 5.47 GB per launch for 4.83 GB of entries).  One wavefront per segment.
+// matrix (PMC: 5.47 GB per launch for 4.83 GB of entries).  The copy's columns are 16-bit offsets into the panel: 10 B per entry.
+// One wavefront per segment.
 template <typename RP>
 __global__ void __launch_bounds__(kBlock) lp_reorder_kernel(const RP *__restrict__ pp, const RP *__restrict__ q, const int32_t *__restrict__ col,
-                                                            const double *__restrict__ val, int32_t *__restrict__ col2, double *__restrict__ val2,
-                                                            int64_t rows, int64_t nseg) {
+                                                            const double *__restrict__ val, uint16_t *__restrict__ col2, double *__restrict__ val2,
+                                                            int64_t rows, int64_t nseg, int32_t W) {
     const int ln = threadIdx.x & 63;
     for (int64_t s = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); s < nseg; s += (int64_t)gridDim.x * (kBlock / 64)) {
         const int64_t b = (int64_t)pp[s], e = (int64_t)pp[s + rows], d = (int64_t)q[s];
+        const int32_t w0 = (int32_t)(s / rows) * W;          // the segment's panel starts at column w0: 16-bit offsets (W <= 16384)
         for (int64_t k = b + ln; k < e; k += 64) {
-            col2[d + (k - b)] = col[k];
+            col2[d + (k - b)] = (uint16_t)(col[k] - w0);
             val2[d + (k - b)] = val[k];
         }
     }
 }
 
-int launch_lp_reorder(sla_ctx *c, bool rp64, const void *pp, const void *q, const int32_t *col, const double *val, int32_t *col2, double *val2,
-                      int64_t rows, int64_t P) {
+int launch_lp_reorder(sla_ctx *c, bool rp64, const void *pp, const void *q, const int32_t *col, const double *val, uint16_t *col2, double *val2,
+                      int64_t rows, int64_t P, int32_t W) {
     const int64_t nseg = rows * P;
     const int grid = (int)std::min<int64_t>(64 * (int64_t)c->n_cu, std::max<int64_t>(1, (nseg + 3) / 4));
     if (rp64)
-        hipLaunchKernelGGL(lp_reorder_kernel<int64_t>, dim3(grid), dim3(kBlock), 0, stream_of(c), (const int64_t *)pp, (const int64_t *)q, col, val, col2, val2, rows, nseg);
+        hipLaunchKernelGGL(lp_reorder_kernel<int64_t>, dim3(grid), dim3(kBlock), 0, stream_of(c), (const int64_t *)pp, (const int64_t *)q, col, val, col2, val2, rows, nseg, W);
     else
-        hipLaunchKernelGGL(lp_reorder_kernel<int32_t>, dim3(grid), dim3(kBlock), 0, stream_of(c), (const int32_t *)pp, (const int32_t *)q, col, val, col2, val2, rows, nseg);
+        hipLaunchKernelGGL(lp_reorder_kernel<int32_t>, dim3(grid), dim3(kBlock), 0, stream_of(c), (const int32_t *)pp, (const int32_t *)q, col, val, col2, val2, rows, nseg, W);
     SLA_HIP_TRY(hipGetLastError());
     SLA_HIP_TRY(hipStreamSynchronize(stream_of(c)));
     return SLA_OK;
@@ -176,19 +181,24 @@ int launch_lpanel_t(const sla_csr *A, const SpmvArgs<RP> &a, int grid) {
     sla_ctx *c = A->ctx;
     // lane-group shape by mean segment length (A->lp_cfg, set at lowering): 64 lanes x 2 segments x 4 loads for long
     // segments, narrower groups with more segments per wavefront for short ones
-#define SLA_LP_LAUNCH(CFG, L_, R_, J_)                                                                                         \
-    case CFG: {                                                                                                             \
-        const int attr_bit = 1 << (2 * CFG + (std::is_same<RP, int32_t>::value ? 0 : 1));                                   \
+#define SLA_LP_LAUNCH_PM(CFG, L_, R_, J_, PM_)                                                                                \
+    {                                                                                                                       \
+        const int attr_bit = 1 << (4 * CFG + 2 * (PM_ ? 1 : 0) + (std::is_same<RP, int32_t>::value ? 0 : 1));              \
         if (!(c->lp_attr & attr_bit)) {   /* per context = per device: 128 KiB of dynamic LDS */                            \
-            SLA_HIP_TRY(hipFuncSetAttribute((const void *)spmv_lpanel_kernel<RP, L_, R_, J_>,                               \
+            SLA_HIP_TRY(hipFuncSetAttribute((const void *)spmv_lpanel_kernel<RP, L_, R_, J_, PM_>,                          \
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kLpW * sizeof(double))));     \
             c->lp_attr |= attr_bit;                                                                                         \
         }                                                                                                                   \
-        hipLaunchKernelGGL((spmv_lpanel_kernel<RP, L_, R_, J_>), dim3(A->lp_G), dim3(kLpBlock), kLpW * sizeof(double),      \
-                           stream_of(c), (const RP *)A->d_lpp, A->d_lpcol ? A->d_lpcol : a.col, A->d_lpval ? A->d_lpval : a.val, a.x, \
+        hipLaunchKernelGGL((spmv_lpanel_kernel<RP, L_, R_, J_, PM_>), dim3(A->lp_G), dim3(kLpBlock), kLpW * sizeof(double), \
+                           stream_of(c), (const RP *)A->d_lpp, PM_ ? (const int32_t *)A->d_lpcol : a.col, PM_ ? A->d_lpval : a.val, a.x, \
                            A->d_lpy, A->d_lpt, a.rows, (int)A->n, A->lp_W, A->lp_chunk, A->lp_C, A->lp_col_lo, A->lp_col_hi,  \
-                           (const SolverScalars *)a.sc, A->d_lpcol ? 1 : 0);                                                \
-    } break;
+                           (const SolverScalars *)a.sc);                                                                    \
+    }
+#define SLA_LP_LAUNCH(CFG, L_, R_, J_)                                  \
+    case CFG:                                                           \
+        if (A->d_lpcol) SLA_LP_LAUNCH_PM(CFG, L_, R_, J_, true)         \
+        else SLA_LP_LAUNCH_PM(CFG, L_, R_, J_, false)                   \
+        break;
     switch (A->lp_cfg) {
         SLA_LP_LAUNCH(1, 32, 4, 2)
         SLA_LP_LAUNCH(2, 16, 4, 2)
@@ -196,6 +206,7 @@ int launch_lpanel_t(const sla_csr *A, const SpmvArgs<RP> &a, int grid) {
         default:
         SLA_LP_LAUNCH(0, 64, kLpRowsInFlight, 4)
     }
+#undef SLA_LP_LAUNCH_PM
 #undef SLA_LP_LAUNCH
     SLA_HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL((lpanel_finish_kernel<EPI, RP>), dim3(grid), dim3(kBlock), 0, stream_of(c), a, A->d_lpy, A->lp_P);
