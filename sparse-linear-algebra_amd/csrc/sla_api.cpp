@@ -1,4 +1,4 @@
-// sla_api.cpp -- C ABI: context, SpMatrix lowering, SpVector, (#>) (<#) (<.>) norm2 axpby.
+// sla_api.cpp -- C ABI: context and options, SpVector, (#>) (<#) (<.>) norm2 axpby, the x exchange of row-sharded contexts, triangular solves and preconditioner builders (the lowering: sla_lower.cpp).
 // Reference citations per entry point are in include/sla_hip.h.
 #include <math.h>
 #include <stdlib.h>
@@ -137,60 +137,6 @@ int gather_x(const sla_csr *A, sla_vec *x, const double **base) {
     return gather_raw(c, A, x->d, x->shard, base);
 }
 
-// sharded only: all-gather every rank's referenced column window and derive the exchange plan
-static int build_xplan(sla_csr *A, int64_t rows, const int64_t *rowptr, const int64_t *col) {
-    sla_ctx *c = A->ctx;
-    if (!c->collectives) return SLA_OK;
-    int64_t w[2] = {1, 0};  // empty
-    const int64_t nnz = rowptr[rows];
-    if (nnz > 0) {
-        w[0] = col[0];
-        w[1] = col[0];
-        for (int64_t i = 0; i < rows; ++i)
-            if (rowptr[i + 1] > rowptr[i]) {  // canonical CSR: first / last entry of a row are its min / max
-                w[0] = std::min(w[0], col[rowptr[i]]);
-                w[1] = std::max(w[1], col[rowptr[i + 1] - 1]);
-            }
-    }
-    // ship the two int64 as raw 8-byte words through the f64 all-gather (no arithmetic touches them)
-    double *d = c->d_result + 64;
-    SLA_HIP_TRY(hipMemcpyAsync(d, w, sizeof(w), hipMemcpyHostToDevice, stream_of(c)));
-    SLA_TRY(dist_allgather_f64(c, d, d + 8, 2));
-    std::vector<int64_t> all((size_t)2 * c->nranks);
-    SLA_HIP_TRY(hipMemcpyAsync(all.data(), d + 8, sizeof(int64_t) * all.size(), hipMemcpyDeviceToHost, stream_of(c)));
-    SLA_HIP_TRY(hipStreamSynchronize(stream_of(c)));
-    A->xplan = new XPlan();
-    plan_window_exchange(c->nranks, c->rank, A->n, all.data(), *A->xplan);
-    return SLA_OK;
-}
-
-// Row-sharded comm / compute overlap.  For the wave-sliced forms the 512-row steps are split into the
-// INTERIOR ones -- every row references columns of this rank's own block only: they can run while the halo exchange is in
-// flight -- and the BOUNDARY ones, each list in the visiting order of the full walk (the plane-tiled `sched` when there is
-// one).  Taken when the window exchange is in use and most steps are interior.
-static int build_overlap_lists(sla_csr *A, int64_t m, int64_t n, int64_t row_begin, int64_t rows, const int64_t *rowptr, const int64_t *col) {
-    sla_ctx *c = A->ctx;
-    if (!c->collectives || c->overlap < 0 || !A->use_wdia || !A->xplan || m != n || rows == 0) return SLA_OK;
-    if (!(A->xplan->use_window || c->x_exchange == 2) || c->x_exchange == 1) return SLA_OK;
-    const int64_t lo = row_begin, hi = row_begin + rows;
-    std::vector<char> bnd((size_t)A->nblk_wd, 0);
-    for (int64_t i = 0; i < rows; ++i)
-        if (rowptr[i + 1] > rowptr[i] && (col[rowptr[i]] < lo || col[rowptr[i + 1] - 1] >= hi)) bnd[(size_t)(i / 512)] = 1;   // canonical CSR: min / max column
-    std::vector<int32_t> li, lb;
-    for (int32_t t = 0; t < A->nblk_wd; ++t) {
-        const int32_t s = A->h_wsched.empty() ? t : A->h_wsched[(size_t)t];
-        (bnd[(size_t)s] ? lb : li).push_back(s);
-    }
-    if (lb.empty() || li.size() < lb.size()) return SLA_OK;   // nothing to exchange for / too little to hide it behind
-    SLA_HIP_TRY(dev_malloc(c, (void **)&A->d_ov_int, sizeof(int32_t) * li.size()));
-    SLA_HIP_TRY(dev_malloc(c, (void **)&A->d_ov_bnd, sizeof(int32_t) * lb.size()));
-    SLA_HIP_TRY(hipMemcpy(A->d_ov_int, li.data(), sizeof(int32_t) * li.size(), hipMemcpyHostToDevice));
-    SLA_HIP_TRY(hipMemcpy(A->d_ov_bnd, lb.data(), sizeof(int32_t) * lb.size(), hipMemcpyHostToDevice));
-    A->ov_nint = (int32_t)li.size();
-    A->ov_nbnd = (int32_t)lb.size();
-    return SLA_OK;
-}
-
 // (#>) with its input exchange.  When the matrix has interior / boundary step lists and the halo lands in place around x:
 //   compute stream:  ... producers of x | record(x ready) | interior launch .................. | wait(halo done) | boundary launch
 //   comm stream:                         wait(x ready) | halo send / recv (RCCL) | record(halo done)
@@ -306,785 +252,6 @@ int vec_alloc(sla_ctx *c, int64_t n, sla_vec **out) {
         return fail(SLA_ERR_HIP, std::string("hipMemsetAsync: ") + hipGetErrorString(err));
     }
     *out = v;
-    return SLA_OK;
-}
-
-static int csr_upload(sla_ctx *c, int64_t m, int64_t n, int64_t row_begin, int64_t rows, const int64_t *rowptr,
-                      const int64_t *col, const double *val, sla_csr **out, bool panel_view = false);
-
-// A rank whose input fails validation still owes its peers the agreement collective of csr_upload (they would block in it
-// forever): contribute "failed", then report the local error.
-static int csr_reject(sla_ctx *c, int rc) {
-    if (c && c->collectives) {
-        const std::string msg = g_last_error;
-        int agree = 2;
-        (void)dist_allreduce_max_i32(c, &agree);
-        set_error(msg);
-    }
-    return rc;
-}
-
-// Column panels for irregular matrices (see launch_spmv_panels): panel p = the entries with column in
-// [p W, (p+1) W), as a CSR view over the same rows.  Worth it when x does not fit the XCD-private L2 and
-// every row still has about one entry per panel.
-static int build_panels(sla_csr *A, int64_t m, int64_t n, int64_t row_begin, int64_t rows, const int64_t *rowptr,
-                        const int64_t *col, const double *val) {
-    sla_ctx *c = A->ctx;
-    const int64_t nnz = rowptr[rows];
-    if (!c->panels || A->use_diag || A->xwin_fraction >= 0.5 || rows == 0) return SLA_OK;
-    const int64_t W = std::max<int64_t>(c->panel_cols, 1);
-    if (n <= 2 * W) return SLA_OK;                                   // x (nearly) fits the L2 already
-    int64_t P = std::min<int64_t>((n + W - 1) / W, nnz / rows);      // >= ~1 entry per row per panel
-    if (P < 2) return SLA_OK;
-    const int64_t Wp = (n + P - 1) / P;
-    std::vector<int64_t> cur(rowptr, rowptr + rows), prp((size_t)rows + 1), pcol;
-    std::vector<double> pval;
-    for (int64_t p = 0; p < P; ++p) {
-        const int64_t chi = std::min<int64_t>(n, (p + 1) * Wp);
-        pcol.clear();
-        pval.clear();
-        prp[0] = 0;
-        for (int64_t i = 0; i < rows; ++i) {
-            int64_t k = cur[(size_t)i];
-            const int64_t e = rowptr[i + 1];
-            while (k < e && col[k] < chi) {
-                pcol.push_back(col[k]);
-                pval.push_back(val[k]);
-                ++k;
-            }
-            cur[(size_t)i] = k;
-            prp[(size_t)i + 1] = (int64_t)pcol.size();
-        }
-        sla_csr *V = nullptr;
-        SLA_TRY(csr_upload(c, m, n, row_begin, rows, prp.data(), pcol.data(), pval.data(), &V, true));
-        V->is_panel_view = true;
-        A->panels.push_back(V);
-    }
-    SLA_HIP_TRY(dev_malloc(c, (void **)&A->d_panel_y, sizeof(double) * (size_t)std::max<int64_t>(rows, 1)));
-    return SLA_OK;
-}
-
-// The lowering analyses (dictionaries, codes, slice records) are row-parallel: run fn(t, lo, hi) over T contiguous row
-// ranges whose boundaries are multiples of `align` rows, on T host threads (SLA_HOST_THREADS, default <= 16).
-static int host_threads() {
-    static const int t = [] {
-        const char *s = getenv("SLA_HOST_THREADS");
-        int v = s ? atoi(s) : (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
-        return std::max(1, std::min(v, 64));
-    }();
-    return t;
-}
-template <class F>
-static int par_rows(int64_t rows, int64_t align, F fn, int64_t serial_below = 200000) {
-    int T = host_threads();
-    const int64_t units = (rows + align - 1) / align;
-    if (units < 64 || rows < serial_below) T = 1;
-    T = (int)std::min<int64_t>(T, std::max<int64_t>(units, 1));
-    auto range = [&](int t, int64_t &lo, int64_t &hi) {
-        lo = std::min<int64_t>(rows, units * t / T * align);
-        hi = std::min<int64_t>(rows, units * (t + 1) / T * align);
-    };
-    if (T == 1) { fn(0, (int64_t)0, rows); return 1; }
-    std::vector<std::thread> th;
-    for (int t = 0; t < T; ++t) {
-        int64_t lo, hi;
-        range(t, lo, hi);
-        th.emplace_back([=, &fn] { fn(t, lo, hi); });
-    }
-    for (auto &x : th) x.join();
-    return T;
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// csr_upload = one lowering analysis per function.  What they share travels in `Low`; SLA_LOW_LOCALS re-opens it under the
-// names the analyses use.
-// ---------------------------------------------------------------------------------------------------------------
-struct Low {
-    sla_ctx *c;
-    sla_csr *A;
-    int64_t m, n, row_begin, rows, nnz;
-    const int64_t *rowptr, *col;
-    const double *val;
-    bool panel_view, dbg_lower;
-    hipError_t err = hipSuccess;
-    std::vector<int32_t> rb;            // row-block starts
-    std::vector<int64_t> offs;          // sorted distinct diagonal offsets (<= 256) when the matrix has that structure
-    std::vector<uint8_t> dcodes;        // per entry: index into offs
-    // (every lowered array carries kArraySlack zeroed bytes behind its end: the pipelined stream kernel reads whole row blocks
-    // with clamped, unconditional loads, and an empty row block at the very end of the matrix reads "its" first entry there)
-    void upload(void **dst, const void *src, size_t bytes) {
-        if (err != hipSuccess) return;
-        err = dev_malloc(c, dst, bytes + kArraySlack);
-        if (err == hipSuccess && bytes) err = hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
-        if (err == hipSuccess) err = hipMemset((char *)*dst + bytes, 0, kArraySlack);
-    }
-};
-#define SLA_LOW_LOCALS(L)                                                                                                  \
-    [[maybe_unused]] sla_ctx *c = (L).c;                                                                                   \
-    [[maybe_unused]] sla_csr *A = (L).A;                                                                                   \
-    [[maybe_unused]] const int64_t m = (L).m, n = (L).n, row_begin = (L).row_begin, rows = (L).rows, nnz = (L).nnz;        \
-    [[maybe_unused]] const int64_t *rowptr = (L).rowptr, *col = (L).col;                                                   \
-    [[maybe_unused]] const double *val = (L).val;                                                                          \
-    [[maybe_unused]] const bool panel_view = (L).panel_view, dbg_lower = (L).dbg_lower;                                    \
-    [[maybe_unused]] hipError_t &err = (L).err;                                                                            \
-    [[maybe_unused]] std::vector<int32_t> &rb = (L).rb;                                                                    \
-    [[maybe_unused]] std::vector<int64_t> &offs = (L).offs;                                                                \
-    [[maybe_unused]] std::vector<uint8_t> &dcodes = (L).dcodes;                                                            \
-    [[maybe_unused]] auto upload = [&](void **dst_, const void *src_, size_t bytes_) { (L).upload(dst_, src_, bytes_); }
-
-// canonical CSR arrays (i32 columns, i32 / i64 row pointers) + the row-block tables of the general kernels
-static void low_csr_arrays(Low &L) {
-    SLA_LOW_LOCALS(L);
-    // the values go up on a second host thread while this one narrows and uploads the indices (pageable copies are
-    // bound by the staging memcpy of the calling thread, not by the link)
-    hipError_t err_val = hipSuccess;
-    struct Joiner {   // (a host allocation failing below must not unwind past a joinable thread)
-        std::thread &t;
-        ~Joiner() { if (t.joinable()) t.join(); }
-    };
-    std::thread val_up([&] {
-        Bind bind(c);   // (a new thread starts on device 0)
-        if (err_val == hipSuccess) err_val = dev_malloc(c, (void **)&A->d_val, sizeof(double) * (size_t)nnz + kArraySlack);
-        if (err_val == hipSuccess && nnz) err_val = hipMemcpy(A->d_val, val, sizeof(double) * (size_t)nnz, hipMemcpyHostToDevice);
-        if (err_val == hipSuccess) err_val = hipMemset((char *)A->d_val + sizeof(double) * (size_t)nnz, 0, kArraySlack);
-    });
-    Joiner val_up_joiner{val_up};
-    {
-        std::vector<int32_t> col32((size_t)nnz);
-        par_rows(rows, 1, [&](int, int64_t lo, int64_t hi) {
-            for (int64_t k = rowptr[lo]; k < rowptr[hi]; ++k) col32[(size_t)k] = (int32_t)col[k];
-        });
-        upload((void **)&A->d_col, col32.data(), sizeof(int32_t) * (size_t)nnz);
-    }
-    if (A->rp64) {
-        upload(&A->d_rowptr, rowptr, sizeof(int64_t) * (size_t)(rows + 1));
-        std::vector<int64_t> rbk(rb.size());
-        for (size_t b = 0; b < rb.size(); ++b) rbk[b] = rowptr[rb[b]];
-        upload(&A->d_rbk, rbk.data(), sizeof(int64_t) * rbk.size());
-    } else {
-        std::vector<int32_t> rbk(rb.size());
-        for (size_t b = 0; b < rb.size(); ++b) rbk[b] = (int32_t)rowptr[rb[b]];
-        upload(&A->d_rbk, rbk.data(), sizeof(int32_t) * rbk.size());
-        std::vector<int32_t> rp32((size_t)rows + 1);
-        for (int64_t i = 0; i <= rows; ++i) rp32[(size_t)i] = (int32_t)rowptr[i];
-        upload(&A->d_rowptr, rp32.data(), sizeof(int32_t) * (size_t)(rows + 1));
-    }
-    upload((void **)&A->d_rb, rb.data(), sizeof(int32_t) * rb.size());
-    val_up.join();
-    if (err == hipSuccess) err = err_val;
-}
-
-// LDS x window of every row block (spmv_xwin_kernel) and the share of the entries that fall inside
-static void low_xwin_statistics(Low &L) {
-    SLA_LOW_LOCALS(L);
-    if (!panel_view) {
-        // LDS x window of each row block: kXWin columns starting kXWinHalo left of its first diagonal column
-        std::vector<int32_t> rbw(rb.size(), 0);
-        int64_t inside = 0, total = 0;
-        const int64_t wmax = std::max<int64_t>(0, n - kXWin);
-        std::vector<int64_t> part_in((size_t)host_threads(), 0), part_tot((size_t)host_threads(), 0);
-        par_rows((int64_t)rb.size() - 1, 1, [&](int t, int64_t blo, int64_t bhi) {
-            int64_t in = 0, tot = 0;
-            for (int64_t b = blo; b < bhi; ++b) {
-                const int64_t w = std::min<int64_t>(wmax, std::max<int64_t>(0, row_begin + rb[(size_t)b] - kXWinHalo));
-                rbw[(size_t)b] = (int32_t)w;
-                const int64_t k0 = rowptr[rb[(size_t)b]], k1 = rowptr[rb[(size_t)b + 1]];
-                if (k1 - k0 > kNnzPerRowBlock) continue;  // long-row blocks gather from global memory
-                tot += k1 - k0;
-                for (int64_t k = k0; k < k1; ++k) in += (col[k] >= w && col[k] < w + kXWin) ? 1 : 0;
-            }
-            part_in[(size_t)t] = in;
-            part_tot[(size_t)t] = tot;
-        }, 4096);
-        for (size_t t = 0; t < part_in.size(); ++t) { inside += part_in[t]; total += part_tot[t]; }
-        A->xwin_fraction = total ? (double)inside / (double)total : 0.0;
-        A->use_xwin = A->xwin_fraction >= 0.5;
-        upload((void **)&A->d_rbw, rbw.data(), sizeof(int32_t) * rbw.size());
-    }
-}
-
-// dictionary of diagonal offsets + 1-byte column codes (spmv_diag_kernel): <= 256 distinct col - row values
-static void low_diagonal_dictionary(Low &L) {
-    SLA_LOW_LOCALS(L);
-    if (!panel_view) {
-        // dictionary of diagonal offsets: worthwhile (and representable in a byte) when col - row takes at
-        // most 256 distinct values, i.e. for stencil / banded structure
-        bool ok = nnz > 0;
-        {   // distinct offsets: per-thread sets, merged
-            std::vector<std::vector<int64_t>> loc((size_t)host_threads());
-            std::vector<char> bad((size_t)host_threads(), 0);
-            par_rows(rows, 1, [&](int t, int64_t lo, int64_t hi) {
-                std::vector<int64_t> &mine = loc[(size_t)t];
-                for (int64_t i = lo; i < hi && !bad[(size_t)t]; ++i) {
-                    const int64_t gr = row_begin + i;
-                    for (int64_t k = rowptr[i]; k < rowptr[i + 1]; ++k) {
-                        const int64_t d = col[k] - gr;
-                        bool found = false;
-                        for (int64_t o : mine) if (o == d) { found = true; break; }   // <= 256 entries: a linear scan is fine
-                        if (!found) {
-                            if (mine.size() == 256) { bad[(size_t)t] = 1; break; }
-                            mine.push_back(d);
-                        }
-                    }
-                }
-            });
-            for (size_t t = 0; t < loc.size() && ok; ++t) {
-                if (bad[t]) ok = false;
-                for (int64_t d : loc[t]) {
-                    if (std::find(offs.begin(), offs.end(), d) != offs.end()) continue;
-                    if (offs.size() == 256) { ok = false; break; }
-                    offs.push_back(d);
-                }
-            }
-            if (!ok) offs.clear();
-        }
-        if (ok) {
-            std::sort(offs.begin(), offs.end());
-            std::vector<int32_t> dict(256, (int32_t)offs.back());
-            for (size_t t = 0; t < offs.size(); ++t) dict[t] = (int32_t)offs[t];
-            std::vector<uint8_t> &codes = dcodes;
-            codes.resize((size_t)nnz);
-            par_rows(rows, 1, [&](int, int64_t lo, int64_t hi) {
-                for (int64_t i = lo; i < hi; ++i) {
-                    const int64_t gr = row_begin + i;
-                    for (int64_t k = rowptr[i]; k < rowptr[i + 1]; ++k)
-                        codes[(size_t)k] = (uint8_t)(std::lower_bound(offs.begin(), offs.end(), col[k] - gr) - offs.begin());
-                }
-            });
-            upload((void **)&A->d_code, codes.data(), codes.size());
-            upload((void **)&A->d_dict, dict.data(), sizeof(int32_t) * dict.size());
-            A->use_diag = true;
-            A->ndiag = (int)offs.size();
-        }
-    }
-}
-
-// value-indexed forms for constant-coefficient stencils: (offset, value) pair dictionary + byte codes (spmv_vdict_kernel), the
-// wave-sliced records and the plane-tiled visiting order (spmv_wdia_kernel)
-static void low_value_indexed(Low &L) {
-    SLA_LOW_LOCALS(L);
-    if (!panel_view && !A->rp64 && nnz > 0 && A->max_row_nnz <= kVdMaxRowNnz) {
-        // value-indexed form: dictionary of (col - row, value bit pattern) pairs, one byte per entry
-        struct Pair { int64_t off; uint64_t bits; };
-        auto bits_of = [](double v) { uint64_t u; memcpy(&u, &v, 8); return u; };
-        constexpr int kSlots = 1024;                       // open addressing, <= 256 live keys
-        struct PairTable {
-            std::vector<int> slot = std::vector<int>(kSlots, -1);
-            std::vector<Pair> pairs;
-            int find(int64_t off, uint64_t bits, bool insert) {
-                uint64_t h = ((uint64_t)off * 0x9E3779B97F4A7C15ull) ^ (bits * 0xC2B2AE3D27D4EB4Full);
-                h ^= h >> 29;
-                for (int i = (int)(h & (kSlots - 1));; i = (i + 1) & (kSlots - 1)) {
-                    const int id = slot[(size_t)i];
-                    if (id < 0) {
-                        if (!insert || pairs.size() == 256) return -1;
-                        slot[(size_t)i] = (int)pairs.size();
-                        pairs.push_back({off, bits});
-                        return (int)pairs.size() - 1;
-                    }
-                    if (pairs[(size_t)id].off == off && pairs[(size_t)id].bits == bits) return id;
-                }
-            }
-        };
-        PairTable tab;                                     // the matrix's table: per-thread tables, merged
-        std::vector<Pair> &pairs = tab.pairs;
-        auto find = [&](int64_t off, uint64_t bits, bool insert) -> int { return tab.find(off, bits, insert); };
-        bool ok = true;
-        {
-            std::vector<PairTable> loc((size_t)host_threads());
-            std::vector<char> bad((size_t)host_threads(), 0);
-            par_rows(rows, 1, [&](int t, int64_t lo, int64_t hi) {
-                PairTable &mine = loc[(size_t)t];
-                for (int64_t i = lo; i < hi && !bad[(size_t)t]; ++i) {
-                    const int64_t gr = row_begin + i;
-                    for (int64_t k = rowptr[i]; k < rowptr[i + 1]; ++k)
-                        if (mine.find(col[k] - gr, bits_of(val[k]), true) < 0) { bad[(size_t)t] = 1; break; }
-                }
-            });
-            for (size_t t = 0; t < loc.size() && ok; ++t) {
-                if (bad[t]) ok = false;
-                for (const Pair &pr : loc[t].pairs)
-                    if (ok && find(pr.off, pr.bits, true) < 0) ok = false;
-            }
-        }
-        if (ok) {
-            // canonical table order: by offset, then by value bits (independent of the input order)
-            std::vector<int> order(pairs.size()), rank(pairs.size());
-            for (size_t t = 0; t < order.size(); ++t) order[t] = (int)t;
-            std::sort(order.begin(), order.end(), [&](int x, int y) {
-                return pairs[(size_t)x].off != pairs[(size_t)y].off ? pairs[(size_t)x].off < pairs[(size_t)y].off
-                                                                      : pairs[(size_t)x].bits < pairs[(size_t)y].bits;
-            });
-            std::vector<int32_t> doff(256, 0);
-            std::vector<double> dval(256, 0.0);
-            for (size_t t = 0; t < order.size(); ++t) {
-                rank[(size_t)order[t]] = (int)t;
-                doff[t] = (int32_t)pairs[(size_t)order[t]].off;
-                memcpy(&dval[t], &pairs[(size_t)order[t]].bits, 8);
-            }
-            std::vector<uint8_t> codes(((size_t)nnz + 3) / 4 * 4 + 16, 0);
-            par_rows(rows, 1, [&](int, int64_t lo, int64_t hi) {   // (lookups only: the table is read-only now)
-                for (int64_t i = lo; i < hi; ++i) {
-                    const int64_t gr = row_begin + i;
-                    for (int64_t k = rowptr[i]; k < rowptr[i + 1]; ++k)
-                        codes[(size_t)k] = (uint8_t)rank[(size_t)find(col[k] - gr, bits_of(val[k]), false)];
-                }
-            });
-            upload((void **)&A->d_vcode, codes.data(), codes.size());
-            upload((void **)&A->d_vdoff, doff.data(), sizeof(int32_t) * doff.size());
-            upload((void **)&A->d_vdval, dval.data(), sizeof(double) * dval.size());
-            A->use_vdict = true;
-            A->npairs = (int)pairs.size();
-            A->nblk_vd = (int32_t)((rows + kVdRows - 1) / kVdRows);
-            // wave-sliced form: per 128 rows (two per lane) the sorted union of the pair codes with an even-row and
-            // an odd-row lane mask each.  Taken when the slices are reasonably full (>= 1/4 of the row slots busy
-            // on average) and x is addressable with a 32-bit byte offset.
-            const int64_t nsl = (rows + 127) / 128;
-            std::vector<int32_t> wptr((size_t)nsl + 1, 0);
-            std::vector<uint64_t> wme, wmo;
-            std::vector<double> wval;
-            std::vector<int32_t> woff;
-            std::vector<uint8_t> wcode;
-            bool wok = n < ((int64_t)1 << 28);
-            if (wok) {   // slices are independent: each thread builds the records of a contiguous range of slices
-                struct Part { std::vector<uint64_t> me, mo; std::vector<double> v; std::vector<int32_t> o, cnt; std::vector<uint8_t> cd; };
-                std::vector<Part> part((size_t)host_threads());
-                const int T = par_rows(rows, 128, [&](int t, int64_t lo, int64_t hi) {
-                    Part &P = part[(size_t)t];
-                    uint64_t lane_mask[2][256];
-                    for (int64_t rlo = lo; rlo < hi; rlo += 128) {
-                        uint64_t present[4] = {0, 0, 0, 0};
-                        const int64_t rhi = std::min<int64_t>(hi, rlo + 128);
-                        for (int64_t i = rlo; i < rhi; ++i)
-                            for (int64_t k = rowptr[i]; k < rowptr[i + 1]; ++k) {
-                                const int cd = codes[(size_t)k];
-                                if (!((present[cd >> 6] >> (cd & 63)) & 1)) {
-                                    present[cd >> 6] |= 1ull << (cd & 63);
-                                    lane_mask[0][cd] = lane_mask[1][cd] = 0;
-                                }
-                                lane_mask[(i - rlo) & 1][cd] |= 1ull << ((i - rlo) >> 1);
-                            }
-                        const size_t first = P.me.size();
-                        for (int cd = 0; cd < 256; ++cd)   // ascending code = ascending (offset, value bits)
-                            if ((present[cd >> 6] >> (cd & 63)) & 1) {
-                                P.me.push_back(lane_mask[0][cd]);
-                                P.mo.push_back(lane_mask[1][cd]);
-                                P.v.push_back(dval[(size_t)cd]);
-                                P.o.push_back(doff[(size_t)cd]);
-                                P.cd.push_back((uint8_t)cd);
-                            }
-                        P.cnt.push_back((int32_t)(P.me.size() - first));
-                    }
-                });
-                int64_t sl = 0;
-                for (int t = 0; t < T && wok; ++t) {
-                    const Part &P = part[(size_t)t];
-                    for (int32_t cnt : P.cnt) {
-                        if (cnt > kWdMaxSliceRecords) wok = false;   // the records past the 8 pipelined ones go chunk by chunk
-                        wptr[(size_t)sl + 1] = wptr[(size_t)sl] + cnt;
-                        ++sl;
-                    }
-                    wme.insert(wme.end(), P.me.begin(), P.me.end());
-                    wmo.insert(wmo.end(), P.mo.begin(), P.mo.end());
-                    wval.insert(wval.end(), P.v.begin(), P.v.end());
-                    woff.insert(woff.end(), P.o.begin(), P.o.end());
-                    wcode.insert(wcode.end(), P.cd.begin(), P.cd.end());
-                }
-                if ((int64_t)wme.size() * 32 > nnz + 2048) wok = false;   // < 1/4 full: the byte-code kernel is the better form
-            }
-            if (wok) {
-                A->nwent = (int64_t)wme.size();
-                for (int t = 0; t < 8; ++t) { wme.push_back(0); wmo.push_back(0); wval.push_back(0.0); woff.push_back(0); }
-                upload((void **)&A->d_wptr, wptr.data(), sizeof(int32_t) * wptr.size());
-                upload((void **)&A->d_wme, wme.data(), sizeof(uint64_t) * wme.size());
-                upload((void **)&A->d_wmo, wmo.data(), sizeof(uint64_t) * wmo.size());
-                upload((void **)&A->d_wval, wval.data(), sizeof(double) * wval.size());
-                upload((void **)&A->d_woff, woff.data(), sizeof(int32_t) * woff.size());
-                A->use_wdia = true;
-                A->nslices = (int32_t)nsl;
-                A->nblk_wd = (int32_t)((nsl + 3) / 4);
-                {   // LDS windows: cluster the offsets (doff[] is ascending); a record then names an element of the staged buffer
-                    WdWin W;
-                    bool lok = true;
-                    int32_t wmax[kWdWinMax] = {};
-                    for (int t = 0; t < A->npairs && lok; ++t) {
-                        const int32_t o = doff[(size_t)t];
-                        if (W.n > 0 && o - wmax[W.n - 1] < kWdWinMerge) { wmax[W.n - 1] = o; continue; }
-                        if (W.n == kWdWinMax) { lok = false; break; }
-                        W.omin[W.n] = o & ~1;        // (floor to even: staged as aligned 16-byte pairs)
-                        wmax[W.n] = o;
-                        ++W.n;
-                    }
-                    for (int k = 0; k < W.n && lok; ++k) {
-                        const int32_t elems = wmax[k] - W.omin[k] + 512 + 2;   // + 1: odd first row of a slab, + 1: second row of the last pair
-                        W.pb[k + 1] = W.pb[k] + (elems + 1) / 2;
-                    }
-                    W.pairs = W.pb[W.n];
-                    if (lok && W.n > 0 && W.pairs <= kWdWinMaxPairs && A->npairs <= 8) {
-                        // uniform records: every slice carries all pairs in table order; a pair it does not use has empty masks
-                        WdUni U;
-                        U.n = A->npairs;
-                        for (int t = 0; t < A->npairs; ++t) {
-                            int k = 0;
-                            while (k + 1 < W.n && doff[(size_t)t] >= W.omin[k + 1]) ++k;
-                            U.lpos[t] = 2 * W.pb[k] + (doff[(size_t)t] - W.omin[k]);
-                            U.val[t] = dval[(size_t)t];
-                        }
-
-                        std::vector<uint64_t> wum((size_t)nsl * 16, 0);
-                        for (int64_t sl2 = 0; sl2 < nsl; ++sl2)
-                            for (int32_t e = wptr[(size_t)sl2]; e < wptr[(size_t)sl2 + 1]; ++e) {
-                                wum[(size_t)sl2 * 16 + wcode[(size_t)e]] = wme[(size_t)e];
-                                wum[(size_t)sl2 * 16 + 8 + wcode[(size_t)e]] = wmo[(size_t)e];
-                            }
-                        upload((void **)&A->d_wum, wum.data(), sizeof(uint64_t) * wum.size());
-                        int64_t clo = n, chi = -1;                // (columns ascend inside a row)
-                        for (int64_t i = 0; i < rows; ++i)
-                            if (rowptr[i + 1] > rowptr[i]) {
-                                clo = std::min<int64_t>(clo, col[rowptr[i]]);
-                                chi = std::max<int64_t>(chi, col[rowptr[i + 1] - 1]);
-                            }
-                        A->wd_col_lo = (int32_t)clo;
-                        A->wd_col_hi = (int32_t)chi;
-                        // x[own row] from the staged buffer (an epilogue operand that is the gathered vector): offset 0 inside a
-                        // window, and every own row inside the column range the windows are filled for
-                        if (clo <= row_begin && row_begin + rows - 1 <= chi)
-                            for (int k = 0; k < W.n; ++k)
-                                if (W.omin[k] <= 0 && 0 <= wmax[k]) U.lpos0 = 2 * W.pb[k] - W.omin[k];
-                        A->wd_win = W;
-                        A->wd_uni = U;
-                        A->wd_lds = true;
-                        // Plane march (spmv_wdia_march_kernel): three windows {-D}, {in-plane}, {+D} with ONE pair in each far
-                        // window, D even, the in-plane window <= 512 pairs and around offset 0, an unsharded matrix.  The masks
-                        // are laid out per (tile, plane, wavefront) for rows plane * D + tile * 512 + wavefront * 128 + [0, 128)
-                        // -- a plane is not a whole number of 128-row slices (216^2 = 364.5 of them).
-                        const int np = A->npairs;
-                        const int64_t D = np >= 3 ? (int64_t)doff[(size_t)np - 1] : 0;
-                        if (W.n == 3 && (np == 5 || np == 7) && row_begin == 0 && rows == m && m == n && D >= 1024 && (D & 1) == 0 &&
-                            doff[0] == -D && doff[1] >= W.omin[1] && doff[(size_t)np - 2] <= wmax[1] && W.omin[1] <= 0 && wmax[1] >= 0 &&
-                            W.pb[2] - W.pb[1] <= 512 && rows >= 2 * D) {
-                            WdMarch G;
-                            G.D = (int32_t)D;
-                            G.T = (int32_t)((D + 511) / 512);
-                            G.planes = (int32_t)((rows + D - 1) / D);
-                            G.omin = W.omin[1];
-                            G.pairs = W.pb[2] - W.pb[1];
-                            const int slots = std::max(1, c->wd_march_occ) * c->n_cu;
-                            G.S = std::max(1, std::min(G.planes, slots / G.T));
-                            G.PS = (G.planes + G.S - 1) / G.S;
-                            G.S = (G.planes + G.PS - 1) / G.PS;
-                            G.ntasks = G.T * G.S;
-                            WdUni M;
-                            M.n = np;
-                            for (int t = 0; t < np; ++t) {
-                                const int64_t o = t == 0 ? 0 : t == np - 1 ? 0 : (int64_t)doff[(size_t)t];   // (relative to the pair's own plane)
-                                M.lpos[t] = (int32_t)(o - G.omin);
-                                M.val[t] = dval[(size_t)t];
-                            }
-                            M.lpos0 = -G.omin;
-                            std::vector<uint64_t> wm((size_t)G.T * (size_t)G.planes * 4 * 16, 0);
-                            par_rows(G.planes, 1, [&](int, int64_t plo, int64_t phi) {   // (the slices of a plane belong to one thread)
-                                for (int64_t kk = plo; kk < phi; ++kk) {
-                                    const int64_t r0 = kk * D, r1 = std::min<int64_t>(rows, r0 + D);
-                                    for (int64_t i = r0; i < r1; ++i) {
-                                        const int64_t pos = i - r0, tile = pos >> 9;
-                                        const size_t sl2 = ((size_t)(tile * G.planes + kk) * 4 + (size_t)((pos >> 7) & 3)) * 16;
-                                        const uint64_t bit = 1ull << ((pos & 127) >> 1);
-                                        for (int64_t k = rowptr[i]; k < rowptr[i + 1]; ++k) wm[sl2 + (size_t)(pos & 1) * 8 + codes[(size_t)k]] |= bit;
-                                    }
-                                }
-                            }, 4);
-                            upload((void **)&A->d_wum_m, wm.data(), sizeof(uint64_t) * wm.size());
-                            A->wd_mg = G;
-                            A->wd_muni = M;
-                            A->wd_march = true;
-                        }
-                    }
-                }
-                // Visiting order of the 512-row steps.  A 3-D stencil row touches x one PLANE (the far diagonal, D rows)
-                // behind and ahead; swept in row order, a line of x is needed again 2 D rows later, by which time
-                // the vectors streaming through the 4 MiB L2 have evicted it (216^3: D = 46656, 1.35 extra reads
-                // of x measured).  So the sweep is tiled: the steps are grouped by their position inside the plane
-                // (tiles of `tile` steps) and each tile is walked plane after plane, which makes the three touches
-                // of a line neighbours in time.  Only the order changes; every step is still done exactly once.
-                int64_t far = 0;
-                for (int t = 0; t < A->npairs; ++t) far = std::max<int64_t>(far, std::llabs((long long)doff[(size_t)t]));
-                const double bpp = (double)far / 512.0;   // steps per plane
-                int tile = c->wd_tile;
-                if (tile < 0) tile = (far * 8 >= (256 << 10) && far * 4 <= rows) ? (int)std::max(8.0, bpp / 6.0 + 0.5) : 0;
-                if (tile > 0 && bpp > 2.0 * tile) {
-                    std::vector<int32_t> sched((size_t)A->nblk_wd);
-                    std::vector<int32_t> key((size_t)A->nblk_wd);
-                    for (int32_t bb = 0; bb < A->nblk_wd; ++bb) {
-                        sched[(size_t)bb] = bb;
-                        const double pos = fmod((double)bb, bpp);   // position of the step inside its plane, in steps
-                        key[(size_t)bb] = (int32_t)(pos / tile);
-                    }
-                    std::stable_sort(sched.begin(), sched.end(), [&](int32_t x, int32_t y) { return key[(size_t)x] < key[(size_t)y]; });
-                    upload((void **)&A->d_wsched, sched.data(), sizeof(int32_t) * sched.size());
-                    A->h_wsched = sched;
-                }
-            }
-        }
-    }
-}
-
-// wave-sliced form for variable coefficients (wdia-vv): diagonal records with per-row value blocks
-static void low_wave_sliced_variable(Low &L) {
-    SLA_LOW_LOCALS(L);
-    if (!panel_view && A->use_diag && !A->use_wdia && !A->rp64 && c->wdia_vv && n < ((int64_t)1 << 28) && nnz > 0) {
-        // Wave-sliced form for VARIABLE coefficients (banded / stencil structure, arbitrary values): per 128-row slice the
-        // sorted union of its diagonal offsets with the two row masks each, and per record a block of 128 values laid out
-        // like the rows (lane l holds rows 2l, 2l+1: one 16-byte load).  8 B per stored slot instead of 8 + 1 B per entry
-        // plus rowptr, no codes, no LDS.  Taken when at least half of the slots hold an entry.
-        const int64_t nsl = (rows + 127) / 128;
-        std::vector<int32_t> wptr((size_t)nsl + 1, 0);
-        std::vector<uint64_t> wme, wmo;
-        std::vector<int32_t> woff;
-        std::vector<double> wvb;
-        uint64_t lane_mask[2][256];
-        int slot_of[256];
-        bool wok = true;
-        for (int64_t sl = 0; sl < nsl && wok; ++sl) {
-            uint64_t present[4] = {0, 0, 0, 0};
-            const int64_t rlo = sl * 128, rhi = std::min<int64_t>(rows, rlo + 128);
-            for (int64_t i = rlo; i < rhi; ++i)
-                for (int64_t k = rowptr[i]; k < rowptr[i + 1]; ++k) {
-                    const int cd = dcodes[(size_t)k];
-                    if (!((present[cd >> 6] >> (cd & 63)) & 1)) {
-                        present[cd >> 6] |= 1ull << (cd & 63);
-                        lane_mask[0][cd] = lane_mask[1][cd] = 0;
-                    }
-                    lane_mask[(i - rlo) & 1][cd] |= 1ull << ((i - rlo) >> 1);
-                }
-            const size_t first = wme.size();
-            for (int cd = 0; cd < 256; ++cd)   // ascending code = ascending offset
-                if ((present[cd >> 6] >> (cd & 63)) & 1) {
-                    slot_of[cd] = (int)(wme.size() - first);
-                    wme.push_back(lane_mask[0][cd]);
-                    wmo.push_back(lane_mask[1][cd]);
-                    woff.push_back((int32_t)offs[(size_t)cd]);
-                }
-            wvb.resize(wme.size() * 128, 0.0);
-            for (int64_t i = rlo; i < rhi; ++i)
-                for (int64_t k = rowptr[i]; k < rowptr[i + 1]; ++k)
-                    wvb[(first + (size_t)slot_of[dcodes[(size_t)k]]) * 128 + (size_t)(i - rlo)] = val[k];
-            wptr[(size_t)sl + 1] = (int32_t)wme.size();
-            if ((int64_t)wme.size() * 64 > nnz + 4096) wok = false;   // less than half of the slots used
-            if (wptr[(size_t)sl + 1] - wptr[(size_t)sl] > kWdMaxSliceRecords) wok = false;
-        }
-        if (wok) {
-            A->nwent = (int64_t)wme.size();
-            for (int t = 0; t < 8; ++t) { wme.push_back(0); wmo.push_back(0); woff.push_back(0); }
-            wvb.resize(wme.size() * 128, 0.0);
-            upload((void **)&A->d_wptr, wptr.data(), sizeof(int32_t) * wptr.size());
-            upload((void **)&A->d_wme, wme.data(), sizeof(uint64_t) * wme.size());
-            upload((void **)&A->d_wmo, wmo.data(), sizeof(uint64_t) * wmo.size());
-            upload((void **)&A->d_woff, woff.data(), sizeof(int32_t) * woff.size());
-            upload((void **)&A->d_wvblk, wvb.data(), sizeof(double) * wvb.size());
-            A->use_wdia = true;
-            A->wd_vv = true;
-            A->nslices = (int32_t)nsl;
-            A->nblk_wd = (int32_t)((nsl + 3) / 4);
-        }
-    }
-}
-
-// LDS-panel form for dense rows (spmv_lpanel_kernel): per (panel, row) entry ranges + the task runs of the persistent grid
-static void low_lds_panels(Low &L) {
-    SLA_LOW_LOCALS(L);
-    if (!panel_view && !A->use_wdia && !A->use_vdict && rows > 0 && err == hipSuccess) {
-        // LDS-panel form (spmv_lpanel_kernel): worthwhile when a row has enough entries per kLpW-column panel to
-        // keep a wavefront's lanes busy, affordable when the (panel, row) pointer table stays a fraction of the matrix
-        const int64_t P = (n + kLpW - 1) / kLpW;
-        const int64_t W = ((n + P - 1) / P + 63) / 64 * 64;   // equal panels (a narrow last panel would be all short segments)
-        const size_t rpsz = A->rp64 ? sizeof(int64_t) : sizeof(int32_t);
-        const int64_t min_seg = c->lp_min_seg;
-        if (P <= 4096 && nnz >= min_seg * rows * P && (P + 1) * rows * (int64_t)rpsz <= nnz * 12 / 4) {
-            std::vector<int64_t> pp((size_t)((P + 1) * rows));
-            par_rows(rows, 1, [&](int, int64_t lo, int64_t hi) {
-                for (int64_t i = lo; i < hi; ++i) {
-                    const int64_t *cb = col + rowptr[i], *ce = col + rowptr[i + 1];
-                    const int64_t *cur = cb;
-                    for (int64_t p = 0; p <= P; ++p) {
-                        cur = std::lower_bound(cur, ce, p * W);
-                        pp[(size_t)(p * rows + i)] = rowptr[i] + (cur - cb);
-                    }
-                }
-            }, 4096);
-            if (A->rp64) {
-                upload(&A->d_lpp, pp.data(), sizeof(int64_t) * pp.size());
-            } else {
-                std::vector<int32_t> pp32(pp.begin(), pp.end());
-                upload(&A->d_lpp, pp32.data(), sizeof(int32_t) * pp32.size());
-            }
-            if (err == hipSuccess) err = dev_malloc(c, (void **)&A->d_lpy, sizeof(double) * (size_t)(P * rows));
-            // panel-major second copy of the entries (sla_spmv_lpanel.hip: lp_reorder_kernel), built on the device from the arrays just
-            // uploaded; when it exists d_lpp is replaced by the P x rows + 1 segment starts into it.  12 B per entry: taken while it
-            // (10 B: 16-bit panel offsets) stays below 48 GB and the allocation succeeds (a failure here is not an error: the row-major arrays serve)
-            if (err == hipSuccess && c->lp_copy && nnz * 12 <= ((int64_t)48 << 30) && A->d_col && A->d_val) {
-                std::vector<int64_t> q((size_t)(P * rows) + 1, 0);
-                for (int64_t p = 0; p < P; ++p)
-                    for (int64_t i = 0; i < rows; ++i)
-                        q[(size_t)(p * rows + i) + 1] = q[(size_t)(p * rows + i)] + (pp[(size_t)((p + 1) * rows + i)] - pp[(size_t)(p * rows + i)]);
-                void *dq = nullptr;
-                uint16_t *c2 = nullptr;
-                double *v2 = nullptr;
-                hipError_t e2 = W <= 65536 ? dev_malloc(c, (void **)&c2, sizeof(uint16_t) * (size_t)nnz + kArraySlack) : hipErrorInvalidValue;
-                if (e2 == hipSuccess) e2 = dev_malloc(c, (void **)&v2, sizeof(double) * (size_t)nnz + kArraySlack);
-                if (e2 == hipSuccess) e2 = dev_malloc(c, &dq, rpsz * q.size() + kArraySlack);
-                if (e2 == hipSuccess) {
-                    if (A->rp64) {
-                        e2 = hipMemcpy(dq, q.data(), sizeof(int64_t) * q.size(), hipMemcpyHostToDevice);
-                    } else {
-                        std::vector<int32_t> q32(q.begin(), q.end());
-                        e2 = hipMemcpy(dq, q32.data(), sizeof(int32_t) * q32.size(), hipMemcpyHostToDevice);
-                    }
-                }
-                if (e2 == hipSuccess && launch_lp_reorder(c, A->rp64, A->d_lpp, dq, A->d_col, A->d_val, c2, v2, rows, P, (int32_t)W) != SLA_OK) e2 = hipErrorUnknown;
-                if (e2 == hipSuccess) {
-                    (void)hipFree(A->d_lpp);
-                    A->d_lpp = dq;
-                    A->d_lpcol = c2;
-                    A->d_lpval = v2;
-                } else {
-                    (void)hipGetLastError();
-                    if (c2) (void)hipFree(c2);
-                    if (v2) (void)hipFree(v2);
-                    if (dq) (void)hipFree(dq);
-                }
-            }
-            // row chunks: ~32 tasks per workgroup of the persistent grid (measured: 8 -> 0.936 ms, 32 -> 0.900 ms, 64 ->
-            // 0.902 ms on the 200k-row 1 % matrix), at least 64 rows (4 per wavefront) each
-            const int tasks_per_cu = std::max(1, c->lp_tasks);
-            const int64_t want = std::max<int64_t>(1, (tasks_per_cu * (int64_t)c->n_cu + P - 1) / P);
-            const int64_t chunk = std::max<int64_t>(64, (rows + want - 1) / want);
-            const int64_t C = (rows + chunk - 1) / chunk;
-            A->lp_P = (int32_t)P;
-            A->lp_W = (int32_t)W;
-            {   // lanes per segment ~ half the mean segment length (so that two strided loads cover a typical segment)
-                const int64_t seg = nnz / (rows * P);
-                // measured, 200 k rows x 13 panels, ms per (#>) [64 / 32 / 16 / 8 lanes]: segment 153: 0.90 / 1.15 / 1.33 / 1.80;
-                // 92: 0.68 / 0.73 / 0.87 / 1.15; 61: 0.65 / 0.52 / 0.59 / 0.77; 30: 0.61 / 0.36 / 0.36 / 0.43; 15: 0.58 / 0.32 /
-                // 0.26 / 0.27 (stream kernel: 2.21 / 1.39 / 1.07 / 0.56 / 0.28)
-                A->lp_cfg = seg >= 80 ? 0 : seg >= 40 ? 1 : 2;
-                if (c->lp_cfg >= 0) A->lp_cfg = std::min(3, c->lp_cfg);
-            }
-            int64_t clo = n, chi = -1;
-            for (int64_t i = 0; i < rows; ++i)
-                if (rowptr[i + 1] > rowptr[i]) {   // canonical CSR: first / last entry of a row are its min / max column
-                    clo = std::min(clo, col[rowptr[i]]);
-                    chi = std::max(chi, col[rowptr[i + 1] - 1]);
-                }
-            A->lp_col_lo = (int32_t)clo;
-            A->lp_col_hi = (int32_t)chi;
-            A->lp_chunk = (int32_t)chunk;
-            A->lp_C = (int32_t)C;
-            // tasks (panel-major) are dealt out in contiguous runs of equal ENTRY counts, one run per workgroup
-            const int64_t ntasks = P * C;
-            const int G = (int)std::min<int64_t>(ntasks, c->n_cu);
-            // (a segment costs a memory round trip however short it is -- with entries alone balanced, workgroups holding
-            // 34-entry segments took 2.4x as long as those with 154-entry ones: weigh a row like row_cost entries)
-            const int64_t row_cost = c->lp_rowcost;
-            std::vector<int64_t> upto((size_t)ntasks + 1, 0);   // weight before task t
-            for (int64_t t = 0; t < ntasks; ++t) {   // (panel-major; row-chunk-major was tried: 0.906 -> 0.971 ms, x reloaded per task)
-                const int64_t p = t / C, cc = t % C;
-                const int64_t lo = cc * chunk, hi = std::min<int64_t>(rows, lo + chunk);
-                int64_t w = 0;
-                for (int64_t i = lo; i < hi; ++i) w += pp[(size_t)((p + 1) * rows + i)] - pp[(size_t)(p * rows + i)];
-                upto[(size_t)t + 1] = upto[(size_t)t] + w + row_cost * (hi - lo);
-            }
-            std::vector<int32_t> tb((size_t)G + 1, 0);
-            for (int g = 1; g < G; ++g) {
-                const int64_t target = upto[(size_t)ntasks] / G * g;
-                tb[(size_t)g] = (int32_t)(std::lower_bound(upto.begin(), upto.end(), target) - upto.begin());
-                tb[(size_t)g] = std::max(tb[(size_t)g], tb[(size_t)g - 1]);
-            }
-            tb[(size_t)G] = (int32_t)ntasks;
-            if (dbg_lower) {
-                fprintf(stderr, "[sla] lpanel: P=%lld C=%lld chunk=%lld G=%d total=%lld tb:", (long long)P, (long long)C, (long long)chunk, G, (long long)upto[(size_t)ntasks]);
-                for (int g = 0; g <= G; g += std::max(1, G / 16)) fprintf(stderr, " %d", tb[(size_t)g]);
-                fprintf(stderr, "\n");
-            }
-            A->lp_G = G;
-            upload((void **)&A->d_lpt, tb.data(), sizeof(int32_t) * tb.size());
-            A->use_lpanel = err == hipSuccess;
-        }
-    }
-}
-
-static int csr_upload(sla_ctx *c, int64_t m, int64_t n, int64_t row_begin, int64_t rows, const int64_t *rowptr,
-                      const int64_t *col, const double *val, sla_csr **out, bool panel_view) {
-    const int64_t nnz = rowptr[rows];
-    if (n > (int64_t)std::numeric_limits<int32_t>::max() || rows >= (int64_t)std::numeric_limits<int32_t>::max())
-        return fail(SLA_ERR_INVALID, "matrix dimension exceeds the 32-bit device index width");
-    static const bool dbg_lower = getenv("SLA_DEBUG_LOWER") != nullptr;
-    auto t_last = std::chrono::steady_clock::now();
-    auto lap = [&](const char *what) {
-        if (!dbg_lower || panel_view) return;
-        const auto t = std::chrono::steady_clock::now();
-        fprintf(stderr, "[sla] lowering: %-28s %7.1f ms\n", what, std::chrono::duration<double, std::milli>(t - t_last).count());
-        t_last = t;
-    };
-    sla_csr *A = new sla_csr();
-    A->ctx = c;
-    A->m = m;
-    A->n = n;
-    A->row_begin = row_begin;
-    A->rows = rows;
-    A->nnz = nnz;
-    // (SLA_FORCE_RP64=1: test hook -- run the 64-bit row-pointer instantiations of the kernels on small matrices)
-    // (SLA_FORCE_RP64=2: the parent only -- its column-panel views keep their natural 32-bit width, the mixed case of a > 2^31-entry matrix)
-    A->rp64 = nnz > (int64_t)std::numeric_limits<int32_t>::max() || c->force_rp64 == 1 || (c->force_rp64 == 2 && !panel_view);
-    Low L{c, A, m, n, row_begin, rows, nnz, rowptr, col, val, panel_view, dbg_lower};
-    hipError_t &err = L.err;
-    build_row_blocks(rows, rowptr, L.rb, A->max_row_nnz, c->row_align, c->rb_nnz);
-    A->nrb = (int32_t)L.rb.size() - 1;
-    int diag_not = host_is_diagonal(rows, row_begin, rowptr, col) ? 0 : 1;
-    if (m != n && rows > 0) { /* isDiagonalSM only counts (i,i) entries; nothing extra to do */ }
-    low_csr_arrays(L);
-    lap("row blocks + CSR upload");
-    low_xwin_statistics(L);
-    lap("x-window statistics");
-    low_diagonal_dictionary(L);
-    low_value_indexed(L);
-    lap("pair dictionary + wave slices");
-    low_wave_sliced_variable(L);
-    lap("variable-coefficient slices");
-    low_lds_panels(L);
-    lap("LDS panel table");
-    if (panel_view) {
-        if (err != hipSuccess) {
-            sla_csr_destroy(A);
-            return fail(SLA_ERR_ALLOC, std::string("CSR upload: ") + hipGetErrorString(err));
-        }
-        *out = A;
-        return SLA_OK;
-    }
-    // Every rank enters the agreement collective, failed or not (a rank returning early would leave its peers blocked in
-    // it): the all-reduced maximum carries isDiagonalSM's verdict in bit 0 and "some rank failed" as a value >= 2.
-    int agree = err != hipSuccess ? 2 : diag_not;
-    int rc = dist_allreduce_max_i32(c, &agree);
-    if (err != hipSuccess) {
-        sla_csr_destroy(A);
-        return fail(SLA_ERR_ALLOC, std::string("CSR upload: ") + hipGetErrorString(err));
-    }
-    if (rc == SLA_OK && agree >= 2) rc = fail(SLA_ERR_INVALID, "matrix creation failed on another rank of the row-sharded job");
-    if (rc != SLA_OK) {
-        sla_csr_destroy(A);
-        return rc;
-    }
-    A->is_diagonal = agree == 0;
-    rc = build_xplan(A, rows, rowptr, col);
-    if (rc == SLA_OK) rc = build_overlap_lists(A, m, n, row_begin, rows, rowptr, col);
-    if (rc == SLA_OK) rc = build_tiles(A, n, rows, rowptr, col, val);
-    lap("tile form");
-    if (rc == SLA_OK && !(A->use_lpanel && c->lpanel) && !A->use_tiles) rc = build_panels(A, m, n, row_begin, rows, rowptr, col, val);
-    if (rc != SLA_OK) {
-        sla_csr_destroy(A);
-        return rc;
-    }
-    *out = A;
     return SLA_OK;
 }
 

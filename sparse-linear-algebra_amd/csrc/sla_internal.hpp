@@ -5,6 +5,8 @@
 #include <map>
 #include <new>
 #include <string>
+#include <algorithm>
+#include <thread>
 #include <vector>
 
 #include "sla_hip.h"
@@ -553,6 +555,34 @@ int gather_raw(sla_ctx *c, const sla_csr *A, const double *local, int64_t shard,
 int reduce_to_host(sla_ctx *c, const double *p1, const double *p2, int np, double *out);
 int vec_alloc(sla_ctx *c, int64_t n, sla_vec **out);
 int csr_transposed(sla_csr *A, sla_csr **out);
+// Host-side set-up work (lowering analyses, COO validation) is row-parallel: par_rows runs fn(t, lo, hi) over T contiguous row ranges
+// whose boundaries are multiples of `align` rows, on T host threads (SLA_HOST_THREADS, default <= 16); returns T.
+int host_threads();   // sla_lower.cpp
+template <class F>
+int par_rows(int64_t rows, int64_t align, F fn, int64_t serial_below = 200000) {
+    int T = host_threads();
+    const int64_t units = (rows + align - 1) / align;
+    if (units < 64 || rows < serial_below) T = 1;
+    T = (int)std::min<int64_t>(T, std::max<int64_t>(units, 1));
+    auto range = [&](int t, int64_t &lo, int64_t &hi) {
+        lo = std::min<int64_t>(rows, units * t / T * align);
+        hi = std::min<int64_t>(rows, units * (t + 1) / T * align);
+    };
+    if (T == 1) { fn(0, (int64_t)0, rows); return 1; }
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; ++t) {
+        int64_t lo, hi;
+        range(t, lo, hi);
+        th.emplace_back([=, &fn] { fn(t, lo, hi); });
+    }
+    for (auto &x : th) x.join();
+    return T;
+}
+// sla_lower.cpp: validate, upload and lower one rank's row block (panel_view: a column-panel view of a parent, lowered plainly);
+// csr_reject: a rank whose input failed validation still joins the agreement collective of csr_upload before it reports
+int csr_upload(sla_ctx *c, int64_t m, int64_t n, int64_t row_begin, int64_t rows, const int64_t *rowptr, const int64_t *col,
+               const double *val, sla_csr **out, bool panel_view = false);
+int csr_reject(sla_ctx *c, int rc);
 int spmv_transposed(sla_csr *A, const double *x_local, double *y_local, int64_t y_shard);
 
 // kernel launchers (sla_spmv.hip dispatch + the family files, sla_vec_kernels.hip, sla_arnoldi.hip, sla_tri.hip) -----------------------------------------------------------------

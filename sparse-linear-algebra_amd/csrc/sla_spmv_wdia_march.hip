@@ -21,7 +21,7 @@
 //     the barrier: K1 45.0 -> 46.3 us; profiles/r03_ab_march.txt);
 //   * fold order, roundings and epilogues are spmv_wdia_kernel's (shared wd_epilogue): every row bit-identical to the other forms
 //     (tests/test_gpu_value_indexed.py).  The partial sums of the fused dot products are grouped by task instead of by step.
-// Taken for 5- and 7-pair stencils (one pair at -D, one at +D) on unsharded matrices (sla_api.cpp: low_wave_sliced).
+// Taken for 5- and 7-pair stencils (one pair at -D, one at +D) on unsharded matrices (sla_lower.cpp: low_value_indexed).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -195,7 +195,7 @@ __global__ void __launch_bounds__(kBlock, 3) spmv_wdia_march_kernel(SpmvArgs<int
     spmv_extra_partials<EPI>(a, s_red, tid);
 }
 
-// one workgroup per task when the tasks fit the chip (they are sized for that, sla_api.cpp), a multiple of 8
+// one workgroup per task when the tasks fit the chip (they are sized for that, sla_lower.cpp), a multiple of 8
 int wd_march_grid(const sla_csr *A) {
     const sla_ctx *c = A->ctx;
     const int slots = std::max(8, (std::max(1, c->wd_march_occ) * c->n_cu) & ~7);
