@@ -615,6 +615,12 @@ int arn_alloc_agreed(ArnoldiWs &ws, sla_csr *A, sla_vec *like, int kn) {
 struct ColParts { const double *p; int np, cs, stride; };
 int arn_publish(ArnoldiWs &ws, const double *parts, int np, int ncols, ColParts *out) {
     sla_ctx *c = ws.c;
+    // one column on a single-rank context (the norms in front of arn_normalize_kernel): the consumer folds the partials itself --
+    // reduce_parts, the very additions the fold launch would make -- and the launch (4.8 us plus a dependent dispatch) is saved
+    if (ncols == 1 && !c->collectives && np <= kMaxParts) {
+        *out = ColParts{parts, np, np, 1};
+        return SLA_OK;
+    }
     // one tiny launch folds the per-workgroup partials to ncols values, so that the producers can use a
     // chip-filling grid without every consumer workgroup re-reducing ncols x grid partials
     double *loc = ws.gath + (size_t)(kMaxKrylov + 2) * c->nranks;
