@@ -665,12 +665,13 @@ static void low_lds_panels(Low &L) {
                 std::vector<int64_t> q((size_t)(P * rows) + 1, 0);
                 for (int64_t p = 0; p < P; ++p)
                     for (int64_t i = 0; i < rows; ++i)
-                        q[(size_t)(p * rows + i) + 1] = q[(size_t)(p * rows + i)] + (pp[(size_t)((p + 1) * rows + i)] - pp[(size_t)(p * rows + i)]);
+                        q[(size_t)(p * rows + i) + 1] = q[(size_t)(p * rows + i)] + ((pp[(size_t)((p + 1) * rows + i)] - pp[(size_t)(p * rows + i)] + 1) & ~(int64_t)1);   // (whole pairs)
                 void *dq = nullptr;
                 uint16_t *c2 = nullptr;
                 double *v2 = nullptr;
-                hipError_t e2 = W <= 65536 ? dev_malloc(c, (void **)&c2, sizeof(uint16_t) * (size_t)nnz + kArraySlack) : hipErrorInvalidValue;
-                if (e2 == hipSuccess) e2 = dev_malloc(c, (void **)&v2, sizeof(double) * (size_t)nnz + kArraySlack);
+                const size_t nnz2 = (size_t)q.back();          // entries + pads
+                hipError_t e2 = W < 65535 && (A->rp64 || nnz2 < ((size_t)1 << 31)) ? dev_malloc(c, (void **)&c2, sizeof(uint16_t) * nnz2 + kArraySlack) : hipErrorInvalidValue;
+                if (e2 == hipSuccess) e2 = dev_malloc(c, (void **)&v2, sizeof(double) * nnz2 + kArraySlack);
                 if (e2 == hipSuccess) e2 = dev_malloc(c, &dq, rpsz * q.size() + kArraySlack);
                 if (e2 == hipSuccess) {
                     if (A->rp64) {

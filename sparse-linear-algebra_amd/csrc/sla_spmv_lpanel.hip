@@ -65,40 +65,74 @@ __global__ void __launch_bounds__(kLpBlock) spmv_lpanel_kernel(const RP *__restr
                 int i = base + r * GPB + gid;
                 if constexpr (L == 64) i = __builtin_amdgcn_readfirstlane(i);   // one segment per wavefront: scalar pointer loads
                 const bool has = i < hi;
-                k[r] = (has ? ps[i] : 0) + gl;
+                k[r] = (has ? ps[i] : 0) + (PM ? 2 : 1) * gl;
                 e[r] = has ? pe[i] : 0;
                 acc[r] = 0.0;
             }
             bool more = true;
-            while (more) {
-                int32_t cj[R][J];
-                double vj[R][J];
-                // all loads of the round in flight before the first use
+            if constexpr (PM) {
+                // panel-major copy: a lane takes PAIRS of consecutive entries (segments start on even entries; an odd segment ends
+                // with a pad whose column is 0xffff): one 4-byte and one 16-byte load per pair
+                static_assert(J % 2 == 0, "pairs");
+                typedef double lp_f64x2 __attribute__((ext_vector_type(2)));
+                while (more) {
+                    uint32_t cj[R][J / 2];
+                    lp_f64x2 vj[R][J / 2];
 #pragma unroll
-                for (int r = 0; r < R; ++r) {
+                    for (int r = 0; r < R; ++r) {
 #pragma unroll
-                    for (int j = 0; j < J; ++j) {
-                        if (k[r] + L * j < e[r]) {
-                            if constexpr (PM) cj[r][j] = (int32_t)__builtin_nontemporal_load(col16 + k[r] + L * j);
-                            else cj[r][j] = __builtin_nontemporal_load(col + k[r] + L * j);   // (- w0 at the use: nothing may touch a loaded value in this phase)
-                            vj[r][j] = __builtin_nontemporal_load(val + k[r] + L * j);
+                        for (int j = 0; j < J / 2; ++j) {
+                            if (k[r] + 2 * L * j < e[r]) {
+                                cj[r][j] = __builtin_nontemporal_load((const uint32_t *)(col16 + k[r] + 2 * L * j));
+                                vj[r][j] = __builtin_nontemporal_load((const lp_f64x2 *)(val + k[r] + 2 * L * j));
+                            }
                         }
                     }
+                    bool mine = false;
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+#pragma unroll
+                        for (int j = 0; j < J / 2; ++j) {
+                            if (k[r] + 2 * L * j < e[r]) {
+                                acc[r] = acc[r] + vj[r][j].x * lp_xs[cj[r][j] & 0xffffu];
+                                if ((cj[r][j] >> 16) != 0xffffu) acc[r] = acc[r] + vj[r][j].y * lp_xs[cj[r][j] >> 16];
+                            }
+                        }
+                        k[r] += L * J;
+                        mine |= k[r] - 2 * gl < e[r];
+                    }
+                    more = __builtin_amdgcn_ballot_w64(mine) != 0;
                 }
-                bool mine = false;
+            } else {
+                while (more) {
+                    int32_t cj[R][J];
+                    double vj[R][J];
+                    // all loads of the round in flight before the first use (nothing may touch a loaded value in this phase)
 #pragma unroll
-                for (int r = 0; r < R; ++r) {
+                    for (int r = 0; r < R; ++r) {
 #pragma unroll
-                    for (int j = 0; j < J; ++j) {
-                        if (k[r] + L * j < e[r]) {
-                            const double prod = vj[r][j] * lp_xs[cj[r][j] - (PM ? 0 : w0)];
-                            acc[r] = acc[r] + prod;
+                        for (int j = 0; j < J; ++j) {
+                            if (k[r] + L * j < e[r]) {
+                                cj[r][j] = __builtin_nontemporal_load(col + k[r] + L * j);
+                                vj[r][j] = __builtin_nontemporal_load(val + k[r] + L * j);
+                            }
                         }
                     }
-                    k[r] += L * J;
-                    mine |= k[r] - gl < e[r];   // (the segment's next base: uniform over the lane group)
+                    bool mine = false;
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+#pragma unroll
+                        for (int j = 0; j < J; ++j) {
+                            if (k[r] + L * j < e[r]) {
+                                const double prod = vj[r][j] * lp_xs[cj[r][j] - w0];
+                                acc[r] = acc[r] + prod;
+                            }
+                        }
+                        k[r] += L * J;
+                        mine |= k[r] - gl < e[r];   // (the segment's next base: uniform over the lane group)
+                    }
+                    more = __builtin_amdgcn_ballot_w64(mine) != 0;
                 }
-                more = __builtin_amdgcn_ballot_w64(mine) != 0;
             }
 #pragma unroll
             for (int r = 0; r < R; ++r) {
@@ -132,6 +166,10 @@ __global__ void __launch_bounds__(kBlock) lp_reorder_kernel(const RP *__restrict
         for (int64_t k = b + ln; k < e; k += 64) {
             col2[d + (k - b)] = (uint16_t)(col[k] - w0);
             val2[d + (k - b)] = val[k];
+        }
+        if (((e - b) & 1) && ln == 0) {                      // segments are padded to whole pairs: the pad is recognised by its column
+            col2[d + (e - b)] = 0xffffu;
+            val2[d + (e - b)] = 0.0;
         }
     }
 }

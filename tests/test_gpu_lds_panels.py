@@ -84,7 +84,9 @@ def test_lds_panels_match_the_oracle_and_the_stream_kernel(sla, name):
         del A
         ctx.close()
     assert np.all(np.abs(got["ldspanels"] - got["stream"]) <= 2 * _bound(csr, x, m))
-    assert np.array_equal(got["ldspanels"], got["ldspanels row-major"])      # same segments, same order: the same bits
+    # same segments; the copy is read in pairs of entries per lane, the row-major arrays one entry per lane: wavefront-segmented sums
+    # either way (the rounding bound of SURVEY 8(a) A1), grouped differently
+    assert np.all(np.abs(got["ldspanels"] - got["ldspanels row-major"]) <= 2 * _bound(csr, x, m))
     empty = np.diff(csr[0]) == 0
     assert np.all(got["ldspanels"][empty] == 0.0)            # a row key with an empty row map gives 0.0 (Common.hs:242-250)
 
