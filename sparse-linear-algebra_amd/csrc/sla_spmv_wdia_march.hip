@@ -203,12 +203,37 @@ int wd_march_grid(const sla_csr *A) {
     return std::min<int>(kMaxParts & ~7, std::min(slots, 8 * per));
 }
 
+// The runs are sized so that the tasks fill the chip ONCE (sla_lower.cpp: 4 workgroups per CU).  An instantiation whose registers
+// allow only 3 per CU (the CGS / CGNE epilogues, the four-sum K3: 133-154 VGPRs) would run such a grid in two rounds -- CGS's C3 took
+// 71 us where 56 us suffice -- so its tasks are re-cut for 3 per CU at launch: fewer, longer runs; the workgroups beyond them write
+// their zero partial sums and leave (the grid, which the consumers of the partial sums know, stays).  The masks are indexed by
+// (tile, plane), not by run: any cut works.
+template <int EPI, int NP, bool WX>
+static int march_occupancy() {
+    static const int occ = [] {
+        hipFuncAttributes at;
+        if (hipFuncGetAttributes(&at, (const void *)spmv_wdia_march_kernel<EPI, NP, WX>) != hipSuccess) { (void)hipGetLastError(); return 3; }
+        return at.numRegs > 128 ? 3 : 4;
+    }();
+    return occ;
+}
+static WdMarch march_cut(const sla_csr *A, int occ) {
+    WdMarch g = A->wd_mg;
+    const int slots = std::max(1, std::min(occ, std::max(1, A->ctx->wd_march_occ))) * A->ctx->n_cu;
+    if (g.ntasks <= slots) return g;                       // (already fits: the lowering's cut)
+    g.S = std::max(1, std::min(g.planes, slots / g.T));
+    g.PS = (g.planes + g.S - 1) / g.S;
+    g.S = (g.planes + g.PS - 1) / g.PS;
+    g.ntasks = g.T * g.S;
+    return g;
+}
+
 template <int EPI>
 static int launch_epi(const sla_csr *A, const SpmvArgs<int32_t> &a, int grid, int stream_nt) {
     sla_ctx *c = A->ctx;
 #define SLA_WDM_LAUNCH(NP_, WX_)                                                                                                         \
     hipLaunchKernelGGL((spmv_wdia_march_kernel<EPI, NP_, WX_>), dim3(grid), dim3(kBlock), 0, stream_of(c), a, (const wdm_u64x8s *)A->d_wum_m, \
-                       a.x, A->wd_mg, A->wd_col_lo, A->wd_col_hi + 1, c->xcd_remap, stream_nt, A->wd_muni)
+                       a.x, march_cut(A, march_occupancy<EPI, NP_, WX_>()), A->wd_col_lo, A->wd_col_hi + 1, c->xcd_remap, stream_nt, A->wd_muni)
     constexpr bool kMayWX = EPI == EPI_DOT || EPI == EPI_DOT2 || EPI == EPI_DOT4;
     const bool wx = kMayWX && a.w == a.x;
     if (A->wd_muni.n != 5 && A->wd_muni.n != 7) return fail(SLA_ERR_INVALID, "launch_wdia_march: 5 or 7 pairs");
