@@ -206,9 +206,16 @@ __device__ __forceinline__ bool spmv_prologue(const SpmvArgs<RP> &a, double *s4,
 struct RbWalk {
     int first, step, last;
 };
-__device__ __forceinline__ RbWalk rb_walk(int nrb, int xcd_remap) {
+// G: the workgroups that take part (a multiple of 8 where the XCD shares matter); the others of the grid get an empty walk -- a
+// launch whose instantiation holds fewer workgroups per CU than the grid was sized for keeps its grid (the consumers of the fused
+// partial sums know it) and lets the surplus leave at once instead of running a second round
+__device__ __forceinline__ RbWalk rb_walk(int nrb, int xcd_remap, int G) {
     RbWalk w;
-    const int G = gridDim.x;
+    if ((int)blockIdx.x >= G) {
+        w.first = w.last = 0;
+        w.step = 1;
+        return w;
+    }
     if (xcd_remap && (G & 7) == 0 && nrb >= G) {
         const int xcd = blockIdx.x & 7, l = blockIdx.x >> 3, per = (nrb + 7) >> 3;
         w.first = xcd * per + l;
@@ -221,6 +228,7 @@ __device__ __forceinline__ RbWalk rb_walk(int nrb, int xcd_remap) {
     }
     return w;
 }
+__device__ __forceinline__ RbWalk rb_walk(int nrb, int xcd_remap) { return rb_walk(nrb, xcd_remap, (int)gridDim.x); }
 
 typedef double wd_f64x2u __attribute__((ext_vector_type(2), aligned(8)));  // a row pair of x at any 8-byte boundary
 typedef double wd_f64x2 __attribute__((ext_vector_type(2)));
