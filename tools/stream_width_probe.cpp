@@ -174,6 +174,49 @@ __global__ void __launch_bounds__(256, 8) k_store(const int *__restrict__ col, c
     if (keep == 123.456) y[tid] = keep;
 }
 
+
+// Wave-private row blocks (round 3, late): every wavefront owns blocks of 64 rows = 448 entries, stages their products in its own
+// 4 KiB of LDS and folds one row per lane -- no workgroup barrier, each wavefront its own pipeline (the next block's pairs are
+// issued in front of the fold when PF).  Same loads as W1 (dwordx2 col + dwordx4 val per lane).
+template <bool GATHER, bool PF>
+__global__ void __launch_bounds__(256, 8) k_wave(const int *__restrict__ col, const double *__restrict__ val, const double *__restrict__ x,
+                                                 double *__restrict__ y, int nblk146) {
+    __shared__ double s_prod[4][512];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long nrows = (long)nblk146 * kRows, nb = nrows / 64;            // whole 64-row blocks (the tail rows are left out: a probe)
+    double *prod = s_prod[wave];
+    const long W = (long)gridDim.x * 4;
+    i32x2 c[4];
+    f64x2 v[4];
+    auto issue = [&](long b) {
+        const long k0 = b * 448;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = min(2 * lane + 128 * j, 446);
+            c[j] = __builtin_nontemporal_load((const i32x2 *)(col + k0 + i));
+            v[j] = __builtin_nontemporal_load((const f64x2 *)(val + k0 + i));
+        }
+    };
+    long b = (long)blockIdx.x * 4 + wave;
+    if (b < nb) issue(b);
+    for (; b < nb; b += W) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = 2 * lane + 128 * j;
+            const double xa = GATHER ? x[c[j].x] : (double)c[j].x, xb = GATHER ? x[c[j].y] : (double)c[j].y;
+            if (i < 448) *(f64x2 *)(prod + i) = f64x2{v[j].x * xa, v[j].y * xb};
+        }
+        if (PF && b + W < nb) issue(b + W);
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): this wavefront's LDS stores are in place
+        double acc = 0.0;
+        for (int k = lane * 7; k < lane * 7 + 7; ++k) acc += prod[k];
+        y[b * 64 + lane] = acc;
+        __builtin_amdgcn_wave_barrier();
+        if (!PF && b + W < nb) issue(b + W);
+    }
+}
+
 int main(int argc, char **argv) {
     const int N = argc > 1 ? atoi(argv[1]) : 216;
     const long n0 = (long)N * N * N, nblk = n0 / kRows, n = nblk * kRows, nnz = n * 7;
@@ -218,6 +261,11 @@ int main(int argc, char **argv) {
     run("W1 dwordx2 col + dwordx4 val, no gather", k_probe<1, false>, bs);
     run("W0 dword col + dwordx2 val, x gathered", k_probe<0, true>, bg);
     run("W1 dwordx2 col + dwordx4 val, x gathered", k_probe<1, true>, bg);
+    run("wave-private 64-row blocks, no gather", k_wave<false, false>, bs);
+    run("wave-private 64-row blocks, no gather, next pairs ahead", k_wave<false, true>, bs);
+    run("wave-private 64-row blocks, x gathered", k_wave<true, false>, bg);
+    run("wave-private 64-row blocks, x gathered, next pairs ahead", k_wave<true, true>, bg);
+    if (getenv("PROBE_WAVE")) return 0;
     auto run2 = [&](const char *name, auto kern, int grid, double bytes) {
         std::vector<float> t;
         for (int i = 0; i < 13; ++i) {
