@@ -209,7 +209,7 @@ struct sla_ctx {
     int bicg_fuse45 = 1;             // single-rank BiCGSTAB: K4 + K5 in one sweep, rho through K3's extra sums (SLA_BICG_FUSE45)
     int wd_lds = 1;                  // stencils with <= 8 (offset, value) pairs: uniform records + x windows staged in LDS (SLA_WD_LDS; 2: at any size)
     int wd_nt_store = 0;             // its y / z stores past the caches (SLA_WD_NT_STORE)
-    int wd_march = 1;                // 3-D stencils on unsharded contexts: plane-march walk of the LDS-window form (SLA_WD_MARCH; 2: at any size, 0: never)
+    int wd_march = 1;                // 3-D stencils (whole-matrix / whole-slab launches): plane-march walk of the LDS-window form (SLA_WD_MARCH; 2: at any size, 0: never)
     int wd_march_occ = 4;            // its workgroups per CU (32 KiB of LDS each)
     int wd_lds_occ = 0;              // its workgroups per CU (SLA_WD_LDS_OCC; 0: as many as the LDS holds, at most 4)
     int wd_tile = -1;                // plane tiling of the wave-sliced walk: -1 automatic, 0 off, > 0 steps per tile (SLA_WD_TILE)

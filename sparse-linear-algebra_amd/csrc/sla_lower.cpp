@@ -494,12 +494,13 @@ static void low_value_indexed(Low &L) {
                         A->wd_uni = U;
                         A->wd_lds = true;
                         // Plane march (spmv_wdia_march_kernel): three windows {-D}, {in-plane}, {+D} with ONE pair in each far
-                        // window, D even, the in-plane window <= 512 pairs and around offset 0, an unsharded matrix.  The masks
+                        // window, D even, the in-plane window <= 512 pairs and around offset 0; a row slab of a sharded matrix is walked like a
+                        // matrix of its own (planes counted from its first row, which must be even: aligned 16-byte pairs of x).  The masks
                         // are laid out per (tile, plane, wavefront) for rows plane * D + tile * 512 + wavefront * 128 + [0, 128)
                         // -- a plane is not a whole number of 128-row slices (216^2 = 364.5 of them).
                         const int np = A->npairs;
                         const int64_t D = np >= 3 ? (int64_t)doff[(size_t)np - 1] : 0;
-                        if (W.n == 3 && (np == 5 || np == 7) && row_begin == 0 && rows == m && m == n && D >= 1024 && (D & 1) == 0 &&
+                        if (W.n == 3 && (np == 5 || np == 7) && (row_begin & 1) == 0 && m == n && D >= 1024 && (D & 1) == 0 &&
                             doff[0] == -D && doff[1] >= W.omin[1] && doff[(size_t)np - 2] <= wmax[1] && W.omin[1] <= 0 && wmax[1] >= 0 &&
                             W.pb[2] - W.pb[1] <= 512 && rows >= 2 * D) {
                             WdMarch G;

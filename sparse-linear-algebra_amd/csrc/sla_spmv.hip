@@ -37,7 +37,7 @@ int spmv_grid(const sla_csr *A) {
     if (!A->panels.empty() && c->panels && c->spmv_algo == 0) return spmv_grid(A->panels.back());
     int64_t g;
     if (c->spmv_algo == 1 || (A->use_lpanel && c->lpanel)) g = (A->rows + kBlock - 1) / kBlock;   // (lpanel: its finish kernel)
-    else if (A->use_wdia && wd_on(A) && wd_march_on(A) && !overlap_split(A)) g = wd_march_grid(A);
+    else if (A->use_wdia && wd_on(A) && wd_march_on(A)) g = wd_march_grid(A);   // (the whole-matrix launch: overlap_grid sizes the split ones)
     else if (A->use_wdia && wd_on(A)) g = std::min<int64_t>(A->nblk_wd, A->wd_vv ? c->wd_grid_max_vv : wd_lds_on(A) ? wd_lds_grid(A) : c->wd_grid_max);
     else if (A->use_vdict && c->vdict) g = A->nblk_vd;
     else g = A->nrb;
@@ -126,7 +126,7 @@ static int launch_spmv_rp(const sla_csr *A, const SpmvLaunch &l) {
             if (l.part == 1) { sched = A->d_ov_int; nblk_wd = A->ov_nint; g = overlap_grid(A, 1); }
             else if (l.part == 2) { sched = A->d_ov_bnd; nblk_wd = A->ov_nbnd; g = overlap_grid(A, 2); }
             const int stream_nt = vec_stream_nt(c, A->rows) ? 1 : 0;
-            if (wd_march_on(A) && l.part == 0 && !overlap_split(A)) return launch_wdia_march(A, l.epi, a, g, stream_nt | (c->wd_nt_store ? 2 : 0));
+            if (wd_march_on(A) && l.part == 0) return launch_wdia_march(A, l.epi, a, g, stream_nt | (c->wd_nt_store ? 2 : 0));
             if (wd_lds_on(A)) return launch_wdia_lds(A, l.epi, a, sched, nblk_wd, g, stream_nt | (c->wd_nt_store ? 2 : 0));
             return launch_spmv_wdia(A, l.epi, a, sched, nblk_wd, g, stream_nt);
         }

@@ -21,7 +21,8 @@
 //     the barrier: K1 45.0 -> 46.3 us; profiles/r03_ab_march.txt);
 //   * fold order, roundings and epilogues are spmv_wdia_kernel's (shared wd_epilogue): every row bit-identical to the other forms
 //     (tests/test_gpu_value_indexed.py).  The partial sums of the fused dot products are grouped by task instead of by step.
-// Taken for 5- and 7-pair stencils (one pair at -D, one at +D) on unsharded matrices (sla_lower.cpp: low_value_indexed).
+// Taken for 5- and 7-pair stencils (one pair at -D, one at +D); a row slab of a sharded matrix is walked like a matrix of its own
+// (its whole-slab launches: the interior / boundary launches of an overlapped exchange stay step-based), sla_lower.cpp: low_value_indexed.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -38,7 +39,7 @@ constexpr int kMarchBufBytes = 512 * 16;   // one staged window: <= 512 pairs
 // WX: the epilogue operand w IS the gathered vector (K3: As . s) and comes from the staged window instead of a global load
 template <int EPI, int NP, bool WX>
 __global__ void __launch_bounds__(kBlock, 3) spmv_wdia_march_kernel(SpmvArgs<int32_t> a, const wdm_u64x8s *__restrict__ wum, const double *__restrict__ xg,
-                                                                    WdMarch m, int32_t xlo, int32_t xhi, int xcd_remap, int stream_nt, WdUni uni) {
+                                                                    WdMarch m, int32_t grow0, int32_t xlo, int32_t xhi, int xcd_remap, int stream_nt, WdUni uni) {
     __shared__ wd_f64x2 wd_buf[4][512];
     __shared__ double s_red[4];
     const int tid = threadIdx.x;
@@ -72,7 +73,7 @@ __global__ void __launch_bounds__(kBlock, 3) spmv_wdia_march_kernel(SpmvArgs<int
     }
     const uint32_t laddr0 = (uint32_t)(wave * 128 + 2 * lane + uni.lpos0) << 3;
     const bool second = tid + 256 < m.pairs;          // this lane stages a second pair of the window
-    const double *wp = a.w ? a.w : xg;                 // (EPI_AXPY_DOT without w: loaded all the same, not used)
+    const double *wp = a.w ? a.w : a.z;                // (EPI_AXPY_DOT without w: loaded all the same -- from z, always there -- not used)
     // The window of plane k of the current tile: pairs tid and tid + 256.  Only columns [xlo, xhi) are known to be readable: a pair
     // that does not touch them is replaced by the pair at xlo and never used (empty masks); one element of slack either side.  No
     // load of the step loop stands under a condition -- uniform or not: with a conditional load in the loop the compiler can no
@@ -105,7 +106,7 @@ __global__ void __launch_bounds__(kBlock, 3) spmv_wdia_march_kernel(SpmvArgs<int
         const int pos = tile * 512 + wave * 128 + 2 * lane;      // this lane's row pair inside the plane
         const bool in_plane = pos < m.D;                         // (D is even: both rows or none)
         const bool wave_in = tile * 512 + wave * 128 < m.D;
-        xbase = (long long)tile * 512 + m.omin - (xlo - 1) + 2 * tid;
+        xbase = (long long)grow0 + (long long)tile * 512 + m.omin - (xlo - 1) + 2 * tid;   // (x is addressed by global column; rows are local)
         wd_f64x2 pa0, pa1, pb0, pb1, r0, r1, wv, zv, wvn, zvn;
         ld(k0 - 1, pa0, pa1);
         ld(k0, pb0, pb1);
@@ -233,9 +234,10 @@ static int launch_epi(const sla_csr *A, const SpmvArgs<int32_t> &a, int grid, in
     sla_ctx *c = A->ctx;
 #define SLA_WDM_LAUNCH(NP_, WX_)                                                                                                         \
     hipLaunchKernelGGL((spmv_wdia_march_kernel<EPI, NP_, WX_>), dim3(grid), dim3(kBlock), 0, stream_of(c), a, (const wdm_u64x8s *)A->d_wum_m, \
-                       a.x, march_cut(A, march_occupancy<EPI, NP_, WX_>()), A->wd_col_lo, A->wd_col_hi + 1, c->xcd_remap, stream_nt, A->wd_muni)
+                       a.x, march_cut(A, march_occupancy<EPI, NP_, WX_>()), (int32_t)A->row_begin, A->wd_col_lo, A->wd_col_hi + 1, c->xcd_remap, stream_nt, \
+                       A->wd_muni)
     constexpr bool kMayWX = EPI == EPI_DOT || EPI == EPI_DOT2 || EPI == EPI_DOT4;
-    const bool wx = kMayWX && a.w == a.x;
+    const bool wx = kMayWX && a.w == a.x + A->row_begin;   // (w holds local rows, x is addressed by global column)
     if (A->wd_muni.n != 5 && A->wd_muni.n != 7) return fail(SLA_ERR_INVALID, "launch_wdia_march: 5 or 7 pairs");
     if constexpr (kMayWX) {
         if (wx) {

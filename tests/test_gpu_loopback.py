@@ -65,6 +65,19 @@ def test_sharded_path_with_the_lds_window_kernel(kind, nranks):
         assert "ldswin" in out.stdout, out.stdout[-3000:]
 
 
+@pytest.mark.parametrize("kind,nranks", [("laplace_big", 2), ("laplace_big", 3), ("laplace_big", 5)])
+def test_sharded_path_with_the_plane_march(kind, nranks):
+    """wd_march=2 walks a row slab like a matrix of its own (planes counted from its first row; slabs whose first row is odd keep the
+    LDS-window kernel): the whole-slab launches of the ghost-row solver flows take spmv_wdia_march_kernel with x addressed by global
+    column, the interior / boundary launches of an overlapped exchange stay on the step-based kernels -- same rows either way.  The
+    worker compares every (#>) with the oracle bit for bit and the solvers with its iterates."""
+    env = dict(os.environ, SLA_WD_LDS="2", SLA_WD_MARCH="2")
+    out = subprocess.run([sys.executable, os.path.join(HERE, "_loopback_worker.py"), str(nranks), kind], env=env,
+                         stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert out.returncode == 0 and f"LOOPBACK_OK {nranks} {kind}" in out.stdout, out.stdout[-3000:]
+    assert "wdia+march" in out.stdout, out.stdout[-3000:]
+
+
 @pytest.mark.parametrize("kind,nranks", [("laplace", 3), ("laplace", 8), ("tiny", 4), ("tinyband", 16), ("banded", 2), ("denseband", 4), ("fuzz2", 3), ("fuzz5", 2), ("random", 2)])
 def test_ghost_row_bicgstab_and_cgs_equal_the_plain_sharded_flow(kind, nranks):
     """Sharded BiCGSTAB keeps r, p, Ap and s valid on the ghost rows and needs 3 grouped exchanges per step instead of 5
