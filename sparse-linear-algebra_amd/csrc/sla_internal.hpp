@@ -637,6 +637,7 @@ inline bool vec_stream_nt(const sla_ctx *c, int64_t n) { return c->vec_nt < 0 ? 
 int launch_wdia_lds(const sla_csr *A, int epi, const SpmvArgs<int32_t> &a, const int32_t *sched, int32_t nblk, int grid, int stream_nt);   // sla_spmv_wdia_lds.hip
 int wd_lds_grid(const sla_csr *A);
 int wd_march_grid(const sla_csr *A);
+void wd_march_prepare();   // (lowering: queries the instantiations' register counts once, outside any stream capture)
 int launch_wdia_march(const sla_csr *A, int epi, const SpmvArgs<int32_t> &a, int grid, int stream_nt);
 bool pipe_on(const sla_csr *A);                                                                              // sla_spmv_pipe.hip
 int launch_spmv_pipe(const sla_csr *A, int epi, const SpmvArgs<int32_t> &a, int grid);

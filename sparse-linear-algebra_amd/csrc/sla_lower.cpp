@@ -538,6 +538,7 @@ static void low_value_indexed(Low &L) {
                             A->wd_mg = G;
                             A->wd_muni = M;
                             A->wd_march = true;
+                            wd_march_prepare();
                         }
                     }
                 }

@@ -254,6 +254,27 @@ static int launch_epi(const sla_csr *A, const SpmvArgs<int32_t> &a, int grid, in
     return SLA_OK;
 }
 
+// the register counts of all instantiations, asked once at lowering time (not inside a stream capture of the first solver step)
+template <int EPI>
+static void march_prepare_epi() {
+    (void)march_occupancy<EPI, 5, false>();
+    (void)march_occupancy<EPI, 7, false>();
+    if constexpr (EPI == EPI_DOT || EPI == EPI_DOT2 || EPI == EPI_DOT4) {
+        (void)march_occupancy<EPI, 5, true>();
+        (void)march_occupancy<EPI, 7, true>();
+    }
+}
+void wd_march_prepare() {
+    march_prepare_epi<EPI_NONE>();
+    march_prepare_epi<EPI_DOT>();
+    march_prepare_epi<EPI_DOT2>();
+    march_prepare_epi<EPI_DOT4>();
+    march_prepare_epi<EPI_RES>();
+    march_prepare_epi<EPI_AXPY_DOT>();
+    march_prepare_epi<EPI_XPBY_NRM>();
+    march_prepare_epi<EPI_SUB>();
+}
+
 int launch_wdia_march(const sla_csr *A, int epi, const SpmvArgs<int32_t> &a, int grid, int stream_nt) {
     switch (epi) {
         case EPI_NONE: return launch_epi<EPI_NONE>(A, a, grid, stream_nt);
