@@ -28,10 +28,17 @@ constexpr int kXWinHalo = 256;       // the window starts kXWinHalo columns left
 #define SLA_WD_STAGES 1
 #endif
 constexpr int kWdBlocksPerCu = SLA_WD_OCC;      // resident workgroups per CU of spmv_wdia_kernel (its persistent grid = that x CUs)
+// ... for the variable-coefficient variant (per-row value blocks): 4 since late round 3 -- at 5 the K1 / K3 / CGS instantiations spilled
+// 8-22 VGPRs into scratch to fit 96 and the four-sum one (108 VGPRs, compiled for 4) ran a 5-per-CU grid in two rounds; at 4 nothing
+// spills: 2 M-row banded problem 12 490 -> 12 830 (four-sum fix) -> 13 100 it/s same-box, K1 24.2 -> 23.2 us
 #if !defined(SLA_WD_OCC_VV)
-#define SLA_WD_OCC_VV 5
+#define SLA_WD_OCC_VV 4
 #endif
-constexpr int kWdBlocksPerCuVV = SLA_WD_OCC_VV;             // same for the variable-coefficient variant (per-row value blocks: 102 VGPRs)
+#ifndef SLA_WD_OCC_VV4
+#define SLA_WD_OCC_VV4 4
+#endif
+constexpr int kWdBlocksPerCuVV4 = SLA_WD_OCC_VV4;           // (its four-sum instantiation)
+constexpr int kWdBlocksPerCuVV = SLA_WD_OCC_VV;
 constexpr int kWdMaxSliceRecords = 40;          // wave-sliced forms: more diagonals per 128-row slice than this and the older kernels are used
                                                 // (27-point stencil, 128^3: wdia 25.5 us, vdict 42 us, diagdict 167 us)
 constexpr int kWdGatherStages = SLA_WD_STAGES;  // 2: the gathers of the next slice are issued before the current one is folded

@@ -71,7 +71,7 @@ __device__ __forceinline__ double wd_lane_f64(double x, int k) {
 // rows (wvblk), fetched with one more 16-byte load per lane; everything else is shared.
 // (VV with the four-sum epilogue: one workgroup per CU less -- 108 VGPRs and no scratch instead of 96 + 44 B of spills per lane)
 template <int EPI, bool VV>
-__global__ void __launch_bounds__(kBlock, VV ? (EPI == EPI_DOT4 ? kWdBlocksPerCuVV - 1 : kWdBlocksPerCuVV) : kWdBlocksPerCu) spmv_wdia_kernel(SpmvArgs<int32_t> a, const int32_t *__restrict__ sptr,
+__global__ void __launch_bounds__(kBlock, VV ? (EPI == EPI_DOT4 ? kWdBlocksPerCuVV4 : kWdBlocksPerCuVV) : kWdBlocksPerCu) spmv_wdia_kernel(SpmvArgs<int32_t> a, const int32_t *__restrict__ sptr,
                                                                const unsigned long long *__restrict__ wme,
                                                                const unsigned long long *__restrict__ wmo,
                                                                const double *__restrict__ wval, const int32_t *__restrict__ woff,
@@ -319,7 +319,7 @@ int launch_wdia_t(const sla_csr *A, const SpmvArgs<int32_t> &a, const int32_t *s
     // the four-sum instantiation of the variable-coefficient form holds one workgroup per CU less than the grid is sized for (its
     // launch bounds): the surplus workgroups leave at once instead of running a second round (2 M-row banded K3 26.7 -> 24.6 us)
     int active = grid;
-    if (A->wd_vv && EPI == EPI_DOT4) active = std::min(grid, std::max(8, ((kWdBlocksPerCuVV - 1) * c->n_cu) & ~7));
+    if (A->wd_vv && EPI == EPI_DOT4) active = std::min(grid, std::max(8, (kWdBlocksPerCuVV4 * c->n_cu) & ~7));
     if (A->wd_vv)
         hipLaunchKernelGGL((spmv_wdia_kernel<EPI, true>), dim3(grid), dim3(kBlock), 0, stream_of(c), a, A->d_wptr, A->d_wme, A->d_wmo,
                            A->d_wval, A->d_woff, A->d_wvblk, a.x, nblk_wd, A->nslices, (int32_t)A->row_begin, (int32_t)A->n,
