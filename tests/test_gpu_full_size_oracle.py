@@ -86,8 +86,8 @@ def test_config4_laplace3d_10m_bit_exact_vs_oracle(sla):
 
 
 def test_config4_laplace3d_10m_reference_split_flow_vs_oracle(sla):
-    """The single-rank default fuses K4 and K5 (the test above); sharded contexts -- config 4 on 8 GPUs -- run the reference's
-    split.  The same full-size check on a context with the option bicg_fuse45=0."""
+    """The default flow fuses K4 and K5 (the test above; since round 3 on sharded contexts too); the reference's own split stays
+    selectable.  The same full-size check on a context with the option bicg_fuse45=0."""
     from sla_amd import workloads as wl
     ctx = sla.Context(0).set_option("bicg_fuse45", 0)
     dims, (rp, ci, va) = wl.laplace3d(216, 216, 216)

@@ -402,9 +402,9 @@ def test_row_partition_matches_python(sla):
 
 def test_forced_collectives_match_single_gpu_path(sla, monkeypatch):
     """Per-rank folding + rank-order summation reproduce the 1-GPU reduction order BIT FOR BIT.  Both contexts run the
-    reference's K4 / K5 split (SLA_BICG_FUSE45=0; knobs are read when a context is created): the single-rank default fuses
-    them and evaluates rho through an identity, sharded contexts never do -- that difference is
-    test_bicgstab_fused_k45_flow_vs_reference_split's subject, not this test's."""
+    reference's K4 / K5 split (option bicg_fuse45=0): the fused sweep evaluates rho through an identity and publishes four sums as one
+    block on a sharded context -- that flow is test_bicgstab_fused_k45_flow_vs_reference_split's and the loopback tests' subject, not
+    this test's."""
     from sla_amd import workloads as wl
     monkeypatch.setenv("SLA_FORCE_COLLECTIVES", "1")       # (read when the communicator is built: not a per-context option)
     ctx = sla.Context(0, 0, 1, sla.Context.unique_id()).set_option("bicg_fuse45", 0)
