@@ -93,7 +93,11 @@ int main(int argc, char **argv) {
     const long n = argc > 1 ? atol(argv[1]) : 10077696;
     const int sets = 3, reps = 30;
     std::vector<std::vector<double *>> v(sets, std::vector<double *>(8));
-    for (auto &set : v) for (auto &p : set) { CK(hipMalloc(&p, n * 8)); CK(hipMemset(p, 0, n * 8)); }
+    // SWEEP_SKEW=<bytes>: vector k of a set starts k * skew bytes into its allocation (do the eight streams of the sweep, all at the same
+    // offset of 2 MiB-aligned allocations, meet in the same HBM channels?)
+    const long skew = getenv("SWEEP_SKEW") ? atol(getenv("SWEEP_SKEW")) : 0;
+    for (auto &set : v) { int k = 0; for (auto &p : set) { char *q; CK(hipMalloc(&q, n * 8 + 8 * skew + 256)); CK(hipMemset(q, 0, n * 8 + 8 * skew + 256)); p = (double *)(q + k * skew); ++k; } }
+    if (skew) printf("# vector k of a set skewed by k * %ld bytes\n", skew);
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     auto run = [&](const char *name, int grid, bool inplace, auto kern) {
