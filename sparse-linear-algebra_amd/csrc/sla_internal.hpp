@@ -229,7 +229,7 @@ struct sla_ctx {
     int force_rp64 = 0;              // test hook: 64-bit row pointers at any size (SLA_FORCE_RP64)
     int lp_copy = 1;                 // LDS-panel form: stream a panel-major second copy of col / val (SLA_LP_COPY=0: the row-major arrays)
     int lpanel = 1;                  // allow the LDS-panel SpMV kernel for matrices with dense rows (SLA_LPANEL=0 disables)
-    int xwin = 1;                    // allow the LDS x-window SpMV kernel (SLA_XWIN=0 disables)
+    int xwin = 1;                    // LDS x windows: 1 = where they pay (the pair-code kernel), 2 = also the dictionary-code kernels, 0 = nowhere (SLA_XWIN); the plain CSR-stream kernel takes its window form only with stream_wide = 0
     int stream_wide = 1;             // spmv_stream_kernel: pairs of entries per load (8-byte col / 16-byte val loads) instead of one (SLA_STREAM_WIDE=0)
     int stream_pipe = 0;             // plain CSR-stream (#>): the three-stage pipelined kernel (sla_spmv_pipe.hip) instead of spmv_stream / spmv_xwin
                                      // (SLA_STREAM_PIPE=1; OFF by default: measured 7-12 % SLOWER than the one-deep prefetch)
@@ -435,6 +435,10 @@ inline bool wd_march_on(const sla_csr *A) {
 // spmv_stream_kernel (stream_wide, default): with them the plain kernel is the faster one (round 3: K1 222-231 vs 232-241 us,
 // K3 -- four sums since the fused K4+K5 flow -- 228-238 vs 258 us on the 216^3 Laplacian), so the window form is an A/B knob now
 inline bool stream_xwin_on(const sla_csr *A) { return A->use_xwin && A->ctx->xwin && !A->ctx->stream_wide; }
+// ... of the dictionary-code kernels (spmv_diag_kernel): only with xwin = 2.  Since the paired loads and the operands issued with the
+// gathers its window variant loses (216^3 Laplacian on 9 B per entry: K1 202 vs 188 us, the four-sum K3 -- 17 spilled VGPRs -- 271 vs
+// 210 us, 1640 vs 1870 it/s); the pair-code kernel (spmv_vdict_kernel) keeps its window at xwin = 1 (K1 85 vs 90 us).
+inline bool diag_xwin_on(const sla_csr *A) { return A->use_xwin && A->ctx->xwin >= 2; }
 inline bool wd_on(const sla_csr *A) { return A->wd_vv ? (A->ctx->wdia && A->ctx->wdia_vv) : A->ctx->wdia != 0; }
 
 // ---------------------------------------------------------------------------------------------------------------

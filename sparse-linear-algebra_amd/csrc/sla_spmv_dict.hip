@@ -124,6 +124,9 @@ __global__ void __launch_bounds__(kBlock, 8) spmv_diag_kernel(SpmvArgs<RP> a, co
                 if (nrows > 64 || cnt <= 8 * nrows) {
                     // one lane per row: decode, gather, multiply, add -- ascending, separately rounded
                     if (tid < nrows) {
+                        // (the epilogue's operands are issued in front of the row's gathers, not behind its fold: sla_spmv_stream.hip)
+                        double wpre, zpre;
+                        spmv_operands<EPI, RP>(a, r0 + tid, wpre, zpre);
                         const int s = rp[tid], e = rp[tid + 1];
                         const int grow = grow0 + r0 + tid;
                         double acc = 0.0;
@@ -147,7 +150,7 @@ __global__ void __launch_bounds__(kBlock, 8) spmv_diag_kernel(SpmvArgs<RP> a, co
                                 acc = acc + prod;
                             }
                         }
-                        spmv_epilogue<EPI, RP>(a, r0 + tid, acc, coef, acc1, acc2);
+                        spmv_epilogue_pre<EPI, RP>(a, r0 + tid, acc, coef, acc1, acc2, wpre, zpre);
                     }
                 } else {
                     int np2 = 1;
@@ -662,7 +665,7 @@ namespace {
 template <int EPI, typename RP>
 int launch_diag_t(const sla_csr *A, const SpmvArgs<RP> &a, int grid) {
     sla_ctx *c = A->ctx;
-    if (A->use_xwin && c->xwin)
+    if (diag_xwin_on(A))
         hipLaunchKernelGGL((spmv_diag_kernel<EPI, RP, true>), dim3(grid), dim3(kBlock), 0, stream_of(c), a, a.rowptr, A->d_code, a.val, a.rb,
                            a.rbk, a.x, A->d_rbw, A->d_dict, (int32_t)A->n, (int32_t)A->row_begin, c->xcd_remap);
     else
@@ -688,7 +691,7 @@ int launch_diag_rp(const sla_csr *A, int epi, const SpmvArgs<RP> &a, int grid) {
 template <typename RP>
 int launch_dual_diag_rp(const sla_csr *A, const SpmvArgs<RP> &a, const double *x2, const double *b2, int grid) {
     sla_ctx *c = A->ctx;
-    if (A->use_xwin && c->xwin)
+    if (diag_xwin_on(A))
         hipLaunchKernelGGL((spmv_dual_diag_kernel<RP, true>), dim3(grid), dim3(kBlock), 0, stream_of(c), a, a.rowptr, A->d_code, a.val,
                            a.rb, a.rbk, a.x, A->d_rbw, A->d_dict, (int32_t)A->n, (int32_t)A->row_begin, x2, b2, c->xcd_remap);
     else

@@ -274,7 +274,8 @@ def test_64_bit_row_pointer_kernels(sla):
         return (n, n), (A.rowptr, A.colidx, A.val)
 
     cases = {
-        "laplace3d": (wl.laplace3d(13, 9, 11), {}, "diagdict"),
+        "laplace3d": (wl.laplace3d(13, 9, 11), {}, "algo=stream+diagdict "),
+        "laplace3d, dictionary codes + x window": (wl.laplace3d(13, 9, 11), {"xwin": 2}, "algo=stream+diagdict+xwin"),
         "laplace3d, plain stream": (wl.laplace3d(13, 9, 11), {"diag": 0, "xwin": 0}, "algo=stream "),
         "random_spd short rows": (wl.random_spd(3000, 4, 3), {}, "algo=stream"),
         "laplace3d, x window (narrow loads)": (wl.laplace3d(13, 9, 11), {"diag": 0, "stream_wide": 0}, "algo=stream+xwin"),
