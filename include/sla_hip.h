@@ -56,8 +56,14 @@ typedef struct sla_csr *sla_csr_t;       /* device CSR (this rank's row block); 
 typedef struct sla_vec *sla_vec_t;       /* device dense f64 vector (this rank's row block) */
 typedef struct sla_solver *sla_solver_t; /* CGS / BiCGSTAB / CGNE state record on the device */
 
-/* solver options; NULL = the reference's hard-coded values (Sparse.hs:1034-1037) */
+/* solver options; NULL = the reference's hard-coded values (Sparse.hs:1034-1037).
+ * ABI versioning: both structs open with `struct_size` = sizeof of the struct in the CALLER's header (SLA_SOLVE_OPTS_INIT /
+ * SLA_SOLVE_INFO_INIT set it).  The library reads / writes only the members that lie inside it, so a caller built against an
+ * older, shorter layout keeps working when members are appended; a struct_size smaller than the first version's layout (or 0:
+ * a caller from before the field existed) is refused with SLA_ERR_INVALID instead of being read past its end. */
+#define SLA_ABI_VERSION 2
 typedef struct {
+    int32_t struct_size;   /* sizeof(sla_solve_opts) */
     int32_t max_iters;     /* nits   = 200  */
     double tol_abs;        /* tolAbs = 1e-6 */
     double tol_rel;        /* tolRel = 1e-4 */
@@ -70,8 +76,10 @@ typedef struct {
     double *history;       /* sla_linsolve0: HOST buffer (may be NULL) receiving the residual trace -- history[j - 1] = the true residual
                               norm ||A x_j - b|| the device evaluated after iteration j, j = 1 .. info->history_len: what cgsStepDebug
                               (Sparse.hs:942-948) prints per iteration, kept in a device buffer during the solve and downloaded once */
-    int32_t history_cap;   /* its capacity in doubles (the trace stops there) */
+    int32_t history_cap;   /* its capacity in doubles (the trace stops there).  The trace needs true_residual = 1: without the
+                              per-iteration residual there is nothing to record and history_len stays 0 */
 } sla_solve_opts;
+#define SLA_SOLVE_OPTS_INIT {(int32_t)sizeof(sla_solve_opts), 200, 1e-6, 1e-4, 16, 1, 0, 0}
 
 enum { /* sla_solve_info.flags */
     SLA_FLAG_CONVERGED = 1,   /* resnorm <= tol reached */
@@ -82,6 +90,7 @@ enum { /* sla_solve_info.flags */
 };
 
 typedef struct {
+    int32_t struct_size; /* IN: sizeof(sla_solve_info) of the caller's header (see above) */
     int32_t iters;   /* solver steps taken */
     int32_t flags;
     double resnorm;  /* last true residual norm ||A x - b||_2 evaluated (NaN if none) */
@@ -89,6 +98,7 @@ typedef struct {
     double tol;      /* max tol_abs (tol_rel * r0norm) */
     int32_t history_len; /* entries written to sla_solve_opts.history (= min (iters, history_cap); 0 without a trace) */
 } sla_solve_info;
+#define SLA_SOLVE_INFO_INIT {(int32_t)sizeof(sla_solve_info), 0, 0, 0.0, 0.0, 0.0, 0}
 
 /* which state vector sla_solver_get returns: record fields _x/_r/_p/_u (Sparse.hs:919),
  * _xBicgstab/_rBicgstab/_pBicgstab (:959-960), _xCgne/_rCgne/_pCgne (:855-856) */
@@ -129,6 +139,7 @@ int sla_ctx_rank(sla_ctx_t, int *rank, int *nranks);
 int sla_ctx_row_range(sla_ctx_t, int64_t m, int64_t *begin, int64_t *end);
 const char *sla_last_error(void);
 const char *sla_version(void);
+int sla_abi_version(void);   /* SLA_ABI_VERSION the library was built with */
 
 /* ---- A0: SpMatrix -> device CSR ("lower once") ------------------------------------------------ */
 

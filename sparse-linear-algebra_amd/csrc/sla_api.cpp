@@ -1,6 +1,8 @@
 // sla_api.cpp -- C ABI: context and options, matrix / vector handles, (#>) (<#) (<.>) norm2 axpby, the x exchange of row-sharded contexts (the lowering: sla_lower.cpp; preconditioner builders and triangular solves: sla_precond.cpp).
 // Reference citations per entry point are in include/sla_hip.h.
+#include <errno.h>
 #include <math.h>
+#include <stddef.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -23,14 +25,22 @@ static thread_local const sla_ctx *t_bound = nullptr;
 int g_debug_binding = [] { const char *e = getenv("SLA_DEBUG_BINDING"); return e ? atoi(e) : 0; }();
 static std::atomic<long> g_binding_violations{0};
 const sla_ctx *bound_ctx() { return t_bound; }
-Bind::Bind(const sla_ctx *c) : prev(t_bound) {
+// (the device ids are kept as plain ints: sla_ctx_destroy opens a Bind on the context it then deletes, and on the failure paths of
+// context creation the enclosing Bind is on that same context -- neither destructor may read through the pointers)
+static thread_local int t_bound_device = -1;
+Bind::Bind(const sla_ctx *c) : prev(t_bound), prev_device(t_bound_device) {
     if (!c || !c->kids.empty()) return;   // (a parent context owns no device: its rank contexts are bound on their worker threads)
-    if (!prev || prev->device != c->device) (void)hipSetDevice(c->device);
+    if (prev_device != c->device) (void)hipSetDevice(c->device);
     t_bound = c;
+    t_bound_device = c->device;
 }
 Bind::~Bind() {
-    if (prev && t_bound && prev->device != t_bound->device) (void)hipSetDevice(prev->device);
+    if (prev_device >= 0 && prev_device != t_bound_device) (void)hipSetDevice(prev_device);
     t_bound = prev;
+    t_bound_device = prev_device;
+}
+void unbind_destroyed(const sla_ctx *c) {   // a context is about to be deleted: no token may keep pointing at it
+    if (t_bound == c) t_bound = nullptr;
 }
 void binding_violation(const sla_ctx *c, const char *what) {
     const long k = ++g_binding_violations;
@@ -43,6 +53,35 @@ long binding_violations() { return g_binding_violations.load(); }
 int fail(int code, const std::string &msg) {
     g_last_error = msg;
     return code;
+}
+
+int read_solve_opts(const sla_solve_opts *in, sla_solve_opts *out, const char *who) {
+    const sla_solve_opts def = SLA_SOLVE_OPTS_INIT;
+    *out = def;
+    if (!in) return SLA_OK;
+    // (the first layout with a struct_size ends behind history_cap; anything shorter is a caller from before the field existed,
+    // whose first member was max_iters -- refuse instead of reading a trace pointer that is not there)
+    if (in->struct_size < (int32_t)(offsetof(sla_solve_opts, history_cap) + sizeof(int32_t)) || in->struct_size > 4096)
+        return fail(SLA_ERR_INVALID, std::string(who) + ": sla_solve_opts.struct_size is not set (use SLA_SOLVE_OPTS_INIT; ABI version " + std::to_string(SLA_ABI_VERSION) + ")");
+    memcpy(out, in, std::min<size_t>((size_t)in->struct_size, sizeof(*out)));
+    out->struct_size = (int32_t)sizeof(*out);
+    return SLA_OK;
+}
+int info_begin(const sla_solve_info *user, sla_solve_info *local, const char *who) {
+    const sla_solve_info def = SLA_SOLVE_INFO_INIT;
+    *local = def;
+    local->resnorm = NAN;
+    local->r0norm = NAN;
+    local->tol = NAN;
+    if (user && (user->struct_size < (int32_t)(offsetof(sla_solve_info, history_len) + sizeof(int32_t)) || user->struct_size > 4096))
+        return fail(SLA_ERR_INVALID, std::string(who) + ": sla_solve_info.struct_size is not set (use SLA_SOLVE_INFO_INIT; ABI version " + std::to_string(SLA_ABI_VERSION) + ")");
+    return SLA_OK;
+}
+void info_commit(sla_solve_info *user, const sla_solve_info &local) {
+    if (!user) return;
+    const int32_t sz = user->struct_size;
+    memcpy(user, &local, std::min<size_t>((size_t)sz, sizeof(local)));
+    user->struct_size = sz;
 }
 
 ProfScope::ProfScope(sla_ctx *ctx, int kernel_id) : c(ctx), on(false) {
@@ -320,7 +359,8 @@ extern "C" {
 
 const char *sla_last_error(void) { return g_last_error.c_str(); }
 long sla_debug_binding_violations(void) { return binding_violations(); }
-const char *sla_version(void) { return "sla_hip 0.1 (gfx950)"; }
+const char *sla_version(void) { return "sla_hip 0.2 (gfx950)"; }
+int sla_abi_version(void) { return SLA_ABI_VERSION; }
 
 // The A/B and test knobs ("Knobs"): every one defaults to the measured-best setting.  ONE table serves both
 // ways of setting them: sla_ctx_set_option(ctx, "wdia", "0") -- the typed, per-context entry of the ABI -- and the environment
@@ -367,20 +407,29 @@ const IntKnob kIntKnobs[] = {
 };
 const char *const kOtherKnobs[] = {"wd_grid", "spmv_algo", "panel_cols", "device_coo_min", "x_exchange"};
 
-// one option, by its lower-case name; false: unknown name or value out of range
+// a whole decimal integer, nothing behind it ("1abc" is rejected)
+bool parse_int(const char *value, long long *out) {
+    char *end = nullptr;
+    errno = 0;
+    const long long v = strtoll(value, &end, 10);
+    if (end == value || *end != '\0' || errno != 0) return false;
+    *out = v;
+    return true;
+}
+// one option, by its lower-case name; false: unknown name or value out of range (the context is then unchanged)
 bool ctx_apply_option(sla_ctx *c, const std::string &name, const char *value) {
     for (const IntKnob &k : kIntKnobs)
         if (name == k.name) {
-            char *end = nullptr;
-            const long v = strtol(value, &end, 10);
-            if (end == value || v < k.lo || v > k.hi) return false;
+            long long v;
+            if (!parse_int(value, &v) || v < k.lo || v > k.hi) return false;
             c->*(k.field) = (int)v;
             return true;
         }
-    if (name == "wd_grid") {        // persistent grid of the wave-sliced kernels (a multiple of 8: one share per XCD)
-        const int g = atoi(value);
-        if (g < 8 || g > kMaxParts) return false;
-        c->wd_grid_max = g & ~7;
+    if (name == "wd_grid") {        // persistent grid of the wave-sliced kernels (a multiple of 8: one share per XCD); both kernel families
+        long long g;
+        if (!parse_int(value, &g) || g < 8 || g > kMaxParts) return false;
+        c->wd_grid_max = (int)g & ~7;
+        c->wd_grid_max_vv = std::min<int>(c->wd_grid_max, std::max(8, (kWdBlocksPerCuVV * c->n_cu) & ~7));   // (its instantiations are compiled for fewer workgroups per CU)
         return true;
     }
     if (name == "spmv_algo") {
@@ -388,8 +437,18 @@ bool ctx_apply_option(sla_ctx *c, const std::string &name, const char *value) {
         c->spmv_algo = strcmp(value, "scalar") == 0 ? 1 : 0;
         return true;
     }
-    if (name == "panel_cols") { c->panel_cols = atoll(value); return c->panel_cols > 0; }
-    if (name == "device_coo_min") { c->device_coo_min = atoll(value); return true; }
+    if (name == "panel_cols") {     // (parsed into a temporary: a rejected value leaves the context as it was)
+        long long v;
+        if (!parse_int(value, &v) || v <= 0) return false;
+        c->panel_cols = v;
+        return true;
+    }
+    if (name == "device_coo_min") {
+        long long v;
+        if (!parse_int(value, &v) || v < 0) return false;
+        c->device_coo_min = v;
+        return true;
+    }
     if (name == "x_exchange") {
         if (strcmp(value, "allgather") == 0) c->x_exchange = 1;
         else if (strcmp(value, "window") == 0) c->x_exchange = 2;
@@ -502,6 +561,7 @@ int sla_ctx_create_loopback(int device_id, int rank, int nranks, int group_key, 
 int sla_ctx_destroy(sla_ctx_t c) {
     if (c && !c->kids.empty()) return m_ctx_destroy(c);
     if (!c) return SLA_OK;
+    {
     Bind bind(c);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     dist_comm_destroy(c);
@@ -517,6 +577,8 @@ int sla_ctx_destroy(sla_ctx_t c) {
     if (c->ev_x_done) (void)hipEventDestroy(c->ev_x_done);
     if (c->comm_stream) (void)hipStreamDestroy(c->comm_stream);
     if (c->stream) (void)hipStreamDestroy(c->stream);
+    }
+    unbind_destroyed(c);   // (the failure paths of context creation call this inside a Bind on c: its token must not outlive c)
     delete c;
     return SLA_OK;
 }
@@ -537,6 +599,7 @@ int sla_ctx_set_option(sla_ctx_t c, const char *name, const char *value) {
     }
     if (!ctx_apply_option(c, name, value))
         return fail(SLA_ERR_INVALID, std::string("sla_ctx_set_option: unknown option or value out of range: ") + name + "=" + value);
+    c->opt_gen++;   // (solver states re-capture their step graphs under the new options)
     return SLA_OK;
 }
 

@@ -246,6 +246,7 @@ struct sla_ctx {
     std::multimap<size_t, void *> vec_pool;
     size_t vec_pool_bytes = 0;
     // profiling
+    int opt_gen = 0;                 // bumped by every sla_ctx_set_option: a solver's captured step graph is only replayed under the options it was captured with
     int prof_kernel = -2, prof_max = 0;   // -2: not recording, SLA_KERNEL_ALL (-1): every kernel id, else one id
     std::vector<int> prof_ids;            // kernel id of each recorded launch
     std::vector<float> prof_ms;           // durations of the last recording (filled by sla_prof_stop)
@@ -378,6 +379,7 @@ struct sla_solver {
     bool have_res = false;               // d_parts[RES] holds the residual of the current x
     bool step_graph_failed = false;      // capture / instantiation failed once: this state record keeps to plain stream launches
     hipGraphExec_t step_graph = nullptr; // two consecutive steps (even, odd parity) captured for replay (sla_solver_step, launch-bound sizes)
+    int step_graph_gen = -1;             // ctx->opt_gen at capture time (flow-selecting knobs -- bicg_fuse45, vec_policy ... -- may change between calls)
     // sharded BiCGSTAB with ghost rows (sla_solvers.cpp): r, p, Ap and s are kept valid on the ghl / ghr rows this
     // rank's SpMV reads from its neighbours, so a step needs 3 grouped exchanges instead of 5
     bool ghost = false;
@@ -451,6 +453,7 @@ inline bool wd_on(const sla_csr *A) { return A->wd_vv ? (A->ctx->wdia && A->ctx-
 // bound to THAT context; violations are counted (sla_debug_binding_violations) and reported on stderr, =2 aborts.
 struct Bind {
     const sla_ctx *prev;
+    int prev_device;
     explicit Bind(const sla_ctx *c);
     ~Bind();
     Bind(const Bind &) = delete;
@@ -459,6 +462,7 @@ struct Bind {
 extern int g_debug_binding;                                   // SLA_DEBUG_BINDING, read once
 void binding_violation(const sla_ctx *c, const char *what);   // out of line: count, report, maybe abort
 const sla_ctx *bound_ctx();
+void unbind_destroyed(const sla_ctx *c);
 inline void check_bound(const sla_ctx *c, const char *what) {
     if (g_debug_binding && bound_ctx() != c) binding_violation(c, what);
 }
@@ -514,6 +518,11 @@ inline int no_throw(const char *what, F body) {
         int _rc = (expr);              \
         if (_rc != SLA_OK) return _rc; \
     } while (0)
+
+// sla_solve_opts / sla_solve_info carry the caller's struct size (include/sla_hip.h): read / write only what lies inside it
+int read_solve_opts(const sla_solve_opts *in, sla_solve_opts *out, const char *who);      // *out = defaults overlaid with the caller's members
+int info_begin(const sla_solve_info *user, sla_solve_info *local, const char *who);       // validates user->struct_size; *local = "nothing evaluated yet"
+void info_commit(sla_solve_info *user, const sla_solve_info &local);                      // copies the members the caller's struct has
 
 // profiling scope: brackets a launch with events when the context is recording that kernel id
 struct ProfScope {

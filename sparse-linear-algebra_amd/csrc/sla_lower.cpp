@@ -758,8 +758,11 @@ static void low_lds_panels(Low &L) {
 int csr_upload(sla_ctx *c, int64_t m, int64_t n, int64_t row_begin, int64_t rows, const int64_t *rowptr,
                const int64_t *col, const double *val, sla_csr **out, bool panel_view) {
     const int64_t nnz = rowptr[rows];
-    if (n > (int64_t)std::numeric_limits<int32_t>::max() || rows >= (int64_t)std::numeric_limits<int32_t>::max())
-        return fail(SLA_ERR_INVALID, "matrix dimension exceeds the 32-bit device index width");
+    if (n > (int64_t)std::numeric_limits<int32_t>::max() || rows >= (int64_t)std::numeric_limits<int32_t>::max()) {
+        // (rows differs per rank: a rank that fails here alone still owes its peers the agreement collective below)
+        const int rc = fail(SLA_ERR_INVALID, "matrix dimension exceeds the 32-bit device index width");
+        return panel_view ? rc : csr_reject(c, rc);
+    }
     static const bool dbg_lower = getenv("SLA_DEBUG_LOWER") != nullptr;
     auto t_last = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) {
@@ -780,21 +783,25 @@ int csr_upload(sla_ctx *c, int64_t m, int64_t n, int64_t row_begin, int64_t rows
     A->rp64 = nnz > (int64_t)std::numeric_limits<int32_t>::max() || c->force_rp64 == 1 || (c->force_rp64 == 2 && !panel_view);
     Low L{c, A, m, n, row_begin, rows, nnz, rowptr, col, val, panel_view, dbg_lower};
     hipError_t &err = L.err;
-    build_row_blocks(rows, rowptr, L.rb, A->max_row_nnz, c->row_align, c->rb_nnz);
-    A->nrb = (int32_t)L.rb.size() - 1;
-    int diag_not = host_is_diagonal(rows, row_begin, rowptr, col) ? 0 : 1;
-    if (m != n && rows > 0) { /* isDiagonalSM only counts (i,i) entries; nothing extra to do */ }
-    low_csr_arrays(L);
-    lap("row blocks + CSR upload");
-    low_xwin_statistics(L);
-    lap("x-window statistics");
-    low_diagonal_dictionary(L);
-    low_value_indexed(L);
-    lap("pair dictionary + wave slices");
-    low_wave_sliced_variable(L);
-    lap("variable-coefficient slices");
-    low_lds_panels(L);
-    lap("LDS panel table");
+    int diag_not = 1;
+    try {   // (a host allocation failing inside an analysis leaves through the agreement collective below like a device one)
+        build_row_blocks(rows, rowptr, L.rb, A->max_row_nnz, c->row_align, c->rb_nnz);
+        A->nrb = (int32_t)L.rb.size() - 1;
+        diag_not = host_is_diagonal(rows, row_begin, rowptr, col) ? 0 : 1;
+        low_csr_arrays(L);
+        lap("row blocks + CSR upload");
+        low_xwin_statistics(L);
+        lap("x-window statistics");
+        low_diagonal_dictionary(L);
+        low_value_indexed(L);
+        lap("pair dictionary + wave slices");
+        low_wave_sliced_variable(L);
+        lap("variable-coefficient slices");
+        low_lds_panels(L);
+        lap("LDS panel table");
+    } catch (const std::bad_alloc &) {
+        if (err == hipSuccess) err = hipErrorOutOfMemory;
+    }
     if (panel_view) {
         if (err != hipSuccess) {
             sla_csr_destroy(A);

@@ -302,29 +302,40 @@ int m_solver_destroy(sla_solver *S) {
 // ---- linSolve0 / GMRES / (<\>) / arnoldi -----------------------------------------------------------------------
 int m_linsolve0(int method, sla_csr *A, sla_vec *b, sla_vec *x0, const sla_solve_opts *o, sla_vec *xo, sla_solve_info *info) {
     SLA_NEED_BUNDLE(b && x0 && xo && A->kids.size() == b->kids.size() && same_shape(b, x0) && same_shape(b, xo) && A->ctx == b->ctx, "sla_linsolve0");
-    std::vector<sla_solve_info> infos(A->kids.size());
+    sla_solve_opts own, rest;   // rank 0 alone fills the caller's residual trace (the values are identical on every rank: one download, no race)
+    SLA_TRY(read_solve_opts(o, &own, "sla_linsolve0"));
+    sla_solve_info probe;
+    SLA_TRY(info_begin(info, &probe, "sla_linsolve0"));
+    rest = own;
+    rest.history = nullptr;
+    rest.history_cap = 0;
+    std::vector<sla_solve_info> infos(A->kids.size(), sla_solve_info SLA_SOLVE_INFO_INIT);
     const int rc = fanout(A->ctx, [&](int r) {
-        return sla_linsolve0(method, A->kids[(size_t)r], b->kids[(size_t)r], x0->kids[(size_t)r], o, xo->kids[(size_t)r], &infos[(size_t)r]);
+        return sla_linsolve0(method, A->kids[(size_t)r], b->kids[(size_t)r], x0->kids[(size_t)r], r == 0 ? &own : &rest, xo->kids[(size_t)r], &infos[(size_t)r]);
     });
-    if (info) *info = infos[0];   // (every rank takes the same decisions from the same rank-ordered sums)
+    info_commit(info, infos[0]);   // (every rank takes the same decisions from the same rank-ordered sums)
     return rc;
 }
 int m_gmres(sla_csr *A, sla_vec *b, sla_vec *x0, int restart, const sla_solve_opts *o, sla_vec *xo, sla_solve_info *info) {
     SLA_NEED_BUNDLE(b && x0 && xo && A->kids.size() == b->kids.size() && same_shape(b, x0) && same_shape(b, xo) && A->ctx == b->ctx, "sla_gmres");
-    std::vector<sla_solve_info> infos(A->kids.size());
+    sla_solve_info probe;
+    SLA_TRY(info_begin(info, &probe, "sla_gmres"));
+    std::vector<sla_solve_info> infos(A->kids.size(), sla_solve_info SLA_SOLVE_INFO_INIT);
     const int rc = fanout(A->ctx, [&](int r) {
         return sla_gmres(A->kids[(size_t)r], b->kids[(size_t)r], x0->kids[(size_t)r], restart, o, xo->kids[(size_t)r], &infos[(size_t)r]);
     });
-    if (info) *info = infos[0];
+    info_commit(info, infos[0]);
     return rc;
 }
 int m_linsolve(sla_csr *A, sla_vec *b, sla_vec *xo, sla_solve_info *info) {
     SLA_NEED_BUNDLE(b && xo && A->kids.size() == b->kids.size() && same_shape(b, xo) && A->ctx == b->ctx, "sla_linsolve");
-    std::vector<sla_solve_info> infos(A->kids.size());
+    sla_solve_info probe;
+    SLA_TRY(info_begin(info, &probe, "sla_linsolve"));
+    std::vector<sla_solve_info> infos(A->kids.size(), sla_solve_info SLA_SOLVE_INFO_INIT);
     const int rc = fanout(A->ctx, [&](int r) {
         return sla_linsolve(A->kids[(size_t)r], b->kids[(size_t)r], xo->kids[(size_t)r], &infos[(size_t)r]);
     });
-    if (info) *info = infos[0];
+    info_commit(info, infos[0]);
     return rc;
 }
 int m_arnoldi(sla_csr *A, sla_vec *b, int kn, double *Q, double *H, int *k_done) {

@@ -742,7 +742,12 @@ int sla_solver_step(sla_solver_t S, int k_steps) {
             SLA_TRY(enqueue_step(S, false, false));
             ++k;
         }
+        if (S->step_graph && S->step_graph_gen != c->opt_gen) {   // options changed since the capture: the stream launches below would run another flow
+            (void)hipGraphExecDestroy(S->step_graph);
+            S->step_graph = nullptr;
+        }
         if (!S->step_graph) {
+            S->step_graph_gen = c->opt_gen;
             // A failed capture or instantiation is not an error of the step: the graph is an optimisation.  Restore the step
             // bookkeeping exactly (enqueue_step may have advanced it by 0, 1 or 2), never try again on this state record and
             // fall through to the plain stream launches below.
@@ -895,17 +900,17 @@ int sla_cgs_step(sla_solver_t S, int k) {
 }
 
 int sla_linsolve0(int method, sla_csr_t A, sla_vec_t b, sla_vec_t x0, const sla_solve_opts *opts, sla_vec_t x_out,
-                  sla_solve_info *info) {
-    if (A && !A->kids.empty()) return m_linsolve0(method, A, b, x0, opts, x_out, info);
+                  sla_solve_info *user_info) {
+    if (A && !A->kids.empty()) return m_linsolve0(method, A, b, x0, opts, x_out, user_info);
     return no_throw("sla_linsolve0", [&]() -> int {
         if (!A || !b || !x0 || !x_out) return fail(SLA_ERR_INVALID, "sla_linsolve0: null argument");
-        sla_solve_opts o = {200, 1e-6, 1e-4, 16, 1, nullptr, 0};
-        if (opts) {
-            o = *opts;
-            if (o.max_iters <= 0) o.max_iters = 200;
-            if (o.check_every <= 0) o.check_every = 16;
-        }
-        if (info) { info->iters = 0; info->flags = 0; info->resnorm = NAN; info->r0norm = NAN; info->tol = NAN; info->history_len = 0; }
+        sla_solve_opts o;
+        SLA_TRY(read_solve_opts(opts, &o, "sla_linsolve0"));
+        if (o.max_iters <= 0) o.max_iters = 200;
+        if (o.check_every <= 0) o.check_every = 16;
+        sla_solve_info local, *info = &local;   // (committed to the caller's struct -- the members it has -- on every exit path)
+        SLA_TRY(info_begin(user_info, &local, "sla_linsolve0"));
+        struct Commit { sla_solve_info *u; const sla_solve_info &l; ~Commit() { info_commit(u, l); } } commit{user_info, local};
         const int hist_cap = (o.history && o.history_cap > 0 && o.true_residual) ? std::min(o.history_cap, o.max_iters) : 0;
         // | m /= nb = throwM (MatVecSizeMismatchException "linSolve0" dm nb)      (Sparse.hs:1022)
         if (A->m != b->n) return fail(SLA_ERR_DIM_MISMATCH, "linSolve0 : matrix rows and rhs dimension differ");
@@ -989,13 +994,16 @@ int sla_arnoldi(sla_csr_t A, sla_vec_t b, int kn, double *Q_colmajor, double *H_
 }
 
 int sla_gmres(sla_csr_t A, sla_vec_t b, sla_vec_t x0, int restart, const sla_solve_opts *opts, sla_vec_t x_out,
-              sla_solve_info *info) {
-    if (A && !A->kids.empty()) return m_gmres(A, b, x0, restart, opts, x_out, info);
+              sla_solve_info *user_info) {
+    if (A && !A->kids.empty()) return m_gmres(A, b, x0, restart, opts, x_out, user_info);
     return no_throw("sla_gmres", [&]() -> int {
         if (!A || !b || !x0 || !x_out) return fail(SLA_ERR_INVALID, "sla_gmres: null argument");
-        sla_solve_opts o = {200, 1e-6, 1e-4, 16, 1, nullptr, 0};
-        if (opts) { o = *opts; if (o.max_iters <= 0) o.max_iters = 200; }
-        if (info) { info->iters = 0; info->flags = 0; info->resnorm = NAN; info->r0norm = NAN; info->tol = NAN; info->history_len = 0; }
+        sla_solve_opts o;
+        SLA_TRY(read_solve_opts(opts, &o, "sla_gmres"));
+        if (o.max_iters <= 0) o.max_iters = 200;
+        sla_solve_info local, *info = &local;
+        SLA_TRY(info_begin(user_info, &local, "sla_gmres"));
+        struct Commit { sla_solve_info *u; const sla_solve_info &l; ~Commit() { info_commit(u, l); } } commit{user_info, local};
         if (A->m != b->n) return fail(SLA_ERR_DIM_MISMATCH, "gmres : matrix rows and rhs dimension differ");
         if (A->m != A->n || A->n != x0->n || x_out->n != A->n) return fail(SLA_ERR_DIM_MISMATCH, "gmres : mismatched dimensions");
         if (restart < 1) return fail(SLA_ERR_INVALID, "sla_gmres: restart must be >= 1");

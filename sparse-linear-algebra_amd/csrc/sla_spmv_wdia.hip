@@ -147,28 +147,30 @@ __global__ void __launch_bounds__(kBlock, VV ? (EPI == EPI_DOT4 ? kWdBlocksPerCu
     auto fold8 = [&](unsigned long long rme, unsigned long long rmo, double rv, int nrec, const wd_f64x2 *xv, const wd_f64x2 *vv,
                      double &ya, double &yb) {
 #pragma clang fp contract(off)  // a*x then +: two roundings like the reference, never an FMA
+        const unsigned long long ex0 = __builtin_amdgcn_read_exec();   // EXEC is put back to its value on entry (not to -1: were a
+                                                                       // compiler-predicated region ever to enclose this, its dead lanes stay dead)
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             if (k >= nrec) break;  // wave-uniform
             const unsigned long long me = wd_lane_u64(rme, k), mo = wd_lane_u64(rmo, k);
             // EXEC = the even rows that hold the entry, then the odd rows; v_mul_f64 then v_add_f64 (two
-            // roundings).  All 64 lanes are active here (wave-uniform control flow only): EXEC goes back to -1.
+            // roundings).  All 64 lanes are active here (wave-uniform control flow only): EXEC goes back to its entry value.
             double p;
             if constexpr (VV) {
                 asm volatile(
                     "s_mov_b64 exec, %[me]\n\tv_mul_f64 %[p], %[va], %[xa]\n\tv_add_f64 %[ya], %[ya], %[p]\n\t"
                     "s_mov_b64 exec, %[mo]\n\tv_mul_f64 %[p], %[vb], %[xb]\n\tv_add_f64 %[yb], %[yb], %[p]\n\t"
-                    "s_mov_b64 exec, -1"
+                    "s_mov_b64 exec, %[ex]"
                     : [ya] "+v"(ya), [yb] "+v"(yb), [p] "=&v"(p)
-                    : [me] "s"(me), [mo] "s"(mo), [va] "v"(vv[k].x), [vb] "v"(vv[k].y), [xa] "v"(xv[k].x), [xb] "v"(xv[k].y));
+                    : [ex] "s"(ex0), [me] "s"(me), [mo] "s"(mo), [va] "v"(vv[k].x), [vb] "v"(vv[k].y), [xa] "v"(xv[k].x), [xb] "v"(xv[k].y));
             } else {
                 const double vk = wd_lane_f64(rv, k);
                 asm volatile(
                     "s_mov_b64 exec, %[me]\n\tv_mul_f64 %[p], %[v], %[xa]\n\tv_add_f64 %[ya], %[ya], %[p]\n\t"
                     "s_mov_b64 exec, %[mo]\n\tv_mul_f64 %[p], %[v], %[xb]\n\tv_add_f64 %[yb], %[yb], %[p]\n\t"
-                    "s_mov_b64 exec, -1"
+                    "s_mov_b64 exec, %[ex]"
                     : [ya] "+v"(ya), [yb] "+v"(yb), [p] "=&v"(p)
-                    : [me] "s"(me), [mo] "s"(mo), [v] "s"(vk), [xa] "v"(xv[k].x), [xb] "v"(xv[k].y));
+                    : [ex] "s"(ex0), [me] "s"(me), [mo] "s"(mo), [v] "s"(vk), [xa] "v"(xv[k].x), [xb] "v"(xv[k].y));
             }
         }
     };

@@ -140,17 +140,18 @@ __global__ void __launch_bounds__(kBlock, NW <= 4 ? 4 : 3) spmv_wdia_lds_kernel(
             wd_f64x2 xv[NP];
 #pragma unroll
             for (int k = 0; k < NP; ++k) xv[k] = *(const wd_f64x2u *)(lb + laddr[k]);
+            const unsigned long long ex0 = __builtin_amdgcn_read_exec();   // (restored after every record: the value on entry, not -1)
 #pragma unroll
             for (int k = 0; k < NP; ++k) {
                 // EXEC = the even rows that hold the entry, then the odd rows; v_mul_f64 then v_add_f64 (two roundings).
-                // All 64 lanes are active here (wave-uniform control flow only): EXEC goes back to -1.
+                // All 64 lanes are active here (wave-uniform control flow only): EXEC goes back to its entry value.
                 double pr;
                 asm volatile(
                     "s_mov_b64 exec, %[me]\n\tv_mul_f64 %[p], %[v], %[xa]\n\tv_add_f64 %[ya], %[ya], %[p]\n\t"
                     "s_mov_b64 exec, %[mo]\n\tv_mul_f64 %[p], %[v], %[xb]\n\tv_add_f64 %[yb], %[yb], %[p]\n\t"
-                    "s_mov_b64 exec, -1"
+                    "s_mov_b64 exec, %[ex]"
                     : [ya] "+v"(ya), [yb] "+v"(yb), [p] "=&v"(pr)
-                    : [me] "s"(me[k]), [mo] "s"(mo[k]), [v] "v"(pval[k]), [xa] "v"(xv[k].x), [xb] "v"(xv[k].y));
+                    : [ex] "s"(ex0), [me] "s"(me[k]), [mo] "s"(mo[k]), [v] "v"(pval[k]), [xa] "v"(xv[k].x), [xb] "v"(xv[k].y));
             }
         }
         auto epilogue = [&]() {

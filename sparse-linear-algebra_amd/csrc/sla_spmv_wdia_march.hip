@@ -153,15 +153,16 @@ __global__ void __launch_bounds__(kBlock, 3) spmv_wdia_march_kernel(SpmvArgs<int
 #pragma unroll
                     for (int k = 1; k < NP - 1; ++k) xv[k] = *(const wd_f64x2u *)(lb + u * kMarchBufBytes + laddr[k]);
                     xv[NP - 1] = *(const wd_f64x2u *)(lb + ((u + 1) & 3) * kMarchBufBytes + laddr[NP - 1]);
+                    const unsigned long long ex0 = __builtin_amdgcn_read_exec();   // (restored after every record: the value on entry, not -1)
 #pragma unroll
                     for (int k = 0; k < NP; ++k) {
                         double pr;
                         asm volatile(
                             "s_mov_b64 exec, %[me]\n\tv_mul_f64 %[p], %[v], %[xa]\n\tv_add_f64 %[ya], %[ya], %[p]\n\t"
                             "s_mov_b64 exec, %[mo]\n\tv_mul_f64 %[p], %[v], %[xb]\n\tv_add_f64 %[yb], %[yb], %[p]\n\t"
-                            "s_mov_b64 exec, -1"
+                            "s_mov_b64 exec, %[ex]"
                             : [ya] "+v"(ya), [yb] "+v"(yb), [p] "=&v"(pr)
-                            : [me] "s"(me[k]), [mo] "s"(mo[k]), [v] "v"(pval[k]), [xa] "v"(xv[k].x), [xb] "v"(xv[k].y));
+                            : [ex] "s"(ex0), [me] "s"(me[k]), [mo] "s"(mo[k]), [v] "v"(pval[k]), [xa] "v"(xv[k].x), [xb] "v"(xv[k].y));
                     }
                     if constexpr (WX) wv = *(const wd_f64x2u *)(lb + u * kMarchBufBytes + laddr0);
                 }

@@ -46,13 +46,20 @@ class IndexOutOfBounds(SlaError):
 
 
 class SolveOpts(C.Structure):
-    _fields_ = [("max_iters", C.c_int32), ("tol_abs", C.c_double), ("tol_rel", C.c_double),
+    """sla_solve_opts.  struct_size (ABI versioning, include/sla_hip.h) is filled in here: positional arguments start at max_iters."""
+    _fields_ = [("struct_size", C.c_int32), ("max_iters", C.c_int32), ("tol_abs", C.c_double), ("tol_rel", C.c_double),
                 ("check_every", C.c_int32), ("true_residual", C.c_int32), ("history", C.c_void_p), ("history_cap", C.c_int32)]
+
+    def __init__(self, max_iters=200, tol_abs=1e-6, tol_rel=1e-4, check_every=16, true_residual=1, history=None, history_cap=0):
+        super().__init__(C.sizeof(SolveOpts), max_iters, tol_abs, tol_rel, check_every, true_residual, history, history_cap)
 
 
 class SolveInfo(C.Structure):
-    _fields_ = [("iters", C.c_int32), ("flags", C.c_int32), ("resnorm", C.c_double),
+    _fields_ = [("struct_size", C.c_int32), ("iters", C.c_int32), ("flags", C.c_int32), ("resnorm", C.c_double),
                 ("r0norm", C.c_double), ("tol", C.c_double), ("history_len", C.c_int32)]
+
+    def __init__(self):
+        super().__init__(C.sizeof(SolveInfo))
 
     def as_dict(self):
         return {"iters": self.iters, "flags": self.flags, "resnorm": self.resnorm,
@@ -80,6 +87,7 @@ PROTOTYPES = [
     ("sla_ctx_row_range", _int, [_vp, _i64, _pi64, _pi64]),
     ("sla_last_error", C.c_char_p, []),
     ("sla_version", C.c_char_p, []),
+    ("sla_abi_version", _int, []),
     ("sla_csr_from_coo", _int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _int, _pp]),
     ("sla_csr_from_csr", _int, [_vp, _i64, _i64, _vp, _vp, _vp, _pp]),
     ("sla_csr_from_csr_rows", _int, [_vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _pp]),

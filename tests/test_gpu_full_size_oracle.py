@@ -82,7 +82,8 @@ def test_config4_laplace3d_10m_bit_exact_vs_oracle(sla):
     from sla_amd import workloads as wl
     dims, (rp, ci, va) = wl.laplace3d(216, 216, 216)
     assert dims[0] == 10077696
-    _check(sla, dims, rp, ci, va, "wdia", True, "ones", "config4")
+    # the plane-march lowering is what the headline times: a silent fall-back to another wave-sliced variant must fail here
+    _check(sla, dims, rp, ci, va, "wdia+march", True, "ones", "config4")
 
 
 def test_config4_laplace3d_10m_reference_split_flow_vs_oracle(sla):
@@ -91,7 +92,7 @@ def test_config4_laplace3d_10m_reference_split_flow_vs_oracle(sla):
     from sla_amd import workloads as wl
     ctx = sla.Context(0).set_option("bicg_fuse45", 0)
     dims, (rp, ci, va) = wl.laplace3d(216, 216, 216)
-    _check(sla, dims, rp, ci, va, "wdia", True, "ones", "config4 split", ctx)
+    _check(sla, dims, rp, ci, va, "wdia+march", True, "ones", "config4 split", ctx)
     ctx.close()
 
 
