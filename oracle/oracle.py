@@ -177,11 +177,12 @@ class BicgstabState:
         v = A.view()
         lib().orc_bicgstab_init(C.byref(v), _p(_f64(b)), _p(_f64(x0)), _p(self.x), _p(self.r), _p(self.p))
 
-    def step(self, r0hat, k=1):
+    def step(self, r0hat, k=1, rho_identity=False):
+        """rho_identity=True: beta's numerator as (s . r0hat) - omega (aas . r0hat), the product's fused-sweep formula (NOT the reference's)."""
         v = self.A.view()
         r0hat = _f64(r0hat)
         for _ in range(k):
-            lib().orc_bicgstab_step(C.byref(v), _p(r0hat), _p(self.x), _p(self.r), _p(self.p))
+            lib().orc_bicgstab_step_ex(C.byref(v), _p(r0hat), _p(self.x), _p(self.r), _p(self.p), C.c_int(1 if rho_identity else 0))
         return self
 
 

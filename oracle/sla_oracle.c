@@ -259,6 +259,13 @@ void orc_bicgstab_init(const orc_csr *A, const double *b, const double *x0, doub
 
 /* bicgstabStep (Sparse.hs:972-981) */
 int orc_bicgstab_step(const orc_csr *A, const double *r0hat, double *x, double *r, double *p) {
+    return orc_bicgstab_step_ex(A, r0hat, x, r, p, 0);
+}
+
+/* rho_identity = 0: the reference's step, term by term.  rho_identity = 1 is NOT a reference formula: the numerator of beta
+ * is evaluated as (s . r0hat) - omega (aas . r0hat) -- what the product's fused K4+K5 sweep does --
+ * with the same left-fold sums.  The tests run both to measure where the two formulas part on a given system. */
+int orc_bicgstab_step_ex(const orc_csr *A, const double *r0hat, double *x, double *r, double *p, int rho_identity) {
     int64_t n = A->m;
     double *aap = tnew(n), *s = tnew(n), *aas = tnew(n), *t = tnew(n), *t2 = tnew(n);
     if (!aap || !s || !aas || !t || !t2) return ORC_ERR_ALLOC;
@@ -276,7 +283,8 @@ int orc_bicgstab_step(const orc_csr *A, const double *r0hat, double *x, double *
     double *rnew = t2;
     orc_scale(n, omega, aas, t);
     orc_sub(n, s, t, rnew);                                         /* rj1 = sj ^-^ omega.*aas*/
-    double beta = orc_dot(n, rnew, r0hat) / rr0 * alpha / omega;    /* ((a/b)*alpha)/omega    */
+    double rho1 = rho_identity ? orc_dot(n, s, r0hat) - omega * orc_dot(n, aas, r0hat) : orc_dot(n, rnew, r0hat);
+    double beta = rho1 / rr0 * alpha / omega;                       /* ((a/b)*alpha)/omega    */
     orc_scale(n, omega, aap, t);
     orc_sub(n, p, t, t);                                            /* p ^-^ omega.*aap       */
     orc_scale(n, beta, t, t);

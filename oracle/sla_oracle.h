@@ -74,6 +74,8 @@ typedef struct {
 void orc_bicgstab_init(const orc_csr *A, const double *b, const double *x0, double *x, double *r,
                        double *p);
 int orc_bicgstab_step(const orc_csr *A, const double *r0hat, double *x, double *r, double *p);
+/* rho_identity = 1: beta's numerator through (s . r0hat) - omega (aas . r0hat) -- the PRODUCT's default formula, not the reference's */
+int orc_bicgstab_step_ex(const orc_csr *A, const double *r0hat, double *x, double *r, double *p, int rho_identity);
 /* A6: cgsInit / cgsStep, Sparse.hs:921-939 */
 void orc_cgs_init(const orc_csr *A, const double *b, const double *x0, double *x, double *r,
                   double *p, double *u);

@@ -87,3 +87,60 @@ def dense_of(A):
         for k in range(A.rowptr[i], A.rowptr[i + 1]):
             D[i, A.colidx[k]] = A.val[k]
     return D
+
+
+def denjoh_beam(nel=500, length=100.0, inertia=400000000.0, emod=210000.0, spring=2000.0):
+    """The user system of issues/issue_denjoh.hs:60-71 re-created as a generator (no values copied: the element formulas of :7-23
+    evaluated here): `nel` Euler-Bernoulli beam elements of equal length / inertia, 2 degrees of freedom per node (deflection,
+    rotation), assembled the way `createStiffnessMatrix` does -- every (row, col) appears ONCE in the triple list, the shared
+    2 x 2 node blocks as `k (a+2) (b+2) + k a b` (so their off-diagonal entries are explicit 0.0 entries, kept by fromListSM) --
+    then `insertSprings` adds `spring` to the diagonal entries 200, 400 .. 1000 (the supports), and the solved system is the
+    submatrix of rows / columns 2 .. 2 nel + 1 shifted by -2 (the clamped first node removed) with the right-hand side
+    `dropSV 2 fVec`: 5000 at the last deflection, 8.19e8 at the last rotation.  Entries are ~1e9 .. 7e12: the ill-conditioned case.
+    Returns (dims, rows, cols, vals, b) of the 2 nel x 2 nel system; triples in assembly order (order is irrelevant: no duplicates).
+    Operation order of every entry follows the Haskell expression (`12 * eMod * i / (l ** 3)` = ((12 * eMod) * i) / pow l 3)."""
+    E, i, l = float(emod), float(inertia), float(length)
+    k00 = 12.0 * E * i / (l ** 3)
+    k01 = 6.0 * E * i / (l ** 2)
+    k11 = 4.0 * E * i / l
+    k13 = 2.0 * E * i / l
+    ke = [[k00, k01, -k00, k01],
+          [k01, k11, -k01, k13],
+          [-k00, -k01, k00, -k01],
+          [k01, k13, -k01, k11]]
+    ndof = 2 * nel + 2
+    ent = {}
+
+    def put(r, c, v):
+        assert (r, c) not in ent        # createStiffnessMatrix never emits a position twice
+        ent[(r, c)] = v
+
+    for a in range(4):                  # first element: everything but its lower-right node block
+        for b_ in range(4):
+            if not (a > 1 and b_ > 1):
+                put(a, b_, ke[a][b_])
+    for e in range(1, nel):             # elements 1 .. nel-1 at rn = 2 e
+        rn = 2 * e
+        for a in range(2):
+            for b_ in range(2):
+                put(rn + a, rn + b_, ke[a + 2][b_ + 2] + ke[a][b_])
+        last = e == nel - 1
+        for a in range(4):
+            for b_ in range(4):
+                if a < 2 and b_ < 2:
+                    continue
+                if a > 1 and b_ > 1 and not last:
+                    continue
+                put(rn + a, rn + b_, ke[a][b_])
+    for x in range(200, 1001, 200):     # insertSprings: k @@! (x, x) + 2000
+        if (x, x) in ent:
+            ent[(x, x)] = ent[(x, x)] + spring
+    rows, cols, vals = [], [], []
+    for (r, c), v in ent.items():       # extractSubmatrixSM (subtract 2) (subtract 2) knew (2, ndof - 1) (2, ndof - 1)
+        if r >= 2 and c >= 2:
+            rows.append(r - 2); cols.append(c - 2); vals.append(v)
+    n = ndof - 2
+    b = np.zeros(n)
+    b[n - 2] = 5000.0
+    b[n - 1] = 819000000.0
+    return (n, n), np.array(rows, dtype=np.int64), np.array(cols, dtype=np.int64), np.array(vals, dtype=np.float64), b

@@ -130,3 +130,25 @@ def test_config3b_dense_rows_200k_vs_oracle(sla):
     dims, (rp, ci, va) = wl.random_spd(200000, 1000, 42)
     assert dims[0] == 200000 and 1990 <= rp[-1] / dims[0] <= 2001      # 1 % density honoured
     _check(sla, dims, rp, ci, va, "ldspanels", False, "xstar", "config3b")
+
+
+def test_config5_arnoldi_2m_kn30_vs_oracle(sla):
+    """`arnoldi aa b 30` (Sparse.hs:630-667) on config 5's matrix at FULL size (2 M rows, the basis GMRES(30) builds) against the
+    oracle's classical Gram-Schmidt with left-fold sums: H to 1e-10 max|H|, every basis vector entry to 1e-9.  (The device sums in a
+    fixed two-stage tree: 30 steps of un-reorthogonalised Gram-Schmidt on this well-conditioned operator amplify that to ~1e-13.)"""
+    from sla_amd import workloads as wl
+    n, kn = 2000000, 30
+    dims, (rp, ci, va) = wl.banded_nonsym(n)
+    A, Ao = sla.fromCSR(dims, rp, ci, va), orc.Csr(n, n, rp, ci, va)
+    assert "wdia-vv" in A.kernel_info(), A.kernel_info()
+    b = np.add.reduceat(va, rp[:-1])                    # b = A . 1, the right-hand side of config 5
+    Q, H = sla.arnoldi(A, sla.fromVector(b), kn)
+    rc, Qo, Ho, k = orc.arnoldi(Ao, b, kn)
+    assert rc == orc.OK and k == kn and H.shape == Ho.shape == (kn + 1, kn) and Q.shape == Qo.shape == (n, kn + 1)
+    assert np.abs(H - Ho).max() <= 1e-10 * np.abs(Ho).max(), np.abs(H - Ho).max() / np.abs(Ho).max()
+    assert np.abs(Q - Qo).max() <= 1e-9, np.abs(Q - Qo).max()
+    del Qo
+    G = Q.T @ Q
+    assert np.abs(G - np.eye(kn + 1)).max() <= 1e-9
+    del A, Q
+    gc.collect()

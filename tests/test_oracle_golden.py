@@ -412,3 +412,36 @@ def test_gmres_least_squares_step_minimises_the_residual():
     rc, Q, H, k = orc.arnoldi(A, b, 12)
     y = np.linalg.lstsq(H, np.linalg.norm(b) * np.eye(k + 1)[:, 0], rcond=None)[0]
     assert iters == k and np.linalg.norm(x - Q[:, :k] @ y) <= 1e-10 * np.linalg.norm(x)
+
+
+def test_denjoh_beam_generator_and_the_oracle_on_it():
+    """issues/issue_denjoh.hs:60-71 re-created (tests/refdata.py: denjoh_beam): structure of the assembled system and what the oracle's
+    linSolve0 does on it -- the ill-conditioned user case the GPU hard-regime tests run (tests/test_gpu_hard_regime.py)."""
+    from refdata import denjoh_beam
+    dims, r, c, v, b = denjoh_beam()
+    assert dims == (1000, 1000) and len(v) == 5992 and len(set(zip(r.tolist(), c.tolist()))) == 5992    # every position once
+    assert int((v == 0.0).sum()) == 998                          # the k23 + k01 entries of the shared node blocks: explicit zeros, kept by fromListSM
+    D = np.zeros(dims)
+    D[r, c] = v
+    assert np.array_equal(D, D.T)
+    EI = 210000.0 * 400000000.0
+    assert D[0, 0] == 2 * 12 * EI / 100.0 ** 3 and D[1, 1] == 2 * 4 * EI / 100.0 and D[0, 2] == -12 * EI / 100.0 ** 3 and D[1, 3] == 2 * EI / 100.0
+    assert D[198, 198] == D[0, 0] + 2000.0 and D[998, 998] == 12 * EI / 100.0 ** 3 + 2000.0 and D[999, 999] == 4 * EI / 100.0
+    assert b[998] == 5000.0 and b[999] == 819000000.0 and np.count_nonzero(b) == 2
+    assert 1e11 < np.linalg.cond(D) < 1e12
+    rc, Ao = orc.coo_to_csr(1000, 1000, r, c, v)
+    assert rc == orc.OK
+    # from x0 = 0.1 * ones the reference's relative tolerance (1e-4 ||r0||, ||r0|| = 2.25e13) is met after 4 steps by both methods
+    for m in (orc.BICGSTAB_, orc.CGS_):
+        rc, x, it, res, r0 = orc.linsolve0(m, Ao, b, np.full(1000, 0.1))
+        assert rc == orc.OK and it == 4 and res <= 1e-4 * r0
+    # from x0 = 0 neither converges in 200 iterations (silent, Sparse.hs:1045)
+    rc, x, it, res, r0 = orc.linsolve0(orc.BICGSTAB_, Ao, b, np.zeros(1000))
+    assert it == 200 and res > 1e-4 * r0
+    # the product's rho identity restated in the oracle (NOT a reference formula): same trace to 1e-9 over the first 15 steps here
+    s0, s1 = orc.BicgstabState(Ao, b, np.zeros(1000)), orc.BicgstabState(Ao, b, np.zeros(1000))
+    for j in range(15):
+        s0.step(b, 1)
+        s1.step(b, 1, rho_identity=True)
+        n0, n1 = np.linalg.norm(orc.spmv(Ao, s0.x) - b), np.linalg.norm(orc.spmv(Ao, s1.x) - b)
+        assert abs(n0 - n1) <= 1e-9 * n0
