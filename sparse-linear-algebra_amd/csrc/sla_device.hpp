@@ -231,6 +231,14 @@ __device__ __forceinline__ RbWalk rb_walk(int nrb, int xcd_remap, int G) {
 __device__ __forceinline__ RbWalk rb_walk(int nrb, int xcd_remap) { return rb_walk(nrb, xcd_remap, (int)gridDim.x); }
 
 typedef double wd_f64x2u __attribute__((ext_vector_type(2), aligned(8)));  // a row pair of x at any 8-byte boundary
+// EXEC on entry of an EXEC-masked asm fold, as an opaque value: the folds put EXEC back to it after every record.  Deliberately NOT
+// __builtin_amdgcn_read_exec(): that is a plain copy of the physical register, which the compiler forwards into the "s" operand of
+// the restoring s_mov_b64 -- "s_mov_b64 exec, exec", i.e. EXEC stays at the last record's odd-row mask (round 4: every row wrong).
+__device__ __forceinline__ unsigned long long wd_save_exec() {
+    unsigned long long e;
+    asm volatile("s_mov_b64 %0, exec" : "=s"(e));
+    return e;
+}
 typedef double wd_f64x2 __attribute__((ext_vector_type(2)));
 
 // the fused epilogue of a row pair (row, row + 1; vb: the second row exists) of the wave-sliced kernels

@@ -147,7 +147,7 @@ __global__ void __launch_bounds__(kBlock, VV ? (EPI == EPI_DOT4 ? kWdBlocksPerCu
     auto fold8 = [&](unsigned long long rme, unsigned long long rmo, double rv, int nrec, const wd_f64x2 *xv, const wd_f64x2 *vv,
                      double &ya, double &yb) {
 #pragma clang fp contract(off)  // a*x then +: two roundings like the reference, never an FMA
-        const unsigned long long ex0 = __builtin_amdgcn_read_exec();   // EXEC is put back to its value on entry (not to -1: were a
+        const unsigned long long ex0 = wd_save_exec();   // EXEC is put back to its value on entry (not to -1: were a
                                                                        // compiler-predicated region ever to enclose this, its dead lanes stay dead)
 #pragma unroll
         for (int k = 0; k < 8; ++k) {

@@ -140,7 +140,7 @@ __global__ void __launch_bounds__(kBlock, NW <= 4 ? 4 : 3) spmv_wdia_lds_kernel(
             wd_f64x2 xv[NP];
 #pragma unroll
             for (int k = 0; k < NP; ++k) xv[k] = *(const wd_f64x2u *)(lb + laddr[k]);
-            const unsigned long long ex0 = __builtin_amdgcn_read_exec();   // (restored after every record: the value on entry, not -1)
+            const unsigned long long ex0 = wd_save_exec();   // (restored after every record: the value on entry, not -1)
 #pragma unroll
             for (int k = 0; k < NP; ++k) {
                 // EXEC = the even rows that hold the entry, then the odd rows; v_mul_f64 then v_add_f64 (two roundings).

@@ -153,7 +153,7 @@ __global__ void __launch_bounds__(kBlock, 3) spmv_wdia_march_kernel(SpmvArgs<int
 #pragma unroll
                     for (int k = 1; k < NP - 1; ++k) xv[k] = *(const wd_f64x2u *)(lb + u * kMarchBufBytes + laddr[k]);
                     xv[NP - 1] = *(const wd_f64x2u *)(lb + ((u + 1) & 3) * kMarchBufBytes + laddr[NP - 1]);
-                    const unsigned long long ex0 = __builtin_amdgcn_read_exec();   // (restored after every record: the value on entry, not -1)
+                    const unsigned long long ex0 = wd_save_exec();   // (restored after every record: the value on entry, not -1)
 #pragma unroll
                     for (int k = 0; k < NP; ++k) {
                         double pr;
