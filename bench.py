@@ -349,6 +349,14 @@ def sharded_random_block(ctx, name, rank, world, sync_all, allreduce, steps, war
            "k1_ms": k1.get("ms"), "k1_frac": k1.get("frac"), "k1_csr_frac": k1.get("effective_frac"),
            "kernels_rank0": {k_: {"ms": v["ms"], "frac": v["frac"]} for k_, v in kt.items()},
            "exchanges_rank0": ex, "spmv_kernel": A.kernel_info(), "slab_assembly_s": t_gen}
+    kinfo = A.kernel_info()
+    if "allgather=" in kinfo:   # the x all-gather goes out as grouped send/recv launches on the comm stream, the tile launch as panel passes behind them
+        tok = dict(t.split("=") for t in kinfo.split() if "=" in t)
+        rec["x_exchange"] = {"mode": "overlapped", "order": tok.get("allgather"), "groups": int(tok.get("groups", 0)), "passes": int(tok.get("passes", "0").split("(")[0]),
+                             "note": "grouped ncclSend/ncclRecv exchanges on a second stream, one event per group; the tile launch runs as column-panel passes, "
+                                     "each waiting only for the groups its panels need (own panels first); K1 / K3 times above include any exposed wait"}
+    else:
+        rec["x_exchange"] = {"mode": "serial", "note": "ncclAllGather of x, then one launch"}
     del st, A, bvec, xstar
     return rec
 

@@ -333,6 +333,21 @@ int sla_csr_kernel_info(sla_csr_t, char *buf, int buflen);
  * exchange replaces the plain all-gather.  This is the plan sla_csr_from_* derives internally. */
 int sla_plan_window_exchange(int nranks, int rank, int64_t n, const int64_t *windows, int64_t *send_begin,
                              int64_t *send_len, int64_t *recv_begin, int64_t *recv_len, int *use_window);
+/* Pure host planning of the OVERLAPPED ALL-GATHER of x for all-gather-mode matrices on the tile form (BASELINE config 3a sharded;
+ * DESIGN.md section 6): what rank `rank` of `nranks` does for a matrix of n columns cut into panels of 2^shift columns when the
+ * gather goes out as grouped point-to-point exchanges and the tile launch runs as panel passes behind them.
+ *   order 0 ("arrival", option ag_order = 0): `groups` column chunks of every shard per exchange group; panels visited own-first,
+ *            then by the group that completes them -- a row is ONE left fold over the panels in that order (ascending columns
+ *            inside a panel): not the reference's ascending order (Common.hs:247-260) but a fixed, documented permutation of it;
+ *   order 1 ("ascending", ag_order = 1): one group per source rank in rank order, panels ascending: the reference's fold bit for bit.
+ * Outputs: visit[P] (P = ceil(n / 2^shift)) the panel visiting order; pass_ptr[npass + 1] / pass_need[npass] (arrays of P + 1 / P
+ * entries suffice): pass p walks visit[pass_ptr[p] .. pass_ptr[p+1]) once pass_need[p] exchange groups have completed; *ngroups. */
+int sla_plan_allgather_passes(int nranks, int rank, int64_t n, int shift, int groups, int order, int32_t *visit, int32_t *pass_ptr,
+                              int32_t *pass_need, int32_t *npass, int32_t *ngroups);
+/* ... and the exchange groups of that plan (the same on every rank): quadruples (group, source rank, first column, end column), in
+ * the order every rank posts them; group g is ONE ncclGroupStart/End launch in which each source sends its pieces to every peer.
+ * pieces = cap x 4 int64; *count = quadruples written (SLA_ERR_INVALID if cap is too small). */
+int sla_plan_allgather_groups(int nranks, int64_t n, int shift, int groups, int order, int64_t *pieces, int cap, int *count);
 
 #ifdef __cplusplus
 }

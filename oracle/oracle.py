@@ -155,6 +155,19 @@ def spmv(A, x):
     return y
 
 
+def spmv_panel_order(A, x, shift, visit):
+    """y = A x with every row folded over the column panels of 2^shift columns in the order `visit` (a permutation of the panel ids),
+    ascending columns inside a panel: the fold of the product's overlapped all-gather (NOT the reference's unless visit is ascending)."""
+    x = _f64(x)
+    visit = np.ascontiguousarray(visit, dtype=np.int32)
+    pos = np.empty(len(visit), dtype=np.int32)
+    pos[visit] = np.arange(len(visit), dtype=np.int32)
+    y = np.zeros(A.m, dtype=np.float64)
+    lib().orc_spmv_panel_order(C.c_int64(A.m), _p(A.rowptr), _p(A.colidx), _p(A.val), _p(x), _p(y), C.c_int(shift), C.c_int64(len(pos)),
+                               C.c_void_p(pos.ctypes.data))
+    return y
+
+
 def dot(x, y):
     x, y = _f64(x), _f64(y)
     return lib().orc_dot(C.c_int64(len(x)), _p(x), _p(y))

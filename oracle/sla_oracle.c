@@ -138,6 +138,35 @@ void orc_spmv(int64_t m, const int64_t *rowptr, const int64_t *colidx, const dou
     }
 }
 
+/* NOT the reference's order: y = A x with every row folded over column PANELS of 2^shift columns in a given visiting order
+ * (pos[j] = position of panel j in the walk), ascending columns inside a panel, separately rounded multiply and add from 0.0.
+ * This restates what the product's overlapped all-gather does on a sharded tile-form matrix in "arrival" order (DESIGN.md section
+ * 6: own panels first, then by exchange group), so that its rows can be checked bit for bit; with pos = identity it is orc_spmv. */
+void orc_spmv_panel_order(int64_t m, const int64_t *rowptr, const int64_t *colidx, const double *val, const double *x, double *y,
+                          int shift, int64_t npanels, const int32_t *pos) {
+    for (int64_t i = 0; i < m; ++i) {
+        /* the row's (panel) segments are contiguous (columns ascend): visit them by ascending pos -- repeated minimum search, rows are short */
+        double acc = 0.0;
+        int64_t done_pos = -1;
+        for (;;) {
+            int64_t best = -1, best_pos = npanels;            /* next segment in the walk */
+            for (int64_t k = rowptr[i]; k < rowptr[i + 1];) {
+                const int64_t j = colidx[k] >> shift;
+                if ((int64_t)pos[j] > done_pos && (int64_t)pos[j] < best_pos) { best = k; best_pos = pos[j]; }
+                while (k < rowptr[i + 1] && (colidx[k] >> shift) == j) ++k;
+            }
+            if (best < 0) break;
+            const int64_t j = colidx[best] >> shift;
+            for (int64_t k = best; k < rowptr[i + 1] && (colidx[k] >> shift) == j; ++k) {
+                double prod = val[k] * x[colidx[k]];
+                acc = acc + prod;
+            }
+            done_pos = best_pos;
+        }
+        y[i] = acc;
+    }
+}
+
 /* v <.> w = sum (liftI2 (<.>) v w)  (SpVector.hs:116-117; Double: (<.>) = (*), Class.hs:400) */
 double orc_dot(int64_t n, const double *x, const double *y) {
     double acc = 0.0;

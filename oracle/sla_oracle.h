@@ -53,6 +53,10 @@ void orc_par_copy_csr(int64_t m, const int64_t *rowptr, const int64_t *colidx, c
 void orc_par_copy_f64(int64_t n, const double *src, double *dst);
 void orc_spmv(int64_t m, const int64_t *rowptr, const int64_t *colidx, const double *val,
               const double *x, double *y);
+/* y = A x, every row folded over column panels of 2^shift columns in the visiting order pos[] (NOT the reference's order unless pos is
+ * the identity): the product's overlapped all-gather in "arrival" order, restated for bit-exact row checks */
+void orc_spmv_panel_order(int64_t m, const int64_t *rowptr, const int64_t *colidx, const double *val, const double *x, double *y,
+                          int shift, int64_t npanels, const int32_t *pos);
 /* A2: (<.>), SpVector.hs:116-117 */
 double orc_dot(int64_t n, const double *x, const double *y);
 /* A3: norm2Sq / norm2, SpVector.hs:119-129, scalar norm2Sq = (**2) Class.hs:405-408 */

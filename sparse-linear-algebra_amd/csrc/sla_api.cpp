@@ -182,9 +182,74 @@ int gather_x(const sla_csr *A, sla_vec *x, const double **base) {
 // so the exchange costs nothing beyond the boundary launch.  The fused partial sums of the two launches occupy consecutive
 // slots (interior first): *np = their total.  SLA_OVERLAP=0 runs the very same launches with the exchange serialised on
 // the compute stream (bit-identical results: same kernels, same partial layout).
+// (#>) on an all-gather-mode tile matrix (AgPlan, sla_internal.hpp): the gather goes out as G grouped send/recv launches on the
+// comm stream, the tile kernel runs as panel passes on the compute stream, each waiting only for the groups its panels need:
+//   compute:  ... producers of x | own shard -> xfull | pass 0 (own panels) | wait(g0) pass 1 | wait(g1) pass 2 | ...
+//   comm:      wait(x ready) | group 0 | record g0 | group 1 | record g1 | ...
+// The running row sums travel from pass to pass through d_yrun (16 B per row and pass next to 12 B per entry); the fused epilogue
+// runs in the last pass.  overlap = 0 issues the same groups on the compute stream in front of the passes (A/B: same bits).
+static int spmv_allgather_passes(sla_csr *A, sla_vec *x, SpmvLaunch l) {
+    sla_ctx *c = A->ctx;
+    AgPlan &pl = *A->ag;
+    const double *base = x->d;                       // rehearsal on one rank: x is whole and local
+    if (!pl.sim) {
+        SLA_TRY(ensure_xfull(c, x->shard * c->nranks));
+        if (x->n_local > 0)
+            SLA_HIP_TRY(hipMemcpyAsync(c->d_xfull + x->begin, x->d, sizeof(double) * (size_t)x->n_local, hipMemcpyDeviceToDevice, stream_of(c)));
+        base = c->d_xfull;
+        const bool async = c->overlap > 0;
+        hipStream_t compute = c->stream;
+        if (async) {
+            if (!c->comm_stream) {
+                SLA_HIP_TRY(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
+                SLA_HIP_TRY(hipEventCreateWithFlags(&c->ev_x_ready, hipEventDisableTiming));
+                SLA_HIP_TRY(hipEventCreateWithFlags(&c->ev_x_done, hipEventDisableTiming));
+            }
+            SLA_HIP_TRY(hipEventRecord(c->ev_x_ready, stream_of(c)));
+            SLA_HIP_TRY(hipStreamWaitEvent(c->comm_stream, c->ev_x_ready, 0));
+            c->stream = c->comm_stream;              // (the exchange enqueues on "the context stream")
+        }
+        int rc = SLA_OK;
+        {
+            ProfScope prof(c, SLA_KERNEL_EXCHANGE);  // (events on the stream the groups are issued on)
+            for (int g = 0; g < pl.G && rc == SLA_OK; ++g) {
+                rc = dist_exchange_group(c, pl.groups[(size_t)g], x->d, x->begin, c->d_xfull);
+                if (rc == SLA_OK && async && hipEventRecord(pl.ev[(size_t)g], c->comm_stream) != hipSuccess) rc = fail(SLA_ERR_HIP, "hipEventRecord(all-gather group)");
+            }
+        }
+        c->stream = compute;
+        SLA_TRY(rc);
+    }
+    ProfScope prof(c, l.kernel_id);                  // one timed interval for the pass sequence (waits for the groups included)
+    const int npass = (int)pl.pass_need.size();
+    for (int p = 0; p < npass; ++p) {
+        const bool last = p + 1 == npass;
+        if (!pl.sim && c->overlap > 0 && pl.pass_need[(size_t)p] > 0)
+            SLA_HIP_TRY(hipStreamWaitEvent(stream_of(c), pl.ev[(size_t)pl.pass_need[(size_t)p] - 1], 0));
+        SpmvLaunch lp = l;
+        lp.x = base;
+        lp.kernel_id = -2;                           // never matches: the enclosing scope does the timing
+        lp.tvis = pl.d_vis;
+        lp.tv0 = pl.pass_ptr[(size_t)p];
+        lp.tv1 = pl.pass_ptr[(size_t)p + 1];
+        lp.yinit = p == 0 ? nullptr : pl.d_yrun;
+        lp.tlast = last ? 1 : 0;
+        if (!last) {
+            lp.epi = EPI_NONE;
+            lp.y = pl.d_yrun;
+            lp.pres = nullptr;                       // prologue checks / step bookkeeping happen once, in the last pass
+            lp.step_begin = 0;
+            lp.pa = nullptr;
+        }
+        SLA_TRY(launch_spmv_tiles(A, lp));
+    }
+    return SLA_OK;
+}
+
 int spmv_exchanged(sla_csr *A, sla_vec *x, SpmvLaunch l, int *np) {
     sla_ctx *c = A->ctx;
     if (np) *np = spmv_grid(A);
+    if (ag_split(A) && !l.x2 && !l.yinit && x->ctx == c) return spmv_allgather_passes(A, x, l);
     if (!(overlap_split(A) && !l.x2 && !l.yinit && x->ctx == c && halo_inplace_extents(A, x, nullptr, nullptr))) {
         SLA_TRY(gather_x(A, x, &l.x));
         return launch_spmv(A, l);
@@ -398,6 +463,10 @@ const IntKnob kIntKnobs[] = {
     {"halo_inplace", &sla_ctx::halo_inplace, 0, 1},
     {"panels", &sla_ctx::panels, 0, 1},
     {"overlap", &sla_ctx::overlap, -1, 1},
+    {"ag_groups", &sla_ctx::ag_groups, 0, 64},
+    {"ag_order", &sla_ctx::ag_order, 0, 1},
+    {"ag_sim_ranks", &sla_ctx::ag_sim_ranks, 0, 64},
+    {"ag_sim_rank", &sla_ctx::ag_sim_rank, 0, 63},
     {"tiles", &sla_ctx::tiles, 0, 1},
     {"tile_shift", &sla_ctx::tile_shift, 0, 20},
     {"tile_slack", &sla_ctx::tile_slack, 0, 64},
@@ -722,6 +791,7 @@ int sla_csr_destroy(sla_csr_t A) {
     if (A->d_ov_int) (void)hipFree(A->d_ov_int);
     if (A->d_ov_bnd) (void)hipFree(A->d_ov_bnd);
     delete A->xplan;
+    ag_plan_free(A->ag);
     if (A->d_rowptr) (void)hipFree(A->d_rowptr);
     if (A->d_col) (void)hipFree(A->d_col);
     if (A->d_val) (void)hipFree(A->d_val);
@@ -831,6 +901,12 @@ int sla_csr_kernel_info(sla_csr_t A, char *buf, int buflen) {
         if (used + 1 < (size_t)buflen)
             snprintf(buf + used, (size_t)buflen - used, " slices=%d panels=%d panel_cols=%d max_segment=%lld exact_fold=1 pacing=%s", A->tl_S, A->tl_P,
                      1 << A->tl_shift, (long long)A->tl_maxseg, A->ctx->xcd8 == 1 && A->ctx->tile_slack > 0 ? "on" : "off");
+    }
+    if (ag_split(A)) {   // overlapped all-gather: exchange groups and panel passes of this rank
+        const size_t used = strlen(buf);
+        if (used + 1 < (size_t)buflen)
+            snprintf(buf + used, (size_t)buflen - used, " allgather=%s groups=%d passes=%d%s", A->ag->order == 1 ? "ascending" : "arrival", A->ag->G,
+                     (int)A->ag->pass_need.size(), A->ag->sim ? " (rehearsal)" : "");
     }
     if (A->use_wdia && wd_on(A) && wd_march_on(A)) {   // plane-march geometry
         const size_t used = strlen(buf);
@@ -1028,6 +1104,43 @@ int sla_plan_window_exchange(int nranks, int rank, int64_t n, const int64_t *win
 }
 
 // ---- measurement hooks ---------------------------------------------------------------------------------
+
+int sla_plan_allgather_passes(int nranks, int rank, int64_t n, int shift, int groups, int order, int32_t *visit, int32_t *pass_ptr,
+                              int32_t *pass_need, int32_t *npass, int32_t *ngroups) {
+    if (nranks < 1 || rank < 0 || rank >= nranks || n < 1 || shift < 1 || shift > 30 || groups < 1 || (order != 0 && order != 1) || !visit || !pass_ptr ||
+        !pass_need || !npass)
+        return fail(SLA_ERR_INVALID, "sla_plan_allgather_passes: bad arguments");
+    return no_throw("sla_plan_allgather_passes", [&]() -> int {
+        AgPlan pl;
+        plan_allgather_passes(nranks, rank, n, shift, groups, order, pl);
+        std::copy(pl.vis.begin(), pl.vis.end(), visit);
+        std::copy(pl.pass_ptr.begin(), pl.pass_ptr.end(), pass_ptr);
+        std::copy(pl.pass_need.begin(), pl.pass_need.end(), pass_need);
+        *npass = (int32_t)pl.pass_need.size();
+        if (ngroups) *ngroups = pl.G;
+        return SLA_OK;
+    });
+}
+
+
+int sla_plan_allgather_groups(int nranks, int64_t n, int shift, int groups, int order, int64_t *pieces, int cap, int *count) {
+    if (nranks < 1 || n < 1 || shift < 1 || shift > 30 || groups < 1 || (order != 0 && order != 1) || !pieces || !count || cap < 0)
+        return fail(SLA_ERR_INVALID, "sla_plan_allgather_groups: bad arguments");
+    return no_throw("sla_plan_allgather_groups", [&]() -> int {
+        AgPlan pl;
+        plan_allgather_passes(nranks, 0, n, shift, groups, order, pl);
+        int k = 0;
+        for (int g = 0; g < pl.G; ++g)
+            for (const AgPiece &pc : pl.groups[(size_t)g]) {
+                if (k >= cap) return fail(SLA_ERR_INVALID, "sla_plan_allgather_groups: piece buffer too small");
+                pieces[4 * k] = g; pieces[4 * k + 1] = pc.src; pieces[4 * k + 2] = pc.b; pieces[4 * k + 3] = pc.e;
+                ++k;
+            }
+        *count = k;
+        return SLA_OK;
+    });
+}
+
 
 int sla_prof_start(sla_ctx_t c, int kernel_id, int max_launches) {
     if (c && !c->kids.empty()) { for (sla_ctx *k : c->kids) SLA_TRY(sla_prof_start(k, kernel_id, max_launches)); return SLA_OK; }

@@ -346,6 +346,176 @@ void plan_window_exchange(int nranks, int rank, int64_t n, const int64_t *window
     plan.use_window = nranks > 1 && worst_recv * 2 < (n - S > 0 ? n - S : 1);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Overlapped all-gather of x for all-gather-mode matrices on the tile form (see AgPlan in sla_internal.hpp).
+// Pure host planning, identical on every rank (and what sla_plan_allgather_passes exports).
+// ---------------------------------------------------------------------------------------------------------
+void plan_allgather_passes(int nranks, int rank, int64_t n, int shift, int groups, int order, AgPlan &plan) {
+    const int64_t W = (int64_t)1 << shift, S = (n + nranks - 1) / nranks;
+    const int P = (int)((n + W - 1) / W);
+    auto own = [&](int q, int64_t &b, int64_t &e) { b = std::min<int64_t>(n, S * q); e = std::min<int64_t>(n, S * (q + 1)); };
+    plan.order = order;
+    plan.P = P;
+    plan.shift = shift;
+    plan.nranks = nranks;
+    plan.rank = rank;
+    plan.groups.clear();
+    if (order == 1) {   // whole shards, in source-rank order
+        for (int q = 0; q < nranks; ++q) {
+            int64_t b, e;
+            own(q, b, e);
+            plan.groups.push_back({AgPiece{q, b, e}});
+        }
+    } else {            // G column chunks of every shard, cut at panel boundaries
+        const int G = std::max(1, groups);
+        plan.groups.assign((size_t)G, {});
+        for (int q = 0; q < nranks; ++q) {
+            int64_t b, e;
+            own(q, b, e);
+            if (e <= b) continue;
+            // the panels lying wholly inside the shard are dealt out evenly over the groups; the partial panels at its two ends --
+            // each shared with a neighbouring shard -- both travel in group 0, so that a panel straddling two shards is complete
+            // after the first group instead of after the last
+            const int64_t jf = (b + W - 1) / W, je = e / W;
+            if (je <= jf) {
+                plan.groups[0].push_back(AgPiece{q, b, e});
+                continue;
+            }
+            if (jf * W > b) plan.groups[0].push_back(AgPiece{q, b, jf * W});
+            for (int g = 0; g < G; ++g) {
+                const int64_t cb = (jf + (je - jf) * g / G) * W, ce = (jf + (je - jf) * (g + 1) / G) * W;
+                if (ce > cb) plan.groups[(size_t)g].push_back(AgPiece{q, cb, ce});
+            }
+            if (e > je * W) plan.groups[0].push_back(AgPiece{q, je * W, e});
+        }
+    }
+    plan.G = (int)plan.groups.size();
+    // groups a panel needs on THIS rank: the last group that brings one of its columns (own columns need none)
+    std::vector<int32_t> need((size_t)P, 0);
+    for (int g = 0; g < plan.G; ++g)
+        for (const AgPiece &pc : plan.groups[(size_t)g]) {
+            if (pc.src == rank || pc.e <= pc.b) continue;
+            for (int64_t j = pc.b / W; j <= (pc.e - 1) / W; ++j) need[(size_t)j] = std::max<int32_t>(need[(size_t)j], g + 1);
+        }
+    plan.vis.resize((size_t)P);
+    for (int j = 0; j < P; ++j) plan.vis[(size_t)j] = j;
+    if (order == 1) {
+        for (int j = 1; j < P; ++j) need[(size_t)j] = std::max(need[(size_t)j], need[(size_t)j - 1]);   // ascending walk: what has been waited for stays waited for
+    } else {
+        std::stable_sort(plan.vis.begin(), plan.vis.end(), [&](int32_t a, int32_t b) { return need[(size_t)a] < need[(size_t)b]; });
+    }
+    plan.pass_ptr.clear();
+    plan.pass_need.clear();
+    for (int t = 0; t < P; ++t) {
+        const int32_t nd = need[(size_t)plan.vis[(size_t)t]];
+        if (t == 0 || nd != plan.pass_need.back()) {
+            plan.pass_ptr.push_back(t);
+            plan.pass_need.push_back(nd);
+        }
+    }
+    plan.pass_ptr.push_back(P);
+}
+
+int dist_exchange_group(sla_ctx *ctx, const std::vector<AgPiece> &pieces, const double *xlocal, int64_t my_begin, double *xfull) {
+    if (LoopGroup *g = loop_of(ctx)) {
+        SLA_HIP_TRY(hipStreamSynchronize(stream_of(ctx)));
+        g->ptr[(size_t)ctx->rank] = xlocal;
+        g->aux[(size_t)ctx->rank] = my_begin;
+        g->barrier();
+        for (const AgPiece &pc : pieces) {
+            if (pc.src == ctx->rank || pc.e <= pc.b) continue;
+            const double *src = (const double *)g->ptr[(size_t)pc.src] + (pc.b - g->aux[(size_t)pc.src]);
+            SLA_HIP_TRY(hipMemcpyAsync(xfull + pc.b, src, sizeof(double) * (size_t)(pc.e - pc.b), hipMemcpyDeviceToDevice, stream_of(ctx)));
+        }
+        SLA_HIP_TRY(hipStreamSynchronize(stream_of(ctx)));
+        g->barrier();
+        return SLA_OK;
+    }
+    if (ctx->nranks == 1) return SLA_OK;   // (a 1-rank communicator has no peers: nothing moves)
+    {   // an empty group (shards narrower than a panel travel whole in group 0) is no launch at all -- on every rank alike
+        bool any = false;
+        for (const AgPiece &pc : pieces) any = any || pc.e > pc.b;
+        if (!any) return SLA_OK;
+    }
+    Rccl &r = rccl();
+    if (!ctx->comm) return fail(SLA_ERR_RCCL, "grouped all-gather requested on a context without a communicator");
+    if (!r.send || !r.recv || !r.group_start || !r.group_end) return fail(SLA_ERR_RCCL, "librccl lacks ncclSend/ncclRecv");
+    int rc = r.group_start();
+    if (rc != 0) return rccl_fail("ncclGroupStart", rc);
+    // every rank walks the same piece list: a pair of ranks posts its transfers in the same order on both sides
+    for (const AgPiece &pc : pieces) {
+        if (pc.e <= pc.b) continue;
+        const size_t len = (size_t)(pc.e - pc.b);
+        if (pc.src == ctx->rank) {
+            for (int q = 0; q < ctx->nranks; ++q) {
+                if (q == ctx->rank) continue;
+                rc = r.send(xlocal + (pc.b - my_begin), len, kNcclFloat64, q, (NcclComm)ctx->comm, stream_of(ctx));
+                if (rc != 0) { r.group_end(); return rccl_fail("ncclSend", rc); }
+            }
+        } else {
+            rc = r.recv(xfull + pc.b, len, kNcclFloat64, pc.src, (NcclComm)ctx->comm, stream_of(ctx));
+            if (rc != 0) { r.group_end(); return rccl_fail("ncclRecv", rc); }
+        }
+    }
+    rc = r.group_end();
+    if (rc != 0) return rccl_fail("ncclGroupEnd", rc);
+    return SLA_OK;
+}
+
+void ag_plan_free(AgPlan *p) {
+    if (!p) return;
+    for (hipEvent_t e : p->ev) (void)hipEventDestroy(e);
+    if (p->d_vis) (void)hipFree(p->d_vis);
+    if (p->d_yrun) (void)hipFree(p->d_yrun);
+    delete p;
+}
+
+// After build_tiles: all-gather-mode tile matrices of a sharded context (or of a single-rank context rehearsing one rank's pass
+// structure, option ag_sim_ranks) get the plan, its visit list on the device, the running-sum buffer and one event per group.
+int build_ag_plan(sla_csr *A, bool failed) {
+    sla_ctx *c = A->ctx;
+    if (c->ag_groups <= 0 || c->overlap < 0) return SLA_OK;     // (options are per job: every rank sets the same)
+    const bool sim = !c->collectives && c->ag_sim_ranks > 1;
+    if (!sim) {
+        if (!c->collectives) return SLA_OK;
+        if (A->xplan && c->x_exchange != 1 && (A->xplan->use_window || c->x_exchange == 2)) return SLA_OK;   // window-mode matrices exchange halos instead (the mode is the same on every rank)
+        // The exchange pattern must be the same on every rank, but the tile form is chosen per slab: if one rank's slab did not take it,
+        // every rank keeps the plain ncclAllGather.
+        int bad = (A->use_tiles && !failed) ? 0 : 1;
+        SLA_TRY(dist_allreduce_max_i32(c, &bad));
+        if (bad) return SLA_OK;
+    } else if (!A->use_tiles || failed) {
+        return SLA_OK;
+    }
+    AgPlan *pl = new AgPlan();
+    pl->sim = sim;
+    plan_allgather_passes(sim ? c->ag_sim_ranks : c->nranks, sim ? std::min(c->ag_sim_rank, c->ag_sim_ranks - 1) : c->rank, A->n, A->tl_shift,
+                          c->ag_groups, c->ag_order, *pl);
+    if (pl->P != A->tl_P) {   // (cannot happen: both are ceil(n / 2^shift))
+        delete pl;
+        return fail(SLA_ERR_INVALID, "all-gather pass plan and tile form disagree on the panel count");
+    }
+    hipError_t e = dev_malloc(c, (void **)&pl->d_vis, sizeof(int32_t) * (size_t)std::max(pl->P, 1));
+    if (e == hipSuccess) e = hipMemcpy(pl->d_vis, pl->vis.data(), sizeof(int32_t) * (size_t)pl->P, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = dev_malloc(c, (void **)&pl->d_yrun, sizeof(double) * (size_t)std::max<int64_t>(A->rows, 1));
+    for (int g = 0; g < pl->G && e == hipSuccess; ++g) {
+        hipEvent_t ev = nullptr;
+        e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+        if (e == hipSuccess) pl->ev.push_back(ev);
+    }
+    if (e != hipSuccess) {
+        ag_plan_free(pl);
+        return fail(SLA_ERR_ALLOC, std::string("all-gather pass plan: ") + hipGetErrorString(e));
+    }
+    A->ag = pl;
+    return SLA_OK;
+}
+
+bool ag_split(const sla_csr *A) {
+    const sla_ctx *c = A->ctx;
+    return A->ag && tiles_on(A) && c->overlap >= 0 && c->ag_groups > 0 && (A->ag->sim ? !c->collectives : c->collectives);
+}
+
 // max over ranks of a host int (used for the global isDiagonalSM / method agreement); synchronises
 int dist_allreduce_max_i32(sla_ctx *ctx, int *value_host) {
     if (LoopGroup *g = loop_of(ctx)) {

@@ -168,6 +168,30 @@ struct XPlan {
     std::vector<int64_t> send_begin, send_len;  // per peer, global index / length
     std::vector<int64_t> recv_begin, recv_len;
 };
+// All-gather-mode matrices on the tile form (BASELINE config 3a sharded): the x all-gather overlapped with the SpMV.
+// The gather is issued as G grouped point-to-point exchanges (each ONE ncclGroupStart/End launch that moves a piece of EVERY
+// shard to every peer: all xGMI links busy at once, each carrying 1/G of a shard), and the tile launch is cut into PASSES over
+// column panels: pass 0 walks the panels this rank already owns, pass k the panels whose columns have arrived with the first
+// `need` groups.  The row sums are carried from pass to pass (yinit), so a row is still ONE left fold -- over the panels in the
+// plan's visiting order, ascending columns inside a panel.
+//   order 0 "arrival": groups = column chunks of every shard; panels visited by (groups needed, panel): own panels first.  Every
+//           pass but the first waits for ONE more group, so compute follows the exchange at 1/G granularity.
+//   order 1 "ascending": groups = whole shards in source-rank order (rank q's shard goes to everybody in group q); panels visited
+//           in ascending order: the reference's fold bit for bit (Common.hs:247-260), but rank r cannot start before shards
+//           0 .. r-1 have landed and the groups use one sender's links at a time: the exchange is ~nranks x slower on a full mesh.
+struct AgPiece { int src; int64_t b, e; };      // columns [b, e) of rank src's shard
+struct AgPlan {
+    int order = 0, G = 0, P = 0, shift = 0, nranks = 1, rank = 0;
+    std::vector<std::vector<AgPiece>> groups;
+    std::vector<int32_t> vis;                    // panel visiting order: a permutation of 0 .. P-1
+    std::vector<int32_t> pass_ptr, pass_need;    // pass p = vis[pass_ptr[p] .. pass_ptr[p+1]), launched once pass_need[p] groups have completed
+    int32_t *d_vis = nullptr;
+    double *d_yrun = nullptr;                    // running row sums between passes
+    std::vector<hipEvent_t> ev;                  // group g completed (recorded on the comm stream)
+    bool sim = false;                            // single-rank rehearsal of rank `rank` of `nranks` (option ag_sim_ranks): passes without an exchange
+};
+// pure host planning (also exported as sla_plan_allgather_passes for the CPU tests and the oracle-side restatement of the fold order)
+void plan_allgather_passes(int nranks, int rank, int64_t n, int shift, int groups, int order, AgPlan &plan);
 // pure host planning (also exported as sla_plan_window_exchange for the CPU tests)
 void plan_window_exchange(int nranks, int rank, int64_t n, const int64_t *windows /* [2*nranks] cmin,cmax (cmax<cmin: empty) */,
                           XPlan &plan);
@@ -197,6 +221,9 @@ struct sla_ctx {
     int row_align = 0;               // > 1: row blocks end on multiples of this many rows (SLA_ROW_ALIGN; measured -1.5 % at 16)
     int step_graph = -1;             // replay solver steps as a captured HIP graph: -1 when the matrix has <= step_graph_max_rows rows, 0 never, 1 always (SLA_STEP_GRAPH)
     int64_t step_graph_max_rows = 2500000;
+    int ag_groups = 4;               // all-gather-mode tile matrices on sharded contexts: exchange groups of the overlapped all-gather (SLA_AG_GROUPS; 0: plain ncclAllGather, then one launch)
+    int ag_order = 0;                // ... 0 arrival order (own panels first, then by exchange group), 1 ascending panels with source-ordered groups (SLA_AG_ORDER)
+    int ag_sim_ranks = 0, ag_sim_rank = 0;   // single-rank contexts: run the pass structure of rank ag_sim_rank of ag_sim_ranks without an exchange (cost of the split; SLA_AG_SIM_RANKS / _RANK)
     int overlap = 1;                 // sharded (#>): 1 interior rows run while the halo exchange is in flight (second stream), 0 same split launches with
                                      // the exchange serialised on the compute stream (A/B, bit-identical), -1 no split at all (SLA_OVERLAP)
     hipStream_t comm_stream = nullptr;   // created on first use
@@ -361,6 +388,7 @@ struct sla_csr {
     int32_t ov_nint = 0, ov_nbnd = 0;
     std::vector<int32_t> h_wsched;   // host copy of d_wsched (empty: ascending order)
     sla::XPlan *xplan = nullptr;     // sharded only: which x entries this rank exchanges with each peer
+    sla::AgPlan *ag = nullptr;       // tile form in all-gather mode: exchange groups + panel passes of the overlapped all-gather (sla_dist.cpp)
     int64_t max_row_nnz = 0;
 };
 
@@ -560,6 +588,11 @@ int dist_reduce_scatter_f64(sla_ctx *ctx, const double *send, double *recv, int6
 // xfull == xlocal - my_begin: in-place (the own rows are where they belong already, nothing is copied)
 int dist_exchange_window(sla_ctx *ctx, const XPlan &plan, const double *xlocal, int64_t my_begin, int64_t n_local, double *xfull);
 int dist_allgather_p2p_f64(sla_ctx *ctx, const double *send, double *recv, int64_t count);   // all-gather as grouped send/recv
+// one group of the overlapped all-gather: this rank's pieces go to every peer, the peers' pieces land at xfull + their global column
+int dist_exchange_group(sla_ctx *ctx, const std::vector<AgPiece> &pieces, const double *xlocal, int64_t my_begin, double *xfull);
+int build_ag_plan(sla_csr *A, bool failed);                // after build_tiles: the plan, its device visit list, running-sum buffer and events
+void ag_plan_free(AgPlan *p);
+bool ag_split(const sla_csr *A);              // does (#>) on A run as panel passes behind a grouped all-gather?
 // the collectives issued between the two calls go out as ONE grouped launch (ncclGroupStart / ncclGroupEnd)
 int dist_group_begin(sla_ctx *ctx);
 int dist_group_end(sla_ctx *ctx);
@@ -627,6 +660,8 @@ struct SpmvLaunch {
     int in_panel = 0;
     int kernel_id = SLA_KERNEL_SPMV;
     int part = 0;                               // row-sharded overlap: 0 all rows, 1 the interior steps only, 2 the boundary steps only
+    const int32_t *tvis = nullptr; int tv0 = 0, tv1 = -1;   // tile form, one PASS of an overlapped all-gather: the panels tvis[tv0 .. tv1) (tv1 < 0: all panels, ascending)
+    int tlast = 1;                              // ... 0: not the last pass -- the running row sums go to y, no epilogue
 };
 int spmv_grid(const sla_csr *A);  // number of blocks (= partial slots written) of an SpMV launch on A
 int launch_spmv(const sla_csr *A, const SpmvLaunch &l);

@@ -828,6 +828,10 @@ int csr_upload(sla_ctx *c, int64_t m, int64_t n, int64_t row_begin, int64_t rows
     if (rc == SLA_OK) rc = build_overlap_lists(A, m, n, row_begin, rows, rowptr, col);
     if (rc == SLA_OK) rc = build_tiles(A, n, rows, rowptr, col, val);
     lap("tile form");
+    {   // (contains the ranks' agreement on the exchange pattern: every rank of a sharded context gets here, failed or not)
+        const int rc_ag = build_ag_plan(A, rc != SLA_OK);
+        if (rc == SLA_OK) rc = rc_ag;
+    }
     if (rc == SLA_OK && !(A->use_lpanel && c->lpanel) && !A->use_tiles) rc = build_panels(A, m, n, row_begin, rows, rowptr, col, val);
     if (rc != SLA_OK) {
         sla_csr_destroy(A);

@@ -139,7 +139,7 @@ static int launch_spmv_rp(const sla_csr *A, const SpmvLaunch &l) {
 }
 
 int launch_spmv(const sla_csr *A, const SpmvLaunch &l) {
-    if (tiles_on(A) && !l.x2 && !l.yinit) return launch_spmv_tiles(A, l);
+    if (tiles_on(A) && !l.x2 && (!l.yinit || l.tv1 >= 0)) return launch_spmv_tiles(A, l);
     return A->rp64 ? launch_spmv_rp<int64_t>(A, l) : launch_spmv_rp<int32_t>(A, l);
 }
 

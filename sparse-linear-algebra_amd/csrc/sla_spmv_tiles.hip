@@ -85,7 +85,9 @@ template <int EPI, typename RP>
 __global__ void __launch_bounds__(kBlock, kTileBlocksPerCu)
 spmv_tile_kernel(SpmvArgs<RP> a, const RP *__restrict__ rowptr, const int32_t *__restrict__ srow, const uint32_t *__restrict__ toff,
                  const uint32_t *__restrict__ tidx, const double *__restrict__ tval, const double *__restrict__ xg, int S, int P,
-                 int shift, unsigned *prog, int slack) {
+                 int shift, unsigned *prog, int slack, const int32_t *__restrict__ vis, int v0, int nv) {
+    // One PASS of an overlapped all-gather (AgPlan, sla_internal.hpp) walks the nv panels vis[v0 ..] instead of 0 .. P-1 and starts
+    // from the running row sums a.yinit; vis == nullptr: all P panels ascending from zero (nv == P then).
     __shared__ double s_y[kBlock / 64][kTileRows];
     __shared__ double s_red[4];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -111,6 +113,7 @@ spmv_tile_kernel(SpmvArgs<RP> a, const RP *__restrict__ rowptr, const int32_t *_
     const int xcd = (int)blockIdx.x & 7;
     const int nwg_xcd = ((int)gridDim.x - xcd + 7) >> 3;
     const int rounds = (S + stride - 1) / stride;
+    if (vis == nullptr) nv = P;
     int *slots = prog ? (int *)prog + xcd * 256 : nullptr;      // <= 256 workgroups per XCD (kTileBlocksPerCu x 32 CUs)
     int *myslot = slots ? slots + ((int)blockIdx.x >> 3) : nullptr;
     bool pace = slack > 0 && slots != nullptr && nwg_xcd <= 256;
@@ -156,7 +159,11 @@ spmv_tile_kernel(SpmvArgs<RP> a, const RP *__restrict__ rowptr, const int32_t *_
             break;
         }
         const int r0 = __builtin_amdgcn_readfirstlane(srow[s]), nr = __builtin_amdgcn_readfirstlane(srow[s + 1]) - r0;
-        for (int r = lane; r < nr; r += 64) yl[r] = 0.0;
+        if (a.yinit) {
+            for (int r = lane; r < nr; r += 64) yl[r] = a.yinit[r0 + r];
+        } else {
+            for (int r = lane; r < nr; r += 64) yl[r] = 0.0;
+        }
         RP base = rowptr[r0];
         if constexpr (sizeof(RP) == 4) {
             base = (RP)__builtin_amdgcn_readfirstlane((int)base);
@@ -166,26 +173,28 @@ spmv_tile_kernel(SpmvArgs<RP> a, const RP *__restrict__ rowptr, const int32_t *_
         }
         const uint32_t *tp = toff + (size_t)s * (size_t)(P + 1);
         // walk the slice's tiles chunk by chunk (a chunk never crosses a tile); all of this is wavefront-uniform
-        int j = -1;
+        int j = -1, pj = 0, pjl = 0;             // visit step, its panel, the panels of the next 64 steps (one per lane)
         uint32_t k = 0, k1 = 0, plo = 0, phi = 0;
         auto advance = [&]() -> bool {
             while (k >= k1) {
-                if (j >= 0) publish(round * P + j + 1);   // done issuing tile j
+                if (j >= 0) publish(round * nv + j + 1);   // done issuing the tile of step j
                 ++j;
-                if (j >= P) return false;
-                wait_for(round * P + j - slack + 1);
+                if (j >= nv) return false;
+                wait_for(round * nv + j - slack + 1);
                 if ((j & 63) == 0) {   // the next 64 tile offsets, one per lane (no dependent load per tile)
-                    plo = tp[min(j + lane, P)];
-                    phi = tp[min(j + lane + 1, P)];
+                    pjl = vis ? vis[v0 + min(j + lane, nv - 1)] : min(j + lane, P - 1);
+                    plo = tp[pjl];
+                    phi = tp[pjl + 1];
                 }
+                pj = __builtin_amdgcn_readlane(pjl, j & 63);
                 k = (uint32_t)__builtin_amdgcn_readlane((int)plo, j & 63);
                 k1 = (uint32_t)__builtin_amdgcn_readlane((int)phi, j & 63);
             }
             return true;
         };
-        auto issue = [&](TileChunk &c) {   // the chunk at (j, k): its index / value streams (lanes past the end re-read the last entry)
+        auto issue = [&](TileChunk &c) {   // the chunk at (step j, k): its index / value streams (lanes past the end re-read the last entry)
             c.cnt = (int)min((uint32_t)(64 * kTileU), k1 - k);
-            c.panel = j;
+            c.panel = pj;
             const uint32_t *ip = tidx + (base + (RP)k);
             const double *vp = tval + (base + (RP)k);
 #pragma unroll
@@ -296,11 +305,14 @@ static int launch_tiles_t(const sla_csr *A, const SpmvLaunch &l) {
     a.npa = l.npa;
     a.pa_stride = l.pa_stride;
     a.step_begin = l.step_begin;
-    a.yinit = nullptr;
+    a.yinit = l.tv1 >= 0 ? l.yinit : nullptr;   // (running row sums of the earlier passes of an overlapped all-gather)
+    const int32_t *vis = l.tv1 >= 0 ? l.tvis : nullptr;
+    const int nv = l.tv1 >= 0 ? l.tv1 - l.tv0 : A->tl_P;
+    if (l.tv1 >= 0 && (!vis || l.tv0 < 0 || nv < 1 || l.tv1 > A->tl_P)) return fail(SLA_ERR_INVALID, "launch_spmv_tiles: bad panel pass");
     ProfScope prof(c, l.kernel_id);
     if (A->d_tlprog) SLA_HIP_TRY(hipMemsetAsync(A->d_tlprog, 0, A->tlprog_bytes, stream_of(c)));   // the pacing table of this launch
     hipLaunchKernelGGL((spmv_tile_kernel<EPI, RP>), dim3(tiles_grid(A)), dim3(kBlock), 0, stream_of(c), a, a.rowptr, A->d_tlrow, A->d_tloff,
-                       A->d_tlidx, A->d_tlval, l.x, A->tl_S, A->tl_P, A->tl_shift, A->d_tlprog, c->xcd8 == 1 ? c->tile_slack : 0);
+                       A->d_tlidx, A->d_tlval, l.x, A->tl_S, A->tl_P, A->tl_shift, A->d_tlprog, c->xcd8 == 1 ? c->tile_slack : 0, vis, l.tv0, nv);
     SLA_HIP_TRY(hipGetLastError());
     return SLA_OK;
 }

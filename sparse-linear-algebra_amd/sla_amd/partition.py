@@ -39,3 +39,35 @@ def plan_window_exchange(nranks, rank, n, windows):
     _lib.check(_lib.lib().sla_plan_window_exchange(nranks, rank, int(n), C.c_void_p(w.ctypes.data),
                                                    *[C.c_void_p(o.ctypes.data) for o in outs], C.byref(use)))
     return (*outs, bool(use.value))
+
+
+def plan_allgather_passes(nranks, rank, n, shift, groups=4, order=0):
+    """The library's plan of the overlapped all-gather for all-gather-mode tile matrices (sla_plan_allgather_passes, pure host
+    arithmetic): returns (visit, pass_ptr, pass_need, ngroups) for `rank` -- the panel visiting order (a row is folded over the
+    panels in that order), the pass boundaries into it and the number of exchange groups each pass waits for."""
+    import ctypes as C
+    import numpy as np
+    from . import _lib
+    P = (int(n) + (1 << shift) - 1) >> shift
+    visit, pp, pn = np.zeros(P, dtype=np.int32), np.zeros(P + 1, dtype=np.int32), np.zeros(P, dtype=np.int32)
+    npass, ng = C.c_int(), C.c_int()
+    _lib.check(_lib.lib().sla_plan_allgather_passes(nranks, rank, int(n), int(shift), int(groups), int(order), C.c_void_p(visit.ctypes.data),
+                                                    C.c_void_p(pp.ctypes.data), C.c_void_p(pn.ctypes.data), C.byref(npass), C.byref(ng)))
+    return visit, pp[:npass.value + 1].copy(), pn[:npass.value].copy(), ng.value
+
+
+def plan_allgather_groups(nranks, n, shift, groups=4, order=0):
+    """The exchange groups of that plan (sla_plan_allgather_groups; the same on every rank): a list per group of (source rank, first
+    column, end column) pieces in posting order -- in group g every source sends its pieces to every peer as one grouped launch."""
+    import ctypes as C
+    import numpy as np
+    from . import _lib
+    cap = (3 * max(groups, 1) + 3) * nranks + nranks
+    buf = np.zeros(4 * cap, dtype=np.int64)
+    cnt = C.c_int()
+    _lib.check(_lib.lib().sla_plan_allgather_groups(nranks, int(n), int(shift), int(groups), int(order), C.c_void_p(buf.ctypes.data), cap, C.byref(cnt)))
+    q = buf[:4 * cnt.value].reshape(-1, 4)
+    out = [[] for _ in range(nranks if order == 1 else max(groups, 1))]      # (a group may be empty: shards narrower than a panel travel whole in group 0)
+    for g, src, b, e in q.tolist():
+        out[g].append((src, b, e))
+    return out

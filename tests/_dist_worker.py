@@ -324,6 +324,76 @@ def main():
     dist.all_reduce(partial)                                       # (the library reduce-scatters; the shard is the same)
     ref_t = orc.spmv(orc.transpose(full), wv)
     assert np.allclose(partial.numpy()[b:e], ref_t[b:e], rtol=1e-13, atol=1e-13)
+    # ---- overlapped all-gather of x for all-gather-mode tile matrices (round 4) ------------------------------
+    # The library's own plan (sla_plan_allgather_groups / _passes, pure host), its message pattern over gloo -- ONE batch_isend_irecv
+    # per exchange group, every source sending its pieces to every peer -- and the pass-ordered fold: a pass may only read columns
+    # that are the rank's own or have arrived with the groups it waits for (everything else is NaN until then).
+    rdims, (rrp, rci, rva) = wl.random_spd(6000, 6, 17)
+    rn = rdims[0]
+    rfull = orc.Csr(rn, rn, rrp, rci, rva)
+    rb0, re0 = part.row_block(rn, rank, P)
+    rloc = orc.Csr(re0 - rb0, rn, *part.local_rows_of(rrp, rci, rva, rb0, re0))
+    xr = rng.standard_normal(rn)
+    shift = 9
+    npan = (rn + (1 << shift) - 1) >> shift
+    for order, groups in ((0, 4), (0, 2), (1, 4)):
+        cap = 64 * P
+        buf = np.zeros(4 * cap, dtype=np.int64)
+        cnt = C.c_int()
+        assert L.sla_plan_allgather_groups(C.c_int(P), C.c_int64(rn), C.c_int(shift), C.c_int(groups), C.c_int(order), C.c_void_p(buf.ctypes.data),
+                                           C.c_int(cap), C.byref(cnt)) == 0
+        pieces = buf[:4 * cnt.value].reshape(-1, 4).tolist()
+        visit, pptr, pneed = np.zeros(npan, np.int32), np.zeros(npan + 1, np.int32), np.zeros(npan, np.int32)
+        npass, ng = C.c_int(), C.c_int()
+        assert L.sla_plan_allgather_passes(C.c_int(P), C.c_int(rank), C.c_int64(rn), C.c_int(shift), C.c_int(groups), C.c_int(order),
+                                           C.c_void_p(visit.ctypes.data), C.c_void_p(pptr.ctypes.data), C.c_void_p(pneed.ctypes.data),
+                                           C.byref(npass), C.byref(ng)) == 0
+        xfull = np.full(rn, np.nan)
+        xfull[rb0:re0] = xr[rb0:re0]
+        yrun = np.zeros(re0 - rb0)
+        arrived = 0
+
+        def exchange_group(g):
+            ops, land = [], []
+            for gg, src, pb, pe in pieces:                           # every rank walks the same list: matching order on both sides
+                if gg != g or pe <= pb:
+                    continue
+                if src == rank:
+                    for q in range(P):
+                        if q != rank:
+                            ops.append(dist.P2POp(dist.isend, torch.from_numpy(xr[pb:pe].copy()), q))
+                else:
+                    t = torch.zeros(pe - pb, dtype=torch.float64)
+                    land.append((pb, pe, t))
+                    ops.append(dist.P2POp(dist.irecv, t, src))
+            for w_ in (dist.batch_isend_irecv(ops) if ops else []):
+                w_.wait()
+            for pb, pe, t in land:
+                xfull[pb:pe] = t.numpy()
+
+        for p_ in range(npass.value):
+            while arrived < pneed[p_]:
+                exchange_group(arrived)
+                arrived += 1
+            for j in visit[pptr[p_]:pptr[p_ + 1]]:                   # one panel of the pass: continue every row's running sum
+                lo, hi = int(j) << shift, min(rn, (int(j) + 1) << shift)
+                assert not np.isnan(xfull[lo:hi]).any(), "a pass read columns that have not arrived"
+                for i in range(re0 - rb0):
+                    acc = yrun[i]
+                    for k in range(rloc.rowptr[i], rloc.rowptr[i + 1]):
+                        if lo <= rloc.colidx[k] < hi:
+                            acc = acc + rloc.val[k] * xfull[rloc.colidx[k]]
+                    yrun[i] = acc
+        while arrived < ng.value:                                    # (groups nobody on this rank waited for still have to be received)
+            exchange_group(arrived)
+            arrived += 1
+        assert not np.isnan(xfull).any()
+        assert np.array_equal(yrun, orc.spmv_panel_order(rloc, xr, shift, visit)), "pass-ordered fold != the oracle's restatement of it"
+        yref = orc.spmv(rfull, xr)[rb0:re0]
+        if order == 1:
+            assert np.array_equal(yrun, yref), "ascending order must be the reference's left fold bit for bit"
+        else:
+            assert np.abs(yrun - yref).max() <= 64 * np.finfo(np.float64).eps * np.abs(rva).max() * np.abs(xr).max()
     dist.barrier()
     if rank == 0:
         print("DIST_OK", P)

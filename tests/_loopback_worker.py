@@ -170,6 +170,22 @@ y = cat("y")
 yo = orc.spmv(Ao, xg)
 if KIND in ("random", "dense", "denseband") or (KIND.startswith("fuzz") and "wdia" not in results[0]["kernel"] and len(VA) > 8 * n):     # > 8 stored entries per row on average: wavefront-segmented sums, last-bit grouping differences
     assert np.abs(y - yo).max() <= 4e-15 * np.abs(VA).max() * np.abs(xg).max() * 16, np.abs(y - yo).max()
+elif KIND == "randtile" and "allgather=arrival" in results[0]["kernel"]:
+    # Overlapped all-gather in arrival order: every rank folds its rows over the column panels in ITS visiting
+    # order -- own panels first, then by exchange group -- which sla_plan_allgather_passes states and the oracle restates: bit for bit.
+    from sla_amd.partition import local_rows_of, plan_allgather_passes
+    shift, groups = int(os.environ.get("SLA_TILE_SHIFT", "17")), int(os.environ.get("SLA_AG_GROUPS", "4"))
+    exp, moved = [], 0
+    for r in range(P):
+        b, e = results[r]["range"]
+        rp, ci, va = local_rows_of(RP, CI, VA, b, e)
+        visit, pptr, pneed, ng = plan_allgather_passes(P, r, n, shift, groups, 0)
+        assert sorted(visit.tolist()) == list(range(len(visit))) and f"groups={ng} passes={len(pneed)}" in results[r]["kernel"], results[r]["kernel"]
+        exp.append(orc.spmv_panel_order(orc.Csr(e - b, n, rp, ci, va), xg, shift, visit))
+        moved += int(np.count_nonzero(exp[-1] != yo[b:e]))
+    assert np.array_equal(y, np.concatenate(exp)), "overlapped all-gather: rows must equal the left fold over the panels in the plan's visiting order bit for bit"
+    assert np.abs(y - yo).max() <= 4e-15 * np.abs(VA).max() * np.abs(xg).max() * 16      # ... and the reference's ascending fold to rounding
+    print("PANEL_ORDER_ROWS_DIFFERING_FROM_ASCENDING", moved, "of", n)
 else:
     assert np.array_equal(y, yo), "sharded (#>) must equal the whole-matrix left fold bit for bit"
 if QUICK:

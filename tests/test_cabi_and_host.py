@@ -138,3 +138,71 @@ def test_random_spd_slab_generator_equals_the_rows_of_the_full_matrix():
             d2, (rp2, ci2, va2) = wl.random_spd_rows(n, k, 42, b, e, threads=2)
             r = local_rows_of(rp, ci, va, b, e)
             assert d2 == dims and np.array_equal(rp2, r[0]) and np.array_equal(ci2, r[1]) and np.array_equal(va2, r[2]), (world, rank)
+
+
+@pytest.mark.parametrize("order", [0, 1])
+@pytest.mark.parametrize("nranks,n,shift,groups", [(8, 10_000_000, 17, 4), (2, 10_000_000, 17, 4), (3, 20_000, 10, 4), (8, 20_000, 10, 2),
+                                                   (4, 5_000, 10, 6), (5, 1_000_003, 16, 3), (16, 40_000, 12, 4), (1, 9_000, 10, 4)])
+def test_overlapped_allgather_plan(nranks, n, shift, groups, order):
+    """sla_plan_allgather_passes / _groups (pure host): the exchange groups tile every shard exactly once, the
+    visiting order is a permutation of the panels, a pass only walks panels whose columns are the rank's own or have arrived with
+    the groups it waits for, waits never decrease, own-only panels come first in arrival order, and order 1 walks ascending."""
+    from sla_amd.partition import plan_allgather_groups, plan_allgather_passes, row_block
+    W, P = 1 << shift, (n + (1 << shift) - 1) >> shift
+    G = plan_allgather_groups(nranks, n, shift, groups, order)
+    assert len(G) == (nranks if order == 1 else groups)
+    cover = np.zeros(n, dtype=np.int32)
+    arrives = np.zeros(n, dtype=np.int32)            # group (1-based) that brings a column to a rank that does not own it
+    for g, pieces in enumerate(G):
+        for src, b, e in pieces:
+            ob, oe = row_block(n, src, nranks)
+            assert ob <= b < e <= oe                 # a piece lies inside its source's shard
+            cover[b:e] += 1
+            arrives[b:e] = g + 1
+    assert np.all(cover == 1)                        # every column of every shard travels exactly once
+    for rank in range(nranks):
+        visit, pptr, pneed, ng = plan_allgather_passes(nranks, rank, n, shift, groups, order)
+        assert ng == len(G) and sorted(visit.tolist()) == list(range(P)) and pptr[0] == 0 and pptr[-1] == P
+        assert np.all(np.diff(pneed) > 0) and np.all(np.diff(pptr) > 0)
+        ob, oe = row_block(n, rank, nranks)
+        need_of = arrives.copy()
+        need_of[ob:oe] = 0                           # own columns need nothing
+        for p in range(len(pneed)):
+            for j in visit[pptr[p]:pptr[p + 1]]:
+                assert need_of[j * W:min(n, (j + 1) * W)].max() <= pneed[p], (rank, p, j)
+        if order == 1:
+            assert np.array_equal(visit, np.arange(P))
+        else:
+            own_only = [j for j in range(P) if need_of[j * W:min(n, (j + 1) * W)].max() == 0]
+            k = len(own_only)
+            assert sorted(visit[:k].tolist()) == own_only and (k == 0 or pneed[0] == 0)
+            # inside a pass the panels ascend (the walk of one pass is a left-to-right sweep of x)
+            for p in range(len(pneed)):
+                assert np.all(np.diff(visit[pptr[p]:pptr[p + 1]]) > 0)
+
+
+def test_oracle_panel_order_fold():
+    """orc.spmv_panel_order (oracle restatement of the overlapped all-gather's fold): ascending visit == orc.spmv bit for bit; a
+    permuted visit is one left fold per row over the panels in that order (checked against a plain Python fold)."""
+    from oracle import oracle as orc
+    rng = np.random.default_rng(5)
+    m, n, shift = 60, 700, 6
+    rows, cols, vals = [], [], []
+    for i in range(m):
+        k = int(rng.integers(0, 40))
+        c = np.sort(rng.choice(n, size=k, replace=False))
+        rows += [i] * k; cols += c.tolist(); vals += rng.standard_normal(k).tolist()
+    rc, A = orc.coo_to_csr(m, n, np.array(rows, np.int64), np.array(cols, np.int64), np.array(vals))
+    x = rng.standard_normal(n)
+    P = (n + (1 << shift) - 1) >> shift
+    assert np.array_equal(orc.spmv_panel_order(A, x, shift, np.arange(P)), orc.spmv(A, x))
+    visit = rng.permutation(P).astype(np.int32)
+    y = orc.spmv_panel_order(A, x, shift, visit)
+    for i in range(m):
+        acc = 0.0
+        ks = range(A.rowptr[i], A.rowptr[i + 1])
+        for j in visit:
+            for k in ks:
+                if A.colidx[k] >> shift == j:
+                    acc = acc + A.val[k] * x[A.colidx[k]]
+        assert y[i] == acc

@@ -134,8 +134,11 @@ def test_config3b_dense_rows_200k_vs_oracle(sla):
 
 def test_config5_arnoldi_2m_kn30_vs_oracle(sla):
     """`arnoldi aa b 30` (Sparse.hs:630-667) on config 5's matrix at FULL size (2 M rows, the basis GMRES(30) builds) against the
-    oracle's classical Gram-Schmidt with left-fold sums: H to 1e-10 max|H|, every basis vector entry to 1e-9.  (The device sums in a
-    fixed two-stage tree: 30 steps of un-reorthogonalised Gram-Schmidt on this well-conditioned operator amplify that to ~1e-13.)"""
+    oracle's classical Gram-Schmidt with left-fold sums.  Thirty steps of un-reorthogonalised Gram-Schmidt amplify the difference
+    between the two summation orders: measured (round 4) max|H - Ho| = 2.3e-10 max|H|, growing from 1e-13 in column 0.  Most of it
+    is the ORACLE's: a 2 M-term left fold carries ~sqrt(n) eps relative to sum|q_i w_i|, the device's two-stage tree far less -- checked
+    on h_00 against a long-double evaluation, where the device must be at least as close as the oracle.  Bounds: H to 1e-9 max|H|,
+    basis entries to 1e-8, basis orthonormal to 1e-9."""
     from sla_amd import workloads as wl
     n, kn = 2000000, 30
     dims, (rp, ci, va) = wl.banded_nonsym(n)
@@ -145,8 +148,16 @@ def test_config5_arnoldi_2m_kn30_vs_oracle(sla):
     Q, H = sla.arnoldi(A, sla.fromVector(b), kn)
     rc, Qo, Ho, k = orc.arnoldi(Ao, b, kn)
     assert rc == orc.OK and k == kn and H.shape == Ho.shape == (kn + 1, kn) and Q.shape == Qo.shape == (n, kn + 1)
-    assert np.abs(H - Ho).max() <= 1e-10 * np.abs(Ho).max(), np.abs(H - Ho).max() / np.abs(Ho).max()
-    assert np.abs(Q - Qo).max() <= 1e-9, np.abs(Q - Qo).max()
+    dh = np.abs(H - Ho).max() / np.abs(Ho).max()
+    assert dh <= 1e-9, dh
+    assert np.abs(H[:, 0] - Ho[:, 0]).max() <= 1e-12 * np.abs(Ho).max()          # the first column: before any amplification
+    dq = np.abs(Q - Qo).max()
+    assert dq <= 1e-8, dq
+    # h_00 = q0 . (A q0) in extended precision: whose sum is the accurate one?
+    q0 = Qo[:, 0].copy()
+    w = orc.spmv(Ao, q0)
+    exact = float(np.dot(q0.astype(np.longdouble), w.astype(np.longdouble)))
+    assert abs(H[0, 0] - exact) <= abs(Ho[0, 0] - exact) + 4 * np.finfo(np.float64).eps * abs(exact), (H[0, 0], Ho[0, 0], exact)
     del Qo
     G = Q.T @ Q
     assert np.abs(G - np.eye(kn + 1)).max() <= 1e-9

@@ -91,12 +91,38 @@ def test_cgs_traces_follow_the_oracle(sla, name, x0v):
         assert len(h) == 200
 
 
+def _gmres_exact_lsq(Ao, b, x0, restart, cycles):
+    """GMRES(restart) over whole cycles built from the ORACLE's arnoldi (Sparse.hs:630-667 restated) and an exact dense least-squares
+    solve of min ||beta e1 - H y|| (numpy lstsq): the comparator for systems on which the reference's own qr + triUpperSolve route
+    (orc.gmres) is not usable -- see the test below."""
+    x, tol, it = x0.copy(), None, 0
+    for cyc in range(cycles + 1):
+        r = b - orc.spmv(Ao, x)
+        beta = np.linalg.norm(r)
+        if tol is None:
+            tol = max(1e-6, 1e-4 * beta)
+        if beta <= tol or cyc == cycles:
+            break
+        rc, Q, H, k = orc.arnoldi(Ao, r, restart)
+        e1 = np.zeros(k + 1)
+        e1[0] = beta
+        y = np.linalg.lstsq(H, e1, rcond=None)[0]
+        x = x + Q[:, :k] @ y
+        it += k
+    return x, it, beta
+
+
 @pytest.mark.parametrize("name", ["e05r0000", "denjoh_beam"])
 def test_gmres_and_backslash_against_the_oracles_x(sla, name):
     """GMRES x against the ORACLE's x (not against the product's own residual).  GMRES(30) and GMRES(60) from 0.1 * ones over whole
-    restart cycles (the oracle restarts on whole cycles): same iteration counts, x within 1e-6 relative (the product's least-squares
-    step is an in-place Givens sweep, the oracle's the reference's qr + triUpperSolve: independent formulations); then (<\\>)
-    (dead instance Sparse.hs:1080-1084: GMRES(30) from 0.1 * ones, 200 iterations) = that GMRES call, bit for bit."""
+    restart cycles: same iteration counts, x within 1e-6 relative of
+      (a) the oracle's arnoldi + an exact dense least-squares solve per cycle (both fixtures), and
+      (b) orc.gmres -- the reference's commented sketch, qr + triUpperSolve (Sparse.hs:837-848) -- on e05r0000.
+    On the beam system (b) is NOT a usable comparator, measured in round 4: the restated reference `qr` leaves a lower part of 3e12
+    (max|R| = 1e13) in the R of this 31 x 30 Hessenberg matrix (Q R = H and Q^T Q = I still hold to 4e-16), so its least-squares step
+    returns ||b - A x|| = 7.3e8 where the exact minimiser over the same Krylov basis gives 1.78e7 -- which is what the product
+    returns (its Givens sweep is an independent formulation).  GMRES is dead code in the reference (parity unpinned).
+    Then (<\\>) (dead instance Sparse.hs:1080-1084: GMRES(30) from 0.1 * ones, 200 iterations) = that GMRES call, bit for bit."""
     _, dims, r, c, v, b = _fixture(name)
     n = dims[0]
     rc, Ao = orc.coo_to_csr(n, n, r, c, v)
@@ -104,15 +130,21 @@ def test_gmres_and_backslash_against_the_oracles_x(sla, name):
     bv, x0 = sla.fromVector(b), np.full(n, 0.1)
     for restart, cycles in ((30, 6), (60, 20)):
         x, info = sla.gmres(A, bv, sla.fromVector(x0), restart=restart, return_info=True, max_iters=restart * cycles)
-        rco, xo, it_o, res_o, r0_o = orc.gmres(Ao, b, x0, restart=restart, max_restarts=cycles)
         xd = x.toDenseListSV()
+        xe, it_e, res_e = _gmres_exact_lsq(Ao, b, x0, restart, cycles)
+        r0_o = np.linalg.norm(b - orc.spmv(Ao, x0))
         assert abs(info["r0norm"] - r0_o) <= 1e-10 * r0_o
-        assert info["iters"] == it_o, (name, restart, info["iters"], it_o)
-        assert np.linalg.norm(xd - xo) <= 1e-6 * np.linalg.norm(xo), (name, restart, np.linalg.norm(xd - xo) / np.linalg.norm(xo))
-        assert abs(info["resnorm"] - res_o) <= 1e-6 * res_o + 1e-12 * r0_o, (name, restart, info["resnorm"], res_o)
+        assert info["iters"] == it_e, (name, restart, info["iters"], it_e)
+        assert np.linalg.norm(xd - xe) <= 1e-6 * np.linalg.norm(xe), (name, restart, np.linalg.norm(xd - xe) / np.linalg.norm(xe))
+        assert abs(info["resnorm"] - res_e) <= 1e-5 * res_e + 1e-12 * r0_o, (name, restart, info["resnorm"], res_e)
         res = np.linalg.norm(orc.spmv(Ao, xd) - b)
         assert abs(res - info["resnorm"]) <= 1e-6 * max(res, info["resnorm"]) + 1e-9 * r0_o
-        assert info["converged"] == (res_o <= max(1e-6, 1e-4 * r0_o))
+        assert info["converged"] == (res_e <= max(1e-6, 1e-4 * r0_o))
+        rco, xo, it_o, res_o, r0o = orc.gmres(Ao, b, x0, restart=restart, max_restarts=cycles)
+        if name == "e05r0000":
+            assert info["iters"] == it_o and np.linalg.norm(xd - xo) <= 1e-6 * np.linalg.norm(xo), (restart, np.linalg.norm(xd - xo) / np.linalg.norm(xo))
+        else:   # the reference-sketch route loses to the exact least-squares step on this system (see above): never the other way round
+            assert res <= np.linalg.norm(orc.spmv(Ao, xo) - b) * (1 + 1e-9)
     xb, ib = sla.linSolve(A, bv, return_info=True)
     xg, ig = sla.gmres(A, bv, sla.fromVector(x0), restart=30, return_info=True, max_iters=200)
     assert np.array_equal(xb.toDenseListSV(), xg.toDenseListSV()) and ib["iters"] == ig["iters"] and ib["flags"] == ig["flags"]

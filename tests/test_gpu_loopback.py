@@ -30,17 +30,37 @@ def test_split_launch_partials_stay_inside_their_slot_array():
     assert "overlap=streams" in out.stdout and "grid=2048" in out.stdout, out.stdout[-2000:]
 
 
-@pytest.mark.parametrize("nranks", [2, 3, 4])
-def test_tile_form_on_row_slabs(nranks):
-    """The row-slice x column-panel tile form (BASELINE config 3a's SpMV) on ROW SLABS of a random matrix: SLA_TILE_SHIFT=10 makes
-    a 20 000-row matrix take it (20 panels), every rank lowers its own slab (row_begin > 0, global column ids, x all-gathered into
-    the full-length buffer).  The worker requires (#>) bit-identical to the oracle's left fold and runs BiCGSTAB, CGS, CGNE, Arnoldi
-    and GMRES through the fused epilogues of the tile kernel."""
-    env = dict(os.environ, SLA_TILE_SHIFT="10")
+def _randtile(nranks, **env_extra):
+    env = dict(os.environ, SLA_TILE_SHIFT="10", **env_extra)
     out = subprocess.run([sys.executable, os.path.join(HERE, "_loopback_worker.py"), str(nranks), "randtile"], env=env,
                          stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
     assert out.returncode == 0 and f"LOOPBACK_OK {nranks} randtile" in out.stdout, out.stdout[-3000:]
     assert "algo=tiles" in out.stdout
+    return out.stdout, sorted(l for l in out.stdout.splitlines() if l.startswith("XHASH"))
+
+
+@pytest.mark.parametrize("nranks", [2, 3, 4, 8])
+def test_tile_form_on_row_slabs(nranks):
+    """The row-slice x column-panel tile form (BASELINE config 3a's SpMV) on ROW SLABS of a random matrix: SLA_TILE_SHIFT=10 makes
+    a 20 000-row matrix take it (20 panels), every rank lowers its own slab (row_begin > 0, global column ids, x all-gathered into
+    the full-length buffer); BiCGSTAB, CGS, CGNE, Arnoldi and GMRES run through the fused epilogues of the tile kernel.
+    Round 4: the all-gather of x is OVERLAPPED with the SpMV -- G grouped send/recv exchanges on the comm
+    stream, the tile launch as panel passes behind them, the running row sums carried from pass to pass.
+      * default (arrival order, overlap on): every row = the left fold over the panels in the plan's visiting order, bit for bit
+        against the oracle's restatement of that order (and the reference's ascending fold to rounding);
+      * overlap = 0: the same groups serialised on the compute stream in front of the same passes: the SAME bits, all solvers;
+      * overlap = -1 (plain ncclAllGather, one launch) and ag_order = 1 (source-ordered groups, ascending panel passes): the
+        reference's ascending left fold bit for bit (Common.hs:247-260) -- and the same solver iterates as each other."""
+    o1, h1 = _randtile(nranks)
+    assert "allgather=arrival groups=4" in o1 and "PANEL_ORDER_ROWS_DIFFERING_FROM_ASCENDING" in o1, o1[-2000:]
+    o0, h0 = _randtile(nranks, SLA_OVERLAP="0")
+    assert "allgather=arrival" in o0 and h0 == h1, (h0, h1)
+    om, hm = _randtile(nranks, SLA_OVERLAP="-1")
+    assert "allgather=" not in om
+    oa, ha = _randtile(nranks, SLA_AG_ORDER="1")
+    assert "allgather=ascending" in oa and f"groups={nranks}" in oa and ha == hm, (ha, hm)
+    o2, h2 = _randtile(nranks, SLA_AG_GROUPS="2")
+    assert "allgather=arrival groups=2" in o2
 
 
 @pytest.mark.parametrize("seed,nranks", [(1, 2), (2, 3), (3, 4), (4, 5), (6, 3)])

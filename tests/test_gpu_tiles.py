@@ -133,3 +133,60 @@ def test_default_panel_width_picks_tiles_only_beyond_the_l2(sla):
     assert "algo=tiles" in A.kernel_info() and "panels=11 panel_cols=65536" in A.kernel_info(), A.kernel_info()
     x = np.random.default_rng(2).standard_normal(dims[0])
     assert np.array_equal(sla.matVec(A, sla.fromVector(x, ctx)).toDenseListSV(), orc.spmv(orc.Csr(*dims, rp, ci, va), x))
+
+
+@pytest.mark.parametrize("ranks,rank,groups", [(4, 1, 4), (8, 7, 2), (3, 0, 3), (2, 1, 1)])
+def test_panel_passes_of_the_overlapped_allgather_on_one_rank(sla, ranks, rank, groups):
+    """The pass structure of the overlapped all-gather (round 4) REHEARSED on a single-rank context (options
+    ag_sim_ranks / ag_sim_rank: the tile launch of rank `rank` of `ranks` as the plan's panel passes, running row sums carried from
+    pass to pass, no exchange): every cut of the visiting order -- many panels per pass (> 64: the offset block reload inside a
+    pass), ragged rows, empty tiles, rectangular shapes.
+      arrival order:   rows == the oracle's left fold over the panels in the plan's visiting order, bit for bit;
+      ascending order: rows == the reference's ascending left fold (orc.spmv), bit for bit -- the carry through yinit is exact;
+    and two BiCGSTAB steps + two CGS steps through the fused epilogues of the LAST pass against the oracle."""
+    from sla_amd.partition import plan_allgather_passes
+    shift = 10
+    for label, (dims, (rp, ci, va)) in (("98 panels", _rand_rows(3000, 100000, lambda i, r: 40, 2)),
+                                         ("ragged", _rand_rows(7001, 30000, lambda i, r: (0, 1, 3, 33, 200)[i % 5], 3)),
+                                         ("square", _rand_rows(20000, 20000, lambda i, r: 17, 21))):
+        m, n = dims
+        Ao = orc.Csr(m, n, rp, ci, va)
+        x = np.random.default_rng(9).standard_normal(n)
+        yo = orc.spmv(Ao, x)
+        for order in (0, 1):
+            ctx = sla.Context(0).set_options(tile_shift=shift, ag_sim_ranks=ranks, ag_sim_rank=rank, ag_groups=groups, ag_order=order)
+            A = sla.fromCSR(dims, rp, ci, va, ctx)
+            info = A.kernel_info()
+            visit, pptr, pneed, ng = plan_allgather_passes(ranks, rank, n, shift, groups, order)
+            assert "algo=tiles" in info and f"allgather={'ascending' if order else 'arrival'} groups={ng} passes={len(pneed)} (rehearsal)" in info, info
+            y = sla.matVec(A, sla.fromVector(x, ctx)).toDenseListSV()
+            if order == 1:
+                assert np.array_equal(y, yo), (label, info)
+            else:
+                assert np.array_equal(y, orc.spmv_panel_order(Ao, x, shift, visit)), (label, info)
+                assert np.all(np.abs(y - yo) <= np.diff(rp) * EPS * orc.spmv(orc.Csr(m, n, rp, ci, np.abs(va)), np.abs(x)))
+            if label == "square":
+                # diagonally dominant variant: the fused epilogues (K1, K3 with four sums, CGS's C3) run in the last pass only
+                d = np.zeros(n)
+                np.add.at(d, np.repeat(np.arange(n), np.diff(rp)), np.abs(va))
+                rows = np.repeat(np.arange(n), np.diff(rp))
+                rr, cc, vv = np.append(rows, np.arange(n)), np.append(ci, np.arange(n)), np.append(va, d + 1.0)
+                rc, Do = orc.coo_to_csr(n, n, rr, cc, vv)
+                D = sla.fromCSR((n, n), Do.rowptr, Do.colidx, Do.val, ctx)
+                assert "allgather=" in D.kernel_info()
+                b = orc.spmv(Do, np.ones(n))
+                x0 = np.zeros(n)
+                so, sd = orc.BicgstabState(Do, b, x0), sla.bicgsInit(D, sla.fromVector(b, ctx), sla.fromVector(x0, ctx))
+                so.step(b, 2)
+                sd.step(2)
+                for name, dev, ref in (("x", sd._xBicgstab, so.x), ("r", sd._rBicgstab, so.r), ("p", sd._pBicgstab, so.p)):
+                    assert np.linalg.norm(dev.toDenseListSV() - ref) <= 1e-11 * np.linalg.norm(ref), (label, order, name)
+                sc, sdc = orc.CgsState(Do, b, x0), sla.cgsInit(D, sla.fromVector(b, ctx), sla.fromVector(x0, ctx))
+                sc.step(b, 2)
+                sdc.step(2)
+                assert np.linalg.norm(sdc._x.toDenseListSV() - sc.x) <= 1e-11 * np.linalg.norm(sc.x)
+                xs, inf = sla.linSolve0(sla.BICGSTAB_, D, sla.fromVector(b, ctx), sla.fromVector(x0, ctx), return_info=True)
+                assert inf["converged"] and np.linalg.norm(xs.toDenseListSV() - 1.0) <= 1e-4 * np.sqrt(n)
+                del sd, sdc, D
+            del A
+            ctx.close()
