@@ -80,6 +80,8 @@ constexpr int kLpBlock = 1024;       // its workgroup: 16 wavefronts, one per CU
 constexpr int kLpRowsInFlight = SLA_LP_ROWS;   // (row, panel) segments a wavefront of spmv_lpanel_kernel keeps in flight (2: 0.900 ms, 3: 0.910, 4: 0.926)
 constexpr int kLpMinSeg = 16;        // mean entries per (row, panel) segment below which the stream kernel wins (tiny segments waste sectors)
 constexpr int kVdMaxRowNnz = 31;     // longest row the value-indexed kernel takes (256 rows x 31 B of codes fit its LDS stage)
+constexpr int kWvMaxRow = 128;       // longest row spmv_wave_kernel takes (one lane folds a row from the wavefront's LDS stage)
+constexpr int kRowptrPad = 192;      // entries (= nnz) behind the rows + 1 row pointers of the 32-bit array: 128-row blocks read past the last row unclamped
 constexpr int kWaveRowMax = 16384;   // rows of 1025..16384 entries: one wavefront each, 4 per row block; longer: whole workgroup
 #ifndef SLA_TILE_ROWS
 #define SLA_TILE_ROWS 4096
@@ -258,6 +260,8 @@ struct sla_ctx {
     int lpanel = 1;                  // allow the LDS-panel SpMV kernel for matrices with dense rows (SLA_LPANEL=0 disables)
     int xwin = 1;                    // LDS x windows: 1 = where they pay (the pair-code kernel), 2 = also the dictionary-code kernels, 0 = nowhere (SLA_XWIN); the plain CSR-stream kernel takes its window form only with stream_wide = 0
     int stream_wide = 1;             // spmv_stream_kernel: pairs of entries per load (8-byte col / 16-byte val loads) instead of one (SLA_STREAM_WIDE=0)
+    int stream_wave = 1;             // plain CSR (#>): wavefront-private 128-row blocks with row-pair stores (sla_spmv_wave.hip) instead of spmv_stream_kernel when no row
+                                     // exceeds kWvMaxRow entries (SLA_STREAM_WAVE: 0 off, 1 on = 4 entry pairs per lane and chunk, 4 / 7 force that chunk size)
     int stream_pipe = 0;             // plain CSR-stream (#>): the three-stage pipelined kernel (sla_spmv_pipe.hip) instead of spmv_stream / spmv_xwin
                                      // (SLA_STREAM_PIPE=1; OFF by default: measured 7-12 % SLOWER than the one-deep prefetch)
     int dual_spmv = 1;               // linSolve0: fuse the true-residual SpMV into the next K1 (SLA_DUAL_SPMV=0 disables)
@@ -694,6 +698,10 @@ int wd_lds_grid(const sla_csr *A);
 int wd_march_grid(const sla_csr *A);
 void wd_march_prepare();   // (lowering: queries the instantiations' register counts once, outside any stream capture)
 int launch_wdia_march(const sla_csr *A, int epi, const SpmvArgs<int32_t> &a, int grid, int stream_nt);
+bool wave_on(const sla_csr *A);                                                                              // sla_spmv_wave.hip
+int wave_grid(const sla_csr *A);
+bool wave_plain(const sla_csr *A);   // sla_spmv.hip: does a plain (#>) on A end up on spmv_wave_kernel?
+int launch_spmv_wave(const sla_csr *A, int epi, const SpmvArgs<int32_t> &a, int grid);
 bool pipe_on(const sla_csr *A);                                                                              // sla_spmv_pipe.hip
 int launch_spmv_pipe(const sla_csr *A, int epi, const SpmvArgs<int32_t> &a, int grid);
 int launch_spmv_pipe(const sla_csr *A, int epi, const SpmvArgs<int64_t> &a, int grid);

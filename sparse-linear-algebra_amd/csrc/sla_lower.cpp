@@ -204,9 +204,11 @@ static void low_csr_arrays(Low &L) {
         std::vector<int32_t> rbk(rb.size());
         for (size_t b = 0; b < rb.size(); ++b) rbk[b] = (int32_t)rowptr[rb[b]];
         upload(&A->d_rbk, rbk.data(), sizeof(int32_t) * rbk.size());
-        std::vector<int32_t> rp32((size_t)rows + 1);
+        // (kRowptrPad entries = nnz behind the last one: spmv_wave_kernel reads the row pointers of whole 128-row blocks unclamped,
+        // rows past the end of the matrix are empty)
+        std::vector<int32_t> rp32((size_t)rows + 1 + kRowptrPad, (int32_t)nnz);
         for (int64_t i = 0; i <= rows; ++i) rp32[(size_t)i] = (int32_t)rowptr[i];
-        upload(&A->d_rowptr, rp32.data(), sizeof(int32_t) * (size_t)(rows + 1));
+        upload(&A->d_rowptr, rp32.data(), sizeof(int32_t) * rp32.size());
     }
     upload((void **)&A->d_rb, rb.data(), sizeof(int32_t) * rb.size());
     val_up.join();

@@ -30,6 +30,12 @@ int overlap_grid(const sla_csr *A, int part) {
     return std::max(1, std::min<int>(A->ov_nint, cap));
 }
 
+// does a plain (#>) on A end up on spmv_wave_kernel?  (the forms dispatched in front of it in launch_spmv_rp all have to be out)
+bool wave_plain(const sla_csr *A) {
+    const sla_ctx *c = A->ctx;
+    return wave_on(A) && !A->is_panel_view && !(A->use_diag && c->diag) && !pipe_on(A) && !stream_xwin_on(A);
+}
+
 int spmv_grid(const sla_csr *A) {
     const sla_ctx *c = A->ctx;
     // with column panels the fused partials are written by the LAST panel pass: its grid is the one that counts
@@ -40,6 +46,7 @@ int spmv_grid(const sla_csr *A) {
     else if (A->use_wdia && wd_on(A) && wd_march_on(A)) g = wd_march_grid(A);   // (the whole-matrix launch: overlap_grid sizes the split ones)
     else if (A->use_wdia && wd_on(A)) g = std::min<int64_t>(A->nblk_wd, A->wd_vv ? c->wd_grid_max_vv : wd_lds_on(A) ? wd_lds_grid(A) : c->wd_grid_max);
     else if (A->use_vdict && c->vdict) g = A->nblk_vd;
+    else if (wave_plain(A)) return wave_grid(A);
     else g = A->nrb;
     if (g < 1) g = 1;
     if (g > c->spmv_grid_max) g = c->spmv_grid_max;
@@ -135,6 +142,9 @@ static int launch_spmv_rp(const sla_csr *A, const SpmvLaunch &l) {
     if (l.x2) return (A->use_diag && c->diag) ? launch_spmv_dual_diag(A, a, l.x2, l.b2, grid) : launch_spmv_dual(A, a, l.x2, l.b2, grid);
     if (c->spmv_algo != 1 && A->use_diag && c->diag) return launch_spmv_diag(A, l.epi, a, grid);
     if (c->spmv_algo != 1 && pipe_on(A)) return launch_spmv_pipe(A, l.epi, a, grid);
+    if constexpr (std::is_same<RP, int32_t>::value) {
+        if (wave_plain(A) && !l.yinit) return launch_spmv_wave(A, l.epi, a, grid);
+    }
     return launch_spmv_stream(A, l.epi, a, grid);   // (also the one-lane-per-row baseline, SLA_SPMV_ALGO=scalar)
 }
 

@@ -1,0 +1,175 @@
+// sla_spmv_wave.hip -- the plain CSR (#>) (f64 values + i32 columns, Data/Sparse/Common.hs:242-260) with WAVEFRONT-PRIVATE row
+// blocks and ROW-PAIR stores (round 4).  Same bytes as spmv_stream_kernel, another structure:
+//
+//   * a block is 128 consecutive rows and belongs to ONE wavefront: its own LDS stage, its own pipeline, no workgroup barrier
+//     anywhere in the walk (round 3's probe: the skeleton with wavefront-private blocks ran 5 % faster than the workgroup-level one);
+//   * the block's entries go through LDS in chunks of 128 x PPL entries: every lane streams PPL PAIRS of consecutive entries per
+//     chunk (one 8-byte column load and one 16-byte value load per pair, lane-strided: coalesced 512 B / 1 KiB wave-instructions),
+//     gathers x, and stages the products;
+//   * the fold is one lane per row, rows t and t + 64 of the block on lane t (neighbouring lanes read neighbouring rows' products:
+//     the LDS access pattern of the lane-per-row fold of spmv_stream_kernel), ascending, one product at a time with FMA contraction
+//     off in the sum -- the reference's left fold bit for bit, whatever the row length (a row may span chunks: the lane's running
+//     sum continues);
+//   * the 128 row sums are then turned into ROW PAIRS through the wave's LDS stage (lane u: rows 2u, 2u + 1) and leave through the
+//     pair epilogue of the wave-sliced kernels (wd_epilogue): ONE 16-byte y store and one 16-byte load per epilogue operand per lane
+//     -- the y store was the expensive stream of the CSR-stream kernel (80 MB of 8-byte stores = 34 % of its time, DESIGN.md
+//     section 4), and 16 bytes per lane is what the vector kernels run at 10.6 B/clk/CU with.
+//
+// Taken for matrices with 32-bit row pointers whose longest row has <= kWvMaxRow entries (one lane folds a row: long rows belong
+// to the segment / wavefront / workgroup reductions of spmv_stream_kernel, which stays the general kernel).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+
+#include "sla_internal.hpp"
+#include "sla_device.hpp"
+
+namespace sla {
+
+typedef int wv_i32x2 __attribute__((ext_vector_type(2)));
+typedef double wv_f64x2 __attribute__((ext_vector_type(2)));
+
+template <int EPI, int PPL, int OCC>
+__global__ void __launch_bounds__(kBlock, OCC)
+spmv_wave_kernel(SpmvArgs<int32_t> a, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col, const double *__restrict__ val,
+                 const double *__restrict__ xg, int nblk, int xcd_remap, int nt) {
+    constexpr int CH = 128 * PPL;                       // entries per chunk
+    __shared__ double s_prod[kBlock / 64][CH];
+    __shared__ double s_red[4];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    double coef;
+    if (!spmv_prologue<EPI, int32_t>(a, s_red, coef)) return;
+    double acc1 = 0.0, acc2 = 0.0;
+    double *prod = s_prod[wave];
+    // the blocks of this wavefront: XCD x (workgroups b with b % 8 == x) takes the x-th contiguous eighth of the blocks, the four
+    // wavefronts of a workgroup neighbouring blocks, so that each private L2 sees one sliding window of x
+    const int G = (int)gridDim.x;
+    int first, step, last;
+    if (xcd_remap && (G & 7) == 0 && nblk >= 4 * G) {
+        const int xcd = (int)blockIdx.x & 7, per = (nblk + 7) >> 3;
+        first = xcd * per + ((int)blockIdx.x >> 3) * (kBlock / 64) + wave;
+        step = (G >> 3) * (kBlock / 64);
+        last = min((xcd + 1) * per, nblk);
+    } else {
+        first = (int)blockIdx.x * (kBlock / 64) + wave;
+        step = G * (kBlock / 64);
+        last = nblk;
+    }
+    constexpr bool kUsesW = EPI == EPI_DOT || EPI == EPI_DOT2 || EPI == EPI_DOT4 || EPI == EPI_RES || EPI == EPI_SUB || EPI == EPI_AXPY_DOT;
+    constexpr bool kUsesZ = EPI == EPI_DOT4 || EPI == EPI_AXPY_DOT || EPI == EPI_XPBY_NRM;
+    const bool w_nt = nt && a.w != xg, z_nt = nt && (const double *)a.z != xg;
+    for (int blk = first; blk < last; blk += step) {
+        const int r0 = blk * 128;
+        // (rowptr carries 192 entries of padding = nnz behind its rows + 1 entries: every index below is readable and rows past the
+        // end of the matrix are empty)
+        const int k0 = rowptr[r0], k1 = rowptr[r0 + 128];
+        const int sa = rowptr[r0 + lane], sb = rowptr[r0 + 64 + lane];
+        const int prow = r0 + 2 * lane;                   // this lane's row PAIR in the epilogue
+        wv_f64x2 wv = {0.0, 0.0}, zv = {0.0, 0.0};
+        if constexpr (kUsesW) {
+            if (EPI != EPI_AXPY_DOT || a.w)
+                wv = w_nt ? __builtin_nontemporal_load((const wd_f64x2u *)(a.w + min(prow, a.rows - 1))) : *(const wd_f64x2u *)(a.w + min(prow, a.rows - 1));
+        }
+        if constexpr (kUsesZ) zv = z_nt ? __builtin_nontemporal_load((const wd_f64x2u *)(a.z + min(prow, a.rows - 1))) : *(const wd_f64x2u *)(a.z + min(prow, a.rows - 1));
+        // row ends: the next lane's start; lane 63's rows end where rows 64 / 128 of the block start
+        int ea = __shfl_down(sa, 1, 64), eb = __shfl_down(sb, 1, 64);
+        if (lane == 63) {
+            ea = __builtin_amdgcn_readfirstlane(sb);
+            eb = k1;
+        }
+        double ya = 0.0, yb = 0.0;
+        for (int kb = k0 & ~1;; kb += CH) {               // chunks: entries [kb, kb + CH) of the (even-aligned) stream
+            const int kend = min(kb + CH, k1);
+            const int kmax = max(0, (kend - 1) & ~1);     // last pair that holds a valid entry (clamp: loads are unconditional)
+            wv_i32x2 cc[PPL];
+            wv_f64x2 vv[PPL];
+#pragma unroll
+            for (int j = 0; j < PPL; ++j) cc[j] = __builtin_nontemporal_load((const wv_i32x2 *)(col + min(kb + 2 * lane + 128 * j, kmax)));
+#pragma unroll
+            for (int j = 0; j < PPL; ++j) vv[j] = __builtin_nontemporal_load((const wv_f64x2 *)(val + min(kb + 2 * lane + 128 * j, kmax)));
+            double xa[PPL], xb[PPL];
+#pragma unroll
+            for (int j = 0; j < PPL; ++j) {
+                xa[j] = xg[cc[j].x];
+                xb[j] = xg[cc[j].y];
+            }
+#pragma unroll
+            for (int j = 0; j < PPL; ++j) {
+                wv_f64x2 p;
+                p.x = vv[j].x * xa[j];
+                p.y = vv[j].y * xb[j];
+                *(wv_f64x2 *)(prod + 2 * lane + 128 * j) = p;
+            }
+            {   // one lane per row, ascending, one product at a time: the reference's left fold (the products are rounded, the sum adds them)
+                const int la = max(sa, kb) - kb, ha = min(ea, kend) - kb;
+                for (int k = la; k < ha; ++k) ya += prod[k];
+                const int lb = max(sb, kb) - kb, hb = min(eb, kend) - kb;
+                for (int k = lb; k < hb; ++k) yb += prod[k];
+            }
+            if (kb + CH >= k1) break;
+        }
+        // rows (t, t + 64) per lane -> row pairs (2u, 2u + 1) per lane through the wave's stage (in order behind the fold's reads)
+        prod[lane] = ya;
+        prod[64 + lane] = yb;
+        const wv_f64x2 yp = *(const wv_f64x2 *)(prod + 2 * lane);
+        if (prow < a.rows) wd_epilogue<EPI>(a, prow, prow + 1 < a.rows, yp.x, yp.y, wv, zv, coef, acc1, acc2);
+    }
+    if constexpr (EPI == EPI_DOT || EPI == EPI_DOT2 || EPI == EPI_DOT4 || EPI == EPI_RES || EPI == EPI_AXPY_DOT || EPI == EPI_XPBY_NRM) {
+        const double s1 = block_sum(acc1, s_red);
+        if (tid == 0) a.p1[blockIdx.x] = s1;
+    }
+    if constexpr (EPI == EPI_DOT2 || EPI == EPI_DOT4) {
+        const double s2 = block_sum(acc2, s_red);
+        if (tid == 0) a.p2[blockIdx.x] = s2;
+    }
+    spmv_extra_partials<EPI>(a, s_red, tid);
+}
+
+bool wave_on(const sla_csr *A) {
+    const sla_ctx *c = A->ctx;
+    return c->stream_wave > 0 && !A->rp64 && A->rows > 0 && A->max_row_nnz <= kWvMaxRow && c->spmv_algo == 0;
+}
+// entry pairs per lane and chunk: 4 (4 KiB of LDS per wavefront, 8 workgroups per CU) or 7 (7 KiB, 5 per CU: a 128-row block of a
+// 7-entries-per-row matrix is ONE chunk)
+static int wave_ppl(const sla_csr *A) {
+    if (A->ctx->stream_wave == 4 || A->ctx->stream_wave == 7) return A->ctx->stream_wave;
+    return 4;
+}
+int wave_grid(const sla_csr *A) {
+    const int64_t nblk = (A->rows + 127) / 128;
+    const int occ = wave_ppl(A) == 7 ? 5 : 8;
+    int64_t g = std::min<int64_t>((nblk + 3) / 4, (int64_t)occ * A->ctx->n_cu);
+    g = std::min<int64_t>(g, A->ctx->spmv_grid_max);
+    if (g >= 8) g &= ~7;                                // a multiple of 8: one share per XCD
+    return (int)std::max<int64_t>(1, g);
+}
+
+template <int EPI>
+static int launch_wave_t(const sla_csr *A, const SpmvArgs<int32_t> &a, int grid) {
+    sla_ctx *c = A->ctx;
+    const int nblk = (int)((A->rows + 127) / 128);
+    const int nt = vec_stream_nt(c, A->rows) ? 1 : 0;
+    if (wave_ppl(A) == 7)
+        hipLaunchKernelGGL((spmv_wave_kernel<EPI, 7, 5>), dim3(grid), dim3(kBlock), 0, stream_of(c), a, a.rowptr, a.col, a.val, a.x, nblk, c->xcd_remap, nt);
+    else
+        hipLaunchKernelGGL((spmv_wave_kernel<EPI, 4, 8>), dim3(grid), dim3(kBlock), 0, stream_of(c), a, a.rowptr, a.col, a.val, a.x, nblk, c->xcd_remap, nt);
+    SLA_HIP_TRY(hipGetLastError());
+    return SLA_OK;
+}
+
+int launch_spmv_wave(const sla_csr *A, int epi, const SpmvArgs<int32_t> &a, int grid) {
+    switch (epi) {
+        case EPI_NONE: return launch_wave_t<EPI_NONE>(A, a, grid);
+        case EPI_DOT: return launch_wave_t<EPI_DOT>(A, a, grid);
+        case EPI_DOT2: return launch_wave_t<EPI_DOT2>(A, a, grid);
+        case EPI_DOT4: return launch_wave_t<EPI_DOT4>(A, a, grid);
+        case EPI_RES: return launch_wave_t<EPI_RES>(A, a, grid);
+        case EPI_AXPY_DOT: return launch_wave_t<EPI_AXPY_DOT>(A, a, grid);
+        case EPI_XPBY_NRM: return launch_wave_t<EPI_XPBY_NRM>(A, a, grid);
+        case EPI_SUB: return launch_wave_t<EPI_SUB>(A, a, grid);
+    }
+    return fail(SLA_ERR_INVALID, "launch_spmv_wave: unknown epilogue");
+}
+
+}  // namespace sla

@@ -154,7 +154,7 @@ def test_panel_passes_of_the_overlapped_allgather_on_one_rank(sla, ranks, rank, 
         x = np.random.default_rng(9).standard_normal(n)
         yo = orc.spmv(Ao, x)
         for order in (0, 1):
-            ctx = sla.Context(0).set_options(tile_shift=shift, ag_sim_ranks=ranks, ag_sim_rank=rank, ag_groups=groups, ag_order=order)
+            ctx = sla.Context(0).set_options(tile_shift=shift, lpanel=0, ag_sim_ranks=ranks, ag_sim_rank=rank, ag_groups=groups, ag_order=order)
             A = sla.fromCSR(dims, rp, ci, va, ctx)
             info = A.kernel_info()
             visit, pptr, pneed, ng = plan_allgather_passes(ranks, rank, n, shift, groups, order)
