@@ -283,7 +283,10 @@ def side_block(name, dims, rp, ci, va, options, steps, warmup, rhs="A.1"):
     steps, warmup = max(steps, 20), max(warmup, 5)
     ctx = sla.Context(0).set_options(**options)
     n, nnz = dims[0], int(rp[-1])
+    t_low = time.perf_counter()
     A = sla.fromCSRRows(dims, 0, rp, ci, va, ctx)
+    ctx.sync()
+    t_low = time.perf_counter() - t_low
     if rhs == "A.1":
         bvec = sla.DeviceVector(ctx, n, np.add.reduceat(va, rp[:-1]), local=True)
     else:
@@ -306,10 +309,55 @@ def side_block(name, dims, rp, ci, va, options, steps, warmup, rhs="A.1"):
            "k1_ms": k1.get("ms"), "k1_gbps": k1.get("gbps"), "k1_frac": k1.get("frac"),
            "k1_csr_gbps": k1.get("effective_gbps"), "k1_csr_frac": k1.get("effective_frac"),
            "kernels": {k: {"ms": v["ms"], "frac": v["frac"]} for k, v in kt.items()},
-           "spmv_kernel": A.kernel_info()}
+           "spmv_kernel": A.kernel_info(),
+           "lowered_once": {"from_csr_s": t_low, "phases_ms": A.lower_info(), "steps_it_buys": t_low * steps / dt}}
     del st, A
     ctx.close()
     return rec
+
+
+def end_to_end_block(ctx, A, dims, rp, ci, va, b_host, t_from_csr, steady_its, with_coo):
+    """What "lowered once" costs next to the steady-state rate: seconds of sla_csr_from_csr (already spent on the
+    headline matrix: `t_from_csr`, phases as the library recorded them), of sla_csr_from_coo on the same entries in toListSM's
+    DESCENDING (row, col) order (SpMatrix.hs:251-253: what a Haskell caller's triple list looks like), and the wall-clock of one COLD
+    reference-faithful linSolve0 BICGSTAB_ through the host-array boundary: upload b and x0, solve (true residual every iteration,
+    <= 200 iterations), download x.  cold_total = lowering + that call."""
+    import sla_amd as sla
+    from sla_amd import _lib
+    import ctypes as C
+    n = dims[0]
+    out = {"workload_form": A.kernel_info().split()[0], "from_csr_s": t_from_csr, "from_csr_phases_ms": A.lower_info(),
+           "host_bytes": int(12 * rp[-1] + 8 * (n + 1))}
+    t0 = time.perf_counter()
+    bv = sla.DeviceVector(ctx, n, b_host, local=True)
+    xv = sla.DeviceVector(ctx, n, np.zeros(n), local=True)
+    ctx.sync()
+    t1 = time.perf_counter()
+    res = sla.DeviceVector(ctx, n)
+    info = _lib.SolveInfo()
+    _lib.check(_lib.lib().sla_linsolve0(4, A.h, bv.h, xv.h, None, res.h, C.byref(info)))
+    t2 = time.perf_counter()
+    xh = res.to_host()
+    t3 = time.perf_counter()
+    solve_s = t2 - t1
+    out["linsolve0"] = {"iters": info.iters, "converged": bool(info.flags & 1), "resnorm": info.resnorm, "tol": info.tol,
+                        "h2d_vectors_s": t1 - t0, "solve_s": solve_s, "iters_per_s_incl_true_residual": info.iters / solve_s if solve_s > 0 else None,
+                        "d2h_x_s": t3 - t2, "x_checksum": float(np.sum(xh))}
+    out["cold_linsolve0_s"] = t_from_csr + (t3 - t0)
+    out["cold_over_solve"] = out["cold_linsolve0_s"] / solve_s if solve_s > 0 else None
+    out["lowering_in_steady_state_steps"] = t_from_csr * steady_its
+    del bv, xv, res
+    if with_coo:
+        rows = np.repeat(np.arange(n, dtype=np.int64), np.diff(rp))[::-1].copy()
+        cols, vals = np.ascontiguousarray(ci[::-1], dtype=np.int64), np.ascontiguousarray(va[::-1])
+        t0 = time.perf_counter()
+        B = sla.fromCOO(dims, rows, cols, vals, ctx)
+        ctx.sync()
+        out["from_coo_s"] = time.perf_counter() - t0
+        out["from_coo_phases_ms"] = B.lower_info()
+        out["from_coo_form"] = B.kernel_info().split()[0]
+        del B, rows, cols, vals
+    return out
 
 
 def sharded_random_block(ctx, name, rank, world, sync_all, allreduce, steps, warmup):
@@ -412,7 +460,10 @@ def run_rank(args, rank, world, local_rank, dist_mode, loop=None):
         desc, (dims, (rp, ci, va)) = workload(args.workload, rb, re_)
     nnz_local = int(rp[-1])
     n_local = re_ - rb
+    t_lower = time.perf_counter()
     A = sla.fromCSRRows(dims, rb, rp, ci, va, ctx)
+    ctx.sync()
+    t_lower = time.perf_counter() - t_lower
     b_local = np.add.reduceat(va, rp[:-1]) if nnz_local else np.zeros(0)   # b = A . 1  (x* = 1), x0 = 0
     if len(b_local) != n_local:                                              # (rows without entries at a slab's end)
         b_local = np.resize(b_local, n_local)
@@ -650,6 +701,11 @@ def run_rank(args, rank, world, local_rank, dist_mode, loop=None):
             rec["general_csr"] = side_block(desc, dims, rp, ci, va, {"wdia": 0, "vdict": 0, "diag": 0}, bs, bw)
         except Exception as e:
             rec["general_csr"] = {"error": repr(e)}
+    if world == 1 and not args.no_extra_blocks and args.mode == "step":
+        try:
+            rec["end_to_end"] = end_to_end_block(ctx, A, dims, rp, ci, va, b_local, t_lower, rec["value"], args.workload == "laplace3d_10m")
+        except Exception as e:
+            rec["end_to_end"] = {"error": repr(e)}
     if not args.no_cpu_baseline and world == 1:
         rec["cpu_baseline"] = cpu_baseline(dims, rp, ci, va, b_local, args.cpu_seconds)
     if world == 1 and args.mode == "step" and args.method == "bicgstab" and args.workload == "laplace3d_10m" and not args.no_extra_blocks:

@@ -324,6 +324,10 @@ int sla_ctx_comm_ranks(sla_ctx_t, int *nranks);
  * 1-byte column codes), "stream[+xwin]" (values + i32 columns), "stream+ldspanels" (dense rows: x in LDS panels), "stream+colpanels" (irregular,
  * x > L2), "scalar"; row-sharded matrices add " x_exchange=window|allgather" */
 int sla_csr_kernel_info(sla_csr_t, char *buf, int buflen);
+/* What "lowered once" cost (fromListSM -> device, SpMatrix.hs:218-224): the wall-clock phases of this matrix's lowering as
+ * "phase=milliseconds;..." (validation + narrowing + upload of the canonical arrays, one analysis per storage form, the exchange plan,
+ * the tile form); bench.py reports it in its end_to_end block. */
+int sla_csr_lower_info(sla_csr_t A, char *buf, int buflen);
 
 /* ---- row-sharded exchange planning (pure host arithmetic, no GPU needed) ------------------------------ */
 

@@ -708,6 +708,16 @@ int sla_csr_from_coo(sla_ctx_t c, int64_t m, int64_t n, int64_t nnz, const int64
         if (!c || !out || (nnz > 0 && (!row || !col || !val))) return fail(SLA_ERR_INVALID, "sla_csr_from_coo: null argument");
         Bind bind(c);
         HostCsr h;
+        const auto t_begin = std::chrono::steady_clock::now();
+        double sort_ms = 0.0;
+        auto prepend_sort_time = [&](int rc) {   // the triple sort / last-wins dedupe in front of the lowering's own phases (sla_csr_lower_info)
+            if (rc == SLA_OK && *out) {
+                char buf[64];
+                snprintf(buf, sizeof(buf), "coo sort + dedupe=%.2f;", sort_ms);
+                (*out)->lower_log = std::string(buf) + (*out)->lower_log;
+            }
+            return rc;
+        };
         if (!c->collectives && nnz >= c->device_coo_min && device_coo_supported(m, n, nnz)) {
             if (m < 0 || n < 0) return fail(SLA_ERR_INVALID, "negative dimension");
             std::vector<char> oob((size_t)host_threads(), 0);
@@ -719,11 +729,13 @@ int sla_csr_from_coo(sla_ctx_t c, int64_t m, int64_t n, int64_t nnz, const int64
             if (std::find(oob.begin(), oob.end(), (char)1) != oob.end())
                 return fail(SLA_ERR_OOB, "insertSpMatrix : index out of bounds");
             SLA_TRY(device_coo_to_csr(c, m, n, nnz, row, col, val, dup_policy, h));
+            sort_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
             // already canonical by construction: skip the validation pass of sla_csr_from_csr
-            return csr_upload(c, m, n, 0, m, h.rowptr.data(), h.col.data(), h.val.data(), out);
+            return prepend_sort_time(csr_upload(c, m, n, 0, m, h.rowptr.data(), h.col.data(), h.val.data(), out));
         }
         SLA_TRY(build_csr_from_coo(m, n, nnz, row, col, val, dup_policy, h));
-        return sla_csr_from_csr(c, m, n, h.rowptr.data(), h.col.data(), h.val.data(), out);
+        sort_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+        return prepend_sort_time(sla_csr_from_csr(c, m, n, h.rowptr.data(), h.col.data(), h.val.data(), out));
     });
 }
 
@@ -749,6 +761,7 @@ int sla_csr_from_csr_rows(sla_ctx_t c, int64_t m, int64_t n, int64_t row_begin, 
         if (!c || !out || !rowptr_local || m < 0 || n < 0 || row_count < 0)
             return fail(SLA_ERR_INVALID, "sla_csr_from_csr_rows: bad argument");
         Bind bind(c);
+        const auto t_begin = std::chrono::steady_clock::now();
         int64_t b, e;
         row_range(c, m, &b, &e);
         if (row_begin != b || row_count != e - b)
@@ -773,7 +786,14 @@ int sla_csr_from_csr_rows(sla_ctx_t c, int64_t m, int64_t n, int64_t row_begin, 
         if (std::find(bad.begin(), bad.end(), 1) != bad.end()) return csr_reject(c, fail(SLA_ERR_OOB, "insertSpMatrix : index out of bounds"));
         if (std::find(bad.begin(), bad.end(), 2) != bad.end())
             return csr_reject(c, fail(SLA_ERR_INVALID, "columns must be strictly ascending inside a row (canonical CSR)"));
-        return csr_upload(c, m, n, row_begin, row_count, rowptr_local, colidx, val, out);
+        const double val_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+        const int rc = csr_upload(c, m, n, row_begin, row_count, rowptr_local, colidx, val, out);
+        if (rc == SLA_OK && *out) {
+            char buf[64];
+            snprintf(buf, sizeof(buf), "validation=%.2f;", val_ms);
+            (*out)->lower_log = std::string(buf) + (*out)->lower_log;
+        }
+        return rc;
     });
 }
 
@@ -862,6 +882,13 @@ int sla_csr_export(sla_csr_t A, int64_t *rowptr, int64_t *colidx, double *val) {
 int sla_csr_is_diagonal(sla_csr_t A, int *out) {
     if (!A || !out) return fail(SLA_ERR_INVALID, "null argument");
     *out = A->is_diagonal ? 1 : 0;
+    return SLA_OK;
+}
+
+int sla_csr_lower_info(sla_csr_t A, char *buf, int buflen) {
+    if (A && !A->kids.empty()) return sla_csr_lower_info(A->kids[0], buf, buflen);
+    if (!A || !buf || buflen <= 0) return fail(SLA_ERR_INVALID, "sla_csr_lower_info: null argument");
+    snprintf(buf, (size_t)buflen, "%s", A->lower_log.c_str());
     return SLA_OK;
 }
 

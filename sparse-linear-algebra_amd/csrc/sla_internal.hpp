@@ -394,6 +394,7 @@ struct sla_csr {
     sla::XPlan *xplan = nullptr;     // sharded only: which x entries this rank exchanges with each peer
     sla::AgPlan *ag = nullptr;       // tile form in all-gather mode: exchange groups + panel passes of the overlapped all-gather (sla_dist.cpp)
     int64_t max_row_nnz = 0;
+    std::string lower_log;           // "phase=milliseconds;..." of this matrix's lowering (csr_upload; sla_csr_lower_info)
 };
 
 struct sla_solver {

@@ -767,13 +767,17 @@ int csr_upload(sla_ctx *c, int64_t m, int64_t n, int64_t row_begin, int64_t rows
     }
     static const bool dbg_lower = getenv("SLA_DEBUG_LOWER") != nullptr;
     auto t_last = std::chrono::steady_clock::now();
-    auto lap = [&](const char *what) {
-        if (!dbg_lower || panel_view) return;
+    sla_csr *A = new sla_csr();
+    auto lap = [&](const char *what) {   // phase times: kept with the matrix (sla_csr_lower_info), printed under SLA_DEBUG_LOWER
+        if (panel_view) return;
         const auto t = std::chrono::steady_clock::now();
-        fprintf(stderr, "[sla] lowering: %-28s %7.1f ms\n", what, std::chrono::duration<double, std::milli>(t - t_last).count());
+        const double ms = std::chrono::duration<double, std::milli>(t - t_last).count();
+        char buf[96];
+        snprintf(buf, sizeof(buf), "%s=%.2f;", what, ms);
+        A->lower_log += buf;
+        if (dbg_lower) fprintf(stderr, "[sla] lowering: %-28s %7.1f ms\n", what, ms);
         t_last = t;
     };
-    sla_csr *A = new sla_csr();
     A->ctx = c;
     A->m = m;
     A->n = n;
@@ -826,8 +830,10 @@ int csr_upload(sla_ctx *c, int64_t m, int64_t n, int64_t row_begin, int64_t rows
         return rc;
     }
     A->is_diagonal = agree == 0;
+    lap("agreement");
     rc = build_xplan(A, rows, rowptr, col);
     if (rc == SLA_OK) rc = build_overlap_lists(A, m, n, row_begin, rows, rowptr, col);
+    lap("exchange plan");
     if (rc == SLA_OK) rc = build_tiles(A, n, rows, rowptr, col, val);
     lap("tile form");
     {   // (contains the ranks' agreement on the exchange pattern: every rank of a sharded context gets here, failed or not)
@@ -835,6 +841,7 @@ int csr_upload(sla_ctx *c, int64_t m, int64_t n, int64_t row_begin, int64_t rows
         if (rc == SLA_OK) rc = rc_ag;
     }
     if (rc == SLA_OK && !(A->use_lpanel && c->lpanel) && !A->use_tiles) rc = build_panels(A, m, n, row_begin, rows, rowptr, col, val);
+    lap("column panels");
     if (rc != SLA_OK) {
         sla_csr_destroy(A);
         return rc;

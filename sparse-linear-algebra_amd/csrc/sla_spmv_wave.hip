@@ -73,9 +73,10 @@ spmv_wave_kernel(SpmvArgs<int32_t> a, const int32_t *__restrict__ rowptr, const 
         }
         if constexpr (kUsesZ) zv = z_nt ? __builtin_nontemporal_load((const wd_f64x2u *)(a.z + min(prow, a.rows - 1))) : *(const wd_f64x2u *)(a.z + min(prow, a.rows - 1));
         // row ends: the next lane's start; lane 63's rows end where rows 64 / 128 of the block start
+        const int sb0 = __builtin_amdgcn_readfirstlane(sb);   // (outside the lane test: readfirstlane reads the first ACTIVE lane)
         int ea = __shfl_down(sa, 1, 64), eb = __shfl_down(sb, 1, 64);
         if (lane == 63) {
-            ea = __builtin_amdgcn_readfirstlane(sb);
+            ea = sb0;
             eb = k1;
         }
         double ya = 0.0, yb = 0.0;
@@ -101,11 +102,26 @@ spmv_wave_kernel(SpmvArgs<int32_t> a, const int32_t *__restrict__ rowptr, const 
                 p.y = vv[j].y * xb[j];
                 *(wv_f64x2 *)(prod + 2 * lane + 128 * j) = p;
             }
-            {   // one lane per row, ascending, one product at a time: the reference's left fold (the products are rounded, the sum adds them)
-                const int la = max(sa, kb) - kb, ha = min(ea, kend) - kb;
-                for (int k = la; k < ha; ++k) ya += prod[k];
-                const int lb = max(sb, kb) - kb, hb = min(eb, kend) - kb;
-                for (int k = lb; k < hb; ++k) yb += prod[k];
+            {   // one lane per row, ascending, one product at a time: the reference's left fold (the products are rounded, the sum adds them).
+                // Eight products of each of the lane's two rows are READ together (clamped addresses, all sixteen reads in flight) and then
+                // added in order under their range tests: one LDS round trip per eight entries instead of one per entry.
+                int ka = max(sa, kb) - kb, kb2 = max(sb, kb) - kb;
+                const int ha = min(ea, kend) - kb, hb = min(eb, kend) - kb;
+                while (ka < ha || kb2 < hb) {
+                    double pa[8], pb[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) pa[i] = prod[min(ka + i, CH - 1)];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) pb[i] = prod[min(kb2 + i, CH - 1)];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)
+                        if (ka + i < ha) ya += pa[i];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)
+                        if (kb2 + i < hb) yb += pb[i];
+                    ka += 8;
+                    kb2 += 8;
+                }
             }
             if (kb + CH >= k1) break;
         }

@@ -137,6 +137,7 @@ PROTOTYPES = [
     ("sla_device_count", _int, [_pint]),
     ("sla_ctx_comm_ranks", _int, [_vp, _pint]),
     ("sla_csr_kernel_info", _int, [_vp, C.c_char_p, _int]),
+    ("sla_csr_lower_info", _int, [_vp, C.c_char_p, _int]),
     ("sla_plan_window_exchange", _int, [_int, _int, _i64, _vp, _vp, _vp, _vp, _vp, _pint]),
     ("sla_plan_allgather_passes", _int, [_int, _int, _i64, _int, _int, _int, _vp, _vp, _vp, _pint, _pint]),
     ("sla_plan_allgather_groups", _int, [_int, _i64, _int, _int, _int, _vp, _int, _pint]),

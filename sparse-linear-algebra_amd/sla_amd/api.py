@@ -363,9 +363,20 @@ class SpMatrix:
         return D
 
     def kernel_info(self):
-        buf = C.create_string_buffer(512)
-        check(lib().sla_csr_kernel_info(self.h, buf, 512))
+        buf = C.create_string_buffer(1024)
+        check(lib().sla_csr_kernel_info(self.h, buf, 1024))
         return buf.value.decode()
+
+    def lower_info(self):
+        """Wall-clock phases of this matrix's lowering in milliseconds (sla_csr_lower_info): {phase: ms}."""
+        buf = C.create_string_buffer(2048)
+        check(lib().sla_csr_lower_info(self.h, buf, 2048))
+        out = {}
+        for tok in buf.value.decode().split(";"):
+            if "=" in tok:
+                k, v = tok.rsplit("=", 1)
+                out[k] = out.get(k, 0.0) + float(v)
+        return out
 
     def __eq__(self, o):                          # structural, like the derived Eq
         if not isinstance(o, SpMatrix) or self.dims != o.dims:

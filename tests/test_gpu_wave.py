@@ -58,7 +58,11 @@ def test_wave_kernel_matches_the_oracle_bit_for_bit(sla, name):
         info = A.kernel_info()
         assert info.startswith("algo=stream+wave " if wave else "algo=stream "), info
         y = sla.matVec(A, sla.fromVector(x, ctx)).toDenseListSV()
-        assert np.array_equal(y, want), (name, wave, int(np.count_nonzero(y != want)))
+        if wave:
+            assert np.array_equal(y, want), (name, wave, int(np.count_nonzero(y != want)))
+        else:   # spmv_stream_kernel reduces blocks of few long rows by wavefront segments: the rounding bound of SURVEY 8(a) A1
+            bound = np.diff(rp) * np.finfo(float).eps * orc.spmv(orc.Csr(m, n, rp, ci, np.abs(va)), np.abs(x)) + 1e-300
+            assert np.all(np.abs(y - want) <= bound), (name, float(np.abs(y - want).max()))
         got[wave] = y
         del A
         ctx.close()
