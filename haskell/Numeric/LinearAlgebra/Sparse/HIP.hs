@@ -1,4 +1,4 @@
-{-# LANGUAGE ForeignFunctionInterface, FlexibleContexts, ScopedTypeVariables #-}
+{-# LANGUAGE ForeignFunctionInterface, FlexibleContexts, ScopedTypeVariables, TypeFamilies #-}
 -- | MI355X backend for the SpMV / CGS / BiCGSTAB / Arnoldi hot path, bound through the C ABI of
 --   libsla_hip.so (include/sla_hip.h).  Re-exports the reference's names WITH THE REFERENCE'S SIGNATURES so callers only
 --   change an import:
@@ -9,12 +9,30 @@
 --     @iterate (bicgstabStep aa r0hat) s0 !! 20@ (README.md:222-226) never aliases two elements;
 --   * an 'R.SpMatrix' is lowered to its device CSR once: 'lower' memoises per heap object ('StableName').
 --
+--   Two routes onto the device (round 4):
+--
+--   * the PLAIN functions of the reference -- 'linSolve0', 'arnoldi', 'bicgsInit' / 'bicgstabStep', 'cgsInit' / 'cgsStep',
+--     'cgneInit' / 'cgneStep', 'triLowerSolve' ... -- are re-defined here on @SpMatrix Double@ / @SpVector Double@ under the same
+--     names: a caller changes an import;
+--   * the CLASS methods -- '(#>)', '(<#)', '(<.>)', 'norm2', '(<\>)' (Class.hs:81-87, 126-153, 224-229, 244-249) -- cannot be
+--     re-defined for @SpVector Double@ (the reference's own instances would overlap), so this module brings a vector type of its own,
+--     'Dev', with instances of the reference's classes: code written against the classes (@V v =>@, 'LinearSystem' ...) dispatches to
+--     the GPU when instantiated at 'Dev' ('toDev' / 'fromDev' at the boundary), and keeps running on the CPU at @SpVector Double@.
+--     The monomorphic spellings 'matVecHIP', 'vecMatHIP', 'dotHIP', 'norm2HIP', 'linSolveHIP' are the same calls without the wrapper;
+--     no name exported here shadows a class method of Numeric.LinearAlgebra.Class.
+--
 --   NOT compiled in the authoring image (no GHC there); see haskell/README.md.  The same C ABI is exercised through
 --   ctypes and the C++ mirror by the test-suite.
 module Numeric.LinearAlgebra.Sparse.HIP
-  ( linSolve0, LinSolveMethod(..), (#>), (<.>), norm2, (##), (##^), arnoldi, (<\>), triLowerSolve, triUpperSolve
+  ( -- * plain functions of the reference, same names and signatures
+    linSolve0, LinSolveMethod(..), arnoldi, triLowerSolve, triUpperSolve
   , BICGSTAB, bicgsInit, bicgstabStep, bicgstabSteps, _xBicgstab, _rBicgstab, _pBicgstab
   , CGS, cgsInit, cgsStep, cgsSteps, _x, _r, _p, _u
+  , CGNE, cgneInit, cgneStep, cgneSteps, _xCgne, _rCgne, _pCgne
+    -- * the class route: a device-dispatching vector type with the reference's instances
+  , Dev(..), toDev, fromDev
+    -- * monomorphic spellings of the class methods (no wrapper)
+  , matVecHIP, vecMatHIP, dotHIP, norm2HIP, linSolveHIP, matMatHIP, matMatTHIP
   ) where
 
 import Control.Exception (SomeException, evaluate, try)
@@ -30,7 +48,9 @@ import System.IO.Unsafe (unsafePerformIO)
 import System.Mem.StableName
 import System.Mem.Weak (mkWeakPtr)
 
+import Control.Monad.Writer.Class (MonadWriter)
 import Control.Exception.Common (IterationException (..), MatrixException (..), OperandSizeMismatch (..))
+import qualified Numeric.LinearAlgebra.Class as K    -- the reference's classes: the instances for 'Dev' are below
 import qualified Data.Sparse.Internal.IntM as I      -- keys of the row map (IntM.hs:52-53)
 import qualified Data.Sparse.SpMatrix as R
 import qualified Data.Sparse.SpVector as R
@@ -50,6 +70,7 @@ foreign import ccall safe "sla_vec_create"        c_vec_create        :: Ptr Ctx
 foreign import ccall safe "&sla_vec_destroy"      p_vec_destroy       :: FunPtr (Ptr Vec -> IO ())
 foreign import ccall safe "sla_vec_to_host"       c_vec_to_host       :: Ptr Vec -> Ptr Double -> IO CInt
 foreign import ccall safe "sla_spmv"              c_spmv              :: Ptr Csr -> Ptr Vec -> Ptr Vec -> IO CInt
+foreign import ccall safe "sla_spmv_t"            c_spmv_t            :: Ptr Csr -> Ptr Vec -> Ptr Vec -> IO CInt
 foreign import ccall safe "sla_dot"               c_dot               :: Ptr Vec -> Ptr Vec -> Ptr Double -> IO CInt
 foreign import ccall safe "sla_nrm2"              c_nrm2              :: Ptr Vec -> Ptr Double -> IO CInt
 foreign import ccall safe "sla_solver_init"       c_solver_init       :: CInt -> Ptr Csr -> Ptr Vec -> Ptr Vec -> Ptr (Ptr Solver) -> IO CInt
@@ -163,8 +184,8 @@ linSolve0 method aa b x0 = pureThrow $ do
 
 -- | (#>) (Common.hs:242-250): the result holds a key for every row present in the matrix and no others.  The present
 --   rows come out of the row map's keys in ascending order (O(rows)); the dense device result is walked once beside them.
-(#>) :: R.SpMatrix Double -> R.SpVector Double -> R.SpVector Double
-aa #> x = unsafePerformIO $ do
+matVecHIP :: R.SpMatrix Double -> R.SpVector Double -> R.SpVector Double
+matVecHIP aa x = unsafePerformIO $ do
   a <- lower aa; vx <- upload x; vy <- zeros (R.nrows aa)
   withForeignPtr a $ \pa -> withForeignPtr vx $ \px -> withForeignPtr vy $ \py -> c_spmv pa px py >>= check "matVec"
   ys <- downloadList (R.nrows aa) vy
@@ -174,19 +195,30 @@ aa #> x = unsafePerformIO $ do
                                   | otherwise = pick (k : ks) rest
     pick _ _ = []
 
-(<.>) :: R.SpVector Double -> R.SpVector Double -> Double
-v <.> w = unsafePerformIO $ do
+-- | (<#) = vecMatSD (Common.hs:253-256): @v <# aa@ = transpose aa #> v, without materialising the transpose on the host (the
+--   library builds the device transpose of a lowered matrix once, lazily); a key for every COLUMN present in the matrix
+vecMatHIP :: R.SpVector Double -> R.SpMatrix Double -> R.SpVector Double
+vecMatHIP v aa = unsafePerformIO $ do
+  a <- lower aa; vx <- upload v; vy <- zeros (R.ncols aa)
+  withForeignPtr a $ \pa -> withForeignPtr vx $ \px -> withForeignPtr vy $ \py -> c_spmv_t pa px py >>= check "vecMat"
+  ys <- downloadList (R.ncols aa) vy
+  let present = IM.keysSet (IM.unions [IM.fromList [(j, ()) | (_, j, _) <- R.toListSM aa]])
+  return (R.fromListSV (R.ncols aa) [(j, y) | (j, y) <- zip [0 ..] ys, j `IM.member` IM.fromSet (const ()) present])
+
+dotHIP :: R.SpVector Double -> R.SpVector Double -> Double
+dotHIP v w = unsafePerformIO $ do
   a <- upload v; b <- upload w
   withForeignPtr a $ \pa -> withForeignPtr b $ \pb -> alloca $ \out -> c_dot pa pb out >>= check "<.>" >> peek out
 
-norm2 :: R.SpVector Double -> Double
-norm2 v = unsafePerformIO $ upload v >>= \a -> withForeignPtr a $ \pa -> alloca $ \out -> c_nrm2 pa out >>= check "norm2" >> peek out
+norm2HIP :: R.SpVector Double -> Double
+norm2HIP v = unsafePerformIO $ upload v >>= \a -> withForeignPtr a $ \pa -> alloca $ \out -> c_nrm2 pa out >>= check "norm2" >> peek out
 
 -- | (##) / (##^) (matMat_ AB / ABt, SpMatrix.hs:768-811): structurally dense over present rows x present columns; a size
 --   mismatch is the reference's @error "matMat : incompatible matrix sizes"@
-(##), (##^) :: R.SpMatrix Double -> R.SpMatrix Double -> R.SpMatrix Double
-(##) = matMatWith 0
-(##^) = matMatWith 1
+--   (class methods of MatrixRing on @SpMatrix Double@ in the reference: bound here under monomorphic names)
+matMatHIP, matMatTHIP :: R.SpMatrix Double -> R.SpMatrix Double -> R.SpMatrix Double
+matMatHIP = matMatWith 0
+matMatTHIP = matMatWith 1
 
 matMatWith :: CInt -> R.SpMatrix Double -> R.SpMatrix Double -> R.SpMatrix Double
 matMatWith tb m1 m2 = unsafePerformIO $ do
@@ -257,6 +289,70 @@ cgsSteps k (CGS (fs, n)) = CGS (steppedCopy "cgsStep" Nothing k fs, n)
 _x, _r, _p, _u :: CGS -> R.SpVector Double
 _x (CGS s) = field 0 s; _r (CGS s) = field 1 s; _p (CGS s) = field 2 s; _u (CGS s) = field 3 s
 
+-- | CGNE (Sparse.hs:855-878): conjugate gradient on the normal equations.  The reference re-transposes the matrix in every step
+--   (@transpose aa #> r@, :878); the device state keeps the lowered transpose.
+newtype CGNE = CGNE (ForeignPtr Solver, Int)
+
+cgneInit :: R.SpMatrix Double -> R.SpVector Double -> R.SpVector Double -> CGNE
+cgneInit aa b x0 = CGNE (unsafePerformIO (initWith 1 aa b x0), R.ncols aa)
+
+-- | cgneStep aa state (Sparse.hs:870-878): a NEW record
+cgneStep :: R.SpMatrix Double -> CGNE -> CGNE
+cgneStep _aa (CGNE (fs, n)) = CGNE (steppedCopy "cgneStep" Nothing 1 fs, n)
+
+cgneSteps :: Int -> CGNE -> CGNE
+cgneSteps k (CGNE (fs, n)) = CGNE (steppedCopy "cgneStep" Nothing k fs, n)
+
+_xCgne, _rCgne, _pCgne :: CGNE -> R.SpVector Double
+_xCgne (CGNE s) = field 0 s; _rCgne (CGNE s) = field 1 s; _pCgne (CGNE s) = field 2 s
+
+-- ---------------------------------------------------------------------------------------------------------------------------
+-- The class route.  'Dev' wraps the reference's own sparse vector; its instances of the reference's classes send the heavy methods
+-- to the device and leave the O(n) structural algebra ((^+^), (.*): unions of key sets, Class.hs:57-78 / SpVector.hs:107-114) to
+-- the reference's host code, so that structural equality and 'Show' of results stay what they are on the CPU path.
+-- (A @newtype@ because @instance LinearVectorSpace (SpVector Double)@ exists in the reference, Common.hs:242-245.)
+-- ---------------------------------------------------------------------------------------------------------------------------
+newtype Dev = Dev { unDev :: R.SpVector Double } deriving (Eq, Show)
+
+toDev :: R.SpVector Double -> Dev
+toDev = Dev
+
+fromDev :: Dev -> R.SpVector Double
+fromDev = unDev
+
+instance K.AdditiveGroup Dev where
+  zeroV = Dev K.zeroV
+  Dev a ^+^ Dev b = Dev (a K.^+^ b)
+  negateV (Dev a) = Dev (K.negateV a)
+  Dev a ^-^ Dev b = Dev (a K.^-^ b)          -- x ^+^ negateV y, like the class default (Class.hs:69)
+
+instance K.VectorSpace Dev where
+  type Scalar Dev = Double
+  s .* Dev a = Dev (s K..* a)
+
+instance K.InnerSpace Dev where
+  Dev a <.> Dev b = dotHIP a b                -- (<.>), Class.hs:81-83
+
+instance K.Normed Dev where
+  type Magnitude Dev = Double
+  type RealScalar Dev = Double
+  norm1 (Dev a) = K.norm1 a
+  norm2Sq (Dev a) = let t = norm2HIP a in t * t
+  normP p (Dev a) = K.normP p a
+  normalize p (Dev a) = Dev (K.normalize p a)
+  normalize2 (Dev a) = Dev ((1 / norm2HIP a) K..* a)   -- normalize2 v = (1 / norm2 v) .* v  (SpVector.hs:127-129)
+  norm2 (Dev a) = norm2HIP a
+
+instance K.LinearVectorSpace Dev where
+  type MatrixType Dev = R.SpMatrix Double
+  aa #> Dev x = Dev (matVecHIP aa x)          -- Class.hs:224-229
+  Dev x <# aa = Dev (vecMatHIP x aa)
+
+-- | the class's own signature: @(MonadThrow m, MonadWriter w m) => MatrixType v -> v -> m v@ (Class.hs:244-249).  The writer is
+--   not written to (the reference's dead instance, Sparse.hs:1080-1088, logs nothing either).
+instance K.LinearSystem Dev where
+  aa <\> Dev b = Dev <$> linSolveHIP aa b
+
 -- | arnoldi (Sparse.hs:630-667): Q n x (k+1), H (k+1) x k
 arnoldi :: MonadThrow m => R.SpMatrix Double -> R.SpVector Double -> Int -> m (R.SpMatrix Double, R.SpMatrix Double)
 arnoldi aa b kn = pureThrow $ do
@@ -271,9 +367,9 @@ arnoldi aa b kn = pureThrow $ do
       return ( R.fromListDenseSM n q
              , R.fromListSM (k + 1, k) [(i, j, h !! (j * (kn + 1) + i)) | j <- [0 .. k - 1], i <- [0 .. j + 1]] )
 
--- | (<\>) (Class.hs:244-249) as the dead instance defined it (Sparse.hs:1080-1084)
-(<\>) :: MonadThrow m => R.SpMatrix Double -> R.SpVector Double -> m (R.SpVector Double)
-aa <\> b = pureThrow $ do
+-- | (<\>) (Class.hs:244-249) as the dead instance defined it (Sparse.hs:1080-1084): GMRES from x0 = 0.1 * ones
+linSolveHIP :: MonadThrow m => R.SpMatrix Double -> R.SpVector Double -> m (R.SpVector Double)
+linSolveHIP aa b = pureThrow $ do
   a <- lower aa; vb <- upload b; vo <- zeros (R.ncols aa)
   withForeignPtr a $ \pa -> withForeignPtr vb $ \pb -> withForeignPtr vo $ \po -> c_linsolve pa pb po nullPtr >>= check "<\\>"
   download (R.ncols aa) vo

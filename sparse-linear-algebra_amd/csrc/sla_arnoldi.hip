@@ -18,6 +18,7 @@ namespace sla {
 // 2-D grid: blockIdx.y selects a group of NC = 4 columns.  One workgroup streaming all (up to 32) columns at once reads
 // the basis at 4.6 TB/s; four columns per workgroup (w re-read per group, from the caches) 6980 instead of 6520 Arnoldi
 // steps/s on the 2 M-row banded problem (groups of 2 / 8 / 16: 6930 / 6940 / 6670).
+constexpr int kArnDotsGroup = 4;   // basis columns per workgroup of the dots pass
 template <int NC>
 __global__ void __launch_bounds__(kBlock) arn_dots_kernel(int64_t n, const double *Q, int64_t ldq, int ncols,
                                                            const double *w, double *parts, SolverScalars *sc) {
@@ -68,11 +69,32 @@ __global__ void __launch_bounds__(kBlock) arn_update_kernel(int64_t n, const dou
     __shared__ double s_red[4];
     if (arn_stopped(sc)) return;
     // every workgroup re-reduces the ncols dot products in the same fixed order
-    for (int j = threadIdx.x >> 6; j < ncols; j += 4) {
-        double a = 0.0;
-        for (int i = threadIdx.x & 63; i < np; i += 64) a += hp[(int64_t)j * cs + (int64_t)i * stride];
-        a = wave_sum(a);
-        if ((threadIdx.x & 63) == 0) s_h[j] = a;
+    if (stride == 1 && (np & 63) == 0 && ((ncols + 3) >> 2) * (np >> 6) <= 16) {
+        // the dots pass's own partials (single-rank contexts, round 4: no fold launch in between; arn_dots_grid sizes the pass so that
+        // a wavefront's columns x partials fit sixteen loads per lane): ALL of them issued before the first add -- one round trip at the
+        // head of the kernel, not one per column -- then per column the same order as the generic loop below: lane sums, wave_sum
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, M = np >> 6;
+        double v[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const int j = wave + 4 * (t / M), m = t - (t / M) * M;
+            v[t] = j < ncols && t / M < 16 ? hp[(int64_t)min(j, ncols - 1) * cs + lane + 64 * m] : 0.0;
+        }
+        for (int jj = 0; wave + 4 * jj < ncols; ++jj) {
+            double a = 0.0;
+#pragma unroll
+            for (int t = 0; t < 16; ++t)
+                if (t / M == jj) a += v[t];
+            a = wave_sum(a);
+            if (lane == 0) s_h[wave + 4 * jj] = a;
+        }
+    } else {
+        for (int j = threadIdx.x >> 6; j < ncols; j += 4) {
+            double a = 0.0;
+            for (int i = threadIdx.x & 63; i < np; i += 64) a += hp[(int64_t)j * cs + (int64_t)i * stride];
+            a = wave_sum(a);
+            if ((threadIdx.x & 63) == 0) s_h[j] = a;
+        }
     }
     __syncthreads();
     double h[NC];
@@ -161,7 +183,6 @@ __global__ void __launch_bounds__(kBlock) gemv_accum_kernel(int64_t n, const dou
     }
 }
 
-constexpr int kArnDotsGroup = 4;   // basis columns per workgroup of the dots pass
 int arn_grid(int64_t n) {
     int g = vec_grid(n);
     return g > kArnGridMax ? kArnGridMax : g;
@@ -177,9 +198,18 @@ int arn_grid(int64_t n) {
         else return fail(SLA_ERR_INVALID, "Krylov basis > 64 columns"); \
     } while (0)
 
+// x-grid (= partials per column) of the dots pass.  Its 2-D grid has ceil(ncols / 4) column groups, so the chip is filled with ~1024
+// workgroups in all when x = 64 floor(16 / groups): and then the update pass can fold the partials of its wavefronts' columns itself with
+// sixteen loads per lane (arn_update_kernel's head) instead of behind a one-workgroup fold launch (round 4: a 4.8 us launch and a
+// dependent dispatch less per Arnoldi step).
+int arn_dots_grid(int64_t n, int ncols) {
+    const int g = arn_grid(n), groups = (ncols + kArnDotsGroup - 1) / kArnDotsGroup;
+    const int gx = 64 * std::max(1, 16 / groups);
+    return g < 64 ? g : std::min(g & ~63, gx);
+}
 int launch_arn_dots(sla_ctx *c, int64_t n, const double *Q, int64_t ldq, int ncols, const double *w, double *parts,
                     SolverScalars *sc) {
-    const int g = arn_grid(n);
+    const int g = arn_dots_grid(n, ncols);
     if (ncols < 1 || ncols > 64) return fail(SLA_ERR_INVALID, "Krylov basis: 1..64 columns");
     hipLaunchKernelGGL((arn_dots_kernel<kArnDotsGroup>), dim3(g, (ncols + kArnDotsGroup - 1) / kArnDotsGroup), dim3(kBlock), 0, stream_of(c),
                        n, Q, ldq, ncols, w, parts, sc);

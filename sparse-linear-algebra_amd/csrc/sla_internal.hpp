@@ -746,7 +746,8 @@ int launch_init_scalars(sla_ctx *c, SolverScalars *sc, Parts rho, Parts r0sq, do
 int launch_set_rho(sla_ctx *c, SolverScalars *sc, Parts rho, int par);   // sc->rho2[par] = sum(rho)
 // Arnoldi (Sparse.hs:630-667); Q column-major with leading dimension ldq
 int launch_arn_dots(sla_ctx *c, int64_t n, const double *Q, int64_t ldq, int ncols, const double *w, double *parts, SolverScalars *sc);
-int arn_grid(int64_t n);  // grid (= partials per column) of the Arnoldi kernels
+int arn_grid(int64_t n);  // grid (= partials per column) of the Arnoldi update / normalise kernels
+int arn_dots_grid(int64_t n, int ncols);   // ... of the dots pass over ncols basis columns
 // partial i of column j lives at hp[j * cs + i * stride], i < np
 int launch_arn_update(sla_ctx *c, int64_t n, const double *Q, int64_t ldq, int ncols, const double *hp, int np, int cs,
                       int stride, double *w, double *pn, double *Hcol, SolverScalars *sc);

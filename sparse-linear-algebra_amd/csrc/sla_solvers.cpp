@@ -621,6 +621,12 @@ int arn_publish(ArnoldiWs &ws, const double *parts, int np, int ncols, ColParts 
         *out = ColParts{parts, np, np, 1};
         return SLA_OK;
     }
+    // the dots pass's partials on a single-rank context: arn_update_kernel folds its wavefronts' columns itself (sixteen loads per
+    // lane, all in flight at once; arn_dots_grid sized the pass for it) -- the fold launch and its dependent dispatch are saved
+    if (!c->collectives && (np & 63) == 0 && ((ncols + 3) / 4) * (np / 64) <= 16) {
+        *out = ColParts{parts, np, np, 1};
+        return SLA_OK;
+    }
     // one tiny launch folds the per-workgroup partials to ncols values, so that the producers can use a
     // chip-filling grid without every consumer workgroup re-reducing ncols x grid partials
     double *loc = ws.gath + (size_t)(kMaxKrylov + 2) * c->nranks;
@@ -668,7 +674,7 @@ int arn_run(ArnoldiWs &ws, sla_csr *A, const double *src_local, int kn, int *k_d
         }
         // hhcoli = fmap (`dot` aqi) qv
         SLA_TRY(launch_arn_dots(c, n, ws.Q, ws.ld, i + 1, ws.w, ws.parts, ws.d_sc));
-        SLA_TRY(arn_publish(ws, ws.parts, g, i + 1, &cp));
+        SLA_TRY(arn_publish(ws, ws.parts, arn_dots_grid(n, i + 1), i + 1, &cp));
         // qipnn = aqi ^-^ sum_k h_k q_k ; partial ||qipnn||^2 ; H[0..i, i]
         double *pn = ws.parts + (size_t)kMaxKrylov * kArnGridMax;
         SLA_TRY(launch_arn_update(c, n, ws.Q, ws.ld, i + 1, cp.p, cp.np, cp.cs, cp.stride, ws.w, pn,
