@@ -29,7 +29,24 @@ namespace sla {
 typedef int wv_i32x2 __attribute__((ext_vector_type(2)));
 typedef double wv_f64x2 __attribute__((ext_vector_type(2)));
 
-template <int EPI, int PPL, int OCC>
+template <int PPL>
+struct WvChunk {
+    wv_i32x2 cc[PPL];
+    wv_f64x2 vv[PPL];
+};
+// the streaming loads of the chunk [kb, kb + 128 PPL) of a block whose entries end at k1 (clamped, unconditional)
+template <int PPL>
+__device__ __forceinline__ void wv_load(WvChunk<PPL> &c, const int32_t *__restrict__ col, const double *__restrict__ val, int kb, int k1, int lane) {
+    const int kmax = max(0, (min(kb + 128 * PPL, k1) - 1) & ~1);     // last pair that holds a valid entry
+#pragma unroll
+    for (int j = 0; j < PPL; ++j) c.cc[j] = __builtin_nontemporal_load((const wv_i32x2 *)(col + min(kb + 2 * lane + 128 * j, kmax)));
+#pragma unroll
+    for (int j = 0; j < PPL; ++j) c.vv[j] = __builtin_nontemporal_load((const wv_f64x2 *)(val + min(kb + 2 * lane + 128 * j, kmax)));
+}
+
+// PRE: the streams of the NEXT chunk (of this block or of the wavefront's next block) are issued before the current chunk is folded
+// (a second register set: fewer wavefronts per CU, more bytes in flight per wavefront)
+template <int EPI, int PPL, int OCC, bool PRE>
 __global__ void __launch_bounds__(kBlock, OCC)
 spmv_wave_kernel(SpmvArgs<int32_t> a, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col, const double *__restrict__ val,
                  const double *__restrict__ xg, int nblk, int xcd_remap, int nt) {
@@ -59,11 +76,26 @@ spmv_wave_kernel(SpmvArgs<int32_t> a, const int32_t *__restrict__ rowptr, const 
     constexpr bool kUsesW = EPI == EPI_DOT || EPI == EPI_DOT2 || EPI == EPI_DOT4 || EPI == EPI_RES || EPI == EPI_SUB || EPI == EPI_AXPY_DOT;
     constexpr bool kUsesZ = EPI == EPI_DOT4 || EPI == EPI_AXPY_DOT || EPI == EPI_XPBY_NRM;
     const bool w_nt = nt && a.w != xg, z_nt = nt && (const double *)a.z != xg;
+    WvChunk<PPL> cur;
+    int nk0 = 0, nk1 = 0;                                   // PRE: entry range of the block whose first chunk `cur` holds
+    if constexpr (PRE) {
+        if (first < last) {
+            nk0 = rowptr[first * 128];
+            nk1 = rowptr[first * 128 + 128];
+            wv_load<PPL>(cur, col, val, nk0 & ~1, nk1, lane);
+        }
+    }
+    const bool st_nt = (nt & 2) != 0;
     for (int blk = first; blk < last; blk += step) {
         const int r0 = blk * 128;
         // (rowptr carries 192 entries of padding = nnz behind its rows + 1 entries: every index below is readable and rows past the
         // end of the matrix are empty)
-        const int k0 = rowptr[r0], k1 = rowptr[r0 + 128];
+        const int k0 = PRE ? nk0 : rowptr[r0], k1 = PRE ? nk1 : rowptr[r0 + 128];
+        if constexpr (PRE) {                                // the next block's range: a scalar load issued a whole block early
+            const int bn = min(blk + step, last - 1);
+            nk0 = rowptr[bn * 128];
+            nk1 = rowptr[bn * 128 + 128];
+        }
         const int sa = rowptr[r0 + lane], sb = rowptr[r0 + 64 + lane];
         const int prow = r0 + 2 * lane;                   // this lane's row PAIR in the epilogue
         wv_f64x2 wv = {0.0, 0.0}, zv = {0.0, 0.0};
@@ -82,26 +114,26 @@ spmv_wave_kernel(SpmvArgs<int32_t> a, const int32_t *__restrict__ rowptr, const 
         double ya = 0.0, yb = 0.0;
         for (int kb = k0 & ~1;; kb += CH) {               // chunks: entries [kb, kb + CH) of the (even-aligned) stream
             const int kend = min(kb + CH, k1);
-            const int kmax = max(0, (kend - 1) & ~1);     // last pair that holds a valid entry (clamp: loads are unconditional)
-            wv_i32x2 cc[PPL];
-            wv_f64x2 vv[PPL];
-#pragma unroll
-            for (int j = 0; j < PPL; ++j) cc[j] = __builtin_nontemporal_load((const wv_i32x2 *)(col + min(kb + 2 * lane + 128 * j, kmax)));
-#pragma unroll
-            for (int j = 0; j < PPL; ++j) vv[j] = __builtin_nontemporal_load((const wv_f64x2 *)(val + min(kb + 2 * lane + 128 * j, kmax)));
+            if constexpr (!PRE) wv_load<PPL>(cur, col, val, kb, k1, lane);
             double xa[PPL], xb[PPL];
 #pragma unroll
             for (int j = 0; j < PPL; ++j) {
-                xa[j] = xg[cc[j].x];
-                xb[j] = xg[cc[j].y];
+                xa[j] = xg[cur.cc[j].x];
+                xb[j] = xg[cur.cc[j].y];
+            }
+            WvChunk<PPL> nxt;
+            if constexpr (PRE) {                            // next chunk of this block, else the first chunk of the wavefront's next block
+                const bool more = kb + CH < k1;
+                wv_load<PPL>(nxt, col, val, more ? kb + CH : (nk0 & ~1), more ? k1 : nk1, lane);
             }
 #pragma unroll
             for (int j = 0; j < PPL; ++j) {
                 wv_f64x2 p;
-                p.x = vv[j].x * xa[j];
-                p.y = vv[j].y * xb[j];
+                p.x = cur.vv[j].x * xa[j];
+                p.y = cur.vv[j].y * xb[j];
                 *(wv_f64x2 *)(prod + 2 * lane + 128 * j) = p;
             }
+            if constexpr (PRE) cur = nxt;
             {   // one lane per row, ascending, one product at a time: the reference's left fold (the products are rounded, the sum adds them).
                 // Eight products of each of the lane's two rows are READ together (clamped addresses, all sixteen reads in flight) and then
                 // added in order under their range tests: one LDS round trip per eight entries instead of one per entry.
@@ -129,7 +161,7 @@ spmv_wave_kernel(SpmvArgs<int32_t> a, const int32_t *__restrict__ rowptr, const 
         prod[lane] = ya;
         prod[64 + lane] = yb;
         const wv_f64x2 yp = *(const wv_f64x2 *)(prod + 2 * lane);
-        if (prow < a.rows) wd_epilogue<EPI>(a, prow, prow + 1 < a.rows, yp.x, yp.y, wv, zv, coef, acc1, acc2);
+        if (prow < a.rows) wd_epilogue<EPI>(a, prow, prow + 1 < a.rows, yp.x, yp.y, wv, zv, coef, acc1, acc2, st_nt);
     }
     if constexpr (EPI == EPI_DOT || EPI == EPI_DOT2 || EPI == EPI_DOT4 || EPI == EPI_RES || EPI == EPI_AXPY_DOT || EPI == EPI_XPBY_NRM) {
         const double s1 = block_sum(acc1, s_red);
@@ -146,15 +178,23 @@ bool wave_on(const sla_csr *A) {
     const sla_ctx *c = A->ctx;
     return c->stream_wave > 0 && !A->rp64 && A->rows > 0 && A->max_row_nnz <= kWvMaxRow && c->spmv_algo == 0;
 }
-// entry pairs per lane and chunk: 4 (4 KiB of LDS per wavefront, 8 workgroups per CU) or 7 (7 KiB, 5 per CU: a 128-row block of a
-// 7-entries-per-row matrix is ONE chunk)
-static int wave_ppl(const sla_csr *A) {
-    if (A->ctx->stream_wave == 4 || A->ctx->stream_wave == 7) return A->ctx->stream_wave;
-    return 4;
+// Variant = (entry pairs per lane and chunk, workgroups per CU, next-chunk prefetch).  Option stream_wave: 1 = automatic; otherwise
+// the decimal code  PRE * 100 + OCC * 10 + PPL  of one of the instantiations below (A/B runs, tools/wave_ab.py).
+struct WvVariant { int ppl, occ, pre; };
+static const WvVariant kWvVariants[] = {{4, 8, 0}, {7, 5, 0}, {4, 6, 0}, {4, 5, 1}, {7, 4, 1}, {7, 3, 1}, {8, 4, 0}};
+static WvVariant wave_variant(const sla_csr *A, int epi) {
+    const int code = A->ctx->stream_wave;
+    if (code > 1)
+        for (const WvVariant &v : kWvVariants)
+            if (v.pre * 100 + v.occ * 10 + v.ppl == code || (code < 10 && v.ppl == code && !v.pre)) return v;
+    (void)epi;
+    return kWvVariants[1];
 }
 int wave_grid(const sla_csr *A) {
     const int64_t nblk = (A->rows + 127) / 128;
-    const int occ = wave_ppl(A) == 7 ? 5 : 8;
+    // (one grid for every epilogue of a matrix: the consumers of the fused partial sums know spmv_grid(A); an instantiation that holds
+    // fewer workgroups per CU than that runs a partial second round)
+    const int occ = wave_variant(A, EPI_NONE).occ;
     int64_t g = std::min<int64_t>((nblk + 3) / 4, (int64_t)occ * A->ctx->n_cu);
     g = std::min<int64_t>(g, A->ctx->spmv_grid_max);
     if (g >= 8) g &= ~7;                                // a multiple of 8: one share per XCD
@@ -165,11 +205,20 @@ template <int EPI>
 static int launch_wave_t(const sla_csr *A, const SpmvArgs<int32_t> &a, int grid) {
     sla_ctx *c = A->ctx;
     const int nblk = (int)((A->rows + 127) / 128);
-    const int nt = vec_stream_nt(c, A->rows) ? 1 : 0;
-    if (wave_ppl(A) == 7)
-        hipLaunchKernelGGL((spmv_wave_kernel<EPI, 7, 5>), dim3(grid), dim3(kBlock), 0, stream_of(c), a, a.rowptr, a.col, a.val, a.x, nblk, c->xcd_remap, nt);
-    else
-        hipLaunchKernelGGL((spmv_wave_kernel<EPI, 4, 8>), dim3(grid), dim3(kBlock), 0, stream_of(c), a, a.rowptr, a.col, a.val, a.x, nblk, c->xcd_remap, nt);
+    const int nt = (vec_stream_nt(c, A->rows) ? 1 : 0) | (c->wd_nt_store ? 2 : 0);
+    const WvVariant v = wave_variant(A, EPI);
+#define SLA_WV(P, O, R)                                                                                                                    \
+    if (v.ppl == P && v.occ == O && v.pre == R)                                                                                            \
+        hipLaunchKernelGGL((spmv_wave_kernel<EPI, P, O, R != 0>), dim3(grid), dim3(kBlock), 0, stream_of(c), a, a.rowptr, a.col, a.val, a.x, nblk, \
+                           c->xcd_remap, nt)
+    SLA_WV(4, 8, 0);
+    else SLA_WV(7, 5, 0);
+    else SLA_WV(4, 6, 0);
+    else SLA_WV(4, 5, 1);
+    else SLA_WV(7, 4, 1);
+    else SLA_WV(7, 3, 1);
+    else SLA_WV(8, 4, 0);
+#undef SLA_WV
     SLA_HIP_TRY(hipGetLastError());
     return SLA_OK;
 }

@@ -11,18 +11,26 @@ import bench  # noqa: E402
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 2
-variants = [("stream", {"stream_wave": 0})] + [(t, dict(stream_wave=int(t.split("=")[1].split()[0]))) for t in os.environ.get("WAVE_VARIANTS", "wave=4,wave=7").split(",")]
+# WAVE_VARIANTS="name=code[:option=value...],..."  (code = PRE * 100 + OCC * 10 + PPL of an instantiation in sla_spmv_wave.hip)
+variants = [("stream", {"stream_wave": 0})]
+for t in os.environ.get("WAVE_VARIANTS", "wave=57,wave=84").split(","):
+    f = t.split(":")
+    opts = {"stream_wave": int(f[0].split("=")[1])}
+    for kv in f[1:]:
+        k, v = kv.split("=")
+        opts[k] = int(v)
+    variants.append((t, opts))
 desc, (dims, (rp, ci, va)) = bench.workload("laplace3d_10m")
 base = {"wdia": 0, "vdict": 0, "diag": 0}
 for rep in range(reps):
     for name, extra in variants:
         r = bench.side_block(desc, dims, rp, ci, va, dict(base, **extra), steps, 5)
-        print(f"laplace3d_10m {name:8s} {r['value']:8.1f} it/s  K1 {r['k1_ms'] * 1e3:7.1f} us ({r['k1_frac']:.3f})  "
+        print(f"laplace3d_10m {name:22s} {r['value']:8.1f} it/s  K1 {r['k1_ms'] * 1e3:7.1f} us ({r['k1_frac']:.3f})  "
               + "  ".join(f"{k} {v['ms'] * 1e3:.1f}" for k, v in r["kernels"].items()) + "  " + " ".join(r["spmv_kernel"].split()[:2]), flush=True)
 del rp, ci, va
 desc, (dims, (rp, ci, va)) = bench.workload("random_spd_1m")
 for rep in range(reps):
     for name, extra in variants:
         r = bench.side_block(desc, dims, rp, ci, va, dict({"tiles": 0, "panels": 0}, **extra), steps, 5, rhs="A.x*")
-        print(f"random_spd_1m {name:8s} {r['value']:8.1f} it/s  K1 {r['k1_ms'] * 1e3:7.1f} us ({r['k1_frac']:.3f})  "
+        print(f"random_spd_1m {name:22s} {r['value']:8.1f} it/s  K1 {r['k1_ms'] * 1e3:7.1f} us ({r['k1_frac']:.3f})  "
               + "  ".join(f"{k} {v['ms'] * 1e3:.1f}" for k, v in r["kernels"].items()) + "  " + " ".join(r["spmv_kernel"].split()[:2]), flush=True)
