@@ -438,7 +438,7 @@ const IntKnob kIntKnobs[] = {
     {"dual_spmv", &sla_ctx::dual_spmv, 0, 1},
     {"xwin", &sla_ctx::xwin, 0, 2},
     {"stream_pipe", &sla_ctx::stream_pipe, 0, 1},
-    {"stream_wave", &sla_ctx::stream_wave, 0, 199},
+    {"stream_wave", &sla_ctx::stream_wave, 0, 1999},
     {"stream_wide", &sla_ctx::stream_wide, 0, 1},
     {"diag", &sla_ctx::diag, 0, 1},
     {"vdict", &sla_ctx::vdict, 0, 1},

@@ -179,16 +179,16 @@ bool wave_on(const sla_csr *A) {
     return c->stream_wave > 0 && !A->rp64 && A->rows > 0 && A->max_row_nnz <= kWvMaxRow && c->spmv_algo == 0;
 }
 // Variant = (entry pairs per lane and chunk, workgroups per CU, next-chunk prefetch).  Option stream_wave: 1 = automatic; otherwise
-// the decimal code  PRE * 100 + OCC * 10 + PPL  of one of the instantiations below (A/B runs, tools/wave_ab.py).
+// the decimal code  PRE * 1000 + OCC * 100 + PPL  of one of the instantiations below (A/B runs, tools/wave_ab.py).
 struct WvVariant { int ppl, occ, pre; };
-static const WvVariant kWvVariants[] = {{4, 8, 0}, {7, 5, 0}, {4, 6, 0}, {4, 5, 1}, {7, 4, 1}, {7, 3, 1}, {8, 4, 0}};
+static const WvVariant kWvVariants[] = {{2, 8, 0}, {4, 6, 0}, {8, 4, 0}, {8, 3, 0}, {12, 3, 0}, {16, 2, 0}, {8, 3, 1}, {6, 5, 0}};
 static WvVariant wave_variant(const sla_csr *A, int epi) {
     const int code = A->ctx->stream_wave;
     if (code > 1)
         for (const WvVariant &v : kWvVariants)
-            if (v.pre * 100 + v.occ * 10 + v.ppl == code || (code < 10 && v.ppl == code && !v.pre)) return v;
+            if (v.pre * 1000 + v.occ * 100 + v.ppl == code) return v;
     (void)epi;
-    return kWvVariants[1];
+    return kWvVariants[2];
 }
 int wave_grid(const sla_csr *A) {
     const int64_t nblk = (A->rows + 127) / 128;
@@ -211,13 +211,14 @@ static int launch_wave_t(const sla_csr *A, const SpmvArgs<int32_t> &a, int grid)
     if (v.ppl == P && v.occ == O && v.pre == R)                                                                                            \
         hipLaunchKernelGGL((spmv_wave_kernel<EPI, P, O, R != 0>), dim3(grid), dim3(kBlock), 0, stream_of(c), a, a.rowptr, a.col, a.val, a.x, nblk, \
                            c->xcd_remap, nt)
-    SLA_WV(4, 8, 0);
-    else SLA_WV(7, 5, 0);
+    SLA_WV(2, 8, 0);
     else SLA_WV(4, 6, 0);
-    else SLA_WV(4, 5, 1);
-    else SLA_WV(7, 4, 1);
-    else SLA_WV(7, 3, 1);
     else SLA_WV(8, 4, 0);
+    else SLA_WV(8, 3, 0);
+    else SLA_WV(12, 3, 0);
+    else SLA_WV(16, 2, 0);
+    else SLA_WV(8, 3, 1);
+    else SLA_WV(6, 5, 0);
 #undef SLA_WV
     SLA_HIP_TRY(hipGetLastError());
     return SLA_OK;

@@ -52,7 +52,7 @@ def test_wave_kernel_matches_the_oracle_bit_for_bit(sla, name):
     x = np.random.default_rng(11).standard_normal(n)
     want = orc.spmv(Ao, x)
     got = {}
-    for wave in (0, 1, 7):
+    for wave in (0, 1, 802, 604, 1602):
         ctx = sla.Context(0).set_options(stream_wave=wave, **BASE)
         A = sla.fromCSR(dims, rp, ci, va, ctx)
         info = A.kernel_info()
@@ -78,7 +78,7 @@ def test_wave_kernel_steps_aside_for_long_rows(sla):
     assert np.all(np.abs(y - yo) <= 129 * np.finfo(float).eps * np.abs(x).max() * 129)
 
 
-@pytest.mark.parametrize("wave", [1, 7])
+@pytest.mark.parametrize("wave", [1, 604, 1203])
 def test_wave_kernel_solver_epilogues(sla, wave):
     """bicgsInit / bicgstabStep fused and split (EPI_SUB, EPI_DOT, EPI_DOT2, EPI_DOT4), cgsStep (EPI_AXPY_DOT), cgneStep (EPI_AXPY_DOT on A,
     EPI_XPBY_NRM on the transpose), linSolve0's residual sweep (EPI_RES): two steps against the oracle, and the iterates bit-identical
