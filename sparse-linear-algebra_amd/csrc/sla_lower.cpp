@@ -794,8 +794,23 @@ int csr_upload(sla_ctx *c, int64_t m, int64_t n, int64_t row_begin, int64_t rows
         build_row_blocks(rows, rowptr, L.rb, A->max_row_nnz, c->row_align, c->rb_nnz);
         A->nrb = (int32_t)L.rb.size() - 1;
         diag_not = host_is_diagonal(rows, row_begin, rowptr, col) ? 0 : 1;
-        low_csr_arrays(L);
-        lap("row blocks + CSR upload");
+        lap("row blocks");
+        // The canonical arrays (narrowed columns, values, row pointers, row-block tables: 12 B per entry over PCIe from pageable memory)
+        // go up on a background thread WHILE the host analyses of the storage forms run (round 4: the two were 106 ms + 106 ms in a row
+        // at 70 M entries; the upload is bound by the staging copies of one or two threads, the analyses use the other cores).
+        Low Lup = L;                       // (own error slot, own copy of the row-block starts)
+        std::thread up([&] {
+            Bind bind(c);                  // (a new thread starts on device 0)
+            try {
+                low_csr_arrays(Lup);
+            } catch (const std::bad_alloc &) {
+                if (Lup.err == hipSuccess) Lup.err = hipErrorOutOfMemory;
+            }
+        });
+        struct Joiner {                    // (an exception below must not unwind past a joinable thread)
+            std::thread &t;
+            ~Joiner() { if (t.joinable()) t.join(); }
+        } up_joiner{up};
         low_xwin_statistics(L);
         lap("x-window statistics");
         low_diagonal_dictionary(L);
@@ -803,7 +818,10 @@ int csr_upload(sla_ctx *c, int64_t m, int64_t n, int64_t row_begin, int64_t rows
         lap("pair dictionary + wave slices");
         low_wave_sliced_variable(L);
         lap("variable-coefficient slices");
-        low_lds_panels(L);
+        up.join();
+        if (err == hipSuccess) err = Lup.err;
+        lap("canonical CSR upload (rest)");
+        low_lds_panels(L);                 // (its panel-major copy is written by a device kernel from the canonical arrays)
         lap("LDS panel table");
     } catch (const std::bad_alloc &) {
         if (err == hipSuccess) err = hipErrorOutOfMemory;

@@ -181,14 +181,22 @@ bool wave_on(const sla_csr *A) {
 // Variant = (entry pairs per lane and chunk, workgroups per CU, next-chunk prefetch).  Option stream_wave: 1 = automatic; otherwise
 // the decimal code  PRE * 1000 + OCC * 100 + PPL  of one of the instantiations below (A/B runs, tools/wave_ab.py).
 struct WvVariant { int ppl, occ, pre; };
-static const WvVariant kWvVariants[] = {{2, 8, 0}, {4, 6, 0}, {8, 4, 0}, {8, 3, 0}, {12, 3, 0}, {16, 2, 0}, {8, 3, 1}, {6, 5, 0}};
+// Measured on the 216^3 Laplacian as plain CSR (7 entries per row: 896 per block; same box, two interleaved runs each,
+// profiles/r04_wave_variants.txt): spmv_stream_kernel K1 238 us | (2,8) 240 | (4,6) 222 | (6,5) 245 (768-entry chunks cut a block 768 + 128) |
+// (8,4) 218 | (8,3) 218 | (12,3) 240 | (16,2) 285 | (8,3)+prefetch 212; on a faster box stream 222 | (4,8) 206 | (7,5) 206 | (4,6) 201 |
+// (8,4) 197.  Few, fat wavefronts with a whole block in flight win, like in the tile kernel; the random 1 M-row matrix (33 per row, L2-gather
+// bound) is within +-1.5 % on all of them.
+static const WvVariant kWvVariants[] = {{2, 8, 0}, {4, 6, 0}, {8, 4, 0}, {8, 3, 1}};
 static WvVariant wave_variant(const sla_csr *A, int epi) {
     const int code = A->ctx->stream_wave;
     if (code > 1)
         for (const WvVariant &v : kWvVariants)
             if (v.pre * 1000 + v.occ * 100 + v.ppl == code) return v;
     (void)epi;
-    return kWvVariants[2];
+    // automatic: the chunk that holds an average block -- 2 / 4 entry pairs per lane for short rows (the loads of a chunk are issued
+    // unconditionally: a chunk much larger than the block only issues clamped loads), else 8 pairs with the next chunk prefetched
+    const int64_t nblk = (A->rows + 127) / 128, avg = nblk > 0 ? A->nnz / nblk : 0;
+    return avg <= 256 ? kWvVariants[0] : avg <= 512 ? kWvVariants[1] : kWvVariants[3];
 }
 int wave_grid(const sla_csr *A) {
     const int64_t nblk = (A->rows + 127) / 128;
@@ -214,11 +222,7 @@ static int launch_wave_t(const sla_csr *A, const SpmvArgs<int32_t> &a, int grid)
     SLA_WV(2, 8, 0);
     else SLA_WV(4, 6, 0);
     else SLA_WV(8, 4, 0);
-    else SLA_WV(8, 3, 0);
-    else SLA_WV(12, 3, 0);
-    else SLA_WV(16, 2, 0);
     else SLA_WV(8, 3, 1);
-    else SLA_WV(6, 5, 0);
 #undef SLA_WV
     SLA_HIP_TRY(hipGetLastError());
     return SLA_OK;

@@ -13,7 +13,7 @@ steps = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 # WAVE_VARIANTS="name=code[:option=value...],..."  (code = PRE * 1000 + OCC * 100 + PPL of an instantiation in sla_spmv_wave.hip)
 variants = [("stream", {"stream_wave": 0})]
-for t in os.environ.get("WAVE_VARIANTS", "wave=408,wave=604").split(","):
+for t in os.environ.get("WAVE_VARIANTS", "auto=1,wave=408,wave=1308,wave=604").split(","):
     f = t.split(":")
     opts = {"stream_wave": int(f[0].split("=")[1])}
     for kv in f[1:]:
