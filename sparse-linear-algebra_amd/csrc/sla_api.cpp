@@ -441,6 +441,7 @@ const IntKnob kIntKnobs[] = {
     {"stream_wave", &sla_ctx::stream_wave, 0, 1999},
     {"stream_wide", &sla_ctx::stream_wide, 0, 1},
     {"diag", &sla_ctx::diag, 0, 1},
+    {"diag_lazy", &sla_ctx::diag_lazy, 0, 1},
     {"vdict", &sla_ctx::vdict, 0, 1},
     {"wdia", &sla_ctx::wdia, 0, 1},
     {"lpanel", &sla_ctx::lpanel, 0, 1},
@@ -469,6 +470,7 @@ const IntKnob kIntKnobs[] = {
     {"ag_sim_ranks", &sla_ctx::ag_sim_ranks, 0, 64},
     {"ag_sim_rank", &sla_ctx::ag_sim_rank, 0, 63},
     {"tiles", &sla_ctx::tiles, 0, 1},
+    {"tiles_device", &sla_ctx::tiles_device, 0, 2},
     {"tile_shift", &sla_ctx::tile_shift, 0, 20},
     {"tile_slack", &sla_ctx::tile_slack, 0, 64},
     {"row_align", &sla_ctx::row_align, 0, 256},

@@ -231,12 +231,14 @@ struct sla_ctx {
     hipStream_t comm_stream = nullptr;   // created on first use
     hipEvent_t ev_x_ready = nullptr, ev_x_done = nullptr;
     int xcd8 = -1;                   // 1: workgroups are dealt round-robin over 8 XCDs (those with equal b % 8 share one; probed once: what the tile kernel's panel pacing relies on), 0: not so
+    int tiles_device = 1;            // the tile form's re-ordering as a device sort (sla_tiles_build.hip): 1 from 2^20 entries on, 2 always, 0 host builder (SLA_TILES_DEVICE)
     int tiles = 1;                   // allow the row-slice x column-panel tile SpMV for irregular matrices with x > L2 (SLA_TILES=0: column-panel passes)
     int tile_slack = 3;              // panel pacing: a wavefront starts panel step q once its XCD has finished step q - slack (SLA_TILE_SLACK, 0: no pacing)
     int tile_shift = 0;              // log2 of its panel width in columns (SLA_TILE_SHIFT; 0: 17 from 6 M columns on, 16 below -- at 10 M rows slack 3 / shift 17: 1.98 ms, slack 4: 2.18, slack 2: 2.1, shift 16: 2.03-2.28, shift 18: +15 %)
     int panels = 1;                  // allow the column-panel SpMV for irregular matrices (SLA_PANELS=0 disables)
     int64_t panel_cols = 384 * 1024; // panel width in columns (SLA_PANEL_COLS): 3 MiB of x per pass
     int diag = 1;                    // allow the dictionary-compressed-index SpMV kernel (SLA_DIAG=0 disables)
+    int diag_lazy = 1;               // skip building its 1-byte codes for matrices that take the constant-coefficient wave-sliced form (SLA_DIAG_LAZY=0: always build)
     int vec_policy = 0x2bff;         // per-stream cache policy of K2 and the K4+K5 sweep when vec_nt applies (sla_vec_kernels.hip: ldpol; default: every BiCGSTAB stream but the p store, and CGS's q and u stores, past the caches)
     int vec_nt = -1;                 // non-temporal loads in the BiCGSTAB vector kernels: -1 when the vectors overflow the memory-side cache, 0 / 1 (SLA_VEC_NT)
     int64_t mall_bytes = 256ll << 20; // capacity of the memory-side cache (MI355X: 256 MiB)
@@ -710,6 +712,8 @@ int tiles_grid(const sla_csr *A);
 int probe_xcd_layout(sla_ctx *c);   // sets c->xcd8 (sla_spmv_tiles.hip)
 // sla_lower_tiles.cpp: builds the tile form of A when it pays (irregular structure, x larger than the L2); no-op otherwise
 int build_tiles(sla_csr *A, int64_t n, int64_t rows, const int64_t *rowptr, const int64_t *col, const double *val);
+// sla_tiles_build.hip: the same re-ordering on the device from A's canonical arrays (*done = false: not taken, use the host builder)
+int build_tiles_device(sla_csr *A, const std::vector<int32_t> &srow, int shift, int64_t P, int64_t *maxseg_out, int64_t *nbreaks_out, bool *done);
 
 int vec_grid(int64_t n_local);
 // p1[b] = sum x.y over block b's elements (grid = vec_grid)

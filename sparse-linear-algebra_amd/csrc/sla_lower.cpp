@@ -480,11 +480,20 @@ static void low_value_indexed(Low &L) {
                             }
                         upload((void **)&A->d_wum, wum.data(), sizeof(uint64_t) * wum.size());
                         int64_t clo = n, chi = -1;                // (columns ascend inside a row)
-                        for (int64_t i = 0; i < rows; ++i)
-                            if (rowptr[i + 1] > rowptr[i]) {
-                                clo = std::min<int64_t>(clo, col[rowptr[i]]);
-                                chi = std::max<int64_t>(chi, col[rowptr[i + 1] - 1]);
-                            }
+                        {
+                            std::vector<int64_t> plo((size_t)host_threads(), n), phi((size_t)host_threads(), -1);
+                            par_rows(rows, 1, [&](int t, int64_t lo, int64_t hi) {
+                                int64_t a = n, b = -1;
+                                for (int64_t i = lo; i < hi; ++i)
+                                    if (rowptr[i + 1] > rowptr[i]) {
+                                        a = std::min<int64_t>(a, col[rowptr[i]]);
+                                        b = std::max<int64_t>(b, col[rowptr[i + 1] - 1]);
+                                    }
+                                plo[(size_t)t] = a;
+                                phi[(size_t)t] = b;
+                            });
+                            for (size_t t = 0; t < plo.size(); ++t) { clo = std::min(clo, plo[t]); chi = std::max(chi, phi[t]); }
+                        }
                         A->wd_col_lo = (int32_t)clo;
                         A->wd_col_hi = (int32_t)chi;
                         // x[own row] from the staged buffer (an epilogue operand that is the gathered vector): offset 0 inside a
@@ -813,9 +822,13 @@ int csr_upload(sla_ctx *c, int64_t m, int64_t n, int64_t row_begin, int64_t rows
         } up_joiner{up};
         low_xwin_statistics(L);
         lap("x-window statistics");
-        low_diagonal_dictionary(L);
         low_value_indexed(L);
         lap("pair dictionary + wave slices");
+        // (the 1-byte column codes serve the dictionary-code kernel and the variable-coefficient slices: a matrix that just took the
+        // constant-coefficient wave-sliced form needs neither -- unless the context's knobs peel that form off again (A/B runs), which
+        // is decided when the matrix is created: two passes over the entries and 1 B per entry of upload saved, round 4)
+        if (!(A->use_wdia && c->wdia && c->diag_lazy)) low_diagonal_dictionary(L);
+        lap("offset dictionary");
         low_wave_sliced_variable(L);
         lap("variable-coefficient slices");
         up.join();

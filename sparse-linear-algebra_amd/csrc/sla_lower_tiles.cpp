@@ -62,6 +62,37 @@ int build_tiles(sla_csr *A, int64_t n, int64_t rows, const int64_t *rowptr, cons
     }
     const int64_t S = (int64_t)srow.size() - 1;
     if (S * (P + 1) > ((int64_t)1 << 31) || S * (P + 1) * 4 > nnz * 12 / 2) return SLA_OK;   // offset table must stay a fraction of the matrix
+    auto finish = [&]() -> int {   // what both builders share once d_tlidx / d_tlval / d_tloff exist: slice starts, pacing table, geometry
+        hipError_t e2 = dev_malloc(c, (void **)&A->d_tlrow, sizeof(int32_t) * srow.size() + 64);
+        if (e2 == hipSuccess) e2 = hipMemcpy(A->d_tlrow, srow.data(), sizeof(int32_t) * srow.size(), hipMemcpyHostToDevice);
+        A->tlprog_bytes = sizeof(int) * 8 * 256;   // pacing table: one progress slot per workgroup, 256 per XCD; zeroed before every launch
+        if (e2 == hipSuccess) e2 = dev_malloc(c, (void **)&A->d_tlprog, A->tlprog_bytes);
+        if (e2 != hipSuccess) return fail(SLA_ERR_ALLOC, std::string("tile form upload: ") + hipGetErrorString(e2));
+        SLA_TRY(probe_xcd_layout(c));
+        A->tl_S = (int32_t)S;
+        A->tl_P = (int32_t)P;
+        A->tl_shift = shift;
+        A->use_tiles = true;
+        return SLA_OK;
+    };
+    // Round 4: the re-ordering as a device sort of the canonical arrays that are on the device already (sla_tiles_build.hip) -- at
+    // 330 M entries the host builder below took 1.2 s (16 threads) plus 4 GB of PCIe; option tiles_device: 1 from 2^20 entries on,
+    // 2 always, 0 never (the two builders are bit-identical: tests/test_gpu_tiles.py).
+    if (c->tiles_device == 2 || (c->tiles_device == 1 && nnz >= ((int64_t)1 << 20))) {
+        int64_t mseg = 0, nb = 0;
+        bool done = false;
+        SLA_TRY(build_tiles_device(A, srow, shift, P, &mseg, &nb, &done));
+        if (done) {
+            A->tl_maxseg = mseg;
+            if (nb * 8 > nnz) {   // (dense rows: see the host builder's test below)
+                (void)hipFree(A->d_tlidx); (void)hipFree(A->d_tlval); (void)hipFree(A->d_tloff);
+                A->d_tlidx = nullptr; A->d_tlval = nullptr; A->d_tloff = nullptr;
+                return SLA_OK;
+            }
+            A->lower_log += "tile builder on device=1;";
+            return finish();
+        }
+    }
     std::vector<uint32_t> toff((size_t)(S * (P + 1)));
     std::vector<uint32_t> tidx((size_t)nnz);
     std::vector<double> tval((size_t)nnz);
@@ -143,19 +174,11 @@ int build_tiles(sla_csr *A, int64_t n, int64_t rows, const int64_t *rowptr, cons
         err = dev_malloc(c, dst, std::max<size_t>(bytes + 64, 8));   // (+64: the streams are read in whole dwords / qwords only, slack for safety)
         if (err == hipSuccess && bytes) err = hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
     };
-    upload((void **)&A->d_tlrow, srow.data(), sizeof(int32_t) * srow.size());
     upload((void **)&A->d_tloff, toff.data(), sizeof(uint32_t) * toff.size());
     upload((void **)&A->d_tlidx, tidx.data(), sizeof(uint32_t) * tidx.size());
     upload((void **)&A->d_tlval, tval.data(), sizeof(double) * tval.size());
-    A->tlprog_bytes = sizeof(int) * 8 * 256;   // pacing table: one progress slot per workgroup, 256 per XCD; zeroed before every launch
-    if (err == hipSuccess) err = dev_malloc(c, (void **)&A->d_tlprog, A->tlprog_bytes);
     if (err != hipSuccess) return fail(SLA_ERR_ALLOC, std::string("tile form upload: ") + hipGetErrorString(err));
-    SLA_TRY(probe_xcd_layout(c));
-    A->tl_S = (int32_t)S;
-    A->tl_P = (int32_t)P;
-    A->tl_shift = shift;
-    A->use_tiles = true;
-    return SLA_OK;
+    return finish();
 }
 
 }  // namespace sla

@@ -1,0 +1,208 @@
+// sla_tiles_build.hip -- the tile form of sla_lower_tiles.cpp built ON THE DEVICE (round 4: "lowered once" for BASELINE config 3a cost
+// 1.2 s of host re-ordering and 4 GB of PCIe for the second, tile-major copy of the entries -- 390 BiCGSTAB steps at the
+// steady-state rate, while linSolve0 runs <= 200).  The canonical CSR arrays are on the device already; the tile order is a sort:
+//
+//   entry k of row i (slice s, panel j = col >> shift, layer l = its rank inside the (row, panel) segment)  ->  key (s, j, l)
+//   STABLE radix sort of (key, k) (rocPRIM): entries of one (slice, panel, layer) keep their input order = ascending rows
+//   tlidx / tlval gathered through the sorted positions, tloff by binary search for every (slice, panel) boundary.
+//
+// Bit-identical to the host builder (tests/test_gpu_tiles.py runs both: option tiles_device).  Reference semantics of the form: the
+// row's left fold over ascending columns, Data/Sparse/Common.hs:247-260 (kernel: sla_spmv_tiles.hip).
+#include <hip/hip_runtime.h>
+
+#include <cstring>  // rocPRIM's texture iterator calls the host memset without including it
+
+#include <rocprim/rocprim.hpp>
+
+#include "sla_internal.hpp"
+
+namespace sla {
+
+namespace {
+
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 8); }
+    template <class T> T *as() { return (T *)p; }
+};
+
+// longest (row, panel) segment: one thread per row walks its entries (rows are short in the matrices that take this form)
+template <typename RP>
+__global__ void __launch_bounds__(256) tile_maxseg_kernel(int64_t rows, const RP *__restrict__ rowptr, const int32_t *__restrict__ col, int shift,
+                                                           unsigned *maxseg) {
+    unsigned mx = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < rows; i += (int64_t)gridDim.x * 256) {
+        int prev = -1;
+        unsigned len = 0;
+        for (RP k = rowptr[i]; k < rowptr[i + 1]; ++k) {
+            const int j = col[k] >> shift;
+            len = j == prev ? len + 1 : 1;
+            prev = j;
+            mx = max(mx, len);
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, off, 64));
+    if ((threadIdx.x & 63) == 0 && mx) atomicMax(maxseg, mx);
+}
+
+// key = slice << (pbits + lbits) | panel << lbits | layer ; value = the entry's position in the canonical arrays
+template <typename RP>
+__global__ void __launch_bounds__(256) tile_keys_kernel(int S, const int32_t *__restrict__ srow, const RP *__restrict__ rowptr,
+                                                         const int32_t *__restrict__ col, int shift, int lbits, int pbits, uint64_t *key, uint32_t *idx) {
+    for (int s = blockIdx.x; s < S; s += gridDim.x) {
+        const uint64_t hi = (uint64_t)s << (pbits + lbits);
+        for (int i = srow[s] + (int)threadIdx.x; i < srow[s + 1]; i += 256) {
+            int prev = -1;
+            unsigned layer = 0;
+            for (RP k = rowptr[i]; k < rowptr[i + 1]; ++k) {
+                const int j = col[k] >> shift;
+                layer = j == prev ? layer + 1 : 0;
+                prev = j;
+                key[k] = hi | ((uint64_t)j << lbits) | layer;
+                idx[k] = (uint32_t)k;
+            }
+        }
+    }
+}
+
+// the entries in tile order; layer boundaries INSIDE a tile are counted (each costs the kernel one more LDS pass)
+template <typename RP>
+__global__ void __launch_bounds__(256) tile_emit_kernel(int64_t nnz, const uint64_t *__restrict__ key, const uint32_t *__restrict__ idx,
+                                                         const int32_t *__restrict__ srow, const RP *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                                         const double *__restrict__ val, const int32_t *__restrict__ row_of_entry, int shift, int lbits,
+                                                         int pbits, uint32_t *tidx, double *tval, unsigned long long *nbreaks) {
+    const uint32_t cmask = (1u << shift) - 1u;
+    unsigned brk = 0;
+    for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < nnz; o += (int64_t)gridDim.x * 256) {
+        const uint64_t kk = key[o];
+        const uint32_t k = idx[o];
+        const int s = (int)(kk >> (pbits + lbits));
+        const int r = row_of_entry[k] - srow[s];
+        tidx[o] = ((uint32_t)r << shift) | ((uint32_t)col[k] & cmask);
+        tval[o] = val[k];
+        if (o > 0) {
+            const uint64_t kp = key[o - 1];
+            brk += (kp >> lbits) == (kk >> lbits) && kp != kk;       // same (slice, panel), another layer
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) brk += (unsigned)__shfl_xor((int)brk, off, 64);
+    if ((threadIdx.x & 63) == 0 && brk) atomicAdd(nbreaks, (unsigned long long)brk);
+}
+
+// row of every entry (the emit kernel needs it; one thread per row)
+template <typename RP>
+__global__ void __launch_bounds__(256) tile_rows_kernel(int64_t rows, const RP *__restrict__ rowptr, int32_t *row_of_entry) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < rows; i += (int64_t)gridDim.x * 256)
+        for (RP k = rowptr[i]; k < rowptr[i + 1]; ++k) row_of_entry[k] = (int32_t)i;
+}
+
+// tloff[s * (P + 1) + j] = first sorted position with (slice, panel) >= (s, j), relative to the slice's first entry
+template <typename RP>
+__global__ void __launch_bounds__(256) tile_offsets_kernel(int S, int P, int64_t nnz, const uint64_t *__restrict__ key, const int32_t *__restrict__ srow,
+                                                            const RP *__restrict__ rowptr, int lbits, int pbits, uint32_t *toff) {
+    const int64_t total = (int64_t)S * (P + 1);
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+        const int s = (int)(t / (P + 1)), j = (int)(t - (int64_t)s * (P + 1));
+        const uint64_t want = ((uint64_t)s << (pbits + lbits)) | ((uint64_t)j << lbits);
+        int64_t lo = (int64_t)rowptr[srow[s]], hi = (int64_t)rowptr[srow[s + 1]];   // the slice owns the same entry range in both orders
+        const int64_t base = lo;
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (key[mid] < want) lo = mid + 1;
+            else hi = mid;
+        }
+        toff[t] = (uint32_t)(lo - base);
+    }
+}
+
+int bits_for(uint64_t v) {
+    int b = 1;
+    while (b < 63 && (v >> b)) ++b;
+    return b;
+}
+
+}  // namespace
+
+// Builds d_tlidx / d_tlval / d_tloff of A from its canonical device arrays.  srow: the slice row starts (host, S + 1).  Outputs the
+// longest segment and the number of layer boundaries.  Returns SLA_OK with *done = false when this path cannot take the matrix
+// (the host builder does then).
+int build_tiles_device(sla_csr *A, const std::vector<int32_t> &srow, int shift, int64_t P, int64_t *maxseg_out, int64_t *nbreaks_out, bool *done) {
+    *done = false;
+    sla_ctx *c = A->ctx;
+    const int64_t nnz = A->nnz, rows = A->rows, S = (int64_t)srow.size() - 1;
+    if (!A->d_col || !A->d_val || !A->d_rowptr || nnz <= 0 || nnz >= ((int64_t)1 << 31) || S <= 0) return SLA_OK;
+    hipStream_t st = stream_of(c);
+    DevBuf d_srow, d_stat, d_key, d_key2, d_idx, d_idx2, d_rows, d_tmp;
+    auto launch_ok = [&]() { return hipGetLastError() == hipSuccess; };
+    hipError_t e = d_srow.alloc(sizeof(int32_t) * srow.size());
+    if (e == hipSuccess) e = hipMemcpyAsync(d_srow.p, srow.data(), sizeof(int32_t) * srow.size(), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = d_stat.alloc(16);
+    if (e == hipSuccess) e = hipMemsetAsync(d_stat.p, 0, 16, st);
+    if (e != hipSuccess) return SLA_OK;   // (no device memory for the scratch: the host path may still work)
+    const int grid = 4096;
+    unsigned long long h_stat[2] = {0, 0};
+    if (A->rp64) hipLaunchKernelGGL((tile_maxseg_kernel<int64_t>), dim3(grid), dim3(256), 0, st, rows, (const int64_t *)A->d_rowptr, A->d_col, shift, d_stat.as<unsigned>());
+    else hipLaunchKernelGGL((tile_maxseg_kernel<int32_t>), dim3(grid), dim3(256), 0, st, rows, (const int32_t *)A->d_rowptr, A->d_col, shift, d_stat.as<unsigned>());
+    if (!launch_ok()) return SLA_OK;
+    SLA_HIP_TRY(hipMemcpyAsync(h_stat, d_stat.p, 8, hipMemcpyDeviceToHost, st));
+    SLA_HIP_TRY(hipStreamSynchronize(st));
+    const int64_t maxseg = (int64_t)(unsigned)h_stat[0];
+    const int lbits = bits_for((uint64_t)std::max<int64_t>(maxseg, 1)), pbits = bits_for((uint64_t)P), sbits = bits_for((uint64_t)S);
+    if (lbits + pbits + sbits > 62) return SLA_OK;
+    // scratch: keys / positions twice (radix sort ping-pong), the row of every entry, rocPRIM's own
+    e = d_key.alloc(8 * (size_t)nnz);
+    if (e == hipSuccess) e = d_key2.alloc(8 * (size_t)nnz);
+    if (e == hipSuccess) e = d_idx.alloc(4 * (size_t)nnz);
+    if (e == hipSuccess) e = d_idx2.alloc(4 * (size_t)nnz);
+    if (e == hipSuccess) e = d_rows.alloc(4 * (size_t)nnz);
+    size_t tmp_bytes = 0;
+    if (e == hipSuccess)
+        e = rocprim::radix_sort_pairs(nullptr, tmp_bytes, d_key.as<uint64_t>(), d_key2.as<uint64_t>(), d_idx.as<uint32_t>(), d_idx2.as<uint32_t>(),
+                                      (size_t)nnz, 0, (unsigned)(lbits + pbits + sbits), st);
+    if (e == hipSuccess) e = d_tmp.alloc(tmp_bytes);
+    if (e == hipSuccess && !A->d_tlidx) e = dev_malloc(c, (void **)&A->d_tlidx, sizeof(uint32_t) * (size_t)nnz + 64);
+    if (e == hipSuccess && !A->d_tlval) e = dev_malloc(c, (void **)&A->d_tlval, sizeof(double) * (size_t)nnz + 64);
+    if (e == hipSuccess && !A->d_tloff) e = dev_malloc(c, (void **)&A->d_tloff, sizeof(uint32_t) * (size_t)(S * (P + 1)) + 64);
+    auto give_up = [&]() {   // out of device memory for the scratch or the copy: release what was taken, let the host path decide
+        (void)hipGetLastError();
+        if (A->d_tlidx) { (void)hipFree(A->d_tlidx); A->d_tlidx = nullptr; }
+        if (A->d_tlval) { (void)hipFree(A->d_tlval); A->d_tlval = nullptr; }
+        if (A->d_tloff) { (void)hipFree(A->d_tloff); A->d_tloff = nullptr; }
+        return SLA_OK;
+    };
+    if (e != hipSuccess) return give_up();
+#define SLA_RP_LAUNCH(KERNEL, GRID, ...)                                                                                                   \
+    do {                                                                                                                                   \
+        if (A->rp64) hipLaunchKernelGGL((KERNEL<int64_t>), dim3(GRID), dim3(256), 0, st, __VA_ARGS__);                                      \
+        else hipLaunchKernelGGL((KERNEL<int32_t>), dim3(GRID), dim3(256), 0, st, __VA_ARGS__);                                              \
+    } while (0)
+    if (A->rp64) {
+        hipLaunchKernelGGL((tile_keys_kernel<int64_t>), dim3((unsigned)std::min<int64_t>(S, 65535)), dim3(256), 0, st, (int)S, d_srow.as<int32_t>(), (const int64_t *)A->d_rowptr, A->d_col, shift, lbits, pbits, d_key.as<uint64_t>(), d_idx.as<uint32_t>());
+        hipLaunchKernelGGL((tile_rows_kernel<int64_t>), dim3(grid), dim3(256), 0, st, rows, (const int64_t *)A->d_rowptr, d_rows.as<int32_t>());
+    } else {
+        hipLaunchKernelGGL((tile_keys_kernel<int32_t>), dim3((unsigned)std::min<int64_t>(S, 65535)), dim3(256), 0, st, (int)S, d_srow.as<int32_t>(), (const int32_t *)A->d_rowptr, A->d_col, shift, lbits, pbits, d_key.as<uint64_t>(), d_idx.as<uint32_t>());
+        hipLaunchKernelGGL((tile_rows_kernel<int32_t>), dim3(grid), dim3(256), 0, st, rows, (const int32_t *)A->d_rowptr, d_rows.as<int32_t>());
+    }
+    if (!launch_ok()) return give_up();
+    e = rocprim::radix_sort_pairs(d_tmp.p, tmp_bytes, d_key.as<uint64_t>(), d_key2.as<uint64_t>(), d_idx.as<uint32_t>(), d_idx2.as<uint32_t>(), (size_t)nnz, 0,
+                                  (unsigned)(lbits + pbits + sbits), st);
+    if (e != hipSuccess) return give_up();
+    if (A->rp64) {
+        hipLaunchKernelGGL((tile_emit_kernel<int64_t>), dim3(grid), dim3(256), 0, st, nnz, d_key2.as<uint64_t>(), d_idx2.as<uint32_t>(), d_srow.as<int32_t>(), (const int64_t *)A->d_rowptr, A->d_col, A->d_val, d_rows.as<int32_t>(), shift, lbits, pbits, A->d_tlidx, A->d_tlval, d_stat.as<unsigned long long>() + 1);
+        hipLaunchKernelGGL((tile_offsets_kernel<int64_t>), dim3(grid), dim3(256), 0, st, (int)S, (int)P, nnz, d_key2.as<uint64_t>(), d_srow.as<int32_t>(), (const int64_t *)A->d_rowptr, lbits, pbits, A->d_tloff);
+    } else {
+        hipLaunchKernelGGL((tile_emit_kernel<int32_t>), dim3(grid), dim3(256), 0, st, nnz, d_key2.as<uint64_t>(), d_idx2.as<uint32_t>(), d_srow.as<int32_t>(), (const int32_t *)A->d_rowptr, A->d_col, A->d_val, d_rows.as<int32_t>(), shift, lbits, pbits, A->d_tlidx, A->d_tlval, d_stat.as<unsigned long long>() + 1);
+        hipLaunchKernelGGL((tile_offsets_kernel<int32_t>), dim3(grid), dim3(256), 0, st, (int)S, (int)P, nnz, d_key2.as<uint64_t>(), d_srow.as<int32_t>(), (const int32_t *)A->d_rowptr, lbits, pbits, A->d_tloff);
+    }
+#undef SLA_RP_LAUNCH
+    if (!launch_ok()) return give_up();
+    SLA_HIP_TRY(hipMemcpyAsync(h_stat, d_stat.p, 16, hipMemcpyDeviceToHost, st));
+    SLA_HIP_TRY(hipStreamSynchronize(st));
+    *maxseg_out = maxseg;
+    *nbreaks_out = (int64_t)h_stat[1];
+    *done = true;
+    return SLA_OK;
+}
+
+}  // namespace sla

@@ -288,7 +288,7 @@ def test_64_bit_row_pointer_kernels(sla):
         "scalar kernel": (wl.random_spd(2000, 5, 6), {"spmv_algo": "scalar"}, "scalar"),
     }
     for name, ((dims, csr), opts, form) in cases.items():
-        opts = dict(opts, wdia=0, vdict=0)       # (the 32-bit run takes the same general form as the 64-bit one)
+        opts = dict(opts, wdia=0, vdict=0, stream_wave=0)       # (the 32-bit run takes the same general form as the 64-bit one: spmv_wave_kernel is 32-bit only)
         m, n = dims
         Ao = orc.Csr(m, n, *csr)
         x, w = rng.standard_normal(n), rng.standard_normal(m)
@@ -390,7 +390,7 @@ def test_pipelined_stream_kernel_is_bit_identical_to_the_stream_kernel(sla):
         n = dims[0]
         out = {}
         for pipe in (0, 1):
-            ctx = sla.Context(0).set_options(wdia=0, vdict=0, diag=0, tiles=0, panels=0, lpanel=0, stream_pipe=pipe)
+            ctx = sla.Context(0).set_options(wdia=0, vdict=0, diag=0, tiles=0, panels=0, lpanel=0, stream_pipe=pipe, stream_wave=0)
             A = sla.fromCSR(dims, *csr, ctx)
             assert ("stream+pipe" in A.kernel_info()) == bool(pipe), A.kernel_info()
             x = np.random.default_rng(3).standard_normal(n)

@@ -66,15 +66,18 @@ def test_tiles_match_the_oracle(sla, name):
     x = rng.standard_normal(n)
     want = orc.spmv(Ao, x)
     bound = np.diff(rp) * EPS * orc.spmv(orc.Csr(m, n, rp, ci, np.abs(va)), np.abs(x)) + 1e-300
-    for rp64 in ("0", "1"):                                      # (lpanel=0: the dense-row cases would otherwise take the LDS-panel form)
-        ctx = sla.Context(0).set_options(tile_shift=10, lpanel=0, force_rp64=rp64)
+    # (lpanel=0: the dense-row cases would otherwise take the LDS-panel form; tiles_device: the re-ordering as a device sort -- round 4,
+    # sla_tiles_build.hip -- and by the host builder: the same decision and the same bits from both)
+    for rp64, dev in (("0", 2), ("1", 2), ("0", 0), ("1", 0)):
+        ctx = sla.Context(0).set_options(tile_shift=10, lpanel=0, force_rp64=rp64, tiles_device=dev)
         A = sla.fromCSR(dims, rp, ci, va, ctx)
         info = A.kernel_info()
         assert ("algo=tiles" in info) == expect_tiles, (name, info)
+        assert ("tile builder on device" in A.lower_info()) == (expect_tiles and dev == 2), (name, dev, A.lower_info())
         y = sla.matVec(A, sla.fromVector(x, ctx)).toDenseListSV()
         if expect_tiles:
             assert "exact_fold=1" in info
-            assert np.array_equal(y, want), (name, rp64, int(np.count_nonzero(y != want)))
+            assert np.array_equal(y, want), (name, rp64, dev, int(np.count_nonzero(y != want)))
         else:
             assert np.all(np.abs(y - want) <= bound), (name, rp64, float(np.abs(y - want).max()))
         y2 = sla.matVec(A, sla.fromVector(x, ctx)).toDenseListSV()

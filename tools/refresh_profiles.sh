@@ -23,6 +23,9 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $S/ks -o ks -- python be
 cp "$(find $S/ks -name '*kernel_stats.csv' | head -1)" $S/${tag}_bench_kernel_stats.csv
 rocprofv3 --kernel-trace --stats --output-format csv -d $S/ks3a -o ks -- python bench.py --workload random_spd_10m --steps 40 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 > $S/${tag}_bench_traced_run_random_spd_10m.json
 cp "$(find $S/ks3a -name '*kernel_stats.csv' | head -1)" $S/${tag}_bench_kernel_stats_random_spd_10m.csv
+# round 4: the same for config 5 (GMRES(30) Arnoldi steps on the 2 M-row banded matrix)
+rocprofv3 --kernel-trace --stats --output-format csv -d $S/ksg -o ks -- python bench.py --mode gmres --workload banded_2m --steps 120 --warmup 0 --no-cpu-baseline 2>/dev/null | tail -1 > $S/${tag}_bench_traced_run_gmres_banded_2m.json
+cp "$(find $S/ksg -name '*kernel_stats.csv' | head -1)" $S/${tag}_bench_kernel_stats_gmres_banded_2m.csv
 # PMC passes (separate --pmc runs, kernel-trace only): FETCH/WRITE size, L2 hit/miss, EA requests
 pmc() { out=$1; shift
   for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum"; do
@@ -42,6 +45,9 @@ pmc $S/${tag}_bench_pmc_counters.txt python bench.py --steps 20 --warmup 3 --no-
 pmc $S/${tag}_bench_pmc_counters_random_spd_10m.txt python bench.py --workload random_spd_10m --steps 8 --warmup 2 --no-cpu-baseline
 pmc $S/${tag}_bench_pmc_counters_poisson2d_1m.txt python bench.py --workload poisson2d_1m --steps 20 --warmup 3 --no-cpu-baseline
 pmc $S/${tag}_bench_pmc_counters_dense_rows_200k.txt python bench.py --workload dense_rows_200k --steps 10 --warmup 2 --no-cpu-baseline
+pmc $S/${tag}_bench_pmc_counters_gmres_banded_2m.txt python bench.py --mode gmres --workload banded_2m --steps 60 --warmup 0 --no-cpu-baseline
+# round 4: the plain CSR kernels (general_csr: spmv_wave_kernel) on the headline matrix -- HBM bytes per launch against 12 nnz + 28 n
+SLA_WDIA=0 SLA_VDICT=0 SLA_DIAG=0 pmc $S/${tag}_bench_pmc_counters_general_csr.txt python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extra-blocks
 # round 3: one rank's 8-GPU slab (108^3 rows) through a 1-rank RCCL communicator: ghost-row flow with the fused K4+K5 sweep on own + ghost rows
 # (2 grouped exchanges per step) against the reference's split (3), window and all-gather exchange
 for f in 1 0; do for xe in window allgather; do
@@ -66,7 +72,7 @@ for f in sorted(glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive
 PY
   d=$S/pmc_tmp; rm -rf $d; mkdir -p $d
   SLA_WDIA=0 SLA_VDICT=0 SLA_DIAG=0 timeout 600 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $d -o p -- python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-extra-blocks > /dev/null 2>&1
-  python - "$d" spmv_stream <<'PY' >> $S/${tag}_pmc_l1_l2_stream_kernel.txt
+  python - "$d" spmv_wave <<'PY' >> $S/${tag}_pmc_l1_l2_stream_kernel.txt
 import csv, glob, collections, sys
 for f in sorted(glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True)):
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
@@ -99,4 +105,8 @@ for f in sorted(glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive
         if sys.argv[2] in k: print(k, {c: (len(v), sum(v) / len(v)) for c, v in cs.items()})
 PY
 done
-ls -la $S | head -40
+# round 4: parity in the hard regime (traces on e05r0000 / the beam system), the split cost of the overlapped all-gather, plain-CSR kernel A/B
+timeout 600 python tools/hard_regime.py > $S/${tag}_hard_regime.txt 2>&1
+timeout 900 python tools/ag_split_bench.py > $S/${tag}_ag_split_cost.txt 2>&1
+timeout 900 python tools/wave_ab.py 30 2 > $S/${tag}_ab_wave_kernel.txt 2>&1
+ls -la $S | head -60
