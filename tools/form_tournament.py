@@ -1,5 +1,5 @@
 """Is the form the lowering picks the fastest one the library has?  One BiCGSTAB step per form on a workload, same box.
-    python tools/form_tournament.py banded_2m|poisson2d_1m|laplace3d_10m|laplace3d_1m [steps]"""
+    python tools/form_tournament.py banded_2m|poisson2d_1m|laplace3d_10m|laplace3d_1m|e05_tiled|varcoef7|rand100|rand200|rand500|powerlaw [steps]"""
 import os
 import sys
 
@@ -7,17 +7,85 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
+import numpy as np  # noqa: E402
+
+
+def zoo(name):
+    """The middle of the matrix zoo: matrices between the stencils and the 33-per-row random matrix.  Diagonally
+    dominant by construction (diagonal = 1 + sum |off-diagonal|) so that BiCGSTAB steps stay finite; b = A.1."""
+    rng = np.random.default_rng(2026)
+    if name == "e05_tiled":          # the reference's real-world fixture (test/data/e05r0000.mtx, 236 x 236, 5856 entries) as 4300 diagonal blocks
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from refdata import GOLDEN, read_mtx_coordinate
+        (m, _), r, c, v = read_mtx_coordinate(f"{GOLDEN}/e05r0000.mtx")
+        order = np.lexsort((c, r))
+        r, c, v = r[order], c[order], v[order]
+        reps = 4300
+        rows = (r[None, :] + m * np.arange(reps)[:, None]).ravel()
+        cols = (c[None, :] + m * np.arange(reps)[:, None]).ravel()
+        vals = np.tile(v, reps)
+        n = m * reps
+    elif name == "varcoef7":         # 7-point grid 128^3 with a different coefficient on every entry (> 256 (offset, value) pairs)
+        g = 128
+        n = g ** 3
+        idx = np.arange(n)
+        x, y, z = idx % g, (idx // g) % g, idx // (g * g)
+        rows, cols = [], []
+        for d, ok in ((-g * g, z > 0), (-g, y > 0), (-1, x > 0), (0, np.ones(n, bool)), (1, x < g - 1), (g, y < g - 1), (g * g, z < g - 1)):
+            rows.append(idx[ok]); cols.append(idx[ok] + d)
+        rows, cols = np.concatenate(rows), np.concatenate(cols)
+        order = np.lexsort((cols, rows))
+        rows, cols = rows[order], cols[order]
+        vals = -rng.uniform(0.5, 1.5, len(rows))
+    elif name.startswith("rand"):    # n rows x k random columns per row (stratified: column j of a row in the j-th n/k-th of the columns)
+        k = int(name[4:])
+        n = 1000000
+        w = n // k
+        cols = (np.arange(k, dtype=np.int64)[None, :] * w + rng.integers(0, w, (n, k))).ravel()
+        rows = np.repeat(np.arange(n, dtype=np.int64), k)
+        vals = rng.uniform(-1.0, 1.0, n * k)
+    elif name == "powerlaw":         # 2 M rows, row lengths ~ Zipf(1.6) clipped to [1, 4000] (mean ~ 12), random columns
+        n = 2000000
+        lens = np.minimum(rng.zipf(1.6, n), 4000).astype(np.int64)
+        rows = np.repeat(np.arange(n, dtype=np.int64), lens)
+        w = n // lens
+        off = np.arange(len(rows)) - np.repeat(np.cumsum(lens) - lens, lens)          # position of the entry inside its row
+        cols = off * np.repeat(w, lens) + (rng.random(len(rows)) * np.repeat(w, lens)).astype(np.int64)
+        vals = rng.uniform(-1.0, 1.0, len(rows))
+    else:
+        return None
+    rp = np.concatenate(([0], np.cumsum(np.bincount(rows, minlength=n)))).astype(np.int64)
+    diag = cols == rows
+    if name != "e05_tiled" and int(diag.sum()) == n:   # a diagonal entry in every row: make it dominant (the random families have none: their
+        absum = np.bincount(rows[~diag], weights=np.abs(vals[~diag]), minlength=n)   # steps are timed on whatever the recurrences produce --
+        vals[diag] = 1.0 + absum[rows[diag]]           # kernel time is data-independent)
+    return f"{name}: {n} rows, {len(vals)} entries ({len(vals) / n:.1f} per row)", ((n, n), (rp, cols.astype(np.int64), vals))
+
+
 name = sys.argv[1] if len(sys.argv) > 1 else "banded_2m"
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 60
-desc, (dims, (rp, ci, va)) = bench.workload(name)
+z = zoo(name)
+desc, (dims, (rp, ci, va)) = z if z else bench.workload(name)
 forms = (("default", {}), ("no march", {"wd_march": 0}), ("gather (wd_lds=0)", {"wd_lds": 0}), ("no wdia-vv", {"wdia_vv": 0}), ("no wdia", {"wdia": 0}),
          ("no wdia, no xwin", {"wdia": 0, "xwin": 0}), ("dictionary codes", {"wdia": 0, "vdict": 0}), ("dictionary codes + xwin", {"wdia": 0, "vdict": 0, "xwin": 2}),
-         ("plain CSR", {"wdia": 0, "vdict": 0, "diag": 0}))
+         ("no tiles", {"tiles": 0}), ("no tiles, no col panels", {"tiles": 0, "panels": 0}), ("no LDS panels", {"lpanel": 0}),
+         ("no LDS panels, no tiles", {"lpanel": 0, "tiles": 0, "panels": 0}), ("LDS panels forced", {"lp_minseg": 1}),
+         ("tiles, 2^16-column panels", {"lpanel": 0, "tile_shift": 16}), ("tiles, 2^15-column panels", {"lpanel": 0, "tile_shift": 15}),
+         ("plain CSR", {"wdia": 0, "vdict": 0, "diag": 0, "tiles": 0, "panels": 0, "lpanel": 0}),
+         ("plain CSR, stream kernel", {"wdia": 0, "vdict": 0, "diag": 0, "tiles": 0, "panels": 0, "lpanel": 0, "stream_wave": 0}))
 seen = set()
+nnz = int(rp[-1])
 for label, opts in forms:
-    r = bench.side_block(desc, dims, rp, ci, va, opts, steps, 10)
-    algo = r["spmv_kernel"].split()[0]
+    try:
+        r = bench.side_block(desc, dims, rp, ci, va, opts, steps, 10)
+    except Exception as e:  # noqa: BLE001
+        print(f"{name:14s} {label:26s} failed: {e!r}", flush=True)
+        continue
+    info = r["spmv_kernel"]
+    algo = info.split()[0] + (" " + [t for t in info.split() if t.startswith("panel_cols=")][0] if "panel_cols=" in info else "")
     if algo in seen and label != "default":
         continue
     seen.add(algo)
-    print(f"{name:14s} {label:26s} {r['value']:9.1f} it/s  " + "  ".join(f"{k} {v['ms'] * 1e3:.1f}" for k, v in r["kernels"].items()) + "  " + algo, flush=True)
+    k1 = r["kernels"].get("K1", {}).get("ms", float("nan"))
+    print(f"{name:14s} {label:30s} {r['value']:9.1f} it/s  " + "  ".join(f"{k} {v['ms'] * 1e3:.1f}" for k, v in r["kernels"].items())
+          + f"  K1 on CSR bytes {(12 * nnz + 28 * dims[0]) / k1 / 1e6 / 8000:.3f} of peak  lowered in {r['lowered_once']['from_csr_s']:.2f} s  " + algo, flush=True)
