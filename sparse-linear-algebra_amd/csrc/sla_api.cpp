@@ -445,6 +445,8 @@ const IntKnob kIntKnobs[] = {
     {"vdict", &sla_ctx::vdict, 0, 1},
     {"wdia", &sla_ctx::wdia, 0, 1},
     {"lpanel", &sla_ctx::lpanel, 0, 1},
+    {"lflat", &sla_ctx::lflat, 0, 2},
+    {"lf_min_seg10", &sla_ctx::lf_min_seg10, 1, 10000},
     {"lp_tasks", &sla_ctx::lp_tasks, 1, 1 << 20},
     {"lp_copy", &sla_ctx::lp_copy, 0, 1},
     {"lp_cfg", &sla_ctx::lp_cfg, -1, 3},
@@ -832,6 +834,9 @@ int sla_csr_destroy(sla_csr_t A) {
     if (A->d_lpcol) (void)hipFree(A->d_lpcol);
     if (A->d_lpval) (void)hipFree(A->d_lpval);
     if (A->d_lpt) (void)hipFree(A->d_lpt);
+    if (A->d_lfq) (void)hipFree(A->d_lfq);
+    if (A->d_lfcol) (void)hipFree(A->d_lfcol);
+    if (A->d_lfval) (void)hipFree(A->d_lfval);
     if (A->d_wvblk) (void)hipFree(A->d_wvblk);
     if (A->d_wme) (void)hipFree(A->d_wme);
     if (A->d_wmo) (void)hipFree(A->d_wmo);
@@ -898,7 +903,7 @@ int sla_csr_kernel_info(sla_csr_t A, char *buf, int buflen) {
     if (A && !A->kids.empty()) return sla_csr_kernel_info(A->kids[0], buf, buflen);
     if (!A || !buf || buflen <= 0) return fail(SLA_ERR_INVALID, "null argument");
     snprintf(buf, (size_t)buflen, "algo=%s grid=%d block=%d row_blocks=%d nnz_per_row_block=%d max_row_nnz=%lld rowptr=%s xcd_remap=%d",
-             A->ctx->spmv_algo == 1 ? "scalar" : (A->use_wdia && wd_on(A)) ? (A->wd_vv ? "wdia-vv" : wd_march_on(A) ? "wdia+march" : wd_lds_on(A) ? "wdia+ldswin" : "wdia") : (A->use_vdict && A->ctx->vdict) ? (A->use_xwin && A->ctx->xwin ? "vdict+xwin" : "vdict") : (A->use_lpanel && A->ctx->lpanel) ? "stream+ldspanels" : tiles_on(A) ? "tiles" : (!A->panels.empty() && A->ctx->panels) ? "stream+colpanels" : (A->use_diag && A->ctx->diag ? (diag_xwin_on(A) ? "stream+diagdict+xwin" : "stream+diagdict") : (pipe_on(A) ? "stream+pipe" : stream_xwin_on(A) ? "stream+xwin" : wave_plain(A) ? "stream+wave" : "stream")), spmv_grid(A), kBlock, A->nrb, kNnzPerRowBlock,
+             A->ctx->spmv_algo == 1 ? "scalar" : (A->use_wdia && wd_on(A)) ? (A->wd_vv ? "wdia-vv" : wd_march_on(A) ? "wdia+march" : wd_lds_on(A) ? "wdia+ldswin" : "wdia") : (A->use_vdict && A->ctx->vdict) ? (A->use_xwin && A->ctx->xwin ? "vdict+xwin" : "vdict") : (A->use_lpanel && A->ctx->lpanel) ? "stream+ldspanels" : lflat_on(A) ? "lflat" : tiles_on(A) ? "tiles" : (!A->panels.empty() && A->ctx->panels) ? "stream+colpanels" : (A->use_diag && A->ctx->diag ? (diag_xwin_on(A) ? "stream+diagdict+xwin" : "stream+diagdict") : (pipe_on(A) ? "stream+pipe" : stream_xwin_on(A) ? "stream+xwin" : wave_plain(A) ? "stream+wave" : "stream")), spmv_grid(A), kBlock, A->nrb, kNnzPerRowBlock,
              (long long)A->max_row_nnz, A->rp64 ? "i64" : "i32", A->ctx->xcd_remap);
     if (A->use_lpanel && A->ctx->lpanel && A->ctx->spmv_algo == 0) {   // LDS-panel geometry
         const size_t used = strlen(buf);

@@ -260,6 +260,8 @@ struct sla_ctx {
     int force_rp64 = 0;              // test hook: 64-bit row pointers at any size (SLA_FORCE_RP64)
     int lp_copy = 1;                 // LDS-panel form: stream a panel-major second copy of col / val (SLA_LP_COPY=0: the row-major arrays)
     int lpanel = 1;                  // allow the LDS-panel SpMV kernel for matrices with dense rows (SLA_LPANEL=0 disables)
+    int lflat = 1;                   // allow its flat variant for segments of 1.5 .. 16 entries (SLA_LFLAT: 0 off, 2: also above the LDS-panel threshold)
+    int lf_min_seg10 = 15;           // ... from this mean (panel, row) segment length on, in tenths (SLA_LF_MIN_SEG10)
     int xwin = 1;                    // LDS x windows: 1 = where they pay (the pair-code kernel), 2 = also the dictionary-code kernels, 0 = nowhere (SLA_XWIN); the plain CSR-stream kernel takes its window form only with stream_wide = 0
     int stream_wide = 1;             // spmv_stream_kernel: pairs of entries per load (8-byte col / 16-byte val loads) instead of one (SLA_STREAM_WIDE=0)
     int stream_wave = 1;             // plain CSR (#>): wavefront-private 128-row blocks with row-pair stores (sla_spmv_wave.hip) instead of spmv_stream_kernel when no row
@@ -359,6 +361,12 @@ struct sla_csr {
     double *d_lpval = nullptr;       //   d_lpp holds P x rows + 1 segment starts into it instead of the (P + 1) x rows table
     double *d_lpy = nullptr;         // P x rows partial sums, summed in ascending panel order by lpanel_finish_kernel
     bool use_lpanel = false;
+    // flat LDS-panel form (sla_spmv_lflat.hip: one lane per (panel, row) segment; mean segment of 1.5 .. 16 entries): panel-major copy + segment starts;
+    // shares lp_P / lp_W / lp_C / lp_chunk / lp_G, d_lpt and d_lpy with the LDS-panel form (the two exclude each other)
+    bool use_lflat = false;
+    uint32_t *d_lfq = nullptr;       // P x rows + 1 segment starts into the copy
+    uint16_t *d_lfcol = nullptr;     // columns as 16-bit offsets into the panel
+    double *d_lfval = nullptr;
     int32_t lp_cfg = 0;              // lane-group shape of spmv_lpanel_kernel (0: 64 lanes per segment ... 3: 8 lanes)
     int32_t lp_P = 0, lp_W = 0, lp_C = 0, lp_chunk = 0;   // panels, columns per panel, row chunks per panel, rows per chunk
     bool use_wdia = false;
@@ -693,6 +701,10 @@ int launch_spmv_wdia(const sla_csr *A, int epi, const SpmvArgs<int32_t> &a, cons
 int launch_lp_reorder(sla_ctx *c, bool rp64, const void *pp, const void *q, const int32_t *col, const double *val, uint16_t *col2, double *val2,
                       int64_t rows, int64_t P, int32_t W);                                                            // sla_spmv_lpanel.hip
 int launch_spmv_lpanel(const sla_csr *A, int epi, const SpmvArgs<int32_t> &a, int grid);
+int launch_lpanel_finish(const sla_csr *A, int epi, const SpmvArgs<int32_t> &a, int grid);   // its finish kernel alone
+bool lflat_on(const sla_csr *A);                                                                             // sla_spmv_lflat.hip
+int build_lflat(sla_csr *A, int64_t n, int64_t rows, int64_t col_lo, int64_t col_hi);
+int launch_spmv_lflat(const sla_csr *A, int epi, const SpmvArgs<int32_t> &a, int grid);
 int launch_spmv_lpanel(const sla_csr *A, int epi, const SpmvArgs<int64_t> &a, int grid);
 // do the solver's vectors (7 of n entries for BiCGSTAB) overflow the memory-side cache?  Then stream them past it.
 inline bool vec_stream_nt(const sla_ctx *c, int64_t n) { return c->vec_nt < 0 ? 7 * 8 * n > c->mall_bytes : c->vec_nt != 0; }

@@ -331,15 +331,22 @@ static void low_value_indexed(Low &L) {
         std::vector<Pair> &pairs = tab.pairs;
         auto find = [&](int64_t off, uint64_t bits, bool insert) -> int { return tab.find(off, bits, insert); };
         bool ok = true;
+        // ONE pass over the entries (round 4: the table pass and the code pass each read col + val, 1.1 GB at 70 M entries): every
+        // thread codes its rows against its OWN table while it builds it; once the tables are merged and ranked the thread-local
+        // codes are translated in place (1 B per entry)
+        std::vector<uint8_t> codes(((size_t)nnz + 3) / 4 * 4 + 16, 0);
+        std::vector<PairTable> loc((size_t)host_threads());
         {
-            std::vector<PairTable> loc((size_t)host_threads());
             std::vector<char> bad((size_t)host_threads(), 0);
             par_rows(rows, 1, [&](int t, int64_t lo, int64_t hi) {
                 PairTable &mine = loc[(size_t)t];
                 for (int64_t i = lo; i < hi && !bad[(size_t)t]; ++i) {
                     const int64_t gr = row_begin + i;
-                    for (int64_t k = rowptr[i]; k < rowptr[i + 1]; ++k)
-                        if (mine.find(col[k] - gr, bits_of(val[k]), true) < 0) { bad[(size_t)t] = 1; break; }
+                    for (int64_t k = rowptr[i]; k < rowptr[i + 1]; ++k) {
+                        const int id = mine.find(col[k] - gr, bits_of(val[k]), true);
+                        if (id < 0) { bad[(size_t)t] = 1; break; }
+                        codes[(size_t)k] = (uint8_t)id;
+                    }
                 }
             });
             for (size_t t = 0; t < loc.size() && ok; ++t) {
@@ -363,13 +370,11 @@ static void low_value_indexed(Low &L) {
                 doff[t] = (int32_t)pairs[(size_t)order[t]].off;
                 memcpy(&dval[t], &pairs[(size_t)order[t]].bits, 8);
             }
-            std::vector<uint8_t> codes(((size_t)nnz + 3) / 4 * 4 + 16, 0);
-            par_rows(rows, 1, [&](int, int64_t lo, int64_t hi) {   // (lookups only: the table is read-only now)
-                for (int64_t i = lo; i < hi; ++i) {
-                    const int64_t gr = row_begin + i;
-                    for (int64_t k = rowptr[i]; k < rowptr[i + 1]; ++k)
-                        codes[(size_t)k] = (uint8_t)rank[(size_t)find(col[k] - gr, bits_of(val[k]), false)];
-                }
+            par_rows(rows, 1, [&](int t, int64_t lo, int64_t hi) {   // (the same row partition as above: thread t translates its own codes)
+                uint8_t lut[256];
+                const PairTable &mine = loc[(size_t)t];
+                for (size_t q = 0; q < mine.pairs.size(); ++q) lut[q] = (uint8_t)rank[(size_t)find(mine.pairs[q].off, mine.pairs[q].bits, false)];
+                for (int64_t k = rowptr[lo]; k < rowptr[hi]; ++k) codes[(size_t)k] = lut[codes[(size_t)k]];
             });
             upload((void **)&A->d_vcode, codes.data(), codes.size());
             upload((void **)&A->d_vdoff, doff.data(), sizeof(int32_t) * doff.size());
@@ -820,10 +825,11 @@ int csr_upload(sla_ctx *c, int64_t m, int64_t n, int64_t row_begin, int64_t rows
             std::thread &t;
             ~Joiner() { if (t.joinable()) t.join(); }
         } up_joiner{up};
-        low_xwin_statistics(L);
-        lap("x-window statistics");
         low_value_indexed(L);
         lap("pair dictionary + wave slices");
+        // (the LDS x windows of the row blocks serve the CSR-stream / dictionary-code kernels only: skipped with them, see below)
+        if (!(A->use_wdia && c->wdia && c->diag_lazy)) low_xwin_statistics(L);
+        lap("x-window statistics");
         // (the 1-byte column codes serve the dictionary-code kernel and the variable-coefficient slices: a matrix that just took the
         // constant-coefficient wave-sliced form needs neither -- unless the context's knobs peel that form off again (A/B runs), which
         // is decided when the matrix is created: two passes over the entries and 1 B per entry of upload saved, round 4)
@@ -836,6 +842,19 @@ int csr_upload(sla_ctx *c, int64_t m, int64_t n, int64_t row_begin, int64_t rows
         lap("canonical CSR upload (rest)");
         low_lds_panels(L);                 // (its panel-major copy is written by a device kernel from the canonical arrays)
         lap("LDS panel table");
+        if (!panel_view && err == hipSuccess && !A->use_lpanel && c->lflat && nnz > 0) {   // medium rows: the flat LDS-panel form (device-built)
+            std::vector<int64_t> plo((size_t)host_threads(), n), phi((size_t)host_threads(), -1);
+            par_rows(rows, 1, [&](int t, int64_t lo, int64_t hi) {   // (canonical CSR: first / last entry of a row are its min / max column)
+                int64_t a = n, b = -1;
+                for (int64_t i = lo; i < hi; ++i)
+                    if (rowptr[i + 1] > rowptr[i]) { a = std::min(a, col[rowptr[i]]); b = std::max(b, col[rowptr[i + 1] - 1]); }
+                plo[(size_t)t] = a;
+                phi[(size_t)t] = b;
+            });
+            const int rc_lf = build_lflat(A, n, rows, *std::min_element(plo.begin(), plo.end()), *std::max_element(phi.begin(), phi.end()));
+            if (rc_lf != SLA_OK && err == hipSuccess) err = hipErrorUnknown;
+            lap("flat LDS-panel form");
+        }
     } catch (const std::bad_alloc &) {
         if (err == hipSuccess) err = hipErrorOutOfMemory;
     }
@@ -871,7 +890,7 @@ int csr_upload(sla_ctx *c, int64_t m, int64_t n, int64_t row_begin, int64_t rows
         const int rc_ag = build_ag_plan(A, rc != SLA_OK);
         if (rc == SLA_OK) rc = rc_ag;
     }
-    if (rc == SLA_OK && !(A->use_lpanel && c->lpanel) && !A->use_tiles) rc = build_panels(A, m, n, row_begin, rows, rowptr, col, val);
+    if (rc == SLA_OK && !(A->use_lpanel && c->lpanel) && !(A->use_lflat && c->lflat) && !A->use_tiles) rc = build_panels(A, m, n, row_begin, rows, rowptr, col, val);
     lap("column panels");
     if (rc != SLA_OK) {
         sla_csr_destroy(A);

@@ -441,7 +441,7 @@ bool dual_ok(const sla_solver *S) {
            // (the wave-sliced form streams ~2 B of matrix per row: fusing the two sweeps saves nothing there)
            !(S->A->use_wdia && wd_on(S->A)) &&
            // (the LDS-panel form has no fused two-vector variant; two of its sweeps beat one L2-gathering dual sweep)
-           !(S->A->use_lpanel && S->ctx->lpanel) && !tiles_on(S->A);
+           !(S->A->use_lpanel && S->ctx->lpanel) && !lflat_on(S->A) && !tiles_on(S->A);
 }
 
 int read_scalars(sla_solver *S) {

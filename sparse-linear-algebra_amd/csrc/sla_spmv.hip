@@ -39,10 +39,10 @@ bool wave_plain(const sla_csr *A) {
 int spmv_grid(const sla_csr *A) {
     const sla_ctx *c = A->ctx;
     // with column panels the fused partials are written by the LAST panel pass: its grid is the one that counts
-    if (tiles_on(A)) return tiles_grid(A);
+    if (tiles_on(A) && !lflat_on(A)) return tiles_grid(A);
     if (!A->panels.empty() && c->panels && c->spmv_algo == 0) return spmv_grid(A->panels.back());
     int64_t g;
-    if (c->spmv_algo == 1 || (A->use_lpanel && c->lpanel)) g = (A->rows + kBlock - 1) / kBlock;   // (lpanel: its finish kernel)
+    if (c->spmv_algo == 1 || (A->use_lpanel && c->lpanel) || lflat_on(A)) g = (A->rows + kBlock - 1) / kBlock;   // (lpanel / lflat: the finish kernel)
     else if (A->use_wdia && wd_on(A) && wd_march_on(A)) g = wd_march_grid(A);   // (the whole-matrix launch: overlap_grid sizes the split ones)
     else if (A->use_wdia && wd_on(A)) g = std::min<int64_t>(A->nblk_wd, A->wd_vv ? c->wd_grid_max_vv : wd_lds_on(A) ? wd_lds_grid(A) : c->wd_grid_max);
     else if (A->use_vdict && c->vdict) g = A->nblk_vd;
@@ -125,6 +125,9 @@ static int launch_spmv_rp(const sla_csr *A, const SpmvLaunch &l) {
     const int grid = spmv_grid(A);
     ProfScope prof(c, l.kernel_id);
     if (A->use_lpanel && c->lpanel && c->spmv_algo == 0 && !l.x2 && !l.yinit) return launch_spmv_lpanel(A, l.epi, a, grid);
+    if constexpr (std::is_same<RP, int32_t>::value) {
+        if (lflat_on(A) && !l.x2 && !l.yinit) return launch_spmv_lflat(A, l.epi, a, grid);
+    }
     if constexpr (std::is_same<RP, int32_t>::value) {   // the value-indexed forms exist with 32-bit row pointers only
         if (A->use_wdia && wd_on(A) && c->spmv_algo == 0 && !l.x2) {
             const int32_t *sched = c->wd_tile != 0 ? A->d_wsched : nullptr;
@@ -149,7 +152,7 @@ static int launch_spmv_rp(const sla_csr *A, const SpmvLaunch &l) {
 }
 
 int launch_spmv(const sla_csr *A, const SpmvLaunch &l) {
-    if (tiles_on(A) && !l.x2 && (!l.yinit || l.tv1 >= 0)) return launch_spmv_tiles(A, l);
+    if (tiles_on(A) && !lflat_on(A) && !l.x2 && (!l.yinit || l.tv1 >= 0)) return launch_spmv_tiles(A, l);
     return A->rp64 ? launch_spmv_rp<int64_t>(A, l) : launch_spmv_rp<int32_t>(A, l);
 }
 

@@ -267,6 +267,19 @@ int launch_lpanel_rp(const sla_csr *A, int epi, const SpmvArgs<RP> &a, int grid)
 }
 }  // namespace
 
+// the finish kernel alone (the flat form, sla_spmv_lflat.hip, leaves its partials in the same layout)
+int launch_lpanel_finish(const sla_csr *A, int epi, const SpmvArgs<int32_t> &a, int grid) {
+    sla_ctx *c = A->ctx;
+#define SLA_LPF(E) case E: hipLaunchKernelGGL((lpanel_finish_kernel<E, int32_t>), dim3(grid), dim3(kBlock), 0, stream_of(c), a, A->d_lpy, A->lp_P); break
+    switch (epi) {
+        SLA_LPF(EPI_NONE); SLA_LPF(EPI_DOT); SLA_LPF(EPI_DOT2); SLA_LPF(EPI_DOT4); SLA_LPF(EPI_RES); SLA_LPF(EPI_AXPY_DOT); SLA_LPF(EPI_XPBY_NRM); SLA_LPF(EPI_SUB);
+        default: return fail(SLA_ERR_INVALID, "launch_lpanel_finish: unknown epilogue");
+    }
+#undef SLA_LPF
+    SLA_HIP_TRY(hipGetLastError());
+    return SLA_OK;
+}
+
 int launch_spmv_lpanel(const sla_csr *A, int epi, const SpmvArgs<int32_t> &a, int grid) { return launch_lpanel_rp<int32_t>(A, epi, a, grid); }
 int launch_spmv_lpanel(const sla_csr *A, int epi, const SpmvArgs<int64_t> &a, int grid) { return launch_lpanel_rp<int64_t>(A, epi, a, grid); }
 

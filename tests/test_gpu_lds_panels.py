@@ -177,3 +177,90 @@ def test_lds_panels_randomised_shapes(sla):
         assert np.all(np.abs(y - want) <= _bound((rp, ci, va), x, m)), (case, A.kernel_info(), np.abs(y - want).max())
         del A
     assert taken >= 12, taken
+
+
+# ---- the flat variant (sla_spmv_lflat.hip, round 4): one lane per (panel, row) segment, for segments of 1.5 .. 16 entries ----------------
+
+FLAT_CASES = {
+    "4 panels, 60000 x 60000, 24 per row (segments of 6)": lambda: _dense_rows(60000, 60000, 24, 21),
+    "7 panels, wide 3000 x 100000, 40 per row": lambda: _dense_rows(3000, 100000, 40, 22),
+    "ragged rows (0, 1, 3, 30, 120, 700 entries), 4 panels": lambda: _dense_rows(5003, 60000, 30, 23, ragged=True),
+    "fewer rows than a workgroup round: 100 x 80000, 60 per row": lambda: _dense_rows(100, 80000, 60, 24),
+    "one row: 1 x 70000, 90 entries": lambda: _dense_rows(1, 70000, 90, 25),
+    "tall 120000 x 50000, 8 per row (segments of 2)": lambda: _dense_rows(120000, 50000, 8, 26),
+}
+
+
+@pytest.mark.parametrize("name", list(FLAT_CASES))
+def test_flat_lds_panel_form_matches_the_oracle(sla, name):
+    """`lflat`: the form between the tile form and the LDS panels.  Device-built panel-major copy, one lane per segment, left fold per
+    segment, segment sums folded in ascending panel order by the shared finish kernel: per row within nnz_i eps sum |a_ij x_j| of the
+    oracle's single left fold, deterministic, and against the forms it replaces (lflat = 0)."""
+    dims, csr = FLAT_CASES[name]()
+    m, n = dims
+    rp, ci, va = csr
+    Ao = orc.Csr(m, n, rp, ci, va)
+    x = np.random.default_rng(11).standard_normal(n)
+    want = orc.spmv(Ao, x)
+    bound = _bound(csr, x, m)
+    ctx = sla.Context(0).set_options(lflat=2, lf_min_seg10=1)      # (force the form onto every case: the lowering's own window is 1.5 .. 16)
+    A = sla.fromCSR(dims, rp, ci, va, ctx)
+    info = A.kernel_info()
+    assert info.startswith("algo=lflat "), (name, info)
+    y = sla.matVec(A, sla.fromVector(x, ctx)).toDenseListSV()
+    assert np.all(np.abs(y - want) <= bound), (name, float(np.abs(y - want).max()), int(np.argmax(np.abs(y - want) - bound)))
+    assert np.array_equal(y, sla.matVec(A, sla.fromVector(x, ctx)).toDenseListSV())
+    if m == n:     # (<#) goes through the lazily built transpose, which picks its own form
+        w = np.random.default_rng(12).standard_normal(m)
+        yt = sla.vecMat(sla.fromVector(w, ctx), A).toDenseListSV()
+        assert np.allclose(yt, orc.spmv(orc.transpose(Ao), w), rtol=1e-12, atol=1e-12)
+    del A
+    ctx.close()
+    ctx0 = sla.Context(0).set_options(lflat=0)
+    A0 = sla.fromCSR(dims, rp, ci, va, ctx0)
+    assert "lflat" not in A0.kernel_info()
+    y0 = sla.matVec(A0, sla.fromVector(x, ctx0)).toDenseListSV()
+    assert np.all(np.abs(y0 - want) <= bound)
+    del A0
+    ctx0.close()
+
+
+def test_flat_lds_panel_form_is_picked_for_medium_rows_and_runs_the_solvers(sla):
+    """The lowering's own choice (no forcing): 50000 x 50000 with 24 random entries per row = 4 panels, segments of 6 -> lflat; 8 per row
+    (segments of 2) too; 3 per row (segments of 0.75) not.  Then every fused epilogue through bicgstabStep (fused and split), cgsStep,
+    cgneStep and linSolve0 against the oracle."""
+    n = 50000
+    for k, expect in ((24, True), (8, True), (3, False)):
+        dims, (rp, ci, va) = _dense_rows(n, n, k, 31 + k, dominant=True)
+        A = sla.fromCSR(dims, rp, ci, va)
+        assert A.kernel_info().startswith("algo=lflat ") == expect, (k, A.kernel_info())
+        del A
+    dims, (rp, ci, va) = _dense_rows(n, n, 24, 55, dominant=True)
+    Ao = orc.Csr(n, n, rp, ci, va)
+    b = orc.spmv(Ao, np.linspace(-1.0, 2.0, n))
+    x0 = np.full(n, 0.25)
+    for fuse in (1, 0):
+        ctx = sla.Context(0).set_options(bicg_fuse45=fuse)
+        A = sla.fromCSR(dims, rp, ci, va, ctx)
+        assert A.kernel_info().startswith("algo=lflat ")
+        so, sd = orc.BicgstabState(Ao, b, x0), sla.bicgsInit(A, sla.fromVector(b, ctx), sla.fromVector(x0, ctx))
+        so.step(b - orc.spmv(Ao, x0), 2)
+        sd.step(2)
+        for nm, dev, ref in (("x", sd._xBicgstab, so.x), ("r", sd._rBicgstab, so.r), ("p", sd._pBicgstab, so.p)):
+            assert np.linalg.norm(dev.toDenseListSV() - ref) <= 1e-11 * np.linalg.norm(ref), (fuse, nm)
+        del sd
+        if fuse:
+            sc, sdc = orc.CgsState(Ao, b, x0), sla.cgsInit(A, sla.fromVector(b, ctx), sla.fromVector(x0, ctx))
+            sc.step(b - orc.spmv(Ao, x0), 2)
+            sdc.step(2)
+            assert np.linalg.norm(sdc._x.toDenseListSV() - sc.x) <= 1e-11 * np.linalg.norm(sc.x)
+            sn, sdn = orc.CgneState(Ao, b, x0), sla.cgneInit(A, sla.fromVector(b, ctx), sla.fromVector(x0, ctx))
+            sn.step(2)
+            sdn.step(2)
+            assert np.linalg.norm(sdn._xCgne.toDenseListSV() - sn.x) <= 1e-11 * np.linalg.norm(sn.x)
+            del sdc, sdn
+            xs, inf = sla.linSolve0(sla.BICGSTAB_, A, sla.fromVector(b, ctx), sla.fromVector(x0, ctx), return_info=True)
+            rc, xo, it_o, res_o, r0_o = orc.linsolve0(orc.BICGSTAB_, Ao, b, x0)
+            assert inf["converged"] and abs(inf["iters"] - it_o) <= 2 and np.linalg.norm(orc.spmv(Ao, xs.toDenseListSV()) - b) <= inf["tol"] * (1 + 1e-9)
+        del A
+        ctx.close()
