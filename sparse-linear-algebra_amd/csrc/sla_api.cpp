@@ -440,7 +440,7 @@ const IntKnob kIntKnobs[] = {
     {"stream_pipe", &sla_ctx::stream_pipe, 0, 1},
     {"stream_wave", &sla_ctx::stream_wave, 0, 1999},
     {"stream_wide", &sla_ctx::stream_wide, 0, 1},
-    {"diag", &sla_ctx::diag, 0, 1},
+    {"diag", &sla_ctx::diag, 0, 2},
     {"diag_lazy", &sla_ctx::diag_lazy, 0, 1},
     {"vdict", &sla_ctx::vdict, 0, 1},
     {"wdia", &sla_ctx::wdia, 0, 1},
@@ -903,7 +903,7 @@ int sla_csr_kernel_info(sla_csr_t A, char *buf, int buflen) {
     if (A && !A->kids.empty()) return sla_csr_kernel_info(A->kids[0], buf, buflen);
     if (!A || !buf || buflen <= 0) return fail(SLA_ERR_INVALID, "null argument");
     snprintf(buf, (size_t)buflen, "algo=%s grid=%d block=%d row_blocks=%d nnz_per_row_block=%d max_row_nnz=%lld rowptr=%s xcd_remap=%d",
-             A->ctx->spmv_algo == 1 ? "scalar" : (A->use_wdia && wd_on(A)) ? (A->wd_vv ? "wdia-vv" : wd_march_on(A) ? "wdia+march" : wd_lds_on(A) ? "wdia+ldswin" : "wdia") : (A->use_vdict && A->ctx->vdict) ? (A->use_xwin && A->ctx->xwin ? "vdict+xwin" : "vdict") : (A->use_lpanel && A->ctx->lpanel) ? "stream+ldspanels" : lflat_on(A) ? "lflat" : tiles_on(A) ? "tiles" : (!A->panels.empty() && A->ctx->panels) ? "stream+colpanels" : (A->use_diag && A->ctx->diag ? (diag_xwin_on(A) ? "stream+diagdict+xwin" : "stream+diagdict") : (pipe_on(A) ? "stream+pipe" : stream_xwin_on(A) ? "stream+xwin" : wave_plain(A) ? "stream+wave" : "stream")), spmv_grid(A), kBlock, A->nrb, kNnzPerRowBlock,
+             A->ctx->spmv_algo == 1 ? "scalar" : (A->use_wdia && wd_on(A)) ? (A->wd_vv ? "wdia-vv" : wd_march_on(A) ? "wdia+march" : wd_lds_on(A) ? "wdia+ldswin" : "wdia") : (A->use_vdict && A->ctx->vdict) ? (A->use_xwin && A->ctx->xwin ? "vdict+xwin" : "vdict") : (A->use_lpanel && A->ctx->lpanel) ? "stream+ldspanels" : lflat_on(A) ? "lflat" : tiles_on(A) ? "tiles" : (!A->panels.empty() && A->ctx->panels) ? "stream+colpanels" : (diag_on(A) ? (diag_xwin_on(A) ? "stream+diagdict+xwin" : "stream+diagdict") : (pipe_on(A) ? "stream+pipe" : stream_xwin_on(A) ? "stream+xwin" : wave_plain(A) ? "stream+wave" : "stream")), spmv_grid(A), kBlock, A->nrb, kNnzPerRowBlock,
              (long long)A->max_row_nnz, A->rp64 ? "i64" : "i32", A->ctx->xcd_remap);
     if (A->use_lpanel && A->ctx->lpanel && A->ctx->spmv_algo == 0) {   // LDS-panel geometry
         const size_t used = strlen(buf);
@@ -923,7 +923,7 @@ int sla_csr_kernel_info(sla_csr_t A, char *buf, int buflen) {
         else if (A->use_lpanel && c->lpanel) mb = (A->d_lpcol ? 10 : 12) * A->nnz + (int64_t)(A->lp_P + 1) * A->rows * rps + 16 * (int64_t)A->lp_P * A->rows;
         else if (tiles_on(A)) mb = 12 * A->nnz + 4 * (int64_t)A->tl_S * (A->tl_P + 1) + 4 * ((int64_t)A->tl_S + 1) + rps * A->tl_S;
         else if (!A->panels.empty() && c->panels) mb = 12 * A->nnz + (int64_t)A->panels.size() * (rps * A->rows + 8 * (int64_t)A->nrb) + 16 * ((int64_t)A->panels.size() - 1) * A->rows;
-        else mb = (A->use_diag && c->diag ? 9 : 12) * A->nnz + rps * (A->rows + 1) + (4 + rps) * (int64_t)A->nrb;
+        else mb = (diag_on(A) ? 9 : 12) * A->nnz + rps * (A->rows + 1) + (4 + rps) * (int64_t)A->nrb;
         const size_t used = strlen(buf);
         if (used + 1 < (size_t)buflen) snprintf(buf + used, (size_t)buflen - used, " matrix_bytes=%lld", (long long)mb);
         if (!A->panels.empty() && c->panels && !tiles_on(A) && c->spmv_algo == 0) {

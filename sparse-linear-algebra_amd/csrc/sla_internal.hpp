@@ -484,6 +484,10 @@ inline bool stream_xwin_on(const sla_csr *A) { return A->use_xwin && A->ctx->xwi
 // gathers its window variant loses (216^3 Laplacian on 9 B per entry: K1 202 vs 188 us, the four-sum K3 -- 17 spilled VGPRs -- 271 vs
 // 210 us, 1640 vs 1870 it/s); the pair-code kernel (spmv_vdict_kernel) keeps its window at xwin = 1 (K1 85 vs 90 us).
 inline bool diag_xwin_on(const sla_csr *A) { return A->use_xwin && A->ctx->xwin >= 2; }
+// ... is the dictionary-code kernel (spmv_diag_kernel: 9 B per entry) the one to run?  Only for short rows: its row phase decodes and
+// gathers per lane, and from ~12 entries per row on the plain CSR kernels win (round 4, e05r0000 tiled to 1 M rows, 25 per row:
+// dictionary codes 4380 it/s, plain CSR 5190-5330; 5-7 per row: dictionary codes +0..10 %); diag = 2 takes it at any row length.
+inline bool diag_on(const sla_csr *A) { return A->use_diag && (A->ctx->diag == 2 || (A->ctx->diag == 1 && A->nnz <= 12 * A->rows)); }
 inline bool wd_on(const sla_csr *A) { return A->wd_vv ? (A->ctx->wdia && A->ctx->wdia_vv) : A->ctx->wdia != 0; }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -3,15 +3,14 @@
 // fell to the L2-gathering forms (tile form: 0.29 .. 0.33 of the 8 TB/s peak on CSR bytes at 100 / 200 entries per row, n = 1 M:
 // one 128-byte line moved per 8-byte gather), because the LDS-panel kernel spends a lane GROUP and a memory round trip per segment.
 //
-// Form `lflat`: the x panel in LDS like spmv_lpanel_kernel (one 1024-thread workgroup per CU, 128 KiB), but ONE LANE PER SEGMENT:
+// Form `lflat`: the x panel in LDS like spmv_lpanel_kernel (one 1024-thread workgroup per CU; 15360 columns = 120 KiB), but ONE LANE PER SEGMENT:
 //   * a panel-major second copy of the entries -- value + 16-bit column offset into the panel, 10 B per entry, the segments of a panel
 //     one after the other in row order -- and the segment starts q[panel x rows + row] (4 B per segment); built on the device from
 //     the canonical arrays (counts -> rocPRIM exclusive scan -> scatter), nothing crosses PCIe;
-//   * lane l of a wavefront takes segment (p, i0 + l): consecutive lanes read consecutive segments, i.e. one contiguous stretch of
-//     the copy per wavefront (~64 x the mean segment length entries: every 128-byte line it touches is used completely, across the
-//     iterations of the lane loops, out of the L1); four entries per lane in flight (clamped loads);
-//   * the lane adds ITS segment's products one by one in ascending column order (separately rounded multiply and add) and stores the
-//     partial sum of (panel, row): 64 consecutive doubles per wavefront, no cross-lane work at all;
+//   * a wavefront takes 64 consecutive segments (p, i0 .. i0 + 63) = one contiguous stretch of the copy, which it streams with
+//     coalesced loads in chunks of 256 entries, multiplies with x from the LDS panel and stages as products in its own 2 KiB of LDS;
+//   * lane l then adds the products of ITS segment (p, i0 + l) one by one in ascending column order (separately rounded multiply and
+//     add) and stores the partial sum of (panel, row): 64 consecutive doubles per wavefront, no cross-lane arithmetic at all;
 //   * lpanel_finish_kernel (shared with the LDS-panel form) adds a row's partials in ascending panel order and runs the fused
 //     epilogue.  Summation order: left folds per (panel, row) segment, then a left fold of the segment sums -- a regrouping of the
 //     reference's single left fold (Common.hs:247-260) like every GPU form for long rows: |dy_i| <= nnz_i eps sum_j |a_ij x_j|
@@ -88,15 +87,25 @@ __global__ void __launch_bounds__(256) lf_task_weights_kernel(int64_t ntasks, in
     }
 }
 
-constexpr int kLfU = 4;   // entries per lane in flight
+constexpr int kLfW = 15360;                 // columns of x per panel: 120 KiB of LDS, which leaves 32 KiB for the wavefronts' product stages
+constexpr int kLfStage = 256;               // products a wavefront stages per chunk (2 KiB; 16 wavefronts)
+constexpr size_t kLfLds = (size_t)kLfW * 8 + (size_t)(kLpBlock / 64) * kLfStage * 8;
 
+// A first version let every lane LOAD its segment's entries itself (addresses ~3 entries apart across the lanes): each wave-load then
+// touches ~14 cache lines instead of 4 and the L1 bounds the kernel -- 100 / 200 entries per row, n = 1 M: 0.62 / 1.21 ms, slower than
+// the L2-gathering tile form (0.53 / 0.91 ms).  So the wavefront STREAMS its contiguous stretch of the copy with coalesced loads (lane l:
+// entries l, l + 64, ...), multiplies with x from the LDS panel, stages the PRODUCTS in its own 2 KiB of LDS, and the lane-per-segment
+// left fold reads them from there -- the structure of spmv_wave_kernel with the x gather served by LDS.
 __global__ void __launch_bounds__(kLpBlock) spmv_lflat_kernel(const uint32_t *__restrict__ q, const uint16_t *__restrict__ col16,
                                                               const double *__restrict__ val, const double *__restrict__ xg, double *__restrict__ ypart,
                                                               const int32_t *__restrict__ task_begin, int rows, int n, int W, int chunk_rows, int C,
                                                               int col_lo, int col_hi, const SolverScalars *sc) {
-    extern __shared__ double lf_xs[];
+    extern __shared__ double lf_lds[];
+    double *lf_xs = lf_lds;
     if (sc && sc->done) return;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    double *stage = lf_lds + kLfW + wave * kLfStage;
     const int t0 = task_begin[blockIdx.x], t1 = task_begin[blockIdx.x + 1];
     int curp = -1;
     for (int t = t0; t < t1; ++t) {
@@ -114,29 +123,37 @@ __global__ void __launch_bounds__(kLpBlock) spmv_lflat_kernel(const uint32_t *__
         const int lo = c * chunk_rows, hi = min(rows, lo + chunk_rows);
         const uint32_t *qs = q + (int64_t)p * rows;
         double *yp = ypart + (int64_t)p * rows;
-        for (int base = lo; base < hi; base += kLpBlock) {   // (wavefront-uniform trip count)
+        for (int base = lo + wave * 64; base < hi; base += kLpBlock) {   // 64 consecutive segments per wavefront and trip
 #pragma clang fp contract(off)  // a*x then +: two roundings like the reference, never an FMA
-            const int i = base + tid;
+            const int i = base + lane;
             const bool has = i < hi;
             const uint32_t k = qs[has ? i : hi], e = qs[has ? i + 1 : hi];
-            const int len = (int)(e - k);
+            const uint32_t ka = (uint32_t)__builtin_amdgcn_readfirstlane((int)k), kb = (uint32_t)__builtin_amdgcn_readlane((int)e, 63);
             double acc = 0.0;
-            // (the lane loops of a wavefront run as long as its longest segment; kLfU clamped loads per lane in flight per trip)
-            for (int j = 0; __builtin_amdgcn_ballot_w64(j < len) != 0; j += kLfU) {
-                uint16_t cj[kLfU];
-                double vj[kLfU];
+            for (uint32_t ca = ka; ca < kb; ca += kLfStage) {   // chunks of the wavefront's contiguous stretch [ka, kb)
+                const uint32_t cb = min(ca + (uint32_t)kLfStage, kb);
+                uint16_t cj[kLfStage / 64];
+                double vj[kLfStage / 64];
 #pragma unroll
-                for (int u = 0; u < kLfU; ++u) {
-                    const uint32_t idx = k + (uint32_t)max(min(j + u, len - 1), 0);   // (an empty segment reads the entry at its start: the arrays carry slack)
+                for (int u = 0; u < kLfStage / 64; ++u) {
+                    const uint32_t idx = min(ca + (uint32_t)(lane + 64 * u), cb - 1);   // (clamped, unconditional: cb > ca)
                     cj[u] = __builtin_nontemporal_load(col16 + idx);
                     vj[u] = __builtin_nontemporal_load(val + idx);
                 }
 #pragma unroll
-                for (int u = 0; u < kLfU; ++u)
-                    if (j + u < len) {
-                        const double prod = vj[u] * lf_xs[cj[u]];
-                        acc = acc + prod;
-                    }
+                for (int u = 0; u < kLfStage / 64; ++u) stage[lane + 64 * u] = vj[u] * lf_xs[cj[u]];
+                // this lane's segment inside the chunk, four staged products read together, added in order
+                int la = (int)(max(k, ca) - ca);
+                const int ha = (int)(min(e, cb) - ca);     // (e < ca: negative, nothing to add)
+                while (__builtin_amdgcn_ballot_w64(la < ha) != 0) {
+                    double pj[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) pj[u] = stage[min(max(la + u, 0), kLfStage - 1)];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (la + u < ha) acc = acc + pj[u];
+                    la += 4;
+                }
             }
             if (has) yp[i] = acc;
         }
@@ -155,10 +172,10 @@ int build_lflat(sla_csr *A, int64_t n, int64_t rows, int64_t col_lo, int64_t col
     if (A->use_wdia || A->use_vdict || A->use_diag || A->xwin_fraction >= 0.5 || (A->use_lpanel && c->lpanel)) return SLA_OK;   // stencil / banded structure, or dense rows (LDS panels)
     {   // one workgroup keeps a panel of x in 128 KiB of LDS
         int lds = 0;
-        if (hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, c->device) != hipSuccess || (int64_t)lds < (int64_t)kLpW * 8) return SLA_OK;
+        if (hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, c->device) != hipSuccess || (size_t)lds < kLfLds) return SLA_OK;
     }
-    const int64_t P = (n + kLpW - 1) / kLpW;
-    const int64_t W = ((n + P - 1) / P + 63) / 64 * 64;   // equal panels
+    const int64_t P = (n + kLfW - 1) / kLfW;
+    const int64_t W = std::min<int64_t>(kLfW, ((n + P - 1) / P + 63) / 64 * 64);   // equal panels
     const int64_t nseg = P * rows;
     // mean segment length: from lf_min_seg10 / 10 (1.5: below that the partials cost more than the entries) up to the LDS-panel form's threshold
     if (P < 3 || P > 4096 || nseg >= ((int64_t)1 << 31) || nnz * 10 < (int64_t)c->lf_min_seg10 * nseg || (c->lflat < 2 && nnz >= (int64_t)c->lp_min_seg * nseg)) return SLA_OK;
@@ -244,10 +261,10 @@ int build_lflat(sla_csr *A, int64_t n, int64_t rows, int64_t col_lo, int64_t col
 int launch_spmv_lflat(const sla_csr *A, int epi, const SpmvArgs<int32_t> &a, int grid) {
     sla_ctx *c = A->ctx;
     if (!(c->lp_attr & (1 << 30))) {   // per context = per device: 128 KiB of dynamic LDS
-        SLA_HIP_TRY(hipFuncSetAttribute((const void *)spmv_lflat_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kLpW * sizeof(double))));
+        SLA_HIP_TRY(hipFuncSetAttribute((const void *)spmv_lflat_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLfLds));
         c->lp_attr |= 1 << 30;
     }
-    hipLaunchKernelGGL(spmv_lflat_kernel, dim3(A->lp_G), dim3(kLpBlock), kLpW * sizeof(double), stream_of(c), A->d_lfq, A->d_lfcol, A->d_lfval, a.x, A->d_lpy,
+    hipLaunchKernelGGL(spmv_lflat_kernel, dim3(A->lp_G), dim3(kLpBlock), kLfLds, stream_of(c), A->d_lfq, A->d_lfcol, A->d_lfval, a.x, A->d_lpy,
                        A->d_lpt, a.rows, (int)A->n, A->lp_W, A->lp_chunk, A->lp_C, A->lp_col_lo, A->lp_col_hi, (const SolverScalars *)a.sc);
     SLA_HIP_TRY(hipGetLastError());
     return launch_lpanel_finish(A, epi, a, grid);
