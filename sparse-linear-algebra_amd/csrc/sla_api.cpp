@@ -911,6 +911,11 @@ int sla_csr_kernel_info(sla_csr_t A, char *buf, int buflen) {
             snprintf(buf + used, (size_t)buflen - used, " lds_panels=%d panel_cols=%d lanes_per_segment=%d tasks=%d entries=%s", A->lp_P, A->lp_W,
                      64 >> A->lp_cfg, A->lp_P * A->lp_C, A->d_lpcol ? "panel-major-copy" : "row-major");
     }
+    if (lflat_on(A)) {   // flat LDS-panel geometry
+        const size_t used = strlen(buf);
+        if (used + 1 < (size_t)buflen)
+            snprintf(buf + used, (size_t)buflen - used, " lds_panels=%d panel_cols=%d rows_per_workgroup=16384 panel_ranges=%d tasks=%d", A->lp_C, A->lp_W, A->lp_P, A->lp_G);
+    }
     {   // bytes of matrix data the chosen form streams per (#>) (what K1's HBM roofline is priced against in bench.py)
         const sla_ctx *c = A->ctx;
         const int64_t rps = A->rp64 ? 8 : 4;
@@ -921,12 +926,13 @@ int sla_csr_kernel_info(sla_csr_t A, char *buf, int buflen) {
         else if (A->use_wdia && wd_on(A)) mb = A->nwent * (A->wd_vv ? 20 + 128 * 8 : 28) + 4 * ((int64_t)A->nslices + 1);
         else if (A->use_vdict && c->vdict) mb = A->nnz + 4 * (A->rows + 1);
         else if (A->use_lpanel && c->lpanel) mb = (A->d_lpcol ? 10 : 12) * A->nnz + (int64_t)(A->lp_P + 1) * A->rows * rps + 16 * (int64_t)A->lp_P * A->rows;
+        else if (lflat_on(A)) mb = 10 * A->nnz + 4 * ((int64_t)A->lp_C * A->rows + 1) + 16 * (int64_t)A->lp_P * A->rows;   // copy + segment starts + one partial per (row, panel range)
         else if (tiles_on(A)) mb = 12 * A->nnz + 4 * (int64_t)A->tl_S * (A->tl_P + 1) + 4 * ((int64_t)A->tl_S + 1) + rps * A->tl_S;
         else if (!A->panels.empty() && c->panels) mb = 12 * A->nnz + (int64_t)A->panels.size() * (rps * A->rows + 8 * (int64_t)A->nrb) + 16 * ((int64_t)A->panels.size() - 1) * A->rows;
         else mb = (diag_on(A) ? 9 : 12) * A->nnz + rps * (A->rows + 1) + (4 + rps) * (int64_t)A->nrb;
         const size_t used = strlen(buf);
         if (used + 1 < (size_t)buflen) snprintf(buf + used, (size_t)buflen - used, " matrix_bytes=%lld", (long long)mb);
-        if (!A->panels.empty() && c->panels && !tiles_on(A) && c->spmv_algo == 0) {
+        if (!A->panels.empty() && c->panels && !tiles_on(A) && !lflat_on(A) && c->spmv_algo == 0) {
             const size_t u2 = strlen(buf);
             if (u2 + 1 < (size_t)buflen) snprintf(buf + u2, (size_t)buflen - u2, " col_panels=%d", (int)A->panels.size());
         }
