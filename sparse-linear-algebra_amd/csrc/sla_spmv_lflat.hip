@@ -122,30 +122,47 @@ __global__ void __launch_bounds__(kLpBlock) spmv_lflat_kernel(const uint32_t *__
         }
         __syncthreads();
         const uint32_t *qs = q + (int64_t)p * rows;
+        // Latency, not bandwidth, bounds a trip (segment starts -> the stretch's streams -> LDS stage -> fold: three dependent round trips,
+        // and the 120 KiB panel leaves room for ONE workgroup = 16 wavefronts per CU to hide them: v3 without the two measures below ran
+        // 100 entries per row no faster than 200, 0.55 vs 0.59 ms).  So (1) the segment starts of all sixteen trips of a panel are loaded
+        // up front, (2) the streams of the NEXT chunk -- of this trip or of the next one -- are issued before the current chunk is folded.
+        uint32_t ks[kLfRpt], kend[kLfRpt];   // per lane: its segment's start; per wavefront (scalar): where its 64 segments end
+#pragma unroll
+        for (int r = 0; r < kLfRpt; ++r) {
+            const int b = lo + r * kLpBlock + wave * 64;
+            ks[r] = qs[min(b + lane, hi)];   // (rows past the chunk: empty segments at qs[hi])
+            kend[r] = qs[min(b + 64, hi)];
+        }
+        uint16_t cj[kLfStage / 64], cn[kLfStage / 64];
+        double vj[kLfStage / 64], vn[kLfStage / 64];
+        auto load_chunk = [&](uint16_t (&cc)[kLfStage / 64], double (&vv)[kLfStage / 64], uint32_t ca, uint32_t kb) {
+            const uint32_t last = max(min(ca + (uint32_t)kLfStage, kb), ca + 1u) - 1u;   // (clamped, unconditional; an empty stretch reads the entry at its start)
+#pragma unroll
+            for (int u = 0; u < kLfStage / 64; ++u) {
+                const uint32_t idx = min(ca + (uint32_t)(lane + 64 * u), last);
+                cc[u] = __builtin_nontemporal_load(col16 + idx);
+                vv[u] = __builtin_nontemporal_load(val + idx);
+            }
+        };
+        load_chunk(cj, vj, (uint32_t)__builtin_amdgcn_readfirstlane((int)ks[0]), kend[0]);
 #pragma unroll
         for (int r = 0; r < kLfRpt; ++r) {   // trip r: the wavefront's 64 consecutive segments (p, base .. base + 63)
 #pragma clang fp contract(off)  // a*x then +: two roundings like the reference, never an FMA
-            const int base = lo + r * kLpBlock + wave * 64;
-            if (base >= hi) break;           // (wavefront-uniform)
-            const int i = base + lane;
-            const bool has = i < hi;
-            const uint32_t k = qs[has ? i : hi], e = qs[has ? i + 1 : hi];
-            const uint32_t ka = (uint32_t)__builtin_amdgcn_readfirstlane((int)k), kb = (uint32_t)__builtin_amdgcn_readlane((int)e, 63);
-            for (uint32_t ca = ka; ca < kb; ca += kLfStage) {   // chunks of the wavefront's contiguous stretch [ka, kb)
+            const uint32_t k = ks[r], kb = kend[r];
+            uint32_t e = (uint32_t)__shfl_down((int)k, 1, 64);   // a segment ends where the next lane's starts; the last one at kb
+            if (lane == 63) e = kb;
+            const uint32_t ka = (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
+            const uint32_t nka = r + 1 < kLfRpt ? (uint32_t)__builtin_amdgcn_readfirstlane((int)ks[r + 1 < kLfRpt ? r + 1 : r]) : ka;
+            const uint32_t nkb = r + 1 < kLfRpt ? kend[r + 1 < kLfRpt ? r + 1 : r] : ka;
+            for (uint32_t ca = ka;; ca += kLfStage) {   // chunks of the wavefront's contiguous stretch [ka, kb) (at least one trip through: an empty stretch folds nothing)
                 const uint32_t cb = min(ca + (uint32_t)kLfStage, kb);
-                uint16_t cj[kLfStage / 64];
-                double vj[kLfStage / 64];
-#pragma unroll
-                for (int u = 0; u < kLfStage / 64; ++u) {
-                    const uint32_t idx = min(ca + (uint32_t)(lane + 64 * u), cb - 1);   // (clamped, unconditional: cb > ca)
-                    cj[u] = __builtin_nontemporal_load(col16 + idx);
-                    vj[u] = __builtin_nontemporal_load(val + idx);
-                }
+                const bool more = ca + kLfStage < kb;
+                load_chunk(cn, vn, more ? ca + kLfStage : nka, more ? kb : nkb);
 #pragma unroll
                 for (int u = 0; u < kLfStage / 64; ++u) stage[lane + 64 * u] = vj[u] * lf_xs[cj[u]];
                 // this lane's segment inside the chunk, four staged products read together, added in order
                 int la = (int)(max(k, ca) - ca);
-                const int ha = (int)(min(e, cb) - ca);     // (e < ca: negative, nothing to add)
+                const int ha = (int)min(e, cb) - (int)ca;  // (a segment that ends before the chunk: negative, nothing to add)
                 while (__builtin_amdgcn_ballot_w64(la < ha) != 0) {
                     double pj[4];
 #pragma unroll
@@ -155,6 +172,9 @@ __global__ void __launch_bounds__(kLpBlock) spmv_lflat_kernel(const uint32_t *__
                         if (la + u < ha) acc[r] = acc[r] + pj[u];
                     la += 4;
                 }
+#pragma unroll
+                for (int u = 0; u < kLfStage / 64; ++u) { cj[u] = cn[u]; vj[u] = vn[u]; }
+                if (!more) break;
             }
         }
     }
@@ -175,7 +195,8 @@ int build_lflat(sla_csr *A, int64_t n, int64_t rows, int64_t col_lo, int64_t col
     sla_ctx *c = A->ctx;
     const int64_t nnz = A->nnz;
     if (!c->lflat || A->rp64 || rows <= 0 || nnz <= 0 || nnz >= ((int64_t)1 << 31) || !A->d_col || !A->d_val || !A->d_rowptr) return SLA_OK;
-    if (A->use_wdia || A->use_vdict || A->use_diag || A->xwin_fraction >= 0.5 || (A->use_lpanel && c->lpanel)) return SLA_OK;   // stencil / banded structure, or dense rows (LDS panels)
+    if (A->use_lpanel && c->lpanel) return SLA_OK;                                                                        // dense rows: LDS panels
+    if (c->lflat < 2 && (A->use_wdia || A->use_vdict || A->use_diag || A->xwin_fraction >= 0.5)) return SLA_OK;         // stencil / banded structure (lflat = 2: test hook, any structure)
     {   // one workgroup keeps a panel of x in 128 KiB of LDS
         int lds = 0;
         if (hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, c->device) != hipSuccess || (size_t)lds < kLfLds) return SLA_OK;

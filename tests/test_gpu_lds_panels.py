@@ -203,7 +203,8 @@ def test_flat_lds_panel_form_matches_the_oracle(sla, name):
     x = np.random.default_rng(11).standard_normal(n)
     want = orc.spmv(Ao, x)
     bound = _bound(csr, x, m)
-    ctx = sla.Context(0).set_options(lflat=2, lf_min_seg10=1, lpanel=0)      # (force the form onto every case: the lowering's own window is 1.5 .. 16)
+    # (force the form onto every case: the lowering's own window is a mean segment of 1.5 .. 16 entries on a matrix without band structure)
+    ctx = sla.Context(0).set_options(lflat=2, lf_min_seg10=1, lpanel=0, diag=0, wdia=0, vdict=0)
     A = sla.fromCSR(dims, rp, ci, va, ctx)
     info = A.kernel_info()
     assert info.startswith("algo=lflat "), (name, info)
