@@ -842,7 +842,7 @@ int csr_upload(sla_ctx *c, int64_t m, int64_t n, int64_t row_begin, int64_t rows
         lap("canonical CSR upload (rest)");
         low_lds_panels(L);                 // (its panel-major copy is written by a device kernel from the canonical arrays)
         lap("LDS panel table");
-        if (!panel_view && err == hipSuccess && !A->use_lpanel && c->lflat && nnz > 0) {   // medium rows: the flat LDS-panel form (device-built)
+        if (!panel_view && err == hipSuccess && !(A->use_lpanel && c->lpanel) && c->lflat && nnz > 0) {   // medium rows: the flat LDS-panel form (device-built)
             std::vector<int64_t> plo((size_t)host_threads(), n), phi((size_t)host_threads(), -1);
             par_rows(rows, 1, [&](int t, int64_t lo, int64_t hi) {   // (canonical CSR: first / last entry of a row are its min / max column)
                 int64_t a = n, b = -1;
