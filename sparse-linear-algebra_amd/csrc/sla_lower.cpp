@@ -92,7 +92,7 @@ static int build_panels(sla_csr *A, int64_t m, int64_t n, int64_t row_begin, int
                         const int64_t *col, const double *val) {
     sla_ctx *c = A->ctx;
     const int64_t nnz = rowptr[rows];
-    if (!c->panels || A->use_diag || A->xwin_fraction >= 0.5 || rows == 0) return SLA_OK;
+    if (!c->panels || A->use_diag || A->use_wdia || A->use_vdict || A->xwin_fraction >= 0.5 || rows == 0) return SLA_OK;   // (stencil / banded structure: the value-indexed forms skip the offset dictionary and the window statistics, round 4)
     const int64_t W = std::max<int64_t>(c->panel_cols, 1);
     if (n <= 2 * W) return SLA_OK;                                   // x (nearly) fits the L2 already
     int64_t P = std::min<int64_t>((n + W - 1) / W, nnz / rows);      // >= ~1 entry per row per panel

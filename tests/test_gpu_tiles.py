@@ -69,7 +69,7 @@ def test_tiles_match_the_oracle(sla, name):
     # (lpanel=0: the dense-row cases would otherwise take the LDS-panel form; tiles_device: the re-ordering as a device sort -- round 4,
     # sla_tiles_build.hip -- and by the host builder: the same decision and the same bits from both)
     for rp64, dev in (("0", 2), ("1", 2), ("0", 0), ("1", 0)):
-        ctx = sla.Context(0).set_options(tile_shift=10, lpanel=0, force_rp64=rp64, tiles_device=dev)
+        ctx = sla.Context(0).set_options(tile_shift=10, lpanel=0, lflat=0, force_rp64=rp64, tiles_device=dev)
         A = sla.fromCSR(dims, rp, ci, va, ctx)
         info = A.kernel_info()
         assert ("algo=tiles" in info) == expect_tiles, (name, info)
@@ -83,7 +83,7 @@ def test_tiles_match_the_oracle(sla, name):
         y2 = sla.matVec(A, sla.fromVector(x, ctx)).toDenseListSV()
         assert np.array_equal(y, y2)                             # deterministic
     # the same matrix on the forms the tile form replaces
-    ctx = sla.Context(0).set_options(tile_shift=10, lpanel=0, tiles=0)
+    ctx = sla.Context(0).set_options(tile_shift=10, lpanel=0, lflat=0, tiles=0)
     A = sla.fromCSR(dims, rp, ci, va, ctx)
     assert "tiles" not in A.kernel_info()
     y0 = sla.matVec(A, sla.fromVector(x, ctx)).toDenseListSV()
@@ -157,7 +157,7 @@ def test_panel_passes_of_the_overlapped_allgather_on_one_rank(sla, ranks, rank, 
         x = np.random.default_rng(9).standard_normal(n)
         yo = orc.spmv(Ao, x)
         for order in (0, 1):
-            ctx = sla.Context(0).set_options(tile_shift=shift, lpanel=0, ag_sim_ranks=ranks, ag_sim_rank=rank, ag_groups=groups, ag_order=order)
+            ctx = sla.Context(0).set_options(tile_shift=shift, lpanel=0, lflat=0, ag_sim_ranks=ranks, ag_sim_rank=rank, ag_groups=groups, ag_order=order)
             A = sla.fromCSR(dims, rp, ci, va, ctx)
             info = A.kernel_info()
             visit, pptr, pneed, ng = plan_allgather_passes(ranks, rank, n, shift, groups, order)

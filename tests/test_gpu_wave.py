@@ -10,7 +10,7 @@ import pytest
 from oracle import oracle as orc
 
 pytestmark = pytest.mark.gpu
-BASE = dict(wdia=0, vdict=0, diag=0, tiles=0, panels=0, lpanel=0)
+BASE = dict(wdia=0, vdict=0, diag=0, tiles=0, panels=0, lpanel=0, lflat=0)
 
 
 @pytest.fixture(scope="module")
