@@ -340,11 +340,21 @@ static void low_value_indexed(Low &L) {
             std::vector<char> bad((size_t)host_threads(), 0);
             par_rows(rows, 1, [&](int t, int64_t lo, int64_t hi) {
                 PairTable &mine = loc[(size_t)t];
+                // (a stencil row repeats its predecessor's pairs position by position: the id found at position j of the previous row is
+                // tried first -- two compares instead of a hash and a probe for all but the boundary rows)
+                int recent[kVdMaxRowNnz + 1];
+                for (int &r_ : recent) r_ = -1;
                 for (int64_t i = lo; i < hi && !bad[(size_t)t]; ++i) {
-                    const int64_t gr = row_begin + i;
-                    for (int64_t k = rowptr[i]; k < rowptr[i + 1]; ++k) {
-                        const int id = mine.find(col[k] - gr, bits_of(val[k]), true);
-                        if (id < 0) { bad[(size_t)t] = 1; break; }
+                    const int64_t gr = row_begin + i, k0 = rowptr[i];
+                    for (int64_t k = k0; k < rowptr[i + 1]; ++k) {
+                        const int64_t off = col[k] - gr;
+                        const uint64_t bits = bits_of(val[k]);
+                        int id = recent[k - k0];
+                        if (id < 0 || mine.pairs[(size_t)id].off != off || mine.pairs[(size_t)id].bits != bits) {
+                            id = mine.find(off, bits, true);
+                            if (id < 0) { bad[(size_t)t] = 1; break; }
+                            recent[k - k0] = id;
+                        }
                         codes[(size_t)k] = (uint8_t)id;
                     }
                 }
@@ -842,7 +852,8 @@ int csr_upload(sla_ctx *c, int64_t m, int64_t n, int64_t row_begin, int64_t rows
         lap("canonical CSR upload (rest)");
         low_lds_panels(L);                 // (its panel-major copy is written by a device kernel from the canonical arrays)
         lap("LDS panel table");
-        if (!panel_view && err == hipSuccess && !(A->use_lpanel && c->lpanel) && c->lflat && nnz > 0) {   // medium rows: the flat LDS-panel form (device-built)
+        if (!panel_view && err == hipSuccess && !(A->use_lpanel && c->lpanel) && c->lflat && nnz > 0 &&
+            (c->lflat == 2 || !(A->use_wdia || A->use_vdict || A->use_diag))) {   // medium rows without band structure: the flat LDS-panel form (device-built)
             std::vector<int64_t> plo((size_t)host_threads(), n), phi((size_t)host_threads(), -1);
             par_rows(rows, 1, [&](int t, int64_t lo, int64_t hi) {   // (canonical CSR: first / last entry of a row are its min / max column)
                 int64_t a = n, b = -1;

@@ -36,6 +36,8 @@ def _check(sla, dims, rp, ci, va, expect_form, bit_exact, b_mode, tag, ctx=None,
     A = sla.fromCSR(dims, rp, ci, va, ctx)
     info = A.kernel_info()
     assert expect_form in info, (tag, info)
+    if expect_form.startswith("wdia"):   # (round 4: a value-indexed matrix once got column-panel views on top -- 6 passes per (#>), K1 45 -> 817 us)
+        assert "col_panels" not in info, (tag, info)
     Ao = orc.Csr(n, n, rp, ci, va)
     rng = np.random.default_rng(20260928)
     x = rng.standard_normal(n)
