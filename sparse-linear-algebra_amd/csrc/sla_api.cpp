@@ -475,6 +475,9 @@ const IntKnob kIntKnobs[] = {
     {"tiles_device", &sla_ctx::tiles_device, 0, 2},
     {"tile_shift", &sla_ctx::tile_shift, 0, 20},
     {"tile_slack", &sla_ctx::tile_slack, 0, 64},
+    {"tile_prefetch", &sla_ctx::tile_prefetch, 0, 16},
+    {"canon_device", &sla_ctx::canon_device, 0, 2},
+    {"tile_poll", &sla_ctx::tile_poll, 0, 1},
     {"row_align", &sla_ctx::row_align, 0, 256},
     {"rb_nnz", &sla_ctx::rb_nnz, 0, 1024},
     {"spmv_grid", &sla_ctx::spmv_grid_max, 1, kMaxParts},
@@ -775,9 +778,12 @@ int sla_csr_from_csr_rows(sla_ctx_t c, int64_t m, int64_t n, int64_t row_begin, 
         if (nnz > 0 && (!colidx || !val)) return csr_reject(c, fail(SLA_ERR_INVALID, "null colidx/val"));
         // monotone row pointers first (the column checks below index through them), then rows in parallel; the
         // lowest-numbered kind of violation wins so that the result does not depend on the thread count
-        for (int64_t i = 0; i < row_count; ++i)
-            if (rowptr_local[i + 1] < rowptr_local[i]) return csr_reject(c, fail(SLA_ERR_INVALID, "rowptr not monotone"));
         std::vector<int> bad((size_t)host_threads(), 0);   // 1: out of bounds, 2: not strictly ascending
+        par_rows(row_count, 1, [&](int t, int64_t lo, int64_t hi) {
+            for (int64_t i = lo; i < hi; ++i)
+                if (rowptr_local[i + 1] < rowptr_local[i]) { bad[(size_t)t] = 1; break; }
+        });
+        if (std::find(bad.begin(), bad.end(), 1) != bad.end()) return csr_reject(c, fail(SLA_ERR_INVALID, "rowptr not monotone"));
         par_rows(row_count, 1, [&](int t, int64_t lo, int64_t hi) {
             int b_ = 0;
             for (int64_t i = lo; i < hi && b_ != 1; ++i)

@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <map>
 #include <new>
+#include <future>
 #include <string>
 #include <algorithm>
 #include <thread>
@@ -84,7 +85,7 @@ constexpr int kWvMaxRow = 128;       // longest row spmv_wave_kernel takes (one 
 constexpr int kRowptrPad = 192;      // entries (= nnz) behind the rows + 1 row pointers of the 32-bit array: 128-row blocks read past the last row unclamped
 constexpr int kWaveRowMax = 16384;   // rows of 1025..16384 entries: one wavefront each, 4 per row block; longer: whole workgroup
 #ifndef SLA_TILE_ROWS
-#define SLA_TILE_ROWS 4096
+#define SLA_TILE_ROWS 4896
 #endif
 #ifndef SLA_TILE_OCC
 #define SLA_TILE_OCC 1
@@ -233,6 +234,10 @@ struct sla_ctx {
     int xcd8 = -1;                   // 1: workgroups are dealt round-robin over 8 XCDs (those with equal b % 8 share one; probed once: what the tile kernel's panel pacing relies on), 0: not so
     int tiles_device = 1;            // the tile form's re-ordering as a device sort (sla_tiles_build.hip): 1 from 2^20 entries on, 2 always, 0 host builder (SLA_TILES_DEVICE)
     int tiles = 1;                   // allow the row-slice x column-panel tile SpMV for irregular matrices with x > L2 (SLA_TILES=0: column-panel passes)
+    std::future<void> deferred_free; // host buffers of the last lowering being released off the caller's thread (sla_lower.cpp)
+    int canon_device = 1;            // value-indexed matrices: canonical col / val written on the device from the 1-byte codes instead of uploaded
+    int tile_prefetch = 0;           // x-panel prefetch distance of spmv_tile_kernel in visit steps (0: demand misses only; measured: never a gain)
+    int tile_poll = 1;               // 1: pacing slots polled one step ahead, 0: dependent poll in front of every tile (rounds 2-3)
     int tile_slack = 3;              // panel pacing: a wavefront starts panel step q once its XCD has finished step q - slack (SLA_TILE_SLACK, 0: no pacing)
     int tile_shift = 0;              // log2 of its panel width in columns (SLA_TILE_SHIFT; 0: 17 from 6 M columns on, 16 below -- at 10 M rows slack 3 / shift 17: 1.98 ms, slack 4: 2.18, slack 2: 2.1, shift 16: 2.03-2.28, shift 18: +15 %)
     int panels = 1;                  // allow the column-panel SpMV for irregular matrices (SLA_PANELS=0 disables)

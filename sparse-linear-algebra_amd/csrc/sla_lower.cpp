@@ -10,6 +10,8 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <future>
+#include <memory>
 #include <cstring>
 #include <limits>
 #include <thread>
@@ -128,7 +130,10 @@ static int build_panels(sla_csr *A, int64_t m, int64_t n, int64_t row_begin, int
 int host_threads() {
     static const int t = [] {
         const char *s = getenv("SLA_HOST_THREADS");
-        int v = s ? atoi(s) : (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
+        // (default: 16 threads, 32 on hosts with >= 64 hardware threads -- the MI355X boxes have 256; the pair-coding pass at 70 M entries
+        // measured 111 / 56 / 42 ms at 8 / 16 / 32 threads and nothing more at 64)
+        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+        int v = s ? atoi(s) : (int)(hw >= 64 ? 32u : std::min(16u, hw));
         return std::max(1, std::min(v, 64));
     }();
     return t;
@@ -146,6 +151,13 @@ struct Low {
     const double *val;
     bool panel_view, dbg_lower;
     hipError_t err = hipSuccess;
+    std::chrono::steady_clock::time_point t_sub = std::chrono::steady_clock::now();
+    void sub(const char *what) {        // SLA_DEBUG_LOWER: times inside one analysis
+        if (!dbg_lower || panel_view) return;
+        const auto t = std::chrono::steady_clock::now();
+        fprintf(stderr, "[sla] lowering:     . %-34s %7.1f ms\n", what, std::chrono::duration<double, std::milli>(t - t_sub).count());
+        t_sub = t;
+    }
     std::vector<int32_t> rb;            // row-block starts
     std::vector<int64_t> offs;          // sorted distinct diagonal offsets (<= 256) when the matrix has that structure
     std::vector<uint8_t> dcodes;        // per entry: index into offs
@@ -171,9 +183,21 @@ struct Low {
     [[maybe_unused]] std::vector<uint8_t> &dcodes = (L).dcodes;                                                            \
     [[maybe_unused]] auto upload = [&](void **dst_, const void *src_, size_t bytes_) { (L).upload(dst_, src_, bytes_); }
 
-// canonical CSR arrays (i32 columns, i32 / i64 row pointers) + the row-block tables of the general kernels
-static void low_csr_arrays(Low &L) {
+// canonical CSR arrays (i32 columns, i32 / i64 row pointers) + the row-block tables of the general kernels.
+// The entry arrays go up in chunks and the upload can be called off (`stop`): a matrix that turns out to be value-indexed gets the rest
+// of its col / val written by a device kernel from its 1-byte codes (vd_expand_kernel below) instead of over PCIe.
+struct CanonUpload {
+    std::atomic<int> stop{0};
+    std::atomic<int> decided{0};          // the value-indexed analysis is through (canon_device = 2: the entry copies wait for it)
+    int64_t done_col = 0, done_val = 0;   // entries [0, done) are on the device
+};
+static void low_csr_arrays(Low &L, CanonUpload *cu) {
     SLA_LOW_LOCALS(L);
+    constexpr int64_t kChunk = (int64_t)1 << 20;   // entries per copy (8 MiB of values, 4 MiB of columns): what a called-off upload still finishes
+    auto stopped = [&] { return cu && cu->stop.load(std::memory_order_relaxed) != 0; };
+    auto await_decision = [&] {   // (canon_device = 2, tests: no entry crosses PCIe before the analysis has said which way it goes)
+        while (cu && c->canon_device == 2 && !cu->decided.load(std::memory_order_acquire)) std::this_thread::yield();
+    };
     // the values go up on a second host thread while this one narrows and uploads the indices (pageable copies are
     // bound by the staging memcpy of the calling thread, not by the link)
     hipError_t err_val = hipSuccess;
@@ -184,17 +208,15 @@ static void low_csr_arrays(Low &L) {
     std::thread val_up([&] {
         Bind bind(c);   // (a new thread starts on device 0)
         if (err_val == hipSuccess) err_val = dev_malloc(c, (void **)&A->d_val, sizeof(double) * (size_t)nnz + kArraySlack);
-        if (err_val == hipSuccess && nnz) err_val = hipMemcpy(A->d_val, val, sizeof(double) * (size_t)nnz, hipMemcpyHostToDevice);
         if (err_val == hipSuccess) err_val = hipMemset((char *)A->d_val + sizeof(double) * (size_t)nnz, 0, kArraySlack);
+        int64_t k = 0;
+        await_decision();
+        for (; k < nnz && err_val == hipSuccess && !stopped(); k += kChunk)
+            err_val = hipMemcpy(A->d_val + k, val + k, sizeof(double) * (size_t)std::min(kChunk, nnz - k), hipMemcpyHostToDevice);
+        if (cu) cu->done_val = std::min(k, nnz);
     });
     Joiner val_up_joiner{val_up};
-    {
-        std::vector<int32_t> col32((size_t)nnz);
-        par_rows(rows, 1, [&](int, int64_t lo, int64_t hi) {
-            for (int64_t k = rowptr[lo]; k < rowptr[hi]; ++k) col32[(size_t)k] = (int32_t)col[k];
-        });
-        upload((void **)&A->d_col, col32.data(), sizeof(int32_t) * (size_t)nnz);
-    }
+    // row pointers and row-block tables first: every form needs them
     if (A->rp64) {
         upload(&A->d_rowptr, rowptr, sizeof(int64_t) * (size_t)(rows + 1));
         std::vector<int64_t> rbk(rb.size());
@@ -207,12 +229,51 @@ static void low_csr_arrays(Low &L) {
         // (kRowptrPad entries = nnz behind the last one: spmv_wave_kernel reads the row pointers of whole 128-row blocks unclamped,
         // rows past the end of the matrix are empty)
         std::vector<int32_t> rp32((size_t)rows + 1 + kRowptrPad, (int32_t)nnz);
-        for (int64_t i = 0; i <= rows; ++i) rp32[(size_t)i] = (int32_t)rowptr[i];
+        par_rows(rows + 1, 1, [&](int, int64_t lo, int64_t hi) {
+            for (int64_t i = lo; i < hi; ++i) rp32[(size_t)i] = (int32_t)rowptr[i];
+        });
         upload(&A->d_rowptr, rp32.data(), sizeof(int32_t) * rp32.size());
     }
     upload((void **)&A->d_rb, rb.data(), sizeof(int32_t) * rb.size());
+    if (err == hipSuccess) err = dev_malloc(c, (void **)&A->d_col, sizeof(int32_t) * (size_t)nnz + kArraySlack);
+    if (err == hipSuccess) err = hipMemset((char *)A->d_col + sizeof(int32_t) * (size_t)nnz, 0, kArraySlack);
+    {
+        std::vector<int32_t> col32((size_t)std::min(kChunk, nnz));
+        int64_t k = 0;
+        await_decision();
+        for (; k < nnz && err == hipSuccess && !stopped(); k += kChunk) {
+            const int64_t cnt = std::min(kChunk, nnz - k);
+            par_rows(cnt, 1 << 16, [&](int, int64_t lo, int64_t hi) {   // ("rows" here: entries of the chunk)
+                for (int64_t q = lo; q < hi; ++q) col32[(size_t)q] = (int32_t)col[k + q];
+            });
+            err = hipMemcpy(A->d_col + k, col32.data(), sizeof(int32_t) * (size_t)cnt, hipMemcpyHostToDevice);
+        }
+        if (cu) cu->done_col = std::min(k, nnz);
+    }
     val_up.join();
     if (err == hipSuccess) err = err_val;
+}
+
+// Canonical col / val of a value-indexed matrix from its 1-byte codes: col[k] = row + offset[code[k]], val[k] = value[code[k]] -- the
+// pair table holds the values' bit patterns, so the arrays are the caller's bit for bit.  At 70 M entries: 0.3 ms on the device against
+// 0.11 s for the 0.84 GB over PCIe from pageable memory, which was the critical path of sla_csr_from_csr (round 4).
+__global__ void __launch_bounds__(256) vd_expand_kernel(int64_t rows, int64_t row_begin, const int32_t *__restrict__ rowptr,
+                                                        const uint8_t *__restrict__ code, const int32_t *__restrict__ doff,
+                                                        const double *__restrict__ dval, int32_t *__restrict__ col, double *__restrict__ val,
+                                                        int64_t from_col, int64_t from_val) {
+    __shared__ int32_t s_off[256];
+    __shared__ double s_val[256];
+    s_off[threadIdx.x] = doff[threadIdx.x];
+    s_val[threadIdx.x] = dval[threadIdx.x];
+    __syncthreads();
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < rows; i += (int64_t)gridDim.x * 256) {
+        const int32_t k1 = rowptr[i + 1];
+        for (int32_t k = rowptr[i]; k < k1; ++k) {
+            const int cd = code[k];
+            if (k >= from_col) col[k] = (int32_t)(row_begin + i + s_off[cd]);
+            if (k >= from_val) val[k] = s_val[cd];
+        }
+    }
 }
 
 // LDS x window of every row block (spmv_xwin_kernel) and the share of the entries that fall inside
@@ -334,7 +395,20 @@ static void low_value_indexed(Low &L) {
         // ONE pass over the entries (round 4: the table pass and the code pass each read col + val, 1.1 GB at 70 M entries): every
         // thread codes its rows against its OWN table while it builds it; once the tables are merged and ranked the thread-local
         // codes are translated in place (1 B per entry)
-        std::vector<uint8_t> codes(((size_t)nnz + 3) / 4 * 4 + 16, 0);
+        L.sub("(start)");
+        // (not value-initialised: a zero fill of 70 MB on this thread cost 12 ms at 216^3; every entry's byte is written by the pass below,
+        // whose threads also take the first-touch page faults)
+        const size_t codes_n = ((size_t)nnz + 3) / 4 * 4 + 16;
+        std::unique_ptr<uint8_t[]> codes_buf(new uint8_t[codes_n]);
+        uint8_t *codes = codes_buf.get();
+        memset(codes + nnz, 0, codes_n - (size_t)nnz);
+        L.sub("codes allocation");
+        hipError_t err_code = hipSuccess;
+        std::thread code_up;
+        struct Joiner {   // (the code upload reads codes[]: joined before the buffer goes, whichever way this block is left)
+            std::thread &t;
+            ~Joiner() { if (t.joinable()) t.join(); }
+        } code_up_joiner{code_up};
         std::vector<PairTable> loc((size_t)host_threads());
         {
             std::vector<char> bad((size_t)host_threads(), 0);
@@ -365,6 +439,7 @@ static void low_value_indexed(Low &L) {
                     if (ok && find(pr.off, pr.bits, true) < 0) ok = false;
             }
         }
+        L.sub("pair coding pass");
         if (ok) {
             // canonical table order: by offset, then by value bits (independent of the input order)
             std::vector<int> order(pairs.size()), rank(pairs.size());
@@ -386,7 +461,14 @@ static void low_value_indexed(Low &L) {
                 for (size_t q = 0; q < mine.pairs.size(); ++q) lut[q] = (uint8_t)rank[(size_t)find(mine.pairs[q].off, mine.pairs[q].bits, false)];
                 for (int64_t k = rowptr[lo]; k < rowptr[hi]; ++k) codes[(size_t)k] = lut[codes[(size_t)k]];
             });
-            upload((void **)&A->d_vcode, codes.data(), codes.size());
+            L.sub("code translation");
+            // (the 1 B per entry goes up on its own thread while this one builds the wave slices: 3-15 ms at 70 M entries)
+            code_up = std::thread([&L, A, codes, codes_n, &err_code] {
+                Bind bind(L.c);
+                err_code = dev_malloc(L.c, (void **)&A->d_vcode, codes_n + kArraySlack);
+                if (err_code == hipSuccess) err_code = hipMemcpy(A->d_vcode, codes, codes_n, hipMemcpyHostToDevice);
+                if (err_code == hipSuccess) err_code = hipMemset((char *)A->d_vcode + codes_n, 0, kArraySlack);
+            });
             upload((void **)&A->d_vdoff, doff.data(), sizeof(int32_t) * doff.size());
             upload((void **)&A->d_vdval, dval.data(), sizeof(double) * dval.size());
             A->use_vdict = true;
@@ -432,6 +514,7 @@ static void low_value_indexed(Low &L) {
                         P.cnt.push_back((int32_t)(P.me.size() - first));
                     }
                 });
+                L.sub("wave slices");
                 int64_t sl = 0;
                 for (int t = 0; t < T && wok; ++t) {
                     const Part &P = part[(size_t)t];
@@ -448,6 +531,7 @@ static void low_value_indexed(Low &L) {
                 }
                 if ((int64_t)wme.size() * 32 > nnz + 2048) wok = false;   // < 1/4 full: the byte-code kernel is the better form
             }
+            L.sub("wave slice merge");
             if (wok) {
                 A->nwent = (int64_t)wme.size();
                 for (int t = 0; t < 8; ++t) { wme.push_back(0); wmo.push_back(0); wval.push_back(0.0); woff.push_back(0); }
@@ -494,6 +578,7 @@ static void low_value_indexed(Low &L) {
                                 wum[(size_t)sl2 * 16 + 8 + wcode[(size_t)e]] = wmo[(size_t)e];
                             }
                         upload((void **)&A->d_wum, wum.data(), sizeof(uint64_t) * wum.size());
+                        L.sub("slice uploads + uniform masks");
                         int64_t clo = n, chi = -1;                // (columns ascend inside a row)
                         {
                             std::vector<int64_t> plo((size_t)host_threads(), n), phi((size_t)host_threads(), -1);
@@ -509,6 +594,7 @@ static void low_value_indexed(Low &L) {
                             });
                             for (size_t t = 0; t < plo.size(); ++t) { clo = std::min(clo, plo[t]); chi = std::max(chi, phi[t]); }
                         }
+                        L.sub("column range");
                         A->wd_col_lo = (int32_t)clo;
                         A->wd_col_hi = (int32_t)chi;
                         // x[own row] from the staged buffer (an epilogue operand that is the gathered vector): offset 0 inside a
@@ -560,11 +646,13 @@ static void low_value_indexed(Low &L) {
                                     }
                                 }
                             }, 4);
+                            L.sub("march masks");
                             upload((void **)&A->d_wum_m, wm.data(), sizeof(uint64_t) * wm.size());
                             A->wd_mg = G;
                             A->wd_muni = M;
                             A->wd_march = true;
                             wd_march_prepare();
+                            L.sub("march upload + prepare");
                         }
                     }
                 }
@@ -574,6 +662,7 @@ static void low_value_indexed(Low &L) {
                 // of x measured).  So the sweep is tiled: the steps are grouped by their position inside the plane
                 // (tiles of `tile` steps) and each tile is walked plane after plane, which makes the three touches
                 // of a line neighbours in time.  Only the order changes; every step is still done exactly once.
+                L.sub("(before the visiting order)");
                 int64_t far = 0;
                 for (int t = 0; t < A->npairs; ++t) far = std::max<int64_t>(far, std::llabs((long long)doff[(size_t)t]));
                 const double bpp = (double)far / 512.0;   // steps per plane
@@ -591,8 +680,16 @@ static void low_value_indexed(Low &L) {
                     upload((void **)&A->d_wsched, sched.data(), sizeof(int32_t) * sched.size());
                     A->h_wsched = sched;
                 }
+                L.sub("visiting order");
             }
         }
+        // (returning 70 MB to the system took 5-10 ms on this thread at 216^3: the codes are released behind the call's back; the context
+        // waits for the previous release before it starts the next one, and when it is destroyed)
+        if (code_up.joinable()) code_up.join();
+        if (err == hipSuccess) err = err_code;
+        L.sub("code upload (rest)");
+        if (c->deferred_free.valid()) c->deferred_free.wait();
+        c->deferred_free = std::async(std::launch::async, [p = codes_buf.release()] { delete[] p; });
     }
 }
 
@@ -823,19 +920,25 @@ int csr_upload(sla_ctx *c, int64_t m, int64_t n, int64_t row_begin, int64_t rows
         // go up on a background thread WHILE the host analyses of the storage forms run (round 4: the two were 106 ms + 106 ms in a row
         // at 70 M entries; the upload is bound by the staging copies of one or two threads, the analyses use the other cores).
         Low Lup = L;                       // (own error slot, own copy of the row-block starts)
+        CanonUpload cu;
         std::thread up([&] {
             Bind bind(c);                  // (a new thread starts on device 0)
             try {
-                low_csr_arrays(Lup);
+                low_csr_arrays(Lup, &cu);
             } catch (const std::bad_alloc &) {
                 if (Lup.err == hipSuccess) Lup.err = hipErrorOutOfMemory;
             }
         });
-        struct Joiner {                    // (an exception below must not unwind past a joinable thread)
+        struct Joiner {                    // (an exception below must not unwind past a joinable thread -- nor leave it waiting for the decision)
             std::thread &t;
-            ~Joiner() { if (t.joinable()) t.join(); }
-        } up_joiner{up};
+            CanonUpload &cu;
+            ~Joiner() { cu.decided.store(1, std::memory_order_release); if (t.joinable()) t.join(); }
+        } up_joiner{up, cu};
         low_value_indexed(L);
+        L.sub("visiting order + return");
+        // value-indexed after all: the rest of the canonical entry arrays is written on the device from the codes (option canon_device)
+        if (A->use_vdict && err == hipSuccess && c->canon_device && !A->rp64) cu.stop.store(1, std::memory_order_relaxed);
+        cu.decided.store(1, std::memory_order_release);
         lap("pair dictionary + wave slices");
         // (the LDS x windows of the row blocks serve the CSR-stream / dictionary-code kernels only: skipped with them, see below)
         if (!(A->use_wdia && c->wdia && c->diag_lazy)) low_xwin_statistics(L);
@@ -849,6 +952,16 @@ int csr_upload(sla_ctx *c, int64_t m, int64_t n, int64_t row_begin, int64_t rows
         lap("variable-coefficient slices");
         up.join();
         if (err == hipSuccess) err = Lup.err;
+        if (err == hipSuccess && cu.stop.load() && (cu.done_col < nnz || cu.done_val < nnz)) {
+            const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((rows + 255) / 256, (int64_t)c->n_cu * 8));
+            hipLaunchKernelGGL(vd_expand_kernel, dim3(grid), dim3(256), 0, stream_of(c), rows, row_begin, (const int32_t *)A->d_rowptr, A->d_vcode,
+                               A->d_vdoff, A->d_vdval, A->d_col, A->d_val, cu.done_col, cu.done_val);
+            err = hipGetLastError();
+            if (err == hipSuccess) err = hipStreamSynchronize(stream_of(c));
+            char buf[96];
+            snprintf(buf, sizeof(buf), "canonical entries over PCIe (fraction)=%.3f;", nnz ? 0.5 * (double)(cu.done_col + cu.done_val) / (double)nnz : 0.0);
+            A->lower_log += buf;
+        }
         lap("canonical CSR upload (rest)");
         low_lds_panels(L);                 // (its panel-major copy is written by a device kernel from the canonical arrays)
         lap("LDS panel table");

@@ -39,6 +39,10 @@ namespace sla {
 #ifndef SLA_TILE_SPIN
 #define SLA_TILE_SPIN 2000   // polls before a wavefront stops pacing for the rest of the launch
 #endif
+#ifndef SLA_TILE_UNIFORM
+#define SLA_TILE_UNIFORM 1
+#endif
+constexpr int kTilePollQ = (kTileBlocksPerCu * 32 + 63) / 64;   // 64-slot groups of the look-ahead poll (<= 32 CUs per XCD)
 constexpr int kTileU = SLA_TILE_U;   // 64-entry groups per chunk: 768 gathers in flight per wavefront (+ the next chunk's streams)
 
 struct TileChunk {
@@ -85,7 +89,7 @@ template <int EPI, typename RP>
 __global__ void __launch_bounds__(kBlock, kTileBlocksPerCu)
 spmv_tile_kernel(SpmvArgs<RP> a, const RP *__restrict__ rowptr, const int32_t *__restrict__ srow, const uint32_t *__restrict__ toff,
                  const uint32_t *__restrict__ tidx, const double *__restrict__ tval, const double *__restrict__ xg, int S, int P,
-                 int shift, unsigned *prog, int slack, const int32_t *__restrict__ vis, int v0, int nv) {
+                 int shift, unsigned *prog, int slack, const int32_t *__restrict__ vis, int v0, int nv, int pfd, int apoll, int64_t ncols, int dlim) {
     // One PASS of an overlapped all-gather (AgPlan, sla_internal.hpp) walks the nv panels vis[v0 ..] instead of 0 .. P-1 and starts
     // from the running row sums a.yinit; vis == nullptr: all P panels ascending from zero (nv == P then).
     __shared__ double s_y[kBlock / 64][kTileRows];
@@ -108,7 +112,10 @@ spmv_tile_kernel(SpmvArgs<RP> a, const RP *__restrict__ rowptr, const int32_t *_
     // and the grid is fully resident (kTileBlocksPerCu per CU).  Pacing is a throttle, never a correctness condition: a
     // wavefront that waits too long (grid not co-resident) stops pacing for the rest of the launch.
     __shared__ int s_prog[kBlock / 64];
+    __shared__ int s_pf[kBlock / 64][64];   // where the x-panel prefetch lands (never read)
+    __shared__ int s_poll[kBlock / 64][64 * kTilePollQ];   // the pacing slots of the XCD as the last look-ahead poll of each wavefront brought them
     if (tid < kBlock / 64) s_prog[tid] = 0;
+    for (int i = tid; i < (kBlock / 64) * 64 * kTilePollQ; i += kBlock) (&s_poll[0][0])[i] = 0;
     __syncthreads();
     const int xcd = (int)blockIdx.x & 7;
     const int nwg_xcd = ((int)gridDim.x - xcd + 7) >> 3;
@@ -124,31 +131,91 @@ spmv_tile_kernel(SpmvArgs<RP> a, const RP *__restrict__ rowptr, const int32_t *_
             // Two wavefronts publishing at once may each miss the other's LDS update, and the staler minimum may reach the slot
             // last.  Stores of one wavefront to one address stay in order, so re-reading the minimum after the store and
             // storing again until it is stable leaves the slot at the true minimum.
-            ((volatile int *)s_prog)[wave] = done;
+            // (LDS accesses as relaxed workgroup-scope atomics, not volatile: the compiler puts s_waitcnt vmcnt(0) lgkmcnt(0) around every
+            // volatile access -- round 4 found every publish, i.e. every tile, draining the wavefront's whole load pipeline there)
+            // The store-then-read order the protocol needs is the LDS's own (one wavefront's LDS operations are served in issue order);
+            // the empty asm statements keep the compiler from moving the reads over the stores.
+            __hip_atomic_store(&s_prog[wave], done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             int stored = -1;
             for (;;) {
+                asm volatile("" ::: "memory");
                 int m = done;
 #pragma unroll
-                for (int w = 0; w < kBlock / 64; ++w) m = min(m, ((volatile int *)s_prog)[w]);
+                for (int w = 0; w < kBlock / 64; ++w) m = min(m, __hip_atomic_load(&s_prog[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
                 if (m == stored) break;
                 __hip_atomic_store(myslot, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 stored = m;
             }
         }
     };
+    // The poll was a dependent L1-bypassing load (~1 us under this kernel's load) in front of every tile, and one the compiler had to put
+    // s_waitcnt vmcnt(0) behind: every outstanding stream and gather of the wavefront drained there.  Round 4: the slots are polled one
+    // step AHEAD and without a destination register -- a direct-to-LDS load (global_load_lds_dword, sc1 like the atomic load) issued at
+    // step q drops the slots into s_poll, where step q + 1 reads them with a plain LDS read, a tile's worth of streams and gathers
+    // later.  Progress only grows, so a stale (or not yet landed) value can only make a wavefront look again, with the loads below.
+    auto poll = [&]() -> int {
+        int v = 0x7fffffff;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (lane + 64 * q < nwg_xcd) v = min(v, __hip_atomic_load(slots + lane + 64 * q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        return v;
+    };
+    int *pollw = s_poll[wave];
+    const unsigned poll_lds = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)(&s_poll[wave][0]));
+    if (apoll && nwg_xcd > 64 * kTilePollQ) apoll = 0;
     auto wait_for = [&](int need) {                              // until all workgroups of the XCD have finished `need` steps
-        int spins = 0;
-        while (pace && known < need) {
+        if (apoll) {
+            if (!pace || need <= 0) return;
             int v = 0x7fffffff;
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-                if (lane + 64 * q < nwg_xcd) v = min(v, __hip_atomic_load(slots + lane + 64 * q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            for (int q = 0; q < kTilePollQ; ++q)
+                if (lane + 64 * q < nwg_xcd) v = min(v, __hip_atomic_load(pollw + lane + 64 * q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+            int spins = 0;
+            while (__ballot(v < need) != 0) {
+                v = poll();
+                if (__ballot(v < need) == 0) break;
+                __builtin_amdgcn_s_sleep(4);
+                if (++spins > SLA_TILE_SPIN) { pace = false; return; }
+            }
+#pragma unroll
+            for (int q = 0; q < kTilePollQ; ++q)
+                if (64 * q < nwg_xcd) {
+                    const int *src = slots + min(lane + 64 * q, nwg_xcd - 1);
+                    const unsigned dst = poll_lds + 256u * q;
+                    unsigned keep;
+                    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off sc1\n\ts_mov_b32 m0, %0"
+                                 : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+                }
+            return;
+        }
+        int spins = 0;
+        while (pace && known < need) {
+            int v = poll();
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) v = min(v, __shfl_xor(v, off, 64));
             known = v;
             if (known >= need) break;
             __builtin_amdgcn_s_sleep(4);
             if (++spins > SLA_TILE_SPIN) pace = false;
+        }
+    };
+    // x-panel prefetch (round 4).  The first touch of every line of a new panel was a demand miss of some gather -- 8192 lines per panel
+    // and XCD, each holding up the chunk it belongs to for a trip to the memory side.  On entering visit step q a wavefront now pulls ITS
+    // 1 / (wavefronts per XCD) of the panel of step q + pfd into the XCD's L2 with one direct-to-LDS load per 64 lines (no destination
+    // register; the data lands in s_pf and is never read), one 128-byte line per lane.
+    const int wix = ((int)blockIdx.x >> 3) * (kBlock / 64) + wave, nwx = nwg_xcd * (kBlock / 64);
+    const int plines = 1 << (shift - 4), lpw = (plines + nwx - 1) / nwx;
+    const unsigned pf_lds = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)(&s_pf[wave][0]));   // (flat address of LDS: the low half is the LDS byte address)
+    auto prefetch_panel = [&](int p) {
+        for (int i = lane; i < lpw; i += 64) {
+            const int64_t line = (int64_t)wix * lpw + i;
+            const int64_t colx = ((int64_t)p << shift) + line * 16;
+            if (line < plines && colx < ncols) {
+                const double *src = xg + colx;
+                unsigned keep;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep) : "v"(src), "s"(pf_lds) : "memory");
+            }
         }
     };
     int round = 0;
@@ -181,6 +248,11 @@ spmv_tile_kernel(SpmvArgs<RP> a, const RP *__restrict__ rowptr, const int32_t *_
                 ++j;
                 if (j >= nv) return false;
                 wait_for(round * nv + j - slack + 1);
+                if (pfd > 0) {   // the panel of visit step j + pfd (of the wavefront's next slice past the end of this one)
+                    int jj = j + pfd;
+                    if (jj >= nv && round + 1 < rounds && s + stride < S) jj -= nv;
+                    if (jj < nv) prefetch_panel(vis ? __builtin_amdgcn_readfirstlane(vis[v0 + jj]) : jj);
+                }
                 if ((j & 63) == 0) {   // the next 64 tile offsets, one per lane (no dependent load per tile)
                     pjl = vis ? vis[v0 + min(j + lane, nv - 1)] : min(j + lane, P - 1);
                     plo = tp[pjl];
@@ -212,6 +284,41 @@ spmv_tile_kernel(SpmvArgs<RP> a, const RP *__restrict__ rowptr, const int32_t *_
         };
         // three chunks in flight per wavefront: A is folded while B's gathers and C's index / value streams are outstanding
         TileChunk A, B, C;
+#if SLA_TILE_UNIFORM
+        // Round 4: the loop issues the SAME loads on every path.  With `if (more) issue(C)` the compiler's wait-count pass had to assume
+        // the path on which C was not issued -- there B's streams are the youngest loads -- and put s_waitcnt vmcnt(0) in front of
+        // gather(B): every chunk waited for the streams it had JUST issued (a full trip to HBM with one wavefront per SIMD and
+        // nothing else to run).  Past the slice's last chunk the loop now issues empty chunks (cnt = 0: the loads re-read the first
+        // entry of the arrays, the fold does nothing) until the pipeline has drained, so the waits are vmcnt(36): a chunk's streams
+        // have one whole iteration -- the previous chunk's gathers and the chunk before's fold -- to arrive.
+        bool live = true;
+        auto next = [&](TileChunk &c) {
+            if (live && !advance()) live = false;
+            if (live) {
+                issue(c);
+            } else {
+                c.cnt = 0;
+                c.panel = 0;
+#pragma unroll
+                for (int u = 0; u < kTileU; ++u) {   // (run-time indices: identical addresses would be merged into one load, and the count is the point)
+                    const int i = min(lane + 64 * u, dlim);
+                    c.idx[u] = __builtin_nontemporal_load(tidx + i);
+                    c.val[u] = __builtin_nontemporal_load(tval + i);
+                }
+            }
+        };
+        next(A);
+        next(B);
+        gather(A);
+        for (;;) {   // unrolled by three: the chunks rotate through the roles without register copies
+            if (A.cnt == 0) break;
+            next(C); gather(B); tile_fold_chunk(yl, A, shift, lane);
+            if (B.cnt == 0) break;
+            next(A); gather(C); tile_fold_chunk(yl, B, shift, lane);
+            if (C.cnt == 0) break;
+            next(B); gather(A); tile_fold_chunk(yl, C, shift, lane);
+        }
+#else
         bool hA = advance(), hB = false, hC = false;
         if (hA) issue(A);
         hB = hA && advance();
@@ -228,6 +335,7 @@ spmv_tile_kernel(SpmvArgs<RP> a, const RP *__restrict__ rowptr, const int32_t *_
             hB = hA && advance(); if (hB) issue(B); if (hA) gather(A);
             tile_fold_chunk(yl, C, shift, lane);
         }
+#endif
         for (int r = lane; r < nr; r += 64) spmv_epilogue<EPI, RP>(a, r0 + r, yl[r], coef, acc1, acc2);
     }
     if constexpr (EPI == EPI_DOT || EPI == EPI_DOT2 || EPI == EPI_DOT4 || EPI == EPI_RES || EPI == EPI_AXPY_DOT || EPI == EPI_XPBY_NRM) {
@@ -312,7 +420,9 @@ static int launch_tiles_t(const sla_csr *A, const SpmvLaunch &l) {
     ProfScope prof(c, l.kernel_id);
     if (A->d_tlprog) SLA_HIP_TRY(hipMemsetAsync(A->d_tlprog, 0, A->tlprog_bytes, stream_of(c)));   // the pacing table of this launch
     hipLaunchKernelGGL((spmv_tile_kernel<EPI, RP>), dim3(tiles_grid(A)), dim3(kBlock), 0, stream_of(c), a, a.rowptr, A->d_tlrow, A->d_tloff,
-                       A->d_tlidx, A->d_tlval, l.x, A->tl_S, A->tl_P, A->tl_shift, A->d_tlprog, c->xcd8 == 1 ? c->tile_slack : 0, vis, l.tv0, nv);
+                       A->d_tlidx, A->d_tlval, l.x, A->tl_S, A->tl_P, A->tl_shift, A->d_tlprog, c->xcd8 == 1 ? c->tile_slack : 0, vis, l.tv0, nv,
+                       c->xcd8 == 1 ? c->tile_prefetch : 0, c->tile_poll, A->n,
+                       (int)std::min<int64_t>(64 * kTileU - 1, A->nnz - 1));
     SLA_HIP_TRY(hipGetLastError());
     return SLA_OK;
 }

@@ -409,3 +409,30 @@ def test_pipelined_stream_kernel_is_bit_identical_to_the_stream_kernel(sla):
             assert np.array_equal(out[1][0], orc.spmv(orc.Csr(n, n, *csr), np.random.default_rng(3).standard_normal(n))), name
         for a, b_ in zip(out[0], out[1]):
             assert np.array_equal(a, b_) if isinstance(a, np.ndarray) else a == b_, name
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_canonical_arrays_written_on_the_device_are_the_callers(sla, mode):
+    """Round 4: a value-indexed matrix (constant-coefficient stencil) gets the part of its canonical col / val arrays that has not crossed
+    PCIe by the time the analysis is through written on the device from its 1-byte codes (sla_lower.cpp: vd_expand_kernel).  The
+    export, the plain-CSR kernels and the transposed product must see the caller's arrays bit for bit whichever way they got there:
+    canon_device = 0 (all uploaded), 1 (default: whatever the race leaves), 2 (nothing uploaded before the decision: all on the device)."""
+    from sla_amd import workloads as wl
+    for dims, (rp, ci, va) in (wl.laplace3d(40, 36, 33), wl.poisson2d(300, 211)):
+        ctx = sla.Context(0).set_options(canon_device=mode)
+        A = sla.fromCSR(dims, rp, ci, va, ctx)
+        assert "wdia" in A.kernel_info() or "vdict" in A.kernel_info(), A.kernel_info()
+        info = A.lower_info()
+        key = "canonical entries over PCIe (fraction)"
+        if mode == 2:
+            assert info.get(key) == 0.0, info
+        if mode == 0:
+            assert key not in info, info
+        rp2, ci2, va2 = A.csr()
+        assert np.array_equal(rp2, rp) and np.array_equal(ci2, ci) and np.array_equal(va2.view(np.uint64), va.view(np.uint64))
+        x = np.random.default_rng(5).standard_normal(dims[1])
+        ctx.set_options(wdia=0, vdict=0, diag=0)                          # the plain-CSR kernel on the generated arrays
+        xd, y = sla.DeviceVector(ctx, dims[1], x), sla.DeviceVector(ctx, dims[0])
+        sla._lib.check(sla._lib.lib().sla_spmv(A.h, xd.h, y.h))
+        assert "stream" in A.kernel_info(), A.kernel_info()
+        assert np.array_equal(y.to_host(), orc.spmv(orc.Csr(dims[0], dims[1], rp, ci, va), x))
