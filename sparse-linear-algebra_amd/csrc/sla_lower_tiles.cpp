@@ -23,7 +23,7 @@ int build_tiles(sla_csr *A, int64_t n, int64_t rows, const int64_t *rowptr, cons
     if (!c->tiles || rows == 0 || nnz == 0) return SLA_OK;
     if (A->use_diag || A->use_wdia || A->use_vdict || A->xwin_fraction >= 0.5) return SLA_OK;   // stencil / banded structure
     if ((A->use_lpanel && c->lpanel) || (A->use_lflat && c->lflat)) return SLA_OK;               // dense / medium rows: x panels in LDS
-    {   // the kernel keeps one slice's row sums per wavefront in static LDS (4 x kTileRows doubles = 128 KiB on the MI355X's 160 KiB)
+    {   // the kernel keeps one slice's row sums per wavefront in static LDS (4 x kTileRows doubles = 153 KiB of the MI355X's 160 KiB)
         int lds = 0;
         if (hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, c->device) != hipSuccess ||
             (int64_t)lds < (int64_t)(kBlock / 64) * kTileRows * 8 + 1024)

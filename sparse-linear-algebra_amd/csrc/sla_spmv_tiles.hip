@@ -7,7 +7,8 @@
 // the L2, i.e. the matrix has to be walked in column panels of <= 2 MiB of x.  Round 1 did that with P = 26 full passes
 // over the rows (y, rowptr re-streamed per pass: 2.7x the algorithmic bytes, PMC).  Here the row sums stay ON CHIP:
 //
-//   * rows are cut into slices of <= 1024 rows (equal entry counts), one wavefront per slice, its row sums in LDS (8 KiB);
+//   * rows are cut into slices of <= 4896 rows (equal entry counts), one wavefront per slice, its row sums in LDS (38 KiB: four
+//     wavefronts fill the CU's 160 KiB; 10 M rows = two rounds of the persistent grid -- at 4096 rows three: 2.04 -> 1.91 ms);
 //   * the slice's entries are stored tile-major -- ordered by (panel, row, column), 12 B each: the value and one dword
 //     (row - slice_row0) << 18 | (col - panel * 2^18) -- so a wavefront streams them with coalesced non-temporal loads,
 //     gathers x from the panel all wavefronts of the XCD are on at that moment, and adds the products into LDS;
