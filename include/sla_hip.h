@@ -310,6 +310,11 @@ int sla_prof_query(sla_ctx_t, int kernel_id, int *launches, double *mean_ms, dou
  * memory-side cache), `reps` launches timed one by one with HIP events.  (reads, writes) = (8, 0) pure read, (5, 3) the K4+K5
  * sweep, (2, 1) a triad.  bench.py's "measured ceiling": bytes = 8 (reads + writes) n per launch. */
 int sla_stream_probe(sla_ctx_t, int reads, int writes, int64_t n, int reps, double *mean_ms, double *min_ms);
+/* Rehearsal of the N > 1 point-to-point transfers on ONE rank: `pieces` grouped ncclRecv / ncclSend pairs with the context's own rank as
+ * the peer move `count` doubles on the context's stream (the entry points, datatype, group calls and stream of the halo exchange and of
+ * the grouped all-gather); *max_abs_err = largest difference between what was sent and what arrived (0 expected).  Needs a context
+ * with an RCCL communicator (sla_ctx_create_dist; nranks may be 1); SLA_ERR_INVALID otherwise. */
+int sla_dist_p2p_selftest(sla_ctx_t, int64_t count, int pieces, double *max_abs_err);
 /* SLA_DEBUG_BINDING=1: launches, copies, collectives or device allocations issued by a thread that is not inside an entry
  * point bound to the context they belong to (HIP's current device is per thread: the bug class of multi-device fan-out,
  * invisible on a one-GPU box).  0 in a correct library; the GPU test suites assert it under the debug switch. */

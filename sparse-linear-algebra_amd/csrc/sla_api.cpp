@@ -616,6 +616,15 @@ int sla_dist_unique_id(void *unique_id_128) {
     return dist_unique_id(unique_id_128);
 }
 
+int sla_dist_p2p_selftest(sla_ctx_t c, int64_t count, int pieces, double *max_abs_err) {
+    if (!c) return fail(SLA_ERR_INVALID, "sla_dist_p2p_selftest: null context");
+    if (!c->kids.empty()) return fail(SLA_ERR_INVALID, "sla_dist_p2p_selftest: not on a multi-device bundle");
+    return no_throw("sla_dist_p2p_selftest", [&]() -> int {
+        Bind bind(c);
+        return dist_p2p_selftest(c, count, pieces, max_abs_err);
+    });
+}
+
 int sla_ctx_create_dist(int device_id, int rank, int nranks, const void *unique_id_128, sla_ctx_t *out) {
     if (!unique_id_128) return fail(SLA_ERR_INVALID, "null unique id");
     return ctx_create_common(device_id, rank, nranks, unique_id_128, out);

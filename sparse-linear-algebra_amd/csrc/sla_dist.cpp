@@ -14,6 +14,7 @@
 #include <condition_variable>
 #include <map>
 #include <mutex>
+#include <cmath>
 #include <vector>
 
 #include "sla_internal.hpp"
@@ -459,6 +460,50 @@ int dist_exchange_group(sla_ctx *ctx, const std::vector<AgPiece> &pieces, const 
     }
     rc = r.group_end();
     if (rc != 0) return rccl_fail("ncclGroupEnd", rc);
+    return SLA_OK;
+}
+
+// Rehearsal of the point-to-point transfers on ONE rank (sla_dist_p2p_selftest; tests/test_gpu_parity.py).  No node with more than
+// one GPU was ever available to the author, and on a 1-rank communicator the exchanges have no peer: ncclSend / ncclRecv had never
+// been CALLED on hardware.  Here the rank is its own peer: `pieces` grouped recv / send pairs on the context's stream -- the same
+// dlsym'd entry points, argument order, datatype constant, group calls and stream the window exchange and the grouped all-gather
+// use -- moving `count` doubles; the result is compared on the host.
+int dist_p2p_selftest(sla_ctx *ctx, int64_t count, int pieces, double *max_abs_err) {
+    if (loop_of(ctx) || !ctx->comm) return fail(SLA_ERR_INVALID, "sla_dist_p2p_selftest: needs a context with an RCCL communicator");
+    if (count < 1 || pieces < 1 || pieces > count) return fail(SLA_ERR_INVALID, "sla_dist_p2p_selftest: bad sizes");
+    Rccl &r = rccl();
+    if (!r.send || !r.recv || !r.group_start || !r.group_end) return fail(SLA_ERR_RCCL, "librccl lacks ncclSend/ncclRecv");
+    std::vector<double> h((size_t)count), back((size_t)count, 0.0);
+    for (int64_t i = 0; i < count; ++i) h[(size_t)i] = 1.0 + (double)i * 0.5;
+    double *src = nullptr, *dst = nullptr;
+    SLA_HIP_TRY(dev_malloc(ctx, (void **)&src, sizeof(double) * (size_t)count));
+    hipError_t e = dev_malloc(ctx, (void **)&dst, sizeof(double) * (size_t)count);
+    if (e == hipSuccess) e = hipMemcpy(src, h.data(), sizeof(double) * (size_t)count, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemsetAsync(dst, 0, sizeof(double) * (size_t)count, stream_of(ctx));
+    int rc = 0;
+    const char *what = nullptr;
+    if (e == hipSuccess) {
+        rc = r.group_start();
+        if (rc != 0) what = "ncclGroupStart";
+        for (int p = 0; p < pieces && rc == 0; ++p) {
+            const int64_t b = count * p / pieces, len = count * (p + 1) / pieces - b;
+            rc = r.recv(dst + b, (size_t)len, kNcclFloat64, ctx->rank, (NcclComm)ctx->comm, stream_of(ctx));
+            if (rc != 0) { what = "ncclRecv"; break; }
+            rc = r.send(src + b, (size_t)len, kNcclFloat64, ctx->rank, (NcclComm)ctx->comm, stream_of(ctx));
+            if (rc != 0) what = "ncclSend";
+        }
+        const int rc2 = r.group_end();
+        if (rc == 0 && rc2 != 0) { rc = rc2; what = "ncclGroupEnd"; }
+        if (rc == 0) e = hipStreamSynchronize(stream_of(ctx));
+        if (rc == 0 && e == hipSuccess) e = hipMemcpy(back.data(), dst, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost);
+    }
+    (void)hipFree(src);
+    if (dst) (void)hipFree(dst);
+    if (rc != 0) return rccl_fail(what, rc);
+    SLA_HIP_TRY(e);
+    double err = 0.0;
+    for (int64_t i = 0; i < count; ++i) err = std::max(err, std::fabs(back[(size_t)i] - h[(size_t)i]));
+    if (max_abs_err) *max_abs_err = err;
     return SLA_OK;
 }
 

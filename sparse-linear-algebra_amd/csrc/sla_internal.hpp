@@ -624,6 +624,7 @@ int dist_group_end(sla_ctx *ctx);
 bool halo_inplace_extents(const sla_csr *A, const sla_vec *x, int64_t *left, int64_t *right);
 int dist_allreduce_max_i32(sla_ctx *ctx, int *value_host);
 int dist_comm_count(sla_ctx *ctx, int *nranks);
+int dist_p2p_selftest(sla_ctx *ctx, int64_t count, int pieces, double *max_abs_err);   // grouped ncclSend / ncclRecv with this rank as its own peer
 
 // shared helpers of sla_api.cpp --------------------------------------------------------------------------
 // full-length gather base for an SpMV with matrix A (null: plain all-gather) whose input is `x`

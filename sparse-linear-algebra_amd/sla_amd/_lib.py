@@ -84,6 +84,7 @@ PROTOTYPES = [
     ("sla_ctx_get_option", _int, [_vp, C.c_char_p, C.c_char_p, _int]),
     ("sla_debug_binding_violations", C.c_long, []),
     ("sla_stream_probe", _int, [_vp, _int, _int, _i64, _int, _pdbl, _pdbl]),
+    ("sla_dist_p2p_selftest", _int, [_vp, _i64, _int, _pdbl]),
     ("sla_ctx_row_range", _int, [_vp, _i64, _pi64, _pi64]),
     ("sla_last_error", C.c_char_p, []),
     ("sla_version", C.c_char_p, []),

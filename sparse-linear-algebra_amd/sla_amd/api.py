@@ -91,6 +91,12 @@ class Context:
             self.set_option(k, v)
         return self
 
+    def p2p_selftest(self, count, pieces=1):
+        """Grouped ncclRecv / ncclSend with this rank as its own peer (sla_dist_p2p_selftest): max |sent - arrived| over `count` doubles."""
+        err = C.c_double(-1.0)
+        check(lib().sla_dist_p2p_selftest(self.h, int(count), int(pieces), C.byref(err)))
+        return err.value
+
     def stream_probe(self, reads, writes, n, reps=20):
         """(mean ms, min ms, GB/s at the mean) of a sweep reading `reads` and writing `writes` vectors of n doubles (sla_stream_probe)."""
         mean, mn = C.c_double(), C.c_double()

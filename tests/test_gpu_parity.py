@@ -437,6 +437,18 @@ def test_forced_collectives_match_single_gpu_path(sla, monkeypatch):
     plain.close()
 
 
+def test_rccl_point_to_point_calls_on_one_rank(sla):
+    """ncclSend / ncclRecv / ncclGroupStart / ncclGroupEnd as the N > 1 exchanges call them (dlsym'd signatures, the f64 datatype
+    constant, the context's stream), with the one rank of a 1-rank communicator as its own peer: what was sent must arrive, for one
+    large piece, for many small ones and for a single element.  (A context without a communicator refuses.)"""
+    ctx = sla.Context(0, 0, 1, sla.Context.unique_id())
+    for count, pieces in ((1, 1), (4096, 1), (1000003, 7), (1 << 22, 64)):
+        assert ctx.p2p_selftest(count, pieces) == 0.0, (count, pieces)
+    ctx.close()
+    with pytest.raises(sla.SlaError):
+        sla.Context(0).p2p_selftest(16, 1)
+
+
 @pytest.mark.parametrize("problem", ["poisson2d 50x40", "laplace3d 14x11x13", "spd 400", "banded_nonsym 4001 (wdia-vv)"])
 def test_bicgstab_fused_k45_flow_vs_reference_split(sla, problem):
     """Single-rank BiCGSTAB fuses K4 and K5 (default): rho_{j+1} = s . r0hat - omega (As . r0hat) from K3's sweep instead of
