@@ -15,10 +15,13 @@ namespace sla {
 // Arnoldi (Sparse.hs:630-667): classical Gram-Schmidt against the SAME A q_i, two passes over Q
 // ---------------------------------------------------------------------------------------------
 // pass 1: parts[j * gridDim.x + block] = partial of (q_j <.> w), j < ncols     (hhcoli, :655)
-// 2-D grid: blockIdx.y selects a group of NC = 4 columns.  One workgroup streaming all (up to 32) columns at once reads
-// the basis at 4.6 TB/s; four columns per workgroup (w re-read per group, from the caches) 6980 instead of 6520 Arnoldi
-// steps/s on the 2 M-row banded problem (groups of 2 / 8 / 16: 6930 / 6940 / 6670).
-constexpr int kArnDotsGroup = 4;   // basis columns per workgroup of the dots pass
+// 2-D grid: blockIdx.y selects a group of NC columns.  One workgroup streaming all (up to 32) columns at once reads the basis at
+// 4.6 TB/s; groups per workgroup (w re-read per group, from the caches) on the 2 M-row banded problem, GMRES(30) Arnoldi steps/s, same
+// box, round 4 (loads of a group issued back to back): 1 column 6820, **2: 7120**, 3: 6990, 4: 6950, 8: 6520 (profiles/r04_ab_arnoldi.txt).
+#ifndef SLA_ARN_DOTS_GROUP
+#define SLA_ARN_DOTS_GROUP 2
+#endif
+constexpr int kArnDotsGroup = SLA_ARN_DOTS_GROUP;   // basis columns per workgroup of the dots pass
 template <int NC>
 __global__ void __launch_bounds__(kBlock) arn_dots_kernel(int64_t n, const double *Q, int64_t ldq, int ncols,
                                                            const double *w, double *parts, SolverScalars *sc) {
@@ -30,16 +33,33 @@ __global__ void __launch_bounds__(kBlock) arn_dots_kernel(int64_t n, const doubl
     double acc[NC];
 #pragma unroll
     for (int j = 0; j < NC; ++j) acc[j] = 0.0;
-    SLA_VEC_LOOP_BEGIN(n)
-        const double2 wv = ld2(w, i2);
+    // No load of the streaming loop stands under a condition (round 4): with `if (j < ncols)` around each column the compiler put
+    // s_waitcnt vmcnt(0) behind every single load -- one trip to memory per column and iteration, hidden by occupancy alone (the pass
+    // ran at 5.1 TB/s).  A full group loads its NC columns back to back; only the last, partial group keeps the conditions.
+    if (ncols == NC) {
+        SLA_VEC_LOOP_BEGIN(n)
+            const double2 wv = ld2(w, i2);
+            double2 qv[NC];
 #pragma unroll
-        for (int j = 0; j < NC; ++j)
-            if (j < ncols) {
-                const double2 qv = ld2(Q + (int64_t)j * ldq, i2);
-                acc[j] += qv.x * wv.x;
-                acc[j] += qv.y * wv.y;
+            for (int j = 0; j < NC; ++j) qv[j] = ld2(Q + (int64_t)j * ldq, i2);
+#pragma unroll
+            for (int j = 0; j < NC; ++j) {
+                acc[j] += qv[j].x * wv.x;
+                acc[j] += qv[j].y * wv.y;
             }
-    SLA_VEC_LOOP_END
+        SLA_VEC_LOOP_END
+    } else {
+        SLA_VEC_LOOP_BEGIN(n)
+            const double2 wv = ld2(w, i2);
+#pragma unroll
+            for (int j = 0; j < NC; ++j)
+                if (j < ncols) {
+                    const double2 qv = ld2(Q + (int64_t)j * ldq, i2);
+                    acc[j] += qv.x * wv.x;
+                    acc[j] += qv.y * wv.y;
+                }
+        SLA_VEC_LOOP_END
+    }
     if (SLA_HAS_TAIL(n)) {
 #pragma unroll
         for (int j = 0; j < NC; ++j)
@@ -61,11 +81,11 @@ __global__ void __launch_bounds__(kBlock) arn_dots_kernel(int64_t n, const doubl
 // NT: the basis is read non-temporally in THIS pass when it overflows the memory-side cache: the columns the dots pass
 // just allocated there then survive for the next pass instead of both passes cycling through an LRU that holds neither
 // (GMRES(30) at 2 M rows, Q = 0.5 GB: +6 % steps/s).
-template <int NC, bool NT>
+template <bool NT>
 __global__ void __launch_bounds__(kBlock) arn_update_kernel(int64_t n, const double *Q, int64_t ldq, int ncols,
                                                              const double *hp, int np, int cs, int stride, double *w,
                                                              double *pn, double *Hcol, SolverScalars *sc) {
-    __shared__ double s_h[NC];
+    __shared__ double s_h[64];
     __shared__ double s_red[4];
     if (arn_stopped(sc)) return;
     // every workgroup re-reduces the ncols dot products in the same fixed order
@@ -97,32 +117,42 @@ __global__ void __launch_bounds__(kBlock) arn_update_kernel(int64_t n, const dou
         }
     }
     __syncthreads();
-    double h[NC];
-#pragma unroll
-    for (int j = 0; j < NC; ++j) h[j] = j < ncols ? s_h[j] : 0.0;
     if (blockIdx.x == 0 && threadIdx.x < ncols) Hcol[threadIdx.x] = s_h[threadIdx.x];
     double acc = 0.0;
+    // The columns go eight (then four, then one to three) at a time, the loads of a group issued back to back and none under a
+    // condition (round 4: the `if (j < ncols)` form of rounds 1-3 waited for every column's load on its own -- 4.3 TB/s); the
+    // coefficients are LDS broadcasts.  The sum over the columns is formed in the same order, one column after the other.
+#define SLA_ARN_COLS(G)                                                                  \
+    {                                                                                    \
+        double2 qv[G];                                                                   \
+        _Pragma("unroll") for (int k = 0; k < G; ++k) qv[k] = ld2s<NT>(Q + (int64_t)(g + k) * ldq, i2); \
+        _Pragma("unroll") for (int k = 0; k < G; ++k) {                                  \
+            const double hk = s_h[g + k];                                                \
+            t.x += hk * qv[k].x;                                                         \
+            t.y += hk * qv[k].y;                                                         \
+        }                                                                                \
+        g += G;                                                                          \
+    }
     SLA_VEC_LOOP_BEGIN(n)
         double2 wv = ld2(w, i2);
         double2 t = make_double2(0.0, 0.0);
-#pragma unroll
-        for (int j = 0; j < NC; ++j)
-            if (j < ncols) {
-                const double2 qv = ld2s<NT>(Q + (int64_t)j * ldq, i2);
-                t.x += h[j] * qv.x;
-                t.y += h[j] * qv.y;
-            }
+        int g = 0;
+        while (g + 8 <= ncols) SLA_ARN_COLS(8)
+        if (g + 4 <= ncols) SLA_ARN_COLS(4)
+        const int rem = ncols - g;
+        if (rem == 3) SLA_ARN_COLS(3)
+        else if (rem == 2) SLA_ARN_COLS(2)
+        else if (rem == 1) SLA_ARN_COLS(1)
         wv.x -= t.x;
         wv.y -= t.y;
         st2(w, i2, wv);
         acc += wv.x * wv.x;
         acc += wv.y * wv.y;
     SLA_VEC_LOOP_END
+#undef SLA_ARN_COLS
     if (SLA_HAS_TAIL(n)) {
         double t = 0.0;
-#pragma unroll
-        for (int j = 0; j < NC; ++j)
-            if (j < ncols) t += h[j] * Q[(int64_t)j * ldq + n - 1];
+        for (int j = 0; j < ncols; ++j) t += s_h[j] * Q[(int64_t)j * ldq + n - 1];
         const double wv = w[n - 1] - t;
         w[n - 1] = wv;
         acc += wv * wv;
@@ -203,7 +233,7 @@ int arn_grid(int64_t n) {
 // sixteen loads per lane (arn_update_kernel's head) instead of behind a one-workgroup fold launch (round 4: a 4.8 us launch and a
 // dependent dispatch less per Arnoldi step).
 int arn_dots_grid(int64_t n, int ncols) {
-    const int g = arn_grid(n), groups = (ncols + kArnDotsGroup - 1) / kArnDotsGroup;
+    const int g = arn_grid(n), groups = (ncols + 3) / 4;   // (columns per wavefront of the update pass's head: four wavefronts)
     const int gx = 64 * std::max(1, 16 / groups);
     return g < 64 ? g : std::min(g & ~63, gx);
 }
@@ -221,15 +251,9 @@ int launch_arn_update(sla_ctx *c, int64_t n, const double *Q, int64_t ldq, int n
     const int g = arn_grid(n);
     // the basis read so far (ncols columns) against the memory-side cache
     const bool nt = c->vec_nt < 0 ? (int64_t)ncols * 8 * n > c->mall_bytes : c->vec_nt != 0;
-    if (nt) {
-#define CALL(NC) hipLaunchKernelGGL((arn_update_kernel<NC, true>), dim3(g), dim3(kBlock), 0, stream_of(c), n, Q, ldq, ncols, hp, np, cs, stride, w, pn, Hcol, sc)
-        SLA_NC_DISPATCH(ncols, CALL);
-#undef CALL
-    } else {
-#define CALL(NC) hipLaunchKernelGGL((arn_update_kernel<NC, false>), dim3(g), dim3(kBlock), 0, stream_of(c), n, Q, ldq, ncols, hp, np, cs, stride, w, pn, Hcol, sc)
-        SLA_NC_DISPATCH(ncols, CALL);
-#undef CALL
-    }
+    if (ncols < 1 || ncols > 64) return fail(SLA_ERR_INVALID, "Krylov basis: 1..64 columns");
+    if (nt) hipLaunchKernelGGL((arn_update_kernel<true>), dim3(g), dim3(kBlock), 0, stream_of(c), n, Q, ldq, ncols, hp, np, cs, stride, w, pn, Hcol, sc);
+    else hipLaunchKernelGGL((arn_update_kernel<false>), dim3(g), dim3(kBlock), 0, stream_of(c), n, Q, ldq, ncols, hp, np, cs, stride, w, pn, Hcol, sc);
     SLA_HIP_TRY(hipGetLastError());
     return SLA_OK;
 }
