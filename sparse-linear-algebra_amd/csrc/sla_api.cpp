@@ -477,6 +477,8 @@ const IntKnob kIntKnobs[] = {
     {"tile_slack", &sla_ctx::tile_slack, 0, 64},
     {"tile_prefetch", &sla_ctx::tile_prefetch, 0, 16},
     {"canon_device", &sla_ctx::canon_device, 0, 2},
+    {"xfer", &sla_ctx::xfer, 0, 1},
+    {"xfer_lanes", &sla_ctx::xfer_lanes, 1, 8},
     {"tile_poll", &sla_ctx::tile_poll, 0, 1},
     {"row_align", &sla_ctx::row_align, 0, 256},
     {"rb_nnz", &sla_ctx::rb_nnz, 0, 1024},
@@ -595,6 +597,10 @@ static int ctx_create_common(int device_id, int rank, int nranks, const void *ui
         }
     }
     ctx_read_knobs(c);   // (after the device-derived defaults: SLA_WD_GRID overrides the per-CU grid)
+    if (c->xfer) {       // the pinned copy lanes of this device, built while the caller assembles its matrix
+        const int dev = c->device, lanes = c->xfer_lanes;
+        c->xfer_warmup = std::async(std::launch::async, [dev, lanes] { xfer_warm(dev, lanes); });
+    }
     if (uid) {
         int rc = dist_comm_init(c, uid);
         if (rc != SLA_OK) {
@@ -896,7 +902,7 @@ int sla_csr_export(sla_csr_t A, int64_t *rowptr, int64_t *colidx, double *val) {
             SLA_HIP_TRY(hipMemcpy(t.data(), A->d_col, sizeof(int32_t) * t.size(), hipMemcpyDeviceToHost));
             for (size_t i = 0; i < t.size(); ++i) colidx[i] = t[i];
         }
-        if (val && A->nnz) SLA_HIP_TRY(hipMemcpy(val, A->d_val, sizeof(double) * (size_t)A->nnz, hipMemcpyDeviceToHost));
+        if (val && A->nnz) SLA_HIP_TRY(xfer_copy(A->ctx, val, A->d_val, sizeof(double) * (size_t)A->nnz, hipMemcpyDeviceToHost));
         return SLA_OK;
     });
 }
@@ -997,8 +1003,7 @@ int sla_vec_create(sla_ctx_t c, int64_t n, const double *host, sla_vec_t *out) {
     sla_vec *v = nullptr;
     SLA_TRY(vec_alloc(c, n, &v));
     if (host && v->n_local > 0) {
-        hipError_t e = hipMemcpyAsync(v->d, host + v->begin, sizeof(double) * (size_t)v->n_local, hipMemcpyHostToDevice, stream_of(c));
-        if (e == hipSuccess) e = hipStreamSynchronize(stream_of(c));
+        hipError_t e = xfer_copy(c, v->d, host + v->begin, sizeof(double) * (size_t)v->n_local, hipMemcpyHostToDevice);
         if (e != hipSuccess) {
             sla_vec_destroy(v);
             return fail(SLA_ERR_HIP, std::string("vector upload: ") + hipGetErrorString(e));
@@ -1015,8 +1020,7 @@ int sla_vec_create_local(sla_ctx_t c, int64_t n, const double *host_local, sla_v
     sla_vec *v = nullptr;
     SLA_TRY(vec_alloc(c, n, &v));
     if (host_local && v->n_local > 0) {
-        hipError_t e = hipMemcpyAsync(v->d, host_local, sizeof(double) * (size_t)v->n_local, hipMemcpyHostToDevice, stream_of(c));
-        if (e == hipSuccess) e = hipStreamSynchronize(stream_of(c));
+        hipError_t e = xfer_copy(c, v->d, host_local, sizeof(double) * (size_t)v->n_local, hipMemcpyHostToDevice);
         if (e != hipSuccess) {
             sla_vec_destroy(v);
             return fail(SLA_ERR_HIP, std::string("vector upload: ") + hipGetErrorString(e));
@@ -1047,9 +1051,8 @@ int sla_vec_to_host_local(sla_vec_t v, double *host_local) {
     if (!v || !host_local) return fail(SLA_ERR_INVALID, "null argument");
     sla_ctx *c = v->ctx;
     Bind bind(c);
-    if (v->n_local > 0)
-        SLA_HIP_TRY(hipMemcpyAsync(host_local, v->d, sizeof(double) * (size_t)v->n_local, hipMemcpyDeviceToHost, stream_of(c)));
-    SLA_HIP_TRY(hipStreamSynchronize(stream_of(c)));
+    SLA_HIP_TRY(hipStreamSynchronize(stream_of(c)));   // (the kernels that wrote it)
+    if (v->n_local > 0) SLA_HIP_TRY(xfer_copy(c, host_local, v->d, sizeof(double) * (size_t)v->n_local, hipMemcpyDeviceToHost));
     return SLA_OK;
 }
 
@@ -1061,8 +1064,8 @@ int sla_vec_to_host(sla_vec_t v, double *host) {
     if (!c->collectives) return sla_vec_to_host_local(v, host);
     const double *base = nullptr;
     SLA_TRY(gather_x(nullptr, v, &base));
-    SLA_HIP_TRY(hipMemcpyAsync(host, base, sizeof(double) * (size_t)v->n, hipMemcpyDeviceToHost, stream_of(c)));
     SLA_HIP_TRY(hipStreamSynchronize(stream_of(c)));
+    SLA_HIP_TRY(xfer_copy(c, host, base, sizeof(double) * (size_t)v->n, hipMemcpyDeviceToHost));
     return SLA_OK;
 }
 

@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <map>
 #include <new>
+#include <atomic>
 #include <future>
 #include <string>
 #include <algorithm>
@@ -234,7 +235,10 @@ struct sla_ctx {
     int xcd8 = -1;                   // 1: workgroups are dealt round-robin over 8 XCDs (those with equal b % 8 share one; probed once: what the tile kernel's panel pacing relies on), 0: not so
     int tiles_device = 1;            // the tile form's re-ordering as a device sort (sla_tiles_build.hip): 1 from 2^20 entries on, 2 always, 0 host builder (SLA_TILES_DEVICE)
     int tiles = 1;                   // allow the row-slice x column-panel tile SpMV for irregular matrices with x > L2 (SLA_TILES=0: column-panel passes)
+    std::future<void> xfer_warmup;   // the copy lanes of this device being built (sla_xfer.cpp)
     std::future<void> deferred_free; // host buffers of the last lowering being released off the caller's thread (sla_lower.cpp)
+    int xfer = 1;                    // copies >= 24 MiB from / to pageable host memory: own pinned staging on xfer_lanes threads (0: plain hipMemcpy)
+    int xfer_lanes = 4;
     int canon_device = 1;            // value-indexed matrices: canonical col / val written on the device from the 1-byte codes instead of uploaded
     int tile_prefetch = 0;           // x-panel prefetch distance of spmv_tile_kernel in visit steps (0: demand misses only; measured: never a gain)
     int tile_poll = 1;               // 1: pacing slots polled one step ahead, 0: dependent poll in front of every tile (rounds 2-3)
@@ -635,6 +639,11 @@ int vec_alloc(sla_ctx *c, int64_t n, sla_vec **out);
 int csr_transposed(sla_csr *A, sla_csr **out);
 // Host-side set-up work (lowering analyses, COO validation) is row-parallel: par_rows runs fn(t, lo, hi) over T contiguous row ranges
 // whose boundaries are multiples of `align` rows, on T host threads (SLA_HOST_THREADS, default <= 16); returns T.
+// sla_xfer.cpp: large copies between the caller's pageable arrays and the device through pinned slots on several host threads
+typedef void (*xfer_stage_fn)(void *slot, size_t off, size_t len, const void *ctx);
+hipError_t xfer_copy(sla_ctx *c, void *dst, const void *src, size_t bytes, hipMemcpyKind kind, const std::atomic<int> *stop = nullptr,
+                     size_t *done = nullptr, xfer_stage_fn stage = nullptr, const void *stage_ctx = nullptr);
+void xfer_warm(int device, int lanes);
 int host_threads();   // sla_lower.cpp
 template <class F>
 int par_rows(int64_t rows, int64_t align, F fn, int64_t serial_below = 200000) {
@@ -713,6 +722,7 @@ int launch_lp_reorder(sla_ctx *c, bool rp64, const void *pp, const void *q, cons
 int launch_spmv_lpanel(const sla_csr *A, int epi, const SpmvArgs<int32_t> &a, int grid);
 int launch_lpanel_finish(const sla_csr *A, int epi, const SpmvArgs<int32_t> &a, int grid);   // its finish kernel alone
 bool lflat_on(const sla_csr *A);                                                                             // sla_spmv_lflat.hip
+bool lflat_candidate(const sla_csr *A, int64_t n, int64_t rows);
 int build_lflat(sla_csr *A, int64_t n, int64_t rows, int64_t col_lo, int64_t col_hi);
 int launch_spmv_lflat(const sla_csr *A, int epi, const SpmvArgs<int32_t> &a, int grid);
 int launch_spmv_lpanel(const sla_csr *A, int epi, const SpmvArgs<int64_t> &a, int grid);

@@ -143,6 +143,15 @@ int host_threads() {
 // csr_upload = one lowering analysis per function.  What they share travels in `Low`; SLA_LOW_LOCALS re-opens it under the
 // names the analyses use.
 // ---------------------------------------------------------------------------------------------------------------
+// The canonical entry arrays go up in the background and the upload can be called off (`stop`): a matrix that turns out to be
+// value-indexed gets its col / val written by a device kernel from its 1-byte codes (vd_expand_kernel below) instead of over PCIe.  The
+// entry copies wait for the analysis's decision (`decided`: it falls right after the pair-coding pass, or after the first 257 distinct
+// pairs of a matrix that is not value-indexed -- microseconds) instead of racing it for the host's memory bandwidth.
+struct CanonUpload {
+    std::atomic<int> stop{0};
+    std::atomic<int> decided{0};
+    int64_t done_col = 0, done_val = 0;   // entries [0, done) are on the device
+};
 struct Low {
     sla_ctx *c;
     sla_csr *A;
@@ -151,6 +160,7 @@ struct Low {
     const double *val;
     bool panel_view, dbg_lower;
     hipError_t err = hipSuccess;
+    CanonUpload *cu = nullptr;          // (csr_upload's; low_value_indexed reports its decision there)
     std::chrono::steady_clock::time_point t_sub = std::chrono::steady_clock::now();
     void sub(const char *what) {        // SLA_DEBUG_LOWER: times inside one analysis
         if (!dbg_lower || panel_view) return;
@@ -166,7 +176,7 @@ struct Low {
     void upload(void **dst, const void *src, size_t bytes) {
         if (err != hipSuccess) return;
         err = dev_malloc(c, dst, bytes + kArraySlack);
-        if (err == hipSuccess && bytes) err = hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
+        if (err == hipSuccess && bytes) err = xfer_copy(c, *dst, src, bytes, hipMemcpyHostToDevice);
         if (err == hipSuccess) err = hipMemset((char *)*dst + bytes, 0, kArraySlack);
     }
 };
@@ -186,17 +196,11 @@ struct Low {
 // canonical CSR arrays (i32 columns, i32 / i64 row pointers) + the row-block tables of the general kernels.
 // The entry arrays go up in chunks and the upload can be called off (`stop`): a matrix that turns out to be value-indexed gets the rest
 // of its col / val written by a device kernel from its 1-byte codes (vd_expand_kernel below) instead of over PCIe.
-struct CanonUpload {
-    std::atomic<int> stop{0};
-    std::atomic<int> decided{0};          // the value-indexed analysis is through (canon_device = 2: the entry copies wait for it)
-    int64_t done_col = 0, done_val = 0;   // entries [0, done) are on the device
-};
 static void low_csr_arrays(Low &L, CanonUpload *cu) {
     SLA_LOW_LOCALS(L);
-    constexpr int64_t kChunk = (int64_t)1 << 20;   // entries per copy (8 MiB of values, 4 MiB of columns): what a called-off upload still finishes
     auto stopped = [&] { return cu && cu->stop.load(std::memory_order_relaxed) != 0; };
-    auto await_decision = [&] {   // (canon_device = 2, tests: no entry crosses PCIe before the analysis has said which way it goes)
-        while (cu && c->canon_device == 2 && !cu->decided.load(std::memory_order_acquire)) std::this_thread::yield();
+    auto await_decision = [&] {
+        while (cu && !cu->decided.load(std::memory_order_acquire)) std::this_thread::yield();
     };
     // the values go up on a second host thread while this one narrows and uploads the indices (pageable copies are
     // bound by the staging memcpy of the calling thread, not by the link)
@@ -209,11 +213,11 @@ static void low_csr_arrays(Low &L, CanonUpload *cu) {
         Bind bind(c);   // (a new thread starts on device 0)
         if (err_val == hipSuccess) err_val = dev_malloc(c, (void **)&A->d_val, sizeof(double) * (size_t)nnz + kArraySlack);
         if (err_val == hipSuccess) err_val = hipMemset((char *)A->d_val + sizeof(double) * (size_t)nnz, 0, kArraySlack);
-        int64_t k = 0;
         await_decision();
-        for (; k < nnz && err_val == hipSuccess && !stopped(); k += kChunk)
-            err_val = hipMemcpy(A->d_val + k, val + k, sizeof(double) * (size_t)std::min(kChunk, nnz - k), hipMemcpyHostToDevice);
-        if (cu) cu->done_val = std::min(k, nnz);
+        size_t done_b = 0;
+        if (err_val == hipSuccess && nnz && !stopped())
+            err_val = xfer_copy(c, A->d_val, val, sizeof(double) * (size_t)nnz, hipMemcpyHostToDevice, cu ? &cu->stop : nullptr, &done_b);
+        if (cu) cu->done_val = (int64_t)(done_b / sizeof(double));
     });
     Joiner val_up_joiner{val_up};
     // row pointers and row-block tables first: every form needs them
@@ -237,18 +241,17 @@ static void low_csr_arrays(Low &L, CanonUpload *cu) {
     upload((void **)&A->d_rb, rb.data(), sizeof(int32_t) * rb.size());
     if (err == hipSuccess) err = dev_malloc(c, (void **)&A->d_col, sizeof(int32_t) * (size_t)nnz + kArraySlack);
     if (err == hipSuccess) err = hipMemset((char *)A->d_col + sizeof(int32_t) * (size_t)nnz, 0, kArraySlack);
-    {
-        std::vector<int32_t> col32((size_t)std::min(kChunk, nnz));
-        int64_t k = 0;
+    {   // the caller's int64 column indices are narrowed on their way into the pinned slots (no 4 B-per-entry host copy, no pass of its own)
         await_decision();
-        for (; k < nnz && err == hipSuccess && !stopped(); k += kChunk) {
-            const int64_t cnt = std::min(kChunk, nnz - k);
-            par_rows(cnt, 1 << 16, [&](int, int64_t lo, int64_t hi) {   // ("rows" here: entries of the chunk)
-                for (int64_t q = lo; q < hi; ++q) col32[(size_t)q] = (int32_t)col[k + q];
-            });
-            err = hipMemcpy(A->d_col + k, col32.data(), sizeof(int32_t) * (size_t)cnt, hipMemcpyHostToDevice);
-        }
-        if (cu) cu->done_col = std::min(k, nnz);
+        size_t done_b = 0;
+        if (err == hipSuccess && nnz && !stopped())
+            err = xfer_copy(c, A->d_col, nullptr, sizeof(int32_t) * (size_t)nnz, hipMemcpyHostToDevice, cu ? &cu->stop : nullptr, &done_b,
+                            [](void *slot, size_t off, size_t len, const void *ctx) {
+                                const int64_t *col64 = (const int64_t *)ctx + off / sizeof(int32_t);
+                                int32_t *o = (int32_t *)slot;
+                                for (size_t q = 0; q < len / sizeof(int32_t); ++q) o[q] = (int32_t)col64[q];
+                            }, col);
+        if (cu) cu->done_col = (int64_t)(done_b / sizeof(int32_t));
     }
     val_up.join();
     if (err == hipSuccess) err = err_val;
@@ -285,11 +288,15 @@ static void low_xwin_statistics(Low &L) {
         int64_t inside = 0, total = 0;
         const int64_t wmax = std::max<int64_t>(0, n - kXWin);
         std::vector<int64_t> part_in((size_t)host_threads(), 0), part_tot((size_t)host_threads(), 0);
-        par_rows((int64_t)rb.size() - 1, 1, [&](int t, int64_t blo, int64_t bhi) {
+        // (the share is a go / no-go statistic with its threshold at one half: from 2^16 row blocks on every (blocks / 2^15)-th block is
+        // counted -- the full count read all of col again, 0.16 s at 330 M entries)
+        const int64_t nblk = (int64_t)rb.size() - 1, samp = nblk >= ((int64_t)1 << 16) ? nblk >> 15 : 1;
+        par_rows(nblk, 1, [&](int t, int64_t blo, int64_t bhi) {
             int64_t in = 0, tot = 0;
             for (int64_t b = blo; b < bhi; ++b) {
                 const int64_t w = std::min<int64_t>(wmax, std::max<int64_t>(0, row_begin + rb[(size_t)b] - kXWinHalo));
                 rbw[(size_t)b] = (int32_t)w;
+                if (b % samp != 0) continue;
                 const int64_t k0 = rowptr[rb[(size_t)b]], k1 = rowptr[rb[(size_t)b + 1]];
                 if (k1 - k0 > kNnzPerRowBlock) continue;  // long-row blocks gather from global memory
                 tot += k1 - k0;
@@ -440,6 +447,10 @@ static void low_value_indexed(Low &L) {
             }
         }
         L.sub("pair coding pass");
+        if (L.cu) {   // the decision the background upload of col / val waits for
+            if (ok && c->canon_device) L.cu->stop.store(1, std::memory_order_relaxed);
+            L.cu->decided.store(1, std::memory_order_release);
+        }
         if (ok) {
             // canonical table order: by offset, then by value bits (independent of the input order)
             std::vector<int> order(pairs.size()), rank(pairs.size());
@@ -919,8 +930,9 @@ int csr_upload(sla_ctx *c, int64_t m, int64_t n, int64_t row_begin, int64_t rows
         // The canonical arrays (narrowed columns, values, row pointers, row-block tables: 12 B per entry over PCIe from pageable memory)
         // go up on a background thread WHILE the host analyses of the storage forms run (round 4: the two were 106 ms + 106 ms in a row
         // at 70 M entries; the upload is bound by the staging copies of one or two threads, the analyses use the other cores).
-        Low Lup = L;                       // (own error slot, own copy of the row-block starts)
         CanonUpload cu;
+        Low Lup = L;                       // (own error slot, own copy of the row-block starts)
+        L.cu = &cu;
         std::thread up([&] {
             Bind bind(c);                  // (a new thread starts on device 0)
             try {
@@ -937,8 +949,7 @@ int csr_upload(sla_ctx *c, int64_t m, int64_t n, int64_t row_begin, int64_t rows
         low_value_indexed(L);
         L.sub("visiting order + return");
         // value-indexed after all: the rest of the canonical entry arrays is written on the device from the codes (option canon_device)
-        if (A->use_vdict && err == hipSuccess && c->canon_device && !A->rp64) cu.stop.store(1, std::memory_order_relaxed);
-        cu.decided.store(1, std::memory_order_release);
+        cu.decided.store(1, std::memory_order_release);   // (matrices the analysis did not look at: rp64, rows too long, no entries)
         lap("pair dictionary + wave slices");
         // (the LDS x windows of the row blocks serve the CSR-stream / dictionary-code kernels only: skipped with them, see below)
         if (!(A->use_wdia && c->wdia && c->diag_lazy)) low_xwin_statistics(L);
@@ -966,7 +977,7 @@ int csr_upload(sla_ctx *c, int64_t m, int64_t n, int64_t row_begin, int64_t rows
         low_lds_panels(L);                 // (its panel-major copy is written by a device kernel from the canonical arrays)
         lap("LDS panel table");
         if (!panel_view && err == hipSuccess && !(A->use_lpanel && c->lpanel) && c->lflat && nnz > 0 &&
-            (c->lflat == 2 || !(A->use_wdia || A->use_vdict || A->use_diag))) {   // medium rows without band structure: the flat LDS-panel form (device-built)
+            (c->lflat == 2 || !(A->use_wdia || A->use_vdict || A->use_diag)) && lflat_candidate(A, n, rows)) {   // medium rows without band structure: the flat LDS-panel form (device-built)
             std::vector<int64_t> plo((size_t)host_threads(), n), phi((size_t)host_threads(), -1);
             par_rows(rows, 1, [&](int t, int64_t lo, int64_t hi) {   // (canonical CSR: first / last entry of a row are its min / max column)
                 int64_t a = n, b = -1;

@@ -191,12 +191,23 @@ __global__ void __launch_bounds__(kLpBlock) spmv_lflat_kernel(const uint32_t *__
 bool lflat_on(const sla_csr *A) { return A->use_lflat && A->ctx->lflat && A->ctx->spmv_algo == 0; }
 
 // Lowering: after the canonical arrays are on the device.  No-op unless the structure calls for the form (see the header).
+// what can be said without looking at an entry (csr_upload asks before it spends a pass over the rows on the column range)
+bool lflat_candidate(const sla_csr *A, int64_t n, int64_t rows) {
+    const sla_ctx *c = A->ctx;
+    const int64_t nnz = A->nnz;
+    if (!c->lflat || A->rp64 || rows <= 0 || nnz <= 0 || nnz >= ((int64_t)1 << 31)) return false;
+    if (A->use_lpanel && c->lpanel) return false;                                                                        // dense rows: LDS panels
+    if (c->lflat < 2 && (A->use_wdia || A->use_vdict || A->use_diag || A->xwin_fraction >= 0.5)) return false;         // stencil / banded structure (lflat = 2: test hook, any structure)
+    const int64_t P = (n + kLfW - 1) / kLfW;
+    const int64_t nseg = P * rows;
+    // mean segment length: from lf_min_seg10 / 10 (1.5: below that the partials cost more than the entries) up to the LDS-panel form's threshold
+    return !(P < 3 || P > 4096 || nseg >= ((int64_t)1 << 31) || nnz * 10 < (int64_t)c->lf_min_seg10 * nseg || (c->lflat < 2 && nnz >= (int64_t)c->lp_min_seg * nseg));
+}
+
 int build_lflat(sla_csr *A, int64_t n, int64_t rows, int64_t col_lo, int64_t col_hi) {
     sla_ctx *c = A->ctx;
     const int64_t nnz = A->nnz;
-    if (!c->lflat || A->rp64 || rows <= 0 || nnz <= 0 || nnz >= ((int64_t)1 << 31) || !A->d_col || !A->d_val || !A->d_rowptr) return SLA_OK;
-    if (A->use_lpanel && c->lpanel) return SLA_OK;                                                                        // dense rows: LDS panels
-    if (c->lflat < 2 && (A->use_wdia || A->use_vdict || A->use_diag || A->xwin_fraction >= 0.5)) return SLA_OK;         // stencil / banded structure (lflat = 2: test hook, any structure)
+    if (!lflat_candidate(A, n, rows) || !A->d_col || !A->d_val || !A->d_rowptr) return SLA_OK;
     {   // one workgroup keeps a panel of x in 128 KiB of LDS
         int lds = 0;
         if (hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, c->device) != hipSuccess || (size_t)lds < kLfLds) return SLA_OK;
@@ -204,8 +215,6 @@ int build_lflat(sla_csr *A, int64_t n, int64_t rows, int64_t col_lo, int64_t col
     const int64_t P = (n + kLfW - 1) / kLfW;
     const int64_t W = std::min<int64_t>(kLfW, ((n + P - 1) / P + 63) / 64 * 64);   // equal panels
     const int64_t nseg = P * rows;
-    // mean segment length: from lf_min_seg10 / 10 (1.5: below that the partials cost more than the entries) up to the LDS-panel form's threshold
-    if (P < 3 || P > 4096 || nseg >= ((int64_t)1 << 31) || nnz * 10 < (int64_t)c->lf_min_seg10 * nseg || (c->lflat < 2 && nnz >= (int64_t)c->lp_min_seg * nseg)) return SLA_OK;
     hipStream_t st = stream_of(c);
     DevBuf d_len, d_tmp;
     uint32_t *dq = nullptr;

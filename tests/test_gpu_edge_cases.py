@@ -416,7 +416,8 @@ def test_canonical_arrays_written_on_the_device_are_the_callers(sla, mode):
     """Round 4: a value-indexed matrix (constant-coefficient stencil) gets the part of its canonical col / val arrays that has not crossed
     PCIe by the time the analysis is through written on the device from its 1-byte codes (sla_lower.cpp: vd_expand_kernel).  The
     export, the plain-CSR kernels and the transposed product must see the caller's arrays bit for bit whichever way they got there:
-    canon_device = 0 (all uploaded), 1 (default: whatever the race leaves), 2 (nothing uploaded before the decision: all on the device)."""
+    canon_device = 0: all uploaded; 1 (default; 2 is accepted as a synonym): the upload waits for the pair analysis's decision, so nothing
+    of col / val crosses PCIe and all of it is written on the device."""
     from sla_amd import workloads as wl
     for dims, (rp, ci, va) in (wl.laplace3d(40, 36, 33), wl.poisson2d(300, 211)):
         ctx = sla.Context(0).set_options(canon_device=mode)
@@ -424,7 +425,7 @@ def test_canonical_arrays_written_on_the_device_are_the_callers(sla, mode):
         assert "wdia" in A.kernel_info() or "vdict" in A.kernel_info(), A.kernel_info()
         info = A.lower_info()
         key = "canonical entries over PCIe (fraction)"
-        if mode == 2:
+        if mode >= 1:
             assert info.get(key) == 0.0, info
         if mode == 0:
             assert key not in info, info
