@@ -11,6 +11,7 @@
 #include <cstring>
 #include <limits>
 #include <thread>
+#include <utility>
 #include <vector>
 
 #include "sla_internal.hpp"
@@ -33,7 +34,7 @@ int build_tiles(sla_csr *A, int64_t n, int64_t rows, const int64_t *rowptr, cons
     while (((int64_t)1 << row_bits) < kTileRows) ++row_bits;
     // panel width: 2^17 columns (1 MiB of x) at 10 M rows, 2^16 below ~6 M (measured: 7-8 % faster at 0.5 / 1 / 3 M rows, 3-15 % slower at 10 M)
     const int want = c->tile_shift > 0 ? c->tile_shift : (n < 6000000 ? 16 : 17);
-    const int shift = std::max(10, std::min(32 - row_bits, want));   // (slice row, panel column) packed in 32 bits
+    const int shift = std::max(10, std::min(31 - row_bits, want));   // (layer flag, slice row, panel column) packed in 32 bits
     const int64_t W = (int64_t)1 << shift;
     if (n <= 2 * W || (c->tile_shift <= 0 && n <= ((int64_t)1 << 18))) return SLA_OK;   // x (nearly) fits the L2 already
     const int64_t P = (n + W - 1) / W;
@@ -101,14 +102,18 @@ int build_tiles(sla_csr *A, int64_t n, int64_t rows, const int64_t *rowptr, cons
     if (const char *e = getenv("SLA_HOST_THREADS")) T = std::max(1, std::min(atoi(e), 64));
     if (nnz < 2000000) T = 1;
     std::vector<int64_t> maxseg((size_t)T, 0);
-    // Inside a tile the entries are ordered by (layer, row): layer = rank of the entry inside its (row, panel) segment in
-    // ascending column order.  A layer holds every row at most once, rows ascending, so 64 consecutive entries of a layer
-    // are 64 DIFFERENT rows -- the kernel adds them to the row sums with plain LDS read-modify-writes, no cross-lane
-    // work -- and a row's entries are still added one by one in ascending column order (layer l before layer l + 1).
+    // Inside a tile the entries are ordered by (layer, column, row): layer = rank of the entry inside its (row, panel) segment in
+    // ascending column order.  A layer holds every row at most once, so 64 consecutive entries of a layer are 64 DIFFERENT
+    // rows -- the kernel adds them to the row sums with plain LDS read-modify-writes, no cross-lane work -- and a row's entries
+    // are still added one by one in ascending column order (layer l before layer l + 1).  Bit 31 of an index marks the first entry
+    // of a layer >= 1 (where a 64-entry group has to be split in two passes).  Inside a layer the entries are sorted by COLUMN
+    // (round 4; rounds 2-3: by row): a wavefront's 64 gathers then fall into a 30-40 KB stretch of the panel instead of all over its
+    // 1 MiB -- tools/gather_locality_probe.cpp measures 243 against 179 G gathers/s for exactly this change on the bare pattern.
     std::vector<int64_t> breaks((size_t)T, 0);
     auto work = [&](int t) {
         std::vector<uint32_t> pos((size_t)P + 1);
-        std::vector<std::vector<uint32_t>> lay((size_t)P);       // per panel: rows holding more than l entries, then layer starts
+        std::vector<std::vector<uint32_t>> lay((size_t)P), lay0;  // per panel: rows holding more than l entries, then layer starts
+        std::vector<std::pair<uint32_t, double>> tmp;
         int64_t mseg = 0, nbreaks = 0;
         for (int64_t s = S * t / T; s < S * (t + 1) / T; ++s) {
             const int64_t r0 = srow[(size_t)s], r1 = srow[(size_t)s + 1], k0 = rowptr[r0];
@@ -137,6 +142,7 @@ int build_tiles(sla_csr *A, int64_t n, int64_t rows, const int64_t *rowptr, cons
                 for (size_t q = 0; q < L.size(); ++q) { const uint32_t c = L[q]; L[q] = run; run += c; }
                 if (!L.empty()) nbreaks += (int64_t)L.size() - 1;
             }
+            lay0 = lay;                                           // (the fill below advances the slots: kept for the per-layer sort)
             for (int64_t i = r0; i < r1; ++i) {
                 int64_t k = rowptr[i];
                 const int64_t e = rowptr[i + 1];
@@ -148,6 +154,20 @@ int build_tiles(sla_csr *A, int64_t n, int64_t rows, const int64_t *rowptr, cons
                         tidx[o] = ((uint32_t)(i - r0) << shift) | ((uint32_t)col[k] & cmask);
                         tval[o] = val[k];
                     }
+                }
+            }
+            for (int64_t j = 0; j < P; ++j) {                     // every layer of every tile: by (column, row); first entry of a layer >= 1 flagged
+                const std::vector<uint32_t> &L0 = lay0[(size_t)j], &L1 = lay[(size_t)j];
+                for (size_t q = 0; q < L0.size(); ++q) {
+                    const size_t b = (size_t)(k0 + pos[(size_t)j] + L0[q]), e = (size_t)(k0 + pos[(size_t)j] + L1[q]);
+                    tmp.resize(e - b);
+                    for (size_t o = b; o < e; ++o) tmp[o - b] = {tidx[o], tval[o]};
+                    std::sort(tmp.begin(), tmp.end(), [&](const std::pair<uint32_t, double> &x, const std::pair<uint32_t, double> &y) {
+                        const uint32_t cx = x.first & cmask, cy = y.first & cmask;
+                        return cx != cy ? cx < cy : x.first < y.first;      // (equal columns: ascending rows, like the stable device sort)
+                    });
+                    for (size_t o = b; o < e; ++o) { tidx[o] = tmp[o - b].first; tval[o] = tmp[o - b].second; }
+                    if (q > 0 && e > b) tidx[b] |= 0x80000000u;
                 }
             }
         }

@@ -12,10 +12,12 @@
 //   * the slice's entries are stored tile-major -- ordered by (panel, row, column), 12 B each: the value and one dword
 //     (row - slice_row0) << 18 | (col - panel * 2^18) -- so a wavefront streams them with coalesced non-temporal loads,
 //     gathers x from the panel all wavefronts of the XCD are on at that moment, and adds the products into LDS;
-//   * inside a tile the entries are ordered by (layer, row), layer = rank of the entry inside its (row, panel) segment in
+//   * inside a tile the entries are ordered by (layer, column), layer = rank of the entry inside its (row, panel) segment in
 //     ascending column order: 64 consecutive entries of one layer are 64 different rows, so a group of 64 products goes
 //     into the row sums with ONE conflict-free LDS read-modify-write (y_r = y_r + a_rc x_c, separately rounded) and no
-//     cross-lane work; a group that spans a layer boundary (rows not ascending) is split there and done in as many passes.
+//     cross-lane work; a group that spans a layer boundary (bit 31 of the index dword) is split there and done in as many passes.
+//     Column order inside a layer (round 4) keeps a wavefront's 64 gathers inside a 30-40 KB stretch of the panel: fewer pages
+//     and L2 channels per instruction (tools/gather_locality_probe.cpp: 179 -> 243 G gathers/s on the bare pattern);
 //     A row's products are therefore added ONE BY ONE in ascending column order (panels ascending, layers ascending): every
 //     row is the reference's left fold bit for bit, whatever its length (an instruction-count matter too: the first
 //     version chained the runs of a (row, column)-sorted tile through DPP shifts -- ~300 instructions per 64 entries,
@@ -65,12 +67,12 @@ __device__ __forceinline__ void tile_fold_chunk(double *yl, const TileChunk &c, 
     for (int u = 0; u < kTileU; ++u) {
         const int cg = c.cnt - 64 * u;                 // valid lanes of this group (wavefront-uniform)
         if (cg <= 0) break;
-        const uint32_t rl = c.idx[u] >> shift;
+        const uint32_t rl = (c.idx[u] & 0x7fffffffu) >> shift;
         const double p = c.val[u] * c.xv[u];
         const bool act = lane < cg;
-        // layer boundaries: rows inside a layer ascend strictly; lane 0 always starts a pass
-        const uint32_t rprev = (uint32_t)wave_shr1((int)rl, -1);
-        unsigned long long B = __ballot(act && lane > 0 && rl <= rprev);
+        // layer boundaries: bit 31 marks the first entry of a layer >= 1 of the tile (inside a layer every row occurs once, in column
+        // order since round 4); lane 0 always starts a pass
+        unsigned long long B = __ballot(act && lane > 0 && (c.idx[u] >> 31) != 0);
         if (B == 0) {                                  // one layer: 64 different rows
             if (act) yl[rl] = yl[rl] + p;
         } else {

@@ -2,9 +2,10 @@
 // 1.2 s of host re-ordering and 4 GB of PCIe for the second, tile-major copy of the entries -- 390 BiCGSTAB steps at the
 // steady-state rate, while linSolve0 runs <= 200).  The canonical CSR arrays are on the device already; the tile order is a sort:
 //
-//   entry k of row i (slice s, panel j = col >> shift, layer l = its rank inside the (row, panel) segment)  ->  key (s, j, l)
-//   STABLE radix sort of (key, k) (rocPRIM): entries of one (slice, panel, layer) keep their input order = ascending rows
-//   tlidx / tlval gathered through the sorted positions, tloff by binary search for every (slice, panel) boundary.
+//   entry k of row i (slice s, panel j = col >> shift, layer l = its rank inside the (row, panel) segment, c = col inside the panel)
+//   ->  key (s, j, l, c);  STABLE radix sort of (key, k) (rocPRIM): the entries of one (slice, panel, layer) in ascending COLUMN order
+//   (equal columns: input order = ascending rows);  tlidx / tlval gathered through the sorted positions, bit 31 of tlidx marks the
+//   first entry of every layer >= 1 of a tile;  tloff by binary search for every (slice, panel) boundary.
 //
 // Bit-identical to the host builder (tests/test_gpu_tiles.py runs both: option tiles_device).  Reference semantics of the form: the
 // row's left fold over ascending columns, Data/Sparse/Common.hs:247-260 (kernel: sla_spmv_tiles.hip).
@@ -46,12 +47,13 @@ __global__ void __launch_bounds__(256) tile_maxseg_kernel(int64_t rows, const RP
     if ((threadIdx.x & 63) == 0 && mx) atomicMax(maxseg, mx);
 }
 
-// key = slice << (pbits + lbits) | panel << lbits | layer ; value = the entry's position in the canonical arrays
+// key = ((slice << pbits | panel) << lbits | layer) << shift | column inside the panel ; value = the entry's position in the canonical arrays
 template <typename RP>
 __global__ void __launch_bounds__(256) tile_keys_kernel(int S, const int32_t *__restrict__ srow, const RP *__restrict__ rowptr,
                                                          const int32_t *__restrict__ col, int shift, int lbits, int pbits, uint64_t *key, uint32_t *idx) {
     for (int s = blockIdx.x; s < S; s += gridDim.x) {
-        const uint64_t hi = (uint64_t)s << (pbits + lbits);
+        const uint64_t hi = (uint64_t)s << (pbits + lbits + shift);
+        const uint32_t cmask = (1u << shift) - 1u;
         for (int i = srow[s] + (int)threadIdx.x; i < srow[s + 1]; i += 256) {
             int prev = -1;
             unsigned layer = 0;
@@ -59,7 +61,7 @@ __global__ void __launch_bounds__(256) tile_keys_kernel(int S, const int32_t *__
                 const int j = col[k] >> shift;
                 layer = j == prev ? layer + 1 : 0;
                 prev = j;
-                key[k] = hi | ((uint64_t)j << lbits) | layer;
+                key[k] = hi | ((uint64_t)j << (lbits + shift)) | ((uint64_t)layer << shift) | ((uint32_t)col[k] & cmask);
                 idx[k] = (uint32_t)k;
             }
         }
@@ -77,14 +79,16 @@ __global__ void __launch_bounds__(256) tile_emit_kernel(int64_t nnz, const uint6
     for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < nnz; o += (int64_t)gridDim.x * 256) {
         const uint64_t kk = key[o];
         const uint32_t k = idx[o];
-        const int s = (int)(kk >> (pbits + lbits));
+        const int s = (int)(kk >> (pbits + lbits + shift));
         const int r = row_of_entry[k] - srow[s];
-        tidx[o] = ((uint32_t)r << shift) | ((uint32_t)col[k] & cmask);
-        tval[o] = val[k];
+        uint32_t first = 0;                                          // first entry of a layer >= 1: same (slice, panel) as its predecessor, another layer
         if (o > 0) {
             const uint64_t kp = key[o - 1];
-            brk += (kp >> lbits) == (kk >> lbits) && kp != kk;       // same (slice, panel), another layer
+            first = (kp >> (lbits + shift)) == (kk >> (lbits + shift)) && (kp >> shift) != (kk >> shift);
         }
+        tidx[o] = (first << 31) | ((uint32_t)r << shift) | ((uint32_t)col[k] & cmask);
+        tval[o] = val[k];
+        brk += first;
     }
     for (int off = 32; off > 0; off >>= 1) brk += (unsigned)__shfl_xor((int)brk, off, 64);
     if ((threadIdx.x & 63) == 0 && brk) atomicAdd(nbreaks, (unsigned long long)brk);
@@ -100,11 +104,11 @@ __global__ void __launch_bounds__(256) tile_rows_kernel(int64_t rows, const RP *
 // tloff[s * (P + 1) + j] = first sorted position with (slice, panel) >= (s, j), relative to the slice's first entry
 template <typename RP>
 __global__ void __launch_bounds__(256) tile_offsets_kernel(int S, int P, int64_t nnz, const uint64_t *__restrict__ key, const int32_t *__restrict__ srow,
-                                                            const RP *__restrict__ rowptr, int lbits, int pbits, uint32_t *toff) {
+                                                            const RP *__restrict__ rowptr, int shift, int lbits, int pbits, uint32_t *toff) {
     const int64_t total = (int64_t)S * (P + 1);
     for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
         const int s = (int)(t / (P + 1)), j = (int)(t - (int64_t)s * (P + 1));
-        const uint64_t want = ((uint64_t)s << (pbits + lbits)) | ((uint64_t)j << lbits);
+        const uint64_t want = ((uint64_t)s << (pbits + lbits + shift)) | ((uint64_t)j << (lbits + shift));
         int64_t lo = (int64_t)rowptr[srow[s]], hi = (int64_t)rowptr[srow[s + 1]];   // the slice owns the same entry range in both orders
         const int64_t base = lo;
         while (lo < hi) {
@@ -149,7 +153,7 @@ int build_tiles_device(sla_csr *A, const std::vector<int32_t> &srow, int shift, 
     SLA_HIP_TRY(hipStreamSynchronize(st));
     const int64_t maxseg = (int64_t)(unsigned)h_stat[0];
     const int lbits = bits_for((uint64_t)std::max<int64_t>(maxseg, 1)), pbits = bits_for((uint64_t)P), sbits = bits_for((uint64_t)S);
-    if (lbits + pbits + sbits > 62) return SLA_OK;
+    if (lbits + pbits + sbits + shift > 62) return SLA_OK;
     // scratch: keys / positions twice (radix sort ping-pong), the row of every entry, rocPRIM's own
     e = d_key.alloc(8 * (size_t)nnz);
     if (e == hipSuccess) e = d_key2.alloc(8 * (size_t)nnz);
@@ -159,7 +163,7 @@ int build_tiles_device(sla_csr *A, const std::vector<int32_t> &srow, int shift, 
     size_t tmp_bytes = 0;
     if (e == hipSuccess)
         e = rocprim::radix_sort_pairs(nullptr, tmp_bytes, d_key.as<uint64_t>(), d_key2.as<uint64_t>(), d_idx.as<uint32_t>(), d_idx2.as<uint32_t>(),
-                                      (size_t)nnz, 0, (unsigned)(lbits + pbits + sbits), st);
+                                      (size_t)nnz, 0, (unsigned)(lbits + pbits + sbits + shift), st);
     if (e == hipSuccess) e = d_tmp.alloc(tmp_bytes);
     if (e == hipSuccess && !A->d_tlidx) e = dev_malloc(c, (void **)&A->d_tlidx, sizeof(uint32_t) * (size_t)nnz + 64);
     if (e == hipSuccess && !A->d_tlval) e = dev_malloc(c, (void **)&A->d_tlval, sizeof(double) * (size_t)nnz + 64);
@@ -186,14 +190,14 @@ int build_tiles_device(sla_csr *A, const std::vector<int32_t> &srow, int shift, 
     }
     if (!launch_ok()) return give_up();
     e = rocprim::radix_sort_pairs(d_tmp.p, tmp_bytes, d_key.as<uint64_t>(), d_key2.as<uint64_t>(), d_idx.as<uint32_t>(), d_idx2.as<uint32_t>(), (size_t)nnz, 0,
-                                  (unsigned)(lbits + pbits + sbits), st);
+                                  (unsigned)(lbits + pbits + sbits + shift), st);
     if (e != hipSuccess) return give_up();
     if (A->rp64) {
         hipLaunchKernelGGL((tile_emit_kernel<int64_t>), dim3(grid), dim3(256), 0, st, nnz, d_key2.as<uint64_t>(), d_idx2.as<uint32_t>(), d_srow.as<int32_t>(), (const int64_t *)A->d_rowptr, A->d_col, A->d_val, d_rows.as<int32_t>(), shift, lbits, pbits, A->d_tlidx, A->d_tlval, d_stat.as<unsigned long long>() + 1);
-        hipLaunchKernelGGL((tile_offsets_kernel<int64_t>), dim3(grid), dim3(256), 0, st, (int)S, (int)P, nnz, d_key2.as<uint64_t>(), d_srow.as<int32_t>(), (const int64_t *)A->d_rowptr, lbits, pbits, A->d_tloff);
+        hipLaunchKernelGGL((tile_offsets_kernel<int64_t>), dim3(grid), dim3(256), 0, st, (int)S, (int)P, nnz, d_key2.as<uint64_t>(), d_srow.as<int32_t>(), (const int64_t *)A->d_rowptr, shift, lbits, pbits, A->d_tloff);
     } else {
         hipLaunchKernelGGL((tile_emit_kernel<int32_t>), dim3(grid), dim3(256), 0, st, nnz, d_key2.as<uint64_t>(), d_idx2.as<uint32_t>(), d_srow.as<int32_t>(), (const int32_t *)A->d_rowptr, A->d_col, A->d_val, d_rows.as<int32_t>(), shift, lbits, pbits, A->d_tlidx, A->d_tlval, d_stat.as<unsigned long long>() + 1);
-        hipLaunchKernelGGL((tile_offsets_kernel<int32_t>), dim3(grid), dim3(256), 0, st, (int)S, (int)P, nnz, d_key2.as<uint64_t>(), d_srow.as<int32_t>(), (const int32_t *)A->d_rowptr, lbits, pbits, A->d_tloff);
+        hipLaunchKernelGGL((tile_offsets_kernel<int32_t>), dim3(grid), dim3(256), 0, st, (int)S, (int)P, nnz, d_key2.as<uint64_t>(), d_srow.as<int32_t>(), (const int32_t *)A->d_rowptr, shift, lbits, pbits, A->d_tloff);
     }
 #undef SLA_RP_LAUNCH
     if (!launch_ok()) return give_up();
