@@ -437,3 +437,31 @@ def test_canonical_arrays_written_on_the_device_are_the_callers(sla, mode):
         sla._lib.check(sla._lib.lib().sla_spmv(A.h, xd.h, y.h))
         assert "stream" in A.kernel_info(), A.kernel_info()
         assert np.array_equal(y.to_host(), orc.spmv(orc.Csr(dims[0], dims[1], rp, ci, va), x))
+
+
+@pytest.mark.parametrize("lanes,xfer", [(1, 1), (3, 1), (8, 1), (4, 0)])
+def test_large_copies_through_the_pinned_lanes_are_exact(sla, lanes, xfer):
+    """Copies of >= 24 MiB between the caller's pageable arrays and the device are staged by the library itself (csrc/sla_xfer.cpp:
+    8 MiB chunks dealt round-robin to `xfer_lanes` host threads with two pinned slots each).  Sizes that are no multiple of a chunk,
+    of the lane count or of anything else must arrive bit for bit, up and down, for vectors and for a matrix's arrays (export),
+    whatever the lane count -- and with the staging switched off."""
+    ctx = sla.Context(0).set_options(xfer=xfer, xfer_lanes=lanes)
+    rng = np.random.default_rng(lanes * 10 + xfer)
+    for n in (3 * (1 << 20) + 1, 9 * (1 << 20) + 12345):           # 24 MiB + 8 B; 72.09 MiB
+        x = rng.standard_normal(n)
+        v = sla.DeviceVector(ctx, n, x)
+        assert np.array_equal(v.to_host().view(np.uint64), x.view(np.uint64)), (n, lanes, xfer)
+        del v
+    # a matrix that is NOT value-indexed (its canonical arrays do cross PCIe): 4 M rows x 3 random entries, values at random
+    n = 4_000_000
+    cols = np.sort(rng.integers(0, n, (n, 3)), axis=1)
+    cols[:, 1] += (cols[:, 1] == cols[:, 0])
+    cols[:, 2] = np.maximum(cols[:, 2], cols[:, 1] + 1)
+    keep = cols[:, 2] < n
+    cols[~keep] = np.array([0, 1, 2])
+    rp = np.arange(0, 3 * n + 1, 3, dtype=np.int64)
+    ci = cols.astype(np.int64).ravel()
+    va = rng.standard_normal(3 * n)
+    A = sla.fromCSR((n, n), rp, ci, va, ctx)
+    rp2, ci2, va2 = A.csr()
+    assert np.array_equal(rp2, rp) and np.array_equal(ci2, ci) and np.array_equal(va2.view(np.uint64), va.view(np.uint64))

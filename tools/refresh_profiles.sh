@@ -37,8 +37,14 @@ for f in sorted(glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(f)):
         agg[r["Kernel_Name"][:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    # (a kernel name can cover launches of different sizes -- e.g. spmv_tile_kernel<1> on a second, smaller matrix of the same run: the
+    # figure per launch is the mean over the launches within 10 % of the largest, i.e. the full-size ones; n = how many those were)
     for k, cs in agg.items():
-        print(k, {c: (len(v), sum(v) / len(v)) for c, v in cs.items()})
+        out = {}
+        for c, v in cs.items():
+            big = [x for x in v if x >= 0.9 * max(v)] if max(v) > 0 else v
+            out[c] = (len(big), sum(big) / len(big))
+        print(k, out)
 PY
   done; }
 pmc $S/${tag}_bench_pmc_counters.txt python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extra-blocks
