@@ -56,9 +56,6 @@ struct TileChunk {
     int panel;
 };
 
-// lane i <- lane i - 1 across the whole wavefront (DPP wave_shr:1); lane 0 <- lane0val
-__device__ __forceinline__ int wave_shr1(int v, int lane0val) { return __builtin_amdgcn_update_dpp(lane0val, v, 0x138, 0xf, 0xf, false); }
-
 // Add one chunk (kTileU groups of 64 consecutive entries of one tile; the chunk's entries [0, cnt) are valid, the lanes past
 // them hold copies of the last entry) into the slice's row sums yl[].
 __device__ __forceinline__ void tile_fold_chunk(double *yl, const TileChunk &c, int shift, int lane) {
