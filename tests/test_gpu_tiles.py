@@ -6,7 +6,7 @@ rectangular shapes, 64-bit row pointers, (row, panel) segments of several entrie
 group: multi-pass groups), rows with hundreds of entries per panel (the lowering must step aside) and every fused
 epilogue through the solvers.
 
-Parity: inside a tile the entries are ordered by (layer, row) and every product is added to its row sum on its own, in
+Parity: inside a tile the entries are ordered by (layer, column; round 4 -- by row before) and every product is added to its row sum on its own, in
 ascending column order, with separately rounded multiply and add -- BIT-EXACT with the reference's left fold
 (Common.hs:247-260) whatever the row length.  Matrices the lowering leaves to the older forms are checked against
 |dy_i| <= nnz_i * eps * sum_j |a_ij x_j|."""
@@ -82,6 +82,13 @@ def test_tiles_match_the_oracle(sla, name):
             assert np.all(np.abs(y - want) <= bound), (name, rp64, float(np.abs(y - want).max()))
         y2 = sla.matVec(A, sla.fromVector(x, ctx)).toDenseListSV()
         assert np.array_equal(y, y2)                             # deterministic
+        if expect_tiles and rp64 == "0" and dev == 2:
+            # the kernel's pacing / prefetch variants (round 4: look-ahead poll by LDS-DMA, x-panel prefetch -- off by default, measured
+            # slower -- and no pacing at all) only change WHEN a tile is walked, never what is added to a row sum
+            for opts in ({"tile_poll": 0}, {"tile_prefetch": 1}, {"tile_prefetch": 3, "tile_slack": 1}, {"tile_slack": 0}):
+                ctx.set_options(**opts)
+                assert np.array_equal(sla.matVec(A, sla.fromVector(x, ctx)).toDenseListSV(), want), (name, opts)
+            ctx.set_options(tile_poll=1, tile_prefetch=0, tile_slack=3)
     # the same matrix on the forms the tile form replaces
     ctx = sla.Context(0).set_options(tile_shift=10, lpanel=0, lflat=0, tiles=0)
     A = sla.fromCSR(dims, rp, ci, va, ctx)
