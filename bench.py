@@ -509,7 +509,7 @@ def run_rank(args, rank, world, local_rank, dist_mode, loop=None):
         graph = (dist_mode is None and args.method == "bicgstab" or dist_mode is None and args.method == "cgs") and n_local <= 2500000 \
             and os.environ.get("SLA_STEP_GRAPH", "-1") != "0"
         extra["step_graph"] = bool(graph)
-        dt, dom_stats, dom_id = timed_steps(ctx, st, args.steps, args.warmup, sync_all, event_free=graph)
+        dt, dom_stats, dom_id = timed_steps(ctx, st, args.steps, args.warmup, sync_all, event_free=graph or os.environ.get("SLA_BENCH_EVENT_FREE") == "1")
         kt = kernel_table(ctx, A, nnz_local, n_local, args.method)
         if dist_mode:
             extra["exchanges"] = exchange_table(ctx)
