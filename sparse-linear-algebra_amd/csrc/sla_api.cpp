@@ -84,16 +84,27 @@ void info_commit(sla_solve_info *user, const sla_solve_info &local) {
     user->struct_size = sz;
 }
 
-ProfScope::ProfScope(sla_ctx *ctx, int kernel_id) : c(ctx), on(false) {
+ProfScope::ProfScope(sla_ctx *ctx, int kernel_id, bool ext) : c(ctx), on(false) {
     if (kernel_id >= 0 && (c->prof_kernel == kernel_id || c->prof_kernel == SLA_KERNEL_ALL) && c->prof_count < c->prof_max) {
         on = true;
         c->prof_ids[(size_t)c->prof_count] = kernel_id;
-        (void)hipEventRecord(c->prof_ev[2 * (size_t)c->prof_count], stream_of(c));
+        if (ext) {
+            deferred = true;
+            c->prof_pending = c->prof_count;
+        } else {
+            (void)hipEventRecord(c->prof_ev[2 * (size_t)c->prof_count], stream_of(c));
+        }
     }
 }
 ProfScope::~ProfScope() {
     if (on) {
-        (void)hipEventRecord(c->prof_ev[2 * (size_t)c->prof_count + 1], stream_of(c));
+        if (deferred && c->prof_pending == c->prof_count) {   // no launch took the pair (an error path): an empty interval
+            c->prof_pending = -1;
+            (void)hipEventRecord(c->prof_ev[2 * (size_t)c->prof_count], stream_of(c));
+            (void)hipEventRecord(c->prof_ev[2 * (size_t)c->prof_count + 1], stream_of(c));
+        } else if (!deferred) {
+            (void)hipEventRecord(c->prof_ev[2 * (size_t)c->prof_count + 1], stream_of(c));
+        }
         c->prof_count++;
     }
 }

@@ -1,6 +1,7 @@
 // sla_internal.hpp -- shared declarations of libsla_hip.so (not part of the public C ABI).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <map>
 #include <memory>
@@ -297,6 +298,7 @@ struct sla_ctx {
     std::vector<float> prof_ms;           // durations of the last recording (filled by sla_prof_stop)
     std::vector<hipEvent_t> prof_ev;
     int prof_count = 0;
+    int prof_pending = -1;           // index of the event pair an `ext` ProfScope has handed to the next SLA_KLAUNCH (-1: none)
 };
 
 struct sla_vec {
@@ -585,9 +587,27 @@ void info_commit(sla_solve_info *user, const sla_solve_info &local);            
 struct ProfScope {
     sla_ctx *c;
     bool on;
-    ProfScope(sla_ctx *ctx, int kernel_id);
+    bool deferred = false;   // the launch site takes the events itself (SLA_KLAUNCH): nothing recorded here unless it did not
+    // ext: the scope holds exactly ONE kernel launch made through SLA_KLAUNCH.  The kernel then carries the two events itself
+    // (hipExtLaunchKernelGGL: its own start / stop stamps) instead of standing between two marker packets -- round 4: the markers
+    // around the SpMV of a 137 us Arnoldi step cost 3 us of it.
+    ProfScope(sla_ctx *ctx, int kernel_id, bool ext = false);
     ~ProfScope();
 };
+// the pending event pair of an `ext` ProfScope, taken (once) by the launch it was opened for
+inline bool prof_take(sla_ctx *c, hipEvent_t *e0, hipEvent_t *e1) {
+    if (c->prof_pending < 0) return false;
+    *e0 = c->prof_ev[2 * (size_t)c->prof_pending];
+    *e1 = c->prof_ev[2 * (size_t)c->prof_pending + 1];
+    c->prof_pending = -1;
+    return true;
+}
+#define SLA_KLAUNCH(c_, kernel, grid, block, shmem, stream, ...)                                                           \
+    do {                                                                                                                   \
+        hipEvent_t e0_ = nullptr, e1_ = nullptr;                                                                           \
+        if (prof_take((c_), &e0_, &e1_)) hipExtLaunchKernelGGL(kernel, grid, block, shmem, stream, e0_, e1_, 0, __VA_ARGS__); \
+        else hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);                                          \
+    } while (0)
 
 // host CSR builder (sla_csr_build.cpp) -------------------------------------------------------------
 // vector whose resize() leaves the new elements uninitialised (assign(n, v) and push_back still initialise): the host CSR arrays are

@@ -123,7 +123,20 @@ static int launch_spmv_rp(const sla_csr *A, const SpmvLaunch &l) {
     a.step_begin = l.step_begin;
     a.yinit = l.yinit;
     const int grid = spmv_grid(A);
-    ProfScope prof(c, l.kernel_id);
+    // (the forms whose launcher is ONE kernel launched through SLA_KLAUNCH carry the profiling events themselves: the gather kernel of the
+    // wave-sliced forms, the wavefront-private CSR kernel -- conditions as in the dispatch below)
+    bool prof_ext = false;
+    if constexpr (std::is_same<RP, int32_t>::value) {
+        const bool lp = A->use_lpanel && c->lpanel && c->spmv_algo == 0 && !l.x2 && !l.yinit;
+        const bool lf = lflat_on(A) && !l.x2 && !l.yinit;
+        const bool wd = A->use_wdia && wd_on(A) && c->spmv_algo == 0 && !l.x2;
+        if (!lp && !lf) {
+            if (wd) prof_ext = !(wd_march_on(A) && l.part == 0) && !wd_lds_on(A);
+            else if (!(A->use_vdict && c->vdict && c->spmv_algo == 0) && !l.x2 && !(c->spmv_algo != 1 && diag_on(A)) && !(c->spmv_algo != 1 && pipe_on(A)))
+                prof_ext = wave_plain(A) && !l.yinit;
+        }
+    }
+    ProfScope prof(c, l.kernel_id, prof_ext);
     if (A->use_lpanel && c->lpanel && c->spmv_algo == 0 && !l.x2 && !l.yinit) return launch_spmv_lpanel(A, l.epi, a, grid);
     if constexpr (std::is_same<RP, int32_t>::value) {
         if (lflat_on(A) && !l.x2 && !l.yinit) return launch_spmv_lflat(A, l.epi, a, grid);

@@ -217,7 +217,7 @@ static int launch_wave_t(const sla_csr *A, const SpmvArgs<int32_t> &a, int grid)
     const WvVariant v = wave_variant(A, EPI);
 #define SLA_WV(P, O, R)                                                                                                                    \
     if (v.ppl == P && v.occ == O && v.pre == R)                                                                                            \
-        hipLaunchKernelGGL((spmv_wave_kernel<EPI, P, O, R != 0>), dim3(grid), dim3(kBlock), 0, stream_of(c), a, a.rowptr, a.col, a.val, a.x, nblk, \
+        SLA_KLAUNCH(c, (spmv_wave_kernel<EPI, P, O, R != 0>), dim3(grid), dim3(kBlock), 0, stream_of(c), a, a.rowptr, a.col, a.val, a.x, nblk, \
                            c->xcd_remap, nt)
     SLA_WV(2, 8, 0);
     else SLA_WV(4, 6, 0);

@@ -323,11 +323,11 @@ int launch_wdia_t(const sla_csr *A, const SpmvArgs<int32_t> &a, const int32_t *s
     int active = grid;
     if (A->wd_vv && EPI == EPI_DOT4) active = std::min(grid, std::max(8, (kWdBlocksPerCuVV4 * c->n_cu) & ~7));
     if (A->wd_vv)
-        hipLaunchKernelGGL((spmv_wdia_kernel<EPI, true>), dim3(grid), dim3(kBlock), 0, stream_of(c), a, A->d_wptr, A->d_wme, A->d_wmo,
+        SLA_KLAUNCH(c, (spmv_wdia_kernel<EPI, true>), dim3(grid), dim3(kBlock), 0, stream_of(c), a, A->d_wptr, A->d_wme, A->d_wmo,
                            A->d_wval, A->d_woff, A->d_wvblk, a.x, nblk_wd, A->nslices, (int32_t)A->row_begin, (int32_t)A->n,
                            sched, c->xcd_remap, stream_nt, active);
     else
-        hipLaunchKernelGGL((spmv_wdia_kernel<EPI, false>), dim3(grid), dim3(kBlock), 0, stream_of(c), a, A->d_wptr, A->d_wme, A->d_wmo,
+        SLA_KLAUNCH(c, (spmv_wdia_kernel<EPI, false>), dim3(grid), dim3(kBlock), 0, stream_of(c), a, A->d_wptr, A->d_wme, A->d_wmo,
                            A->d_wval, A->d_woff, A->d_wvblk, a.x, nblk_wd, A->nslices, (int32_t)A->row_begin, (int32_t)A->n,
                            sched, c->xcd_remap, stream_nt, active);
     SLA_HIP_TRY(hipGetLastError());

@@ -269,40 +269,40 @@ __global__ void __launch_bounds__(kBlock) bicg_k5_kernel(int64_t n, SolverScalar
 
 int launch_bicg_k2(sla_ctx *c, int64_t n, SolverScalars *sc, Parts apr, int par, Parts res, int count_iter,
                    const double *r, const double *ap, double *s) {
-    ProfScope prof(c, SLA_KERNEL_BICG_K2);
+    ProfScope prof(c, SLA_KERNEL_BICG_K2, true);
     if (vec_stream_nt(c, n))
-        hipLaunchKernelGGL(bicg_k2_kernel<true>, dim3(vec_grid(n)), dim3(kBlock), 0, stream_of(c), n, sc, apr, par, res, count_iter, r, ap, s, c->vec_policy);
+        SLA_KLAUNCH(c, bicg_k2_kernel<true>, dim3(vec_grid(n)), dim3(kBlock), 0, stream_of(c), n, sc, apr, par, res, count_iter, r, ap, s, c->vec_policy);
     else
-        hipLaunchKernelGGL(bicg_k2_kernel<false>, dim3(vec_grid(n)), dim3(kBlock), 0, stream_of(c), n, sc, apr, par, res, count_iter, r, ap, s, 0);
+        SLA_KLAUNCH(c, bicg_k2_kernel<false>, dim3(vec_grid(n)), dim3(kBlock), 0, stream_of(c), n, sc, apr, par, res, count_iter, r, ap, s, 0);
     SLA_HIP_TRY(hipGetLastError());
     return SLA_OK;
 }
 int launch_bicg_k4(sla_ctx *c, int64_t n, SolverScalars *sc, Parts ass, Parts asas, const double *p, const double *s,
                    const double *as, const double *r0hat, double *x, double *r, double *prho) {
-    ProfScope prof(c, SLA_KERNEL_BICG_K4);
+    ProfScope prof(c, SLA_KERNEL_BICG_K4, true);
     if (vec_stream_nt(c, n))
-        hipLaunchKernelGGL(bicg_k4_kernel<true>, dim3(vec_grid(n)), dim3(kBlock), 0, stream_of(c), n, sc, ass, asas, p, s, as, r0hat, x, r, prho);
+        SLA_KLAUNCH(c, bicg_k4_kernel<true>, dim3(vec_grid(n)), dim3(kBlock), 0, stream_of(c), n, sc, ass, asas, p, s, as, r0hat, x, r, prho);
     else
-        hipLaunchKernelGGL(bicg_k4_kernel<false>, dim3(vec_grid(n)), dim3(kBlock), 0, stream_of(c), n, sc, ass, asas, p, s, as, r0hat, x, r, prho);
+        SLA_KLAUNCH(c, bicg_k4_kernel<false>, dim3(vec_grid(n)), dim3(kBlock), 0, stream_of(c), n, sc, ass, asas, p, s, as, r0hat, x, r, prho);
     SLA_HIP_TRY(hipGetLastError());
     return SLA_OK;
 }
 int launch_bicg_k5(sla_ctx *c, int64_t n, SolverScalars *sc, Parts rhonew, int par, const double *r, const double *ap, double *p) {
-    ProfScope prof(c, SLA_KERNEL_BICG_K5);
+    ProfScope prof(c, SLA_KERNEL_BICG_K5, true);
     if (vec_stream_nt(c, n))
-        hipLaunchKernelGGL(bicg_k5_kernel<true>, dim3(vec_grid(n)), dim3(kBlock), 0, stream_of(c), n, sc, rhonew, par, r, ap, p);
+        SLA_KLAUNCH(c, bicg_k5_kernel<true>, dim3(vec_grid(n)), dim3(kBlock), 0, stream_of(c), n, sc, rhonew, par, r, ap, p);
     else
-        hipLaunchKernelGGL(bicg_k5_kernel<false>, dim3(vec_grid(n)), dim3(kBlock), 0, stream_of(c), n, sc, rhonew, par, r, ap, p);
+        SLA_KLAUNCH(c, bicg_k5_kernel<false>, dim3(vec_grid(n)), dim3(kBlock), 0, stream_of(c), n, sc, rhonew, par, r, ap, p);
     SLA_HIP_TRY(hipGetLastError());
     return SLA_OK;
 }
 int launch_bicg_k45(sla_ctx *c, int64_t n, SolverScalars *sc, Parts ass, Parts asas, Parts tr0, Parts sr0, int par, const double *s,
                     const double *as, const double *ap, double *x, double *r, double *p) {
-    ProfScope prof(c, SLA_KERNEL_BICG_K45);
+    ProfScope prof(c, SLA_KERNEL_BICG_K45, true);
     if (vec_stream_nt(c, n))
-        hipLaunchKernelGGL(bicg_k45_kernel<true>, dim3(vec_grid(n)), dim3(kBlock), 0, stream_of(c), n, sc, ass, asas, tr0, sr0, par, s, as, ap, x, r, p, c->vec_policy);
+        SLA_KLAUNCH(c, bicg_k45_kernel<true>, dim3(vec_grid(n)), dim3(kBlock), 0, stream_of(c), n, sc, ass, asas, tr0, sr0, par, s, as, ap, x, r, p, c->vec_policy);
     else
-        hipLaunchKernelGGL(bicg_k45_kernel<false>, dim3(vec_grid(n)), dim3(kBlock), 0, stream_of(c), n, sc, ass, asas, tr0, sr0, par, s, as, ap, x, r, p, 0);
+        SLA_KLAUNCH(c, bicg_k45_kernel<false>, dim3(vec_grid(n)), dim3(kBlock), 0, stream_of(c), n, sc, ass, asas, tr0, sr0, par, s, as, ap, x, r, p, 0);
     SLA_HIP_TRY(hipGetLastError());
     return SLA_OK;
 }
@@ -385,21 +385,21 @@ __global__ void __launch_bounds__(kBlock) cgs_c4_kernel(int64_t n, SolverScalars
 
 int launch_cgs_c2(sla_ctx *c, int64_t n, SolverScalars *sc, Parts apr, int par, Parts res, int count_iter,
                   const double *u, const double *aap, double *q, double *uq, double *x) {
-    ProfScope prof(c, SLA_KERNEL_CGS_C2);
+    ProfScope prof(c, SLA_KERNEL_CGS_C2, true);
     if (vec_stream_nt(c, n))
-        hipLaunchKernelGGL(cgs_c2_kernel<true>, dim3(vec_grid(n)), dim3(kBlock), 0, stream_of(c), n, sc, apr, par, res, count_iter, u, aap, q, uq, x, c->vec_policy);
+        SLA_KLAUNCH(c, cgs_c2_kernel<true>, dim3(vec_grid(n)), dim3(kBlock), 0, stream_of(c), n, sc, apr, par, res, count_iter, u, aap, q, uq, x, c->vec_policy);
     else
-        hipLaunchKernelGGL(cgs_c2_kernel<false>, dim3(vec_grid(n)), dim3(kBlock), 0, stream_of(c), n, sc, apr, par, res, count_iter, u, aap, q, uq, x, 0);
+        SLA_KLAUNCH(c, cgs_c2_kernel<false>, dim3(vec_grid(n)), dim3(kBlock), 0, stream_of(c), n, sc, apr, par, res, count_iter, u, aap, q, uq, x, 0);
     SLA_HIP_TRY(hipGetLastError());
     return SLA_OK;
 }
 int launch_cgs_c4(sla_ctx *c, int64_t n, SolverScalars *sc, Parts rhonew, int par, const double *r, const double *q,
                   double *u, double *p) {
-    ProfScope prof(c, SLA_KERNEL_CGS_C4);
+    ProfScope prof(c, SLA_KERNEL_CGS_C4, true);
     if (vec_stream_nt(c, n))
-        hipLaunchKernelGGL(cgs_c4_kernel<true>, dim3(vec_grid(n)), dim3(kBlock), 0, stream_of(c), n, sc, rhonew, par, r, q, u, p, c->vec_policy);
+        SLA_KLAUNCH(c, cgs_c4_kernel<true>, dim3(vec_grid(n)), dim3(kBlock), 0, stream_of(c), n, sc, rhonew, par, r, q, u, p, c->vec_policy);
     else
-        hipLaunchKernelGGL(cgs_c4_kernel<false>, dim3(vec_grid(n)), dim3(kBlock), 0, stream_of(c), n, sc, rhonew, par, r, q, u, p, 0);
+        SLA_KLAUNCH(c, cgs_c4_kernel<false>, dim3(vec_grid(n)), dim3(kBlock), 0, stream_of(c), n, sc, rhonew, par, r, q, u, p, 0);
     SLA_HIP_TRY(hipGetLastError());
     return SLA_OK;
 }
