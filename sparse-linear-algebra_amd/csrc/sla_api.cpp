@@ -488,6 +488,7 @@ const IntKnob kIntKnobs[] = {
     {"tile_slack", &sla_ctx::tile_slack, 0, 64},
     {"tile_prefetch", &sla_ctx::tile_prefetch, 0, 16},
     {"canon_device", &sla_ctx::canon_device, 0, 2},
+    {"canon_lazy", &sla_ctx::canon_lazy, 0, 1},
     {"xfer", &sla_ctx::xfer, 0, 1},
     {"xfer_lanes", &sla_ctx::xfer_lanes, 1, 8},
     {"tile_poll", &sla_ctx::tile_poll, 0, 1},
@@ -898,6 +899,7 @@ int sla_csr_export(sla_csr_t A, int64_t *rowptr, int64_t *colidx, double *val) {
         if (!A) return fail(SLA_ERR_INVALID, "null matrix");
         sla_ctx *c = A->ctx;
         Bind bind(c);
+        if ((colidx || val) && A->nnz) SLA_TRY(csr_ensure_canon(A));
         SLA_HIP_TRY(hipStreamSynchronize(stream_of(c)));
         if (rowptr) {
             if (A->rp64) {

@@ -241,6 +241,8 @@ struct sla_ctx {
     std::future<void> deferred_free; // host buffers of the last lowering being released off the caller's thread (sla_lower.cpp)
     int xfer = 1;                    // copies >= 24 MiB from / to pageable host memory: own pinned staging on xfer_lanes threads (0: plain hipMemcpy)
     int xfer_lanes = 4;
+    int canon_lazy = 1;              // ... and only when something asks for them (export, transpose, a CSR kernel after the form was peeled off): 843 MB and 12-23 ms of
+                                     // first-touch allocation less at 216^3
     int canon_device = 1;            // value-indexed matrices: canonical col / val written on the device from the 1-byte codes instead of uploaded
     int tile_prefetch = 0;           // x-panel prefetch distance of spmv_tile_kernel in visit steps (0: demand misses only; measured: never a gain)
     int tile_poll = 1;               // 1: pacing slots polled one step ahead, 0: dependent poll in front of every tile (rounds 2-3)
@@ -347,6 +349,7 @@ struct sla_csr {
     uint8_t *d_vcode = nullptr;      // value-indexed form: code[k] indexes the (offset, value) pair table (padded to dwords)
     int32_t *d_vdoff = nullptr;      // 256 pair offsets (col - row), sorted by (offset, value bits)
     double *d_vdval = nullptr;       // 256 pair values
+    bool canon_lazy = false;         // value-indexed matrix whose canonical col / val arrays have not been materialised (csr_ensure_canon writes them from the codes)
     bool use_vdict = false;          // <= 256 distinct (col - row, value) pairs, rows <= kVdMaxRowNnz: spmv_vdict_kernel streams 1 B per entry
     int npairs = 0;
     int32_t nblk_vd = 0;             // ceil(rows / kVdRows)
@@ -501,6 +504,13 @@ inline bool diag_xwin_on(const sla_csr *A) { return A->use_xwin && A->ctx->xwin 
 // dictionary codes 4380 it/s, plain CSR 5190-5330; 5-7 per row: dictionary codes +0..10 %); diag = 2 takes it at any row length.
 inline bool diag_on(const sla_csr *A) { return A->use_diag && (A->ctx->diag == 2 || (A->ctx->diag == 1 && A->nnz <= 12 * A->rows)); }
 inline bool wd_on(const sla_csr *A) { return A->wd_vv ? (A->ctx->wdia && A->ctx->wdia_vv) : A->ctx->wdia != 0; }
+// a (#>) of this matrix runs one of the value-indexed kernels, which never touch col / val (the dispatch of launch_spmv_t, sla_spmv.hip)
+inline bool spmv_value_indexed(const sla_csr *A, bool dual) {
+    const sla_ctx *c = A->ctx;
+    if (A->rp64 || c->spmv_algo != 0) return false;
+    return (A->use_wdia && wd_on(A) && !dual) || (A->use_vdict && c->vdict);
+}
+int csr_ensure_canon(sla_csr *A);   // sla_lower.cpp: materialise col / val of a canon_lazy matrix (allocation + one kernel); no-op otherwise
 
 // ---------------------------------------------------------------------------------------------------------------
 // Device binding.  HIP's current device is a per-THREAD setting and a new thread starts on device 0, so every C-ABI entry

@@ -211,9 +211,10 @@ static void low_csr_arrays(Low &L, CanonUpload *cu) {
     };
     std::thread val_up([&] {
         Bind bind(c);   // (a new thread starts on device 0)
+        await_decision();   // (a value-indexed matrix does not even get the arrays allocated here: csr_ensure_canon, if ever)
+        if (stopped()) return;
         if (err_val == hipSuccess) err_val = dev_malloc(c, (void **)&A->d_val, sizeof(double) * (size_t)nnz + kArraySlack);
         if (err_val == hipSuccess) err_val = hipMemset((char *)A->d_val + sizeof(double) * (size_t)nnz, 0, kArraySlack);
-        await_decision();
         size_t done_b = 0;
         if (err_val == hipSuccess && nnz && !stopped())
             err_val = xfer_copy(c, A->d_val, val, sizeof(double) * (size_t)nnz, hipMemcpyHostToDevice, cu ? &cu->stop : nullptr, &done_b);
@@ -239,10 +240,11 @@ static void low_csr_arrays(Low &L, CanonUpload *cu) {
         upload(&A->d_rowptr, rp32.data(), sizeof(int32_t) * rp32.size());
     }
     upload((void **)&A->d_rb, rb.data(), sizeof(int32_t) * rb.size());
-    if (err == hipSuccess) err = dev_malloc(c, (void **)&A->d_col, sizeof(int32_t) * (size_t)nnz + kArraySlack);
-    if (err == hipSuccess) err = hipMemset((char *)A->d_col + sizeof(int32_t) * (size_t)nnz, 0, kArraySlack);
-    {   // the caller's int64 column indices are narrowed on their way into the pinned slots (no 4 B-per-entry host copy, no pass of its own)
-        await_decision();
+    L.sub("[upload thread] row pointers + row blocks up");
+    await_decision();
+    if (!stopped()) {   // the caller's int64 column indices are narrowed on their way into the pinned slots (no 4 B-per-entry host copy, no pass of its own)
+        if (err == hipSuccess) err = dev_malloc(c, (void **)&A->d_col, sizeof(int32_t) * (size_t)nnz + kArraySlack);
+        if (err == hipSuccess) err = hipMemset((char *)A->d_col + sizeof(int32_t) * (size_t)nnz, 0, kArraySlack);
         size_t done_b = 0;
         if (err == hipSuccess && nnz && !stopped())
             err = xfer_copy(c, A->d_col, nullptr, sizeof(int32_t) * (size_t)nnz, hipMemcpyHostToDevice, cu ? &cu->stop : nullptr, &done_b,
@@ -264,18 +266,36 @@ __global__ void __launch_bounds__(256) vd_expand_kernel(int64_t rows, int64_t ro
                                                         const uint8_t *__restrict__ code, const int32_t *__restrict__ doff,
                                                         const double *__restrict__ dval, int32_t *__restrict__ col, double *__restrict__ val,
                                                         int64_t from_col, int64_t from_val) {
+    // A wavefront takes 64 consecutive rows: their entries are one contiguous range, walked lane by lane (coalesced loads of the codes,
+    // coalesced stores of col / val); the row of an entry is a binary search over the 65 row pointers in LDS.  (The first version gave a
+    // thread a row: 28- and 56-byte pieces at row-strided addresses -- 12-23 ms for 70 M entries; this one: < 1 ms.)
     __shared__ int32_t s_off[256];
     __shared__ double s_val[256];
+    __shared__ int32_t s_rp[4][65];
     s_off[threadIdx.x] = doff[threadIdx.x];
     s_val[threadIdx.x] = dval[threadIdx.x];
     __syncthreads();
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < rows; i += (int64_t)gridDim.x * 256) {
-        const int32_t k1 = rowptr[i + 1];
-        for (int32_t k = rowptr[i]; k < k1; ++k) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t nblk = (rows + 63) / 64;
+    for (int64_t blk = (int64_t)blockIdx.x * 4 + wave; blk < nblk; blk += (int64_t)gridDim.x * 4) {   // (wavefront-uniform trip count per wavefront: no barrier inside)
+        const int64_t r0 = blk * 64;
+        s_rp[wave][lane] = rowptr[std::min<int64_t>(r0 + lane, rows)];
+        if (lane == 0) s_rp[wave][64] = rowptr[std::min<int64_t>(r0 + 64, rows)];
+        __builtin_amdgcn_wave_barrier();
+        const int32_t k0 = s_rp[wave][0], k1 = s_rp[wave][64];
+        for (int32_t k = k0 + lane; k < k1; k += 64) {
+            int lo = 0, hi = 64;
+#pragma unroll
+            for (int step = 0; step < 6; ++step) {
+                const int mid = (lo + hi) >> 1;
+                if (s_rp[wave][mid] <= k) lo = mid;
+                else hi = mid;
+            }
             const int cd = code[k];
-            if (k >= from_col) col[k] = (int32_t)(row_begin + i + s_off[cd]);
+            if (k >= from_col) col[k] = (int32_t)(row_begin + r0 + lo + s_off[cd]);
             if (k >= from_val) val[k] = s_val[cd];
         }
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -889,6 +909,34 @@ static void low_lds_panels(Low &L) {
     }
 }
 
+// Canonical col / val of a value-indexed matrix, written on the device from its 1-byte codes the first time something needs them
+// (sla_csr_export and through it transpose / the preconditioner builders, (##), a CSR kernel once the value-indexed form is peeled off by
+// an option).  Never called inside a stream capture: it allocates.
+int csr_ensure_canon(sla_csr *A) {
+    if (!A || !A->canon_lazy) return SLA_OK;
+    sla_ctx *c = A->ctx;
+    Bind bind(c);
+    const int64_t nnz = A->nnz;
+    if (!A->d_vcode || !A->d_vdoff || !A->d_vdval || A->rp64) return fail(SLA_ERR_INVALID, "csr_ensure_canon: the matrix has no value-indexed codes");
+    hipError_t e = hipSuccess;
+    if (!A->d_col) {
+        e = dev_malloc(c, (void **)&A->d_col, sizeof(int32_t) * (size_t)nnz + kArraySlack);
+        if (e == hipSuccess) e = hipMemsetAsync((char *)A->d_col + sizeof(int32_t) * (size_t)nnz, 0, kArraySlack, stream_of(c));
+    }
+    if (e == hipSuccess && !A->d_val) {
+        e = dev_malloc(c, (void **)&A->d_val, sizeof(double) * (size_t)nnz + kArraySlack);
+        if (e == hipSuccess) e = hipMemsetAsync((char *)A->d_val + sizeof(double) * (size_t)nnz, 0, kArraySlack, stream_of(c));
+    }
+    if (e != hipSuccess) return fail(SLA_ERR_ALLOC, std::string("canonical arrays of a value-indexed matrix: ") + hipGetErrorString(e));
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((A->rows + 255) / 256, (int64_t)c->n_cu * 16));
+    hipLaunchKernelGGL(vd_expand_kernel, dim3(grid), dim3(256), 0, stream_of(c), A->rows, A->row_begin, (const int32_t *)A->d_rowptr, A->d_vcode,
+                       A->d_vdoff, A->d_vdval, A->d_col, A->d_val, (int64_t)0, (int64_t)0);
+    SLA_HIP_TRY(hipGetLastError());
+    SLA_HIP_TRY(hipStreamSynchronize(stream_of(c)));
+    A->canon_lazy = false;
+    return SLA_OK;
+}
+
 int csr_upload(sla_ctx *c, int64_t m, int64_t n, int64_t row_begin, int64_t rows, const int64_t *rowptr,
                const int64_t *col, const double *val, sla_csr **out, bool panel_view) {
     const int64_t nnz = rowptr[rows];
@@ -961,17 +1009,22 @@ int csr_upload(sla_ctx *c, int64_t m, int64_t n, int64_t row_begin, int64_t rows
         lap("offset dictionary");
         low_wave_sliced_variable(L);
         lap("variable-coefficient slices");
+        L.sub("(before the join)");
         up.join();
+        L.sub("join of the upload thread");
         if (err == hipSuccess) err = Lup.err;
-        if (err == hipSuccess && cu.stop.load() && (cu.done_col < nnz || cu.done_val < nnz)) {
-            const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((rows + 255) / 256, (int64_t)c->n_cu * 8));
-            hipLaunchKernelGGL(vd_expand_kernel, dim3(grid), dim3(256), 0, stream_of(c), rows, row_begin, (const int32_t *)A->d_rowptr, A->d_vcode,
-                               A->d_vdoff, A->d_vdval, A->d_col, A->d_val, cu.done_col, cu.done_val);
-            err = hipGetLastError();
-            if (err == hipSuccess) err = hipStreamSynchronize(stream_of(c));
-            char buf[96];
-            snprintf(buf, sizeof(buf), "canonical entries over PCIe (fraction)=%.3f;", nnz ? 0.5 * (double)(cu.done_col + cu.done_val) / (double)nnz : 0.0);
-            A->lower_log += buf;
+        if (err == hipSuccess && cu.stop.load()) {
+            // value-indexed: nothing of col / val crossed PCIe.  The arrays are written on the device from the codes -- now, or (option
+            // canon_lazy, default) when something first asks for them: export, transpose, a CSR kernel after the form was peeled off
+            A->canon_lazy = true;
+            A->lower_log += "canonical entries over PCIe (fraction)=0.000;";
+            if (!(c->canon_lazy && spmv_value_indexed(A, false))) {
+                const int rc_c = csr_ensure_canon(A);
+                if (rc_c != SLA_OK) err = hipErrorOutOfMemory;
+                L.sub("col / val written on the device");
+            } else {
+                A->lower_log += "canonical arrays lazy=1;";
+            }
         }
         lap("canonical CSR upload (rest)");
         low_lds_panels(L);                 // (its panel-major copy is written by a device kernel from the canonical arrays)

@@ -66,6 +66,8 @@ extern "C" int sla_csr_matmat(sla_csr_t A, sla_csr_t B, int transpose_b, sla_csr
         // rows of "B by output column": A ## B walks the columns of B = rows of transpose B; A ##^ B the rows of B itself
         sla_csr *Bt = B;
         if (!transpose_b) SLA_TRY(csr_transposed(B, &Bt));
+        SLA_TRY(csr_ensure_canon(A));    // (the product kernel reads the canonical arrays of both factors)
+        SLA_TRY(csr_ensure_canon(Bt));
         // present rows of A / of Bt (host copies of the two row-pointer arrays: m + 1 and cols + 1 integers)
         auto present = [&](const sla_csr *M, std::vector<int32_t> &keys) -> int {
             const size_t cnt = (size_t)M->rows + 1;

@@ -759,6 +759,7 @@ int sla_solver_step(sla_solver_t S, int k_steps) {
             // fall through to the plain stream launches below.
             hipGraph_t g = nullptr;
             const int index0 = ctl_of(S).step_index;
+            if (S->A->canon_lazy && !spmv_value_indexed(S->A, false)) SLA_TRY(csr_ensure_canon(S->A));   // (an allocation: not inside the capture)
             hipError_t e = hipStreamBeginCapture(stream_of(c), hipStreamCaptureModeThreadLocal);
             if (e == hipSuccess) {
                 int rc = enqueue_step(S, false, false);
@@ -926,6 +927,7 @@ int sla_linsolve0(int method, sla_csr_t A, sla_vec_t b, sla_vec_t x0, const sla_
         Bind bind(c);
         // solve aa' b' | isDiagonalSM aa' = return $ reciprocal aa' #> b'           (Sparse.hs:1024-1025)
         if (A->is_diagonal) {
+            SLA_TRY(csr_ensure_canon(A));
             SLA_TRY(launch_diag_solve(c, b->n_local, A->d_val, b->d, x_out->d));
             SLA_HIP_TRY(hipStreamSynchronize(stream_of(c)));
             if (info) info->flags = SLA_FLAG_DIAGONAL;

@@ -96,6 +96,7 @@ static int launch_spmv_rp(const sla_csr *A, const SpmvLaunch &l) {
     if (l.x2 && l.epi != EPI_DOT) return fail(SLA_ERR_INVALID, "dual SpMV is only defined for the K1 epilogue");
     SpmvArgs<RP> a;
     a.rowptr = (const RP *)A->d_rowptr;
+    if (A->canon_lazy && !spmv_value_indexed(A, l.x2 != nullptr)) SLA_TRY(csr_ensure_canon(const_cast<sla_csr *>(A)));   // (a CSR kernel after all)
     a.col = A->d_col;
     a.val = A->d_val;
     a.x = l.x;
