@@ -437,17 +437,23 @@ static void low_value_indexed(Low &L) {
             ~Joiner() { if (t.joinable()) t.join(); }
         } code_up_joiner{code_up};
         std::vector<PairTable> loc((size_t)host_threads());
+        std::vector<int64_t> cr_lo((size_t)host_threads(), n), cr_hi((size_t)host_threads(), -1);   // smallest / largest column (taken along in the pass below)
         {
             std::vector<char> bad((size_t)host_threads(), 0);
             par_rows(rows, 1, [&](int t, int64_t lo, int64_t hi) {
                 PairTable &mine = loc[(size_t)t];
+                int64_t cmin = n, cmax = -1;
                 // (a stencil row repeats its predecessor's pairs position by position: the id found at position j of the previous row is
                 // tried first -- two compares instead of a hash and a probe for all but the boundary rows)
                 int recent[kVdMaxRowNnz + 1];
                 for (int &r_ : recent) r_ = -1;
                 for (int64_t i = lo; i < hi && !bad[(size_t)t]; ++i) {
-                    const int64_t gr = row_begin + i, k0 = rowptr[i];
-                    for (int64_t k = k0; k < rowptr[i + 1]; ++k) {
+                    const int64_t gr = row_begin + i, k0 = rowptr[i], k1 = rowptr[i + 1];
+                    if (k1 > k0) {   // (columns ascend inside a row)
+                        cmin = std::min<int64_t>(cmin, col[k0]);
+                        cmax = std::max<int64_t>(cmax, col[k1 - 1]);
+                    }
+                    for (int64_t k = k0; k < k1; ++k) {
                         const int64_t off = col[k] - gr;
                         const uint64_t bits = bits_of(val[k]);
                         int id = recent[k - k0];
@@ -459,6 +465,8 @@ static void low_value_indexed(Low &L) {
                         codes[(size_t)k] = (uint8_t)id;
                     }
                 }
+                cr_lo[(size_t)t] = cmin;
+                cr_hi[(size_t)t] = cmax;
             });
             for (size_t t = 0; t < loc.size() && ok; ++t) {
                 if (bad[t]) ok = false;
@@ -603,28 +611,17 @@ static void low_value_indexed(Low &L) {
                         }
 
                         std::vector<uint64_t> wum((size_t)nsl * 16, 0);
-                        for (int64_t sl2 = 0; sl2 < nsl; ++sl2)
-                            for (int32_t e = wptr[(size_t)sl2]; e < wptr[(size_t)sl2 + 1]; ++e) {
-                                wum[(size_t)sl2 * 16 + wcode[(size_t)e]] = wme[(size_t)e];
-                                wum[(size_t)sl2 * 16 + 8 + wcode[(size_t)e]] = wmo[(size_t)e];
-                            }
+                        par_rows(nsl, 1, [&](int, int64_t slo, int64_t shi) {
+                            for (int64_t sl2 = slo; sl2 < shi; ++sl2)
+                                for (int32_t e = wptr[(size_t)sl2]; e < wptr[(size_t)sl2 + 1]; ++e) {
+                                    wum[(size_t)sl2 * 16 + wcode[(size_t)e]] = wme[(size_t)e];
+                                    wum[(size_t)sl2 * 16 + 8 + wcode[(size_t)e]] = wmo[(size_t)e];
+                                }
+                        }, 16384);
                         upload((void **)&A->d_wum, wum.data(), sizeof(uint64_t) * wum.size());
                         L.sub("slice uploads + uniform masks");
-                        int64_t clo = n, chi = -1;                // (columns ascend inside a row)
-                        {
-                            std::vector<int64_t> plo((size_t)host_threads(), n), phi((size_t)host_threads(), -1);
-                            par_rows(rows, 1, [&](int t, int64_t lo, int64_t hi) {
-                                int64_t a = n, b = -1;
-                                for (int64_t i = lo; i < hi; ++i)
-                                    if (rowptr[i + 1] > rowptr[i]) {
-                                        a = std::min<int64_t>(a, col[rowptr[i]]);
-                                        b = std::max<int64_t>(b, col[rowptr[i + 1] - 1]);
-                                    }
-                                plo[(size_t)t] = a;
-                                phi[(size_t)t] = b;
-                            });
-                            for (size_t t = 0; t < plo.size(); ++t) { clo = std::min(clo, plo[t]); chi = std::max(chi, phi[t]); }
-                        }
+                        int64_t clo = n, chi = -1;                // (from the pair-coding pass: no pass of its own)
+                        for (size_t t = 0; t < cr_lo.size(); ++t) { clo = std::min(clo, cr_lo[t]); chi = std::max(chi, cr_hi[t]); }
                         L.sub("column range");
                         A->wd_col_lo = (int32_t)clo;
                         A->wd_col_hi = (int32_t)chi;
