@@ -1016,7 +1016,7 @@ int sla_vec_create(sla_ctx_t c, int64_t n, const double *host, sla_vec_t *out) {
     sla_vec *v = nullptr;
     SLA_TRY(vec_alloc(c, n, &v));
     if (host && v->n_local > 0) {
-        hipError_t e = xfer_copy(c, v->d, host + v->begin, sizeof(double) * (size_t)v->n_local, hipMemcpyHostToDevice);
+        hipError_t e = xfer_copy(c, v->d, host + v->begin, sizeof(double) * (size_t)v->n_local, hipMemcpyHostToDevice, nullptr, nullptr, nullptr, nullptr, true);
         if (e != hipSuccess) {
             sla_vec_destroy(v);
             return fail(SLA_ERR_HIP, std::string("vector upload: ") + hipGetErrorString(e));
@@ -1033,7 +1033,7 @@ int sla_vec_create_local(sla_ctx_t c, int64_t n, const double *host_local, sla_v
     sla_vec *v = nullptr;
     SLA_TRY(vec_alloc(c, n, &v));
     if (host_local && v->n_local > 0) {
-        hipError_t e = xfer_copy(c, v->d, host_local, sizeof(double) * (size_t)v->n_local, hipMemcpyHostToDevice);
+        hipError_t e = xfer_copy(c, v->d, host_local, sizeof(double) * (size_t)v->n_local, hipMemcpyHostToDevice, nullptr, nullptr, nullptr, nullptr, true);
         if (e != hipSuccess) {
             sla_vec_destroy(v);
             return fail(SLA_ERR_HIP, std::string("vector upload: ") + hipGetErrorString(e));

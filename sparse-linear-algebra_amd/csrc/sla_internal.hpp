@@ -685,7 +685,7 @@ int csr_transposed(sla_csr *A, sla_csr **out);
 // sla_xfer.cpp: large copies between the caller's pageable arrays and the device through pinned slots on several host threads
 typedef void (*xfer_stage_fn)(void *slot, size_t off, size_t len, const void *ctx);
 hipError_t xfer_copy(sla_ctx *c, void *dst, const void *src, size_t bytes, hipMemcpyKind kind, const std::atomic<int> *stop = nullptr,
-                     size_t *done = nullptr, xfer_stage_fn stage = nullptr, const void *stage_ctx = nullptr);
+                     size_t *done = nullptr, xfer_stage_fn stage = nullptr, const void *stage_ctx = nullptr, bool ordered = false);
 void xfer_warm(int device, int lanes);
 int host_threads();   // sla_lower.cpp
 template <class F>

@@ -98,8 +98,10 @@ void lanes_release(XferPool *p, int n, const int *ids) {
 // the copy was called off).  Device-side ordering is the caller's: the buffers must not be in use by work still queued on a stream.
 // stage (host-to-device only, optional): fills a pinned slot with the bytes [off, off + len) of the DEVICE image instead of a memcpy from
 // src -- e.g. the narrowing of the caller's int64 column indices to the device's int32, done on the way instead of in a pass of its own.
+// ordered: the buffers may still be in use by work queued on the context's stream (a new vector's zero fill, the kernels that wrote a
+// vector): the copy goes behind it.  Lowering uploads into fresh allocations pass false and do not meet on that one stream.
 hipError_t xfer_copy(sla_ctx *c, void *dst, const void *src, size_t bytes, hipMemcpyKind kind, const std::atomic<int> *stop, size_t *done,
-                     xfer_stage_fn stage, const void *stage_ctx) {
+                     xfer_stage_fn stage, const void *stage_ctx, bool ordered) {
     if (done) *done = 0;
     if (bytes == 0) return hipSuccess;
     auto stopped = [&] { return stop && stop->load(std::memory_order_relaxed) != 0; };
@@ -115,9 +117,14 @@ hipError_t xfer_copy(sla_ctx *c, void *dst, const void *src, size_t bytes, hipMe
         for (; off < bytes && !stopped(); off += step) {
             const size_t len = std::min(step, bytes - off);
             if (stage) stage(tmp.data(), off, len, stage_ctx);
-            // (on the context's stream, behind what it has queued for these buffers -- a new vector's zero fill, say)
-            hipError_t e = hipMemcpyAsync((char *)dst + off, stage ? (const void *)tmp.data() : (const void *)((const char *)src + off), len, kind, stream_of(c));
-            if (e == hipSuccess) e = hipStreamSynchronize(stream_of(c));
+            const void *from = stage ? (const void *)tmp.data() : (const void *)((const char *)src + off);
+            hipError_t e;
+            if (ordered) {   // on the context's stream, behind what it has queued for these buffers
+                e = hipMemcpyAsync((char *)dst + off, from, len, kind, stream_of(c));
+                if (e == hipSuccess) e = hipStreamSynchronize(stream_of(c));
+            } else {
+                e = hipMemcpy((char *)dst + off, from, len, kind);
+            }
             if (e != hipSuccess) return e;
         }
         if (done) *done = std::min(off, bytes);
@@ -125,7 +132,7 @@ hipError_t xfer_copy(sla_ctx *c, void *dst, const void *src, size_t bytes, hipMe
     }
     {   // the lanes have streams of their own: what the context's stream still has queued for these buffers (a vector's zero fill, the
         // kernels that wrote it) comes first
-        const hipError_t e0 = hipStreamSynchronize(stream_of(c));
+        const hipError_t e0 = ordered ? hipStreamSynchronize(stream_of(c)) : hipSuccess;
         if (e0 != hipSuccess) {
             lanes_release(pool, L, ids);
             return e0;
