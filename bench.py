@@ -808,6 +808,24 @@ def main():
     use_dist = world > 1 or os.environ.get("SLA_BENCH_FORCE_DIST") == "1"
     if use_dist and world == 1:
         os.environ["SLA_FORCE_COLLECTIVES"] = "1"
+    if use_dist:
+        # A hung collective on the first multi-GPU contact must not take the whole run with it: past SLA_BENCH_WATCHDOG_S (default
+        # 1500 s; 0 = off) every rank dumps its Python stacks to stderr, rank 0 writes an error line where the driver reads the JSON,
+        # and the process exits (os._exit: a rank stuck inside RCCL cannot be unwound).
+        limit = float(os.environ.get("SLA_BENCH_WATCHDOG_S", "1500"))
+        if limit > 0:
+            import faulthandler
+
+            def _bark():
+                faulthandler.dump_traceback(file=sys.stderr, all_threads=True)
+                if rank == 0:
+                    os.write(json_fd, (json.dumps({"metric": "bicgstab_iters_per_sec", "value": None, "unit": "iters/s", "n_gpus": world,
+                                                   "error": f"watchdog: rank 0 still running after {limit:.0f} s (stacks on stderr)"}) + "\n").encode())
+                os._exit(3)
+
+            wd = threading.Timer(limit, _bark)
+            wd.daemon = True
+            wd.start()
     rec = run_rank(args, rank, world, local_rank, "rccl" if use_dist else None)
     if rank == 0:
         sys.stdout.flush()
