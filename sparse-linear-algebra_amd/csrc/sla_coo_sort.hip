@@ -166,4 +166,101 @@ int device_coo_to_csr(sla_ctx *c, int64_t m, int64_t n, int64_t nnz, const int64
     return SLA_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// transposeSM (SpMatrix.hs:717) of a lowered matrix, on the device (round 4).  The first (<#) / cgneStep of a matrix used to export its
+// 12 B per entry to the host, transpose there on one thread and lower the result: 0.99 s at 216^3, ten times sla_csr_from_csr.  Here the
+// entries are sorted by (column, row) where they are (stable rocPRIM radix sort of 64-bit keys carrying the entry's position), the
+// transposed CSR arrays are emitted on the device and only then copied down for the lowering analyses of the transpose.
+namespace {
+
+template <typename RP>
+__global__ void __launch_bounds__(256) tr_keys_kernel(int64_t rows, int64_t nnz, const RP *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                                       uint64_t *key, uint32_t *idx) {
+    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < nnz; k += (int64_t)gridDim.x * 256) {
+        int64_t lo = 0, hi = rows;                    // last row whose first entry is <= k (empty rows: the last of equal starts)
+        while (hi - lo > 1) {
+            const int64_t mid = (lo + hi) >> 1;
+            if ((int64_t)rowptr[mid] <= k) lo = mid;
+            else hi = mid;
+        }
+        key[k] = ((uint64_t)(uint32_t)col[k] << 32) | (uint64_t)(uint32_t)lo;
+        idx[k] = (uint32_t)k;
+    }
+}
+
+__global__ void __launch_bounds__(256) tr_emit_kernel(int64_t nnz, const uint64_t *__restrict__ key, const uint32_t *__restrict__ idx,
+                                                       const double *__restrict__ val, int64_t *trow, int64_t *tcol, double *tval) {
+    for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < nnz; o += (int64_t)gridDim.x * 256) {
+        const uint64_t k = key[o];
+        trow[o] = (int64_t)(k >> 32);
+        tcol[o] = (int64_t)(uint32_t)k;
+        tval[o] = val[idx[o]];
+    }
+}
+
+}  // namespace
+
+// t = transpose of A's row block: t.m = A->n rows, columns = LOCAL row ids 0 .. A->rows - 1 (like transpose_csr of the exported block).
+// *done = false: this path could not take the matrix (sizes, device memory) -- the host path does then.
+int device_transpose_to_host(sla_csr *A, HostCsr &t, bool *done) {
+    *done = false;
+    sla_ctx *c = A->ctx;
+    const int64_t nnz = A->nnz, rows = A->rows;
+    if (nnz <= 0 || nnz >= ((int64_t)1 << 32) - 1 || rows >= ((int64_t)1 << 32) || A->n >= ((int64_t)1 << 32)) return SLA_OK;
+    SLA_TRY(csr_ensure_canon(A));
+    hipStream_t st = stream_of(c);
+    DevBuf d_key, d_key2, d_idx, d_idx2, d_trow, d_tcol, d_tval, d_rp, d_tmp;
+    const size_t N = (size_t)nnz;
+    hipError_t e = d_key.alloc(8 * N);
+    if (e == hipSuccess) e = d_key2.alloc(8 * N);
+    if (e == hipSuccess) e = d_idx.alloc(4 * N);
+    if (e == hipSuccess) e = d_idx2.alloc(4 * N);
+    if (e == hipSuccess) e = d_trow.alloc(8 * N);
+    if (e == hipSuccess) e = d_tcol.alloc(8 * N);
+    if (e == hipSuccess) e = d_tval.alloc(8 * N);
+    if (e == hipSuccess) e = d_rp.alloc(8 * (size_t)(A->n + 1));
+    int col_bits = 1;
+    while (((int64_t)1 << col_bits) < A->n) ++col_bits;
+    size_t tmp_bytes = 0;
+    if (e == hipSuccess)
+        e = rocprim::radix_sort_pairs(nullptr, tmp_bytes, d_key.as<uint64_t>(), d_key2.as<uint64_t>(), d_idx.as<uint32_t>(), d_idx2.as<uint32_t>(), N, 0,
+                                      (unsigned)(32 + col_bits), st);
+    if (e == hipSuccess) e = d_tmp.alloc(tmp_bytes);
+    if (e != hipSuccess) {   // (no room for the scratch: not an error)
+        (void)hipGetLastError();
+        return SLA_OK;
+    }
+    const int grid = (int)std::min<int64_t>((nnz + 255) / 256, 8192);
+    if (A->rp64) hipLaunchKernelGGL((tr_keys_kernel<int64_t>), dim3(grid), dim3(256), 0, st, rows, nnz, (const int64_t *)A->d_rowptr, A->d_col, d_key.as<uint64_t>(), d_idx.as<uint32_t>());
+    else hipLaunchKernelGGL((tr_keys_kernel<int32_t>), dim3(grid), dim3(256), 0, st, rows, nnz, (const int32_t *)A->d_rowptr, A->d_col, d_key.as<uint64_t>(), d_idx.as<uint32_t>());
+    SLA_HIP_TRY(hipGetLastError());
+    SLA_HIP_TRY(rocprim::radix_sort_pairs(d_tmp.p, tmp_bytes, d_key.as<uint64_t>(), d_key2.as<uint64_t>(), d_idx.as<uint32_t>(), d_idx2.as<uint32_t>(), N, 0,
+                                          (unsigned)(32 + col_bits), st));
+    hipLaunchKernelGGL(tr_emit_kernel, dim3(grid), dim3(256), 0, st, nnz, d_key2.as<uint64_t>(), d_idx2.as<uint32_t>(), A->d_val, d_trow.as<int64_t>(),
+                       d_tcol.as<int64_t>(), d_tval.as<double>());
+    const int grid_r = (int)std::min<int64_t>((A->n + 1 + 255) / 256, 4096);
+    hipLaunchKernelGGL(coo_rowptr_kernel, dim3(grid_r), dim3(256), 0, st, A->n, nnz, d_trow.as<int64_t>(), d_rp.as<int64_t>());
+    SLA_HIP_TRY(hipGetLastError());
+    SLA_HIP_TRY(hipStreamSynchronize(st));
+    t.m = A->n;
+    t.n = A->rows;
+    t.rowptr.resize((size_t)A->n + 1);
+    t.col.resize(N);
+    t.val.resize(N);
+    {
+        hipError_t e2 = hipSuccess;
+        std::thread th([&] {
+            Bind bind(c);
+            e2 = xfer_copy(c, t.val.data(), d_tval.p, 8 * N, hipMemcpyDeviceToHost);
+        });
+        hipError_t e1 = xfer_copy(c, t.rowptr.data(), d_rp.p, 8 * (size_t)(A->n + 1), hipMemcpyDeviceToHost);
+        if (e1 == hipSuccess) e1 = xfer_copy(c, t.col.data(), d_tcol.p, 8 * N, hipMemcpyDeviceToHost);
+        th.join();
+        SLA_HIP_TRY(e1);
+        SLA_HIP_TRY(e2);
+    }
+    *done = true;
+    return SLA_OK;
+}
+
 }  // namespace sla

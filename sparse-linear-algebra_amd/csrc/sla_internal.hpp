@@ -243,6 +243,7 @@ struct sla_ctx {
     int xfer_lanes = 4;
     int canon_lazy = 1;              // ... and only when something asks for them (export, transpose, a CSR kernel after the form was peeled off): 843 MB and 12-23 ms of
                                      // first-touch allocation less at 216^3
+    int transpose_device = 1;        // transposeSM of a lowered matrix as a device sort (1: from 2^18 entries on, 2: always, 0: host)
     int canon_device = 1;            // value-indexed matrices: canonical col / val written on the device from the 1-byte codes instead of uploaded
     int tile_prefetch = 0;           // x-panel prefetch distance of spmv_tile_kernel in visit steps (0: demand misses only; measured: never a gain)
     int tile_poll = 1;               // 1: pacing slots polled one step ahead, 0: dependent poll in front of every tile (rounds 2-3)
@@ -645,6 +646,7 @@ void transpose_csr(const HostCsr &a, HostCsr &t);
 bool device_coo_supported(int64_t m, int64_t n, int64_t nnz);
 int device_coo_to_csr(sla_ctx *c, int64_t m, int64_t n, int64_t nnz, const int64_t *row, const int64_t *col,
                       const double *val, int dup_policy, HostCsr &out);
+int device_transpose_to_host(sla_csr *A, HostCsr &t, bool *done);   // sla_coo_sort.hip: transposeSM of a lowered row block by a device sort
 bool host_is_diagonal(int64_t rows, int64_t row_begin, const int64_t *rowptr, const int64_t *col);
 void build_row_blocks(int64_t rows, const int64_t *rowptr, std::vector<int32_t> &rb, int64_t &max_row_nnz, int row_align,
                       int nnz_target);

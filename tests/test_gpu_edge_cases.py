@@ -465,3 +465,41 @@ def test_large_copies_through_the_pinned_lanes_are_exact(sla, lanes, xfer):
     A = sla.fromCSR((n, n), rp, ci, va, ctx)
     rp2, ci2, va2 = A.csr()
     assert np.array_equal(rp2, rp) and np.array_equal(ci2, ci) and np.array_equal(va2.view(np.uint64), va.view(np.uint64))
+
+
+@pytest.mark.parametrize("rp64", [0, 1])
+def test_device_transpose_equals_the_host_transpose(sla, rp64):
+    """transposeSM of a lowered matrix (the first (<#) / cgneStep builds it): as a device sort by (column, row) (round 4, option
+    transpose_device) and by the host path (export + counting sort).  (<#) through either must be the oracle's fold over the
+    transposed matrix (to the row-length bound; bit for bit BETWEEN the two paths) -- rectangular shapes, empty rows and columns, a stencil, 64-bit row pointers."""
+    from sla_amd import workloads as wl
+    rng = np.random.default_rng(31 + rp64)
+
+    def ragged(m, n, maxlen):
+        lens = rng.integers(0, maxlen + 1, m)
+        lens[rng.random(m) < 0.2] = 0
+        rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        ci = np.concatenate([np.sort(rng.choice(n - n // 5, size=int(k), replace=False)) for k in lens] + [np.zeros(0, np.int64)]).astype(np.int64)   # (the last fifth of the columns: empty)
+        return (m, n), (rp, ci, rng.standard_normal(len(ci)))
+
+    for dims, (rp, ci, va) in (ragged(700, 2900, 40), ragged(5000, 300, 12), wl.laplace3d(17, 13, 11), wl.poisson2d(90, 41)):
+        Ao = orc.Csr(dims[0], dims[1], rp, ci, va)
+        x = rng.standard_normal(dims[0])
+        want = orc.spmv(orc.transpose(Ao), x)
+        cnt = np.bincount(ci, minlength=dims[1])
+        bound = (cnt + 8) * np.finfo(float).eps * orc.spmv(orc.transpose(orc.Csr(dims[0], dims[1], rp, ci, np.abs(va))), np.abs(x)) + 1e-300
+        got = {}
+        for dev in (2, 0):
+            ctx = sla.Context(0).set_options(transpose_device=dev, force_rp64=rp64)
+            A = sla.fromCSR(dims, rp, ci, va, ctx)
+            y = sla.DeviceVector(ctx, dims[1])
+            xd = sla.DeviceVector(ctx, dims[0], x)
+            sla._lib.check(sla._lib.lib().sla_spmv_t(A.h, xd.h, y.h))
+            got[dev] = y.to_host()
+            # (the transposes of the ragged cases have rows of hundreds of entries: the long-row kernels are not a strict left fold)
+            assert np.all(np.abs(got[dev] - want) <= bound), (dims, dev, rp64, float(np.abs(got[dev] - want).max()))
+            assert np.all(got[dev][cnt == 0] == 0.0)
+            del A, y, xd
+            ctx.close()
+        # the same arrays from both paths: the same kernel gives the same bits
+        assert np.array_equal(got[2].view(np.uint64), got[0].view(np.uint64)), (dims, rp64)
