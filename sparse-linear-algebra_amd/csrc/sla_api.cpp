@@ -913,15 +913,19 @@ int sla_csr_export(sla_csr_t A, int64_t *rowptr, int64_t *colidx, double *val) {
             if (A->rp64) {
                 SLA_HIP_TRY(hipMemcpy(rowptr, A->d_rowptr, sizeof(int64_t) * (size_t)(A->rows + 1), hipMemcpyDeviceToHost));
             } else {
-                std::vector<int32_t> t((size_t)A->rows + 1);
-                SLA_HIP_TRY(hipMemcpy(t.data(), A->d_rowptr, sizeof(int32_t) * t.size(), hipMemcpyDeviceToHost));
-                for (size_t i = 0; i < t.size(); ++i) rowptr[i] = t[i];
+                raw_vector<int32_t> t((size_t)A->rows + 1);
+                SLA_HIP_TRY(xfer_copy(c, t.data(), A->d_rowptr, sizeof(int32_t) * t.size(), hipMemcpyDeviceToHost));
+                par_rows((int64_t)t.size(), 1, [&](int, int64_t lo, int64_t hi) {
+                    for (int64_t i = lo; i < hi; ++i) rowptr[i] = t[(size_t)i];
+                });
             }
         }
         if (colidx && A->nnz) {
-            std::vector<int32_t> t((size_t)A->nnz);
-            SLA_HIP_TRY(hipMemcpy(t.data(), A->d_col, sizeof(int32_t) * t.size(), hipMemcpyDeviceToHost));
-            for (size_t i = 0; i < t.size(); ++i) colidx[i] = t[i];
+            raw_vector<int32_t> t((size_t)A->nnz);
+            SLA_HIP_TRY(xfer_copy(c, t.data(), A->d_col, sizeof(int32_t) * t.size(), hipMemcpyDeviceToHost));
+            par_rows((int64_t)t.size(), 1 << 16, [&](int, int64_t lo, int64_t hi) {   // (widened in parallel: 70 M entries took 70 ms on one thread)
+                for (int64_t i = lo; i < hi; ++i) colidx[i] = t[(size_t)i];
+            });
         }
         if (val && A->nnz) SLA_HIP_TRY(xfer_copy(A->ctx, val, A->d_val, sizeof(double) * (size_t)A->nnz, hipMemcpyDeviceToHost));
         return SLA_OK;
