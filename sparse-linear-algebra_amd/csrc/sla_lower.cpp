@@ -200,7 +200,7 @@ static void low_csr_arrays(Low &L, CanonUpload *cu) {
     SLA_LOW_LOCALS(L);
     auto stopped = [&] { return cu && cu->stop.load(std::memory_order_relaxed) != 0; };
     auto await_decision = [&] {
-        while (cu && !cu->decided.load(std::memory_order_acquire)) std::this_thread::yield();
+        while (cu && !cu->decided.load(std::memory_order_acquire)) std::this_thread::sleep_for(std::chrono::microseconds(50));   // (not a spin: the analysis wants the cores)
     };
     // the values go up on a second host thread while this one narrows and uploads the indices (pageable copies are
     // bound by the staging memcpy of the calling thread, not by the link)
