@@ -38,6 +38,9 @@ import sys
 import threading
 import time
 
+# (the host driver of this pool only supports dmabuf IPC: without this RCCL's buffer sharing between ranks fails with
+# hipIpcGetMemHandle: invalid argument -- set before any HIP / HSA library is loaded, whoever launched the ranks)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (ROOT, os.path.join(ROOT, "sparse-linear-algebra_amd")):
     if p not in sys.path:
