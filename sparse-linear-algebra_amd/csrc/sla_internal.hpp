@@ -93,6 +93,10 @@ constexpr int kWaveRowMax = 16384;   // rows of 1025..16384 entries: one wavefro
 #ifndef SLA_TILE_OCC
 #define SLA_TILE_OCC 1
 #endif
+#ifndef SLA_TILE_WAVES
+#define SLA_TILE_WAVES 4
+#endif
+constexpr int kTileWaves = SLA_TILE_WAVES;  // wavefronts of its workgroup that walk slices (the others only join the reductions): 4 x 4896 rows or e.g. 2 x 9792
 constexpr int kTileRows = SLA_TILE_ROWS;  // rows per slice of spmv_tile_kernel: one wavefront's row sums in LDS (38 KiB; 4 x 4896 x 8 B + the pacing tables = all of the CU's 160 KiB)
 constexpr int kTileBlocksPerCu = SLA_TILE_OCC;  // its resident workgroups per CU (1 x 128 KiB of LDS, 4 wavefronts with 12 x 64 gathers in flight each: few, fat
                                                 // wavefronts drift apart less and keep more misses in flight than 16 thin ones -- 2.26 -> 1.98 ms at 10 M rows)

@@ -27,7 +27,7 @@ int build_tiles(sla_csr *A, int64_t n, int64_t rows, const int64_t *rowptr, cons
     {   // the kernel keeps one slice's row sums per wavefront in static LDS (4 x kTileRows doubles = 153 KiB of the MI355X's 160 KiB)
         int lds = 0;
         if (hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, c->device) != hipSuccess ||
-            (int64_t)lds < (int64_t)(kBlock / 64) * kTileRows * 8 + 1024)
+            (int64_t)lds < (int64_t)kTileWaves * kTileRows * 8 + 1024)
             return SLA_OK;
     }
     int row_bits = 0;
@@ -40,7 +40,7 @@ int build_tiles(sla_csr *A, int64_t n, int64_t rows, const int64_t *rowptr, cons
     const int64_t P = (n + W - 1) / W;
     if (P > 16384) return SLA_OK;
     // slices: whole rounds of the persistent grid (kTileBlocksPerCu workgroup(s) of 4 wavefronts per CU)
-    const int64_t waves = (int64_t)kTileBlocksPerCu * c->n_cu * (kBlock / 64);
+    const int64_t waves = (int64_t)kTileBlocksPerCu * c->n_cu * kTileWaves;
     const int64_t rounds = std::max<int64_t>(1, (rows + (int64_t)kTileRows * waves - 1) / ((int64_t)kTileRows * waves));
     int64_t S0 = rounds * waves;
     S0 = std::max<int64_t>(1, std::min<int64_t>(S0, (rows + 63) / 64));

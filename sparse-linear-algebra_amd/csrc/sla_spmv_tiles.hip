@@ -92,15 +92,15 @@ spmv_tile_kernel(SpmvArgs<RP> a, const RP *__restrict__ rowptr, const int32_t *_
                  int shift, unsigned *prog, int slack, const int32_t *__restrict__ vis, int v0, int nv, int pfd, int apoll, int64_t ncols, int dlim) {
     // One PASS of an overlapped all-gather (AgPlan, sla_internal.hpp) walks the nv panels vis[v0 ..] instead of 0 .. P-1 and starts
     // from the running row sums a.yinit; vis == nullptr: all P panels ascending from zero (nv == P then).
-    __shared__ double s_y[kBlock / 64][kTileRows];
+    __shared__ double s_y[kTileWaves][kTileRows];
     __shared__ double s_red[4];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     double coef;
     if (!spmv_prologue<EPI, RP>(a, s_red, coef)) return;
     double acc1 = 0.0, acc2 = 0.0;
-    double *yl = s_y[wave];
+    double *yl = s_y[wave < kTileWaves ? wave : 0];
     const uint32_t cmask = (1u << shift) - 1u;
-    const int stride = (int)gridDim.x * (kBlock / 64);
+    const int stride = (int)gridDim.x * kTileWaves;
     // Panel pacing.  The gathers only hit the L2 while the wavefronts of an XCD are on (nearly) the same panel, and left
     // alone they drift apart within a fraction of a slice (the SIMD arbiter favours the oldest wavefront; measured without
     // pacing: 78 % L2 misses, 33 GB through the fabric per launch).  So a wavefront does not START panel step q before every
@@ -114,7 +114,7 @@ spmv_tile_kernel(SpmvArgs<RP> a, const RP *__restrict__ rowptr, const int32_t *_
     __shared__ int s_prog[kBlock / 64];
     __shared__ int s_pf[kBlock / 64][64];   // where the x-panel prefetch lands (never read)
     __shared__ int s_poll[kBlock / 64][64 * kTilePollQ];   // the pacing slots of the XCD as the last look-ahead poll of each wavefront brought them
-    if (tid < kBlock / 64) s_prog[tid] = 0;
+    if (tid < kBlock / 64) s_prog[tid] = tid < kTileWaves ? 0 : 0x7fffffff;
     for (int i = tid; i < (kBlock / 64) * 64 * kTilePollQ; i += kBlock) (&s_poll[0][0])[i] = 0;
     __syncthreads();
     const int xcd = (int)blockIdx.x & 7;
@@ -203,7 +203,7 @@ spmv_tile_kernel(SpmvArgs<RP> a, const RP *__restrict__ rowptr, const int32_t *_
     // and XCD, each holding up the chunk it belongs to for a trip to the memory side.  On entering visit step q a wavefront now pulls ITS
     // 1 / (wavefronts per XCD) of the panel of step q + pfd into the XCD's L2 with one direct-to-LDS load per 64 lines (no destination
     // register; the data lands in s_pf and is never read), one 128-byte line per lane.
-    const int wix = ((int)blockIdx.x >> 3) * (kBlock / 64) + wave, nwx = nwg_xcd * (kBlock / 64);
+    const int wix = ((int)blockIdx.x >> 3) * kTileWaves + wave, nwx = nwg_xcd * kTileWaves;
     const int plines = 1 << (shift - 4), lpw = (plines + nwx - 1) / nwx;
     const unsigned pf_lds = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)(&s_pf[wave][0]));   // (flat address of LDS: the low half is the LDS byte address)
     auto prefetch_panel = [&](int p) {
@@ -219,7 +219,7 @@ spmv_tile_kernel(SpmvArgs<RP> a, const RP *__restrict__ rowptr, const int32_t *_
         }
     };
     int round = 0;
-    for (int sv = (int)blockIdx.x * (kBlock / 64) + wave;; sv += stride, ++round) {
+    for (int sv = (int)blockIdx.x * kTileWaves + wave; wave < kTileWaves; sv += stride, ++round) {   // (wavefronts beyond kTileWaves only join the reductions below)
         const int s = __builtin_amdgcn_readfirstlane(sv);   // everything per slice is wavefront-uniform: keep it in SGPRs
         if (round >= rounds || s >= S) {   // no (more) slices: count as finished with everything, the others must not wait for this one
             publish(0x7fffffff);
@@ -384,7 +384,7 @@ int probe_xcd_layout(sla_ctx *c) {
 bool tiles_on(const sla_csr *A) { return A->use_tiles && A->ctx->tiles && A->ctx->spmv_algo == 0; }
 
 int tiles_grid(const sla_csr *A) {
-    const int64_t blocks = ((int64_t)A->tl_S + kBlock / 64 - 1) / (kBlock / 64);
+    const int64_t blocks = ((int64_t)A->tl_S + kTileWaves - 1) / kTileWaves;
     return (int)std::max<int64_t>(1, std::min<int64_t>(blocks, (int64_t)kTileBlocksPerCu * A->ctx->n_cu));
 }
 
