@@ -323,7 +323,7 @@ def end_to_end_block(ctx, A, dims, rp, ci, va, b_host, t_from_csr, steady_its, w
     """What "lowered once" costs next to the steady-state rate: seconds of sla_csr_from_csr (already spent on the
     headline matrix: `t_from_csr`, phases as the library recorded them), of sla_csr_from_coo on the same entries in toListSM's
     DESCENDING (row, col) order (SpMatrix.hs:251-253: what a Haskell caller's triple list looks like), and the wall-clock of one COLD
-    reference-faithful linSolve0 BICGSTAB_ through the host-array boundary: upload b and x0, solve (true residual every iteration,
+    reference-faithful linSolve0 BICGSTAB_ through the host-array boundary: upload b (x0 = 0 needs none), solve (true residual every iteration,
     <= 200 iterations), download x.  cold_total = lowering + that call."""
     import sla_amd as sla
     from sla_amd import _lib
@@ -333,7 +333,7 @@ def end_to_end_block(ctx, A, dims, rp, ci, va, b_host, t_from_csr, steady_its, w
            "host_bytes": int(12 * rp[-1] + 8 * (n + 1))}
     t0 = time.perf_counter()
     bv = sla.DeviceVector(ctx, n, b_host, local=True)
-    xv = sla.DeviceVector(ctx, n, np.zeros(n), local=True)
+    xv = sla.DeviceVector(ctx, n)                      # x0 = 0 (the reference's empty SpVector): created on the device, nothing to upload
     ctx.sync()
     t1 = time.perf_counter()
     res = sla.DeviceVector(ctx, n)

@@ -717,7 +717,7 @@ int par_rows(int64_t rows, int64_t align, F fn, int64_t serial_below = 200000) {
 // sla_lower.cpp: validate, upload and lower one rank's row block (panel_view: a column-panel view of a parent, lowered plainly);
 // csr_reject: a rank whose input failed validation still joins the agreement collective of csr_upload before it reports
 int csr_upload(sla_ctx *c, int64_t m, int64_t n, int64_t row_begin, int64_t rows, const int64_t *rowptr, const int64_t *col,
-               const double *val, sla_csr **out, bool panel_view = false);
+               const double *val, sla_csr **out, bool panel_view = false, bool validate_cols = false);
 int csr_reject(sla_ctx *c, int rc);
 void tri_plan_free(sla_tri_plan *p);   // sla_precond.cpp (sla_csr_destroy releases a matrix's level schedules)
 int spmv_transposed(sla_csr *A, const double *x_local, double *y_local, int64_t y_shard);

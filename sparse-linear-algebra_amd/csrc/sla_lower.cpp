@@ -161,6 +161,8 @@ struct Low {
     bool panel_view, dbg_lower;
     hipError_t err = hipSuccess;
     CanonUpload *cu = nullptr;          // (csr_upload's; low_value_indexed reports its decision there)
+    bool validate = false;              // the caller's columns still have to be checked (bounds, ascending inside a row)
+    int col_verdict = -1;               // -1: not checked yet; 0 fine, 1 out of bounds, 2 not ascending (validate_columns' codes)
     std::chrono::steady_clock::time_point t_sub = std::chrono::steady_clock::now();
     void sub(const char *what) {        // SLA_DEBUG_LOWER: times inside one analysis
         if (!dbg_lower || panel_view) return;
@@ -437,12 +439,14 @@ static void low_value_indexed(Low &L) {
             ~Joiner() { if (t.joinable()) t.join(); }
         } code_up_joiner{code_up};
         std::vector<PairTable> loc((size_t)host_threads());
+        std::vector<int> vcol((size_t)host_threads(), 0);
         std::vector<int64_t> cr_lo((size_t)host_threads(), n), cr_hi((size_t)host_threads(), -1);   // smallest / largest column (taken along in the pass below)
         {
             std::vector<char> bad((size_t)host_threads(), 0);
             par_rows(rows, 1, [&](int t, int64_t lo, int64_t hi) {
                 PairTable &mine = loc[(size_t)t];
                 int64_t cmin = n, cmax = -1;
+                int vbad = 0;   // (the canonical-CSR check of the caller's columns rides along: the pass reads every column anyway)
                 // (a stencil row repeats its predecessor's pairs position by position: the id found at position j of the previous row is
                 // tried first -- two compares instead of a hash and a probe for all but the boundary rows)
                 int recent[kVdMaxRowNnz + 1];
@@ -454,6 +458,8 @@ static void low_value_indexed(Low &L) {
                         cmax = std::max<int64_t>(cmax, col[k1 - 1]);
                     }
                     for (int64_t k = k0; k < k1; ++k) {
+                        if (col[k] < 0 || col[k] >= n) vbad = 1;
+                        else if (k > k0 && col[k] <= col[k - 1] && vbad == 0) vbad = 2;
                         const int64_t off = col[k] - gr;
                         const uint64_t bits = bits_of(val[k]);
                         int id = recent[k - k0];
@@ -467,7 +473,12 @@ static void low_value_indexed(Low &L) {
                 }
                 cr_lo[(size_t)t] = cmin;
                 cr_hi[(size_t)t] = cmax;
+                vcol[(size_t)t] = vbad;
             });
+            if (L.validate && std::find(bad.begin(), bad.end(), 1) == bad.end()) {   // (every thread went through all of its rows)
+                L.col_verdict = std::find(vcol.begin(), vcol.end(), 1) != vcol.end() ? 1 : std::find(vcol.begin(), vcol.end(), 2) != vcol.end() ? 2 : 0;
+                if (L.col_verdict != 0) ok = false;
+            }
             for (size_t t = 0; t < loc.size() && ok; ++t) {
                 if (bad[t]) ok = false;
                 for (const Pair &pr : loc[t].pairs)
@@ -934,8 +945,25 @@ int csr_ensure_canon(sla_csr *A) {
     return SLA_OK;
 }
 
+// canonical-CSR check of the caller's columns (sla_csr_from_csr_rows): 0 fine, 1 some index out of bounds, 2 not strictly ascending
+// inside a row; the lowest-numbered kind of violation wins so that the verdict does not depend on the thread count
+static int validate_columns(int64_t rows, int64_t n, const int64_t *rowptr, const int64_t *col) {
+    std::vector<int> bad((size_t)host_threads(), 0);
+    par_rows(rows, 1, [&](int t, int64_t lo, int64_t hi) {
+        int b_ = 0;
+        for (int64_t i = lo; i < hi && b_ != 1; ++i)
+            for (int64_t k = rowptr[i]; k < rowptr[i + 1]; ++k) {
+                if (col[k] < 0 || col[k] >= n) { b_ = 1; break; }
+                if (k > rowptr[i] && col[k] <= col[k - 1]) b_ = 2;
+            }
+        bad[(size_t)t] = b_;
+    });
+    if (std::find(bad.begin(), bad.end(), 1) != bad.end()) return 1;
+    return std::find(bad.begin(), bad.end(), 2) != bad.end() ? 2 : 0;
+}
+
 int csr_upload(sla_ctx *c, int64_t m, int64_t n, int64_t row_begin, int64_t rows, const int64_t *rowptr,
-               const int64_t *col, const double *val, sla_csr **out, bool panel_view) {
+               const int64_t *col, const double *val, sla_csr **out, bool panel_view, bool validate_cols) {
     const int64_t nnz = rowptr[rows];
     if (n > (int64_t)std::numeric_limits<int32_t>::max() || rows >= (int64_t)std::numeric_limits<int32_t>::max()) {
         // (rows differs per rank: a rank that fails here alone still owes its peers the agreement collective below)
@@ -967,6 +995,10 @@ int csr_upload(sla_ctx *c, int64_t m, int64_t n, int64_t row_begin, int64_t rows
     Low L{c, A, m, n, row_begin, rows, nnz, rowptr, col, val, panel_view, dbg_lower};
     hipError_t &err = L.err;
     int diag_not = 1;
+    // The caller's columns are checked NEXT TO the first analyses (which compare and subtract column values, never index with them); the
+    // verdict is taken before anything uses a column as an index (the LDS-panel / flat / tile builders, the exchange plan).
+    int bad_cols = 0;
+    L.validate = validate_cols && nnz > 0;
     try {   // (a host allocation failing inside an analysis leaves through the agreement collective below like a device one)
         build_row_blocks(rows, rowptr, L.rb, A->max_row_nnz, c->row_align, c->rb_nnz);
         A->nrb = (int32_t)L.rb.size() - 1;
@@ -993,6 +1025,10 @@ int csr_upload(sla_ctx *c, int64_t m, int64_t n, int64_t row_begin, int64_t rows
         } up_joiner{up, cu};
         low_value_indexed(L);
         L.sub("visiting order + return");
+        if (L.validate) {   // the pair-coding pass checked the columns on its way unless it left early (not a value-indexed matrix): then here
+            bad_cols = L.col_verdict >= 0 ? L.col_verdict : validate_columns(rows, n, rowptr, col);
+            if (bad_cols && err == hipSuccess) err = hipErrorInvalidValue;   // (nothing below runs; reported after the agreement)
+        }
         // value-indexed after all: the rest of the canonical entry arrays is written on the device from the codes (option canon_device)
         cu.decided.store(1, std::memory_order_release);   // (matrices the analysis did not look at: rp64, rows too long, no entries)
         lap("pair dictionary + wave slices");
@@ -1055,6 +1091,11 @@ int csr_upload(sla_ctx *c, int64_t m, int64_t n, int64_t row_begin, int64_t rows
     // it): the all-reduced maximum carries isDiagonalSM's verdict in bit 0 and "some rank failed" as a value >= 2.
     int agree = err != hipSuccess ? 2 : diag_not;
     int rc = dist_allreduce_max_i32(c, &agree);
+    if (bad_cols) {   // (every rank has been through the agreement: its peers learn "failed on another rank")
+        sla_csr_destroy(A);
+        return bad_cols == 1 ? fail(SLA_ERR_OOB, "insertSpMatrix : index out of bounds")
+                             : fail(SLA_ERR_INVALID, "columns must be strictly ascending inside a row (canonical CSR)");
+    }
     if (err != hipSuccess) {
         sla_csr_destroy(A);
         return fail(SLA_ERR_ALLOC, std::string("CSR upload: ") + hipGetErrorString(err));
