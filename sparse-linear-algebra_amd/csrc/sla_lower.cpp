@@ -1000,19 +1000,40 @@ int csr_upload(sla_ctx *c, int64_t m, int64_t n, int64_t row_begin, int64_t rows
     int bad_cols = 0;
     L.validate = validate_cols && nnz > 0;
     try {   // (a host allocation failing inside an analysis leaves through the agreement collective below like a device one)
-        build_row_blocks(rows, rowptr, L.rb, A->max_row_nnz, c->row_align, c->rb_nnz);
-        A->nrb = (int32_t)L.rb.size() - 1;
-        diag_not = host_is_diagonal(rows, row_begin, rowptr, col) ? 0 : 1;
+        // The row blocks (a sequential greedy pass over the rows, 5 ms at 10 M) and isDiagonalSM are built at the head of the background
+        // thread below; here only the longest row, which the first analysis asks for (parallel).
+        {
+            std::vector<int64_t> mx((size_t)host_threads(), 0);
+            par_rows(rows, 1, [&](int t, int64_t lo, int64_t hi) {
+                int64_t v = 0;
+                for (int64_t i = lo; i < hi; ++i) v = std::max(v, rowptr[i + 1] - rowptr[i]);
+                mx[(size_t)t] = v;
+            });
+            A->max_row_nnz = *std::max_element(mx.begin(), mx.end());
+        }
+        std::atomic<int> rb_ready{0};
+        auto await_rb = [&] {              // (the analyses that walk row blocks: not the value-indexed one)
+            while (!rb_ready.load(std::memory_order_acquire)) std::this_thread::sleep_for(std::chrono::microseconds(50));
+        };
         lap("row blocks");
         // The canonical arrays (narrowed columns, values, row pointers, row-block tables: 12 B per entry over PCIe from pageable memory)
         // go up on a background thread WHILE the host analyses of the storage forms run (round 4: the two were 106 ms + 106 ms in a row
         // at 70 M entries; the upload is bound by the staging copies of one or two threads, the analyses use the other cores).
         CanonUpload cu;
-        Low Lup = L;                       // (own error slot, own copy of the row-block starts)
+        Low Lup = L;                       // (own error slot)
         L.cu = &cu;
         std::thread up([&] {
             Bind bind(c);                  // (a new thread starts on device 0)
+            struct Ready { std::atomic<int> &f; ~Ready() { f.store(1, std::memory_order_release); } };
             try {
+                {
+                    Ready ready{rb_ready};   // (set however the block is left: the main thread waits for it)
+                    int64_t mx_unused = 0;
+                    build_row_blocks(rows, rowptr, L.rb, mx_unused, c->row_align, c->rb_nnz);
+                    A->nrb = (int32_t)L.rb.size() - 1;
+                    diag_not = host_is_diagonal(rows, row_begin, rowptr, col) ? 0 : 1;
+                    Lup.rb = L.rb;
+                }
                 low_csr_arrays(Lup, &cu);
             } catch (const std::bad_alloc &) {
                 if (Lup.err == hipSuccess) Lup.err = hipErrorOutOfMemory;
@@ -1033,6 +1054,8 @@ int csr_upload(sla_ctx *c, int64_t m, int64_t n, int64_t row_begin, int64_t rows
         cu.decided.store(1, std::memory_order_release);   // (matrices the analysis did not look at: rp64, rows too long, no entries)
         lap("pair dictionary + wave slices");
         // (the LDS x windows of the row blocks serve the CSR-stream / dictionary-code kernels only: skipped with them, see below)
+        await_rb();
+        if (L.rb.empty()) throw std::bad_alloc();   // (the background thread could not build them)
         if (!(A->use_wdia && c->wdia && c->diag_lazy)) low_xwin_statistics(L);
         lap("x-window statistics");
         // (the 1-byte column codes serve the dictionary-code kernel and the variable-coefficient slices: a matrix that just took the
