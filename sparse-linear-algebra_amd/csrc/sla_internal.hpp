@@ -7,6 +7,7 @@
 #include <memory>
 #include <new>
 #include <atomic>
+#include <chrono>
 #include <future>
 #include <string>
 #include <algorithm>
@@ -242,7 +243,7 @@ struct sla_ctx {
     int tiles_device = 1;            // the tile form's re-ordering as a device sort (sla_tiles_build.hip): 1 from 2^20 entries on, 2 always, 0 host builder (SLA_TILES_DEVICE)
     int tiles = 1;                   // allow the row-slice x column-panel tile SpMV for irregular matrices with x > L2 (SLA_TILES=0: column-panel passes)
     std::future<void> xfer_warmup;   // the copy lanes of this device being built (sla_xfer.cpp)
-    std::future<void> deferred_free; // host buffers of the last lowering being released off the caller's thread (sla_lower.cpp)
+    std::vector<std::future<void>> deferred;   // host buffers being released off the caller's thread (defer_release below): returning a GB to the system costs ~0.1 s
     int xfer = 1;                    // copies >= 24 MiB from / to pageable host memory: own pinned staging on xfer_lanes threads (0: plain hipMemcpy)
     int xfer_lanes = 4;
     int canon_lazy = 1;              // ... and only when something asks for them (export, transpose, a CSR kernel after the form was peeled off): 843 MB and 12-23 ms of
@@ -693,6 +694,16 @@ typedef void (*xfer_stage_fn)(void *slot, size_t off, size_t len, const void *ct
 hipError_t xfer_copy(sla_ctx *c, void *dst, const void *src, size_t bytes, hipMemcpyKind kind, const std::atomic<int> *stop = nullptr,
                      size_t *done = nullptr, xfer_stage_fn stage = nullptr, const void *stage_ctx = nullptr, bool ordered = false);
 void xfer_warm(int device, int lanes);
+// Run `release` (the destruction of large host buffers) on a background thread; finished ones are forgotten, the context's destructor
+// waits for the rest.
+template <class F>
+inline void defer_release(sla_ctx *c, F &&release) {
+    auto &d = c->deferred;
+    for (size_t i = 0; i < d.size();)
+        if (d[i].wait_for(std::chrono::seconds(0)) == std::future_status::ready) { d[i] = std::move(d.back()); d.pop_back(); }
+        else ++i;
+    d.push_back(std::async(std::launch::async, std::forward<F>(release)));
+}
 int host_threads();   // sla_lower.cpp
 template <class F>
 int par_rows(int64_t rows, int64_t align, F fn, int64_t serial_below = 200000) {

@@ -722,13 +722,11 @@ static void low_value_indexed(Low &L) {
                 L.sub("visiting order");
             }
         }
-        // (returning 70 MB to the system took 5-10 ms on this thread at 216^3: the codes are released behind the call's back; the context
-        // waits for the previous release before it starts the next one, and when it is destroyed)
+        // (returning 70 MB to the system took 5-10 ms on this thread at 216^3: the codes are released behind the call's back)
         if (code_up.joinable()) code_up.join();
         if (err == hipSuccess) err = err_code;
         L.sub("code upload (rest)");
-        if (c->deferred_free.valid()) c->deferred_free.wait();
-        c->deferred_free = std::async(std::launch::async, [p = codes_buf.release()] { delete[] p; });
+        defer_release(c, [p = codes_buf.release()] { delete[] p; });
     }
 }
 
