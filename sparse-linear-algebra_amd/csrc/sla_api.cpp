@@ -594,6 +594,7 @@ static int ctx_create_common(int device_id, int rank, int nranks, const void *ui
         return fail(SLA_ERR_NO_DEVICE, "no HIP device visible: libsla_hip has no CPU fallback");
     if (device_id < 0 || device_id >= ndev) return fail(SLA_ERR_INVALID, "sla_ctx_create: device id out of range");
     SLA_HIP_TRY(hipSetDevice(device_id));
+    bg_exit_handler_once();   // (after the runtime's own initialisation, so that it runs before the runtime's exit handler)
     sla_ctx *c = new sla_ctx();
     c->device = device_id;
     c->rank = rank;
@@ -620,7 +621,11 @@ static int ctx_create_common(int device_id, int rank, int nranks, const void *ui
     ctx_read_knobs(c);   // (after the device-derived defaults: SLA_WD_GRID overrides the per-CU grid)
     if (c->xfer) {       // the pinned copy lanes of this device, built while the caller assembles its matrix
         const int dev = c->device, lanes = c->xfer_lanes;
-        c->xfer_warmup = std::async(std::launch::async, [dev, lanes] { xfer_warm(dev, lanes); });
+        bg_begin();
+        c->xfer_warmup = std::async(std::launch::async, [dev, lanes] {
+            BgTask task;
+            xfer_warm(dev, lanes);
+        });
     }
     if (uid) {
         int rc = dist_comm_init(c, uid);
@@ -674,6 +679,11 @@ int sla_ctx_create_loopback(int device_id, int rank, int nranks, int group_key, 
 int sla_ctx_destroy(sla_ctx_t c) {
     if (c && !c->kids.empty()) return m_ctx_destroy(c);
     if (!c) return SLA_OK;
+    // Background work of this context first: the copy lanes still being built (a context destroyed right after its creation tore its
+    // stream down under the lane thread's hipStreamCreate / hipHostMalloc: a segfault inside the runtime) and host buffers being released.
+    if (c->xfer_warmup.valid()) c->xfer_warmup.wait();
+    for (auto &f : c->deferred)
+        if (f.valid()) f.wait();
     {
     Bind bind(c);
     if (c->stream) (void)hipStreamSynchronize(c->stream);

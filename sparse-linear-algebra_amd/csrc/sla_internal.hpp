@@ -694,6 +694,17 @@ typedef void (*xfer_stage_fn)(void *slot, size_t off, size_t len, const void *ct
 hipError_t xfer_copy(sla_ctx *c, void *dst, const void *src, size_t bytes, hipMemcpyKind kind, const std::atomic<int> *stop = nullptr,
                      size_t *done = nullptr, xfer_stage_fn stage = nullptr, const void *stage_ctx = nullptr, bool ordered = false);
 void xfer_warm(int device, int lanes);
+// Background threads that outlive the call that started them (the lane warm-up, deferred releases) are counted; a process-exit handler
+// registered on the first context waits for the count to reach zero BEFORE the HIP runtime's own exit handler runs (a context alive at
+// exit -- a caller that never destroys it -- had the warm-up inside hipHostMalloc while the runtime unmapped itself: a segfault at exit).
+void bg_begin();
+void bg_end();
+void bg_exit_handler_once();
+struct BgTask {   // bg_begin() is the starter's (before the thread exists); the thread owns the matching bg_end()
+    BgTask() = default;
+    BgTask(const BgTask &) = delete;
+    ~BgTask() { bg_end(); }
+};
 // Run `release` (the destruction of large host buffers) on a background thread; finished ones are forgotten, the context's destructor
 // waits for the rest.
 template <class F>
@@ -702,7 +713,11 @@ inline void defer_release(sla_ctx *c, F &&release) {
     for (size_t i = 0; i < d.size();)
         if (d[i].wait_for(std::chrono::seconds(0)) == std::future_status::ready) { d[i] = std::move(d.back()); d.pop_back(); }
         else ++i;
-    d.push_back(std::async(std::launch::async, std::forward<F>(release)));
+    bg_begin();
+    d.push_back(std::async(std::launch::async, [r = std::forward<F>(release)]() mutable {
+        BgTask task;
+        r();
+    }));
 }
 int host_threads();   // sla_lower.cpp
 template <class F>

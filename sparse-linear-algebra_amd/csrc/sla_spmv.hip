@@ -32,7 +32,6 @@ int overlap_grid(const sla_csr *A, int part) {
 
 // does a plain (#>) on A end up on spmv_wave_kernel?  (the forms dispatched in front of it in launch_spmv_rp all have to be out)
 bool wave_plain(const sla_csr *A) {
-    const sla_ctx *c = A->ctx;
     return wave_on(A) && !A->is_panel_view && !diag_on(A) && !pipe_on(A) && !stream_xwin_on(A);
 }
 

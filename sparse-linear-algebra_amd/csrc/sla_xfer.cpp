@@ -11,6 +11,7 @@
 // the canonical CSR upload is abandoned that way when the matrix turns out to be value-indexed (sla_lower.cpp).
 #include <atomic>
 #include <condition_variable>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <thread>
@@ -204,6 +205,43 @@ void xfer_warm(int device, int lanes) {
     int ids[kXferMaxLanes];
     const int L = lanes_acquire(pool, std::max(1, std::min(lanes, kXferMaxLanes)), ids);
     if (L > 0) lanes_release(pool, L, ids);
+}
+
+namespace {
+struct BgGate {
+    std::mutex mu;
+    std::condition_variable cv;
+    int inflight = 0;
+};
+BgGate *bg_gate() {
+    static BgGate *g = new BgGate();   // never destroyed: threads may still touch it while statics are being torn down
+    return g;
+}
+void bg_wait_all() {
+    BgGate *g = bg_gate();
+    std::unique_lock<std::mutex> lk(g->mu);
+    g->cv.wait(lk, [g] { return g->inflight == 0; });
+}
+}  // namespace
+
+void bg_begin() {
+    BgGate *g = bg_gate();
+    std::lock_guard<std::mutex> lk(g->mu);
+    ++g->inflight;
+}
+void bg_end() {
+    BgGate *g = bg_gate();
+    {
+        std::lock_guard<std::mutex> lk(g->mu);
+        --g->inflight;
+    }
+    g->cv.notify_all();
+}
+// Exit handlers run in reverse order of registration: this one is registered after the HIP runtime initialised (and registered its own),
+// so it runs first.
+void bg_exit_handler_once() {
+    static std::once_flag once;
+    std::call_once(once, [] { (void)atexit(bg_wait_all); });
 }
 
 }  // namespace sla

@@ -503,3 +503,29 @@ def test_device_transpose_equals_the_host_transpose(sla, rp64):
             ctx.close()
         # the same arrays from both paths: the same kernel gives the same bits
         assert np.array_equal(got[2].view(np.uint64), got[0].view(np.uint64)), (dims, rp64)
+
+
+def test_process_exit_with_background_work_in_flight():
+    """A process that exits while the library still has background threads running (the pinned copy lanes of a new context being
+    built; large host buffers being released) must exit cleanly: the context is never destroyed here, as in a caller that leaks it.
+    (Before the exit handler of sla_xfer.cpp: a segfault inside the HIP runtime's own teardown, exit code 139.)"""
+    import os
+    import subprocess
+    import sys
+    pkg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "sparse-linear-algebra_amd")
+    cases = {
+        "context alive at exit": "import sla_amd as sla\nc = sla.Context(0)\n",
+        "context closed right away": "import sla_amd as sla\nc = sla.Context(0)\nc.close()\n",
+        "matrix from triples, then exit": (
+            "import sla_amd as sla, numpy as np\n"
+            "c = sla.Context(0)\n"
+            "n = 2000000\n"
+            "r = np.repeat(np.arange(n, dtype=np.int64), 3)\n"
+            "k = (r + np.tile(np.array([0, 7, 1000003], dtype=np.int64), n)) % n\n"
+            "M = sla.fromCOO((n, n), r, k, np.ones(3 * n), ctx=c)\n"),
+    }
+    env = dict(os.environ, PYTHONPATH=pkg + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    for name, src in cases.items():
+        for rep in range(4):
+            out = subprocess.run([sys.executable, "-c", src], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300, env=env)
+            assert out.returncode == 0, (name, rep, out.returncode, out.stderr[-400:])
