@@ -508,7 +508,7 @@ const IntKnob kIntKnobs[] = {
 const char *const kOtherKnobs[] = {"wd_grid", "spmv_algo", "panel_cols", "device_coo_min", "x_exchange"};
 
 // a whole decimal integer, nothing behind it ("1abc" is rejected)
-bool parse_int(const char *value, long long *out) {
+static bool parse_int(const char *value, long long *out) {
     char *end = nullptr;
     errno = 0;
     const long long v = strtoll(value, &end, 10);
@@ -517,7 +517,7 @@ bool parse_int(const char *value, long long *out) {
     return true;
 }
 // one option, by its lower-case name; false: unknown name or value out of range (the context is then unchanged)
-bool ctx_apply_option(sla_ctx *c, const std::string &name, const char *value) {
+static bool ctx_apply_option(sla_ctx *c, const std::string &name, const char *value) {
     for (const IntKnob &k : kIntKnobs)
         if (name == k.name) {
             long long v;
@@ -558,7 +558,7 @@ bool ctx_apply_option(sla_ctx *c, const std::string &name, const char *value) {
     }
     return false;
 }
-std::string ctx_option_value(const sla_ctx *c, const std::string &name, bool *known) {
+static std::string ctx_option_value(const sla_ctx *c, const std::string &name, bool *known) {
     *known = true;
     for (const IntKnob &k : kIntKnobs)
         if (name == k.name) return std::to_string(c->*(k.field));
@@ -570,7 +570,7 @@ std::string ctx_option_value(const sla_ctx *c, const std::string &name, bool *kn
     *known = false;
     return "";
 }
-std::string env_name(const char *knob) {
+static std::string env_name(const char *knob) {
     std::string e = "SLA_";
     for (const char *p = knob; *p; ++p) e += (char)toupper((unsigned char)*p);
     return e;

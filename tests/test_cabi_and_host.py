@@ -27,6 +27,14 @@ def test_library_exports_every_header_symbol():
     for s in syms:
         assert hasattr(L, s), f"libsla_hip.so does not export {s}"
     assert sorted(p[0] for p in _lib.PROTOTYPES) == syms, "ctypes prototypes drifted from include/sla_hip.h"
+    # ... and nothing else under a C name: helpers of the extern "C" block stay internal (static)
+    import shutil
+    import subprocess
+    nm = shutil.which("nm")
+    if nm:
+        out = subprocess.run([nm, "-D", "--defined-only", _lib.LIB_PATH], stdout=subprocess.PIPE, text=True, check=True).stdout
+        stray = [ln.split()[-1] for ln in out.splitlines() if " T " in ln and not ln.split()[-1].startswith(("sla_", "_Z", "__hip", "_init", "_fini"))]
+        assert stray == [], stray
 
 
 def test_no_cpu_fallback_without_gpu():
