@@ -622,10 +622,14 @@ static int ctx_create_common(int device_id, int rank, int nranks, const void *ui
     if (c->xfer) {       // the pinned copy lanes of this device, built while the caller assembles its matrix
         const int dev = c->device, lanes = c->xfer_lanes;
         bg_begin();
-        c->xfer_warmup = std::async(std::launch::async, [dev, lanes] {
-            BgTask task;
-            xfer_warm(dev, lanes);
-        });
+        try {
+            c->xfer_warmup = std::async(std::launch::async, [dev, lanes] {
+                BgTask task;
+                xfer_warm(dev, lanes);
+            });
+        } catch (...) {   // no thread to be had: the first large copy builds the lanes itself
+            bg_end();
+        }
     }
     if (uid) {
         int rc = dist_comm_init(c, uid);

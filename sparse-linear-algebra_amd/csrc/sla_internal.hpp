@@ -713,11 +713,17 @@ inline void defer_release(sla_ctx *c, F &&release) {
     for (size_t i = 0; i < d.size();)
         if (d[i].wait_for(std::chrono::seconds(0)) == std::future_status::ready) { d[i] = std::move(d.back()); d.pop_back(); }
         else ++i;
+    auto r = std::make_shared<typename std::decay<F>::type>(std::forward<F>(release));
     bg_begin();
-    d.push_back(std::async(std::launch::async, [r = std::forward<F>(release)]() mutable {
-        BgTask task;
-        r();
-    }));
+    try {
+        d.push_back(std::async(std::launch::async, [r] {
+            BgTask task;
+            (*r)();
+        }));
+    } catch (...) {   // no thread to be had: release here (the count must not stay up, the exit handler waits for it)
+        bg_end();
+        (*r)();
+    }
 }
 int host_threads();   // sla_lower.cpp
 template <class F>
