@@ -14,6 +14,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <new>
+#include <pthread.h>
 #include <thread>
 #include <vector>
 
@@ -241,7 +243,11 @@ void bg_end() {
 // so it runs first.
 void bg_exit_handler_once() {
     static std::once_flag once;
-    std::call_once(once, [] { (void)atexit(bg_wait_all); });
+    std::call_once(once, [] {
+        (void)atexit(bg_wait_all);
+        // a forked child has the count but not the threads: it would wait for ever at its own exit
+        (void)pthread_atfork(nullptr, nullptr, [] { new (bg_gate()) BgGate(); });
+    });
 }
 
 }  // namespace sla

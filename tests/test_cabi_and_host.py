@@ -214,3 +214,39 @@ def test_oracle_panel_order_fold():
                 if A.colidx[k] >> shift == j:
                     acc = acc + A.val[k] * x[A.colidx[k]]
         assert y[i] == acc
+
+
+def test_background_gate_and_forked_children():
+    """The process-exit handler of csrc/sla_xfer.cpp waits for the library's background threads (counted by bg_begin / bg_end).  A forked
+    child inherits the count but not the threads: its own exit must not wait for them (the at-fork handler resets the gate)."""
+    import subprocess
+    import sys
+    from sla_amd import _lib
+    src = r'''
+import ctypes, os, sys, time
+L = ctypes.CDLL(sys.argv[1])
+once, begin, end = (getattr(L, n) for n in ("_ZN3sla20bg_exit_handler_onceEv", "_ZN3sla8bg_beginEv", "_ZN3sla6bg_endEv"))
+for f in (once, begin, end):
+    f.restype = None
+once()
+begin()                       # a background task of the parent is "in flight"
+pid = os.fork()
+if pid == 0:
+    ctypes.CDLL(None).exit(0)  # C exit(): runs the exit handlers, the gate's among them
+t0 = time.time()
+while True:
+    got, status = os.waitpid(pid, os.WNOHANG)
+    if got == pid:
+        break
+    if time.time() - t0 > 20.0:
+        os.kill(pid, 9)
+        print("child hung at exit")
+        end()
+        sys.exit(3)
+    time.sleep(0.01)
+end()                         # the parent's task is over: its own exit goes through the handler too
+print("child status", status)
+sys.exit(0 if status == 0 else 4)
+'''
+    out = subprocess.run([sys.executable, "-c", src, _lib.LIB_PATH], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout[-600:]
