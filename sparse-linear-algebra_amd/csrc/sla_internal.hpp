@@ -101,6 +101,11 @@ constexpr int kTileWaves = SLA_TILE_WAVES;  // wavefronts of its workgroup that 
 constexpr int kTileRows = SLA_TILE_ROWS;  // rows per slice of spmv_tile_kernel: one wavefront's row sums in LDS (38 KiB; 4 x 4896 x 8 B + the pacing tables = all of the CU's 160 KiB)
 constexpr int kTileBlocksPerCu = SLA_TILE_OCC;  // its resident workgroups per CU (1 x 128 KiB of LDS, 4 wavefronts with 12 x 64 gathers in flight each: few, fat
                                                 // wavefronts drift apart less and keep more misses in flight than 16 thin ones -- 2.26 -> 1.98 ms at 10 M rows)
+#ifndef SLA_CT_ROWS
+#define SLA_CT_ROWS 19584
+#endif
+constexpr int kCtRows = SLA_CT_ROWS;  // rows per slice of spmv_ctile_kernel (round 5): ONE array of row sums shared by the workgroup's four wavefronts (153 KiB of the CU's 160)
+constexpr int kCtWaves = 4;           // its wavefronts (= kBlock / 64): the layout deals a tile's 64-entry groups to them
 constexpr int kMaxParts = 2048;      // partial-sum slots per reduction (256 CUs x 8)
 constexpr int kVecGridMax = 1024;    // grid cap of the streaming BLAS-1 kernels
 constexpr int kSpmvGridMax = 2048;   // persistent grid cap of the SpMV kernels
@@ -250,6 +255,8 @@ struct sla_ctx {
                                      // first-touch allocation less at 216^3
     int transpose_device = 1;        // transposeSM of a lowered matrix as a device sort (1: from 2^18 entries on, 2: always, 0: host)
     int canon_device = 1;            // value-indexed matrices: canonical col / val written on the device from the 1-byte codes instead of uploaded
+    int tile_cu = 1;                 // 1: CU-wide slices (spmv_ctile_kernel, round 5: 64 consecutive column-sorted entries per gather instruction share x lines), 0: wavefront-private slices (rounds 2-4)
+    int tile_relaxed = 0;            // CU-wide slices only: 1 = one column-sorted run per tile, LDS floating-point atomics, no barriers (row sums within nnz_i eps sum|a_ij x_j|, not bit-exact)
     int tile_prefetch = 0;           // x-panel prefetch distance of spmv_tile_kernel in visit steps (0: demand misses only; measured: never a gain)
     int tile_poll = 1;               // 1: pacing slots polled one step ahead, 0: dependent poll in front of every tile (rounds 2-3)
     int tile_slack = 3;              // panel pacing: a wavefront starts panel step q once its XCD has finished step q - slack (SLA_TILE_SLACK, 0: no pacing)
@@ -416,6 +423,8 @@ struct sla_csr {
     unsigned *d_tlprog = nullptr;    // per-XCD (round, panel) arrival counters of the launch in flight (panel pacing)
     size_t tlprog_bytes = 0;
     int64_t tl_maxseg = 0;           // longest (row, panel) segment = layers of the deepest tile
+    bool tl_cu = false;              // CU-wide slices (sla_spmv_ctiles.hip): entries [slice][wavefront][panel][phase], d_tloff = tl_S x 4 x (2 tl_P + 1)
+    bool tl_relaxed = false;         // ... built for the relaxed-order kernel (everything in phase 0)
     sla_tri_plan *tri[2] = {nullptr, nullptr};  // [0] lower, [1] upper triangle schedules (built on first use)
     // comm / compute overlap of the sharded (#>) (wave-sliced forms): the 512-row steps whose rows reference own columns only
     // (interior: they can run while the halo exchange is in flight) and the rest, each in the visiting order of d_wsched
@@ -822,11 +831,15 @@ bool pipe_on(const sla_csr *A);                                                 
 int launch_spmv_pipe(const sla_csr *A, int epi, const SpmvArgs<int32_t> &a, int grid);
 int launch_spmv_pipe(const sla_csr *A, int epi, const SpmvArgs<int64_t> &a, int grid);
 int tiles_grid(const sla_csr *A);
+int launch_spmv_ctiles(const sla_csr *A, const SpmvLaunch &l);   // sla_spmv_ctiles.hip (CU-wide slices)
+int ctiles_grid(const sla_csr *A);
 int probe_xcd_layout(sla_ctx *c);   // sets c->xcd8 (sla_spmv_tiles.hip)
 // sla_lower_tiles.cpp: builds the tile form of A when it pays (irregular structure, x larger than the L2); no-op otherwise
 int build_tiles(sla_csr *A, int64_t n, int64_t rows, const int64_t *rowptr, const int64_t *col, const double *val);
 // sla_tiles_build.hip: the same re-ordering on the device from A's canonical arrays (*done = false: not taken, use the host builder)
 int build_tiles_device(sla_csr *A, const std::vector<int32_t> &srow, int shift, int64_t P, int64_t *maxseg_out, int64_t *nbreaks_out, bool *done);
+// ... and the CU-wide layout of sla_spmv_ctiles.hip (relaxed: one column-sorted run per tile)
+int build_ctiles_device(sla_csr *A, const std::vector<int32_t> &srow, int shift, int64_t P, bool relaxed, int64_t *maxseg_out, int64_t *nbreaks_out, bool *done);
 
 int vec_grid(int64_t n_local);
 // p1[b] = sum x.y over block b's elements (grid = vec_grid)

@@ -18,30 +18,164 @@
 
 namespace sla {
 
+namespace {
+// The CU-wide layout of sla_spmv_ctiles.hip on the host (small matrices, option tiles_device = 0, and the cross-check of the device
+// builder: both produce the same bits).  Per slice: the entries keyed like sla_tiles_build.hip's ctile_keys_kernel, sorted (ties: input
+// order), phase-0 groups of 64 dealt round-robin to the four wavefronts, phase-1 entries to the wavefront (local row & 3).
+template <typename Finish>
+int build_ctiles_host(sla_csr *A, const std::vector<int32_t> &srow, int shift, int64_t P, bool relaxed, const int64_t *rowptr, const int64_t *col,
+                      const double *val, Finish finish) {
+    sla_ctx *c = A->ctx;
+    const int64_t S = (int64_t)srow.size() - 1, nnz = rowptr[srow.back()];
+    const size_t rowlen = (size_t)(2 * P + 1);
+    std::vector<uint32_t> toff((size_t)S * kCtWaves * rowlen);
+    std::vector<uint32_t> tidx((size_t)nnz);
+    std::vector<double> tval((size_t)nnz);
+    const uint32_t cmask = (uint32_t)(((int64_t)1 << shift) - 1);
+    int T = (int)std::min<int64_t>(std::max(1u, std::min(16u, std::thread::hardware_concurrency())), S);
+    if (const char *e = getenv("SLA_HOST_THREADS")) T = std::max(1, std::min(atoi(e), 64));
+    if (nnz < 2000000) T = 1;
+    std::vector<int64_t> maxseg((size_t)T, 0), breaks((size_t)T, 0);
+    struct Ent { uint64_t key; int64_t k; uint32_t rl; };
+    auto work = [&](int t) {
+        std::vector<Ent> ent;
+        int64_t mseg = 0, nbreaks = 0;
+        for (int64_t s = S * t / T; s < S * (t + 1) / T; ++s) {
+            const int64_t r0 = srow[(size_t)s], r1 = srow[(size_t)s + 1], k0 = rowptr[r0];
+            ent.clear();
+            // key = ((panel << 1 | phase) << 40) | sub;  phase 1 sub = owner << 38 | layer << shift | column  (layer < 2^(38 - shift))
+            for (int64_t i = r0; i < r1; ++i) {
+                int64_t prev = -1, layer = 0;
+                for (int64_t k = rowptr[i]; k < rowptr[i + 1]; ++k) {
+                    const int64_t j = col[k] >> shift;
+                    layer = j == prev ? layer + 1 : 0;
+                    prev = j;
+                    mseg = std::max(mseg, layer + 1);
+                    const uint64_t cc = (uint32_t)col[k] & cmask;
+                    const bool ph = !relaxed && layer > 0;
+                    const uint32_t rl = (uint32_t)(i - r0);
+                    const uint64_t sub = ph ? ((uint64_t)(rl & 3u) << 38) | ((uint64_t)layer << shift) | cc : cc;
+                    ent.push_back({((uint64_t)j << 41) | ((uint64_t)(ph ? 1 : 0) << 40) | sub, k, rl});
+                }
+            }
+            std::sort(ent.begin(), ent.end(), [](const Ent &x, const Ent &y) { return x.key != y.key ? x.key < y.key : x.k < y.k; });
+            // ranges of every (panel, phase, wavefront)
+            uint32_t *off = toff.data() + (size_t)s * kCtWaves * rowlen;
+            std::vector<size_t> b((size_t)P * 5 + 1);
+            {
+                size_t o = 0;
+                for (int64_t j = 0; j < P; ++j)
+                    for (int which = 0; which < 5; ++which) {
+                        uint64_t want = (uint64_t)j << 41;
+                        if (which > 0) want |= ((uint64_t)1 << 40) | ((uint64_t)(which - 1) << 38);
+                        while (o < ent.size() && ent[o].key < want) ++o;
+                        b[(size_t)j * 5 + which] = o;
+                    }
+                b[(size_t)P * 5] = ent.size();
+            }
+            for (int64_t j = 0; j < P; ++j) {
+                const size_t *bb = b.data() + (size_t)j * 5;
+                const uint32_t n0 = (uint32_t)(bb[1] - bb[0]), G = (n0 + 63) >> 6, tail = n0 & 63;
+                for (uint32_t w = 0; w < 4; ++w) {
+                    uint32_t ng = G > w ? (G - w + 3) >> 2 : 0, na = ng * 64;
+                    if (tail && G > 0 && ((G - 1) & 3) == w) na -= 64 - tail;
+                    off[w * rowlen + 2 * (size_t)j] = na;
+                    off[w * rowlen + 2 * (size_t)j + 1] = (uint32_t)(bb[2 + w] - bb[1 + w]);   // (bb[5] = the next tile's start)
+                }
+            }
+            uint32_t run = 0;
+            for (uint32_t w = 0; w < 4; ++w)
+                for (size_t q = 0; q <= (size_t)(2 * P); ++q) {
+                    uint32_t &o = off[w * rowlen + q];
+                    if (q == (size_t)(2 * P)) { o = run; break; }
+                    const uint32_t cnt = o;
+                    o = run;
+                    run += cnt;
+                }
+            for (size_t o = 0; o < ent.size(); ++o) {
+                const Ent &e = ent[o];
+                const int64_t j = (int64_t)(e.key >> 41);
+                const int ph = (int)((e.key >> 40) & 1);
+                const size_t *bb = b.data() + (size_t)j * 5;
+                const uint32_t cc = (uint32_t)col[e.k] & cmask;
+                uint32_t w, rank, word;
+                if (ph == 0) {
+                    const uint32_t tt = (uint32_t)(o - bb[0]), g = tt >> 6;
+                    w = g & 3;
+                    rank = ((g >> 2) << 6) + (tt & 63);
+                    word = (e.rl << shift) | cc;
+                } else {
+                    w = (uint32_t)(e.key >> 38) & 3u;
+                    rank = (uint32_t)(o - bb[1 + w]);
+                    const uint32_t first = rank > 0 && ((ent[o - 1].key >> shift) != (e.key >> shift));
+                    word = (first << 31) | ((e.rl >> 2) << shift) | cc;
+                    nbreaks += first;
+                }
+                const size_t dst = (size_t)(k0 + off[w * rowlen + 2 * (size_t)j + ph] + rank);
+                tidx[dst] = word;
+                tval[dst] = val[e.k];
+            }
+        }
+        maxseg[(size_t)t] = mseg;
+        breaks[(size_t)t] = nbreaks;
+    };
+    if (T == 1) {
+        work(0);
+    } else {
+        std::vector<std::thread> th;
+        for (int t = 0; t < T; ++t) th.emplace_back(work, t);
+        for (auto &x : th) x.join();
+    }
+    A->tl_maxseg = *std::max_element(maxseg.begin(), maxseg.end());
+    if (A->tl_maxseg >= ((int64_t)1 << (38 - shift))) { A->lower_log += "tile form not taken=segment length;"; return SLA_OK; }   // (layer field of the host key; such rows belong to the LDS-panel / stream kernels anyway)
+    {
+        int64_t nb = 0;
+        for (int64_t x : breaks) nb += x;
+        if (nb * 2 > nnz) { A->lower_log += "tile form not taken=layer boundaries (dense rows);"; return SLA_OK; }   // (per wavefront: four layer sequences per tile)
+    }
+    hipError_t err = hipSuccess;
+    auto upload = [&](void **dst, const void *src, size_t bytes) {
+        if (err != hipSuccess) return;
+        err = dev_malloc(c, dst, std::max<size_t>(bytes + 64, 8));
+        if (err == hipSuccess && bytes) err = hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
+    };
+    upload((void **)&A->d_tloff, toff.data(), sizeof(uint32_t) * toff.size());
+    upload((void **)&A->d_tlidx, tidx.data(), sizeof(uint32_t) * tidx.size());
+    upload((void **)&A->d_tlval, tval.data(), sizeof(double) * tval.size());
+    if (err != hipSuccess) return fail(SLA_ERR_ALLOC, std::string("tile form upload: ") + hipGetErrorString(err));
+    A->lower_log += "cu tiles=1;";
+    return finish();
+}
+}  // namespace
+
 int build_tiles(sla_csr *A, int64_t n, int64_t rows, const int64_t *rowptr, const int64_t *col, const double *val) {
     sla_ctx *c = A->ctx;
     const int64_t nnz = rowptr[rows];
     if (!c->tiles || rows == 0 || nnz == 0) return SLA_OK;
+    auto skip = [&](const char *why) { A->lower_log += std::string("tile form not taken=") + why + ";"; return SLA_OK; };   // (sla_csr_lower_info)
     if (A->use_diag || A->use_wdia || A->use_vdict || A->xwin_fraction >= 0.5) return SLA_OK;   // stencil / banded structure
     if ((A->use_lpanel && c->lpanel) || (A->use_lflat && c->lflat)) return SLA_OK;               // dense / medium rows: x panels in LDS
     {   // the kernel keeps one slice's row sums per wavefront in static LDS (4 x kTileRows doubles = 153 KiB of the MI355X's 160 KiB)
         int lds = 0;
         if (hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, c->device) != hipSuccess ||
-            (int64_t)lds < (int64_t)kTileWaves * kTileRows * 8 + 1024)
-            return SLA_OK;
+            (int64_t)lds < (int64_t)kTileWaves * kTileRows * 8 + 1024 || (int64_t)lds < (int64_t)kCtRows * 8 + 2048)
+            return skip("LDS per workgroup");
     }
+    // round 5: CU-wide slices (sla_spmv_ctiles.hip) -- one slice of kCtRows rows per WORKGROUP, its row sums shared by the four wavefronts
+    const bool cu = c->tile_cu != 0, relaxed = cu && c->tile_relaxed != 0;
+    const int64_t slice_rows = cu ? kCtRows : kTileRows;
     int row_bits = 0;
-    while (((int64_t)1 << row_bits) < kTileRows) ++row_bits;
+    while (((int64_t)1 << row_bits) < slice_rows) ++row_bits;
     // panel width: 2^17 columns (1 MiB of x) at 10 M rows, 2^16 below ~6 M (measured: 7-8 % faster at 0.5 / 1 / 3 M rows, 3-15 % slower at 10 M)
     const int want = c->tile_shift > 0 ? c->tile_shift : (n < 6000000 ? 16 : 17);
-    const int shift = std::max(10, std::min(31 - row_bits, want));   // (layer flag, slice row, panel column) packed in 32 bits
+    const int shift = std::max(10, std::min((cu ? 32 : 31) - row_bits, want));   // (layer flag, slice row, panel column) packed in 32 bits (CU-wide: no flag in phase 0, row >> 2 in phase 1)
     const int64_t W = (int64_t)1 << shift;
     if (n <= 2 * W || (c->tile_shift <= 0 && n <= ((int64_t)1 << 18))) return SLA_OK;   // x (nearly) fits the L2 already
     const int64_t P = (n + W - 1) / W;
-    if (P > 16384) return SLA_OK;
+    if (P > 16384) return skip("more than 16384 panels");
     // slices: whole rounds of the persistent grid (kTileBlocksPerCu workgroup(s) of 4 wavefronts per CU)
-    const int64_t waves = (int64_t)kTileBlocksPerCu * c->n_cu * kTileWaves;
-    const int64_t rounds = std::max<int64_t>(1, (rows + (int64_t)kTileRows * waves - 1) / ((int64_t)kTileRows * waves));
+    const int64_t waves = cu ? (int64_t)c->n_cu : (int64_t)kTileBlocksPerCu * c->n_cu * kTileWaves;   // (CU-wide: slice owners = workgroups)
+    const int64_t rounds = std::max<int64_t>(1, (rows + slice_rows * waves - 1) / (slice_rows * waves));
     int64_t S0 = rounds * waves;
     S0 = std::max<int64_t>(1, std::min<int64_t>(S0, (rows + 63) / 64));
     const int64_t target = (nnz + S0 - 1) / S0;
@@ -52,17 +186,18 @@ int build_tiles(sla_csr *A, int64_t n, int64_t rows, const int64_t *rowptr, cons
         int64_t r = 0;
         while (r < rows) {
             // close the slice at kTileRows rows or once it holds `target` entries (a row is never split)
-            const int64_t rcap = std::min<int64_t>(rows, r + kTileRows);
+            const int64_t rcap = std::min<int64_t>(rows, r + slice_rows);
             const int64_t want = rowptr[r] + target;
             int64_t e = std::upper_bound(rowptr + r + 1, rowptr + rcap + 1, want) - rowptr;   // first row end beyond the target
             e = std::max<int64_t>(r + 1, std::min<int64_t>(e, rcap));
-            if (rowptr[e] - rowptr[r] > (int64_t)std::numeric_limits<uint32_t>::max() - 1024) return SLA_OK;   // 32-bit tile offsets
+            if (rowptr[e] - rowptr[r] > (int64_t)std::numeric_limits<uint32_t>::max() - 1024) return skip("slice beyond 32-bit offsets");   // 32-bit tile offsets
             srow.push_back((int32_t)e);
             r = e;
         }
     }
     const int64_t S = (int64_t)srow.size() - 1;
-    if (S * (P + 1) > ((int64_t)1 << 31) || S * (P + 1) * 4 > nnz * 12 / 2) return SLA_OK;   // offset table must stay a fraction of the matrix
+    const int64_t ntoff = cu ? S * kCtWaves * (2 * P + 1) : S * (P + 1);
+    if (ntoff > ((int64_t)1 << 31) || ntoff * 4 > nnz * 12 / 2) return skip("offset table larger than half the matrix");   // offset table must stay a fraction of the matrix
     auto finish = [&]() -> int {   // what both builders share once d_tlidx / d_tlval / d_tloff exist: slice starts, pacing table, geometry
         hipError_t e2 = dev_malloc(c, (void **)&A->d_tlrow, sizeof(int32_t) * srow.size() + 64);
         if (e2 == hipSuccess) e2 = hipMemcpy(A->d_tlrow, srow.data(), sizeof(int32_t) * srow.size(), hipMemcpyHostToDevice);
@@ -73,6 +208,8 @@ int build_tiles(sla_csr *A, int64_t n, int64_t rows, const int64_t *rowptr, cons
         A->tl_S = (int32_t)S;
         A->tl_P = (int32_t)P;
         A->tl_shift = shift;
+        A->tl_cu = cu;
+        A->tl_relaxed = relaxed;
         A->use_tiles = true;
         return SLA_OK;
     };
@@ -82,18 +219,20 @@ int build_tiles(sla_csr *A, int64_t n, int64_t rows, const int64_t *rowptr, cons
     if (c->tiles_device == 2 || (c->tiles_device == 1 && nnz >= ((int64_t)1 << 20))) {
         int64_t mseg = 0, nb = 0;
         bool done = false;
-        SLA_TRY(build_tiles_device(A, srow, shift, P, &mseg, &nb, &done));
+        if (cu) SLA_TRY(build_ctiles_device(A, srow, shift, P, relaxed, &mseg, &nb, &done));
+        else SLA_TRY(build_tiles_device(A, srow, shift, P, &mseg, &nb, &done));
         if (done) {
             A->tl_maxseg = mseg;
-            if (nb * 8 > nnz) {   // (dense rows: see the host builder's test below)
+            if (nb * (cu ? 2 : 8) > nnz) {   // (dense rows: see the host builder's test below; CU-wide: boundaries are counted per wavefront)
                 (void)hipFree(A->d_tlidx); (void)hipFree(A->d_tlval); (void)hipFree(A->d_tloff);
                 A->d_tlidx = nullptr; A->d_tlval = nullptr; A->d_tloff = nullptr;
-                return SLA_OK;
+                return skip("layer boundaries (dense rows)");
             }
-            A->lower_log += "tile builder on device=1;";
+            A->lower_log += cu ? "tile builder on device=1;cu tiles=1;" : "tile builder on device=1;";
             return finish();
         }
     }
+    if (cu) return build_ctiles_host(A, srow, shift, P, relaxed, rowptr, col, val, finish);
     std::vector<uint32_t> toff((size_t)(S * (P + 1)));
     std::vector<uint32_t> tidx((size_t)nnz);
     std::vector<double> tval((size_t)nnz);
@@ -186,7 +325,7 @@ int build_tiles(sla_csr *A, int64_t n, int64_t rows, const int64_t *rowptr, cons
         // (dense rows) belong to the LDS-panel / stream kernels
         int64_t nb = 0;
         for (int64_t b : breaks) nb += b;
-        if (nb * 8 > nnz) return SLA_OK;
+        if (nb * 8 > nnz) return skip("layer boundaries (dense rows)");
     }
     hipError_t err = hipSuccess;
     auto upload = [&](void **dst, const void *src, size_t bytes) {

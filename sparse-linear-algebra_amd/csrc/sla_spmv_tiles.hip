@@ -384,6 +384,7 @@ int probe_xcd_layout(sla_ctx *c) {
 bool tiles_on(const sla_csr *A) { return A->use_tiles && A->ctx->tiles && A->ctx->spmv_algo == 0; }
 
 int tiles_grid(const sla_csr *A) {
+    if (A->tl_cu) return ctiles_grid(A);
     const int64_t blocks = ((int64_t)A->tl_S + kTileWaves - 1) / kTileWaves;
     return (int)std::max<int64_t>(1, std::min<int64_t>(blocks, (int64_t)kTileBlocksPerCu * A->ctx->n_cu));
 }
@@ -443,6 +444,7 @@ static int launch_tiles_rp(const sla_csr *A, const SpmvLaunch &l) {
 }
 
 int launch_spmv_tiles(const sla_csr *A, const SpmvLaunch &l) {
+    if (A->tl_cu) return launch_spmv_ctiles(A, l);   // CU-wide slices (round 5)
     return A->rp64 ? launch_tiles_rp<int64_t>(A, l) : launch_tiles_rp<int32_t>(A, l);
 }
 

@@ -381,7 +381,10 @@ class SpMatrix:
         for tok in buf.value.decode().split(";"):
             if "=" in tok:
                 k, v = tok.rsplit("=", 1)
-                out[k] = out.get(k, 0.0) + float(v)
+                try:
+                    out[k] = out.get(k, 0.0) + float(v)
+                except (TypeError, ValueError):   # a note, e.g. "tile form not taken=layer boundaries (dense rows)"
+                    out[k] = v
         return out
 
     def __eq__(self, o):                          # structural, like the derived Eq
