@@ -495,7 +495,6 @@ const IntKnob kIntKnobs[] = {
     {"tile_shift", &sla_ctx::tile_shift, 0, 20},
     {"tile_slack", &sla_ctx::tile_slack, 0, 64},
     {"tile_prefetch", &sla_ctx::tile_prefetch, 0, 16},
-    {"tile_cu", &sla_ctx::tile_cu, 0, 1},
     {"tile_relaxed", &sla_ctx::tile_relaxed, 0, 1},
     {"canon_device", &sla_ctx::canon_device, 0, 2},
     {"canon_lazy", &sla_ctx::canon_lazy, 0, 1},
@@ -983,7 +982,7 @@ int sla_csr_kernel_info(sla_csr_t A, char *buf, int buflen) {
         else if (A->use_vdict && c->vdict) mb = A->nnz + 4 * (A->rows + 1);
         else if (A->use_lpanel && c->lpanel) mb = (A->d_lpcol ? 10 : 12) * A->nnz + (int64_t)(A->lp_P + 1) * A->rows * rps + 16 * (int64_t)A->lp_P * A->rows;
         else if (lflat_on(A)) mb = 10 * A->nnz + 4 * ((int64_t)A->lp_C * A->rows + 1) + 16 * (int64_t)A->lp_P * A->rows;   // copy + segment starts + one partial per (row, panel range)
-        else if (tiles_on(A)) mb = 12 * A->nnz + 4 * (A->tl_cu ? (int64_t)A->tl_S * kCtWaves * (2 * A->tl_P + 1) : (int64_t)A->tl_S * (A->tl_P + 1)) + 4 * ((int64_t)A->tl_S + 1) + rps * A->tl_S;
+        else if (tiles_on(A)) mb = 12 * A->nnz + 4 * (A->tl_cu ? (int64_t)A->tl_S * kCtWaves * (A->tl_P + 1) : (int64_t)A->tl_S * (A->tl_P + 1)) + 4 * ((int64_t)A->tl_S + 1) + rps * A->tl_S;
         else if (!A->panels.empty() && c->panels) mb = 12 * A->nnz + (int64_t)A->panels.size() * (rps * A->rows + 8 * (int64_t)A->nrb) + 16 * ((int64_t)A->panels.size() - 1) * A->rows;
         else mb = (diag_on(A) ? 9 : 12) * A->nnz + rps * (A->rows + 1) + (4 + rps) * (int64_t)A->nrb;
         const size_t used = strlen(buf);
@@ -997,7 +996,7 @@ int sla_csr_kernel_info(sla_csr_t A, char *buf, int buflen) {
         const size_t used = strlen(buf);
         if (used + 1 < (size_t)buflen)
             snprintf(buf + used, (size_t)buflen - used, " slices=%d panels=%d panel_cols=%d max_segment=%lld exact_fold=%d cu_slices=%d pacing=%s", A->tl_S, A->tl_P,
-                     1 << A->tl_shift, (long long)A->tl_maxseg, A->tl_relaxed ? 0 : 1, A->tl_cu ? 1 : 0, A->ctx->xcd8 == 1 && A->ctx->tile_slack > 0 ? "on" : "off");
+                     1 << A->tl_shift, (long long)A->tl_maxseg, A->tl_cu ? 0 : 1, A->tl_cu ? 1 : 0, A->ctx->xcd8 == 1 && A->ctx->tile_slack > 0 ? "on" : "off");
     }
     if (ag_split(A)) {   // overlapped all-gather: exchange groups and panel passes of this rank
         const size_t used = strlen(buf);

@@ -255,8 +255,9 @@ struct sla_ctx {
                                      // first-touch allocation less at 216^3
     int transpose_device = 1;        // transposeSM of a lowered matrix as a device sort (1: from 2^18 entries on, 2: always, 0: host)
     int canon_device = 1;            // value-indexed matrices: canonical col / val written on the device from the 1-byte codes instead of uploaded
-    int tile_cu = 1;                 // 1: CU-wide slices (spmv_ctile_kernel, round 5: 64 consecutive column-sorted entries per gather instruction share x lines), 0: wavefront-private slices (rounds 2-4)
-    int tile_relaxed = 0;            // CU-wide slices only: 1 = one column-sorted run per tile, LDS floating-point atomics, no barriers (row sums within nnz_i eps sum|a_ij x_j|, not bit-exact)
+    int tile_relaxed = 1;            // the tile form of irregular matrices: 1 = CU-wide slices (spmv_ctile_kernel, round 5: column-sorted gathers that share x lines, row sums by LDS
+                                     // atomics in relaxed order -- within nnz_i eps sum|a_ij x_j| of the reference's fold, not reproducible bit for bit), 0 = wavefront-private slices
+                                     // (spmv_tile_kernel, rounds 2-4: the reference's left fold bit for bit; 18 % slower on config 3a, 2.2 x on power-law rows)
     int tile_prefetch = 0;           // x-panel prefetch distance of spmv_tile_kernel in visit steps (0: demand misses only; measured: never a gain)
     int tile_poll = 1;               // 1: pacing slots polled one step ahead, 0: dependent poll in front of every tile (rounds 2-3)
     int tile_slack = 3;              // panel pacing: a wavefront starts panel step q once its XCD has finished step q - slack (SLA_TILE_SLACK, 0: no pacing)
@@ -423,8 +424,7 @@ struct sla_csr {
     unsigned *d_tlprog = nullptr;    // per-XCD (round, panel) arrival counters of the launch in flight (panel pacing)
     size_t tlprog_bytes = 0;
     int64_t tl_maxseg = 0;           // longest (row, panel) segment = layers of the deepest tile
-    bool tl_cu = false;              // CU-wide slices (sla_spmv_ctiles.hip): entries [slice][wavefront][panel][phase], d_tloff = tl_S x 4 x (2 tl_P + 1)
-    bool tl_relaxed = false;         // ... built for the relaxed-order kernel (everything in phase 0)
+    bool tl_cu = false;              // CU-wide slices, relaxed order (sla_spmv_ctiles.hip): entries [slice][wavefront][panel], d_tloff = tl_S x 4 x (tl_P + 1)
     sla_tri_plan *tri[2] = {nullptr, nullptr};  // [0] lower, [1] upper triangle schedules (built on first use)
     // comm / compute overlap of the sharded (#>) (wave-sliced forms): the 512-row steps whose rows reference own columns only
     // (interior: they can run while the halo exchange is in flight) and the rest, each in the visiting order of d_wsched
@@ -839,7 +839,7 @@ int build_tiles(sla_csr *A, int64_t n, int64_t rows, const int64_t *rowptr, cons
 // sla_tiles_build.hip: the same re-ordering on the device from A's canonical arrays (*done = false: not taken, use the host builder)
 int build_tiles_device(sla_csr *A, const std::vector<int32_t> &srow, int shift, int64_t P, int64_t *maxseg_out, int64_t *nbreaks_out, bool *done);
 // ... and the CU-wide layout of sla_spmv_ctiles.hip (relaxed: one column-sorted run per tile)
-int build_ctiles_device(sla_csr *A, const std::vector<int32_t> &srow, int shift, int64_t P, bool relaxed, int64_t *maxseg_out, int64_t *nbreaks_out, bool *done);
+int build_ctiles_device(sla_csr *A, const std::vector<int32_t> &srow, int shift, int64_t P, bool *done);
 
 int vec_grid(int64_t n_local);
 // p1[b] = sum x.y over block b's elements (grid = vec_grid)

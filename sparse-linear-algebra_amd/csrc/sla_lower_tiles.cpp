@@ -20,14 +20,14 @@ namespace sla {
 
 namespace {
 // The CU-wide layout of sla_spmv_ctiles.hip on the host (small matrices, option tiles_device = 0, and the cross-check of the device
-// builder: both produce the same bits).  Per slice: the entries keyed like sla_tiles_build.hip's ctile_keys_kernel, sorted (ties: input
-// order), phase-0 groups of 64 dealt round-robin to the four wavefronts, phase-1 entries to the wavefront (local row & 3).
+// builder: both produce the same bits).  Per slice: the entries sorted by (panel, column inside the panel; ties: input order =
+// ascending rows), every tile's groups of 64 dealt round-robin to the four wavefronts.
 template <typename Finish>
-int build_ctiles_host(sla_csr *A, const std::vector<int32_t> &srow, int shift, int64_t P, bool relaxed, const int64_t *rowptr, const int64_t *col,
-                      const double *val, Finish finish) {
+int build_ctiles_host(sla_csr *A, const std::vector<int32_t> &srow, int shift, int64_t P, const int64_t *rowptr, const int64_t *col, const double *val,
+                      Finish finish) {
     sla_ctx *c = A->ctx;
     const int64_t S = (int64_t)srow.size() - 1, nnz = rowptr[srow.back()];
-    const size_t rowlen = (size_t)(2 * P + 1);
+    const size_t rowlen = (size_t)(P + 1);
     std::vector<uint32_t> toff((size_t)S * kCtWaves * rowlen);
     std::vector<uint32_t> tidx((size_t)nnz);
     std::vector<double> tval((size_t)nnz);
@@ -35,89 +35,46 @@ int build_ctiles_host(sla_csr *A, const std::vector<int32_t> &srow, int shift, i
     int T = (int)std::min<int64_t>(std::max(1u, std::min(16u, std::thread::hardware_concurrency())), S);
     if (const char *e = getenv("SLA_HOST_THREADS")) T = std::max(1, std::min(atoi(e), 64));
     if (nnz < 2000000) T = 1;
-    std::vector<int64_t> maxseg((size_t)T, 0), breaks((size_t)T, 0);
-    struct Ent { uint64_t key; int64_t k; uint32_t rl; };
+    struct Ent { int64_t col, k; uint32_t rl; };
     auto work = [&](int t) {
         std::vector<Ent> ent;
-        int64_t mseg = 0, nbreaks = 0;
+        std::vector<size_t> b((size_t)P + 1);
         for (int64_t s = S * t / T; s < S * (t + 1) / T; ++s) {
             const int64_t r0 = srow[(size_t)s], r1 = srow[(size_t)s + 1], k0 = rowptr[r0];
             ent.clear();
-            // key = ((panel << 1 | phase) << 40) | sub;  phase 1 sub = owner << 38 | layer << shift | column  (layer < 2^(38 - shift))
-            for (int64_t i = r0; i < r1; ++i) {
-                int64_t prev = -1, layer = 0;
-                for (int64_t k = rowptr[i]; k < rowptr[i + 1]; ++k) {
-                    const int64_t j = col[k] >> shift;
-                    layer = j == prev ? layer + 1 : 0;
-                    prev = j;
-                    mseg = std::max(mseg, layer + 1);
-                    const uint64_t cc = (uint32_t)col[k] & cmask;
-                    const bool ph = !relaxed && layer > 0;
-                    const uint32_t rl = (uint32_t)(i - r0);
-                    const uint64_t sub = ph ? ((uint64_t)(rl & 3u) << 38) | ((uint64_t)layer << shift) | cc : cc;
-                    ent.push_back({((uint64_t)j << 41) | ((uint64_t)(ph ? 1 : 0) << 40) | sub, k, rl});
+            for (int64_t i = r0; i < r1; ++i)
+                for (int64_t k = rowptr[i]; k < rowptr[i + 1]; ++k) ent.push_back({col[k], k, (uint32_t)(i - r0)});
+            std::sort(ent.begin(), ent.end(), [](const Ent &x, const Ent &y) { return x.col != y.col ? x.col < y.col : x.k < y.k; });
+            {   // tile starts
+                size_t o = 0;
+                for (int64_t j = 0; j <= P; ++j) {
+                    while (o < ent.size() && (ent[o].col >> shift) < j) ++o;
+                    b[(size_t)j] = o;
                 }
             }
-            std::sort(ent.begin(), ent.end(), [](const Ent &x, const Ent &y) { return x.key != y.key ? x.key < y.key : x.k < y.k; });
-            // ranges of every (panel, phase, wavefront)
             uint32_t *off = toff.data() + (size_t)s * kCtWaves * rowlen;
-            std::vector<size_t> b((size_t)P * 5 + 1);
-            {
-                size_t o = 0;
-                for (int64_t j = 0; j < P; ++j)
-                    for (int which = 0; which < 5; ++which) {
-                        uint64_t want = (uint64_t)j << 41;
-                        if (which > 0) want |= ((uint64_t)1 << 40) | ((uint64_t)(which - 1) << 38);
-                        while (o < ent.size() && ent[o].key < want) ++o;
-                        b[(size_t)j * 5 + which] = o;
-                    }
-                b[(size_t)P * 5] = ent.size();
-            }
             for (int64_t j = 0; j < P; ++j) {
-                const size_t *bb = b.data() + (size_t)j * 5;
-                const uint32_t n0 = (uint32_t)(bb[1] - bb[0]), G = (n0 + 63) >> 6, tail = n0 & 63;
+                const uint32_t n0 = (uint32_t)(b[(size_t)j + 1] - b[(size_t)j]), G = (n0 + 63) >> 6, tail = n0 & 63;
                 for (uint32_t w = 0; w < 4; ++w) {
                     uint32_t ng = G > w ? (G - w + 3) >> 2 : 0, na = ng * 64;
                     if (tail && G > 0 && ((G - 1) & 3) == w) na -= 64 - tail;
-                    off[w * rowlen + 2 * (size_t)j] = na;
-                    off[w * rowlen + 2 * (size_t)j + 1] = (uint32_t)(bb[2 + w] - bb[1 + w]);   // (bb[5] = the next tile's start)
+                    off[w * rowlen + (size_t)j] = na;
                 }
             }
             uint32_t run = 0;
-            for (uint32_t w = 0; w < 4; ++w)
-                for (size_t q = 0; q <= (size_t)(2 * P); ++q) {
-                    uint32_t &o = off[w * rowlen + q];
-                    if (q == (size_t)(2 * P)) { o = run; break; }
-                    const uint32_t cnt = o;
-                    o = run;
-                    run += cnt;
-                }
+            for (uint32_t w = 0; w < 4; ++w) {
+                for (size_t j = 0; j < (size_t)P; ++j) { const uint32_t cnt = off[w * rowlen + j]; off[w * rowlen + j] = run; run += cnt; }
+                off[w * rowlen + (size_t)P] = run;
+            }
             for (size_t o = 0; o < ent.size(); ++o) {
                 const Ent &e = ent[o];
-                const int64_t j = (int64_t)(e.key >> 41);
-                const int ph = (int)((e.key >> 40) & 1);
-                const size_t *bb = b.data() + (size_t)j * 5;
-                const uint32_t cc = (uint32_t)col[e.k] & cmask;
-                uint32_t w, rank, word;
-                if (ph == 0) {
-                    const uint32_t tt = (uint32_t)(o - bb[0]), g = tt >> 6;
-                    w = g & 3;
-                    rank = ((g >> 2) << 6) + (tt & 63);
-                    word = (e.rl << shift) | cc;
-                } else {
-                    w = (uint32_t)(e.key >> 38) & 3u;
-                    rank = (uint32_t)(o - bb[1 + w]);
-                    const uint32_t first = rank > 0 && ((ent[o - 1].key >> shift) != (e.key >> shift));
-                    word = (first << 31) | ((e.rl >> 2) << shift) | cc;
-                    nbreaks += first;
-                }
-                const size_t dst = (size_t)(k0 + off[w * rowlen + 2 * (size_t)j + ph] + rank);
-                tidx[dst] = word;
+                const int64_t j = e.col >> shift;
+                const uint32_t tt = (uint32_t)(o - b[(size_t)j]), g = tt >> 6, w = g & 3;
+                const size_t dst = (size_t)(k0 + off[w * rowlen + (size_t)j] + ((g >> 2) << 6) + (tt & 63));
+                tidx[dst] = (e.rl << shift) | ((uint32_t)e.col & cmask);
                 tval[dst] = val[e.k];
             }
         }
-        maxseg[(size_t)t] = mseg;
-        breaks[(size_t)t] = nbreaks;
     };
     if (T == 1) {
         work(0);
@@ -125,13 +82,6 @@ int build_ctiles_host(sla_csr *A, const std::vector<int32_t> &srow, int shift, i
         std::vector<std::thread> th;
         for (int t = 0; t < T; ++t) th.emplace_back(work, t);
         for (auto &x : th) x.join();
-    }
-    A->tl_maxseg = *std::max_element(maxseg.begin(), maxseg.end());
-    if (A->tl_maxseg >= ((int64_t)1 << (38 - shift))) { A->lower_log += "tile form not taken=segment length;"; return SLA_OK; }   // (layer field of the host key; such rows belong to the LDS-panel / stream kernels anyway)
-    {
-        int64_t nb = 0;
-        for (int64_t x : breaks) nb += x;
-        if (nb * 2 > nnz) { A->lower_log += "tile form not taken=layer boundaries (dense rows);"; return SLA_OK; }   // (per wavefront: four layer sequences per tile)
     }
     hipError_t err = hipSuccess;
     auto upload = [&](void **dst, const void *src, size_t bytes) {
@@ -162,13 +112,13 @@ int build_tiles(sla_csr *A, int64_t n, int64_t rows, const int64_t *rowptr, cons
             return skip("LDS per workgroup");
     }
     // round 5: CU-wide slices (sla_spmv_ctiles.hip) -- one slice of kCtRows rows per WORKGROUP, its row sums shared by the four wavefronts
-    const bool cu = c->tile_cu != 0, relaxed = cu && c->tile_relaxed != 0;
+    const bool cu = c->tile_relaxed != 0;
     const int64_t slice_rows = cu ? kCtRows : kTileRows;
     int row_bits = 0;
     while (((int64_t)1 << row_bits) < slice_rows) ++row_bits;
     // panel width: 2^17 columns (1 MiB of x) at 10 M rows, 2^16 below ~6 M (measured: 7-8 % faster at 0.5 / 1 / 3 M rows, 3-15 % slower at 10 M)
     const int want = c->tile_shift > 0 ? c->tile_shift : (n < 6000000 ? 16 : 17);
-    const int shift = std::max(10, std::min((cu ? 32 : 31) - row_bits, want));   // (layer flag, slice row, panel column) packed in 32 bits (CU-wide: no flag in phase 0, row >> 2 in phase 1)
+    const int shift = std::max(10, std::min((cu ? 32 : 31) - row_bits, want));   // (layer flag, slice row, panel column) packed in 32 bits (CU-wide slices: no flag, 15 + 17 bits)
     const int64_t W = (int64_t)1 << shift;
     if (n <= 2 * W || (c->tile_shift <= 0 && n <= ((int64_t)1 << 18))) return SLA_OK;   // x (nearly) fits the L2 already
     const int64_t P = (n + W - 1) / W;
@@ -196,7 +146,7 @@ int build_tiles(sla_csr *A, int64_t n, int64_t rows, const int64_t *rowptr, cons
         }
     }
     const int64_t S = (int64_t)srow.size() - 1;
-    const int64_t ntoff = cu ? S * kCtWaves * (2 * P + 1) : S * (P + 1);
+    const int64_t ntoff = cu ? S * kCtWaves * (P + 1) : S * (P + 1);
     if (ntoff > ((int64_t)1 << 31) || ntoff * 4 > nnz * 12 / 2) return skip("offset table larger than half the matrix");   // offset table must stay a fraction of the matrix
     auto finish = [&]() -> int {   // what both builders share once d_tlidx / d_tlval / d_tloff exist: slice starts, pacing table, geometry
         hipError_t e2 = dev_malloc(c, (void **)&A->d_tlrow, sizeof(int32_t) * srow.size() + 64);
@@ -209,7 +159,6 @@ int build_tiles(sla_csr *A, int64_t n, int64_t rows, const int64_t *rowptr, cons
         A->tl_P = (int32_t)P;
         A->tl_shift = shift;
         A->tl_cu = cu;
-        A->tl_relaxed = relaxed;
         A->use_tiles = true;
         return SLA_OK;
     };
@@ -219,20 +168,27 @@ int build_tiles(sla_csr *A, int64_t n, int64_t rows, const int64_t *rowptr, cons
     if (c->tiles_device == 2 || (c->tiles_device == 1 && nnz >= ((int64_t)1 << 20))) {
         int64_t mseg = 0, nb = 0;
         bool done = false;
-        if (cu) SLA_TRY(build_ctiles_device(A, srow, shift, P, relaxed, &mseg, &nb, &done));
-        else SLA_TRY(build_tiles_device(A, srow, shift, P, &mseg, &nb, &done));
+        if (cu) {   // (relaxed order: no layers, nothing to step aside for)
+            SLA_TRY(build_ctiles_device(A, srow, shift, P, &done));
+            if (done) {
+                A->lower_log += "tile builder on device=1;cu tiles=1;";
+                return finish();
+            }
+        } else {
+            SLA_TRY(build_tiles_device(A, srow, shift, P, &mseg, &nb, &done));
+        }
         if (done) {
             A->tl_maxseg = mseg;
-            if (nb * (cu ? 2 : 8) > nnz) {   // (dense rows: see the host builder's test below; CU-wide: boundaries are counted per wavefront)
+            if (nb * 8 > nnz) {   // (dense rows: see the host builder's test below)
                 (void)hipFree(A->d_tlidx); (void)hipFree(A->d_tlval); (void)hipFree(A->d_tloff);
                 A->d_tlidx = nullptr; A->d_tlval = nullptr; A->d_tloff = nullptr;
                 return skip("layer boundaries (dense rows)");
             }
-            A->lower_log += cu ? "tile builder on device=1;cu tiles=1;" : "tile builder on device=1;";
+            A->lower_log += "tile builder on device=1;";
             return finish();
         }
     }
-    if (cu) return build_ctiles_host(A, srow, shift, P, relaxed, rowptr, col, val, finish);
+    if (cu) return build_ctiles_host(A, srow, shift, P, rowptr, col, val, finish);
     std::vector<uint32_t> toff((size_t)(S * (P + 1)));
     std::vector<uint32_t> tidx((size_t)nnz);
     std::vector<double> tval((size_t)nnz);

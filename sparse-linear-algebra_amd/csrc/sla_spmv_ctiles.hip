@@ -1,34 +1,27 @@
 // sla_spmv_ctiles.hip -- (#>) on CU-WIDE tiles (round 5): the row-slice x column-panel form of sla_spmv_tiles.hip with the slice
-// owned by the whole workgroup instead of one wavefront.  Reference semantics: Data/Sparse/Common.hs:242-260 (ascending left fold).
+// owned by the whole workgroup instead of one wavefront, and the row sums added in RELAXED order.
+// Reference semantics: Data/Sparse/Common.hs:242-260; contract: |dy_i| <= nnz_i eps sum_j |a_ij x_j|.
 //
 // Why.  With x in the L2 the tile kernel of rounds 2-4 ran at the L2's REQUEST rate: every 8-byte gather fetched its own 128-byte
-// line (181 G gathers/s; profiles/r04_pmc_l1_l2_tile_kernel_10m.txt).  tools/gather_share_probe.cpp (profiles/r05_gather_share_probe.txt)
-// shows what lifts that: when the 64 lanes of ONE gather instruction hold 64 CONSECUTIVE entries of a column-sorted run with d entries
-// per line, neighbouring lanes share lines and the texture unit asks the L2 once per line -- 218 (random) -> 307 (d = 1) -> 393 (d = 2)
-// G gathers/s.  d = rows of the slice x entries per row x 16 / columns, so the slice has to be as tall as the LDS allows: all
-// 19584 row sums of the CU in ONE array shared by its four wavefronts (d = 1.03 on BASELINE config 3a; a wavefront-private slice
-// of 4896 rows has d = 0.26).
+// line (181 G gathers/s, 1.02 requests per entry; profiles/r04_pmc_l1_l2_tile_kernel_10m.txt).  tools/gather_share_probe.cpp
+// (profiles/r05_gather_share_probe.txt) shows what lifts that: when the 64 lanes of ONE gather instruction hold 64 CONSECUTIVE
+// entries of a column-sorted run with d entries per line, neighbouring lanes share lines and the L1 asks the L2 once per line --
+// 218 (random) -> 307 (d = 1) -> 393 (d = 2) -> 485 (d = 4) G gathers/s.  d = rows of the slice x entries per row x 16 / columns, so
+// the slice has to be as tall as the LDS allows: all 19584 row sums of the CU in ONE array shared by its four wavefronts (d = 1.03
+// on BASELINE config 3a, 31 at 100 entries per row and 1 M columns; a wavefront-private slice of 4896 rows has a quarter of that).
 //
-// The price is that a row's products now come from different wavefronts, and the reference's fold is ordered.  Inside a tile
-// (slice x panel) the entries are split in two PHASES:
-//   phase 0: the first entry of every (row, panel) segment ("layer 0": every row at most once), sorted by column, dealt to the four
-//            wavefronts in 64-entry groups round-robin (group g -> wavefront g & 3).  Any wavefront may add to any row: the rows of
-//            a layer are distinct, so the four wavefronts' plain LDS read-modify-writes never meet;
-//   phase 1: the later entries of the segments (layers >= 1: 18 % of config 3a's entries at 2^17-column panels), each handled by
-//            the wavefront that OWNS the row (local row & 3), sorted by (layer, column), bit 31 of the index marking the first entry of
-//            a layer like the wavefront-private form does.  One wavefront's LDS operations execute in order.
-// and the workgroup meets at a barrier in front of every phase: a row's products are added one by one, panels ascending, inside a
-// panel in ascending column order -- the reference's left fold BIT FOR BIT, like the form this replaces.  The barriers wait on LDS
-// only (s_waitcnt lgkmcnt(0); s_barrier): the streams and gathers of the next chunks stay in flight across them.
+// The price: a row's products now come from different wavefronts at different times.  An order-preserving version of this kernel was
+// built and measured (layer-0 entries shared, later layers by row-owning wavefronts, a workgroup barrier in front of every phase:
+// bit-exact, 1.83 ms on config 3a against 1.85 for the wavefront-private form -- the barriers and the unshared second phase eat the
+// gain; profiles/r05_ab_ctile_kernel.txt) and dropped.  This kernel adds the products with LDS floating-point atomics (ds_add_f64)
+// in whatever order the wavefronts reach them: every product is still rounded separately (no FMA), a row's sum is the same set of
+// numbers as the reference's fold, added in another order -- within nnz_i eps sum_j |a_ij x_j| of it, and NOT reproducible bit for
+// bit from run to run.  Option tile_relaxed = 0 selects the bit-exact wavefront-private form instead (sla_spmv_tiles.hip).
 //
-// RELAXED (option tile_relaxed = 1): everything in phase 0 sorted by column alone (d = 1.03 for all entries), products added with LDS
-// floating-point atomics, no barriers between tiles.  A row's sum is then the same set of separately rounded products added in an
-// order that depends on timing: |dy_i| <= nnz_i eps sum_j |a_ij x_j| (SURVEY A1's contract for (#>)), not reproducible bit for bit.
-//
-// Layout (sla_lower_tiles.cpp / sla_tiles_build.hip): entries [slice][wavefront][panel][phase], 12 B each (value + one dword);
-// ctoff[(s * 4 + w) * (2 P + 1) + 2 j + phase] = first entry of that range relative to the slice's first entry.
-//   phase 0 dword: (row - slice_row0) << shift | (col - panel * 2^shift)              (15 + 17 bits)
-//   phase 1 dword: first-of-layer << 31 | ((row - slice_row0) >> 2) << shift | (col - panel * 2^shift)
+// Layout (sla_lower_tiles.cpp / sla_tiles_build.hip): inside a tile (slice x panel) the entries are sorted by column and dealt to the
+// four wavefronts in 64-entry groups round-robin (group g -> wavefront g & 3); stored [slice][wavefront][panel], 12 B each:
+// the value and (row - slice_row0) << shift | (col - panel * 2^shift)   (15 + 17 bits);
+// ctoff[(s * 4 + w) * (P + 1) + j] = first entry of wavefront w's share of tile (s, j), relative to the slice's first entry.
 // Panel pacing, the look-ahead poll and the three-chunk software pipeline are those of sla_spmv_tiles.hip.
 #include <hip/hip_runtime.h>
 
@@ -41,66 +34,36 @@
 namespace sla {
 
 #ifndef SLA_CT_U
-#define SLA_CT_U 8      // exact: a chunk never crosses a (tile, phase) range, ~27 + ~6 groups per wavefront and tile on config 3a (12: 2.05 ms against 1.83)
-#endif
-#ifndef SLA_CT_UR
-#define SLA_CT_UR 12    // relaxed: one range of ~33 groups per wavefront and tile (8: 1.57 ms, 12: 1.52)
+#define SLA_CT_U 12     // 64-entry groups per chunk (8: 1.57 ms on config 3a, 12: 1.52)
 #endif
 #ifndef SLA_CT_SPIN
 #define SLA_CT_SPIN 2000
 #endif
-template <bool RELAXED> struct CtU { static constexpr int n = RELAXED ? SLA_CT_UR : SLA_CT_U; };   // 64-entry groups per chunk
+constexpr int kCtU = SLA_CT_U;
 
-template <int U>
 struct CtChunk {
-    uint32_t idx[U];
-    double val[U];
-    double xv[U];
+    uint32_t idx[kCtU];
+    double val[kCtU];
+    double xv[kCtU];
     int cnt;      // entries of this chunk (<= 64 * kCtU)
     int panel;
-    int phase;
-    int sync;     // workgroup barriers in front of this chunk's fold
 };
 
-// every wavefront of the workgroup executes the same number of these per slice
+// LDS only: the streams and gathers of the next chunks stay in flight across it
 __device__ __forceinline__ void ct_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <bool RELAXED>
-__device__ __forceinline__ void ct_fold_chunk(double *yl, const CtChunk<CtU<RELAXED>::n> &c, int shift, int lane, int wave) {
+__device__ __forceinline__ void ct_fold_chunk(double *yl, const CtChunk &c, int shift, int lane) {
 #pragma clang fp contract(off)
 #pragma unroll
-    for (int u = 0; u < CtU<RELAXED>::n; ++u) {
+    for (int u = 0; u < kCtU; ++u) {
         const int cg = c.cnt - 64 * u;                 // valid lanes of this group (wavefront-uniform)
         if (cg <= 0) break;
-        const double p = c.val[u] * c.xv[u];
-        const bool act = lane < cg;
-        if (c.phase == 0) {
-            const uint32_t rl = c.idx[u] >> shift;
-            if constexpr (RELAXED) {
-#ifdef SLA_CT_RELAXED_RMW   // (measurement only: what the atomics cost -- races between the wavefronts)
-                if (act) yl[rl] = yl[rl] + p;
-#else
-                if (act) unsafeAtomicAdd(yl + rl, p);
-#endif
-            } else {
-                if (act) yl[rl] = yl[rl] + p;          // one layer: 64 different rows
-            }
-        } else {
-            const uint32_t rl = (((c.idx[u] & 0x7fffffffu) >> shift) << 2) | (uint32_t)wave;
-            unsigned long long B = __ballot(act && lane > 0 && (c.idx[u] >> 31) != 0);
-            int lo = 0;
-            for (;;) {                                 // passes [lo, hi) between layer boundaries, in order
-                const int hi = B ? __builtin_ctzll(B) : 64;
-                if (act && lane >= lo && lane < hi) yl[rl] = yl[rl] + p;
-                if (!B) break;
-                B &= B - 1;
-                lo = hi;
-            }
-        }
+        const double p = c.val[u] * c.xv[u];           // (separately rounded: the sum below is an add, never an FMA)
+        if (lane < cg) unsafeAtomicAdd(yl + (c.idx[u] >> shift), p);   // ds_add_f64
     }
 }
 
-template <int EPI, typename RP, bool RELAXED>
+template <int EPI, typename RP>
 __global__ void __launch_bounds__(kBlock, 1)
 spmv_ctile_kernel(SpmvArgs<RP> a, const RP *__restrict__ rowptr, const int32_t *__restrict__ srow, const uint32_t *__restrict__ toff,
                   const uint32_t *__restrict__ tidx, const double *__restrict__ tval, const double *__restrict__ xg, int S, int P,
@@ -124,10 +87,7 @@ spmv_ctile_kernel(SpmvArgs<RP> a, const RP *__restrict__ rowptr, const int32_t *
     const int nwg_xcd = ((int)gridDim.x - xcd + 7) >> 3;
     const int rounds = (S + (int)gridDim.x - 1) / (int)gridDim.x;
     if (vis == nullptr) nv = P;
-    constexpr int kCtU = CtU<RELAXED>::n;
-    using Chunk = CtChunk<kCtU>;
-    constexpr int SUB = RELAXED ? 1 : 2;                         // sub-steps per panel step: its phases (relaxed: everything is phase 0)
-    const int nq = SUB * nv;                                     // sub-steps of a slice
+    using Chunk = CtChunk;
     int *slots = prog ? (int *)prog + xcd * 256 : nullptr;
     int *myslot = slots ? slots + ((int)blockIdx.x >> 3) : nullptr;
     bool pace = slack > 0 && slots != nullptr && nwg_xcd <= 64;
@@ -187,30 +147,28 @@ spmv_ctile_kernel(SpmvArgs<RP> a, const RP *__restrict__ rowptr, const int32_t *
             base = (RP)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned long long)base >> 32)) << 32) |
                         (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned long long)base));
         }
-        const uint32_t *tp = toff + ((size_t)s * 4 + (size_t)wave) * (size_t)(2 * P + 1);
-        // The ranges of the sub-steps come through the SCALAR cache, one sub-step ahead (and the panel of a pass's visiting list two
-        // ahead): a per-lane block of offsets re-read every 64 sub-steps, as the wavefront-private kernel keeps it, puts s_waitcnt vmcnt(0)
+        const uint32_t *tp = toff + ((size_t)s * 4 + (size_t)wave) * (size_t)(P + 1);
+        // The ranges of the panel steps come through the SCALAR cache, one step ahead (and the panel of a pass's visiting list two
+        // ahead): a per-lane block of offsets re-read every 64 steps, as the wavefront-private kernel keeps it, puts s_waitcnt vmcnt(0)
         // -- the whole load pipeline drained -- on EVERY path through advance(), because the wait-count pass cannot tell the path that
         // skipped the reload from the one that took it.
-        int q = -1, pj = 0, pend = 0;            // sub-step, its panel, barriers owed before the next chunk's fold
+        int q = -1, pj = 0;                      // panel step, its panel
         uint32_t k = 0, k1 = 0;
-        auto panel_of = [&](int qq) -> int { return vis ? vis[v0 + min(qq, nq - 1) / SUB] : min(qq, nq - 1) / SUB; };
+        auto panel_of = [&](int qq) -> int { return vis ? vis[v0 + min(qq, nv - 1)] : min(qq, nv - 1); };
         int npj = panel_of(0), pn2 = panel_of(1);
-        uint32_t nk = tp[2 * npj], nk1 = tp[2 * npj + 1];
+        uint32_t nk = tp[npj], nk1 = tp[npj + 1];
         auto advance = [&]() -> bool {
             while (k >= k1) {
-                if (q >= 0 && (q % SUB) == SUB - 1) publish(round * nv + q / SUB + 1);   // done issuing the tile of panel step q / SUB
+                if (q >= 0) publish(round * nv + q + 1);   // done issuing the tile of panel step q
                 ++q;
-                if (q >= nq) return false;
-                if (!RELAXED || q == 0) ++pend;
-                if ((q % SUB) == 0) wait_for(round * nv + q / SUB - slack + 1);
+                if (q >= nv) return false;
+                wait_for(round * nv + q - slack + 1);
                 pj = npj;
                 k = nk;
                 k1 = nk1;
-                npj = pn2;                                   // sub-step q + 1
-                const int o = 2 * npj + (RELAXED ? 0 : ((q + 1) & 1));
-                nk = tp[o];
-                nk1 = tp[o + 1];
+                npj = pn2;                                 // step q + 1
+                nk = tp[npj];
+                nk1 = tp[npj + 1];
                 pn2 = panel_of(q + 2);
             }
             return true;
@@ -218,9 +176,6 @@ spmv_ctile_kernel(SpmvArgs<RP> a, const RP *__restrict__ rowptr, const int32_t *
         auto issue = [&](Chunk &c) {   // the chunk at (sub-step q, k): its index / value streams (lanes past the end re-read the last entry)
             c.cnt = (int)min((uint32_t)(64 * kCtU), k1 - k);
             c.panel = pj;
-            c.phase = RELAXED ? 0 : (q & 1);
-            c.sync = pend;
-            pend = 0;
             const uint32_t *ip = tidx + (base + (RP)k);
             const double *vp = tval + (base + (RP)k);
 #pragma unroll
@@ -236,12 +191,7 @@ spmv_ctile_kernel(SpmvArgs<RP> a, const RP *__restrict__ rowptr, const int32_t *
 #pragma unroll
             for (int u = 0; u < kCtU; ++u) c.xv[u] = *(const double *)(xb + (uint32_t)((c.idx[u] & cmask) << 3));
         };
-        auto fold = [&](const Chunk &c) {
-#ifndef SLA_CT_NOBARRIER   // (measurement only: what the phase barriers cost -- the fold is then no longer ordered)
-            for (int i = 0; i < c.sync; ++i) ct_barrier();
-#endif
-            ct_fold_chunk<RELAXED>(yl, c, shift, lane, wave);
-        };
+        auto fold = [&](const Chunk &c) { ct_fold_chunk(yl, c, shift, lane); };
         // three chunks in flight per wavefront; the loop issues the SAME loads on every path (past the slice's last chunk: empty chunks)
         Chunk A, B, C;
         bool live = true;
@@ -252,8 +202,6 @@ spmv_ctile_kernel(SpmvArgs<RP> a, const RP *__restrict__ rowptr, const int32_t *
             } else {
                 c.cnt = 0;
                 c.panel = 0;
-                c.phase = 0;
-                c.sync = 0;
 #pragma unroll
                 for (int u = 0; u < kCtU; ++u) {
                     const int i = min(lane + 64 * u, dlim);
@@ -262,6 +210,7 @@ spmv_ctile_kernel(SpmvArgs<RP> a, const RP *__restrict__ rowptr, const int32_t *
                 }
             }
         };
+        ct_barrier();                                       // the sums are initialised
         next(A);
         next(B);
         gather(A);
@@ -273,7 +222,7 @@ spmv_ctile_kernel(SpmvArgs<RP> a, const RP *__restrict__ rowptr, const int32_t *
             if (C.cnt == 0) break;
             next(B); gather(A); fold(C);
         }
-        for (int i = 0; i < pend + 1; ++i) ct_barrier();   // the barriers no chunk carried (empty ranges at the end) + the one in front of the epilogue
+        ct_barrier();                                       // every wavefront's atomics have landed
         for (int r = tid; r < nr; r += kBlock) spmv_epilogue<EPI, RP>(a, r0 + r, yl[r], coef, acc1, acc2);
         ct_barrier();                                       // the next slice's initialisation overwrites the sums
     }
@@ -290,7 +239,7 @@ spmv_ctile_kernel(SpmvArgs<RP> a, const RP *__restrict__ rowptr, const int32_t *
 
 int ctiles_grid(const sla_csr *A) { return (int)std::max<int64_t>(1, std::min<int64_t>(A->tl_S, (int64_t)A->ctx->n_cu)); }
 
-template <int EPI, typename RP, bool RELAXED>
+template <int EPI, typename RP>
 static int launch_ctiles_t(const sla_csr *A, const SpmvLaunch &l) {
     sla_ctx *c = A->ctx;
     SpmvArgs<RP> a{};
@@ -321,31 +270,30 @@ static int launch_ctiles_t(const sla_csr *A, const SpmvLaunch &l) {
     if (l.tv1 >= 0 && (!vis || l.tv0 < 0 || nv < 1 || l.tv1 > A->tl_P)) return fail(SLA_ERR_INVALID, "launch_spmv_tiles: bad panel pass");
     ProfScope prof(c, l.kernel_id);
     if (A->d_tlprog) SLA_HIP_TRY(hipMemsetAsync(A->d_tlprog, 0, A->tlprog_bytes, stream_of(c)));   // the pacing table of this launch
-    hipLaunchKernelGGL((spmv_ctile_kernel<EPI, RP, RELAXED>), dim3(ctiles_grid(A)), dim3(kBlock), 0, stream_of(c), a, a.rowptr, A->d_tlrow, A->d_tloff,
+    hipLaunchKernelGGL((spmv_ctile_kernel<EPI, RP>), dim3(ctiles_grid(A)), dim3(kBlock), 0, stream_of(c), a, a.rowptr, A->d_tlrow, A->d_tloff,
                        A->d_tlidx, A->d_tlval, l.x, A->tl_S, A->tl_P, A->tl_shift, A->d_tlprog, c->xcd8 == 1 ? c->tile_slack : 0, vis, l.tv0, nv,
-                       (int)std::min<int64_t>(64 * CtU<RELAXED>::n - 1, A->nnz - 1));
+                       (int)std::min<int64_t>(64 * kCtU - 1, A->nnz - 1));
     SLA_HIP_TRY(hipGetLastError());
     return SLA_OK;
 }
 
-template <typename RP, bool RELAXED>
+template <typename RP>
 static int launch_ctiles_rp(const sla_csr *A, const SpmvLaunch &l) {
     switch (l.epi) {
-        case EPI_NONE: return launch_ctiles_t<EPI_NONE, RP, RELAXED>(A, l);
-        case EPI_DOT: return launch_ctiles_t<EPI_DOT, RP, RELAXED>(A, l);
-        case EPI_DOT2: return launch_ctiles_t<EPI_DOT2, RP, RELAXED>(A, l);
-        case EPI_DOT4: return launch_ctiles_t<EPI_DOT4, RP, RELAXED>(A, l);
-        case EPI_RES: return launch_ctiles_t<EPI_RES, RP, RELAXED>(A, l);
-        case EPI_AXPY_DOT: return launch_ctiles_t<EPI_AXPY_DOT, RP, RELAXED>(A, l);
-        case EPI_XPBY_NRM: return launch_ctiles_t<EPI_XPBY_NRM, RP, RELAXED>(A, l);
-        case EPI_SUB: return launch_ctiles_t<EPI_SUB, RP, RELAXED>(A, l);
+        case EPI_NONE: return launch_ctiles_t<EPI_NONE, RP>(A, l);
+        case EPI_DOT: return launch_ctiles_t<EPI_DOT, RP>(A, l);
+        case EPI_DOT2: return launch_ctiles_t<EPI_DOT2, RP>(A, l);
+        case EPI_DOT4: return launch_ctiles_t<EPI_DOT4, RP>(A, l);
+        case EPI_RES: return launch_ctiles_t<EPI_RES, RP>(A, l);
+        case EPI_AXPY_DOT: return launch_ctiles_t<EPI_AXPY_DOT, RP>(A, l);
+        case EPI_XPBY_NRM: return launch_ctiles_t<EPI_XPBY_NRM, RP>(A, l);
+        case EPI_SUB: return launch_ctiles_t<EPI_SUB, RP>(A, l);
     }
     return fail(SLA_ERR_INVALID, "launch_spmv_ctiles: unknown epilogue");
 }
 
 int launch_spmv_ctiles(const sla_csr *A, const SpmvLaunch &l) {
-    if (A->tl_relaxed) return A->rp64 ? launch_ctiles_rp<int64_t, true>(A, l) : launch_ctiles_rp<int32_t, true>(A, l);
-    return A->rp64 ? launch_ctiles_rp<int64_t, false>(A, l) : launch_ctiles_rp<int32_t, false>(A, l);
+    return A->rp64 ? launch_ctiles_rp<int64_t>(A, l) : launch_ctiles_rp<int32_t>(A, l);
 }
 
 }  // namespace sla

@@ -200,8 +200,11 @@ bool lflat_candidate(const sla_csr *A, int64_t n, int64_t rows) {
     if (c->lflat < 2 && (A->use_wdia || A->use_vdict || A->use_diag || A->xwin_fraction >= 0.5)) return false;         // stencil / banded structure (lflat = 2: test hook, any structure)
     const int64_t P = (n + kLfW - 1) / kLfW;
     const int64_t nseg = P * rows;
-    // mean segment length: from lf_min_seg10 / 10 (1.5: below that the partials cost more than the entries) up to the LDS-panel form's threshold
-    return !(P < 3 || P > 4096 || nseg >= ((int64_t)1 << 31) || nnz * 10 < (int64_t)c->lf_min_seg10 * nseg || (c->lflat < 2 && nnz >= (int64_t)c->lp_min_seg * nseg));
+    // mean segment length: from lf_min_seg10 / 10 (1.5: below that the partials cost more than the entries) up to the LDS-panel form's threshold.
+    // Round 5: where the CU-wide tile form applies (relaxed order allowed, x beyond the L2) it wins up to segments of ~6 entries
+    // (profiles/r05_form_tournament.txt: 100 per row 0.36 -> 0.54 of peak, 200 per row 0.61 -> 0.65; 500 per row, segments of 8: 0.755 here against 0.74)
+    const int64_t min10 = (c->tiles && c->tile_relaxed && c->lflat < 2 && n > ((int64_t)1 << 18)) ? std::max<int64_t>(c->lf_min_seg10, 60) : c->lf_min_seg10;
+    return !(P < 3 || P > 4096 || nseg >= ((int64_t)1 << 31) || nnz * 10 < min10 * nseg || (c->lflat < 2 && nnz >= (int64_t)c->lp_min_seg * nseg));
 }
 
 int build_lflat(sla_csr *A, int64_t n, int64_t rows, int64_t col_lo, int64_t col_hi) {

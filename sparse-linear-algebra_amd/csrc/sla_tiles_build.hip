@@ -121,96 +121,46 @@ __global__ void __launch_bounds__(256) tile_offsets_kernel(int S, int P, int64_t
 }
 
 // ---- CU-wide slices (sla_spmv_ctiles.hip, round 5) ----------------------------------------------------------------------------
-// key = (((slice << pbits | panel) << 1 | phase) << subbits) | sub,  subbits = 2 + lbits + shift
-//   phase 0 (first entry of its (row, panel) segment; relaxed: every entry): sub = column inside the panel
-//   phase 1 (layers >= 1):                                                  sub = (local row & 3) << (lbits + shift) | layer << shift | column
-// STABLE sort: equal keys stay in input order = ascending rows.
+// key = (slice << pbits | panel) << shift | column inside the panel; STABLE sort: equal columns stay in input order = ascending rows.
+// Inside a tile the sorted entries are dealt to the workgroup's four wavefronts in 64-entry groups round-robin; the layout is
+// [slice][wavefront][panel], toff[(s * 4 + w) * (P + 1) + j] relative to the slice's first entry.
 template <typename RP>
 __global__ void __launch_bounds__(256) ctile_keys_kernel(int S, const int32_t *__restrict__ srow, const RP *__restrict__ rowptr,
-                                                          const int32_t *__restrict__ col, int shift, int lbits, int pbits, int relaxed, uint64_t *key,
-                                                          uint32_t *idx) {
-    const int subbits = 2 + lbits + shift;
+                                                          const int32_t *__restrict__ col, int shift, int pbits, uint64_t *key, uint32_t *idx) {
     for (int s = blockIdx.x; s < S; s += gridDim.x) {
-        const uint64_t hi = (uint64_t)s << (pbits + 1 + subbits);
+        const uint64_t hi = (uint64_t)s << (pbits + shift);
         const uint32_t cmask = (1u << shift) - 1u;
-        const int r0 = srow[s];
-        for (int i = r0 + (int)threadIdx.x; i < srow[s + 1]; i += 256) {
-            int prev = -1;
-            unsigned layer = 0;
-            const uint64_t own = (uint64_t)((unsigned)(i - r0) & 3u) << (lbits + shift);
-            for (RP k = rowptr[i]; k < rowptr[i + 1]; ++k) {
-                const int j = col[k] >> shift;
-                layer = j == prev ? layer + 1 : 0;
-                prev = j;
-                const uint64_t c = (uint32_t)col[k] & cmask;
-                const bool ph = !relaxed && layer > 0;
-                key[k] = hi | ((uint64_t)j << (1 + subbits)) | ((uint64_t)(ph ? 1 : 0) << subbits) | (ph ? (own | ((uint64_t)layer << shift) | c) : c);
-                idx[k] = (uint32_t)k;
-            }
+        const RP k0 = rowptr[srow[s]], k1 = rowptr[srow[s + 1]];
+        for (RP k = k0 + (RP)threadIdx.x; k < k1; k += 256) {
+            key[k] = hi | ((uint64_t)(col[k] >> shift) << shift) | ((uint32_t)col[k] & cmask);
+            idx[k] = (uint32_t)k;
         }
     }
 }
 
-// bs[(s * P + j) * 5 + t]: first sorted position (relative to the slice's first entry) of phase 0 (t = 0) and of phase 1's wavefront t - 1
-template <typename RP>
-__global__ void __launch_bounds__(256) ctile_bounds_kernel(int S, int P, const uint64_t *__restrict__ key, const int32_t *__restrict__ srow,
-                                                            const RP *__restrict__ rowptr, int shift, int lbits, int pbits, uint32_t *bs) {
-    const int subbits = 2 + lbits + shift;
-    const int64_t total = (int64_t)S * P * 5;
-    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
-        const int64_t tile = t / 5;
-        const int which = (int)(t - tile * 5);
-        const int s = (int)(tile / P), j = (int)(tile - (int64_t)s * P);
-        uint64_t want = ((uint64_t)s << (pbits + 1 + subbits)) | ((uint64_t)j << (1 + subbits));
-        if (which > 0) want |= ((uint64_t)1 << subbits) | ((uint64_t)(which - 1) << (lbits + shift));
-        int64_t lo = (int64_t)rowptr[srow[s]], hi = (int64_t)rowptr[srow[s + 1]];
-        const int64_t base = lo;
-        while (lo < hi) {
-            const int64_t mid = (lo + hi) >> 1;
-            if (key[mid] < want) lo = mid + 1;
-            else hi = mid;
-        }
-        bs[t] = (uint32_t)(lo - base);
-    }
-}
-
-// entries of range (s, w, j, phase) -> toff[(s * 4 + w) * (2 P + 1) + 2 j + phase] (counts; scanned below)
-template <typename RP>
-__global__ void __launch_bounds__(256) ctile_counts_kernel(int S, int P, const uint32_t *__restrict__ bs, const int32_t *__restrict__ srow,
-                                                            const RP *__restrict__ rowptr, uint32_t *toff) {
+// entries of wavefront w's share of tile (s, j) -> toff[(s * 4 + w) * (P + 1) + j] (counts; scanned below); bs = tile starts, S x (P + 1)
+__global__ void __launch_bounds__(256) ctile_counts_kernel(int S, int P, const uint32_t *__restrict__ bs, uint32_t *toff) {
     const int64_t total = (int64_t)S * P;
     for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
         const int s = (int)(t / P), j = (int)(t - (int64_t)s * P);
-        const uint32_t *b = bs + t * 5;
-        const uint32_t end = j + 1 < P ? b[5] : (uint32_t)((int64_t)rowptr[srow[s + 1]] - (int64_t)rowptr[srow[s]]);
+        const uint32_t *b = bs + (size_t)s * (P + 1) + j;
         const uint32_t n0 = b[1] - b[0], G = (n0 + 63) >> 6, tail = n0 & 63;
         for (uint32_t w = 0; w < 4; ++w) {
             uint32_t ng = G > w ? (G - w + 3) >> 2 : 0, na = ng * 64;
             if (tail && G > 0 && ((G - 1) & 3) == w) na -= 64 - tail;
-            uint32_t *o = toff + ((size_t)s * 4 + w) * (size_t)(2 * P + 1) + 2 * (size_t)j;
-            o[0] = na;
-            o[1] = (w < 3 ? b[2 + w] : end) - b[1 + w];
+            toff[((size_t)s * 4 + w) * (size_t)(P + 1) + (size_t)j] = na;
         }
     }
 }
-// exclusive scan of every (slice, wavefront) row of counts; tot[s * 4 + w] = its total
-__global__ void __launch_bounds__(64) ctile_scan_kernel(int S, int P, uint32_t *toff, uint32_t *tot) {
-    const int t = blockIdx.x * 64 + threadIdx.x;
-    if (t >= S * 4) return;
-    uint32_t *o = toff + (size_t)t * (size_t)(2 * P + 1);
+// exclusive scan of every slice's 4 x (P + 1) counts in [wavefront][panel] order (the last slot of a wavefront's row = the next one's start)
+__global__ void __launch_bounds__(64) ctile_scan_kernel(int S, int P, uint32_t *toff) {
+    const int s = blockIdx.x * 64 + threadIdx.x;
+    if (s >= S) return;
+    uint32_t *o = toff + (size_t)s * 4 * (size_t)(P + 1);
     uint32_t run = 0;
-    for (int q = 0; q < 2 * P; ++q) { const uint32_t c = o[q]; o[q] = run; run += c; }
-    o[2 * P] = run;
-    tot[t] = run;
-}
-__global__ void __launch_bounds__(256) ctile_wavebase_kernel(int S, int P, uint32_t *toff, const uint32_t *__restrict__ tot) {
-    const int64_t total = (int64_t)S * 4 * (2 * P + 1);
-    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
-        const int64_t sw = t / (2 * P + 1);
-        const int w = (int)(sw & 3);
-        uint32_t base = 0;
-        for (int v = 0; v < w; ++v) base += tot[sw - w + v];
-        toff[t] += base;
+    for (int w = 0; w < 4; ++w) {
+        for (int j = 0; j < P; ++j) { const uint32_t c = o[(size_t)w * (P + 1) + j]; o[(size_t)w * (P + 1) + j] = run; run += c; }
+        o[(size_t)w * (P + 1) + P] = run;
     }
 }
 
@@ -218,40 +168,20 @@ template <typename RP>
 __global__ void __launch_bounds__(256) ctile_emit_kernel(int64_t nnz, int P, const uint64_t *__restrict__ key, const uint32_t *__restrict__ idx,
                                                           const int32_t *__restrict__ srow, const RP *__restrict__ rowptr, const int32_t *__restrict__ col,
                                                           const double *__restrict__ val, const int32_t *__restrict__ row_of_entry,
-                                                          const uint32_t *__restrict__ bs, const uint32_t *__restrict__ toff, int shift, int lbits, int pbits,
-                                                          uint32_t *tidx, double *tval, unsigned long long *nbreaks) {
-    const int subbits = 2 + lbits + shift;
+                                                          const uint32_t *__restrict__ bs, const uint32_t *__restrict__ toff, int shift, int pbits,
+                                                          uint32_t *tidx, double *tval) {
     const uint32_t cmask = (1u << shift) - 1u;
-    unsigned brk = 0;
     for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < nnz; o += (int64_t)gridDim.x * 256) {
         const uint64_t kk = key[o];
         const uint32_t k = idx[o];
-        const int s = (int)(kk >> (pbits + 1 + subbits));
-        const int j = (int)((kk >> (1 + subbits)) & (((uint64_t)1 << pbits) - 1));
-        const int ph = (int)((kk >> subbits) & 1);
+        const int s = (int)(kk >> (pbits + shift));
+        const int j = (int)((kk >> shift) & (((uint64_t)1 << pbits) - 1));
         const int64_t base = (int64_t)rowptr[srow[s]];
-        const uint32_t orel = (uint32_t)(o - base);
-        const uint32_t *b = bs + ((size_t)s * P + j) * 5;
-        const uint32_t rl = (uint32_t)(row_of_entry[k] - srow[s]), c = (uint32_t)col[k] & cmask;
-        uint32_t w, rank, word;
-        if (ph == 0) {
-            const uint32_t t = orel - b[0], g = t >> 6;
-            w = g & 3;
-            rank = ((g >> 2) << 6) + (t & 63);
-            word = (rl << shift) | c;
-        } else {
-            w = (uint32_t)(kk >> (lbits + shift)) & 3u;
-            rank = orel - b[1 + w];
-            const uint32_t first = rank > 0 && ((key[o - 1] >> shift) != (kk >> shift));   // same (slice, panel, phase, wavefront), another layer
-            word = (first << 31) | ((rl >> 2) << shift) | c;
-            brk += first;
-        }
-        const int64_t dst = base + toff[((size_t)s * 4 + w) * (size_t)(2 * P + 1) + 2 * (size_t)j + ph] + rank;
-        tidx[dst] = word;
+        const uint32_t t = (uint32_t)(o - base) - bs[(size_t)s * (P + 1) + j], g = t >> 6, w = g & 3;
+        const int64_t dst = base + toff[((size_t)s * 4 + w) * (size_t)(P + 1) + (size_t)j] + ((g >> 2) << 6) + (t & 63);
+        tidx[dst] = ((uint32_t)(row_of_entry[k] - srow[s]) << shift) | ((uint32_t)col[k] & cmask);
         tval[dst] = val[k];
     }
-    for (int off = 32; off > 0; off >>= 1) brk += (unsigned)__shfl_xor((int)brk, off, 64);
-    if ((threadIdx.x & 63) == 0 && brk) atomicAdd(nbreaks, (unsigned long long)brk);
 }
 
 int bits_for(uint64_t v) {
@@ -344,45 +274,33 @@ int build_tiles_device(sla_csr *A, const std::vector<int32_t> &srow, int shift, 
 }
 
 // The CU-wide layout of sla_spmv_ctiles.hip from A's canonical device arrays (same contract as build_tiles_device).
-int build_ctiles_device(sla_csr *A, const std::vector<int32_t> &srow, int shift, int64_t P, bool relaxed, int64_t *maxseg_out, int64_t *nbreaks_out,
-                        bool *done) {
+int build_ctiles_device(sla_csr *A, const std::vector<int32_t> &srow, int shift, int64_t P, bool *done) {
     *done = false;
     sla_ctx *c = A->ctx;
     const int64_t nnz = A->nnz, rows = A->rows, S = (int64_t)srow.size() - 1;
     if (!A->d_col || !A->d_val || !A->d_rowptr || nnz <= 0 || nnz >= ((int64_t)1 << 31) || S <= 0) return SLA_OK;
     hipStream_t st = stream_of(c);
-    DevBuf d_srow, d_stat, d_key, d_key2, d_idx, d_idx2, d_rows, d_tmp, d_bs, d_tot;
+    DevBuf d_srow, d_key, d_key2, d_idx, d_idx2, d_rows, d_tmp, d_bs;
     auto launch_ok = [&]() { return hipGetLastError() == hipSuccess; };
+    const int pbits = bits_for((uint64_t)P), sbits = bits_for((uint64_t)S);
+    const int keybits = sbits + pbits + shift;
+    if (keybits > 62) return SLA_OK;
+    const size_t ntoff = (size_t)S * 4 * (size_t)(P + 1);
     hipError_t e = d_srow.alloc(sizeof(int32_t) * srow.size());
     if (e == hipSuccess) e = hipMemcpyAsync(d_srow.p, srow.data(), sizeof(int32_t) * srow.size(), hipMemcpyHostToDevice, st);
-    if (e == hipSuccess) e = d_stat.alloc(16);
-    if (e == hipSuccess) e = hipMemsetAsync(d_stat.p, 0, 16, st);
-    if (e != hipSuccess) return SLA_OK;
-    const int grid = 4096;
-    unsigned long long h_stat[2] = {0, 0};
-    if (A->rp64) hipLaunchKernelGGL((tile_maxseg_kernel<int64_t>), dim3(grid), dim3(256), 0, st, rows, (const int64_t *)A->d_rowptr, A->d_col, shift, d_stat.as<unsigned>());
-    else hipLaunchKernelGGL((tile_maxseg_kernel<int32_t>), dim3(grid), dim3(256), 0, st, rows, (const int32_t *)A->d_rowptr, A->d_col, shift, d_stat.as<unsigned>());
-    if (!launch_ok()) return SLA_OK;
-    SLA_HIP_TRY(hipMemcpyAsync(h_stat, d_stat.p, 8, hipMemcpyDeviceToHost, st));
-    SLA_HIP_TRY(hipStreamSynchronize(st));
-    const int64_t maxseg = (int64_t)(unsigned)h_stat[0];
-    const int lbits = bits_for((uint64_t)std::max<int64_t>(maxseg, 1)), pbits = bits_for((uint64_t)P), sbits = bits_for((uint64_t)S);
-    const int keybits = sbits + pbits + 1 + 2 + lbits + shift;
-    if (keybits > 62) return SLA_OK;
-    const size_t ntoff = (size_t)S * 4 * (size_t)(2 * P + 1);
-    e = d_key.alloc(8 * (size_t)nnz);
+    if (e == hipSuccess) e = d_key.alloc(8 * (size_t)nnz);
     if (e == hipSuccess) e = d_key2.alloc(8 * (size_t)nnz);
     if (e == hipSuccess) e = d_idx.alloc(4 * (size_t)nnz);
     if (e == hipSuccess) e = d_idx2.alloc(4 * (size_t)nnz);
     if (e == hipSuccess) e = d_rows.alloc(4 * (size_t)nnz);
-    if (e == hipSuccess) e = d_bs.alloc(4 * ((size_t)S * P * 5 + 8));
-    if (e == hipSuccess) e = d_tot.alloc(4 * (size_t)S * 4);
+    if (e == hipSuccess) e = d_bs.alloc(4 * ((size_t)S * (P + 1) + 8));
     size_t tmp_bytes = 0;
     if (e == hipSuccess)
         e = rocprim::radix_sort_pairs(nullptr, tmp_bytes, d_key.as<uint64_t>(), d_key2.as<uint64_t>(), d_idx.as<uint32_t>(), d_idx2.as<uint32_t>(),
                                       (size_t)nnz, 0, (unsigned)keybits, st);
     if (e == hipSuccess) e = d_tmp.alloc(tmp_bytes);
-    if (e == hipSuccess && !A->d_tlidx) e = dev_malloc(c, (void **)&A->d_tlidx, sizeof(uint32_t) * (size_t)nnz + 64);
+    if (e != hipSuccess) { (void)hipGetLastError(); return SLA_OK; }   // (no device memory for the scratch: the host path may still work)
+    if (!A->d_tlidx) e = dev_malloc(c, (void **)&A->d_tlidx, sizeof(uint32_t) * (size_t)nnz + 64);
     if (e == hipSuccess && !A->d_tlval) e = dev_malloc(c, (void **)&A->d_tlval, sizeof(double) * (size_t)nnz + 64);
     if (e == hipSuccess && !A->d_tloff) e = dev_malloc(c, (void **)&A->d_tloff, sizeof(uint32_t) * ntoff + 64);
     auto give_up = [&]() {
@@ -393,46 +311,31 @@ int build_ctiles_device(sla_csr *A, const std::vector<int32_t> &srow, int shift,
         return SLA_OK;
     };
     if (e != hipSuccess) return give_up();
+    const int grid = 4096;
     const unsigned gs = (unsigned)std::min<int64_t>(S, 65535);
-    const unsigned gt = (unsigned)std::min<int64_t>(((int64_t)S * P * 5 + 255) / 256, 65535);
-    const unsigned go = (unsigned)std::min<int64_t>(((int64_t)ntoff + 255) / 256, 65535);
-#define SLA_CT_LAUNCH(KERNEL, GRID, BLOCK, ...)                                                                          \
-    do {                                                                                                                 \
-        if (A->rp64) hipLaunchKernelGGL((KERNEL<int64_t>), dim3(GRID), dim3(BLOCK), 0, st, __VA_ARGS__);                  \
-        else hipLaunchKernelGGL((KERNEL<int32_t>), dim3(GRID), dim3(BLOCK), 0, st, __VA_ARGS__);                          \
-    } while (0)
-#define SLA_CT_RP(T) ((const T *)A->d_rowptr)
+    const unsigned gt = (unsigned)std::min<int64_t>(((int64_t)S * (P + 1) + 255) / 256, 65535);
     if (A->rp64) {
-        hipLaunchKernelGGL((ctile_keys_kernel<int64_t>), dim3(gs), dim3(256), 0, st, (int)S, d_srow.as<int32_t>(), SLA_CT_RP(int64_t), A->d_col, shift, lbits, pbits, relaxed ? 1 : 0, d_key.as<uint64_t>(), d_idx.as<uint32_t>());
-        hipLaunchKernelGGL((tile_rows_kernel<int64_t>), dim3(grid), dim3(256), 0, st, rows, SLA_CT_RP(int64_t), d_rows.as<int32_t>());
+        hipLaunchKernelGGL((ctile_keys_kernel<int64_t>), dim3(gs), dim3(256), 0, st, (int)S, d_srow.as<int32_t>(), (const int64_t *)A->d_rowptr, A->d_col, shift, pbits, d_key.as<uint64_t>(), d_idx.as<uint32_t>());
+        hipLaunchKernelGGL((tile_rows_kernel<int64_t>), dim3(grid), dim3(256), 0, st, rows, (const int64_t *)A->d_rowptr, d_rows.as<int32_t>());
     } else {
-        hipLaunchKernelGGL((ctile_keys_kernel<int32_t>), dim3(gs), dim3(256), 0, st, (int)S, d_srow.as<int32_t>(), SLA_CT_RP(int32_t), A->d_col, shift, lbits, pbits, relaxed ? 1 : 0, d_key.as<uint64_t>(), d_idx.as<uint32_t>());
-        hipLaunchKernelGGL((tile_rows_kernel<int32_t>), dim3(grid), dim3(256), 0, st, rows, SLA_CT_RP(int32_t), d_rows.as<int32_t>());
+        hipLaunchKernelGGL((ctile_keys_kernel<int32_t>), dim3(gs), dim3(256), 0, st, (int)S, d_srow.as<int32_t>(), (const int32_t *)A->d_rowptr, A->d_col, shift, pbits, d_key.as<uint64_t>(), d_idx.as<uint32_t>());
+        hipLaunchKernelGGL((tile_rows_kernel<int32_t>), dim3(grid), dim3(256), 0, st, rows, (const int32_t *)A->d_rowptr, d_rows.as<int32_t>());
     }
     if (!launch_ok()) return give_up();
     e = rocprim::radix_sort_pairs(d_tmp.p, tmp_bytes, d_key.as<uint64_t>(), d_key2.as<uint64_t>(), d_idx.as<uint32_t>(), d_idx2.as<uint32_t>(), (size_t)nnz, 0,
                                   (unsigned)keybits, st);
     if (e != hipSuccess) return give_up();
-    if (A->rp64) {
-        hipLaunchKernelGGL((ctile_bounds_kernel<int64_t>), dim3(gt), dim3(256), 0, st, (int)S, (int)P, d_key2.as<uint64_t>(), d_srow.as<int32_t>(), SLA_CT_RP(int64_t), shift, lbits, pbits, d_bs.as<uint32_t>());
-        hipLaunchKernelGGL((ctile_counts_kernel<int64_t>), dim3(gt), dim3(256), 0, st, (int)S, (int)P, d_bs.as<uint32_t>(), d_srow.as<int32_t>(), SLA_CT_RP(int64_t), A->d_tloff);
-    } else {
-        hipLaunchKernelGGL((ctile_bounds_kernel<int32_t>), dim3(gt), dim3(256), 0, st, (int)S, (int)P, d_key2.as<uint64_t>(), d_srow.as<int32_t>(), SLA_CT_RP(int32_t), shift, lbits, pbits, d_bs.as<uint32_t>());
-        hipLaunchKernelGGL((ctile_counts_kernel<int32_t>), dim3(gt), dim3(256), 0, st, (int)S, (int)P, d_bs.as<uint32_t>(), d_srow.as<int32_t>(), SLA_CT_RP(int32_t), A->d_tloff);
-    }
-    hipLaunchKernelGGL(ctile_scan_kernel, dim3((unsigned)((S * 4 + 63) / 64)), dim3(64), 0, st, (int)S, (int)P, A->d_tloff, d_tot.as<uint32_t>());
-    hipLaunchKernelGGL(ctile_wavebase_kernel, dim3(go), dim3(256), 0, st, (int)S, (int)P, A->d_tloff, d_tot.as<uint32_t>());
+    // tile starts: the wavefront-private form's offsets kernel with no layer field (lbits = 0)
+    if (A->rp64) hipLaunchKernelGGL((tile_offsets_kernel<int64_t>), dim3(gt), dim3(256), 0, st, (int)S, (int)P, nnz, d_key2.as<uint64_t>(), d_srow.as<int32_t>(), (const int64_t *)A->d_rowptr, shift, 0, pbits, d_bs.as<uint32_t>());
+    else hipLaunchKernelGGL((tile_offsets_kernel<int32_t>), dim3(gt), dim3(256), 0, st, (int)S, (int)P, nnz, d_key2.as<uint64_t>(), d_srow.as<int32_t>(), (const int32_t *)A->d_rowptr, shift, 0, pbits, d_bs.as<uint32_t>());
+    hipLaunchKernelGGL(ctile_counts_kernel, dim3(gt), dim3(256), 0, st, (int)S, (int)P, d_bs.as<uint32_t>(), A->d_tloff);
+    hipLaunchKernelGGL(ctile_scan_kernel, dim3((unsigned)((S + 63) / 64)), dim3(64), 0, st, (int)S, (int)P, A->d_tloff);
     if (A->rp64)
-        hipLaunchKernelGGL((ctile_emit_kernel<int64_t>), dim3(grid), dim3(256), 0, st, nnz, (int)P, d_key2.as<uint64_t>(), d_idx2.as<uint32_t>(), d_srow.as<int32_t>(), SLA_CT_RP(int64_t), A->d_col, A->d_val, d_rows.as<int32_t>(), d_bs.as<uint32_t>(), A->d_tloff, shift, lbits, pbits, A->d_tlidx, A->d_tlval, d_stat.as<unsigned long long>() + 1);
+        hipLaunchKernelGGL((ctile_emit_kernel<int64_t>), dim3(grid), dim3(256), 0, st, nnz, (int)P, d_key2.as<uint64_t>(), d_idx2.as<uint32_t>(), d_srow.as<int32_t>(), (const int64_t *)A->d_rowptr, A->d_col, A->d_val, d_rows.as<int32_t>(), d_bs.as<uint32_t>(), A->d_tloff, shift, pbits, A->d_tlidx, A->d_tlval);
     else
-        hipLaunchKernelGGL((ctile_emit_kernel<int32_t>), dim3(grid), dim3(256), 0, st, nnz, (int)P, d_key2.as<uint64_t>(), d_idx2.as<uint32_t>(), d_srow.as<int32_t>(), SLA_CT_RP(int32_t), A->d_col, A->d_val, d_rows.as<int32_t>(), d_bs.as<uint32_t>(), A->d_tloff, shift, lbits, pbits, A->d_tlidx, A->d_tlval, d_stat.as<unsigned long long>() + 1);
-#undef SLA_CT_LAUNCH
-#undef SLA_CT_RP
+        hipLaunchKernelGGL((ctile_emit_kernel<int32_t>), dim3(grid), dim3(256), 0, st, nnz, (int)P, d_key2.as<uint64_t>(), d_idx2.as<uint32_t>(), d_srow.as<int32_t>(), (const int32_t *)A->d_rowptr, A->d_col, A->d_val, d_rows.as<int32_t>(), d_bs.as<uint32_t>(), A->d_tloff, shift, pbits, A->d_tlidx, A->d_tlval);
     if (!launch_ok()) return give_up();
-    SLA_HIP_TRY(hipMemcpyAsync(h_stat, d_stat.p, 16, hipMemcpyDeviceToHost, st));
     SLA_HIP_TRY(hipStreamSynchronize(st));
-    *maxseg_out = maxseg;
-    *nbreaks_out = (int64_t)h_stat[1];
     *done = true;
     return SLA_OK;
 }

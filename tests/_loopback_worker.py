@@ -170,6 +170,12 @@ y = cat("y")
 yo = orc.spmv(Ao, xg)
 if KIND in ("random", "dense", "denseband") or (KIND.startswith("fuzz") and "wdia" not in results[0]["kernel"] and len(VA) > 8 * n):     # > 8 stored entries per row on average: wavefront-segmented sums, last-bit grouping differences
     assert np.abs(y - yo).max() <= 4e-15 * np.abs(VA).max() * np.abs(xg).max() * 16, np.abs(y - yo).max()
+elif KIND == "randtile" and "cu_slices=1" in results[0]["kernel"]:
+    # CU-wide tiles (round 5 default, tile_relaxed = 1): the products of a row are added by LDS atomics in timing order -- every row
+    # within nnz_i eps sum |a_ij x_j| of the reference's fold, whatever the exchange flow (overlapped passes, plain all-gather)
+    bound = np.diff(RP) * np.finfo(np.float64).eps * orc.spmv(orc.Csr(n, n, RP, CI, np.abs(VA)), np.abs(xg))
+    assert np.all(np.abs(y - yo) <= bound), float((np.abs(y - yo) / np.maximum(bound, 1e-300)).max())
+    print("RELAXED_ORDER_ROWS_WITHIN_BOUND", n)
 elif KIND == "randtile" and "allgather=arrival" in results[0]["kernel"]:
     # Overlapped all-gather in arrival order: every rank folds its rows over the column panels in ITS visiting
     # order -- own panels first, then by exchange group -- which sla_plan_allgather_passes states and the oracle restates: bit for bit.

@@ -31,7 +31,7 @@ def test_split_launch_partials_stay_inside_their_slot_array():
 
 
 def _randtile(nranks, **env_extra):
-    env = dict(os.environ, SLA_TILE_SHIFT="10", **env_extra)
+    env = dict(os.environ, SLA_TILE_SHIFT="10", **{"SLA_TILE_RELAXED": "0", **env_extra})   # (the bit-for-bit claims below are the exact form's)
     out = subprocess.run([sys.executable, os.path.join(HERE, "_loopback_worker.py"), str(nranks), "randtile"], env=env,
                          stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
     assert out.returncode == 0 and f"LOOPBACK_OK {nranks} randtile" in out.stdout, out.stdout[-3000:]
@@ -61,6 +61,17 @@ def test_tile_form_on_row_slabs(nranks):
     assert "allgather=ascending" in oa and f"groups={nranks}" in oa and ha == hm, (ha, hm)
     o2, h2 = _randtile(nranks, SLA_AG_GROUPS="2")
     assert "allgather=arrival groups=2" in o2
+
+
+@pytest.mark.parametrize("nranks", [2, 5])
+def test_cu_wide_tile_form_on_row_slabs(nranks):
+    """The default tile form since round 5 (tile_relaxed = 1: CU-wide slices, LDS atomics, csrc/sla_spmv_ctiles.hip) on row slabs:
+    overlapped all-gather passes (running row sums carried through yinit), serialised groups, the plain all-gather and ascending
+    source-ordered groups -- every row within nnz_i eps sum |a_ij x_j| of the reference's fold (the worker checks it), all solvers
+    converge like the oracle's."""
+    for extra in ({}, {"SLA_OVERLAP": "0"}, {"SLA_OVERLAP": "-1"}, {"SLA_AG_ORDER": "1"}):
+        out, _ = _randtile(nranks, SLA_TILE_RELAXED="1", **extra)
+        assert "cu_slices=1" in out and "RELAXED_ORDER_ROWS_WITHIN_BOUND" in out, out[-2000:]
 
 
 @pytest.mark.parametrize("seed,nranks", [(1, 2), (2, 3), (3, 4), (4, 5), (6, 3)])

@@ -56,6 +56,43 @@ CASES = {
 
 
 @pytest.mark.parametrize("name", list(CASES))
+def test_cu_wide_tiles_relaxed_order_within_the_bound(sla, name):
+    """Round 5, the default tile form (option tile_relaxed = 1, csrc/sla_spmv_ctiles.hip): slices shared by a workgroup's four wavefronts,
+    every tile one column-sorted run, products added into the row sums by LDS atomics in whatever order the wavefronts get there.
+    Contract: |y_i - fold_i| <= nnz_i eps sum_j |a_ij x_j| -- every product is rounded separately, only the order
+    of the additions differs from the reference's left fold; a row with ONE or TWO entries is still exact (no order to differ).
+    Device builder and host builder produce the same layout: same kernel, so compared through y within the bound and through
+    rows of <= 2 entries bit for bit."""
+    build, _ = CASES[name]
+    dims, csr = build()
+    m, n = dims
+    rp, ci, va = csr
+    Ao = orc.Csr(m, n, rp, ci, va)
+    x = np.random.default_rng(11).standard_normal(n)
+    want = orc.spmv(Ao, x)
+    lens = np.diff(rp)
+    bound = lens * EPS * orc.spmv(orc.Csr(m, n, rp, ci, np.abs(va)), np.abs(x)) + 1e-300
+    for rp64, dev in (("0", 2), ("1", 2), ("0", 0), ("1", 0)):
+        ctx = sla.Context(0).set_options(tile_shift=10, lpanel=0, lflat=0, force_rp64=rp64, tiles_device=dev, tile_relaxed=1)
+        A = sla.fromCSR(dims, rp, ci, va, ctx)
+        info = A.kernel_info()
+        if m > 1:   # (relaxed order has no layers to step aside for: every case but the single row takes the form)
+            assert "algo=tiles" in info and "cu_slices=1" in info and "exact_fold=0" in info, (name, info)
+            assert ("tile builder on device" in A.lower_info()) == (dev == 2), (name, dev, A.lower_info())
+        for rep in range(3):
+            y = sla.matVec(A, sla.fromVector(x, ctx)).toDenseListSV()
+            assert np.all(np.abs(y - want) <= bound), (name, rp64, dev, float((np.abs(y - want) / bound).max()))
+            assert np.array_equal(y[lens <= 2], want[lens <= 2]), (name, rp64, dev)
+        if rp64 == "0" and dev == 2:   # pacing variants only change WHEN a tile is walked
+            for opts in ({"tile_slack": 1}, {"tile_slack": 0}):
+                ctx.set_options(**opts)
+                y = sla.matVec(A, sla.fromVector(x, ctx)).toDenseListSV()
+                assert np.all(np.abs(y - want) <= bound), (name, opts)
+        del A
+        ctx.close()
+
+
+@pytest.mark.parametrize("name", list(CASES))
 def test_tiles_match_the_oracle(sla, name):
     build, expect_tiles = CASES[name]
     dims, csr = build()
@@ -69,14 +106,14 @@ def test_tiles_match_the_oracle(sla, name):
     # (lpanel=0: the dense-row cases would otherwise take the LDS-panel form; tiles_device: the re-ordering as a device sort -- round 4,
     # sla_tiles_build.hip -- and by the host builder: the same decision and the same bits from both)
     for rp64, dev in (("0", 2), ("1", 2), ("0", 0), ("1", 0)):
-        ctx = sla.Context(0).set_options(tile_shift=10, lpanel=0, lflat=0, force_rp64=rp64, tiles_device=dev)
+        ctx = sla.Context(0).set_options(tile_shift=10, lpanel=0, lflat=0, force_rp64=rp64, tiles_device=dev, tile_relaxed=0)
         A = sla.fromCSR(dims, rp, ci, va, ctx)
         info = A.kernel_info()
         assert ("algo=tiles" in info) == expect_tiles, (name, info)
         assert ("tile builder on device" in A.lower_info()) == (expect_tiles and dev == 2), (name, dev, A.lower_info())
         y = sla.matVec(A, sla.fromVector(x, ctx)).toDenseListSV()
         if expect_tiles:
-            assert "exact_fold=1" in info
+            assert "exact_fold=1" in info and "cu_slices=0" in info
             assert np.array_equal(y, want), (name, rp64, dev, int(np.count_nonzero(y != want)))
         else:
             assert np.all(np.abs(y - want) <= bound), (name, rp64, float(np.abs(y - want).max()))
@@ -90,30 +127,35 @@ def test_tiles_match_the_oracle(sla, name):
                 assert np.array_equal(sla.matVec(A, sla.fromVector(x, ctx)).toDenseListSV(), want), (name, opts)
             ctx.set_options(tile_poll=1, tile_prefetch=0, tile_slack=3)
     # the same matrix on the forms the tile form replaces
-    ctx = sla.Context(0).set_options(tile_shift=10, lpanel=0, lflat=0, tiles=0)
+    ctx = sla.Context(0).set_options(tile_shift=10, lpanel=0, lflat=0, tiles=0, tile_relaxed=0)
     A = sla.fromCSR(dims, rp, ci, va, ctx)
     assert "tiles" not in A.kernel_info()
     y0 = sla.matVec(A, sla.fromVector(x, ctx)).toDenseListSV()
     assert np.all(np.abs(y0 - want) <= bound)
 
 
-def test_tiles_transpose_and_solver_epilogues(sla):
+@pytest.mark.parametrize("relaxed", [1, 0])
+def test_tiles_transpose_and_solver_epilogues(sla, relaxed):
     """(<#), bicgsInit / bicgstabStep (EPI_SUB, EPI_DOT, EPI_DOT2), cgsStep (EPI_AXPY_DOT), cgneStep (EPI_AXPY_DOT on A,
-    EPI_XPBY_NRM on the transpose) and linSolve0's residual sweep (EPI_RES) on the tile form."""
+    EPI_XPBY_NRM on the transpose) and linSolve0's residual sweep (EPI_RES) on the tile form -- the CU-wide relaxed-order kernel
+    (default) and the bit-exact wavefront-private one."""
     from sla_amd import workloads as wl
-    ctx = sla.Context(0).set_option("tile_shift", 10)
+    ctx = sla.Context(0).set_options(tile_shift=10, tile_relaxed=relaxed)
     n = 6000
     dims, (rp, ci, va) = wl.random_spd(n, 5, 3)
     A, Ao = sla.fromCSR(dims, rp, ci, va, ctx), orc.Csr(n, n, rp, ci, va)
-    assert "algo=tiles" in A.kernel_info()
+    assert "algo=tiles" in A.kernel_info() and f"cu_slices={relaxed}" in A.kernel_info()
     rng = np.random.default_rng(5)
     u = rng.standard_normal(n)
-    assert np.array_equal(sla.vecMat(sla.fromVector(u, ctx), A).toDenseListSV(), orc.spmv(orc.transpose(Ao), u))
+    absA = orc.Csr(n, n, rp, ci, np.abs(va))
+    same = (lambda got, ref, bnd: np.array_equal(got, ref)) if not relaxed else (lambda got, ref, bnd: bool(np.all(np.abs(got - ref) <= bnd)))
+    assert same(sla.vecMat(sla.fromVector(u, ctx), A).toDenseListSV(), orc.spmv(orc.transpose(Ao), u),
+                np.diff(orc.transpose(Ao).rowptr) * EPS * orc.spmv(orc.transpose(absA), np.abs(u)))
     xs = rng.standard_normal(n)
     b, x0 = orc.spmv(Ao, xs), np.full(n, 0.1)
     r0hat = b - orc.spmv(Ao, x0)
     so, sd = orc.BicgstabState(Ao, b, x0), sla.bicgsInit(A, sla.fromVector(b, ctx), sla.fromVector(x0, ctx))
-    assert np.array_equal(sd._rBicgstab.toDenseListSV(), so.r)               # r0 = b - A x0: exact fold, same subtraction
+    assert same(sd._rBicgstab.toDenseListSV(), so.r, np.diff(rp) * EPS * orc.spmv(absA, np.abs(x0)) + EPS * np.abs(so.r))   # r0 = b - A x0: same subtraction (relaxed: of a row sum within the bound)
     for k in (1, 2):
         so.step(r0hat, k); sd.step(k)
         assert np.linalg.norm(sd._xBicgstab.toDenseListSV() - so.x) <= 1e-9 * np.linalg.norm(so.x)
@@ -140,19 +182,27 @@ def test_default_panel_width_picks_tiles_only_beyond_the_l2(sla):
     assert "tiles" not in sla.fromCSR(dims, rp, ci, va, ctx).kernel_info()
     dims, (rp, ci, va) = wl.random_spd(700000, 4, 1)          # 5.6 MB of x: eleven 512 KiB panels (2^16 columns below 6 M columns)
     A = sla.fromCSR(dims, rp, ci, va, ctx)
-    assert "algo=tiles" in A.kernel_info() and "panels=11 panel_cols=65536" in A.kernel_info(), A.kernel_info()
+    assert "algo=tiles" in A.kernel_info() and "panels=11 panel_cols=65536" in A.kernel_info() and "cu_slices=1" in A.kernel_info(), A.kernel_info()
     x = np.random.default_rng(2).standard_normal(dims[0])
-    assert np.array_equal(sla.matVec(A, sla.fromVector(x, ctx)).toDenseListSV(), orc.spmv(orc.Csr(*dims, rp, ci, va), x))
+    yo = orc.spmv(orc.Csr(*dims, rp, ci, va), x)
+    bound = np.diff(rp) * EPS * orc.spmv(orc.Csr(*dims, rp, ci, np.abs(va)), np.abs(x))
+    assert np.all(np.abs(sla.matVec(A, sla.fromVector(x, ctx)).toDenseListSV() - yo) <= bound)
+    ctx0 = sla.Context(0).set_option("tile_relaxed", 0)        # the bit-exact form: same geometry rule, the reference's fold
+    A0 = sla.fromCSR(dims, rp, ci, va, ctx0)
+    assert "panels=11 panel_cols=65536" in A0.kernel_info() and "exact_fold=1" in A0.kernel_info(), A0.kernel_info()
+    assert np.array_equal(sla.matVec(A0, sla.fromVector(x, ctx0)).toDenseListSV(), yo)
 
 
+@pytest.mark.parametrize("relaxed", [0, 1])
 @pytest.mark.parametrize("ranks,rank,groups", [(4, 1, 4), (8, 7, 2), (3, 0, 3), (2, 1, 1)])
-def test_panel_passes_of_the_overlapped_allgather_on_one_rank(sla, ranks, rank, groups):
+def test_panel_passes_of_the_overlapped_allgather_on_one_rank(sla, ranks, rank, groups, relaxed):
     """The pass structure of the overlapped all-gather (round 4) REHEARSED on a single-rank context (options
     ag_sim_ranks / ag_sim_rank: the tile launch of rank `rank` of `ranks` as the plan's panel passes, running row sums carried from
     pass to pass, no exchange): every cut of the visiting order -- many panels per pass (> 64: the offset block reload inside a
     pass), ragged rows, empty tiles, rectangular shapes.
       arrival order:   rows == the oracle's left fold over the panels in the plan's visiting order, bit for bit;
       ascending order: rows == the reference's ascending left fold (orc.spmv), bit for bit -- the carry through yinit is exact;
+    (tile_relaxed = 1, the CU-wide kernel: the same passes, every row within nnz_i eps sum |a_ij x_j| of the ascending fold)
     and two BiCGSTAB steps + two CGS steps through the fused epilogues of the LAST pass against the oracle."""
     from sla_amd.partition import plan_allgather_passes
     shift = 10
@@ -164,13 +214,16 @@ def test_panel_passes_of_the_overlapped_allgather_on_one_rank(sla, ranks, rank, 
         x = np.random.default_rng(9).standard_normal(n)
         yo = orc.spmv(Ao, x)
         for order in (0, 1):
-            ctx = sla.Context(0).set_options(tile_shift=shift, lpanel=0, lflat=0, ag_sim_ranks=ranks, ag_sim_rank=rank, ag_groups=groups, ag_order=order)
+            ctx = sla.Context(0).set_options(tile_shift=shift, lpanel=0, lflat=0, ag_sim_ranks=ranks, ag_sim_rank=rank, ag_groups=groups, ag_order=order, tile_relaxed=relaxed)
             A = sla.fromCSR(dims, rp, ci, va, ctx)
             info = A.kernel_info()
             visit, pptr, pneed, ng = plan_allgather_passes(ranks, rank, n, shift, groups, order)
             assert "algo=tiles" in info and f"allgather={'ascending' if order else 'arrival'} groups={ng} passes={len(pneed)} (rehearsal)" in info, info
             y = sla.matVec(A, sla.fromVector(x, ctx)).toDenseListSV()
-            if order == 1:
+            if relaxed:
+                assert f"cu_slices=1" in info
+                assert np.all(np.abs(y - yo) <= np.diff(rp) * EPS * orc.spmv(orc.Csr(m, n, rp, ci, np.abs(va)), np.abs(x))), (label, info)
+            elif order == 1:
                 assert np.array_equal(y, yo), (label, info)
             else:
                 assert np.array_equal(y, orc.spmv_panel_order(Ao, x, shift, visit)), (label, info)

@@ -71,6 +71,11 @@ forms = (("default", {}), ("no march", {"wd_march": 0}), ("gather (wd_lds=0)", {
          ("no tiles", {"tiles": 0}), ("no tiles, no col panels", {"tiles": 0, "panels": 0}), ("no LDS panels", {"lpanel": 0}),
          ("no LDS panels, no tiles", {"lpanel": 0, "tiles": 0, "panels": 0}), ("LDS panels forced", {"lp_minseg": 1}),
          ("tiles, 2^16-column panels", {"lpanel": 0, "tile_shift": 16}), ("tiles, 2^15-column panels", {"lpanel": 0, "tile_shift": 15}),
+         ("wavefront-private tiles (r4)", {"lpanel": 0, "lflat": 0, "tile_cu": 0}),
+         ("CU tiles exact", {"lpanel": 0, "lflat": 0, "tile_cu": 1, "tile_relaxed": 0}),
+         ("CU tiles relaxed", {"lpanel": 0, "lflat": 0, "tile_cu": 1, "tile_relaxed": 1}),
+         ("CU tiles relaxed 2^15", {"lpanel": 0, "lflat": 0, "tile_cu": 1, "tile_relaxed": 1, "tile_shift": 15}),
+         ("CU tiles relaxed 2^17", {"lpanel": 0, "lflat": 0, "tile_cu": 1, "tile_relaxed": 1, "tile_shift": 17}),
          ("plain CSR", {"wdia": 0, "vdict": 0, "diag": 0, "tiles": 0, "panels": 0, "lpanel": 0}),
          ("plain CSR, stream kernel", {"wdia": 0, "vdict": 0, "diag": 0, "tiles": 0, "panels": 0, "lpanel": 0, "stream_wave": 0}))
 seen = set()
@@ -82,7 +87,7 @@ for label, opts in forms:
         print(f"{name:14s} {label:26s} failed: {e!r}", flush=True)
         continue
     info = r["spmv_kernel"]
-    algo = info.split()[0] + (" " + [t for t in info.split() if t.startswith("panel_cols=")][0] if "panel_cols=" in info else "")
+    algo = info.split()[0] + "".join(" " + t for t in info.split() if t.startswith(("panel_cols=", "exact_fold=", "cu_slices=")))
     if algo in seen and label != "default":
         continue
     seen.add(algo)
