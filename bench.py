@@ -153,7 +153,7 @@ def cpu_baseline(dims, rp, ci, va, b, seconds):
         st.step(r0p, osteps)
         odt = time.perf_counter() - t0
         out["omp"] = {"value": osteps / odt, "unit": "iters/s", "cores": threads, "kind": "port",
-                      "step_gbps_csr": (24 * len(ci) + 160 * n) * osteps / odt / 1e9,
+                      "step_effective_gbps_on_csr_bytes": (24 * len(ci) + 160 * n) * osteps / odt / 1e9,
                       "temporaries": "kept across steps (no per-step malloc / first-touch faults in the timing build)",
                       "first_touch": "matrix and vectors copied row-parallel before timing (orc_par_copy_csr)",
                       "sample": f"{osteps} bicgstabStep iterations, OpenMP build of the same port (liboracle_omp.so), {threads} threads"}
@@ -307,8 +307,8 @@ def side_block(name, dims, rp, ci, va, options, steps, warmup, rhs="A.1"):
     rec = {"workload": name, "rows": n, "nnz": nnz, "steps": steps, "warmup": warmup, "options": options, "rhs": rhs + ", x0 = 0",
            "convergence": convergence_note(ctx, st, n, r0norm, conv.get("res_before", float("nan"))),
            "value": steps / dt, "unit": "iters/s", "ms_per_step": dt / steps * 1e3,
-           "step_gbps_csr": (24 * nnz + 160 * n) / (dt / steps) / 1e9,
-           "step_frac_of_hbm_peak_csr": (24 * nnz + 160 * n) / (dt / steps) / 1e9 / HBM_PEAK_GBS,
+           "step_effective_gbps_on_csr_bytes": (24 * nnz + 160 * n) / (dt / steps) / 1e9,
+           "step_effective_frac_on_csr_bytes": (24 * nnz + 160 * n) / (dt / steps) / 1e9 / HBM_PEAK_GBS,
            "k1_ms": k1.get("ms"), "k1_gbps": k1.get("gbps"), "k1_frac": k1.get("frac"),
            "k1_csr_gbps": k1.get("effective_gbps"), "k1_csr_frac": k1.get("effective_frac"),
            "kernels": {k: {"ms": v["ms"], "frac": v["frac"]} for k, v in kt.items()},
@@ -395,8 +395,8 @@ def sharded_random_block(ctx, name, rank, world, sync_all, allreduce, steps, war
     rec = {"workload": f"{n}-row fp64 random SPD (~33 nnz/row), row-sharded x{world}", "rows": n, "nnz": nnz, "steps": steps, "warmup": warmup,
            "rhs": "A.x* (x* = N(0,1), seed 7), x0 = 0", "convergence": note,
            "value": steps / dt, "unit": "iters/s", "ms_per_step": dt / steps * 1e3,
-           "step_gbps_csr": (24 * nnz + 160 * n) / (dt / steps) / 1e9,
-           "step_frac_of_hbm_peak_csr": (24 * nnz + 160 * n) / (dt / steps) / 1e9 / (HBM_PEAK_GBS * world),
+           "step_effective_gbps_on_csr_bytes": (24 * nnz + 160 * n) / (dt / steps) / 1e9,
+           "step_effective_frac_on_csr_bytes": (24 * nnz + 160 * n) / (dt / steps) / 1e9 / (HBM_PEAK_GBS * world),
            "k1_ms": k1.get("ms"), "k1_frac": k1.get("frac"), "k1_csr_frac": k1.get("effective_frac"),
            "kernels_rank0": {k_: {"ms": v["ms"], "frac": v["frac"]} for k_, v in kt.items()},
            "exchanges_rank0": ex, "spmv_kernel": A.kernel_info(), "slab_assembly_s": t_gen}
@@ -422,6 +422,85 @@ def pmc_traffic(workload_name, mode, world, kernel_name, kinfo):
     except OSError:
         pass
     return None
+
+
+# ---- N > 1: first contact ------------------------------------------------------------------------------------------------------
+# What the multi-rank run is doing right now, for the staged watchdog of main(): a hang names its collective.
+STAGE = {"name": "start", "deadline": None}
+
+
+def stamp(rank, text):
+    sys.stderr.write(f"[bench {time.strftime('%H:%M:%S')}] rank {rank}: {text}\n")
+    sys.stderr.flush()
+
+
+def enter_stage(rank, name, limit_s=None):
+    STAGE["name"] = name
+    STAGE["deadline"] = None if limit_s is None else time.monotonic() + limit_s
+    stamp(rank, name)
+
+
+FALLBACK_OPTIONS = {"x_exchange": "allgather", "ag_groups": 0, "bicg_ghost": 0}
+
+
+def preflight(ctx, rank, world, fallback):
+    """One checked collective at a time across the real ranks BEFORE anything is lowered or timed (sla_dist_preflight), each phase
+    stamped on stderr: ncclAllGather, the integer all-reduce, then the all-gather as one ncclSend / ncclRecv group (the pattern of
+    the halo exchange and of the overlapped all-gather).  If the grouped phase fails, the job falls back to the plain all-gather
+    flow (FALLBACK_OPTIONS: every (#>) input through ncclAllGather, no ghost-row flows) and says so in its line; a phase that hangs
+    is the staged watchdog's business (main()).  `fallback`: set when this process IS the re-run on the fallback flow."""
+    import sla_amd as sla
+    from sla_amd import _lib
+    limit = float(os.environ.get("SLA_BENCH_PREFLIGHT_S", "120"))
+    out = {}
+    phases = [(0, "ncclAllGather"), (2, "ncclAllReduce(max, int32)")] + ([] if fallback else [(1, "grouped ncclSend/ncclRecv all-gather")])
+    for ph, name in phases:
+        enter_stage(rank, f"preflight: {name} across {world} rank(s)", limit)
+        try:
+            err, ms = ctx.preflight(ph, 1 << 16)
+            if err != 0.0:
+                raise _lib.SlaError(-1, f"{name}: data arrived wrong (max |arrived - sent| = {err:g})")
+        except _lib.SlaError as e:
+            if ph != 1:
+                raise
+            fallback = f"pre-flight of the grouped ncclSend/ncclRecv flow failed ({e}); every exchange through plain ncclAllGather instead"
+            stamp(rank, "FALLBACK: " + fallback)
+            break
+        out[name] = {"ms": ms, "max_abs_err": err}
+        stamp(rank, f"preflight: {name} ok in {ms:.1f} ms")
+    if fallback:
+        ctx.set_options(**FALLBACK_OPTIONS)
+    enter_stage(rank, "lowering / timing")
+    return out, fallback
+
+
+def contract_allgather_block(ctx, dims, rb, rp, ci, va, b_local, n, method, steps, warmup, sync_all, allreduce):
+    """BASELINE.json config 4 to the letter: "RCCL all-gather(x) per BiCGSTAB step" -- the same slabs lowered again under
+    x_exchange = allgather / ag_groups = 0 (every (#>) input through ONE ncclAllGather into the full-length buffer, no halo
+    exchange, no ghost-row flow), timed with the headline's protocol, collectives event-timed.  Every rank must call this."""
+    import sla_amd as sla
+    saved = {k: ctx.get_option(k) for k in FALLBACK_OPTIONS}
+    ctx.set_options(**FALLBACK_OPTIONS)
+    try:
+        A = sla.fromCSRRows(dims, rb, rp, ci, va, ctx)
+        kinfo = A.kernel_info()
+        bvec = sla.DeviceVector(ctx, n, b_local, local=True)
+        st = sla.bicgsInit(A, bvec, sla.DeviceVector(ctx, n)) if method == "bicgstab" else sla.cgsInit(A, bvec, sla.DeviceVector(ctx, n))
+        dt, _, _ = timed_steps(ctx, st, steps, warmup, sync_all)
+        dt = allreduce(dt, "max")
+        kt = kernel_table(ctx, A, int(rp[-1]), len(b_local), method)
+        ex = exchange_table(ctx)
+        del st, A, bvec
+    finally:
+        ctx.set_options(**saved)
+    xb = ex.get("x_exchange", {})
+    return {"what": "config 4 with the contract's collective: ncclAllGather of the SpMV input vector (2 per step) into a full-length buffer; "
+                    "the headline above exchanges halos instead (DESIGN.md section 6)",
+            "value": steps / dt, "unit": "iters/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup,
+            "x_exchange": "ncclAllGather" if "x_exchange=allgather" in kinfo and "allgather=" not in kinfo else "see spmv_kernel",
+            "allgather_ms": xb.get("ms"), "allgather_launches": xb.get("launches"),
+            "allgather_bytes_received_per_rank": 8 * (n - len(b_local)),
+            "kernels_rank0": {k_: {"ms": v["ms"], "frac": v["frac"]} for k_, v in kt.items()}, "exchanges_rank0": ex, "spmv_kernel": kinfo}
 
 
 def run_rank(args, rank, world, local_rank, dist_mode, loop=None):
@@ -450,6 +529,9 @@ def run_rank(args, rank, world, local_rank, dist_mode, loop=None):
     else:
         ctx = sla.Context(0)
         sla.set_default_context(ctx)
+    fallback, pre = os.environ.get("SLA_BENCH_FALLBACK"), None
+    if dist_mode:
+        pre, fallback = preflight(ctx, rank, world, fallback)
 
     # ---- build this rank's slab on the host, lower it once to the device CSR ---------------------------
     if world == 1:
@@ -571,7 +653,15 @@ def run_rank(args, rank, world, local_rank, dist_mode, loop=None):
     rblock = None
     rname = {"auto": {"laplace3d_10m": "random_spd_10m", "laplace3d_small": "random_spd_small"}.get(args.workload)}.get(args.random_block, args.random_block)
     if dist_mode and args.mode == "step" and args.method == "bicgstab" and rname and rname != "none":
+        enter_stage(rank, f"{rname} block (row-sharded random matrix, x all-gathered)")
         rblock = sharded_random_block(ctx, rname, rank, world, sync_all, allreduce, max(20, args.steps // 4), max(5, args.warmup // 2))
+
+    cblock = None
+    if dist_mode and args.mode == "step" and args.workload.startswith("laplace3d") and os.environ.get("SLA_BENCH_CONTRACT", "1") != "0":
+        enter_stage(rank, "contract_allgather block (config 4 through ncclAllGather)")
+        cblock = contract_allgather_block(ctx, dims, rb, rp, ci, va, b_local, n, args.method, max(20, args.steps // 2), max(5, args.warmup // 2),
+                                          sync_all, allreduce)
+        enter_stage(rank, "plain (#>) timing")
 
     # ---- plain SpMV bandwidth (rank-local rows; includes the exchange when sharded) -----------------------
     # Over ROTATING vector pairs: with one pair the 2 x 80 MB stay in the 256 MB memory-side cache (MALL) between
@@ -639,8 +729,10 @@ def run_rank(args, rank, world, local_rank, dist_mode, loop=None):
                + (" + the residual sweep's own exchange and sum" if args.mode == "linsolve0" else "") if ghost
                else ("; plain flow" if args.mode != "gmres" else "; Arnoldi: one exchange per SpMV, per-column sums all-gathered")))
     rec.update({
-        "step_gbps_csr": step_bytes / (dt / args.steps) / 1e9,   # SURVEY 8(d) CSR bytes of the step / step time ("effective")
-        "spmv_gbps": spmv_bytes_local * world / (sp_mean_ms * 1e-3) / 1e9 if sp_launch else None,
+        "step_effective_gbps_on_csr_bytes": step_bytes / (dt / args.steps) / 1e9,   # SURVEY 8(d) CSR bytes of the step / step time ("effective")
+        # (#>) alone, priced on the SURVEY 8(d) CSR bytes 12 nnz + 20 n whatever the storage form streams: on a value-indexed form
+        # (the 216^3 stencil is stored in 10 MB) this EXCEEDS the HBM peak -- it is not a bandwidth; the literal CSR kernel's is csr_spmv_gbps
+        "spmv_effective_gbps_on_csr_bytes": spmv_bytes_local * world / (sp_mean_ms * 1e-3) / 1e9 if sp_launch else None,
         "spmv_ms": sp_mean_ms,                     # rotating over `spmv_vector_pairs` x / y pairs (HBM-resident)
         "spmv_ms_cache_resident": sp_cached_ms,    # one pair re-used: x and y stay in the memory-side cache
         "spmv_vector_pairs": pairs,
@@ -695,6 +787,12 @@ def run_rank(args, rank, world, local_rank, dist_mode, loop=None):
                                                "prices the same time on the SURVEY 8(d) CSR bytes",
                            "avg_launch_ms": mean_ms, "min_launch_ms": min_ms, "launches_timed": launches}
     rec.update(extra)
+    if dist_mode:
+        rec["preflight"] = pre
+        if fallback:
+            rec["fallback"] = fallback
+    if cblock:
+        rec["contract_allgather"] = cblock
     if rblock:
         rec[rname if rname != "random_spd_small" else "random_spd_10m"] = rblock
     # ---- the blocks the default line carries next to the headline (single GPU, default workload only) --------
@@ -719,6 +817,15 @@ def run_rank(args, rank, world, local_rank, dist_mode, loop=None):
             rec["random_spd_10m"] = side_block(d3, dm3, rp3, ci3, va3, {}, max(20, args.steps // 4), max(5, args.warmup // 2), rhs="A.x*")
         except Exception as e:
             rec["random_spd_10m"] = {"error": repr(e)}
+    # ---- BASELINE.json's metric, answered at the top level: "BiCGSTAB iters/sec + CSR SpMV achieved HBM GB/s, 10 M x 10 M fp64" ----
+    g = rec.get("general_csr") or {}
+    if g.get("k1_csr_gbps"):     # the literal CSR SpMV (f64 values + i32 columns + i32 row pointers) on config 4's matrix, K1 inside BiCGSTAB
+        rec["csr_spmv_gbps"], rec["csr_spmv_frac"] = g["k1_csr_gbps"], g["k1_csr_frac"]
+        rec["csr_spmv_kernel"] = g["spmv_kernel"].split()[0]
+    r3 = rec.get("random_spd_10m") or {}
+    if r3.get("value"):          # the north star's Target sentence: the 10 M-row random matrix (config 3a)
+        rec["north_star_target"] = {"workload": r3["workload"], "iters_per_s": r3["value"], "k1_ms": r3.get("k1_ms"), "k1_frac": r3.get("k1_csr_frac"),
+                                    "spmv_kernel": " ".join(t for t in r3.get("spmv_kernel", "").split() if t.startswith(("algo=", "exact_fold=", "cu_slices=")))}
     return rec
 
 
@@ -782,6 +889,72 @@ def main():
                     help="N > 1: also time the row-sharded random SPD matrix on the same context (auto: random_spd_10m next to the default workload; none)")
     args = ap.parse_args()
 
+    # The driver reads ONE JSON line from rank 0's stdout.  Native libraries print there too (gloo announces its connections, RCCL its
+    # version banner at ncclCommInitRank): everything but the line goes to stderr, the line itself to the saved descriptor (handed
+    # on through SLA_BENCH_JSON_FD when the staged watchdog below re-runs the process on the fallback flow).
+    def claim_stdout():
+        sys.stdout.flush()
+        fd = int(os.environ["SLA_BENCH_JSON_FD"]) if os.environ.get("SLA_BENCH_JSON_FD") else os.dup(1)
+        os.dup2(2, 1)
+        return fd
+
+    def start_watchdog(json_fd, rank, world):
+        """A hung collective on the first multi-GPU contact must not take the run with it.  Two stages:
+          1. a stage with a deadline of its own (the pre-flight phases: SLA_BENCH_PREFLIGHT_S, default 120 s each) that runs out -- or a
+             peer rank saying so through a flag file (one node: /tmp is shared) -- makes EVERY rank replace itself (execve: a rank stuck
+             inside RCCL cannot be unwound) by the same command on the fallback flow: SLA_BENCH_FALLBACK set, rendezvous one port up,
+             grouped send / recv skipped, every exchange through plain ncclAllGather; the line then carries "fallback";
+          2. past SLA_BENCH_WATCHDOG_S (default 1500 s; 0 = off) -- or a stage deadline missed on the fallback flow itself -- every rank
+             dumps its Python stacks, rank 0 writes an error line naming the stage where the driver reads the JSON, and the process exits."""
+        limit = float(os.environ.get("SLA_BENCH_WATCHDOG_S", "1500"))
+        if limit <= 0:
+            return
+        import faulthandler
+        t_end = time.monotonic() + limit
+        flag = f"/tmp/sla_bench_fallback_{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}"
+        in_fallback = bool(os.environ.get("SLA_BENCH_FALLBACK"))
+        if rank == 0 and not in_fallback and os.path.exists(flag):
+            os.unlink(flag)                      # (stale: a flag is at least one stage deadline younger than its job)
+
+        def bark(why):
+            faulthandler.dump_traceback(file=sys.stderr, all_threads=True)
+            if rank == 0:
+                os.write(json_fd, (json.dumps({"metric": "bicgstab_iters_per_sec", "value": None, "unit": "iters/s", "n_gpus": world,
+                                               "error": f"watchdog: {why}; stage: {STAGE['name']} (stacks on stderr)"}) + "\n").encode())
+            os._exit(3)
+
+        def rerun(reason):
+            stamp(rank, f"WATCHDOG: {reason} -> re-running on the fallback flow (plain ncclAllGather)")
+            try:
+                with open(flag, "w") as f:
+                    f.write(reason)
+            except OSError:
+                pass
+            os.set_inheritable(json_fd, True)
+            env = dict(os.environ, SLA_BENCH_FALLBACK=f"watchdog: {reason}; re-run with every exchange through plain ncclAllGather",
+                       SLA_BENCH_JSON_FD=str(json_fd))
+            if env.get("MASTER_PORT"):
+                env["MASTER_PORT"] = str(int(env["MASTER_PORT"]) + 1)
+            os.execve(sys.executable, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env)
+
+        def watch():
+            t_start = time.monotonic()
+            while True:
+                time.sleep(0.5)
+                now = time.monotonic()
+                dl = STAGE["deadline"]
+                if dl is not None and now > dl:
+                    if in_fallback:
+                        bark(f"stage deadline missed on the fallback flow after {now - t_start:.0f} s")
+                    rerun(f"stage '{STAGE['name']}' did not finish within its deadline")
+                if not in_fallback and now - t_start > 5 and os.path.exists(flag):
+                    rerun("a peer rank asked for the fallback flow")
+                if now > t_end:
+                    bark(f"rank 0 still running after {limit:.0f} s")
+
+        th = threading.Thread(target=watch, daemon=True)
+        th.start()
+
     world_env = os.environ.get("WORLD_SIZE")
     if world_env is None and args.gpus > 1:
         import sla_amd as sla
@@ -789,9 +962,8 @@ def main():
         if have >= args.gpus:
             spawn_ranks(args)                      # does not return
         if os.environ.get("SLA_BENCH_LOOPBACK") == "1" and have >= 1:
-            sys.stdout.flush()
-            json_fd = os.dup(1)
-            os.dup2(2, 1)
+            json_fd = claim_stdout()
+            start_watchdog(json_fd, 0, args.gpus)
             rec = loopback_ranks(args)
             sys.stdout.flush()
             os.write(json_fd, (json.dumps(rec) + "\n").encode())
@@ -801,34 +973,14 @@ def main():
     world = int(world_env or "1")
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     args.gpus = world
-    # The driver reads ONE JSON line from rank 0's stdout.  Native libraries print there too (gloo announces its connections, RCCL its
-    # version banner at ncclCommInitRank): everything but the line goes to stderr, the line itself to the saved descriptor.
-    sys.stdout.flush()
-    json_fd = os.dup(1)
-    os.dup2(2, 1)
+    json_fd = claim_stdout()
     # SLA_BENCH_FORCE_DIST=1 drives the multi-rank code path (gloo control plane, RCCL communicator, forced collectives)
     # with a 1-rank communicator on a single GPU
     use_dist = world > 1 or os.environ.get("SLA_BENCH_FORCE_DIST") == "1"
     if use_dist and world == 1:
         os.environ["SLA_FORCE_COLLECTIVES"] = "1"
     if use_dist:
-        # A hung collective on the first multi-GPU contact must not take the whole run with it: past SLA_BENCH_WATCHDOG_S (default
-        # 1500 s; 0 = off) every rank dumps its Python stacks to stderr, rank 0 writes an error line where the driver reads the JSON,
-        # and the process exits (os._exit: a rank stuck inside RCCL cannot be unwound).
-        limit = float(os.environ.get("SLA_BENCH_WATCHDOG_S", "1500"))
-        if limit > 0:
-            import faulthandler
-
-            def _bark():
-                faulthandler.dump_traceback(file=sys.stderr, all_threads=True)
-                if rank == 0:
-                    os.write(json_fd, (json.dumps({"metric": "bicgstab_iters_per_sec", "value": None, "unit": "iters/s", "n_gpus": world,
-                                                   "error": f"watchdog: rank 0 still running after {limit:.0f} s (stacks on stderr)"}) + "\n").encode())
-                os._exit(3)
-
-            wd = threading.Timer(limit, _bark)
-            wd.daemon = True
-            wd.start()
+        start_watchdog(json_fd, rank, world)
     rec = run_rank(args, rank, world, local_rank, "rccl" if use_dist else None)
     if rank == 0:
         sys.stdout.flush()

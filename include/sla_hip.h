@@ -315,6 +315,13 @@ int sla_stream_probe(sla_ctx_t, int reads, int writes, int64_t n, int reps, doub
  * the grouped all-gather); *max_abs_err = largest difference between what was sent and what arrived (0 expected).  Needs a context
  * with an RCCL communicator (sla_ctx_create_dist; nranks may be 1); SLA_ERR_INVALID otherwise. */
 int sla_dist_p2p_selftest(sla_ctx_t, int64_t count, int pieces, double *max_abs_err);
+/* First contact of a multi-rank job: ONE checked collective across the context's real ranks (every rank calls it with the same
+ * arguments), so that a hang or an error names its collective before anything is timed.  phase 0: ncclAllGather of `count` doubles
+ * per rank; 1: the same all-gather as one group of ncclSend / ncclRecv pairs between all ranks (the pattern of the halo exchange
+ * and of the overlapped all-gather); 2: the integer max all-reduce of the lowering's cross-rank decisions.  *max_abs_err: largest
+ * difference between what arrived and what the peers sent (0 expected); *ms: wall-clock of the phase.  Works on loopback and
+ * 1-rank contexts too.  (Serves linSolve0's sharded flow, Sparse.hs:1016-1072) */
+int sla_dist_preflight(sla_ctx_t, int phase, int64_t count, double *max_abs_err, double *ms);
 /* SLA_DEBUG_BINDING=1: launches, copies, collectives or device allocations issued by a thread that is not inside an entry
  * point bound to the context they belong to (HIP's current device is per thread: the bug class of multi-device fan-out,
  * invisible on a one-GPU box).  0 in a correct library; the GPU test suites assert it under the debug switch. */

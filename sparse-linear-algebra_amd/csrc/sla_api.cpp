@@ -662,6 +662,15 @@ int sla_dist_p2p_selftest(sla_ctx_t c, int64_t count, int pieces, double *max_ab
     });
 }
 
+int sla_dist_preflight(sla_ctx_t c, int phase, int64_t count, double *max_abs_err, double *ms) {
+    if (!c) return fail(SLA_ERR_INVALID, "sla_dist_preflight: null context");
+    if (!c->kids.empty()) return fail(SLA_ERR_INVALID, "sla_dist_preflight: not on a multi-device bundle");
+    return no_throw("sla_dist_preflight", [&]() -> int {
+        Bind bind(c);
+        return dist_preflight(c, phase, count, max_abs_err, ms);
+    });
+}
+
 int sla_ctx_create_dist(int device_id, int rank, int nranks, const void *unique_id_128, sla_ctx_t *out) {
     if (!unique_id_128) return fail(SLA_ERR_INVALID, "null unique id");
     return ctx_create_common(device_id, rank, nranks, unique_id_128, out);

@@ -11,6 +11,8 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
+#include <thread>
 #include <condition_variable>
 #include <map>
 #include <mutex>
@@ -114,6 +116,17 @@ std::mutex g_loop_mu;
 std::map<int, LoopGroup *> g_loop_groups;
 
 LoopGroup *loop_of(sla_ctx *c) { return (LoopGroup *)c->loop; }
+
+// SLA_FAULT_INJECT (test hook, read once): "p2p" makes every grouped send / recv flow of this file fail with SLA_ERR_RCCL before it
+// touches the communicator, "p2p_hang" makes the pre-flight's send / recv phase sleep on the host forever (no GPU work in flight):
+// what bench.py's fallback ladder and staged watchdog are rehearsed with on a one-GPU box.
+int fault_inject() {
+    static const int f = [] {
+        const char *e = getenv("SLA_FAULT_INJECT");
+        return !e ? 0 : strcmp(e, "p2p") == 0 ? 1 : strcmp(e, "p2p_hang") == 0 ? 2 : 0;
+    }();
+    return f;
+}
 
 int rccl_fail(const char *what, int rc) {
     Rccl &r = rccl();
@@ -258,6 +271,7 @@ int dist_exchange_window(sla_ctx *ctx, const XPlan &plan, const double *xlocal, 
     }
     Rccl &r = rccl();
     if (!ctx->comm) return fail(SLA_ERR_RCCL, "window exchange requested on a context without a communicator");
+    if (fault_inject() == 1) return fail(SLA_ERR_RCCL, "fault injected: grouped ncclSend / ncclRecv (SLA_FAULT_INJECT=p2p)");
     if (!r.send || !r.recv || !r.group_start || !r.group_end) return fail(SLA_ERR_RCCL, "librccl lacks ncclSend/ncclRecv");
     if (n_local > 0 && xfull + my_begin != xlocal)
         SLA_HIP_TRY(hipMemcpyAsync(xfull + my_begin, xlocal, sizeof(double) * (size_t)n_local, hipMemcpyDeviceToDevice, stream_of(ctx)));
@@ -282,6 +296,7 @@ int dist_exchange_window(sla_ctx *ctx, const XPlan &plan, const double *xlocal, 
 // The same all-gather written as grouped point-to-point transfers: inside a dist_group_begin/end pair together with a
 // window exchange, everything is ONE pure send/recv group (the all-to-all pattern), i.e. one RCCL launch.
 int dist_allgather_p2p_f64(sla_ctx *ctx, const double *send, double *recv, int64_t count) {
+    if (fault_inject() == 1) return fail(SLA_ERR_RCCL, "fault injected: grouped ncclSend / ncclRecv (SLA_FAULT_INJECT=p2p)");
     if (loop_of(ctx) || !ctx->comm || ctx->nranks == 1) return dist_allgather_f64(ctx, send, recv, count);
     Rccl &r = rccl();
     if (!r.send || !r.recv || !r.group_start || !r.group_end) return dist_allgather_f64(ctx, send, recv, count);
@@ -440,6 +455,7 @@ int dist_exchange_group(sla_ctx *ctx, const std::vector<AgPiece> &pieces, const 
     }
     Rccl &r = rccl();
     if (!ctx->comm) return fail(SLA_ERR_RCCL, "grouped all-gather requested on a context without a communicator");
+    if (fault_inject() == 1) return fail(SLA_ERR_RCCL, "fault injected: grouped ncclSend / ncclRecv (SLA_FAULT_INJECT=p2p)");
     if (!r.send || !r.recv || !r.group_start || !r.group_end) return fail(SLA_ERR_RCCL, "librccl lacks ncclSend/ncclRecv");
     int rc = r.group_start();
     if (rc != 0) return rccl_fail("ncclGroupStart", rc);
@@ -472,6 +488,7 @@ int dist_p2p_selftest(sla_ctx *ctx, int64_t count, int pieces, double *max_abs_e
     if (loop_of(ctx) || !ctx->comm) return fail(SLA_ERR_INVALID, "sla_dist_p2p_selftest: needs a context with an RCCL communicator");
     if (count < 1 || pieces < 1 || pieces > count) return fail(SLA_ERR_INVALID, "sla_dist_p2p_selftest: bad sizes");
     Rccl &r = rccl();
+    if (fault_inject() == 1) return fail(SLA_ERR_RCCL, "fault injected: grouped ncclSend / ncclRecv (SLA_FAULT_INJECT=p2p)");
     if (!r.send || !r.recv || !r.group_start || !r.group_end) return fail(SLA_ERR_RCCL, "librccl lacks ncclSend/ncclRecv");
     std::vector<double> h((size_t)count), back((size_t)count, 0.0);
     for (int64_t i = 0; i < count; ++i) h[(size_t)i] = 1.0 + (double)i * 0.5;
@@ -504,6 +521,49 @@ int dist_p2p_selftest(sla_ctx *ctx, int64_t count, int pieces, double *max_abs_e
     double err = 0.0;
     for (int64_t i = 0; i < count; ++i) err = std::max(err, std::fabs(back[(size_t)i] - h[(size_t)i]));
     if (max_abs_err) *max_abs_err = err;
+    return SLA_OK;
+}
+
+// First contact of a multi-rank job (sla_dist_preflight): one collective at a time across the REAL ranks, checked on the host, so that a
+// hang or an error names its collective before anything is timed.  phase 0: ncclAllGather; 1: the all-gather as ONE group of
+// ncclSend / ncclRecv pairs between all ranks (the pattern of the halo exchange and of the overlapped all-gather); 2: the integer
+// all-reduce (max) the lowering uses for its cross-rank decisions.  Every rank must call it with the same arguments.
+int dist_preflight(sla_ctx *ctx, int phase, int64_t count, double *max_abs_err, double *ms) {
+    if (count < 1 || phase < 0 || phase > 2) return fail(SLA_ERR_INVALID, "sla_dist_preflight: bad arguments");
+    const auto t0 = std::chrono::steady_clock::now();
+    double err = 0.0;
+    if (phase == 2) {
+        int v = 100 + ctx->rank;
+        SLA_TRY(dist_allreduce_max_i32(ctx, &v));
+        err = std::fabs((double)v - (double)(100 + ctx->nranks - 1));
+    } else {
+        if (phase == 1 && fault_inject() == 1) return fail(SLA_ERR_RCCL, "fault injected: grouped ncclSend / ncclRecv (SLA_FAULT_INJECT=p2p)");
+        if (phase == 1 && fault_inject() == 2)
+            for (;;) std::this_thread::sleep_for(std::chrono::seconds(1));
+        const size_t n = (size_t)count, P = (size_t)ctx->nranks;
+        std::vector<double> h(n), back(n * P, -1.0);
+        for (size_t i = 0; i < n; ++i) h[i] = 1.0e6 * (double)(ctx->rank + 1) + (double)i;
+        double *src = nullptr, *dst = nullptr;
+        SLA_HIP_TRY(dev_malloc(ctx, (void **)&src, sizeof(double) * n));
+        hipError_t e = dev_malloc(ctx, (void **)&dst, sizeof(double) * n * P);
+        if (e == hipSuccess) e = hipMemcpy(src, h.data(), sizeof(double) * n, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemset(dst, 0xff, sizeof(double) * n * P);
+        int rc = SLA_OK;
+        if (e == hipSuccess) rc = phase == 0 ? dist_allgather_f64(ctx, src, dst, count) : dist_allgather_p2p_f64(ctx, src, dst, count);
+        if (rc == SLA_OK && e == hipSuccess) e = hipStreamSynchronize(stream_of(ctx));
+        if (rc == SLA_OK && e == hipSuccess) e = hipMemcpy(back.data(), dst, sizeof(double) * n * P, hipMemcpyDeviceToHost);
+        (void)hipFree(src);
+        if (dst) (void)hipFree(dst);
+        SLA_TRY(rc);
+        SLA_HIP_TRY(e);
+        for (size_t q = 0; q < P; ++q)
+            for (size_t i = 0; i < n; ++i) {
+                const double d = std::fabs(back[q * n + i] - (1.0e6 * (double)(q + 1) + (double)i));
+                err = d == d ? std::max(err, d) : 1.0e300;
+            }
+    }
+    if (max_abs_err) *max_abs_err = err;
+    if (ms) *ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return SLA_OK;
 }
 

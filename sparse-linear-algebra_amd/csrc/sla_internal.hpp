@@ -687,7 +687,8 @@ int dist_group_end(sla_ctx *ctx);
 bool halo_inplace_extents(const sla_csr *A, const sla_vec *x, int64_t *left, int64_t *right);
 int dist_allreduce_max_i32(sla_ctx *ctx, int *value_host);
 int dist_comm_count(sla_ctx *ctx, int *nranks);
-int dist_p2p_selftest(sla_ctx *ctx, int64_t count, int pieces, double *max_abs_err);   // grouped ncclSend / ncclRecv with this rank as its own peer
+int dist_p2p_selftest(sla_ctx *ctx, int64_t count, int pieces, double *max_abs_err);
+int dist_preflight(sla_ctx *ctx, int phase, int64_t count, double *max_abs_err, double *ms);   // one checked collective across the real ranks (sla_dist_preflight)   // grouped ncclSend / ncclRecv with this rank as its own peer
 
 // shared helpers of sla_api.cpp --------------------------------------------------------------------------
 // full-length gather base for an SpMV with matrix A (null: plain all-gather) whose input is `x`

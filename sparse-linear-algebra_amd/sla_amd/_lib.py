@@ -85,6 +85,7 @@ PROTOTYPES = [
     ("sla_debug_binding_violations", C.c_long, []),
     ("sla_stream_probe", _int, [_vp, _int, _int, _i64, _int, _pdbl, _pdbl]),
     ("sla_dist_p2p_selftest", _int, [_vp, _i64, _int, _pdbl]),
+    ("sla_dist_preflight", _int, [_vp, _int, _i64, _pdbl, _pdbl]),
     ("sla_ctx_row_range", _int, [_vp, _i64, _pi64, _pi64]),
     ("sla_last_error", C.c_char_p, []),
     ("sla_version", C.c_char_p, []),

@@ -97,6 +97,13 @@ class Context:
         check(lib().sla_dist_p2p_selftest(self.h, int(count), int(pieces), C.byref(err)))
         return err.value
 
+    def preflight(self, phase, count=4096):
+        """One checked collective across this context's ranks (sla_dist_preflight; every rank calls it): phase 0 ncclAllGather,
+        1 the all-gather as one ncclSend / ncclRecv group, 2 the integer max all-reduce.  Returns (max |arrived - sent|, ms)."""
+        err, ms = C.c_double(-1.0), C.c_double(0.0)
+        check(lib().sla_dist_preflight(self.h, int(phase), int(count), C.byref(err), C.byref(ms)))
+        return err.value, ms.value
+
     def stream_probe(self, reads, writes, n, reps=20):
         """(mean ms, min ms, GB/s at the mean) of a sweep reading `reads` and writing `writes` vectors of n doubles (sla_stream_probe)."""
         mean, mn = C.c_double(), C.c_double()

@@ -87,6 +87,17 @@ def test_bench_contract_small(fuse45):
         assert 0.0 < k["frac"] <= 1.0 and k["bytes"] <= k["csr_bytes"] + 64 and k["launches"] == 8
     assert d["roofline"]["kernel"].split(":")[0] in d["kernels"] and d["roofline"]["launches_timed"] == 8
     assert d["rccl_ranks"] is None and "general_csr" not in d          # (side blocks ride on the default workload only)
+    # nothing named *_gbps without "effective" may exceed the chip's HBM peak: value-indexed forms stream less
+    # than the CSR bytes they are priced on, and say so in the key
+    assert "spmv_gbps" not in d and d["spmv_effective_gbps_on_csr_bytes"] > 0
+
+    def walk(o, path=""):
+        if isinstance(o, dict):
+            for k, v in o.items():
+                if isinstance(v, (int, float)) and k.endswith("gbps") and "effective" not in k:
+                    assert v <= d["roofline"]["peak"] * 1.0001, (path + k, v)
+                walk(v, path + k + ".")
+    walk(d)
 
 
 def test_bench_two_ranks_without_a_launcher_loopback_rehearsal():
@@ -114,6 +125,30 @@ def test_bench_two_ranks_without_a_launcher_loopback_rehearsal():
     assert rb["exchanges_rank0"]["x_exchange"]["launches"] > 0 and rb["exchanges_rank0"]["sums"]["launches"] > 0
     assert d["exchanges"]["sums"]["launches"] > 0
     assert d["hbm_measured_ceiling_gbps"] >= d["hbm_measured"]["sweep_5r3w"]["gbps"] > 0
+    # round 5: the three blocks of the N > 1 line -- halo headline, the contract's literal ncclAllGather flow, the random matrix --
+    # behind a pre-flight that exercised every collective once (and checked what arrived)
+    assert set(d["preflight"]) == {"ncclAllGather", "ncclAllReduce(max, int32)", "grouped ncclSend/ncclRecv all-gather"}
+    assert all(v["max_abs_err"] == 0.0 for v in d["preflight"].values()) and "fallback" not in d
+    c = d["contract_allgather"]
+    assert c["value"] > 0 and "x_exchange=allgather" in c["spmv_kernel"] and c["x_exchange"] == "ncclAllGather" and c["allgather_launches"] > 0
+
+
+@pytest.mark.parametrize("fault,word", [("p2p", "pre-flight of the grouped"), ("p2p_hang", "watchdog")])
+def test_bench_two_ranks_fallback_ladder(fault, word):
+    """First contact gone wrong, rehearsed on one GPU (SLA_FAULT_INJECT, csrc/sla_dist.cpp): the grouped ncclSend / ncclRecv flow
+    ERRORS in the pre-flight ("p2p") or HANGS there ("p2p_hang": the staged watchdog replaces the process after
+    SLA_BENCH_PREFLIGHT_S) -- either way the driver still gets ONE line, on the plain ncclAllGather flow, with "fallback" saying why."""
+    env = dict(os.environ, SLA_BENCH_LOOPBACK="1", SLA_FAULT_INJECT=fault, SLA_BENCH_PREFLIGHT_S="4")
+    env.pop("WORLD_SIZE", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "laplace3d_small", "--steps", "8",
+                          "--warmup", "2"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=400, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["value"] and d["value"] > 0 and word in d["fallback"], d.get("fallback")
+    assert "x_exchange=allgather" in d["config"]["spmv_kernel"] and "grouped ncclSend/ncclRecv all-gather" not in d["preflight"]
+    assert d["random_spd_10m"]["value"] > 0 and d["random_spd_10m"]["x_exchange"]["mode"] == "serial"
 
 
 def test_full_size_triangular_solves_recover_ones(sla):
