@@ -55,13 +55,18 @@ int fail(int code, const std::string &msg) {
     return code;
 }
 
+static bool struct_size_ok(int32_t got, size_t current) {
+    return got == (int32_t)current || (got > (int32_t)current && got <= (int32_t)current + 256 && got % 8 == 0);
+}
 int read_solve_opts(const sla_solve_opts *in, sla_solve_opts *out, const char *who) {
     const sla_solve_opts def = SLA_SOLVE_OPTS_INIT;
     *out = def;
     if (!in) return SLA_OK;
     // (the first layout with a struct_size ends behind history_cap; anything shorter is a caller from before the field existed,
     // whose first member was max_iters -- refuse instead of reading a trace pointer that is not there)
-    if (in->struct_size < (int32_t)(offsetof(sla_solve_opts, history_cap) + sizeof(int32_t)) || in->struct_size > 4096)
+    // Only layouts that were ever published pass: the current one, or a LARGER one of a newer header (8-byte granularity, at most 256
+    // bytes more) -- a v1 caller's max_iters (200 by default) must not be taken for a size ([44, 4096] let it through)
+    if (!struct_size_ok(in->struct_size, sizeof(sla_solve_opts)))
         return fail(SLA_ERR_INVALID, std::string(who) + ": sla_solve_opts.struct_size is not set (use SLA_SOLVE_OPTS_INIT; ABI version " + std::to_string(SLA_ABI_VERSION) + ")");
     memcpy(out, in, std::min<size_t>((size_t)in->struct_size, sizeof(*out)));
     out->struct_size = (int32_t)sizeof(*out);
@@ -73,7 +78,7 @@ int info_begin(const sla_solve_info *user, sla_solve_info *local, const char *wh
     local->resnorm = NAN;
     local->r0norm = NAN;
     local->tol = NAN;
-    if (user && (user->struct_size < (int32_t)(offsetof(sla_solve_info, history_len) + sizeof(int32_t)) || user->struct_size > 4096))
+    if (user && !struct_size_ok(user->struct_size, sizeof(sla_solve_info)))
         return fail(SLA_ERR_INVALID, std::string(who) + ": sla_solve_info.struct_size is not set (use SLA_SOLVE_INFO_INIT; ABI version " + std::to_string(SLA_ABI_VERSION) + ")");
     return SLA_OK;
 }
@@ -254,6 +259,10 @@ static int spmv_allgather_passes(sla_csr *A, sla_vec *x, SpmvLaunch l) {
         }
         SLA_TRY(launch_spmv_tiles(A, lp));
     }
+    // The passes wait only for the groups whose columns this rank READS; a group that only SENDS from x->d (the rank's own shard as the last
+    // group of the ascending order, a shard that holds no whole panel) is waited for by nobody, and the kernels that follow may overwrite
+    // x->d under a send in flight.  Join the comm stream: whatever comes next on the compute stream waits for the last group.
+    if (!pl.sim && c->overlap > 0 && pl.G > 0) SLA_HIP_TRY(hipStreamWaitEvent(stream_of(c), pl.ev[(size_t)pl.G - 1], 0));
     return SLA_OK;
 }
 

@@ -424,6 +424,7 @@ struct sla_csr {
     unsigned *d_tlprog = nullptr;    // per-XCD (round, panel) arrival counters of the launch in flight (panel pacing)
     size_t tlprog_bytes = 0;
     int64_t tl_maxseg = 0;           // longest (row, panel) segment = layers of the deepest tile
+    int32_t tl_dpanel = 0;           // the panel of the matrix's first entry: where the kernels' empty pipeline-drain chunks gather (always inside what this rank may read)
     bool tl_cu = false;              // CU-wide slices, relaxed order (sla_spmv_ctiles.hip): entries [slice][wavefront][panel], d_tloff = tl_S x 4 x (tl_P + 1)
     sla_tri_plan *tri[2] = {nullptr, nullptr};  // [0] lower, [1] upper triangle schedules (built on first use)
     // comm / compute overlap of the sharded (#>) (wave-sliced forms): the 512-row steps whose rows reference own columns only
@@ -660,7 +661,8 @@ void transpose_csr(const HostCsr &a, HostCsr &t);
 bool device_coo_supported(int64_t m, int64_t n, int64_t nnz);
 int device_coo_to_csr(sla_ctx *c, int64_t m, int64_t n, int64_t nnz, const int64_t *row, const int64_t *col,
                       const double *val, int dup_policy, HostCsr &out);
-int device_transpose_to_host(sla_csr *A, HostCsr &t, bool *done);   // sla_coo_sort.hip: transposeSM of a lowered row block by a device sort
+int device_transpose_to_host(sla_csr *A, HostCsr &t, bool *done);
+int validate_columns_device(sla_csr *A, int64_t n, int *verdict);   // sla_coo_sort.hip: canonical-CSR check of uploaded columns (0 fine, 1 out of bounds, 2 not ascending)   // sla_coo_sort.hip: transposeSM of a lowered row block by a device sort
 bool host_is_diagonal(int64_t rows, int64_t row_begin, const int64_t *rowptr, const int64_t *col);
 void build_row_blocks(int64_t rows, const int64_t *rowptr, std::vector<int32_t> &rb, int64_t &max_row_nnz, int row_align,
                       int nnz_target);
@@ -832,6 +834,7 @@ bool pipe_on(const sla_csr *A);                                                 
 int launch_spmv_pipe(const sla_csr *A, int epi, const SpmvArgs<int32_t> &a, int grid);
 int launch_spmv_pipe(const sla_csr *A, int epi, const SpmvArgs<int64_t> &a, int grid);
 int tiles_grid(const sla_csr *A);
+int launch_col_slack_fill(sla_ctx *c, int32_t *d_col, int64_t nnz);   // sla_spmv_wave.hip: the slack behind the column array repeats the last column
 int launch_spmv_ctiles(const sla_csr *A, const SpmvLaunch &l);   // sla_spmv_ctiles.hip (CU-wide slices)
 int ctiles_grid(const sla_csr *A);
 int probe_xcd_layout(sla_ctx *c);   // sets c->xcd8 (sla_spmv_tiles.hip)

@@ -7,6 +7,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <sched.h>
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -127,13 +128,39 @@ static int build_panels(sla_csr *A, int64_t m, int64_t n, int64_t row_begin, int
     return SLA_OK;
 }
 
+// cores this process may use: the affinity mask capped by a container CPU quota (cgroup v2 cpu.max, cgroup v1 cfs_quota_us)
+static int host_cores_available() {
+    int n = (int)std::max(1u, std::thread::hardware_concurrency());
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) n = std::max(1, std::min(n, CPU_COUNT(&set)));
+    long long quota = -1, period = 0;
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char q[64] = {0};
+        if (fscanf(f, "%63s %lld", q, &period) == 2 && strcmp(q, "max") != 0) quota = atoll(q);
+        fclose(f);
+    } else if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+        if (fscanf(g, "%lld", &quota) != 1) quota = -1;
+        fclose(g);
+        if (FILE *h = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+            if (fscanf(h, "%lld", &period) != 1) period = 0;
+            fclose(h);
+        }
+    }
+    if (quota > 0 && period > 0) n = std::max(1, std::min<int>(n, (int)(quota / period)));
+    return n;
+}
+
 int host_threads() {
     static const int t = [] {
         const char *s = getenv("SLA_HOST_THREADS");
         // (default: 16 threads, 32 on hosts with >= 64 hardware threads -- the MI355X boxes have 256; the pair-coding pass at 70 M entries
         // measured 111 / 56 / 42 ms at 8 / 16 / 32 threads and nothing more at 64)
         const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-        int v = s ? atoi(s) : (int)(hw >= 64 ? 32u : std::min(16u, hw));
+        // Round 5: capped by what the process may actually USE.  The GPU boxes run this in a container with a CFS quota of 16 cores: 32
+        // analysis threads next to the 8 staging threads of the upload overran it, and a throttled group stalls ALL its threads for the
+        // rest of the period -- the x-window statistics of config 3a took 72 ms inside bench.py against 6 ms stand-alone, the 4 GB upload
+        // 240 ms against 90.
+        int v = s ? atoi(s) : std::min((int)(hw >= 64 ? 32u : std::min(16u, hw)), host_cores_available());
         return std::max(1, std::min(v, 64));
     }();
     return t;
@@ -150,6 +177,10 @@ int host_threads() {
 struct CanonUpload {
     std::atomic<int> stop{0};
     std::atomic<int> decided{0};
+    // the canonical-CSR check of the caller's columns rides on the narrowing of the upload (set before `decided`): 0 fine, 1 out of
+    // bounds, 2 not ascending inside a row -- validate_columns' codes, the lowest kind wins
+    bool validate = false;
+    std::atomic<int> col_bad{0};
     int64_t done_col = 0, done_val = 0;   // entries [0, done) are on the device
 };
 struct Low {
@@ -223,6 +254,46 @@ static void low_csr_arrays(Low &L, CanonUpload *cu) {
         if (cu) cu->done_val = (int64_t)(done_b / sizeof(double));
     });
     Joiner val_up_joiner{val_up};
+    // ... and the indices on a third (round 5: they used to follow the row pointers and row-block tables on THIS thread -- 40-100 ms of
+    // allocations, narrowing and small copies at 10 M rows during which 1.3 GB of columns waited)
+    hipError_t err_col = hipSuccess;
+    std::thread col_up([&] {
+        Bind bind(c);
+        await_decision();
+        if (!stopped()) {   // the caller's int64 column indices are narrowed on their way into the pinned slots (no 4 B-per-entry host copy, no pass of its own)
+            if (err_col == hipSuccess) err_col = dev_malloc(c, (void **)&A->d_col, sizeof(int32_t) * (size_t)nnz + kArraySlack);
+            if (err_col == hipSuccess) {   // the slack repeats the last valid column (zero = x[0] can lie outside a slab's vector: see launch_col_slack_fill)
+                const std::vector<int32_t> tail(kArraySlack / sizeof(int32_t), nnz ? (int32_t)col[nnz - 1] : 0);
+                err_col = hipMemcpy((char *)A->d_col + sizeof(int32_t) * (size_t)nnz, tail.data(), kArraySlack, hipMemcpyHostToDevice);
+            }
+            size_t done_b = 0;
+            struct NarrowCtx { const int64_t *col, *rowptr; int64_t rows, n; bool validate; std::atomic<int> *bad; } nctx{col, rowptr, rows, n, cu && cu->validate, cu ? &cu->col_bad : nullptr};
+            if (err_col == hipSuccess && nnz && !stopped())
+                err_col = xfer_copy(c, A->d_col, nullptr, sizeof(int32_t) * (size_t)nnz, hipMemcpyHostToDevice, cu ? &cu->stop : nullptr, &done_b,
+                                [](void *slot, size_t off, size_t len, const void *ctx) {
+                                    const NarrowCtx &x = *(const NarrowCtx *)ctx;
+                                    const int64_t k0 = (int64_t)(off / sizeof(int32_t)), cnt = (int64_t)(len / sizeof(int32_t));
+                                    const int64_t *col64 = x.col + k0;
+                                    int32_t *o = (int32_t *)slot;
+                                    if (!x.validate) {
+                                        for (int64_t q = 0; q < cnt; ++q) o[q] = (int32_t)col64[q];
+                                        return;
+                                    }
+                                    // (round 5: the check used to be a pass of its own over the 2.6 GB of config 3a's columns -- 167 ms on the main
+                                    // thread with the upload waiting for its verdict.  Here only the bits the narrowing drops are kept: a column
+                                    // with a bit from 31 up is negative or >= 2^31 = out of bounds; the rest of the check -- < n, ascending
+                                    // inside a row -- runs on the device over the narrowed copy: validate_columns_device)
+                                    uint64_t acc = 0;
+                                    for (int64_t q = 0; q < cnt; ++q) {
+                                        acc |= (uint64_t)col64[q];
+                                        o[q] = (int32_t)col64[q];
+                                    }
+                                    if (acc >> 31) x.bad->store(1, std::memory_order_relaxed);
+                                }, &nctx);
+            if (cu) cu->done_col = (int64_t)(done_b / sizeof(int32_t));
+        }
+    });
+    Joiner col_up_joiner{col_up};
     // row pointers and row-block tables first: every form needs them
     if (A->rp64) {
         upload(&A->d_rowptr, rowptr, sizeof(int64_t) * (size_t)(rows + 1));
@@ -243,21 +314,9 @@ static void low_csr_arrays(Low &L, CanonUpload *cu) {
     }
     upload((void **)&A->d_rb, rb.data(), sizeof(int32_t) * rb.size());
     L.sub("[upload thread] row pointers + row blocks up");
-    await_decision();
-    if (!stopped()) {   // the caller's int64 column indices are narrowed on their way into the pinned slots (no 4 B-per-entry host copy, no pass of its own)
-        if (err == hipSuccess) err = dev_malloc(c, (void **)&A->d_col, sizeof(int32_t) * (size_t)nnz + kArraySlack);
-        if (err == hipSuccess) err = hipMemset((char *)A->d_col + sizeof(int32_t) * (size_t)nnz, 0, kArraySlack);
-        size_t done_b = 0;
-        if (err == hipSuccess && nnz && !stopped())
-            err = xfer_copy(c, A->d_col, nullptr, sizeof(int32_t) * (size_t)nnz, hipMemcpyHostToDevice, cu ? &cu->stop : nullptr, &done_b,
-                            [](void *slot, size_t off, size_t len, const void *ctx) {
-                                const int64_t *col64 = (const int64_t *)ctx + off / sizeof(int32_t);
-                                int32_t *o = (int32_t *)slot;
-                                for (size_t q = 0; q < len / sizeof(int32_t); ++q) o[q] = (int32_t)col64[q];
-                            }, col);
-        if (cu) cu->done_col = (int64_t)(done_b / sizeof(int32_t));
-    }
+    col_up.join();
     val_up.join();
+    if (err == hipSuccess) err = err_col;
     if (err == hipSuccess) err = err_val;
 }
 
@@ -311,8 +370,8 @@ static void low_xwin_statistics(Low &L) {
         const int64_t wmax = std::max<int64_t>(0, n - kXWin);
         std::vector<int64_t> part_in((size_t)host_threads(), 0), part_tot((size_t)host_threads(), 0);
         // (the share is a go / no-go statistic with its threshold at one half: from 2^16 row blocks on every (blocks / 2^15)-th block is
-        // counted -- the full count read all of col again, 0.16 s at 330 M entries)
-        const int64_t nblk = (int64_t)rb.size() - 1, samp = nblk >= ((int64_t)1 << 16) ? nblk >> 15 : 1;
+        // counted -- the full count read all of col again, 0.16 s at 330 M entries; since round 5 from 2^14 blocks on, every (blocks / 2^12)-th)
+        const int64_t nblk = (int64_t)rb.size() - 1, samp = nblk >= ((int64_t)1 << 14) ? nblk >> 12 : 1;   // (round 5: 4096 sampled blocks = 4 M entries decide a threshold at one half as well as 32768 did)
         par_rows(nblk, 1, [&](int t, int64_t blo, int64_t bhi) {
             int64_t in = 0, tot = 0;
             for (int64_t b = blo; b < bhi; ++b) {
@@ -938,6 +997,7 @@ int csr_ensure_canon(sla_csr *A) {
     hipLaunchKernelGGL(vd_expand_kernel, dim3(grid), dim3(256), 0, stream_of(c), A->rows, A->row_begin, (const int32_t *)A->d_rowptr, A->d_vcode,
                        A->d_vdoff, A->d_vdval, A->d_col, A->d_val, (int64_t)0, (int64_t)0);
     SLA_HIP_TRY(hipGetLastError());
+    SLA_TRY(launch_col_slack_fill(c, A->d_col, nnz));
     SLA_HIP_TRY(hipStreamSynchronize(stream_of(c)));
     A->canon_lazy = false;
     return SLA_OK;
@@ -1042,11 +1102,24 @@ int csr_upload(sla_ctx *c, int64_t m, int64_t n, int64_t row_begin, int64_t rows
             CanonUpload &cu;
             ~Joiner() { cu.decided.store(1, std::memory_order_release); if (t.joinable()) t.join(); }
         } up_joiner{up, cu};
-        low_value_indexed(L);
+        // (an analysis whose forms the context's options peel off is not run: `wdia = 0 vdict = 0 diag = 0` -- bench.py's plain-CSR block -- paid
+        // 48 + 15 ms for dictionaries nothing would read; options steer the lowering of matrices created AFTER they are set)
+        if (c->wdia || c->vdict) low_value_indexed(L);
         L.sub("visiting order + return");
-        if (L.validate) {   // the pair-coding pass checked the columns on its way unless it left early (not a value-indexed matrix): then here
-            bad_cols = L.col_verdict >= 0 ? L.col_verdict : validate_columns(rows, n, rowptr, col);
-            if (bad_cols && err == hipSuccess) err = hipErrorInvalidValue;   // (nothing below runs; reported after the agreement)
+        bool verdict_with_upload = false;
+        if (L.validate) {   // the pair-coding pass checked the columns on its way unless it left early (not a value-indexed matrix): then the
+            // upload thread does, while it narrows them (nothing between here and its join uses a column as an INDEX: the window / offset
+            // analyses compare and subtract column values)
+            if (L.col_verdict >= 0) {
+                bad_cols = L.col_verdict;
+                if (bad_cols && err == hipSuccess) err = hipErrorInvalidValue;   // (nothing below runs; reported after the agreement)
+            } else if (cu.stop.load() == 0 && nnz > 0) {
+                cu.validate = true;
+                verdict_with_upload = true;
+            } else {
+                bad_cols = validate_columns(rows, n, rowptr, col);
+                if (bad_cols && err == hipSuccess) err = hipErrorInvalidValue;
+            }
         }
         // value-indexed after all: the rest of the canonical entry arrays is written on the device from the codes (option canon_device)
         cu.decided.store(1, std::memory_order_release);   // (matrices the analysis did not look at: rp64, rows too long, no entries)
@@ -1059,13 +1132,23 @@ int csr_upload(sla_ctx *c, int64_t m, int64_t n, int64_t row_begin, int64_t rows
         // (the 1-byte column codes serve the dictionary-code kernel and the variable-coefficient slices: a matrix that just took the
         // constant-coefficient wave-sliced form needs neither -- unless the context's knobs peel that form off again (A/B runs), which
         // is decided when the matrix is created: two passes over the entries and 1 B per entry of upload saved, round 4)
-        if (!(A->use_wdia && c->wdia && c->diag_lazy)) low_diagonal_dictionary(L);
+        if (!(A->use_wdia && c->wdia && c->diag_lazy) && c->diag) low_diagonal_dictionary(L);
         lap("offset dictionary");
         low_wave_sliced_variable(L);
         lap("variable-coefficient slices");
         L.sub("(before the join)");
         up.join();
         L.sub("join of the upload thread");
+        if (verdict_with_upload) {
+            // (an upload that failed or was skipped checked nothing: the separate pass then)
+            if (Lup.err == hipSuccess && cu.done_col == nnz && A->d_col && A->d_rowptr) {
+                bad_cols = cu.col_bad.load();
+                if (!bad_cols && validate_columns_device(A, n, &bad_cols) != SLA_OK) bad_cols = validate_columns(rows, n, rowptr, col);
+            } else {
+                bad_cols = validate_columns(rows, n, rowptr, col);
+            }
+            if (bad_cols && err == hipSuccess) err = hipErrorInvalidValue;
+        }
         if (err == hipSuccess) err = Lup.err;
         if (err == hipSuccess && cu.stop.load()) {
             // value-indexed: nothing of col / val crossed PCIe.  The arrays are written on the device from the codes -- now, or (option

@@ -67,7 +67,7 @@ template <int EPI, typename RP>
 __global__ void __launch_bounds__(kBlock, 1)
 spmv_ctile_kernel(SpmvArgs<RP> a, const RP *__restrict__ rowptr, const int32_t *__restrict__ srow, const uint32_t *__restrict__ toff,
                   const uint32_t *__restrict__ tidx, const double *__restrict__ tval, const double *__restrict__ xg, int S, int P,
-                  int shift, unsigned *prog, int slack, const int32_t *__restrict__ vis, int v0, int nv, int dlim) {
+                  int shift, unsigned *prog, int slack, const int32_t *__restrict__ vis, int v0, int nv, int dlim, int dpanel) {
     __shared__ double s_y[kCtRows];
     __shared__ double s_red[4];
     __shared__ int s_prog[kBlock / 64];
@@ -201,7 +201,7 @@ spmv_ctile_kernel(SpmvArgs<RP> a, const RP *__restrict__ rowptr, const int32_t *
                 issue(c);
             } else {
                 c.cnt = 0;
-                c.panel = 0;
+                c.panel = dpanel;   // (a panel that holds a column this rank references: on a window-mode slab panel 0 may lie outside the vector's guard)
 #pragma unroll
                 for (int u = 0; u < kCtU; ++u) {
                     const int i = min(lane + 64 * u, dlim);
@@ -272,7 +272,7 @@ static int launch_ctiles_t(const sla_csr *A, const SpmvLaunch &l) {
     if (A->d_tlprog) SLA_HIP_TRY(hipMemsetAsync(A->d_tlprog, 0, A->tlprog_bytes, stream_of(c)));   // the pacing table of this launch
     hipLaunchKernelGGL((spmv_ctile_kernel<EPI, RP>), dim3(ctiles_grid(A)), dim3(kBlock), 0, stream_of(c), a, a.rowptr, A->d_tlrow, A->d_tloff,
                        A->d_tlidx, A->d_tlval, l.x, A->tl_S, A->tl_P, A->tl_shift, A->d_tlprog, c->xcd8 == 1 ? c->tile_slack : 0, vis, l.tv0, nv,
-                       (int)std::min<int64_t>(64 * kCtU - 1, A->nnz - 1));
+                       (int)std::min<int64_t>(64 * kCtU - 1, A->nnz - 1), A->tl_dpanel);
     SLA_HIP_TRY(hipGetLastError());
     return SLA_OK;
 }

@@ -44,6 +44,21 @@ __device__ __forceinline__ void wv_load(WvChunk<PPL> &c, const int32_t *__restri
     for (int j = 0; j < PPL; ++j) c.vv[j] = __builtin_nontemporal_load((const wv_f64x2 *)(val + min(kb + 2 * lane + 128 * j, kmax)));
 }
 
+// The wave kernel loads entries in aligned PAIRS and gathers x for both halves with no range test: the pair that holds the last
+// entry of a matrix with an odd entry count reads col[nnz] from the slack behind the array.  Zeroed slack meant x[0] -- harmless on
+// one GPU, but on a row slab whose vector is addressed by global column (in-place halo exchange: base = x - first_row) x[0] lies
+// first_row doubles in front of the allocation, beyond the 4 MiB guard from 512 K rows on.  The slack now repeats the last
+// valid column of THIS matrix.
+__global__ void col_slack_fill_kernel(int32_t *col, int64_t nnz) {
+    if (nnz > 0 && threadIdx.x < kArraySlack / sizeof(int32_t)) col[nnz + threadIdx.x] = col[nnz - 1];
+}
+int launch_col_slack_fill(sla_ctx *c, int32_t *d_col, int64_t nnz) {
+    if (!d_col || nnz <= 0) return SLA_OK;
+    hipLaunchKernelGGL(col_slack_fill_kernel, dim3(1), dim3(64), 0, stream_of(c), d_col, nnz);
+    SLA_HIP_TRY(hipGetLastError());
+    return SLA_OK;
+}
+
 // PRE: the streams of the NEXT chunk (of this block or of the wavefront's next block) are issued before the current chunk is folded
 // (a second register set: fewer wavefronts per CU, more bytes in flight per wavefront)
 template <int EPI, int PPL, int OCC, bool PRE>

@@ -16,6 +16,7 @@
 #include <mutex>
 #include <new>
 #include <pthread.h>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -54,12 +55,24 @@ XferPool *pool_of(int device) {
 }
 
 bool lane_create(XferLane &l) {
-    if (hipStreamCreateWithFlags(&l.st, hipStreamNonBlocking) != hipSuccess) return false;
-    for (int s = 0; s < 2; ++s) {
-        if (hipHostMalloc(&l.buf[s], kXferSlot, hipHostMallocDefault) != hipSuccess) return false;
-        if (hipEventCreateWithFlags(&l.ev[s], hipEventDisableTiming) != hipSuccess) return false;
+    bool ok = hipStreamCreateWithFlags(&l.st, hipStreamNonBlocking) == hipSuccess;
+    if (!ok) l.st = nullptr;
+    for (int s = 0; s < 2 && ok; ++s) {
+        ok = hipHostMalloc(&l.buf[s], kXferSlot, hipHostMallocDefault) == hipSuccess;
+        if (!ok) l.buf[s] = nullptr;
+        if (ok) {
+            ok = hipEventCreateWithFlags(&l.ev[s], hipEventDisableTiming) == hipSuccess;
+            if (!ok) l.ev[s] = nullptr;
+        }
     }
-    return true;
+    if (!ok) {   // a lane that failed part-way gives back what it got: the next attempt starts from an empty slot
+        for (int s = 0; s < 2; ++s) {
+            if (l.ev[s]) { (void)hipEventDestroy(l.ev[s]); l.ev[s] = nullptr; }
+            if (l.buf[s]) { (void)hipHostFree(l.buf[s]); l.buf[s] = nullptr; }
+        }
+        if (l.st) { (void)hipStreamDestroy(l.st); l.st = nullptr; }
+    }
+    return ok;
 }
 
 // up to `want` free lanes (at least one: waits for one if all are taken by other callers)
@@ -185,8 +198,14 @@ hipError_t xfer_copy(sla_ctx *c, void *dst, const void *src, size_t bytes, hipMe
         err[(size_t)li] = e;
     };
     std::vector<std::thread> th;
-    for (int li = 1; li < L; ++li) th.emplace_back(work, li);
+    th.reserve((size_t)L);
+    int started = 1;                                 // lanes with a thread of their own (lane 0 is the caller's)
+    try {
+        for (; started < L; ++started) th.emplace_back(work, started);
+    } catch (const std::system_error &) {            // thread limit: the lanes without a thread run here, one after the other
+    }
     work(0);
+    for (int li = started; li < L; ++li) work(li);
     for (auto &t : th) t.join();
     lanes_release(pool, L, ids);
     (void)hipSetDevice(c->device);
