@@ -499,7 +499,7 @@ const IntKnob kIntKnobs[] = {
     {"ag_order", &sla_ctx::ag_order, 0, 1},
     {"ag_sim_ranks", &sla_ctx::ag_sim_ranks, 0, 64},
     {"ag_sim_rank", &sla_ctx::ag_sim_rank, 0, 63},
-    {"tiles", &sla_ctx::tiles, 0, 1},
+    {"tiles", &sla_ctx::tiles, 0, 2},
     {"tiles_device", &sla_ctx::tiles_device, 0, 2},
     {"tile_shift", &sla_ctx::tile_shift, 0, 20},
     {"tile_slack", &sla_ctx::tile_slack, 0, 64},

@@ -103,7 +103,8 @@ int build_tiles(sla_csr *A, int64_t n, int64_t rows, const int64_t *rowptr, cons
     const int64_t nnz = rowptr[rows];
     if (!c->tiles || rows == 0 || nnz == 0) return SLA_OK;
     auto skip = [&](const char *why) { A->lower_log += std::string("tile form not taken=") + why + ";"; return SLA_OK; };   // (sla_csr_lower_info)
-    if (A->use_diag || A->use_wdia || A->use_vdict || A->xwin_fraction >= 0.5) return SLA_OK;   // stencil / banded structure
+    const bool force = c->tiles == 2;   // (A/B hook: the tile form wherever it is structurally possible)
+    if (!force && (A->use_diag || A->use_wdia || A->use_vdict || A->xwin_fraction >= 0.5)) return SLA_OK;   // stencil / banded structure
     if ((A->use_lpanel && c->lpanel) || (A->use_lflat && c->lflat)) return SLA_OK;               // dense / medium rows: x panels in LDS
     {   // the kernel keeps one slice's row sums per wavefront in static LDS (4 x kTileRows doubles = 153 KiB of the MI355X's 160 KiB)
         int lds = 0;
@@ -120,7 +121,7 @@ int build_tiles(sla_csr *A, int64_t n, int64_t rows, const int64_t *rowptr, cons
     const int want = c->tile_shift > 0 ? c->tile_shift : (n < 6000000 ? 16 : 17);
     const int shift = std::max(10, std::min((cu ? 32 : 31) - row_bits, want));   // (layer flag, slice row, panel column) packed in 32 bits (CU-wide slices: no flag, 15 + 17 bits)
     const int64_t W = (int64_t)1 << shift;
-    if (n <= 2 * W || (c->tile_shift <= 0 && n <= ((int64_t)1 << 18))) return SLA_OK;   // x (nearly) fits the L2 already
+    if (n <= 2 * W || (c->tile_shift <= 0 && !force && n <= ((int64_t)1 << 18))) return SLA_OK;   // x (nearly) fits the L2 already
     const int64_t P = (n + W - 1) / W;
     if (P > 16384) return skip("more than 16384 panels");
     // slices: whole rounds of the persistent grid (kTileBlocksPerCu workgroup(s) of 4 wavefronts per CU)

@@ -506,12 +506,11 @@ def test_device_transpose_equals_the_host_transpose(sla, rp64):
         assert np.array_equal(got[2].view(np.uint64), got[0].view(np.uint64)), (dims, rp64)
 
 
-@pytest.mark.skipif(os.environ.get("SLA_TEST_EXIT_RACE", "0") != "1",
-                    reason="opt-in (SLA_TEST_EXIT_RACE=1): a dozen short-lived GPU processes; tools/exit_race.sh is the same check by hand")
 def test_process_exit_with_background_work_in_flight():
     """A process that exits while the library still has background threads running (the pinned copy lanes of a new context being
     built; large host buffers being released) must exit cleanly: the context is never destroyed here, as in a caller that leaks it.
-    (Before the exit handler of sla_xfer.cpp: a segfault inside the HIP runtime's own teardown, exit code 139.)"""
+    (Before the exit handler of sla_xfer.cpp: a segfault inside the HIP runtime's own teardown, exit code 139.)
+    Runs by default since round 5 (a dozen short-lived GPU processes, well under a minute); tools/exit_race.sh is the same check by hand."""
     import subprocess
     import sys
     pkg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "sparse-linear-algebra_amd")

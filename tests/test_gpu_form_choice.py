@@ -1,0 +1,50 @@
+"""The lowering's choice of storage form as a TEST: for ten matrix families -- stencil, banded, Poisson, the
+reference's own FEM fixture tiled, variable coefficients, random rows of 33 / 100 / 200 / 500 entries, power-law rows -- the form
+`sla_csr_from_csr` picks must be the kernel the family is documented with (`kernel_info()` pinned: a threshold regression changes
+which kernel a caller's matrix runs) AND within 7 % (+ 3 % timing noise) of the fastest form the library can be forced to, measured
+here: K1 of a bicgstabStep (`(#>)` + one dot: Sparse.hs:972-981, Common.hs:247-260), HIP-event timed, same box, same process.
+
+The forms and the matrix zoo are tools/form_tournament.py's (the full lists, at full sizes: profiles/r05_form_tournament.txt)."""
+import os
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+# family: (workload, scale of the zoo's row count, the pick (substrings of kernel_info), labels of the forced alternatives)
+FAMILIES = {
+    "stencil 108^3": ("laplace3d_1m", None, ("algo=wdia",), ("gather (wd_lds=0)", "no wdia", "plain CSR")),
+    "banded 2 M": ("banded_2m", None, ("algo=wdia-vv",), ("no wdia-vv", "no wdia", "plain CSR")),
+    "Poisson 1000^2": ("poisson2d_1m", None, ("algo=wdia",), ("no wdia", "dictionary codes", "plain CSR")),
+    "e05r0000 tiled": ("e05_tiled", None, ("algo=stream+wave",), ("plain CSR, stream kernel", "CU tiles relaxed, forced, no pacing")),
+    "variable coefficients 128^3": ("varcoef7", None, ("algo=wdia-vv",), ("no wdia-vv", "plain CSR")),
+    "random, 33 per row": ("random_spd_1m", None, ("algo=tiles", "cu_slices=1"), ("wavefront-private exact tiles", "no tiles", "plain CSR")),
+    "random, 100 per row": ("rand100", 0.5, ("algo=tiles", "cu_slices=1"), ("wavefront-private exact tiles", "lflat forced", "no tiles")),
+    "random, 200 per row": ("rand200", 1.0, ("algo=tiles", "cu_slices=1"), ("wavefront-private exact tiles", "lflat forced")),
+    "random, 500 per row": ("rand500", 0.6, ("algo=lflat",), ("CU tiles relaxed", "wavefront-private exact tiles")),
+    "power-law rows": ("powerlaw", 0.5, ("algo=tiles", "cu_slices=1"), ("wavefront-private exact tiles", "no tiles")),
+}
+
+
+@pytest.fixture(scope="module")
+def tournament():
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import form_tournament
+    return form_tournament
+
+
+@pytest.mark.parametrize("family", list(FAMILIES))
+def test_the_lowering_picks_the_fastest_form(tournament, family):
+    name, scale, pick, alts = FAMILIES[family]
+    forms = [f for f in tournament.FORMS if f[0] == "default" or f[0] in alts]
+    assert len(forms) == 1 + len(alts), [f[0] for f in forms]
+    lines = []
+    rows = tournament.run(name, steps=30, forms=forms, out=lines.append, scale=scale)
+    assert rows and rows[0][0] == "default", lines
+    _, algo, k1_pick, _ = rows[0]
+    info = algo
+    assert all(tok in info for tok in pick), (family, info)
+    best = min(r[2] for r in rows)
+    assert k1_pick <= 1.10 * best, (family, "\n".join(lines))

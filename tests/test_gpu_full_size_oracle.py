@@ -89,6 +89,17 @@ def test_config4_laplace3d_10m_bit_exact_vs_oracle(sla):
     _check(sla, dims, rp, ci, va, "wdia+march", True, "ones", "config4")
 
 
+def test_config4_plain_csr_10m_bit_exact_vs_oracle(sla):
+    """The kernel behind the metric's "CSR SpMV achieved HBM GB/s" (bench.py's general_csr block: the 216^3 Laplacian stored as plain
+    CSR -- f64 values, i32 columns, i32 row pointers -- options wdia = 0 vdict = 0 diag = 0) at full size: spmv_wave_kernel folds a row in
+    one lane, ascending -- the reference's left fold (Common.hs:247-260) bit for bit -- then two bicgstabSteps at 1e-9."""
+    from sla_amd import workloads as wl
+    ctx = sla.Context(0).set_options(wdia=0, vdict=0, diag=0)
+    dims, (rp, ci, va) = wl.laplace3d(216, 216, 216)
+    _check(sla, dims, rp, ci, va, "stream+wave", True, "ones", "config4 plain CSR", ctx)
+    ctx.close()
+
+
 def test_config4_laplace3d_10m_reference_split_flow_vs_oracle(sla):
     """The default flow fuses K4 and K5 (the test above; since round 3 on sharded contexts too); the reference's own split stays
     selectable.  The same full-size check on a context with the option bicg_fuse45=0."""

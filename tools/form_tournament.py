@@ -10,17 +10,17 @@ import bench  # noqa: E402
 import numpy as np  # noqa: E402
 
 
-def zoo(name):
+def zoo(name, scale=1.0):
     """The middle of the matrix zoo: matrices between the stencils and the 33-per-row random matrix.  Diagonally
     dominant by construction (diagonal = 1 + sum |off-diagonal|) so that BiCGSTAB steps stay finite; b = A.1."""
     rng = np.random.default_rng(2026)
-    if name == "e05_tiled":          # the reference's real-world fixture (test/data/e05r0000.mtx, 236 x 236, 5856 entries) as 4300 diagonal blocks
+    if name in ("e05_tiled", "e05_tiled_10m"):   # the reference's real-world fixture (test/data/e05r0000.mtx, 236 x 236, 5856 entries) as 4300 diagonal blocks
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         from refdata import GOLDEN, read_mtx_coordinate
         (m, _), r, c, v = read_mtx_coordinate(f"{GOLDEN}/e05r0000.mtx")
         order = np.lexsort((c, r))
         r, c, v = r[order], c[order], v[order]
-        reps = 4300
+        reps = 4300 if name == "e05_tiled" else 43000   # (1 M rows / 10 M rows: the same blocks, ten times the launch)
         rows = (r[None, :] + m * np.arange(reps)[:, None]).ravel()
         cols = (c[None, :] + m * np.arange(reps)[:, None]).ravel()
         vals = np.tile(v, reps)
@@ -37,15 +37,15 @@ def zoo(name):
         order = np.lexsort((cols, rows))
         rows, cols = rows[order], cols[order]
         vals = -rng.uniform(0.5, 1.5, len(rows))
-    elif name.startswith("rand"):    # n rows x k random columns per row (stratified: column j of a row in the j-th n/k-th of the columns)
+    elif name.startswith("rand") and name[4:].isdigit():    # n rows x k random columns per row (stratified: column j of a row in the j-th n/k-th of the columns)
         k = int(name[4:])
-        n = 1000000
+        n = int(1000000 * scale)
         w = n // k
         cols = (np.arange(k, dtype=np.int64)[None, :] * w + rng.integers(0, w, (n, k))).ravel()
         rows = np.repeat(np.arange(n, dtype=np.int64), k)
         vals = rng.uniform(-1.0, 1.0, n * k)
     elif name == "powerlaw":         # 2 M rows, row lengths ~ Zipf(1.6) clipped to [1, 4000] (mean ~ 12), random columns
-        n = 2000000
+        n = int(2000000 * scale)
         lens = np.minimum(rng.zipf(1.6, n), 4000).astype(np.int64)
         rows = np.repeat(np.arange(n, dtype=np.int64), lens)
         w = n // lens
@@ -56,41 +56,54 @@ def zoo(name):
         return None
     rp = np.concatenate(([0], np.cumsum(np.bincount(rows, minlength=n)))).astype(np.int64)
     diag = cols == rows
-    if name != "e05_tiled" and int(diag.sum()) == n:   # a diagonal entry in every row: make it dominant (the random families have none: their
+    if not name.startswith("e05_tiled") and int(diag.sum()) == n:   # a diagonal entry in every row: make it dominant (the random families have none: their
         absum = np.bincount(rows[~diag], weights=np.abs(vals[~diag]), minlength=n)   # steps are timed on whatever the recurrences produce --
         vals[diag] = 1.0 + absum[rows[diag]]           # kernel time is data-independent)
     return f"{name}: {n} rows, {len(vals)} entries ({len(vals) / n:.1f} per row)", ((n, n), (rp, cols.astype(np.int64), vals))
 
 
-name = sys.argv[1] if len(sys.argv) > 1 else "banded_2m"
-steps = int(sys.argv[2]) if len(sys.argv) > 2 else 60
-z = zoo(name)
-desc, (dims, (rp, ci, va)) = z if z else bench.workload(name)
-forms = (("default", {}), ("no march", {"wd_march": 0}), ("gather (wd_lds=0)", {"wd_lds": 0}), ("no wdia-vv", {"wdia_vv": 0}), ("no wdia", {"wdia": 0}),
+FORMS = (("default", {}), ("no march", {"wd_march": 0}), ("gather (wd_lds=0)", {"wd_lds": 0}), ("no wdia-vv", {"wdia_vv": 0}), ("no wdia", {"wdia": 0}),
          ("no wdia, no xwin", {"wdia": 0, "xwin": 0}), ("dictionary codes", {"wdia": 0, "vdict": 0}), ("dictionary codes + xwin", {"wdia": 0, "vdict": 0, "xwin": 2}),
          ("no tiles", {"tiles": 0}), ("no tiles, no col panels", {"tiles": 0, "panels": 0}), ("no LDS panels", {"lpanel": 0}),
          ("no LDS panels, no tiles", {"lpanel": 0, "tiles": 0, "panels": 0}), ("LDS panels forced", {"lp_minseg": 1}),
          ("tiles, 2^16-column panels", {"lpanel": 0, "tile_shift": 16}), ("tiles, 2^15-column panels", {"lpanel": 0, "tile_shift": 15}),
-         ("wavefront-private tiles (r4)", {"lpanel": 0, "lflat": 0, "tile_cu": 0}),
-         ("CU tiles exact", {"lpanel": 0, "lflat": 0, "tile_cu": 1, "tile_relaxed": 0}),
-         ("CU tiles relaxed", {"lpanel": 0, "lflat": 0, "tile_cu": 1, "tile_relaxed": 1}),
-         ("CU tiles relaxed 2^15", {"lpanel": 0, "lflat": 0, "tile_cu": 1, "tile_relaxed": 1, "tile_shift": 15}),
-         ("CU tiles relaxed 2^17", {"lpanel": 0, "lflat": 0, "tile_cu": 1, "tile_relaxed": 1, "tile_shift": 17}),
+         ("wavefront-private exact tiles", {"lpanel": 0, "lflat": 0, "tile_relaxed": 0}),
+         ("CU tiles relaxed", {"lpanel": 0, "lflat": 0, "tile_relaxed": 1}),
+         ("CU tiles relaxed 2^15", {"lpanel": 0, "lflat": 0, "tile_relaxed": 1, "tile_shift": 15}),
+         ("CU tiles relaxed 2^17", {"lpanel": 0, "lflat": 0, "tile_relaxed": 1, "tile_shift": 17}),
+         ("lflat forced", {"lflat": 2, "tiles": 0}),
+         ("CU tiles relaxed, forced, no pacing", {"wdia": 0, "vdict": 0, "diag": 0, "lpanel": 0, "lflat": 0, "tiles": 2, "tile_relaxed": 1, "tile_slack": 0}),
+         ("CU tiles relaxed, forced", {"wdia": 0, "vdict": 0, "diag": 0, "lpanel": 0, "lflat": 0, "tiles": 2, "tile_relaxed": 1}),
+         ("CU tiles relaxed, forced, 2^14", {"wdia": 0, "vdict": 0, "diag": 0, "lpanel": 0, "lflat": 0, "tiles": 2, "tile_relaxed": 1, "tile_shift": 14}),
          ("plain CSR", {"wdia": 0, "vdict": 0, "diag": 0, "tiles": 0, "panels": 0, "lpanel": 0}),
          ("plain CSR, stream kernel", {"wdia": 0, "vdict": 0, "diag": 0, "tiles": 0, "panels": 0, "lpanel": 0, "stream_wave": 0}))
-seen = set()
-nnz = int(rp[-1])
-for label, opts in forms:
-    try:
-        r = bench.side_block(desc, dims, rp, ci, va, opts, steps, 10)
-    except Exception as e:  # noqa: BLE001
-        print(f"{name:14s} {label:26s} failed: {e!r}", flush=True)
-        continue
-    info = r["spmv_kernel"]
-    algo = info.split()[0] + "".join(" " + t for t in info.split() if t.startswith(("panel_cols=", "exact_fold=", "cu_slices=")))
-    if algo in seen and label != "default":
-        continue
-    seen.add(algo)
-    k1 = r["kernels"].get("K1", {}).get("ms", float("nan"))
-    print(f"{name:14s} {label:30s} {r['value']:9.1f} it/s  " + "  ".join(f"{k} {v['ms'] * 1e3:.1f}" for k, v in r["kernels"].items())
-          + f"  K1 on CSR bytes {(12 * nnz + 28 * dims[0]) / k1 / 1e6 / 8000:.3f} of peak  lowered in {r['lowered_once']['from_csr_s']:.2f} s  " + algo, flush=True)
+
+
+def algo_of(info):
+    return info.split()[0] + "".join(" " + t for t in info.split() if t.startswith(("panel_cols=", "exact_fold=", "cu_slices=")))
+
+
+def run(name, steps=60, forms=FORMS, out=print, scale=None):
+    """One bicgstabStep block per form on workload `name`; returns [(label, algo, K1 ms, it/s)], distinct kernels only (default first)."""
+    z = zoo(name, scale) if scale else zoo(name)
+    desc, (dims, (rp, ci, va)) = z if z else bench.workload(name)
+    seen, rows, nnz = set(), [], int(rp[-1])
+    for label, opts in forms:
+        try:
+            r = bench.side_block(desc, dims, rp, ci, va, opts, steps, 10)
+        except Exception as e:  # noqa: BLE001
+            out(f"{name:14s} {label:26s} failed: {e!r}")
+            continue
+        algo = algo_of(r["spmv_kernel"])
+        if algo in seen and label != "default":
+            continue
+        seen.add(algo)
+        k1 = r["kernels"].get("K1", {}).get("ms", float("nan"))
+        rows.append((label, algo, k1, r["value"]))
+        out(f"{name:14s} {label:30s} {r['value']:9.1f} it/s  " + "  ".join(f"{k} {v['ms'] * 1e3:.1f}" for k, v in r["kernels"].items())
+            + f"  K1 on CSR bytes {(12 * nnz + 28 * dims[0]) / k1 / 1e6 / 8000:.3f} of peak  lowered in {r['lowered_once']['from_csr_s']:.2f} s  " + algo)
+    return rows
+
+
+if __name__ == "__main__":
+    run(sys.argv[1] if len(sys.argv) > 1 else "banded_2m", int(sys.argv[2]) if len(sys.argv) > 2 else 60, out=lambda t: print(t, flush=True))
