@@ -505,6 +505,7 @@ const IntKnob kIntKnobs[] = {
     {"tile_slack", &sla_ctx::tile_slack, 0, 64},
     {"tile_prefetch", &sla_ctx::tile_prefetch, 0, 16},
     {"tile_relaxed", &sla_ctx::tile_relaxed, 0, 1},
+    {"tile_depth", &sla_ctx::tile_depth, 0, 2},
     {"canon_device", &sla_ctx::canon_device, 0, 2},
     {"canon_lazy", &sla_ctx::canon_lazy, 0, 1},
     {"transpose_device", &sla_ctx::transpose_device, 0, 2},

@@ -258,6 +258,7 @@ struct sla_ctx {
     int tile_relaxed = 1;            // the tile form of irregular matrices: 1 = CU-wide slices (spmv_ctile_kernel, round 5: column-sorted gathers that share x lines, row sums by LDS
                                      // atomics in relaxed order -- within nnz_i eps sum|a_ij x_j| of the reference's fold, not reproducible bit for bit), 0 = wavefront-private slices
                                      // (spmv_tile_kernel, rounds 2-4: the reference's left fold bit for bit; 18 % slower on config 3a, 2.2 x on power-law rows)
+    int tile_depth = 0;              // CU-wide tile kernel, 64-entry groups per chunk: 0 by the tiles' density (20 below 4 entries per x line, else 12), 1 always 12, 2 always 20 (A/B)
     int tile_prefetch = 0;           // x-panel prefetch distance of spmv_tile_kernel in visit steps (0: demand misses only; measured: never a gain)
     int tile_poll = 1;               // 1: pacing slots polled one step ahead, 0: dependent poll in front of every tile (rounds 2-3)
     int tile_slack = 3;              // panel pacing: a wavefront starts panel step q once its XCD has finished step q - slack (SLA_TILE_SLACK, 0: no pacing)

@@ -118,7 +118,8 @@ int build_tiles(sla_csr *A, int64_t n, int64_t rows, const int64_t *rowptr, cons
     int row_bits = 0;
     while (((int64_t)1 << row_bits) < slice_rows) ++row_bits;
     // panel width: 2^17 columns (1 MiB of x) at 10 M rows, 2^16 below ~6 M (measured: 7-8 % faster at 0.5 / 1 / 3 M rows, 3-15 % slower at 10 M)
-    const int want = c->tile_shift > 0 ? c->tile_shift : (n < 6000000 ? 16 : 17);
+    // (CU-wide slices, round 5: 2^17 at every size -- 100 / 200 per row at 1 M rows 0.49 -> 0.51 / 0.53 -> 0.56 of peak against 2^16, power-law rows equal)
+    const int want = c->tile_shift > 0 ? c->tile_shift : cu ? 17 : (n < 6000000 ? 16 : 17);
     const int shift = std::max(10, std::min((cu ? 32 : 31) - row_bits, want));   // (layer flag, slice row, panel column) packed in 32 bits (CU-wide slices: no flag, 15 + 17 bits)
     const int64_t W = (int64_t)1 << shift;
     if (n <= 2 * W || (c->tile_shift <= 0 && !force && n <= ((int64_t)1 << 18))) return SLA_OK;   // x (nearly) fits the L2 already

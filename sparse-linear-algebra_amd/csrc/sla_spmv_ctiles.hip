@@ -34,28 +34,42 @@
 namespace sla {
 
 #ifndef SLA_CT_U
-#define SLA_CT_U 12     // 64-entry groups per chunk (8: 1.57 ms on config 3a, 12: 1.52)
+#define SLA_CT_U 20     // 64-entry groups per chunk: 1280 gathers in flight per wavefront + the next chunk's streams (config 3a: 8: 1.49 ms, 12: 1.47, 16: 1.40, 20: 1.33; 23 is the last that fits 256 + 256 registers)
+#endif
+#ifndef SLA_CT_CROSS
+#define SLA_CT_CROSS 1  // chunks run over one tile boundary
+#endif
+#ifndef SLA_CT_VAL_LATE
+#define SLA_CT_VAL_LATE 0   // (1: value loads issued with the gathers -- deeper chunks fit the registers, but the fold then waits for HBM: 1.60 ms against 1.34 at 20 groups)
 #endif
 #ifndef SLA_CT_SPIN
 #define SLA_CT_SPIN 2000
 #endif
-constexpr int kCtU = SLA_CT_U;
+#ifndef SLA_CT_U_DENSE
+#define SLA_CT_U_DENSE 12   // ... and for tiles with many entries per x line (d >= 4: the gathers are nearly free there and the launch is bound by the
+                            // streams -- the deep chunks' register shuffling through the AGPRs costs more than their depth gains: 200 per row at
+                            // 1 M rows 464 us with 12 groups, 572 with 20)
+#endif
 
+template <int U>
 struct CtChunk {
-    uint32_t idx[kCtU];
-    double val[kCtU];
-    double xv[kCtU];
+    uint32_t idx[U];
+    double val[U];
+    double xv[U];
+    uint32_t start;   // its first entry, relative to the slice's
     int cnt;      // entries of this chunk (<= 64 * kCtU)
-    int panel;
+    int split;    // its entries [0, split) belong to tile `panel`, the others to `panel2`
+    int panel, panel2;
 };
 
 // LDS only: the streams and gathers of the next chunks stay in flight across it
 __device__ __forceinline__ void ct_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-__device__ __forceinline__ void ct_fold_chunk(double *yl, const CtChunk &c, int shift, int lane) {
+template <int U>
+__device__ __forceinline__ void ct_fold_chunk(double *yl, const CtChunk<U> &c, int shift, int lane) {
 #pragma clang fp contract(off)
 #pragma unroll
-    for (int u = 0; u < kCtU; ++u) {
+    for (int u = 0; u < U; ++u) {
         const int cg = c.cnt - 64 * u;                 // valid lanes of this group (wavefront-uniform)
         if (cg <= 0) break;
         const double p = c.val[u] * c.xv[u];           // (separately rounded: the sum below is an add, never an FMA)
@@ -63,7 +77,7 @@ __device__ __forceinline__ void ct_fold_chunk(double *yl, const CtChunk &c, int 
     }
 }
 
-template <int EPI, typename RP>
+template <int EPI, typename RP, int kCtU>
 __global__ void __launch_bounds__(kBlock, 1)
 spmv_ctile_kernel(SpmvArgs<RP> a, const RP *__restrict__ rowptr, const int32_t *__restrict__ srow, const uint32_t *__restrict__ toff,
                   const uint32_t *__restrict__ tidx, const double *__restrict__ tval, const double *__restrict__ xg, int S, int P,
@@ -87,7 +101,7 @@ spmv_ctile_kernel(SpmvArgs<RP> a, const RP *__restrict__ rowptr, const int32_t *
     const int nwg_xcd = ((int)gridDim.x - xcd + 7) >> 3;
     const int rounds = (S + (int)gridDim.x - 1) / (int)gridDim.x;
     if (vis == nullptr) nv = P;
-    using Chunk = CtChunk;
+    using Chunk = CtChunk<kCtU>;
     int *slots = prog ? (int *)prog + xcd * 256 : nullptr;
     int *myslot = slots ? slots + ((int)blockIdx.x >> 3) : nullptr;
     bool pace = slack > 0 && slots != nullptr && nwg_xcd <= 64;
@@ -173,40 +187,80 @@ spmv_ctile_kernel(SpmvArgs<RP> a, const RP *__restrict__ rowptr, const int32_t *
             }
             return true;
         };
-        auto issue = [&](Chunk &c) {   // the chunk at (sub-step q, k): its index / value streams (lanes past the end re-read the last entry)
-            c.cnt = (int)min((uint32_t)(64 * kCtU), k1 - k);
+        bool live = true;
+        // A chunk holds up to 64 kCtU CONSECUTIVE entries of the wavefront's stream and may run over ONE tile boundary (SLA_CT_CROSS): the
+        // entries [0, split) gather from panel, the rest from panel2.  (A wavefront's share of a tile is ~33 groups on config 3a: chunks
+        // that stop at every tile end leave a quarter of every third chunk empty.)  The ranges of consecutive panel steps are adjacent in
+        // memory when the panels are visited in ascending order; a pass of an overlapped all-gather visits them in the plan's order, and a
+        // chunk then ends with its tile.
+        auto issue = [&](Chunk &c) {   // precondition k < k1; lanes past the end re-read the last entry
+            const uint32_t start = k;
+            uint32_t take = min((uint32_t)(64 * kCtU), k1 - k);
             c.panel = pj;
-            const uint32_t *ip = tidx + (base + (RP)k);
-            const double *vp = tval + (base + (RP)k);
+            c.panel2 = pj;
+            c.split = (int)take;
+            k += take;
+#if SLA_CT_CROSS
+            if (take < (uint32_t)(64 * kCtU)) {   // the tile ends inside the chunk: go on with the next non-empty one if it follows in memory
+                if (!advance()) {
+                    live = false;
+                } else if (k == start + take) {
+                    const uint32_t more = min((uint32_t)(64 * kCtU) - take, k1 - k);
+                    c.panel2 = pj;
+                    k += more;
+                    take += more;
+                }
+            }
+#endif
+            c.cnt = (int)take;
+            c.start = start;
+            const uint32_t *ip = tidx + (base + (RP)start);
+#if !SLA_CT_VAL_LATE
+            const double *vp = tval + (base + (RP)start);
+#endif
 #pragma unroll
             for (int u = 0; u < kCtU; ++u) {
                 const uint32_t i = (uint32_t)min(lane + 64 * u, c.cnt - 1);
                 c.idx[u] = __builtin_nontemporal_load(ip + i);
+#if !SLA_CT_VAL_LATE
                 c.val[u] = __builtin_nontemporal_load(vp + i);
+#endif
             }
-            k += 64 * kCtU;
         };
         auto gather = [&](Chunk &c) {
-            const char *xb = (const char *)(xg + ((size_t)c.panel << shift));
+            const char *xa = (const char *)(xg + ((size_t)c.panel << shift)), *xb = (const char *)(xg + ((size_t)c.panel2 << shift));
+#if SLA_CT_VAL_LATE   // the values are not needed before the fold: their loads go out with the gathers, one pipeline stage later (8 B per entry
+            // less to hold per chunk in its first stage: deeper chunks fit the register file)
+            const double *vp = (c.cnt ? tval + (base + (RP)c.start) : tval);
 #pragma unroll
-            for (int u = 0; u < kCtU; ++u) c.xv[u] = *(const double *)(xb + (uint32_t)((c.idx[u] & cmask) << 3));
+            for (int u = 0; u < kCtU; ++u) c.val[u] = __builtin_nontemporal_load(vp + (uint32_t)min(lane + 64 * u, c.cnt ? c.cnt - 1 : dlim));
+#endif
+#pragma unroll
+            for (int u = 0; u < kCtU; ++u) {
+                const char *b = (lane + 64 * u < c.split) ? xa : xb;
+                c.xv[u] = *(const double *)(b + (uint32_t)((c.idx[u] & cmask) << 3));
+            }
         };
-        auto fold = [&](const Chunk &c) { ct_fold_chunk(yl, c, shift, lane); };
+        auto fold = [&](const Chunk &c) { ct_fold_chunk<kCtU>(yl, c, shift, lane); };
         // three chunks in flight per wavefront; the loop issues the SAME loads on every path (past the slice's last chunk: empty chunks)
         Chunk A, B, C;
-        bool live = true;
         auto next = [&](Chunk &c) {
-            if (live && !advance()) live = false;
+            if (live && k >= k1 && !advance()) live = false;
             if (live) {
                 issue(c);
             } else {
                 c.cnt = 0;
+                c.start = 0;
+                c.split = 0;
+                c.panel2 = dpanel;
                 c.panel = dpanel;   // (a panel that holds a column this rank references: on a window-mode slab panel 0 may lie outside the vector's guard)
 #pragma unroll
                 for (int u = 0; u < kCtU; ++u) {
                     const int i = min(lane + 64 * u, dlim);
                     c.idx[u] = __builtin_nontemporal_load(tidx + i);
+#if !SLA_CT_VAL_LATE
                     c.val[u] = __builtin_nontemporal_load(tval + i);
+#endif
                 }
             }
         };
@@ -270,9 +324,17 @@ static int launch_ctiles_t(const sla_csr *A, const SpmvLaunch &l) {
     if (l.tv1 >= 0 && (!vis || l.tv0 < 0 || nv < 1 || l.tv1 > A->tl_P)) return fail(SLA_ERR_INVALID, "launch_spmv_tiles: bad panel pass");
     ProfScope prof(c, l.kernel_id);
     if (A->d_tlprog) SLA_HIP_TRY(hipMemsetAsync(A->d_tlprog, 0, A->tlprog_bytes, stream_of(c)));   // the pacing table of this launch
-    hipLaunchKernelGGL((spmv_ctile_kernel<EPI, RP>), dim3(ctiles_grid(A)), dim3(kBlock), 0, stream_of(c), a, a.rowptr, A->d_tlrow, A->d_tloff,
-                       A->d_tlidx, A->d_tlval, l.x, A->tl_S, A->tl_P, A->tl_shift, A->d_tlprog, c->xcd8 == 1 ? c->tile_slack : 0, vis, l.tv0, nv,
-                       (int)std::min<int64_t>(64 * kCtU - 1, A->nnz - 1), A->tl_dpanel);
+    // chunk depth by the tiles' density d = entries per 128-byte line of x per slice sweep (see SLA_CT_U_DENSE)
+    const double d = (double)A->nnz / (double)std::max<int64_t>(1, A->tl_S) * 16.0 / (double)std::max<int64_t>(1, A->n);
+    const bool deep = c->tile_depth == 0 ? d < 4.0 : c->tile_depth == 2;
+    if (deep)
+        hipLaunchKernelGGL((spmv_ctile_kernel<EPI, RP, SLA_CT_U>), dim3(ctiles_grid(A)), dim3(kBlock), 0, stream_of(c), a, a.rowptr, A->d_tlrow, A->d_tloff,
+                           A->d_tlidx, A->d_tlval, l.x, A->tl_S, A->tl_P, A->tl_shift, A->d_tlprog, c->xcd8 == 1 ? c->tile_slack : 0, vis, l.tv0, nv,
+                           (int)std::min<int64_t>(64 * SLA_CT_U - 1, A->nnz - 1), A->tl_dpanel);
+    else
+        hipLaunchKernelGGL((spmv_ctile_kernel<EPI, RP, SLA_CT_U_DENSE>), dim3(ctiles_grid(A)), dim3(kBlock), 0, stream_of(c), a, a.rowptr, A->d_tlrow, A->d_tloff,
+                           A->d_tlidx, A->d_tlval, l.x, A->tl_S, A->tl_P, A->tl_shift, A->d_tlprog, c->xcd8 == 1 ? c->tile_slack : 0, vis, l.tv0, nv,
+                           (int)std::min<int64_t>(64 * SLA_CT_U_DENSE - 1, A->nnz - 1), A->tl_dpanel);
     SLA_HIP_TRY(hipGetLastError());
     return SLA_OK;
 }

@@ -180,14 +180,14 @@ def test_default_panel_width_picks_tiles_only_beyond_the_l2(sla):
     ctx = sla.Context(0)
     dims, (rp, ci, va) = wl.random_spd(250000, 4, 1)          # x = 2 MB: fits the L2, no panels of any kind
     assert "tiles" not in sla.fromCSR(dims, rp, ci, va, ctx).kernel_info()
-    dims, (rp, ci, va) = wl.random_spd(700000, 4, 1)          # 5.6 MB of x: eleven 512 KiB panels (2^16 columns below 6 M columns)
+    dims, (rp, ci, va) = wl.random_spd(700000, 4, 1)          # 5.6 MB of x: six 1 MiB panels (CU-wide slices: 2^17 columns at every size)
     A = sla.fromCSR(dims, rp, ci, va, ctx)
-    assert "algo=tiles" in A.kernel_info() and "panels=11 panel_cols=65536" in A.kernel_info() and "cu_slices=1" in A.kernel_info(), A.kernel_info()
+    assert "algo=tiles" in A.kernel_info() and "panels=6 panel_cols=131072" in A.kernel_info() and "cu_slices=1" in A.kernel_info(), A.kernel_info()
     x = np.random.default_rng(2).standard_normal(dims[0])
     yo = orc.spmv(orc.Csr(*dims, rp, ci, va), x)
     bound = np.diff(rp) * EPS * orc.spmv(orc.Csr(*dims, rp, ci, np.abs(va)), np.abs(x))
     assert np.all(np.abs(sla.matVec(A, sla.fromVector(x, ctx)).toDenseListSV() - yo) <= bound)
-    ctx0 = sla.Context(0).set_option("tile_relaxed", 0)        # the bit-exact form: same geometry rule, the reference's fold
+    ctx0 = sla.Context(0).set_option("tile_relaxed", 0)        # the bit-exact form: eleven 512 KiB panels (2^16 columns below 6 M columns), the reference's fold
     A0 = sla.fromCSR(dims, rp, ci, va, ctx0)
     assert "panels=11 panel_cols=65536" in A0.kernel_info() and "exact_fold=1" in A0.kernel_info(), A0.kernel_info()
     assert np.array_equal(sla.matVec(A0, sla.fromVector(x, ctx0)).toDenseListSV(), yo)
