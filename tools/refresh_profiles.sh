@@ -67,7 +67,7 @@ SLA_BENCH_LOOPBACK=1 timeout 900 python bench.py --gpus 2 --steps 40 --warmup 5 
 for set in "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_PENDING_STALL_CYCLES_sum TCP_GATE_EN1_sum" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES" "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_REQ_sum"; do
   d=$S/pmc_tmp; rm -rf $d; mkdir -p $d
   timeout 600 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $d -o p -- python bench.py --workload random_spd_10m --steps 6 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
-  python - "$d" tile <<'PY' >> $S/${tag}_pmc_l1_l2_tile_kernel_10m.txt
+  python - "$d" tile_kernel <<'PY' >> $S/${tag}_pmc_l1_l2_tile_kernel_10m.txt
 import csv, glob, collections, sys
 for f in sorted(glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True)):
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
@@ -115,4 +115,16 @@ done
 timeout 600 python tools/hard_regime.py > $S/${tag}_hard_regime.txt 2>&1
 timeout 900 python tools/ag_split_bench.py > $S/${tag}_ag_split_cost.txt 2>&1
 timeout 900 python tools/wave_ab.py 30 2 > $S/${tag}_ab_wave_kernel.txt 2>&1
-ls -la $S | head -60
+# round 5: kernel trace of the plain-CSR block (spmv_wave_kernel on the 216^3 Laplacian: the metric's "CSR SpMV achieved HBM GB/s")
+SLA_WDIA=0 SLA_VDICT=0 SLA_DIAG=0 rocprofv3 --kernel-trace --stats --output-format csv -d $S/ksc -o ks -- python bench.py --no-cpu-baseline --no-extra-blocks 2>/dev/null | tail -1 > $S/${tag}_bench_traced_run_general_csr.json
+cp "$(find $S/ksc -name '*kernel_stats.csv' | head -1)" $S/${tag}_bench_kernel_stats_general_csr.csv
+# round 5: first contact of a multi-rank job rehearsed on one GPU -- the three blocks of the N > 1 line behind the pre-flight (1-rank RCCL
+# communicator and two loopback ranks), and the fallback ladder under an injected grouped-send/recv failure and an injected hang
+SLA_BENCH_FORCE_DIST=1 timeout 900 python bench.py --steps 40 --warmup 5 --no-cpu-baseline 2>$S/${tag}_bench_1rank_rccl_stderr.txt | grep '^{' | tail -1 > $S/${tag}_bench_1rank_rccl.json
+SLA_BENCH_LOOPBACK=1 SLA_FAULT_INJECT=p2p timeout 900 python bench.py --gpus 2 --workload laplace3d_small --steps 20 --warmup 5 2>$S/${tag}_bench_loopback_fault_p2p_stderr.txt | grep '^{' | tail -1 > $S/${tag}_bench_loopback_fault_p2p.json
+SLA_BENCH_LOOPBACK=1 SLA_FAULT_INJECT=p2p_hang SLA_BENCH_PREFLIGHT_S=5 timeout 900 python bench.py --gpus 2 --workload laplace3d_small --steps 20 --warmup 5 2>$S/${tag}_bench_loopback_fault_hang_stderr.txt | grep '^{' | tail -1 > $S/${tag}_bench_loopback_fault_hang.json
+# round 5: the form tournament over the matrix zoo (the pick against every forced form) and the lowering phases of configs 3a / 4
+for w in laplace3d_10m laplace3d_1m banded_2m poisson2d_1m e05_tiled e05_tiled_10m varcoef7 random_spd_1m rand100 rand200 rand500 powerlaw; do timeout 900 python tools/form_tournament.py $w 40 2>/dev/null | grep -v "^#"; done > $S/${tag}_form_tournament.txt 2>&1
+{ timeout 600 python tools/lower_phases.py random_spd_10m 3; timeout 600 python tools/lower_phases.py laplace3d_10m 3; } > $S/${tag}_lowering_phases.txt 2>&1
+timeout 900 python tools/tile_bench.py 10000000 "DEFAULT=1" "SLA_TILE_RELAXED=0" "SLA_TILE_DEPTH=1" "SLA_TILE_SLACK=2" "SLA_TILE_SLACK=4" "SLA_TILE_SLACK=0" "SLA_TILE_SHIFT=16" > $S/${tag}_ab_tile_knobs.txt 2>&1
+ls -la $S | head -80
