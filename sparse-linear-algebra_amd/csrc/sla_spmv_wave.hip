@@ -61,8 +61,10 @@ int launch_col_slack_fill(sla_ctx *c, int32_t *d_col, int64_t nnz) {
 
 // PRE: the streams of the NEXT chunk (of this block or of the wavefront's next block) are issued before the current chunk is folded
 // (a second register set: fewer wavefronts per CU, more bytes in flight per wavefront)
+// (the two-pair instantiations of the three-operand epilogues are compiled for 7 workgroups per CU instead of 8: at 8 they spilled 14-16
+// registers to scratch -- profiles/r04_kernel_resources.txt; the launch keeps its grid, the surplus workgroups queue behind the first round)
 template <int EPI, int PPL, int OCC, bool PRE>
-__global__ void __launch_bounds__(kBlock, OCC)
+__global__ void __launch_bounds__(kBlock, (PPL == 2 && OCC == 8 && (EPI == EPI_DOT4 || EPI == EPI_AXPY_DOT)) ? 7 : OCC)
 spmv_wave_kernel(SpmvArgs<int32_t> a, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col, const double *__restrict__ val,
                  const double *__restrict__ xg, int nblk, int xcd_remap, int nt) {
     constexpr int CH = 128 * PPL;                       // entries per chunk
