@@ -98,6 +98,13 @@ defaultCtx = unsafePerformIO $ do
   case lit of
     Just "1" -> withCString "bicg_fuse45" $ \k -> withCString "0" $ \v -> c_ctx_set_option c k v >>= check "sla_ctx_set_option"
     _ -> return ()
+  -- SLA_EXACT_FOLD=1: (#>) on irregular matrices (the tile form: more than 2^18 columns, no band structure) as the reference's ascending
+  -- left fold bit for bit and reproducible, instead of the default relaxed-order kernel (within nnz_i eps sum |a_ij x_j| of it, 1.4 x
+  -- faster on BASELINE config 3a; INTEGRATION.md, "(#>) on irregular matrices and the order of a row's sum")
+  ex <- lookupEnv "SLA_EXACT_FOLD"
+  case ex of
+    Just "1" -> withCString "tile_relaxed" $ \k -> withCString "0" $ \v -> c_ctx_set_option c k v >>= check "sla_ctx_set_option"
+    _ -> return ()
   return c
 
 -- | status code -> the reference's exception / error (Control/Exception/Common.hs:44-76).  INTEGRATION.md section 2 shows

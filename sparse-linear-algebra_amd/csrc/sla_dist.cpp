@@ -546,8 +546,11 @@ int dist_preflight(sla_ctx *ctx, int phase, int64_t count, double *max_abs_err, 
         double *src = nullptr, *dst = nullptr;
         SLA_HIP_TRY(dev_malloc(ctx, (void **)&src, sizeof(double) * n));
         hipError_t e = dev_malloc(ctx, (void **)&dst, sizeof(double) * n * P);
-        if (e == hipSuccess) e = hipMemcpy(src, h.data(), sizeof(double) * n, hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMemset(dst, 0xff, sizeof(double) * n * P);
+        // (on the context's stream: a memset on the legacy stream is not ordered against a collective on this non-blocking one -- the first
+        // 1-rank rehearsal of this function saw its own NaN fill land AFTER the gather)
+        if (e == hipSuccess) e = hipMemcpyAsync(src, h.data(), sizeof(double) * n, hipMemcpyHostToDevice, stream_of(ctx));
+        if (e == hipSuccess) e = hipMemsetAsync(dst, 0xff, sizeof(double) * n * P, stream_of(ctx));
+        if (e == hipSuccess) e = hipStreamSynchronize(stream_of(ctx));
         int rc = SLA_OK;
         if (e == hipSuccess) rc = phase == 0 ? dist_allgather_f64(ctx, src, dst, count) : dist_allgather_p2p_f64(ctx, src, dst, count);
         if (rc == SLA_OK && e == hipSuccess) e = hipStreamSynchronize(stream_of(ctx));
