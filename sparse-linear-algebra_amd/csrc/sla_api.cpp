@@ -465,7 +465,6 @@ const IntKnob kIntKnobs[] = {
     {"xcd_remap", &sla_ctx::xcd_remap, 0, 1},
     {"dual_spmv", &sla_ctx::dual_spmv, 0, 1},
     {"xwin", &sla_ctx::xwin, 0, 2},
-    {"stream_pipe", &sla_ctx::stream_pipe, 0, 1},
     {"stream_wave", &sla_ctx::stream_wave, 0, 1999},
     {"stream_wide", &sla_ctx::stream_wide, 0, 1},
     {"diag", &sla_ctx::diag, 0, 2},
@@ -977,7 +976,7 @@ int sla_csr_kernel_info(sla_csr_t A, char *buf, int buflen) {
     if (A && !A->kids.empty()) return sla_csr_kernel_info(A->kids[0], buf, buflen);
     if (!A || !buf || buflen <= 0) return fail(SLA_ERR_INVALID, "null argument");
     snprintf(buf, (size_t)buflen, "algo=%s grid=%d block=%d row_blocks=%d nnz_per_row_block=%d max_row_nnz=%lld rowptr=%s xcd_remap=%d",
-             A->ctx->spmv_algo == 1 ? "scalar" : (A->use_wdia && wd_on(A)) ? (A->wd_vv ? "wdia-vv" : wd_march_on(A) ? "wdia+march" : wd_lds_on(A) ? "wdia+ldswin" : "wdia") : (A->use_vdict && A->ctx->vdict) ? (A->use_xwin && A->ctx->xwin ? "vdict+xwin" : "vdict") : (A->use_lpanel && A->ctx->lpanel) ? "stream+ldspanels" : lflat_on(A) ? "lflat" : tiles_on(A) ? "tiles" : (!A->panels.empty() && A->ctx->panels) ? "stream+colpanels" : (diag_on(A) ? (diag_xwin_on(A) ? "stream+diagdict+xwin" : "stream+diagdict") : (pipe_on(A) ? "stream+pipe" : stream_xwin_on(A) ? "stream+xwin" : wave_plain(A) ? "stream+wave" : "stream")), spmv_grid(A), kBlock, A->nrb, kNnzPerRowBlock,
+             A->ctx->spmv_algo == 1 ? "scalar" : (A->use_wdia && wd_on(A)) ? (A->wd_vv ? "wdia-vv" : wd_march_on(A) ? "wdia+march" : wd_lds_on(A) ? "wdia+ldswin" : "wdia") : (A->use_vdict && A->ctx->vdict) ? (A->use_xwin && A->ctx->xwin ? "vdict+xwin" : "vdict") : (A->use_lpanel && A->ctx->lpanel) ? "stream+ldspanels" : lflat_on(A) ? "lflat" : tiles_on(A) ? "tiles" : (!A->panels.empty() && A->ctx->panels) ? "stream+colpanels" : (diag_on(A) ? (diag_xwin_on(A) ? "stream+diagdict+xwin" : "stream+diagdict") : (stream_xwin_on(A) ? "stream+xwin" : wave_plain(A) ? "stream+wave" : "stream")), spmv_grid(A), kBlock, A->nrb, kNnzPerRowBlock,
              (long long)A->max_row_nnz, A->rp64 ? "i64" : "i32", A->ctx->xcd_remap);
     if (A->use_lpanel && A->ctx->lpanel && A->ctx->spmv_algo == 0) {   // LDS-panel geometry
         const size_t used = strlen(buf);

@@ -294,7 +294,6 @@ struct sla_ctx {
     int stream_wide = 1;             // spmv_stream_kernel: pairs of entries per load (8-byte col / 16-byte val loads) instead of one (SLA_STREAM_WIDE=0)
     int stream_wave = 1;             // plain CSR (#>): wavefront-private 128-row blocks with row-pair stores (sla_spmv_wave.hip) instead of spmv_stream_kernel when no row
                                      // exceeds kWvMaxRow entries (SLA_STREAM_WAVE: 0 off, 1 on = 4 entry pairs per lane and chunk, 4 / 7 force that chunk size)
-    int stream_pipe = 0;             // plain CSR-stream (#>): the three-stage pipelined kernel (sla_spmv_pipe.hip) instead of spmv_stream / spmv_xwin
                                      // (SLA_STREAM_PIPE=1; OFF by default: measured 7-12 % SLOWER than the one-deep prefetch)
     int dual_spmv = 1;               // linSolve0: fuse the true-residual SpMV into the next K1 (SLA_DUAL_SPMV=0 disables)
     int x_exchange = 0;              // 0 auto (window exchange when it pays), 1 always all-gather, 2 always window (SLA_X_EXCHANGE=allgather|window)
@@ -831,9 +830,6 @@ bool wave_on(const sla_csr *A);                                                 
 int wave_grid(const sla_csr *A);
 bool wave_plain(const sla_csr *A);   // sla_spmv.hip: does a plain (#>) on A end up on spmv_wave_kernel?
 int launch_spmv_wave(const sla_csr *A, int epi, const SpmvArgs<int32_t> &a, int grid);
-bool pipe_on(const sla_csr *A);                                                                              // sla_spmv_pipe.hip
-int launch_spmv_pipe(const sla_csr *A, int epi, const SpmvArgs<int32_t> &a, int grid);
-int launch_spmv_pipe(const sla_csr *A, int epi, const SpmvArgs<int64_t> &a, int grid);
 int tiles_grid(const sla_csr *A);
 int launch_col_slack_fill(sla_ctx *c, int32_t *d_col, int64_t nnz);   // sla_spmv_wave.hip: the slack behind the column array repeats the last column
 int launch_spmv_ctiles(const sla_csr *A, const SpmvLaunch &l);   // sla_spmv_ctiles.hip (CU-wide slices)

@@ -32,7 +32,7 @@ int overlap_grid(const sla_csr *A, int part) {
 
 // does a plain (#>) on A end up on spmv_wave_kernel?  (the forms dispatched in front of it in launch_spmv_rp all have to be out)
 bool wave_plain(const sla_csr *A) {
-    return wave_on(A) && !A->is_panel_view && !diag_on(A) && !pipe_on(A) && !stream_xwin_on(A);
+    return wave_on(A) && !A->is_panel_view && !diag_on(A) && !stream_xwin_on(A);
 }
 
 int spmv_grid(const sla_csr *A) {
@@ -132,7 +132,7 @@ static int launch_spmv_rp(const sla_csr *A, const SpmvLaunch &l) {
         const bool wd = A->use_wdia && wd_on(A) && c->spmv_algo == 0 && !l.x2;
         if (!lp && !lf) {
             if (wd) prof_ext = !(wd_march_on(A) && l.part == 0) && !wd_lds_on(A);
-            else if (!(A->use_vdict && c->vdict && c->spmv_algo == 0) && !l.x2 && !(c->spmv_algo != 1 && diag_on(A)) && !(c->spmv_algo != 1 && pipe_on(A)))
+            else if (!(A->use_vdict && c->vdict && c->spmv_algo == 0) && !l.x2 && !(c->spmv_algo != 1 && diag_on(A)))
                 prof_ext = wave_plain(A) && !l.yinit;
         }
     }
@@ -157,7 +157,6 @@ static int launch_spmv_rp(const sla_csr *A, const SpmvLaunch &l) {
     }
     if (l.x2) return diag_on(A) ? launch_spmv_dual_diag(A, a, l.x2, l.b2, grid) : launch_spmv_dual(A, a, l.x2, l.b2, grid);
     if (c->spmv_algo != 1 && diag_on(A)) return launch_spmv_diag(A, l.epi, a, grid);
-    if (c->spmv_algo != 1 && pipe_on(A)) return launch_spmv_pipe(A, l.epi, a, grid);
     if constexpr (std::is_same<RP, int32_t>::value) {
         if (wave_plain(A) && !l.yinit) return launch_spmv_wave(A, l.epi, a, grid);
     }

@@ -281,8 +281,6 @@ def test_64_bit_row_pointer_kernels(sla):
         "random_spd short rows": (wl.random_spd(3000, 4, 3), {}, "algo=stream"),
         "laplace3d, x window (narrow loads)": (wl.laplace3d(13, 9, 11), {"diag": 0, "stream_wide": 0}, "algo=stream+xwin"),
         "random_spd, narrow loads": (wl.random_spd(3000, 4, 3), {"stream_wide": 0}, "algo=stream"),
-        "laplace3d, pipelined stream": (wl.laplace3d(13, 9, 11), {"diag": 0, "stream_pipe": 1}, "algo=stream+pipe"),
-        "random_spd, pipelined stream": (wl.random_spd(3000, 4, 3), {"stream_pipe": 1}, "algo=stream+pipe"),
         "random_spd, column panels": (wl.random_spd(5000, 6, 4), {"panel_cols": 600}, "colpanels"),
         "dense rows, LDS panels": (dense_rows(900, 20000, 120), {}, "ldspanels"),
         "row-block limits": (limits(), {"lpanel": 0}, "algo=stream"),
@@ -364,52 +362,6 @@ def test_step_graph_replay_is_bit_identical_to_stream_launches(sla):
     for a, b_ in zip(out["1"], out["0"]):
         assert np.array_equal(a, b_)
     assert np.isfinite(out["1"][3]).all() and np.linalg.norm(out["1"][3] - 1.0) < np.linalg.norm(np.ones(n))     # and it is heading for x* = 1
-
-
-def test_pipelined_stream_kernel_is_bit_identical_to_the_stream_kernel(sla):
-    """sla_spmv_pipe.hip (knob stream_pipe; off by default -- measured slower) folds every row exactly like
-    spmv_stream_kernel: (#>) and every fused epilogue through the solvers give the same bits, on stencil, random, ragged and
-    empty-row structure, including matrices whose last row blocks are empty (the clamped whole-block loads read the zeroed slack)."""
-    from sla_amd import workloads as wl
-    rng = np.random.default_rng(11)
-
-    def ragged():
-        n = 5000
-        rows, cols, vals = [], [], []
-        for i in range(n):
-            if i % 7 == 3 or i > n - 400:
-                continue                                    # empty rows, and an empty tail: whole row blocks without entries
-            k = int(rng.integers(1, 40))
-            c = np.unique(rng.integers(0, n, k))
-            rows.append(np.full(len(c), i)), cols.append(c), vals.append(rng.standard_normal(len(c)))
-        rc, A = orc.coo_to_csr(n, n, np.concatenate(rows), np.concatenate(cols), np.concatenate(vals))
-        return (n, n), (A.rowptr, A.colidx, A.val)
-
-    # ("random13": ~13 entries per row -- wavefront-segmented row sums, the same in both kernels, not the oracle's left fold)
-    for name, (dims, csr) in {"laplace": wl.laplace3d(21, 17, 19), "random": wl.random_spd(20000, 3, 9), "random13": wl.random_spd(20000, 6, 9),
-                              "ragged": ragged()}.items():
-        n = dims[0]
-        out = {}
-        for pipe in (0, 1):
-            ctx = sla.Context(0).set_options(wdia=0, vdict=0, diag=0, tiles=0, panels=0, lpanel=0, stream_pipe=pipe, stream_wave=0)
-            A = sla.fromCSR(dims, *csr, ctx)
-            assert ("stream+pipe" in A.kernel_info()) == bool(pipe), A.kernel_info()
-            x = np.random.default_rng(3).standard_normal(n)
-            res = [sla.matVec(A, sla.fromVector(x, ctx)).toDenseListSV()]
-            if name != "ragged":
-                b = orc.spmv(orc.Csr(n, n, *csr), np.ones(n))
-                for meth in (sla.BICGSTAB_, sla.CGS_, sla.CGNE_):
-                    xs, inf = sla.linSolve0(meth, A, sla.fromVector(b, ctx), sla.fromVector(np.zeros(n), ctx), return_info=True)
-                    res += [xs.toDenseListSV(), inf["iters"]]
-                st = sla.bicgsInit(A, sla.fromVector(b, ctx), sla.fromVector(np.zeros(n), ctx)).step(3)
-                res.append(st._xBicgstab.toDenseListSV())
-            out[pipe] = res
-            del A
-            ctx.close()
-        if name in ("laplace", "random"):
-            assert np.array_equal(out[1][0], orc.spmv(orc.Csr(n, n, *csr), np.random.default_rng(3).standard_normal(n))), name
-        for a, b_ in zip(out[0], out[1]):
-            assert np.array_equal(a, b_) if isinstance(a, np.ndarray) else a == b_, name
 
 
 @pytest.mark.parametrize("mode", [0, 1, 2])

@@ -1,3 +1,7 @@
+// NOT BUILT (round 5): the three-stage pipelined CSR-stream kernel of round 3 -- measured 7-12 % slower than spmv_stream_kernel on every workload
+// (profiles/r03_pmc_l1_l2_stream_kernel.txt, LABNOTES L4), superseded by spmv_wave_kernel in round 4; removed from the library with its option
+// stream_pipe, kept here for the record.
+
 // sla_spmv_pipe.hip -- the general CSR-stream (#>) (f64 values + i32 columns) as a THREE-stage software pipeline.
 // Reference semantics: Data/Sparse/Common.hs:242-260 (rows summed by one lane are the reference's ascending left fold).
 //

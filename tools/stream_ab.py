@@ -1,5 +1,5 @@
 """Same-box A/B of the general CSR-stream kernels (SLA_WDIA=0 SLA_VDICT=0 SLA_DIAG=0) on the 216^3 Laplacian and on a random
-1 M-row matrix: the pipelined kernel (sla_spmv_pipe.hip) against spmv_stream / spmv_xwin.  Prints K1 / K3 / step timings.
+1 M-row matrix under typed options (round 3 used it for the pipelined kernel, which left the library in round 5: tools/experiments/r03_spmv_pipe_kernel.hip).  Prints K1 / K3 / step timings.
     python tools/stream_ab.py [steps]"""
 import json
 import os
