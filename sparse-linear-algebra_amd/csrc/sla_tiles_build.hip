@@ -11,6 +11,8 @@
 // row's left fold over ascending columns, Data/Sparse/Common.hs:247-260 (kernel: sla_spmv_tiles.hip).
 #include <hip/hip_runtime.h>
 
+#include <chrono>
+#include <cstdio>
 #include <cstring>  // rocPRIM's texture iterator calls the host memset without including it
 
 #include <rocprim/rocprim.hpp>
@@ -280,6 +282,16 @@ int build_ctiles_device(sla_csr *A, const std::vector<int32_t> &srow, int shift,
     const int64_t nnz = A->nnz, rows = A->rows, S = (int64_t)srow.size() - 1;
     if (!A->d_col || !A->d_val || !A->d_rowptr || nnz <= 0 || nnz >= ((int64_t)1 << 31) || S <= 0) return SLA_OK;
     hipStream_t st = stream_of(c);
+    static const bool dbg = getenv("SLA_DEBUG_LOWER") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {   // SLA_DEBUG_LOWER: where the build's time goes (device work included: synchronises)
+        if (!dbg) return;
+        (void)hipStreamSynchronize(st);
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[sla] lowering:     . [cu tiles] %-28s %7.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    };
+    struct FreeLap { decltype(lap) &l; ~FreeLap() { l("(scope exit: after the frees)"); } };
     DevBuf d_srow, d_key, d_key2, d_idx, d_idx2, d_rows, d_tmp, d_bs;
     auto launch_ok = [&]() { return hipGetLastError() == hipSuccess; };
     const int pbits = bits_for((uint64_t)P), sbits = bits_for((uint64_t)S);
@@ -300,6 +312,7 @@ int build_ctiles_device(sla_csr *A, const std::vector<int32_t> &srow, int shift,
                                       (size_t)nnz, 0, (unsigned)keybits, st);
     if (e == hipSuccess) e = d_tmp.alloc(tmp_bytes);
     if (e != hipSuccess) { (void)hipGetLastError(); return SLA_OK; }   // (no device memory for the scratch: the host path may still work)
+    lap("scratch allocations");
     if (!A->d_tlidx) e = dev_malloc(c, (void **)&A->d_tlidx, sizeof(uint32_t) * (size_t)nnz + 64);
     if (e == hipSuccess && !A->d_tlval) e = dev_malloc(c, (void **)&A->d_tlval, sizeof(double) * (size_t)nnz + 64);
     if (e == hipSuccess && !A->d_tloff) e = dev_malloc(c, (void **)&A->d_tloff, sizeof(uint32_t) * ntoff + 64);
@@ -311,6 +324,7 @@ int build_ctiles_device(sla_csr *A, const std::vector<int32_t> &srow, int shift,
         return SLA_OK;
     };
     if (e != hipSuccess) return give_up();
+    lap("tile array allocations");
     const int grid = 4096;
     const unsigned gs = (unsigned)std::min<int64_t>(S, 65535);
     const unsigned gt = (unsigned)std::min<int64_t>(((int64_t)S * (P + 1) + 255) / 256, 65535);
@@ -322,9 +336,11 @@ int build_ctiles_device(sla_csr *A, const std::vector<int32_t> &srow, int shift,
         hipLaunchKernelGGL((tile_rows_kernel<int32_t>), dim3(grid), dim3(256), 0, st, rows, (const int32_t *)A->d_rowptr, d_rows.as<int32_t>());
     }
     if (!launch_ok()) return give_up();
+    lap("keys + rows");
     e = rocprim::radix_sort_pairs(d_tmp.p, tmp_bytes, d_key.as<uint64_t>(), d_key2.as<uint64_t>(), d_idx.as<uint32_t>(), d_idx2.as<uint32_t>(), (size_t)nnz, 0,
                                   (unsigned)keybits, st);
     if (e != hipSuccess) return give_up();
+    lap("radix sort");
     // tile starts: the wavefront-private form's offsets kernel with no layer field (lbits = 0)
     if (A->rp64) hipLaunchKernelGGL((tile_offsets_kernel<int64_t>), dim3(gt), dim3(256), 0, st, (int)S, (int)P, nnz, d_key2.as<uint64_t>(), d_srow.as<int32_t>(), (const int64_t *)A->d_rowptr, shift, 0, pbits, d_bs.as<uint32_t>());
     else hipLaunchKernelGGL((tile_offsets_kernel<int32_t>), dim3(gt), dim3(256), 0, st, (int)S, (int)P, nnz, d_key2.as<uint64_t>(), d_srow.as<int32_t>(), (const int32_t *)A->d_rowptr, shift, 0, pbits, d_bs.as<uint32_t>());
@@ -336,6 +352,7 @@ int build_ctiles_device(sla_csr *A, const std::vector<int32_t> &srow, int shift,
         hipLaunchKernelGGL((ctile_emit_kernel<int32_t>), dim3(grid), dim3(256), 0, st, nnz, (int)P, d_key2.as<uint64_t>(), d_idx2.as<uint32_t>(), d_srow.as<int32_t>(), (const int32_t *)A->d_rowptr, A->d_col, A->d_val, d_rows.as<int32_t>(), d_bs.as<uint32_t>(), A->d_tloff, shift, pbits, A->d_tlidx, A->d_tlval);
     if (!launch_ok()) return give_up();
     SLA_HIP_TRY(hipStreamSynchronize(st));
+    lap("offsets + emit");
     *done = true;
     return SLA_OK;
 }
