@@ -840,7 +840,7 @@ int build_tiles(sla_csr *A, int64_t n, int64_t rows, const int64_t *rowptr, cons
 // sla_tiles_build.hip: the same re-ordering on the device from A's canonical arrays (*done = false: not taken, use the host builder)
 int build_tiles_device(sla_csr *A, const std::vector<int32_t> &srow, int shift, int64_t P, int64_t *maxseg_out, int64_t *nbreaks_out, bool *done);
 // ... and the CU-wide layout of sla_spmv_ctiles.hip (relaxed: one column-sorted run per tile)
-int build_ctiles_device(sla_csr *A, const std::vector<int32_t> &srow, int shift, int64_t P, bool *done);
+int build_ctiles_device(sla_csr *A, const std::vector<int32_t> &srow, int shift, int64_t P, const int64_t *rowptr_host, bool *done);
 
 int vec_grid(int64_t n_local);
 // p1[b] = sum x.y over block b's elements (grid = vec_grid)

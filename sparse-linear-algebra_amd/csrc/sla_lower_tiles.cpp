@@ -172,7 +172,7 @@ int build_tiles(sla_csr *A, int64_t n, int64_t rows, const int64_t *rowptr, cons
         int64_t mseg = 0, nb = 0;
         bool done = false;
         if (cu) {   // (relaxed order: no layers, nothing to step aside for)
-            SLA_TRY(build_ctiles_device(A, srow, shift, P, &done));
+            SLA_TRY(build_ctiles_device(A, srow, shift, P, rowptr, &done));
             if (done) {
                 A->lower_log += "tile builder on device=1;cu tiles=1;";
                 return finish();

@@ -126,26 +126,52 @@ __global__ void __launch_bounds__(256) tile_offsets_kernel(int S, int P, int64_t
 // key = (slice << pbits | panel) << shift | column inside the panel; STABLE sort: equal columns stay in input order = ascending rows.
 // Inside a tile the sorted entries are dealt to the workgroup's four wavefronts in 64-entry groups round-robin; the layout is
 // [slice][wavefront][panel], toff[(s * 4 + w) * (P + 1) + j] relative to the slice's first entry.
+// The build runs over CHUNKS of whole slices [s_lo, s_hi) = entries [k_lo, k_hi): the scratch (sort keys and positions twice, the row of
+// every entry, the tile starts) is sized for one chunk -- 9.2 GB for config 3a in one piece made every third lowering of a process wait
+// 1.5 s in hipMalloc (LABNOTES R5).  key / idx / row_of_entry / bs are chunk-local arrays.
 template <typename RP>
-__global__ void __launch_bounds__(256) ctile_keys_kernel(int S, const int32_t *__restrict__ srow, const RP *__restrict__ rowptr,
-                                                          const int32_t *__restrict__ col, int shift, int pbits, uint64_t *key, uint32_t *idx) {
-    for (int s = blockIdx.x; s < S; s += gridDim.x) {
+__global__ void __launch_bounds__(256) ctile_keys_kernel(int s_lo, int s_hi, const int32_t *__restrict__ srow, const RP *__restrict__ rowptr,
+                                                          const int32_t *__restrict__ col, int shift, int pbits, int64_t k_lo, uint64_t *key, uint32_t *idx) {
+    for (int s = s_lo + (int)blockIdx.x; s < s_hi; s += gridDim.x) {
         const uint64_t hi = (uint64_t)s << (pbits + shift);
         const uint32_t cmask = (1u << shift) - 1u;
         const RP k0 = rowptr[srow[s]], k1 = rowptr[srow[s + 1]];
         for (RP k = k0 + (RP)threadIdx.x; k < k1; k += 256) {
-            key[k] = hi | ((uint64_t)(col[k] >> shift) << shift) | ((uint32_t)col[k] & cmask);
-            idx[k] = (uint32_t)k;
+            key[(int64_t)k - k_lo] = hi | ((uint64_t)(col[k] >> shift) << shift) | ((uint32_t)col[k] & cmask);
+            idx[(int64_t)k - k_lo] = (uint32_t)k;
         }
     }
 }
-
-// entries of wavefront w's share of tile (s, j) -> toff[(s * 4 + w) * (P + 1) + j] (counts; scanned below); bs = tile starts, S x (P + 1)
-__global__ void __launch_bounds__(256) ctile_counts_kernel(int S, int P, const uint32_t *__restrict__ bs, uint32_t *toff) {
-    const int64_t total = (int64_t)S * P;
+template <typename RP>
+__global__ void __launch_bounds__(256) ctile_rows_kernel(int64_t r_lo, int64_t r_hi, const RP *__restrict__ rowptr, int64_t k_lo, int32_t *row_of_entry) {
+    for (int64_t i = r_lo + (int64_t)blockIdx.x * 256 + threadIdx.x; i < r_hi; i += (int64_t)gridDim.x * 256)
+        for (RP k = rowptr[i]; k < rowptr[i + 1]; ++k) row_of_entry[(int64_t)k - k_lo] = (int32_t)i;
+}
+// bs[(s - s_lo) * (P + 1) + j] = first sorted position with (slice, panel) >= (s, j), relative to the slice's first entry
+template <typename RP>
+__global__ void __launch_bounds__(256) ctile_bounds_kernel(int s_lo, int s_hi, int P, const uint64_t *__restrict__ key, const int32_t *__restrict__ srow,
+                                                            const RP *__restrict__ rowptr, int shift, int pbits, int64_t k_lo, uint32_t *bs) {
+    const int64_t total = (int64_t)(s_hi - s_lo) * (P + 1);
     for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
-        const int s = (int)(t / P), j = (int)(t - (int64_t)s * P);
-        const uint32_t *b = bs + (size_t)s * (P + 1) + j;
+        const int sl = (int)(t / (P + 1)), j = (int)(t - (int64_t)sl * (P + 1)), s = s_lo + sl;
+        const uint64_t want = ((uint64_t)s << (pbits + shift)) | ((uint64_t)j << shift);
+        int64_t lo = (int64_t)rowptr[srow[s]], hi = (int64_t)rowptr[srow[s + 1]];   // the slice owns the same entry range in both orders
+        const int64_t base = lo;
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (key[mid - k_lo] < want) lo = mid + 1;
+            else hi = mid;
+        }
+        bs[t] = (uint32_t)(lo - base);
+    }
+}
+
+// entries of wavefront w's share of tile (s, j) -> toff[(s * 4 + w) * (P + 1) + j] (counts; scanned below)
+__global__ void __launch_bounds__(256) ctile_counts_kernel(int s_lo, int s_hi, int P, const uint32_t *__restrict__ bs, uint32_t *toff) {
+    const int64_t total = (int64_t)(s_hi - s_lo) * P;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+        const int sl = (int)(t / P), j = (int)(t - (int64_t)sl * P), s = s_lo + sl;
+        const uint32_t *b = bs + (size_t)sl * (P + 1) + j;
         const uint32_t n0 = b[1] - b[0], G = (n0 + 63) >> 6, tail = n0 & 63;
         for (uint32_t w = 0; w < 4; ++w) {
             uint32_t ng = G > w ? (G - w + 3) >> 2 : 0, na = ng * 64;
@@ -155,9 +181,9 @@ __global__ void __launch_bounds__(256) ctile_counts_kernel(int S, int P, const u
     }
 }
 // exclusive scan of every slice's 4 x (P + 1) counts in [wavefront][panel] order (the last slot of a wavefront's row = the next one's start)
-__global__ void __launch_bounds__(64) ctile_scan_kernel(int S, int P, uint32_t *toff) {
-    const int s = blockIdx.x * 64 + threadIdx.x;
-    if (s >= S) return;
+__global__ void __launch_bounds__(64) ctile_scan_kernel(int s_lo, int s_hi, int P, uint32_t *toff) {
+    const int s = s_lo + blockIdx.x * 64 + threadIdx.x;
+    if (s >= s_hi) return;
     uint32_t *o = toff + (size_t)s * 4 * (size_t)(P + 1);
     uint32_t run = 0;
     for (int w = 0; w < 4; ++w) {
@@ -167,21 +193,21 @@ __global__ void __launch_bounds__(64) ctile_scan_kernel(int S, int P, uint32_t *
 }
 
 template <typename RP>
-__global__ void __launch_bounds__(256) ctile_emit_kernel(int64_t nnz, int P, const uint64_t *__restrict__ key, const uint32_t *__restrict__ idx,
+__global__ void __launch_bounds__(256) ctile_emit_kernel(int64_t k_lo, int64_t n, int s_lo, int P, const uint64_t *__restrict__ key, const uint32_t *__restrict__ idx,
                                                           const int32_t *__restrict__ srow, const RP *__restrict__ rowptr, const int32_t *__restrict__ col,
                                                           const double *__restrict__ val, const int32_t *__restrict__ row_of_entry,
                                                           const uint32_t *__restrict__ bs, const uint32_t *__restrict__ toff, int shift, int pbits,
                                                           uint32_t *tidx, double *tval) {
     const uint32_t cmask = (1u << shift) - 1u;
-    for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < nnz; o += (int64_t)gridDim.x * 256) {
+    for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < n; o += (int64_t)gridDim.x * 256) {
         const uint64_t kk = key[o];
         const uint32_t k = idx[o];
         const int s = (int)(kk >> (pbits + shift));
         const int j = (int)((kk >> shift) & (((uint64_t)1 << pbits) - 1));
         const int64_t base = (int64_t)rowptr[srow[s]];
-        const uint32_t t = (uint32_t)(o - base) - bs[(size_t)s * (P + 1) + j], g = t >> 6, w = g & 3;
+        const uint32_t t = (uint32_t)(o + k_lo - base) - bs[(size_t)(s - s_lo) * (P + 1) + j], g = t >> 6, w = g & 3;
         const int64_t dst = base + toff[((size_t)s * 4 + w) * (size_t)(P + 1) + (size_t)j] + ((g >> 2) << 6) + (t & 63);
-        tidx[dst] = ((uint32_t)(row_of_entry[k] - srow[s]) << shift) | ((uint32_t)col[k] & cmask);
+        tidx[dst] = ((uint32_t)(row_of_entry[(int64_t)k - k_lo] - srow[s]) << shift) | ((uint32_t)col[k] & cmask);
         tval[dst] = val[k];
     }
 }
@@ -276,10 +302,10 @@ int build_tiles_device(sla_csr *A, const std::vector<int32_t> &srow, int shift, 
 }
 
 // The CU-wide layout of sla_spmv_ctiles.hip from A's canonical device arrays (same contract as build_tiles_device).
-int build_ctiles_device(sla_csr *A, const std::vector<int32_t> &srow, int shift, int64_t P, bool *done) {
+int build_ctiles_device(sla_csr *A, const std::vector<int32_t> &srow, int shift, int64_t P, const int64_t *rowptr_host, bool *done) {
     *done = false;
     sla_ctx *c = A->ctx;
-    const int64_t nnz = A->nnz, rows = A->rows, S = (int64_t)srow.size() - 1;
+    const int64_t nnz = A->nnz, S = (int64_t)srow.size() - 1;
     if (!A->d_col || !A->d_val || !A->d_rowptr || nnz <= 0 || nnz >= ((int64_t)1 << 31) || S <= 0) return SLA_OK;
     hipStream_t st = stream_of(c);
     static const bool dbg = getenv("SLA_DEBUG_LOWER") != nullptr;
@@ -291,7 +317,20 @@ int build_ctiles_device(sla_csr *A, const std::vector<int32_t> &srow, int shift,
         fprintf(stderr, "[sla] lowering:     . [cu tiles] %-28s %7.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
         t_last = now;
     };
-    struct FreeLap { decltype(lap) &l; ~FreeLap() { l("(scope exit: after the frees)"); } };
+    // chunks of whole slices holding <= ~2^26 entries each (one slice at least)
+    int64_t chunk_target = (int64_t)1 << 26;
+    if (const char *ev = getenv("SLA_TILE_BUILD_CHUNK")) chunk_target = std::max<int64_t>(1, atoll(ev));   // (test hook: many chunks on small matrices)
+    std::vector<int32_t> cs{0};                       // chunk c = slices [cs[c], cs[c + 1])
+    int64_t nmax = 0, smax = 0;
+    for (int64_t s = 0; s < S;) {
+        const int64_t k_lo = rowptr_host[srow[(size_t)s]];
+        int64_t e = s + 1;
+        while (e < S && rowptr_host[srow[(size_t)e + 1]] - k_lo <= chunk_target) ++e;
+        nmax = std::max(nmax, rowptr_host[srow[(size_t)e]] - k_lo);
+        smax = std::max(smax, e - s);
+        cs.push_back((int32_t)e);
+        s = e;
+    }
     DevBuf d_srow, d_key, d_key2, d_idx, d_idx2, d_rows, d_tmp, d_bs;
     auto launch_ok = [&]() { return hipGetLastError() == hipSuccess; };
     const int pbits = bits_for((uint64_t)P), sbits = bits_for((uint64_t)S);
@@ -300,16 +339,16 @@ int build_ctiles_device(sla_csr *A, const std::vector<int32_t> &srow, int shift,
     const size_t ntoff = (size_t)S * 4 * (size_t)(P + 1);
     hipError_t e = d_srow.alloc(sizeof(int32_t) * srow.size());
     if (e == hipSuccess) e = hipMemcpyAsync(d_srow.p, srow.data(), sizeof(int32_t) * srow.size(), hipMemcpyHostToDevice, st);
-    if (e == hipSuccess) e = d_key.alloc(8 * (size_t)nnz);
-    if (e == hipSuccess) e = d_key2.alloc(8 * (size_t)nnz);
-    if (e == hipSuccess) e = d_idx.alloc(4 * (size_t)nnz);
-    if (e == hipSuccess) e = d_idx2.alloc(4 * (size_t)nnz);
-    if (e == hipSuccess) e = d_rows.alloc(4 * (size_t)nnz);
-    if (e == hipSuccess) e = d_bs.alloc(4 * ((size_t)S * (P + 1) + 8));
+    if (e == hipSuccess) e = d_key.alloc(8 * (size_t)nmax);
+    if (e == hipSuccess) e = d_key2.alloc(8 * (size_t)nmax);
+    if (e == hipSuccess) e = d_idx.alloc(4 * (size_t)nmax);
+    if (e == hipSuccess) e = d_idx2.alloc(4 * (size_t)nmax);
+    if (e == hipSuccess) e = d_rows.alloc(4 * (size_t)nmax);
+    if (e == hipSuccess) e = d_bs.alloc(4 * ((size_t)smax * (P + 1) + 8));
     size_t tmp_bytes = 0;
     if (e == hipSuccess)
         e = rocprim::radix_sort_pairs(nullptr, tmp_bytes, d_key.as<uint64_t>(), d_key2.as<uint64_t>(), d_idx.as<uint32_t>(), d_idx2.as<uint32_t>(),
-                                      (size_t)nnz, 0, (unsigned)keybits, st);
+                                      (size_t)nmax, 0, (unsigned)keybits, st);
     if (e == hipSuccess) e = d_tmp.alloc(tmp_bytes);
     if (e != hipSuccess) { (void)hipGetLastError(); return SLA_OK; }   // (no device memory for the scratch: the host path may still work)
     lap("scratch allocations");
@@ -326,33 +365,38 @@ int build_ctiles_device(sla_csr *A, const std::vector<int32_t> &srow, int shift,
     if (e != hipSuccess) return give_up();
     lap("tile array allocations");
     const int grid = 4096;
-    const unsigned gs = (unsigned)std::min<int64_t>(S, 65535);
-    const unsigned gt = (unsigned)std::min<int64_t>(((int64_t)S * (P + 1) + 255) / 256, 65535);
-    if (A->rp64) {
-        hipLaunchKernelGGL((ctile_keys_kernel<int64_t>), dim3(gs), dim3(256), 0, st, (int)S, d_srow.as<int32_t>(), (const int64_t *)A->d_rowptr, A->d_col, shift, pbits, d_key.as<uint64_t>(), d_idx.as<uint32_t>());
-        hipLaunchKernelGGL((tile_rows_kernel<int64_t>), dim3(grid), dim3(256), 0, st, rows, (const int64_t *)A->d_rowptr, d_rows.as<int32_t>());
-    } else {
-        hipLaunchKernelGGL((ctile_keys_kernel<int32_t>), dim3(gs), dim3(256), 0, st, (int)S, d_srow.as<int32_t>(), (const int32_t *)A->d_rowptr, A->d_col, shift, pbits, d_key.as<uint64_t>(), d_idx.as<uint32_t>());
-        hipLaunchKernelGGL((tile_rows_kernel<int32_t>), dim3(grid), dim3(256), 0, st, rows, (const int32_t *)A->d_rowptr, d_rows.as<int32_t>());
+    for (size_t ch = 0; ch + 1 < cs.size(); ++ch) {
+        const int s_lo = cs[ch], s_hi = cs[ch + 1];
+        const int64_t r_lo = srow[(size_t)s_lo], r_hi = srow[(size_t)s_hi], k_lo = rowptr_host[r_lo], n = rowptr_host[r_hi] - k_lo;
+        if (n <= 0) {   // slices without entries: their offset rows are all zero
+            SLA_HIP_TRY(hipMemsetAsync(A->d_tloff + (size_t)s_lo * 4 * (size_t)(P + 1), 0, sizeof(uint32_t) * (size_t)(s_hi - s_lo) * 4 * (size_t)(P + 1), st));
+            continue;
+        }
+        const unsigned gs = (unsigned)std::min<int64_t>(s_hi - s_lo, 65535);
+        const unsigned gt = (unsigned)std::min<int64_t>(((int64_t)(s_hi - s_lo) * (P + 1) + 255) / 256, 65535);
+        if (A->rp64) {
+            hipLaunchKernelGGL((ctile_keys_kernel<int64_t>), dim3(gs), dim3(256), 0, st, s_lo, s_hi, d_srow.as<int32_t>(), (const int64_t *)A->d_rowptr, A->d_col, shift, pbits, k_lo, d_key.as<uint64_t>(), d_idx.as<uint32_t>());
+            hipLaunchKernelGGL((ctile_rows_kernel<int64_t>), dim3(grid), dim3(256), 0, st, r_lo, r_hi, (const int64_t *)A->d_rowptr, k_lo, d_rows.as<int32_t>());
+        } else {
+            hipLaunchKernelGGL((ctile_keys_kernel<int32_t>), dim3(gs), dim3(256), 0, st, s_lo, s_hi, d_srow.as<int32_t>(), (const int32_t *)A->d_rowptr, A->d_col, shift, pbits, k_lo, d_key.as<uint64_t>(), d_idx.as<uint32_t>());
+            hipLaunchKernelGGL((ctile_rows_kernel<int32_t>), dim3(grid), dim3(256), 0, st, r_lo, r_hi, (const int32_t *)A->d_rowptr, k_lo, d_rows.as<int32_t>());
+        }
+        if (!launch_ok()) return give_up();
+        e = rocprim::radix_sort_pairs(d_tmp.p, tmp_bytes, d_key.as<uint64_t>(), d_key2.as<uint64_t>(), d_idx.as<uint32_t>(), d_idx2.as<uint32_t>(), (size_t)n, 0,
+                                      (unsigned)keybits, st);
+        if (e != hipSuccess) return give_up();
+        if (A->rp64) hipLaunchKernelGGL((ctile_bounds_kernel<int64_t>), dim3(gt), dim3(256), 0, st, s_lo, s_hi, (int)P, d_key2.as<uint64_t>(), d_srow.as<int32_t>(), (const int64_t *)A->d_rowptr, shift, pbits, k_lo, d_bs.as<uint32_t>());
+        else hipLaunchKernelGGL((ctile_bounds_kernel<int32_t>), dim3(gt), dim3(256), 0, st, s_lo, s_hi, (int)P, d_key2.as<uint64_t>(), d_srow.as<int32_t>(), (const int32_t *)A->d_rowptr, shift, pbits, k_lo, d_bs.as<uint32_t>());
+        hipLaunchKernelGGL(ctile_counts_kernel, dim3(gt), dim3(256), 0, st, s_lo, s_hi, (int)P, d_bs.as<uint32_t>(), A->d_tloff);
+        hipLaunchKernelGGL(ctile_scan_kernel, dim3((unsigned)((s_hi - s_lo + 63) / 64)), dim3(64), 0, st, s_lo, s_hi, (int)P, A->d_tloff);
+        if (A->rp64)
+            hipLaunchKernelGGL((ctile_emit_kernel<int64_t>), dim3(grid), dim3(256), 0, st, k_lo, n, s_lo, (int)P, d_key2.as<uint64_t>(), d_idx2.as<uint32_t>(), d_srow.as<int32_t>(), (const int64_t *)A->d_rowptr, A->d_col, A->d_val, d_rows.as<int32_t>(), d_bs.as<uint32_t>(), A->d_tloff, shift, pbits, A->d_tlidx, A->d_tlval);
+        else
+            hipLaunchKernelGGL((ctile_emit_kernel<int32_t>), dim3(grid), dim3(256), 0, st, k_lo, n, s_lo, (int)P, d_key2.as<uint64_t>(), d_idx2.as<uint32_t>(), d_srow.as<int32_t>(), (const int32_t *)A->d_rowptr, A->d_col, A->d_val, d_rows.as<int32_t>(), d_bs.as<uint32_t>(), A->d_tloff, shift, pbits, A->d_tlidx, A->d_tlval);
+        if (!launch_ok()) return give_up();
     }
-    if (!launch_ok()) return give_up();
-    lap("keys + rows");
-    e = rocprim::radix_sort_pairs(d_tmp.p, tmp_bytes, d_key.as<uint64_t>(), d_key2.as<uint64_t>(), d_idx.as<uint32_t>(), d_idx2.as<uint32_t>(), (size_t)nnz, 0,
-                                  (unsigned)keybits, st);
-    if (e != hipSuccess) return give_up();
-    lap("radix sort");
-    // tile starts: the wavefront-private form's offsets kernel with no layer field (lbits = 0)
-    if (A->rp64) hipLaunchKernelGGL((tile_offsets_kernel<int64_t>), dim3(gt), dim3(256), 0, st, (int)S, (int)P, nnz, d_key2.as<uint64_t>(), d_srow.as<int32_t>(), (const int64_t *)A->d_rowptr, shift, 0, pbits, d_bs.as<uint32_t>());
-    else hipLaunchKernelGGL((tile_offsets_kernel<int32_t>), dim3(gt), dim3(256), 0, st, (int)S, (int)P, nnz, d_key2.as<uint64_t>(), d_srow.as<int32_t>(), (const int32_t *)A->d_rowptr, shift, 0, pbits, d_bs.as<uint32_t>());
-    hipLaunchKernelGGL(ctile_counts_kernel, dim3(gt), dim3(256), 0, st, (int)S, (int)P, d_bs.as<uint32_t>(), A->d_tloff);
-    hipLaunchKernelGGL(ctile_scan_kernel, dim3((unsigned)((S + 63) / 64)), dim3(64), 0, st, (int)S, (int)P, A->d_tloff);
-    if (A->rp64)
-        hipLaunchKernelGGL((ctile_emit_kernel<int64_t>), dim3(grid), dim3(256), 0, st, nnz, (int)P, d_key2.as<uint64_t>(), d_idx2.as<uint32_t>(), d_srow.as<int32_t>(), (const int64_t *)A->d_rowptr, A->d_col, A->d_val, d_rows.as<int32_t>(), d_bs.as<uint32_t>(), A->d_tloff, shift, pbits, A->d_tlidx, A->d_tlval);
-    else
-        hipLaunchKernelGGL((ctile_emit_kernel<int32_t>), dim3(grid), dim3(256), 0, st, nnz, (int)P, d_key2.as<uint64_t>(), d_idx2.as<uint32_t>(), d_srow.as<int32_t>(), (const int32_t *)A->d_rowptr, A->d_col, A->d_val, d_rows.as<int32_t>(), d_bs.as<uint32_t>(), A->d_tloff, shift, pbits, A->d_tlidx, A->d_tlval);
-    if (!launch_ok()) return give_up();
     SLA_HIP_TRY(hipStreamSynchronize(st));
-    lap("offsets + emit");
+    lap("keys, sort, offsets, emit (all chunks)");
     *done = true;
     return SLA_OK;
 }

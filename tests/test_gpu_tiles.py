@@ -92,6 +92,40 @@ def test_cu_wide_tiles_relaxed_order_within_the_bound(sla, name):
         ctx.close()
 
 
+def test_cu_wide_tile_builder_in_chunks_gives_the_same_layout(sla):
+    """The device builder sorts chunks of whole slices (bounded scratch: csrc/sla_tiles_build.hip); SLA_TILE_BUILD_CHUNK (entries per
+    chunk, a test hook read at every build) cuts a test-sized matrix into many chunks -- one slice each, a few slices each, all in one --
+    and the layout must not depend on it: rows of <= 2 entries are bit-exact in the relaxed kernel, all rows are within the bound, and
+    the host builder (no chunks) agrees."""
+    import os
+    dims, (rp, ci, va) = _rand_rows(40000, 300000, lambda i, r: (1, 2, 2, 9, 30)[i % 5], 12)
+    m, n = dims
+    x = np.random.default_rng(4).standard_normal(n)
+    want = orc.spmv(orc.Csr(m, n, rp, ci, va), x)
+    lens = np.diff(rp)
+    bound = lens * EPS * orc.spmv(orc.Csr(m, n, rp, ci, np.abs(va)), np.abs(x)) + 1e-300
+    old = os.environ.get("SLA_TILE_BUILD_CHUNK")
+    try:
+        for chunk, dev in (("1", 2), ("3000", 2), ("50000", 2), (None, 2), (None, 0)):
+            if chunk is None:
+                os.environ.pop("SLA_TILE_BUILD_CHUNK", None)
+            else:
+                os.environ["SLA_TILE_BUILD_CHUNK"] = chunk
+            ctx = sla.Context(0).set_options(tile_shift=12, lpanel=0, lflat=0, tiles_device=dev, tile_relaxed=1)
+            A = sla.fromCSR(dims, rp, ci, va, ctx)
+            assert "cu_slices=1" in A.kernel_info(), A.kernel_info()
+            y = sla.matVec(A, sla.fromVector(x, ctx)).toDenseListSV()
+            assert np.all(np.abs(y - want) <= bound), (chunk, dev)
+            assert np.array_equal(y[lens <= 2], want[lens <= 2]), (chunk, dev)
+            del A
+            ctx.close()
+    finally:
+        if old is None:
+            os.environ.pop("SLA_TILE_BUILD_CHUNK", None)
+        else:
+            os.environ["SLA_TILE_BUILD_CHUNK"] = old
+
+
 @pytest.mark.parametrize("name", list(CASES))
 def test_tiles_match_the_oracle(sla, name):
     build, expect_tiles = CASES[name]
