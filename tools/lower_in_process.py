@@ -44,6 +44,10 @@ cb = bench.cpu_baseline(dims, rp, ci, va, b, 4.0)
 lower("after the CPU baseline (oracle, 1 thread + OpenMP)", dm3, rp3, ci3, va3)
 g = bench.side_block(desc, dims, rp, ci, va, {"wdia": 0, "vdict": 0, "diag": 0}, 20, 5)
 lower("after the general_csr block", dm3, rp3, ci3, va3)
+e2e = bench.end_to_end_block(ctx, A, dims, rp, ci, va, b, 0.05, 4500.0, True)
+lower("after the end_to_end block (cold linSolve0 + from_coo)", dm3, rp3, ci3, va3)
+probes = [ctx.stream_probe(r_, w_, dims[0], 20) for r_, w_ in ((8, 0), (5, 3), (2, 1))]
+lower("after the stream probes", dm3, rp3, ci3, va3)
 del st, A
 ctx.close()
 rp = ci = va = None
