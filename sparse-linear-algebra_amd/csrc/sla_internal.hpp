@@ -258,6 +258,10 @@ struct sla_ctx {
     int tile_relaxed = 1;            // the tile form of irregular matrices: 1 = CU-wide slices (spmv_ctile_kernel, round 5: column-sorted gathers that share x lines, row sums by LDS
                                      // atomics in relaxed order -- within nnz_i eps sum|a_ij x_j| of the reference's fold, not reproducible bit for bit), 0 = wavefront-private slices
                                      // (spmv_tile_kernel, rounds 2-4: the reference's left fold bit for bit; 18 % slower on config 3a, 2.2 x on power-law rows)
+    int tri_syncfree = 0;            // triLowerSolve / triUpperSolve as one persistent launch whose rows poll x for the rows they read (sla_tri.hip), 0: one launch per dependency level
+    int tri_grid = 256;              // ... its workgroups (co-resident: <= 8 per CU)
+    long tri_fallbacks = 0;          // solves that left the persistent kernel for the level schedule (sla_ctx_get_option "tri_fallbacks")
+    int tri_spin = 200000;           // ... polls without progress after which a lane gives up and the host runs the level schedule instead
     int tile_depth = 0;              // CU-wide tile kernel, 64-entry groups per chunk: 0 by the tiles' density (20 below 4 entries per x line, else 12), 1 always 12, 2 always 20 (A/B)
     int tile_prefetch = 0;           // x-panel prefetch distance of spmv_tile_kernel in visit steps (0: demand misses only; measured: never a gain)
     int tile_poll = 1;               // 1: pacing slots polled one step ahead, 0: dependent poll in front of every tile (rounds 2-3)
@@ -831,6 +835,7 @@ int wave_grid(const sla_csr *A);
 bool wave_plain(const sla_csr *A);   // sla_spmv.hip: does a plain (#>) on A end up on spmv_wave_kernel?
 int launch_spmv_wave(const sla_csr *A, int epi, const SpmvArgs<int32_t> &a, int grid);
 int tiles_grid(const sla_csr *A);
+int launch_tri_syncfree(const sla_csr *T, const sla_tri_plan *p, const double *b, double *x, int *d_fail);   // sla_tri.hip
 int launch_col_slack_fill(sla_ctx *c, int32_t *d_col, int64_t nnz);   // sla_spmv_wave.hip: the slack behind the column array repeats the last column
 int launch_spmv_ctiles(const sla_csr *A, const SpmvLaunch &l);   // sla_spmv_ctiles.hip (CU-wide slices)
 int ctiles_grid(const sla_csr *A);

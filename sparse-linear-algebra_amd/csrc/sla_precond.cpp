@@ -164,6 +164,16 @@ int sla_tri_solve(sla_csr_t T, int upper, sla_vec_t b, sla_vec_t x, int64_t *bad
         SLA_TRY(tri_plan_build(T, upper, bad_row));
         sla_tri_plan *p = T->tri[upper];
         if (T->m == 0) return SLA_OK;
+        if (c->tri_syncfree) {   // one persistent launch; a lane that waited too long says so and the level schedule below runs instead
+            int *d_fail = (int *)(c->d_result + 1600);
+            SLA_TRY(launch_tri_syncfree(T, p, b->d, x->d, d_fail));
+            SLA_TRY(launch_tri_sparsify(c, T->m, x->d));
+            int h_fail = 0;
+            SLA_HIP_TRY(hipMemcpyAsync(&h_fail, d_fail, sizeof(int), hipMemcpyDeviceToHost, stream_of(c)));
+            SLA_HIP_TRY(hipStreamSynchronize(stream_of(c)));
+            if (!h_fail) return SLA_OK;
+            T->ctx->tri_fallbacks++;
+        }
         if (!p->graph || p->gb != b->d || p->gx != x->d) {
             // capture the level launches once per (b, x) buffer pair; later solves with the same buffers replay the graph
             if (p->graph) { (void)hipGraphExecDestroy(p->graph); p->graph = nullptr; }

@@ -73,6 +73,21 @@ def test_triangular_solve_is_the_reference_substitution(sla, kind, upper):
     rc, want2, _ = (orc.tri_upper_solve if upper else orc.tri_lower_solve)(A, b2)
     x2 = (sla.triUpperSolve if upper else sla.triLowerSolve)(T, sla.DeviceVector(T.ctx, n, b2)).to_host()
     assert np.array_equal(x2, want2)
+    # round 5: the same substitution as ONE persistent launch whose rows poll x for the rows they read (option tri_syncfree,
+    # csrc/sla_tri.hip): the same bits at every grid size -- the chain (a dependency between neighbouring LANES of one wavefront in every
+    # slot) included -- and a spin limit of one poll makes lanes give up: the level schedule then runs instead, same bits again
+    ctx = sla.Context(0)
+    T2 = sla.fromCSR(dims, rp, ci, va, ctx)
+    bv2 = sla.DeviceVector(ctx, n, b)
+    for grid, spin in ((1, 200000), (7, 200000), (256, 200000), (256, 1)):
+        ctx.set_options(tri_syncfree=1, tri_grid=grid, tri_spin=spin)
+        before = int(ctx.get_option("tri_fallbacks"))
+        x3 = (sla.triUpperSolve if upper else sla.triLowerSolve)(T2, bv2).to_host()
+        assert np.array_equal(x3.view(np.uint64), want.view(np.uint64)), (kind, upper, grid, spin)
+        fell_back = int(ctx.get_option("tri_fallbacks")) - before
+        assert fell_back == (1 if spin == 1 and lv > 1 else 0) or spin == 1, (kind, grid, spin, fell_back)
+    del T2, bv2
+    ctx.close()
 
 
 def test_needs_pivoting_and_sparsify(sla):

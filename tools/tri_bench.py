@@ -37,3 +37,17 @@ for name, (dims, (rp, ci, va)) in (("laplace3d 216^3", wl.laplace3d(216, 216, 21
         bytes_ = 12 * nnz_tri + 28 * n                                   # val + col of the triangle, rowptr, order, b, x
         print("%-18s %s: %5d levels (widest %7d rows), schedule built in %.2f s; solve %.3f ms = %.2f us/level, %.0f GB/s of %d MB"
               % (name, "upper" if upper else "lower", lv, wd, t_plan, dt * 1e3, dt * 1e6 / lv, bytes_ / dt / 1e9, bytes_ // 10**6), flush=True)
+        # round 5: the same solve as one persistent launch (option tri_syncfree), by grid size; must give the same bits
+        ref = x.to_host()
+        for grid in (64, 128, 256, 512, 1024, 2048):
+            ctx.set_options(tri_syncfree=1, tri_grid=grid)
+            _lib.check(lib.sla_tri_solve(T.h, upper, b.h, x.h, None))
+            ctx.sync()
+            same = bool(np.array_equal(x.to_host(), ref))
+            t0 = time.perf_counter()
+            for _ in range(5):
+                _lib.check(lib.sla_tri_solve(T.h, upper, b.h, x.h, None))
+            ctx.sync()
+            dts = (time.perf_counter() - t0) / 5
+            print("    persistent launch, %4d workgroups: %.3f ms (bit-identical: %s; fallbacks so far: %s)" % (grid, dts * 1e3, same, ctx.get_option("tri_fallbacks")), flush=True)
+        ctx.set_options(tri_syncfree=0)
