@@ -118,16 +118,7 @@ int build_tiles(sla_csr *A, int64_t n, int64_t rows, const int64_t *rowptr, cons
     // round 5: CU-wide slices (sla_spmv_ctiles.hip) -- one slice of kCtRows rows per WORKGROUP, its row sums shared by the four wavefronts
     const bool cu = c->tile_relaxed != 0;
     const int64_t slice_rows = cu ? kCtRows : kTileRows;
-    int row_bits = 0;
-    while (((int64_t)1 << row_bits) < slice_rows) ++row_bits;
-    // panel width: 2^17 columns (1 MiB of x) at 10 M rows, 2^16 below ~6 M (measured: 7-8 % faster at 0.5 / 1 / 3 M rows, 3-15 % slower at 10 M)
-    // (CU-wide slices, round 5: 2^17 at every size -- 100 / 200 per row at 1 M rows 0.49 -> 0.51 / 0.53 -> 0.56 of peak against 2^16, power-law rows equal)
-    const int want = c->tile_shift > 0 ? c->tile_shift : cu ? 17 : (n < 6000000 ? 16 : 17);
-    const int shift = std::max(10, std::min((cu ? 32 : 31) - row_bits, want));   // (layer flag, slice row, panel column) packed in 32 bits (CU-wide slices: no flag, 15 + 17 bits)
-    const int64_t W = (int64_t)1 << shift;
-    if (n <= 2 * W || (c->tile_shift <= 0 && !force && n <= ((int64_t)1 << 18))) return SLA_OK;   // x (nearly) fits the L2 already
-    const int64_t P = (n + W - 1) / W;
-    if (P > 16384) return skip("more than 16384 panels");
+    // (the slices come first: they do not depend on the panel width, and the widest one decides how many bits a local row takes)
     // slices: whole rounds of the persistent grid (kTileBlocksPerCu workgroup(s) of 4 wavefronts per CU)
     const int64_t waves = cu ? (int64_t)c->n_cu : (int64_t)kTileBlocksPerCu * c->n_cu * kTileWaves;   // (CU-wide: slice owners = workgroups)
     const int64_t rounds = std::max<int64_t>(1, (rows + slice_rows * waves - 1) / (slice_rows * waves));
@@ -150,6 +141,23 @@ int build_tiles(sla_csr *A, int64_t n, int64_t rows, const int64_t *rowptr, cons
             r = e;
         }
     }
+    int row_bits = 0;
+    {
+        int64_t widest = 1;
+        for (size_t i = 0; i + 1 < srow.size(); ++i) widest = std::max<int64_t>(widest, srow[i + 1] - srow[i]);
+        // CU-wide slices pack (local row, panel column) in 32 bits with no flag: a matrix whose slices are short (1 M rows: 3906 rows per
+        // slice = 12 bits) may take panels wider than 2^17 columns (option tile_shift); the wavefront-private layout keeps its fixed 13 bits
+        const int64_t span = cu ? widest : slice_rows;
+        while (((int64_t)1 << row_bits) < span) ++row_bits;
+    }
+    // panel width: 2^17 columns (1 MiB of x) at 10 M rows, 2^16 below ~6 M (measured: 7-8 % faster at 0.5 / 1 / 3 M rows, 3-15 % slower at 10 M)
+    // (CU-wide slices, round 5: 2^17 at every size -- 100 / 200 per row at 1 M rows 0.49 -> 0.51 / 0.53 -> 0.56 of peak against 2^16, power-law rows equal)
+    const int want = c->tile_shift > 0 ? c->tile_shift : cu ? 17 : (n < 6000000 ? 16 : 17);
+    const int shift = std::max(10, std::min((cu ? 32 : 31) - row_bits, want));   // (layer flag, slice row, panel column) packed in 32 bits (CU-wide slices: no flag, 15 + 17 bits)
+    const int64_t W = (int64_t)1 << shift;
+    if (n <= 2 * W || (c->tile_shift <= 0 && !force && n <= ((int64_t)1 << 18))) return SLA_OK;   // x (nearly) fits the L2 already
+    const int64_t P = (n + W - 1) / W;
+    if (P > 16384) return skip("more than 16384 panels");
     const int64_t S = (int64_t)srow.size() - 1;
     const int64_t ntoff = cu ? S * kCtWaves * (P + 1) : S * (P + 1);
     if (ntoff > ((int64_t)1 << 31) || ntoff * 4 > nnz * 12 / 2) return skip("offset table larger than half the matrix");   // offset table must stay a fraction of the matrix
