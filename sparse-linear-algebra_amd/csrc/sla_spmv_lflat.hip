@@ -201,9 +201,12 @@ bool lflat_candidate(const sla_csr *A, int64_t n, int64_t rows) {
     const int64_t P = (n + kLfW - 1) / kLfW;
     const int64_t nseg = P * rows;
     // mean segment length: from lf_min_seg10 / 10 (1.5: below that the partials cost more than the entries) up to the LDS-panel form's threshold.
-    // Round 5: where the CU-wide tile form applies (relaxed order allowed, x beyond the L2) it wins up to segments of ~6 entries
-    // (profiles/r05_form_tournament.txt: 100 per row 0.36 -> 0.54 of peak, 200 per row 0.61 -> 0.65; 500 per row, segments of 8: 0.755 here against 0.74)
-    const int64_t min10 = (c->tiles && c->tile_relaxed && c->lflat < 2 && n > ((int64_t)1 << 18)) ? std::max<int64_t>(c->lf_min_seg10, 60) : c->lf_min_seg10;
+    // Round 5: where the CU-wide tile form applies (relaxed order allowed, x beyond the L2) it takes these matrices instead: 100 per row
+    // 0.36 -> 0.52 of peak, 200 per row 0.61 -> 0.65; at 500 per row the two are within 3 % of each other at 1 M rows (0.754 here, 0.734
+    // there) and the tile form is 8 % ahead at 600 k rows (profiles/r05_form_tournament.txt, tests/test_gpu_form_choice.py) -- one form
+    // less in the default ladder.  This form stays for n <= 2^18 columns, for tile_relaxed = 0 / tiles = 0 and when forced (lflat = 2).
+    if (c->tiles && c->tile_relaxed && c->lflat < 2 && n > ((int64_t)1 << 18)) return false;
+    const int64_t min10 = c->lf_min_seg10;
     return !(P < 3 || P > 4096 || nseg >= ((int64_t)1 << 31) || nnz * 10 < min10 * nseg || (c->lflat < 2 && nnz >= (int64_t)c->lp_min_seg * nseg));
 }
 
