@@ -505,8 +505,9 @@ const IntKnob kIntKnobs[] = {
     {"tile_prefetch", &sla_ctx::tile_prefetch, 0, 16},
     {"tile_relaxed", &sla_ctx::tile_relaxed, 0, 1},
     {"tile_depth", &sla_ctx::tile_depth, 0, 2},
-    {"tri_syncfree", &sla_ctx::tri_syncfree, 0, 1},
-    {"tri_grid", &sla_ctx::tri_grid, 1, 2048},
+    {"tri_syncfree", &sla_ctx::tri_syncfree, 0, 3},
+    {"tri_block_rows", &sla_ctx::tri_block_rows, 8, kTriBlockRows},
+    {"tri_grid", &sla_ctx::tri_grid, 0, 4096},
     {"tri_spin", &sla_ctx::tri_spin, 1, 1 << 30},
     {"canon_device", &sla_ctx::canon_device, 0, 2},
     {"canon_lazy", &sla_ctx::canon_lazy, 0, 1},
@@ -580,6 +581,7 @@ static std::string ctx_option_value(const sla_ctx *c, const std::string &name, b
     if (name == "panel_cols") return std::to_string(c->panel_cols);
     if (name == "device_coo_min") return std::to_string(c->device_coo_min);
     if (name == "x_exchange") return c->x_exchange == 1 ? "allgather" : c->x_exchange == 2 ? "window" : "auto";
+    if (name == "tri_mode_used") return std::to_string(c->tri_mode_used);
     if (name == "tri_fallbacks") return std::to_string(c->tri_fallbacks);   // (read-only: solves that left the persistent triangular kernel)
     *known = false;
     return "";

@@ -111,6 +111,7 @@ constexpr int kVecGridMax = 1024;    // grid cap of the streaming BLAS-1 kernels
 constexpr int kSpmvGridMax = 2048;   // persistent grid cap of the SpMV kernels
 constexpr int kArnGridMax = 1024;    // grid cap (= partials per column) of the Arnoldi kernels
 constexpr size_t kArraySlack = 64;              // zeroed bytes behind every lowered matrix array (clamped whole-block loads of the pipelined stream kernel)
+constexpr int kTriBlockRows = 16384;            // rows of one block of the block-local triangular solve (128 KiB of LDS)
 constexpr size_t kGuardBytes = 256;             // readable slack on both sides of every buffer an SpMV gathers from
 constexpr size_t kHaloBytes = (size_t)4 << 20;  // the same for vectors of sharded contexts: room for the neighbours' halo planes
 constexpr int kMaxKrylov = 64;       // max Arnoldi basis columns handled by the fused GS kernels
@@ -258,8 +259,10 @@ struct sla_ctx {
     int tile_relaxed = 1;            // the tile form of irregular matrices: 1 = CU-wide slices (spmv_ctile_kernel, round 5: column-sorted gathers that share x lines, row sums by LDS
                                      // atomics in relaxed order -- within nnz_i eps sum|a_ij x_j| of the reference's fold, not reproducible bit for bit), 0 = wavefront-private slices
                                      // (spmv_tile_kernel, rounds 2-4: the reference's left fold bit for bit; 18 % slower on config 3a, 2.2 x on power-law rows)
-    int tri_syncfree = 0;            // triLowerSolve / triUpperSolve as one persistent launch whose rows poll x for the rows they read (sla_tri.hip), 0: one launch per dependency level
-    int tri_grid = 256;              // ... its workgroups (co-resident: <= 8 per CU)
+    int tri_block_rows = 16384;      // tri_syncfree = 2: rows per block (<= kTriBlockRows: the block's x sits in LDS; small values are for the tests)
+    int tri_syncfree = 3;            // triLowerSolve / triUpperSolve: 0 one launch per dependency level, 1 one persistent launch whose rows poll x in memory, 2 the block-local persistent launch (sla_tri.hip), 3 pick 2 or 0 by the schedule's shape (sla_precond.cpp)
+    int tri_grid = 0;                // ... its workgroups (0: 256 for the row-polling kernel, as many as are co-resident for the block-local one)
+    int tri_mode_used = 0;           // what the last triangular solve ran as (sla_ctx_get_option "tri_mode_used")
     long tri_fallbacks = 0;          // solves that left the persistent kernel for the level schedule (sla_ctx_get_option "tri_fallbacks")
     int tri_spin = 200000;           // ... polls without progress after which a lane gives up and the host runs the level schedule instead
     int tile_depth = 0;              // CU-wide tile kernel, 64-entry groups per chunk: 0 by the tiles' density (20 below 4 entries per x line, else 12), 1 always 12, 2 always 20 (A/B)
@@ -345,6 +348,19 @@ struct sla_tri_plan {
     hipGraphExec_t graph = nullptr;   // the level launches captured for (gb, gx)
     const double *gb = nullptr;
     double *gx = nullptr;
+    // the block-local form (option tri_syncfree = 2, tri_blocks_kernel in sla_tri.hip): the sweep order cut into blocks of brows consecutive
+    // rows, one workgroup per block with the block's x in LDS; blocks stored in the order the workgroups take them ((block level, block)),
+    // rows of a block by (level inside the block, position); slot s: row bl_row[s], diagonal bl_diag[s], strictly-triangular entries
+    // bl_col / bl_val[bl_ptr[s] .. bl_ptr[s + 1]) in ascending column order, bl_col >= 0: x index of another block's row, < 0: ~(LDS cell =
+    // slot inside the block) of a row of the same block
+    int64_t nb = 0;
+    int32_t brows = 0;
+    bool bricks = false;              // the block order is the stencil-brick order, not the sweep's
+    double bl_cross = 0.0;            // share of the triangle's entries that read a row of another block (polled in memory)
+    int64_t *d_bl_slots = nullptr;    // [2 * p]: first slot of the p-th block taken, [2 * p + 1]: its first sweep position; [2 * nb]: n
+    int32_t *d_bl_row = nullptr, *d_bl_col = nullptr;
+    int64_t *d_bl_ptr = nullptr;
+    double *d_bl_val = nullptr, *d_bl_diag = nullptr;
 };
 
 struct sla_csr {
@@ -428,7 +444,7 @@ struct sla_csr {
     unsigned *d_tlprog = nullptr;    // per-XCD (round, panel) arrival counters of the launch in flight (panel pacing)
     size_t tlprog_bytes = 0;
     int64_t tl_maxseg = 0;           // longest (row, panel) segment = layers of the deepest tile
-    int32_t tl_dpanel = 0;           // the panel of the matrix's first entry: where the kernels' empty pipeline-drain chunks gather (always inside what this rank may read)
+    int32_t tl_dcol = 0;             // the column of the matrix's first entry: what the kernels' empty pipeline-drain chunks gather (always inside what this rank may read)
     bool tl_cu = false;              // CU-wide slices, relaxed order (sla_spmv_ctiles.hip): entries [slice][wavefront][panel], d_tloff = tl_S x 4 x (tl_P + 1)
     sla_tri_plan *tri[2] = {nullptr, nullptr};  // [0] lower, [1] upper triangle schedules (built on first use)
     // comm / compute overlap of the sharded (#>) (wave-sliced forms): the 512-row steps whose rows reference own columns only
@@ -836,6 +852,7 @@ bool wave_plain(const sla_csr *A);   // sla_spmv.hip: does a plain (#>) on A end
 int launch_spmv_wave(const sla_csr *A, int epi, const SpmvArgs<int32_t> &a, int grid);
 int tiles_grid(const sla_csr *A);
 int launch_tri_syncfree(const sla_csr *T, const sla_tri_plan *p, const double *b, double *x, int *d_fail);   // sla_tri.hip
+int launch_tri_blocks(const sla_csr *T, const sla_tri_plan *p, int upper, const double *b, double *x, int *d_fail);
 int launch_col_slack_fill(sla_ctx *c, int32_t *d_col, int64_t nnz);   // sla_spmv_wave.hip: the slack behind the column array repeats the last column
 int launch_spmv_ctiles(const sla_csr *A, const SpmvLaunch &l);   // sla_spmv_ctiles.hip (CU-wide slices)
 int ctiles_grid(const sla_csr *A);

@@ -171,7 +171,7 @@ int build_tiles(sla_csr *A, int64_t n, int64_t rows, const int64_t *rowptr, cons
         A->tl_S = (int32_t)S;
         A->tl_P = (int32_t)P;
         A->tl_shift = shift;
-        A->tl_dpanel = (int32_t)(col[rowptr[0]] >> shift);   // (nnz > 0: rows without entries in front share rowptr[0] = 0)
+        A->tl_dcol = (int32_t)col[rowptr[0]];   // (nnz > 0: rows without entries in front share rowptr[0] = 0)
         A->tl_cu = cu;
         A->use_tiles = true;
         return SLA_OK;

@@ -15,6 +15,20 @@
 using namespace sla;
 
 namespace sla {
+static void tri_blocks_free(sla_tri_plan *p) {
+    if (p->d_bl_slots) (void)hipFree(p->d_bl_slots);
+    if (p->d_bl_row) (void)hipFree(p->d_bl_row);
+    if (p->d_bl_col) (void)hipFree(p->d_bl_col);
+    if (p->d_bl_ptr) (void)hipFree(p->d_bl_ptr);
+    if (p->d_bl_val) (void)hipFree(p->d_bl_val);
+    if (p->d_bl_diag) (void)hipFree(p->d_bl_diag);
+    p->d_bl_slots = nullptr;
+    p->d_bl_row = p->d_bl_col = nullptr;
+    p->d_bl_ptr = nullptr;
+    p->d_bl_val = p->d_bl_diag = nullptr;
+    p->nb = 0;
+    p->brows = 0;
+}
 void tri_plan_free(sla_tri_plan *p) {
     if (!p) return;
     if (p->graph) (void)hipGraphExecDestroy(p->graph);
@@ -23,6 +37,7 @@ void tri_plan_free(sla_tri_plan *p) {
     if (p->d_tcol) (void)hipFree(p->d_tcol);
     if (p->d_tval) (void)hipFree(p->d_tval);
     if (p->d_tdiag) (void)hipFree(p->d_tdiag);
+    tri_blocks_free(p);
     delete p;
 }
 }  // namespace sla
@@ -139,6 +154,179 @@ static int tri_plan_build(sla_csr *T, int upper, int64_t *bad_row) {
     return SLA_OK;
 }
 
+// The block-local form of the schedule (option tri_syncfree = 2; kernel and rationale: sla_tri.hip).  q = position in the reference's
+// sweep (row q of a lower, row n - 1 - q of an upper triangle): every row reads rows of smaller q only.  The rows are laid out in a
+// BLOCK ORDER -- any order in which every row still comes after the rows it reads (checked here, row by row) -- and cut into blocks of
+// <= R consecutive positions; inside a block the rows are ordered by their level counted over the block's OWN rows, so a workgroup that
+// walks its slots in order never waits for a later slot; a block's level counts blocks the same way, and the workgroups take the blocks
+// in (level, block) order -- everything a block reads from another block sits earlier in that order.
+//
+// Block order.  What a solve costs is the longest chain of blocks times the ~5 us a value takes from one CU to another through memory.
+// In the sweep order itself a block of a 3-D stencil is a strip of ONE grid plane, and the chain crosses a block boundary per plane (216
+// at 216^3).  When the triangle's rows reach back by exactly three distances 1 < s2 < s3 with s2 | s3 (a 7-point-like stencil on an
+// s2 x s3 / s2 x . grid), the positions are re-ordered into bricks of a whole line x b lines x c planes (b ~ c, b c s2 <= R), brick after
+// brick: the chain then crosses ~ (lines / b + planes / c) boundaries.  The guess is only a guess about speed: an order that puts a row
+// before one it reads is thrown away for the sweep order.
+static int tri_blocks_build(sla_csr *T, int upper) {
+    sla_tri_plan *p = T->tri[upper];
+    const int64_t n = T->m;
+    const int64_t R = std::max<int64_t>(8, std::min<int64_t>(T->ctx->tri_block_rows, kTriBlockRows));
+    if (p->nb && p->brows == (int32_t)R) return SLA_OK;
+    tri_blocks_free(p);
+    HostCsr h;
+    SLA_TRY(export_host(T, h));
+    auto row_of = [&](int64_t q) { return upper ? n - 1 - q : q; };   // (its own inverse)
+    auto for_deps = [&](int64_t q, auto &&f) {                          // f(sweep position of a row that row_of(q) reads)
+        const int64_t i = row_of(q);
+        for (int64_t k = h.rowptr[(size_t)i]; k < h.rowptr[(size_t)i + 1]; ++k) {
+            const int64_t j = h.col[(size_t)k];
+            if (j != i && (upper ? j > i : j < i)) f(row_of(j));
+        }
+    };
+    // the distances the rows reach back by (at most a handful are kept: more than three and the order stays the sweep's)
+    int64_t dist[4] = {0, 0, 0, 0};
+    int ndist = 0;
+    for (int64_t q = 0; q < n && ndist <= 3; ++q)
+        for_deps(q, [&](int64_t qq) {
+            const int64_t d = q - qq;
+            bool known = false;
+            for (int t = 0; t < std::min(ndist, 4); ++t) known = known || dist[t] == d;
+            if (!known) { if (ndist < 4) dist[ndist] = d; ++ndist; }
+        });
+    std::vector<int32_t> ord((size_t)n), pos((size_t)n);   // block-order position -> sweep position, and back
+    std::vector<int64_t> bq{0};                             // block b = positions [bq[b], bq[b + 1])
+    bool bricks = false;
+    if (ndist == 3) {
+        std::sort(dist, dist + 3);
+        const int64_t s2 = dist[1], s3 = dist[2];
+        if (dist[0] == 1 && s2 > 1 && s3 % s2 == 0 && s3 / s2 > 1 && s2 <= R / 4) {
+            const int64_t nl = s3 / s2, per = R / s2;                       // lines per plane; lines a block may hold
+            int64_t c = std::max<int64_t>(1, (int64_t)floor(sqrt((double)per)));
+            int64_t b = std::max<int64_t>(1, per / c);
+            b = std::min(b, nl);
+            const int64_t npl = (n + s3 - 1) / s3;
+            c = std::min(c, npl);
+            int64_t at = 0;
+            for (int64_t K = 0; K < npl; K += c)
+                for (int64_t J = 0; J < nl; J += b) {
+                    for (int64_t k = K; k < std::min(npl, K + c); ++k)
+                        for (int64_t j = J; j < std::min(nl, J + b); ++j) {
+                            const int64_t q0 = k * s3 + j * s2;
+                            for (int64_t q = q0; q < std::min(n, q0 + s2); ++q) ord[(size_t)at++] = (int32_t)q;
+                        }
+                    if (at > bq.back()) bq.push_back(at);
+                }
+            bricks = at == n;
+            if (bricks) {
+                for (int64_t t = 0; t < n; ++t) pos[(size_t)ord[(size_t)t]] = (int32_t)t;
+                for (int64_t q = 0; q < n && bricks; ++q) for_deps(q, [&](int64_t qq) { bricks = bricks && pos[(size_t)qq] < pos[(size_t)q]; });
+            }
+        }
+    }
+    if (!bricks) {
+        for (int64_t q = 0; q < n; ++q) ord[(size_t)q] = pos[(size_t)q] = (int32_t)q;
+        // Cuts in the sweep order.  A block can only start once its FIRST row's dependencies are there, and the rows behind it usually
+        // hang on that row: a cut in the middle of a chain (row q reads row q - 1: a stencil line) makes the block wait for the END of
+        // the block before it -- the blocks would run one after the other.  So a cut goes where the first row of the new block reaches
+        // back FARTHEST (the start of a line, better still of a plane), searched over the second half of the positions a block may hold.
+        std::vector<int32_t> reach((size_t)n);   // q - (largest position row q reads), saturated; n for a row that reads nothing
+        for (int64_t q = 0; q < n; ++q) {
+            int64_t far = -1;
+            for_deps(q, [&](int64_t qq) { far = std::max(far, qq); });
+            reach[(size_t)q] = (int32_t)std::min<int64_t>(far < 0 ? n : q - far, std::numeric_limits<int32_t>::max());
+        }
+        bq.assign(1, 0);
+        while (bq.back() < n) {
+            const int64_t q0 = bq.back(), hi = std::min(n, q0 + R);
+            int64_t cut = hi;
+            if (hi < n) {
+                int32_t best = -1;
+                for (int64_t q = q0 + (R + 1) / 2; q <= hi; ++q)
+                    if (reach[(size_t)q] >= best) { best = reach[(size_t)q]; cut = q; }
+            }
+            bq.push_back(cut);
+        }
+    }
+    const int64_t nb = (int64_t)bq.size() - 1;
+    std::vector<int32_t> blk((size_t)n), lv((size_t)n), cell((size_t)n);   // per position: block, level inside it, slot inside it
+    for (int64_t b = 0; b < nb; ++b) std::fill(blk.begin() + bq[(size_t)b], blk.begin() + bq[(size_t)b + 1], (int32_t)b);
+    std::vector<int32_t> blevel((size_t)nb, 1), slot_pos((size_t)n);
+    std::vector<int32_t> cnt;
+    for (int64_t b = 0; b < nb; ++b) {
+        const int64_t t0 = bq[(size_t)b], t1 = bq[(size_t)b + 1];
+        int32_t maxlv = 0;
+        for (int64_t t = t0; t < t1; ++t) {
+            int32_t l = 0;
+            for_deps(ord[(size_t)t], [&](int64_t qq) {
+                const int64_t tt = pos[(size_t)qq];
+                if (tt >= t0) l = std::max(l, lv[(size_t)tt]);
+                else blevel[(size_t)b] = std::max(blevel[(size_t)b], blevel[(size_t)blk[(size_t)tt]] + 1);
+            });
+            lv[(size_t)t] = l + 1;
+            maxlv = std::max(maxlv, l + 1);
+        }
+        cnt.assign((size_t)maxlv + 2, 0);   // the block's rows by (level, position): counting sort
+        for (int64_t t = t0; t < t1; ++t) cnt[(size_t)lv[(size_t)t] + 1]++;
+        for (int32_t l = 1; l <= maxlv + 1; ++l) cnt[(size_t)l] += cnt[(size_t)l - 1];
+        for (int64_t t = t0; t < t1; ++t) {
+            const int32_t sl = cnt[(size_t)lv[(size_t)t]]++;
+            cell[(size_t)t] = sl;
+            slot_pos[(size_t)(t0 + sl)] = (int32_t)t;
+        }
+    }
+    std::vector<int64_t> taken((size_t)nb);
+    for (int64_t b = 0; b < nb; ++b) taken[(size_t)b] = b;
+    std::stable_sort(taken.begin(), taken.end(), [&](int64_t a, int64_t b) { return blevel[(size_t)a] < blevel[(size_t)b]; });
+    std::vector<int64_t> slots((size_t)(2 * nb + 2), 0), tptr((size_t)n + 1, 0);
+    std::vector<int32_t> rows((size_t)std::max<int64_t>(n, 1)), tcol;
+    std::vector<double> tval, tdiag((size_t)std::max<int64_t>(n, 1), 1.0);
+    tcol.reserve((size_t)h.col.size() / 2 + 16);
+    tval.reserve((size_t)h.col.size() / 2 + 16);
+    int64_t s = 0, ncross = 0;
+    for (int64_t pi = 0; pi < nb; ++pi) {
+        const int64_t b = taken[(size_t)pi], t0 = bq[(size_t)b], t1 = bq[(size_t)b + 1];
+        slots[(size_t)(2 * pi)] = s;
+        slots[(size_t)(2 * pi + 1)] = ord[(size_t)t0];
+        for (int64_t t = t0; t < t1; ++t, ++s) {
+            const int64_t i = row_of(ord[(size_t)slot_pos[(size_t)t]]);
+            rows[(size_t)s] = (int32_t)i;
+            for (int64_t k = h.rowptr[(size_t)i]; k < h.rowptr[(size_t)i + 1]; ++k) {   // ascending columns: the reference's fold order
+                const int64_t j = h.col[(size_t)k];
+                if (j == i) { tdiag[(size_t)s] = h.val[(size_t)k]; continue; }
+                if (!(upper ? j > i : j < i)) continue;
+                const int64_t tt = pos[(size_t)row_of(j)];
+                const bool own = tt >= t0 && tt < t1;
+                ncross += own ? 0 : 1;
+                tcol.push_back(own ? ~cell[(size_t)tt] : (int32_t)j);
+                tval.push_back(h.val[(size_t)k]);
+            }
+            tptr[(size_t)s + 1] = (int64_t)tcol.size();
+        }
+    }
+    slots[(size_t)(2 * nb)] = s;
+    hipError_t e = hipSuccess;
+    auto up = [&](void **dst, const void *src, size_t bytes) {
+        if (e != hipSuccess) return;
+        e = dev_malloc(T->ctx, dst, std::max<size_t>(bytes, 8));
+        if (e == hipSuccess && bytes) e = hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
+    };
+    up((void **)&p->d_bl_slots, slots.data(), sizeof(int64_t) * slots.size());
+    up((void **)&p->d_bl_row, rows.data(), sizeof(int32_t) * rows.size());
+    up((void **)&p->d_bl_ptr, tptr.data(), sizeof(int64_t) * tptr.size());
+    up((void **)&p->d_bl_col, tcol.data(), sizeof(int32_t) * tcol.size());
+    up((void **)&p->d_bl_val, tval.data(), sizeof(double) * tval.size());
+    up((void **)&p->d_bl_diag, tdiag.data(), sizeof(double) * tdiag.size());
+    if (e != hipSuccess) {
+        tri_blocks_free(p);
+        return fail(SLA_ERR_ALLOC, std::string("triangular schedule (blocks): ") + hipGetErrorString(e));
+    }
+    p->nb = nb;
+    p->brows = (int32_t)R;
+    p->bricks = bricks;
+    p->bl_cross = tcol.empty() ? 0.0 : (double)ncross / (double)tcol.size();
+    return SLA_OK;
+}
+
 int sla_tri_solve_info(sla_csr_t T, int upper, int64_t *levels, int64_t *widest_level) {
     if (T && !T->kids.empty()) return multi_unsupported("sla_tri_solve_info");
     if (!T) return fail(SLA_ERR_INVALID, "null matrix");
@@ -164,15 +352,37 @@ int sla_tri_solve(sla_csr_t T, int upper, sla_vec_t b, sla_vec_t x, int64_t *bad
         SLA_TRY(tri_plan_build(T, upper, bad_row));
         sla_tri_plan *p = T->tri[upper];
         if (T->m == 0) return SLA_OK;
-        if (c->tri_syncfree) {   // one persistent launch; a lane that waited too long says so and the level schedule below runs instead
+        // 0: one launch per dependency level (a HIP graph), 1: one persistent launch whose rows poll x in memory, 2: the block-local
+        // persistent launch, 3 (default): 2 where the schedule is deep and narrow (from 64 levels of <= 65536 rows on the average the
+        // levels' launch latency, 5 us each, is what the solve costs) AND at most a quarter of the entries read another block's row -- else 0
+        int mode = c->tri_syncfree;
+        if (mode == 3) {
+            mode = 0;
+            if (p->nlevels >= 64 && T->m / p->nlevels <= 65536) {
+                SLA_TRY(tri_blocks_build(T, upper));
+                if (p->bl_cross <= 0.25) mode = 2;   // (else most values would be polled in memory: a random matrix' triangle ran 38 ms that way, 1.1 ms by levels)
+            }
+        }
+        c->tri_mode_used = mode;
+        if (mode) {   // a lane that waited too long says so and the level schedule below runs instead
             int *d_fail = (int *)(c->d_result + 1600);
-            SLA_TRY(launch_tri_syncfree(T, p, b->d, x->d, d_fail));
+            if (mode == 2) {
+                SLA_TRY(tri_blocks_build(T, upper));
+                SLA_TRY(launch_tri_blocks(T, p, upper, b->d, x->d, d_fail));
+            } else {
+                SLA_TRY(launch_tri_syncfree(T, p, b->d, x->d, d_fail));
+            }
             SLA_TRY(launch_tri_sparsify(c, T->m, x->d));
             int h_fail = 0;
             SLA_HIP_TRY(hipMemcpyAsync(&h_fail, d_fail, sizeof(int), hipMemcpyDeviceToHost, stream_of(c)));
             SLA_HIP_TRY(hipStreamSynchronize(stream_of(c)));
             if (!h_fail) return SLA_OK;
             T->ctx->tri_fallbacks++;
+        }
+        if (p->nlevels > 65536) {   // (a graph of that many nodes is not worth its memory: plain launches)
+            for (int64_t l = 0; l < p->nlevels; ++l)
+                SLA_TRY(launch_tri_level(T, p, p->level_ptr[(size_t)l], p->level_ptr[(size_t)l + 1] - p->level_ptr[(size_t)l], b->d, x->d));
+            return launch_tri_sparsify(c, T->m, x->d);
         }
         if (!p->graph || p->gb != b->d || p->gx != x->d) {
             // capture the level launches once per (b, x) buffer pair; later solves with the same buffers replay the graph

@@ -69,6 +69,8 @@ def test_triangular_solve_is_the_reference_substitution(sla, kind, upper):
     for rep in range(3):                                         # first call captures the graph, later ones replay it
         x = (sla.triUpperSolve if upper else sla.triLowerSolve)(T, bv).to_host()
         assert np.array_equal(x.view(np.uint64), want.view(np.uint64)), (kind, upper, rep, np.abs(x - want).max())
+    # the default picks the form by the schedule's shape: deep and narrow with the dependencies inside the blocks -> the block-local launch
+    assert int(T.ctx.get_option("tri_mode_used")) == {"chain": 2, "banded": 2, "random": 0, "laplace3d": 0}[kind], (kind, lv, wd)
     b2 = rng.standard_normal(n)                                  # another right-hand side buffer: re-captured
     rc, want2, _ = (orc.tri_upper_solve if upper else orc.tri_lower_solve)(A, b2)
     x2 = (sla.triUpperSolve if upper else sla.triLowerSolve)(T, sla.DeviceVector(T.ctx, n, b2)).to_host()
@@ -79,6 +81,10 @@ def test_triangular_solve_is_the_reference_substitution(sla, kind, upper):
     ctx = sla.Context(0)
     T2 = sla.fromCSR(dims, rp, ci, va, ctx)
     bv2 = sla.DeviceVector(ctx, n, b)
+    ctx.set_options(tri_syncfree=0)                              # (the default picks by the schedule's shape: here the level schedule by name)
+    for rep in range(2):
+        x0 = (sla.triUpperSolve if upper else sla.triLowerSolve)(T2, bv2).to_host()
+        assert np.array_equal(x0.view(np.uint64), want.view(np.uint64)), (kind, upper, "levels", rep)
     for grid, spin in ((1, 200000), (7, 200000), (256, 200000), (256, 1)):
         ctx.set_options(tri_syncfree=1, tri_grid=grid, tri_spin=spin)
         before = int(ctx.get_option("tri_fallbacks"))
@@ -86,6 +92,15 @@ def test_triangular_solve_is_the_reference_substitution(sla, kind, upper):
         assert np.array_equal(x3.view(np.uint64), want.view(np.uint64)), (kind, upper, grid, spin)
         fell_back = int(ctx.get_option("tri_fallbacks")) - before
         assert fell_back == (1 if spin == 1 and lv > 1 else 0) or spin == 1, (kind, grid, spin, fell_back)
+    # ... and the block-local form (tri_syncfree = 2): blocks of consecutive rows, one workgroup each with the block's x in LDS, other
+    # blocks' rows polled in memory; tiny blocks put most dependencies ACROSS blocks, one big block keeps them all in LDS
+    for rows_per_block, grid, spin in ((8, 256, 200000), (8, 3, 200000), (64, 256, 200000), (200, 1, 200000), (16384, 256, 200000), (8, 256, 1)):
+        ctx.set_options(tri_syncfree=2, tri_block_rows=rows_per_block, tri_grid=grid, tri_spin=spin)
+        before = int(ctx.get_option("tri_fallbacks"))
+        for rep in range(2):
+            x4 = (sla.triUpperSolve if upper else sla.triLowerSolve)(T2, bv2).to_host()
+            assert np.array_equal(x4.view(np.uint64), want.view(np.uint64)), (kind, upper, rows_per_block, grid, spin, rep)
+        assert spin == 1 or int(ctx.get_option("tri_fallbacks")) == before, (kind, rows_per_block, grid)
     del T2, bv2
     ctx.close()
 

@@ -15,7 +15,17 @@ from sla_amd import _lib, workloads as wl  # noqa: E402
 
 lib = _lib.lib()
 ctx = sla.default_context()
-for name, (dims, (rp, ci, va)) in (("laplace3d 216^3", wl.laplace3d(216, 216, 216)), ("poisson2d 1000^2", wl.poisson2d(1000, 1000))):
+def cases():
+    yield "laplace3d 216^3", wl.laplace3d(216, 216, 216)
+    yield "poisson2d 1000^2", wl.poisson2d(1000, 1000)
+    if os.environ.get("TRI_BENCH_ZOO") == "1":
+        yield "banded 2 M", wl.banded_nonsym(2_000_000)
+        yield "random 1 M x 33", wl.random_spd(1_000_000, 16, 3)
+        yield "laplace3d 100^3", wl.laplace3d(100, 100, 100)
+        yield "poisson2d 3000^2", wl.poisson2d(3000, 3000)
+
+
+for name, (dims, (rp, ci, va)) in cases():
     n = dims[0]
     T = sla.fromCSR(dims, rp, ci, va, ctx)
     rows = np.repeat(np.arange(n), np.diff(rp))
@@ -26,9 +36,10 @@ for name, (dims, (rp, ci, va)) in (("laplace3d 216^3", wl.laplace3d(216, 216, 21
         lv, wd = sla.triSolveLevels(T, bool(upper))
         t_plan = time.perf_counter() - t0
         nnz_tri = int(((ci >= rows) if upper else (ci <= rows)).sum())
+        ctx.set_options(tri_syncfree=2 if lv > 100000 else 0)          # (that many dependent launches take seconds: the reference bits from the block form then)
         _lib.check(lib.sla_tri_solve(T.h, upper, b.h, x.h, None))      # capture
         ctx.sync()
-        reps = 20
+        reps = 20 if lv <= 100000 else 1
         t0 = time.perf_counter()
         for _ in range(reps):
             _lib.check(lib.sla_tri_solve(T.h, upper, b.h, x.h, None))
@@ -39,15 +50,31 @@ for name, (dims, (rp, ci, va)) in (("laplace3d 216^3", wl.laplace3d(216, 216, 21
               % (name, "upper" if upper else "lower", lv, wd, t_plan, dt * 1e3, dt * 1e6 / lv, bytes_ / dt / 1e9, bytes_ // 10**6), flush=True)
         # round 5: the same solve as one persistent launch (option tri_syncfree), by grid size; must give the same bits
         ref = x.to_host()
-        for grid in (64, 128, 256, 512, 1024, 2048):
-            ctx.set_options(tri_syncfree=1, tri_grid=grid)
+        fast = os.environ.get("TRI_BENCH_FAST") == "1"
+        for mode, grid, brows in [(1, g, 0) for g in ((256,) if fast else (64, 128, 256, 512, 1024))] + [(2, 0, r) for r in ((16384,) if fast else (4096, 8192, 16384))]:
+            if mode == 1 and lv > 100000:
+                continue
+            ctx.set_options(tri_syncfree=mode, tri_grid=grid)
+            if brows:
+                ctx.set_options(tri_block_rows=brows)
+                t0 = time.perf_counter()
             _lib.check(lib.sla_tri_solve(T.h, upper, b.h, x.h, None))
             ctx.sync()
+            t_first = time.perf_counter() - t0 if brows else 0.0
             same = bool(np.array_equal(x.to_host(), ref))
             t0 = time.perf_counter()
             for _ in range(5):
                 _lib.check(lib.sla_tri_solve(T.h, upper, b.h, x.h, None))
             ctx.sync()
             dts = (time.perf_counter() - t0) / 5
-            print("    persistent launch, %4d workgroups: %.3f ms (bit-identical: %s; fallbacks so far: %s)" % (grid, dts * 1e3, same, ctx.get_option("tri_fallbacks")), flush=True)
-        ctx.set_options(tri_syncfree=0)
+            what = "rows poll x in memory" if mode == 1 else "blocks of %5d rows in LDS (plan + first solve %.2f s)" % (brows, t_first)
+            print("    persistent launch, %4d workgroups, %s: %.3f ms (bit-identical: %s; fallbacks so far: %s)" % (grid, what, dts * 1e3, same, ctx.get_option("tri_fallbacks")), flush=True)
+        ctx.set_options(tri_syncfree=3, tri_grid=0, tri_block_rows=16384)
+        _lib.check(lib.sla_tri_solve(T.h, upper, b.h, x.h, None))
+        ctx.sync()
+        t0 = time.perf_counter()
+        for _ in range(5 if lv <= 100000 else 1):
+            _lib.check(lib.sla_tri_solve(T.h, upper, b.h, x.h, None))
+        ctx.sync()
+        dta = (time.perf_counter() - t0) / (5 if lv <= 100000 else 1)
+        print("    default (picked form %s): %.3f ms (bit-identical: %s)" % (ctx.get_option("tri_mode_used"), dta * 1e3, bool(np.array_equal(x.to_host(), ref))), flush=True)
