@@ -46,8 +46,9 @@ for name, (dims, (rp, ci, va)) in cases():
         ctx.sync()
         dt = (time.perf_counter() - t0) / reps
         bytes_ = 12 * nnz_tri + 28 * n                                   # val + col of the triangle, rowptr, order, b, x
-        print("%-18s %s: %5d levels (widest %7d rows), schedule built in %.2f s; solve %.3f ms = %.2f us/level, %.0f GB/s of %d MB"
-              % (name, "upper" if upper else "lower", lv, wd, t_plan, dt * 1e3, dt * 1e6 / lv, bytes_ / dt / 1e9, bytes_ // 10**6), flush=True)
+        print("%-18s %s: %5d levels (widest %7d rows), schedule built in %.2f s; %s %.3f ms = %.2f us/level, %.0f GB/s of %d MB"
+              % (name, "upper" if upper else "lower", lv, wd, t_plan, "level schedule" if lv <= 100000 else "(level schedule = that many dependent launches: not timed) block-local form",
+                 dt * 1e3, dt * 1e6 / lv, bytes_ / dt / 1e9, bytes_ // 10**6), flush=True)
         # round 5: the same solve as one persistent launch (option tri_syncfree), by grid size; must give the same bits
         ref = x.to_host()
         fast = os.environ.get("TRI_BENCH_FAST") == "1"
