@@ -887,6 +887,7 @@ int sla_csr_destroy(sla_csr_t A) {
     if (A->d_tlidx) (void)hipFree(A->d_tlidx);
     if (A->d_tlval) (void)hipFree(A->d_tlval);
     if (A->d_tlprog) (void)hipFree(A->d_tlprog);
+    if (A->d_tldummy) (void)hipFree(A->d_tldummy);
     if (A->d_ov_int) (void)hipFree(A->d_ov_int);
     if (A->d_ov_bnd) (void)hipFree(A->d_ov_bnd);
     delete A->xplan;

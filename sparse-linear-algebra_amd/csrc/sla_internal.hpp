@@ -444,7 +444,7 @@ struct sla_csr {
     unsigned *d_tlprog = nullptr;    // per-XCD (round, panel) arrival counters of the launch in flight (panel pacing)
     size_t tlprog_bytes = 0;
     int64_t tl_maxseg = 0;           // longest (row, panel) segment = layers of the deepest tile
-    int32_t tl_dcol = 0;             // the column of the matrix's first entry: what the kernels' empty pipeline-drain chunks gather (always inside what this rank may read)
+    double *d_tldummy = nullptr;     // one all-zero panel (2^tl_shift doubles): what the tile kernels' empty pipeline-drain chunks gather from
     bool tl_cu = false;              // CU-wide slices, relaxed order (sla_spmv_ctiles.hip): entries [slice][wavefront][panel], d_tloff = tl_S x 4 x (tl_P + 1)
     sla_tri_plan *tri[2] = {nullptr, nullptr};  // [0] lower, [1] upper triangle schedules (built on first use)
     // comm / compute overlap of the sharded (#>) (wave-sliced forms): the 512-row steps whose rows reference own columns only

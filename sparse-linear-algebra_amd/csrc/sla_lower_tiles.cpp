@@ -166,12 +166,14 @@ int build_tiles(sla_csr *A, int64_t n, int64_t rows, const int64_t *rowptr, cons
         if (e2 == hipSuccess) e2 = hipMemcpy(A->d_tlrow, srow.data(), sizeof(int32_t) * srow.size(), hipMemcpyHostToDevice);
         A->tlprog_bytes = sizeof(int) * 8 * 256;   // pacing table: one progress slot per workgroup, 256 per XCD; zeroed before every launch
         if (e2 == hipSuccess) e2 = dev_malloc(c, (void **)&A->d_tlprog, A->tlprog_bytes);
+        if (A->d_tldummy) { (void)hipFree(A->d_tldummy); A->d_tldummy = nullptr; }
+        if (e2 == hipSuccess) e2 = dev_malloc(c, (void **)&A->d_tldummy, sizeof(double) << shift);
+        if (e2 == hipSuccess) e2 = hipMemset(A->d_tldummy, 0, sizeof(double) << shift);
         if (e2 != hipSuccess) return fail(SLA_ERR_ALLOC, std::string("tile form upload: ") + hipGetErrorString(e2));
         SLA_TRY(probe_xcd_layout(c));
         A->tl_S = (int32_t)S;
         A->tl_P = (int32_t)P;
         A->tl_shift = shift;
-        A->tl_dcol = (int32_t)col[rowptr[0]];   // (nnz > 0: rows without entries in front share rowptr[0] = 0)
         A->tl_cu = cu;
         A->use_tiles = true;
         return SLA_OK;

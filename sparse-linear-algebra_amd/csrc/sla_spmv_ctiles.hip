@@ -81,7 +81,7 @@ template <int EPI, typename RP, int kCtU>
 __global__ void __launch_bounds__(kBlock, 1)
 spmv_ctile_kernel(SpmvArgs<RP> a, const RP *__restrict__ rowptr, const int32_t *__restrict__ srow, const uint32_t *__restrict__ toff,
                   const uint32_t *__restrict__ tidx, const double *__restrict__ tval, const double *__restrict__ xg, int S, int P,
-                  int shift, unsigned *prog, int slack, const int32_t *__restrict__ vis, int v0, int nv, int dlim, int dcol) {
+                  int shift, unsigned *prog, int slack, const int32_t *__restrict__ vis, int v0, int nv, int dlim, const double *__restrict__ dummy) {
     __shared__ double s_y[kCtRows];
     __shared__ double s_red[4];
     __shared__ int s_prog[kBlock / 64];
@@ -228,7 +228,7 @@ spmv_ctile_kernel(SpmvArgs<RP> a, const RP *__restrict__ rowptr, const int32_t *
             }
         };
         auto gather = [&](Chunk &c) {
-            const char *xa = (const char *)(xg + ((size_t)c.panel << shift)), *xb = (const char *)(xg + ((size_t)c.panel2 << shift));
+            const char *xa = (const char *)(c.panel < 0 ? dummy : xg + ((size_t)c.panel << shift)), *xb = (const char *)(c.panel2 < 0 ? dummy : xg + ((size_t)c.panel2 << shift));
 #if SLA_CT_VAL_LATE   // the values are not needed before the fold: their loads go out with the gathers, one pipeline stage later (8 B per entry
             // less to hold per chunk in its first stage: deeper chunks fit the register file)
             const double *vp = (c.cnt ? tval + (base + (RP)c.start) : tval);
@@ -252,16 +252,12 @@ spmv_ctile_kernel(SpmvArgs<RP> a, const RP *__restrict__ rowptr, const int32_t *
                 c.cnt = 0;
                 c.start = 0;
                 c.split = 0;
-                // every lane gathers x[dcol], a column this rank's matrix references (panel 0 may lie outside a window-mode slab's guard, and
-                // the low bits of somebody else's entry may point past the end of a partial last panel); the loads stay for the wait counts
-                c.panel2 = dcol >> shift;
-                c.panel = dcol >> shift;
-                uint32_t zero = 0;
-                asm volatile("" : "+v"(zero));
+                c.panel2 = -1;   // gathers from the matrix's all-zero dummy panel: whatever column bits the re-read entries carry, the address
+                c.panel = -1;    // is inside an allocation (panel 0 may lie outside a window-mode slab's guard, a partial last panel ends early)
 #pragma unroll
                 for (int u = 0; u < kCtU; ++u) {
                     const int i = min(lane + 64 * u, dlim);
-                    c.idx[u] = (__builtin_nontemporal_load(tidx + i) & zero) | ((uint32_t)dcol & cmask);
+                    c.idx[u] = __builtin_nontemporal_load(tidx + i);
 #if !SLA_CT_VAL_LATE
                     c.val[u] = __builtin_nontemporal_load(tval + i);
 #endif
@@ -334,11 +330,11 @@ static int launch_ctiles_t(const sla_csr *A, const SpmvLaunch &l) {
     if (deep)
         hipLaunchKernelGGL((spmv_ctile_kernel<EPI, RP, SLA_CT_U>), dim3(ctiles_grid(A)), dim3(kBlock), 0, stream_of(c), a, a.rowptr, A->d_tlrow, A->d_tloff,
                            A->d_tlidx, A->d_tlval, l.x, A->tl_S, A->tl_P, A->tl_shift, A->d_tlprog, c->xcd8 == 1 ? c->tile_slack : 0, vis, l.tv0, nv,
-                           (int)std::min<int64_t>(64 * SLA_CT_U - 1, A->nnz - 1), A->tl_dcol);
+                           (int)std::min<int64_t>(64 * SLA_CT_U - 1, A->nnz - 1), A->d_tldummy);
     else
         hipLaunchKernelGGL((spmv_ctile_kernel<EPI, RP, SLA_CT_U_DENSE>), dim3(ctiles_grid(A)), dim3(kBlock), 0, stream_of(c), a, a.rowptr, A->d_tlrow, A->d_tloff,
                            A->d_tlidx, A->d_tlval, l.x, A->tl_S, A->tl_P, A->tl_shift, A->d_tlprog, c->xcd8 == 1 ? c->tile_slack : 0, vis, l.tv0, nv,
-                           (int)std::min<int64_t>(64 * SLA_CT_U_DENSE - 1, A->nnz - 1), A->tl_dcol);
+                           (int)std::min<int64_t>(64 * SLA_CT_U_DENSE - 1, A->nnz - 1), A->d_tldummy);
     SLA_HIP_TRY(hipGetLastError());
     return SLA_OK;
 }

@@ -89,7 +89,7 @@ template <int EPI, typename RP>
 __global__ void __launch_bounds__(kBlock, kTileBlocksPerCu)
 spmv_tile_kernel(SpmvArgs<RP> a, const RP *__restrict__ rowptr, const int32_t *__restrict__ srow, const uint32_t *__restrict__ toff,
                  const uint32_t *__restrict__ tidx, const double *__restrict__ tval, const double *__restrict__ xg, int S, int P,
-                 int shift, unsigned *prog, int slack, const int32_t *__restrict__ vis, int v0, int nv, int pfd, int apoll, int64_t ncols, int dlim, int dcol) {
+                 int shift, unsigned *prog, int slack, const int32_t *__restrict__ vis, int v0, int nv, int pfd, int apoll, int64_t ncols, int dlim, const double *__restrict__ dummy) {
     // One PASS of an overlapped all-gather (AgPlan, sla_internal.hpp) walks the nv panels vis[v0 ..] instead of 0 .. P-1 and starts
     // from the running row sums a.yinit; vis == nullptr: all P panels ascending from zero (nv == P then).
     __shared__ double s_y[kTileWaves][kTileRows];
@@ -278,7 +278,7 @@ spmv_tile_kernel(SpmvArgs<RP> a, const RP *__restrict__ rowptr, const int32_t *_
             k += 64 * kTileU;
         };
         auto gather = [&](TileChunk &c) {
-            const char *xb = (const char *)(xg + ((size_t)c.panel << shift));
+            const char *xb = (const char *)(c.panel < 0 ? dummy : xg + ((size_t)c.panel << shift));
 #pragma unroll
             for (int u = 0; u < kTileU; ++u) c.xv[u] = *(const double *)(xb + (uint32_t)((c.idx[u] & cmask) << 3));
         };
@@ -298,15 +298,12 @@ spmv_tile_kernel(SpmvArgs<RP> a, const RP *__restrict__ rowptr, const int32_t *_
                 issue(c);
             } else {
                 c.cnt = 0;
-                // every lane gathers x[dcol], a column this rank's matrix references (panel 0 may lie outside a window-mode slab's guard, and
-                // the low bits of somebody else's entry may point past the end of a partial last panel)
-                c.panel = dcol >> shift;
-                uint32_t zero = 0;
-                asm volatile("" : "+v"(zero));
+                c.panel = -1;   // gathers from the matrix's all-zero dummy panel: whatever column bits the re-read entries carry, the address is inside
+                                // an allocation (panel 0 may lie outside a window-mode slab's guard, a partial last panel ends early)
 #pragma unroll
                 for (int u = 0; u < kTileU; ++u) {   // (run-time indices: identical addresses would be merged into one load, and the count is the point)
                     const int i = min(lane + 64 * u, dlim);
-                    c.idx[u] = (__builtin_nontemporal_load(tidx + i) & zero) | ((uint32_t)dcol & cmask);
+                    c.idx[u] = __builtin_nontemporal_load(tidx + i);
                     c.val[u] = __builtin_nontemporal_load(tval + i);
                 }
             }
@@ -427,7 +424,7 @@ static int launch_tiles_t(const sla_csr *A, const SpmvLaunch &l) {
     hipLaunchKernelGGL((spmv_tile_kernel<EPI, RP>), dim3(tiles_grid(A)), dim3(kBlock), 0, stream_of(c), a, a.rowptr, A->d_tlrow, A->d_tloff,
                        A->d_tlidx, A->d_tlval, l.x, A->tl_S, A->tl_P, A->tl_shift, A->d_tlprog, c->xcd8 == 1 ? c->tile_slack : 0, vis, l.tv0, nv,
                        c->xcd8 == 1 ? c->tile_prefetch : 0, c->tile_poll, A->n,
-                       (int)std::min<int64_t>(64 * kTileU - 1, A->nnz - 1), A->tl_dcol);
+                       (int)std::min<int64_t>(64 * kTileU - 1, A->nnz - 1), A->d_tldummy);
     SLA_HIP_TRY(hipGetLastError());
     return SLA_OK;
 }
