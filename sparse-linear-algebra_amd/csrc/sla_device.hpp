@@ -8,6 +8,11 @@
 
 namespace sla {
 
+// Workgroups per CU the 8-per-CU kernels are compiled for: 64-bit row pointers and the heaviest epilogue (x + beta y with the norm) do not
+// fit 64 registers -- at 8 they spilled up to 116 VGPRs to scratch (tools/kernel_resources.py); those instantiations get 96 registers.
+template <int EPI, typename RP>
+constexpr int kOcc8 = (sizeof(RP) == 8 || EPI == 7) ? 5 : 8;
+
 // ---------------------------------------------------------------------------------------------
 // reduction helpers (deterministic)
 // ---------------------------------------------------------------------------------------------

@@ -23,7 +23,7 @@ namespace sla {
 // wavefront segment per row) decodes col = row + dict[code], takes x from the LDS window or from L2 and
 // accumulates with SEPARATE multiply and add roundings (the reference's left fold, bit for bit).
 template <int EPI, typename RP, bool XW>
-__global__ void __launch_bounds__(kBlock, 8) spmv_diag_kernel(SpmvArgs<RP> a, const RP *__restrict__ rowptr,
+__global__ void __launch_bounds__(kBlock, (XW ? (EPI == 2 && sizeof(RP) == 4 ? 7 : (kOcc8<EPI, RP>)) : 8)) spmv_diag_kernel(SpmvArgs<RP> a, const RP *__restrict__ rowptr,
                                                                const uint8_t *__restrict__ code, const double *__restrict__ val,
                                                                const int32_t *__restrict__ rb, const RP *__restrict__ rbk,
                                                                const double *__restrict__ xg, const int32_t *__restrict__ rbw,
@@ -246,7 +246,7 @@ __global__ void __launch_bounds__(kBlock, 8) spmv_diag_kernel(SpmvArgs<RP> a, co
 // Dual SpMV on the dictionary-compressed indices: K1 plus the true residual of the previous iterate from one
 // sweep over val (8 B) + code (1 B); the column is decoded once per entry and used for both gathers.
 template <typename RP, bool XW>
-__global__ void __launch_bounds__(kBlock, 8) spmv_dual_diag_kernel(SpmvArgs<RP> a, const RP *__restrict__ rowptr,
+__global__ void __launch_bounds__(kBlock, (XW ? 6 : 8)) spmv_dual_diag_kernel(SpmvArgs<RP> a, const RP *__restrict__ rowptr,
                                                                const uint8_t *__restrict__ code, const double *__restrict__ val,
                                                                const int32_t *__restrict__ rb, const RP *__restrict__ rbk,
                                                                const double *__restrict__ xg, const int32_t *__restrict__ rbw,

@@ -30,7 +30,7 @@ typedef double sla_f64x2 __attribute__((ext_vector_type(2)));
 // descriptors (rb, rbk) are indexed by the block number only, so they prefetch without a dependent
 // chain.  s_prod / s_rp are double-buffered: one barrier per row block.
 template <int EPI, typename RP>
-__global__ void __launch_bounds__(kBlock, 8) spmv_stream_kernel(SpmvArgs<RP> a, const RP *__restrict__ rowptr, const int32_t *__restrict__ col,
+__global__ void __launch_bounds__(kBlock, (kOcc8<EPI, RP>)) spmv_stream_kernel(SpmvArgs<RP> a, const RP *__restrict__ rowptr, const int32_t *__restrict__ col,
                                                                  const double *__restrict__ val, const int32_t *__restrict__ rb,
                                                                  const RP *__restrict__ rbk, const double *__restrict__ xg,
                                                                  int xcd_remap, int wide) {
@@ -258,7 +258,7 @@ __global__ void __launch_bounds__(kBlock, 8) spmv_stream_kernel(SpmvArgs<RP> a, 
 // gather that falls inside it from LDS; only the far legs go to L1/L2.  Everything is single-buffered
 // except the row offsets (two barriers per row block).
 template <int EPI, typename RP>
-__global__ void __launch_bounds__(kBlock, 8) spmv_xwin_kernel(SpmvArgs<RP> a, const RP *__restrict__ rowptr, const int32_t *__restrict__ col,
+__global__ void __launch_bounds__(kBlock, (kOcc8<EPI, RP>)) spmv_xwin_kernel(SpmvArgs<RP> a, const RP *__restrict__ rowptr, const int32_t *__restrict__ col,
                                                                  const double *__restrict__ val, const int32_t *__restrict__ rb,
                                                                  const RP *__restrict__ rbk, const double *__restrict__ xg,
                                                                  const int32_t *__restrict__ rbw, int32_t ncols, int xcd_remap) {
