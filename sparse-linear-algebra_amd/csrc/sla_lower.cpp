@@ -161,6 +161,11 @@ int host_threads() {
         // rest of the period -- the x-window statistics of config 3a took 72 ms inside bench.py against 6 ms stand-alone, the 4 GB upload
         // 240 ms against 90.
         int v = s ? atoi(s) : std::min((int)(hw >= 64 ? 32u : std::min(16u, hw)), host_cores_available());
+        // one process per GPU (torchrun: LOCAL_WORLD_SIZE ranks in this container share the cores and the quota): an equal share, at least 2
+        if (const char *lw = s ? nullptr : getenv("LOCAL_WORLD_SIZE")) {
+            const int ranks = atoi(lw);
+            if (ranks > 1) v = std::max(2, std::min(v, host_cores_available() / ranks));
+        }
         return std::max(1, std::min(v, 64));
     }();
     return t;
