@@ -262,6 +262,7 @@ struct sla_ctx {
     int tri_block_rows = 16384;      // tri_syncfree = 2: rows per block (<= kTriBlockRows: the block's x sits in LDS; small values are for the tests)
     int tri_syncfree = 3;            // triLowerSolve / triUpperSolve: 0 one launch per dependency level, 1 one persistent launch whose rows poll x in memory, 2 the block-local persistent launch (sla_tri.hip), 3 pick 2 or 0 by the schedule's shape (sla_precond.cpp)
     int tri_grid = 0;                // ... its workgroups (0: 256 for the row-polling kernel, as many as are co-resident for the block-local one)
+    std::string tri_plan_note;       // ... and the shape of its plan (sla_ctx_get_option "tri_plan")
     int tri_mode_used = 0;           // what the last triangular solve ran as (sla_ctx_get_option "tri_mode_used")
     long tri_fallbacks = 0;          // solves that left the persistent kernel for the level schedule (sla_ctx_get_option "tri_fallbacks")
     int tri_spin = 200000;           // ... polls without progress after which a lane gives up and the host runs the level schedule instead

@@ -364,6 +364,9 @@ int sla_tri_solve(sla_csr_t T, int upper, sla_vec_t b, sla_vec_t x, int64_t *bad
             }
         }
         c->tri_mode_used = mode;
+        c->tri_plan_note = mode == 2 ? "blocks=" + std::to_string(p->nb) + " block_rows=" + std::to_string(p->brows) + " bricks=" + std::to_string(p->bricks ? 1 : 0) +
+                                           " outside_share=" + std::to_string(p->bl_cross)
+                                     : std::string("levels=") + std::to_string(p->nlevels);
         if (mode) {   // a lane that waited too long says so and the level schedule below runs instead
             int *d_fail = (int *)(c->d_result + 1600);
             if (mode == 2) {

@@ -33,7 +33,7 @@ def test_reference_triangular_cases(sla, name):
     assert np.sqrt((resid ** 2).sum()) <= 1e-12
 
 
-@pytest.mark.parametrize("kind", ["laplace3d", "banded", "random", "chain"])
+@pytest.mark.parametrize("kind", ["laplace3d", "banded", "random", "chain", "band3"])
 @pytest.mark.parametrize("upper", [False, True])
 def test_triangular_solve_is_the_reference_substitution(sla, kind, upper):
     from sla_amd import workloads as wl
@@ -44,6 +44,20 @@ def test_triangular_solve_is_the_reference_substitution(sla, kind, upper):
         dims, (rp, ci, va) = wl.banded_nonsym(4001)
     elif kind == "random":
         dims, (rp, ci, va) = wl.random_spd(1500, 5, 3)
+    elif kind == "band3":                                        # offsets +-1, +-24, +-144 on EVERY row (no grid boundaries): looks like a 24 x 6 x . stencil to
+        n = 24 * 6 * 7                                           # the block-local plan, but its brick order would put rows before rows they read -- the
+        rows, cols = [], []                                      # plan must notice and keep the sweep order
+        for d in (-144, -24, -1, 0, 1, 24, 144):
+            i = np.arange(max(0, -d), min(n, n - d))
+            rows.append(i)
+            cols.append(i + d)
+        rows, cols = np.concatenate(rows), np.concatenate(cols)
+        order = np.lexsort((cols, rows))
+        rows, cols = rows[order], cols[order]
+        rp = np.zeros(n + 1, np.int64)
+        np.add.at(rp, rows + 1, 1)
+        rp = np.cumsum(rp)
+        ci, va, dims = cols, rng.uniform(0.5, 1.5, len(cols)) * np.where(cols == rows, 6.0, 1.0), (n, n)
     else:                                                        # bidiagonal: n levels of one row each
         n = 700
         rows = np.repeat(np.arange(n), 3)[1:-1]
@@ -70,7 +84,7 @@ def test_triangular_solve_is_the_reference_substitution(sla, kind, upper):
         x = (sla.triUpperSolve if upper else sla.triLowerSolve)(T, bv).to_host()
         assert np.array_equal(x.view(np.uint64), want.view(np.uint64)), (kind, upper, rep, np.abs(x - want).max())
     # the default picks the form by the schedule's shape: deep and narrow with the dependencies inside the blocks -> the block-local launch
-    assert int(T.ctx.get_option("tri_mode_used")) == {"chain": 2, "banded": 2, "random": 0, "laplace3d": 0}[kind], (kind, lv, wd)
+    assert int(T.ctx.get_option("tri_mode_used")) == {"chain": 2, "banded": 2, "random": 0, "laplace3d": 0, "band3": 2}[kind], (kind, lv, wd)
     b2 = rng.standard_normal(n)                                  # another right-hand side buffer: re-captured
     rc, want2, _ = (orc.tri_upper_solve if upper else orc.tri_lower_solve)(A, b2)
     x2 = (sla.triUpperSolve if upper else sla.triLowerSolve)(T, sla.DeviceVector(T.ctx, n, b2)).to_host()
@@ -101,6 +115,12 @@ def test_triangular_solve_is_the_reference_substitution(sla, kind, upper):
             x4 = (sla.triUpperSolve if upper else sla.triLowerSolve)(T2, bv2).to_host()
             assert np.array_equal(x4.view(np.uint64), want.view(np.uint64)), (kind, upper, rows_per_block, grid, spin, rep)
         assert spin == 1 or int(ctx.get_option("tri_fallbacks")) == before, (kind, rows_per_block, grid)
+        plan = ctx.get_option("tri_plan")
+        if kind == "laplace3d" and rows_per_block in (64, 200):    # 13-row lines: bricks of 2 x 2 / 5 x 3 lines
+            assert "bricks=1" in plan, plan
+        if kind in ("banded", "chain", "random") or (kind == "band3" and rows_per_block == 200):
+            assert "bricks=0" in plan, (kind, plan)               # (band3 in bricks of 4 lines x 2 planes: row (0, 0, odd plane) reads the last line of
+                                                                   # the plane before it, which a LATER brick holds -- not a valid order, dropped)
     del T2, bv2
     ctx.close()
 
