@@ -177,8 +177,13 @@ def kernel_table(ctx, A, nnz_local, n_local, method):
         # K4 and K5 are ONE sweep over p, s, As, x, Ap -> x, r, p; the reference's split (sharded contexts, SLA_BICG_FUSE45=0)
         # shows up as K4 + K5 instead of K45
         fused = ctx.prof_query(_lib.KERNEL_BICG_K45)[0] > 0
+        # round 5 (option bicg_fuse23, plane-march form on one rank): K2 is folded into K3 -- s = r - alpha Ap is built while the x windows are
+        # staged and never stored (K4+K5 rebuild it from r and Ap): ONE launch "K23" that streams r, Ap, r0hat in and As out
+        k23 = fused and ctx.prof_query(_lib.KERNEL_BICG_K2)[0] == 0 and ctx.prof_query(_lib.KERNEL_SPMV_DOT2)[0] > 0
         defs = [("K1", _lib.KERNEL_SPMV_DOT, "Ap = A p ; Ap . r0hat", mb + 24 * n, 12 * z + 28 * n),
                 ("K2", _lib.KERNEL_BICG_K2, "alpha ; s = r - alpha Ap", 24 * n, 24 * n),
+                ("K23", _lib.KERNEL_SPMV_DOT2, "alpha ; s = r - alpha Ap (staged, never stored) ; As = A s ; As . s, As . As, As . r0hat, s . r0hat",
+                 mb + 32 * n, 12 * z + 52 * n) if k23 else
                 ("K3", _lib.KERNEL_SPMV_DOT2, "As = A s ; As . s, As . As" + (", As . r0hat, s . r0hat" if fused else ""),
                  mb + (24 if fused else 16) * n, 12 * z + (28 if fused else 20) * n),
                 ("K4", _lib.KERNEL_BICG_K4, "omega ; x += alpha p + omega s ; r = s - omega As ; r . r0hat", 56 * n, 56 * n),
@@ -753,7 +758,7 @@ def run_rank(args, rank, world, local_rank, dist_mode, loop=None):
         rec["step_gbps"] = rec["step_bytes_streamed"] / (dt / args.steps) / 1e9
         rec["step_frac_of_hbm_peak"] = rec["step_gbps"] / (HBM_PEAK_GBS * world)
         rec["roofline"] = {
-            "bound": "hbm", "kernel": f"{dom}: {d['what']}" + (f" [{kinfo.split()[0]}]" if dom in ("K1", "K3", "C1", "C3") else ""),
+            "bound": "hbm", "kernel": f"{dom}: {d['what']}" + (f" [{kinfo.split()[0]}]" if dom in ("K1", "K3", "K23", "C1", "C3") else ""),
             "share_of_step": d["ms"] * d["launches"] / args.steps / step_ms,
             "bytes_definition": "compulsory bytes of the storage form the kernel streams (matrix_bytes of the chosen SpMV form + the "
                                 "vectors; equal to the SURVEY 8(d) figure for the vector kernels and for the plain CSR forms); "

@@ -173,6 +173,7 @@ struct SpmvArgs {
     int32_t npa, pa_stride;
     int32_t step_begin;      // bit 0: this launch opens a solver step (iters++); bit 1: step parity
     const double *yinit;     // column-panel passes: running row sums of the previous panels (or null)
+    const double *fs_ap;     // plane-march kernel, K2 folded into K3: the gathered vector is x - alpha fs_ap, alpha from pa (or null)
 };
 
 }  // namespace sla
@@ -280,6 +281,7 @@ struct sla_ctx {
     int64_t mall_bytes = 256ll << 20; // capacity of the memory-side cache (MI355X: 256 MiB)
     int wdia_vv = 1;                 // allow the variable-coefficient wave-sliced form (SLA_WDIA_VV=0 disables)
     int wd_grid_max_vv = sla::kWdBlocksPerCuVV * 256;
+    int bicg_fuse23 = 1;             // ... and K2 folded into K3 where the plane-march kernel runs it: s = r - alpha Ap is built in the staged windows, never stored (SLA_BICG_FUSE23)
     int bicg_fuse45 = 1;             // single-rank BiCGSTAB: K4 + K5 in one sweep, rho through K3's extra sums (SLA_BICG_FUSE45)
     int wd_lds = 1;                  // stencils with <= 8 (offset, value) pairs: uniform records + x windows staged in LDS (SLA_WD_LDS; 2: at any size)
     int wd_nt_store = 0;             // its y / z stores past the caches (SLA_WD_NT_STORE)
@@ -810,7 +812,9 @@ struct SpmvLaunch {
     int part = 0;                               // row-sharded overlap: 0 all rows, 1 the interior steps only, 2 the boundary steps only
     const int32_t *tvis = nullptr; int tv0 = 0, tv1 = -1;   // tile form, one PASS of an overlapped all-gather: the panels tvis[tv0 .. tv1) (tv1 < 0: all panels, ascending)
     int tlast = 1;                              // ... 0: not the last pass -- the running row sums go to y, no epilogue
+    const double *fs_ap = nullptr;              // BiCGSTAB's K2 folded into K3 (spmv_fuse_s_ok): gather from s = x - alpha fs_ap, alpha = rho / sum(pa)
 };
+bool spmv_fuse_s_ok(const sla_csr *A);          // would a whole-matrix (#>) on A run the plane-march kernel, on one rank?
 int spmv_grid(const sla_csr *A);  // number of blocks (= partial slots written) of an SpMV launch on A
 int launch_spmv(const sla_csr *A, const SpmvLaunch &l);
 // exchange the input vector of a (#>) and launch it; on row-sharded contexts the interior rows run while the halo is in flight.
@@ -883,7 +887,7 @@ int launch_bicg_k2(sla_ctx *c, int64_t n, SolverScalars *sc, Parts apr, int par,
 int launch_bicg_k4(sla_ctx *c, int64_t n, SolverScalars *sc, Parts ass, Parts asas, const double *p, const double *s,
                    const double *as, const double *r0hat, double *x, double *r, double *prho);
 int launch_bicg_k5(sla_ctx *c, int64_t n, SolverScalars *sc, Parts rhonew, int par, const double *r, const double *ap, double *p);
-int launch_bicg_k45(sla_ctx *c, int64_t n, SolverScalars *sc, Parts ass, Parts asas, Parts tr0, Parts sr0, int par, const double *s,
+int launch_bicg_k45(sla_ctx *c, int64_t n, SolverScalars *sc, Parts ass, Parts asas, Parts tr0, Parts sr0, int par, const double *s,   // (s == nullptr: rebuilt from r and ap)
                     const double *as, const double *ap, double *x, double *r, double *p);
 // CGS (Sparse.hs:928-939)
 int launch_cgs_c2(sla_ctx *c, int64_t n, SolverScalars *sc, Parts apr, int par, Parts res, int count_iter,

@@ -232,8 +232,13 @@ int enqueue_bicgstab(sla_solver *S, int par, const Parts *check, bool dual_prev)
         SLA_TRY(spmv_exchanged(A, S->p, l, &gk));
         SLA_TRY(publish(S, P_APR, -1, gk, &apr, nullptr));
     }
-    SLA_TRY(launch_bicg_k2(c, n, S->d_sc, apr, par, dual_prev ? Parts{slot(S, P_RES), g, 1} : Parts{nullptr, 0, 1},
-                           dual_prev ? 1 : 0, S->r->d, S->t1->d, S->t2->d));
+    // Round 5: where K3 runs on the plane-march kernel (one rank, 3-D stencils from 8 M rows on) K2 is folded into it -- s = r - alpha Ap is
+    // built while the x windows are staged and never stored; the fused K4+K5 sweep rebuilds it from r and Ap, which it reads anyway.  Three
+    // launches and 121 n bytes per step instead of four and 138 n; the same bits (bicg_k2_kernel's alpha and multiply-add).
+    const bool fuse23 = c->bicg_fuse23 != 0 && c->bicg_fuse45 != 0 && !dual_prev && spmv_fuse_s_ok(A);
+    if (!fuse23)
+        SLA_TRY(launch_bicg_k2(c, n, S->d_sc, apr, par, dual_prev ? Parts{slot(S, P_RES), g, 1} : Parts{nullptr, 0, 1},
+                               dual_prev ? 1 : 0, S->r->d, S->t1->d, S->t2->d));
     {
         SpmvLaunch l;  // K3: aasj = aa #> sj ; aasj <.> sj ; aasj <.> aasj
         l.epi = EPI_DOT2;
@@ -256,11 +261,23 @@ int enqueue_bicgstab(sla_solver *S, int par, const Parts *check, bool dual_prev)
             l.p4 = slot(S, P_SR0);
         }
         int gk = g;
-        SLA_TRY(spmv_exchanged(A, S->t2, l, &gk));
+        if (fuse23) {
+            l.x = S->r->d;          // (one rank: the gather base is the vector itself)
+            l.fs_ap = S->t1->d;
+            l.w = nullptr;          // (As . s takes s from the staged window)
+            l.pa = apr.p;
+            l.npa = apr.n;
+            l.pa_stride = apr.stride;
+            l.step_begin = par << 1;
+            l.kernel_id = SLA_KERNEL_SPMV_DOT2;
+            SLA_TRY(launch_spmv(A, l));
+        } else {
+            SLA_TRY(spmv_exchanged(A, S->t2, l, &gk));
+        }
         if (fuse) {   // (row-sharded: the four sums travel as ONE all-gather; the rho exchange and K5 are gone)
             Parts q[4];
             SLA_TRY(publish4(S, gk, q, nullptr));
-            return launch_bicg_k45(c, n, S->d_sc, q[0], q[1], q[2], q[3], par, S->t2->d, S->t3->d, S->t1->d, S->x->d, S->r->d, S->p->d);
+            return launch_bicg_k45(c, n, S->d_sc, q[0], q[1], q[2], q[3], par, fuse23 ? nullptr : S->t2->d, S->t3->d, S->t1->d, S->x->d, S->r->d, S->p->d);
         }
         SLA_TRY(publish(S, P_ASS, P_ASAS, gk, &ass, &asas));
     }

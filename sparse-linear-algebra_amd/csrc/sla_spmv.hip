@@ -35,6 +35,17 @@ bool wave_plain(const sla_csr *A) {
     return wave_on(A) && !A->is_panel_view && !diag_on(A) && !stream_xwin_on(A);
 }
 
+// BiCGSTAB's K2 folded into K3 (SpmvLaunch::fs_ap): one rank, and the whole-matrix launch lands on the plane-march kernel -- the
+// conditions of the dispatch below, in its order
+bool spmv_fuse_s_ok(const sla_csr *A) {
+    const sla_ctx *c = A->ctx;
+    if (c->collectives || A->rp64 || A->row_begin != 0 || A->is_panel_view) return false;
+    if (tiles_on(A) && !lflat_on(A)) return false;
+    if (!A->panels.empty() && c->panels && c->spmv_algo == 0) return false;
+    if ((A->use_lpanel && c->lpanel && c->spmv_algo == 0) || lflat_on(A)) return false;
+    return A->use_wdia && wd_on(A) && c->spmv_algo == 0 && wd_march_on(A);
+}
+
 int spmv_grid(const sla_csr *A) {
     const sla_ctx *c = A->ctx;
     // with column panels the fused partials are written by the LAST panel pass: its grid is the one that counts
@@ -122,6 +133,8 @@ static int launch_spmv_rp(const sla_csr *A, const SpmvLaunch &l) {
     a.pa_stride = l.pa_stride;
     a.step_begin = l.step_begin;
     a.yinit = l.yinit;
+    a.fs_ap = l.fs_ap;
+    if (l.fs_ap && !(spmv_fuse_s_ok(A) && l.part == 0 && !l.x2 && !l.yinit)) return fail(SLA_ERR_INVALID, "launch_spmv: fused s off the plane-march kernel");
     const int grid = spmv_grid(A);
     // (the forms whose launcher is ONE kernel launched through SLA_KLAUNCH carry the profiling events themselves: the gather kernel of the
     // wave-sliced forms, the wavefront-private CSR kernel -- conditions as in the dispatch below)
@@ -164,6 +177,7 @@ static int launch_spmv_rp(const sla_csr *A, const SpmvLaunch &l) {
 }
 
 int launch_spmv(const sla_csr *A, const SpmvLaunch &l) {
+    if (l.fs_ap && !spmv_fuse_s_ok(A)) return fail(SLA_ERR_INVALID, "launch_spmv: fused s off the plane-march kernel");
     if (tiles_on(A) && !lflat_on(A) && !l.x2 && (!l.yinit || l.tv1 >= 0)) return launch_spmv_tiles(A, l);
     return A->rp64 ? launch_spmv_rp<int64_t>(A, l) : launch_spmv_rp<int32_t>(A, l);
 }

@@ -37,13 +37,20 @@ typedef unsigned long long wdm_u64x8s __attribute__((ext_vector_type(8)));
 constexpr int kMarchBufBytes = 512 * 16;   // one staged window: <= 512 pairs
 
 // WX: the epilogue operand w IS the gathered vector (K3: As . s) and comes from the staged window instead of a global load
-template <int EPI, int NP, bool WX>
+// SF (round 5, BiCGSTAB's K2 folded into K3): the gathered vector does not exist in memory -- it is s = r - alpha Ap (Sparse.hs:975-976),
+// built WHILE the windows are staged: xg is r, a.fs_ap is Ap, alpha = rho / (Ap . r0hat) from K1's partial sums (a.pa) exactly as
+// bicg_k2_kernel forms it (same re-reduction, same division, the same fused multiply-add per element: the staged values are that kernel's
+// bits).  Per step a workgroup loads two windows instead of one and no kernel writes or re-reads s: K2 + K3 streamed 24 n + 25 n bytes,
+// this launch 32 n (r, Ap, r0hat in; As out); the fused K4+K5 sweep rebuilds s from r and Ap, which it reads anyway (bicg_k45_kernel<.., true>).
+template <int EPI, int NP, bool WX, bool SF>
 __global__ void __launch_bounds__(kBlock, 3) spmv_wdia_march_kernel(SpmvArgs<int32_t> a, const wdm_u64x8s *__restrict__ wum, const double *__restrict__ xg,
                                                                     WdMarch m, int32_t grow0, int32_t xlo, int32_t xhi, int xcd_remap, int stream_nt, WdUni uni) {
     __shared__ wd_f64x2 wd_buf[4][512];
     __shared__ double s_red[4];
     const int tid = threadIdx.x;
     double coef = 0.0;
+    double alpha = 0.0;                                // SF: s = r - alpha Ap
+    const double *apg = SF ? a.fs_ap : nullptr;
     const bool w_nt = (stream_nt & 1) != 0;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
@@ -80,15 +87,34 @@ __global__ void __launch_bounds__(kBlock, 3) spmv_wdia_march_kernel(SpmvArgs<int
     // longer count vmcnt and drains it in front of every use.
     long long xbase = 0;                               // tile * 512 + omin - (xlo - 1) + 2 tid, set per task
     const unsigned long long span = (unsigned long long)((long long)xhi - xlo + 1);
-    auto ld = [&](int k, wd_f64x2 &r0, wd_f64x2 &r1) {
+    // (SF: q0 / q1 are the same pairs of Ap; st combines)
+    auto ld = [&](int k, wd_f64x2 &r0, wd_f64x2 &r1, wd_f64x2 &q0, wd_f64x2 &q1) {
         const long long g0 = (long long)k * m.D + xbase;                                   // relative to xlo - 1
         const long long g1 = g0 + (second ? 512 : 0);
-        r0 = *(const wd_f64x2u *)(xg + (xlo - 1) + ((unsigned long long)g0 < span ? g0 : 1));
-        r1 = *(const wd_f64x2u *)(xg + (xlo - 1) + ((unsigned long long)g1 < span ? g1 : 1));
+        const long long o0 = (xlo - 1) + ((unsigned long long)g0 < span ? g0 : 1), o1 = (xlo - 1) + ((unsigned long long)g1 < span ? g1 : 1);
+        r0 = *(const wd_f64x2u *)(xg + o0);
+        r1 = *(const wd_f64x2u *)(xg + o1);
+        if constexpr (SF) {
+            q0 = *(const wd_f64x2u *)(apg + o0);
+            q1 = *(const wd_f64x2u *)(apg + o1);
+        }
     };
-    auto st = [&](int buf, const wd_f64x2 &r0, const wd_f64x2 &r1) {
+    auto st = [&](int buf, wd_f64x2 r0, wd_f64x2 r1, const wd_f64x2 &q0, const wd_f64x2 &q1) {
+        if constexpr (SF) {   // bicg_k2_kernel's expression: one fused multiply-add per element
+            r0.x = __builtin_fma(-alpha, q0.x, r0.x);
+            r0.y = __builtin_fma(-alpha, q0.y, r0.y);
+            r1.x = __builtin_fma(-alpha, q1.x, r1.x);
+            r1.y = __builtin_fma(-alpha, q1.y, r1.y);
+        }
         wd_buf[buf][tid] = r0;
         if (second) wd_buf[buf][tid + 256] = r1;
+    };
+    // SF: alpha as bicg_k2_kernel forms it, once per workgroup (behind the prologue: sc->done has been looked at)
+    auto form_alpha = [&]() {
+        if constexpr (SF) {
+            alpha = a.sc->rho2[(a.step_begin >> 1) & 1] / reduce_parts(a.pa, a.npa, a.pa_stride, s_red);
+            if (blockIdx.x == 0 && tid == 0) a.sc->alpha = alpha;
+        }
     };
     // the epilogue operands of a row pair: one 16-byte load each.  Rows past the end re-read the last pair; the last row of an odd
     // row count is the second element of the pair one row back.
@@ -108,21 +134,23 @@ __global__ void __launch_bounds__(kBlock, 3) spmv_wdia_march_kernel(SpmvArgs<int
         const bool wave_in = tile * 512 + wave * 128 < m.D;
         xbase = (long long)grow0 + (long long)tile * 512 + m.omin - (xlo - 1) + 2 * tid;   // (x is addressed by global column; rows are local)
         wd_f64x2 pa0, pa1, pb0, pb1, r0, r1, wv, zv, wvn, zvn;
-        ld(k0 - 1, pa0, pa1);
-        ld(k0, pb0, pb1);
-        ld(k0 + 1, r0, r1);
+        wd_f64x2 qa0 = {0.0, 0.0}, qa1 = qa0, qb0 = qa0, qb1 = qa0, q0 = qa0, q1 = qa0;
+        ld(k0 - 1, pa0, pa1, qa0, qa1);
+        ld(k0, pb0, pb1, qb0, qb1);
+        ld(k0 + 1, r0, r1, q0, q1);
         load_operands(k0 * m.D + pos, wv, zv);
 
         if (first) {
             // (the prologue's loads -- solver scalars, partials -- share the round trip of the first windows)
             if (!spmv_prologue<EPI, int32_t>(a, s_red, coef)) return;
+            form_alpha();
             first = false;
         } else {
             __syncthreads();                                     // the previous task's last fold has read its buffers
         }
-        st(3, pa0, pa1);
-        st(0, pb0, pb1);
-        st(1, r0, r1);
+        st(3, pa0, pa1, qa0, qa1);
+        st(0, pb0, pb1, qb0, qb1);
+        st(1, r0, r1, q0, q1);
         __builtin_amdgcn_s_waitcnt(0x0f70);                      // vmcnt(0): the loop is entered with nothing in flight
         __syncthreads();
         const wdm_u64x8s *wm = wum + 2 * (((size_t)tile * (size_t)m.planes + (size_t)k0) * 4 + (size_t)wave);
@@ -135,7 +163,7 @@ __global__ void __launch_bounds__(kBlock, 3) spmv_wdia_march_kernel(SpmvArgs<int
                 const int row = kk * m.D + pos;
                 // issued first and in flight together while this step is folded out of LDS: the window of plane kk + 2 (the last
                 // steps of a run re-load plane k1, cache hits), the operands of step i + 1, this step's masks
-                ld(min(kk + 2, k1), r0, r1);
+                ld(min(kk + 2, k1), r0, r1, q0, q1);
                 load_operands(row + m.D, wvn, zvn);
                 __builtin_amdgcn_sched_barrier(0);
                 wdm_u64x8s me = {}, mo = {};
@@ -169,7 +197,7 @@ __global__ void __launch_bounds__(kBlock, 3) spmv_wdia_march_kernel(SpmvArgs<int
                 // everything issued at the top is here now; the wait stands in front of this step's y store (vmcnt counts stores
                 // too: behind it, every step would sit out the store's acknowledgement)
                 __builtin_amdgcn_s_waitcnt(0x0f70);              // vmcnt(0)
-                st((u + 2) & 3, r0, r1);                         // plane kk + 2: read from step i + 1 on
+                st((u + 2) & 3, r0, r1, q0, q1);                 // plane kk + 2: read from step i + 1 on
                 if (va) {
                     if (row + 1 == a.rows && row > 0) {          // the last row of an odd row count (load_operands)
                         if constexpr (!WX) wv.x = wv.y;          // (the window holds the row's own pair)
@@ -185,6 +213,7 @@ __global__ void __launch_bounds__(kBlock, 3) spmv_wdia_march_kernel(SpmvArgs<int
     }
     if (first) {
         if (!spmv_prologue<EPI, int32_t>(a, s_red, coef)) return;
+        form_alpha();   // (workgroup 0 always has a task; the others' value is not used)
     }
     if constexpr (EPI == EPI_DOT || EPI == EPI_DOT2 || EPI == EPI_DOT4 || EPI == EPI_RES || EPI == EPI_AXPY_DOT || EPI == EPI_XPBY_NRM) {
         const double s1 = block_sum(acc1, s_red);
@@ -210,11 +239,11 @@ int wd_march_grid(const sla_csr *A) {
 // 71 us where 56 us suffice -- so its tasks are re-cut for 3 per CU at launch: fewer, longer runs; the workgroups beyond them write
 // their zero partial sums and leave (the grid, which the consumers of the partial sums know, stays).  The masks are indexed by
 // (tile, plane), not by run: any cut works.
-template <int EPI, int NP, bool WX>
+template <int EPI, int NP, bool WX, bool SF = false>
 static int march_occupancy() {
     static const int occ = [] {
         hipFuncAttributes at;
-        if (hipFuncGetAttributes(&at, (const void *)spmv_wdia_march_kernel<EPI, NP, WX>) != hipSuccess) { (void)hipGetLastError(); return 3; }
+        if (hipFuncGetAttributes(&at, (const void *)spmv_wdia_march_kernel<EPI, NP, WX, SF>) != hipSuccess) { (void)hipGetLastError(); return 3; }
         return at.numRegs > 128 ? 3 : 4;
     }();
     return occ;
@@ -233,22 +262,32 @@ static WdMarch march_cut(const sla_csr *A, int occ) {
 template <int EPI>
 static int launch_epi(const sla_csr *A, const SpmvArgs<int32_t> &a, int grid, int stream_nt) {
     sla_ctx *c = A->ctx;
-#define SLA_WDM_LAUNCH(NP_, WX_)                                                                                                         \
-    hipLaunchKernelGGL((spmv_wdia_march_kernel<EPI, NP_, WX_>), dim3(grid), dim3(kBlock), 0, stream_of(c), a, (const wdm_u64x8s *)A->d_wum_m, \
-                       a.x, march_cut(A, march_occupancy<EPI, NP_, WX_>()), (int32_t)A->row_begin, A->wd_col_lo, A->wd_col_hi + 1, c->xcd_remap, stream_nt, \
+#define SLA_WDM_LAUNCH(NP_, WX_, SF_)                                                                                                    \
+    hipLaunchKernelGGL((spmv_wdia_march_kernel<EPI, NP_, WX_, SF_>), dim3(grid), dim3(kBlock), 0, stream_of(c), a, (const wdm_u64x8s *)A->d_wum_m, \
+                       a.x, march_cut(A, march_occupancy<EPI, NP_, WX_, SF_>()), (int32_t)A->row_begin, A->wd_col_lo, A->wd_col_hi + 1, c->xcd_remap, stream_nt, \
                        A->wd_muni)
     constexpr bool kMayWX = EPI == EPI_DOT || EPI == EPI_DOT2 || EPI == EPI_DOT4;
     const bool wx = kMayWX && a.w == a.x + A->row_begin;   // (w holds local rows, x is addressed by global column)
     if (A->wd_muni.n != 5 && A->wd_muni.n != 7) return fail(SLA_ERR_INVALID, "launch_wdia_march: 5 or 7 pairs");
+    if (a.fs_ap) {   // K2 folded into K3: the gathered vector is built from r (= a.x) and Ap while the windows are staged
+        if constexpr (EPI == EPI_DOT4) {
+            if (!a.sc || !a.pa || A->row_begin != 0) return fail(SLA_ERR_INVALID, "launch_wdia_march: fused s needs the solver scalars and K1's partial sums");
+            if (A->wd_muni.n == 5) SLA_WDM_LAUNCH(5, true, true);
+            else SLA_WDM_LAUNCH(7, true, true);
+            SLA_HIP_TRY(hipGetLastError());
+            return SLA_OK;
+        }
+        return fail(SLA_ERR_INVALID, "launch_wdia_march: fused s is defined for the four-sum epilogue only");
+    }
     if constexpr (kMayWX) {
         if (wx) {
-            if (A->wd_muni.n == 5) SLA_WDM_LAUNCH(5, true);
-            else SLA_WDM_LAUNCH(7, true);
+            if (A->wd_muni.n == 5) SLA_WDM_LAUNCH(5, true, false);
+            else SLA_WDM_LAUNCH(7, true, false);
         }
     }
     if (!wx) {
-        if (A->wd_muni.n == 5) SLA_WDM_LAUNCH(5, false);
-        else SLA_WDM_LAUNCH(7, false);
+        if (A->wd_muni.n == 5) SLA_WDM_LAUNCH(5, false, false);
+        else SLA_WDM_LAUNCH(7, false, false);
     }
 #undef SLA_WDM_LAUNCH
     SLA_HIP_TRY(hipGetLastError());
@@ -263,6 +302,10 @@ static void march_prepare_epi() {
     if constexpr (EPI == EPI_DOT || EPI == EPI_DOT2 || EPI == EPI_DOT4) {
         (void)march_occupancy<EPI, 5, true>();
         (void)march_occupancy<EPI, 7, true>();
+    }
+    if constexpr (EPI == EPI_DOT4) {
+        (void)march_occupancy<EPI, 5, true, true>();
+        (void)march_occupancy<EPI, 7, true, true>();
     }
 }
 void wd_march_prepare() {

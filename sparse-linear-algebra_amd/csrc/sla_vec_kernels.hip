@@ -198,10 +198,13 @@ __global__ void __launch_bounds__(kBlock) bicg_k4_kernel(int64_t n, SolverScalar
 // eps (|s| + |omega| |As|) . |r0hat| either way: the elementwise r_{j+1} = s - omega As carries the same cancellation).  Eight
 // vector passes (p, s, As, x, Ap in; x, r, p out) instead of seven + four, and the r0hat pass moves into K3: 16 instead of 19
 // passes per step.
-template <bool NT>
+// FS (round 5, K2 folded into K3 -- spmv_wdia_march_kernel<.., SF>): s was never stored.  It is rebuilt here as r - alpha Ap from the old r
+// (read in place of s: the same five input streams) and Ap, with bicg_k2_kernel's fused multiply-add: the bits the SpMV gathered.
+template <bool NT, bool FS>
 __global__ void __launch_bounds__(kBlock) bicg_k45_kernel(int64_t n, SolverScalars *sc, Parts ass, Parts asas, Parts tr0, Parts sr0,
                                                            int par, const double *s, const double *as, const double *ap, double *x,
                                                            double *r, double *p, int pol) {
+    if constexpr (FS) s = r;
     __shared__ double s_red[16];
     // the four sums, the scalars and the first element pairs of the five input vectors are issued together (see bicg_k2_kernel)
     const int64_t n2 = n >> 1, gs = (int64_t)gridDim.x * kBlock, i0 = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -229,6 +232,10 @@ __global__ void __launch_bounds__(kBlock) bicg_k45_kernel(int64_t n, SolverScala
     }
     for (int64_t i2 = i0; i2 < n2; i2 += gs) {
         if (i2 != i0) { sv = ldpol(s, i2, pol, 3); av = ldpol(as, i2, pol, 4); vv = ldpol(ap, i2, pol, 5); pv = ldpol(p, i2, pol, 6); xv = ldpol(x, i2, pol, 7); }
+        if constexpr (FS) {
+            sv.x = __builtin_fma(-alpha, vv.x, sv.x);
+            sv.y = __builtin_fma(-alpha, vv.y, sv.y);
+        }
         xv.x = (xv.x + alpha * pv.x) + omega * sv.x;
         xv.y = (xv.y + alpha * pv.y) + omega * sv.y;
         stpol(x, i2, xv, pol, 8);   // (default past the caches: nobody reads x before the next step's sweep)
@@ -240,8 +247,9 @@ __global__ void __launch_bounds__(kBlock) bicg_k45_kernel(int64_t n, SolverScala
     }
     if (SLA_HAS_TAIL(n)) {
         const int64_t i = n - 1;
-        x[i] = (x[i] + alpha * p[i]) + omega * s[i];
-        const double rv = s[i] - omega * as[i];
+        const double si = FS ? __builtin_fma(-alpha, ap[i], r[i]) : s[i];
+        x[i] = (x[i] + alpha * p[i]) + omega * si;
+        const double rv = si - omega * as[i];
         r[i] = rv;
         p[i] = rv + beta * (p[i] - omega * ap[i]);
     }
@@ -299,10 +307,15 @@ int launch_bicg_k5(sla_ctx *c, int64_t n, SolverScalars *sc, Parts rhonew, int p
 int launch_bicg_k45(sla_ctx *c, int64_t n, SolverScalars *sc, Parts ass, Parts asas, Parts tr0, Parts sr0, int par, const double *s,
                     const double *as, const double *ap, double *x, double *r, double *p) {
     ProfScope prof(c, SLA_KERNEL_BICG_K45, true);
-    if (vec_stream_nt(c, n))
-        SLA_KLAUNCH(c, bicg_k45_kernel<true>, dim3(vec_grid(n)), dim3(kBlock), 0, stream_of(c), n, sc, ass, asas, tr0, sr0, par, s, as, ap, x, r, p, c->vec_policy);
+    if (!s) {   // (K2 folded into K3: s is rebuilt from r and ap)
+        if (vec_stream_nt(c, n))
+            SLA_KLAUNCH(c, (bicg_k45_kernel<true, true>), dim3(vec_grid(n)), dim3(kBlock), 0, stream_of(c), n, sc, ass, asas, tr0, sr0, par, s, as, ap, x, r, p, c->vec_policy);
+        else
+            SLA_KLAUNCH(c, (bicg_k45_kernel<false, true>), dim3(vec_grid(n)), dim3(kBlock), 0, stream_of(c), n, sc, ass, asas, tr0, sr0, par, s, as, ap, x, r, p, 0);
+    } else if (vec_stream_nt(c, n))
+        SLA_KLAUNCH(c, (bicg_k45_kernel<true, false>), dim3(vec_grid(n)), dim3(kBlock), 0, stream_of(c), n, sc, ass, asas, tr0, sr0, par, s, as, ap, x, r, p, c->vec_policy);
     else
-        SLA_KLAUNCH(c, bicg_k45_kernel<false>, dim3(vec_grid(n)), dim3(kBlock), 0, stream_of(c), n, sc, ass, asas, tr0, sr0, par, s, as, ap, x, r, p, 0);
+        SLA_KLAUNCH(c, (bicg_k45_kernel<false, false>), dim3(vec_grid(n)), dim3(kBlock), 0, stream_of(c), n, sc, ass, asas, tr0, sr0, par, s, as, ap, x, r, p, 0);
     SLA_HIP_TRY(hipGetLastError());
     return SLA_OK;
 }

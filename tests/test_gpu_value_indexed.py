@@ -379,6 +379,52 @@ def test_plane_march_form_step_for_step_against_the_oracle(sla):
     ctx.close()
 
 
+@pytest.mark.parametrize("name", list(_march_cases()))
+@pytest.mark.parametrize("grid", [0, 8])
+def test_plane_march_k2_folded_into_k3_same_bits(sla, name, grid):
+    """BiCGSTAB on the plane-march form, one rank: K2 (alpha ; s = r - alpha Ap, Sparse.hs:975-976) is folded into K3 -- s is built while
+    the x windows are staged and never stored, the fused K4 + K5 sweep rebuilds it from r and Ap (option bicg_fuse23, default 1).  Same
+    alpha, same multiply-add, same fold: x, r, p after 1, 2 and 7 steps are bit-identical to the four-launch flow, the kernel table shows
+    three launches per step, and linSolve0 returns the same iterate."""
+    from sla_amd import _lib
+    dims, csr = _march_cases()[name]
+    n = dims[0]
+    Ao = _oracle_csr(dims, csr)
+    b = orc.spmv(Ao, np.linspace(-1.0, 2.0, n))
+    x0 = np.full(n, 0.25)
+    states, sols, launches = {}, {}, {}
+    for f23 in (1, 0):
+        ctx = sla.Context(0).set_options(wd_lds=2, wd_march=2, bicg_fuse23=f23)
+        if grid:
+            ctx.set_option("spmv_grid", grid)
+        A = sla.fromCSR(dims, *csr, ctx)
+        assert "wdia+march" in A.kernel_info().split()[0], A.kernel_info()
+        st = sla.bicgsInit(A, sla.fromVector(b, ctx), sla.fromVector(x0, ctx))
+        snaps = []
+        ctx.prof_start(_lib.KERNEL_ALL, 64)
+        for k in (1, 1, 5):
+            st.step(k)
+            snaps.append([v.toDenseListSV().copy() for v in (st._xBicgstab, st._rBicgstab, st._pBicgstab)])
+        ctx.prof_stop()
+        launches[f23] = (ctx.prof_query(_lib.KERNEL_BICG_K2)[0], ctx.prof_query(_lib.KERNEL_SPMV_DOT2)[0], ctx.prof_query(_lib.KERNEL_BICG_K45)[0])
+        states[f23] = snaps
+        xs, info = sla.linSolve0(sla.BICGSTAB_, A, sla.fromVector(b, ctx), sla.fromVector(x0, ctx), return_info=True)
+        sols[f23] = (xs.toDenseListSV(), info["iters"], info["resnorm"])
+        del A, st
+        ctx.close()
+    assert launches[1] == (0, 7, 7) and launches[0] == (7, 7, 7), launches
+    for a, c in zip(states[1], states[0]):
+        for u, v in zip(a, c):
+            assert np.array_equal(u.view(np.uint64), v.view(np.uint64)), (name, grid, np.abs(u - v).max())
+    assert sols[1][1] == sols[0][1] and sols[1][2] == sols[0][2], (sols[1][1:], sols[0][1:])
+    assert np.array_equal(sols[1][0].view(np.uint64), sols[0][0].view(np.uint64))
+    # and against the oracle's two steps (the reference's expressions: mul then subtract -- tolerance as in the test above)
+    so = orc.BicgstabState(Ao, b, x0)
+    so.step(b - orc.spmv(Ao, x0), 2)
+    for got, want in zip(states[1][1], (so.x, so.r, so.p)):
+        assert np.linalg.norm(got - want) <= 1e-11 * np.linalg.norm(want)
+
+
 def test_plane_march_randomised_patterns(sla):
     """40 seeded random 5- / 7-pair stencils with one pair at -D and one at +D (D even, 1024..3000; in-plane offsets up to +-254: a window of at most 512 pairs; row
     counts that are not multiples of D; random holes; several values share no offset): the march form must be taken, and (#>), (<#)

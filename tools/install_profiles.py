@@ -74,9 +74,11 @@ for w, fname, bench in (("laplace3d_10m", tag + "_bench_pmc_counters.txt", tag +
                     r0, w0 = bytes_of(cs[pre[0]])
                     r1, w1 = bytes_of(cs[fin[0]])
                     rd, wr, parts = r0 + r1, w0 + w1, [pre[0], fin[0]]
+        if kid == "K3" and "K23" in rec.get("kernels", {}) and "K3" not in rec.get("kernels", {}):
+            kid = "K23"   # (bicg_fuse23: K2 folded into the plane-march K3)
         krec = rec.get("kernels", {}).get(kid, {})
         traffic["%s/step/n1/%s" % (w, kid)] = {
-            "kernel": " + ".join(p.replace("void ", "")[:100] for p in parts), "kernel_algo": algo if kid in ("K1", "K3") else "",
+            "kernel": " + ".join(p.replace("void ", "")[:100] for p in parts), "kernel_algo": algo if kid in ("K1", "K3", "K23") else "",
             "read_bytes": int(rd), "write_bytes": int(wr), "traffic_bytes": int(rd + wr),
             "bytes_streamed_by_design": krec.get("bytes"), "csr_bytes": krec.get("csr_bytes"),
             "l2_hit": cs[names[0]].get("TCC_HIT_sum", (0, None))[1], "l2_miss": cs[names[0]].get("TCC_MISS_sum", (0, None))[1],

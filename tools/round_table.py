@@ -43,7 +43,7 @@ if d:
     cb = d.get("cpu_baseline", {})
     e = d.get("end_to_end", {})
     print(row("4 (10 M 7-pt, 216³) bicgstabStep — the driver's command", d,
-              f"K2 {kern(d, 'K2')}; K3 {kern(d, 'K3')}; K45 {kern(d, 'K45')}; measured stream ceiling {d.get('hbm_measured_ceiling_gbps', 0) / 1e3:.2f} TB/s"))
+              (f"K23 (K2 folded into K3) {kern(d, 'K23')}" if 'K23' in (d.get('kernels') or {}) else f"K2 {kern(d, 'K2')}; K3 {kern(d, 'K3')}") + f"; K45 {kern(d, 'K45')}; measured stream ceiling {d.get('hbm_measured_ceiling_gbps', 0) / 1e3:.2f} TB/s"))
     g = d.get("general_csr") or {}
     if g.get("value"):
         ks = g["kernels"]
