@@ -814,7 +814,7 @@ struct SpmvLaunch {
     int tlast = 1;                              // ... 0: not the last pass -- the running row sums go to y, no epilogue
     const double *fs_ap = nullptr;              // BiCGSTAB's K2 folded into K3 (spmv_fuse_s_ok): gather from s = x - alpha fs_ap, alpha = rho / sum(pa)
 };
-bool spmv_fuse_s_ok(const sla_csr *A);          // would a whole-matrix (#>) on A run the plane-march kernel, on one rank?
+bool spmv_fuse_s_ok(const sla_csr *A, bool slab = false);   // would a whole-matrix (slab: whole-slab) (#>) on A run the plane-march kernel?
 int spmv_grid(const sla_csr *A);  // number of blocks (= partial slots written) of an SpMV launch on A
 int launch_spmv(const sla_csr *A, const SpmvLaunch &l);
 // exchange the input vector of a (#>) and launch it; on row-sharded contexts the interior rows run while the halo is in flight.

@@ -170,7 +170,10 @@ static int enqueue_bicgstab_ghost(sla_solver *S, int par, const Parts *check) {
         SLA_TRY(launch_spmv(A, l));
         SLA_TRY(publish_with_halo(S, P_APR, -1, g, &apr, nullptr, S->t1));
     }
-    SLA_TRY(launch_bicg_k2(c, next, S->d_sc, apr, par, Parts{nullptr, 0, 1}, 0, S->r->d - gl, S->t1->d - gl, S->t2->d - gl));
+    // (K2 folded into K3 where the whole-slab launch runs the plane-march kernel -- see enqueue_bicgstab: r and Ap are valid on the ghost
+    // rows, so the staged windows and the sweep's rebuilt s hold there what K2 would have written)
+    const bool fuse23 = c->bicg_fuse23 != 0 && c->bicg_fuse45 != 0 && spmv_fuse_s_ok(A, true);
+    if (!fuse23) SLA_TRY(launch_bicg_k2(c, next, S->d_sc, apr, par, Parts{nullptr, 0, 1}, 0, S->r->d - gl, S->t1->d - gl, S->t2->d - gl));
     {
         SpmvLaunch l;  // K3: aasj = aa #> sj ; aasj <.> sj ; aasj <.> aasj      (halo(s) was computed by K2)
         l.epi = EPI_DOT2;
@@ -190,10 +193,19 @@ static int enqueue_bicgstab_ghost(sla_solver *S, int par, const Parts *check) {
             l.z = S->r0hat->d;
             l.p3 = slot(S, P_TR0);
             l.p4 = slot(S, P_SR0);
+            if (fuse23) {
+                l.x = S->r->d - b;
+                l.fs_ap = S->t1->d - b;
+                l.w = nullptr;
+                l.pa = apr.p;
+                l.npa = apr.n;
+                l.pa_stride = apr.stride;
+                l.step_begin = par << 1;
+            }
             SLA_TRY(launch_spmv(A, l));
             Parts q[4];
             SLA_TRY(publish4(S, g, q, S->t3));
-            return launch_bicg_k45(c, next, S->d_sc, q[0], q[1], q[2], q[3], par, S->t2->d - gl, S->t3->d - gl, S->t1->d - gl, S->x->d - gl,
+            return launch_bicg_k45(c, next, S->d_sc, q[0], q[1], q[2], q[3], par, fuse23 ? nullptr : S->t2->d - gl, S->t3->d - gl, S->t1->d - gl, S->x->d - gl,
                                    S->r->d - gl, S->p->d - gl);
         }
         SLA_TRY(launch_spmv(A, l));

@@ -37,9 +37,10 @@ bool wave_plain(const sla_csr *A) {
 
 // BiCGSTAB's K2 folded into K3 (SpmvLaunch::fs_ap): one rank, and the whole-matrix launch lands on the plane-march kernel -- the
 // conditions of the dispatch below, in its order
-bool spmv_fuse_s_ok(const sla_csr *A) {
+bool spmv_fuse_s_ok(const sla_csr *A, bool slab) {
     const sla_ctx *c = A->ctx;
-    if (c->collectives || A->rp64 || A->row_begin != 0 || A->is_panel_view) return false;
+    // (slab: the whole-slab launches of the ghost-row flow -- r and Ap are valid on the ghost rows, x is addressed by global column)
+    if ((!slab && (c->collectives || A->row_begin != 0)) || A->rp64 || A->is_panel_view) return false;
     if (tiles_on(A) && !lflat_on(A)) return false;
     if (!A->panels.empty() && c->panels && c->spmv_algo == 0) return false;
     if ((A->use_lpanel && c->lpanel && c->spmv_algo == 0) || lflat_on(A)) return false;
@@ -134,7 +135,7 @@ static int launch_spmv_rp(const sla_csr *A, const SpmvLaunch &l) {
     a.step_begin = l.step_begin;
     a.yinit = l.yinit;
     a.fs_ap = l.fs_ap;
-    if (l.fs_ap && !(spmv_fuse_s_ok(A) && l.part == 0 && !l.x2 && !l.yinit)) return fail(SLA_ERR_INVALID, "launch_spmv: fused s off the plane-march kernel");
+    if (l.fs_ap && !(spmv_fuse_s_ok(A, true) && l.part == 0 && !l.x2 && !l.yinit)) return fail(SLA_ERR_INVALID, "launch_spmv: fused s off the plane-march kernel");
     const int grid = spmv_grid(A);
     // (the forms whose launcher is ONE kernel launched through SLA_KLAUNCH carry the profiling events themselves: the gather kernel of the
     // wave-sliced forms, the wavefront-private CSR kernel -- conditions as in the dispatch below)
@@ -177,7 +178,7 @@ static int launch_spmv_rp(const sla_csr *A, const SpmvLaunch &l) {
 }
 
 int launch_spmv(const sla_csr *A, const SpmvLaunch &l) {
-    if (l.fs_ap && !spmv_fuse_s_ok(A)) return fail(SLA_ERR_INVALID, "launch_spmv: fused s off the plane-march kernel");
+    if (l.fs_ap && !spmv_fuse_s_ok(A, true)) return fail(SLA_ERR_INVALID, "launch_spmv: fused s off the plane-march kernel");
     if (tiles_on(A) && !lflat_on(A) && !l.x2 && (!l.yinit || l.tv1 >= 0)) return launch_spmv_tiles(A, l);
     return A->rp64 ? launch_spmv_rp<int64_t>(A, l) : launch_spmv_rp<int32_t>(A, l);
 }

@@ -271,7 +271,7 @@ static int launch_epi(const sla_csr *A, const SpmvArgs<int32_t> &a, int grid, in
     if (A->wd_muni.n != 5 && A->wd_muni.n != 7) return fail(SLA_ERR_INVALID, "launch_wdia_march: 5 or 7 pairs");
     if (a.fs_ap) {   // K2 folded into K3: the gathered vector is built from r (= a.x) and Ap while the windows are staged
         if constexpr (EPI == EPI_DOT4) {
-            if (!a.sc || !a.pa || A->row_begin != 0) return fail(SLA_ERR_INVALID, "launch_wdia_march: fused s needs the solver scalars and K1's partial sums");
+            if (!a.sc || !a.pa) return fail(SLA_ERR_INVALID, "launch_wdia_march: fused s needs the solver scalars and K1's partial sums");
             if (A->wd_muni.n == 5) SLA_WDM_LAUNCH(5, true, true);
             else SLA_WDM_LAUNCH(7, true, true);
             SLA_HIP_TRY(hipGetLastError());

@@ -109,6 +109,22 @@ def test_sharded_path_with_the_plane_march(kind, nranks):
     assert "wdia+march" in out.stdout, out.stdout[-3000:]
 
 
+@pytest.mark.parametrize("nranks", [2, 3])
+def test_k2_folded_into_k3_on_row_slabs_same_bits(nranks):
+    """bicg_fuse23 on the ghost-row flow: where the whole-slab K3 runs the plane-march kernel, s = r - alpha Ap is built in the staged
+    windows (ghost planes included: r and Ap are valid there) and the fused K4+K5 sweep rebuilds it on own + ghost rows -- the solution
+    must be BIT-identical to the flow with K2 as a launch of its own, same iteration count."""
+    got = {}
+    for f23 in ("1", "0"):
+        env = dict(os.environ, SLA_WD_LDS="2", SLA_WD_MARCH="2", SLA_BICG_FUSE23=f23, SLA_DEBUG_EXCHANGE="1")
+        out = subprocess.run([sys.executable, os.path.join(HERE, "_loopback_worker.py"), str(nranks), "laplace_big"], env=env,
+                             stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+        assert out.returncode == 0 and f"LOOPBACK_OK {nranks} laplace_big" in out.stdout, out.stdout[-3000:]
+        assert "wdia+march" in out.stdout and "ghost-row BiCGSTAB" in out.stdout, out.stdout[-3000:]
+        got[f23] = [l for l in out.stdout.splitlines() if l.startswith("XHASH")]
+    assert got["1"] and got["1"] == got["0"], got
+
+
 @pytest.mark.parametrize("kind,nranks", [("laplace", 3), ("laplace", 8), ("tiny", 4), ("tinyband", 16), ("banded", 2), ("denseband", 4), ("fuzz2", 3), ("fuzz5", 2), ("random", 2)])
 def test_ghost_row_bicgstab_and_cgs_equal_the_plain_sharded_flow(kind, nranks):
     """Sharded BiCGSTAB keeps r, p, Ap and s valid on the ghost rows and needs 3 grouped exchanges per step instead of 5
