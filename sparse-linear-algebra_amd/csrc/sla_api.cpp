@@ -483,7 +483,7 @@ const IntKnob kIntKnobs[] = {
     {"bicg_ghost", &sla_ctx::bicg_ghost, 0, 1},
     {"wd_tile", &sla_ctx::wd_tile, -1, 1 << 20},
     {"bicg_fuse45", &sla_ctx::bicg_fuse45, 0, 1},
-    {"bicg_fuse23", &sla_ctx::bicg_fuse23, 0, 1},
+    {"bicg_fuse23", &sla_ctx::bicg_fuse23, 0, 2},
     {"wd_lds", &sla_ctx::wd_lds, 0, 2},
     {"wd_lds_occ", &sla_ctx::wd_lds_occ, 0, 4},
     {"wd_march", &sla_ctx::wd_march, 0, 2},

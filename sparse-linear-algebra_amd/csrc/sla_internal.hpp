@@ -281,7 +281,7 @@ struct sla_ctx {
     int64_t mall_bytes = 256ll << 20; // capacity of the memory-side cache (MI355X: 256 MiB)
     int wdia_vv = 1;                 // allow the variable-coefficient wave-sliced form (SLA_WDIA_VV=0 disables)
     int wd_grid_max_vv = sla::kWdBlocksPerCuVV * 256;
-    int bicg_fuse23 = 1;             // ... and K2 folded into K3 where the plane-march kernel runs it: s = r - alpha Ap is built in the staged windows, never stored (SLA_BICG_FUSE23)
+    int bicg_fuse23 = 1;             // ... and K2 folded into K3 on the wave-sliced forms (plane march: s = r - alpha Ap built in the staged windows; gather kernel up to 4 M rows: r and Ap gathered), never stored (SLA_BICG_FUSE23; 2: the gather kernel at any size)
     int bicg_fuse45 = 1;             // single-rank BiCGSTAB: K4 + K5 in one sweep, rho through K3's extra sums (SLA_BICG_FUSE45)
     int wd_lds = 1;                  // stencils with <= 8 (offset, value) pairs: uniform records + x windows staged in LDS (SLA_WD_LDS; 2: at any size)
     int wd_nt_store = 0;             // its y / z stores past the caches (SLA_WD_NT_STORE)

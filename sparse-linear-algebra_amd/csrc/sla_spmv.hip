@@ -44,7 +44,12 @@ bool spmv_fuse_s_ok(const sla_csr *A, bool slab) {
     if (tiles_on(A) && !lflat_on(A)) return false;
     if (!A->panels.empty() && c->panels && c->spmv_algo == 0) return false;
     if ((A->use_lpanel && c->lpanel && c->spmv_algo == 0) || lflat_on(A)) return false;
-    return A->use_wdia && wd_on(A) && c->spmv_algo == 0 && wd_march_on(A);
+    if (!(A->use_wdia && wd_on(A) && c->spmv_algo == 0)) return false;
+    if (wd_march_on(A)) return true;
+    // the gather kernel of the wave-sliced forms (spmv_wdia_kernel<.., SF>: every gather loads r AND Ap) where the two vectors stay in the
+    // caches -- 4 M rows = 2 x 32 MB; beyond that the doubled gathers cost more than the 24 n-byte pass they save (bicg_fuse23 = 2: always)
+    if (wd_lds_on(A)) return false;                    // (the three-window kernel has no such variant: round 2's probe, LABNOTES L7)
+    return c->bicg_fuse23 == 2 || A->rows <= ((int64_t)1 << 22);
 }
 
 int spmv_grid(const sla_csr *A) {

@@ -70,8 +70,14 @@ __device__ __forceinline__ double wd_lane_f64(double x, int k) {
 // VV: variable coefficients -- a record carries no scalar value but a block of 128 values laid out like the slice's
 // rows (wvblk), fetched with one more 16-byte load per lane; everything else is shared.
 // (VV with the four-sum epilogue: one workgroup per CU less -- 108 VGPRs and no scratch instead of 96 + 44 B of spills per lane)
-template <int EPI, bool VV>
-__global__ void __launch_bounds__(kBlock, VV ? (EPI == EPI_DOT4 ? kWdBlocksPerCuVV4 : kWdBlocksPerCuVV) : kWdBlocksPerCu) spmv_wdia_kernel(SpmvArgs<int32_t> a, const int32_t *__restrict__ sptr,
+// SF (round 5): BiCGSTAB's K2 folded into K3 -- the gathered vector is s = r - alpha Ap and is never stored: every gather loads the row
+// pair of r (xg) AND of Ap (a.fs_ap) and the fold combines them with bicg_k2_kernel's multiply-add (alpha formed like there, from K1's
+// partial sums a.pa); As . s takes s for the own rows the same way.  Twice the gathers (cache hits at the sizes this kernel serves), one
+// launch and a 24 n-byte pass less per step; the K4+K5 sweep rebuilds s from r and Ap (bicg_k45_kernel<.., true>).  Eight more row pairs in
+// registers: compiled for 4 (VV: 3) workgroups per CU, the surplus of the grid leaves at once (`active`).
+constexpr int kWdBlocksPerCuSF = 4, kWdBlocksPerCuSFVV = 3;
+template <int EPI, bool VV, bool SF = false>
+__global__ void __launch_bounds__(kBlock, SF ? (VV ? kWdBlocksPerCuSFVV : kWdBlocksPerCuSF) : VV ? (EPI == EPI_DOT4 ? kWdBlocksPerCuVV4 : kWdBlocksPerCuVV) : kWdBlocksPerCu) spmv_wdia_kernel(SpmvArgs<int32_t> a, const int32_t *__restrict__ sptr,
                                                                const unsigned long long *__restrict__ wme,
                                                                const unsigned long long *__restrict__ wmo,
                                                                const double *__restrict__ wval, const int32_t *__restrict__ woff,
@@ -80,6 +86,14 @@ __global__ void __launch_bounds__(kBlock, VV ? (EPI == EPI_DOT4 ? kWdBlocksPerCu
     __shared__ double s_red[4];
     const int tid = threadIdx.x;
     double coef = 0.0;   // (set by the prologue, which runs BEHIND the first descriptor / record loads: see below)
+    double alpha = 0.0;  // SF: s = r - alpha Ap
+    const double *apg = SF ? a.fs_ap : nullptr;
+    auto form_alpha = [&]() {   // as bicg_k2_kernel forms it (behind the prologue: sc->done has been looked at)
+        if constexpr (SF) {
+            alpha = a.sc->rho2[(a.step_begin >> 1) & 1] / reduce_parts(a.pa, a.npa, a.pa_stride, s_red);
+            if (blockIdx.x == 0 && tid == 0) a.sc->alpha = alpha;
+        }
+    };
     const bool w_nt = stream_nt && a.w != xg + grow0;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
@@ -122,13 +136,15 @@ __global__ void __launch_bounds__(kBlock, VV ? (EPI == EPI_DOT4 ? kWdBlocksPerCu
     struct Stage {
         wd_f64x2 xv[8];
         wd_f64x2 vv[VV ? 8 : 1];    // VV: the row pair's two values of record k
+        wd_f64x2 qv[SF ? 8 : 1];    // SF: the same row pairs of Ap
+        wd_f64x2 qw;                // SF: Ap on the lane's own rows
         wd_f64x2 wv, zv;
         unsigned long long me, mo;  // lane k: masks of record k
         double v;                   // lane k: value of record k
         int blk, e0, cnt;
     };
     // gathers of the 8 records held by lanes 0..7 of `r` (first record e0) for the row pair starting at `row`
-    auto gather8 = [&](const WdRec &r, int e0, int row, wd_f64x2 *xv, wd_f64x2 *vv) {
+    auto gather8 = [&](const WdRec &r, int e0, int row, wd_f64x2 *xv, wd_f64x2 *vv, wd_f64x2 *qv) {
         // byte offset of x[global row]; a record's diagonal offset moves the scalar base instead
         const uint32_t g8 = (uint32_t)(grow0 + row) * 8u;
 #pragma unroll
@@ -139,6 +155,7 @@ __global__ void __launch_bounds__(kBlock, VV ? (EPI == EPI_DOT4 ? kWdBlocksPerCu
             // loaded and ignored; at the two ends of x it lies in the guard slack (guard_malloc).
             if (__builtin_amdgcn_inverse_ballot_w64(mb)) {
                 xv[k] = *(const wd_f64x2u *)((const char *)(xg + ok) + g8);
+                if constexpr (SF) qv[k] = *(const wd_f64x2u *)((const char *)(apg + ok) + g8);
                 if (VV) vv[k] = *(const wd_f64x2 *)(wvblk + ((size_t)(e0 + k) << 7) + 2 * lane);
             }
         }
@@ -188,44 +205,71 @@ __global__ void __launch_bounds__(kBlock, VV ? (EPI == EPI_DOT4 ? kWdBlocksPerCu
         for (int k = 0; k < 8; ++k) {  // "defined" without an instruction: a lane that does not load holds garbage,
             asm("" : "=v"(st.xv[k]));  // which EXEC never lets the fold use
             if (VV) asm("" : "=v"(st.vv[k]));
+            if (SF) asm("" : "=v"(st.qv[k]));
         }
+        st.qw = wd_f64x2{0.0, 0.0};
         if (cnt < 0) return;
         const int row = (blk * 4 + wave) * 128 + 2 * lane;  // this lane's rows: row, row + 1
         const bool va = row < a.rows, vb = row + 1 < a.rows;
+        if constexpr (SF) {   // w = s on the own rows: r and Ap there (the gathers' lines)
+            if (vb) {
+                st.wv = *(const wd_f64x2u *)(xg + grow0 + row);
+                st.qw = *(const wd_f64x2u *)(apg + grow0 + row);
+            } else if (va) {
+                st.wv.x = xg[grow0 + row];
+                st.qw.x = apg[grow0 + row];
+            }
+        }
         if (vb) {
             // epilogue operands are single-use streams: past the caches when the vectors overflow them anyway (see
             // vec_stream_nt) -- except an operand that IS the gathered vector (K3: w = s = x), which must stay
-            if constexpr (kUsesW) {
+            if constexpr (kUsesW && !SF) {
                 if (EPI != EPI_AXPY_DOT || a.w)
                     st.wv = w_nt ? __builtin_nontemporal_load((const wd_f64x2 *)(a.w + row)) : *(const wd_f64x2 *)(a.w + row);
             }
             if constexpr (kUsesZ)
                 st.zv = stream_nt ? __builtin_nontemporal_load((const wd_f64x2 *)(a.z + row)) : *(const wd_f64x2 *)(a.z + row);
         } else if (va) {
-            if constexpr (kUsesW) { if (EPI != EPI_AXPY_DOT || a.w) st.wv.x = a.w[row]; }
+            if constexpr (kUsesW && !SF) { if (EPI != EPI_AXPY_DOT || a.w) st.wv.x = a.w[row]; }
             if constexpr (kUsesZ) st.zv.x = a.z[row];
         }
-        gather8(r, e0, row, st.xv, st.vv);
+        gather8(r, e0, row, st.xv, st.vv, st.qv);
+    };
+    auto combine8 = [&](wd_f64x2 *xv, const wd_f64x2 *qv) {   // SF: bicg_k2_kernel's multiply-add (lanes that did not load hold garbage the fold never uses)
+        if constexpr (SF) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                xv[k].x = __builtin_fma(-alpha, qv[k].x, xv[k].x);
+                xv[k].y = __builtin_fma(-alpha, qv[k].y, xv[k].y);
+            }
+        }
     };
     // fold the slice's products row by row and run the epilogue
-    auto fold = [&](const Stage &st) {
+    auto fold = [&](Stage &st) {
         if (st.cnt < 0) return;
         const int row = (st.blk * 4 + wave) * 128 + 2 * lane;
         const bool va = row < a.rows, vb = row + 1 < a.rows;
         double ya = 0.0, yb = 0.0;
+        combine8(st.xv, st.qv);
+        if constexpr (SF) {
+            st.wv.x = __builtin_fma(-alpha, st.qw.x, st.wv.x);
+            st.wv.y = __builtin_fma(-alpha, st.qw.y, st.wv.y);
+        }
         fold8(st.me, st.mo, st.v, st.cnt, st.xv, st.vv, ya, yb);
         // slices with more than 8 records (27-point stencils, wide bands): further chunks of 8, fetched, gathered and
         // folded one after the other (no pipelining across chunks)
         for (int c0 = 8; c0 < st.cnt; c0 += 8) {
             WdRec rr;
             load_rec(st.e0 + c0, st.cnt - c0, rr);
-            wd_f64x2 xt[8], vt[VV ? 8 : 1];
+            wd_f64x2 xt[8], vt[VV ? 8 : 1], qt[SF ? 8 : 1];
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 asm("" : "=v"(xt[k]));
                 if (VV) asm("" : "=v"(vt[k]));
+                if (SF) asm("" : "=v"(qt[k]));
             }
-            gather8(rr, st.e0 + c0, row, xt, vt);
+            gather8(rr, st.e0 + c0, row, xt, vt, qt);
+            combine8(xt, qt);
             fold8(rr.me, rr.mo, rr.v, st.cnt - c0, xt, vt, ya, yb);
         }
         if (va) wd_epilogue<EPI>(a, row, vb, ya, yb, st.wv, st.zv, coef, acc1, acc2);
@@ -250,6 +294,7 @@ __global__ void __launch_bounds__(kBlock, VV ? (EPI == EPI_DOT4 ? kWdBlocksPerCu
             load_rec(e00, cnt0, r0);
             load_rec(e01, cnt1, r1);
             if (!spmv_prologue<EPI, int32_t>(a, s_red, coef)) return;
+            form_alpha();
             issue(sa, blk0, e00, cnt0, r0);
         }
 #define SLA_WD_STEP(cur, nxt)                         \
@@ -284,6 +329,7 @@ __global__ void __launch_bounds__(kBlock, VV ? (EPI == EPI_DOT4 ? kWdBlocksPerCu
         // was five dependent trips to memory (prologue, schedule, descriptor, records, gathers), a third of a 10 us launch at
         // 1 M rows.  A workgroup that must exit has only loaded a few words it does not use.
         if (!spmv_prologue<EPI, int32_t>(a, s_red, coef)) return;
+        form_alpha();
         for (; b < wk.last; b += wk.step) {
             int blk_f, e0_f, cnt_f;
             WD_STAMP(0)
@@ -322,6 +368,23 @@ int launch_wdia_t(const sla_csr *A, const SpmvArgs<int32_t> &a, const int32_t *s
     // launch bounds): the surplus workgroups leave at once instead of running a second round (2 M-row banded K3 26.7 -> 24.6 us)
     int active = grid;
     if (A->wd_vv && EPI == EPI_DOT4) active = std::min(grid, std::max(8, (kWdBlocksPerCuVV4 * c->n_cu) & ~7));
+    if (a.fs_ap) {   // K2 folded into K3 (see the kernel's header)
+        if constexpr (EPI == EPI_DOT4) {
+            if (!a.sc || !a.pa) return fail(SLA_ERR_INVALID, "launch_spmv_wdia: fused s needs the solver scalars and K1's partial sums");
+            active = std::min(grid, std::max(8, ((A->wd_vv ? kWdBlocksPerCuSFVV : kWdBlocksPerCuSF) * c->n_cu) & ~7));
+            if (A->wd_vv)
+                SLA_KLAUNCH(c, (spmv_wdia_kernel<EPI, true, true>), dim3(grid), dim3(kBlock), 0, stream_of(c), a, A->d_wptr, A->d_wme, A->d_wmo,
+                                   A->d_wval, A->d_woff, A->d_wvblk, a.x, nblk_wd, A->nslices, (int32_t)A->row_begin, (int32_t)A->n,
+                                   sched, c->xcd_remap, stream_nt, active);
+            else
+                SLA_KLAUNCH(c, (spmv_wdia_kernel<EPI, false, true>), dim3(grid), dim3(kBlock), 0, stream_of(c), a, A->d_wptr, A->d_wme, A->d_wmo,
+                                   A->d_wval, A->d_woff, A->d_wvblk, a.x, nblk_wd, A->nslices, (int32_t)A->row_begin, (int32_t)A->n,
+                                   sched, c->xcd_remap, stream_nt, active);
+            SLA_HIP_TRY(hipGetLastError());
+            return SLA_OK;
+        }
+        return fail(SLA_ERR_INVALID, "launch_spmv_wdia: fused s is defined for the four-sum epilogue only");
+    }
     if (A->wd_vv)
         SLA_KLAUNCH(c, (spmv_wdia_kernel<EPI, true>), dim3(grid), dim3(kBlock), 0, stream_of(c), a, A->d_wptr, A->d_wme, A->d_wmo,
                            A->d_wval, A->d_woff, A->d_wvblk, a.x, nblk_wd, A->nslices, (int32_t)A->row_begin, (int32_t)A->n,

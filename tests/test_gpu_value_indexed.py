@@ -425,6 +425,61 @@ def test_plane_march_k2_folded_into_k3_same_bits(sla, name, grid):
         assert np.linalg.norm(got - want) <= 1e-11 * np.linalg.norm(want)
 
 
+def _gather_cases():
+    from sla_amd import workloads as wl
+    return {
+        # constant coefficients, gather kernel (spmv_wdia_kernel): 2-D 5-point grid, odd row count; a 3-D grid of 12 planes
+        "poisson2d 301x211": (wl.poisson2d(301, 211), "algo=wdia", {"wd_lds": 0}),
+        "laplace3d 40x40x12": (wl.laplace3d(40, 40, 12), "algo=wdia", {"wd_lds": 0}),
+        # variable coefficients (per-row value blocks): the non-symmetric banded matrix of config 5
+        "banded 20011": (wl.banded_nonsym(20011), "algo=wdia-vv", {}),
+    }
+
+
+@pytest.mark.parametrize("name", list(_gather_cases()))
+@pytest.mark.parametrize("grid", [0, 8])
+def test_gather_kernel_k2_folded_into_k3_same_bits(sla, name, grid):
+    """bicg_fuse23 on the gather kernel of the wave-sliced forms (constant and variable coefficients, <= 4 M rows): every gather of K3 loads
+    the row pair of r and of Ap and combines them with K2's multiply-add; x, r, p after 1, 2 and 7 steps bit-identical to the four-launch
+    flow, three launches per step, linSolve0 returns the same iterate."""
+    from sla_amd import _lib
+    (dims, csr), algo, opts = _gather_cases()[name]
+    n = dims[0]
+    Ao = _oracle_csr(dims, csr)
+    b = orc.spmv(Ao, np.linspace(-1.0, 2.0, n))
+    x0 = np.full(n, 0.25)
+    states, sols, launches = {}, {}, {}
+    for f23 in (1, 0):
+        ctx = sla.Context(0).set_options(bicg_fuse23=f23, **opts)
+        if grid:
+            ctx.set_option("spmv_grid", grid)
+        A = sla.fromCSR(dims, *csr, ctx)
+        assert A.kernel_info().split()[0] == algo, A.kernel_info()
+        st = sla.bicgsInit(A, sla.fromVector(b, ctx), sla.fromVector(x0, ctx))
+        snaps = []
+        ctx.prof_start(_lib.KERNEL_ALL, 64)
+        for k in (1, 1, 5):
+            st.step(k)
+            snaps.append([v.toDenseListSV().copy() for v in (st._xBicgstab, st._rBicgstab, st._pBicgstab)])
+        ctx.prof_stop()
+        launches[f23] = (ctx.prof_query(_lib.KERNEL_BICG_K2)[0], ctx.prof_query(_lib.KERNEL_SPMV_DOT2)[0], ctx.prof_query(_lib.KERNEL_BICG_K45)[0])
+        states[f23] = snaps
+        xs, info = sla.linSolve0(sla.BICGSTAB_, A, sla.fromVector(b, ctx), sla.fromVector(x0, ctx), return_info=True)
+        sols[f23] = (xs.toDenseListSV(), info["iters"], info["resnorm"])
+        del A, st
+        ctx.close()
+    assert launches[1] == (0, 7, 7) and launches[0] == (7, 7, 7), launches
+    for a, c in zip(states[1], states[0]):
+        for u, v in zip(a, c):
+            assert np.array_equal(u.view(np.uint64), v.view(np.uint64)), (name, grid, np.abs(u - v).max())
+    assert sols[1][1] == sols[0][1] and sols[1][2] == sols[0][2], (sols[1][1:], sols[0][1:])
+    assert np.array_equal(sols[1][0].view(np.uint64), sols[0][0].view(np.uint64))
+    so = orc.BicgstabState(Ao, b, x0)
+    so.step(b - orc.spmv(Ao, x0), 2)
+    for got, want in zip(states[1][1], (so.x, so.r, so.p)):
+        assert np.linalg.norm(got - want) <= 1e-10 * np.linalg.norm(want)
+
+
 def test_plane_march_randomised_patterns(sla):
     """40 seeded random 5- / 7-pair stencils with one pair at -D and one at +D (D even, 1024..3000; in-plane offsets up to +-254: a window of at most 512 pairs; row
     counts that are not multiples of D; random holes; several values share no offset): the march form must be taken, and (#>), (<#)
