@@ -82,7 +82,8 @@ def test_bench_contract_small(fuse45):
     assert abs(d["value"] - 1e3 / d["ms_per_step"]) <= 1e-6 * d["value"]
     # a roofline statement: every printed fraction is priced on bytes the kernel really streams and stays <= 1
     assert 0.0 < d["roofline"]["frac"] <= 1.0 and d["roofline"]["achieved"] <= d["roofline"]["peak"]
-    assert set(d["kernels"]) == ({"K1", "K2", "K3", "K45"} if fuse45 == "1" else {"K1", "K2", "K3", "K4", "K5"})
+    # (fuse45 = 1 on this stencil: K2 is folded into K3 as well -- option bicg_fuse23, one launch "K23" that never stores s)
+    assert set(d["kernels"]) == ({"K1", "K23", "K45"} if fuse45 == "1" else {"K1", "K2", "K3", "K4", "K5"})
     for k in d["kernels"].values():
         assert 0.0 < k["frac"] <= 1.0 and k["bytes"] <= k["csr_bytes"] + 64 and k["launches"] == 8
     assert d["roofline"]["kernel"].split(":")[0] in d["kernels"] and d["roofline"]["launches_timed"] == 8
@@ -180,4 +181,5 @@ def test_bench_stdout_is_one_json_line_on_the_rccl_path():
     assert out.stdout.count("\n") == 1 and out.stdout.startswith("{"), out.stdout[:400]
     d = json.loads(out.stdout)
     assert d["rccl_ranks"] == 1 and d["exchanges"]["sums"]["launches"] > 0
-    assert set(d["kernels"]) == {"K1", "K2", "K3", "K45"}             # the fused sweep runs on sharded contexts too (round 3)
+    # the fused sweep runs on sharded contexts too (round 3); with ghost rows K2 is folded into K3 as on one rank (round 5)
+    assert set(d["kernels"]) in ({"K1", "K2", "K3", "K45"}, {"K1", "K23", "K45"})
