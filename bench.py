@@ -192,10 +192,15 @@ def kernel_table(ctx, A, nnz_local, n_local, method):
                  64 * n, 64 * n)]
     else:   # cgsStep (Sparse.hs:928-939); the vectors each launch really streams (sla_solvers.cpp: enqueue_cgs -- the x update
         # rides in C2, which reads u, A p, x and writes q, u + q, x; C3 reads u + q, r, rhat and writes r)
-        defs = [("C1", _lib.KERNEL_SPMV_DOT, "A p ; A p . rhat", mb + 24 * n, 12 * z + 28 * n),
+        # (round 5, plane-march form on one rank: C2 folded away -- C3 builds u + q in its staged windows ("C23": u, A p, r, rhat in; r out),
+        # one sweep does C2's x update and C4's u, p ("C24": u, A p, x, r, p in; x, u, p out))
+        c23 = ctx.prof_query(_lib.KERNEL_CGS_C2)[0] == 0 and ctx.prof_query(_lib.KERNEL_CGS_C4)[0] > 0
+        defs = [("C1", _lib.KERNEL_SPMV_DOT, "A p ; A p . rhat", mb + 24 * n, 12 * z + 28 * n)] + ([
+                ("C23", _lib.KERNEL_SPMV_DOT2, "alpha ; u + q with q = u - alpha A p (staged, never stored) ; r -= alpha A (u + q) ; r . rhat", mb + 40 * n, 12 * z + 60 * n),
+                ("C24", _lib.KERNEL_CGS_C4, "x += alpha (u + q) ; beta ; u, p updates", 64 * n, 64 * n)] if c23 else [
                 ("C2", _lib.KERNEL_CGS_C2, "alpha ; q = u - alpha A p ; u + q ; x += alpha (u + q)", 48 * n, 48 * n),
                 ("C3", _lib.KERNEL_SPMV_DOT2, "r -= alpha A (u + q) ; r . rhat", mb + 32 * n, 12 * z + 36 * n),
-                ("C4", _lib.KERNEL_CGS_C4, "beta ; u, p updates", 40 * n, 40 * n)]
+                ("C4", _lib.KERNEL_CGS_C4, "beta ; u, p updates", 40 * n, 40 * n)])
     out = {}
     for name, kid, what, bts, csr in defs:
         cnt, mean, mn = ctx.prof_query(kid)
@@ -758,7 +763,7 @@ def run_rank(args, rank, world, local_rank, dist_mode, loop=None):
         rec["step_gbps"] = rec["step_bytes_streamed"] / (dt / args.steps) / 1e9
         rec["step_frac_of_hbm_peak"] = rec["step_gbps"] / (HBM_PEAK_GBS * world)
         rec["roofline"] = {
-            "bound": "hbm", "kernel": f"{dom}: {d['what']}" + (f" [{kinfo.split()[0]}]" if dom in ("K1", "K3", "K23", "C1", "C3") else ""),
+            "bound": "hbm", "kernel": f"{dom}: {d['what']}" + (f" [{kinfo.split()[0]}]" if dom in ("K1", "K3", "K23", "C1", "C3", "C23") else ""),
             "share_of_step": d["ms"] * d["launches"] / args.steps / step_ms,
             "bytes_definition": "compulsory bytes of the storage form the kernel streams (matrix_bytes of the chosen SpMV form + the "
                                 "vectors; equal to the SURVEY 8(d) figure for the vector kernels and for the plain CSR forms); "

@@ -887,6 +887,7 @@ int launch_bicg_k2(sla_ctx *c, int64_t n, SolverScalars *sc, Parts apr, int par,
 int launch_bicg_k4(sla_ctx *c, int64_t n, SolverScalars *sc, Parts ass, Parts asas, const double *p, const double *s,
                    const double *as, const double *r0hat, double *x, double *r, double *prho);
 int launch_bicg_k5(sla_ctx *c, int64_t n, SolverScalars *sc, Parts rhonew, int par, const double *r, const double *ap, double *p);
+int launch_cgs_c24(sla_ctx *c, int64_t n, SolverScalars *sc, Parts rhonew, int par, const double *r, const double *aap, double *u, double *p, double *x);
 int launch_bicg_k45(sla_ctx *c, int64_t n, SolverScalars *sc, Parts ass, Parts asas, Parts tr0, Parts sr0, int par, const double *s,   // (s == nullptr: rebuilt from r and ap)
                     const double *as, const double *ap, double *x, double *r, double *p);
 // CGS (Sparse.hs:928-939)

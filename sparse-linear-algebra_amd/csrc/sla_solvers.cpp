@@ -371,6 +371,27 @@ int enqueue_cgs(sla_solver *S, int par, const Parts *check, bool dual_prev) {
         SLA_TRY(spmv_exchanged(A, S->p, l, &gk));
         SLA_TRY(publish(S, P_APR, -1, gk, &apr, nullptr));
     }
+    // Round 5, plane-march form on one rank (see enqueue_bicgstab): C2 is folded away -- C3 builds u + q in its staged windows from u and
+    // A p (q = u - alpha A p), and ONE sweep after it does C2's x update and C4's u, p (cgs_c24_kernel): three launches, 129 n bytes per step
+    // instead of four and 146 n, the same bits
+    if (c->bicg_fuse23 != 0 && !dual_prev && spmv_fuse_s_ok(A) && wd_march_on(A)) {
+        SpmvLaunch l;
+        l.epi = EPI_AXPY_DOT;
+        l.x = S->u->d;
+        l.fs_ap = S->t1->d;
+        l.pa = apr.p;
+        l.npa = apr.n;
+        l.pa_stride = apr.stride;
+        l.z = S->r->d;
+        l.w = S->r0hat->d;
+        l.p1 = slot(S, P_RHO);
+        l.sc = S->d_sc;
+        l.step_begin = par << 1;
+        l.kernel_id = SLA_KERNEL_SPMV_DOT2;
+        SLA_TRY(launch_spmv(A, l));
+        SLA_TRY(publish(S, P_RHO, -1, g, &rhon, nullptr));
+        return launch_cgs_c24(c, n, S->d_sc, rhon, par, S->r->d, S->t1->d, S->u->d, S->p->d, S->x->d);
+    }
     SLA_TRY(launch_cgs_c2(c, n, S->d_sc, apr, par, dual_prev ? Parts{slot(S, P_RES), g, 1} : Parts{nullptr, 0, 1},
                           dual_prev ? 1 : 0, S->u->d, S->t1->d, S->t2->d, S->t3->d, S->x->d));
     {

@@ -42,7 +42,9 @@ constexpr int kMarchBufBytes = 512 * 16;   // one staged window: <= 512 pairs
 // bicg_k2_kernel forms it (same re-reduction, same division, the same fused multiply-add per element: the staged values are that kernel's
 // bits).  Per step a workgroup loads two windows instead of one and no kernel writes or re-reads s: K2 + K3 streamed 24 n + 25 n bytes,
 // this launch 32 n (r, Ap, r0hat in; As out); the fused K4+K5 sweep rebuilds s from r and Ap, which it reads anyway (bicg_k45_kernel<.., true>).
-template <int EPI, int NP, bool WX, bool SF>
+// SF = 2: the same for cgsStep (Sparse.hs:931-933) -- the gathered vector is u + q with q = u - alpha Ap (xg is u), cgs_c2_kernel's
+// expressions; alpha is the prologue's coefficient (formed from a.pa like CGNE's); q, u + q and x are left to cgs_c24_kernel.
+template <int EPI, int NP, bool WX, int SF>
 __global__ void __launch_bounds__(kBlock, 3) spmv_wdia_march_kernel(SpmvArgs<int32_t> a, const wdm_u64x8s *__restrict__ wum, const double *__restrict__ xg,
                                                                     WdMarch m, int32_t grow0, int32_t xlo, int32_t xhi, int xcd_remap, int stream_nt, WdUni uni) {
     __shared__ wd_f64x2 wd_buf[4][512];
@@ -100,20 +102,27 @@ __global__ void __launch_bounds__(kBlock, 3) spmv_wdia_march_kernel(SpmvArgs<int
         }
     };
     auto st = [&](int buf, wd_f64x2 r0, wd_f64x2 r1, const wd_f64x2 &q0, const wd_f64x2 &q1) {
-        if constexpr (SF) {   // bicg_k2_kernel's expression: one fused multiply-add per element
+        if constexpr (SF == 1) {   // bicg_k2_kernel's expression: one fused multiply-add per element
             r0.x = __builtin_fma(-alpha, q0.x, r0.x);
             r0.y = __builtin_fma(-alpha, q0.y, r0.y);
             r1.x = __builtin_fma(-alpha, q1.x, r1.x);
             r1.y = __builtin_fma(-alpha, q1.y, r1.y);
+        } else if constexpr (SF == 2) {   // cgs_c2_kernel's: q = u - alpha Ap (one multiply-add), then u + q
+            r0.x = r0.x + __builtin_fma(-alpha, q0.x, r0.x);
+            r0.y = r0.y + __builtin_fma(-alpha, q0.y, r0.y);
+            r1.x = r1.x + __builtin_fma(-alpha, q1.x, r1.x);
+            r1.y = r1.y + __builtin_fma(-alpha, q1.y, r1.y);
         }
         wd_buf[buf][tid] = r0;
         if (second) wd_buf[buf][tid + 256] = r1;
     };
     // SF: alpha as bicg_k2_kernel forms it, once per workgroup (behind the prologue: sc->done has been looked at)
     auto form_alpha = [&]() {
-        if constexpr (SF) {
+        if constexpr (SF == 1) {
             alpha = a.sc->rho2[(a.step_begin >> 1) & 1] / reduce_parts(a.pa, a.npa, a.pa_stride, s_red);
             if (blockIdx.x == 0 && tid == 0) a.sc->alpha = alpha;
+        } else if constexpr (SF == 2) {
+            alpha = coef;   // (spmv_prologue<EPI_AXPY_DOT> with a.pa: rho / sum, published as sc->alpha -- cgs_c2_kernel's alpha)
         }
     };
     // the epilogue operands of a row pair: one 16-byte load each.  Rows past the end re-read the last pair; the last row of an odd
@@ -239,7 +248,7 @@ int wd_march_grid(const sla_csr *A) {
 // 71 us where 56 us suffice -- so its tasks are re-cut for 3 per CU at launch: fewer, longer runs; the workgroups beyond them write
 // their zero partial sums and leave (the grid, which the consumers of the partial sums know, stays).  The masks are indexed by
 // (tile, plane), not by run: any cut works.
-template <int EPI, int NP, bool WX, bool SF = false>
+template <int EPI, int NP, bool WX, int SF = 0>
 static int march_occupancy() {
     static const int occ = [] {
         hipFuncAttributes at;
@@ -272,22 +281,29 @@ static int launch_epi(const sla_csr *A, const SpmvArgs<int32_t> &a, int grid, in
     if (a.fs_ap) {   // K2 folded into K3: the gathered vector is built from r (= a.x) and Ap while the windows are staged
         if constexpr (EPI == EPI_DOT4) {
             if (!a.sc || !a.pa) return fail(SLA_ERR_INVALID, "launch_wdia_march: fused s needs the solver scalars and K1's partial sums");
-            if (A->wd_muni.n == 5) SLA_WDM_LAUNCH(5, true, true);
-            else SLA_WDM_LAUNCH(7, true, true);
+            if (A->wd_muni.n == 5) SLA_WDM_LAUNCH(5, true, 1);
+            else SLA_WDM_LAUNCH(7, true, 1);
             SLA_HIP_TRY(hipGetLastError());
             return SLA_OK;
         }
-        return fail(SLA_ERR_INVALID, "launch_wdia_march: fused s is defined for the four-sum epilogue only");
+        if constexpr (EPI == EPI_AXPY_DOT) {   // cgsStep's C2 folded into C3
+            if (!a.sc || !a.pa || !a.w) return fail(SLA_ERR_INVALID, "launch_wdia_march: fused u + q needs the solver scalars, C1's partial sums and rhat");
+            if (A->wd_muni.n == 5) SLA_WDM_LAUNCH(5, false, 2);
+            else SLA_WDM_LAUNCH(7, false, 2);
+            SLA_HIP_TRY(hipGetLastError());
+            return SLA_OK;
+        }
+        return fail(SLA_ERR_INVALID, "launch_wdia_march: a fused input vector is defined for the four-sum and the r - alpha A x epilogues only");
     }
     if constexpr (kMayWX) {
         if (wx) {
-            if (A->wd_muni.n == 5) SLA_WDM_LAUNCH(5, true, false);
-            else SLA_WDM_LAUNCH(7, true, false);
+            if (A->wd_muni.n == 5) SLA_WDM_LAUNCH(5, true, 0);
+            else SLA_WDM_LAUNCH(7, true, 0);
         }
     }
     if (!wx) {
-        if (A->wd_muni.n == 5) SLA_WDM_LAUNCH(5, false, false);
-        else SLA_WDM_LAUNCH(7, false, false);
+        if (A->wd_muni.n == 5) SLA_WDM_LAUNCH(5, false, 0);
+        else SLA_WDM_LAUNCH(7, false, 0);
     }
 #undef SLA_WDM_LAUNCH
     SLA_HIP_TRY(hipGetLastError());
@@ -304,8 +320,12 @@ static void march_prepare_epi() {
         (void)march_occupancy<EPI, 7, true>();
     }
     if constexpr (EPI == EPI_DOT4) {
-        (void)march_occupancy<EPI, 5, true, true>();
-        (void)march_occupancy<EPI, 7, true, true>();
+        (void)march_occupancy<EPI, 5, true, 1>();
+        (void)march_occupancy<EPI, 7, true, 1>();
+    }
+    if constexpr (EPI == EPI_AXPY_DOT) {
+        (void)march_occupancy<EPI, 5, false, 2>();
+        (void)march_occupancy<EPI, 7, false, 2>();
     }
 }
 void wd_march_prepare() {

@@ -396,6 +396,58 @@ __global__ void __launch_bounds__(kBlock) cgs_c4_kernel(int64_t n, SolverScalars
     }
 }
 
+// C2 + C4 in one sweep (round 5; C2's u + q is built inside C3 -- spmv_wdia_march_kernel<.., 2> -- and nobody else reads q or u + q):
+// q = u - alpha aap and u + q rebuilt here with C2's expressions, x updated, then C4's u and p from the new r.  Reads u, aap, x, r, p and
+// writes x, u, p: 64 n bytes where C2 + C4 moved 88 n.  alpha was published by C3's prologue.
+template <bool NT>
+__global__ void __launch_bounds__(kBlock) cgs_c24_kernel(int64_t n, SolverScalars *sc, Parts rhonew, int par, const double *r, const double *aap,
+                                                          double *u, double *p, double *x, int pol) {
+    __shared__ double s_red[4];
+    const int64_t n2 = n >> 1, gs = (int64_t)gridDim.x * kBlock, i0 = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int done = sc->done;
+    const double rho = sc->rho2[par], alpha = sc->alpha;
+    double pq[8];
+    parts_issue(rhonew.p, rhonew.n, rhonew.stride, pq);
+    const int64_t i0c = n2 > 0 ? min(i0, n2 - 1) : 0;
+    double2 rv = make_double2(0.0, 0.0), uv = rv, av = rv, pv = rv, xv = rv;
+    if (n2 > 0) { rv = ld2s<NT>(r, i0c); uv = ld2s<NT>(u, i0c); av = ld2s<NT>(aap, i0c); pv = ld2s<NT>(p, i0c); xv = ld2s<NT>(x, i0c); }
+    if (done) return;
+    const double rn = block_sum(parts_fold(pq, rhonew.n), s_red);
+    const double beta = rn / rho;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { sc->beta = beta; sc->rho2[par ^ 1] = rn; }
+    for (int64_t i2 = i0; i2 < n2; i2 += gs) {
+        if (i2 != i0) { rv = ld2s<NT>(r, i2); uv = ld2s<NT>(u, i2); av = ld2s<NT>(aap, i2); pv = ld2s<NT>(p, i2); xv = ld2s<NT>(x, i2); }
+        const double2 qv = make_double2(uv.x - alpha * av.x, uv.y - alpha * av.y);
+        const double2 sv = make_double2(uv.x + qv.x, uv.y + qv.y);
+        xv.x += alpha * sv.x;
+        xv.y += alpha * sv.y;
+        if (NT) st2_nt(x, i2, xv);
+        else st2(x, i2, xv);
+        const double2 un = make_double2(rv.x + beta * qv.x, rv.y + beta * qv.y);
+        pv.x = un.x + beta * (qv.x + beta * pv.x);
+        pv.y = un.y + beta * (qv.y + beta * pv.y);
+        stpol(u, i2, un, pol, 13);
+        stpol(p, i2, pv, pol, 14);
+    }
+    if (SLA_HAS_TAIL(n)) {
+        const int64_t i = n - 1;
+        const double qv = u[i] - alpha * aap[i], sv = u[i] + qv;
+        x[i] += alpha * sv;
+        const double un = r[i] + beta * qv;
+        u[i] = un;
+        p[i] = un + beta * (qv + beta * p[i]);
+    }
+}
+int launch_cgs_c24(sla_ctx *c, int64_t n, SolverScalars *sc, Parts rhonew, int par, const double *r, const double *aap, double *u, double *p, double *x) {
+    ProfScope prof(c, SLA_KERNEL_CGS_C4, true);
+    if (vec_stream_nt(c, n))
+        SLA_KLAUNCH(c, cgs_c24_kernel<true>, dim3(vec_grid(n)), dim3(kBlock), 0, stream_of(c), n, sc, rhonew, par, r, aap, u, p, x, c->vec_policy);
+    else
+        SLA_KLAUNCH(c, cgs_c24_kernel<false>, dim3(vec_grid(n)), dim3(kBlock), 0, stream_of(c), n, sc, rhonew, par, r, aap, u, p, x, 0);
+    SLA_HIP_TRY(hipGetLastError());
+    return SLA_OK;
+}
+
 int launch_cgs_c2(sla_ctx *c, int64_t n, SolverScalars *sc, Parts apr, int par, Parts res, int count_iter,
                   const double *u, const double *aap, double *q, double *uq, double *x) {
     ProfScope prof(c, SLA_KERNEL_CGS_C2, true);

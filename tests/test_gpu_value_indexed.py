@@ -425,6 +425,50 @@ def test_plane_march_k2_folded_into_k3_same_bits(sla, name, grid):
         assert np.linalg.norm(got - want) <= 1e-11 * np.linalg.norm(want)
 
 
+@pytest.mark.parametrize("name", list(_march_cases()))
+@pytest.mark.parametrize("grid", [0, 8])
+def test_plane_march_cgs_c2_folded_into_c3_same_bits(sla, name, grid):
+    """cgsStep (Sparse.hs:928-939) on the plane-march form, one rank: C2 is folded away -- C3 builds u + q (q = u - alpha A p) in its staged
+    windows, one sweep after it does C2's x update and C4's u, p (cgs_c24_kernel); q and u + q are never stored.  x, r, p, u after 1, 2
+    and 7 steps bit-identical to the four-launch flow (bicg_fuse23 = 0), three launches per step, linSolve0 CGS_ returns the same iterate."""
+    from sla_amd import _lib
+    dims, csr = _march_cases()[name]
+    n = dims[0]
+    Ao = _oracle_csr(dims, csr)
+    b = orc.spmv(Ao, np.linspace(-1.0, 2.0, n))
+    x0 = np.full(n, 0.25)
+    states, sols, launches = {}, {}, {}
+    for f23 in (1, 0):
+        ctx = sla.Context(0).set_options(wd_lds=2, wd_march=2, bicg_fuse23=f23)
+        if grid:
+            ctx.set_option("spmv_grid", grid)
+        A = sla.fromCSR(dims, *csr, ctx)
+        assert "wdia+march" in A.kernel_info().split()[0], A.kernel_info()
+        st = sla.cgsInit(A, sla.fromVector(b, ctx), sla.fromVector(x0, ctx))
+        snaps = []
+        ctx.prof_start(_lib.KERNEL_ALL, 64)
+        for k in (1, 1, 5):
+            st.step(k)
+            snaps.append([v.toDenseListSV().copy() for v in (st._x, st._r, st._p, st._u)])
+        ctx.prof_stop()
+        launches[f23] = (ctx.prof_query(_lib.KERNEL_CGS_C2)[0], ctx.prof_query(_lib.KERNEL_SPMV_DOT2)[0], ctx.prof_query(_lib.KERNEL_CGS_C4)[0])
+        states[f23] = snaps
+        xs, info = sla.linSolve0(sla.CGS_, A, sla.fromVector(b, ctx), sla.fromVector(x0, ctx), return_info=True)
+        sols[f23] = (xs.toDenseListSV(), info["iters"], info["resnorm"])
+        del A, st
+        ctx.close()
+    assert launches[1] == (0, 7, 7) and launches[0] == (7, 7, 7), launches
+    for a, c in zip(states[1], states[0]):
+        for u, v in zip(a, c):
+            assert np.array_equal(u.view(np.uint64), v.view(np.uint64)), (name, grid, np.abs(u - v).max())
+    assert sols[1][1] == sols[0][1] and sols[1][2] == sols[0][2], (sols[1][1:], sols[0][1:])
+    assert np.array_equal(sols[1][0].view(np.uint64), sols[0][0].view(np.uint64))
+    co = orc.CgsState(Ao, b, x0)
+    co.step(b - orc.spmv(Ao, x0), 2)
+    for got, want in zip(states[1][1], (co.x, co.r, co.p, co.u)):
+        assert np.linalg.norm(got - want) <= 1e-10 * np.linalg.norm(want)
+
+
 def _gather_cases():
     from sla_amd import workloads as wl
     return {
