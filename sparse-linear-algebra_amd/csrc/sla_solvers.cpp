@@ -246,7 +246,8 @@ int enqueue_bicgstab(sla_solver *S, int par, const Parts *check, bool dual_prev)
     }
     // Round 5: where K3 runs on the plane-march kernel (one rank, 3-D stencils from 8 M rows on) K2 is folded into it -- s = r - alpha Ap is
     // built while the x windows are staged and never stored; the fused K4+K5 sweep rebuilds it from r and Ap, which it reads anyway.  Three
-    // launches and 121 n bytes per step instead of four and 138 n; the same bits (bicg_k2_kernel's alpha and multiply-add).
+    // launches and 121 n bytes per step instead of four and 138 n; the same s and As bit for bit (bicg_k2_kernel's alpha and multiply-add -- the
+    // iterates differ in the last bits only where the folded instantiation's occupancy regroups K3's fused sums: INTEGRATION.md).
     const bool fuse23 = c->bicg_fuse23 != 0 && c->bicg_fuse45 != 0 && !dual_prev && spmv_fuse_s_ok(A);
     if (!fuse23)
         SLA_TRY(launch_bicg_k2(c, n, S->d_sc, apr, par, dual_prev ? Parts{slot(S, P_RES), g, 1} : Parts{nullptr, 0, 1},
