@@ -170,7 +170,8 @@ static int enqueue_bicgstab_ghost(sla_solver *S, int par, const Parts *check) {
         SLA_TRY(launch_spmv(A, l));
         SLA_TRY(publish_with_halo(S, P_APR, -1, g, &apr, nullptr, S->t1));
     }
-    // (K2 folded into K3 where the whole-slab launch runs the plane-march kernel -- see enqueue_bicgstab: r and Ap are valid on the ghost
+    // (K2 folded into K3 where the whole-slab launch runs the plane-march or the gather kernel -- see enqueue_bicgstab; a rank's own decision, no
+    // collective depends on it: r and Ap are valid on the ghost
     // rows, so the staged windows and the sweep's rebuilt s hold there what K2 would have written)
     const bool fuse23 = c->bicg_fuse23 != 0 && c->bicg_fuse45 != 0 && spmv_fuse_s_ok(A, true);
     if (!fuse23) SLA_TRY(launch_bicg_k2(c, next, S->d_sc, apr, par, Parts{nullptr, 0, 1}, 0, S->r->d - gl, S->t1->d - gl, S->t2->d - gl));
@@ -244,8 +245,8 @@ int enqueue_bicgstab(sla_solver *S, int par, const Parts *check, bool dual_prev)
         SLA_TRY(spmv_exchanged(A, S->p, l, &gk));
         SLA_TRY(publish(S, P_APR, -1, gk, &apr, nullptr));
     }
-    // Round 5: where K3 runs on the plane-march kernel (one rank, 3-D stencils from 8 M rows on) K2 is folded into it -- s = r - alpha Ap is
-    // built while the x windows are staged and never stored; the fused K4+K5 sweep rebuilds it from r and Ap, which it reads anyway.  Three
+    // Round 5: where K3 runs on the plane-march kernel, or on the gather kernel of the wave-sliced forms up to 4 M rows (spmv_fuse_s_ok), K2 is
+    // folded into it -- s = r - alpha Ap is built while the x windows are staged (gather kernel: from the gathered row pairs of r and Ap) and never stored; the fused K4+K5 sweep rebuilds it from r and Ap, which it reads anyway.  Three
     // launches and 121 n bytes per step instead of four and 138 n; the same s and As bit for bit (bicg_k2_kernel's alpha and multiply-add -- the
     // iterates differ in the last bits only where the folded instantiation's occupancy regroups K3's fused sums: INTEGRATION.md).
     const bool fuse23 = c->bicg_fuse23 != 0 && c->bicg_fuse45 != 0 && !dual_prev && spmv_fuse_s_ok(A);

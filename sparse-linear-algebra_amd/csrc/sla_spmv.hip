@@ -35,8 +35,9 @@ bool wave_plain(const sla_csr *A) {
     return wave_on(A) && !A->is_panel_view && !diag_on(A) && !stream_xwin_on(A);
 }
 
-// BiCGSTAB's K2 folded into K3 (SpmvLaunch::fs_ap): one rank, and the whole-matrix launch lands on the plane-march kernel -- the
-// conditions of the dispatch below, in its order
+// BiCGSTAB's K2 folded into K3 (SpmvLaunch::fs_ap; cgsStep's C2 into C3 on the plane march): would the whole-matrix (slab: whole-slab) launch
+// land on a kernel that has the variant -- the plane march, or the gather kernel of the wave-sliced forms?  The conditions of the dispatch
+// below, in its order
 bool spmv_fuse_s_ok(const sla_csr *A, bool slab) {
     const sla_ctx *c = A->ctx;
     // (slab: the whole-slab launches of the ghost-row flow -- r and Ap are valid on the ghost rows, x is addressed by global column)
@@ -140,7 +141,7 @@ static int launch_spmv_rp(const sla_csr *A, const SpmvLaunch &l) {
     a.step_begin = l.step_begin;
     a.yinit = l.yinit;
     a.fs_ap = l.fs_ap;
-    if (l.fs_ap && !(spmv_fuse_s_ok(A, true) && l.part == 0 && !l.x2 && !l.yinit)) return fail(SLA_ERR_INVALID, "launch_spmv: fused s off the plane-march kernel");
+    if (l.fs_ap && !(spmv_fuse_s_ok(A, true) && l.part == 0 && !l.x2 && !l.yinit)) return fail(SLA_ERR_INVALID, "launch_spmv: a fused input vector needs the plane-march or the wave-sliced gather kernel");
     const int grid = spmv_grid(A);
     // (the forms whose launcher is ONE kernel launched through SLA_KLAUNCH carry the profiling events themselves: the gather kernel of the
     // wave-sliced forms, the wavefront-private CSR kernel -- conditions as in the dispatch below)
@@ -183,7 +184,7 @@ static int launch_spmv_rp(const sla_csr *A, const SpmvLaunch &l) {
 }
 
 int launch_spmv(const sla_csr *A, const SpmvLaunch &l) {
-    if (l.fs_ap && !spmv_fuse_s_ok(A, true)) return fail(SLA_ERR_INVALID, "launch_spmv: fused s off the plane-march kernel");
+    if (l.fs_ap && !spmv_fuse_s_ok(A, true)) return fail(SLA_ERR_INVALID, "launch_spmv: a fused input vector needs the plane-march or the wave-sliced gather kernel");
     if (tiles_on(A) && !lflat_on(A) && !l.x2 && (!l.yinit || l.tv1 >= 0)) return launch_spmv_tiles(A, l);
     return A->rp64 ? launch_spmv_rp<int64_t>(A, l) : launch_spmv_rp<int32_t>(A, l);
 }
