@@ -306,6 +306,59 @@ __global__ void __launch_bounds__(256, OCC) march_kernel(const double *__restric
     }
 }
 
+// The same march with the windows staged by direct-to-LDS loads (round 5 probe: global_load_lds, 16 B per lane -- the window layout is
+// lane-contiguous already): no staging registers, no ds_write, and DIST planes in flight cost LDS (DIST + 3 buffers of 256 + D1 pairs)
+// instead of registers.  One raw s_barrier per step; the wait is counted (vmcnt(2 DIST): the planes further ahead stay in flight -- stores
+// share the counter, so the count is the conservative one).  Buffer of plane p: (p - (k0 - 1)) mod (DIST + 3); the buffer written at the
+// top of step kk held plane kk - 2, which every wavefront finished reading before it passed the barrier of step kk - 1.
+template <int OCC, int DIST>
+__global__ void __launch_bounds__(256, OCC) march_glds_kernel(const double *__restrict__ x, double *__restrict__ y, int D1, int D2, int G, int T,
+                                                              int TX, int PS) {
+    constexpr int NB = DIST + 3;
+    extern __shared__ d2 gbuf[];
+    const int tid = threadIdx.x, wave = tid >> 6;
+    const int stride = 256 + D1;                          // pairs per buffer
+    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+    const int tile = xcd * TX + local % TX, seg = local / TX;
+    if (tile >= T || local % TX >= TX) return;
+    const int k0 = seg * PS, k1 = min(k0 + PS, G);
+    if (k0 >= k1) return;
+    const int valid = min(512, D2 - tile * 512);
+    const int h1 = D1 >> 1;
+    const double *xt = x + (size_t)tile * 512 - D1 + 2 * tid;
+    auto glds = [&](int k, int q) {
+        const double *b = xt + (ptrdiff_t)min(k, G) * D2;
+        d2 *dst = gbuf + (size_t)q * stride;
+        __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)b, (void __attribute__((address_space(3))) *)(dst + wave * 64), 16, 0, 0);
+        if (tid < D1)
+            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(b + 512), (void __attribute__((address_space(3))) *)(dst + 256 + wave * 64), 16, 0, 0);
+    };
+#pragma unroll
+    for (int i = 0; i < DIST + 2; ++i) glds(k0 - 1 + i, i);          // planes k0 - 1 .. k0 + DIST
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * DIST));             // plane k0 - 1 and k0 are in
+    __builtin_amdgcn_s_barrier();
+    d2 a = gbuf[h1 + tid];                                            // centre pair of plane k0 - 1 (buffer 0)
+    int jb = 1, jw = DIST + 2;                                        // buffer of plane kk; buffer the next glds goes to
+    for (int kk = k0; kk < k1; ++kk) {
+        const int jn = jb + 1 == NB ? 0 : jb + 1;                     // buffer of plane kk + 1
+        glds(kk + 1 + DIST, jw);
+        jw = jw + 1 == NB ? 0 : jw + 1;
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * DIST) : "memory");   // plane kk + 1 is in (this wavefront's part)
+        __builtin_amdgcn_s_barrier();
+        const d2 *cur = gbuf + (size_t)jb * stride, *nxt = gbuf + (size_t)jn * stride;
+        const double *w = (const double *)cur + D1 + 2 * tid;
+        const d2 g = nxt[h1 + tid];
+        const d2 bb = *(const d2 *)(w - D1), f = *(const d2 *)(w + D1);
+        const d2 d = *(const d2 *)w;
+        const double lo = w[-1], hi = w[2];
+        const d2 c = d2{lo, d.x}, e = d2{d.y, hi};
+        const d2 r = fold7(a, bb, c, d, e, f, g);
+        if (2 * tid < valid) __builtin_nontemporal_store(r, (d2 *)(y + (size_t)kk * D2 + (size_t)tile * 512 + 2 * tid));
+        a = d;
+        jb = jn;
+    }
+}
+
 // z-march with K2 folded into the staging (round 3): the window of r - alpha v is formed on the fly (two staging loads per vector and
 // lane instead of two), own rows of s written for K4+K5.  Product structure: one round trip per step, the wait in front of the stores.
 // FUSED = false: the same kernel on a precomputed s (what spmv_wdia_march_kernel does).
@@ -523,6 +576,11 @@ int main(int argc, char **argv) {
         MARCH3(3, 1); MARCH3(4, 1); MARCH3(5, 1);
         MARCH3(2, 2); MARCH3(3, 2); MARCH3(4, 2);
         MARCH3(2, 3); MARCH3(3, 3);
+#define MARCHG(OCC, DIST) do { const int S = std::max(1, (OCC * 256) / (8 * TX)), PS = (G + S - 1) / S; char nm[64]; snprintf(nm, sizeof nm, "march glds occ %d dist %d", OCC, DIST); \
+        const size_t lds = sizeof(double) * 2 * (size_t)(DIST + 3) * (256 + D1); \
+        CK(hipFuncSetAttribute((const void *)march_glds_kernel<OCC, DIST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        run(nm, [&](const double *x, double *y) { hipLaunchKernelGGL((march_glds_kernel<OCC, DIST>), dim3(8 * TX * S), dim3(256), lds, 0, x, y, D1, D2, G, T, TX, PS); }, true); } while (0)
+        MARCHG(4, 1); MARCHG(4, 2); MARCHG(3, 2); MARCHG(3, 3); MARCHG(5, 1); MARCHG(6, 1); MARCHG(2, 4);
         MARCH(3, 1); MARCH(3, 2); MARCH(3, 3);
         MARCH(4, 1); MARCH(4, 2); MARCH(4, 3); MARCH(4, 4);
         MARCH(5, 2); MARCH(5, 3);
