@@ -60,7 +60,7 @@ def test_config3a_random_spd_1m_cgs_vs_bicgstab(sla):
 @pytest.mark.parametrize("fuse45", ["1", "0"])
 def test_bench_contract_small(fuse45):
     """fuse45 = 1 (default, single rank): K4 and K5 are one sweep (K45), K3 also streams r0hat; 0: the reference's split."""
-    env = dict(os.environ, SLA_BICG_FUSE45=fuse45)
+    env = dict(os.environ, SLA_BICG_FUSE45=fuse45, SLA_BICG_FUSE23="1")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "laplace3d_small", "--steps", "8",
                           "--warmup", "2", "--cpu-seconds", "0.5"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300,
                          env=env)

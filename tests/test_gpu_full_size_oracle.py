@@ -122,7 +122,7 @@ def test_config4_k2_folded_into_k3_at_full_size(sla):
     b = np.add.reduceat(va, rp[:-1])
     out, launches = {}, {}
     for key, opts in (("folded, 3 per CU", {"bicg_fuse23": 1, "wd_march_occ": 3}), ("four launches, 3 per CU", {"bicg_fuse23": 0, "wd_march_occ": 3}),
-                      ("folded, default", {})):
+                      ("folded, default", {"bicg_fuse23": 1})):
         ctx = sla.Context(0).set_options(**opts)
         A = sla.fromCSR(dims, rp, ci, va, ctx)
         assert "wdia+march" in A.kernel_info().split()[0], A.kernel_info()
