@@ -62,6 +62,8 @@ def workload(name, row_begin=0, row_end=None):
         return "2M-row fp64 non-symmetric banded (5 bands), BiCGSTAB", wl.banded_nonsym(2000000, 99, row_begin, row_end)
     if name == "laplace3d_1m":   # the size of one rank's slab of the 216^3 problem at 8 GPUs
         return "108^3 7-pt Laplacian (1.26M rows)", wl.laplace3d(108, 108, 108, row_begin, row_end)
+    if name == "laplace3d_slab8":  # ... in its real shape: 27 planes of 216 x 216
+        return "216x216x27 7-pt Laplacian (1.26M rows: one rank's slab of the 216^3 problem at 8 GPUs)", wl.laplace3d(216, 216, 27, row_begin, row_end)
     if name == "laplace3d_5m":   # ... at 2 GPUs
         return "216x216x108 7-pt Laplacian (5.04M rows)", wl.laplace3d(216, 216, 108, row_begin, row_end)
     if name == "laplace3d_2m5":  # ... at 4 GPUs
@@ -164,7 +166,7 @@ def cpu_baseline(dims, rp, ci, va, b, seconds):
     return out
 
 
-def kernel_table(ctx, A, nnz_local, n_local, method):
+def kernel_table(ctx, A, nnz_local, n_local, method, steps_per_launch=1):
     """Per-kernel HIP-event statistics of the last ctx.prof_start(KERNEL_ALL) recording, priced two ways: `bytes` = the
     compulsory bytes of the storage form the kernel streams (matrix_bytes of sla_csr_kernel_info + the vectors),
     `csr_bytes` = the algorithmic CSR figure of SURVEY 8(d)."""
@@ -202,6 +204,17 @@ def kernel_table(ctx, A, nnz_local, n_local, method):
                 ("C3", _lib.KERNEL_SPMV_DOT2, "r -= alpha A (u + q) ; r . rhat", mb + 32 * n, 12 * z + 36 * n),
                 ("C4", _lib.KERNEL_CGS_C4, "beta ; u, p updates", 40 * n, 40 * n)])
     out = {}
+    # round 6 (option onchip): the whole step loop as ONE persistent launch with the solver state in registers + LDS (csrc/sla_onchip.hip).
+    # What crosses HBM per LAUNCH: x, r, p, r0hat in and x, r, p out + the plan's tables (12 B per row); the steps themselves move the
+    # boundary rows of Ap and As through the L2 / memory-side cache and nothing else -- `csr_bytes` (the SURVEY 8(d) step bytes x steps) is
+    # what the launch flow would have streamed, so effective_* is an equivalence, not a bandwidth
+    cnt, mean, mn = ctx.prof_query(_lib.KERNEL_ONCHIP)
+    if cnt:
+        bts, csr = 68 * n, (24 * z + 160 * n) * steps_per_launch
+        out["ONCHIP"] = {"id": _lib.KERNEL_ONCHIP, "what": f"{steps_per_launch} bicgstabSteps in one persistent launch, solver state on chip; two counter barriers per step "
+                         "carry the sums and the boundary rows of Ap / As", "launches": cnt, "ms": mean, "min_ms": mn, "steps_per_launch": steps_per_launch,
+                         "ms_per_step": mean / steps_per_launch, "bytes": bts, "csr_bytes": csr, "gbps": bts / mean / 1e6, "frac": bts / mean / 1e6 / HBM_PEAK_GBS,
+                         "effective_gbps": csr / mean / 1e6, "effective_frac": csr / mean / 1e6 / HBM_PEAK_GBS, "plan": ctx.get_option("onchip_plan")}
     for name, kid, what, bts, csr in defs:
         cnt, mean, mn = ctx.prof_query(kid)
         if not cnt:
@@ -232,12 +245,14 @@ def timed_steps(ctx, st, steps, warmup, sync_all, event_free=False, conv=None):
     Returns (seconds of the timed region, (launches, mean ms, min ms) of the dominant kernel inside it, its kernel id)."""
     from sla_amd import _lib
     ids = (_lib.KERNEL_SPMV_DOT, _lib.KERNEL_SPMV_DOT2, _lib.KERNEL_BICG_K2, _lib.KERNEL_BICG_K4, _lib.KERNEL_BICG_K5,
-           _lib.KERNEL_CGS_C2, _lib.KERNEL_CGS_C4, _lib.KERNEL_BICG_K45)
+           _lib.KERNEL_CGS_C2, _lib.KERNEL_CGS_C4, _lib.KERNEL_BICG_K45, _lib.KERNEL_ONCHIP)
     ctx.prof_start(_lib.KERNEL_ALL, max(warmup, 1) * 6 + 8)
     st.step(max(warmup, 1))
     ctx.prof_stop()
     tot = {k: (lambda c, m, _: c * m)(*ctx.prof_query(k)) for k in ids}
     dom = max(tot, key=tot.get)
+    if dom == _lib.KERNEL_ONCHIP:
+        event_free = False   # (one launch for all the steps: no graph replay, and the launch carries its own pair of events)
     if conv is not None:   # residual of the state the timed region starts from (collective when sharded: every rank calls it)
         conv["res_before"] = state_residual(ctx, st, st.A.ncols)
     sync_all()
@@ -312,7 +327,7 @@ def side_block(name, dims, rp, ci, va, options, steps, warmup, rhs="A.1"):
     r0norm = state_residual(ctx, st, n)
     conv = {}
     dt, _, _ = timed_steps(ctx, st, steps, warmup, ctx.sync, conv=conv)
-    kt = kernel_table(ctx, A, nnz, n, "bicgstab")
+    kt = kernel_table(ctx, A, nnz, n, "bicgstab", steps)
     k1 = kt.get("K1", {})
     rec = {"workload": name, "rows": n, "nnz": nnz, "steps": steps, "warmup": warmup, "options": options, "rhs": rhs + ", x0 = 0",
            "convergence": convergence_note(ctx, st, n, r0norm, conv.get("res_before", float("nan"))),
@@ -605,7 +620,10 @@ def run_rank(args, rank, world, local_rank, dist_mode, loop=None):
             and os.environ.get("SLA_STEP_GRAPH", "-1") != "0"
         extra["step_graph"] = bool(graph)
         dt, dom_stats, dom_id = timed_steps(ctx, st, args.steps, args.warmup, sync_all, event_free=graph or os.environ.get("SLA_BENCH_EVENT_FREE") == "1")
-        kt = kernel_table(ctx, A, nnz_local, n_local, args.method)
+        kt = kernel_table(ctx, A, nnz_local, n_local, args.method, args.steps)
+        extra["onchip"] = "ONCHIP" in kt
+        if extra["onchip"]:
+            extra["step_graph"] = False
         if dist_mode:
             extra["exchanges"] = exchange_table(ctx)
         launches, mean_ms, min_ms = dom_stats
@@ -778,6 +796,12 @@ def run_rank(args, rank, world, local_rank, dist_mode, loop=None):
                        "from an untimed pass of the same length right after it, every kernel event-timed") if launches else
                       ("the timed region replays the steps as a captured HIP graph (launch-bound size: no stream events inside a graph); "
                        "this kernel's duration is from the event-timed pass of the same length right after it")}
+        if dom == "ONCHIP":
+            rec["roofline"]["note"] = ("persistent on-chip launch: the solver state lives in registers + LDS, so `achieved` (the bytes one LAUNCH moves: state in and "
+                                       "out) says nothing about the steps -- they are bound by two grid-wide counter barriers and the issue rate of "
+                                       "the CUs, not by HBM; effective_* = the SURVEY 8(d) step bytes the launch flow would stream / this time; ms_per_step "
+                                       "is the figure of merit")
+            rec["roofline"]["ms_per_step"] = d["ms"] / args.steps
         tr = pmc_traffic(args.workload, args.mode, world, dom, kinfo)
         if tr:
             rec["roofline"].update({"traffic": tr["traffic_bytes"], "traffic_source": tr["source"],

@@ -86,7 +86,9 @@ enum { /* sla_solve_info.flags */
     SLA_FLAG_MAX_ITERS = 2,   /* returned after max_iters without meeting tol (reference: silent) */
     SLA_FLAG_DIAGONAL = 4,    /* isDiagonalSM shortcut taken (Sparse.hs:1024-1025) */
     SLA_FLAG_BREAKDOWN = 8,   /* Arnoldi: nearZero h_{i+1,i} (Sparse.hs:665-667) */
-    SLA_FLAG_NONFINITE = 16   /* residual became NaN/Inf (reference propagates NaN, no guard) */
+    SLA_FLAG_NONFINITE = 16,  /* residual became NaN/Inf (reference propagates NaN, no guard) */
+    SLA_FLAG_SYNC_TIMEOUT = 32 /* a persistent on-chip step launch gave up waiting for its other workgroups (another job holding CUs): the state record is
+                                  unchanged by that launch's unfinished steps only up to the step it stopped in -- treat it as lost */
 };
 
 typedef struct {
@@ -297,6 +299,7 @@ typedef enum {
                                  events on the stream it is issued on (the second stream when it overlaps the interior rows) */
     SLA_KERNEL_SUMS = 12,     /* row-sharded: per-rank partial sums made global (finalize + all-gather; in the ghost-row flows the grouped
                                  exchange that also carries a halo) */
+    SLA_KERNEL_ONCHIP = 13,   /* sla_solver_step(k) as ONE persistent launch with the solver state on chip (constant-coefficient stencils that fit) */
     SLA_KERNEL_COUNT = 16
 } sla_kernel_id;
 /* record up to `max_launches` event pairs around launches of `kernel_id` (SLA_KERNEL_ALL: of every kernel above) from now on */

@@ -506,6 +506,10 @@ const IntKnob kIntKnobs[] = {
     {"tile_prefetch", &sla_ctx::tile_prefetch, 0, 16},
     {"tile_relaxed", &sla_ctx::tile_relaxed, 0, 1},
     {"tile_depth", &sla_ctx::tile_depth, 0, 2},
+    {"onchip", &sla_ctx::onchip, 0, 2},
+    {"onchip_grid", &sla_ctx::onchip_grid, 0, 4096},
+    {"onchip_rows", &sla_ctx::onchip_rows, 0, 1 << 20},
+    {"onchip_bricks", &sla_ctx::onchip_bricks, 0, 2},
     {"tri_syncfree", &sla_ctx::tri_syncfree, 0, 3},
     {"tri_block_rows", &sla_ctx::tri_block_rows, 8, kTriBlockRows},
     {"tri_grid", &sla_ctx::tri_grid, 0, 4096},
@@ -582,6 +586,8 @@ static std::string ctx_option_value(const sla_ctx *c, const std::string &name, b
     if (name == "panel_cols") return std::to_string(c->panel_cols);
     if (name == "device_coo_min") return std::to_string(c->device_coo_min);
     if (name == "x_exchange") return c->x_exchange == 1 ? "allgather" : c->x_exchange == 2 ? "window" : "auto";
+    if (name == "onchip_launches") return std::to_string(c->onchip_launches);   // (read-only)
+    if (name == "onchip_plan") return c->onchip_note;
     if (name == "tri_mode_used") return std::to_string(c->tri_mode_used);
     if (name == "tri_plan") return c->tri_plan_note;
     if (name == "tri_fallbacks") return std::to_string(c->tri_fallbacks);   // (read-only: solves that left the persistent triangular kernel)
@@ -904,6 +910,7 @@ int sla_csr_destroy(sla_csr_t A) {
     if (A->d_dict) (void)hipFree(A->d_dict);
     tri_plan_free(A->tri[0]);
     tri_plan_free(A->tri[1]);
+    onchip_plan_free(A->oc);
     if (A->d_wptr) (void)hipFree(A->d_wptr);
     if (A->d_wsched) (void)hipFree(A->d_wsched);
     if (A->d_lpp) (void)hipFree(A->d_lpp);

@@ -260,6 +260,13 @@ struct sla_ctx {
     int tile_relaxed = 1;            // the tile form of irregular matrices: 1 = CU-wide slices (spmv_ctile_kernel, round 5: column-sorted gathers that share x lines, row sums by LDS
                                      // atomics in relaxed order -- within nnz_i eps sum|a_ij x_j| of the reference's fold, not reproducible bit for bit), 0 = wavefront-private slices
                                      // (spmv_tile_kernel, rounds 2-4: the reference's left fold bit for bit; 18 % slower on config 3a, 2.2 x on power-law rows)
+    int onchip = 1;                  // sla_solver_step on constant-coefficient stencil / banded matrices that fit the chip's registers + LDS: the whole step loop as ONE persistent
+                                     // launch (sla_onchip.hip; SLA_ONCHIP: 0 never, 1 when the plan says it fits, 2 the same and a plan failure is an error: tests)
+    int onchip_grid = 0;             // ... its workgroups at most (0: one per CU; tests use small grids)
+    int onchip_rows = 0;             // ... rows per workgroup at most (0: what the registers hold: 12 x 512; tests force short blocks)
+    int onchip_bricks = 1;           // ... 1: bricks where consecutive rows do not fit (3-D stencils), 2: bricks wherever the stencil allows them, 0: never
+    long onchip_launches = 0;        // (read-only) persistent launches so far (sla_ctx_get_option "onchip_launches")
+    std::string onchip_note;         // (read-only) the last plan's shape or the reason there is none ("onchip_plan")
     int tri_block_rows = 16384;      // tri_syncfree = 2: rows per block (<= kTriBlockRows: the block's x sits in LDS; small values are for the tests)
     int tri_syncfree = 3;            // triLowerSolve / triUpperSolve: 0 one launch per dependency level, 1 one persistent launch whose rows poll x in memory, 2 the block-local persistent launch (sla_tri.hip), 3 pick 2 or 0 by the schedule's shape (sla_precond.cpp)
     int tri_grid = 0;                // ... its workgroups (0: 256 for the row-polling kernel, as many as are co-resident for the block-local one)
@@ -366,6 +373,33 @@ struct sla_tri_plan {
     double *d_bl_val = nullptr, *d_bl_diag = nullptr;
 };
 
+// On-chip solver plan (sla_onchip.hip, round 6): constant-coefficient stencil / banded matrices of <= 8 (offset, value) pairs whose rows are
+// dealt to one 512-thread workgroup per CU -- consecutive rows (2-D / banded) or bricks (3-D) -- so that a whole BiCGSTAB / CGS state lives in
+// registers + LDS and sla_solver_step(k) is ONE persistent launch.  Built lazily by the first step on a matrix, kept with the matrix.
+namespace sla {
+constexpr int kOcThreads = 512;      // 8 wavefronts of 256 VGPRs, one workgroup per CU
+constexpr int kOcMaxPairs = 8;
+struct OcPlan {
+    bool ok = false;
+    std::string note;                // the plan's shape, or why there is none (sla_ctx_get_option "onchip_plan")
+    int G = 0, L = 0, rpt = 0, hpt = 0, np = 0, mode = 0;   // workgroups, local cells, own rows / halo cells per thread (instantiation classes), pairs, 0 rows / 1 bricks
+    int bx = 0, by = 0, bz = 0;
+    int64_t own_max = 0, halo_max = 0, nbound = 0;
+    int loff[kOcMaxPairs] = {};      // local cell offset of pair k
+    double val[kOcMaxPairs] = {};
+    uint32_t *d_own_cm = nullptr;    // [G][rpt * 512]: local cell | pair mask << 16 | boundary << 24 | valid << 25
+    int32_t *d_own_row = nullptr;    // [G][rpt * 512]: global row
+    uint32_t *d_halo_cell = nullptr; // [G][hpt * 512]: local cell (slots without one: the dummy cell L)
+    int32_t *d_halo_row = nullptr;   // [G][hpt * 512]: the row the cell mirrors
+    int32_t *d_halo_src = nullptr;   // [G][hpt * 512]: ... and the slot its owner publishes it in
+    double *d_pubA = nullptr, *d_pubS = nullptr;   // boundary rows of the two SpMV results of a step, by the owner's slot
+    double *d_parts = nullptr;       // [4][G] partial sums
+    unsigned *d_bar = nullptr;       // barrier words (zeroed in front of every launch)
+    size_t lds_bytes = 0;
+};
+void onchip_plan_free(OcPlan *p);
+}  // namespace sla
+
 struct sla_csr {
     std::vector<sla_csr *> kids;     // non-empty: a bundle of per-rank row blocks of a multi-device context
     sla_ctx *ctx = nullptr;
@@ -450,6 +484,7 @@ struct sla_csr {
     double *d_tldummy = nullptr;     // one all-zero panel (2^tl_shift doubles): what the tile kernels' empty pipeline-drain chunks gather from
     bool tl_cu = false;              // CU-wide slices, relaxed order (sla_spmv_ctiles.hip): entries [slice][wavefront][panel], d_tloff = tl_S x 4 x (tl_P + 1)
     sla_tri_plan *tri[2] = {nullptr, nullptr};  // [0] lower, [1] upper triangle schedules (built on first use)
+    sla::OcPlan *oc = nullptr;       // on-chip solver plan (built by the first sla_solver_step that could use it; ok = false: tried, not eligible)
     // comm / compute overlap of the sharded (#>) (wave-sliced forms): the 512-row steps whose rows reference own columns only
     // (interior: they can run while the halo exchange is in flight) and the rest, each in the visiting order of d_wsched
     int32_t *d_ov_int = nullptr, *d_ov_bnd = nullptr;
@@ -868,6 +903,10 @@ int build_tiles(sla_csr *A, int64_t n, int64_t rows, const int64_t *rowptr, cons
 int build_tiles_device(sla_csr *A, const std::vector<int32_t> &srow, int shift, int64_t P, int64_t *maxseg_out, int64_t *nbreaks_out, bool *done);
 // ... and the CU-wide layout of sla_spmv_ctiles.hip (relaxed: one column-sorted run per tile)
 int build_ctiles_device(sla_csr *A, const std::vector<int32_t> &srow, int shift, int64_t P, const int64_t *rowptr_host, bool *done);
+
+// sla_onchip.hip: can `k` steps of S run as one persistent launch (builds the matrix's plan on first use)?  Then run them.
+bool onchip_usable(sla_solver *S);
+int launch_onchip_steps(sla_solver *S, int par, int k);
 
 int vec_grid(int64_t n_local);
 // p1[b] = sum x.y over block b's elements (grid = vec_grid)

@@ -789,6 +789,17 @@ int sla_solver_step(sla_solver_t S, int k_steps) {
     sla_ctx *c = S->ctx;
     Bind bind(c);
     int k = 0;
+    // Round 6: constant-coefficient stencil / banded matrices whose whole solver state fits the chip's registers + LDS run the k steps as ONE
+    // persistent launch (sla_onchip.hip): same formulas, two counter barriers per step instead of three launches.
+    if (k_steps > 0 && c->onchip != 0) {
+        if (onchip_usable(S)) {
+            SLA_TRY(launch_onchip_steps(S, ctl_of(S).step_index & 1, k_steps));
+            ctl_of(S).step_index += k_steps;
+            return SLA_OK;
+        }
+        if (c->onchip == 2 && S->method == SLA_BICGSTAB_)
+            return fail(SLA_ERR_INVALID, "sla_solver_step: onchip = 2 but this state record cannot run on chip (" + c->onchip_note + ")");
+    }
     // Launch-bound sizes ("Launches and HIP graphs"): below ~2 M rows the five dependent launches of a step
     // cost about as much as its kernels.  Two consecutive steps (both parities of the double-buffered rho) are captured ONCE
     // into a HIP graph and replayed: the same kernels with the same arguments in the same order -- bit-identical iterates --

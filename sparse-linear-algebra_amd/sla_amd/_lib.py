@@ -19,6 +19,7 @@ KERNEL_SPMV, KERNEL_SPMV_DOT, KERNEL_SPMV_DOT2, KERNEL_SPMV_RES, KERNEL_SPMV_DUA
 KERNEL_BICG_K2, KERNEL_BICG_K4, KERNEL_BICG_K5, KERNEL_CGS_C2, KERNEL_CGS_C4 = 5, 6, 7, 8, 9
 KERNEL_BICG_K45 = 10
 KERNEL_EXCHANGE, KERNEL_SUMS = 11, 12
+KERNEL_ONCHIP = 13
 
 
 class SlaError(RuntimeError):

@@ -111,8 +111,8 @@ class Context:
         return mean.value, mn.value, 8.0 * (reads + writes) * (int(n) & ~1) / (mean.value * 1e-3) / 1e9
 
     def get_option(self, name):
-        buf = C.create_string_buffer(64)
-        check(lib().sla_ctx_get_option(self.h, str(name).encode(), buf, 64))
+        buf = C.create_string_buffer(512)
+        check(lib().sla_ctx_get_option(self.h, str(name).encode(), buf, 512))
         return buf.value.decode()
 
     @staticmethod

@@ -1,0 +1,224 @@
+"""sla_solver_step as ONE persistent launch with the solver state on chip (csrc/sla_onchip.hip, round 6): bicgstabStep
+(Sparse.hs:972-981) on constant-coefficient stencil / banded matrices.  Checked against the launch flow (same formulas, other grouping of the
+inner products: agreement to rounding, growing like BiCGSTAB's own sensitivity) and against the oracle's steps at the suite's 1e-9, on
+consecutive-row plans and brick plans, short blocks, ragged stencils, non-symmetric bands, many small workgroups, and in the ways a state
+record is used: step(1) after step(k), clone, an explicit shadow residual, a launch-flow step in between."""
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def sla():
+    import sla_amd
+    return sla_amd
+
+
+def _banded(n, offsets, values, keep=None):
+    from sla_amd import workloads as wl
+    order = np.argsort(offsets)
+    offsets, values = [offsets[i] for i in order], [values[i] for i in order]
+
+    def valid(rows, t):
+        c = rows + offsets[t]
+        ok = (c >= 0) & (c < n)
+        if keep is not None:
+            ok &= keep(rows, t)
+        return ok
+
+    return (n, n), wl._stencil_rows(0, n, offsets, valid, lambda rows, t: np.full(len(rows), values[t]))
+
+
+def _cases():
+    from sla_amd import workloads as wl
+    rng = np.random.default_rng(17)
+    drop = rng.random((6000, 8)) < 0.2
+    return {
+        # name: (matrix, context options, what the plan note must contain)
+        "poisson2d 48x48, consecutive rows": (wl.poisson2d(48, 48), {}, "consecutive rows"),
+        "poisson2d 61x37 (odd sizes), 7 workgroups": (wl.poisson2d(61, 37), {"onchip_grid": 7}, "7 workgroups"),
+        "poisson2d 40x40, blocks of 100 rows (halo spans blocks)": (wl.poisson2d(40, 40), {"onchip_rows": 100}, "consecutive rows"),
+        "laplace3d 36x30x9, consecutive rows": (wl.laplace3d(36, 30, 9), {}, "consecutive rows"),
+        "laplace3d 36x30x9, bricks": (wl.laplace3d(36, 30, 9), {"onchip_bricks": 2}, "bricks"),
+        "laplace3d 20x17x13, bricks, 60 workgroups": (wl.laplace3d(20, 17, 13), {"onchip_bricks": 2, "onchip_grid": 60}, "bricks"),
+        "poisson2d 50x41 as 2-D bricks": (wl.poisson2d(50, 41), {"onchip_bricks": 2, "onchip_grid": 24}, "bricks"),
+        "non-symmetric band {-2,-1,0,1,3}": (_banded(5000, [-2, -1, 0, 1, 3], [-1.0, -1.5, 4.2, -0.5, -1.0]), {}, "consecutive rows"),
+        "tridiagonal n = 1000 (3 pairs: the any-pair-count kernel)": (_banded(1000, [-1, 0, 1], [-1.0, 2.5, -1.0]), {}, "consecutive rows"),
+        "ragged 7 diagonals (20 % of the entries missing)": (_banded(6000, [-300, -40, -1, 0, 1, 40, 300], [-1.0, -0.5, -1.0, 9.0, -1.0, -0.75, -1.0],
+                                                                     keep=lambda r, t: ~drop[r, t] | (t == 3)), {}, "consecutive rows"),
+        "8 pairs, two values on one diagonal": (_banded_two_values(), {}, "consecutive rows"),
+    }
+
+
+def _banded_two_values():
+    from sla_amd import workloads as wl
+    n, offsets = 3000, [-50, -1, 0, 1, 50]
+    # value of diagonal 0 alternates with the row parity: 6 distinct (offset, value) pairs
+    def valid(rows, t):
+        c = rows + offsets[t]
+        return (c >= 0) & (c < n)
+    return (n, n), wl._stencil_rows(0, n, offsets, valid, lambda rows, t: np.where(t == 2, 8.0 + (rows % 2), -1.0 - 0.25 * t) * np.ones(len(rows)))
+
+
+def _problem(dims, csr, seed=3):
+    rp, ci, va = csr
+    n = dims[0]
+    Ao = orc.Csr(n, n, rp, ci, va)
+    rng = np.random.default_rng(seed)
+    b = orc.spmv(Ao, np.ones(n)) + 0.05 * rng.standard_normal(n)
+    x0 = 0.1 * rng.standard_normal(n)
+    return Ao, b, x0
+
+
+def _rel(a, b):
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+
+
+@pytest.mark.parametrize("name", list(_cases()))
+def test_onchip_steps_match_the_launch_flow_and_the_oracle(sla, name):
+    (dims, csr), opts, must = _cases()[name]
+    Ao, b, x0 = _problem(dims, csr)
+    n = dims[0]
+    states = {}
+    for mode in (2, 0):   # 2: on chip or an error, 0: the launch flow
+        ctx = sla.Context(0).set_options(onchip=mode, **(opts if mode else {}))
+        A = sla.fromCSR(dims, *csr, ctx)
+        sd = sla.bicgsInit(A, sla.fromVector(b, ctx), sla.fromVector(x0, ctx))
+        sd.step(2)
+        got2 = [getattr(sd, f).toDenseListSV() for f in ("_xBicgstab", "_rBicgstab", "_pBicgstab")]
+        sd.step(5)
+        got7 = [getattr(sd, f).toDenseListSV() for f in ("_xBicgstab", "_rBicgstab", "_pBicgstab")]
+        if mode:
+            note = ctx.get_option("onchip_plan")
+            assert must in note, note
+            assert int(ctx.get_option("onchip_launches")) == 2
+        else:
+            assert int(ctx.get_option("onchip_launches")) == 0
+        states[mode] = (got2, got7)
+        del sd, A
+        ctx.close()
+    so = orc.BicgstabState(Ao, b, x0)
+    so.step(b - orc.spmv(Ao, x0), 2)
+    for got, want, what in zip(states[2][0], (so.x, so.r, so.p), "xrp"):
+        assert _rel(got, want) <= 1e-9, (name, what, "two steps against the oracle", _rel(got, want))
+    for (g2, g0, what) in zip(states[2][0], states[0][0], "xrp"):
+        assert _rel(g2, g0) <= 1e-11, (name, what, "two steps against the launch flow", _rel(g2, g0))
+    for (g2, g0, what) in zip(states[2][1], states[0][1], "xrp"):
+        assert _rel(g2, g0) <= 1e-8, (name, what, "seven steps against the launch flow", _rel(g2, g0))
+
+
+def test_onchip_state_records_behave_like_the_launch_flows(sla):
+    """step(k) == k x step(1) bit for bit; a clone steps on its own; an explicit shadow residual; a launch-flow step in between (the
+    on-chip launch reads and leaves the state record in memory exactly as the launch flow does)."""
+    from sla_amd import workloads as wl
+    dims, csr = wl.laplace3d(24, 20, 11)
+    Ao, b, x0 = _problem(dims, csr, seed=9)
+    ctx = sla.Context(0).set_options(onchip=2, onchip_bricks=2)
+    A = sla.fromCSR(dims, *csr, ctx)
+    bv, xv = sla.fromVector(b, ctx), sla.fromVector(x0, ctx)
+    s1, s2 = sla.bicgsInit(A, bv, xv), sla.bicgsInit(A, bv, xv)
+    s1.step(6)
+    for _ in range(6):
+        s2.step(1)
+    assert np.array_equal(s1._xBicgstab.toDenseListSV(), s2._xBicgstab.toDenseListSV())
+    assert np.array_equal(s1._pBicgstab.toDenseListSV(), s2._pBicgstab.toDenseListSV())
+    # clone: the copy moves, the original stays
+    x_before = s1._xBicgstab.toDenseListSV()
+    s3 = s1.clone().step(3)
+    assert np.array_equal(s1._xBicgstab.toDenseListSV(), x_before)
+    s1.step(3)
+    assert np.array_equal(s1._xBicgstab.toDenseListSV(), s3._xBicgstab.toDenseListSV())
+    # the reference's pure step with an explicit shadow residual, against the oracle
+    shadow = np.random.default_rng(1).standard_normal(dims[0])
+    s4 = sla.bicgsInit(A, bv, xv)
+    s5 = sla.bicgstabStep(A, sla.fromVector(shadow, ctx), s4, k=2)
+    so = orc.BicgstabState(Ao, b, x0)
+    so.step(shadow, 2)
+    assert _rel(s5._xBicgstab.toDenseListSV(), so.x) <= 1e-9
+    # a launch-flow step between two on-chip launches
+    s6, s7 = sla.bicgsInit(A, bv, xv), sla.bicgsInit(A, bv, xv)
+    s6.step(5)
+    s7.step(2)
+    ctx.set_options(onchip=0)
+    s7.step(1)
+    ctx.set_options(onchip=2)
+    s7.step(2)
+    assert _rel(s7._xBicgstab.toDenseListSV(), s6._xBicgstab.toDenseListSV()) <= 1e-10
+    del s1, s2, s3, s4, s5, s6, s7, A
+    ctx.close()
+
+
+def test_onchip_declines_what_it_cannot_hold(sla):
+    """Variable coefficients, more than 8 pairs, CGS, a pending residual evaluation: the launch flow runs, nothing errors under onchip = 1,
+    and the plan note says why; onchip = 2 turns the refusal into an error."""
+    from sla_amd import workloads as wl
+    ctx = sla.Context(0)
+    dims, csr = wl.banded_nonsym(4000, seed=99)          # +-5 % noise on every entry: not constant-coefficient
+    Ao, b, x0 = _problem(dims, csr)
+    A = sla.fromCSR(dims, *csr, ctx)
+    sd = sla.bicgsInit(A, sla.fromVector(b, ctx), sla.fromVector(x0, ctx)).step(3)
+    assert int(ctx.get_option("onchip_launches")) == 0
+    assert "constant-coefficient" in ctx.get_option("onchip_plan")
+    so = orc.BicgstabState(Ao, b, x0)
+    so.step(b - orc.spmv(Ao, x0), 3)
+    assert _rel(sd._xBicgstab.toDenseListSV(), so.x) <= 1e-9
+    ctx.set_options(onchip=2)
+    with pytest.raises(Exception, match="cannot run on chip"):
+        sd.step(1)
+    ctx.set_options(onchip=1)
+    # CGS on an eligible matrix: the launch flow (no on-chip cgsStep)
+    dims2, csr2 = wl.poisson2d(40, 40)
+    Ao2, b2, x02 = _problem(dims2, csr2)
+    A2 = sla.fromCSR(dims2, *csr2, ctx)
+    sc = sla.cgsInit(A2, sla.fromVector(b2, ctx), sla.fromVector(x02, ctx)).step(2)
+    soc = orc.CgsState(Ao2, b2, x02)
+    soc.step(b2 - orc.spmv(Ao2, x02), 2)
+    assert _rel(sc._x.toDenseListSV(), soc.x) <= 1e-9
+    assert int(ctx.get_option("onchip_launches")) == 0
+    # linSolve0 (true residual every iteration) stays on the launch flow and still converges to the reference's answer
+    x, info = sla.linSolve0(sla.BICGSTAB_, A2, sla.fromVector(b2, ctx), sla.fromVector(np.zeros(dims2[0]), ctx), return_info=True)
+    assert info["converged"] and int(ctx.get_option("onchip_launches")) == 0
+    # ... and BiCGSTAB steps on the same matrix do go on chip
+    sb = sla.bicgsInit(A2, sla.fromVector(b2, ctx), sla.fromVector(x02, ctx)).step(4)
+    assert int(ctx.get_option("onchip_launches")) == 1
+    sob = orc.BicgstabState(Ao2, b2, x02)
+    sob.step(b2 - orc.spmv(Ao2, x02), 4)
+    assert _rel(sb._xBicgstab.toDenseListSV(), sob.x) <= 1e-9
+    del sd, sc, sb, A, A2
+    ctx.close()
+
+
+def test_config2_poisson_1m_onchip_vs_oracle(sla):
+    """BASELINE config 2 at full size on the on-chip path: two oracle steps at 1e-9, and the plan is one workgroup per CU."""
+    from sla_amd import workloads as wl
+    dims, csr = wl.poisson2d(1000, 1000)
+    Ao, b, x0 = _problem(dims, csr, seed=21)
+    ctx = sla.Context(0).set_options(onchip=2)
+    A = sla.fromCSR(dims, *csr, ctx)
+    sd = sla.bicgsInit(A, sla.fromVector(b, ctx), sla.fromVector(x0, ctx)).step(2)
+    so = orc.BicgstabState(Ao, b, x0)
+    so.step(b - orc.spmv(Ao, x0), 2)
+    assert _rel(sd._xBicgstab.toDenseListSV(), so.x) <= 1e-9
+    assert _rel(sd._rBicgstab.toDenseListSV(), so.r) <= 1e-9
+    assert "consecutive rows" in ctx.get_option("onchip_plan")
+    del sd, A
+    ctx.close()
+
+
+def test_slab_216x216x27_onchip_vs_oracle(sla):
+    """One N = 8 slab of BASELINE config 4 (216 x 216 x 27) as a problem of its own: the brick plan, two oracle steps at 1e-9."""
+    from sla_amd import workloads as wl
+    dims, csr = wl.laplace3d(216, 216, 27)
+    Ao, b, x0 = _problem(dims, csr, seed=22)
+    ctx = sla.Context(0).set_options(onchip=2)
+    A = sla.fromCSR(dims, *csr, ctx)
+    sd = sla.bicgsInit(A, sla.fromVector(b, ctx), sla.fromVector(x0, ctx)).step(2)
+    so = orc.BicgstabState(Ao, b, x0)
+    so.step(b - orc.spmv(Ao, x0), 2)
+    assert _rel(sd._xBicgstab.toDenseListSV(), so.x) <= 1e-9
+    assert "bricks" in ctx.get_option("onchip_plan"), ctx.get_option("onchip_plan")
+    del sd, A
+    ctx.close()
