@@ -255,25 +255,34 @@ def timed_steps(ctx, st, steps, warmup, sync_all, event_free=False, conv=None):
         event_free = False   # (one launch for all the steps: no graph replay, and the launch carries its own pair of events)
     if conv is not None:   # residual of the state the timed region starts from (collective when sharded: every rank calls it)
         conv["res_before"] = state_residual(ctx, st, st.A.ncols)
+    # median and spread.  The timed region is `windows` consecutive windows of EXACTLY `steps` steps, each bracketed by
+    # barrier + sync on both sides; the line's `value` is the MEDIAN window (ms_per_step x steps = that window), value_min / value_max the
+    # slowest / fastest one.  timed_steps.windows holds every window's seconds (N > 1: the caller takes the max over ranks per window).
+    windows = max(1, int(os.environ.get("SLA_BENCH_WINDOWS", "5")))
     sync_all()
+    dts = []
     if event_free:
         # launch-bound sizes: the library replays the steps as a captured HIP graph (sla_solver_step) -- kernels inside a graph
         # cannot be bracketed by stream events, so the timed region runs clean and the dominant kernel's duration comes from the
         # untimed event pass below
         st.step(4)                                      # (capture + instantiate outside the timed region)
         sync_all()
-        t0 = time.perf_counter()
-        st.step(steps)
-        sync_all()
-        dt = time.perf_counter() - t0
+        for _ in range(windows):
+            t0 = time.perf_counter()
+            st.step(steps)
+            sync_all()
+            dts.append(time.perf_counter() - t0)
         dom_stats = (0, 0.0, 0.0)
     else:
-        ctx.prof_start(dom, steps)
-        t0 = time.perf_counter()
-        st.step(steps)
-        sync_all()
-        dt = time.perf_counter() - t0
+        ctx.prof_start(dom, steps * windows)
+        for _ in range(windows):
+            t0 = time.perf_counter()
+            st.step(steps)
+            sync_all()
+            dts.append(time.perf_counter() - t0)
         dom_stats = ctx.prof_stop()
+    timed_steps.windows = dts
+    dt = sorted(dts)[len(dts) // 2]
     ctx.prof_start(_lib.KERNEL_ALL, steps * 6 + 8)      # untimed: the per-kernel table
     st.step(steps)
     ctx.prof_stop()
@@ -674,7 +683,14 @@ def run_rank(args, rank, world, local_rank, dist_mode, loop=None):
         extra["dual_spmv"] = dual
         extra["linsolve0_iters"] = info.iters
 
-    dt = allreduce(dt, "max")
+    if args.mode == "step":   # (every rank timed the same windows: max over ranks per window, then the median window)
+        wins = [allreduce(w, "max") for w in timed_steps.windows]
+        dt = sorted(wins)[len(wins) // 2]
+        extra["value_windows"] = {"windows": len(wins), "steps_per_window": args.steps, "iters_per_s": [args.steps / w for w in wins],
+                                  "note": "value = the median window; each window is exactly `steps` steps between barrier + device synchronisation"}
+        extra["value_min"], extra["value_max"] = args.steps / max(wins), args.steps / min(wins)
+    else:
+        dt = allreduce(dt, "max")
 
     # ---- N > 1: the north star's literal target next to the Laplacian -- the 10 M-row random matrix on the SAME sharded context
     # (x all-gathered per SpMV: its rows reference all of x), so that the driver's 1/2/4/8 sweep yields a curve for it as well

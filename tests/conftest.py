@@ -14,6 +14,12 @@ for p in (ROOT, os.path.join(ROOT, "sparse-linear-algebra_amd"), os.path.join(RO
 # (sla_internal.hpp: Bind / stream_of / dev_malloc).  On a one-GPU box a wrong current device is invisible -- every id is 0 --
 # so this is how the multi-device fan-out (sla_ctx_create_multi's worker threads) is checked there.  Read when the library loads.
 os.environ.setdefault("SLA_DEBUG_BINDING", "1")
+# Round 6 made ONE persistent on-chip launch the default way to run bicgstabSteps on small constant-coefficient stencils -- exactly the
+# matrices most of this suite uses to exercise the launch flow's kernels (K1 / K23 / K45 with every fused epilogue, the plane march, the
+# gather kernel's folded K2 ...), which remain what runs at 10 M rows.  The suite therefore keeps the launch flow as ITS default (the
+# environment is a context's default, sla_ctx_set_option overrides it): tests of the on-chip path (test_gpu_onchip.py, the bench contract)
+# switch it on explicitly, through the typed option or the child's environment.
+os.environ.setdefault("SLA_ONCHIP", "0")
 
 
 def pytest_configure(config):

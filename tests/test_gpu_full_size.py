@@ -57,10 +57,13 @@ def test_config3a_random_spd_1m_cgs_vs_bicgstab(sla):
         assert np.linalg.norm(x.toDenseListSV() - xs) <= 1e-3 * np.linalg.norm(xs)
 
 
-@pytest.mark.parametrize("fuse45", ["1", "0"])
+@pytest.mark.parametrize("fuse45", ["1", "0", "onchip"])
 def test_bench_contract_small(fuse45):
-    """fuse45 = 1 (default, single rank): K4 and K5 are one sweep (K45), K3 also streams r0hat; 0: the reference's split."""
-    env = dict(os.environ, SLA_BICG_FUSE45=fuse45, SLA_BICG_FUSE23="1")
+    """fuse45 = 1 (single rank): K4 and K5 are one sweep (K45), K3 also streams r0hat; 0: the reference's split -- both with the launch
+    flow (SLA_ONCHIP=0); "onchip": the default at this size since round 6 -- the whole timed window is ONE persistent launch."""
+    onchip = fuse45 == "onchip"
+    env = dict(os.environ, SLA_BICG_FUSE45="1" if onchip else fuse45, SLA_BICG_FUSE23="1", SLA_ONCHIP="1" if onchip else "0")
+    env.pop("SLA_BENCH_WINDOWS", None)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "laplace3d_small", "--steps", "8",
                           "--warmup", "2", "--cpu-seconds", "0.5"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300,
                          env=env)
@@ -80,13 +83,23 @@ def test_bench_contract_small(fuse45):
         assert k in d["cpu_baseline"], k
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] == 1
     assert abs(d["value"] - 1e3 / d["ms_per_step"]) <= 1e-6 * d["value"]
+    # value = the median of five consecutive windows of exactly `steps` steps, with the spread beside it
+    assert d["value_windows"]["windows"] == 5 and d["value_windows"]["steps_per_window"] == 8 and len(d["value_windows"]["iters_per_s"]) == 5
+    assert d["value_min"] <= d["value"] <= d["value_max"] and sorted(d["value_windows"]["iters_per_s"])[2] == pytest.approx(d["value"], rel=1e-9)
     # a roofline statement: every printed fraction is priced on bytes the kernel really streams and stays <= 1
     assert 0.0 < d["roofline"]["frac"] <= 1.0 and d["roofline"]["achieved"] <= d["roofline"]["peak"]
     # (fuse45 = 1 on this stencil: K2 is folded into K3 as well -- option bicg_fuse23, one launch "K23" that never stores s)
-    assert set(d["kernels"]) == ({"K1", "K23", "K45"} if fuse45 == "1" else {"K1", "K2", "K3", "K4", "K5"})
+    assert d["onchip"] is onchip
+    if onchip:   # one launch per window: the table's entry is per LAUNCH (8 steps), the roofline says what the figure means
+        assert set(d["kernels"]) == {"ONCHIP"} and d["kernels"]["ONCHIP"]["launches"] == 1 and d["kernels"]["ONCHIP"]["steps_per_launch"] == 8
+        assert d["roofline"]["launches_timed"] == 5 and "ms_per_step" in d["roofline"] and "note" in d["roofline"]
+        assert "onchip:" in d["kernels"]["ONCHIP"]["plan"]
+    else:
+        assert set(d["kernels"]) == ({"K1", "K23", "K45"} if fuse45 == "1" else {"K1", "K2", "K3", "K4", "K5"})
+        assert d["roofline"]["launches_timed"] == 8 * 5
     for k in d["kernels"].values():
-        assert 0.0 < k["frac"] <= 1.0 and k["bytes"] <= k["csr_bytes"] + 64 and k["launches"] == 8
-    assert d["roofline"]["kernel"].split(":")[0] in d["kernels"] and d["roofline"]["launches_timed"] == 8
+        assert 0.0 < k["frac"] <= 1.0 and k["bytes"] <= k["csr_bytes"] + 64 and k["launches"] == (1 if onchip else 8)
+    assert d["roofline"]["kernel"].split(":")[0] in d["kernels"]
     assert d["rccl_ranks"] is None and "general_csr" not in d          # (side blocks ride on the default workload only)
     # nothing named *_gbps without "effective" may exceed the chip's HBM peak: value-indexed forms stream less
     # than the CSR bytes they are priced on, and say so in the key

@@ -155,7 +155,7 @@ def test_onchip_declines_what_it_cannot_hold(sla):
     """Variable coefficients, more than 8 pairs, CGS, a pending residual evaluation: the launch flow runs, nothing errors under onchip = 1,
     and the plan note says why; onchip = 2 turns the refusal into an error."""
     from sla_amd import workloads as wl
-    ctx = sla.Context(0)
+    ctx = sla.Context(0).set_options(onchip=1)      # (the product's default; the suite's environment says 0, see conftest.py)
     dims, csr = wl.banded_nonsym(4000, seed=99)          # +-5 % noise on every entry: not constant-coefficient
     Ao, b, x0 = _problem(dims, csr)
     A = sla.fromCSR(dims, *csr, ctx)

@@ -89,8 +89,8 @@ def run(name, steps=60, forms=FORMS, out=print, scale=None):
     desc, (dims, (rp, ci, va)) = z if z else bench.workload(name)
     seen, rows, nnz = set(), [], int(rp[-1])
     for label, opts in forms:
-        try:
-            r = bench.side_block(desc, dims, rp, ci, va, opts, steps, 10)
+        try:   # (onchip = 0: the tournament is about the (#>) kernels of the launch flow -- on chip a step has no K1 of its own)
+            r = bench.side_block(desc, dims, rp, ci, va, dict(opts, onchip=0), steps, 10)
         except Exception as e:  # noqa: BLE001
             out(f"{name:14s} {label:26s} failed: {e!r}")
             continue
@@ -102,6 +102,10 @@ def run(name, steps=60, forms=FORMS, out=print, scale=None):
         rows.append((label, algo, k1, r["value"]))
         out(f"{name:14s} {label:30s} {r['value']:9.1f} it/s  " + "  ".join(f"{k} {v['ms'] * 1e3:.1f}" for k, v in r["kernels"].items())
             + f"  K1 on CSR bytes {(12 * nnz + 28 * dims[0]) / k1 / 1e6 / 8000:.3f} of peak  lowered in {r['lowered_once']['from_csr_s']:.2f} s  " + algo)
+    # the statement the test used to make (a comparison that needs re-sampling is a benchmark, so it lives here)
+    if rows and rows[0][0] == "default":
+        best = min(rows, key=lambda q: q[2])
+        out(f"{name:14s} pick = {rows[0][1].split()[0]}: K1 {rows[0][2] * 1e3:.1f} us, {100.0 * (rows[0][2] / best[2] - 1.0):+.1f} % against the fastest form measured here ({best[0]})")
     return rows
 
 
