@@ -228,6 +228,23 @@ class CgneState:
         return self
 
 
+class BcgState:
+    """bcgInit / bcgStep: the COMMENTED code of Sparse.hs:886-909 (extension; parity unpinned by the reference -- dead code there)."""
+
+    def __init__(self, A, b, x0):
+        self.A, self.At = A, transpose(A)
+        n = A.m
+        self.x, self.r, self.rhat, self.p, self.phat = (np.zeros(n) for _ in range(5))
+        v = A.view()
+        lib().orc_bcg_init(C.byref(v), _p(_f64(b)), _p(_f64(x0)), _p(self.x), _p(self.r), _p(self.rhat), _p(self.p), _p(self.phat))
+
+    def step(self, k=1):
+        v, vt = self.A.view(), self.At.view()
+        for _ in range(k):
+            lib().orc_bcg_step(C.byref(v), C.byref(vt), _p(self.x), _p(self.r), _p(self.rhat), _p(self.p), _p(self.phat))
+        return self
+
+
 def linsolve0(method, A, b, x0):
     """Returns (rc, x, iters, resnorm, r0norm)."""
     b, x0 = _f64(b), _f64(x0)

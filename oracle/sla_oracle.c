@@ -394,6 +394,44 @@ int orc_cgne_step(const orc_csr *A, const orc_csr *At, double *x, double *r, dou
     return ORC_OK;
 }
 
+/* ---------------------------------------------------------------- (f).3: BCG (extension) */
+
+/* bcgInit / bcgStep restate the COMMENTED code of Sparse.hs:886-909 (dead in the reference: `linSolve0 BCG_` throws, :1031,
+ * and orc_linsolve0 keeps doing so).  PARITY UNPINNED BY THE REFERENCE: no test, golden vector or call site of it exists there;
+ * this restatement is pinned only to the commented formulas, with the two initialisers the comment leaves out completed the
+ * only way the step can use them (p0 = r0, p0hat = r0hat).
+ * bcgInit aa b x0 = BCG x0 r0 r0hat p0 p0hat where r0 = b ^-^ (aa #> x0) ; r0hat = r0   (:891-897) */
+void orc_bcg_init(const orc_csr *A, const double *b, const double *x0, double *x, double *r, double *rhat, double *p, double *phat) {
+    int64_t n = A->m;
+    orc_bicgstab_init(A, b, x0, x, r, p);          /* x = x0, r = b ^-^ (aa #> x0), p = r  */
+    memcpy(rhat, r, sizeof(double) * (size_t)n);
+    memcpy(phat, r, sizeof(double) * (size_t)n);
+}
+
+/* bcgStep aa (BCG x r rhat p phat) (Sparse.hs:899-909); At = transpose aa, built once by the caller */
+int orc_bcg_step(const orc_csr *A, const orc_csr *At, double *x, double *r, double *rhat, double *p, double *phat) {
+    int64_t n = A->m;
+    double *aap = tnew(n), *atp = tnew(n), *t = tnew(n);
+    if (!aap || !atp || !t) return ORC_ERR_ALLOC;
+    orc_spmv(A->m, A->rowptr, A->colidx, A->val, p, aap);           /* aap = aa #> p                     */
+    double rr = orc_dot(n, r, rhat);
+    double alpha = rr / orc_dot(n, aap, phat);                      /* alpha                             */
+    orc_scale(n, alpha, p, t);
+    orc_add(n, x, t, x);                                            /* x1 = x ^+^ alpha.*p               */
+    orc_scale(n, alpha, aap, t);
+    orc_sub(n, r, t, r);                                            /* r1 = r ^-^ alpha.*aap             */
+    orc_spmv(At->m, At->rowptr, At->colidx, At->val, phat, atp);    /* transpose aa #> phat              */
+    orc_scale(n, alpha, atp, t);
+    orc_sub(n, rhat, t, rhat);                                      /* rhat1 = rhat ^-^ alpha.*(...)     */
+    double beta = orc_dot(n, r, rhat) / rr;                         /* beta = (r1.rhat1) / (r.rhat)      */
+    orc_scale(n, beta, p, t);
+    orc_add(n, r, t, p);                                            /* p1 = r1 ^+^ beta.*p               */
+    orc_scale(n, beta, phat, t);
+    orc_add(n, rhat, t, phat);                                      /* phat1 = rhat1 ^+^ beta.*phat      */
+    tfree(aap, n); tfree(atp, n); tfree(t, n);
+    return ORC_OK;
+}
+
 /* ---------------------------------------------------------------- A8: linSolve0 */
 
 /* trueResidualNorm x = norm2 ((aa #> x) ^-^ b)   (Sparse.hs:1041) */

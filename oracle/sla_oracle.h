@@ -88,6 +88,9 @@ int orc_cgs_step(const orc_csr *A, const double *rhat, double *x, double *r, dou
 void orc_cgne_init(const orc_csr *A, const orc_csr *At, const double *b, const double *x0,
                    double *x, double *r, double *p);
 int orc_cgne_step(const orc_csr *A, const orc_csr *At, double *x, double *r, double *p);
+/* (f).3 extension: bcgInit / bcgStep, the commented code of Sparse.hs:886-909 (parity unpinned by the reference: dead code there) */
+void orc_bcg_init(const orc_csr *A, const double *b, const double *x0, double *x, double *r, double *rhat, double *p, double *phat);
+int orc_bcg_step(const orc_csr *A, const orc_csr *At, double *x, double *r, double *rhat, double *p, double *phat);
 
 /* A8: linSolve0, Sparse.hs:1016-1072.  Returns ORC_OK / ORC_ERR_DIM / ORC_ERR_UNSUPPORTED.
  * nb = dim b.  iters_out = number of steps taken (200 = silent return), resnorm_out = last true

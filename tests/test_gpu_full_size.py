@@ -96,7 +96,10 @@ def test_bench_contract_small(fuse45):
         assert "onchip:" in d["kernels"]["ONCHIP"]["plan"]
     else:
         assert set(d["kernels"]) == ({"K1", "K23", "K45"} if fuse45 == "1" else {"K1", "K2", "K3", "K4", "K5"})
-        assert d["roofline"]["launches_timed"] == 8 * 5
+        # (launch-bound size: the timed windows replay a captured graph -- no stream events inside it -- and the dominant kernel's figure comes
+        # from the event-timed pass of one window's length right after them; otherwise its events cover all five windows)
+        graph_replay = "captured HIP graph" in d["roofline"]["timing"]
+        assert d["roofline"]["launches_timed"] == (8 if graph_replay else 8 * 5)
     for k in d["kernels"].values():
         assert 0.0 < k["frac"] <= 1.0 and k["bytes"] <= k["csr_bytes"] + 64 and k["launches"] == (1 if onchip else 8)
     assert d["roofline"]["kernel"].split(":")[0] in d["kernels"]
