@@ -238,6 +238,59 @@ def exchange_table(ctx):
     return out
 
 
+# xGMI on MI355X: 7 links per GPU (one to each peer of an 8-GPU node), ~153 GB/s per link and direction (SURVEY section 5 / the hardware brief).
+XGMI_LINK_GBS = 153.0
+XGMI_LINKS = 7
+RCCL_LAUNCH_US = 20.0   # LABNOTES L6: 15-25 us per grouped RCCL launch over xGMI (an ESTIMATE until an N > 1 run replaces it)
+
+
+def exchange_roofline(A, ex, kt, steps_recorded, step_ms, real_links, halo_rides_with_sums):
+    """the link roofline of a row-sharded block.  For every event-timed exchange of exchange_table(): the bytes the PLAN
+    moves per peer in one exchange (sla_csr_exchange_plan), GB/s on the busiest link against the per-link xGMI peak, aggregate receive rate
+    against the links in use -- and next to the measurement the model DESIGN.md section 6 / LABNOTES L6 predict the first N > 1 run with
+    (launch latency + busiest-peer bytes / link peak, exchanges not overlapped), so that a deviation names itself on first contact.
+    real_links: the ranks are distinct GPUs (an RCCL communicator of > 1 rank); otherwise the bytes cross no link (loopback ranks / one rank)
+    and the fractions only say what these bytes WOULD cost."""
+    try:
+        send, recv = A.exchange_plan()
+        props = A.props()
+    except Exception as e:   # (a single-rank matrix: no plan)
+        return {"available": False, "why": str(e)}
+    busiest = int(8 * max(int(send.max(initial=0)), int(recv.max(initial=0))))
+    recv_total, send_total = int(8 * recv.sum()), int(8 * send.sum())
+    peers = int(((send > 0) | (recv > 0)).sum())
+    nr = int(props["nranks"])
+    sums_bytes = 32 * max(nr - 1, 0)      # per-rank partial sums: <= 4 doubles to / from every peer
+    out = {"link_peak_gbps": XGMI_LINK_GBS, "links_per_gpu": XGMI_LINKS, "mode": {0: "none", 1: "allgather", 2: "window"}[int(props["x_exchange"])],
+           "peers": peers, "bytes_to_busiest_peer": busiest, "bytes_received_per_exchange": recv_total, "bytes_sent_per_exchange": send_total,
+           "real_links": bool(real_links),
+           "links": "xGMI between distinct GPUs" if real_links else
+                    "none -- rehearsal (loopback ranks on one GPU or a 1-rank communicator): no byte crosses a link; fractions say what the plan's bytes would cost",
+           "model": {"launch_latency_us": RCCL_LAUNCH_US, "link_gbps": XGMI_LINK_GBS, "formula": "ms = latency + bytes_to_busiest_peer / link peak, per exchange; "
+                     "step = sum of the kernels' event times + the exchanges of a step, nothing overlapped (an upper bound where halos overlap interior rows)",
+                     "source": "DESIGN.md section 6 / LABNOTES L6 (estimates; no N > 1 run exists yet)"},
+           "exchanges": {}}
+    model_step = sum(v["ms"] * v["launches"] for v in kt.values()) / max(steps_recorded, 1) if kt else 0.0
+    for name, e in ex.items():
+        carries_plan = name == "x_exchange" or (name == "sums" and halo_rides_with_sums)
+        b_peer = (busiest if carries_plan else 0) + (32 if name == "sums" and nr > 1 else 0)
+        b_recv = (recv_total if carries_plan else 0) + (sums_bytes if name == "sums" else 0)
+        ms = e["ms"]
+        model_ms = RCCL_LAUNCH_US * 1e-3 + b_peer / (XGMI_LINK_GBS * 1e9) * 1e3
+        per_step = e["launches"] / max(steps_recorded, 1)
+        model_step += per_step * model_ms
+        out["exchanges"][name] = {
+            "bytes_to_busiest_peer": b_peer, "bytes_received": b_recv, "ms": ms, "per_step": per_step,
+            "gbps_busiest_link": b_peer / (ms * 1e-3) / 1e9 if ms else None,
+            "frac_of_link_peak": b_peer / (ms * 1e-3) / 1e9 / XGMI_LINK_GBS if ms else None,
+            "gbps_received": b_recv / (ms * 1e-3) / 1e9 if ms else None,
+            "frac_of_links_in_use": b_recv / (ms * 1e-3) / 1e9 / (XGMI_LINK_GBS * max(1, min(peers, XGMI_LINKS))) if ms else None,
+            "model_ms": model_ms, "measured_over_model": ms / model_ms if model_ms else None,
+            "bound": "latency" if b_peer / (XGMI_LINK_GBS * 1e9) * 1e6 < RCCL_LAUNCH_US else "link"}
+    out["step"] = {"measured_ms": step_ms, "model_ms": model_step, "measured_over_model": step_ms / model_step if model_step else None}
+    return out
+
+
 def timed_steps(ctx, st, steps, warmup, sync_all, event_free=False, conv=None):
     """Warm-up (which also finds the kernel with the largest share of a step), then EXACTLY `steps` timed steps bracketed by
     barrier + sync, with HIP events around the dominant kernel's launches only (events around all five kernels of a
@@ -397,7 +450,7 @@ def end_to_end_block(ctx, A, dims, rp, ci, va, b_host, t_from_csr, steady_its, w
     return out
 
 
-def sharded_random_block(ctx, name, rank, world, sync_all, allreduce, steps, warmup):
+def sharded_random_block(ctx, name, rank, world, sync_all, allreduce, steps, warmup, real_links=False):
     """BASELINE config 3a (n rows, 16 random picks per row, symmetrised: ~33 entries per row) row-sharded over the ranks of `ctx`:
     every rank assembles its own slab (workloads.random_spd_rows), b = A x* with x* = N(0, 1) seed 7 (SURVEY 8(d)), x0 = 0;
     timed like the headline (barrier + sync on both sides, max over ranks).  Every rank must call this (collectives inside)."""
@@ -424,6 +477,7 @@ def sharded_random_block(ctx, name, rank, world, sync_all, allreduce, steps, war
     nnz = int(allreduce(nnz_local))
     kt = kernel_table(ctx, A, nnz_local, n_local, "bicgstab")
     ex = exchange_table(ctx)
+    xroof = exchange_roofline(A, ex, kt, steps, dt / steps * 1e3, real_links, False)
     note = convergence_note(ctx, st, n, r0norm, conv.get("res_before", float("nan")))
     k1 = kt.get("K1", {})
     rec = {"workload": f"{n}-row fp64 random SPD (~33 nnz/row), row-sharded x{world}", "rows": n, "nnz": nnz, "steps": steps, "warmup": warmup,
@@ -433,7 +487,7 @@ def sharded_random_block(ctx, name, rank, world, sync_all, allreduce, steps, war
            "step_effective_frac_on_csr_bytes": (24 * nnz + 160 * n) / (dt / steps) / 1e9 / (HBM_PEAK_GBS * world),
            "k1_ms": k1.get("ms"), "k1_frac": k1.get("frac"), "k1_csr_frac": k1.get("effective_frac"),
            "kernels_rank0": {k_: {"ms": v["ms"], "frac": v["frac"]} for k_, v in kt.items()},
-           "exchanges_rank0": ex, "spmv_kernel": A.kernel_info(), "slab_assembly_s": t_gen}
+           "exchanges_rank0": ex, "exchange_roofline": xroof, "spmv_kernel": A.kernel_info(), "slab_assembly_s": t_gen}
     kinfo = A.kernel_info()
     if "allgather=" in kinfo:   # the x all-gather goes out as grouped send/recv launches on the comm stream, the tile launch as panel passes behind them
         tok = dict(t.split("=") for t in kinfo.split() if "=" in t)
@@ -477,7 +531,7 @@ def enter_stage(rank, name, limit_s=None):
 FALLBACK_OPTIONS = {"x_exchange": "allgather", "ag_groups": 0, "bicg_ghost": 0}
 
 
-def preflight(ctx, rank, world, fallback):
+def preflight(ctx, rank, world, fallback, allreduce=None):
     """One checked collective at a time across the real ranks BEFORE anything is lowered or timed (sla_dist_preflight), each phase
     stamped on stderr: ncclAllGather, the integer all-reduce, then the all-gather as one ncclSend / ncclRecv group (the pattern of
     the halo exchange and of the overlapped all-gather).  If the grouped phase fails, the job falls back to the plain all-gather
@@ -502,13 +556,23 @@ def preflight(ctx, rank, world, fallback):
             break
         out[name] = {"ms": ms, "max_abs_err": err}
         stamp(rank, f"preflight: {name} ok in {ms:.1f} ms")
+    # The fallback decision must be the SAME on every rank: a grouped phase that failed on some ranks only would leave the
+    # ranks issuing different collectives in the next stage -- a hang with no deadline.  Agree over the CONTROL plane (gloo / the loopback
+    # barrier, not the communicator under test): anyone's failure sends everybody to the fallback flow.
+    if allreduce is not None and world > 1:
+        enter_stage(rank, "preflight: agreeing on the flow across ranks", limit)
+        anyone = allreduce(1.0 if fallback else 0.0, "max") > 0.0
+        if anyone and not fallback:
+            fallback = "pre-flight of the grouped ncclSend/ncclRecv flow failed on another rank; every exchange through plain ncclAllGather instead"
+            out.pop("grouped ncclSend/ncclRecv all-gather", None)
+            stamp(rank, "FALLBACK: " + fallback)
     if fallback:
         ctx.set_options(**FALLBACK_OPTIONS)
     enter_stage(rank, "lowering / timing")
     return out, fallback
 
 
-def contract_allgather_block(ctx, dims, rb, rp, ci, va, b_local, n, method, steps, warmup, sync_all, allreduce):
+def contract_allgather_block(ctx, dims, rb, rp, ci, va, b_local, n, method, steps, warmup, sync_all, allreduce, real_links=False):
     """BASELINE.json config 4 to the letter: "RCCL all-gather(x) per BiCGSTAB step" -- the same slabs lowered again under
     x_exchange = allgather / ag_groups = 0 (every (#>) input through ONE ncclAllGather into the full-length buffer, no halo
     exchange, no ghost-row flow), timed with the headline's protocol, collectives event-timed.  Every rank must call this."""
@@ -524,6 +588,7 @@ def contract_allgather_block(ctx, dims, rb, rp, ci, va, b_local, n, method, step
         dt = allreduce(dt, "max")
         kt = kernel_table(ctx, A, int(rp[-1]), len(b_local), method)
         ex = exchange_table(ctx)
+        xroof = exchange_roofline(A, ex, kt, steps, dt / steps * 1e3, real_links, False)
         del st, A, bvec
     finally:
         ctx.set_options(**saved)
@@ -534,7 +599,7 @@ def contract_allgather_block(ctx, dims, rb, rp, ci, va, b_local, n, method, step
             "x_exchange": "ncclAllGather" if "x_exchange=allgather" in kinfo and "allgather=" not in kinfo else "see spmv_kernel",
             "allgather_ms": xb.get("ms"), "allgather_launches": xb.get("launches"),
             "allgather_bytes_received_per_rank": 8 * (n - len(b_local)),
-            "kernels_rank0": {k_: {"ms": v["ms"], "frac": v["frac"]} for k_, v in kt.items()}, "exchanges_rank0": ex, "spmv_kernel": kinfo}
+            "kernels_rank0": {k_: {"ms": v["ms"], "frac": v["frac"]} for k_, v in kt.items()}, "exchanges_rank0": ex, "exchange_roofline": xroof, "spmv_kernel": kinfo}
 
 
 def run_rank(args, rank, world, local_rank, dist_mode, loop=None):
@@ -564,8 +629,29 @@ def run_rank(args, rank, world, local_rank, dist_mode, loop=None):
         ctx = sla.Context(0)
         sla.set_default_context(ctx)
     fallback, pre = os.environ.get("SLA_BENCH_FALLBACK"), None
+    real_links = dist_mode == "rccl" and world > 1      # distinct GPUs behind the ranks: the exchanges cross xGMI (exchange_roofline)
+
+    def allreduce(v, op="sum"):
+        if dist_mode == "rccl":
+            import torch
+            t = torch.tensor([v], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX if op == "max" else dist.ReduceOp.SUM)
+            return float(t.item())
+        if dist_mode == "loopback":
+            barrier, shared = loop
+            shared.setdefault(("ar", op), {})[rank] = v
+            barrier.wait()
+            vals = list(shared[("ar", op)].values())
+            out = max(vals) if op == "max" else sum(vals)
+            barrier.wait()
+            if rank == 0:
+                shared[("ar", op)] = {}
+            barrier.wait()
+            return out
+        return v
+
     if dist_mode:
-        pre, fallback = preflight(ctx, rank, world, fallback)
+        pre, fallback = preflight(ctx, rank, world, fallback, allreduce)
 
     # ---- build this rank's slab on the host, lower it once to the device CSR ---------------------------
     if world == 1:
@@ -586,25 +672,6 @@ def run_rank(args, rank, world, local_rank, dist_mode, loop=None):
     b_local = np.add.reduceat(va, rp[:-1]) if nnz_local else np.zeros(0)   # b = A . 1  (x* = 1), x0 = 0
     if len(b_local) != n_local:                                              # (rows without entries at a slab's end)
         b_local = np.resize(b_local, n_local)
-
-    def allreduce(v, op="sum"):
-        if dist_mode == "rccl":
-            import torch
-            t = torch.tensor([v], dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX if op == "max" else dist.ReduceOp.SUM)
-            return float(t.item())
-        if dist_mode == "loopback":
-            barrier, shared = loop
-            shared.setdefault(("ar", op), {})[rank] = v
-            barrier.wait()
-            vals = list(shared[("ar", op)].values())
-            out = max(vals) if op == "max" else sum(vals)
-            barrier.wait()
-            if rank == 0:
-                shared[("ar", op)] = {}
-            barrier.wait()
-            return out
-        return v
 
     nnz = int(allreduce(nnz_local))
     bvec = sla.DeviceVector(ctx, n, b_local, local=True)
@@ -635,6 +702,8 @@ def run_rank(args, rank, world, local_rank, dist_mode, loop=None):
             extra["step_graph"] = False
         if dist_mode:
             extra["exchanges"] = exchange_table(ctx)
+            ghost_flow = "x_exchange=window" in A.kernel_info() and ctx.get_option("bicg_ghost") != "0"
+            extra["exchange_roofline"] = exchange_roofline(A, extra["exchanges"], kt, args.steps, dt / args.steps * 1e3, real_links, ghost_flow)
         launches, mean_ms, min_ms = dom_stats
         step_bytes = 24 * nnz + 160 * n
         mode_desc = f"{'bicgstabStep' if args.method == 'bicgstab' else 'cgsStep'} (2 SpMV, no true-residual SpMV)"
@@ -698,13 +767,13 @@ def run_rank(args, rank, world, local_rank, dist_mode, loop=None):
     rname = {"auto": {"laplace3d_10m": "random_spd_10m", "laplace3d_small": "random_spd_small"}.get(args.workload)}.get(args.random_block, args.random_block)
     if dist_mode and args.mode == "step" and args.method == "bicgstab" and rname and rname != "none":
         enter_stage(rank, f"{rname} block (row-sharded random matrix, x all-gathered)")
-        rblock = sharded_random_block(ctx, rname, rank, world, sync_all, allreduce, max(20, args.steps // 4), max(5, args.warmup // 2))
+        rblock = sharded_random_block(ctx, rname, rank, world, sync_all, allreduce, max(20, args.steps // 4), max(5, args.warmup // 2), real_links)
 
     cblock = None
     if dist_mode and args.mode == "step" and args.workload.startswith("laplace3d") and os.environ.get("SLA_BENCH_CONTRACT", "1") != "0":
         enter_stage(rank, "contract_allgather block (config 4 through ncclAllGather)")
         cblock = contract_allgather_block(ctx, dims, rb, rp, ci, va, b_local, n, args.method, max(20, args.steps // 2), max(5, args.warmup // 2),
-                                          sync_all, allreduce)
+                                          sync_all, allreduce, real_links)
         enter_stage(rank, "plain (#>) timing")
 
     # ---- plain SpMV bandwidth (rank-local rows; includes the exchange when sharded) -----------------------

@@ -29,6 +29,8 @@ module Numeric.LinearAlgebra.Sparse.HIP
   , BICGSTAB, bicgsInit, bicgstabStep, bicgstabSteps, _xBicgstab, _rBicgstab, _pBicgstab
   , CGS, cgsInit, cgsStep, cgsSteps, _x, _r, _p, _u
   , CGNE, cgneInit, cgneStep, cgneSteps, _xCgne, _rCgne, _pCgne
+    -- * extension: the reference keeps bcgInit / bcgStep commented out (Sparse.hs:889-909)
+  , BCG, bcgInit, bcgStep, bcgSteps, _xBcg, _rBcg, _rHatBcg, _pBcg, _pHatBcg
     -- * the class route: a device-dispatching vector type with the reference's instances
   , Dev(..), toDev, fromDev
     -- * monomorphic spellings of the class methods (no wrapper)
@@ -312,6 +314,24 @@ cgneSteps k (CGNE (fs, n)) = CGNE (steppedCopy "cgneStep" Nothing k fs, n)
 
 _xCgne, _rCgne, _pCgne :: CGNE -> R.SpVector Double
 _xCgne (CGNE s) = field 0 s; _rCgne (CGNE s) = field 1 s; _pCgne (CGNE s) = field 2 s
+
+-- | BCG (Sparse.hs:886-909): an EXTENSION -- the reference declares the record and keeps @bcgInit@ / @bcgStep@ commented out; the device
+--   runs exactly those formulas (one @(#>)@, one @(<#)@, two sweeps per step) with @p0 = r0@, @p0hat = r0hat = r0@.  @linSolve0 BCG_@
+--   throws @IterE@ here as it does there (:1031).
+newtype BCG = BCG (ForeignPtr Solver, Int)
+
+bcgInit :: R.SpMatrix Double -> R.SpVector Double -> R.SpVector Double -> BCG
+bcgInit aa b x0 = BCG (unsafePerformIO (initWith 2 aa b x0), R.ncols aa)
+
+-- | bcgStep aa state (the commented code, Sparse.hs:899-909): a NEW record
+bcgStep :: R.SpMatrix Double -> BCG -> BCG
+bcgStep _aa (BCG (fs, n)) = BCG (steppedCopy "bcgStep" Nothing 1 fs, n)
+
+bcgSteps :: Int -> BCG -> BCG
+bcgSteps k (BCG (fs, n)) = BCG (steppedCopy "bcgStep" Nothing k fs, n)
+
+_xBcg, _rBcg, _rHatBcg, _pBcg, _pHatBcg :: BCG -> R.SpVector Double
+_xBcg (BCG s) = field 0 s; _rBcg (BCG s) = field 1 s; _pBcg (BCG s) = field 2 s; _rHatBcg (BCG s) = field 4 s; _pHatBcg (BCG s) = field 5 s
 
 -- ---------------------------------------------------------------------------------------------------------------------------
 -- The class route.  'Dev' wraps the reference's own sparse vector; its instances of the reference's classes send the heavy methods

@@ -87,8 +87,12 @@ enum { /* sla_solve_info.flags */
     SLA_FLAG_DIAGONAL = 4,    /* isDiagonalSM shortcut taken (Sparse.hs:1024-1025) */
     SLA_FLAG_BREAKDOWN = 8,   /* Arnoldi: nearZero h_{i+1,i} (Sparse.hs:665-667) */
     SLA_FLAG_NONFINITE = 16,  /* residual became NaN/Inf (reference propagates NaN, no guard) */
-    SLA_FLAG_SYNC_TIMEOUT = 32 /* a persistent on-chip step launch gave up waiting for its other workgroups (another job holding CUs): the state record is
+    SLA_FLAG_SYNC_TIMEOUT = 32, /* a persistent on-chip step launch gave up waiting for its other workgroups (another job holding CUs): the state record is
                                   unchanged by that launch's unfinished steps only up to the step it stopped in -- treat it as lost */
+    SLA_FLAG_RELAXED_ORDER = 64 /* the matrix's (#>) adds a row's products in an order that is not fixed from run to run (sla_csr_props.fold ==
+                                  SLA_FOLD_RELAXED: the CU-wide tile form, option tile_relaxed = 1): x, iters and resnorm of this solve are within
+                                  the rounding bound of the reference's fold but may differ in the last bits next time.  Set by sla_linsolve0 /
+                                  sla_gmres / sla_linsolve; tile_relaxed = 0 before the matrix is created gives the bit-reproducible form */
 };
 
 typedef struct {
@@ -104,7 +108,8 @@ typedef struct {
 
 /* which state vector sla_solver_get returns: record fields _x/_r/_p/_u (Sparse.hs:919),
  * _xBicgstab/_rBicgstab/_pBicgstab (:959-960), _xCgne/_rCgne/_pCgne (:855-856) */
-typedef enum { SLA_STATE_X = 0, SLA_STATE_R = 1, SLA_STATE_P = 2, SLA_STATE_U = 3 } sla_state_field;
+typedef enum { SLA_STATE_X = 0, SLA_STATE_R = 1, SLA_STATE_P = 2, SLA_STATE_U = 3,
+               SLA_STATE_RHAT = 4, SLA_STATE_PHAT = 5 /* BCG records only: _rHatBcg, _pHatBcg (Sparse.hs:886-887) */ } sla_state_field;
 
 /* ---- context ---------------------------------------------------------------------------------- */
 
@@ -236,12 +241,14 @@ int sla_scal(double a, sla_vec_t x);                   /* x := a .* x; normalize
 
 /* cgsInit / bicgsInit / cgneInit (Sparse.hs:921-924, 962-965, 864-868).  `method` is SLA_CGS_,
  * SLA_BICGSTAB_ or SLA_CGNE_.  The shadow residual r0hat = b - A x0 of the README usage
- * (README.md:205-226) is kept inside the state. */
+ * (README.md:205-226) is kept inside the state.
+ * Extension: SLA_BCG_ builds the record of the reference's COMMENTED bcgInit / bcgStep (Sparse.hs:886-909: x r rhat p phat with
+ * rhat0 = p0 = phat0 = r0; one (#>) and one (<#) per step).  sla_linsolve0 still rejects SLA_BCG_ like linSolve0 does (:1031). */
 int sla_solver_init(int method, sla_csr_t A, sla_vec_t b, sla_vec_t x0, sla_solver_t *out);
 /* k applications of cgsStep / bicgstabStep / cgneStep (Sparse.hs:928-939, 972-981, 870-878):
  * `iterate step s !! k`.  Enqueues and returns; no convergence test. */
 int sla_solver_step(sla_solver_t, int k_steps);
-/* copy a state field (_x, _r, _p, _u) into `out` */
+/* copy a state field (_x, _r, _p, _u; BCG records: _x, _r, _p, _rHat, _pHat) into `out` */
 int sla_solver_get(sla_solver_t, int field, sla_vec_t out);
 /* A deep copy of a state record.  The reference's step functions are pure (`bicgstabStep aa r0hat s` returns a new record,
  * Sparse.hs:972-981): a binding that must keep s while stepping on -- `iterate (bicgstabStep aa r0hat) s0 !! k`,
@@ -339,6 +346,32 @@ int sla_ctx_comm_ranks(sla_ctx_t, int *nranks);
  * 1-byte column codes), "stream[+xwin]" (values + i32 columns), "stream+ldspanels" (dense rows: x in LDS panels), "stream+colpanels" (irregular,
  * x > L2), "scalar"; row-sharded matrices add " x_exchange=window|allgather" */
 int sla_csr_kernel_info(sla_csr_t, char *buf, int buflen);
+/* Typed properties of a lowered matrix (what sla_csr_kernel_info prints, for callers that must not parse a string).
+ * fold: how (#>) adds the products of a row (Common.hs:247-260 folds them left to right in ascending column order):
+ *   SLA_FOLD_EXACT      that fold bit for bit on every row, reruns bit-identical (value-indexed forms, wave / exact tile forms);
+ *   SLA_FOLD_REGROUPED  a FIXED regrouping for long rows (lane-group / wavefront / workgroup partial sums): within
+ *                       nnz_i * eps * sum |a_ij x_j| of the reference's value, reruns bit-identical;
+ *   SLA_FOLD_RELAXED    the same set of separately rounded products added in timing order (LDS atomics of the CU-wide tile form):
+ *                       same bound, NOT reproducible bit for bit from run to run.
+ * x_exchange: 0 single rank, 1 all-gather of x per (#>), 2 window (halo) exchange.  struct_size as in sla_solve_info. */
+typedef enum { SLA_FOLD_EXACT = 0, SLA_FOLD_REGROUPED = 1, SLA_FOLD_RELAXED = 2 } sla_fold_kind;
+typedef struct {
+    int32_t struct_size;  /* IN: sizeof(sla_csr_props) of the caller's header */
+    int32_t fold;         /* sla_fold_kind */
+    int32_t x_exchange;
+    int32_t nranks;
+    int64_t rows_local;   /* rows / stored entries of this rank's block */
+    int64_t nnz_local;
+    int32_t rowptr_bits;  /* 32 or 64 */
+    int32_t reserved;
+} sla_csr_props;
+#define SLA_CSR_PROPS_INIT {(int32_t)sizeof(sla_csr_props), 0, 0, 0, 0, 0, 0, 0}
+int sla_csr_get_props(sla_csr_t A, sla_csr_props *out);
+/* Row-sharded matrices: what ONE exchange of a (#>) input moves, as planned at creation -- doubles this rank sends to /
+ * receives from each peer (nranks entries each, cap >= nranks; the own slot is 0).  Window mode: the peers' parts of this rank's column
+ * window; all-gather mode: whole shards.  bench.py prices the event-timed exchanges against the xGMI link peak with it.  Single-rank
+ * matrices: SLA_ERR_INVALID. */
+int sla_csr_exchange_plan(sla_csr_t A, int64_t *send_len, int64_t *recv_len, int cap);
 /* What "lowered once" cost (fromListSM -> device, SpMatrix.hs:218-224): the wall-clock phases of this matrix's lowering as
  * "phase=milliseconds;..." (validation + narrowing + upload of the canonical arrays, one analysis per storage form, the exchange plan,
  * the tile form); bench.py reports it in its end_to_end block. */

@@ -262,6 +262,8 @@ class SolverState {
     SpVector _r() const { return field(SLA_STATE_R, A_.nrows()); }
     SpVector _p() const { return field(SLA_STATE_P, A_.ncols()); }
     SpVector _u() const { return field(SLA_STATE_U, A_.nrows()); }
+    SpVector _rHat() const { return field(SLA_STATE_RHAT, A_.nrows()); }   // BCG records only (Sparse.hs:886-887)
+    SpVector _pHat() const { return field(SLA_STATE_PHAT, A_.nrows()); }
 
   private:
     SpMatrix A_;
@@ -270,6 +272,9 @@ class SolverState {
 inline SolverState bicgsInit(const SpMatrix &A, const SpVector &b, const SpVector &x0) { return SolverState(LinSolveMethod::BICGSTAB_, A, b, x0); }
 inline SolverState cgsInit(const SpMatrix &A, const SpVector &b, const SpVector &x0) { return SolverState(LinSolveMethod::CGS_, A, b, x0); }
 inline SolverState cgneInit(const SpMatrix &A, const SpVector &b, const SpVector &x0) { return SolverState(LinSolveMethod::CGNE_, A, b, x0); }
+// extension: the reference's bcgInit / bcgStep are commented out (Sparse.hs:889-909); linSolve0(BCG_) throws like the reference
+inline SolverState bcgInit(const SpMatrix &A, const SpVector &b, const SpVector &x0) { return SolverState(LinSolveMethod::BCG_, A, b, x0); }
+inline SolverState &bcgStep(SolverState &s, int k = 1) { return s.step(k); }
 inline SolverState &bicgstabStep(SolverState &s, int k = 1) { return s.step(k); }
 inline SolverState &cgsStep(SolverState &s, int k = 1) { return s.step(k); }
 inline SolverState &cgneStep(SolverState &s, int k = 1) { return s.step(k); }

@@ -55,17 +55,21 @@ int fail(int code, const std::string &msg) {
     return code;
 }
 
+// Sizes that pass: the layout this library was built with, or a LARGER one of a newer header -- 8-byte granularity and at most 64 bytes
+// more.  The window is kept that narrow on purpose: a caller from before struct_size existed has max_iters in the first
+// member, and the reference's default nits = 200 (Sparse.hs:1038) satisfied the earlier "+256" window (200 > 48, <= 304, 200 % 8 == 0) --
+// 48 bytes were then read from a 32-byte struct.  With +64 every value from 113 up, 200 included, is refused; so are 0 .. 47.
 static bool struct_size_ok(int32_t got, size_t current) {
-    return got == (int32_t)current || (got > (int32_t)current && got <= (int32_t)current + 256 && got % 8 == 0);
+    return got == (int32_t)current || (got > (int32_t)current && got <= (int32_t)current + 64 && got % 8 == 0);
 }
+static_assert(sizeof(sla_solve_opts) + 64 < 200 && sizeof(sla_solve_info) + 64 < 200, "a v1 caller's max_iters = 200 must never pass for a struct_size");
 int read_solve_opts(const sla_solve_opts *in, sla_solve_opts *out, const char *who) {
     const sla_solve_opts def = SLA_SOLVE_OPTS_INIT;
     *out = def;
     if (!in) return SLA_OK;
     // (the first layout with a struct_size ends behind history_cap; anything shorter is a caller from before the field existed,
     // whose first member was max_iters -- refuse instead of reading a trace pointer that is not there)
-    // Only layouts that were ever published pass: the current one, or a LARGER one of a newer header (8-byte granularity, at most 256
-    // bytes more) -- a v1 caller's max_iters (200 by default) must not be taken for a size ([44, 4096] let it through)
+    // (which sizes pass: struct_size_ok above)
     if (!struct_size_ok(in->struct_size, sizeof(sla_solve_opts)))
         return fail(SLA_ERR_INVALID, std::string(who) + ": sla_solve_opts.struct_size is not set (use SLA_SOLVE_OPTS_INIT; ABI version " + std::to_string(SLA_ABI_VERSION) + ")");
     memcpy(out, in, std::min<size_t>((size_t)in->struct_size, sizeof(*out)));
@@ -442,6 +446,26 @@ int spmv_transposed(sla_csr *A, const double *x_local, double *y_local, int64_t 
     l.y = c->d_tfull;
     SLA_TRY(launch_spmv(T, l));
     return dist_reduce_scatter_f64(c, c->d_tfull, y_local, y_shard);
+}
+
+// how this matrix's (#>) folds a row (sla_fold_kind): the forms that keep one lane per row whatever its length are exact, the relaxed tile
+// form is order-free, everything else may regroup long rows in a fixed way
+int fold_kind(const sla_csr *A) {
+    const sla_ctx *c = A->ctx;
+    if (c->spmv_algo == 1) return SLA_FOLD_EXACT;
+    if (A->use_wdia && wd_on(A)) return SLA_FOLD_EXACT;
+    if (A->use_vdict && c->vdict) return SLA_FOLD_EXACT;
+    if (A->use_lpanel && c->lpanel) return SLA_FOLD_REGROUPED;
+    if (lflat_on(A)) return SLA_FOLD_REGROUPED;
+    if (tiles_on(A)) return A->tl_cu ? SLA_FOLD_RELAXED : SLA_FOLD_EXACT;
+    if (!A->panels.empty() && c->panels) return SLA_FOLD_REGROUPED;
+    if (!diag_on(A) && !stream_xwin_on(A) && wave_plain(A)) return SLA_FOLD_EXACT;
+    return SLA_FOLD_REGROUPED;
+}
+bool csr_fold_relaxed(const sla_csr *A) {
+    if (!A) return false;
+    if (!A->kids.empty()) return csr_fold_relaxed(A->kids[0]);
+    return fold_kind(A) == SLA_FOLD_RELAXED;
 }
 
 }  // namespace sla
@@ -1058,6 +1082,46 @@ int sla_csr_kernel_info(sla_csr_t A, char *buf, int buflen) {
         if (used + 1 < (size_t)buflen)
             snprintf(buf + used, (size_t)buflen - used, " x_exchange=%s",
                      A->ctx->x_exchange != 1 && (A->xplan->use_window || A->ctx->x_exchange == 2) ? "window" : "allgather");
+    }
+    return SLA_OK;
+}
+
+int sla_csr_get_props(sla_csr_t A, sla_csr_props *out) {
+    if (!A || !out) return fail(SLA_ERR_INVALID, "sla_csr_get_props: null argument");
+    const int32_t sz = out->struct_size;
+    if (sz < 16 || sz > (int32_t)sizeof(sla_csr_props) + 64 || sz % 8 != 0)
+        return fail(SLA_ERR_INVALID, "sla_csr_get_props: sla_csr_props.struct_size is not set (use SLA_CSR_PROPS_INIT)");
+    const sla_csr *K = A->kids.empty() ? A : A->kids[0];
+    sla_csr_props p = SLA_CSR_PROPS_INIT;
+    p.fold = fold_kind(K);
+    p.x_exchange = !K->xplan ? 0 : (K->ctx->x_exchange != 1 && (K->xplan->use_window || K->ctx->x_exchange == 2)) ? 2 : 1;
+    p.nranks = A->kids.empty() ? K->ctx->nranks : (int32_t)A->kids.size();
+    p.rows_local = K->rows;
+    p.nnz_local = K->nnz;
+    p.rowptr_bits = K->rp64 ? 64 : 32;
+    memcpy(out, &p, std::min<size_t>((size_t)sz, sizeof(p)));
+    out->struct_size = sz;
+    return SLA_OK;
+}
+
+int sla_csr_exchange_plan(sla_csr_t A, int64_t *send_len, int64_t *recv_len, int cap) {
+    if (!A || !send_len || !recv_len) return fail(SLA_ERR_INVALID, "sla_csr_exchange_plan: null argument");
+    if (!A->kids.empty()) return fail(SLA_ERR_INVALID, "sla_csr_exchange_plan: per-rank matrices only (a multi-device bundle plans one exchange per device)");
+    const sla_ctx *c = A->ctx;
+    if (!A->xplan || c->nranks < 1) return fail(SLA_ERR_INVALID, "sla_csr_exchange_plan: not a row-sharded matrix");
+    if (cap < c->nranks) return fail(SLA_ERR_INVALID, "sla_csr_exchange_plan: cap < nranks");
+    const bool window = c->x_exchange != 1 && (A->xplan->use_window || c->x_exchange == 2);
+    const int64_t shard = shard_of(c, A->n);
+    for (int q = 0; q < c->nranks; ++q) {
+        if (q == c->rank) { send_len[q] = recv_len[q] = 0; continue; }
+        if (window) {
+            send_len[q] = (size_t)q < A->xplan->send_len.size() ? A->xplan->send_len[(size_t)q] : 0;
+            recv_len[q] = (size_t)q < A->xplan->recv_len.size() ? A->xplan->recv_len[(size_t)q] : 0;
+        } else {   // whole shards (the last one may be short)
+            auto len = [&](int r) { return std::max<int64_t>(0, std::min<int64_t>(A->n, (int64_t)(r + 1) * shard) - (int64_t)r * shard); };
+            send_len[q] = len(c->rank);
+            recv_len[q] = len(q);
+        }
     }
     return SLA_OK;
 }

@@ -119,11 +119,13 @@ LoopGroup *loop_of(sla_ctx *c) { return (LoopGroup *)c->loop; }
 
 // SLA_FAULT_INJECT (test hook, read once): "p2p" makes every grouped send / recv flow of this file fail with SLA_ERR_RCCL before it
 // touches the communicator, "p2p_hang" makes the pre-flight's send / recv phase sleep on the host forever (no GPU work in flight):
-// what bench.py's fallback ladder and staged watchdog are rehearsed with on a one-GPU box.
+// what bench.py's fallback ladder and staged watchdog are rehearsed with on a one-GPU box.  "p2p_data_rank1": the pre-flight's send / recv
+// phase completes everywhere but RANK 1 ALONE reports that the data arrived wrong -- an asymmetric failure: the ranks must still end
+// up on the same flow (bench.py agrees on the fallback over its control plane).
 int fault_inject() {
     static const int f = [] {
         const char *e = getenv("SLA_FAULT_INJECT");
-        return !e ? 0 : strcmp(e, "p2p") == 0 ? 1 : strcmp(e, "p2p_hang") == 0 ? 2 : 0;
+        return !e ? 0 : strcmp(e, "p2p") == 0 ? 1 : strcmp(e, "p2p_hang") == 0 ? 2 : strcmp(e, "p2p_data_rank1") == 0 ? 3 : 0;
     }();
     return f;
 }
@@ -565,6 +567,7 @@ int dist_preflight(sla_ctx *ctx, int phase, int64_t count, double *max_abs_err, 
                 err = d == d ? std::max(err, d) : 1.0e300;
             }
     }
+    if (phase == 1 && fault_inject() == 3 && ctx->rank == 1) err = 1.0;
     if (max_abs_err) *max_abs_err = err;
     if (ms) *ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return SLA_OK;

@@ -888,6 +888,8 @@ void wd_march_prepare();   // (lowering: queries the instantiations' register co
 int launch_wdia_march(const sla_csr *A, int epi, const SpmvArgs<int32_t> &a, int grid, int stream_nt);
 bool wave_on(const sla_csr *A);                                                                              // sla_spmv_wave.hip
 int wave_grid(const sla_csr *A);
+int fold_kind(const sla_csr *A);           // sla_api.cpp: sla_fold_kind of A's (#>)
+bool csr_fold_relaxed(const sla_csr *A);   // sla_api.cpp: is A's (#>) the order-relaxed tile form (SLA_FLAG_RELAXED_ORDER)?
 bool wave_plain(const sla_csr *A);   // sla_spmv.hip: does a plain (#>) on A end up on spmv_wave_kernel?
 int launch_spmv_wave(const sla_csr *A, int epi, const SpmvArgs<int32_t> &a, int grid);
 int tiles_grid(const sla_csr *A);
@@ -938,6 +940,10 @@ int launch_cgs_c4(sla_ctx *c, int64_t n, SolverScalars *sc, Parts rhonew, int pa
 int launch_cgne_n2(sla_ctx *c, int64_t n, SolverScalars *sc, const double *p, double *x);
 // unfused N3 for the sharded path: beta ; p1 = t ^+^ beta .* p (t = transpose aa #> r1 after the reduce-scatter) ; p1 . p1
 int launch_cgne_n3b(sla_ctx *c, int64_t n, SolverScalars *sc, Parts rr1, int par, const double *t, double *p, double *ppout);
+// BCG (extension: the commented bcgStep, Sparse.hs:899-909)
+int launch_bcg_b3(sla_ctx *c, int64_t n, SolverScalars *sc, Parts app, int par, const double *p, const double *aap, const double *atp, double *x,
+                  double *r, double *rhat, double *rrout);
+int launch_bcg_b4(sla_ctx *c, int64_t n, SolverScalars *sc, Parts rr1, int par, const double *r, const double *rhat, double *p, double *phat);
 // residual check at the end of a host batch (one block): publishes resnorm / done
 int launch_check(sla_ctx *c, SolverScalars *sc, Parts res);
 int launch_init_scalars(sla_ctx *c, SolverScalars *sc, Parts rho, Parts r0sq, double tol_abs, double tol_rel, double *hist = nullptr, int hist_cap = 0);

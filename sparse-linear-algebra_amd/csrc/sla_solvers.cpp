@@ -101,7 +101,7 @@ int solver_alloc(sla_csr *A, int method, sla_solver **out) {
     mk(nx, &S->p);
     mk(nr, &S->r0hat);
     mk(nr, &S->b);
-    if (method == SLA_CGS_) mk(nr, &S->u);
+    if (method == SLA_CGS_ || method == SLA_BCG_) mk(nr, &S->u);   // (BCG: u holds phat)
     if (method != SLA_CGNE_) { mk(nr, &S->t1); mk(nr, &S->t2); mk(nr, &S->t3); }
     else if (c->collectives) mk(nx, &S->t1);  // CGNE, row-sharded: landing buffer of the reduce-scattered A^T r
     hipError_t e = hipSuccess;
@@ -461,6 +461,39 @@ int enqueue_cgne(sla_solver *S, int par, const Parts *check, StepCtl *ctl) {
     return SLA_OK;
 }
 
+// bcgStep -- an EXTENSION: the reference keeps it commented out (Sparse.hs:899-909) and `linSolve0 BCG_` throws (:1031; sla_linsolve0 keeps
+// doing that).  State record BCG x r rhat p phat (:886-887): rhat lives in S->r0hat, phat in S->u.  One (#>), one (<#) and two sweeps:
+//   B1  aap = aa #> p ; aap <.> phat                              (SpMV, EPI_DOT)
+//   B2  transpose aa #> phat                                      (SpMV on the transposed copy; row-sharded: partial + reduce-scatter)
+//   B3  alpha ; x1, r1, rhat1 ; r1 <.> rhat1                      (bcg_b3_kernel)
+//   B4  beta ; p1 = r1 ^+^ beta .* p ; phat1 = rhat1 ^+^ beta .* phat   (bcg_b4_kernel)
+// rho = r <.> rhat is carried from step to step (rho2[par], as in the other methods): the same sum the reference would recompute.
+int enqueue_bcg(sla_solver *S, int par, const Parts *check) {
+    sla_ctx *c = S->ctx;
+    sla_csr *A = S->A;
+    const int64_t n = S->x->n_local;
+    Parts app, rr1;
+    {
+        SpmvLaunch l;
+        l.epi = EPI_DOT;
+        l.y = S->t1->d;
+        l.w = S->u->d;
+        l.p1 = slot(S, P_APR);
+        l.sc = S->d_sc;
+        if (check && check->p) { l.pres = check->p; l.npres = check->n; l.pres_stride = check->stride; }
+        l.step_begin = 1 | (par << 1);
+        l.kernel_id = SLA_KERNEL_SPMV_DOT;
+        int gk = 0;
+        SLA_TRY(spmv_exchanged(A, S->p, l, &gk));
+        SLA_TRY(publish(S, P_APR, -1, gk, &app, nullptr));
+    }
+    SLA_TRY(spmv_transposed(A, S->u->d, S->t2->d, S->t2->shard));
+    SLA_TRY(launch_bcg_b3(c, n, S->d_sc, app, par, S->p->d, S->t1->d, S->t2->d, S->x->d, S->r->d, S->r0hat->d, slot(S, P_RHO)));
+    SLA_TRY(publish(S, P_RHO, -1, vec_grid(n), &rr1, nullptr));
+    SLA_TRY(launch_bcg_b4(c, n, S->d_sc, rr1, par, S->r->d, S->r0hat->d, S->p->d, S->u->d));
+    return SLA_OK;
+}
+
 StepCtl &ctl_of(sla_solver *S) {
     static_assert(sizeof(StepCtl) <= 128, "StepCtl fits the solver's opaque block");
     return *reinterpret_cast<StepCtl *>(S->ctl_storage);
@@ -475,6 +508,7 @@ int enqueue_step(sla_solver *S, bool res_after, bool dual_prev) {
     const Parts *check = S->have_res ? &ctl.res : nullptr;
     if (S->method == SLA_BICGSTAB_) SLA_TRY(enqueue_bicgstab(S, par, check, dual_prev));
     else if (S->method == SLA_CGS_) SLA_TRY(enqueue_cgs(S, par, check, dual_prev));
+    else if (S->method == SLA_BCG_) SLA_TRY(enqueue_bcg(S, par, check));
     else SLA_TRY(enqueue_cgne(S, par, check, &ctl));
     ctl.step_index++;
     S->have_res = false;
@@ -488,7 +522,7 @@ int enqueue_step(sla_solver *S, bool res_after, bool dual_prev) {
 // the dual-SpMV flow needs x and p resident on this rank as whole vectors and the stream kernel
 bool dual_ok(const sla_solver *S) {
     // (with column panels the residual SpMV is cheaper as its own panel-blocked sweep than fused into K1)
-    return !S->ctx->collectives && S->ctx->spmv_algo == 0 && S->ctx->dual_spmv && S->method != SLA_CGNE_ &&
+    return !S->ctx->collectives && S->ctx->spmv_algo == 0 && S->ctx->dual_spmv && S->method != SLA_CGNE_ && S->method != SLA_BCG_ &&
            (S->A->panels.empty() || !S->ctx->panels) &&
            // (the wave-sliced form streams ~2 B of matrix per row: fusing the two sweeps saves nothing there)
            !(S->A->use_wdia && wd_on(S->A)) &&
@@ -506,11 +540,13 @@ int read_scalars(sla_solver *S) {
 // *Init (Sparse.hs:921-924, 962-965, 864-868) + the tolerance of linSolve0 (:1032-1037)
 int solver_init_common(int method, sla_csr *A, sla_vec *b, sla_vec *x0, double tol_abs, double tol_rel, sla_solver **out, int hist_cap = 0) {
     if (!A || !b || !x0 || !out) return fail(SLA_ERR_INVALID, "solver init: null argument");
-    if (method != SLA_BICGSTAB_ && method != SLA_CGS_ && method != SLA_CGNE_)
+    // (SLA_BCG_ is an extension of the STATE-RECORD interface only -- the reference's bcgStep is commented out, Sparse.hs:886-909;
+    // sla_linsolve0 rejects it like the reference's linSolve0 does)
+    if (method != SLA_BICGSTAB_ && method != SLA_CGS_ && method != SLA_CGNE_ && method != SLA_BCG_)
         return fail(SLA_ERR_UNSUPPORTED_METHOD, "Only BICGSTAB_, CGS_, and CGNE_ are implemented");
     if (A->m != b->n) return fail(SLA_ERR_DIM_MISMATCH, "linSolve0 : matrix rows and rhs dimension differ");
     if (A->n != x0->n) return fail(SLA_ERR_DIM_MISMATCH, "matVec : mismatched dimensions");
-    if (method != SLA_CGNE_ && A->m != A->n) return fail(SLA_ERR_DIM_MISMATCH, "CGS/BiCGSTAB need a square matrix");
+    if (method != SLA_CGNE_ && A->m != A->n) return fail(SLA_ERR_DIM_MISMATCH, "CGS/BiCGSTAB/BCG need a square matrix");
     sla_ctx *c = A->ctx;
     if (!b->kids.empty() || !x0->kids.empty() || b->ctx != c || x0->ctx != c) return mixed_handles("solver init");
     Bind bind(c);
@@ -549,7 +585,11 @@ int solver_init_common(int method, sla_csr *A, sla_vec *b, sla_vec *x0, double t
             if ((rc = publish(S, P_ASS, -1, vec_grid(S->p->n_local), &ctl_of(S).pp, nullptr)) != SLA_OK) break;
         } else {
             if ((rc = sla_vec_copy(S->r, S->p)) != SLA_OK) break;
-            if (method == SLA_CGS_ && (rc = sla_vec_copy(S->r, S->u)) != SLA_OK) break;
+            if ((method == SLA_CGS_ || method == SLA_BCG_) && (rc = sla_vec_copy(S->r, S->u)) != SLA_OK) break;   // u0 = r0 (CGS) / p0hat = r0hat = r0 (BCG)
+            if (method == SLA_BCG_) {   // the transposed copy is built here, not inside the first step (a captured step graph must not allocate)
+                sla_csr *T = nullptr;
+                if ((rc = csr_transposed(A, &T)) != SLA_OK) break;
+            }
         }
         if ((method == SLA_BICGSTAB_ || method == SLA_CGS_) && c->collectives && c->bicg_ghost) {
             // ghost-row flow (enqueue_bicgstab_ghost / enqueue_cgs_ghost): every rank must take the same decision -- the
@@ -587,7 +627,7 @@ void fill_info(sla_solver *S, sla_solve_info *info, bool hit_max) {
     if (!info) return;
     const SolverScalars &h = *S->h_sc;
     info->iters = h.iters;
-    info->flags = h.flags | (h.done ? 0 : (hit_max ? SLA_FLAG_MAX_ITERS : 0));
+    info->flags = h.flags | (h.done ? 0 : (hit_max ? SLA_FLAG_MAX_ITERS : 0)) | (csr_fold_relaxed(S->A) ? SLA_FLAG_RELAXED_ORDER : 0);
     info->resnorm = h.resnorm;
     info->r0norm = h.r0norm;
     info->tol = h.tol;
@@ -857,7 +897,9 @@ int sla_solver_get(sla_solver_t S, int field, sla_vec_t out) {
         case SLA_STATE_X: src = S->x; break;
         case SLA_STATE_R: src = S->r; break;
         case SLA_STATE_P: src = S->p; break;
-        case SLA_STATE_U: src = S->u; break;
+        case SLA_STATE_U: src = S->method == SLA_BCG_ ? nullptr : S->u; break;
+        case SLA_STATE_RHAT: src = S->method == SLA_BCG_ ? S->r0hat : nullptr; break;
+        case SLA_STATE_PHAT: src = S->method == SLA_BCG_ ? S->u : nullptr; break;
     }
     if (!src) return fail(SLA_ERR_INVALID, "sla_solver_get: this method has no such state field");
     if (!out->kids.empty() || out->ctx != S->ctx) return mixed_handles("sla_solver_get");
@@ -1141,7 +1183,7 @@ int sla_gmres(sla_csr_t A, sla_vec_t b, sla_vec_t x0, int restart, const sla_sol
         }
         if (rc == SLA_OK && info) {
             info->iters = total;
-            info->flags = flags;
+            info->flags = flags | (csr_fold_relaxed(A) ? SLA_FLAG_RELAXED_ORDER : 0);
             info->resnorm = beta;
             info->r0norm = r0norm;
             info->tol = tol;

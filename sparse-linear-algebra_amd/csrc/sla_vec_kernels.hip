@@ -520,6 +520,80 @@ int launch_cgne_n2(sla_ctx *c, int64_t n, SolverScalars *sc, const double *p, do
     return SLA_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// BCG (extension: the commented bcgStep of Sparse.hs:899-909; `linSolve0 BCG_` keeps throwing like the reference, :1031)
+// ---------------------------------------------------------------------------------------------
+// B3: alpha = (r <.> rhat) / (aap <.> phat) ; x1 = x ^+^ alpha .* p ; r1 = r ^-^ alpha .* aap ;
+//     rhat1 = rhat ^-^ alpha .* (transpose aa #> phat) ; partial r1 <.> rhat1          (5 reads + 3 writes of n doubles: 64 n bytes)
+__global__ void __launch_bounds__(kBlock) bcg_b3_kernel(int64_t n, SolverScalars *sc, Parts app, int par, const double *p, const double *aap,
+                                                         const double *atp, double *x, double *r, double *rhat, double *rrout) {
+    __shared__ double s_red[4];
+    if (sc->done) return;
+    const double alpha = sc->rho2[par] / reduce_parts(app.p, app.n, app.stride, s_red);
+    if (blockIdx.x == 0 && threadIdx.x == 0) sc->alpha = alpha;
+    double acc = 0.0;
+    SLA_VEC_LOOP_BEGIN(n)
+        const double2 pv = ld2(p, i2), av = ld2(aap, i2), tv = ld2(atp, i2);
+        double2 xv = ld2(x, i2), rv = ld2(r, i2), hv = ld2(rhat, i2);
+        xv.x += alpha * pv.x;
+        xv.y += alpha * pv.y;
+        rv.x -= alpha * av.x;
+        rv.y -= alpha * av.y;
+        hv.x -= alpha * tv.x;
+        hv.y -= alpha * tv.y;
+        st2(x, i2, xv);
+        st2(r, i2, rv);
+        st2(rhat, i2, hv);
+        acc += rv.x * hv.x;
+        acc += rv.y * hv.y;
+    SLA_VEC_LOOP_END
+    if (SLA_HAS_TAIL(n)) {
+        const int64_t i = n - 1;
+        x[i] += alpha * p[i];
+        const double rv = r[i] - alpha * aap[i], hv = rhat[i] - alpha * atp[i];
+        r[i] = rv;
+        rhat[i] = hv;
+        acc += rv * hv;
+    }
+    const double sum = block_sum(acc, s_red);
+    if (threadIdx.x == 0) rrout[blockIdx.x] = sum;
+}
+// B4: beta = (r1 <.> rhat1) / (r <.> rhat) ; p1 = r1 ^+^ beta .* p ; phat1 = rhat1 ^+^ beta .* phat      (4 reads + 2 writes: 48 n bytes)
+__global__ void __launch_bounds__(kBlock) bcg_b4_kernel(int64_t n, SolverScalars *sc, Parts rr1, int par, const double *r, const double *rhat,
+                                                         double *p, double *phat) {
+    __shared__ double s_red[4];
+    if (sc->done) return;
+    const double rr = reduce_parts(rr1.p, rr1.n, rr1.stride, s_red);
+    const double beta = rr / sc->rho2[par];
+    if (blockIdx.x == 0 && threadIdx.x == 0) { sc->beta = beta; sc->rho2[par ^ 1] = rr; }
+    SLA_VEC_LOOP_BEGIN(n)
+        const double2 rv = ld2(r, i2), hv = ld2(rhat, i2);
+        double2 pv = ld2(p, i2), qv = ld2(phat, i2);
+        pv.x = rv.x + beta * pv.x;
+        pv.y = rv.y + beta * pv.y;
+        qv.x = hv.x + beta * qv.x;
+        qv.y = hv.y + beta * qv.y;
+        st2(p, i2, pv);
+        st2(phat, i2, qv);
+    SLA_VEC_LOOP_END
+    if (SLA_HAS_TAIL(n)) {
+        const int64_t i = n - 1;
+        p[i] = r[i] + beta * p[i];
+        phat[i] = rhat[i] + beta * phat[i];
+    }
+}
+int launch_bcg_b3(sla_ctx *c, int64_t n, SolverScalars *sc, Parts app, int par, const double *p, const double *aap, const double *atp, double *x,
+                  double *r, double *rhat, double *rrout) {
+    SLA_KLAUNCH(c, bcg_b3_kernel, dim3(vec_grid(n)), dim3(kBlock), 0, stream_of(c), n, sc, app, par, p, aap, atp, x, r, rhat, rrout);
+    SLA_HIP_TRY(hipGetLastError());
+    return SLA_OK;
+}
+int launch_bcg_b4(sla_ctx *c, int64_t n, SolverScalars *sc, Parts rr1, int par, const double *r, const double *rhat, double *p, double *phat) {
+    SLA_KLAUNCH(c, bcg_b4_kernel, dim3(vec_grid(n)), dim3(kBlock), 0, stream_of(c), n, sc, rr1, par, r, rhat, p, phat);
+    SLA_HIP_TRY(hipGetLastError());
+    return SLA_OK;
+}
+
 // linSolve0 diagonal shortcut: reciprocal aa #> b  (Sparse.hs:1024-1025, Class.hs:174): every row holds
 // exactly its diagonal entry, so val[i] is a_ii
 __global__ void __launch_bounds__(kBlock) diag_solve_kernel(int64_t n, const double *diag, const double *b, double *x) {

@@ -14,6 +14,8 @@ CSRC = os.path.join(_ROOT, "csrc")
  ERR_NO_DEVICE, ERR_NEEDS_PIVOTING) = range(10)
 
 FLAG_CONVERGED, FLAG_MAX_ITERS, FLAG_DIAGONAL, FLAG_BREAKDOWN, FLAG_NONFINITE = 1, 2, 4, 8, 16
+FLAG_SYNC_TIMEOUT, FLAG_RELAXED_ORDER = 32, 64
+FOLD_EXACT, FOLD_REGROUPED, FOLD_RELAXED = 0, 1, 2   # sla_fold_kind
 KERNEL_ALL = -1
 KERNEL_SPMV, KERNEL_SPMV_DOT, KERNEL_SPMV_DOT2, KERNEL_SPMV_RES, KERNEL_SPMV_DUAL = 0, 1, 2, 3, 4
 KERNEL_BICG_K2, KERNEL_BICG_K4, KERNEL_BICG_K5, KERNEL_CGS_C2, KERNEL_CGS_C4 = 5, 6, 7, 8, 9
@@ -55,6 +57,15 @@ class SolveOpts(C.Structure):
         super().__init__(C.sizeof(SolveOpts), max_iters, tol_abs, tol_rel, check_every, true_residual, history, history_cap)
 
 
+class CsrProps(C.Structure):
+    """sla_csr_props (include/sla_hip.h): typed properties of a lowered matrix."""
+    _fields_ = [("struct_size", C.c_int32), ("fold", C.c_int32), ("x_exchange", C.c_int32), ("nranks", C.c_int32),
+                ("rows_local", C.c_int64), ("nnz_local", C.c_int64), ("rowptr_bits", C.c_int32), ("reserved", C.c_int32)]
+
+    def __init__(self):
+        super().__init__(C.sizeof(CsrProps))
+
+
 class SolveInfo(C.Structure):
     _fields_ = [("struct_size", C.c_int32), ("iters", C.c_int32), ("flags", C.c_int32), ("resnorm", C.c_double),
                 ("r0norm", C.c_double), ("tol", C.c_double), ("history_len", C.c_int32)]
@@ -65,7 +76,7 @@ class SolveInfo(C.Structure):
     def as_dict(self):
         return {"iters": self.iters, "flags": self.flags, "resnorm": self.resnorm,
                 "r0norm": self.r0norm, "tol": self.tol,
-                "converged": bool(self.flags & FLAG_CONVERGED)}
+                "converged": bool(self.flags & FLAG_CONVERGED), "relaxed_order": bool(self.flags & FLAG_RELAXED_ORDER)}
 
 
 # every symbol include/sla_hip.h declares: (name, restype, argtypes)
@@ -141,6 +152,8 @@ PROTOTYPES = [
     ("sla_ctx_comm_ranks", _int, [_vp, _pint]),
     ("sla_csr_kernel_info", _int, [_vp, C.c_char_p, _int]),
     ("sla_csr_lower_info", _int, [_vp, C.c_char_p, _int]),
+    ("sla_csr_get_props", _int, [_vp, C.POINTER(CsrProps)]),
+    ("sla_csr_exchange_plan", _int, [_vp, _vp, _vp, _int]),
     ("sla_plan_window_exchange", _int, [_int, _int, _i64, _vp, _vp, _vp, _vp, _vp, _pint]),
     ("sla_plan_allgather_passes", _int, [_int, _int, _i64, _int, _int, _int, _vp, _vp, _vp, _pint, _pint]),
     ("sla_plan_allgather_groups", _int, [_int, _i64, _int, _int, _int, _vp, _int, _pint]),

@@ -380,6 +380,21 @@ class SpMatrix:
         check(lib().sla_csr_kernel_info(self.h, buf, 1024))
         return buf.value.decode()
 
+    def props(self):
+        """Typed properties (sla_csr_get_props): fold (0 exact left fold / 1 fixed regrouping of long rows / 2 relaxed order, not reproducible
+        bit for bit), x_exchange (0 one rank / 1 all-gather / 2 window), nranks, rows_local, nnz_local, rowptr_bits."""
+        from ._lib import CsrProps
+        p = CsrProps()
+        check(lib().sla_csr_get_props(self.h, C.byref(p)))
+        return {k: getattr(p, k) for k, _ in CsrProps._fields_ if k not in ("struct_size", "reserved")}
+
+    def exchange_plan(self):
+        """Row-sharded matrices: (send_len, recv_len) -- doubles this rank sends to / receives from each peer in ONE exchange of a (#>) input."""
+        nr = self.props()["nranks"]
+        s, r = np.zeros(nr, dtype=np.int64), np.zeros(nr, dtype=np.int64)
+        check(lib().sla_csr_exchange_plan(self.h, s.ctypes.data, r.ctypes.data, nr))
+        return s, r
+
     def lower_info(self):
         """Wall-clock phases of this matrix's lowering in milliseconds (sla_csr_lower_info): {phase: ms}."""
         buf = C.create_string_buffer(2048)
@@ -699,6 +714,16 @@ class CGNE(_SolverState):
     _pCgne = property(lambda s: s._get(2, s.A.ncols))
 
 
+class BCG(_SolverState):
+    """data BCG = BCG {_xBcg, _rBcg, _rHatBcg, _pBcg, _pHatBcg} (Sparse.hs:886-887).  An extension: the reference's bcgInit / bcgStep are
+    commented out (:889-909) and `linSolve0 BCG_` throws there and here."""
+    _xBcg = property(lambda s: s._get(0, s.A.ncols))
+    _rBcg = property(lambda s: s._get(1, s.A.nrows))
+    _pBcg = property(lambda s: s._get(2, s.A.ncols))
+    _rHatBcg = property(lambda s: s._get(4, s.A.nrows))
+    _pHatBcg = property(lambda s: s._get(5, s.A.nrows))
+
+
 def bicgsInit(aa, b, x0):
     return BICGSTAB(BICGSTAB_, aa, b, x0)         # Sparse.hs:962-965
 
@@ -738,6 +763,20 @@ def cgneInit(aa, b, x0):
 
 def cgneStep(state, k=1):
     return state.step(k)                          # Sparse.hs:870-878
+
+
+def bcgInit(aa, b, x0):
+    return BCG(BCG_, aa, b, x0)                   # the commented bcgInit, Sparse.hs:889-897 (p0 = r0, p0hat = r0hat = r0)
+
+
+def bcgStep(*args, k=1):
+    """bcgStep aa state (the commented code of Sparse.hs:899-909) -> new state; bcgStep(state, k=..) steps in place."""
+    if len(args) == 1:
+        return args[0].step(k)
+    aa, state = args
+    if aa is not state.A:
+        raise ValueError("the state record was initialised with a different matrix")
+    return state.clone().step(k)
 
 
 # ---- linSolve0 / arnoldi / gmres / (<\>) ---------------------------------------------------------------

@@ -148,13 +148,30 @@ def test_bench_two_ranks_without_a_launcher_loopback_rehearsal():
     assert all(v["max_abs_err"] == 0.0 for v in d["preflight"].values()) and "fallback" not in d
     c = d["contract_allgather"]
     assert c["value"] > 0 and "x_exchange=allgather" in c["spmv_kernel"] and c["x_exchange"] == "ncclAllGather" and c["allgather_launches"] > 0
+    # round 6, SURVEY 8(d)/(e): every N > 1 block prices its event-timed exchanges against the xGMI link peak on the PLAN's bytes and puts the
+    # model's prediction beside the measured step (a rehearsal says that no link was crossed)
+    two_gpus = sla_amd.Context.device_count() >= 2
+    for blk, mode in ((d, "window"), (rb, "allgather"), (c, "allgather")):
+        xr = blk["exchange_roofline"]
+        assert xr["link_peak_gbps"] == 153.0 and xr["links_per_gpu"] == 7 and xr["mode"] == mode and xr["peers"] == 1
+        assert xr["real_links"] is two_gpus and ("rehearsal" in xr["links"]) is (not two_gpus)
+        assert xr["bytes_to_busiest_peer"] > 0 and xr["step"]["model_ms"] > 0 and xr["step"]["measured_ms"] == pytest.approx(blk["ms_per_step"])
+        for e in xr["exchanges"].values():
+            for k in ("bytes_to_busiest_peer", "ms", "per_step", "gbps_busiest_link", "frac_of_link_peak", "model_ms", "measured_over_model", "bound"):
+                assert k in e, k
+            assert e["per_step"] > 0 and e["model_ms"] >= 0.02
+    # the halo of the 64^3 test grid: one 64 x 64 plane of doubles per neighbour; the all-gather moves the peer's whole shard
+    assert d["exchange_roofline"]["bytes_to_busiest_peer"] == 8 * 64 * 64
+    assert d["exchange_roofline"]["exchanges"]["sums"]["bytes_to_busiest_peer"] == 8 * 64 * 64 + 32       # ghost-row flow: the halo rides with the sums
+    assert c["exchange_roofline"]["bytes_to_busiest_peer"] == 8 * (64 ** 3) // 2
 
 
-@pytest.mark.parametrize("fault,word", [("p2p", "pre-flight of the grouped"), ("p2p_hang", "watchdog")])
+@pytest.mark.parametrize("fault,word", [("p2p", "pre-flight of the grouped"), ("p2p_hang", "watchdog"), ("p2p_data_rank1", "failed on another rank")])
 def test_bench_two_ranks_fallback_ladder(fault, word):
     """First contact gone wrong, rehearsed on one GPU (SLA_FAULT_INJECT, csrc/sla_dist.cpp): the grouped ncclSend / ncclRecv flow
-    ERRORS in the pre-flight ("p2p") or HANGS there ("p2p_hang": the staged watchdog replaces the process after
-    SLA_BENCH_PREFLIGHT_S) -- either way the driver still gets ONE line, on the plain ncclAllGather flow, with "fallback" saying why."""
+    ERRORS in the pre-flight ("p2p"), HANGS there ("p2p_hang": the staged watchdog replaces the process after
+    SLA_BENCH_PREFLIGHT_S) or fails on ONE rank only ("p2p_data_rank1": rank 1 alone sees wrong data; the ranks agree on the fallback over
+    the control plane, so rank 0 -- whose own pre-flight passed -- follows) -- either way the driver still gets ONE line, on the plain ncclAllGather flow, with "fallback" saying why."""
     env = dict(os.environ, SLA_BENCH_LOOPBACK="1", SLA_FAULT_INJECT=fault, SLA_BENCH_PREFLIGHT_S="4")
     env.pop("WORLD_SIZE", None)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "laplace3d_small", "--steps", "8",
@@ -197,5 +214,7 @@ def test_bench_stdout_is_one_json_line_on_the_rccl_path():
     assert out.stdout.count("\n") == 1 and out.stdout.startswith("{"), out.stdout[:400]
     d = json.loads(out.stdout)
     assert d["rccl_ranks"] == 1 and d["exchanges"]["sums"]["launches"] > 0
+    xr = d["exchange_roofline"]          # one rank: the plan moves nothing, the line still carries the model and says it is a rehearsal
+    assert xr["real_links"] is False and xr["peers"] == 0 and xr["bytes_to_busiest_peer"] == 0 and xr["step"]["model_ms"] > 0
     # the fused sweep runs on sharded contexts too (round 3); with ghost rows K2 is folded into K3 as on one rank (round 5)
     assert set(d["kernels"]) in ({"K1", "K2", "K3", "K45"}, {"K1", "K23", "K45"})
