@@ -367,6 +367,7 @@ struct sla_tri_plan {
     int32_t brows = 0;
     bool bricks = false;              // the block order is the stencil-brick order, not the sweep's
     double bl_cross = 0.0;            // share of the triangle's entries that read a row of another block (polled in memory)
+    bool bl_rejected = false;         // the automatic mode measured bl_cross > 1/4 once: the block arrays were freed, the level schedule stays
     int64_t *d_bl_slots = nullptr;    // [2 * p]: first slot of the p-th block taken, [2 * p + 1]: its first sweep position; [2 * nb]: n
     int32_t *d_bl_row = nullptr, *d_bl_col = nullptr;
     int64_t *d_bl_ptr = nullptr;
@@ -894,6 +895,7 @@ bool wave_plain(const sla_csr *A);   // sla_spmv.hip: does a plain (#>) on A end
 int launch_spmv_wave(const sla_csr *A, int epi, const SpmvArgs<int32_t> &a, int grid);
 int tiles_grid(const sla_csr *A);
 int launch_tri_syncfree(const sla_csr *T, const sla_tri_plan *p, const double *b, double *x, int *d_fail);   // sla_tri.hip
+constexpr int SLA_TRI_NO_FIT = -100;   // launch_tri_blocks: the block kernel cannot be made resident on this device (not an error: the level schedule runs)
 int launch_tri_blocks(const sla_csr *T, const sla_tri_plan *p, int upper, const double *b, double *x, int *d_fail);
 int launch_col_slack_fill(sla_ctx *c, int32_t *d_col, int64_t nnz);   // sla_spmv_wave.hip: the slack behind the column array repeats the last column
 int launch_spmv_ctiles(const sla_csr *A, const SpmvLaunch &l);   // sla_spmv_ctiles.hip (CU-wide slices)

@@ -358,9 +358,15 @@ int sla_tri_solve(sla_csr_t T, int upper, sla_vec_t b, sla_vec_t x, int64_t *bad
         int mode = c->tri_syncfree;
         if (mode == 3) {
             mode = 0;
-            if (p->nlevels >= 64 && T->m / p->nlevels <= 65536) {
+            if (p->nlevels >= 64 && T->m / p->nlevels <= 65536 && !p->bl_rejected) {
                 SLA_TRY(tri_blocks_build(T, upper));
                 if (p->bl_cross <= 0.25) mode = 2;   // (else most values would be polled in memory: a random matrix' triangle ran 38 ms that way, 1.1 ms by levels)
+                else {   // rejected: keep the decision, not the second copy of the triangle (it stayed allocated for the matrix's lifetime)
+                    const double cross = p->bl_cross;
+                    tri_blocks_free(p);
+                    p->bl_cross = cross;
+                    p->bl_rejected = true;
+                }
             }
         }
         c->tri_mode_used = mode;
@@ -369,17 +375,23 @@ int sla_tri_solve(sla_csr_t T, int upper, sla_vec_t b, sla_vec_t x, int64_t *bad
                                      : std::string("levels=") + std::to_string(p->nlevels);
         if (mode) {   // a lane that waited too long says so and the level schedule below runs instead
             int *d_fail = (int *)(c->d_result + 1600);
+            int h_fail = 0;
             if (mode == 2) {
                 SLA_TRY(tri_blocks_build(T, upper));
-                SLA_TRY(launch_tri_blocks(T, p, upper, b->d, x->d, d_fail));
+                // (a device whose CUs cannot hold the block kernel -- less LDS, a failing attribute or occupancy query -- is not an error of
+                // the solve: the level schedule below runs instead, counted like a run-time give-up)
+                const int rc = launch_tri_blocks(T, p, upper, b->d, x->d, d_fail);
+                if (rc == SLA_TRI_NO_FIT) h_fail = 1;
+                else SLA_TRY(rc);
             } else {
                 SLA_TRY(launch_tri_syncfree(T, p, b->d, x->d, d_fail));
             }
-            SLA_TRY(launch_tri_sparsify(c, T->m, x->d));
-            int h_fail = 0;
-            SLA_HIP_TRY(hipMemcpyAsync(&h_fail, d_fail, sizeof(int), hipMemcpyDeviceToHost, stream_of(c)));
-            SLA_HIP_TRY(hipStreamSynchronize(stream_of(c)));
-            if (!h_fail) return SLA_OK;
+            if (!h_fail) {
+                SLA_TRY(launch_tri_sparsify(c, T->m, x->d));
+                SLA_HIP_TRY(hipMemcpyAsync(&h_fail, d_fail, sizeof(int), hipMemcpyDeviceToHost, stream_of(c)));
+                SLA_HIP_TRY(hipStreamSynchronize(stream_of(c)));
+                if (!h_fail) return SLA_OK;
+            }
             T->ctx->tri_fallbacks++;
         }
         if (p->nlevels > 65536) {   // (a graph of that many nodes is not worth its memory: plain launches)

@@ -26,6 +26,15 @@
 
 namespace sla {
 
+// Ablation build (tools/build_variant_one.sh abl<N> sla_spmv_wave.hip -DSLA_WV_ABLATE=<N>; round 6): which stage of the
+// kernel owns the gap to the streaming ceiling -- bits REMOVE one stage each (the results are then wrong; timing only):
+//   1 the x gather (a constant instead), 2 the LDS product stage + lane-per-row fold (lanes add their own products), 4 the row-pair
+//   transpose through LDS, 8 the epilogue (y store, operand arithmetic), 16 the epilogue operand loads (w / z).  0 = the product.
+#ifndef SLA_WV_ABLATE
+#define SLA_WV_ABLATE 0
+#endif
+constexpr int kWvAbl = SLA_WV_ABLATE;
+
 typedef int wv_i32x2 __attribute__((ext_vector_type(2)));
 typedef double wv_f64x2 __attribute__((ext_vector_type(2)));
 
@@ -116,11 +125,11 @@ spmv_wave_kernel(SpmvArgs<int32_t> a, const int32_t *__restrict__ rowptr, const 
         const int sa = rowptr[r0 + lane], sb = rowptr[r0 + 64 + lane];
         const int prow = r0 + 2 * lane;                   // this lane's row PAIR in the epilogue
         wv_f64x2 wv = {0.0, 0.0}, zv = {0.0, 0.0};
-        if constexpr (kUsesW) {
+        if constexpr (kUsesW && !(kWvAbl & 16)) {
             if (EPI != EPI_AXPY_DOT || a.w)
                 wv = w_nt ? __builtin_nontemporal_load((const wd_f64x2u *)(a.w + min(prow, a.rows - 1))) : *(const wd_f64x2u *)(a.w + min(prow, a.rows - 1));
         }
-        if constexpr (kUsesZ) zv = z_nt ? __builtin_nontemporal_load((const wd_f64x2u *)(a.z + min(prow, a.rows - 1))) : *(const wd_f64x2u *)(a.z + min(prow, a.rows - 1));
+        if constexpr (kUsesZ && !(kWvAbl & 16)) zv = z_nt ? __builtin_nontemporal_load((const wd_f64x2u *)(a.z + min(prow, a.rows - 1))) : *(const wd_f64x2u *)(a.z + min(prow, a.rows - 1));
         // row ends: the next lane's start; lane 63's rows end where rows 64 / 128 of the block start
         const int sb0 = __builtin_amdgcn_readfirstlane(sb);   // (outside the lane test: readfirstlane reads the first ACTIVE lane)
         int ea = __shfl_down(sa, 1, 64), eb = __shfl_down(sb, 1, 64);
@@ -135,8 +144,13 @@ spmv_wave_kernel(SpmvArgs<int32_t> a, const int32_t *__restrict__ rowptr, const 
             double xa[PPL], xb[PPL];
 #pragma unroll
             for (int j = 0; j < PPL; ++j) {
-                xa[j] = xg[cur.cc[j].x];
-                xb[j] = xg[cur.cc[j].y];
+                if constexpr (kWvAbl & 1) {
+                    xa[j] = 1.0 + (double)(cur.cc[j].x & 3);
+                    xb[j] = 1.0 + (double)(cur.cc[j].y & 3);
+                } else {
+                    xa[j] = xg[cur.cc[j].x];
+                    xb[j] = xg[cur.cc[j].y];
+                }
             }
             WvChunk<PPL> nxt;
             if constexpr (PRE) {                            // next chunk of this block, else the first chunk of the wavefront's next block
@@ -148,10 +162,15 @@ spmv_wave_kernel(SpmvArgs<int32_t> a, const int32_t *__restrict__ rowptr, const 
                 wv_f64x2 p;
                 p.x = cur.vv[j].x * xa[j];
                 p.y = cur.vv[j].y * xb[j];
-                *(wv_f64x2 *)(prod + 2 * lane + 128 * j) = p;
+                if constexpr (kWvAbl & 2) {
+                    ya += p.x;
+                    yb += p.y;
+                } else {
+                    *(wv_f64x2 *)(prod + 2 * lane + 128 * j) = p;
+                }
             }
             if constexpr (PRE) cur = nxt;
-            {   // one lane per row, ascending, one product at a time: the reference's left fold (the products are rounded, the sum adds them).
+            if constexpr (!(kWvAbl & 2)) {   // one lane per row, ascending, one product at a time: the reference's left fold (the products are rounded, the sum adds them).
                 // Eight products of each of the lane's two rows are READ together (clamped addresses, all sixteen reads in flight) and then
                 // added in order under their range tests: one LDS round trip per eight entries instead of one per entry.
                 int ka = max(sa, kb) - kb, kb2 = max(sb, kb) - kb;
@@ -175,10 +194,15 @@ spmv_wave_kernel(SpmvArgs<int32_t> a, const int32_t *__restrict__ rowptr, const 
             if (kb + CH >= k1) break;
         }
         // rows (t, t + 64) per lane -> row pairs (2u, 2u + 1) per lane through the wave's stage (in order behind the fold's reads)
-        prod[lane] = ya;
-        prod[64 + lane] = yb;
-        const wv_f64x2 yp = *(const wv_f64x2 *)(prod + 2 * lane);
-        if (prow < a.rows) wd_epilogue<EPI>(a, prow, prow + 1 < a.rows, yp.x, yp.y, wv, zv, coef, acc1, acc2, st_nt);
+        wv_f64x2 yp = {ya, yb};
+        if constexpr (!(kWvAbl & 4)) {
+            prod[lane] = ya;
+            prod[64 + lane] = yb;
+            yp = *(const wv_f64x2 *)(prod + 2 * lane);
+        }
+        if constexpr (kWvAbl & 8) {
+            acc1 += yp.x + yp.y + wv.x + zv.y;          // (keeps everything above alive)
+        } else if (prow < a.rows) wd_epilogue<EPI>(a, prow, prow + 1 < a.rows, yp.x, yp.y, wv, zv, coef, acc1, acc2, st_nt);
     }
     if constexpr (EPI == EPI_DOT || EPI == EPI_DOT2 || EPI == EPI_DOT4 || EPI == EPI_RES || EPI == EPI_AXPY_DOT || EPI == EPI_XPBY_NRM) {
         const double s1 = block_sum(acc1, s_red);

@@ -315,14 +315,17 @@ int launch_tri_blocks(const sla_csr *T, const sla_tri_plan *p, int upper, const 
     sla_ctx *c = T->ctx;
     const int64_t n = T->m;
     hipStream_t st = stream_of(c);
-    SLA_HIP_TRY(hipMemsetAsync(d_fail, 0, 2 * sizeof(int), st));   // [0] somebody gave up, [1] blocks finished (the grid's progress)
-    hipLaunchKernelGGL(tri_fill_pending_kernel, dim3(vec_grid(n)), dim3(kBlock), 0, st, n, x);
     // co-resident by construction: as many workgroups per CU as their LDS (the block's cells) leaves room for, never more than tri_grid
     const size_t lds = sizeof(unsigned long long) * ((size_t)p->brows + 1);
-    SLA_HIP_TRY(hipFuncSetAttribute((const void *)tri_blocks_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(unsigned long long) * (kTriBlockRows + 1))));
+    // (checked BEFORE anything is enqueued: a device with less LDS per workgroup than a block's cells, or a runtime that refuses the attribute /
+    // the occupancy query, sends the solve to the level schedule -- SLA_TRI_NO_FIT, no error)
+    int lds_max = 0;
+    if (hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, c->device) != hipSuccess || (size_t)lds_max < lds) { (void)hipGetLastError(); return SLA_TRI_NO_FIT; }
+    if (hipFuncSetAttribute((const void *)tri_blocks_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(unsigned long long) * (kTriBlockRows + 1))) != hipSuccess) { (void)hipGetLastError(); return SLA_TRI_NO_FIT; }
     int per_cu = 0;   // (what the runtime says fits: registers, wavefront slots and this launch's LDS)
-    SLA_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)tri_blocks_kernel, kTriBlockThreads, lds));
-    if (per_cu < 1) return fail(SLA_ERR_INVALID, "launch_tri_blocks: the kernel does not fit a CU");
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)tri_blocks_kernel, kTriBlockThreads, lds) != hipSuccess || per_cu < 1) { (void)hipGetLastError(); return SLA_TRI_NO_FIT; }
+    SLA_HIP_TRY(hipMemsetAsync(d_fail, 0, 2 * sizeof(int), st));   // [0] somebody gave up, [1] blocks finished (the grid's progress)
+    hipLaunchKernelGGL(tri_fill_pending_kernel, dim3(vec_grid(n)), dim3(kBlock), 0, st, n, x);
     const int grid = (int)std::max<int64_t>(1, std::min<int64_t>({c->tri_grid ? (int64_t)c->tri_grid : (int64_t)1 << 30, (int64_t)per_cu * (int64_t)c->n_cu, p->nb}));
     // SLA_TRI_TRACE=<file>: per block taken (in the order taken) the 100 MHz clock at: cells initialised | first row tried | last row done | block left
     static const char *trace_path = getenv("SLA_TRI_TRACE");

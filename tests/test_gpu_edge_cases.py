@@ -112,6 +112,28 @@ def test_rerun_is_bit_identical(sla):
     assert np.array_equal(a, c)                                       # deterministic two-stage reductions
 
 
+def test_solve_opts_struct_size_window(sla):
+    """a caller from before struct_size existed has max_iters as its first member; the reference's default nits = 200 must not
+    pass for a size (it did: 200 > 48, <= 48 + 256, 200 % 8 == 0 -- 48 bytes were then read from a 32-byte struct).  Sizes that pass: the
+    library's own layout and a newer header's larger one, 8-byte granularity, at most 64 bytes more."""
+    import ctypes as C
+    from sla_amd import _lib
+    A = sla.fromListSM((3, 3), [(0, 0, 2.0), (0, 1, -1.0), (1, 0, -1.0), (1, 1, 2.0), (1, 2, -1.0), (2, 1, -1.0), (2, 2, 2.0)])
+    b, x0 = sla.fromListDenseSV(3, [1, 0, 1]).device(), sla.fromListSV(3, []).device()
+    out = sla.DeviceVector(A.ctx, 3)
+    own = C.sizeof(_lib.SolveOpts)
+    for size, ok in ((own, True), (own + 8, True), (own + 64, True), (own + 72, False), (200, False), (own - 8, False), (0, False), (own + 4, False)):
+        o, info = _lib.SolveOpts(), _lib.SolveInfo()
+        o.struct_size = size
+        rc = _lib.lib().sla_linsolve0(int(sla.BICGSTAB_), A.h, b.h, x0.h, C.byref(o), out.h, C.byref(info))
+        assert (rc == 0) is ok, (size, rc)
+        if not ok:
+            assert rc == _lib.ERR_INVALID and b"struct_size" in _lib.lib().sla_last_error()
+    info = _lib.SolveInfo()
+    info.struct_size = 200
+    assert _lib.lib().sla_linsolve0(int(sla.BICGSTAB_), A.h, b.h, x0.h, None, out.h, C.byref(info)) == _lib.ERR_INVALID
+
+
 def test_dual_spmv_flow_equals_three_sweep_flow(sla):
     """linSolve0 with the true residual fused into the next K1 (default) must return exactly what the
     three-SpMV-per-iteration flow returns: same iterate, same iteration count, same residual."""
