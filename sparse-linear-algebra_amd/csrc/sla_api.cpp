@@ -490,6 +490,7 @@ const IntKnob kIntKnobs[] = {
     {"dual_spmv", &sla_ctx::dual_spmv, 0, 1},
     {"xwin", &sla_ctx::xwin, 0, 2},
     {"stream_wave", &sla_ctx::stream_wave, 0, 1999},
+    {"wave_run", &sla_ctx::wave_run, 1, 4096},
     {"stream_wide", &sla_ctx::stream_wide, 0, 1},
     {"diag", &sla_ctx::diag, 0, 2},
     {"diag_lazy", &sla_ctx::diag_lazy, 0, 1},

@@ -247,59 +247,68 @@ __device__ __forceinline__ unsigned long long wd_save_exec() {
 typedef double wd_f64x2 __attribute__((ext_vector_type(2)));
 
 // the fused epilogue of a row pair (row, row + 1; vb: the second row exists) of the wave-sliced kernels
+// The arithmetic of the pair epilogue without its store: `out` = what would be stored; returns 0 (nothing stored: EPI_RES), 1 (into y) or
+// 2 (into z).  wd_epilogue = this + the store; the wave kernel's prefetching instantiations hold the store back (sla_spmv_wave.hip, round 6).
 template <int EPI>
-__device__ __forceinline__ void wd_epilogue(const SpmvArgs<int32_t> &a, int row, bool vb, double ya, double yb, wd_f64x2 wv, wd_f64x2 zv,
-                                            double coef, double &acc1, double &acc2, bool nt_store = false) {
-    wd_f64x2 out = {ya, yb};  // what the epilogue stores (y or z), if it stores
-    bool store_y = false, store_z = false;
+__device__ __forceinline__ int wd_epilogue_calc(const SpmvArgs<int32_t> &a, bool vb, double ya, double yb, wd_f64x2 wv, wd_f64x2 zv, double coef,
+                                                 double &acc1, double &acc2, wd_f64x2 &out) {
+    out = wd_f64x2{ya, yb};
     if constexpr (EPI == EPI_NONE) {
-        store_y = true;
+        return 1;
     } else if constexpr (EPI == EPI_DOT) {
-        store_y = true;
         acc1 += ya * wv.x;
         if (vb) acc1 += yb * wv.y;
+        return 1;
     } else if constexpr (EPI == EPI_DOT2) {
-        store_y = true;
         acc1 += ya * wv.x;
         acc2 += ya * ya;
         if (vb) { acc1 += yb * wv.y; acc2 += yb * yb; }
+        return 1;
     } else if constexpr (EPI == EPI_DOT4) {   // (zv = the row pair of the read-only operand z)
-        store_y = true;
         acc1 += ya * wv.x;
         acc2 += ya * ya;
         a.acc3 += ya * zv.x;
         a.acc4 += wv.x * zv.x;
         if (vb) { acc1 += yb * wv.y; acc2 += yb * yb; a.acc3 += yb * zv.y; a.acc4 += wv.y * zv.y; }
+        return 1;
     } else if constexpr (EPI == EPI_RES) {
         const double ta = ya - wv.x, tb = yb - wv.y;  // (aa #> x) ^-^ b
         acc1 += ta * ta;
         if (vb) acc1 += tb * tb;
+        return 0;
     } else if constexpr (EPI == EPI_AXPY_DOT) {
         out.x = zv.x - coef * ya;
         out.y = zv.y - coef * yb;
-        store_z = true;
         acc1 += out.x * (a.w ? wv.x : out.x);
         if (vb) acc1 += out.y * (a.w ? wv.y : out.y);
+        return 2;
     } else if constexpr (EPI == EPI_XPBY_NRM) {
         out.x = ya + coef * zv.x;
         out.y = yb + coef * zv.y;
-        store_z = true;
         acc1 += out.x * out.x;
         if (vb) acc1 += out.y * out.y;
-    } else if constexpr (EPI == EPI_SUB) {
+        return 2;
+    } else {   // EPI_SUB
         out.x = wv.x - ya;  // b ^-^ (aa #> x)
         out.y = wv.y - yb;
-        store_y = true;
+        return 1;
     }
-    double *dst = store_y ? a.y : (store_z ? a.z : nullptr);
-    if (dst) {
-        if (vb) {
-            if (nt_store) __builtin_nontemporal_store(out, (wd_f64x2 *)(dst + row));
-            else *(wd_f64x2 *)(dst + row) = out;
-        } else {
-            dst[row] = out.x;
-        }
+}
+__device__ __forceinline__ void wd_store_pair(double *dst, int row, bool vb, wd_f64x2 out, bool nt_store) {
+    if (vb) {
+        if (nt_store) __builtin_nontemporal_store(out, (wd_f64x2 *)(dst + row));
+        else *(wd_f64x2 *)(dst + row) = out;
+    } else {
+        dst[row] = out.x;
     }
+}
+template <int EPI>
+__device__ __forceinline__ void wd_epilogue(const SpmvArgs<int32_t> &a, int row, bool vb, double ya, double yb, wd_f64x2 wv, wd_f64x2 zv,
+                                            double coef, double &acc1, double &acc2, bool nt_store = false) {
+    wd_f64x2 out;
+    const int where = wd_epilogue_calc<EPI>(a, vb, ya, yb, wv, zv, coef, acc1, acc2, out);
+    double *dst = where == 1 ? a.y : (where == 2 ? a.z : nullptr);
+    if (dst) wd_store_pair(dst, row, vb, out, nt_store);
 }
 
 // ---------------------------------------------------------------------------------------------

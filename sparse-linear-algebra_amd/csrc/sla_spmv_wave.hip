@@ -34,9 +34,26 @@ namespace sla {
 #define SLA_WV_ABLATE 0
 #endif
 constexpr int kWvAbl = SLA_WV_ABLATE;
+// Round 6: the prefetching instantiations also fetch the NEXT block's row starts and epilogue operands one block early (behind the next
+// chunk's streams).  Before, every block opened with three fresh vector loads (rowptr[r0 + lane], rowptr[r0 + 64 + lane], the operand pair)
+// that the row-end shuffle needed at once: `s_waitcnt vmcnt(0)` at the top of the block loop (seen in the ISA) -- a full memory round trip per
+// block with nothing of the wavefront in flight behind it, and the previous block's y store drained with it.  -DSLA_WV_PREOPS=0: the old order.
+#ifndef SLA_WV_PREOPS
+#define SLA_WV_PREOPS 1
+#endif
+// ... and HOLD A BLOCK'S y STORE BACK until the next block's gathers and prefetch streams have been issued (SLA_WV_DEFER, default on with the
+// above).  vmcnt retires in order and counts stores: a store issued at the end of a block stands as the youngest operation in front of the
+// wait that opens the next block -- its acknowledgement (a write round trip) was drained there block after block.  Issued BEHIND the next
+// block's loads it has a whole block's time to retire before anything waits for it.  (Round 3 tried this on the workgroup-level kernel and
+// lost to spills at 64 VGPRs; this instantiation holds 3 workgroups per CU and has the registers.)
+#ifndef SLA_WV_DEFER
+#define SLA_WV_DEFER 1
+#endif
 
 typedef int wv_i32x2 __attribute__((ext_vector_type(2)));
 typedef double wv_f64x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ bool st_nt_of(int nt) { return (nt & 2) != 0; }
 
 template <int PPL>
 struct WvChunk {
@@ -75,7 +92,7 @@ int launch_col_slack_fill(sla_ctx *c, int32_t *d_col, int64_t nnz) {
 template <int EPI, int PPL, int OCC, bool PRE>
 __global__ void __launch_bounds__(kBlock, (PPL == 2 && OCC == 8 && (EPI == EPI_DOT4 || EPI == EPI_AXPY_DOT)) ? 7 : OCC)
 spmv_wave_kernel(SpmvArgs<int32_t> a, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col, const double *__restrict__ val,
-                 const double *__restrict__ xg, int nblk, int xcd_remap, int nt) {
+                 const double *__restrict__ xg, int nblk, int xcd_remap, int nt, int rl) {
     constexpr int CH = 128 * PPL;                       // entries per chunk
     __shared__ double s_prod[kBlock / 64][CH];
     __shared__ double s_red[4];
@@ -87,49 +104,77 @@ spmv_wave_kernel(SpmvArgs<int32_t> a, const int32_t *__restrict__ rowptr, const 
     double *prod = s_prod[wave];
     // the blocks of this wavefront: XCD x (workgroups b with b % 8 == x) takes the x-th contiguous eighth of the blocks, the four
     // wavefronts of a workgroup neighbouring blocks, so that each private L2 sees one sliding window of x
+    // Round 6 (option wave_run): a wavefront walks RUNS of rl consecutive blocks before it jumps -- the x lines a block shares with its
+    // successor (matrices whose columns lie near the diagonal: all of a stencil's legs but the far planes) are then re-used by the SAME
+    // wavefront one block later instead of being fetched by four different wavefronts at once (rl = 1: the round-4 walk).  The unit
+    // of the walk below is the run; `first`, `step`, `last` count runs.
     const int G = (int)gridDim.x;
+    const int nrun = (nblk + rl - 1) / rl;
     int first, step, last;
-    if (xcd_remap && (G & 7) == 0 && nblk >= 4 * G) {
-        const int xcd = (int)blockIdx.x & 7, per = (nblk + 7) >> 3;
+    if (xcd_remap && (G & 7) == 0 && nrun >= 4 * G) {
+        const int xcd = (int)blockIdx.x & 7, per = (nrun + 7) >> 3;
         first = xcd * per + ((int)blockIdx.x >> 3) * (kBlock / 64) + wave;
         step = (G >> 3) * (kBlock / 64);
-        last = min((xcd + 1) * per, nblk);
+        last = min((xcd + 1) * per, nrun);
     } else {
         first = (int)blockIdx.x * (kBlock / 64) + wave;
         step = G * (kBlock / 64);
-        last = nblk;
+        last = nrun;
     }
     constexpr bool kUsesW = EPI == EPI_DOT || EPI == EPI_DOT2 || EPI == EPI_DOT4 || EPI == EPI_RES || EPI == EPI_SUB || EPI == EPI_AXPY_DOT;
     constexpr bool kUsesZ = EPI == EPI_DOT4 || EPI == EPI_AXPY_DOT || EPI == EPI_XPBY_NRM;
     const bool w_nt = nt && a.w != xg, z_nt = nt && (const double *)a.z != xg;
     WvChunk<PPL> cur;
     int nk0 = 0, nk1 = 0;                                   // PRE: entry range of the block whose first chunk `cur` holds
+    constexpr bool PREOPS = PRE && SLA_WV_PREOPS != 0;
+    constexpr bool DEFER = PREOPS && SLA_WV_DEFER != 0 && !(kWvAbl & 8);
+    wv_f64x2 pend_out = {0.0, 0.0};                         // DEFER: the row pair of the previous block that is still to be stored
+    int pend_row = -1, pend_where = 0;
+    bool pend_vb = false;
+    auto flush = [&]() {
+        if (pend_row >= 0 && pend_where) wd_store_pair(pend_where == 1 ? a.y : a.z, pend_row, pend_vb, pend_out, st_nt_of(nt));
+        pend_row = -1;
+    };
+    int sa_n = 0, sb_n = 0;                                 // PREOPS: row starts / operand pairs of the block whose first chunk `cur` holds
+    wv_f64x2 wv_n = {0.0, 0.0}, zv_n = {0.0, 0.0};
+    auto load_ops = [&](int b, int &sa_o, int &sb_o, wv_f64x2 &wv_o, wv_f64x2 &zv_o) {
+        const int r = b * 128, pr = min(r + 2 * lane, a.rows - 1);
+        sa_o = rowptr[r + lane];
+        sb_o = rowptr[r + 64 + lane];
+        if constexpr (kUsesW && !(kWvAbl & 16)) {
+            if (EPI != EPI_AXPY_DOT || a.w) wv_o = w_nt ? __builtin_nontemporal_load((const wd_f64x2u *)(a.w + pr)) : *(const wd_f64x2u *)(a.w + pr);
+        }
+        if constexpr (kUsesZ && !(kWvAbl & 16)) zv_o = z_nt ? __builtin_nontemporal_load((const wd_f64x2u *)(a.z + pr)) : *(const wd_f64x2u *)(a.z + pr);
+    };
     if constexpr (PRE) {
         if (first < last) {
-            nk0 = rowptr[first * 128];
-            nk1 = rowptr[first * 128 + 128];
+            nk0 = rowptr[first * rl * 128];
+            nk1 = rowptr[first * rl * 128 + 128];
             wv_load<PPL>(cur, col, val, nk0 & ~1, nk1, lane);
+            if constexpr (PREOPS) load_ops(first * rl, sa_n, sb_n, wv_n, zv_n);
         }
     }
-    const bool st_nt = (nt & 2) != 0;
-    for (int blk = first; blk < last; blk += step) {
+    const bool st_nt = st_nt_of(nt);
+    for (int run = first; run < last; run += step)
+    for (int blk = run * rl, bend = min(run * rl + rl, nblk); blk < bend; ++blk) {
         const int r0 = blk * 128;
         // (rowptr carries 192 entries of padding = nnz behind its rows + 1 entries: every index below is readable and rows past the
         // end of the matrix are empty)
         const int k0 = PRE ? nk0 : rowptr[r0], k1 = PRE ? nk1 : rowptr[r0 + 128];
+        int bn = blk;
         if constexpr (PRE) {                                // the next block's range: a scalar load issued a whole block early
-            const int bn = min(blk + step, last - 1);
+            bn = blk + 1 < bend ? blk + 1 : min(run + step, last - 1) * rl;   // (past the last run: any valid block -- its chunk is loaded and dropped)
             nk0 = rowptr[bn * 128];
             nk1 = rowptr[bn * 128 + 128];
         }
-        const int sa = rowptr[r0 + lane], sb = rowptr[r0 + 64 + lane];
         const int prow = r0 + 2 * lane;                   // this lane's row PAIR in the epilogue
+        int sa, sb;
         wv_f64x2 wv = {0.0, 0.0}, zv = {0.0, 0.0};
-        if constexpr (kUsesW && !(kWvAbl & 16)) {
-            if (EPI != EPI_AXPY_DOT || a.w)
-                wv = w_nt ? __builtin_nontemporal_load((const wd_f64x2u *)(a.w + min(prow, a.rows - 1))) : *(const wd_f64x2u *)(a.w + min(prow, a.rows - 1));
+        if constexpr (PREOPS) {
+            sa = sa_n; sb = sb_n; wv = wv_n; zv = zv_n;     // fetched a block ago
+        } else {
+            load_ops(blk, sa, sb, wv, zv);
         }
-        if constexpr (kUsesZ && !(kWvAbl & 16)) zv = z_nt ? __builtin_nontemporal_load((const wd_f64x2u *)(a.z + min(prow, a.rows - 1))) : *(const wd_f64x2u *)(a.z + min(prow, a.rows - 1));
         // row ends: the next lane's start; lane 63's rows end where rows 64 / 128 of the block start
         const int sb0 = __builtin_amdgcn_readfirstlane(sb);   // (outside the lane test: readfirstlane reads the first ACTIVE lane)
         int ea = __shfl_down(sa, 1, 64), eb = __shfl_down(sb, 1, 64);
@@ -156,6 +201,10 @@ spmv_wave_kernel(SpmvArgs<int32_t> a, const int32_t *__restrict__ rowptr, const 
             if constexpr (PRE) {                            // next chunk of this block, else the first chunk of the wavefront's next block
                 const bool more = kb + CH < k1;
                 wv_load<PPL>(nxt, col, val, more ? kb + CH : (nk0 & ~1), more ? k1 : nk1, lane);
+                if constexpr (PREOPS) {
+                    if (!more) load_ops(bn, sa_n, sb_n, wv_n, zv_n);   // the next block's row starts and operands ride behind its first chunk
+                }
+                if constexpr (DEFER) flush();                          // the previous block's y store: the youngest operation, nobody waits for it soon
             }
 #pragma unroll
             for (int j = 0; j < PPL; ++j) {
@@ -202,8 +251,17 @@ spmv_wave_kernel(SpmvArgs<int32_t> a, const int32_t *__restrict__ rowptr, const 
         }
         if constexpr (kWvAbl & 8) {
             acc1 += yp.x + yp.y + wv.x + zv.y;          // (keeps everything above alive)
-        } else if (prow < a.rows) wd_epilogue<EPI>(a, prow, prow + 1 < a.rows, yp.x, yp.y, wv, zv, coef, acc1, acc2, st_nt);
+        } else if (prow < a.rows) {
+            if constexpr (DEFER) {
+                pend_vb = prow + 1 < a.rows;
+                pend_where = wd_epilogue_calc<EPI>(a, pend_vb, yp.x, yp.y, wv, zv, coef, acc1, acc2, pend_out);
+                pend_row = prow;
+            } else {
+                wd_epilogue<EPI>(a, prow, prow + 1 < a.rows, yp.x, yp.y, wv, zv, coef, acc1, acc2, st_nt);
+            }
+        }
     }
+    if constexpr (DEFER) flush();
     if constexpr (EPI == EPI_DOT || EPI == EPI_DOT2 || EPI == EPI_DOT4 || EPI == EPI_RES || EPI == EPI_AXPY_DOT || EPI == EPI_XPBY_NRM) {
         const double s1 = block_sum(acc1, s_red);
         if (tid == 0) a.p1[blockIdx.x] = s1;
@@ -259,7 +317,7 @@ static int launch_wave_t(const sla_csr *A, const SpmvArgs<int32_t> &a, int grid)
 #define SLA_WV(P, O, R)                                                                                                                    \
     if (v.ppl == P && v.occ == O && v.pre == R)                                                                                            \
         SLA_KLAUNCH(c, (spmv_wave_kernel<EPI, P, O, R != 0>), dim3(grid), dim3(kBlock), 0, stream_of(c), a, a.rowptr, a.col, a.val, a.x, nblk, \
-                           c->xcd_remap, nt)
+                           c->xcd_remap, nt, std::max(1, c->wave_run))
     SLA_WV(2, 8, 0);
     else SLA_WV(4, 6, 0);
     else SLA_WV(8, 4, 0);
