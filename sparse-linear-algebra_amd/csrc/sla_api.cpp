@@ -530,6 +530,7 @@ const IntKnob kIntKnobs[] = {
     {"tile_slack", &sla_ctx::tile_slack, 0, 64},
     {"tile_prefetch", &sla_ctx::tile_prefetch, 0, 16},
     {"tile_relaxed", &sla_ctx::tile_relaxed, 0, 1},
+    {"tile_rowown", &sla_ctx::tile_rowown, 0, 1},
     {"tile_depth", &sla_ctx::tile_depth, 0, 2},
     {"onchip", &sla_ctx::onchip, 0, 2},
     {"onchip_grid", &sla_ctx::onchip_grid, 0, 4096},

@@ -257,6 +257,7 @@ struct sla_ctx {
                                      // first-touch allocation less at 216^3
     int transpose_device = 1;        // transposeSM of a lowered matrix as a device sort (1: from 2^18 entries on, 2: always, 0: host)
     int canon_device = 1;            // value-indexed matrices: canonical col / val written on the device from the 1-byte codes instead of uploaded
+    int tile_rowown = 0;             // EXPERIMENT (round 6): CU-wide tiles with every row owned by one wavefront (host builder only): reproducible row sums at a quarter of the gather density
     int tile_relaxed = 1;            // the tile form of irregular matrices: 1 = CU-wide slices (spmv_ctile_kernel, round 5: column-sorted gathers that share x lines, row sums by LDS
                                      // atomics in relaxed order -- within nnz_i eps sum|a_ij x_j| of the reference's fold, not reproducible bit for bit), 0 = wavefront-private slices
                                      // (spmv_tile_kernel, rounds 2-4: the reference's left fold bit for bit; 18 % slower on config 3a, 2.2 x on power-law rows)

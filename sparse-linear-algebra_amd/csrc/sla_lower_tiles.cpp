@@ -56,7 +56,18 @@ int build_ctiles_host(sla_csr *A, const std::vector<int32_t> &srow, int shift, i
                 }
             }
             uint32_t *off = toff.data() + (size_t)s * kCtWaves * rowlen;
+            // Experiment of round 6 (option tile_rowown = 1): every ROW of the slice belongs to one wavefront (local row & 3) --
+            // a tile's column-sorted entries are split into the four wavefronts' column-sorted sub-runs instead of being dealt in 64-entry
+            // groups.  All ds_add_f64 of a row then come from one wavefront in program order (ascending panels, ascending columns): the row
+            // sums become reproducible.  The price is the density of a gather instruction: a quarter of the tile's entries per x line.
+            const bool rowown = c->tile_rowown != 0;
             for (int64_t j = 0; j < P; ++j) {
+                if (rowown) {
+                    uint32_t cnt[4] = {0, 0, 0, 0};
+                    for (size_t o = b[(size_t)j]; o < b[(size_t)j + 1]; ++o) cnt[ent[o].rl & 3]++;
+                    for (uint32_t w = 0; w < 4; ++w) off[w * rowlen + (size_t)j] = cnt[w];
+                    continue;
+                }
                 const uint32_t n0 = (uint32_t)(b[(size_t)j + 1] - b[(size_t)j]), G = (n0 + 63) >> 6, tail = n0 & 63;
                 for (uint32_t w = 0; w < 4; ++w) {
                     uint32_t ng = G > w ? (G - w + 3) >> 2 : 0, na = ng * 64;
@@ -69,11 +80,14 @@ int build_ctiles_host(sla_csr *A, const std::vector<int32_t> &srow, int shift, i
                 for (size_t j = 0; j < (size_t)P; ++j) { const uint32_t cnt = off[w * rowlen + j]; off[w * rowlen + j] = run; run += cnt; }
                 off[w * rowlen + (size_t)P] = run;
             }
+            std::vector<uint32_t> fill;
+            if (rowown) fill.assign((size_t)4 * (size_t)P, 0u);
             for (size_t o = 0; o < ent.size(); ++o) {
                 const Ent &e = ent[o];
                 const int64_t j = e.col >> shift;
-                const uint32_t tt = (uint32_t)(o - b[(size_t)j]), g = tt >> 6, w = g & 3;
-                const size_t dst = (size_t)(k0 + off[w * rowlen + (size_t)j] + ((g >> 2) << 6) + (tt & 63));
+                const uint32_t tt = (uint32_t)(o - b[(size_t)j]), g = tt >> 6, w = rowown ? (e.rl & 3) : (g & 3);
+                const size_t dst = rowown ? (size_t)(k0 + off[w * rowlen + (size_t)j] + fill[(size_t)w * (size_t)P + (size_t)j]++)
+                                          : (size_t)(k0 + off[w * rowlen + (size_t)j] + ((g >> 2) << 6) + (tt & 63));
                 tidx[dst] = (e.rl << shift) | ((uint32_t)e.col & cmask);
                 tval[dst] = val[e.k];
             }
@@ -181,7 +195,7 @@ int build_tiles(sla_csr *A, int64_t n, int64_t rows, const int64_t *rowptr, cons
     // Round 4: the re-ordering as a device sort of the canonical arrays that are on the device already (sla_tiles_build.hip) -- at
     // 330 M entries the host builder below took 1.2 s (16 threads) plus 4 GB of PCIe; option tiles_device: 1 from 2^20 entries on,
     // 2 always, 0 never (the two builders are bit-identical: tests/test_gpu_tiles.py).
-    if (c->tiles_device == 2 || (c->tiles_device == 1 && nnz >= ((int64_t)1 << 20))) {
+    if ((c->tiles_device == 2 || (c->tiles_device == 1 && nnz >= ((int64_t)1 << 20))) && !(cu && c->tile_rowown)) {   // (the row-owning experiment exists in the host builder only)
         int64_t mseg = 0, nb = 0;
         bool done = false;
         if (cu) {   // (relaxed order: no layers, nothing to step aside for)

@@ -138,7 +138,7 @@ __global__ void __launch_bounds__(256) ctile_keys_kernel(int s_lo, int s_hi, con
         const RP k0 = rowptr[srow[s]], k1 = rowptr[srow[s + 1]];
         for (RP k = k0 + (RP)threadIdx.x; k < k1; k += 256) {
             key[(int64_t)k - k_lo] = hi | ((uint64_t)(col[k] >> shift) << shift) | ((uint32_t)col[k] & cmask);
-            idx[(int64_t)k - k_lo] = (uint32_t)k;
+            idx[(int64_t)k - k_lo] = (uint32_t)((int64_t)k - k_lo);   // chunk-local (round 6: the matrix may hold more than 2^32 entries, a chunk never does)
         }
     }
 }
@@ -201,13 +201,13 @@ __global__ void __launch_bounds__(256) ctile_emit_kernel(int64_t k_lo, int64_t n
     const uint32_t cmask = (1u << shift) - 1u;
     for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < n; o += (int64_t)gridDim.x * 256) {
         const uint64_t kk = key[o];
-        const uint32_t k = idx[o];
+        const int64_t k = k_lo + (int64_t)idx[o];
         const int s = (int)(kk >> (pbits + shift));
         const int j = (int)((kk >> shift) & (((uint64_t)1 << pbits) - 1));
         const int64_t base = (int64_t)rowptr[srow[s]];
         const uint32_t t = (uint32_t)(o + k_lo - base) - bs[(size_t)(s - s_lo) * (P + 1) + j], g = t >> 6, w = g & 3;
         const int64_t dst = base + toff[((size_t)s * 4 + w) * (size_t)(P + 1) + (size_t)j] + ((g >> 2) << 6) + (t & 63);
-        tidx[dst] = ((uint32_t)(row_of_entry[(int64_t)k - k_lo] - srow[s]) << shift) | ((uint32_t)col[k] & cmask);
+        tidx[dst] = ((uint32_t)(row_of_entry[k - k_lo] - srow[s]) << shift) | ((uint32_t)col[k] & cmask);
         tval[dst] = val[k];
     }
 }
@@ -306,7 +306,10 @@ int build_ctiles_device(sla_csr *A, const std::vector<int32_t> &srow, int shift,
     *done = false;
     sla_ctx *c = A->ctx;
     const int64_t nnz = A->nnz, S = (int64_t)srow.size() - 1;
-    if (!A->d_col || !A->d_val || !A->d_rowptr || nnz <= 0 || nnz >= ((int64_t)1 << 31) || S <= 0) return SLA_OK;
+    // (no bound on nnz: the build runs over chunks of <= 2^26 entries with chunk-local positions, every global offset is 64-bit, and a slice's
+    // own offsets fit 32 bits by the caller's check; round 5 refused >= 2^31 entries here and the 2.2e9-entry run of tools/big_nnz.py spent 17.4 of
+    // its 18.5 s of lowering in the host builder)
+    if (!A->d_col || !A->d_val || !A->d_rowptr || nnz <= 0 || S <= 0) return SLA_OK;
     hipStream_t st = stream_of(c);
     static const bool dbg = getenv("SLA_DEBUG_LOWER") != nullptr;
     auto t_last = std::chrono::steady_clock::now();
