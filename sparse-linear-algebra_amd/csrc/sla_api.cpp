@@ -457,7 +457,7 @@ int fold_kind(const sla_csr *A) {
     if (A->use_vdict && c->vdict) return SLA_FOLD_EXACT;
     if (A->use_lpanel && c->lpanel) return SLA_FOLD_REGROUPED;
     if (lflat_on(A)) return SLA_FOLD_REGROUPED;
-    if (tiles_on(A)) return A->tl_cu ? SLA_FOLD_RELAXED : SLA_FOLD_EXACT;
+    if (tiles_on(A)) return (A->tl_cu && !A->tl_rowown) ? SLA_FOLD_RELAXED : SLA_FOLD_EXACT;
     if (!A->panels.empty() && c->panels) return SLA_FOLD_REGROUPED;
     if (!diag_on(A) && !stream_xwin_on(A) && wave_plain(A)) return SLA_FOLD_EXACT;
     return SLA_FOLD_REGROUPED;
@@ -530,7 +530,7 @@ const IntKnob kIntKnobs[] = {
     {"tile_slack", &sla_ctx::tile_slack, 0, 64},
     {"tile_prefetch", &sla_ctx::tile_prefetch, 0, 16},
     {"tile_relaxed", &sla_ctx::tile_relaxed, 0, 1},
-    {"tile_rowown", &sla_ctx::tile_rowown, 0, 1},
+    {"tile_rowown", &sla_ctx::tile_rowown, -1, 1},
     {"tile_depth", &sla_ctx::tile_depth, 0, 2},
     {"onchip", &sla_ctx::onchip, 0, 2},
     {"onchip_grid", &sla_ctx::onchip_grid, 0, 4096},
@@ -1055,8 +1055,9 @@ int sla_csr_kernel_info(sla_csr_t A, char *buf, int buflen) {
     if (tiles_on(A)) {   // tile geometry; exact_fold: every row is folded entry by entry in ascending column order
         const size_t used = strlen(buf);
         if (used + 1 < (size_t)buflen)
-            snprintf(buf + used, (size_t)buflen - used, " slices=%d panels=%d panel_cols=%d max_segment=%lld exact_fold=%d cu_slices=%d pacing=%s", A->tl_S, A->tl_P,
-                     1 << A->tl_shift, (long long)A->tl_maxseg, A->tl_cu ? 0 : 1, A->tl_cu ? 1 : 0, A->ctx->xcd8 == 1 && A->ctx->tile_slack > 0 ? "on" : "off");
+            snprintf(buf + used, (size_t)buflen - used, " slices=%d panels=%d panel_cols=%d max_segment=%lld exact_fold=%d cu_slices=%d%s pacing=%s", A->tl_S, A->tl_P,
+                     1 << A->tl_shift, (long long)A->tl_maxseg, (A->tl_cu && !A->tl_rowown) ? 0 : 1, A->tl_cu ? 1 : 0, A->tl_rowown ? " row_owned=1" : "",
+                     A->ctx->xcd8 == 1 && A->ctx->tile_slack > 0 ? "on" : "off");
     }
     if (ag_split(A)) {   // overlapped all-gather: exchange groups and panel passes of this rank
         const size_t used = strlen(buf);

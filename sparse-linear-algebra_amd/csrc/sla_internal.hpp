@@ -257,7 +257,8 @@ struct sla_ctx {
                                      // first-touch allocation less at 216^3
     int transpose_device = 1;        // transposeSM of a lowered matrix as a device sort (1: from 2^18 entries on, 2: always, 0: host)
     int canon_device = 1;            // value-indexed matrices: canonical col / val written on the device from the 1-byte codes instead of uploaded
-    int tile_rowown = 0;             // EXPERIMENT (round 6): CU-wide tiles with every row owned by one wavefront (host builder only): reproducible row sums at a quarter of the gather density
+    int tile_rowown = -1;            // round 6: CU-wide tiles with every row of a slice owned by ONE wavefront (reproducible row sums, the reference's left fold; a quarter of the
+                                     // relaxed dealing's gather density): -1 = whenever tile_relaxed = 0 asks for the exact form, 0 = never (exact = wavefront-private slices), 1 = always
     int tile_relaxed = 1;            // the tile form of irregular matrices: 1 = CU-wide slices (spmv_ctile_kernel, round 5: column-sorted gathers that share x lines, row sums by LDS
                                      // atomics in relaxed order -- within nnz_i eps sum|a_ij x_j| of the reference's fold, not reproducible bit for bit), 0 = wavefront-private slices
                                      // (spmv_tile_kernel, rounds 2-4: the reference's left fold bit for bit; 18 % slower on config 3a, 2.2 x on power-law rows)
@@ -486,6 +487,7 @@ struct sla_csr {
     int64_t tl_maxseg = 0;           // longest (row, panel) segment = layers of the deepest tile
     double *d_tldummy = nullptr;     // one all-zero panel (2^tl_shift doubles): what the tile kernels' empty pipeline-drain chunks gather from
     bool tl_cu = false;              // CU-wide slices, relaxed order (sla_spmv_ctiles.hip): entries [slice][wavefront][panel], d_tloff = tl_S x 4 x (tl_P + 1)
+    bool tl_rowown = false;          // ... with every row owned by one wavefront: exact, reproducible (round 6)
     sla_tri_plan *tri[2] = {nullptr, nullptr};  // [0] lower, [1] upper triangle schedules (built on first use)
     sla::OcPlan *oc = nullptr;       // on-chip solver plan (built by the first sla_solver_step that could use it; ok = false: tried, not eligible)
     // comm / compute overlap of the sharded (#>) (wave-sliced forms): the 512-row steps whose rows reference own columns only

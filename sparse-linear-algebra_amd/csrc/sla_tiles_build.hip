@@ -129,15 +129,20 @@ __global__ void __launch_bounds__(256) tile_offsets_kernel(int S, int P, int64_t
 // The build runs over CHUNKS of whole slices [s_lo, s_hi) = entries [k_lo, k_hi): the scratch (sort keys and positions twice, the row of
 // every entry, the tile starts) is sized for one chunk -- 9.2 GB for config 3a in one piece made every third lowering of a process wait
 // 1.5 s in hipMalloc (LABNOTES R5).  key / idx / row_of_entry / bs are chunk-local arrays.
+// Row-owning variant (round 6, `wb` = 2): the wavefront that owns the entry's row -- (row - slice's first row) & 3 -- sits between the panel and the
+// column in the key, so that a tile's run splits into four column-sorted sub-runs, one per wavefront (row_of_entry is filled first then).
 template <typename RP>
 __global__ void __launch_bounds__(256) ctile_keys_kernel(int s_lo, int s_hi, const int32_t *__restrict__ srow, const RP *__restrict__ rowptr,
-                                                          const int32_t *__restrict__ col, int shift, int pbits, int64_t k_lo, uint64_t *key, uint32_t *idx) {
+                                                          const int32_t *__restrict__ col, int shift, int pbits, int64_t k_lo, uint64_t *key, uint32_t *idx,
+                                                          int wb, const int32_t *__restrict__ row_of_entry) {
     for (int s = s_lo + (int)blockIdx.x; s < s_hi; s += gridDim.x) {
-        const uint64_t hi = (uint64_t)s << (pbits + shift);
+        const uint64_t hi = (uint64_t)s << (pbits + wb + shift);
         const uint32_t cmask = (1u << shift) - 1u;
-        const RP k0 = rowptr[srow[s]], k1 = rowptr[srow[s + 1]];
+        const int32_t r0 = srow[s];
+        const RP k0 = rowptr[r0], k1 = rowptr[srow[s + 1]];
         for (RP k = k0 + (RP)threadIdx.x; k < k1; k += 256) {
-            key[(int64_t)k - k_lo] = hi | ((uint64_t)(col[k] >> shift) << shift) | ((uint32_t)col[k] & cmask);
+            const uint64_t pw = wb ? (((uint64_t)(col[k] >> shift) << wb) | (uint64_t)((row_of_entry[(int64_t)k - k_lo] - r0) & 3)) : (uint64_t)(col[k] >> shift);
+            key[(int64_t)k - k_lo] = hi | (pw << shift) | ((uint32_t)col[k] & cmask);
             idx[(int64_t)k - k_lo] = (uint32_t)((int64_t)k - k_lo);   // chunk-local (round 6: the matrix may hold more than 2^32 entries, a chunk never does)
         }
     }
@@ -207,6 +212,54 @@ __global__ void __launch_bounds__(256) ctile_emit_kernel(int64_t k_lo, int64_t n
         const int64_t base = (int64_t)rowptr[srow[s]];
         const uint32_t t = (uint32_t)(o + k_lo - base) - bs[(size_t)(s - s_lo) * (P + 1) + j], g = t >> 6, w = g & 3;
         const int64_t dst = base + toff[((size_t)s * 4 + w) * (size_t)(P + 1) + (size_t)j] + ((g >> 2) << 6) + (t & 63);
+        tidx[dst] = ((uint32_t)(row_of_entry[k - k_lo] - srow[s]) << shift) | ((uint32_t)col[k] & cmask);
+        tval[dst] = val[k];
+    }
+}
+
+// ---- row-owning layout: bounds per (slice, panel, wavefront), counts, emit --------------------------------------------------------------
+// bs4[((s - s_lo) * P + j) * 4 + w] = first sorted position with (slice, panel, wavefront) >= (s, j, w), relative to the slice's first entry
+// (one more slot per slice: its entry count)
+template <typename RP>
+__global__ void __launch_bounds__(256) ctile_bounds4_kernel(int s_lo, int s_hi, int P, const uint64_t *__restrict__ key, const int32_t *__restrict__ srow,
+                                                             const RP *__restrict__ rowptr, int shift, int pbits, int64_t k_lo, uint32_t *bs4) {
+    const int64_t per = (int64_t)P * 4 + 1, total = (int64_t)(s_hi - s_lo) * per;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+        const int sl = (int)(t / per), q = (int)(t - (int64_t)sl * per), s = s_lo + sl;   // q = panel * 4 + wavefront (P * 4: the end)
+        const uint64_t want = ((uint64_t)s << (pbits + 2 + shift)) | ((uint64_t)q << shift);
+        int64_t lo = (int64_t)rowptr[srow[s]], hi = (int64_t)rowptr[srow[s + 1]];
+        const int64_t base = lo;
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (key[mid - k_lo] < want) lo = mid + 1;
+            else hi = mid;
+        }
+        bs4[t] = (uint32_t)(lo - base);
+    }
+}
+__global__ void __launch_bounds__(256) ctile_counts4_kernel(int s_lo, int s_hi, int P, const uint32_t *__restrict__ bs4, uint32_t *toff) {
+    const int64_t total = (int64_t)(s_hi - s_lo) * P * 4;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+        const int sl = (int)(t / ((int64_t)P * 4)), q = (int)(t - (int64_t)sl * P * 4), j = q >> 2, w = q & 3, s = s_lo + sl;
+        const uint32_t *b = bs4 + (size_t)sl * ((size_t)P * 4 + 1) + q;
+        toff[((size_t)s * 4 + w) * (size_t)(P + 1) + (size_t)j] = b[1] - b[0];
+    }
+}
+template <typename RP>
+__global__ void __launch_bounds__(256) ctile_emit4_kernel(int64_t k_lo, int64_t n, int s_lo, int P, const uint64_t *__restrict__ key, const uint32_t *__restrict__ idx,
+                                                           const int32_t *__restrict__ srow, const RP *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                                           const double *__restrict__ val, const int32_t *__restrict__ row_of_entry,
+                                                           const uint32_t *__restrict__ bs4, const uint32_t *__restrict__ toff, int shift, int pbits,
+                                                           uint32_t *tidx, double *tval) {
+    const uint32_t cmask = (1u << shift) - 1u;
+    for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < n; o += (int64_t)gridDim.x * 256) {
+        const uint64_t kk = key[o];
+        const int64_t k = k_lo + (int64_t)idx[o];
+        const int s = (int)(kk >> (pbits + 2 + shift));
+        const int q = (int)((kk >> shift) & (((uint64_t)1 << (pbits + 2)) - 1)), j = q >> 2, w = q & 3;
+        const int64_t base = (int64_t)rowptr[srow[s]];
+        const uint32_t t = (uint32_t)(o + k_lo - base) - bs4[(size_t)(s - s_lo) * ((size_t)P * 4 + 1) + (size_t)q];
+        const int64_t dst = base + toff[((size_t)s * 4 + w) * (size_t)(P + 1) + (size_t)j] + t;
         tidx[dst] = ((uint32_t)(row_of_entry[k - k_lo] - srow[s]) << shift) | ((uint32_t)col[k] & cmask);
         tval[dst] = val[k];
     }
@@ -336,8 +389,10 @@ int build_ctiles_device(sla_csr *A, const std::vector<int32_t> &srow, int shift,
     }
     DevBuf d_srow, d_key, d_key2, d_idx, d_idx2, d_rows, d_tmp, d_bs;
     auto launch_ok = [&]() { return hipGetLastError() == hipSuccess; };
+    const bool rowown = A->tl_rowown;   // (round 6: every row of a slice owned by one wavefront -- reproducible, ascending row sums)
+    const int wb = rowown ? 2 : 0;
     const int pbits = bits_for((uint64_t)P), sbits = bits_for((uint64_t)S);
-    const int keybits = sbits + pbits + shift;
+    const int keybits = sbits + pbits + wb + shift;
     if (keybits > 62) return SLA_OK;
     const size_t ntoff = (size_t)S * 4 * (size_t)(P + 1);
     hipError_t e = d_srow.alloc(sizeof(int32_t) * srow.size());
@@ -347,7 +402,7 @@ int build_ctiles_device(sla_csr *A, const std::vector<int32_t> &srow, int shift,
     if (e == hipSuccess) e = d_idx.alloc(4 * (size_t)nmax);
     if (e == hipSuccess) e = d_idx2.alloc(4 * (size_t)nmax);
     if (e == hipSuccess) e = d_rows.alloc(4 * (size_t)nmax);
-    if (e == hipSuccess) e = d_bs.alloc(4 * ((size_t)smax * (P + 1) + 8));
+    if (e == hipSuccess) e = d_bs.alloc(4 * ((size_t)smax * (rowown ? (size_t)P * 4 + 1 : (size_t)(P + 1)) + 8));
     size_t tmp_bytes = 0;
     if (e == hipSuccess)
         e = rocprim::radix_sort_pairs(nullptr, tmp_bytes, d_key.as<uint64_t>(), d_key2.as<uint64_t>(), d_idx.as<uint32_t>(), d_idx2.as<uint32_t>(),
@@ -377,17 +432,30 @@ int build_ctiles_device(sla_csr *A, const std::vector<int32_t> &srow, int shift,
         }
         const unsigned gs = (unsigned)std::min<int64_t>(s_hi - s_lo, 65535);
         const unsigned gt = (unsigned)std::min<int64_t>(((int64_t)(s_hi - s_lo) * (P + 1) + 255) / 256, 65535);
-        if (A->rp64) {
-            hipLaunchKernelGGL((ctile_keys_kernel<int64_t>), dim3(gs), dim3(256), 0, st, s_lo, s_hi, d_srow.as<int32_t>(), (const int64_t *)A->d_rowptr, A->d_col, shift, pbits, k_lo, d_key.as<uint64_t>(), d_idx.as<uint32_t>());
+        if (A->rp64) {   // (the rows first: the row-owning keys read them)
             hipLaunchKernelGGL((ctile_rows_kernel<int64_t>), dim3(grid), dim3(256), 0, st, r_lo, r_hi, (const int64_t *)A->d_rowptr, k_lo, d_rows.as<int32_t>());
+            hipLaunchKernelGGL((ctile_keys_kernel<int64_t>), dim3(gs), dim3(256), 0, st, s_lo, s_hi, d_srow.as<int32_t>(), (const int64_t *)A->d_rowptr, A->d_col, shift, pbits, k_lo, d_key.as<uint64_t>(), d_idx.as<uint32_t>(), wb, d_rows.as<int32_t>());
         } else {
-            hipLaunchKernelGGL((ctile_keys_kernel<int32_t>), dim3(gs), dim3(256), 0, st, s_lo, s_hi, d_srow.as<int32_t>(), (const int32_t *)A->d_rowptr, A->d_col, shift, pbits, k_lo, d_key.as<uint64_t>(), d_idx.as<uint32_t>());
             hipLaunchKernelGGL((ctile_rows_kernel<int32_t>), dim3(grid), dim3(256), 0, st, r_lo, r_hi, (const int32_t *)A->d_rowptr, k_lo, d_rows.as<int32_t>());
+            hipLaunchKernelGGL((ctile_keys_kernel<int32_t>), dim3(gs), dim3(256), 0, st, s_lo, s_hi, d_srow.as<int32_t>(), (const int32_t *)A->d_rowptr, A->d_col, shift, pbits, k_lo, d_key.as<uint64_t>(), d_idx.as<uint32_t>(), wb, d_rows.as<int32_t>());
         }
         if (!launch_ok()) return give_up();
         e = rocprim::radix_sort_pairs(d_tmp.p, tmp_bytes, d_key.as<uint64_t>(), d_key2.as<uint64_t>(), d_idx.as<uint32_t>(), d_idx2.as<uint32_t>(), (size_t)n, 0,
                                       (unsigned)keybits, st);
         if (e != hipSuccess) return give_up();
+        if (rowown) {
+            const unsigned gt4 = (unsigned)std::min<int64_t>(((int64_t)(s_hi - s_lo) * (P * 4 + 1) + 255) / 256, 65535);
+            if (A->rp64) hipLaunchKernelGGL((ctile_bounds4_kernel<int64_t>), dim3(gt4), dim3(256), 0, st, s_lo, s_hi, (int)P, d_key2.as<uint64_t>(), d_srow.as<int32_t>(), (const int64_t *)A->d_rowptr, shift, pbits, k_lo, d_bs.as<uint32_t>());
+            else hipLaunchKernelGGL((ctile_bounds4_kernel<int32_t>), dim3(gt4), dim3(256), 0, st, s_lo, s_hi, (int)P, d_key2.as<uint64_t>(), d_srow.as<int32_t>(), (const int32_t *)A->d_rowptr, shift, pbits, k_lo, d_bs.as<uint32_t>());
+            hipLaunchKernelGGL(ctile_counts4_kernel, dim3(gt4), dim3(256), 0, st, s_lo, s_hi, (int)P, d_bs.as<uint32_t>(), A->d_tloff);
+            hipLaunchKernelGGL(ctile_scan_kernel, dim3((unsigned)((s_hi - s_lo + 63) / 64)), dim3(64), 0, st, s_lo, s_hi, (int)P, A->d_tloff);
+            if (A->rp64)
+                hipLaunchKernelGGL((ctile_emit4_kernel<int64_t>), dim3(grid), dim3(256), 0, st, k_lo, n, s_lo, (int)P, d_key2.as<uint64_t>(), d_idx2.as<uint32_t>(), d_srow.as<int32_t>(), (const int64_t *)A->d_rowptr, A->d_col, A->d_val, d_rows.as<int32_t>(), d_bs.as<uint32_t>(), A->d_tloff, shift, pbits, A->d_tlidx, A->d_tlval);
+            else
+                hipLaunchKernelGGL((ctile_emit4_kernel<int32_t>), dim3(grid), dim3(256), 0, st, k_lo, n, s_lo, (int)P, d_key2.as<uint64_t>(), d_idx2.as<uint32_t>(), d_srow.as<int32_t>(), (const int32_t *)A->d_rowptr, A->d_col, A->d_val, d_rows.as<int32_t>(), d_bs.as<uint32_t>(), A->d_tloff, shift, pbits, A->d_tlidx, A->d_tlval);
+            if (!launch_ok()) return give_up();
+            continue;
+        }
         if (A->rp64) hipLaunchKernelGGL((ctile_bounds_kernel<int64_t>), dim3(gt), dim3(256), 0, st, s_lo, s_hi, (int)P, d_key2.as<uint64_t>(), d_srow.as<int32_t>(), (const int64_t *)A->d_rowptr, shift, pbits, k_lo, d_bs.as<uint32_t>());
         else hipLaunchKernelGGL((ctile_bounds_kernel<int32_t>), dim3(gt), dim3(256), 0, st, s_lo, s_hi, (int)P, d_key2.as<uint64_t>(), d_srow.as<int32_t>(), (const int32_t *)A->d_rowptr, shift, pbits, k_lo, d_bs.as<uint32_t>());
         hipLaunchKernelGGL(ctile_counts_kernel, dim3(gt), dim3(256), 0, st, s_lo, s_hi, (int)P, d_bs.as<uint32_t>(), A->d_tloff);

@@ -126,8 +126,12 @@ def test_cu_wide_tile_builder_in_chunks_gives_the_same_layout(sla):
             os.environ["SLA_TILE_BUILD_CHUNK"] = old
 
 
+@pytest.mark.parametrize("rowown", [-1, 0])
 @pytest.mark.parametrize("name", list(CASES))
-def test_tiles_match_the_oracle(sla, name):
+def test_tiles_match_the_oracle(sla, name, rowown):
+    """The EXACT tile forms (tile_relaxed = 0): rowown = -1 (default since round 6) -- CU-wide slices with every row owned by one wavefront, all
+    LDS adds of a row from that wavefront in program order (ascending panels, ascending columns); rowown = 0 -- the wavefront-private slices of
+    rounds 2-4.  Both: every row bit for bit the reference's left fold, reruns bit-identical, device builder == host builder."""
     build, expect_tiles = CASES[name]
     dims, csr = build()
     m, n = dims
@@ -140,14 +144,17 @@ def test_tiles_match_the_oracle(sla, name):
     # (lpanel=0: the dense-row cases would otherwise take the LDS-panel form; tiles_device: the re-ordering as a device sort -- round 4,
     # sla_tiles_build.hip -- and by the host builder: the same decision and the same bits from both)
     for rp64, dev in (("0", 2), ("1", 2), ("0", 0), ("1", 0)):
-        ctx = sla.Context(0).set_options(tile_shift=10, lpanel=0, lflat=0, force_rp64=rp64, tiles_device=dev, tile_relaxed=0)
+        ctx = sla.Context(0).set_options(tile_shift=10, lpanel=0, lflat=0, force_rp64=rp64, tiles_device=dev, tile_relaxed=0, tile_rowown=rowown)
         A = sla.fromCSR(dims, rp, ci, va, ctx)
         info = A.kernel_info()
+        if rowown != 0:
+            expect_tiles = m > 1         # (CU-wide slices have no layers: dense rows among sparse ones do not turn the form down; only the single row does)
         assert ("algo=tiles" in info) == expect_tiles, (name, info)
         assert ("tile builder on device" in A.lower_info()) == (expect_tiles and dev == 2), (name, dev, A.lower_info())
         y = sla.matVec(A, sla.fromVector(x, ctx)).toDenseListSV()
         if expect_tiles:
-            assert "exact_fold=1" in info and "cu_slices=0" in info
+            assert "exact_fold=1" in info and ("cu_slices=0" if rowown == 0 else "cu_slices=1 row_owned=1") in info, info
+            assert A.props()["fold"] == 0                                     # SLA_FOLD_EXACT
             assert np.array_equal(y, want), (name, rp64, dev, int(np.count_nonzero(y != want)))
         else:
             assert np.all(np.abs(y - want) <= bound), (name, rp64, float(np.abs(y - want).max()))
@@ -178,7 +185,7 @@ def test_tiles_transpose_and_solver_epilogues(sla, relaxed):
     n = 6000
     dims, (rp, ci, va) = wl.random_spd(n, 5, 3)
     A, Ao = sla.fromCSR(dims, rp, ci, va, ctx), orc.Csr(n, n, rp, ci, va)
-    assert "algo=tiles" in A.kernel_info() and f"cu_slices={relaxed}" in A.kernel_info()
+    assert "algo=tiles" in A.kernel_info() and ("cu_slices=1 pacing" if relaxed else "cu_slices=1 row_owned=1") in A.kernel_info()
     rng = np.random.default_rng(5)
     u = rng.standard_normal(n)
     absA = orc.Csr(n, n, rp, ci, np.abs(va))
@@ -221,10 +228,14 @@ def test_default_panel_width_picks_tiles_only_beyond_the_l2(sla):
     yo = orc.spmv(orc.Csr(*dims, rp, ci, va), x)
     bound = np.diff(rp) * EPS * orc.spmv(orc.Csr(*dims, rp, ci, np.abs(va)), np.abs(x))
     assert np.all(np.abs(sla.matVec(A, sla.fromVector(x, ctx)).toDenseListSV() - yo) <= bound)
-    ctx0 = sla.Context(0).set_option("tile_relaxed", 0)        # the bit-exact form: eleven 512 KiB panels (2^16 columns below 6 M columns), the reference's fold
+    ctx0 = sla.Context(0).set_options(tile_relaxed=0, tile_rowown=0)   # the wavefront-private exact form: eleven 512 KiB panels (2^16 columns below 6 M columns), the reference's fold
     A0 = sla.fromCSR(dims, rp, ci, va, ctx0)
-    assert "panels=11 panel_cols=65536" in A0.kernel_info() and "exact_fold=1" in A0.kernel_info(), A0.kernel_info()
+    assert "panels=11 panel_cols=65536" in A0.kernel_info() and "exact_fold=1 cu_slices=0" in A0.kernel_info(), A0.kernel_info()
     assert np.array_equal(sla.matVec(A0, sla.fromVector(x, ctx0)).toDenseListSV(), yo)
+    ctx1 = sla.Context(0).set_option("tile_relaxed", 0)        # the exact form since round 6: the CU-wide slices, rows owned by wavefronts
+    A1 = sla.fromCSR(dims, rp, ci, va, ctx1)
+    assert "panels=6 panel_cols=131072" in A1.kernel_info() and "exact_fold=1 cu_slices=1 row_owned=1" in A1.kernel_info(), A1.kernel_info()
+    assert np.array_equal(sla.matVec(A1, sla.fromVector(x, ctx1)).toDenseListSV(), yo)
 
 
 @pytest.mark.parametrize("relaxed", [0, 1])
@@ -340,3 +351,39 @@ def test_fold_kind_of_the_other_forms(sla):
     y1 = sla.matVec(A, sla.fromVector(x, ctx)).toDenseListSV()
     y2 = sla.matVec(A, sla.fromVector(x, ctx)).toDenseListSV()
     assert np.array_equal(y1, y2)                                                                # regrouped, but fixed: reruns bit-identical
+
+
+def test_row_owned_tiles_fold_in_ascending_order_when_lanes_collide(sla):
+    """The exact CU-wide form relies on ONE wavefront adding all products of a row in program order -- and, where several lanes of one
+    ds_add_f64 instruction hold the SAME row, on the LDS resolving them in ascending lane (= ascending column) order.  Provoked here: rows whose
+    entries sit in clusters of consecutive columns that few other rows share (so a 64-entry group of a tile's column-sorted run is full of
+    repeats of a row), with values whose sum depends on the order of the additions (+-2^60, +-1 and small fractions in one row).  Every row must
+    still be the reference's left fold bit for bit, on both builders, and twice the same."""
+    rng = np.random.default_rng(31)
+    m, n, per = 6000, 40000, 24
+    rows, cols, vals = [], [], []
+    for i in range(m):
+        starts = rng.choice(n - per, size=3, replace=False)
+        cj = np.unique(np.concatenate([np.arange(s0, s0 + per // 3) for s0 in starts]))
+        v = rng.standard_normal(len(cj))
+        big = rng.choice(len(cj), size=4, replace=False)
+        v[big] = np.array([2.0 ** 60, -2.0 ** 60, 2.0 ** 40, -2.0 ** 40]) * (1.0 + rng.random(4))
+        rows.append(np.full(len(cj), i)); cols.append(cj); vals.append(v)
+    rc, Ao = orc.coo_to_csr(m, n, np.concatenate(rows), np.concatenate(cols), np.concatenate(vals))
+    assert rc == orc.OK
+    x = 1.0 + rng.random(n)
+    want = orc.spmv(Ao, x)
+    other = orc.spmv(Ao, x)   # (sanity of the construction: a reversed fold differs on most rows)
+    rev = np.array([np.sum((Ao.val[Ao.rowptr[i]:Ao.rowptr[i + 1]] * x[Ao.colidx[Ao.rowptr[i]:Ao.rowptr[i + 1]]])[::-1].cumsum()[-1:]) for i in range(200)])
+    assert np.count_nonzero(rev != want[:200]) > 50 and np.array_equal(other, want)
+    for dev in (2, 0):
+        for shift in (10, 13):
+            ctx = sla.Context(0).set_options(tile_shift=shift, lpanel=0, lflat=0, tiles_device=dev, tile_relaxed=0)
+            A = sla.fromCSR((m, n), Ao.rowptr, Ao.colidx, Ao.val, ctx)
+            assert "row_owned=1" in A.kernel_info(), A.kernel_info()
+            y1 = sla.matVec(A, sla.fromVector(x, ctx)).toDenseListSV()
+            y2 = sla.matVec(A, sla.fromVector(x, ctx)).toDenseListSV()
+            assert np.array_equal(y1, y2)
+            assert np.array_equal(y1, want), (dev, shift, int(np.count_nonzero(y1 != want)))
+            del A
+            ctx.close()

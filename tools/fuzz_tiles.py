@@ -59,15 +59,17 @@ for case in range(cases):
         del A
         ctx.close()
     got = {}
-    for dev in (2, 0):
-        ctx = sla.Context(0).set_options(tile_shift=shift, lpanel=0, lflat=0, tiles_device=dev, force_rp64=1 if case % 3 == 0 else 0, tile_relaxed=0)
+    # the exact forms: rows owned by wavefronts inside CU-wide slices (round 6, tile_rowown = -1: what tile_relaxed = 0 selects) and the
+    # wavefront-private slices (tile_rowown = 0); both builders each
+    for dev, ro in ((2, -1), (0, -1), (2, 0), (0, 0)):
+        ctx = sla.Context(0).set_options(tile_shift=shift, lpanel=0, lflat=0, tiles_device=dev, force_rp64=1 if case % 3 == 0 else 0, tile_relaxed=0, tile_rowown=ro)
         A = sla.fromCSR((m, n), rp, ci, va, ctx)
         info = A.kernel_info()
         if "algo=tiles" not in info:
             del A
             ctx.close()
             break
-        if dev == 2:
+        if dev == 2 and ro == 0:
             taken += 1
         for opts in ({}, {"tile_poll": 0}, {"tile_slack": 0}, {"tile_prefetch": 2}):
             ctx.set_options(**opts)
@@ -76,9 +78,11 @@ for case in range(cases):
             keys = np.nonzero(lens > 0)[0]
             assert np.array_equal(y.view(np.uint64)[keys], want.view(np.uint64)[keys]) or \
                 (np.array_equal(np.isnan(y), np.isnan(want)) and np.array_equal(y[~np.isnan(want)], want[~np.isnan(want)])), (case, dev, opts, shift, info)
-        got[dev] = y
+        got[(dev, ro)] = y
         del A
         ctx.close()
-    if len(got) == 2:
-        assert np.array_equal(np.isnan(got[0]), np.isnan(got[2])) and np.array_equal(got[0][~np.isnan(got[0])], got[2][~np.isnan(got[2])]), (case, "builders differ")
+    for ro in (-1, 0):
+        if (0, ro) in got and (2, ro) in got:
+            a, b = got[(0, ro)], got[(2, ro)]
+            assert np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(a[~np.isnan(a)], b[~np.isnan(b)]), (case, ro, "builders differ")
 print(f"tile fuzz ok: {cases} cases, exact tile form taken in {taken}, CU-wide relaxed form in {globals().get('relaxed_taken', 0)}")

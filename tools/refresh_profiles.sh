@@ -127,4 +127,18 @@ SLA_BENCH_LOOPBACK=1 SLA_FAULT_INJECT=p2p_hang SLA_BENCH_PREFLIGHT_S=5 timeout 9
 for w in laplace3d_10m laplace3d_1m banded_2m poisson2d_1m e05_tiled e05_tiled_10m varcoef7 random_spd_1m rand100 rand200 rand500 powerlaw; do timeout 900 python tools/form_tournament.py $w 40 2>/dev/null | grep -v "^#"; done > $S/${tag}_form_tournament.txt 2>&1
 { timeout 600 python tools/lower_phases.py random_spd_10m 3; timeout 600 python tools/lower_phases.py laplace3d_10m 3; } > $S/${tag}_lowering_phases.txt 2>&1
 timeout 900 python tools/tile_bench.py 10000000 "DEFAULT=1" "SLA_TILE_RELAXED=0" "SLA_TILE_DEPTH=1" "SLA_TILE_SLACK=2" "SLA_TILE_SLACK=4" "SLA_TILE_SLACK=0" "SLA_TILE_SHIFT=16" > $S/${tag}_ab_tile_knobs.txt 2>&1
-ls -la $S | head -80
+# round 6: the on-chip solver step (one persistent launch) against the launch flow on the sizes it takes -- config 2 and config 4's per-rank slab at N = 8
+for w in poisson2d_1m laplace3d_slab8 laplace3d_1m; do
+  run onchip_$w $B --workload $w --no-cpu-baseline --no-extra-blocks
+  SLA_ONCHIP=0 run launchflow_$w $B --workload $w --no-cpu-baseline --no-extra-blocks
+done
+run onchip_poisson2d_1m_20steps python bench.py --workload poisson2d_1m --steps 20 --warmup 5 --no-cpu-baseline --no-extra-blocks
+rocprofv3 --kernel-trace --stats --output-format csv -d $S/kso -o ks -- python bench.py --workload poisson2d_1m --steps 200 --warmup 20 --no-cpu-baseline --no-extra-blocks 2>/dev/null | tail -1 > $S/${tag}_bench_traced_run_poisson2d_1m.json
+cp "$(find $S/kso -name '*kernel_stats.csv' | head -1)" $S/${tag}_bench_kernel_stats_poisson2d_1m.csv
+# round 6: the exact tile forms (rows owned by wavefronts / wavefront-private slices) beside the relaxed default on config 3a; the asymmetric pre-flight failure
+timeout 900 python tools/tile_bench.py 10000000 "DEFAULT=1" "SLA_TILE_RELAXED=0" "SLA_TILE_RELAXED=0 SLA_TILE_ROWOWN=0" > $S/${tag}_tile_exact_forms.txt 2>&1
+SLA_BENCH_LOOPBACK=1 SLA_FAULT_INJECT=p2p_data_rank1 timeout 900 python bench.py --gpus 2 --workload laplace3d_small --steps 20 --warmup 5 2>$S/${tag}_bench_loopback_fault_rank1_stderr.txt | grep '^{' | tail -1 > $S/${tag}_bench_loopback_fault_rank1.json
+SLA_BENCH_LOOPBACK=1 timeout 900 python bench.py --gpus 2 --steps 40 --warmup 5 --no-cpu-baseline 2>$S/${tag}_bench_loopback_2ranks_stderr.txt | grep '^{' | tail -1 > $S/${tag}_bench_loopback_2ranks.json
+# round 6: one real run past 2^31 stored entries (lowering, (#>) on all rows and two bicgstabSteps against the oracle)
+timeout 1500 python tools/big_nnz.py --full > $S/${tag}_big_nnz.json 2> $S/${tag}_big_nnz_log.txt
+ls -la $S | head -120
