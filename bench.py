@@ -944,8 +944,48 @@ def run_rank(args, rank, world, local_rank, dist_mode, loop=None):
     r3 = rec.get("random_spd_10m") or {}
     if r3.get("value"):          # the north star's Target sentence: the 10 M-row random matrix (config 3a)
         rec["north_star_target"] = {"workload": r3["workload"], "iters_per_s": r3["value"], "k1_ms": r3.get("k1_ms"), "k1_frac": r3.get("k1_csr_frac"),
-                                    "spmv_kernel": " ".join(t for t in r3.get("spmv_kernel", "").split() if t.startswith(("algo=", "exact_fold=", "cu_slices=")))}
+                                    "spmv_kernel": " ".join(t for t in r3.get("spmv_kernel", "").split() if t.startswith(("algo=", "exact_fold=", "cu_slices=", "row_owned=")))}
+        c = tile_form_ceiling(r3)
+        if c:
+            rec["north_star_target"]["ceiling"] = c
     return rec
+
+
+# The bare gather pattern of the CU-wide tile kernel (a workgroup walks ONE column-sorted run, 64 consecutive entries per gather instruction,
+# products into LDS by ds_add_f64, 12 B per entry streamed) measured by tools/gather_share_probe.cpp at d entries per 128-byte line of x:
+# G gathers / s, column "lds atomic: wg256" of profiles/r05_gather_share_probe.txt.
+GATHER_SHARE_PROBE = ((0.25, 159.3), (0.5, 175.8), (1.0, 283.7), (2.0, 353.8), (4.0, 443.2), (16.0, 439.7))
+L2_AGGREGATE_TBS = 34.5     # L2 -> L1 fabric of the eight XCDs together (MI355X_MICROARCH.md)
+
+
+def tile_form_ceiling(r3):
+    """what bounds config 3a's (#>) is not HBM.  With x beyond the L2 every row slice of the tile form touches (nearly)
+    every 128-byte line of x once, so slices x 8 n bytes cross the L2 -> L1 fabric whatever the kernel does; the rate at which a CU turns such
+    gathers around is what the bare pattern of the probe reaches at the matrix's density d = slice rows x entries per row x 16 / columns.
+    k1_ms_at_ceiling = entries / that rate; frac_of_ceiling = it / the measured K1 -- the headroom the 0.39-of-HBM figure does not mean."""
+    import math
+    info = dict(t.split("=", 1) for t in r3.get("spmv_kernel", "").split() if "=" in t)
+    if info.get("algo") != "tiles" or not r3.get("k1_ms") or "slices" not in info:
+        return None
+    rows, nnz, slices = r3["rows"], r3["nnz"], int(info["slices"])
+    d = (rows / slices) * (nnz / rows) * 16.0 / rows
+    pts = GATHER_SHARE_PROBE
+    if d <= pts[0][0]:
+        rate = pts[0][1]
+    elif d >= pts[-1][0]:
+        rate = pts[-1][1]
+    else:
+        (d0, r0), (d1, r1) = next((a, b) for a, b in zip(pts, pts[1:]) if a[0] <= d <= b[0])
+        rate = r0 + (r1 - r0) * (math.log(d) - math.log(d0)) / (math.log(d1) - math.log(d0))
+    ms_probe = nnz / (rate * 1e9) * 1e3
+    ms_fabric = slices * 8.0 * rows / (L2_AGGREGATE_TBS * 1e12) * 1e3
+    return {"basis": "L2 -> L1 gather fabric, one 128-byte line per touched line of x and slice -- not HBM (x is re-read from the L2s `slices` times)",
+            "entries_per_x_line_and_slice": d, "probe_gathers_per_s": rate * 1e9,
+            "probe": "tools/gather_share_probe.cpp, bare pattern with LDS atomics at this density (profiles/r05_gather_share_probe.txt)",
+            "k1_ms_at_ceiling": ms_probe, "frac_of_ceiling": ms_probe / r3["k1_ms"],
+            "fabric_bytes": slices * 8 * rows, "fabric_ms_at_34_5_TBs": ms_fabric,
+            "hbm_roof_ms": (12 * nnz + 28 * rows) / 8e12 * 1e3,
+            "note": "k1_frac prices K1 on CSR bytes against 8 TB/s of HBM, a roof this matrix cannot reach with 160 KB of LDS per CU; frac_of_ceiling is the honest headroom"}
 
 
 def free_port():

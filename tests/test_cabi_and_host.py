@@ -250,3 +250,19 @@ sys.exit(0 if status == 0 else 4)
 '''
     out = subprocess.run([sys.executable, "-c", src, _lib.LIB_PATH], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120)
     assert out.returncode == 0, out.stdout[-600:]
+
+
+def test_bench_tile_form_ceiling_is_stated_against_the_gather_fabric():
+    """the north star's matrix is not HBM-bound -- bench.py's north_star_target carries the ceiling of the gather fabric
+    (probe rate at the matrix's density; slices x 8 n bytes through the L2 -> L1 fabric) beside the HBM fraction.  Pure arithmetic: no GPU."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    r3 = {"spmv_kernel": "algo=tiles slices=512 panels=77 exact_fold=0 cu_slices=1", "k1_ms": 1.346, "rows": 10000000, "nnz": 329999456, "value": 350.0}
+    c = bench.tile_form_ceiling(r3)
+    assert abs(c["entries_per_x_line_and_slice"] - 1.031) < 1e-3                       # 19531 rows x 33 per row x 16 / 10 M columns
+    assert 1.10 < c["k1_ms_at_ceiling"] < 1.20 and 0.80 < c["frac_of_ceiling"] < 0.90   # 284-287 G gathers/s -> 1.15 ms; measured 1.346
+    assert c["fabric_bytes"] == 512 * 8 * 10000000 and 1.15 < c["fabric_ms_at_34_5_TBs"] < 1.22
+    assert c["hbm_roof_ms"] < 0.54 < c["k1_ms_at_ceiling"]                              # the HBM roof is not the binding one
+    assert bench.tile_form_ceiling({"spmv_kernel": "algo=stream+wave", "k1_ms": 1.0, "rows": 10, "nnz": 10}) is None
