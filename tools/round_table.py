@@ -54,7 +54,9 @@ if d:
     if r3.get("value"):
         print(f"| **3a (10 M random SPD, 33 per row)** — `random_spd_10m` block of the same line | {r3['ms_per_step']:.2f} ms | **{r3['value']:.1f}** | "
               f"**{r3['k1_ms']:.3f} ms = {r3['k1_csr_frac']:.3f}** on CSR bytes (`north_star_target`) | K1 / K3 | "
-              f"{' '.join(t for t in r3['spmv_kernel'].split() if t.startswith(('algo=', 'exact_fold', 'cu_slices', 'slices', 'panels')))}; lowered in {r3['lowered_once']['from_csr_s']:.3f} s |")
+              f"{' '.join(t for t in r3['spmv_kernel'].split() if t.startswith(('algo=', 'exact_fold', 'cu_slices', 'slices', 'panels')))}; lowered in {r3['lowered_once']['from_csr_s']:.3f} s"
+              + (f"; gather-fabric ceiling {d['north_star_target']['ceiling']['k1_ms_at_ceiling']:.2f} ms: K1 at {d['north_star_target']['ceiling']['frac_of_ceiling']:.2f} of it"
+                 if (d.get('north_star_target') or {}).get('ceiling') else "") + " |")
     if cb:
         print(f"| 4, CPU oracle port (same run, host cores of the GPU box) | | {cb.get('value', 0):.2f} ({cb.get('cores')} thread) / "
               f"{(cb.get('omp') or {}).get('value', 0):.1f} ({(cb.get('omp') or {}).get('cores')} threads OpenMP) | | | {cb.get('sample', '')[:120]} |")
@@ -64,7 +66,22 @@ if d:
               f"{e.get('cold_over_solve', 0):.2f} × its solve time; `from_coo` {e.get('from_coo_s', 0):.3f} s; {ls.get('iters_per_s_incl_true_residual', 0):.0f} it/s incl. the true residual |")
 print(row("4, cgsStep", load("cgs")))
 print(row("4, linSolve0 iteration (true residual every iteration)", load("linsolve0")))
-print(row("2 (1 M 5-pt Poisson) bicgstabStep (step graph replay)", load("poisson2d_1m")))
+def onchip_row(label, name):
+    """round 6: sla_solver_step(k) as ONE persistent launch (the default at these sizes) beside the launch flow (SLA_ONCHIP=0) of the same box"""
+    on, lf = load(f"onchip_{name}"), load(f"launchflow_{name}")
+    if not on or not on.get("value"):
+        return f"| {label} | — | — | — | — | (no line) |"
+    k = (on.get("kernels") or {}).get("ONCHIP") or {}
+    return (f"| {label} | {on['ms_per_step'] * 1e3:.1f} µs | **{on['value']:.0f}** | one launch for all the steps (no K1 of its own) | "
+            f"ONCHIP: {on['ms_per_step'] * 1e3:.1f} µs per step, two grid-wide counter barriers each | launch flow on the same box: "
+            f"{(lf or {}).get('ms_per_step', 0) * 1e3:.1f} µs = {(lf or {}).get('value', 0):.0f} it/s; {str(k.get('plan', ''))[:150]} |")
+
+
+d2 = load("poisson2d_1m")
+print(row("2 (1 M 5-pt Poisson) bicgstabStep" + (" — ONE persistent on-chip launch (round 6)" if d2 and d2.get("onchip") else " (step graph replay)"), d2))
+print(onchip_row("2 (1 M 5-pt Poisson), 200-step window, on-chip against the launch flow", "poisson2d_1m"))
+print(onchip_row("4's per-rank slab at N = 8 (216 × 216 × 27), on-chip against the launch flow", "laplace3d_slab8"))
+print(onchip_row("108³ (1.26 M rows), on-chip against the launch flow", "laplace3d_1m"))
 print(row("5-matrix (2 M banded) bicgstabStep", load("banded_2m")))
 print(row("5 (2 M banded) GMRES(30) Arnoldi step", load("gmres_banded_2m")))
 print(row("3a BiCGSTAB as the headline workload", load("random_spd_10m_bicgstab")))
@@ -84,7 +101,12 @@ if d and d.get("value"):
     c, r3 = d.get("contract_allgather") or {}, d.get("random_spd_10m") or {}
     print(f"| … on 2 loopback ranks (threads on one GPU: a rehearsal, not a scaling number) | {d['ms_per_step'] * 1e3:.1f} µs | {d['value']:.0f} | | | "
           f"`contract_allgather` {c.get('value', 0):.0f} it/s; `random_spd_10m` {r3.get('value', 0):.1f} it/s, x exchange {(r3.get('x_exchange') or {}).get('mode')} |")
-for f in ("p2p", "hang"):
+    xr = d.get("exchange_roofline") or {}
+    if xr.get("exchanges"):
+        ex = "; ".join(f"{k}: {v['bytes_to_busiest_peer']} B to the busiest peer in {v['ms'] * 1e3:.1f} µs (model {v['model_ms'] * 1e3:.1f} µs, {v['bound']}-bound)" for k, v in xr["exchanges"].items())
+        print(f"| … its `exchange_roofline` (plan bytes per peer against {xr['link_peak_gbps']:.0f} GB/s per xGMI link; {'real links' if xr['real_links'] else 'rehearsal: no link crossed'}) | | | | | "
+              f"{ex}; step measured {xr['step']['measured_ms'] * 1e3:.1f} µs against the model's {xr['step']['model_ms'] * 1e3:.1f} µs |")
+for f, inj in (("p2p", "p2p"), ("hang", "p2p_hang"), ("rank1", "p2p_data_rank1")):
     d = load(f"loopback_fault_{f}")
     if d:
-        print(f"| … with `SLA_FAULT_INJECT={'p2p' if f == 'p2p' else 'p2p_hang'}` | | {d.get('value') or 0:.0f} | | | fallback: {str(d.get('fallback'))[:160]} |")
+        print(f"| … with `SLA_FAULT_INJECT={inj}` | | {d.get('value') or 0:.0f} | | | fallback: {str(d.get('fallback'))[:160]} |")
