@@ -491,6 +491,7 @@ const IntKnob kIntKnobs[] = {
     {"xwin", &sla_ctx::xwin, 0, 2},
     {"stream_wave", &sla_ctx::stream_wave, 0, 1999},
     {"wave_run", &sla_ctx::wave_run, 1, 4096},
+    {"wave_flat", &sla_ctx::wave_flat, 0, 1},
     {"stream_wide", &sla_ctx::stream_wide, 0, 1},
     {"diag", &sla_ctx::diag, 0, 2},
     {"diag_lazy", &sla_ctx::diag_lazy, 0, 1},

@@ -314,6 +314,8 @@ struct sla_ctx {
     int stream_wave = 1;             // plain CSR (#>): wavefront-private 128-row blocks with row-pair stores (sla_spmv_wave.hip) instead of spmv_stream_kernel when no row
                                      // exceeds kWvMaxRow entries (SLA_STREAM_WAVE: 0 off, 1 on = 4 entry pairs per lane and chunk, 4 / 7 force that chunk size)
                                      // (SLA_STREAM_PIPE=1; OFF by default: measured 7-12 % SLOWER than the one-deep prefetch)
+    int wave_flat = 0;               // ... 1: the prefetching instantiation as a flat chunk walk over two register sets (no `cur = nxt` drain per chunk, counted waits, unconditional
+                                     // store; round 6): bit-identical, measured 3-6 % SLOWER (profiles/r06_ab_wave_flat.txt) -- like round 3's deeper ring: the waits were not the bound
     int wave_run = 1;                // ... consecutive 128-row blocks a wavefront of spmv_wave_kernel walks before it jumps (round 6; 1 = the round-4 walk)
     int dual_spmv = 1;               // linSolve0: fuse the true-residual SpMV into the next K1 (SLA_DUAL_SPMV=0 disables)
     int x_exchange = 0;              // 0 auto (window exchange when it pays), 1 always all-gather, 2 always window (SLA_X_EXCHANGE=allgather|window)

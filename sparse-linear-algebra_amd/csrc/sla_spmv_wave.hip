@@ -273,6 +273,194 @@ spmv_wave_kernel(SpmvArgs<int32_t> a, const int32_t *__restrict__ rowptr, const 
     spmv_extra_partials<EPI>(a, s_red, tid);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The same kernel with the one-deep ring UNROLLED BY TWO over two register sets (round 6, option wave_flat).  spmv_wave_kernel's prefetching
+// instantiation ends every chunk with `cur = nxt`: a register copy that needs EVERY load of the next chunk, i.e. a drain of the wavefront's
+// whole memory pipeline (the held-back y store included) once per chunk.  Here the walk is flattened into ONE sequence of chunks -- block
+// begin (row starts, row ends, the next block's scalar range) and block end (row-pair transpose, epilogue, pending store) are wave-uniform
+// branches inside the chunk step -- and the step is instantiated twice, (A, B) and (B, A): the next chunk's streams land in the set the
+// following step reads, nothing is copied, and the only waits left are the ones data flow needs (the gathers before the products, the next
+// chunk's columns before its gathers).  Same loads, same products, same fold order, same epilogue: bit-identical to spmv_wave_kernel.
+// MEASURED (profiles/r06_ab_wave_flat.txt, same box, three interleaved passes): K1 213-216 us against 201-208 us for the nested loops -- slower, as round 3's
+// three-stage ring was: with the drains gone a wavefront keeps more in flight, and that only lengthens the queues of a memory path that is already
+// saturated by this access mix.  Kept as an A/B knob (wave_flat = 1), off by default.
+template <int EPI, int PPL, int OCC>
+__global__ void __launch_bounds__(kBlock, OCC)
+spmv_wave_flat_kernel(SpmvArgs<int32_t> a, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col, const double *__restrict__ val,
+                      const double *__restrict__ xg, int nblk, int xcd_remap, int nt, int rl, double *__restrict__ dump) {
+    constexpr int CH = 128 * PPL;
+    __shared__ double s_prod[kBlock / 64][CH];
+    __shared__ double s_red[4];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    double coef;
+    if (!spmv_prologue<EPI, int32_t>(a, s_red, coef)) return;
+    double acc1 = 0.0, acc2 = 0.0;
+    double *prod = s_prod[wave];
+    const int G = (int)gridDim.x;
+    const int nrun = (nblk + rl - 1) / rl;
+    int first, step, last;
+    if (xcd_remap && (G & 7) == 0 && nrun >= 4 * G) {
+        const int xcd = (int)blockIdx.x & 7, per = (nrun + 7) >> 3;
+        first = xcd * per + ((int)blockIdx.x >> 3) * (kBlock / 64) + wave;
+        step = (G >> 3) * (kBlock / 64);
+        last = min((xcd + 1) * per, nrun);
+    } else {
+        first = (int)blockIdx.x * (kBlock / 64) + wave;
+        step = G * (kBlock / 64);
+        last = nrun;
+    }
+    constexpr bool kUsesW = EPI == EPI_DOT || EPI == EPI_DOT2 || EPI == EPI_DOT4 || EPI == EPI_RES || EPI == EPI_SUB || EPI == EPI_AXPY_DOT;
+    constexpr bool kUsesZ = EPI == EPI_DOT4 || EPI == EPI_AXPY_DOT || EPI == EPI_XPBY_NRM;
+    const bool w_nt = nt && a.w != xg, z_nt = nt && (const double *)a.z != xg;
+    const bool st_nt = st_nt_of(nt);
+    auto load_ops = [&](int b, int &sa_o, int &sb_o, wv_f64x2 &wv_o, wv_f64x2 &zv_o) {
+        const int r = b * 128, pr = min(r + 2 * lane, a.rows - 1);
+        sa_o = rowptr[r + lane];
+        sb_o = rowptr[r + 64 + lane];
+        if constexpr (kUsesW) {
+            if (EPI != EPI_AXPY_DOT || a.w) wv_o = w_nt ? __builtin_nontemporal_load((const wd_f64x2u *)(a.w + pr)) : *(const wd_f64x2u *)(a.w + pr);
+        }
+        if constexpr (kUsesZ) zv_o = z_nt ? __builtin_nontemporal_load((const wd_f64x2u *)(a.z + pr)) : *(const wd_f64x2u *)(a.z + pr);
+    };
+    // The pending store is ONE unconditional 16-byte store per step on every path: lanes with nothing to store (no block yet, rows past the end,
+    // the single last row of an odd row count) write their pair to a 1 KiB dump of the context's scratch instead.  A store inside a divergent
+    // branch makes the number of outstanding operations path-dependent, and the compiler then waits with vmcnt(0) -- for the store as well --
+    // wherever it needs one of the loads in front of it; with the same operations on every path it counts.  (The odd last row, if any, is an
+    // 8-byte store of its own behind a wave-uniform test.)
+    wv_f64x2 pend_out = {0.0, 0.0};
+    int pend_row = -1, pend_where = 0;
+    bool pend_vb = false;
+    constexpr bool kStores = EPI != EPI_RES;
+    auto flush = [&]() {
+        if constexpr (kStores) {
+            const bool live = pend_row >= 0 && pend_where != 0;
+            double *base = pend_where == 2 ? a.z : a.y;
+            double *dst = (live && pend_vb) ? base + pend_row : dump + 2 * lane;
+            if (st_nt) __builtin_nontemporal_store(pend_out, (wv_f64x2 *)dst);
+            else *(wv_f64x2 *)dst = pend_out;
+            if (__builtin_amdgcn_ballot_w64(live && !pend_vb) != 0) {
+                if (live && !pend_vb) base[pend_row] = pend_out.x;
+            }
+        }
+        pend_row = -1;
+    };
+    bool have = first < last;
+    if (have) {
+        // the walk's state: the block under way (run, blk, bend), its entry range [k0, k1) and the chunk [kb, kb + CH) the current set holds;
+        // the block after it (bn: -1 = none) with its scalar range and, from its first chunk's step on, its row starts and operands
+        int run = first, blk = first * rl, bend = min(first * rl + rl, nblk);
+        // (scalars: the walk's control state must live in SGPRs -- a VGPR copy of k0 made the compiler wait for EVERY outstanding load at the loop
+        // header before it could compare it)
+        int k0 = __builtin_amdgcn_readfirstlane(rowptr[blk * 128]), k1 = __builtin_amdgcn_readfirstlane(rowptr[blk * 128 + 128]), kb = k0 & ~1;
+        int bn = -1, bn_run = 0, nk0 = 0, nk1 = 0;
+        int sa = 0, sb = 0, ea = 0, eb = 0, sa_n = 0, sb_n = 0, prow = 0;
+        wv_f64x2 wv = {0.0, 0.0}, zv = {0.0, 0.0}, wv_n = {0.0, 0.0}, zv_n = {0.0, 0.0};
+        double ya = 0.0, yb = 0.0;
+        WvChunk<PPL> A, B;
+        wv_load<PPL>(A, col, val, kb, k1, lane);
+        load_ops(blk, sa_n, sb_n, wv_n, zv_n);
+        flush();   // (nothing pending: a store into the dump -- the loop is entered with the operation sequence a step leaves behind, so the
+                   // compiler's wait counts at the loop header are the same from both sides)
+        auto chunk_step = [&](WvChunk<PPL> &cur, WvChunk<PPL> &nxt) {
+            if (kb == (k0 & ~1)) {                              // ---- block begin (wave-uniform) ----
+                sa = sa_n; sb = sb_n; wv = wv_n; zv = zv_n;
+                prow = blk * 128 + 2 * lane;
+                const int sb0 = __builtin_amdgcn_readfirstlane(sb);
+                ea = __shfl_down(sa, 1, 64);
+                eb = __shfl_down(sb, 1, 64);
+                if (lane == 63) { ea = sb0; eb = k1; }
+                ya = yb = 0.0;
+                if (blk + 1 < bend) { bn = blk + 1; bn_run = run; }
+                else if (run + step < last) { bn = (run + step) * rl; bn_run = run + step; }
+                else { bn = -1; bn_run = run; }
+                const int bq = bn >= 0 ? bn : blk;              // (no next block: any valid one -- its loads are issued and dropped)
+                nk0 = __builtin_amdgcn_readfirstlane(rowptr[bq * 128]);
+                nk1 = __builtin_amdgcn_readfirstlane(rowptr[bq * 128 + 128]);
+            }
+            const int kend = min(kb + CH, k1);
+            double xa[PPL], xb[PPL];
+#pragma unroll
+            for (int j = 0; j < PPL; ++j) {
+                xa[j] = xg[cur.cc[j].x];
+                xb[j] = xg[cur.cc[j].y];
+            }
+            const bool more = kb + CH < k1;
+            wv_load<PPL>(nxt, col, val, more ? kb + CH : (nk0 & ~1), more ? k1 : nk1, lane);
+            // (the row starts and operands of the block the NEXT chunk belongs to: the next block's behind the last chunk, this block's own again
+            // otherwise -- three small loads that keep the operation count of a step the same on every path, see flush())
+            load_ops(more ? blk : (bn >= 0 ? bn : blk), sa_n, sb_n, wv_n, zv_n);
+            flush();                                            // the previous block's y store: behind this chunk's gathers and the next one's streams
+#pragma unroll
+            for (int j = 0; j < PPL; ++j) {
+                wv_f64x2 p;
+                p.x = cur.vv[j].x * xa[j];
+                p.y = cur.vv[j].y * xb[j];
+                *(wv_f64x2 *)(prod + 2 * lane + 128 * j) = p;
+            }
+            {   // the lane-per-row fold of spmv_wave_kernel, unchanged
+                int ka = max(sa, kb) - kb, kb2 = max(sb, kb) - kb;
+                const int ha = min(ea, kend) - kb, hb = min(eb, kend) - kb;
+                while (ka < ha || kb2 < hb) {
+                    double pa[8], pb[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) pa[i] = prod[min(ka + i, CH - 1)];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) pb[i] = prod[min(kb2 + i, CH - 1)];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)
+                        if (ka + i < ha) ya += pa[i];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)
+                        if (kb2 + i < hb) yb += pb[i];
+                    ka += 8;
+                    kb2 += 8;
+                }
+            }
+            if (more) {
+                kb += CH;
+                return;
+            }
+            // ---- block end (wave-uniform): row pairs through the stage, epilogue arithmetic, the store left pending ----
+            prod[lane] = ya;
+            prod[64 + lane] = yb;
+            const wv_f64x2 yp = *(const wv_f64x2 *)(prod + 2 * lane);
+            if (prow < a.rows) {
+                pend_vb = prow + 1 < a.rows;
+                pend_where = wd_epilogue_calc<EPI>(a, pend_vb, yp.x, yp.y, wv, zv, coef, acc1, acc2, pend_out);
+                pend_row = prow;
+            }
+            if (bn < 0) {
+                have = false;
+                return;
+            }
+            if (bn_run != run) { run = bn_run; bend = min(run * rl + rl, nblk); }
+            blk = bn;
+            k0 = nk0;
+            k1 = nk1;
+            kb = k0 & ~1;
+        };
+        // (the first step is peeled: the loop header is then reached from the end of a step on both sides -- entry and back edge -- and the
+        // compiler's wait counts there are those of the steady state; entered from the set-up code it fell back to vmcnt(0))
+        chunk_step(A, B);
+        while (have) {
+            chunk_step(B, A);
+            if (!have) break;
+            chunk_step(A, B);
+        }
+        flush();
+    }
+    if constexpr (EPI == EPI_DOT || EPI == EPI_DOT2 || EPI == EPI_DOT4 || EPI == EPI_RES || EPI == EPI_AXPY_DOT || EPI == EPI_XPBY_NRM) {
+        const double s1 = block_sum(acc1, s_red);
+        if (tid == 0) a.p1[blockIdx.x] = s1;
+    }
+    if constexpr (EPI == EPI_DOT2 || EPI == EPI_DOT4) {
+        const double s2 = block_sum(acc2, s_red);
+        if (tid == 0) a.p2[blockIdx.x] = s2;
+    }
+    spmv_extra_partials<EPI>(a, s_red, tid);
+}
+
 bool wave_on(const sla_csr *A) {
     const sla_ctx *c = A->ctx;
     return c->stream_wave > 0 && !A->rp64 && A->rows > 0 && A->max_row_nnz <= kWvMaxRow && c->spmv_algo == 0;
@@ -318,7 +506,10 @@ static int launch_wave_t(const sla_csr *A, const SpmvArgs<int32_t> &a, int grid)
     if (v.ppl == P && v.occ == O && v.pre == R)                                                                                            \
         SLA_KLAUNCH(c, (spmv_wave_kernel<EPI, P, O, R != 0>), dim3(grid), dim3(kBlock), 0, stream_of(c), a, a.rowptr, a.col, a.val, a.x, nblk, \
                            c->xcd_remap, nt, std::max(1, c->wave_run))
-    SLA_WV(2, 8, 0);
+    if (v.ppl == 8 && v.occ == 3 && v.pre == 1 && c->wave_flat)
+        SLA_KLAUNCH(c, (spmv_wave_flat_kernel<EPI, 8, 3>), dim3(grid), dim3(kBlock), 0, stream_of(c), a, a.rowptr, a.col, a.val, a.x, nblk, c->xcd_remap, nt,
+                    std::max(1, c->wave_run), c->d_result + 2048);   // (128 doubles of the context's scratch: the dump of the unconditional store)
+    else SLA_WV(2, 8, 0);
     else SLA_WV(4, 6, 0);
     else SLA_WV(8, 4, 0);
     else SLA_WV(8, 3, 1);
