@@ -402,6 +402,8 @@ struct OcPlan {
     double *d_parts = nullptr;       // [4][G] partial sums
     unsigned *d_bar = nullptr;       // barrier words (zeroed in front of every launch)
     size_t lds_bytes = 0;
+    int cgs_state = 0;               // the cgsStep kernel on this plan: 0 not asked yet, 1 resident, -1 declined (cgs_note says why)
+    std::string cgs_note;
 };
 void onchip_plan_free(OcPlan *p);
 }  // namespace sla

@@ -44,6 +44,7 @@ struct OcArgs {
     int loff[kOcMaxPairs];
     double val[kOcMaxPairs];
     double *x, *r, *p;
+    double *u;                 // CGS only
     const double *rhat;
     double *pubA, *pubS, *parts;
     unsigned *bar;
@@ -292,6 +293,184 @@ __global__ void __launch_bounds__(T) oc_bicgstab_kernel(OcArgs a) {
     }
 }
 
+// cgsStep (Numeric/LinearAlgebra/Sparse.hs:928-939) on chip, the same plan and the same two synchronisations per step:
+//   C1  aap = aa #> p ; aap <.> rhat                                   | sync 1: the sum + the boundary rows of aap
+//   C2  alpha ; q = u ^-^ alpha .* aap ; u ^+^ q ; x1 (own + halo cells: u is kept valid on the halo in registers, p and u + q in LDS)
+//   C3  aa #> (u ^+^ q) ; r1 = r ^-^ alpha .* (...) ; r1 <.> rhat       | sync 2: the sum + the boundary rows of aa #> (u + q)
+//   C4  beta ; u1 = r1 ^+^ beta .* q ; p1 = u1 ^+^ beta .* (q ^+^ beta .* p)   (own + halo cells: r is kept valid on the halo too)
+// Expressions are cgs_c24_kernel's and the SpMV epilogue's (EPI_AXPY_DOT) term by term; the grouping of the two inner products differs from
+// the launch flow's, so the iterates agree with it to rounding.
+template <int RPT, int HPT, int NP>
+__global__ void __launch_bounds__(T) oc_cgs_kernel(OcArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double oc_lds[];
+    __shared__ int s_ok;
+    const int LA = (a.L + 2) & ~1;
+    double *P = oc_lds, *S = oc_lds + LA, *red = S + LA;
+    const int b = blockIdx.x, t = threadIdx.x, G = gridDim.x, wave = t >> 6;
+    SolverScalars *sc = a.sc;
+    if (sc->done) return;
+    uint32_t cm[RPT];
+    double x[RPT], rh[RPT], r[RPT], p[RPT], u[RPT], q[RPT];   // (q: aap until alpha is known, then q)
+    const int np = NP ? NP : a.np;
+    int fullbits = 0;
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+        const size_t j = ((size_t)b * RPT + i) * T + t;
+        cm[i] = a.own_cm[j];
+        if (NP && __builtin_amdgcn_ballot_w64(((cm[i] >> 16) & 0xff) != (1u << np) - 1) == 0) fullbits |= 1 << i;
+    }
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+        const bool v = (cm[i] >> 25) & 1;
+        const int32_t g = a.own_row[((size_t)b * RPT + i) * T + t];
+        const double x0 = a.x[g], r0 = a.r[g], p0 = a.p[g], u0 = a.u[g], h0 = a.rhat[g];
+        x[i] = v ? x0 : 0.0;
+        r[i] = v ? r0 : 0.0;
+        p[i] = v ? p0 : 0.0;
+        u[i] = v ? u0 : 0.0;
+        rh[i] = v ? h0 : 0.0;
+        q[i] = 0.0;
+    }
+    auto wcell = [&](uint32_t c) -> int { return ((c >> 25) & 1) ? (int)(c & 0xffff) : a.L; };
+    uint32_t hc[HPT];
+    int32_t hg[HPT];
+    double hu[HPT], hr[HPT], hq[HPT];   // u, r and q of this thread's halo cells (p and u + q of the halo live in LDS with the own cells)
+#pragma unroll
+    for (int i = 0; i < HPT; ++i) {
+        const size_t j = ((size_t)b * HPT + i) * T + t;
+        hc[i] = a.halo_cell[j];
+        hg[i] = a.halo_src[j];
+        const int32_t g = a.halo_row[j];
+        P[hc[i]] = a.p[g];
+        hu[i] = a.u[g];
+        hr[i] = a.r[g];
+        hq[i] = 0.0;
+    }
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) P[wcell(cm[i])] = p[i];
+    __syncthreads();
+    double rho = sc->rho2[a.par], alpha = 0.0, beta = 0.0;
+    unsigned epoch = 0;
+    auto fold = [&](const double *V, uint32_t c, bool full) -> double {
+#pragma clang fp contract(off)
+        const int cell = c & 0xffff;
+        double y = 0.0;
+        if (NP && full) {
+#pragma unroll
+            for (int k = 0; k < (NP ? NP : 1); ++k) {
+                const double pk = a.val[k] * V[cell + a.loff[k]];
+                y = y + pk;
+            }
+        } else {
+            const uint32_t m = c >> 16;
+#pragma unroll
+            for (int k = 0; k < kOcMaxPairs; ++k) {
+                if (k < np) {
+                    const double pk = a.val[k] * V[cell + a.loff[k]];
+                    y = ((m >> k) & 1) ? y + pk : y;
+                }
+            }
+        }
+        return y;
+    };
+    for (int step = 0; step < a.k; ++step) {
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) asm volatile("" : "+v"(cm[i]));
+        int sl = b * RPT * T + t;
+        asm volatile("" : "+v"(sl));
+#pragma unroll
+        for (int i = 0; i < HPT; ++i) asm volatile("" : "+v"(hc[i]), "+v"(hg[i]));
+        // ---- C1: aap = aa #> p ; aap <.> rhat ----
+        {
+            double acc = 0.0;
+#pragma unroll
+            for (int i = 0; i < RPT; ++i) {
+                q[i] = fold(P, cm[i], (fullbits >> i) & 1);
+                acc += q[i] * rh[i];
+                if ((cm[i] >> 24) & 1) st_agent(a.pubA + (sl + i * T), q[i]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            acc = wave_sum(acc);
+            if ((t & 63) == 0) red[wave] = acc;
+        }
+        if (!oc_grid_sync<1>(a.bar, ++epoch, sc, red, a.parts, &s_ok)) return;
+        // ---- C2 on own + halo cells: alphaj ; q = u ^-^ alphaj .* aap ; uq = u ^+^ q ; xj1 = x ^+^ alphaj .* uq ----
+        {
+            double hap[HPT];
+#pragma unroll
+            for (int i = 0; i < HPT; ++i) hap[i] = ld_agent(a.pubA + hg[i]);
+            alpha = rho / oc_wave_total(a.parts, G);
+#pragma unroll
+            for (int i = 0; i < HPT; ++i) {
+                hq[i] = __builtin_fma(-alpha, hap[i], hu[i]);
+                S[hc[i]] = hu[i] + hq[i];
+            }
+#pragma unroll
+            for (int i = 0; i < RPT; ++i) {
+                q[i] = __builtin_fma(-alpha, q[i], u[i]);
+                const double sv = u[i] + q[i];
+                x[i] = __builtin_fma(alpha, sv, x[i]);
+                S[wcell(cm[i])] = sv;
+            }
+        }
+        __syncthreads();
+        // ---- C3: aa #> (u ^+^ q) ; rj1 = r ^-^ alphaj .* (...) ; rj1 <.> rhat ----
+        {
+            double acc = 0.0;
+#pragma unroll
+            for (int i = 0; i < RPT; ++i) {
+                const double auq = fold(S, cm[i], (fullbits >> i) & 1);
+                if ((cm[i] >> 24) & 1) st_agent(a.pubS + (sl + i * T), auq);
+                r[i] = __builtin_fma(-alpha, auq, r[i]);
+                acc += r[i] * rh[i];
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            acc = wave_sum(acc);
+            if ((t & 63) == 0) red[wave] = acc;
+        }
+        if (!oc_grid_sync<1>(a.bar, ++epoch, sc, red, a.parts, &s_ok)) return;
+        // ---- C4 on own + halo cells: betaj ; uj1 = rj1 ^+^ betaj .* q ; pj1 = uj1 ^+^ betaj .* (q ^+^ betaj .* p) ----
+        {
+            double hauq[HPT];
+#pragma unroll
+            for (int i = 0; i < HPT; ++i) hauq[i] = ld_agent(a.pubS + hg[i]);
+            const double rn = oc_wave_total(a.parts, G);
+            beta = rn / rho;
+            rho = rn;
+#pragma unroll
+            for (int i = 0; i < HPT; ++i) {
+                hr[i] = __builtin_fma(-alpha, hauq[i], hr[i]);
+                const double un = __builtin_fma(beta, hq[i], hr[i]);
+                P[hc[i]] = __builtin_fma(beta, __builtin_fma(beta, P[hc[i]], hq[i]), un);
+                hu[i] = un;
+            }
+#pragma unroll
+            for (int i = 0; i < RPT; ++i) {
+                const double un = __builtin_fma(beta, q[i], r[i]);
+                p[i] = __builtin_fma(beta, __builtin_fma(beta, p[i], q[i]), un);
+                u[i] = un;
+                P[wcell(cm[i])] = p[i];
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < RPT; ++i)
+        if ((cm[i] >> 25) & 1) {
+            const int32_t g = a.own_row[((size_t)b * RPT + i) * T + t];
+            a.x[g] = x[i];
+            a.r[g] = r[i];
+            a.p[g] = p[i];
+            a.u[g] = u[i];
+        }
+    if (b == 0 && t == 0) {
+        sc->rho2[(a.par + a.k) & 1] = rho;
+        sc->alpha = alpha;
+        sc->beta = beta;
+        sc->iters += a.k;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------------------------
 // the plan: rows -> workgroups -> local cells
 // ------------------------------------------------------------------------------------------------------------------------------
@@ -315,6 +494,22 @@ static const void *oc_kernel_np(int np) {
     if (np == 5) return (const void *)oc_bicgstab_kernel<RPT, HPT, 5>;
     if (np == 7) return (const void *)oc_bicgstab_kernel<RPT, HPT, 7>;
     return (const void *)oc_bicgstab_kernel<RPT, HPT, 0>;
+}
+template <int RPT, int HPT>
+static const void *oc_cgs_kernel_np(int np) {
+    if (np == 5) return (const void *)oc_cgs_kernel<RPT, HPT, 5>;
+    if (np == 7) return (const void *)oc_cgs_kernel<RPT, HPT, 7>;
+    return (const void *)oc_cgs_kernel<RPT, HPT, 0>;
+}
+// (CGS keeps u, r and q of the halo cells in registers where BiCGSTAB keeps one array: the 12 x 4 class does not fit 256 registers and is declined)
+static const void *oc_kernel_cgs(int rpt, int hpt, int np) {
+    switch (rpt * 16 + hpt) {
+        case 4 * 16 + 4: return oc_cgs_kernel_np<4, 4>(np);
+        case 4 * 16 + 8: return oc_cgs_kernel_np<4, 8>(np);
+        case 8 * 16 + 4: return oc_cgs_kernel_np<8, 4>(np);
+        case 8 * 16 + 8: return oc_cgs_kernel_np<8, 8>(np);
+    }
+    return nullptr;   // (12 x 4: ~60 registers spilled -- declined, the launch flow runs; cgsStep on chip holds 8 x 512 rows per CU = 1.05 M rows)
 }
 static const void *oc_kernel(int rpt, int hpt, int np) {
     switch (rpt * 16 + hpt) {
@@ -586,7 +781,8 @@ void onchip_plan_free(OcPlan *p) {
 // residual evaluation pending, the kernel profiler not asking for per-kernel events of the launch flow, and a plan for the matrix.
 bool onchip_usable(sla_solver *S) {
     sla_ctx *c = S->ctx;
-    if (c->onchip == 0 || S->method != SLA_BICGSTAB_ || c->collectives || S->ghost || S->have_res || !c->bicg_fuse45) return false;
+    if (c->onchip == 0 || (S->method != SLA_BICGSTAB_ && S->method != SLA_CGS_) || c->collectives || S->ghost || S->have_res) return false;
+    if (S->method == SLA_BICGSTAB_ && !c->bicg_fuse45) return false;
     sla_csr *A = S->A;
     if (!A->oc) {
         A->oc = new OcPlan();
@@ -599,6 +795,22 @@ bool onchip_usable(sla_solver *S) {
         if (getenv("SLA_DEBUG_ONCHIP")) fprintf(stderr, "[sla] %s\n", A->oc->note.c_str());
     }
     c->onchip_note = A->oc->note;
+    if (A->oc->ok && S->method == SLA_CGS_) {   // the cgsStep kernel is its own function: its LDS grant and co-residency are asked once per plan
+        OcPlan &pl = *A->oc;
+        if (pl.cgs_state == 0) {
+            const void *kern = oc_kernel_cgs(pl.rpt, pl.hpt, pl.np);
+            int per_cu = 0;
+            pl.cgs_state = -1;
+            if (!kern) pl.cgs_note = "no cgsStep instantiation for " + std::to_string(pl.rpt) + " x " + std::to_string(pl.hpt) + " slots per thread";
+            else if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kOcLdsMax) != hipSuccess) { (void)hipGetLastError(); pl.cgs_note = "the device does not grant the cgsStep kernel its LDS"; }
+            else if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, T, pl.lds_bytes) != hipSuccess || per_cu < 1 || pl.G > c->n_cu * per_cu) { (void)hipGetLastError(); pl.cgs_note = "the occupancy query does not grant the cgsStep kernel one workgroup per CU"; }
+            else pl.cgs_state = 1;
+        }
+        if (pl.cgs_state < 0) {
+            c->onchip_note += "; " + pl.cgs_note;
+            return false;
+        }
+    }
     return A->oc->ok;
 }
 
@@ -617,6 +829,7 @@ int launch_onchip_steps(sla_solver *S, int par, int k) {
     a.x = S->x->d;
     a.r = S->r->d;
     a.p = S->p->d;
+    a.u = S->method == SLA_CGS_ ? S->u->d : nullptr;
     a.rhat = S->r0hat->d;
     a.pubA = pl.d_pubA;
     a.pubS = pl.d_pubS;
@@ -625,7 +838,8 @@ int launch_onchip_steps(sla_solver *S, int par, int k) {
     a.sc = S->d_sc;
     a.par = par;
     a.k = k;
-    const void *kern = oc_kernel(pl.rpt, pl.hpt, pl.np);
+    const void *kern = S->method == SLA_CGS_ ? oc_kernel_cgs(pl.rpt, pl.hpt, pl.np) : oc_kernel(pl.rpt, pl.hpt, pl.np);
+    if (!kern) return fail(SLA_ERR_INVALID, "launch_onchip_steps: no instantiation for this plan");
     SLA_HIP_TRY(hipMemsetAsync(pl.d_bar, 0, sizeof(unsigned) * 32 * 17, stream_of(c)));
     ProfScope prof(c, SLA_KERNEL_ONCHIP, true);
     void *params[] = {&a};

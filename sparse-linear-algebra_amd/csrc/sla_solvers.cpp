@@ -837,7 +837,7 @@ int sla_solver_step(sla_solver_t S, int k_steps) {
             ctl_of(S).step_index += k_steps;
             return SLA_OK;
         }
-        if (c->onchip == 2 && S->method == SLA_BICGSTAB_)
+        if (c->onchip == 2 && (S->method == SLA_BICGSTAB_ || S->method == SLA_CGS_))
             return fail(SLA_ERR_INVALID, "sla_solver_step: onchip = 2 but this state record cannot run on chip (" + c->onchip_note + ")");
     }
     // Launch-bound sizes ("Launches and HIP graphs"): below ~2 M rows the five dependent launches of a step

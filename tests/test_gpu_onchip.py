@@ -152,7 +152,7 @@ def test_onchip_state_records_behave_like_the_launch_flows(sla):
 
 
 def test_onchip_declines_what_it_cannot_hold(sla):
-    """Variable coefficients, more than 8 pairs, CGS, a pending residual evaluation: the launch flow runs, nothing errors under onchip = 1,
+    """Variable coefficients, more than 8 pairs, CGNE, a pending residual evaluation: the launch flow runs, nothing errors under onchip = 1,
     and the plan note says why; onchip = 2 turns the refusal into an error."""
     from sla_amd import workloads as wl
     ctx = sla.Context(0).set_options(onchip=1)      # (the product's default; the suite's environment says 0, see conftest.py)
@@ -169,14 +169,14 @@ def test_onchip_declines_what_it_cannot_hold(sla):
     with pytest.raises(Exception, match="cannot run on chip"):
         sd.step(1)
     ctx.set_options(onchip=1)
-    # CGS on an eligible matrix: the launch flow (no on-chip cgsStep)
+    # CGNE on an eligible matrix: the launch flow (no on-chip cgneStep)
     dims2, csr2 = wl.poisson2d(40, 40)
     Ao2, b2, x02 = _problem(dims2, csr2)
     A2 = sla.fromCSR(dims2, *csr2, ctx)
-    sc = sla.cgsInit(A2, sla.fromVector(b2, ctx), sla.fromVector(x02, ctx)).step(2)
-    soc = orc.CgsState(Ao2, b2, x02)
-    soc.step(b2 - orc.spmv(Ao2, x02), 2)
-    assert _rel(sc._x.toDenseListSV(), soc.x) <= 1e-9
+    sc = sla.cgneInit(A2, sla.fromVector(b2, ctx), sla.fromVector(x02, ctx)).step(2)
+    soc = orc.CgneState(Ao2, b2, x02)
+    soc.step(2)
+    assert _rel(sc._xCgne.toDenseListSV(), soc.x) <= 1e-9
     assert int(ctx.get_option("onchip_launches")) == 0
     # linSolve0 (true residual every iteration) stays on the launch flow and still converges to the reference's answer
     x, info = sla.linSolve0(sla.BICGSTAB_, A2, sla.fromVector(b2, ctx), sla.fromVector(np.zeros(dims2[0]), ctx), return_info=True)
@@ -220,5 +220,92 @@ def test_slab_216x216x27_onchip_vs_oracle(sla):
     so.step(b - orc.spmv(Ao, x0), 2)
     assert _rel(sd._xBicgstab.toDenseListSV(), so.x) <= 1e-9
     assert "bricks" in ctx.get_option("onchip_plan"), ctx.get_option("onchip_plan")
+    del sd, A
+    ctx.close()
+
+
+@pytest.mark.parametrize("name", list(_cases()))
+def test_onchip_cgs_steps_match_the_launch_flow_and_the_oracle(sla, name):
+    """cgsStep (Sparse.hs:928-939) on chip (round 6, second half): the same plans, two synchronisations per step, u and r kept valid on the
+    halo cells in registers.  Against the launch flow (agreement to rounding) and the oracle (1e-9 after two steps)."""
+    (dims, csr), opts, must = _cases()[name]
+    Ao, b, x0 = _problem(dims, csr, seed=5)
+    fields = ("_x", "_r", "_p", "_u")
+    states = {}
+    for mode in (2, 0):
+        ctx = sla.Context(0).set_options(onchip=mode, **(opts if mode else {}))
+        A = sla.fromCSR(dims, *csr, ctx)
+        sd = sla.cgsInit(A, sla.fromVector(b, ctx), sla.fromVector(x0, ctx))
+        sd.step(2)
+        got2 = [getattr(sd, f).toDenseListSV() for f in fields]
+        sd.step(3)
+        got5 = [getattr(sd, f).toDenseListSV() for f in fields]
+        if mode:
+            assert must in ctx.get_option("onchip_plan"), ctx.get_option("onchip_plan")
+            assert int(ctx.get_option("onchip_launches")) == 2
+        else:
+            assert int(ctx.get_option("onchip_launches")) == 0
+        states[mode] = (got2, got5)
+        del sd, A
+        ctx.close()
+    so = orc.CgsState(Ao, b, x0)
+    so.step(b - orc.spmv(Ao, x0), 2)
+    for got, want, what in zip(states[2][0], (so.x, so.r, so.p, so.u), "xrpu"):
+        assert _rel(got, want) <= 1e-9, (name, what, "two steps against the oracle", _rel(got, want))
+    for (g2, g0, what) in zip(states[2][0], states[0][0], "xrpu"):
+        assert _rel(g2, g0) <= 1e-11, (name, what, "two steps against the launch flow", _rel(g2, g0))
+    for (g2, g0, what) in zip(states[2][1], states[0][1], "xrpu"):
+        assert _rel(g2, g0) <= 1e-8, (name, what, "five steps against the launch flow", _rel(g2, g0))
+
+
+def test_onchip_cgs_state_records_and_the_class_it_declines(sla):
+    """step(k) == k x step(1) bit for bit, clones, the pure step with an explicit rhat; config 2 at full size (8 x 4 slots per thread: on chip)
+    against the oracle; one N = 8 slab of config 4 (12 x 4 slots: the cgsStep kernel would spill) stays on the launch flow and says why."""
+    from sla_amd import workloads as wl
+    dims, csr = wl.laplace3d(24, 20, 11)
+    Ao, b, x0 = _problem(dims, csr, seed=9)
+    ctx = sla.Context(0).set_options(onchip=2, onchip_bricks=2)
+    A = sla.fromCSR(dims, *csr, ctx)
+    bv, xv = sla.fromVector(b, ctx), sla.fromVector(x0, ctx)
+    s1, s2 = sla.cgsInit(A, bv, xv), sla.cgsInit(A, bv, xv)
+    s1.step(6)
+    for _ in range(6):
+        s2.step(1)
+    for f in ("_x", "_r", "_p", "_u"):
+        assert np.array_equal(getattr(s1, f).toDenseListSV(), getattr(s2, f).toDenseListSV()), f
+    x_before = s1._x.toDenseListSV()
+    s3 = s1.clone().step(3)
+    assert np.array_equal(s1._x.toDenseListSV(), x_before)
+    s1.step(3)
+    assert np.array_equal(s1._x.toDenseListSV(), s3._x.toDenseListSV())
+    shadow = np.random.default_rng(1).standard_normal(dims[0])
+    s5 = sla.cgsStep(A, sla.fromVector(shadow, ctx), sla.cgsInit(A, bv, xv), k=2)
+    so = orc.CgsState(Ao, b, x0)
+    so.step(shadow, 2)
+    assert _rel(s5._x.toDenseListSV(), so.x) <= 1e-9
+    del s1, s2, s3, s5, A
+    ctx.close()
+    # config 2 at full size
+    dims, csr = wl.poisson2d(1000, 1000)
+    Ao, b, x0 = _problem(dims, csr, seed=21)
+    ctx = sla.Context(0).set_options(onchip=2)
+    A = sla.fromCSR(dims, *csr, ctx)
+    sd = sla.cgsInit(A, sla.fromVector(b, ctx), sla.fromVector(x0, ctx)).step(2)
+    so = orc.CgsState(Ao, b, x0)
+    so.step(b - orc.spmv(Ao, x0), 2)
+    assert _rel(sd._x.toDenseListSV(), so.x) <= 1e-9 and _rel(sd._u.toDenseListSV(), so.u) <= 1e-9
+    assert int(ctx.get_option("onchip_launches")) == 1
+    del sd, A
+    ctx.close()
+    # the slab: 12 x 4 slots per thread
+    dims, csr = wl.laplace3d(216, 216, 27)
+    Ao, b, x0 = _problem(dims, csr, seed=22)
+    ctx = sla.Context(0).set_options(onchip=1)
+    A = sla.fromCSR(dims, *csr, ctx)
+    sd = sla.cgsInit(A, sla.fromVector(b, ctx), sla.fromVector(x0, ctx)).step(2)
+    assert int(ctx.get_option("onchip_launches")) == 0 and "no cgsStep instantiation for 12 x 4" in ctx.get_option("onchip_plan"), ctx.get_option("onchip_plan")
+    so = orc.CgsState(Ao, b, x0)
+    so.step(b - orc.spmv(Ao, x0), 2)
+    assert _rel(sd._x.toDenseListSV(), so.x) <= 1e-9
     del sd, A
     ctx.close()
