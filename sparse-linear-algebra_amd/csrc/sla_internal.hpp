@@ -402,8 +402,8 @@ struct OcPlan {
     double *d_parts = nullptr;       // [4][G] partial sums
     unsigned *d_bar = nullptr;       // barrier words (zeroed in front of every launch)
     size_t lds_bytes = 0;
-    int cgs_state = 0;               // the cgsStep kernel on this plan: 0 not asked yet, 1 resident, -1 declined (cgs_note says why)
-    std::string cgs_note;
+    int kstate[4] = {1, 0, 0, 0};    // per kernel (bicgstabStep -- asked by the plan builder --, linSolve0 BICGSTAB_, cgsStep, linSolve0 CGS_): 0 not asked yet, 1 resident, -1 declined
+    std::string knote[4];            // ... and why
 };
 void onchip_plan_free(OcPlan *p);
 }  // namespace sla
@@ -917,8 +917,8 @@ int build_tiles_device(sla_csr *A, const std::vector<int32_t> &srow, int shift, 
 int build_ctiles_device(sla_csr *A, const std::vector<int32_t> &srow, int shift, int64_t P, const int64_t *rowptr_host, bool *done);
 
 // sla_onchip.hip: can `k` steps of S run as one persistent launch (builds the matrix's plan on first use)?  Then run them.
-bool onchip_usable(sla_solver *S);
-int launch_onchip_steps(sla_solver *S, int par, int k);
+bool onchip_usable(sla_solver *S, bool res = false);   // res: linSolve0's loop (step, true residual, test) inside the launch
+int launch_onchip_steps(sla_solver *S, int par, int k, bool res = false);
 
 int vec_grid(int64_t n_local);
 // p1[b] = sum x.y over block b's elements (grid = vec_grid)

@@ -46,6 +46,7 @@ struct OcArgs {
     double *x, *r, *p;
     double *u;                 // CGS only
     const double *rhat;
+    const double *b;           // RES instantiations (linSolve0): the right-hand side
     double *pubA, *pubS, *parts;
     unsigned *bar;
     SolverScalars *sc;
@@ -115,12 +116,16 @@ __device__ __forceinline__ double oc_wave_total(const double *parts, int G) {
 
 // RPT / HPT: own rows / halo cells per thread (instantiation classes; unused slots are harmless, see below).  NP: the matrix's pairs
 // (0: any number <= 8 -- every row through the mask tests).
-template <int RPT, int HPT, int NP>
+// RES (round 6, linSolve0 on chip): after every step the TRUE residual norm2 ((aa #> x) ^-^ b) is evaluated the way runIter does
+// (Sparse.hs:1041-1052) -- x of own + halo cells in a third LDS array, b of the own rows in registers, a third synchronisation carrying the sum of
+// squares -- and every workgroup takes the same decision: stop at the first iterate with resnorm <= tol, or after a.k steps (silently, like the
+// reference's nits).  Workgroup 0 keeps resnorm, the residual trace and the flags the way check_kernel / residual_converged do.
+template <int RPT, int HPT, int NP, bool RES>
 __global__ void __launch_bounds__(T) oc_bicgstab_kernel(OcArgs a) {
     extern __shared__ __attribute__((aligned(16))) double oc_lds[];
     __shared__ int s_ok;
     const int LA = (a.L + 2) & ~1;   // cells 0 .. L-1 + one dummy cell (L): what the slots of a short block write to
-    double *P = oc_lds, *S = oc_lds + LA, *red = S + LA;
+    double *P = oc_lds, *S = oc_lds + LA, *X = S + LA, *red = RES ? X + LA : S + LA;
     const int b = blockIdx.x, t = threadIdx.x, G = gridDim.x, wave = t >> 6;
     SolverScalars *sc = a.sc;
     if (sc->done) return;   // (written by an earlier launch: every workgroup takes the same exit)
@@ -147,6 +152,15 @@ __global__ void __launch_bounds__(T) oc_bicgstab_kernel(OcArgs a) {
         rh[i] = v ? h0 : 0.0;
         ap[i] = as[i] = 0.0;
     }
+    double bb[RES ? RPT : 1];
+    if constexpr (RES) {
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) {
+            const int32_t g = a.own_row[((size_t)b * RPT + i) * T + t];
+            const double b0 = a.b[g];
+            bb[i] = ((cm[i] >> 25) & 1) ? b0 : 0.0;
+        }
+    }
     auto wcell = [&](uint32_t c) -> int { return ((c >> 25) & 1) ? (int)(c & 0xffff) : a.L; };
     uint32_t hc[HPT];
     int32_t hg[HPT];
@@ -159,12 +173,17 @@ __global__ void __launch_bounds__(T) oc_bicgstab_kernel(OcArgs a) {
         const int32_t g = a.halo_row[j];
         P[hc[i]] = a.p[g];   // halo(p) and halo(r): the invariant every step starts from
         S[hc[i]] = a.r[g];
+        if constexpr (RES) X[hc[i]] = a.x[g];
         hap[i] = 0.0;
     }
 #pragma unroll
     for (int i = 0; i < RPT; ++i) P[wcell(cm[i])] = p[i];
     __syncthreads();
     double rho = sc->rho2[a.par], alpha = 0.0, omega = 0.0, beta = 0.0;
+    const double tol = RES ? sc->tol : 0.0;
+    const int it0 = sc->iters;
+    int steps_done = 0;
+    bool conv = false;
     unsigned epoch = 0;
     // one row's left fold: a * x then +, two roundings like the reference's, never an FMA; ascending pair (= column) order
     auto fold = [&](const double *V, uint32_t c, bool full) -> double {
@@ -189,7 +208,7 @@ __global__ void __launch_bounds__(T) oc_bicgstab_kernel(OcArgs a) {
         }
         return y;
     };
-    for (int step = 0; step < a.k; ++step) {
+    for (int step = 0; step < a.k && !conv; ++step) {
         // (opaque per step: nothing derived from the slot words -- LDS addresses, publish addresses, mask tests -- is hoisted out of the loop
         // and kept in registers next to the state: 130 live registers otherwise)
 #pragma unroll
@@ -262,6 +281,7 @@ __global__ void __launch_bounds__(T) oc_bicgstab_kernel(OcArgs a) {
             rho = rn;
 #pragma unroll
             for (int i = 0; i < HPT; ++i) {
+                if constexpr (RES) X[hc[i]] = __builtin_fma(omega, S[hc[i]], __builtin_fma(alpha, P[hc[i]], X[hc[i]]));   // halo(x): the same update, from the old p and s
                 const double rv = __builtin_fma(-omega, has[i], S[hc[i]]);
                 S[hc[i]] = rv;   // halo(r) of the next step
                 P[hc[i]] = __builtin_fma(beta, __builtin_fma(-omega, hap[i], P[hc[i]]), rv);
@@ -272,9 +292,33 @@ __global__ void __launch_bounds__(T) oc_bicgstab_kernel(OcArgs a) {
                 r[i] = __builtin_fma(-omega, as[i], r[i]);
                 p[i] = __builtin_fma(beta, __builtin_fma(-omega, ap[i], p[i]), r[i]);
                 P[wcell(cm[i])] = p[i];
+                if constexpr (RES) X[wcell(cm[i])] = x[i];
             }
         }
         __syncthreads();
+        steps_done = step + 1;
+        if constexpr (RES) {
+            // ---- trueResidualNorm x = norm2 ((aa #> x) ^-^ b)   (Sparse.hs:1041) and runIter's test (:1047-1050) ----
+            double acc = 0.0;
+#pragma unroll
+            for (int i = 0; i < RPT; ++i) {
+                const double d = fold(X, cm[i], (fullbits >> i) & 1) - bb[i];
+                acc += d * d;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            acc = wave_sum(acc);
+            if ((t & 63) == 0) red[wave] = acc;
+            if (!oc_grid_sync<1>(a.bar, ++epoch, sc, red, a.parts, &s_ok)) return;
+            const double rn = sqrt(oc_wave_total(a.parts, G));
+            conv = rn <= tol;
+            if (b == 0 && t == 0) {
+                const int it = it0 + steps_done;
+                sc->resnorm = rn;
+                if (sc->hist && it >= 1 && it <= sc->hist_cap) sc->hist[it - 1] = rn;
+                if (conv) { sc->done = 1; sc->flags |= SLA_FLAG_CONVERGED; }
+                if (!is_finite(rn)) sc->flags |= SLA_FLAG_NONFINITE;
+            }
+        }
     }
 #pragma unroll
     for (int i = 0; i < RPT; ++i)
@@ -285,11 +329,11 @@ __global__ void __launch_bounds__(T) oc_bicgstab_kernel(OcArgs a) {
             a.p[g] = p[i];
         }
     if (b == 0 && t == 0) {
-        sc->rho2[(a.par + a.k) & 1] = rho;   // where the launch flow's next step (parity par + k) reads it
+        sc->rho2[(a.par + steps_done) & 1] = rho;   // where the launch flow's next step (parity par + steps) reads it
         sc->alpha = alpha;
         sc->omega = omega;
         sc->beta = beta;
-        sc->iters += a.k;
+        sc->iters = it0 + steps_done;
     }
 }
 
@@ -484,16 +528,26 @@ struct Geo {                         // how rows are dealt: mode 0 consecutive r
 };
 
 constexpr size_t kOcLdsMax = 160 * 1024 - 512;   // dynamic LDS a workgroup may ask for (the static part: a few words)
-static size_t oc_lds_bytes(int L) { return sizeof(double) * ((size_t)2 * ((L + 2) & ~1) + 4 * NW + 8); }
+static size_t oc_lds_bytes(int L, bool res = false) { return sizeof(double) * ((size_t)(res ? 3 : 2) * ((L + 2) & ~1) + 4 * NW + 8); }
 static int rpt_class(int64_t own) { return own <= 4 * T ? 4 : own <= 8 * T ? 8 : own <= 12 * T ? 12 : 0; }
 static int hpt_class(int64_t halo) { return halo <= 4 * T ? 4 : halo <= 8 * T ? 8 : 0; }
 static bool class_ok(int rpt, int hpt) { return rpt != 0 && hpt != 0 && !(rpt == 12 && hpt == 8); }   // (12 x 8 slots do not fit 256 registers: ~50 spilled)
 
-template <int RPT, int HPT>
+template <int RPT, int HPT, bool RES = false>
 static const void *oc_kernel_np(int np) {
-    if (np == 5) return (const void *)oc_bicgstab_kernel<RPT, HPT, 5>;
-    if (np == 7) return (const void *)oc_bicgstab_kernel<RPT, HPT, 7>;
-    return (const void *)oc_bicgstab_kernel<RPT, HPT, 0>;
+    if (np == 5) return (const void *)oc_bicgstab_kernel<RPT, HPT, 5, RES>;
+    if (np == 7) return (const void *)oc_bicgstab_kernel<RPT, HPT, 7, RES>;
+    return (const void *)oc_bicgstab_kernel<RPT, HPT, 0, RES>;
+}
+// linSolve0 on chip: b of the own rows in registers on top of the step's state -- the classes that still fit 256 registers
+static const void *oc_kernel_res(int rpt, int hpt, int np) {
+    switch (rpt * 16 + hpt) {
+        case 4 * 16 + 4: return oc_kernel_np<4, 4, true>(np);
+        case 4 * 16 + 8: return oc_kernel_np<4, 8, true>(np);
+        case 8 * 16 + 4: return oc_kernel_np<8, 4, true>(np);
+        case 8 * 16 + 8: return oc_kernel_np<8, 8, true>(np);
+    }
+    return nullptr;
 }
 template <int RPT, int HPT>
 static const void *oc_cgs_kernel_np(int np) {
@@ -777,9 +831,13 @@ void onchip_plan_free(OcPlan *p) {
     delete p;
 }
 
-// Can steps of S run on chip?  BiCGSTAB with the fused flows on (the on-chip step IS the fused K4+K5 flow), a single-rank context, no
-// residual evaluation pending, the kernel profiler not asking for per-kernel events of the launch flow, and a plan for the matrix.
-bool onchip_usable(sla_solver *S) {
+// Can steps of S run on chip?  BiCGSTAB (with the fused flows on: the on-chip step IS the fused K4+K5 flow) or CGS, a single-rank context, no
+// residual evaluation pending, and a plan for the matrix.  res: linSolve0's loop -- step, true residual, test -- inside the launch.
+static const void *oc_pick(int method, bool res, const OcPlan &pl) {
+    if (method == SLA_CGS_) return res ? nullptr : oc_kernel_cgs(pl.rpt, pl.hpt, pl.np);
+    return res ? oc_kernel_res(pl.rpt, pl.hpt, pl.np) : oc_kernel(pl.rpt, pl.hpt, pl.np);
+}
+bool onchip_usable(sla_solver *S, bool res) {
     sla_ctx *c = S->ctx;
     if (c->onchip == 0 || (S->method != SLA_BICGSTAB_ && S->method != SLA_CGS_) || c->collectives || S->ghost || S->have_res) return false;
     if (S->method == SLA_BICGSTAB_ && !c->bicg_fuse45) return false;
@@ -795,26 +853,29 @@ bool onchip_usable(sla_solver *S) {
         if (getenv("SLA_DEBUG_ONCHIP")) fprintf(stderr, "[sla] %s\n", A->oc->note.c_str());
     }
     c->onchip_note = A->oc->note;
-    if (A->oc->ok && S->method == SLA_CGS_) {   // the cgsStep kernel is its own function: its LDS grant and co-residency are asked once per plan
-        OcPlan &pl = *A->oc;
-        if (pl.cgs_state == 0) {
-            const void *kern = oc_kernel_cgs(pl.rpt, pl.hpt, pl.np);
-            int per_cu = 0;
-            pl.cgs_state = -1;
-            if (!kern) pl.cgs_note = "no cgsStep instantiation for " + std::to_string(pl.rpt) + " x " + std::to_string(pl.hpt) + " slots per thread";
-            else if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kOcLdsMax) != hipSuccess) { (void)hipGetLastError(); pl.cgs_note = "the device does not grant the cgsStep kernel its LDS"; }
-            else if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, T, pl.lds_bytes) != hipSuccess || per_cu < 1 || pl.G > c->n_cu * per_cu) { (void)hipGetLastError(); pl.cgs_note = "the occupancy query does not grant the cgsStep kernel one workgroup per CU"; }
-            else pl.cgs_state = 1;
-        }
-        if (pl.cgs_state < 0) {
-            c->onchip_note += "; " + pl.cgs_note;
-            return false;
-        }
+    if (!A->oc->ok) return false;
+    OcPlan &pl = *A->oc;
+    const int slot = (S->method == SLA_CGS_ ? 2 : 0) + (res ? 1 : 0);
+    if (slot != 0 && pl.kstate[slot] == 0) {   // every kernel is its own function: LDS grant and co-residency are asked once per plan and kernel
+        const char *what = S->method == SLA_CGS_ ? (res ? "linSolve0 CGS_" : "cgsStep") : "linSolve0 BICGSTAB_";
+        const void *kern = oc_pick(S->method, res, pl);
+        const size_t lds = oc_lds_bytes(pl.L, res);
+        int per_cu = 0;
+        pl.kstate[slot] = -1;
+        if (!kern) pl.knote[slot] = std::string("no ") + what + " instantiation for " + std::to_string(pl.rpt) + " x " + std::to_string(pl.hpt) + " slots per thread";
+        else if (lds > kOcLdsMax) pl.knote[slot] = std::string(what) + ": x of own + halo cells does not fit the LDS next to p and s";
+        else if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kOcLdsMax) != hipSuccess) { (void)hipGetLastError(); pl.knote[slot] = std::string("the device does not grant the ") + what + " kernel its LDS"; }
+        else if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, T, lds) != hipSuccess || per_cu < 1 || pl.G > c->n_cu * per_cu) { (void)hipGetLastError(); pl.knote[slot] = std::string("the occupancy query does not grant the ") + what + " kernel one workgroup per CU"; }
+        else pl.kstate[slot] = 1;
     }
-    return A->oc->ok;
+    if (slot != 0 && pl.kstate[slot] < 0) {
+        c->onchip_note += "; " + pl.knote[slot];
+        return false;
+    }
+    return true;
 }
 
-int launch_onchip_steps(sla_solver *S, int par, int k) {
+int launch_onchip_steps(sla_solver *S, int par, int k, bool res) {
     sla_ctx *c = S->ctx;
     const OcPlan &pl = *S->A->oc;
     OcArgs a{};
@@ -831,6 +892,7 @@ int launch_onchip_steps(sla_solver *S, int par, int k) {
     a.p = S->p->d;
     a.u = S->method == SLA_CGS_ ? S->u->d : nullptr;
     a.rhat = S->r0hat->d;
+    a.b = S->b->d;
     a.pubA = pl.d_pubA;
     a.pubS = pl.d_pubS;
     a.parts = pl.d_parts;
@@ -838,16 +900,17 @@ int launch_onchip_steps(sla_solver *S, int par, int k) {
     a.sc = S->d_sc;
     a.par = par;
     a.k = k;
-    const void *kern = S->method == SLA_CGS_ ? oc_kernel_cgs(pl.rpt, pl.hpt, pl.np) : oc_kernel(pl.rpt, pl.hpt, pl.np);
+    const void *kern = oc_pick(S->method, res, pl);
     if (!kern) return fail(SLA_ERR_INVALID, "launch_onchip_steps: no instantiation for this plan");
     SLA_HIP_TRY(hipMemsetAsync(pl.d_bar, 0, sizeof(unsigned) * 32 * 17, stream_of(c)));
     ProfScope prof(c, SLA_KERNEL_ONCHIP, true);
     void *params[] = {&a};
+    const size_t lds = oc_lds_bytes(pl.L, res);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (prof_take(c, &e0, &e1))
-        SLA_HIP_TRY(hipExtLaunchKernel(kern, dim3(pl.G), dim3(T), params, pl.lds_bytes, stream_of(c), e0, e1, 0));
+        SLA_HIP_TRY(hipExtLaunchKernel(kern, dim3(pl.G), dim3(T), params, lds, stream_of(c), e0, e1, 0));
     else
-        SLA_HIP_TRY(hipLaunchKernel(kern, dim3(pl.G), dim3(T), params, pl.lds_bytes, stream_of(c)));
+        SLA_HIP_TRY(hipLaunchKernel(kern, dim3(pl.G), dim3(T), params, lds, stream_of(c)));
     SLA_HIP_TRY(hipGetLastError());
     c->onchip_launches += 1;
     return SLA_OK;

@@ -1043,7 +1043,18 @@ int sla_linsolve0(int method, sla_csr_t A, sla_vec_t b, sla_vec_t x0, const sla_
         sla_solver *S = nullptr;
         SLA_TRY(solver_init_common(method, A, b, x0, o.tol_abs, o.tol_rel, &S, hist_cap));
         int rc = SLA_OK, total = 0;
-        while (total < o.max_iters) {  // runIter n state | n >= nits = return x        (:1045)
+        // Round 6: on matrices with an on-chip plan the whole loop -- step, true residual, test (runIter, :1043-1052) -- is ONE persistent
+        // launch that stops at the first iterate with resnorm <= tol or after max_iters steps (sla_onchip.hip, RES instantiations); the
+        // device keeps iters, resnorm, the flags and the residual trace exactly as the launch flow's check does.
+        if (o.true_residual && o.max_iters > 0 && c->onchip != 0 && onchip_usable(S, true)) {
+            rc = launch_onchip_steps(S, ctl_of(S).step_index & 1, o.max_iters, true);
+            if (rc == SLA_OK) rc = read_scalars(S);
+            if (rc == SLA_OK) {
+                ctl_of(S).step_index += S->h_sc->iters;
+                total = o.max_iters;   // (done, or max_iters steps taken: either way the loop below has nothing left to do)
+            }
+        }
+        while (rc == SLA_OK && total < o.max_iters) {  // runIter n state | n >= nits = return x        (:1045)
             const int k = std::min(o.check_every, o.max_iters - total);
             const bool dual = o.true_residual != 0 && dual_ok(S);
             for (int j = 0; j < k && rc == SLA_OK; ++j) {

