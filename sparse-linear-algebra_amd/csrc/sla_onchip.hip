@@ -117,9 +117,9 @@ __device__ __forceinline__ double oc_wave_total(const double *parts, int G) {
 // RPT / HPT: own rows / halo cells per thread (instantiation classes; unused slots are harmless, see below).  NP: the matrix's pairs
 // (0: any number <= 8 -- every row through the mask tests).
 // RES (round 6, linSolve0 on chip): after every step the TRUE residual norm2 ((aa #> x) ^-^ b) is evaluated the way runIter does
-// (Sparse.hs:1041-1052) -- x of own + halo cells in a third LDS array, b of the own rows in registers, a third synchronisation carrying the sum of
-// squares -- and every workgroup takes the same decision: stop at the first iterate with resnorm <= tol, or after a.k steps (silently, like the
-// reference's nits).  Workgroup 0 keeps resnorm, the residual trace and the flags the way check_kernel / residual_converged do.
+// (Sparse.hs:1041-1052) -- x of own + halo cells in a third LDS array, b of the own rows in registers, the sum of squares riding on the NEXT pass's
+// first synchronisation -- and every workgroup takes the same decision: stop at the first iterate with resnorm <= tol, or after a.k steps
+// (silently, like the reference's nits).  Workgroup 0 keeps resnorm, the residual trace and the flags the way check_kernel / residual_converged do.
 template <int RPT, int HPT, int NP, bool RES>
 __global__ void __launch_bounds__(T) oc_bicgstab_kernel(OcArgs a) {
     extern __shared__ __attribute__((aligned(16))) double oc_lds[];
@@ -208,7 +208,10 @@ __global__ void __launch_bounds__(T) oc_bicgstab_kernel(OcArgs a) {
         }
         return y;
     };
-    for (int step = 0; step < a.k && !conv; ++step) {
+    // RES: pass `step` first evaluates the true residual of the iterate after `step` steps -- in the K1 phase, its sum of squares riding on the first
+    // synchronisation (the launch flow's dual-SpMV idea: two synchronisations per iteration, not three) --, tests it, and only then applies step
+    // `step + 1`; one more pass than steps, the last one for the residual of the final iterate alone.
+    for (int step = 0; step < a.k + (RES ? 1 : 0); ++step) {
         // (opaque per step: nothing derived from the slot words -- LDS addresses, publish addresses, mask tests -- is hoisted out of the loop
         // and kept in registers next to the state: 130 live registers otherwise)
 #pragma unroll
@@ -230,8 +233,35 @@ __global__ void __launch_bounds__(T) oc_bicgstab_kernel(OcArgs a) {
             }
             acc = wave_sum(acc);
             if ((t & 63) == 0) red[wave] = acc;
+            if constexpr (RES) {   // trueResidualNorm of the current x = norm2 ((aa #> x) ^-^ b)   (Sparse.hs:1041)
+                double acr = 0.0;
+                if (step > 0) {
+#pragma unroll
+                    for (int i = 0; i < RPT; ++i) {
+                        const double d = fold(X, cm[i], (fullbits >> i) & 1) - bb[i];
+                        acr += d * d;
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                acr = wave_sum(acr);
+                if ((t & 63) == 0) red[NW + wave] = acr;
+            }
         }
-        if (!oc_grid_sync<1>(a.bar, ++epoch, sc, red, a.parts, &s_ok)) return;
+        if (!oc_grid_sync<RES ? 2 : 1>(a.bar, ++epoch, sc, red, a.parts, &s_ok)) return;
+        if constexpr (RES) {
+            if (step > 0) {   // runIter's test (:1047-1050) on the iterate after `step` steps
+                const double rn = sqrt(oc_wave_total(a.parts + G, G));
+                conv = rn <= tol;
+                if (b == 0 && t == 0) {
+                    const int it = it0 + step;
+                    sc->resnorm = rn;
+                    if (sc->hist && it >= 1 && it <= sc->hist_cap) sc->hist[it - 1] = rn;
+                    if (conv) { sc->done = 1; sc->flags |= SLA_FLAG_CONVERGED; }
+                    if (!is_finite(rn)) sc->flags |= SLA_FLAG_NONFINITE;
+                }
+            }
+            if (conv || step == a.k) break;   // (the same decision in every workgroup: the total is formed from the same partials in the same order)
+        }
         // ---- K2 on own + halo cells: alphaj = (r <.> r0hat) / (aap <.> r0hat) ; sj = r ^-^ (alphaj .* aap) ----
         {
 #pragma unroll
@@ -297,28 +327,6 @@ __global__ void __launch_bounds__(T) oc_bicgstab_kernel(OcArgs a) {
         }
         __syncthreads();
         steps_done = step + 1;
-        if constexpr (RES) {
-            // ---- trueResidualNorm x = norm2 ((aa #> x) ^-^ b)   (Sparse.hs:1041) and runIter's test (:1047-1050) ----
-            double acc = 0.0;
-#pragma unroll
-            for (int i = 0; i < RPT; ++i) {
-                const double d = fold(X, cm[i], (fullbits >> i) & 1) - bb[i];
-                acc += d * d;
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            acc = wave_sum(acc);
-            if ((t & 63) == 0) red[wave] = acc;
-            if (!oc_grid_sync<1>(a.bar, ++epoch, sc, red, a.parts, &s_ok)) return;
-            const double rn = sqrt(oc_wave_total(a.parts, G));
-            conv = rn <= tol;
-            if (b == 0 && t == 0) {
-                const int it = it0 + steps_done;
-                sc->resnorm = rn;
-                if (sc->hist && it >= 1 && it <= sc->hist_cap) sc->hist[it - 1] = rn;
-                if (conv) { sc->done = 1; sc->flags |= SLA_FLAG_CONVERGED; }
-                if (!is_finite(rn)) sc->flags |= SLA_FLAG_NONFINITE;
-            }
-        }
     }
 #pragma unroll
     for (int i = 0; i < RPT; ++i)
@@ -340,16 +348,18 @@ __global__ void __launch_bounds__(T) oc_bicgstab_kernel(OcArgs a) {
 // cgsStep (Numeric/LinearAlgebra/Sparse.hs:928-939) on chip, the same plan and the same two synchronisations per step:
 //   C1  aap = aa #> p ; aap <.> rhat                                   | sync 1: the sum + the boundary rows of aap
 //   C2  alpha ; q = u ^-^ alpha .* aap ; u ^+^ q ; x1 (own + halo cells: u is kept valid on the halo in registers, p and u + q in LDS)
-//   C3  aa #> (u ^+^ q) ; r1 = r ^-^ alpha .* (...) ; r1 <.> rhat       | sync 2: the sum + the boundary rows of aa #> (u + q)
-//   C4  beta ; u1 = r1 ^+^ beta .* q ; p1 = u1 ^+^ beta .* (q ^+^ beta .* p)   (own + halo cells: r is kept valid on the halo too)
+//   C3  aa #> (u ^+^ q) ; r1 = r ^-^ alpha .* (...) ; r1 <.> rhat       | sync 2: the sum + the boundary rows of r1
+//   C4  beta ; u1 = r1 ^+^ beta .* q ; p1 = u1 ^+^ beta .* (q ^+^ beta .* p)   (own + halo cells: r1 of a halo cell comes from its owner)
 // Expressions are cgs_c24_kernel's and the SpMV epilogue's (EPI_AXPY_DOT) term by term; the grouping of the two inner products differs from
 // the launch flow's, so the iterates agree with it to rounding.
-template <int RPT, int HPT, int NP>
+// RES (linSolve0 CGS_ on chip): x1 is complete right after alpha, so its true residual is folded in the C3 phase and its sum of squares rides on
+// the step's SECOND synchronisation -- no third one; the test (Sparse.hs:1047-1050) is taken by every workgroup alike after C4.
+template <int RPT, int HPT, int NP, bool RES>
 __global__ void __launch_bounds__(T) oc_cgs_kernel(OcArgs a) {
     extern __shared__ __attribute__((aligned(16))) double oc_lds[];
     __shared__ int s_ok;
     const int LA = (a.L + 2) & ~1;
-    double *P = oc_lds, *S = oc_lds + LA, *red = S + LA;
+    double *P = oc_lds, *S = oc_lds + LA, *X = S + LA, *red = RES ? X + LA : S + LA;
     const int b = blockIdx.x, t = threadIdx.x, G = gridDim.x, wave = t >> 6;
     SolverScalars *sc = a.sc;
     if (sc->done) return;
@@ -375,10 +385,20 @@ __global__ void __launch_bounds__(T) oc_cgs_kernel(OcArgs a) {
         rh[i] = v ? h0 : 0.0;
         q[i] = 0.0;
     }
+    double bb[RES ? RPT : 1];
+    if constexpr (RES) {
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) {
+            const int32_t g = a.own_row[((size_t)b * RPT + i) * T + t];
+            const double b0 = a.b[g];
+            bb[i] = ((cm[i] >> 25) & 1) ? b0 : 0.0;
+        }
+    }
     auto wcell = [&](uint32_t c) -> int { return ((c >> 25) & 1) ? (int)(c & 0xffff) : a.L; };
     uint32_t hc[HPT];
     int32_t hg[HPT];
-    double hu[HPT], hr[HPT], hq[HPT];   // u, r and q of this thread's halo cells (p and u + q of the halo live in LDS with the own cells)
+    double hu[HPT], hq[HPT];   // u and q of this thread's halo cells (p and u + q of the halo live in LDS with the own cells; r1 of a halo cell is read
+                               // from its owner, who publishes r1 -- not aa #> (u + q) -- for its boundary rows: one register array less)
 #pragma unroll
     for (int i = 0; i < HPT; ++i) {
         const size_t j = ((size_t)b * HPT + i) * T + t;
@@ -386,14 +406,18 @@ __global__ void __launch_bounds__(T) oc_cgs_kernel(OcArgs a) {
         hg[i] = a.halo_src[j];
         const int32_t g = a.halo_row[j];
         P[hc[i]] = a.p[g];
+        if constexpr (RES) X[hc[i]] = a.x[g];
         hu[i] = a.u[g];
-        hr[i] = a.r[g];
         hq[i] = 0.0;
     }
 #pragma unroll
     for (int i = 0; i < RPT; ++i) P[wcell(cm[i])] = p[i];
     __syncthreads();
     double rho = sc->rho2[a.par], alpha = 0.0, beta = 0.0;
+    const double tol = RES ? sc->tol : 0.0;
+    const int it0 = sc->iters;
+    int steps_done = 0;
+    bool conv = false;
     unsigned epoch = 0;
     auto fold = [&](const double *V, uint32_t c, bool full) -> double {
 #pragma clang fp contract(off)
@@ -417,7 +441,7 @@ __global__ void __launch_bounds__(T) oc_cgs_kernel(OcArgs a) {
         }
         return y;
     };
-    for (int step = 0; step < a.k; ++step) {
+    for (int step = 0; step < a.k && !conv; ++step) {
 #pragma unroll
         for (int i = 0; i < RPT; ++i) asm volatile("" : "+v"(cm[i]));
         int sl = b * RPT * T + t;
@@ -447,7 +471,9 @@ __global__ void __launch_bounds__(T) oc_cgs_kernel(OcArgs a) {
 #pragma unroll
             for (int i = 0; i < HPT; ++i) {
                 hq[i] = __builtin_fma(-alpha, hap[i], hu[i]);
-                S[hc[i]] = hu[i] + hq[i];
+                const double sv = hu[i] + hq[i];
+                S[hc[i]] = sv;
+                if constexpr (RES) X[hc[i]] = __builtin_fma(alpha, sv, X[hc[i]]);   // halo(x): the same update
             }
 #pragma unroll
             for (int i = 0; i < RPT; ++i) {
@@ -455,6 +481,7 @@ __global__ void __launch_bounds__(T) oc_cgs_kernel(OcArgs a) {
                 const double sv = u[i] + q[i];
                 x[i] = __builtin_fma(alpha, sv, x[i]);
                 S[wcell(cm[i])] = sv;
+                if constexpr (RES) X[wcell(cm[i])] = x[i];
             }
         }
         __syncthreads();
@@ -464,26 +491,47 @@ __global__ void __launch_bounds__(T) oc_cgs_kernel(OcArgs a) {
 #pragma unroll
             for (int i = 0; i < RPT; ++i) {
                 const double auq = fold(S, cm[i], (fullbits >> i) & 1);
-                if ((cm[i] >> 24) & 1) st_agent(a.pubS + (sl + i * T), auq);
                 r[i] = __builtin_fma(-alpha, auq, r[i]);
+                if ((cm[i] >> 24) & 1) st_agent(a.pubS + (sl + i * T), r[i]);
                 acc += r[i] * rh[i];
                 __builtin_amdgcn_sched_barrier(0);
             }
             acc = wave_sum(acc);
             if ((t & 63) == 0) red[wave] = acc;
+            if constexpr (RES) {   // trueResidualNorm of xj1 = norm2 ((aa #> x) ^-^ b)   (Sparse.hs:1041)
+                double acr = 0.0;
+#pragma unroll
+                for (int i = 0; i < RPT; ++i) {
+                    const double d = fold(X, cm[i], (fullbits >> i) & 1) - bb[i];
+                    acr += d * d;
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                acr = wave_sum(acr);
+                if ((t & 63) == 0) red[NW + wave] = acr;
+            }
         }
-        if (!oc_grid_sync<1>(a.bar, ++epoch, sc, red, a.parts, &s_ok)) return;
+        if (!oc_grid_sync<RES ? 2 : 1>(a.bar, ++epoch, sc, red, a.parts, &s_ok)) return;
+        if constexpr (RES) {   // runIter's test on the iterate after step + 1 steps (the state record is completed below either way)
+            const double rn = sqrt(oc_wave_total(a.parts + G, G));
+            conv = rn <= tol;
+            if (b == 0 && t == 0) {
+                const int it = it0 + step + 1;
+                sc->resnorm = rn;
+                if (sc->hist && it >= 1 && it <= sc->hist_cap) sc->hist[it - 1] = rn;
+                if (conv) { sc->done = 1; sc->flags |= SLA_FLAG_CONVERGED; }
+                if (!is_finite(rn)) sc->flags |= SLA_FLAG_NONFINITE;
+            }
+        }
         // ---- C4 on own + halo cells: betaj ; uj1 = rj1 ^+^ betaj .* q ; pj1 = uj1 ^+^ betaj .* (q ^+^ betaj .* p) ----
         {
-            double hauq[HPT];
+            double hr[HPT];
 #pragma unroll
-            for (int i = 0; i < HPT; ++i) hauq[i] = ld_agent(a.pubS + hg[i]);
+            for (int i = 0; i < HPT; ++i) hr[i] = ld_agent(a.pubS + hg[i]);   // r1 of the halo cells, from their owners
             const double rn = oc_wave_total(a.parts, G);
             beta = rn / rho;
             rho = rn;
 #pragma unroll
             for (int i = 0; i < HPT; ++i) {
-                hr[i] = __builtin_fma(-alpha, hauq[i], hr[i]);
                 const double un = __builtin_fma(beta, hq[i], hr[i]);
                 P[hc[i]] = __builtin_fma(beta, __builtin_fma(beta, P[hc[i]], hq[i]), un);
                 hu[i] = un;
@@ -497,6 +545,7 @@ __global__ void __launch_bounds__(T) oc_cgs_kernel(OcArgs a) {
             }
         }
         __syncthreads();
+        steps_done = step + 1;
     }
 #pragma unroll
     for (int i = 0; i < RPT; ++i)
@@ -508,10 +557,10 @@ __global__ void __launch_bounds__(T) oc_cgs_kernel(OcArgs a) {
             a.u[g] = u[i];
         }
     if (b == 0 && t == 0) {
-        sc->rho2[(a.par + a.k) & 1] = rho;
+        sc->rho2[(a.par + steps_done) & 1] = rho;
         sc->alpha = alpha;
         sc->beta = beta;
-        sc->iters += a.k;
+        sc->iters = it0 + steps_done;
     }
 }
 
@@ -549,11 +598,19 @@ static const void *oc_kernel_res(int rpt, int hpt, int np) {
     }
     return nullptr;
 }
-template <int RPT, int HPT>
+template <int RPT, int HPT, bool RES = false>
 static const void *oc_cgs_kernel_np(int np) {
-    if (np == 5) return (const void *)oc_cgs_kernel<RPT, HPT, 5>;
-    if (np == 7) return (const void *)oc_cgs_kernel<RPT, HPT, 7>;
-    return (const void *)oc_cgs_kernel<RPT, HPT, 0>;
+    if (np == 5) return (const void *)oc_cgs_kernel<RPT, HPT, 5, RES>;
+    if (np == 7) return (const void *)oc_cgs_kernel<RPT, HPT, 7, RES>;
+    return (const void *)oc_cgs_kernel<RPT, HPT, 0, RES>;
+}
+static const void *oc_kernel_cgs_res(int rpt, int hpt, int np) {   // (+ b of the own rows: 8 x 8 no longer fits)
+    switch (rpt * 16 + hpt) {
+        case 4 * 16 + 4: return oc_cgs_kernel_np<4, 4, true>(np);
+        case 4 * 16 + 8: return oc_cgs_kernel_np<4, 8, true>(np);
+        case 8 * 16 + 4: return oc_cgs_kernel_np<8, 4, true>(np);
+    }
+    return nullptr;
 }
 // (CGS keeps u, r and q of the halo cells in registers where BiCGSTAB keeps one array: the 12 x 4 class does not fit 256 registers and is declined)
 static const void *oc_kernel_cgs(int rpt, int hpt, int np) {
@@ -834,7 +891,7 @@ void onchip_plan_free(OcPlan *p) {
 // Can steps of S run on chip?  BiCGSTAB (with the fused flows on: the on-chip step IS the fused K4+K5 flow) or CGS, a single-rank context, no
 // residual evaluation pending, and a plan for the matrix.  res: linSolve0's loop -- step, true residual, test -- inside the launch.
 static const void *oc_pick(int method, bool res, const OcPlan &pl) {
-    if (method == SLA_CGS_) return res ? nullptr : oc_kernel_cgs(pl.rpt, pl.hpt, pl.np);
+    if (method == SLA_CGS_) return res ? oc_kernel_cgs_res(pl.rpt, pl.hpt, pl.np) : oc_kernel_cgs(pl.rpt, pl.hpt, pl.np);
     return res ? oc_kernel_res(pl.rpt, pl.hpt, pl.np) : oc_kernel(pl.rpt, pl.hpt, pl.np);
 }
 bool onchip_usable(sla_solver *S, bool res) {

@@ -178,9 +178,9 @@ def test_onchip_declines_what_it_cannot_hold(sla):
     soc.step(2)
     assert _rel(sc._xCgne.toDenseListSV(), soc.x) <= 1e-9
     assert int(ctx.get_option("onchip_launches")) == 0
-    # linSolve0 CGS_ (no on-chip residual loop for CGS) stays on the launch flow and still converges to the reference's answer
-    x, info = sla.linSolve0(sla.CGS_, A2, sla.fromVector(b2, ctx), sla.fromVector(np.zeros(dims2[0]), ctx), return_info=True)
-    assert info["converged"] and int(ctx.get_option("onchip_launches")) == 0
+    # linSolve0 CGNE_ stays on the launch flow and still converges to the reference's answer
+    x, info = sla.linSolve0(sla.CGNE_, A2, sla.fromVector(b2, ctx), sla.fromVector(np.zeros(dims2[0]), ctx), return_info=True)
+    assert int(ctx.get_option("onchip_launches")) == 0
     # ... and BiCGSTAB steps on the same matrix do go on chip
     sb = sla.bicgsInit(A2, sla.fromVector(b2, ctx), sla.fromVector(x02, ctx)).step(4)
     assert int(ctx.get_option("onchip_launches")) == 1
@@ -314,9 +314,11 @@ def test_onchip_cgs_state_records_and_the_class_it_declines(sla):
 @pytest.mark.parametrize("name", ["poisson2d 48x48, consecutive rows", "poisson2d 61x37 (odd sizes), 7 workgroups", "laplace3d 36x30x9, consecutive rows",
                                   "laplace3d 20x17x13, bricks, 60 workgroups", "non-symmetric band {-2,-1,0,1,3}",
                                   "tridiagonal n = 1000 (3 pairs: the any-pair-count kernel)", "ragged 7 diagonals (20 % of the entries missing)"])
-def test_linsolve0_onchip_is_the_launch_flows_linsolve0(sla, name):
-    """linSolve0 BICGSTAB_ (Sparse.hs:1016-1072) as ONE persistent launch (round 6): step, true residual norm2 ((aa #> x) ^-^ b), test -- on the device,
-    stopping at the first iterate with resnorm <= max tolAbs (tolRel * r0norm) or silently after max_iters.  Against the launch flow's linSolve0
+@pytest.mark.parametrize("meth", ["BICGSTAB_", "CGS_"])
+def test_linsolve0_onchip_is_the_launch_flows_linsolve0(sla, name, meth):
+    """linSolve0 BICGSTAB_ / CGS_ (Sparse.hs:1016-1072) as ONE persistent launch (round 6): step, true residual norm2 ((aa #> x) ^-^ b), test -- on the device,
+    stopping at the first iterate with resnorm <= max tolAbs (tolRel * r0norm) or silently after max_iters (BiCGSTAB: the residual of an iterate rides on
+    the next pass's first synchronisation; CGS: on the step's own second one).  Against the launch flow's linSolve0
     (same stopping rule; inner products grouped differently): same iteration count up to the tolerance's knife edge (+-1), x to 1e-8, the same
     residual trace to 1e-6 relative, and against the oracle's linsolve0."""
     (dims, csr), opts, must = _cases()[name]
@@ -326,13 +328,13 @@ def test_linsolve0_onchip_is_the_launch_flows_linsolve0(sla, name):
     for mode in (1, 0):
         ctx = sla.Context(0).set_options(onchip=mode, **(opts if mode else {}))
         A = sla.fromCSR(dims, *csr, ctx)
-        x, info = sla.linSolve0(sla.BICGSTAB_, A, sla.fromVector(b, ctx), sla.fromVector(x0, ctx), return_info=True, history=True)
+        x, info = sla.linSolve0(getattr(sla, meth), A, sla.fromVector(b, ctx), sla.fromVector(x0, ctx), return_info=True, history=True)
         assert int(ctx.get_option("onchip_launches")) == (1 if mode else 0), ctx.get_option("onchip_plan")
         if mode:
             assert must in ctx.get_option("onchip_plan")
         res[mode] = (x.toDenseListSV(), info)
         # silent return at max_iters (the reference's nits): exactly 3 steps, three residuals in the trace, not converged
-        x3, info3 = sla.linSolve0(sla.BICGSTAB_, A, sla.fromVector(b, ctx), sla.fromVector(x0, ctx), return_info=True, history=True, max_iters=3, tol_abs=0.0, tol_rel=0.0)
+        x3, info3 = sla.linSolve0(getattr(sla, meth), A, sla.fromVector(b, ctx), sla.fromVector(x0, ctx), return_info=True, history=True, max_iters=3, tol_abs=0.0, tol_rel=0.0)
         assert info3["iters"] == 3 and not info3["converged"] and len(info3["history"]) == 3 and (info3["flags"] & 2)
         res[(mode, 3)] = (x3.toDenseListSV(), info3)
         del A
@@ -348,7 +350,7 @@ def test_linsolve0_onchip_is_the_launch_flows_linsolve0(sla, name):
     assert _rel(x1, x0_) <= 20.0 * i1["tol"] / np.linalg.norm(b)                      # both stopped at resnorm <= tol: x agrees to the tolerance's order
     assert len(i1["history"]) == i1["iters"] and i1["history"][-1] == i1["resnorm"]
     assert np.linalg.norm(orc.spmv(Ao, x1) - b) <= i1["tol"] * (1 + 1e-9)          # what it returns IS below the tolerance
-    rc, xo, it_o, res_o, r0_o = orc.linsolve0(orc.BICGSTAB_, Ao, b, x0)
+    rc, xo, it_o, res_o, r0_o = orc.linsolve0(getattr(orc, meth), Ao, b, x0)
     assert rc == orc.OK and abs(i1["iters"] - it_o) <= max(3, it_o // 12) and abs(i1["r0norm"] - r0_o) <= 1e-12 * r0_o
     assert _rel(res[(1, 3)][0], res[(0, 3)][0]) <= 1e-10                            # three steps: same iterate as the launch flow's
     assert np.allclose(res[(1, 3)][1]["history"], res[(0, 3)][1]["history"], rtol=1e-9)
