@@ -61,13 +61,34 @@ struct WvChunk {
     wv_f64x2 vv[PPL];
 };
 // the streaming loads of the chunk [kb, kb + 128 PPL) of a block whose entries end at k1 (clamped, unconditional)
+// -DSLA_WV_STREAM_SCOPE=1 / 2 (experiment, round 6): the streams as agent- / system-scope loads (sc1 / sc0 sc1: they miss in the L1 by definition) instead
+// of non-temporal ones -- does the L1 then keep the x lines the four wavefronts of a workgroup share?
+#ifndef SLA_WV_STREAM_SCOPE
+#define SLA_WV_STREAM_SCOPE 0
+#endif
 template <int PPL>
 __device__ __forceinline__ void wv_load(WvChunk<PPL> &c, const int32_t *__restrict__ col, const double *__restrict__ val, int kb, int k1, int lane) {
     const int kmax = max(0, (min(kb + 128 * PPL, k1) - 1) & ~1);     // last pair that holds a valid entry
+#if SLA_WV_STREAM_SCOPE
+    constexpr auto scope = SLA_WV_STREAM_SCOPE == 1 ? __HIP_MEMORY_SCOPE_AGENT : __HIP_MEMORY_SCOPE_SYSTEM;
+#pragma unroll
+    for (int j = 0; j < PPL; ++j) {
+        const unsigned long long u = __hip_atomic_load((const unsigned long long *)(col + min(kb + 2 * lane + 128 * j, kmax)), __ATOMIC_RELAXED, scope);
+        c.cc[j].x = (int)(unsigned)u;
+        c.cc[j].y = (int)(unsigned)(u >> 32);
+    }
+#pragma unroll
+    for (int j = 0; j < PPL; ++j) {
+        const double *pv = val + min(kb + 2 * lane + 128 * j, kmax);
+        c.vv[j].x = __hip_atomic_load(pv, __ATOMIC_RELAXED, scope);
+        c.vv[j].y = __hip_atomic_load(pv + 1, __ATOMIC_RELAXED, scope);
+    }
+#else
 #pragma unroll
     for (int j = 0; j < PPL; ++j) c.cc[j] = __builtin_nontemporal_load((const wv_i32x2 *)(col + min(kb + 2 * lane + 128 * j, kmax)));
 #pragma unroll
     for (int j = 0; j < PPL; ++j) c.vv[j] = __builtin_nontemporal_load((const wv_f64x2 *)(val + min(kb + 2 * lane + 128 * j, kmax)));
+#endif
 }
 
 // The wave kernel loads entries in aligned PAIRS and gathers x for both halves with no range test: the pair that holds the last
