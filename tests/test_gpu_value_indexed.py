@@ -394,7 +394,7 @@ def test_plane_march_k2_folded_into_k3_same_bits(sla, name, grid):
     x0 = np.full(n, 0.25)
     states, sols, launches = {}, {}, {}
     for f23 in (1, 0):
-        ctx = sla.Context(0).set_options(wd_lds=2, wd_march=2, bicg_fuse23=f23)
+        ctx = sla.Context(0).set_options(wd_lds=2, wd_march=2, bicg_fuse23=f23, onchip=0)   # (onchip = 0: these are tests of the LAUNCH flow's kernels)
         if grid:
             ctx.set_option("spmv_grid", grid)
         A = sla.fromCSR(dims, *csr, ctx)
@@ -439,7 +439,7 @@ def test_plane_march_cgs_c2_folded_into_c3_same_bits(sla, name, grid):
     x0 = np.full(n, 0.25)
     states, sols, launches = {}, {}, {}
     for f23 in (1, 0):
-        ctx = sla.Context(0).set_options(wd_lds=2, wd_march=2, bicg_fuse23=f23)
+        ctx = sla.Context(0).set_options(wd_lds=2, wd_march=2, bicg_fuse23=f23, onchip=0)   # (onchip = 0: these are tests of the LAUNCH flow's kernels)
         if grid:
             ctx.set_option("spmv_grid", grid)
         A = sla.fromCSR(dims, *csr, ctx)
@@ -494,7 +494,7 @@ def test_gather_kernel_k2_folded_into_k3_same_bits(sla, name, grid):
     x0 = np.full(n, 0.25)
     states, sols, launches = {}, {}, {}
     for f23 in (1, 0):
-        ctx = sla.Context(0).set_options(bicg_fuse23=f23, **opts)
+        ctx = sla.Context(0).set_options(bicg_fuse23=f23, onchip=0, **opts)   # (the launch flow's gather kernel: not the on-chip step)
         if grid:
             ctx.set_option("spmv_grid", grid)
         A = sla.fromCSR(dims, *csr, ctx)
