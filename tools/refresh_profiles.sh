@@ -133,6 +133,11 @@ for w in poisson2d_1m laplace3d_slab8 laplace3d_1m; do
   SLA_ONCHIP=0 run launchflow_$w $B --workload $w --no-cpu-baseline --no-extra-blocks
 done
 run onchip_poisson2d_1m_20steps python bench.py --workload poisson2d_1m --steps 20 --warmup 5 --no-cpu-baseline --no-extra-blocks
+# ... cgsStep on chip, and linSolve0 (step + true residual + test in the launch) for both methods, each against the launch flow
+run onchip_cgs_poisson2d_1m $B --workload poisson2d_1m --method cgs --no-cpu-baseline --no-extra-blocks
+SLA_ONCHIP=0 run launchflow_cgs_poisson2d_1m $B --workload poisson2d_1m --method cgs --no-cpu-baseline --no-extra-blocks
+run linsolve0_onchip_poisson2d_1m $B --workload poisson2d_1m --mode linsolve0 --no-cpu-baseline --no-extra-blocks
+SLA_ONCHIP=0 run linsolve0_launchflow_poisson2d_1m $B --workload poisson2d_1m --mode linsolve0 --no-cpu-baseline --no-extra-blocks
 rocprofv3 --kernel-trace --stats --output-format csv -d $S/kso -o ks -- python bench.py --workload poisson2d_1m --steps 200 --warmup 20 --no-cpu-baseline --no-extra-blocks 2>/dev/null | tail -1 > $S/${tag}_bench_traced_run_poisson2d_1m.json
 cp "$(find $S/kso -name '*kernel_stats.csv' | head -1)" $S/${tag}_bench_kernel_stats_poisson2d_1m.csv
 # round 6: the exact tile forms (rows owned by wavefronts / wavefront-private slices) beside the relaxed default on config 3a; the asymmetric pre-flight failure

@@ -80,6 +80,16 @@ def onchip_row(label, name):
 d2 = load("poisson2d_1m")
 print(row("2 (1 M 5-pt Poisson) bicgstabStep" + (" — ONE persistent on-chip launch (round 6)" if d2 and d2.get("onchip") else " (step graph replay)"), d2))
 print(onchip_row("2 (1 M 5-pt Poisson), 200-step window, on-chip against the launch flow", "poisson2d_1m"))
+def pair_row(label, on_name, lf_name):
+    on, lf = load(on_name), load(lf_name)
+    if not on or not on.get("value"):
+        return f"| {label} | — | — | — | — | (no line) |"
+    return (f"| {label} | {on['ms_per_step'] * 1e3:.1f} µs | **{on['value']:.0f}** | one launch | ONCHIP | launch flow on the same box: "
+            f"{(lf or {}).get('ms_per_step', 0) * 1e3:.1f} µs = {(lf or {}).get('value', 0):.0f} it/s |")
+
+
+print(pair_row("2, cgsStep on chip against the launch flow", "onchip_cgs_poisson2d_1m", "launchflow_cgs_poisson2d_1m"))
+print(pair_row("2, `linSolve0 BICGSTAB_` on chip (step + true residual + test per iteration) against the launch flow", "linsolve0_onchip_poisson2d_1m", "linsolve0_launchflow_poisson2d_1m"))
 print(onchip_row("4's per-rank slab at N = 8 (216 × 216 × 27), on-chip against the launch flow", "laplace3d_slab8"))
 print(onchip_row("108³ (1.26 M rows), on-chip against the launch flow", "laplace3d_1m"))
 print(row("5-matrix (2 M banded) bicgstabStep", load("banded_2m")))
