@@ -176,7 +176,16 @@ spmv_wave_kernel(SpmvArgs<int32_t> a, const int32_t *__restrict__ rowptr, const 
         }
     }
     const bool st_nt = st_nt_of(nt);
-    for (int run = first; run < last; run += step)
+    // Experiment of round 6 (option wave_sync, bit 2 of `nt`): the four wavefronts of a workgroup walk ADJACENT blocks, whose x windows near the
+    // diagonal overlap -- but they drift apart, and the L1 fills of x per block (58 lines measured) are those of no sharing at all (54).  A raw
+    // s_barrier at the top of every run keeps them within one block of each other so that their requests for the same x lines meet in the L1
+    // (in flight or resident).  The trip count is made the workgroup's (wavefront 0's): a wavefront without a run left only meets the barrier.
+    const bool wsync = (nt & 4) != 0;
+    const int first0 = first - wave;
+    const int nit = wsync ? (first0 < last ? (last - first0 + step - 1) / step : 0) : (first < last ? (last - first + step - 1) / step : 0);
+    for (int it = 0, run = first; it < nit; ++it, run += step) {
+    if (wsync) __builtin_amdgcn_s_barrier();
+    if (run < last)
     for (int blk = run * rl, bend = min(run * rl + rl, nblk); blk < bend; ++blk) {
         const int r0 = blk * 128;
         // (rowptr carries 192 entries of padding = nnz behind its rows + 1 entries: every index below is readable and rows past the
@@ -281,6 +290,7 @@ spmv_wave_kernel(SpmvArgs<int32_t> a, const int32_t *__restrict__ rowptr, const 
                 wd_epilogue<EPI>(a, prow, prow + 1 < a.rows, yp.x, yp.y, wv, zv, coef, acc1, acc2, st_nt);
             }
         }
+    }
     }
     if constexpr (DEFER) flush();
     if constexpr (EPI == EPI_DOT || EPI == EPI_DOT2 || EPI == EPI_DOT4 || EPI == EPI_RES || EPI == EPI_AXPY_DOT || EPI == EPI_XPBY_NRM) {
@@ -521,7 +531,7 @@ template <int EPI>
 static int launch_wave_t(const sla_csr *A, const SpmvArgs<int32_t> &a, int grid) {
     sla_ctx *c = A->ctx;
     const int nblk = (int)((A->rows + 127) / 128);
-    const int nt = (vec_stream_nt(c, A->rows) ? 1 : 0) | (c->wd_nt_store ? 2 : 0);
+    const int nt = (vec_stream_nt(c, A->rows) ? 1 : 0) | (c->wd_nt_store ? 2 : 0) | (c->wave_sync ? 4 : 0);
     const WvVariant v = wave_variant(A, EPI);
 #define SLA_WV(P, O, R)                                                                                                                    \
     if (v.ppl == P && v.occ == O && v.pre == R)                                                                                            \
