@@ -35,13 +35,15 @@ module Numeric.LinearAlgebra.Sparse.HIP
   , Dev(..), toDev, fromDev
     -- * monomorphic spellings of the class methods (no wrapper)
   , matVecHIP, vecMatHIP, dotHIP, norm2HIP, linSolveHIP, matMatHIP, matMatTHIP
+    -- * what the device does with a matrix (typed, round 6)
+  , FoldKind(..), foldKindHIP
   ) where
 
 import Control.Exception (SomeException, evaluate, try)
 import Control.Monad.Catch (MonadThrow, throwM)
 import Data.IORef
 import qualified Data.IntMap.Strict as IM
-import Data.Int (Int64)
+import Data.Int (Int32, Int64)
 import Foreign
 import Foreign.C.String
 import Foreign.C.Types
@@ -85,6 +87,7 @@ foreign import ccall safe "sla_linsolve0"         c_linsolve0         :: CInt ->
 foreign import ccall safe "sla_arnoldi"           c_arnoldi           :: Ptr Csr -> Ptr Vec -> CInt -> Ptr Double -> Ptr Double -> Ptr CInt -> IO CInt
 foreign import ccall safe "sla_linsolve"          c_linsolve          :: Ptr Csr -> Ptr Vec -> Ptr Vec -> Ptr () -> IO CInt
 foreign import ccall safe "sla_tri_solve"         c_tri_solve         :: Ptr Csr -> CInt -> Ptr Vec -> Ptr Vec -> Ptr Int64 -> IO CInt
+foreign import ccall safe "sla_csr_get_props"     c_csr_get_props     :: Ptr Csr -> Ptr Int32 -> IO CInt
 foreign import ccall unsafe "sla_last_error"      c_last_error        :: IO CString
 
 -- | One GPU by default; SLA_GPUS=n makes every matrix / vector / solver of this module span the first n devices of the
@@ -193,6 +196,21 @@ linSolve0 method aa b x0 = pureThrow $ do
 
 -- | (#>) (Common.hs:242-250): the result holds a key for every row present in the matrix and no others.  The present
 --   rows come out of the row map's keys in ascending order (O(rows)); the dense device result is walked once beside them.
+-- | How @(#>)@ on the lowered matrix adds the products of a row (@sla_fold_kind@, include/sla_hip.h): 'FoldExact' = the reference's ascending left
+--   fold bit for bit (Common.hs:247-260), reruns bit-identical; 'FoldRegrouped' = a fixed regrouping of long rows (within the rounding bound, reruns
+--   bit-identical); 'FoldRelaxed' = order not fixed from run to run (the default tile form of irregular matrices; @SLA_EXACT_FOLD=1@ avoids it).
+data FoldKind = FoldExact | FoldRegrouped | FoldRelaxed deriving (Eq, Show, Enum)
+
+foldKindHIP :: R.SpMatrix Double -> FoldKind
+foldKindHIP aa = unsafePerformIO $ do
+  a <- lower aa
+  -- sla_csr_props: struct_size, fold, x_exchange, nranks :: int32; rows_local, nnz_local :: int64; rowptr_bits, reserved :: int32  (40 bytes)
+  allocaBytes 40 $ \p -> do
+    pokeElemOff p 0 (40 :: Int32)
+    withForeignPtr a $ \pa -> c_csr_get_props pa p >>= check "sla_csr_get_props"
+    k <- peekElemOff p 1
+    return (toEnum (fromIntegral k))
+
 matVecHIP :: R.SpMatrix Double -> R.SpVector Double -> R.SpVector Double
 matVecHIP aa x = unsafePerformIO $ do
   a <- lower aa; vx <- upload x; vy <- zeros (R.nrows aa)
