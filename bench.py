@@ -291,6 +291,10 @@ def exchange_roofline(A, ex, kt, steps_recorded, step_ms, real_links, halo_rides
     return out
 
 
+import threading as _threading
+_TIMED = _threading.local()
+
+
 def timed_steps(ctx, st, steps, warmup, sync_all, event_free=False, conv=None):
     """Warm-up (which also finds the kernel with the largest share of a step), then EXACTLY `steps` timed steps bracketed by
     barrier + sync, with HIP events around the dominant kernel's launches only (events around all five kernels of a
@@ -310,7 +314,7 @@ def timed_steps(ctx, st, steps, warmup, sync_all, event_free=False, conv=None):
         conv["res_before"] = state_residual(ctx, st, st.A.ncols)
     # median and spread.  The timed region is `windows` consecutive windows of EXACTLY `steps` steps, each bracketed by
     # barrier + sync on both sides; the line's `value` is the MEDIAN window (ms_per_step x steps = that window), value_min / value_max the
-    # slowest / fastest one.  timed_steps.windows holds every window's seconds (N > 1: the caller takes the max over ranks per window).
+    # slowest / fastest one.  _TIMED.windows holds every window's seconds (N > 1: the caller takes the max over ranks per window).
     windows = max(1, int(os.environ.get("SLA_BENCH_WINDOWS", "5")))
     sync_all()
     dts = []
@@ -334,7 +338,7 @@ def timed_steps(ctx, st, steps, warmup, sync_all, event_free=False, conv=None):
             sync_all()
             dts.append(time.perf_counter() - t0)
         dom_stats = ctx.prof_stop()
-    timed_steps.windows = dts
+    _TIMED.windows = dts   # (thread-local: the loopback rehearsal runs its ranks as threads of one process)
     dt = sorted(dts)[len(dts) // 2]
     ctx.prof_start(_lib.KERNEL_ALL, steps * 6 + 8)      # untimed: the per-kernel table
     st.step(steps)
@@ -702,8 +706,7 @@ def run_rank(args, rank, world, local_rank, dist_mode, loop=None):
             extra["step_graph"] = False
         if dist_mode:
             extra["exchanges"] = exchange_table(ctx)
-            ghost_flow = "x_exchange=window" in A.kernel_info() and ctx.get_option("bicg_ghost") != "0"
-            extra["exchange_roofline"] = exchange_roofline(A, extra["exchanges"], kt, args.steps, dt / args.steps * 1e3, real_links, ghost_flow)
+            # (exchange_roofline is added below, once `dt` is the median over the ranks' windows -- the step time the line reports)
         launches, mean_ms, min_ms = dom_stats
         step_bytes = 24 * nnz + 160 * n
         mode_desc = f"{'bicgstabStep' if args.method == 'bicgstab' else 'cgsStep'} (2 SpMV, no true-residual SpMV)"
@@ -753,11 +756,14 @@ def run_rank(args, rank, world, local_rank, dist_mode, loop=None):
         extra["linsolve0_iters"] = info.iters
 
     if args.mode == "step":   # (every rank timed the same windows: max over ranks per window, then the median window)
-        wins = [allreduce(w, "max") for w in timed_steps.windows]
+        wins = [allreduce(w, "max") for w in _TIMED.windows]
         dt = sorted(wins)[len(wins) // 2]
         extra["value_windows"] = {"windows": len(wins), "steps_per_window": args.steps, "iters_per_s": [args.steps / w for w in wins],
                                   "note": "value = the median window; each window is exactly `steps` steps between barrier + device synchronisation"}
         extra["value_min"], extra["value_max"] = args.steps / max(wins), args.steps / min(wins)
+        if dist_mode:
+            ghost_flow = "x_exchange=window" in A.kernel_info() and ctx.get_option("bicg_ghost") != "0"
+            extra["exchange_roofline"] = exchange_roofline(A, extra["exchanges"], kt, args.steps, dt / args.steps * 1e3, real_links, ghost_flow)
     else:
         dt = allreduce(dt, "max")
 
