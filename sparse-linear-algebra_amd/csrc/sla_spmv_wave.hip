@@ -222,6 +222,11 @@ spmv_wave_kernel(SpmvArgs<int32_t> a, const int32_t *__restrict__ rowptr, const 
                 if constexpr (kWvAbl & 1) {
                     xa[j] = 1.0 + (double)(cur.cc[j].x & 3);
                     xb[j] = 1.0 + (double)(cur.cc[j].y & 3);
+                } else if constexpr (kWvAbl & 32) {   // (bit 32: only the FAR gathers -- columns outside [r0 - 256, r0 + 384) -- are issued: what an ideal, free
+                                                      // LDS window for the near-diagonal part of a block would leave)
+                    const unsigned da = (unsigned)(cur.cc[j].x - (r0 - 256)), db = (unsigned)(cur.cc[j].y - (r0 - 256));
+                    xa[j] = da < 640u ? 1.0 + (double)(da & 3) : xg[cur.cc[j].x];
+                    xb[j] = db < 640u ? 1.0 + (double)(db & 3) : xg[cur.cc[j].y];
                 } else {
                     xa[j] = xg[cur.cc[j].x];
                     xb[j] = xg[cur.cc[j].y];
