@@ -616,6 +616,7 @@ static std::string ctx_option_value(const sla_ctx *c, const std::string &name, b
     if (name == "x_exchange") return c->x_exchange == 1 ? "allgather" : c->x_exchange == 2 ? "window" : "auto";
     if (name == "onchip_launches") return std::to_string(c->onchip_launches);   // (read-only)
     if (name == "onchip_plan") return c->onchip_note;
+    if (name == "onchip_plan_ms") return std::to_string(c->onchip_plan_ms);   // (read-only) planning time of the last matrix planned
     if (name == "tri_mode_used") return std::to_string(c->tri_mode_used);
     if (name == "tri_plan") return c->tri_plan_note;
     if (name == "tri_fallbacks") return std::to_string(c->tri_fallbacks);   // (read-only: solves that left the persistent triangular kernel)

@@ -268,6 +268,7 @@ struct sla_ctx {
     int onchip_rows = 0;             // ... rows per workgroup at most (0: what the registers hold: 12 x 512; tests force short blocks)
     int onchip_bricks = 1;           // ... 1: bricks where consecutive rows do not fit (3-D stencils), 2: bricks wherever the stencil allows them, 0: never
     long onchip_launches = 0;        // (read-only) persistent launches so far (sla_ctx_get_option "onchip_launches")
+    double onchip_plan_ms = 0.0;     // (read-only) what the last on-chip plan cost to build
     std::string onchip_note;         // (read-only) the last plan's shape or the reason there is none ("onchip_plan")
     int tri_block_rows = 16384;      // tri_syncfree = 2: rows per block (<= kTriBlockRows: the block's x sits in LDS; small values are for the tests)
     int tri_syncfree = 3;            // triLowerSolve / triUpperSolve: 0 one launch per dependency level, 1 one persistent launch whose rows poll x in memory, 2 the block-local persistent launch (sla_tri.hip), 3 pick 2 or 0 by the schedule's shape (sla_precond.cpp)
@@ -403,6 +404,7 @@ struct OcPlan {
     double *d_parts = nullptr;       // [4][G] partial sums
     unsigned *d_bar = nullptr;       // barrier words (zeroed in front of every launch)
     size_t lds_bytes = 0;
+    double build_ms = 0.0;           // what planning cost (host threads + uploads); sla_ctx_get_option "onchip_plan_ms"
     int kstate[4] = {1, 0, 0, 0};    // per kernel (bicgstabStep -- asked by the plan builder --, linSolve0 BICGSTAB_, cgsStep, linSolve0 CGS_): 0 not asked yet, 1 resident, -1 declined
     std::string knote[4];            // ... and why
 };

@@ -21,6 +21,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstring>
 
@@ -752,61 +754,79 @@ static void build_plan(sla_csr *A, OcPlan &pl) {
     }
     if (!have) { pl.note = why0; return; }
     // ---- blocks: (row, local cell) lists ----
+    // (everything per block below runs on the library's host threads -- par_rows over the blocks: the plan of a 1 M-row matrix took 48 ms on one
+    // thread, five times the 200 iterations of the linSolve0 call that asked for it)
     std::vector<std::vector<std::pair<int32_t, int32_t>>> blocks;
     if (g.mode == 0) {
         blocks.resize((size_t)g.G);
-        for (int b = 0; b < g.G; ++b) {
-            const int64_t r0 = (int64_t)b * g.R, r1 = std::min(n, r0 + g.R);
-            blocks[(size_t)b].reserve((size_t)(r1 - r0));
-            for (int64_t i = r0; i < r1; ++i) blocks[(size_t)b].push_back({(int32_t)i, (int32_t)(-lo + (i - r0))});
-        }
+        par_rows(g.G, 1, [&](int, int64_t b0, int64_t b1) {
+            for (int64_t b = b0; b < b1; ++b) {
+                const int64_t r0 = b * g.R, r1 = std::min(n, r0 + g.R);
+                auto &blk = blocks[(size_t)b];
+                blk.resize((size_t)(r1 - r0));
+                for (int64_t i = r0; i < r1; ++i) blk[(size_t)(i - r0)] = {(int32_t)i, (int32_t)(-lo + (i - r0))};
+            }
+        }, 2);
     } else {
         const int LX = g.bx + 2, LY = g.by + 2, zpad = g.nz > 1 ? 1 : 0;
+        struct Org { int64_t x0, y0, z0; };
+        std::vector<Org> orgs;
         for (int64_t z0 = 0; z0 < g.nz; z0 += g.bz)
             for (int64_t y0 = 0; y0 < g.ny; y0 += g.by)
-                for (int64_t x0 = 0; x0 < g.nx; x0 += g.bx) {
-                    std::vector<std::pair<int32_t, int32_t>> blk;
-                    for (int64_t z = z0; z < std::min<int64_t>(g.nz, z0 + g.bz); ++z)
-                        for (int64_t y = y0; y < std::min<int64_t>(g.ny, y0 + g.by); ++y)
-                            for (int64_t x = x0; x < std::min<int64_t>(g.nx, x0 + g.bx); ++x) {
-                                const int64_t row = (z * g.ny + y) * g.nx + x;
-                                if (row < n) blk.push_back({(int32_t)row, (int32_t)(((z - z0 + zpad) * LY + (y - y0 + 1)) * LX + (x - x0 + 1))});
-                            }
-                    if (!blk.empty()) blocks.push_back(std::move(blk));
-                }
+                for (int64_t x0 = 0; x0 < g.nx; x0 += g.bx)
+                    if ((z0 * g.ny + y0) * g.nx + x0 < n) orgs.push_back({x0, y0, z0});   // (a brick's first cell is its lowest row: the brick holds a row iff that one exists)
+        blocks.resize(orgs.size());
+        par_rows((int64_t)orgs.size(), 1, [&](int, int64_t q0, int64_t q1) {
+            for (int64_t q = q0; q < q1; ++q) {
+                const Org o = orgs[(size_t)q];
+                auto &blk = blocks[(size_t)q];
+                for (int64_t z = o.z0; z < std::min<int64_t>(g.nz, o.z0 + g.bz); ++z)
+                    for (int64_t y = o.y0; y < std::min<int64_t>(g.ny, o.y0 + g.by); ++y)
+                        for (int64_t x = o.x0; x < std::min<int64_t>(g.nx, o.x0 + g.bx); ++x) {
+                            const int64_t row = (z * g.ny + y) * g.nx + x;
+                            if (row < n) blk.push_back({(int32_t)row, (int32_t)(((z - o.z0 + zpad) * LY + (y - o.y0 + 1)) * LX + (x - o.x0 + 1))});
+                        }
+            }
+        }, 2);
         g.G = (int)blocks.size();
         if (g.G > cus) { pl.note = "brick count exceeds the workgroups"; return; }
     }
     // ---- halo cells, boundary rows; every entry must land on the cell that mirrors its column ----
     const int G = g.G, L = g.L;
-    std::vector<uint8_t> needed((size_t)n, 0);
+    std::vector<uint8_t> needed((size_t)n, 0);   // (set from several threads: a byte that only ever becomes 1 -- relaxed atomic stores)
     std::vector<std::vector<std::pair<int32_t, int32_t>>> halos((size_t)G);
-    std::vector<int32_t> cell_row((size_t)L, -1);
     int64_t own_max = 0, halo_max = 0;
-    for (int b = 0; b < G; ++b) {
-        auto &blk = blocks[(size_t)b];
-        for (auto &rc : blk) cell_row[(size_t)rc.second] = rc.first;
-        bool bad = false;
-        for (auto &rc : blk) {
-            const unsigned m = mask[(size_t)rc.first];
-            for (int k = 0; k < np && !bad; ++k)
-                if ((m >> k) & 1) {
-                    const int64_t cc = (int64_t)rc.second + g.loff[k], col = (int64_t)rc.first + off[k];
-                    if (cc < 0 || cc >= L || col < 0 || col >= n) { bad = true; break; }
-                    if (cell_row[(size_t)cc] < 0) {
-                        cell_row[(size_t)cc] = (int32_t)col;
-                        halos[(size_t)b].push_back({(int32_t)cc, (int32_t)col});
-                        needed[(size_t)col] = 1;
-                    } else if (cell_row[(size_t)cc] != col) {
-                        bad = true;
+    std::atomic<int> any_bad{0};
+    par_rows(G, 1, [&](int, int64_t b0, int64_t b1) {
+        std::vector<int32_t> cell_row((size_t)L, -1);   // this thread's scratch: which row a local cell mirrors in the block under way
+        for (int64_t b = b0; b < b1; ++b) {
+            auto &blk = blocks[(size_t)b];
+            for (auto &rc : blk) cell_row[(size_t)rc.second] = rc.first;
+            bool bad = false;
+            for (auto &rc : blk) {
+                const unsigned m = mask[(size_t)rc.first];
+                for (int k = 0; k < np && !bad; ++k)
+                    if ((m >> k) & 1) {
+                        const int64_t cc = (int64_t)rc.second + g.loff[k], col = (int64_t)rc.first + off[k];
+                        if (cc < 0 || cc >= L || col < 0 || col >= n) { bad = true; break; }
+                        if (cell_row[(size_t)cc] < 0) {
+                            cell_row[(size_t)cc] = (int32_t)col;
+                            halos[(size_t)b].push_back({(int32_t)cc, (int32_t)col});
+                            __atomic_store_n(&needed[(size_t)col], (uint8_t)1, __ATOMIC_RELAXED);
+                        } else if (cell_row[(size_t)cc] != col) {
+                            bad = true;
+                        }
                     }
-                }
-            if (bad) break;
+                if (bad) break;
+            }
+            for (auto &rc : blk) cell_row[(size_t)rc.second] = -1;
+            for (auto &h : halos[(size_t)b]) cell_row[(size_t)h.first] = -1;
+            if (bad) any_bad.store(1, std::memory_order_relaxed);
         }
-        for (auto &rc : blk) cell_row[(size_t)rc.second] = -1;
-        for (auto &h : halos[(size_t)b]) cell_row[(size_t)h.first] = -1;
-        if (bad) { pl.note = "an entry's column is not where the local cell layout expects it (a wrapped or irregular stencil)"; return; }
-        own_max = std::max<int64_t>(own_max, (int64_t)blk.size());
+    }, 2);
+    if (any_bad.load()) { pl.note = "an entry's column is not where the local cell layout expects it (a wrapped or irregular stencil)"; return; }
+    for (int b = 0; b < G; ++b) {
+        own_max = std::max<int64_t>(own_max, (int64_t)blocks[(size_t)b].size());
         halo_max = std::max<int64_t>(halo_max, (int64_t)halos[(size_t)b].size());
     }
     const int rpt = rpt_class(own_max), hpt = hpt_class(std::max<int64_t>(halo_max, 1));
@@ -817,33 +837,45 @@ static void build_plan(sla_csr *A, OcPlan &pl) {
     std::vector<int32_t> slot_of((size_t)n, 0);
     int64_t nbound = 0;
     const unsigned fullm = (1u << np) - 1;
-    for (int b = 0; b < G; ++b) {
-        auto &blk = blocks[(size_t)b];
-        size_t j = (size_t)b * rpt * T;
-        for (size_t q = 0; q < (size_t)rpt * T; ++q) own_cm[j + q] = (uint32_t)blk[0].second;   // (no row: mask 0, a cell to read around)
-        // boundary rows first (their write-through stores are in flight while the rest is folded), rows with all their entries last
-        // (whole wavefronts of interior rows skip the mask tests)
-        std::stable_sort(blk.begin(), blk.end(), [&](const std::pair<int32_t, int32_t> &u, const std::pair<int32_t, int32_t> &v) {
-            const int ku = needed[(size_t)u.first] ? 0 : (mask[(size_t)u.first] == fullm ? 2 : 1), kv = needed[(size_t)v.first] ? 0 : (mask[(size_t)v.first] == fullm ? 2 : 1);
-            return ku < kv;
-        });
-        for (auto &rc : blk) {
-            own_cm[j] = (uint32_t)rc.second | ((uint32_t)mask[(size_t)rc.first] << 16) | ((uint32_t)needed[(size_t)rc.first] << 24) | (1u << 25);
-            own_row[j] = rc.first;
-            slot_of[(size_t)rc.first] = (int32_t)j;
-            nbound += needed[(size_t)rc.first];
-            ++j;
+    std::atomic<long long> nbound_a{0};
+    par_rows(G, 1, [&](int, int64_t b0, int64_t b1) {
+        long long nb = 0;
+        for (int64_t b = b0; b < b1; ++b) {
+            auto &blk = blocks[(size_t)b];
+            size_t j = (size_t)b * rpt * T;
+            for (size_t q = 0; q < (size_t)rpt * T; ++q) own_cm[j + q] = (uint32_t)blk[0].second;   // (no row: mask 0, a cell to read around)
+            // boundary rows first (their write-through stores are in flight while the rest is folded), rows with all their entries last
+            // (whole wavefronts of interior rows skip the mask tests): a stable three-way partition of the block's rows
+            std::vector<std::pair<int32_t, int32_t>> ord;
+            ord.reserve(blk.size());
+            for (int cls = 0; cls < 3; ++cls)
+                for (auto &rc : blk) {
+                    const int kc = needed[(size_t)rc.first] ? 0 : (mask[(size_t)rc.first] == fullm ? 2 : 1);
+                    if (kc == cls) ord.push_back(rc);
+                }
+            blk.swap(ord);
+            for (auto &rc : blk) {
+                own_cm[j] = (uint32_t)rc.second | ((uint32_t)mask[(size_t)rc.first] << 16) | ((uint32_t)needed[(size_t)rc.first] << 24) | (1u << 25);
+                own_row[j] = rc.first;
+                slot_of[(size_t)rc.first] = (int32_t)j;
+                nb += needed[(size_t)rc.first];
+                ++j;
+            }
         }
-    }
-    for (int b = 0; b < G; ++b) {
-        size_t j = (size_t)b * hpt * T;
-        for (auto &h : halos[(size_t)b]) {
-            halo_cell[j] = (uint32_t)h.first;
-            halo_row[j] = h.second;
-            halo_src[j] = slot_of[(size_t)h.second];
-            ++j;
+        nbound_a.fetch_add(nb, std::memory_order_relaxed);
+    }, 2);
+    nbound = nbound_a.load();
+    par_rows(G, 1, [&](int, int64_t b0, int64_t b1) {
+        for (int64_t b = b0; b < b1; ++b) {
+            size_t j = (size_t)b * hpt * T;
+            for (auto &h : halos[(size_t)b]) {
+                halo_cell[j] = (uint32_t)h.first;
+                halo_row[j] = h.second;
+                halo_src[j] = slot_of[(size_t)h.second];
+                ++j;
+            }
         }
-    }
+    }, 2);
     // ---- co-residency: one workgroup per CU must be resident for the counter barrier to complete ----
     const void *kern = oc_kernel(rpt, hpt, np);
     const size_t lds = oc_lds_bytes(L);
@@ -901,13 +933,16 @@ bool onchip_usable(sla_solver *S, bool res) {
     sla_csr *A = S->A;
     if (!A->oc) {
         A->oc = new OcPlan();
+        const auto t0 = std::chrono::steady_clock::now();
         try {
             build_plan(A, *A->oc);
         } catch (...) {
             A->oc->ok = false;
             A->oc->note = "host allocation failed while planning";
         }
-        if (getenv("SLA_DEBUG_ONCHIP")) fprintf(stderr, "[sla] %s\n", A->oc->note.c_str());
+        A->oc->build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        if (getenv("SLA_DEBUG_ONCHIP")) fprintf(stderr, "[sla] %s (planned in %.1f ms)\n", A->oc->note.c_str(), A->oc->build_ms);
+        c->onchip_plan_ms = A->oc->build_ms;
     }
     c->onchip_note = A->oc->note;
     if (!A->oc->ok) return false;
