@@ -536,6 +536,7 @@ const IntKnob kIntKnobs[] = {
     {"tile_depth", &sla_ctx::tile_depth, 0, 2},
     {"onchip", &sla_ctx::onchip, 0, 2},
     {"onchip_grid", &sla_ctx::onchip_grid, 0, 4096},
+    {"onchip_sync", &sla_ctx::onchip_sync, 0, 1},
     {"onchip_rows", &sla_ctx::onchip_rows, 0, 1 << 20},
     {"onchip_bricks", &sla_ctx::onchip_bricks, 0, 2},
     {"tri_syncfree", &sla_ctx::tri_syncfree, 0, 3},

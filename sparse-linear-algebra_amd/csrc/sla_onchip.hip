@@ -53,6 +53,7 @@ struct OcArgs {
     unsigned *bar;
     SolverScalars *sc;
     int par, k;
+    int sync;                  // 0: counter barrier (XCD-hierarchical), 1: epoch words polled by everybody
 };
 
 __device__ __forceinline__ void st_agent(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -63,8 +64,16 @@ __device__ __forceinline__ double ld_agent(const double *p) { return __hip_atomi
 // fixed tree, lane 0 publishes them in parts[k * G + b], drains that store too and arrives: workgroups with equal b % 8 (observed: one
 // XCD) share an arrival counter, the last arriver of a group bumps the top counter, the last group releases everybody through per-group
 // generation words.  Returns false when the other workgroups did not show up (a co-residency failure: sc->flags gets SLA_FLAG_SYNC_TIMEOUT).
+// flags (round 6, second half; option onchip_sync = 1; NOT the default -- measured slower, see below): ONE hop instead of three.  Every workgroup owns an epoch word; it publishes its
+// partial sums, drains them, stores the epoch into its word -- and the first wavefront of every workgroup polls all G words (one 16-byte
+// load per lane) until none is behind.  No atomic read-modify-write stands on the path (the counters cost two dependent atomics and a
+// release store); the sums are read afterwards exactly as before, so the bits do not change.  MEASURED (config 2, same box): BiCGSTAB 17.4 us per step against
+// 14.6 with the counters, CGS 15.1 against 12.05, linSolve0 22.3 against 18.8 -- every round of polling is 256 x 256 agent-scope loads on the memory side,
+// which costs more than the two dependent atomics it removes.  The counters stay.
+// `parts` is the buffer of THIS epoch's parity in both modes: a workgroup that is already past the barrier publishes its next partial sums
+// into the other half, never into the one a slower workgroup may still be reading.
 template <int K>
-__device__ __forceinline__ bool oc_grid_sync(unsigned *bar, unsigned epoch, SolverScalars *sc, const double *red, double *parts, int *s_ok) {
+__device__ __forceinline__ bool oc_grid_sync(unsigned *bar, unsigned epoch, SolverScalars *sc, const double *red, double *parts, int *s_ok, int flags_mode) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x < 64) {
@@ -76,7 +85,32 @@ __device__ __forceinline__ bool oc_grid_sync(unsigned *bar, unsigned epoch, Solv
             for (int off = NW / 2; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
             if (threadIdx.x == 0) st_agent(parts + (size_t)k * G + blockIdx.x, s);
         }
-        if (threadIdx.x == 0) {
+        if (flags_mode) {
+            unsigned *words = bar + 32 * 17;   // G <= 256 epoch words behind the counters' block
+            if (threadIdx.x == 0) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(words + blockIdx.x, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            const int lane = threadIdx.x;
+            int ok = 1;
+            const long long t0 = wall_clock64();
+            for (;;) {
+                bool behind = false;
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const int j = lane + 64 * m;
+                    if (j < G) behind |= __hip_atomic_load(words + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch;
+                }
+                if (__builtin_amdgcn_ballot_w64(behind) == 0) break;
+                __builtin_amdgcn_s_sleep(1);
+                if (wall_clock64() - t0 > 200000000ll) {
+                    if (lane == 0) __hip_atomic_fetch_or(&sc->flags, (int)SLA_FLAG_SYNC_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ok = 0;
+                    break;
+                }
+            }
+            if (lane == 0) *s_ok = ok;
+        } else if (threadIdx.x == 0) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const unsigned Gu = gridDim.x, g = blockIdx.x & 7, ng = Gu < 8 ? Gu : 8;
             const unsigned members = (Gu - g + 7) / 8;
@@ -249,10 +283,11 @@ __global__ void __launch_bounds__(T) oc_bicgstab_kernel(OcArgs a) {
                 if ((t & 63) == 0) red[NW + wave] = acr;
             }
         }
-        if (!oc_grid_sync<RES ? 2 : 1>(a.bar, ++epoch, sc, red, a.parts, &s_ok)) return;
+        ++epoch;
+        if (!oc_grid_sync<RES ? 2 : 1>(a.bar, epoch, sc, red, a.parts + (size_t)(epoch & 1) * 4 * G, &s_ok, a.sync)) return;
         if constexpr (RES) {
             if (step > 0) {   // runIter's test (:1047-1050) on the iterate after `step` steps
-                const double rn = sqrt(oc_wave_total(a.parts + G, G));
+                const double rn = sqrt(oc_wave_total(a.parts + (size_t)(epoch & 1) * 4 * G + G, G));
                 conv = rn <= tol;
                 if (b == 0 && t == 0) {
                     const int it = it0 + step;
@@ -268,7 +303,7 @@ __global__ void __launch_bounds__(T) oc_bicgstab_kernel(OcArgs a) {
         {
 #pragma unroll
             for (int i = 0; i < HPT; ++i) hap[i] = ld_agent(a.pubA + hg[i]);
-            alpha = rho / oc_wave_total(a.parts, G);
+            alpha = rho / oc_wave_total(a.parts + (size_t)(epoch & 1) * 4 * G, G);
 #pragma unroll
             for (int i = 0; i < HPT; ++i) S[hc[i]] = __builtin_fma(-alpha, hap[i], S[hc[i]]);
 #pragma unroll
@@ -297,7 +332,8 @@ __global__ void __launch_bounds__(T) oc_bicgstab_kernel(OcArgs a) {
                 if ((t & 63) == 0) red[NW * k + wave] = q[k];
             }
         }
-        if (!oc_grid_sync<4>(a.bar, ++epoch, sc, red, a.parts, &s_ok)) return;
+        ++epoch;
+        if (!oc_grid_sync<4>(a.bar, epoch, sc, red, a.parts + (size_t)(epoch & 1) * 4 * G, &s_ok, a.sync)) return;
         // ---- K4 + K5 on own + halo cells: omegaj ; xj1 = x ^+^ alphaj .* p ^+^ omegaj .* sj ; rj1 = sj ^-^ omegaj .* aasj ;
         //      betaj = rho' / rho * alphaj / omegaj with rho' = sj . r0hat - omegaj (aasj . r0hat) ; pj1 = rj1 ^+^ betaj .* (p ^-^ omegaj .* aap) ----
         {
@@ -306,7 +342,7 @@ __global__ void __launch_bounds__(T) oc_bicgstab_kernel(OcArgs a) {
             for (int i = 0; i < HPT; ++i) has[i] = ld_agent(a.pubS + hg[i]);
             double q[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) q[k] = oc_wave_total(a.parts + (size_t)k * G, G);
+            for (int k = 0; k < 4; ++k) q[k] = oc_wave_total(a.parts + (size_t)(epoch & 1) * 4 * G + (size_t)k * G, G);
             omega = q[0] / q[1];
             const double rn = q[3] - omega * q[2];
             beta = rn / rho * alpha / omega;
@@ -463,13 +499,14 @@ __global__ void __launch_bounds__(T) oc_cgs_kernel(OcArgs a) {
             acc = wave_sum(acc);
             if ((t & 63) == 0) red[wave] = acc;
         }
-        if (!oc_grid_sync<1>(a.bar, ++epoch, sc, red, a.parts, &s_ok)) return;
+        ++epoch;
+        if (!oc_grid_sync<1>(a.bar, epoch, sc, red, a.parts + (size_t)(epoch & 1) * 4 * G, &s_ok, a.sync)) return;
         // ---- C2 on own + halo cells: alphaj ; q = u ^-^ alphaj .* aap ; uq = u ^+^ q ; xj1 = x ^+^ alphaj .* uq ----
         {
             double hap[HPT];
 #pragma unroll
             for (int i = 0; i < HPT; ++i) hap[i] = ld_agent(a.pubA + hg[i]);
-            alpha = rho / oc_wave_total(a.parts, G);
+            alpha = rho / oc_wave_total(a.parts + (size_t)(epoch & 1) * 4 * G, G);
 #pragma unroll
             for (int i = 0; i < HPT; ++i) {
                 hq[i] = __builtin_fma(-alpha, hap[i], hu[i]);
@@ -512,9 +549,10 @@ __global__ void __launch_bounds__(T) oc_cgs_kernel(OcArgs a) {
                 if ((t & 63) == 0) red[NW + wave] = acr;
             }
         }
-        if (!oc_grid_sync<RES ? 2 : 1>(a.bar, ++epoch, sc, red, a.parts, &s_ok)) return;
+        ++epoch;
+        if (!oc_grid_sync<RES ? 2 : 1>(a.bar, epoch, sc, red, a.parts + (size_t)(epoch & 1) * 4 * G, &s_ok, a.sync)) return;
         if constexpr (RES) {   // runIter's test on the iterate after step + 1 steps (the state record is completed below either way)
-            const double rn = sqrt(oc_wave_total(a.parts + G, G));
+            const double rn = sqrt(oc_wave_total(a.parts + (size_t)(epoch & 1) * 4 * G + G, G));
             conv = rn <= tol;
             if (b == 0 && t == 0) {
                 const int it = it0 + step + 1;
@@ -529,7 +567,7 @@ __global__ void __launch_bounds__(T) oc_cgs_kernel(OcArgs a) {
             double hr[HPT];
 #pragma unroll
             for (int i = 0; i < HPT; ++i) hr[i] = ld_agent(a.pubS + hg[i]);   // r1 of the halo cells, from their owners
-            const double rn = oc_wave_total(a.parts, G);
+            const double rn = oc_wave_total(a.parts + (size_t)(epoch & 1) * 4 * G, G);
             beta = rn / rho;
             rho = rn;
 #pragma unroll
@@ -892,7 +930,7 @@ static void build_plan(sla_csr *A, OcPlan &pl) {
                up((void **)&pl.d_halo_cell, halo_cell.data(), halo_cell.size() * 4) && up((void **)&pl.d_halo_row, halo_row.data(), halo_row.size() * 4) &&
                up((void **)&pl.d_halo_src, halo_src.data(), halo_src.size() * 4);
     okd = okd && dev_malloc(c, (void **)&pl.d_pubA, sizeof(double) * own_cm.size()) == hipSuccess && dev_malloc(c, (void **)&pl.d_pubS, sizeof(double) * own_cm.size()) == hipSuccess &&
-          dev_malloc(c, (void **)&pl.d_parts, sizeof(double) * 4 * (size_t)G) == hipSuccess && dev_malloc(c, (void **)&pl.d_bar, sizeof(unsigned) * 32 * 17) == hipSuccess;
+          dev_malloc(c, (void **)&pl.d_parts, sizeof(double) * 8 * (size_t)G) == hipSuccess && dev_malloc(c, (void **)&pl.d_bar, sizeof(unsigned) * (32 * 17 + 256)) == hipSuccess;
     if (!okd) { (void)hipGetLastError(); pl.note = "device allocation of the plan failed"; return; }
     pl.G = G; pl.L = L; pl.rpt = rpt; pl.hpt = hpt; pl.np = np; pl.mode = g.mode;
     pl.bx = g.bx; pl.by = g.by; pl.bz = g.bz;
@@ -992,9 +1030,10 @@ int launch_onchip_steps(sla_solver *S, int par, int k, bool res) {
     a.sc = S->d_sc;
     a.par = par;
     a.k = k;
+    a.sync = c->onchip_sync;
     const void *kern = oc_pick(S->method, res, pl);
     if (!kern) return fail(SLA_ERR_INVALID, "launch_onchip_steps: no instantiation for this plan");
-    SLA_HIP_TRY(hipMemsetAsync(pl.d_bar, 0, sizeof(unsigned) * 32 * 17, stream_of(c)));
+    SLA_HIP_TRY(hipMemsetAsync(pl.d_bar, 0, sizeof(unsigned) * (32 * 17 + 256), stream_of(c)));
     ProfScope prof(c, SLA_KERNEL_ONCHIP, true);
     void *params[] = {&a};
     const size_t lds = oc_lds_bytes(pl.L, res);
