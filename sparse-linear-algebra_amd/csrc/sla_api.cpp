@@ -537,6 +537,7 @@ const IntKnob kIntKnobs[] = {
     {"onchip", &sla_ctx::onchip, 0, 2},
     {"onchip_grid", &sla_ctx::onchip_grid, 0, 4096},
     {"onchip_sync", &sla_ctx::onchip_sync, 0, 1},
+    {"onchip_fault", &sla_ctx::onchip_fault, 0, 1},
     {"onchip_rows", &sla_ctx::onchip_rows, 0, 1 << 20},
     {"onchip_bricks", &sla_ctx::onchip_bricks, 0, 2},
     {"tri_syncfree", &sla_ctx::tri_syncfree, 0, 3},
@@ -616,6 +617,7 @@ static std::string ctx_option_value(const sla_ctx *c, const std::string &name, b
     if (name == "device_coo_min") return std::to_string(c->device_coo_min);
     if (name == "x_exchange") return c->x_exchange == 1 ? "allgather" : c->x_exchange == 2 ? "window" : "auto";
     if (name == "onchip_launches") return std::to_string(c->onchip_launches);   // (read-only)
+    if (name == "onchip_fallbacks") return std::to_string(c->onchip_fallbacks);   // (read-only)
     if (name == "onchip_plan") return c->onchip_note;
     if (name == "onchip_plan_ms") return std::to_string(c->onchip_plan_ms);   // (read-only) planning time of the last matrix planned
     if (name == "tri_mode_used") return std::to_string(c->tri_mode_used);

@@ -266,6 +266,8 @@ struct sla_ctx {
                                      // launch (sla_onchip.hip; SLA_ONCHIP: 0 never, 1 when the plan says it fits, 2 the same and a plan failure is an error: tests)
     int onchip_sync = 0;             // ... its grid-wide synchronisation: 0 = XCD-hierarchical arrival counters (default), 1 = one epoch word per workgroup polled by everybody
                                      // (one hop on paper; measured SLOWER: 17.4 against 14.6 us per BiCGSTAB step at 1 M rows -- 256 x 256 scoped polling loads per round)
+    int onchip_fault = 0;            // test hook: 1 = the last workgroup of an on-chip launch leaves at once (the others' barrier times out after 2 s: a lost CU, rehearsed)
+    long onchip_fallbacks = 0;       // (read-only) linSolve0 calls re-run on the launch flow after an on-chip launch reported SLA_FLAG_SYNC_TIMEOUT
     int onchip_grid = 0;             // ... its workgroups at most (0: one per CU; tests use small grids)
     int onchip_rows = 0;             // ... rows per workgroup at most (0: what the registers hold: 12 x 512; tests force short blocks)
     int onchip_bricks = 1;           // ... 1: bricks where consecutive rows do not fit (3-D stencils), 2: bricks wherever the stencil allows them, 0: never

@@ -54,6 +54,7 @@ struct OcArgs {
     SolverScalars *sc;
     int par, k;
     int sync;                  // 0: counter barrier (XCD-hierarchical), 1: epoch words polled by everybody
+    int fault;                 // test hook (option onchip_fault): the last workgroup leaves at once -- the others' barrier times out (a lost CU, rehearsed)
 };
 
 __device__ __forceinline__ void st_agent(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -165,6 +166,7 @@ __global__ void __launch_bounds__(T) oc_bicgstab_kernel(OcArgs a) {
     const int b = blockIdx.x, t = threadIdx.x, G = gridDim.x, wave = t >> 6;
     SolverScalars *sc = a.sc;
     if (sc->done) return;   // (written by an earlier launch: every workgroup takes the same exit)
+    if (a.fault && b == G - 1) return;
     // Branch-free slots: a slot without a row (short blocks) has pair mask 0, boundary 0, an in-range cell to read around and zeros
     // for its state, and writes to the dummy cell; a halo slot without a cell reads row 0 and writes the dummy cell.
     uint32_t cm[RPT];
@@ -401,6 +403,7 @@ __global__ void __launch_bounds__(T) oc_cgs_kernel(OcArgs a) {
     const int b = blockIdx.x, t = threadIdx.x, G = gridDim.x, wave = t >> 6;
     SolverScalars *sc = a.sc;
     if (sc->done) return;
+    if (a.fault && b == G - 1) return;
     uint32_t cm[RPT];
     double x[RPT], rh[RPT], r[RPT], p[RPT], u[RPT], q[RPT];   // (q: aap until alpha is known, then q)
     const int np = NP ? NP : a.np;
@@ -1031,6 +1034,7 @@ int launch_onchip_steps(sla_solver *S, int par, int k, bool res) {
     a.par = par;
     a.k = k;
     a.sync = c->onchip_sync;
+    a.fault = c->onchip_fault;
     const void *kern = oc_pick(S->method, res, pl);
     if (!kern) return fail(SLA_ERR_INVALID, "launch_onchip_steps: no instantiation for this plan");
     SLA_HIP_TRY(hipMemsetAsync(pl.d_bar, 0, sizeof(unsigned) * (32 * 17 + 256), stream_of(c)));

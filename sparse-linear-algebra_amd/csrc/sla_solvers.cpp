@@ -1049,7 +1049,14 @@ int sla_linsolve0(int method, sla_csr_t A, sla_vec_t b, sla_vec_t x0, const sla_
         if (o.true_residual && o.max_iters > 0 && c->onchip != 0 && onchip_usable(S, true)) {
             rc = launch_onchip_steps(S, ctl_of(S).step_index & 1, o.max_iters, true);
             if (rc == SLA_OK) rc = read_scalars(S);
-            if (rc == SLA_OK) {
+            if (rc == SLA_OK && (S->h_sc->flags & SLA_FLAG_SYNC_TIMEOUT)) {
+                // The launch lost its co-residency (a workgroup never arrived: another job on the device holding a CU): its state is not to be
+                // trusted.  linSolve0 owns this record -- build it again from b and x0 and let the launch flow below do the solve.
+                c->onchip_fallbacks += 1;
+                sla_solver_destroy(S);
+                S = nullptr;
+                SLA_TRY(solver_init_common(method, A, b, x0, o.tol_abs, o.tol_rel, &S, hist_cap));
+            } else if (rc == SLA_OK) {
                 ctl_of(S).step_index += S->h_sc->iters;
                 total = o.max_iters;   // (done, or max_iters steps taken: either way the loop below has nothing left to do)
             }

