@@ -492,6 +492,7 @@ const IntKnob kIntKnobs[] = {
     {"stream_wave", &sla_ctx::stream_wave, 0, 1999},
     {"wave_run", &sla_ctx::wave_run, 1, 4096},
     {"wave_flat", &sla_ctx::wave_flat, 0, 1},
+    {"wave_cc", &sla_ctx::wave_cc, 0, 4096},
     {"wave_sync", &sla_ctx::wave_sync, 0, 1},
     {"stream_wide", &sla_ctx::stream_wide, 0, 1},
     {"diag", &sla_ctx::diag, 0, 2},

@@ -497,6 +497,160 @@ spmv_wave_flat_kernel(SpmvArgs<int32_t> a, const int32_t *__restrict__ rowptr, c
     spmv_extra_partials<EPI>(a, s_red, tid);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// CONTINUOUS CHUNKS (round 6, option wave_cc): the chunk walk decoupled from the blocks.  In spmv_wave_kernel every 128-row block starts a chunk of
+// its own, so a block of E entries costs ceil(E / CH) chunk iterations -- 4 for the 3175 entries of a block of the FEM-shaped matrix (e05r0000 tiled),
+// the last one nearly empty, and an iteration costs about the same full or empty (measured: 512-entry chunks, 7 per block, run 881 us where 1024-entry
+// ones, 4 per block, run 695).  Here a wavefront walks RUNS of `rl` consecutive blocks and streams the run's entries -- contiguous in the CSR
+// arrays -- in back-to-back chunks: E_run / CH iterations, one partial chunk per RUN.  A chunk may hold the end of one block and the start of the
+// next (or several short blocks): the fold loops over the blocks that intersect it; a block that ends inside the chunk is finished on the spot
+// (row-pair transpose through its own LDS words, epilogue, store) and the next one takes over the lanes -- its row starts and operands were fetched
+// while its predecessor was being folded.  Same loads, same products, same per-row fold order, same epilogue: bit-identical to spmv_wave_kernel.
+template <int EPI, int PPL, int OCC>
+__global__ void __launch_bounds__(kBlock, OCC)
+spmv_wave_cc_kernel(SpmvArgs<int32_t> a, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col, const double *__restrict__ val,
+                    const double *__restrict__ xg, int nblk, int xcd_remap, int nt, int rl) {
+    constexpr int CH = 128 * PPL;
+    __shared__ double s_prod[kBlock / 64][CH];
+    __shared__ double s_tr[kBlock / 64][128];             // the row-pair transpose of a block that ends inside a chunk (the products stay where they are)
+    __shared__ double s_red[4];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    double coef;
+    if (!spmv_prologue<EPI, int32_t>(a, s_red, coef)) return;
+    double acc1 = 0.0, acc2 = 0.0;
+    double *prod = s_prod[wave], *tr = s_tr[wave];
+    const int G = (int)gridDim.x;
+    const int nrun = (nblk + rl - 1) / rl;
+    int first, step, last;
+    if (xcd_remap && (G & 7) == 0 && nrun >= 4 * G) {
+        const int xcd = (int)blockIdx.x & 7, per = (nrun + 7) >> 3;
+        first = xcd * per + ((int)blockIdx.x >> 3) * (kBlock / 64) + wave;
+        step = (G >> 3) * (kBlock / 64);
+        last = min((xcd + 1) * per, nrun);
+    } else {
+        first = (int)blockIdx.x * (kBlock / 64) + wave;
+        step = G * (kBlock / 64);
+        last = nrun;
+    }
+    constexpr bool kUsesW = EPI == EPI_DOT || EPI == EPI_DOT2 || EPI == EPI_DOT4 || EPI == EPI_RES || EPI == EPI_SUB || EPI == EPI_AXPY_DOT;
+    constexpr bool kUsesZ = EPI == EPI_DOT4 || EPI == EPI_AXPY_DOT || EPI == EPI_XPBY_NRM;
+    const bool w_nt = nt && a.w != xg, z_nt = nt && (const double *)a.z != xg;
+    const bool st_nt = st_nt_of(nt);
+    auto load_ops = [&](int b, int &sa_o, int &sb_o, wv_f64x2 &wv_o, wv_f64x2 &zv_o) {
+        const int r = b * 128, pr = min(r + 2 * lane, a.rows - 1);
+        sa_o = rowptr[r + lane];
+        sb_o = rowptr[r + 64 + lane];
+        if constexpr (kUsesW) {
+            if (EPI != EPI_AXPY_DOT || a.w) wv_o = w_nt ? __builtin_nontemporal_load((const wd_f64x2u *)(a.w + pr)) : *(const wd_f64x2u *)(a.w + pr);
+        }
+        if constexpr (kUsesZ) zv_o = z_nt ? __builtin_nontemporal_load((const wd_f64x2u *)(a.z + pr)) : *(const wd_f64x2u *)(a.z + pr);
+    };
+    WvChunk<PPL> cur;
+    // the run whose first chunk `cur` holds, fetched a run early: its block range, its entry range, the row starts / operands of its first block
+    int nb0 = 0, nb1 = 0, nkA = 0, nkB = 0;
+    int sa_n = 0, sb_n = 0;
+    wv_f64x2 wv_n = {0.0, 0.0}, zv_n = {0.0, 0.0};
+    auto run_range = [&](int run, int &b0, int &b1, int &kA, int &kB) {
+        b0 = run * rl;
+        b1 = min(run * rl + rl, nblk);
+        kA = __builtin_amdgcn_readfirstlane(rowptr[b0 * 128]);
+        kB = __builtin_amdgcn_readfirstlane(rowptr[b1 * 128]);   // (rows past the end are empty: rowptr is padded with nnz)
+    };
+    if (first < last) {
+        run_range(first, nb0, nb1, nkA, nkB);
+        wv_load<PPL>(cur, col, val, nkA & ~1, nkB, lane);
+        load_ops(nb0, sa_n, sb_n, wv_n, zv_n);
+    }
+    for (int run = first; run < last; run += step) {
+        const int b1 = nb1, kA = nkA, kB = nkB;
+        int blk = nb0;
+        // the block under way: its entries end at k1, this lane's rows blk * 128 + lane / + 64 + lane with starts sa / sb and ends ea / eb
+        int k1 = __builtin_amdgcn_readfirstlane(rowptr[min(blk + 1, b1) * 128]);   // (the block's entries end here; they start where the lanes' row starts say)
+        int sa = sa_n, sb = sb_n;
+        wv_f64x2 wv = wv_n, zv = zv_n;
+        auto row_ends = [&](int &ea_o, int &eb_o) {
+            const int sb0 = __builtin_amdgcn_readfirstlane(sb);
+            ea_o = __shfl_down(sa, 1, 64);
+            eb_o = __shfl_down(sb, 1, 64);
+            if (lane == 63) { ea_o = sb0; eb_o = k1; }
+        };
+        int ea, eb;
+        row_ends(ea, eb);
+        double ya = 0.0, yb = 0.0;
+        // the block after it inside the run (its row starts and operands: loaded while this one is folded); the next run's first block otherwise
+        const int run_n = min(run + step, last - 1);                       // (past the last run: any valid run -- loaded and dropped)
+        run_range(run_n, nb0, nb1, nkA, nkB);
+        load_ops(blk + 1 < b1 ? blk + 1 : nb0, sa_n, sb_n, wv_n, zv_n);
+        for (int kb = kA & ~1;; kb += CH) {
+            const int kend = min(kb + CH, kB);
+            double xa[PPL], xb[PPL];
+#pragma unroll
+            for (int j = 0; j < PPL; ++j) {
+                xa[j] = xg[cur.cc[j].x];
+                xb[j] = xg[cur.cc[j].y];
+            }
+            WvChunk<PPL> nxt;
+            const bool more = kb + CH < kB;
+            wv_load<PPL>(nxt, col, val, more ? kb + CH : (nkA & ~1), more ? kB : nkB, lane);
+#pragma unroll
+            for (int j = 0; j < PPL; ++j) {
+                wv_f64x2 p;
+                p.x = cur.vv[j].x * xa[j];
+                p.y = cur.vv[j].y * xb[j];
+                *(wv_f64x2 *)(prod + 2 * lane + 128 * j) = p;
+            }
+            cur = nxt;
+            for (;;) {   // the blocks that intersect the chunk [kb, kend)
+                {   // this block's share of the chunk: the lane-per-row fold of spmv_wave_kernel on [max(k0, kb), min(k1, kend))
+                    const int lim = min(k1, kend);
+                    int ka = max(sa, kb) - kb, kb2 = max(sb, kb) - kb;
+                    const int ha = min(ea, lim) - kb, hb = min(eb, lim) - kb;
+                    while (ka < ha || kb2 < hb) {
+                        double pa[8], pb[8];
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) pa[i] = prod[min(ka + i, CH - 1)];
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) pb[i] = prod[min(kb2 + i, CH - 1)];
+#pragma unroll
+                        for (int i = 0; i < 8; ++i)
+                            if (ka + i < ha) ya += pa[i];
+#pragma unroll
+                        for (int i = 0; i < 8; ++i)
+                            if (kb2 + i < hb) yb += pb[i];
+                        ka += 8;
+                        kb2 += 8;
+                    }
+                }
+                if (k1 > kend) break;                 // the block goes on in the next chunk
+                // ---- the block ends inside this chunk: row pairs, epilogue, store ----
+                tr[lane] = ya;
+                tr[64 + lane] = yb;
+                const wv_f64x2 yp = *(const wv_f64x2 *)(tr + 2 * lane);
+                const int prow = blk * 128 + 2 * lane;
+                if (prow < a.rows) wd_epilogue<EPI>(a, prow, prow + 1 < a.rows, yp.x, yp.y, wv, zv, coef, acc1, acc2, st_nt);
+                if (++blk >= b1) break;               // the run is done (kend == kB)
+                // ---- the next block of the run takes over the lanes ----
+                k1 = __builtin_amdgcn_readfirstlane(rowptr[min(blk + 1, b1) * 128]);
+                sa = sa_n; sb = sb_n; wv = wv_n; zv = zv_n;
+                row_ends(ea, eb);
+                ya = yb = 0.0;
+                load_ops(blk + 1 < b1 ? blk + 1 : nb0, sa_n, sb_n, wv_n, zv_n);
+            }
+            if (!more) break;
+        }
+    }
+    if constexpr (EPI == EPI_DOT || EPI == EPI_DOT2 || EPI == EPI_DOT4 || EPI == EPI_RES || EPI == EPI_AXPY_DOT || EPI == EPI_XPBY_NRM) {
+        const double s1 = block_sum(acc1, s_red);
+        if (tid == 0) a.p1[blockIdx.x] = s1;
+    }
+    if constexpr (EPI == EPI_DOT2 || EPI == EPI_DOT4) {
+        const double s2 = block_sum(acc2, s_red);
+        if (tid == 0) a.p2[blockIdx.x] = s2;
+    }
+    spmv_extra_partials<EPI>(a, s_red, tid);
+}
+
 bool wave_on(const sla_csr *A) {
     const sla_ctx *c = A->ctx;
     return c->stream_wave > 0 && !A->rp64 && A->rows > 0 && A->max_row_nnz <= kWvMaxRow && c->spmv_algo == 0;
@@ -542,7 +696,10 @@ static int launch_wave_t(const sla_csr *A, const SpmvArgs<int32_t> &a, int grid)
     if (v.ppl == P && v.occ == O && v.pre == R)                                                                                            \
         SLA_KLAUNCH(c, (spmv_wave_kernel<EPI, P, O, R != 0>), dim3(grid), dim3(kBlock), 0, stream_of(c), a, a.rowptr, a.col, a.val, a.x, nblk, \
                            c->xcd_remap, nt, std::max(1, c->wave_run))
-    if (v.ppl == 8 && v.occ == 3 && v.pre == 1 && c->wave_flat)
+    if (v.ppl == 8 && v.occ == 3 && v.pre == 1 && c->wave_cc)
+        SLA_KLAUNCH(c, (spmv_wave_cc_kernel<EPI, 8, 3>), dim3(grid), dim3(kBlock), 0, stream_of(c), a, a.rowptr, a.col, a.val, a.x, nblk, c->xcd_remap, nt,
+                    std::max(1, c->wave_cc));   // (wave_cc = the run length: blocks whose entries are streamed as one sequence of chunks)
+    else if (v.ppl == 8 && v.occ == 3 && v.pre == 1 && c->wave_flat)
         SLA_KLAUNCH(c, (spmv_wave_flat_kernel<EPI, 8, 3>), dim3(grid), dim3(kBlock), 0, stream_of(c), a, a.rowptr, a.col, a.val, a.x, nblk, c->xcd_remap, nt,
                     std::max(1, c->wave_run), c->d_result + 2048);   // (128 doubles of the context's scratch: the dump of the unconditional store)
     else SLA_WV(2, 8, 0);
