@@ -142,6 +142,14 @@ def rank_main(rank):
         for name, meth in (("bicgstab", sla.BICGSTAB_), ("cgs", sla.CGS_), ("cgne", sla.CGNE_)):
             out, info = solve(ctx, meth, A, bvec, x0)
             r[name] = (out.to_host_local(), info.iters, info.flags, info.resnorm)
+        # bcgStep (extension, round 6): one (#>) and one (<#) per step -- the sharded (<#) is a partial product + reduce-scatter
+        sb = sla.bcgInit(A, bvec, x0).step(3)
+        xb = sla.DeviceVector(ctx, n)
+        _lib.check(lib.sla_solver_get(sb.h, 0, xb.h))
+        r["bcg_x3"] = xb.to_host_local()
+        _lib.check(lib.sla_solver_get(sb.h, 5, xb.h))
+        r["bcg_phat3"] = xb.to_host_local()
+        del sb
         Q = np.zeros((6 + 1) * (e - b))
         H = np.zeros((6 + 1) * 6)
         kd = C.c_int()
@@ -208,6 +216,11 @@ assert np.allclose(yt, orc.spmv(orc.transpose(Ao), xg), rtol=1e-13, atol=1e-13)
 assert all(np.array_equal(results[r]["full"], yt) for r in range(P))
 assert all(results[r]["dot"] == results[0]["dot"] for r in range(P))            # rank-ordered sum: identical on all ranks
 assert abs(results[0]["dot"] - orc.dot(xg, xg)) <= 1e-12 * orc.dot(xg, xg)
+if "bcg_x3" in results[0]:   # the sharded bcgStep against the oracle's (the commented Sparse.hs:899-909)
+    sob = orc.BcgState(Ao, bg, np.zeros(n)).step(3)
+    assert np.linalg.norm(cat("bcg_x3") - sob.x) <= 1e-9 * np.linalg.norm(sob.x), "sharded bcgStep: x"
+    assert np.linalg.norm(cat("bcg_phat3") - sob.phat) <= 1e-8 * np.linalg.norm(sob.phat) + 1e-12 * np.linalg.norm(bg), "sharded bcgStep: phat"
+    print("BCG_OK", P)
 for name, ometh in (("bicgstab", orc.BICGSTAB_), ("cgs", orc.CGS_), ("cgne", orc.CGNE_)):
     x = np.concatenate([results[r][name][0] for r in range(P)])
     iters = {results[r][name][1] for r in range(P)}

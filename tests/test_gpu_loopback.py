@@ -16,6 +16,7 @@ def test_sharded_path_on_loopback_ranks(nranks, kind):
     out = subprocess.run([sys.executable, os.path.join(HERE, "_loopback_worker.py"), str(nranks), kind],
                          stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
     assert out.returncode == 0 and f"LOOPBACK_OK {nranks} {kind}" in out.stdout, out.stdout[-3000:]
+    assert f"BCG_OK {nranks}" in out.stdout      # (round 6: the sharded bcgStep -- (#>) with exchange, (<#) with reduce-scatter -- against the oracle)
 
 
 def test_split_launch_partials_stay_inside_their_slot_array():
