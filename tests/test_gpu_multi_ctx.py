@@ -55,6 +55,15 @@ def test_one_caller_many_devices(sla, nranks):
     so.step(b, 2)
     assert np.linalg.norm(s2._xBicgstab.toDenseListSV() - so.x) <= 1e-9 * np.linalg.norm(so.x)
     assert np.array_equal(s0._xBicgstab.toDenseListSV(), np.zeros(n))
+    # bcgStep (the extension of Sparse.hs:886-909): (#>) and (<#) per step, the five fields downloaded whole
+    g0 = sla.bcgInit(A, sla.fromVector(b, ctx), sla.fromVector(np.zeros(n), ctx))
+    g2 = sla.bcgStep(A, sla.bcgStep(A, g0))
+    go = orc.BcgState(Ao, b, np.zeros(n))
+    go.step(2)
+    for got, want in ((g2._xBcg, go.x), (g2._rBcg, go.r), (g2._rHatBcg, go.rhat), (g2._pBcg, go.p), (g2._pHatBcg, go.phat)):
+        assert np.linalg.norm(got.toDenseListSV() - want) <= 1e-9 * max(np.linalg.norm(want), 1e-300)
+    assert np.array_equal(g0._pHatBcg.toDenseListSV(), b)               # the record the pure step started from keeps its value
+    del g0, g2
     # arnoldi: Q assembled from the ranks' row blocks, H from rank 0
     Q, H = sla.arnoldi(A, sla.fromVector(b, ctx), 6)
     rc, Qo, Ho, k = orc.arnoldi(Ao, b, 6)
