@@ -494,6 +494,7 @@ const IntKnob kIntKnobs[] = {
     {"wave_flat", &sla_ctx::wave_flat, 0, 1},
     {"wave_cc", &sla_ctx::wave_cc, 0, 4096},
     {"wave_sync", &sla_ctx::wave_sync, 0, 1},
+    {"wave_over", &sla_ctx::wave_over, 0, 8},
     {"stream_wide", &sla_ctx::stream_wide, 0, 1},
     {"diag", &sla_ctx::diag, 0, 2},
     {"diag_lazy", &sla_ctx::diag_lazy, 0, 1},

@@ -322,6 +322,7 @@ struct sla_ctx {
     int wave_flat = 0;               // ... 1: the prefetching instantiation as a flat chunk walk over two register sets (no `cur = nxt` drain per chunk, counted waits, unconditional
                                      // store; round 6): bit-identical, measured 3-6 % SLOWER (profiles/r06_ab_wave_flat.txt) -- like round 3's deeper ring: the waits were not the bound
     int wave_sync = 0;               // ... EXPERIMENT (round 6): a raw workgroup barrier per run so that the four wavefronts' requests for shared x lines meet in the L1
+    int wave_over = 0;               // ... grid of the plain-CSR wave kernel: 0 = automatic (short launches are oversubscribed, see wave_grid), k >= 1 = k resident rounds
     int wave_cc = 0;                 // ... EXPERIMENT (round 6): continuous chunks over runs of wave_cc consecutive blocks (one partial chunk per run instead of per block); 0 off
     int wave_run = 1;                // ... consecutive 128-row blocks a wavefront of spmv_wave_kernel walks before it jumps (round 6; 1 = the round-4 walk)
     int dual_spmv = 1;               // linSolve0: fuse the true-residual SpMV into the next K1 (SLA_DUAL_SPMV=0 disables)

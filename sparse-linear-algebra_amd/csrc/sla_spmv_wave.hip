@@ -673,6 +673,11 @@ static WvVariant wave_variant(const sla_csr *A, int epi) {
     // automatic: the chunk that holds an average block -- 2 / 4 entry pairs per lane for short rows (the loads of a chunk are issued
     // unconditionally: a chunk much larger than the block only issues clamped loads), else 8 pairs with the next chunk prefetched
     const int64_t nblk = (A->rows + 127) / 128, avg = nblk > 0 ? A->nnz / nblk : 0;
+    // Short launches of single-chunk blocks (round 6, tools/wave_variant_small_ab.py, profiles/r06_ab_wave_variant_small.txt): with <= ~5 blocks per
+    // wavefront the cross-block prefetch has little to prefetch for, a fourth workgroup per CU buys more -- 7-per-row Laplacian as plain CSR, K1 same
+    // box (8, 4) against (8, 3, prefetch): 262 k rows 7.8 / 9.2 us, 1 M 22.4 / 24.2, 2 M 44.4 / 45.6, 4 M 88.3 / 87.7, 6.9 M 138.6 / 140.2 (noise);
+    // blocks of several chunks (e05r0000 tiled, 3176 per block, 1 M rows) keep the prefetch: 79.7 / 76.8.
+    if (avg > 512 && avg <= 1024 && nblk <= (int64_t)64 * A->ctx->n_cu) return kWvVariants[2];
     return avg <= 256 ? kWvVariants[0] : avg <= 512 ? kWvVariants[1] : kWvVariants[3];
 }
 int wave_grid(const sla_csr *A) {
@@ -680,7 +685,8 @@ int wave_grid(const sla_csr *A) {
     // (one grid for every epilogue of a matrix: the consumers of the fused partial sums know spmv_grid(A); an instantiation that holds
     // fewer workgroups per CU than that runs a partial second round)
     const int occ = wave_variant(A, EPI_NONE).occ;
-    int64_t g = std::min<int64_t>((nblk + 3) / 4, (int64_t)occ * A->ctx->n_cu);
+    const int over = A->ctx->wave_over > 0 ? A->ctx->wave_over : 1;
+    int64_t g = std::min<int64_t>((nblk + 3) / 4, (int64_t)over * occ * A->ctx->n_cu);
     g = std::min<int64_t>(g, A->ctx->spmv_grid_max);
     if (g >= 8) g &= ~7;                                // a multiple of 8: one share per XCD
     return (int)std::max<int64_t>(1, g);
