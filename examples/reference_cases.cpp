@@ -49,6 +49,18 @@ int main() {
         EXPECT(nearZero(norm2(s3._x() - mkSpVR(3, {1.5, -2, 1}))));
         EXPECT(norm2(s1._x() - s3._x()) > 1e-6);
     }
+    // CscMatrix arrays in and out, transposeSM as a handle (vector/src/Data/Sparse/Internal/CSC.hs:17-24, :121-125: the triplet example at the foot of the file)
+    {
+        SpMatrix a = SpMatrix::fromCSC(3, 3, {0, 2, 3, 6}, {0, 2, 2, 0, 1, 2}, {1, 4, 5, 2, 3, 6});
+        auto l = a.toAscList();
+        EXPECT(l.size() == 6 && std::get<1>(l[1]) == 2 && std::get<2>(l[1]) == 2.0 && std::get<0>(l[3]) == 2 && std::get<2>(l[3]) == 4.0);
+        std::vector<int64_t> cp, ri;
+        std::vector<double> va;
+        a.toCSC(cp, ri, va);
+        EXPECT((cp == std::vector<int64_t>{0, 2, 3, 6}) && (ri == std::vector<int64_t>{0, 2, 2, 0, 1, 2}) && (va == std::vector<double>{1, 4, 5, 2, 3, 6}));
+        auto t = a.transposeSM().toAscList();
+        EXPECT(t.size() == 6 && std::get<0>(t[1]) == 0 && std::get<1>(t[1]) == 2 && std::get<2>(t[1]) == 4.0);
+    }
     // m1 ## m2 (LibSpec.hs:61-62, fixtures :1263-1271) and the size check of matMat_ (SpMatrix.hs:795)
     {
         SpMatrix m1 = fromListDenseSM(2, {1, 3, 2, 4}), m2 = fromListDenseSM(2, {5, 7, 6, 8});

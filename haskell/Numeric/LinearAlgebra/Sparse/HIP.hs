@@ -34,7 +34,7 @@ module Numeric.LinearAlgebra.Sparse.HIP
     -- * the class route: a device-dispatching vector type with the reference's instances
   , Dev(..), toDev, fromDev
     -- * monomorphic spellings of the class methods (no wrapper)
-  , matVecHIP, vecMatHIP, dotHIP, norm2HIP, linSolveHIP, matMatHIP, matMatTHIP
+  , matVecHIP, vecMatHIP, dotHIP, norm2HIP, linSolveHIP, matMatHIP, matMatTHIP, transposeHIP
     -- * what the device does with a matrix (typed, round 6)
   , FoldKind(..), foldKindHIP
   ) where
@@ -69,6 +69,7 @@ foreign import ccall safe "sla_csr_from_coo"      c_csr_from_coo      :: Ptr Ctx
 foreign import ccall safe "sla_csr_dims"          c_csr_dims          :: Ptr Csr -> Ptr Int64 -> Ptr Int64 -> Ptr Int64 -> Ptr Int64 -> IO CInt
 foreign import ccall safe "sla_csr_export"        c_csr_export        :: Ptr Csr -> Ptr Int64 -> Ptr Int64 -> Ptr Double -> IO CInt
 foreign import ccall safe "sla_csr_matmat"        c_csr_matmat        :: Ptr Csr -> Ptr Csr -> CInt -> Ptr (Ptr Csr) -> IO CInt
+foreign import ccall safe "sla_csr_transpose"     c_csr_transpose     :: Ptr Csr -> Ptr (Ptr Csr) -> IO CInt
 foreign import ccall safe "&sla_csr_destroy"      p_csr_destroy       :: FunPtr (Ptr Csr -> IO ())
 foreign import ccall safe "sla_vec_create"        c_vec_create        :: Ptr Ctx -> Int64 -> Ptr Double -> Ptr (Ptr Vec) -> IO CInt
 foreign import ccall safe "&sla_vec_destroy"      p_vec_destroy       :: FunPtr (Ptr Vec -> IO ())
@@ -246,6 +247,15 @@ norm2HIP v = unsafePerformIO $ upload v >>= \a -> withForeignPtr a $ \pa -> allo
 matMatHIP, matMatTHIP :: R.SpMatrix Double -> R.SpMatrix Double -> R.SpMatrix Double
 matMatHIP = matMatWith 0
 matMatTHIP = matMatWith 1
+
+-- | transposeSM (SpMatrix.hs:717) as a device sort by (column, row)
+transposeHIP :: R.SpMatrix Double -> R.SpMatrix Double
+transposeHIP m1 = unsafePerformIO $ do
+  a <- lower m1
+  t <- withForeignPtr a $ \pa -> alloca $ \out -> do
+    c_csr_transpose pa out >>= check "transposeSM"
+    peek out >>= newForeignPtr p_csr_destroy
+  liftCsr t
 
 matMatWith :: CInt -> R.SpMatrix Double -> R.SpMatrix Double -> R.SpMatrix Double
 matMatWith tb m1 m2 = unsafePerformIO $ do

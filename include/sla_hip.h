@@ -167,6 +167,27 @@ int sla_csr_from_csr_rows(sla_ctx_t, int64_t m, int64_t n, int64_t row_begin, in
  * expansion; `matrix array` files give dense vectors (right-hand sides). */
 int sla_csr_from_matrix_market(sla_ctx_t, const char *path, int dup_policy, sla_csr_t *out);
 int sla_vec_from_matrix_market(sla_ctx_t, const char *path, sla_vec_t *out);
+/* The array layouts of the reference's `vector/` package, single-device contexts unless noted.
+ * CSC (vector/src/Data/Sparse/Internal/CSC.hs:17-24: cscColPtr has n+1 entries, cscRowIx / cscVal one per stored entry; toCSC
+ * :51-55): the arrays are the canonical CSR of the transpose and are validated as such (row indices in [0, m), ascending and
+ * unrepeated inside a column; otherwise SLA_ERR_INVALID / SLA_ERR_OOB -- unsorted triplets go through sla_csr_from_coo).  The
+ * result is the same lowered matrix sla_csr_from_csr gives for the CSR arrays of A (device sort); the CSC side stays attached as
+ * A's cached transpose, so (<#), CGNE_ and bcgStep need no second sort. */
+int sla_csr_from_csc(sla_ctx_t, int64_t m, int64_t n, const int64_t *colptr, const int64_t *rowidx, const double *val,
+                     sla_csr_t *out);
+/* The lowered matrix as CSC arrays (fromCSC0, CSC.hs:61-77, gives the triplets back): colptr n+1 entries, rowidx / val nnz;
+ * any pointer may be NULL. */
+int sla_csr_export_csc(sla_csr_t, int64_t *colptr, int64_t *rowidx, double *val);
+/* transposeSM (src/Data/Sparse/SpMatrix.hs:717) / transposeCSR (vector/.../CSR.hs:138-141) / transposeCSC (CSC.hs:104-108):
+ * a new lowered matrix owned by the caller (sort by (column, row) on the device). */
+int sla_csr_transpose(sla_csr_t A, sla_csr_t *out);
+/* CSB (vector/src/Data/Sparse/Internal/CSB.hs:38-70, Buluc et al.): square blocks of edge `beta`; blkptr has nbx * nby + 1
+ * entries with nbx = ceil(m / beta), nby = ceil(n / beta) (csbParams :72-77); block f(i, j) = (i div beta) + (j div beta) * nbx
+ * (blockIx :88-92); rowix / colix are RELATIVE to the block (0 .. beta-1), unordered inside it.  Expanded to coordinates and
+ * lowered through fromListSM's path (a repeated (i, j): the later one wins); an index outside its block or the matrix =>
+ * SLA_ERR_OOB.  Works on every kind of context (each rank passes all the arrays, like sla_csr_from_coo). */
+int sla_csr_from_csb(sla_ctx_t, int64_t m, int64_t n, int64_t beta, const int64_t *blkptr, const int64_t *rowix,
+                     const int64_t *colix, const double *val, sla_csr_t *out);
 /* jacobiPre x = recip <$> extractDiag x (Sparse.hs:689-690): the diagonal matrix of reciprocal diagonal
  * entries (rows without a stored diagonal entry stay empty).  Single-rank contexts. */
 int sla_jacobi_pre(sla_csr_t A, sla_csr_t *out);

@@ -172,6 +172,27 @@ class SpMatrix {
         check(sla_csr_is_diagonal(h_.get(), &d));
         return d != 0;
     }
+    // CscMatrix arrays (vector/src/Data/Sparse/Internal/CSC.hs:17-24) in and out
+    static SpMatrix fromCSC(int64_t m, int64_t n, const std::vector<int64_t> &colptr, const std::vector<int64_t> &rowidx, const std::vector<double> &val) {
+        sla_csr_t a;
+        check(sla_csr_from_csc(Context::instance().get(), m, n, colptr.data(), rowidx.data(), val.data(), &a));
+        return SpMatrix(m, n, a);
+    }
+    void toCSC(std::vector<int64_t> &colptr, std::vector<int64_t> &rowidx, std::vector<double> &val) const {
+        int64_t nnz = 0;
+        check(sla_csr_dims(h_.get(), nullptr, nullptr, &nnz, nullptr));
+        colptr.assign((size_t)n_ + 1, 0);
+        rowidx.assign((size_t)std::max<int64_t>(nnz, 1), 0);
+        val.assign((size_t)std::max<int64_t>(nnz, 1), 0.0);
+        check(sla_csr_export_csc(h_.get(), colptr.data(), rowidx.data(), val.data()));
+        rowidx.resize((size_t)nnz);
+        val.resize((size_t)nnz);
+    }
+    SpMatrix transposeSM() const {  // SpMatrix.hs:717
+        sla_csr_t t;
+        check(sla_csr_transpose(h_.get(), &t));
+        return SpMatrix(n_, m_, t);
+    }
 
   private:
     int64_t m_, n_;

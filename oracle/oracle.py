@@ -129,6 +129,51 @@ def transpose(A):
     return Csr(A.n, A.m, tp, tc[:A.nnz].copy(), tv[:A.nnz].copy())
 
 
+def to_csc(m, n, row, col, val):
+    """toCSC m n ijxv (vector/src/Data/Sparse/Internal/CSC.hs:51-55): STABLE sort of the triplets by column, unzip, column pointer by
+    csPtrV.  (The reference passes m to csPtrV, :55 -- right for square matrices only; restated with n, the length a column pointer has.)
+    Returns (colptr, rowidx, val).  Index work in numpy (a stable argsort is the reference's merge sort on one key)."""
+    row, col, val = _i64(row), _i64(col), _f64(val)
+    order = np.argsort(col, kind="stable")
+    return cs_ptr(n, col[order]), row[order].copy(), val[order].copy()
+
+
+def csc_to_csr(m, n, colptr, rowidx, val):
+    """CscMatrix arrays -> the canonical CSR of the same matrix: fromCSC0 (CSC.hs:61-77) gives the triplets, toCSR (CSR.hs:74-78) sorts them by
+    row; for canonical CSC input (rows ascending inside a column) that is the transpose of the n x m matrix the arrays are the CSR of."""
+    return transpose(Csr(n, m, colptr, rowidx, val))
+
+
+def csb_block_index(dims, beta, i, j):
+    """blockIx (vector/src/Data/Sparse/Internal/CSB.hs:88-92): bx + by * nbx with (bx, by) = (i div beta, j div beta) and nbx = ceiling (m / beta)
+    (csbParams :72-77) -- the block ROW index runs fastest."""
+    nbx = -(-int(dims[0]) // int(beta))
+    return _i64(i) // beta + (_i64(j) // beta) * nbx
+
+
+def to_csb(dims, beta, row, col, val):
+    """The CsbMatrix arrays (CSB.hs:62-66: csbVal, csbBlkPtr, csbRowIx, csbColIx) of a triplet list: consBlocks (:103-107) bins the triplets by
+    blockIx -- each new element is consed in FRONT of its block's list, so a block holds its elements in reverse input order -- and the blocks are laid
+    out in ascending block index with bCoords (:84-85) as block-relative indices.  Returns (blkptr, rowix, colix, val)."""
+    row, col, val = _i64(row), _i64(col), _f64(val)
+    m, n = int(dims[0]), int(dims[1])
+    nblk = (-(-m // beta)) * (-(-n // beta))
+    ib = csb_block_index(dims, beta, row, col)
+    order = np.argsort(ib[::-1], kind="stable")              # reverse input order inside a block, blocks ascending
+    order = (len(row) - 1 - order) if len(row) else order
+    blkptr = np.concatenate(([0], np.cumsum(np.bincount(ib, minlength=nblk)))).astype(np.int64)
+    return blkptr, (row % beta)[order].copy(), (col % beta)[order].copy(), val[order].copy()
+
+
+def csb_to_coo(dims, beta, blkptr, rowix, colix, val):
+    """The triplets of CsbMatrix arrays in storage order (the definition of the layout, CSB.hs:44-56): element k of block f = bx + by * nbx is
+    a (bx * beta + rowix[k], by * beta + colix[k])."""
+    blkptr, rowix, colix = _i64(blkptr), _i64(rowix), _i64(colix)
+    nbx = -(-int(dims[0]) // int(beta))
+    f = np.repeat(np.arange(len(blkptr) - 1, dtype=np.int64), np.diff(blkptr))
+    return (f % nbx) * beta + rowix, (f // nbx) * beta + colix, _f64(val)
+
+
 def is_diagonal(A):
     return bool(lib().orc_is_diagonal(C.c_int64(A.m), _p(A.rowptr), _p(A.colidx)))
 

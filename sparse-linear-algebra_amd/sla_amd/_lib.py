@@ -106,6 +106,10 @@ PROTOTYPES = [
     ("sla_csr_from_csr", _int, [_vp, _i64, _i64, _vp, _vp, _vp, _pp]),
     ("sla_csr_from_csr_rows", _int, [_vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _pp]),
     ("sla_csr_from_matrix_market", _int, [_vp, C.c_char_p, _int, _pp]),
+    ("sla_csr_from_csc", _int, [_vp, _i64, _i64, _vp, _vp, _vp, _pp]),
+    ("sla_csr_export_csc", _int, [_vp, _vp, _vp, _vp]),
+    ("sla_csr_transpose", _int, [_vp, _pp]),
+    ("sla_csr_from_csb", _int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _pp]),
     ("sla_vec_from_matrix_market", _int, [_vp, C.c_char_p, _pp]),
     ("sla_jacobi_pre", _int, [_vp, _pp]),
     ("sla_csr_diag_mul", _int, [_vp, _vp, _pp]),

@@ -354,6 +354,16 @@ class SpMatrix:
             self._host = (rp, ci[:nnz.value], va[:nnz.value])
         return self._host
 
+    def csc(self):
+        """(colptr, rowidx, val): the CscMatrix arrays of this matrix (CSC.hs:17-24), copied back from the device (single-device contexts)."""
+        nnz = C.c_int64()
+        check(lib().sla_csr_dims(self.h, None, None, C.byref(nnz), None))
+        cp = np.zeros(self.ncols + 1, dtype=np.int64)
+        ri = np.zeros(max(nnz.value, 1), dtype=np.int64)
+        va = np.zeros(max(nnz.value, 1), dtype=np.float64)
+        check(lib().sla_csr_export_csc(self.h, _p(cp), _p(ri), _p(va)))
+        return cp, ri[:nnz.value], va[:nnz.value]
+
     def nnz(self):
         return int(self.csr()[0][-1])
 
@@ -454,6 +464,36 @@ def fromCSR(dims, rowptr, colidx, vals, ctx=None):
     va = np.ascontiguousarray(vals, dtype=np.float64)
     h = C.c_void_p()
     check(lib().sla_csr_from_csr(ctx.h, int(dims[0]), int(dims[1]), _p(rp), _p(ci), _p(va), C.byref(h)))
+    return SpMatrix(dims, h, ctx)
+
+
+def fromCSC(dims, colptr, rowidx, vals, ctx=None):
+    """CscMatrix arrays (vector/src/Data/Sparse/Internal/CSC.hs:17-24; toCSC :51-55) -> the lowered matrix; the CSC side stays attached
+    as its transpose.  Single-device contexts."""
+    ctx = ctx or default_context()
+    cp = np.ascontiguousarray(colptr, dtype=np.int64)
+    ri = np.ascontiguousarray(rowidx, dtype=np.int64)
+    va = np.ascontiguousarray(vals, dtype=np.float64)
+    if len(cp) != int(dims[1]) + 1:
+        raise ValueError("colptr must have ncols + 1 entries")
+    h = C.c_void_p()
+    check(lib().sla_csr_from_csc(ctx.h, int(dims[0]), int(dims[1]), _p(cp), _p(ri), _p(va), C.byref(h)))
+    return SpMatrix(dims, h, ctx)
+
+
+def fromCSB(dims, beta, blkptr, rowix, colix, vals, ctx=None):
+    """CsbMatrix arrays (vector/src/Data/Sparse/Internal/CSB.hs:38-70): blocks of edge beta in blockIx order (:88-92: the block row runs
+    fastest), block-relative indices."""
+    ctx = ctx or default_context()
+    bp = np.ascontiguousarray(blkptr, dtype=np.int64)
+    ri = np.ascontiguousarray(rowix, dtype=np.int64)
+    ci = np.ascontiguousarray(colix, dtype=np.int64)
+    va = np.ascontiguousarray(vals, dtype=np.float64)
+    nblk = (-(-int(dims[0]) // int(beta))) * (-(-int(dims[1]) // int(beta))) if beta > 0 else 0
+    if len(bp) != nblk + 1:
+        raise ValueError("blkptr must have ceil(m / beta) * ceil(n / beta) + 1 entries")
+    h = C.c_void_p()
+    check(lib().sla_csr_from_csb(ctx.h, int(dims[0]), int(dims[1]), int(beta), _p(bp), _p(ri), _p(ci), _p(va), C.byref(h)))
     return SpMatrix(dims, h, ctx)
 
 
@@ -569,7 +609,11 @@ def diagMatMatSparsified(D, A):
 
 
 def transpose(A):
-    """transposeSM (SpMatrix.hs:717)."""
+    """transposeSM (SpMatrix.hs:717): on a single-device context a device sort by (column, row) (sla_csr_transpose); sharded contexts go
+    through the triplets."""
+    h = C.c_void_p()
+    if lib().sla_csr_transpose(A.h, C.byref(h)) == 0:      # (refused on sharded / multi-device contexts: a row block's transpose is a column block)
+        return SpMatrix((A.ncols, A.nrows), h, A.ctx)
     return fromListSM((A.ncols, A.nrows), [(j, i, x) for (i, j, x) in A.toListSM()[::-1]], A.ctx)
 
 
