@@ -104,12 +104,12 @@ defaultCtx = unsafePerformIO $ do
   case lit of
     Just "1" -> withCString "bicg_fuse45" $ \k -> withCString "0" $ \v -> c_ctx_set_option c k v >>= check "sla_ctx_set_option"
     _ -> return ()
-  -- SLA_EXACT_FOLD=1: (#>) on irregular matrices (the tile form: more than 2^18 columns, no band structure) as the reference's ascending
-  -- left fold bit for bit and reproducible, instead of the default relaxed-order kernel (within nnz_i eps sum |a_ij x_j| of it, 1.4 x
-  -- faster on BASELINE config 3a; INTEGRATION.md, "(#>) on irregular matrices and the order of a row's sum")
-  ex <- lookupEnv "SLA_EXACT_FOLD"
+  -- SLA_RELAXED_FOLD=1 (opt-in): (#>) on irregular matrices (the tile form: more than 2^18 columns, no band structure) with a row's products added in
+  -- relaxed order -- within nnz_i eps sum |a_ij x_j| of the reference's ascending left fold, 17 - 20 % faster on BASELINE config 3a, NOT reproducible
+  -- bit for bit from run to run (INTEGRATION.md, "(#>) on irregular matrices and the order of a row's sum").  The default is the fold itself.
+  ex <- lookupEnv "SLA_RELAXED_FOLD"
   case ex of
-    Just "1" -> withCString "tile_relaxed" $ \k -> withCString "0" $ \v -> c_ctx_set_option c k v >>= check "sla_ctx_set_option"
+    Just "1" -> withCString "tile_relaxed" $ \k -> withCString "1" $ \v -> c_ctx_set_option c k v >>= check "sla_ctx_set_option"
     _ -> return ()
   return c
 
@@ -199,7 +199,7 @@ linSolve0 method aa b x0 = pureThrow $ do
 --   rows come out of the row map's keys in ascending order (O(rows)); the dense device result is walked once beside them.
 -- | How @(#>)@ on the lowered matrix adds the products of a row (@sla_fold_kind@, include/sla_hip.h): 'FoldExact' = the reference's ascending left
 --   fold bit for bit (Common.hs:247-260), reruns bit-identical; 'FoldRegrouped' = a fixed regrouping of long rows (within the rounding bound, reruns
---   bit-identical); 'FoldRelaxed' = order not fixed from run to run (the default tile form of irregular matrices; @SLA_EXACT_FOLD=1@ avoids it).
+--   bit-identical); 'FoldRelaxed' = order not fixed from run to run (only after the opt-in @SLA_RELAXED_FOLD=1@: no default form is order-relaxed).
 data FoldKind = FoldExact | FoldRegrouped | FoldRelaxed deriving (Eq, Show, Enum)
 
 foldKindHIP :: R.SpMatrix Double -> FoldKind

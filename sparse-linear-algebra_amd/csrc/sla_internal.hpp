@@ -259,9 +259,12 @@ struct sla_ctx {
     int canon_device = 1;            // value-indexed matrices: canonical col / val written on the device from the 1-byte codes instead of uploaded
     int tile_rowown = -1;            // round 6: CU-wide tiles with every row of a slice owned by ONE wavefront (reproducible row sums, the reference's left fold; a quarter of the
                                      // relaxed dealing's gather density): -1 = whenever tile_relaxed = 0 asks for the exact form, 0 = never (exact = wavefront-private slices), 1 = always
-    int tile_relaxed = 1;            // the tile form of irregular matrices: 1 = CU-wide slices (spmv_ctile_kernel, round 5: column-sorted gathers that share x lines, row sums by LDS
-                                     // atomics in relaxed order -- within nnz_i eps sum|a_ij x_j| of the reference's fold, not reproducible bit for bit), 0 = wavefront-private slices
-                                     // (spmv_tile_kernel, rounds 2-4: the reference's left fold bit for bit; 18 % slower on config 3a, 2.2 x on power-law rows)
+    int tile_relaxed = 0;            // the tile form of irregular matrices.  0 (DEFAULT since the end of round 6; ADVICE r05: reruns must be bit-identical, like the reference's pure
+                                     // functions) = the exact forms: CU-wide slices with every row owned by one wavefront (tile_rowown; the reference's left fold bit for bit) and,
+                                     // for rows of ~100 entries and more, the LDS-flat form (a fixed regrouping).  1 = OPT-IN: CU-wide slices with the row sums added by LDS atomics in
+                                     // relaxed order (spmv_ctile_kernel, round 5) -- within nnz_i eps sum|a_ij x_j| of the reference's fold, NOT reproducible bit for bit, announced by
+                                     // sla_csr_get_props().fold and SLA_FLAG_RELAXED_ORDER; config 3a (#>) 1.35 ms against 1.62 exact, power-law rows 170 against 230 us, rows of
+                                     // 100 - 500 entries 2 - 8 % (profiles/r06_tile_default_ab.txt)
     int onchip = 1;                  // sla_solver_step on constant-coefficient stencil / banded matrices that fit the chip's registers + LDS: the whole step loop as ONE persistent
                                      // launch (sla_onchip.hip; SLA_ONCHIP: 0 never, 1 when the plan says it fits, 2 the same and a plan failure is an error: tests)
     int onchip_sync = 0;             // ... its grid-wide synchronisation: 0 = XCD-hierarchical arrival counters (default), 1 = one epoch word per workgroup polled by everybody

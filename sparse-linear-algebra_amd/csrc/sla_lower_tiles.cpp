@@ -7,9 +7,10 @@
 //                       number of rounds of the kernel's persistent grid (every wavefront gets the same number of slices);
 //   tloff[S x (P + 1)]  first entry of tile (slice, panel) relative to the slice's first entry (= rowptr[tlrow[s]]: a
 //                       slice owns the same entry range in both orders, so slices are built independently, in parallel).
-// Round 5, option tile_relaxed = 1 (default): CU-WIDE slices of <= kCtRows rows, every tile's entries sorted by column and dealt to
+// Round 5, option tile_relaxed = 1 (the default of round 5; an opt-in since the end of round 6): CU-WIDE slices of <= kCtRows rows, every tile's entries sorted by column and dealt to
 // the workgroup's four wavefronts in 64-entry groups, stored [slice][wavefront][panel] with tloff[S x 4 x (P + 1)] (kernel:
-// sla_spmv_ctiles.hip, relaxed-order row sums); tile_relaxed = 0: the wavefront-private layout above (bit-exact left fold).
+// sla_spmv_ctiles.hip, relaxed-order row sums); tile_relaxed = 0 (default): the same CU-wide slices with every row owned by one wavefront (round 6, below) or,
+// with tile_rowown = 0, the wavefront-private layout above -- both the bit-exact left fold.
 #include <algorithm>
 #include <cstring>
 #include <limits>

@@ -16,7 +16,9 @@
 // gain; profiles/r05_ab_ctile_kernel.txt) and dropped.  This kernel adds the products with LDS floating-point atomics (ds_add_f64)
 // in whatever order the wavefronts reach them: every product is still rounded separately (no FMA), a row's sum is the same set of
 // numbers as the reference's fold, added in another order -- within nnz_i eps sum_j |a_ij x_j| of it, and NOT reproducible bit for
-// bit from run to run.  Option tile_relaxed = 0 selects the bit-exact wavefront-private form instead (sla_spmv_tiles.hip).
+// bit from run to run.  That is why this order is an OPT-IN (tile_relaxed = 1) since the end of round 6: the default deals a tile's column-sorted run so
+// that every row belongs to one wavefront (row-owned layout, same kernel: in-order LDS adds of one wavefront are the reference's left fold, bit for bit and
+// reproducible), at 1.62 ms against this order's 1.35 on config 3a.
 //
 // Layout (sla_lower_tiles.cpp / sla_tiles_build.hip): inside a tile (slice x panel) the entries are sorted by column and dealt to the
 // four wavefronts in 64-entry groups round-robin (group g -> wavefront g & 3); stored [slice][wavefront][panel], 12 B each:

@@ -3,7 +3,7 @@ banded, Poisson, the reference's own FEM fixture tiled, variable coefficients, r
   (1) the form `sla_csr_from_csr` picks is the kernel the family is documented with: `kernel_info()`'s form tokens pinned EXACTLY
       (deterministic: a threshold regression in sla_lower.cpp changes which kernel a caller's matrix runs, and fails here);
   (2) the pick's K1 (`(#>)` + one dot of a bicgstabStep: Sparse.hs:972-981, Common.hs:247-260; HIP-event timed, same box, same process) is
-      FASTER than every alternative form that the recorded tournament (profiles/r05_form_tournament.txt) shows more than 15 % behind it --
+      FASTER than every alternative form that the recorded tournament (profiles/r06_form_tournament.txt, profiles/r06_tile_default_ab.txt) shows more than 15 % behind it --
       a comparison with that much room does not need a second sample.  Forms within 15 % of the pick in that record are not timed here;
       "how close is the pick to the fastest form" is the tournament tool's own summary line (tools/form_tournament.py, profiles/).
 The forms and the matrix zoo are tools/form_tournament.py's."""
@@ -24,11 +24,13 @@ FAMILIES = {
     "Poisson 1000^2": ("poisson2d_1m", None, "algo=wdia", {"no wdia": 1.66, "dictionary codes": 2.6, "plain CSR": 2.9}),
     "e05r0000 tiled": ("e05_tiled", None, "algo=stream+wave", {}),   # (its alternatives sit within 16 %: pinned, not timed)
     "variable coefficients 128^3": ("varcoef7", None, "algo=wdia-vv", {"no wdia-vv": 1.68, "plain CSR": 1.83}),
-    "random, 33 per row": ("random_spd_1m", None, "algo=tiles exact_fold=0 cu_slices=1", {"wavefront-private exact tiles": 1.49, "no tiles": 1.81}),
-    "random, 100 per row": ("rand100", 0.5, "algo=tiles exact_fold=0 cu_slices=1", {"wavefront-private exact tiles": 1.64, "no tiles": 1.52}),
-    "random, 200 per row": ("rand200", 1.0, "algo=tiles exact_fold=0 cu_slices=1", {"wavefront-private exact tiles": 1.52}),
-    "random, 500 per row": ("rand500", 0.6, "algo=tiles exact_fold=0 cu_slices=1", {"wavefront-private exact tiles": 1.36}),
-    "power-law rows": ("powerlaw", 0.5, "algo=tiles exact_fold=0 cu_slices=1", {"wavefront-private exact tiles": 2.46, "no tiles": 4.6}),
+    # irregular rows (default since the end of round 6: forms whose reruns are bit-identical -- row-owned exact CU tiles, the LDS-flat form for long rows;
+    # the relaxed-order tiles are an opt-in and faster: tools/tile_default_ab.py, profiles/r06_tile_default_ab.txt)
+    "random, 33 per row": ("random_spd_1m", None, "algo=tiles exact_fold=1 cu_slices=1 row_owned=1", {"wavefront-private exact tiles": 1.20, "no tiles": 1.44}),
+    "random, 100 per row": ("rand100", 0.5, "algo=lflat", {"no tiles, no lflat": 2.2}),
+    "random, 200 per row": ("rand200", 1.0, "algo=lflat", {"no tiles, no lflat": 2.5}),
+    "random, 500 per row": ("rand500", 0.6, "algo=lflat", {"no tiles, no lflat": 3.3}),
+    "power-law rows": ("powerlaw", 0.5, "algo=tiles exact_fold=1 cu_slices=1 row_owned=1", {"wavefront-private exact tiles": 2.5, "no tiles": 2.3}),
 }
 
 

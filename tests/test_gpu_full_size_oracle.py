@@ -6,9 +6,9 @@ with `orc.spmv` (the reference's ascending left fold, Common.hs:247-260 / IntM.h
   * forms that fold a row in one lane (wdia, wdia-vv: the stencil / banded configs 2, 4, 5) must be BIT-EXACT --
     at size this exercises what the small tests cannot: the plane-tiled `sched[]` walk, the guard-slack reads at both
     ends of x, the 32-bit byte offsets of the record gathers;
-  * config 3a (10 M rows, 33 random columns per row: the tile form): since round 5 the default is the CU-wide kernel that
-    adds a row's products by LDS atomics in timing order -- |dy_i| <= nnz_i * eps * sum_j |a_ij x_j|; the wavefront-private
-    form (option tile_relaxed = 0) folds every row entry by entry in ascending column order: BIT-EXACT, at the same size;
+  * config 3a (10 M rows, 33 random columns per row: the tile form): the default (CU-wide slices, every row owned by one wavefront)
+    folds every row entry by entry in ascending column order: BIT-EXACT; the opt-in tile_relaxed = 1 adds a row's products by LDS
+    atomics in timing order -- |dy_i| <= nnz_i * eps * sum_j |a_ij x_j| -- at the same size;
   * config 3b (LDS panels at 2000 entries per row) reduces a row in wavefront segments:
     |dy_i| <= nnz_i * eps * sum_j |a_ij x_j| (the bound of SURVEY 8(a) A1).
 
@@ -153,9 +153,9 @@ def test_config3a_random_spd_10m_vs_oracle(sla):
     dims, (rp, ci, va) = wl.random_spd(10000000, 16, 42)
     assert dims[0] == 10000000 and rp[-1] == 329999456
     # ... and CGS, the second half of config 3 ("CGS vs BiCGSTAB"), at the same 10 M rows through the tile form's fused epilogues
-    _check(sla, dims, rp, ci, va, "cu_slices=1", False, "xstar", "config3a", cgs=True)
-    ctx = sla.Context(0).set_option("tile_relaxed", 0)   # mode (a): the reference's fold bit for bit
-    _check(sla, dims, rp, ci, va, "exact_fold=1", True, "xstar", "config3a exact", ctx, cgs=True)
+    _check(sla, dims, rp, ci, va, "exact_fold=1 cu_slices=1 row_owned=1", True, "xstar", "config3a (default: the reference's fold bit for bit)", cgs=True)
+    ctx = sla.Context(0).set_option("tile_relaxed", 1)   # the opt-in: relaxed order, within the rounding bound
+    _check(sla, dims, rp, ci, va, "exact_fold=0", False, "xstar", "config3a relaxed order", ctx, cgs=True)
     ctx.close()
 
 

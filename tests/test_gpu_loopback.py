@@ -66,7 +66,7 @@ def test_tile_form_on_row_slabs(nranks):
 
 @pytest.mark.parametrize("nranks", [2, 5])
 def test_cu_wide_tile_form_on_row_slabs(nranks):
-    """The default tile form since round 5 (tile_relaxed = 1: CU-wide slices, LDS atomics, csrc/sla_spmv_ctiles.hip) on row slabs:
+    """The relaxed-order tile form (opt-in tile_relaxed = 1: CU-wide slices, LDS atomics, csrc/sla_spmv_ctiles.hip) on row slabs:
     overlapped all-gather passes (running row sums carried through yinit), serialised groups, the plain all-gather and ascending
     source-ordered groups -- every row within nnz_i eps sum |a_ij x_j| of the reference's fold (the worker checks it), all solvers
     converge like the oracle's."""

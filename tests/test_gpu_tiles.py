@@ -57,7 +57,7 @@ CASES = {
 
 @pytest.mark.parametrize("name", list(CASES))
 def test_cu_wide_tiles_relaxed_order_within_the_bound(sla, name):
-    """Round 5, the default tile form (option tile_relaxed = 1, csrc/sla_spmv_ctiles.hip): slices shared by a workgroup's four wavefronts,
+    """The OPT-IN relaxed order of the CU-wide tile form (option tile_relaxed = 1, round 5's default; csrc/sla_spmv_ctiles.hip): slices shared by a workgroup's four wavefronts,
     every tile one column-sorted run, products added into the row sums by LDS atomics in whatever order the wavefronts get there.
     Contract: |y_i - fold_i| <= nnz_i eps sum_j |a_ij x_j| -- every product is rounded separately, only the order
     of the additions differs from the reference's left fold; a row with ONE or TWO entries is still exact (no order to differ).
@@ -129,7 +129,7 @@ def test_cu_wide_tile_builder_in_chunks_gives_the_same_layout(sla):
 @pytest.mark.parametrize("rowown", [-1, 0])
 @pytest.mark.parametrize("name", list(CASES))
 def test_tiles_match_the_oracle(sla, name, rowown):
-    """The EXACT tile forms (tile_relaxed = 0): rowown = -1 (default since round 6) -- CU-wide slices with every row owned by one wavefront, all
+    """The EXACT tile forms (tile_relaxed = 0, the default since the end of round 6): rowown = -1 (default) -- CU-wide slices with every row owned by one wavefront, all
     LDS adds of a row from that wavefront in program order (ascending panels, ascending columns); rowown = 0 -- the wavefront-private slices of
     rounds 2-4.  Both: every row bit for bit the reference's left fold, reruns bit-identical, device builder == host builder."""
     build, expect_tiles = CASES[name]

@@ -67,7 +67,9 @@ FORMS = (("default", {}), ("no march", {"wd_march": 0}), ("gather (wd_lds=0)", {
          ("no tiles", {"tiles": 0}), ("no tiles, no col panels", {"tiles": 0, "panels": 0}), ("no LDS panels", {"lpanel": 0}),
          ("no LDS panels, no tiles", {"lpanel": 0, "tiles": 0, "panels": 0}), ("LDS panels forced", {"lp_minseg": 1}),
          ("tiles, 2^16-column panels", {"lpanel": 0, "tile_shift": 16}), ("tiles, 2^15-column panels", {"lpanel": 0, "tile_shift": 15}),
-         ("wavefront-private exact tiles", {"lpanel": 0, "lflat": 0, "tile_relaxed": 0}),
+         ("wavefront-private exact tiles", {"lpanel": 0, "lflat": 0, "tile_relaxed": 0, "tile_rowown": 0}),
+         ("row-owned exact CU tiles", {"lpanel": 0, "lflat": 0, "tile_relaxed": 0}),
+         ("no tiles, no lflat", {"tiles": 0, "lflat": 0}),
          ("CU tiles relaxed", {"lpanel": 0, "lflat": 0, "tile_relaxed": 1}),
          ("CU tiles relaxed 2^15", {"lpanel": 0, "lflat": 0, "tile_relaxed": 1, "tile_shift": 15}),
          ("CU tiles relaxed 2^17", {"lpanel": 0, "lflat": 0, "tile_relaxed": 1, "tile_shift": 17}),
@@ -80,7 +82,7 @@ FORMS = (("default", {}), ("no march", {"wd_march": 0}), ("gather (wd_lds=0)", {
 
 
 def algo_of(info):
-    return info.split()[0] + "".join(" " + t for t in info.split() if t.startswith(("panel_cols=", "exact_fold=", "cu_slices=")))
+    return info.split()[0] + "".join(" " + t for t in info.split() if t.startswith(("panel_cols=", "exact_fold=", "cu_slices=", "row_owned=")))
 
 
 def run(name, steps=60, forms=FORMS, out=print, scale=None):

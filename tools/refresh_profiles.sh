@@ -18,6 +18,10 @@ run random_spd_1m $B --workload random_spd_1m --no-cpu-baseline
 run random_spd_10m_bicgstab python bench.py --workload random_spd_10m --steps 40 --warmup 5 --no-cpu-baseline
 run random_spd_10m_cgs python bench.py --workload random_spd_10m --method cgs --steps 40 --warmup 5 --no-cpu-baseline
 run dense_rows_200k python bench.py --workload dense_rows_200k --steps 40 --warmup 5 --no-cpu-baseline
+# (end of round 6: the exact fold is the default; the relaxed order of round 5 beside it as the opt-in it is now)
+SLA_TILE_RELAXED=1 run random_spd_1m_relaxed $B --workload random_spd_1m --no-cpu-baseline
+SLA_TILE_RELAXED=1 run random_spd_10m_bicgstab_relaxed python bench.py --workload random_spd_10m --steps 40 --warmup 5 --no-cpu-baseline
+SLA_TILE_RELAXED=1 run random_spd_10m_cgs_relaxed python bench.py --workload random_spd_10m --method cgs --steps 40 --warmup 5 --no-cpu-baseline
 # the same default command under the kernel tracer (per-kernel durations must agree with bench.py's HIP events)
 rocprofv3 --kernel-trace --stats --output-format csv -d $S/ks -o ks -- python bench.py --no-cpu-baseline --no-extra-blocks 2>/dev/null | tail -1 > $S/${tag}_bench_traced_run.json
 cp "$(find $S/ks -name '*kernel_stats.csv' | head -1)" $S/${tag}_bench_kernel_stats.csv
@@ -126,7 +130,7 @@ SLA_BENCH_LOOPBACK=1 SLA_FAULT_INJECT=p2p_hang SLA_BENCH_PREFLIGHT_S=5 timeout 9
 # round 5: the form tournament over the matrix zoo (the pick against every forced form) and the lowering phases of configs 3a / 4
 for w in laplace3d_10m laplace3d_1m banded_2m poisson2d_1m e05_tiled e05_tiled_10m varcoef7 random_spd_1m rand100 rand200 rand500 powerlaw; do timeout 900 python tools/form_tournament.py $w 40 2>/dev/null | grep -v "^#"; done > $S/${tag}_form_tournament.txt 2>&1
 { timeout 600 python tools/lower_phases.py random_spd_10m 3; timeout 600 python tools/lower_phases.py laplace3d_10m 3; } > $S/${tag}_lowering_phases.txt 2>&1
-timeout 900 python tools/tile_bench.py 10000000 "DEFAULT=1" "SLA_TILE_RELAXED=0" "SLA_TILE_DEPTH=1" "SLA_TILE_SLACK=2" "SLA_TILE_SLACK=4" "SLA_TILE_SLACK=0" "SLA_TILE_SHIFT=16" > $S/${tag}_ab_tile_knobs.txt 2>&1
+timeout 900 python tools/tile_bench.py 10000000 "DEFAULT=1" "SLA_TILE_RELAXED=1" "SLA_TILE_RELAXED=1 SLA_TILE_DEPTH=1" "SLA_TILE_SLACK=2" "SLA_TILE_SLACK=4" "SLA_TILE_SLACK=0" "SLA_TILE_SHIFT=16" > $S/${tag}_ab_tile_knobs.txt 2>&1
 # round 6: the on-chip solver step (one persistent launch) against the launch flow on the sizes it takes -- config 2 and config 4's per-rank slab at N = 8
 for w in poisson2d_1m laplace3d_slab8 laplace3d_1m; do
   run onchip_$w $B --workload $w --no-cpu-baseline --no-extra-blocks
@@ -140,8 +144,9 @@ run linsolve0_onchip_poisson2d_1m $B --workload poisson2d_1m --mode linsolve0 --
 SLA_ONCHIP=0 run linsolve0_launchflow_poisson2d_1m $B --workload poisson2d_1m --mode linsolve0 --no-cpu-baseline --no-extra-blocks
 rocprofv3 --kernel-trace --stats --output-format csv -d $S/kso -o ks -- python bench.py --workload poisson2d_1m --steps 200 --warmup 20 --no-cpu-baseline --no-extra-blocks 2>/dev/null | tail -1 > $S/${tag}_bench_traced_run_poisson2d_1m.json
 cp "$(find $S/kso -name '*kernel_stats.csv' | head -1)" $S/${tag}_bench_kernel_stats_poisson2d_1m.csv
-# round 6: the exact tile forms (rows owned by wavefronts / wavefront-private slices) beside the relaxed default on config 3a; the asymmetric pre-flight failure
-timeout 900 python tools/tile_bench.py 10000000 "DEFAULT=1" "SLA_TILE_RELAXED=0" "SLA_TILE_RELAXED=0 SLA_TILE_ROWOWN=0" > $S/${tag}_tile_exact_forms.txt 2>&1
+# round 6: the exact tile forms (rows owned by wavefronts = the default / wavefront-private slices) beside the relaxed order (opt-in) on config 3a; the asymmetric pre-flight failure
+timeout 900 python tools/tile_bench.py 10000000 "DEFAULT=1" "SLA_TILE_RELAXED=1" "SLA_TILE_ROWOWN=0" > $S/${tag}_tile_exact_forms.txt 2>&1
+timeout 1200 python tools/tile_default_ab.py 2>/dev/null | grep -v "^\[" > $S/${tag}_tile_default_ab.txt
 SLA_BENCH_LOOPBACK=1 SLA_FAULT_INJECT=p2p_data_rank1 timeout 900 python bench.py --gpus 2 --workload laplace3d_small --steps 20 --warmup 5 2>$S/${tag}_bench_loopback_fault_rank1_stderr.txt | grep '^{' | tail -1 > $S/${tag}_bench_loopback_fault_rank1.json
 SLA_BENCH_LOOPBACK=1 timeout 900 python bench.py --gpus 2 --steps 40 --warmup 5 --no-cpu-baseline 2>$S/${tag}_bench_loopback_2ranks_stderr.txt | grep '^{' | tail -1 > $S/${tag}_bench_loopback_2ranks.json
 # round 6: one real run past 2^31 stored entries (lowering, (#>) on all rows and two bicgstabSteps against the oracle)

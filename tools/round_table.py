@@ -54,9 +54,15 @@ if d:
     if r3.get("value"):
         print(f"| **3a (10 M random SPD, 33 per row)** — `random_spd_10m` block of the same line | {r3['ms_per_step']:.2f} ms | **{r3['value']:.1f}** | "
               f"**{r3['k1_ms']:.3f} ms = {r3['k1_csr_frac']:.3f}** on CSR bytes (`north_star_target`) | K1 / K3 | "
-              f"{' '.join(t for t in r3['spmv_kernel'].split() if t.startswith(('algo=', 'exact_fold', 'cu_slices', 'slices', 'panels')))}; lowered in {r3['lowered_once']['from_csr_s']:.3f} s"
+              f"{' '.join(t for t in r3['spmv_kernel'].split() if t.startswith(('algo=', 'exact_fold', 'cu_slices', 'row_owned', 'slices', 'panels')))}; lowered in {r3['lowered_once']['from_csr_s']:.3f} s"
               + (f"; gather-fabric ceiling {d['north_star_target']['ceiling']['k1_ms_at_ceiling']:.2f} ms: K1 at {d['north_star_target']['ceiling']['frac_of_ceiling']:.2f} of it"
                  if (d.get('north_star_target') or {}).get('ceiling') else "") + " |")
+    rx = (d.get("north_star_target") or {}).get("relaxed_order_opt_in") or {}
+    if rx.get("iters_per_s"):
+        cx = rx.get("ceiling") or {}
+        print(f"| … 3a with the OPT-IN `tile_relaxed = 1` (row sums in relaxed order: within the rounding bound, not reproducible bit for bit) — same line | | **{rx['iters_per_s']:.1f}** | "
+              f"{rx['k1_ms']:.3f} ms = {rx['k1_frac']:.3f} on CSR bytes | K1 / K3 | {rx['spmv_kernel']}"
+              + (f"; gather-fabric ceiling {cx['k1_ms_at_ceiling']:.2f} ms: K1 at {cx['frac_of_ceiling']:.2f} of it" if cx else "") + " |")
     if cb:
         print(f"| 4, CPU oracle port (same run, host cores of the GPU box) | | {cb.get('value', 0):.2f} ({cb.get('cores')} thread) / "
               f"{(cb.get('omp') or {}).get('value', 0):.1f} ({(cb.get('omp') or {}).get('cores')} threads OpenMP) | | | {cb.get('sample', '')[:120]} |")
@@ -94,9 +100,12 @@ print(onchip_row("4's per-rank slab at N = 8 (216 × 216 × 27), on-chip against
 print(onchip_row("108³ (1.26 M rows), on-chip against the launch flow", "laplace3d_1m"))
 print(row("5-matrix (2 M banded) bicgstabStep", load("banded_2m")))
 print(row("5 (2 M banded) GMRES(30) Arnoldi step", load("gmres_banded_2m")))
-print(row("3a BiCGSTAB as the headline workload", load("random_spd_10m_bicgstab")))
-print(row("3a CGS", load("random_spd_10m_cgs")))
-print(row("3a at 1 M rows", load("random_spd_1m")))
+print(row("3a BiCGSTAB as the headline workload (default: exact fold)", load("random_spd_10m_bicgstab")))
+print(row("3a BiCGSTAB, opt-in relaxed order (`SLA_TILE_RELAXED=1`)", load("random_spd_10m_bicgstab_relaxed")))
+print(row("3a CGS (default: exact fold)", load("random_spd_10m_cgs")))
+print(row("3a CGS, opt-in relaxed order", load("random_spd_10m_cgs_relaxed")))
+print(row("3a at 1 M rows (default: exact fold)", load("random_spd_1m")))
+print(row("3a at 1 M rows, opt-in relaxed order", load("random_spd_1m_relaxed")))
 print(row("3b (200 k rows, 2000 per row)", load("dense_rows_200k")))
 for xe in ("window", "allgather"):
     for f in (1, 0):
