@@ -57,6 +57,27 @@ def test_config3a_random_spd_1m_cgs_vs_bicgstab(sla):
         assert np.linalg.norm(x.toDenseListSV() - xs) <= 1e-3 * np.linalg.norm(xs)
 
 
+def test_bench_default_line_as_the_driver_types_it():
+    """`python bench.py --gpus 1 --steps 20 --warmup 5` at FULL size (the CPU leg shortened): BASELINE.json's metric answered at the top level -- BiCGSTAB
+    iterations / s on config 4, the literal CSR SpMV fraction, and the north star's own matrix (config 3a) under BOTH folds: the default (exact, reruns
+    bit-identical: rows owned by wavefronts) and the opt-in relaxed order with the ceiling of its access pattern."""
+    env = {k: v for k, v in os.environ.items() if not k.startswith("SLA_")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5", "--cpu-seconds", "0.5"],
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["metric"] == "bicgstab_iters_per_sec" and d["n_gpus"] == 1 and d["steps"] == 20 and d["config"]["rows"] == 10077696
+    assert 0.5 < d["roofline"]["frac"] <= 1.0 and 0.5 < d["csr_spmv_frac"] <= 1.0 and d["csr_spmv_kernel"] == "algo=stream+wave"
+    ns = d["north_star_target"]
+    assert "exact_fold=1" in ns["spmv_kernel"] and "row_owned=1" in ns["spmv_kernel"] and ns["fold"].startswith("exact")
+    rx = ns["relaxed_order_opt_in"]
+    assert "exact_fold=0" in rx["spmv_kernel"] and rx["option"] == "tile_relaxed=1"
+    assert rx["iters_per_s"] > ns["iters_per_s"] > 0.7 * rx["iters_per_s"]                # the price of a reproducible default: 15 - 20 %
+    assert 0.6 < rx["ceiling"]["frac_of_ceiling"] <= 1.0 and rx["ceiling"]["hbm_roof_ms"] < rx["ceiling"]["k1_ms_at_ceiling"] < rx["k1_ms"]
+
+
 @pytest.mark.parametrize("fuse45", ["1", "0", "onchip"])
 def test_bench_contract_small(fuse45):
     """fuse45 = 1 (single rank): K4 and K5 are one sweep (K45), K3 also streams r0hat; 0: the reference's split -- both with the launch
