@@ -370,7 +370,8 @@ int sla_csr_kernel_info(sla_csr_t, char *buf, int buflen);
 /* Typed properties of a lowered matrix (what sla_csr_kernel_info prints, for callers that must not parse a string).
  * fold: how (#>) adds the products of a row (Common.hs:247-260 folds them left to right in ascending column order):
  *   SLA_FOLD_EXACT      that fold bit for bit on every row, reruns bit-identical (value-indexed forms, wave / exact tile forms);
- *   SLA_FOLD_REGROUPED  a FIXED regrouping for long rows (lane-group / wavefront / workgroup partial sums): within
+ *   SLA_FOLD_REGROUPED  a FIXED regrouping for long rows (lane-group / wavefront / workgroup partial sums; on a row slab whose x arrives in
+ *                       exchange groups, the tile form's fold over the column panels in the plan's visiting order): within
  *                       nnz_i * eps * sum |a_ij x_j| of the reference's value, reruns bit-identical;
  *   SLA_FOLD_RELAXED    the same set of separately rounded products added in timing order (LDS atomics of the CU-wide tile form):
  *                       same bound, NOT reproducible bit for bit from run to run.  Only with option tile_relaxed = 1 (opt-in: 17 % more

@@ -457,7 +457,12 @@ int fold_kind(const sla_csr *A) {
     if (A->use_vdict && c->vdict) return SLA_FOLD_EXACT;
     if (A->use_lpanel && c->lpanel) return SLA_FOLD_REGROUPED;
     if (lflat_on(A)) return SLA_FOLD_REGROUPED;
-    if (tiles_on(A)) return (A->tl_cu && !A->tl_rowown) ? SLA_FOLD_RELAXED : SLA_FOLD_EXACT;
+    if (tiles_on(A)) {
+        if (A->tl_cu && !A->tl_rowown) return SLA_FOLD_RELAXED;
+        // row slabs whose x arrives in exchange groups: a row is folded over the column panels in the plan's VISITING order (own panels first, then by
+        // group) -- fixed, reproducible, the oracle restates it (orc_spmv_panel_order), but not the ascending order: a regrouping
+        return (ag_split(A) && A->ag->order != 1) ? SLA_FOLD_REGROUPED : SLA_FOLD_EXACT;
+    }
     if (!A->panels.empty() && c->panels) return SLA_FOLD_REGROUPED;
     if (!diag_on(A) && !stream_xwin_on(A) && wave_plain(A)) return SLA_FOLD_EXACT;
     return SLA_FOLD_REGROUPED;

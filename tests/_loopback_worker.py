@@ -120,7 +120,7 @@ def rank_main(rank):
         xv = sla.DeviceVector(ctx, n, xg[b:e], local=True)
         yv = sla.DeviceVector(ctx, n)
         _lib.check(lib.sla_spmv(A.h, xv.h, yv.h))
-        r = {"kernel": A.kernel_info(), "y": yv.to_host_local(), "range": (b, e)}
+        r = {"kernel": A.kernel_info(), "y": yv.to_host_local(), "range": (b, e), "fold": A.props()["fold"]}
         if QUICK:
             bvec = sla.DeviceVector(ctx, n, bg[b:e], local=True)
             st = sla.bicgsInit(A, bvec, sla.DeviceVector(ctx, n))
@@ -183,6 +183,7 @@ elif KIND == "randtile" and "exact_fold=0" in results[0]["kernel"]:
     # within nnz_i eps sum |a_ij x_j| of the reference's fold, whatever the exchange flow (overlapped passes, plain all-gather)
     bound = np.diff(RP) * np.finfo(np.float64).eps * orc.spmv(orc.Csr(n, n, RP, CI, np.abs(VA)), np.abs(xg))
     assert np.all(np.abs(y - yo) <= bound), float((np.abs(y - yo) / np.maximum(bound, 1e-300)).max())
+    assert all(results[r]["fold"] == 2 for r in range(P))           # SLA_FOLD_RELAXED, typed
     print("RELAXED_ORDER_ROWS_WITHIN_BOUND", n)
 elif KIND == "randtile" and "allgather=arrival" in results[0]["kernel"]:
     # Overlapped all-gather in arrival order: every rank folds its rows over the column panels in ITS visiting
@@ -199,9 +200,12 @@ elif KIND == "randtile" and "allgather=arrival" in results[0]["kernel"]:
         moved += int(np.count_nonzero(exp[-1] != yo[b:e]))
     assert np.array_equal(y, np.concatenate(exp)), "overlapped all-gather: rows must equal the left fold over the panels in the plan's visiting order bit for bit"
     assert np.abs(y - yo).max() <= 4e-15 * np.abs(VA).max() * np.abs(xg).max() * 16      # ... and the reference's ascending fold to rounding
+    assert all(results[r]["fold"] == 1 for r in range(P))           # SLA_FOLD_REGROUPED: a fixed panel order that is not the ascending one
     print("PANEL_ORDER_ROWS_DIFFERING_FROM_ASCENDING", moved, "of", n)
 else:
     assert np.array_equal(y, yo), "sharded (#>) must equal the whole-matrix left fold bit for bit"
+    if KIND == "randtile":
+        assert all(results[r]["fold"] == 0 for r in range(P))       # SLA_FOLD_EXACT: ascending panel passes / one launch behind a plain all-gather
 if QUICK:
     so = orc.BicgstabState(Ao, bg, np.zeros(n))
     so.step(bg, 3)
