@@ -99,6 +99,7 @@ def test_options_are_typed_per_context_and_reach_every_rank(sla):
     assert a.set_option("x_exchange", "window").get_option("x_exchange") == "window"
     # the knobs of round 3: defaults, ranges
     assert b.get_option("wd_march") == "1" and b.get_option("wd_march_occ") == "4" and b.get_option("lp_copy") == "1"
+    assert b.get_option("tile_relaxed") == "0" and b.get_option("tile_rowown") == "-1"   # no default form is order-relaxed (end of round 6)
     assert int(b.get_option("vec_policy")) == 0x2bff          # every BiCGSTAB stream but the p store, CGS's q and u stores: past the caches
     for name, bad in (("wd_march", 3), ("wd_march_occ", 5), ("lp_copy", 2), ("vec_policy", 1 << 15)):
         with pytest.raises(sla.SlaError):
