@@ -500,6 +500,7 @@ const IntKnob kIntKnobs[] = {
     {"wave_cc", &sla_ctx::wave_cc, 0, 4096},
     {"wave_sync", &sla_ctx::wave_sync, 0, 1},
     {"wave_over", &sla_ctx::wave_over, 0, 8},
+    {"arn_orth", &sla_ctx::arn_orth, 0, 1},
     {"stream_wide", &sla_ctx::stream_wide, 0, 1},
     {"diag", &sla_ctx::diag, 0, 2},
     {"diag_lazy", &sla_ctx::diag_lazy, 0, 1},
@@ -625,6 +626,8 @@ static std::string ctx_option_value(const sla_ctx *c, const std::string &name, b
     if (name == "x_exchange") return c->x_exchange == 1 ? "allgather" : c->x_exchange == 2 ? "window" : "auto";
     if (name == "onchip_launches") return std::to_string(c->onchip_launches);   // (read-only)
     if (name == "onchip_fallbacks") return std::to_string(c->onchip_fallbacks);   // (read-only)
+    if (name == "arn_orth_launches") return std::to_string(c->arn_orth_launches);   // (read-only)
+    if (name == "arn_orth_fallbacks") return std::to_string(c->arn_orth_fallbacks);   // (read-only)
     if (name == "onchip_plan") return c->onchip_note;
     if (name == "onchip_plan_ms") return std::to_string(c->onchip_plan_ms);   // (read-only) planning time of the last matrix planned
     if (name == "tri_mode_used") return std::to_string(c->tri_mode_used);

@@ -270,6 +270,11 @@ struct sla_ctx {
     int onchip_sync = 0;             // ... its grid-wide synchronisation: 0 = XCD-hierarchical arrival counters (default), 1 = one epoch word per workgroup polled by everybody
                                      // (one hop on paper; measured SLOWER: 17.4 against 14.6 us per BiCGSTAB step at 1 M rows -- 256 x 256 scoped polling loads per round)
     int onchip_fault = 0;            // test hook: 1 = the last workgroup of an on-chip launch leaves at once (the others' barrier times out after 2 s: a lost CU, rehearsed)
+    int arn_orth = 1;                // one Arnoldi step's Gram-Schmidt (dots | update | normalisation) as ONE persistent launch with w in registers and six basis columns of
+                                     // the block kept on chip between the passes (sla_arnoldi_orth.hip; single-rank, <= 8192 rows per CU): 0 = the three launches
+    int arn_orth_state = 0;          // ... 0 not asked yet, 1 the kernel is resident with one workgroup per CU, -1 it is not (launch flow)
+    long arn_orth_launches = 0;      // (read-only)
+    long arn_orth_fallbacks = 0;     // (read-only) Arnoldi runs repeated on the launch flow after a fused step reported SLA_FLAG_SYNC_TIMEOUT
     long onchip_fallbacks = 0;       // (read-only) linSolve0 calls re-run on the launch flow after an on-chip launch reported SLA_FLAG_SYNC_TIMEOUT
     int onchip_grid = 0;             // ... its workgroups at most (0: one per CU; tests use small grids)
     int onchip_rows = 0;             // ... rows per workgroup at most (0: what the registers hold: 12 x 512; tests force short blocks)
@@ -972,6 +977,11 @@ int launch_init_scalars(sla_ctx *c, SolverScalars *sc, Parts rho, Parts r0sq, do
 int launch_set_rho(sla_ctx *c, SolverScalars *sc, Parts rho, int par);   // sc->rho2[par] = sum(rho)
 // Arnoldi (Sparse.hs:630-667); Q column-major with leading dimension ldq
 int launch_arn_dots(sla_ctx *c, int64_t n, const double *Q, int64_t ldq, int ncols, const double *w, double *parts, SolverScalars *sc);
+// sla_arnoldi_orth.hip: the three Gram-Schmidt launches of an Arnoldi step as one persistent launch (single-rank contexts that fit)
+size_t arn_orth_bar_bytes();
+bool arn_orth_usable(sla_ctx *c, int64_t n, int64_t ldq, int ncols_max);
+int launch_arn_orth(sla_ctx *c, int64_t n, const double *Q, int64_t ldq, int ncols, const double *w, double *qnext, double *Hcol, double *hsub,
+                    SolverScalars *sc, double *parts, unsigned *bar, int first);
 int arn_grid(int64_t n);  // grid (= partials per column) of the Arnoldi update / normalise kernels
 int arn_dots_grid(int64_t n, int ncols);   // ... of the dots pass over ncols basis columns
 // partial i of column j lives at hp[j * cs + i * stride], i < np

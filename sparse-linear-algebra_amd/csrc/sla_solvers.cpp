@@ -643,8 +643,10 @@ struct ArnoldiWs {
     int64_t halo = 0;           // row-sharded, window exchange: slack on both sides of every basis column for the neighbours' planes
     int64_t begin = 0, shard = 0;
     SolverScalars *d_sc = nullptr, *h_sc = nullptr;
+    unsigned *bar = nullptr;    // arrival counters + epoch word of the fused Gram-Schmidt step (sla_arnoldi_orth.hip); zeroed once
     std::vector<double> Hhost;
     ~ArnoldiWs() {
+        if (bar) (void)hipFree(bar);
         if (Qalloc) (void)guard_free(Qalloc);
         if (w) (void)hipFree(w);
         if (H) (void)hipFree(H);
@@ -686,6 +688,8 @@ int arn_alloc(ArnoldiWs &ws, sla_csr *A, sla_vec *like, int kn) {
     SLA_HIP_TRY(dev_malloc(c, (void **)&ws.gath, sizeof(double) * ((size_t)(kMaxKrylov + 2) * (size_t)c->nranks + kMaxKrylov + 8)));
     SLA_HIP_TRY(dev_malloc(c, (void **)&ws.ycoef, sizeof(double) * (kMaxKrylov + 2)));
     SLA_HIP_TRY(dev_malloc(c, (void **)&ws.d_sc, sizeof(SolverScalars)));
+    SLA_HIP_TRY(dev_malloc(c, (void **)&ws.bar, arn_orth_bar_bytes()));
+    SLA_HIP_TRY(hipMemsetAsync(ws.bar, 0, arn_orth_bar_bytes(), stream_of(c)));
     SLA_HIP_TRY(hipHostMalloc((void **)&ws.h_sc, sizeof(SolverScalars), hipHostMallocDefault));
     ws.Hhost.assign((size_t)(kn + 1) * (size_t)kn, 0.0);
     return SLA_OK;
@@ -739,6 +743,7 @@ int arn_run(ArnoldiWs &ws, sla_csr *A, const double *src_local, int kn, int *k_d
     const int64_t n = ws.n_local;
     const int ldh = ws.kn + 1;
     const int g = arn_grid(n);
+    const bool orth = ws.halo == 0 && arn_orth_usable(c, n, ws.ld, kn);
     SLA_HIP_TRY(hipMemsetAsync(ws.H, 0, sizeof(double) * (size_t)ldh * (size_t)ws.kn, stream_of(c)));
     SLA_HIP_TRY(hipMemsetAsync(ws.d_sc, 0, sizeof(SolverScalars), stream_of(c)));
     ColParts cp;
@@ -764,6 +769,11 @@ int arn_run(ArnoldiWs &ws, sla_csr *A, const double *src_local, int kn, int *k_d
             SLA_TRY(gather_raw(c, A, qi, (ws.n + c->nranks - 1) / c->nranks, &l.x));
             SLA_TRY(launch_spmv(A, l));
         }
+        if (orth) {   // hhcoli, qipnn, qip, h_{i+1,i} and the breakdown test in ONE persistent launch (sla_arnoldi_orth.hip)
+            SLA_TRY(launch_arn_orth(c, n, ws.Q, ws.ld, i + 1, ws.w, ws.Q + (size_t)(i + 1) * ws.ld, ws.H + (size_t)i * ldh, ws.H + (size_t)i * ldh + i + 1,
+                                    ws.d_sc, ws.parts, ws.bar, i == 0 ? 1 : 0));
+            continue;
+        }
         // hhcoli = fmap (`dot` aqi) qv
         SLA_TRY(launch_arn_dots(c, n, ws.Q, ws.ld, i + 1, ws.w, ws.parts, ws.d_sc));
         SLA_TRY(arn_publish(ws, ws.parts, arn_dots_grid(n, i + 1), i + 1, &cp));
@@ -780,6 +790,14 @@ int arn_run(ArnoldiWs &ws, sla_csr *A, const double *src_local, int kn, int *k_d
     SLA_HIP_TRY(hipMemcpyAsync(ws.Hhost.data(), ws.H, sizeof(double) * (size_t)ldh * (size_t)ws.kn, hipMemcpyDeviceToHost, stream_of(c)));
     SLA_HIP_TRY(hipMemcpyAsync(ws.h_sc, ws.d_sc, sizeof(SolverScalars), hipMemcpyDeviceToHost, stream_of(c)));
     SLA_HIP_TRY(hipStreamSynchronize(stream_of(c)));
+    if (orth && (ws.h_sc->flags & SLA_FLAG_SYNC_TIMEOUT)) {
+        // a fused step gave up waiting for its other workgroups (CUs held by another job): its counters are in an unknown state and the basis is
+        // incomplete -- the launch flow from here on for this context, the counters cleared, the whole run repeated (src is untouched)
+        c->arn_orth = 0;
+        c->arn_orth_fallbacks += 1;
+        SLA_HIP_TRY(hipMemsetAsync(ws.bar, 0, arn_orth_bar_bytes(), stream_of(c)));
+        return arn_run(ws, A, src_local, kn, k_done);
+    }
     *k_done = ws.h_sc->kdone;
     return SLA_OK;
 }

@@ -409,7 +409,7 @@ def test_forced_collectives_match_single_gpu_path(sla, monkeypatch):
     monkeypatch.setenv("SLA_FORCE_COLLECTIVES", "1")       # (read when the communicator is built: not a per-context option)
     ctx = sla.Context(0, 0, 1, sla.Context.unique_id()).set_option("bicg_fuse45", 0)
     monkeypatch.delenv("SLA_FORCE_COLLECTIVES")
-    plain = sla.Context(0).set_options(bicg_fuse45=0, onchip=0)   # (the launch flow on both sides: the comparison is bit for bit)
+    plain = sla.Context(0).set_options(bicg_fuse45=0, onchip=0, arn_orth=0)   # (the launch flows on both sides: the comparison is bit for bit)
     dims, (rp, ci, va) = wl.poisson2d(50, 40)
     n = dims[0]
     b = np.add.reduceat(va, rp[:-1])
