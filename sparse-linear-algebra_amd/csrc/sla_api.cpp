@@ -501,6 +501,7 @@ const IntKnob kIntKnobs[] = {
     {"wave_sync", &sla_ctx::wave_sync, 0, 1},
     {"wave_over", &sla_ctx::wave_over, 0, 8},
     {"arn_orth", &sla_ctx::arn_orth, 0, 1},
+    {"arn_orth_fault", &sla_ctx::arn_orth_fault, 0, 1},
     {"stream_wide", &sla_ctx::stream_wide, 0, 1},
     {"diag", &sla_ctx::diag, 0, 2},
     {"diag_lazy", &sla_ctx::diag_lazy, 0, 1},

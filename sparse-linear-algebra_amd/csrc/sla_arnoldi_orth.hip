@@ -66,6 +66,7 @@ struct ArnOrthArgs {
     int first;
     int R;             // rows per workgroup (even)
     int nt;            // pass 2 reads the streamed columns non-temporally (the basis overflows the memory-side cache)
+    int fault;         // test hook (option arn_orth_fault): the last workgroup leaves at once -- the others' barrier times out (a lost CU, rehearsed)
 };
 
 __device__ __forceinline__ void ao_st_agent(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -124,6 +125,7 @@ __global__ void __launch_bounds__(AT) arn_orth_kernel(ArnOrthArgs a) {
     if (arn_stopped(sc)) return;                       // (a flag of an EARLIER launch: every workgroup takes the same exit)
     if (sc->flags & SLA_FLAG_SYNC_TIMEOUT) return;     // (an earlier fused step of this run lost its barrier: the host repeats the run on the launch flow)
     const int b = blockIdx.x, t = threadIdx.x, G = gridDim.x, wave = t >> 6, lane = t & 63;
+    if (a.fault && b == G - 1 && G > 1) return;
     const int ncols = a.ncols;
     const unsigned e0 = __hip_atomic_load(a.bar + 32 * 18, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int64_t r0 = (int64_t)b * a.R, r1 = min(a.n, r0 + a.R);
@@ -363,6 +365,7 @@ int launch_arn_orth(sla_ctx *c, int64_t n, const double *Q, int64_t ldq, int nco
     a.n = n; a.Q = Q; a.ldq = ldq; a.ncols = ncols; a.w = w; a.qnext = qnext; a.Hcol = Hcol; a.hsub = hsub; a.sc = sc; a.parts = parts; a.bar = bar;
     a.first = first;
     a.R = (int)R;
+    a.fault = c->arn_orth_fault;
     a.nt = c->vec_nt < 0 ? ((int64_t)ncols * 8 * n > c->mall_bytes ? 1 : 0) : (c->vec_nt != 0 ? 1 : 0);
     hipLaunchKernelGGL(arn_orth_kernel, dim3(G), dim3(AT), kArnOrthLds, stream_of(c), a);
     SLA_HIP_TRY(hipGetLastError());

@@ -272,6 +272,7 @@ struct sla_ctx {
     int onchip_fault = 0;            // test hook: 1 = the last workgroup of an on-chip launch leaves at once (the others' barrier times out after 2 s: a lost CU, rehearsed)
     int arn_orth = 1;                // one Arnoldi step's Gram-Schmidt (dots | update | normalisation) as ONE persistent launch with w in registers and six basis columns of
                                      // the block kept on chip between the passes (sla_arnoldi_orth.hip; single-rank, <= 8192 rows per CU): 0 = the three launches
+    int arn_orth_fault = 0;          // ... test hook: the last workgroup of a fused step leaves at once (the timeout / fallback path, tests/test_gpu_arnoldi_orth.py)
     int arn_orth_state = 0;          // ... 0 not asked yet, 1 the kernel is resident with one workgroup per CU, -1 it is not (launch flow)
     long arn_orth_launches = 0;      // (read-only)
     long arn_orth_fallbacks = 0;     // (read-only) Arnoldi runs repeated on the launch flow after a fused step reported SLA_FLAG_SYNC_TIMEOUT

@@ -93,3 +93,22 @@ def test_gmres_through_the_fused_step(sla):
     assert np.linalg.norm(orc.spmv(Ao, x1) - b) <= i1["tol"] * (1 + 1e-9)
     rc, xo, it_o, res_o, r0_o = orc.gmres(Ao, b, np.zeros(n), restart=30, max_restarts=10)
     assert i1["iters"] == it_o and np.linalg.norm(x1 - xo) <= 1e-9 * np.linalg.norm(xo)
+
+
+def test_a_lost_workgroup_falls_back_to_the_launch_flow(sla):
+    """arn_orth_fault = 1: the last workgroup of every fused step leaves at once, the others' first barrier times out (~2 s), the step flags
+    SLA_FLAG_SYNC_TIMEOUT, the later steps of the run return at once -- and the host repeats the whole run on the launch flow and keeps it for the context."""
+    from sla_amd import workloads as wl
+    n, kn = 40000, 6
+    dims, (rp, ci, va) = wl.banded_nonsym(n)
+    b = np.random.default_rng(8).standard_normal(n)
+    ctx = sla.Context(0).set_options(arn_orth=1, arn_orth_fault=1)
+    A = sla.fromCSR(dims, rp, ci, va, ctx)
+    Q, H = sla.arnoldi(A, sla.fromVector(b, ctx), kn)
+    assert int(ctx.get_option("arn_orth_fallbacks")) == 1 and ctx.get_option("arn_orth") == "0"
+    rc, Qo, Ho, k = orc.arnoldi(orc.Csr(n, n, rp, ci, va), b, kn)
+    assert np.abs(H - Ho).max() <= 1e-10 * np.abs(Ho).max() and np.abs(Q - Qo).max() <= 1e-9
+    Q2, H2 = sla.arnoldi(A, sla.fromVector(b, ctx), kn)                     # the context stays on the launch flow: no second timeout
+    assert int(ctx.get_option("arn_orth_fallbacks")) == 1 and np.array_equal(H2, H)
+    del A
+    ctx.close()
