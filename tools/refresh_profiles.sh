@@ -14,6 +14,7 @@ run cgs $B --method cgs --no-cpu-baseline --no-extra-blocks
 run poisson2d_1m $B --workload poisson2d_1m --no-cpu-baseline
 run banded_2m $B --workload banded_2m --no-cpu-baseline
 run gmres_banded_2m python bench.py --mode gmres --workload banded_2m --steps 120 --warmup 0 --no-cpu-baseline
+SLA_ARN_ORTH=0 run gmres_banded_2m_launchflow python bench.py --mode gmres --workload banded_2m --steps 120 --warmup 0 --no-cpu-baseline
 run random_spd_1m $B --workload random_spd_1m --no-cpu-baseline
 run random_spd_10m_bicgstab python bench.py --workload random_spd_10m --steps 40 --warmup 5 --no-cpu-baseline
 run random_spd_10m_cgs python bench.py --workload random_spd_10m --method cgs --steps 40 --warmup 5 --no-cpu-baseline

@@ -99,7 +99,9 @@ print(pair_row("2, `linSolve0 BICGSTAB_` on chip (step + true residual + test pe
 print(onchip_row("4's per-rank slab at N = 8 (216 × 216 × 27), on-chip against the launch flow", "laplace3d_slab8"))
 print(onchip_row("108³ (1.26 M rows), on-chip against the launch flow", "laplace3d_1m"))
 print(row("5-matrix (2 M banded) bicgstabStep", load("banded_2m")))
-print(row("5 (2 M banded) GMRES(30) Arnoldi step", load("gmres_banded_2m")))
+lf = load("gmres_banded_2m_launchflow") or {}
+print(row("5 (2 M banded) GMRES(30) Arnoldi step — the Gram–Schmidt as ONE persistent launch per step (end of round 6)", load("gmres_banded_2m"),
+          f"three launches per step (`arn_orth = 0`) on the same box: {lf.get('ms_per_step', 0) * 1e3:.1f} µs = {lf.get('value', 0):.0f} steps / s" if lf.get("value") else ""))
 print(row("3a BiCGSTAB as the headline workload (default: exact fold)", load("random_spd_10m_bicgstab")))
 print(row("3a BiCGSTAB, opt-in relaxed order (`SLA_TILE_RELAXED=1`)", load("random_spd_10m_bicgstab_relaxed")))
 print(row("3a CGS (default: exact fold)", load("random_spd_10m_cgs")))
