@@ -410,6 +410,68 @@ def side_block(name, dims, rp, ci, va, options, steps, warmup, rhs="A.1"):
     return rec
 
 
+def baseline_config_blocks():
+    """BASELINE configs 2 and 5 beside the headline, in the driver's own line (round 6): each in its default flow -- ONE persistent launch where
+    the state fits the chip (bicgstabStep on the 1 M-row Poisson matrix: csrc/sla_onchip.hip; the Gram-Schmidt of an Arnoldi step on the 2 M-row
+    banded matrix: csrc/sla_arnoldi_orth.hip) -- and in the launch flow it replaces, same process, same box.  Median of five windows each."""
+    import ctypes as C
+    import sla_amd as sla
+    from sla_amd import _lib, workloads as wl
+    lib = _lib.lib()
+    out = {}
+
+    def median_rate(fn, units):
+        dts = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            fn()
+            dts.append(time.perf_counter() - t0)
+        dt = sorted(dts)[2]
+        return {"value": units / dt, "us_per_unit": dt / units * 1e6, "value_min": units / max(dts), "value_max": units / min(dts)}
+
+    dims, (rp, ci, va) = wl.poisson2d(1000, 1000)
+    n, steps = dims[0], 200
+    blk = {"workload": "config 2: 1M-row fp64 5-pt Poisson (1000^2), bicgstabStep, windows of 200 steps", "unit": "iters/s"}
+    for label, opts in (("default", {}), ("launch_flow", {"onchip": 0})):
+        ctx = sla.Context(0).set_options(**opts)
+        A = sla.fromCSRRows(dims, 0, rp, ci, va, ctx)
+        st = sla.bicgsInit(A, sla.DeviceVector(ctx, n, np.add.reduceat(va, rp[:-1]), local=True), sla.DeviceVector(ctx, n))
+        st.step(steps)                                   # (plan / graph capture outside the timed windows)
+        ctx.sync()
+        r = median_rate(lambda: (st.step(steps), ctx.sync()), steps)
+        r["onchip_launches"] = int(ctx.get_option("onchip_launches"))
+        r["flow"] = "ONE persistent on-chip launch per window" if r["onchip_launches"] else "three launches per step (K1 | K23 | K45)"
+        r["spmv_kernel"] = A.kernel_info().split()[0]
+        blk[label] = r
+        del st, A
+        ctx.close()
+    out["config2_poisson2d_1m"] = blk
+
+    dims, (rp, ci, va) = wl.banded_nonsym(2000000)
+    n, steps, restart = dims[0], 120, 30
+    blk = {"workload": "config 5: 2M-row fp64 non-symmetric banded, GMRES(30), windows of 120 Arnoldi steps", "unit": "arnoldi_steps/s"}
+    for label, opts in (("default", {}), ("launch_flow", {"arn_orth": 0})):
+        ctx = sla.Context(0).set_options(**opts)
+        A = sla.fromCSRRows(dims, 0, rp, ci, va, ctx)
+        bvec, x0, res = sla.DeviceVector(ctx, n, np.add.reduceat(va, rp[:-1]), local=True), sla.DeviceVector(ctx, n), sla.DeviceVector(ctx, n)
+        info = _lib.SolveInfo()
+        o = _lib.SolveOpts(steps, 0.0, 0.0, 16, 1)       # tol 0: exactly `steps` Arnoldi steps
+
+        def run():
+            _lib.check(lib.sla_gmres(A.h, bvec.h, x0.h, restart, C.byref(o), res.h, C.byref(info)))
+            ctx.sync()
+        run()
+        r = median_rate(run, steps)
+        r["fused_gram_schmidt_launches"] = int(ctx.get_option("arn_orth_launches"))
+        r["flow"] = "(#>) + ONE persistent Gram-Schmidt launch per step" if r["fused_gram_schmidt_launches"] else "(#>) + dots | update | normalisation"
+        r["spmv_kernel"] = A.kernel_info().split()[0]
+        blk[label] = r
+        del bvec, x0, res, A
+        ctx.close()
+    out["config5_gmres_banded_2m"] = blk
+    return out
+
+
 def end_to_end_block(ctx, A, dims, rp, ci, va, b_host, t_from_csr, steady_its, with_coo):
     """What "lowered once" costs next to the steady-state rate: seconds of sla_csr_from_csr (already spent on the
     headline matrix: `t_from_csr`, phases as the library recorded them), of sla_csr_from_coo on the same entries in toListSM's
@@ -946,6 +1008,11 @@ def run_rank(args, rank, world, local_rank, dist_mode, loop=None):
             rec["random_spd_10m_relaxed_order"] = side_block(d3, dm3, rp3, ci3, va3, {"tile_relaxed": 1}, max(20, args.steps // 4), max(5, args.warmup // 2), rhs="A.x*")
         except Exception as e:
             rec["random_spd_10m_relaxed_order"] = {"error": repr(e)}
+        rp3 = ci3 = va3 = None
+        try:   # configs 2 and 5 in the same line (default flow and the launch flow it replaces)
+            rec["baseline_configs"] = baseline_config_blocks()
+        except Exception as e:
+            rec["baseline_configs"] = {"error": repr(e)}
     # ---- BASELINE.json's metric, answered at the top level: "BiCGSTAB iters/sec + CSR SpMV achieved HBM GB/s, 10 M x 10 M fp64" ----
     g = rec.get("general_csr") or {}
     if g.get("k1_csr_gbps"):     # the literal CSR SpMV (f64 values + i32 columns + i32 row pointers) on config 4's matrix, K1 inside BiCGSTAB

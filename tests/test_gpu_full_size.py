@@ -76,6 +76,12 @@ def test_bench_default_line_as_the_driver_types_it():
     assert "exact_fold=0" in rx["spmv_kernel"] and rx["option"] == "tile_relaxed=1"
     assert rx["iters_per_s"] > ns["iters_per_s"] > 0.7 * rx["iters_per_s"]                # the price of a reproducible default: 15 - 20 %
     assert 0.6 < rx["ceiling"]["frac_of_ceiling"] <= 1.0 and rx["ceiling"]["hbm_roof_ms"] < rx["ceiling"]["k1_ms_at_ceiling"] < rx["k1_ms"]
+    # configs 2 and 5 ride in the same line: the default flows (one persistent launch per window / per Gram-Schmidt step) beside the launch flows
+    c2, c5 = d["baseline_configs"]["config2_poisson2d_1m"], d["baseline_configs"]["config5_gmres_banded_2m"]
+    assert c2["default"]["onchip_launches"] > 0 and c2["launch_flow"]["onchip_launches"] == 0
+    assert c2["default"]["value"] > 1.5 * c2["launch_flow"]["value"] > 15000
+    assert c5["default"]["fused_gram_schmidt_launches"] > 0 and c5["launch_flow"]["fused_gram_schmidt_launches"] == 0
+    assert c5["default"]["value"] > c5["launch_flow"]["value"] > 4000
 
 
 @pytest.mark.parametrize("fuse45", ["1", "0", "onchip"])
