@@ -49,7 +49,6 @@ constexpr bool kAoPipe = SLA_AO_PIPE != 0;   // two register sets for the stream
 constexpr int kArnOrthCols = 32; // columns one launch handles (GMRES(30): 31 basis columns at most)
 
 typedef double ao_f64x2 __attribute__((ext_vector_type(2)));
-typedef ao_f64x2 ao_f64x2u __attribute__((aligned(8)));
 
 struct ArnOrthArgs {
     int64_t n;
@@ -142,8 +141,7 @@ __global__ void __launch_bounds__(AT) arn_orth_kernel(ArnOrthArgs a) {
         wv[i].x = (vm >> (2 * i)) & 1 ? x.x : 0.0;
         wv[i].y = (vm >> (2 * i + 1)) & 1 ? x.y : 0.0;
     }
-    // ---- pass 1: hhcoli = fmap (`dot` aqi) qv.  Columns 0 .. ACR-1 stay in registers, ACR .. ACR+ACL-1 in LDS.  The loads of the NEXT column are
-    //      issued before the current one is folded (two register sets): a wavefront never sits between columns with nothing in flight ----
+    // ---- pass 1: hhcoli = fmap (`dot` aqi) qv.  Columns 0 .. ACR-1 stay in registers, ACR .. ACR+ACL-1 in LDS ----
     ao_f64x2 qc[ACR][APT];
     auto load_col = [&](ao_f64x2 (&q)[APT], int c) {
         const ao_f64x2 *col = (const ao_f64x2 *)(a.Q + (int64_t)c * a.ldq);
